@@ -1,0 +1,97 @@
+"""ctypes binding of libfsgs.so (C-ABI declared in include/fsgs.h).
+
+The product path has NO fallback: if the shared library is missing or a call fails, this
+module raises.  Pointers are raw device addresses taken from torch tensors; torch is used for
+memory and streams only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfsgs.so")
+
+_i, _i64, _f, _p, _sz = C.c_int, C.c_int64, C.c_float, C.c_void_p, C.c_size_t
+
+# name -> (restype, argtypes); mirrors include/fsgs.h one to one
+SIGNATURES = {
+    "fsgs_version": (_i, []),
+    "fsgs_error_string": (C.c_char_p, [_i]),
+    "fsgs_last_hip_error": (_i, []),
+    "fsgs_project_fwd": (_i, [_i, _i, _p, _p, _p, _p, _p, _i, _i, _f, _f, _f, _f, _p, _p, _p, _p, _p, _p]),
+    "fsgs_project_bwd": (_i, [_i, _i, _p, _p, _p, _p, _p, _i, _i, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "fsgs_sh_fwd": (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p]),
+    "fsgs_sh_bwd": (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p]),
+    "fsgs_scan_scratch_bytes": (_sz, [_i64]),
+    "fsgs_isect_count": (_i, [_i, _i, _p, _p, _i, _i, _i, _i, _p, _p, _p, _sz, C.POINTER(_i64), _p]),
+    "fsgs_isect_emit": (_i, [_i, _i, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p]),
+    "fsgs_sort_scratch_bytes": (_sz, [_i64]),
+    "fsgs_sort_pairs": (_i, [_i64, _p, _p, _p, _p, _i, _p, _sz, C.POINTER(_i), _p]),
+    "fsgs_isect_offset_encode": (_i, [_i64, _p, _i, _i, _i, _p, _p]),
+    "fsgs_raster_fwd": (_i, [_i, _i, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _i64, _p, _p, _p, _p]),
+    "fsgs_raster_bwd": (_i, [_i, _i, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "fsgs_normals_fwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _p]),
+    "fsgs_normals_bwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _p]),
+    "fsgs_densify_stats": (_i, [_i, _p, _p, _f, _p, _p, _p, _p]),
+    "fsgs_mask_scan": (_i, [_i64, _p, _p, _p, _sz, _p]),
+    "fsgs_compact_rows": (_i, [_i64, _i, _p, _p, _p, _p, _p]),
+    "fsgs_split_samples": (_i, [_i64, _i, _p, _p, _p, _p, _p, _p, _p, _p]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+class FsgsError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """Load libfsgs.so (built in-tree by ``__graft_entry__.build()`` / csrc/Makefile)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FsgsError(
+            f"{LIB_PATH} not found: the HIP extension is not built. Run "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C fusionsense_amd/csrc`). "
+            "There is no CPU fallback."
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def ptr(t: Optional[torch.Tensor]):
+    """Raw device pointer of a contiguous tensor (None -> NULL)."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), "fsgs: tensor must be contiguous"
+    return t.data_ptr()
+
+
+def stream_ptr(device: torch.device):
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        lib = load()
+        msg = lib.fsgs_error_string(rc).decode()
+        raise FsgsError(f"{what} failed: {msg} (code {rc}, hipError {lib.fsgs_last_hip_error()})")
+
+
+def require_gpu_tensor(t: torch.Tensor, name: str, dtype=torch.float32) -> None:
+    if not isinstance(t, torch.Tensor):
+        raise ValueError(f"{name} must be a torch.Tensor")
+    if not t.is_cuda:
+        raise ValueError(f"{name} must live on the GPU (there is no CPU path); got device {t.device}")
+    if t.dtype != dtype:
+        raise ValueError(f"{name} must be {dtype}, got {t.dtype}")

@@ -1,0 +1,52 @@
+// Shared helpers for the gfx950 kernels of libfsgs.so.  CDNA4 only: wave = 64 lanes.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/fsgs.h"
+
+namespace fsgs {
+
+constexpr int kWave = 64;
+constexpr float kAlphaMax = 0.999f;       // gsplat: alpha = min(0.999, opac*exp(-sigma))
+constexpr float kAlphaMin = 1.0f / 255.f; // skip below
+constexpr float kTMin = 1e-4f;            // stop before T would reach this
+
+extern thread_local int g_last_hip_error;
+
+inline int check_launch() {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        g_last_hip_error = (int)e;
+        return FSGS_ELAUNCH;
+    }
+    return FSGS_OK;
+}
+
+inline hipStream_t as_stream(fsgs_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// ---- wave64 reductions on DPP (no LDS traffic) ------------------------------------------
+// dpp_ctrl encodings (GCN3+/CDNA): quad_perm = sel0|sel1<<2|sel2<<4|sel3<<6,
+// row_half_mirror 0x141, row_mirror 0x140, row_bcast15 0x142, row_bcast31 0x143.
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __builtin_bit_cast(
+        float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false));
+}
+
+// Sum over the 64 lanes; the total is valid in lanes 48..63 (read it from lane 63).
+__device__ __forceinline__ float wave_sum_to_last_row(float v) {
+    v += dpp_f<0xB1>(v);        // quad_perm [1,0,3,2]
+    v += dpp_f<0x4E>(v);        // quad_perm [2,3,0,1]
+    v += dpp_f<0x141>(v);       // row_half_mirror: 8-lane sums
+    v += dpp_f<0x140>(v);       // row_mirror: every lane holds its 16-lane row sum
+    v += dpp_f<0x142, 0xA>(v);  // row_bcast15 into rows 1,3
+    v += dpp_f<0x143, 0xC>(v);  // row_bcast31 into rows 2,3
+    return v;
+}
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+}  // namespace fsgs

@@ -1,0 +1,198 @@
+// E4 + E6: Gaussian<->tile intersection (count, emit) and per-tile offset encoding
+// (SURVEY.md §8a-5, 8a-7).  Replaces gsplat 1.0.0 `isect_tiles` / `isect_offset_encode`
+// (new path, /root/reference/dn_splatter/dn_model.py:570-591) and the legacy
+// `map_gaussian_to_intersects` / `get_tile_bin_edges` behind gsplat.rasterize_gaussians
+// (dn_model.py:644-653).  Integer work: every output is bit-exact against the oracle.
+#include "common.h"
+#include "scan.h"
+
+namespace fsgs {
+
+struct TileRect {
+    int x0, y0, x1, y1;  // [min, max) in tile units
+};
+
+// New path: floor/ceil.  Legacy: C-cast truncation of (c - r) and (c + r + 1).  Negative
+// values are clamped BEFORE the integer conversion (CUDA relies on saturating casts).
+__device__ __forceinline__ TileRect tile_rect(float mx, float my, int radius, int tile_size, int tw,
+                                              int th, int legacy) {
+    const float ts = (float)tile_size;
+    const float tr = (float)radius / ts;
+    const float tx = mx / ts, ty = my / ts;
+    float lx = tx - tr, ly = ty - tr, hx = tx + tr, hy = ty + tr;
+    if (legacy) {
+        lx = truncf(lx); ly = truncf(ly);
+        hx = truncf(hx + 1.f); hy = truncf(hy + 1.f);
+    } else {
+        lx = floorf(lx); ly = floorf(ly);
+        hx = ceilf(hx); hy = ceilf(hy);
+    }
+    TileRect r;
+    r.x0 = (int)fminf(fmaxf(lx, 0.f), (float)tw);
+    r.y0 = (int)fminf(fmaxf(ly, 0.f), (float)th);
+    r.x1 = (int)fminf(fmaxf(hx, 0.f), (float)tw);
+    r.y1 = (int)fminf(fmaxf(hy, 0.f), (float)th);
+    return r;
+}
+
+__global__ void __launch_bounds__(256)
+isect_count_kernel(int64_t total, const float *__restrict__ means2d, const int32_t *__restrict__ radii,
+                   int tile_size, int tw, int th, int legacy, int32_t *__restrict__ tiles_per_gauss) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int r = radii[idx];
+    int cnt = 0;
+    if (r > 0) {
+        const float2 m = reinterpret_cast<const float2 *>(means2d)[idx];
+        const TileRect t = tile_rect(m.x, m.y, r, tile_size, tw, th, legacy);
+        cnt = (t.x1 - t.x0) * (t.y1 - t.y0);
+    }
+    tiles_per_gauss[idx] = cnt;
+}
+
+// One thread per (camera, Gaussian) writes its row-major tile list.  Gaussians covering many
+// tiles (>= kWideTiles) are deferred to the whole wave, which writes them 64 tiles at a time
+// so that one large splat does not serialise its wave.
+constexpr int kWideTiles = 128;
+
+__global__ void __launch_bounds__(256)
+isect_emit_kernel(int C, int N, const float *__restrict__ means2d, const int32_t *__restrict__ radii,
+                  const float *__restrict__ depths, const int64_t *__restrict__ cum_tiles,
+                  int tile_size, int tw, int th, int legacy, int tile_bits,
+                  int64_t *__restrict__ isect_ids, int32_t *__restrict__ flatten_ids) {
+    const int64_t total = (int64_t)C * N;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    TileRect t = {0, 0, 0, 0};
+    int64_t key_hi_base = 0, depth_bits = 0, start = 0;
+    int cnt = 0;
+    if (idx < total) {
+        const int r = radii[idx];
+        if (r > 0) {
+            const float2 m = reinterpret_cast<const float2 *>(means2d)[idx];
+            t = tile_rect(m.x, m.y, r, tile_size, tw, th, legacy);
+            cnt = (t.x1 - t.x0) * (t.y1 - t.y0);
+            const int64_t c = idx / N;
+            key_hi_base = c << (32 + tile_bits);
+            depth_bits = (int64_t)(uint32_t)__float_as_int(depths[idx]);
+            start = (idx == 0) ? 0 : cum_tiles[idx - 1];
+        }
+    }
+    const bool wide = cnt >= kWideTiles;
+    if (cnt > 0 && !wide) {
+        int64_t o = start;
+        for (int y = t.y0; y < t.y1; ++y)
+            for (int x = t.x0; x < t.x1; ++x) {
+                isect_ids[o] = key_hi_base | ((int64_t)(y * tw + x) << 32) | depth_bits;
+                flatten_ids[o] = (int32_t)idx;
+                ++o;
+            }
+    }
+    // wave-cooperative path for wide splats
+    unsigned long long wide_mask = __ballot(wide);
+    while (wide_mask) {
+        const int src = __ffsll((long long)wide_mask) - 1;
+        wide_mask &= wide_mask - 1;
+        const int x0 = __shfl(t.x0, src, 64), y0 = __shfl(t.y0, src, 64);
+        const int x1 = __shfl(t.x1, src, 64);
+        const int n = __shfl(cnt, src, 64);
+        const int64_t kb = __shfl(key_hi_base, src, 64), db = __shfl(depth_bits, src, 64);
+        const int64_t st = __shfl(start, src, 64);
+        const int32_t gid = (int32_t)__shfl((long long)idx, src, 64);
+        const int wdt = x1 - x0;
+        for (int k = lane; k < n; k += 64) {
+            const int y = y0 + k / wdt, x = x0 + k % wdt;
+            isect_ids[st + k] = kb | ((int64_t)(y * tw + x) << 32) | db;
+            flatten_ids[st + k] = gid;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+offset_encode_kernel(int64_t n_isects, const int64_t *__restrict__ ids, int n_tiles, int tile_bits,
+                     int n_total, int32_t *__restrict__ offsets) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_isects) return;
+    const int64_t hi = ids[idx] >> 32;
+    const int64_t cur = (hi >> tile_bits) * n_tiles + (hi & ((1ll << tile_bits) - 1));
+    if (idx == 0) {
+        for (int64_t i = 0; i <= cur; ++i) offsets[i] = 0;
+    } else {
+        const int64_t hp = ids[idx - 1] >> 32;
+        const int64_t prev = (hp >> tile_bits) * n_tiles + (hp & ((1ll << tile_bits) - 1));
+        for (int64_t i = prev + 1; i <= cur; ++i) offsets[i] = (int32_t)idx;
+    }
+    if (idx == n_isects - 1) {
+        for (int64_t i = cur + 1; i < n_total; ++i) offsets[i] = (int32_t)n_isects;
+    }
+}
+
+inline int tile_bits_for(int n_tiles) {
+    int b = 0;
+    while ((1ll << b) <= n_tiles) ++b;  // floor(log2(n_tiles)) + 1
+    return b < 1 ? 1 : b;
+}
+
+}  // namespace fsgs
+
+using namespace fsgs;
+
+extern "C" size_t fsgs_scan_scratch_bytes(int64_t n) {
+    return (size_t)(scan_num_blocks(n) + 1) * sizeof(int64_t);
+}
+
+extern "C" int fsgs_isect_count(int C, int N, const float *means2d, const int32_t *radii,
+                                int tile_size, int tile_width, int tile_height, int legacy,
+                                int32_t *tiles_per_gauss, int64_t *cum_tiles, void *scratch,
+                                size_t scratch_bytes, int64_t *n_isects_host, fsgs_stream_t stream) {
+    if (C < 0 || N < 0 || tile_size < 1 || !n_isects_host) return FSGS_EINVAL;
+    const int64_t total = (int64_t)C * N;
+    *n_isects_host = 0;
+    if (total == 0) return FSGS_OK;
+    if (!means2d || !radii || !tiles_per_gauss || !cum_tiles) return FSGS_EINVAL;
+    hipStream_t s = as_stream(stream);
+    hipLaunchKernelGGL(isect_count_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, s, total, means2d,
+                       radii, tile_size, tile_width, tile_height, legacy, tiles_per_gauss);
+    int rc = device_scan<int32_t, true>(total, tiles_per_gauss, cum_tiles, scratch, scratch_bytes, s);
+    if (rc != FSGS_OK) return rc;
+    hipError_t e = hipMemcpyAsync(n_isects_host, cum_tiles + (total - 1), sizeof(int64_t),
+                                  hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) {
+        g_last_hip_error = (int)e;
+        return FSGS_ELAUNCH;
+    }
+    return FSGS_OK;
+}
+
+extern "C" int fsgs_isect_emit(int C, int N, const float *means2d, const int32_t *radii,
+                               const float *depths, const int64_t *cum_tiles, int tile_size,
+                               int tile_width, int tile_height, int legacy, int64_t *isect_ids,
+                               int32_t *flatten_ids, fsgs_stream_t stream) {
+    if (C < 0 || N < 0 || tile_size < 1) return FSGS_EINVAL;
+    const int64_t total = (int64_t)C * N;
+    if (total == 0) return FSGS_OK;
+    if (!means2d || !radii || !depths || !cum_tiles || !isect_ids || !flatten_ids) return FSGS_EINVAL;
+    const int tb = tile_bits_for(tile_width * tile_height);
+    hipLaunchKernelGGL(isect_emit_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, as_stream(stream), C,
+                       N, means2d, radii, depths, cum_tiles, tile_size, tile_width, tile_height, legacy,
+                       tb, isect_ids, flatten_ids);
+    return check_launch();
+}
+
+extern "C" int fsgs_isect_offset_encode(int64_t n_isects, const int64_t *isect_ids_sorted, int C,
+                                        int n_tiles, int tile_bits, int32_t *offsets,
+                                        fsgs_stream_t stream) {
+    if (n_isects < 0 || C < 0 || n_tiles < 0 || !offsets) return FSGS_EINVAL;
+    const int n_total = C * n_tiles;
+    hipStream_t s = as_stream(stream);
+    if (n_isects == 0) {
+        hipError_t e = hipMemsetAsync(offsets, 0, (size_t)n_total * sizeof(int32_t), s);
+        if (e != hipSuccess) { g_last_hip_error = (int)e; return FSGS_ELAUNCH; }
+        return FSGS_OK;
+    }
+    if (!isect_ids_sorted) return FSGS_EINVAL;
+    hipLaunchKernelGGL(offset_encode_kernel, dim3(ceil_div(n_isects, 256)), dim3(256), 0, s, n_isects,
+                       isect_ids_sorted, n_tiles, tile_bits, n_total, offsets);
+    return check_launch();
+}

@@ -1,0 +1,350 @@
+// E2: fused 3D->2D Gaussian projection, forward and VJP.
+// Replaces gsplat 1.0.0 `fully_fused_projection_{fwd,bwd}` as called from
+// gsplat.rendering.rasterization at /root/reference/dn_splatter/dn_model.py:570-591.
+//
+// One thread per (camera, Gaussian).  Per-Gaussian attributes are SoA tensors of 3/4 floats,
+// so consecutive lanes read consecutive 12/16-byte records: fully coalesced, no LDS needed.
+// HBM-bound: 40 B read + 28 B written per Gaussian (forward).
+#include "common.h"
+
+namespace fsgs {
+
+struct Mat3 {
+    float m[3][3];
+};
+
+__device__ __forceinline__ void quat_to_rot(float w, float x, float y, float z, Mat3 &R) {
+    R.m[0][0] = 1.f - 2.f * (y * y + z * z);
+    R.m[0][1] = 2.f * (x * y - w * z);
+    R.m[0][2] = 2.f * (x * z + w * y);
+    R.m[1][0] = 2.f * (x * y + w * z);
+    R.m[1][1] = 1.f - 2.f * (x * x + z * z);
+    R.m[1][2] = 2.f * (y * z - w * x);
+    R.m[2][0] = 2.f * (x * z - w * y);
+    R.m[2][1] = 2.f * (y * z + w * x);
+    R.m[2][2] = 1.f - 2.f * (x * x + y * y);
+}
+
+// Sigma_c = W (Rq S)(Rq S)^T W^T, returned as a full symmetric 3x3.
+__device__ __forceinline__ void covar_cam(const Mat3 &Rq, const float s[3], const float W[3][3],
+                                           float Sc[3][3]) {
+    float A[3][3];  // A = W * Rq * S
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            A[i][j] = (W[i][0] * Rq.m[0][j] + W[i][1] * Rq.m[1][j] + W[i][2] * Rq.m[2][j]) * s[j];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) Sc[i][j] = A[i][0] * A[j][0] + A[i][1] * A[j][1] + A[i][2] * A[j][2];
+}
+
+__global__ void __launch_bounds__(256)
+project_fwd_kernel(int C, int N, const float *__restrict__ means, const float *__restrict__ quats,
+                   const float *__restrict__ scales, const float *__restrict__ viewmats,
+                   const float *__restrict__ Ks, int width, int height, float eps2d, float near_plane,
+                   float far_plane, float radius_clip, int32_t *__restrict__ radii,
+                   float *__restrict__ means2d, float *__restrict__ depths,
+                   float *__restrict__ conics, float *__restrict__ compensations) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)C * N) return;
+    const int c = (int)(idx / N);
+    const int n = (int)(idx - (int64_t)c * N);
+
+    const float *vm = viewmats + c * 16;
+    float W[3][3] = {{vm[0], vm[1], vm[2]}, {vm[4], vm[5], vm[6]}, {vm[8], vm[9], vm[10]}};
+    const float t[3] = {vm[3], vm[7], vm[11]};
+    const float mx = means[n * 3 + 0], my = means[n * 3 + 1], mz = means[n * 3 + 2];
+    const float x = W[0][0] * mx + W[0][1] * my + W[0][2] * mz + t[0];
+    const float y = W[1][0] * mx + W[1][1] * my + W[1][2] * mz + t[1];
+    const float z = W[2][0] * mx + W[2][1] * my + W[2][2] * mz + t[2];
+
+    int32_t radius_out = 0;
+    float o_m2[2] = {0.f, 0.f}, o_depth = 0.f, o_conic[3] = {0.f, 0.f, 0.f}, o_comp = 0.f;
+
+    if (z >= near_plane && z <= far_plane) {
+        const float4 q = reinterpret_cast<const float4 *>(quats)[n];
+        const float inv = 1.f / fmaxf(sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w), 1e-12f);
+        Mat3 Rq;
+        quat_to_rot(q.x * inv, q.y * inv, q.z * inv, q.w * inv, Rq);
+        const float s[3] = {scales[n * 3 + 0], scales[n * 3 + 1], scales[n * 3 + 2]};
+        float Sc[3][3];
+        covar_cam(Rq, s, W, Sc);
+
+        const float *K = Ks + c * 9;
+        const float fx = K[0], fy = K[4], cx = K[2], cy = K[5];
+        const float lim_x = 1.3f * (0.5f * width / fx), lim_y = 1.3f * (0.5f * height / fy);
+        const float rz = 1.f / z, rz2 = rz * rz;
+        const float tx = z * fminf(lim_x, fmaxf(-lim_x, x * rz));
+        const float ty = z * fminf(lim_y, fmaxf(-lim_y, y * rz));
+        const float J00 = fx * rz, J02 = -fx * tx * rz2, J11 = fy * rz, J12 = -fy * ty * rz2;
+        // Sigma2 = J Sigma_c J^T with J = [[J00,0,J02],[0,J11,J12]]
+        const float r0[3] = {J00 * Sc[0][0] + J02 * Sc[2][0], J00 * Sc[0][1] + J02 * Sc[2][1],
+                             J00 * Sc[0][2] + J02 * Sc[2][2]};
+        const float r1[3] = {J11 * Sc[1][0] + J12 * Sc[2][0], J11 * Sc[1][1] + J12 * Sc[2][1],
+                             J11 * Sc[1][2] + J12 * Sc[2][2]};
+        const float a0 = r0[0] * J00 + r0[2] * J02;
+        const float b0 = 0.5f * ((r0[1] * J11 + r0[2] * J12) + (r1[0] * J00 + r1[2] * J02));
+        const float c0 = r1[1] * J11 + r1[2] * J12;
+        const float det0 = a0 * c0 - b0 * b0;
+        const float a = a0 + eps2d, cc = c0 + eps2d;
+        const float det = a * cc - b0 * b0;
+        if (det > 0.f) {
+            const float bb = 0.5f * (a + cc);
+            const float v1 = bb + sqrtf(fmaxf(0.01f, bb * bb - det));
+            const float radius = ceilf(3.f * sqrtf(v1));
+            const float u = fx * x * rz + cx, v = fy * y * rz + cy;
+            const bool inside = (u + radius > 0.f) && (u - radius < (float)width) &&
+                                (v + radius > 0.f) && (v - radius < (float)height);
+            if (radius > radius_clip && inside) {
+                const float idet = 1.f / det;
+                radius_out = (int32_t)radius;
+                o_m2[0] = u;
+                o_m2[1] = v;
+                o_depth = z;
+                o_conic[0] = cc * idet;
+                o_conic[1] = -b0 * idet;
+                o_conic[2] = a * idet;
+                o_comp = sqrtf(fmaxf(0.f, det0 * idet));
+            }
+        }
+    }
+    radii[idx] = radius_out;
+    reinterpret_cast<float2 *>(means2d)[idx] = make_float2(o_m2[0], o_m2[1]);
+    depths[idx] = o_depth;
+    conics[idx * 3 + 0] = o_conic[0];
+    conics[idx * 3 + 1] = o_conic[1];
+    conics[idx * 3 + 2] = o_conic[2];
+    if (compensations) compensations[idx] = o_comp;
+}
+
+// VJP.  One thread per Gaussian, looping over cameras (C is 1 on the training path), so the
+// per-Gaussian gradients are written once, without atomics, deterministically.
+__global__ void __launch_bounds__(256)
+project_bwd_kernel(int C, int N, const float *__restrict__ means, const float *__restrict__ quats,
+                   const float *__restrict__ scales, const float *__restrict__ viewmats,
+                   const float *__restrict__ Ks, int width, int height, float eps2d,
+                   const int32_t *__restrict__ radii, const float *__restrict__ conics,
+                   const float *__restrict__ compensations, const float *__restrict__ v_means2d,
+                   const float *__restrict__ v_depths, const float *__restrict__ v_conics,
+                   const float *__restrict__ v_compensations, float *__restrict__ v_means,
+                   float *__restrict__ v_quats, float *__restrict__ v_scales,
+                   float *__restrict__ v_viewmats) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const float mean[3] = {means[n * 3 + 0], means[n * 3 + 1], means[n * 3 + 2]};
+    const float4 q = reinterpret_cast<const float4 *>(quats)[n];
+    const float qn = fmaxf(sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w), 1e-12f);
+    const float inv = 1.f / qn;
+    const float qw = q.x * inv, qx = q.y * inv, qy = q.z * inv, qz = q.w * inv;
+    Mat3 Rq;
+    quat_to_rot(qw, qx, qy, qz, Rq);
+    const float s[3] = {scales[n * 3 + 0], scales[n * 3 + 1], scales[n * 3 + 2]};
+
+    float g_mean[3] = {0.f, 0.f, 0.f};
+    float g_Sigma[3][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};  // world-space covariance
+
+    for (int c = 0; c < C; ++c) {
+        const int64_t idx = (int64_t)c * N + n;
+        if (radii[idx] <= 0) continue;
+        const float *vm = viewmats + c * 16;
+        float W[3][3] = {{vm[0], vm[1], vm[2]}, {vm[4], vm[5], vm[6]}, {vm[8], vm[9], vm[10]}};
+        const float x = W[0][0] * mean[0] + W[0][1] * mean[1] + W[0][2] * mean[2] + vm[3];
+        const float y = W[1][0] * mean[0] + W[1][1] * mean[1] + W[1][2] * mean[2] + vm[7];
+        const float z = W[2][0] * mean[0] + W[2][1] * mean[1] + W[2][2] * mean[2] + vm[11];
+        float Sc[3][3];
+        covar_cam(Rq, s, W, Sc);
+        const float *K = Ks + c * 9;
+        const float fx = K[0], fy = K[4];
+        const float lim_x = 1.3f * (0.5f * width / fx), lim_y = 1.3f * (0.5f * height / fy);
+        const float rz = 1.f / z, rz2 = rz * rz, rz3 = rz2 * rz;
+        const float xr = x * rz, yr = y * rz;
+        const bool free_x = (xr <= lim_x) && (xr >= -lim_x);
+        const bool free_y = (yr <= lim_y) && (yr >= -lim_y);
+        const float tx = z * fminf(lim_x, fmaxf(-lim_x, xr));
+        const float ty = z * fminf(lim_y, fmaxf(-lim_y, yr));
+        const float J00 = fx * rz, J02 = -fx * tx * rz2, J11 = fy * rz, J12 = -fy * ty * rz2;
+
+        // conic = inverse(Sigma2 + eps I):  G = -X V X, X = conic matrix, V = sym(v_conic)
+        const float ca = conics[idx * 3 + 0], cb = conics[idx * 3 + 1], cc = conics[idx * 3 + 2];
+        const float va = v_conics[idx * 3 + 0], vb = 0.5f * v_conics[idx * 3 + 1], vc = v_conics[idx * 3 + 2];
+        // T = X V
+        const float t00 = ca * va + cb * vb, t01 = ca * vb + cb * vc;
+        const float t10 = cb * va + cc * vb, t11 = cb * vb + cc * vc;
+        float G00 = -(t00 * ca + t01 * cb);
+        float G01 = -(t00 * cb + t01 * cc);
+        float G11 = -(t10 * cb + t11 * cc);
+        if (v_compensations != nullptr && compensations != nullptr) {
+            // comp = sqrt(det0/det); Sigma2' = Sigma2 + eps I has inverse X, det = 1/det(X)
+            const float comp = compensations[idx];
+            const float vcomp = v_compensations[idx];
+            if (comp > 0.f && vcomp != 0.f) {
+                const float detX = ca * cc - cb * cb;  // 1/det
+                const float det = 1.f / detX;
+                // Sigma2' entries from X: a = cc*det, b0 = -cb*det, c = ca*det
+                const float a = cc * det, b0 = -cb * det, c2 = ca * det;
+                const float a0 = a - eps2d, c0 = c2 - eps2d;
+                const float det0 = a0 * c0 - b0 * b0;
+                const float k = vcomp * 0.5f / comp;  // d comp / d (det0/det)
+                // d(det0/det) = d det0 / det - det0/det^2 d det
+                const float k0 = k / det, k1 = -k * det0 / (det * det);
+                G00 += k0 * c0 + k1 * c2;
+                G11 += k0 * a0 + k1 * a;
+                G01 += -(k0 + k1) * b0;  // per off-diagonal entry (single-b gradient is -2b(k0+k1))
+            }
+        }
+        // Sigma2 = J Sc J^T :  v_Sc = J^T G J ;  v_J = 2 G J Sc
+        const float GJ0[3] = {G00 * J00, G01 * J11, G00 * J02 + G01 * J12};  // row 0 of G J
+        const float GJ1[3] = {G01 * J00, G11 * J11, G01 * J02 + G11 * J12};  // row 1 of G J
+        float vSc[3][3];
+        const float Jc0[3] = {J00, 0.f, J02}, Jc1[3] = {0.f, J11, J12};
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) vSc[i][j] = Jc0[i] * GJ0[j] + Jc1[i] * GJ1[j];
+        float vJ0[3], vJ1[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            vJ0[j] = 2.f * (GJ0[0] * Sc[0][j] + GJ0[1] * Sc[1][j] + GJ0[2] * Sc[2][j]);
+            vJ1[j] = 2.f * (GJ1[0] * Sc[0][j] + GJ1[1] * Sc[1][j] + GJ1[2] * Sc[2][j]);
+        }
+        // camera-space mean gradient
+        const float vu = v_means2d[idx * 2 + 0], vv = v_means2d[idx * 2 + 1];
+        float gx = fx * rz * vu;
+        float gy = fy * rz * vv;
+        float gz = -(fx * x * vu + fy * y * vv) * rz2 + v_depths[idx];
+        gz += -fx * rz2 * vJ0[0] - fy * rz2 * vJ1[1];
+        if (free_x) {
+            gx += -fx * rz2 * vJ0[2];
+            gz += 2.f * fx * tx * rz3 * vJ0[2];
+        } else {
+            gz += fx * tx * rz3 * vJ0[2];
+        }
+        if (free_y) {
+            gy += -fy * rz2 * vJ1[2];
+            gz += 2.f * fy * ty * rz3 * vJ1[2];
+        } else {
+            gz += fy * ty * rz3 * vJ1[2];
+        }
+        // back to world: v_mean += W^T g ; v_Sigma += W^T vSc W
+#pragma unroll
+        for (int j = 0; j < 3; ++j) g_mean[j] += W[0][j] * gx + W[1][j] * gy + W[2][j] * gz;
+        float Tm[3][3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                Tm[i][j] = vSc[i][0] * W[0][j] + vSc[i][1] * W[1][j] + vSc[i][2] * W[2][j];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                g_Sigma[i][j] += W[0][i] * Tm[0][j] + W[1][i] * Tm[1][j] + W[2][i] * Tm[2][j];
+
+        if (v_viewmats != nullptr) {
+            // p = W mean + t ; Sc = W Sigma W^T  ->  v_W = g mean^T + 2 vSc W Sigma ; v_t = g
+            float Sig[3][3];
+            {
+                float A[3][3];
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) A[i][j] = Rq.m[i][j] * s[j];
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j)
+                        Sig[i][j] = A[i][0] * A[j][0] + A[i][1] * A[j][1] + A[i][2] * A[j][2];
+            }
+            const float g[3] = {gx, gy, gz};
+            float *vvm = v_viewmats + c * 16;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    // (vSc_sym W Sigma)_{ij}, vSc is symmetric here
+                    float acc = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) acc += Tm[i][k] * Sig[k][j];
+                    atomicAdd(&vvm[i * 4 + j], g[i] * mean[j] + 2.f * acc);
+                }
+                atomicAdd(&vvm[i * 4 + 3], g[i]);
+            }
+        }
+    }
+
+    // Sigma = M M^T, M = Rq S :  v_M = 2 v_Sigma M
+    float vM[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            vM[i][j] = 2.f * (g_Sigma[i][0] * Rq.m[0][j] + g_Sigma[i][1] * Rq.m[1][j] +
+                              g_Sigma[i][2] * Rq.m[2][j]) * s[j];
+    float vs[3], vR[3][3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        vs[j] = Rq.m[0][j] * vM[0][j] + Rq.m[1][j] * vM[1][j] + Rq.m[2][j] * vM[2][j];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) vR[i][j] = vM[i][j] * s[j];
+    }
+    const float gw = 2.f * (qx * (vR[2][1] - vR[1][2]) + qy * (vR[0][2] - vR[2][0]) + qz * (vR[1][0] - vR[0][1]));
+    const float gqx = 2.f * (-2.f * qx * (vR[1][1] + vR[2][2]) + qy * (vR[0][1] + vR[1][0]) +
+                             qz * (vR[0][2] + vR[2][0]) + qw * (vR[2][1] - vR[1][2]));
+    const float gqy = 2.f * (qx * (vR[0][1] + vR[1][0]) - 2.f * qy * (vR[0][0] + vR[2][2]) +
+                             qz * (vR[1][2] + vR[2][1]) + qw * (vR[0][2] - vR[2][0]));
+    const float gqz = 2.f * (qx * (vR[0][2] + vR[2][0]) + qy * (vR[1][2] + vR[2][1]) -
+                             2.f * qz * (vR[0][0] + vR[1][1]) + qw * (vR[1][0] - vR[0][1]));
+    // through q_hat = q/|q|
+    const float dotp = gw * qw + gqx * qx + gqy * qy + gqz * qz;
+    v_means[n * 3 + 0] = g_mean[0];
+    v_means[n * 3 + 1] = g_mean[1];
+    v_means[n * 3 + 2] = g_mean[2];
+    reinterpret_cast<float4 *>(v_quats)[n] =
+        make_float4((gw - dotp * qw) * inv, (gqx - dotp * qx) * inv, (gqy - dotp * qy) * inv,
+                    (gqz - dotp * qz) * inv);
+    v_scales[n * 3 + 0] = vs[0];
+    v_scales[n * 3 + 1] = vs[1];
+    v_scales[n * 3 + 2] = vs[2];
+}
+
+}  // namespace fsgs
+
+using namespace fsgs;
+
+extern "C" int fsgs_project_fwd(int C, int N, const float *means, const float *quats,
+                                const float *scales, const float *viewmats, const float *Ks,
+                                int width, int height, float eps2d, float near_plane,
+                                float far_plane, float radius_clip, int32_t *radii, float *means2d,
+                                float *depths, float *conics, float *compensations,
+                                fsgs_stream_t stream) {
+    if (C < 0 || N < 0) return FSGS_EINVAL;
+    if ((int64_t)C * N == 0) return FSGS_OK;
+    if (!means || !quats || !scales || !viewmats || !Ks || !radii || !means2d || !depths || !conics)
+        return FSGS_EINVAL;
+    const int64_t total = (int64_t)C * N;
+    hipLaunchKernelGGL(project_fwd_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, as_stream(stream),
+                       C, N, means, quats, scales, viewmats, Ks, width, height, eps2d, near_plane,
+                       far_plane, radius_clip, radii, means2d, depths, conics, compensations);
+    return check_launch();
+}
+
+extern "C" int fsgs_project_bwd(int C, int N, const float *means, const float *quats,
+                                const float *scales, const float *viewmats, const float *Ks,
+                                int width, int height, float eps2d, const int32_t *radii,
+                                const float *conics, const float *compensations,
+                                const float *v_means2d, const float *v_depths, const float *v_conics,
+                                const float *v_compensations, float *v_means, float *v_quats,
+                                float *v_scales, float *v_viewmats, fsgs_stream_t stream) {
+    if (C < 0 || N < 0) return FSGS_EINVAL;
+    if (N == 0) return FSGS_OK;
+    if (!means || !quats || !scales || !viewmats || !Ks || !radii || !conics || !v_means2d ||
+        !v_depths || !v_conics || !v_means || !v_quats || !v_scales)
+        return FSGS_EINVAL;
+    hipLaunchKernelGGL(project_bwd_kernel, dim3(ceil_div(N, 256)), dim3(256), 0, as_stream(stream), C,
+                       N, means, quats, scales, viewmats, Ks, width, height, eps2d, radii, conics,
+                       compensations, v_means2d, v_depths, v_conics, v_compensations, v_means,
+                       v_quats, v_scales, v_viewmats);
+    return check_launch();
+}

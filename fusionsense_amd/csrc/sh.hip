@@ -1,0 +1,285 @@
+// E3: view-dependent colour from real spherical harmonics, forward and VJP.
+// Replaces gsplat 1.0.0 `compute_sh_{fwd,bwd}` plus the torch glue that rasterization() wraps
+// around it (`dirs = means - campos`, `+0.5`, `clamp_min(0)`, depth-channel concat for
+// render_mode "RGB+ED") — call site /root/reference/dn_splatter/dn_model.py:570-591.
+//
+// Layout: coeffs[N,K,3] (K*12 = 192 B per Gaussian at degree 3) is the widest per-Gaussian
+// stream on the whole path.  A 256-thread workgroup stages its 256 consecutive Gaussians'
+// records (one contiguous 48 KiB span) through LDS with 16-byte coalesced loads, then each
+// lane consumes its own record; LDS rows are padded by one dword so the per-lane stride is odd.
+#include "common.h"
+
+namespace fsgs {
+
+constexpr int kMaxK = 25;
+
+// basis values b[k] and (optionally) their gradients w.r.t. the unit direction.
+template <bool GRAD>
+__device__ __forceinline__ void sh_basis(int degree, float x, float y, float z, float *b, float *bx,
+                                         float *by, float *bz) {
+    b[0] = 0.2820947917738781f;
+    if (GRAD) bx[0] = by[0] = bz[0] = 0.f;
+    if (degree < 1) return;
+    const float C1 = 0.48860251190292f;
+    b[1] = -C1 * y; b[2] = C1 * z; b[3] = -C1 * x;
+    if (GRAD) {
+        bx[1] = 0.f; by[1] = -C1; bz[1] = 0.f;
+        bx[2] = 0.f; by[2] = 0.f; bz[2] = C1;
+        bx[3] = -C1; by[3] = 0.f; bz[3] = 0.f;
+    }
+    if (degree < 2) return;
+    const float z2 = z * z;
+    const float fTmp0B = -1.092548430592079f * z;
+    const float fC1 = x * x - y * y;
+    const float fS1 = 2.f * x * y;
+    const float kA = 0.5462742152960395f;
+    const float pSH6 = 0.9461746957575601f * z2 - 0.3153915652525201f;
+    b[4] = kA * fS1; b[5] = fTmp0B * y; b[6] = pSH6; b[7] = fTmp0B * x; b[8] = kA * fC1;
+    if (GRAD) {
+        bx[4] = kA * 2.f * y; by[4] = kA * 2.f * x; bz[4] = 0.f;
+        bx[5] = 0.f; by[5] = fTmp0B; bz[5] = -1.092548430592079f * y;
+        bx[6] = 0.f; by[6] = 0.f; bz[6] = 2.f * 0.9461746957575601f * z;
+        bx[7] = fTmp0B; by[7] = 0.f; bz[7] = -1.092548430592079f * x;
+        bx[8] = kA * 2.f * x; by[8] = -kA * 2.f * y; bz[8] = 0.f;
+    }
+    if (degree < 3) return;
+    const float fTmp0C = -2.285228997322329f * z2 + 0.4570457994644658f;
+    const float fTmp1B = 1.445305721320277f * z;
+    const float fC2 = x * fC1 - y * fS1;
+    const float fS2 = x * fS1 + y * fC1;
+    const float pSH12 = z * (1.865881662950577f * z2 - 1.119528997770346f);
+    const float kB = 0.5900435899266435f;
+    b[9] = -kB * fS2; b[10] = fTmp1B * fS1; b[11] = fTmp0C * y; b[12] = pSH12;
+    b[13] = fTmp0C * x; b[14] = fTmp1B * fC1; b[15] = -kB * fC2;
+    const float fTmp0C_z = -2.f * 2.285228997322329f * z;
+    const float pSH12_z = 3.f * 1.865881662950577f * z2 - 1.119528997770346f;
+    if (GRAD) {
+        bx[9] = -kB * 3.f * fS1; by[9] = -kB * 3.f * fC1; bz[9] = 0.f;
+        bx[10] = fTmp1B * 2.f * y; by[10] = fTmp1B * 2.f * x; bz[10] = 1.445305721320277f * fS1;
+        bx[11] = 0.f; by[11] = fTmp0C; bz[11] = fTmp0C_z * y;
+        bx[12] = 0.f; by[12] = 0.f; bz[12] = pSH12_z;
+        bx[13] = fTmp0C; by[13] = 0.f; bz[13] = fTmp0C_z * x;
+        bx[14] = fTmp1B * 2.f * x; by[14] = -fTmp1B * 2.f * y; bz[14] = 1.445305721320277f * fC1;
+        bx[15] = -kB * 3.f * fC1; by[15] = kB * 3.f * fS1; bz[15] = 0.f;
+    }
+    if (degree < 4) return;
+    const float fTmp0D = z * (-4.683325804901025f * z2 + 2.007139630671868f);
+    const float fTmp1C = 3.31161143515146f * z2 - 0.47308734787878f;
+    const float fTmp2B = -1.770130769779931f * z;
+    const float fC3 = x * fC2 - y * fS2;
+    const float fS3 = x * fS2 + y * fC2;
+    const float kC = 0.6258357354491763f;
+    b[16] = kC * fS3; b[17] = fTmp2B * fS2; b[18] = fTmp1C * fS1; b[19] = fTmp0D * y;
+    b[20] = 1.984313483298443f * z * pSH12 - 1.006230589874905f * pSH6;
+    b[21] = fTmp0D * x; b[22] = fTmp1C * fC1; b[23] = fTmp2B * fC2; b[24] = kC * fC3;
+    if (GRAD) {
+        const float fTmp0D_z = -3.f * 4.683325804901025f * z2 + 2.007139630671868f;
+        const float fTmp1C_z = 2.f * 3.31161143515146f * z;
+        bx[16] = kC * 4.f * fS2; by[16] = kC * 4.f * fC2; bz[16] = 0.f;
+        bx[17] = fTmp2B * 3.f * fS1; by[17] = fTmp2B * 3.f * fC1; bz[17] = -1.770130769779931f * fS2;
+        bx[18] = fTmp1C * 2.f * y; by[18] = fTmp1C * 2.f * x; bz[18] = fTmp1C_z * fS1;
+        bx[19] = 0.f; by[19] = fTmp0D; bz[19] = fTmp0D_z * y;
+        bx[20] = 0.f; by[20] = 0.f;
+        bz[20] = 1.984313483298443f * (pSH12 + z * pSH12_z) -
+                 1.006230589874905f * 2.f * 0.9461746957575601f * z;
+        bx[21] = fTmp0D; by[21] = 0.f; bz[21] = fTmp0D_z * x;
+        bx[22] = fTmp1C * 2.f * x; by[22] = -fTmp1C * 2.f * y; bz[22] = fTmp1C_z * fC1;
+        bx[23] = fTmp2B * 3.f * fC1; by[23] = -fTmp2B * 3.f * fS1; bz[23] = -1.770130769779931f * fC2;
+        bx[24] = kC * 4.f * fC2; by[24] = -kC * 4.f * fS2; bz[24] = 0.f;
+    }
+}
+
+constexpr int kShBlock = 256;
+
+// Stage `rows` consecutive records of `row_floats` floats (contiguous in HBM) into LDS with
+// a row pitch of row_floats+1 dwords.
+__device__ __forceinline__ void stage_rows(const float *__restrict__ src, int rows, int row_floats,
+                                           float *lds) {
+    const int total = rows * row_floats;
+    const int pitch = row_floats + 1;
+    // src is 4-byte aligned only in general (row start = n0*K*3 floats); n0 is a multiple of 256
+    // so the span start is 16-byte aligned whenever the tensor base is.
+    const float4 *src4 = reinterpret_cast<const float4 *>(src);
+    const int total4 = total >> 2;
+    for (int i = threadIdx.x; i < total4; i += kShBlock) {
+        const float4 v = src4[i];
+        const int e = i << 2;
+        const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int r = (e + k) / row_floats, col = (e + k) - r * row_floats;
+            lds[r * pitch + col] = vv[k];
+        }
+    }
+    for (int i = (total4 << 2) + threadIdx.x; i < total; i += kShBlock) {
+        const int r = i / row_floats, col = i - r * row_floats;
+        lds[r * pitch + col] = src[i];
+    }
+}
+
+__global__ void __launch_bounds__(kShBlock)
+sh_fwd_kernel(int C, int N, int K, int degree, const float *__restrict__ means,
+              const float *__restrict__ campos, const float *__restrict__ coeffs,
+              const int32_t *__restrict__ radii, const float *__restrict__ depths,
+              float *__restrict__ colors_out) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int n0 = blockIdx.x * kShBlock;
+    const int rows = min(kShBlock, N - n0);
+    const int kk = (degree + 1) * (degree + 1);
+    const int row_floats = K * 3;
+    stage_rows(coeffs + (int64_t)n0 * row_floats, rows, row_floats, lds);
+    __syncthreads();
+    const int n = n0 + threadIdx.x;
+    if (n >= N) return;
+    const float *my = lds + threadIdx.x * (row_floats + 1);
+    const float mx = means[n * 3 + 0], myy = means[n * 3 + 1], mz = means[n * 3 + 2];
+    const int D = depths ? 4 : 3;
+    for (int c = 0; c < C; ++c) {
+        const int64_t idx = (int64_t)c * N + n;
+        float r = 0.5f, g = 0.5f, bl = 0.5f;
+        if (radii[idx] > 0) {
+            float dx = mx - campos[c * 3 + 0], dy = myy - campos[c * 3 + 1], dz = mz - campos[c * 3 + 2];
+            const float inorm = 1.f / fmaxf(sqrtf(dx * dx + dy * dy + dz * dz), 1e-12f);
+            dx *= inorm; dy *= inorm; dz *= inorm;
+            float b[kMaxK];
+            sh_basis<false>(degree, dx, dy, dz, b, nullptr, nullptr, nullptr);
+            float ar = 0.f, ag = 0.f, ab = 0.f;
+#pragma unroll
+            for (int k = 0; k < kMaxK; ++k) {
+                if (k < kk) {
+                    ar += b[k] * my[k * 3 + 0];
+                    ag += b[k] * my[k * 3 + 1];
+                    ab += b[k] * my[k * 3 + 2];
+                }
+            }
+            r = fmaxf(ar + 0.5f, 0.f);
+            g = fmaxf(ag + 0.5f, 0.f);
+            bl = fmaxf(ab + 0.5f, 0.f);
+        }
+        if (D == 4) {
+            reinterpret_cast<float4 *>(colors_out)[idx] = make_float4(r, g, bl, depths[idx]);
+        } else {
+            colors_out[idx * 3 + 0] = r;
+            colors_out[idx * 3 + 1] = g;
+            colors_out[idx * 3 + 2] = bl;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(kShBlock)
+sh_bwd_kernel(int C, int N, int K, int degree, const float *__restrict__ means,
+              const float *__restrict__ campos, const float *__restrict__ coeffs,
+              const int32_t *__restrict__ radii, int D, const float *__restrict__ v_colors,
+              float *__restrict__ v_coeffs, float *__restrict__ v_means,
+              float *__restrict__ v_depths) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int n0 = blockIdx.x * kShBlock;
+    const int rows = min(kShBlock, N - n0);
+    const int kk = (degree + 1) * (degree + 1);
+    const int row_floats = K * 3;
+    const int pitch = row_floats + 1;
+    stage_rows(coeffs + (int64_t)n0 * row_floats, rows, row_floats, lds);
+    __syncthreads();
+    const int n = n0 + threadIdx.x;
+    float *my = lds + threadIdx.x * pitch;
+    if (n < N) {
+        const float mx = means[n * 3 + 0], myy = means[n * 3 + 1], mz = means[n * 3 + 2];
+        float acc[kMaxK * 3];
+#pragma unroll
+        for (int k = 0; k < kMaxK * 3; ++k) acc[k] = 0.f;
+        float gmx = 0.f, gmy = 0.f, gmz = 0.f;
+        for (int c = 0; c < C; ++c) {
+            const int64_t idx = (int64_t)c * N + n;
+            if (D == 4 && v_depths) v_depths[idx] = v_colors[idx * 4 + 3];
+            if (radii[idx] <= 0) continue;
+            float dx = mx - campos[c * 3 + 0], dy = myy - campos[c * 3 + 1], dz = mz - campos[c * 3 + 2];
+            const float inorm = 1.f / fmaxf(sqrtf(dx * dx + dy * dy + dz * dz), 1e-12f);
+            dx *= inorm; dy *= inorm; dz *= inorm;
+            float b[kMaxK], bx[kMaxK], by[kMaxK], bz[kMaxK];
+            sh_basis<true>(degree, dx, dy, dz, b, bx, by, bz);
+            float ar = 0.f, ag = 0.f, ab = 0.f;
+#pragma unroll
+            for (int k = 0; k < kMaxK; ++k) {
+                if (k < kk) {
+                    ar += b[k] * my[k * 3 + 0];
+                    ag += b[k] * my[k * 3 + 1];
+                    ab += b[k] * my[k * 3 + 2];
+                }
+            }
+            // clamp_min(colour + 0.5, 0): gradient passes only where the clamp is inactive
+            const float vr = (ar + 0.5f > 0.f) ? v_colors[idx * D + 0] : 0.f;
+            const float vg = (ag + 0.5f > 0.f) ? v_colors[idx * D + 1] : 0.f;
+            const float vb = (ab + 0.5f > 0.f) ? v_colors[idx * D + 2] : 0.f;
+            float gdx = 0.f, gdy = 0.f, gdz = 0.f;
+#pragma unroll
+            for (int k = 0; k < kMaxK; ++k) {
+                if (k < kk) {
+                    acc[k * 3 + 0] += b[k] * vr;
+                    acc[k * 3 + 1] += b[k] * vg;
+                    acc[k * 3 + 2] += b[k] * vb;
+                    const float w = my[k * 3 + 0] * vr + my[k * 3 + 1] * vg + my[k * 3 + 2] * vb;
+                    gdx += bx[k] * w;
+                    gdy += by[k] * w;
+                    gdz += bz[k] * w;
+                }
+            }
+            // through normalisation: v_dir = (g - (g.d) d) / |dir|
+            const float dp = gdx * dx + gdy * dy + gdz * dz;
+            gmx += (gdx - dp * dx) * inorm;
+            gmy += (gdy - dp * dy) * inorm;
+            gmz += (gdz - dp * dz) * inorm;
+        }
+        v_means[n * 3 + 0] += gmx;
+        v_means[n * 3 + 1] += gmy;
+        v_means[n * 3 + 2] += gmz;
+        // reuse this lane's LDS row for the coefficient gradient, then stream it out coalesced
+#pragma unroll
+        for (int k = 0; k < kMaxK; ++k) {
+            if (k < K) {
+                my[k * 3 + 0] = (k < kk) ? acc[k * 3 + 0] : 0.f;
+                my[k * 3 + 1] = (k < kk) ? acc[k * 3 + 1] : 0.f;
+                my[k * 3 + 2] = (k < kk) ? acc[k * 3 + 2] : 0.f;
+            }
+        }
+    }
+    __syncthreads();
+    float *dst = v_coeffs + (int64_t)n0 * row_floats;
+    const int total = rows * row_floats;
+    for (int i = threadIdx.x; i < total; i += kShBlock) {
+        const int r = i / row_floats, col = i - r * row_floats;
+        dst[i] = lds[r * pitch + col];
+    }
+}
+
+}  // namespace fsgs
+
+using namespace fsgs;
+
+extern "C" int fsgs_sh_fwd(int C, int N, int K, int degree, const float *means, const float *campos,
+                           const float *coeffs, const int32_t *radii, const float *depths,
+                           float *colors_out, fsgs_stream_t stream) {
+    if (C < 0 || N < 0 || degree < 0 || degree > 4 || K < (degree + 1) * (degree + 1) || K > kMaxK)
+        return FSGS_EINVAL;
+    if ((int64_t)C * N == 0) return FSGS_OK;
+    if (!means || !campos || !coeffs || !radii || !colors_out) return FSGS_EINVAL;
+    const size_t lds_bytes = (size_t)kShBlock * (K * 3 + 1) * sizeof(float);
+    hipLaunchKernelGGL(sh_fwd_kernel, dim3(ceil_div(N, kShBlock)), dim3(kShBlock), lds_bytes,
+                       as_stream(stream), C, N, K, degree, means, campos, coeffs, radii, depths,
+                       colors_out);
+    return check_launch();
+}
+
+extern "C" int fsgs_sh_bwd(int C, int N, int K, int degree, const float *means, const float *campos,
+                           const float *coeffs, const int32_t *radii, int D, const float *v_colors,
+                           float *v_coeffs, float *v_means, float *v_depths, fsgs_stream_t stream) {
+    if (C < 0 || N < 0 || degree < 0 || degree > 4 || K < (degree + 1) * (degree + 1) || K > kMaxK ||
+        (D != 3 && D != 4))
+        return FSGS_EINVAL;
+    if (N == 0) return FSGS_OK;
+    if (!means || !campos || !coeffs || !radii || !v_colors || !v_coeffs || !v_means) return FSGS_EINVAL;
+    const size_t lds_bytes = (size_t)kShBlock * (K * 3 + 1) * sizeof(float);
+    hipLaunchKernelGGL(sh_bwd_kernel, dim3(ceil_div(N, kShBlock)), dim3(kShBlock), lds_bytes,
+                       as_stream(stream), C, N, K, degree, means, campos, coeffs, radii, D, v_colors,
+                       v_coeffs, v_means, v_depths);
+    return check_launch();
+}

@@ -1,0 +1,173 @@
+// E5: stable LSD radix sort of (int64 key, int32 value) pairs — the depth sort within tiles
+// (SURVEY.md §8a-6).  Replaces `cub::DeviceRadixSort::SortPairs` inside gsplat 1.0.0's
+// isect_tiles (reached from /root/reference/dn_splatter/dn_model.py:570-591) and the
+// `torch.sort` of the legacy path (dn_model.py:644-653).
+//
+// Written for wave64: 8-bit digits; a workgroup of 4 waves owns a tile of 4 x R x 64 keys, wave w
+// owning the contiguous slice [w*R*64, (w+1)*R*64) so that "earlier key" == (wave, round, lane)
+// order and every load is a 512-byte coalesced row.  Lanes with equal digits find each other
+// with 8 wave ballots (the 64-bit exec-mask form of a match-any), so ranking needs neither LDS
+// atomics nor a per-lane counter array: one LDS counter row per wave, touched once per group.
+// Stability makes the result bit-identical to any other stable sort of the same keys.
+#include "common.h"
+#include "scan.h"
+
+namespace fsgs {
+
+constexpr int kSortWaves = 4;
+constexpr int kSortBlock = kSortWaves * 64;
+constexpr int kSortRounds = 8;
+constexpr int kSortTile = kSortBlock * kSortRounds;  // 2048 keys per workgroup
+constexpr int kRadix = 256;
+
+// Mask of lanes in this wave whose digit equals mine (inactive lanes pass active=false).
+__device__ __forceinline__ unsigned long long match_digit(unsigned d, bool active) {
+    unsigned long long m = __ballot(active);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+        const unsigned long long vote = __ballot((d >> b) & 1u);
+        m &= ((d >> b) & 1u) ? vote : ~vote;
+    }
+    return m;
+}
+
+__device__ __forceinline__ unsigned long long lanemask_lt() {
+    const int lane = threadIdx.x & 63;
+    return (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+}
+
+// Per-workgroup digit histogram, written digit-major: hist[d * nblocks + block].
+__global__ void __launch_bounds__(kSortBlock)
+radix_hist_kernel(int64_t n, const uint64_t *__restrict__ keys, int shift, int nblocks,
+                  int32_t *__restrict__ hist) {
+    __shared__ unsigned counters[kSortWaves][kRadix];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int i = threadIdx.x; i < kSortWaves * kRadix; i += kSortBlock) (&counters[0][0])[i] = 0;
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * kSortTile + (int64_t)w * (kSortRounds * 64);
+#pragma unroll
+    for (int r = 0; r < kSortRounds; ++r) {
+        const int64_t i = base + r * 64 + lane;
+        const bool act = i < n;
+        const unsigned d = act ? (unsigned)((keys[i] >> shift) & 0xFFu) : 0u;
+        const unsigned long long m = match_digit(d, act);
+        if (act && (m & lanemask_lt()) == 0) counters[w][d] += (unsigned)__popcll(m);
+    }
+    __syncthreads();
+    for (int d = threadIdx.x; d < kRadix; d += kSortBlock) {
+        unsigned s = 0;
+#pragma unroll
+        for (int k = 0; k < kSortWaves; ++k) s += counters[k][d];
+        hist[(int64_t)d * nblocks + blockIdx.x] = (int32_t)s;
+    }
+}
+
+__global__ void __launch_bounds__(kSortBlock)
+radix_scatter_kernel(int64_t n, const uint64_t *__restrict__ keys_in, const int32_t *__restrict__ vals_in,
+                     uint64_t *__restrict__ keys_out, int32_t *__restrict__ vals_out, int shift,
+                     int nblocks, const int64_t *__restrict__ hist_scanned) {
+    __shared__ unsigned counters[kSortWaves][kRadix];
+    __shared__ int64_t bases[kSortWaves][kRadix];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int i = threadIdx.x; i < kSortWaves * kRadix; i += kSortBlock) (&counters[0][0])[i] = 0;
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * kSortTile + (int64_t)w * (kSortRounds * 64);
+    uint64_t key[kSortRounds];
+    int32_t val[kSortRounds];
+    unsigned rank[kSortRounds];
+    const unsigned long long lt = lanemask_lt();
+#pragma unroll
+    for (int r = 0; r < kSortRounds; ++r) {
+        const int64_t i = base + r * 64 + lane;
+        const bool act = i < n;
+        key[r] = act ? keys_in[i] : 0ull;
+        val[r] = act ? vals_in[i] : 0;
+    }
+#pragma unroll
+    for (int r = 0; r < kSortRounds; ++r) {
+        const int64_t i = base + r * 64 + lane;
+        const bool act = i < n;
+        const unsigned d = (unsigned)((key[r] >> shift) & 0xFFu);
+        const unsigned long long m = match_digit(d, act);
+        const unsigned before = (unsigned)__popcll(m & lt);
+        unsigned prev = 0;
+        if (act) prev = counters[w][d];
+        // every lane of the group has read `prev` (same wave, program order) before the
+        // group leader bumps the counter
+        if (act && before == 0) counters[w][d] = prev + (unsigned)__popcll(m);
+        rank[r] = prev + before;
+    }
+    __syncthreads();
+    for (int d = threadIdx.x; d < kRadix; d += kSortBlock) {
+        int64_t run = hist_scanned[(int64_t)d * nblocks + blockIdx.x];
+#pragma unroll
+        for (int k = 0; k < kSortWaves; ++k) {
+            bases[k][d] = run;
+            run += counters[k][d];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < kSortRounds; ++r) {
+        const int64_t i = base + r * 64 + lane;
+        if (i < n) {
+            const unsigned d = (unsigned)((key[r] >> shift) & 0xFFu);
+            const int64_t pos = bases[w][d] + rank[r];
+            keys_out[pos] = key[r];
+            vals_out[pos] = val[r];
+        }
+    }
+}
+
+inline int64_t sort_num_blocks(int64_t n) { return (n + kSortTile - 1) / kSortTile; }
+
+}  // namespace fsgs
+
+using namespace fsgs;
+
+// scratch layout: [hist int32: 256*nb] [hist_scanned int64: 256*nb] [scan block sums]
+extern "C" size_t fsgs_sort_scratch_bytes(int64_t n) {
+    const int64_t nb = sort_num_blocks(n > 0 ? n : 1);
+    const int64_t h = kRadix * nb;
+    size_t bytes = (size_t)h * sizeof(int32_t);
+    bytes = (bytes + 15) & ~(size_t)15;
+    bytes += (size_t)h * sizeof(int64_t);
+    bytes += fsgs_scan_scratch_bytes(h);
+    return bytes + 64;
+}
+
+extern "C" int fsgs_sort_pairs(int64_t n, int64_t *keys_a, int32_t *vals_a, int64_t *keys_b,
+                               int32_t *vals_b, int end_bit, void *scratch, size_t scratch_bytes,
+                               int *result_in_b, fsgs_stream_t stream) {
+    if (n < 0 || end_bit < 0 || end_bit > 64 || !result_in_b) return FSGS_EINVAL;
+    *result_in_b = 0;
+    if (n <= 1 || end_bit == 0) return FSGS_OK;
+    if (!keys_a || !vals_a || !keys_b || !vals_b || !scratch) return FSGS_EINVAL;
+    if (scratch_bytes < fsgs_sort_scratch_bytes(n)) return FSGS_ESCRATCH;
+    const int64_t nb = sort_num_blocks(n);
+    const int64_t h = kRadix * nb;
+    char *p = reinterpret_cast<char *>(scratch);
+    int32_t *hist = reinterpret_cast<int32_t *>(p);
+    size_t off = ((size_t)h * sizeof(int32_t) + 15) & ~(size_t)15;
+    int64_t *hist_scanned = reinterpret_cast<int64_t *>(p + off);
+    off += (size_t)h * sizeof(int64_t);
+    void *scan_scratch = p + off;
+    const size_t scan_bytes = scratch_bytes - off;
+    hipStream_t s = as_stream(stream);
+    uint64_t *kin = reinterpret_cast<uint64_t *>(keys_a), *kout = reinterpret_cast<uint64_t *>(keys_b);
+    int32_t *vin = vals_a, *vout = vals_b;
+    int in_b = 0;
+    for (int shift = 0; shift < end_bit; shift += 8) {
+        hipLaunchKernelGGL(radix_hist_kernel, dim3((unsigned)nb), dim3(kSortBlock), 0, s, n, kin, shift,
+                           (int)nb, hist);
+        int rc = device_scan<int32_t, false>(h, hist, hist_scanned, scan_scratch, scan_bytes, s);
+        if (rc != FSGS_OK) return rc;
+        hipLaunchKernelGGL(radix_scatter_kernel, dim3((unsigned)nb), dim3(kSortBlock), 0, s, n, kin, vin,
+                           kout, vout, shift, (int)nb, hist_scanned);
+        uint64_t *tk = kin; kin = kout; kout = tk;
+        int32_t *tv = vin; vin = vout; vout = tv;
+        in_b ^= 1;
+    }
+    *result_in_b = in_b;
+    return check_launch();
+}

@@ -1,0 +1,339 @@
+"""Operator layer: thin Python wrappers + autograd Functions over the C-ABI (include/fsgs.h).
+
+These are the operators gsplat 1.0.0 exposes under ``gsplat.cuda._wrapper`` and that
+``gsplat.rendering.rasterization`` (reference call site dn_splatter/dn_model.py:570-591)
+strings together.  torch provides device memory, the current stream and the autograd tape;
+all arithmetic happens in libfsgs.so.  There is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Optional, Tuple
+
+import torch
+from torch import Tensor
+
+from . import _lib
+from ._lib import check, load, ptr, stream_ptr
+
+
+def _c(t: Optional[Tensor]) -> Optional[Tensor]:
+    return None if t is None else t.contiguous()
+
+
+def tile_bits(n_tiles: int) -> int:
+    return int(math.floor(math.log2(n_tiles))) + 1 if n_tiles > 0 else 1
+
+
+# --------------------------------------------------------------------------------------
+# raw (non-differentiable) calls
+# --------------------------------------------------------------------------------------
+def project_fwd(means, quats, scales, viewmats, Ks, width, height, eps2d, near_plane, far_plane,
+                radius_clip, calc_compensations=False):
+    lib = load()
+    N, Cn = means.shape[0], viewmats.shape[0]
+    dev = means.device
+    radii = torch.empty(Cn, N, dtype=torch.int32, device=dev)
+    means2d = torch.empty(Cn, N, 2, dtype=torch.float32, device=dev)
+    depths = torch.empty(Cn, N, dtype=torch.float32, device=dev)
+    conics = torch.empty(Cn, N, 3, dtype=torch.float32, device=dev)
+    comp = torch.empty(Cn, N, dtype=torch.float32, device=dev) if calc_compensations else None
+    check(lib.fsgs_project_fwd(Cn, N, ptr(means), ptr(quats), ptr(scales), ptr(viewmats), ptr(Ks),
+                               width, height, eps2d, near_plane, far_plane, radius_clip, ptr(radii),
+                               ptr(means2d), ptr(depths), ptr(conics), ptr(comp), stream_ptr(dev)),
+          "fsgs_project_fwd")
+    return radii, means2d, depths, conics, comp
+
+
+def isect_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tile_size: int, tile_width: int,
+                tile_height: int, legacy: bool = False, sort: bool = True):
+    """Returns tiles_per_gauss [C,N] i32, isect_ids [M] i64, flatten_ids [M] i32 (sorted if
+    ``sort``).  One host sync (n_isects), like the reference."""
+    lib = load()
+    dev = means2d.device
+    Cn, N = radii.shape
+    total = Cn * N
+    tpg = torch.empty(Cn, N, dtype=torch.int32, device=dev)
+    cum = torch.empty(max(total, 1), dtype=torch.int64, device=dev)
+    sbytes = lib.fsgs_scan_scratch_bytes(max(total, 1))
+    scratch = torch.empty(sbytes, dtype=torch.uint8, device=dev)
+    m_host = C.c_int64(0)
+    check(lib.fsgs_isect_count(Cn, N, ptr(means2d), ptr(radii), tile_size, tile_width, tile_height,
+                               int(legacy), ptr(tpg), ptr(cum), ptr(scratch), sbytes, C.byref(m_host),
+                               stream_ptr(dev)), "fsgs_isect_count")
+    M = int(m_host.value)
+    ids = torch.empty(M, dtype=torch.int64, device=dev)
+    flat = torch.empty(M, dtype=torch.int32, device=dev)
+    if M > 0:
+        check(lib.fsgs_isect_emit(Cn, N, ptr(means2d), ptr(radii), ptr(depths), ptr(cum), tile_size,
+                                  tile_width, tile_height, int(legacy), ptr(ids), ptr(flat),
+                                  stream_ptr(dev)), "fsgs_isect_emit")
+        if sort:
+            n_tiles = tile_width * tile_height
+            cam_bits = tile_bits(Cn) if Cn > 1 else 0
+            end_bit = 32 + tile_bits(n_tiles) + cam_bits
+            ids, flat = sort_pairs(ids, flat, end_bit)
+    return tpg, ids, flat
+
+
+def sort_pairs(keys: Tensor, vals: Tensor, end_bit: int = 64) -> Tuple[Tensor, Tensor]:
+    """Stable radix sort of (i64, i32) pairs on key bits [0, end_bit).  Inputs are clobbered."""
+    lib = load()
+    n = keys.numel()
+    if n <= 1:
+        return keys, vals
+    dev = keys.device
+    kb = torch.empty_like(keys)
+    vb = torch.empty_like(vals)
+    sbytes = lib.fsgs_sort_scratch_bytes(n)
+    scratch = torch.empty(sbytes, dtype=torch.uint8, device=dev)
+    in_b = C.c_int(0)
+    check(lib.fsgs_sort_pairs(n, ptr(keys), ptr(vals), ptr(kb), ptr(vb), end_bit, ptr(scratch), sbytes,
+                              C.byref(in_b), stream_ptr(dev)), "fsgs_sort_pairs")
+    return (kb, vb) if in_b.value else (keys, vals)
+
+
+def isect_offset_encode(isect_ids: Tensor, n_cameras: int, tile_width: int, tile_height: int) -> Tensor:
+    lib = load()
+    dev = isect_ids.device
+    n_tiles = tile_width * tile_height
+    offsets = torch.empty(n_cameras, tile_height, tile_width, dtype=torch.int32, device=dev)
+    check(lib.fsgs_isect_offset_encode(isect_ids.numel(), ptr(isect_ids), n_cameras, n_tiles,
+                                       tile_bits(n_tiles), ptr(offsets), stream_ptr(dev)),
+          "fsgs_isect_offset_encode")
+    return offsets
+
+
+# --------------------------------------------------------------------------------------
+# autograd Functions
+# --------------------------------------------------------------------------------------
+class _Projection(torch.autograd.Function):
+    """fully_fused_projection."""
+
+    @staticmethod
+    def forward(ctx, means, quats, scales, viewmats, Ks, width, height, eps2d, near_plane, far_plane,
+                radius_clip, calc_compensations):
+        means, quats, scales, viewmats, Ks = map(_c, (means, quats, scales, viewmats, Ks))
+        radii, means2d, depths, conics, comp = project_fwd(
+            means, quats, scales, viewmats, Ks, width, height, eps2d, near_plane, far_plane, radius_clip,
+            calc_compensations)
+        ctx.save_for_backward(means, quats, scales, viewmats, Ks, radii, conics,
+                              comp if comp is not None else torch.empty(0, device=means.device))
+        ctx.dims = (width, height, eps2d, calc_compensations)
+        ctx.mark_non_differentiable(radii)
+        if comp is None:
+            comp = torch.empty(0, device=means.device)
+            ctx.mark_non_differentiable(comp)
+        return radii, means2d, depths, conics, comp
+
+    @staticmethod
+    def backward(ctx, _v_radii, v_means2d, v_depths, v_conics, v_comp):
+        means, quats, scales, viewmats, Ks, radii, conics, comp = ctx.saved_tensors
+        width, height, eps2d, calc_comp = ctx.dims
+        lib = load()
+        dev = means.device
+        Cn, N = radii.shape
+        v_means2d = _c(v_means2d) if v_means2d is not None else torch.zeros(Cn, N, 2, device=dev)
+        v_depths = _c(v_depths) if v_depths is not None else torch.zeros(Cn, N, device=dev)
+        v_conics = _c(v_conics) if v_conics is not None else torch.zeros(Cn, N, 3, device=dev)
+        use_comp = calc_comp and v_comp is not None
+        v_means = torch.empty_like(means)
+        v_quats = torch.empty_like(quats)
+        v_scales = torch.empty_like(scales)
+        v_viewmats = torch.zeros_like(viewmats) if ctx.needs_input_grad[3] else None
+        check(lib.fsgs_project_bwd(Cn, N, ptr(means), ptr(quats), ptr(scales), ptr(viewmats), ptr(Ks),
+                                   width, height, eps2d, ptr(radii), ptr(conics),
+                                   ptr(comp) if use_comp else None, ptr(v_means2d), ptr(v_depths),
+                                   ptr(v_conics), ptr(_c(v_comp)) if use_comp else None, ptr(v_means),
+                                   ptr(v_quats), ptr(v_scales), ptr(v_viewmats), stream_ptr(dev)),
+              "fsgs_project_bwd")
+        return (v_means, v_quats, v_scales, v_viewmats, None, None, None, None, None, None, None, None)
+
+
+class _SHColors(torch.autograd.Function):
+    """spherical_harmonics fused with the rasterization() glue: dirs, +0.5, clamp_min(0) and the
+    optional depth channel."""
+
+    @staticmethod
+    def forward(ctx, means, coeffs, campos, radii, depths, degree):
+        means, coeffs, campos = map(_c, (means, coeffs, campos))
+        depths = _c(depths)
+        lib = load()
+        dev = means.device
+        Cn, N = radii.shape
+        K = coeffs.shape[1]
+        D = 4 if depths is not None else 3
+        colors = torch.empty(Cn, N, D, dtype=torch.float32, device=dev)
+        check(lib.fsgs_sh_fwd(Cn, N, K, degree, ptr(means), ptr(campos), ptr(coeffs), ptr(radii),
+                              ptr(depths), ptr(colors), stream_ptr(dev)), "fsgs_sh_fwd")
+        ctx.save_for_backward(means, coeffs, campos, radii)
+        ctx.meta = (degree, D, depths is not None)
+        return colors
+
+    @staticmethod
+    def backward(ctx, v_colors):
+        means, coeffs, campos, radii = ctx.saved_tensors
+        degree, D, has_depth = ctx.meta
+        lib = load()
+        dev = means.device
+        Cn, N = radii.shape
+        K = coeffs.shape[1]
+        v_colors = _c(v_colors)
+        v_coeffs = torch.empty_like(coeffs)
+        v_means = torch.zeros_like(means)
+        v_depths = torch.empty(Cn, N, dtype=torch.float32, device=dev) if has_depth else None
+        check(lib.fsgs_sh_bwd(Cn, N, K, degree, ptr(means), ptr(campos), ptr(coeffs), ptr(radii), D,
+                              ptr(v_colors), ptr(v_coeffs), ptr(v_means), ptr(v_depths), stream_ptr(dev)),
+              "fsgs_sh_bwd")
+        return v_means, v_coeffs, None, None, v_depths, None
+
+
+class _Rasterize(torch.autograd.Function):
+    """rasterize_to_pixels.  D in {1,3,4}."""
+
+    @staticmethod
+    def forward(ctx, means2d, conics, colors, opacities, backgrounds, isect_offsets, flatten_ids, width,
+                height, tile_size, absgrad):
+        means2d_in = means2d
+        means2d, conics, colors, opacities = map(_c, (means2d, conics, colors, opacities))
+        backgrounds = _c(backgrounds)
+        lib = load()
+        dev = means2d.device
+        Cn, N = opacities.shape
+        D = colors.shape[-1]
+        th, tw = isect_offsets.shape[1:]
+        M = flatten_ids.numel()
+        render = torch.empty(Cn, height, width, D, dtype=torch.float32, device=dev)
+        alphas = torch.empty(Cn, height, width, 1, dtype=torch.float32, device=dev)
+        last_ids = torch.empty(Cn, height, width, dtype=torch.int32, device=dev)
+        check(lib.fsgs_raster_fwd(Cn, N, D, ptr(means2d), ptr(conics), ptr(colors), ptr(opacities),
+                                  ptr(backgrounds), width, height, tile_size, tw, th, ptr(isect_offsets),
+                                  ptr(flatten_ids), M, ptr(render), ptr(alphas), ptr(last_ids),
+                                  stream_ptr(dev)), "fsgs_raster_fwd")
+        ctx.save_for_backward(means2d, conics, colors, opacities,
+                              backgrounds if backgrounds is not None else torch.empty(0, device=dev),
+                              isect_offsets, flatten_ids, alphas, last_ids)
+        ctx.dims = (width, height, tile_size, absgrad, backgrounds is not None)
+        # the tensor object the caller holds (meta["means2d"]) receives `.absgrad` in backward
+        ctx.means2d_obj = means2d_in
+        ctx.mark_non_differentiable(last_ids)
+        return render, alphas, last_ids
+
+    @staticmethod
+    def backward(ctx, v_render, v_alphas, _v_last):
+        (means2d, conics, colors, opacities, backgrounds, isect_offsets, flatten_ids, alphas,
+         last_ids) = ctx.saved_tensors
+        width, height, tile_size, absgrad, has_bg = ctx.dims
+        lib = load()
+        dev = means2d.device
+        Cn, N = opacities.shape
+        D = colors.shape[-1]
+        th, tw = isect_offsets.shape[1:]
+        M = flatten_ids.numel()
+        v_render = _c(v_render) if v_render is not None else torch.zeros(Cn, height, width, D, device=dev)
+        v_alphas = _c(v_alphas) if v_alphas is not None else torch.zeros(Cn, height, width, 1, device=dev)
+        v_means2d = torch.zeros_like(means2d)
+        v_conics = torch.zeros_like(conics)
+        v_colors = torch.zeros_like(colors)
+        v_opacities = torch.zeros_like(opacities)
+        v_abs = torch.zeros_like(means2d) if absgrad else None
+        check(lib.fsgs_raster_bwd(Cn, N, D, ptr(means2d), ptr(conics), ptr(colors), ptr(opacities),
+                                  ptr(backgrounds) if has_bg else None, width, height, tile_size, tw, th,
+                                  ptr(isect_offsets), ptr(flatten_ids), M, ptr(alphas), ptr(last_ids),
+                                  ptr(v_render), ptr(v_alphas), ptr(v_means2d), ptr(v_abs), ptr(v_conics),
+                                  ptr(v_colors), ptr(v_opacities), stream_ptr(dev)), "fsgs_raster_bwd")
+        if absgrad:
+            ctx.means2d_obj.absgrad = v_abs
+        v_bg = None
+        if has_bg and ctx.needs_input_grad[4]:
+            v_bg = (v_render * (1.0 - alphas)).sum(dim=(1, 2))
+        ctx.means2d_obj = None
+        return v_means2d, v_conics, v_colors, v_opacities, v_bg, None, None, None, None, None, None
+
+
+class _GaussianNormals(torch.autograd.Function):
+    """Per-Gaussian normals of dn_splatter/dn_model.py:618-636 in one kernel."""
+
+    @staticmethod
+    def forward(ctx, quats, log_scales, means, c2w):
+        quats, log_scales, means, c2w = map(_c, (quats, log_scales, means, c2w))
+        lib = load()
+        dev = quats.device
+        N = quats.shape[0]
+        n_world = torch.empty(N, 3, dtype=torch.float32, device=dev)
+        n_cam = torch.empty(N, 3, dtype=torch.float32, device=dev)
+        check(lib.fsgs_normals_fwd(N, ptr(quats), ptr(log_scales), ptr(means), ptr(c2w), ptr(n_world),
+                                   ptr(n_cam), stream_ptr(dev)), "fsgs_normals_fwd")
+        ctx.save_for_backward(quats, log_scales, means, c2w)
+        ctx.mark_non_differentiable(n_world)
+        return n_world, n_cam
+
+    @staticmethod
+    def backward(ctx, _v_world, v_cam):
+        quats, log_scales, means, c2w = ctx.saved_tensors
+        lib = load()
+        dev = quats.device
+        N = quats.shape[0]
+        v_quats = torch.empty_like(quats)
+        check(lib.fsgs_normals_bwd(N, ptr(quats), ptr(log_scales), ptr(means), ptr(c2w), ptr(_c(v_cam)),
+                                   ptr(v_quats), stream_ptr(dev)), "fsgs_normals_bwd")
+        return v_quats, None, None, None
+
+
+def gaussian_normals(quats: Tensor, log_scales: Tensor, means: Tensor, c2w: Tensor):
+    """-> (normals_world [N,3] detached, normals_cam [N,3] differentiable w.r.t. quats)."""
+    return _GaussianNormals.apply(quats, log_scales, means.detach(), c2w.detach()[:3, :4])
+
+
+def densify_stats_(radii: Tensor, absgrad: Tensor, max_hw: int, xys_grad_norm: Tensor,
+                   vis_counts: Tensor, max_2Dsize: Tensor) -> None:
+    """In-place SplatfactoModel.after_train accumulation."""
+    lib = load()
+    N = radii.numel()
+    check(lib.fsgs_densify_stats(N, ptr(radii), ptr(_c(absgrad)), 1.0 / float(max_hw), ptr(xys_grad_norm),
+                                 ptr(vis_counts), ptr(max_2Dsize), stream_ptr(radii.device)),
+          "fsgs_densify_stats")
+
+
+def mask_positions(keep: Tensor) -> Tensor:
+    """Exclusive scan of a bool/uint8 keep mask -> destination row of every kept row (i64)."""
+    lib = load()
+    keep8 = keep.to(torch.uint8).contiguous()
+    n = keep8.numel()
+    pos = torch.empty(max(n, 1), dtype=torch.int64, device=keep.device)
+    sbytes = lib.fsgs_scan_scratch_bytes(max(n, 1))
+    scratch = torch.empty(sbytes, dtype=torch.uint8, device=keep.device)
+    check(lib.fsgs_mask_scan(n, ptr(keep8), ptr(pos), ptr(scratch), sbytes, stream_ptr(keep.device)),
+          "fsgs_mask_scan")
+    return pos[:n]
+
+
+def compact_rows(src: Tensor, keep8: Tensor, positions: Tensor, n_keep: int,
+                 out: Optional[Tensor] = None, out_offset: int = 0) -> Tensor:
+    """Order-preserving row compaction of a [n, ...] fp32 tensor.  Writes into
+    ``out[out_offset:out_offset+n_keep]`` when given (used to build the grown tensor in place)."""
+    lib = load()
+    src = src.contiguous()
+    n = src.shape[0]
+    row = int(src[0].numel()) if n > 0 else 1
+    if out is None:
+        out = torch.empty((n_keep,) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+        out_offset = 0
+    dst = out[out_offset:]
+    check(lib.fsgs_compact_rows(n, row, ptr(keep8), ptr(positions), ptr(src), dst.data_ptr(),
+                                stream_ptr(src.device)), "fsgs_compact_rows")
+    return out
+
+
+def split_samples(ids: Tensor, n_samples: int, means: Tensor, quats: Tensor, log_scales: Tensor,
+                  randn: Tensor) -> Tuple[Tensor, Tensor]:
+    lib = load()
+    S = ids.numel()
+    dev = means.device
+    new_means = torch.empty(S * n_samples, 3, dtype=torch.float32, device=dev)
+    new_ls = torch.empty(S * n_samples, 3, dtype=torch.float32, device=dev)
+    check(lib.fsgs_split_samples(S, n_samples, ptr(ids.contiguous()), ptr(_c(means)), ptr(_c(quats)),
+                                 ptr(_c(log_scales)), ptr(_c(randn)), ptr(new_means), ptr(new_ls),
+                                 stream_ptr(dev)), "fsgs_split_samples")
+    return new_means, new_ls

@@ -1,0 +1,184 @@
+"""``gsplat.rendering.rasterization`` re-implemented on libfsgs.so.
+
+Drop-in for the call at /root/reference/dn_splatter/dn_model.py:570-591: same name, argument
+meaning, return triple and ``meta`` keys as gsplat 1.0.0.  FusionSense passes
+``packed=False, render_mode="RGB+ED", absgrad=True, sparse_grad=False, tile_size=16``.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional, Tuple
+
+import torch
+from torch import Tensor
+
+from . import ops
+from ._lib import require_gpu_tensor
+
+_RENDER_MODES = ("RGB", "D", "ED", "RGB+D", "RGB+ED")
+
+
+def _validate(means, quats, scales, opacities, colors, viewmats, Ks, sh_degree, backgrounds, render_mode,
+              tile_size, rasterize_mode):
+    for name, t in (("means", means), ("quats", quats), ("scales", scales), ("opacities", opacities),
+                    ("colors", colors), ("viewmats", viewmats), ("Ks", Ks)):
+        require_gpu_tensor(t, name)
+    N = means.shape[0]
+    C = viewmats.shape[0]
+    if means.shape != (N, 3):
+        raise ValueError(f"means must be [N,3], got {tuple(means.shape)}")
+    if quats.shape != (N, 4):
+        raise ValueError(f"quats must be [N,4], got {tuple(quats.shape)}")
+    if scales.shape != (N, 3):
+        raise ValueError(f"scales must be [N,3], got {tuple(scales.shape)}")
+    if opacities.shape != (N,):
+        raise ValueError(f"opacities must be [N], got {tuple(opacities.shape)}")
+    if viewmats.shape != (C, 4, 4):
+        raise ValueError(f"viewmats must be [C,4,4], got {tuple(viewmats.shape)}")
+    if Ks.shape != (C, 3, 3):
+        raise ValueError(f"Ks must be [C,3,3], got {tuple(Ks.shape)}")
+    if render_mode not in _RENDER_MODES:
+        raise ValueError(f"render_mode must be one of {_RENDER_MODES}, got {render_mode!r}")
+    if rasterize_mode not in ("classic", "antialiased"):
+        raise ValueError(f"rasterize_mode must be 'classic' or 'antialiased', got {rasterize_mode!r}")
+    if not (2 <= tile_size <= 16):
+        raise ValueError("tile_size must be in [2,16]")
+    if sh_degree is None:
+        if not ((colors.dim() == 2 and colors.shape[0] == N) or
+                (colors.dim() == 3 and colors.shape[:2] == (C, N))):
+            raise ValueError(f"colors must be [N,D] or [C,N,D], got {tuple(colors.shape)}")
+    else:
+        if not (colors.dim() == 3 and colors.shape[0] == N and colors.shape[2] == 3):
+            raise ValueError(f"colors must be SH coefficients [N,K,3], got {tuple(colors.shape)}")
+        if (sh_degree + 1) ** 2 > colors.shape[1]:
+            raise ValueError(f"sh_degree {sh_degree} needs {(sh_degree + 1) ** 2} bases, got {colors.shape[1]}")
+        if not 0 <= sh_degree <= 4:
+            raise ValueError("sh_degree must be in [0,4]")
+    if backgrounds is not None:
+        require_gpu_tensor(backgrounds, "backgrounds")
+        if backgrounds.dim() != 2 or backgrounds.shape[0] != C:
+            raise ValueError(f"backgrounds must be [C,D], got {tuple(backgrounds.shape)}")
+    return N, C
+
+
+def rasterization(
+    means: Tensor,  # [N,3]
+    quats: Tensor,  # [N,4] wxyz
+    scales: Tensor,  # [N,3]
+    opacities: Tensor,  # [N]
+    colors: Tensor,  # [N,D] | [C,N,D] | SH [N,K,3]
+    viewmats: Tensor,  # [C,4,4] world-to-camera (OpenCV)
+    Ks: Tensor,  # [C,3,3]
+    width: int,
+    height: int,
+    near_plane: float = 0.01,
+    far_plane: float = 1e10,
+    radius_clip: float = 0.0,
+    eps2d: float = 0.3,
+    sh_degree: Optional[int] = None,
+    packed: bool = True,
+    tile_size: int = 16,
+    backgrounds: Optional[Tensor] = None,
+    render_mode: str = "RGB",
+    sparse_grad: bool = False,
+    absgrad: bool = False,
+    rasterize_mode: str = "classic",
+    channel_chunk: int = 32,
+) -> Tuple[Tensor, Tensor, Dict]:
+    """Render C views of N Gaussians.  Returns (render [C,H,W,D'], alphas [C,H,W,1], meta).
+
+    ``packed`` only changes gsplat's internal memory layout, never the result; this
+    implementation always uses the dense ``[C,N,...]`` layout FusionSense asks for
+    (``packed=False``) and reports ``camera_ids = gaussian_ids = None`` accordingly.
+    ``sparse_grad`` is a packed-mode option and must be False."""
+    if sparse_grad:
+        raise ValueError("sparse_grad=True requires packed mode, which this backend does not expose")
+    N, C = _validate(means, quats, scales, opacities, colors, viewmats, Ks, sh_degree, backgrounds,
+                     render_mode, tile_size, rasterize_mode)
+    width, height = int(width), int(height)
+    dev = means.device
+    antialiased = rasterize_mode == "antialiased"
+
+    radii, means2d, depths, conics, comp = ops._Projection.apply(
+        means, quats, scales, viewmats, Ks, width, height, float(eps2d), float(near_plane),
+        float(far_plane), float(radius_clip), antialiased)
+    opac = opacities[None, :].expand(C, N)
+    if antialiased:
+        opac = opac * comp
+
+    tile_width = math.ceil(width / tile_size)
+    tile_height = math.ceil(height / tile_size)
+    with torch.no_grad():
+        tiles_per_gauss, isect_ids, flatten_ids = ops.isect_tiles(
+            means2d, radii, depths, tile_size, tile_width, tile_height, legacy=False, sort=True)
+        isect_offsets = ops.isect_offset_encode(isect_ids, C, tile_width, tile_height)
+
+    want_depth = render_mode in ("RGB+D", "RGB+ED")
+    only_depth = render_mode in ("D", "ED")
+    if only_depth:
+        cols = depths[..., None]
+        if backgrounds is not None:
+            backgrounds = torch.zeros(C, 1, device=dev)
+    elif sh_degree is None:
+        cols = colors[None].expand(C, -1, -1) if colors.dim() == 2 else colors
+        if want_depth:
+            cols = torch.cat([cols, depths[..., None]], dim=-1)
+    else:
+        if viewmats.requires_grad:
+            raise NotImplementedError("SH colours with a differentiable camera pose are not supported")
+        campos = torch.linalg.inv(viewmats.detach())[:, :3, 3].contiguous()
+        cols = ops._SHColors.apply(means, colors, campos, radii, depths if want_depth else None,
+                                   int(sh_degree))
+    if want_depth and backgrounds is not None:
+        backgrounds = torch.cat([backgrounds, torch.zeros(C, 1, device=dev)], dim=-1)
+
+    D = cols.shape[-1]
+    if D in (1, 3, 4):
+        render, alphas, last_ids = ops._Rasterize.apply(
+            means2d, conics, cols, opac, backgrounds, isect_offsets, flatten_ids, width, height, tile_size,
+            absgrad)
+    else:
+        # arbitrary channel counts: composite in chunks of <=4 channels over the same lists
+        if absgrad:
+            raise NotImplementedError("absgrad is defined per pixel over all channels; only D in {1,3,4}")
+        outs = []
+        alphas = last_ids = None
+        for s in range(0, D, 4):
+            e = min(s + 4, D)
+            w = e - s
+            chunk = cols[..., s:e]
+            bg = backgrounds[..., s:e] if backgrounds is not None else None
+            if w == 2:
+                chunk = torch.cat([chunk, torch.zeros_like(chunk[..., :1])], dim=-1)
+                bg = torch.cat([bg, torch.zeros_like(bg[..., :1])], dim=-1) if bg is not None else None
+            r, alphas, last_ids = ops._Rasterize.apply(
+                means2d, conics, chunk.contiguous(), opac, bg, isect_offsets, flatten_ids, width, height,
+                tile_size, False)
+            outs.append(r[..., :w])
+        render = torch.cat(outs, dim=-1)
+
+    if render_mode in ("ED", "RGB+ED"):
+        render = torch.cat([render[..., :-1], render[..., -1:] / alphas.clamp(min=1e-10)], dim=-1)
+
+    meta = {
+        "camera_ids": None,
+        "gaussian_ids": None,
+        "radii": radii,
+        "means2d": means2d,
+        "depths": depths,
+        "conics": conics,
+        "opacities": opac,
+        "tile_width": tile_width,
+        "tile_height": tile_height,
+        "tiles_per_gauss": tiles_per_gauss,
+        "isect_ids": isect_ids,
+        "flatten_ids": flatten_ids,
+        "isect_offsets": isect_offsets,
+        "width": width,
+        "height": height,
+        "tile_size": tile_size,
+        "n_cameras": C,
+        # extras (not in gsplat's meta): let the legacy normal pass reuse this frame's sorted lists
+        "last_ids": last_ids,
+    }
+    return render, alphas, meta

@@ -1,0 +1,195 @@
+"""Synthetic scenes for the BASELINE.json configurations.
+
+There is no network for datasets or checkpoints, so every scene is seeded random data of
+the shape the reference trains on.  Parameters are returned in the *stored* (pre-activation)
+form FusionSense keeps in ``gauss_params`` (dn_splatter/dn_model.py:294-304): log-scales,
+opacity logits, SH split into ``features_dc`` [N,3] and ``features_rest`` [N,K-1,3].
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Dict, Tuple
+
+import torch
+from torch import Tensor
+
+C0 = 0.28209479177387814
+
+
+def rgb_to_sh(rgb: Tensor) -> Tensor:
+    """nerfstudio RGB2SH (imported at dn_model.py:47): (rgb - 0.5) / C0."""
+    return (rgb - 0.5) / C0
+
+
+def sh_to_rgb(sh: Tensor) -> Tensor:
+    """dn_model.py:2050-2055."""
+    return sh * C0 + 0.5
+
+
+def random_quat_tensor(n: int, generator=None) -> Tensor:
+    """Uniform random unit quaternions, same construction as dn_model.py:2035-2047."""
+    u = torch.rand(n, generator=generator)
+    v = torch.rand(n, generator=generator)
+    w = torch.rand(n, generator=generator)
+    return torch.stack(
+        [
+            torch.sqrt(1 - u) * torch.sin(2 * math.pi * v),
+            torch.sqrt(1 - u) * torch.cos(2 * math.pi * v),
+            torch.sqrt(u) * torch.sin(2 * math.pi * w),
+            torch.sqrt(u) * torch.cos(2 * math.pi * w),
+        ],
+        dim=-1,
+    )
+
+
+def look_at_c2w(eye: Tensor, target: Tensor, up=(0.0, 0.0, 1.0)) -> Tensor:
+    """OpenGL-convention camera-to-world [3,4]: camera looks along -z, +y up."""
+    eye = eye.to(torch.float32)
+    fwd = torch.nn.functional.normalize(target.to(torch.float32) - eye, dim=0)
+    upv = torch.tensor(up, dtype=torch.float32)
+    right = torch.linalg.cross(fwd, upv)
+    if right.norm() < 1e-6:
+        right = torch.linalg.cross(fwd, torch.tensor([0.0, 1.0, 0.0]))
+    right = torch.nn.functional.normalize(right, dim=0)
+    true_up = torch.linalg.cross(right, fwd)
+    return torch.stack([right, true_up, -fwd, eye], dim=1)
+
+
+@dataclass
+class Camera:
+    c2w: Tensor  # [3,4] OpenGL
+    fx: float
+    fy: float
+    cx: float
+    cy: float
+    width: int
+    height: int
+
+    def K(self) -> Tensor:
+        return torch.tensor([[self.fx, 0.0, self.cx], [0.0, self.fy, self.cy], [0.0, 0.0, 1.0]])
+
+
+def _sh_params(n: int, sh_degree: int, g) -> Tuple[Tensor, Tensor]:
+    k = (sh_degree + 1) ** 2
+    dc = rgb_to_sh(torch.rand(n, 3, generator=g))
+    rest = 0.1 * torch.randn(n, k - 1, 3, generator=g)
+    return dc, rest
+
+
+def cube_scene(n: int = 1000, seed: int = 0, sh_degree: int = 3) -> Tuple[Dict[str, Tensor], Camera]:
+    """Config #1: Gaussians on the surface of [-0.5,0.5]^3, one 128x128 camera."""
+    g = torch.Generator().manual_seed(seed)
+    face = torch.randint(0, 6, (n,), generator=g)
+    uv = torch.rand(n, 2, generator=g) - 0.5
+    axis = face // 2
+    sign = (face % 2).to(torch.float32) - 0.5
+    means = torch.zeros(n, 3)
+    for a in range(3):
+        sel = axis == a
+        others = [i for i in range(3) if i != a]
+        means[sel, a] = sign[sel]
+        means[sel, others[0]] = uv[sel, 0]
+        means[sel, others[1]] = uv[sel, 1]
+    lo, hi = math.log(0.01), math.log(0.05)
+    scales = lo + (hi - lo) * torch.rand(n, 3, generator=g)
+    quats = random_quat_tensor(n, g)
+    opac = torch.randn(n, 1, generator=g)
+    dc, rest = _sh_params(n, sh_degree, g)
+    params = dict(means=means, scales=scales, quats=quats, features_dc=dc, features_rest=rest, opacities=opac)
+    # looking at the origin from (0,0,2.5); "up" chosen as +y because the view axis is z
+    cam = Camera(look_at_c2w(torch.tensor([0.0, 0.0, 2.5]), torch.zeros(3), up=(0.0, 1.0, 0.0)),
+                 128.0, 128.0, 64.0, 64.0, 128, 128)
+    return params, cam
+
+
+def lego_like_scene(
+    n: int = 300_000, seed: int = 0, sh_degree: int = 3, n_boxes: int = 200
+) -> Dict[str, Tensor]:
+    """Config #2 Gaussians: 80 % on the faces of random boxes inside [-1,1]^3, 20 % uniform;
+    disc-like scales (one axis x0.1, the `two_d_gaussians` prior dn_model.py:98,817-819);
+    opacity logits N(2,1.5)."""
+    g = torch.Generator().manual_seed(seed)
+    n_surf = int(0.8 * n)
+    centers = torch.rand(n_boxes, 3, generator=g) * 1.6 - 0.8
+    half = 0.03 + 0.17 * torch.rand(n_boxes, 3, generator=g)
+    b = torch.randint(0, n_boxes, (n_surf,), generator=g)
+    face = torch.randint(0, 6, (n_surf,), generator=g)
+    uvw = torch.rand(n_surf, 3, generator=g) * 2 - 1
+    axis = face // 2
+    sign = (face % 2).to(torch.float32) * 2 - 1
+    uvw[torch.arange(n_surf), axis] = sign
+    surf = (centers[b] + half[b] * uvw).clamp(-1, 1)
+    vol = torch.rand(n - n_surf, 3, generator=g) * 2 - 1
+    means = torch.cat([surf, vol], 0)
+    lo, hi = math.log(0.003), math.log(0.03)
+    scales = lo + (hi - lo) * torch.rand(n, 3, generator=g)
+    thin = torch.randint(0, 3, (n,), generator=g)
+    scales[torch.arange(n), thin] += math.log(0.1)
+    quats = random_quat_tensor(n, g)
+    opac = 2.0 + 1.5 * torch.randn(n, 1, generator=g)
+    dc, rest = _sh_params(n, sh_degree, g)
+    perm = torch.randperm(n, generator=g)  # storage order carries no spatial locality
+    return dict(
+        means=means[perm], scales=scales[perm], quats=quats[perm],
+        features_dc=dc[perm], features_rest=rest[perm], opacities=opac[perm],
+    )
+
+
+def hemisphere_cameras(
+    n_views: int = 100, radius: float = 4.031, width: int = 800, height: int = 800,
+    focal: float = 1111.11, seed: int = 0,
+) -> list:
+    """Blender-synthetic style rig: cameras on the upper hemisphere looking at the origin."""
+    g = torch.Generator().manual_seed(seed + 12345)
+    cams = []
+    for _ in range(n_views):
+        az = 2 * math.pi * torch.rand(1, generator=g).item()
+        el = math.radians(10.0 + 70.0 * torch.rand(1, generator=g).item())
+        eye = radius * torch.tensor([math.cos(el) * math.cos(az), math.cos(el) * math.sin(az), math.sin(el)])
+        cams.append(Camera(look_at_c2w(eye, torch.zeros(3)), focal, focal, width / 2.0, height / 2.0, width, height))
+    return cams
+
+
+def fusionsense_like_scene(seed: int = 0, n_hull: int = 20_000, n_bg: int = 40_000, sh_degree: int = 3):
+    """Config #3: a dense 0.1-radius object blob ('visual hull' seeds, utils/VisualHull.py:135)
+    inside a sparse background shell (utils/generate_pcd.py:99), 9 views at 1280x720 with the
+    RealSense-like intrinsics the reference preprocesses for
+    (utils/metric3dv2_depth_generation.py:55)."""
+    g = torch.Generator().manual_seed(seed)
+    d = torch.randn(n_hull, 3, generator=g)
+    hull = 0.1 * d / d.norm(dim=-1, keepdim=True) * torch.rand(n_hull, 1, generator=g) ** (1 / 3)
+    bg = torch.rand(n_bg, 3, generator=g) * 1.6 - 0.8
+    bg[:, 2] = bg[:, 2] * 0.25 - 0.3
+    means = torch.cat([hull, bg], 0)
+    n = means.shape[0]
+    scales = torch.cat([
+        torch.full((n_hull, 3), math.log(0.005)) + 0.3 * torch.randn(n_hull, 3, generator=g),
+        torch.full((n_bg, 3), math.log(0.02)) + 0.3 * torch.randn(n_bg, 3, generator=g),
+    ])
+    quats = random_quat_tensor(n, g)
+    opac = torch.logit(torch.full((n, 1), 0.1)) + 0.5 * torch.randn(n, 1, generator=g)
+    dc, rest = _sh_params(n, sh_degree, g)
+    params = dict(means=means, scales=scales, quats=quats, features_dc=dc, features_rest=0.0 * rest, opacities=opac)
+    cams = []
+    for i in range(9):
+        az = 2 * math.pi * i / 9
+        eye = torch.tensor([math.cos(az), math.sin(az), 0.35])
+        eye = eye / eye.abs().max()  # max |translation| = 1 (normal_nerfstudio.py:325-330)
+        cams.append(Camera(look_at_c2w(eye, torch.zeros(3)), 641.299, 641.299, 636.707, 362.299, 1280, 720))
+    return params, cams
+
+
+def bicycle_like_scene(n: int = 6_000_000, seed: int = 0, sh_degree: int = 3) -> Dict[str, Tensor]:
+    """Config #4/#5 Gaussians: unbounded-scene-like radial distribution, small splats."""
+    g = torch.Generator().manual_seed(seed)
+    d = torch.randn(n, 3, generator=g)
+    r = 0.2 + 3.0 * torch.rand(n, 1, generator=g) ** 2
+    means = d / d.norm(dim=-1, keepdim=True) * r
+    means[:, 2] = means[:, 2].abs() * 0.3 - 0.2
+    lo, hi = math.log(0.002), math.log(0.02)
+    scales = lo + (hi - lo) * torch.rand(n, 3, generator=g)
+    quats = random_quat_tensor(n, g)
+    opac = 1.0 + 1.5 * torch.randn(n, 1, generator=g)
+    dc, rest = _sh_params(n, sh_degree, g)
+    return dict(means=means, scales=scales, quats=quats, features_dc=dc, features_rest=rest, opacities=opac)

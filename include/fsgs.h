@@ -1,0 +1,165 @@
+/*
+ * fsgs.h — C-ABI of the MI355X-native Gaussian-splatting hot path (libfsgs.so).
+ *
+ * This is the drop-in boundary below FusionSense's gsplat operator surface.  The reference
+ * reaches the same operations through gsplat 1.0.0's pybind11 module `gsplat.cuda._C`
+ * (un-vendored; pinned at /root/reference/pyproject.toml:8) from two call sites:
+ *     dn_splatter/dn_model.py:570-591   gsplat.rendering.rasterization(...)
+ *     dn_splatter/dn_model.py:644-653   gsplat.rasterize_gaussians(...)   (legacy 0.1.x path)
+ * and, for densify/prune statistics, nerfstudio's SplatfactoModel.after_train
+ * (registered at dn_splatter/dn_model.py:1385-1389).
+ *
+ * Conventions (all entry points):
+ *   - plain pointers to DEVICE memory + sizes; no torch types; fp32 / int32 / int64 only
+ *   - all tensors contiguous, row-major, layouts as in the per-function comments
+ *   - the caller owns every buffer (including scratch); the library never allocates
+ *   - every call enqueues on `stream` (a hipStream_t passed as void*) and returns at once;
+ *     the ONLY call that synchronises is fsgs_isect_count (it returns n_isects to the host,
+ *     the same point at which the reference syncs)
+ *   - return 0 on success, a negative FSGS_E* code otherwise; never throws; re-entrant
+ */
+#ifndef FSGS_H
+#define FSGS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *fsgs_stream_t; /* hipStream_t */
+
+#define FSGS_OK 0
+#define FSGS_EINVAL -1   /* bad argument (null pointer, unsupported size / channel count) */
+#define FSGS_ELAUNCH -2  /* hipLaunch / runtime error; see fsgs_last_hip_error() */
+#define FSGS_ESCRATCH -3 /* scratch arena too small */
+
+int fsgs_version(void);
+const char *fsgs_error_string(int code);
+int fsgs_last_hip_error(void); /* last hipError_t seen by this thread's failing call */
+
+/* ---- E2: fully_fused_projection (gsplat._C.fully_fused_projection_fwd/bwd) ------------------
+ * means[N,3] quats[N,4] (wxyz, normalised in-kernel) scales[N,3] viewmats[C,4,4] Ks[C,3,3]
+ * -> radii[C,N] i32, means2d[C,N,2], depths[C,N], conics[C,N,3], compensations[C,N] (nullable).
+ * Culled Gaussians get radii=0 and zeroed outputs. */
+int fsgs_project_fwd(int C, int N, const float *means, const float *quats, const float *scales,
+                     const float *viewmats, const float *Ks, int width, int height, float eps2d,
+                     float near_plane, float far_plane, float radius_clip, int32_t *radii,
+                     float *means2d, float *depths, float *conics, float *compensations,
+                     fsgs_stream_t stream);
+
+/* VJP of the above.  v_compensations nullable.  Writes (not accumulates) v_means[N,3],
+ * v_quats[N,4], v_scales[N,3]; sums over cameras inside the kernel (deterministic).
+ * v_viewmats[C,4,4] nullable; when given it is ACCUMULATED with atomics (zero it first). */
+int fsgs_project_bwd(int C, int N, const float *means, const float *quats, const float *scales,
+                     const float *viewmats, const float *Ks, int width, int height, float eps2d,
+                     const int32_t *radii, const float *conics, const float *compensations,
+                     const float *v_means2d, const float *v_depths, const float *v_conics,
+                     const float *v_compensations, float *v_means, float *v_quats,
+                     float *v_scales, float *v_viewmats, fsgs_stream_t stream);
+
+/* ---- E3: spherical harmonics colour, fused with the rasterization() glue ---------------------
+ * (gsplat._C.compute_sh_fwd/bwd + `dirs = means - campos`, `+0.5`, `clamp_min(0)` and the
+ * depth-channel concat of render_mode "RGB+ED").
+ * coeffs[N,K,3]; campos[C,3]; radii[C,N] mask; depths[C,N] (nullable -> no depth channel).
+ * colors_out[C,N,D] with D = 3 (+1 if depths).  Gaussians with radii<=0 get rgb = 0.5. */
+int fsgs_sh_fwd(int C, int N, int K, int degree, const float *means, const float *campos,
+                const float *coeffs, const int32_t *radii, const float *depths,
+                float *colors_out, fsgs_stream_t stream);
+
+/* v_colors[C,N,D] -> v_coeffs[N,K,3] (written; bases above `degree` get 0), v_means[N,3]
+ * (ACCUMULATED into: the projection VJP has usually written it already), and
+ * v_depths[C,N] (written, nullable; the pass-through gradient of the depth channel). */
+int fsgs_sh_bwd(int C, int N, int K, int degree, const float *means, const float *campos,
+                const float *coeffs, const int32_t *radii, int D, const float *v_colors,
+                float *v_coeffs, float *v_means, float *v_depths, fsgs_stream_t stream);
+
+/* ---- E4: isect_tiles (gsplat._C.isect_tiles), two passes --------------------------------------
+ * Pass 1: tiles_per_gauss[C,N] i32 and its inclusive prefix sum cum_tiles[C,N] i64.
+ * `legacy` != 0 selects the cuda_legacy bbox rule ((int)(c-r), (int)(c+r+1)) used by
+ * gsplat.rasterize_gaussians.  Synchronises `stream` and stores the total in *n_isects_host.
+ * scratch: fsgs_scan_scratch_bytes(C*N) bytes. */
+size_t fsgs_scan_scratch_bytes(int64_t n);
+int fsgs_isect_count(int C, int N, const float *means2d, const int32_t *radii, int tile_size,
+                     int tile_width, int tile_height, int legacy, int32_t *tiles_per_gauss,
+                     int64_t *cum_tiles, void *scratch, size_t scratch_bytes,
+                     int64_t *n_isects_host, fsgs_stream_t stream);
+
+/* Pass 2: emit isect_ids[M] i64 = cam<<(32+tile_bits) | tile<<32 | bits(depth) and
+ * flatten_ids[M] i32 = c*N+n, in (Gaussian, row-major tile) order. */
+int fsgs_isect_emit(int C, int N, const float *means2d, const int32_t *radii, const float *depths,
+                    const int64_t *cum_tiles, int tile_size, int tile_width, int tile_height,
+                    int legacy, int64_t *isect_ids, int32_t *flatten_ids, fsgs_stream_t stream);
+
+/* ---- E5: stable LSD radix sort of (i64 key, i32 value) pairs over key bits [0,end_bit) --------
+ * Replaces cub::DeviceRadixSort::SortPairs.  Ping-pongs between (keys_a, vals_a) and
+ * (keys_b, vals_b); returns 0 or 1 in *result_in_b to say where the sorted data ended up. */
+size_t fsgs_sort_scratch_bytes(int64_t n);
+int fsgs_sort_pairs(int64_t n, int64_t *keys_a, int32_t *vals_a, int64_t *keys_b, int32_t *vals_b,
+                    int end_bit, void *scratch, size_t scratch_bytes, int *result_in_b,
+                    fsgs_stream_t stream);
+
+/* ---- E6: isect_offset_encode (gsplat._C.isect_offset_encode) ---------------------------------
+ * offsets[C*n_tiles] i32: first sorted index of every (camera, tile). */
+int fsgs_isect_offset_encode(int64_t n_isects, const int64_t *isect_ids_sorted, int C, int n_tiles,
+                             int tile_bits, int32_t *offsets, fsgs_stream_t stream);
+
+/* ---- E7 / E8: rasterize_to_pixels fwd/bwd (gsplat._C.rasterize_to_pixels_fwd/bwd and the
+ * legacy rasterize_forward/backward).  D in {1,3,4}.  tile_size in [2,16].
+ * means2d[C,N,2] conics[C,N,3] colors[C,N,D] opacities[C,N] backgrounds[C,D] (nullable)
+ * -> render[C,H,W,D], alphas[C,H,W], last_ids[C,H,W] i32 (absolute index into flatten_ids). */
+int fsgs_raster_fwd(int C, int N, int D, const float *means2d, const float *conics,
+                    const float *colors, const float *opacities, const float *backgrounds,
+                    int width, int height, int tile_size, int tile_width, int tile_height,
+                    const int32_t *isect_offsets, const int32_t *flatten_ids, int64_t n_isects,
+                    float *render, float *alphas, int32_t *last_ids, fsgs_stream_t stream);
+
+/* Gradient outputs are ACCUMULATED with fp32 atomics: zero them first.
+ * v_means2d_abs (the `absgrad` side output) nullable. */
+int fsgs_raster_bwd(int C, int N, int D, const float *means2d, const float *conics,
+                    const float *colors, const float *opacities, const float *backgrounds,
+                    int width, int height, int tile_size, int tile_width, int tile_height,
+                    const int32_t *isect_offsets, const int32_t *flatten_ids, int64_t n_isects,
+                    const float *alphas, const int32_t *last_ids, const float *v_render,
+                    const float *v_alphas, float *v_means2d, float *v_means2d_abs,
+                    float *v_conics, float *v_colors, float *v_opacities, fsgs_stream_t stream);
+
+/* ---- a-11: per-Gaussian normals (dn_splatter/dn_model.py:618-636 as one kernel) ---------------
+ * quats[N,4] (any norm), log_scales[N,3], means[N,3], c2w[3,4] (OpenGL) ->
+ * normals_world[N,3] (what the reference stores in gauss_params["normals"]),
+ * normals_cam[N,3] = n @ c2w[:3,:3]. */
+int fsgs_normals_fwd(int N, const float *quats, const float *log_scales, const float *means,
+                     const float *c2w, float *normals_world, float *normals_cam,
+                     fsgs_stream_t stream);
+/* v_normals_cam[N,3] -> v_quats[N,4] (written). */
+int fsgs_normals_bwd(int N, const float *quats, const float *log_scales, const float *means,
+                     const float *c2w, const float *v_normals_cam, float *v_quats,
+                     fsgs_stream_t stream);
+
+/* ---- a-12: SplatfactoModel.after_train statistics in one pass ----------------------------------
+ * vis = radii>0: vis_counts += 1; xys_grad_norm += ||absgrad||_2; max_2Dsize = max(., radii/max(H,W)) */
+int fsgs_densify_stats(int N, const int32_t *radii, const float *absgrad, float inv_max_hw,
+                       float *xys_grad_norm, float *vis_counts, float *max_2Dsize,
+                       fsgs_stream_t stream);
+
+/* ---- a-13: densify/prune row movement -----------------------------------------------------------
+ * Order-preserving stream compaction of row-major [n_rows, row_floats] fp32 tensors by a
+ * byte mask (keep[i] != 0).  fsgs_mask_scan builds positions once (exclusive scan of keep,
+ * i64) and returns nothing to the host; fsgs_compact_rows applies them to one tensor. */
+int fsgs_mask_scan(int64_t n_rows, const uint8_t *keep, int64_t *positions, void *scratch,
+                   size_t scratch_bytes, fsgs_stream_t stream);
+int fsgs_compact_rows(int64_t n_rows, int row_floats, const uint8_t *keep,
+                      const int64_t *positions, const float *src, float *dst,
+                      fsgs_stream_t stream);
+/* split_gaussians sample kernel: for every selected parent p (ids[S]) and sample s<n_samples,
+ * new_mean = mean[p] + R(q[p]/|q|) (exp(log_scale[p]) * z[s*S+i]); new_log_scale = log(exp(ls)/1.6).
+ * Writes new_means[n_samples*S,3], new_log_scales[n_samples*S,3] (sample-major, like .repeat). */
+int fsgs_split_samples(int64_t S, int n_samples, const int64_t *ids, const float *means,
+                       const float *quats, const float *log_scales, const float *randn,
+                       float *new_means, float *new_log_scales, fsgs_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FSGS_H */

@@ -1,0 +1,279 @@
+"""GPU parity: the HIP path (through the C-ABI, via fusionsense_amd.ops) against the CPU oracle
+on the same seeded inputs.  Bit-exact for integer outputs, stated tolerances for fp32."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from fusionsense_amd import scenes
+from oracle import gsplat_ref as R
+from tests.helpers import activated, adversarial_gaussians, camera_mats, oracle_frame, rel_err
+
+pytestmark = pytest.mark.gpu
+
+FWD_RTOL = 1e-4   # fp32 forward tolerance (relative to the tensor's max magnitude)
+BWD_RTOL = 2e-3   # fp32 backward tolerance (atomics reorder the sums)
+
+
+def test_library_loads_on_gpu(dev):
+    from fusionsense_amd import _lib
+    assert _lib.load().fsgs_version() >= 100
+
+
+@pytest.mark.parametrize("scene", ["cube", "adversarial"])
+def test_project_fwd(dev, scene):
+    from fusionsense_amd import ops
+    params, cam = scenes.cube_scene(1000, seed=0)
+    viewmat, K = camera_mats(cam)
+    if scene == "cube":
+        act = activated(params)
+        means, quats, scl = act["means"], act["quats"], act["scales"]
+    else:
+        means, quats, scl, _ = adversarial_gaussians(cam)
+    W, H = cam.width, cam.height
+    r64 = R.project(means.double(), quats.double(), scl.double(), viewmat.double(), K.double(), W, H)
+    r32 = R.project(means, quats, scl, viewmat, K, W, H)
+    radii, m2, dp, cn, comp = ops.project_fwd(means.to(dev), quats.to(dev).contiguous(), scl.to(dev),
+                                              viewmat.to(dev), K.to(dev), W, H, 0.3, 0.01, 1e10, 0.0, True)
+    radii_c = radii.cpu()
+    # radii: exact, except where the fp64 pre-ceil value sits within 1e-3 of an integer or a cull
+    # decision is borderline (fp32 vs fp64 oracles disagree)
+    stable = r64[0] == r32[0]
+    mism = (radii_c != r32[0]) & stable
+    assert mism.sum().item() == 0, f"{mism.sum().item()} radii differ: {radii_c[mism][:8]} vs {r32[0][mism][:8]}"
+    vis = (radii_c > 0) & (r32[0] > 0)
+    assert vis.sum() > 0
+    for name, got, ref in (("means2d", m2, r32[1]), ("depths", dp, r32[2]), ("conics", cn, r32[3]),
+                           ("comp", comp, r32[4])):
+        g = got.cpu()[vis]
+        r = ref[vis]
+        err = ((g - r).abs() / (r.abs() + 1.0)).max().item()
+        assert err < FWD_RTOL, f"{name}: {err}"
+    # culled Gaussians are zeroed
+    assert (m2.cpu()[radii_c == 0] == 0).all() and (cn.cpu()[radii_c == 0] == 0).all()
+
+
+@pytest.mark.parametrize("legacy", [False, True])
+def test_isect_sort_offsets_bit_exact(dev, legacy):
+    from fusionsense_amd import ops
+    params, cam = scenes.cube_scene(3000, seed=3)
+    act = activated(params)
+    viewmat, K = camera_mats(cam)
+    W, H = cam.width, cam.height
+    radii, m2, dp, cn, _ = R.project(act["means"], act["quats"], act["scales"], viewmat, K, W, H)
+    tw, th = math.ceil(W / 16), math.ceil(H / 16)
+    tpg, ids, flat = R.isect_tiles(m2, radii, dp, 16, tw, th, legacy=legacy)
+    ids_s, flat_s = R.sort_isects(ids, flat)
+    offs = R.isect_offset_encode(ids_s, 1, tw, th)
+    g_tpg, g_ids, g_flat = ops.isect_tiles(m2.to(dev), radii.to(dev), dp.to(dev), 16, tw, th, legacy=legacy,
+                                           sort=False)
+    assert np.array_equal(g_tpg.cpu().numpy(), tpg)
+    assert np.array_equal(g_ids.cpu().numpy(), ids)
+    assert np.array_equal(g_flat.cpu().numpy(), flat)
+    g_tpg, g_ids, g_flat = ops.isect_tiles(m2.to(dev), radii.to(dev), dp.to(dev), 16, tw, th, legacy=legacy,
+                                           sort=True)
+    assert np.array_equal(g_ids.cpu().numpy(), ids_s)
+    assert np.array_equal(g_flat.cpu().numpy(), flat_s)
+    g_off = ops.isect_offset_encode(g_ids, 1, tw, th)
+    assert np.array_equal(g_off.cpu().numpy(), offs)
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 63, 64, 65, 2047, 2048, 2049, 100_003, 1_500_000])
+def test_sort_pairs_stable(dev, n):
+    from fusionsense_amd import ops
+    rng = np.random.default_rng(n)
+    # few distinct keys -> many ties: stability is visible in the payload order
+    keys = rng.integers(0, 1 << 44, size=n, dtype=np.int64)
+    if n > 10:
+        keys[rng.integers(0, n, size=n // 2)] = keys[0]
+    vals = np.arange(n, dtype=np.int32)
+    order = np.argsort(keys.view(np.uint64), kind="stable")
+    k, v = ops.sort_pairs(torch.from_numpy(keys).to(dev), torch.from_numpy(vals).to(dev), end_bit=44)
+    assert np.array_equal(k.cpu().numpy(), keys[order])
+    assert np.array_equal(v.cpu().numpy(), vals[order])
+
+
+def test_sort_pairs_full_64bit(dev):
+    from fusionsense_amd import ops
+    rng = np.random.default_rng(7)
+    keys = rng.integers(0, np.iinfo(np.int64).max, size=300_000, dtype=np.int64)
+    vals = rng.integers(0, 1 << 31, size=keys.size, dtype=np.int32)
+    order = np.argsort(keys.view(np.uint64), kind="stable")
+    k, v = ops.sort_pairs(torch.from_numpy(keys).to(dev), torch.from_numpy(vals).to(dev), end_bit=64)
+    assert np.array_equal(k.cpu().numpy(), keys[order])
+    assert np.array_equal(v.cpu().numpy(), vals[order])
+
+
+def _frame(seed=0, n=1000, with_bg=False, D=4):
+    params, cam = scenes.cube_scene(n, seed=seed)
+    act = activated(params)
+    viewmat, K = camera_mats(cam)
+    W, H = cam.width, cam.height
+    fr = oracle_frame(act, viewmat, K, W, H)
+    g = torch.Generator().manual_seed(seed + 99)
+    cols = torch.rand(1, n, D, generator=g)
+    opac = act["opacities"][None].contiguous()
+    bg = torch.rand(1, D, generator=g) if with_bg else None
+    return cam, fr, cols, opac, bg
+
+
+@pytest.mark.parametrize("D,with_bg", [(4, False), (3, True), (1, False)])
+def test_raster_fwd(dev, D, with_bg):
+    from fusionsense_amd import ops
+    cam, fr, cols, opac, bg = _frame(seed=1, D=D, with_bg=with_bg)
+    W, H = cam.width, cam.height
+    ref, ref_a, ref_last = R.rasterize_to_pixels(fr["means2d"], fr["conics"], cols, opac, W, H, 16,
+                                                 fr["offsets"], fr["flat_s"], bg)
+    out, alpha, last = ops._Rasterize.apply(
+        fr["means2d"].to(dev), fr["conics"].to(dev), cols.to(dev), opac.to(dev),
+        bg.to(dev) if bg is not None else None, torch.from_numpy(fr["offsets"]).to(dev),
+        torch.from_numpy(fr["flat_s"]).to(dev), W, H, 16, False)
+    assert (out.cpu() - ref).abs().max().item() < FWD_RTOL * max(1.0, ref.abs().max().item())
+    assert (alpha.cpu() - ref_a).abs().max().item() < FWD_RTOL
+    # last_ids: exact except where an fp32 threshold decision (alpha<1/255, T<=1e-4) is borderline
+    mism = (last.cpu().numpy() != ref_last).mean()
+    assert mism < 2e-3, f"last_ids mismatch fraction {mism}"
+
+
+@pytest.mark.parametrize("D,with_bg", [(4, False), (3, True)])
+def test_raster_bwd(dev, D, with_bg):
+    from fusionsense_amd import ops
+    cam, fr, cols, opac, bg = _frame(seed=2, D=D, with_bg=with_bg)
+    W, H = cam.width, cam.height
+    g = torch.Generator().manual_seed(5)
+    v_render = torch.randn(1, H, W, D, generator=g)
+    v_alpha = torch.randn(1, H, W, 1, generator=g)
+    ref = R.rasterize_to_pixels_bwd(fr["means2d"], fr["conics"], cols, opac, W, H, 16, fr["offsets"],
+                                    fr["flat_s"], v_render, v_alpha, bg)
+    ins = [t.to(dev).requires_grad_(True) for t in (fr["means2d"], fr["conics"], cols, opac)]
+    out, alpha, _ = ops._Rasterize.apply(*ins, bg.to(dev) if bg is not None else None,
+                                         torch.from_numpy(fr["offsets"]).to(dev),
+                                         torch.from_numpy(fr["flat_s"]).to(dev), W, H, 16, True)
+    torch.autograd.backward([out, alpha], [v_render.to(dev), v_alpha.to(dev)])
+    got = dict(v_means2d=ins[0].grad, v_conics=ins[1].grad, v_colors=ins[2].grad, v_opacities=ins[3].grad,
+               v_means2d_abs=ins[0].absgrad)
+    for k, v in got.items():
+        e = rel_err(v, ref[k])
+        assert e < BWD_RTOL, f"{k}: rel err {e}"
+
+
+@pytest.mark.parametrize("degree", [0, 1, 2, 3, 4])
+def test_sh_fwd_bwd(dev, degree):
+    from fusionsense_amd import ops
+    g = torch.Generator().manual_seed(degree)
+    N, K, C = 777, 25 if degree == 4 else 16, 2
+    means = torch.randn(N, 3, generator=g)
+    campos = torch.randn(C, 3, generator=g)
+    coeffs = torch.randn(N, K, 3, generator=g) * 0.5
+    radii = (torch.rand(C, N, generator=g) > 0.2).to(torch.int32) * 3
+    depths = torch.rand(C, N, generator=g)
+    v = torch.randn(C, N, 4, generator=g)
+
+    m_r = means.clone().requires_grad_(True)
+    c_r = coeffs.clone().requires_grad_(True)
+    d_r = depths.clone().requires_grad_(True)
+    dirs = m_r[None] - campos[:, None]
+    col = R.spherical_harmonics(degree, dirs, c_r[None].expand(C, -1, -1, -1), masks=radii > 0)
+    col = torch.cat([torch.clamp_min(col + 0.5, 0.0), d_r[..., None]], -1)
+    col.backward(v)
+
+    m_g = means.to(dev).requires_grad_(True)
+    c_g = coeffs.to(dev).requires_grad_(True)
+    d_g = depths.to(dev).requires_grad_(True)
+    out = ops._SHColors.apply(m_g, c_g, campos.to(dev), radii.to(dev), d_g, degree)
+    out.backward(v.to(dev))
+    assert (out.cpu() - col.detach()).abs().max().item() < 1e-5
+    assert rel_err(c_g.grad, c_r.grad) < 1e-5
+    m_ref = m_r.grad if m_r.grad is not None else torch.zeros_like(means)  # degree 0: no dependence
+    assert (m_g.grad.cpu() - m_ref).abs().max().item() < 1e-4 * (1 + m_ref.abs().max().item())
+    assert rel_err(d_g.grad, d_r.grad) < 1e-6
+
+
+@pytest.mark.parametrize("scene,antialiased", [("cube", False), ("adversarial", False), ("cube", True)])
+def test_project_bwd(dev, scene, antialiased):
+    from fusionsense_amd import ops
+    params, cam = scenes.cube_scene(500, seed=4)
+    viewmat, K = camera_mats(cam)
+    if scene == "cube":
+        act = activated(params)
+        means, quats, scl = act["means"], act["quats"] * 1.7, act["scales"]
+    else:
+        means, quats, scl, _ = adversarial_gaussians(cam)
+    W, H = cam.width, cam.height
+    g = torch.Generator().manual_seed(11)
+    N = means.shape[0]
+    v_m2, v_dp, v_cn, v_cp = (torch.randn(1, N, 2, generator=g), torch.randn(1, N, generator=g),
+                              torch.randn(1, N, 3, generator=g) * 1e-2, torch.randn(1, N, generator=g))
+    leaves = [t.clone().double().requires_grad_(True) for t in (means, quats, scl)]
+    vm64 = viewmat.double().requires_grad_(True)
+    radii, m2, dp, cn, cp = R.project(*leaves, vm64, K.double(), W, H)
+    loss = (m2 * v_m2).sum() + (dp * v_dp).sum() + (cn * v_cn).sum()
+    if antialiased:
+        loss = loss + (cp * v_cp).sum()
+    loss.backward()
+
+    gl = [t.to(dev).contiguous().requires_grad_(True) for t in (means, quats, scl)]
+    vm = viewmat.to(dev).requires_grad_(True)
+    r_g, m2_g, dp_g, cn_g, cp_g = ops._Projection.apply(*gl, vm, K.to(dev), W, H, 0.3, 0.01, 1e10, 0.0,
+                                                        antialiased)
+    same = (r_g.cpu() == radii)
+    loss_g = (m2_g * v_m2.to(dev)).sum() + (dp_g * v_dp.to(dev)).sum() + (cn_g * v_cn.to(dev)).sum()
+    if antialiased:
+        loss_g = loss_g + (cp_g * v_cp.to(dev)).sum()
+    loss_g.backward()
+    assert same.all()
+    for name, a, b in (("means", gl[0].grad, leaves[0].grad), ("quats", gl[1].grad, leaves[1].grad),
+                       ("scales", gl[2].grad, leaves[2].grad), ("viewmats", vm.grad, vm64.grad)):
+        assert rel_err(a, b) < 5e-4, f"{name}: {rel_err(a, b)}"
+
+
+def test_normals_fwd_bwd(dev):
+    from fusionsense_amd import ops
+    params, cam = scenes.cube_scene(2000, seed=8)
+    q = (params["quats"] * 2.5).clone()
+    ls = params["scales"].clone()
+    ls[:10] = ls[:10, :1]  # ties in argmin -> first index
+    v = torch.randn(2000, 3, generator=torch.Generator().manual_seed(1))
+    q_r = q.clone().double().requires_grad_(True)
+    nw, nc = R.gaussian_normals(q_r, ls.double(), params["means"].double(), cam.c2w.double())
+    (nc * v).sum().backward()
+    q_g = q.to(dev).requires_grad_(True)
+    nw_g, nc_g = ops.gaussian_normals(q_g, ls.to(dev), params["means"].to(dev), cam.c2w.to(dev))
+    (nc_g * v.to(dev)).sum().backward()
+    assert (nw_g.cpu() - nw.detach().float()).abs().max().item() < 1e-5
+    assert (nc_g.cpu() - nc.detach().float()).abs().max().item() < 1e-5
+    assert rel_err(q_g.grad, q_r.grad) < 1e-4
+
+
+def test_end_to_end_get_outputs(dev):
+    """render_fusionsense (= DNSplatterModel.get_outputs) forward + backward on config #1."""
+    from fusionsense_amd.fusion import render_fusionsense
+    from oracle.fusion_ref import render_fusionsense as render_ref
+    params, cam = scenes.cube_scene(1000, seed=0)
+    gp = {k: v.to(dev).requires_grad_(True) for k, v in params.items()}
+    out = render_fusionsense(gp, cam, sh_degree=3, device=dev)
+    g = torch.Generator().manual_seed(3)
+    w_rgb, w_d, w_n = (torch.rand(128, 128, 3, generator=g), torch.rand(128, 128, 1, generator=g),
+                       torch.rand(128, 128, 3, generator=g))
+    loss = (out["rgb"] * w_rgb.to(dev)).mean() + (out["depth"] * w_d.to(dev)).mean() + \
+        (out["normal"] * w_n.to(dev)).mean()
+    loss.backward()
+    cp = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    ref = render_ref(cp, cam, sh_degree=3)
+    loss_r = (ref["rgb"] * w_rgb).mean() + (ref["depth"] * w_d).mean() + (ref["normal"] * w_n).mean()
+    loss_r.backward()
+    for k in ("rgb", "depth", "accumulation"):
+        assert (out[k].detach().cpu() - ref[k].detach()).abs().max().item() < 1e-3, k
+    # normal image: pixels with ~zero splatted normal are ill-conditioned under normalisation
+    dn = (out["normal"].detach().cpu() - ref["normal"].detach()).abs()
+    assert dn.mean().item() < 1e-4 and (dn > 1e-2).float().mean().item() < 1e-3
+    assert np.array_equal(out["info"]["tiles_per_gauss"].cpu().numpy(), ref["info"]["tiles_per_gauss"].numpy())
+    assert np.array_equal(out["info"]["flatten_ids"].cpu().numpy(), ref["info"]["flatten_ids"].numpy())
+    assert np.array_equal(out["info"]["isect_ids"].cpu().numpy(), ref["info"]["isect_ids"].numpy())
+    assert np.array_equal(out["info"]["isect_offsets"].cpu().numpy(), ref["info"]["isect_offsets"].numpy())
+    for k in gp:
+        e = rel_err(gp[k].grad, cp[k].grad)
+        assert e < 1e-2, f"grad {k}: rel err {e}"
+    # absgrad side output exists with the right shape
+    assert out["xys"].absgrad.shape == (1, 1000, 2)
