@@ -1,0 +1,268 @@
+#!/usr/bin/env python3
+"""Headline benchmark: train iters/s (+ rendered Mpix/s) on BASELINE.json config #2 —
+synthetic "lego-like" scene, 300k Gaussians, 800x800, SH degree 3, one view per rank per step.
+
+A step = one full training iteration of the hot path exactly as FusionSense drives it
+(dn_splatter/dn_model.py:469-671 + trainer order): RGB+ED rasterization,
+per-Gaussian normals + legacy normal rasterization, losses, backward through both rasterizers /
+SH / projection, gradient all-reduce (N>1), Adam step on the 6 live parameter groups, densify
+statistics.  Prints ONE JSON line (rank 0).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+_T0 = time.time()
+
+
+def log(msg):
+    if os.environ.get("FSGS_BENCH_VERBOSE"):
+        print(f"[bench +{time.time() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--n-gauss", type=int, default=300_000)
+    ap.add_argument("--res", type=int, default=800)
+    ap.add_argument("--views", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-crop", type=int, default=128, help="CPU-baseline sample: central crop edge")
+    ap.add_argument("--cpu-timeout", type=float, default=150.0)
+    ap.add_argument("--cpu-threads", type=int, default=8)
+    ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
+    return ap.parse_args()
+
+
+def cpu_baseline_worker(n_gauss: int, res: int, crop: int, threads: int):
+    """Child-process body: oracle (pure-PyTorch CPU rasterizer) forward+backward on a central
+    crop of view 0 of the same scene; scaled to full-frame-equivalent iters/s by pixel count."""
+    from fusionsense_amd import scenes
+    from fusionsense_amd.scenes import Camera
+    from oracle.fusion_ref import render_fusionsense as render_ref
+
+    torch.set_num_threads(threads)
+    params = scenes.lego_like_scene(n_gauss, seed=0)
+    cam = scenes.hemisphere_cameras(1, width=res, height=res, focal=1111.11 * res / 800.0, seed=0)[0]
+    x0 = (cam.width - crop) // 2
+    y0 = (cam.height - crop) // 2
+    ccam = Camera(cam.c2w, cam.fx, cam.fy, cam.cx - x0, cam.cy - y0, crop, crop)
+    cp = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    t0 = time.time()
+    out = render_ref(cp, ccam, sh_degree=3)
+    loss = out["rgb"].mean() + 0.2 * out["depth"].mean() + 0.1 * out["normal"].mean()
+    loss.backward()
+    dt = time.time() - t0
+    frac = (crop * crop) / float(cam.width * cam.height)
+    print(json.dumps({
+        "value": round(frac / dt, 6),
+        "unit": "iters/s (full-frame equivalent)",
+        "cores": threads,
+        "kind": "port",
+        "sample": f"oracle fwd+bwd of view 0, central {crop}x{crop} crop of {cam.width}x{cam.height} "
+                  f"({frac:.4f} of the pixels) in {dt:.1f}s on {threads} threads, scaled by pixel count",
+    }))
+
+
+def cpu_baseline(args):
+    """Run the oracle in a child process (never touches the GPU) under a hard wall-clock limit."""
+    import subprocess
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    threads = max(1, min(avail, 8))
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", "--n-gauss", str(args.n_gauss),
+           "--res", str(args.res), "--cpu-crop", str(args.cpu_crop), "--cpu-threads", str(threads)]
+    env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads), HIP_VISIBLE_DEVICES="")
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=args.cpu_timeout, env=env)
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if r.returncode == 0 and lines:
+            return json.loads(lines[-1])
+        return {"value": None, "unit": "iters/s", "cores": threads, "kind": "port",
+                "sample": f"oracle child failed rc={r.returncode}: {r.stderr[-200:]}"}
+    except subprocess.TimeoutExpired:
+        return {"value": None, "unit": "iters/s", "cores": threads, "kind": "port",
+                "sample": f"oracle child exceeded {args.cpu_timeout}s on a {args.cpu_crop}^2 crop"}
+
+
+def main():
+    args = parse()
+    if args.cpu_baseline_worker:
+        cpu_baseline_worker(args.n_gauss, args.res, args.cpu_crop, args.cpu_threads)
+        return
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus or world == 1, f"WORLD_SIZE {world} != --gpus {args.gpus}"
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from fusionsense_amd import ops, scenes
+    from fusionsense_amd.splatfacto import DensifyStrategy, SplatfactoConfig
+    from fusionsense_amd.trainer import SplatTrainer
+
+    W = H = args.res
+    focal = 1111.11 * args.res / 800.0
+    cams = scenes.hemisphere_cameras(args.views, width=W, height=H, focal=focal, seed=0)
+    log('building scene')
+    params = scenes.lego_like_scene(args.n_gauss, seed=0)
+    log('scene built')
+    # statistics only (no refinement inside the timed window: refine_every > steps)
+    strategy = DensifyStrategy(SplatfactoConfig(), num_train_data=args.views, stats_only=True)
+    trainer = SplatTrainer(params, dev, sh_degree=3, strategy=strategy, seed=0)
+
+    # targets: renders of a differently seeded scene, so gradients are non-trivial
+    tgt_tr = SplatTrainer(scenes.lego_like_scene(args.n_gauss, seed=1), dev, sh_degree=3)
+    targets = []
+    with torch.no_grad():
+        for ci, cam in enumerate(cams):
+            o = tgt_tr.forward(cam)
+            torch.cuda.synchronize()
+            log(f'target {ci} rendered, M={o["info"]["flatten_ids"].numel()}')
+            targets.append({k: o[k].detach().clone() for k in ("rgb", "depth", "normal")})
+    del tgt_tr
+    torch.cuda.empty_cache()
+
+    def view_of(step):
+        return (step * world + rank) % len(cams)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    # ---- warmup ----
+    for s in range(args.warmup):
+        v = view_of(s)
+        trainer.train_step(cams[v], targets[v])
+        torch.cuda.synchronize()
+        log(f'warmup step {s} done')
+    torch.cuda.synchronize()
+    barrier()
+
+    # ---- timed region: EXACTLY args.steps full iterations ----
+    ops.TIMER.reset(enabled=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for s in range(args.steps):
+        v = view_of(args.warmup + s)
+        trainer.train_step(cams[v], targets[v])
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = ops.TIMER.summary()
+    log(f'timed region done: {elapsed:.3f}s')
+    ops.TIMER.reset(enabled=False)
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+
+    # ---- side measurements (outside the timed region) ----
+    info = trainer.last_info
+    N = trainer.num_gaussians()
+    M = int(info["flatten_ids"].numel())
+    n_vis = int((info["radii"] > 0).sum().item())
+    P = W * H
+    # iteration without the optimizer step
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for s in range(args.steps):
+        v = view_of(s)
+        trainer.train_step(cams[v], targets[v], optimizer_step=False)
+    torch.cuda.synchronize()
+    t_noopt = (time.perf_counter() - t1) / args.steps
+    # forward-only latency -> rendered Mpix/s (num_rays_per_sec of dn_pipeline.py:246-248)
+    with torch.no_grad():
+        for s in range(2):
+            trainer.forward(cams[view_of(s)])
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        for s in range(args.steps):
+            trainer.forward(cams[view_of(s)])
+        torch.cuda.synchronize()
+        t_fwd = (time.perf_counter() - t2) / args.steps
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        iters_per_s = world * args.steps / elapsed
+        # algorithmic bytes.  The normal plane re-bins with the legacy rule
+        # (reference-faithful variant: +244 B/isect) in this round.
+        key_bits = 32 + ops.tile_bits((W // 16 + (W % 16 > 0)) * (H // 16 + (H % 16 > 0)))
+        sort_b = 2 * 12 * ((key_bits + 7) // 8)
+        b_isect = 12 + sort_b + 8 + 44 + 44
+        b_isect_normal = 12 + sort_b + 8 + 40 + 40
+        b_iter = N * 352 + n_vis * 444 + M * (b_isect + b_isect_normal) + P * 92
+        # dominant kernel: raster_bwd of the RGB+ED pass (D=4, absgrad)
+        dom = "raster_bwd_d4"
+        dom_ms = kernel_ms.get(dom, {}).get("avg_ms")
+        dom_bytes = M * 44 + P * 28 + n_vis * 48
+        roofline = None
+        if dom_ms:
+            ach = dom_bytes / (dom_ms * 1e-3) / 1e9
+            roofline = {"kernel": "raster_bwd_kernel<4,true>", "bound": "hbm", "achieved": round(ach, 2),
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
+                        "traffic": None, "algorithmic_bytes": dom_bytes,
+                        "avg_launch_ms": round(dom_ms, 4)}
+        line = {
+            "metric": "train_iters_per_s",
+            "value": round(iters_per_s, 3),
+            "unit": "iters/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"BASELINE config #2: synthetic lego-like, {N} Gaussians, {W}x{H}, "
+                                   "SH deg 3, RGB+ED + normal pass, fwd+bwd+Adam+densify stats, "
+                                   "1 view/rank/step",
+                       "n_gaussians": N, "width": W, "height": H, "views": len(cams),
+                       "n_isects": M, "n_visible": n_vis, "isects_per_gaussian": round(M / max(N, 1), 3),
+                       "parallelism": f"dp{world}"},
+            "rendered_mpix_per_s": round(world * P / t_fwd / 1e6, 2),
+            "fwd_ms": round(t_fwd * 1e3, 3),
+            "iters_per_s_excl_optimizer": round(world / t_noopt, 3),
+            "iter_algorithmic_bytes": b_iter,
+            "iter_hbm_frac": round(b_iter / (elapsed / args.steps) / (HBM_PEAK_GBS * 1e9), 5),
+            "kernels_ms": kernel_ms,
+            "roofline": roofline,
+        }
+        log('gpu part done')
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(args)
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,63 @@
+"""Loss formulas that consume the render: the `v_render` the backward kernels
+receive is defined by these.  Plain torch elementwise math mirroring
+/root/reference/dn_splatter/dn_model.py:673-925 and dn_splatter/losses.py:161-214,269-285
+(host-side glue, not a kernel target in this round; "next" row N2)."""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+from torch import Tensor
+
+
+def _gaussian_window(size: int, sigma: float, device, dtype) -> Tensor:
+    x = torch.arange(size, device=device, dtype=dtype) - (size - 1) / 2.0
+    g = torch.exp(-(x**2) / (2 * sigma**2))
+    return g / g.sum()
+
+
+def ssim(pred: Tensor, gt: Tensor, kernel_size: int = 11, sigma: float = 1.5, data_range: float = 1.0) -> Tensor:
+    """Mean SSIM over a [3,H,W] image pair with an 11x11 Gaussian window — the
+    torchmetrics StructuralSimilarityIndexMeasure(kernel_size=11) FusionSense swaps in at
+    dn_model.py:244 (separable window, reflect padding, valid-region crop)."""
+    C = pred.shape[0]
+    w = _gaussian_window(kernel_size, sigma, pred.device, pred.dtype)
+    pad = (kernel_size - 1) // 2
+    x = torch.stack([pred, gt, pred * pred, gt * gt, pred * gt], 0)  # [5,C,H,W]
+    x = F.pad(x, (pad, pad, pad, pad), mode="reflect").reshape(1, 5 * C, x.shape[-2] + 2 * pad, x.shape[-1] + 2 * pad)
+    kh = w.view(1, 1, 1, -1).expand(5 * C, 1, 1, kernel_size)
+    kv = w.view(1, 1, -1, 1).expand(5 * C, 1, kernel_size, 1)
+    y = F.conv2d(F.conv2d(x, kh, groups=5 * C), kv, groups=5 * C).reshape(5, C, pred.shape[-2], pred.shape[-1])
+    mu_p, mu_g, e_pp, e_gg, e_pg = y
+    c1, c2 = (0.01 * data_range) ** 2, (0.03 * data_range) ** 2
+    s_pp = e_pp - mu_p * mu_p
+    s_gg = e_gg - mu_g * mu_g
+    s_pg = e_pg - mu_p * mu_g
+    m = ((2 * mu_p * mu_g + c1) * (2 * s_pg + c2)) / ((mu_p * mu_p + mu_g * mu_g + c1) * (s_pp + s_gg + c2))
+    return m[..., pad:-pad, pad:-pad].mean()
+
+
+def rgb_loss(pred: Tensor, gt: Tensor, ssim_lambda: float = 0.2) -> Tensor:
+    """(1-l)*L1 + l*(1-SSIM); pred/gt [H,W,3] (splatfacto main loss)."""
+    l1 = torch.abs(gt - pred).mean()
+    sim = 1 - ssim(pred.permute(2, 0, 1), gt.permute(2, 0, 1))
+    return (1 - ssim_lambda) * l1 + ssim_lambda * sim
+
+
+def edge_aware_log_l1(pred_depth: Tensor, gt_depth: Tensor, rgb: Tensor, mask: Tensor = None) -> Tensor:
+    """dn_splatter/losses.py:177-214 (EdgeAwareLogL1): log(1+|d-d*|) weighted by exp(-|grad I|)."""
+    logl1 = torch.log(1 + torch.abs(pred_depth - gt_depth))
+    grad_x = torch.mean(torch.abs(rgb[:, :-1, :] - rgb[:, 1:, :]), -1, keepdim=True)
+    grad_y = torch.mean(torch.abs(rgb[:-1, :, :] - rgb[1:, :, :]), -1, keepdim=True)
+    loss_x = torch.exp(-grad_x) * logl1[:, :-1, :]
+    loss_y = torch.exp(-grad_y) * logl1[:-1, :, :]
+    if mask is not None:
+        loss_x = loss_x[mask[:, :-1, :]]
+        loss_y = loss_y[mask[:-1, :, :]]
+    return loss_x.mean() + loss_y.mean()
+
+
+def tv_loss(pred: Tensor) -> Tensor:
+    """dn_splatter/losses.py:269-285 (TVLoss) on a [H,W,C] image."""
+    h_diff = pred[:, :-1, :] - pred[:, 1:, :]
+    w_diff = pred[:-1, :, :] - pred[1:, :, :]
+    return torch.mean(torch.abs(h_diff)) + torch.mean(torch.abs(w_diff))

@@ -22,6 +22,61 @@ def _c(t: Optional[Tensor]) -> Optional[Tensor]:
     return None if t is None else t.contiguous()
 
 
+class _KernelTimer:
+    """HIP-event timing of the C-ABI launches on torch's current stream (the stream every kernel
+    is enqueued on).  Disabled by default; bench.py enables it over its timed region."""
+
+    def __init__(self):
+        self.enabled = False
+        self.records = []
+
+    def reset(self, enabled: bool = False) -> None:
+        self.enabled = enabled
+        self.records = []
+
+    class _Span:
+        def __init__(self, timer, name):
+            self.timer, self.name = timer, name
+
+        def __enter__(self):
+            if self.timer.enabled:
+                self.start = torch.cuda.Event(enable_timing=True)
+                self.end = torch.cuda.Event(enable_timing=True)
+                self.start.record()
+            return self
+
+        def __exit__(self, *exc):
+            if self.timer.enabled:
+                self.end.record()
+                self.timer.records.append((self.name, self.start, self.end))
+            return False
+
+    def span(self, name: str):
+        return _KernelTimer._Span(self, name)
+
+    def summary(self):
+        if not self.records:
+            return {}
+        torch.cuda.synchronize()
+        acc = {}
+        for name, s, e in self.records:
+            t = s.elapsed_time(e)
+            a = acc.setdefault(name, [0.0, 0])
+            a[0] += t
+            a[1] += 1
+        return {k: {"avg_ms": round(v[0] / v[1], 4), "calls": v[1]} for k, v in sorted(acc.items())}
+
+
+TIMER = _KernelTimer()
+
+
+def _run(fn, args, what: str, tag: str = "") -> None:
+    """Call one C-ABI entry point, time it if the timer is on, raise on a non-zero code."""
+    with TIMER.span(what[5:] + tag):
+        rc = fn(*args)
+    check(rc, what)
+
+
 def tile_bits(n_tiles: int) -> int:
     return int(math.floor(math.log2(n_tiles))) + 1 if n_tiles > 0 else 1
 
@@ -39,7 +94,7 @@ def project_fwd(means, quats, scales, viewmats, Ks, width, height, eps2d, near_p
     depths = torch.empty(Cn, N, dtype=torch.float32, device=dev)
     conics = torch.empty(Cn, N, 3, dtype=torch.float32, device=dev)
     comp = torch.empty(Cn, N, dtype=torch.float32, device=dev) if calc_compensations else None
-    check(lib.fsgs_project_fwd(Cn, N, ptr(means), ptr(quats), ptr(scales), ptr(viewmats), ptr(Ks),
+    _run(lib.fsgs_project_fwd, (Cn, N, ptr(means), ptr(quats), ptr(scales), ptr(viewmats), ptr(Ks),
                                width, height, eps2d, near_plane, far_plane, radius_clip, ptr(radii),
                                ptr(means2d), ptr(depths), ptr(conics), ptr(comp), stream_ptr(dev)),
           "fsgs_project_fwd")
@@ -59,14 +114,14 @@ def isect_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tile_size: int, 
     sbytes = lib.fsgs_scan_scratch_bytes(max(total, 1))
     scratch = torch.empty(sbytes, dtype=torch.uint8, device=dev)
     m_host = C.c_int64(0)
-    check(lib.fsgs_isect_count(Cn, N, ptr(means2d), ptr(radii), tile_size, tile_width, tile_height,
+    _run(lib.fsgs_isect_count, (Cn, N, ptr(means2d), ptr(radii), tile_size, tile_width, tile_height,
                                int(legacy), ptr(tpg), ptr(cum), ptr(scratch), sbytes, C.byref(m_host),
                                stream_ptr(dev)), "fsgs_isect_count")
     M = int(m_host.value)
     ids = torch.empty(M, dtype=torch.int64, device=dev)
     flat = torch.empty(M, dtype=torch.int32, device=dev)
     if M > 0:
-        check(lib.fsgs_isect_emit(Cn, N, ptr(means2d), ptr(radii), ptr(depths), ptr(cum), tile_size,
+        _run(lib.fsgs_isect_emit, (Cn, N, ptr(means2d), ptr(radii), ptr(depths), ptr(cum), tile_size,
                                   tile_width, tile_height, int(legacy), ptr(ids), ptr(flat),
                                   stream_ptr(dev)), "fsgs_isect_emit")
         if sort:
@@ -89,7 +144,7 @@ def sort_pairs(keys: Tensor, vals: Tensor, end_bit: int = 64) -> Tuple[Tensor, T
     sbytes = lib.fsgs_sort_scratch_bytes(n)
     scratch = torch.empty(sbytes, dtype=torch.uint8, device=dev)
     in_b = C.c_int(0)
-    check(lib.fsgs_sort_pairs(n, ptr(keys), ptr(vals), ptr(kb), ptr(vb), end_bit, ptr(scratch), sbytes,
+    _run(lib.fsgs_sort_pairs, (n, ptr(keys), ptr(vals), ptr(kb), ptr(vb), end_bit, ptr(scratch), sbytes,
                               C.byref(in_b), stream_ptr(dev)), "fsgs_sort_pairs")
     return (kb, vb) if in_b.value else (keys, vals)
 
@@ -99,7 +154,7 @@ def isect_offset_encode(isect_ids: Tensor, n_cameras: int, tile_width: int, tile
     dev = isect_ids.device
     n_tiles = tile_width * tile_height
     offsets = torch.empty(n_cameras, tile_height, tile_width, dtype=torch.int32, device=dev)
-    check(lib.fsgs_isect_offset_encode(isect_ids.numel(), ptr(isect_ids), n_cameras, n_tiles,
+    _run(lib.fsgs_isect_offset_encode, (isect_ids.numel(), ptr(isect_ids), n_cameras, n_tiles,
                                        tile_bits(n_tiles), ptr(offsets), stream_ptr(dev)),
           "fsgs_isect_offset_encode")
     return offsets
@@ -142,7 +197,7 @@ class _Projection(torch.autograd.Function):
         v_quats = torch.empty_like(quats)
         v_scales = torch.empty_like(scales)
         v_viewmats = torch.zeros_like(viewmats) if ctx.needs_input_grad[3] else None
-        check(lib.fsgs_project_bwd(Cn, N, ptr(means), ptr(quats), ptr(scales), ptr(viewmats), ptr(Ks),
+        _run(lib.fsgs_project_bwd, (Cn, N, ptr(means), ptr(quats), ptr(scales), ptr(viewmats), ptr(Ks),
                                    width, height, eps2d, ptr(radii), ptr(conics),
                                    ptr(comp) if use_comp else None, ptr(v_means2d), ptr(v_depths),
                                    ptr(v_conics), ptr(_c(v_comp)) if use_comp else None, ptr(v_means),
@@ -165,7 +220,7 @@ class _SHColors(torch.autograd.Function):
         K = coeffs.shape[1]
         D = 4 if depths is not None else 3
         colors = torch.empty(Cn, N, D, dtype=torch.float32, device=dev)
-        check(lib.fsgs_sh_fwd(Cn, N, K, degree, ptr(means), ptr(campos), ptr(coeffs), ptr(radii),
+        _run(lib.fsgs_sh_fwd, (Cn, N, K, degree, ptr(means), ptr(campos), ptr(coeffs), ptr(radii),
                               ptr(depths), ptr(colors), stream_ptr(dev)), "fsgs_sh_fwd")
         ctx.save_for_backward(means, coeffs, campos, radii)
         ctx.meta = (degree, D, depths is not None)
@@ -183,7 +238,7 @@ class _SHColors(torch.autograd.Function):
         v_coeffs = torch.empty_like(coeffs)
         v_means = torch.zeros_like(means)
         v_depths = torch.empty(Cn, N, dtype=torch.float32, device=dev) if has_depth else None
-        check(lib.fsgs_sh_bwd(Cn, N, K, degree, ptr(means), ptr(campos), ptr(coeffs), ptr(radii), D,
+        _run(lib.fsgs_sh_bwd, (Cn, N, K, degree, ptr(means), ptr(campos), ptr(coeffs), ptr(radii), D,
                               ptr(v_colors), ptr(v_coeffs), ptr(v_means), ptr(v_depths), stream_ptr(dev)),
               "fsgs_sh_bwd")
         return v_means, v_coeffs, None, None, v_depths, None
@@ -207,10 +262,10 @@ class _Rasterize(torch.autograd.Function):
         render = torch.empty(Cn, height, width, D, dtype=torch.float32, device=dev)
         alphas = torch.empty(Cn, height, width, 1, dtype=torch.float32, device=dev)
         last_ids = torch.empty(Cn, height, width, dtype=torch.int32, device=dev)
-        check(lib.fsgs_raster_fwd(Cn, N, D, ptr(means2d), ptr(conics), ptr(colors), ptr(opacities),
+        _run(lib.fsgs_raster_fwd, (Cn, N, D, ptr(means2d), ptr(conics), ptr(colors), ptr(opacities),
                                   ptr(backgrounds), width, height, tile_size, tw, th, ptr(isect_offsets),
                                   ptr(flatten_ids), M, ptr(render), ptr(alphas), ptr(last_ids),
-                                  stream_ptr(dev)), "fsgs_raster_fwd")
+                                  stream_ptr(dev)), "fsgs_raster_fwd", f"_d{D}")
         ctx.save_for_backward(means2d, conics, colors, opacities,
                               backgrounds if backgrounds is not None else torch.empty(0, device=dev),
                               isect_offsets, flatten_ids, alphas, last_ids)
@@ -238,11 +293,11 @@ class _Rasterize(torch.autograd.Function):
         v_colors = torch.zeros_like(colors)
         v_opacities = torch.zeros_like(opacities)
         v_abs = torch.zeros_like(means2d) if absgrad else None
-        check(lib.fsgs_raster_bwd(Cn, N, D, ptr(means2d), ptr(conics), ptr(colors), ptr(opacities),
+        _run(lib.fsgs_raster_bwd, (Cn, N, D, ptr(means2d), ptr(conics), ptr(colors), ptr(opacities),
                                   ptr(backgrounds) if has_bg else None, width, height, tile_size, tw, th,
                                   ptr(isect_offsets), ptr(flatten_ids), M, ptr(alphas), ptr(last_ids),
                                   ptr(v_render), ptr(v_alphas), ptr(v_means2d), ptr(v_abs), ptr(v_conics),
-                                  ptr(v_colors), ptr(v_opacities), stream_ptr(dev)), "fsgs_raster_bwd")
+                                  ptr(v_colors), ptr(v_opacities), stream_ptr(dev)), "fsgs_raster_bwd", f"_d{D}")
         if absgrad:
             ctx.means2d_obj.absgrad = v_abs
         v_bg = None
@@ -263,7 +318,7 @@ class _GaussianNormals(torch.autograd.Function):
         N = quats.shape[0]
         n_world = torch.empty(N, 3, dtype=torch.float32, device=dev)
         n_cam = torch.empty(N, 3, dtype=torch.float32, device=dev)
-        check(lib.fsgs_normals_fwd(N, ptr(quats), ptr(log_scales), ptr(means), ptr(c2w), ptr(n_world),
+        _run(lib.fsgs_normals_fwd, (N, ptr(quats), ptr(log_scales), ptr(means), ptr(c2w), ptr(n_world),
                                    ptr(n_cam), stream_ptr(dev)), "fsgs_normals_fwd")
         ctx.save_for_backward(quats, log_scales, means, c2w)
         ctx.mark_non_differentiable(n_world)
@@ -276,7 +331,7 @@ class _GaussianNormals(torch.autograd.Function):
         dev = quats.device
         N = quats.shape[0]
         v_quats = torch.empty_like(quats)
-        check(lib.fsgs_normals_bwd(N, ptr(quats), ptr(log_scales), ptr(means), ptr(c2w), ptr(_c(v_cam)),
+        _run(lib.fsgs_normals_bwd, (N, ptr(quats), ptr(log_scales), ptr(means), ptr(c2w), ptr(_c(v_cam)),
                                    ptr(v_quats), stream_ptr(dev)), "fsgs_normals_bwd")
         return v_quats, None, None, None
 
@@ -291,7 +346,7 @@ def densify_stats_(radii: Tensor, absgrad: Tensor, max_hw: int, xys_grad_norm: T
     """In-place SplatfactoModel.after_train accumulation."""
     lib = load()
     N = radii.numel()
-    check(lib.fsgs_densify_stats(N, ptr(radii), ptr(_c(absgrad)), 1.0 / float(max_hw), ptr(xys_grad_norm),
+    _run(lib.fsgs_densify_stats, (N, ptr(radii), ptr(_c(absgrad)), 1.0 / float(max_hw), ptr(xys_grad_norm),
                                  ptr(vis_counts), ptr(max_2Dsize), stream_ptr(radii.device)),
           "fsgs_densify_stats")
 
@@ -304,7 +359,7 @@ def mask_positions(keep: Tensor) -> Tensor:
     pos = torch.empty(max(n, 1), dtype=torch.int64, device=keep.device)
     sbytes = lib.fsgs_scan_scratch_bytes(max(n, 1))
     scratch = torch.empty(sbytes, dtype=torch.uint8, device=keep.device)
-    check(lib.fsgs_mask_scan(n, ptr(keep8), ptr(pos), ptr(scratch), sbytes, stream_ptr(keep.device)),
+    _run(lib.fsgs_mask_scan, (n, ptr(keep8), ptr(pos), ptr(scratch), sbytes, stream_ptr(keep.device)),
           "fsgs_mask_scan")
     return pos[:n]
 
@@ -321,7 +376,7 @@ def compact_rows(src: Tensor, keep8: Tensor, positions: Tensor, n_keep: int,
         out = torch.empty((n_keep,) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
         out_offset = 0
     dst = out[out_offset:]
-    check(lib.fsgs_compact_rows(n, row, ptr(keep8), ptr(positions), ptr(src), dst.data_ptr(),
+    _run(lib.fsgs_compact_rows, (n, row, ptr(keep8), ptr(positions), ptr(src), dst.data_ptr(),
                                 stream_ptr(src.device)), "fsgs_compact_rows")
     return out
 
@@ -333,7 +388,7 @@ def split_samples(ids: Tensor, n_samples: int, means: Tensor, quats: Tensor, log
     dev = means.device
     new_means = torch.empty(S * n_samples, 3, dtype=torch.float32, device=dev)
     new_ls = torch.empty(S * n_samples, 3, dtype=torch.float32, device=dev)
-    check(lib.fsgs_split_samples(S, n_samples, ptr(ids.contiguous()), ptr(_c(means)), ptr(_c(quats)),
+    _run(lib.fsgs_split_samples, (S, n_samples, ptr(ids.contiguous()), ptr(_c(means)), ptr(_c(quats)),
                                  ptr(_c(log_scales)), ptr(_c(randn)), ptr(new_means), ptr(new_ls),
                                  stream_ptr(dev)), "fsgs_split_samples")
     return new_means, new_ls

@@ -1,0 +1,259 @@
+"""Densify / prune host logic: the SplatfactoModel methods FusionSense inherits or overrides
+(SURVEY.md §8a-12, 8a-13, Appendix A.1/A.2), operating on a :class:`SplatTrainer`.
+
+Reference behaviour mirrored (same names, argument meaning and order of operations):
+  * ``after_train``            nerfstudio SplatfactoModel (registered dn_splatter/dn_model.py:1385-1389)
+  * ``refinement_after``       dn_splatter/dn_model.py:326-451
+  * ``split_gaussians`` / ``dup_gaussians`` / ``cull_gaussians`` / ``dup_in_optim`` /
+    ``remove_from_optim``      nerfstudio SplatfactoModel (called at dn_model.py:369,379,398-401,415,426)
+
+The mask arithmetic is a handful of elementwise torch ops over [N]; everything that moves
+rows (62 parameter floats + 2x59 Adam-moment floats per Gaussian) or touches per-Gaussian
+statistics goes through libfsgs.so (fsgs_densify_stats, fsgs_split_samples, fsgs_mask_scan,
+fsgs_compact_rows): one order-preserving compaction per tensor straight into the grown
+allocation instead of the reference's ``torch.cat`` followed by ``param[~culls]``.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, Optional
+
+import torch
+import torch.distributed as dist
+from torch import Tensor
+
+from . import ops
+
+
+@dataclass
+class SplatfactoConfig:
+    """nerfstudio 1.1.3 SplatfactoModelConfig defaults with the overrides of
+    DNSplatterModelConfig (dn_model.py:116-141) and configs/config.py:3-7."""
+    warmup_length: int = 500
+    refine_every: int = 100
+    cull_alpha_thresh: float = 0.1
+    cull_scale_thresh: float = 0.5
+    continue_cull_post_densification: bool = True
+    reset_alpha_every: int = 30
+    densify_grad_thresh: float = 0.0008
+    densify_size_thresh: float = 0.01
+    n_split_samples: int = 2
+    sh_degree_interval: int = 1000
+    cull_screen_size: float = 0.15
+    split_screen_size: float = 0.05
+    stop_screen_size_at: int = 4000
+    stop_split_at: int = 10000
+    sh_degree: int = 3
+
+
+def refine_schedule(cfg: SplatfactoConfig, step: int, num_train_data: int) -> Dict[str, bool]:
+    """The three decisions of refinement_after (dn_model.py:328-341, 416-431) as pure host logic."""
+    if step <= cfg.warmup_length:
+        return dict(active=False, densify=False, cull_only=False, reset_opacity=False)
+    reset_interval = cfg.reset_alpha_every * cfg.refine_every
+    densify = step < cfg.stop_split_at and step % reset_interval > num_train_data + cfg.refine_every
+    cull_only = (not densify) and step >= cfg.stop_split_at and cfg.continue_cull_post_densification
+    reset = step < cfg.stop_split_at and step % reset_interval == cfg.refine_every
+    return dict(active=True, densify=densify, cull_only=cull_only, reset_opacity=reset)
+
+
+def densify_masks(cfg: SplatfactoConfig, step: int, xys_grad_norm: Tensor, vis_counts: Tensor,
+                  max_2Dsize: Tensor, log_scales: Tensor, last_size, add_mask: Optional[Tensor]):
+    """split / dup selection of dn_model.py:350-379.  NOTE the reference computes ``dups`` AFTER
+    ``split_gaussians`` has divided the selected parents' scales by 1.6 in place (nerfstudio
+    split_gaussians), so a parent just above the size threshold can be both
+    split and duplicated; reproduced here.  Returns (splits, dups, scale_max_after)."""
+    avg_grad_norm = (xys_grad_norm / vis_counts) * 0.5 * max(last_size[0], last_size[1])
+    high_grads = avg_grad_norm > cfg.densify_grad_thresh
+    scale_max = log_scales.exp().max(dim=-1).values
+    splits = scale_max > cfg.densify_size_thresh
+    if step < cfg.stop_screen_size_at:
+        splits = splits | (max_2Dsize > cfg.split_screen_size)
+    splits = splits & high_grads
+    if add_mask is not None:
+        splits = splits & ~add_mask
+    shrunk = torch.log(torch.exp(log_scales) / 1.6).exp().max(dim=-1).values
+    scale_max_after = torch.where(splits, shrunk, scale_max)
+    dups = (scale_max_after <= cfg.densify_size_thresh) & high_grads
+    if add_mask is not None:
+        dups = dups & ~add_mask
+    return splits, dups
+
+
+def cull_mask(cfg: SplatfactoConfig, step: int, opacities: Tensor, log_scales: Tensor,
+              max_2Dsize: Optional[Tensor], extra_cull_mask: Optional[Tensor]) -> Tensor:
+    """cull_gaussians: which rows of the (grown) tensors are removed."""
+    culls = (torch.sigmoid(opacities) < cfg.cull_alpha_thresh).squeeze(-1)
+    if extra_cull_mask is not None:
+        culls = culls | extra_cull_mask
+    if step > cfg.refine_every * cfg.reset_alpha_every:
+        toobigs = log_scales.exp().max(dim=-1).values > cfg.cull_scale_thresh
+        if step < cfg.stop_screen_size_at and max_2Dsize is not None:
+            toobigs = toobigs | (max_2Dsize > cfg.cull_screen_size)
+        culls = culls | toobigs
+    return culls
+
+
+class DensifyStrategy:
+    def __init__(self, cfg: Optional[SplatfactoConfig] = None, num_train_data: int = 1,
+                 stats_only: bool = False):
+        self.cfg = cfg or SplatfactoConfig()
+        self.num_train_data = num_train_data
+        self.stats_only = stats_only
+        self.xys_grad_norm: Optional[Tensor] = None
+        self.vis_counts: Optional[Tensor] = None
+        self.max_2Dsize: Optional[Tensor] = None
+        self.last_size = (1, 1)
+        self.add_mask: Optional[Tensor] = None  # touch anchors (dn_model.py:292, 366-378)
+        self.extra_cull_fn = None  # hook for hull / touch pruning (a-14)
+        self.last_report: Dict[str, int] = {}
+
+    # ---- a-12 ---------------------------------------------------------------------------
+    @torch.no_grad()
+    def after_train(self, trainer, out, camera) -> None:
+        if trainer.step >= self.cfg.stop_split_at:
+            return
+        radii = out["radii"]
+        N = radii.shape[0]
+        dev = radii.device
+        self.last_size = (camera.height, camera.width)
+        if self.xys_grad_norm is None:
+            self.xys_grad_norm = torch.zeros(N, device=dev)
+            self.vis_counts = torch.ones(N, device=dev)
+        if self.max_2Dsize is None:
+            self.max_2Dsize = torch.zeros(N, device=dev)
+        absgrad = out["xys"].absgrad[0]
+        ops.densify_stats_(radii, absgrad, max(camera.height, camera.width), self.xys_grad_norm,
+                           self.vis_counts, self.max_2Dsize)
+
+    def _all_reduce_stats(self) -> None:
+        """DP: every rank must take identical split/cull decisions."""
+        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+            return
+        if self.xys_grad_norm is None:
+            return
+        dist.all_reduce(self.xys_grad_norm, op=dist.ReduceOp.SUM)
+        extra = self.vis_counts - 1.0
+        dist.all_reduce(extra, op=dist.ReduceOp.SUM)
+        self.vis_counts = extra + 1.0
+        dist.all_reduce(self.max_2Dsize, op=dist.ReduceOp.MAX)
+
+    def maybe_refine(self, trainer) -> None:
+        """AFTER_TRAIN_ITERATION callback with update_every_num_iters=refine_every
+        (dn_model.py:1398-1404)."""
+        if self.stats_only:
+            return
+        if trainer.step % self.cfg.refine_every == 0:
+            self.refinement_after(trainer, trainer.step)
+
+    # ---- a-13 ---------------------------------------------------------------------------
+    @torch.no_grad()
+    def refinement_after(self, trainer, step: int) -> None:
+        cfg = self.cfg
+        sched = refine_schedule(cfg, step, self.num_train_data)
+        if not sched["active"]:
+            return
+        self._all_reduce_stats()
+        P = trainer.params
+        N = P["means"].shape[0]
+        dev = P["means"].device
+        new_rows: Dict[str, Tensor] = {}
+        n_new = 0
+        extra_old: Optional[Tensor] = None
+        do_cull = False
+        n_split = n_dup = 0
+        if sched["densify"]:
+            assert self.xys_grad_norm is not None and self.vis_counts is not None and self.max_2Dsize is not None
+            splits, dups = densify_masks(cfg, step, self.xys_grad_norm, self.vis_counts, self.max_2Dsize,
+                                         P["scales"].data, self.last_size, self.add_mask)
+            split_ids = torch.where(splits)[0]
+            dup_ids = torch.where(dups)[0]
+            n_split, n_dup = split_ids.numel(), dup_ids.numel()
+            samps = cfg.n_split_samples
+            randn = torch.randn((samps * n_split, 3), device=dev, generator=trainer.rng)
+            sp_means, sp_scales = ops.split_samples(split_ids, samps, P["means"].data, P["quats"].data,
+                                                    P["scales"].data, randn)
+            shrunk = torch.log(torch.exp(P["scales"].data) / 1.6)
+            scales_after = torch.where(splits[:, None], shrunk, P["scales"].data)
+            for name, p in P.items():
+                reps = (samps,) + (1,) * (p.dim() - 1)
+                if name == "means":
+                    s_rows = sp_means
+                elif name == "scales":
+                    s_rows = sp_scales
+                else:
+                    s_rows = p.data[split_ids].repeat(*reps)
+                d_rows = scales_after[dup_ids] if name == "scales" else p.data[dup_ids]
+                new_rows[name] = torch.cat([s_rows, d_rows], dim=0)
+            n_new = samps * n_split + n_dup
+            extra_old = splits  # a split parent is pruned (dn_model.py:403-415)
+            do_cull = True
+        elif sched["cull_only"]:
+            do_cull = True
+
+        deleted = 0
+        if do_cull:
+            max2d_old = self.max_2Dsize
+            extra = extra_old
+            if self.extra_cull_fn is not None:
+                e2 = self.extra_cull_fn(trainer)
+                extra = e2 if extra is None else (extra | e2)
+            cull_old = cull_mask(cfg, step, P["opacities"].data, P["scales"].data, max2d_old, extra)
+            keep_old = ~cull_old
+            if n_new > 0:
+                cull_new = cull_mask(cfg, step, new_rows["opacities"], new_rows["scales"],
+                                     torch.zeros(n_new, device=dev) if max2d_old is not None else None, None)
+                keep_new = ~cull_new
+            else:
+                keep_new = torch.zeros(0, dtype=torch.bool, device=dev)
+            n_keep_old = int(keep_old.sum().item())
+            n_keep_new = int(keep_new.sum().item()) if n_new > 0 else 0
+            deleted = (N - n_keep_old) + (n_new - n_keep_new)
+            self._rebuild(trainer, keep_old, n_keep_old, new_rows, keep_new, n_keep_new)
+            if self.add_mask is not None:
+                self.add_mask = torch.cat([self.add_mask[keep_old],
+                                           torch.zeros(n_keep_new, dtype=torch.bool, device=dev)])
+
+        if sched["reset_opacity"]:
+            reset_value = cfg.cull_alpha_thresh * 2.0
+            logit = torch.logit(torch.tensor(reset_value)).item()
+            op = trainer.params["opacities"]
+            op.data = torch.clamp(op.data, max=logit)
+            st = trainer.optimizers["opacities"].state.get(op, None)
+            if st:
+                st["exp_avg"] = torch.zeros_like(st["exp_avg"])
+                st["exp_avg_sq"] = torch.zeros_like(st["exp_avg_sq"])
+
+        self.xys_grad_norm = None
+        self.vis_counts = None
+        self.max_2Dsize = None
+        self.last_report = dict(step=step, n_before=N, n_split=n_split, n_dup=n_dup, n_deleted=deleted,
+                                n_after=trainer.params["means"].shape[0])
+
+    def _rebuild(self, trainer, keep_old: Tensor, n_keep_old: int, new_rows: Dict[str, Tensor],
+                 keep_new: Tensor, n_keep_new: int) -> None:
+        """New parameter tensors + Adam moments: kept old rows (order preserved, HIP compaction)
+        followed by the kept new rows; new rows get zero moments (dup_in_optim), culled rows
+        drop theirs (remove_from_optim)."""
+        keep8 = keep_old.to(torch.uint8).contiguous()
+        positions = ops.mask_positions(keep8)
+        n_final = n_keep_old + n_keep_new
+        for name in list(trainer.params.keys()):
+            old_p = trainer.params[name]
+            opt = trainer.optimizers[name]
+            shape = (n_final,) + tuple(old_p.shape[1:])
+            new_data = torch.empty(shape, dtype=old_p.dtype, device=old_p.device)
+            ops.compact_rows(old_p.data, keep8, positions, n_keep_old, out=new_data, out_offset=0)
+            if n_keep_new > 0:
+                new_data[n_keep_old:] = new_rows[name][keep_new]
+            new_p = torch.nn.Parameter(new_data)
+            state = opt.state.pop(old_p, None)
+            if state:
+                for key in ("exp_avg", "exp_avg_sq"):
+                    buf = torch.zeros(shape, dtype=old_p.dtype, device=old_p.device)
+                    ops.compact_rows(state[key], keep8, positions, n_keep_old, out=buf, out_offset=0)
+                    state[key] = buf
+                opt.state[new_p] = state
+            opt.param_groups[0]["params"] = [new_p]
+            trainer.params[name] = new_p
+        trainer.slab.rebuild(trainer.params)

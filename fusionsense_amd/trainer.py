@@ -1,0 +1,129 @@
+"""A minimal training loop around the hot path, for measurement and for multi-GPU data
+parallelism.  It mirrors the iteration order of nerfstudio's Trainer
+(SURVEY.md A.3): zero_grad -> get_outputs -> losses -> backward -> [grad all-reduce] ->
+Adam step -> after_train statistics -> refinement_after every ``refine_every`` steps, with the
+8 Adam groups of /root/reference/dn_splatter/dn_config.py:36-75.
+
+Multi-GPU: one process per GPU, every rank holds a full replica of the Gaussians and renders
+a different training view (views r, r+W, r+2W, ...).  Gradients of all parameter groups live in
+ONE contiguous fp32 slab, so the exchange step is a single RCCL all-reduce over xGMI
+(236 B/Gaussian) plus one 12 B/Gaussian all-reduce of the densification statistics; densify/
+prune then runs redundantly with a shared RNG seed so N stays identical on every rank.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional
+
+import torch
+import torch.distributed as dist
+from torch import Tensor
+
+from .scenes import Camera
+
+PARAM_ORDER = ["means", "scales", "quats", "features_dc", "features_rest", "opacities"]
+
+
+@dataclass
+class OptimConfig:
+    """dn_config.py:36-75 (the 'normals' and 'camera_opt' groups are inert: SURVEY.md A.2/A.3)."""
+    lr: Dict[str, float] = field(default_factory=lambda: {
+        "means": 1.6e-4, "features_dc": 0.0025, "features_rest": 0.0025 / 20, "opacities": 0.05,
+        "scales": 0.005, "quats": 0.001})
+    eps: float = 1e-15
+    means_lr_final: float = 1.6e-6
+    means_lr_max_steps: int = 30000
+
+
+class GradSlab:
+    """All parameter gradients as views into one flat fp32 buffer (one collective per step)."""
+
+    def __init__(self, params: Dict[str, torch.nn.Parameter]):
+        self.rebuild(params)
+
+    def rebuild(self, params: Dict[str, torch.nn.Parameter]) -> None:
+        total = sum(p.numel() for p in params.values())
+        dev = next(iter(params.values())).device
+        self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        off = 0
+        self.views = {}
+        for name in PARAM_ORDER:
+            p = params[name]
+            v = self.flat[off:off + p.numel()].view_as(p)
+            self.views[name] = v
+            p.grad = v
+            off += p.numel()
+
+    def zero_(self) -> None:
+        self.flat.zero_()
+
+    def all_reduce_mean_(self, group=None) -> None:
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+            self.flat.mul_(1.0 / dist.get_world_size(group))
+
+
+class SplatTrainer:
+    def __init__(self, params: Dict[str, Tensor], device: torch.device, sh_degree: int = 3,
+                 optim: Optional[OptimConfig] = None, fused_adam: bool = True, seed: int = 0,
+                 strategy=None):
+        self.device = device
+        self.sh_degree = sh_degree
+        self.optim_cfg = optim or OptimConfig()
+        self.params: Dict[str, torch.nn.Parameter] = {
+            k: torch.nn.Parameter(params[k].to(device=device, dtype=torch.float32).contiguous())
+            for k in PARAM_ORDER}
+        self.fused_adam = fused_adam and device.type == "cuda"
+        self.optimizers: Dict[str, torch.optim.Adam] = {}
+        for name in PARAM_ORDER:
+            self.optimizers[name] = torch.optim.Adam(
+                [self.params[name]], lr=self.optim_cfg.lr[name], eps=self.optim_cfg.eps,
+                fused=self.fused_adam)
+        self.slab = GradSlab(self.params)
+        self.step = 0
+        self.strategy = strategy  # fusionsense_amd.splatfacto.DensifyStrategy or None
+        self.rng = torch.Generator(device=device)
+        self.rng.manual_seed(seed)
+        self.last_info = None
+
+    # -- schedule: ExponentialDecayScheduler on the means group (dn_config.py:38-41) --------
+    def _means_lr(self, step: int) -> float:
+        c = self.optim_cfg
+        t = min(max(step / c.means_lr_max_steps, 0.0), 1.0)
+        return math.exp(math.log(c.lr["means"]) * (1 - t) + math.log(c.means_lr_final) * t)
+
+    def num_gaussians(self) -> int:
+        return self.params["means"].shape[0]
+
+    def forward(self, camera: Camera, sh_degree_to_use: Optional[int] = None):
+        from .fusion import render_fusionsense
+        deg = self.sh_degree if sh_degree_to_use is None else sh_degree_to_use
+        return render_fusionsense(self.params, camera, sh_degree=deg, device=self.device)
+
+    def loss(self, out, target) -> Tensor:
+        """Config #2 loss: 0.8*L1 + 0.2*(1-SSIM) on rgb, L1 on depth, L1 on normals."""
+        from .losses import rgb_loss
+        l = rgb_loss(out["rgb"], target["rgb"])
+        if "depth" in target:
+            l = l + 0.2 * torch.abs(out["depth"] - target["depth"]).mean()
+        if "normal" in target:
+            l = l + 0.1 * torch.abs(out["normal"] - target["normal"]).mean()
+        return l
+
+    def train_step(self, camera: Camera, target: Dict[str, Tensor], optimizer_step: bool = True):
+        self.slab.zero_()
+        out = self.forward(camera)
+        loss = self.loss(out, target)
+        loss.backward()
+        self.slab.all_reduce_mean_()
+        if optimizer_step:
+            self.optimizers["means"].param_groups[0]["lr"] = self._means_lr(self.step)
+            for opt in self.optimizers.values():
+                opt.step()
+        if self.strategy is not None:
+            self.strategy.after_train(self, out, camera)
+            self.strategy.maybe_refine(self)
+        self.step += 1
+        self.last_info = out["info"]
+        return loss.detach(), out
