@@ -61,3 +61,17 @@ def tv_loss(pred: Tensor) -> Tensor:
     h_diff = pred[:, :-1, :] - pred[:, 1:, :]
     w_diff = pred[:-1, :, :] - pred[1:, :, :]
     return torch.mean(torch.abs(h_diff)) + torch.mean(torch.abs(w_diff))
+
+
+def log_l1(pred: Tensor, gt: Tensor) -> Tensor:
+    """dn_splatter/losses.py:161-174 (LogL1, scalar)."""
+    return torch.log(1 + torch.abs(pred - gt)).mean()
+
+
+def edge_aware_tv(depth: Tensor, rgb: Tensor) -> Tensor:
+    """dn_splatter/losses.py:241-266 (EdgeAwareTV) on [H,W,1] depth and [H,W,3] rgb."""
+    gdx = torch.abs(depth[:, :-1, :] - depth[:, 1:, :])
+    gdy = torch.abs(depth[:-1, :, :] - depth[1:, :, :])
+    gix = torch.mean(torch.abs(rgb[:, :-1, :] - rgb[:, 1:, :]), -1, keepdim=True)
+    giy = torch.mean(torch.abs(rgb[:-1, :, :] - rgb[1:, :, :]), -1, keepdim=True)
+    return (gdx * torch.exp(-gix)).mean() + (gdy * torch.exp(-giy)).mean()

@@ -230,6 +230,89 @@ class DensifyStrategy:
         self.last_report = dict(step=step, n_before=N, n_split=n_split, n_dup=n_dup, n_deleted=deleted,
                                 n_after=trainer.params["means"].shape[0])
 
+    # ---- a-14: FusionSense-specific callbacks (dn_model.py:1156-1302) ----------------------
+    @torch.no_grad()
+    def cull_gaussians(self, trainer, extra_cull_mask: Optional[Tensor] = None) -> Tensor:
+        """SplatfactoModel.cull_gaussians + remove_from_all_optim in one pass.  Returns the
+        deleted mask over the rows that existed before the call."""
+        P = trainer.params
+        culls = cull_mask(self.cfg, trainer.step, P["opacities"].data, P["scales"].data, self.max_2Dsize,
+                          extra_cull_mask)
+        keep = ~culls
+        self._rebuild(trainer, keep, int(keep.sum().item()), {}, torch.zeros(0, dtype=torch.bool), 0)
+        if self.add_mask is not None:
+            self.add_mask = self.add_mask[keep]
+        for name in ("xys_grad_norm", "vis_counts", "max_2Dsize"):
+            t = getattr(self, name)
+            if t is not None:
+                setattr(self, name, t[keep])
+        return culls
+
+    @torch.no_grad()
+    def append_gaussians(self, trainer, rows: Dict[str, Tensor]) -> None:
+        """Append rows with zero Adam moments (add_in_all_optim, dn_model.py:1150-1152)."""
+        n_old = trainer.params["means"].shape[0]
+        n_new = rows["means"].shape[0]
+        dev = trainer.params["means"].device
+        keep = torch.ones(n_old, dtype=torch.bool, device=dev)
+        rows = {k: v.to(dev) for k, v in rows.items()}
+        self._rebuild(trainer, keep, n_old, rows, torch.ones(n_new, dtype=torch.bool, device=dev), n_new)
+
+    @torch.no_grad()
+    def add_touch_patch(self, trainer, touch_patches, gel_scale_factor: float, colors_fn=None) -> int:
+        """dn_model.py:1156-1247 at step == add_touch_at: cull Gaussians inside the patches'
+        oriented boxes, then append the touch points as fixed anchors (``add_mask``).  Colours
+        of the new points come from the nearest existing Gaussian (knn_sk, k=1, dn_model.py:1181-1182)."""
+        from .touch import make_touch_gaussians, touch_aabb_mask
+        P = trainer.params
+        means = P["means"].data
+        aabb = touch_aabb_mask(means, touch_patches)
+        pts, nrm, rgb = [], [], []
+        from .scenes import sh_to_rgb
+        base_rgb = sh_to_rgb(P["features_dc"].data) if self.cfg.sh_degree > 0 else torch.sigmoid(P["features_dc"].data)
+        for patch in touch_patches:
+            x = patch["points_xyz"].to(means.device)
+            if x.shape[0] == 0:
+                continue
+            nn_idx = torch.cdist(x, means).argmin(dim=-1)  # 1-NN on the device (reference: sklearn on CPU)
+            pts.append(x)
+            nrm.append(patch["normals"].to(means.device))
+            rgb.append(base_rgb[nn_idx])
+        self.max_2Dsize = self.max_2Dsize  # statistics survive the cull, then are reset below
+        self.cull_gaussians(trainer, aabb)
+        if not pts:
+            return 0
+        pts, nrm, rgb = torch.cat(pts), torch.cat(nrm), torch.cat(rgb)
+        rows = make_touch_gaussians(pts, nrm, rgb, gel_scale_factor, self.cfg.sh_degree)
+        n_before = trainer.params["means"].shape[0]
+        self.append_gaussians(trainer, rows)
+        added = pts.shape[0]
+        self.add_mask = torch.cat([torch.zeros(n_before, dtype=torch.bool, device=means.device),
+                                   torch.ones(added, dtype=torch.bool, device=means.device)])
+        self.xys_grad_norm = self.vis_counts = self.max_2Dsize = None
+        return added
+
+    @torch.no_grad()
+    def hull_pruning(self, trainer, visual_hull: Tensor, scale_factor: float) -> Optional[Tensor]:
+        """dn_model.py:1249-1276."""
+        from .touch import hull_prune_mask
+        if trainer.step <= self.cfg.warmup_length:
+            return None
+        mask = hull_prune_mask(trainer.params["means"].data, visual_hull.to(trainer.device), scale_factor,
+                               self.add_mask)
+        self.max_2Dsize = None
+        return self.cull_gaussians(trainer, mask)
+
+    @torch.no_grad()
+    def touch_pruning(self, trainer, touch_patches) -> Optional[Tensor]:
+        """dn_model.py:1279-1302."""
+        from .touch import touch_aabb_mask
+        if trainer.step <= self.cfg.warmup_length or self.add_mask is None:
+            return None
+        mask = touch_aabb_mask(trainer.params["means"].data, touch_patches)
+        mask[self.add_mask] = False
+        return self.cull_gaussians(trainer, mask)
+
     def _rebuild(self, trainer, keep_old: Tensor, n_keep_old: int, new_rows: Dict[str, Tensor],
                  keep_new: Tensor, n_keep_new: int) -> None:
         """New parameter tensors + Adam moments: kept old rows (order preserved, HIP compaction)
@@ -245,7 +328,7 @@ class DensifyStrategy:
             new_data = torch.empty(shape, dtype=old_p.dtype, device=old_p.device)
             ops.compact_rows(old_p.data, keep8, positions, n_keep_old, out=new_data, out_offset=0)
             if n_keep_new > 0:
-                new_data[n_keep_old:] = new_rows[name][keep_new]
+                new_data[n_keep_old:] = new_rows[name][keep_new.to(new_rows[name].device)]
             new_p = torch.nn.Parameter(new_data)
             state = opt.state.pop(old_p, None)
             if state:

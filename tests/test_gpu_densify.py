@@ -1,0 +1,158 @@
+"""GPU parity for the densify/prune rows: statistics kernel, row
+compaction, split sampler and the full refinement_after against the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+from fusionsense_amd import scenes
+from fusionsense_amd.splatfacto import DensifyStrategy, SplatfactoConfig, densify_masks
+from fusionsense_amd.trainer import PARAM_ORDER, SplatTrainer
+from oracle import splatfacto_ref
+
+pytestmark = pytest.mark.gpu
+
+
+def test_densify_stats_kernel(dev):
+    from fusionsense_amd import ops
+    g = torch.Generator().manual_seed(0)
+    n = 5000
+    radii = (torch.rand(n, generator=g) * 40 - 10).clamp(min=0).to(torch.int32)
+    absgrad = torch.rand(1, n, 2, generator=g)
+    state = {}
+    for it in range(3):
+        splatfacto_ref.after_train(state, radii, absgrad[0] * (it + 1), 720, 1280, it, 10000)
+    xg = torch.zeros(n, device=dev)
+    vc = torch.ones(n, device=dev)
+    m2 = torch.zeros(n, device=dev)
+    for it in range(3):
+        ops.densify_stats_(radii.to(dev), (absgrad[0] * (it + 1)).to(dev), 1280, xg, vc, m2)
+    assert torch.allclose(xg.cpu(), state["xys_grad_norm"], rtol=1e-6, atol=1e-7)
+    assert torch.equal(vc.cpu(), state["vis_counts"])
+    assert torch.allclose(m2.cpu(), state["max_2Dsize"], rtol=1e-6)
+
+
+@pytest.mark.parametrize("n,row", [(0, 3), (1, 3), (2049, 1), (10007, 45), (4096, 4)])
+def test_compact_rows_bit_exact(dev, n, row):
+    from fusionsense_amd import ops
+    g = torch.Generator().manual_seed(n)
+    src = torch.randn(n, row, generator=g)
+    keep = torch.rand(n, generator=g) > 0.4
+    if n == 0:
+        return
+    keep8 = keep.to(torch.uint8).to(dev)
+    pos = ops.mask_positions(keep8)
+    out = ops.compact_rows(src.to(dev), keep8, pos, int(keep.sum()))
+    assert torch.equal(out.cpu(), src[keep])
+
+
+def test_split_samples_kernel(dev):
+    from fusionsense_amd import ops
+    from oracle.gsplat_ref import quat_to_rotmat
+    g = torch.Generator().manual_seed(1)
+    n, S, samps = 300, 40, 2
+    means, quats, ls = torch.randn(n, 3, generator=g), torch.randn(n, 4, generator=g), torch.randn(n, 3, generator=g) - 3
+    ids = torch.randperm(n, generator=g)[:S].sort().values
+    z = torch.randn(samps * S, 3, generator=g)
+    nm, nls = ops.split_samples(ids.to(dev), samps, means.to(dev), quats.to(dev), ls.to(dev), z.to(dev))
+    q = quats[ids] / quats[ids].norm(dim=-1, keepdim=True)
+    ref_m = torch.bmm(quat_to_rotmat(q.repeat(samps, 1)), (torch.exp(ls[ids].repeat(samps, 1)) * z)[..., None]).squeeze(-1) \
+        + means[ids].repeat(samps, 1)
+    ref_s = torch.log(torch.exp(ls[ids]) / 1.6).repeat(samps, 1)
+    assert torch.allclose(nm.cpu(), ref_m, atol=1e-5)
+    assert torch.allclose(nls.cpu(), ref_s, atol=1e-6)
+
+
+def _trainer_with_state(dev, n, seed, step):
+    params, _ = scenes.cube_scene(n, seed=seed)
+    g = torch.Generator().manual_seed(seed)
+    params["scales"] = torch.log(0.002 + 0.03 * torch.rand(n, 3, generator=g))
+    params["opacities"] = 2 * torch.randn(n, 1, generator=g)
+    st = DensifyStrategy(SplatfactoConfig(), num_train_data=9)
+    tr = SplatTrainer(params, dev, strategy=st, seed=77)
+    # give Adam non-trivial moments
+    for k in PARAM_ORDER:
+        tr.params[k].grad.copy_(torch.randn(tr.params[k].shape, generator=g).to(dev))
+    for opt in tr.optimizers.values():
+        opt.step()
+    tr.step = step
+    st.xys_grad_norm = (torch.rand(n, generator=g) * 0.01).to(dev)
+    st.vis_counts = (1 + torch.randint(0, 5, (n,), generator=g).float()).to(dev)
+    st.max_2Dsize = (torch.rand(n, generator=g) * 0.2).to(dev)
+    st.last_size = (720, 1280)
+    return tr, st
+
+
+@pytest.mark.parametrize("step", [700, 3100, 3500, 10000])
+def test_refinement_after_matches_oracle(dev, step):
+    cfg = SplatfactoConfig()
+    n = 3000
+    tr, st = _trainer_with_state(dev, n, 3, step)
+    params_cpu = {k: v.detach().cpu().clone() for k, v in tr.params.items()}
+    adam_cpu = {k: {m: tr.optimizers[k].state[tr.params[k]][m].cpu().clone() for m in ("exp_avg", "exp_avg_sq")}
+                for k in PARAM_ORDER}
+    state_cpu = dict(xys_grad_norm=st.xys_grad_norm.cpu().clone(), vis_counts=st.vis_counts.cpu().clone(),
+                     max_2Dsize=st.max_2Dsize.cpu().clone())
+    splits, _ = densify_masks(cfg, step, state_cpu["xys_grad_norm"], state_cpu["vis_counts"],
+                              state_cpu["max_2Dsize"], params_cpu["scales"], (720, 1280), None)
+    g2 = torch.Generator(device=dev)
+    g2.manual_seed(77)
+    z = torch.randn((cfg.n_split_samples * int(splits.sum()), 3), device=dev, generator=g2).cpu()
+    ref_p, ref_a, rep = splatfacto_ref.refinement_after(params_cpu, adam_cpu, state_cpu, cfg, step, 9, (720, 1280), z)
+
+    st.refinement_after(tr, step)
+    assert tr.params["means"].shape[0] == ref_p["means"].shape[0], (st.last_report, rep)
+    for k in PARAM_ORDER:
+        assert torch.allclose(tr.params[k].detach().cpu(), ref_p[k], atol=1e-5), k
+        s = tr.optimizers[k].state[tr.params[k]]
+        assert torch.equal(s["exp_avg"].cpu(), ref_a[k]["exp_avg"]), k
+        assert torch.equal(s["exp_avg_sq"].cpu(), ref_a[k]["exp_avg_sq"]), k
+        assert tr.params[k].grad.data_ptr() == tr.slab.views[k].data_ptr()
+    assert st.xys_grad_norm is None and st.max_2Dsize is None
+    if step in (700, 3500):
+        assert rep["n_split"] > 0 and rep["n_dup"] > 0 and rep["n_deleted"] > 0
+    # the model still trains after surgery
+    cam = scenes.cube_scene(10)[1]
+    out = tr.forward(cam)
+    out["rgb"].mean().backward()
+    for opt in tr.optimizers.values():
+        opt.step()
+
+
+def test_touch_and_hull_callbacks(dev):
+    from fusionsense_amd import touch
+    n = 2000
+    tr, st = _trainer_with_state(dev, n, 5, 1000)
+    means = tr.params["means"].detach().clone()
+    g = torch.Generator().manual_seed(0)
+    ax = torch.linalg.qr(torch.randn(3, 3, generator=g))[0]
+    ext = torch.tensor([0.2, 0.2, 0.1])
+    c = torch.tensor([0.5, 0.0, 0.0])
+    box = torch.stack([c + (ax * ((torch.tensor([(i >> 0) & 1, (i >> 1) & 1, (i >> 2) & 1]).float() * 2 - 1) * ext)[None]).sum(-1)
+                       for i in range(8)])
+    pts = c + 0.01 * torch.randn(50, 3, generator=g)
+    nrm = torch.nn.functional.normalize(torch.randn(50, 3, generator=g), dim=-1)
+    patches = [dict(points_xyz=pts, normals=nrm, bbox=box), dict(points_xyz=torch.zeros(0, 3), normals=torch.zeros(0, 3), bbox=box)]
+    inside = touch.points_in_non_aabb(means.cpu(), box)
+    low_alpha = (torch.sigmoid(tr.params["opacities"].detach().cpu()) < 0.1).squeeze(-1)
+    expected_after_cull = n - int((inside | low_alpha).sum())
+    added = st.add_touch_patch(tr, patches, gel_scale_factor=6.34e-4)
+    assert added == 50
+    assert tr.params["means"].shape[0] == expected_after_cull + 50
+    assert int(st.add_mask.sum()) == 50 and st.add_mask[-50:].all()
+    assert torch.allclose(tr.params["means"][-50:].detach().cpu(), pts, atol=1e-6)
+    assert (tr.params["opacities"][-50:] == 1).all()
+    # anchors survive touch pruning; everything else inside the box is gone
+    tr.params["means"].data[:5] = c.to(dev)  # move 5 ordinary Gaussians into the box
+    tr.step = 1100
+    deleted = st.touch_pruning(tr, patches)
+    assert deleted is not None and int(deleted[:5].sum()) == 5
+    assert int(st.add_mask.sum()) == 50
+    # hull pruning: points in the (0.005, 0.02] shell around the hull are culled
+    hull = torch.zeros(1, 3)
+    m = tr.params["means"]
+    m.data[:3] = torch.tensor([[0.01, 0, 0], [0.001, 0, 0], [0.05, 0, 0]], device=dev)
+    tr.params["opacities"].data[:3] = 5.0
+    n_before = m.shape[0]
+    d = st.hull_pruning(tr, hull, scale_factor=1.0)
+    assert bool(d[0]) and not bool(d[1]) and not bool(d[2])
+    assert tr.params["means"].shape[0] == n_before - int(d.sum())
