@@ -123,7 +123,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
-    from fusionsense_amd import ops, scenes
+    from fusionsense_amd import frame_cache, ops, scenes
     from fusionsense_amd.splatfacto import DensifyStrategy, SplatfactoConfig
     from fusionsense_amd.trainer import SplatTrainer
 
@@ -211,12 +211,13 @@ def main():
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         iters_per_s = world * args.steps / elapsed
-        # algorithmic bytes.  The normal plane re-bins with the legacy rule
-        # (reference-faithful variant: +244 B/isect) in this round.
+        # algorithmic bytes.  The normal plane reuses the RGB+ED pass's sorted
+        # lists when both bbox rules bin the frame identically (+80 B/isect), else re-bins (+244).
         key_bits = 32 + ops.tile_bits((W // 16 + (W % 16 > 0)) * (H // 16 + (H % 16 > 0)))
         sort_b = 2 * 12 * ((key_bits + 7) // 8)
         b_isect = 12 + sort_b + 8 + 44 + 44
-        b_isect_normal = 12 + sort_b + 8 + 40 + 40
+        reused = frame_cache.hits > 0 and frame_cache.misses == 0
+        b_isect_normal = (40 + 40) if reused else (12 + sort_b + 8 + 40 + 40)
         b_iter = N * 352 + n_vis * 444 + M * (b_isect + b_isect_normal) + P * 92
         # dominant kernel: raster_bwd of the RGB+ED pass (D=4, absgrad)
         dom = "raster_bwd_d4"
@@ -247,7 +248,7 @@ def main():
                                    "1 view/rank/step",
                        "n_gaussians": N, "width": W, "height": H, "views": len(cams),
                        "n_isects": M, "n_visible": n_vis, "isects_per_gaussian": round(M / max(N, 1), 3),
-                       "parallelism": f"dp{world}"},
+                       "normal_pass_list_reuse": bool(reused), "parallelism": f"dp{world}"},
             "rendered_mpix_per_s": round(world * P / t_fwd / 1e6, 2),
             "fwd_ms": round(t_fwd * 1e3, 3),
             "iters_per_s_excl_optimizer": round(world / t_noopt, 3),

@@ -27,7 +27,7 @@ SIGNATURES = {
     "fsgs_sh_fwd": (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p]),
     "fsgs_sh_bwd": (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p]),
     "fsgs_scan_scratch_bytes": (_sz, [_i64]),
-    "fsgs_isect_count": (_i, [_i, _i, _p, _p, _i, _i, _i, _i, _p, _p, _p, _sz, C.POINTER(_i64), _p]),
+    "fsgs_isect_count": (_i, [_i, _i, _p, _p, _i, _i, _i, _i, _p, _p, _p, _sz, C.POINTER(_i64), C.POINTER(_i64), _p]),
     "fsgs_isect_emit": (_i, [_i, _i, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p]),
     "fsgs_sort_scratch_bytes": (_sz, [_i64]),
     "fsgs_sort_pairs": (_i, [_i64, _p, _p, _p, _p, _i, _p, _sz, C.POINTER(_i), _p]),
@@ -40,6 +40,8 @@ SIGNATURES = {
     "fsgs_mask_scan": (_i, [_i64, _p, _p, _p, _sz, _p]),
     "fsgs_compact_rows": (_i, [_i64, _i, _p, _p, _p, _p, _p]),
     "fsgs_split_samples": (_i, [_i64, _i, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "fsgs_ssim_l1_fwd": (_i, [_i, _i, _p, _p, _p, _p, _p, _p, _p]),
+    "fsgs_ssim_l1_bwd": (_i, [_i, _i, _p, _p, _p, _p, _p, _p, _f, _f, _p, _p]),
 }
 
 _lib: Optional[C.CDLL] = None

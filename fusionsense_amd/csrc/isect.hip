@@ -35,9 +35,12 @@ __device__ __forceinline__ TileRect tile_rect(float mx, float my, int radius, in
     return r;
 }
 
+// Also counts (into *rule_diff, when given) the Gaussians whose rectangle differs under the
+// OTHER bbox rule: zero means the legacy normal pass may reuse this frame's sorted lists.
 __global__ void __launch_bounds__(256)
 isect_count_kernel(int64_t total, const float *__restrict__ means2d, const int32_t *__restrict__ radii,
-                   int tile_size, int tw, int th, int legacy, int32_t *__restrict__ tiles_per_gauss) {
+                   int tile_size, int tw, int th, int legacy, int32_t *__restrict__ tiles_per_gauss,
+                   unsigned long long *__restrict__ rule_diff) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
     const int r = radii[idx];
@@ -46,6 +49,10 @@ isect_count_kernel(int64_t total, const float *__restrict__ means2d, const int32
         const float2 m = reinterpret_cast<const float2 *>(means2d)[idx];
         const TileRect t = tile_rect(m.x, m.y, r, tile_size, tw, th, legacy);
         cnt = (t.x1 - t.x0) * (t.y1 - t.y0);
+        if (rule_diff) {
+            const TileRect o = tile_rect(m.x, m.y, r, tile_size, tw, th, !legacy);
+            if (o.x0 != t.x0 || o.y0 != t.y0 || o.x1 != t.x1 || o.y1 != t.y1) atomicAdd(rule_diff, 1ull);
+        }
     }
     tiles_per_gauss[idx] = cnt;
 }
@@ -138,25 +145,36 @@ inline int tile_bits_for(int n_tiles) {
 using namespace fsgs;
 
 extern "C" size_t fsgs_scan_scratch_bytes(int64_t n) {
-    return (size_t)(scan_num_blocks(n) + 1) * sizeof(int64_t);
+    return (size_t)(scan_num_blocks(n) + 2) * sizeof(int64_t);  // + one spare word (rule_diff counter)
 }
 
 extern "C" int fsgs_isect_count(int C, int N, const float *means2d, const int32_t *radii,
                                 int tile_size, int tile_width, int tile_height, int legacy,
                                 int32_t *tiles_per_gauss, int64_t *cum_tiles, void *scratch,
-                                size_t scratch_bytes, int64_t *n_isects_host, fsgs_stream_t stream) {
+                                size_t scratch_bytes, int64_t *n_isects_host,
+                                int64_t *n_rule_diff_host, fsgs_stream_t stream) {
     if (C < 0 || N < 0 || tile_size < 1 || !n_isects_host) return FSGS_EINVAL;
     const int64_t total = (int64_t)C * N;
     *n_isects_host = 0;
+    if (n_rule_diff_host) *n_rule_diff_host = 0;
     if (total == 0) return FSGS_OK;
     if (!means2d || !radii || !tiles_per_gauss || !cum_tiles) return FSGS_EINVAL;
+    if (scratch_bytes < fsgs_scan_scratch_bytes(total) || !scratch) return FSGS_ESCRATCH;
     hipStream_t s = as_stream(stream);
+    unsigned long long *diff_dev = nullptr;
+    hipError_t e = hipSuccess;
+    if (n_rule_diff_host) {
+        diff_dev = reinterpret_cast<unsigned long long *>(scratch) + (scan_num_blocks(total) + 1);
+        e = hipMemsetAsync(diff_dev, 0, sizeof(unsigned long long), s);
+        if (e != hipSuccess) { g_last_hip_error = (int)e; return FSGS_ELAUNCH; }
+    }
     hipLaunchKernelGGL(isect_count_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, s, total, means2d,
-                       radii, tile_size, tile_width, tile_height, legacy, tiles_per_gauss);
+                       radii, tile_size, tile_width, tile_height, legacy, tiles_per_gauss, diff_dev);
     int rc = device_scan<int32_t, true>(total, tiles_per_gauss, cum_tiles, scratch, scratch_bytes, s);
     if (rc != FSGS_OK) return rc;
-    hipError_t e = hipMemcpyAsync(n_isects_host, cum_tiles + (total - 1), sizeof(int64_t),
-                                  hipMemcpyDeviceToHost, s);
+    e = hipMemcpyAsync(n_isects_host, cum_tiles + (total - 1), sizeof(int64_t), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess && n_rule_diff_host)
+        e = hipMemcpyAsync(n_rule_diff_host, diff_dev, sizeof(int64_t), hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (e != hipSuccess) {
         g_last_hip_error = (int)e;

@@ -1,0 +1,185 @@
+// N2: the photometric loss on the render as two kernels instead of ~40 torch
+// launches (5 depthwise convolutions forward, their transposes backward).
+//   loss = (1-l) * mean|pred-gt| + l * (1 - SSIM11(pred, gt))
+// as FusionSense computes it (/root/reference/dn_splatter/dn_model.py:683 -> splatfacto main loss
+// with the torchmetrics StructuralSimilarityIndexMeasure(kernel_size=11) swapped in at :244):
+// Gaussian 11x11 window, sigma 1.5, the SSIM map averaged over the (H-10)x(W-10) interior.
+//
+// One workgroup per 16x16 output tile and channel: the 26x26 halo of pred and gt is staged in
+// LDS once, blurred separably (rows, then columns) for the five moments, and the SSIM value plus
+// its three partial derivatives (w.r.t. mu1, sigma1^2, sigma12) are formed per pixel.  The
+// backward blurs those three maps with the same window:
+//   dSSIM/dpred = G*(dm_dmu1) + 2 pred G*(dm_dsigma1sq) + gt G*(dm_dsigma12).
+// Layout: images are [H,W,3] (channel-last, as the renderer writes them).
+#include "common.h"
+
+namespace fsgs {
+
+constexpr int kLT = 16;           // output tile edge
+constexpr int kLR = 5;            // window radius
+constexpr int kLH = kLT + 2 * kLR;  // 26
+
+__constant__ float kGauss11[11] = {0.0010283801f, 0.0075987581f, 0.0360007721f, 0.1093606895f,
+                                   0.2130055377f, 0.2660117249f, 0.2130055377f, 0.1093606895f,
+                                   0.0360007721f, 0.0075987581f, 0.0010283801f};
+
+__device__ __forceinline__ float block_sum_256(float v, float *lds4) {
+    v = wave_sum_to_last_row(v);
+    const int tr = threadIdx.y * blockDim.x + threadIdx.x;
+    if ((tr & 63) == 63) lds4[tr >> 6] = v;
+    __syncthreads();
+    return lds4[0] + lds4[1] + lds4[2] + lds4[3];
+}
+
+// sums[0] += sum |pred-gt| (this channel tile), sums[1] += sum of interior SSIM values
+__global__ void __launch_bounds__(256)
+ssim_l1_fwd_kernel(int H, int W, const float *__restrict__ pred, const float *__restrict__ gt,
+                   float *__restrict__ dm_dmu1, float *__restrict__ dm_dsigma1, float *__restrict__ dm_dsigma12,
+                   float *__restrict__ sums) {
+    __shared__ float sp[kLH][kLH + 1], sg[kLH][kLH + 1];
+    __shared__ float hb[5][kLH][kLT + 1];
+    __shared__ float red[4];
+    const int ch = blockIdx.z;
+    const int x0 = blockIdx.x * kLT, y0 = blockIdx.y * kLT;
+    const int tr = threadIdx.y * kLT + threadIdx.x;
+    for (int i = tr; i < kLH * kLH; i += 256) {
+        const int ly = i / kLH, lx = i - ly * kLH;
+        const int y = y0 + ly - kLR, x = x0 + lx - kLR;
+        float p = 0.f, g = 0.f;
+        if (y >= 0 && y < H && x >= 0 && x < W) {
+            p = pred[((int64_t)y * W + x) * 3 + ch];
+            g = gt[((int64_t)y * W + x) * 3 + ch];
+        }
+        sp[ly][lx] = p;
+        sg[ly][lx] = g;
+    }
+    __syncthreads();
+    // horizontal pass: 26 rows x 16 columns
+    for (int i = tr; i < kLH * kLT; i += 256) {
+        const int ly = i / kLT, lx = i - ly * kLT;
+        float m1 = 0.f, m2 = 0.f, s11 = 0.f, s22 = 0.f, s12 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 11; ++k) {
+            const float w = kGauss11[k];
+            const float p = sp[ly][lx + k], g = sg[ly][lx + k];
+            m1 += w * p; m2 += w * g; s11 += w * p * p; s22 += w * g * g; s12 += w * p * g;
+        }
+        hb[0][ly][lx] = m1; hb[1][ly][lx] = m2; hb[2][ly][lx] = s11; hb[3][ly][lx] = s22; hb[4][ly][lx] = s12;
+    }
+    __syncthreads();
+    const int lx = threadIdx.x, ly = threadIdx.y;
+    const int x = x0 + lx, y = y0 + ly;
+    float mu1 = 0.f, mu2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 11; ++k) {
+        const float w = kGauss11[k];
+        mu1 += w * hb[0][ly + k][lx]; mu2 += w * hb[1][ly + k][lx];
+        e11 += w * hb[2][ly + k][lx]; e22 += w * hb[3][ly + k][lx]; e12 += w * hb[4][ly + k][lx];
+    }
+    const bool in_img = (x < W) && (y < H);
+    const bool interior = in_img && x >= kLR && x < W - kLR && y >= kLR && y < H - kLR;
+    float l1 = 0.f, ssim = 0.f, d_mu1 = 0.f, d_s1 = 0.f, d_s12 = 0.f;
+    if (in_img) l1 = fabsf(sp[ly + kLR][lx + kLR] - sg[ly + kLR][lx + kLR]);
+    if (interior) {
+        const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+        const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
+        const float s1 = e11 - mu1_sq, s2 = e22 - mu2_sq, s12 = e12 - mu12;
+        const float A = mu1_sq + mu2_sq + C1, B = s1 + s2 + C2;
+        const float C = 2.f * mu12 + C1, D = 2.f * s12 + C2;
+        ssim = (C * D) / (A * B);
+        d_mu1 = (mu2 * 2.f * D) / (A * B) - (mu2 * 2.f * C) / (A * B) - (mu1 * 2.f * C * D) / (A * A * B) +
+                (mu1 * 2.f * C * D) / (A * B * B);
+        d_s1 = (-C * D) / (A * B * B);
+        d_s12 = (2.f * C) / (A * B);
+    }
+    if (in_img) {
+        const int64_t o = ((int64_t)y * W + x) * 3 + ch;
+        dm_dmu1[o] = d_mu1;
+        dm_dsigma1[o] = d_s1;
+        dm_dsigma12[o] = d_s12;
+    }
+    const float t_l1 = block_sum_256(l1, red);
+    __syncthreads();
+    const float t_ss = block_sum_256(ssim, red);
+    if (tr == 255) {
+        atomicAdd(&sums[0], t_l1);
+        atomicAdd(&sums[1], t_ss);
+    }
+}
+
+// v_pred = g_l1 * sign(pred-gt) + g_ssim * (G*dm_dmu1 + 2 pred G*dm_dsigma1 + gt G*dm_dsigma12)
+__global__ void __launch_bounds__(256)
+ssim_l1_bwd_kernel(int H, int W, const float *__restrict__ pred, const float *__restrict__ gt,
+                   const float *__restrict__ dm_dmu1, const float *__restrict__ dm_dsigma1,
+                   const float *__restrict__ dm_dsigma12, const float *__restrict__ v_loss, float g_l1,
+                   float g_ssim, float *__restrict__ v_pred) {
+    __shared__ float sm[3][kLH][kLH + 1];
+    __shared__ float hb[3][kLH][kLT + 1];
+    const int ch = blockIdx.z;
+    const int x0 = blockIdx.x * kLT, y0 = blockIdx.y * kLT;
+    const int tr = threadIdx.y * kLT + threadIdx.x;
+    for (int i = tr; i < kLH * kLH; i += 256) {
+        const int ly = i / kLH, lx = i - ly * kLH;
+        const int y = y0 + ly - kLR, x = x0 + lx - kLR;
+        float a = 0.f, b = 0.f, c = 0.f;
+        if (y >= 0 && y < H && x >= 0 && x < W) {
+            const int64_t o = ((int64_t)y * W + x) * 3 + ch;
+            a = dm_dmu1[o]; b = dm_dsigma1[o]; c = dm_dsigma12[o];
+        }
+        sm[0][ly][lx] = a; sm[1][ly][lx] = b; sm[2][ly][lx] = c;
+    }
+    __syncthreads();
+    for (int i = tr; i < kLH * kLT; i += 256) {
+        const int ly = i / kLT, lx = i - ly * kLT;
+        float a = 0.f, b = 0.f, c = 0.f;
+#pragma unroll
+        for (int k = 0; k < 11; ++k) {
+            const float w = kGauss11[k];
+            a += w * sm[0][ly][lx + k]; b += w * sm[1][ly][lx + k]; c += w * sm[2][ly][lx + k];
+        }
+        hb[0][ly][lx] = a; hb[1][ly][lx] = b; hb[2][ly][lx] = c;
+    }
+    __syncthreads();
+    const int lx = threadIdx.x, ly = threadIdx.y;
+    const int x = x0 + lx, y = y0 + ly;
+    if (x >= W || y >= H) return;
+    float a = 0.f, b = 0.f, c = 0.f;
+#pragma unroll
+    for (int k = 0; k < 11; ++k) {
+        const float w = kGauss11[k];
+        a += w * hb[0][ly + k][lx]; b += w * hb[1][ly + k][lx]; c += w * hb[2][ly + k][lx];
+    }
+    const int64_t o = ((int64_t)y * W + x) * 3 + ch;
+    const float p = pred[o], g = gt[o];
+    const float d = p - g;
+    const float sgn = (d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f);
+    const float up = v_loss[0];
+    v_pred[o] = up * (g_l1 * sgn + g_ssim * (a + 2.f * p * b + g * c));
+}
+
+}  // namespace fsgs
+
+using namespace fsgs;
+
+extern "C" int fsgs_ssim_l1_fwd(int H, int W, const float *pred, const float *gt, float *dm_dmu1,
+                                float *dm_dsigma1, float *dm_dsigma12, float *sums, fsgs_stream_t stream) {
+    if (H < 11 || W < 11) return FSGS_EINVAL;
+    if (!pred || !gt || !dm_dmu1 || !dm_dsigma1 || !dm_dsigma12 || !sums) return FSGS_EINVAL;
+    hipStream_t s = as_stream(stream);
+    hipError_t e = hipMemsetAsync(sums, 0, 2 * sizeof(float), s);
+    if (e != hipSuccess) { g_last_hip_error = (int)e; return FSGS_ELAUNCH; }
+    hipLaunchKernelGGL(ssim_l1_fwd_kernel, dim3(ceil_div(W, kLT), ceil_div(H, kLT), 3), dim3(kLT, kLT), 0, s,
+                       H, W, pred, gt, dm_dmu1, dm_dsigma1, dm_dsigma12, sums);
+    return check_launch();
+}
+
+extern "C" int fsgs_ssim_l1_bwd(int H, int W, const float *pred, const float *gt, const float *dm_dmu1,
+                                const float *dm_dsigma1, const float *dm_dsigma12, const float *v_loss,
+                                float g_l1, float g_ssim, float *v_pred, fsgs_stream_t stream) {
+    if (H < 11 || W < 11) return FSGS_EINVAL;
+    if (!pred || !gt || !dm_dmu1 || !dm_dsigma1 || !dm_dsigma12 || !v_loss || !v_pred) return FSGS_EINVAL;
+    hipLaunchKernelGGL(ssim_l1_bwd_kernel, dim3(ceil_div(W, kLT), ceil_div(H, kLT), 3), dim3(kLT, kLT), 0,
+                       as_stream(stream), H, W, pred, gt, dm_dmu1, dm_dsigma1, dm_dsigma12, v_loss, g_l1,
+                       g_ssim, v_pred);
+    return check_launch();
+}

@@ -13,7 +13,7 @@ import torch
 import torch.nn.functional as F
 from torch import Tensor
 
-from . import ops
+from . import frame_cache, ops
 from ._lib import require_gpu_tensor
 
 
@@ -94,11 +94,15 @@ def rasterize_gaussians(
 
     tw = (img_width + block_width - 1) // block_width
     th = (img_height + block_width - 1) // block_width
-    with torch.no_grad():
-        _, isect_ids, flatten_ids = ops.isect_tiles(
-            xys.detach()[None], radii[None], depths.detach()[None], block_width, tw, th, legacy=True,
-            sort=True)
-        offsets = ops.isect_offset_encode(isect_ids, 1, tw, th)
+    cached = frame_cache.lookup(xys, depths, radii, img_width, img_height, block_width)
+    if cached is not None:
+        offsets, flatten_ids = cached  # same frame, both bbox rules agree: lists are identical
+    else:
+        with torch.no_grad():
+            _, isect_ids, flatten_ids = ops.isect_tiles(
+                xys.detach()[None], radii[None], depths.detach()[None], block_width, tw, th, legacy=True,
+                sort=True)
+            offsets = ops.isect_offset_encode(isect_ids, 1, tw, th)
 
     pad = 0
     cols = colors

@@ -102,9 +102,10 @@ def project_fwd(means, quats, scales, viewmats, Ks, width, height, eps2d, near_p
 
 
 def isect_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tile_size: int, tile_width: int,
-                tile_height: int, legacy: bool = False, sort: bool = True):
+                tile_height: int, legacy: bool = False, sort: bool = True, return_rule_diff: bool = False):
     """Returns tiles_per_gauss [C,N] i32, isect_ids [M] i64, flatten_ids [M] i32 (sorted if
-    ``sort``).  One host sync (n_isects), like the reference."""
+    ``sort``).  One host sync (n_isects), like the reference.  With ``return_rule_diff`` a fourth
+    value says how many Gaussians would be binned differently by the other bbox rule."""
     lib = load()
     dev = means2d.device
     Cn, N = radii.shape
@@ -114,9 +115,11 @@ def isect_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tile_size: int, 
     sbytes = lib.fsgs_scan_scratch_bytes(max(total, 1))
     scratch = torch.empty(sbytes, dtype=torch.uint8, device=dev)
     m_host = C.c_int64(0)
+    diff_host = C.c_int64(0)
     _run(lib.fsgs_isect_count, (Cn, N, ptr(means2d), ptr(radii), tile_size, tile_width, tile_height,
                                int(legacy), ptr(tpg), ptr(cum), ptr(scratch), sbytes, C.byref(m_host),
-                               stream_ptr(dev)), "fsgs_isect_count")
+                               C.byref(diff_host) if return_rule_diff else None, stream_ptr(dev)),
+         "fsgs_isect_count")
     M = int(m_host.value)
     ids = torch.empty(M, dtype=torch.int64, device=dev)
     flat = torch.empty(M, dtype=torch.int32, device=dev)
@@ -129,6 +132,8 @@ def isect_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tile_size: int, 
             cam_bits = tile_bits(Cn) if Cn > 1 else 0
             end_bit = 32 + tile_bits(n_tiles) + cam_bits
             ids, flat = sort_pairs(ids, flat, end_bit)
+    if return_rule_diff:
+        return tpg, ids, flat, int(diff_host.value)
     return tpg, ids, flat
 
 
@@ -392,3 +397,41 @@ def split_samples(ids: Tensor, n_samples: int, means: Tensor, quats: Tensor, log
                                  ptr(_c(log_scales)), ptr(_c(randn)), ptr(new_means), ptr(new_ls),
                                  stream_ptr(dev)), "fsgs_split_samples")
     return new_means, new_ls
+
+
+class _SsimL1Loss(torch.autograd.Function):
+    """(1-l)*L1 + l*(1-SSIM11) on [H,W,3] images as one forward and one backward kernel (row N2)."""
+
+    @staticmethod
+    def forward(ctx, pred, gt, ssim_lambda):
+        pred, gt = _c(pred), _c(gt)
+        lib = load()
+        dev = pred.device
+        H, W = pred.shape[0], pred.shape[1]
+        maps = torch.empty(3, H, W, 3, dtype=torch.float32, device=dev)
+        sums = torch.empty(2, dtype=torch.float32, device=dev)
+        _run(lib.fsgs_ssim_l1_fwd, (H, W, ptr(pred), ptr(gt), maps[0].data_ptr(), maps[1].data_ptr(),
+                                    maps[2].data_ptr(), ptr(sums), stream_ptr(dev)), "fsgs_ssim_l1_fwd")
+        g_l1 = (1.0 - ssim_lambda) / (3.0 * H * W)
+        g_ssim = -ssim_lambda / (3.0 * (H - 10) * (W - 10))
+        ctx.save_for_backward(pred, gt, maps)
+        ctx.g = (g_l1, g_ssim)
+        return sums[0] * g_l1 + sums[1] * g_ssim + ssim_lambda
+
+    @staticmethod
+    def backward(ctx, v_loss):
+        pred, gt, maps = ctx.saved_tensors
+        g_l1, g_ssim = ctx.g
+        lib = load()
+        dev = pred.device
+        H, W = pred.shape[0], pred.shape[1]
+        v_pred = torch.empty_like(pred)
+        v_loss = v_loss.reshape(1).contiguous().to(torch.float32)
+        _run(lib.fsgs_ssim_l1_bwd, (H, W, ptr(pred), ptr(gt), maps[0].data_ptr(), maps[1].data_ptr(),
+                                    maps[2].data_ptr(), ptr(v_loss), g_l1, g_ssim, ptr(v_pred),
+                                    stream_ptr(dev)), "fsgs_ssim_l1_bwd")
+        return v_pred, None, None
+
+
+def ssim_l1_loss(pred: Tensor, gt: Tensor, ssim_lambda: float = 0.2) -> Tensor:
+    return _SsimL1Loss.apply(pred, gt, float(ssim_lambda))

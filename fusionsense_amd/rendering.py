@@ -12,7 +12,7 @@ from typing import Dict, Optional, Tuple
 import torch
 from torch import Tensor
 
-from . import ops
+from . import frame_cache, ops
 from ._lib import require_gpu_tensor
 
 _RENDER_MODES = ("RGB", "D", "ED", "RGB+D", "RGB+ED")
@@ -109,9 +109,14 @@ def rasterization(
     tile_width = math.ceil(width / tile_size)
     tile_height = math.ceil(height / tile_size)
     with torch.no_grad():
-        tiles_per_gauss, isect_ids, flatten_ids = ops.isect_tiles(
-            means2d, radii, depths, tile_size, tile_width, tile_height, legacy=False, sort=True)
+        tiles_per_gauss, isect_ids, flatten_ids, rule_diff = ops.isect_tiles(
+            means2d, radii, depths, tile_size, tile_width, tile_height, legacy=False, sort=True,
+            return_rule_diff=True)
         isect_offsets = ops.isect_offset_encode(isect_ids, C, tile_width, tile_height)
+    # let the legacy normal pass (dn_model.py:644-653) reuse these lists when it is handed this
+    # frame's own xys / depths / radii and both bbox rules bin the frame identically
+    frame_cache.remember(means2d, depths, radii, width, height, tile_size, isect_offsets, flatten_ids,
+                         lists_valid_for_legacy=(rule_diff == 0 and C == 1))
 
     want_depth = render_mode in ("RGB+D", "RGB+ED")
     only_depth = render_mode in ("D", "ED")

@@ -79,12 +79,15 @@ int fsgs_sh_bwd(int C, int N, int K, int degree, const float *means, const float
  * Pass 1: tiles_per_gauss[C,N] i32 and its inclusive prefix sum cum_tiles[C,N] i64.
  * `legacy` != 0 selects the cuda_legacy bbox rule ((int)(c-r), (int)(c+r+1)) used by
  * gsplat.rasterize_gaussians.  Synchronises `stream` and stores the total in *n_isects_host.
+ * n_rule_diff_host (nullable) receives the number of Gaussians whose tile rectangle differs
+ * under the OTHER bbox rule; 0 means both rules bin this frame identically, so the legacy
+ * normal pass may reuse the sorted lists of the RGB+ED pass.
  * scratch: fsgs_scan_scratch_bytes(C*N) bytes. */
 size_t fsgs_scan_scratch_bytes(int64_t n);
 int fsgs_isect_count(int C, int N, const float *means2d, const int32_t *radii, int tile_size,
                      int tile_width, int tile_height, int legacy, int32_t *tiles_per_gauss,
                      int64_t *cum_tiles, void *scratch, size_t scratch_bytes,
-                     int64_t *n_isects_host, fsgs_stream_t stream);
+                     int64_t *n_isects_host, int64_t *n_rule_diff_host, fsgs_stream_t stream);
 
 /* Pass 2: emit isect_ids[M] i64 = cam<<(32+tile_bits) | tile<<32 | bits(depth) and
  * flatten_ids[M] i32 = c*N+n, in (Gaussian, row-major tile) order. */
@@ -158,6 +161,17 @@ int fsgs_compact_rows(int64_t n_rows, int row_floats, const uint8_t *keep,
 int fsgs_split_samples(int64_t S, int n_samples, const int64_t *ids, const float *means,
                        const float *quats, const float *log_scales, const float *randn,
                        float *new_means, float *new_log_scales, fsgs_stream_t stream);
+
+/* ---- N2: photometric loss on the render, fused (dn_splatter/dn_model.py:683 main loss with the
+ * torchmetrics SSIM(kernel_size=11) of :244).  pred, gt: [H,W,3] channel-last.
+ * fwd: sums[0] = sum |pred-gt|, sums[1] = sum of the SSIM map over the (H-10)x(W-10) interior
+ * (both zeroed by the call), and the three partial-derivative maps [H,W,3] the backward needs.
+ * bwd: v_pred = v_loss[0] * (g_l1 * sign(pred-gt) + g_ssim * dSSIMsum/dpred). */
+int fsgs_ssim_l1_fwd(int H, int W, const float *pred, const float *gt, float *dm_dmu1,
+                     float *dm_dsigma1, float *dm_dsigma12, float *sums, fsgs_stream_t stream);
+int fsgs_ssim_l1_bwd(int H, int W, const float *pred, const float *gt, const float *dm_dmu1,
+                     const float *dm_dsigma1, const float *dm_dsigma12, const float *v_loss,
+                     float g_l1, float g_ssim, float *v_pred, fsgs_stream_t stream);
 
 #ifdef __cplusplus
 }
