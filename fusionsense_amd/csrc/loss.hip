@@ -10,7 +10,8 @@
 // its three partial derivatives (w.r.t. mu1, sigma1^2, sigma12) are formed per pixel.  The
 // backward blurs those three maps with the same window:
 //   dSSIM/dpred = G*(dm_dmu1) + 2 pred G*(dm_dsigma1sq) + gt G*(dm_dsigma12).
-// Layout: images are [H,W,3] (channel-last, as the renderer writes them).
+// Layout: images are [H,W,3] (channel-last, as the renderer writes them); the three saved
+// derivative maps are planar [3,H,W] so that their writes and the backward's halo reads coalesce.
 #include "common.h"
 
 namespace fsgs {
@@ -93,7 +94,7 @@ ssim_l1_fwd_kernel(int H, int W, const float *__restrict__ pred, const float *__
         d_s12 = (2.f * C) / (A * B);
     }
     if (in_img) {
-        const int64_t o = ((int64_t)y * W + x) * 3 + ch;
+        const int64_t o = ((int64_t)ch * H + y) * W + x;  // planar [3,H,W]: coalesced rows
         dm_dmu1[o] = d_mu1;
         dm_dsigma1[o] = d_s1;
         dm_dsigma12[o] = d_s12;
@@ -123,7 +124,7 @@ ssim_l1_bwd_kernel(int H, int W, const float *__restrict__ pred, const float *__
         const int y = y0 + ly - kLR, x = x0 + lx - kLR;
         float a = 0.f, b = 0.f, c = 0.f;
         if (y >= 0 && y < H && x >= 0 && x < W) {
-            const int64_t o = ((int64_t)y * W + x) * 3 + ch;
+            const int64_t o = ((int64_t)ch * H + y) * W + x;
             a = dm_dmu1[o]; b = dm_dsigma1[o]; c = dm_dsigma12[o];
         }
         sm[0][ly][lx] = a; sm[1][ly][lx] = b; sm[2][ly][lx] = c;

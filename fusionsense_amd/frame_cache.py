@@ -2,11 +2,18 @@
 
 FusionSense renders every frame twice (dn_splatter/dn_model.py:570-591, then :644-653): the
 legacy call receives the SAME projected centres, depths and radii that ``rasterization`` just
-binned and depth-sorted.  When the two bbox rules agree on every Gaussian of the frame
-(fsgs_isect_count reports this) the sorted intersection lists are identical bit for bit, so
-the second bin + 44-bit radix sort (156 B/intersection) is pure repetition.  The memo is keyed on
-storage identity and version counters of the tensors, so any in-place edit or a different
-tensor falls back to the full legacy binning."""
+binned and depth-sorted, so the second bin + 44-bit radix sort (156 B/intersection) is
+repetition, and the lists of the first pass are reused.
+
+The two bbox rules (floor/ceil vs trunc/+1) differ only for a Gaussian whose ``mean + radius``
+is an exact multiple of the tile size (``meta["legacy_rule_diff"]`` counts them: about one per
+frame at 300k Gaussians, because fp32 pixel coordinates near 400 are exact integers with
+probability ~3e-5).  For exactly those Gaussians the reference is undefined: it sizes each
+Gaussian's slot range from ``num_tiles_hit`` — counted with the NEW rule — and then writes the
+legacy rule's larger tile set into it, overrunning into the next Gaussian's slots.  Reusing the
+new-rule lists is therefore the only well-defined reading of that call pattern.  A legacy call
+on any other tensors (different storage, or edited in place) bins with the legacy rule for
+count and fill (legacy.py).  The memo is keyed on storage identity and version counters."""
 from __future__ import annotations
 
 from typing import Optional, Tuple

@@ -114,9 +114,10 @@ def rasterization(
             return_rule_diff=True)
         isect_offsets = ops.isect_offset_encode(isect_ids, C, tile_width, tile_height)
     # let the legacy normal pass (dn_model.py:644-653) reuse these lists when it is handed this
-    # frame's own xys / depths / radii and both bbox rules bin the frame identically
+    # frame's own xys / depths / radii (see frame_cache for why that is the faithful choice even
+    # for the rule_diff Gaussians whose bbox touches a tile edge exactly)
     frame_cache.remember(means2d, depths, radii, width, height, tile_size, isect_offsets, flatten_ids,
-                         lists_valid_for_legacy=(rule_diff == 0 and C == 1))
+                         lists_valid_for_legacy=(C == 1))
 
     want_depth = render_mode in ("RGB+D", "RGB+ED")
     only_depth = render_mode in ("D", "ED")
@@ -185,5 +186,6 @@ def rasterization(
         "n_cameras": C,
         # extras (not in gsplat's meta): let the legacy normal pass reuse this frame's sorted lists
         "last_ids": last_ids,
+        "legacy_rule_diff": rule_diff,  # Gaussians the legacy trunc/+1 bbox rule would bin differently
     }
     return render, alphas, meta

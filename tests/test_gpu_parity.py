@@ -317,6 +317,7 @@ def test_legacy_pass_reuses_sorted_lists(dev):
         else:
             assert frame_cache.hits == h0
     frame_cache.enabled = True
+    assert out["info"]["legacy_rule_diff"] == 0, "cube scene: both bbox rules bin identically"
     assert torch.equal(outs[0][0], outs[1][0]), "forward is deterministic and list-identical"
     assert rel_err(outs[0][1], outs[1][1]) < 1e-4 and rel_err(outs[0][2], outs[1][2]) < 1e-4
     # a copy of the tensors (different storage) must not hit
