@@ -32,7 +32,7 @@ __device__ __forceinline__ float block_sum_256(float v, float *lds4) {
     return lds4[0] + lds4[1] + lds4[2] + lds4[3];
 }
 
-// sums[0] += sum |pred-gt| (this channel tile), sums[1] += sum of interior SSIM values
+// partials[2*blk] = sum |pred-gt| of this (tile, channel), partials[2*blk+1] = sum of its interior SSIM values
 __global__ void __launch_bounds__(256)
 ssim_l1_fwd_kernel(int H, int W, const float *__restrict__ pred, const float *__restrict__ gt,
                    float *__restrict__ dm_dmu1, float *__restrict__ dm_dsigma1, float *__restrict__ dm_dsigma12,
@@ -102,9 +102,10 @@ ssim_l1_fwd_kernel(int H, int W, const float *__restrict__ pred, const float *__
     const float t_l1 = block_sum_256(l1, red);
     __syncthreads();
     const float t_ss = block_sum_256(ssim, red);
-    if (tr == 255) {
-        atomicAdd(&sums[0], t_l1);
-        atomicAdd(&sums[1], t_ss);
+    if (tr == 255) {  // per-workgroup partials: same-address float atomics from 7500 blocks serialise
+        const int blk = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        sums[2 * blk + 0] = t_l1;
+        sums[2 * blk + 1] = t_ss;
     }
 }
 
@@ -162,13 +163,15 @@ ssim_l1_bwd_kernel(int H, int W, const float *__restrict__ pred, const float *__
 
 using namespace fsgs;
 
+extern "C" int64_t fsgs_ssim_l1_num_partials(int H, int W) {
+    return (int64_t)ceil_div(W, kLT) * ceil_div(H, kLT) * 3;
+}
+
 extern "C" int fsgs_ssim_l1_fwd(int H, int W, const float *pred, const float *gt, float *dm_dmu1,
                                 float *dm_dsigma1, float *dm_dsigma12, float *sums, fsgs_stream_t stream) {
     if (H < 11 || W < 11) return FSGS_EINVAL;
     if (!pred || !gt || !dm_dmu1 || !dm_dsigma1 || !dm_dsigma12 || !sums) return FSGS_EINVAL;
     hipStream_t s = as_stream(stream);
-    hipError_t e = hipMemsetAsync(sums, 0, 2 * sizeof(float), s);
-    if (e != hipSuccess) { g_last_hip_error = (int)e; return FSGS_ELAUNCH; }
     hipLaunchKernelGGL(ssim_l1_fwd_kernel, dim3(ceil_div(W, kLT), ceil_div(H, kLT), 3), dim3(kLT, kLT), 0, s,
                        H, W, pred, gt, dm_dmu1, dm_dsigma1, dm_dsigma12, sums);
     return check_launch();

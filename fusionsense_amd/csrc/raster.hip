@@ -4,10 +4,10 @@
 // `rasterize_forward/backward` behind gsplat.rasterize_gaussians (dn_model.py:644-653, 3 channels).
 //
 // Mapping to CDNA4: one workgroup per 16x16 tile = 256 threads = 4 wave64, wave w covering the
-// pixel strip of rows 4w..4w+3.  The tile's depth-sorted list is walked in batches of 256:
+// 8x8 pixel quadrant w.  The tile's depth-sorted list is walked in batches of 256:
 //   * STAGE  each thread gathers one list entry's (xy, opacity, conic, colour) record from HBM
 //            into registers *before* the current batch is composited (latency hides under
-//            compute) and decides, exactly, which of the four wave strips the Gaussian can reach:
+//            compute) and decides, exactly, which of the four wave quadrants the Gaussian can reach:
 //            it minimises the conic's quadratic form over each strip's rectangle of pixel centres
 //            in closed form and compares with ln(255*opacity) (the alpha >= 1/255 level set) —
 //            the square 3-sigma bbox the lists were built from is far looser than that ellipse.
@@ -70,7 +70,34 @@ __device__ __forceinline__ float min_sigma_rect(float mx, float my, float a, flo
     return best;
 }
 
-// Which wave strips can this Gaussian reach?  Conservative: a set bit never hides a contribution.
+// Thread -> pixel mapping inside a tile.  For the 16x16 tile each wave owns an 8x8 quadrant
+// (compact footprints touch fewer waves than with 16x4 strips); other tile sizes use row strips.
+struct PixRect { int x0, x1, y0, y1; };  // inclusive pixel offsets inside the tile
+
+__device__ __forceinline__ void thread_pixel(int tr, int tile_size, int &tx, int &ty) {
+    if (tile_size == 16) {
+        const int w = tr >> 6, l = tr & 63;
+        tx = ((w & 1) << 3) + (l & 7);
+        ty = ((w >> 1) << 3) + (l >> 3);
+    } else {
+        ty = tr / tile_size;
+        tx = tr - ty * tile_size;
+    }
+}
+
+__device__ __forceinline__ bool wave_rect(int w, int tile_size, PixRect &r) {
+    if (tile_size == 16) {
+        r.x0 = (w & 1) << 3; r.x1 = r.x0 + 7;
+        r.y0 = (w >> 1) << 3; r.y1 = r.y0 + 7;
+        return true;
+    }
+    r.x0 = 0; r.x1 = tile_size - 1;
+    r.y0 = (64 * w) / tile_size;
+    r.y1 = min((64 * w + 63) / tile_size, tile_size - 1);
+    return r.y0 < tile_size;
+}
+
+// Which wave regions can this Gaussian reach?  Conservative: a set bit never hides a contribution.
 __device__ __forceinline__ unsigned strip_mask(float mx, float my, float opac, float a, float b, float c,
                                                float tile_x0, float tile_y0, int tile_size, int n_waves) {
     const unsigned all = (1u << n_waves) - 1u;
@@ -78,14 +105,13 @@ __device__ __forceinline__ unsigned strip_mask(float mx, float my, float opac, f
     if (!(a > 0.f && c > 0.f && a * c - b * b > 0.f)) return all;  // not positive definite: no bound
     const float tau = __logf(255.f * opac) + kCullMargin;
     const float inv_a = 1.f / a, inv_c = 1.f / c;
-    const float x_lo = tile_x0 + 0.5f, x_hi = tile_x0 + (float)tile_size - 0.5f;
     unsigned m = 0u;
     for (int w = 0; w < n_waves; ++w) {
-        const int r0 = (64 * w) / tile_size;
-        const int r1 = min((64 * w + 63) / tile_size, tile_size - 1);
-        if (r0 >= tile_size) break;
-        const float y_lo = tile_y0 + (float)r0 + 0.5f, y_hi = tile_y0 + (float)r1 + 0.5f;
-        const float smin = min_sigma_rect(mx, my, a, b, c, inv_a, inv_c, x_lo, x_hi, y_lo, y_hi);
+        PixRect r;
+        if (!wave_rect(w, tile_size, r)) break;
+        const float smin = min_sigma_rect(mx, my, a, b, c, inv_a, inv_c, tile_x0 + (float)r.x0 + 0.5f,
+                                          tile_x0 + (float)r.x1 + 0.5f, tile_y0 + (float)r.y0 + 0.5f,
+                                          tile_y0 + (float)r.y1 + 0.5f);
         if (smin <= tau) m |= (1u << w);
     }
     return m;
@@ -157,7 +183,8 @@ raster_fwd_kernel(int N, int64_t n_isects, const float *__restrict__ means2d,
     // DPP reductions always see 64 live lanes; surplus threads only help with staging.
     const int tr = threadIdx.x;
     const int block_size = blockDim.x;
-    const int ty = tr / tile_size, tx = tr - ty * tile_size;
+    int tx, ty;
+    thread_pixel(tr, tile_size, tx, ty);
     const int i = blockIdx.y * tile_size + ty;
     const int j = blockIdx.x * tile_size + tx;
     const int w = tr >> 6, lane = tr & 63;
@@ -275,7 +302,8 @@ raster_bwd_kernel(int N, int64_t n_isects, const float *__restrict__ means2d,
     const int n_tiles_total = gridDim.z * th * tw;
     const int tr = threadIdx.x;
     const int block_size = blockDim.x;
-    const int ty = tr / tile_size, tx = tr - ty * tile_size;
+    int tx, ty;
+    thread_pixel(tr, tile_size, tx, ty);
     const int i = blockIdx.y * tile_size + ty;
     const int j = blockIdx.x * tile_size + tx;
     const int w = tr >> 6, lane = tr & 63;

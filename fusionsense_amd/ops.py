@@ -409,14 +409,15 @@ class _SsimL1Loss(torch.autograd.Function):
         dev = pred.device
         H, W = pred.shape[0], pred.shape[1]
         maps = torch.empty(3, H, W, 3, dtype=torch.float32, device=dev)
-        sums = torch.empty(2, dtype=torch.float32, device=dev)
+        sums = torch.empty(lib.fsgs_ssim_l1_num_partials(H, W), 2, dtype=torch.float32, device=dev)
         _run(lib.fsgs_ssim_l1_fwd, (H, W, ptr(pred), ptr(gt), maps[0].data_ptr(), maps[1].data_ptr(),
                                     maps[2].data_ptr(), ptr(sums), stream_ptr(dev)), "fsgs_ssim_l1_fwd")
         g_l1 = (1.0 - ssim_lambda) / (3.0 * H * W)
         g_ssim = -ssim_lambda / (3.0 * (H - 10) * (W - 10))
         ctx.save_for_backward(pred, gt, maps)
         ctx.g = (g_l1, g_ssim)
-        return sums[0] * g_l1 + sums[1] * g_ssim + ssim_lambda
+        tot = sums.sum(dim=0)
+        return tot[0] * g_l1 + tot[1] * g_ssim + ssim_lambda
 
     @staticmethod
     def backward(ctx, v_loss):

@@ -164,9 +164,11 @@ int fsgs_split_samples(int64_t S, int n_samples, const int64_t *ids, const float
 
 /* ---- N2: photometric loss on the render, fused (dn_splatter/dn_model.py:683 main loss with the
  * torchmetrics SSIM(kernel_size=11) of :244).  pred, gt: [H,W,3] channel-last.
- * fwd: sums[0] = sum |pred-gt|, sums[1] = sum of the SSIM map over the (H-10)x(W-10) interior
- * (both zeroed by the call), and the three partial-derivative maps (planar [3,H,W]) the backward needs.
+ * fwd: sums[P,2] per-workgroup partials (P = fsgs_ssim_l1_num_partials(H,W)): column 0 sums to
+ * sum |pred-gt|, column 1 to the sum of the SSIM map over the (H-10)x(W-10) interior; plus the
+ * three partial-derivative maps (planar [3,H,W]) the backward needs.
  * bwd: v_pred = v_loss[0] * (g_l1 * sign(pred-gt) + g_ssim * dSSIMsum/dpred). */
+int64_t fsgs_ssim_l1_num_partials(int H, int W);
 int fsgs_ssim_l1_fwd(int H, int W, const float *pred, const float *gt, float *dm_dmu1,
                      float *dm_dsigma1, float *dm_dsigma12, float *sums, fsgs_stream_t stream);
 int fsgs_ssim_l1_bwd(int H, int W, const float *pred, const float *gt, const float *dm_dmu1,
