@@ -1,0 +1,258 @@
+// "Live lists": an exact, massively parallel culling + compaction pass between binning and
+// compositing (internal acceleration structure; the gsplat-visible lists in `meta` are untouched).
+//
+// Why: the sorted tile lists come from each Gaussian's square 3-sigma bounding box.  Measured on
+// BASELINE config #2, only ~23 % of the (tile, Gaussian) entries can reach ANY pixel of their
+// tile at alpha >= 1/255, and a surviving entry reaches 1.8 of the tile's four 8x8 quadrants on
+// average.  Walking the raw lists inside the compositing kernel made it latency-bound: a serial
+// per-tile chain of (index load -> dependent 44-byte gather -> barrier) per batch, mostly for
+// entries that were then skipped.  On MI355X bandwidth is plentiful and latency is not, so:
+//   1. live_mask    one thread per list entry (M-way parallel): closed-form minimum of the
+//                   conic's quadratic form over each quadrant's rectangle of pixel centres vs
+//                   ln(255*opacity) (+ safety margin) -> 4-bit quadrant mask.
+//   2. scan4        exclusive prefix sums of the four mask bits over the whole list (one pass over
+//                   M bytes, four counters at once).
+//   3. live_compact one thread per entry: for every quadrant it reaches, write a self-contained
+//                   48-byte record (xy, opacity, conic, list index, Gaussian id, colour) at its
+//                   rank in that quadrant's stream.  Depth order is preserved (stable).
+// The compositing kernels then run ONE wave per 8x8 quadrant over a contiguous, coalesced record
+// stream: no dependent gathers, no barriers, no wasted entries.  A quadrant's list is
+// stream q, range [pos4[offsets[tile]].q, pos4[offsets[tile+1]].q).
+// Exactness: an entry is dropped for a quadrant only if no pixel centre in it can satisfy
+// alpha >= 1/255, so images, last_ids and gradients equal those of the plain walk.
+#include "common.h"
+#include "scan.h"
+
+namespace fsgs {
+
+constexpr float kCullMargin = 0.02f;  // slack on ln(255*opacity) against fp32 rounding of sigma / exp
+
+// min over the rectangle [x_lo,x_hi] x [y_lo,y_hi] of q(p) = 0.5*(a dx^2 + c dy^2) + b dx dy,
+// (dx,dy) = (mx,my) - p, for a positive-definite conic.  Convex => attained at the centre
+// (if inside) or on one of the four edges, each a clamped 1-D parabola.
+__device__ __forceinline__ float min_sigma_rect(float mx, float my, float a, float b, float c, float inv_a,
+                                                float inv_c, float x_lo, float x_hi, float y_lo, float y_hi) {
+    const float dx_lo = mx - x_hi, dx_hi = mx - x_lo, dy_lo = my - y_hi, dy_hi = my - y_lo;
+    if (dx_lo <= 0.f && dx_hi >= 0.f && dy_lo <= 0.f && dy_hi >= 0.f) return 0.f;
+    float best = 3.0e38f;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const float dxe = e ? dx_hi : dx_lo;
+        const float dy = fminf(fmaxf(-b * dxe * inv_c, dy_lo), dy_hi);
+        best = fminf(best, 0.5f * (a * dxe * dxe + c * dy * dy) + b * dxe * dy);
+        const float dye = e ? dy_hi : dy_lo;
+        const float dx = fminf(fmaxf(-b * dye * inv_a, dx_lo), dx_hi);
+        best = fminf(best, 0.5f * (a * dx * dx + c * dye * dye) + b * dx * dye);
+    }
+    return best;
+}
+
+// 4-bit mask: bit q = qy*2+qx set if the Gaussian can reach quadrant q of the 16x16 tile at
+// (tile_x0, tile_y0).  Conservative: a set bit never hides a contribution.
+__device__ __forceinline__ unsigned quadrant_mask(float mx, float my, float opac, float a, float b, float c,
+                                                  float tile_x0, float tile_y0) {
+    if (!(opac >= kAlphaMin * 0.999f)) return 0u;                   // alpha <= opac < 1/255 everywhere
+    if (!(a > 0.f && c > 0.f && a * c - b * b > 0.f)) return 0xFu;  // not positive definite: no bound
+    const float tau = __logf(255.f * opac) + kCullMargin;
+    const float inv_a = 1.f / a, inv_c = 1.f / c;
+    unsigned m = 0u;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float x0 = tile_x0 + (float)((q & 1) * 8) + 0.5f, y0 = tile_y0 + (float)((q >> 1) * 8) + 0.5f;
+        if (min_sigma_rect(mx, my, a, b, c, inv_a, inv_c, x0, x0 + 7.f, y0, y0 + 7.f) <= tau) m |= 1u << q;
+    }
+    return m;
+}
+
+__global__ void __launch_bounds__(256)
+live_mask_kernel(int64_t M, const int64_t *__restrict__ isect_ids, const int32_t *__restrict__ flatten_ids,
+                 const float *__restrict__ means2d, const float *__restrict__ conics,
+                 const float *__restrict__ opacities, int tw, int tile_bits, uint8_t *__restrict__ mask8) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > M) return;
+    if (i == M) { mask8[i] = 0; return; }  // sentinel so that pos4[M] holds the totals
+    const int tile = (int)((isect_ids[i] >> 32) & ((1ll << tile_bits) - 1));
+    const int ty = tile / tw, tx = tile - ty * tw;
+    const int32_t g = flatten_ids[i];
+    const float2 m = reinterpret_cast<const float2 *>(means2d)[g];
+    const float a = conics[(int64_t)g * 3 + 0], b = conics[(int64_t)g * 3 + 1], c = conics[(int64_t)g * 3 + 2];
+    mask8[i] = (uint8_t)quadrant_mask(m.x, m.y, opacities[g], a, b, c, (float)(tx * 16), (float)(ty * 16));
+}
+
+// ---- four prefix sums at once over the mask bits ------------------------------------------
+constexpr int kS4Block = 256, kS4Items = 8, kS4Tile = kS4Block * kS4Items;
+
+__device__ __forceinline__ int4 bits4(unsigned m) {
+    return make_int4(m & 1u, (m >> 1) & 1u, (m >> 2) & 1u, (m >> 3) & 1u);
+}
+__device__ __forceinline__ int4 add4(int4 a, int4 b) { return make_int4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+
+__device__ __forceinline__ int4 wave_incl_scan4(int4 v) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int ox = __shfl_up(v.x, d, 64), oy = __shfl_up(v.y, d, 64);
+        const int oz = __shfl_up(v.z, d, 64), ow = __shfl_up(v.w, d, 64);
+        if (lane >= d) v = add4(v, make_int4(ox, oy, oz, ow));
+    }
+    return v;
+}
+
+// exclusive scan of one int4 per thread across the block; *total = block sum
+__device__ __forceinline__ int4 block_excl_scan4(int4 v, int4 *total, int4 *lds4) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int4 inc = wave_incl_scan4(v);
+    if (lane == 63) lds4[w] = inc;
+    __syncthreads();
+    int4 base = make_int4(0, 0, 0, 0), tot = make_int4(0, 0, 0, 0);
+#pragma unroll
+    for (int k = 0; k < kS4Block / 64; ++k) {
+        if (k < w) base = add4(base, lds4[k]);
+        tot = add4(tot, lds4[k]);
+    }
+    *total = tot;
+    __syncthreads();
+    return make_int4(base.x + inc.x - v.x, base.y + inc.y - v.y, base.z + inc.z - v.z, base.w + inc.w - v.w);
+}
+
+__global__ void __launch_bounds__(kS4Block)
+scan4_reduce_kernel(int64_t n, const uint8_t *__restrict__ mask8, int4 *__restrict__ block_sums) {
+    __shared__ int4 lds4[4];
+    const int64_t base = (int64_t)blockIdx.x * kS4Tile;
+    int4 s = make_int4(0, 0, 0, 0);
+#pragma unroll
+    for (int k = 0; k < kS4Items; ++k) {
+        const int64_t i = base + k * kS4Block + threadIdx.x;
+        if (i < n) s = add4(s, bits4(mask8[i]));
+    }
+    int4 tot;
+    block_excl_scan4(s, &tot, lds4);
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
+}
+
+__global__ void __launch_bounds__(kS4Block)
+scan4_block_sums_kernel(int64_t nb, int4 *__restrict__ block_sums) {
+    __shared__ int4 lds4[4];
+    int4 carry = make_int4(0, 0, 0, 0);
+    for (int64_t base = 0; base < nb; base += kS4Block) {
+        const int64_t i = base + threadIdx.x;
+        const int4 v = (i < nb) ? block_sums[i] : make_int4(0, 0, 0, 0);
+        int4 tot;
+        const int4 ex = block_excl_scan4(v, &tot, lds4);
+        if (i < nb) block_sums[i] = add4(carry, ex);
+        carry = add4(carry, tot);
+    }
+}
+
+__global__ void __launch_bounds__(kS4Block)
+scan4_apply_kernel(int64_t n, const uint8_t *__restrict__ mask8, const int4 *__restrict__ block_sums,
+                   int4 *__restrict__ pos4) {
+    __shared__ int4 lds4[4];
+    const int64_t base = (int64_t)blockIdx.x * kS4Tile + (int64_t)threadIdx.x * kS4Items;
+    unsigned m[kS4Items];
+    int4 s = make_int4(0, 0, 0, 0);
+    if (base + kS4Items <= n) {
+        const uint2 raw = *reinterpret_cast<const uint2 *>(mask8 + base);  // 8 masks, 8-byte aligned
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            m[k] = (raw.x >> (8 * k)) & 0xFFu;
+            m[4 + k] = (raw.y >> (8 * k)) & 0xFFu;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < kS4Items; ++k) m[k] = (base + k < n) ? mask8[base + k] : 0u;
+    }
+#pragma unroll
+    for (int k = 0; k < kS4Items; ++k) s = add4(s, bits4(m[k]));
+    int4 tot;
+    int4 run = add4(block_excl_scan4(s, &tot, lds4), block_sums[blockIdx.x]);
+#pragma unroll
+    for (int k = 0; k < kS4Items; ++k) {
+        if (base + k < n) pos4[base + k] = run;
+        run = add4(run, bits4(m[k]));
+    }
+}
+
+// Records: rec[3*p+0] = {x, y, opacity, conic.a}; rec[3*p+1] = {conic.b, conic.c, bits(list index),
+// bits(Gaussian id)}; rec[3*p+2] = colour (D floats, zero padded).  Stream q starts at record q*cap.
+template <int D>
+__global__ void __launch_bounds__(256)
+live_compact_kernel(int64_t M, int64_t cap, const uint8_t *__restrict__ mask8, const int4 *__restrict__ pos4,
+                    const int32_t *__restrict__ flatten_ids, const float *__restrict__ means2d,
+                    const float *__restrict__ conics, const float *__restrict__ colors,
+                    const float *__restrict__ opacities, float4 *__restrict__ rec) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M) return;
+    const unsigned m = mask8[i];
+    if (!m) return;
+    const int4 p = pos4[i];
+    const int32_t g = flatten_ids[i];
+    const float2 xy = reinterpret_cast<const float2 *>(means2d)[g];
+    const float a = conics[(int64_t)g * 3 + 0], b = conics[(int64_t)g * 3 + 1], c = conics[(int64_t)g * 3 + 2];
+    const float4 r0 = make_float4(xy.x, xy.y, opacities[g], a);
+    const float4 r1 = make_float4(b, c, __int_as_float((int)i), __int_as_float(g));
+    float4 r2 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (D == 4) {
+        r2 = reinterpret_cast<const float4 *>(colors)[g];
+    } else {
+        r2.x = colors[(int64_t)g * D + 0];
+        if (D > 1) r2.y = colors[(int64_t)g * D + 1];
+        if (D > 2) r2.z = colors[(int64_t)g * D + 2];
+    }
+    const int pq[4] = {p.x, p.y, p.z, p.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        if (m & (1u << q)) {
+            float4 *dst = rec + 3 * ((int64_t)q * cap + pq[q]);
+            dst[0] = r0; dst[1] = r1; dst[2] = r2;
+        }
+    }
+}
+
+inline int64_t scan4_blocks(int64_t n) { return (n + kS4Tile - 1) / kS4Tile; }
+
+}  // namespace fsgs
+
+using namespace fsgs;
+
+extern "C" size_t fsgs_live_scratch_bytes(int64_t n_isects) {
+    return (size_t)(scan4_blocks(n_isects + 1) + 1) * sizeof(int4);
+}
+
+extern "C" int fsgs_live_prepare(int D, const float *means2d, const float *conics, const float *colors,
+                                 const float *opacities, int tile_width, int tile_bits,
+                                 const int64_t *isect_ids, const int32_t *flatten_ids, int64_t n_isects,
+                                 uint8_t *mask8, int32_t *pos4, float *records, void *scratch,
+                                 size_t scratch_bytes, fsgs_stream_t stream) {
+    if (n_isects < 0 || (D != 1 && D != 3 && D != 4)) return FSGS_EINVAL;
+    if (!mask8 || !pos4) return FSGS_EINVAL;
+    if (n_isects > 0x7FFFFFF0ll) return FSGS_EINVAL;  // list indices are 32-bit (as in the reference)
+    hipStream_t s = as_stream(stream);
+    const int64_t n = n_isects + 1;
+    if (scratch_bytes < fsgs_live_scratch_bytes(n_isects) || !scratch) return FSGS_ESCRATCH;
+    if (n_isects > 0 && (!means2d || !conics || !colors || !opacities || !isect_ids || !flatten_ids || !records))
+        return FSGS_EINVAL;
+    int4 *block_sums = reinterpret_cast<int4 *>(scratch);
+    hipLaunchKernelGGL(live_mask_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, n_isects, isect_ids,
+                       flatten_ids, means2d, conics, opacities, tile_width, tile_bits, mask8);
+    const int64_t nb = scan4_blocks(n);
+    hipLaunchKernelGGL(scan4_reduce_kernel, dim3((unsigned)nb), dim3(kS4Block), 0, s, n, mask8, block_sums);
+    hipLaunchKernelGGL(scan4_block_sums_kernel, dim3(1), dim3(kS4Block), 0, s, nb, block_sums);
+    hipLaunchKernelGGL(scan4_apply_kernel, dim3((unsigned)nb), dim3(kS4Block), 0, s, n, mask8, block_sums,
+                       reinterpret_cast<int4 *>(pos4));
+    if (n_isects > 0) {
+        const dim3 grid(ceil_div(n_isects, 256));
+        float4 *rec = reinterpret_cast<float4 *>(records);
+        const int4 *p4 = reinterpret_cast<const int4 *>(pos4);
+        if (D == 4)
+            hipLaunchKernelGGL((live_compact_kernel<4>), grid, dim3(256), 0, s, n_isects, n_isects, mask8, p4,
+                               flatten_ids, means2d, conics, colors, opacities, rec);
+        else if (D == 3)
+            hipLaunchKernelGGL((live_compact_kernel<3>), grid, dim3(256), 0, s, n_isects, n_isects, mask8, p4,
+                               flatten_ids, means2d, conics, colors, opacities, rec);
+        else
+            hipLaunchKernelGGL((live_compact_kernel<1>), grid, dim3(256), 0, s, n_isects, n_isects, mask8, p4,
+                               flatten_ids, means2d, conics, colors, opacities, rec);
+    }
+    return check_launch();
+}

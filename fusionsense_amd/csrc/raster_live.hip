@@ -1,0 +1,335 @@
+// E7 / E8 on live lists: front-to-back alpha compositing, forward and VJP, ONE wave64 per 8x8
+// pixel quadrant walking that quadrant's compacted record stream (see live.hip).  Same arithmetic
+// and the same results as the generic tile kernels in raster.hip (replaces
+// gsplat 1.0.0 `rasterize_to_pixels_{fwd,bwd}` for /root/reference/dn_splatter/dn_model.py:570-591
+// and the legacy rasterize_forward/backward for :644-653), for tile_size == 16.
+//
+// Per batch each lane loads ONE 48-byte record of the stream (three coalesced 16-byte loads, the
+// next batch is in flight while the current one is composited), parks it in the wave's LDS slot,
+// and the wave then iterates over the 64 records with broadcast LDS reads.  A workgroup is a
+// single wave: no cross-wave barriers, no tile-level early-exit protocol, ~4 tiles' worth of
+// independent waves per tile for latency hiding.
+// Backward: the 64 per-pixel partials of each gradient component are summed with DPP row ops;
+// the 12 totals are handed to lanes 0..11 through LDS and leave as ONE 12-lane
+// global_atomic_add_f32 into a packed 64-byte per-Gaussian record (one cache line), instead of
+// 12 single-lane atomics to five different arrays; fsgs_raster_unpack_grads splits the records.
+#include "common.h"
+
+namespace fsgs {
+
+template <int D>
+struct QLds {
+    float4 r0[64], r1[64], r2[64];
+    float tot[16];
+};
+
+struct Rec {
+    float4 r0, r1, r2;
+};
+
+__device__ __forceinline__ void load_rec(Rec &r, const float4 *__restrict__ rec, int64_t p, bool ok) {
+    if (ok) {
+        const float4 *src = rec + 3 * p;
+        r.r0 = src[0]; r.r1 = src[1]; r.r2 = src[2];
+    }
+}
+
+template <int D>
+__global__ void __launch_bounds__(64)
+raster_fwd_live_kernel(int64_t cap, const float4 *__restrict__ rec, const int4 *__restrict__ pos4,
+                       const int32_t *__restrict__ tile_offsets, int64_t n_isects,
+                       const float *__restrict__ backgrounds, int W, int H, int tw, int th,
+                       float *__restrict__ render, float *__restrict__ alphas,
+                       int32_t *__restrict__ last_ids) {
+    __shared__ QLds<D> L;
+    const int cam = blockIdx.z;
+    const int tile_x = blockIdx.x >> 1, tile_y = blockIdx.y >> 1;
+    const int q = ((blockIdx.y & 1) << 1) | (blockIdx.x & 1);
+    const int tile_lin = (cam * th + tile_y) * tw + tile_x;
+    const int n_tiles_total = gridDim.z * th * tw;
+    const int lane = threadIdx.x;
+    const int j = blockIdx.x * 8 + (lane & 7), i = blockIdx.y * 8 + (lane >> 3);
+    const float px = (float)j + 0.5f, py = (float)i + 0.5f;
+    const bool inside = (i < H) && (j < W);
+    bool done = !inside;
+
+    const int64_t l0 = tile_offsets[tile_lin];
+    const int64_t l1 = (tile_lin == n_tiles_total - 1) ? n_isects : (int64_t)tile_offsets[tile_lin + 1];
+    const int4 p0 = pos4[l0], p1 = pos4[l1];
+    const int s = (q == 0) ? p0.x : (q == 1) ? p0.y : (q == 2) ? p0.z : p0.w;
+    const int e = (q == 0) ? p1.x : (q == 1) ? p1.y : (q == 2) ? p1.z : p1.w;
+    const float4 *stream = rec + 3 * ((int64_t)q * cap);
+
+    float T = 1.f;
+    int32_t cur_idx = 0;
+    float pix[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) pix[k] = 0.f;
+
+    Rec r;
+    load_rec(r, stream, (int64_t)s + lane, s + lane < e);
+    for (int b = s; b < e; b += 64) {
+        __syncthreads();  // single wave: orders the previous batch's LDS reads before these writes
+        L.r0[lane] = r.r0; L.r1[lane] = r.r1; L.r2[lane] = r.r2;
+        const int n = min(64, e - b);
+        load_rec(r, stream, (int64_t)b + 64 + lane, b + 64 + lane < e);
+        __syncthreads();
+        for (int t = 0; t < n && !done; ++t) {
+            const float4 a0 = L.r0[t], a1 = L.r1[t];
+            const float dx = a0.x - px, dy = a0.y - py;
+            const float sigma = 0.5f * (a0.w * dx * dx + a1.y * dy * dy) + a1.x * dx * dy;
+            const float alpha = fminf(kAlphaMax, a0.z * __expf(-sigma));
+            if (sigma < 0.f || alpha < kAlphaMin) continue;
+            const float next_T = T * (1.f - alpha);
+            if (next_T <= kTMin) {
+                done = true;
+                break;
+            }
+            const float vis = alpha * T;
+            const float4 c = L.r2[t];
+            pix[0] += c.x * vis;
+            if (D > 1) pix[1] += c.y * vis;
+            if (D > 2) pix[2] += c.z * vis;
+            if (D > 3) pix[D - 1] += c.w * vis;
+            cur_idx = __float_as_int(a1.z);
+            T = next_T;
+        }
+        if (__all(done)) break;
+    }
+
+    if (inside) {
+        const int64_t pix_id = ((int64_t)cam * H + i) * W + j;
+        if (D == 4) {
+            float4 o = make_float4(pix[0], pix[1], pix[2], pix[D - 1]);
+            if (backgrounds) {
+                const float *bg = backgrounds + cam * D;
+                o.x += T * bg[0]; o.y += T * bg[1]; o.z += T * bg[2]; o.w += T * bg[D - 1];
+            }
+            reinterpret_cast<float4 *>(render)[pix_id] = o;
+        } else {
+#pragma unroll
+            for (int k = 0; k < D; ++k)
+                render[pix_id * D + k] = pix[k] + (backgrounds ? T * backgrounds[cam * D + k] : 0.f);
+        }
+        alphas[pix_id] = 1.f - T;
+        last_ids[pix_id] = cur_idx;
+    }
+}
+
+__device__ __forceinline__ int wave_max_i32q(int v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = max(v, __shfl_xor(v, d, 64));
+    return v;
+}
+
+// packed gradient record, 16 floats per (camera, Gaussian):
+//   [0..3] v_colors  [4..6] v_conics  [7..8] v_means2d  [9..10] v_means2d_abs  [11] v_opacities
+template <int D, bool ABS>
+__global__ void __launch_bounds__(64)
+raster_bwd_live_kernel(int64_t cap, const float4 *__restrict__ rec, const int4 *__restrict__ pos4,
+                       const int32_t *__restrict__ tile_offsets, int64_t n_isects,
+                       const float *__restrict__ backgrounds, int W, int H, int tw, int th,
+                       const float *__restrict__ alphas, const int32_t *__restrict__ last_ids,
+                       const float *__restrict__ v_render, const float *__restrict__ v_alphas,
+                       float *__restrict__ v_packed) {
+    __shared__ QLds<D> L;
+    const int cam = blockIdx.z;
+    const int tile_x = blockIdx.x >> 1, tile_y = blockIdx.y >> 1;
+    const int q = ((blockIdx.y & 1) << 1) | (blockIdx.x & 1);
+    const int tile_lin = (cam * th + tile_y) * tw + tile_x;
+    const int n_tiles_total = gridDim.z * th * tw;
+    const int lane = threadIdx.x;
+    const int j = blockIdx.x * 8 + (lane & 7), i = blockIdx.y * 8 + (lane >> 3);
+    const float px = (float)j + 0.5f, py = (float)i + 0.5f;
+    const bool inside = (i < H) && (j < W);
+    const int64_t pix_id = ((int64_t)cam * H + min(i, H - 1)) * W + min(j, W - 1);
+
+    const int64_t l0 = tile_offsets[tile_lin];
+    const int64_t l1 = (tile_lin == n_tiles_total - 1) ? n_isects : (int64_t)tile_offsets[tile_lin + 1];
+    const int4 p0 = pos4[l0], p1 = pos4[l1];
+    const int s = (q == 0) ? p0.x : (q == 1) ? p0.y : (q == 2) ? p0.z : p0.w;
+    const int e = (q == 0) ? p1.x : (q == 1) ? p1.y : (q == 2) ? p1.z : p1.w;
+    if (e <= s) return;
+    const float4 *stream = rec + 3 * ((int64_t)q * cap);
+
+    const float T_final = 1.f - alphas[pix_id];
+    float T = T_final;
+    float buffer[D], v_out[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+        buffer[k] = 0.f;
+        v_out[k] = inside ? v_render[pix_id * D + k] : 0.f;
+    }
+    const float v_out_a = inside ? v_alphas[pix_id] : 0.f;
+    float bg_dot = 0.f;
+    if (backgrounds) {
+#pragma unroll
+        for (int k = 0; k < D; ++k) bg_dot += backgrounds[cam * D + k] * v_out[k];
+    }
+    const int bin_final = inside ? last_ids[pix_id] : -1;
+    const int wave_bin_final = wave_max_i32q(bin_final);
+
+    Rec r;
+    load_rec(r, stream, (int64_t)e - 1 - lane, e - 1 - lane >= s);
+    for (int b = e - 1; b >= s; b -= 64) {  // slot t of the batch holds stream position b - t
+        __syncthreads();
+        L.r0[lane] = r.r0; L.r1[lane] = r.r1; L.r2[lane] = r.r2;
+        const int n = min(64, b - s + 1);
+        load_rec(r, stream, (int64_t)b - 64 - lane, b - 64 - lane >= s);
+        __syncthreads();
+        // descending list order: nothing above wave_bin_final was composited by this wave
+        if (__float_as_int(L.r1[n - 1].z) > wave_bin_final) continue;
+        for (int t = 0; t < n; ++t) {
+            const float4 a0 = L.r0[t], a1 = L.r1[t];
+            const int isect = __float_as_int(a1.z);
+            if (isect > wave_bin_final) continue;  // wave-uniform
+            bool valid = inside && (isect <= bin_final);
+            const float dx = a0.x - px, dy = a0.y - py;
+            const float sigma = 0.5f * (a0.w * dx * dx + a1.y * dy * dy) + a1.x * dx * dy;
+            const float vis = __expf(-sigma);
+            const float alpha = fminf(kAlphaMax, a0.z * vis);
+            if (sigma < 0.f || alpha < kAlphaMin) valid = false;
+            if (!__any(valid)) continue;
+
+            float g[12];
+#pragma unroll
+            for (int k = 0; k < 12; ++k) g[k] = 0.f;
+            if (valid) {
+                const float4 c4 = L.r2[t];
+                const float col[4] = {c4.x, c4.y, c4.z, c4.w};
+                const float ra = 1.f / (1.f - alpha);
+                T *= ra;
+                const float fac = alpha * T;
+                float v_alpha = 0.f;
+#pragma unroll
+                for (int k = 0; k < D; ++k) {
+                    g[k] = fac * v_out[k];
+                    v_alpha += (col[k] * T - buffer[k] * ra) * v_out[k];
+                    buffer[k] += col[k] * fac;
+                }
+                v_alpha += T_final * ra * v_out_a;
+                if (backgrounds) v_alpha -= T_final * ra * bg_dot;
+                if (a0.z * vis <= kAlphaMax) {
+                    const float v_sigma = -a0.z * vis * v_alpha;
+                    g[4] = 0.5f * v_sigma * dx * dx;
+                    g[5] = v_sigma * dx * dy;
+                    g[6] = 0.5f * v_sigma * dy * dy;
+                    g[7] = v_sigma * (a0.w * dx + a1.x * dy);
+                    g[8] = v_sigma * (a1.x * dx + a1.y * dy);
+                    if (ABS) {
+                        g[9] = fabsf(g[7]);
+                        g[10] = fabsf(g[8]);
+                    }
+                    g[11] = vis * v_alpha;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 12; ++k) {
+                const bool used = (k < D) || (k >= 4 && k <= 8) || (ABS && (k == 9 || k == 10)) || (k == 11);
+                if (used) g[k] = wave_sum_to_last_row(g[k]);
+            }
+            if (lane == 63) {
+#pragma unroll
+                for (int k = 0; k < 12; ++k) L.tot[k] = g[k];
+            }
+            __syncthreads();
+            if (lane < 12) {
+                const bool used = (lane < D) || (lane >= 4 && lane <= 8) || (ABS && (lane == 9 || lane == 10)) ||
+                                  (lane == 11);
+                if (used) {
+                    const int64_t gid = __float_as_int(a1.w);
+                    unsafeAtomicAdd(&v_packed[gid * 16 + lane], L.tot[lane]);
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+unpack_grads_kernel(int64_t total, int D, const float4 *__restrict__ v_packed, float *__restrict__ v_means2d,
+                    float *__restrict__ v_means2d_abs, float *__restrict__ v_conics,
+                    float *__restrict__ v_colors, float *__restrict__ v_opacities) {
+    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= total) return;
+    const float4 a = v_packed[n * 4 + 0], b = v_packed[n * 4 + 1], c = v_packed[n * 4 + 2];
+    if (D == 4) {
+        reinterpret_cast<float4 *>(v_colors)[n] = a;
+    } else {
+        v_colors[n * D + 0] = a.x;
+        if (D > 1) v_colors[n * D + 1] = a.y;
+        if (D > 2) v_colors[n * D + 2] = a.z;
+    }
+    v_conics[n * 3 + 0] = b.x; v_conics[n * 3 + 1] = b.y; v_conics[n * 3 + 2] = b.z;
+    reinterpret_cast<float2 *>(v_means2d)[n] = make_float2(b.w, c.x);
+    if (v_means2d_abs) reinterpret_cast<float2 *>(v_means2d_abs)[n] = make_float2(c.y, c.z);
+    v_opacities[n] = c.w;
+}
+
+}  // namespace fsgs
+
+using namespace fsgs;
+
+extern "C" int fsgs_raster_fwd_live(int C, int D, const float *records, const int32_t *pos4,
+                                    const int32_t *isect_offsets, int64_t n_isects, const float *backgrounds,
+                                    int width, int height, int tile_width, int tile_height, float *render,
+                                    float *alphas, int32_t *last_ids, fsgs_stream_t stream) {
+    if (C < 0 || width < 0 || height < 0 || n_isects < 0) return FSGS_EINVAL;
+    if (C == 0 || width == 0 || height == 0) return FSGS_OK;
+    if (!pos4 || !isect_offsets || !render || !alphas || !last_ids || (n_isects > 0 && !records))
+        return FSGS_EINVAL;
+    hipStream_t s = as_stream(stream);
+    const dim3 grid(2 * tile_width, 2 * tile_height, C);
+    const float4 *rec = reinterpret_cast<const float4 *>(records);
+    const int4 *p4 = reinterpret_cast<const int4 *>(pos4);
+#define FSGS_FWD_LIVE(DD)                                                                                   \
+    hipLaunchKernelGGL((raster_fwd_live_kernel<DD>), grid, dim3(64), 0, s, n_isects, rec, p4, isect_offsets, \
+                       n_isects, backgrounds, width, height, tile_width, tile_height, render, alphas, last_ids)
+    switch (D) {
+        case 1: FSGS_FWD_LIVE(1); break;
+        case 3: FSGS_FWD_LIVE(3); break;
+        case 4: FSGS_FWD_LIVE(4); break;
+        default: return FSGS_EINVAL;
+    }
+#undef FSGS_FWD_LIVE
+    return check_launch();
+}
+
+extern "C" int fsgs_raster_bwd_live(int C, int D, const float *records, const int32_t *pos4,
+                                    const int32_t *isect_offsets, int64_t n_isects, const float *backgrounds,
+                                    int width, int height, int tile_width, int tile_height, const float *alphas,
+                                    const int32_t *last_ids, const float *v_render, const float *v_alphas,
+                                    int with_abs, float *v_packed, fsgs_stream_t stream) {
+    if (C < 0 || width < 0 || height < 0 || n_isects < 0) return FSGS_EINVAL;
+    if (C == 0 || width == 0 || height == 0 || n_isects == 0) return FSGS_OK;
+    if (!records || !pos4 || !isect_offsets || !alphas || !last_ids || !v_render || !v_alphas || !v_packed)
+        return FSGS_EINVAL;
+    hipStream_t s = as_stream(stream);
+    const dim3 grid(2 * tile_width, 2 * tile_height, C);
+    const float4 *rec = reinterpret_cast<const float4 *>(records);
+    const int4 *p4 = reinterpret_cast<const int4 *>(pos4);
+#define FSGS_BWD_LIVE(DD, AA)                                                                                    \
+    hipLaunchKernelGGL((raster_bwd_live_kernel<DD, AA>), grid, dim3(64), 0, s, n_isects, rec, p4, isect_offsets, \
+                       n_isects, backgrounds, width, height, tile_width, tile_height, alphas, last_ids, v_render, \
+                       v_alphas, v_packed)
+    switch (D) {
+        case 1: if (with_abs) FSGS_BWD_LIVE(1, true); else FSGS_BWD_LIVE(1, false); break;
+        case 3: if (with_abs) FSGS_BWD_LIVE(3, true); else FSGS_BWD_LIVE(3, false); break;
+        case 4: if (with_abs) FSGS_BWD_LIVE(4, true); else FSGS_BWD_LIVE(4, false); break;
+        default: return FSGS_EINVAL;
+    }
+#undef FSGS_BWD_LIVE
+    return check_launch();
+}
+
+extern "C" int fsgs_raster_unpack_grads(int64_t total, int D, const float *v_packed, float *v_means2d,
+                                        float *v_means2d_abs, float *v_conics, float *v_colors,
+                                        float *v_opacities, fsgs_stream_t stream) {
+    if (total < 0 || (D != 1 && D != 3 && D != 4)) return FSGS_EINVAL;
+    if (total == 0) return FSGS_OK;
+    if (!v_packed || !v_means2d || !v_conics || !v_colors || !v_opacities) return FSGS_EINVAL;
+    hipLaunchKernelGGL(unpack_grads_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, as_stream(stream), total, D,
+                       reinterpret_cast<const float4 *>(v_packed), v_means2d, v_means2d_abs, v_conics, v_colors,
+                       v_opacities);
+    return check_launch();
+}

@@ -30,25 +30,26 @@ def _key(t: torch.Tensor) -> Tuple:
     return (t.data_ptr(), t._version, tuple(t.shape[-1:]), t.device)
 
 
-def remember(means2d, depths, radii, width, height, tile_size, isect_offsets, flatten_ids,
+def remember(means2d, depths, radii, width, height, tile_size, isect_offsets, flatten_ids, isect_ids,
              lists_valid_for_legacy: bool) -> None:
     global _frame
     if not lists_valid_for_legacy:
         _frame = None
         return
     _frame = dict(xys=_key(means2d), depths=_key(depths), radii=_key(radii), n=radii.shape[-1],
-                  dims=(int(width), int(height), int(tile_size)), offsets=isect_offsets, flat=flatten_ids)
+                  dims=(int(width), int(height), int(tile_size)), offsets=isect_offsets, flat=flatten_ids,
+                  ids=isect_ids)
 
 
-def lookup(xys, depths, radii, width, height, tile_size) -> Optional[Tuple[torch.Tensor, torch.Tensor]]:
-    """(isect_offsets [1,th,tw], flatten_ids [M]) of the remembered frame, or None."""
+def lookup(xys, depths, radii, width, height, tile_size):
+    """(isect_offsets [1,th,tw], flatten_ids [M], isect_ids [M]) of the remembered frame, or None."""
     global hits, misses
     f = _frame
     if (enabled and f is not None and f["dims"] == (int(width), int(height), int(tile_size))
             and xys.shape[0] == f["n"] and _key(xys) == f["xys"] and _key(depths) == f["depths"]
             and _key(radii) == f["radii"]):
         hits += 1
-        return f["offsets"], f["flat"]
+        return f["offsets"], f["flat"], f["ids"]
     misses += 1
     return None
 

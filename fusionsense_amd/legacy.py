@@ -96,7 +96,7 @@ def rasterize_gaussians(
     th = (img_height + block_width - 1) // block_width
     cached = frame_cache.lookup(xys, depths, radii, img_width, img_height, block_width)
     if cached is not None:
-        offsets, flatten_ids = cached  # same frame, both bbox rules agree: lists are identical
+        offsets, flatten_ids, isect_ids = cached  # same frame: reuse the first pass's sorted lists
     else:
         with torch.no_grad():
             _, isect_ids, flatten_ids = ops.isect_tiles(
@@ -116,7 +116,7 @@ def rasterize_gaussians(
         bg = torch.cat([bg, torch.zeros(pad, device=dev)])
     out, alpha, _ = ops._Rasterize.apply(
         xys[None], conics[None], cols[None], opacity.reshape(1, N), bg[None], offsets, flatten_ids,
-        int(img_width), int(img_height), int(block_width), False)
+        int(img_width), int(img_height), int(block_width), False, isect_ids)
     out = out[0, ..., :ch]
     if return_alpha:
         return out, alpha[0, ..., 0]

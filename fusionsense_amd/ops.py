@@ -249,12 +249,20 @@ class _SHColors(torch.autograd.Function):
         return v_means, v_coeffs, None, None, v_depths, None
 
 
+USE_LIVE_LISTS = True  # tile_size == 16 fast path (csrc/live.hip); False forces the generic tile kernels
+
+
 class _Rasterize(torch.autograd.Function):
-    """rasterize_to_pixels.  D in {1,3,4}."""
+    """rasterize_to_pixels.  D in {1,3,4}.
+
+    With ``isect_ids`` (the sorted keys) and tile_size 16 the compositing runs on "live lists":
+    an exact culling/compaction pre-pass (fsgs_live_prepare) followed by one-wave-per-8x8-quadrant
+    kernels over contiguous record streams; otherwise the generic tile kernels walk the raw lists.
+    Both give the same images, last_ids and gradients."""
 
     @staticmethod
     def forward(ctx, means2d, conics, colors, opacities, backgrounds, isect_offsets, flatten_ids, width,
-                height, tile_size, absgrad):
+                height, tile_size, absgrad, isect_ids=None):
         means2d_in = means2d
         means2d, conics, colors, opacities = map(_c, (means2d, conics, colors, opacities))
         backgrounds = _c(backgrounds)
@@ -267,14 +275,32 @@ class _Rasterize(torch.autograd.Function):
         render = torch.empty(Cn, height, width, D, dtype=torch.float32, device=dev)
         alphas = torch.empty(Cn, height, width, 1, dtype=torch.float32, device=dev)
         last_ids = torch.empty(Cn, height, width, dtype=torch.int32, device=dev)
-        _run(lib.fsgs_raster_fwd, (Cn, N, D, ptr(means2d), ptr(conics), ptr(colors), ptr(opacities),
-                                  ptr(backgrounds), width, height, tile_size, tw, th, ptr(isect_offsets),
-                                  ptr(flatten_ids), M, ptr(render), ptr(alphas), ptr(last_ids),
-                                  stream_ptr(dev)), "fsgs_raster_fwd", f"_d{D}")
-        ctx.save_for_backward(means2d, conics, colors, opacities,
-                              backgrounds if backgrounds is not None else torch.empty(0, device=dev),
-                              isect_offsets, flatten_ids, alphas, last_ids)
-        ctx.dims = (width, height, tile_size, absgrad, backgrounds is not None)
+        live = USE_LIVE_LISTS and tile_size == 16 and isect_ids is not None
+        if live:
+            mask8 = torch.empty(M + 1, dtype=torch.uint8, device=dev)
+            pos4 = torch.empty(M + 1, 4, dtype=torch.int32, device=dev)
+            records = torch.empty(4 * max(M, 1), 12, dtype=torch.float32, device=dev)
+            sbytes = lib.fsgs_live_scratch_bytes(M)
+            scratch = torch.empty(sbytes, dtype=torch.uint8, device=dev)
+            _run(lib.fsgs_live_prepare, (D, ptr(means2d), ptr(conics), ptr(colors), ptr(opacities), tw,
+                                        tile_bits(tw * th), ptr(isect_ids), ptr(flatten_ids), M, ptr(mask8),
+                                        ptr(pos4), ptr(records), ptr(scratch), sbytes, stream_ptr(dev)),
+                 "fsgs_live_prepare", f"_d{D}")
+            _run(lib.fsgs_raster_fwd_live, (Cn, D, ptr(records), ptr(pos4), ptr(isect_offsets), M,
+                                           ptr(backgrounds), width, height, tw, th, ptr(render), ptr(alphas),
+                                           ptr(last_ids), stream_ptr(dev)), "fsgs_raster_fwd_live", f"_d{D}")
+            ctx.save_for_backward(records, pos4,
+                                  backgrounds if backgrounds is not None else torch.empty(0, device=dev),
+                                  isect_offsets, alphas, last_ids)
+        else:
+            _run(lib.fsgs_raster_fwd, (Cn, N, D, ptr(means2d), ptr(conics), ptr(colors), ptr(opacities),
+                                      ptr(backgrounds), width, height, tile_size, tw, th, ptr(isect_offsets),
+                                      ptr(flatten_ids), M, ptr(render), ptr(alphas), ptr(last_ids),
+                                      stream_ptr(dev)), "fsgs_raster_fwd", f"_d{D}")
+            ctx.save_for_backward(means2d, conics, colors, opacities,
+                                  backgrounds if backgrounds is not None else torch.empty(0, device=dev),
+                                  isect_offsets, flatten_ids, alphas, last_ids)
+        ctx.dims = (width, height, tile_size, absgrad, backgrounds is not None, live, Cn, N, D, M)
         # the tensor object the caller holds (meta["means2d"]) receives `.absgrad` in backward
         ctx.means2d_obj = means2d_in
         ctx.mark_non_differentiable(last_ids)
@@ -282,34 +308,51 @@ class _Rasterize(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, v_render, v_alphas, _v_last):
-        (means2d, conics, colors, opacities, backgrounds, isect_offsets, flatten_ids, alphas,
-         last_ids) = ctx.saved_tensors
-        width, height, tile_size, absgrad, has_bg = ctx.dims
+        width, height, tile_size, absgrad, has_bg, live, Cn, N, D, M = ctx.dims
         lib = load()
-        dev = means2d.device
-        Cn, N = opacities.shape
-        D = colors.shape[-1]
+        if live:
+            records, pos4, backgrounds, isect_offsets, alphas, last_ids = ctx.saved_tensors
+        else:
+            (means2d, conics, colors, opacities, backgrounds, isect_offsets, flatten_ids, alphas,
+             last_ids) = ctx.saved_tensors
+        dev = alphas.device
         th, tw = isect_offsets.shape[1:]
-        M = flatten_ids.numel()
         v_render = _c(v_render) if v_render is not None else torch.zeros(Cn, height, width, D, device=dev)
         v_alphas = _c(v_alphas) if v_alphas is not None else torch.zeros(Cn, height, width, 1, device=dev)
-        v_means2d = torch.zeros_like(means2d)
-        v_conics = torch.zeros_like(conics)
-        v_colors = torch.zeros_like(colors)
-        v_opacities = torch.zeros_like(opacities)
-        v_abs = torch.zeros_like(means2d) if absgrad else None
-        _run(lib.fsgs_raster_bwd, (Cn, N, D, ptr(means2d), ptr(conics), ptr(colors), ptr(opacities),
-                                  ptr(backgrounds) if has_bg else None, width, height, tile_size, tw, th,
-                                  ptr(isect_offsets), ptr(flatten_ids), M, ptr(alphas), ptr(last_ids),
-                                  ptr(v_render), ptr(v_alphas), ptr(v_means2d), ptr(v_abs), ptr(v_conics),
-                                  ptr(v_colors), ptr(v_opacities), stream_ptr(dev)), "fsgs_raster_bwd", f"_d{D}")
+        if live:
+            v_packed = torch.zeros(Cn * N, 16, dtype=torch.float32, device=dev)
+            _run(lib.fsgs_raster_bwd_live, (Cn, D, ptr(records), ptr(pos4), ptr(isect_offsets), M,
+                                           ptr(backgrounds) if has_bg else None, width, height, tw, th,
+                                           ptr(alphas), ptr(last_ids), ptr(v_render), ptr(v_alphas),
+                                           int(bool(absgrad)), ptr(v_packed), stream_ptr(dev)),
+                 "fsgs_raster_bwd_live", f"_d{D}")
+            v_means2d = torch.empty(Cn, N, 2, dtype=torch.float32, device=dev)
+            v_conics = torch.empty(Cn, N, 3, dtype=torch.float32, device=dev)
+            v_colors = torch.empty(Cn, N, D, dtype=torch.float32, device=dev)
+            v_opacities = torch.empty(Cn, N, dtype=torch.float32, device=dev)
+            v_abs = torch.empty(Cn, N, 2, dtype=torch.float32, device=dev) if absgrad else None
+            _run(lib.fsgs_raster_unpack_grads, (Cn * N, D, ptr(v_packed), ptr(v_means2d), ptr(v_abs),
+                                               ptr(v_conics), ptr(v_colors), ptr(v_opacities),
+                                               stream_ptr(dev)), "fsgs_raster_unpack_grads")
+        else:
+            v_means2d = torch.zeros_like(means2d)
+            v_conics = torch.zeros_like(conics)
+            v_colors = torch.zeros_like(colors)
+            v_opacities = torch.zeros_like(opacities)
+            v_abs = torch.zeros_like(means2d) if absgrad else None
+            _run(lib.fsgs_raster_bwd, (Cn, N, D, ptr(means2d), ptr(conics), ptr(colors), ptr(opacities),
+                                      ptr(backgrounds) if has_bg else None, width, height, tile_size, tw, th,
+                                      ptr(isect_offsets), ptr(flatten_ids), M, ptr(alphas), ptr(last_ids),
+                                      ptr(v_render), ptr(v_alphas), ptr(v_means2d), ptr(v_abs), ptr(v_conics),
+                                      ptr(v_colors), ptr(v_opacities), stream_ptr(dev)), "fsgs_raster_bwd",
+                 f"_d{D}")
         if absgrad:
             ctx.means2d_obj.absgrad = v_abs
         v_bg = None
         if has_bg and ctx.needs_input_grad[4]:
             v_bg = (v_render * (1.0 - alphas)).sum(dim=(1, 2))
         ctx.means2d_obj = None
-        return v_means2d, v_conics, v_colors, v_opacities, v_bg, None, None, None, None, None, None
+        return (v_means2d, v_conics, v_colors, v_opacities, v_bg, None, None, None, None, None, None, None)
 
 
 class _GaussianNormals(torch.autograd.Function):

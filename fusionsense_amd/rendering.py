@@ -116,7 +116,7 @@ def rasterization(
     # let the legacy normal pass (dn_model.py:644-653) reuse these lists when it is handed this
     # frame's own xys / depths / radii (see frame_cache for why that is the faithful choice even
     # for the rule_diff Gaussians whose bbox touches a tile edge exactly)
-    frame_cache.remember(means2d, depths, radii, width, height, tile_size, isect_offsets, flatten_ids,
+    frame_cache.remember(means2d, depths, radii, width, height, tile_size, isect_offsets, flatten_ids, isect_ids,
                          lists_valid_for_legacy=(C == 1))
 
     want_depth = render_mode in ("RGB+D", "RGB+ED")
@@ -142,7 +142,7 @@ def rasterization(
     if D in (1, 3, 4):
         render, alphas, last_ids = ops._Rasterize.apply(
             means2d, conics, cols, opac, backgrounds, isect_offsets, flatten_ids, width, height, tile_size,
-            absgrad)
+            absgrad, isect_ids)
     else:
         # arbitrary channel counts: composite in chunks of <=4 channels over the same lists
         if absgrad:
@@ -159,7 +159,7 @@ def rasterization(
                 bg = torch.cat([bg, torch.zeros_like(bg[..., :1])], dim=-1) if bg is not None else None
             r, alphas, last_ids = ops._Rasterize.apply(
                 means2d, conics, chunk.contiguous(), opac, bg, isect_offsets, flatten_ids, width, height,
-                tile_size, False)
+                tile_size, False, isect_ids)
             outs.append(r[..., :w])
         render = torch.cat(outs, dim=-1)
 

@@ -128,6 +128,36 @@ int fsgs_raster_bwd(int C, int N, int D, const float *means2d, const float *coni
                     const float *v_alphas, float *v_means2d, float *v_means2d_abs,
                     float *v_conics, float *v_colors, float *v_opacities, fsgs_stream_t stream);
 
+/* ---- E7 / E8 fast path (tile_size == 16): "live lists" ----------------------------------------
+ * An exact culling + compaction pass between binning and compositing (csrc/live.hip).  For every
+ * entry of the sorted tile lists it decides which of the tile's four 8x8 quadrants the Gaussian
+ * can reach at alpha >= 1/255 and writes one self-contained 48-byte record per reached quadrant
+ * into that quadrant's stream (depth order preserved).  Results of compositing are identical to
+ * fsgs_raster_fwd/bwd on the raw lists; `meta` lists are untouched.
+ *   mask8[M+1] u8, pos4[(M+1)*4] i32 (exclusive prefix sums of the 4 mask bits; pos4[M] = totals),
+ *   records[4*M*12] f32 (stream q starts at record q*M; record = 3 x float4:
+ *   {x,y,opacity,conic.a} {conic.b,conic.c,bits(list index),bits(flatten id)} {colour, zero padded}). */
+size_t fsgs_live_scratch_bytes(int64_t n_isects);
+int fsgs_live_prepare(int D, const float *means2d, const float *conics, const float *colors,
+                      const float *opacities, int tile_width, int tile_bits, const int64_t *isect_ids,
+                      const int32_t *flatten_ids, int64_t n_isects, uint8_t *mask8, int32_t *pos4,
+                      float *records, void *scratch, size_t scratch_bytes, fsgs_stream_t stream);
+int fsgs_raster_fwd_live(int C, int D, const float *records, const int32_t *pos4,
+                         const int32_t *isect_offsets, int64_t n_isects, const float *backgrounds,
+                         int width, int height, int tile_width, int tile_height, float *render,
+                         float *alphas, int32_t *last_ids, fsgs_stream_t stream);
+/* v_packed[C*N,16] f32, ACCUMULATED with atomics (zero it first): per (camera, Gaussian)
+ * [0..3] v_colors [4..6] v_conics [7..8] v_means2d [9..10] v_means2d_abs [11] v_opacities. */
+int fsgs_raster_bwd_live(int C, int D, const float *records, const int32_t *pos4,
+                         const int32_t *isect_offsets, int64_t n_isects, const float *backgrounds,
+                         int width, int height, int tile_width, int tile_height, const float *alphas,
+                         const int32_t *last_ids, const float *v_render, const float *v_alphas,
+                         int with_abs, float *v_packed, fsgs_stream_t stream);
+/* Split packed gradient records into the five gsplat-shaped arrays (written, not accumulated). */
+int fsgs_raster_unpack_grads(int64_t total, int D, const float *v_packed, float *v_means2d,
+                             float *v_means2d_abs, float *v_conics, float *v_colors,
+                             float *v_opacities, fsgs_stream_t stream);
+
 /* ---- a-11: per-Gaussian normals (dn_splatter/dn_model.py:618-636 as one kernel) ---------------
  * quats[N,4] (any norm), log_scales[N,3], means[N,3], c2w[3,4] (OpenGL) ->
  * normals_world[N,3] (what the reference stores in gauss_params["normals"]),

@@ -118,17 +118,19 @@ def _frame(seed=0, n=1000, with_bg=False, D=4):
     return cam, fr, cols, opac, bg
 
 
+@pytest.mark.parametrize("live", [False, True])
 @pytest.mark.parametrize("D,with_bg", [(4, False), (3, True), (1, False)])
-def test_raster_fwd(dev, D, with_bg):
+def test_raster_fwd(dev, D, with_bg, live):
     from fusionsense_amd import ops
     cam, fr, cols, opac, bg = _frame(seed=1, D=D, with_bg=with_bg)
+    ids = torch.from_numpy(fr["ids_s"]).to(dev) if live else None
     W, H = cam.width, cam.height
     ref, ref_a, ref_last = R.rasterize_to_pixels(fr["means2d"], fr["conics"], cols, opac, W, H, 16,
                                                  fr["offsets"], fr["flat_s"], bg)
     out, alpha, last = ops._Rasterize.apply(
         fr["means2d"].to(dev), fr["conics"].to(dev), cols.to(dev), opac.to(dev),
         bg.to(dev) if bg is not None else None, torch.from_numpy(fr["offsets"]).to(dev),
-        torch.from_numpy(fr["flat_s"]).to(dev), W, H, 16, False)
+        torch.from_numpy(fr["flat_s"]).to(dev), W, H, 16, False, ids)
     assert (out.cpu() - ref).abs().max().item() < FWD_RTOL * max(1.0, ref.abs().max().item())
     assert (alpha.cpu() - ref_a).abs().max().item() < FWD_RTOL
     # last_ids: exact except where an fp32 threshold decision (alpha<1/255, T<=1e-4) is borderline
@@ -136,10 +138,12 @@ def test_raster_fwd(dev, D, with_bg):
     assert mism < 2e-3, f"last_ids mismatch fraction {mism}"
 
 
+@pytest.mark.parametrize("live", [False, True])
 @pytest.mark.parametrize("D,with_bg", [(4, False), (3, True)])
-def test_raster_bwd(dev, D, with_bg):
+def test_raster_bwd(dev, D, with_bg, live):
     from fusionsense_amd import ops
     cam, fr, cols, opac, bg = _frame(seed=2, D=D, with_bg=with_bg)
+    ids = torch.from_numpy(fr["ids_s"]).to(dev) if live else None
     W, H = cam.width, cam.height
     g = torch.Generator().manual_seed(5)
     v_render = torch.randn(1, H, W, D, generator=g)
@@ -149,7 +153,7 @@ def test_raster_bwd(dev, D, with_bg):
     ins = [t.to(dev).requires_grad_(True) for t in (fr["means2d"], fr["conics"], cols, opac)]
     out, alpha, _ = ops._Rasterize.apply(*ins, bg.to(dev) if bg is not None else None,
                                          torch.from_numpy(fr["offsets"]).to(dev),
-                                         torch.from_numpy(fr["flat_s"]).to(dev), W, H, 16, True)
+                                         torch.from_numpy(fr["flat_s"]).to(dev), W, H, 16, True, ids)
     torch.autograd.backward([out, alpha], [v_render.to(dev), v_alpha.to(dev)])
     got = dict(v_means2d=ins[0].grad, v_conics=ins[1].grad, v_colors=ins[2].grad, v_opacities=ins[3].grad,
                v_means2d_abs=ins[0].absgrad)
@@ -330,3 +334,38 @@ def test_legacy_pass_reuses_sorted_lists(dev):
                                 info["tiles_per_gauss"][0], torch.rand(1500, 3, device=dev),
                                 torch.rand(1500, 1, device=dev), cam.height, cam.width, 16)
     assert frame_cache.hits == h0 and n_img.shape == (128, 128, 3)
+
+
+@pytest.mark.parametrize("res", [(128, 128), (100, 75)])
+def test_live_lists_equal_generic_walk(dev, res):
+    """The culling/compaction fast path must not change a single bit of the forward outputs
+    (same entries, same order per pixel) and must agree on gradients up to atomic ordering;
+    also on images whose size is not a multiple of the tile."""
+    from fusionsense_amd import ops
+    W, H = res
+    params, cam = scenes.cube_scene(4000, seed=21)
+    act = activated(params)
+    # a few huge, a few nearly transparent and a few needle-like Gaussians
+    act["scales"][:20] *= 15
+    act["opacities"][20:60] = 0.004
+    act["scales"][60:200, 0] *= 0.02
+    viewmat, K = camera_mats(cam)
+    K = K.clone()
+    K[0, 0, 2], K[0, 1, 2] = W / 2, H / 2
+    fr = oracle_frame(act, viewmat, K, W, H)
+    g = torch.Generator().manual_seed(3)
+    cols = torch.rand(1, 4000, 4, generator=g)
+    opac = act["opacities"][None].contiguous()
+    v_r, v_a = torch.randn(1, H, W, 4, generator=g), torch.randn(1, H, W, 1, generator=g)
+    res_ = []
+    for ids in (None, torch.from_numpy(fr["ids_s"]).to(dev)):
+        ins = [t.to(dev).requires_grad_(True) for t in (fr["means2d"], fr["conics"], cols, opac)]
+        out, alpha, last = ops._Rasterize.apply(*ins, None, torch.from_numpy(fr["offsets"]).to(dev),
+                                                torch.from_numpy(fr["flat_s"]).to(dev), W, H, 16, True, ids)
+        torch.autograd.backward([out, alpha], [v_r.to(dev), v_a.to(dev)])
+        res_.append((out.detach(), alpha.detach(), last, [t.grad for t in ins], ins[0].absgrad))
+    a, b = res_
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    for ga, gb in zip(a[3], b[3]):
+        assert rel_err(gb, ga) < 1e-4
+    assert rel_err(b[4], a[4]) < 1e-4
