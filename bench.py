@@ -168,6 +168,7 @@ def main():
     # ---- timed region: EXACTLY args.steps full iterations ----
     ops.TIMER.reset(enabled=True)
     torch.cuda.synchronize()
+    n_alloc0 = torch.cuda.memory_stats(dev).get('num_device_alloc', 0)
     t0 = time.perf_counter()
     for s in range(args.steps):
         v = view_of(args.warmup + s)
@@ -176,6 +177,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     kernel_ms = ops.TIMER.summary()
+    n_alloc = torch.cuda.memory_stats(dev).get('num_device_alloc', 0) - n_alloc0
     log(f'timed region done: {elapsed:.3f}s')
     ops.TIMER.reset(enabled=False)
     if world > 1:
@@ -254,6 +256,7 @@ def main():
             "iters_per_s_excl_optimizer": round(world / t_noopt, 3),
             "iter_algorithmic_bytes": b_iter,
             "iter_hbm_frac": round(b_iter / (elapsed / args.steps) / (HBM_PEAK_GBS * 1e9), 5),
+            "device_mallocs_in_timed_region": n_alloc,
             "kernels_ms": kernel_ms,
             "roofline": roofline,
         }

@@ -252,6 +252,37 @@ class _SHColors(torch.autograd.Function):
 USE_LIVE_LISTS = True  # tile_size == 16 fast path (csrc/live.hip); False forces the generic tile kernels
 
 
+class _Workspace:
+    """Size-stable pool for the big per-frame scratch buffers (live-list records are 192 B per
+    list entry worst case and their size follows M, which changes every frame: handing such
+    requests to the caching allocator makes it split and re-malloc blocks all the time).
+    Buffers are handed out with 25 % slack and come back when the consumer is done."""
+
+    def __init__(self):
+        self.free = {}
+
+    def take(self, nbytes: int, device) -> Tensor:
+        lst = self.free.setdefault(str(device), [])
+        best = None
+        for i, t in enumerate(lst):
+            if t.numel() >= nbytes and (best is None or t.numel() < lst[best].numel()):
+                best = i
+        if best is not None:
+            return lst.pop(best)
+        return torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=device)
+
+    def give(self, t: Optional[Tensor]) -> None:
+        if t is not None:
+            lst = self.free.setdefault(str(t.device), [])
+            lst.append(t)
+            if len(lst) > 8:  # drop the smallest
+                lst.sort(key=lambda x: x.numel())
+                lst.pop(0)
+
+
+WORKSPACE = _Workspace()
+
+
 class _Rasterize(torch.autograd.Function):
     """rasterize_to_pixels.  D in {1,3,4}.
 
@@ -277,11 +308,16 @@ class _Rasterize(torch.autograd.Function):
         last_ids = torch.empty(Cn, height, width, dtype=torch.int32, device=dev)
         live = USE_LIVE_LISTS and tile_size == 16 and isect_ids is not None
         if live:
-            mask8 = torch.empty(M + 1, dtype=torch.uint8, device=dev)
-            pos4 = torch.empty(M + 1, 4, dtype=torch.int32, device=dev)
-            records = torch.empty(4 * max(M, 1), 12, dtype=torch.float32, device=dev)
             sbytes = lib.fsgs_live_scratch_bytes(M)
-            scratch = torch.empty(sbytes, dtype=torch.uint8, device=dev)
+            rec_bytes = 4 * max(M, 1) * 48
+            pos_bytes = (M + 1) * 16
+            a = lambda n: (n + 255) // 256 * 256  # noqa: E731
+            arena = WORKSPACE.take(a(rec_bytes) + a(pos_bytes) + a(M + 1) + a(sbytes), dev)
+            records = arena[:rec_bytes].view(torch.float32)
+            pos4 = arena[a(rec_bytes):a(rec_bytes) + pos_bytes].view(torch.int32)
+            o = a(rec_bytes) + a(pos_bytes)
+            mask8 = arena[o:o + M + 1]
+            scratch = arena[o + a(M + 1):o + a(M + 1) + sbytes]
             _run(lib.fsgs_live_prepare, (D, ptr(means2d), ptr(conics), ptr(colors), ptr(opacities), tw,
                                         tile_bits(tw * th), ptr(isect_ids), ptr(flatten_ids), M, ptr(mask8),
                                         ptr(pos4), ptr(records), ptr(scratch), sbytes, stream_ptr(dev)),
@@ -292,6 +328,13 @@ class _Rasterize(torch.autograd.Function):
             ctx.save_for_backward(records, pos4,
                                   backgrounds if backgrounds is not None else torch.empty(0, device=dev),
                                   isect_offsets, alphas, last_ids)
+            needs_bwd = torch.is_grad_enabled() and any(
+                t is not None and t.requires_grad for t in (means2d_in, conics, colors, opacities))
+            if needs_bwd:
+                ctx.arena = arena  # returned to the pool at the end of backward
+            else:
+                ctx.arena = None
+                WORKSPACE.give(arena)
         else:
             _run(lib.fsgs_raster_fwd, (Cn, N, D, ptr(means2d), ptr(conics), ptr(colors), ptr(opacities),
                                       ptr(backgrounds), width, height, tile_size, tw, th, ptr(isect_offsets),
@@ -346,6 +389,9 @@ class _Rasterize(torch.autograd.Function):
                                       ptr(v_render), ptr(v_alphas), ptr(v_means2d), ptr(v_abs), ptr(v_conics),
                                       ptr(v_colors), ptr(v_opacities), stream_ptr(dev)), "fsgs_raster_bwd",
                  f"_d{D}")
+        if live:
+            WORKSPACE.give(getattr(ctx, "arena", None))
+            ctx.arena = None
         if absgrad:
             ctx.means2d_obj.absgrad = v_abs
         v_bg = None
