@@ -328,9 +328,8 @@ class _Rasterize(torch.autograd.Function):
             ctx.save_for_backward(records, pos4,
                                   backgrounds if backgrounds is not None else torch.empty(0, device=dev),
                                   isect_offsets, alphas, last_ids)
-            needs_bwd = torch.is_grad_enabled() and any(
-                t is not None and t.requires_grad for t in (means2d_in, conics, colors, opacities))
-            if needs_bwd:
+            # (grad mode is always off inside Function.forward: ask the tape, not torch.is_grad_enabled)
+            if any(ctx.needs_input_grad[:5]):
                 ctx.arena = arena  # returned to the pool at the end of backward
             else:
                 ctx.arena = None
