@@ -40,7 +40,7 @@ raster_fwd_live_kernel(int64_t cap, const float4 *__restrict__ rec, const int4 *
                        const int32_t *__restrict__ tile_offsets, int64_t n_isects,
                        const float *__restrict__ backgrounds, int W, int H, int tw, int th,
                        float *__restrict__ render, float *__restrict__ alphas,
-                       int32_t *__restrict__ last_ids) {
+                       int32_t *__restrict__ last_ids, float *__restrict__ seg_state, int64_t seg_cap) {
     __shared__ QLds<D> L;
     const int cam = blockIdx.z;
     const int tile_x = blockIdx.x >> 1, tile_y = blockIdx.y >> 1;
@@ -66,6 +66,10 @@ raster_fwd_live_kernel(int64_t cap, const float4 *__restrict__ rec, const int4 *
 #pragma unroll
     for (int k = 0; k < D; ++k) pix[k] = 0.f;
 
+    // State of every pixel AFTER each 64-entry segment of this quadrant's list (= before the next
+    // one), for the segment-parallel backward: slot (b/64 + tile_lin) of stream q, b = the next
+    // segment's first stream position, is unique per (quadrant, segment).
+    float *seg_q = seg_state ? seg_state + (int64_t)q * seg_cap * (64 * (1 + D)) : nullptr;
     Rec r;
     load_rec(r, stream, (int64_t)s + lane, s + lane < e);
     for (int b = s; b < e; b += 64) {
@@ -93,6 +97,13 @@ raster_fwd_live_kernel(int64_t cap, const float4 *__restrict__ rec, const int4 *
             if (D > 3) pix[D - 1] += c.w * vis;
             cur_idx = __float_as_int(a1.z);
             T = next_T;
+        }
+        // written even when the wave stops early: the backward of THIS segment reads it
+        if (seg_q && b + 64 < e) {
+            float *slot = seg_q + ((int64_t)((b + 64) >> 6) + tile_lin) * (64 * (1 + D));
+            slot[lane] = T;
+#pragma unroll
+            for (int k = 0; k < D; ++k) slot[64 * (1 + k) + lane] = pix[k];
         }
         if (__all(done)) break;
     }
@@ -124,21 +135,32 @@ __device__ __forceinline__ int wave_max_i32q(int v) {
 
 // packed gradient record, 16 floats per (camera, Gaussian):
 //   [0..3] v_colors  [4..6] v_conics  [7..8] v_means2d  [9..10] v_means2d_abs  [11] v_opacities
+//
+// Segment-parallel backward.  The forward saved every pixel's (T, accumulated colour) before each
+// 64-entry segment of its quadrant list, so the two recurrences of the back-to-front walk can be
+// restarted at any segment end:  T_end(k) = T_before(k+1)  (or the final T),  and the colour still
+// to come  buffer_end(k) = C_total - C_before(k+1)  (or 0).  A workgroup of kBwdWaves waves owns a
+// quadrant; wave w takes segments w, w+kBwdWaves, ... independently (no barriers between waves), which
+// removes the long-list tail that otherwise sets the kernel's duration.
+constexpr int kBwdWaves = 4;
+
 template <int D, bool ABS>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64 * kBwdWaves)
 raster_bwd_live_kernel(int64_t cap, const float4 *__restrict__ rec, const int4 *__restrict__ pos4,
                        const int32_t *__restrict__ tile_offsets, int64_t n_isects,
                        const float *__restrict__ backgrounds, int W, int H, int tw, int th,
-                       const float *__restrict__ alphas, const int32_t *__restrict__ last_ids,
-                       const float *__restrict__ v_render, const float *__restrict__ v_alphas,
-                       float *__restrict__ v_packed) {
-    __shared__ QLds<D> L;
+                       const float *__restrict__ render, const float *__restrict__ alphas,
+                       const int32_t *__restrict__ last_ids, const float *__restrict__ v_render,
+                       const float *__restrict__ v_alphas, const float *__restrict__ seg_state,
+                       int64_t seg_cap, float *__restrict__ v_packed) {
+    __shared__ QLds<D> Lw[kBwdWaves];
     const int cam = blockIdx.z;
     const int tile_x = blockIdx.x >> 1, tile_y = blockIdx.y >> 1;
     const int q = ((blockIdx.y & 1) << 1) | (blockIdx.x & 1);
     const int tile_lin = (cam * th + tile_y) * tw + tile_x;
     const int n_tiles_total = gridDim.z * th * tw;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    QLds<D> &L = Lw[w];
     const int j = blockIdx.x * 8 + (lane & 7), i = blockIdx.y * 8 + (lane >> 3);
     const float px = (float)j + 0.5f, py = (float)i + 0.5f;
     const bool inside = (i < H) && (j < W);
@@ -149,16 +171,17 @@ raster_bwd_live_kernel(int64_t cap, const float4 *__restrict__ rec, const int4 *
     const int4 p0 = pos4[l0], p1 = pos4[l1];
     const int s = (q == 0) ? p0.x : (q == 1) ? p0.y : (q == 2) ? p0.z : p0.w;
     const int e = (q == 0) ? p1.x : (q == 1) ? p1.y : (q == 2) ? p1.z : p1.w;
-    if (e <= s) return;
+    const int n_seg = (e - s + 63) >> 6;
+    if (w >= n_seg) return;
     const float4 *stream = rec + 3 * ((int64_t)q * cap);
+    const float *seg_q = seg_state + (int64_t)q * seg_cap * (64 * (1 + D));
 
     const float T_final = 1.f - alphas[pix_id];
-    float T = T_final;
-    float buffer[D], v_out[D];
+    float v_out[D], c_total[D];
 #pragma unroll
     for (int k = 0; k < D; ++k) {
-        buffer[k] = 0.f;
         v_out[k] = inside ? v_render[pix_id * D + k] : 0.f;
+        c_total[k] = render[pix_id * D + k] - (backgrounds ? T_final * backgrounds[cam * D + k] : 0.f);
     }
     const float v_out_a = inside ? v_alphas[pix_id] : 0.f;
     float bg_dot = 0.f;
@@ -169,16 +192,28 @@ raster_bwd_live_kernel(int64_t cap, const float4 *__restrict__ rec, const int4 *
     const int bin_final = inside ? last_ids[pix_id] : -1;
     const int wave_bin_final = wave_max_i32q(bin_final);
 
-    Rec r;
-    load_rec(r, stream, (int64_t)e - 1 - lane, e - 1 - lane >= s);
-    for (int b = e - 1; b >= s; b -= 64) {  // slot t of the batch holds stream position b - t
-        __syncthreads();
+    for (int seg = n_seg - 1 - w; seg >= 0; seg -= kBwdWaves) {
+        const int b0 = s + (seg << 6);          // first stream position of the segment
+        const int n = min(64, e - b0);
+        // slot t holds stream position b0 + n - 1 - t (descending list order)
+        Rec r;
+        load_rec(r, stream, (int64_t)b0 + n - 1 - lane, lane < n);
         L.r0[lane] = r.r0; L.r1[lane] = r.r1; L.r2[lane] = r.r2;
-        const int n = min(64, b - s + 1);
-        load_rec(r, stream, (int64_t)b - 64 - lane, b - 64 - lane >= s);
-        __syncthreads();
-        // descending list order: nothing above wave_bin_final was composited by this wave
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // nothing above wave_bin_final was composited by this wave's pixels
         if (__float_as_int(L.r1[n - 1].z) > wave_bin_final) continue;
+        float T, buffer[D];
+        if (seg == n_seg - 1) {
+            T = T_final;
+#pragma unroll
+            for (int k = 0; k < D; ++k) buffer[k] = 0.f;
+        } else {
+            const float *slot = seg_q + ((int64_t)((b0 + 64) >> 6) + tile_lin) * (64 * (1 + D));
+            T = slot[lane];
+#pragma unroll
+            for (int k = 0; k < D; ++k) buffer[k] = c_total[k] - slot[64 * (1 + k) + lane];
+        }
         for (int t = 0; t < n; ++t) {
             const float4 a0 = L.r0[t], a1 = L.r1[t];
             const int isect = __float_as_int(a1.z);
@@ -232,7 +267,8 @@ raster_bwd_live_kernel(int64_t cap, const float4 *__restrict__ rec, const int4 *
 #pragma unroll
                 for (int k = 0; k < 12; ++k) L.tot[k] = g[k];
             }
-            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
             if (lane < 12) {
                 const bool used = (lane < D) || (lane >= 4 && lane <= 8) || (ABS && (lane == 9 || lane == 10)) ||
                                   (lane == 11);
@@ -241,8 +277,9 @@ raster_bwd_live_kernel(int64_t cap, const float4 *__restrict__ rec, const int4 *
                     unsafeAtomicAdd(&v_packed[gid * 16 + lane], L.tot[lane]);
                 }
             }
-            __syncthreads();
+            __builtin_amdgcn_wave_barrier();
         }
+        __builtin_amdgcn_wave_barrier();  // LDS reads of this segment precede the next segment's writes
     }
 }
 
@@ -270,10 +307,17 @@ unpack_grads_kernel(int64_t total, int D, const float4 *__restrict__ v_packed, f
 
 using namespace fsgs;
 
+// Segment-state slots per stream: one per 64-entry block of the stream plus one per tile (a
+// quadrant's first, partial block gets its own slot).
+extern "C" int64_t fsgs_live_seg_slots(int C, int tile_width, int tile_height, int64_t n_isects) {
+    return (n_isects >> 6) + (int64_t)C * tile_width * tile_height + 2;
+}
+
 extern "C" int fsgs_raster_fwd_live(int C, int D, const float *records, const int32_t *pos4,
                                     const int32_t *isect_offsets, int64_t n_isects, const float *backgrounds,
                                     int width, int height, int tile_width, int tile_height, float *render,
-                                    float *alphas, int32_t *last_ids, fsgs_stream_t stream) {
+                                    float *alphas, int32_t *last_ids, float *seg_state,
+                                    fsgs_stream_t stream) {
     if (C < 0 || width < 0 || height < 0 || n_isects < 0) return FSGS_EINVAL;
     if (C == 0 || width == 0 || height == 0) return FSGS_OK;
     if (!pos4 || !isect_offsets || !render || !alphas || !last_ids || (n_isects > 0 && !records))
@@ -282,9 +326,11 @@ extern "C" int fsgs_raster_fwd_live(int C, int D, const float *records, const in
     const dim3 grid(2 * tile_width, 2 * tile_height, C);
     const float4 *rec = reinterpret_cast<const float4 *>(records);
     const int4 *p4 = reinterpret_cast<const int4 *>(pos4);
+    const int64_t seg_cap = fsgs_live_seg_slots(C, tile_width, tile_height, n_isects);
 #define FSGS_FWD_LIVE(DD)                                                                                   \
     hipLaunchKernelGGL((raster_fwd_live_kernel<DD>), grid, dim3(64), 0, s, n_isects, rec, p4, isect_offsets, \
-                       n_isects, backgrounds, width, height, tile_width, tile_height, render, alphas, last_ids)
+                       n_isects, backgrounds, width, height, tile_width, tile_height, render, alphas, last_ids,  \
+                       seg_state, seg_cap)
     switch (D) {
         case 1: FSGS_FWD_LIVE(1); break;
         case 3: FSGS_FWD_LIVE(3); break;
@@ -297,21 +343,24 @@ extern "C" int fsgs_raster_fwd_live(int C, int D, const float *records, const in
 
 extern "C" int fsgs_raster_bwd_live(int C, int D, const float *records, const int32_t *pos4,
                                     const int32_t *isect_offsets, int64_t n_isects, const float *backgrounds,
-                                    int width, int height, int tile_width, int tile_height, const float *alphas,
-                                    const int32_t *last_ids, const float *v_render, const float *v_alphas,
-                                    int with_abs, float *v_packed, fsgs_stream_t stream) {
+                                    int width, int height, int tile_width, int tile_height, const float *render,
+                                    const float *alphas, const int32_t *last_ids, const float *v_render,
+                                    const float *v_alphas, const float *seg_state, int with_abs,
+                                    float *v_packed, fsgs_stream_t stream) {
     if (C < 0 || width < 0 || height < 0 || n_isects < 0) return FSGS_EINVAL;
     if (C == 0 || width == 0 || height == 0 || n_isects == 0) return FSGS_OK;
-    if (!records || !pos4 || !isect_offsets || !alphas || !last_ids || !v_render || !v_alphas || !v_packed)
+    if (!records || !pos4 || !isect_offsets || !render || !alphas || !last_ids || !v_render || !v_alphas ||
+        !seg_state || !v_packed)
         return FSGS_EINVAL;
+    const int64_t seg_cap = fsgs_live_seg_slots(C, tile_width, tile_height, n_isects);
     hipStream_t s = as_stream(stream);
     const dim3 grid(2 * tile_width, 2 * tile_height, C);
     const float4 *rec = reinterpret_cast<const float4 *>(records);
     const int4 *p4 = reinterpret_cast<const int4 *>(pos4);
 #define FSGS_BWD_LIVE(DD, AA)                                                                                    \
-    hipLaunchKernelGGL((raster_bwd_live_kernel<DD, AA>), grid, dim3(64), 0, s, n_isects, rec, p4, isect_offsets, \
-                       n_isects, backgrounds, width, height, tile_width, tile_height, alphas, last_ids, v_render, \
-                       v_alphas, v_packed)
+    hipLaunchKernelGGL((raster_bwd_live_kernel<DD, AA>), grid, dim3(64 * kBwdWaves), 0, s, n_isects, rec, p4,   \
+                       isect_offsets, n_isects, backgrounds, width, height, tile_width, tile_height, render,     \
+                       alphas, last_ids, v_render, v_alphas, seg_state, seg_cap, v_packed)
     switch (D) {
         case 1: if (with_abs) FSGS_BWD_LIVE(1, true); else FSGS_BWD_LIVE(1, false); break;
         case 3: if (with_abs) FSGS_BWD_LIVE(3, true); else FSGS_BWD_LIVE(3, false); break;

@@ -312,24 +312,30 @@ class _Rasterize(torch.autograd.Function):
             rec_bytes = 4 * max(M, 1) * 48
             pos_bytes = (M + 1) * 16
             a = lambda n: (n + 255) // 256 * 256  # noqa: E731
-            arena = WORKSPACE.take(a(rec_bytes) + a(pos_bytes) + a(M + 1) + a(sbytes), dev)
+            needs_bwd = any(ctx.needs_input_grad[:5])
+            seg_bytes = 4 * lib.fsgs_live_seg_slots(Cn, tw, th, M) * 64 * (1 + D) * 4 if needs_bwd else 0
+            arena = WORKSPACE.take(a(rec_bytes) + a(pos_bytes) + a(M + 1) + a(sbytes) + a(seg_bytes), dev)
             records = arena[:rec_bytes].view(torch.float32)
             pos4 = arena[a(rec_bytes):a(rec_bytes) + pos_bytes].view(torch.int32)
             o = a(rec_bytes) + a(pos_bytes)
             mask8 = arena[o:o + M + 1]
             scratch = arena[o + a(M + 1):o + a(M + 1) + sbytes]
+            o2 = o + a(M + 1) + a(sbytes)
+            seg_state = arena[o2:o2 + seg_bytes].view(torch.float32) if needs_bwd else None
             _run(lib.fsgs_live_prepare, (D, ptr(means2d), ptr(conics), ptr(colors), ptr(opacities), tw,
                                         tile_bits(tw * th), ptr(isect_ids), ptr(flatten_ids), M, ptr(mask8),
                                         ptr(pos4), ptr(records), ptr(scratch), sbytes, stream_ptr(dev)),
                  "fsgs_live_prepare", f"_d{D}")
             _run(lib.fsgs_raster_fwd_live, (Cn, D, ptr(records), ptr(pos4), ptr(isect_offsets), M,
                                            ptr(backgrounds), width, height, tw, th, ptr(render), ptr(alphas),
-                                           ptr(last_ids), stream_ptr(dev)), "fsgs_raster_fwd_live", f"_d{D}")
+                                           ptr(last_ids), ptr(seg_state), stream_ptr(dev)),
+                 "fsgs_raster_fwd_live", f"_d{D}")
             ctx.save_for_backward(records, pos4,
                                   backgrounds if backgrounds is not None else torch.empty(0, device=dev),
-                                  isect_offsets, alphas, last_ids)
+                                  isect_offsets, alphas, last_ids, render,
+                                  seg_state if seg_state is not None else torch.empty(0, device=dev))
             # (grad mode is always off inside Function.forward: ask the tape, not torch.is_grad_enabled)
-            if any(ctx.needs_input_grad[:5]):
+            if needs_bwd:
                 ctx.arena = arena  # returned to the pool at the end of backward
             else:
                 ctx.arena = None
@@ -353,7 +359,7 @@ class _Rasterize(torch.autograd.Function):
         width, height, tile_size, absgrad, has_bg, live, Cn, N, D, M = ctx.dims
         lib = load()
         if live:
-            records, pos4, backgrounds, isect_offsets, alphas, last_ids = ctx.saved_tensors
+            records, pos4, backgrounds, isect_offsets, alphas, last_ids, render, seg_state = ctx.saved_tensors
         else:
             (means2d, conics, colors, opacities, backgrounds, isect_offsets, flatten_ids, alphas,
              last_ids) = ctx.saved_tensors
@@ -365,8 +371,8 @@ class _Rasterize(torch.autograd.Function):
             v_packed = torch.zeros(Cn * N, 16, dtype=torch.float32, device=dev)
             _run(lib.fsgs_raster_bwd_live, (Cn, D, ptr(records), ptr(pos4), ptr(isect_offsets), M,
                                            ptr(backgrounds) if has_bg else None, width, height, tw, th,
-                                           ptr(alphas), ptr(last_ids), ptr(v_render), ptr(v_alphas),
-                                           int(bool(absgrad)), ptr(v_packed), stream_ptr(dev)),
+                                           ptr(render), ptr(alphas), ptr(last_ids), ptr(v_render), ptr(v_alphas),
+                                           ptr(seg_state), int(bool(absgrad)), ptr(v_packed), stream_ptr(dev)),
                  "fsgs_raster_bwd_live", f"_d{D}")
             v_means2d = torch.empty(Cn, N, 2, dtype=torch.float32, device=dev)
             v_conics = torch.empty(Cn, N, 3, dtype=torch.float32, device=dev)

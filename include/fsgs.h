@@ -142,17 +142,22 @@ int fsgs_live_prepare(int D, const float *means2d, const float *conics, const fl
                       const float *opacities, int tile_width, int tile_bits, const int64_t *isect_ids,
                       const int32_t *flatten_ids, int64_t n_isects, uint8_t *mask8, int32_t *pos4,
                       float *records, void *scratch, size_t scratch_bytes, fsgs_stream_t stream);
+/* seg_state (nullable for inference): 4 * fsgs_live_seg_slots(...) * 64 * (1+D) floats; the forward
+ * stores every pixel's (T, accumulated colour) before each 64-entry segment of its quadrant list
+ * so that the backward can process segments independently. */
+int64_t fsgs_live_seg_slots(int C, int tile_width, int tile_height, int64_t n_isects);
 int fsgs_raster_fwd_live(int C, int D, const float *records, const int32_t *pos4,
                          const int32_t *isect_offsets, int64_t n_isects, const float *backgrounds,
                          int width, int height, int tile_width, int tile_height, float *render,
-                         float *alphas, int32_t *last_ids, fsgs_stream_t stream);
+                         float *alphas, int32_t *last_ids, float *seg_state, fsgs_stream_t stream);
 /* v_packed[C*N,16] f32, ACCUMULATED with atomics (zero it first): per (camera, Gaussian)
  * [0..3] v_colors [4..6] v_conics [7..8] v_means2d [9..10] v_means2d_abs [11] v_opacities. */
 int fsgs_raster_bwd_live(int C, int D, const float *records, const int32_t *pos4,
                          const int32_t *isect_offsets, int64_t n_isects, const float *backgrounds,
-                         int width, int height, int tile_width, int tile_height, const float *alphas,
-                         const int32_t *last_ids, const float *v_render, const float *v_alphas,
-                         int with_abs, float *v_packed, fsgs_stream_t stream);
+                         int width, int height, int tile_width, int tile_height, const float *render,
+                         const float *alphas, const int32_t *last_ids, const float *v_render,
+                         const float *v_alphas, const float *seg_state, int with_abs, float *v_packed,
+                         fsgs_stream_t stream);
 /* Split packed gradient records into the five gsplat-shaped arrays (written, not accumulated). */
 int fsgs_raster_unpack_grads(int64_t total, int D, const float *v_packed, float *v_means2d,
                              float *v_means2d_abs, float *v_conics, float *v_colors,
