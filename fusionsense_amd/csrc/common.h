@@ -47,6 +47,33 @@ __device__ __forceinline__ float wave_sum_to_last_row(float v) {
     return v;
 }
 
+// Sum 12 values within each 16-lane row (every lane of a row ends with the 12 row sums).
+// Hand-written: under -O3 hipcc SLP-packs the adds into v_pk_add_f32, which cannot carry a DPP
+// operand, and emits v_mov 0 + v_mov_dpp + v_pk_add per step (~2.5 instructions per value per
+// step).  Here each step is one v_add_f32_dpp per value.  The 12 chains are independent, so within
+// a block every DPP source was written >= 11 instructions earlier (the VALU-write -> DPP-read
+// hazard needs 2 wait states); the leading s_nop covers the first block's inputs.
+#define FSGS_DPP12(CTRL)                                                                                   \
+    "v_add_f32_dpp %0, %0, %0 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                                      \
+    "v_add_f32_dpp %1, %1, %1 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                                      \
+    "v_add_f32_dpp %2, %2, %2 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                                      \
+    "v_add_f32_dpp %3, %3, %3 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                                      \
+    "v_add_f32_dpp %4, %4, %4 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                                      \
+    "v_add_f32_dpp %5, %5, %5 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                                      \
+    "v_add_f32_dpp %6, %6, %6 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                                      \
+    "v_add_f32_dpp %7, %7, %7 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                                      \
+    "v_add_f32_dpp %8, %8, %8 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                                      \
+    "v_add_f32_dpp %9, %9, %9 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                                      \
+    "v_add_f32_dpp %10, %10, %10 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                                   \
+    "v_add_f32_dpp %11, %11, %11 " CTRL " row_mask:0xf bank_mask:0xf\n\t"
+
+__device__ __forceinline__ void row_sum16_x12(float (&g)[12]) {
+    asm volatile("s_nop 1\n\t" FSGS_DPP12("quad_perm:[1,0,3,2]") FSGS_DPP12("quad_perm:[2,3,0,1]")
+                     FSGS_DPP12("row_half_mirror") FSGS_DPP12("row_mirror")
+                 : "+v"(g[0]), "+v"(g[1]), "+v"(g[2]), "+v"(g[3]), "+v"(g[4]), "+v"(g[5]), "+v"(g[6]),
+                   "+v"(g[7]), "+v"(g[8]), "+v"(g[9]), "+v"(g[10]), "+v"(g[11]));
+}
+
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
 }  // namespace fsgs

@@ -20,7 +20,7 @@ namespace fsgs {
 template <int D>
 struct QLds {
     float4 r0[64], r1[64], r2[64];
-    float tot[16];
+    float tot[4][12];  // per 16-lane row partial sums of the 12 gradient components
 };
 
 struct Rec {
@@ -258,14 +258,13 @@ raster_bwd_live_kernel(int64_t cap, const float4 *__restrict__ rec, const int4 *
                     g[11] = vis * v_alpha;
                 }
             }
-#pragma unroll
-            for (int k = 0; k < 12; ++k) {
-                const bool used = (k < D) || (k >= 4 && k <= 8) || (ABS && (k == 9 || k == 10)) || (k == 11);
-                if (used) g[k] = wave_sum_to_last_row(g[k]);
-            }
-            if (lane == 63) {
-#pragma unroll
-                for (int k = 0; k < 12; ++k) L.tot[k] = g[k];
+            row_sum16_x12(g);
+            // the four row sums meet in LDS; lanes 0..11 finish the sum and issue ONE atomic
+            if ((lane & 15) == 15) {
+                float4 *dst = reinterpret_cast<float4 *>(&L.tot[lane >> 4][0]);
+                dst[0] = make_float4(g[0], g[1], g[2], g[3]);
+                dst[1] = make_float4(g[4], g[5], g[6], g[7]);
+                dst[2] = make_float4(g[8], g[9], g[10], g[11]);
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -273,8 +272,9 @@ raster_bwd_live_kernel(int64_t cap, const float4 *__restrict__ rec, const int4 *
                 const bool used = (lane < D) || (lane >= 4 && lane <= 8) || (ABS && (lane == 9 || lane == 10)) ||
                                   (lane == 11);
                 if (used) {
+                    const float tot = (L.tot[0][lane] + L.tot[1][lane]) + (L.tot[2][lane] + L.tot[3][lane]);
                     const int64_t gid = __float_as_int(a1.w);
-                    unsafeAtomicAdd(&v_packed[gid * 16 + lane], L.tot[lane]);
+                    unsafeAtomicAdd(&v_packed[gid * 16 + lane], tot);
                 }
             }
             __builtin_amdgcn_wave_barrier();

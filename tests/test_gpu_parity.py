@@ -368,6 +368,8 @@ def test_live_lists_equal_generic_walk(dev, res):
     # same entries in the same order per pixel; the two kernels may contract FMAs differently
     assert (a[0] - b[0]).abs().max().item() < 2e-6 and (a[1] - b[1]).abs().max().item() < 2e-6
     assert (a[2] != b[2]).float().mean().item() < 1e-3
+    # (the live backward restarts T / the colour suffix from the forward's saved segment states,
+    # the generic one reconstructs them by division: same maths, different fp32 rounding)
     for ga, gb in zip(a[3], b[3]):
-        assert rel_err(gb, ga) < 1e-4
-    assert rel_err(b[4], a[4]) < 1e-4
+        assert rel_err(gb, ga) < 5e-4
+    assert rel_err(b[4], a[4]) < 5e-4
