@@ -40,7 +40,8 @@ raster_fwd_live_kernel(int64_t cap, const float4 *__restrict__ rec, const int4 *
                        const int32_t *__restrict__ tile_offsets, int64_t n_isects,
                        const float *__restrict__ backgrounds, int W, int H, int tw, int th,
                        float *__restrict__ render, float *__restrict__ alphas,
-                       int32_t *__restrict__ last_ids, float *__restrict__ seg_state, int64_t seg_cap) {
+                       int32_t *__restrict__ last_ids, float *__restrict__ seg_state, int64_t seg_cap,
+                       int normalize_last) {
     __shared__ QLds<D> L;
     const int cam = blockIdx.z;
     const int tile_x = blockIdx.x >> 1, tile_y = blockIdx.y >> 1;
@@ -110,17 +111,16 @@ raster_fwd_live_kernel(int64_t cap, const float4 *__restrict__ rec, const int4 *
 
     if (inside) {
         const int64_t pix_id = ((int64_t)cam * H + i) * W + j;
+        if (backgrounds) {
+#pragma unroll
+            for (int k = 0; k < D; ++k) pix[k] += T * backgrounds[cam * D + k];
+        }
+        if (normalize_last) pix[D - 1] = pix[D - 1] / fmaxf(1.f - T, 1e-10f);  // expected depth
         if (D == 4) {
-            float4 o = make_float4(pix[0], pix[1], pix[2], pix[D - 1]);
-            if (backgrounds) {
-                const float *bg = backgrounds + cam * D;
-                o.x += T * bg[0]; o.y += T * bg[1]; o.z += T * bg[2]; o.w += T * bg[D - 1];
-            }
-            reinterpret_cast<float4 *>(render)[pix_id] = o;
+            reinterpret_cast<float4 *>(render)[pix_id] = make_float4(pix[0], pix[1], pix[2], pix[D - 1]);
         } else {
 #pragma unroll
-            for (int k = 0; k < D; ++k)
-                render[pix_id * D + k] = pix[k] + (backgrounds ? T * backgrounds[cam * D + k] : 0.f);
+            for (int k = 0; k < D; ++k) render[pix_id * D + k] = pix[k];
         }
         alphas[pix_id] = 1.f - T;
         last_ids[pix_id] = cur_idx;
@@ -152,7 +152,7 @@ raster_bwd_live_kernel(int64_t cap, const float4 *__restrict__ rec, const int4 *
                        const float *__restrict__ render, const float *__restrict__ alphas,
                        const int32_t *__restrict__ last_ids, const float *__restrict__ v_render,
                        const float *__restrict__ v_alphas, const float *__restrict__ seg_state,
-                       int64_t seg_cap, float *__restrict__ v_packed) {
+                       int64_t seg_cap, float *__restrict__ v_packed, int normalize_last) {
     __shared__ QLds<D> Lw[kBwdWaves];
     const int cam = blockIdx.z;
     const int tile_x = blockIdx.x >> 1, tile_y = blockIdx.y >> 1;
@@ -176,14 +176,28 @@ raster_bwd_live_kernel(int64_t cap, const float4 *__restrict__ rec, const int4 *
     const float4 *stream = rec + 3 * ((int64_t)q * cap);
     const float *seg_q = seg_state + (int64_t)q * seg_cap * (64 * (1 + D));
 
-    const float T_final = 1.f - alphas[pix_id];
+    const float alpha_px = alphas[pix_id];
+    const float T_final = 1.f - alpha_px;
     float v_out[D], c_total[D];
 #pragma unroll
     for (int k = 0; k < D; ++k) {
         v_out[k] = inside ? v_render[pix_id * D + k] : 0.f;
-        c_total[k] = render[pix_id * D + k] - (backgrounds ? T_final * backgrounds[cam * D + k] : 0.f);
+        c_total[k] = render[pix_id * D + k];
     }
-    const float v_out_a = inside ? v_alphas[pix_id] : 0.f;
+    float v_out_a = inside ? v_alphas[pix_id] : 0.f;
+    if (normalize_last) {
+        // render[D-1] = acc / max(alpha, 1e-10): undo for the colour total, chain the two gradients
+        const float a_c = fmaxf(alpha_px, 1e-10f);
+        const float ed = c_total[D - 1];
+        c_total[D - 1] = ed * a_c;
+        const float v_ed = v_out[D - 1];
+        v_out[D - 1] = v_ed / a_c;
+        if (alpha_px > 1e-10f) v_out_a -= v_ed * ed / a_c;
+    }
+    if (backgrounds) {
+#pragma unroll
+        for (int k = 0; k < D; ++k) c_total[k] -= T_final * backgrounds[cam * D + k];
+    }
     float bg_dot = 0.f;
     if (backgrounds) {
 #pragma unroll
@@ -315,8 +329,8 @@ extern "C" int64_t fsgs_live_seg_slots(int C, int tile_width, int tile_height, i
 
 extern "C" int fsgs_raster_fwd_live(int C, int D, const float *records, const int32_t *pos4,
                                     const int32_t *isect_offsets, int64_t n_isects, const float *backgrounds,
-                                    int width, int height, int tile_width, int tile_height, float *render,
-                                    float *alphas, int32_t *last_ids, float *seg_state,
+                                    int width, int height, int tile_width, int tile_height, int normalize_last,
+                                    float *render, float *alphas, int32_t *last_ids, float *seg_state,
                                     fsgs_stream_t stream) {
     if (C < 0 || width < 0 || height < 0 || n_isects < 0) return FSGS_EINVAL;
     if (C == 0 || width == 0 || height == 0) return FSGS_OK;
@@ -330,7 +344,7 @@ extern "C" int fsgs_raster_fwd_live(int C, int D, const float *records, const in
 #define FSGS_FWD_LIVE(DD)                                                                                   \
     hipLaunchKernelGGL((raster_fwd_live_kernel<DD>), grid, dim3(64), 0, s, n_isects, rec, p4, isect_offsets, \
                        n_isects, backgrounds, width, height, tile_width, tile_height, render, alphas, last_ids,  \
-                       seg_state, seg_cap)
+                       seg_state, seg_cap, normalize_last)
     switch (D) {
         case 1: FSGS_FWD_LIVE(1); break;
         case 3: FSGS_FWD_LIVE(3); break;
@@ -343,8 +357,9 @@ extern "C" int fsgs_raster_fwd_live(int C, int D, const float *records, const in
 
 extern "C" int fsgs_raster_bwd_live(int C, int D, const float *records, const int32_t *pos4,
                                     const int32_t *isect_offsets, int64_t n_isects, const float *backgrounds,
-                                    int width, int height, int tile_width, int tile_height, const float *render,
-                                    const float *alphas, const int32_t *last_ids, const float *v_render,
+                                    int width, int height, int tile_width, int tile_height, int normalize_last,
+                                    const float *render, const float *alphas, const int32_t *last_ids,
+                                    const float *v_render,
                                     const float *v_alphas, const float *seg_state, int with_abs,
                                     float *v_packed, fsgs_stream_t stream) {
     if (C < 0 || width < 0 || height < 0 || n_isects < 0) return FSGS_EINVAL;
@@ -360,7 +375,7 @@ extern "C" int fsgs_raster_bwd_live(int C, int D, const float *records, const in
 #define FSGS_BWD_LIVE(DD, AA)                                                                                    \
     hipLaunchKernelGGL((raster_bwd_live_kernel<DD, AA>), grid, dim3(64 * kBwdWaves), 0, s, n_isects, rec, p4,   \
                        isect_offsets, n_isects, backgrounds, width, height, tile_width, tile_height, render,     \
-                       alphas, last_ids, v_render, v_alphas, seg_state, seg_cap, v_packed)
+                       alphas, last_ids, v_render, v_alphas, seg_state, seg_cap, v_packed, normalize_last)
     switch (D) {
         case 1: if (with_abs) FSGS_BWD_LIVE(1, true); else FSGS_BWD_LIVE(1, false); break;
         case 3: if (with_abs) FSGS_BWD_LIVE(3, true); else FSGS_BWD_LIVE(3, false); break;

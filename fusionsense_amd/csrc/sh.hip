@@ -251,9 +251,38 @@ sh_bwd_kernel(int C, int N, int K, int degree, const float *__restrict__ means,
     }
 }
 
+// Camera centres from world-to-camera matrices: campos = -A^-1 t for [A t; 0 1] (what
+// torch.inverse(viewmats)[:, :3, 3] yields in gsplat's rasterization()), one thread per camera,
+// no solver library and no host synchronisation.
+__global__ void campos_kernel(int C, const float *__restrict__ viewmats, float *__restrict__ campos) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float *m = viewmats + c * 16;
+    const float a = m[0], b = m[1], cc = m[2], d = m[4], e = m[5], f = m[6], g = m[8], h = m[9], i = m[10];
+    const float tx = m[3], ty = m[7], tz = m[11];
+    const float A = e * i - f * h, B = -(d * i - f * g), Cc = d * h - e * g;
+    const float det = a * A + b * B + cc * Cc;
+    const float id = 1.f / det;
+    // inverse = adj / det ; rows of the inverse:
+    const float i00 = A * id, i01 = -(b * i - cc * h) * id, i02 = (b * f - cc * e) * id;
+    const float i10 = B * id, i11 = (a * i - cc * g) * id, i12 = -(a * f - cc * d) * id;
+    const float i20 = Cc * id, i21 = -(a * h - b * g) * id, i22 = (a * e - b * d) * id;
+    campos[c * 3 + 0] = -(i00 * tx + i01 * ty + i02 * tz);
+    campos[c * 3 + 1] = -(i10 * tx + i11 * ty + i12 * tz);
+    campos[c * 3 + 2] = -(i20 * tx + i21 * ty + i22 * tz);
+}
+
 }  // namespace fsgs
 
 using namespace fsgs;
+
+extern "C" int fsgs_campos_from_viewmats(int C, const float *viewmats, float *campos, fsgs_stream_t stream) {
+    if (C < 0) return FSGS_EINVAL;
+    if (C == 0) return FSGS_OK;
+    if (!viewmats || !campos) return FSGS_EINVAL;
+    hipLaunchKernelGGL(campos_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, as_stream(stream), C, viewmats, campos);
+    return check_launch();
+}
 
 extern "C" int fsgs_sh_fwd(int C, int N, int K, int degree, const float *means, const float *campos,
                            const float *coeffs, const int32_t *radii, const float *depths,

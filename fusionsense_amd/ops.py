@@ -293,7 +293,7 @@ class _Rasterize(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, means2d, conics, colors, opacities, backgrounds, isect_offsets, flatten_ids, width,
-                height, tile_size, absgrad, isect_ids=None):
+                height, tile_size, absgrad, isect_ids=None, normalize_last=False):
         means2d_in = means2d
         means2d, conics, colors, opacities = map(_c, (means2d, conics, colors, opacities))
         backgrounds = _c(backgrounds)
@@ -307,6 +307,8 @@ class _Rasterize(torch.autograd.Function):
         alphas = torch.empty(Cn, height, width, 1, dtype=torch.float32, device=dev)
         last_ids = torch.empty(Cn, height, width, dtype=torch.int32, device=dev)
         live = USE_LIVE_LISTS and tile_size == 16 and isect_ids is not None
+        if normalize_last and not live:
+            raise ValueError("normalize_last is implemented by the live-list kernels only")
         if live:
             sbytes = lib.fsgs_live_scratch_bytes(M)
             rec_bytes = 4 * max(M, 1) * 48
@@ -327,8 +329,9 @@ class _Rasterize(torch.autograd.Function):
                                         ptr(pos4), ptr(records), ptr(scratch), sbytes, stream_ptr(dev)),
                  "fsgs_live_prepare", f"_d{D}")
             _run(lib.fsgs_raster_fwd_live, (Cn, D, ptr(records), ptr(pos4), ptr(isect_offsets), M,
-                                           ptr(backgrounds), width, height, tw, th, ptr(render), ptr(alphas),
-                                           ptr(last_ids), ptr(seg_state), stream_ptr(dev)),
+                                           ptr(backgrounds), width, height, tw, th, int(normalize_last),
+                                           ptr(render), ptr(alphas), ptr(last_ids), ptr(seg_state),
+                                           stream_ptr(dev)),
                  "fsgs_raster_fwd_live", f"_d{D}")
             ctx.save_for_backward(records, pos4,
                                   backgrounds if backgrounds is not None else torch.empty(0, device=dev),
@@ -348,7 +351,8 @@ class _Rasterize(torch.autograd.Function):
             ctx.save_for_backward(means2d, conics, colors, opacities,
                                   backgrounds if backgrounds is not None else torch.empty(0, device=dev),
                                   isect_offsets, flatten_ids, alphas, last_ids)
-        ctx.dims = (width, height, tile_size, absgrad, backgrounds is not None, live, Cn, N, D, M)
+        ctx.dims = (width, height, tile_size, absgrad, backgrounds is not None, live, Cn, N, D, M,
+                    bool(normalize_last))
         # the tensor object the caller holds (meta["means2d"]) receives `.absgrad` in backward
         ctx.means2d_obj = means2d_in
         ctx.mark_non_differentiable(last_ids)
@@ -356,7 +360,7 @@ class _Rasterize(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, v_render, v_alphas, _v_last):
-        width, height, tile_size, absgrad, has_bg, live, Cn, N, D, M = ctx.dims
+        width, height, tile_size, absgrad, has_bg, live, Cn, N, D, M, normalize_last = ctx.dims
         lib = load()
         if live:
             records, pos4, backgrounds, isect_offsets, alphas, last_ids, render, seg_state = ctx.saved_tensors
@@ -371,7 +375,8 @@ class _Rasterize(torch.autograd.Function):
             v_packed = torch.zeros(Cn * N, 16, dtype=torch.float32, device=dev)
             _run(lib.fsgs_raster_bwd_live, (Cn, D, ptr(records), ptr(pos4), ptr(isect_offsets), M,
                                            ptr(backgrounds) if has_bg else None, width, height, tw, th,
-                                           ptr(render), ptr(alphas), ptr(last_ids), ptr(v_render), ptr(v_alphas),
+                                           int(normalize_last), ptr(render), ptr(alphas), ptr(last_ids),
+                                           ptr(v_render), ptr(v_alphas),
                                            ptr(seg_state), int(bool(absgrad)), ptr(v_packed), stream_ptr(dev)),
                  "fsgs_raster_bwd_live", f"_d{D}")
             v_means2d = torch.empty(Cn, N, 2, dtype=torch.float32, device=dev)
@@ -403,7 +408,8 @@ class _Rasterize(torch.autograd.Function):
         if has_bg and ctx.needs_input_grad[4]:
             v_bg = (v_render * (1.0 - alphas)).sum(dim=(1, 2))
         ctx.means2d_obj = None
-        return (v_means2d, v_conics, v_colors, v_opacities, v_bg, None, None, None, None, None, None, None)
+        return (v_means2d, v_conics, v_colors, v_opacities, v_bg, None, None, None, None, None, None, None,
+                None)
 
 
 class _GaussianNormals(torch.autograd.Function):
@@ -530,3 +536,14 @@ class _SsimL1Loss(torch.autograd.Function):
 
 def ssim_l1_loss(pred: Tensor, gt: Tensor, ssim_lambda: float = 0.2) -> Tensor:
     return _SsimL1Loss.apply(pred, gt, float(ssim_lambda))
+
+
+def campos_from_viewmats(viewmats: Tensor) -> Tensor:
+    """torch.inverse(viewmats)[:, :3, 3] without a solver library or a host sync."""
+    lib = load()
+    viewmats = viewmats.detach().contiguous()
+    Cn = viewmats.shape[0]
+    campos = torch.empty(Cn, 3, dtype=torch.float32, device=viewmats.device)
+    _run(lib.fsgs_campos_from_viewmats, (Cn, ptr(viewmats), ptr(campos), stream_ptr(viewmats.device)),
+         "fsgs_campos_from_viewmats")
+    return campos

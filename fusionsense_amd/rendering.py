@@ -132,17 +132,19 @@ def rasterization(
     else:
         if viewmats.requires_grad:
             raise NotImplementedError("SH colours with a differentiable camera pose are not supported")
-        campos = torch.linalg.inv(viewmats.detach())[:, :3, 3].contiguous()
+        campos = ops.campos_from_viewmats(viewmats)
         cols = ops._SHColors.apply(means, colors, campos, radii, depths if want_depth else None,
                                    int(sh_degree))
     if want_depth and backgrounds is not None:
         backgrounds = torch.cat([backgrounds, torch.zeros(C, 1, device=dev)], dim=-1)
 
     D = cols.shape[-1]
+    expected_depth = render_mode in ("ED", "RGB+ED")
+    fused_ed = expected_depth and D in (1, 3, 4) and tile_size == 16 and ops.USE_LIVE_LISTS
     if D in (1, 3, 4):
         render, alphas, last_ids = ops._Rasterize.apply(
             means2d, conics, cols, opac, backgrounds, isect_offsets, flatten_ids, width, height, tile_size,
-            absgrad, isect_ids)
+            absgrad, isect_ids, fused_ed)
     else:
         # arbitrary channel counts: composite in chunks of <=4 channels over the same lists
         if absgrad:
@@ -163,7 +165,7 @@ def rasterization(
             outs.append(r[..., :w])
         render = torch.cat(outs, dim=-1)
 
-    if render_mode in ("ED", "RGB+ED"):
+    if expected_depth and not fused_ed:
         render = torch.cat([render[..., :-1], render[..., -1:] / alphas.clamp(min=1e-10)], dim=-1)
 
     meta = {

@@ -64,6 +64,8 @@ int fsgs_project_bwd(int C, int N, const float *means, const float *quats, const
  * depth-channel concat of render_mode "RGB+ED").
  * coeffs[N,K,3]; campos[C,3]; radii[C,N] mask; depths[C,N] (nullable -> no depth channel).
  * colors_out[C,N,D] with D = 3 (+1 if depths).  Gaussians with radii<=0 get rgb = 0.5. */
+/* campos[C,3] = torch.inverse(viewmats)[:, :3, 3] for affine world-to-camera matrices. */
+int fsgs_campos_from_viewmats(int C, const float *viewmats, float *campos, fsgs_stream_t stream);
 int fsgs_sh_fwd(int C, int N, int K, int degree, const float *means, const float *campos,
                 const float *coeffs, const int32_t *radii, const float *depths,
                 float *colors_out, fsgs_stream_t stream);
@@ -146,18 +148,22 @@ int fsgs_live_prepare(int D, const float *means2d, const float *conics, const fl
  * stores every pixel's (T, accumulated colour) before each 64-entry segment of its quadrant list
  * so that the backward can process segments independently. */
 int64_t fsgs_live_seg_slots(int C, int tile_width, int tile_height, int64_t n_isects);
+/* normalize_last != 0 implements render_mode "ED"/"RGB+ED" in-kernel: the last channel leaves as
+ * accumulated / max(alpha, 1e-10) (gsplat does this with three torch ops after the kernel), and
+ * the backward expects v_render's last channel to be the gradient of that normalised value. */
 int fsgs_raster_fwd_live(int C, int D, const float *records, const int32_t *pos4,
                          const int32_t *isect_offsets, int64_t n_isects, const float *backgrounds,
-                         int width, int height, int tile_width, int tile_height, float *render,
-                         float *alphas, int32_t *last_ids, float *seg_state, fsgs_stream_t stream);
+                         int width, int height, int tile_width, int tile_height, int normalize_last,
+                         float *render, float *alphas, int32_t *last_ids, float *seg_state,
+                         fsgs_stream_t stream);
 /* v_packed[C*N,16] f32, ACCUMULATED with atomics (zero it first): per (camera, Gaussian)
  * [0..3] v_colors [4..6] v_conics [7..8] v_means2d [9..10] v_means2d_abs [11] v_opacities. */
 int fsgs_raster_bwd_live(int C, int D, const float *records, const int32_t *pos4,
                          const int32_t *isect_offsets, int64_t n_isects, const float *backgrounds,
-                         int width, int height, int tile_width, int tile_height, const float *render,
-                         const float *alphas, const int32_t *last_ids, const float *v_render,
-                         const float *v_alphas, const float *seg_state, int with_abs, float *v_packed,
-                         fsgs_stream_t stream);
+                         int width, int height, int tile_width, int tile_height, int normalize_last,
+                         const float *render, const float *alphas, const int32_t *last_ids,
+                         const float *v_render, const float *v_alphas, const float *seg_state,
+                         int with_abs, float *v_packed, fsgs_stream_t stream);
 /* Split packed gradient records into the five gsplat-shaped arrays (written, not accumulated). */
 int fsgs_raster_unpack_grads(int64_t total, int D, const float *v_packed, float *v_means2d,
                              float *v_means2d_abs, float *v_conics, float *v_colors,
