@@ -35,12 +35,18 @@ SIGNATURES = {
     "fsgs_raster_fwd": (_i, [_i, _i, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _i64, _p, _p, _p, _p]),
     "fsgs_raster_bwd": (_i, [_i, _i, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "fsgs_live_scratch_bytes": (_sz, [_i64]),
-    "fsgs_live_prepare": (_i, [_i, _p, _p, _p, _p, _i, _i, _p, _p, _i64, _p, _p, _p, _p, _sz, _p]),
+    "fsgs_live_prepare": (_i, [_i, _p, _p, _p, _p, _p, _i, _i, _p, _p, _i64, _p, _p, _p, _p, _sz, _p]),
     "fsgs_live_seg_slots": (_i64, [_i, _i, _i, _i64]),
-    "fsgs_raster_fwd_live": (_i, [_i, _i, _p, _p, _p, _i64, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p]),
-    "fsgs_raster_bwd_live": (_i, [_i, _i, _p, _p, _p, _i64, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _i, _p, _p]),
+    "fsgs_raster_fwd_live": (_i, [_i, _i, _p, _p, _p, _i64, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p]),
+    "fsgs_raster_bwd_live": (_i, [_i, _i, _p, _p, _p, _i64, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p]),
     "fsgs_campos_from_viewmats": (_i, [_i, _p, _p, _p]),
-    "fsgs_raster_unpack_grads": (_i, [_i64, _i, _p, _p, _p, _p, _p, _p, _p]),
+    "fsgs_raster_unpack_grads": (_i, [_i64, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "fsgs_sh_fwd_split": (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "fsgs_sh_bwd_split": (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p]),
+    "fsgs_activate_fwd": (_i, [_i, _p, _p, _p, _p, _p]),
+    "fsgs_activate_bwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "fsgs_epilogue_fwd": (_i, [_i64, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p]),
+    "fsgs_epilogue_bwd": (_i, [_i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "fsgs_normals_fwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _p]),
     "fsgs_normals_bwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _p]),
     "fsgs_densify_stats": (_i, [_i, _p, _p, _f, _p, _p, _p, _p]),

@@ -74,6 +74,19 @@ __device__ __forceinline__ void row_sum16_x12(float (&g)[12]) {
                    "+v"(g[7]), "+v"(g[8]), "+v"(g[9]), "+v"(g[10]), "+v"(g[11]));
 }
 
+// three more values (the normal plane's colour gradients); consecutive steps of one value are
+// separated by the other two values' instructions = the 2 wait states the DPP read needs.
+#define FSGS_DPP3(CTRL)                                                  \
+    "v_add_f32_dpp %0, %0, %0 " CTRL " row_mask:0xf bank_mask:0xf\n\t"    \
+    "v_add_f32_dpp %1, %1, %1 " CTRL " row_mask:0xf bank_mask:0xf\n\t"    \
+    "v_add_f32_dpp %2, %2, %2 " CTRL " row_mask:0xf bank_mask:0xf\n\t"
+
+__device__ __forceinline__ void row_sum16_x3(float &a, float &b, float &c) {
+    asm volatile("s_nop 1\n\t" FSGS_DPP3("quad_perm:[1,0,3,2]") FSGS_DPP3("quad_perm:[2,3,0,1]")
+                     FSGS_DPP3("row_half_mirror") FSGS_DPP3("row_mirror")
+                 : "+v"(a), "+v"(b), "+v"(c));
+}
+
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
 }  // namespace fsgs

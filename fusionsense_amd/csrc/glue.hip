@@ -1,0 +1,175 @@
+// Caller-side glue of DNSplatterModel.get_outputs fused into a handful of kernels (SURVEY.md §8f
+// row N2 and the "fuse" notes of §8a-11 / §7): the reference performs these steps as ~60 separate
+// torch launches per iteration around its two rasterizer calls
+// (/root/reference/dn_splatter/dn_model.py:572-575 activations, :602-613 rgb / depth, :655-656 normals).
+//   activate_fwd/bwd : exp(scales), sigmoid(opacities) and their VJPs (+ the sum of the two
+//                      quaternion gradient streams: projection and normals)
+//   epilogue_fwd/bwd : rgb = clamp(render + (1-alpha) * bg, 0, 1); depth = alpha > 0 ? ED : max(ED);
+//                      normal = (n / |n| + 1) / 2
+// Elementwise, HBM-bound, coalesced; used by fusionsense_amd/fused.py only.
+#include "common.h"
+
+namespace fsgs {
+
+__global__ void __launch_bounds__(256)
+activate_fwd_kernel(int N, const float *__restrict__ log_scales, const float *__restrict__ opac_logit,
+                    float *__restrict__ scales, float *__restrict__ opac) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N * 3) scales[i] = expf(log_scales[i]);
+    if (i < N) opac[i] = 1.f / (1.f + expf(-opac_logit[i]));
+}
+
+__global__ void __launch_bounds__(256)
+activate_bwd_kernel(int N, const float *__restrict__ scales, const float *__restrict__ opac,
+                    const float *__restrict__ v_scales, const float *__restrict__ v_opac,
+                    const float *__restrict__ v_quats_a, const float *__restrict__ v_quats_b,
+                    float *__restrict__ v_log_scales, float *__restrict__ v_opac_logit,
+                    float *__restrict__ v_quats) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N * 3) v_log_scales[i] = v_scales[i] * scales[i];
+    if (i < N) {
+        const float s = opac[i];
+        v_opac_logit[i] = v_opac[i] * s * (1.f - s);
+    }
+    if (i < N * 4) v_quats[i] = v_quats_a[i] + (v_quats_b ? v_quats_b[i] : 0.f);
+}
+
+// one workgroup: max over the per-quadrant partial maxima
+__global__ void __launch_bounds__(1024)
+max_reduce_kernel(int n, const float *__restrict__ partial, float *__restrict__ out) {
+    __shared__ float red[16];
+    float m = 0.f;
+    for (int i = threadIdx.x; i < n; i += 1024) m = fmaxf(m, partial[i]);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float r = red[0];
+        for (int k = 1; k < 16; ++k) r = fmaxf(r, red[k]);
+        out[0] = r;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+epilogue_fwd_kernel(int64_t P, const float4 *__restrict__ render, const float *__restrict__ alphas,
+                    const float *__restrict__ render_extra, const float *__restrict__ bg,
+                    const float *__restrict__ max_last, float *__restrict__ rgb, float *__restrict__ depth,
+                    float *__restrict__ normal) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    const float4 r = render[p];
+    const float a = alphas[p];
+    const float t = 1.f - a;
+    rgb[p * 3 + 0] = fminf(fmaxf(r.x + t * bg[0], 0.f), 1.f);
+    rgb[p * 3 + 1] = fminf(fmaxf(r.y + t * bg[1], 0.f), 1.f);
+    rgb[p * 3 + 2] = fminf(fmaxf(r.z + t * bg[2], 0.f), 1.f);
+    depth[p] = (a > 0.f) ? r.w : max_last[0];
+    if (normal) {
+        const float nx = render_extra[p * 3 + 0], ny = render_extra[p * 3 + 1], nz = render_extra[p * 3 + 2];
+        const float inv = 1.f / sqrtf(nx * nx + ny * ny + nz * nz);
+        normal[p * 3 + 0] = (nx * inv + 1.f) * 0.5f;
+        normal[p * 3 + 1] = (ny * inv + 1.f) * 0.5f;
+        normal[p * 3 + 2] = (nz * inv + 1.f) * 0.5f;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+epilogue_bwd_kernel(int64_t P, const float4 *__restrict__ render, const float *__restrict__ alphas,
+                    const float *__restrict__ render_extra, const float *__restrict__ bg,
+                    const float *__restrict__ v_rgb, const float *__restrict__ v_depth,
+                    const float *__restrict__ v_normal, const float *__restrict__ v_alpha_in,
+                    float4 *__restrict__ v_render, float *__restrict__ v_alphas,
+                    float *__restrict__ v_render_extra) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    const float4 r = render[p];
+    const float a = alphas[p];
+    const float t = 1.f - a;
+    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+    float va = v_alpha_in ? v_alpha_in[p] : 0.f;
+    if (v_rgb) {
+        const float pre[3] = {r.x + t * bg[0], r.y + t * bg[1], r.z + t * bg[2]};
+        float gg[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            gg[k] = (pre[k] >= 0.f && pre[k] <= 1.f) ? v_rgb[p * 3 + k] : 0.f;
+            va -= bg[k] * gg[k];
+        }
+        g.x = gg[0]; g.y = gg[1]; g.z = gg[2];
+    }
+    if (v_depth) g.w = (a > 0.f) ? v_depth[p] : 0.f;
+    v_render[p] = g;
+    v_alphas[p] = va;
+    if (v_render_extra) {
+        float gx = 0.f, gy = 0.f, gz = 0.f;
+        if (v_normal) {
+            const float nx = render_extra[p * 3 + 0], ny = render_extra[p * 3 + 1], nz = render_extra[p * 3 + 2];
+            const float inv = 1.f / sqrtf(nx * nx + ny * ny + nz * nz);
+            const float ux = nx * inv, uy = ny * inv, uz = nz * inv;
+            const float hx = 0.5f * v_normal[p * 3 + 0], hy = 0.5f * v_normal[p * 3 + 1], hz = 0.5f * v_normal[p * 3 + 2];
+            const float d = hx * ux + hy * uy + hz * uz;
+            gx = (hx - d * ux) * inv; gy = (hy - d * uy) * inv; gz = (hz - d * uz) * inv;
+        }
+        v_render_extra[p * 3 + 0] = gx; v_render_extra[p * 3 + 1] = gy; v_render_extra[p * 3 + 2] = gz;
+    }
+}
+
+}  // namespace fsgs
+
+using namespace fsgs;
+
+extern "C" int fsgs_activate_fwd(int N, const float *log_scales, const float *opac_logit, float *scales,
+                                 float *opac, fsgs_stream_t stream) {
+    if (N < 0) return FSGS_EINVAL;
+    if (N == 0) return FSGS_OK;
+    if (!log_scales || !opac_logit || !scales || !opac) return FSGS_EINVAL;
+    hipLaunchKernelGGL(activate_fwd_kernel, dim3(ceil_div((int64_t)N * 3, 256)), dim3(256), 0, as_stream(stream),
+                       N, log_scales, opac_logit, scales, opac);
+    return check_launch();
+}
+
+extern "C" int fsgs_activate_bwd(int N, const float *scales, const float *opac, const float *v_scales,
+                                 const float *v_opac, const float *v_quats_a, const float *v_quats_b,
+                                 float *v_log_scales, float *v_opac_logit, float *v_quats,
+                                 fsgs_stream_t stream) {
+    if (N < 0) return FSGS_EINVAL;
+    if (N == 0) return FSGS_OK;
+    if (!scales || !opac || !v_scales || !v_opac || !v_quats_a || !v_log_scales || !v_opac_logit || !v_quats)
+        return FSGS_EINVAL;
+    hipLaunchKernelGGL(activate_bwd_kernel, dim3(ceil_div((int64_t)N * 4, 256)), dim3(256), 0, as_stream(stream),
+                       N, scales, opac, v_scales, v_opac, v_quats_a, v_quats_b, v_log_scales, v_opac_logit,
+                       v_quats);
+    return check_launch();
+}
+
+extern "C" int fsgs_epilogue_fwd(int64_t n_pixels, const float *render, const float *alphas,
+                                 const float *render_extra, const float *bg, const float *max_last_partial,
+                                 int n_partial, float *max_last, float *rgb, float *depth, float *normal,
+                                 fsgs_stream_t stream) {
+    if (n_pixels < 0 || n_partial < 0) return FSGS_EINVAL;
+    if (n_pixels == 0) return FSGS_OK;
+    if (!render || !alphas || !bg || !max_last_partial || !max_last || !rgb || !depth) return FSGS_EINVAL;
+    if (normal && !render_extra) return FSGS_EINVAL;
+    hipStream_t s = as_stream(stream);
+    hipLaunchKernelGGL(max_reduce_kernel, dim3(1), dim3(1024), 0, s, n_partial, max_last_partial, max_last);
+    hipLaunchKernelGGL(epilogue_fwd_kernel, dim3(ceil_div(n_pixels, 256)), dim3(256), 0, s, n_pixels,
+                       reinterpret_cast<const float4 *>(render), alphas, render_extra, bg, max_last, rgb, depth,
+                       normal);
+    return check_launch();
+}
+
+extern "C" int fsgs_epilogue_bwd(int64_t n_pixels, const float *render, const float *alphas,
+                                 const float *render_extra, const float *bg, const float *v_rgb,
+                                 const float *v_depth, const float *v_normal, const float *v_alpha_in,
+                                 float *v_render, float *v_alphas, float *v_render_extra,
+                                 fsgs_stream_t stream) {
+    if (n_pixels < 0) return FSGS_EINVAL;
+    if (n_pixels == 0) return FSGS_OK;
+    if (!render || !alphas || !bg || !v_render || !v_alphas) return FSGS_EINVAL;
+    if (v_render_extra && !render_extra) return FSGS_EINVAL;
+    hipLaunchKernelGGL(epilogue_bwd_kernel, dim3(ceil_div(n_pixels, 256)), dim3(256), 0, as_stream(stream),
+                       n_pixels, reinterpret_cast<const float4 *>(render), alphas, render_extra, bg, v_rgb, v_depth,
+                       v_normal, v_alpha_in, reinterpret_cast<float4 *>(v_render), v_alphas, v_render_extra);
+    return check_launch();
+}

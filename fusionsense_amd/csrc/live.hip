@@ -173,14 +173,17 @@ scan4_apply_kernel(int64_t n, const uint8_t *__restrict__ mask8, const int4 *__r
     }
 }
 
-// Records: rec[3*p+0] = {x, y, opacity, conic.a}; rec[3*p+1] = {conic.b, conic.c, bits(list index),
-// bits(Gaussian id)}; rec[3*p+2] = colour (D floats, zero padded).  Stream q starts at record q*cap.
+// Records (RS float4 each, RS = 3 or 4): [0] = {x, y, opacity, conic.a}; [1] = {conic.b, conic.c,
+// bits(list index), bits(Gaussian id)}; [2] = colour (D floats, zero padded); [3] (only when an
+// `extra` per-Gaussian 3-vector rides along, e.g. the normal plane) = {e0, e1, e2, 0}.
+// Stream q starts at record q*cap.
 template <int D>
 __global__ void __launch_bounds__(256)
 live_compact_kernel(int64_t M, int64_t cap, const uint8_t *__restrict__ mask8, const int4 *__restrict__ pos4,
                     const int32_t *__restrict__ flatten_ids, const float *__restrict__ means2d,
                     const float *__restrict__ conics, const float *__restrict__ colors,
-                    const float *__restrict__ opacities, float4 *__restrict__ rec) {
+                    const float *__restrict__ opacities, const float *__restrict__ extra,
+                    float4 *__restrict__ rec) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= M) return;
     const unsigned m = mask8[i];
@@ -200,11 +203,15 @@ live_compact_kernel(int64_t M, int64_t cap, const uint8_t *__restrict__ mask8, c
         if (D > 2) r2.z = colors[(int64_t)g * D + 2];
     }
     const int pq[4] = {p.x, p.y, p.z, p.w};
+    const int RS = extra ? 4 : 3;
+    float4 r3 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (extra) r3 = make_float4(extra[(int64_t)g * 3 + 0], extra[(int64_t)g * 3 + 1], extra[(int64_t)g * 3 + 2], 0.f);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         if (m & (1u << q)) {
-            float4 *dst = rec + 3 * ((int64_t)q * cap + pq[q]);
+            float4 *dst = rec + RS * ((int64_t)q * cap + pq[q]);
             dst[0] = r0; dst[1] = r1; dst[2] = r2;
+            if (extra) dst[3] = r3;
         }
     }
 }
@@ -220,7 +227,7 @@ extern "C" size_t fsgs_live_scratch_bytes(int64_t n_isects) {
 }
 
 extern "C" int fsgs_live_prepare(int D, const float *means2d, const float *conics, const float *colors,
-                                 const float *opacities, int tile_width, int tile_bits,
+                                 const float *opacities, const float *extra, int tile_width, int tile_bits,
                                  const int64_t *isect_ids, const int32_t *flatten_ids, int64_t n_isects,
                                  uint8_t *mask8, int32_t *pos4, float *records, void *scratch,
                                  size_t scratch_bytes, fsgs_stream_t stream) {
@@ -246,13 +253,13 @@ extern "C" int fsgs_live_prepare(int D, const float *means2d, const float *conic
         const int4 *p4 = reinterpret_cast<const int4 *>(pos4);
         if (D == 4)
             hipLaunchKernelGGL((live_compact_kernel<4>), grid, dim3(256), 0, s, n_isects, n_isects, mask8, p4,
-                               flatten_ids, means2d, conics, colors, opacities, rec);
+                               flatten_ids, means2d, conics, colors, opacities, extra, rec);
         else if (D == 3)
             hipLaunchKernelGGL((live_compact_kernel<3>), grid, dim3(256), 0, s, n_isects, n_isects, mask8, p4,
-                               flatten_ids, means2d, conics, colors, opacities, rec);
+                               flatten_ids, means2d, conics, colors, opacities, extra, rec);
         else
             hipLaunchKernelGGL((live_compact_kernel<1>), grid, dim3(256), 0, s, n_isects, n_isects, mask8, p4,
-                               flatten_ids, means2d, conics, colors, opacities, rec);
+                               flatten_ids, means2d, conics, colors, opacities, extra, rec);
     }
     return check_launch();
 }

@@ -17,32 +17,39 @@
 
 namespace fsgs {
 
-template <int D>
+// E = number of "extra" channels (0 or 3) composited in the same walk from the record's 4th
+// float4 — FusionSense's normal plane: background 1, and its gradient must not reach the projected
+// centres (xys are detached at /root/reference/dn_splatter/dn_model.py:638) nor absgrad.
+template <int E>
 struct QLds {
-    float4 r0[64], r1[64], r2[64];
-    float tot[4][12];  // per 16-lane row partial sums of the 12 gradient components
+    float4 r0[64], r1[64], r2[64], r3[E ? 64 : 1];
+    float tot[4][16];  // per 16-lane row partial sums of the gradient components
 };
 
 struct Rec {
-    float4 r0, r1, r2;
+    float4 r0, r1, r2, r3;
 };
 
+template <int E>
 __device__ __forceinline__ void load_rec(Rec &r, const float4 *__restrict__ rec, int64_t p, bool ok) {
     if (ok) {
-        const float4 *src = rec + 3 * p;
+        const float4 *src = rec + (E ? 4 : 3) * p;
         r.r0 = src[0]; r.r1 = src[1]; r.r2 = src[2];
+        if (E) r.r3 = src[3];
     }
 }
 
-template <int D>
+template <int D, int E>
 __global__ void __launch_bounds__(64)
 raster_fwd_live_kernel(int64_t cap, const float4 *__restrict__ rec, const int4 *__restrict__ pos4,
                        const int32_t *__restrict__ tile_offsets, int64_t n_isects,
                        const float *__restrict__ backgrounds, int W, int H, int tw, int th,
                        float *__restrict__ render, float *__restrict__ alphas,
                        int32_t *__restrict__ last_ids, float *__restrict__ seg_state, int64_t seg_cap,
-                       int normalize_last) {
-    __shared__ QLds<D> L;
+                       int normalize_last, float *__restrict__ render_extra,
+                       float *__restrict__ max_last_partial) {
+    __shared__ QLds<E> L;
+    constexpr int RS = E ? 4 : 3;
     const int cam = blockIdx.z;
     const int tile_x = blockIdx.x >> 1, tile_y = blockIdx.y >> 1;
     const int q = ((blockIdx.y & 1) << 1) | (blockIdx.x & 1);
@@ -59,25 +66,29 @@ raster_fwd_live_kernel(int64_t cap, const float4 *__restrict__ rec, const int4 *
     const int4 p0 = pos4[l0], p1 = pos4[l1];
     const int s = (q == 0) ? p0.x : (q == 1) ? p0.y : (q == 2) ? p0.z : p0.w;
     const int e = (q == 0) ? p1.x : (q == 1) ? p1.y : (q == 2) ? p1.z : p1.w;
-    const float4 *stream = rec + 3 * ((int64_t)q * cap);
+    const float4 *stream = rec + RS * ((int64_t)q * cap);
 
     float T = 1.f;
     int32_t cur_idx = 0;
-    float pix[D];
+    float pix[D], pxe[E ? E : 1];
 #pragma unroll
     for (int k = 0; k < D; ++k) pix[k] = 0.f;
+#pragma unroll
+    for (int k = 0; k < E; ++k) pxe[k] = 0.f;
 
     // State of every pixel AFTER each 64-entry segment of this quadrant's list (= before the next
     // one), for the segment-parallel backward: slot (b/64 + tile_lin) of stream q, b = the next
     // segment's first stream position, is unique per (quadrant, segment).
-    float *seg_q = seg_state ? seg_state + (int64_t)q * seg_cap * (64 * (1 + D)) : nullptr;
+    constexpr int SS = 64 * (1 + D + E);  // floats per segment-state slot
+    float *seg_q = seg_state ? seg_state + (int64_t)q * seg_cap * SS : nullptr;
     Rec r;
-    load_rec(r, stream, (int64_t)s + lane, s + lane < e);
+    load_rec<E>(r, stream, (int64_t)s + lane, s + lane < e);
     for (int b = s; b < e; b += 64) {
         __syncthreads();  // single wave: orders the previous batch's LDS reads before these writes
         L.r0[lane] = r.r0; L.r1[lane] = r.r1; L.r2[lane] = r.r2;
+        if (E) L.r3[lane] = r.r3;
         const int n = min(64, e - b);
-        load_rec(r, stream, (int64_t)b + 64 + lane, b + 64 + lane < e);
+        load_rec<E>(r, stream, (int64_t)b + 64 + lane, b + 64 + lane < e);
         __syncthreads();
         for (int t = 0; t < n && !done; ++t) {
             const float4 a0 = L.r0[t], a1 = L.r1[t];
@@ -96,15 +107,23 @@ raster_fwd_live_kernel(int64_t cap, const float4 *__restrict__ rec, const int4 *
             if (D > 1) pix[1] += c.y * vis;
             if (D > 2) pix[2] += c.z * vis;
             if (D > 3) pix[D - 1] += c.w * vis;
+            if (E) {
+                const float4 ce = L.r3[t];
+                pxe[0] += ce.x * vis;
+                if (E > 1) pxe[1] += ce.y * vis;
+                if (E > 2) pxe[E - 1] += ce.z * vis;
+            }
             cur_idx = __float_as_int(a1.z);
             T = next_T;
         }
         // written even when the wave stops early: the backward of THIS segment reads it
         if (seg_q && b + 64 < e) {
-            float *slot = seg_q + ((int64_t)((b + 64) >> 6) + tile_lin) * (64 * (1 + D));
+            float *slot = seg_q + ((int64_t)((b + 64) >> 6) + tile_lin) * SS;
             slot[lane] = T;
 #pragma unroll
             for (int k = 0; k < D; ++k) slot[64 * (1 + k) + lane] = pix[k];
+#pragma unroll
+            for (int k = 0; k < E; ++k) slot[64 * (1 + D + k) + lane] = pxe[k];
         }
         if (__all(done)) break;
     }
@@ -122,8 +141,18 @@ raster_fwd_live_kernel(int64_t cap, const float4 *__restrict__ rec, const int4 *
 #pragma unroll
             for (int k = 0; k < D; ++k) render[pix_id * D + k] = pix[k];
         }
+        if (E) {
+#pragma unroll
+            for (int k = 0; k < E; ++k) render_extra[pix_id * E + k] = pxe[k] + T;  // background = 1
+        }
         alphas[pix_id] = 1.f - T;
         last_ids[pix_id] = cur_idx;
+    }
+    if (max_last_partial) {  // per-wave max of the (normalised) last channel, for depth_im's fill value
+        float m = inside ? pix[D - 1] : 0.f;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d, 64));
+        if (lane == 0) max_last_partial[((int64_t)cam * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = m;
     }
 }
 
@@ -135,6 +164,7 @@ __device__ __forceinline__ int wave_max_i32q(int v) {
 
 // packed gradient record, 16 floats per (camera, Gaussian):
 //   [0..3] v_colors  [4..6] v_conics  [7..8] v_means2d  [9..10] v_means2d_abs  [11] v_opacities
+//   [12..14] v_extra (normal plane)
 //
 // Segment-parallel backward.  The forward saved every pixel's (T, accumulated colour) before each
 // 64-entry segment of its quadrant list, so the two recurrences of the back-to-front walk can be
@@ -144,7 +174,7 @@ __device__ __forceinline__ int wave_max_i32q(int v) {
 // removes the long-list tail that otherwise sets the kernel's duration.
 constexpr int kBwdWaves = 4;
 
-template <int D, bool ABS>
+template <int D, bool ABS, int E>
 __global__ void __launch_bounds__(64 * kBwdWaves)
 raster_bwd_live_kernel(int64_t cap, const float4 *__restrict__ rec, const int4 *__restrict__ pos4,
                        const int32_t *__restrict__ tile_offsets, int64_t n_isects,
@@ -152,15 +182,18 @@ raster_bwd_live_kernel(int64_t cap, const float4 *__restrict__ rec, const int4 *
                        const float *__restrict__ render, const float *__restrict__ alphas,
                        const int32_t *__restrict__ last_ids, const float *__restrict__ v_render,
                        const float *__restrict__ v_alphas, const float *__restrict__ seg_state,
-                       int64_t seg_cap, float *__restrict__ v_packed, int normalize_last) {
-    __shared__ QLds<D> Lw[kBwdWaves];
+                       int64_t seg_cap, float *__restrict__ v_packed, int normalize_last,
+                       const float *__restrict__ render_extra, const float *__restrict__ v_render_extra) {
+    __shared__ QLds<E> Lw[kBwdWaves];
+    constexpr int RS = E ? 4 : 3;
+    constexpr int SS = 64 * (1 + D + E);
     const int cam = blockIdx.z;
     const int tile_x = blockIdx.x >> 1, tile_y = blockIdx.y >> 1;
     const int q = ((blockIdx.y & 1) << 1) | (blockIdx.x & 1);
     const int tile_lin = (cam * th + tile_y) * tw + tile_x;
     const int n_tiles_total = gridDim.z * th * tw;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    QLds<D> &L = Lw[w];
+    QLds<E> &L = Lw[w];
     const int j = blockIdx.x * 8 + (lane & 7), i = blockIdx.y * 8 + (lane >> 3);
     const float px = (float)j + 0.5f, py = (float)i + 0.5f;
     const bool inside = (i < H) && (j < W);
@@ -173,8 +206,8 @@ raster_bwd_live_kernel(int64_t cap, const float4 *__restrict__ rec, const int4 *
     const int e = (q == 0) ? p1.x : (q == 1) ? p1.y : (q == 2) ? p1.z : p1.w;
     const int n_seg = (e - s + 63) >> 6;
     if (w >= n_seg) return;
-    const float4 *stream = rec + 3 * ((int64_t)q * cap);
-    const float *seg_q = seg_state + (int64_t)q * seg_cap * (64 * (1 + D));
+    const float4 *stream = rec + RS * ((int64_t)q * cap);
+    const float *seg_q = seg_state + (int64_t)q * seg_cap * SS;
 
     const float alpha_px = alphas[pix_id];
     const float T_final = 1.f - alpha_px;
@@ -198,6 +231,14 @@ raster_bwd_live_kernel(int64_t cap, const float4 *__restrict__ rec, const int4 *
 #pragma unroll
         for (int k = 0; k < D; ++k) c_total[k] -= T_final * backgrounds[cam * D + k];
     }
+    float v_oute[E ? E : 1], ce_total[E ? E : 1];
+    float bge_dot = 0.f;
+#pragma unroll
+    for (int k = 0; k < E; ++k) {
+        v_oute[k] = inside ? v_render_extra[pix_id * E + k] : 0.f;
+        ce_total[k] = render_extra[pix_id * E + k] - T_final;  // background = 1
+        bge_dot += v_oute[k];
+    }
     float bg_dot = 0.f;
     if (backgrounds) {
 #pragma unroll
@@ -211,22 +252,27 @@ raster_bwd_live_kernel(int64_t cap, const float4 *__restrict__ rec, const int4 *
         const int n = min(64, e - b0);
         // slot t holds stream position b0 + n - 1 - t (descending list order)
         Rec r;
-        load_rec(r, stream, (int64_t)b0 + n - 1 - lane, lane < n);
+        load_rec<E>(r, stream, (int64_t)b0 + n - 1 - lane, lane < n);
         L.r0[lane] = r.r0; L.r1[lane] = r.r1; L.r2[lane] = r.r2;
+        if (E) L.r3[lane] = r.r3;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         // nothing above wave_bin_final was composited by this wave's pixels
         if (__float_as_int(L.r1[n - 1].z) > wave_bin_final) continue;
-        float T, buffer[D];
+        float T, buffer[D], bufe[E ? E : 1];
         if (seg == n_seg - 1) {
             T = T_final;
 #pragma unroll
             for (int k = 0; k < D; ++k) buffer[k] = 0.f;
+#pragma unroll
+            for (int k = 0; k < E; ++k) bufe[k] = 0.f;
         } else {
-            const float *slot = seg_q + ((int64_t)((b0 + 64) >> 6) + tile_lin) * (64 * (1 + D));
+            const float *slot = seg_q + ((int64_t)((b0 + 64) >> 6) + tile_lin) * SS;
             T = slot[lane];
 #pragma unroll
             for (int k = 0; k < D; ++k) buffer[k] = c_total[k] - slot[64 * (1 + k) + lane];
+#pragma unroll
+            for (int k = 0; k < E; ++k) bufe[k] = ce_total[k] - slot[64 * (1 + D + k) + lane];
         }
         for (int t = 0; t < n; ++t) {
             const float4 a0 = L.r0[t], a1 = L.r1[t];
@@ -240,9 +286,11 @@ raster_bwd_live_kernel(int64_t cap, const float4 *__restrict__ rec, const int4 *
             if (sigma < 0.f || alpha < kAlphaMin) valid = false;
             if (!__any(valid)) continue;
 
-            float g[12];
+            float g[12], ge[E ? E : 1];
 #pragma unroll
             for (int k = 0; k < 12; ++k) g[k] = 0.f;
+#pragma unroll
+            for (int k = 0; k < E; ++k) ge[k] = 0.f;
             if (valid) {
                 const float4 c4 = L.r2[t];
                 const float col[4] = {c4.x, c4.y, c4.z, c4.w};
@@ -258,33 +306,48 @@ raster_bwd_live_kernel(int64_t cap, const float4 *__restrict__ rec, const int4 *
                 }
                 v_alpha += T_final * ra * v_out_a;
                 if (backgrounds) v_alpha -= T_final * ra * bg_dot;
+                float v_alpha_e = 0.f;  // the extra plane's share: conics / opacity only
+                if (E) {
+                    const float4 e4 = L.r3[t];
+                    const float ce[3] = {e4.x, e4.y, e4.z};
+#pragma unroll
+                    for (int k = 0; k < E; ++k) {
+                        ge[k] = fac * v_oute[k];
+                        v_alpha_e += (ce[k] * T - bufe[k] * ra) * v_oute[k];
+                        bufe[k] += ce[k] * fac;
+                    }
+                    v_alpha_e -= T_final * ra * bge_dot;
+                }
                 if (a0.z * vis <= kAlphaMax) {
-                    const float v_sigma = -a0.z * vis * v_alpha;
+                    const float v_sigma_xy = -a0.z * vis * v_alpha;
+                    const float v_sigma = -a0.z * vis * (v_alpha + v_alpha_e);
                     g[4] = 0.5f * v_sigma * dx * dx;
                     g[5] = v_sigma * dx * dy;
                     g[6] = 0.5f * v_sigma * dy * dy;
-                    g[7] = v_sigma * (a0.w * dx + a1.x * dy);
-                    g[8] = v_sigma * (a1.x * dx + a1.y * dy);
+                    g[7] = v_sigma_xy * (a0.w * dx + a1.x * dy);
+                    g[8] = v_sigma_xy * (a1.x * dx + a1.y * dy);
                     if (ABS) {
                         g[9] = fabsf(g[7]);
                         g[10] = fabsf(g[8]);
                     }
-                    g[11] = vis * v_alpha;
+                    g[11] = vis * (v_alpha + v_alpha_e);
                 }
             }
             row_sum16_x12(g);
+            if (E == 3) row_sum16_x3(ge[0], ge[1], ge[E - 1]);
             // the four row sums meet in LDS; lanes 0..11 finish the sum and issue ONE atomic
             if ((lane & 15) == 15) {
                 float4 *dst = reinterpret_cast<float4 *>(&L.tot[lane >> 4][0]);
                 dst[0] = make_float4(g[0], g[1], g[2], g[3]);
                 dst[1] = make_float4(g[4], g[5], g[6], g[7]);
                 dst[2] = make_float4(g[8], g[9], g[10], g[11]);
+                if (E) dst[3] = make_float4(ge[0], E > 1 ? ge[1] : 0.f, E > 2 ? ge[E - 1] : 0.f, 0.f);
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            if (lane < 12) {
+            if (lane < 12 + E) {
                 const bool used = (lane < D) || (lane >= 4 && lane <= 8) || (ABS && (lane == 9 || lane == 10)) ||
-                                  (lane == 11);
+                                  (lane == 11) || (lane >= 12);
                 if (used) {
                     const float tot = (L.tot[0][lane] + L.tot[1][lane]) + (L.tot[2][lane] + L.tot[3][lane]);
                     const int64_t gid = __float_as_int(a1.w);
@@ -300,10 +363,16 @@ raster_bwd_live_kernel(int64_t cap, const float4 *__restrict__ rec, const int4 *
 __global__ void __launch_bounds__(256)
 unpack_grads_kernel(int64_t total, int D, const float4 *__restrict__ v_packed, float *__restrict__ v_means2d,
                     float *__restrict__ v_means2d_abs, float *__restrict__ v_conics,
-                    float *__restrict__ v_colors, float *__restrict__ v_opacities) {
+                    float *__restrict__ v_colors, float *__restrict__ v_opacities,
+                    float *__restrict__ v_extra, float *__restrict__ v_last) {
     const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= total) return;
     const float4 a = v_packed[n * 4 + 0], b = v_packed[n * 4 + 1], c = v_packed[n * 4 + 2];
+    if (v_last) v_last[n] = (D == 4) ? a.w : ((D == 3) ? a.z : a.x);  // gradient of the last colour channel
+    if (v_extra) {
+        const float4 d = v_packed[n * 4 + 3];
+        v_extra[n * 3 + 0] = d.x; v_extra[n * 3 + 1] = d.y; v_extra[n * 3 + 2] = d.z;
+    }
     if (D == 4) {
         reinterpret_cast<float4 *>(v_colors)[n] = a;
     } else {
@@ -331,7 +400,7 @@ extern "C" int fsgs_raster_fwd_live(int C, int D, const float *records, const in
                                     const int32_t *isect_offsets, int64_t n_isects, const float *backgrounds,
                                     int width, int height, int tile_width, int tile_height, int normalize_last,
                                     float *render, float *alphas, int32_t *last_ids, float *seg_state,
-                                    fsgs_stream_t stream) {
+                                    float *render_extra, float *max_last_partial, fsgs_stream_t stream) {
     if (C < 0 || width < 0 || height < 0 || n_isects < 0) return FSGS_EINVAL;
     if (C == 0 || width == 0 || height == 0) return FSGS_OK;
     if (!pos4 || !isect_offsets || !render || !alphas || !last_ids || (n_isects > 0 && !records))
@@ -341,14 +410,19 @@ extern "C" int fsgs_raster_fwd_live(int C, int D, const float *records, const in
     const float4 *rec = reinterpret_cast<const float4 *>(records);
     const int4 *p4 = reinterpret_cast<const int4 *>(pos4);
     const int64_t seg_cap = fsgs_live_seg_slots(C, tile_width, tile_height, n_isects);
-#define FSGS_FWD_LIVE(DD)                                                                                   \
-    hipLaunchKernelGGL((raster_fwd_live_kernel<DD>), grid, dim3(64), 0, s, n_isects, rec, p4, isect_offsets, \
-                       n_isects, backgrounds, width, height, tile_width, tile_height, render, alphas, last_ids,  \
-                       seg_state, seg_cap, normalize_last)
+#define FSGS_FWD_LIVE(DD, EE)                                                                                     \
+    hipLaunchKernelGGL((raster_fwd_live_kernel<DD, EE>), grid, dim3(64), 0, s, n_isects, rec, p4, isect_offsets,   \
+                       n_isects, backgrounds, width, height, tile_width, tile_height, render, alphas, last_ids,   \
+                       seg_state, seg_cap, normalize_last, render_extra, max_last_partial)
+    if (render_extra) {
+        if (D != 4) return FSGS_EINVAL;  // the fused RGB+depth + normal-plane walk
+        FSGS_FWD_LIVE(4, 3);
+        return check_launch();
+    }
     switch (D) {
-        case 1: FSGS_FWD_LIVE(1); break;
-        case 3: FSGS_FWD_LIVE(3); break;
-        case 4: FSGS_FWD_LIVE(4); break;
+        case 1: FSGS_FWD_LIVE(1, 0); break;
+        case 3: FSGS_FWD_LIVE(3, 0); break;
+        case 4: FSGS_FWD_LIVE(4, 0); break;
         default: return FSGS_EINVAL;
     }
 #undef FSGS_FWD_LIVE
@@ -361,6 +435,7 @@ extern "C" int fsgs_raster_bwd_live(int C, int D, const float *records, const in
                                     const float *render, const float *alphas, const int32_t *last_ids,
                                     const float *v_render,
                                     const float *v_alphas, const float *seg_state, int with_abs,
+                                    const float *render_extra, const float *v_render_extra,
                                     float *v_packed, fsgs_stream_t stream) {
     if (C < 0 || width < 0 || height < 0 || n_isects < 0) return FSGS_EINVAL;
     if (C == 0 || width == 0 || height == 0 || n_isects == 0) return FSGS_OK;
@@ -372,14 +447,20 @@ extern "C" int fsgs_raster_bwd_live(int C, int D, const float *records, const in
     const dim3 grid(2 * tile_width, 2 * tile_height, C);
     const float4 *rec = reinterpret_cast<const float4 *>(records);
     const int4 *p4 = reinterpret_cast<const int4 *>(pos4);
-#define FSGS_BWD_LIVE(DD, AA)                                                                                    \
-    hipLaunchKernelGGL((raster_bwd_live_kernel<DD, AA>), grid, dim3(64 * kBwdWaves), 0, s, n_isects, rec, p4,   \
-                       isect_offsets, n_isects, backgrounds, width, height, tile_width, tile_height, render,     \
-                       alphas, last_ids, v_render, v_alphas, seg_state, seg_cap, v_packed, normalize_last)
+#define FSGS_BWD_LIVE(DD, AA, EE)                                                                                \
+    hipLaunchKernelGGL((raster_bwd_live_kernel<DD, AA, EE>), grid, dim3(64 * kBwdWaves), 0, s, n_isects, rec, p4, \
+                       isect_offsets, n_isects, backgrounds, width, height, tile_width, tile_height, render,      \
+                       alphas, last_ids, v_render, v_alphas, seg_state, seg_cap, v_packed, normalize_last,         \
+                       render_extra, v_render_extra)
+    if (render_extra) {
+        if (D != 4 || !v_render_extra) return FSGS_EINVAL;
+        if (with_abs) FSGS_BWD_LIVE(4, true, 3); else FSGS_BWD_LIVE(4, false, 3);
+        return check_launch();
+    }
     switch (D) {
-        case 1: if (with_abs) FSGS_BWD_LIVE(1, true); else FSGS_BWD_LIVE(1, false); break;
-        case 3: if (with_abs) FSGS_BWD_LIVE(3, true); else FSGS_BWD_LIVE(3, false); break;
-        case 4: if (with_abs) FSGS_BWD_LIVE(4, true); else FSGS_BWD_LIVE(4, false); break;
+        case 1: if (with_abs) FSGS_BWD_LIVE(1, true, 0); else FSGS_BWD_LIVE(1, false, 0); break;
+        case 3: if (with_abs) FSGS_BWD_LIVE(3, true, 0); else FSGS_BWD_LIVE(3, false, 0); break;
+        case 4: if (with_abs) FSGS_BWD_LIVE(4, true, 0); else FSGS_BWD_LIVE(4, false, 0); break;
         default: return FSGS_EINVAL;
     }
 #undef FSGS_BWD_LIVE
@@ -388,12 +469,13 @@ extern "C" int fsgs_raster_bwd_live(int C, int D, const float *records, const in
 
 extern "C" int fsgs_raster_unpack_grads(int64_t total, int D, const float *v_packed, float *v_means2d,
                                         float *v_means2d_abs, float *v_conics, float *v_colors,
-                                        float *v_opacities, fsgs_stream_t stream) {
+                                        float *v_opacities, float *v_extra, float *v_last,
+                                        fsgs_stream_t stream) {
     if (total < 0 || (D != 1 && D != 3 && D != 4)) return FSGS_EINVAL;
     if (total == 0) return FSGS_OK;
     if (!v_packed || !v_means2d || !v_conics || !v_colors || !v_opacities) return FSGS_EINVAL;
     hipLaunchKernelGGL(unpack_grads_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, as_stream(stream), total, D,
                        reinterpret_cast<const float4 *>(v_packed), v_means2d, v_means2d_abs, v_conics, v_colors,
-                       v_opacities);
+                       v_opacities, v_extra, v_last);
     return check_launch();
 }

@@ -94,9 +94,9 @@ constexpr int kShBlock = 256;
 // Stage `rows` consecutive records of `row_floats` floats (contiguous in HBM) into LDS with
 // a row pitch of row_floats+1 dwords.
 __device__ __forceinline__ void stage_rows(const float *__restrict__ src, int rows, int row_floats,
-                                           float *lds) {
+                                           float *lds, int pitch, int col_off) {
     const int total = rows * row_floats;
-    const int pitch = row_floats + 1;
+    lds += col_off;
     // src is 4-byte aligned only in general (row start = n0*K*3 floats); n0 is a multiple of 256
     // so the span start is 16-byte aligned whenever the tensor base is.
     const float4 *src4 = reinterpret_cast<const float4 *>(src);
@@ -120,14 +120,19 @@ __device__ __forceinline__ void stage_rows(const float *__restrict__ src, int ro
 __global__ void __launch_bounds__(kShBlock)
 sh_fwd_kernel(int C, int N, int K, int degree, const float *__restrict__ means,
               const float *__restrict__ campos, const float *__restrict__ coeffs,
-              const int32_t *__restrict__ radii, const float *__restrict__ depths,
-              float *__restrict__ colors_out) {
+              const float *__restrict__ coeffs_rest, const int32_t *__restrict__ radii,
+              const float *__restrict__ depths, float *__restrict__ colors_out) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int n0 = blockIdx.x * kShBlock;
     const int rows = min(kShBlock, N - n0);
     const int kk = (degree + 1) * (degree + 1);
     const int row_floats = K * 3;
-    stage_rows(coeffs + (int64_t)n0 * row_floats, rows, row_floats, lds);
+    if (coeffs_rest) {  // split storage: coeffs = features_dc [N,3], coeffs_rest = features_rest [N,K-1,3]
+        stage_rows(coeffs + (int64_t)n0 * 3, rows, 3, lds, row_floats + 1, 0);
+        if (K > 1) stage_rows(coeffs_rest + (int64_t)n0 * (row_floats - 3), rows, row_floats - 3, lds, row_floats + 1, 3);
+    } else {
+        stage_rows(coeffs + (int64_t)n0 * row_floats, rows, row_floats, lds, row_floats + 1, 0);
+    }
     __syncthreads();
     const int n = n0 + threadIdx.x;
     if (n >= N) return;
@@ -169,8 +174,9 @@ sh_fwd_kernel(int C, int N, int K, int degree, const float *__restrict__ means,
 __global__ void __launch_bounds__(kShBlock)
 sh_bwd_kernel(int C, int N, int K, int degree, const float *__restrict__ means,
               const float *__restrict__ campos, const float *__restrict__ coeffs,
-              const int32_t *__restrict__ radii, int D, const float *__restrict__ v_colors,
-              float *__restrict__ v_coeffs, float *__restrict__ v_means,
+              const float *__restrict__ coeffs_rest, const int32_t *__restrict__ radii, int D,
+              const float *__restrict__ v_colors, float *__restrict__ v_coeffs,
+              float *__restrict__ v_coeffs_rest, float *__restrict__ v_means,
               float *__restrict__ v_depths) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int n0 = blockIdx.x * kShBlock;
@@ -178,7 +184,12 @@ sh_bwd_kernel(int C, int N, int K, int degree, const float *__restrict__ means,
     const int kk = (degree + 1) * (degree + 1);
     const int row_floats = K * 3;
     const int pitch = row_floats + 1;
-    stage_rows(coeffs + (int64_t)n0 * row_floats, rows, row_floats, lds);
+    if (coeffs_rest) {
+        stage_rows(coeffs + (int64_t)n0 * 3, rows, 3, lds, pitch, 0);
+        if (K > 1) stage_rows(coeffs_rest + (int64_t)n0 * (row_floats - 3), rows, row_floats - 3, lds, pitch, 3);
+    } else {
+        stage_rows(coeffs + (int64_t)n0 * row_floats, rows, row_floats, lds, pitch, 0);
+    }
     __syncthreads();
     const int n = n0 + threadIdx.x;
     float *my = lds + threadIdx.x * pitch;
@@ -243,6 +254,20 @@ sh_bwd_kernel(int C, int N, int K, int degree, const float *__restrict__ means,
         }
     }
     __syncthreads();
+    if (v_coeffs_rest) {  // split gradient storage, mirroring the split inputs
+        float *dst_dc = v_coeffs + (int64_t)n0 * 3;
+        for (int i = threadIdx.x; i < rows * 3; i += kShBlock) {
+            const int r = i / 3, col = i - r * 3;
+            dst_dc[i] = lds[r * pitch + col];
+        }
+        const int rf = row_floats - 3;
+        float *dst_rest = v_coeffs_rest + (int64_t)n0 * rf;
+        for (int i = threadIdx.x; i < rows * rf; i += kShBlock) {
+            const int r = i / rf, col = i - r * rf;
+            dst_rest[i] = lds[r * pitch + 3 + col];
+        }
+        return;
+    }
     float *dst = v_coeffs + (int64_t)n0 * row_floats;
     const int total = rows * row_floats;
     for (int i = threadIdx.x; i < total; i += kShBlock) {
@@ -284,23 +309,38 @@ extern "C" int fsgs_campos_from_viewmats(int C, const float *viewmats, float *ca
     return check_launch();
 }
 
-extern "C" int fsgs_sh_fwd(int C, int N, int K, int degree, const float *means, const float *campos,
-                           const float *coeffs, const int32_t *radii, const float *depths,
-                           float *colors_out, fsgs_stream_t stream) {
+static int sh_fwd_impl(int C, int N, int K, int degree, const float *means, const float *campos,
+                       const float *coeffs, const float *coeffs_rest, const int32_t *radii, const float *depths,
+                       float *colors_out, fsgs_stream_t stream) {
     if (C < 0 || N < 0 || degree < 0 || degree > 4 || K < (degree + 1) * (degree + 1) || K > kMaxK)
         return FSGS_EINVAL;
     if ((int64_t)C * N == 0) return FSGS_OK;
     if (!means || !campos || !coeffs || !radii || !colors_out) return FSGS_EINVAL;
     const size_t lds_bytes = (size_t)kShBlock * (K * 3 + 1) * sizeof(float);
     hipLaunchKernelGGL(sh_fwd_kernel, dim3(ceil_div(N, kShBlock)), dim3(kShBlock), lds_bytes,
-                       as_stream(stream), C, N, K, degree, means, campos, coeffs, radii, depths,
+                       as_stream(stream), C, N, K, degree, means, campos, coeffs, coeffs_rest, radii, depths,
                        colors_out);
     return check_launch();
 }
 
-extern "C" int fsgs_sh_bwd(int C, int N, int K, int degree, const float *means, const float *campos,
-                           const float *coeffs, const int32_t *radii, int D, const float *v_colors,
-                           float *v_coeffs, float *v_means, float *v_depths, fsgs_stream_t stream) {
+extern "C" int fsgs_sh_fwd(int C, int N, int K, int degree, const float *means, const float *campos,
+                           const float *coeffs, const int32_t *radii, const float *depths,
+                           float *colors_out, fsgs_stream_t stream) {
+    return sh_fwd_impl(C, N, K, degree, means, campos, coeffs, nullptr, radii, depths, colors_out, stream);
+}
+
+extern "C" int fsgs_sh_fwd_split(int C, int N, int K, int degree, const float *means, const float *campos,
+                                 const float *features_dc, const float *features_rest, const int32_t *radii,
+                                 const float *depths, float *colors_out, fsgs_stream_t stream) {
+    if (!features_rest && K > 1) return FSGS_EINVAL;
+    return sh_fwd_impl(C, N, K, degree, means, campos, features_dc, features_rest ? features_rest : features_dc,
+                       radii, depths, colors_out, stream);
+}
+
+static int sh_bwd_impl(int C, int N, int K, int degree, const float *means, const float *campos,
+                       const float *coeffs, const float *coeffs_rest, const int32_t *radii, int D,
+                       const float *v_colors, float *v_coeffs, float *v_coeffs_rest, float *v_means,
+                       float *v_depths, fsgs_stream_t stream) {
     if (C < 0 || N < 0 || degree < 0 || degree > 4 || K < (degree + 1) * (degree + 1) || K > kMaxK ||
         (D != 3 && D != 4))
         return FSGS_EINVAL;
@@ -308,7 +348,24 @@ extern "C" int fsgs_sh_bwd(int C, int N, int K, int degree, const float *means, 
     if (!means || !campos || !coeffs || !radii || !v_colors || !v_coeffs || !v_means) return FSGS_EINVAL;
     const size_t lds_bytes = (size_t)kShBlock * (K * 3 + 1) * sizeof(float);
     hipLaunchKernelGGL(sh_bwd_kernel, dim3(ceil_div(N, kShBlock)), dim3(kShBlock), lds_bytes,
-                       as_stream(stream), C, N, K, degree, means, campos, coeffs, radii, D, v_colors,
-                       v_coeffs, v_means, v_depths);
+                       as_stream(stream), C, N, K, degree, means, campos, coeffs, coeffs_rest, radii, D, v_colors,
+                       v_coeffs, v_coeffs_rest, v_means, v_depths);
     return check_launch();
+}
+
+extern "C" int fsgs_sh_bwd(int C, int N, int K, int degree, const float *means, const float *campos,
+                           const float *coeffs, const int32_t *radii, int D, const float *v_colors,
+                           float *v_coeffs, float *v_means, float *v_depths, fsgs_stream_t stream) {
+    return sh_bwd_impl(C, N, K, degree, means, campos, coeffs, nullptr, radii, D, v_colors, v_coeffs, nullptr,
+                       v_means, v_depths, stream);
+}
+
+extern "C" int fsgs_sh_bwd_split(int C, int N, int K, int degree, const float *means, const float *campos,
+                                 const float *features_dc, const float *features_rest, const int32_t *radii,
+                                 int D, const float *v_colors, float *v_features_dc, float *v_features_rest,
+                                 float *v_means, float *v_depths, fsgs_stream_t stream) {
+    if ((!features_rest || !v_features_rest) && K > 1) return FSGS_EINVAL;
+    return sh_bwd_impl(C, N, K, degree, means, campos, features_dc, features_rest ? features_rest : features_dc,
+                       radii, D, v_colors, v_features_dc, v_features_rest ? v_features_rest : v_features_dc,
+                       v_means, v_depths, stream);
 }

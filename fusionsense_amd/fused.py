@@ -1,0 +1,239 @@
+"""``DNSplatterModel.get_outputs`` as ONE autograd node.
+
+Semantically identical to :func:`fusionsense_amd.fusion.render_fusionsense` — which mirrors the
+reference's op-by-op formulation (/root/reference/dn_splatter/dn_model.py:469-671) through the
+drop-in ``rasterization`` / ``rasterize_gaussians`` surface — but organised the way the hardware
+wants it:
+
+* the RGB+depth pass and the normal pass see the same centres, conics, opacities and sorted
+  lists, so they are composited in ONE walk over 64-byte live-list records (4 + 3 channels; the
+  normal plane's gradient is kept away from the projected centres and ``absgrad`` exactly as the
+  reference's ``xys.detach()`` does);
+* activations, SH evaluation straight from the split ``features_dc`` / ``features_rest``
+  storage, the rgb / depth / normal epilogue and all their VJPs are single kernels; no
+  ``torch.cat`` of the 192 B/Gaussian SH tensor, no per-op autograd nodes, no gradient
+  accumulation kernels;
+* gradients are written straight into views of the trainer's flat gradient slab.
+
+Everything goes through libfsgs.so; results are tested against the unfused path and the oracle.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional
+
+import torch
+from torch import Tensor
+
+from . import ops
+from ._lib import load, ptr, stream_ptr
+from .ops import WORKSPACE, _run, tile_bits
+from .scenes import Camera
+
+TILE = 16
+
+
+class FrameInfo:
+    """Per-frame side outputs (the ``meta`` of gsplat + what after_train reads)."""
+
+    def __init__(self):
+        self.radii = self.means2d = self.depths = self.conics = self.tiles_per_gauss = None
+        self.isect_ids = self.flatten_ids = self.isect_offsets = self.last_ids = None
+        self.absgrad: Optional[Tensor] = None  # [1,N,2], set by backward
+        self.normals_world = None
+        self.legacy_rule_diff = 0
+
+    def __getitem__(self, key):  # dict-style access like gsplat's meta
+        return getattr(self, key)
+
+
+def _camera_on_device(camera: Camera, dev) -> Dict[str, Tensor]:
+    """viewmat / K / c2w / campos as device tensors, computed once per (camera, device) on the host
+    (get_viewmat of dn_model.py:550 is a handful of 4x4 operations)."""
+    cache = camera.__dict__.setdefault("_dev_cache", {})
+    key = str(dev)
+    if key not in cache:
+        c2w = camera.c2w.to(torch.float32)
+        R = c2w[:3, :3] * torch.tensor([[1.0, -1.0, -1.0]])
+        Rinv = R.T
+        viewmat = torch.eye(4)
+        viewmat[:3, :3] = Rinv
+        viewmat[:3, 3] = -(Rinv @ c2w[:3, 3])
+        cache[key] = dict(viewmat=viewmat[None].contiguous().to(dev), K=camera.K()[None].contiguous().to(dev),
+                          c2w=c2w.contiguous().to(dev), campos=c2w[:3, 3][None].contiguous().to(dev))
+    return cache[key]
+
+
+class _FusedGetOutputs(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means, scales, quats, features_dc, features_rest, opacities, cam, width, height,
+                sh_degree, background, info: FrameInfo, grad_out: Optional[Dict[str, Tensor]]):
+        lib = load()
+        dev = means.device
+        sp = stream_ptr(dev)
+        N = means.shape[0]
+        K = 1 + features_rest.shape[1]
+        W, H = width, height
+        tw, th = math.ceil(W / TILE), math.ceil(H / TILE)
+        f32 = dict(dtype=torch.float32, device=dev)
+        means, scales, quats, features_dc, features_rest, opacities = (
+            t.contiguous() for t in (means, scales, quats, features_dc, features_rest, opacities))
+
+        scales_exp = torch.empty(N, 3, **f32)
+        opac_sig = torch.empty(N, **f32)
+        _run(lib.fsgs_activate_fwd, (N, ptr(scales), ptr(opacities), ptr(scales_exp), ptr(opac_sig), sp),
+             "fsgs_activate_fwd")
+        radii, means2d, depths, conics, _ = ops.project_fwd(means, quats, scales_exp, cam["viewmat"], cam["K"],
+                                                             W, H, 0.3, 0.01, 1e10, 0.0, False)
+        tpg, isect_ids, flatten_ids, rule_diff = ops.isect_tiles(means2d, radii, depths, TILE, tw, th,
+                                                                 legacy=False, sort=True, return_rule_diff=True)
+        offsets = ops.isect_offset_encode(isect_ids, 1, tw, th)
+        M = flatten_ids.numel()
+
+        colors = torch.empty(1, N, 4, **f32)
+        _run(lib.fsgs_sh_fwd_split, (1, N, K, sh_degree, ptr(means), ptr(cam["campos"]), ptr(features_dc),
+                                     ptr(features_rest), ptr(radii), ptr(depths), ptr(colors), sp),
+             "fsgs_sh_fwd_split")
+        normals_world = torch.empty(N, 3, **f32)
+        normals_cam = torch.empty(N, 3, **f32)
+        _run(lib.fsgs_normals_fwd, (N, ptr(quats), ptr(scales), ptr(means), ptr(cam["c2w"]), ptr(normals_world),
+                                    ptr(normals_cam), sp), "fsgs_normals_fwd")
+
+        needs_bwd = any(ctx.needs_input_grad[:6])
+        a = lambda n: (n + 255) // 256 * 256  # noqa: E731
+        sbytes = lib.fsgs_live_scratch_bytes(M)
+        rec_bytes = 4 * max(M, 1) * 64
+        pos_bytes = (M + 1) * 16
+        seg_slots = lib.fsgs_live_seg_slots(1, tw, th, M)
+        seg_bytes = 4 * seg_slots * 64 * (1 + 4 + 3) * 4 if needs_bwd else 0
+        arena = WORKSPACE.take(a(rec_bytes) + a(pos_bytes) + a(M + 1) + a(sbytes) + a(seg_bytes), dev)
+        o = 0
+        records = arena[o:o + rec_bytes].view(torch.float32); o += a(rec_bytes)
+        pos4 = arena[o:o + pos_bytes].view(torch.int32); o += a(pos_bytes)
+        mask8 = arena[o:o + M + 1]; o += a(M + 1)
+        scratch = arena[o:o + sbytes]; o += a(sbytes)
+        seg_state = arena[o:o + seg_bytes].view(torch.float32) if needs_bwd else None
+        _run(lib.fsgs_live_prepare, (4, ptr(means2d), ptr(conics), ptr(colors), ptr(opac_sig), ptr(normals_cam),
+                                    tw, tile_bits(tw * th), ptr(isect_ids), ptr(flatten_ids), M, ptr(mask8),
+                                    ptr(pos4), ptr(records), ptr(scratch), sbytes, sp), "fsgs_live_prepare", "_d4e3")
+
+        render = torch.empty(1, H, W, 4, **f32)
+        alphas = torch.empty(1, H, W, 1, **f32)
+        last_ids = torch.empty(1, H, W, dtype=torch.int32, device=dev)
+        render_extra = torch.empty(1, H, W, 3, **f32)
+        n_part = 4 * tw * th
+        max_part = torch.empty(n_part + 1, **f32)
+        _run(lib.fsgs_raster_fwd_live, (1, 4, ptr(records), ptr(pos4), ptr(offsets), M, None, W, H, tw, th, 1,
+                                       ptr(render), ptr(alphas), ptr(last_ids), ptr(seg_state), ptr(render_extra),
+                                       ptr(max_part), sp), "fsgs_raster_fwd_live", "_d4e3")
+        rgb = torch.empty(H, W, 3, **f32)
+        depth = torch.empty(H, W, 1, **f32)
+        normal = torch.empty(H, W, 3, **f32)
+        _run(lib.fsgs_epilogue_fwd, (H * W, ptr(render), ptr(alphas), ptr(render_extra), ptr(background),
+                                    ptr(max_part), n_part, max_part[n_part:].data_ptr(), ptr(rgb), ptr(depth),
+                                    ptr(normal), sp), "fsgs_epilogue_fwd")
+
+        info.radii, info.means2d, info.depths, info.conics = radii, means2d, depths, conics
+        info.tiles_per_gauss, info.isect_ids, info.flatten_ids = tpg, isect_ids, flatten_ids
+        info.isect_offsets, info.last_ids, info.normals_world = offsets, last_ids, normals_world
+        info.legacy_rule_diff = rule_diff
+
+        if needs_bwd:
+            ctx.save_for_backward(means, scales, quats, features_dc, features_rest, scales_exp, opac_sig, radii,
+                                  conics, records, pos4, offsets, render, alphas, last_ids, render_extra, seg_state,
+                                  background)
+            ctx.arena = arena
+        else:
+            WORKSPACE.give(arena)
+        ctx.cam = cam
+        ctx.dims = (N, K, W, H, tw, th, M, sh_degree)
+        ctx.info = info
+        ctx.grad_out = grad_out
+        return rgb, depth, normal, alphas[0]
+
+    @staticmethod
+    def backward(ctx, v_rgb, v_depth, v_normal, v_alpha_out):
+        (means, scales, quats, features_dc, features_rest, scales_exp, opac_sig, radii, conics, records, pos4,
+         offsets, render, alphas, last_ids, render_extra, seg_state, background) = ctx.saved_tensors
+        N, K, W, H, tw, th, M, sh_degree = ctx.dims
+        cam = ctx.cam
+        lib = load()
+        dev = means.device
+        sp = stream_ptr(dev)
+        f32 = dict(dtype=torch.float32, device=dev)
+        c = lambda t: None if t is None else t.contiguous()  # noqa: E731
+        v_rgb, v_depth, v_normal, v_alpha_out = c(v_rgb), c(v_depth), c(v_normal), c(v_alpha_out)
+
+        v_render = torch.empty(1, H, W, 4, **f32)
+        v_alphas = torch.empty(1, H, W, 1, **f32)
+        v_render_extra = torch.empty(1, H, W, 3, **f32)
+        _run(lib.fsgs_epilogue_bwd, (H * W, ptr(render), ptr(alphas), ptr(render_extra), ptr(background), ptr(v_rgb),
+                                    ptr(v_depth), ptr(v_normal), ptr(v_alpha_out), ptr(v_render), ptr(v_alphas),
+                                    ptr(v_render_extra), sp), "fsgs_epilogue_bwd")
+        v_packed = torch.zeros(N, 16, **f32)
+        _run(lib.fsgs_raster_bwd_live, (1, 4, ptr(records), ptr(pos4), ptr(offsets), M, None, W, H, tw, th, 1,
+                                       ptr(render), ptr(alphas), ptr(last_ids), ptr(v_render), ptr(v_alphas),
+                                       ptr(seg_state), 1, ptr(render_extra), ptr(v_render_extra), ptr(v_packed), sp),
+             "fsgs_raster_bwd_live", "_d4e3")
+        v_means2d = torch.empty(1, N, 2, **f32)
+        v_abs = torch.empty(1, N, 2, **f32)
+        v_conics = torch.empty(1, N, 3, **f32)
+        v_colors = torch.empty(1, N, 4, **f32)
+        v_opac = torch.empty(N, **f32)
+        v_ncam = torch.empty(N, 3, **f32)
+        v_depths = torch.empty(1, N, **f32)
+        _run(lib.fsgs_raster_unpack_grads, (N, 4, ptr(v_packed), ptr(v_means2d), ptr(v_abs), ptr(v_conics),
+                                           ptr(v_colors), ptr(v_opac), ptr(v_ncam), ptr(v_depths), sp),
+             "fsgs_raster_unpack_grads")
+        WORKSPACE.give(getattr(ctx, "arena", None))
+        ctx.arena = None
+        ctx.info.absgrad = v_abs
+
+        # final gradients go straight into the caller's buffers (views of the gradient slab) if given
+        go = ctx.grad_out or {}
+
+        def out(name, like):
+            t = go.get(name)
+            return t if t is not None else torch.empty_like(like)
+
+        g_means, g_scales, g_quats = out("means", means), out("scales", scales), out("quats", quats)
+        g_dc, g_rest = out("features_dc", features_dc), out("features_rest", features_rest)
+        g_opac = out("opacities", opac_sig.view(N, 1))
+        v_quats_a = torch.empty(N, 4, **f32)
+        v_scales_exp = torch.empty(N, 3, **f32)
+        _run(lib.fsgs_project_bwd, (1, N, ptr(means), ptr(quats), ptr(scales_exp), ptr(cam["viewmat"]), ptr(cam["K"]),
+                                   W, H, 0.3, ptr(radii), ptr(conics), None, ptr(v_means2d), ptr(v_depths),
+                                   ptr(v_conics), None, ptr(g_means), ptr(v_quats_a), ptr(v_scales_exp), None, sp),
+             "fsgs_project_bwd")
+        _run(lib.fsgs_sh_bwd_split, (1, N, K, sh_degree, ptr(means), ptr(cam["campos"]), ptr(features_dc),
+                                     ptr(features_rest), ptr(radii), 4, ptr(v_colors), ptr(g_dc), ptr(g_rest),
+                                     ptr(g_means), None, sp), "fsgs_sh_bwd_split")
+        v_quats_b = torch.empty(N, 4, **f32)
+        _run(lib.fsgs_normals_bwd, (N, ptr(quats), ptr(scales), ptr(means), ptr(cam["c2w"]), ptr(v_ncam),
+                                    ptr(v_quats_b), sp), "fsgs_normals_bwd")
+        _run(lib.fsgs_activate_bwd, (N, ptr(scales_exp), ptr(opac_sig), ptr(v_scales_exp), ptr(v_opac),
+                                    ptr(v_quats_a), ptr(v_quats_b), ptr(g_scales), ptr(g_opac), ptr(g_quats), sp),
+             "fsgs_activate_bwd")
+        if ctx.grad_out:
+            # already written into the caller's gradient buffers (the trainer's slab views, which ARE the
+            # parameters' .grad): returning them as well would make autograd add them a second time
+            return (None,) * 13
+        return (g_means, g_scales, g_quats, g_dc, g_rest, g_opac, None, None, None, None, None, None, None)
+
+
+def render_fusionsense_fused(gauss_params: Dict[str, Tensor], camera: Camera, sh_degree: int = 3,
+                             background: Optional[Tensor] = None, device: Optional[torch.device] = None,
+                             grad_out: Optional[Dict[str, Tensor]] = None) -> Dict[str, Tensor]:
+    """Same outputs as :func:`fusionsense_amd.fusion.render_fusionsense` (rgb, depth, normal,
+    accumulation, radii, normals_world, ...), computed by one fused autograd node."""
+    dev = device or gauss_params["means"].device
+    if background is None:
+        background = torch.ones(3, device=dev)
+    cam = _camera_on_device(camera, dev)
+    info = FrameInfo()
+    rgb, depth, normal, alpha = _FusedGetOutputs.apply(
+        gauss_params["means"], gauss_params["scales"], gauss_params["quats"], gauss_params["features_dc"],
+        gauss_params["features_rest"], gauss_params["opacities"], cam, camera.width, camera.height, int(sh_degree),
+        background.contiguous(), info, grad_out)
+    return {"rgb": rgb, "depth": depth, "normal": normal, "accumulation": alpha, "background": background,
+            "info": info, "xys": info, "radii": info.radii[0], "normals_world": info.normals_world}

@@ -324,13 +324,13 @@ class _Rasterize(torch.autograd.Function):
             scratch = arena[o + a(M + 1):o + a(M + 1) + sbytes]
             o2 = o + a(M + 1) + a(sbytes)
             seg_state = arena[o2:o2 + seg_bytes].view(torch.float32) if needs_bwd else None
-            _run(lib.fsgs_live_prepare, (D, ptr(means2d), ptr(conics), ptr(colors), ptr(opacities), tw,
+            _run(lib.fsgs_live_prepare, (D, ptr(means2d), ptr(conics), ptr(colors), ptr(opacities), None, tw,
                                         tile_bits(tw * th), ptr(isect_ids), ptr(flatten_ids), M, ptr(mask8),
                                         ptr(pos4), ptr(records), ptr(scratch), sbytes, stream_ptr(dev)),
                  "fsgs_live_prepare", f"_d{D}")
             _run(lib.fsgs_raster_fwd_live, (Cn, D, ptr(records), ptr(pos4), ptr(isect_offsets), M,
                                            ptr(backgrounds), width, height, tw, th, int(normalize_last),
-                                           ptr(render), ptr(alphas), ptr(last_ids), ptr(seg_state),
+                                           ptr(render), ptr(alphas), ptr(last_ids), ptr(seg_state), None, None,
                                            stream_ptr(dev)),
                  "fsgs_raster_fwd_live", f"_d{D}")
             ctx.save_for_backward(records, pos4,
@@ -377,7 +377,8 @@ class _Rasterize(torch.autograd.Function):
                                            ptr(backgrounds) if has_bg else None, width, height, tw, th,
                                            int(normalize_last), ptr(render), ptr(alphas), ptr(last_ids),
                                            ptr(v_render), ptr(v_alphas),
-                                           ptr(seg_state), int(bool(absgrad)), ptr(v_packed), stream_ptr(dev)),
+                                           ptr(seg_state), int(bool(absgrad)), None, None, ptr(v_packed),
+                                           stream_ptr(dev)),
                  "fsgs_raster_bwd_live", f"_d{D}")
             v_means2d = torch.empty(Cn, N, 2, dtype=torch.float32, device=dev)
             v_conics = torch.empty(Cn, N, 3, dtype=torch.float32, device=dev)
@@ -385,7 +386,7 @@ class _Rasterize(torch.autograd.Function):
             v_opacities = torch.empty(Cn, N, dtype=torch.float32, device=dev)
             v_abs = torch.empty(Cn, N, 2, dtype=torch.float32, device=dev) if absgrad else None
             _run(lib.fsgs_raster_unpack_grads, (Cn * N, D, ptr(v_packed), ptr(v_means2d), ptr(v_abs),
-                                               ptr(v_conics), ptr(v_colors), ptr(v_opacities),
+                                               ptr(v_conics), ptr(v_colors), ptr(v_opacities), None, None,
                                                stream_ptr(dev)), "fsgs_raster_unpack_grads")
         else:
             v_means2d = torch.zeros_like(means2d)

@@ -67,8 +67,11 @@ class GradSlab:
 class SplatTrainer:
     def __init__(self, params: Dict[str, Tensor], device: torch.device, sh_degree: int = 3,
                  optim: Optional[OptimConfig] = None, fused_adam: bool = True, seed: int = 0,
-                 strategy=None):
+                 strategy=None, fused: bool = True):
         self.device = device
+        # fused=True: get_outputs as one autograd node (fusionsense_amd/fused.py); False: the
+        # reference's op-by-op caller through the drop-in rasterization()/rasterize_gaussians() surface
+        self.fused = fused
         self.sh_degree = sh_degree
         self.optim_cfg = optim or OptimConfig()
         self.params: Dict[str, torch.nn.Parameter] = {
@@ -97,8 +100,12 @@ class SplatTrainer:
         return self.params["means"].shape[0]
 
     def forward(self, camera: Camera, sh_degree_to_use: Optional[int] = None):
-        from .fusion import render_fusionsense
         deg = self.sh_degree if sh_degree_to_use is None else sh_degree_to_use
+        if self.fused:
+            from .fused import render_fusionsense_fused
+            return render_fusionsense_fused(self.params, camera, sh_degree=deg, device=self.device,
+                                            grad_out=self.slab.views if torch.is_grad_enabled() else None)
+        from .fusion import render_fusionsense
         return render_fusionsense(self.params, camera, sh_degree=deg, device=self.device)
 
     def loss(self, out, target) -> Tensor:
@@ -112,7 +119,8 @@ class SplatTrainer:
         return l
 
     def train_step(self, camera: Camera, target: Dict[str, Tensor], optimizer_step: bool = True):
-        self.slab.zero_()
+        if not self.fused:
+            self.slab.zero_()  # autograd accumulates into the slab views; the fused node overwrites them
         out = self.forward(camera)
         loss = self.loss(out, target)
         loss.backward()

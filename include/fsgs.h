@@ -77,6 +77,17 @@ int fsgs_sh_bwd(int C, int N, int K, int degree, const float *means, const float
                 const float *coeffs, const int32_t *radii, int D, const float *v_colors,
                 float *v_coeffs, float *v_means, float *v_depths, fsgs_stream_t stream);
 
+/* Same kernels with the SH coefficients in FusionSense's stored split form
+ * (gauss_params["features_dc"] [N,3] and ["features_rest"] [N,K-1,3], dn_model.py:294-304), which
+ * saves the 2 x 192 B/Gaussian torch.cat at dn_model.py:543 and the split of its gradient. */
+int fsgs_sh_fwd_split(int C, int N, int K, int degree, const float *means, const float *campos,
+                      const float *features_dc, const float *features_rest, const int32_t *radii,
+                      const float *depths, float *colors_out, fsgs_stream_t stream);
+int fsgs_sh_bwd_split(int C, int N, int K, int degree, const float *means, const float *campos,
+                      const float *features_dc, const float *features_rest, const int32_t *radii, int D,
+                      const float *v_colors, float *v_features_dc, float *v_features_rest,
+                      float *v_means, float *v_depths, fsgs_stream_t stream);
+
 /* ---- E4: isect_tiles (gsplat._C.isect_tiles), two passes --------------------------------------
  * Pass 1: tiles_per_gauss[C,N] i32 and its inclusive prefix sum cum_tiles[C,N] i64.
  * `legacy` != 0 selects the cuda_legacy bbox rule ((int)(c-r), (int)(c+r+1)) used by
@@ -140,8 +151,12 @@ int fsgs_raster_bwd(int C, int N, int D, const float *means2d, const float *coni
  *   records[4*M*12] f32 (stream q starts at record q*M; record = 3 x float4:
  *   {x,y,opacity,conic.a} {conic.b,conic.c,bits(list index),bits(flatten id)} {colour, zero padded}). */
 size_t fsgs_live_scratch_bytes(int64_t n_isects);
+/* extra (nullable): a second per-Gaussian 3-vector [C*N,3] (FusionSense's camera-space normals)
+ * carried in a 4th float4 of every record, so that RGB+depth and the normal plane are composited
+ * in ONE walk (records then take 64 B; records buffer = 4*M*16 floats). */
 int fsgs_live_prepare(int D, const float *means2d, const float *conics, const float *colors,
-                      const float *opacities, int tile_width, int tile_bits, const int64_t *isect_ids,
+                      const float *opacities, const float *extra, int tile_width, int tile_bits,
+                      const int64_t *isect_ids,
                       const int32_t *flatten_ids, int64_t n_isects, uint8_t *mask8, int32_t *pos4,
                       float *records, void *scratch, size_t scratch_bytes, fsgs_stream_t stream);
 /* seg_state (nullable for inference): 4 * fsgs_live_seg_slots(...) * 64 * (1+D) floats; the forward
@@ -155,19 +170,29 @@ int fsgs_raster_fwd_live(int C, int D, const float *records, const int32_t *pos4
                          const int32_t *isect_offsets, int64_t n_isects, const float *backgrounds,
                          int width, int height, int tile_width, int tile_height, int normalize_last,
                          float *render, float *alphas, int32_t *last_ids, float *seg_state,
-                         fsgs_stream_t stream);
+                         float *render_extra, float *max_last_partial, fsgs_stream_t stream);
+/* render_extra[C,H,W,3] (nullable; needs records prepared with `extra`, D == 4): the extra plane
+ * composited over a background of ones, exactly what gsplat.rasterize_gaussians returns for it.
+ * max_last_partial[C*2th*2tw] (nullable): per-quadrant maxima of the last output channel
+ * (FusionSense fills empty depth pixels with the image maximum, dn_model.py:611-613).
+ * seg_state then holds 64*(1+D+3) floats per slot. */
 /* v_packed[C*N,16] f32, ACCUMULATED with atomics (zero it first): per (camera, Gaussian)
- * [0..3] v_colors [4..6] v_conics [7..8] v_means2d [9..10] v_means2d_abs [11] v_opacities. */
+ * [0..3] v_colors [4..6] v_conics [7..8] v_means2d [9..10] v_means2d_abs [11] v_opacities
+ * [12..14] v_extra.  The extra plane's gradient reaches conics / opacities / its own colours but NOT
+ * v_means2d / v_means2d_abs (the reference detaches xys for that pass, dn_model.py:638). */
 int fsgs_raster_bwd_live(int C, int D, const float *records, const int32_t *pos4,
                          const int32_t *isect_offsets, int64_t n_isects, const float *backgrounds,
                          int width, int height, int tile_width, int tile_height, int normalize_last,
                          const float *render, const float *alphas, const int32_t *last_ids,
                          const float *v_render, const float *v_alphas, const float *seg_state,
-                         int with_abs, float *v_packed, fsgs_stream_t stream);
+                         int with_abs, const float *render_extra, const float *v_render_extra,
+                         float *v_packed, fsgs_stream_t stream);
 /* Split packed gradient records into the five gsplat-shaped arrays (written, not accumulated). */
 int fsgs_raster_unpack_grads(int64_t total, int D, const float *v_packed, float *v_means2d,
                              float *v_means2d_abs, float *v_conics, float *v_colors,
-                             float *v_opacities, fsgs_stream_t stream);
+                             float *v_opacities, float *v_extra, float *v_last, fsgs_stream_t stream);
+/* v_extra[C*N,3] and v_last[C*N] (the last colour channel's gradient, i.e. v_depths when the depth
+ * channel rides in colours) are optional outputs. */
 
 /* ---- a-11: per-Gaussian normals (dn_splatter/dn_model.py:618-636 as one kernel) ---------------
  * quats[N,4] (any norm), log_scales[N,3], means[N,3], c2w[3,4] (OpenGL) ->
@@ -202,6 +227,27 @@ int fsgs_compact_rows(int64_t n_rows, int row_floats, const uint8_t *keep,
 int fsgs_split_samples(int64_t S, int n_samples, const int64_t *ids, const float *means,
                        const float *quats, const float *log_scales, const float *randn,
                        float *new_means, float *new_log_scales, fsgs_stream_t stream);
+
+/* ---- caller-side glue of get_outputs, fused (csrc/glue.hip; used by fusionsense_amd/fused.py) -----
+ * activations of dn_model.py:573-574 and their VJPs (v_quats = v_quats_a + v_quats_b sums the
+ * projection and normal-pass gradient streams; v_quats_b nullable). */
+int fsgs_activate_fwd(int N, const float *log_scales, const float *opac_logit, float *scales,
+                      float *opac, fsgs_stream_t stream);
+int fsgs_activate_bwd(int N, const float *scales, const float *opac, const float *v_scales,
+                      const float *v_opac, const float *v_quats_a, const float *v_quats_b,
+                      float *v_log_scales, float *v_opac_logit, float *v_quats, fsgs_stream_t stream);
+/* dn_model.py:602-613, 655-656: rgb = clamp(render[:3] + (1-alpha) bg, 0, 1); depth = alpha > 0 ?
+ * render[3] : max(render[3]); normal = (n/|n| + 1)/2.  render [P,4], alphas [P], render_extra [P,3],
+ * bg [3]; max_last_partial from fsgs_raster_fwd_live.  bwd: any of v_rgb / v_depth / v_normal /
+ * v_alpha_in may be NULL (= zero); writes v_render [P,4], v_alphas [P], v_render_extra [P,3]. */
+int fsgs_epilogue_fwd(int64_t n_pixels, const float *render, const float *alphas,
+                      const float *render_extra, const float *bg, const float *max_last_partial,
+                      int n_partial, float *max_last, float *rgb, float *depth, float *normal,
+                      fsgs_stream_t stream);
+int fsgs_epilogue_bwd(int64_t n_pixels, const float *render, const float *alphas,
+                      const float *render_extra, const float *bg, const float *v_rgb,
+                      const float *v_depth, const float *v_normal, const float *v_alpha_in,
+                      float *v_render, float *v_alphas, float *v_render_extra, fsgs_stream_t stream);
 
 /* ---- N2: photometric loss on the render, fused (dn_splatter/dn_model.py:683 main loss with the
  * torchmetrics SSIM(kernel_size=11) of :244).  pred, gt: [H,W,3] channel-last.

@@ -419,3 +419,61 @@ def test_render_modes_fused_vs_generic(dev, mode):
     assert set(outs[0][2]) == set(outs[1][2])  # depth-only modes leave the SH coefficients untouched
     for k in outs[0][2]:
         assert rel_err(outs[0][2][k], outs[1][2][k]) < 2e-3, k
+
+
+def test_fused_get_outputs_matches_unfused_and_oracle(dev):
+    """One-node get_outputs (single 7-channel walk, fused glue) against the op-by-op caller that
+    goes through the drop-in surface, and against the CPU oracle, forward and gradients."""
+    from fusionsense_amd.fused import render_fusionsense_fused
+    from fusionsense_amd.fusion import render_fusionsense
+    from oracle.fusion_ref import render_fusionsense as render_ref
+    params, cam = scenes.cube_scene(1200, seed=31)
+    g = torch.Generator().manual_seed(3)
+    w_rgb, w_d, w_n, w_a = (torch.rand(128, 128, 3, generator=g), torch.rand(128, 128, 1, generator=g),
+                            torch.rand(128, 128, 3, generator=g), torch.rand(128, 128, 1, generator=g))
+
+    def run(fn, p, to=lambda t: t):
+        out = fn(p, cam)
+        loss = (out["rgb"] * to(w_rgb)).mean() + (out["depth"] * to(w_d)).mean() + \
+            (out["normal"] * to(w_n)).mean() + (out["accumulation"] * to(w_a)).mean()
+        loss.backward()
+        return out
+
+    pf = {k: v.to(dev).requires_grad_(True) for k, v in params.items()}
+    of = run(lambda p, c: render_fusionsense_fused(p, c, sh_degree=3, device=dev), pf, lambda t: t.to(dev))
+    pu = {k: v.to(dev).requires_grad_(True) for k, v in params.items()}
+    ou = run(lambda p, c: render_fusionsense(p, c, sh_degree=3, device=dev), pu, lambda t: t.to(dev))
+    pr = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    orf = run(lambda p, c: render_ref(p, c, sh_degree=3), pr)
+    for k in ("rgb", "depth", "accumulation"):
+        assert (of[k].detach() - ou[k].detach()).abs().max().item() < 2e-5, k
+        assert (of[k].detach().cpu() - orf[k].detach()).abs().max().item() < 1e-3, k
+    dn = (of["normal"].detach() - ou["normal"].detach()).abs()
+    assert dn.mean().item() < 1e-5 and (dn > 1e-2).float().mean().item() < 1e-3
+    for k in pf:
+        assert rel_err(pf[k].grad, pu[k].grad) < 2e-3, f"fused vs unfused grad {k}: {rel_err(pf[k].grad, pu[k].grad)}"
+        assert rel_err(pf[k].grad, pr[k].grad) < 1e-2, f"fused vs oracle grad {k}"
+    assert rel_err(of["info"].absgrad, ou["xys"].absgrad) < 2e-3
+    assert torch.equal(of["radii"], ou["radii"])
+    assert np.array_equal(of["info"]["flatten_ids"].cpu().numpy(), orf["info"]["flatten_ids"].numpy())
+
+
+def test_fused_trainer_step_equals_unfused(dev):
+    """Two trainers from the same state, fused vs op-by-op caller: same loss, same parameters after
+    an Adam step (gradients land in the slab views either way)."""
+    from fusionsense_amd.trainer import SplatTrainer
+    params, cam = scenes.cube_scene(900, seed=5)
+    target = {"rgb": torch.rand(128, 128, 3).to(dev), "depth": torch.rand(128, 128, 1).to(dev),
+              "normal": torch.rand(128, 128, 3).to(dev)}
+    res = []
+    for fused in (True, False):
+        tr = SplatTrainer(params, dev, fused=fused)
+        losses = [tr.train_step(cam, target)[0].item() for _ in range(3)]
+        res.append((losses, {k: v.detach().clone() for k, v in tr.params.items()},
+                    {k: tr.slab.views[k].clone() for k in tr.params}))
+    for a, b in zip(res[0][0], res[1][0]):
+        assert abs(a - b) < 1e-5 * max(1.0, abs(b)), (res[0][0], res[1][0])
+    for k in res[0][2]:
+        assert rel_err(res[0][2][k], res[1][2][k]) < 5e-3, f"slab grad {k}"
+    for k in res[0][1]:
+        assert (res[0][1][k] - res[1][1][k]).abs().max().item() < 5e-3, f"param {k} after 3 Adam steps"
