@@ -47,6 +47,9 @@ def parse():
     ap.add_argument("--res", type=int, default=800)
     ap.add_argument("--views", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--unfused-caller", action="store_true",
+                    help="drive the rasterizer through the drop-in rasterization()/rasterize_gaussians() "
+                         "surface with the reference's op-by-op caller glue instead of the fused get_outputs node")
     ap.add_argument("--cpu-crop", type=int, default=128, help="CPU-baseline sample: central crop edge")
     ap.add_argument("--cpu-timeout", type=float, default=150.0)
     ap.add_argument("--cpu-threads", type=int, default=8)
@@ -135,10 +138,10 @@ def main():
     log('scene built')
     # statistics only (no refinement inside the timed window: refine_every > steps)
     strategy = DensifyStrategy(SplatfactoConfig(), num_train_data=args.views, stats_only=True)
-    trainer = SplatTrainer(params, dev, sh_degree=3, strategy=strategy, seed=0)
+    trainer = SplatTrainer(params, dev, sh_degree=3, strategy=strategy, seed=0, fused=not args.unfused_caller)
 
     # targets: renders of a differently seeded scene, so gradients are non-trivial
-    tgt_tr = SplatTrainer(scenes.lego_like_scene(args.n_gauss, seed=1), dev, sh_degree=3)
+    tgt_tr = SplatTrainer(scenes.lego_like_scene(args.n_gauss, seed=1), dev, sh_degree=3, fused=not args.unfused_caller)
     targets = []
     with torch.no_grad():
         for ci, cam in enumerate(cams):
@@ -218,20 +221,36 @@ def main():
         key_bits = 32 + ops.tile_bits((W // 16 + (W % 16 > 0)) * (H // 16 + (H % 16 > 0)))
         sort_b = 2 * 12 * ((key_bits + 7) // 8)
         b_isect = 12 + sort_b + 8 + 44 + 44
-        reused = frame_cache.hits > 0 and frame_cache.misses == 0
+        fused = not args.unfused_caller
+        reused = fused or (frame_cache.hits > 0 and frame_cache.misses == 0)
         b_isect_normal = (40 + 40) if reused else (12 + sort_b + 8 + 40 + 40)
         b_iter = N * 352 + n_vis * 444 + M * (b_isect + b_isect_normal) + P * 92
-        # dominant kernel: raster_bwd of the RGB+ED pass (D=4, absgrad)
-        dom = "raster_bwd_d4"
-        dom_ms = kernel_ms.get(dom, {}).get("avg_ms")
-        dom_bytes = M * 44 + P * 28 + n_vis * 48
+        # dominant kernel = the libfsgs launch with the largest share of the step; algorithmic bytes
+        # per launch from the per-unit figures of SURVEY.md §8d
+        alg = {
+            "raster_bwd_live_d4e3": ("raster_bwd_live_kernel<4,true,3> (RGB+ED and normal plane, one walk)",
+                                     M * (44 + 40) + P * (28 + 20) + n_vis * (48 + 28)),
+            "raster_fwd_live_d4e3": ("raster_fwd_live_kernel<4,3>", M * (44 + 40) + P * (24 + 20)),
+            "raster_bwd_live_d4": ("raster_bwd_live_kernel<4,true,0>", M * 44 + P * 28 + n_vis * 48),
+            "raster_bwd_live_d3": ("raster_bwd_live_kernel<3,false,0>", M * 40 + P * 20 + n_vis * 28),
+            "raster_fwd_live_d4": ("raster_fwd_live_kernel<4,0>", M * 44 + P * 24),
+            "raster_fwd_live_d3": ("raster_fwd_live_kernel<3,0>", M * 40 + P * 20),
+            "raster_bwd_d4": ("raster_bwd_kernel<4,true>", M * 44 + P * 28 + n_vis * 48),
+            "sort_pairs": ("radix sort (hist + scan + scatter per 8-bit pass)", M * sort_b),
+            "live_prepare_d4e3": ("live_mask + scan4 + live_compact", M * (12 + 28) + int(0.42 * M) * 64),
+        }
+        cand = [(v["avg_ms"] * v["calls"], k) for k, v in kernel_ms.items() if k in alg]
         roofline = None
-        if dom_ms:
+        if cand:
+            _, dom = max(cand)
+            dom_ms = kernel_ms[dom]["avg_ms"]
+            name, dom_bytes = alg[dom]
             ach = dom_bytes / (dom_ms * 1e-3) / 1e9
-            roofline = {"kernel": "raster_bwd_kernel<4,true>", "bound": "hbm", "achieved": round(ach, 2),
-                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
-                        "traffic": None, "algorithmic_bytes": dom_bytes,
-                        "avg_launch_ms": round(dom_ms, 4)}
+            roofline = {"kernel": name, "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
+                        # PMC counters cannot be read from inside the timed process; the rocprofv3 --pmc
+                        # FETCH_SIZE / WRITE_SIZE figures for this kernel are in profiles/ 
+                        "traffic": None, "algorithmic_bytes": dom_bytes, "avg_launch_ms": round(dom_ms, 4)}
         line = {
             "metric": "train_iters_per_s",
             "value": round(iters_per_s, 3),
@@ -247,7 +266,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"BASELINE config #2: synthetic lego-like, {N} Gaussians, {W}x{H}, "
                                    "SH deg 3, RGB+ED + normal pass, fwd+bwd+Adam+densify stats, "
-                                   "1 view/rank/step",
+                                   "1 view/rank/step; caller = " + ("fused get_outputs node" if fused else
+                                                                    "reference-style op-by-op glue over the drop-in surface"),
                        "n_gaussians": N, "width": W, "height": H, "views": len(cams),
                        "n_isects": M, "n_visible": n_vis, "isects_per_gaussian": round(M / max(N, 1), 3),
                        "normal_pass_list_reuse": bool(reused), "parallelism": f"dp{world}"},

@@ -445,8 +445,9 @@ def test_fused_get_outputs_matches_unfused_and_oracle(dev):
     ou = run(lambda p, c: render_fusionsense(p, c, sh_degree=3, device=dev), pu, lambda t: t.to(dev))
     pr = {k: v.clone().requires_grad_(True) for k, v in params.items()}
     orf = run(lambda p, c: render_ref(p, c, sh_degree=3), pr)
-    for k in ("rgb", "depth", "accumulation"):
-        assert (of[k].detach() - ou[k].detach()).abs().max().item() < 2e-5, k
+    # expected depth = acc / alpha: at alpha ~ 1/255 one ulp of T moves it by ~5e-5
+    for k, tol in (("rgb", 2e-5), ("depth", 3e-4), ("accumulation", 2e-5)):
+        assert (of[k].detach() - ou[k].detach()).abs().max().item() < tol, k
         assert (of[k].detach().cpu() - orf[k].detach()).abs().max().item() < 1e-3, k
     dn = (of["normal"].detach() - ou["normal"].detach()).abs()
     assert dn.mean().item() < 1e-5 and (dn > 1e-2).float().mean().item() < 1e-3
