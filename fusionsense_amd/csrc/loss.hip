@@ -159,9 +159,76 @@ ssim_l1_bwd_kernel(int H, int W, const float *__restrict__ pred, const float *__
     v_pred[o] = up * (g_l1 * sgn + g_ssim * (a + 2.f * p * b + g * c));
 }
 
+// Auxiliary L1 terms of the FusionSense loss on the depth and normal images
+// (/root/reference/dn_splatter/dn_model.py:673-925: sensor-depth and normal supervision), one pass:
+// partial[blk] = (sum |depth - depth_gt|, sum |normal - normal_gt|); the backward writes
+// w * sign(.) / count straight into the two gradient images.
+__global__ void __launch_bounds__(256)
+aux_l1_fwd_kernel(int64_t P, const float *__restrict__ depth, const float *__restrict__ depth_gt,
+                  const float *__restrict__ normal, const float *__restrict__ normal_gt,
+                  float *__restrict__ partial) {
+    __shared__ float red[4];
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    float sd = 0.f, sn = 0.f;
+    if (p < P) {
+        sd = fabsf(depth[p] - depth_gt[p]);
+        if (normal) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) sn += fabsf(normal[p * 3 + k] - normal_gt[p * 3 + k]);
+        }
+    }
+    const float td = block_sum_256(sd, red);
+    __syncthreads();
+    const float tn = block_sum_256(sn, red);
+    if (threadIdx.x == 255) {
+        partial[2 * blockIdx.x + 0] = td;
+        partial[2 * blockIdx.x + 1] = tn;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+aux_l1_bwd_kernel(int64_t P, const float *__restrict__ depth, const float *__restrict__ depth_gt,
+                  const float *__restrict__ normal, const float *__restrict__ normal_gt,
+                  const float *__restrict__ v_loss, float g_depth, float g_normal,
+                  float *__restrict__ v_depth, float *__restrict__ v_normal) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    const float up = v_loss[0];
+    const float d = depth[p] - depth_gt[p];
+    v_depth[p] = up * g_depth * ((d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f));
+    if (normal) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float e = normal[p * 3 + k] - normal_gt[p * 3 + k];
+            v_normal[p * 3 + k] = up * g_normal * ((e > 0.f) ? 1.f : ((e < 0.f) ? -1.f : 0.f));
+        }
+    }
+}
+
 }  // namespace fsgs
 
 using namespace fsgs;
+
+extern "C" int fsgs_aux_l1_fwd(int64_t n_pixels, const float *depth, const float *depth_gt, const float *normal,
+                               const float *normal_gt, float *partial, fsgs_stream_t stream) {
+    if (n_pixels < 0) return FSGS_EINVAL;
+    if (n_pixels == 0) return FSGS_OK;
+    if (!depth || !depth_gt || !partial || (normal && !normal_gt)) return FSGS_EINVAL;
+    hipLaunchKernelGGL(aux_l1_fwd_kernel, dim3(ceil_div(n_pixels, 256)), dim3(256), 0, as_stream(stream), n_pixels,
+                       depth, depth_gt, normal, normal_gt, partial);
+    return check_launch();
+}
+
+extern "C" int fsgs_aux_l1_bwd(int64_t n_pixels, const float *depth, const float *depth_gt, const float *normal,
+                               const float *normal_gt, const float *v_loss, float g_depth, float g_normal,
+                               float *v_depth, float *v_normal, fsgs_stream_t stream) {
+    if (n_pixels < 0) return FSGS_EINVAL;
+    if (n_pixels == 0) return FSGS_OK;
+    if (!depth || !depth_gt || !v_loss || !v_depth || (normal && (!normal_gt || !v_normal))) return FSGS_EINVAL;
+    hipLaunchKernelGGL(aux_l1_bwd_kernel, dim3(ceil_div(n_pixels, 256)), dim3(256), 0, as_stream(stream), n_pixels,
+                       depth, depth_gt, normal, normal_gt, v_loss, g_depth, g_normal, v_depth, v_normal);
+    return check_launch();
+}
 
 extern "C" int64_t fsgs_ssim_l1_num_partials(int H, int W) {
     return (int64_t)ceil_div(W, kLT) * ceil_div(H, kLT) * 3;

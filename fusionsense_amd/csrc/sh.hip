@@ -171,6 +171,7 @@ sh_fwd_kernel(int C, int N, int K, int degree, const float *__restrict__ means,
     }
 }
 
+template <bool SINGLE_CAM>
 __global__ void __launch_bounds__(kShBlock)
 sh_bwd_kernel(int C, int N, int K, int degree, const float *__restrict__ means,
               const float *__restrict__ campos, const float *__restrict__ coeffs,
@@ -193,7 +194,55 @@ sh_bwd_kernel(int C, int N, int K, int degree, const float *__restrict__ means,
     __syncthreads();
     const int n = n0 + threadIdx.x;
     float *my = lds + threadIdx.x * pitch;
-    if (n < N) {
+    if (SINGLE_CAM) {
+      if (n < N) {
+        // single-camera fast path (the training case): the coefficient gradient is formed in place in
+        // this lane's LDS row, no per-lane accumulator array (75 VGPRs) is needed
+        const float mx = means[n * 3 + 0], myy = means[n * 3 + 1], mz = means[n * 3 + 2];
+        if (D == 4 && v_depths) v_depths[n] = v_colors[(int64_t)n * 4 + 3];
+        float vr = 0.f, vg = 0.f, vb = 0.f;
+        float b[kMaxK], bx[kMaxK], by[kMaxK], bz[kMaxK];
+        float dx = 0.f, dy = 0.f, dz = 0.f, inorm = 0.f;
+        const bool vis = radii[n] > 0;
+        if (vis) {
+            dx = mx - campos[0]; dy = myy - campos[1]; dz = mz - campos[2];
+            inorm = 1.f / fmaxf(sqrtf(dx * dx + dy * dy + dz * dz), 1e-12f);
+            dx *= inorm; dy *= inorm; dz *= inorm;
+            sh_basis<true>(degree, dx, dy, dz, b, bx, by, bz);
+            float ar = 0.f, ag = 0.f, ab = 0.f;
+#pragma unroll
+            for (int k = 0; k < kMaxK; ++k) {
+                if (k < kk) {
+                    ar += b[k] * my[k * 3 + 0];
+                    ag += b[k] * my[k * 3 + 1];
+                    ab += b[k] * my[k * 3 + 2];
+                }
+            }
+            vr = (ar + 0.5f > 0.f) ? v_colors[(int64_t)n * D + 0] : 0.f;
+            vg = (ag + 0.5f > 0.f) ? v_colors[(int64_t)n * D + 1] : 0.f;
+            vb = (ab + 0.5f > 0.f) ? v_colors[(int64_t)n * D + 2] : 0.f;
+        }
+        float gdx = 0.f, gdy = 0.f, gdz = 0.f;
+#pragma unroll
+        for (int k = 0; k < kMaxK; ++k) {
+            if (k < K) {
+                const bool on = vis && (k < kk);
+                const float c0 = my[k * 3 + 0], c1 = my[k * 3 + 1], c2 = my[k * 3 + 2];
+                if (on) {
+                    const float w = c0 * vr + c1 * vg + c2 * vb;
+                    gdx += bx[k] * w; gdy += by[k] * w; gdz += bz[k] * w;
+                }
+                my[k * 3 + 0] = on ? b[k] * vr : 0.f;
+                my[k * 3 + 1] = on ? b[k] * vg : 0.f;
+                my[k * 3 + 2] = on ? b[k] * vb : 0.f;
+            }
+        }
+        const float dp = gdx * dx + gdy * dy + gdz * dz;
+        v_means[n * 3 + 0] += (gdx - dp * dx) * inorm;
+        v_means[n * 3 + 1] += (gdy - dp * dy) * inorm;
+        v_means[n * 3 + 2] += (gdz - dp * dz) * inorm;
+      }
+    } else if (n < N) {
         const float mx = means[n * 3 + 0], myy = means[n * 3 + 1], mz = means[n * 3 + 2];
         float acc[kMaxK * 3];
 #pragma unroll
@@ -347,9 +396,14 @@ static int sh_bwd_impl(int C, int N, int K, int degree, const float *means, cons
     if (N == 0) return FSGS_OK;
     if (!means || !campos || !coeffs || !radii || !v_colors || !v_coeffs || !v_means) return FSGS_EINVAL;
     const size_t lds_bytes = (size_t)kShBlock * (K * 3 + 1) * sizeof(float);
-    hipLaunchKernelGGL(sh_bwd_kernel, dim3(ceil_div(N, kShBlock)), dim3(kShBlock), lds_bytes,
-                       as_stream(stream), C, N, K, degree, means, campos, coeffs, coeffs_rest, radii, D, v_colors,
-                       v_coeffs, v_coeffs_rest, v_means, v_depths);
+    if (C == 1)
+        hipLaunchKernelGGL((sh_bwd_kernel<true>), dim3(ceil_div(N, kShBlock)), dim3(kShBlock), lds_bytes,
+                           as_stream(stream), C, N, K, degree, means, campos, coeffs, coeffs_rest, radii, D,
+                           v_colors, v_coeffs, v_coeffs_rest, v_means, v_depths);
+    else
+        hipLaunchKernelGGL((sh_bwd_kernel<false>), dim3(ceil_div(N, kShBlock)), dim3(kShBlock), lds_bytes,
+                           as_stream(stream), C, N, K, degree, means, campos, coeffs, coeffs_rest, radii, D,
+                           v_colors, v_coeffs, v_coeffs_rest, v_means, v_depths);
     return check_launch();
 }
 

@@ -548,3 +548,45 @@ def campos_from_viewmats(viewmats: Tensor) -> Tensor:
     _run(lib.fsgs_campos_from_viewmats, (Cn, ptr(viewmats), ptr(campos), stream_ptr(viewmats.device)),
          "fsgs_campos_from_viewmats")
     return campos
+
+
+class _AuxL1Loss(torch.autograd.Function):
+    """w_d * mean|depth - gt| + w_n * mean|normal - gt| as one forward and one backward kernel."""
+
+    @staticmethod
+    def forward(ctx, depth, depth_gt, normal, normal_gt, w_depth, w_normal):
+        depth, depth_gt, normal, normal_gt = map(_c, (depth, depth_gt, normal, normal_gt))
+        lib = load()
+        dev = depth.device
+        P = depth.numel()
+        nblk = (P + 255) // 256
+        partial = torch.empty(nblk, 2, dtype=torch.float32, device=dev)
+        _run(lib.fsgs_aux_l1_fwd, (P, ptr(depth), ptr(depth_gt), ptr(normal), ptr(normal_gt), ptr(partial),
+                                   stream_ptr(dev)), "fsgs_aux_l1_fwd")
+        ctx.save_for_backward(depth, depth_gt, normal if normal is not None else torch.empty(0, device=dev),
+                              normal_gt if normal_gt is not None else torch.empty(0, device=dev))
+        g_d = w_depth / P
+        g_n = w_normal / (3.0 * P) if normal is not None else 0.0
+        ctx.g = (g_d, g_n, normal is not None)
+        tot = partial.sum(dim=0)
+        return tot[0] * g_d + tot[1] * g_n
+
+    @staticmethod
+    def backward(ctx, v_loss):
+        depth, depth_gt, normal, normal_gt = ctx.saved_tensors
+        g_d, g_n, has_n = ctx.g
+        lib = load()
+        dev = depth.device
+        P = depth.numel()
+        v_depth = torch.empty_like(depth)
+        v_normal = torch.empty_like(normal) if has_n else None
+        v_loss = v_loss.reshape(1).contiguous().to(torch.float32)
+        _run(lib.fsgs_aux_l1_bwd, (P, ptr(depth), ptr(depth_gt), ptr(normal) if has_n else None,
+                                   ptr(normal_gt) if has_n else None, ptr(v_loss), g_d, g_n, ptr(v_depth),
+                                   ptr(v_normal), stream_ptr(dev)), "fsgs_aux_l1_bwd")
+        return v_depth, None, v_normal, None, None, None
+
+
+def aux_l1_loss(depth: Tensor, depth_gt: Tensor, normal: Optional[Tensor], normal_gt: Optional[Tensor],
+                w_depth: float, w_normal: float) -> Tensor:
+    return _AuxL1Loss.apply(depth, depth_gt, normal, normal_gt, float(w_depth), float(w_normal))

@@ -262,6 +262,15 @@ int fsgs_ssim_l1_bwd(int H, int W, const float *pred, const float *gt, const flo
                      const float *dm_dsigma1, const float *dm_dsigma12, const float *v_loss,
                      float g_l1, float g_ssim, float *v_pred, fsgs_stream_t stream);
 
+/* Auxiliary L1 terms on the depth [P] and normal [P,3] images (normal nullable), fused:
+ * fwd: partial[ceil(P/256), 2] per-workgroup sums of |depth-gt| and |normal-gt|;
+ * bwd: v_depth = v_loss[0]*g_depth*sign(depth-gt), v_normal likewise (written). */
+int fsgs_aux_l1_fwd(int64_t n_pixels, const float *depth, const float *depth_gt, const float *normal,
+                    const float *normal_gt, float *partial, fsgs_stream_t stream);
+int fsgs_aux_l1_bwd(int64_t n_pixels, const float *depth, const float *depth_gt, const float *normal,
+                    const float *normal_gt, const float *v_loss, float g_depth, float g_normal,
+                    float *v_depth, float *v_normal, fsgs_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
