@@ -460,8 +460,9 @@ def test_fused_get_outputs_matches_unfused_and_oracle(dev):
 
 
 def test_fused_trainer_step_equals_unfused(dev):
-    """Two trainers from the same state, fused vs op-by-op caller: same loss, same parameters after
-    an Adam step (gradients land in the slab views either way)."""
+    """Two trainers from the same state, fused vs op-by-op caller: same loss, same gradients in the
+    slab views, same parameters after the Adam step wherever the gradient is not numerically
+    zero (Adam's g/sqrt(v) turns rounding noise on ~0 gradients into +-lr steps)."""
     from fusionsense_amd.trainer import SplatTrainer
     params, cam = scenes.cube_scene(900, seed=5)
     target = {"rgb": torch.rand(128, 128, 3).to(dev), "depth": torch.rand(128, 128, 1).to(dev),
@@ -469,12 +470,14 @@ def test_fused_trainer_step_equals_unfused(dev):
     res = []
     for fused in (True, False):
         tr = SplatTrainer(params, dev, fused=fused)
-        losses = [tr.train_step(cam, target)[0].item() for _ in range(3)]
-        res.append((losses, {k: v.detach().clone() for k, v in tr.params.items()},
-                    {k: tr.slab.views[k].clone() for k in tr.params}))
-    for a, b in zip(res[0][0], res[1][0]):
-        assert abs(a - b) < 1e-5 * max(1.0, abs(b)), (res[0][0], res[1][0])
-    for k in res[0][2]:
-        assert rel_err(res[0][2][k], res[1][2][k]) < 5e-3, f"slab grad {k}"
+        before = {k: v.detach().clone() for k, v in tr.params.items()}
+        loss = tr.train_step(cam, target)[0].item()
+        res.append((loss, {k: tr.slab.views[k].clone() for k in tr.params},
+                    {k: (tr.params[k].detach() - before[k]) for k in tr.params}))
+    assert abs(res[0][0] - res[1][0]) < 1e-5 * max(1.0, abs(res[1][0]))
     for k in res[0][1]:
-        assert (res[0][1][k] - res[1][1][k]).abs().max().item() < 5e-3, f"param {k} after 3 Adam steps"
+        gf, gu = res[0][1][k], res[1][1][k]
+        assert rel_err(gf, gu) < 5e-3, f"slab grad {k}: {rel_err(gf, gu)}"
+        solid = gu.abs() > 1e-3 * gu.abs().max()
+        assert solid.any()
+        assert (res[0][2][k][solid] - res[1][2][k][solid]).abs().max().item() < 1e-3 * tr.optim_cfg.lr[k] + 1e-9, k
