@@ -85,9 +85,8 @@ class _FusedGetOutputs(torch.autograd.Function):
              "fsgs_activate_fwd")
         radii, means2d, depths, conics, _ = ops.project_fwd(means, quats, scales_exp, cam["viewmat"], cam["K"],
                                                              W, H, 0.3, 0.01, 1e10, 0.0, False)
-        tpg, isect_ids, flatten_ids, rule_diff = ops.isect_tiles(means2d, radii, depths, TILE, tw, th,
-                                                                 legacy=False, sort=True, return_rule_diff=True)
-        offsets = ops.isect_offset_encode(isect_ids, 1, tw, th)
+        tpg, isect_ids, flatten_ids, offsets, rule_diff = ops.bin_and_sort(means2d, radii, depths, TILE, tw, th,
+                                                                           legacy=False)
         M = flatten_ids.numel()
 
         colors = torch.empty(1, N, 4, **f32)

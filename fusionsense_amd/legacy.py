@@ -99,10 +99,9 @@ def rasterize_gaussians(
         offsets, flatten_ids, isect_ids = cached  # same frame: reuse the first pass's sorted lists
     else:
         with torch.no_grad():
-            _, isect_ids, flatten_ids = ops.isect_tiles(
-                xys.detach()[None], radii[None], depths.detach()[None], block_width, tw, th, legacy=True,
-                sort=True)
-            offsets = ops.isect_offset_encode(isect_ids, 1, tw, th)
+            _, isect_ids, flatten_ids, offsets, _ = ops.bin_and_sort(
+                xys.detach()[None].contiguous(), radii[None].contiguous(), depths.detach()[None].contiguous(),
+                block_width, tw, th, legacy=True)
 
     pad = 0
     cols = colors

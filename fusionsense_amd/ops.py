@@ -137,6 +137,44 @@ def isect_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tile_size: int, 
     return tpg, ids, flat
 
 
+USE_BUCKET_BINNING = True  # tile-bucketed binning + per-tile LDS sort; False forces the radix path
+
+
+def bin_and_sort(means2d: Tensor, radii: Tensor, depths: Tensor, tile_size: int, tile_width: int,
+                 tile_height: int, legacy: bool = False):
+    """isect_tiles + sort + isect_offset_encode in one go.  Returns tiles_per_gauss [C,N] i32,
+    isect_ids [M] i64 (sorted), flatten_ids [M] i32, isect_offsets [C,th,tw] i32, rule_diff.
+    Uses the bucketed path (csrc/bucket.hip) unless a tile holds more entries than fit in LDS."""
+    lib = load()
+    dev = means2d.device
+    Cn, N = radii.shape
+    if USE_BUCKET_BINNING:
+        T = Cn * tile_width * tile_height
+        tpg = torch.empty(Cn, N, dtype=torch.int32, device=dev)
+        counts = torch.empty(T, dtype=torch.int32, device=dev)
+        offsets = torch.empty(T + 1, dtype=torch.int32, device=dev)
+        stats = torch.empty(3, dtype=torch.int64, device=dev)
+        m_host, max_host, diff_host = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        _run(lib.fsgs_bucket_count, (Cn, N, ptr(means2d), ptr(radii), tile_size, tile_width, tile_height, int(legacy),
+                                    ptr(tpg), ptr(counts), ptr(offsets), ptr(stats), C.byref(m_host),
+                                    C.byref(max_host), C.byref(diff_host), stream_ptr(dev)), "fsgs_bucket_count")
+        M, max_bucket = int(m_host.value), int(max_host.value)
+        if max_bucket <= lib.fsgs_bucket_max_tile():
+            ids = torch.empty(M, dtype=torch.int64, device=dev)
+            flat = torch.empty(M, dtype=torch.int32, device=dev)
+            if M > 0:
+                keys = torch.empty(M, dtype=torch.int64, device=dev)
+                _run(lib.fsgs_bucket_fill_sort, (Cn, N, ptr(means2d), ptr(radii), ptr(depths), tile_size, tile_width,
+                                                tile_height, int(legacy), ptr(counts), ptr(offsets), M, max_bucket,
+                                                ptr(keys), ptr(ids), ptr(flat), stream_ptr(dev)),
+                     "fsgs_bucket_fill_sort")
+            return tpg, ids, flat, offsets[:T].view(Cn, tile_height, tile_width), int(diff_host.value)
+    tpg, ids, flat, diff = isect_tiles(means2d, radii, depths, tile_size, tile_width, tile_height, legacy=legacy,
+                                       sort=True, return_rule_diff=True)
+    offsets = isect_offset_encode(ids, Cn, tile_width, tile_height)
+    return tpg, ids, flat, offsets, diff
+
+
 def sort_pairs(keys: Tensor, vals: Tensor, end_bit: int = 64) -> Tuple[Tensor, Tensor]:
     """Stable radix sort of (i64, i32) pairs on key bits [0, end_bit).  Inputs are clobbered."""
     lib = load()

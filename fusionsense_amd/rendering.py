@@ -109,10 +109,8 @@ def rasterization(
     tile_width = math.ceil(width / tile_size)
     tile_height = math.ceil(height / tile_size)
     with torch.no_grad():
-        tiles_per_gauss, isect_ids, flatten_ids, rule_diff = ops.isect_tiles(
-            means2d, radii, depths, tile_size, tile_width, tile_height, legacy=False, sort=True,
-            return_rule_diff=True)
-        isect_offsets = ops.isect_offset_encode(isect_ids, C, tile_width, tile_height)
+        tiles_per_gauss, isect_ids, flatten_ids, isect_offsets, rule_diff = ops.bin_and_sort(
+            means2d, radii, depths, tile_size, tile_width, tile_height, legacy=False)
     # let the legacy normal pass (dn_model.py:644-653) reuse these lists when it is handed this
     # frame's own xys / depths / radii (see frame_cache for why that is the faithful choice even
     # for the rule_diff Gaussians whose bbox touches a tile edge exactly)

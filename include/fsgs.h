@@ -108,6 +108,27 @@ int fsgs_isect_emit(int C, int N, const float *means2d, const int32_t *radii, co
                     const int64_t *cum_tiles, int tile_size, int tile_width, int tile_height,
                     int legacy, int64_t *isect_ids, int32_t *flatten_ids, fsgs_stream_t stream);
 
+/* ---- E4-E6 fast path: tile-bucketed binning + per-tile LDS sort (csrc/bucket.hip) -------------
+ * Same outputs as isect_count + isect_emit + sort_pairs + isect_offset_encode, bit for bit, in
+ * four launches: per-tile counts with atomics -> one-workgroup scan (= isect_offsets) -> scatter of
+ * 64-bit in-tile keys (bits(depth)<<32 | flatten id) -> one workgroup per tile sorts its bucket in
+ * LDS.  Usable when the largest bucket has <= fsgs_bucket_max_tile() entries (the caller falls
+ * back to the radix path otherwise).
+ * fsgs_bucket_count: tile_counts[T] (T = C*tiles; scratch, left zeroed = the cursors of the next
+ * call), tile_offsets[T+1] (exclusive scan; [T] = M), stats_dev[3] i64 scratch; synchronises and
+ * returns M, the largest bucket and (nullable) the other-bbox-rule count. */
+int fsgs_bucket_max_tile(void);
+int fsgs_bucket_count(int C, int N, const float *means2d, const int32_t *radii, int tile_size,
+                      int tile_width, int tile_height, int legacy, int32_t *tiles_per_gauss,
+                      int32_t *tile_counts, int32_t *tile_offsets, int64_t *stats_dev,
+                      int64_t *n_isects_host, int64_t *max_bucket_host, int64_t *n_rule_diff_host,
+                      fsgs_stream_t stream);
+int fsgs_bucket_fill_sort(int C, int N, const float *means2d, const int32_t *radii, const float *depths,
+                          int tile_size, int tile_width, int tile_height, int legacy,
+                          int32_t *tile_cursors, const int32_t *tile_offsets, int64_t n_isects,
+                          int64_t max_bucket, void *keys_scratch, int64_t *isect_ids,
+                          int32_t *flatten_ids, fsgs_stream_t stream);
+
 /* ---- E5: stable LSD radix sort of (i64 key, i32 value) pairs over key bits [0,end_bit) --------
  * Replaces cub::DeviceRadixSort::SortPairs.  Ping-pongs between (keys_a, vals_a) and
  * (keys_b, vals_b); returns 0 or 1 in *result_in_b to say where the sorted data ended up. */
