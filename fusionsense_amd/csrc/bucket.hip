@@ -44,6 +44,12 @@ __device__ __forceinline__ TileRectB tile_rect_b(float mx, float my, int radius,
 }
 
 constexpr int kWideB = 64;  // Gaussians touching >= this many tiles are spread over their wave
+// ~800 increments land on every tile counter; same-address atomics serialise at the memory side, so
+// each tile gets kShards counters (one per wave index mod kShards), stored shard-major so that a
+// tile's shards sit in different cache lines.  Bucket (tile, shard) is the contiguous range
+// [offsets[tile*kShards+shard], offsets[tile*kShards+shard+1]); a tile's shards are adjacent.
+constexpr int kShards = 16;
+__device__ __forceinline__ int shard_of_wave() { return (int)((blockIdx.x * 4 + (threadIdx.x >> 6)) & (kShards - 1)); }
 
 // FILL = false: count pass (A1).  FILL = true: scatter pass (B1).
 template <bool FILL>
@@ -51,9 +57,12 @@ __global__ void __launch_bounds__(256)
 bucket_pass_kernel(int C, int N, const float *__restrict__ means2d, const int32_t *__restrict__ radii,
                    const float *__restrict__ depths, int tile_size, int tw, int th, int legacy,
                    int32_t *__restrict__ tiles_per_gauss, int32_t *__restrict__ tile_counts,
-                   const int32_t *__restrict__ tile_offsets, unsigned long long *__restrict__ keys,
+                   const int32_t *__restrict__ shard_offsets, unsigned long long *__restrict__ keys,
                    unsigned long long *__restrict__ rule_diff) {
     const int64_t total = (int64_t)C * N;
+    const int T = C * tw * th;
+    int32_t *my_counts = tile_counts + (int64_t)shard_of_wave() * T;   // shard-major counters
+    const int sh = shard_of_wave();
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const int n_tiles = tw * th;
@@ -82,10 +91,10 @@ bucket_pass_kernel(int C, int N, const float *__restrict__ means2d, const int32_
             for (int x = t.x0; x < t.x1; ++x) {
                 const int tile = tile_base + y * tw + x;
                 if (FILL) {
-                    const int slot = atomicAdd(&tile_counts[tile], 1);
-                    keys[(int64_t)tile_offsets[tile] + slot] = key;
+                    const int slot = atomicAdd(&my_counts[tile], 1);
+                    keys[(int64_t)shard_offsets[tile * kShards + sh] + slot] = key;
                 } else {
-                    atomicAdd(&tile_counts[tile], 1);
+                    atomicAdd(&my_counts[tile], 1);
                 }
             }
     }
@@ -100,43 +109,58 @@ bucket_pass_kernel(int C, int N, const float *__restrict__ means2d, const int32_
         for (int j = lane; j < n; j += 64) {
             const int tile = tb + (y0 + j / wdt) * tw + x0 + j % wdt;
             if (FILL) {
-                const int slot = atomicAdd(&tile_counts[tile], 1);
-                keys[(int64_t)tile_offsets[tile] + slot] = k;
+                const int slot = atomicAdd(&my_counts[tile], 1);
+                keys[(int64_t)shard_offsets[tile * kShards + sh] + slot] = k;
             } else {
-                atomicAdd(&tile_counts[tile], 1);
+                atomicAdd(&my_counts[tile], 1);
             }
         }
     }
 }
 
-// A2: exclusive scan of T tile counts by one workgroup; stats[0] = total, stats[1] = max count.
-// Also re-zeroes the counters so that B1 can use them as cursors.
+// A2: exclusive scan, by one workgroup, of the T*kShards counters visited tile-major (the counters are
+// stored shard-major): shard_offsets[T*kShards + 1], tile_offsets[T + 1] (every kShards-th value),
+// stats[0] = total, stats[1] = largest TILE bucket.  Re-zeroes the counters: they become B1's cursors.
 __global__ void __launch_bounds__(1024)
-tile_scan_kernel(int T, int32_t *__restrict__ tile_counts, int32_t *__restrict__ tile_offsets,
-                 long long *__restrict__ stats) {
+tile_scan_kernel(int T, int32_t *__restrict__ tile_counts, int32_t *__restrict__ shard_offsets,
+                 int32_t *__restrict__ tile_offsets, long long *__restrict__ stats) {
     __shared__ int wsum[16];
     __shared__ int carry_s, max_s;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     if (tid == 0) { carry_s = 0; max_s = 0; }
     __syncthreads();
+    const int n = T * kShards;
     int local_max = 0;
-    for (int base = 0; base < T; base += 1024) {
+    for (int base = 0; base < n; base += 1024) {
         const int i = base + tid;
-        const int v = (i < T) ? tile_counts[i] : 0;
-        if (i < T) tile_counts[i] = 0;
-        local_max = max(local_max, v);
+        int v = 0;
+        if (i < n) {
+            const int tile = i / kShards, sh = i - tile * kShards;
+            const int64_t src = (int64_t)sh * T + tile;
+            v = tile_counts[src];
+            tile_counts[src] = 0;
+        }
         int inc = v;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
             const int o = __shfl_up(inc, d, 64);
             if (lane >= d) inc += o;
         }
+        // size of each tile's bucket = sum over its kShards consecutive entries (kShards | 64)
+        int tsum = v;
+#pragma unroll
+        for (int d = 1; d < kShards; d <<= 1) tsum += __shfl_xor(tsum, d, 64);
+        local_max = max(local_max, tsum);
         if (lane == 63) wsum[w] = inc;
         __syncthreads();
         int wbase = 0;
         for (int k = 0; k < w; ++k) wbase += wsum[k];
         const int carry = carry_s;
-        if (i < T) tile_offsets[i] = carry + wbase + inc - v;
+        if (i < n) {
+            const int ex = carry + wbase + inc - v;
+            shard_offsets[i] = ex;
+            if ((i & (kShards - 1)) == 0) tile_offsets[i / kShards] = ex;
+        }
         __syncthreads();
         if (tid == 1023) carry_s = carry + wbase + inc;
         __syncthreads();
@@ -146,6 +170,7 @@ tile_scan_kernel(int T, int32_t *__restrict__ tile_counts, int32_t *__restrict__
     if (lane == 0) atomicMax(&max_s, local_max);
     __syncthreads();
     if (tid == 0) {
+        shard_offsets[n] = carry_s;
         tile_offsets[T] = carry_s;
         stats[0] = carry_s;
         stats[1] = max_s;
@@ -196,12 +221,15 @@ constexpr int kMaxBucket = 8192;  // 64 KiB of LDS keys per workgroup
 using namespace fsgs;
 
 extern "C" int fsgs_bucket_max_tile(void) { return kMaxBucket; }
+extern "C" int fsgs_bucket_shards(void) { return kShards; }
 
-// tile_counts[T] (scratch, becomes the zeroed cursor array), tile_offsets[T+1] (= isect_offsets + total),
-// stats_dev[3] i64 scratch.  Synchronises; host outputs: n_isects, largest bucket, rule_diff (nullable).
+// tile_counts[T*fsgs_bucket_shards()] (scratch, becomes the zeroed cursor array), shard_offsets[T*shards+1],
+// tile_offsets[T+1] (= isect_offsets + total), stats_dev[3] i64 scratch.
+// Synchronises; host outputs: n_isects, largest bucket, rule_diff (nullable).
 extern "C" int fsgs_bucket_count(int C, int N, const float *means2d, const int32_t *radii, int tile_size,
                                  int tile_width, int tile_height, int legacy, int32_t *tiles_per_gauss,
-                                 int32_t *tile_counts, int32_t *tile_offsets, int64_t *stats_dev,
+                                 int32_t *tile_counts, int32_t *shard_offsets, int32_t *tile_offsets,
+                                 int64_t *stats_dev,
                                  int64_t *n_isects_host, int64_t *max_bucket_host, int64_t *n_rule_diff_host,
                                  fsgs_stream_t stream) {
     if (C < 0 || N < 0 || tile_size < 1 || !n_isects_host || !max_bucket_host) return FSGS_EINVAL;
@@ -210,10 +238,10 @@ extern "C" int fsgs_bucket_count(int C, int N, const float *means2d, const int32
     *n_isects_host = 0;
     *max_bucket_host = 0;
     if (n_rule_diff_host) *n_rule_diff_host = 0;
-    if (!tile_counts || !tile_offsets || !stats_dev) return FSGS_EINVAL;
+    if (!tile_counts || !shard_offsets || !tile_offsets || !stats_dev) return FSGS_EINVAL;
     if (total > 0 && (!means2d || !radii || !tiles_per_gauss)) return FSGS_EINVAL;
     hipStream_t s = as_stream(stream);
-    hipError_t e = hipMemsetAsync(tile_counts, 0, (size_t)T * sizeof(int32_t), s);
+    hipError_t e = hipMemsetAsync(tile_counts, 0, (size_t)T * kShards * sizeof(int32_t), s);
     if (e == hipSuccess) e = hipMemsetAsync(stats_dev, 0, 3 * sizeof(int64_t), s);
     if (e != hipSuccess) { g_last_hip_error = (int)e; return FSGS_ELAUNCH; }
     unsigned long long *diff_dev = n_rule_diff_host ? reinterpret_cast<unsigned long long *>(stats_dev + 2) : nullptr;
@@ -221,7 +249,7 @@ extern "C" int fsgs_bucket_count(int C, int N, const float *means2d, const int32
         hipLaunchKernelGGL((bucket_pass_kernel<false>), dim3(ceil_div(total, 256)), dim3(256), 0, s, C, N, means2d,
                            radii, nullptr, tile_size, tile_width, tile_height, legacy, tiles_per_gauss,
                            tile_counts, nullptr, nullptr, diff_dev);
-    hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, s, T, tile_counts, tile_offsets,
+    hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, s, T, tile_counts, shard_offsets, tile_offsets,
                        reinterpret_cast<long long *>(stats_dev));
     int64_t host[3] = {0, 0, 0};
     e = hipMemcpyAsync(host, stats_dev, 3 * sizeof(int64_t), hipMemcpyDeviceToHost, s);
@@ -236,13 +264,13 @@ extern "C" int fsgs_bucket_count(int C, int N, const float *means2d, const int32
 // keys_scratch[M] u64.  max_bucket must be <= fsgs_bucket_max_tile().
 extern "C" int fsgs_bucket_fill_sort(int C, int N, const float *means2d, const int32_t *radii,
                                      const float *depths, int tile_size, int tile_width, int tile_height,
-                                     int legacy, int32_t *tile_cursors, const int32_t *tile_offsets,
-                                     int64_t n_isects, int64_t max_bucket, void *keys_scratch,
+                                     int legacy, int32_t *tile_cursors, const int32_t *shard_offsets,
+                                     const int32_t *tile_offsets, int64_t n_isects, int64_t max_bucket, void *keys_scratch,
                                      int64_t *isect_ids, int32_t *flatten_ids, fsgs_stream_t stream) {
     if (C < 0 || N < 0 || tile_size < 1 || n_isects < 0 || max_bucket < 0 || max_bucket > kMaxBucket)
         return FSGS_EINVAL;
     if (n_isects == 0) return FSGS_OK;
-    if (!means2d || !radii || !depths || !tile_cursors || !tile_offsets || !keys_scratch || !isect_ids ||
+    if (!means2d || !radii || !depths || !tile_cursors || !shard_offsets || !tile_offsets || !keys_scratch || !isect_ids ||
         !flatten_ids)
         return FSGS_EINVAL;
     const int64_t total = (int64_t)C * N;
@@ -254,7 +282,7 @@ extern "C" int fsgs_bucket_fill_sort(int C, int N, const float *means2d, const i
     hipStream_t s = as_stream(stream);
     unsigned long long *keys = reinterpret_cast<unsigned long long *>(keys_scratch);
     hipLaunchKernelGGL((bucket_pass_kernel<true>), dim3(ceil_div(total, 256)), dim3(256), 0, s, C, N, means2d, radii,
-                       depths, tile_size, tile_width, tile_height, legacy, nullptr, tile_cursors, tile_offsets, keys,
+                       depths, tile_size, tile_width, tile_height, legacy, nullptr, tile_cursors, shard_offsets, keys,
                        nullptr);
     int np = 1;
     while (np < max_bucket) np <<= 1;

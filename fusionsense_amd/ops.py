@@ -151,12 +151,14 @@ def bin_and_sort(means2d: Tensor, radii: Tensor, depths: Tensor, tile_size: int,
     if USE_BUCKET_BINNING:
         T = Cn * tile_width * tile_height
         tpg = torch.empty(Cn, N, dtype=torch.int32, device=dev)
-        counts = torch.empty(T, dtype=torch.int32, device=dev)
+        S = lib.fsgs_bucket_shards()
+        counts = torch.empty(T * S, dtype=torch.int32, device=dev)
+        shard_offsets = torch.empty(T * S + 1, dtype=torch.int32, device=dev)
         offsets = torch.empty(T + 1, dtype=torch.int32, device=dev)
         stats = torch.empty(3, dtype=torch.int64, device=dev)
         m_host, max_host, diff_host = C.c_int64(0), C.c_int64(0), C.c_int64(0)
         _run(lib.fsgs_bucket_count, (Cn, N, ptr(means2d), ptr(radii), tile_size, tile_width, tile_height, int(legacy),
-                                    ptr(tpg), ptr(counts), ptr(offsets), ptr(stats), C.byref(m_host),
+                                    ptr(tpg), ptr(counts), ptr(shard_offsets), ptr(offsets), ptr(stats), C.byref(m_host),
                                     C.byref(max_host), C.byref(diff_host), stream_ptr(dev)), "fsgs_bucket_count")
         M, max_bucket = int(m_host.value), int(max_host.value)
         if max_bucket <= lib.fsgs_bucket_max_tile():
@@ -165,7 +167,8 @@ def bin_and_sort(means2d: Tensor, radii: Tensor, depths: Tensor, tile_size: int,
             if M > 0:
                 keys = torch.empty(M, dtype=torch.int64, device=dev)
                 _run(lib.fsgs_bucket_fill_sort, (Cn, N, ptr(means2d), ptr(radii), ptr(depths), tile_size, tile_width,
-                                                tile_height, int(legacy), ptr(counts), ptr(offsets), M, max_bucket,
+                                                tile_height, int(legacy), ptr(counts), ptr(shard_offsets), ptr(offsets), M,
+                                                max_bucket,
                                                 ptr(keys), ptr(ids), ptr(flat), stream_ptr(dev)),
                      "fsgs_bucket_fill_sort")
             return tpg, ids, flat, offsets[:T].view(Cn, tile_height, tile_width), int(diff_host.value)

@@ -114,18 +114,22 @@ int fsgs_isect_emit(int C, int N, const float *means2d, const int32_t *radii, co
  * 64-bit in-tile keys (bits(depth)<<32 | flatten id) -> one workgroup per tile sorts its bucket in
  * LDS.  Usable when the largest bucket has <= fsgs_bucket_max_tile() entries (the caller falls
  * back to the radix path otherwise).
- * fsgs_bucket_count: tile_counts[T] (T = C*tiles; scratch, left zeroed = the cursors of the next
- * call), tile_offsets[T+1] (exclusive scan; [T] = M), stats_dev[3] i64 scratch; synchronises and
- * returns M, the largest bucket and (nullable) the other-bbox-rule count. */
+ * fsgs_bucket_count: tile_counts[T*S] (T = C*tiles, S = fsgs_bucket_shards(): every tile has S
+ * counters so that ~M/T increments do not serialise on one address; scratch, left zeroed = the
+ * cursors of the next call), shard_offsets[T*S+1], tile_offsets[T+1] (exclusive scans; [T] = M),
+ * stats_dev[3] i64 scratch; synchronises and returns M, the largest tile bucket and (nullable) the
+ * other-bbox-rule count. */
 int fsgs_bucket_max_tile(void);
+int fsgs_bucket_shards(void);
 int fsgs_bucket_count(int C, int N, const float *means2d, const int32_t *radii, int tile_size,
                       int tile_width, int tile_height, int legacy, int32_t *tiles_per_gauss,
-                      int32_t *tile_counts, int32_t *tile_offsets, int64_t *stats_dev,
-                      int64_t *n_isects_host, int64_t *max_bucket_host, int64_t *n_rule_diff_host,
+                      int32_t *tile_counts, int32_t *shard_offsets, int32_t *tile_offsets,
+                      int64_t *stats_dev, int64_t *n_isects_host, int64_t *max_bucket_host, int64_t *n_rule_diff_host,
                       fsgs_stream_t stream);
 int fsgs_bucket_fill_sort(int C, int N, const float *means2d, const int32_t *radii, const float *depths,
                           int tile_size, int tile_width, int tile_height, int legacy,
-                          int32_t *tile_cursors, const int32_t *tile_offsets, int64_t n_isects,
+                          int32_t *tile_cursors, const int32_t *shard_offsets,
+                          const int32_t *tile_offsets, int64_t n_isects,
                           int64_t max_bucket, void *keys_scratch, int64_t *isect_ids,
                           int32_t *flatten_ids, fsgs_stream_t stream);
 
