@@ -137,7 +137,10 @@ def isect_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tile_size: int, 
     return tpg, ids, flat
 
 
-USE_BUCKET_BINNING = True  # tile-bucketed binning + per-tile LDS sort; False forces the radix path
+# Tile-bucketed binning + per-tile LDS sort (csrc/bucket.hip): bit-exact and 4 launches, but measured
+# SLOWER than the radix path on MI355X at config #2 (0.48 vs 0.33 ms: ~M memory-side atomics per pass, even
+# with 16-way sharded counters).  Kept as a tested alternative; off by default.
+USE_BUCKET_BINNING = False
 
 
 def bin_and_sort(means2d: Tensor, radii: Tensor, depths: Tensor, tile_size: int, tile_width: int,

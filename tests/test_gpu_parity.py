@@ -489,6 +489,7 @@ def test_bucketed_binning_bit_exact(dev, case):
     tiles_per_gauss, sorted isect_ids / flatten_ids and isect_offsets must match bit for bit,
     including ties in depth, several cameras and the fall-back when a bucket exceeds LDS."""
     from fusionsense_amd import ops
+    ops.USE_BUCKET_BINNING = True
     legacy = case == "cube_legacy"
     params, cam = scenes.cube_scene(4000, seed=17)
     act = activated(params)
@@ -514,8 +515,11 @@ def test_bucketed_binning_bit_exact(dev, case):
     tpg, ids, flat = R.isect_tiles(m2, radii, dp, 16, tw, th, legacy=legacy)
     ids_s, flat_s = R.sort_isects(ids, flat)
     offs = R.isect_offset_encode(ids_s, Cn, tw, th)
-    g_tpg, g_ids, g_flat, g_off, _ = ops.bin_and_sort(m2.to(dev).contiguous(), radii.to(dev).contiguous(),
-                                                       dp.to(dev).contiguous(), 16, tw, th, legacy=legacy)
+    try:
+        g_tpg, g_ids, g_flat, g_off, _ = ops.bin_and_sort(m2.to(dev).contiguous(), radii.to(dev).contiguous(),
+                                                           dp.to(dev).contiguous(), 16, tw, th, legacy=legacy)
+    finally:
+        ops.USE_BUCKET_BINNING = False
     assert np.array_equal(g_tpg.cpu().numpy(), tpg)
     assert np.array_equal(g_ids.cpu().numpy(), ids_s)
     assert np.array_equal(g_flat.cpu().numpy(), flat_s)
