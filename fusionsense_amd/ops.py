@@ -634,3 +634,18 @@ class _AuxL1Loss(torch.autograd.Function):
 def aux_l1_loss(depth: Tensor, depth_gt: Tensor, normal: Optional[Tensor], normal_gt: Optional[Tensor],
                 w_depth: float, w_normal: float) -> Tensor:
     return _AuxL1Loss.apply(depth, depth_gt, normal, normal_gt, float(w_depth), float(w_normal))
+
+
+def adam_step_(params, grads, exp_avgs, exp_avg_sqs, lrs, step: int, beta1: float = 0.9, beta2: float = 0.999,
+               eps: float = 1e-15) -> None:
+    """In-place torch.optim.Adam update of several parameter tensors in ONE launch (row N1)."""
+    lib = load()
+    n = len(params)
+    dev = params[0].device
+    VP = C.c_void_p * n
+    numel = (C.c_int64 * n)(*[p.numel() for p in params])
+    lr = (C.c_float * n)(*[float(x) for x in lrs])
+    _run(lib.fsgs_adam_step, (n, VP(*[p.data_ptr() for p in params]), VP(*[g.data_ptr() for g in grads]),
+                              VP(*[m.data_ptr() for m in exp_avgs]), VP(*[v.data_ptr() for v in exp_avg_sqs]),
+                              numel, lr, int(step), float(beta1), float(beta2), float(eps), stream_ptr(dev)),
+         "fsgs_adam_step")

@@ -122,6 +122,26 @@ class SplatTrainer:
             l = l + 0.1 * torch.abs(out["normal"] - target["normal"]).mean()
         return l
 
+    def _fused_adam_step(self) -> None:
+        """All six groups in one launch (row N1).  The torch optimizers stay the owners of the state
+        (exp_avg / exp_avg_sq per parameter), so densify/prune surgery and checkpoints see the usual
+        layout; only their step() is replaced."""
+        from .ops import adam_step_
+        ps, gs, ms, vs, lrs = [], [], [], [], []
+        for name in PARAM_ORDER:
+            p = self.params[name]
+            opt = self.optimizers[name]
+            st = opt.state[p]
+            if "exp_avg" not in st:
+                st["step"] = torch.tensor(0.0)
+                st["exp_avg"] = torch.zeros_like(p)
+                st["exp_avg_sq"] = torch.zeros_like(p)
+            st["step"] += 1
+            ps.append(p.data); gs.append(self.slab.views[name]); ms.append(st["exp_avg"]); vs.append(st["exp_avg_sq"])
+            lrs.append(opt.param_groups[0]["lr"])
+        self.adam_steps = getattr(self, "adam_steps", 0) + 1
+        adam_step_(ps, gs, ms, vs, lrs, self.adam_steps, 0.9, 0.999, self.optim_cfg.eps)
+
     def train_step(self, camera: Camera, target: Dict[str, Tensor], optimizer_step: bool = True):
         if not self.fused:
             self.slab.zero_()  # autograd accumulates into the slab views; the fused node overwrites them
@@ -131,8 +151,11 @@ class SplatTrainer:
         self.slab.all_reduce_mean_()
         if optimizer_step:
             self.optimizers["means"].param_groups[0]["lr"] = self._means_lr(self.step)
-            for opt in self.optimizers.values():
-                opt.step()
+            if self.fused and self.device.type == "cuda":
+                self._fused_adam_step()
+            else:
+                for opt in self.optimizers.values():
+                    opt.step()
         if self.strategy is not None:
             self.strategy.after_train(self, out, camera)
             self.strategy.maybe_refine(self)

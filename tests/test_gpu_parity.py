@@ -524,3 +524,25 @@ def test_bucketed_binning_bit_exact(dev, case):
     assert np.array_equal(g_ids.cpu().numpy(), ids_s)
     assert np.array_equal(g_flat.cpu().numpy(), flat_s)
     assert np.array_equal(g_off.cpu().numpy(), offs)
+
+
+def test_fused_adam_matches_torch(dev):
+    """Row N1: one-launch Adam over several groups vs torch.optim.Adam (eps=1e-15 as in dn_config.py)."""
+    from fusionsense_amd import ops
+    g = torch.Generator().manual_seed(0)
+    shapes = [(1000, 3), (1000, 4), (1000, 15, 3), (1000, 1), (7,)]
+    lrs = [1.6e-4, 1e-3, 1.25e-4, 5e-2, 1e-2]
+    ps = [torch.randn(*s, generator=g).to(dev) for s in shapes]
+    ref = [torch.nn.Parameter(p.clone()) for p in ps]
+    opts = [torch.optim.Adam([r], lr=lr, eps=1e-15) for r, lr in zip(ref, lrs)]
+    ms = [torch.zeros_like(p) for p in ps]
+    vs = [torch.zeros_like(p) for p in ps]
+    for step in range(1, 6):
+        grads = [torch.randn(*s, generator=g).to(dev) * (10.0 ** -step) for s in shapes]
+        for r, gr, o in zip(ref, grads, opts):
+            r.grad = gr.clone()
+            o.step()
+        ops.adam_step_(ps, grads, ms, vs, lrs, step, 0.9, 0.999, 1e-15)
+        for p, r, o in zip(ps, ref, opts):
+            assert (p - r.detach()).abs().max().item() < 2e-6, step
+            assert rel_err(ms[ps.index(p)], o.state[r]["exp_avg"]) < 1e-5
