@@ -181,35 +181,52 @@ extern "C" int fsgs_epilogue_bwd(int64_t n_pixels, const float *render, const fl
 // HBM-bound by construction: 28 B per parameter float (1.65 KB per Gaussian per step).
 namespace fsgs {
 constexpr int kAdamMaxGroups = 8;
+constexpr int kAdamChunk = 1024;  // floats per workgroup (256 threads x float4)
 struct AdamArgs {
     float *p[kAdamMaxGroups];
     const float *g[kAdamMaxGroups];
     float *m[kAdamMaxGroups];
     float *v[kAdamMaxGroups];
-    long long end[kAdamMaxGroups];  // exclusive prefix ends of the groups in the flattened index space
+    long long n[kAdamMaxGroups];
+    int block_end[kAdamMaxGroups];  // exclusive prefix ends of each group's workgroup range
     float step_size[kAdamMaxGroups];
     int n_groups;
     float b1, b2, inv_sqrt_bc2, eps;
 };
 
+__device__ __forceinline__ void adam_one(float &p, float g, float &m, float &v, float b1, float b2, float ss,
+                                         float isb2, float eps) {
+    m = b1 * m + (1.f - b1) * g;
+    v = b2 * v + (1.f - b2) * g * g;
+    p -= ss * m / (sqrtf(v) * isb2 + eps);
+}
+
+// every group owns a whole number of workgroups; a thread updates 4 consecutive floats
 __global__ void __launch_bounds__(256) adam_kernel(AdamArgs a) {
-    const long long total = a.end[a.n_groups - 1];
-    for (long long i4 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i4 < total;
-         i4 += (long long)gridDim.x * blockDim.x * 4) {
+    int grp = 0;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const long long i = i4 + k;
-            if (i >= total) break;
-            int grp = 0;
-#pragma unroll
-            for (int q = 0; q < kAdamMaxGroups - 1; ++q) grp += (q < a.n_groups - 1 && i >= a.end[q]) ? 1 : 0;
-            const long long j = i - (grp ? a.end[grp - 1] : 0);
-            const float g = a.g[grp][j];
-            const float m = a.b1 * a.m[grp][j] + (1.f - a.b1) * g;
-            const float v = a.b2 * a.v[grp][j] + (1.f - a.b2) * g * g;
-            a.m[grp][j] = m;
-            a.v[grp][j] = v;
-            a.p[grp][j] -= a.step_size[grp] * m / (sqrtf(v) * a.inv_sqrt_bc2 + a.eps);
+    for (int q = 0; q < kAdamMaxGroups - 1; ++q) grp += (q < a.n_groups - 1 && (int)blockIdx.x >= a.block_end[q]) ? 1 : 0;
+    const int blk = blockIdx.x - (grp ? a.block_end[grp - 1] : 0);
+    const long long j = (long long)blk * kAdamChunk + threadIdx.x * 4;
+    const long long n = a.n[grp];
+    if (j >= n) return;
+    float *P = a.p[grp] + j, *M = a.m[grp] + j, *V = a.v[grp] + j;
+    const float *G = a.g[grp] + j;
+    const float ss = a.step_size[grp];
+    const bool vec = (j + 3 < n) && ((((uintptr_t)P | (uintptr_t)M | (uintptr_t)V | (uintptr_t)G) & 15) == 0);
+    if (vec) {
+        float4 p = *reinterpret_cast<float4 *>(P), m = *reinterpret_cast<float4 *>(M), v = *reinterpret_cast<float4 *>(V);
+        const float4 g = *reinterpret_cast<const float4 *>(G);
+        adam_one(p.x, g.x, m.x, v.x, a.b1, a.b2, ss, a.inv_sqrt_bc2, a.eps);
+        adam_one(p.y, g.y, m.y, v.y, a.b1, a.b2, ss, a.inv_sqrt_bc2, a.eps);
+        adam_one(p.z, g.z, m.z, v.z, a.b1, a.b2, ss, a.inv_sqrt_bc2, a.eps);
+        adam_one(p.w, g.w, m.w, v.w, a.b1, a.b2, ss, a.inv_sqrt_bc2, a.eps);
+        *reinterpret_cast<float4 *>(P) = p; *reinterpret_cast<float4 *>(M) = m; *reinterpret_cast<float4 *>(V) = v;
+    } else {
+        for (int k = 0; k < 4 && j + k < n; ++k) {
+            float p = P[k], m = M[k], v = V[k];
+            adam_one(p, G[k], m, v, a.b1, a.b2, ss, a.inv_sqrt_bc2, a.eps);
+            P[k] = p; M[k] = m; V[k] = v;
         }
     }
 }
@@ -221,23 +238,22 @@ extern "C" int fsgs_adam_step(int n_groups, float *const *params, const float *c
     if (n_groups < 1 || n_groups > fsgs::kAdamMaxGroups || step < 1) return FSGS_EINVAL;
     if (!params || !grads || !exp_avg || !exp_avg_sq || !numel || !lr) return FSGS_EINVAL;
     fsgs::AdamArgs a;
-    long long run = 0;
+    int blocks = 0;
     const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
-    for (int k = 0; k < n_groups; ++k) {
-        if (!params[k] || !grads[k] || !exp_avg[k] || !exp_avg_sq[k] || numel[k] < 0) return FSGS_EINVAL;
-        a.p[k] = params[k]; a.g[k] = grads[k]; a.m[k] = exp_avg[k]; a.v[k] = exp_avg_sq[k];
-        run += numel[k];
-        a.end[k] = run;
-        a.step_size[k] = (float)((double)lr[k] / bc1);
-    }
-    for (int k = n_groups; k < fsgs::kAdamMaxGroups; ++k) {
-        a.p[k] = nullptr; a.g[k] = nullptr; a.m[k] = nullptr; a.v[k] = nullptr; a.end[k] = run; a.step_size[k] = 0.f;
+    for (int k = 0; k < fsgs::kAdamMaxGroups; ++k) {
+        if (k < n_groups) {
+            if (!params[k] || !grads[k] || !exp_avg[k] || !exp_avg_sq[k] || numel[k] < 0) return FSGS_EINVAL;
+            a.p[k] = params[k]; a.g[k] = grads[k]; a.m[k] = exp_avg[k]; a.v[k] = exp_avg_sq[k];
+            a.n[k] = numel[k];
+            blocks += (int)((numel[k] + fsgs::kAdamChunk - 1) / fsgs::kAdamChunk);
+            a.step_size[k] = (float)((double)lr[k] / bc1);
+        } else {
+            a.p[k] = nullptr; a.g[k] = nullptr; a.m[k] = nullptr; a.v[k] = nullptr; a.n[k] = 0; a.step_size[k] = 0.f;
+        }
+        a.block_end[k] = blocks;
     }
     a.n_groups = n_groups; a.b1 = beta1; a.b2 = beta2; a.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2)); a.eps = eps;
-    if (run == 0) return FSGS_OK;
-    const long long threads = (run + 3) / 4;
-    long long blocks = (threads + 255) / 256;
-    if (blocks > 256 * 16) blocks = 256 * 16;
+    if (blocks == 0) return FSGS_OK;
     hipLaunchKernelGGL(fsgs::adam_kernel, dim3((unsigned)blocks), dim3(256), 0, fsgs::as_stream(stream), a);
     return fsgs::check_launch();
 }

@@ -543,6 +543,7 @@ def test_fused_adam_matches_torch(dev):
             r.grad = gr.clone()
             o.step()
         ops.adam_step_(ps, grads, ms, vs, lrs, step, 0.9, 0.999, 1e-15)
-        for p, r, o in zip(ps, ref, opts):
+        for k, (p, r, o) in enumerate(zip(ps, ref, opts)):
             assert (p - r.detach()).abs().max().item() < 2e-6, step
-            assert rel_err(ms[ps.index(p)], o.state[r]["exp_avg"]) < 1e-5
+            assert rel_err(ms[k], o.state[r]["exp_avg"]) < 1e-5
+            assert rel_err(vs[k], o.state[r]["exp_avg_sq"]) < 1e-5
