@@ -60,7 +60,7 @@ SIGNATURES = {
     "fsgs_split_samples": (_i, [_i64, _i, _p, _p, _p, _p, _p, _p, _p, _p]),
     "fsgs_ssim_l1_num_partials": (_i64, [_i, _i]),
     "fsgs_ssim_l1_fwd": (_i, [_i, _i, _p, _p, _p, _p, _p, _p, _p]),
-    "fsgs_adam_step": (_i, [_i, _p, _p, _p, _p, _p, _p, _i, _f, _f, _f, _p]),
+    "fsgs_adam_step": (_i, [_i, _p, _p, _p, _p, _p, _p, _i, C.c_double, C.c_double, _f, _p]),
     "fsgs_aux_l1_fwd": (_i, [_i64, _p, _p, _p, _p, _p, _p]),
     "fsgs_aux_l1_bwd": (_i, [_i64, _p, _p, _p, _p, _p, _f, _f, _p, _p, _p]),
     "fsgs_ssim_l1_bwd": (_i, [_i, _i, _p, _p, _p, _p, _p, _p, _f, _f, _p, _p]),

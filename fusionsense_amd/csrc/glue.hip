@@ -191,13 +191,13 @@ struct AdamArgs {
     int block_end[kAdamMaxGroups];  // exclusive prefix ends of each group's workgroup range
     float step_size[kAdamMaxGroups];
     int n_groups;
-    float b1, b2, inv_sqrt_bc2, eps;
+    float b1, b2, omb1, omb2, inv_sqrt_bc2, eps;  // omb = 1 - beta, rounded from double like torch does
 };
 
-__device__ __forceinline__ void adam_one(float &p, float g, float &m, float &v, float b1, float b2, float ss,
-                                         float isb2, float eps) {
-    m = b1 * m + (1.f - b1) * g;
-    v = b2 * v + (1.f - b2) * g * g;
+__device__ __forceinline__ void adam_one(float &p, float g, float &m, float &v, float b1, float b2, float omb1,
+                                         float omb2, float ss, float isb2, float eps) {
+    m = b1 * m + omb1 * g;
+    v = b2 * v + omb2 * g * g;
     p -= ss * m / (sqrtf(v) * isb2 + eps);
 }
 
@@ -217,15 +217,15 @@ __global__ void __launch_bounds__(256) adam_kernel(AdamArgs a) {
     if (vec) {
         float4 p = *reinterpret_cast<float4 *>(P), m = *reinterpret_cast<float4 *>(M), v = *reinterpret_cast<float4 *>(V);
         const float4 g = *reinterpret_cast<const float4 *>(G);
-        adam_one(p.x, g.x, m.x, v.x, a.b1, a.b2, ss, a.inv_sqrt_bc2, a.eps);
-        adam_one(p.y, g.y, m.y, v.y, a.b1, a.b2, ss, a.inv_sqrt_bc2, a.eps);
-        adam_one(p.z, g.z, m.z, v.z, a.b1, a.b2, ss, a.inv_sqrt_bc2, a.eps);
-        adam_one(p.w, g.w, m.w, v.w, a.b1, a.b2, ss, a.inv_sqrt_bc2, a.eps);
+        adam_one(p.x, g.x, m.x, v.x, a.b1, a.b2, a.omb1, a.omb2, ss, a.inv_sqrt_bc2, a.eps);
+        adam_one(p.y, g.y, m.y, v.y, a.b1, a.b2, a.omb1, a.omb2, ss, a.inv_sqrt_bc2, a.eps);
+        adam_one(p.z, g.z, m.z, v.z, a.b1, a.b2, a.omb1, a.omb2, ss, a.inv_sqrt_bc2, a.eps);
+        adam_one(p.w, g.w, m.w, v.w, a.b1, a.b2, a.omb1, a.omb2, ss, a.inv_sqrt_bc2, a.eps);
         *reinterpret_cast<float4 *>(P) = p; *reinterpret_cast<float4 *>(M) = m; *reinterpret_cast<float4 *>(V) = v;
     } else {
         for (int k = 0; k < 4 && j + k < n; ++k) {
             float p = P[k], m = M[k], v = V[k];
-            adam_one(p, G[k], m, v, a.b1, a.b2, ss, a.inv_sqrt_bc2, a.eps);
+            adam_one(p, G[k], m, v, a.b1, a.b2, a.omb1, a.omb2, ss, a.inv_sqrt_bc2, a.eps);
             P[k] = p; M[k] = m; V[k] = v;
         }
     }
@@ -233,13 +233,14 @@ __global__ void __launch_bounds__(256) adam_kernel(AdamArgs a) {
 }  // namespace fsgs
 
 extern "C" int fsgs_adam_step(int n_groups, float *const *params, const float *const *grads, float *const *exp_avg,
-                              float *const *exp_avg_sq, const int64_t *numel, const float *lr, int step, float beta1,
-                              float beta2, float eps, fsgs_stream_t stream) {
+                              float *const *exp_avg_sq, const int64_t *numel, const float *lr, int step, double beta1_d,
+                              double beta2_d, float eps, fsgs_stream_t stream) {
+    const float beta1 = (float)beta1_d, beta2 = (float)beta2_d;
     if (n_groups < 1 || n_groups > fsgs::kAdamMaxGroups || step < 1) return FSGS_EINVAL;
     if (!params || !grads || !exp_avg || !exp_avg_sq || !numel || !lr) return FSGS_EINVAL;
     fsgs::AdamArgs a;
     int blocks = 0;
-    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    const double bc1 = 1.0 - pow(beta1_d, (double)step), bc2 = 1.0 - pow(beta2_d, (double)step);
     for (int k = 0; k < fsgs::kAdamMaxGroups; ++k) {
         if (k < n_groups) {
             if (!params[k] || !grads[k] || !exp_avg[k] || !exp_avg_sq[k] || numel[k] < 0) return FSGS_EINVAL;
@@ -253,6 +254,7 @@ extern "C" int fsgs_adam_step(int n_groups, float *const *params, const float *c
         a.block_end[k] = blocks;
     }
     a.n_groups = n_groups; a.b1 = beta1; a.b2 = beta2; a.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2)); a.eps = eps;
+    a.omb1 = (float)(1.0 - (double)beta1_d); a.omb2 = (float)(1.0 - (double)beta2_d);
     if (blocks == 0) return FSGS_OK;
     hipLaunchKernelGGL(fsgs::adam_kernel, dim3((unsigned)blocks), dim3(256), 0, fsgs::as_stream(stream), a);
     return fsgs::check_launch();

@@ -278,8 +278,8 @@ int fsgs_epilogue_bwd(int64_t n_pixels, const float *render, const float *alphas
  * launch (dn_splatter/dn_config.py:36-75 steps one optimizer per group).  Arrays of n_groups HOST
  * entries holding device pointers; step is the 1-based step count after the increment. */
 int fsgs_adam_step(int n_groups, float *const *params, const float *const *grads, float *const *exp_avg,
-                   float *const *exp_avg_sq, const int64_t *numel, const float *lr, int step, float beta1,
-                   float beta2, float eps, fsgs_stream_t stream);
+                   float *const *exp_avg_sq, const int64_t *numel, const float *lr, int step, double beta1,
+                   double beta2, float eps, fsgs_stream_t stream);
 
 /* ---- N2: photometric loss on the render, fused (dn_splatter/dn_model.py:683 main loss with the
  * torchmetrics SSIM(kernel_size=11) of :244).  pred, gt: [H,W,3] channel-last.
