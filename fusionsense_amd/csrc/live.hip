@@ -64,6 +64,75 @@ __device__ __forceinline__ unsigned quadrant_mask(float mx, float my, float opac
     return m;
 }
 
+// One 64-byte line per (camera, Gaussian): {x, y, opacity, conic.a} {conic.b, conic.c, 0, 0}
+// {colour, zero padded} {extra xyz, 0}.  The list-order kernels below then gather ONE line per entry
+// instead of five to seven 4..16-byte pieces from five arrays (Gaussians sit in arbitrary storage
+// order, so every piece is its own sector fetch: PMC showed 268 MB fetched by live_compact).
+template <int D>
+__global__ void __launch_bounds__(256)
+live_pack_kernel(int64_t total, const float *__restrict__ means2d, const float *__restrict__ conics,
+                 const float *__restrict__ colors, const float *__restrict__ opacities,
+                 const float *__restrict__ extra, float4 *__restrict__ packed) {
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= total) return;
+    const float2 xy = reinterpret_cast<const float2 *>(means2d)[g];
+    float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (D == 4) {
+        c = reinterpret_cast<const float4 *>(colors)[g];
+    } else {
+        c.x = colors[g * D + 0];
+        if (D > 1) c.y = colors[g * D + 1];
+        if (D > 2) c.z = colors[g * D + 2];
+    }
+    packed[g * 4 + 0] = make_float4(xy.x, xy.y, opacities[g], conics[g * 3 + 0]);
+    packed[g * 4 + 1] = make_float4(conics[g * 3 + 1], conics[g * 3 + 2], 0.f, 0.f);
+    packed[g * 4 + 2] = c;
+    packed[g * 4 + 3] = extra ? make_float4(extra[g * 3 + 0], extra[g * 3 + 1], extra[g * 3 + 2], 0.f)
+                              : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+__global__ void __launch_bounds__(256)
+live_mask_packed_kernel(int64_t M, const int64_t *__restrict__ isect_ids, const int32_t *__restrict__ flatten_ids,
+                        const float4 *__restrict__ packed, int tw, int tile_bits, uint8_t *__restrict__ mask8) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > M) return;
+    if (i == M) { mask8[i] = 0; return; }
+    const int tile = (int)((isect_ids[i] >> 32) & ((1ll << tile_bits) - 1));
+    const int ty = tile / tw, tx = tile - ty * tw;
+    const int64_t g = flatten_ids[i];
+    const float4 r0 = packed[g * 4 + 0], r1 = packed[g * 4 + 1];
+    mask8[i] = (uint8_t)quadrant_mask(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, (float)(tx * 16), (float)(ty * 16));
+}
+
+__global__ void __launch_bounds__(256)
+live_compact_packed_kernel(int64_t M, int64_t cap, int rs, const uint8_t *__restrict__ mask8,
+                           const int4 *__restrict__ pos4, const int32_t *__restrict__ flatten_ids,
+                           const float4 *__restrict__ packed, float4 *__restrict__ rec) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M) return;
+    const unsigned m = mask8[i];
+    if (!m) return;
+    const int4 p = pos4[i];
+    const int32_t g = flatten_ids[i];
+    const float4 *src = packed + (int64_t)g * 4;
+    const float4 r0 = src[0];
+    float4 r1 = src[1];
+    const float4 r2 = src[2];
+    r1.z = __int_as_float((int)i);
+    r1.w = __int_as_float(g);
+    float4 r3 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (rs == 4) r3 = src[3];
+    const int pq[4] = {p.x, p.y, p.z, p.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        if (m & (1u << q)) {
+            float4 *dst = rec + rs * ((int64_t)q * cap + pq[q]);
+            dst[0] = r0; dst[1] = r1; dst[2] = r2;
+            if (rs == 4) dst[3] = r3;
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256)
 live_mask_kernel(int64_t M, const int64_t *__restrict__ isect_ids, const int32_t *__restrict__ flatten_ids,
                  const float *__restrict__ means2d, const float *__restrict__ conics,
@@ -229,8 +298,8 @@ extern "C" size_t fsgs_live_scratch_bytes(int64_t n_isects) {
 extern "C" int fsgs_live_prepare(int D, const float *means2d, const float *conics, const float *colors,
                                  const float *opacities, const float *extra, int tile_width, int tile_bits,
                                  const int64_t *isect_ids, const int32_t *flatten_ids, int64_t n_isects,
-                                 uint8_t *mask8, int32_t *pos4, float *records, void *scratch,
-                                 size_t scratch_bytes, fsgs_stream_t stream) {
+                                 int64_t n_gauss_total, float *packed, uint8_t *mask8, int32_t *pos4,
+                                 float *records, void *scratch, size_t scratch_bytes, fsgs_stream_t stream) {
     if (n_isects < 0 || (D != 1 && D != 3 && D != 4)) return FSGS_EINVAL;
     if (!mask8 || !pos4) return FSGS_EINVAL;
     if (n_isects > 0x7FFFFFF0ll) return FSGS_EINVAL;  // list indices are 32-bit (as in the reference)
@@ -240,14 +309,35 @@ extern "C" int fsgs_live_prepare(int D, const float *means2d, const float *conic
     if (n_isects > 0 && (!means2d || !conics || !colors || !opacities || !isect_ids || !flatten_ids || !records))
         return FSGS_EINVAL;
     int4 *block_sums = reinterpret_cast<int4 *>(scratch);
-    hipLaunchKernelGGL(live_mask_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, n_isects, isect_ids,
-                       flatten_ids, means2d, conics, opacities, tile_width, tile_bits, mask8);
+    float4 *pk = reinterpret_cast<float4 *>(packed);
+    const bool use_packed = packed != nullptr && n_gauss_total > 0 && n_isects > 0;
+    if (use_packed) {
+        const dim3 gp(ceil_div(n_gauss_total, 256));
+        if (D == 4)
+            hipLaunchKernelGGL((live_pack_kernel<4>), gp, dim3(256), 0, s, n_gauss_total, means2d, conics, colors,
+                               opacities, extra, pk);
+        else if (D == 3)
+            hipLaunchKernelGGL((live_pack_kernel<3>), gp, dim3(256), 0, s, n_gauss_total, means2d, conics, colors,
+                               opacities, extra, pk);
+        else
+            hipLaunchKernelGGL((live_pack_kernel<1>), gp, dim3(256), 0, s, n_gauss_total, means2d, conics, colors,
+                               opacities, extra, pk);
+        hipLaunchKernelGGL(live_mask_packed_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, n_isects, isect_ids,
+                           flatten_ids, pk, tile_width, tile_bits, mask8);
+    } else {
+        hipLaunchKernelGGL(live_mask_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, n_isects, isect_ids,
+                           flatten_ids, means2d, conics, opacities, tile_width, tile_bits, mask8);
+    }
     const int64_t nb = scan4_blocks(n);
     hipLaunchKernelGGL(scan4_reduce_kernel, dim3((unsigned)nb), dim3(kS4Block), 0, s, n, mask8, block_sums);
     hipLaunchKernelGGL(scan4_block_sums_kernel, dim3(1), dim3(kS4Block), 0, s, nb, block_sums);
     hipLaunchKernelGGL(scan4_apply_kernel, dim3((unsigned)nb), dim3(kS4Block), 0, s, n, mask8, block_sums,
                        reinterpret_cast<int4 *>(pos4));
-    if (n_isects > 0) {
+    if (n_isects > 0 && use_packed) {
+        hipLaunchKernelGGL(live_compact_packed_kernel, dim3(ceil_div(n_isects, 256)), dim3(256), 0, s, n_isects,
+                           n_isects, extra ? 4 : 3, mask8, reinterpret_cast<const int4 *>(pos4), flatten_ids, pk,
+                           reinterpret_cast<float4 *>(records));
+    } else if (n_isects > 0) {
         const dim3 grid(ceil_div(n_isects, 256));
         float4 *rec = reinterpret_cast<float4 *>(records);
         const int4 *p4 = reinterpret_cast<const int4 *>(pos4);

@@ -112,8 +112,10 @@ class _FusedGetOutputs(torch.autograd.Function):
         mask8 = arena[o:o + M + 1]; o += a(M + 1)
         scratch = arena[o:o + sbytes]; o += a(sbytes)
         seg_state = arena[o:o + seg_bytes].view(torch.float32) if needs_bwd else None
+        packed = torch.empty(N, 16, **f32)
         _run(lib.fsgs_live_prepare, (4, ptr(means2d), ptr(conics), ptr(colors), ptr(opac_sig), ptr(normals_cam),
-                                    tw, tile_bits(tw * th), ptr(isect_ids), ptr(flatten_ids), M, ptr(mask8),
+                                    tw, tile_bits(tw * th), ptr(isect_ids), ptr(flatten_ids), M, N, ptr(packed),
+                                    ptr(mask8),
                                     ptr(pos4), ptr(records), ptr(scratch), sbytes, sp), "fsgs_live_prepare", "_d4e3")
 
         render = torch.empty(1, H, W, 4, **f32)

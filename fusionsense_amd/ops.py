@@ -368,8 +368,10 @@ class _Rasterize(torch.autograd.Function):
             scratch = arena[o + a(M + 1):o + a(M + 1) + sbytes]
             o2 = o + a(M + 1) + a(sbytes)
             seg_state = arena[o2:o2 + seg_bytes].view(torch.float32) if needs_bwd else None
+            packed = torch.empty(Cn * N, 16, dtype=torch.float32, device=dev)
             _run(lib.fsgs_live_prepare, (D, ptr(means2d), ptr(conics), ptr(colors), ptr(opacities), None, tw,
-                                        tile_bits(tw * th), ptr(isect_ids), ptr(flatten_ids), M, ptr(mask8),
+                                        tile_bits(tw * th), ptr(isect_ids), ptr(flatten_ids), M, Cn * N,
+                                        ptr(packed), ptr(mask8),
                                         ptr(pos4), ptr(records), ptr(scratch), sbytes, stream_ptr(dev)),
                  "fsgs_live_prepare", f"_d{D}")
             _run(lib.fsgs_raster_fwd_live, (Cn, D, ptr(records), ptr(pos4), ptr(isect_offsets), M,

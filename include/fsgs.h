@@ -182,8 +182,12 @@ size_t fsgs_live_scratch_bytes(int64_t n_isects);
 int fsgs_live_prepare(int D, const float *means2d, const float *conics, const float *colors,
                       const float *opacities, const float *extra, int tile_width, int tile_bits,
                       const int64_t *isect_ids,
-                      const int32_t *flatten_ids, int64_t n_isects, uint8_t *mask8, int32_t *pos4,
-                      float *records, void *scratch, size_t scratch_bytes, fsgs_stream_t stream);
+                      const int32_t *flatten_ids, int64_t n_isects, int64_t n_gauss_total,
+                      float *packed, uint8_t *mask8, int32_t *pos4, float *records, void *scratch,
+                      size_t scratch_bytes, fsgs_stream_t stream);
+/* packed (nullable scratch, n_gauss_total = C*N rows of 16 floats): when given, every Gaussian's
+ * attributes are first packed into one 64-B line so that the list-order kernels gather one line
+ * per entry instead of 5-7 scattered pieces. */
 /* seg_state (nullable for inference): 4 * fsgs_live_seg_slots(...) * 64 * (1+D) floats; the forward
  * stores every pixel's (T, accumulated colour) before each 64-entry segment of its quadrant list
  * so that the backward can process segments independently. */
