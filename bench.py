@@ -169,7 +169,9 @@ def main():
     barrier()
 
     # ---- timed region: EXACTLY args.steps full iterations ----
-    ops.TIMER.reset(enabled=True)
+    # inside the timed region only the heavy kernels are event-timed (roofline); the complete
+    # per-kernel table is taken in a separate, untimed pass below
+    ops.TIMER.reset(enabled=True, only=("raster_", "sort_pairs", "live_prepare"))
     torch.cuda.synchronize()
     n_alloc0 = torch.cuda.memory_stats(dev).get('num_device_alloc', 0)
     t0 = time.perf_counter()
@@ -189,6 +191,15 @@ def main():
         elapsed = t.item()
 
     # ---- side measurements (outside the timed region) ----
+    ops.TIMER.reset(enabled=True)
+    for s in range(min(args.steps, 10)):
+        v = view_of(s)
+        trainer.train_step(cams[v], targets[v])
+    torch.cuda.synchronize()
+    kernel_ms_all = ops.TIMER.summary()
+    ops.TIMER.reset(enabled=False)
+    for k_, v_ in kernel_ms_all.items():
+        kernel_ms.setdefault(k_, v_)  # heavy kernels keep their in-region figures
     info = trainer.last_info
     N = trainer.num_gaussians()
     M = int(info["flatten_ids"].numel())

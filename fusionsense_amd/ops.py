@@ -29,24 +29,29 @@ class _KernelTimer:
     def __init__(self):
         self.enabled = False
         self.records = []
+        self.only = None
 
-    def reset(self, enabled: bool = False) -> None:
+    def reset(self, enabled: bool = False, only=None) -> None:
+        """only: optional tuple of name prefixes; other launches are not timed (two event records
+        per launch are not free on the host)."""
         self.enabled = enabled
         self.records = []
+        self.only = tuple(only) if only else None
 
     class _Span:
         def __init__(self, timer, name):
             self.timer, self.name = timer, name
 
         def __enter__(self):
-            if self.timer.enabled:
+            self.on = self.timer.enabled and (self.timer.only is None or self.name.startswith(self.timer.only))
+            if self.on:
                 self.start = torch.cuda.Event(enable_timing=True)
                 self.end = torch.cuda.Event(enable_timing=True)
                 self.start.record()
             return self
 
         def __exit__(self, *exc):
-            if self.timer.enabled:
+            if self.on:
                 self.end.record()
                 self.timer.records.append((self.name, self.start, self.end))
             return False
