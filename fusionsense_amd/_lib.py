@@ -36,6 +36,8 @@ SIGNATURES = {
     "fsgs_bucket_fill_sort": (_i, [_i, _i, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _i64, _i64, _p, _p, _p, _p]),
     "fsgs_sort_scratch_bytes": (_sz, [_i64]),
     "fsgs_sort_pairs": (_i, [_i64, _p, _p, _p, _p, _i, _p, _sz, C.POINTER(_i), _p]),
+    "fsgs_sort_onesweep_scratch_bytes": (_sz, [_i64]),
+    "fsgs_sort_pairs_onesweep": (_i, [_i64, _p, _p, _p, _p, _i, _p, _sz, C.POINTER(_i), C.POINTER(_p), _p]),
     "fsgs_isect_offset_encode": (_i, [_i64, _p, _i, _i, _i, _p, _p]),
     "fsgs_raster_fwd": (_i, [_i, _i, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _i64, _p, _p, _p, _p]),
     "fsgs_raster_bwd": (_i, [_i, _i, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),

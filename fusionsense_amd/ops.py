@@ -126,6 +126,7 @@ def isect_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tile_size: int, 
                                C.byref(diff_host) if return_rule_diff else None, stream_ptr(dev)),
          "fsgs_isect_count")
     M = int(m_host.value)
+    check_onesweep_errors()  # the stream was just synchronised: earlier sorts' error words have landed
     ids = torch.empty(M, dtype=torch.int64, device=dev)
     flat = torch.empty(M, dtype=torch.int32, device=dev)
     if M > 0:
@@ -186,6 +187,23 @@ def bin_and_sort(means2d: Tensor, radii: Tensor, depths: Tensor, tile_size: int,
     return tpg, ids, flat, offsets, diff
 
 
+USE_ONESWEEP_SORT = False  # single-sweep radix passes (csrc/sort.hip); set by tests / after validation
+_onesweep_errors = []       # device error words of recent sorts, checked lazily (no extra sync)
+
+
+def check_onesweep_errors(sync: bool = False) -> None:
+    """Raise if any single-sweep sort since the last check reported a look-back timeout.  The error
+    words were copied to pinned host memory right after each sort; this is called where the stream
+    has just been synchronised anyway (after fsgs_isect_count), so it costs no extra sync."""
+    global _onesweep_errors
+    if sync and _onesweep_errors:
+        torch.cuda.synchronize()
+    pending, _onesweep_errors = _onesweep_errors, []
+    for t in pending:
+        if int(t[0]) != 0:
+            raise _lib.FsgsError("single-sweep radix sort: look-back spin timed out; results invalid")
+
+
 def sort_pairs(keys: Tensor, vals: Tensor, end_bit: int = 64) -> Tuple[Tensor, Tensor]:
     """Stable radix sort of (i64, i32) pairs on key bits [0, end_bit).  Inputs are clobbered."""
     lib = load()
@@ -195,6 +213,18 @@ def sort_pairs(keys: Tensor, vals: Tensor, end_bit: int = 64) -> Tuple[Tensor, T
     dev = keys.device
     kb = torch.empty_like(keys)
     vb = torch.empty_like(vals)
+    if USE_ONESWEEP_SORT:
+        sbytes = lib.fsgs_sort_onesweep_scratch_bytes(n)
+        scratch = torch.empty(sbytes, dtype=torch.uint8, device=dev)
+        in_b = C.c_int(0)
+        err_ptr = C.c_void_p(0)
+        _run(lib.fsgs_sort_pairs_onesweep, (n, ptr(keys), ptr(vals), ptr(kb), ptr(vb), end_bit, ptr(scratch), sbytes,
+                                           C.byref(in_b), C.byref(err_ptr), stream_ptr(dev)), "fsgs_sort_pairs")
+        off = err_ptr.value - scratch.data_ptr()
+        host_flag = torch.zeros(1, dtype=torch.int32).pin_memory()
+        host_flag.copy_(scratch[off:off + 4].view(torch.int32), non_blocking=True)
+        _onesweep_errors.append(host_flag)
+        return (kb, vb) if in_b.value else (keys, vals)
     sbytes = lib.fsgs_sort_scratch_bytes(n)
     scratch = torch.empty(sbytes, dtype=torch.uint8, device=dev)
     in_b = C.c_int(0)

@@ -141,6 +141,16 @@ int fsgs_sort_pairs(int64_t n, int64_t *keys_a, int32_t *vals_a, int64_t *keys_b
                     int end_bit, void *scratch, size_t scratch_bytes, int *result_in_b,
                     fsgs_stream_t stream);
 
+/* Single-sweep variant of the same sort: one launch per 8-bit pass (decoupled look-back over
+ * ticket-ordered tiles, 8-byte {flag,value} agent-scope status granules, bounded spins) plus two
+ * up-front histogram launches, instead of five launches per pass.  Same result, bit for bit.
+ * *error_dev_out receives the address of a device word that becomes non-zero if a look-back spin
+ * timed out (the output is then invalid and the caller must re-sort with fsgs_sort_pairs). */
+size_t fsgs_sort_onesweep_scratch_bytes(int64_t n);
+int fsgs_sort_pairs_onesweep(int64_t n, int64_t *keys_a, int32_t *vals_a, int64_t *keys_b,
+                             int32_t *vals_b, int end_bit, void *scratch, size_t scratch_bytes,
+                             int *result_in_b, uint32_t **error_dev_out, fsgs_stream_t stream);
+
 /* ---- E6: isect_offset_encode (gsplat._C.isect_offset_encode) ---------------------------------
  * offsets[C*n_tiles] i32: first sorted index of every (camera, tile). */
 int fsgs_isect_offset_encode(int64_t n_isects, const int64_t *isect_ids_sorted, int C, int n_tiles,

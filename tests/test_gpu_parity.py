@@ -79,8 +79,18 @@ def test_isect_sort_offsets_bit_exact(dev, legacy):
     assert np.array_equal(g_off.cpu().numpy(), offs)
 
 
-@pytest.mark.parametrize("n", [0, 1, 2, 63, 64, 65, 2047, 2048, 2049, 100_003, 1_500_000])
-def test_sort_pairs_stable(dev, n):
+@pytest.fixture(params=[False, True], ids=["5launch", "onesweep"])
+def sort_variant(request):
+    from fusionsense_amd import ops
+    old = ops.USE_ONESWEEP_SORT
+    ops.USE_ONESWEEP_SORT = request.param
+    yield request.param
+    ops.check_onesweep_errors(sync=True)
+    ops.USE_ONESWEEP_SORT = old
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 63, 64, 65, 2047, 2048, 2049, 100_003, 1_500_000, 5_000_001])
+def test_sort_pairs_stable(dev, n, sort_variant):
     from fusionsense_amd import ops
     rng = np.random.default_rng(n)
     # few distinct keys -> many ties: stability is visible in the payload order
@@ -94,7 +104,7 @@ def test_sort_pairs_stable(dev, n):
     assert np.array_equal(v.cpu().numpy(), vals[order])
 
 
-def test_sort_pairs_full_64bit(dev):
+def test_sort_pairs_full_64bit(dev, sort_variant):
     from fusionsense_amd import ops
     rng = np.random.default_rng(7)
     keys = rng.integers(0, np.iinfo(np.int64).max, size=300_000, dtype=np.int64)
