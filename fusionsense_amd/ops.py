@@ -187,7 +187,7 @@ def bin_and_sort(means2d: Tensor, radii: Tensor, depths: Tensor, tile_size: int,
     return tpg, ids, flat, offsets, diff
 
 
-USE_ONESWEEP_SORT = False  # single-sweep radix passes (csrc/sort.hip); set by tests / after validation
+USE_ONESWEEP_SORT = True   # single-sweep radix passes (csrc/sort.hip); False = 5 launches per pass
 _onesweep_errors = []       # device error words of recent sorts, checked lazily (no extra sync)
 
 
