@@ -187,7 +187,7 @@ def bin_and_sort(means2d: Tensor, radii: Tensor, depths: Tensor, tile_size: int,
     return tpg, ids, flat, offsets, diff
 
 
-USE_ONESWEEP_SORT = True   # single-sweep radix passes (csrc/sort.hip); False = 5 launches per pass
+USE_ONESWEEP_SORT = False  # single-sweep radix passes (csrc/sort.hip): correct but 0.52 vs 0.23 ms (serial look-back over memory-side status words)
 _onesweep_errors = []       # device error words of recent sorts, checked lazily (no extra sync)
 
 
