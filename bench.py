@@ -202,7 +202,10 @@ def main():
         kernel_ms.setdefault(k_, v_)  # heavy kernels keep their in-region figures
     info = trainer.last_info
     N = trainer.num_gaussians()
-    M = int(info["flatten_ids"].numel())
+    # M = gsplat's intersection count (sum of tiles_per_gauss): the unit of the byte model; the fused
+    # node bins and sorts only the live subset
+    M = int(info["tiles_per_gauss"].sum().item())
+    n_live = int(info["flatten_ids"].numel())
     n_vis = int((info["radii"] > 0).sum().item())
     P = W * H
     # iteration without the optimizer step
@@ -280,7 +283,7 @@ def main():
                                    "1 view/rank/step; caller = " + ("fused get_outputs node" if fused else
                                                                     "reference-style op-by-op glue over the drop-in surface"),
                        "n_gaussians": N, "width": W, "height": H, "views": len(cams),
-                       "n_isects": M, "n_visible": n_vis, "isects_per_gaussian": round(M / max(N, 1), 3),
+                       "n_isects": M, "n_isects_live": n_live, "n_visible": n_vis, "isects_per_gaussian": round(M / max(N, 1), 3),
                        "normal_pass_list_reuse": bool(reused), "parallelism": f"dp{world}"},
             "rendered_mpix_per_s": round(world * P / t_fwd / 1e6, 2),
             "fwd_ms": round(t_fwd * 1e3, 3),

@@ -42,7 +42,9 @@ SIGNATURES = {
     "fsgs_raster_fwd": (_i, [_i, _i, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _i64, _p, _p, _p, _p]),
     "fsgs_raster_bwd": (_i, [_i, _i, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "fsgs_live_scratch_bytes": (_sz, [_i64]),
-    "fsgs_live_prepare": (_i, [_i, _p, _p, _p, _p, _p, _i, _i, _p, _p, _i64, _i64, _p, _p, _p, _p, _p, _sz, _p]),
+    "fsgs_live_prepare": (_i, [_i, _p, _p, _p, _p, _p, _i, _i, _p, _p, _i64, _i64, _p, _i, _p, _p, _p, _p, _sz, _p]),
+    "fsgs_isect_count_live": (_i, [_i, _i, _p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _sz, C.POINTER(_i64), _p]),
+    "fsgs_isect_emit_live": (_i, [_i, _i, _p, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p]),
     "fsgs_live_seg_slots": (_i64, [_i, _i, _i, _i64]),
     "fsgs_raster_fwd_live": (_i, [_i, _i, _p, _p, _p, _i64, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p]),
     "fsgs_raster_bwd_live": (_i, [_i, _i, _p, _p, _p, _i64, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p]),

@@ -4,6 +4,7 @@
 // `map_gaussian_to_intersects` / `get_tile_bin_edges` behind gsplat.rasterize_gaussians
 // (dn_model.py:644-653).  Integer work: every output is bit-exact against the oracle.
 #include "common.h"
+#include "cull.h"
 #include "scan.h"
 
 namespace fsgs {
@@ -115,6 +116,94 @@ isect_emit_kernel(int C, int N, const float *__restrict__ means2d, const int32_t
     }
 }
 
+// ---- live emission (fused get_outputs node) -------------------------------------------------------
+// Same tile rectangles as above, but a (Gaussian, tile) pair is only counted / emitted if the
+// Gaussian can reach at least one 8x8 quadrant of the tile at alpha >= 1/255 (cull.h).  The 4-bit
+// quadrant mask rides in the payload's top bits (flatten id < 2^28), so the separate list-order
+// mask kernel and ~3/4 of the sort, scan and compaction traffic disappear.  tiles_per_gauss still
+// reports gsplat's full rectangle count.  EMIT = false: count pass; EMIT = true: emit pass.
+template <bool EMIT>
+__global__ void __launch_bounds__(256)
+isect_live_kernel(int C, int N, const float *__restrict__ means2d, const int32_t *__restrict__ radii,
+                  const float *__restrict__ depths, const float *__restrict__ conics,
+                  const float *__restrict__ opacities, const int64_t *__restrict__ cum_live, int tw, int th,
+                  int tile_bits, int32_t *__restrict__ tiles_per_gauss, int32_t *__restrict__ live_per_gauss,
+                  int64_t *__restrict__ isect_ids, int32_t *__restrict__ payload) {
+    const int64_t total = (int64_t)C * N;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    TileRect t = {0, 0, 0, 0};
+    int cnt = 0;
+    float mx = 0.f, my = 0.f, op = 0.f, ca = 0.f, cb = 0.f, cc = 0.f;
+    int64_t key_hi_base = 0, depth_bits = 0, start = 0;
+    if (idx < total) {
+        const int r = radii[idx];
+        if (r > 0) {
+            const float2 m = reinterpret_cast<const float2 *>(means2d)[idx];
+            mx = m.x; my = m.y;
+            t = tile_rect(mx, my, r, 16, tw, th, 0);
+            cnt = (t.x1 - t.x0) * (t.y1 - t.y0);
+            op = opacities[idx];
+            ca = conics[idx * 3 + 0]; cb = conics[idx * 3 + 1]; cc = conics[idx * 3 + 2];
+            if (EMIT) {
+                const int64_t c = idx / N;
+                key_hi_base = c << (32 + tile_bits);
+                depth_bits = (int64_t)(uint32_t)__float_as_int(depths[idx]);
+                start = (idx == 0) ? 0 : cum_live[idx - 1];
+            }
+        }
+        if (!EMIT) tiles_per_gauss[idx] = cnt;
+    }
+    const bool wide = cnt >= kWideTiles;
+    int live = 0;
+    if (cnt > 0 && !wide) {
+        for (int y = t.y0; y < t.y1; ++y)
+            for (int x = t.x0; x < t.x1; ++x) {
+                const unsigned m = quadrant_mask(mx, my, op, ca, cb, cc, (float)(x * 16), (float)(y * 16));
+                if (m) {
+                    if (EMIT) {
+                        isect_ids[start + live] = key_hi_base | ((int64_t)(y * tw + x) << 32) | depth_bits;
+                        payload[start + live] = (int32_t)((m << 28) | (uint32_t)idx);
+                    }
+                    ++live;
+                }
+            }
+    }
+    // wave-cooperative path for wide splats: 64 tiles per step, ballot-compacted
+    unsigned long long wide_mask = __ballot(wide);
+    while (wide_mask) {
+        const int src = __ffsll((long long)wide_mask) - 1;
+        wide_mask &= wide_mask - 1;
+        const int x0 = __shfl(t.x0, src, 64), y0 = __shfl(t.y0, src, 64), x1 = __shfl(t.x1, src, 64);
+        const int n = __shfl(cnt, src, 64);
+        const float smx = __shfl(mx, src, 64), smy = __shfl(my, src, 64), sop = __shfl(op, src, 64);
+        const float sca = __shfl(ca, src, 64), scb = __shfl(cb, src, 64), scc = __shfl(cc, src, 64);
+        const int64_t kb = __shfl(key_hi_base, src, 64), db = __shfl(depth_bits, src, 64);
+        const int64_t st = __shfl(start, src, 64);
+        const uint32_t gid = (uint32_t)__shfl((long long)idx, src, 64);
+        const int wdt = x1 - x0;
+        int run = 0;
+        for (int k0 = 0; k0 < n; k0 += 64) {
+            const int k = k0 + lane;
+            unsigned m = 0u;
+            int x = 0, y = 0;
+            if (k < n) {
+                y = y0 + k / wdt; x = x0 + k % wdt;
+                m = quadrant_mask(smx, smy, sop, sca, scb, scc, (float)(x * 16), (float)(y * 16));
+            }
+            const unsigned long long b = __ballot(m != 0u);
+            if (EMIT && m) {
+                const int pos = run + __popcll(b & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))));
+                isect_ids[st + pos] = kb | ((int64_t)(y * tw + x) << 32) | db;
+                payload[st + pos] = (int32_t)((m << 28) | gid);
+            }
+            run += __popcll(b);
+        }
+        if (lane == src) live = run;
+    }
+    if (!EMIT && idx < total) live_per_gauss[idx] = live;
+}
+
 __global__ void __launch_bounds__(256)
 offset_encode_kernel(int64_t n_isects, const int64_t *__restrict__ ids, int n_tiles, int tile_bits,
                      int n_total, int32_t *__restrict__ offsets) {
@@ -212,5 +301,50 @@ extern "C" int fsgs_isect_offset_encode(int64_t n_isects, const int64_t *isect_i
     if (!isect_ids_sorted) return FSGS_EINVAL;
     hipLaunchKernelGGL(offset_encode_kernel, dim3(ceil_div(n_isects, 256)), dim3(256), 0, s, n_isects,
                        isect_ids_sorted, n_tiles, tile_bits, n_total, offsets);
+    return check_launch();
+}
+
+
+// Live emission, pass 1: tiles_per_gauss (gsplat's rectangle count), live_per_gauss and its inclusive
+// scan cum_live; synchronises and returns the number of LIVE intersections.  tile_size is 16.
+extern "C" int fsgs_isect_count_live(int C, int N, const float *means2d, const int32_t *radii,
+                                     const float *conics, const float *opacities, int tile_width,
+                                     int tile_height, int32_t *tiles_per_gauss, int32_t *live_per_gauss,
+                                     int64_t *cum_live, void *scratch, size_t scratch_bytes,
+                                     int64_t *n_live_host, fsgs_stream_t stream) {
+    if (C < 0 || N < 0 || !n_live_host) return FSGS_EINVAL;
+    const int64_t total = (int64_t)C * N;
+    *n_live_host = 0;
+    if (total == 0) return FSGS_OK;
+    if (total >= (1ll << 28)) return FSGS_EINVAL;  // the payload keeps 28 bits for the flatten id
+    if (!means2d || !radii || !conics || !opacities || !tiles_per_gauss || !live_per_gauss || !cum_live)
+        return FSGS_EINVAL;
+    if (scratch_bytes < fsgs_scan_scratch_bytes(total) || !scratch) return FSGS_ESCRATCH;
+    hipStream_t s = as_stream(stream);
+    hipLaunchKernelGGL((isect_live_kernel<false>), dim3(ceil_div(total, 256)), dim3(256), 0, s, C, N, means2d, radii,
+                       nullptr, conics, opacities, nullptr, tile_width, tile_height, 0, tiles_per_gauss,
+                       live_per_gauss, nullptr, nullptr);
+    int rc = device_scan<int32_t, true>(total, live_per_gauss, cum_live, scratch, scratch_bytes, s);
+    if (rc != FSGS_OK) return rc;
+    hipError_t e = hipMemcpyAsync(n_live_host, cum_live + (total - 1), sizeof(int64_t), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) { g_last_hip_error = (int)e; return FSGS_ELAUNCH; }
+    return FSGS_OK;
+}
+
+// Pass 2: isect_ids[M_live] and payload[M_live] = quadrant mask << 28 | flatten id.
+extern "C" int fsgs_isect_emit_live(int C, int N, const float *means2d, const int32_t *radii,
+                                    const float *depths, const float *conics, const float *opacities,
+                                    const int64_t *cum_live, int tile_width, int tile_height,
+                                    int64_t *isect_ids, int32_t *payload, fsgs_stream_t stream) {
+    if (C < 0 || N < 0) return FSGS_EINVAL;
+    const int64_t total = (int64_t)C * N;
+    if (total == 0) return FSGS_OK;
+    if (!means2d || !radii || !depths || !conics || !opacities || !cum_live || !isect_ids || !payload)
+        return FSGS_EINVAL;
+    const int tb = tile_bits_for(tile_width * tile_height);
+    hipLaunchKernelGGL((isect_live_kernel<true>), dim3(ceil_div(total, 256)), dim3(256), 0, as_stream(stream), C, N,
+                       means2d, radii, depths, conics, opacities, cum_live, tile_width, tile_height, tb, nullptr,
+                       nullptr, isect_ids, payload);
     return check_launch();
 }

@@ -21,48 +21,10 @@
 // Exactness: an entry is dropped for a quadrant only if no pixel centre in it can satisfy
 // alpha >= 1/255, so images, last_ids and gradients equal those of the plain walk.
 #include "common.h"
+#include "cull.h"
 #include "scan.h"
 
 namespace fsgs {
-
-constexpr float kCullMargin = 0.02f;  // slack on ln(255*opacity) against fp32 rounding of sigma / exp
-
-// min over the rectangle [x_lo,x_hi] x [y_lo,y_hi] of q(p) = 0.5*(a dx^2 + c dy^2) + b dx dy,
-// (dx,dy) = (mx,my) - p, for a positive-definite conic.  Convex => attained at the centre
-// (if inside) or on one of the four edges, each a clamped 1-D parabola.
-__device__ __forceinline__ float min_sigma_rect(float mx, float my, float a, float b, float c, float inv_a,
-                                                float inv_c, float x_lo, float x_hi, float y_lo, float y_hi) {
-    const float dx_lo = mx - x_hi, dx_hi = mx - x_lo, dy_lo = my - y_hi, dy_hi = my - y_lo;
-    if (dx_lo <= 0.f && dx_hi >= 0.f && dy_lo <= 0.f && dy_hi >= 0.f) return 0.f;
-    float best = 3.0e38f;
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-        const float dxe = e ? dx_hi : dx_lo;
-        const float dy = fminf(fmaxf(-b * dxe * inv_c, dy_lo), dy_hi);
-        best = fminf(best, 0.5f * (a * dxe * dxe + c * dy * dy) + b * dxe * dy);
-        const float dye = e ? dy_hi : dy_lo;
-        const float dx = fminf(fmaxf(-b * dye * inv_a, dx_lo), dx_hi);
-        best = fminf(best, 0.5f * (a * dx * dx + c * dye * dye) + b * dx * dye);
-    }
-    return best;
-}
-
-// 4-bit mask: bit q = qy*2+qx set if the Gaussian can reach quadrant q of the 16x16 tile at
-// (tile_x0, tile_y0).  Conservative: a set bit never hides a contribution.
-__device__ __forceinline__ unsigned quadrant_mask(float mx, float my, float opac, float a, float b, float c,
-                                                  float tile_x0, float tile_y0) {
-    if (!(opac >= kAlphaMin * 0.999f)) return 0u;                   // alpha <= opac < 1/255 everywhere
-    if (!(a > 0.f && c > 0.f && a * c - b * b > 0.f)) return 0xFu;  // not positive definite: no bound
-    const float tau = __logf(255.f * opac) + kCullMargin;
-    const float inv_a = 1.f / a, inv_c = 1.f / c;
-    unsigned m = 0u;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const float x0 = tile_x0 + (float)((q & 1) * 8) + 0.5f, y0 = tile_y0 + (float)((q >> 1) * 8) + 0.5f;
-        if (min_sigma_rect(mx, my, a, b, c, inv_a, inv_c, x0, x0 + 7.f, y0, y0 + 7.f) <= tau) m |= 1u << q;
-    }
-    return m;
-}
 
 // One 64-byte line per (camera, Gaussian): {x, y, opacity, conic.a} {conic.b, conic.c, 0, 0}
 // {colour, zero padded} {extra xyz, 0}.  The list-order kernels below then gather ONE line per entry
@@ -285,6 +247,18 @@ live_compact_kernel(int64_t M, int64_t cap, const uint8_t *__restrict__ mask8, c
     }
 }
 
+// Live emission (isect.hip) carries the quadrant mask in the payload's top 4 bits: split it into
+// the mask array and clean flatten ids (one pass over the ~M/4 live entries).
+__global__ void __launch_bounds__(256)
+payload_split_kernel(int64_t M, int32_t *__restrict__ payload_ids, uint8_t *__restrict__ mask8) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > M) return;
+    if (i == M) { mask8[i] = 0; return; }
+    const uint32_t v = (uint32_t)payload_ids[i];
+    mask8[i] = (uint8_t)(v >> 28);
+    payload_ids[i] = (int32_t)(v & 0x0FFFFFFFu);
+}
+
 inline int64_t scan4_blocks(int64_t n) { return (n + kS4Tile - 1) / kS4Tile; }
 
 }  // namespace fsgs
@@ -298,8 +272,9 @@ extern "C" size_t fsgs_live_scratch_bytes(int64_t n_isects) {
 extern "C" int fsgs_live_prepare(int D, const float *means2d, const float *conics, const float *colors,
                                  const float *opacities, const float *extra, int tile_width, int tile_bits,
                                  const int64_t *isect_ids, const int32_t *flatten_ids, int64_t n_isects,
-                                 int64_t n_gauss_total, float *packed, uint8_t *mask8, int32_t *pos4,
-                                 float *records, void *scratch, size_t scratch_bytes, fsgs_stream_t stream) {
+                                 int64_t n_gauss_total, float *packed, int masks_in_payload, uint8_t *mask8,
+                                 int32_t *pos4, float *records, void *scratch, size_t scratch_bytes,
+                                 fsgs_stream_t stream) {
     if (n_isects < 0 || (D != 1 && D != 3 && D != 4)) return FSGS_EINVAL;
     if (!mask8 || !pos4) return FSGS_EINVAL;
     if (n_isects > 0x7FFFFFF0ll) return FSGS_EINVAL;  // list indices are 32-bit (as in the reference)
@@ -311,6 +286,11 @@ extern "C" int fsgs_live_prepare(int D, const float *means2d, const float *conic
     int4 *block_sums = reinterpret_cast<int4 *>(scratch);
     float4 *pk = reinterpret_cast<float4 *>(packed);
     const bool use_packed = packed != nullptr && n_gauss_total > 0 && n_isects > 0;
+    if (masks_in_payload) {
+        // flatten_ids arrive as (mask << 28 | id) from fsgs_isect_emit_live: nothing to gather for the mask
+        hipLaunchKernelGGL(payload_split_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, n_isects,
+                           const_cast<int32_t *>(flatten_ids), mask8);
+    }
     if (use_packed) {
         const dim3 gp(ceil_div(n_gauss_total, 256));
         if (D == 4)
@@ -322,9 +302,10 @@ extern "C" int fsgs_live_prepare(int D, const float *means2d, const float *conic
         else
             hipLaunchKernelGGL((live_pack_kernel<1>), gp, dim3(256), 0, s, n_gauss_total, means2d, conics, colors,
                                opacities, extra, pk);
-        hipLaunchKernelGGL(live_mask_packed_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, n_isects, isect_ids,
-                           flatten_ids, pk, tile_width, tile_bits, mask8);
-    } else {
+        if (!masks_in_payload)
+            hipLaunchKernelGGL(live_mask_packed_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, n_isects,
+                               isect_ids, flatten_ids, pk, tile_width, tile_bits, mask8);
+    } else if (!masks_in_payload) {
         hipLaunchKernelGGL(live_mask_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, n_isects, isect_ids,
                            flatten_ids, means2d, conics, opacities, tile_width, tile_bits, mask8);
     }

@@ -85,8 +85,11 @@ class _FusedGetOutputs(torch.autograd.Function):
              "fsgs_activate_fwd")
         radii, means2d, depths, conics, _ = ops.project_fwd(means, quats, scales_exp, cam["viewmat"], cam["K"],
                                                              W, H, 0.3, 0.01, 1e10, 0.0, False)
-        tpg, isect_ids, flatten_ids, offsets, rule_diff = ops.bin_and_sort(means2d, radii, depths, TILE, tw, th,
-                                                                           legacy=False)
+        # live emission: only (Gaussian, tile) pairs that can reach a pixel are binned and sorted; the
+        # quadrant masks ride in the payload (gsplat's full lists are not an output of get_outputs)
+        opac_row = opac_sig.view(1, N)
+        tpg, isect_ids, flatten_ids, offsets = ops.bin_and_sort_live(means2d, radii, depths, conics, opac_row, tw, th)
+        rule_diff = 0
         M = flatten_ids.numel()
 
         colors = torch.empty(1, N, 4, **f32)
@@ -114,7 +117,7 @@ class _FusedGetOutputs(torch.autograd.Function):
         seg_state = arena[o:o + seg_bytes].view(torch.float32) if needs_bwd else None
         packed = torch.empty(N, 16, **f32)
         _run(lib.fsgs_live_prepare, (4, ptr(means2d), ptr(conics), ptr(colors), ptr(opac_sig), ptr(normals_cam),
-                                    tw, tile_bits(tw * th), ptr(isect_ids), ptr(flatten_ids), M, N, ptr(packed),
+                                    tw, tile_bits(tw * th), ptr(isect_ids), ptr(flatten_ids), M, N, ptr(packed), 1,
                                     ptr(mask8),
                                     ptr(pos4), ptr(records), ptr(scratch), sbytes, sp), "fsgs_live_prepare", "_d4e3")
 

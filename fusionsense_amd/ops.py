@@ -204,6 +204,38 @@ def check_onesweep_errors(sync: bool = False) -> None:
             raise _lib.FsgsError("single-sweep radix sort: look-back spin timed out; results invalid")
 
 
+def bin_and_sort_live(means2d: Tensor, radii: Tensor, depths: Tensor, conics: Tensor, opacities: Tensor,
+                      tile_width: int, tile_height: int):
+    """Live emission + sort + offsets (tile 16).  Returns tiles_per_gauss [C,N] (gsplat's count), sorted
+    isect_ids [M_live], payload [M_live] (quadrant mask << 28 | flatten id) and isect_offsets [C,th,tw]."""
+    lib = load()
+    dev = means2d.device
+    Cn, N = radii.shape
+    total = Cn * N
+    tpg = torch.empty(Cn, N, dtype=torch.int32, device=dev)
+    lpg = torch.empty(Cn, N, dtype=torch.int32, device=dev)
+    cum = torch.empty(max(total, 1), dtype=torch.int64, device=dev)
+    sbytes = lib.fsgs_scan_scratch_bytes(max(total, 1))
+    scratch = torch.empty(sbytes, dtype=torch.uint8, device=dev)
+    m_host = C.c_int64(0)
+    _run(lib.fsgs_isect_count_live, (Cn, N, ptr(means2d), ptr(radii), ptr(conics), ptr(opacities), tile_width,
+                                    tile_height, ptr(tpg), ptr(lpg), ptr(cum), ptr(scratch), sbytes, C.byref(m_host),
+                                    stream_ptr(dev)), "fsgs_isect_count_live")
+    M = int(m_host.value)
+    check_onesweep_errors()
+    ids = torch.empty(M, dtype=torch.int64, device=dev)
+    pay = torch.empty(M, dtype=torch.int32, device=dev)
+    if M > 0:
+        _run(lib.fsgs_isect_emit_live, (Cn, N, ptr(means2d), ptr(radii), ptr(depths), ptr(conics), ptr(opacities),
+                                       ptr(cum), tile_width, tile_height, ptr(ids), ptr(pay), stream_ptr(dev)),
+             "fsgs_isect_emit_live")
+        n_tiles = tile_width * tile_height
+        end_bit = 32 + tile_bits(n_tiles) + (tile_bits(Cn) if Cn > 1 else 0)
+        ids, pay = sort_pairs(ids, pay, end_bit)
+    offsets = isect_offset_encode(ids, Cn, tile_width, tile_height)
+    return tpg, ids, pay, offsets
+
+
 def sort_pairs(keys: Tensor, vals: Tensor, end_bit: int = 64) -> Tuple[Tensor, Tensor]:
     """Stable radix sort of (i64, i32) pairs on key bits [0, end_bit).  Inputs are clobbered."""
     lib = load()
@@ -406,7 +438,7 @@ class _Rasterize(torch.autograd.Function):
             packed = torch.empty(Cn * N, 16, dtype=torch.float32, device=dev)
             _run(lib.fsgs_live_prepare, (D, ptr(means2d), ptr(conics), ptr(colors), ptr(opacities), None, tw,
                                         tile_bits(tw * th), ptr(isect_ids), ptr(flatten_ids), M, Cn * N,
-                                        ptr(packed), ptr(mask8),
+                                        ptr(packed), 0, ptr(mask8),
                                         ptr(pos4), ptr(records), ptr(scratch), sbytes, stream_ptr(dev)),
                  "fsgs_live_prepare", f"_d{D}")
             _run(lib.fsgs_raster_fwd_live, (Cn, D, ptr(records), ptr(pos4), ptr(isect_offsets), M,

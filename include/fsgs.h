@@ -133,6 +133,20 @@ int fsgs_bucket_fill_sort(int C, int N, const float *means2d, const int32_t *rad
                           int64_t max_bucket, void *keys_scratch, int64_t *isect_ids,
                           int32_t *flatten_ids, fsgs_stream_t stream);
 
+/* Live emission (tile_size 16; used by the fused get_outputs node, where gsplat's full lists are not
+ * an output): a (Gaussian, tile) pair is counted / emitted only if the Gaussian can reach one of the
+ * tile's 8x8 quadrants at alpha >= 1/255 (the same conservative test as fsgs_live_prepare), and the
+ * payload is  quadrant_mask << 28 | flatten_id  (C*N < 2^28).  tiles_per_gauss is still gsplat's
+ * rectangle count.  Everything downstream (sort, offsets, prepare) then works on ~1/4 of the entries. */
+int fsgs_isect_count_live(int C, int N, const float *means2d, const int32_t *radii, const float *conics,
+                          const float *opacities, int tile_width, int tile_height,
+                          int32_t *tiles_per_gauss, int32_t *live_per_gauss, int64_t *cum_live,
+                          void *scratch, size_t scratch_bytes, int64_t *n_live_host, fsgs_stream_t stream);
+int fsgs_isect_emit_live(int C, int N, const float *means2d, const int32_t *radii, const float *depths,
+                         const float *conics, const float *opacities, const int64_t *cum_live,
+                         int tile_width, int tile_height, int64_t *isect_ids, int32_t *payload,
+                         fsgs_stream_t stream);
+
 /* ---- E5: stable LSD radix sort of (i64 key, i32 value) pairs over key bits [0,end_bit) --------
  * Replaces cub::DeviceRadixSort::SortPairs.  Ping-pongs between (keys_a, vals_a) and
  * (keys_b, vals_b); returns 0 or 1 in *result_in_b to say where the sorted data ended up. */
@@ -193,8 +207,10 @@ int fsgs_live_prepare(int D, const float *means2d, const float *conics, const fl
                       const float *opacities, const float *extra, int tile_width, int tile_bits,
                       const int64_t *isect_ids,
                       const int32_t *flatten_ids, int64_t n_isects, int64_t n_gauss_total,
-                      float *packed, uint8_t *mask8, int32_t *pos4, float *records, void *scratch,
-                      size_t scratch_bytes, fsgs_stream_t stream);
+                      float *packed, int masks_in_payload, uint8_t *mask8, int32_t *pos4, float *records,
+                      void *scratch, size_t scratch_bytes, fsgs_stream_t stream);
+/* masks_in_payload != 0: flatten_ids come from fsgs_isect_emit_live (mask << 28 | id); they are split
+ * IN PLACE into mask8 and clean ids instead of running the list-order mask kernel. */
 /* packed (nullable scratch, n_gauss_total = C*N rows of 16 floats): when given, every Gaussian's
  * attributes are first packed into one 64-B line so that the list-order kernels gather one line
  * per entry instead of 5-7 scattered pieces. */
