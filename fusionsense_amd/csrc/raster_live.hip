@@ -281,57 +281,55 @@ raster_bwd_live_kernel(int64_t cap, const float4 *__restrict__ rec, const int4 *
             bool valid = inside && (isect <= bin_final);
             const float dx = a0.x - px, dy = a0.y - py;
             const float sigma = 0.5f * (a0.w * dx * dx + a1.y * dy * dy) + a1.x * dx * dy;
-            const float vis = __expf(-sigma);
-            const float alpha = fminf(kAlphaMax, a0.z * vis);
-            if (sigma < 0.f || alpha < kAlphaMin) valid = false;
+            const float vis0 = __expf(-sigma);
+            if (sigma < 0.f || fminf(kAlphaMax, a0.z * vis0) < kAlphaMin) valid = false;
             if (!__any(valid)) continue;
 
+            // Branch-free from here: a lane that does not contribute gets vis = 0, hence alpha = 0,
+            // ra = 1 (T unchanged), fac = 0 and v_sigma = 0 — every term below vanishes by itself.
+            const float vis = valid ? vis0 : 0.f;
+            const float alpha = fminf(kAlphaMax, a0.z * vis);
             float g[12], ge[E ? E : 1];
+            const float4 c4 = L.r2[t];
+            const float col[4] = {c4.x, c4.y, c4.z, c4.w};
+            const float ra = 1.f / (1.f - alpha);
+            T *= ra;
+            const float fac = alpha * T;
+            float v_alpha = 0.f;
 #pragma unroll
-            for (int k = 0; k < 12; ++k) g[k] = 0.f;
+            for (int k = 0; k < 4; ++k) g[k] = 0.f;
 #pragma unroll
-            for (int k = 0; k < E; ++k) ge[k] = 0.f;
-            if (valid) {
-                const float4 c4 = L.r2[t];
-                const float col[4] = {c4.x, c4.y, c4.z, c4.w};
-                const float ra = 1.f / (1.f - alpha);
-                T *= ra;
-                const float fac = alpha * T;
-                float v_alpha = 0.f;
+            for (int k = 0; k < D; ++k) {
+                g[k] = fac * v_out[k];
+                v_alpha += (col[k] * T - buffer[k] * ra) * v_out[k];
+                buffer[k] += col[k] * fac;
+            }
+            v_alpha += T_final * ra * v_out_a;
+            if (backgrounds) v_alpha -= T_final * ra * bg_dot;
+            float v_alpha_e = 0.f;  // the extra plane's share: conics / opacity only
+            if (E) {
+                const float4 e4 = L.r3[t];
+                const float ce[3] = {e4.x, e4.y, e4.z};
 #pragma unroll
-                for (int k = 0; k < D; ++k) {
-                    g[k] = fac * v_out[k];
-                    v_alpha += (col[k] * T - buffer[k] * ra) * v_out[k];
-                    buffer[k] += col[k] * fac;
+                for (int k = 0; k < E; ++k) {
+                    ge[k] = fac * v_oute[k];
+                    v_alpha_e += (ce[k] * T - bufe[k] * ra) * v_oute[k];
+                    bufe[k] += ce[k] * fac;
                 }
-                v_alpha += T_final * ra * v_out_a;
-                if (backgrounds) v_alpha -= T_final * ra * bg_dot;
-                float v_alpha_e = 0.f;  // the extra plane's share: conics / opacity only
-                if (E) {
-                    const float4 e4 = L.r3[t];
-                    const float ce[3] = {e4.x, e4.y, e4.z};
-#pragma unroll
-                    for (int k = 0; k < E; ++k) {
-                        ge[k] = fac * v_oute[k];
-                        v_alpha_e += (ce[k] * T - bufe[k] * ra) * v_oute[k];
-                        bufe[k] += ce[k] * fac;
-                    }
-                    v_alpha_e -= T_final * ra * bge_dot;
-                }
-                if (a0.z * vis <= kAlphaMax) {
-                    const float v_sigma_xy = -a0.z * vis * v_alpha;
-                    const float v_sigma = -a0.z * vis * (v_alpha + v_alpha_e);
-                    g[4] = 0.5f * v_sigma * dx * dx;
-                    g[5] = v_sigma * dx * dy;
-                    g[6] = 0.5f * v_sigma * dy * dy;
-                    g[7] = v_sigma_xy * (a0.w * dx + a1.x * dy);
-                    g[8] = v_sigma_xy * (a1.x * dx + a1.y * dy);
-                    if (ABS) {
-                        g[9] = fabsf(g[7]);
-                        g[10] = fabsf(g[8]);
-                    }
-                    g[11] = vis * (v_alpha + v_alpha_e);
-                }
+                v_alpha_e -= T_final * ra * bge_dot;
+            }
+            {
+                const float ov = (a0.z * vis <= kAlphaMax) ? a0.z * vis : 0.f;  // clamp active: no sigma grads
+                const float v_sigma_xy = -ov * v_alpha;
+                const float v_sigma = -ov * (v_alpha + v_alpha_e);
+                g[4] = 0.5f * v_sigma * dx * dx;
+                g[5] = v_sigma * dx * dy;
+                g[6] = 0.5f * v_sigma * dy * dy;
+                g[7] = v_sigma_xy * (a0.w * dx + a1.x * dy);
+                g[8] = v_sigma_xy * (a1.x * dx + a1.y * dy);
+                g[9] = ABS ? fabsf(g[7]) : 0.f;
+                g[10] = ABS ? fabsf(g[8]) : 0.f;
+                g[11] = (a0.z * vis <= kAlphaMax) ? vis * (v_alpha + v_alpha_e) : 0.f;
             }
             row_sum16_x12(g);
             if (E == 3) row_sum16_x3(ge[0], ge[1], ge[E - 1]);
