@@ -162,20 +162,6 @@ scan4_reduce_kernel(int64_t n, const uint8_t *__restrict__ mask8, int4 *__restri
 }
 
 __global__ void __launch_bounds__(kS4Block)
-scan4_block_sums_kernel(int64_t nb, int4 *__restrict__ block_sums) {
-    __shared__ int4 lds4[4];
-    int4 carry = make_int4(0, 0, 0, 0);
-    for (int64_t base = 0; base < nb; base += kS4Block) {
-        const int64_t i = base + threadIdx.x;
-        const int4 v = (i < nb) ? block_sums[i] : make_int4(0, 0, 0, 0);
-        int4 tot;
-        const int4 ex = block_excl_scan4(v, &tot, lds4);
-        if (i < nb) block_sums[i] = add4(carry, ex);
-        carry = add4(carry, tot);
-    }
-}
-
-__global__ void __launch_bounds__(kS4Block)
 scan4_apply_kernel(int64_t n, const uint8_t *__restrict__ mask8, const int4 *__restrict__ block_sums,
                    int4 *__restrict__ pos4) {
     __shared__ int4 lds4[4];
@@ -195,8 +181,12 @@ scan4_apply_kernel(int64_t n, const uint8_t *__restrict__ mask8, const int4 *__r
     }
 #pragma unroll
     for (int k = 0; k < kS4Items; ++k) s = add4(s, bits4(m[k]));
+    int4 before = make_int4(0, 0, 0, 0);  // totals of all earlier workgroups, summed here (no scan launch)
+    for (int64_t b = threadIdx.x; b < (int64_t)blockIdx.x; b += kS4Block) before = add4(before, block_sums[b]);
+    int4 btot;
+    block_excl_scan4(before, &btot, lds4);
     int4 tot;
-    int4 run = add4(block_excl_scan4(s, &tot, lds4), block_sums[blockIdx.x]);
+    int4 run = add4(block_excl_scan4(s, &tot, lds4), btot);
 #pragma unroll
     for (int k = 0; k < kS4Items; ++k) {
         if (base + k < n) pos4[base + k] = run;
@@ -311,7 +301,6 @@ extern "C" int fsgs_live_prepare(int D, const float *means2d, const float *conic
     }
     const int64_t nb = scan4_blocks(n);
     hipLaunchKernelGGL(scan4_reduce_kernel, dim3((unsigned)nb), dim3(kS4Block), 0, s, n, mask8, block_sums);
-    hipLaunchKernelGGL(scan4_block_sums_kernel, dim3(1), dim3(kS4Block), 0, s, nb, block_sums);
     hipLaunchKernelGGL(scan4_apply_kernel, dim3((unsigned)nb), dim3(kS4Block), 0, s, n, mask8, block_sums,
                        reinterpret_cast<int4 *>(pos4));
     if (n_isects > 0 && use_packed) {

@@ -1,6 +1,7 @@
 // Device-wide prefix sums used by tile binning, the radix sort and densify compaction.
-// Three launches (block reduce -> single-block scan of block totals -> block scan + offset):
-// 2 reads + 1 write per element, no inter-workgroup spinning, so it is placement-independent.
+// Two launches (block reduce -> block scan + offset, where every workgroup sums the totals of the
+// workgroups before it by itself): 2 reads + 1 write per element, no inter-workgroup spinning, so it
+// is placement-independent, and one dependent launch fewer than a separate scan of the totals.
 #pragma once
 #include "common.h"
 
@@ -59,21 +60,6 @@ scan_reduce_kernel(int64_t n, const InT *__restrict__ in, int64_t *__restrict__ 
     if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
 }
 
-// exclusive scan of the block totals, in place, by ONE workgroup
-static __global__ void __launch_bounds__(kScanBlock)
-scan_block_sums_kernel(int64_t nb, int64_t *__restrict__ block_sums) {
-    __shared__ int64_t lds4[4];
-    int64_t carry = 0;
-    for (int64_t base = 0; base < nb; base += kScanBlock) {
-        const int64_t i = base + threadIdx.x;
-        const int64_t v = (i < nb) ? block_sums[i] : 0;
-        int64_t tot;
-        const int64_t ex = block_exclusive_scan(v, &tot, lds4);
-        if (i < nb) block_sums[i] = carry + ex;
-        carry += tot;
-    }
-}
-
 // out[i] = (INCLUSIVE ? in[i] : 0) + sum_{j<i} in[j]
 template <typename InT, bool INCLUSIVE>
 __global__ void __launch_bounds__(kScanBlock)
@@ -90,8 +76,13 @@ scan_apply_kernel(int64_t n, const InT *__restrict__ in, const int64_t *__restri
         v[k] = (i < n) ? (int64_t)in[i] : 0;
         s += v[k];
     }
+    // prefix of this workgroup = sum of the totals of all earlier workgroups
+    int64_t before = 0;
+    for (int64_t b = threadIdx.x; b < (int64_t)blockIdx.x; b += kScanBlock) before += block_sums[b];
+    int64_t btot;
+    block_exclusive_scan(before, &btot, lds4);
     int64_t tot;
-    int64_t run = block_exclusive_scan(s, &tot, lds4) + block_sums[blockIdx.x];
+    int64_t run = block_exclusive_scan(s, &tot, lds4) + btot;
 #pragma unroll
     for (int k = 0; k < kScanItems; ++k) {
         const int64_t i = base + k;
@@ -109,7 +100,6 @@ inline int device_scan(int64_t n, const InT *in, int64_t *out, void *scratch, si
     int64_t *block_sums = reinterpret_cast<int64_t *>(scratch);
     hipLaunchKernelGGL((scan_reduce_kernel<InT>), dim3((unsigned)nb), dim3(kScanBlock), 0, stream, n, in,
                        block_sums);
-    hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(kScanBlock), 0, stream, nb, block_sums);
     hipLaunchKernelGGL((scan_apply_kernel<InT, INCLUSIVE>), dim3((unsigned)nb), dim3(kScanBlock), 0,
                        stream, n, in, block_sums, out);
     return check_launch();
