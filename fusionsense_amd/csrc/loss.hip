@@ -205,9 +205,64 @@ aux_l1_bwd_kernel(int64_t P, const float *__restrict__ depth, const float *__res
     }
 }
 
+// out[0] = bias + sum_t (w[2t] * colsum0(partials_t) + w[2t+1] * colsum1(partials_t)): the scalar loss
+// from the per-workgroup partials of up to four fused terms, in one launch and without a host sync.
+constexpr int kCombineMaxTerms = 4;
+struct CombineArgs {
+    const float *partials[kCombineMaxTerms];
+    long long rows[kCombineMaxTerms];
+    float w[2 * kCombineMaxTerms];
+    int n_terms;
+    float bias;
+};
+
+__global__ void __launch_bounds__(1024) loss_combine_kernel(CombineArgs a, float *__restrict__ out) {
+    __shared__ double red[16];
+    double acc = 0.0;
+    for (int t = 0; t < a.n_terms; ++t) {
+        const float2 *p = reinterpret_cast<const float2 *>(a.partials[t]);
+        const float w0 = a.w[2 * t], w1 = a.w[2 * t + 1];
+        double s0 = 0.0, s1 = 0.0;
+        for (long long r = threadIdx.x; r < a.rows[t]; r += 1024) {
+            const float2 v = p[r];
+            s0 += v.x;
+            s1 += v.y;
+        }
+        acc += s0 * (double)w0 + s1 * (double)w1;
+    }
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) acc += __shfl_xor(acc, s, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double tot = 0.0;
+        for (int k = 0; k < 16; ++k) tot += red[k];
+        out[0] = (float)(tot + (double)a.bias);
+    }
+}
+
 }  // namespace fsgs
 
 using namespace fsgs;
+
+extern "C" int fsgs_loss_combine(int n_terms, const float *const *partials, const int64_t *rows,
+                                 const float *weights, float bias, float *out, fsgs_stream_t stream) {
+    if (n_terms < 0 || n_terms > kCombineMaxTerms || !out) return FSGS_EINVAL;
+    if (n_terms && (!partials || !rows || !weights)) return FSGS_EINVAL;
+    CombineArgs a;
+    for (int t = 0; t < kCombineMaxTerms; ++t) {
+        const bool on = t < n_terms;
+        if (on && (rows[t] < 0 || (rows[t] > 0 && !partials[t]))) return FSGS_EINVAL;
+        a.partials[t] = on ? partials[t] : nullptr;
+        a.rows[t] = on ? rows[t] : 0;
+        a.w[2 * t] = on ? weights[2 * t] : 0.f;
+        a.w[2 * t + 1] = on ? weights[2 * t + 1] : 0.f;
+    }
+    a.n_terms = n_terms;
+    a.bias = bias;
+    hipLaunchKernelGGL(loss_combine_kernel, dim3(1), dim3(1024), 0, as_stream(stream), a, out);
+    return check_launch();
+}
 
 extern "C" int fsgs_aux_l1_fwd(int64_t n_pixels, const float *depth, const float *depth_gt, const float *normal,
                                const float *normal_gt, float *partial, fsgs_stream_t stream) {

@@ -613,6 +613,20 @@ def split_samples(ids: Tensor, n_samples: int, means: Tensor, quats: Tensor, log
     return new_means, new_ls
 
 
+def loss_combine(partials, weights, bias: float) -> Tensor:
+    """bias + sum_t (w[t][0]*colsum0(partials[t]) + w[t][1]*colsum1(partials[t])) as a 0-d device tensor, one launch."""
+    lib = load()
+    n = len(partials)
+    dev = partials[0].device
+    out = torch.empty((), dtype=torch.float32, device=dev)
+    VP = C.c_void_p * n
+    rows = (C.c_int64 * n)(*[p.shape[0] for p in partials])
+    w = (C.c_float * (2 * n))(*[float(x) for pair in weights for x in pair])
+    _run(lib.fsgs_loss_combine, (n, VP(*[p.data_ptr() for p in partials]), rows, w, float(bias), ptr(out),
+                                 stream_ptr(dev)), "fsgs_loss_combine")
+    return out
+
+
 class _SsimL1Loss(torch.autograd.Function):
     """(1-l)*L1 + l*(1-SSIM11) on [H,W,3] images as one forward and one backward kernel (row N2)."""
 
@@ -630,8 +644,7 @@ class _SsimL1Loss(torch.autograd.Function):
         g_ssim = -ssim_lambda / (3.0 * (H - 10) * (W - 10))
         ctx.save_for_backward(pred, gt, maps)
         ctx.g = (g_l1, g_ssim)
-        tot = sums.sum(dim=0)
-        return tot[0] * g_l1 + tot[1] * g_ssim + ssim_lambda
+        return loss_combine([sums], [(g_l1, g_ssim)], ssim_lambda)
 
     @staticmethod
     def backward(ctx, v_loss):
@@ -681,8 +694,7 @@ class _AuxL1Loss(torch.autograd.Function):
         g_d = w_depth / P
         g_n = w_normal / (3.0 * P) if normal is not None else 0.0
         ctx.g = (g_d, g_n, normal is not None)
-        tot = partial.sum(dim=0)
-        return tot[0] * g_d + tot[1] * g_n
+        return loss_combine([partial], [(g_d, g_n)], 0.0)
 
     @staticmethod
     def backward(ctx, v_loss):
@@ -703,6 +715,63 @@ class _AuxL1Loss(torch.autograd.Function):
 def aux_l1_loss(depth: Tensor, depth_gt: Tensor, normal: Optional[Tensor], normal_gt: Optional[Tensor],
                 w_depth: float, w_normal: float) -> Tensor:
     return _AuxL1Loss.apply(depth, depth_gt, normal, normal_gt, float(w_depth), float(w_normal))
+
+
+class _TrainLoss(torch.autograd.Function):
+    """The whole config-#2 training loss as ONE autograd node:
+    (1-l)*L1(rgb) + l*(1-SSIM11(rgb)) + w_d*L1(depth) + w_n*L1(normal)  — two partial-sum kernels and
+    one combine launch forward, two kernels backward, no torch glue in between."""
+
+    @staticmethod
+    def forward(ctx, rgb, rgb_gt, depth, depth_gt, normal, normal_gt, ssim_lambda, w_depth, w_normal):
+        rgb, rgb_gt, depth, depth_gt, normal, normal_gt = map(_c, (rgb, rgb_gt, depth, depth_gt, normal, normal_gt))
+        lib = load()
+        dev = rgb.device
+        H, W = rgb.shape[0], rgb.shape[1]
+        P = depth.numel()
+        maps = torch.empty(3, H, W, 3, dtype=torch.float32, device=dev)
+        sums = torch.empty(lib.fsgs_ssim_l1_num_partials(H, W), 2, dtype=torch.float32, device=dev)
+        _run(lib.fsgs_ssim_l1_fwd, (H, W, ptr(rgb), ptr(rgb_gt), maps[0].data_ptr(), maps[1].data_ptr(),
+                                    maps[2].data_ptr(), ptr(sums), stream_ptr(dev)), "fsgs_ssim_l1_fwd")
+        partial = torch.empty((P + 255) // 256, 2, dtype=torch.float32, device=dev)
+        _run(lib.fsgs_aux_l1_fwd, (P, ptr(depth), ptr(depth_gt), ptr(normal), ptr(normal_gt), ptr(partial),
+                                   stream_ptr(dev)), "fsgs_aux_l1_fwd")
+        g_l1 = (1.0 - ssim_lambda) / (3.0 * H * W)
+        g_ssim = -ssim_lambda / (3.0 * (H - 10) * (W - 10))
+        g_d = w_depth / P
+        g_n = w_normal / (3.0 * P) if normal is not None else 0.0
+        ctx.save_for_backward(rgb, rgb_gt, maps, depth, depth_gt,
+                              normal if normal is not None else torch.empty(0, device=dev),
+                              normal_gt if normal_gt is not None else torch.empty(0, device=dev))
+        ctx.g = (g_l1, g_ssim, g_d, g_n, normal is not None)
+        return loss_combine([sums, partial], [(g_l1, g_ssim), (g_d, g_n)], ssim_lambda)
+
+    @staticmethod
+    def backward(ctx, v_loss):
+        rgb, rgb_gt, maps, depth, depth_gt, normal, normal_gt = ctx.saved_tensors
+        g_l1, g_ssim, g_d, g_n, has_n = ctx.g
+        lib = load()
+        dev = rgb.device
+        H, W = rgb.shape[0], rgb.shape[1]
+        P = depth.numel()
+        v_loss = v_loss.reshape(1).contiguous().to(torch.float32)
+        v_rgb = torch.empty_like(rgb)
+        v_depth = torch.empty_like(depth)
+        v_normal = torch.empty_like(normal) if has_n else None
+        _run(lib.fsgs_aux_l1_bwd, (P, ptr(depth), ptr(depth_gt), ptr(normal) if has_n else None,
+                                   ptr(normal_gt) if has_n else None, ptr(v_loss), g_d, g_n, ptr(v_depth),
+                                   ptr(v_normal), stream_ptr(dev)), "fsgs_aux_l1_bwd")
+        _run(lib.fsgs_ssim_l1_bwd, (H, W, ptr(rgb), ptr(rgb_gt), maps[0].data_ptr(), maps[1].data_ptr(),
+                                    maps[2].data_ptr(), ptr(v_loss), g_l1, g_ssim, ptr(v_rgb),
+                                    stream_ptr(dev)), "fsgs_ssim_l1_bwd")
+        return v_rgb, None, v_depth, None, v_normal, None, None, None, None
+
+
+def train_loss(rgb: Tensor, rgb_gt: Tensor, depth: Tensor, depth_gt: Tensor, normal: Optional[Tensor],
+               normal_gt: Optional[Tensor], ssim_lambda: float = 0.2, w_depth: float = 0.2,
+               w_normal: float = 0.1) -> Tensor:
+    return _TrainLoss.apply(rgb, rgb_gt, depth, depth_gt, normal, normal_gt, float(ssim_lambda),
+                            float(w_depth), float(w_normal))
 
 
 def adam_step_(params, grads, exp_avgs, exp_avg_sqs, lrs, step: int, beta1: float = 0.9, beta2: float = 0.999,

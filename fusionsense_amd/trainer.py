@@ -111,11 +111,12 @@ class SplatTrainer:
     def loss(self, out, target) -> Tensor:
         """Config #2 loss: 0.8*L1 + 0.2*(1-SSIM) on rgb, L1 on depth, L1 on normals."""
         from .losses import rgb_loss
-        l = rgb_loss(out["rgb"], target["rgb"])
         if self.fused and "depth" in target and out["rgb"].is_cuda:
-            from .ops import aux_l1_loss
-            n = out["normal"] if "normal" in target else None
-            return l + aux_l1_loss(out["depth"], target["depth"], n, target.get("normal"), 0.2, 0.1)
+            from .ops import train_loss
+            has_n = "normal" in target
+            return train_loss(out["rgb"], target["rgb"], out["depth"], target["depth"],
+                              out["normal"] if has_n else None, target["normal"] if has_n else None, 0.2, 0.2, 0.1)
+        l = rgb_loss(out["rgb"], target["rgb"])
         if "depth" in target:
             l = l + 0.2 * torch.abs(out["depth"] - target["depth"]).mean()
         if "normal" in target:

@@ -333,6 +333,13 @@ int fsgs_aux_l1_bwd(int64_t n_pixels, const float *depth, const float *depth_gt,
                     const float *normal_gt, const float *v_loss, float g_depth, float g_normal,
                     float *v_depth, float *v_normal, fsgs_stream_t stream);
 
+/* The scalar loss from the partials above without torch reductions or a host sync:
+ * out[0] = bias + sum_t (weights[2t] * sum_r partials[t][r,0] + weights[2t+1] * sum_r partials[t][r,1]),
+ * t < n_terms <= 4; partials[t] is [rows[t],2] on the device, the three arrays are HOST arrays.
+ * (dn_model.py:673-925 adds its terms with python scalars; the sum is accumulated in f64.) */
+int fsgs_loss_combine(int n_terms, const float *const *partials, const int64_t *rows,
+                      const float *weights, float bias, float *out, fsgs_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -311,6 +311,32 @@ def test_fused_ssim_l1_loss(dev, H, W):
     assert rel_err(p_g.grad / 3.0, p_ref.grad) < 1e-3
 
 
+@pytest.mark.parametrize("with_normal", [True, False])
+def test_train_loss_single_node(dev, with_normal):
+    """The whole config-#2 loss as one node (ssim+l1 on rgb, l1 on depth and normal) against torch."""
+    from fusionsense_amd import losses
+    from fusionsense_amd.ops import train_loss
+    H, W = 45, 70
+    g = torch.Generator().manual_seed(5)
+    gt = {"rgb": torch.rand(H, W, 3, generator=g), "depth": torch.rand(H, W, 1, generator=g) * 3,
+          "normal": torch.rand(H, W, 3, generator=g)}
+    pred = {k: (v + 0.1 * torch.randn(v.shape, generator=g)) for k, v in gt.items()}
+    pred["rgb"] = pred["rgb"].clamp(0, 1)
+    ref = {k: v.clone().double().requires_grad_(True) for k, v in pred.items()}
+    l_ref = losses.rgb_loss(ref["rgb"], gt["rgb"].double(), fused=False) \
+        + 0.2 * (ref["depth"] - gt["depth"].double()).abs().mean()
+    if with_normal:
+        l_ref = l_ref + 0.1 * (ref["normal"] - gt["normal"].double()).abs().mean()
+    l_ref.backward()
+    gp = {k: v.to(dev).requires_grad_(True) for k, v in pred.items()}
+    l_g = train_loss(gp["rgb"], gt["rgb"].to(dev), gp["depth"], gt["depth"].to(dev),
+                     gp["normal"] if with_normal else None, gt["normal"].to(dev) if with_normal else None)
+    (l_g * 2.0).backward()
+    assert abs(l_g.item() - l_ref.item()) < 2e-5
+    for k in ("rgb", "depth") + (("normal",) if with_normal else ()):
+        assert rel_err(gp[k].grad / 2.0, ref[k].grad) < 1e-3, k
+
+
 def test_legacy_pass_reuses_sorted_lists(dev):
     """The normal pass handed this frame's own xys/depths/radii skips its binning + sort; the
     image and gradients are identical to the full legacy binning, and any other tensor misses."""
