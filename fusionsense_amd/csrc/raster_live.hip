@@ -14,6 +14,7 @@
 // global_atomic_add_f32 into a packed 64-byte per-Gaussian record (one cache line), instead of
 // 12 single-lane atomics to five different arrays; fsgs_raster_unpack_grads splits the records.
 #include "common.h"
+#include <cstdlib>
 
 namespace fsgs {
 
@@ -30,12 +31,23 @@ struct Rec {
     float4 r0, r1, r2, r3;
 };
 
+#ifndef FSGS_FWD_GROUP
+#define FSGS_FWD_GROUP 4
+#endif
+constexpr int kFwdGroup = FSGS_FWD_GROUP;  // records composited per unrolled step of the forward (divides 64)
+
 template <int E>
 __device__ __forceinline__ void load_rec(Rec &r, const float4 *__restrict__ rec, int64_t p, bool ok) {
     if (ok) {
         const float4 *src = rec + (E ? 4 : 3) * p;
         r.r0 = src[0]; r.r1 = src[1]; r.r2 = src[2];
         if (E) r.r3 = src[3];
+    } else {
+        // past the end of the list: an all-zero record composites to alpha = 0, so the forward can
+        // walk whole groups of records without a bounds test
+        r.r0 = make_float4(0.f, 0.f, 0.f, 0.f);
+        r.r1 = r.r0; r.r2 = r.r0;
+        if (E) r.r3 = r.r0;
     }
 }
 
@@ -47,25 +59,39 @@ raster_fwd_live_kernel(int64_t cap, const float4 *__restrict__ rec, const int4 *
                        float *__restrict__ render, float *__restrict__ alphas,
                        int32_t *__restrict__ last_ids, float *__restrict__ seg_state, int64_t seg_cap,
                        int normalize_last, float *__restrict__ render_extra,
-                       float *__restrict__ max_last_partial) {
+                       float *__restrict__ max_last_partial, int n_cams, unsigned perm_stride, int abl,
+                       unsigned long long *__restrict__ dbg) {
     __shared__ QLds<E> L;
+    const unsigned long long t_start = dbg ? __builtin_readcyclecounter() : 0;
+    const unsigned long long w_start = dbg ? wall_clock64() : 0;
     constexpr int RS = E ? 4 : 3;
-    const int cam = blockIdx.z;
-    const int tile_x = blockIdx.x >> 1, tile_y = blockIdx.y >> 1;
-    const int q = ((blockIdx.y & 1) << 1) | (blockIdx.x & 1);
+    // All workgroups are resident at once and neighbouring quadrants have similar list lengths, so
+    // consecutive workgroup ids (which land on the same CU) are scattered over the image with a
+    // multiplicative permutation: every SIMD then gets a mixed sample of long and short lists.
+    const unsigned qid = (unsigned)(((uint64_t)blockIdx.x * perm_stride) % gridDim.x);
+    const int qx = qid % (2 * tw), qy = (qid / (2 * tw)) % (2 * th);
+    const int cam = qid / (4 * tw * th);
+    const int tile_x = qx >> 1, tile_y = qy >> 1;
+    const int q = ((qy & 1) << 1) | (qx & 1);
     const int tile_lin = (cam * th + tile_y) * tw + tile_x;
-    const int n_tiles_total = gridDim.z * th * tw;
+    const int n_tiles_total = n_cams * th * tw;
     const int lane = threadIdx.x;
-    const int j = blockIdx.x * 8 + (lane & 7), i = blockIdx.y * 8 + (lane >> 3);
+    const int j = qx * 8 + (lane & 7), i = qy * 8 + (lane >> 3);
     const float px = (float)j + 0.5f, py = (float)i + 0.5f;
     const bool inside = (i < H) && (j < W);
     bool done = !inside;
 
+    int s = 0, e = 0;
+    if (!(abl & 32)) {
     const int64_t l0 = tile_offsets[tile_lin];
     const int64_t l1 = (tile_lin == n_tiles_total - 1) ? n_isects : (int64_t)tile_offsets[tile_lin + 1];
     const int4 p0 = pos4[l0], p1 = pos4[l1];
-    const int s = (q == 0) ? p0.x : (q == 1) ? p0.y : (q == 2) ? p0.z : p0.w;
-    const int e = (q == 0) ? p1.x : (q == 1) ? p1.y : (q == 2) ? p1.z : p1.w;
+    s = (q == 0) ? p0.x : (q == 1) ? p0.y : (q == 2) ? p0.z : p0.w;
+    e = (q == 0) ? p1.x : (q == 1) ? p1.y : (q == 2) ? p1.z : p1.w;
+    }
+    if (abl & 16) e = s;
+    const unsigned long long t_lists = dbg ? (__builtin_amdgcn_s_waitcnt(0), __builtin_readcyclecounter()) : 0;
+    int n_batches = 0;
     const float4 *stream = rec + RS * ((int64_t)q * cap);
 
     float T = 1.f;
@@ -80,41 +106,69 @@ raster_fwd_live_kernel(int64_t cap, const float4 *__restrict__ rec, const int4 *
     // one), for the segment-parallel backward: slot (b/64 + tile_lin) of stream q, b = the next
     // segment's first stream position, is unique per (quadrant, segment).
     constexpr int SS = 64 * (1 + D + E);  // floats per segment-state slot
-    float *seg_q = seg_state ? seg_state + (int64_t)q * seg_cap * SS : nullptr;
+    float *seg_q = (seg_state && !(abl & 1)) ? seg_state + (int64_t)q * seg_cap * SS : nullptr;
     Rec r;
-    load_rec<E>(r, stream, (int64_t)s + lane, s + lane < e);
+    load_rec<E>(r, stream, (int64_t)s + lane, s + lane < e && !(abl & 4));
     for (int b = s; b < e; b += 64) {
+        // The kernel ends when its longest list does: waves with more of their list ahead of them
+        // get a higher issue priority, so the critical path runs at single-wave speed and the short
+        // lists fill the gaps.
+        if (!(abl & 64)) {
+            const int rem = (e - b + 63) >> 6;
+            if (rem >= 5) __builtin_amdgcn_s_setprio(3);
+            else if (rem >= 3) __builtin_amdgcn_s_setprio(2);
+            else if (rem >= 2) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
+        }
         __syncthreads();  // single wave: orders the previous batch's LDS reads before these writes
         L.r0[lane] = r.r0; L.r1[lane] = r.r1; L.r2[lane] = r.r2;
         if (E) L.r3[lane] = r.r3;
         const int n = min(64, e - b);
-        load_rec<E>(r, stream, (int64_t)b + 64 + lane, b + 64 + lane < e);
+        load_rec<E>(r, stream, (int64_t)b + 64 + lane, b + 64 + lane < e && !(abl & 4));
         __syncthreads();
-        for (int t = 0; t < n && !done; ++t) {
-            const float4 a0 = L.r0[t], a1 = L.r1[t];
-            const float dx = a0.x - px, dy = a0.y - py;
-            const float sigma = 0.5f * (a0.w * dx * dx + a1.y * dy * dy) + a1.x * dx * dy;
-            const float alpha = fminf(kAlphaMax, a0.z * __expf(-sigma));
-            if (sigma < 0.f || alpha < kAlphaMin) continue;
-            const float next_T = T * (1.f - alpha);
-            if (next_T <= kTMin) {
-                done = true;
-                break;
+        // Records are taken kFwdGroup at a time with no per-record branching.  A wave walks its list
+        // alone, so its speed is set by the dependent chain LDS read -> sigma -> exp -> T; the LDS reads
+        // and the alphas of a group do not depend on T and are issued together, only the T chain
+        // (a multiply, a compare and three selects per record) stays serial.  A lane that is finished,
+        // or whose alpha is below 1/255, commits vis = 0.
+        const int ng = (abl & 2) ? 0 : ((n + kFwdGroup - 1) / kFwdGroup) * kFwdGroup;  // padding records are all-zero
+        for (int t = 0; t < ng; t += kFwdGroup) {
+            float4 A0[kFwdGroup], A1[kFwdGroup], CC[kFwdGroup], CE[kFwdGroup];
+#pragma unroll
+            for (int u = 0; u < kFwdGroup; ++u) {
+                A0[u] = L.r0[t + u]; A1[u] = L.r1[t + u]; CC[u] = L.r2[t + u];
+                if (E) CE[u] = L.r3[t + u];
             }
-            const float vis = alpha * T;
-            const float4 c = L.r2[t];
-            pix[0] += c.x * vis;
-            if (D > 1) pix[1] += c.y * vis;
-            if (D > 2) pix[2] += c.z * vis;
-            if (D > 3) pix[D - 1] += c.w * vis;
-            if (E) {
-                const float4 ce = L.r3[t];
-                pxe[0] += ce.x * vis;
-                if (E > 1) pxe[1] += ce.y * vis;
-                if (E > 2) pxe[E - 1] += ce.z * vis;
+            float alpha[kFwdGroup];
+            bool pass[kFwdGroup];
+#pragma unroll
+            for (int u = 0; u < kFwdGroup; ++u) {
+                const float dx = A0[u].x - px, dy = A0[u].y - py;
+                const float sigma = 0.5f * (A0[u].w * dx * dx + A1[u].y * dy * dy) + A1[u].x * dx * dy;
+                alpha[u] = fminf(kAlphaMax, A0[u].z * __expf(-sigma));
+                pass[u] = !(sigma < 0.f) && !(alpha[u] < kAlphaMin);
             }
-            cur_idx = __float_as_int(a1.z);
-            T = next_T;
+#pragma unroll
+            for (int u = 0; u < kFwdGroup; ++u) {
+                const bool live = !done && pass[u];
+                const float next_T = T * (1.f - alpha[u]);
+                const bool stop = live && (next_T <= kTMin);
+                done = done || stop;
+                const bool commit = live && !stop;
+                const float vis = commit ? alpha[u] * T : 0.f;
+                pix[0] += CC[u].x * vis;
+                if (D > 1) pix[1] += CC[u].y * vis;
+                if (D > 2) pix[2] += CC[u].z * vis;
+                if (D > 3) pix[D - 1] += CC[u].w * vis;
+                if (E) {
+                    pxe[0] += CE[u].x * vis;
+                    if (E > 1) pxe[1] += CE[u].y * vis;
+                    if (E > 2) pxe[E - 1] += CE[u].z * vis;
+                }
+                cur_idx = commit ? __float_as_int(A1[u].z) : cur_idx;
+                T = commit ? next_T : T;
+            }
+            if (__all(done)) break;
         }
         // written even when the wave stops early: the backward of THIS segment reads it
         if (seg_q && b + 64 < e) {
@@ -125,10 +179,12 @@ raster_fwd_live_kernel(int64_t cap, const float4 *__restrict__ rec, const int4 *
 #pragma unroll
             for (int k = 0; k < E; ++k) slot[64 * (1 + D + k) + lane] = pxe[k];
         }
+        ++n_batches;
         if (__all(done)) break;
     }
+    const unsigned long long t_loop = dbg ? __builtin_readcyclecounter() : 0;
 
-    if (inside) {
+    if (inside && !(abl & 8)) {
         const int64_t pix_id = ((int64_t)cam * H + i) * W + j;
         if (backgrounds) {
 #pragma unroll
@@ -148,11 +204,25 @@ raster_fwd_live_kernel(int64_t cap, const float4 *__restrict__ rec, const int4 *
         alphas[pix_id] = 1.f - T;
         last_ids[pix_id] = cur_idx;
     }
+    if (dbg) {
+        const unsigned long long t_issued = __builtin_readcyclecounter();
+        __builtin_amdgcn_s_waitcnt(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long t_done = __builtin_readcyclecounter();
+        if (lane == 0) {
+            unsigned long long *d = dbg + (size_t)blockIdx.x * 8;
+            d[0] = t_start; d[1] = t_lists; d[2] = t_loop; d[3] = t_issued; d[4] = t_done;
+            d[5] = ((unsigned long long)(e - s) << 40) | (w_start & 0xffffffffffull); d[6] = ((unsigned long long)n_batches << 40) | (wall_clock64() & 0xffffffffffull);
+            unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            unsigned hwid; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+            d[7] = ((unsigned long long)xcc << 32) | hwid;
+        }
+    }
     if (max_last_partial) {  // per-wave max of the (normalised) last channel, for depth_im's fill value
         float m = inside ? pix[D - 1] : 0.f;
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d, 64));
-        if (lane == 0) max_last_partial[((int64_t)cam * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = m;
+        if (lane == 0) max_last_partial[qid] = m;
     }
 }
 
@@ -394,6 +464,16 @@ extern "C" int64_t fsgs_live_seg_slots(int C, int tile_width, int tile_height, i
     return (n_isects >> 6) + (int64_t)C * tile_width * tile_height + 2;
 }
 
+static unsigned long long *g_fwd_dbg = nullptr;
+static long long g_fwd_dbg_n = 0;
+extern "C" long long fsgs_debug_fwd_dump(unsigned long long *host, long long cap) {
+    if (!g_fwd_dbg) return 0;
+    (void)hipDeviceSynchronize();
+    const long long n = g_fwd_dbg_n < cap ? g_fwd_dbg_n : cap;
+    (void)hipMemcpy(host, g_fwd_dbg, (size_t)n * 64, hipMemcpyDeviceToHost);
+    return n;
+}
+
 extern "C" int fsgs_raster_fwd_live(int C, int D, const float *records, const int32_t *pos4,
                                     const int32_t *isect_offsets, int64_t n_isects, const float *backgrounds,
                                     int width, int height, int tile_width, int tile_height, int normalize_last,
@@ -404,14 +484,28 @@ extern "C" int fsgs_raster_fwd_live(int C, int D, const float *records, const in
     if (!pos4 || !isect_offsets || !render || !alphas || !last_ids || (n_isects > 0 && !records))
         return FSGS_EINVAL;
     hipStream_t s = as_stream(stream);
-    const dim3 grid(2 * tile_width, 2 * tile_height, C);
+    const int64_t n_quads = 4ll * tile_width * tile_height * C;
+    if (n_quads >= (1ll << 31)) return FSGS_EINVAL;
+    const dim3 grid((unsigned)n_quads);
+    // a stride coprime with the grid size makes  id -> id * stride mod n  a bijection
+    static const unsigned primes[] = {7919u, 7907u, 7901u, 7883u};
+    unsigned perm_stride = 1;
+    for (unsigned pr : primes)
+        if (n_quads % pr != 0) { perm_stride = pr; break; }
+    if (getenv("FSGS_FWD_NO_PERM")) perm_stride = 1;
     const float4 *rec = reinterpret_cast<const float4 *>(records);
     const int4 *p4 = reinterpret_cast<const int4 *>(pos4);
     const int64_t seg_cap = fsgs_live_seg_slots(C, tile_width, tile_height, n_isects);
+    if (getenv("FSGS_FWD_DBG") && !g_fwd_dbg) {
+        (void)hipMalloc(&g_fwd_dbg, (size_t)n_quads * 64);
+        g_fwd_dbg_n = n_quads;
+    }
+    static const int abl = getenv("FSGS_FWD_ABL") ? atoi(getenv("FSGS_FWD_ABL")) : 0;
+    static const int lds_pad = getenv("FSGS_FWD_LDS_PAD") ? atoi(getenv("FSGS_FWD_LDS_PAD")) : 0;
 #define FSGS_FWD_LIVE(DD, EE)                                                                                     \
-    hipLaunchKernelGGL((raster_fwd_live_kernel<DD, EE>), grid, dim3(64), 0, s, n_isects, rec, p4, isect_offsets,   \
+    hipLaunchKernelGGL((raster_fwd_live_kernel<DD, EE>), grid, dim3(64), lds_pad, s, n_isects, rec, p4, isect_offsets,   \
                        n_isects, backgrounds, width, height, tile_width, tile_height, render, alphas, last_ids,   \
-                       seg_state, seg_cap, normalize_last, render_extra, max_last_partial)
+                       seg_state, seg_cap, normalize_last, render_extra, max_last_partial, C, perm_stride, abl, g_fwd_dbg)
     if (render_extra) {
         if (D != 4) return FSGS_EINVAL;  // the fused RGB+depth + normal-plane walk
         FSGS_FWD_LIVE(4, 3);
