@@ -46,6 +46,13 @@ SIGNATURES = {
     "fsgs_isect_count_live": (_i, [_i, _i, _p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _sz, C.POINTER(_i64), _p]),
     "fsgs_isect_emit_live": (_i, [_i, _i, _p, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p]),
     "fsgs_live_seg_slots": (_i64, [_i, _i, _i, _i64]),
+    "fsgs_quad_stream_capacity": (_i64, [_i, _i, _i, _i64]),
+    "fsgs_quad_seg_slots": (_i64, [_i, _i, _i, _i64]),
+    "fsgs_raster_quad_max_partials": (_i64, [_i, _i, _i]),
+    "fsgs_live_pack": (_i, [_i, _i64, _p, _p, _p, _p, _p, _p, _p]),
+    "fsgs_live_payload": (_i, [_p, _p, _i64, _p, _i64, _i, _i, _p, _p]),
+    "fsgs_raster_fwd_quad": (_i, [_i, _i, _p, _p, _p, _i64, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "fsgs_raster_bwd_quad": (_i, [_i, _i, _p, _p, _p, _i64, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p]),
     "fsgs_raster_fwd_live": (_i, [_i, _i, _p, _p, _p, _i64, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p]),
     "fsgs_raster_bwd_live": (_i, [_i, _i, _p, _p, _p, _i64, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p]),
     "fsgs_campos_from_viewmats": (_i, [_i, _p, _p, _p]),

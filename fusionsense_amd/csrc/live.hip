@@ -237,6 +237,21 @@ live_compact_kernel(int64_t M, int64_t cap, const uint8_t *__restrict__ mask8, c
     }
 }
 
+// (quadrant mask << 28 | flatten id) for lists that arrive without masks (the gsplat-visible lists of
+// fsgs_isect_emit): what fsgs_isect_emit_live writes directly.
+__global__ void __launch_bounds__(256)
+live_payload_kernel(int64_t M, const int64_t *__restrict__ isect_ids, const int32_t *__restrict__ flatten_ids,
+                    const float4 *__restrict__ packed, int tw, int tile_bits, int32_t *__restrict__ payload) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M) return;
+    const int tile = (int)((isect_ids[i] >> 32) & ((1ll << tile_bits) - 1));
+    const int ty = tile / tw, tx = tile - ty * tw;
+    const int64_t g = flatten_ids[i];
+    const float4 r0 = packed[g * 4 + 0], r1 = packed[g * 4 + 1];
+    const unsigned m = quadrant_mask(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, (float)(tx * 16), (float)(ty * 16));
+    payload[i] = (int32_t)((m << 28) | ((uint32_t)g & 0x0FFFFFFFu));
+}
+
 // Live emission (isect.hip) carries the quadrant mask in the payload's top 4 bits: split it into
 // the mask array and clean flatten ids (one pass over the ~M/4 live entries).
 __global__ void __launch_bounds__(256)
@@ -254,6 +269,39 @@ inline int64_t scan4_blocks(int64_t n) { return (n + kS4Tile - 1) / kS4Tile; }
 }  // namespace fsgs
 
 using namespace fsgs;
+
+extern "C" int fsgs_live_pack(int D, int64_t n_gauss_total, const float *means2d, const float *conics,
+                              const float *colors, const float *opacities, const float *extra, float *packed,
+                              fsgs_stream_t stream) {
+    if (n_gauss_total < 0 || (D != 1 && D != 3 && D != 4)) return FSGS_EINVAL;
+    if (n_gauss_total == 0) return FSGS_OK;
+    if (!means2d || !conics || !colors || !opacities || !packed) return FSGS_EINVAL;
+    hipStream_t s = as_stream(stream);
+    float4 *pk = reinterpret_cast<float4 *>(packed);
+    const dim3 gp(ceil_div(n_gauss_total, 256));
+    if (D == 4)
+        hipLaunchKernelGGL((live_pack_kernel<4>), gp, dim3(256), 0, s, n_gauss_total, means2d, conics, colors,
+                           opacities, extra, pk);
+    else if (D == 3)
+        hipLaunchKernelGGL((live_pack_kernel<3>), gp, dim3(256), 0, s, n_gauss_total, means2d, conics, colors,
+                           opacities, extra, pk);
+    else
+        hipLaunchKernelGGL((live_pack_kernel<1>), gp, dim3(256), 0, s, n_gauss_total, means2d, conics, colors,
+                           opacities, extra, pk);
+    return check_launch();
+}
+
+extern "C" int fsgs_live_payload(const int64_t *isect_ids, const int32_t *flatten_ids, int64_t n_isects,
+                                 const float *packed, int64_t n_gauss_total, int tile_width, int tile_bits,
+                                 int32_t *payload, fsgs_stream_t stream) {
+    if (n_isects < 0 || n_gauss_total < 0 || n_gauss_total >= (1ll << 28)) return FSGS_EINVAL;
+    if (n_isects == 0) return FSGS_OK;
+    if (!isect_ids || !flatten_ids || !packed || !payload) return FSGS_EINVAL;
+    hipLaunchKernelGGL(live_payload_kernel, dim3(ceil_div(n_isects, 256)), dim3(256), 0, as_stream(stream), n_isects,
+                       isect_ids, flatten_ids, reinterpret_cast<const float4 *>(packed), tile_width, tile_bits,
+                       payload);
+    return check_launch();
+}
 
 extern "C" size_t fsgs_live_scratch_bytes(int64_t n_isects) {
     return (size_t)(scan4_blocks(n_isects + 1) + 1) * sizeof(int4);

@@ -253,7 +253,8 @@ raster_bwd_live_kernel(int64_t cap, const float4 *__restrict__ rec, const int4 *
                        const int32_t *__restrict__ last_ids, const float *__restrict__ v_render,
                        const float *__restrict__ v_alphas, const float *__restrict__ seg_state,
                        int64_t seg_cap, float *__restrict__ v_packed, int normalize_last,
-                       const float *__restrict__ render_extra, const float *__restrict__ v_render_extra) {
+                       const float *__restrict__ render_extra, const float *__restrict__ v_render_extra,
+                       const int32_t *__restrict__ n_rec) {
     __shared__ QLds<E> Lw[kBwdWaves];
     constexpr int RS = E ? 4 : 3;
     constexpr int SS = 64 * (1 + D + E);
@@ -271,9 +272,16 @@ raster_bwd_live_kernel(int64_t cap, const float4 *__restrict__ rec, const int4 *
 
     const int64_t l0 = tile_offsets[tile_lin];
     const int64_t l1 = (tile_lin == n_tiles_total - 1) ? n_isects : (int64_t)tile_offsets[tile_lin + 1];
-    const int4 p0 = pos4[l0], p1 = pos4[l1];
-    const int s = (q == 0) ? p0.x : (q == 1) ? p0.y : (q == 2) ? p0.z : p0.w;
-    const int e = (q == 0) ? p1.x : (q == 1) ? p1.y : (q == 2) ? p1.z : p1.w;
+    int s, e;
+    if (n_rec) {
+        // streams written by fsgs_raster_fwd_quad: stream position l0 + 4 * tile, count from the forward
+        s = (int)l0 + 4 * tile_lin;
+        e = s + n_rec[(int64_t)q * n_tiles_total + tile_lin];
+    } else {
+        const int4 p0 = pos4[l0], p1 = pos4[l1];
+        s = (q == 0) ? p0.x : (q == 1) ? p0.y : (q == 2) ? p0.z : p0.w;
+        e = (q == 0) ? p1.x : (q == 1) ? p1.y : (q == 2) ? p1.z : p1.w;
+    }
     const int n_seg = (e - s + 63) >> 6;
     if (w >= n_seg) return;
     const float4 *stream = rec + RS * ((int64_t)q * cap);
@@ -521,29 +529,30 @@ extern "C" int fsgs_raster_fwd_live(int C, int D, const float *records, const in
     return check_launch();
 }
 
-extern "C" int fsgs_raster_bwd_live(int C, int D, const float *records, const int32_t *pos4,
-                                    const int32_t *isect_offsets, int64_t n_isects, const float *backgrounds,
-                                    int width, int height, int tile_width, int tile_height, int normalize_last,
-                                    const float *render, const float *alphas, const int32_t *last_ids,
-                                    const float *v_render,
-                                    const float *v_alphas, const float *seg_state, int with_abs,
-                                    const float *render_extra, const float *v_render_extra,
-                                    float *v_packed, fsgs_stream_t stream) {
+extern "C" int64_t fsgs_quad_stream_capacity(int C, int tile_width, int tile_height, int64_t n_isects);
+extern "C" int64_t fsgs_quad_seg_slots(int C, int tile_width, int tile_height, int64_t n_isects);
+
+static int launch_bwd_live(int C, int D, const float *records, const int32_t *pos4, const int32_t *n_rec,
+                           int64_t cap, int64_t seg_cap, const int32_t *isect_offsets, int64_t n_isects,
+                           const float *backgrounds, int width, int height, int tile_width, int tile_height,
+                           int normalize_last, const float *render, const float *alphas, const int32_t *last_ids,
+                           const float *v_render, const float *v_alphas, const float *seg_state, int with_abs,
+                           const float *render_extra, const float *v_render_extra, float *v_packed,
+                           fsgs_stream_t stream) {
     if (C < 0 || width < 0 || height < 0 || n_isects < 0) return FSGS_EINVAL;
     if (C == 0 || width == 0 || height == 0 || n_isects == 0) return FSGS_OK;
-    if (!records || !pos4 || !isect_offsets || !render || !alphas || !last_ids || !v_render || !v_alphas ||
-        !seg_state || !v_packed)
+    if (!records || (!pos4 && !n_rec) || !isect_offsets || !render || !alphas || !last_ids || !v_render ||
+        !v_alphas || !seg_state || !v_packed)
         return FSGS_EINVAL;
-    const int64_t seg_cap = fsgs_live_seg_slots(C, tile_width, tile_height, n_isects);
     hipStream_t s = as_stream(stream);
     const dim3 grid(2 * tile_width, 2 * tile_height, C);
     const float4 *rec = reinterpret_cast<const float4 *>(records);
     const int4 *p4 = reinterpret_cast<const int4 *>(pos4);
 #define FSGS_BWD_LIVE(DD, AA, EE)                                                                                \
-    hipLaunchKernelGGL((raster_bwd_live_kernel<DD, AA, EE>), grid, dim3(64 * kBwdWaves), 0, s, n_isects, rec, p4, \
+    hipLaunchKernelGGL((raster_bwd_live_kernel<DD, AA, EE>), grid, dim3(64 * kBwdWaves), 0, s, cap, rec, p4,      \
                        isect_offsets, n_isects, backgrounds, width, height, tile_width, tile_height, render,      \
                        alphas, last_ids, v_render, v_alphas, seg_state, seg_cap, v_packed, normalize_last,         \
-                       render_extra, v_render_extra)
+                       render_extra, v_render_extra, n_rec)
     if (render_extra) {
         if (D != 4 || !v_render_extra) return FSGS_EINVAL;
         if (with_abs) FSGS_BWD_LIVE(4, true, 3); else FSGS_BWD_LIVE(4, false, 3);
@@ -557,6 +566,39 @@ extern "C" int fsgs_raster_bwd_live(int C, int D, const float *records, const in
     }
 #undef FSGS_BWD_LIVE
     return check_launch();
+}
+
+extern "C" int fsgs_raster_bwd_live(int C, int D, const float *records, const int32_t *pos4,
+                                    const int32_t *isect_offsets, int64_t n_isects, const float *backgrounds,
+                                    int width, int height, int tile_width, int tile_height, int normalize_last,
+                                    const float *render, const float *alphas, const int32_t *last_ids,
+                                    const float *v_render,
+                                    const float *v_alphas, const float *seg_state, int with_abs,
+                                    const float *render_extra, const float *v_render_extra,
+                                    float *v_packed, fsgs_stream_t stream) {
+    if (n_isects > 0 && !pos4) return FSGS_EINVAL;
+    return launch_bwd_live(C, D, records, pos4, nullptr, n_isects,
+                           fsgs_live_seg_slots(C, tile_width, tile_height, n_isects), isect_offsets, n_isects,
+                           backgrounds, width, height, tile_width, tile_height, normalize_last, render, alphas,
+                           last_ids, v_render, v_alphas, seg_state, with_abs, render_extra, v_render_extra,
+                           v_packed, stream);
+}
+
+// the same backward over the streams written by fsgs_raster_fwd_quad (records + n_rec)
+extern "C" int fsgs_raster_bwd_quad(int C, int D, const float *records, const int32_t *n_rec,
+                                    const int32_t *isect_offsets, int64_t n_isects, const float *backgrounds,
+                                    int width, int height, int tile_width, int tile_height, int normalize_last,
+                                    const float *render, const float *alphas, const int32_t *last_ids,
+                                    const float *v_render, const float *v_alphas, const float *seg_state,
+                                    int with_abs, const float *render_extra, const float *v_render_extra,
+                                    float *v_packed, fsgs_stream_t stream) {
+    if (n_isects > 0 && !n_rec) return FSGS_EINVAL;
+    return launch_bwd_live(C, D, records, nullptr, n_rec,
+                           fsgs_quad_stream_capacity(C, tile_width, tile_height, n_isects),
+                           fsgs_quad_seg_slots(C, tile_width, tile_height, n_isects), isect_offsets, n_isects,
+                           backgrounds, width, height, tile_width, tile_height, normalize_last, render, alphas,
+                           last_ids, v_render, v_alphas, seg_state, with_abs, render_extra, v_render_extra,
+                           v_packed, stream);
 }
 
 extern "C" int fsgs_raster_unpack_grads(int64_t total, int D, const float *v_packed, float *v_means2d,

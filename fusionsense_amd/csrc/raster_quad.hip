@@ -1,0 +1,337 @@
+// E7 forward on live lists, second generation: the culling filter, the per-quadrant compaction and the
+// compositing in ONE kernel (replaces gsplat 1.0.0 `rasterize_to_pixels_fwd` for
+// /root/reference/dn_splatter/dn_model.py:570-591 and the legacy rasterize_forward for :644-653).
+//
+// What the first generation (live.hip scan4 + compact, raster_live.hip forward) measured on BASELINE
+// config #2, per-wave timestamps over one launch:
+//   * 2.43 M quadrant records were written by the compaction pass, 1.17 M were ever composited (the
+//     rest sit behind the point where every pixel of the quadrant is opaque);
+//   * one wave walked a quadrant's list alone at ~400 cycles per record (LDS read -> sigma -> exp ->
+//     T is a dependent chain), so the kernel lasted as long as its longest list (7 x 64 records,
+//     ~90 us) while the machine stood 2/3 empty.
+// Here a workgroup of four waves owns one 8x8 quadrant:
+//   * it reads the tile's sorted list itself (payload = quadrant mask << 28 | Gaussian id, written
+//     by fsgs_isect_emit_live), keeps the entries whose mask has this quadrant's bit, gathers their
+//     64-byte line from the packed per-Gaussian table and parks them in LDS in list order — only as
+//     far as the pixels are still transparent; the records are streamed out once for the backward;
+//   * a wave composites 16 pixels x 4 consecutive records per step: lane = (pixel, record slot),
+//     the transmittance chain across the four slots is a quad prefix product (two DPP multiplies),
+//     so a list of n records costs n/4 dependent steps instead of n.
+// Arithmetic per record is that of the reference (alpha = min(.999, o*exp(-sigma)), skip < 1/255,
+// stop before T <= 1e-4); products/sums over the four slots associate differently from a strictly
+// sequential walk (<= 1 ulp per step), which the float tolerance of the parity tests covers.
+#include "common.h"
+
+namespace fsgs {
+
+constexpr int kQuadChunk = 256;             // list entries examined per step by the workgroup
+constexpr int kQuadStage = kQuadChunk + 4;  // staged records (+ padding to a multiple of 4)
+
+template <int E>
+struct QuadLds {
+    float4 r0[kQuadStage], r1[kQuadStage], r2[kQuadStage], r3[E ? kQuadStage : 1];
+    int wcount[4];
+    int wdone[4];
+};
+
+// quad_perm DPP controls: lane i of every 4-lane group reads lane sel[i]
+#define FSGS_QP(a, b, c, d) ((a) | ((b) << 2) | ((c) << 4) | ((d) << 6))
+template <int CTRL>
+__device__ __forceinline__ float quad_f(float v) {
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+template <int CTRL>
+__device__ __forceinline__ int quad_i(int v) {
+    return __builtin_amdgcn_mov_dpp(v, CTRL, 0xF, 0xF, true);
+}
+__device__ __forceinline__ float quad_sum(float v) {
+    v += quad_f<FSGS_QP(1, 0, 3, 2)>(v);
+    v += quad_f<FSGS_QP(2, 3, 0, 1)>(v);
+    return v;
+}
+
+template <int D, int E>
+__global__ void __launch_bounds__(256)
+raster_fwd_quad_kernel(int64_t cap, const float4 *__restrict__ packed, const int32_t *__restrict__ payload,
+                       const int32_t *__restrict__ tile_offsets, int64_t n_isects,
+                       const float *__restrict__ backgrounds, int W, int H, int tw, int th, int n_tiles_total,
+                       float *__restrict__ render, float *__restrict__ alphas, int32_t *__restrict__ last_ids,
+                       float4 *__restrict__ rec_out, int32_t *__restrict__ n_rec,
+                       float *__restrict__ seg_state, int64_t seg_cap, int normalize_last,
+                       float *__restrict__ render_extra, float *__restrict__ max_last_partial) {
+    __shared__ QuadLds<E> S;
+    constexpr int RS = E ? 4 : 3;
+    // workgroup b runs on XCD b % 8: the four quadrants of a tile share its list and its Gaussians,
+    // so they are given ids that differ by 8 (same XCD, dispatched together)
+    const int tile_lin = (blockIdx.x >> 5) * 8 + (blockIdx.x & 7);
+    const int q = (blockIdx.x >> 3) & 3;
+    if (tile_lin >= n_tiles_total) return;
+    const int cam = tile_lin / (tw * th);
+    const int tile_in = tile_lin - cam * tw * th;
+    const int tile_y = tile_in / tw, tile_x = tile_in - tile_y * tw;
+    const int qx = 2 * tile_x + (q & 1), qy = 2 * tile_y + (q >> 1);
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, slot = lane & 3;
+    const int p = w * 16 + (lane >> 2);  // pixel of the quadrant, row-major 8x8
+    const int j = qx * 8 + (p & 7), i = qy * 8 + (p >> 3);
+    const float px = (float)j + 0.5f, py = (float)i + 0.5f;
+    const bool inside = (i < H) && (j < W);
+    bool done = !inside;
+
+    const int l0 = tile_offsets[tile_lin];
+    const int l1 = (tile_lin == n_tiles_total - 1) ? (int)n_isects : tile_offsets[tile_lin + 1];
+    // A quadrant's records go to stream q from position sbase on.  Padding can exceed the tile's own
+    // entry count by at most 3 (last chunk only), hence the 4 spare positions per tile.
+    const int64_t sbase = (int64_t)l0 + 4ll * tile_lin;
+    float4 *stream = rec_out ? rec_out + RS * ((int64_t)q * cap + sbase) : nullptr;
+    constexpr int SS = 64 * (1 + D + E);  // floats per segment-state slot
+    float *seg_q = seg_state ? seg_state + (int64_t)q * seg_cap * SS : nullptr;
+
+    float T = 1.f;
+    int32_t cur_idx = 0;
+    float pix[D], pxe[E ? E : 1];  // this lane's share (its record slot) of the pixel's sums
+#pragma unroll
+    for (int k = 0; k < D; ++k) pix[k] = 0.f;
+#pragma unroll
+    for (int k = 0; k < E; ++k) pxe[k] = 0.f;
+
+    // one list entry per thread, fetched one chunk ahead of the compositing
+    bool live = false;
+    float4 f0, f1, f2, f3;
+    auto fetch = [&](int c0) {
+        const int idx = c0 + tid;
+        live = false;
+        if (idx < l1) {
+            const uint32_t pay = (uint32_t)payload[idx];
+            if ((pay >> (28 + q)) & 1u) {
+                live = true;
+                const int32_t g = (int32_t)(pay & 0x0FFFFFFFu);
+                const float4 *src = packed + (int64_t)g * 4;
+                f0 = src[0]; f1 = src[1]; f2 = src[2];
+                if (E) f3 = src[3];
+                f1.z = __int_as_float(idx);
+                f1.w = __int_as_float(g);
+            }
+        }
+    };
+    fetch(l0);
+
+    int cnt = 0;  // records composited so far (always a multiple of 4; padding records included)
+    for (int c0 = l0; c0 < l1; c0 += kQuadChunk) {
+        const uint64_t bal = __ballot(live);
+        const int before = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) {
+            S.wcount[w] = __popcll(bal);
+            S.wdone[w] = __all(done) ? 1 : 0;
+        }
+        __syncthreads();  // counts visible; the previous chunk's LDS reads are finished
+        if (S.wdone[0] & S.wdone[1] & S.wdone[2] & S.wdone[3]) break;  // every pixel is opaque
+        int base = 0, total = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = S.wcount[k];
+            base += (k < w) ? c : 0;
+            total += c;
+        }
+        const int n_proc = (total + 3) & ~3;
+        if (live) {
+            const int pos = base + before;
+            S.r0[pos] = f0; S.r1[pos] = f1; S.r2[pos] = f2;
+            if (E) S.r3[pos] = f3;
+            if (stream) {
+                float4 *dst = stream + RS * (int64_t)(cnt + pos);
+                dst[0] = f0; dst[1] = f1; dst[2] = f2;
+                if (E) dst[3] = f3;
+            }
+        }
+        // padding to a whole group: zero opacity (alpha = 0) and the list index of the chunk's last
+        // record, so the stream stays sorted by list index for the backward's range tests
+        if (tid >= total && tid < n_proc) {
+            const int last_idx = min(c0 + kQuadChunk, l1) - 1;
+            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 z1 = make_float4(0.f, 0.f, __int_as_float(last_idx), __int_as_float(0));
+            S.r0[tid] = z; S.r1[tid] = z1; S.r2[tid] = z;
+            if (E) S.r3[tid] = z;
+            if (stream) {
+                float4 *dst = stream + RS * (int64_t)(cnt + tid);
+                dst[0] = z; dst[1] = z1; dst[2] = z;
+                if (E) dst[3] = z;
+            }
+        }
+        if (c0 + kQuadChunk < l1) fetch(c0 + kQuadChunk);  // in flight while this chunk is composited
+        __syncthreads();  // staged records visible
+
+        if (!__all(done)) {
+            for (int t = 0; t < n_proc; t += 4) {
+                const float4 a0 = S.r0[t + slot], a1 = S.r1[t + slot];
+                const float dx = a0.x - px, dy = a0.y - py;
+                const float sigma = 0.5f * (a0.w * dx * dx + a1.y * dy * dy) + a1.x * dx * dy;
+                const float alpha = fminf(kAlphaMax, a0.z * __expf(-sigma));
+                const bool pass = !done && !(sigma < 0.f) && !(alpha < kAlphaMin);
+                if (__any(pass)) {
+                    // transmittance before / after this lane's record: quad prefix product of (1 - alpha)
+                    const float om = pass ? 1.f - alpha : 1.f;
+                    float inc = om;
+                    const float s1 = quad_f<FSGS_QP(0, 0, 1, 2)>(inc);
+                    inc = (slot >= 1) ? inc * s1 : inc;
+                    const float s2 = quad_f<FSGS_QP(0, 1, 0, 1)>(inc);
+                    inc = (slot >= 2) ? inc * s2 : inc;
+                    const float e1 = quad_f<FSGS_QP(0, 0, 1, 2)>(inc);
+                    const float exc = (slot >= 1) ? e1 : 1.f;
+                    // a record that would take T to <= 1e-4 ends the pixel and is not composited; every
+                    // later record then fails the same test (T only falls), so the test is per lane
+                    const bool stop = pass && (T * inc <= kTMin);
+                    const bool commit = pass && !stop;
+                    const float vis = commit ? alpha * (T * exc) : 0.f;
+                    const float4 c = S.r2[t + slot];
+                    pix[0] += c.x * vis;
+                    if (D > 1) pix[1] += c.y * vis;
+                    if (D > 2) pix[2] += c.z * vis;
+                    if (D > 3) pix[D - 1] += c.w * vis;
+                    if (E) {
+                        const float4 ce = S.r3[t + slot];
+                        pxe[0] += ce.x * vis;
+                        if (E > 1) pxe[1] += ce.y * vis;
+                        if (E > 2) pxe[E - 1] += ce.z * vis;
+                    }
+                    cur_idx = commit ? __float_as_int(a1.z) : cur_idx;
+                    float f = commit ? om : 1.f;
+                    f *= quad_f<FSGS_QP(1, 0, 3, 2)>(f);
+                    f *= quad_f<FSGS_QP(2, 3, 0, 1)>(f);
+                    T *= f;
+                    int st = stop ? 1 : 0;
+                    st |= quad_i<FSGS_QP(1, 0, 3, 2)>(st);
+                    st |= quad_i<FSGS_QP(2, 3, 0, 1)>(st);
+                    done = done || (st != 0);
+                }
+                // state of every pixel after each 64-record segment, for the segment-parallel backward
+                if (seg_q && ((cnt + t + 4) & 63) == 0) {
+                    float *sl = seg_q + (((sbase + cnt + t + 4) >> 6) + tile_lin) * SS;
+                    float tot[D + (E ? E : 0)];
+#pragma unroll
+                    for (int k = 0; k < D; ++k) tot[k] = quad_sum(pix[k]);
+#pragma unroll
+                    for (int k = 0; k < E; ++k) tot[D + k] = quad_sum(pxe[k]);
+                    if (slot == 0) {
+                        sl[p] = T;
+#pragma unroll
+                        for (int k = 0; k < D + E; ++k) sl[64 * (1 + k) + p] = tot[k];
+                    }
+                }
+            }
+        } else if (seg_q) {
+            // a finished wave still owes the segment states of the records the others walk
+            for (int t = 0; t < n_proc; t += 4) {
+                if (((cnt + t + 4) & 63) == 0) {
+                    float *sl = seg_q + (((sbase + cnt + t + 4) >> 6) + tile_lin) * SS;
+                    float tot[D + (E ? E : 0)];
+#pragma unroll
+                    for (int k = 0; k < D; ++k) tot[k] = quad_sum(pix[k]);
+#pragma unroll
+                    for (int k = 0; k < E; ++k) tot[D + k] = quad_sum(pxe[k]);
+                    if (slot == 0) {
+                        sl[p] = T;
+#pragma unroll
+                        for (int k = 0; k < D + E; ++k) sl[64 * (1 + k) + p] = tot[k];
+                    }
+                }
+            }
+        }
+        cnt += n_proc;
+    }
+    if (n_rec && tid == 0) n_rec[(int64_t)q * n_tiles_total + tile_lin] = cnt;
+
+    // a pixel's sums are spread over its four slot lanes
+#pragma unroll
+    for (int k = 0; k < D; ++k) pix[k] = quad_sum(pix[k]);
+#pragma unroll
+    for (int k = 0; k < E; ++k) pxe[k] = quad_sum(pxe[k]);
+    cur_idx = max(cur_idx, quad_i<FSGS_QP(1, 0, 3, 2)>(cur_idx));
+    cur_idx = max(cur_idx, quad_i<FSGS_QP(2, 3, 0, 1)>(cur_idx));
+
+    if (backgrounds) {
+#pragma unroll
+        for (int k = 0; k < D; ++k) pix[k] += T * backgrounds[cam * D + k];
+    }
+    if (normalize_last) pix[D - 1] = pix[D - 1] / fmaxf(1.f - T, 1e-10f);  // expected depth
+    if (inside && slot == 0) {
+        const int64_t pix_id = ((int64_t)cam * H + i) * W + j;
+        if (D == 4) {
+            reinterpret_cast<float4 *>(render)[pix_id] = make_float4(pix[0], pix[1], pix[2], pix[D - 1]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < D; ++k) render[pix_id * D + k] = pix[k];
+        }
+        if (E) {
+#pragma unroll
+            for (int k = 0; k < E; ++k) render_extra[pix_id * E + k] = pxe[k] + T;  // background = 1
+        }
+        alphas[pix_id] = 1.f - T;
+        last_ids[pix_id] = cur_idx;
+    }
+    if (max_last_partial) {  // per-wave max of the (normalised) last channel, for depth_im's fill value
+        float m = inside ? pix[D - 1] : 0.f;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d, 64));
+        if (lane == 0) max_last_partial[((int64_t)tile_lin * 4 + q) * 4 + w] = m;
+    }
+}
+
+}  // namespace fsgs
+
+using namespace fsgs;
+
+// records per stream (there are four): every list entry plus 4 padding positions per tile
+extern "C" int64_t fsgs_quad_stream_capacity(int C, int tile_width, int tile_height, int64_t n_isects) {
+    return n_isects + 4ll * C * tile_width * tile_height;
+}
+
+// segment-state slots per stream: one per 64 stream positions plus one per tile (see the slot formula)
+extern "C" int64_t fsgs_quad_seg_slots(int C, int tile_width, int tile_height, int64_t n_isects) {
+    return (fsgs_quad_stream_capacity(C, tile_width, tile_height, n_isects) >> 6) +
+           (int64_t)C * tile_width * tile_height + 2;
+}
+
+extern "C" int64_t fsgs_raster_quad_max_partials(int C, int tile_width, int tile_height) {
+    return 16ll * C * tile_width * tile_height;
+}
+
+extern "C" int fsgs_raster_fwd_quad(int C, int D, const float *packed, const int32_t *payload,
+                                    const int32_t *isect_offsets, int64_t n_isects, const float *backgrounds,
+                                    int width, int height, int tile_width, int tile_height, int normalize_last,
+                                    float *render, float *alphas, int32_t *last_ids, float *records,
+                                    int32_t *n_rec, float *seg_state, float *render_extra,
+                                    float *max_last_partial, fsgs_stream_t stream) {
+    if (C < 0 || width < 0 || height < 0 || n_isects < 0) return FSGS_EINVAL;
+    if (C == 0 || width == 0 || height == 0) return FSGS_OK;
+    if (n_isects > 0x7FFFFFF0ll) return FSGS_EINVAL;  // list indices are 32-bit (as in the reference)
+    if (!isect_offsets || !render || !alphas || !last_ids || (n_isects > 0 && (!packed || !payload)))
+        return FSGS_EINVAL;
+    if ((records != nullptr) != (n_rec != nullptr)) return FSGS_EINVAL;
+    if (seg_state && !records) return FSGS_EINVAL;
+    const int64_t n_tiles = (int64_t)C * tile_width * tile_height;
+    if (n_tiles >= (1ll << 26)) return FSGS_EINVAL;
+    const dim3 grid((unsigned)(((n_tiles + 7) / 8) * 32));
+    hipStream_t s = as_stream(stream);
+    const float4 *pk = reinterpret_cast<const float4 *>(packed);
+    float4 *rec = reinterpret_cast<float4 *>(records);
+    const int64_t seg_cap = fsgs_quad_seg_slots(C, tile_width, tile_height, n_isects);
+    const int64_t cap = fsgs_quad_stream_capacity(C, tile_width, tile_height, n_isects);
+#define FSGS_FWD_QUAD(DD, EE)                                                                                    \
+    hipLaunchKernelGGL((raster_fwd_quad_kernel<DD, EE>), grid, dim3(256), 0, s, cap, pk, payload,                 \
+                       isect_offsets, n_isects, backgrounds, width, height, tile_width, tile_height, (int)n_tiles, \
+                       render, alphas, last_ids, rec, n_rec, seg_state, seg_cap, normalize_last, render_extra,     \
+                       max_last_partial)
+    if (render_extra) {
+        if (D != 4) return FSGS_EINVAL;  // the fused RGB+depth + normal-plane walk
+        FSGS_FWD_QUAD(4, 3);
+        return check_launch();
+    }
+    switch (D) {
+        case 1: FSGS_FWD_QUAD(1, 0); break;
+        case 3: FSGS_FWD_QUAD(3, 0); break;
+        case 4: FSGS_FWD_QUAD(4, 0); break;
+        default: return FSGS_EINVAL;
+    }
+#undef FSGS_FWD_QUAD
+    return check_launch();
+}

@@ -38,10 +38,15 @@ class FrameInfo:
 
     def __init__(self):
         self.radii = self.means2d = self.depths = self.conics = self.tiles_per_gauss = None
-        self.isect_ids = self.flatten_ids = self.isect_offsets = self.last_ids = None
+        self.isect_ids = self.payload = self.isect_offsets = self.last_ids = None
         self.absgrad: Optional[Tensor] = None  # [1,N,2], set by backward
         self.normals_world = None
         self.legacy_rule_diff = 0
+
+    @property
+    def flatten_ids(self):
+        """Gaussian id of every LIVE list entry (the sorted payload carries the quadrant mask in its top 4 bits)."""
+        return None if self.payload is None else self.payload & 0x0FFFFFFF
 
     def __getitem__(self, key):  # dict-style access like gsplat's meta
         return getattr(self, key)
@@ -103,33 +108,33 @@ class _FusedGetOutputs(torch.autograd.Function):
 
         needs_bwd = any(ctx.needs_input_grad[:6])
         a = lambda n: (n + 255) // 256 * 256  # noqa: E731
-        sbytes = lib.fsgs_live_scratch_bytes(M)
-        rec_bytes = 4 * max(M, 1) * 64
-        pos_bytes = (M + 1) * 16
-        seg_slots = lib.fsgs_live_seg_slots(1, tw, th, M)
-        seg_bytes = 4 * seg_slots * 64 * (1 + 4 + 3) * 4 if needs_bwd else 0
-        arena = WORKSPACE.take(a(rec_bytes) + a(pos_bytes) + a(M + 1) + a(sbytes) + a(seg_bytes), dev)
-        o = 0
-        records = arena[o:o + rec_bytes].view(torch.float32); o += a(rec_bytes)
-        pos4 = arena[o:o + pos_bytes].view(torch.int32); o += a(pos_bytes)
-        mask8 = arena[o:o + M + 1]; o += a(M + 1)
-        scratch = arena[o:o + sbytes]; o += a(sbytes)
-        seg_state = arena[o:o + seg_bytes].view(torch.float32) if needs_bwd else None
+        n_tiles = tw * th
+        if needs_bwd:
+            cap = lib.fsgs_quad_stream_capacity(1, tw, th, M)
+            rec_bytes = 4 * cap * 64
+            seg_bytes = 4 * lib.fsgs_quad_seg_slots(1, tw, th, M) * 64 * (1 + 4 + 3) * 4
+            nrec_bytes = 4 * n_tiles * 4
+            arena = WORKSPACE.take(a(rec_bytes) + a(seg_bytes) + a(nrec_bytes), dev)
+            records = arena[:rec_bytes].view(torch.float32)
+            seg_state = arena[a(rec_bytes):a(rec_bytes) + seg_bytes].view(torch.float32)
+            o = a(rec_bytes) + a(seg_bytes)
+            n_rec = arena[o:o + nrec_bytes].view(torch.int32)
+        else:
+            arena = records = seg_state = n_rec = None
         packed = torch.empty(N, 16, **f32)
-        _run(lib.fsgs_live_prepare, (4, ptr(means2d), ptr(conics), ptr(colors), ptr(opac_sig), ptr(normals_cam),
-                                    tw, tile_bits(tw * th), ptr(isect_ids), ptr(flatten_ids), M, N, ptr(packed), 1,
-                                    ptr(mask8),
-                                    ptr(pos4), ptr(records), ptr(scratch), sbytes, sp), "fsgs_live_prepare", "_d4e3")
+        _run(lib.fsgs_live_pack, (4, N, ptr(means2d), ptr(conics), ptr(colors), ptr(opac_sig), ptr(normals_cam),
+                                 ptr(packed), sp), "fsgs_live_pack", "_d4e3")
 
         render = torch.empty(1, H, W, 4, **f32)
         alphas = torch.empty(1, H, W, 1, **f32)
         last_ids = torch.empty(1, H, W, dtype=torch.int32, device=dev)
         render_extra = torch.empty(1, H, W, 3, **f32)
-        n_part = 4 * tw * th
+        n_part = lib.fsgs_raster_quad_max_partials(1, tw, th)
         max_part = torch.empty(n_part + 1, **f32)
-        _run(lib.fsgs_raster_fwd_live, (1, 4, ptr(records), ptr(pos4), ptr(offsets), M, None, W, H, tw, th, 1,
-                                       ptr(render), ptr(alphas), ptr(last_ids), ptr(seg_state), ptr(render_extra),
-                                       ptr(max_part), sp), "fsgs_raster_fwd_live", "_d4e3")
+        _run(lib.fsgs_raster_fwd_quad, (1, 4, ptr(packed), ptr(flatten_ids), ptr(offsets), M, None, W, H, tw, th, 1,
+                                       ptr(render), ptr(alphas), ptr(last_ids), ptr(records), ptr(n_rec),
+                                       ptr(seg_state), ptr(render_extra), ptr(max_part), sp),
+             "fsgs_raster_fwd_quad", "_d4e3")
         rgb = torch.empty(H, W, 3, **f32)
         depth = torch.empty(H, W, 1, **f32)
         normal = torch.empty(H, W, 3, **f32)
@@ -138,13 +143,13 @@ class _FusedGetOutputs(torch.autograd.Function):
                                     ptr(normal), sp), "fsgs_epilogue_fwd")
 
         info.radii, info.means2d, info.depths, info.conics = radii, means2d, depths, conics
-        info.tiles_per_gauss, info.isect_ids, info.flatten_ids = tpg, isect_ids, flatten_ids
+        info.tiles_per_gauss, info.isect_ids, info.payload = tpg, isect_ids, flatten_ids
         info.isect_offsets, info.last_ids, info.normals_world = offsets, last_ids, normals_world
         info.legacy_rule_diff = rule_diff
 
         if needs_bwd:
             ctx.save_for_backward(means, scales, quats, features_dc, features_rest, scales_exp, opac_sig, radii,
-                                  conics, records, pos4, offsets, render, alphas, last_ids, render_extra, seg_state,
+                                  conics, records, n_rec, offsets, render, alphas, last_ids, render_extra, seg_state,
                                   background)
             ctx.arena = arena
         else:
@@ -157,7 +162,7 @@ class _FusedGetOutputs(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, v_rgb, v_depth, v_normal, v_alpha_out):
-        (means, scales, quats, features_dc, features_rest, scales_exp, opac_sig, radii, conics, records, pos4,
+        (means, scales, quats, features_dc, features_rest, scales_exp, opac_sig, radii, conics, records, n_rec,
          offsets, render, alphas, last_ids, render_extra, seg_state, background) = ctx.saved_tensors
         N, K, W, H, tw, th, M, sh_degree = ctx.dims
         cam = ctx.cam
@@ -175,10 +180,10 @@ class _FusedGetOutputs(torch.autograd.Function):
                                     ptr(v_depth), ptr(v_normal), ptr(v_alpha_out), ptr(v_render), ptr(v_alphas),
                                     ptr(v_render_extra), sp), "fsgs_epilogue_bwd")
         v_packed = torch.zeros(N, 16, **f32)
-        _run(lib.fsgs_raster_bwd_live, (1, 4, ptr(records), ptr(pos4), ptr(offsets), M, None, W, H, tw, th, 1,
+        _run(lib.fsgs_raster_bwd_quad, (1, 4, ptr(records), ptr(n_rec), ptr(offsets), M, None, W, H, tw, th, 1,
                                        ptr(render), ptr(alphas), ptr(last_ids), ptr(v_render), ptr(v_alphas),
                                        ptr(seg_state), 1, ptr(render_extra), ptr(v_render_extra), ptr(v_packed), sp),
-             "fsgs_raster_bwd_live", "_d4e3")
+             "fsgs_raster_bwd_quad", "_d4e3")
         v_means2d = torch.empty(1, N, 2, **f32)
         v_abs = torch.empty(1, N, 2, **f32)
         v_conics = torch.empty(1, N, 3, **f32)

@@ -242,6 +242,38 @@ int fsgs_raster_bwd_live(int C, int D, const float *records, const int32_t *pos4
                          const float *v_render, const float *v_alphas, const float *seg_state,
                          int with_abs, const float *render_extra, const float *v_render_extra,
                          float *v_packed, fsgs_stream_t stream);
+/* ---- Second-generation live forward: filter + per-quadrant compaction + compositing in one kernel
+ * (same reference functions as fsgs_raster_fwd_live; tile_size 16).  A workgroup of four waves owns an
+ * 8x8 quadrant, reads the tile's sorted list itself and composites 16 pixels x 4 records per step.
+ *   packed   [C*N,16] f32 from fsgs_live_pack: {x,y,opacity,conic.a}{conic.b,conic.c,-,-}{colour[4]}{extra[3],-}
+ *   payload  [M] i32: (quadrant mask << 28) | flatten id — what fsgs_isect_emit_live writes, or
+ *            fsgs_live_payload from plain lists (so C*N < 2^28)
+ *   records  4 * fsgs_quad_stream_capacity(...) * (render_extra ? 16 : 12) floats, n_rec [4, C*th*tw] i32:
+ *            the walked part of every quadrant's list, written for fsgs_raster_bwd_quad (both nullable
+ *            together for inference); seg_state: 4 * fsgs_quad_seg_slots(...) * 64 * (1+D+E) floats
+ *   max_last_partial [fsgs_raster_quad_max_partials(...)] (nullable). */
+int64_t fsgs_quad_stream_capacity(int C, int tile_width, int tile_height, int64_t n_isects);
+int64_t fsgs_quad_seg_slots(int C, int tile_width, int tile_height, int64_t n_isects);
+int64_t fsgs_raster_quad_max_partials(int C, int tile_width, int tile_height);
+int fsgs_live_pack(int D, int64_t n_gauss_total, const float *means2d, const float *conics,
+                   const float *colors, const float *opacities, const float *extra, float *packed,
+                   fsgs_stream_t stream);
+int fsgs_live_payload(const int64_t *isect_ids, const int32_t *flatten_ids, int64_t n_isects,
+                      const float *packed, int64_t n_gauss_total, int tile_width, int tile_bits,
+                      int32_t *payload, fsgs_stream_t stream);
+int fsgs_raster_fwd_quad(int C, int D, const float *packed, const int32_t *payload,
+                         const int32_t *isect_offsets, int64_t n_isects, const float *backgrounds,
+                         int width, int height, int tile_width, int tile_height, int normalize_last,
+                         float *render, float *alphas, int32_t *last_ids, float *records, int32_t *n_rec,
+                         float *seg_state, float *render_extra, float *max_last_partial,
+                         fsgs_stream_t stream);
+int fsgs_raster_bwd_quad(int C, int D, const float *records, const int32_t *n_rec,
+                         const int32_t *isect_offsets, int64_t n_isects, const float *backgrounds,
+                         int width, int height, int tile_width, int tile_height, int normalize_last,
+                         const float *render, const float *alphas, const int32_t *last_ids,
+                         const float *v_render, const float *v_alphas, const float *seg_state,
+                         int with_abs, const float *render_extra, const float *v_render_extra,
+                         float *v_packed, fsgs_stream_t stream);
 /* Split packed gradient records into the five gsplat-shaped arrays (written, not accumulated). */
 int fsgs_raster_unpack_grads(int64_t total, int D, const float *v_packed, float *v_means2d,
                              float *v_means2d_abs, float *v_conics, float *v_colors,
