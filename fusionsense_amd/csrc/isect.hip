@@ -4,6 +4,7 @@
 // `map_gaussian_to_intersects` / `get_tile_bin_edges` behind gsplat.rasterize_gaussians
 // (dn_model.py:644-653).  Integer work: every output is bit-exact against the oracle.
 #include "common.h"
+#include <cstdlib>
 #include "cull.h"
 #include "scan.h"
 
@@ -204,6 +205,116 @@ isect_live_kernel(int C, int N, const float *__restrict__ means2d, const int32_t
     if (!EMIT && idx < total) live_per_gauss[idx] = live;
 }
 
+// The same two passes with the (Gaussian, tile) pairs of a wave's 64 Gaussians FLATTENED over its
+// lanes: a Gaussian covers 7 tiles on average but hundreds at the tail, and with one thread per
+// Gaussian a wave lasted as long as its largest splat (47 + 51 us on BASELINE config #2, the mask
+// arithmetic itself is ~5 us of the machine).  Per window of 64 consecutive pairs a lane finds its
+// Gaussian by bisection over the wave's exclusive prefix of rectangle sizes (LDS), evaluates the
+// quadrant mask of its own tile, and the live pairs of each Gaussian are ranked with one ballot.
+struct FlatLds {
+    int excl[64];       // exclusive prefix of the rectangle sizes
+    float4 a[64];       // mx, my, opacity, conic a
+    float4 b[64];       // conic b, conic c, depth bits, -
+    int4 rect[64];      // x0, y0, width, count
+    int run[64];        // live pairs of the Gaussian so far
+    long long start[64];  // EMIT: first output position of the Gaussian
+};
+
+template <bool EMIT>
+__global__ void __launch_bounds__(256)
+isect_live_flat_kernel(int C, int N, const float *__restrict__ means2d, const int32_t *__restrict__ radii,
+                       const float *__restrict__ depths, const float *__restrict__ conics,
+                       const float *__restrict__ opacities, const int64_t *__restrict__ cum_live, int tw,
+                       int th, int tile_bits, int32_t *__restrict__ tiles_per_gauss,
+                       int32_t *__restrict__ live_per_gauss, int64_t *__restrict__ isect_ids,
+                       int32_t *__restrict__ payload) {
+    __shared__ FlatLds Ls[4];
+    const int64_t total = (int64_t)C * N;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    FlatLds &L = Ls[w];
+    const int64_t idx0 = (int64_t)blockIdx.x * blockDim.x + w * 64;  // the wave's first Gaussian
+    const int64_t idx = idx0 + lane;
+    int cnt = 0;
+    {
+        TileRect t = {0, 0, 0, 0};
+        float mx = 0.f, my = 0.f, op = 0.f, ca = 0.f, cb = 0.f, cc = 0.f, db = 0.f;
+        if (idx < total) {
+            const int r = radii[idx];
+            if (r > 0) {
+                const float2 m = reinterpret_cast<const float2 *>(means2d)[idx];
+                mx = m.x; my = m.y;
+                t = tile_rect(mx, my, r, 16, tw, th, 0);
+                cnt = (t.x1 - t.x0) * (t.y1 - t.y0);
+                op = opacities[idx];
+                ca = conics[idx * 3 + 0]; cb = conics[idx * 3 + 1]; cc = conics[idx * 3 + 2];
+                if (EMIT) {
+                    db = depths[idx];
+                    L.start[lane] = (idx == 0) ? 0 : cum_live[idx - 1];
+                }
+            }
+            if (!EMIT) tiles_per_gauss[idx] = cnt;
+        }
+        L.a[lane] = make_float4(mx, my, op, ca);
+        L.b[lane] = make_float4(cb, cc, db, 0.f);
+        L.rect[lane] = make_int4(t.x0, t.y0, t.x1 - t.x0, cnt);
+        L.run[lane] = 0;
+    }
+    int inc = cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += o;
+    }
+    L.excl[lane] = inc - cnt;
+    const int wave_total = __shfl(inc, 63, 64);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    for (int base = 0; base < wave_total; base += 64) {
+        const int p = base + lane;
+        const bool valid = p < wave_total;
+        // owner = last lane whose exclusive prefix is <= p (empty rectangles share the prefix of the
+        // next non-empty one, so "last" skips them)
+        int lo = 0;
+#pragma unroll
+        for (int step = 32; step >= 1; step >>= 1) {
+            const int mid = lo + step;
+            if (L.excl[mid] <= p) lo = mid;
+        }
+        const int o = lo;
+        const int4 rc = L.rect[o];
+        const int first = L.excl[o];
+        unsigned m = 0u;
+        int x = 0, y = 0;
+        if (valid) {
+            const float4 A = L.a[o], B = L.b[o];
+            const int jj = p - first;
+            y = rc.y + jj / rc.z; x = rc.x + jj - (jj / rc.z) * rc.z;
+            m = quadrant_mask(A.x, A.y, A.z, A.w, B.x, B.y, (float)(x * 16), (float)(y * 16));
+        }
+        const unsigned long long bal = __ballot(m != 0u);
+        // lanes [s0, s1) of this window belong to the same Gaussian
+        const int s0 = max(first - base, 0), s1 = min(max(first + rc.w - base, 0), 64);
+        const unsigned long long upto = (lane == 0) ? 0ull : (~0ull >> (64 - lane));          // bits [0, lane)
+        const unsigned long long from = (s0 == 0) ? ~0ull : (~0ull << s0);                     // bits [s0, 64)
+        const unsigned long long to = (s1 >= 64) ? ~0ull : ((1ull << s1) - 1ull);              // bits [0, s1)
+        const int before = L.run[o];
+        if (EMIT && m) {
+            const int64_t pos = L.start[o] + before + __popcll(bal & from & upto);
+            const int64_t gidx = idx0 + o;
+            const int64_t c = (C == 1) ? 0 : gidx / N;
+            const int64_t dbits = (int64_t)(uint32_t)__float_as_int(L.b[o].z);
+            isect_ids[pos] = (c << (32 + tile_bits)) | ((int64_t)(y * tw + x) << 32) | dbits;
+            payload[pos] = (int32_t)((m << 28) | (uint32_t)gidx);
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (valid && lane == s0) L.run[o] = before + __popcll(bal & from & to);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (!EMIT && idx < total) live_per_gauss[idx] = L.run[lane];
+}
+
 __global__ void __launch_bounds__(256)
 offset_encode_kernel(int64_t n_isects, const int64_t *__restrict__ ids, int n_tiles, int tile_bits,
                      int n_total, int32_t *__restrict__ offsets) {
@@ -321,9 +432,15 @@ extern "C" int fsgs_isect_count_live(int C, int N, const float *means2d, const i
         return FSGS_EINVAL;
     if (scratch_bytes < fsgs_scan_scratch_bytes(total) || !scratch) return FSGS_ESCRATCH;
     hipStream_t s = as_stream(stream);
-    hipLaunchKernelGGL((isect_live_kernel<false>), dim3(ceil_div(total, 256)), dim3(256), 0, s, C, N, means2d, radii,
-                       nullptr, conics, opacities, nullptr, tile_width, tile_height, 0, tiles_per_gauss,
-                       live_per_gauss, nullptr, nullptr);
+    static const bool per_thread = getenv("FSGS_ISECT_PER_THREAD") != nullptr;
+    if (per_thread)
+        hipLaunchKernelGGL((isect_live_kernel<false>), dim3(ceil_div(total, 256)), dim3(256), 0, s, C, N, means2d,
+                           radii, nullptr, conics, opacities, nullptr, tile_width, tile_height, 0, tiles_per_gauss,
+                           live_per_gauss, nullptr, nullptr);
+    else
+        hipLaunchKernelGGL((isect_live_flat_kernel<false>), dim3(ceil_div(total, 256)), dim3(256), 0, s, C, N,
+                           means2d, radii, nullptr, conics, opacities, nullptr, tile_width, tile_height, 0,
+                           tiles_per_gauss, live_per_gauss, nullptr, nullptr);
     int rc = device_scan<int32_t, true>(total, live_per_gauss, cum_live, scratch, scratch_bytes, s);
     if (rc != FSGS_OK) return rc;
     hipError_t e = hipMemcpyAsync(n_live_host, cum_live + (total - 1), sizeof(int64_t), hipMemcpyDeviceToHost, s);
@@ -343,8 +460,14 @@ extern "C" int fsgs_isect_emit_live(int C, int N, const float *means2d, const in
     if (!means2d || !radii || !depths || !conics || !opacities || !cum_live || !isect_ids || !payload)
         return FSGS_EINVAL;
     const int tb = tile_bits_for(tile_width * tile_height);
-    hipLaunchKernelGGL((isect_live_kernel<true>), dim3(ceil_div(total, 256)), dim3(256), 0, as_stream(stream), C, N,
-                       means2d, radii, depths, conics, opacities, cum_live, tile_width, tile_height, tb, nullptr,
-                       nullptr, isect_ids, payload);
+    static const bool per_thread = getenv("FSGS_ISECT_PER_THREAD") != nullptr;
+    if (per_thread)
+        hipLaunchKernelGGL((isect_live_kernel<true>), dim3(ceil_div(total, 256)), dim3(256), 0, as_stream(stream), C,
+                           N, means2d, radii, depths, conics, opacities, cum_live, tile_width, tile_height, tb,
+                           nullptr, nullptr, isect_ids, payload);
+    else
+        hipLaunchKernelGGL((isect_live_flat_kernel<true>), dim3(ceil_div(total, 256)), dim3(256), 0,
+                           as_stream(stream), C, N, means2d, radii, depths, conics, opacities, cum_live, tile_width,
+                           tile_height, tb, nullptr, nullptr, isect_ids, payload);
     return check_launch();
 }
