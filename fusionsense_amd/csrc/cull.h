@@ -27,21 +27,74 @@ __device__ __forceinline__ float min_sigma_rect(float mx, float my, float a, flo
     return best;
 }
 
+// Per-Gaussian constants of the reach test (computed once, reused for every tile of its rectangle).
+struct CullPrep {
+    float mx, my, b, tau;          // tau = ln(255 * opacity) + margin: reachable iff min sigma <= tau
+    float ha, hc, inv_a, inv_c;    // 0.5 * a, 0.5 * c, 1 / a, 1 / c
+};
+
+__device__ __forceinline__ CullPrep cull_prepare(float mx, float my, float opac, float a, float b, float c) {
+    CullPrep p;
+    p.mx = mx; p.my = my;
+    if (!(opac >= kAlphaMin * 0.999f)) {
+        // alpha <= opacity < 1/255 everywhere: nothing is reachable (min sigma >= 0 > -inf)
+        p.b = 0.f; p.ha = 0.5f; p.hc = 0.5f; p.inv_a = 1.f; p.inv_c = 1.f;
+        p.tau = -__builtin_huge_valf();
+    } else if (!(a > 0.f && c > 0.f && a * c - b * b > 0.f)) {
+        // not positive definite: no bound, every quadrant stays
+        p.b = 0.f; p.ha = 0.5f; p.hc = 0.5f; p.inv_a = 1.f; p.inv_c = 1.f;
+        p.tau = __builtin_huge_valf();
+    } else {
+        p.b = b; p.ha = 0.5f * a; p.hc = 0.5f * c;
+        p.inv_a = __builtin_amdgcn_rcpf(a); p.inv_c = __builtin_amdgcn_rcpf(c);
+        p.tau = __logf(255.f * opac) + kCullMargin;
+    }
+    return p;
+}
+
 // 4-bit mask: bit q = qy*2+qx set if the Gaussian can reach quadrant q of the 16x16 tile at
 // (tile_x0, tile_y0).  Conservative: a set bit never hides a contribution.
-__device__ __forceinline__ unsigned quadrant_mask(float mx, float my, float opac, float a, float b, float c,
-                                                  float tile_x0, float tile_y0) {
-    if (!(opac >= kAlphaMin * 0.999f)) return 0u;                   // alpha <= opac < 1/255 everywhere
-    if (!(a > 0.f && c > 0.f && a * c - b * b > 0.f)) return 0xFu;  // not positive definite: no bound
-    const float tau = __logf(255.f * opac) + kCullMargin;
-    const float inv_a = 1.f / a, inv_c = 1.f / c;
+// The four quadrants' rectangles of pixel centres are bounded by 4 vertical and 4 horizontal lines
+// (x0 + {0.5, 7.5, 8.5, 15.5}); on each line the form is a 1-D parabola, minimised over each of the
+// two half ranges by clamping its vertex: 16 three-instruction evaluations per tile.
+__device__ __forceinline__ unsigned quadrant_mask(const CullPrep &p, float tile_x0, float tile_y0) {
+    float dx[4], dy[4];  // centre minus line coordinate (decreasing in k)
+    dx[0] = p.mx - (tile_x0 + 0.5f); dx[1] = p.mx - (tile_x0 + 7.5f);
+    dx[2] = p.mx - (tile_x0 + 8.5f); dx[3] = p.mx - (tile_x0 + 15.5f);
+    dy[0] = p.my - (tile_y0 + 0.5f); dy[1] = p.my - (tile_y0 + 7.5f);
+    dy[2] = p.my - (tile_y0 + 8.5f); dy[3] = p.my - (tile_y0 + 15.5f);
+    float qv[4][2], qh[4][2];  // [line][half of the other axis]
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float u = p.b * dx[k], t = -u * p.inv_c, A = p.ha * dx[k] * dx[k];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const float d = fminf(fmaxf(t, dy[2 * h + 1]), dy[2 * h]);
+            qv[k][h] = fmaf(d, fmaf(p.hc, d, u), A);
+        }
+        const float v = p.b * dy[k], s = -v * p.inv_a, Cc = p.hc * dy[k] * dy[k];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const float d = fminf(fmaxf(s, dx[2 * h + 1]), dx[2 * h]);
+            qh[k][h] = fmaf(d, fmaf(p.ha, d, v), Cc);
+        }
+    }
+    const bool in_x[2] = {dx[1] <= 0.f && dx[0] >= 0.f, dx[3] <= 0.f && dx[2] >= 0.f};
+    const bool in_y[2] = {dy[1] <= 0.f && dy[0] >= 0.f, dy[3] <= 0.f && dy[2] >= 0.f};
     unsigned m = 0u;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const float x0 = tile_x0 + (float)((q & 1) * 8) + 0.5f, y0 = tile_y0 + (float)((q >> 1) * 8) + 0.5f;
-        if (min_sigma_rect(mx, my, a, b, c, inv_a, inv_c, x0, x0 + 7.f, y0, y0 + 7.f) <= tau) m |= 1u << q;
+        const int qx = q & 1, qy = q >> 1;
+        float best = fminf(fminf(qv[2 * qx][qy], qv[2 * qx + 1][qy]), fminf(qh[2 * qy][qx], qh[2 * qy + 1][qx]));
+        if (in_x[qx] && in_y[qy]) best = 0.f;
+        if (best <= p.tau) m |= 1u << q;
     }
     return m;
+}
+
+__device__ __forceinline__ unsigned quadrant_mask(float mx, float my, float opac, float a, float b, float c,
+                                                  float tile_x0, float tile_y0) {
+    return quadrant_mask(cull_prepare(mx, my, opac, a, b, c), tile_x0, tile_y0);
 }
 
 }  // namespace fsgs

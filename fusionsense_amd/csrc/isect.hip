@@ -213,8 +213,9 @@ isect_live_kernel(int C, int N, const float *__restrict__ means2d, const int32_t
 // quadrant mask of its own tile, and the live pairs of each Gaussian are ranked with one ballot.
 struct FlatLds {
     int excl[64];       // exclusive prefix of the rectangle sizes
-    float4 a[64];       // mx, my, opacity, conic a
-    float4 b[64];       // conic b, conic c, depth bits, -
+    float4 a[64];       // CullPrep: mx, my, b, tau
+    float4 b[64];       // CullPrep: ha, hc, inv_a, inv_c
+    float depth[64];    // EMIT: the sort key's low word
     int4 rect[64];      // x0, y0, width, count
     int run[64];        // live pairs of the Gaussian so far
     long long start[64];  // EMIT: first output position of the Gaussian
@@ -254,8 +255,10 @@ isect_live_flat_kernel(int C, int N, const float *__restrict__ means2d, const in
             }
             if (!EMIT) tiles_per_gauss[idx] = cnt;
         }
-        L.a[lane] = make_float4(mx, my, op, ca);
-        L.b[lane] = make_float4(cb, cc, db, 0.f);
+        const CullPrep cp = cull_prepare(mx, my, op, ca, cb, cc);
+        L.a[lane] = make_float4(cp.mx, cp.my, cp.b, cp.tau);
+        L.b[lane] = make_float4(cp.ha, cp.hc, cp.inv_a, cp.inv_c);
+        if (EMIT) L.depth[lane] = db;
         L.rect[lane] = make_int4(t.x0, t.y0, t.x1 - t.x0, cnt);
         L.run[lane] = 0;
     }
@@ -288,9 +291,10 @@ isect_live_flat_kernel(int C, int N, const float *__restrict__ means2d, const in
         int x = 0, y = 0;
         if (valid) {
             const float4 A = L.a[o], B = L.b[o];
+            const CullPrep cp = {A.x, A.y, A.z, A.w, B.x, B.y, B.z, B.w};
             const int jj = p - first;
             y = rc.y + jj / rc.z; x = rc.x + jj - (jj / rc.z) * rc.z;
-            m = quadrant_mask(A.x, A.y, A.z, A.w, B.x, B.y, (float)(x * 16), (float)(y * 16));
+            m = quadrant_mask(cp, (float)(x * 16), (float)(y * 16));
         }
         const unsigned long long bal = __ballot(m != 0u);
         // lanes [s0, s1) of this window belong to the same Gaussian
@@ -303,7 +307,7 @@ isect_live_flat_kernel(int C, int N, const float *__restrict__ means2d, const in
             const int64_t pos = L.start[o] + before + __popcll(bal & from & upto);
             const int64_t gidx = idx0 + o;
             const int64_t c = (C == 1) ? 0 : gidx / N;
-            const int64_t dbits = (int64_t)(uint32_t)__float_as_int(L.b[o].z);
+            const int64_t dbits = (int64_t)(uint32_t)__float_as_int(L.depth[o]);
             isect_ids[pos] = (c << (32 + tile_bits)) | ((int64_t)(y * tw + x) << 32) | dbits;
             payload[pos] = (int32_t)((m << 28) | (uint32_t)gidx);
         }
