@@ -427,9 +427,9 @@ extern "C" int fsgs_isect_count_live(int C, int N, const float *means2d, const i
                                      int tile_height, int32_t *tiles_per_gauss, int32_t *live_per_gauss,
                                      int64_t *cum_live, void *scratch, size_t scratch_bytes,
                                      int64_t *n_live_host, fsgs_stream_t stream) {
-    if (C < 0 || N < 0 || !n_live_host) return FSGS_EINVAL;
+    if (C < 0 || N < 0) return FSGS_EINVAL;
     const int64_t total = (int64_t)C * N;
-    *n_live_host = 0;
+    if (n_live_host) *n_live_host = 0;
     if (total == 0) return FSGS_OK;
     if (total >= (1ll << 28)) return FSGS_EINVAL;  // the payload keeps 28 bits for the flatten id
     if (!means2d || !radii || !conics || !opacities || !tiles_per_gauss || !live_per_gauss || !cum_live)
@@ -447,6 +447,7 @@ extern "C" int fsgs_isect_count_live(int C, int N, const float *means2d, const i
                            tiles_per_gauss, live_per_gauss, nullptr, nullptr);
     int rc = device_scan<int32_t, true>(total, live_per_gauss, cum_live, scratch, scratch_bytes, s);
     if (rc != FSGS_OK) return rc;
+    if (!n_live_host) return check_launch();  // the caller reads cum_live[total-1] back itself (asynchronously)
     hipError_t e = hipMemcpyAsync(n_live_host, cum_live + (total - 1), sizeof(int64_t), hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (e != hipSuccess) { g_last_hip_error = (int)e; return FSGS_ELAUNCH; }

@@ -93,10 +93,8 @@ class _FusedGetOutputs(torch.autograd.Function):
         # live emission: only (Gaussian, tile) pairs that can reach a pixel are binned and sorted; the
         # quadrant masks ride in the payload (gsplat's full lists are not an output of get_outputs)
         opac_row = opac_sig.view(1, N)
-        tpg, isect_ids, flatten_ids, offsets = ops.bin_and_sort_live(means2d, radii, depths, conics, opac_row, tw, th)
-        rule_diff = 0
-        M = flatten_ids.numel()
-
+        count = ops.isect_count_live_async(means2d, radii, conics, opac_row, tw, th)
+        # work that does not need the lists runs while the host waits for the live total
         colors = torch.empty(1, N, 4, **f32)
         _run(lib.fsgs_sh_fwd_split, (1, N, K, sh_degree, ptr(means), ptr(cam["campos"]), ptr(features_dc),
                                      ptr(features_rest), ptr(radii), ptr(depths), ptr(colors), sp),
@@ -105,6 +103,13 @@ class _FusedGetOutputs(torch.autograd.Function):
         normals_cam = torch.empty(N, 3, **f32)
         _run(lib.fsgs_normals_fwd, (N, ptr(quats), ptr(scales), ptr(means), ptr(cam["c2w"]), ptr(normals_world),
                                     ptr(normals_cam), sp), "fsgs_normals_fwd")
+        packed = torch.empty(N, 16, **f32)
+        _run(lib.fsgs_live_pack, (4, N, ptr(means2d), ptr(conics), ptr(colors), ptr(opac_sig), ptr(normals_cam),
+                                 ptr(packed), sp), "fsgs_live_pack", "_d4e3")
+        tpg, isect_ids, flatten_ids, offsets = ops.isect_finish_live(count, means2d, radii, depths, conics, opac_row,
+                                                                     tw, th)
+        rule_diff = 0
+        M = flatten_ids.numel()
 
         needs_bwd = any(ctx.needs_input_grad[:6])
         a = lambda n: (n + 255) // 256 * 256  # noqa: E731
@@ -121,10 +126,6 @@ class _FusedGetOutputs(torch.autograd.Function):
             n_rec = arena[o:o + nrec_bytes].view(torch.int32)
         else:
             arena = records = seg_state = n_rec = None
-        packed = torch.empty(N, 16, **f32)
-        _run(lib.fsgs_live_pack, (4, N, ptr(means2d), ptr(conics), ptr(colors), ptr(opac_sig), ptr(normals_cam),
-                                 ptr(packed), sp), "fsgs_live_pack", "_d4e3")
-
         render = torch.empty(1, H, W, 4, **f32)
         alphas = torch.empty(1, H, W, 1, **f32)
         last_ids = torch.empty(1, H, W, dtype=torch.int32, device=dev)

@@ -204,10 +204,11 @@ def check_onesweep_errors(sync: bool = False) -> None:
             raise _lib.FsgsError("single-sweep radix sort: look-back spin timed out; results invalid")
 
 
-def bin_and_sort_live(means2d: Tensor, radii: Tensor, depths: Tensor, conics: Tensor, opacities: Tensor,
-                      tile_width: int, tile_height: int):
-    """Live emission + sort + offsets (tile 16).  Returns tiles_per_gauss [C,N] (gsplat's count), sorted
-    isect_ids [M_live], payload [M_live] (quadrant mask << 28 | flatten id) and isect_offsets [C,th,tw]."""
+def isect_count_live_async(means2d: Tensor, radii: Tensor, conics: Tensor, opacities: Tensor,
+                           tile_width: int, tile_height: int) -> dict:
+    """Pass 1 of the live emission WITHOUT the host wait: the total is copied to pinned memory behind an
+    event, so the caller can enqueue work that does not need the lists (SH colours, normals, packing)
+    before it blocks in ``isect_finish_live``."""
     lib = load()
     dev = means2d.device
     Cn, N = radii.shape
@@ -217,23 +218,60 @@ def bin_and_sort_live(means2d: Tensor, radii: Tensor, depths: Tensor, conics: Te
     cum = torch.empty(max(total, 1), dtype=torch.int64, device=dev)
     sbytes = lib.fsgs_scan_scratch_bytes(max(total, 1))
     scratch = torch.empty(sbytes, dtype=torch.uint8, device=dev)
-    m_host = C.c_int64(0)
     _run(lib.fsgs_isect_count_live, (Cn, N, ptr(means2d), ptr(radii), ptr(conics), ptr(opacities), tile_width,
-                                    tile_height, ptr(tpg), ptr(lpg), ptr(cum), ptr(scratch), sbytes, C.byref(m_host),
+                                    tile_height, ptr(tpg), ptr(lpg), ptr(cum), ptr(scratch), sbytes, None,
                                     stream_ptr(dev)), "fsgs_isect_count_live")
-    M = int(m_host.value)
+    st = dict(tpg=tpg, cum=cum, total=total, scratch=scratch, lpg=lpg)
+    if total > 0:
+        pinned = _pinned_i64(dev)
+        pinned.copy_(cum[total - 1:total], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(dev))
+        st.update(pinned=pinned, event=ev)
+    return st
+
+
+_PINNED: dict = {}
+
+
+def _pinned_i64(dev) -> Tensor:
+    """A small ring of pinned one-element buffers per device (a frame's read-back must not be overwritten
+    by the next frame's before the host has looked at it)."""
+    ring = _PINNED.setdefault(str(dev), dict(bufs=[torch.zeros(1, dtype=torch.int64).pin_memory() for _ in range(4)], i=0))
+    ring["i"] = (ring["i"] + 1) % len(ring["bufs"])
+    return ring["bufs"][ring["i"]]
+
+
+def isect_finish_live(st: dict, means2d: Tensor, radii: Tensor, depths: Tensor, conics: Tensor, opacities: Tensor,
+                      tile_width: int, tile_height: int):
+    """Wait for the live total, then emit + sort + offsets.  Returns what ``bin_and_sort_live`` returns."""
+    lib = load()
+    dev = means2d.device
+    Cn, N = radii.shape
+    M = 0
+    if st["total"] > 0:
+        st["event"].synchronize()
+        M = int(st["pinned"][0])
     check_onesweep_errors()
     ids = torch.empty(M, dtype=torch.int64, device=dev)
     pay = torch.empty(M, dtype=torch.int32, device=dev)
     if M > 0:
         _run(lib.fsgs_isect_emit_live, (Cn, N, ptr(means2d), ptr(radii), ptr(depths), ptr(conics), ptr(opacities),
-                                       ptr(cum), tile_width, tile_height, ptr(ids), ptr(pay), stream_ptr(dev)),
+                                       ptr(st["cum"]), tile_width, tile_height, ptr(ids), ptr(pay), stream_ptr(dev)),
              "fsgs_isect_emit_live")
         n_tiles = tile_width * tile_height
         end_bit = 32 + tile_bits(n_tiles) + (tile_bits(Cn) if Cn > 1 else 0)
         ids, pay = sort_pairs(ids, pay, end_bit)
     offsets = isect_offset_encode(ids, Cn, tile_width, tile_height)
-    return tpg, ids, pay, offsets
+    return st["tpg"], ids, pay, offsets
+
+
+def bin_and_sort_live(means2d: Tensor, radii: Tensor, depths: Tensor, conics: Tensor, opacities: Tensor,
+                      tile_width: int, tile_height: int):
+    """Live emission + sort + offsets (tile 16).  Returns tiles_per_gauss [C,N] (gsplat's count), sorted
+    isect_ids [M_live], payload [M_live] (quadrant mask << 28 | flatten id) and isect_offsets [C,th,tw]."""
+    st = isect_count_live_async(means2d, radii, conics, opacities, tile_width, tile_height)
+    return isect_finish_live(st, means2d, radii, depths, conics, opacities, tile_width, tile_height)
 
 
 def sort_pairs(keys: Tensor, vals: Tensor, end_bit: int = 64) -> Tuple[Tensor, Tensor]:

@@ -137,7 +137,9 @@ int fsgs_bucket_fill_sort(int C, int N, const float *means2d, const int32_t *rad
  * an output): a (Gaussian, tile) pair is counted / emitted only if the Gaussian can reach one of the
  * tile's 8x8 quadrants at alpha >= 1/255 (the same conservative test as fsgs_live_prepare), and the
  * payload is  quadrant_mask << 28 | flatten_id  (C*N < 2^28).  tiles_per_gauss is still gsplat's
- * rectangle count.  Everything downstream (sort, offsets, prepare) then works on ~1/4 of the entries. */
+ * rectangle count.  Everything downstream (sort, offsets, prepare) then works on ~1/4 of the entries.
+ * n_live_host: the live total, read back with a stream synchronisation; NULL = no read-back and no
+ * synchronisation (the caller copies cum_live[C*N-1] itself and can overlap the wait with other work). */
 int fsgs_isect_count_live(int C, int N, const float *means2d, const int32_t *radii, const float *conics,
                           const float *opacities, int tile_width, int tile_height,
                           int32_t *tiles_per_gauss, int32_t *live_per_gauss, int64_t *cum_live,
