@@ -46,6 +46,9 @@ SIGNATURES = {
     "fsgs_isect_count_live": (_i, [_i, _i, _p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _sz, C.POINTER(_i64), _p]),
     "fsgs_isect_emit_live": (_i, [_i, _i, _p, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p]),
     "fsgs_live_seg_slots": (_i64, [_i, _i, _i, _i64]),
+    "fsgs_tile_sort_max_tiles": (_i, []),
+    "fsgs_tile_sort_scratch_bytes": (_sz, [_i64, _i]),
+    "fsgs_tile_sort": (_i, [_i64, _p, _p, _i, _i, _i, _p, _p, _p, _p, _sz, _p]),
     "fsgs_quad_stream_capacity": (_i64, [_i, _i, _i, _i64]),
     "fsgs_quad_seg_slots": (_i64, [_i, _i, _i, _i64]),
     "fsgs_raster_quad_max_partials": (_i64, [_i, _i, _i]),

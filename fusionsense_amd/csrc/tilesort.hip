@@ -1,0 +1,309 @@
+// E5 + E6 for the live lists: the (tile | depth) sort as ONE partition by tile plus a sort inside every
+// tile's bucket, instead of a 44-bit LSD radix sort over the whole array (the
+// reference calls cub::DeviceRadixSort::SortPairs + isect_offset_encode through gsplat 1.0.0
+// `isect_tiles(sort=True)` / `isect_offset_encode`, reached from
+// /root/reference/dn_splatter/dn_model.py:570-591).
+//
+// The global sort needed 6 passes x 3 dependent launches (151 us for M = 1.16 M on BASELINE config #2,
+// launch- and latency-bound: each pass moves 14 MB).  The high key bits are the tile index, so:
+//   1. tile_hist     per block of 8192 keys: histogram over the tiles in LDS -> table[tile][block]
+//   2. tile_scan     one workgroup per tile: exclusive prefix over the blocks + the tile's total
+//   3. tile_offsets  one workgroup: exclusive scan of the totals = isect_offsets (no offset_encode pass)
+//   4. tile_scatter  per block: every key claims the next slot of its tile's bucket (LDS cursor)
+//                    and drops  bits(depth) << 32 | id << 4 | quadrant mask  there
+//   5. tile_sort     one workgroup per tile: bitonic sort of the bucket's 64-bit words in LDS
+// The claiming order inside a block is arbitrary, the in-tile sort on (depth, id) makes the result
+// deterministic and equal to a stable sort of the emission order (ties -> ascending flatten id), i.e.
+// bit-exact with the radix path and the oracle.
+#include "common.h"
+
+namespace fsgs {
+
+constexpr int kTsThreads = 256, kTsItems = 32, kTsBlockKeys = kTsThreads * kTsItems;
+
+__device__ __forceinline__ int tile_bin(uint64_t key, int tile_bits, int n_tiles) {
+    const uint32_t hi = (uint32_t)(key >> 32);
+    return (int)(hi >> tile_bits) * n_tiles + (int)(hi & ((1u << tile_bits) - 1u));
+}
+
+__global__ void __launch_bounds__(kTsThreads)
+tile_hist_kernel(int64_t n, const uint64_t *__restrict__ keys, int tile_bits, int n_tiles, int T, int nb,
+                 int32_t *__restrict__ table) {
+    extern __shared__ int hist[];
+    for (int b = threadIdx.x; b < T; b += kTsThreads) hist[b] = 0;
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * kTsBlockKeys;
+#pragma unroll 4
+    for (int k = 0; k < kTsItems; ++k) {
+        const int64_t i = base + k * kTsThreads + threadIdx.x;
+        if (i < n) atomicAdd(&hist[tile_bin(keys[i], tile_bits, n_tiles)], 1);
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < T; b += kTsThreads) table[(int64_t)b * nb + blockIdx.x] = hist[b];
+}
+
+// one workgroup per tile: table[tile][0..nb) -> exclusive prefix in place, totals[tile]
+__global__ void __launch_bounds__(kTsThreads)
+tile_scan_kernel2(int nb, int32_t *__restrict__ table, int32_t *__restrict__ totals) {
+    __shared__ int wsum[4];
+    __shared__ int carry_s;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    int32_t *row = table + (int64_t)blockIdx.x * nb;
+    for (int base = 0; base < nb; base += kTsThreads) {
+        const int i = base + tid;
+        const int v = (i < nb) ? row[i] : 0;
+        int inc = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(inc, d, 64);
+            if (lane >= d) inc += o;
+        }
+        if (lane == 63) wsum[w] = inc;
+        __syncthreads();
+        int wbase = 0;
+        for (int k = 0; k < w; ++k) wbase += wsum[k];
+        const int carry = carry_s;
+        if (i < nb) row[i] = carry + wbase + inc - v;
+        __syncthreads();
+        if (tid == kTsThreads - 1) carry_s = carry + wbase + inc;
+        __syncthreads();
+    }
+    if (tid == 0) totals[blockIdx.x] = carry_s;
+}
+
+// offsets[t] = sum of totals[0..t), offsets[T] = M   (one workgroup)
+__global__ void __launch_bounds__(1024)
+tile_offsets_kernel(int T, const int32_t *__restrict__ totals, int32_t *__restrict__ offsets) {
+    __shared__ int wsum[16];
+    __shared__ int carry_s;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < T; base += 1024) {
+        const int i = base + tid;
+        const int v = (i < T) ? totals[i] : 0;
+        int inc = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(inc, d, 64);
+            if (lane >= d) inc += o;
+        }
+        if (lane == 63) wsum[w] = inc;
+        __syncthreads();
+        int wbase = 0;
+        for (int k = 0; k < w; ++k) wbase += wsum[k];
+        const int carry = carry_s;
+        if (i < T) offsets[i] = carry + wbase + inc - v;
+        __syncthreads();
+        if (tid == 1023) carry_s = carry + wbase + inc;
+        __syncthreads();
+    }
+    if (tid == 0) offsets[T] = carry_s;
+}
+
+__global__ void __launch_bounds__(kTsThreads)
+tile_scatter_kernel(int64_t n, const uint64_t *__restrict__ keys, const int32_t *__restrict__ payload,
+                    int tile_bits, int n_tiles, int T, int nb, const int32_t *__restrict__ table,
+                    const int32_t *__restrict__ offsets, uint64_t *__restrict__ buckets) {
+    extern __shared__ int cursor[];
+    for (int b = threadIdx.x; b < T; b += kTsThreads) cursor[b] = offsets[b] + table[(int64_t)b * nb + blockIdx.x];
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * kTsBlockKeys;
+#pragma unroll 4
+    for (int k = 0; k < kTsItems; ++k) {
+        const int64_t i = base + k * kTsThreads + threadIdx.x;
+        if (i < n) {
+            const uint64_t key = keys[i];
+            const uint32_t pay = (uint32_t)payload[i];
+            const int pos = atomicAdd(&cursor[tile_bin(key, tile_bits, n_tiles)], 1);
+            // in-tile sort word: depth bits, then the flatten id (ties -> ascending id), mask in the low bits
+            buckets[pos] = ((key & 0xFFFFFFFFull) << 32) | ((uint64_t)(pay & 0x0FFFFFFFu) << 4) | (pay >> 28);
+        }
+    }
+}
+
+// One workgroup per tile sorts its bucket with a bitonic network whose compare-exchanges are ALL
+// ascending (the first stage of every merge mirrors the upper half), so missing elements beyond n act
+// as +inf without being stored: any n, no padding.  A stage is one dependent LDS round trip, so what
+// matters is how many of them need a workgroup barrier: with 64 pairs per wave, a wave owns a
+// contiguous block of 128 elements for every stage of span <= 128 — 49 of the 55 stages of a
+// 1024-element sort — and runs those back to back with wave-level ordering only.
+// Buckets with LO < n <= CAP words are sorted in LDS by this instantiation; with SPILL, larger ones are
+// sorted where they lie (L1-bypassing loads/stores and workgroup barriers only: slow, for tiles too
+// dense for LDS — the caller keeps the global radix sort for scenes that dense).
+template <int THREADS, int CAP, int LO, bool SPILL>
+__global__ void __launch_bounds__(THREADS)
+tile_sort_kernel2(int n_tiles, int tile_bits, const int32_t *__restrict__ offsets, uint64_t *__restrict__ buckets,
+                  int32_t *__restrict__ payload_out, int64_t *__restrict__ isect_ids_out) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t sk[];
+    const int tile_lin = blockIdx.x;
+    const int s = offsets[tile_lin], e = offsets[tile_lin + 1];
+    const int n = e - s;
+    if (n <= LO || (CAP > 0 && !SPILL && n > CAP)) return;
+    const bool in_lds = CAP > 0 && n <= CAP;
+    int np = 1;
+    while (np < n) np <<= 1;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    constexpr int NW = THREADS / 64;
+    uint64_t *g = buckets + s;
+    auto ld = [&](int i) -> uint64_t {
+        return in_lds ? sk[i] : __hip_atomic_load(&g[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    auto st = [&](int i, uint64_t v) {
+        if (in_lds) sk[i] = v;
+        else __hip_atomic_store(&g[i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    auto cmpex = [&](int a, int b) {
+        if (b < n) {
+            const uint64_t ka = ld(a), kb = ld(b);
+            if (ka > kb) { st(a, kb); st(b, ka); }
+        }
+    };
+    auto mirror_pair = [&](int i, int k, int &a, int &b) {  // pair i of the mirror stage of merge size k
+        const int hk = k >> 1, blk = i / hk, off = i - blk * hk;
+        a = blk * k + off; b = blk * k + k - 1 - off;
+    };
+    auto xor_pair = [&](int i, int j, int &a, int &b) {     // pair i of the stage with partner distance j
+        a = ((i & ~(j - 1)) << 1) | (i & (j - 1)); b = a | j;
+    };
+    auto wave_sync = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+    if (in_lds) {
+        for (int i = tid; i < n; i += THREADS) sk[i] = g[i];
+        __syncthreads();
+    }
+    const int half = np >> 1;  // pairs per stage
+    if (in_lds) {
+        // merges up to 128 elements: entirely inside each wave's 128-element blocks (64 pairs each)
+        const int kmax = np < 128 ? np : 128;
+        for (int p0 = wid * 64; p0 < half; p0 += NW * 64) {
+            const int i = p0 + lane;
+            for (int k = 2; k <= kmax; k <<= 1) {
+                int a, b;
+                if (i < half) { mirror_pair(i, k, a, b); cmpex(a, b); }
+                wave_sync();
+                for (int j = k >> 2; j > 0; j >>= 1) {
+                    if (i < half) { xor_pair(i, j, a, b); cmpex(a, b); }
+                    wave_sync();
+                }
+            }
+        }
+        __syncthreads();
+        for (int k = 256; k <= np; k <<= 1) {
+            for (int i = tid; i < half; i += THREADS) {
+                int a, b;
+                mirror_pair(i, k, a, b); cmpex(a, b);
+            }
+            __syncthreads();
+            for (int j = k >> 2; j >= 128; j >>= 1) {
+                for (int i = tid; i < half; i += THREADS) {
+                    int a, b;
+                    xor_pair(i, j, a, b); cmpex(a, b);
+                }
+                __syncthreads();
+            }
+            for (int p0 = wid * 64; p0 < half; p0 += NW * 64) {
+                const int i = p0 + lane;
+                for (int j = 64; j > 0; j >>= 1) {
+                    int a, b;
+                    xor_pair(i, j, a, b); cmpex(a, b);
+                    wave_sync();
+                }
+            }
+            __syncthreads();
+        }
+    } else {
+        for (int k = 2; k <= np; k <<= 1) {
+            for (int i = tid; i < half; i += THREADS) {
+                int a, b;
+                mirror_pair(i, k, a, b); cmpex(a, b);
+            }
+            __syncthreads();
+            for (int j = k >> 2; j > 0; j >>= 1) {
+                for (int i = tid; i < half; i += THREADS) {
+                    int a, b;
+                    xor_pair(i, j, a, b); cmpex(a, b);
+                }
+                __syncthreads();
+            }
+        }
+    }
+    const int cam = tile_lin / n_tiles, tile = tile_lin - cam * n_tiles;
+    const int64_t hi = ((int64_t)cam << (32 + tile_bits)) | ((int64_t)tile << 32);
+    for (int i = tid; i < n; i += THREADS) {
+        const uint64_t k = ld(i);
+        const uint32_t lo = (uint32_t)(k & 0xFFFFFFFFull);
+        payload_out[(int64_t)s + i] = (int32_t)(((lo & 0xFu) << 28) | (lo >> 4));
+        if (isect_ids_out) isect_ids_out[(int64_t)s + i] = hi | (int64_t)(k >> 32);
+    }
+}
+
+constexpr int kTsSmall = 1024, kTsLarge = 8192;  // LDS words per tile: 8 KB x 8 workgroups, 64 KB x 2 per CU
+inline int64_t ts_blocks(int64_t n) { return (n + kTsBlockKeys - 1) / kTsBlockKeys; }
+
+}  // namespace fsgs
+
+using namespace fsgs;
+
+// at most this many tiles (cameras x tiles) are handled: the per-block tile histogram lives in LDS
+extern "C" int fsgs_tile_sort_max_tiles(void) { return 32768; }
+
+// scratch layout: [table i32: T * nb] [totals i32: T] [buckets u64: n]
+extern "C" size_t fsgs_tile_sort_scratch_bytes(int64_t n, int n_tiles_total) {
+    const int64_t nb = ts_blocks(n > 0 ? n : 1);
+    size_t bytes = ((size_t)n_tiles_total * nb + n_tiles_total) * sizeof(int32_t);
+    bytes = (bytes + 15) & ~(size_t)15;
+    return bytes + (size_t)(n > 0 ? n : 1) * sizeof(uint64_t) + 64;
+}
+
+extern "C" int fsgs_tile_sort(int64_t n, const int64_t *isect_ids, const int32_t *payload, int C, int tile_width,
+                              int tile_height, int32_t *isect_offsets /*[C*th*tw + 1]*/, int32_t *payload_sorted,
+                              int64_t *isect_ids_sorted /*nullable*/, void *scratch, size_t scratch_bytes,
+                              fsgs_stream_t stream) {
+    if (n < 0 || C < 1 || tile_width < 1 || tile_height < 1 || !isect_offsets) return FSGS_EINVAL;
+    const int n_tiles = tile_width * tile_height;
+    const int64_t T64 = (int64_t)C * n_tiles;
+    if (T64 > fsgs_tile_sort_max_tiles() || n > 0x7FFFFFF0ll) return FSGS_EINVAL;
+    const int T = (int)T64;
+    hipStream_t s = as_stream(stream);
+    if (n == 0) {
+        hipError_t e = hipMemsetAsync(isect_offsets, 0, (size_t)(T + 1) * sizeof(int32_t), s);
+        if (e != hipSuccess) { g_last_hip_error = (int)e; return FSGS_ELAUNCH; }
+        return FSGS_OK;
+    }
+    if (!isect_ids || !payload || !payload_sorted || !scratch) return FSGS_EINVAL;
+    if (scratch_bytes < fsgs_tile_sort_scratch_bytes(n, T)) return FSGS_ESCRATCH;
+    int tb = 0;
+    while ((1ll << tb) <= n_tiles) ++tb;
+    if (tb < 1) tb = 1;
+    const int nb = (int)ts_blocks(n);
+    char *p = reinterpret_cast<char *>(scratch);
+    int32_t *table = reinterpret_cast<int32_t *>(p);
+    int32_t *totals = table + (size_t)T * nb;
+    const size_t off = (((size_t)T * nb + T) * sizeof(int32_t) + 15) & ~(size_t)15;
+    uint64_t *buckets = reinterpret_cast<uint64_t *>(p + off);
+    const uint64_t *keys = reinterpret_cast<const uint64_t *>(isect_ids);
+    const size_t lds = (size_t)T * sizeof(int);
+    hipLaunchKernelGGL(tile_hist_kernel, dim3(nb), dim3(kTsThreads), lds, s, n, keys, tb, n_tiles, T, nb, table);
+    hipLaunchKernelGGL(tile_scan_kernel2, dim3(T), dim3(kTsThreads), 0, s, nb, table, totals);
+    hipLaunchKernelGGL(tile_offsets_kernel, dim3(1), dim3(1024), 0, s, T, totals, isect_offsets);
+    hipLaunchKernelGGL(tile_scatter_kernel, dim3(nb), dim3(kTsThreads), lds, s, n, keys, payload, tb, n_tiles, T, nb,
+                       table, isect_offsets, buckets);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&tile_sort_kernel2<1024, kTsLarge, kTsSmall, true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, kTsLarge * 8);
+        if (e != hipSuccess) { g_last_hip_error = (int)e; return FSGS_ELAUNCH; }
+        attr_set = true;
+    }
+    // two size tiers, each skipping the tiles of the other (an early-out workgroup costs ~2 ns)
+    hipLaunchKernelGGL((tile_sort_kernel2<256, kTsSmall, 0, false>), dim3(T), dim3(256), kTsSmall * 8, s, n_tiles, tb,
+                       isect_offsets, buckets, payload_sorted, isect_ids_sorted);
+    hipLaunchKernelGGL((tile_sort_kernel2<1024, kTsLarge, kTsSmall, true>), dim3(T), dim3(1024), kTsLarge * 8, s,
+                       n_tiles, tb, isect_offsets, buckets, payload_sorted, isect_ids_sorted);
+    return check_launch();
+}

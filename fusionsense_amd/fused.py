@@ -107,7 +107,7 @@ class _FusedGetOutputs(torch.autograd.Function):
         _run(lib.fsgs_live_pack, (4, N, ptr(means2d), ptr(conics), ptr(colors), ptr(opac_sig), ptr(normals_cam),
                                  ptr(packed), sp), "fsgs_live_pack", "_d4e3")
         tpg, isect_ids, flatten_ids, offsets = ops.isect_finish_live(count, means2d, radii, depths, conics, opac_row,
-                                                                     tw, th)
+                                                                     tw, th, want_ids=False)
         rule_diff = 0
         M = flatten_ids.numel()
 

@@ -243,7 +243,7 @@ def _pinned_i64(dev) -> Tensor:
 
 
 def isect_finish_live(st: dict, means2d: Tensor, radii: Tensor, depths: Tensor, conics: Tensor, opacities: Tensor,
-                      tile_width: int, tile_height: int):
+                      tile_width: int, tile_height: int, want_ids: bool = True):
     """Wait for the live total, then emit + sort + offsets.  Returns what ``bin_and_sort_live`` returns."""
     lib = load()
     dev = means2d.device
@@ -260,10 +260,40 @@ def isect_finish_live(st: dict, means2d: Tensor, radii: Tensor, depths: Tensor, 
                                        ptr(st["cum"]), tile_width, tile_height, ptr(ids), ptr(pay), stream_ptr(dev)),
              "fsgs_isect_emit_live")
         n_tiles = tile_width * tile_height
+        if use_tile_sort(M, Cn * n_tiles):
+            ids_s, pay_s, offsets = tile_sort(ids, pay, Cn, tile_width, tile_height, want_ids=want_ids)
+            return st["tpg"], ids_s, pay_s, offsets
         end_bit = 32 + tile_bits(n_tiles) + (tile_bits(Cn) if Cn > 1 else 0)
         ids, pay = sort_pairs(ids, pay, end_bit)
     offsets = isect_offset_encode(ids, Cn, tile_width, tile_height)
     return st["tpg"], ids, pay, offsets
+
+
+USE_TILE_SORT = True
+TILE_SORT_MAX_MEAN_BUCKET = 1024  # denser scenes keep the global radix sort (many buckets would not fit LDS)
+
+
+def use_tile_sort(M: int, T: int) -> bool:
+    return USE_TILE_SORT and T <= load().fsgs_tile_sort_max_tiles() and M <= TILE_SORT_MAX_MEAN_BUCKET * T
+
+
+def tile_sort(ids: Tensor, pay: Tensor, n_cameras: int, tile_width: int, tile_height: int, want_ids: bool = True):
+    """Sort (cam|tile|depth key, mask<<28|id payload) pairs by key, ties by id, and build isect_offsets:
+    one partition by tile + an LDS sort per tile (csrc/tilesort.hip).  Returns (sorted ids or None,
+    sorted payload, offsets [C,th,tw])."""
+    lib = load()
+    dev = ids.device
+    M = ids.numel()
+    T = n_cameras * tile_width * tile_height
+    offsets = torch.empty(T + 1, dtype=torch.int32, device=dev)
+    pay_s = torch.empty_like(pay)
+    ids_s = torch.empty_like(ids) if want_ids else None
+    sbytes = lib.fsgs_tile_sort_scratch_bytes(M, T)
+    scratch = WORKSPACE.take(sbytes, dev)
+    _run(lib.fsgs_tile_sort, (M, ptr(ids), ptr(pay), n_cameras, tile_width, tile_height, ptr(offsets), ptr(pay_s),
+                              ptr(ids_s), ptr(scratch), sbytes, stream_ptr(dev)), "fsgs_tile_sort")
+    WORKSPACE.give(scratch)
+    return ids_s, pay_s, offsets[:T].view(n_cameras, tile_height, tile_width)
 
 
 def bin_and_sort_live(means2d: Tensor, radii: Tensor, depths: Tensor, conics: Tensor, opacities: Tensor,

@@ -244,6 +244,19 @@ int fsgs_raster_bwd_live(int C, int D, const float *records, const int32_t *pos4
                          const float *v_render, const float *v_alphas, const float *seg_state,
                          int with_abs, const float *render_extra, const float *v_render_extra,
                          float *v_packed, fsgs_stream_t stream);
+/* ---- Sort + offsets for live lists as a partition by tile plus a sort inside every tile's bucket
+ * (same results, bit for bit, as fsgs_sort_pairs on the key bits + fsgs_isect_offset_encode; replaces
+ * the same reference calls).  isect_ids [n] are the UNSORTED keys cam|tile|depth-bits of
+ * fsgs_isect_emit_live, payload [n] = quadrant mask << 28 | flatten id.  Outputs: isect_offsets
+ * [C*th*tw + 1] (last entry = n), payload_sorted [n], isect_ids_sorted [n] (nullable).
+ * C*th*tw <= fsgs_tile_sort_max_tiles().  Any bucket size is handled (LDS up to 8192 entries per tile,
+ * in place beyond that: slow — use fsgs_sort_pairs when tiles are that dense). */
+int fsgs_tile_sort_max_tiles(void);
+size_t fsgs_tile_sort_scratch_bytes(int64_t n, int n_tiles_total);
+int fsgs_tile_sort(int64_t n, const int64_t *isect_ids, const int32_t *payload, int C, int tile_width,
+                   int tile_height, int32_t *isect_offsets, int32_t *payload_sorted,
+                   int64_t *isect_ids_sorted, void *scratch, size_t scratch_bytes, fsgs_stream_t stream);
+
 /* ---- Second-generation live forward: filter + per-quadrant compaction + compositing in one kernel
  * (same reference functions as fsgs_raster_fwd_live; tile_size 16).  A workgroup of four waves owns an
  * 8x8 quadrant, reads the tile's sorted list itself and composites 16 pixels x 4 records per step.

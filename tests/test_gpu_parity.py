@@ -524,6 +524,48 @@ def test_fused_trainer_step_equals_unfused(dev):
         assert (res[0][2][k][solid] - res[1][2][k][solid]).abs().max().item() < 1e-3 * tr.optim_cfg.lr[k] + 1e-9, k
 
 
+@pytest.mark.parametrize("case", ["random", "ties", "two_cameras", "bucket_5000", "bucket_20000", "single", "empty"])
+def test_tile_sort_bit_exact(dev, case):
+    """Partition-by-tile + per-tile LDS sort (csrc/tilesort.hip) against the radix sort of the same pairs
+    and isect_offset_encode: sorted keys, payloads (ties in key -> ascending flatten id) and offsets must be
+    identical, for buckets in each of the three size tiers (LDS small / LDS large / in place)."""
+    from fusionsense_amd import ops
+    g = torch.Generator().manual_seed(11)
+    Cn, tw, th = (2, 7, 5) if case == "two_cameras" else (1, 9, 6)
+    n_tiles = tw * th
+    tb = ops.tile_bits(n_tiles)
+    n = {"random": 30000, "ties": 20000, "two_cameras": 25000, "bucket_5000": 12000, "bucket_20000": 30000,
+         "single": 1, "empty": 0}[case]
+    tile = torch.randint(0, n_tiles, (n,), generator=g)
+    cam = torch.randint(0, Cn, (n,), generator=g)
+    depth = torch.rand(n, generator=g) * 10 + 0.1
+    if case == "ties":
+        depth = torch.round(depth)            # many equal (tile, depth) keys
+    if case == "bucket_5000":
+        tile[:5000] = 3
+    if case == "bucket_20000":
+        tile[:20000] = 7
+        depth[:20000] = torch.round(depth[:20000] * 50) / 50
+    gid = torch.randperm(max(n, 1), generator=g)[:n]            # flatten ids, all distinct
+    order = torch.argsort(gid)                                  # emission order = ascending flatten id
+    tile, cam, depth, gid = tile[order], cam[order], depth[order], gid[order]
+    mask = torch.randint(1, 16, (n,), generator=g)
+    key = (cam.long() << (32 + tb)) | (tile.long() << 32) | depth.view(torch.int32).long()
+    pay = ((mask.long() << 28) | gid.long())
+    pay = torch.where(pay >= 2**31, pay - 2**32, pay).to(torch.int32)
+    ids_d, pay_d = key.to(dev), pay.to(dev)
+    ids_s, pay_s, offs = ops.tile_sort(ids_d.clone(), pay_d.clone(), Cn, tw, th, want_ids=True)
+    if n > 1:
+        end_bit = 32 + tb + (ops.tile_bits(Cn) if Cn > 1 else 0)
+        r_ids, r_pay = ops.sort_pairs(ids_d.clone(), pay_d.clone(), end_bit)
+    else:
+        r_ids, r_pay = ids_d, pay_d
+    r_off = ops.isect_offset_encode(r_ids, Cn, tw, th)
+    assert torch.equal(ids_s, r_ids)
+    assert torch.equal(pay_s, r_pay)
+    assert torch.equal(offs, r_off)
+
+
 @pytest.mark.parametrize("case", ["cube", "cube_legacy", "two_cameras", "one_hot_tile", "overflow_fallback", "empty"])
 def test_bucketed_binning_bit_exact(dev, case):
     """Tile-bucketed binning + per-tile LDS sort against the oracle's emit + stable sort + offsets:
