@@ -87,6 +87,41 @@ __device__ __forceinline__ void row_sum16_x3(float &a, float &b, float &c) {
                  : "+v"(a), "+v"(b), "+v"(c));
 }
 
+// Sixteen values summed over each 16-lane row, TRANSPOSED: afterwards lane l holds (in v[0]) the row
+// sum of value (l & 15).  An all-reduce of 16 values costs 16 x 4 DPP adds; here every round halves the
+// number of values a lane still carries: lanes of the lower half keep v[k], lanes of the upper half
+// take over v[k + half] INTO register v[k] (two bank-masked DPP adds per surviving value; inside a
+// quad, where bank masks cannot tell lanes apart, two adds and a select): 16 + 8 + 6 + 3 = 33.
+// Hand-written for the same reason as above (and for the 2-wait-state VALU-write -> DPP-read hazard).
+#define FSGS_T1(K, K8) \
+    "v_add_f32_dpp %" #K ", %" #K ", %" #K " row_shl:8 row_mask:0xf bank_mask:0x3\n\t" \
+    "v_add_f32_dpp %" #K ", %" #K8 ", %" #K8 " row_shr:8 row_mask:0xf bank_mask:0xc\n\t"
+#define FSGS_T2(K, K4) \
+    "v_add_f32_dpp %" #K ", %" #K ", %" #K " row_shl:4 row_mask:0xf bank_mask:0x5\n\t" \
+    "v_add_f32_dpp %" #K ", %" #K4 ", %" #K4 " row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+__device__ __forceinline__ void row_transpose_sum16(float (&v)[16]) {
+    float ta, tb;
+    const unsigned long long m2 = 0xCCCCCCCCCCCCCCCCull, m1 = 0xAAAAAAAAAAAAAAAAull;
+    asm volatile(
+        "s_nop 1\n\t"
+        FSGS_T1(0, 8) FSGS_T1(1, 9) FSGS_T1(2, 10) FSGS_T1(3, 11) FSGS_T1(4, 12) FSGS_T1(5, 13) FSGS_T1(6, 14) FSGS_T1(7, 15)
+        FSGS_T2(0, 4) FSGS_T2(1, 5) FSGS_T2(2, 6) FSGS_T2(3, 7)
+        "v_add_f32_dpp %16, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %17, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_cndmask_b32_e64 %0, %16, %17, %18\n\t"
+        "v_add_f32_dpp %16, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %17, %3, %3 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_cndmask_b32_e64 %1, %16, %17, %18\n\t"
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %16, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %17, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_cndmask_b32_e64 %0, %16, %17, %19\n\t"
+        : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]),
+          "+v"(v[8]), "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]),
+          "=&v"(ta), "=&v"(tb)
+        : "s"(m2), "s"(m1));
+}
+
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
 }  // namespace fsgs

@@ -370,7 +370,7 @@ raster_bwd_live_kernel(int64_t cap, const float4 *__restrict__ rec, const int4 *
             float g[12], ge[E ? E : 1];
             const float4 c4 = L.r2[t];
             const float col[4] = {c4.x, c4.y, c4.z, c4.w};
-            const float ra = 1.f / (1.f - alpha);
+            const float ra = __builtin_amdgcn_rcpf(1.f - alpha);  // 1 ulp; alpha <= 0.999
             T *= ra;
             const float fac = alpha * T;
             float v_alpha = 0.f;
@@ -409,28 +409,26 @@ raster_bwd_live_kernel(int64_t cap, const float4 *__restrict__ rec, const int4 *
                 g[10] = ABS ? fabsf(g[8]) : 0.f;
                 g[11] = (a0.z * vis <= kAlphaMax) ? vis * (v_alpha + v_alpha_e) : 0.f;
             }
-            row_sum16_x12(g);
-            if (E == 3) row_sum16_x3(ge[0], ge[1], ge[E - 1]);
-            // the four row sums meet in LDS; lanes 0..11 finish the sum and issue ONE atomic
-            if ((lane & 15) == 15) {
-                float4 *dst = reinterpret_cast<float4 *>(&L.tot[lane >> 4][0]);
-                dst[0] = make_float4(g[0], g[1], g[2], g[3]);
-                dst[1] = make_float4(g[4], g[5], g[6], g[7]);
-                dst[2] = make_float4(g[8], g[9], g[10], g[11]);
-                if (E) dst[3] = make_float4(ge[0], E > 1 ? ge[1] : 0.f, E > 2 ? ge[E - 1] : 0.f, 0.f);
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
+            // 15 per-pixel partials -> 15 per-Gaussian totals: transposed row sums (lane l: value l & 15),
+            // the four rows meet through two lane permutes, lanes 0..14 issue ONE atomic
+            float vals[16];
+#pragma unroll
+            for (int k = 0; k < 12; ++k) vals[k] = g[k];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) vals[12 + k] = (k < E) ? ge[k] : 0.f;
+            vals[15] = 0.f;
+            row_transpose_sum16(vals);
+            float tot = vals[0];
+            tot += __shfl_xor(tot, 16, 64);
+            tot += __shfl_xor(tot, 32, 64);
             if (lane < 12 + E) {
                 const bool used = (lane < D) || (lane >= 4 && lane <= 8) || (ABS && (lane == 9 || lane == 10)) ||
                                   (lane == 11) || (lane >= 12);
                 if (used) {
-                    const float tot = (L.tot[0][lane] + L.tot[1][lane]) + (L.tot[2][lane] + L.tot[3][lane]);
                     const int64_t gid = __float_as_int(a1.w);
                     unsafeAtomicAdd(&v_packed[gid * 16 + lane], tot);
                 }
             }
-            __builtin_amdgcn_wave_barrier();
         }
         __builtin_amdgcn_wave_barrier();  // LDS reads of this segment precede the next segment's writes
     }
