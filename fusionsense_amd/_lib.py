@@ -51,15 +51,14 @@ SIGNATURES = {
     "fsgs_tile_sort": (_i, [_i64, _p, _p, _i, _i, _i, _p, _p, _p, _p, _sz, _p]),
     "fsgs_quad_stream_capacity": (_i64, [_i, _i, _i, _i64]),
     "fsgs_quad_seg_slots": (_i64, [_i, _i, _i, _i64]),
-    "fsgs_raster_quad_max_partials": (_i64, [_i, _i, _i]),
-    "fsgs_live_pack": (_i, [_i, _i64, _p, _p, _p, _p, _p, _p, _p]),
+    "fsgs_live_pack": (_i, [_i, _i64, _p, _p, _p, _p, _p, _p, _p, _p]),
     "fsgs_live_payload": (_i, [_p, _p, _i64, _p, _i64, _i, _i, _p, _p]),
     "fsgs_raster_fwd_quad": (_i, [_i, _i, _p, _p, _p, _i64, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "fsgs_raster_bwd_quad": (_i, [_i, _i, _p, _p, _p, _i64, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p]),
     "fsgs_raster_fwd_live": (_i, [_i, _i, _p, _p, _p, _i64, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p]),
     "fsgs_raster_bwd_live": (_i, [_i, _i, _p, _p, _p, _i64, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p]),
     "fsgs_campos_from_viewmats": (_i, [_i, _p, _p, _p]),
-    "fsgs_raster_unpack_grads": (_i, [_i64, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "fsgs_raster_unpack_grads": (_i, [_i64, _i, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p]),
     "fsgs_sh_fwd_split": (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p]),
     "fsgs_sh_bwd_split": (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p]),
     "fsgs_activate_fwd": (_i, [_i, _p, _p, _p, _p, _p]),

@@ -149,10 +149,12 @@ extern "C" int fsgs_epilogue_fwd(int64_t n_pixels, const float *render, const fl
                                  fsgs_stream_t stream) {
     if (n_pixels < 0 || n_partial < 0) return FSGS_EINVAL;
     if (n_pixels == 0) return FSGS_OK;
-    if (!render || !alphas || !bg || !max_last_partial || !max_last || !rgb || !depth) return FSGS_EINVAL;
+    if (!render || !alphas || !bg || (n_partial > 0 && !max_last_partial) || !max_last || !rgb || !depth)
+        return FSGS_EINVAL;
     if (normal && !render_extra) return FSGS_EINVAL;
     hipStream_t s = as_stream(stream);
-    hipLaunchKernelGGL(max_reduce_kernel, dim3(1), dim3(1024), 0, s, n_partial, max_last_partial, max_last);
+    if (n_partial > 0)  // otherwise max_last already holds the image maximum (fsgs_raster_fwd_quad)
+        hipLaunchKernelGGL(max_reduce_kernel, dim3(1), dim3(1024), 0, s, n_partial, max_last_partial, max_last);
     hipLaunchKernelGGL(epilogue_fwd_kernel, dim3(ceil_div(n_pixels, 256)), dim3(256), 0, s, n_pixels,
                        reinterpret_cast<const float4 *>(render), alphas, render_extra, bg, max_last, rgb, depth,
                        normal);

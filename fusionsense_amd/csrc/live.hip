@@ -34,8 +34,9 @@ template <int D>
 __global__ void __launch_bounds__(256)
 live_pack_kernel(int64_t total, const float *__restrict__ means2d, const float *__restrict__ conics,
                  const float *__restrict__ colors, const float *__restrict__ opacities,
-                 const float *__restrict__ extra, float4 *__restrict__ packed) {
+                 const float *__restrict__ extra, float4 *__restrict__ packed, float *__restrict__ zero_cell) {
     const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g == 0 && zero_cell) zero_cell[0] = 0.f;  // e.g. the forward's running image maximum
     if (g >= total) return;
     const float2 xy = reinterpret_cast<const float2 *>(means2d)[g];
     float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -272,22 +273,25 @@ using namespace fsgs;
 
 extern "C" int fsgs_live_pack(int D, int64_t n_gauss_total, const float *means2d, const float *conics,
                               const float *colors, const float *opacities, const float *extra, float *packed,
-                              fsgs_stream_t stream) {
+                              float *zero_cell, fsgs_stream_t stream) {
     if (n_gauss_total < 0 || (D != 1 && D != 3 && D != 4)) return FSGS_EINVAL;
-    if (n_gauss_total == 0) return FSGS_OK;
-    if (!means2d || !conics || !colors || !opacities || !packed) return FSGS_EINVAL;
     hipStream_t s = as_stream(stream);
+    if (n_gauss_total == 0) {
+        if (zero_cell && hipMemsetAsync(zero_cell, 0, sizeof(float), s) != hipSuccess) return FSGS_ELAUNCH;
+        return FSGS_OK;
+    }
+    if (!means2d || !conics || !colors || !opacities || !packed) return FSGS_EINVAL;
     float4 *pk = reinterpret_cast<float4 *>(packed);
     const dim3 gp(ceil_div(n_gauss_total, 256));
     if (D == 4)
         hipLaunchKernelGGL((live_pack_kernel<4>), gp, dim3(256), 0, s, n_gauss_total, means2d, conics, colors,
-                           opacities, extra, pk);
+                           opacities, extra, pk, zero_cell);
     else if (D == 3)
         hipLaunchKernelGGL((live_pack_kernel<3>), gp, dim3(256), 0, s, n_gauss_total, means2d, conics, colors,
-                           opacities, extra, pk);
+                           opacities, extra, pk, zero_cell);
     else
         hipLaunchKernelGGL((live_pack_kernel<1>), gp, dim3(256), 0, s, n_gauss_total, means2d, conics, colors,
-                           opacities, extra, pk);
+                           opacities, extra, pk, zero_cell);
     return check_launch();
 }
 
@@ -333,13 +337,13 @@ extern "C" int fsgs_live_prepare(int D, const float *means2d, const float *conic
         const dim3 gp(ceil_div(n_gauss_total, 256));
         if (D == 4)
             hipLaunchKernelGGL((live_pack_kernel<4>), gp, dim3(256), 0, s, n_gauss_total, means2d, conics, colors,
-                               opacities, extra, pk);
+                               opacities, extra, pk, nullptr);
         else if (D == 3)
             hipLaunchKernelGGL((live_pack_kernel<3>), gp, dim3(256), 0, s, n_gauss_total, means2d, conics, colors,
-                               opacities, extra, pk);
+                               opacities, extra, pk, nullptr);
         else
             hipLaunchKernelGGL((live_pack_kernel<1>), gp, dim3(256), 0, s, n_gauss_total, means2d, conics, colors,
-                               opacities, extra, pk);
+                               opacities, extra, pk, nullptr);
         if (!masks_in_payload)
             hipLaunchKernelGGL(live_mask_packed_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, n_isects,
                                isect_ids, flatten_ids, pk, tile_width, tile_bits, mask8);

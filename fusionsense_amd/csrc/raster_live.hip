@@ -435,7 +435,7 @@ raster_bwd_live_kernel(int64_t cap, const float4 *__restrict__ rec, const int4 *
 }
 
 __global__ void __launch_bounds__(256)
-unpack_grads_kernel(int64_t total, int D, const float4 *__restrict__ v_packed, float *__restrict__ v_means2d,
+unpack_grads_kernel(int64_t total, int D, float4 *__restrict__ v_packed, int rezero, float *__restrict__ v_means2d,
                     float *__restrict__ v_means2d_abs, float *__restrict__ v_conics,
                     float *__restrict__ v_colors, float *__restrict__ v_opacities,
                     float *__restrict__ v_extra, float *__restrict__ v_last) {
@@ -443,8 +443,12 @@ unpack_grads_kernel(int64_t total, int D, const float4 *__restrict__ v_packed, f
     if (n >= total) return;
     const float4 a = v_packed[n * 4 + 0], b = v_packed[n * 4 + 1], c = v_packed[n * 4 + 2];
     if (v_last) v_last[n] = (D == 4) ? a.w : ((D == 3) ? a.z : a.x);  // gradient of the last colour channel
+    const float4 d = v_packed[n * 4 + 3];
+    if (rezero) {  // leave the accumulator ready for the next frame's atomics (saves a 64 B/Gaussian fill launch)
+        const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        v_packed[n * 4 + 0] = zero4; v_packed[n * 4 + 1] = zero4; v_packed[n * 4 + 2] = zero4; v_packed[n * 4 + 3] = zero4;
+    }
     if (v_extra) {
-        const float4 d = v_packed[n * 4 + 3];
         v_extra[n * 3 + 0] = d.x; v_extra[n * 3 + 1] = d.y; v_extra[n * 3 + 2] = d.z;
     }
     if (D == 4) {
@@ -599,7 +603,7 @@ extern "C" int fsgs_raster_bwd_quad(int C, int D, const float *records, const in
                            v_packed, stream);
 }
 
-extern "C" int fsgs_raster_unpack_grads(int64_t total, int D, const float *v_packed, float *v_means2d,
+extern "C" int fsgs_raster_unpack_grads(int64_t total, int D, float *v_packed, int rezero, float *v_means2d,
                                         float *v_means2d_abs, float *v_conics, float *v_colors,
                                         float *v_opacities, float *v_extra, float *v_last,
                                         fsgs_stream_t stream) {
@@ -607,7 +611,7 @@ extern "C" int fsgs_raster_unpack_grads(int64_t total, int D, const float *v_pac
     if (total == 0) return FSGS_OK;
     if (!v_packed || !v_means2d || !v_conics || !v_colors || !v_opacities) return FSGS_EINVAL;
     hipLaunchKernelGGL(unpack_grads_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, as_stream(stream), total, D,
-                       reinterpret_cast<const float4 *>(v_packed), v_means2d, v_means2d_abs, v_conics, v_colors,
+                       reinterpret_cast<float4 *>(v_packed), rezero, v_means2d, v_means2d_abs, v_conics, v_colors,
                        v_opacities, v_extra, v_last);
     return check_launch();
 }

@@ -58,7 +58,7 @@ raster_fwd_quad_kernel(int64_t cap, const float4 *__restrict__ packed, const int
                        float *__restrict__ render, float *__restrict__ alphas, int32_t *__restrict__ last_ids,
                        float4 *__restrict__ rec_out, int32_t *__restrict__ n_rec,
                        float *__restrict__ seg_state, int64_t seg_cap, int normalize_last,
-                       float *__restrict__ render_extra, float *__restrict__ max_last_partial) {
+                       float *__restrict__ render_extra, float *__restrict__ max_last) {
     __shared__ QuadLds<E> S;
     constexpr int RS = E ? 4 : 3;
     // workgroup b runs on XCD b % 8: the four quadrants of a tile share its list and its Gaussians,
@@ -268,11 +268,13 @@ raster_fwd_quad_kernel(int64_t cap, const float4 *__restrict__ packed, const int
         alphas[pix_id] = 1.f - T;
         last_ids[pix_id] = cur_idx;
     }
-    if (max_last_partial) {  // per-wave max of the (normalised) last channel, for depth_im's fill value
+    if (max_last) {  // image maximum of the (normalised) last channel, for depth_im's fill value
         float m = inside ? pix[D - 1] : 0.f;
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d, 64));
-        if (lane == 0) max_last_partial[((int64_t)tile_lin * 4 + q) * 4 + w] = m;
+        // non-negative floats order like their bit patterns; a stale read only costs a redundant atomic
+        if (lane == 0 && m > __hip_atomic_load(max_last, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            atomicMax(reinterpret_cast<int *>(max_last), __float_as_int(m));
     }
 }
 
@@ -291,16 +293,12 @@ extern "C" int64_t fsgs_quad_seg_slots(int C, int tile_width, int tile_height, i
            (int64_t)C * tile_width * tile_height + 2;
 }
 
-extern "C" int64_t fsgs_raster_quad_max_partials(int C, int tile_width, int tile_height) {
-    return 16ll * C * tile_width * tile_height;
-}
-
 extern "C" int fsgs_raster_fwd_quad(int C, int D, const float *packed, const int32_t *payload,
                                     const int32_t *isect_offsets, int64_t n_isects, const float *backgrounds,
                                     int width, int height, int tile_width, int tile_height, int normalize_last,
                                     float *render, float *alphas, int32_t *last_ids, float *records,
                                     int32_t *n_rec, float *seg_state, float *render_extra,
-                                    float *max_last_partial, fsgs_stream_t stream) {
+                                    float *max_last, fsgs_stream_t stream) {
     if (C < 0 || width < 0 || height < 0 || n_isects < 0) return FSGS_EINVAL;
     if (C == 0 || width == 0 || height == 0) return FSGS_OK;
     if (n_isects > 0x7FFFFFF0ll) return FSGS_EINVAL;  // list indices are 32-bit (as in the reference)
@@ -320,7 +318,7 @@ extern "C" int fsgs_raster_fwd_quad(int C, int D, const float *packed, const int
     hipLaunchKernelGGL((raster_fwd_quad_kernel<DD, EE>), grid, dim3(256), 0, s, cap, pk, payload,                 \
                        isect_offsets, n_isects, backgrounds, width, height, tile_width, tile_height, (int)n_tiles, \
                        render, alphas, last_ids, rec, n_rec, seg_state, seg_cap, normalize_last, render_extra,     \
-                       max_last_partial)
+                       max_last)
     if (render_extra) {
         if (D != 4) return FSGS_EINVAL;  // the fused RGB+depth + normal-plane walk
         FSGS_FWD_QUAD(4, 3);

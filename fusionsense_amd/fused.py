@@ -69,10 +69,26 @@ def _camera_on_device(camera: Camera, dev) -> Dict[str, Tensor]:
     return cache[key]
 
 
+_ACCUM: Dict[str, Tensor] = {}
+_ONES3: Dict[str, Tensor] = {}
+
+
+def _grad_accumulator(dev, N: int) -> Tensor:
+    """The packed [N,16] gradient accumulator of the backward, kept zeroed between frames (one per device;
+    re-created when N changes, i.e. after densify / prune)."""
+    key = str(dev)
+    t = _ACCUM.get(key)
+    if t is None or t.shape[0] != N:
+        t = torch.zeros(N, 16, dtype=torch.float32, device=dev)
+        _ACCUM[key] = t
+    return t
+
+
 class _FusedGetOutputs(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means, scales, quats, features_dc, features_rest, opacities, cam, width, height,
                 sh_degree, background, info: FrameInfo, grad_out: Optional[Dict[str, Tensor]]):
+        ctx.set_materialize_grads(False)  # unused outputs (accumulation) arrive as None, not as a zero image
         lib = load()
         dev = means.device
         sp = stream_ptr(dev)
@@ -104,8 +120,9 @@ class _FusedGetOutputs(torch.autograd.Function):
         _run(lib.fsgs_normals_fwd, (N, ptr(quats), ptr(scales), ptr(means), ptr(cam["c2w"]), ptr(normals_world),
                                     ptr(normals_cam), sp), "fsgs_normals_fwd")
         packed = torch.empty(N, 16, **f32)
+        max_last = torch.empty(1, **f32)  # zeroed by the pack kernel, raised by the forward
         _run(lib.fsgs_live_pack, (4, N, ptr(means2d), ptr(conics), ptr(colors), ptr(opac_sig), ptr(normals_cam),
-                                 ptr(packed), sp), "fsgs_live_pack", "_d4e3")
+                                 ptr(packed), ptr(max_last), sp), "fsgs_live_pack", "_d4e3")
         tpg, isect_ids, flatten_ids, offsets = ops.isect_finish_live(count, means2d, radii, depths, conics, opac_row,
                                                                      tw, th, want_ids=False)
         rule_diff = 0
@@ -130,17 +147,15 @@ class _FusedGetOutputs(torch.autograd.Function):
         alphas = torch.empty(1, H, W, 1, **f32)
         last_ids = torch.empty(1, H, W, dtype=torch.int32, device=dev)
         render_extra = torch.empty(1, H, W, 3, **f32)
-        n_part = lib.fsgs_raster_quad_max_partials(1, tw, th)
-        max_part = torch.empty(n_part + 1, **f32)
         _run(lib.fsgs_raster_fwd_quad, (1, 4, ptr(packed), ptr(flatten_ids), ptr(offsets), M, None, W, H, tw, th, 1,
                                        ptr(render), ptr(alphas), ptr(last_ids), ptr(records), ptr(n_rec),
-                                       ptr(seg_state), ptr(render_extra), ptr(max_part), sp),
+                                       ptr(seg_state), ptr(render_extra), ptr(max_last), sp),
              "fsgs_raster_fwd_quad", "_d4e3")
         rgb = torch.empty(H, W, 3, **f32)
         depth = torch.empty(H, W, 1, **f32)
         normal = torch.empty(H, W, 3, **f32)
         _run(lib.fsgs_epilogue_fwd, (H * W, ptr(render), ptr(alphas), ptr(render_extra), ptr(background),
-                                    ptr(max_part), n_part, max_part[n_part:].data_ptr(), ptr(rgb), ptr(depth),
+                                    None, 0, ptr(max_last), ptr(rgb), ptr(depth),
                                     ptr(normal), sp), "fsgs_epilogue_fwd")
 
         info.radii, info.means2d, info.depths, info.conics = radii, means2d, depths, conics
@@ -180,7 +195,7 @@ class _FusedGetOutputs(torch.autograd.Function):
         _run(lib.fsgs_epilogue_bwd, (H * W, ptr(render), ptr(alphas), ptr(render_extra), ptr(background), ptr(v_rgb),
                                     ptr(v_depth), ptr(v_normal), ptr(v_alpha_out), ptr(v_render), ptr(v_alphas),
                                     ptr(v_render_extra), sp), "fsgs_epilogue_bwd")
-        v_packed = torch.zeros(N, 16, **f32)
+        v_packed = _grad_accumulator(dev, N)  # all zeros: the unpack kernel clears it again after reading
         _run(lib.fsgs_raster_bwd_quad, (1, 4, ptr(records), ptr(n_rec), ptr(offsets), M, None, W, H, tw, th, 1,
                                        ptr(render), ptr(alphas), ptr(last_ids), ptr(v_render), ptr(v_alphas),
                                        ptr(seg_state), 1, ptr(render_extra), ptr(v_render_extra), ptr(v_packed), sp),
@@ -192,7 +207,7 @@ class _FusedGetOutputs(torch.autograd.Function):
         v_opac = torch.empty(N, **f32)
         v_ncam = torch.empty(N, 3, **f32)
         v_depths = torch.empty(1, N, **f32)
-        _run(lib.fsgs_raster_unpack_grads, (N, 4, ptr(v_packed), ptr(v_means2d), ptr(v_abs), ptr(v_conics),
+        _run(lib.fsgs_raster_unpack_grads, (N, 4, ptr(v_packed), 1, ptr(v_means2d), ptr(v_abs), ptr(v_conics),
                                            ptr(v_colors), ptr(v_opac), ptr(v_ncam), ptr(v_depths), sp),
              "fsgs_raster_unpack_grads")
         WORKSPACE.give(getattr(ctx, "arena", None))
@@ -238,7 +253,9 @@ def render_fusionsense_fused(gauss_params: Dict[str, Tensor], camera: Camera, sh
     accumulation, radii, normals_world, ...), computed by one fused autograd node."""
     dev = device or gauss_params["means"].device
     if background is None:
-        background = torch.ones(3, device=dev)
+        background = _ONES3.get(str(dev))
+        if background is None:
+            background = _ONES3.setdefault(str(dev), torch.ones(3, device=dev))
     cam = _camera_on_device(camera, dev)
     info = FrameInfo()
     rgb, depth, normal, alpha = _FusedGetOutputs.apply(

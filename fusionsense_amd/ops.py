@@ -566,7 +566,7 @@ class _Rasterize(torch.autograd.Function):
             v_colors = torch.empty(Cn, N, D, dtype=torch.float32, device=dev)
             v_opacities = torch.empty(Cn, N, dtype=torch.float32, device=dev)
             v_abs = torch.empty(Cn, N, 2, dtype=torch.float32, device=dev) if absgrad else None
-            _run(lib.fsgs_raster_unpack_grads, (Cn * N, D, ptr(v_packed), ptr(v_means2d), ptr(v_abs),
+            _run(lib.fsgs_raster_unpack_grads, (Cn * N, D, ptr(v_packed), 0, ptr(v_means2d), ptr(v_abs),
                                                ptr(v_conics), ptr(v_colors), ptr(v_opacities), None, None,
                                                stream_ptr(dev)), "fsgs_raster_unpack_grads")
         else:

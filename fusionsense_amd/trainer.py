@@ -148,7 +148,9 @@ class SplatTrainer:
             self.slab.zero_()  # autograd accumulates into the slab views; the fused node overwrites them
         out = self.forward(camera)
         loss = self.loss(out, target)
-        loss.backward()
+        if getattr(self, "_one", None) is None or self._one.device != loss.device:
+            self._one = torch.ones((), dtype=loss.dtype, device=loss.device)
+        loss.backward(gradient=self._one)  # (the default would launch a fill kernel for the seed gradient)
         self.slab.all_reduce_mean_()
         if optimizer_step:
             self.optimizers["means"].param_groups[0]["lr"] = self._means_lr(self.step)

@@ -266,13 +266,13 @@ int fsgs_tile_sort(int64_t n, const int64_t *isect_ids, const int32_t *payload, 
  *   records  4 * fsgs_quad_stream_capacity(...) * (render_extra ? 16 : 12) floats, n_rec [4, C*th*tw] i32:
  *            the walked part of every quadrant's list, written for fsgs_raster_bwd_quad (both nullable
  *            together for inference); seg_state: 4 * fsgs_quad_seg_slots(...) * 64 * (1+D+E) floats
- *   max_last_partial [fsgs_raster_quad_max_partials(...)] (nullable). */
+ *   max_last [1] (nullable): running maximum of the last output channel, raised with atomics — zero it
+ *            first (fsgs_live_pack does); feeds fsgs_epilogue_fwd with n_partial = 0. */
 int64_t fsgs_quad_stream_capacity(int C, int tile_width, int tile_height, int64_t n_isects);
 int64_t fsgs_quad_seg_slots(int C, int tile_width, int tile_height, int64_t n_isects);
-int64_t fsgs_raster_quad_max_partials(int C, int tile_width, int tile_height);
 int fsgs_live_pack(int D, int64_t n_gauss_total, const float *means2d, const float *conics,
                    const float *colors, const float *opacities, const float *extra, float *packed,
-                   fsgs_stream_t stream);
+                   float *zero_cell /* nullable: one float set to 0 */, fsgs_stream_t stream);
 int fsgs_live_payload(const int64_t *isect_ids, const int32_t *flatten_ids, int64_t n_isects,
                       const float *packed, int64_t n_gauss_total, int tile_width, int tile_bits,
                       int32_t *payload, fsgs_stream_t stream);
@@ -280,7 +280,7 @@ int fsgs_raster_fwd_quad(int C, int D, const float *packed, const int32_t *paylo
                          const int32_t *isect_offsets, int64_t n_isects, const float *backgrounds,
                          int width, int height, int tile_width, int tile_height, int normalize_last,
                          float *render, float *alphas, int32_t *last_ids, float *records, int32_t *n_rec,
-                         float *seg_state, float *render_extra, float *max_last_partial,
+                         float *seg_state, float *render_extra, float *max_last,
                          fsgs_stream_t stream);
 int fsgs_raster_bwd_quad(int C, int D, const float *records, const int32_t *n_rec,
                          const int32_t *isect_offsets, int64_t n_isects, const float *backgrounds,
@@ -289,8 +289,9 @@ int fsgs_raster_bwd_quad(int C, int D, const float *records, const int32_t *n_re
                          const float *v_render, const float *v_alphas, const float *seg_state,
                          int with_abs, const float *render_extra, const float *v_render_extra,
                          float *v_packed, fsgs_stream_t stream);
-/* Split packed gradient records into the five gsplat-shaped arrays (written, not accumulated). */
-int fsgs_raster_unpack_grads(int64_t total, int D, const float *v_packed, float *v_means2d,
+/* Split packed gradient records into the five gsplat-shaped arrays (written, not accumulated).
+ * rezero != 0: v_packed is cleared after it has been read, ready for the next frame's atomics. */
+int fsgs_raster_unpack_grads(int64_t total, int D, float *v_packed, int rezero, float *v_means2d,
                              float *v_means2d_abs, float *v_conics, float *v_colors,
                              float *v_opacities, float *v_extra, float *v_last, fsgs_stream_t stream);
 /* v_extra[C*N,3] and v_last[C*N] (the last colour channel's gradient, i.e. v_depths when the depth
