@@ -51,7 +51,8 @@ SIGNATURES = {
     "fsgs_tile_sort": (_i, [_i64, _p, _p, _i, _i, _i, _p, _p, _p, _p, _sz, _p]),
     "fsgs_quad_stream_capacity": (_i64, [_i, _i, _i, _i64]),
     "fsgs_quad_seg_slots": (_i64, [_i, _i, _i, _i64]),
-    "fsgs_live_pack": (_i, [_i, _i64, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "fsgs_live_pack": (_i, [_i, _i64, _p, _p, _p, _p, _p, _p, _p, _i, _p]),
+    "fsgs_raster_quad_max_cells": (_i, []),
     "fsgs_live_payload": (_i, [_p, _p, _i64, _p, _i64, _i, _i, _p, _p]),
     "fsgs_raster_fwd_quad": (_i, [_i, _i, _p, _p, _p, _i64, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "fsgs_raster_bwd_quad": (_i, [_i, _i, _p, _p, _p, _i64, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p]),

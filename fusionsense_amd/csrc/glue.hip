@@ -54,17 +54,24 @@ max_reduce_kernel(int n, const float *__restrict__ partial, float *__restrict__ 
 __global__ void __launch_bounds__(256)
 epilogue_fwd_kernel(int64_t P, const float4 *__restrict__ render, const float *__restrict__ alphas,
                     const float *__restrict__ render_extra, const float *__restrict__ bg,
-                    const float *__restrict__ max_last, float *__restrict__ rgb, float *__restrict__ depth,
-                    float *__restrict__ normal) {
+                    const float *__restrict__ max_last, int n_cells, float *__restrict__ rgb,
+                    float *__restrict__ depth, float *__restrict__ normal) {
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const float4 r = (p < P) ? render[p] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float a = (p < P) ? alphas[p] : 1.f;
+    // the image maximum arrives as n_cells partial maxima; only waves with an empty pixel need it
+    float fill = 0.f;
+    if (__any(!(a > 0.f))) {
+        for (int k = threadIdx.x & 63; k < n_cells; k += 64) fill = fmaxf(fill, max_last[k]);
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) fill = fmaxf(fill, __shfl_xor(fill, d, 64));
+    }
     if (p >= P) return;
-    const float4 r = render[p];
-    const float a = alphas[p];
     const float t = 1.f - a;
     rgb[p * 3 + 0] = fminf(fmaxf(r.x + t * bg[0], 0.f), 1.f);
     rgb[p * 3 + 1] = fminf(fmaxf(r.y + t * bg[1], 0.f), 1.f);
     rgb[p * 3 + 2] = fminf(fmaxf(r.z + t * bg[2], 0.f), 1.f);
-    depth[p] = (a > 0.f) ? r.w : max_last[0];
+    depth[p] = (a > 0.f) ? r.w : fill;
     if (normal) {
         const float nx = render_extra[p * 3 + 0], ny = render_extra[p * 3 + 1], nz = render_extra[p * 3 + 2];
         const float inv = 1.f / sqrtf(nx * nx + ny * ny + nz * nz);
@@ -147,16 +154,17 @@ extern "C" int fsgs_epilogue_fwd(int64_t n_pixels, const float *render, const fl
                                  const float *render_extra, const float *bg, const float *max_last_partial,
                                  int n_partial, float *max_last, float *rgb, float *depth, float *normal,
                                  fsgs_stream_t stream) {
-    if (n_pixels < 0 || n_partial < 0) return FSGS_EINVAL;
+    if (n_pixels < 0) return FSGS_EINVAL;
     if (n_pixels == 0) return FSGS_OK;
     if (!render || !alphas || !bg || (n_partial > 0 && !max_last_partial) || !max_last || !rgb || !depth)
         return FSGS_EINVAL;
     if (normal && !render_extra) return FSGS_EINVAL;
     hipStream_t s = as_stream(stream);
-    if (n_partial > 0)  // otherwise max_last already holds the image maximum (fsgs_raster_fwd_quad)
+    if (n_partial > 0)  // n_partial <= 0: max_last already holds max(1, -n_partial) partial maxima (fsgs_raster_fwd_quad)
         hipLaunchKernelGGL(max_reduce_kernel, dim3(1), dim3(1024), 0, s, n_partial, max_last_partial, max_last);
+    const int n_cells = n_partial < 0 ? -n_partial : 1;
     hipLaunchKernelGGL(epilogue_fwd_kernel, dim3(ceil_div(n_pixels, 256)), dim3(256), 0, s, n_pixels,
-                       reinterpret_cast<const float4 *>(render), alphas, render_extra, bg, max_last, rgb, depth,
+                       reinterpret_cast<const float4 *>(render), alphas, render_extra, bg, max_last, n_cells, rgb, depth,
                        normal);
     return check_launch();
 }

@@ -34,9 +34,11 @@ template <int D>
 __global__ void __launch_bounds__(256)
 live_pack_kernel(int64_t total, const float *__restrict__ means2d, const float *__restrict__ conics,
                  const float *__restrict__ colors, const float *__restrict__ opacities,
-                 const float *__restrict__ extra, float4 *__restrict__ packed, float *__restrict__ zero_cell) {
+                 const float *__restrict__ extra, float4 *__restrict__ packed, float *__restrict__ zero_cells,
+                 int n_zero) {
     const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g == 0 && zero_cell) zero_cell[0] = 0.f;  // e.g. the forward's running image maximum
+    if (blockIdx.x == 0 && zero_cells)  // e.g. the forward's running image maxima
+        for (int k = threadIdx.x; k < n_zero; k += blockDim.x) zero_cells[k] = 0.f;
     if (g >= total) return;
     const float2 xy = reinterpret_cast<const float2 *>(means2d)[g];
     float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -273,11 +275,12 @@ using namespace fsgs;
 
 extern "C" int fsgs_live_pack(int D, int64_t n_gauss_total, const float *means2d, const float *conics,
                               const float *colors, const float *opacities, const float *extra, float *packed,
-                              float *zero_cell, fsgs_stream_t stream) {
+                              float *zero_cells, int n_zero, fsgs_stream_t stream) {
     if (n_gauss_total < 0 || (D != 1 && D != 3 && D != 4)) return FSGS_EINVAL;
     hipStream_t s = as_stream(stream);
     if (n_gauss_total == 0) {
-        if (zero_cell && hipMemsetAsync(zero_cell, 0, sizeof(float), s) != hipSuccess) return FSGS_ELAUNCH;
+        if (zero_cells && n_zero > 0 && hipMemsetAsync(zero_cells, 0, sizeof(float) * n_zero, s) != hipSuccess)
+            return FSGS_ELAUNCH;
         return FSGS_OK;
     }
     if (!means2d || !conics || !colors || !opacities || !packed) return FSGS_EINVAL;
@@ -285,13 +288,13 @@ extern "C" int fsgs_live_pack(int D, int64_t n_gauss_total, const float *means2d
     const dim3 gp(ceil_div(n_gauss_total, 256));
     if (D == 4)
         hipLaunchKernelGGL((live_pack_kernel<4>), gp, dim3(256), 0, s, n_gauss_total, means2d, conics, colors,
-                           opacities, extra, pk, zero_cell);
+                           opacities, extra, pk, zero_cells, n_zero);
     else if (D == 3)
         hipLaunchKernelGGL((live_pack_kernel<3>), gp, dim3(256), 0, s, n_gauss_total, means2d, conics, colors,
-                           opacities, extra, pk, zero_cell);
+                           opacities, extra, pk, zero_cells, n_zero);
     else
         hipLaunchKernelGGL((live_pack_kernel<1>), gp, dim3(256), 0, s, n_gauss_total, means2d, conics, colors,
-                           opacities, extra, pk, zero_cell);
+                           opacities, extra, pk, zero_cells, n_zero);
     return check_launch();
 }
 
@@ -337,13 +340,13 @@ extern "C" int fsgs_live_prepare(int D, const float *means2d, const float *conic
         const dim3 gp(ceil_div(n_gauss_total, 256));
         if (D == 4)
             hipLaunchKernelGGL((live_pack_kernel<4>), gp, dim3(256), 0, s, n_gauss_total, means2d, conics, colors,
-                               opacities, extra, pk, nullptr);
+                               opacities, extra, pk, nullptr, 0);
         else if (D == 3)
             hipLaunchKernelGGL((live_pack_kernel<3>), gp, dim3(256), 0, s, n_gauss_total, means2d, conics, colors,
-                               opacities, extra, pk, nullptr);
+                               opacities, extra, pk, nullptr, 0);
         else
             hipLaunchKernelGGL((live_pack_kernel<1>), gp, dim3(256), 0, s, n_gauss_total, means2d, conics, colors,
-                               opacities, extra, pk, nullptr);
+                               opacities, extra, pk, nullptr, 0);
         if (!masks_in_payload)
             hipLaunchKernelGGL(live_mask_packed_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, n_isects,
                                isect_ids, flatten_ids, pk, tile_width, tile_bits, mask8);

@@ -24,6 +24,7 @@
 
 namespace fsgs {
 
+constexpr int kMaxCells = 256;               // partial image maxima (fsgs_raster_quad_max_cells)
 constexpr int kQuadChunk = 256;             // list entries examined per step by the workgroup
 constexpr int kQuadStage = kQuadChunk + 4;  // staged records (+ padding to a multiple of 4)
 
@@ -272,9 +273,14 @@ raster_fwd_quad_kernel(int64_t cap, const float4 *__restrict__ packed, const int
         float m = inside ? pix[D - 1] : 0.f;
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d, 64));
-        // non-negative floats order like their bit patterns; a stale read only costs a redundant atomic
-        if (lane == 0 && m > __hip_atomic_load(max_last, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-            atomicMax(reinterpret_cast<int *>(max_last), __float_as_int(m));
+        if (lane == 0) S.wcount[w] = __float_as_int(m);
+        __syncthreads();
+        // one atomic per workgroup, spread over kMaxCells addresses (same-address atomics serialise at
+        // the memory side); non-negative floats order like their bit patterns
+        if (tid == 0) {
+            const int mm = max(max(S.wcount[0], S.wcount[1]), max(S.wcount[2], S.wcount[3]));
+            if (mm > 0) atomicMax(reinterpret_cast<int *>(max_last) + (blockIdx.x & (kMaxCells - 1)), mm);
+        }
     }
 }
 
@@ -292,6 +298,8 @@ extern "C" int64_t fsgs_quad_seg_slots(int C, int tile_width, int tile_height, i
     return (fsgs_quad_stream_capacity(C, tile_width, tile_height, n_isects) >> 6) +
            (int64_t)C * tile_width * tile_height + 2;
 }
+
+extern "C" int fsgs_raster_quad_max_cells(void) { return kMaxCells; }
 
 extern "C" int fsgs_raster_fwd_quad(int C, int D, const float *packed, const int32_t *payload,
                                     const int32_t *isect_offsets, int64_t n_isects, const float *backgrounds,

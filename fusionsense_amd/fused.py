@@ -120,9 +120,10 @@ class _FusedGetOutputs(torch.autograd.Function):
         _run(lib.fsgs_normals_fwd, (N, ptr(quats), ptr(scales), ptr(means), ptr(cam["c2w"]), ptr(normals_world),
                                     ptr(normals_cam), sp), "fsgs_normals_fwd")
         packed = torch.empty(N, 16, **f32)
-        max_last = torch.empty(1, **f32)  # zeroed by the pack kernel, raised by the forward
+        n_cells = lib.fsgs_raster_quad_max_cells()
+        max_last = torch.empty(n_cells, **f32)  # partial image maxima: zeroed by the pack kernel, raised by the forward
         _run(lib.fsgs_live_pack, (4, N, ptr(means2d), ptr(conics), ptr(colors), ptr(opac_sig), ptr(normals_cam),
-                                 ptr(packed), ptr(max_last), sp), "fsgs_live_pack", "_d4e3")
+                                 ptr(packed), ptr(max_last), n_cells, sp), "fsgs_live_pack", "_d4e3")
         tpg, isect_ids, flatten_ids, offsets = ops.isect_finish_live(count, means2d, radii, depths, conics, opac_row,
                                                                      tw, th, want_ids=False)
         rule_diff = 0
@@ -155,7 +156,7 @@ class _FusedGetOutputs(torch.autograd.Function):
         depth = torch.empty(H, W, 1, **f32)
         normal = torch.empty(H, W, 3, **f32)
         _run(lib.fsgs_epilogue_fwd, (H * W, ptr(render), ptr(alphas), ptr(render_extra), ptr(background),
-                                    None, 0, ptr(max_last), ptr(rgb), ptr(depth),
+                                    None, -n_cells, ptr(max_last), ptr(rgb), ptr(depth),
                                     ptr(normal), sp), "fsgs_epilogue_fwd")
 
         info.radii, info.means2d, info.depths, info.conics = radii, means2d, depths, conics

@@ -266,13 +266,15 @@ int fsgs_tile_sort(int64_t n, const int64_t *isect_ids, const int32_t *payload, 
  *   records  4 * fsgs_quad_stream_capacity(...) * (render_extra ? 16 : 12) floats, n_rec [4, C*th*tw] i32:
  *            the walked part of every quadrant's list, written for fsgs_raster_bwd_quad (both nullable
  *            together for inference); seg_state: 4 * fsgs_quad_seg_slots(...) * 64 * (1+D+E) floats
- *   max_last [1] (nullable): running maximum of the last output channel, raised with atomics — zero it
- *            first (fsgs_live_pack does); feeds fsgs_epilogue_fwd with n_partial = 0. */
+ *   max_last [fsgs_raster_quad_max_cells()] (nullable): partial maxima of the last output channel, raised
+ *            with atomics — zero them first (fsgs_live_pack does); feed fsgs_epilogue_fwd with
+ *            n_partial = -fsgs_raster_quad_max_cells(). */
+int fsgs_raster_quad_max_cells(void);
 int64_t fsgs_quad_stream_capacity(int C, int tile_width, int tile_height, int64_t n_isects);
 int64_t fsgs_quad_seg_slots(int C, int tile_width, int tile_height, int64_t n_isects);
 int fsgs_live_pack(int D, int64_t n_gauss_total, const float *means2d, const float *conics,
                    const float *colors, const float *opacities, const float *extra, float *packed,
-                   float *zero_cell /* nullable: one float set to 0 */, fsgs_stream_t stream);
+                   float *zero_cells /* nullable: n_zero floats set to 0 */, int n_zero, fsgs_stream_t stream);
 int fsgs_live_payload(const int64_t *isect_ids, const int32_t *flatten_ids, int64_t n_isects,
                       const float *packed, int64_t n_gauss_total, int tile_width, int tile_bits,
                       int32_t *payload, fsgs_stream_t stream);
@@ -341,7 +343,8 @@ int fsgs_activate_bwd(int N, const float *scales, const float *opac, const float
                       float *v_log_scales, float *v_opac_logit, float *v_quats, fsgs_stream_t stream);
 /* dn_model.py:602-613, 655-656: rgb = clamp(render[:3] + (1-alpha) bg, 0, 1); depth = alpha > 0 ?
  * render[3] : max(render[3]); normal = (n/|n| + 1)/2.  render [P,4], alphas [P], render_extra [P,3],
- * bg [3]; max_last_partial from fsgs_raster_fwd_live.  bwd: any of v_rgb / v_depth / v_normal /
+ * bg [3]; n_partial > 0: max_last_partial [n_partial] (fsgs_raster_fwd_live) is reduced into max_last[0]
+ * first; n_partial <= 0: max_last already holds max(1, -n_partial) partial maxima.  bwd: any of v_rgb / v_depth / v_normal /
  * v_alpha_in may be NULL (= zero); writes v_render [P,4], v_alphas [P], v_render_extra [P,3]. */
 int fsgs_epilogue_fwd(int64_t n_pixels, const float *render, const float *alphas,
                       const float *render_extra, const float *bg, const float *max_last_partial,
