@@ -6,6 +6,7 @@
 // so consecutive lanes read consecutive 12/16-byte records: fully coalesced, no LDS needed.
 // HBM-bound: 40 B read + 28 B written per Gaussian (forward).
 #include "common.h"
+#include "normal_math.h"
 
 namespace fsgs {
 
@@ -121,6 +122,25 @@ project_fwd_kernel(int C, int N, const float *__restrict__ means, const float *_
 
 // VJP.  One thread per Gaussian, looping over cameras (C is 1 on the training path), so the
 // per-Gaussian gradients are written once, without atomics, deterministically.
+// FUSED (C == 1, the training path of fusionsense_amd/fused.py): the whole per-Gaussian tail of the
+// backward in this one kernel — the image-space gradients come straight from the rasterizer's packed
+// accumulator (which is cleared for the next frame), and the VJPs of exp(scales) / sigmoid(opacity),
+// of the normal pass (quaternions), the absgrad output and SplatfactoModel.after_train's statistics
+// are applied in place.  Replaces five launches (unpack, project_bwd, normals_bwd, activate_bwd,
+// densify_stats) that each moved the same 300 k records.
+struct GaussBwdFused {
+    float4 *v_packed;            // [N,4] float4: [0..3] v_colors [4..6] v_conics [7..8] v_means2d [9..10] abs [11] v_opac [12..14] v_ncam
+    const float *log_scales;     // raw scales (argmin axis of the normal)
+    const float *opac;           // sigmoid(opacities)
+    const float *c2w;            // [3,4] camera-to-world of the normal pass
+    float *absgrad;              // [N,2] out
+    float *v_opac_logit;         // [N] out
+    int accumulate_means;        // v_means += (the SH backward wrote its share first) instead of =
+    float *xys_grad_norm, *vis_counts, *max_2Dsize;  // after_train statistics (nullable together)
+    float inv_max_hw;
+};
+
+template <bool FUSED>
 __global__ void __launch_bounds__(256)
 project_bwd_kernel(int C, int N, const float *__restrict__ means, const float *__restrict__ quats,
                    const float *__restrict__ scales, const float *__restrict__ viewmats,
@@ -130,9 +150,16 @@ project_bwd_kernel(int C, int N, const float *__restrict__ means, const float *_
                    const float *__restrict__ v_depths, const float *__restrict__ v_conics,
                    const float *__restrict__ v_compensations, float *__restrict__ v_means,
                    float *__restrict__ v_quats, float *__restrict__ v_scales,
-                   float *__restrict__ v_viewmats) {
+                   float *__restrict__ v_viewmats, GaussBwdFused fz) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= N) return;
+    float4 pa, pb, pc, pd;  // FUSED: this Gaussian's packed gradient record
+    if (FUSED) {
+        pa = fz.v_packed[n * 4 + 0]; pb = fz.v_packed[n * 4 + 1]; pc = fz.v_packed[n * 4 + 2]; pd = fz.v_packed[n * 4 + 3];
+        const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        fz.v_packed[n * 4 + 0] = zero4; fz.v_packed[n * 4 + 1] = zero4; fz.v_packed[n * 4 + 2] = zero4; fz.v_packed[n * 4 + 3] = zero4;
+        reinterpret_cast<float2 *>(fz.absgrad)[n] = make_float2(pc.y, pc.z);
+    }
     const float mean[3] = {means[n * 3 + 0], means[n * 3 + 1], means[n * 3 + 2]};
     const float4 q = reinterpret_cast<const float4 *>(quats)[n];
     const float qn = fmaxf(sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w), 1e-12f);
@@ -168,7 +195,9 @@ project_bwd_kernel(int C, int N, const float *__restrict__ means, const float *_
 
         // conic = inverse(Sigma2 + eps I):  G = -X V X, X = conic matrix, V = sym(v_conic)
         const float ca = conics[idx * 3 + 0], cb = conics[idx * 3 + 1], cc = conics[idx * 3 + 2];
-        const float va = v_conics[idx * 3 + 0], vb = 0.5f * v_conics[idx * 3 + 1], vc = v_conics[idx * 3 + 2];
+        const float va = FUSED ? pb.x : v_conics[idx * 3 + 0];
+        const float vb = 0.5f * (FUSED ? pb.y : v_conics[idx * 3 + 1]);
+        const float vc = FUSED ? pb.z : v_conics[idx * 3 + 2];
         // T = X V
         const float t00 = ca * va + cb * vb, t01 = ca * vb + cb * vc;
         const float t10 = cb * va + cc * vb, t11 = cb * vb + cc * vc;
@@ -210,10 +239,10 @@ project_bwd_kernel(int C, int N, const float *__restrict__ means, const float *_
             vJ1[j] = 2.f * (GJ1[0] * Sc[0][j] + GJ1[1] * Sc[1][j] + GJ1[2] * Sc[2][j]);
         }
         // camera-space mean gradient
-        const float vu = v_means2d[idx * 2 + 0], vv = v_means2d[idx * 2 + 1];
+        const float vu = FUSED ? pb.w : v_means2d[idx * 2 + 0], vv = FUSED ? pc.x : v_means2d[idx * 2 + 1];
         float gx = fx * rz * vu;
         float gy = fy * rz * vv;
-        float gz = -(fx * x * vu + fy * y * vv) * rz2 + v_depths[idx];
+        float gz = -(fx * x * vu + fy * y * vv) * rz2 + (FUSED ? pa.w : v_depths[idx]);
         gz += -fx * rz2 * vJ0[0] - fy * rz2 * vJ1[1];
         if (free_x) {
             gx += -fx * rz2 * vJ0[2];
@@ -298,15 +327,44 @@ project_bwd_kernel(int C, int N, const float *__restrict__ means, const float *_
                              2.f * qz * (vR[0][0] + vR[1][1]) + qw * (vR[1][0] - vR[0][1]));
     // through q_hat = q/|q|
     const float dotp = gw * qw + gqx * qx + gqy * qy + gqz * qz;
-    v_means[n * 3 + 0] = g_mean[0];
-    v_means[n * 3 + 1] = g_mean[1];
-    v_means[n * 3 + 2] = g_mean[2];
-    reinterpret_cast<float4 *>(v_quats)[n] =
-        make_float4((gw - dotp * qw) * inv, (gqx - dotp * qx) * inv, (gqy - dotp * qy) * inv,
-                    (gqz - dotp * qz) * inv);
-    v_scales[n * 3 + 0] = vs[0];
-    v_scales[n * 3 + 1] = vs[1];
-    v_scales[n * 3 + 2] = vs[2];
+    float4 vq = make_float4((gw - dotp * qw) * inv, (gqx - dotp * qx) * inv, (gqy - dotp * qy) * inv,
+                            (gqz - dotp * qz) * inv);
+    if (!FUSED) {
+        v_means[n * 3 + 0] = g_mean[0];
+        v_means[n * 3 + 1] = g_mean[1];
+        v_means[n * 3 + 2] = g_mean[2];
+        reinterpret_cast<float4 *>(v_quats)[n] = vq;
+        v_scales[n * 3 + 0] = vs[0];
+        v_scales[n * 3 + 1] = vs[1];
+        v_scales[n * 3 + 2] = vs[2];
+        return;
+    }
+    if (fz.accumulate_means) {
+        v_means[n * 3 + 0] += g_mean[0]; v_means[n * 3 + 1] += g_mean[1]; v_means[n * 3 + 2] += g_mean[2];
+    } else {
+        v_means[n * 3 + 0] = g_mean[0]; v_means[n * 3 + 1] = g_mean[1]; v_means[n * 3 + 2] = g_mean[2];
+    }
+    // `scales` holds exp(log_scales): d/d log_scale = v * exp(log_scale)
+    v_scales[n * 3 + 0] = vs[0] * s[0];
+    v_scales[n * 3 + 1] = vs[1] * s[1];
+    v_scales[n * 3 + 2] = vs[2] * s[2];
+    const float o = fz.opac[n];
+    fz.v_opac_logit[n] = pc.w * o * (1.f - o);
+    {   // the normal pass reaches the quaternions only (dn_model.py:618-656)
+        const float ls[3] = {fz.log_scales[n * 3 + 0], fz.log_scales[n * 3 + 1], fz.log_scales[n * 3 + 2]};
+        const float vn[3] = {pd.x, pd.y, pd.z};
+        const float4 vqb = normal_backward(q, ls, mean, fz.c2w, vn);
+        vq.x += vqb.x; vq.y += vqb.y; vq.z += vqb.z; vq.w += vqb.w;
+    }
+    reinterpret_cast<float4 *>(v_quats)[n] = vq;
+    if (fz.xys_grad_norm) {  // SplatfactoModel.after_train (dn_model.py:1385-1389 registration)
+        const int r = radii[n];
+        if (r > 0) {
+            fz.xys_grad_norm[n] += sqrtf(pc.y * pc.y + pc.z * pc.z);
+            fz.vis_counts[n] += 1.f;
+            fz.max_2Dsize[n] = fmaxf(fz.max_2Dsize[n], (float)r * fz.inv_max_hw);
+        }
+    }
 }
 
 }  // namespace fsgs
@@ -342,9 +400,34 @@ extern "C" int fsgs_project_bwd(int C, int N, const float *means, const float *q
     if (!means || !quats || !scales || !viewmats || !Ks || !radii || !conics || !v_means2d ||
         !v_depths || !v_conics || !v_means || !v_quats || !v_scales)
         return FSGS_EINVAL;
-    hipLaunchKernelGGL(project_bwd_kernel, dim3(ceil_div(N, 256)), dim3(256), 0, as_stream(stream), C,
+    hipLaunchKernelGGL((project_bwd_kernel<false>), dim3(ceil_div(N, 256)), dim3(256), 0, as_stream(stream), C,
                        N, means, quats, scales, viewmats, Ks, width, height, eps2d, radii, conics,
                        compensations, v_means2d, v_depths, v_conics, v_compensations, v_means,
-                       v_quats, v_scales, v_viewmats);
+                       v_quats, v_scales, v_viewmats, GaussBwdFused{});
+    return check_launch();
+}
+
+extern "C" int fsgs_gaussian_bwd(int N, const float *means, const float *quats, const float *log_scales,
+                                 const float *scales, const float *opac, const float *viewmat, const float *K,
+                                 const float *c2w, int width, int height, float eps2d, const int32_t *radii,
+                                 const float *conics, float *v_packed, int accumulate_means, float *v_means,
+                                 float *v_quats, float *v_log_scales, float *v_opac_logit, float *absgrad,
+                                 float *xys_grad_norm, float *vis_counts, float *max_2Dsize, float inv_max_hw,
+                                 fsgs_stream_t stream) {
+    if (N < 0) return FSGS_EINVAL;
+    if (N == 0) return FSGS_OK;
+    if (!means || !quats || !log_scales || !scales || !opac || !viewmat || !K || !c2w || !radii || !conics ||
+        !v_packed || !v_means || !v_quats || !v_log_scales || !v_opac_logit || !absgrad)
+        return FSGS_EINVAL;
+    if ((xys_grad_norm != nullptr) != (vis_counts != nullptr) || (xys_grad_norm != nullptr) != (max_2Dsize != nullptr))
+        return FSGS_EINVAL;
+    GaussBwdFused fz;
+    fz.v_packed = reinterpret_cast<float4 *>(v_packed);
+    fz.log_scales = log_scales; fz.opac = opac; fz.c2w = c2w; fz.absgrad = absgrad; fz.v_opac_logit = v_opac_logit;
+    fz.accumulate_means = accumulate_means;
+    fz.xys_grad_norm = xys_grad_norm; fz.vis_counts = vis_counts; fz.max_2Dsize = max_2Dsize; fz.inv_max_hw = inv_max_hw;
+    hipLaunchKernelGGL((project_bwd_kernel<true>), dim3(ceil_div(N, 256)), dim3(256), 0, as_stream(stream), 1, N,
+                       means, quats, scales, viewmat, K, width, height, eps2d, radii, conics, nullptr, nullptr,
+                       nullptr, nullptr, nullptr, v_means, v_quats, v_log_scales, nullptr, fz);
     return check_launch();
 }

@@ -178,7 +178,7 @@ sh_bwd_kernel(int C, int N, int K, int degree, const float *__restrict__ means,
               const float *__restrict__ coeffs_rest, const int32_t *__restrict__ radii, int D,
               const float *__restrict__ v_colors, float *__restrict__ v_coeffs,
               float *__restrict__ v_coeffs_rest, float *__restrict__ v_means,
-              float *__restrict__ v_depths) {
+              float *__restrict__ v_depths, int overwrite_means) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int n0 = blockIdx.x * kShBlock;
     const int rows = min(kShBlock, N - n0);
@@ -238,9 +238,10 @@ sh_bwd_kernel(int C, int N, int K, int degree, const float *__restrict__ means,
             }
         }
         const float dp = gdx * dx + gdy * dy + gdz * dz;
-        v_means[n * 3 + 0] += (gdx - dp * dx) * inorm;
-        v_means[n * 3 + 1] += (gdy - dp * dy) * inorm;
-        v_means[n * 3 + 2] += (gdz - dp * dz) * inorm;
+        const float g0 = (gdx - dp * dx) * inorm, g1 = (gdy - dp * dy) * inorm, g2 = (gdz - dp * dz) * inorm;
+        v_means[n * 3 + 0] = overwrite_means ? g0 : v_means[n * 3 + 0] + g0;
+        v_means[n * 3 + 1] = overwrite_means ? g1 : v_means[n * 3 + 1] + g1;
+        v_means[n * 3 + 2] = overwrite_means ? g2 : v_means[n * 3 + 2] + g2;
       }
     } else if (n < N) {
         const float mx = means[n * 3 + 0], myy = means[n * 3 + 1], mz = means[n * 3 + 2];
@@ -289,9 +290,9 @@ sh_bwd_kernel(int C, int N, int K, int degree, const float *__restrict__ means,
             gmy += (gdy - dp * dy) * inorm;
             gmz += (gdz - dp * dz) * inorm;
         }
-        v_means[n * 3 + 0] += gmx;
-        v_means[n * 3 + 1] += gmy;
-        v_means[n * 3 + 2] += gmz;
+        v_means[n * 3 + 0] = overwrite_means ? gmx : v_means[n * 3 + 0] + gmx;
+        v_means[n * 3 + 1] = overwrite_means ? gmy : v_means[n * 3 + 1] + gmy;
+        v_means[n * 3 + 2] = overwrite_means ? gmz : v_means[n * 3 + 2] + gmz;
         // reuse this lane's LDS row for the coefficient gradient, then stream it out coalesced
 #pragma unroll
         for (int k = 0; k < kMaxK; ++k) {
@@ -389,9 +390,10 @@ extern "C" int fsgs_sh_fwd_split(int C, int N, int K, int degree, const float *m
 static int sh_bwd_impl(int C, int N, int K, int degree, const float *means, const float *campos,
                        const float *coeffs, const float *coeffs_rest, const int32_t *radii, int D,
                        const float *v_colors, float *v_coeffs, float *v_coeffs_rest, float *v_means,
-                       float *v_depths, fsgs_stream_t stream) {
-    if (C < 0 || N < 0 || degree < 0 || degree > 4 || K < (degree + 1) * (degree + 1) || K > kMaxK ||
-        (D != 3 && D != 4))
+                       float *v_depths, int overwrite_means, fsgs_stream_t stream) {
+    // D = floats per v_colors row (the colour gradient is its first three): 3, 4 (v_depths = column 3), or a
+    // wider stride such as the rasterizer's packed 16-float gradient records
+    if (C < 0 || N < 0 || degree < 0 || degree > 4 || K < (degree + 1) * (degree + 1) || K > kMaxK || D < 3)
         return FSGS_EINVAL;
     if (N == 0) return FSGS_OK;
     if (!means || !campos || !coeffs || !radii || !v_colors || !v_coeffs || !v_means) return FSGS_EINVAL;
@@ -399,11 +401,11 @@ static int sh_bwd_impl(int C, int N, int K, int degree, const float *means, cons
     if (C == 1)
         hipLaunchKernelGGL((sh_bwd_kernel<true>), dim3(ceil_div(N, kShBlock)), dim3(kShBlock), lds_bytes,
                            as_stream(stream), C, N, K, degree, means, campos, coeffs, coeffs_rest, radii, D,
-                           v_colors, v_coeffs, v_coeffs_rest, v_means, v_depths);
+                           v_colors, v_coeffs, v_coeffs_rest, v_means, v_depths, overwrite_means);
     else
         hipLaunchKernelGGL((sh_bwd_kernel<false>), dim3(ceil_div(N, kShBlock)), dim3(kShBlock), lds_bytes,
                            as_stream(stream), C, N, K, degree, means, campos, coeffs, coeffs_rest, radii, D,
-                           v_colors, v_coeffs, v_coeffs_rest, v_means, v_depths);
+                           v_colors, v_coeffs, v_coeffs_rest, v_means, v_depths, overwrite_means);
     return check_launch();
 }
 
@@ -411,15 +413,15 @@ extern "C" int fsgs_sh_bwd(int C, int N, int K, int degree, const float *means, 
                            const float *coeffs, const int32_t *radii, int D, const float *v_colors,
                            float *v_coeffs, float *v_means, float *v_depths, fsgs_stream_t stream) {
     return sh_bwd_impl(C, N, K, degree, means, campos, coeffs, nullptr, radii, D, v_colors, v_coeffs, nullptr,
-                       v_means, v_depths, stream);
+                       v_means, v_depths, 0, stream);
 }
 
 extern "C" int fsgs_sh_bwd_split(int C, int N, int K, int degree, const float *means, const float *campos,
                                  const float *features_dc, const float *features_rest, const int32_t *radii,
                                  int D, const float *v_colors, float *v_features_dc, float *v_features_rest,
-                                 float *v_means, float *v_depths, fsgs_stream_t stream) {
+                                 float *v_means, float *v_depths, int overwrite_means, fsgs_stream_t stream) {
     if ((!features_rest || !v_features_rest) && K > 1) return FSGS_EINVAL;
     return sh_bwd_impl(C, N, K, degree, means, campos, features_dc, features_rest ? features_rest : features_dc,
                        radii, D, v_colors, v_features_dc, v_features_rest ? v_features_rest : v_features_dc,
-                       v_means, v_depths, stream);
+                       v_means, v_depths, overwrite_means, stream);
 }

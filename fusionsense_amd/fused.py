@@ -42,6 +42,10 @@ class FrameInfo:
         self.absgrad: Optional[Tensor] = None  # [1,N,2], set by backward
         self.normals_world = None
         self.legacy_rule_diff = 0
+        # after_train statistics fused into the backward: {"xys_grad_norm","vis_counts","max_2Dsize": [N] tensors,
+        # "inv_max_hw": float} supplied by the caller; stats_done tells it they have been applied
+        self.stats_out: Optional[dict] = None
+        self.stats_done = False
 
     @property
     def flatten_ids(self):
@@ -201,19 +205,8 @@ class _FusedGetOutputs(torch.autograd.Function):
                                        ptr(render), ptr(alphas), ptr(last_ids), ptr(v_render), ptr(v_alphas),
                                        ptr(seg_state), 1, ptr(render_extra), ptr(v_render_extra), ptr(v_packed), sp),
              "fsgs_raster_bwd_quad", "_d4e3")
-        v_means2d = torch.empty(1, N, 2, **f32)
-        v_abs = torch.empty(1, N, 2, **f32)
-        v_conics = torch.empty(1, N, 3, **f32)
-        v_colors = torch.empty(1, N, 4, **f32)
-        v_opac = torch.empty(N, **f32)
-        v_ncam = torch.empty(N, 3, **f32)
-        v_depths = torch.empty(1, N, **f32)
-        _run(lib.fsgs_raster_unpack_grads, (N, 4, ptr(v_packed), 1, ptr(v_means2d), ptr(v_abs), ptr(v_conics),
-                                           ptr(v_colors), ptr(v_opac), ptr(v_ncam), ptr(v_depths), sp),
-             "fsgs_raster_unpack_grads")
         WORKSPACE.give(getattr(ctx, "arena", None))
         ctx.arena = None
-        ctx.info.absgrad = v_abs
 
         # final gradients go straight into the caller's buffers (views of the gradient slab) if given
         go = ctx.grad_out or {}
@@ -225,21 +218,25 @@ class _FusedGetOutputs(torch.autograd.Function):
         g_means, g_scales, g_quats = out("means", means), out("scales", scales), out("quats", quats)
         g_dc, g_rest = out("features_dc", features_dc), out("features_rest", features_rest)
         g_opac = out("opacities", opac_sig.view(N, 1))
-        v_quats_a = torch.empty(N, 4, **f32)
-        v_scales_exp = torch.empty(N, 3, **f32)
-        _run(lib.fsgs_project_bwd, (1, N, ptr(means), ptr(quats), ptr(scales_exp), ptr(cam["viewmat"]), ptr(cam["K"]),
-                                   W, H, 0.3, ptr(radii), ptr(conics), None, ptr(v_means2d), ptr(v_depths),
-                                   ptr(v_conics), None, ptr(g_means), ptr(v_quats_a), ptr(v_scales_exp), None, sp),
-             "fsgs_project_bwd")
+        # SH: colour gradients are the first floats of the packed records; writes the view-direction share of v_means
         _run(lib.fsgs_sh_bwd_split, (1, N, K, sh_degree, ptr(means), ptr(cam["campos"]), ptr(features_dc),
-                                     ptr(features_rest), ptr(radii), 4, ptr(v_colors), ptr(g_dc), ptr(g_rest),
-                                     ptr(g_means), None, sp), "fsgs_sh_bwd_split")
-        v_quats_b = torch.empty(N, 4, **f32)
-        _run(lib.fsgs_normals_bwd, (N, ptr(quats), ptr(scales), ptr(means), ptr(cam["c2w"]), ptr(v_ncam),
-                                    ptr(v_quats_b), sp), "fsgs_normals_bwd")
-        _run(lib.fsgs_activate_bwd, (N, ptr(scales_exp), ptr(opac_sig), ptr(v_scales_exp), ptr(v_opac),
-                                    ptr(v_quats_a), ptr(v_quats_b), ptr(g_scales), ptr(g_opac), ptr(g_quats), sp),
-             "fsgs_activate_bwd")
+                                     ptr(features_rest), ptr(radii), 16, ptr(v_packed), ptr(g_dc), ptr(g_rest),
+                                     ptr(g_means), None, 1, sp), "fsgs_sh_bwd_split")
+        # everything else per Gaussian in one launch (projection / normal / activation VJPs, absgrad, statistics)
+        v_abs = torch.empty(1, N, 2, **f32)
+        stats = ctx.info.stats_out
+        if stats is not None and stats["xys_grad_norm"].shape[0] != N:
+            stats = None
+        _run(lib.fsgs_gaussian_bwd, (N, ptr(means), ptr(quats), ptr(scales), ptr(scales_exp), ptr(opac_sig),
+                                    ptr(cam["viewmat"]), ptr(cam["K"]), ptr(cam["c2w"]), W, H, 0.3, ptr(radii),
+                                    ptr(conics), ptr(v_packed), 1, ptr(g_means), ptr(g_quats), ptr(g_scales),
+                                    ptr(g_opac), ptr(v_abs),
+                                    ptr(stats["xys_grad_norm"]) if stats else None,
+                                    ptr(stats["vis_counts"]) if stats else None,
+                                    ptr(stats["max_2Dsize"]) if stats else None,
+                                    float(stats["inv_max_hw"]) if stats else 0.0, sp), "fsgs_gaussian_bwd")
+        ctx.info.absgrad = v_abs
+        ctx.info.stats_done = stats is not None
         if ctx.grad_out:
             # already written into the caller's gradient buffers (the trainer's slab views, which ARE the
             # parameters' .grad): returning them as well would make autograd add them a second time
@@ -249,7 +246,8 @@ class _FusedGetOutputs(torch.autograd.Function):
 
 def render_fusionsense_fused(gauss_params: Dict[str, Tensor], camera: Camera, sh_degree: int = 3,
                              background: Optional[Tensor] = None, device: Optional[torch.device] = None,
-                             grad_out: Optional[Dict[str, Tensor]] = None) -> Dict[str, Tensor]:
+                             grad_out: Optional[Dict[str, Tensor]] = None,
+                             stats_out: Optional[dict] = None) -> Dict[str, Tensor]:
     """Same outputs as :func:`fusionsense_amd.fusion.render_fusionsense` (rgb, depth, normal,
     accumulation, radii, normals_world, ...), computed by one fused autograd node."""
     dev = device or gauss_params["means"].device
@@ -259,6 +257,7 @@ def render_fusionsense_fused(gauss_params: Dict[str, Tensor], camera: Camera, sh
             background = _ONES3.setdefault(str(dev), torch.ones(3, device=dev))
     cam = _camera_on_device(camera, dev)
     info = FrameInfo()
+    info.stats_out = stats_out
     rgb, depth, normal, alpha = _FusedGetOutputs.apply(
         gauss_params["means"], gauss_params["scales"], gauss_params["quats"], gauss_params["features_dc"],
         gauss_params["features_rest"], gauss_params["opacities"], cam, camera.width, camera.height, int(sh_degree),

@@ -110,6 +110,22 @@ class DensifyStrategy:
 
     # ---- a-12 ---------------------------------------------------------------------------
     @torch.no_grad()
+    def _ensure_stats(self, N: int, dev) -> None:
+        if self.xys_grad_norm is None:
+            self.xys_grad_norm = torch.zeros(N, device=dev)
+            self.vis_counts = torch.ones(N, device=dev)
+        if self.max_2Dsize is None:
+            self.max_2Dsize = torch.zeros(N, device=dev)
+
+    def stats_target(self, trainer, N: int, dev, camera) -> Optional[dict]:
+        """The statistics buffers for a backward that applies after_train itself (the fused get_outputs
+        node does, in its per-Gaussian kernel); None when after_train would not run at this step."""
+        if trainer.step >= self.cfg.stop_split_at:
+            return None
+        self._ensure_stats(N, dev)
+        return {"xys_grad_norm": self.xys_grad_norm, "vis_counts": self.vis_counts, "max_2Dsize": self.max_2Dsize,
+                "inv_max_hw": 1.0 / float(max(camera.height, camera.width))}
+
     def after_train(self, trainer, out, camera) -> None:
         if trainer.step >= self.cfg.stop_split_at:
             return
@@ -117,11 +133,9 @@ class DensifyStrategy:
         N = radii.shape[0]
         dev = radii.device
         self.last_size = (camera.height, camera.width)
-        if self.xys_grad_norm is None:
-            self.xys_grad_norm = torch.zeros(N, device=dev)
-            self.vis_counts = torch.ones(N, device=dev)
-        if self.max_2Dsize is None:
-            self.max_2Dsize = torch.zeros(N, device=dev)
+        if getattr(out.get("info"), "stats_done", False):
+            return  # already applied by the fused backward of this frame
+        self._ensure_stats(N, dev)
         absgrad = out["xys"].absgrad[0]
         ops.densify_stats_(radii, absgrad, max(camera.height, camera.width), self.xys_grad_norm,
                            self.vis_counts, self.max_2Dsize)

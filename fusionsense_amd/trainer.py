@@ -103,8 +103,12 @@ class SplatTrainer:
         deg = self.sh_degree if sh_degree_to_use is None else sh_degree_to_use
         if self.fused:
             from .fused import render_fusionsense_fused
+            grad = torch.is_grad_enabled()
+            stats = None
+            if grad and self.strategy is not None and hasattr(self.strategy, "stats_target"):
+                stats = self.strategy.stats_target(self, self.num_gaussians(), self.device, camera)
             return render_fusionsense_fused(self.params, camera, sh_degree=deg, device=self.device,
-                                            grad_out=self.slab.views if torch.is_grad_enabled() else None)
+                                            grad_out=self.slab.views if grad else None, stats_out=stats)
         from .fusion import render_fusionsense
         return render_fusionsense(self.params, camera, sh_degree=deg, device=self.device)
 

@@ -86,7 +86,10 @@ int fsgs_sh_fwd_split(int C, int N, int K, int degree, const float *means, const
 int fsgs_sh_bwd_split(int C, int N, int K, int degree, const float *means, const float *campos,
                       const float *features_dc, const float *features_rest, const int32_t *radii, int D,
                       const float *v_colors, float *v_features_dc, float *v_features_rest,
-                      float *v_means, float *v_depths, fsgs_stream_t stream);
+                      float *v_means, float *v_depths, int overwrite_means, fsgs_stream_t stream);
+/* D = floats per v_colors row (its first three are the colour gradient): 3, 4 (then v_depths, if given,
+ * receives column 3) or a wider stride, e.g. 16 for the rasterizer's packed gradient records.
+ * overwrite_means != 0: v_means is written instead of accumulated into. */
 
 /* ---- E4: isect_tiles (gsplat._C.isect_tiles), two passes --------------------------------------
  * Pass 1: tiles_per_gauss[C,N] i32 and its inclusive prefix sum cum_tiles[C,N] i64.
@@ -341,6 +344,19 @@ int fsgs_activate_fwd(int N, const float *log_scales, const float *opac_logit, f
 int fsgs_activate_bwd(int N, const float *scales, const float *opac, const float *v_scales,
                       const float *v_opac, const float *v_quats_a, const float *v_quats_b,
                       float *v_log_scales, float *v_opac_logit, float *v_quats, fsgs_stream_t stream);
+/* The per-Gaussian tail of the fused backward in ONE launch (C == 1): reads each Gaussian's packed
+ * gradient record (fsgs_raster_bwd_quad; cleared afterwards), applies the VJP of the projection
+ * (as fsgs_project_bwd with v_means2d / v_conics / v_depths taken from the record), of the normal pass
+ * (fsgs_normals_bwd), of exp(scales) / sigmoid(opacities) (fsgs_activate_bwd), writes absgrad [N,2] and,
+ * when the three statistics arrays are given, applies fsgs_densify_stats.  scales = exp(log_scales),
+ * opac = sigmoid(opacity logits); accumulate_means != 0: v_means += (after fsgs_sh_bwd_split wrote it). */
+int fsgs_gaussian_bwd(int N, const float *means, const float *quats, const float *log_scales,
+                      const float *scales, const float *opac, const float *viewmat, const float *K,
+                      const float *c2w, int width, int height, float eps2d, const int32_t *radii,
+                      const float *conics, float *v_packed, int accumulate_means, float *v_means,
+                      float *v_quats, float *v_log_scales, float *v_opac_logit, float *absgrad,
+                      float *xys_grad_norm, float *vis_counts, float *max_2Dsize, float inv_max_hw,
+                      fsgs_stream_t stream);
 /* dn_model.py:602-613, 655-656: rgb = clamp(render[:3] + (1-alpha) bg, 0, 1); depth = alpha > 0 ?
  * render[3] : max(render[3]); normal = (n/|n| + 1)/2.  render [P,4], alphas [P], render_extra [P,3],
  * bg [3]; n_partial > 0: max_last_partial [n_partial] (fsgs_raster_fwd_live) is reduced into max_last[0]
