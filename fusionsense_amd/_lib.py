@@ -53,6 +53,7 @@ SIGNATURES = {
     "fsgs_quad_seg_slots": (_i64, [_i, _i, _i, _i64]),
     "fsgs_live_pack": (_i, [_i, _i64, _p, _p, _p, _p, _p, _p, _p, _i, _p]),
     "fsgs_raster_quad_max_cells": (_i, []),
+    "fsgs_live_pack_normals": (_i, [_i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p]),
     "fsgs_live_payload": (_i, [_p, _p, _i64, _p, _i64, _i, _i, _p, _p]),
     "fsgs_raster_fwd_quad": (_i, [_i, _i, _p, _p, _p, _i64, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "fsgs_raster_bwd_quad": (_i, [_i, _i, _p, _p, _p, _i64, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p]),
@@ -62,6 +63,7 @@ SIGNATURES = {
     "fsgs_raster_unpack_grads": (_i, [_i64, _i, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p]),
     "fsgs_sh_fwd_split": (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p]),
     "fsgs_sh_bwd_split": (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _i, _p]),
+    "fsgs_project_fwd_act": (_i, [_i, _i, _p, _p, _p, _p, _p, _p, _i, _i, _f, _f, _f, _f, _p, _p, _p, _p, _p, _p, _p]),
     "fsgs_gaussian_bwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _f, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _f, _p]),
     "fsgs_activate_fwd": (_i, [_i, _p, _p, _p, _p, _p]),
     "fsgs_activate_bwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),

@@ -22,6 +22,7 @@
 // alpha >= 1/255, so images, last_ids and gradients equal those of the plain walk.
 #include "common.h"
 #include "cull.h"
+#include "normal_math.h"
 #include "scan.h"
 
 namespace fsgs {
@@ -35,11 +36,31 @@ __global__ void __launch_bounds__(256)
 live_pack_kernel(int64_t total, const float *__restrict__ means2d, const float *__restrict__ conics,
                  const float *__restrict__ colors, const float *__restrict__ opacities,
                  const float *__restrict__ extra, float4 *__restrict__ packed, float *__restrict__ zero_cells,
-                 int n_zero) {
+                 int n_zero, const float *__restrict__ quats, const float *__restrict__ log_scales,
+                 const float *__restrict__ means, const float *__restrict__ c2w,
+                 float *__restrict__ normals_world) {
     const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (blockIdx.x == 0 && zero_cells)  // e.g. the forward's running image maxima
         for (int k = threadIdx.x; k < n_zero; k += blockDim.x) zero_cells[k] = 0.f;
     if (g >= total) return;
+    float ex[3] = {0.f, 0.f, 0.f};
+    bool has_extra = extra != nullptr;
+    if (quats) {
+        // the extra plane is the Gaussian's camera-space normal, computed here (dn_model.py:618-636)
+        // instead of by a separate launch; normals_world is the side output get_outputs returns
+        const float4 q = reinterpret_cast<const float4 *>(quats)[g];
+        const float ls[3] = {log_scales[g * 3], log_scales[g * 3 + 1], log_scales[g * 3 + 2]};
+        const float mean[3] = {means[g * 3], means[g * 3 + 1], means[g * 3 + 2]};
+        NormalCtx o;
+        normal_forward(q, ls, mean, c2w, o);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) normals_world[g * 3 + k] = o.n[k];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) ex[j] = o.n[0] * c2w[0 * 4 + j] + o.n[1] * c2w[1 * 4 + j] + o.n[2] * c2w[2 * 4 + j];
+        has_extra = true;
+    } else if (extra) {
+        ex[0] = extra[g * 3 + 0]; ex[1] = extra[g * 3 + 1]; ex[2] = extra[g * 3 + 2];
+    }
     const float2 xy = reinterpret_cast<const float2 *>(means2d)[g];
     float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
     if (D == 4) {
@@ -52,8 +73,7 @@ live_pack_kernel(int64_t total, const float *__restrict__ means2d, const float *
     packed[g * 4 + 0] = make_float4(xy.x, xy.y, opacities[g], conics[g * 3 + 0]);
     packed[g * 4 + 1] = make_float4(conics[g * 3 + 1], conics[g * 3 + 2], 0.f, 0.f);
     packed[g * 4 + 2] = c;
-    packed[g * 4 + 3] = extra ? make_float4(extra[g * 3 + 0], extra[g * 3 + 1], extra[g * 3 + 2], 0.f)
-                              : make_float4(0.f, 0.f, 0.f, 0.f);
+    packed[g * 4 + 3] = has_extra ? make_float4(ex[0], ex[1], ex[2], 0.f) : make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
 __global__ void __launch_bounds__(256)
@@ -273,9 +293,10 @@ inline int64_t scan4_blocks(int64_t n) { return (n + kS4Tile - 1) / kS4Tile; }
 
 using namespace fsgs;
 
-extern "C" int fsgs_live_pack(int D, int64_t n_gauss_total, const float *means2d, const float *conics,
-                              const float *colors, const float *opacities, const float *extra, float *packed,
-                              float *zero_cells, int n_zero, fsgs_stream_t stream) {
+static int live_pack_impl(int D, int64_t n_gauss_total, const float *means2d, const float *conics,
+                          const float *colors, const float *opacities, const float *extra, float *packed,
+                          float *zero_cells, int n_zero, const float *quats, const float *log_scales,
+                          const float *means, const float *c2w, float *normals_world, fsgs_stream_t stream) {
     if (n_gauss_total < 0 || (D != 1 && D != 3 && D != 4)) return FSGS_EINVAL;
     hipStream_t s = as_stream(stream);
     if (n_gauss_total == 0) {
@@ -288,14 +309,32 @@ extern "C" int fsgs_live_pack(int D, int64_t n_gauss_total, const float *means2d
     const dim3 gp(ceil_div(n_gauss_total, 256));
     if (D == 4)
         hipLaunchKernelGGL((live_pack_kernel<4>), gp, dim3(256), 0, s, n_gauss_total, means2d, conics, colors,
-                           opacities, extra, pk, zero_cells, n_zero);
+                           opacities, extra, pk, zero_cells, n_zero, quats, log_scales, means, c2w, normals_world);
     else if (D == 3)
         hipLaunchKernelGGL((live_pack_kernel<3>), gp, dim3(256), 0, s, n_gauss_total, means2d, conics, colors,
-                           opacities, extra, pk, zero_cells, n_zero);
+                           opacities, extra, pk, zero_cells, n_zero, quats, log_scales, means, c2w, normals_world);
     else
         hipLaunchKernelGGL((live_pack_kernel<1>), gp, dim3(256), 0, s, n_gauss_total, means2d, conics, colors,
-                           opacities, extra, pk, zero_cells, n_zero);
+                           opacities, extra, pk, zero_cells, n_zero, quats, log_scales, means, c2w, normals_world);
     return check_launch();
+}
+
+extern "C" int fsgs_live_pack(int D, int64_t n_gauss_total, const float *means2d, const float *conics,
+                              const float *colors, const float *opacities, const float *extra, float *packed,
+                              float *zero_cells, int n_zero, fsgs_stream_t stream) {
+    return live_pack_impl(D, n_gauss_total, means2d, conics, colors, opacities, extra, packed, zero_cells, n_zero,
+                          nullptr, nullptr, nullptr, nullptr, nullptr, stream);
+}
+
+// fsgs_live_pack with the extra plane = the Gaussians' camera-space normals, computed in the same launch
+// (what fsgs_normals_fwd would write: normals_world [N,3] is still returned; single camera)
+extern "C" int fsgs_live_pack_normals(int64_t N, const float *means2d, const float *conics, const float *colors,
+                                      const float *opacities, const float *quats, const float *log_scales,
+                                      const float *means, const float *c2w, float *packed, float *normals_world,
+                                      float *zero_cells, int n_zero, fsgs_stream_t stream) {
+    if (N > 0 && (!quats || !log_scales || !means || !c2w || !normals_world)) return FSGS_EINVAL;
+    return live_pack_impl(4, N, means2d, conics, colors, opacities, nullptr, packed, zero_cells, n_zero, quats,
+                          log_scales, means, c2w, normals_world, stream);
 }
 
 extern "C" int fsgs_live_payload(const int64_t *isect_ids, const int32_t *flatten_ids, int64_t n_isects,
@@ -340,13 +379,13 @@ extern "C" int fsgs_live_prepare(int D, const float *means2d, const float *conic
         const dim3 gp(ceil_div(n_gauss_total, 256));
         if (D == 4)
             hipLaunchKernelGGL((live_pack_kernel<4>), gp, dim3(256), 0, s, n_gauss_total, means2d, conics, colors,
-                               opacities, extra, pk, nullptr, 0);
+                               opacities, extra, pk, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr);
         else if (D == 3)
             hipLaunchKernelGGL((live_pack_kernel<3>), gp, dim3(256), 0, s, n_gauss_total, means2d, conics, colors,
-                               opacities, extra, pk, nullptr, 0);
+                               opacities, extra, pk, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr);
         else
             hipLaunchKernelGGL((live_pack_kernel<1>), gp, dim3(256), 0, s, n_gauss_total, means2d, conics, colors,
-                               opacities, extra, pk, nullptr, 0);
+                               opacities, extra, pk, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr);
         if (!masks_in_payload)
             hipLaunchKernelGGL(live_mask_packed_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, n_isects,
                                isect_ids, flatten_ids, pk, tile_width, tile_bits, mask8);

@@ -41,17 +41,31 @@ __device__ __forceinline__ void covar_cam(const Mat3 &Rq, const float s[3], cons
         for (int j = 0; j < 3; ++j) Sc[i][j] = A[i][0] * A[j][0] + A[i][1] * A[j][1] + A[i][2] * A[j][2];
 }
 
+// ACT: `scales` holds log-scales and the activations of dn_model.py:573-574 are applied here
+// (scales_out = exp(scales), opac_out = sigmoid(opac_logit)): one launch less and the projection
+// never re-reads the activated scales from memory.
+template <bool ACT>
 __global__ void __launch_bounds__(256)
 project_fwd_kernel(int C, int N, const float *__restrict__ means, const float *__restrict__ quats,
                    const float *__restrict__ scales, const float *__restrict__ viewmats,
                    const float *__restrict__ Ks, int width, int height, float eps2d, float near_plane,
                    float far_plane, float radius_clip, int32_t *__restrict__ radii,
                    float *__restrict__ means2d, float *__restrict__ depths,
-                   float *__restrict__ conics, float *__restrict__ compensations) {
+                   float *__restrict__ conics, float *__restrict__ compensations,
+                   const float *__restrict__ opac_logit, float *__restrict__ scales_out,
+                   float *__restrict__ opac_out) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (int64_t)C * N) return;
     const int c = (int)(idx / N);
     const int n = (int)(idx - (int64_t)c * N);
+    float s_act[3] = {0.f, 0.f, 0.f};
+    if (ACT) {
+        s_act[0] = expf(scales[n * 3 + 0]); s_act[1] = expf(scales[n * 3 + 1]); s_act[2] = expf(scales[n * 3 + 2]);
+        if (c == 0) {
+            scales_out[n * 3 + 0] = s_act[0]; scales_out[n * 3 + 1] = s_act[1]; scales_out[n * 3 + 2] = s_act[2];
+            opac_out[n] = 1.f / (1.f + expf(-opac_logit[n]));
+        }
+    }
 
     const float *vm = viewmats + c * 16;
     float W[3][3] = {{vm[0], vm[1], vm[2]}, {vm[4], vm[5], vm[6]}, {vm[8], vm[9], vm[10]}};
@@ -69,7 +83,8 @@ project_fwd_kernel(int C, int N, const float *__restrict__ means, const float *_
         const float inv = 1.f / fmaxf(sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w), 1e-12f);
         Mat3 Rq;
         quat_to_rot(q.x * inv, q.y * inv, q.z * inv, q.w * inv, Rq);
-        const float s[3] = {scales[n * 3 + 0], scales[n * 3 + 1], scales[n * 3 + 2]};
+        const float s[3] = {ACT ? s_act[0] : scales[n * 3 + 0], ACT ? s_act[1] : scales[n * 3 + 1],
+                            ACT ? s_act[2] : scales[n * 3 + 2]};
         float Sc[3][3];
         covar_cam(Rq, s, W, Sc);
 
@@ -382,9 +397,28 @@ extern "C" int fsgs_project_fwd(int C, int N, const float *means, const float *q
     if (!means || !quats || !scales || !viewmats || !Ks || !radii || !means2d || !depths || !conics)
         return FSGS_EINVAL;
     const int64_t total = (int64_t)C * N;
-    hipLaunchKernelGGL(project_fwd_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, as_stream(stream),
+    hipLaunchKernelGGL((project_fwd_kernel<false>), dim3(ceil_div(total, 256)), dim3(256), 0, as_stream(stream),
                        C, N, means, quats, scales, viewmats, Ks, width, height, eps2d, near_plane,
-                       far_plane, radius_clip, radii, means2d, depths, conics, compensations);
+                       far_plane, radius_clip, radii, means2d, depths, conics, compensations, nullptr, nullptr,
+                       nullptr);
+    return check_launch();
+}
+
+extern "C" int fsgs_project_fwd_act(int C, int N, const float *means, const float *quats,
+                                    const float *log_scales, const float *opac_logit, const float *viewmats,
+                                    const float *Ks, int width, int height, float eps2d, float near_plane,
+                                    float far_plane, float radius_clip, float *scales_out, float *opac_out,
+                                    int32_t *radii, float *means2d, float *depths, float *conics,
+                                    fsgs_stream_t stream) {
+    if (C < 0 || N < 0) return FSGS_EINVAL;
+    if ((int64_t)C * N == 0) return FSGS_OK;
+    if (!means || !quats || !log_scales || !opac_logit || !viewmats || !Ks || !scales_out || !opac_out || !radii ||
+        !means2d || !depths || !conics)
+        return FSGS_EINVAL;
+    const int64_t total = (int64_t)C * N;
+    hipLaunchKernelGGL((project_fwd_kernel<true>), dim3(ceil_div(total, 256)), dim3(256), 0, as_stream(stream),
+                       C, N, means, quats, log_scales, viewmats, Ks, width, height, eps2d, near_plane, far_plane,
+                       radius_clip, radii, means2d, depths, conics, nullptr, opac_logit, scales_out, opac_out);
     return check_launch();
 }
 

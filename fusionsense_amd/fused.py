@@ -106,10 +106,13 @@ class _FusedGetOutputs(torch.autograd.Function):
 
         scales_exp = torch.empty(N, 3, **f32)
         opac_sig = torch.empty(N, **f32)
-        _run(lib.fsgs_activate_fwd, (N, ptr(scales), ptr(opacities), ptr(scales_exp), ptr(opac_sig), sp),
-             "fsgs_activate_fwd")
-        radii, means2d, depths, conics, _ = ops.project_fwd(means, quats, scales_exp, cam["viewmat"], cam["K"],
-                                                             W, H, 0.3, 0.01, 1e10, 0.0, False)
+        radii = torch.empty(1, N, dtype=torch.int32, device=dev)
+        means2d = torch.empty(1, N, 2, **f32)
+        depths = torch.empty(1, N, **f32)
+        conics = torch.empty(1, N, 3, **f32)
+        _run(lib.fsgs_project_fwd_act, (1, N, ptr(means), ptr(quats), ptr(scales), ptr(opacities), ptr(cam["viewmat"]),
+                                       ptr(cam["K"]), W, H, 0.3, 0.01, 1e10, 0.0, ptr(scales_exp), ptr(opac_sig),
+                                       ptr(radii), ptr(means2d), ptr(depths), ptr(conics), sp), "fsgs_project_fwd_act")
         # live emission: only (Gaussian, tile) pairs that can reach a pixel are binned and sorted; the
         # quadrant masks ride in the payload (gsplat's full lists are not an output of get_outputs)
         opac_row = opac_sig.view(1, N)
@@ -120,14 +123,12 @@ class _FusedGetOutputs(torch.autograd.Function):
                                      ptr(features_rest), ptr(radii), ptr(depths), ptr(colors), sp),
              "fsgs_sh_fwd_split")
         normals_world = torch.empty(N, 3, **f32)
-        normals_cam = torch.empty(N, 3, **f32)
-        _run(lib.fsgs_normals_fwd, (N, ptr(quats), ptr(scales), ptr(means), ptr(cam["c2w"]), ptr(normals_world),
-                                    ptr(normals_cam), sp), "fsgs_normals_fwd")
         packed = torch.empty(N, 16, **f32)
         n_cells = lib.fsgs_raster_quad_max_cells()
         max_last = torch.empty(n_cells, **f32)  # partial image maxima: zeroed by the pack kernel, raised by the forward
-        _run(lib.fsgs_live_pack, (4, N, ptr(means2d), ptr(conics), ptr(colors), ptr(opac_sig), ptr(normals_cam),
-                                 ptr(packed), ptr(max_last), n_cells, sp), "fsgs_live_pack", "_d4e3")
+        _run(lib.fsgs_live_pack_normals, (N, ptr(means2d), ptr(conics), ptr(colors), ptr(opac_sig), ptr(quats),
+                                         ptr(scales), ptr(means), ptr(cam["c2w"]), ptr(packed), ptr(normals_world),
+                                         ptr(max_last), n_cells, sp), "fsgs_live_pack_normals", "_d4e3")
         tpg, isect_ids, flatten_ids, offsets = ops.isect_finish_live(count, means2d, radii, depths, conics, opac_row,
                                                                      tw, th, want_ids=False)
         rule_diff = 0

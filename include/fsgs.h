@@ -278,6 +278,12 @@ int64_t fsgs_quad_seg_slots(int C, int tile_width, int tile_height, int64_t n_is
 int fsgs_live_pack(int D, int64_t n_gauss_total, const float *means2d, const float *conics,
                    const float *colors, const float *opacities, const float *extra, float *packed,
                    float *zero_cells /* nullable: n_zero floats set to 0 */, int n_zero, fsgs_stream_t stream);
+/* fsgs_live_pack (D = 4) whose extra plane is the camera-space normal of every Gaussian, computed in the
+ * same launch instead of by fsgs_normals_fwd; normals_world [N,3] is the side output (single camera). */
+int fsgs_live_pack_normals(int64_t N, const float *means2d, const float *conics, const float *colors,
+                           const float *opacities, const float *quats, const float *log_scales,
+                           const float *means, const float *c2w, float *packed, float *normals_world,
+                           float *zero_cells, int n_zero, fsgs_stream_t stream);
 int fsgs_live_payload(const int64_t *isect_ids, const int32_t *flatten_ids, int64_t n_isects,
                       const float *packed, int64_t n_gauss_total, int tile_width, int tile_bits,
                       int32_t *payload, fsgs_stream_t stream);
@@ -344,6 +350,13 @@ int fsgs_activate_fwd(int N, const float *log_scales, const float *opac_logit, f
 int fsgs_activate_bwd(int N, const float *scales, const float *opac, const float *v_scales,
                       const float *v_opac, const float *v_quats_a, const float *v_quats_b,
                       float *v_log_scales, float *v_opac_logit, float *v_quats, fsgs_stream_t stream);
+/* fsgs_project_fwd with the activations of dn_model.py:573-574 applied in the same launch:
+ * scales_out [N,3] = exp(log_scales), opac_out [N] = sigmoid(opac_logit); the projection uses scales_out. */
+int fsgs_project_fwd_act(int C, int N, const float *means, const float *quats, const float *log_scales,
+                         const float *opac_logit, const float *viewmats, const float *Ks, int width,
+                         int height, float eps2d, float near_plane, float far_plane, float radius_clip,
+                         float *scales_out, float *opac_out, int32_t *radii, float *means2d, float *depths,
+                         float *conics, fsgs_stream_t stream);
 /* The per-Gaussian tail of the fused backward in ONE launch (C == 1): reads each Gaussian's packed
  * gradient record (fsgs_raster_bwd_quad; cleared afterwards), applies the VJP of the projection
  * (as fsgs_project_bwd with v_means2d / v_conics / v_depths taken from the record), of the normal pass
