@@ -120,9 +120,10 @@ raster_fwd_quad_kernel(int64_t cap, const float4 *__restrict__ packed, const int
     for (int c0 = l0; c0 < l1; c0 += kQuadChunk) {
         const uint64_t bal = __ballot(live);
         const int before = __popcll(bal & ((1ull << lane) - 1ull));
+        const int wave_done = __all(done) ? 1 : 0;  // (a vote must not sit inside the lane-0 branch)
         if (lane == 0) {
             S.wcount[w] = __popcll(bal);
-            S.wdone[w] = __all(done) ? 1 : 0;
+            S.wdone[w] = wave_done;
         }
         __syncthreads();  // counts visible; the previous chunk's LDS reads are finished
         if (S.wdone[0] & S.wdone[1] & S.wdone[2] & S.wdone[3]) break;  // every pixel is opaque

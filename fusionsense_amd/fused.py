@@ -20,6 +20,7 @@ Everything goes through libfsgs.so; results are tested against the unfused path 
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, Optional
 
 import torch
@@ -85,6 +86,9 @@ def _grad_accumulator(dev, N: int) -> Tensor:
     if t is None or t.shape[0] != N:
         t = torch.zeros(N, 16, dtype=torch.float32, device=dev)
         _ACCUM[key] = t
+        if os.environ.get("FSGS_DEBUG_PTRS"):
+            import sys
+            print(f"[fsgs] grad accumulator N={N} at 0x{t.data_ptr():x}", file=sys.stderr)
     return t
 
 

@@ -8,6 +8,7 @@ all arithmetic happens in libfsgs.so.  There is no CPU fallback.
 from __future__ import annotations
 
 import ctypes as C
+import time
 import math
 from typing import Optional, Tuple
 
@@ -47,13 +48,14 @@ class _KernelTimer:
             if self.on:
                 self.start = torch.cuda.Event(enable_timing=True)
                 self.end = torch.cuda.Event(enable_timing=True)
+                self.h0 = time.perf_counter()
                 self.start.record()
             return self
 
         def __exit__(self, *exc):
             if self.on:
                 self.end.record()
-                self.timer.records.append((self.name, self.start, self.end))
+                self.timer.records.append((self.name, self.start, self.end, (time.perf_counter() - self.h0) * 1e3))
             return False
 
     def span(self, name: str):
@@ -64,12 +66,16 @@ class _KernelTimer:
             return {}
         torch.cuda.synchronize()
         acc = {}
-        for name, s, e in self.records:
+        for name, s, e, host_ms in self.records:
             t = s.elapsed_time(e)
-            a = acc.setdefault(name, [0.0, 0])
+            a = acc.setdefault(name, [0.0, 0, t, t, 0.0])
             a[0] += t
             a[1] += 1
-        return {k: {"avg_ms": round(v[0] / v[1], 4), "calls": v[1]} for k, v in sorted(acc.items())}
+            a[2] = min(a[2], t)
+            a[3] = max(a[3], t)
+            a[4] = max(a[4], host_ms)
+        return {k: {"avg_ms": round(v[0] / v[1], 4), "calls": v[1], "min_ms": round(v[2], 4), "max_ms": round(v[3], 4),
+                    "host_max_ms": round(v[4], 4)} for k, v in sorted(acc.items())}
 
 
 TIMER = _KernelTimer()
@@ -465,10 +471,11 @@ WORKSPACE = _Workspace()
 class _Rasterize(torch.autograd.Function):
     """rasterize_to_pixels.  D in {1,3,4}.
 
-    With ``isect_ids`` (the sorted keys) and tile_size 16 the compositing runs on "live lists":
-    an exact culling/compaction pre-pass (fsgs_live_prepare) followed by one-wave-per-8x8-quadrant
-    kernels over contiguous record streams; otherwise the generic tile kernels walk the raw lists.
-    Both give the same images, last_ids and gradients."""
+    With ``isect_ids`` (the sorted keys) and tile_size 16 the compositing runs on "live lists": every
+    list entry gets an exact 4-bit reach mask over the tile's 8x8 quadrants (fsgs_live_payload), and a
+    workgroup per quadrant filters, gathers and composites its entries (fsgs_raster_fwd_quad), leaving
+    the walked records behind for the segment-parallel backward; otherwise the generic tile kernels
+    walk the raw lists.  Both give the same images, last_ids and gradients."""
 
     @staticmethod
     def forward(ctx, means2d, conics, colors, opacities, backgrounds, isect_offsets, flatten_ids, width,
@@ -489,41 +496,41 @@ class _Rasterize(torch.autograd.Function):
         if normalize_last and not live:
             raise ValueError("normalize_last is implemented by the live-list kernels only")
         if live:
-            sbytes = lib.fsgs_live_scratch_bytes(M)
-            rec_bytes = 4 * max(M, 1) * 48
-            pos_bytes = (M + 1) * 16
             a = lambda n: (n + 255) // 256 * 256  # noqa: E731
             needs_bwd = any(ctx.needs_input_grad[:5])
-            seg_bytes = 4 * lib.fsgs_live_seg_slots(Cn, tw, th, M) * 64 * (1 + D) * 4 if needs_bwd else 0
-            arena = WORKSPACE.take(a(rec_bytes) + a(pos_bytes) + a(M + 1) + a(sbytes) + a(seg_bytes), dev)
-            records = arena[:rec_bytes].view(torch.float32)
-            pos4 = arena[a(rec_bytes):a(rec_bytes) + pos_bytes].view(torch.int32)
-            o = a(rec_bytes) + a(pos_bytes)
-            mask8 = arena[o:o + M + 1]
-            scratch = arena[o + a(M + 1):o + a(M + 1) + sbytes]
-            o2 = o + a(M + 1) + a(sbytes)
-            seg_state = arena[o2:o2 + seg_bytes].view(torch.float32) if needs_bwd else None
+            n_tiles = Cn * tw * th
             packed = torch.empty(Cn * N, 16, dtype=torch.float32, device=dev)
-            _run(lib.fsgs_live_prepare, (D, ptr(means2d), ptr(conics), ptr(colors), ptr(opacities), None, tw,
-                                        tile_bits(tw * th), ptr(isect_ids), ptr(flatten_ids), M, Cn * N,
-                                        ptr(packed), 0, ptr(mask8),
-                                        ptr(pos4), ptr(records), ptr(scratch), sbytes, stream_ptr(dev)),
-                 "fsgs_live_prepare", f"_d{D}")
-            _run(lib.fsgs_raster_fwd_live, (Cn, D, ptr(records), ptr(pos4), ptr(isect_offsets), M,
-                                           ptr(backgrounds), width, height, tw, th, int(normalize_last),
-                                           ptr(render), ptr(alphas), ptr(last_ids), ptr(seg_state), None, None,
-                                           stream_ptr(dev)),
-                 "fsgs_raster_fwd_live", f"_d{D}")
-            ctx.save_for_backward(records, pos4,
-                                  backgrounds if backgrounds is not None else torch.empty(0, device=dev),
-                                  isect_offsets, alphas, last_ids, render,
-                                  seg_state if seg_state is not None else torch.empty(0, device=dev))
-            # (grad mode is always off inside Function.forward: ask the tape, not torch.is_grad_enabled)
+            _run(lib.fsgs_live_pack, (D, Cn * N, ptr(means2d), ptr(conics), ptr(colors), ptr(opacities), None,
+                                     ptr(packed), None, 0, stream_ptr(dev)), "fsgs_live_pack", f"_d{D}")
+            # quadrant mask << 28 | flatten id for every entry of the caller's sorted lists
+            payload = torch.empty(max(M, 1), dtype=torch.int32, device=dev)
+            _run(lib.fsgs_live_payload, (ptr(isect_ids), ptr(flatten_ids), M, ptr(packed), Cn * N, tw,
+                                        tile_bits(tw * th), ptr(payload), stream_ptr(dev)), "fsgs_live_payload")
             if needs_bwd:
-                ctx.arena = arena  # returned to the pool at the end of backward
+                cap = lib.fsgs_quad_stream_capacity(Cn, tw, th, M)
+                rec_bytes = 4 * cap * 48
+                seg_bytes = 4 * lib.fsgs_quad_seg_slots(Cn, tw, th, M) * 64 * (1 + D) * 4
+                nrec_bytes = 4 * n_tiles * 4
+                arena = WORKSPACE.take(a(rec_bytes) + a(seg_bytes) + a(nrec_bytes), dev)
+                records = arena[:rec_bytes].view(torch.float32)
+                seg_state = arena[a(rec_bytes):a(rec_bytes) + seg_bytes].view(torch.float32)
+                o = a(rec_bytes) + a(seg_bytes)
+                n_rec = arena[o:o + nrec_bytes].view(torch.int32)
             else:
-                ctx.arena = None
-                WORKSPACE.give(arena)
+                arena = records = seg_state = n_rec = None
+            _run(lib.fsgs_raster_fwd_quad, (Cn, D, ptr(packed), ptr(payload), ptr(isect_offsets), M,
+                                           ptr(backgrounds), width, height, tw, th, int(normalize_last),
+                                           ptr(render), ptr(alphas), ptr(last_ids), ptr(records), ptr(n_rec),
+                                           ptr(seg_state), None, None, stream_ptr(dev)),
+                 "fsgs_raster_fwd_quad", f"_d{D}")
+            empty = torch.empty(0, device=dev)
+            ctx.save_for_backward(records if records is not None else empty,
+                                  n_rec if n_rec is not None else empty,
+                                  backgrounds if backgrounds is not None else empty,
+                                  isect_offsets, alphas, last_ids, render,
+                                  seg_state if seg_state is not None else empty)
+            # (grad mode is always off inside Function.forward: ask the tape, not torch.is_grad_enabled)
+            ctx.arena = arena  # returned to the pool at the end of backward
         else:
             _run(lib.fsgs_raster_fwd, (Cn, N, D, ptr(means2d), ptr(conics), ptr(colors), ptr(opacities),
                                       ptr(backgrounds), width, height, tile_size, tw, th, ptr(isect_offsets),
@@ -544,7 +551,7 @@ class _Rasterize(torch.autograd.Function):
         width, height, tile_size, absgrad, has_bg, live, Cn, N, D, M, normalize_last = ctx.dims
         lib = load()
         if live:
-            records, pos4, backgrounds, isect_offsets, alphas, last_ids, render, seg_state = ctx.saved_tensors
+            records, n_rec, backgrounds, isect_offsets, alphas, last_ids, render, seg_state = ctx.saved_tensors
         else:
             (means2d, conics, colors, opacities, backgrounds, isect_offsets, flatten_ids, alphas,
              last_ids) = ctx.saved_tensors
@@ -554,13 +561,13 @@ class _Rasterize(torch.autograd.Function):
         v_alphas = _c(v_alphas) if v_alphas is not None else torch.zeros(Cn, height, width, 1, device=dev)
         if live:
             v_packed = torch.zeros(Cn * N, 16, dtype=torch.float32, device=dev)
-            _run(lib.fsgs_raster_bwd_live, (Cn, D, ptr(records), ptr(pos4), ptr(isect_offsets), M,
+            _run(lib.fsgs_raster_bwd_quad, (Cn, D, ptr(records), ptr(n_rec), ptr(isect_offsets), M,
                                            ptr(backgrounds) if has_bg else None, width, height, tw, th,
                                            int(normalize_last), ptr(render), ptr(alphas), ptr(last_ids),
                                            ptr(v_render), ptr(v_alphas),
                                            ptr(seg_state), int(bool(absgrad)), None, None, ptr(v_packed),
                                            stream_ptr(dev)),
-                 "fsgs_raster_bwd_live", f"_d{D}")
+                 "fsgs_raster_bwd_quad", f"_d{D}")
             v_means2d = torch.empty(Cn, N, 2, dtype=torch.float32, device=dev)
             v_conics = torch.empty(Cn, N, 3, dtype=torch.float32, device=dev)
             v_colors = torch.empty(Cn, N, D, dtype=torch.float32, device=dev)
