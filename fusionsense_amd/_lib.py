@@ -41,11 +41,8 @@ SIGNATURES = {
     "fsgs_isect_offset_encode": (_i, [_i64, _p, _i, _i, _i, _p, _p]),
     "fsgs_raster_fwd": (_i, [_i, _i, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _i64, _p, _p, _p, _p]),
     "fsgs_raster_bwd": (_i, [_i, _i, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
-    "fsgs_live_scratch_bytes": (_sz, [_i64]),
-    "fsgs_live_prepare": (_i, [_i, _p, _p, _p, _p, _p, _i, _i, _p, _p, _i64, _i64, _p, _i, _p, _p, _p, _p, _sz, _p]),
     "fsgs_isect_count_live": (_i, [_i, _i, _p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _sz, C.POINTER(_i64), _p]),
     "fsgs_isect_emit_live": (_i, [_i, _i, _p, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p]),
-    "fsgs_live_seg_slots": (_i64, [_i, _i, _i, _i64]),
     "fsgs_tile_sort_max_tiles": (_i, []),
     "fsgs_tile_sort_scratch_bytes": (_sz, [_i64, _i]),
     "fsgs_tile_sort": (_i, [_i64, _p, _p, _i, _i, _i, _p, _p, _p, _p, _sz, _p]),
@@ -57,8 +54,6 @@ SIGNATURES = {
     "fsgs_live_payload": (_i, [_p, _p, _i64, _p, _i64, _i, _i, _p, _p]),
     "fsgs_raster_fwd_quad": (_i, [_i, _i, _p, _p, _p, _i64, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "fsgs_raster_bwd_quad": (_i, [_i, _i, _p, _p, _p, _i64, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p]),
-    "fsgs_raster_fwd_live": (_i, [_i, _i, _p, _p, _p, _i64, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p]),
-    "fsgs_raster_bwd_live": (_i, [_i, _i, _p, _p, _p, _i64, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p]),
     "fsgs_campos_from_viewmats": (_i, [_i, _p, _p, _p]),
     "fsgs_raster_unpack_grads": (_i, [_i64, _i, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p]),
     "fsgs_sh_fwd_split": (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p]),

@@ -1,20 +1,18 @@
-// E7 / E8 on live lists: front-to-back alpha compositing, forward and VJP, ONE wave64 per 8x8
-// pixel quadrant walking that quadrant's compacted record stream (see live.hip).  Same arithmetic
-// and the same results as the generic tile kernels in raster.hip (replaces
-// gsplat 1.0.0 `rasterize_to_pixels_{fwd,bwd}` for /root/reference/dn_splatter/dn_model.py:570-591
-// and the legacy rasterize_forward/backward for :644-653), for tile_size == 16.
+// E8 on live lists: the VJP of front-to-back alpha compositing over the per-quadrant record streams
+// that fsgs_raster_fwd_quad (raster_quad.hip) leaves behind.  Same arithmetic and the same results as
+// the generic tile kernel in raster.hip (replaces gsplat 1.0.0
+// `rasterize_to_pixels_bwd` for /root/reference/dn_splatter/dn_model.py:570-591 and the legacy
+// rasterize_backward for :644-653), for tile_size == 16.
 //
-// Per batch each lane loads ONE 48-byte record of the stream (three coalesced 16-byte loads, the
-// next batch is in flight while the current one is composited), parks it in the wave's LDS slot,
-// and the wave then iterates over the 64 records with broadcast LDS reads.  A workgroup is a
-// single wave: no cross-wave barriers, no tile-level early-exit protocol, ~4 tiles' worth of
-// independent waves per tile for latency hiding.
-// Backward: the 64 per-pixel partials of each gradient component are summed with DPP row ops;
-// the 12 totals are handed to lanes 0..11 through LDS and leave as ONE 12-lane
-// global_atomic_add_f32 into a packed 64-byte per-Gaussian record (one cache line), instead of
-// 12 single-lane atomics to five different arrays; fsgs_raster_unpack_grads splits the records.
+// A workgroup of four waves owns one 8x8 quadrant; wave w takes the 64-record segments w, w+4, ... of
+// the quadrant's stream independently (the forward saved every pixel's state at each segment end).
+// Per segment each lane loads one record (three or four coalesced 16-byte loads), parks it in its
+// wave's LDS slot, and the wave iterates over the records with broadcast LDS reads, one pixel per lane.
+// The 64 per-pixel partials of the 15 gradient components are summed with a TRANSPOSED row reduction
+// (common.h: 33 DPP adds instead of 60), the four rows meet through two lane permutes, and lanes
+// 0..14 issue ONE global_atomic_add_f32 into a packed 64-byte per-Gaussian record (one cache line),
+// instead of 15 single-lane atomics to six different arrays.
 #include "common.h"
-#include <cstdlib>
 
 namespace fsgs {
 
@@ -24,17 +22,11 @@ namespace fsgs {
 template <int E>
 struct QLds {
     float4 r0[64], r1[64], r2[64], r3[E ? 64 : 1];
-    float tot[4][16];  // per 16-lane row partial sums of the gradient components
 };
 
 struct Rec {
     float4 r0, r1, r2, r3;
 };
-
-#ifndef FSGS_FWD_GROUP
-#define FSGS_FWD_GROUP 4
-#endif
-constexpr int kFwdGroup = FSGS_FWD_GROUP;  // records composited per unrolled step of the forward (divides 64)
 
 template <int E>
 __device__ __forceinline__ void load_rec(Rec &r, const float4 *__restrict__ rec, int64_t p, bool ok) {
@@ -48,181 +40,6 @@ __device__ __forceinline__ void load_rec(Rec &r, const float4 *__restrict__ rec,
         r.r0 = make_float4(0.f, 0.f, 0.f, 0.f);
         r.r1 = r.r0; r.r2 = r.r0;
         if (E) r.r3 = r.r0;
-    }
-}
-
-template <int D, int E>
-__global__ void __launch_bounds__(64)
-raster_fwd_live_kernel(int64_t cap, const float4 *__restrict__ rec, const int4 *__restrict__ pos4,
-                       const int32_t *__restrict__ tile_offsets, int64_t n_isects,
-                       const float *__restrict__ backgrounds, int W, int H, int tw, int th,
-                       float *__restrict__ render, float *__restrict__ alphas,
-                       int32_t *__restrict__ last_ids, float *__restrict__ seg_state, int64_t seg_cap,
-                       int normalize_last, float *__restrict__ render_extra,
-                       float *__restrict__ max_last_partial, int n_cams, unsigned perm_stride, int abl,
-                       unsigned long long *__restrict__ dbg) {
-    __shared__ QLds<E> L;
-    const unsigned long long t_start = dbg ? __builtin_readcyclecounter() : 0;
-    const unsigned long long w_start = dbg ? wall_clock64() : 0;
-    constexpr int RS = E ? 4 : 3;
-    // All workgroups are resident at once and neighbouring quadrants have similar list lengths, so
-    // consecutive workgroup ids (which land on the same CU) are scattered over the image with a
-    // multiplicative permutation: every SIMD then gets a mixed sample of long and short lists.
-    const unsigned qid = (unsigned)(((uint64_t)blockIdx.x * perm_stride) % gridDim.x);
-    const int qx = qid % (2 * tw), qy = (qid / (2 * tw)) % (2 * th);
-    const int cam = qid / (4 * tw * th);
-    const int tile_x = qx >> 1, tile_y = qy >> 1;
-    const int q = ((qy & 1) << 1) | (qx & 1);
-    const int tile_lin = (cam * th + tile_y) * tw + tile_x;
-    const int n_tiles_total = n_cams * th * tw;
-    const int lane = threadIdx.x;
-    const int j = qx * 8 + (lane & 7), i = qy * 8 + (lane >> 3);
-    const float px = (float)j + 0.5f, py = (float)i + 0.5f;
-    const bool inside = (i < H) && (j < W);
-    bool done = !inside;
-
-    int s = 0, e = 0;
-    if (!(abl & 32)) {
-    const int64_t l0 = tile_offsets[tile_lin];
-    const int64_t l1 = (tile_lin == n_tiles_total - 1) ? n_isects : (int64_t)tile_offsets[tile_lin + 1];
-    const int4 p0 = pos4[l0], p1 = pos4[l1];
-    s = (q == 0) ? p0.x : (q == 1) ? p0.y : (q == 2) ? p0.z : p0.w;
-    e = (q == 0) ? p1.x : (q == 1) ? p1.y : (q == 2) ? p1.z : p1.w;
-    }
-    if (abl & 16) e = s;
-    const unsigned long long t_lists = dbg ? (__builtin_amdgcn_s_waitcnt(0), __builtin_readcyclecounter()) : 0;
-    int n_batches = 0;
-    const float4 *stream = rec + RS * ((int64_t)q * cap);
-
-    float T = 1.f;
-    int32_t cur_idx = 0;
-    float pix[D], pxe[E ? E : 1];
-#pragma unroll
-    for (int k = 0; k < D; ++k) pix[k] = 0.f;
-#pragma unroll
-    for (int k = 0; k < E; ++k) pxe[k] = 0.f;
-
-    // State of every pixel AFTER each 64-entry segment of this quadrant's list (= before the next
-    // one), for the segment-parallel backward: slot (b/64 + tile_lin) of stream q, b = the next
-    // segment's first stream position, is unique per (quadrant, segment).
-    constexpr int SS = 64 * (1 + D + E);  // floats per segment-state slot
-    float *seg_q = (seg_state && !(abl & 1)) ? seg_state + (int64_t)q * seg_cap * SS : nullptr;
-    Rec r;
-    load_rec<E>(r, stream, (int64_t)s + lane, s + lane < e && !(abl & 4));
-    for (int b = s; b < e; b += 64) {
-        // The kernel ends when its longest list does: waves with more of their list ahead of them
-        // get a higher issue priority, so the critical path runs at single-wave speed and the short
-        // lists fill the gaps.
-        if (!(abl & 64)) {
-            const int rem = (e - b + 63) >> 6;
-            if (rem >= 5) __builtin_amdgcn_s_setprio(3);
-            else if (rem >= 3) __builtin_amdgcn_s_setprio(2);
-            else if (rem >= 2) __builtin_amdgcn_s_setprio(1);
-            else __builtin_amdgcn_s_setprio(0);
-        }
-        __syncthreads();  // single wave: orders the previous batch's LDS reads before these writes
-        L.r0[lane] = r.r0; L.r1[lane] = r.r1; L.r2[lane] = r.r2;
-        if (E) L.r3[lane] = r.r3;
-        const int n = min(64, e - b);
-        load_rec<E>(r, stream, (int64_t)b + 64 + lane, b + 64 + lane < e && !(abl & 4));
-        __syncthreads();
-        // Records are taken kFwdGroup at a time with no per-record branching.  A wave walks its list
-        // alone, so its speed is set by the dependent chain LDS read -> sigma -> exp -> T; the LDS reads
-        // and the alphas of a group do not depend on T and are issued together, only the T chain
-        // (a multiply, a compare and three selects per record) stays serial.  A lane that is finished,
-        // or whose alpha is below 1/255, commits vis = 0.
-        const int ng = (abl & 2) ? 0 : ((n + kFwdGroup - 1) / kFwdGroup) * kFwdGroup;  // padding records are all-zero
-        for (int t = 0; t < ng; t += kFwdGroup) {
-            float4 A0[kFwdGroup], A1[kFwdGroup], CC[kFwdGroup], CE[kFwdGroup];
-#pragma unroll
-            for (int u = 0; u < kFwdGroup; ++u) {
-                A0[u] = L.r0[t + u]; A1[u] = L.r1[t + u]; CC[u] = L.r2[t + u];
-                if (E) CE[u] = L.r3[t + u];
-            }
-            float alpha[kFwdGroup];
-            bool pass[kFwdGroup];
-#pragma unroll
-            for (int u = 0; u < kFwdGroup; ++u) {
-                const float dx = A0[u].x - px, dy = A0[u].y - py;
-                const float sigma = 0.5f * (A0[u].w * dx * dx + A1[u].y * dy * dy) + A1[u].x * dx * dy;
-                alpha[u] = fminf(kAlphaMax, A0[u].z * __expf(-sigma));
-                pass[u] = !(sigma < 0.f) && !(alpha[u] < kAlphaMin);
-            }
-#pragma unroll
-            for (int u = 0; u < kFwdGroup; ++u) {
-                const bool live = !done && pass[u];
-                const float next_T = T * (1.f - alpha[u]);
-                const bool stop = live && (next_T <= kTMin);
-                done = done || stop;
-                const bool commit = live && !stop;
-                const float vis = commit ? alpha[u] * T : 0.f;
-                pix[0] += CC[u].x * vis;
-                if (D > 1) pix[1] += CC[u].y * vis;
-                if (D > 2) pix[2] += CC[u].z * vis;
-                if (D > 3) pix[D - 1] += CC[u].w * vis;
-                if (E) {
-                    pxe[0] += CE[u].x * vis;
-                    if (E > 1) pxe[1] += CE[u].y * vis;
-                    if (E > 2) pxe[E - 1] += CE[u].z * vis;
-                }
-                cur_idx = commit ? __float_as_int(A1[u].z) : cur_idx;
-                T = commit ? next_T : T;
-            }
-            if (__all(done)) break;
-        }
-        // written even when the wave stops early: the backward of THIS segment reads it
-        if (seg_q && b + 64 < e) {
-            float *slot = seg_q + ((int64_t)((b + 64) >> 6) + tile_lin) * SS;
-            slot[lane] = T;
-#pragma unroll
-            for (int k = 0; k < D; ++k) slot[64 * (1 + k) + lane] = pix[k];
-#pragma unroll
-            for (int k = 0; k < E; ++k) slot[64 * (1 + D + k) + lane] = pxe[k];
-        }
-        ++n_batches;
-        if (__all(done)) break;
-    }
-    const unsigned long long t_loop = dbg ? __builtin_readcyclecounter() : 0;
-
-    if (inside && !(abl & 8)) {
-        const int64_t pix_id = ((int64_t)cam * H + i) * W + j;
-        if (backgrounds) {
-#pragma unroll
-            for (int k = 0; k < D; ++k) pix[k] += T * backgrounds[cam * D + k];
-        }
-        if (normalize_last) pix[D - 1] = pix[D - 1] / fmaxf(1.f - T, 1e-10f);  // expected depth
-        if (D == 4) {
-            reinterpret_cast<float4 *>(render)[pix_id] = make_float4(pix[0], pix[1], pix[2], pix[D - 1]);
-        } else {
-#pragma unroll
-            for (int k = 0; k < D; ++k) render[pix_id * D + k] = pix[k];
-        }
-        if (E) {
-#pragma unroll
-            for (int k = 0; k < E; ++k) render_extra[pix_id * E + k] = pxe[k] + T;  // background = 1
-        }
-        alphas[pix_id] = 1.f - T;
-        last_ids[pix_id] = cur_idx;
-    }
-    if (dbg) {
-        const unsigned long long t_issued = __builtin_readcyclecounter();
-        __builtin_amdgcn_s_waitcnt(0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned long long t_done = __builtin_readcyclecounter();
-        if (lane == 0) {
-            unsigned long long *d = dbg + (size_t)blockIdx.x * 8;
-            d[0] = t_start; d[1] = t_lists; d[2] = t_loop; d[3] = t_issued; d[4] = t_done;
-            d[5] = ((unsigned long long)(e - s) << 40) | (w_start & 0xffffffffffull); d[6] = ((unsigned long long)n_batches << 40) | (wall_clock64() & 0xffffffffffull);
-            unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-            unsigned hwid; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-            d[7] = ((unsigned long long)xcc << 32) | hwid;
-        }
-    }
-    if (max_last_partial) {  // per-wave max of the (normalised) last channel, for depth_im's fill value
-        float m = inside ? pix[D - 1] : 0.f;
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d, 64));
-        if (lane == 0) max_last_partial[qid] = m;
     }
 }
 
@@ -246,7 +63,7 @@ constexpr int kBwdWaves = 4;
 
 template <int D, bool ABS, int E>
 __global__ void __launch_bounds__(64 * kBwdWaves)
-raster_bwd_live_kernel(int64_t cap, const float4 *__restrict__ rec, const int4 *__restrict__ pos4,
+raster_bwd_live_kernel(int64_t cap, const float4 *__restrict__ rec,
                        const int32_t *__restrict__ tile_offsets, int64_t n_isects,
                        const float *__restrict__ backgrounds, int W, int H, int tw, int th,
                        const float *__restrict__ render, const float *__restrict__ alphas,
@@ -272,16 +89,9 @@ raster_bwd_live_kernel(int64_t cap, const float4 *__restrict__ rec, const int4 *
 
     const int64_t l0 = tile_offsets[tile_lin];
     const int64_t l1 = (tile_lin == n_tiles_total - 1) ? n_isects : (int64_t)tile_offsets[tile_lin + 1];
-    int s, e;
-    if (n_rec) {
-        // streams written by fsgs_raster_fwd_quad: stream position l0 + 4 * tile, count from the forward
-        s = (int)l0 + 4 * tile_lin;
-        e = s + n_rec[(int64_t)q * n_tiles_total + tile_lin];
-    } else {
-        const int4 p0 = pos4[l0], p1 = pos4[l1];
-        s = (q == 0) ? p0.x : (q == 1) ? p0.y : (q == 2) ? p0.z : p0.w;
-        e = (q == 0) ? p1.x : (q == 1) ? p1.y : (q == 2) ? p1.z : p1.w;
-    }
+    // streams written by fsgs_raster_fwd_quad: stream position l0 + 4 * tile, record count from the forward
+    const int s = (int)l0 + 4 * tile_lin;
+    const int e = s + n_rec[(int64_t)q * n_tiles_total + tile_lin];
     const int n_seg = (e - s + 63) >> 6;
     if (w >= n_seg) return;
     const float4 *stream = rec + RS * ((int64_t)q * cap);
@@ -468,73 +278,10 @@ unpack_grads_kernel(int64_t total, int D, float4 *__restrict__ v_packed, int rez
 
 using namespace fsgs;
 
-// Segment-state slots per stream: one per 64-entry block of the stream plus one per tile (a
-// quadrant's first, partial block gets its own slot).
-extern "C" int64_t fsgs_live_seg_slots(int C, int tile_width, int tile_height, int64_t n_isects) {
-    return (n_isects >> 6) + (int64_t)C * tile_width * tile_height + 2;
-}
-
-static unsigned long long *g_fwd_dbg = nullptr;
-static long long g_fwd_dbg_n = 0;
-extern "C" long long fsgs_debug_fwd_dump(unsigned long long *host, long long cap) {
-    if (!g_fwd_dbg) return 0;
-    (void)hipDeviceSynchronize();
-    const long long n = g_fwd_dbg_n < cap ? g_fwd_dbg_n : cap;
-    (void)hipMemcpy(host, g_fwd_dbg, (size_t)n * 64, hipMemcpyDeviceToHost);
-    return n;
-}
-
-extern "C" int fsgs_raster_fwd_live(int C, int D, const float *records, const int32_t *pos4,
-                                    const int32_t *isect_offsets, int64_t n_isects, const float *backgrounds,
-                                    int width, int height, int tile_width, int tile_height, int normalize_last,
-                                    float *render, float *alphas, int32_t *last_ids, float *seg_state,
-                                    float *render_extra, float *max_last_partial, fsgs_stream_t stream) {
-    if (C < 0 || width < 0 || height < 0 || n_isects < 0) return FSGS_EINVAL;
-    if (C == 0 || width == 0 || height == 0) return FSGS_OK;
-    if (!pos4 || !isect_offsets || !render || !alphas || !last_ids || (n_isects > 0 && !records))
-        return FSGS_EINVAL;
-    hipStream_t s = as_stream(stream);
-    const int64_t n_quads = 4ll * tile_width * tile_height * C;
-    if (n_quads >= (1ll << 31)) return FSGS_EINVAL;
-    const dim3 grid((unsigned)n_quads);
-    // a stride coprime with the grid size makes  id -> id * stride mod n  a bijection
-    static const unsigned primes[] = {7919u, 7907u, 7901u, 7883u};
-    unsigned perm_stride = 1;
-    for (unsigned pr : primes)
-        if (n_quads % pr != 0) { perm_stride = pr; break; }
-    if (getenv("FSGS_FWD_NO_PERM")) perm_stride = 1;
-    const float4 *rec = reinterpret_cast<const float4 *>(records);
-    const int4 *p4 = reinterpret_cast<const int4 *>(pos4);
-    const int64_t seg_cap = fsgs_live_seg_slots(C, tile_width, tile_height, n_isects);
-    if (getenv("FSGS_FWD_DBG") && !g_fwd_dbg) {
-        (void)hipMalloc(&g_fwd_dbg, (size_t)n_quads * 64);
-        g_fwd_dbg_n = n_quads;
-    }
-    static const int abl = getenv("FSGS_FWD_ABL") ? atoi(getenv("FSGS_FWD_ABL")) : 0;
-    static const int lds_pad = getenv("FSGS_FWD_LDS_PAD") ? atoi(getenv("FSGS_FWD_LDS_PAD")) : 0;
-#define FSGS_FWD_LIVE(DD, EE)                                                                                     \
-    hipLaunchKernelGGL((raster_fwd_live_kernel<DD, EE>), grid, dim3(64), lds_pad, s, n_isects, rec, p4, isect_offsets,   \
-                       n_isects, backgrounds, width, height, tile_width, tile_height, render, alphas, last_ids,   \
-                       seg_state, seg_cap, normalize_last, render_extra, max_last_partial, C, perm_stride, abl, g_fwd_dbg)
-    if (render_extra) {
-        if (D != 4) return FSGS_EINVAL;  // the fused RGB+depth + normal-plane walk
-        FSGS_FWD_LIVE(4, 3);
-        return check_launch();
-    }
-    switch (D) {
-        case 1: FSGS_FWD_LIVE(1, 0); break;
-        case 3: FSGS_FWD_LIVE(3, 0); break;
-        case 4: FSGS_FWD_LIVE(4, 0); break;
-        default: return FSGS_EINVAL;
-    }
-#undef FSGS_FWD_LIVE
-    return check_launch();
-}
-
 extern "C" int64_t fsgs_quad_stream_capacity(int C, int tile_width, int tile_height, int64_t n_isects);
 extern "C" int64_t fsgs_quad_seg_slots(int C, int tile_width, int tile_height, int64_t n_isects);
 
-static int launch_bwd_live(int C, int D, const float *records, const int32_t *pos4, const int32_t *n_rec,
+static int launch_bwd_live(int C, int D, const float *records, const int32_t *n_rec,
                            int64_t cap, int64_t seg_cap, const int32_t *isect_offsets, int64_t n_isects,
                            const float *backgrounds, int width, int height, int tile_width, int tile_height,
                            int normalize_last, const float *render, const float *alphas, const int32_t *last_ids,
@@ -543,15 +290,14 @@ static int launch_bwd_live(int C, int D, const float *records, const int32_t *po
                            fsgs_stream_t stream) {
     if (C < 0 || width < 0 || height < 0 || n_isects < 0) return FSGS_EINVAL;
     if (C == 0 || width == 0 || height == 0 || n_isects == 0) return FSGS_OK;
-    if (!records || (!pos4 && !n_rec) || !isect_offsets || !render || !alphas || !last_ids || !v_render ||
+    if (!records || !n_rec || !isect_offsets || !render || !alphas || !last_ids || !v_render ||
         !v_alphas || !seg_state || !v_packed)
         return FSGS_EINVAL;
     hipStream_t s = as_stream(stream);
     const dim3 grid(2 * tile_width, 2 * tile_height, C);
     const float4 *rec = reinterpret_cast<const float4 *>(records);
-    const int4 *p4 = reinterpret_cast<const int4 *>(pos4);
 #define FSGS_BWD_LIVE(DD, AA, EE)                                                                                \
-    hipLaunchKernelGGL((raster_bwd_live_kernel<DD, AA, EE>), grid, dim3(64 * kBwdWaves), 0, s, cap, rec, p4,      \
+    hipLaunchKernelGGL((raster_bwd_live_kernel<DD, AA, EE>), grid, dim3(64 * kBwdWaves), 0, s, cap, rec,          \
                        isect_offsets, n_isects, backgrounds, width, height, tile_width, tile_height, render,      \
                        alphas, last_ids, v_render, v_alphas, seg_state, seg_cap, v_packed, normalize_last,         \
                        render_extra, v_render_extra, n_rec)
@@ -570,23 +316,6 @@ static int launch_bwd_live(int C, int D, const float *records, const int32_t *po
     return check_launch();
 }
 
-extern "C" int fsgs_raster_bwd_live(int C, int D, const float *records, const int32_t *pos4,
-                                    const int32_t *isect_offsets, int64_t n_isects, const float *backgrounds,
-                                    int width, int height, int tile_width, int tile_height, int normalize_last,
-                                    const float *render, const float *alphas, const int32_t *last_ids,
-                                    const float *v_render,
-                                    const float *v_alphas, const float *seg_state, int with_abs,
-                                    const float *render_extra, const float *v_render_extra,
-                                    float *v_packed, fsgs_stream_t stream) {
-    if (n_isects > 0 && !pos4) return FSGS_EINVAL;
-    return launch_bwd_live(C, D, records, pos4, nullptr, n_isects,
-                           fsgs_live_seg_slots(C, tile_width, tile_height, n_isects), isect_offsets, n_isects,
-                           backgrounds, width, height, tile_width, tile_height, normalize_last, render, alphas,
-                           last_ids, v_render, v_alphas, seg_state, with_abs, render_extra, v_render_extra,
-                           v_packed, stream);
-}
-
-// the same backward over the streams written by fsgs_raster_fwd_quad (records + n_rec)
 extern "C" int fsgs_raster_bwd_quad(int C, int D, const float *records, const int32_t *n_rec,
                                     const int32_t *isect_offsets, int64_t n_isects, const float *backgrounds,
                                     int width, int height, int tile_width, int tile_height, int normalize_last,
@@ -595,7 +324,7 @@ extern "C" int fsgs_raster_bwd_quad(int C, int D, const float *records, const in
                                     int with_abs, const float *render_extra, const float *v_render_extra,
                                     float *v_packed, fsgs_stream_t stream) {
     if (n_isects > 0 && !n_rec) return FSGS_EINVAL;
-    return launch_bwd_live(C, D, records, nullptr, n_rec,
+    return launch_bwd_live(C, D, records, n_rec,
                            fsgs_quad_stream_capacity(C, tile_width, tile_height, n_isects),
                            fsgs_quad_seg_slots(C, tile_width, tile_height, n_isects), isect_offsets, n_isects,
                            backgrounds, width, height, tile_width, tile_height, normalize_last, render, alphas,

@@ -138,7 +138,7 @@ int fsgs_bucket_fill_sort(int C, int N, const float *means2d, const int32_t *rad
 
 /* Live emission (tile_size 16; used by the fused get_outputs node, where gsplat's full lists are not
  * an output): a (Gaussian, tile) pair is counted / emitted only if the Gaussian can reach one of the
- * tile's 8x8 quadrants at alpha >= 1/255 (the same conservative test as fsgs_live_prepare), and the
+ * tile's 8x8 quadrants at alpha >= 1/255 (the same conservative test as fsgs_live_payload), and the
  * payload is  quadrant_mask << 28 | flatten_id  (C*N < 2^28).  tiles_per_gauss is still gsplat's
  * rectangle count.  Everything downstream (sort, offsets, prepare) then works on ~1/4 of the entries.
  * n_live_host: the live total, read back with a stream synchronisation; NULL = no read-back and no
@@ -196,82 +196,39 @@ int fsgs_raster_bwd(int C, int N, int D, const float *means2d, const float *coni
                     float *v_conics, float *v_colors, float *v_opacities, fsgs_stream_t stream);
 
 /* ---- E7 / E8 fast path (tile_size == 16): "live lists" ----------------------------------------
- * An exact culling + compaction pass between binning and compositing (csrc/live.hip).  For every
- * entry of the sorted tile lists it decides which of the tile's four 8x8 quadrants the Gaussian
- * can reach at alpha >= 1/255 and writes one self-contained 48-byte record per reached quadrant
- * into that quadrant's stream (depth order preserved).  Results of compositing are identical to
- * fsgs_raster_fwd/bwd on the raw lists; `meta` lists are untouched.
- *   mask8[M+1] u8, pos4[(M+1)*4] i32 (exclusive prefix sums of the 4 mask bits; pos4[M] = totals),
- *   records[4*M*12] f32 (stream q starts at record q*M; record = 3 x float4:
- *   {x,y,opacity,conic.a} {conic.b,conic.c,bits(list index),bits(flatten id)} {colour, zero padded}). */
-size_t fsgs_live_scratch_bytes(int64_t n_isects);
-/* extra (nullable): a second per-Gaussian 3-vector [C*N,3] (FusionSense's camera-space normals)
- * carried in a 4th float4 of every record, so that RGB+depth and the normal plane are composited
- * in ONE walk (records then take 64 B; records buffer = 4*M*16 floats). */
-int fsgs_live_prepare(int D, const float *means2d, const float *conics, const float *colors,
-                      const float *opacities, const float *extra, int tile_width, int tile_bits,
-                      const int64_t *isect_ids,
-                      const int32_t *flatten_ids, int64_t n_isects, int64_t n_gauss_total,
-                      float *packed, int masks_in_payload, uint8_t *mask8, int32_t *pos4, float *records,
-                      void *scratch, size_t scratch_bytes, fsgs_stream_t stream);
-/* masks_in_payload != 0: flatten_ids come from fsgs_isect_emit_live (mask << 28 | id); they are split
- * IN PLACE into mask8 and clean ids instead of running the list-order mask kernel. */
-/* packed (nullable scratch, n_gauss_total = C*N rows of 16 floats): when given, every Gaussian's
- * attributes are first packed into one 64-B line so that the list-order kernels gather one line
- * per entry instead of 5-7 scattered pieces. */
-/* seg_state (nullable for inference): 4 * fsgs_live_seg_slots(...) * 64 * (1+D) floats; the forward
- * stores every pixel's (T, accumulated colour) before each 64-entry segment of its quadrant list
- * so that the backward can process segments independently. */
-int64_t fsgs_live_seg_slots(int C, int tile_width, int tile_height, int64_t n_isects);
-/* normalize_last != 0 implements render_mode "ED"/"RGB+ED" in-kernel: the last channel leaves as
- * accumulated / max(alpha, 1e-10) (gsplat does this with three torch ops after the kernel), and
- * the backward expects v_render's last channel to be the gradient of that normalised value. */
-int fsgs_raster_fwd_live(int C, int D, const float *records, const int32_t *pos4,
-                         const int32_t *isect_offsets, int64_t n_isects, const float *backgrounds,
-                         int width, int height, int tile_width, int tile_height, int normalize_last,
-                         float *render, float *alphas, int32_t *last_ids, float *seg_state,
-                         float *render_extra, float *max_last_partial, fsgs_stream_t stream);
-/* render_extra[C,H,W,3] (nullable; needs records prepared with `extra`, D == 4): the extra plane
- * composited over a background of ones, exactly what gsplat.rasterize_gaussians returns for it.
- * max_last_partial[C*2th*2tw] (nullable): per-quadrant maxima of the last output channel
- * (FusionSense fills empty depth pixels with the image maximum, dn_model.py:611-613).
- * seg_state then holds 64*(1+D+3) floats per slot. */
-/* v_packed[C*N,16] f32, ACCUMULATED with atomics (zero it first): per (camera, Gaussian)
- * [0..3] v_colors [4..6] v_conics [7..8] v_means2d [9..10] v_means2d_abs [11] v_opacities
- * [12..14] v_extra.  The extra plane's gradient reaches conics / opacities / its own colours but NOT
- * v_means2d / v_means2d_abs (the reference detaches xys for that pass, dn_model.py:638). */
-int fsgs_raster_bwd_live(int C, int D, const float *records, const int32_t *pos4,
-                         const int32_t *isect_offsets, int64_t n_isects, const float *backgrounds,
-                         int width, int height, int tile_width, int tile_height, int normalize_last,
-                         const float *render, const float *alphas, const int32_t *last_ids,
-                         const float *v_render, const float *v_alphas, const float *seg_state,
-                         int with_abs, const float *render_extra, const float *v_render_extra,
-                         float *v_packed, fsgs_stream_t stream);
-/* ---- Sort + offsets for live lists as a partition by tile plus a sort inside every tile's bucket
- * (same results, bit for bit, as fsgs_sort_pairs on the key bits + fsgs_isect_offset_encode; replaces
- * the same reference calls).  isect_ids [n] are the UNSORTED keys cam|tile|depth-bits of
- * fsgs_isect_emit_live, payload [n] = quadrant mask << 28 | flatten id.  Outputs: isect_offsets
- * [C*th*tw + 1] (last entry = n), payload_sorted [n], isect_ids_sorted [n] (nullable).
- * C*th*tw <= fsgs_tile_sort_max_tiles().  Any bucket size is handled (LDS up to 8192 entries per tile,
- * in place beyond that: slow — use fsgs_sort_pairs when tiles are that dense). */
-int fsgs_tile_sort_max_tiles(void);
-size_t fsgs_tile_sort_scratch_bytes(int64_t n, int n_tiles_total);
-int fsgs_tile_sort(int64_t n, const int64_t *isect_ids, const int32_t *payload, int C, int tile_width,
-                   int tile_height, int32_t *isect_offsets, int32_t *payload_sorted,
-                   int64_t *isect_ids_sorted, void *scratch, size_t scratch_bytes, fsgs_stream_t stream);
-
-/* ---- Second-generation live forward: filter + per-quadrant compaction + compositing in one kernel
- * (same reference functions as fsgs_raster_fwd_live; tile_size 16).  A workgroup of four waves owns an
- * 8x8 quadrant, reads the tile's sorted list itself and composites 16 pixels x 4 records per step.
+ * (csrc/live.hip, raster_quad.hip, raster_live.hip; same reference functions as fsgs_raster_fwd/bwd:
+ * gsplat 1.0.0 rasterize_to_pixels_{fwd,bwd} for dn_model.py:570-591 and the legacy
+ * rasterize_forward/backward behind gsplat.rasterize_gaussians for dn_model.py:644-653.)
+ * Every entry of the sorted tile lists carries an exact 4-bit mask of the tile's 8x8 quadrants the
+ * Gaussian can reach at alpha >= 1/255.  A workgroup of four waves owns one quadrant: it reads the
+ * tile's list itself, keeps the entries with its bit, gathers their 64-byte line from the packed
+ * per-Gaussian table and composites 16 pixels x 4 consecutive records per step (quad prefix products
+ * for the transmittance chain); the walked records are streamed out once for the segment-parallel
+ * backward.  Results equal fsgs_raster_fwd/bwd on the raw lists; `meta` lists are untouched.
  *   packed   [C*N,16] f32 from fsgs_live_pack: {x,y,opacity,conic.a}{conic.b,conic.c,-,-}{colour[4]}{extra[3],-}
  *   payload  [M] i32: (quadrant mask << 28) | flatten id — what fsgs_isect_emit_live writes, or
  *            fsgs_live_payload from plain lists (so C*N < 2^28)
  *   records  4 * fsgs_quad_stream_capacity(...) * (render_extra ? 16 : 12) floats, n_rec [4, C*th*tw] i32:
  *            the walked part of every quadrant's list, written for fsgs_raster_bwd_quad (both nullable
- *            together for inference); seg_state: 4 * fsgs_quad_seg_slots(...) * 64 * (1+D+E) floats
+ *            together for inference).  Record = {x,y,opacity,conic.a} {conic.b,conic.c,bits(list index),
+ *            bits(flatten id)} {colour, zero padded} [{extra xyz,-}]
+ *   seg_state (nullable for inference) 4 * fsgs_quad_seg_slots(...) * 64 * (1+D+E) floats: every pixel's
+ *            (T, accumulated colour) after each 64-record segment of its quadrant's stream, so that the
+ *            backward can process segments independently
+ *   render_extra [C,H,W,3] (nullable, D == 4): a second per-Gaussian 3-vector (FusionSense's camera-space
+ *            normals, the 4th float4 of the packed line) composited in the SAME walk over a background of
+ *            ones — what gsplat.rasterize_gaussians returns for it; E = 3 then, else 0
  *   max_last [fsgs_raster_quad_max_cells()] (nullable): partial maxima of the last output channel, raised
  *            with atomics — zero them first (fsgs_live_pack does); feed fsgs_epilogue_fwd with
- *            n_partial = -fsgs_raster_quad_max_cells(). */
+ *            n_partial = -fsgs_raster_quad_max_cells() (dn_model.py:611-613 fills empty depth pixels with
+ *            the image maximum)
+ *   normalize_last != 0 implements render_mode "ED"/"RGB+ED" in-kernel: the last channel leaves as
+ *            accumulated / max(alpha, 1e-10) (gsplat does this with three torch ops after the kernel), and
+ *            the backward expects v_render's last channel to be the gradient of that normalised value.
+ *   v_packed [C*N,16] f32, ACCUMULATED with atomics (zero it first): per (camera, Gaussian)
+ *            [0..3] v_colors [4..6] v_conics [7..8] v_means2d [9..10] v_means2d_abs [11] v_opacities
+ *            [12..14] v_extra.  The extra plane's gradient reaches conics / opacities / its own colours but
+ *            NOT v_means2d / v_means2d_abs (the reference detaches xys for that pass, dn_model.py:638). */
 int fsgs_raster_quad_max_cells(void);
 int64_t fsgs_quad_stream_capacity(int C, int tile_width, int tile_height, int64_t n_isects);
 int64_t fsgs_quad_seg_slots(int C, int tile_width, int tile_height, int64_t n_isects);
@@ -300,6 +257,19 @@ int fsgs_raster_bwd_quad(int C, int D, const float *records, const int32_t *n_re
                          const float *v_render, const float *v_alphas, const float *seg_state,
                          int with_abs, const float *render_extra, const float *v_render_extra,
                          float *v_packed, fsgs_stream_t stream);
+/* ---- Sort + offsets for live lists as a partition by tile plus a sort inside every tile's bucket
+ * (same results, bit for bit, as fsgs_sort_pairs on the key bits + fsgs_isect_offset_encode; replaces
+ * the same reference calls).  isect_ids [n] are the UNSORTED keys cam|tile|depth-bits of
+ * fsgs_isect_emit_live, payload [n] = quadrant mask << 28 | flatten id.  Outputs: isect_offsets
+ * [C*th*tw + 1] (last entry = n), payload_sorted [n], isect_ids_sorted [n] (nullable).
+ * C*th*tw <= fsgs_tile_sort_max_tiles().  Any bucket size is handled (LDS up to 8192 entries per tile,
+ * in place beyond that: slow — use fsgs_sort_pairs when tiles are that dense). */
+int fsgs_tile_sort_max_tiles(void);
+size_t fsgs_tile_sort_scratch_bytes(int64_t n, int n_tiles_total);
+int fsgs_tile_sort(int64_t n, const int64_t *isect_ids, const int32_t *payload, int C, int tile_width,
+                   int tile_height, int32_t *isect_offsets, int32_t *payload_sorted,
+                   int64_t *isect_ids_sorted, void *scratch, size_t scratch_bytes, fsgs_stream_t stream);
+
 /* Split packed gradient records into the five gsplat-shaped arrays (written, not accumulated).
  * rezero != 0: v_packed is cleared after it has been read, ready for the next frame's atomics. */
 int fsgs_raster_unpack_grads(int64_t total, int D, float *v_packed, int rezero, float *v_means2d,
@@ -372,7 +342,7 @@ int fsgs_gaussian_bwd(int N, const float *means, const float *quats, const float
                       fsgs_stream_t stream);
 /* dn_model.py:602-613, 655-656: rgb = clamp(render[:3] + (1-alpha) bg, 0, 1); depth = alpha > 0 ?
  * render[3] : max(render[3]); normal = (n/|n| + 1)/2.  render [P,4], alphas [P], render_extra [P,3],
- * bg [3]; n_partial > 0: max_last_partial [n_partial] (fsgs_raster_fwd_live) is reduced into max_last[0]
+ * bg [3]; n_partial > 0: max_last_partial [n_partial] (per-workgroup partial maxima) is reduced into max_last[0]
  * first; n_partial <= 0: max_last already holds max(1, -n_partial) partial maxima.  bwd: any of v_rgb / v_depth / v_normal /
  * v_alpha_in may be NULL (= zero); writes v_render [P,4], v_alphas [P], v_render_extra [P,3]. */
 int fsgs_epilogue_fwd(int64_t n_pixels, const float *render, const float *alphas,
