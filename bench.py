@@ -51,7 +51,7 @@ def parse():
     ap.add_argument("--unfused-caller", action="store_true",
                     help="drive the rasterizer through the drop-in rasterization()/rasterize_gaussians() "
                          "surface with the reference's op-by-op caller glue instead of the fused get_outputs node")
-    ap.add_argument("--cpu-crop", type=int, default=128, help="CPU-baseline sample: central crop edge")
+    ap.add_argument("--cpu-crop", type=int, default=400, help="CPU-baseline sample: central crop edge")
     ap.add_argument("--cpu-timeout", type=float, default=150.0)
     ap.add_argument("--cpu-threads", type=int, default=8)
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
@@ -109,6 +109,21 @@ def cpu_baseline(args):
     except subprocess.TimeoutExpired:
         return {"value": None, "unit": "iters/s", "cores": threads, "kind": "port",
                 "sample": f"oracle child exceeded {args.cpu_timeout}s on a {args.cpu_crop}^2 crop"}
+
+
+def pmc_record(kernel_key):
+    """Counters of a kernel from the committed PMC run (profiles/pmc_traffic.json), or {}."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f).get(kernel_key, {}) or {}
+    except (OSError, ValueError):
+        return {}
+
+
+def pmc_traffic(kernel_key):
+    """HBM bytes per launch of a kernel from the committed PMC run, or None."""
+    return pmc_record(kernel_key).get("hbm_bytes_per_launch")
 
 
 def main():
@@ -181,7 +196,7 @@ def main():
     # ---- timed region: EXACTLY args.steps full iterations ----
     # inside the timed region only the heavy kernels are event-timed (roofline); the complete
     # per-kernel table is taken in a separate, untimed pass below
-    ops.TIMER.reset(enabled=True, only=("raster_", "sort_pairs", "live_prepare"))
+    ops.TIMER.reset(enabled=True, only=("raster_", "sort_pairs", "tile_sort"))
     # keep the interpreter's cyclic collector out of the timed region (a generation-2 pass costs tens of ms).
     # No gc.collect() here: freeing the setup's garbage right now reshuffles the caching allocator's pools and
     # was measured to cost 7 % in the steps that follow.
@@ -264,16 +279,17 @@ def main():
         # dominant kernel = the libfsgs launch with the largest share of the step; algorithmic bytes
         # per launch from the per-unit figures of SURVEY.md §8d
         alg = {
-            "raster_bwd_live_d4e3": ("raster_bwd_live_kernel<4,true,3> (RGB+ED and normal plane, one walk)",
+            "raster_bwd_quad_d4e3": ("raster_bwd_live_kernel<4,true,3> (RGB+ED and normal plane, one walk)",
                                      M * (44 + 40) + P * (28 + 20) + n_vis * (48 + 28)),
-            "raster_fwd_live_d4e3": ("raster_fwd_live_kernel<4,3>", M * (44 + 40) + P * (24 + 20)),
-            "raster_bwd_live_d4": ("raster_bwd_live_kernel<4,true,0>", M * 44 + P * 28 + n_vis * 48),
-            "raster_bwd_live_d3": ("raster_bwd_live_kernel<3,false,0>", M * 40 + P * 20 + n_vis * 28),
-            "raster_fwd_live_d4": ("raster_fwd_live_kernel<4,0>", M * 44 + P * 24),
-            "raster_fwd_live_d3": ("raster_fwd_live_kernel<3,0>", M * 40 + P * 20),
+            "raster_fwd_quad_d4e3": ("raster_fwd_quad_kernel<4,3> (filter + gather + composite, RGB+ED and normal plane)",
+                                     M * (44 + 40) + P * (24 + 20)),
+            "raster_bwd_quad_d4": ("raster_bwd_live_kernel<4,true,0>", M * 44 + P * 28 + n_vis * 48),
+            "raster_bwd_quad_d3": ("raster_bwd_live_kernel<3,false,0>", M * 40 + P * 20 + n_vis * 28),
+            "raster_fwd_quad_d4": ("raster_fwd_quad_kernel<4,0>", M * 44 + P * 24),
+            "raster_fwd_quad_d3": ("raster_fwd_quad_kernel<3,0>", M * 40 + P * 20),
             "raster_bwd_d4": ("raster_bwd_kernel<4,true>", M * 44 + P * 28 + n_vis * 48),
             "sort_pairs": ("radix sort (hist + scan + scatter per 8-bit pass)", M * sort_b),
-            "live_prepare_d4e3": ("live_mask + scan4 + live_compact", M * (12 + 28) + int(0.42 * M) * 64),
+            "tile_sort": ("partition by tile + per-tile LDS sort", M * sort_b),
         }
         cand = [(v["avg_ms"] * v["calls"], k) for k, v in kernel_ms.items() if k in alg]
         roofline = None
@@ -284,9 +300,17 @@ def main():
             ach = dom_bytes / (dom_ms * 1e-3) / 1e9
             roofline = {"kernel": name, "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
-                        # PMC counters cannot be read from inside the timed process; the rocprofv3 --pmc
-                        # FETCH_SIZE / WRITE_SIZE figures for this kernel are in profiles/ 
-                        "traffic": None, "algorithmic_bytes": dom_bytes, "avg_launch_ms": round(dom_ms, 4)}
+                        # PMC counters cannot be read from inside the timed process: `traffic` is the
+                        # rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE figure (bytes per launch, gfx950-corrected)
+                        # of this kernel from the committed run in profiles/ (DESIGN.md §5), null if absent
+                        "traffic": pmc_traffic(dom), "algorithmic_bytes": dom_bytes,
+                        "avg_launch_ms": round(dom_ms, 4)}
+            # the compositing kernels are bound by fp32 VALU issue, not by HBM (the contract's `bound` has no
+            # such value): say how busy the vector ALUs are, from the committed SQ counters and THIS run's time
+            q = pmc_record(dom).get("sq_active_inst_valu_quadcycles_per_launch")
+            if q:
+                roofline["valu_busy_frac"] = round(4.0 * q / (1024 * dom_ms * 1e-3 * 2.4e9), 4)
+                roofline["limiter"] = "fp32 VALU issue (see DESIGN.md 5)"
         line = {
             "metric": "train_iters_per_s",
             "value": round(iters_per_s, 3),

@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Per-kernel averages of rocprofv3 --pmc counter_collection CSVs (one or more passes) as CSV, plus the
+HBM traffic per launch that bench.py reports as `roofline.traffic`.
+
+Usage: tools/pmc_summary.py OUT_CSV OUT_JSON counter_collection.csv [more.csv ...]
+
+Traffic model (MI355X_MICROARCH.md, HBM section): FETCH_SIZE and WRITE_SIZE are in KB; on gfx950
+FETCH_SIZE tallies 128-byte requests at 64 B, so it is doubled; WRITE_SIZE is taken as reported."""
+import collections
+import csv
+import json
+import sys
+
+# kernel symbol -> bench.py span key (several symbols may share a span)
+SPAN = [
+    ("raster_bwd_live_kernel<4, true, 3>", "raster_bwd_quad_d4e3"),
+    ("raster_fwd_quad_kernel<4, 3>", "raster_fwd_quad_d4e3"),
+    ("tile_hist_kernel", "tile_sort"), ("tile_scan_kernel2", "tile_sort"), ("tile_offsets_kernel", "tile_sort"),
+    ("tile_scatter_kernel", "tile_sort"), ("tile_sort_kernel2", "tile_sort"),
+    ("adam_kernel", "adam_step"), ("sh_bwd_kernel", "sh_bwd_split"), ("sh_fwd_kernel", "sh_fwd_split"),
+    ("ssim_l1_fwd_kernel", "ssim_l1_fwd"), ("ssim_l1_bwd_kernel", "ssim_l1_bwd"),
+    ("project_bwd_kernel<true>", "gaussian_bwd"), ("project_fwd_kernel<true>", "project_fwd_act"),
+    ("isect_live_flat_kernel<false>", "isect_count_live"), ("isect_live_flat_kernel<true>", "isect_emit_live"),
+    ("live_pack_kernel", "live_pack_normals_d4e3"),
+]
+
+
+def main():
+    out_csv, out_json, files = sys.argv[1], sys.argv[2], sys.argv[3:]
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for f in files:
+        for r in csv.DictReader(open(f)):
+            acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    counters = sorted({c for d in acc.values() for c in d})
+    with open(out_csv, "w", newline="") as fh:
+        w = csv.writer(fh)
+        w.writerow(["kernel", "launches"] + [c + "_avg" for c in counters])
+        for k, d in sorted(acc.items()):
+            if "fsgs" not in k:
+                continue
+            n = max(len(v) for v in d.values())
+            w.writerow([k.split("(")[0], n] + [round(sum(d[c]) / len(d[c]), 3) if d[c] else "" for c in counters])
+    traffic = collections.defaultdict(lambda: {"fetch_kb": 0.0, "write_kb": 0.0})
+    for k, d in acc.items():
+        for sym, span in SPAN:
+            if sym in k:
+                # launches per step differ between symbols of one span: normalise by the span's dominant launch count
+                f = d.get("FETCH_SIZE", [])
+                wv = d.get("WRITE_SIZE", [])
+                traffic[span]["fetch_kb"] += sum(f)
+                traffic[span]["write_kb"] += sum(wv)
+                traffic[span].setdefault("n", 0)
+                traffic[span]["n"] = max(traffic[span]["n"], len(f), len(wv))
+                break
+    out = {}
+    for span, t in traffic.items():
+        if not t.get("n"):
+            continue  # this pass did not collect FETCH_SIZE / WRITE_SIZE
+        n = max(t.get("n", 1), 1)
+        # tile_sort: 6 launches per call, 5 different symbols -> calls = launches of the histogram kernel
+        if span == "tile_sort":
+            n = max(len(d.get("FETCH_SIZE", d.get("WRITE_SIZE", []))) for k, d in acc.items() if "tile_hist_kernel" in k)
+        fetch_b = 2.0 * t["fetch_kb"] * 1024.0 / n
+        write_b = t["write_kb"] * 1024.0 / n
+        out[span] = {"fetch_bytes_per_launch": round(fetch_b), "write_bytes_per_launch": round(write_b),
+                     "hbm_bytes_per_launch": round(fetch_b + write_b), "launches_sampled": n}
+    json.dump(out, open(out_json, "w"), indent=1, sort_keys=True)
+
+
+if __name__ == "__main__":
+    main()
