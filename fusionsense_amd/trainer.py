@@ -60,8 +60,12 @@ class GradSlab:
 
     def all_reduce_mean_(self, group=None) -> None:
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
-            self.flat.mul_(1.0 / dist.get_world_size(group))
+            if dist.get_backend(group) == "nccl":
+                # RCCL averages inside the collective: no extra 2 x 236 B/Gaussian scaling pass
+                dist.all_reduce(self.flat, op=dist.ReduceOp.AVG, group=group)
+            else:
+                dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+                self.flat.mul_(1.0 / dist.get_world_size(group))
 
 
 class SplatTrainer:
