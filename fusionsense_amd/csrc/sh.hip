@@ -382,6 +382,7 @@ extern "C" int fsgs_sh_fwd(int C, int N, int K, int degree, const float *means, 
 extern "C" int fsgs_sh_fwd_split(int C, int N, int K, int degree, const float *means, const float *campos,
                                  const float *features_dc, const float *features_rest, const int32_t *radii,
                                  const float *depths, float *colors_out, fsgs_stream_t stream) {
+    if (C >= 0 && N >= 0 && (int64_t)C * N == 0) return FSGS_OK;  // (empty tensors have no address)
     if (!features_rest && K > 1) return FSGS_EINVAL;
     return sh_fwd_impl(C, N, K, degree, means, campos, features_dc, features_rest ? features_rest : features_dc,
                        radii, depths, colors_out, stream);
@@ -420,6 +421,7 @@ extern "C" int fsgs_sh_bwd_split(int C, int N, int K, int degree, const float *m
                                  const float *features_dc, const float *features_rest, const int32_t *radii,
                                  int D, const float *v_colors, float *v_features_dc, float *v_features_rest,
                                  float *v_means, float *v_depths, int overwrite_means, fsgs_stream_t stream) {
+    if (C >= 0 && N == 0) return FSGS_OK;  // (empty tensors have no address)
     if ((!features_rest || !v_features_rest) && K > 1) return FSGS_EINVAL;
     return sh_bwd_impl(C, N, K, degree, means, campos, features_dc, features_rest ? features_rest : features_dc,
                        radii, D, v_colors, v_features_dc, v_features_rest ? v_features_rest : v_features_dc,
