@@ -19,27 +19,28 @@
 
 namespace fsgs {
 
-constexpr int kTsThreads = 256, kTsItems = 32, kTsBlockKeys = kTsThreads * kTsItems;
+constexpr int kTsThreads = 256;                                  // scan / small-sort workgroup
+constexpr int kTpThreads = 1024, kTpItems = 8, kTsBlockKeys = kTpThreads * kTpItems;  // partition kernels: 8192 keys / workgroup
 
 __device__ __forceinline__ int tile_bin(uint64_t key, int tile_bits, int n_tiles) {
     const uint32_t hi = (uint32_t)(key >> 32);
     return (int)(hi >> tile_bits) * n_tiles + (int)(hi & ((1u << tile_bits) - 1u));
 }
 
-__global__ void __launch_bounds__(kTsThreads)
+__global__ void __launch_bounds__(kTpThreads)
 tile_hist_kernel(int64_t n, const uint64_t *__restrict__ keys, int tile_bits, int n_tiles, int T, int nb,
                  int32_t *__restrict__ table) {
     extern __shared__ int hist[];
-    for (int b = threadIdx.x; b < T; b += kTsThreads) hist[b] = 0;
+    for (int b = threadIdx.x; b < T; b += kTpThreads) hist[b] = 0;
     __syncthreads();
     const int64_t base = (int64_t)blockIdx.x * kTsBlockKeys;
-#pragma unroll 4
-    for (int k = 0; k < kTsItems; ++k) {
-        const int64_t i = base + k * kTsThreads + threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < kTpItems; ++k) {
+        const int64_t i = base + k * kTpThreads + threadIdx.x;
         if (i < n) atomicAdd(&hist[tile_bin(keys[i], tile_bits, n_tiles)], 1);
     }
     __syncthreads();
-    for (int b = threadIdx.x; b < T; b += kTsThreads) table[(int64_t)b * nb + blockIdx.x] = hist[b];
+    for (int b = threadIdx.x; b < T; b += kTpThreads) table[(int64_t)b * nb + blockIdx.x] = hist[b];
 }
 
 // one workgroup per tile: table[tile][0..nb) -> exclusive prefix in place, totals[tile]
@@ -103,17 +104,17 @@ tile_offsets_kernel(int T, const int32_t *__restrict__ totals, int32_t *__restri
     if (tid == 0) offsets[T] = carry_s;
 }
 
-__global__ void __launch_bounds__(kTsThreads)
+__global__ void __launch_bounds__(kTpThreads)
 tile_scatter_kernel(int64_t n, const uint64_t *__restrict__ keys, const int32_t *__restrict__ payload,
                     int tile_bits, int n_tiles, int T, int nb, const int32_t *__restrict__ table,
                     const int32_t *__restrict__ offsets, uint64_t *__restrict__ buckets) {
     extern __shared__ int cursor[];
-    for (int b = threadIdx.x; b < T; b += kTsThreads) cursor[b] = offsets[b] + table[(int64_t)b * nb + blockIdx.x];
+    for (int b = threadIdx.x; b < T; b += kTpThreads) cursor[b] = offsets[b] + table[(int64_t)b * nb + blockIdx.x];
     __syncthreads();
     const int64_t base = (int64_t)blockIdx.x * kTsBlockKeys;
-#pragma unroll 4
-    for (int k = 0; k < kTsItems; ++k) {
-        const int64_t i = base + k * kTsThreads + threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < kTpItems; ++k) {
+        const int64_t i = base + k * kTpThreads + threadIdx.x;
         if (i < n) {
             const uint64_t key = keys[i];
             const uint32_t pay = (uint32_t)payload[i];
@@ -288,10 +289,10 @@ extern "C" int fsgs_tile_sort(int64_t n, const int64_t *isect_ids, const int32_t
     uint64_t *buckets = reinterpret_cast<uint64_t *>(p + off);
     const uint64_t *keys = reinterpret_cast<const uint64_t *>(isect_ids);
     const size_t lds = (size_t)T * sizeof(int);
-    hipLaunchKernelGGL(tile_hist_kernel, dim3(nb), dim3(kTsThreads), lds, s, n, keys, tb, n_tiles, T, nb, table);
+    hipLaunchKernelGGL(tile_hist_kernel, dim3(nb), dim3(kTpThreads), lds, s, n, keys, tb, n_tiles, T, nb, table);
     hipLaunchKernelGGL(tile_scan_kernel2, dim3(T), dim3(kTsThreads), 0, s, nb, table, totals);
     hipLaunchKernelGGL(tile_offsets_kernel, dim3(1), dim3(1024), 0, s, T, totals, isect_offsets);
-    hipLaunchKernelGGL(tile_scatter_kernel, dim3(nb), dim3(kTsThreads), lds, s, n, keys, payload, tb, n_tiles, T, nb,
+    hipLaunchKernelGGL(tile_scatter_kernel, dim3(nb), dim3(kTpThreads), lds, s, n, keys, payload, tb, n_tiles, T, nb,
                        table, isect_offsets, buckets);
     static bool attr_set = false;
     if (!attr_set) {
