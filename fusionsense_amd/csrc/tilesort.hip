@@ -125,15 +125,68 @@ tile_scatter_kernel(int64_t n, const uint64_t *__restrict__ keys, const int32_t 
     }
 }
 
-// One workgroup per tile sorts its bucket with a bitonic network whose compare-exchanges are ALL
-// ascending (the first stage of every merge mirrors the upper half), so missing elements beyond n act
-// as +inf without being stored: any n, no padding.  A stage is one dependent LDS round trip, so what
-// matters is how many of them need a workgroup barrier: with 64 pairs per wave, a wave owns a
-// contiguous block of 128 elements for every stage of span <= 128 — 49 of the 55 stages of a
-// 1024-element sort — and runs those back to back with wave-level ordering only.
-// Buckets with LO < n <= CAP words are sorted in LDS by this instantiation; with SPILL, larger ones are
-// sorted where they lie (L1-bypassing loads/stores and workgroup barriers only: slow, for tiles too
-// dense for LDS — the caller keeps the global radix sort for scenes that dense).
+// ---- a wave sorts 128 64-bit words in REGISTERS: lane l holds words l and l + 64 of the block -------------
+// Every stage of a bitonic merge of span <= 128 pairs a word with the same slot of lane (l ^ mask) — except
+// the span-128 mirror (other slot of lane 63 - l) and distance 64 (the lane's own two words) — so the
+// exchange is a DPP move (masks 1, 2, 3, 7, 15), a ds_swizzle (4, 8, 16, 31) or a ds_bpermute (32, 63):
+// no LDS storage traffic at all, where the LDS version moved 32 bytes per lane per stage through banks
+// that the 64-bit stride-2 patterns of the low stages only half use (measured: LDS-bandwidth-bound).
+template <int M>
+__device__ __forceinline__ uint32_t lane_xor32(uint32_t v) {
+    if (M == 1) return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+    if (M == 2) return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
+    if (M == 3) return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x1B, 0xF, 0xF, true);   // quad_perm [3,2,1,0]
+    if (M == 7) return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x141, 0xF, 0xF, true);  // row_half_mirror
+    if (M == 15) return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x140, 0xF, 0xF, true); // row_mirror
+    if (M < 32) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, (M << 10) | 0x1F);    // bit mode: lane ^ M
+    return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((threadIdx.x & 63) ^ M) << 2), (int)v);
+}
+template <int M>
+__device__ __forceinline__ uint64_t lane_xor64(uint64_t v) {
+    return ((uint64_t)lane_xor32<M>((uint32_t)(v >> 32)) << 32) | lane_xor32<M>((uint32_t)v);
+}
+__device__ __forceinline__ void keep(uint64_t &a, uint64_t p, bool keep_min) {
+    a = ((a > p) == keep_min) ? p : a;
+}
+// both slots against lane (l ^ M); the lane whose bit LOWBIT is clear holds the lower position
+template <int M, int LOWBIT>
+__device__ __forceinline__ void xstage(uint64_t &e0, uint64_t &e1, int lane) {
+    const bool lower = (lane & LOWBIT) == 0;
+    const uint64_t p0 = lane_xor64<M>(e0), p1 = lane_xor64<M>(e1);
+    keep(e0, p0, lower);
+    keep(e1, p1, lower);
+}
+// the xor stages j = 32 .. 1 that end every merge of span >= 128
+__device__ __forceinline__ void merge_tail_32(uint64_t &e0, uint64_t &e1, int lane) {
+    xstage<32, 32>(e0, e1, lane); xstage<16, 16>(e0, e1, lane); xstage<8, 8>(e0, e1, lane);
+    xstage<4, 4>(e0, e1, lane); xstage<2, 2>(e0, e1, lane); xstage<1, 1>(e0, e1, lane);
+}
+__device__ __forceinline__ void sort128(uint64_t &e0, uint64_t &e1, int lane) {
+    xstage<1, 1>(e0, e1, lane);                                                                    // k = 2
+    xstage<3, 2>(e0, e1, lane); xstage<1, 1>(e0, e1, lane);                                         // k = 4
+    xstage<7, 4>(e0, e1, lane); xstage<2, 2>(e0, e1, lane); xstage<1, 1>(e0, e1, lane);              // k = 8
+    xstage<15, 8>(e0, e1, lane); xstage<4, 4>(e0, e1, lane); xstage<2, 2>(e0, e1, lane);
+    xstage<1, 1>(e0, e1, lane);                                                                    // k = 16
+    xstage<31, 16>(e0, e1, lane); xstage<8, 8>(e0, e1, lane); xstage<4, 4>(e0, e1, lane);
+    xstage<2, 2>(e0, e1, lane); xstage<1, 1>(e0, e1, lane);                                         // k = 32
+    xstage<63, 32>(e0, e1, lane); xstage<16, 16>(e0, e1, lane); xstage<8, 8>(e0, e1, lane);
+    xstage<4, 4>(e0, e1, lane); xstage<2, 2>(e0, e1, lane); xstage<1, 1>(e0, e1, lane);              // k = 64
+    {   // k = 128 mirror: word l <-> word 127 - l = slot 1 of lane 63 - l
+        const uint64_t q0 = lane_xor64<63>(e1), q1 = lane_xor64<63>(e0);
+        keep(e0, q0, true);
+        keep(e1, q1, false);
+    }
+    merge_tail_32(e0, e1, lane);
+}
+
+// One workgroup per tile sorts its bucket with a bitonic network whose compare-exchanges are ALL ascending
+// (the first stage of every merge mirrors the upper half).  Buckets with LO < n <= CAP words: every wave
+// sorts 128-word blocks in registers (above); merges of span >= 256 do their mirror stage and the stages
+// of distance >= 128 in LDS (workgroup barriers), then each wave takes its blocks back into registers
+// for the distances 64 .. 1 — for a 512-word bucket that is 6 LDS passes instead of 45, and the last
+// pass leaves the registers straight for global memory.  With SPILL, buckets larger than CAP are sorted
+// where they lie (L1-bypassing loads/stores, missing words act as +inf without being stored: slow, for
+// tiles too dense for LDS — the caller keeps the global radix sort for scenes that dense).
 template <int THREADS, int CAP, int LO, bool SPILL>
 __global__ void __launch_bounds__(THREADS)
 tile_sort_kernel2(int n_tiles, int tile_bits, const int32_t *__restrict__ offsets, uint64_t *__restrict__ buckets,
@@ -169,54 +222,57 @@ tile_sort_kernel2(int n_tiles, int tile_bits, const int32_t *__restrict__ offset
     auto xor_pair = [&](int i, int j, int &a, int &b) {     // pair i of the stage with partner distance j
         a = ((i & ~(j - 1)) << 1) | (i & (j - 1)); b = a | j;
     };
-    auto wave_sync = [&]() {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+    const int half = np >> 1;  // pairs per stage
+    const int cam = tile_lin / n_tiles, tile = tile_lin - cam * n_tiles;
+    const int64_t hi = ((int64_t)cam << (32 + tile_bits)) | ((int64_t)tile << 32);
+    auto emit = [&](int pos, uint64_t k) {
+        if (pos < n) {
+            const uint32_t lo = (uint32_t)(k & 0xFFFFFFFFull);
+            payload_out[(int64_t)s + pos] = (int32_t)(((lo & 0xFu) << 28) | (lo >> 4));
+            if (isect_ids_out) isect_ids_out[(int64_t)s + pos] = hi | (int64_t)(k >> 32);
+        }
     };
     if (in_lds) {
-        for (int i = tid; i < n; i += THREADS) sk[i] = g[i];
-        __syncthreads();
-    }
-    const int half = np >> 1;  // pairs per stage
-    if (in_lds) {
-        // merges up to 128 elements: entirely inside each wave's 128-element blocks (64 pairs each)
-        const int kmax = np < 128 ? np : 128;
-        for (int p0 = wid * 64; p0 < half; p0 += NW * 64) {
-            const int i = p0 + lane;
-            for (int k = 2; k <= kmax; k <<= 1) {
-                int a, b;
-                if (i < half) { mirror_pair(i, k, a, b); cmpex(a, b); }
-                wave_sync();
-                for (int j = k >> 2; j > 0; j >>= 1) {
-                    if (i < half) { xor_pair(i, j, a, b); cmpex(a, b); }
-                    wave_sync();
-                }
-            }
+        // 128-word blocks are sorted in registers (missing words are +inf there and in LDS: np <= CAP words)
+        const int nblk = np > 128 ? np >> 7 : 1;
+        for (int blk = wid; blk < nblk; blk += NW) {
+            const int base = blk << 7;
+            uint64_t e0 = (base + lane < n) ? g[base + lane] : ~0ull;
+            uint64_t e1 = (base + lane + 64 < n) ? g[base + lane + 64] : ~0ull;
+            sort128(e0, e1, lane);
+            if (np > 128) { sk[base + lane] = e0; sk[base + lane + 64] = e1; }
+            else { emit(lane, e0); emit(lane + 64, e1); }
         }
+        if (np <= 128) return;
         __syncthreads();
         for (int k = 256; k <= np; k <<= 1) {
-            for (int i = tid; i < half; i += THREADS) {
+            for (int i = tid; i < half; i += THREADS) {  // mirror stage of the merge, across waves: LDS
                 int a, b;
-                mirror_pair(i, k, a, b); cmpex(a, b);
+                mirror_pair(i, k, a, b);
+                const uint64_t ka = sk[a], kb = sk[b];
+                if (ka > kb) { sk[a] = kb; sk[b] = ka; }
             }
             __syncthreads();
             for (int j = k >> 2; j >= 128; j >>= 1) {
                 for (int i = tid; i < half; i += THREADS) {
                     int a, b;
-                    xor_pair(i, j, a, b); cmpex(a, b);
+                    xor_pair(i, j, a, b);
+                    const uint64_t ka = sk[a], kb = sk[b];
+                    if (ka > kb) { sk[a] = kb; sk[b] = ka; }
                 }
                 __syncthreads();
             }
-            for (int p0 = wid * 64; p0 < half; p0 += NW * 64) {
-                const int i = p0 + lane;
-                for (int j = 64; j > 0; j >>= 1) {
-                    int a, b;
-                    xor_pair(i, j, a, b); cmpex(a, b);
-                    wave_sync();
-                }
+            for (int blk = wid; blk < nblk; blk += NW) {  // distances 64 .. 1: back in registers
+                const int base = blk << 7;
+                uint64_t e0 = sk[base + lane], e1 = sk[base + lane + 64];
+                if (e0 > e1) { const uint64_t t = e0; e0 = e1; e1 = t; }
+                merge_tail_32(e0, e1, lane);
+                if (k < np) { sk[base + lane] = e0; sk[base + lane + 64] = e1; }
+                else { emit(base + lane, e0); emit(base + lane + 64, e1); }
             }
-            __syncthreads();
+            if (k < np) __syncthreads();
         }
+        return;
     } else {
         for (int k = 2; k <= np; k <<= 1) {
             for (int i = tid; i < half; i += THREADS) {
@@ -233,14 +289,7 @@ tile_sort_kernel2(int n_tiles, int tile_bits, const int32_t *__restrict__ offset
             }
         }
     }
-    const int cam = tile_lin / n_tiles, tile = tile_lin - cam * n_tiles;
-    const int64_t hi = ((int64_t)cam << (32 + tile_bits)) | ((int64_t)tile << 32);
-    for (int i = tid; i < n; i += THREADS) {
-        const uint64_t k = ld(i);
-        const uint32_t lo = (uint32_t)(k & 0xFFFFFFFFull);
-        payload_out[(int64_t)s + i] = (int32_t)(((lo & 0xFu) << 28) | (lo >> 4));
-        if (isect_ids_out) isect_ids_out[(int64_t)s + i] = hi | (int64_t)(k >> 32);
-    }
+    for (int i = tid; i < n; i += THREADS) emit(i, ld(i));
 }
 
 constexpr int kTsSmall = 1024, kTsLarge = 8192;  // LDS words per tile: 8 KB x 8 workgroups, 64 KB x 2 per CU
