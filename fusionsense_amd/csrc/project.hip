@@ -52,8 +52,8 @@ project_fwd_kernel(int C, int N, const float *__restrict__ means, const float *_
                    float far_plane, float radius_clip, int32_t *__restrict__ radii,
                    float *__restrict__ means2d, float *__restrict__ depths,
                    float *__restrict__ conics, float *__restrict__ compensations,
-                   const float *__restrict__ opac_logit, float *__restrict__ scales_out,
-                   float *__restrict__ opac_out) {
+                   float *__restrict__ opac_logit, float *__restrict__ scales_out,
+                   float *__restrict__ opac_out, int binarise, float binary_threshold) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (int64_t)C * N) return;
     const int c = (int)(idx / N);
@@ -63,7 +63,12 @@ project_fwd_kernel(int C, int N, const float *__restrict__ means, const float *_
         s_act[0] = expf(scales[n * 3 + 0]); s_act[1] = expf(scales[n * 3 + 1]); s_act[2] = expf(scales[n * 3 + 2]);
         if (c == 0) {
             scales_out[n * 3 + 0] = s_act[0]; scales_out[n * 3 + 1] = s_act[1]; scales_out[n * 3 + 2] = s_act[2];
-            opac_out[n] = 1.f / (1.f + expf(-opac_logit[n]));
+            float ol = opac_logit[n];
+            if (binarise) {  // the binary-opacity write of get_outputs (dn_model.py:492-503), on the parameter itself
+                ol = (ol >= binary_threshold) ? 1.f : 0.f;
+                opac_logit[n] = ol;
+            }
+            opac_out[n] = 1.f / (1.f + expf(-ol));
         }
     }
 
@@ -151,6 +156,7 @@ struct GaussBwdFused {
     float *absgrad;              // [N,2] out
     float *v_opac_logit;         // [N] out
     int accumulate_means;        // v_means += (the SH backward wrote its share first) instead of =
+    const uint8_t *frozen;       // nullable [N]: touch anchors — no gradient for means / scales / opacity (dn_model.py:535-541)
     float *xys_grad_norm, *vis_counts, *max_2Dsize;  // after_train statistics (nullable together)
     float inv_max_hw;
 };
@@ -354,17 +360,20 @@ project_bwd_kernel(int C, int N, const float *__restrict__ means, const float *_
         v_scales[n * 3 + 2] = vs[2];
         return;
     }
-    if (fz.accumulate_means) {
+    const bool frozen = fz.frozen != nullptr && fz.frozen[n] != 0;
+    if (frozen) {
+        v_means[n * 3 + 0] = 0.f; v_means[n * 3 + 1] = 0.f; v_means[n * 3 + 2] = 0.f;
+    } else if (fz.accumulate_means) {
         v_means[n * 3 + 0] += g_mean[0]; v_means[n * 3 + 1] += g_mean[1]; v_means[n * 3 + 2] += g_mean[2];
     } else {
         v_means[n * 3 + 0] = g_mean[0]; v_means[n * 3 + 1] = g_mean[1]; v_means[n * 3 + 2] = g_mean[2];
     }
     // `scales` holds exp(log_scales): d/d log_scale = v * exp(log_scale)
-    v_scales[n * 3 + 0] = vs[0] * s[0];
-    v_scales[n * 3 + 1] = vs[1] * s[1];
-    v_scales[n * 3 + 2] = vs[2] * s[2];
+    v_scales[n * 3 + 0] = frozen ? 0.f : vs[0] * s[0];
+    v_scales[n * 3 + 1] = frozen ? 0.f : vs[1] * s[1];
+    v_scales[n * 3 + 2] = frozen ? 0.f : vs[2] * s[2];
     const float o = fz.opac[n];
-    fz.v_opac_logit[n] = pc.w * o * (1.f - o);
+    fz.v_opac_logit[n] = frozen ? 0.f : pc.w * o * (1.f - o);
     {   // the normal pass reaches the quaternions only (dn_model.py:618-656)
         const float ls[3] = {fz.log_scales[n * 3 + 0], fz.log_scales[n * 3 + 1], fz.log_scales[n * 3 + 2]};
         const float vn[3] = {pd.x, pd.y, pd.z};
@@ -400,12 +409,13 @@ extern "C" int fsgs_project_fwd(int C, int N, const float *means, const float *q
     hipLaunchKernelGGL((project_fwd_kernel<false>), dim3(ceil_div(total, 256)), dim3(256), 0, as_stream(stream),
                        C, N, means, quats, scales, viewmats, Ks, width, height, eps2d, near_plane,
                        far_plane, radius_clip, radii, means2d, depths, conics, compensations, nullptr, nullptr,
-                       nullptr);
+                       nullptr, 0, 0.f);
     return check_launch();
 }
 
 extern "C" int fsgs_project_fwd_act(int C, int N, const float *means, const float *quats,
-                                    const float *log_scales, const float *opac_logit, const float *viewmats,
+                                    const float *log_scales, float *opac_logit, int binarise,
+                                    float binary_threshold, const float *viewmats,
                                     const float *Ks, int width, int height, float eps2d, float near_plane,
                                     float far_plane, float radius_clip, float *scales_out, float *opac_out,
                                     int32_t *radii, float *means2d, float *depths, float *conics,
@@ -418,7 +428,8 @@ extern "C" int fsgs_project_fwd_act(int C, int N, const float *means, const floa
     const int64_t total = (int64_t)C * N;
     hipLaunchKernelGGL((project_fwd_kernel<true>), dim3(ceil_div(total, 256)), dim3(256), 0, as_stream(stream),
                        C, N, means, quats, log_scales, viewmats, Ks, width, height, eps2d, near_plane, far_plane,
-                       radius_clip, radii, means2d, depths, conics, nullptr, opac_logit, scales_out, opac_out);
+                       radius_clip, radii, means2d, depths, conics, nullptr, opac_logit, scales_out, opac_out,
+                       binarise, binary_threshold);
     return check_launch();
 }
 
@@ -447,7 +458,7 @@ extern "C" int fsgs_gaussian_bwd(int N, const float *means, const float *quats, 
                                  const float *conics, float *v_packed, int accumulate_means, float *v_means,
                                  float *v_quats, float *v_log_scales, float *v_opac_logit, float *absgrad,
                                  float *xys_grad_norm, float *vis_counts, float *max_2Dsize, float inv_max_hw,
-                                 fsgs_stream_t stream) {
+                                 const uint8_t *frozen, fsgs_stream_t stream) {
     if (N < 0) return FSGS_EINVAL;
     if (N == 0) return FSGS_OK;
     if (!means || !quats || !log_scales || !scales || !opac || !viewmat || !K || !c2w || !radii || !conics ||
@@ -459,6 +470,7 @@ extern "C" int fsgs_gaussian_bwd(int N, const float *means, const float *quats, 
     fz.v_packed = reinterpret_cast<float4 *>(v_packed);
     fz.log_scales = log_scales; fz.opac = opac; fz.c2w = c2w; fz.absgrad = absgrad; fz.v_opac_logit = v_opac_logit;
     fz.accumulate_means = accumulate_means;
+    fz.frozen = frozen;
     fz.xys_grad_norm = xys_grad_norm; fz.vis_counts = vis_counts; fz.max_2Dsize = max_2Dsize; fz.inv_max_hw = inv_max_hw;
     hipLaunchKernelGGL((project_bwd_kernel<true>), dim3(ceil_div(N, 256)), dim3(256), 0, as_stream(stream), 1, N,
                        means, quats, scales, viewmat, K, width, height, eps2d, radii, conics, nullptr, nullptr,

@@ -47,6 +47,8 @@ class FrameInfo:
         # "inv_max_hw": float} supplied by the caller; stats_done tells it they have been applied
         self.stats_out: Optional[dict] = None
         self.stats_done = False
+        self.frozen: Optional[Tensor] = None           # [N] uint8: touch anchors (dn_model.py:535-541)
+        self.binary_threshold: Optional[float] = None  # perform the binary-opacity write (dn_model.py:492-503)
 
     @property
     def flatten_ids(self):
@@ -114,7 +116,10 @@ class _FusedGetOutputs(torch.autograd.Function):
         means2d = torch.empty(1, N, 2, **f32)
         depths = torch.empty(1, N, **f32)
         conics = torch.empty(1, N, 3, **f32)
-        _run(lib.fsgs_project_fwd_act, (1, N, ptr(means), ptr(quats), ptr(scales), ptr(opacities), ptr(cam["viewmat"]),
+        bthr = info.binary_threshold
+        _run(lib.fsgs_project_fwd_act, (1, N, ptr(means), ptr(quats), ptr(scales), ptr(opacities),
+                                       0 if bthr is None else 1, 0.0 if bthr is None else float(bthr),
+                                       ptr(cam["viewmat"]),
                                        ptr(cam["K"]), W, H, 0.3, 0.01, 1e10, 0.0, ptr(scales_exp), ptr(opac_sig),
                                        ptr(radii), ptr(means2d), ptr(depths), ptr(conics), sp), "fsgs_project_fwd_act")
         # live emission: only (Gaussian, tile) pairs that can reach a pixel are binned and sorted; the
@@ -239,7 +244,8 @@ class _FusedGetOutputs(torch.autograd.Function):
                                     ptr(stats["xys_grad_norm"]) if stats else None,
                                     ptr(stats["vis_counts"]) if stats else None,
                                     ptr(stats["max_2Dsize"]) if stats else None,
-                                    float(stats["inv_max_hw"]) if stats else 0.0, sp), "fsgs_gaussian_bwd")
+                                    float(stats["inv_max_hw"]) if stats else 0.0, ptr(ctx.info.frozen), sp),
+             "fsgs_gaussian_bwd")
         ctx.info.absgrad = v_abs
         ctx.info.stats_done = stats is not None
         if ctx.grad_out:
@@ -252,17 +258,35 @@ class _FusedGetOutputs(torch.autograd.Function):
 def render_fusionsense_fused(gauss_params: Dict[str, Tensor], camera: Camera, sh_degree: int = 3,
                              background: Optional[Tensor] = None, device: Optional[torch.device] = None,
                              grad_out: Optional[Dict[str, Tensor]] = None,
-                             stats_out: Optional[dict] = None) -> Dict[str, Tensor]:
+                             stats_out: Optional[dict] = None, add_mask: Optional[Tensor] = None,
+                             crop_box=None, training: bool = True,
+                             binary_threshold: Optional[float] = None) -> Dict[str, Tensor]:
     """Same outputs as :func:`fusionsense_amd.fusion.render_fusionsense` (rgb, depth, normal,
-    accumulation, radii, normals_world, ...), computed by one fused autograd node."""
+    accumulation, radii, normals_world, ...), computed by one fused autograd node.  ``add_mask``,
+    ``crop_box`` / ``training`` and ``binary_threshold`` have the meaning they have there
+    (dn_model.py:535-541, :505-532, :492-503)."""
     dev = device or gauss_params["means"].device
     if background is None:
         background = _ONES3.get(str(dev))
         if background is None:
             background = _ONES3.setdefault(str(dev), torch.ones(3, device=dev))
+    if crop_box is not None and not training:
+        from .crop import crop_params, get_empty_outputs
+        if binary_threshold is not None:  # the write precedes the crop in get_outputs
+            from .splatfacto import binary_opacity_write_
+            binary_opacity_write_(gauss_params["opacities"], binary_threshold)
+            binary_threshold = None
+        crop_ids = crop_box.within(gauss_params["means"].detach())
+        if crop_ids.sum() == 0:
+            return get_empty_outputs(camera.width, camera.height, background)
+        gauss_params = crop_params(gauss_params, crop_ids)
+        grad_out = None
     cam = _camera_on_device(camera, dev)
     info = FrameInfo()
     info.stats_out = stats_out
+    info.binary_threshold = binary_threshold
+    if add_mask is not None:
+        info.frozen = add_mask.to(device=dev, dtype=torch.uint8).contiguous()
     rgb, depth, normal, alpha = _FusedGetOutputs.apply(
         gauss_params["means"], gauss_params["scales"], gauss_params["quats"], gauss_params["features_dc"],
         gauss_params["features_rest"], gauss_params["opacities"], cam, camera.width, camera.height, int(sh_degree),

@@ -43,15 +43,40 @@ def render_fusionsense(
     rasterize_mode: str = "classic",
     device: Optional[torch.device] = None,
     fused_normals: bool = True,
+    add_mask: Optional[Tensor] = None,
+    crop_box=None,
+    training: bool = True,
+    binary_threshold: Optional[float] = None,
 ) -> Dict[str, Tensor]:
     """One ``get_outputs`` call.  ``gauss_params`` uses the reference's stored parametrisation
     (dn_model.py:294-304): means, scales (log), quats, features_dc [N,3], features_rest [N,K-1,3],
-    opacities (logit) [N,1].  ``sh_degree`` is ``sh_degree_to_use`` (dn_model.py:562-568)."""
+    opacities (logit) [N,1].  ``sh_degree`` is ``sh_degree_to_use`` (dn_model.py:562-568).
+    ``binary_threshold``: perform the binary-opacity write of :492-503 (the caller decides with
+    ``splatfacto.binary_opacity_active``); ``crop_box`` (:class:`fusionsense_amd.crop.OrientedBox`) is used
+    only when not ``training`` (:505-532); ``add_mask`` [N] bool marks the touch anchors whose means /
+    opacities / scales receive no gradient (:535-541)."""
     dev = device or gauss_params["means"].device
+    if binary_threshold is not None:
+        from .splatfacto import binary_opacity_write_
+        binary_opacity_write_(gauss_params["opacities"], binary_threshold)
+    if crop_box is not None and not training:
+        from .crop import crop_params, get_empty_outputs
+        crop_ids = crop_box.within(gauss_params["means"].detach())
+        if crop_ids.sum() == 0:
+            bg = background if background is not None else torch.ones(3, device=dev)
+            return get_empty_outputs(camera.width, camera.height, bg)
+        gauss_params = crop_params(gauss_params, crop_ids)
     means = gauss_params["means"]
     scales = gauss_params["scales"]
     quats = gauss_params["quats"]
     opacities = gauss_params["opacities"]
+    if add_mask is not None:
+        opacities = opacities.clone()
+        opacities[add_mask] = opacities[add_mask].detach()
+        means = means.clone()
+        means[add_mask] = means[add_mask].detach()
+        scales = scales.clone()
+        scales[add_mask] = scales[add_mask].detach()
     colors = torch.cat((gauss_params["features_dc"][:, None, :], gauss_params["features_rest"]), dim=1)
     c2w = camera.c2w.to(dev)
     viewmat = get_viewmat(c2w[None])

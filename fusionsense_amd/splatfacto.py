@@ -44,6 +44,24 @@ class SplatfactoConfig:
     stop_screen_size_at: int = 4000
     stop_split_at: int = 10000
     sh_degree: int = 3
+    use_binary_opacities: bool = True        # dn_model.py:94
+    binary_opacities_threshold: float = 0.9  # dn_model.py:96 (compared with the RAW opacity parameter)
+
+
+def binary_opacity_active(cfg: SplatfactoConfig, step: int) -> bool:
+    """Whether get_outputs overwrites ``opacities.data`` with {0, 1} at this step (dn_model.py:492-503):
+    after the warm-up, except on the opacity-reset steps and the 200 steps that follow each of them."""
+    if not (cfg.use_binary_opacities and step > cfg.warmup_length):
+        return False
+    skip_steps = cfg.reset_alpha_every * cfg.refine_every
+    margin = 200
+    return (step % skip_steps != 0) and (step % skip_steps not in range(1, margin + 1))
+
+
+def binary_opacity_write_(opacities: Tensor, threshold: float) -> None:
+    """``opacities.data = where(opacities >= thr, 1, 0)`` — in logit space, as the reference does."""
+    opacities.data = torch.where(opacities.data >= threshold, torch.ones_like(opacities.data),
+                                 torch.zeros_like(opacities.data))
 
 
 def refine_schedule(cfg: SplatfactoConfig, step: int, num_train_data: int) -> Dict[str, bool]:

@@ -103,18 +103,32 @@ class SplatTrainer:
     def num_gaussians(self) -> int:
         return self.params["means"].shape[0]
 
-    def forward(self, camera: Camera, sh_degree_to_use: Optional[int] = None):
+    def forward(self, camera: Camera, sh_degree_to_use: Optional[int] = None, crop_box=None):
+        """get_outputs.  In training mode (grad enabled) the strategy supplies what the model state supplies
+        in the reference: the binary-opacity schedule (dn_model.py:492-503) and the touch-anchor mask
+        (:535-541); ``crop_box`` is honoured only without grad, like ``not self.training`` there (:505-532)."""
         deg = self.sh_degree if sh_degree_to_use is None else sh_degree_to_use
+        grad = torch.is_grad_enabled()
+        add_mask, bthr = None, None
+        if self.strategy is not None:
+            add_mask = getattr(self.strategy, "add_mask", None)
+            cfg = getattr(self.strategy, "cfg", None)
+            if cfg is not None:
+                from .splatfacto import binary_opacity_active
+                if binary_opacity_active(cfg, self.step):
+                    bthr = cfg.binary_opacities_threshold
         if self.fused:
             from .fused import render_fusionsense_fused
-            grad = torch.is_grad_enabled()
             stats = None
             if grad and self.strategy is not None and hasattr(self.strategy, "stats_target"):
                 stats = self.strategy.stats_target(self, self.num_gaussians(), self.device, camera)
             return render_fusionsense_fused(self.params, camera, sh_degree=deg, device=self.device,
-                                            grad_out=self.slab.views if grad else None, stats_out=stats)
+                                            grad_out=self.slab.views if grad else None, stats_out=stats,
+                                            add_mask=add_mask, crop_box=crop_box, training=grad,
+                                            binary_threshold=bthr)
         from .fusion import render_fusionsense
-        return render_fusionsense(self.params, camera, sh_degree=deg, device=self.device)
+        return render_fusionsense(self.params, camera, sh_degree=deg, device=self.device, add_mask=add_mask,
+                                  crop_box=crop_box, training=grad, binary_threshold=bthr)
 
     def loss(self, out, target) -> Tensor:
         """Config #2 loss: 0.8*L1 + 0.2*(1-SSIM) on rgb, L1 on depth, L1 on normals."""

@@ -321,9 +321,12 @@ int fsgs_activate_bwd(int N, const float *scales, const float *opac, const float
                       const float *v_opac, const float *v_quats_a, const float *v_quats_b,
                       float *v_log_scales, float *v_opac_logit, float *v_quats, fsgs_stream_t stream);
 /* fsgs_project_fwd with the activations of dn_model.py:573-574 applied in the same launch:
- * scales_out [N,3] = exp(log_scales), opac_out [N] = sigmoid(opac_logit); the projection uses scales_out. */
+ * scales_out [N,3] = exp(log_scales), opac_out [N] = sigmoid(opac_logit); the projection uses scales_out.
+ * binarise != 0: first opac_logit[n] = opac_logit[n] >= binary_threshold ? 1 : 0, written back to the parameter
+ * (the binary-opacity write at the top of get_outputs, dn_model.py:492-503). */
 int fsgs_project_fwd_act(int C, int N, const float *means, const float *quats, const float *log_scales,
-                         const float *opac_logit, const float *viewmats, const float *Ks, int width,
+                         float *opac_logit, int binarise, float binary_threshold,
+                         const float *viewmats, const float *Ks, int width,
                          int height, float eps2d, float near_plane, float far_plane, float radius_clip,
                          float *scales_out, float *opac_out, int32_t *radii, float *means2d, float *depths,
                          float *conics, fsgs_stream_t stream);
@@ -339,7 +342,9 @@ int fsgs_gaussian_bwd(int N, const float *means, const float *quats, const float
                       const float *conics, float *v_packed, int accumulate_means, float *v_means,
                       float *v_quats, float *v_log_scales, float *v_opac_logit, float *absgrad,
                       float *xys_grad_norm, float *vis_counts, float *max_2Dsize, float inv_max_hw,
-                      fsgs_stream_t stream);
+                      const uint8_t *frozen, fsgs_stream_t stream);
+/* frozen (nullable, [N] u8): rows whose v_means / v_log_scales / v_opac_logit are zero — FusionSense's touch
+ * anchors, detached at dn_model.py:535-541 (their quaternion and colour gradients still flow). */
 /* dn_model.py:602-613, 655-656: rgb = clamp(render[:3] + (1-alpha) bg, 0, 1); depth = alpha > 0 ?
  * render[3] : max(render[3]); normal = (n/|n| + 1)/2.  render [P,4], alphas [P], render_extra [P,3],
  * bg [3]; n_partial > 0: max_last_partial [n_partial] (per-workgroup partial maxima) is reduced into max_last[0]

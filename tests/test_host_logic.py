@@ -236,3 +236,76 @@ def test_data_parallel_allreduce_gloo_world2():
     for p in procs:
         out, err = p.communicate(timeout=180)
         assert p.returncode == 0 and "ok" in out, err[-2000:]
+
+
+def test_binary_opacity_schedule_matches_reference_transcription():
+    """dn_model.py:492-499: after the warm-up, every step except the reset steps and the 200 after them."""
+    from fusionsense_amd.splatfacto import SplatfactoConfig, binary_opacity_active, binary_opacity_write_
+    from oracle.fusion_ref import binary_opacity_step
+    cfg = SplatfactoConfig()
+    for step in range(0, 9500):
+        assert binary_opacity_active(cfg, step) == binary_opacity_step(step), step
+    assert not binary_opacity_active(cfg, 500) and binary_opacity_active(cfg, 501)
+    assert not binary_opacity_active(cfg, 3000) and not binary_opacity_active(cfg, 3200) and binary_opacity_active(cfg, 3201)
+    off = SplatfactoConfig(use_binary_opacities=False)
+    assert not any(binary_opacity_active(off, s) for s in range(0, 4000, 7))
+    o = torch.nn.Parameter(torch.tensor([[0.89999], [0.9], [5.0], [-3.0]]))
+    binary_opacity_write_(o, cfg.binary_opacities_threshold)
+    assert o.detach().flatten().tolist() == [0.0, 1.0, 1.0, 0.0] and o.requires_grad
+
+
+def test_oriented_box_and_empty_outputs():
+    """OrientedBox.within against the homogeneous-transform statement of nerfstudio's method; empty outputs."""
+    from fusionsense_amd.crop import OrientedBox, get_empty_outputs, crop_params
+    from fusionsense_amd import scenes
+    from oracle.fusion_ref import obb_within
+    g = torch.Generator().manual_seed(3)
+    for _ in range(5):
+        R = scenes.look_at_c2w(torch.randn(3, generator=g), torch.randn(3, generator=g))[:3, :3]
+        T = torch.randn(3, generator=g) * 0.3
+        S = torch.rand(3, generator=g) + 0.2
+        pts = torch.randn(4000, 3, generator=g)
+        box = OrientedBox(R, T, S)
+        a, b = box.within(pts), obb_within(R, T, S, pts)
+        assert a.dtype == torch.bool and 0 < int(a.sum()) < 4000
+        assert int((a != b).sum()) == 0
+    out = get_empty_outputs(7, 5, torch.tensor([0.1, 0.2, 0.3]))
+    assert out["rgb"].shape == (5, 7, 3) and torch.equal(out["rgb"][4, 6], torch.tensor([0.1, 0.2, 0.3]))
+    assert out["depth"].shape == (5, 7, 1) and float(out["depth"].min()) == 10.0
+    assert out["accumulation"].shape == (5, 7, 1) and float(out["accumulation"].abs().max()) == 0.0
+    p = {"means": torch.arange(12.0).view(4, 3), "opacities": torch.arange(4.0).view(4, 1)}
+    c = crop_params(p, torch.tensor([True, False, True, False]))
+    assert c["means"].shape == (2, 3) and c["opacities"].flatten().tolist() == [0.0, 2.0]
+
+
+def test_oracle_touch_anchor_detach_and_crop():
+    """The oracle's get_outputs with add_mask (anchors get no means / opacity / scale gradient, but do get
+    quaternion and colour gradients) and with an eval crop (= rendering the kept subset; nothing kept ->
+    empty outputs)."""
+    from fusionsense_amd import scenes
+    from oracle.fusion_ref import render_fusionsense as render_ref
+    params, cam = scenes.cube_scene(60, seed=2)
+    cam = scenes.Camera(cam.c2w, 32.0, 32.0, 16.0, 16.0, 32, 32)
+    add_mask = torch.zeros(60, dtype=torch.bool)
+    add_mask[::3] = True
+    p = {k: v.clone().double().requires_grad_(True) for k, v in params.items()}
+    out = render_ref(p, cam, sh_degree=3, add_mask=add_mask)
+    (out["rgb"].sum() + out["depth"].sum() + out["normal"].sum()).backward()
+    for k in ("means", "opacities", "scales"):
+        assert float(p[k].grad[add_mask].abs().max()) == 0.0, k
+        assert float(p[k].grad[~add_mask].abs().max()) > 0.0, k
+    assert float(p["quats"].grad[add_mask].abs().max()) > 0.0
+    assert float(p["features_dc"].grad[add_mask].abs().max()) > 0.0
+    box = (torch.eye(3), torch.zeros(3), torch.tensor([0.6, 2.0, 2.0]))
+    with torch.no_grad():
+        pc = {k: v.clone().double() for k, v in params.items()}
+        keep = (pc["means"][:, 0].abs() < 0.3)
+        full = render_ref(pc, cam, sh_degree=3, crop_box=box, training=False)
+        sub = render_ref({k: v[keep] for k, v in pc.items()}, cam, sh_degree=3)
+        assert 0 < int(keep.sum()) < 60
+        assert torch.equal(full["rgb"], sub["rgb"]) and torch.equal(full["depth"], sub["depth"])
+        same = render_ref(pc, cam, sh_degree=3, crop_box=box, training=True)      # ignored while training
+        ref = render_ref(pc, cam, sh_degree=3)
+        assert torch.equal(same["rgb"], ref["rgb"])
+        none = render_ref(pc, cam, sh_degree=3, crop_box=(torch.eye(3), torch.full((3,), 50.0), torch.ones(3)), training=False)
+        assert set(none) == {"rgb", "depth", "accumulation", "background"} and float(none["depth"].min()) == 10.0
