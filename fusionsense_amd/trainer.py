@@ -71,12 +71,15 @@ class GradSlab:
 class SplatTrainer:
     def __init__(self, params: Dict[str, Tensor], device: torch.device, sh_degree: int = 3,
                  optim: Optional[OptimConfig] = None, fused_adam: bool = True, seed: int = 0,
-                 strategy=None, fused: bool = True):
+                 strategy=None, fused: bool = True, sh_degree_interval: Optional[int] = None):
         self.device = device
         # fused=True: get_outputs as one autograd node (fusionsense_amd/fused.py); False: the
         # reference's op-by-op caller through the drop-in rasterization()/rasterize_gaussians() surface
         self.fused = fused
         self.sh_degree = sh_degree
+        # sh_degree_to_use = min(step // sh_degree_interval, sh_degree) (dn_model.py:562-565; nerfstudio default
+        # interval 1000); None = always the full degree (BASELINE config #2 is quoted at degree 3)
+        self.sh_degree_interval = sh_degree_interval
         self.optim_cfg = optim or OptimConfig()
         self.params: Dict[str, torch.nn.Parameter] = {
             k: torch.nn.Parameter(params[k].to(device=device, dtype=torch.float32).contiguous())
@@ -107,7 +110,12 @@ class SplatTrainer:
         """get_outputs.  In training mode (grad enabled) the strategy supplies what the model state supplies
         in the reference: the binary-opacity schedule (dn_model.py:492-503) and the touch-anchor mask
         (:535-541); ``crop_box`` is honoured only without grad, like ``not self.training`` there (:505-532)."""
-        deg = self.sh_degree if sh_degree_to_use is None else sh_degree_to_use
+        if sh_degree_to_use is not None:
+            deg = sh_degree_to_use
+        elif self.sh_degree_interval:
+            deg = min(self.step // self.sh_degree_interval, self.sh_degree)
+        else:
+            deg = self.sh_degree
         grad = torch.is_grad_enabled()
         add_mask, bthr = None, None
         if self.strategy is not None:
