@@ -309,3 +309,102 @@ def test_oracle_touch_anchor_detach_and_crop():
         assert torch.equal(same["rgb"], ref["rgb"])
         none = render_ref(pc, cam, sh_degree=3, crop_box=(torch.eye(3), torch.full((3,), 50.0), torch.ones(3)), training=False)
         assert set(none) == {"rgb", "depth", "accumulation", "background"} and float(none["depth"].min()) == 10.0
+
+
+def test_on_disk_formats_roundtrip(tmp_path):
+    """Row N3: PLY / PCD parsing (ascii and binary), seed initialisation of populate_modules (dn_model.py:196-300),
+    the ns-export gaussian-splat PLY layout, and the nerfstudio checkpoint dictionary."""
+    import numpy as np
+    from fusionsense_amd import io as fio, scenes
+    from fusionsense_amd.scenes import C0
+    g = torch.Generator().manual_seed(0)
+    n = 257
+    pts = torch.randn(n, 3, generator=g)
+    col = torch.randint(0, 256, (n, 3), generator=g).to(torch.uint8)
+    nrm = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1)
+    # --- PLY: binary written by us, ascii written by hand; both parse to the same arrays
+    props = {"x": pts[:, 0].numpy(), "y": pts[:, 1].numpy(), "z": pts[:, 2].numpy(),
+             "nx": nrm[:, 0].numpy(), "ny": nrm[:, 1].numpy(), "nz": nrm[:, 2].numpy(),
+             "red": col[:, 0].numpy(), "green": col[:, 1].numpy(), "blue": col[:, 2].numpy()}
+    fio.write_ply(str(tmp_path / "seed.ply"), props)
+    with open(tmp_path / "seed_ascii.ply", "w") as f:
+        f.write("ply\nformat ascii 1.0\ncomment hand written\nelement vertex %d\n" % n)
+        for k in ("x", "y", "z", "nx", "ny", "nz"):
+            f.write(f"property float {k}\n")
+        for k in ("red", "green", "blue"):
+            f.write(f"property uchar {k}\n")
+        f.write("element face 0\nproperty list uchar int vertex_indices\nend_header\n")
+        for i in range(n):
+            f.write(" ".join(repr(float(props[k][i])) for k in ("x", "y", "z", "nx", "ny", "nz")) + " " +
+                    " ".join(str(int(props[k][i])) for k in ("red", "green", "blue")) + "\n")
+    a, b = fio.read_ply(str(tmp_path / "seed.ply")), fio.read_ply(str(tmp_path / "seed_ascii.ply"))
+    assert list(a) == list(props) == list(b)
+    for k in props:
+        assert a[k].dtype == props[k].dtype and np.array_equal(a[k], props[k]) and np.array_equal(b[k], props[k]), k
+    # --- PCD ascii
+    with open(tmp_path / "patch.pcd", "w") as f:
+        f.write("# .PCD v0.7\nVERSION 0.7\nFIELDS x y z\nSIZE 4 4 4\nTYPE F F F\nCOUNT 1 1 1\nWIDTH 5\nHEIGHT 1\n"
+                "VIEWPOINT 0 0 0 1 0 0 0\nPOINTS 5\nDATA ascii\n")
+        for i in range(5):
+            f.write(f"{pts[i, 0].item()!r} {pts[i, 1].item()!r} {pts[i, 2].item()!r}\n")
+    pc = fio.read_pcd(str(tmp_path / "patch.pcd"))
+    assert np.array_equal(np.stack([pc["x"], pc["y"], pc["z"]], -1), pts[:5].numpy())
+    # --- seeds -> Gaussians
+    P, C, Nn = fio.load_seed_points(str(tmp_path / "seed.ply"))
+    assert torch.equal(P, pts) and torch.equal(C, col.float()) and torch.allclose(Nn, nrm)
+    d = torch.cdist(pts.double(), pts.double())
+    d.fill_diagonal_(float("inf"))
+    want = d.topk(3, largest=False).values.mean(-1, keepdim=True).float()
+    assert torch.allclose(fio.knn_mean_distance(pts, 3), want, rtol=1e-4, atol=1e-6)
+    gp = fio.init_gauss_params(P, C, None, sh_degree=3, generator=torch.Generator().manual_seed(1))
+    assert gp["features_rest"].shape == (n, 15, 3) and float(gp["features_rest"].abs().max()) == 0.0
+    assert torch.allclose(gp["features_dc"], (C / 255 - 0.5) / C0)
+    assert torch.allclose(gp["scales"], torch.log(want).repeat(1, 3), rtol=1e-4, atol=1e-5)
+    assert torch.allclose(gp["opacities"], torch.full((n, 1), -2.1972246), atol=1e-5)
+    assert torch.allclose(gp["quats"].norm(dim=-1), torch.ones(n), atol=1e-5)
+    gn = fio.init_gauss_params(P, C, Nn, sh_degree=3)
+    assert torch.allclose(gn["scales"][:, 2], torch.log(want[:, 0] / 10), rtol=1e-4, atol=1e-5)
+    from fusionsense_amd.legacy import quat_to_rotmat
+    z_axis = quat_to_rotmat(gn["quats"] / gn["quats"].norm(dim=-1, keepdim=True))[:, :, 2]
+    assert (z_axis - Nn).abs().max().item() < 1e-4, "the thin axis is turned onto the seed normal"
+    # --- splat PLY: header order, channel-major f_rest, non-finite rows dropped, exact round trip
+    gp["features_rest"] = torch.randn(n, 15, 3, generator=g)
+    gp["means"][3, 1] = float("nan")
+    kept = fio.export_gaussian_splat_ply(gp, str(tmp_path / "splat.ply"))
+    assert kept == n - 1
+    raw = fio.read_ply(str(tmp_path / "splat.ply"))
+    names = ["x", "y", "z", "nx", "ny", "nz", "f_dc_0", "f_dc_1", "f_dc_2"] + [f"f_rest_{i}" for i in range(45)] + \
+            ["opacity", "scale_0", "scale_1", "scale_2", "rot_0", "rot_1", "rot_2", "rot_3"]
+    assert list(raw) == names and all(v.dtype == np.float32 for v in raw.values())
+    ok = torch.ones(n, dtype=torch.bool)
+    ok[3] = False
+    assert np.array_equal(raw["f_rest_1"], gp["features_rest"][ok][:, 1, 0].numpy())       # channel 0, band 2
+    assert np.array_equal(raw["f_rest_15"], gp["features_rest"][ok][:, 0, 1].numpy())      # channel 1, band 1
+    back = fio.import_gaussian_splat_ply(str(tmp_path / "splat.ply"))
+    for k in gp:
+        assert torch.equal(back[k], gp[k][ok]), k
+
+
+def test_checkpoint_roundtrip_resizes_like_splatfacto(tmp_path):
+    from fusionsense_amd import io as fio, scenes
+    from fusionsense_amd.trainer import SplatTrainer
+    dev = torch.device("cpu")
+    pa, _ = scenes.cube_scene(50, seed=1)
+    pb, _ = scenes.cube_scene(31, seed=2)
+    a = SplatTrainer(pa, dev, fused=False)
+    for k, p in a.params.items():           # one hand-made optimizer step so that the Adam moments exist
+        p.grad = torch.full_like(p, 0.01)
+    for opt in a.optimizers.values():
+        opt.step()
+    a.step = 1234
+    fio.save_checkpoint(a, str(tmp_path / "step-000001234.ckpt"))
+    ck = torch.load(str(tmp_path / "step-000001234.ckpt"), weights_only=False)
+    assert set(ck) >= {"step", "pipeline", "optimizers"} and "_model.gauss_params.means" in ck["pipeline"]
+    b = SplatTrainer(pb, dev, fused=False)
+    assert fio.load_checkpoint(b, str(tmp_path / "step-000001234.ckpt")) == 1234
+    assert b.num_gaussians() == 50 and b.slab.flat.numel() == 50 * 59
+    for k in a.params:
+        assert torch.equal(a.params[k].detach(), b.params[k].detach()), k
+        sa, sb = a.optimizers[k].state[a.params[k]], b.optimizers[k].state[b.params[k]]
+        assert torch.equal(sa["exp_avg"], sb["exp_avg"]) and torch.equal(sa["exp_avg_sq"], sb["exp_avg_sq"])
+        assert b.params[k].grad is b.slab.views[k]
