@@ -72,7 +72,11 @@ raster_fwd_quad_kernel(int64_t cap, const float4 *__restrict__ packed, const int
     const int tile_y = tile_in / tw, tile_x = tile_in - tile_y * tw;
     const int qx = 2 * tile_x + (q & 1), qy = 2 * tile_y + (q >> 1);
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, slot = lane & 3;
-    const int p = w * 16 + (lane >> 2);  // pixel of the quadrant, row-major 8x8
+    // wave w composites the 4x4 pixel block (w >> 1, w & 1) of the quadrant (a compact footprint: fewer
+    // records reach any of its pixels than would reach an 8x2 strip, so more steps skip their second half);
+    // p = the pixel's row-major index in the 8x8 quadrant, the order the backward expects
+    const int pl = lane >> 2;
+    const int p = (((w >> 1) << 2) + (pl >> 2)) * 8 + ((w & 1) << 2) + (pl & 3);
     const int j = qx * 8 + (p & 7), i = qy * 8 + (p >> 3);
     const float px = (float)j + 0.5f, py = (float)i + 0.5f;
     const bool inside = (i < H) && (j < W);
