@@ -8,6 +8,7 @@ all arithmetic happens in libfsgs.so.  There is no CPU fallback.
 from __future__ import annotations
 
 import ctypes as C
+import os
 import time
 import math
 from typing import Optional, Tuple
@@ -276,7 +277,7 @@ def isect_finish_live(st: dict, means2d: Tensor, radii: Tensor, depths: Tensor, 
 
 
 USE_TILE_SORT = True
-TILE_SORT_MAX_MEAN_BUCKET = 1024  # denser scenes keep the global radix sort (many buckets would not fit LDS)
+TILE_SORT_MAX_MEAN_BUCKET = int(os.environ.get("FSGS_TILE_SORT_MAX_MEAN", "1024"))  # denser scenes keep the global radix sort (many buckets would not fit LDS)
 
 
 def use_tile_sort(M: int, T: int) -> bool:
