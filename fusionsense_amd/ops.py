@@ -32,13 +32,23 @@ class _KernelTimer:
         self.enabled = False
         self.records = []
         self.only = None
+        self.pool = []
 
-    def reset(self, enabled: bool = False, only=None) -> None:
-        """only: optional tuple of name prefixes; other launches are not timed (two event records
-        per launch are not free on the host)."""
+    def reset(self, enabled: bool = False, only=None, prealloc: int = 0) -> None:
+        """only: optional tuple of name prefixes; other launches are not timed (creating and recording two
+        events per launch costs ~10 us of host time, i.e. a GPU bubble in front of the launch).  prealloc:
+        number of spans whose events are created AND instantiated now, outside the region being timed."""
         self.enabled = enabled
         self.records = []
         self.only = tuple(only) if only else None
+        self.pool = []
+        for _ in range(2 * prealloc):
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()  # (the HIP event is created lazily at its first record)
+            self.pool.append(e)
+
+    def _event(self):
+        return self.pool.pop() if self.pool else torch.cuda.Event(enable_timing=True)
 
     class _Span:
         def __init__(self, timer, name):
@@ -47,8 +57,8 @@ class _KernelTimer:
         def __enter__(self):
             self.on = self.timer.enabled and (self.timer.only is None or self.name.startswith(self.timer.only))
             if self.on:
-                self.start = torch.cuda.Event(enable_timing=True)
-                self.end = torch.cuda.Event(enable_timing=True)
+                self.start = self.timer._event()
+                self.end = self.timer._event()
                 self.h0 = time.perf_counter()
                 self.start.record()
             return self
