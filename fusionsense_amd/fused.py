@@ -293,3 +293,58 @@ def render_fusionsense_fused(gauss_params: Dict[str, Tensor], camera: Camera, sh
         background.contiguous(), info, grad_out)
     return {"rgb": rgb, "depth": depth, "normal": normal, "accumulation": alpha, "background": background,
             "info": info, "xys": info, "radii": info.radii[0], "normals_world": info.normals_world}
+
+
+class _DirectCtx:
+    """What ``_FusedGetOutputs`` / ``ops._TrainLoss`` need from an autograd context, without the tape: the
+    trainer's step is a fixed two-node graph, so it calls forward and backward of both nodes itself and
+    skips torch.autograd's bookkeeping and the hand-off to its engine thread (~15 us of GPU bubble in front
+    of the first backward launch, ~80 us of host time per step)."""
+
+    def __init__(self, needs_input_grad):
+        self.needs_input_grad = tuple(needs_input_grad)
+        self.saved_tensors = ()
+
+    def save_for_backward(self, *tensors):
+        self.saved_tensors = tensors
+
+    def set_materialize_grads(self, value):
+        pass
+
+    def mark_non_differentiable(self, *args):
+        pass
+
+
+def fused_step_forward_backward(gauss_params: Dict[str, Tensor], camera: Camera, target: Dict[str, Tensor],
+                                sh_degree: int, device, grad_out: Dict[str, Tensor], seed_grad: Tensor,
+                                stats_out: Optional[dict] = None, add_mask: Optional[Tensor] = None,
+                                binary_threshold: Optional[float] = None, ssim_lambda: float = 0.2,
+                                w_depth: float = 0.2, w_normal: float = 0.1):
+    """get_outputs -> config-#2 loss -> both backward passes, without the autograd tape.  The parameter
+    gradients land in ``grad_out`` (the trainer's slab views).  Returns (loss 0-d tensor, outputs dict)."""
+    dev = device
+    background = _ONES3.get(str(dev))
+    if background is None:
+        background = _ONES3.setdefault(str(dev), torch.ones(3, device=dev))
+    cam = _camera_on_device(camera, dev)
+    info = FrameInfo()
+    info.stats_out = stats_out
+    info.binary_threshold = binary_threshold
+    if add_mask is not None:
+        info.frozen = add_mask.to(device=dev, dtype=torch.uint8).contiguous()
+    has_n = "normal" in target
+    with torch.no_grad():
+        ctx = _DirectCtx((True,) * 6 + (False,) * 7)
+        rgb, depth, normal, alpha = _FusedGetOutputs.forward(
+            ctx, gauss_params["means"], gauss_params["scales"], gauss_params["quats"], gauss_params["features_dc"],
+            gauss_params["features_rest"], gauss_params["opacities"], cam, camera.width, camera.height,
+            int(sh_degree), background, info, grad_out)
+        lctx = _DirectCtx((True, False, True, False, has_n, False, False, False, False))
+        loss = ops._TrainLoss.forward(lctx, rgb, target["rgb"], depth, target["depth"], normal if has_n else None,
+                                      target["normal"] if has_n else None, float(ssim_lambda), float(w_depth),
+                                      float(w_normal))
+        v = ops._TrainLoss.backward(lctx, seed_grad)
+        _FusedGetOutputs.backward(ctx, v[0], v[2], v[4], None)
+    out = {"rgb": rgb, "depth": depth, "normal": normal, "accumulation": alpha, "background": background,
+           "info": info, "xys": info, "radii": info.radii[0], "normals_world": info.normals_world}
+    return loss, out

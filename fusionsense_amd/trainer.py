@@ -71,11 +71,15 @@ class GradSlab:
 class SplatTrainer:
     def __init__(self, params: Dict[str, Tensor], device: torch.device, sh_degree: int = 3,
                  optim: Optional[OptimConfig] = None, fused_adam: bool = True, seed: int = 0,
-                 strategy=None, fused: bool = True, sh_degree_interval: Optional[int] = None):
+                 strategy=None, fused: bool = True, sh_degree_interval: Optional[int] = None,
+                 direct: bool = True):
         self.device = device
         # fused=True: get_outputs as one autograd node (fusionsense_amd/fused.py); False: the
         # reference's op-by-op caller through the drop-in rasterization()/rasterize_gaussians() surface
         self.fused = fused
+        # direct=True (fused only): the step's fixed two-node graph (get_outputs, loss) is run forward and
+        # backward by hand instead of through torch.autograd (same kernels, same gradients in the slab)
+        self.direct = direct
         self.sh_degree = sh_degree
         # sh_degree_to_use = min(step // sh_degree_interval, sh_degree) (dn_model.py:562-565; nerfstudio default
         # interval 1000); None = always the full degree (BASELINE config #2 is quoted at degree 3)
@@ -106,18 +110,17 @@ class SplatTrainer:
     def num_gaussians(self) -> int:
         return self.params["means"].shape[0]
 
-    def forward(self, camera: Camera, sh_degree_to_use: Optional[int] = None, crop_box=None):
-        """get_outputs.  In training mode (grad enabled) the strategy supplies what the model state supplies
-        in the reference: the binary-opacity schedule (dn_model.py:492-503) and the touch-anchor mask
-        (:535-541); ``crop_box`` is honoured only without grad, like ``not self.training`` there (:505-532)."""
+    def _sh_degree_now(self, sh_degree_to_use: Optional[int] = None) -> int:
         if sh_degree_to_use is not None:
-            deg = sh_degree_to_use
-        elif self.sh_degree_interval:
-            deg = min(self.step // self.sh_degree_interval, self.sh_degree)
-        else:
-            deg = self.sh_degree
-        grad = torch.is_grad_enabled()
-        add_mask, bthr = None, None
+            return sh_degree_to_use
+        if self.sh_degree_interval:
+            return min(self.step // self.sh_degree_interval, self.sh_degree)
+        return self.sh_degree
+
+    def _frame_state(self, camera: Camera, grad: bool):
+        """(after_train statistics target, touch-anchor mask, binary-opacity threshold or None) for this step:
+        what the model state supplies to get_outputs in the reference (dn_model.py:492-503, 535-541)."""
+        stats, add_mask, bthr = None, None, None
         if self.strategy is not None:
             add_mask = getattr(self.strategy, "add_mask", None)
             cfg = getattr(self.strategy, "cfg", None)
@@ -125,11 +128,19 @@ class SplatTrainer:
                 from .splatfacto import binary_opacity_active
                 if binary_opacity_active(cfg, self.step):
                     bthr = cfg.binary_opacities_threshold
+            if grad and self.fused and hasattr(self.strategy, "stats_target"):
+                stats = self.strategy.stats_target(self, self.num_gaussians(), self.device, camera)
+        return stats, add_mask, bthr
+
+    def forward(self, camera: Camera, sh_degree_to_use: Optional[int] = None, crop_box=None):
+        """get_outputs.  In training mode (grad enabled) the strategy supplies what the model state supplies
+        in the reference: the binary-opacity schedule (dn_model.py:492-503) and the touch-anchor mask
+        (:535-541); ``crop_box`` is honoured only without grad, like ``not self.training`` there (:505-532)."""
+        deg = self._sh_degree_now(sh_degree_to_use)
+        grad = torch.is_grad_enabled()
+        stats, add_mask, bthr = self._frame_state(camera, grad)
         if self.fused:
             from .fused import render_fusionsense_fused
-            stats = None
-            if grad and self.strategy is not None and hasattr(self.strategy, "stats_target"):
-                stats = self.strategy.stats_target(self, self.num_gaussians(), self.device, camera)
             return render_fusionsense_fused(self.params, camera, sh_degree=deg, device=self.device,
                                             grad_out=self.slab.views if grad else None, stats_out=stats,
                                             add_mask=add_mask, crop_box=crop_box, training=grad,
@@ -174,13 +185,20 @@ class SplatTrainer:
         adam_step_(ps, gs, ms, vs, lrs, self.adam_steps, 0.9, 0.999, self.optim_cfg.eps)
 
     def train_step(self, camera: Camera, target: Dict[str, Tensor], optimizer_step: bool = True):
-        if not self.fused:
-            self.slab.zero_()  # autograd accumulates into the slab views; the fused node overwrites them
-        out = self.forward(camera)
-        loss = self.loss(out, target)
-        if getattr(self, "_one", None) is None or self._one.device != loss.device:
-            self._one = torch.ones((), dtype=loss.dtype, device=loss.device)
-        loss.backward(gradient=self._one)  # (the default would launch a fill kernel for the seed gradient)
+        if getattr(self, "_one", None) is None or self._one.device != self.device:
+            self._one = torch.ones((), dtype=torch.float32, device=self.device)
+        if self.fused and self.direct and self.device.type == "cuda" and "depth" in target:
+            from .fused import fused_step_forward_backward
+            stats, add_mask, bthr = self._frame_state(camera, True)
+            loss, out = fused_step_forward_backward(self.params, camera, target, self._sh_degree_now(), self.device,
+                                                    self.slab.views, self._one, stats_out=stats, add_mask=add_mask,
+                                                    binary_threshold=bthr)
+        else:
+            if not self.fused:
+                self.slab.zero_()  # autograd accumulates into the slab views; the fused node overwrites them
+            out = self.forward(camera)
+            loss = self.loss(out, target)
+            loss.backward(gradient=self._one)  # (the default would launch a fill kernel for the seed gradient)
         self.slab.all_reduce_mean_()
         if optimizer_step:
             self.optimizers["means"].param_groups[0]["lr"] = self._means_lr(self.step)
