@@ -147,20 +147,22 @@ raster_bwd_live_kernel(int64_t cap, const float4 *__restrict__ rec,
         __builtin_amdgcn_wave_barrier();
         // nothing above wave_bin_final was composited by this wave's pixels
         if (__float_as_int(L.r1[n - 1].z) > wave_bin_final) continue;
-        float T, buffer[D], bufe[E ? E : 1];
+        // Per pixel the walk needs the colour still behind the current record only through its product with
+        // the pixel's output gradient:  sum_k (c_k T - buffer_k ra) v_k = T (c . v) - ra (buffer . v),  and
+        // buffer . v grows by fac (c . v) per record.  One running scalar per plane instead of D (+E) channel
+        // accumulators: 4 instead of 5 instructions per channel, 5 fewer live registers.
+        float T, Bd, Be = 0.f;
         if (seg == n_seg - 1) {
             T = T_final;
-#pragma unroll
-            for (int k = 0; k < D; ++k) buffer[k] = 0.f;
-#pragma unroll
-            for (int k = 0; k < E; ++k) bufe[k] = 0.f;
+            Bd = 0.f;
         } else {
             const float *slot = seg_q + ((int64_t)((b0 + 64) >> 6) + tile_lin) * SS;
             T = slot[lane];
+            Bd = 0.f;
 #pragma unroll
-            for (int k = 0; k < D; ++k) buffer[k] = c_total[k] - slot[64 * (1 + k) + lane];
+            for (int k = 0; k < D; ++k) Bd += (c_total[k] - slot[64 * (1 + k) + lane]) * v_out[k];
 #pragma unroll
-            for (int k = 0; k < E; ++k) bufe[k] = ce_total[k] - slot[64 * (1 + D + k) + lane];
+            for (int k = 0; k < E; ++k) Be += (ce_total[k] - slot[64 * (1 + D + k) + lane]) * v_oute[k];
         }
         for (int t = 0; t < n; ++t) {
             const float4 a0 = L.r0[t], a1 = L.r1[t];
@@ -183,28 +185,30 @@ raster_bwd_live_kernel(int64_t cap, const float4 *__restrict__ rec,
             const float ra = __builtin_amdgcn_rcpf(1.f - alpha);  // 1 ulp; alpha <= 0.999
             T *= ra;
             const float fac = alpha * T;
-            float v_alpha = 0.f;
 #pragma unroll
             for (int k = 0; k < 4; ++k) g[k] = 0.f;
+            float Cd = 0.f;
 #pragma unroll
             for (int k = 0; k < D; ++k) {
                 g[k] = fac * v_out[k];
-                v_alpha += (col[k] * T - buffer[k] * ra) * v_out[k];
-                buffer[k] += col[k] * fac;
+                Cd += col[k] * v_out[k];
             }
+            float v_alpha = T * Cd - ra * Bd;
+            Bd += fac * Cd;
             v_alpha += T_final * ra * v_out_a;
             if (backgrounds) v_alpha -= T_final * ra * bg_dot;
             float v_alpha_e = 0.f;  // the extra plane's share: conics / opacity only
             if (E) {
                 const float4 e4 = L.r3[t];
                 const float ce[3] = {e4.x, e4.y, e4.z};
+                float Ce = 0.f;
 #pragma unroll
                 for (int k = 0; k < E; ++k) {
                     ge[k] = fac * v_oute[k];
-                    v_alpha_e += (ce[k] * T - bufe[k] * ra) * v_oute[k];
-                    bufe[k] += ce[k] * fac;
+                    Ce += ce[k] * v_oute[k];
                 }
-                v_alpha_e -= T_final * ra * bge_dot;
+                v_alpha_e = T * Ce - ra * Be - T_final * ra * bge_dot;
+                Be += fac * Ce;
             }
             {
                 const float ov = (a0.z * vis <= kAlphaMax) ? a0.z * vis : 0.f;  // clamp active: no sigma grads
