@@ -1,5 +1,6 @@
-// Exact reach test of a projected Gaussian against the 8x8 pixel quadrants of a 16x16 tile
-// (shared by live.hip and the live emission kernels of isect.hip).
+// Exact reach test of a projected Gaussian against the 8x8 pixel quadrants of a 16x16 tile and the 4x4
+// blocks of a quadrant (shared by live.hip, the live emission kernels of isect.hip and the compositing
+// kernels).
 #pragma once
 #include "common.h"
 
@@ -52,17 +53,20 @@ __device__ __forceinline__ CullPrep cull_prepare(float mx, float my, float opac,
     return p;
 }
 
-// 4-bit mask: bit q = qy*2+qx set if the Gaussian can reach quadrant q of the 16x16 tile at
-// (tile_x0, tile_y0).  Conservative: a set bit never hides a contribution.
-// The four quadrants' rectangles of pixel centres are bounded by 4 vertical and 4 horizontal lines
-// (x0 + {0.5, 7.5, 8.5, 15.5}); on each line the form is a 1-D parabola, minimised over each of the
-// two half ranges by clamping its vertex: 16 three-instruction evaluations per tile.
-__device__ __forceinline__ unsigned quadrant_mask(const CullPrep &p, float tile_x0, float tile_y0) {
+// 4-bit mask: bit q = qy*2+qx set if the Gaussian can reach sub-square q of the (2*HALF)x(2*HALF) pixel
+// square at (x0, y0).  HALF = 8: the 8x8 quadrants of a 16x16 tile; HALF = 4: the 4x4 blocks of a
+// quadrant.  Conservative: a set bit never hides a contribution.
+// The four sub-squares' rectangles of pixel centres are bounded by 4 vertical and 4 horizontal lines
+// (x0 + {0.5, HALF-0.5, HALF+0.5, 2*HALF-0.5}); on each line the form is a 1-D parabola, minimised over
+// each of the two half ranges by clamping its vertex: 16 three-instruction evaluations per square.
+template <int HALF>
+__device__ __forceinline__ unsigned subsquare_mask(const CullPrep &p, float x0, float y0) {
+    constexpr float kL1 = (float)HALF - 0.5f, kL2 = (float)HALF + 0.5f, kL3 = 2.f * (float)HALF - 0.5f;
     float dx[4], dy[4];  // centre minus line coordinate (decreasing in k)
-    dx[0] = p.mx - (tile_x0 + 0.5f); dx[1] = p.mx - (tile_x0 + 7.5f);
-    dx[2] = p.mx - (tile_x0 + 8.5f); dx[3] = p.mx - (tile_x0 + 15.5f);
-    dy[0] = p.my - (tile_y0 + 0.5f); dy[1] = p.my - (tile_y0 + 7.5f);
-    dy[2] = p.my - (tile_y0 + 8.5f); dy[3] = p.my - (tile_y0 + 15.5f);
+    dx[0] = p.mx - (x0 + 0.5f); dx[1] = p.mx - (x0 + kL1);
+    dx[2] = p.mx - (x0 + kL2); dx[3] = p.mx - (x0 + kL3);
+    dy[0] = p.my - (y0 + 0.5f); dy[1] = p.my - (y0 + kL1);
+    dy[2] = p.my - (y0 + kL2); dy[3] = p.my - (y0 + kL3);
     float qv[4][2], qh[4][2];  // [line][half of the other axis]
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -90,6 +94,15 @@ __device__ __forceinline__ unsigned quadrant_mask(const CullPrep &p, float tile_
         if (best <= p.tau) m |= 1u << q;
     }
     return m;
+}
+
+__device__ __forceinline__ unsigned quadrant_mask(const CullPrep &p, float tile_x0, float tile_y0) {
+    return subsquare_mask<8>(p, tile_x0, tile_y0);
+}
+
+// the 4x4 pixel blocks of the 8x8 quadrant at (quad_x0, quad_y0): bit = by*2 + bx
+__device__ __forceinline__ unsigned block_mask(const CullPrep &p, float quad_x0, float quad_y0) {
+    return subsquare_mask<4>(p, quad_x0, quad_y0);
 }
 
 __device__ __forceinline__ unsigned quadrant_mask(float mx, float my, float opac, float a, float b, float c,

@@ -13,6 +13,7 @@
 // 0..14 issue ONE global_atomic_add_f32 into a packed 64-byte per-Gaussian record (one cache line),
 // instead of 15 single-lane atomics to six different arrays.
 #include "common.h"
+#include "cull.h"
 
 namespace fsgs {
 
@@ -22,31 +23,24 @@ namespace fsgs {
 template <int E>
 struct QLds {
     float4 r0[64], r1[64], r2[64], r3[E ? 64 : 1];
+    uint8_t list[4][64];  // per 4x4 pixel block: the segment's slots that can reach it, back to front
 };
 
 struct Rec {
     float4 r0, r1, r2, r3;
 };
 
+// A lane past the end of the segment reads the segment's first record instead (always in range) and
+// zeroes it: an all-zero record composites to alpha = 0.  (No branch: a struct filled on two paths is
+// kept in scratch memory by the compiler.)
 template <int E>
-__device__ __forceinline__ void load_rec(Rec &r, const float4 *__restrict__ rec, int64_t p, bool ok) {
-    if (ok) {
-        const float4 *src = rec + (E ? 4 : 3) * p;
-        r.r0 = src[0]; r.r1 = src[1]; r.r2 = src[2];
-        if (E) r.r3 = src[3];
-    } else {
-        // past the end of the list: an all-zero record composites to alpha = 0, so the forward can
-        // walk whole groups of records without a bounds test
-        r.r0 = make_float4(0.f, 0.f, 0.f, 0.f);
-        r.r1 = r.r0; r.r2 = r.r0;
-        if (E) r.r3 = r.r0;
-    }
-}
-
-__device__ __forceinline__ int wave_max_i32q(int v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v = max(v, __shfl_xor(v, d, 64));
-    return v;
+__device__ __forceinline__ void load_rec(Rec &r, const float4 *__restrict__ rec, int64_t p, int64_t p_safe, bool ok) {
+    const float4 *src = rec + (E ? 4 : 3) * (ok ? p : p_safe);
+    auto keep = [ok](float4 v) {
+        return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+    };
+    r.r0 = keep(src[0]); r.r1 = keep(src[1]); r.r2 = keep(src[2]);
+    if (E) r.r3 = keep(src[3]);
 }
 
 // packed gradient record, 16 floats per (camera, Gaussian):
@@ -82,13 +76,17 @@ raster_bwd_live_kernel(int64_t cap, const float4 *__restrict__ rec,
     const int n_tiles_total = gridDim.z * th * tw;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     QLds<E> &L = Lw[w];
-    const int j = blockIdx.x * 8 + (lane & 7), i = blockIdx.y * 8 + (lane >> 3);
+    // row r of the wave (16 lanes) owns the 4x4 pixel block (r >> 1, r & 1) of the quadrant and walks ITS OWN
+    // list of the segment's records (those that can reach the block): a record reaches 2.6 of a quadrant's 4
+    // blocks on average, so a 64-record segment costs max_r(n_r) ~ 45 steps instead of 64
+    const int row = lane >> 4, pl = lane & 15;
+    const int p = (((row >> 1) << 2) + (pl >> 2)) * 8 + ((row & 1) << 2) + (pl & 3);  // row-major in the quadrant
+    const int j = blockIdx.x * 8 + (p & 7), i = blockIdx.y * 8 + (p >> 3);
     const float px = (float)j + 0.5f, py = (float)i + 0.5f;
     const bool inside = (i < H) && (j < W);
     const int64_t pix_id = ((int64_t)cam * H + min(i, H - 1)) * W + min(j, W - 1);
 
     const int64_t l0 = tile_offsets[tile_lin];
-    const int64_t l1 = (tile_lin == n_tiles_total - 1) ? n_isects : (int64_t)tile_offsets[tile_lin + 1];
     // streams written by fsgs_raster_fwd_quad: stream position l0 + 4 * tile, record count from the forward
     const int s = (int)l0 + 4 * tile_lin;
     const int e = s + n_rec[(int64_t)q * n_tiles_total + tile_lin];
@@ -133,42 +131,61 @@ raster_bwd_live_kernel(int64_t cap, const float4 *__restrict__ rec,
         for (int k = 0; k < D; ++k) bg_dot += backgrounds[cam * D + k] * v_out[k];
     }
     const int bin_final = inside ? last_ids[pix_id] : -1;
-    const int wave_bin_final = wave_max_i32q(bin_final);
+    int rbf = bin_final;  // last composited list index over the row's 16 pixels
+#pragma unroll
+    for (int d = 8; d >= 1; d >>= 1) rbf = max(rbf, __shfl_xor(rbf, d, 64));
+    int row_bin_final[4];
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) row_bin_final[r4] = __builtin_amdgcn_readlane(rbf, 16 * r4);
+    const float quad_x0 = (float)(blockIdx.x * 8), quad_y0 = (float)(blockIdx.y * 8);
 
     for (int seg = n_seg - 1 - w; seg >= 0; seg -= kBwdWaves) {
         const int b0 = s + (seg << 6);          // first stream position of the segment
         const int n = min(64, e - b0);
         // slot t holds stream position b0 + n - 1 - t (descending list order)
         Rec r;
-        load_rec<E>(r, stream, (int64_t)b0 + n - 1 - lane, lane < n);
+        load_rec<E>(r, stream, (int64_t)b0 + n - 1 - lane, (int64_t)b0, lane < n);
         L.r0[lane] = r.r0; L.r1[lane] = r.r1; L.r2[lane] = r.r2;
         if (E) L.r3[lane] = r.r3;
+        // which blocks this lane's record can reach (exact in the conservative direction, cull.h; padding
+        // records have opacity 0 and reach nothing), and whether any of the block's pixels composited it
+        unsigned bm = 0u;
+        if (lane < n) {
+            const CullPrep cp = cull_prepare(r.r0.x, r.r0.y, r.r0.z, r.r0.w, r.r1.x, r.r1.y);
+            bm = block_mask(cp, quad_x0, quad_y0);
+        }
+        const int isect_l = __float_as_int(r.r1.z);
+        int my_n = 0, steps = 0;
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+            const bool lv = ((bm >> r4) & 1u) && (isect_l <= row_bin_final[r4]);
+            const uint64_t m = __ballot(lv);
+            if (lv) L.list[r4][__popcll(m & ((1ull << lane) - 1ull))] = (uint8_t)lane;
+            const int c = __popcll(m);
+            my_n = (row == r4) ? c : my_n;
+            steps = max(steps, c);
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        // nothing above wave_bin_final was composited by this wave's pixels
-        if (__float_as_int(L.r1[n - 1].z) > wave_bin_final) continue;
         // Per pixel the walk needs the colour still behind the current record only through its product with
         // the pixel's output gradient:  sum_k (c_k T - buffer_k ra) v_k = T (c . v) - ra (buffer . v),  and
         // buffer . v grows by fac (c . v) per record.  One running scalar per plane instead of D (+E) channel
         // accumulators: 4 instead of 5 instructions per channel, 5 fewer live registers.
-        float T, Bd, Be = 0.f;
-        if (seg == n_seg - 1) {
-            T = T_final;
-            Bd = 0.f;
-        } else {
+        float T = T_final, Bd = 0.f, Be = 0.f;
+        if (steps > 0 && seg != n_seg - 1) {
             const float *slot = seg_q + ((int64_t)((b0 + 64) >> 6) + tile_lin) * SS;
-            T = slot[lane];
-            Bd = 0.f;
+            T = slot[p];
 #pragma unroll
-            for (int k = 0; k < D; ++k) Bd += (c_total[k] - slot[64 * (1 + k) + lane]) * v_out[k];
+            for (int k = 0; k < D; ++k) Bd += (c_total[k] - slot[64 * (1 + k) + p]) * v_out[k];
 #pragma unroll
-            for (int k = 0; k < E; ++k) Be += (ce_total[k] - slot[64 * (1 + D + k) + lane]) * v_oute[k];
+            for (int k = 0; k < E; ++k) Be += (ce_total[k] - slot[64 * (1 + D + k) + p]) * v_oute[k];
         }
-        for (int t = 0; t < n; ++t) {
+        for (int kk = 0; kk < steps; ++kk) {
+            const bool have = kk < my_n;
+            const int t = have ? (int)L.list[row][kk] : 0;
             const float4 a0 = L.r0[t], a1 = L.r1[t];
             const int isect = __float_as_int(a1.z);
-            if (isect > wave_bin_final) continue;  // wave-uniform
-            bool valid = inside && (isect <= bin_final);
+            bool valid = have && inside && (isect <= bin_final);
             const float dx = a0.x - px, dy = a0.y - py;
             const float sigma = 0.5f * (a0.w * dx * dx + a1.y * dy * dy) + a1.x * dx * dy;
             const float vis0 = __expf(-sigma);
@@ -223,8 +240,9 @@ raster_bwd_live_kernel(int64_t cap, const float4 *__restrict__ rec,
                 g[10] = ABS ? fabsf(g[8]) : 0.f;
                 g[11] = (a0.z * vis <= kAlphaMax) ? vis * (v_alpha + v_alpha_e) : 0.f;
             }
-            // 15 per-pixel partials -> 15 per-Gaussian totals: transposed row sums (lane l: value l & 15),
-            // the four rows meet through two lane permutes, lanes 0..14 issue ONE atomic
+            // 15 per-pixel partials -> the row's 15 per-Gaussian totals: transposed row sum (lane l ends with
+            // the sum of value l & 15 over its row's 16 pixels); lanes 0..14 of every row add their record's
+            // totals with ONE atomic instruction (four Gaussians, one cache line each)
             float vals[16];
 #pragma unroll
             for (int k = 0; k < 12; ++k) vals[k] = g[k];
@@ -232,15 +250,13 @@ raster_bwd_live_kernel(int64_t cap, const float4 *__restrict__ rec,
             for (int k = 0; k < 3; ++k) vals[12 + k] = (k < E) ? ge[k] : 0.f;
             vals[15] = 0.f;
             row_transpose_sum16(vals);
-            float tot = vals[0];
-            tot += __shfl_xor(tot, 16, 64);
-            tot += __shfl_xor(tot, 32, 64);
-            if (lane < 12 + E) {
-                const bool used = (lane < D) || (lane >= 4 && lane <= 8) || (ABS && (lane == 9 || lane == 10)) ||
-                                  (lane == 11) || (lane >= 12);
+            const float tot = vals[0];
+            if (pl < 12 + E && tot != 0.f) {
+                const bool used = (pl < D) || (pl >= 4 && pl <= 8) || (ABS && (pl == 9 || pl == 10)) ||
+                                  (pl == 11) || (pl >= 12);
                 if (used) {
-                    const int64_t gid = __float_as_int(a1.w);
-                    unsafeAtomicAdd(&v_packed[gid * 16 + lane], tot);
+                    const int64_t gid = __float_as_int(a1.w) & 0x0FFFFFFF;
+                    unsafeAtomicAdd(&v_packed[gid * 16 + pl], tot);
                 }
             }
         }

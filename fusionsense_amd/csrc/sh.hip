@@ -89,26 +89,71 @@ __device__ __forceinline__ void sh_basis(int degree, float x, float y, float z, 
     }
 }
 
-constexpr int kShBlock = 256;
+#ifndef FSGS_SH_BLOCK
+#define FSGS_SH_BLOCK 256
+#endif
+constexpr int kShBlock = FSGS_SH_BLOCK;  // Gaussians (= threads) per workgroup
 
-// Stage `rows` consecutive records of `row_floats` floats (contiguous in HBM) into LDS with
-// a row pitch of row_floats+1 dwords.
-__device__ __forceinline__ void stage_rows(const float *__restrict__ src, int rows, int row_floats,
-                                           float *lds, int pitch, int col_off) {
-    const int total = rows * row_floats;
-    lds += col_off;
+// Stage `rows` consecutive records of `row_floats` floats (contiguous in HBM) into LDS with a row pitch of
+// `pitch` dwords, 16 bytes per lane per load.  RF > 0 fixes row_floats at compile time: the (row, column)
+// of a float4's first element then costs a multiply-shift instead of a ~20-instruction integer division
+// per ELEMENT, and the other three follow by increment-and-wrap.  Loading and parking are separate calls so
+// that a kernel can issue EVERY global load it needs (both coefficient arrays, means, radii, gradients)
+// before it waits for the first one: written as one loop the compiler waits for each load in turn, and
+// a workgroup then spends a dozen serialised HBM round trips (~20 us of a 23 us kernel) staging.
+template <int RF>
+struct Staged {
+    float4 v[RF ? (RF + 3) / 4 : 1];
+};
+
+template <int RF>
+__device__ __forceinline__ void stage_load(Staged<RF> &st, const float *__restrict__ src, int rows) {
+    if (!RF) return;
     // src is 4-byte aligned only in general (row start = n0*K*3 floats); n0 is a multiple of 256
     // so the span start is 16-byte aligned whenever the tensor base is.
     const float4 *src4 = reinterpret_cast<const float4 *>(src);
-    const int total4 = total >> 2;
-    for (int i = threadIdx.x; i < total4; i += kShBlock) {
-        const float4 v = src4[i];
-        const int e = i << 2;
-        const float vv[4] = {v.x, v.y, v.z, v.w};
+    const int total4 = (rows * RF) >> 2;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int r = (e + k) / row_floats, col = (e + k) - r * row_floats;
-            lds[r * pitch + col] = vv[k];
+    for (int it = 0; it < (RF + 3) / 4; ++it) {
+        const int i = threadIdx.x + it * kShBlock;
+        if (i < total4) st.v[it] = src4[i];  // (a select between float4s would go through scratch memory)
+    }
+}
+
+template <int RF>
+__device__ __forceinline__ void stage_store(const Staged<RF> &st, const float *__restrict__ src, int rows,
+                                            int row_floats_rt, float *lds, int pitch, int col_off) {
+    const int row_floats = RF ? RF : row_floats_rt;
+    const int total = rows * row_floats;
+    lds += col_off;
+    const int total4 = total >> 2;
+    if (RF) {
+#pragma unroll
+        for (int it = 0; it < (RF + 3) / 4; ++it) {
+            const int i = threadIdx.x + it * kShBlock;
+            if (i < total4) {
+                const int e = i << 2;
+                const float vv[4] = {st.v[it].x, st.v[it].y, st.v[it].z, st.v[it].w};
+                int r = e / row_floats, col = e - r * row_floats;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    lds[r * pitch + col] = vv[k];
+                    if (++col == row_floats) { col = 0; ++r; }
+                }
+            }
+        }
+    } else {
+        const float4 *src4 = reinterpret_cast<const float4 *>(src);
+        for (int i = threadIdx.x; i < total4; i += kShBlock) {
+            const float4 v = src4[i];
+            const int e = i << 2;
+            const float vv[4] = {v.x, v.y, v.z, v.w};
+            int r = e / row_floats, col = e - r * row_floats;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                lds[r * pitch + col] = vv[k];
+                if (++col == row_floats) { col = 0; ++r; }
+            }
         }
     }
     for (int i = (total4 << 2) + threadIdx.x; i < total; i += kShBlock) {
@@ -117,6 +162,70 @@ __device__ __forceinline__ void stage_rows(const float *__restrict__ src, int ro
     }
 }
 
+// The coefficients come either split (features_dc [N,3] + features_rest [N,K-1,3], SPLIT) or as one
+// [N,K,3] array.  (SPLIT is a template parameter: a struct of register arrays that is filled on one of
+// two run-time paths is kept in scratch memory by the compiler.)
+template <int KT, bool SPLIT>
+struct StagedCoeffs {
+    Staged<SPLIT ? 3 : KT * 3> a;            // features_dc, or the whole array
+    Staged<(SPLIT && KT) ? KT * 3 - 3 : 0> b;  // features_rest
+};
+
+template <int KT, bool SPLIT>
+__device__ __forceinline__ void coeffs_load(StagedCoeffs<KT, SPLIT> &st, const float *__restrict__ coeffs,
+                                            const float *__restrict__ coeffs_rest, int n0, int rows, int K) {
+    const int row_floats = K * 3;
+    if (SPLIT) {
+        stage_load(st.a, coeffs + (int64_t)n0 * 3, rows);
+        if (K > 1) stage_load(st.b, coeffs_rest + (int64_t)n0 * (row_floats - 3), rows);
+    } else {
+        stage_load(st.a, coeffs + (int64_t)n0 * row_floats, rows);
+    }
+}
+
+template <int KT, bool SPLIT>
+__device__ __forceinline__ void coeffs_park(const StagedCoeffs<KT, SPLIT> &st, const float *__restrict__ coeffs,
+                                            const float *__restrict__ coeffs_rest, int n0, int rows, int K,
+                                            float *lds) {
+    const int row_floats = K * 3, pitch = row_floats + 1;
+    if (SPLIT) {
+        stage_store(st.a, coeffs + (int64_t)n0 * 3, rows, 3, lds, pitch, 0);
+        if (K > 1)
+            stage_store(st.b, coeffs_rest + (int64_t)n0 * (row_floats - 3), rows, row_floats - 3, lds, pitch, 3);
+    } else {
+        stage_store(st.a, coeffs + (int64_t)n0 * row_floats, rows, row_floats, lds, pitch, 0);
+    }
+}
+
+// The reverse: LDS rows back to a contiguous HBM span, 16 bytes per lane per store.
+template <int RF>
+__device__ __forceinline__ void unstage_rows(float *__restrict__ dst, int rows, int row_floats_rt,
+                                             const float *lds, int pitch, int col_off) {
+    const int row_floats = RF ? RF : row_floats_rt;
+    const int total = rows * row_floats;
+    lds += col_off;
+    float4 *dst4 = reinterpret_cast<float4 *>(dst);
+    const int total4 = total >> 2;
+    for (int i = threadIdx.x; i < total4; i += kShBlock) {
+        const int e = i << 2;
+        int r = e / row_floats, col = e - r * row_floats;
+        float vv[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            vv[k] = lds[r * pitch + col];
+            if (++col == row_floats) { col = 0; ++r; }
+        }
+        dst4[i] = make_float4(vv[0], vv[1], vv[2], vv[3]);
+    }
+    for (int i = (total4 << 2) + threadIdx.x; i < total; i += kShBlock) {
+        const int r = i / row_floats, col = i - r * row_floats;
+        dst[i] = lds[r * pitch + col];
+    }
+}
+
+// KT > 0: the coefficient count per Gaussian is the compile-time constant KT (16 = degree-3 storage,
+// FusionSense's configuration); KT = 0: any K <= kMaxK.
+template <int KT, bool SPLIT>
 __global__ void __launch_bounds__(kShBlock)
 sh_fwd_kernel(int C, int N, int K, int degree, const float *__restrict__ means,
               const float *__restrict__ campos, const float *__restrict__ coeffs,
@@ -126,23 +235,31 @@ sh_fwd_kernel(int C, int N, int K, int degree, const float *__restrict__ means,
     const int n0 = blockIdx.x * kShBlock;
     const int rows = min(kShBlock, N - n0);
     const int kk = (degree + 1) * (degree + 1);
+    if (KT) K = KT;
     const int row_floats = K * 3;
-    if (coeffs_rest) {  // split storage: coeffs = features_dc [N,3], coeffs_rest = features_rest [N,K-1,3]
-        stage_rows(coeffs + (int64_t)n0 * 3, rows, 3, lds, row_floats + 1, 0);
-        if (K > 1) stage_rows(coeffs_rest + (int64_t)n0 * (row_floats - 3), rows, row_floats - 3, lds, row_floats + 1, 3);
-    } else {
-        stage_rows(coeffs + (int64_t)n0 * row_floats, rows, row_floats, lds, row_floats + 1, 0);
-    }
-    __syncthreads();
     const int n = n0 + threadIdx.x;
-    if (n >= N) return;
+    const bool in_range = n < N;
+    // every global load of the first camera is in flight before the first wait.  (A persistent variant that
+    // prefetches the next block's coefficients into registers while this one is evaluated measured no
+    // faster: 20.8 vs 19.6 us at N = 300 k.)
+    StagedCoeffs<KT, SPLIT> st;
+    coeffs_load(st, coeffs, coeffs_rest, n0, rows, K);
+    float mx = 0.f, myy = 0.f, mz = 0.f, dep0 = 0.f;
+    int rad0 = 0;
+    if (in_range) {
+        mx = means[n * 3 + 0]; myy = means[n * 3 + 1]; mz = means[n * 3 + 2];
+        rad0 = radii[n];
+        if (depths) dep0 = depths[n];
+    }
+    coeffs_park(st, coeffs, coeffs_rest, n0, rows, K, lds);
+    __syncthreads();
+    if (!in_range) return;
     const float *my = lds + threadIdx.x * (row_floats + 1);
-    const float mx = means[n * 3 + 0], myy = means[n * 3 + 1], mz = means[n * 3 + 2];
     const int D = depths ? 4 : 3;
     for (int c = 0; c < C; ++c) {
         const int64_t idx = (int64_t)c * N + n;
         float r = 0.5f, g = 0.5f, bl = 0.5f;
-        if (radii[idx] > 0) {
+        if ((c ? radii[idx] : rad0) > 0) {
             float dx = mx - campos[c * 3 + 0], dy = myy - campos[c * 3 + 1], dz = mz - campos[c * 3 + 2];
             const float inorm = 1.f / fmaxf(sqrtf(dx * dx + dy * dy + dz * dz), 1e-12f);
             dx *= inorm; dy *= inorm; dz *= inorm;
@@ -162,7 +279,7 @@ sh_fwd_kernel(int C, int N, int K, int degree, const float *__restrict__ means,
             bl = fmaxf(ab + 0.5f, 0.f);
         }
         if (D == 4) {
-            reinterpret_cast<float4 *>(colors_out)[idx] = make_float4(r, g, bl, depths[idx]);
+            reinterpret_cast<float4 *>(colors_out)[idx] = make_float4(r, g, bl, c ? depths[idx] : dep0);
         } else {
             colors_out[idx * 3 + 0] = r;
             colors_out[idx * 3 + 1] = g;
@@ -171,7 +288,7 @@ sh_fwd_kernel(int C, int N, int K, int degree, const float *__restrict__ means,
     }
 }
 
-template <bool SINGLE_CAM>
+template <bool SINGLE_CAM, int KT, bool SPLIT>
 __global__ void __launch_bounds__(kShBlock)
 sh_bwd_kernel(int C, int N, int K, int degree, const float *__restrict__ means,
               const float *__restrict__ campos, const float *__restrict__ coeffs,
@@ -183,27 +300,35 @@ sh_bwd_kernel(int C, int N, int K, int degree, const float *__restrict__ means,
     const int n0 = blockIdx.x * kShBlock;
     const int rows = min(kShBlock, N - n0);
     const int kk = (degree + 1) * (degree + 1);
+    if (KT) K = KT;
     const int row_floats = K * 3;
     const int pitch = row_floats + 1;
-    if (coeffs_rest) {
-        stage_rows(coeffs + (int64_t)n0 * 3, rows, 3, lds, pitch, 0);
-        if (K > 1) stage_rows(coeffs_rest + (int64_t)n0 * (row_floats - 3), rows, row_floats - 3, lds, pitch, 3);
-    } else {
-        stage_rows(coeffs + (int64_t)n0 * row_floats, rows, row_floats, lds, pitch, 0);
-    }
-    __syncthreads();
     const int n = n0 + threadIdx.x;
+    StagedCoeffs<KT, SPLIT> st;
+    coeffs_load(st, coeffs, coeffs_rest, n0, rows, K);
+    // (single camera) this Gaussian's own inputs, in flight together with the coefficients
+    float mx = 0.f, myy = 0.f, mz = 0.f, vc0 = 0.f, vc1 = 0.f, vc2 = 0.f, vc3 = 0.f;
+    float o0 = 0.f, o1 = 0.f, o2 = 0.f;
+    int rad0 = 0;
+    if (SINGLE_CAM && n < N) {
+        mx = means[n * 3 + 0]; myy = means[n * 3 + 1]; mz = means[n * 3 + 2];
+        rad0 = radii[n];
+        vc0 = v_colors[(int64_t)n * D + 0]; vc1 = v_colors[(int64_t)n * D + 1]; vc2 = v_colors[(int64_t)n * D + 2];
+        if (D == 4 && v_depths) vc3 = v_colors[(int64_t)n * 4 + 3];
+        if (!overwrite_means) { o0 = v_means[n * 3 + 0]; o1 = v_means[n * 3 + 1]; o2 = v_means[n * 3 + 2]; }
+    }
+    coeffs_park(st, coeffs, coeffs_rest, n0, rows, K, lds);
+    __syncthreads();
     float *my = lds + threadIdx.x * pitch;
     if (SINGLE_CAM) {
       if (n < N) {
         // single-camera fast path (the training case): the coefficient gradient is formed in place in
         // this lane's LDS row, no per-lane accumulator array (75 VGPRs) is needed
-        const float mx = means[n * 3 + 0], myy = means[n * 3 + 1], mz = means[n * 3 + 2];
-        if (D == 4 && v_depths) v_depths[n] = v_colors[(int64_t)n * 4 + 3];
+        if (D == 4 && v_depths) v_depths[n] = vc3;
         float vr = 0.f, vg = 0.f, vb = 0.f;
         float b[kMaxK], bx[kMaxK], by[kMaxK], bz[kMaxK];
         float dx = 0.f, dy = 0.f, dz = 0.f, inorm = 0.f;
-        const bool vis = radii[n] > 0;
+        const bool vis = rad0 > 0;
         if (vis) {
             dx = mx - campos[0]; dy = myy - campos[1]; dz = mz - campos[2];
             inorm = 1.f / fmaxf(sqrtf(dx * dx + dy * dy + dz * dz), 1e-12f);
@@ -218,9 +343,9 @@ sh_bwd_kernel(int C, int N, int K, int degree, const float *__restrict__ means,
                     ab += b[k] * my[k * 3 + 2];
                 }
             }
-            vr = (ar + 0.5f > 0.f) ? v_colors[(int64_t)n * D + 0] : 0.f;
-            vg = (ag + 0.5f > 0.f) ? v_colors[(int64_t)n * D + 1] : 0.f;
-            vb = (ab + 0.5f > 0.f) ? v_colors[(int64_t)n * D + 2] : 0.f;
+            vr = (ar + 0.5f > 0.f) ? vc0 : 0.f;
+            vg = (ag + 0.5f > 0.f) ? vc1 : 0.f;
+            vb = (ab + 0.5f > 0.f) ? vc2 : 0.f;
         }
         float gdx = 0.f, gdy = 0.f, gdz = 0.f;
 #pragma unroll
@@ -239,9 +364,9 @@ sh_bwd_kernel(int C, int N, int K, int degree, const float *__restrict__ means,
         }
         const float dp = gdx * dx + gdy * dy + gdz * dz;
         const float g0 = (gdx - dp * dx) * inorm, g1 = (gdy - dp * dy) * inorm, g2 = (gdz - dp * dz) * inorm;
-        v_means[n * 3 + 0] = overwrite_means ? g0 : v_means[n * 3 + 0] + g0;
-        v_means[n * 3 + 1] = overwrite_means ? g1 : v_means[n * 3 + 1] + g1;
-        v_means[n * 3 + 2] = overwrite_means ? g2 : v_means[n * 3 + 2] + g2;
+        v_means[n * 3 + 0] = o0 + g0;
+        v_means[n * 3 + 1] = o1 + g1;
+        v_means[n * 3 + 2] = o2 + g2;
       }
     } else if (n < N) {
         const float mx = means[n * 3 + 0], myy = means[n * 3 + 1], mz = means[n * 3 + 2];
@@ -304,26 +429,14 @@ sh_bwd_kernel(int C, int N, int K, int degree, const float *__restrict__ means,
         }
     }
     __syncthreads();
-    if (v_coeffs_rest) {  // split gradient storage, mirroring the split inputs
-        float *dst_dc = v_coeffs + (int64_t)n0 * 3;
-        for (int i = threadIdx.x; i < rows * 3; i += kShBlock) {
-            const int r = i / 3, col = i - r * 3;
-            dst_dc[i] = lds[r * pitch + col];
-        }
-        const int rf = row_floats - 3;
-        float *dst_rest = v_coeffs_rest + (int64_t)n0 * rf;
-        for (int i = threadIdx.x; i < rows * rf; i += kShBlock) {
-            const int r = i / rf, col = i - r * rf;
-            dst_rest[i] = lds[r * pitch + 3 + col];
-        }
+    if (SPLIT) {  // split gradient storage, mirroring the split inputs
+        unstage_rows<3>(v_coeffs + (int64_t)n0 * 3, rows, 3, lds, pitch, 0);
+        if (K > 1)
+            unstage_rows<KT ? KT * 3 - 3 : 0>(v_coeffs_rest + (int64_t)n0 * (row_floats - 3), rows, row_floats - 3, lds,
+                                              pitch, 3);
         return;
     }
-    float *dst = v_coeffs + (int64_t)n0 * row_floats;
-    const int total = rows * row_floats;
-    for (int i = threadIdx.x; i < total; i += kShBlock) {
-        const int r = i / row_floats, col = i - r * row_floats;
-        dst[i] = lds[r * pitch + col];
-    }
+    unstage_rows<KT * 3>(v_coeffs + (int64_t)n0 * row_floats, rows, row_floats, lds, pitch, 0);
 }
 
 // Camera centres from world-to-camera matrices: campos = -A^-1 t for [A t; 0 1] (what
@@ -367,9 +480,16 @@ static int sh_fwd_impl(int C, int N, int K, int degree, const float *means, cons
     if ((int64_t)C * N == 0) return FSGS_OK;
     if (!means || !campos || !coeffs || !radii || !colors_out) return FSGS_EINVAL;
     const size_t lds_bytes = (size_t)kShBlock * (K * 3 + 1) * sizeof(float);
-    hipLaunchKernelGGL(sh_fwd_kernel, dim3(ceil_div(N, kShBlock)), dim3(kShBlock), lds_bytes,
-                       as_stream(stream), C, N, K, degree, means, campos, coeffs, coeffs_rest, radii, depths,
-                       colors_out);
+#define FSGS_SH_FWD(KT, SP)                                                                               \
+    hipLaunchKernelGGL((sh_fwd_kernel<KT, SP>), dim3(ceil_div(N, kShBlock)), dim3(kShBlock), lds_bytes,   \
+                       as_stream(stream), C, N, K, degree, means, campos, coeffs, coeffs_rest, radii, depths, \
+                       colors_out)
+    if (coeffs_rest) {
+        if (K == 16) FSGS_SH_FWD(16, true); else FSGS_SH_FWD(0, true);
+    } else {
+        if (K == 16) FSGS_SH_FWD(16, false); else FSGS_SH_FWD(0, false);
+    }
+#undef FSGS_SH_FWD
     return check_launch();
 }
 
@@ -399,14 +519,18 @@ static int sh_bwd_impl(int C, int N, int K, int degree, const float *means, cons
     if (N == 0) return FSGS_OK;
     if (!means || !campos || !coeffs || !radii || !v_colors || !v_coeffs || !v_means) return FSGS_EINVAL;
     const size_t lds_bytes = (size_t)kShBlock * (K * 3 + 1) * sizeof(float);
-    if (C == 1)
-        hipLaunchKernelGGL((sh_bwd_kernel<true>), dim3(ceil_div(N, kShBlock)), dim3(kShBlock), lds_bytes,
-                           as_stream(stream), C, N, K, degree, means, campos, coeffs, coeffs_rest, radii, D,
-                           v_colors, v_coeffs, v_coeffs_rest, v_means, v_depths, overwrite_means);
-    else
-        hipLaunchKernelGGL((sh_bwd_kernel<false>), dim3(ceil_div(N, kShBlock)), dim3(kShBlock), lds_bytes,
-                           as_stream(stream), C, N, K, degree, means, campos, coeffs, coeffs_rest, radii, D,
-                           v_colors, v_coeffs, v_coeffs_rest, v_means, v_depths, overwrite_means);
+#define FSGS_SH_BWD(SC, KT, SP)                                                                           \
+    hipLaunchKernelGGL((sh_bwd_kernel<SC, KT, SP>), dim3(ceil_div(N, kShBlock)), dim3(kShBlock), lds_bytes,  \
+                       as_stream(stream), C, N, K, degree, means, campos, coeffs, coeffs_rest, radii, D,      \
+                       v_colors, v_coeffs, v_coeffs_rest, v_means, v_depths, overwrite_means)
+#define FSGS_SH_BWD_K(SC, SP) do { if (K == 16) FSGS_SH_BWD(SC, 16, SP); else FSGS_SH_BWD(SC, 0, SP); } while (0)
+    if (C == 1) {
+        if (coeffs_rest) FSGS_SH_BWD_K(true, true); else FSGS_SH_BWD_K(true, false);
+    } else {
+        if (coeffs_rest) FSGS_SH_BWD_K(false, true); else FSGS_SH_BWD_K(false, false);
+    }
+#undef FSGS_SH_BWD_K
+#undef FSGS_SH_BWD
     return check_launch();
 }
 
