@@ -5,10 +5,12 @@
 // with the torchmetrics StructuralSimilarityIndexMeasure(kernel_size=11) swapped in at :244):
 // Gaussian 11x11 window, sigma 1.5, the SSIM map averaged over the (H-10)x(W-10) interior.
 //
-// One workgroup per 16x16 output tile and channel: the 26x26 halo of pred and gt is staged in
-// LDS once, blurred separably (rows, then columns) for the five moments, and the SSIM value plus
-// its three partial derivatives (w.r.t. mu1, sigma1^2, sigma12) are formed per pixel.  The
-// backward blurs those three maps with the same window:
+// One workgroup (256 threads) per 32x32 output tile and channel: the 42x42 halo of pred and gt is staged
+// in LDS once and blurred separably (rows, then columns) for the five moments; every thread produces FOUR
+// adjacent outputs per pass from a sliding window of 14 inputs held in registers (14 LDS reads per map
+// instead of 44: with one output per thread the kernel was bound by its ~90 LDS reads per pixel), then the
+// SSIM value plus its three partial derivatives (w.r.t. mu1, sigma1^2, sigma12) per pixel.  The backward
+// blurs those three maps with the same window:
 //   dSSIM/dpred = G*(dm_dmu1) + 2 pred G*(dm_dsigma1sq) + gt G*(dm_dsigma12).
 // Layout: images are [H,W,3] (channel-last, as the renderer writes them); the three saved
 // derivative maps are planar [3,H,W] so that their writes and the backward's halo reads coalesce.
@@ -16,9 +18,12 @@
 
 namespace fsgs {
 
-constexpr int kLT = 16;           // output tile edge
-constexpr int kLR = 5;            // window radius
-constexpr int kLH = kLT + 2 * kLR;  // 26
+constexpr int kLT = 32;             // output tile edge
+constexpr int kLR = 5;              // window radius
+constexpr int kLH = kLT + 2 * kLR;  // 42
+constexpr int kLP = kLH + 1;        // halo row pitch (odd: the row pass reads 8 rows x 8 column groups per wave)
+constexpr int kLQ = kLT + 8;        // blurred-row pitch: 4 rows apart = 32 banks apart (column pass, 2 row groups per wave)
+constexpr int kHaloIters = (kLH * kLH + 255) / 256;
 
 __constant__ float kGauss11[11] = {0.0010283801f, 0.0075987581f, 0.0360007721f, 0.1093606895f,
                                    0.2130055377f, 0.2660117249f, 0.2130055377f, 0.1093606895f,
@@ -26,7 +31,7 @@ __constant__ float kGauss11[11] = {0.0010283801f, 0.0075987581f, 0.0360007721f, 
 
 __device__ __forceinline__ float block_sum_256(float v, float *lds4) {
     v = wave_sum_to_last_row(v);
-    const int tr = threadIdx.y * blockDim.x + threadIdx.x;
+    const int tr = threadIdx.x;
     if ((tr & 63) == 63) lds4[tr >> 6] = v;
     __syncthreads();
     return lds4[0] + lds4[1] + lds4[2] + lds4[3];
@@ -37,72 +42,118 @@ __global__ void __launch_bounds__(256)
 ssim_l1_fwd_kernel(int H, int W, const float *__restrict__ pred, const float *__restrict__ gt,
                    float *__restrict__ dm_dmu1, float *__restrict__ dm_dsigma1, float *__restrict__ dm_dsigma12,
                    float *__restrict__ sums) {
-    __shared__ float sp[kLH][kLH + 1], sg[kLH][kLH + 1];
-    __shared__ float hb[5][kLH][kLT + 1];
+    __shared__ float sp[kLH][kLP], sg[kLH][kLP];
+    __shared__ float hb[5][kLH][kLQ];
     __shared__ float red[4];
     const int ch = blockIdx.z;
     const int x0 = blockIdx.x * kLT, y0 = blockIdx.y * kLT;
-    const int tr = threadIdx.y * kLT + threadIdx.x;
-    for (int i = tr; i < kLH * kLH; i += 256) {
+    const int tr = threadIdx.x;
+    // the halo: every load of this thread is issued before the first LDS write (written as one loop the
+    // compiler waits for each element in turn: serialised HBM round trips)
+    float hp[kHaloIters], hg[kHaloIters];
+#pragma unroll
+    for (int it = 0; it < kHaloIters; ++it) {
+        const int i = tr + it * 256;
         const int ly = i / kLH, lx = i - ly * kLH;
         const int y = y0 + ly - kLR, x = x0 + lx - kLR;
-        float p = 0.f, g = 0.f;
-        if (y >= 0 && y < H && x >= 0 && x < W) {
-            p = pred[((int64_t)y * W + x) * 3 + ch];
-            g = gt[((int64_t)y * W + x) * 3 + ch];
+        hp[it] = 0.f; hg[it] = 0.f;
+        if (i < kLH * kLH && y >= 0 && y < H && x >= 0 && x < W) {
+            hp[it] = pred[((int64_t)y * W + x) * 3 + ch];
+            hg[it] = gt[((int64_t)y * W + x) * 3 + ch];
         }
-        sp[ly][lx] = p;
-        sg[ly][lx] = g;
+    }
+#pragma unroll
+    for (int it = 0; it < kHaloIters; ++it) {
+        const int i = tr + it * 256;
+        const int ly = i / kLH, lx = i - ly * kLH;
+        if (i < kLH * kLH) {
+            sp[ly][lx] = hp[it];
+            sg[ly][lx] = hg[it];
+        }
     }
     __syncthreads();
-    // horizontal pass: 26 rows x 16 columns
-    for (int i = tr; i < kLH * kLT; i += 256) {
-        const int ly = i / kLT, lx = i - ly * kLT;
-        float m1 = 0.f, m2 = 0.f, s11 = 0.f, s22 = 0.f, s12 = 0.f;
+    // row pass: 42 rows x 8 groups of 4 columns; the 14 inputs of a group slide through registers
+    for (int item = tr; item < kLH * (kLT / 4); item += 256) {
+        const int ly = item >> 3, cx = (item & 7) * 4;
+        float acc[4][5];
 #pragma unroll
-        for (int k = 0; k < 11; ++k) {
-            const float w = kGauss11[k];
-            const float p = sp[ly][lx + k], g = sg[ly][lx + k];
-            m1 += w * p; m2 += w * g; s11 += w * p * p; s22 += w * g * g; s12 += w * p * g;
+        for (int o = 0; o < 4; ++o)
+#pragma unroll
+            for (int m = 0; m < 5; ++m) acc[o][m] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 14; ++t) {
+            const float p = sp[ly][cx + t], g = sg[ly][cx + t];
+            const float pp = p * p, gg = g * g, pg = p * g;
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                const int k = t - o;
+                if (k >= 0 && k < 11) {
+                    const float w = kGauss11[k];
+                    acc[o][0] += w * p; acc[o][1] += w * g; acc[o][2] += w * pp; acc[o][3] += w * gg; acc[o][4] += w * pg;
+                }
+            }
         }
-        hb[0][ly][lx] = m1; hb[1][ly][lx] = m2; hb[2][ly][lx] = s11; hb[3][ly][lx] = s22; hb[4][ly][lx] = s12;
+#pragma unroll
+        for (int m = 0; m < 5; ++m)
+#pragma unroll
+            for (int o = 0; o < 4; ++o) hb[m][ly][cx + o] = acc[o][m];
     }
     __syncthreads();
-    const int lx = threadIdx.x, ly = threadIdx.y;
-    const int x = x0 + lx, y = y0 + ly;
-    float mu1 = 0.f, mu2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+    // column pass: thread = (column lx, group of 4 rows)
+    const int lx = tr & 31, ry = (tr >> 5) * 4;
+    float mom[4][5];
 #pragma unroll
-    for (int k = 0; k < 11; ++k) {
-        const float w = kGauss11[k];
-        mu1 += w * hb[0][ly + k][lx]; mu2 += w * hb[1][ly + k][lx];
-        e11 += w * hb[2][ly + k][lx]; e22 += w * hb[3][ly + k][lx]; e12 += w * hb[4][ly + k][lx];
+    for (int o = 0; o < 4; ++o)
+#pragma unroll
+        for (int m = 0; m < 5; ++m) mom[o][m] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 14; ++t) {
+        float v[5];
+#pragma unroll
+        for (int m = 0; m < 5; ++m) v[m] = hb[m][ry + t][lx];
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            const int k = t - o;
+            if (k >= 0 && k < 11) {
+                const float w = kGauss11[k];
+#pragma unroll
+                for (int m = 0; m < 5; ++m) mom[o][m] += w * v[m];
+            }
+        }
     }
-    const bool in_img = (x < W) && (y < H);
-    const bool interior = in_img && x >= kLR && x < W - kLR && y >= kLR && y < H - kLR;
-    float l1 = 0.f, ssim = 0.f, d_mu1 = 0.f, d_s1 = 0.f, d_s12 = 0.f;
-    if (in_img) l1 = fabsf(sp[ly + kLR][lx + kLR] - sg[ly + kLR][lx + kLR]);
-    if (interior) {
-        const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
-        const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
-        const float s1 = e11 - mu1_sq, s2 = e22 - mu2_sq, s12 = e12 - mu12;
-        const float A = mu1_sq + mu2_sq + C1, B = s1 + s2 + C2;
-        const float C = 2.f * mu12 + C1, D = 2.f * s12 + C2;
-        ssim = (C * D) / (A * B);
-        d_mu1 = (mu2 * 2.f * D) / (A * B) - (mu2 * 2.f * C) / (A * B) - (mu1 * 2.f * C * D) / (A * A * B) +
-                (mu1 * 2.f * C * D) / (A * B * B);
-        d_s1 = (-C * D) / (A * B * B);
-        d_s12 = (2.f * C) / (A * B);
-    }
-    if (in_img) {
-        const int64_t o = ((int64_t)ch * H + y) * W + x;  // planar [3,H,W]: coalesced rows
-        dm_dmu1[o] = d_mu1;
-        dm_dsigma1[o] = d_s1;
-        dm_dsigma12[o] = d_s12;
+    const int x = x0 + lx;
+    float l1 = 0.f, ssim = 0.f;
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+        const int ly = ry + o, y = y0 + ly;
+        const bool in_img = (x < W) && (y < H);
+        const bool interior = in_img && x >= kLR && x < W - kLR && y >= kLR && y < H - kLR;
+        float d_mu1 = 0.f, d_s1 = 0.f, d_s12 = 0.f;
+        if (in_img) l1 += fabsf(sp[ly + kLR][lx + kLR] - sg[ly + kLR][lx + kLR]);
+        if (interior) {
+            const float mu1 = mom[o][0], mu2 = mom[o][1], e11 = mom[o][2], e22 = mom[o][3], e12 = mom[o][4];
+            const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+            const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
+            const float s1 = e11 - mu1_sq, s2 = e22 - mu2_sq, s12 = e12 - mu12;
+            const float A = mu1_sq + mu2_sq + C1, B = s1 + s2 + C2;
+            const float C = 2.f * mu12 + C1, D = 2.f * s12 + C2;
+            ssim += (C * D) / (A * B);
+            d_mu1 = (mu2 * 2.f * D) / (A * B) - (mu2 * 2.f * C) / (A * B) - (mu1 * 2.f * C * D) / (A * A * B) +
+                    (mu1 * 2.f * C * D) / (A * B * B);
+            d_s1 = (-C * D) / (A * B * B);
+            d_s12 = (2.f * C) / (A * B);
+        }
+        if (in_img) {
+            const int64_t oo = ((int64_t)ch * H + y) * W + x;  // planar [3,H,W]: coalesced rows
+            dm_dmu1[oo] = d_mu1;
+            dm_dsigma1[oo] = d_s1;
+            dm_dsigma12[oo] = d_s12;
+        }
     }
     const float t_l1 = block_sum_256(l1, red);
     __syncthreads();
     const float t_ss = block_sum_256(ssim, red);
-    if (tr == 255) {  // per-workgroup partials: same-address float atomics from 7500 blocks serialise
+    if (tr == 255) {  // per-workgroup partials: same-address float atomics from thousands of blocks serialise
         const int blk = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
         sums[2 * blk + 0] = t_l1;
         sums[2 * blk + 1] = t_ss;
@@ -115,48 +166,101 @@ ssim_l1_bwd_kernel(int H, int W, const float *__restrict__ pred, const float *__
                    const float *__restrict__ dm_dmu1, const float *__restrict__ dm_dsigma1,
                    const float *__restrict__ dm_dsigma12, const float *__restrict__ v_loss, float g_l1,
                    float g_ssim, float *__restrict__ v_pred) {
-    __shared__ float sm[3][kLH][kLH + 1];
-    __shared__ float hb[3][kLH][kLT + 1];
+    __shared__ float sm[3][kLH][kLP];
+    __shared__ float hb[3][kLH][kLQ];
     const int ch = blockIdx.z;
     const int x0 = blockIdx.x * kLT, y0 = blockIdx.y * kLT;
-    const int tr = threadIdx.y * kLT + threadIdx.x;
-    for (int i = tr; i < kLH * kLH; i += 256) {
+    const int tr = threadIdx.x;
+    float ha[kHaloIters], hbv[kHaloIters], hc[kHaloIters];  // (all loads first, as in the forward)
+#pragma unroll
+    for (int it = 0; it < kHaloIters; ++it) {
+        const int i = tr + it * 256;
         const int ly = i / kLH, lx = i - ly * kLH;
         const int y = y0 + ly - kLR, x = x0 + lx - kLR;
-        float a = 0.f, b = 0.f, c = 0.f;
-        if (y >= 0 && y < H && x >= 0 && x < W) {
+        ha[it] = 0.f; hbv[it] = 0.f; hc[it] = 0.f;
+        if (i < kLH * kLH && y >= 0 && y < H && x >= 0 && x < W) {
             const int64_t o = ((int64_t)ch * H + y) * W + x;
-            a = dm_dmu1[o]; b = dm_dsigma1[o]; c = dm_dsigma12[o];
+            ha[it] = dm_dmu1[o]; hbv[it] = dm_dsigma1[o]; hc[it] = dm_dsigma12[o];
         }
-        sm[0][ly][lx] = a; sm[1][ly][lx] = b; sm[2][ly][lx] = c;
     }
-    __syncthreads();
-    for (int i = tr; i < kLH * kLT; i += 256) {
-        const int ly = i / kLT, lx = i - ly * kLT;
-        float a = 0.f, b = 0.f, c = 0.f;
+    // this thread's own four pixels and the upstream scalar, in flight with the halo
+    const int lx = tr & 31, ry = (tr >> 5) * 4;
+    const int x = x0 + lx;
+    float own_p[4], own_g[4];
 #pragma unroll
-        for (int k = 0; k < 11; ++k) {
-            const float w = kGauss11[k];
-            a += w * sm[0][ly][lx + k]; b += w * sm[1][ly][lx + k]; c += w * sm[2][ly][lx + k];
-        }
-        hb[0][ly][lx] = a; hb[1][ly][lx] = b; hb[2][ly][lx] = c;
+    for (int o = 0; o < 4; ++o) {
+        const int y = y0 + ry + o;
+        const int64_t oo = ((int64_t)min(y, H - 1) * W + min(x, W - 1)) * 3 + ch;
+        own_p[o] = pred[oo]; own_g[o] = gt[oo];
     }
-    __syncthreads();
-    const int lx = threadIdx.x, ly = threadIdx.y;
-    const int x = x0 + lx, y = y0 + ly;
-    if (x >= W || y >= H) return;
-    float a = 0.f, b = 0.f, c = 0.f;
-#pragma unroll
-    for (int k = 0; k < 11; ++k) {
-        const float w = kGauss11[k];
-        a += w * hb[0][ly + k][lx]; b += w * hb[1][ly + k][lx]; c += w * hb[2][ly + k][lx];
-    }
-    const int64_t o = ((int64_t)y * W + x) * 3 + ch;
-    const float p = pred[o], g = gt[o];
-    const float d = p - g;
-    const float sgn = (d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f);
     const float up = v_loss[0];
-    v_pred[o] = up * (g_l1 * sgn + g_ssim * (a + 2.f * p * b + g * c));
+#pragma unroll
+    for (int it = 0; it < kHaloIters; ++it) {
+        const int i = tr + it * 256;
+        const int ly = i / kLH, lxx = i - ly * kLH;
+        if (i < kLH * kLH) {
+            sm[0][ly][lxx] = ha[it]; sm[1][ly][lxx] = hbv[it]; sm[2][ly][lxx] = hc[it];
+        }
+    }
+    __syncthreads();
+    for (int item = tr; item < kLH * (kLT / 4); item += 256) {
+        const int ly = item >> 3, cx = (item & 7) * 4;
+        float acc[4][3];
+#pragma unroll
+        for (int o = 0; o < 4; ++o)
+#pragma unroll
+            for (int m = 0; m < 3; ++m) acc[o][m] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 14; ++t) {
+            float v[3];
+#pragma unroll
+            for (int m = 0; m < 3; ++m) v[m] = sm[m][ly][cx + t];
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                const int k = t - o;
+                if (k >= 0 && k < 11) {
+                    const float w = kGauss11[k];
+#pragma unroll
+                    for (int m = 0; m < 3; ++m) acc[o][m] += w * v[m];
+                }
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < 3; ++m)
+#pragma unroll
+            for (int o = 0; o < 4; ++o) hb[m][ly][cx + o] = acc[o][m];
+    }
+    __syncthreads();
+    float out[4][3];
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+#pragma unroll
+        for (int m = 0; m < 3; ++m) out[o][m] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 14; ++t) {
+        float v[3];
+#pragma unroll
+        for (int m = 0; m < 3; ++m) v[m] = hb[m][ry + t][lx];
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            const int k = t - o;
+            if (k >= 0 && k < 11) {
+                const float w = kGauss11[k];
+#pragma unroll
+                for (int m = 0; m < 3; ++m) out[o][m] += w * v[m];
+            }
+        }
+    }
+    if (x >= W) return;
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+        const int y = y0 + ry + o;
+        if (y >= H) break;
+        const float p = own_p[o], g = own_g[o];
+        const float d = p - g;
+        const float sgn = (d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f);
+        v_pred[((int64_t)y * W + x) * 3 + ch] = up * (g_l1 * sgn + g_ssim * (out[o][0] + 2.f * p * out[o][1] + g * out[o][2]));
+    }
 }
 
 // Auxiliary L1 terms of the FusionSense loss on the depth and normal images
@@ -294,7 +398,7 @@ extern "C" int fsgs_ssim_l1_fwd(int H, int W, const float *pred, const float *gt
     if (H < 11 || W < 11) return FSGS_EINVAL;
     if (!pred || !gt || !dm_dmu1 || !dm_dsigma1 || !dm_dsigma12 || !sums) return FSGS_EINVAL;
     hipStream_t s = as_stream(stream);
-    hipLaunchKernelGGL(ssim_l1_fwd_kernel, dim3(ceil_div(W, kLT), ceil_div(H, kLT), 3), dim3(kLT, kLT), 0, s,
+    hipLaunchKernelGGL(ssim_l1_fwd_kernel, dim3(ceil_div(W, kLT), ceil_div(H, kLT), 3), dim3(256), 0, s,
                        H, W, pred, gt, dm_dmu1, dm_dsigma1, dm_dsigma12, sums);
     return check_launch();
 }
@@ -304,7 +408,7 @@ extern "C" int fsgs_ssim_l1_bwd(int H, int W, const float *pred, const float *gt
                                 float g_l1, float g_ssim, float *v_pred, fsgs_stream_t stream) {
     if (H < 11 || W < 11) return FSGS_EINVAL;
     if (!pred || !gt || !dm_dmu1 || !dm_dsigma1 || !dm_dsigma12 || !v_loss || !v_pred) return FSGS_EINVAL;
-    hipLaunchKernelGGL(ssim_l1_bwd_kernel, dim3(ceil_div(W, kLT), ceil_div(H, kLT), 3), dim3(kLT, kLT), 0,
+    hipLaunchKernelGGL(ssim_l1_bwd_kernel, dim3(ceil_div(W, kLT), ceil_div(H, kLT), 3), dim3(256), 0,
                        as_stream(stream), H, W, pred, gt, dm_dmu1, dm_dsigma1, dm_dsigma12, v_loss, g_l1,
                        g_ssim, v_pred);
     return check_launch();
