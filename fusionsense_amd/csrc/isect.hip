@@ -319,6 +319,122 @@ isect_live_flat_kernel(int C, int N, const float *__restrict__ means2d, const in
     if (!EMIT && idx < total) live_per_gauss[idx] = L.run[lane];
 }
 
+// ---- direct binning (row a-5/a-6/a-7 in one chain): the live pairs go straight into their tile's bucket ----
+// The count -> scan -> emit -> tile_hist -> tile_scan -> tile_offsets -> tile_scatter chain writes every
+// pair to a list in emission order only to read it back twice for the partition by tile.  Here the two
+// enumeration passes do the partition themselves:
+//   pass 1 (SCATTER = false): a workgroup of 16 waves enumerates the pairs of its 1024 Gaussians (flattened
+//       over the lanes as above) and counts them per tile in LDS -> table[tile][workgroup]
+//   tile_scan / tile_offsets (tilesort.hip): exclusive prefix over the workgroups per tile, isect_offsets
+//   pass 2 (SCATTER = true): the same enumeration; every live pair claims the next slot of its tile's
+//       bucket (LDS cursor, started at isect_offsets[tile] + table[tile][workgroup]) and drops its sort
+//       word  bits(depth) << 32 | flatten id << 4 | quadrant mask  there
+// followed by the in-tile sorts.  Four launches fewer, no emission-order arrays, no per-Gaussian scan.
+// The claiming order inside a bucket is arbitrary; the in-tile sort on (depth, id) makes the result
+// deterministic and bit-identical to the list chain's.
+constexpr int kBinWaves = 16, kBinThreads = 64 * kBinWaves;
+
+// per workgroup: its 1024 Gaussians' reach-test constants and tile rectangles.  The pairs of ALL of them are
+// flattened over the 1024 threads (pair p of the workgroup -> its Gaussian by bisection over the exclusive
+// prefix of the rectangle sizes), so every wave gets the same share however large single splats are.
+struct BinLds {
+    int excl[kBinThreads];     // exclusive prefix of the rectangle sizes
+    float4 a[kBinThreads];     // CullPrep: mx, my, b, tau
+    float4 b[kBinThreads];     // CullPrep: ha, hc, inv_a, inv_c
+    int4 rect[kBinThreads];    // x0, y0, width, count
+    uint32_t depth[kBinThreads];
+    int wave_sum[kBinWaves];
+};
+
+template <bool SCATTER>
+__global__ void __launch_bounds__(kBinThreads)
+isect_live_bin_kernel(int C, int N, const float *__restrict__ means2d, const int32_t *__restrict__ radii,
+                      const float *__restrict__ depths, const float *__restrict__ conics,
+                      const float *__restrict__ opacities, int tw, int th, int T, int nb,
+                      int32_t *__restrict__ tiles_per_gauss, int32_t *__restrict__ table,
+                      const int32_t *__restrict__ offsets, uint64_t *__restrict__ buckets) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char bin_smem[];
+    BinLds &L = *reinterpret_cast<BinLds *>(bin_smem);
+    int *slots = reinterpret_cast<int *>(bin_smem + sizeof(BinLds));
+    const int64_t total = (int64_t)C * N;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int64_t idx0 = (int64_t)blockIdx.x * kBinThreads;  // the workgroup's first Gaussian
+    const int64_t idx = idx0 + tid;
+    int cnt = 0;
+    {
+        TileRect t = {0, 0, 0, 0};
+        float mx = 0.f, my = 0.f, op = 0.f, ca = 0.f, cb = 0.f, cc = 0.f;
+        uint32_t db = 0u;
+        if (idx < total) {
+            const int r = radii[idx];
+            if (r > 0) {
+                const float2 m = reinterpret_cast<const float2 *>(means2d)[idx];
+                mx = m.x; my = m.y;
+                t = tile_rect(mx, my, r, 16, tw, th, 0);
+                cnt = (t.x1 - t.x0) * (t.y1 - t.y0);
+                op = opacities[idx];
+                ca = conics[idx * 3 + 0]; cb = conics[idx * 3 + 1]; cc = conics[idx * 3 + 2];
+                if (SCATTER) db = (uint32_t)__float_as_int(depths[idx]);
+            }
+            if (!SCATTER && tiles_per_gauss) tiles_per_gauss[idx] = cnt;
+        }
+        const CullPrep cp = cull_prepare(mx, my, op, ca, cb, cc);
+        L.a[tid] = make_float4(cp.mx, cp.my, cp.b, cp.tau);
+        L.b[tid] = make_float4(cp.ha, cp.hc, cp.inv_a, cp.inv_c);
+        L.rect[tid] = make_int4(t.x0, t.y0, t.x1 - t.x0, cnt);
+        L.depth[tid] = db;
+    }
+    for (int t = tid; t < T; t += kBinThreads)
+        slots[t] = SCATTER ? offsets[t] + table[(int64_t)t * nb + blockIdx.x] : 0;
+    int inc = cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += o;
+    }
+    if (lane == 63) L.wave_sum[w] = inc;
+    __syncthreads();
+    int wbase = 0, wg_total = 0;
+#pragma unroll
+    for (int k = 0; k < kBinWaves; ++k) {
+        const int v = L.wave_sum[k];
+        wbase += (k < w) ? v : 0;
+        wg_total += v;
+    }
+    L.excl[tid] = wbase + inc - cnt;
+    __syncthreads();  // prefix, constants and tile slots ready
+    const int n_tiles = tw * th;
+    for (int p = tid; p < wg_total; p += kBinThreads) {
+        // owner = last Gaussian whose exclusive prefix is <= p (empty rectangles share the prefix of the
+        // next non-empty one, so "last" skips them)
+        int lo = 0;
+#pragma unroll
+        for (int step = kBinThreads / 2; step >= 1; step >>= 1) {
+            const int mid = lo + step;
+            if (L.excl[mid] <= p) lo = mid;
+        }
+        const int o = lo;
+        const int4 rc = L.rect[o];
+        const float4 A = L.a[o], B = L.b[o];
+        const CullPrep cp = {A.x, A.y, A.z, A.w, B.x, B.y, B.z, B.w};
+        const int jj = p - L.excl[o];
+        const int ry = jj / rc.z;
+        const int y = rc.y + ry, x = rc.x + jj - ry * rc.z;
+        const unsigned m = quadrant_mask(cp, (float)(x * 16), (float)(y * 16));
+        if (m) {
+            const int64_t gidx = idx0 + o;
+            const int c = (C == 1) ? 0 : (int)(gidx / N);
+            const int slot = atomicAdd(&slots[c * n_tiles + y * tw + x], 1);
+            if (SCATTER)
+                buckets[slot] = ((uint64_t)L.depth[o] << 32) | ((uint64_t)(uint32_t)gidx << 4) | (uint64_t)m;
+        }
+    }
+    if (!SCATTER) {
+        __syncthreads();
+        for (int t = tid; t < T; t += kBinThreads) table[(int64_t)t * nb + blockIdx.x] = slots[t];
+    }
+}
+
 __global__ void __launch_bounds__(256)
 offset_encode_kernel(int64_t n_isects, const int64_t *__restrict__ ids, int n_tiles, int tile_bits,
                      int n_total, int32_t *__restrict__ offsets) {
@@ -475,4 +591,102 @@ extern "C" int fsgs_isect_emit_live(int C, int N, const float *means2d, const in
                            as_stream(stream), C, N, means2d, radii, depths, conics, opacities, cum_live, tile_width,
                            tile_height, tb, nullptr, nullptr, isect_ids, payload);
     return check_launch();
+}
+
+// ---- direct binning: C entry points -----------------------------------------------------------------------
+namespace fsgs {
+int launch_tile_scan_offsets(int T, int nb, int32_t *table, int32_t *totals, int32_t *isect_offsets, hipStream_t s);
+int launch_tile_sort_tiers(int T, int n_tiles, int tile_bits, const int32_t *isect_offsets, uint64_t *buckets,
+                           int32_t *payload_sorted, int64_t *isect_ids_sorted, hipStream_t s);
+}
+
+static inline int64_t bin_blocks(int64_t total) { return (total + kBinThreads - 1) / kBinThreads; }
+static inline size_t bin_lds_bytes(int T) { return sizeof(BinLds) + (size_t)T * sizeof(int); }
+
+// tiles (cameras x tiles) the direct path can take: the per-workgroup tile slots live in LDS (160 KB per CU)
+extern "C" int fsgs_bin_live_max_tiles(void) { return 24576; }
+
+// table scratch: [table i32: T * blocks] [totals i32: T]
+extern "C" size_t fsgs_bin_live_table_bytes(int C, int N, int tile_width, int tile_height) {
+    const int64_t T = (int64_t)C * tile_width * tile_height;
+    const int64_t nb = bin_blocks((int64_t)C * N > 0 ? (int64_t)C * N : 1);
+    return (size_t)(T * nb + T) * sizeof(int32_t) + 64;
+}
+
+static int bin_set_lds(int T) {
+    static size_t have[2] = {0, 0};
+    const size_t need = bin_lds_bytes(T);
+    if (need > have[0]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&isect_live_bin_kernel<false>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)need);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(&isect_live_bin_kernel<true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)need);
+        if (e != hipSuccess) { g_last_hip_error = (int)e; return FSGS_ELAUNCH; }
+        have[0] = need;
+    }
+    return FSGS_OK;
+}
+
+// Pass 1 + the per-tile scans: tiles_per_gauss (gsplat's count, nullable), isect_offsets[T + 1] with
+// isect_offsets[T] = the number of live pairs (read it back to size pass 2's buffers).
+extern "C" int fsgs_bin_live_count(int C, int N, const float *means2d, const int32_t *radii, const float *conics,
+                                   const float *opacities, int tile_width, int tile_height,
+                                   int32_t *tiles_per_gauss, int32_t *isect_offsets, void *table_scratch,
+                                   size_t table_bytes, fsgs_stream_t stream) {
+    if (C < 1 || N < 0 || tile_width < 1 || tile_height < 1 || !isect_offsets) return FSGS_EINVAL;
+    const int64_t T64 = (int64_t)C * tile_width * tile_height;
+    if (T64 > fsgs_bin_live_max_tiles()) return FSGS_EINVAL;
+    const int T = (int)T64;
+    hipStream_t s = as_stream(stream);
+    const int64_t total = (int64_t)C * N;
+    if (total == 0) {
+        hipError_t e = hipMemsetAsync(isect_offsets, 0, (size_t)(T + 1) * sizeof(int32_t), s);
+        if (e != hipSuccess) { g_last_hip_error = (int)e; return FSGS_ELAUNCH; }
+        return FSGS_OK;
+    }
+    if (!means2d || !radii || !conics || !opacities || !table_scratch) return FSGS_EINVAL;
+    if (table_bytes < fsgs_bin_live_table_bytes(C, N, tile_width, tile_height)) return FSGS_ESCRATCH;
+    const int nb = (int)bin_blocks(total);
+    int32_t *table = reinterpret_cast<int32_t *>(table_scratch);
+    int32_t *totals = table + (size_t)T * nb;
+    int rc = bin_set_lds(T);
+    if (rc != FSGS_OK) return rc;
+    hipLaunchKernelGGL((isect_live_bin_kernel<false>), dim3(nb), dim3(kBinThreads), bin_lds_bytes(T), s, C, N, means2d,
+                       radii, nullptr, conics, opacities, tile_width, tile_height, T, nb, tiles_per_gauss, table,
+                       nullptr, nullptr);
+    rc = check_launch();
+    if (rc != FSGS_OK) return rc;
+    return launch_tile_scan_offsets(T, nb, table, totals, isect_offsets, s);
+}
+
+// Pass 2 + the in-tile sorts: payload_sorted[n_live] = quadrant mask << 28 | flatten id in (tile, depth, id)
+// order.  `buckets` = n_live 64-bit words of scratch; table_scratch / isect_offsets as left by pass 1.
+extern "C" int fsgs_bin_live_emit(int C, int N, const float *means2d, const int32_t *radii, const float *depths,
+                                  const float *conics, const float *opacities, int tile_width, int tile_height,
+                                  const int32_t *isect_offsets, const void *table_scratch, int64_t n_live,
+                                  void *buckets, int32_t *payload_sorted, fsgs_stream_t stream) {
+    if (C < 1 || N < 0 || tile_width < 1 || tile_height < 1 || n_live < 0 || !isect_offsets) return FSGS_EINVAL;
+    const int64_t T64 = (int64_t)C * tile_width * tile_height;
+    if (T64 > fsgs_bin_live_max_tiles() || n_live > 0x7FFFFFF0ll) return FSGS_EINVAL;
+    if (n_live == 0 || (int64_t)C * N == 0) return FSGS_OK;
+    if (!means2d || !radii || !depths || !conics || !opacities || !table_scratch || !buckets || !payload_sorted)
+        return FSGS_EINVAL;
+    const int T = (int)T64;
+    const int n_tiles = tile_width * tile_height;
+    hipStream_t s = as_stream(stream);
+    const int nb = (int)bin_blocks((int64_t)C * N);
+    int32_t *table = const_cast<int32_t *>(reinterpret_cast<const int32_t *>(table_scratch));
+    int rc = bin_set_lds(T);
+    if (rc != FSGS_OK) return rc;
+    hipLaunchKernelGGL((isect_live_bin_kernel<true>), dim3(nb), dim3(kBinThreads), bin_lds_bytes(T), s, C, N, means2d,
+                       radii, depths, conics, opacities, tile_width, tile_height, T, nb, nullptr, table,
+                       isect_offsets, reinterpret_cast<uint64_t *>(buckets));
+    rc = check_launch();
+    if (rc != FSGS_OK) return rc;
+    int tb = 0;
+    while ((1ll << tb) <= n_tiles) ++tb;
+    if (tb < 1) tb = 1;
+    return launch_tile_sort_tiers(T, n_tiles, tb, isect_offsets, reinterpret_cast<uint64_t *>(buckets),
+                                  payload_sorted, nullptr, s);
 }

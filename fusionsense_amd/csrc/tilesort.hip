@@ -295,6 +295,30 @@ tile_sort_kernel2(int n_tiles, int tile_bits, const int32_t *__restrict__ offset
 constexpr int kTsSmall = 1024, kTsLarge = 8192;  // LDS words per tile: 8 KB x 8 workgroups, 64 KB x 2 per CU
 inline int64_t ts_blocks(int64_t n) { return (n + kTsBlockKeys - 1) / kTsBlockKeys; }
 
+// (shared with the direct-binning entry points of isect.hip)
+int launch_tile_scan_offsets(int T, int nb, int32_t *table, int32_t *totals, int32_t *isect_offsets, hipStream_t s) {
+    hipLaunchKernelGGL(tile_scan_kernel2, dim3(T), dim3(kTsThreads), 0, s, nb, table, totals);
+    hipLaunchKernelGGL(tile_offsets_kernel, dim3(1), dim3(1024), 0, s, T, totals, isect_offsets);
+    return check_launch();
+}
+
+int launch_tile_sort_tiers(int T, int n_tiles, int tile_bits, const int32_t *isect_offsets, uint64_t *buckets,
+                           int32_t *payload_sorted, int64_t *isect_ids_sorted, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&tile_sort_kernel2<1024, kTsLarge, kTsSmall, true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, kTsLarge * 8);
+        if (e != hipSuccess) { g_last_hip_error = (int)e; return FSGS_ELAUNCH; }
+        attr_set = true;
+    }
+    // two size tiers, each skipping the tiles of the other (an early-out workgroup costs ~2 ns)
+    hipLaunchKernelGGL((tile_sort_kernel2<256, kTsSmall, 0, false>), dim3(T), dim3(256), kTsSmall * 8, s, n_tiles,
+                       tile_bits, isect_offsets, buckets, payload_sorted, isect_ids_sorted);
+    hipLaunchKernelGGL((tile_sort_kernel2<1024, kTsLarge, kTsSmall, true>), dim3(T), dim3(1024), kTsLarge * 8, s,
+                       n_tiles, tile_bits, isect_offsets, buckets, payload_sorted, isect_ids_sorted);
+    return check_launch();
+}
+
 }  // namespace fsgs
 
 using namespace fsgs;
@@ -339,21 +363,8 @@ extern "C" int fsgs_tile_sort(int64_t n, const int64_t *isect_ids, const int32_t
     const uint64_t *keys = reinterpret_cast<const uint64_t *>(isect_ids);
     const size_t lds = (size_t)T * sizeof(int);
     hipLaunchKernelGGL(tile_hist_kernel, dim3(nb), dim3(kTpThreads), lds, s, n, keys, tb, n_tiles, T, nb, table);
-    hipLaunchKernelGGL(tile_scan_kernel2, dim3(T), dim3(kTsThreads), 0, s, nb, table, totals);
-    hipLaunchKernelGGL(tile_offsets_kernel, dim3(1), dim3(1024), 0, s, T, totals, isect_offsets);
+    launch_tile_scan_offsets(T, nb, table, totals, isect_offsets, s);
     hipLaunchKernelGGL(tile_scatter_kernel, dim3(nb), dim3(kTpThreads), lds, s, n, keys, payload, tb, n_tiles, T, nb,
                        table, isect_offsets, buckets);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&tile_sort_kernel2<1024, kTsLarge, kTsSmall, true>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, kTsLarge * 8);
-        if (e != hipSuccess) { g_last_hip_error = (int)e; return FSGS_ELAUNCH; }
-        attr_set = true;
-    }
-    // two size tiers, each skipping the tiles of the other (an early-out workgroup costs ~2 ns)
-    hipLaunchKernelGGL((tile_sort_kernel2<256, kTsSmall, 0, false>), dim3(T), dim3(256), kTsSmall * 8, s, n_tiles, tb,
-                       isect_offsets, buckets, payload_sorted, isect_ids_sorted);
-    hipLaunchKernelGGL((tile_sort_kernel2<1024, kTsLarge, kTsSmall, true>), dim3(T), dim3(1024), kTsLarge * 8, s,
-                       n_tiles, tb, isect_offsets, buckets, payload_sorted, isect_ids_sorted);
-    return check_launch();
+    return launch_tile_sort_tiers(T, n_tiles, tb, isect_offsets, buckets, payload_sorted, isect_ids_sorted, s);
 }

@@ -125,7 +125,11 @@ class _FusedGetOutputs(torch.autograd.Function):
         # live emission: only (Gaussian, tile) pairs that can reach a pixel are binned and sorted; the
         # quadrant masks ride in the payload (gsplat's full lists are not an output of get_outputs)
         opac_row = opac_sig.view(1, N)
-        count = ops.isect_count_live_async(means2d, radii, conics, opac_row, tw, th)
+        direct_bins = ops.USE_BIN_LIVE and tw * th <= lib.fsgs_bin_live_max_tiles()
+        if direct_bins:  # pairs go straight into their tile's bucket (no emission-order lists, 4 launches fewer)
+            count = ops.bin_live_count_async(means2d, radii, conics, opac_row, tw, th)
+        else:
+            count = ops.isect_count_live_async(means2d, radii, conics, opac_row, tw, th)
         # work that does not need the lists runs while the host waits for the live total
         colors = torch.empty(1, N, 4, **f32)
         _run(lib.fsgs_sh_fwd_split, (1, N, K, sh_degree, ptr(means), ptr(cam["campos"]), ptr(features_dc),
@@ -138,8 +142,12 @@ class _FusedGetOutputs(torch.autograd.Function):
         _run(lib.fsgs_live_pack_normals, (N, ptr(means2d), ptr(conics), ptr(colors), ptr(opac_sig), ptr(quats),
                                          ptr(scales), ptr(means), ptr(cam["c2w"]), ptr(packed), ptr(normals_world),
                                          ptr(max_last), n_cells, sp), "fsgs_live_pack_normals", "_d4e3")
-        tpg, isect_ids, flatten_ids, offsets = ops.isect_finish_live(count, means2d, radii, depths, conics, opac_row,
-                                                                     tw, th, want_ids=False)
+        if direct_bins:
+            tpg, isect_ids, flatten_ids, offsets = ops.bin_live_finish(count, means2d, radii, depths, conics, opac_row,
+                                                                       tw, th)
+        else:
+            tpg, isect_ids, flatten_ids, offsets = ops.isect_finish_live(count, means2d, radii, depths, conics,
+                                                                         opac_row, tw, th, want_ids=False)
         rule_diff = 0
         M = flatten_ids.numel()
 

@@ -313,6 +313,65 @@ def tile_sort(ids: Tensor, pay: Tensor, n_cameras: int, tile_width: int, tile_he
     return ids_s, pay_s, offsets[:T].view(n_cameras, tile_height, tile_width)
 
 
+USE_BIN_LIVE = os.environ.get("FSGS_BIN_LIVE", "1") != "0"
+
+
+def _pinned_i32(dev) -> Tensor:
+    ring = _PINNED.setdefault(str(dev) + ":i32",
+                              dict(bufs=[torch.zeros(1, dtype=torch.int32).pin_memory() for _ in range(4)], i=0))
+    ring["i"] = (ring["i"] + 1) % len(ring["bufs"])
+    return ring["bufs"][ring["i"]]
+
+
+def bin_live_count_async(means2d: Tensor, radii: Tensor, conics: Tensor, opacities: Tensor,
+                         tile_width: int, tile_height: int) -> dict:
+    """Pass 1 of the direct binning (csrc/isect.hip: fsgs_bin_live_count) WITHOUT the host wait: per-tile
+    counts of the live pairs, isect_offsets, and the live total on its way to pinned memory behind an event."""
+    lib = load()
+    dev = means2d.device
+    Cn, N = radii.shape
+    T = Cn * tile_width * tile_height
+    tpg = torch.empty(Cn, N, dtype=torch.int32, device=dev)
+    offsets = torch.empty(T + 1, dtype=torch.int32, device=dev)
+    tbytes = lib.fsgs_bin_live_table_bytes(Cn, N, tile_width, tile_height)
+    table = WORKSPACE.take(tbytes, dev)
+    _run(lib.fsgs_bin_live_count, (Cn, N, ptr(means2d), ptr(radii), ptr(conics), ptr(opacities), tile_width,
+                                  tile_height, ptr(tpg), ptr(offsets), ptr(table), tbytes, stream_ptr(dev)),
+         "fsgs_isect_count_live")
+    pinned = _pinned_i32(dev)
+    pinned.copy_(offsets[T:T + 1], non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(dev))
+    return dict(direct=True, tpg=tpg, offsets=offsets, table=table, pinned=pinned, event=ev, T=T)
+
+
+def bin_live_finish(st: dict, means2d: Tensor, radii: Tensor, depths: Tensor, conics: Tensor, opacities: Tensor,
+                    tile_width: int, tile_height: int):
+    """Wait for the live total, then scatter into the tile buckets + sort them.  Returns (tiles_per_gauss,
+    None, payload_sorted, isect_offsets [C,th,tw]) — or falls back to the list chain (radix sort) when the
+    tiles are too dense for LDS buckets."""
+    lib = load()
+    dev = means2d.device
+    Cn, N = radii.shape
+    T = st["T"]
+    st["event"].synchronize()
+    M = int(st["pinned"][0])
+    if not use_tile_sort(M, T):
+        WORKSPACE.give(st["table"])
+        st2 = isect_count_live_async(means2d, radii, conics, opacities, tile_width, tile_height)
+        return isect_finish_live(st2, means2d, radii, depths, conics, opacities, tile_width, tile_height,
+                                 want_ids=False)
+    pay_s = torch.empty(M, dtype=torch.int32, device=dev)
+    if M > 0:
+        buckets = WORKSPACE.take(8 * M, dev)
+        _run(lib.fsgs_bin_live_emit, (Cn, N, ptr(means2d), ptr(radii), ptr(depths), ptr(conics), ptr(opacities),
+                                     tile_width, tile_height, ptr(st["offsets"]), ptr(st["table"]), M, ptr(buckets),
+                                     ptr(pay_s), stream_ptr(dev)), "fsgs_tile_sort")
+        WORKSPACE.give(buckets)
+    WORKSPACE.give(st["table"])
+    return st["tpg"], None, pay_s, st["offsets"][:T].view(Cn, tile_height, tile_width)
+
+
 def bin_and_sort_live(means2d: Tensor, radii: Tensor, depths: Tensor, conics: Tensor, opacities: Tensor,
                       tile_width: int, tile_height: int):
     """Live emission + sort + offsets (tile 16).  Returns tiles_per_gauss [C,N] (gsplat's count), sorted

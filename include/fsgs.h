@@ -270,6 +270,27 @@ int fsgs_tile_sort(int64_t n, const int64_t *isect_ids, const int32_t *payload, 
                    int tile_height, int32_t *isect_offsets, int32_t *payload_sorted,
                    int64_t *isect_ids_sorted, void *scratch, size_t scratch_bytes, fsgs_stream_t stream);
 
+/* ---- Direct binning of the live pairs: fsgs_isect_count_live + fsgs_isect_emit_live + fsgs_tile_sort as two
+ * calls that never write the pairs in emission order (same outputs, bit for bit; replaces gsplat 1.0.0
+ * `isect_tiles(sort=True)` + `isect_offset_encode` as reached from
+ * /root/reference/dn_splatter/dn_model.py:570-591, for tile 16).
+ *   fsgs_bin_live_count: enumerates the (Gaussian, tile) pairs, counts the live ones per tile and scans:
+ *       tiles_per_gauss [C,N] (gsplat's count, nullable), isect_offsets [C*th*tw + 1] with the last entry =
+ *       the number of live pairs (copy it to the host to size the second call's buffers).
+ *   fsgs_bin_live_emit: enumerates again, drops every live pair into its tile's bucket and sorts the
+ *       buckets on (depth, flatten id): payload_sorted [n_live] = quadrant mask << 28 | flatten id.
+ * table_scratch: fsgs_bin_live_table_bytes(C, N, tw, th) bytes, untouched between the two calls;
+ * buckets: n_live 64-bit words.  C*th*tw <= fsgs_bin_live_max_tiles(). */
+int fsgs_bin_live_max_tiles(void);
+size_t fsgs_bin_live_table_bytes(int C, int N, int tile_width, int tile_height);
+int fsgs_bin_live_count(int C, int N, const float *means2d, const int32_t *radii, const float *conics,
+                        const float *opacities, int tile_width, int tile_height, int32_t *tiles_per_gauss,
+                        int32_t *isect_offsets, void *table_scratch, size_t table_bytes, fsgs_stream_t stream);
+int fsgs_bin_live_emit(int C, int N, const float *means2d, const int32_t *radii, const float *depths,
+                       const float *conics, const float *opacities, int tile_width, int tile_height,
+                       const int32_t *isect_offsets, const void *table_scratch, int64_t n_live, void *buckets,
+                       int32_t *payload_sorted, fsgs_stream_t stream);
+
 /* Split packed gradient records into the five gsplat-shaped arrays (written, not accumulated).
  * rezero != 0: v_packed is cleared after it has been read, ready for the next frame's atomics. */
 int fsgs_raster_unpack_grads(int64_t total, int D, float *v_packed, int rezero, float *v_means2d,

@@ -65,6 +65,12 @@ def test_full_size_binning_sorted_and_consistent(dev, full_scene):
     finally:
         ops.USE_TILE_SORT = True
     assert torch.equal(r_ids, ids) and torch.equal(r_pay, pay) and torch.equal(r_offs, offs)
+    # direct binning (pairs straight into their tile's bucket, no emission-order lists): the same bits
+    st = ops.bin_live_count_async(info.means2d, info.radii, info.conics, opac, tw, th)
+    d_tpg, d_ids, d_pay, d_offs = ops.bin_live_finish(st, info.means2d, info.radii, info.depths, info.conics, opac, tw, th)
+    assert d_ids is None
+    assert torch.equal(d_tpg, tpg) and torch.equal(d_pay, pay) and torch.equal(d_offs, offs)
+    assert torch.equal(info.payload, pay), "the fused node's own lists are the direct path's"
 
 
 def test_full_size_forward_deterministic_and_in_range(dev, full_scene):

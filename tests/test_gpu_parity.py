@@ -566,6 +566,45 @@ def test_tile_sort_bit_exact(dev, case):
     assert torch.equal(offs, r_off)
 
 
+@pytest.mark.parametrize("case", ["one_camera", "two_cameras", "ties", "one_hot_tile", "tiny_image", "nothing_visible", "empty"])
+def test_direct_binning_equals_list_chain(dev, case):
+    """fsgs_bin_live_count + fsgs_bin_live_emit (pairs counted per tile and dropped straight into their
+    tile's bucket) against fsgs_isect_count_live + emit_live + tile_sort on the same projected Gaussians:
+    tiles_per_gauss, sorted payload (quadrant mask | flatten id) and isect_offsets bit for bit — several
+    cameras, equal depths, one tile holding thousands of pairs (both sort tiers), an image smaller than a
+    tile, nothing visible, N = 0."""
+    from fusionsense_amd import ops
+    g = torch.Generator().manual_seed(5)
+    Cn = 2 if case == "two_cameras" else 1
+    N = 0 if case == "empty" else 6000
+    W, H = (12, 9) if case == "tiny_image" else (200, 136)
+    tw, th = math.ceil(W / 16), math.ceil(H / 16)
+    means2d = torch.rand(Cn, N, 2, generator=g) * torch.tensor([W, H]) * 1.2 - torch.tensor([W, H]) * 0.1
+    radii = torch.randint(0, 40, (Cn, N), generator=g, dtype=torch.int32)
+    radii[torch.rand(Cn, N, generator=g) < 0.2] = 0
+    if case == "nothing_visible":
+        radii.zero_()
+    depths = torch.rand(Cn, N, generator=g) * 5 + 0.2
+    if case == "ties":
+        depths = torch.round(depths * 2) / 2
+    if case == "one_hot_tile":
+        means2d[:, :5000] = torch.tensor([40.0, 40.0]) + torch.rand(Cn, 5000, 2, generator=g) * 4
+        radii[:, :5000] = 6
+    # conics of isotropic Gaussians whose 3-sigma radius is the bbox radius, some much tighter (culled pairs)
+    sig = (radii.float().clamp(min=1) / 3) * (0.2 + 0.8 * torch.rand(Cn, N, generator=g))
+    conics = torch.stack([1 / sig**2, 0.3 * torch.rand(Cn, N, generator=g) / sig**2, 1 / sig**2], -1)
+    opac = torch.rand(Cn, N, generator=g)
+    a = [t.to(dev).contiguous() for t in (means2d, radii, depths, conics, opac)]
+    tpg, ids, pay, offs = ops.bin_and_sort_live(a[0], a[1], a[2], a[3], a[4], tw, th)
+    st = ops.bin_live_count_async(a[0], a[1], a[3], a[4], tw, th)
+    d_tpg, _, d_pay, d_offs = ops.bin_live_finish(st, a[0], a[1], a[2], a[3], a[4], tw, th)
+    assert torch.equal(d_tpg, tpg)
+    assert torch.equal(d_offs, offs)
+    assert torch.equal(d_pay, pay)
+    if case not in ("nothing_visible", "empty"):
+        assert pay.numel() > 0
+
+
 @pytest.mark.parametrize("case", ["cube", "cube_legacy", "two_cameras", "one_hot_tile", "overflow_fallback", "empty"])
 def test_bucketed_binning_bit_exact(dev, case):
     """Tile-bucketed binning + per-tile LDS sort against the oracle's emit + stable sort + offsets:
