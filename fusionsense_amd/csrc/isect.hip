@@ -327,7 +327,7 @@ isect_live_flat_kernel(int C, int N, const float *__restrict__ means2d, const in
 //       over the lanes as above) and counts them per tile in LDS -> table[tile][workgroup]
 //   tile_scan / tile_offsets (tilesort.hip): exclusive prefix over the workgroups per tile, isect_offsets
 //   pass 2 (SCATTER = true): the same enumeration; every live pair claims the next slot of its tile's
-//       bucket (LDS cursor, started at isect_offsets[tile] + table[tile][workgroup]) and drops its sort
+//       bucket (LDS cursor, started at isect_offsets[tile] + table[workgroup][tile]) and drops its sort
 //       word  bits(depth) << 32 | flatten id << 4 | quadrant mask  there
 // followed by the in-tile sorts.  Four launches fewer, no emission-order arrays, no per-Gaussian scan.
 // The claiming order inside a bucket is arbitrary; the in-tile sort on (depth, id) makes the result
@@ -385,7 +385,7 @@ isect_live_bin_kernel(int C, int N, const float *__restrict__ means2d, const int
         L.depth[tid] = db;
     }
     for (int t = tid; t < T; t += kBinThreads)
-        slots[t] = SCATTER ? offsets[t] + table[(int64_t)t * nb + blockIdx.x] : 0;
+        slots[t] = SCATTER ? offsets[t] + table[(int64_t)blockIdx.x * T + t] : 0;
     int inc = cnt;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -431,7 +431,7 @@ isect_live_bin_kernel(int C, int N, const float *__restrict__ means2d, const int
     }
     if (!SCATTER) {
         __syncthreads();
-        for (int t = tid; t < T; t += kBinThreads) table[(int64_t)t * nb + blockIdx.x] = slots[t];
+        for (int t = tid; t < T; t += kBinThreads) table[(int64_t)blockIdx.x * T + t] = slots[t];
     }
 }
 
@@ -595,7 +595,7 @@ extern "C" int fsgs_isect_emit_live(int C, int N, const float *means2d, const in
 
 // ---- direct binning: C entry points -----------------------------------------------------------------------
 namespace fsgs {
-int launch_tile_scan_offsets(int T, int nb, int32_t *table, int32_t *totals, int32_t *isect_offsets, hipStream_t s);
+int launch_tile_scan_rows_offsets(int T, int nb, int32_t *table, int32_t *totals, int32_t *isect_offsets, hipStream_t s);
 int launch_tile_sort_tiers(int T, int n_tiles, int tile_bits, const int32_t *isect_offsets, uint64_t *buckets,
                            int32_t *payload_sorted, int64_t *isect_ids_sorted, hipStream_t s);
 }
@@ -606,7 +606,7 @@ static inline size_t bin_lds_bytes(int T) { return sizeof(BinLds) + (size_t)T * 
 // tiles (cameras x tiles) the direct path can take: the per-workgroup tile slots live in LDS (160 KB per CU)
 extern "C" int fsgs_bin_live_max_tiles(void) { return 24576; }
 
-// table scratch: [table i32: T * blocks] [totals i32: T]
+// table scratch: [table i32: blocks x T] [totals i32: T]
 extern "C" size_t fsgs_bin_live_table_bytes(int C, int N, int tile_width, int tile_height) {
     const int64_t T = (int64_t)C * tile_width * tile_height;
     const int64_t nb = bin_blocks((int64_t)C * N > 0 ? (int64_t)C * N : 1);
@@ -657,7 +657,7 @@ extern "C" int fsgs_bin_live_count(int C, int N, const float *means2d, const int
                        nullptr, nullptr);
     rc = check_launch();
     if (rc != FSGS_OK) return rc;
-    return launch_tile_scan_offsets(T, nb, table, totals, isect_offsets, s);
+    return launch_tile_scan_rows_offsets(T, nb, table, totals, isect_offsets, s);
 }
 
 // Pass 2 + the in-tile sorts: payload_sorted[n_live] = quadrant mask << 28 | flatten id in (tile, depth, id)

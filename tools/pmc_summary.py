@@ -21,6 +21,7 @@ SPAN = [
     ("ssim_l1_fwd_kernel", "ssim_l1_fwd"), ("ssim_l1_bwd_kernel", "ssim_l1_bwd"),
     ("project_bwd_kernel<true>", "gaussian_bwd"), ("project_fwd_kernel<true>", "project_fwd_act"),
     ("isect_live_flat_kernel<false>", "isect_count_live"), ("isect_live_flat_kernel<true>", "isect_emit_live"),
+    ("isect_live_bin_kernel<false>", "isect_count_live"), ("isect_live_bin_kernel<true>", "tile_sort"),
     ("live_pack_kernel", "live_pack_normals_d4e3"),
 ]
 
@@ -59,11 +60,22 @@ def main():
         n = max(t.get("n", 1), 1)
         # tile_sort: 6 launches per call, 5 different symbols -> calls = launches of the histogram kernel
         if span == "tile_sort":
-            n = max(len(d.get("FETCH_SIZE", d.get("WRITE_SIZE", []))) for k, d in acc.items() if "tile_hist_kernel" in k)
+            n = max(len(d.get("FETCH_SIZE", d.get("WRITE_SIZE", []))) for k, d in acc.items() if "tile_offsets_kernel" in k)
         fetch_b = 2.0 * t["fetch_kb"] * 1024.0 / n
         write_b = t["write_kb"] * 1024.0 / n
         out[span] = {"fetch_bytes_per_launch": round(fetch_b), "write_bytes_per_launch": round(write_b),
                      "hbm_bytes_per_launch": round(fetch_b + write_b), "launches_sampled": n}
+    # vector-ALU counters of single-symbol spans (a separate --pmc pass): instructions and busy quad-cycles per launch
+    for k, d in acc.items():
+        for sym, span in SPAN:
+            if sym in k and span != "tile_sort" and d.get("SQ_INSTS_VALU") and span in out:
+                out[span]["sq_insts_valu_per_launch"] = round(sum(d["SQ_INSTS_VALU"]) / len(d["SQ_INSTS_VALU"]))
+                a = d.get("SQ_ACTIVE_INST_VALU")
+                if a:
+                    out[span]["sq_active_inst_valu_quadcycles_per_launch"] = round(sum(a) / len(a))
+                break
+    out["_note"] = ("per-launch averages of rocprofv3 --pmc passes (FETCH_SIZE x2 per the gfx950 correction, WRITE_SIZE, "
+                    "SQ_INSTS_VALU, SQ_ACTIVE_INST_VALU) of `python3 bench.py --steps 6 --warmup 2`; made by tools/pmc_summary.py")
     json.dump(out, open(out_json, "w"), indent=1, sort_keys=True)
 
 
