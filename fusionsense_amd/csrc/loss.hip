@@ -267,18 +267,29 @@ ssim_l1_bwd_kernel(int H, int W, const float *__restrict__ pred, const float *__
 // (/root/reference/dn_splatter/dn_model.py:673-925: sensor-depth and normal supervision), one pass:
 // partial[blk] = (sum |depth - depth_gt|, sum |normal - normal_gt|); the backward writes
 // w * sign(.) / count straight into the two gradient images.
+// GRADS: the gradient images are written in the same pass (the caller knows the upstream gradient of the
+// loss already — the trainer's tape-free step seeds it itself): one launch and one read of the images less.
+template <bool GRADS>
 __global__ void __launch_bounds__(256)
 aux_l1_fwd_kernel(int64_t P, const float *__restrict__ depth, const float *__restrict__ depth_gt,
                   const float *__restrict__ normal, const float *__restrict__ normal_gt,
-                  float *__restrict__ partial) {
+                  float *__restrict__ partial, const float *__restrict__ v_loss, float g_depth, float g_normal,
+                  float *__restrict__ v_depth, float *__restrict__ v_normal) {
     __shared__ float red[4];
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     float sd = 0.f, sn = 0.f;
     if (p < P) {
-        sd = fabsf(depth[p] - depth_gt[p]);
+        const float up = GRADS ? v_loss[0] : 0.f;
+        const float d = depth[p] - depth_gt[p];
+        sd = fabsf(d);
+        if (GRADS) v_depth[p] = up * g_depth * ((d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f));
         if (normal) {
 #pragma unroll
-            for (int k = 0; k < 3; ++k) sn += fabsf(normal[p * 3 + k] - normal_gt[p * 3 + k]);
+            for (int k = 0; k < 3; ++k) {
+                const float e = normal[p * 3 + k] - normal_gt[p * 3 + k];
+                sn += fabsf(e);
+                if (GRADS) v_normal[p * 3 + k] = up * g_normal * ((e > 0.f) ? 1.f : ((e < 0.f) ? -1.f : 0.f));
+            }
         }
     }
     const float td = block_sum_256(sd, red);
@@ -373,8 +384,21 @@ extern "C" int fsgs_aux_l1_fwd(int64_t n_pixels, const float *depth, const float
     if (n_pixels < 0) return FSGS_EINVAL;
     if (n_pixels == 0) return FSGS_OK;
     if (!depth || !depth_gt || !partial || (normal && !normal_gt)) return FSGS_EINVAL;
-    hipLaunchKernelGGL(aux_l1_fwd_kernel, dim3(ceil_div(n_pixels, 256)), dim3(256), 0, as_stream(stream), n_pixels,
-                       depth, depth_gt, normal, normal_gt, partial);
+    hipLaunchKernelGGL(aux_l1_fwd_kernel<false>, dim3(ceil_div(n_pixels, 256)), dim3(256), 0, as_stream(stream),
+                       n_pixels, depth, depth_gt, normal, normal_gt, partial, nullptr, 0.f, 0.f, nullptr, nullptr);
+    return check_launch();
+}
+
+extern "C" int fsgs_aux_l1_fwd_bwd(int64_t n_pixels, const float *depth, const float *depth_gt, const float *normal,
+                                   const float *normal_gt, float *partial, const float *v_loss, float g_depth,
+                                   float g_normal, float *v_depth, float *v_normal, fsgs_stream_t stream) {
+    if (n_pixels < 0) return FSGS_EINVAL;
+    if (n_pixels == 0) return FSGS_OK;
+    if (!depth || !depth_gt || !partial || !v_loss || !v_depth || (normal && (!normal_gt || !v_normal)))
+        return FSGS_EINVAL;
+    hipLaunchKernelGGL(aux_l1_fwd_kernel<true>, dim3(ceil_div(n_pixels, 256)), dim3(256), 0, as_stream(stream),
+                       n_pixels, depth, depth_gt, normal, normal_gt, partial, v_loss, g_depth, g_normal, v_depth,
+                       v_normal);
     return check_launch();
 }
 

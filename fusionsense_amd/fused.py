@@ -350,7 +350,7 @@ def fused_step_forward_backward(gauss_params: Dict[str, Tensor], camera: Camera,
         lctx = _DirectCtx((True, False, True, False, has_n, False, False, False, False))
         loss = ops._TrainLoss.forward(lctx, rgb, target["rgb"], depth, target["depth"], normal if has_n else None,
                                       target["normal"] if has_n else None, float(ssim_lambda), float(w_depth),
-                                      float(w_normal))
+                                      float(w_normal), seed=seed_grad)
         v = ops._TrainLoss.backward(lctx, seed_grad)
         _FusedGetOutputs.backward(ctx, v[0], v[2], v[4], None)
     out = {"rgb": rgb, "depth": depth, "normal": normal, "accumulation": alpha, "background": background,

@@ -408,6 +408,11 @@ int fsgs_aux_l1_fwd(int64_t n_pixels, const float *depth, const float *depth_gt,
 int fsgs_aux_l1_bwd(int64_t n_pixels, const float *depth, const float *depth_gt, const float *normal,
                     const float *normal_gt, const float *v_loss, float g_depth, float g_normal,
                     float *v_depth, float *v_normal, fsgs_stream_t stream);
+/* fsgs_aux_l1_fwd and fsgs_aux_l1_bwd in one pass, for callers that know the upstream gradient of the loss
+ * when they evaluate it (v_loss[0], device): partial sums as fsgs_aux_l1_fwd, gradient images as fsgs_aux_l1_bwd. */
+int fsgs_aux_l1_fwd_bwd(int64_t n_pixels, const float *depth, const float *depth_gt, const float *normal,
+                        const float *normal_gt, float *partial, const float *v_loss, float g_depth,
+                        float g_normal, float *v_depth, float *v_normal, fsgs_stream_t stream);
 
 /* The scalar loss from the partials above without torch reductions or a host sync:
  * out[0] = bias + sum_t (weights[2t] * sum_r partials[t][r,0] + weights[2t+1] * sum_r partials[t][r,1]),
