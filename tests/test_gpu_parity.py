@@ -524,7 +524,8 @@ def test_fused_trainer_step_equals_unfused(dev):
         assert (res[0][2][k][solid] - res[1][2][k][solid]).abs().max().item() < 1e-3 * tr.optim_cfg.lr[k] + 1e-9, k
 
 
-@pytest.mark.parametrize("case", ["random", "ties", "two_cameras", "bucket_5000", "bucket_20000", "single", "empty"])
+@pytest.mark.parametrize("case", ["random", "ties", "two_cameras", "bucket_1500", "bucket_2048", "bucket_3000", "bucket_4096",
+                                  "bucket_5000", "bucket_20000", "single", "empty"])
 def test_tile_sort_bit_exact(dev, case):
     """Partition-by-tile + per-tile LDS sort (csrc/tilesort.hip) against the radix sort of the same pairs
     and isect_offset_encode: sorted keys, payloads (ties in key -> ascending flatten id) and offsets must be
@@ -535,12 +536,18 @@ def test_tile_sort_bit_exact(dev, case):
     n_tiles = tw * th
     tb = ops.tile_bits(n_tiles)
     n = {"random": 30000, "ties": 20000, "two_cameras": 25000, "bucket_5000": 12000, "bucket_20000": 30000,
-         "single": 1, "empty": 0}[case]
+         "bucket_1500": 9000, "bucket_2048": 9000, "bucket_3000": 9000, "bucket_4096": 9000, "single": 1, "empty": 0}[case]
     tile = torch.randint(0, n_tiles, (n,), generator=g)
     cam = torch.randint(0, Cn, (n,), generator=g)
     depth = torch.rand(n, generator=g) * 10 + 0.1
     if case == "ties":
         depth = torch.round(depth)            # many equal (tile, depth) keys
+    if case in ("bucket_1500", "bucket_2048", "bucket_3000", "bucket_4096"):  # the large LDS tier at and around its power-of-two sizes
+        big = int(case.split("_")[1])
+        tile[:] = torch.randint(0, n_tiles - 1, (n,), generator=g)
+        tile[tile == 3] = 4
+        tile[:big] = 3
+        depth[:big // 2] = torch.round(depth[:big // 2] * 20) / 20   # ties inside the big bucket
     if case == "bucket_5000":
         tile[:5000] = 3
     if case == "bucket_20000":
