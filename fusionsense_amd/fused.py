@@ -125,7 +125,8 @@ class _FusedGetOutputs(torch.autograd.Function):
         # live emission: only (Gaussian, tile) pairs that can reach a pixel are binned and sorted; the
         # quadrant masks ride in the payload (gsplat's full lists are not an output of get_outputs)
         opac_row = opac_sig.view(1, N)
-        direct_bins = ops.USE_BIN_LIVE and tw * th <= lib.fsgs_bin_live_max_tiles()
+        direct_bins = (ops.USE_BIN_LIVE and tw * th <= lib.fsgs_bin_live_max_tiles()
+                       and not ops.bin_live_is_dense(dev, N, tw * th))
         if direct_bins:  # pairs go straight into their tile's bucket (no emission-order lists, 4 launches fewer)
             count = ops.bin_live_count_async(means2d, radii, conics, opac_row, tw, th)
         else:

@@ -277,6 +277,7 @@ def isect_finish_live(st: dict, means2d: Tensor, radii: Tensor, depths: Tensor, 
                                        ptr(st["cum"]), tile_width, tile_height, ptr(ids), ptr(pay), stream_ptr(dev)),
              "fsgs_isect_emit_live")
         n_tiles = tile_width * tile_height
+        _DENSE_HINT[(str(dev), N, Cn * n_tiles)] = not use_tile_sort(M, Cn * n_tiles)
         if use_tile_sort(M, Cn * n_tiles):
             ids_s, pay_s, offsets = tile_sort(ids, pay, Cn, tile_width, tile_height, want_ids=want_ids)
             return st["tpg"], ids_s, pay_s, offsets
@@ -323,6 +324,15 @@ def _pinned_i32(dev) -> Tensor:
     return ring["bufs"][ring["i"]]
 
 
+_DENSE_HINT: dict = {}  # (device, N, T) -> the last frame of this shape was too dense for LDS buckets
+
+
+def bin_live_is_dense(dev, n_gaussians: int, n_tiles_total: int) -> bool:
+    """True if the previous frame of this shape fell back to the list chain + radix sort: the caller then starts
+    with that chain (whose count pass it needs anyway) instead of a direct count that would be thrown away."""
+    return _DENSE_HINT.get((str(dev), n_gaussians, n_tiles_total), False)
+
+
 def bin_live_count_async(means2d: Tensor, radii: Tensor, conics: Tensor, opacities: Tensor,
                          tile_width: int, tile_height: int) -> dict:
     """Pass 1 of the direct binning (csrc/isect.hip: fsgs_bin_live_count) WITHOUT the host wait: per-tile
@@ -356,6 +366,7 @@ def bin_live_finish(st: dict, means2d: Tensor, radii: Tensor, depths: Tensor, co
     T = st["T"]
     st["event"].synchronize()
     M = int(st["pinned"][0])
+    _DENSE_HINT[(str(dev), N, T)] = not use_tile_sort(M, T)
     if not use_tile_sort(M, T):
         WORKSPACE.give(st["table"])
         st2 = isect_count_live_async(means2d, radii, conics, opacities, tile_width, tile_height)
