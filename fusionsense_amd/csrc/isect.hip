@@ -350,7 +350,7 @@ template <bool SCATTER>
 __global__ void __launch_bounds__(kBinThreads)
 isect_live_bin_kernel(int C, int N, const float *__restrict__ means2d, const int32_t *__restrict__ radii,
                       const float *__restrict__ depths, const float *__restrict__ conics,
-                      const float *__restrict__ opacities, int tw, int th, int T, int nb,
+                      const float *__restrict__ opacities, int tw, int th, int T, int nb, int chunks,
                       int32_t *__restrict__ tiles_per_gauss, int32_t *__restrict__ table,
                       const int32_t *__restrict__ offsets, uint64_t *__restrict__ buckets) {
     extern __shared__ __attribute__((aligned(16))) unsigned char bin_smem[];
@@ -358,8 +358,16 @@ isect_live_bin_kernel(int C, int N, const float *__restrict__ means2d, const int
     int *slots = reinterpret_cast<int *>(bin_smem + sizeof(BinLds));
     const int64_t total = (int64_t)C * N;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int64_t idx0 = (int64_t)blockIdx.x * kBinThreads;  // the workgroup's first Gaussian
+    for (int t = tid; t < T; t += kBinThreads)
+        slots[t] = SCATTER ? offsets[t] + table[(int64_t)blockIdx.x * T + t] : 0;
+    // `chunks` groups of 1024 Gaussians per workgroup, one after the other into the same tile slots: the table has
+    // one row per WORKGROUP, so large N is given more chunks instead of more rows (N / 1024 rows of T counters
+    // each would be 234 MB at 6 M Gaussians x 10 000 tiles)
+    for (int ch = 0; ch < chunks; ++ch) {
+    const int64_t idx0 = ((int64_t)blockIdx.x * chunks + ch) * kBinThreads;  // the chunk's first Gaussian
     const int64_t idx = idx0 + tid;
+    if (idx0 >= total) break;
+    if (ch) __syncthreads();  // the previous chunk's constants are no longer read
     int cnt = 0;
     {
         TileRect t = {0, 0, 0, 0};
@@ -384,8 +392,6 @@ isect_live_bin_kernel(int C, int N, const float *__restrict__ means2d, const int
         L.rect[tid] = make_int4(t.x0, t.y0, t.x1 - t.x0, cnt);
         L.depth[tid] = db;
     }
-    for (int t = tid; t < T; t += kBinThreads)
-        slots[t] = SCATTER ? offsets[t] + table[(int64_t)blockIdx.x * T + t] : 0;
     int inc = cnt;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -429,6 +435,7 @@ isect_live_bin_kernel(int C, int N, const float *__restrict__ means2d, const int
                 buckets[slot] = ((uint64_t)L.depth[o] << 32) | ((uint64_t)(uint32_t)gidx << 4) | (uint64_t)m;
         }
     }
+    }  // chunks
     if (!SCATTER) {
         __syncthreads();
         for (int t = tid; t < T; t += kBinThreads) table[(int64_t)blockIdx.x * T + t] = slots[t];
@@ -598,9 +605,21 @@ namespace fsgs {
 int launch_tile_scan_rows_offsets(int T, int nb, int32_t *table, int32_t *totals, int32_t *isect_offsets, hipStream_t s);
 int launch_tile_sort_tiers(int T, int n_tiles, int tile_bits, const int32_t *isect_offsets, uint64_t *buckets,
                            int32_t *payload_sorted, int64_t *isect_ids_sorted, hipStream_t s);
+int launch_split_sort(int T, int n_tiles, int tile_bits, const int32_t *isect_offsets, int64_t n_live,
+                      const uint64_t *buckets, uint64_t *buckets2, int32_t *scratch, int32_t *payload_sorted,
+                      hipStream_t s);
+int64_t split_scratch_ints(int T, int64_t n_live);
 }
 
-static inline int64_t bin_blocks(int64_t total) { return (total + kBinThreads - 1) / kBinThreads; }
+// chunks of 1024 Gaussians per workgroup: as many as keep the table at ~512 rows
+static inline int bin_chunks(int64_t total) {
+    const int64_t c = (total + (int64_t)kBinThreads * 512 - 1) / ((int64_t)kBinThreads * 512);
+    return c < 1 ? 1 : (int)c;
+}
+static inline int64_t bin_blocks(int64_t total) {
+    const int64_t per = (int64_t)kBinThreads * bin_chunks(total);
+    return (total + per - 1) / per;
+}
 static inline size_t bin_lds_bytes(int T) { return sizeof(BinLds) + (size_t)T * sizeof(int); }
 
 // tiles (cameras x tiles) the direct path can take: the per-workgroup tile slots live in LDS (160 KB per CU)
@@ -653,8 +672,8 @@ extern "C" int fsgs_bin_live_count(int C, int N, const float *means2d, const int
     int rc = bin_set_lds(T);
     if (rc != FSGS_OK) return rc;
     hipLaunchKernelGGL((isect_live_bin_kernel<false>), dim3(nb), dim3(kBinThreads), bin_lds_bytes(T), s, C, N, means2d,
-                       radii, nullptr, conics, opacities, tile_width, tile_height, T, nb, tiles_per_gauss, table,
-                       nullptr, nullptr);
+                       radii, nullptr, conics, opacities, tile_width, tile_height, T, nb, bin_chunks(total), tiles_per_gauss,
+                       table, nullptr, nullptr);
     rc = check_launch();
     if (rc != FSGS_OK) return rc;
     return launch_tile_scan_rows_offsets(T, nb, table, totals, isect_offsets, s);
@@ -662,10 +681,43 @@ extern "C" int fsgs_bin_live_count(int C, int N, const float *means2d, const int
 
 // Pass 2 + the in-tile sorts: payload_sorted[n_live] = quadrant mask << 28 | flatten id in (tile, depth, id)
 // order.  `buckets` = n_live 64-bit words of scratch; table_scratch / isect_offsets as left by pass 1.
+static int bin_live_emit_impl(int C, int N, const float *means2d, const int32_t *radii, const float *depths,
+                              const float *conics, const float *opacities, int tile_width, int tile_height,
+                              const int32_t *isect_offsets, const void *table_scratch, int64_t n_live,
+                              void *buckets, void *buckets2, void *split_scratch, int32_t *payload_sorted,
+                              fsgs_stream_t stream);
+
+extern "C" size_t fsgs_bin_live_split_scratch_bytes(int C, int tile_width, int tile_height, int64_t n_live) {
+    return (size_t)split_scratch_ints(C * tile_width * tile_height, n_live > 0 ? n_live : 0) * sizeof(int32_t) + 64;
+}
+
+// fsgs_bin_live_emit for buckets of any size: tiles with more than 1024 live pairs are split into depth slabs of
+// ~512 before the LDS sorts (tilesort.hip), so dense scenes need neither the radix sort nor its lists.
+// buckets, buckets2: n_live 64-bit words each; split_scratch: fsgs_bin_live_split_scratch_bytes().
+extern "C" int fsgs_bin_live_emit_split(int C, int N, const float *means2d, const int32_t *radii, const float *depths,
+                                        const float *conics, const float *opacities, int tile_width, int tile_height,
+                                        const int32_t *isect_offsets, const void *table_scratch, int64_t n_live,
+                                        void *buckets, void *buckets2, void *split_scratch, size_t split_bytes,
+                                        int32_t *payload_sorted, fsgs_stream_t stream) {
+    if (n_live > 0 && (!buckets2 || !split_scratch)) return FSGS_EINVAL;
+    if (n_live > 0 && split_bytes < fsgs_bin_live_split_scratch_bytes(C, tile_width, tile_height, n_live)) return FSGS_ESCRATCH;
+    return bin_live_emit_impl(C, N, means2d, radii, depths, conics, opacities, tile_width, tile_height, isect_offsets,
+                              table_scratch, n_live, buckets, buckets2, split_scratch, payload_sorted, stream);
+}
+
 extern "C" int fsgs_bin_live_emit(int C, int N, const float *means2d, const int32_t *radii, const float *depths,
                                   const float *conics, const float *opacities, int tile_width, int tile_height,
                                   const int32_t *isect_offsets, const void *table_scratch, int64_t n_live,
                                   void *buckets, int32_t *payload_sorted, fsgs_stream_t stream) {
+    return bin_live_emit_impl(C, N, means2d, radii, depths, conics, opacities, tile_width, tile_height, isect_offsets,
+                              table_scratch, n_live, buckets, nullptr, nullptr, payload_sorted, stream);
+}
+
+static int bin_live_emit_impl(int C, int N, const float *means2d, const int32_t *radii, const float *depths,
+                              const float *conics, const float *opacities, int tile_width, int tile_height,
+                              const int32_t *isect_offsets, const void *table_scratch, int64_t n_live,
+                              void *buckets, void *buckets2, void *split_scratch, int32_t *payload_sorted,
+                              fsgs_stream_t stream) {
     if (C < 1 || N < 0 || tile_width < 1 || tile_height < 1 || n_live < 0 || !isect_offsets) return FSGS_EINVAL;
     const int64_t T64 = (int64_t)C * tile_width * tile_height;
     if (T64 > fsgs_bin_live_max_tiles() || n_live > 0x7FFFFFF0ll) return FSGS_EINVAL;
@@ -680,13 +732,17 @@ extern "C" int fsgs_bin_live_emit(int C, int N, const float *means2d, const int3
     int rc = bin_set_lds(T);
     if (rc != FSGS_OK) return rc;
     hipLaunchKernelGGL((isect_live_bin_kernel<true>), dim3(nb), dim3(kBinThreads), bin_lds_bytes(T), s, C, N, means2d,
-                       radii, depths, conics, opacities, tile_width, tile_height, T, nb, nullptr, table,
+                       radii, depths, conics, opacities, tile_width, tile_height, T, nb, bin_chunks((int64_t)C * N), nullptr, table,
                        isect_offsets, reinterpret_cast<uint64_t *>(buckets));
     rc = check_launch();
     if (rc != FSGS_OK) return rc;
     int tb = 0;
     while ((1ll << tb) <= n_tiles) ++tb;
     if (tb < 1) tb = 1;
+    if (buckets2)
+        return launch_split_sort(T, n_tiles, tb, isect_offsets, n_live, reinterpret_cast<const uint64_t *>(buckets),
+                                 reinterpret_cast<uint64_t *>(buckets2), reinterpret_cast<int32_t *>(split_scratch),
+                                 payload_sorted, s);
     return launch_tile_sort_tiers(T, n_tiles, tb, isect_offsets, reinterpret_cast<uint64_t *>(buckets),
                                   payload_sorted, nullptr, s);
 }

@@ -364,6 +364,152 @@ int launch_tile_scan_rows_offsets(int T, int nb, int32_t *table, int32_t *totals
     return check_launch();
 }
 
+// ---- depth slabs: buckets too large for the LDS sorts are split by depth first --------------------------------
+// A tile's bucket of n > kSplitMin words is partitioned into S = ceil(n / kSplitTarget) slabs by
+// slab(depth) = floor((bits(depth) - min) * S / (max - min + 1))  (monotone in depth, equal depths share a slab),
+// every slab is then sorted on (depth, id) like a small tile and the slabs lie in order: the tile is sorted.
+// One more pass over the words (24 B / word) instead of the 6 radix passes (32 B / pair each) that scenes with
+// thousands of pairs per tile needed.  Slabs that still exceed the LDS tiers (skewed depths) are sorted in place.
+constexpr int kSplitMin = 1024, kSplitTarget = 512, kSplitMaxSlabs = 2048, kSplitThreads = 512;
+
+__device__ __host__ inline int split_slabs(int n) {
+    if (n <= kSplitMin) return 1;
+    const int s = (n + kSplitTarget - 1) / kSplitTarget;
+    return s < kSplitMaxSlabs ? s : kSplitMaxSlabs;
+}
+
+// sub_base[t] = number of sub-buckets in front of tile t, sub_base[T] = their total   (one workgroup)
+__global__ void __launch_bounds__(1024)
+split_base_kernel(int T, const int32_t *__restrict__ offsets, int32_t *__restrict__ sub_base) {
+    __shared__ int wsum[16];
+    __shared__ int carry_s;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < T; base += 1024) {
+        const int i = base + tid;
+        const int v = (i < T) ? split_slabs(offsets[i + 1] - offsets[i]) : 0;
+        int inc = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(inc, d, 64);
+            if (lane >= d) inc += o;
+        }
+        if (lane == 63) wsum[w] = inc;
+        __syncthreads();
+        int wbase = 0;
+        for (int k = 0; k < w; ++k) wbase += wsum[k];
+        const int carry = carry_s;
+        if (i < T) sub_base[i] = carry + wbase + inc - v;
+        __syncthreads();
+        if (tid == 1023) carry_s = carry + wbase + inc;
+        __syncthreads();
+    }
+    if (tid == 0) sub_base[T] = carry_s;
+}
+
+// one workgroup per tile: words of the tile's bucket -> `out`, grouped by slab; sub_offsets[sub_base[t] + k] =
+// first word of slab k; the last tile's workgroup also closes the list (entries up to max_sub = total words).
+// The slabs are cut at QUANTILES of a 2048-bin depth histogram of the bucket (bin b belongs to slab
+// floor(words in front of b / kSplitTarget)): depths cluster on surfaces, equal-width slabs left most words in a
+// few slabs that only the large sort tier could take.
+constexpr int kSplitBins = 2048;
+__global__ void __launch_bounds__(kSplitThreads)
+split_slabs_kernel(int T, const int32_t *__restrict__ offsets, const int32_t *__restrict__ sub_base,
+                   const uint64_t *__restrict__ in, uint64_t *__restrict__ out, int32_t *__restrict__ sub_offsets,
+                   int max_sub) {
+    __shared__ unsigned int red_min[kSplitThreads / 64], red_max[kSplitThreads / 64];
+    __shared__ int excl[kSplitBins];    // words per depth bin, then words in front of the bin
+    __shared__ int cursor[kSplitMaxSlabs];
+    __shared__ int wsum[kSplitThreads / 64];
+    const int t = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int s = offsets[t], e = offsets[t + 1], n = e - s;
+    const int sb = sub_base[t], S = sub_base[t + 1] - sb;
+    if (t == T - 1) {
+        const int total = offsets[T];
+        for (int i = sub_base[T] + tid; i <= max_sub; i += kSplitThreads) sub_offsets[i] = total;
+    }
+    if (S <= 1) {
+        for (int i = tid; i < n; i += kSplitThreads) out[s + i] = in[s + i];
+        if (tid == 0) sub_offsets[sb] = s;
+        return;
+    }
+    // depth range of the bucket
+    unsigned int lo = 0xFFFFFFFFu, hi = 0u;
+    for (int i = tid; i < n; i += kSplitThreads) {
+        const unsigned int d = (unsigned int)(in[s + i] >> 32);
+        lo = min(lo, d); hi = max(hi, d);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        lo = min(lo, (unsigned int)__shfl_xor((int)lo, d, 64));
+        hi = max(hi, (unsigned int)__shfl_xor((int)hi, d, 64));
+    }
+    if (lane == 0) { red_min[w] = lo; red_max[w] = hi; }
+    for (int k = tid; k < kSplitBins; k += kSplitThreads) excl[k] = 0;
+    for (int k = tid; k < S; k += kSplitThreads) cursor[k] = e;  // slabs no bin starts stay empty at the end
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kSplitThreads / 64; ++k) { lo = min(lo, red_min[k]); hi = max(hi, red_max[k]); }
+    const unsigned long long span = (unsigned long long)(hi - lo) + 1ull;
+    auto bin_of = [&](unsigned int d) -> int {
+        return (int)(((unsigned long long)(d - lo) * (unsigned long long)kSplitBins) / span);
+    };
+    for (int i = tid; i < n; i += kSplitThreads) atomicAdd(&excl[bin_of((unsigned int)(in[s + i] >> 32))], 1);
+    __syncthreads();
+    // exclusive scan of the 2048 bin counts: 4 per thread
+    int v[4], mine = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { v[k] = excl[4 * tid + k]; mine += v[k]; }
+    int inc = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += o;
+    }
+    if (lane == 63) wsum[w] = inc;
+    __syncthreads();
+    int run = inc - mine;
+    for (int k = 0; k < w; ++k) run += wsum[k];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { excl[4 * tid + k] = run; run += v[k]; }
+    __syncthreads();
+    // bin b opens the slabs in (slab of the bin in front of it, slab(b)]: their first word is the bin's first word
+    for (int b = tid; b < kSplitBins; b += kSplitThreads) {
+        const int sl = min(excl[b] / kSplitTarget, S - 1);
+        const int before = (b == 0) ? -1 : min(excl[b - 1] / kSplitTarget, S - 1);
+        for (int k = before + 1; k <= sl; ++k) cursor[k] = s + excl[b];
+    }
+    __syncthreads();
+    for (int k = tid; k < S; k += kSplitThreads) sub_offsets[sb + k] = cursor[k];
+    __syncthreads();
+    for (int i = tid; i < n; i += kSplitThreads) {
+        const uint64_t word = in[s + i];
+        const int sl = min(excl[bin_of((unsigned int)(word >> 32))] / kSplitTarget, S - 1);
+        const int pos = atomicAdd(&cursor[sl], 1);
+        out[pos] = word;
+    }
+}
+
+int launch_tile_sort_tiers(int T, int n_tiles, int tile_bits, const int32_t *isect_offsets, uint64_t *buckets,
+                           int32_t *payload_sorted, int64_t *isect_ids_sorted, hipStream_t s);
+
+// buckets -> (split by depth where large) buckets2 -> sorted payload.  scratch: [sub_base i32: T + 1][sub_offsets i32: max_sub + 1]
+int launch_split_sort(int T, int n_tiles, int tile_bits, const int32_t *isect_offsets, int64_t n_live,
+                      const uint64_t *buckets, uint64_t *buckets2, int32_t *scratch, int32_t *payload_sorted,
+                      hipStream_t s) {
+    const int max_sub = (int)(T + n_live / kSplitTarget + 1);
+    int32_t *sub_base = scratch, *sub_offsets = scratch + (T + 1);
+    hipLaunchKernelGGL(split_base_kernel, dim3(1), dim3(1024), 0, s, T, isect_offsets, sub_base);
+    hipLaunchKernelGGL(split_slabs_kernel, dim3(T), dim3(kSplitThreads), 0, s, T, isect_offsets, sub_base, buckets,
+                       buckets2, sub_offsets, max_sub);
+    int rc = check_launch();
+    if (rc != FSGS_OK) return rc;
+    return launch_tile_sort_tiers(max_sub, n_tiles, tile_bits, sub_offsets, buckets2, payload_sorted, nullptr, s);
+}
+
+int64_t split_scratch_ints(int T, int64_t n_live) { return (int64_t)(T + 1) + (T + n_live / kSplitTarget + 1) + 1; }
+
 int launch_tile_sort_tiers(int T, int n_tiles, int tile_bits, const int32_t *isect_offsets, uint64_t *buckets,
                            int32_t *payload_sorted, int64_t *isect_ids_sorted, hipStream_t s) {
     static bool attr_set = false;

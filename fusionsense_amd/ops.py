@@ -315,6 +315,8 @@ def tile_sort(ids: Tensor, pay: Tensor, n_cameras: int, tile_width: int, tile_he
 
 
 USE_BIN_LIVE = os.environ.get("FSGS_BIN_LIVE", "1") != "0"
+# depth-slab split of large buckets: "auto" = where the mean bucket exceeds the LDS tiers, "always", "never"
+BIN_SPLIT = os.environ.get("FSGS_BIN_SPLIT", "auto")
 
 
 def _pinned_i32(dev) -> Tensor:
@@ -366,14 +368,26 @@ def bin_live_finish(st: dict, means2d: Tensor, radii: Tensor, depths: Tensor, co
     T = st["T"]
     st["event"].synchronize()
     M = int(st["pinned"][0])
-    _DENSE_HINT[(str(dev), N, T)] = not use_tile_sort(M, T)
-    if not use_tile_sort(M, T):
+    dense = not use_tile_sort(M, T)  # mean bucket beyond the LDS tiers
+    split = BIN_SPLIT == "always" or (BIN_SPLIT == "auto" and dense)
+    _DENSE_HINT[(str(dev), N, T)] = dense and not split
+    if dense and not split:
         WORKSPACE.give(st["table"])
         st2 = isect_count_live_async(means2d, radii, conics, opacities, tile_width, tile_height)
         return isect_finish_live(st2, means2d, radii, depths, conics, opacities, tile_width, tile_height,
                                  want_ids=False)
     pay_s = torch.empty(M, dtype=torch.int32, device=dev)
-    if M > 0:
+    if M > 0 and split:
+        # large buckets are split into depth slabs before the LDS sorts (no radix sort, no emission-order lists)
+        sbytes = lib.fsgs_bin_live_split_scratch_bytes(Cn, tile_width, tile_height, M)
+        arena = WORKSPACE.take(16 * M + sbytes + 512, dev)
+        b2 = (8 * M + 255) // 256 * 256
+        _run(lib.fsgs_bin_live_emit_split, (Cn, N, ptr(means2d), ptr(radii), ptr(depths), ptr(conics), ptr(opacities),
+                                           tile_width, tile_height, ptr(st["offsets"]), ptr(st["table"]), M,
+                                           arena.data_ptr(), arena.data_ptr() + b2, arena.data_ptr() + 2 * b2, sbytes,
+                                           ptr(pay_s), stream_ptr(dev)), "fsgs_tile_sort")
+        WORKSPACE.give(arena)
+    elif M > 0:
         buckets = WORKSPACE.take(8 * M, dev)
         _run(lib.fsgs_bin_live_emit, (Cn, N, ptr(means2d), ptr(radii), ptr(depths), ptr(conics), ptr(opacities),
                                      tile_width, tile_height, ptr(st["offsets"]), ptr(st["table"]), M, ptr(buckets),

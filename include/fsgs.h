@@ -291,6 +291,17 @@ int fsgs_bin_live_emit(int C, int N, const float *means2d, const int32_t *radii,
                        const int32_t *isect_offsets, const void *table_scratch, int64_t n_live, void *buckets,
                        int32_t *payload_sorted, fsgs_stream_t stream);
 
+/* fsgs_bin_live_emit for buckets of any size: tiles with more than 1024 live pairs are first split into depth
+ * slabs of ~512 (monotone in depth, so sorted slabs in order = a sorted tile), every slab sorted like a small
+ * tile.  Same outputs, bit for bit; one more pass over the 64-bit words instead of the six radix passes that
+ * scenes with thousands of pairs per tile otherwise need.  buckets, buckets2: n_live words each. */
+size_t fsgs_bin_live_split_scratch_bytes(int C, int tile_width, int tile_height, int64_t n_live);
+int fsgs_bin_live_emit_split(int C, int N, const float *means2d, const int32_t *radii, const float *depths,
+                             const float *conics, const float *opacities, int tile_width, int tile_height,
+                             const int32_t *isect_offsets, const void *table_scratch, int64_t n_live, void *buckets,
+                             void *buckets2, void *split_scratch, size_t split_bytes, int32_t *payload_sorted,
+                             fsgs_stream_t stream);
+
 /* Split packed gradient records into the five gsplat-shaped arrays (written, not accumulated).
  * rezero != 0: v_packed is cleared after it has been read, ready for the next frame's atomics. */
 int fsgs_raster_unpack_grads(int64_t total, int D, float *v_packed, int rezero, float *v_means2d,

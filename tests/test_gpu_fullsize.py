@@ -71,6 +71,13 @@ def test_full_size_binning_sorted_and_consistent(dev, full_scene):
     assert d_ids is None
     assert torch.equal(d_tpg, tpg) and torch.equal(d_pay, pay) and torch.equal(d_offs, offs)
     assert torch.equal(info.payload, pay), "the fused node's own lists are the direct path's"
+    ops.BIN_SPLIT = "always"  # and with the tiles over 1024 pairs split into depth slabs first
+    try:
+        st = ops.bin_live_count_async(info.means2d, info.radii, info.conics, opac, tw, th)
+        _, _, s_pay, s_offs = ops.bin_live_finish(st, info.means2d, info.radii, info.depths, info.conics, opac, tw, th)
+    finally:
+        ops.BIN_SPLIT = "auto"
+    assert torch.equal(s_pay, pay) and torch.equal(s_offs, offs)
 
 
 def test_full_size_forward_deterministic_and_in_range(dev, full_scene):

@@ -573,7 +573,8 @@ def test_tile_sort_bit_exact(dev, case):
     assert torch.equal(offs, r_off)
 
 
-@pytest.mark.parametrize("case", ["one_camera", "two_cameras", "ties", "one_hot_tile", "tiny_image", "nothing_visible", "empty"])
+@pytest.mark.parametrize("case", ["one_camera", "two_cameras", "ties", "one_hot_tile", "one_depth_hot_tile", "tiny_image",
+                                  "nothing_visible", "empty"])
 def test_direct_binning_equals_list_chain(dev, case):
     """fsgs_bin_live_count + fsgs_bin_live_emit (pairs counted per tile and dropped straight into their
     tile's bucket) against fsgs_isect_count_live + emit_live + tile_sort on the same projected Gaussians:
@@ -594,20 +595,27 @@ def test_direct_binning_equals_list_chain(dev, case):
     depths = torch.rand(Cn, N, generator=g) * 5 + 0.2
     if case == "ties":
         depths = torch.round(depths * 2) / 2
-    if case == "one_hot_tile":
+    if case in ("one_hot_tile", "one_depth_hot_tile"):
         means2d[:, :5000] = torch.tensor([40.0, 40.0]) + torch.rand(Cn, 5000, 2, generator=g) * 4
         radii[:, :5000] = 6
+    if case == "one_depth_hot_tile":  # a single depth value: the slab split cannot separate anything
+        depths[:, :5000] = 1.25
     # conics of isotropic Gaussians whose 3-sigma radius is the bbox radius, some much tighter (culled pairs)
     sig = (radii.float().clamp(min=1) / 3) * (0.2 + 0.8 * torch.rand(Cn, N, generator=g))
     conics = torch.stack([1 / sig**2, 0.3 * torch.rand(Cn, N, generator=g) / sig**2, 1 / sig**2], -1)
     opac = torch.rand(Cn, N, generator=g)
     a = [t.to(dev).contiguous() for t in (means2d, radii, depths, conics, opac)]
     tpg, ids, pay, offs = ops.bin_and_sort_live(a[0], a[1], a[2], a[3], a[4], tw, th)
-    st = ops.bin_live_count_async(a[0], a[1], a[3], a[4], tw, th)
-    d_tpg, _, d_pay, d_offs = ops.bin_live_finish(st, a[0], a[1], a[2], a[3], a[4], tw, th)
-    assert torch.equal(d_tpg, tpg)
-    assert torch.equal(d_offs, offs)
-    assert torch.equal(d_pay, pay)
+    for split in ("never", "always"):  # "always": buckets over 1024 pairs go through the depth-slab split
+        ops.BIN_SPLIT = split
+        try:
+            st = ops.bin_live_count_async(a[0], a[1], a[3], a[4], tw, th)
+            d_tpg, _, d_pay, d_offs = ops.bin_live_finish(st, a[0], a[1], a[2], a[3], a[4], tw, th)
+        finally:
+            ops.BIN_SPLIT = "auto"
+        assert torch.equal(d_tpg, tpg)
+        assert torch.equal(d_offs, offs)
+        assert torch.equal(d_pay, pay), split
     if case not in ("nothing_visible", "empty"):
         assert pay.numel() > 0
 
