@@ -346,7 +346,7 @@ struct BinLds {
     int wave_sum[kBinWaves];
 };
 
-template <bool SCATTER>
+template <bool SCATTER, bool MULTI>
 __global__ void __launch_bounds__(kBinThreads)
 isect_live_bin_kernel(int C, int N, const float *__restrict__ means2d, const int32_t *__restrict__ radii,
                       const float *__restrict__ depths, const float *__restrict__ conics,
@@ -358,13 +358,12 @@ isect_live_bin_kernel(int C, int N, const float *__restrict__ means2d, const int
     int *slots = reinterpret_cast<int *>(bin_smem + sizeof(BinLds));
     const int64_t total = (int64_t)C * N;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    for (int t = tid; t < T; t += kBinThreads)
-        slots[t] = SCATTER ? offsets[t] + table[(int64_t)blockIdx.x * T + t] : 0;
     // `chunks` groups of 1024 Gaussians per workgroup, one after the other into the same tile slots: the table has
     // one row per WORKGROUP, so large N is given more chunks instead of more rows (N / 1024 rows of T counters
     // each would be 234 MB at 6 M Gaussians x 10 000 tiles)
-    for (int ch = 0; ch < chunks; ++ch) {
-    const int64_t idx0 = ((int64_t)blockIdx.x * chunks + ch) * kBinThreads;  // the chunk's first Gaussian
+    const int n_chunks = MULTI ? chunks : 1;  // (MULTI = false: the single-chunk code without the loop, 4 us faster)
+    for (int ch = 0; ch < n_chunks; ++ch) {
+    const int64_t idx0 = ((int64_t)blockIdx.x * n_chunks + ch) * kBinThreads;  // the chunk's first Gaussian
     const int64_t idx = idx0 + tid;
     if (idx0 >= total) break;
     if (ch) __syncthreads();  // the previous chunk's constants are no longer read
@@ -391,6 +390,10 @@ isect_live_bin_kernel(int C, int N, const float *__restrict__ means2d, const int
         L.b[tid] = make_float4(cp.ha, cp.hc, cp.inv_a, cp.inv_c);
         L.rect[tid] = make_int4(t.x0, t.y0, t.x1 - t.x0, cnt);
         L.depth[tid] = db;
+    }
+    if (ch == 0) {  // (after the chunk's own loads were issued: the slot rows come from memory in the fill pass)
+        for (int t = tid; t < T; t += kBinThreads)
+            slots[t] = SCATTER ? offsets[t] + table[(int64_t)blockIdx.x * T + t] : 0;
     }
     int inc = cnt;
 #pragma unroll
@@ -636,11 +639,13 @@ static int bin_set_lds(int T) {
     static size_t have[2] = {0, 0};
     const size_t need = bin_lds_bytes(T);
     if (need > have[0]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&isect_live_bin_kernel<false>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)need);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void *>(&isect_live_bin_kernel<true>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)need);
+        const void *kernels[4] = {reinterpret_cast<const void *>(&isect_live_bin_kernel<false, false>),
+                                  reinterpret_cast<const void *>(&isect_live_bin_kernel<false, true>),
+                                  reinterpret_cast<const void *>(&isect_live_bin_kernel<true, false>),
+                                  reinterpret_cast<const void *>(&isect_live_bin_kernel<true, true>)};
+        hipError_t e = hipSuccess;
+        for (int k = 0; k < 4 && e == hipSuccess; ++k)
+            e = hipFuncSetAttribute(kernels[k], hipFuncAttributeMaxDynamicSharedMemorySize, (int)need);
         if (e != hipSuccess) { g_last_hip_error = (int)e; return FSGS_ELAUNCH; }
         have[0] = need;
     }
@@ -671,9 +676,12 @@ extern "C" int fsgs_bin_live_count(int C, int N, const float *means2d, const int
     int32_t *totals = table + (size_t)T * nb;
     int rc = bin_set_lds(T);
     if (rc != FSGS_OK) return rc;
-    hipLaunchKernelGGL((isect_live_bin_kernel<false>), dim3(nb), dim3(kBinThreads), bin_lds_bytes(T), s, C, N, means2d,
-                       radii, nullptr, conics, opacities, tile_width, tile_height, T, nb, bin_chunks(total), tiles_per_gauss,
-                       table, nullptr, nullptr);
+#define FSGS_BIN_COUNT(MU)                                                                                          \
+    hipLaunchKernelGGL((isect_live_bin_kernel<false, MU>), dim3(nb), dim3(kBinThreads), bin_lds_bytes(T), s, C, N,    \
+                       means2d, radii, nullptr, conics, opacities, tile_width, tile_height, T, nb, bin_chunks(total),  \
+                       tiles_per_gauss, table, nullptr, nullptr)
+    if (bin_chunks(total) > 1) FSGS_BIN_COUNT(true); else FSGS_BIN_COUNT(false);
+#undef FSGS_BIN_COUNT
     rc = check_launch();
     if (rc != FSGS_OK) return rc;
     return launch_tile_scan_rows_offsets(T, nb, table, totals, isect_offsets, s);
@@ -731,9 +739,12 @@ static int bin_live_emit_impl(int C, int N, const float *means2d, const int32_t 
     int32_t *table = const_cast<int32_t *>(reinterpret_cast<const int32_t *>(table_scratch));
     int rc = bin_set_lds(T);
     if (rc != FSGS_OK) return rc;
-    hipLaunchKernelGGL((isect_live_bin_kernel<true>), dim3(nb), dim3(kBinThreads), bin_lds_bytes(T), s, C, N, means2d,
-                       radii, depths, conics, opacities, tile_width, tile_height, T, nb, bin_chunks((int64_t)C * N), nullptr, table,
-                       isect_offsets, reinterpret_cast<uint64_t *>(buckets));
+#define FSGS_BIN_FILL(MU)                                                                                           \
+    hipLaunchKernelGGL((isect_live_bin_kernel<true, MU>), dim3(nb), dim3(kBinThreads), bin_lds_bytes(T), s, C, N,     \
+                       means2d, radii, depths, conics, opacities, tile_width, tile_height, T, nb,                      \
+                       bin_chunks((int64_t)C * N), nullptr, table, isect_offsets, reinterpret_cast<uint64_t *>(buckets))
+    if (bin_chunks((int64_t)C * N) > 1) FSGS_BIN_FILL(true); else FSGS_BIN_FILL(false);
+#undef FSGS_BIN_FILL
     rc = check_launch();
     if (rc != FSGS_OK) return rc;
     int tb = 0;
