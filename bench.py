@@ -213,6 +213,7 @@ def main():
     for s in range(args.steps):
         v = view_of(args.warmup + s)
         trainer.train_step(cams[v], targets[v])
+    trainer.flush()  # (data-parallel runs: the last step's deferred feature update belongs to the timed work)
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0

@@ -295,7 +295,7 @@ sh_bwd_kernel(int C, int N, int K, int degree, const float *__restrict__ means,
               const float *__restrict__ coeffs_rest, const int32_t *__restrict__ radii, int D,
               const float *__restrict__ v_colors, float *__restrict__ v_coeffs,
               float *__restrict__ v_coeffs_rest, float *__restrict__ v_means,
-              float *__restrict__ v_depths, int overwrite_means) {
+              float *__restrict__ v_depths, int overwrite_means, float4 *__restrict__ v_rgb_masked) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int n0 = blockIdx.x * kShBlock;
     const int rows = min(kShBlock, N - n0);
@@ -367,7 +367,14 @@ sh_bwd_kernel(int C, int N, int K, int degree, const float *__restrict__ means,
         v_means[n * 3 + 0] = o0 + g0;
         v_means[n * 3 + 1] = o1 + g1;
         v_means[n * 3 + 2] = o2 + g2;
+        // data-parallel runs exchange this instead of the 48 coefficient gradients it determines
+        // (basis(dir) x colour gradient, fsgs_sh_coeff_grad): 16 B instead of 192 B per Gaussian
+        if (v_rgb_masked) {
+            v_rgb_masked[n] = make_float4(vr, vg, vb, 0.f);
+            if (n == 0) v_rgb_masked[N] = make_float4(campos[0], campos[1], campos[2], 0.f);  // row N: the camera centre
+        }
       }
+      if (v_rgb_masked) return;  // (no coefficient gradient is written)
     } else if (n < N) {
         const float mx = means[n * 3 + 0], myy = means[n * 3 + 1], mz = means[n * 3 + 2];
         float acc[kMaxK * 3];
@@ -437,6 +444,63 @@ sh_bwd_kernel(int C, int N, int K, int degree, const float *__restrict__ means,
         return;
     }
     unstage_rows<KT * 3>(v_coeffs + (int64_t)n0 * row_floats, rows, row_floats, lds, pitch, 0);
+}
+
+// Coefficient gradients from their factors, for R views at once (data-parallel training: every rank all-gathers
+// the ranks' masked colour gradients [N,4] + camera centre, 16 B per Gaussian and rank, instead of all-reducing the
+// 192 B per Gaussian they determine):  v_coeffs[n,k,:] = scale * sum_r basis_k(dir_r(n)) * v_rgb_r[n,:].
+// `gathered` = R blocks of (N + 1) float4: rows 0..N-1 = (v_r, v_g, v_b, -), row N = the rank's camera centre.
+// The sum runs over r = 0..R-1 in this order on every rank: all replicas get bit-identical gradients.
+template <int KT>
+__global__ void __launch_bounds__(kShBlock)
+sh_coeff_grad_kernel(int R, int N, int K, int degree, const float *__restrict__ means,
+                     const float4 *__restrict__ gathered, float scale, float *__restrict__ v_dc,
+                     float *__restrict__ v_rest) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int n0 = blockIdx.x * kShBlock;
+    const int rows = min(kShBlock, N - n0);
+    const int kk = (degree + 1) * (degree + 1);
+    if (KT) K = KT;
+    const int row_floats = K * 3, pitch = row_floats + 1;
+    const int n = n0 + threadIdx.x;
+    if (n < N) {
+        const float mx = means[n * 3 + 0], myy = means[n * 3 + 1], mz = means[n * 3 + 2];
+        float acc[kMaxK * 3];
+#pragma unroll
+        for (int k = 0; k < kMaxK * 3; ++k) acc[k] = 0.f;
+        for (int r = 0; r < R; ++r) {
+            const float4 *blk = gathered + (int64_t)r * (N + 1);
+            const float4 v = blk[n];
+            if (v.x == 0.f && v.y == 0.f && v.z == 0.f) continue;  // invisible / clamped / no gradient in this view
+            const float4 cp = blk[N];
+            float dx = mx - cp.x, dy = myy - cp.y, dz = mz - cp.z;
+            const float inorm = 1.f / fmaxf(sqrtf(dx * dx + dy * dy + dz * dz), 1e-12f);
+            dx *= inorm; dy *= inorm; dz *= inorm;
+            float b[kMaxK];
+            sh_basis<false>(degree, dx, dy, dz, b, nullptr, nullptr, nullptr);
+#pragma unroll
+            for (int k = 0; k < kMaxK; ++k) {
+                if (k < kk) {
+                    acc[k * 3 + 0] += b[k] * v.x;
+                    acc[k * 3 + 1] += b[k] * v.y;
+                    acc[k * 3 + 2] += b[k] * v.z;
+                }
+            }
+        }
+        float *my = lds + threadIdx.x * pitch;
+#pragma unroll
+        for (int k = 0; k < kMaxK; ++k) {
+            if (k < K) {
+                my[k * 3 + 0] = (k < kk) ? acc[k * 3 + 0] * scale : 0.f;
+                my[k * 3 + 1] = (k < kk) ? acc[k * 3 + 1] * scale : 0.f;
+                my[k * 3 + 2] = (k < kk) ? acc[k * 3 + 2] * scale : 0.f;
+            }
+        }
+    }
+    __syncthreads();
+    unstage_rows<3>(v_dc + (int64_t)n0 * 3, rows, 3, lds, pitch, 0);
+    if (K > 1)
+        unstage_rows<KT ? KT * 3 - 3 : 0>(v_rest + (int64_t)n0 * (row_floats - 3), rows, row_floats - 3, lds, pitch, 3);
 }
 
 // Camera centres from world-to-camera matrices: campos = -A^-1 t for [A t; 0 1] (what
@@ -511,18 +575,20 @@ extern "C" int fsgs_sh_fwd_split(int C, int N, int K, int degree, const float *m
 static int sh_bwd_impl(int C, int N, int K, int degree, const float *means, const float *campos,
                        const float *coeffs, const float *coeffs_rest, const int32_t *radii, int D,
                        const float *v_colors, float *v_coeffs, float *v_coeffs_rest, float *v_means,
-                       float *v_depths, int overwrite_means, fsgs_stream_t stream) {
+                       float *v_depths, int overwrite_means, fsgs_stream_t stream, float *v_rgb_masked = nullptr) {
     // D = floats per v_colors row (the colour gradient is its first three): 3, 4 (v_depths = column 3), or a
     // wider stride such as the rasterizer's packed 16-float gradient records
     if (C < 0 || N < 0 || degree < 0 || degree > 4 || K < (degree + 1) * (degree + 1) || K > kMaxK || D < 3)
         return FSGS_EINVAL;
     if (N == 0) return FSGS_OK;
-    if (!means || !campos || !coeffs || !radii || !v_colors || !v_coeffs || !v_means) return FSGS_EINVAL;
+    if (!means || !campos || !coeffs || !radii || !v_colors || (!v_coeffs && !v_rgb_masked) || !v_means) return FSGS_EINVAL;
+    if (v_rgb_masked && C != 1) return FSGS_EINVAL;
     const size_t lds_bytes = (size_t)kShBlock * (K * 3 + 1) * sizeof(float);
 #define FSGS_SH_BWD(SC, KT, SP)                                                                           \
     hipLaunchKernelGGL((sh_bwd_kernel<SC, KT, SP>), dim3(ceil_div(N, kShBlock)), dim3(kShBlock), lds_bytes,  \
                        as_stream(stream), C, N, K, degree, means, campos, coeffs, coeffs_rest, radii, D,      \
-                       v_colors, v_coeffs, v_coeffs_rest, v_means, v_depths, overwrite_means)
+                       v_colors, v_coeffs, v_coeffs_rest, v_means, v_depths, overwrite_means,                 \
+                       reinterpret_cast<float4 *>(v_rgb_masked))
 #define FSGS_SH_BWD_K(SC, SP) do { if (K == 16) FSGS_SH_BWD(SC, 16, SP); else FSGS_SH_BWD(SC, 0, SP); } while (0)
     if (C == 1) {
         if (coeffs_rest) FSGS_SH_BWD_K(true, true); else FSGS_SH_BWD_K(true, false);
@@ -550,4 +616,33 @@ extern "C" int fsgs_sh_bwd_split(int C, int N, int K, int degree, const float *m
     return sh_bwd_impl(C, N, K, degree, means, campos, features_dc, features_rest ? features_rest : features_dc,
                        radii, D, v_colors, v_features_dc, v_features_rest ? v_features_rest : v_features_dc,
                        v_means, v_depths, overwrite_means, stream);
+}
+
+// fsgs_sh_bwd_split for one camera that leaves the coefficient gradients to fsgs_sh_coeff_grad: writes v_means (as
+// fsgs_sh_bwd_split) and v_rgb_masked [N + 1,4]: rows 0..N-1 = the colour gradient where the colour clamp is inactive and the Gaussian
+// visible, else 0.
+extern "C" int fsgs_sh_bwd_colors(int N, int K, int degree, const float *means, const float *campos,
+                                  const float *features_dc, const float *features_rest, const int32_t *radii, int D,
+                                  const float *v_colors, float *v_rgb_masked, float *v_means, int overwrite_means,
+                                  fsgs_stream_t stream) {
+    if (N == 0) return FSGS_OK;
+    if ((!features_rest && K > 1) || !v_rgb_masked) return FSGS_EINVAL;
+    return sh_bwd_impl(1, N, K, degree, means, campos, features_dc, features_rest ? features_rest : features_dc,
+                       radii, D, v_colors, nullptr, nullptr, v_means, nullptr, overwrite_means, stream, v_rgb_masked);
+}
+
+extern "C" int fsgs_sh_coeff_grad(int R, int N, int K, int degree, const float *means, const float *gathered,
+                                  float scale, float *v_features_dc, float *v_features_rest, fsgs_stream_t stream) {
+    if (R < 1 || N < 0 || degree < 0 || degree > 4 || K < (degree + 1) * (degree + 1) || K > kMaxK) return FSGS_EINVAL;
+    if (N == 0) return FSGS_OK;
+    if (!means || !gathered || !v_features_dc || (K > 1 && !v_features_rest)) return FSGS_EINVAL;
+    const size_t lds_bytes = (size_t)kShBlock * (K * 3 + 1) * sizeof(float);
+    const float4 *g4 = reinterpret_cast<const float4 *>(gathered);
+    if (K == 16)
+        hipLaunchKernelGGL((sh_coeff_grad_kernel<16>), dim3(ceil_div(N, kShBlock)), dim3(kShBlock), lds_bytes,
+                           as_stream(stream), R, N, K, degree, means, g4, scale, v_features_dc, v_features_rest);
+    else
+        hipLaunchKernelGGL((sh_coeff_grad_kernel<0>), dim3(ceil_div(N, kShBlock)), dim3(kShBlock), lds_bytes,
+                           as_stream(stream), R, N, K, degree, means, g4, scale, v_features_dc, v_features_rest);
+    return check_launch();
 }

@@ -49,6 +49,11 @@ class FrameInfo:
         self.stats_done = False
         self.frozen: Optional[Tensor] = None           # [N] uint8: touch anchors (dn_model.py:535-541)
         self.binary_threshold: Optional[float] = None  # perform the binary-opacity write (dn_model.py:492-503)
+        # called right before the SH colours are evaluated (the trainer's deferred feature update, data-parallel runs)
+        self.pre_sh = None
+        # [N + 1,4] buffer: the backward writes the factors of the SH coefficient gradients there INSTEAD of the
+        # gradients themselves (trainer's factored exchange, data-parallel runs)
+        self.sh_factors_out: Optional[Tensor] = None
 
     @property
     def flatten_ids(self):
@@ -131,24 +136,35 @@ class _FusedGetOutputs(torch.autograd.Function):
             count = ops.bin_live_count_async(means2d, radii, conics, opac_row, tw, th)
         else:
             count = ops.isect_count_live_async(means2d, radii, conics, opac_row, tw, th)
-        # work that does not need the lists runs while the host waits for the live total
         colors = torch.empty(1, N, 4, **f32)
-        _run(lib.fsgs_sh_fwd_split, (1, N, K, sh_degree, ptr(means), ptr(cam["campos"]), ptr(features_dc),
-                                     ptr(features_rest), ptr(radii), ptr(depths), ptr(colors), sp),
-             "fsgs_sh_fwd_split")
         normals_world = torch.empty(N, 3, **f32)
         packed = torch.empty(N, 16, **f32)
         n_cells = lib.fsgs_raster_quad_max_cells()
         max_last = torch.empty(n_cells, **f32)  # partial image maxima: zeroed by the pack kernel, raised by the forward
-        _run(lib.fsgs_live_pack_normals, (N, ptr(means2d), ptr(conics), ptr(colors), ptr(opac_sig), ptr(quats),
-                                         ptr(scales), ptr(means), ptr(cam["c2w"]), ptr(packed), ptr(normals_world),
-                                         ptr(max_last), n_cells, sp), "fsgs_live_pack_normals", "_d4e3")
+
+        def colours_and_packing():
+            _run(lib.fsgs_sh_fwd_split, (1, N, K, sh_degree, ptr(means), ptr(cam["campos"]), ptr(features_dc),
+                                         ptr(features_rest), ptr(radii), ptr(depths), ptr(colors), sp),
+                 "fsgs_sh_fwd_split")
+            _run(lib.fsgs_live_pack_normals, (N, ptr(means2d), ptr(conics), ptr(colors), ptr(opac_sig), ptr(quats),
+                                             ptr(scales), ptr(means), ptr(cam["c2w"]), ptr(packed),
+                                             ptr(normals_world), ptr(max_last), n_cells, sp),
+                 "fsgs_live_pack_normals", "_d4e3")
+
+        # Work that does not need the lists runs while the host waits for the live total — unless the SH features
+        # are still being exchanged between the ranks (info.pre_sh: the trainer's deferred feature update): then
+        # the colours come last, so that the exchange overlaps the whole binning + sort chain.
+        if info.pre_sh is None:
+            colours_and_packing()
         if direct_bins:
             tpg, isect_ids, flatten_ids, offsets = ops.bin_live_finish(count, means2d, radii, depths, conics, opac_row,
                                                                        tw, th)
         else:
             tpg, isect_ids, flatten_ids, offsets = ops.isect_finish_live(count, means2d, radii, depths, conics,
                                                                          opac_row, tw, th, want_ids=False)
+        if info.pre_sh is not None:
+            info.pre_sh()
+            colours_and_packing()
         rule_diff = 0
         M = flatten_ids.numel()
 
@@ -238,9 +254,19 @@ class _FusedGetOutputs(torch.autograd.Function):
         g_dc, g_rest = out("features_dc", features_dc), out("features_rest", features_rest)
         g_opac = out("opacities", opac_sig.view(N, 1))
         # SH: colour gradients are the first floats of the packed records; writes the view-direction share of v_means
-        _run(lib.fsgs_sh_bwd_split, (1, N, K, sh_degree, ptr(means), ptr(cam["campos"]), ptr(features_dc),
-                                     ptr(features_rest), ptr(radii), 16, ptr(v_packed), ptr(g_dc), ptr(g_rest),
-                                     ptr(g_means), None, 1, sp), "fsgs_sh_bwd_split")
+        factors = ctx.info.sh_factors_out
+        if factors is not None:
+            # data-parallel step: only the FACTORS of the coefficient gradients are produced here ([N + 1,4]: masked
+            # colour gradients + the camera centre); the trainer all-gathers them and fsgs_sh_coeff_grad rebuilds the
+            # mean of the ranks' coefficient gradients in the slab (16 B instead of 192 B per Gaussian on the links)
+            assert tuple(factors.shape) == (N + 1, 4) and factors.is_contiguous()
+            _run(lib.fsgs_sh_bwd_colors, (N, K, sh_degree, ptr(means), ptr(cam["campos"]), ptr(features_dc),
+                                          ptr(features_rest), ptr(radii), 16, ptr(v_packed), ptr(factors),
+                                          ptr(g_means), 1, sp), "fsgs_sh_bwd_split")
+        else:
+            _run(lib.fsgs_sh_bwd_split, (1, N, K, sh_degree, ptr(means), ptr(cam["campos"]), ptr(features_dc),
+                                         ptr(features_rest), ptr(radii), 16, ptr(v_packed), ptr(g_dc), ptr(g_rest),
+                                         ptr(g_means), None, 1, sp), "fsgs_sh_bwd_split")
         # everything else per Gaussian in one launch (projection / normal / activation VJPs, absgrad, statistics)
         v_abs = torch.empty(1, N, 2, **f32)
         stats = ctx.info.stats_out
@@ -328,7 +354,7 @@ def fused_step_forward_backward(gauss_params: Dict[str, Tensor], camera: Camera,
                                 sh_degree: int, device, grad_out: Dict[str, Tensor], seed_grad: Tensor,
                                 stats_out: Optional[dict] = None, add_mask: Optional[Tensor] = None,
                                 binary_threshold: Optional[float] = None, ssim_lambda: float = 0.2,
-                                w_depth: float = 0.2, w_normal: float = 0.1):
+                                w_depth: float = 0.2, w_normal: float = 0.1, pre_sh=None, sh_factors_out=None):
     """get_outputs -> config-#2 loss -> both backward passes, without the autograd tape.  The parameter
     gradients land in ``grad_out`` (the trainer's slab views).  Returns (loss 0-d tensor, outputs dict)."""
     dev = device
@@ -339,6 +365,8 @@ def fused_step_forward_backward(gauss_params: Dict[str, Tensor], camera: Camera,
     info = FrameInfo()
     info.stats_out = stats_out
     info.binary_threshold = binary_threshold
+    info.pre_sh = pre_sh
+    info.sh_factors_out = sh_factors_out
     if add_mask is not None:
         info.frozen = add_mask.to(device=dev, dtype=torch.uint8).contiguous()
     has_n = "normal" in target

@@ -235,6 +235,8 @@ _CKPT_PREFIX = "_model.gauss_params."
 def save_checkpoint(trainer, path: str) -> None:
     """nerfstudio's ``step-XXXXXXXXX.ckpt`` dictionary for the Gaussian model state: the parameters under
     ``pipeline`` as ``_model.gauss_params.<name>`` and one optimizer state dict per parameter group."""
+    if hasattr(trainer, "flush"):
+        trainer.flush()  # a deferred feature update (data-parallel runs) must be in the parameters
     pipeline = {_CKPT_PREFIX + k: v.detach().cpu() for k, v in trainer.params.items()}
     optimizers = {k: opt.state_dict() for k, opt in trainer.optimizers.items()}
     torch.save({"step": int(trainer.step), "pipeline": pipeline, "optimizers": optimizers,
@@ -244,6 +246,8 @@ def save_checkpoint(trainer, path: str) -> None:
 def load_checkpoint(trainer, path: str) -> int:
     """Inverse of ``save_checkpoint``; like ``SplatfactoModel.load_state_dict`` it first resizes every
     parameter (and with it the gradient slab and the optimizers) to the stored shapes.  Returns the step."""
+    if hasattr(trainer, "flush"):
+        trainer.flush()
     from .trainer import PARAM_ORDER, GradSlab
     ck = torch.load(path, map_location="cpu", weights_only=False)
     dev = trainer.device

@@ -176,6 +176,8 @@ class DensifyStrategy:
         if self.stats_only:
             return
         if trainer.step % self.cfg.refine_every == 0:
+            if hasattr(trainer, "flush"):
+                trainer.flush()  # a deferred feature update must land before rows are split / culled
             self.refinement_after(trainer, trainer.step)
 
     # ---- a-13 ---------------------------------------------------------------------------

@@ -13,6 +13,7 @@ prune then runs redundantly with a shared RNG seed so N stays identical on every
 from __future__ import annotations
 
 import math
+import os
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional
 
@@ -23,6 +24,12 @@ from torch import Tensor
 from .scenes import Camera
 
 PARAM_ORDER = ["means", "scales", "quats", "features_dc", "features_rest", "opacities"]
+# The gradient slab keeps the two SH feature groups (48 of the 59 floats per Gaussian) at its end, so that the
+# geometry half (what projection and binning of the NEXT frame need) and the feature half are one contiguous
+# range each: see SplatTrainer._reduce_and_step.
+GEOMETRY_GROUPS = ["means", "scales", "quats", "opacities"]
+FEATURE_GROUPS = ["features_dc", "features_rest"]
+SLAB_ORDER = GEOMETRY_GROUPS + FEATURE_GROUPS
 
 
 @dataclass
@@ -48,8 +55,11 @@ class GradSlab:
         self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
         off = 0
         self.views = {}
-        for name in PARAM_ORDER:
+        self.split = 0  # first element of the feature half
+        for name in SLAB_ORDER:
             p = params[name]
+            if name == FEATURE_GROUPS[0]:
+                self.split = off
             v = self.flat[off:off + p.numel()].view_as(p)
             self.views[name] = v
             p.grad = v
@@ -58,14 +68,38 @@ class GradSlab:
     def zero_(self) -> None:
         self.flat.zero_()
 
+    @staticmethod
+    def _world(group=None) -> int:
+        return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+
+    def _reduce_mean(self, t: Tensor, group, async_op: bool):
+        """Mean over the ranks, in place.  Returns None (done, in stream order) or a callable that completes it."""
+        if self._world(group) <= 1 or t.numel() == 0:
+            return None
+        if dist.get_backend(group) == "nccl":
+            # RCCL averages inside the collective: no extra 2 x 236 B/Gaussian scaling pass
+            work = dist.all_reduce(t, op=dist.ReduceOp.AVG, group=group, async_op=async_op)
+            return work.wait if async_op else None
+        work = dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+        scale = 1.0 / self._world(group)
+        if not async_op:
+            t.mul_(scale)
+            return None
+
+        def finish():
+            work.wait()
+            t.mul_(scale)
+        return finish
+
     def all_reduce_mean_(self, group=None) -> None:
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-            if dist.get_backend(group) == "nccl":
-                # RCCL averages inside the collective: no extra 2 x 236 B/Gaussian scaling pass
-                dist.all_reduce(self.flat, op=dist.ReduceOp.AVG, group=group)
-            else:
-                dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
-                self.flat.mul_(1.0 / dist.get_world_size(group))
+        self._reduce_mean(self.flat, group, False)
+
+    def all_reduce_geometry_mean_(self, group=None) -> None:
+        self._reduce_mean(self.flat[:self.split], group, False)
+
+    def all_reduce_features_async(self, group=None):
+        """Starts the exchange of the feature half; the returned callable (or None) completes it."""
+        return self._reduce_mean(self.flat[self.split:], group, True)
 
 
 class SplatTrainer:
@@ -95,6 +129,20 @@ class SplatTrainer:
                 [self.params[name]], lr=self.optim_cfg.lr[name], eps=self.optim_cfg.eps,
                 fused=self.fused_adam)
         self.slab = GradSlab(self.params)
+        # Data-parallel runs: the SH features' share of the all-reduce (81 % of the slab) and their Adam launch are
+        # deferred until the next frame needs the colours, i.e. they overlap that frame's projection, binning and
+        # sort, which read geometry only (exact: every parameter still sees its fully reduced gradient before its
+        # next use).  FSGS_DEFER_FEATURES=0 switches it off; FSGS_FORCE_SPLIT_STEP=1 takes the same code path on a
+        # single rank (for the tests).
+        self.defer_features = os.environ.get("FSGS_DEFER_FEATURES", "1") != "0"
+        self.force_split_step = os.environ.get("FSGS_FORCE_SPLIT_STEP", "0") == "1"
+        # ... and what travels for the features is not their gradient (48 floats per Gaussian) but its factors: the
+        # masked colour gradient + the camera centre of every rank's view (4 floats per Gaussian and rank,
+        # all-gathered); fsgs_sh_coeff_grad rebuilds the mean gradient on every rank, in rank order, so the
+        # replicas stay bit-identical.  Fused CUDA path only; FSGS_FACTORED_FEATURES=0 switches it off.
+        self.factored_features = os.environ.get("FSGS_FACTORED_FEATURES", "1") != "0"
+        self._factors = None
+        self._pending = None
         self.step = 0
         self.strategy = strategy  # fusionsense_amd.splatfacto.DensifyStrategy or None
         self.rng = torch.Generator(device=device)
@@ -136,6 +184,7 @@ class SplatTrainer:
         """get_outputs.  In training mode (grad enabled) the strategy supplies what the model state supplies
         in the reference: the binary-opacity schedule (dn_model.py:492-503) and the touch-anchor mask
         (:535-541); ``crop_box`` is honoured only without grad, like ``not self.training`` there (:505-532)."""
+        self.flush()
         deg = self._sh_degree_now(sh_degree_to_use)
         grad = torch.is_grad_enabled()
         stats, add_mask, bthr = self._frame_state(camera, grad)
@@ -164,13 +213,13 @@ class SplatTrainer:
             l = l + 0.1 * torch.abs(out["normal"] - target["normal"]).mean()
         return l
 
-    def _fused_adam_step(self) -> None:
-        """All six groups in one launch (row N1).  The torch optimizers stay the owners of the state
-        (exp_avg / exp_avg_sq per parameter), so densify/prune surgery and checkpoints see the usual
-        layout; only their step() is replaced."""
+    def _fused_adam_step(self, names=None, step_no: Optional[int] = None) -> int:
+        """All six groups in one launch (row N1) — or the given subset, as Adam step ``step_no``.  The torch
+        optimizers stay the owners of the state (exp_avg / exp_avg_sq per parameter), so densify/prune surgery
+        and checkpoints see the usual layout; only their step() is replaced.  Returns the step number used."""
         from .ops import adam_step_
         ps, gs, ms, vs, lrs = [], [], [], [], []
-        for name in PARAM_ORDER:
+        for name in (names or PARAM_ORDER):
             p = self.params[name]
             opt = self.optimizers[name]
             st = opt.state[p]
@@ -181,8 +230,93 @@ class SplatTrainer:
             st["step"] += 1
             ps.append(p.data); gs.append(self.slab.views[name]); ms.append(st["exp_avg"]); vs.append(st["exp_avg_sq"])
             lrs.append(opt.param_groups[0]["lr"])
-        self.adam_steps = getattr(self, "adam_steps", 0) + 1
-        adam_step_(ps, gs, ms, vs, lrs, self.adam_steps, 0.9, 0.999, self.optim_cfg.eps)
+        if step_no is None:
+            self.adam_steps = getattr(self, "adam_steps", 0) + 1
+            step_no = self.adam_steps
+        adam_step_(ps, gs, ms, vs, lrs, step_no, 0.9, 0.999, self.optim_cfg.eps)
+        return step_no
+
+    def _optimizer_step(self, names, step_no: Optional[int] = None) -> Optional[int]:
+        if self.fused and self.device.type == "cuda":
+            return self._fused_adam_step(names, step_no)
+        for name in names:
+            self.optimizers[name].step()
+        return None
+
+    def _split_step(self, optimizer_step: bool) -> bool:
+        return optimizer_step and self.defer_features and (GradSlab._world() > 1 or self.force_split_step)
+
+    def _factor_buffers(self, optimizer_step: bool):
+        """(own [N + 1,4], gathered [R, N + 1,4]) when this step exchanges the SH gradients as factors, else None."""
+        if not (self._split_step(optimizer_step) and self.factored_features and self.fused
+                and self.device.type == "cuda"):
+            return None
+        R, N = GradSlab._world(), self.num_gaussians()
+        f = self._factors
+        if f is None or f[1].shape[0] != R or f[1].shape[1] != N + 1:
+            gathered = torch.empty(R, N + 1, 4, dtype=torch.float32, device=self.device)
+            # a single rank writes straight into the gathered buffer
+            own = gathered[0] if R == 1 else torch.empty(N + 1, 4, dtype=torch.float32, device=self.device)
+            self._factors = f = (own, gathered)
+        return f
+
+    def _features_from_factors(self, sh_degree: int) -> None:
+        from ._lib import load, ptr, stream_ptr
+        own, gathered = self._factors
+        R, N = gathered.shape[0], self.num_gaussians()
+        K = 1 + self.params["features_rest"].shape[1]
+        # (the view directions of the step that produced the factors: the means have been stepped since)
+        rc = load().fsgs_sh_coeff_grad(R, N, K, sh_degree, ptr(self._means_prev), ptr(gathered), 1.0 / R,
+                                       ptr(self.slab.views["features_dc"]), ptr(self.slab.views["features_rest"]),
+                                       stream_ptr(self.device))
+        if rc != 0:
+            raise RuntimeError(f"fsgs_sh_coeff_grad failed ({rc})")
+
+    def _reduce_and_step(self, optimizer_step: bool) -> None:
+        """Gradient exchange + Adam for the gradients now in the slab.  With several ranks (and an optimizer step)
+        the feature half is only STARTED here; ``flush`` completes it when the next frame needs the colours."""
+        assert self._pending is None, "the previous step's feature update has not been flushed"
+        split = self._split_step(optimizer_step)
+        if not split:
+            self.slab.all_reduce_mean_()
+            if optimizer_step:
+                self.optimizers["means"].param_groups[0]["lr"] = self._means_lr(self.step)
+                self._optimizer_step(PARAM_ORDER)
+            return
+        self.slab.all_reduce_geometry_mean_()
+        factors = getattr(self, "_factors_used", None)
+        self._factors_used = None
+        if factors is not None:
+            own, gathered = factors
+            work = None
+            if GradSlab._world() > 1:
+                work = dist.all_gather_into_tensor(gathered.view(-1), own.view(-1), async_op=True)
+            deg = self._sh_degree_now()
+            mp = getattr(self, "_means_prev", None)
+            if mp is None or mp.shape != self.params["means"].shape:
+                mp = self._means_prev = torch.empty_like(self.params["means"].data)
+            mp.copy_(self.params["means"].data)  # before Adam moves them (12 B per Gaussian)
+
+            def finish():
+                if work is not None:
+                    work.wait()
+                self._features_from_factors(deg)
+        else:
+            finish = self.slab.all_reduce_features_async()
+        self.optimizers["means"].param_groups[0]["lr"] = self._means_lr(self.step)
+        step_no = self._optimizer_step(GEOMETRY_GROUPS)
+        self._pending = (finish, step_no)
+
+    def flush(self) -> None:
+        """Completes a deferred feature update (no-op otherwise).  Called before the colours are evaluated, before
+        densification touches the parameters, and by anything that reads them (checkpoints, exports)."""
+        if self._pending is None:
+            return
+        finish, step_no = self._pending
+        self._pending = None
+        if finish is not None:
+            finish()
+        self._optimizer_step(FEATURE_GROUPS, step_no)
 
     def train_step(self, camera: Camera, target: Dict[str, Tensor], optimizer_step: bool = True):
         if getattr(self, "_one", None) is None or self._one.device != self.device:
@@ -190,23 +324,20 @@ class SplatTrainer:
         if self.fused and self.direct and self.device.type == "cuda" and "depth" in target:
             from .fused import fused_step_forward_backward
             stats, add_mask, bthr = self._frame_state(camera, True)
+            factors = self._factor_buffers(optimizer_step)
             loss, out = fused_step_forward_backward(self.params, camera, target, self._sh_degree_now(), self.device,
                                                     self.slab.views, self._one, stats_out=stats, add_mask=add_mask,
-                                                    binary_threshold=bthr)
+                                                    binary_threshold=bthr,
+                                                    pre_sh=self.flush if self._pending is not None else None,
+                                                    sh_factors_out=factors[0] if factors else None)
+            self._factors_used = factors
         else:
             if not self.fused:
                 self.slab.zero_()  # autograd accumulates into the slab views; the fused node overwrites them
             out = self.forward(camera)
             loss = self.loss(out, target)
             loss.backward(gradient=self._one)  # (the default would launch a fill kernel for the seed gradient)
-        self.slab.all_reduce_mean_()
-        if optimizer_step:
-            self.optimizers["means"].param_groups[0]["lr"] = self._means_lr(self.step)
-            if self.fused and self.device.type == "cuda":
-                self._fused_adam_step()
-            else:
-                for opt in self.optimizers.values():
-                    opt.step()
+        self._reduce_and_step(optimizer_step)
         if self.strategy is not None:
             self.strategy.after_train(self, out, camera)
             self.strategy.maybe_refine(self)

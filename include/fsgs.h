@@ -87,6 +87,20 @@ int fsgs_sh_bwd_split(int C, int N, int K, int degree, const float *means, const
                       const float *features_dc, const float *features_rest, const int32_t *radii, int D,
                       const float *v_colors, float *v_features_dc, float *v_features_rest,
                       float *v_means, float *v_depths, int overwrite_means, fsgs_stream_t stream);
+
+/* Data-parallel training exchanges the FACTORS of the SH coefficient gradient instead of the gradient: per rank
+ * and Gaussian the masked colour gradient (16 B) instead of 48 coefficient gradients (192 B), since
+ * v_coeffs[n,k,:] = basis_k(dir(n)) * v_rgb[n,:].  fsgs_sh_bwd_colors = fsgs_sh_bwd_split for one camera without
+ * the coefficient outputs: writes v_means and v_rgb_masked [N + 1,4] (rows 0..N-1: the colour gradient where the
+ * clamp of `colors = max(SH + 0.5, 0)` is inactive and the Gaussian visible, else 0; row N: the camera centre).  fsgs_sh_coeff_grad rebuilds
+ * scale * sum over R views; `gathered` = R blocks of (N + 1) x 4 floats: rows 0..N-1 = v_rgb_masked of view r,
+ * row N = (camera centre, -).  Same replaced reference call as fsgs_sh_bwd. */
+int fsgs_sh_bwd_colors(int N, int K, int degree, const float *means, const float *campos,
+                       const float *features_dc, const float *features_rest, const int32_t *radii, int D,
+                       const float *v_colors, float *v_rgb_masked, float *v_means, int overwrite_means,
+                       fsgs_stream_t stream);
+int fsgs_sh_coeff_grad(int R, int N, int K, int degree, const float *means, const float *gathered, float scale,
+                       float *v_features_dc, float *v_features_rest, fsgs_stream_t stream);
 /* D = floats per v_colors row (its first three are the colour gradient): 3, 4 (then v_depths, if given,
  * receives column 3) or a wider stride, e.g. 16 for the rasterizer's packed gradient records.
  * overwrite_means != 0: v_means is written instead of accumulated into. */

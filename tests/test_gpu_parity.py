@@ -204,6 +204,49 @@ def test_sh_fwd_bwd(dev, degree):
     assert rel_err(d_g.grad, d_r.grad) < 1e-6
 
 
+@pytest.mark.parametrize("degree", [0, 2, 3])
+def test_sh_gradient_from_factors(dev, degree):
+    """The data-parallel exchange format: fsgs_sh_bwd_colors (masked colour gradient + camera centre, [N + 1,4]) +
+    fsgs_sh_coeff_grad over R gathered views against fsgs_sh_bwd_split per view: R = 1 reproduces the coefficient
+    gradients and v_means bit for bit; R = 2 equals the mean of the two views' gradients (and the oracle's)."""
+    from fusionsense_amd._lib import load, ptr, stream_ptr
+    lib = load()
+    g = torch.Generator().manual_seed(20 + degree)
+    N, K = 1003, 16
+    means = torch.randn(N, 3, generator=g).to(dev)
+    dc = (torch.randn(N, 3, generator=g) * 0.5).to(dev)
+    rest = (torch.randn(N, K - 1, 3, generator=g) * 0.5).to(dev)
+    sp = stream_ptr(dev)
+    views = []
+    for r in range(2):
+        campos = torch.randn(3, generator=g).to(dev)
+        radii = ((torch.rand(1, N, generator=g) > 0.25).to(torch.int32) * 4).to(dev)
+        v_packed = torch.randn(N, 16, generator=g).to(dev)
+        # per-view reference: the ordinary backward
+        g_dc, g_rest, g_means = torch.empty_like(dc), torch.empty_like(rest), torch.empty_like(means)
+        assert lib.fsgs_sh_bwd_split(1, N, K, degree, ptr(means), ptr(campos), ptr(dc), ptr(rest), ptr(radii), 16,
+                                     ptr(v_packed), ptr(g_dc), ptr(g_rest), ptr(g_means), None, 1, sp) == 0
+        fac = torch.full((N + 1, 4), float("nan"), device=dev)
+        g_means2 = torch.empty_like(means)
+        assert lib.fsgs_sh_bwd_colors(N, K, degree, ptr(means), ptr(campos), ptr(dc), ptr(rest), ptr(radii), 16,
+                                      ptr(v_packed), ptr(fac), ptr(g_means2), 1, sp) == 0
+        assert torch.equal(g_means2, g_means)
+        assert torch.equal(fac[N, :3], campos) and bool((fac[:N, :3][radii[0] <= 0] == 0).all())
+        r_dc, r_rest = torch.empty_like(dc), torch.empty_like(rest)
+        assert lib.fsgs_sh_coeff_grad(1, N, K, degree, ptr(means), ptr(fac), 1.0, ptr(r_dc), ptr(r_rest), sp) == 0
+        assert torch.equal(r_dc, g_dc) and torch.equal(r_rest, g_rest)
+        views.append((fac, g_dc, g_rest))
+    gathered = torch.stack([views[0][0], views[1][0]]).contiguous()
+    m_dc, m_rest = torch.empty_like(dc), torch.empty_like(rest)
+    assert lib.fsgs_sh_coeff_grad(2, N, K, degree, ptr(means), ptr(gathered), 0.5, ptr(m_dc), ptr(m_rest), sp) == 0
+    want_dc, want_rest = 0.5 * (views[0][1] + views[1][1]), 0.5 * (views[0][2] + views[1][2])
+    assert (m_dc - want_dc).abs().max().item() <= 1e-6 * (1 + want_dc.abs().max().item())
+    assert (m_rest - want_rest).abs().max().item() <= 1e-6 * (1 + want_rest.abs().max().item())
+    if degree < 3:
+        kk = (degree + 1) ** 2
+        assert bool((m_rest[:, kk - 1:] == 0).all()), "bands above sh_degree_to_use get no gradient"
+
+
 @pytest.mark.parametrize("scene,antialiased", [("cube", False), ("adversarial", False), ("cube", True)])
 def test_project_bwd(dev, scene, antialiased):
     from fusionsense_amd import ops

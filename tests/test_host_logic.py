@@ -238,6 +238,74 @@ def test_data_parallel_allreduce_gloo_world2():
         assert p.returncode == 0 and "ok" in out, err[-2000:]
 
 
+_DEFER_WORKER = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+from fusionsense_amd.trainer import SplatTrainer, PARAM_ORDER, GEOMETRY_GROUPS, FEATURE_GROUPS
+rank = int(os.environ["RANK"]); world = int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d", rank=rank, world_size=world)
+torch.manual_seed(0)
+n = 40
+shapes = dict(means=(n,3), scales=(n,3), quats=(n,4), features_dc=(n,3), features_rest=(n,15,3), opacities=(n,1))
+init = {k: torch.randn(*shapes[k]) for k in PARAM_ORDER}
+dev = torch.device("cpu")
+a = SplatTrainer(init, dev, fused=False)   # feature half of the exchange + its Adam deferred to the next frame
+b = SplatTrainer(init, dev, fused=False)   # everything at once
+b.defer_features = False
+assert a.slab.split == n * 11 and a.slab.flat.numel() == n * 59
+def grads(tr, it):
+    for i, k in enumerate(PARAM_ORDER):
+        tr.slab.views[k].copy_(torch.sin(tr.params[k].data * (i + 1) + it) * (rank + 1) + 0.1 * rank)
+for it in range(4):
+    grads(a, it); grads(b, it)
+    feat_before = {k: a.params[k].data.clone() for k in FEATURE_GROUPS}
+    geom_before = {k: a.params[k].data.clone() for k in GEOMETRY_GROUPS}
+    a._reduce_and_step(True)
+    assert a._pending is not None
+    for k in FEATURE_GROUPS:
+        assert torch.equal(a.params[k].data, feat_before[k]), "features must wait for the flush"
+    for k in GEOMETRY_GROUPS:
+        assert not torch.equal(a.params[k].data, geom_before[k]), "geometry is stepped at once"
+    a.flush(); a.flush()
+    assert a._pending is None
+    b._reduce_and_step(True)
+    a.step += 1; b.step += 1
+    for k in PARAM_ORDER:
+        assert torch.equal(a.params[k].data, b.params[k].data), (it, k)
+        assert torch.equal(a.slab.views[k], b.slab.views[k]), (it, k)
+        sa, sb = a.optimizers[k].state[a.params[k]], b.optimizers[k].state[b.params[k]]
+        assert torch.equal(sa["exp_avg_sq"], sb["exp_avg_sq"]) and float(sa["step"]) == float(sb["step"]) == it + 1
+# without an optimizer step nothing is deferred
+grads(a, 9); a._reduce_and_step(False); assert a._pending is None
+# every rank holds the same parameters
+for k in PARAM_ORDER:
+    t = a.params[k].data.clone(); dist.broadcast(t, 0)
+    assert torch.equal(t, a.params[k].data), k
+dist.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+def test_deferred_feature_exchange_equals_plain_step_gloo_world2():
+    """Data-parallel step with the SH features' share of the all-reduce (and their Adam) deferred to the next
+    frame (trainer._reduce_and_step / flush) against the plain all-reduce + step: identical parameters, gradients
+    and optimizer state on both ranks over several steps."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    code = _DEFER_WORKER % (ROOT, port)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    for p in procs:
+        out, err = p.communicate(timeout=180)
+        assert p.returncode == 0 and "ok" in out, err[-2000:]
+
+
 def test_binary_opacity_schedule_matches_reference_transcription():
     """dn_model.py:492-499: after the warm-up, every step except the reset steps and the 200 after them."""
     from fusionsense_amd.splatfacto import SplatfactoConfig, binary_opacity_active, binary_opacity_write_
