@@ -136,11 +136,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus or world == 1, f"WORLD_SIZE {world} != --gpus {args.gpus}"
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    # FSGS_DIST_BACKEND=gloo: functional check of the multi-rank path on a box with fewer GPUs than ranks (the ranks
+    # then share devices and the collectives are staged through the host); the default is RCCL, one GPU per rank
+    backend = os.environ.get("FSGS_DIST_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from fusionsense_amd import frame_cache, ops, scenes
     from fusionsense_amd.splatfacto import DensifyStrategy, SplatfactoConfig
@@ -220,6 +228,13 @@ def main():
     gc.enable()
     gc.unfreeze()
     kernel_ms = ops.TIMER.summary()
+    if world > 1 and os.environ.get("FSGS_BENCH_CHECK_REPLICAS"):
+        # the ranks must hold bit-identical parameters after the timed steps (rank-ordered gradient sums)
+        for name, prm in trainer.params.items():
+            ref = prm.data.clone()
+            dist.broadcast(ref, 0)
+            assert torch.equal(ref, prm.data), f"rank {rank}: replica of {name} differs from rank 0"
+        log('replicas identical')
     n_alloc = torch.cuda.memory_stats(dev).get('num_device_alloc', 0) - n_alloc0
     log(f'timed region done: {elapsed:.3f}s')
     ops.TIMER.reset(enabled=False)

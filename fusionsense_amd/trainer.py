@@ -290,7 +290,10 @@ class SplatTrainer:
             own, gathered = factors
             work = None
             if GradSlab._world() > 1:
-                work = dist.all_gather_into_tensor(gathered.view(-1), own.view(-1), async_op=True)
+                if dist.get_backend() == "nccl":
+                    work = dist.all_gather_into_tensor(gathered.view(-1), own.view(-1), async_op=True)
+                else:  # (gloo: list form)
+                    work = dist.all_gather(list(gathered.unbind(0)), own, async_op=True)
             deg = self._sh_degree_now()
             mp = getattr(self, "_means_prev", None)
             if mp is None or mp.shape != self.params["means"].shape:
