@@ -359,3 +359,25 @@ def test_deferred_feature_update_is_the_same_training(dev, factored):
         assert a._pending is not None
         oa, ob = a.forward(cams[1]), b.forward(cams[1])
     assert a._pending is None and float((oa["rgb"] - ob["rgb"]).abs().max()) < 1e-4
+
+
+@pytest.mark.parametrize("mode", ["factored_deferred", "allreduce_deferred", "plain"])
+def test_two_ranks_train_identical_replicas(mode):
+    """bench.py as the driver launches it for 2 ranks (torch.distributed.run), here with both ranks on this one GPU
+    and the collectives on gloo: the whole data-parallel step (view sharding, geometry all-reduce, SH factors or
+    gradients exchanged, deferred feature update, flush, barrier + max timing) runs, and after the timed steps both
+    ranks hold bit-identical parameters."""
+    import json, os, socket, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, FSGS_DIST_BACKEND="gloo", FSGS_BENCH_CHECK_REPLICAS="1", FSGS_BENCH_VERBOSE="1",
+               FSGS_DEFER_FEATURES="0" if mode == "plain" else "1",
+               FSGS_FACTORED_FEATURES="1" if mode == "factored_deferred" else "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4",
+           "--warmup", "1", "--n-gauss", "20000", "--res", "160", "--views", "4", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0
+    assert r.stderr.count("replicas identical") == 2, r.stderr[-2000:]
