@@ -324,6 +324,31 @@ def test_trainer_applies_binary_write_and_anchor_mask(dev):
         assert d <= 2.1 * 0.05 + 1e-6, (k, d)
 
 
+def test_dense_scene_takes_the_depth_slab_path_and_matches_the_radix_chain(dev):
+    """1.2 M Gaussians on 40x40 tiles: thousands of live pairs per tile, so the fused node's binning splits the
+    buckets into depth slabs on its own (FSGS_BIN_SPLIT=auto).  Its lists must equal, bit for bit, the list chain
+    with the 6-pass radix sort; the frame renders deterministically."""
+    from fusionsense_amd import ops
+    from fusionsense_amd.fused import render_fusionsense_fused
+    params = {k: v.to(dev) for k, v in scenes.lego_like_scene(1_200_000, seed=2).items()}
+    cam = scenes.hemisphere_cameras(1, width=640, height=640, focal=888.9, seed=2)[0]
+    with torch.no_grad():
+        a = render_fusionsense_fused(params, cam, sh_degree=3, device=dev)
+        b = render_fusionsense_fused(params, cam, sh_degree=3, device=dev)
+    info = a["info"]
+    tw = th = 40
+    M = info.payload.numel()
+    assert M > 1024 * tw * th and not ops.use_tile_sort(M, tw * th), "the scene must be too dense for plain LDS buckets"
+    assert torch.equal(a["rgb"], b["rgb"]) and torch.equal(a["depth"], b["depth"])
+    opac = torch.sigmoid(params["opacities"]).view(1, -1).contiguous()
+    st = ops.isect_count_live_async(info.means2d, info.radii, info.conics, opac, tw, th)
+    tpg, ids, pay, offs = ops.isect_finish_live(st, info.means2d, info.radii, info.depths, info.conics, opac, tw, th)
+    assert torch.equal(info.payload, pay) and torch.equal(info.isect_offsets, offs)
+    assert torch.equal(info.tiles_per_gauss, tpg)
+    n_tile = torch.diff(torch.cat([offs.flatten(), torch.tensor([M], device=dev, dtype=offs.dtype)]))
+    assert int(n_tile.max()) > 8192, "some tiles exceed even the large LDS tier before the split"
+
+
 @pytest.mark.parametrize("factored", [True, False])
 def test_deferred_feature_update_is_the_same_training(dev, factored):
     """The data-parallel step order on ONE rank (FSGS_FORCE_SPLIT_STEP: geometry stepped at once, the SH features'
