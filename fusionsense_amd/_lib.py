@@ -64,6 +64,7 @@ SIGNATURES = {
     "fsgs_raster_unpack_grads": (_i, [_i64, _i, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p]),
     "fsgs_sh_fwd_split": (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p]),
     "fsgs_sh_bwd_split": (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _i, _p]),
+    "fsgs_sh_fwd_pack": (_i, [_i, _i, _i] + [_p] * 15 + [_i, _p]),
     "fsgs_sh_bwd_colors": (_i, [_i, _i, _i, _p, _p, _p, _p, _p, _i, _p, _p, _p, _i, _p]),
     "fsgs_sh_coeff_grad": (_i, [_i, _i, _i, _i, _p, _p, _f, _p, _p, _p]),
     "fsgs_project_fwd_act": (_i, [_i, _i, _p, _p, _p, _p, _i, _f, _p, _p, _i, _i, _f, _f, _f, _f, _p, _p, _p, _p, _p, _p, _p]),

@@ -8,6 +8,7 @@
 // records (one contiguous 48 KiB span) through LDS with 16-byte coalesced loads, then each
 // lane consumes its own record; LDS rows are padded by one dword so the per-lane stride is odd.
 #include "common.h"
+#include "normal_math.h"
 
 namespace fsgs {
 
@@ -225,12 +226,22 @@ __device__ __forceinline__ void unstage_rows(float *__restrict__ dst, int rows, 
 
 // KT > 0: the coefficient count per Gaussian is the compile-time constant KT (16 = degree-3 storage,
 // FusionSense's configuration); KT = 0: any K <= kMaxK.
-template <int KT, bool SPLIT>
+// PACK (single camera, depth channel): the kernel also writes what fsgs_live_pack_normals would — the 64-byte
+// record per Gaussian the compositing kernels gather (centre, opacity, conic, colour + depth, camera-space normal)
+// and normals_world — instead of the colour array: one launch and a round trip of the colours less.
+struct ShPackArgs {
+    const float *means2d, *conics, *opacities, *quats, *log_scales, *c2w;
+    float4 *packed;
+    float *normals_world, *zero_cells;
+    int n_zero;
+};
+
+template <int KT, bool SPLIT, bool PACK>
 __global__ void __launch_bounds__(kShBlock)
 sh_fwd_kernel(int C, int N, int K, int degree, const float *__restrict__ means,
               const float *__restrict__ campos, const float *__restrict__ coeffs,
               const float *__restrict__ coeffs_rest, const int32_t *__restrict__ radii,
-              const float *__restrict__ depths, float *__restrict__ colors_out) {
+              const float *__restrict__ depths, float *__restrict__ colors_out, ShPackArgs pk) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int n0 = blockIdx.x * kShBlock;
     const int rows = min(kShBlock, N - n0);
@@ -246,10 +257,22 @@ sh_fwd_kernel(int C, int N, int K, int degree, const float *__restrict__ means,
     coeffs_load(st, coeffs, coeffs_rest, n0, rows, K);
     float mx = 0.f, myy = 0.f, mz = 0.f, dep0 = 0.f;
     int rad0 = 0;
+    float4 pq = make_float4(0.f, 0.f, 0.f, 0.f);
+    float2 pxy = make_float2(0.f, 0.f);
+    float pls[3] = {0.f, 0.f, 0.f}, pcon[3] = {0.f, 0.f, 0.f}, pop = 0.f;
+    if (PACK && blockIdx.x == 0)  // e.g. the forward's running image maxima
+        for (int k = threadIdx.x; k < pk.n_zero; k += kShBlock) pk.zero_cells[k] = 0.f;
     if (in_range) {
         mx = means[n * 3 + 0]; myy = means[n * 3 + 1]; mz = means[n * 3 + 2];
         rad0 = radii[n];
         if (depths) dep0 = depths[n];
+        if (PACK) {
+            pq = reinterpret_cast<const float4 *>(pk.quats)[n];
+            pxy = reinterpret_cast<const float2 *>(pk.means2d)[n];
+            pop = pk.opacities[n];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { pls[k] = pk.log_scales[n * 3 + k]; pcon[k] = pk.conics[n * 3 + k]; }
+        }
     }
     coeffs_park(st, coeffs, coeffs_rest, n0, rows, K, lds);
     __syncthreads();
@@ -278,7 +301,22 @@ sh_fwd_kernel(int C, int N, int K, int degree, const float *__restrict__ means,
             g = fmaxf(ag + 0.5f, 0.f);
             bl = fmaxf(ab + 0.5f, 0.f);
         }
-        if (D == 4) {
+        if (PACK) {
+            // the Gaussian's camera-space normal (dn_model.py:618-636), as fsgs_live_pack_normals computes it
+            const float mean[3] = {mx, myy, mz};
+            NormalCtx o;
+            normal_forward(pq, pls, mean, pk.c2w, o);
+            float ex[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) pk.normals_world[n * 3 + k] = o.n[k];
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                ex[j] = o.n[0] * pk.c2w[0 * 4 + j] + o.n[1] * pk.c2w[1 * 4 + j] + o.n[2] * pk.c2w[2 * 4 + j];
+            pk.packed[n * 4 + 0] = make_float4(pxy.x, pxy.y, pop, pcon[0]);
+            pk.packed[n * 4 + 1] = make_float4(pcon[1], pcon[2], 0.f, 0.f);
+            pk.packed[n * 4 + 2] = make_float4(r, g, bl, dep0);
+            pk.packed[n * 4 + 3] = make_float4(ex[0], ex[1], ex[2], 0.f);
+        } else if (D == 4) {
             reinterpret_cast<float4 *>(colors_out)[idx] = make_float4(r, g, bl, c ? depths[idx] : dep0);
         } else {
             colors_out[idx * 3 + 0] = r;
@@ -544,10 +582,11 @@ static int sh_fwd_impl(int C, int N, int K, int degree, const float *means, cons
     if ((int64_t)C * N == 0) return FSGS_OK;
     if (!means || !campos || !coeffs || !radii || !colors_out) return FSGS_EINVAL;
     const size_t lds_bytes = (size_t)kShBlock * (K * 3 + 1) * sizeof(float);
+    ShPackArgs pk = {};
 #define FSGS_SH_FWD(KT, SP)                                                                               \
-    hipLaunchKernelGGL((sh_fwd_kernel<KT, SP>), dim3(ceil_div(N, kShBlock)), dim3(kShBlock), lds_bytes,   \
+    hipLaunchKernelGGL((sh_fwd_kernel<KT, SP, false>), dim3(ceil_div(N, kShBlock)), dim3(kShBlock), lds_bytes, \
                        as_stream(stream), C, N, K, degree, means, campos, coeffs, coeffs_rest, radii, depths, \
-                       colors_out)
+                       colors_out, pk)
     if (coeffs_rest) {
         if (K == 16) FSGS_SH_FWD(16, true); else FSGS_SH_FWD(0, true);
     } else {
@@ -644,5 +683,39 @@ extern "C" int fsgs_sh_coeff_grad(int R, int N, int K, int degree, const float *
     else
         hipLaunchKernelGGL((sh_coeff_grad_kernel<0>), dim3(ceil_div(N, kShBlock)), dim3(kShBlock), lds_bytes,
                            as_stream(stream), R, N, K, degree, means, g4, scale, v_features_dc, v_features_rest);
+    return check_launch();
+}
+
+// fsgs_sh_fwd_split (one camera, depth channel) + fsgs_live_pack_normals in one launch: the colours go straight into
+// the packed per-Gaussian records [N,16] (no colour array), normals_world [N,3] and the zeroed cells as there.
+extern "C" int fsgs_sh_fwd_pack(int N, int K, int degree, const float *means, const float *campos,
+                                const float *features_dc, const float *features_rest, const int32_t *radii,
+                                const float *depths, const float *means2d, const float *conics,
+                                const float *opacities, const float *quats, const float *log_scales,
+                                const float *c2w, float *packed, float *normals_world, float *zero_cells,
+                                int n_zero, fsgs_stream_t stream) {
+    if (N < 0 || degree < 0 || degree > 4 || K < (degree + 1) * (degree + 1) || K > kMaxK) return FSGS_EINVAL;
+    if (N == 0) {
+        if (zero_cells && n_zero > 0) {
+            hipError_t e = hipMemsetAsync(zero_cells, 0, (size_t)n_zero * sizeof(float), as_stream(stream));
+            if (e != hipSuccess) { g_last_hip_error = (int)e; return FSGS_ELAUNCH; }
+        }
+        return FSGS_OK;
+    }
+    if (!means || !campos || !features_dc || (!features_rest && K > 1) || !radii || !depths || !means2d || !conics ||
+        !opacities || !quats || !log_scales || !c2w || !packed || !normals_world)
+        return FSGS_EINVAL;
+    ShPackArgs pk = {means2d, conics, opacities, quats, log_scales, c2w, reinterpret_cast<float4 *>(packed),
+                     normals_world, zero_cells, zero_cells ? n_zero : 0};
+    const float *rest = features_rest ? features_rest : features_dc;
+    const size_t lds_bytes = (size_t)kShBlock * (K * 3 + 1) * sizeof(float);
+    if (K == 16)
+        hipLaunchKernelGGL((sh_fwd_kernel<16, true, true>), dim3(ceil_div(N, kShBlock)), dim3(kShBlock), lds_bytes,
+                           as_stream(stream), 1, N, K, degree, means, campos, features_dc, rest, radii, depths,
+                           nullptr, pk);
+    else
+        hipLaunchKernelGGL((sh_fwd_kernel<0, true, true>), dim3(ceil_div(N, kShBlock)), dim3(kShBlock), lds_bytes,
+                           as_stream(stream), 1, N, K, degree, means, campos, features_dc, rest, radii, depths,
+                           nullptr, pk);
     return check_launch();
 }

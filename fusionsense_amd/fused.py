@@ -136,20 +136,17 @@ class _FusedGetOutputs(torch.autograd.Function):
             count = ops.bin_live_count_async(means2d, radii, conics, opac_row, tw, th)
         else:
             count = ops.isect_count_live_async(means2d, radii, conics, opac_row, tw, th)
-        colors = torch.empty(1, N, 4, **f32)
         normals_world = torch.empty(N, 3, **f32)
         packed = torch.empty(N, 16, **f32)
         n_cells = lib.fsgs_raster_quad_max_cells()
         max_last = torch.empty(n_cells, **f32)  # partial image maxima: zeroed by the pack kernel, raised by the forward
 
         def colours_and_packing():
-            _run(lib.fsgs_sh_fwd_split, (1, N, K, sh_degree, ptr(means), ptr(cam["campos"]), ptr(features_dc),
-                                         ptr(features_rest), ptr(radii), ptr(depths), ptr(colors), sp),
-                 "fsgs_sh_fwd_split")
-            _run(lib.fsgs_live_pack_normals, (N, ptr(means2d), ptr(conics), ptr(colors), ptr(opac_sig), ptr(quats),
-                                             ptr(scales), ptr(means), ptr(cam["c2w"]), ptr(packed),
-                                             ptr(normals_world), ptr(max_last), n_cells, sp),
-                 "fsgs_live_pack_normals", "_d4e3")
+            # SH colours (+ depth) and the camera-space normals straight into the packed records (one launch)
+            _run(lib.fsgs_sh_fwd_pack, (N, K, sh_degree, ptr(means), ptr(cam["campos"]), ptr(features_dc),
+                                        ptr(features_rest), ptr(radii), ptr(depths), ptr(means2d), ptr(conics),
+                                        ptr(opac_sig), ptr(quats), ptr(scales), ptr(cam["c2w"]), ptr(packed),
+                                        ptr(normals_world), ptr(max_last), n_cells, sp), "fsgs_sh_fwd_split")
 
         # Work that does not need the lists runs while the host waits for the live total — unless the SH features
         # are still being exchanged between the ranks (info.pre_sh: the trainer's deferred feature update): then

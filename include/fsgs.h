@@ -88,6 +88,15 @@ int fsgs_sh_bwd_split(int C, int N, int K, int degree, const float *means, const
                       const float *v_colors, float *v_features_dc, float *v_features_rest,
                       float *v_means, float *v_depths, int overwrite_means, fsgs_stream_t stream);
 
+/* fsgs_sh_fwd_split (one camera, with the depth channel) and fsgs_live_pack_normals in one launch: the colours go
+ * straight into the packed per-Gaussian records [N,16] that the live-list kernels gather (no colour array is
+ * written), normals_world [N,3] and the n_zero zeroed cells come out as from fsgs_live_pack_normals. */
+int fsgs_sh_fwd_pack(int N, int K, int degree, const float *means, const float *campos, const float *features_dc,
+                     const float *features_rest, const int32_t *radii, const float *depths, const float *means2d,
+                     const float *conics, const float *opacities, const float *quats, const float *log_scales,
+                     const float *c2w, float *packed, float *normals_world, float *zero_cells, int n_zero,
+                     fsgs_stream_t stream);
+
 /* Data-parallel training exchanges the FACTORS of the SH coefficient gradient instead of the gradient: per rank
  * and Gaussian the masked colour gradient (16 B) instead of 48 coefficient gradients (192 B), since
  * v_coeffs[n,k,:] = basis_k(dir(n)) * v_rgb[n,:].  fsgs_sh_bwd_colors = fsgs_sh_bwd_split for one camera without
