@@ -55,8 +55,18 @@ __device__ __forceinline__ void load_rec(Rec &r, const float4 *__restrict__ rec,
 // removes the long-list tail that otherwise sets the kernel's duration.
 constexpr int kBwdWaves = 4;
 
+// Optional: the gradients arrive as those of FusionSense's get_outputs images (D = 4, E = 3, C = 1; what
+// fsgs_epilogue_bwd would first turn into v_render / v_alphas / v_render_extra, dn_model.py:602-613, 655-664):
+//   rgb = clamp(render.rgb + (1 - alpha) bg, 0, 1),  depth = alpha > 0 ? render.w : fill,
+//   normal = (normalize(render_extra) + 1) / 2.
+// Every lane derives its pixel's gradients itself (pointwise, ~40 instructions per wave): one launch and a
+// write + read of 32 B per pixel less.
+struct GetOutputsGrads {
+    const float *v_rgb, *v_depth, *v_normal, *v_alpha_in, *bg;  // v_rgb == nullptr: not used
+};
+
 template <int D, bool ABS, int E>
-__global__ void __launch_bounds__(64 * kBwdWaves)
+__global__ void __launch_bounds__(64 * kBwdWaves) __attribute__((amdgpu_waves_per_eu(6, 6)))
 raster_bwd_live_kernel(int64_t cap, const float4 *__restrict__ rec,
                        const int32_t *__restrict__ tile_offsets, int64_t n_isects,
                        const float *__restrict__ backgrounds, int W, int H, int tw, int th,
@@ -65,7 +75,7 @@ raster_bwd_live_kernel(int64_t cap, const float4 *__restrict__ rec,
                        const float *__restrict__ v_alphas, const float *__restrict__ seg_state,
                        int64_t seg_cap, float *__restrict__ v_packed, int normalize_last,
                        const float *__restrict__ render_extra, const float *__restrict__ v_render_extra,
-                       const int32_t *__restrict__ n_rec) {
+                       const int32_t *__restrict__ n_rec, GetOutputsGrads ep) {
     __shared__ QLds<E> Lw[kBwdWaves];
     constexpr int RS = E ? 4 : 3;
     constexpr int SS = 64 * (1 + D + E);
@@ -99,11 +109,25 @@ raster_bwd_live_kernel(int64_t cap, const float4 *__restrict__ rec,
     const float T_final = 1.f - alpha_px;
     float v_out[D], c_total[D];
 #pragma unroll
-    for (int k = 0; k < D; ++k) {
-        v_out[k] = inside ? v_render[pix_id * D + k] : 0.f;
-        c_total[k] = render[pix_id * D + k];
+    for (int k = 0; k < D; ++k) c_total[k] = render[pix_id * D + k];
+    float v_out_a = 0.f;
+    const bool from_images = (D == 4 && E == 3) && ep.v_rgb != nullptr;
+    if (from_images) {
+        float va = (inside && ep.v_alpha_in) ? ep.v_alpha_in[pix_id] : 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float pre = c_total[k] + T_final * ep.bg[k];
+            const float gk = (inside && pre >= 0.f && pre <= 1.f) ? ep.v_rgb[pix_id * 3 + k] : 0.f;
+            v_out[k] = gk;
+            va -= ep.bg[k] * gk;
+        }
+        v_out[D - 1] = (inside && ep.v_depth && alpha_px > 0.f) ? ep.v_depth[pix_id] : 0.f;
+        v_out_a = va;
+    } else {
+#pragma unroll
+        for (int k = 0; k < D; ++k) v_out[k] = inside ? v_render[pix_id * D + k] : 0.f;
+        v_out_a = inside ? v_alphas[pix_id] : 0.f;
     }
-    float v_out_a = inside ? v_alphas[pix_id] : 0.f;
     if (normalize_last) {
         // render[D-1] = acc / max(alpha, 1e-10): undo for the colour total, chain the two gradients
         const float a_c = fmaxf(alpha_px, 1e-10f);
@@ -119,11 +143,32 @@ raster_bwd_live_kernel(int64_t cap, const float4 *__restrict__ rec,
     }
     float v_oute[E ? E : 1], ce_total[E ? E : 1];
     float bge_dot = 0.f;
+    if (from_images) {
+        const float nx = render_extra[pix_id * 3 + 0], ny = render_extra[pix_id * 3 + 1], nz = render_extra[pix_id * 3 + 2];
+        float gx = 0.f, gy = 0.f, gz = 0.f;
+        if (inside && ep.v_normal) {
+            const float inv = 1.f / sqrtf(nx * nx + ny * ny + nz * nz);
+            const float ux = nx * inv, uy = ny * inv, uz = nz * inv;
+            const float hx = 0.5f * ep.v_normal[pix_id * 3 + 0], hy = 0.5f * ep.v_normal[pix_id * 3 + 1],
+                        hz = 0.5f * ep.v_normal[pix_id * 3 + 2];
+            const float d = hx * ux + hy * uy + hz * uz;
+            gx = (hx - d * ux) * inv; gy = (hy - d * uy) * inv; gz = (hz - d * uz) * inv;
+        }
+        const float gg[3] = {gx, gy, gz};
+        const float nn[3] = {nx, ny, nz};
 #pragma unroll
-    for (int k = 0; k < E; ++k) {
-        v_oute[k] = inside ? v_render_extra[pix_id * E + k] : 0.f;
-        ce_total[k] = render_extra[pix_id * E + k] - T_final;  // background = 1
-        bge_dot += v_oute[k];
+        for (int k = 0; k < E; ++k) {
+            v_oute[k] = gg[k];
+            ce_total[k] = nn[k] - T_final;  // background = 1
+            bge_dot += v_oute[k];
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < E; ++k) {
+            v_oute[k] = inside ? v_render_extra[pix_id * E + k] : 0.f;
+            ce_total[k] = render_extra[pix_id * E + k] - T_final;  // background = 1
+            bge_dot += v_oute[k];
+        }
     }
     float bg_dot = 0.f;
     if (backgrounds) {
@@ -307,12 +352,16 @@ static int launch_bwd_live(int C, int D, const float *records, const int32_t *n_
                            int normalize_last, const float *render, const float *alphas, const int32_t *last_ids,
                            const float *v_render, const float *v_alphas, const float *seg_state, int with_abs,
                            const float *render_extra, const float *v_render_extra, float *v_packed,
-                           fsgs_stream_t stream) {
+                           fsgs_stream_t stream, GetOutputsGrads ep = GetOutputsGrads{nullptr, nullptr, nullptr, nullptr, nullptr}) {
     if (C < 0 || width < 0 || height < 0 || n_isects < 0) return FSGS_EINVAL;
     if (C == 0 || width == 0 || height == 0 || n_isects == 0) return FSGS_OK;
-    if (!records || !n_rec || !isect_offsets || !render || !alphas || !last_ids || !v_render ||
-        !v_alphas || !seg_state || !v_packed)
+    if (!records || !n_rec || !isect_offsets || !render || !alphas || !last_ids || !seg_state || !v_packed)
         return FSGS_EINVAL;
+    if (ep.v_rgb) {
+        if (C != 1 || D != 4 || !render_extra || !ep.bg) return FSGS_EINVAL;
+    } else if (!v_render || !v_alphas) {
+        return FSGS_EINVAL;
+    }
     hipStream_t s = as_stream(stream);
     const dim3 grid(2 * tile_width, 2 * tile_height, C);
     const float4 *rec = reinterpret_cast<const float4 *>(records);
@@ -320,9 +369,9 @@ static int launch_bwd_live(int C, int D, const float *records, const int32_t *n_
     hipLaunchKernelGGL((raster_bwd_live_kernel<DD, AA, EE>), grid, dim3(64 * kBwdWaves), 0, s, cap, rec,          \
                        isect_offsets, n_isects, backgrounds, width, height, tile_width, tile_height, render,      \
                        alphas, last_ids, v_render, v_alphas, seg_state, seg_cap, v_packed, normalize_last,         \
-                       render_extra, v_render_extra, n_rec)
+                       render_extra, v_render_extra, n_rec, ep)
     if (render_extra) {
-        if (D != 4 || !v_render_extra) return FSGS_EINVAL;
+        if (D != 4 || (!v_render_extra && !ep.v_rgb)) return FSGS_EINVAL;
         if (with_abs) FSGS_BWD_LIVE(4, true, 3); else FSGS_BWD_LIVE(4, false, 3);
         return check_launch();
     }
@@ -363,4 +412,22 @@ extern "C" int fsgs_raster_unpack_grads(int64_t total, int D, float *v_packed, i
                        reinterpret_cast<float4 *>(v_packed), rezero, v_means2d, v_means2d_abs, v_conics, v_colors,
                        v_opacities, v_extra, v_last);
     return check_launch();
+}
+
+// fsgs_epilogue_bwd + fsgs_raster_bwd_quad (one camera, RGB + expected depth and the normal plane in one walk): the
+// gradients of the get_outputs images go in directly; v_depth / v_normal / v_alpha_in may be NULL (no gradient).
+extern "C" int fsgs_raster_bwd_quad_images(const float *records, const int32_t *n_rec, const int32_t *isect_offsets,
+                                           int64_t n_isects, int width, int height, int tile_width, int tile_height,
+                                           const float *render, const float *alphas, const int32_t *last_ids,
+                                           const float *render_extra, const float *background, const float *v_rgb,
+                                           const float *v_depth, const float *v_normal, const float *v_alpha_in,
+                                           const float *seg_state, int with_abs, float *v_packed,
+                                           fsgs_stream_t stream) {
+    if (n_isects > 0 && (!n_rec || !v_rgb || !background)) return FSGS_EINVAL;
+    if (!v_rgb) return FSGS_EINVAL;
+    const GetOutputsGrads ep = {v_rgb, v_depth, v_normal, v_alpha_in, background};
+    return launch_bwd_live(1, 4, records, n_rec, fsgs_quad_stream_capacity(1, tile_width, tile_height, n_isects),
+                           fsgs_quad_seg_slots(1, tile_width, tile_height, n_isects), isect_offsets, n_isects, nullptr,
+                           width, height, tile_width, tile_height, 1, render, alphas, last_ids, nullptr, nullptr,
+                           seg_state, with_abs, render_extra, nullptr, v_packed, stream, ep);
 }

@@ -99,6 +99,9 @@ def _grad_accumulator(dev, N: int) -> Tensor:
     return t
 
 
+IMAGE_GRADS_IN_BWD = os.environ.get("FSGS_IMAGE_GRADS_IN_BWD", "1") != "0"
+
+
 class _FusedGetOutputs(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means, scales, quats, features_dc, features_rest, opacities, cam, width, height,
@@ -226,17 +229,26 @@ class _FusedGetOutputs(torch.autograd.Function):
         c = lambda t: None if t is None else t.contiguous()  # noqa: E731
         v_rgb, v_depth, v_normal, v_alpha_out = c(v_rgb), c(v_depth), c(v_normal), c(v_alpha_out)
 
-        v_render = torch.empty(1, H, W, 4, **f32)
-        v_alphas = torch.empty(1, H, W, 1, **f32)
-        v_render_extra = torch.empty(1, H, W, 3, **f32)
-        _run(lib.fsgs_epilogue_bwd, (H * W, ptr(render), ptr(alphas), ptr(render_extra), ptr(background), ptr(v_rgb),
-                                    ptr(v_depth), ptr(v_normal), ptr(v_alpha_out), ptr(v_render), ptr(v_alphas),
-                                    ptr(v_render_extra), sp), "fsgs_epilogue_bwd")
         v_packed = _grad_accumulator(dev, N)  # all zeros: the unpack kernel clears it again after reading
-        _run(lib.fsgs_raster_bwd_quad, (1, 4, ptr(records), ptr(n_rec), ptr(offsets), M, None, W, H, tw, th, 1,
-                                       ptr(render), ptr(alphas), ptr(last_ids), ptr(v_render), ptr(v_alphas),
-                                       ptr(seg_state), 1, ptr(render_extra), ptr(v_render_extra), ptr(v_packed), sp),
-             "fsgs_raster_bwd_quad", "_d4e3")
+        if v_rgb is not None and IMAGE_GRADS_IN_BWD:
+            # the image gradients go straight into the compositing backward, which derives v_render / v_alphas /
+            # v_render_extra per pixel itself (no epilogue launch, no 32 B/pixel round trip)
+            _run(lib.fsgs_raster_bwd_quad_images, (ptr(records), ptr(n_rec), ptr(offsets), M, W, H, tw, th, ptr(render),
+                                                  ptr(alphas), ptr(last_ids), ptr(render_extra), ptr(background),
+                                                  ptr(v_rgb), ptr(v_depth), ptr(v_normal), ptr(v_alpha_out),
+                                                  ptr(seg_state), 1, ptr(v_packed), sp),
+                 "fsgs_raster_bwd_quad", "_d4e3")
+        else:
+            v_render = torch.empty(1, H, W, 4, **f32)
+            v_alphas = torch.empty(1, H, W, 1, **f32)
+            v_render_extra = torch.empty(1, H, W, 3, **f32)
+            _run(lib.fsgs_epilogue_bwd, (H * W, ptr(render), ptr(alphas), ptr(render_extra), ptr(background), ptr(v_rgb),
+                                        ptr(v_depth), ptr(v_normal), ptr(v_alpha_out), ptr(v_render), ptr(v_alphas),
+                                        ptr(v_render_extra), sp), "fsgs_epilogue_bwd")
+            _run(lib.fsgs_raster_bwd_quad, (1, 4, ptr(records), ptr(n_rec), ptr(offsets), M, None, W, H, tw, th, 1,
+                                           ptr(render), ptr(alphas), ptr(last_ids), ptr(v_render), ptr(v_alphas),
+                                           ptr(seg_state), 1, ptr(render_extra), ptr(v_render_extra), ptr(v_packed),
+                                           sp), "fsgs_raster_bwd_quad", "_d4e3")
         WORKSPACE.give(getattr(ctx, "arena", None))
         ctx.arena = None
 

@@ -280,6 +280,16 @@ int fsgs_raster_bwd_quad(int C, int D, const float *records, const int32_t *n_re
                          const float *v_render, const float *v_alphas, const float *seg_state,
                          int with_abs, const float *render_extra, const float *v_render_extra,
                          float *v_packed, fsgs_stream_t stream);
+/* fsgs_epilogue_bwd + fsgs_raster_bwd_quad for FusionSense's get_outputs (one camera; RGB + expected depth and the
+ * normal plane in one walk): takes the gradients of the rgb / depth / normal images (and of the accumulation,
+ * nullable) and derives v_render / v_alphas / v_render_extra per pixel inside the kernel
+ * (/root/reference/dn_splatter/dn_model.py:602-613, 655-664).  background: 3 floats. */
+int fsgs_raster_bwd_quad_images(const float *records, const int32_t *n_rec, const int32_t *isect_offsets,
+                                int64_t n_isects, int width, int height, int tile_width, int tile_height,
+                                const float *render, const float *alphas, const int32_t *last_ids,
+                                const float *render_extra, const float *background, const float *v_rgb,
+                                const float *v_depth, const float *v_normal, const float *v_alpha_in,
+                                const float *seg_state, int with_abs, float *v_packed, fsgs_stream_t stream);
 /* ---- Sort + offsets for live lists as a partition by tile plus a sort inside every tile's bucket
  * (same results, bit for bit, as fsgs_sort_pairs on the key bits + fsgs_isect_offset_encode; replaces
  * the same reference calls).  isect_ids [n] are the UNSORTED keys cam|tile|depth-bits of
