@@ -6,6 +6,7 @@
 #include "common.h"
 #include <cstdlib>
 #include "cull.h"
+#include "project_math.h"
 #include "scan.h"
 
 namespace fsgs {
@@ -346,13 +347,24 @@ struct BinLds {
     int wave_sum[kBinWaves];
 };
 
-template <bool SCATTER, bool MULTI>
+// PROJ (count pass, one camera): the workgroup PROJECTS its Gaussians itself (project_math.h, with the activations
+// and the binary-opacity write of fsgs_project_fwd_act) and writes the projection's outputs for the later passes:
+// no projection launch, and the count pass reads 48 B of parameters instead of 28 B of projected attributes.
+struct BinProjArgs {
+    const float *means, *quats, *log_scales, *viewmat, *K;
+    float *opac_logit, *scales_out, *opac_out, *means2d, *depths, *conics;
+    int32_t *radii;
+    int width, height, binarise;
+    float eps2d, near_plane, far_plane, radius_clip, binary_threshold;
+};
+
+template <bool SCATTER, bool MULTI, bool PROJ>
 __global__ void __launch_bounds__(kBinThreads)
 isect_live_bin_kernel(int C, int N, const float *__restrict__ means2d, const int32_t *__restrict__ radii,
                       const float *__restrict__ depths, const float *__restrict__ conics,
                       const float *__restrict__ opacities, int tw, int th, int T, int nb, int chunks,
                       int32_t *__restrict__ tiles_per_gauss, int32_t *__restrict__ table,
-                      const int32_t *__restrict__ offsets, uint64_t *__restrict__ buckets) {
+                      const int32_t *__restrict__ offsets, uint64_t *__restrict__ buckets, BinProjArgs pj) {
     extern __shared__ __attribute__((aligned(16))) unsigned char bin_smem[];
     BinLds &L = *reinterpret_cast<BinLds *>(bin_smem);
     int *slots = reinterpret_cast<int *>(bin_smem + sizeof(BinLds));
@@ -372,7 +384,33 @@ isect_live_bin_kernel(int C, int N, const float *__restrict__ means2d, const int
         TileRect t = {0, 0, 0, 0};
         float mx = 0.f, my = 0.f, op = 0.f, ca = 0.f, cb = 0.f, cc = 0.f;
         uint32_t db = 0u;
-        if (idx < total) {
+        if (PROJ && idx < total) {
+            const int64_t n = idx;  // (one camera)
+            const float s_act[3] = {expf(pj.log_scales[n * 3 + 0]), expf(pj.log_scales[n * 3 + 1]),
+                                    expf(pj.log_scales[n * 3 + 2])};
+            pj.scales_out[n * 3 + 0] = s_act[0]; pj.scales_out[n * 3 + 1] = s_act[1]; pj.scales_out[n * 3 + 2] = s_act[2];
+            float ol = pj.opac_logit[n];
+            if (pj.binarise) {  // the binary-opacity write of get_outputs (dn_model.py:492-503), on the parameter itself
+                ol = (ol >= pj.binary_threshold) ? 1.f : 0.f;
+                pj.opac_logit[n] = ol;
+            }
+            const float o_act = 1.f / (1.f + expf(-ol));
+            pj.opac_out[n] = o_act;
+            const ProjOut po = project_one(pj.means[n * 3 + 0], pj.means[n * 3 + 1], pj.means[n * 3 + 2],
+                                           reinterpret_cast<const float4 *>(pj.quats)[n], s_act, pj.viewmat, pj.K,
+                                           pj.width, pj.height, pj.eps2d, pj.near_plane, pj.far_plane, pj.radius_clip);
+            pj.radii[n] = po.radius;
+            reinterpret_cast<float2 *>(pj.means2d)[n] = make_float2(po.u, po.v);
+            pj.depths[n] = po.depth;
+            pj.conics[n * 3 + 0] = po.ca; pj.conics[n * 3 + 1] = po.cb; pj.conics[n * 3 + 2] = po.cc;
+            if (po.radius > 0) {
+                mx = po.u; my = po.v;
+                t = tile_rect(mx, my, po.radius, 16, tw, th, 0);
+                cnt = (t.x1 - t.x0) * (t.y1 - t.y0);
+                op = o_act; ca = po.ca; cb = po.cb; cc = po.cc;
+            }
+            if (tiles_per_gauss) tiles_per_gauss[idx] = cnt;
+        } else if (idx < total) {
             const int r = radii[idx];
             if (r > 0) {
                 const float2 m = reinterpret_cast<const float2 *>(means2d)[idx];
@@ -639,12 +677,14 @@ static int bin_set_lds(int T) {
     static size_t have[2] = {0, 0};
     const size_t need = bin_lds_bytes(T);
     if (need > have[0]) {
-        const void *kernels[4] = {reinterpret_cast<const void *>(&isect_live_bin_kernel<false, false>),
-                                  reinterpret_cast<const void *>(&isect_live_bin_kernel<false, true>),
-                                  reinterpret_cast<const void *>(&isect_live_bin_kernel<true, false>),
-                                  reinterpret_cast<const void *>(&isect_live_bin_kernel<true, true>)};
+        const void *kernels[6] = {reinterpret_cast<const void *>(&isect_live_bin_kernel<false, false, false>),
+                                  reinterpret_cast<const void *>(&isect_live_bin_kernel<false, true, false>),
+                                  reinterpret_cast<const void *>(&isect_live_bin_kernel<true, false, false>),
+                                  reinterpret_cast<const void *>(&isect_live_bin_kernel<true, true, false>),
+                                  reinterpret_cast<const void *>(&isect_live_bin_kernel<false, false, true>),
+                                  reinterpret_cast<const void *>(&isect_live_bin_kernel<false, true, true>)};
         hipError_t e = hipSuccess;
-        for (int k = 0; k < 4 && e == hipSuccess; ++k)
+        for (int k = 0; k < 6 && e == hipSuccess; ++k)
             e = hipFuncSetAttribute(kernels[k], hipFuncAttributeMaxDynamicSharedMemorySize, (int)need);
         if (e != hipSuccess) { g_last_hip_error = (int)e; return FSGS_ELAUNCH; }
         have[0] = need;
@@ -677,11 +717,56 @@ extern "C" int fsgs_bin_live_count(int C, int N, const float *means2d, const int
     int rc = bin_set_lds(T);
     if (rc != FSGS_OK) return rc;
 #define FSGS_BIN_COUNT(MU)                                                                                          \
-    hipLaunchKernelGGL((isect_live_bin_kernel<false, MU>), dim3(nb), dim3(kBinThreads), bin_lds_bytes(T), s, C, N,    \
-                       means2d, radii, nullptr, conics, opacities, tile_width, tile_height, T, nb, bin_chunks(total),  \
-                       tiles_per_gauss, table, nullptr, nullptr)
+    hipLaunchKernelGGL((isect_live_bin_kernel<false, MU, false>), dim3(nb), dim3(kBinThreads), bin_lds_bytes(T), s,   \
+                       C, N, means2d, radii, nullptr, conics, opacities, tile_width, tile_height, T, nb,               \
+                       bin_chunks(total), tiles_per_gauss, table, nullptr, nullptr, BinProjArgs{})
     if (bin_chunks(total) > 1) FSGS_BIN_COUNT(true); else FSGS_BIN_COUNT(false);
 #undef FSGS_BIN_COUNT
+    rc = check_launch();
+    if (rc != FSGS_OK) return rc;
+    return launch_tile_scan_rows_offsets(T, nb, table, totals, isect_offsets, s);
+}
+
+// fsgs_project_fwd_act (one camera) + fsgs_bin_live_count in one launch chain: the count pass projects the
+// Gaussians itself.  Outputs of both: scales_out, opac_out, radii, means2d, depths, conics [N..], tiles_per_gauss,
+// isect_offsets[T + 1]; opac_logit is rewritten when binarise != 0.
+extern "C" int fsgs_project_bin_live_count(int N, const float *means, const float *quats, const float *log_scales,
+                                           float *opac_logit, int binarise, float binary_threshold,
+                                           const float *viewmat, const float *K, int width, int height, float eps2d,
+                                           float near_plane, float far_plane, float radius_clip, float *scales_out,
+                                           float *opac_out, int32_t *radii, float *means2d, float *depths,
+                                           float *conics, int tile_width, int tile_height, int32_t *tiles_per_gauss,
+                                           int32_t *isect_offsets, void *table_scratch, size_t table_bytes,
+                                           fsgs_stream_t stream) {
+    if (N < 0 || tile_width < 1 || tile_height < 1 || !isect_offsets) return FSGS_EINVAL;
+    const int64_t T64 = (int64_t)tile_width * tile_height;
+    if (T64 > fsgs_bin_live_max_tiles()) return FSGS_EINVAL;
+    const int T = (int)T64;
+    hipStream_t s = as_stream(stream);
+    if (N == 0) {
+        hipError_t e = hipMemsetAsync(isect_offsets, 0, (size_t)(T + 1) * sizeof(int32_t), s);
+        if (e != hipSuccess) { g_last_hip_error = (int)e; return FSGS_ELAUNCH; }
+        return FSGS_OK;
+    }
+    if (!means || !quats || !log_scales || !opac_logit || !viewmat || !K || !scales_out || !opac_out || !radii ||
+        !means2d || !depths || !conics || !table_scratch)
+        return FSGS_EINVAL;
+    if (table_bytes < fsgs_bin_live_table_bytes(1, N, tile_width, tile_height)) return FSGS_ESCRATCH;
+    const int64_t total = N;
+    const int nb = (int)bin_blocks(total);
+    int32_t *table = reinterpret_cast<int32_t *>(table_scratch);
+    int32_t *totals = table + (size_t)T * nb;
+    int rc = bin_set_lds(T);
+    if (rc != FSGS_OK) return rc;
+    const BinProjArgs pj = {means, quats, log_scales, viewmat, K, opac_logit, scales_out, opac_out, means2d, depths,
+                            conics, radii, width, height, binarise, eps2d, near_plane, far_plane, radius_clip,
+                            binary_threshold};
+#define FSGS_BIN_PCOUNT(MU)                                                                                         \
+    hipLaunchKernelGGL((isect_live_bin_kernel<false, MU, true>), dim3(nb), dim3(kBinThreads), bin_lds_bytes(T), s, 1, \
+                       N, nullptr, nullptr, nullptr, nullptr, nullptr, tile_width, tile_height, T, nb,                 \
+                       bin_chunks(total), tiles_per_gauss, table, nullptr, nullptr, pj)
+    if (bin_chunks(total) > 1) FSGS_BIN_PCOUNT(true); else FSGS_BIN_PCOUNT(false);
+#undef FSGS_BIN_PCOUNT
     rc = check_launch();
     if (rc != FSGS_OK) return rc;
     return launch_tile_scan_rows_offsets(T, nb, table, totals, isect_offsets, s);
@@ -740,9 +825,10 @@ static int bin_live_emit_impl(int C, int N, const float *means2d, const int32_t 
     int rc = bin_set_lds(T);
     if (rc != FSGS_OK) return rc;
 #define FSGS_BIN_FILL(MU)                                                                                           \
-    hipLaunchKernelGGL((isect_live_bin_kernel<true, MU>), dim3(nb), dim3(kBinThreads), bin_lds_bytes(T), s, C, N,     \
-                       means2d, radii, depths, conics, opacities, tile_width, tile_height, T, nb,                      \
-                       bin_chunks((int64_t)C * N), nullptr, table, isect_offsets, reinterpret_cast<uint64_t *>(buckets))
+    hipLaunchKernelGGL((isect_live_bin_kernel<true, MU, false>), dim3(nb), dim3(kBinThreads), bin_lds_bytes(T), s, C, \
+                       N, means2d, radii, depths, conics, opacities, tile_width, tile_height, T, nb,                   \
+                       bin_chunks((int64_t)C * N), nullptr, table, isect_offsets, reinterpret_cast<uint64_t *>(buckets), \
+                       BinProjArgs{})
     if (bin_chunks((int64_t)C * N) > 1) FSGS_BIN_FILL(true); else FSGS_BIN_FILL(false);
 #undef FSGS_BIN_FILL
     rc = check_launch();

@@ -125,19 +125,25 @@ class _FusedGetOutputs(torch.autograd.Function):
         depths = torch.empty(1, N, **f32)
         conics = torch.empty(1, N, 3, **f32)
         bthr = info.binary_threshold
-        _run(lib.fsgs_project_fwd_act, (1, N, ptr(means), ptr(quats), ptr(scales), ptr(opacities),
-                                       0 if bthr is None else 1, 0.0 if bthr is None else float(bthr),
-                                       ptr(cam["viewmat"]),
-                                       ptr(cam["K"]), W, H, 0.3, 0.01, 1e10, 0.0, ptr(scales_exp), ptr(opac_sig),
-                                       ptr(radii), ptr(means2d), ptr(depths), ptr(conics), sp), "fsgs_project_fwd_act")
         # live emission: only (Gaussian, tile) pairs that can reach a pixel are binned and sorted; the
         # quadrant masks ride in the payload (gsplat's full lists are not an output of get_outputs)
         opac_row = opac_sig.view(1, N)
         direct_bins = (ops.USE_BIN_LIVE and tw * th <= lib.fsgs_bin_live_max_tiles()
                        and not ops.bin_live_is_dense(dev, N, tw * th))
-        if direct_bins:  # pairs go straight into their tile's bucket (no emission-order lists, 4 launches fewer)
-            count = ops.bin_live_count_async(means2d, radii, conics, opac_row, tw, th)
+        if direct_bins:
+            # pairs go straight into their tile's bucket (no emission-order lists), and the count pass projects the
+            # Gaussians itself (activations + binary-opacity write included): no projection launch
+            count = ops.project_bin_live_count_async(
+                means, quats, scales, opacities, bthr, cam["viewmat"], cam["K"], W, H, tw, th,
+                dict(scales_exp=scales_exp, opac_sig=opac_sig, radii=radii, means2d=means2d, depths=depths,
+                     conics=conics))
         else:
+            _run(lib.fsgs_project_fwd_act, (1, N, ptr(means), ptr(quats), ptr(scales), ptr(opacities),
+                                           0 if bthr is None else 1, 0.0 if bthr is None else float(bthr),
+                                           ptr(cam["viewmat"]),
+                                           ptr(cam["K"]), W, H, 0.3, 0.01, 1e10, 0.0, ptr(scales_exp), ptr(opac_sig),
+                                           ptr(radii), ptr(means2d), ptr(depths), ptr(conics), sp),
+                 "fsgs_project_fwd_act")
             count = ops.isect_count_live_async(means2d, radii, conics, opac_row, tw, th)
         normals_world = torch.empty(N, 3, **f32)
         packed = torch.empty(N, 16, **f32)

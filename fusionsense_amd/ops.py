@@ -357,6 +357,33 @@ def bin_live_count_async(means2d: Tensor, radii: Tensor, conics: Tensor, opaciti
     return dict(direct=True, tpg=tpg, offsets=offsets, table=table, pinned=pinned, event=ev, T=T)
 
 
+def project_bin_live_count_async(means: Tensor, quats: Tensor, log_scales: Tensor, opac_logit: Tensor,
+                                 binary_threshold, viewmat: Tensor, K: Tensor, width: int, height: int,
+                                 tile_width: int, tile_height: int, out: dict) -> dict:
+    """``fsgs_project_fwd_act`` + ``bin_live_count_async`` in one launch chain (one camera): the count pass projects
+    its Gaussians itself.  ``out`` holds the projection's output tensors (scales_exp, opac_sig, radii [1,N],
+    means2d, depths, conics).  Returns the same state ``bin_live_count_async`` does."""
+    lib = load()
+    dev = means.device
+    N = means.shape[0]
+    T = tile_width * tile_height
+    tpg = torch.empty(1, N, dtype=torch.int32, device=dev)
+    offsets = torch.empty(T + 1, dtype=torch.int32, device=dev)
+    tbytes = lib.fsgs_bin_live_table_bytes(1, N, tile_width, tile_height)
+    table = WORKSPACE.take(tbytes, dev)
+    _run(lib.fsgs_project_bin_live_count,
+         (N, ptr(means), ptr(quats), ptr(log_scales), ptr(opac_logit), 0 if binary_threshold is None else 1,
+          0.0 if binary_threshold is None else float(binary_threshold), ptr(viewmat), ptr(K), width, height, 0.3, 0.01,
+          1e10, 0.0, ptr(out["scales_exp"]), ptr(out["opac_sig"]), ptr(out["radii"]), ptr(out["means2d"]),
+          ptr(out["depths"]), ptr(out["conics"]), tile_width, tile_height, ptr(tpg), ptr(offsets), ptr(table), tbytes,
+          stream_ptr(dev)), "fsgs_isect_count_live")
+    pinned = _pinned_i32(dev)
+    pinned.copy_(offsets[T:T + 1], non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(dev))
+    return dict(direct=True, tpg=tpg, offsets=offsets, table=table, pinned=pinned, event=ev, T=T)
+
+
 def bin_live_finish(st: dict, means2d: Tensor, radii: Tensor, depths: Tensor, conics: Tensor, opacities: Tensor,
                     tile_width: int, tile_height: int):
     """Wait for the live total, then scatter into the tile buckets + sort them.  Returns (tiles_per_gauss,

@@ -319,6 +319,15 @@ size_t fsgs_bin_live_table_bytes(int C, int N, int tile_width, int tile_height);
 int fsgs_bin_live_count(int C, int N, const float *means2d, const int32_t *radii, const float *conics,
                         const float *opacities, int tile_width, int tile_height, int32_t *tiles_per_gauss,
                         int32_t *isect_offsets, void *table_scratch, size_t table_bytes, fsgs_stream_t stream);
+/* fsgs_project_fwd_act (one camera) + fsgs_bin_live_count as one call: the count pass projects its Gaussians itself
+ * (same statements, csrc/project_math.h) and writes the projection's outputs for the later passes. */
+int fsgs_project_bin_live_count(int N, const float *means, const float *quats, const float *log_scales,
+                                float *opac_logit, int binarise, float binary_threshold, const float *viewmat,
+                                const float *K, int width, int height, float eps2d, float near_plane, float far_plane,
+                                float radius_clip, float *scales_out, float *opac_out, int32_t *radii, float *means2d,
+                                float *depths, float *conics, int tile_width, int tile_height,
+                                int32_t *tiles_per_gauss, int32_t *isect_offsets, void *table_scratch,
+                                size_t table_bytes, fsgs_stream_t stream);
 int fsgs_bin_live_emit(int C, int N, const float *means2d, const int32_t *radii, const float *depths,
                        const float *conics, const float *opacities, int tile_width, int tile_height,
                        const int32_t *isect_offsets, const void *table_scratch, int64_t n_live, void *buckets,

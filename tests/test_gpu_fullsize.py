@@ -392,17 +392,27 @@ def test_two_ranks_train_identical_replicas(mode):
     and the collectives on gloo: the whole data-parallel step (view sharding, geometry all-reduce, SH factors or
     gradients exchanged, deferred feature update, flush, barrier + max timing) runs, and after the timed steps both
     ranks hold bit-identical parameters."""
-    import json, os, socket, subprocess, sys
+    import json, os, signal, socket, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     env = dict(os.environ, FSGS_DIST_BACKEND="gloo", FSGS_BENCH_CHECK_REPLICAS="1", FSGS_BENCH_VERBOSE="1",
                FSGS_DEFER_FEATURES="0" if mode == "plain" else "1",
                FSGS_FACTORED_FEATURES="1" if mode == "factored_deferred" else "0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4",
-           "--warmup", "1", "--n-gauss", "20000", "--res", "160", "--views", "4", "--no-cpu-baseline"]
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
-    assert r.returncode == 0, r.stderr[-3000:]
-    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    out = err = ""
+    for attempt in range(2):  # (the launcher's rendezvous on a just-freed port can stall: one retry on a new port)
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+               "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4",
+               "--warmup", "1", "--n-gauss", "20000", "--res", "160", "--views", "4", "--no-cpu-baseline"]
+        p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=root,
+                             start_new_session=True)
+        try:
+            out, err = p.communicate(timeout=150)
+            break
+        except subprocess.TimeoutExpired:
+            os.killpg(p.pid, signal.SIGKILL)  # this launcher's own process group only
+            out, err = p.communicate()
+            assert attempt == 0, "2-rank run hung twice:\n" + err[-3000:]
+    assert p.returncode == 0, err[-3000:]
+    line = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0
-    assert r.stderr.count("replicas identical") == 2, r.stderr[-2000:]
+    assert err.count("replicas identical") == 2, err[-2000:]
