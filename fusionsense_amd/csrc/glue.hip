@@ -51,11 +51,22 @@ max_reduce_kernel(int n, const float *__restrict__ partial, float *__restrict__ 
     }
 }
 
+// LOSS: the depth / normal L1 terms of the training loss (fsgs_aux_l1_fwd_bwd of loss.hip) are evaluated on the
+// pixel this thread has just produced: partial sums per workgroup and the two gradient images, no second pass over
+// the depth and normal images and one launch less (the trainer's tape-free step, which knows targets and loss seed).
+struct EpilogueLoss {
+    const float *depth_gt, *normal_gt, *v_loss;
+    float *partial, *v_depth, *v_normal;
+    float g_depth, g_normal;
+};
+
+template <bool LOSS>
 __global__ void __launch_bounds__(256)
 epilogue_fwd_kernel(int64_t P, const float4 *__restrict__ render, const float *__restrict__ alphas,
                     const float *__restrict__ render_extra, const float *__restrict__ bg,
                     const float *__restrict__ max_last, int n_cells, float *__restrict__ rgb,
-                    float *__restrict__ depth, float *__restrict__ normal) {
+                    float *__restrict__ depth, float *__restrict__ normal, EpilogueLoss L) {
+    __shared__ float red[4];
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const float4 r = (p < P) ? render[p] : make_float4(0.f, 0.f, 0.f, 0.f);
     const float a = (p < P) ? alphas[p] : 1.f;
@@ -66,18 +77,46 @@ epilogue_fwd_kernel(int64_t P, const float4 *__restrict__ render, const float *_
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) fill = fmaxf(fill, __shfl_xor(fill, d, 64));
     }
-    if (p >= P) return;
-    const float t = 1.f - a;
-    rgb[p * 3 + 0] = fminf(fmaxf(r.x + t * bg[0], 0.f), 1.f);
-    rgb[p * 3 + 1] = fminf(fmaxf(r.y + t * bg[1], 0.f), 1.f);
-    rgb[p * 3 + 2] = fminf(fmaxf(r.z + t * bg[2], 0.f), 1.f);
-    depth[p] = (a > 0.f) ? r.w : fill;
-    if (normal) {
-        const float nx = render_extra[p * 3 + 0], ny = render_extra[p * 3 + 1], nz = render_extra[p * 3 + 2];
-        const float inv = 1.f / sqrtf(nx * nx + ny * ny + nz * nz);
-        normal[p * 3 + 0] = (nx * inv + 1.f) * 0.5f;
-        normal[p * 3 + 1] = (ny * inv + 1.f) * 0.5f;
-        normal[p * 3 + 2] = (nz * inv + 1.f) * 0.5f;
+    float sd = 0.f, sn = 0.f;
+    if (p < P) {
+        const float t = 1.f - a;
+        rgb[p * 3 + 0] = fminf(fmaxf(r.x + t * bg[0], 0.f), 1.f);
+        rgb[p * 3 + 1] = fminf(fmaxf(r.y + t * bg[1], 0.f), 1.f);
+        rgb[p * 3 + 2] = fminf(fmaxf(r.z + t * bg[2], 0.f), 1.f);
+        const float dep = (a > 0.f) ? r.w : fill;
+        depth[p] = dep;
+        const float up = LOSS ? L.v_loss[0] : 0.f;
+        if (LOSS) {
+            const float d = dep - L.depth_gt[p];
+            sd = fabsf(d);
+            L.v_depth[p] = up * L.g_depth * ((d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f));
+        }
+        if (normal) {
+            const float nx = render_extra[p * 3 + 0], ny = render_extra[p * 3 + 1], nz = render_extra[p * 3 + 2];
+            const float inv = 1.f / sqrtf(nx * nx + ny * ny + nz * nz);
+            const float nn[3] = {(nx * inv + 1.f) * 0.5f, (ny * inv + 1.f) * 0.5f, (nz * inv + 1.f) * 0.5f};
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                normal[p * 3 + k] = nn[k];
+                if (LOSS && L.normal_gt) {
+                    const float e = nn[k] - L.normal_gt[p * 3 + k];
+                    sn += fabsf(e);
+                    L.v_normal[p * 3 + k] = up * L.g_normal * ((e > 0.f) ? 1.f : ((e < 0.f) ? -1.f : 0.f));
+                }
+            }
+        }
+    }
+    if (LOSS) {  // per-workgroup partial sums, same layout as fsgs_aux_l1_fwd (256 pixels per row)
+        sd = wave_sum_to_last_row(sd);
+        sn = wave_sum_to_last_row(sn);
+        const int tr = threadIdx.x;
+        __shared__ float red2[4];
+        if ((tr & 63) == 63) { red[tr >> 6] = sd; red2[tr >> 6] = sn; }
+        __syncthreads();
+        if (tr == 0) {
+            L.partial[2 * blockIdx.x + 0] = red[0] + red[1] + red[2] + red[3];
+            L.partial[2 * blockIdx.x + 1] = red2[0] + red2[1] + red2[2] + red2[3];
+        }
     }
 }
 
@@ -163,9 +202,28 @@ extern "C" int fsgs_epilogue_fwd(int64_t n_pixels, const float *render, const fl
     if (n_partial > 0)  // n_partial <= 0: max_last already holds max(1, -n_partial) partial maxima (fsgs_raster_fwd_quad)
         hipLaunchKernelGGL(max_reduce_kernel, dim3(1), dim3(1024), 0, s, n_partial, max_last_partial, max_last);
     const int n_cells = n_partial < 0 ? -n_partial : 1;
-    hipLaunchKernelGGL(epilogue_fwd_kernel, dim3(ceil_div(n_pixels, 256)), dim3(256), 0, s, n_pixels,
+    hipLaunchKernelGGL(epilogue_fwd_kernel<false>, dim3(ceil_div(n_pixels, 256)), dim3(256), 0, s, n_pixels,
                        reinterpret_cast<const float4 *>(render), alphas, render_extra, bg, max_last, n_cells, rgb, depth,
-                       normal);
+                       normal, EpilogueLoss{});
+    return check_launch();
+}
+
+// fsgs_epilogue_fwd (max_last = n_cells partial maxima as left by fsgs_raster_fwd_quad) + fsgs_aux_l1_fwd_bwd in one
+// pass: the depth / normal L1 partial sums [ceil(n_pixels / 256), 2] and gradient images come out with the images.
+extern "C" int fsgs_epilogue_loss_fwd(int64_t n_pixels, const float *render, const float *alphas,
+                                      const float *render_extra, const float *bg, const float *max_last, int n_cells,
+                                      float *rgb, float *depth, float *normal, const float *depth_gt,
+                                      const float *normal_gt, const float *v_loss, float g_depth, float g_normal,
+                                      float *partial, float *v_depth, float *v_normal, fsgs_stream_t stream) {
+    if (n_pixels < 0 || n_cells < 1) return FSGS_EINVAL;
+    if (n_pixels == 0) return FSGS_OK;
+    if (!render || !alphas || !bg || !max_last || !rgb || !depth || !depth_gt || !v_loss || !partial || !v_depth)
+        return FSGS_EINVAL;
+    if ((normal && !render_extra) || (normal_gt && (!normal || !v_normal))) return FSGS_EINVAL;
+    const EpilogueLoss L = {depth_gt, normal_gt, v_loss, partial, v_depth, v_normal, g_depth, g_normal};
+    hipLaunchKernelGGL(epilogue_fwd_kernel<true>, dim3(ceil_div(n_pixels, 256)), dim3(256), 0, as_stream(stream),
+                       n_pixels, reinterpret_cast<const float4 *>(render), alphas, render_extra, bg, max_last, n_cells,
+                       rgb, depth, normal, L);
     return check_launch();
 }
 

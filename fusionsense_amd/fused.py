@@ -54,6 +54,10 @@ class FrameInfo:
         # [N + 1,4] buffer: the backward writes the factors of the SH coefficient gradients there INSTEAD of the
         # gradients themselves (trainer's factored exchange, data-parallel runs)
         self.sh_factors_out: Optional[Tensor] = None
+        # {"depth","normal" (or None),"seed","g_depth","g_normal"}: evaluate the depth / normal L1 terms with the
+        # images (fsgs_epilogue_loss_fwd); the results land in aux_loss = (partial sums, v_depth, v_normal)
+        self.loss_targets: Optional[dict] = None
+        self.aux_loss = None
 
     @property
     def flatten_ids(self):
@@ -200,9 +204,24 @@ class _FusedGetOutputs(torch.autograd.Function):
         rgb = torch.empty(H, W, 3, **f32)
         depth = torch.empty(H, W, 1, **f32)
         normal = torch.empty(H, W, 3, **f32)
-        _run(lib.fsgs_epilogue_fwd, (H * W, ptr(render), ptr(alphas), ptr(render_extra), ptr(background),
-                                    None, -n_cells, ptr(max_last), ptr(rgb), ptr(depth),
-                                    ptr(normal), sp), "fsgs_epilogue_fwd")
+        lt = info.loss_targets
+        if lt is not None:
+            # the trainer's tape-free step: the depth / normal L1 terms of its loss are evaluated on the pixels as
+            # they are formed (partial sums + gradient images), no separate pass over the two images
+            P = H * W
+            partial = torch.empty((P + 255) // 256, 2, **f32)
+            v_depth_img = torch.empty(H, W, 1, **f32)
+            v_normal_img = torch.empty(H, W, 3, **f32) if lt.get("normal") is not None else None
+            _run(lib.fsgs_epilogue_loss_fwd, (P, ptr(render), ptr(alphas), ptr(render_extra), ptr(background),
+                                             ptr(max_last), n_cells, ptr(rgb), ptr(depth), ptr(normal),
+                                             ptr(lt["depth"]), ptr(lt.get("normal")), ptr(lt["seed"]),
+                                             float(lt["g_depth"]), float(lt["g_normal"]), ptr(partial),
+                                             ptr(v_depth_img), ptr(v_normal_img), sp), "fsgs_epilogue_fwd")
+            info.aux_loss = (partial, v_depth_img, v_normal_img)
+        else:
+            _run(lib.fsgs_epilogue_fwd, (H * W, ptr(render), ptr(alphas), ptr(render_extra), ptr(background),
+                                        None, -n_cells, ptr(max_last), ptr(rgb), ptr(depth),
+                                        ptr(normal), sp), "fsgs_epilogue_fwd")
 
         info.radii, info.means2d, info.depths, info.conics = radii, means2d, depths, conics
         info.tiles_per_gauss, info.isect_ids, info.payload = tpg, isect_ids, flatten_ids
@@ -385,6 +404,10 @@ def fused_step_forward_backward(gauss_params: Dict[str, Tensor], camera: Camera,
     if add_mask is not None:
         info.frozen = add_mask.to(device=dev, dtype=torch.uint8).contiguous()
     has_n = "normal" in target
+    n_pix = camera.width * camera.height
+    info.loss_targets = dict(depth=target["depth"].contiguous(), normal=target["normal"].contiguous() if has_n else None,
+                             seed=seed_grad, g_depth=float(w_depth) / n_pix,
+                             g_normal=float(w_normal) / (3.0 * n_pix) if has_n else 0.0)
     with torch.no_grad():
         ctx = _DirectCtx((True,) * 6 + (False,) * 7)
         rgb, depth, normal, alpha = _FusedGetOutputs.forward(
@@ -394,7 +417,7 @@ def fused_step_forward_backward(gauss_params: Dict[str, Tensor], camera: Camera,
         lctx = _DirectCtx((True, False, True, False, has_n, False, False, False, False))
         loss = ops._TrainLoss.forward(lctx, rgb, target["rgb"], depth, target["depth"], normal if has_n else None,
                                       target["normal"] if has_n else None, float(ssim_lambda), float(w_depth),
-                                      float(w_normal), seed=seed_grad)
+                                      float(w_normal), seed=seed_grad, aux_done=info.aux_loss)
         v = ops._TrainLoss.backward(lctx, seed_grad)
         _FusedGetOutputs.backward(ctx, v[0], v[2], v[4], None)
     out = {"rgb": rgb, "depth": depth, "normal": normal, "accumulation": alpha, "background": background,

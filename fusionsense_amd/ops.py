@@ -920,7 +920,8 @@ class _TrainLoss(torch.autograd.Function):
     one combine launch forward, two kernels backward, no torch glue in between."""
 
     @staticmethod
-    def forward(ctx, rgb, rgb_gt, depth, depth_gt, normal, normal_gt, ssim_lambda, w_depth, w_normal, seed=None):
+    def forward(ctx, rgb, rgb_gt, depth, depth_gt, normal, normal_gt, ssim_lambda, w_depth, w_normal, seed=None,
+                aux_done=None):
         """seed: the upstream gradient of the loss (1-element device tensor) when the caller knows it already
         (the trainer's tape-free step): the depth / normal gradient images are then written by the forward's
         own pass over those images and ``backward`` skips its aux launch."""
@@ -933,13 +934,17 @@ class _TrainLoss(torch.autograd.Function):
         sums = torch.empty(lib.fsgs_ssim_l1_num_partials(H, W), 2, dtype=torch.float32, device=dev)
         _run(lib.fsgs_ssim_l1_fwd, (H, W, ptr(rgb), ptr(rgb_gt), maps[0].data_ptr(), maps[1].data_ptr(),
                                     maps[2].data_ptr(), ptr(sums), stream_ptr(dev)), "fsgs_ssim_l1_fwd")
-        partial = torch.empty((P + 255) // 256, 2, dtype=torch.float32, device=dev)
+        partial = None if aux_done is not None else torch.empty((P + 255) // 256, 2, dtype=torch.float32, device=dev)
         g_l1 = (1.0 - ssim_lambda) / (3.0 * H * W)
         g_ssim = -ssim_lambda / (3.0 * (H - 10) * (W - 10))
         g_d = w_depth / P
         g_n = w_normal / (3.0 * P) if normal is not None else 0.0
         ctx.aux_grads = None
-        if seed is not None:
+        if aux_done is not None and seed is not None:
+            # the depth / normal terms were evaluated with the images (fsgs_epilogue_loss_fwd, same weights and seed)
+            partial, v_depth, v_normal = aux_done
+            ctx.aux_grads = (seed, v_depth, v_normal)
+        elif seed is not None:
             v_depth = torch.empty_like(depth)
             v_normal = torch.empty_like(normal) if normal is not None else None
             _run(lib.fsgs_aux_l1_fwd_bwd, (P, ptr(depth), ptr(depth_gt), ptr(normal), ptr(normal_gt), ptr(partial),
@@ -978,14 +983,14 @@ class _TrainLoss(torch.autograd.Function):
         _run(lib.fsgs_ssim_l1_bwd, (H, W, ptr(rgb), ptr(rgb_gt), maps[0].data_ptr(), maps[1].data_ptr(),
                                     maps[2].data_ptr(), ptr(v_loss), g_l1, g_ssim, ptr(v_rgb),
                                     stream_ptr(dev)), "fsgs_ssim_l1_bwd")
-        return v_rgb, None, v_depth, None, v_normal, None, None, None, None, None
+        return v_rgb, None, v_depth, None, v_normal, None, None, None, None, None, None
 
 
 def train_loss(rgb: Tensor, rgb_gt: Tensor, depth: Tensor, depth_gt: Tensor, normal: Optional[Tensor],
                normal_gt: Optional[Tensor], ssim_lambda: float = 0.2, w_depth: float = 0.2,
                w_normal: float = 0.1) -> Tensor:
     return _TrainLoss.apply(rgb, rgb_gt, depth, depth_gt, normal, normal_gt, float(ssim_lambda),
-                            float(w_depth), float(w_normal), None)
+                            float(w_depth), float(w_normal), None, None)
 
 
 def adam_step_(params, grads, exp_avgs, exp_avg_sqs, lrs, step: int, beta1: float = 0.9, beta2: float = 0.999,

@@ -428,6 +428,14 @@ int fsgs_epilogue_fwd(int64_t n_pixels, const float *render, const float *alphas
                       const float *render_extra, const float *bg, const float *max_last_partial,
                       int n_partial, float *max_last, float *rgb, float *depth, float *normal,
                       fsgs_stream_t stream);
+/* fsgs_epilogue_fwd (max_last = n_cells partial image maxima, as fsgs_raster_fwd_quad leaves them) and
+ * fsgs_aux_l1_fwd_bwd in one pass over the pixels, for a caller that knows the targets and the upstream gradient of
+ * the loss when the images are formed: partial [ceil(n_pixels / 256), 2], v_depth, v_normal as there. */
+int fsgs_epilogue_loss_fwd(int64_t n_pixels, const float *render, const float *alphas, const float *render_extra,
+                           const float *bg, const float *max_last, int n_cells, float *rgb, float *depth,
+                           float *normal, const float *depth_gt, const float *normal_gt, const float *v_loss,
+                           float g_depth, float g_normal, float *partial, float *v_depth, float *v_normal,
+                           fsgs_stream_t stream);
 int fsgs_epilogue_bwd(int64_t n_pixels, const float *render, const float *alphas,
                       const float *render_extra, const float *bg, const float *v_rgb,
                       const float *v_depth, const float *v_normal, const float *v_alpha_in,
