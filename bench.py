@@ -218,9 +218,11 @@ def main():
     torch.cuda.synchronize()
     n_alloc0 = torch.cuda.memory_stats(dev).get('num_device_alloc', 0)
     t0 = time.perf_counter()
+    step_ends = []
     for s in range(args.steps):
         v = view_of(args.warmup + s)
         trainer.train_step(cams[v], targets[v])
+        step_ends.append(time.perf_counter())  # (every step waits for its live-pair count: host time tracks the GPU)
     trainer.flush()  # (data-parallel runs: the last step's deferred feature update belongs to the timed work)
     torch.cuda.synchronize()
     barrier()
@@ -353,6 +355,8 @@ def main():
             "iter_algorithmic_bytes": b_iter,
             "iter_hbm_frac": round(b_iter / (elapsed / args.steps) / (HBM_PEAK_GBS * 1e9), 5),
             "device_mallocs_in_timed_region": n_alloc,
+            "max_step_ms": round(1e3 * max(b - a for a, b in zip([t0] + step_ends[:-1], step_ends)), 3),
+            "slowest_step": max(range(len(step_ends)), key=lambda i: step_ends[i] - ([t0] + step_ends)[i]),
             "kernels_ms": kernel_ms,
             "roofline": roofline,
         }

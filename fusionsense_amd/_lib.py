@@ -89,6 +89,7 @@ SIGNATURES = {
     "fsgs_aux_l1_bwd": (_i, [_i64, _p, _p, _p, _p, _p, _f, _f, _p, _p, _p]),
     "fsgs_aux_l1_fwd_bwd": (_i, [_i64, _p, _p, _p, _p, _p, _p, _f, _f, _p, _p, _p]),
     "fsgs_ssim_l1_bwd": (_i, [_i, _i, _p, _p, _p, _p, _p, _p, _f, _f, _p, _p]),
+    "fsgs_ssim_l1_bwd_combine": (_i, [_i, _i, _p, _p, _p, _p, _p, _p, _f, _f, _p, _i, _p, _p, _p, _f, _p, _p]),
     "fsgs_loss_combine": (_i, [_i, _p, _p, _p, _f, _p, _p]),
 }
 

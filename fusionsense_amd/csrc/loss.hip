@@ -160,14 +160,58 @@ ssim_l1_fwd_kernel(int H, int W, const float *__restrict__ pred, const float *__
     }
 }
 
+// out[0] = bias + sum_t (w[2t] * colsum0(partials_t) + w[2t+1] * colsum1(partials_t)): the scalar loss
+// from the per-workgroup partials of up to four fused terms, in one launch and without a host sync.
+constexpr int kCombineMaxTerms = 4;
+struct CombineArgs {
+    const float *partials[kCombineMaxTerms];
+    long long rows[kCombineMaxTerms];
+    float w[2 * kCombineMaxTerms];
+    int n_terms;
+    float bias;
+};
+
+// the combine on THREADS threads of one workgroup (f64 accumulation)
+template <int THREADS>
+__device__ __forceinline__ void combine_partials(const CombineArgs &a, float *__restrict__ out, double *red) {
+    double acc = 0.0;
+    for (int t = 0; t < a.n_terms; ++t) {
+        const float2 *p = reinterpret_cast<const float2 *>(a.partials[t]);
+        const float w0 = a.w[2 * t], w1 = a.w[2 * t + 1];
+        double s0 = 0.0, s1 = 0.0;
+        for (long long r = threadIdx.x; r < a.rows[t]; r += THREADS) {
+            const float2 v = p[r];
+            s0 += v.x;
+            s1 += v.y;
+        }
+        acc += s0 * (double)w0 + s1 * (double)w1;
+    }
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) acc += __shfl_xor(acc, s, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double tot = 0.0;
+        for (int k = 0; k < THREADS / 64; ++k) tot += red[k];
+        out[0] = (float)(tot + (double)a.bias);
+    }
+}
+
 // v_pred = g_l1 * sign(pred-gt) + g_ssim * (G*dm_dmu1 + 2 pred G*dm_dsigma1 + gt G*dm_dsigma12)
 __global__ void __launch_bounds__(256)
 ssim_l1_bwd_kernel(int H, int W, const float *__restrict__ pred, const float *__restrict__ gt,
                    const float *__restrict__ dm_dmu1, const float *__restrict__ dm_dsigma1,
                    const float *__restrict__ dm_dsigma12, const float *__restrict__ v_loss, float g_l1,
-                   float g_ssim, float *__restrict__ v_pred) {
+                   float g_ssim, float *__restrict__ v_pred, CombineArgs comb, float *__restrict__ loss_out) {
     __shared__ float sm[3][kLH][kLP];
     __shared__ float hb[3][kLH][kLQ];
+    __shared__ double comb_red[4];
+    if (blockIdx.z == 3) {
+        // a fourth z-slice (when launched): one workgroup of it combines the loss partials into the scalar loss —
+        // the value is only reported, so it rides in this launch instead of one of its own
+        if (blockIdx.x == 0 && blockIdx.y == 0) combine_partials<256>(comb, loss_out, comb_red);
+        return;
+    }
     const int ch = blockIdx.z;
     const int x0 = blockIdx.x * kLT, y0 = blockIdx.y * kLT;
     const int tr = threadIdx.x;
@@ -320,40 +364,9 @@ aux_l1_bwd_kernel(int64_t P, const float *__restrict__ depth, const float *__res
     }
 }
 
-// out[0] = bias + sum_t (w[2t] * colsum0(partials_t) + w[2t+1] * colsum1(partials_t)): the scalar loss
-// from the per-workgroup partials of up to four fused terms, in one launch and without a host sync.
-constexpr int kCombineMaxTerms = 4;
-struct CombineArgs {
-    const float *partials[kCombineMaxTerms];
-    long long rows[kCombineMaxTerms];
-    float w[2 * kCombineMaxTerms];
-    int n_terms;
-    float bias;
-};
-
 __global__ void __launch_bounds__(1024) loss_combine_kernel(CombineArgs a, float *__restrict__ out) {
     __shared__ double red[16];
-    double acc = 0.0;
-    for (int t = 0; t < a.n_terms; ++t) {
-        const float2 *p = reinterpret_cast<const float2 *>(a.partials[t]);
-        const float w0 = a.w[2 * t], w1 = a.w[2 * t + 1];
-        double s0 = 0.0, s1 = 0.0;
-        for (long long r = threadIdx.x; r < a.rows[t]; r += 1024) {
-            const float2 v = p[r];
-            s0 += v.x;
-            s1 += v.y;
-        }
-        acc += s0 * (double)w0 + s1 * (double)w1;
-    }
-#pragma unroll
-    for (int s = 32; s >= 1; s >>= 1) acc += __shfl_xor(acc, s, 64);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double tot = 0.0;
-        for (int k = 0; k < 16; ++k) tot += red[k];
-        out[0] = (float)(tot + (double)a.bias);
-    }
+    combine_partials<1024>(a, out, red);
 }
 
 }  // namespace fsgs
@@ -434,6 +447,41 @@ extern "C" int fsgs_ssim_l1_bwd(int H, int W, const float *pred, const float *gt
     if (!pred || !gt || !dm_dmu1 || !dm_dsigma1 || !dm_dsigma12 || !v_loss || !v_pred) return FSGS_EINVAL;
     hipLaunchKernelGGL(ssim_l1_bwd_kernel, dim3(ceil_div(W, kLT), ceil_div(H, kLT), 3), dim3(256), 0,
                        as_stream(stream), H, W, pred, gt, dm_dmu1, dm_dsigma1, dm_dsigma12, v_loss, g_l1,
-                       g_ssim, v_pred);
+                       g_ssim, v_pred, CombineArgs{}, nullptr);
+    return check_launch();
+}
+
+static int fill_combine_args(CombineArgs &a, int n_terms, const float *const *partials, const int64_t *rows,
+                             const float *weights, float bias) {
+    if (n_terms < 0 || n_terms > kCombineMaxTerms) return FSGS_EINVAL;
+    if (n_terms && (!partials || !rows || !weights)) return FSGS_EINVAL;
+    for (int t = 0; t < kCombineMaxTerms; ++t) {
+        const bool on = t < n_terms;
+        if (on && (rows[t] < 0 || (rows[t] > 0 && !partials[t]))) return FSGS_EINVAL;
+        a.partials[t] = on ? partials[t] : nullptr;
+        a.rows[t] = on ? rows[t] : 0;
+        a.w[2 * t] = on ? weights[2 * t] : 0.f;
+        a.w[2 * t + 1] = on ? weights[2 * t + 1] : 0.f;
+    }
+    a.n_terms = n_terms;
+    a.bias = bias;
+    return FSGS_OK;
+}
+
+// fsgs_ssim_l1_bwd + fsgs_loss_combine in one launch (the scalar loss is only reported: one workgroup of an extra
+// grid slice sums the partials while the others run the backward)
+extern "C" int fsgs_ssim_l1_bwd_combine(int H, int W, const float *pred, const float *gt, const float *dm_dmu1,
+                                        const float *dm_dsigma1, const float *dm_dsigma12, const float *v_loss,
+                                        float g_l1, float g_ssim, float *v_pred, int n_terms,
+                                        const float *const *partials, const int64_t *rows, const float *weights,
+                                        float bias, float *loss_out, fsgs_stream_t stream) {
+    if (H < 11 || W < 11) return FSGS_EINVAL;
+    if (!pred || !gt || !dm_dmu1 || !dm_dsigma1 || !dm_dsigma12 || !v_loss || !v_pred || !loss_out) return FSGS_EINVAL;
+    CombineArgs a;
+    const int rc = fill_combine_args(a, n_terms, partials, rows, weights, bias);
+    if (rc != FSGS_OK) return rc;
+    hipLaunchKernelGGL(ssim_l1_bwd_kernel, dim3(ceil_div(W, kLT), ceil_div(H, kLT), 4), dim3(256), 0,
+                       as_stream(stream), H, W, pred, gt, dm_dmu1, dm_dsigma1, dm_dsigma12, v_loss, g_l1,
+                       g_ssim, v_pred, a, loss_out);
     return check_launch();
 }

@@ -914,6 +914,9 @@ def aux_l1_loss(depth: Tensor, depth_gt: Tensor, normal: Optional[Tensor], norma
     return _AuxL1Loss.apply(depth, depth_gt, normal, normal_gt, float(w_depth), float(w_normal))
 
 
+DEFER_COMBINE = os.environ.get("FSGS_DEFER_COMBINE", "1") != "0"
+
+
 class _TrainLoss(torch.autograd.Function):
     """The whole config-#2 training loss as ONE autograd node:
     (1-l)*L1(rgb) + l*(1-SSIM11(rgb)) + w_d*L1(depth) + w_n*L1(normal)  — two partial-sum kernels and
@@ -958,6 +961,12 @@ class _TrainLoss(torch.autograd.Function):
                               normal if normal is not None else torch.empty(0, device=dev),
                               normal_gt if normal_gt is not None else torch.empty(0, device=dev))
         ctx.g = (g_l1, g_ssim, g_d, g_n, normal is not None)
+        ctx.deferred_loss = None
+        if seed is not None and DEFER_COMBINE:
+            # tape-free step: the scalar is only reported, its combine rides in the backward's SSIM launch
+            out = torch.empty((), dtype=torch.float32, device=dev)
+            ctx.deferred_loss = (out, sums, partial, ssim_lambda)
+            return out
         return loss_combine([sums, partial], [(g_l1, g_ssim), (g_d, g_n)], ssim_lambda)
 
     @staticmethod
@@ -980,9 +989,21 @@ class _TrainLoss(torch.autograd.Function):
             _run(lib.fsgs_aux_l1_bwd, (P, ptr(depth), ptr(depth_gt), ptr(normal) if has_n else None,
                                        ptr(normal_gt) if has_n else None, ptr(v_loss), g_d, g_n, ptr(v_depth),
                                        ptr(v_normal), stream_ptr(dev)), "fsgs_aux_l1_bwd")
-        _run(lib.fsgs_ssim_l1_bwd, (H, W, ptr(rgb), ptr(rgb_gt), maps[0].data_ptr(), maps[1].data_ptr(),
-                                    maps[2].data_ptr(), ptr(v_loss), g_l1, g_ssim, ptr(v_rgb),
-                                    stream_ptr(dev)), "fsgs_ssim_l1_bwd")
+        dl = getattr(ctx, "deferred_loss", None)
+        if dl is not None:
+            out, sums, partial, ssim_lambda = dl
+            ctx.deferred_loss = None
+            VP = C.c_void_p * 2
+            rows = (C.c_int64 * 2)(sums.shape[0], partial.shape[0])
+            w = (C.c_float * 4)(g_l1, g_ssim, g_d, g_n)
+            _run(lib.fsgs_ssim_l1_bwd_combine, (H, W, ptr(rgb), ptr(rgb_gt), maps[0].data_ptr(), maps[1].data_ptr(),
+                                                maps[2].data_ptr(), ptr(v_loss), g_l1, g_ssim, ptr(v_rgb), 2,
+                                                VP(sums.data_ptr(), partial.data_ptr()), rows, w, float(ssim_lambda),
+                                                ptr(out), stream_ptr(dev)), "fsgs_ssim_l1_bwd")
+        else:
+            _run(lib.fsgs_ssim_l1_bwd, (H, W, ptr(rgb), ptr(rgb_gt), maps[0].data_ptr(), maps[1].data_ptr(),
+                                        maps[2].data_ptr(), ptr(v_loss), g_l1, g_ssim, ptr(v_rgb),
+                                        stream_ptr(dev)), "fsgs_ssim_l1_bwd")
         return v_rgb, None, v_depth, None, v_normal, None, None, None, None, None, None
 
 

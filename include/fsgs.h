@@ -460,6 +460,12 @@ int fsgs_ssim_l1_fwd(int H, int W, const float *pred, const float *gt, float *dm
 int fsgs_ssim_l1_bwd(int H, int W, const float *pred, const float *gt, const float *dm_dmu1,
                      const float *dm_dsigma1, const float *dm_dsigma12, const float *v_loss,
                      float g_l1, float g_ssim, float *v_pred, fsgs_stream_t stream);
+/* fsgs_ssim_l1_bwd and fsgs_loss_combine in one launch (arguments of both). */
+int fsgs_ssim_l1_bwd_combine(int H, int W, const float *pred, const float *gt, const float *dm_dmu1,
+                             const float *dm_dsigma1, const float *dm_dsigma12, const float *v_loss, float g_l1,
+                             float g_ssim, float *v_pred, int n_terms, const float *const *partials,
+                             const int64_t *rows, const float *weights, float bias, float *loss_out,
+                             fsgs_stream_t stream);
 
 /* Auxiliary L1 terms on the depth [P] and normal [P,3] images (normal nullable), fused:
  * fwd: partial[ceil(P/256), 2] per-workgroup sums of |depth-gt| and |normal-gt|;
