@@ -21,7 +21,8 @@ SPAN = [
     ("ssim_l1_fwd_kernel", "ssim_l1_fwd"), ("ssim_l1_bwd_kernel", "ssim_l1_bwd"),
     ("project_bwd_kernel<true>", "gaussian_bwd"), ("project_fwd_kernel<true>", "project_fwd_act"),
     ("isect_live_flat_kernel<false>", "isect_count_live"), ("isect_live_flat_kernel<true>", "isect_emit_live"),
-    ("isect_live_bin_kernel<false>", "isect_count_live"), ("isect_live_bin_kernel<true>", "tile_sort"),
+    ("isect_live_bin_kernel<false", "isect_count_live"), ("isect_live_bin_kernel<true", "tile_sort"),
+    ("tile_scan_rows_kernel", "isect_count_live"),
     ("live_pack_kernel", "live_pack_normals_d4e3"),
 ]
 
