@@ -1,5 +1,6 @@
 // Projection math shared by project.hip and the direct-binning count pass of isect.hip (E2):
-// one Gaussian, one camera.  Same statements in both callers, so both produce the same numbers.
+// one Gaussian, one camera.  Same statements in both callers; the compiler schedules / contracts them differently in
+// the two kernels, so the conics agree to rounding (~1e-6 relative, both within 1e-6 of an f64 evaluation), not to the bit.
 #pragma once
 #include "common.h"
 

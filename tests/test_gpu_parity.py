@@ -727,3 +727,162 @@ def test_fused_adam_matches_torch(dev):
             assert (p - r.detach()).abs().max().item() < 2e-6, step
             assert rel_err(ms[k], o.state[r]["exp_avg"]) < 1e-5
             assert rel_err(vs[k], o.state[r]["exp_avg_sq"]) < 1e-5
+
+
+def test_folded_entry_points_equal_the_chains_they_replace(dev):
+    """Every launch-saving entry point of the fused step against the calls it folds, on one frame of a cube scene
+    (some Gaussians off screen or too small; covered and empty pixels), through the C-ABI:
+      fsgs_project_bin_live_count  ==  fsgs_project_fwd_act + fsgs_bin_live_count           (projection to rounding,
+                                                                                             counts bit for bit)
+      fsgs_sh_fwd_pack             ==  fsgs_sh_fwd_split + fsgs_live_pack_normals           (to rounding)
+      fsgs_epilogue_loss_fwd       ==  fsgs_epilogue_fwd + fsgs_aux_l1_fwd_bwd              (to rounding)
+      fsgs_ssim_l1_bwd_combine     ==  fsgs_ssim_l1_bwd + fsgs_loss_combine                 (gradient bit for bit)
+      fsgs_raster_bwd_quad_images  ==  fsgs_epilogue_bwd + fsgs_raster_bwd_quad             (float atomics: 1e-5)"""
+    import ctypes as C
+    from fusionsense_amd import ops
+    from fusionsense_amd._lib import load, ptr, stream_ptr
+    from fusionsense_amd.fused import _camera_on_device
+    lib = load()
+    sp = stream_ptr(dev)
+    params, cam = scenes.cube_scene(3000, seed=7)
+    P = {k: v.clone() for k, v in params.items()}
+    P["means"][:40] *= 6.0        # some Gaussians off screen / behind the camera
+    P["scales"][40:60] -= 3.0     # some below the radius threshold
+    P = {k: v.to(dev).contiguous() for k, v in P.items()}
+    N, K = P["means"].shape[0], 1 + P["features_rest"].shape[1]
+    W, H = cam.width, cam.height
+    tw, th = math.ceil(W / 16), math.ceil(H / 16)
+    T = tw * th
+    cd = _camera_on_device(cam, dev)
+    f32 = dict(dtype=torch.float32, device=dev)
+
+    def proj_bufs():
+        return dict(scales_exp=torch.empty(N, 3, **f32), opac_sig=torch.empty(N, **f32),
+                    radii=torch.empty(1, N, dtype=torch.int32, device=dev), means2d=torch.empty(1, N, 2, **f32),
+                    depths=torch.empty(1, N, **f32), conics=torch.empty(1, N, 3, **f32))
+
+    # ---- projection + count ------------------------------------------------------------------------------
+    a, b = proj_bufs(), proj_bufs()
+    opl_a, opl_b = P["opacities"].clone(), P["opacities"].clone()
+    assert lib.fsgs_project_fwd_act(1, N, ptr(P["means"]), ptr(P["quats"]), ptr(P["scales"]), ptr(opl_a), 1, 0.1,
+                                    ptr(cd["viewmat"]), ptr(cd["K"]), W, H, 0.3, 0.01, 1e10, 0.0, ptr(a["scales_exp"]),
+                                    ptr(a["opac_sig"]), ptr(a["radii"]), ptr(a["means2d"]), ptr(a["depths"]),
+                                    ptr(a["conics"]), sp) == 0
+    st_a = ops.bin_live_count_async(a["means2d"], a["radii"], a["conics"], a["opac_sig"].view(1, N), tw, th)
+    st_b = ops.project_bin_live_count_async(P["means"], P["quats"], P["scales"], opl_b, 0.1, cd["viewmat"], cd["K"],
+                                            W, H, tw, th, b)
+    torch.cuda.synchronize()
+    assert torch.equal(opl_a, opl_b), "binary-opacity write on the parameter"
+    for k in ("scales_exp", "opac_sig", "radii", "depths"):
+        assert torch.equal(a[k], b[k]), k
+    # the projection is the same statements inlined into two kernels: equal to rounding, not to the bit
+    assert (a["means2d"] - b["means2d"]).abs().max().item() <= 1e-4
+    assert rel_err(b["conics"], a["conics"]) < 1e-5
+    assert torch.equal(st_a["tpg"], st_b["tpg"])
+    assert int((a["radii"] > 0).sum()) > 1000
+    # its counts are those of the stand-alone count pass on ITS projection, bit for bit
+    st_c = ops.bin_live_count_async(b["means2d"], b["radii"], b["conics"], b["opac_sig"].view(1, N), tw, th)
+    torch.cuda.synchronize()
+    assert torch.equal(st_c["tpg"], st_b["tpg"]) and torch.equal(st_c["offsets"], st_b["offsets"])
+    rc = ops.bin_live_finish(st_c, b["means2d"], b["radii"], b["depths"], b["conics"], b["opac_sig"].view(1, N), tw, th)
+    rb = ops.bin_live_finish(st_b, b["means2d"], b["radii"], b["depths"], b["conics"], b["opac_sig"].view(1, N), tw, th)
+    assert torch.equal(rc[2], rb[2])
+    ra = ops.bin_live_finish(st_a, a["means2d"], a["radii"], a["depths"], a["conics"], a["opac_sig"].view(1, N), tw, th)
+    payload, offsets = ra[2], st_a["offsets"]
+    M = payload.numel()
+
+    # ---- SH colours + packing ---------------------------------------------------------------------------
+    n_cells = lib.fsgs_raster_quad_max_cells()
+    colors = torch.empty(1, N, 4, **f32)
+    pk_a, pk_b = torch.empty(N, 16, **f32), torch.empty(N, 16, **f32)
+    nw_a, nw_b = torch.empty(N, 3, **f32), torch.empty(N, 3, **f32)
+    mx_a, mx_b = torch.full((n_cells,), 7.0, **f32), torch.full((n_cells,), 7.0, **f32)
+    assert lib.fsgs_sh_fwd_split(1, N, K, 3, ptr(P["means"]), ptr(cd["campos"]), ptr(P["features_dc"]),
+                                 ptr(P["features_rest"]), ptr(a["radii"]), ptr(a["depths"]), ptr(colors), sp) == 0
+    assert lib.fsgs_live_pack_normals(N, ptr(a["means2d"]), ptr(a["conics"]), ptr(colors), ptr(a["opac_sig"]),
+                                      ptr(P["quats"]), ptr(P["scales"]), ptr(P["means"]), ptr(cd["c2w"]), ptr(pk_a),
+                                      ptr(nw_a), ptr(mx_a), n_cells, sp) == 0
+    assert lib.fsgs_sh_fwd_pack(N, K, 3, ptr(P["means"]), ptr(cd["campos"]), ptr(P["features_dc"]),
+                                ptr(P["features_rest"]), ptr(a["radii"]), ptr(a["depths"]), ptr(a["means2d"]),
+                                ptr(a["conics"]), ptr(a["opac_sig"]), ptr(P["quats"]), ptr(P["scales"]), ptr(cd["c2w"]),
+                                ptr(pk_b), ptr(nw_b), ptr(mx_b), n_cells, sp) == 0
+    assert torch.equal(pk_a[:, :8], pk_b[:, :8]) and torch.equal(mx_a, mx_b)  # copied fields: centre, opacity, conic
+    # colours and normals are the same statements compiled into another kernel: equal to rounding
+    assert (pk_a[:, 8:] - pk_b[:, 8:]).abs().max().item() <= 2e-6 and (nw_a - nw_b).abs().max().item() <= 2e-6
+
+    # ---- forward compositing (shared), then epilogue (+ aux loss) ---------------------------------------------
+    cap = lib.fsgs_quad_stream_capacity(1, tw, th, M)
+    records = torch.empty(4 * cap * 16, **f32)
+    seg_state = torch.empty(4 * lib.fsgs_quad_seg_slots(1, tw, th, M) * 64 * 8, **f32)
+    n_rec = torch.empty(4 * T, dtype=torch.int32, device=dev)
+    render, alphas = torch.empty(1, H, W, 4, **f32), torch.empty(1, H, W, 1, **f32)
+    last_ids = torch.empty(1, H, W, dtype=torch.int32, device=dev)
+    extra = torch.empty(1, H, W, 3, **f32)
+    assert lib.fsgs_raster_fwd_quad(1, 4, ptr(pk_a), ptr(payload), ptr(offsets), M, None, W, H, tw, th, 1, ptr(render),
+                                    ptr(alphas), ptr(last_ids), ptr(records), ptr(n_rec), ptr(seg_state), ptr(extra),
+                                    ptr(mx_a), sp) == 0
+    g = torch.Generator().manual_seed(3)
+    bg = torch.tensor([1.0, 0.5, 0.25], device=dev)
+    depth_gt, normal_gt = torch.rand(H, W, 1, generator=g).to(dev), torch.rand(H, W, 3, generator=g).to(dev)
+    seed = torch.tensor(0.75, device=dev)
+    Pn = H * W
+    gd, gn = 0.2 / Pn, 0.1 / (3 * Pn)
+
+    def imgs():
+        return torch.empty(H, W, 3, **f32), torch.empty(H, W, 1, **f32), torch.empty(H, W, 3, **f32)
+    rgb_a, dep_a, nrm_a = imgs()
+    rgb_b, dep_b, nrm_b = imgs()
+    part_a, part_b = torch.empty((Pn + 255) // 256, 2, **f32), torch.empty((Pn + 255) // 256, 2, **f32)
+    vd_a, vd_b = torch.empty(H, W, 1, **f32), torch.empty(H, W, 1, **f32)
+    vn_a, vn_b = torch.empty(H, W, 3, **f32), torch.empty(H, W, 3, **f32)
+    assert lib.fsgs_epilogue_fwd(Pn, ptr(render), ptr(alphas), ptr(extra), ptr(bg), None, -n_cells, ptr(mx_a), ptr(rgb_a),
+                                 ptr(dep_a), ptr(nrm_a), sp) == 0
+    assert lib.fsgs_aux_l1_fwd_bwd(Pn, ptr(dep_a), ptr(depth_gt), ptr(nrm_a), ptr(normal_gt), ptr(part_a), ptr(seed), gd,
+                                   gn, ptr(vd_a), ptr(vn_a), sp) == 0
+    assert lib.fsgs_epilogue_loss_fwd(Pn, ptr(render), ptr(alphas), ptr(extra), ptr(bg), ptr(mx_a), n_cells, ptr(rgb_b),
+                                      ptr(dep_b), ptr(nrm_b), ptr(depth_gt), ptr(normal_gt), ptr(seed), gd, gn,
+                                      ptr(part_b), ptr(vd_b), ptr(vn_b), sp) == 0
+    # (another instantiation of the same statements: images equal to rounding; the gradient images are signs, so
+    # they can differ only where prediction and target agree to the last bit)
+    for x, y in ((rgb_a, rgb_b), (dep_a, dep_b), (nrm_a, nrm_b)):
+        assert (x - y).abs().max().item() <= 2e-6
+    assert rel_err(part_b, part_a) < 1e-5
+    for x, y in ((vd_a, vd_b), (vn_a, vn_b)):
+        assert float((x != y).float().mean()) < 1e-3
+    assert float(alphas.max()) > 0.5 and bool((alphas == 0).any()), "covered and empty pixels (the depth fill path)"
+
+    # ---- SSIM backward (+ loss combine) ------------------------------------------------------------------
+    rgb_gt = torch.rand(H, W, 3, generator=g).to(dev)
+    maps = torch.empty(3, H, W, 3, **f32)
+    sums = torch.empty(lib.fsgs_ssim_l1_num_partials(H, W), 2, **f32)
+    assert lib.fsgs_ssim_l1_fwd(H, W, ptr(rgb_a), ptr(rgb_gt), maps[0].data_ptr(), maps[1].data_ptr(),
+                                maps[2].data_ptr(), ptr(sums), sp) == 0
+    g1, gs = 0.8 / (3 * Pn), -0.2 / (3.0 * (H - 10) * (W - 10))
+    vr_a, vr_b = torch.empty(H, W, 3, **f32), torch.empty(H, W, 3, **f32)
+    assert lib.fsgs_ssim_l1_bwd(H, W, ptr(rgb_a), ptr(rgb_gt), maps[0].data_ptr(), maps[1].data_ptr(),
+                                maps[2].data_ptr(), ptr(seed), g1, gs, ptr(vr_a), sp) == 0
+    loss_a = ops.loss_combine([sums, part_a], [(g1, gs), (gd, gn)], 0.2)
+    loss_b = torch.empty((), **f32)
+    VP = C.c_void_p * 2
+    rows = (C.c_int64 * 2)(sums.shape[0], part_a.shape[0])
+    w = (C.c_float * 4)(g1, gs, gd, gn)
+    assert lib.fsgs_ssim_l1_bwd_combine(H, W, ptr(rgb_a), ptr(rgb_gt), maps[0].data_ptr(), maps[1].data_ptr(),
+                                        maps[2].data_ptr(), ptr(seed), g1, gs, ptr(vr_b), 2,
+                                        VP(sums.data_ptr(), part_a.data_ptr()), rows, w, 0.2, ptr(loss_b), sp) == 0
+    assert torch.equal(vr_a, vr_b)
+    assert abs(float(loss_a) - float(loss_b)) <= 1e-6 * abs(float(loss_a))  # (f64 sums in a different order)
+
+    # ---- backward compositing from the image gradients -----------------------------------------------------------
+    v_alpha = torch.randn(H, W, 1, generator=g).to(dev) * 1e-3
+    v_render, v_alphas, v_extra = torch.empty(1, H, W, 4, **f32), torch.empty(1, H, W, 1, **f32), torch.empty(1, H, W, 3, **f32)
+    assert lib.fsgs_epilogue_bwd(Pn, ptr(render), ptr(alphas), ptr(extra), ptr(bg), ptr(vr_a), ptr(vd_a), ptr(vn_a),
+                                 ptr(v_alpha), ptr(v_render), ptr(v_alphas), ptr(v_extra), sp) == 0
+    acc_a, acc_b = torch.zeros(N, 16, **f32), torch.zeros(N, 16, **f32)
+    assert lib.fsgs_raster_bwd_quad(1, 4, ptr(records), ptr(n_rec), ptr(offsets), M, None, W, H, tw, th, 1, ptr(render),
+                                    ptr(alphas), ptr(last_ids), ptr(v_render), ptr(v_alphas), ptr(seg_state), 1,
+                                    ptr(extra), ptr(v_extra), ptr(acc_a), sp) == 0
+    assert lib.fsgs_raster_bwd_quad_images(ptr(records), ptr(n_rec), ptr(offsets), M, W, H, tw, th, ptr(render),
+                                           ptr(alphas), ptr(last_ids), ptr(extra), ptr(bg), ptr(vr_a), ptr(vd_a),
+                                           ptr(vn_a), ptr(v_alpha), ptr(seg_state), 1, ptr(acc_b), sp) == 0
+    assert float(acc_a.abs().max()) > 0
+    assert rel_err(acc_b, acc_a) < 1e-5
