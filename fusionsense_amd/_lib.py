@@ -69,6 +69,7 @@ SIGNATURES = {
     "fsgs_sh_fwd_pack": (_i, [_i, _i, _i] + [_p] * 15 + [_i, _p]),
     "fsgs_sh_bwd_colors": (_i, [_i, _i, _i, _p, _p, _p, _p, _p, _i, _p, _p, _p, _i, _p]),
     "fsgs_sh_coeff_grad": (_i, [_i, _i, _i, _i, _p, _p, _f, _p, _p, _p]),
+    "fsgs_sh_coeff_grad_adam": (_i, [_i, _i, _i, _i, _p, _p, _f, _p, _p, _p, _f, _p, _p, _p, _f, _i, C.c_double, C.c_double, _f, _p]),
     "fsgs_project_fwd_act": (_i, [_i, _i, _p, _p, _p, _p, _i, _f, _p, _p, _i, _i, _f, _f, _f, _f, _p, _p, _p, _p, _p, _p, _p]),
     "fsgs_gaussian_bwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _f, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _f, _p, _p]),
     "fsgs_activate_fwd": (_i, [_i, _p, _p, _p, _p, _p]),

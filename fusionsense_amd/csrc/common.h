@@ -122,6 +122,14 @@ __device__ __forceinline__ void row_transpose_sum16(float (&v)[16]) {
         : "s"(m2), "s"(m1));
 }
 
+// one Adam update (torch.optim.Adam, amsgrad = False, weight_decay = 0): ss = lr / (1 - b1^t), isb2 = 1 / sqrt(1 - b2^t)
+__device__ __forceinline__ void adam_one(float &p, float g, float &m, float &v, float b1, float b2, float omb1,
+                                         float omb2, float ss, float isb2, float eps) {
+    m = b1 * m + omb1 * g;
+    v = b2 * v + omb2 * g * g;
+    p -= ss * m / (sqrtf(v) * isb2 + eps);
+}
+
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
 }  // namespace fsgs

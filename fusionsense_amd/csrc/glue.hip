@@ -262,12 +262,6 @@ struct AdamArgs {
     float b1, b2, omb1, omb2, inv_sqrt_bc2, eps;  // omb = 1 - beta, rounded from double like torch does
 };
 
-__device__ __forceinline__ void adam_one(float &p, float g, float &m, float &v, float b1, float b2, float omb1,
-                                         float omb2, float ss, float isb2, float eps) {
-    m = b1 * m + omb1 * g;
-    v = b2 * v + omb2 * g * g;
-    p -= ss * m / (sqrtf(v) * isb2 + eps);
-}
 
 // every group owns a whole number of workgroups; a thread updates 4 consecutive floats
 __global__ void __launch_bounds__(256) adam_kernel(AdamArgs a) {

@@ -7,6 +7,8 @@
 // stream on the whole path.  A 256-thread workgroup stages its 256 consecutive Gaussians'
 // records (one contiguous 48 KiB span) through LDS with 16-byte coalesced loads, then each
 // lane consumes its own record; LDS rows are padded by one dword so the per-lane stride is odd.
+#include <math.h>
+
 #include "common.h"
 #include "normal_math.h"
 
@@ -489,11 +491,50 @@ sh_bwd_kernel(int C, int N, int K, int degree, const float *__restrict__ means,
 // 192 B per Gaussian they determine):  v_coeffs[n,k,:] = scale * sum_r basis_k(dir_r(n)) * v_rgb_r[n,:].
 // `gathered` = R blocks of (N + 1) float4: rows 0..N-1 = (v_r, v_g, v_b, -), row N = the rank's camera centre.
 // The sum runs over r = 0..R-1 in this order on every rank: all replicas get bit-identical gradients.
-template <int KT>
+// ADAM: the rebuilt gradients are not written out but applied: the Adam update of features_dc / features_rest runs
+// on the rows as they leave LDS (same arithmetic as adam_kernel of glue.hip), saving the gradient's write + read.
+struct ShAdamArgs {
+    float *p_dc, *m_dc, *v_dc, *p_rest, *m_rest, *v_rest;
+    float ss_dc, ss_rest, b1, b2, omb1, omb2, inv_sqrt_bc2, eps;
+};
+
+template <int RF>
+__device__ __forceinline__ void adam_rows(float *__restrict__ P, float *__restrict__ M, float *__restrict__ V, int rows,
+                                          int row_floats_rt, const float *lds, int pitch, int col_off, float ss,
+                                          const ShAdamArgs &a) {
+    const int row_floats = RF ? RF : row_floats_rt;
+    const int total = rows * row_floats;
+    lds += col_off;
+    const int total4 = total >> 2;
+    for (int i = threadIdx.x; i < total4; i += kShBlock) {
+        const int e = i << 2;
+        int r = e / row_floats, col = e - r * row_floats;
+        float g[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            g[k] = lds[r * pitch + col];
+            if (++col == row_floats) { col = 0; ++r; }
+        }
+        float4 p = reinterpret_cast<float4 *>(P)[i], m = reinterpret_cast<float4 *>(M)[i], v = reinterpret_cast<float4 *>(V)[i];
+        adam_one(p.x, g[0], m.x, v.x, a.b1, a.b2, a.omb1, a.omb2, ss, a.inv_sqrt_bc2, a.eps);
+        adam_one(p.y, g[1], m.y, v.y, a.b1, a.b2, a.omb1, a.omb2, ss, a.inv_sqrt_bc2, a.eps);
+        adam_one(p.z, g[2], m.z, v.z, a.b1, a.b2, a.omb1, a.omb2, ss, a.inv_sqrt_bc2, a.eps);
+        adam_one(p.w, g[3], m.w, v.w, a.b1, a.b2, a.omb1, a.omb2, ss, a.inv_sqrt_bc2, a.eps);
+        reinterpret_cast<float4 *>(P)[i] = p; reinterpret_cast<float4 *>(M)[i] = m; reinterpret_cast<float4 *>(V)[i] = v;
+    }
+    for (int i = (total4 << 2) + threadIdx.x; i < total; i += kShBlock) {
+        const int r = i / row_floats, col = i - r * row_floats;
+        float p = P[i], m = M[i], v = V[i];
+        adam_one(p, lds[r * pitch + col], m, v, a.b1, a.b2, a.omb1, a.omb2, ss, a.inv_sqrt_bc2, a.eps);
+        P[i] = p; M[i] = m; V[i] = v;
+    }
+}
+
+template <int KT, bool ADAM>
 __global__ void __launch_bounds__(kShBlock)
 sh_coeff_grad_kernel(int R, int N, int K, int degree, const float *__restrict__ means,
                      const float4 *__restrict__ gathered, float scale, float *__restrict__ v_dc,
-                     float *__restrict__ v_rest) {
+                     float *__restrict__ v_rest, ShAdamArgs ad) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int n0 = blockIdx.x * kShBlock;
     const int rows = min(kShBlock, N - n0);
@@ -536,6 +577,16 @@ sh_coeff_grad_kernel(int R, int N, int K, int degree, const float *__restrict__ 
         }
     }
     __syncthreads();
+    if (ADAM) {
+        adam_rows<3>(ad.p_dc + (int64_t)n0 * 3, ad.m_dc + (int64_t)n0 * 3, ad.v_dc + (int64_t)n0 * 3, rows, 3, lds, pitch, 0,
+                     ad.ss_dc, ad);
+        if (K > 1) {
+            const int64_t o = (int64_t)n0 * (row_floats - 3);
+            adam_rows<KT ? KT * 3 - 3 : 0>(ad.p_rest + o, ad.m_rest + o, ad.v_rest + o, rows, row_floats - 3, lds, pitch, 3,
+                                           ad.ss_rest, ad);
+        }
+        return;
+    }
     unstage_rows<3>(v_dc + (int64_t)n0 * 3, rows, 3, lds, pitch, 0);
     if (K > 1)
         unstage_rows<KT ? KT * 3 - 3 : 0>(v_rest + (int64_t)n0 * (row_floats - 3), rows, row_floats - 3, lds, pitch, 3);
@@ -678,11 +729,42 @@ extern "C" int fsgs_sh_coeff_grad(int R, int N, int K, int degree, const float *
     const size_t lds_bytes = (size_t)kShBlock * (K * 3 + 1) * sizeof(float);
     const float4 *g4 = reinterpret_cast<const float4 *>(gathered);
     if (K == 16)
-        hipLaunchKernelGGL((sh_coeff_grad_kernel<16>), dim3(ceil_div(N, kShBlock)), dim3(kShBlock), lds_bytes,
-                           as_stream(stream), R, N, K, degree, means, g4, scale, v_features_dc, v_features_rest);
+        hipLaunchKernelGGL((sh_coeff_grad_kernel<16, false>), dim3(ceil_div(N, kShBlock)), dim3(kShBlock), lds_bytes,
+                           as_stream(stream), R, N, K, degree, means, g4, scale, v_features_dc, v_features_rest,
+                           ShAdamArgs{});
     else
-        hipLaunchKernelGGL((sh_coeff_grad_kernel<0>), dim3(ceil_div(N, kShBlock)), dim3(kShBlock), lds_bytes,
-                           as_stream(stream), R, N, K, degree, means, g4, scale, v_features_dc, v_features_rest);
+        hipLaunchKernelGGL((sh_coeff_grad_kernel<0, false>), dim3(ceil_div(N, kShBlock)), dim3(kShBlock), lds_bytes,
+                           as_stream(stream), R, N, K, degree, means, g4, scale, v_features_dc, v_features_rest,
+                           ShAdamArgs{});
+    return check_launch();
+}
+
+// fsgs_sh_coeff_grad + the Adam step of the two feature groups in one launch: the rebuilt mean gradient is applied
+// to features_dc / features_rest (and their exp_avg / exp_avg_sq) as it leaves LDS; it is never written.  Arguments
+// of fsgs_adam_step for the two groups; `step` = the Adam step number of this update.
+extern "C" int fsgs_sh_coeff_grad_adam(int R, int N, int K, int degree, const float *means, const float *gathered,
+                                       float scale, float *features_dc, float *exp_avg_dc, float *exp_avg_sq_dc,
+                                       float lr_dc, float *features_rest, float *exp_avg_rest,
+                                       float *exp_avg_sq_rest, float lr_rest, int step, double beta1_d, double beta2_d,
+                                       float eps, fsgs_stream_t stream) {
+    if (R < 1 || N < 0 || degree < 0 || degree > 4 || K < (degree + 1) * (degree + 1) || K > kMaxK || step < 1)
+        return FSGS_EINVAL;
+    if (N == 0) return FSGS_OK;
+    if (!means || !gathered || !features_dc || !exp_avg_dc || !exp_avg_sq_dc ||
+        (K > 1 && (!features_rest || !exp_avg_rest || !exp_avg_sq_rest)))
+        return FSGS_EINVAL;
+    const double bc1 = 1.0 - pow(beta1_d, (double)step), bc2 = 1.0 - pow(beta2_d, (double)step);
+    ShAdamArgs ad = {features_dc, exp_avg_dc, exp_avg_sq_dc, features_rest, exp_avg_rest, exp_avg_sq_rest,
+                     (float)((double)lr_dc / bc1), (float)((double)lr_rest / bc1), (float)beta1_d, (float)beta2_d,
+                     (float)(1.0 - beta1_d), (float)(1.0 - beta2_d), (float)(1.0 / sqrt(bc2)), eps};
+    const size_t lds_bytes = (size_t)kShBlock * (K * 3 + 1) * sizeof(float);
+    const float4 *g4 = reinterpret_cast<const float4 *>(gathered);
+    if (K == 16)
+        hipLaunchKernelGGL((sh_coeff_grad_kernel<16, true>), dim3(ceil_div(N, kShBlock)), dim3(kShBlock), lds_bytes,
+                           as_stream(stream), R, N, K, degree, means, g4, scale, nullptr, nullptr, ad);
+    else
+        hipLaunchKernelGGL((sh_coeff_grad_kernel<0, true>), dim3(ceil_div(N, kShBlock)), dim3(kShBlock), lds_bytes,
+                           as_stream(stream), R, N, K, degree, means, g4, scale, nullptr, nullptr, ad);
     return check_launch();
 }
 

@@ -260,17 +260,31 @@ class SplatTrainer:
             self._factors = f = (own, gathered)
         return f
 
-    def _features_from_factors(self, sh_degree: int) -> None:
+    def _features_from_factors(self, sh_degree: int, step_no: int) -> None:
+        """The mean SH coefficient gradient of the gathered views, rebuilt AND applied (Adam step ``step_no`` of the
+        two feature groups) in one launch: the gradient itself is never written (fsgs_sh_coeff_grad_adam)."""
         from ._lib import load, ptr, stream_ptr
         own, gathered = self._factors
         R, N = gathered.shape[0], self.num_gaussians()
         K = 1 + self.params["features_rest"].shape[1]
+        st = []
+        for name in FEATURE_GROUPS:
+            p = self.params[name]
+            opt = self.optimizers[name]
+            s_ = opt.state[p]
+            if "exp_avg" not in s_:
+                s_["step"] = torch.tensor(0.0)
+                s_["exp_avg"] = torch.zeros_like(p)
+                s_["exp_avg_sq"] = torch.zeros_like(p)
+            s_["step"] += 1
+            st.append((p.data, s_["exp_avg"], s_["exp_avg_sq"], float(opt.param_groups[0]["lr"])))
         # (the view directions of the step that produced the factors: the means have been stepped since)
-        rc = load().fsgs_sh_coeff_grad(R, N, K, sh_degree, ptr(self._means_prev), ptr(gathered), 1.0 / R,
-                                       ptr(self.slab.views["features_dc"]), ptr(self.slab.views["features_rest"]),
-                                       stream_ptr(self.device))
+        rc = load().fsgs_sh_coeff_grad_adam(R, N, K, sh_degree, ptr(self._means_prev), ptr(gathered), 1.0 / R,
+                                            ptr(st[0][0]), ptr(st[0][1]), ptr(st[0][2]), st[0][3],
+                                            ptr(st[1][0]), ptr(st[1][1]), ptr(st[1][2]), st[1][3],
+                                            int(step_no), 0.9, 0.999, self.optim_cfg.eps, stream_ptr(self.device))
         if rc != 0:
-            raise RuntimeError(f"fsgs_sh_coeff_grad failed ({rc})")
+            raise RuntimeError(f"fsgs_sh_coeff_grad_adam failed ({rc})")
 
     def _reduce_and_step(self, optimizer_step: bool) -> None:
         """Gradient exchange + Adam for the gradients now in the slab.  With several ranks (and an optimizer step)
@@ -300,10 +314,11 @@ class SplatTrainer:
                 mp = self._means_prev = torch.empty_like(self.params["means"].data)
             mp.copy_(self.params["means"].data)  # before Adam moves them (12 B per Gaussian)
 
-            def finish():
+            def finish(step_no):
                 if work is not None:
                     work.wait()
-                self._features_from_factors(deg)
+                self._features_from_factors(deg, step_no)  # (rebuild + Adam in one launch)
+            finish.applies_update = True
         else:
             finish = self.slab.all_reduce_features_async()
         self.optimizers["means"].param_groups[0]["lr"] = self._means_lr(self.step)
@@ -317,6 +332,9 @@ class SplatTrainer:
             return
         finish, step_no = self._pending
         self._pending = None
+        if getattr(finish, "applies_update", False):
+            finish(step_no)
+            return
         if finish is not None:
             finish()
         self._optimizer_step(FEATURE_GROUPS, step_no)

@@ -110,6 +110,12 @@ int fsgs_sh_bwd_colors(int N, int K, int degree, const float *means, const float
                        fsgs_stream_t stream);
 int fsgs_sh_coeff_grad(int R, int N, int K, int degree, const float *means, const float *gathered, float scale,
                        float *v_features_dc, float *v_features_rest, fsgs_stream_t stream);
+/* fsgs_sh_coeff_grad and the Adam step of the two SH feature groups (as fsgs_adam_step would do it) in one launch:
+ * the rebuilt mean gradient is applied as it leaves LDS and never written. */
+int fsgs_sh_coeff_grad_adam(int R, int N, int K, int degree, const float *means, const float *gathered, float scale,
+                            float *features_dc, float *exp_avg_dc, float *exp_avg_sq_dc, float lr_dc,
+                            float *features_rest, float *exp_avg_rest, float *exp_avg_sq_rest, float lr_rest,
+                            int step, double beta1, double beta2, float eps, fsgs_stream_t stream);
 /* D = floats per v_colors row (its first three are the colour gradient): 3, 4 (then v_depths, if given,
  * receives column 3) or a wider stride, e.g. 16 for the rasterizer's packed gradient records.
  * overwrite_means != 0: v_means is written instead of accumulated into. */

@@ -245,6 +245,19 @@ def test_sh_gradient_from_factors(dev, degree):
     if degree < 3:
         kk = (degree + 1) ** 2
         assert bool((m_rest[:, kk - 1:] == 0).all()), "bands above sh_degree_to_use get no gradient"
+    # ... and applied in the same launch (fsgs_sh_coeff_grad_adam) = fsgs_sh_coeff_grad + fsgs_adam_step
+    from fusionsense_amd import ops
+    p1 = [dc.clone(), rest.clone()]
+    m1 = [torch.rand_like(dc) * 1e-3, torch.rand_like(rest) * 1e-3]
+    v1 = [torch.rand_like(dc) * 1e-6, torch.rand_like(rest) * 1e-6]
+    p2, m2, v2 = [t.clone() for t in p1], [t.clone() for t in m1], [t.clone() for t in v1]
+    lrs, step = (0.0025, 0.000125), 7
+    ops.adam_step_(p1, [m_dc, m_rest], m1, v1, lrs, step, 0.9, 0.999, 1e-15)
+    assert lib.fsgs_sh_coeff_grad_adam(2, N, K, degree, ptr(means), ptr(gathered), 0.5, ptr(p2[0]), ptr(m2[0]),
+                                       ptr(v2[0]), lrs[0], ptr(p2[1]), ptr(m2[1]), ptr(v2[1]), lrs[1], step, 0.9, 0.999,
+                                       1e-15, sp) == 0
+    for x, y in zip(p1 + m1 + v1, p2 + m2 + v2):
+        assert (x - y).abs().max().item() <= 1e-6 * (1e-3 + x.abs().max().item())
 
 
 @pytest.mark.parametrize("scene,antialiased", [("cube", False), ("adversarial", False), ("cube", True)])
