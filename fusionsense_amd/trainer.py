@@ -141,6 +141,9 @@ class SplatTrainer:
         # all-gathered); fsgs_sh_coeff_grad rebuilds the mean gradient on every rank, in rank order, so the
         # replicas stay bit-identical.  Fused CUDA path only; FSGS_FACTORED_FEATURES=0 switches it off.
         self.factored_features = os.environ.get("FSGS_FACTORED_FEATURES", "1") != "0"
+        # single rank: the same factored form saves the gradient's write + read (sh_bwd writes 16 B instead of 192 B
+        # per Gaussian, the features' Adam launch rebuilds the gradient in LDS)
+        self.factored_single = os.environ.get("FSGS_FACTORED_SINGLE", "0") == "1"  # (measured: -3 us only; off, so that the feature gradients stay materialised)
         self._factors = None
         self._pending = None
         self.step = 0
@@ -248,7 +251,8 @@ class SplatTrainer:
 
     def _factor_buffers(self, optimizer_step: bool):
         """(own [N + 1,4], gathered [R, N + 1,4]) when this step exchanges the SH gradients as factors, else None."""
-        if not (self._split_step(optimizer_step) and self.factored_features and self.fused
+        single = (optimizer_step and self.factored_single and GradSlab._world() == 1 and not self.force_split_step)
+        if not ((self._split_step(optimizer_step) or single) and self.factored_features and self.fused
                 and self.device.type == "cuda"):
             return None
         R, N = GradSlab._world(), self.num_gaussians()
@@ -291,6 +295,18 @@ class SplatTrainer:
         the feature half is only STARTED here; ``flush`` completes it when the next frame needs the colours."""
         assert self._pending is None, "the previous step's feature update has not been flushed"
         split = self._split_step(optimizer_step)
+        factors = getattr(self, "_factors_used", None)
+        if not split and factors is not None:
+            # single rank, factored features (see _factor_buffers): rebuild + Adam of the two feature groups in one
+            # launch from this frame's factors, then the geometry groups
+            self._factors_used = None
+            self._means_prev = self.params["means"].data  # (not stepped yet)
+            self.optimizers["means"].param_groups[0]["lr"] = self._means_lr(self.step)
+            self.adam_steps = getattr(self, "adam_steps", 0) + 1
+            self._features_from_factors(self._sh_degree_now(), self.adam_steps)
+            self._optimizer_step(GEOMETRY_GROUPS, self.adam_steps)
+            self._means_prev = None
+            return
         if not split:
             self.slab.all_reduce_mean_()
             if optimizer_step:
