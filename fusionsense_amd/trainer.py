@@ -320,9 +320,13 @@ class SplatTrainer:
             own, gathered = factors
             work = None
             if GradSlab._world() > 1:
+                work = None
                 if dist.get_backend() == "nccl":
-                    work = dist.all_gather_into_tensor(gathered.view(-1), own.view(-1), async_op=True)
-                else:  # (gloo: list form)
+                    try:
+                        work = dist.all_gather_into_tensor(gathered.view(-1), own.view(-1), async_op=True)
+                    except (RuntimeError, AttributeError, NotImplementedError):
+                        work = None  # (every rank takes the same branch: the list form below)
+                if work is None:  # gloo, or a backend without the flat form
                     work = dist.all_gather(list(gathered.unbind(0)), own, async_op=True)
             deg = self._sh_degree_now()
             mp = getattr(self, "_means_prev", None)
