@@ -251,6 +251,19 @@ def isect_count_live_async(means2d: Tensor, radii: Tensor, conics: Tensor, opaci
 _PINNED: dict = {}
 
 
+SPIN_WAIT = os.environ.get("FSGS_SPIN_WAIT", "1") != "0"
+
+
+def _wait_event(ev) -> None:
+    """The step's one host wait (the live-pair count).  Polling the event instead of sleeping in
+    hipEventSynchronize brings the host back some microseconds earlier, and the GPU idles until it is."""
+    if SPIN_WAIT:
+        for _ in range(200000):
+            if ev.query():
+                return
+    ev.synchronize()
+
+
 def _pinned_i64(dev) -> Tensor:
     """A small ring of pinned one-element buffers per device (a frame's read-back must not be overwritten
     by the next frame's before the host has looked at it)."""
@@ -267,7 +280,7 @@ def isect_finish_live(st: dict, means2d: Tensor, radii: Tensor, depths: Tensor, 
     Cn, N = radii.shape
     M = 0
     if st["total"] > 0:
-        st["event"].synchronize()
+        _wait_event(st["event"])
         M = int(st["pinned"][0])
     check_onesweep_errors()
     ids = torch.empty(M, dtype=torch.int64, device=dev)
@@ -393,7 +406,7 @@ def bin_live_finish(st: dict, means2d: Tensor, radii: Tensor, depths: Tensor, co
     dev = means2d.device
     Cn, N = radii.shape
     T = st["T"]
-    st["event"].synchronize()
+    _wait_event(st["event"])
     M = int(st["pinned"][0])
     dense = not use_tile_sort(M, T)  # mean bucket beyond the LDS tiers
     split = BIN_SPLIT == "always" or (BIN_SPLIT == "auto" and dense)
