@@ -643,7 +643,8 @@ extern "C" int fsgs_isect_emit_live(int C, int N, const float *means2d, const in
 
 // ---- direct binning: C entry points -----------------------------------------------------------------------
 namespace fsgs {
-int launch_tile_scan_rows_offsets(int T, int nb, int32_t *table, int32_t *totals, int32_t *isect_offsets, hipStream_t s);
+int launch_tile_scan_rows_offsets(int T, int nb, int32_t *table, int32_t *totals, int32_t *isect_offsets,
+                                  int32_t *total_mapped, hipStream_t s);
 int launch_tile_sort_tiers(int T, int n_tiles, int tile_bits, const int32_t *isect_offsets, uint64_t *buckets,
                            int32_t *payload_sorted, int64_t *isect_ids_sorted, hipStream_t s);
 int launch_split_sort(int T, int n_tiles, int tile_bits, const int32_t *isect_offsets, int64_t n_live,
@@ -697,7 +698,7 @@ static int bin_set_lds(int T) {
 extern "C" int fsgs_bin_live_count(int C, int N, const float *means2d, const int32_t *radii, const float *conics,
                                    const float *opacities, int tile_width, int tile_height,
                                    int32_t *tiles_per_gauss, int32_t *isect_offsets, void *table_scratch,
-                                   size_t table_bytes, fsgs_stream_t stream) {
+                                   size_t table_bytes, int32_t *n_live_mapped, fsgs_stream_t stream) {
     if (C < 1 || N < 0 || tile_width < 1 || tile_height < 1 || !isect_offsets) return FSGS_EINVAL;
     const int64_t T64 = (int64_t)C * tile_width * tile_height;
     if (T64 > fsgs_bin_live_max_tiles()) return FSGS_EINVAL;
@@ -706,6 +707,7 @@ extern "C" int fsgs_bin_live_count(int C, int N, const float *means2d, const int
     const int64_t total = (int64_t)C * N;
     if (total == 0) {
         hipError_t e = hipMemsetAsync(isect_offsets, 0, (size_t)(T + 1) * sizeof(int32_t), s);
+        if (e == hipSuccess && n_live_mapped) e = hipMemsetAsync(n_live_mapped, 0, sizeof(int32_t), s);
         if (e != hipSuccess) { g_last_hip_error = (int)e; return FSGS_ELAUNCH; }
         return FSGS_OK;
     }
@@ -724,7 +726,7 @@ extern "C" int fsgs_bin_live_count(int C, int N, const float *means2d, const int
 #undef FSGS_BIN_COUNT
     rc = check_launch();
     if (rc != FSGS_OK) return rc;
-    return launch_tile_scan_rows_offsets(T, nb, table, totals, isect_offsets, s);
+    return launch_tile_scan_rows_offsets(T, nb, table, totals, isect_offsets, n_live_mapped, s);
 }
 
 // fsgs_project_fwd_act (one camera) + fsgs_bin_live_count in one launch chain: the count pass projects the
@@ -737,7 +739,7 @@ extern "C" int fsgs_project_bin_live_count(int N, const float *means, const floa
                                            float *opac_out, int32_t *radii, float *means2d, float *depths,
                                            float *conics, int tile_width, int tile_height, int32_t *tiles_per_gauss,
                                            int32_t *isect_offsets, void *table_scratch, size_t table_bytes,
-                                           fsgs_stream_t stream) {
+                                           int32_t *n_live_mapped, fsgs_stream_t stream) {
     if (N < 0 || tile_width < 1 || tile_height < 1 || !isect_offsets) return FSGS_EINVAL;
     const int64_t T64 = (int64_t)tile_width * tile_height;
     if (T64 > fsgs_bin_live_max_tiles()) return FSGS_EINVAL;
@@ -745,6 +747,7 @@ extern "C" int fsgs_project_bin_live_count(int N, const float *means, const floa
     hipStream_t s = as_stream(stream);
     if (N == 0) {
         hipError_t e = hipMemsetAsync(isect_offsets, 0, (size_t)(T + 1) * sizeof(int32_t), s);
+        if (e == hipSuccess && n_live_mapped) e = hipMemsetAsync(n_live_mapped, 0, sizeof(int32_t), s);
         if (e != hipSuccess) { g_last_hip_error = (int)e; return FSGS_ELAUNCH; }
         return FSGS_OK;
     }
@@ -769,7 +772,7 @@ extern "C" int fsgs_project_bin_live_count(int N, const float *means, const floa
 #undef FSGS_BIN_PCOUNT
     rc = check_launch();
     if (rc != FSGS_OK) return rc;
-    return launch_tile_scan_rows_offsets(T, nb, table, totals, isect_offsets, s);
+    return launch_tile_scan_rows_offsets(T, nb, table, totals, isect_offsets, n_live_mapped, s);
 }
 
 // Pass 2 + the in-tile sorts: payload_sorted[n_live] = quadrant mask << 28 | flatten id in (tile, depth, id)

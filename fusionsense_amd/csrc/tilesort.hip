@@ -132,7 +132,8 @@ tile_scan_rows_kernel(int T, int nb, int32_t *__restrict__ table, int32_t *__res
 
 // offsets[t] = sum of totals[0..t), offsets[T] = M   (one workgroup)
 __global__ void __launch_bounds__(1024)
-tile_offsets_kernel(int T, const int32_t *__restrict__ totals, int32_t *__restrict__ offsets) {
+tile_offsets_kernel(int T, const int32_t *__restrict__ totals, int32_t *__restrict__ offsets,
+                    int32_t *__restrict__ total_mapped) {
     __shared__ int wsum[16];
     __shared__ int carry_s;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -157,7 +158,12 @@ tile_offsets_kernel(int T, const int32_t *__restrict__ totals, int32_t *__restri
         if (tid == 1023) carry_s = carry + wbase + inc;
         __syncthreads();
     }
-    if (tid == 0) offsets[T] = carry_s;
+    if (tid == 0) {
+        offsets[T] = carry_s;
+        // (optional) the total straight into host-mapped pinned memory: no device-to-host copy launch for the one
+        // number the host waits for
+        if (total_mapped) total_mapped[0] = carry_s;
+    }
 }
 
 __global__ void __launch_bounds__(kTpThreads)
@@ -354,13 +360,14 @@ inline int64_t ts_blocks(int64_t n) { return (n + kTsBlockKeys - 1) / kTsBlockKe
 // (shared with the direct-binning entry points of isect.hip)
 int launch_tile_scan_offsets(int T, int nb, int32_t *table, int32_t *totals, int32_t *isect_offsets, hipStream_t s) {
     hipLaunchKernelGGL(tile_scan_kernel2, dim3(T), dim3(kTsThreads), 0, s, nb, table, totals);
-    hipLaunchKernelGGL(tile_offsets_kernel, dim3(1), dim3(1024), 0, s, T, totals, isect_offsets);
+    hipLaunchKernelGGL(tile_offsets_kernel, dim3(1), dim3(1024), 0, s, T, totals, isect_offsets, nullptr);
     return check_launch();
 }
 
-int launch_tile_scan_rows_offsets(int T, int nb, int32_t *table, int32_t *totals, int32_t *isect_offsets, hipStream_t s) {
+int launch_tile_scan_rows_offsets(int T, int nb, int32_t *table, int32_t *totals, int32_t *isect_offsets,
+                                  int32_t *total_mapped, hipStream_t s) {
     hipLaunchKernelGGL(tile_scan_rows_kernel, dim3((T + kTrTiles - 1) / kTrTiles), dim3(256), 0, s, T, nb, table, totals);
-    hipLaunchKernelGGL(tile_offsets_kernel, dim3(1), dim3(1024), 0, s, T, totals, isect_offsets);
+    hipLaunchKernelGGL(tile_offsets_kernel, dim3(1), dim3(1024), 0, s, T, totals, isect_offsets, total_mapped);
     return check_launch();
 }
 

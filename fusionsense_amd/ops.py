@@ -360,11 +360,10 @@ def bin_live_count_async(means2d: Tensor, radii: Tensor, conics: Tensor, opaciti
     offsets = torch.empty(T + 1, dtype=torch.int32, device=dev)
     tbytes = lib.fsgs_bin_live_table_bytes(Cn, N, tile_width, tile_height)
     table = WORKSPACE.take(tbytes, dev)
+    pinned = _pinned_i32(dev)  # mapped host memory: the last kernel of the call writes the total there itself
     _run(lib.fsgs_bin_live_count, (Cn, N, ptr(means2d), ptr(radii), ptr(conics), ptr(opacities), tile_width,
-                                  tile_height, ptr(tpg), ptr(offsets), ptr(table), tbytes, stream_ptr(dev)),
-         "fsgs_isect_count_live")
-    pinned = _pinned_i32(dev)
-    pinned.copy_(offsets[T:T + 1], non_blocking=True)
+                                  tile_height, ptr(tpg), ptr(offsets), ptr(table), tbytes, pinned.data_ptr(),
+                                  stream_ptr(dev)), "fsgs_isect_count_live")
     ev = torch.cuda.Event()
     ev.record(torch.cuda.current_stream(dev))
     return dict(direct=True, tpg=tpg, offsets=offsets, table=table, pinned=pinned, event=ev, T=T)
@@ -384,14 +383,13 @@ def project_bin_live_count_async(means: Tensor, quats: Tensor, log_scales: Tenso
     offsets = torch.empty(T + 1, dtype=torch.int32, device=dev)
     tbytes = lib.fsgs_bin_live_table_bytes(1, N, tile_width, tile_height)
     table = WORKSPACE.take(tbytes, dev)
+    pinned = _pinned_i32(dev)
     _run(lib.fsgs_project_bin_live_count,
          (N, ptr(means), ptr(quats), ptr(log_scales), ptr(opac_logit), 0 if binary_threshold is None else 1,
           0.0 if binary_threshold is None else float(binary_threshold), ptr(viewmat), ptr(K), width, height, 0.3, 0.01,
           1e10, 0.0, ptr(out["scales_exp"]), ptr(out["opac_sig"]), ptr(out["radii"]), ptr(out["means2d"]),
           ptr(out["depths"]), ptr(out["conics"]), tile_width, tile_height, ptr(tpg), ptr(offsets), ptr(table), tbytes,
-          stream_ptr(dev)), "fsgs_isect_count_live")
-    pinned = _pinned_i32(dev)
-    pinned.copy_(offsets[T:T + 1], non_blocking=True)
+          pinned.data_ptr(), stream_ptr(dev)), "fsgs_isect_count_live")
     ev = torch.cuda.Event()
     ev.record(torch.cuda.current_stream(dev))
     return dict(direct=True, tpg=tpg, offsets=offsets, table=table, pinned=pinned, event=ev, T=T)

@@ -318,13 +318,16 @@ int fsgs_tile_sort(int64_t n, const int64_t *isect_ids, const int32_t *payload, 
  *       the number of live pairs (copy it to the host to size the second call's buffers).
  *   fsgs_bin_live_emit: enumerates again, drops every live pair into its tile's bucket and sorts the
  *       buckets on (depth, flatten id): payload_sorted [n_live] = quadrant mask << 28 | flatten id.
+ * n_live_mapped (nullable): a DEVICE-ACCESSIBLE HOST pointer (mapped pinned memory) that also receives the number of
+ * live pairs, written by the last kernel of the call: the caller waits for the stream and reads it, no copy launch.
  * table_scratch: fsgs_bin_live_table_bytes(C, N, tw, th) bytes, untouched between the two calls;
  * buckets: n_live 64-bit words.  C*th*tw <= fsgs_bin_live_max_tiles(). */
 int fsgs_bin_live_max_tiles(void);
 size_t fsgs_bin_live_table_bytes(int C, int N, int tile_width, int tile_height);
 int fsgs_bin_live_count(int C, int N, const float *means2d, const int32_t *radii, const float *conics,
                         const float *opacities, int tile_width, int tile_height, int32_t *tiles_per_gauss,
-                        int32_t *isect_offsets, void *table_scratch, size_t table_bytes, fsgs_stream_t stream);
+                        int32_t *isect_offsets, void *table_scratch, size_t table_bytes, int32_t *n_live_mapped,
+                        fsgs_stream_t stream);
 /* fsgs_project_fwd_act (one camera) + fsgs_bin_live_count as one call: the count pass projects its Gaussians itself
  * (same statements, csrc/project_math.h) and writes the projection's outputs for the later passes. */
 int fsgs_project_bin_live_count(int N, const float *means, const float *quats, const float *log_scales,
@@ -333,7 +336,7 @@ int fsgs_project_bin_live_count(int N, const float *means, const float *quats, c
                                 float radius_clip, float *scales_out, float *opac_out, int32_t *radii, float *means2d,
                                 float *depths, float *conics, int tile_width, int tile_height,
                                 int32_t *tiles_per_gauss, int32_t *isect_offsets, void *table_scratch,
-                                size_t table_bytes, fsgs_stream_t stream);
+                                size_t table_bytes, int32_t *n_live_mapped, fsgs_stream_t stream);
 int fsgs_bin_live_emit(int C, int N, const float *means2d, const int32_t *radii, const float *depths,
                        const float *conics, const float *opacities, int tile_width, int tile_height,
                        const int32_t *isect_offsets, const void *table_scratch, int64_t n_live, void *buckets,
