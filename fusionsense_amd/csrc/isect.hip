@@ -707,7 +707,10 @@ extern "C" int fsgs_bin_live_count(int C, int N, const float *means2d, const int
     const int64_t total = (int64_t)C * N;
     if (total == 0) {
         hipError_t e = hipMemsetAsync(isect_offsets, 0, (size_t)(T + 1) * sizeof(int32_t), s);
-        if (e == hipSuccess && n_live_mapped) e = hipMemsetAsync(n_live_mapped, 0, sizeof(int32_t), s);
+        if (e == hipSuccess && n_live_mapped) {
+            static const int32_t kZeroDone[2] = {0, 1};
+            e = hipMemcpyAsync(n_live_mapped, kZeroDone, sizeof(kZeroDone), hipMemcpyHostToHost, s);
+        }
         if (e != hipSuccess) { g_last_hip_error = (int)e; return FSGS_ELAUNCH; }
         return FSGS_OK;
     }
@@ -747,7 +750,10 @@ extern "C" int fsgs_project_bin_live_count(int N, const float *means, const floa
     hipStream_t s = as_stream(stream);
     if (N == 0) {
         hipError_t e = hipMemsetAsync(isect_offsets, 0, (size_t)(T + 1) * sizeof(int32_t), s);
-        if (e == hipSuccess && n_live_mapped) e = hipMemsetAsync(n_live_mapped, 0, sizeof(int32_t), s);
+        if (e == hipSuccess && n_live_mapped) {
+            static const int32_t kZeroDone[2] = {0, 1};
+            e = hipMemcpyAsync(n_live_mapped, kZeroDone, sizeof(kZeroDone), hipMemcpyHostToHost, s);
+        }
         if (e != hipSuccess) { g_last_hip_error = (int)e; return FSGS_ELAUNCH; }
         return FSGS_OK;
     }

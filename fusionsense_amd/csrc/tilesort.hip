@@ -162,7 +162,11 @@ tile_offsets_kernel(int T, const int32_t *__restrict__ totals, int32_t *__restri
         offsets[T] = carry_s;
         // (optional) the total straight into host-mapped pinned memory: no device-to-host copy launch for the one
         // number the host waits for
-        if (total_mapped) total_mapped[0] = carry_s;
+        if (total_mapped) {
+            total_mapped[0] = carry_s;
+            __threadfence_system();
+            __hip_atomic_store(&total_mapped[1], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);  // "the total has landed"
+        }
     }
 }
 

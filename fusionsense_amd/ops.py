@@ -252,6 +252,7 @@ _PINNED: dict = {}
 
 
 SPIN_WAIT = os.environ.get("FSGS_SPIN_WAIT", "1") != "0"
+WAIT_ON_FLAG = os.environ.get("FSGS_WAIT_ON_FLAG", "0") == "1"  # (polling the kernel-set flag instead of the event: measured no faster)
 
 
 def _wait_event(ev) -> None:
@@ -333,10 +334,30 @@ BIN_SPLIT = os.environ.get("FSGS_BIN_SPLIT", "auto")
 
 
 def _pinned_i32(dev) -> Tensor:
-    ring = _PINNED.setdefault(str(dev) + ":i32",
-                              dict(bufs=[torch.zeros(1, dtype=torch.int32).pin_memory() for _ in range(4)], i=0))
+    """A ring of mapped pinned (total, done-flag) pairs per device; the flag is cleared here, set by the kernel that
+    writes the total.  The tensor carries a numpy view (``._np``) for cheap polling."""
+    ring = _PINNED.get(str(dev) + ":i32")
+    if ring is None:
+        bufs = [torch.zeros(2, dtype=torch.int32).pin_memory() for _ in range(4)]
+        for b in bufs:
+            b._np = b.numpy()
+        ring = _PINNED.setdefault(str(dev) + ":i32", dict(bufs=bufs, i=0))
     ring["i"] = (ring["i"] + 1) % len(ring["bufs"])
-    return ring["bufs"][ring["i"]]
+    buf = ring["bufs"][ring["i"]]
+    buf._np[1] = 0
+    return buf
+
+
+def _wait_total(st: dict) -> int:
+    """The step's one host wait: poll the done-flag the offsets kernel sets in mapped host memory right after the
+    total (falls back to the event)."""
+    arr = st["pinned"]._np
+    if SPIN_WAIT and WAIT_ON_FLAG:
+        for _ in range(400000):
+            if arr[1] != 0:
+                return int(arr[0])
+    _wait_event(st["event"])
+    return int(arr[0])
 
 
 _DENSE_HINT: dict = {}  # (device, N, T) -> the last frame of this shape was too dense for LDS buckets
@@ -404,8 +425,7 @@ def bin_live_finish(st: dict, means2d: Tensor, radii: Tensor, depths: Tensor, co
     dev = means2d.device
     Cn, N = radii.shape
     T = st["T"]
-    _wait_event(st["event"])
-    M = int(st["pinned"][0])
+    M = _wait_total(st)
     dense = not use_tile_sort(M, T)  # mean bucket beyond the LDS tiers
     split = BIN_SPLIT == "always" or (BIN_SPLIT == "auto" and dense)
     _DENSE_HINT[(str(dev), N, T)] = dense and not split
