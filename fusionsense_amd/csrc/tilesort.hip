@@ -15,6 +15,8 @@
 // The claiming order inside a block is arbitrary, the in-tile sort on (depth, id) makes the result
 // deterministic and equal to a stable sort of the emission order (ties -> ascending flatten id), i.e.
 // bit-exact with the radix path and the oracle.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace fsgs {
@@ -529,6 +531,28 @@ int launch_tile_sort_tiers(int T, int n_tiles, int tile_bits, const int32_t *ise
                                            hipFuncAttributeMaxDynamicSharedMemorySize, kTsLarge * 8);
         if (e != hipSuccess) { g_last_hip_error = (int)e; return FSGS_ELAUNCH; }
         attr_set = true;
+    }
+    static int one_tier = -1;
+    if (one_tier < 0) {
+        const char *e = getenv("FSGS_SORT_ONE_TIER");
+        one_tier = e ? atoi(e) : 1;
+    }
+    if (one_tier && T <= 8192) {
+        // a moderate number of buckets: EVERY bucket through the 1024-thread kernel in one launch — the small
+        // buckets' workgroups (12 of their 16 waves have nothing to do and only meet the barriers) run beside the
+        // few long ones instead of in a launch of their own in front of them: 15 + 31 -> 40 us at config #2.
+        // With tens of thousands of buckets (large images, the depth-slab path) the 64 KB of LDS per workgroup would
+        // limit the small ones to 2 per CU: there the two tiers stay.
+        static bool attr2 = false;
+        if (!attr2) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&tile_sort_kernel2<1024, kTsLarge, 0, true>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, kTsLarge * 8);
+            if (e != hipSuccess) { g_last_hip_error = (int)e; return FSGS_ELAUNCH; }
+            attr2 = true;
+        }
+        hipLaunchKernelGGL((tile_sort_kernel2<1024, kTsLarge, 0, true>), dim3(T), dim3(1024), kTsLarge * 8, s, n_tiles,
+                           tile_bits, isect_offsets, buckets, payload_sorted, isect_ids_sorted);
+        return check_launch();
     }
     // two size tiers, each skipping the tiles of the other (an early-out workgroup costs ~2 ns)
     hipLaunchKernelGGL((tile_sort_kernel2<256, kTsSmall, 0, false>), dim3(T), dim3(256), kTsSmall * 8, s, n_tiles,
