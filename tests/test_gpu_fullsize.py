@@ -449,3 +449,31 @@ def test_training_with_densification_converges(dev):
     assert len(sizes) > 1, "densification never changed the Gaussian count"
     for k, p_ in tr.params.items():
         assert bool(torch.isfinite(p_.data).all()), k
+
+
+@pytest.mark.parametrize("mode", ["factored_deferred", "plain"])
+def test_two_ranks_with_densification_stay_identical(mode):
+    """tests/dp_soak_worker.py under torch.distributed.run: 2 ranks (gloo, both on this GPU) train different views
+    for 300 steps with splits / culls / opacity resets on; at the end both hold the same number of Gaussians and
+    bit-identical parameters (shared split noise, all-reduced statistics, rank-ordered gradient sums, the deferred
+    feature update flushed before every refinement)."""
+    import os, signal, socket, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FSGS_DEFER_FEATURES="0" if mode == "plain" else "1",
+               FSGS_FACTORED_FEATURES="0" if mode == "plain" else "1")
+    out = ""
+    for attempt in range(2):
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+               "127.0.0.1", "--master-port", str(port), os.path.join(root, "tests", "dp_soak_worker.py"), "300"]
+        p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, cwd=root,
+                             start_new_session=True)
+        try:
+            out, _ = p.communicate(timeout=200)
+            break
+        except subprocess.TimeoutExpired:
+            os.killpg(p.pid, signal.SIGKILL)
+            out, _ = p.communicate()
+            assert attempt == 0, "2-rank run hung twice:\n" + out[-3000:]
+    assert p.returncode == 0, out[-3000:]
+    assert out.count(": ok, N ") == 2, out[-2000:]
