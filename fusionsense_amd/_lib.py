@@ -29,15 +29,8 @@ SIGNATURES = {
     "fsgs_scan_scratch_bytes": (_sz, [_i64]),
     "fsgs_isect_count": (_i, [_i, _i, _p, _p, _i, _i, _i, _i, _p, _p, _p, _sz, C.POINTER(_i64), C.POINTER(_i64), _p]),
     "fsgs_isect_emit": (_i, [_i, _i, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p]),
-    "fsgs_bucket_max_tile": (_i, []),
-    "fsgs_bucket_shards": (_i, []),
-    "fsgs_bucket_count": (_i, [_i, _i, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, C.POINTER(_i64), C.POINTER(_i64),
-                               C.POINTER(_i64), _p]),
-    "fsgs_bucket_fill_sort": (_i, [_i, _i, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _i64, _i64, _p, _p, _p, _p]),
     "fsgs_sort_scratch_bytes": (_sz, [_i64]),
     "fsgs_sort_pairs": (_i, [_i64, _p, _p, _p, _p, _i, _p, _sz, C.POINTER(_i), _p]),
-    "fsgs_sort_onesweep_scratch_bytes": (_sz, [_i64]),
-    "fsgs_sort_pairs_onesweep": (_i, [_i64, _p, _p, _p, _p, _i, _p, _sz, C.POINTER(_i), C.POINTER(_p), _p]),
     "fsgs_isect_offset_encode": (_i, [_i64, _p, _i, _i, _i, _p, _p]),
     "fsgs_raster_fwd": (_i, [_i, _i, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _i64, _p, _p, _p, _p]),
     "fsgs_raster_bwd": (_i, [_i, _i, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),

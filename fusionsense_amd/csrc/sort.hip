@@ -171,158 +171,6 @@ radix_scatter_kernel(int64_t n, const uint64_t *__restrict__ keys_in, const int3
 
 inline int64_t sort_num_blocks(int64_t n) { return (n + kSortTile - 1) / kSortTile; }
 
-// ---------------------------------------------------------------------------------------------
-// Single-sweep variant: ONE launch per pass.  The 3-launch scan of the [digit][block] table is
-// replaced by a decoupled look-back chain: workgroups take their tile index from an atomic
-// ticket (so every predecessor is already running: no dependence on dispatch order or placement),
-// publish their per-digit count, and thread d walks back over earlier tiles' status words until it
-// meets an inclusive prefix.  A status word is ONE naturally aligned 8-byte granule
-// {2-bit flag, 62-bit value} written and read with relaxed agent-scope atomics — the data is the
-// flag, so no fence or separate flag store is needed (cdna_hip_programming.md §6 G16, form R2).
-// The per-pass digit bases come from global histograms of all passes, built once up front.
-// Every spin is bounded; on timeout an error word is set and the caller falls back.
-// ---------------------------------------------------------------------------------------------
-constexpr unsigned long long kFlagAgg = 1ull << 62, kFlagPrefix = 2ull << 62, kValMask = (1ull << 62) - 1;
-constexpr int kMaxPasses = 8;
-constexpr unsigned kSpinLimit = 1u << 22;
-
-typedef __attribute__((address_space(1))) unsigned long long gu64;
-
-__device__ __forceinline__ void status_store(unsigned long long *p, unsigned long long v) {
-    __hip_atomic_store((gu64 *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ unsigned long long status_load(const unsigned long long *p) {
-    return __hip_atomic_load((gu64 *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// per-workgroup histograms of ALL passes' digits in one read of the keys: part[blk][pass][256]
-__global__ void __launch_bounds__(kSortBlock)
-onesweep_hist_kernel(int64_t n, const uint64_t *__restrict__ keys, int n_passes, int32_t *__restrict__ part) {
-    __shared__ unsigned counters[kMaxPasses][kRadix];
-    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int i = threadIdx.x; i < kMaxPasses * kRadix; i += kSortBlock) (&counters[0][0])[i] = 0;
-    __syncthreads();
-    const unsigned long long lt = lanemask_lt();
-    const int64_t base = (int64_t)blockIdx.x * kSortTile + (int64_t)w * (kSortRounds * 64);
-#pragma unroll
-    for (int r = 0; r < kSortRounds; ++r) {
-        const int64_t i = base + r * 64 + lane;
-        const bool act = i < n;
-        const uint64_t k = act ? keys[i] : 0ull;
-        for (int p = 0; p < n_passes; ++p) {
-            const unsigned d = (unsigned)((k >> (8 * p)) & 0xFFu);
-            const unsigned long long m = match_digit(d, act);
-            if (act && (m & lt) == 0) atomicAdd(&counters[p][d], (unsigned)__popcll(m));
-        }
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < n_passes * kRadix; i += kSortBlock)
-        part[(int64_t)blockIdx.x * (kMaxPasses * kRadix) + i] = (int32_t)(&counters[0][0])[i];
-}
-
-// one workgroup per pass: digit totals over all blocks, exclusive scan over the 256 digits
-__global__ void __launch_bounds__(kRadix)
-onesweep_base_kernel(int nblocks, const int32_t *__restrict__ part, int64_t *__restrict__ digit_base) {
-    __shared__ int64_t wtot[4];
-    const int p = blockIdx.x, d = threadIdx.x, lane = d & 63, w = d >> 6;
-    int64_t tot = 0;
-    for (int b = 0; b < nblocks; ++b) tot += part[(int64_t)b * (kMaxPasses * kRadix) + p * kRadix + d];
-    int64_t inc = tot;
-#pragma unroll
-    for (int s = 1; s < 64; s <<= 1) {
-        const int64_t o = __shfl_up(inc, s, 64);
-        if (lane >= s) inc += o;
-    }
-    if (lane == 63) wtot[w] = inc;
-    __syncthreads();
-    int64_t wbase = 0;
-    for (int k = 0; k < w; ++k) wbase += wtot[k];
-    digit_base[p * kRadix + d] = wbase + inc - tot;
-}
-
-__global__ void __launch_bounds__(kSortBlock)
-onesweep_pass_kernel(int64_t n, const uint64_t *__restrict__ keys_in, const int32_t *__restrict__ vals_in,
-                     uint64_t *__restrict__ keys_out, int32_t *__restrict__ vals_out, int shift,
-                     const int64_t *__restrict__ digit_base, unsigned long long *__restrict__ status,
-                     unsigned *__restrict__ ticket, unsigned *__restrict__ error) {
-    __shared__ unsigned counters[kSortWaves][kRadix];
-    __shared__ int64_t bases[kSortWaves][kRadix];
-    __shared__ unsigned s_tile;
-    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);
-    for (int i = threadIdx.x; i < kSortWaves * kRadix; i += kSortBlock) (&counters[0][0])[i] = 0;
-    __syncthreads();
-    const unsigned tile = s_tile;
-    const int64_t base = (int64_t)tile * kSortTile + (int64_t)w * (kSortRounds * 64);
-    uint64_t key[kSortRounds];
-    int32_t val[kSortRounds];
-    unsigned rank[kSortRounds];
-    const unsigned long long lt = lanemask_lt();
-#pragma unroll
-    for (int r = 0; r < kSortRounds; ++r) {
-        const int64_t i = base + r * 64 + lane;
-        const bool act = i < n;
-        key[r] = act ? keys_in[i] : 0ull;
-        val[r] = act ? vals_in[i] : 0;
-    }
-#pragma unroll
-    for (int r = 0; r < kSortRounds; ++r) {
-        const int64_t i = base + r * 64 + lane;
-        const bool act = i < n;
-        const unsigned d = (unsigned)((key[r] >> shift) & 0xFFu);
-        const unsigned long long m = match_digit(d, act);
-        const unsigned before = (unsigned)__popcll(m & lt);
-        unsigned prev = 0;
-        if (act) prev = counters[w][d];
-        if (act && before == 0) counters[w][d] = prev + (unsigned)__popcll(m);
-        rank[r] = prev + before;
-    }
-    __syncthreads();
-    {
-        const int d = threadIdx.x;  // kSortBlock == kRadix
-        unsigned cnt = 0;
-#pragma unroll
-        for (int k = 0; k < kSortWaves; ++k) cnt += counters[k][d];
-        unsigned long long *mine = status + (int64_t)tile * kRadix + d;
-        status_store(mine, (tile == 0 ? kFlagPrefix : kFlagAgg) | cnt);
-        unsigned long long excl = 0;
-        if (tile > 0) {
-            int64_t j = (int64_t)tile - 1;
-            unsigned spins = 0;
-            while (true) {
-                const unsigned long long v = status_load(status + j * kRadix + d);
-                const unsigned long long flag = v & ~kValMask;
-                if (flag == 0ull) {
-                    if (++spins > kSpinLimit) { atomicExch(error, 1u); break; }
-                    __builtin_amdgcn_s_sleep(1);
-                    continue;
-                }
-                excl += v & kValMask;
-                if (flag == kFlagPrefix) break;
-                --j;  // j >= 0 always: tile 0 publishes a PREFIX
-            }
-            status_store(mine, kFlagPrefix | (excl + cnt));
-        }
-        int64_t run = digit_base[d] + (int64_t)excl;
-#pragma unroll
-        for (int k = 0; k < kSortWaves; ++k) {
-            bases[k][d] = run;
-            run += counters[k][d];
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < kSortRounds; ++r) {
-        const int64_t i = base + r * 64 + lane;
-        if (i < n) {
-            const unsigned d = (unsigned)((key[r] >> shift) & 0xFFu);
-            const int64_t pos = bases[w][d] + rank[r];
-            keys_out[pos] = key[r];
-            vals_out[pos] = val[r];
-        }
-    }
-}
-
 }  // namespace fsgs
 
 using namespace fsgs;
@@ -370,57 +218,3 @@ extern "C" int fsgs_sort_pairs(int64_t n, int64_t *keys_a, int32_t *vals_a, int6
 }
 
 
-// ---- single-sweep entry point -----------------------------------------------------------------
-// scratch: [part i32: nb*8*256] [digit_base i64: 8*256] [status u64: passes*nb*256] [tickets u32: 8] [error u32]
-extern "C" size_t fsgs_sort_onesweep_scratch_bytes(int64_t n) {
-    const int64_t nb = sort_num_blocks(n > 0 ? n : 1);
-    return (size_t)nb * kMaxPasses * kRadix * 4 + (size_t)kMaxPasses * kRadix * 8 +
-           (size_t)kMaxPasses * nb * kRadix * 8 + 64 + 256;
-}
-
-// Same contract as fsgs_sort_pairs.  *error_host (nullable) is NOT read back here (no sync); the
-// device error word lives at the end of scratch and is returned through error_dev_out for the caller
-// to inspect at its next synchronisation point.
-extern "C" int fsgs_sort_pairs_onesweep(int64_t n, int64_t *keys_a, int32_t *vals_a, int64_t *keys_b,
-                                        int32_t *vals_b, int end_bit, void *scratch, size_t scratch_bytes,
-                                        int *result_in_b, uint32_t **error_dev_out, fsgs_stream_t stream) {
-    if (n < 0 || end_bit < 0 || end_bit > 64 || !result_in_b) return FSGS_EINVAL;
-    *result_in_b = 0;
-    if (error_dev_out) *error_dev_out = nullptr;
-    if (n <= 1 || end_bit == 0) return FSGS_OK;
-    if (!keys_a || !vals_a || !keys_b || !vals_b || !scratch) return FSGS_EINVAL;
-    if (scratch_bytes < fsgs_sort_onesweep_scratch_bytes(n)) return FSGS_ESCRATCH;
-    const int n_passes = (end_bit + 7) / 8;
-    const int64_t nb = sort_num_blocks(n);
-    char *p = reinterpret_cast<char *>(scratch);
-    int32_t *part = reinterpret_cast<int32_t *>(p);
-    p += (size_t)nb * kMaxPasses * kRadix * 4;
-    int64_t *digit_base = reinterpret_cast<int64_t *>(p);
-    p += (size_t)kMaxPasses * kRadix * 8;
-    unsigned long long *status = reinterpret_cast<unsigned long long *>(p);
-    const size_t status_bytes = (size_t)n_passes * nb * kRadix * 8;
-    p += (size_t)kMaxPasses * nb * kRadix * 8;
-    unsigned *tickets = reinterpret_cast<unsigned *>(p);
-    unsigned *error = tickets + 8;
-    hipStream_t s = as_stream(stream);
-    // every polled word is re-initialised on every call (status, tickets, error are contiguous)
-    hipError_t e = hipMemsetAsync(status, 0, status_bytes, s);
-    if (e == hipSuccess) e = hipMemsetAsync(tickets, 0, 64, s);
-    if (e != hipSuccess) { g_last_hip_error = (int)e; return FSGS_ELAUNCH; }
-    uint64_t *kin = reinterpret_cast<uint64_t *>(keys_a), *kout = reinterpret_cast<uint64_t *>(keys_b);
-    int32_t *vin = vals_a, *vout = vals_b;
-    hipLaunchKernelGGL(onesweep_hist_kernel, dim3((unsigned)nb), dim3(kSortBlock), 0, s, n, kin, n_passes, part);
-    hipLaunchKernelGGL(onesweep_base_kernel, dim3(n_passes), dim3(kRadix), 0, s, (int)nb, part, digit_base);
-    int in_b = 0;
-    for (int pass = 0; pass < n_passes; ++pass) {
-        hipLaunchKernelGGL(onesweep_pass_kernel, dim3((unsigned)nb), dim3(kSortBlock), 0, s, n, kin, vin, kout, vout,
-                           pass * 8, digit_base + pass * kRadix, status + (size_t)pass * nb * kRadix, tickets + pass,
-                           error);
-        uint64_t *tk = kin; kin = kout; kout = tk;
-        int32_t *tv = vin; vin = vout; vout = tv;
-        in_b ^= 1;
-    }
-    *result_in_b = in_b;
-    if (error_dev_out) *error_dev_out = error;
-    return check_launch();
-}

@@ -238,9 +238,16 @@ def save_checkpoint(trainer, path: str) -> None:
     if hasattr(trainer, "flush"):
         trainer.flush()  # a deferred feature update (data-parallel runs) must be in the parameters
     pipeline = {_CKPT_PREFIX + k: v.detach().cpu() for k, v in trainer.params.items()}
+    # gauss_params["normals"] is re-derived by every get_outputs (dn_model.py:634) but is a key of the reference's
+    # state dict: the last frame's world-space normals, or zeros before the first frame
+    n = trainer.params["means"].shape[0]
+    nw = getattr(getattr(trainer, "last_info", None), "normals_world", None)
+    pipeline[_CKPT_PREFIX + "normals"] = (nw.detach().cpu() if nw is not None and nw.shape[0] == n
+                                          else torch.zeros(n, 3))
     optimizers = {k: opt.state_dict() for k, opt in trainer.optimizers.items()}
-    torch.save({"step": int(trainer.step), "pipeline": pipeline, "optimizers": optimizers,
-                "adam_steps": int(getattr(trainer, "adam_steps", 0))}, path)
+    # nerfstudio stores the step it has just COMPLETED and resumes at step + 1; trainer.step counts completed steps
+    torch.save({"step": max(int(trainer.step) - 1, 0), "fsgs_next_step": int(trainer.step), "pipeline": pipeline,
+                "optimizers": optimizers, "adam_steps": int(getattr(trainer, "adam_steps", 0))}, path)
 
 
 def load_checkpoint(trainer, path: str) -> int:
@@ -268,8 +275,13 @@ def load_checkpoint(trainer, path: str) -> int:
                 for k2, t2 in list(st.items()):
                     if torch.is_tensor(t2) and k2 != "step":
                         st[k2] = t2.to(dev)
-    trainer.step = int(ck["step"])
-    trainer.adam_steps = int(ck.get("adam_steps", 0))
+    # a nerfstudio-written file has only "step" (the completed one): resume at step + 1, as its Trainer does
+    trainer.step = int(ck["fsgs_next_step"]) if "fsgs_next_step" in ck else int(ck["step"]) + 1
+    if "adam_steps" in ck:
+        trainer.adam_steps = int(ck["adam_steps"])
+    else:  # the bias-correction count of warm moments comes from the optimizer state, not from zero
+        steps = [float(st["step"]) for opt in trainer.optimizers.values() for st in opt.state.values() if "step" in st]
+        trainer.adam_steps = int(max(steps)) if steps else 0
     strat = getattr(trainer, "strategy", None)
     if strat is not None:  # statistics are not part of a nerfstudio checkpoint: they restart
         strat.xys_grad_norm = strat.vis_counts = strat.max_2Dsize = None

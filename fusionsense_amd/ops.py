@@ -143,7 +143,6 @@ def isect_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tile_size: int, 
                                C.byref(diff_host) if return_rule_diff else None, stream_ptr(dev)),
          "fsgs_isect_count")
     M = int(m_host.value)
-    check_onesweep_errors()  # the stream was just synchronised: earlier sorts' error words have landed
     ids = torch.empty(M, dtype=torch.int64, device=dev)
     flat = torch.empty(M, dtype=torch.int32, device=dev)
     if M > 0:
@@ -160,65 +159,16 @@ def isect_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tile_size: int, 
     return tpg, ids, flat
 
 
-# Tile-bucketed binning + per-tile LDS sort (csrc/bucket.hip): bit-exact and 4 launches, but measured
-# SLOWER than the radix path on MI355X at config #2 (0.48 vs 0.33 ms: ~M memory-side atomics per pass, even
-# with 16-way sharded counters).  Kept as a tested alternative; off by default.
-USE_BUCKET_BINNING = False
-
-
 def bin_and_sort(means2d: Tensor, radii: Tensor, depths: Tensor, tile_size: int, tile_width: int,
                  tile_height: int, legacy: bool = False):
     """isect_tiles + sort + isect_offset_encode in one go.  Returns tiles_per_gauss [C,N] i32,
     isect_ids [M] i64 (sorted), flatten_ids [M] i32, isect_offsets [C,th,tw] i32, rule_diff.
-    Uses the bucketed path (csrc/bucket.hip) unless a tile holds more entries than fit in LDS."""
-    lib = load()
-    dev = means2d.device
-    Cn, N = radii.shape
-    if USE_BUCKET_BINNING:
-        T = Cn * tile_width * tile_height
-        tpg = torch.empty(Cn, N, dtype=torch.int32, device=dev)
-        S = lib.fsgs_bucket_shards()
-        counts = torch.empty(T * S, dtype=torch.int32, device=dev)
-        shard_offsets = torch.empty(T * S + 1, dtype=torch.int32, device=dev)
-        offsets = torch.empty(T + 1, dtype=torch.int32, device=dev)
-        stats = torch.empty(3, dtype=torch.int64, device=dev)
-        m_host, max_host, diff_host = C.c_int64(0), C.c_int64(0), C.c_int64(0)
-        _run(lib.fsgs_bucket_count, (Cn, N, ptr(means2d), ptr(radii), tile_size, tile_width, tile_height, int(legacy),
-                                    ptr(tpg), ptr(counts), ptr(shard_offsets), ptr(offsets), ptr(stats), C.byref(m_host),
-                                    C.byref(max_host), C.byref(diff_host), stream_ptr(dev)), "fsgs_bucket_count")
-        M, max_bucket = int(m_host.value), int(max_host.value)
-        if max_bucket <= lib.fsgs_bucket_max_tile():
-            ids = torch.empty(M, dtype=torch.int64, device=dev)
-            flat = torch.empty(M, dtype=torch.int32, device=dev)
-            if M > 0:
-                keys = torch.empty(M, dtype=torch.int64, device=dev)
-                _run(lib.fsgs_bucket_fill_sort, (Cn, N, ptr(means2d), ptr(radii), ptr(depths), tile_size, tile_width,
-                                                tile_height, int(legacy), ptr(counts), ptr(shard_offsets), ptr(offsets), M,
-                                                max_bucket,
-                                                ptr(keys), ptr(ids), ptr(flat), stream_ptr(dev)),
-                     "fsgs_bucket_fill_sort")
-            return tpg, ids, flat, offsets[:T].view(Cn, tile_height, tile_width), int(diff_host.value)
+    (count + emit, the stable radix sort, offset_encode)."""
+    Cn = radii.shape[0]
     tpg, ids, flat, diff = isect_tiles(means2d, radii, depths, tile_size, tile_width, tile_height, legacy=legacy,
                                        sort=True, return_rule_diff=True)
     offsets = isect_offset_encode(ids, Cn, tile_width, tile_height)
     return tpg, ids, flat, offsets, diff
-
-
-USE_ONESWEEP_SORT = False  # single-sweep radix passes (csrc/sort.hip): correct but 0.52 vs 0.23 ms (serial look-back over memory-side status words)
-_onesweep_errors = []       # device error words of recent sorts, checked lazily (no extra sync)
-
-
-def check_onesweep_errors(sync: bool = False) -> None:
-    """Raise if any single-sweep sort since the last check reported a look-back timeout.  The error
-    words were copied to pinned host memory right after each sort; this is called where the stream
-    has just been synchronised anyway (after fsgs_isect_count), so it costs no extra sync."""
-    global _onesweep_errors
-    if sync and _onesweep_errors:
-        torch.cuda.synchronize()
-    pending, _onesweep_errors = _onesweep_errors, []
-    for t in pending:
-        if int(t[0]) != 0:
-            raise _lib.FsgsError("single-sweep radix sort: look-back spin timed out; results invalid")
 
 
 def isect_count_live_async(means2d: Tensor, radii: Tensor, conics: Tensor, opacities: Tensor,
@@ -283,7 +233,6 @@ def isect_finish_live(st: dict, means2d: Tensor, radii: Tensor, depths: Tensor, 
     if st["total"] > 0:
         _wait_event(st["event"])
         M = int(st["pinned"][0])
-    check_onesweep_errors()
     ids = torch.empty(M, dtype=torch.int64, device=dev)
     pay = torch.empty(M, dtype=torch.int32, device=dev)
     if M > 0:
@@ -472,18 +421,6 @@ def sort_pairs(keys: Tensor, vals: Tensor, end_bit: int = 64) -> Tuple[Tensor, T
     dev = keys.device
     kb = torch.empty_like(keys)
     vb = torch.empty_like(vals)
-    if USE_ONESWEEP_SORT:
-        sbytes = lib.fsgs_sort_onesweep_scratch_bytes(n)
-        scratch = torch.empty(sbytes, dtype=torch.uint8, device=dev)
-        in_b = C.c_int(0)
-        err_ptr = C.c_void_p(0)
-        _run(lib.fsgs_sort_pairs_onesweep, (n, ptr(keys), ptr(vals), ptr(kb), ptr(vb), end_bit, ptr(scratch), sbytes,
-                                           C.byref(in_b), C.byref(err_ptr), stream_ptr(dev)), "fsgs_sort_pairs")
-        off = err_ptr.value - scratch.data_ptr()
-        host_flag = torch.zeros(1, dtype=torch.int32).pin_memory()
-        host_flag.copy_(scratch[off:off + 4].view(torch.int32), non_blocking=True)
-        _onesweep_errors.append(host_flag)
-        return (kb, vb) if in_b.value else (keys, vals)
     sbytes = lib.fsgs_sort_scratch_bytes(n)
     scratch = torch.empty(sbytes, dtype=torch.uint8, device=dev)
     in_b = C.c_int(0)
@@ -822,6 +759,8 @@ def compact_rows(src: Tensor, keep8: Tensor, positions: Tensor, n_keep: int,
     if out is None:
         out = torch.empty((n_keep,) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
         out_offset = 0
+    if n == 0 or n_keep == 0 or src[0].numel() == 0:
+        return out  # nothing to move (features_rest is [N,0,3] at sh_degree 0; everything culled; empty source)
     dst = out[out_offset:]
     _run(lib.fsgs_compact_rows, (n, row, ptr(keep8), ptr(positions), ptr(src), dst.data_ptr(),
                                 stream_ptr(src.device)), "fsgs_compact_rows")

@@ -352,6 +352,10 @@ class DensifyStrategy:
         """New parameter tensors + Adam moments: kept old rows (order preserved, HIP compaction)
         followed by the kept new rows; new rows get zero moments (dup_in_optim), culled rows
         drop theirs (remove_from_optim)."""
+        if hasattr(trainer, "flush"):
+            # a deferred feature update (data-parallel runs) is sized for the old N and reads the old slab: it must
+            # land before any row moves — add_touch_patch / hull_pruning / touch_pruning run between two steps
+            trainer.flush()
         keep8 = keep_old.to(torch.uint8).contiguous()
         positions = ops.mask_positions(keep8)
         n_final = n_keep_old + n_keep_new

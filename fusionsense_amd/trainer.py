@@ -119,8 +119,9 @@ class SplatTrainer:
         # interval 1000); None = always the full degree (BASELINE config #2 is quoted at degree 3)
         self.sh_degree_interval = sh_degree_interval
         self.optim_cfg = optim or OptimConfig()
+        # (a copy: training must not write into the caller's tensors)
         self.params: Dict[str, torch.nn.Parameter] = {
-            k: torch.nn.Parameter(params[k].to(device=device, dtype=torch.float32).contiguous())
+            k: torch.nn.Parameter(params[k].detach().to(device=device, dtype=torch.float32, copy=True).contiguous())
             for k in PARAM_ORDER}
         self.fused_adam = fused_adam and device.type == "cuda"
         self.optimizers: Dict[str, torch.optim.Adam] = {}
@@ -141,9 +142,9 @@ class SplatTrainer:
         # all-gathered); fsgs_sh_coeff_grad rebuilds the mean gradient on every rank, in rank order, so the
         # replicas stay bit-identical.  Fused CUDA path only; FSGS_FACTORED_FEATURES=0 switches it off.
         self.factored_features = os.environ.get("FSGS_FACTORED_FEATURES", "1") != "0"
-        # single rank: the same factored form saves the gradient's write + read (sh_bwd writes 16 B instead of 192 B
-        # per Gaussian, the features' Adam launch rebuilds the gradient in LDS)
-        self.factored_single = os.environ.get("FSGS_FACTORED_SINGLE", "0") == "1"  # (measured: -3 us only; off, so that the feature gradients stay materialised)
+        # How the factor blocks are gathered is decided ONCE, here, from the backend — never by catching an exception
+        # inside a step: ranks that disagreed on the collective would deadlock.
+        self._gather_flat = None
         self._factors = None
         self._pending = None
         self.step = 0
@@ -251,8 +252,7 @@ class SplatTrainer:
 
     def _factor_buffers(self, optimizer_step: bool):
         """(own [N + 1,4], gathered [R, N + 1,4]) when this step exchanges the SH gradients as factors, else None."""
-        single = (optimizer_step and self.factored_single and GradSlab._world() == 1 and not self.force_split_step)
-        if not ((self._split_step(optimizer_step) or single) and self.factored_features and self.fused
+        if not (self._split_step(optimizer_step) and self.factored_features and self.fused
                 and self.device.type == "cuda"):
             return None
         R, N = GradSlab._world(), self.num_gaussians()
@@ -295,18 +295,6 @@ class SplatTrainer:
         the feature half is only STARTED here; ``flush`` completes it when the next frame needs the colours."""
         assert self._pending is None, "the previous step's feature update has not been flushed"
         split = self._split_step(optimizer_step)
-        factors = getattr(self, "_factors_used", None)
-        if not split and factors is not None:
-            # single rank, factored features (see _factor_buffers): rebuild + Adam of the two feature groups in one
-            # launch from this frame's factors, then the geometry groups
-            self._factors_used = None
-            self._means_prev = self.params["means"].data  # (not stepped yet)
-            self.optimizers["means"].param_groups[0]["lr"] = self._means_lr(self.step)
-            self.adam_steps = getattr(self, "adam_steps", 0) + 1
-            self._features_from_factors(self._sh_degree_now(), self.adam_steps)
-            self._optimizer_step(GEOMETRY_GROUPS, self.adam_steps)
-            self._means_prev = None
-            return
         if not split:
             self.slab.all_reduce_mean_()
             if optimizer_step:
@@ -320,14 +308,15 @@ class SplatTrainer:
             own, gathered = factors
             work = None
             if GradSlab._world() > 1:
-                work = None
-                if dist.get_backend() == "nccl":
-                    try:
-                        work = dist.all_gather_into_tensor(gathered.view(-1), own.view(-1), async_op=True)
-                    except (RuntimeError, AttributeError, NotImplementedError):
-                        work = None  # (every rank takes the same branch: the list form below)
-                if work is None:  # gloo, or a backend without the flat form
+                if self._gather_flat is None:
+                    # RCCL has the flat form; gloo only the list form.  A function of the backend alone, so every
+                    # rank decides the same way.
+                    self._gather_flat = dist.get_backend() == "nccl"
+                if self._gather_flat:
+                    work = dist.all_gather_into_tensor(gathered.view(-1), own.view(-1), async_op=True)
+                else:
                     work = dist.all_gather(list(gathered.unbind(0)), own, async_op=True)
+                self.comm_bytes_last_step = 4 * (self.slab.split * 2 + gathered.numel())
             deg = self._sh_degree_now()
             mp = getattr(self, "_means_prev", None)
             if mp is None or mp.shape != self.params["means"].shape:
@@ -362,7 +351,12 @@ class SplatTrainer:
     def train_step(self, camera: Camera, target: Dict[str, Tensor], optimizer_step: bool = True):
         if getattr(self, "_one", None) is None or self._one.device != self.device:
             self._one = torch.ones((), dtype=torch.float32, device=self.device)
-        if self.fused and self.direct and self.device.type == "cuda" and "depth" in target:
+        direct = self.fused and self.direct and self.device.type == "cuda" and "depth" in target
+        if not direct:
+            # the previous step's deferred feature update reads the slab: it must land before the slab is cleared
+            # (the tape-free step hands flush to the frame instead, which calls it right before the SH colours)
+            self.flush()
+        if direct:
             from .fused import fused_step_forward_backward
             stats, add_mask, bthr = self._frame_state(camera, True)
             factors = self._factor_buffers(optimizer_step)

@@ -140,31 +140,6 @@ int fsgs_isect_emit(int C, int N, const float *means2d, const int32_t *radii, co
                     const int64_t *cum_tiles, int tile_size, int tile_width, int tile_height,
                     int legacy, int64_t *isect_ids, int32_t *flatten_ids, fsgs_stream_t stream);
 
-/* ---- E4-E6 fast path: tile-bucketed binning + per-tile LDS sort (csrc/bucket.hip) -------------
- * Same outputs as isect_count + isect_emit + sort_pairs + isect_offset_encode, bit for bit, in
- * four launches: per-tile counts with atomics -> one-workgroup scan (= isect_offsets) -> scatter of
- * 64-bit in-tile keys (bits(depth)<<32 | flatten id) -> one workgroup per tile sorts its bucket in
- * LDS.  Usable when the largest bucket has <= fsgs_bucket_max_tile() entries (the caller falls
- * back to the radix path otherwise).
- * fsgs_bucket_count: tile_counts[T*S] (T = C*tiles, S = fsgs_bucket_shards(): every tile has S
- * counters so that ~M/T increments do not serialise on one address; scratch, left zeroed = the
- * cursors of the next call), shard_offsets[T*S+1], tile_offsets[T+1] (exclusive scans; [T] = M),
- * stats_dev[3] i64 scratch; synchronises and returns M, the largest tile bucket and (nullable) the
- * other-bbox-rule count. */
-int fsgs_bucket_max_tile(void);
-int fsgs_bucket_shards(void);
-int fsgs_bucket_count(int C, int N, const float *means2d, const int32_t *radii, int tile_size,
-                      int tile_width, int tile_height, int legacy, int32_t *tiles_per_gauss,
-                      int32_t *tile_counts, int32_t *shard_offsets, int32_t *tile_offsets,
-                      int64_t *stats_dev, int64_t *n_isects_host, int64_t *max_bucket_host, int64_t *n_rule_diff_host,
-                      fsgs_stream_t stream);
-int fsgs_bucket_fill_sort(int C, int N, const float *means2d, const int32_t *radii, const float *depths,
-                          int tile_size, int tile_width, int tile_height, int legacy,
-                          int32_t *tile_cursors, const int32_t *shard_offsets,
-                          const int32_t *tile_offsets, int64_t n_isects,
-                          int64_t max_bucket, void *keys_scratch, int64_t *isect_ids,
-                          int32_t *flatten_ids, fsgs_stream_t stream);
-
 /* Live emission (tile_size 16; used by the fused get_outputs node, where gsplat's full lists are not
  * an output): a (Gaussian, tile) pair is counted / emitted only if the Gaussian can reach one of the
  * tile's 8x8 quadrants at alpha >= 1/255 (the same conservative test as fsgs_live_payload), and the
@@ -188,16 +163,6 @@ size_t fsgs_sort_scratch_bytes(int64_t n);
 int fsgs_sort_pairs(int64_t n, int64_t *keys_a, int32_t *vals_a, int64_t *keys_b, int32_t *vals_b,
                     int end_bit, void *scratch, size_t scratch_bytes, int *result_in_b,
                     fsgs_stream_t stream);
-
-/* Single-sweep variant of the same sort: one launch per 8-bit pass (decoupled look-back over
- * ticket-ordered tiles, 8-byte {flag,value} agent-scope status granules, bounded spins) plus two
- * up-front histogram launches, instead of five launches per pass.  Same result, bit for bit.
- * *error_dev_out receives the address of a device word that becomes non-zero if a look-back spin
- * timed out (the output is then invalid and the caller must re-sort with fsgs_sort_pairs). */
-size_t fsgs_sort_onesweep_scratch_bytes(int64_t n);
-int fsgs_sort_pairs_onesweep(int64_t n, int64_t *keys_a, int32_t *vals_a, int64_t *keys_b,
-                             int32_t *vals_b, int end_bit, void *scratch, size_t scratch_bytes,
-                             int *result_in_b, uint32_t **error_dev_out, fsgs_stream_t stream);
 
 /* ---- E6: isect_offset_encode (gsplat._C.isect_offset_encode) ---------------------------------
  * offsets[C*n_tiles] i32: first sorted index of every (camera, tile). */

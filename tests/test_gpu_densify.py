@@ -156,3 +156,39 @@ def test_touch_and_hull_callbacks(dev):
     d = st.hull_pruning(tr, hull, scale_factor=1.0)
     assert bool(d[0]) and not bool(d[1]) and not bool(d[2])
     assert tr.params["means"].shape[0] == n_before - int(d.sum())
+
+
+def test_row_moving_callbacks_flush_a_deferred_feature_update(dev):
+    """add_touch_patch is a BEFORE_TRAIN_ITERATION callback; in a data-parallel run the previous
+    step's deferred feature update (sized for the old N, reading the old slab) is still pending when it runs.
+    _rebuild must land it first.  Forced split step on one rank, both exchange formats, against the plain step."""
+    from fusionsense_amd.splatfacto import DensifyStrategy, SplatfactoConfig
+    from fusionsense_amd.trainer import PARAM_ORDER, SplatTrainer
+    params = scenes.lego_like_scene(6000, seed=5)
+    cams = scenes.hemisphere_cameras(2, width=160, height=128, focal=180.0, seed=1)
+    g = torch.Generator().manual_seed(0)
+    tgts = [{"rgb": torch.rand(128, 160, 3, generator=g).to(dev), "depth": torch.rand(128, 160, 1, generator=g).to(dev),
+             "normal": torch.rand(128, 160, 3, generator=g).to(dev)} for _ in cams]
+    pts = 0.05 * torch.randn(40, 3, generator=g)
+    nrm = torch.nn.functional.normalize(torch.randn(40, 3, generator=g), dim=-1)
+    box = torch.tensor([[(i & 1) * 0.2 - 0.1, ((i >> 1) & 1) * 0.2 - 0.1, ((i >> 2) & 1) * 0.2 - 0.1] for i in range(8)])
+    patches = [dict(points_xyz=pts, normals=nrm, bbox=box)]
+    for factored in (True, False):
+        trs = []
+        for split in (True, False):
+            st = DensifyStrategy(SplatfactoConfig(), num_train_data=2, stats_only=True)
+            tr = SplatTrainer(params, dev, seed=0, strategy=st)
+            tr.force_split_step = split
+            tr.factored_features = factored
+            tr.train_step(cams[0], tgts[0])
+            assert (tr._pending is not None) == split
+            added = st.add_touch_patch(tr, patches, gel_scale_factor=6.34e-4)
+            assert added == 40 and tr._pending is None
+            tr.train_step(cams[1], tgts[1])
+            tr.flush()
+            trs.append(tr)
+        a, b = trs
+        assert a.num_gaussians() == b.num_gaussians()
+        for k in PARAM_ORDER:
+            d = (a.params[k].data - b.params[k].data).abs()
+            assert float((d > 2e-5).float().mean()) < 2e-3 and float(d.mean()) < 2e-6, (factored, k)

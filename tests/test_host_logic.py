@@ -476,3 +476,44 @@ def test_checkpoint_roundtrip_resizes_like_splatfacto(tmp_path):
         sa, sb = a.optimizers[k].state[a.params[k]], b.optimizers[k].state[b.params[k]]
         assert torch.equal(sa["exp_avg"], sb["exp_avg"]) and torch.equal(sa["exp_avg_sq"], sb["exp_avg_sq"])
         assert b.params[k].grad is b.slab.views[k]
+    # nerfstudio's conventions: "step" is the COMPLETED step (resume at step + 1), gauss_params.normals is a key,
+    # and a file without this package's private keys still restores the Adam bias-correction count
+    assert ck["step"] == 1233 and ck["pipeline"]["_model.gauss_params.normals"].shape == (50, 3)
+    ns = {k: v for k, v in ck.items() if k not in ("fsgs_next_step", "adam_steps")}
+    torch.save(ns, str(tmp_path / "ns.ckpt"))
+    c = SplatTrainer(pb, dev, fused=False)
+    assert fio.load_checkpoint(c, str(tmp_path / "ns.ckpt")) == 1234 and c.adam_steps == 1
+
+
+def test_unfused_train_step_flushes_deferred_features_before_clearing_the_slab(monkeypatch):
+    """with the deferred feature update (data-parallel step order, forced on one rank) the op-by-op
+    trainer zeroes the gradient slab at the top of train_step — the previous step's pending feature update reads
+    that slab, so it must have landed first.  Driven through train_step itself with a CPU stand-in for get_outputs."""
+    from fusionsense_amd.trainer import PARAM_ORDER, SplatTrainer
+
+    class T(SplatTrainer):
+        def forward(self, camera, **kw):
+            self.flush()
+            val = sum(((p * (i + 1)).sin() * (1.0 + 0.1 * self.step)).sum() for i, p in enumerate(self.params.values()))
+            return {"val": val, "info": None}
+
+        def loss(self, out, target):
+            return out["val"]
+
+    torch.manual_seed(0)
+    n = 30
+    shapes = dict(means=(n, 3), scales=(n, 3), quats=(n, 4), features_dc=(n, 3), features_rest=(n, 15, 3), opacities=(n, 1))
+    init = {k: torch.randn(*shapes[k]) for k in PARAM_ORDER}
+    init0 = {k: v.clone() for k, v in init.items()}
+    cpu = torch.device("cpu")
+    a, b = T(init, cpu, fused=False), T(init, cpu, fused=False)
+    a.force_split_step = True
+    for it in range(4):
+        a.train_step(None, {})
+        b.train_step(None, {})
+        assert a._pending is not None and b._pending is None
+    a.flush()
+    for k in PARAM_ORDER:
+        assert torch.equal(a.params[k].data, b.params[k].data), k
+    for k in PARAM_ORDER:  # the trainer owns a copy: the caller's tensors are untouched
+        assert torch.equal(init[k], init0[k]) and not torch.equal(init[k], a.params[k].data), k
