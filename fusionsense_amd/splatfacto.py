@@ -112,6 +112,13 @@ def cull_mask(cfg: SplatfactoConfig, step: int, opacities: Tensor, log_scales: T
     return culls
 
 
+def _flush(trainer) -> None:
+    """Callbacks that read or move parameter rows run between two steps; in a data-parallel run the previous step's
+    deferred feature update (trainer.flush) must have landed before they look at anything."""
+    if hasattr(trainer, "flush"):
+        trainer.flush()
+
+
 class DensifyStrategy:
     def __init__(self, cfg: Optional[SplatfactoConfig] = None, num_train_data: int = 1,
                  stats_only: bool = False):
@@ -269,6 +276,7 @@ class DensifyStrategy:
     def cull_gaussians(self, trainer, extra_cull_mask: Optional[Tensor] = None) -> Tensor:
         """SplatfactoModel.cull_gaussians + remove_from_all_optim in one pass.  Returns the
         deleted mask over the rows that existed before the call."""
+        _flush(trainer)
         P = trainer.params
         culls = cull_mask(self.cfg, trainer.step, P["opacities"].data, P["scales"].data, self.max_2Dsize,
                           extra_cull_mask)
@@ -285,6 +293,7 @@ class DensifyStrategy:
     @torch.no_grad()
     def append_gaussians(self, trainer, rows: Dict[str, Tensor]) -> None:
         """Append rows with zero Adam moments (add_in_all_optim, dn_model.py:1150-1152)."""
+        _flush(trainer)
         n_old = trainer.params["means"].shape[0]
         n_new = rows["means"].shape[0]
         dev = trainer.params["means"].device
@@ -297,6 +306,7 @@ class DensifyStrategy:
         """dn_model.py:1156-1247 at step == add_touch_at: cull Gaussians inside the patches'
         oriented boxes, then append the touch points as fixed anchors (``add_mask``).  Colours
         of the new points come from the nearest existing Gaussian (knn_sk, k=1, dn_model.py:1181-1182)."""
+        _flush(trainer)
         from .touch import make_touch_gaussians, touch_aabb_mask
         P = trainer.params
         means = P["means"].data
@@ -329,6 +339,7 @@ class DensifyStrategy:
     @torch.no_grad()
     def hull_pruning(self, trainer, visual_hull: Tensor, scale_factor: float) -> Optional[Tensor]:
         """dn_model.py:1249-1276."""
+        _flush(trainer)
         from .touch import hull_prune_mask
         if trainer.step <= self.cfg.warmup_length:
             return None
@@ -340,6 +351,7 @@ class DensifyStrategy:
     @torch.no_grad()
     def touch_pruning(self, trainer, touch_patches) -> Optional[Tensor]:
         """dn_model.py:1279-1302."""
+        _flush(trainer)
         from .touch import touch_aabb_mask
         if trainer.step <= self.cfg.warmup_length or self.add_mask is None:
             return None

@@ -1,0 +1,134 @@
+#!/usr/bin/env python3
+"""Golden vectors of the FusionSense training loss, made by EXECUTING the reference's own
+``DNSplatterModel.get_loss_dict`` (/root/reference/dn_splatter/dn_model.py:673-925) in this container.
+
+The method is called unbound on a bare instance whose base class is a small stand-in for nerfstudio's
+``SplatfactoModel`` (nerfstudio is not installed): the stand-in's ``get_loss_dict`` returns a ZERO main loss, so
+the stored value is exactly what FusionSense's own code adds on top of splatfacto's photometric term — mask
+handling, EdgeAwareLogL1 on the sensor depth with the valid mask, TV on depth, normal L1 + TV, the min-scale term
+and the touch-normal MSE — with the weights of /root/reference/configs/config.py.  Gradients with respect to the
+rendered depth / normal images and the log-scales come from autograd through that same code.
+
+Runs only where /root/reference exists.  Nothing of the reference's source travels: only the seeded inputs and the
+numbers it produced (tests/golden/reference_loss.npz), next to this script.
+"""
+import dataclasses
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import make_reference_goldens as base  # noqa: E402  (stub machinery)
+
+OUT = os.path.join(HERE, "reference_loss.npz")
+
+
+def _splatfacto_standin():
+    """nerfstudio.models.splatfacto with a SplatfactoModel that supplies what get_loss_dict touches."""
+    m = base._Stub("nerfstudio.models.splatfacto")
+    m.__path__ = []
+
+    @dataclasses.dataclass
+    class SplatfactoModelConfig:
+        pass
+
+    class SplatfactoModel:
+        def get_gt_img(self, image):
+            return image.to(self.device)  # float images, num_downscales = 0 (dn_model.py:118)
+
+        def get_loss_dict(self, outputs, batch, metrics_dict=None):
+            z = torch.zeros((), device=self.device)
+            return {"main_loss": z, "scale_reg": z.clone()}
+
+        @property
+        def scales(self):
+            return self.gauss_params["scales"]
+
+    m.SplatfactoModel = SplatfactoModel
+    m.SplatfactoModelConfig = SplatfactoModelConfig
+    return m
+
+
+def case(model_mod, losses, seed, H, W, n_gauss, with_mask, with_touch, holes):
+    g = torch.Generator().manual_seed(seed)
+    cfgd = {}
+    sys.path.insert(0, os.path.join(base.REF, "configs"))
+    import config as ref_cfg  # /root/reference/configs/config.py: the values scripts/train.py passes on
+    cfg = types.SimpleNamespace(
+        use_depth_loss=ref_cfg.use_depth_loss, sensor_depth_lambda=ref_cfg.sensor_depth_lambda,
+        depth_tolerance=0.1, depth_loss_type=losses.DepthLossType.EdgeAwareLogL1, mono_depth_lambda=0.2,
+        use_depth_smooth_loss=ref_cfg.use_depth_smooth_loss, smooth_loss_type=losses.DepthLossType.TV,
+        smooth_loss_lambda=0.1, use_normal_loss=ref_cfg.use_normal_loss, normal_supervision=ref_cfg.normal_supervision,
+        use_normal_cosine_loss=False, use_normal_tv_loss=True, normal_lambda=ref_cfg.normal_lambda,
+        two_d_gaussians=True, use_sparse_loss=False, use_sdf_loss=False, sdf_loss_lambda=0.1,
+        reset_alpha_every=30, refine_every=100)
+    self = object.__new__(model_mod.DNSplatterModel)
+    self.config = cfg
+    self.device = torch.device("cpu")
+    self.step = 7  # (not a multiple of 100: the reference writes a debug JPEG there)
+    self.depth_loss = losses.DepthLoss(cfg.depth_loss_type)
+    self.smooth_loss = losses.DepthLoss(depth_loss_type=losses.DepthLossType.TV)
+    self.tv_loss = losses.TVLoss()
+    scales = (torch.randn(n_gauss, 3, generator=g) * 0.7 - 4.0).requires_grad_(True)
+    normals_world = torch.nn.functional.normalize(torch.randn(n_gauss, 3, generator=g), dim=-1)
+    self.gauss_params = {"scales": scales, "normals": normals_world}
+    n_touch = 9 if with_touch else 0
+    if with_touch:
+        add_mask = torch.zeros(n_gauss, dtype=torch.bool)
+        add_mask[-n_touch:] = True
+        self.add_mask = add_mask
+        tn = torch.nn.functional.normalize(torch.randn(n_touch, 3, generator=g), dim=-1)
+        self.kwargs = {"metadata": {"touch_patches": [{"normals": tn[:4]}, {"normals": tn[4:]}]}}
+    else:
+        self.add_mask = None
+        tn = torch.zeros(0, 3)
+    rgb = torch.rand(H, W, 3, generator=g)
+    depth = (0.3 + 2.0 * torch.rand(H, W, 1, generator=g)).requires_grad_(True)
+    normal = torch.rand(H, W, 3, generator=g).requires_grad_(True)
+    image = torch.rand(H, W, 3, generator=g)
+    image[: H // 4] *= 0.02  # dark rows: the clamp(min=10/255) of dn_model.py:692 is active
+    sensor = 0.3 + 2.0 * torch.rand(H, W, 1, generator=g)
+    if holes:
+        sensor[torch.rand(H, W, 1, generator=g) < 0.25] = 0.0  # invalid sensor depth (<= depth_tolerance)
+    normal_gt = torch.rand(H, W, 3, generator=g)
+    batch = {"image": image.clone(), "sensor_depth": sensor.clone(), "normal": normal_gt.clone()}
+    if with_mask:
+        mask = torch.rand(H, W, 1, generator=g) > 0.3
+        batch["mask"] = mask
+    else:
+        mask = torch.ones(H, W, 1, dtype=torch.bool)
+    outputs = {"rgb": rgb, "depth": depth, "normal": normal, "background": torch.ones(3)}
+    ld = model_mod.DNSplatterModel.get_loss_dict(self, outputs, batch)
+    loss = ld["main_loss"] + ld["scale_reg"]
+    loss.backward()
+    return dict(rgb=rgb, depth=depth.detach(), normal=normal.detach(), image=image, sensor_depth=sensor,
+                normal_gt=normal_gt, mask=mask, has_mask=np.array(with_mask), scales=scales.detach(),
+                normals_world=normals_world, n_touch=np.array(n_touch), touch_normals=tn,
+                loss=loss.detach(), v_depth=depth.grad, v_normal=normal.grad, v_scales=scales.grad)
+
+
+def main():
+    if not os.path.isdir(base.REF):
+        raise SystemExit("reference not present; goldens can only be regenerated in the authoring container")
+    base._install_stubs()
+    sys.modules["nerfstudio.models.splatfacto"] = _splatfacto_standin()
+    sys.modules["nerfstudio.models"].splatfacto = sys.modules["nerfstudio.models.splatfacto"]
+    losses = base._load(os.path.join(base.REF, "dn_splatter", "losses.py"), "dn_splatter.losses")
+    model = base._load(os.path.join(base.REF, "dn_splatter", "dn_model.py"), "dn_splatter.dn_model")
+    out = {}
+    cases = {"full": dict(seed=1, H=24, W=40, n_gauss=50, with_mask=True, with_touch=True, holes=True),
+             "nomask": dict(seed=2, H=17, W=33, n_gauss=30, with_mask=False, with_touch=False, holes=True),
+             "dense": dict(seed=3, H=32, W=32, n_gauss=64, with_mask=True, with_touch=True, holes=False)}
+    for name, kw in cases.items():
+        for k, v in case(model, losses, **kw).items():
+            out[f"{name}.{k}"] = v.numpy() if torch.is_tensor(v) else v
+    np.savez_compressed(OUT, **out)
+    print("wrote", OUT, {k: (v.shape, float(v)) if v.ndim == 0 else v.shape for k, v in out.items() if ".loss" in k or "v_" in k})
+
+
+if __name__ == "__main__":
+    main()

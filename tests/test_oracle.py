@@ -202,3 +202,48 @@ def test_config1_full_frame_matches_committed_checksum():
     assert meta["flatten_ids"].numel() == int(g["cfg1_n_isects"])
     assert int(meta["flatten_ids"].long().sum()) == int(g["cfg1_flat_sum"])
     assert np.array_equal(meta["isect_offsets"].numpy(), g["cfg1_offsets"])
+
+
+@pytest.mark.parametrize("case", ["full", "nomask", "dense"])
+def test_loss_oracle_matches_reference_goldens(case):
+    """oracle/loss_ref.dn_terms against numbers produced by EXECUTING the reference's own
+    DNSplatterModel.get_loss_dict (tests/golden/make_reference_loss_goldens.py): value and the gradients with
+    respect to the rendered depth / normal images and the log-scales."""
+    from oracle import loss_ref
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_loss.npz"))
+    t = lambda k: torch.from_numpy(d[f"{case}.{k}"])  # noqa: E731
+    depth = t("depth").clone().requires_grad_(True)
+    normal = t("normal").clone().requires_grad_(True)
+    scales = t("scales").clone().requires_grad_(True)
+    batch = {"image": t("image"), "sensor_depth": t("sensor_depth"), "normal": t("normal_gt")}
+    if bool(d[f"{case}.has_mask"]):
+        batch["mask"] = t("mask")
+    n_touch = int(d[f"{case}.n_touch"])
+    add_mask = None
+    if n_touch:
+        add_mask = torch.zeros(scales.shape[0], dtype=torch.bool)
+        add_mask[-n_touch:] = True
+    out = {"rgb": t("rgb"), "depth": depth, "normal": normal}
+    loss = loss_ref.dn_terms(out, batch, scales, t("normals_world"), add_mask, t("touch_normals") if n_touch else None,
+                             loss_ref.LossConfig())
+    loss.backward()
+    assert abs(float(loss) - float(d[f"{case}.loss"])) <= 1e-6 * abs(float(d[f"{case}.loss"]))
+    for name, g in (("v_depth", depth.grad), ("v_normal", normal.grad), ("v_scales", scales.grad)):
+        ref = t(name)
+        assert torch.allclose(g, ref, rtol=1e-5, atol=1e-9), (name, float((g - ref).abs().max()))
+
+
+def test_ssim_oracle_known_answers():
+    """The photometric term's SSIM is recalled (torchmetrics absent): identical images -> 1, symmetric, and the
+    closed form for two constant images ((2ab + c1) / (a^2 + b^2 + c1))."""
+    from oracle import loss_ref
+    g = torch.Generator().manual_seed(0)
+    x, y = torch.rand(3, 40, 36, generator=g, dtype=torch.float64), torch.rand(3, 40, 36, generator=g, dtype=torch.float64)
+    assert abs(float(loss_ref.ssim_torchmetrics(x, x)) - 1.0) < 1e-12
+    assert abs(float(loss_ref.ssim_torchmetrics(x, y)) - float(loss_ref.ssim_torchmetrics(y, x))) < 1e-12
+    a, b = 0.3, 0.7
+    v = float(loss_ref.ssim_torchmetrics(torch.full((3, 30, 30), a, dtype=torch.float64), torch.full((3, 30, 30), b, dtype=torch.float64)))
+    assert abs(v - (2 * a * b + 1e-4) / (a * a + b * b + 1e-4)) < 1e-9
+    # the product's CPU mirror (separable formulation) agrees with this one
+    from fusionsense_amd import losses
+    assert abs(float(losses.ssim(x.float(), y.float())) - float(loss_ref.ssim_torchmetrics(x, y))) < 1e-5
