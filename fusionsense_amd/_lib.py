@@ -85,6 +85,14 @@ SIGNATURES = {
     "fsgs_ssim_l1_bwd": (_i, [_i, _i, _p, _p, _p, _p, _p, _p, _f, _f, _p, _p]),
     "fsgs_ssim_l1_bwd_combine": (_i, [_i, _i, _p, _p, _p, _p, _p, _p, _f, _f, _p, _i, _p, _p, _p, _f, _p, _p]),
     "fsgs_loss_combine": (_i, [_i, _p, _p, _p, _f, _p, _p]),
+    "fsgs_loss_combine_cols": (_i, [_i, _p, _p, _p, _p, _f, _p, _p]),
+    "fsgs_ssim_l1_fwd_masked": (_i, [_i, _i, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "fsgs_ssim_l1_bwd_masked": (_i, [_i, _i, _p, _p, _p, _p, _p, _p, _p, _f, _f, _p, _i, _p, _p, _p, _p, _f, _p, _p]),
+    "fsgs_fusion_aux_num_partials": (_i64, [_i, _i]),
+    "fsgs_fusion_aux_loss": (_i, [_i, _i, _p, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p, _p]),
+    "fsgs_depth_valid_counts": (_i, [_i, _i, _p, _p, _f, _p, _p]),
+    "fsgs_min_scale_loss": (_i, [_i, _p, _f, _p, _p, _p, _p]),
+    "fsgs_touch_normal_sqerr": (_i, [_i, _p, _p, _p, _p, _p]),
 }
 
 _lib: Optional[C.CDLL] = None

@@ -1,0 +1,256 @@
+// a-15: the terms DNSplatterModel.get_loss_dict adds to splatfacto's photometric loss
+// (/root/reference/dn_splatter/dn_model.py:673-925), as one stencil pass over the rendered depth / normal images
+// plus two tiny per-Gaussian kernels.  The reference evaluates them as ~60 elementwise torch launches with
+// boolean-mask gathers; here a thread owns a pixel, reads its right / left / down / up neighbours through the
+// cache, and writes the two gradient images in the same pass when the caller knows the loss seed.
+//   EdgeAwareLogL1 (dn_splatter/losses.py:177-214), TVLoss (:269-285), mask handling (dn_model.py:702-714),
+//   valid mask (:721), clamp of the edge image (:692), normal L1 + TV (:809-815), min-scale (:817-819),
+//   touch-normal MSE (:893-902).
+// HBM-bound: ~70 B/pixel algorithmic (depth 4, normal 12, image 12, sensor 4, normal_gt 12, mask 4; writes 16 + partials).
+#include "common.h"
+
+namespace fsgs {
+
+constexpr int kFA = 8;  // columns of the partial-sum table
+
+__device__ __forceinline__ float sgnf(float v) { return (v > 0.f) ? 1.f : ((v < 0.f) ? -1.f : 0.f); }
+
+struct FusionAuxW { float w[8]; };
+
+// 256 threads = 32 x 8 pixels
+template <bool GRADS>
+__global__ void __launch_bounds__(256)
+fusion_aux_kernel(int H, int W, const float *__restrict__ depth, const float *__restrict__ normal,
+                  const float *__restrict__ image, const float *__restrict__ sensor,
+                  const float *__restrict__ normal_gt, const float *__restrict__ mask, float tol, FusionAuxW ww,
+                  const float *__restrict__ v_loss, float *__restrict__ partial, float *__restrict__ v_depth,
+                  float *__restrict__ v_normal) {
+    __shared__ float red[4][kFA];
+    const int x = blockIdx.x * 32 + (threadIdx.x & 31);
+    const int y = blockIdx.y * 8 + (threadIdx.x >> 5);
+    const bool in = x < W && y < H;
+    float acc[kFA];
+#pragma unroll
+    for (int k = 0; k < kFA; ++k) acc[k] = 0.f;
+    if (in) {
+        const int64_t p = (int64_t)y * W + x;
+        const bool hr = x + 1 < W, hl = x > 0, hd = y + 1 < H, hu = y > 0;
+        const int64_t pr = hr ? p + 1 : p, pl = hl ? p - 1 : p, pd = hd ? p + W : p, pu = hu ? p - W : p;
+        const float m = mask ? mask[p] : 1.f;
+        const float mr = mask ? mask[pr] : 1.f, ml = mask ? mask[pl] : 1.f, md = mask ? mask[pd] : 1.f,
+                    mu = mask ? mask[pu] : 1.f;
+        const float up = GRADS ? v_loss[0] : 0.f;
+        // ---- depth: EdgeAwareLogL1 against the sensor depth + TV ----
+        const float d = depth[p] * m;
+        const float dr = depth[pr] * mr, dl = depth[pl] * ml, dd = depth[pd] * md, du = depth[pu] * mu;
+        const float g = sensor[p] * m;
+        const bool valid = g > tol;
+        float gd = 0.f;
+        if (valid) {
+            const float c0 = fmaxf(image[p * 3 + 0], 10.f / 255.f), c1 = fmaxf(image[p * 3 + 1], 10.f / 255.f),
+                        c2 = fmaxf(image[p * 3 + 2], 10.f / 255.f);
+            const float e = d - g;
+            const float ll = logf(1.f + fabsf(e));
+            float wsum = 0.f;
+            if (hr) {
+                const float gx = (fabsf(c0 - fmaxf(image[pr * 3 + 0], 10.f / 255.f)) +
+                                  fabsf(c1 - fmaxf(image[pr * 3 + 1], 10.f / 255.f)) +
+                                  fabsf(c2 - fmaxf(image[pr * 3 + 2], 10.f / 255.f))) * (1.f / 3.f);
+                const float lam = expf(-gx);
+                acc[0] = lam * ll;
+                wsum += lam * ww.w[0];
+            }
+            if (hd) {
+                const float gy = (fabsf(c0 - fmaxf(image[pd * 3 + 0], 10.f / 255.f)) +
+                                  fabsf(c1 - fmaxf(image[pd * 3 + 1], 10.f / 255.f)) +
+                                  fabsf(c2 - fmaxf(image[pd * 3 + 2], 10.f / 255.f))) * (1.f / 3.f);
+                const float lam = expf(-gy);
+                acc[1] = lam * ll;
+                wsum += lam * ww.w[1];
+            }
+            gd = wsum * sgnf(e) / (1.f + fabsf(e));
+        }
+        if (hr) acc[2] = fabsf(d - dr);
+        if (hd) acc[3] = fabsf(d - dd);
+        if (GRADS) {
+            gd += ww.w[2] * ((hr ? sgnf(d - dr) : 0.f) - (hl ? sgnf(dl - d) : 0.f)) +
+                  ww.w[3] * ((hd ? sgnf(d - dd) : 0.f) - (hu ? sgnf(du - d) : 0.f));
+            v_depth[p] = up * m * gd;
+        }
+        // ---- normals: L1 against the monocular normals + TV ----
+        if (normal) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float n = normal[p * 3 + k] * m;
+                const float nr = normal[pr * 3 + k] * mr, nl = normal[pl * 3 + k] * ml, nd = normal[pd * 3 + k] * md,
+                            nu = normal[pu * 3 + k] * mu;
+                float gn = 0.f;
+                if (normal_gt) {
+                    const float e = n - normal_gt[p * 3 + k] * m;
+                    acc[4] += fabsf(e);
+                    gn = ww.w[4] * sgnf(e);
+                }
+                if (hr) acc[5] += fabsf(n - nr);
+                if (hd) acc[6] += fabsf(n - nd);
+                if (GRADS) {
+                    gn += ww.w[5] * ((hr ? sgnf(n - nr) : 0.f) - (hl ? sgnf(nl - n) : 0.f)) +
+                          ww.w[6] * ((hd ? sgnf(n - nd) : 0.f) - (hu ? sgnf(nu - n) : 0.f));
+                    v_normal[p * 3 + k] = up * m * gn;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < kFA - 1; ++k) {
+        const float s = wave_sum_to_last_row(acc[k]);
+        if ((threadIdx.x & 63) == 63) red[threadIdx.x >> 6][k] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < kFA) {
+        const int blk = blockIdx.y * gridDim.x + blockIdx.x;
+        const int k = threadIdx.x;
+        partial[(int64_t)blk * kFA + k] = (k < kFA - 1) ? red[0][k] + red[1][k] + red[2][k] + red[3][k] : 0.f;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+depth_valid_counts_kernel(int H, int W, const float *__restrict__ sensor, const float *__restrict__ mask, float tol,
+                          unsigned long long *__restrict__ counts) {
+    const int64_t P = (int64_t)H * W;
+    unsigned cx = 0, cy = 0;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (int64_t)gridDim.x * blockDim.x) {
+        const float g = sensor[p] * (mask ? mask[p] : 1.f);
+        if (g > tol) {
+            const int x = (int)(p % W), y = (int)(p / W);
+            cx += (x + 1 < W);
+            cy += (y + 1 < H);
+        }
+    }
+    // integer wave sums (exact), one atomic pair per wave
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) {
+        cx += __shfl_xor(cx, s, 64);
+        cy += __shfl_xor(cy, s, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&counts[0], (unsigned long long)cx);
+        atomicAdd(&counts[1], (unsigned long long)cy);
+    }
+}
+
+template <bool GRADS>
+__global__ void __launch_bounds__(256)
+min_scale_kernel(int N, const float *__restrict__ log_scales, float g, const float *__restrict__ v_loss,
+                 float *__restrict__ partial, float *__restrict__ g_log_scales) {
+    __shared__ float red[4];
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    float v = 0.f;
+    if (n < N) {
+        const float s0 = log_scales[n * 3 + 0], s1 = log_scales[n * 3 + 1], s2 = log_scales[n * 3 + 2];
+        int k = 0;
+        float sm = s0;
+        if (s1 < sm) { sm = s1; k = 1; }
+        if (s2 < sm) { sm = s2; k = 2; }
+        v = expf(sm);  // min exp = exp min (monotone)
+        if (GRADS) g_log_scales[n * 3 + k] += v_loss[0] * g * v;
+    }
+    v = wave_sum_to_last_row(v);
+    if ((threadIdx.x & 63) == 63) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        partial[2 * blockIdx.x + 0] = red[0] + red[1] + red[2] + red[3];
+        partial[2 * blockIdx.x + 1] = 0.f;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+touch_normal_sqerr_kernel(int n, const int64_t *__restrict__ idx, const float *__restrict__ normals_world,
+                          const float *__restrict__ touch_normals, float *__restrict__ partial) {
+    __shared__ float red[4];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    float v = 0.f;
+    if (i < n) {
+        const int64_t r = idx[i];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float e = normals_world[r * 3 + k] - touch_normals[(int64_t)i * 3 + k];
+            v += e * e;
+        }
+    }
+    v = wave_sum_to_last_row(v);
+    if ((threadIdx.x & 63) == 63) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        partial[2 * blockIdx.x + 0] = red[0] + red[1] + red[2] + red[3];
+        partial[2 * blockIdx.x + 1] = 0.f;
+    }
+}
+
+}  // namespace fsgs
+
+using namespace fsgs;
+
+extern "C" int64_t fsgs_fusion_aux_num_partials(int H, int W) {
+    return (int64_t)ceil_div(W, 32) * ceil_div(H, 8);
+}
+
+extern "C" int fsgs_fusion_aux_loss(int H, int W, const float *depth, const float *normal, const float *image,
+                                    const float *sensor_depth, const float *normal_gt, const float *mask,
+                                    float depth_tol, const float *w, const float *v_loss, float *partial,
+                                    float *v_depth, float *v_normal, fsgs_stream_t stream) {
+    if (H < 0 || W < 0) return FSGS_EINVAL;
+    if (H == 0 || W == 0) return FSGS_OK;
+    if (!depth || !image || !sensor_depth || !w || !partial) return FSGS_EINVAL;
+    if (normal_gt && !normal) return FSGS_EINVAL;
+    if (v_loss && (!v_depth || (normal && !v_normal))) return FSGS_EINVAL;
+    FusionAuxW ww;
+    for (int k = 0; k < 7; ++k) ww.w[k] = w[k];
+    ww.w[7] = 0.f;
+    const dim3 grid(ceil_div(W, 32), ceil_div(H, 8));
+    if (v_loss)
+        hipLaunchKernelGGL(fusion_aux_kernel<true>, grid, dim3(256), 0, as_stream(stream), H, W, depth, normal, image,
+                           sensor_depth, normal_gt, mask, depth_tol, ww, v_loss, partial, v_depth, v_normal);
+    else
+        hipLaunchKernelGGL(fusion_aux_kernel<false>, grid, dim3(256), 0, as_stream(stream), H, W, depth, normal, image,
+                           sensor_depth, normal_gt, mask, depth_tol, ww, nullptr, partial, nullptr, nullptr);
+    return check_launch();
+}
+
+extern "C" int fsgs_depth_valid_counts(int H, int W, const float *sensor_depth, const float *mask, float depth_tol,
+                                       int64_t *counts, fsgs_stream_t stream) {
+    if (H < 0 || W < 0 || !counts) return FSGS_EINVAL;
+    hipStream_t s = as_stream(stream);
+    hipError_t e = hipMemsetAsync(counts, 0, 2 * sizeof(int64_t), s);
+    if (e != hipSuccess) { g_last_hip_error = (int)e; return FSGS_ELAUNCH; }
+    if (H == 0 || W == 0) return FSGS_OK;
+    if (!sensor_depth) return FSGS_EINVAL;
+    const int64_t P = (int64_t)H * W;
+    const int blocks = (int)((P + 255) / 256 < 1024 ? (P + 255) / 256 : 1024);
+    hipLaunchKernelGGL(depth_valid_counts_kernel, dim3(blocks), dim3(256), 0, s, H, W, sensor_depth, mask, depth_tol,
+                       reinterpret_cast<unsigned long long *>(counts));
+    return check_launch();
+}
+
+extern "C" int fsgs_min_scale_loss(int N, const float *log_scales, float g, const float *v_loss, float *partial,
+                                   float *g_log_scales, fsgs_stream_t stream) {
+    if (N < 0) return FSGS_EINVAL;
+    if (N == 0) return FSGS_OK;
+    if (!log_scales || !partial || (v_loss && !g_log_scales)) return FSGS_EINVAL;
+    if (v_loss)
+        hipLaunchKernelGGL(min_scale_kernel<true>, dim3(ceil_div(N, 256)), dim3(256), 0, as_stream(stream), N,
+                           log_scales, g, v_loss, partial, g_log_scales);
+    else
+        hipLaunchKernelGGL(min_scale_kernel<false>, dim3(ceil_div(N, 256)), dim3(256), 0, as_stream(stream), N,
+                           log_scales, g, nullptr, partial, nullptr);
+    return check_launch();
+}
+
+extern "C" int fsgs_touch_normal_sqerr(int n, const int64_t *idx, const float *normals_world,
+                                       const float *touch_normals, float *partial, fsgs_stream_t stream) {
+    if (n < 0) return FSGS_EINVAL;
+    if (n == 0) return FSGS_OK;
+    if (!idx || !normals_world || !touch_normals || !partial) return FSGS_EINVAL;
+    hipLaunchKernelGGL(touch_normal_sqerr_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, as_stream(stream), n, idx,
+                       normals_world, touch_normals, partial);
+    return check_launch();
+}

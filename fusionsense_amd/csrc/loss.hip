@@ -40,8 +40,8 @@ __device__ __forceinline__ float block_sum_256(float v, float *lds4) {
 // partials[2*blk] = sum |pred-gt| of this (tile, channel), partials[2*blk+1] = sum of its interior SSIM values
 __global__ void __launch_bounds__(256)
 ssim_l1_fwd_kernel(int H, int W, const float *__restrict__ pred, const float *__restrict__ gt,
-                   float *__restrict__ dm_dmu1, float *__restrict__ dm_dsigma1, float *__restrict__ dm_dsigma12,
-                   float *__restrict__ sums) {
+                   const float *__restrict__ mask, float *__restrict__ dm_dmu1, float *__restrict__ dm_dsigma1,
+                   float *__restrict__ dm_dsigma12, float *__restrict__ sums) {
     __shared__ float sp[kLH][kLP], sg[kLH][kLP];
     __shared__ float hb[5][kLH][kLQ];
     __shared__ float red[4];
@@ -58,8 +58,11 @@ ssim_l1_fwd_kernel(int H, int W, const float *__restrict__ pred, const float *__
         const int y = y0 + ly - kLR, x = x0 + lx - kLR;
         hp[it] = 0.f; hg[it] = 0.f;
         if (i < kLH * kLH && y >= 0 && y < H && x >= 0 && x < W) {
-            hp[it] = pred[((int64_t)y * W + x) * 3 + ch];
-            hg[it] = gt[((int64_t)y * W + x) * 3 + ch];
+            // mask (FusionSense object mask, nullable): both images are multiplied by it first
+            // (splatfacto get_loss_dict, called at /root/reference/dn_splatter/dn_model.py:683)
+            const float m = mask ? mask[(int64_t)y * W + x] : 1.f;
+            hp[it] = pred[((int64_t)y * W + x) * 3 + ch] * m;
+            hg[it] = gt[((int64_t)y * W + x) * 3 + ch] * m;
         }
     }
 #pragma unroll
@@ -162,11 +165,13 @@ ssim_l1_fwd_kernel(int H, int W, const float *__restrict__ pred, const float *__
 
 // out[0] = bias + sum_t (w[2t] * colsum0(partials_t) + w[2t+1] * colsum1(partials_t)): the scalar loss
 // from the per-workgroup partials of up to four fused terms, in one launch and without a host sync.
-constexpr int kCombineMaxTerms = 4;
+constexpr int kCombineMaxTerms = 6;
+constexpr int kCombineMaxCols = 8;
 struct CombineArgs {
-    const float *partials[kCombineMaxTerms];
+    const float *partials[kCombineMaxTerms];  // [rows, cols] each
     long long rows[kCombineMaxTerms];
-    float w[2 * kCombineMaxTerms];
+    int cols[kCombineMaxTerms];
+    float w[kCombineMaxTerms][kCombineMaxCols];  // weight of every column
     int n_terms;
     float bias;
 };
@@ -176,15 +181,10 @@ template <int THREADS>
 __device__ __forceinline__ void combine_partials(const CombineArgs &a, float *__restrict__ out, double *red) {
     double acc = 0.0;
     for (int t = 0; t < a.n_terms; ++t) {
-        const float2 *p = reinterpret_cast<const float2 *>(a.partials[t]);
-        const float w0 = a.w[2 * t], w1 = a.w[2 * t + 1];
-        double s0 = 0.0, s1 = 0.0;
-        for (long long r = threadIdx.x; r < a.rows[t]; r += THREADS) {
-            const float2 v = p[r];
-            s0 += v.x;
-            s1 += v.y;
-        }
-        acc += s0 * (double)w0 + s1 * (double)w1;
+        const float *p = a.partials[t];
+        const int cols = a.cols[t];
+        const long long n = a.rows[t] * cols;
+        for (long long e = threadIdx.x; e < n; e += THREADS) acc += (double)p[e] * (double)a.w[t][e % cols];
     }
 #pragma unroll
     for (int s = 32; s >= 1; s >>= 1) acc += __shfl_xor(acc, s, 64);
@@ -200,7 +200,7 @@ __device__ __forceinline__ void combine_partials(const CombineArgs &a, float *__
 // v_pred = g_l1 * sign(pred-gt) + g_ssim * (G*dm_dmu1 + 2 pred G*dm_dsigma1 + gt G*dm_dsigma12)
 __global__ void __launch_bounds__(256)
 ssim_l1_bwd_kernel(int H, int W, const float *__restrict__ pred, const float *__restrict__ gt,
-                   const float *__restrict__ dm_dmu1, const float *__restrict__ dm_dsigma1,
+                   const float *__restrict__ mask, const float *__restrict__ dm_dmu1, const float *__restrict__ dm_dsigma1,
                    const float *__restrict__ dm_dsigma12, const float *__restrict__ v_loss, float g_l1,
                    float g_ssim, float *__restrict__ v_pred, CombineArgs comb, float *__restrict__ loss_out) {
     __shared__ float sm[3][kLH][kLP];
@@ -230,12 +230,13 @@ ssim_l1_bwd_kernel(int H, int W, const float *__restrict__ pred, const float *__
     // this thread's own four pixels and the upstream scalar, in flight with the halo
     const int lx = tr & 31, ry = (tr >> 5) * 4;
     const int x = x0 + lx;
-    float own_p[4], own_g[4];
+    float own_p[4], own_g[4], own_m[4];
 #pragma unroll
     for (int o = 0; o < 4; ++o) {
         const int y = y0 + ry + o;
-        const int64_t oo = ((int64_t)min(y, H - 1) * W + min(x, W - 1)) * 3 + ch;
-        own_p[o] = pred[oo]; own_g[o] = gt[oo];
+        const int64_t op = (int64_t)min(y, H - 1) * W + min(x, W - 1);
+        own_m[o] = mask ? mask[op] : 1.f;
+        own_p[o] = pred[op * 3 + ch] * own_m[o]; own_g[o] = gt[op * 3 + ch] * own_m[o];
     }
     const float up = v_loss[0];
 #pragma unroll
@@ -303,7 +304,8 @@ ssim_l1_bwd_kernel(int H, int W, const float *__restrict__ pred, const float *__
         const float p = own_p[o], g = own_g[o];
         const float d = p - g;
         const float sgn = (d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f);
-        v_pred[((int64_t)y * W + x) * 3 + ch] = up * (g_l1 * sgn + g_ssim * (out[o][0] + 2.f * p * out[o][1] + g * out[o][2]));
+        v_pred[((int64_t)y * W + x) * 3 + ch] =
+            own_m[o] * up * (g_l1 * sgn + g_ssim * (out[o][0] + 2.f * p * out[o][1] + g * out[o][2]));
     }
 }
 
@@ -373,21 +375,37 @@ __global__ void __launch_bounds__(1024) loss_combine_kernel(CombineArgs a, float
 
 using namespace fsgs;
 
-extern "C" int fsgs_loss_combine(int n_terms, const float *const *partials, const int64_t *rows,
-                                 const float *weights, float bias, float *out, fsgs_stream_t stream) {
-    if (n_terms < 0 || n_terms > kCombineMaxTerms || !out) return FSGS_EINVAL;
+static int fill_combine_args(CombineArgs &a, int n_terms, const float *const *partials, const int64_t *rows,
+                             const int *cols, const float *weights, float bias) {
+    // cols == NULL: two columns per term and two weights per term (the original layout)
+    if (n_terms < 0 || n_terms > kCombineMaxTerms) return FSGS_EINVAL;
     if (n_terms && (!partials || !rows || !weights)) return FSGS_EINVAL;
-    CombineArgs a;
+    const float *w = weights;
     for (int t = 0; t < kCombineMaxTerms; ++t) {
         const bool on = t < n_terms;
-        if (on && (rows[t] < 0 || (rows[t] > 0 && !partials[t]))) return FSGS_EINVAL;
+        const int c = on ? (cols ? cols[t] : 2) : 0;
+        if (on && (rows[t] < 0 || c < 1 || c > kCombineMaxCols || (rows[t] > 0 && !partials[t]))) return FSGS_EINVAL;
         a.partials[t] = on ? partials[t] : nullptr;
         a.rows[t] = on ? rows[t] : 0;
-        a.w[2 * t] = on ? weights[2 * t] : 0.f;
-        a.w[2 * t + 1] = on ? weights[2 * t + 1] : 0.f;
+        a.cols[t] = c;
+        for (int k = 0; k < kCombineMaxCols; ++k) a.w[t][k] = (k < c) ? *w++ : 0.f;
     }
     a.n_terms = n_terms;
     a.bias = bias;
+    return FSGS_OK;
+}
+
+extern "C" int fsgs_loss_combine(int n_terms, const float *const *partials, const int64_t *rows,
+                                 const float *weights, float bias, float *out, fsgs_stream_t stream) {
+    return fsgs_loss_combine_cols(n_terms, partials, rows, nullptr, weights, bias, out, stream);
+}
+
+extern "C" int fsgs_loss_combine_cols(int n_terms, const float *const *partials, const int64_t *rows, const int *cols,
+                                      const float *weights, float bias, float *out, fsgs_stream_t stream) {
+    if (!out) return FSGS_EINVAL;
+    CombineArgs a;
+    const int rc = fill_combine_args(a, n_terms, partials, rows, cols, weights, bias);
+    if (rc != FSGS_OK) return rc;
     hipLaunchKernelGGL(loss_combine_kernel, dim3(1), dim3(1024), 0, as_stream(stream), a, out);
     return check_launch();
 }
@@ -432,40 +450,25 @@ extern "C" int64_t fsgs_ssim_l1_num_partials(int H, int W) {
 
 extern "C" int fsgs_ssim_l1_fwd(int H, int W, const float *pred, const float *gt, float *dm_dmu1,
                                 float *dm_dsigma1, float *dm_dsigma12, float *sums, fsgs_stream_t stream) {
+    return fsgs_ssim_l1_fwd_masked(H, W, pred, gt, nullptr, dm_dmu1, dm_dsigma1, dm_dsigma12, sums, stream);
+}
+
+extern "C" int fsgs_ssim_l1_fwd_masked(int H, int W, const float *pred, const float *gt, const float *mask,
+                                       float *dm_dmu1, float *dm_dsigma1, float *dm_dsigma12, float *sums,
+                                       fsgs_stream_t stream) {
     if (H < 11 || W < 11) return FSGS_EINVAL;
     if (!pred || !gt || !dm_dmu1 || !dm_dsigma1 || !dm_dsigma12 || !sums) return FSGS_EINVAL;
     hipStream_t s = as_stream(stream);
     hipLaunchKernelGGL(ssim_l1_fwd_kernel, dim3(ceil_div(W, kLT), ceil_div(H, kLT), 3), dim3(256), 0, s,
-                       H, W, pred, gt, dm_dmu1, dm_dsigma1, dm_dsigma12, sums);
+                       H, W, pred, gt, mask, dm_dmu1, dm_dsigma1, dm_dsigma12, sums);
     return check_launch();
 }
 
 extern "C" int fsgs_ssim_l1_bwd(int H, int W, const float *pred, const float *gt, const float *dm_dmu1,
                                 const float *dm_dsigma1, const float *dm_dsigma12, const float *v_loss,
                                 float g_l1, float g_ssim, float *v_pred, fsgs_stream_t stream) {
-    if (H < 11 || W < 11) return FSGS_EINVAL;
-    if (!pred || !gt || !dm_dmu1 || !dm_dsigma1 || !dm_dsigma12 || !v_loss || !v_pred) return FSGS_EINVAL;
-    hipLaunchKernelGGL(ssim_l1_bwd_kernel, dim3(ceil_div(W, kLT), ceil_div(H, kLT), 3), dim3(256), 0,
-                       as_stream(stream), H, W, pred, gt, dm_dmu1, dm_dsigma1, dm_dsigma12, v_loss, g_l1,
-                       g_ssim, v_pred, CombineArgs{}, nullptr);
-    return check_launch();
-}
-
-static int fill_combine_args(CombineArgs &a, int n_terms, const float *const *partials, const int64_t *rows,
-                             const float *weights, float bias) {
-    if (n_terms < 0 || n_terms > kCombineMaxTerms) return FSGS_EINVAL;
-    if (n_terms && (!partials || !rows || !weights)) return FSGS_EINVAL;
-    for (int t = 0; t < kCombineMaxTerms; ++t) {
-        const bool on = t < n_terms;
-        if (on && (rows[t] < 0 || (rows[t] > 0 && !partials[t]))) return FSGS_EINVAL;
-        a.partials[t] = on ? partials[t] : nullptr;
-        a.rows[t] = on ? rows[t] : 0;
-        a.w[2 * t] = on ? weights[2 * t] : 0.f;
-        a.w[2 * t + 1] = on ? weights[2 * t + 1] : 0.f;
-    }
-    a.n_terms = n_terms;
-    a.bias = bias;
-    return FSGS_OK;
+    return fsgs_ssim_l1_bwd_masked(H, W, pred, gt, nullptr, dm_dmu1, dm_dsigma1, dm_dsigma12, v_loss, g_l1, g_ssim,
+                                   v_pred, 0, nullptr, nullptr, nullptr, nullptr, 0.f, nullptr, stream);
 }
 
 // fsgs_ssim_l1_bwd + fsgs_loss_combine in one launch (the scalar loss is only reported: one workgroup of an extra
@@ -475,13 +478,27 @@ extern "C" int fsgs_ssim_l1_bwd_combine(int H, int W, const float *pred, const f
                                         float g_l1, float g_ssim, float *v_pred, int n_terms,
                                         const float *const *partials, const int64_t *rows, const float *weights,
                                         float bias, float *loss_out, fsgs_stream_t stream) {
+    if (!loss_out) return FSGS_EINVAL;
+    return fsgs_ssim_l1_bwd_masked(H, W, pred, gt, nullptr, dm_dmu1, dm_dsigma1, dm_dsigma12, v_loss, g_l1, g_ssim,
+                                   v_pred, n_terms, partials, rows, nullptr, weights, bias, loss_out, stream);
+}
+
+// The general form: optional pixel mask (v_pred = mask * d loss / d(pred * mask)), optional combine slice
+// (loss_out != NULL) over up to 6 partial-sum tables of up to 8 weighted columns each.
+extern "C" int fsgs_ssim_l1_bwd_masked(int H, int W, const float *pred, const float *gt, const float *mask,
+                                       const float *dm_dmu1, const float *dm_dsigma1, const float *dm_dsigma12,
+                                       const float *v_loss, float g_l1, float g_ssim, float *v_pred, int n_terms,
+                                       const float *const *partials, const int64_t *rows, const int *cols,
+                                       const float *weights, float bias, float *loss_out, fsgs_stream_t stream) {
     if (H < 11 || W < 11) return FSGS_EINVAL;
-    if (!pred || !gt || !dm_dmu1 || !dm_dsigma1 || !dm_dsigma12 || !v_loss || !v_pred || !loss_out) return FSGS_EINVAL;
-    CombineArgs a;
-    const int rc = fill_combine_args(a, n_terms, partials, rows, weights, bias);
-    if (rc != FSGS_OK) return rc;
-    hipLaunchKernelGGL(ssim_l1_bwd_kernel, dim3(ceil_div(W, kLT), ceil_div(H, kLT), 4), dim3(256), 0,
-                       as_stream(stream), H, W, pred, gt, dm_dmu1, dm_dsigma1, dm_dsigma12, v_loss, g_l1,
+    if (!pred || !gt || !dm_dmu1 || !dm_dsigma1 || !dm_dsigma12 || !v_loss || !v_pred) return FSGS_EINVAL;
+    CombineArgs a{};
+    if (loss_out) {
+        const int rc = fill_combine_args(a, n_terms, partials, rows, cols, weights, bias);
+        if (rc != FSGS_OK) return rc;
+    }
+    hipLaunchKernelGGL(ssim_l1_bwd_kernel, dim3(ceil_div(W, kLT), ceil_div(H, kLT), loss_out ? 4 : 3), dim3(256), 0,
+                       as_stream(stream), H, W, pred, gt, mask, dm_dmu1, dm_dsigma1, dm_dsigma12, v_loss, g_l1,
                        g_ssim, v_pred, a, loss_out);
     return check_launch();
 }

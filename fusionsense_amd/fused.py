@@ -388,9 +388,13 @@ def fused_step_forward_backward(gauss_params: Dict[str, Tensor], camera: Camera,
                                 sh_degree: int, device, grad_out: Dict[str, Tensor], seed_grad: Tensor,
                                 stats_out: Optional[dict] = None, add_mask: Optional[Tensor] = None,
                                 binary_threshold: Optional[float] = None, ssim_lambda: float = 0.2,
-                                w_depth: float = 0.2, w_normal: float = 0.1, pre_sh=None, sh_factors_out=None):
-    """get_outputs -> config-#2 loss -> both backward passes, without the autograd tape.  The parameter
-    gradients land in ``grad_out`` (the trainer's slab views).  Returns (loss 0-d tensor, outputs dict)."""
+                                w_depth: float = 0.2, w_normal: float = 0.1, pre_sh=None, sh_factors_out=None,
+                                fusion=None):
+    """get_outputs -> loss -> both backward passes, without the autograd tape.  The parameter gradients land in
+    ``grad_out`` (the trainer's slab views).  Returns (loss 0-d tensor, outputs dict).
+    ``target`` is either the benchmark targets of BASELINE config #2 (dict rgb / depth / normal: L1 + SSIM on rgb,
+    plain L1 on depth and normal) or, with ``fusion = (LossConfig, touch_idx, touch_normals)``, a
+    prepared FrameBatch: the reference's get_loss_dict (dn_model.py:673-925, ops._FusionLoss)."""
     dev = device
     background = _ONES3.get(str(dev))
     if background is None:
@@ -403,6 +407,25 @@ def fused_step_forward_backward(gauss_params: Dict[str, Tensor], camera: Camera,
     info.sh_factors_out = sh_factors_out
     if add_mask is not None:
         info.frozen = add_mask.to(device=dev, dtype=torch.uint8).contiguous()
+    if fusion is not None:
+        with torch.no_grad():
+            cfg, touch_idx, touch_normals = fusion
+            ctx = _DirectCtx((True,) * 6 + (False,) * 7)
+            rgb, depth, normal, alpha = _FusedGetOutputs.forward(
+                ctx, gauss_params["means"], gauss_params["scales"], gauss_params["quats"], gauss_params["features_dc"],
+                gauss_params["features_rest"], gauss_params["opacities"], cam, camera.width, camera.height,
+                int(sh_degree), background, info, grad_out)
+            lctx = _DirectCtx((True, True, True, False) + (False,) * 7)
+            loss = ops._FusionLoss.forward(lctx, rgb, depth, normal, gauss_params["scales"].data, target, cfg,
+                                           info.normals_world, touch_idx, touch_normals, seed_grad, True)
+            v = ops._FusionLoss.backward(lctx, seed_grad)
+            _FusedGetOutputs.backward(ctx, v[0], v[1], v[2], None)
+            g_min = lctx.g[3]
+            if g_min != 0.0:  # the min-scale term reaches the log-scales directly, touch anchors included (:817-819)
+                ops.min_scale_grad_(gauss_params["scales"].data, g_min, seed_grad.reshape(1), grad_out["scales"])
+        out = {"rgb": rgb, "depth": depth, "normal": normal, "accumulation": alpha, "background": background,
+               "info": info, "xys": info, "radii": info.radii[0], "normals_world": info.normals_world}
+        return loss, out
     has_n = "normal" in target
     n_pix = camera.width * camera.height
     info.loss_targets = dict(depth=target["depth"].contiguous(), normal=target["normal"].contiguous() if has_n else None,

@@ -4,9 +4,63 @@ receive is defined by these.  Plain torch elementwise math mirroring
 (host-side glue, not a kernel target in this round; "next" row N2)."""
 from __future__ import annotations
 
+from dataclasses import dataclass
+from typing import Dict, Optional
+
 import torch
 import torch.nn.functional as F
 from torch import Tensor
+
+
+@dataclass
+class LossConfig:
+    """The loss switches of DNSplatterModelConfig (dn_splatter/dn_model.py:60-141) with the values FusionSense's
+    scripts/train.py passes on from configs/config.py:9-15 (sensor depth + monocular normals)."""
+    ssim_lambda: float = 0.2            # nerfstudio SplatfactoModelConfig default
+    use_depth_loss: bool = True         # configs/config.py:9
+    sensor_depth_lambda: float = 0.2    # configs/config.py:11
+    depth_tolerance: float = 0.1        # dn_model.py:64
+    use_depth_smooth_loss: bool = True  # configs/config.py:12
+    smooth_loss_lambda: float = 0.1     # dn_model.py:74
+    use_normal_loss: bool = True        # configs/config.py:14 (normal_supervision = "mono")
+    use_normal_tv_loss: bool = True     # dn_model.py:82
+    normal_lambda: float = 0.4          # configs/config.py:10
+    two_d_gaussians: bool = True        # dn_model.py:98
+    touch_normal_loss_lambda: float = 1.0  # dn_model.py:901
+
+
+class FrameBatch:
+    """One training view's supervision, resident on the device in the layout the loss kernels read:
+    ``image`` [H,W,3], ``sensor_depth`` [H,W], ``normal`` [H,W,3] or None, ``mask`` [H,W] float (0/1) or None, and
+    the two per-view constants of EdgeAwareLogL1's masked means (dn_splatter/losses.py:208-209): the number of
+    valid sensor-depth pixels with a right / a lower neighbour.  Built once per view by :func:`prepare_batch`
+    (the reference's datamanager likewise keeps its images cached on the device)."""
+
+    def __init__(self, image, sensor_depth, normal, mask, cnt_x, cnt_y, has_sensor):
+        self.image, self.sensor_depth, self.normal, self.mask = image, sensor_depth, normal, mask
+        self.cnt_x, self.cnt_y, self.has_sensor = cnt_x, cnt_y, has_sensor
+        self.height, self.width = image.shape[0], image.shape[1]
+
+
+def prepare_batch(batch: Dict[str, Tensor], cfg: LossConfig, device) -> FrameBatch:
+    """``batch`` as the reference's datamanager hands it to get_loss_dict: "image" [H,W,3] (uint8 or float),
+    optional "sensor_depth" [H,W,1], "normal" [H,W,3], "mask" [H,W,1] bool.  get_gt_img's uint8 -> float / 255
+    conversion is applied here (num_downscales = 0: no resize, dn_model.py:118)."""
+    from . import ops
+    f32 = dict(device=device, dtype=torch.float32)
+
+    def img(t):
+        t = t.to(device)
+        return (t.float() / 255.0 if t.dtype == torch.uint8 else t.to(torch.float32)).contiguous()
+
+    image = img(batch["image"])[..., :3].contiguous()
+    H, W = image.shape[0], image.shape[1]
+    has_sensor = "sensor_depth" in batch
+    sensor = batch["sensor_depth"].to(**f32).reshape(H, W).contiguous() if has_sensor else torch.zeros(H, W, **f32)
+    normal = img(batch["normal"]) if "normal" in batch else None
+    mask = batch["mask"].to(**f32).reshape(H, W).contiguous() if "mask" in batch else None
+    cnt_x, cnt_y = ops.depth_valid_counts(sensor, mask, cfg.depth_tolerance) if has_sensor else (0, 0)
+    return FrameBatch(image, sensor, normal, mask, cnt_x, cnt_y, has_sensor)
 
 
 def _gaussian_window(size: int, sigma: float, device, dtype) -> Tensor:

@@ -984,6 +984,185 @@ def train_loss(rgb: Tensor, rgb_gt: Tensor, depth: Tensor, depth_gt: Tensor, nor
                             float(w_depth), float(w_normal), None, None)
 
 
+def loss_combine_cols(partials, weights, bias: float) -> Tensor:
+    """bias + sum_t sum_c w[t][c] * colsum_c(partials[t]) as a 0-d device tensor; partials[t] is [rows, cols]."""
+    lib = load()
+    n = len(partials)
+    dev = partials[0].device
+    out = torch.empty((), dtype=torch.float32, device=dev)
+    a = _combine_args(partials, weights)
+    _run(lib.fsgs_loss_combine_cols, (n, a[0], a[1], a[2], a[3], float(bias), ptr(out), stream_ptr(dev)),
+         "fsgs_loss_combine")
+    return out
+
+
+def _combine_args(partials, weights):
+    n = len(partials)
+    VP = C.c_void_p * n
+    rows = (C.c_int64 * n)(*[p.shape[0] for p in partials])
+    cols = (C.c_int * n)(*[p.shape[1] for p in partials])
+    flat = [float(x) for w, p in zip(weights, partials) for x in list(w)[:p.shape[1]]]
+    assert len(flat) == sum(p.shape[1] for p in partials), "one weight per column"
+    return VP(*[p.data_ptr() for p in partials]), rows, cols, (C.c_float * len(flat))(*flat)
+
+
+def depth_valid_counts(sensor_depth: Tensor, mask: Optional[Tensor], depth_tol: float) -> Tuple[int, int]:
+    """(#valid pixels with a right neighbour, #valid with a lower neighbour), valid = sensor*mask > tol: the sizes
+    of EdgeAwareLogL1's two masked selections (dn_splatter/losses.py:208-209).  One host read-back — per VIEW, at
+    batch preparation, never inside a step."""
+    lib = load()
+    H, W = sensor_depth.shape[0], sensor_depth.shape[1]
+    counts = torch.empty(2, dtype=torch.int64, device=sensor_depth.device)
+    _run(lib.fsgs_depth_valid_counts, (H, W, ptr(sensor_depth), ptr(mask), float(depth_tol), ptr(counts),
+                                       stream_ptr(sensor_depth.device)), "fsgs_depth_valid_counts")
+    cx, cy = counts.tolist()
+    return int(cx), int(cy)
+
+
+def fusion_loss_weights(cfg, fb, n_gauss: int, n_touch: int):
+    """Every partial-sum column's weight in get_loss_dict's total (dn_model.py:673-925), as host floats:
+    (g_l1, g_ssim), w_aux[7], g_minscale, g_touch."""
+    H, W = fb.height, fb.width
+    g_l1 = (1.0 - cfg.ssim_lambda) / (3.0 * H * W)
+    g_ssim = -cfg.ssim_lambda / (3.0 * (H - 10) * (W - 10))
+    w = [0.0] * 7
+    if cfg.use_depth_loss and fb.has_sensor and cfg.sensor_depth_lambda > 0.0:
+        # (an empty selection makes the reference's mean NaN; so does 0 * inf here)
+        w[0] = cfg.sensor_depth_lambda / fb.cnt_x if fb.cnt_x else float("inf")
+        w[1] = cfg.sensor_depth_lambda / fb.cnt_y if fb.cnt_y else float("inf")
+    if cfg.use_depth_smooth_loss:
+        w[2] = cfg.smooth_loss_lambda / (H * (W - 1))
+        w[3] = cfg.smooth_loss_lambda / ((H - 1) * W)
+    if cfg.use_normal_loss:
+        if fb.normal is not None:
+            w[4] = cfg.normal_lambda / (3.0 * H * W)
+        if cfg.use_normal_tv_loss:
+            w[5] = cfg.normal_lambda / (3.0 * H * (W - 1))
+            w[6] = cfg.normal_lambda / (3.0 * (H - 1) * W)
+    g_min = cfg.normal_lambda / n_gauss if (cfg.two_d_gaussians and n_gauss > 0) else 0.0
+    g_touch = cfg.touch_normal_loss_lambda / (3.0 * n_touch) if n_touch > 0 else 0.0
+    return (g_l1, g_ssim), w, g_min, g_touch
+
+
+def min_scale_grad_(log_scales: Tensor, g: float, seed: Tensor, g_log_scales: Tensor) -> None:
+    """g_log_scales[n, argmin] += seed * g * exp(min_k log_scales[n,k]): the gradient of the two_d_gaussians term
+    (dn_model.py:817-819), accumulated onto whatever the rasterizer's backward has written."""
+    lib = load()
+    N = log_scales.shape[0]
+    dev = log_scales.device
+    scratch = torch.empty((N + 255) // 256, 2, dtype=torch.float32, device=dev)
+    _run(lib.fsgs_min_scale_loss, (N, ptr(log_scales), float(g), ptr(seed), ptr(scratch), ptr(g_log_scales),
+                                   stream_ptr(dev)), "fsgs_min_scale_loss")
+
+
+class _FusionLoss(torch.autograd.Function):
+    """DNSplatterModel.get_loss_dict (dn_splatter/dn_model.py:673-925; sensor-depth + mono-normal configuration)
+    as ONE autograd node: masked L1 + SSIM11 on rgb, EdgeAwareLogL1 + TV on depth, L1 + TV on the normals, the
+    min-scale term and the touch-normal MSE — four partial-sum kernels and one combine forward (the depth / normal
+    gradient images come out of the forward's own pass when the caller hands in the loss seed), one or two kernels
+    backward.  Returns main_loss + scale_reg (scale_reg = 0: use_scale_regularization is off, dn_model.py:120)."""
+
+    @staticmethod
+    def forward(ctx, rgb, depth, normal, log_scales, fb, cfg, normals_world=None, touch_idx=None,
+                touch_normals=None, seed=None, defer_combine=False):
+        rgb, depth, normal, log_scales = map(_c, (rgb, depth, normal, log_scales))
+        lib = load()
+        dev = rgb.device
+        sp = stream_ptr(dev)
+        H, W = fb.height, fb.width
+        N = log_scales.shape[0]
+        n_touch = 0 if touch_idx is None else int(touch_idx.numel())
+        (g_l1, g_ssim), w_aux, g_min, g_touch = fusion_loss_weights(cfg, fb, N, n_touch)
+        f32 = dict(dtype=torch.float32, device=dev)
+        maps = torch.empty(3, H, W, 3, **f32)
+        sums = torch.empty(lib.fsgs_ssim_l1_num_partials(H, W), 2, **f32)
+        _run(lib.fsgs_ssim_l1_fwd_masked, (H, W, ptr(rgb), ptr(fb.image), ptr(fb.mask), maps[0].data_ptr(),
+                                           maps[1].data_ptr(), maps[2].data_ptr(), ptr(sums), sp), "fsgs_ssim_l1_fwd")
+        aux = torch.empty(lib.fsgs_fusion_aux_num_partials(H, W), 8, **f32)
+        wa = (C.c_float * 7)(*w_aux)
+        v_depth = v_normal = None
+        if seed is not None:
+            v_depth = torch.empty_like(depth)
+            v_normal = torch.empty_like(normal) if normal is not None else None
+        _run(lib.fsgs_fusion_aux_loss, (H, W, ptr(depth), ptr(normal), ptr(fb.image), ptr(fb.sensor_depth),
+                                        ptr(fb.normal) if normal is not None else None, ptr(fb.mask),
+                                        float(cfg.depth_tolerance), wa, ptr(seed), ptr(aux), ptr(v_depth),
+                                        ptr(v_normal), sp), "fsgs_fusion_aux_loss")
+        partials, weights = [sums, aux], [(g_l1, g_ssim), tuple(w_aux) + (0.0,)]
+        if g_min != 0.0:
+            pm = torch.empty((N + 255) // 256, 2, **f32)
+            _run(lib.fsgs_min_scale_loss, (N, ptr(log_scales), 0.0, None, ptr(pm), None, sp), "fsgs_min_scale_loss")
+            partials.append(pm)
+            weights.append((g_min, 0.0))
+        if n_touch > 0:
+            pt = torch.empty((n_touch + 255) // 256, 2, **f32)
+            _run(lib.fsgs_touch_normal_sqerr, (n_touch, ptr(touch_idx), ptr(normals_world), ptr(_c(touch_normals)),
+                                               ptr(pt), sp), "fsgs_touch_normal_sqerr")
+            partials.append(pt)
+            weights.append((g_touch, 0.0))
+        ctx.save_for_backward(rgb, maps, depth, normal if normal is not None else torch.empty(0, device=dev),
+                              log_scales)
+        ctx.fb, ctx.cfg = fb, cfg
+        ctx.g = (g_l1, g_ssim, w_aux, g_min, normal is not None)
+        ctx.aux_grads = (seed, v_depth, v_normal) if seed is not None else None
+        ctx.deferred_loss = None
+        if seed is not None and defer_combine:
+            # tape-free step: the scalar is only reported, its combine rides in the backward's SSIM launch
+            out = torch.empty((), **f32)
+            ctx.deferred_loss = (out, partials, weights, cfg.ssim_lambda)
+            return out
+        return loss_combine_cols(partials, weights, cfg.ssim_lambda)
+
+    @staticmethod
+    def backward(ctx, v_loss):
+        rgb, maps, depth, normal, log_scales = ctx.saved_tensors
+        g_l1, g_ssim, w_aux, g_min, has_n = ctx.g
+        fb, cfg = ctx.fb, ctx.cfg
+        lib = load()
+        dev = rgb.device
+        sp = stream_ptr(dev)
+        H, W = fb.height, fb.width
+        v_loss_in = v_loss
+        v_loss = v_loss.reshape(1).contiguous().to(torch.float32)
+        aux = ctx.aux_grads
+        if aux is not None and aux[0] is v_loss_in:
+            v_depth, v_normal = aux[1], aux[2]  # written by the forward's pass with this very seed
+        else:
+            v_depth = torch.empty_like(depth)
+            v_normal = torch.empty_like(normal) if has_n else None
+            scratch = torch.empty(lib.fsgs_fusion_aux_num_partials(H, W), 8, dtype=torch.float32, device=dev)
+            _run(lib.fsgs_fusion_aux_loss, (H, W, ptr(depth), ptr(normal) if has_n else None, ptr(fb.image),
+                                            ptr(fb.sensor_depth), ptr(fb.normal) if has_n else None, ptr(fb.mask),
+                                            float(cfg.depth_tolerance), (C.c_float * 7)(*w_aux), ptr(v_loss),
+                                            ptr(scratch), ptr(v_depth), ptr(v_normal), sp), "fsgs_fusion_aux_loss")
+        v_rgb = torch.empty_like(rgb)
+        dl = ctx.deferred_loss
+        if dl is not None:
+            out, partials, weights, bias = dl
+            ctx.deferred_loss = None
+            a = _combine_args(partials, weights)
+            comb = (len(partials), a[0], a[1], a[2], a[3], float(bias), ptr(out))
+        else:
+            comb = (0, None, None, None, None, 0.0, None)
+        _run(lib.fsgs_ssim_l1_bwd_masked, (H, W, ptr(rgb), ptr(fb.image), ptr(fb.mask), maps[0].data_ptr(),
+                                           maps[1].data_ptr(), maps[2].data_ptr(), ptr(v_loss), g_l1, g_ssim,
+                                           ptr(v_rgb)) + comb + (sp,), "fsgs_ssim_l1_bwd")
+        v_scales = None
+        if ctx.needs_input_grad[3]:
+            v_scales = torch.zeros_like(log_scales)
+            if g_min != 0.0:
+                min_scale_grad_(log_scales, g_min, v_loss, v_scales)
+        return v_rgb, v_depth, v_normal, v_scales, None, None, None, None, None, None, None
+
+
+def fusion_loss(out, fb, cfg, log_scales: Tensor, touch_idx: Optional[Tensor] = None,
+                touch_normals: Optional[Tensor] = None) -> Tensor:
+    """get_loss_dict's main_loss + scale_reg for the outputs of get_outputs (``out``: rgb, depth, normal,
+    normals_world) against a prepared :class:`fusionsense_amd.losses.FrameBatch`."""
+    return _FusionLoss.apply(out["rgb"], out["depth"], out.get("normal"), log_scales, fb, cfg,
+                             out.get("normals_world"), touch_idx, touch_normals, None, False)
+
+
 def adam_step_(params, grads, exp_avgs, exp_avg_sqs, lrs, step: int, beta1: float = 0.9, beta2: float = 0.999,
                eps: float = 1e-15) -> None:
     """In-place torch.optim.Adam update of several parameter tensors in ONE launch (row N1)."""

@@ -130,8 +130,18 @@ class DensifyStrategy:
         self.max_2Dsize: Optional[Tensor] = None
         self.last_size = (1, 1)
         self.add_mask: Optional[Tensor] = None  # touch anchors (dn_model.py:292, 366-378)
+        self.touch_normals: Optional[Tensor] = None  # [n_touch,3] contact normals of the anchors, patch order (:897-899)
+        self._touch_rows = (None, None)
         self.extra_cull_fn = None  # hook for hull / touch pruning (a-14)
         self.last_report: Dict[str, int] = {}
+
+    def touch_rows(self) -> Optional[Tensor]:
+        """Row indices of the touch anchors (``add_mask.nonzero()``), recomputed only when the mask object changed."""
+        if self.add_mask is None:
+            return None
+        if self._touch_rows[0] is not self.add_mask:
+            self._touch_rows = (self.add_mask, torch.nonzero(self.add_mask).squeeze(-1).contiguous())
+        return self._touch_rows[1]
 
     # ---- a-12 ---------------------------------------------------------------------------
     @torch.no_grad()
@@ -333,6 +343,7 @@ class DensifyStrategy:
         added = pts.shape[0]
         self.add_mask = torch.cat([torch.zeros(n_before, dtype=torch.bool, device=means.device),
                                    torch.ones(added, dtype=torch.bool, device=means.device)])
+        self.touch_normals = nrm.to(torch.float32).contiguous()
         self.xys_grad_norm = self.vis_counts = self.max_2Dsize = None
         return added
 

@@ -106,7 +106,7 @@ class SplatTrainer:
     def __init__(self, params: Dict[str, Tensor], device: torch.device, sh_degree: int = 3,
                  optim: Optional[OptimConfig] = None, fused_adam: bool = True, seed: int = 0,
                  strategy=None, fused: bool = True, sh_degree_interval: Optional[int] = None,
-                 direct: bool = True):
+                 direct: bool = True, loss_cfg=None):
         self.device = device
         # fused=True: get_outputs as one autograd node (fusionsense_amd/fused.py); False: the
         # reference's op-by-op caller through the drop-in rasterization()/rasterize_gaussians() surface
@@ -115,6 +115,15 @@ class SplatTrainer:
         # backward by hand instead of through torch.autograd (same kernels, same gradients in the slab)
         self.direct = direct
         self.sh_degree = sh_degree
+        # The loss.  A step's supervision is either a prepared ``losses.FrameBatch`` (image, sensor depth, mono
+        # normals, mask): then the loss is the reference's get_loss_dict (dn_model.py:673-925) with the switches of
+        # ``loss_cfg`` (losses.LossConfig; default = FusionSense's configs/config.py) — or a plain dict of target
+        # images rgb / depth / normal: the BENCHMARK loss of BASELINE config #2 (L1 + SSIM on rgb,
+        # plain L1 on depth and normals over every pixel), which is a measurement harness and not get_loss_dict.
+        if loss_cfg is None:
+            from .losses import LossConfig
+            loss_cfg = LossConfig()
+        self.loss_cfg = loss_cfg
         # sh_degree_to_use = min(step // sh_degree_interval, sh_degree) (dn_model.py:562-565; nerfstudio default
         # interval 1000); None = always the full degree (BASELINE config #2 is quoted at degree 3)
         self.sh_degree_interval = sh_degree_interval
@@ -202,9 +211,25 @@ class SplatTrainer:
         return render_fusionsense(self.params, camera, sh_degree=deg, device=self.device, add_mask=add_mask,
                                   crop_box=crop_box, training=grad, binary_threshold=bthr)
 
+    def _touch_rows(self):
+        """(row indices of the touch anchors, their contact normals) for the touch-normal MSE (dn_model.py:893-902)."""
+        st = self.strategy
+        if st is None or getattr(st, "add_mask", None) is None or getattr(st, "touch_normals", None) is None:
+            return None, None
+        return st.touch_rows(), st.touch_normals
+
     def loss(self, out, target) -> Tensor:
-        """Config #2 loss: 0.8*L1 + 0.2*(1-SSIM) on rgb, L1 on depth, L1 on normals."""
-        from .losses import rgb_loss
+        """FrameBatch -> get_loss_dict (dn_model.py:673-925).  Dict of target images -> the config-#2 benchmark loss
+        (SURVEY.md §8d): 0.8*L1 + 0.2*(1-SSIM) on rgb, L1 on depth, L1 on normals."""
+        from .losses import FrameBatch, rgb_loss
+        if isinstance(target, FrameBatch):
+            from .ops import fusion_loss
+            ti, tn = self._touch_rows()
+            # The fused get_outputs node WRITES its gradients into the slab (it does not accumulate), so on that route
+            # the min-scale term's direct gradient to the log-scales is added by train_step after the backward
+            # instead of travelling through autograd's accumulation, whose order against the node's write is open.
+            scales = self.params["scales"].detach() if self.fused else self.params["scales"]
+            return fusion_loss(out, target, self.loss_cfg, scales, ti, tn)
         if self.fused and "depth" in target and out["rgb"].is_cuda:
             from .ops import train_loss
             has_n = "normal" in target
@@ -351,7 +376,9 @@ class SplatTrainer:
     def train_step(self, camera: Camera, target: Dict[str, Tensor], optimizer_step: bool = True):
         if getattr(self, "_one", None) is None or self._one.device != self.device:
             self._one = torch.ones((), dtype=torch.float32, device=self.device)
-        direct = self.fused and self.direct and self.device.type == "cuda" and "depth" in target
+        from .losses import FrameBatch
+        is_fb = isinstance(target, FrameBatch)
+        direct = self.fused and self.direct and self.device.type == "cuda" and (is_fb or "depth" in target)
         if not direct:
             # the previous step's deferred feature update reads the slab: it must land before the slab is cleared
             # (the tape-free step hands flush to the frame instead, which calls it right before the SH colours)
@@ -364,7 +391,8 @@ class SplatTrainer:
                                                     self.slab.views, self._one, stats_out=stats, add_mask=add_mask,
                                                     binary_threshold=bthr,
                                                     pre_sh=self.flush if self._pending is not None else None,
-                                                    sh_factors_out=factors[0] if factors else None)
+                                                    sh_factors_out=factors[0] if factors else None,
+                                                    fusion=((self.loss_cfg,) + self._touch_rows()) if is_fb else None)
             self._factors_used = factors
         else:
             if not self.fused:
@@ -372,6 +400,11 @@ class SplatTrainer:
             out = self.forward(camera)
             loss = self.loss(out, target)
             loss.backward(gradient=self._one)  # (the default would launch a fill kernel for the seed gradient)
+            if is_fb and self.fused:
+                from .ops import fusion_loss_weights, min_scale_grad_
+                g_min = fusion_loss_weights(self.loss_cfg, target, self.num_gaussians(), 0)[2]
+                if g_min != 0.0:
+                    min_scale_grad_(self.params["scales"].data, g_min, self._one.reshape(1), self.slab.views["scales"])
         self._reduce_and_step(optimizer_step)
         if self.strategy is not None:
             self.strategy.after_train(self, out, camera)

@@ -458,10 +458,59 @@ int fsgs_aux_l1_fwd_bwd(int64_t n_pixels, const float *depth, const float *depth
 
 /* The scalar loss from the partials above without torch reductions or a host sync:
  * out[0] = bias + sum_t (weights[2t] * sum_r partials[t][r,0] + weights[2t+1] * sum_r partials[t][r,1]),
- * t < n_terms <= 4; partials[t] is [rows[t],2] on the device, the three arrays are HOST arrays.
+ * t < n_terms <= 6; partials[t] is [rows[t],2] on the device, the three arrays are HOST arrays.
  * (dn_model.py:673-925 adds its terms with python scalars; the sum is accumulated in f64.) */
 int fsgs_loss_combine(int n_terms, const float *const *partials, const int64_t *rows,
                       const float *weights, float bias, float *out, fsgs_stream_t stream);
+/* General form: partials[t] is [rows[t], cols[t]] (cols[t] <= 8, n_terms <= 6); weights holds cols[t] consecutive
+ * floats per term, one per column.  cols == NULL: two columns per term (fsgs_loss_combine). */
+int fsgs_loss_combine_cols(int n_terms, const float *const *partials, const int64_t *rows, const int *cols,
+                           const float *weights, float bias, float *out, fsgs_stream_t stream);
+
+/* ---- a-15: the FusionSense training loss, DNSplatterModel.get_loss_dict (dn_splatter/dn_model.py:673-925) ----
+ * Photometric term with the object mask (splatfacto get_loss_dict called at dn_model.py:683 multiplies both
+ * images by batch["mask"]): mask [H,W] float or NULL; pred and gt are multiplied by it as they are loaded and
+ * v_pred = mask * d loss / d(pred * mask).  The backward optionally carries the combine of all loss partials
+ * (loss_out != NULL; arguments of fsgs_loss_combine_cols). */
+int fsgs_ssim_l1_fwd_masked(int H, int W, const float *pred, const float *gt, const float *mask, float *dm_dmu1,
+                            float *dm_dsigma1, float *dm_dsigma12, float *sums, fsgs_stream_t stream);
+int fsgs_ssim_l1_bwd_masked(int H, int W, const float *pred, const float *gt, const float *mask,
+                            const float *dm_dmu1, const float *dm_dsigma1, const float *dm_dsigma12,
+                            const float *v_loss, float g_l1, float g_ssim, float *v_pred, int n_terms,
+                            const float *const *partials, const int64_t *rows, const int *cols,
+                            const float *weights, float bias, float *loss_out, fsgs_stream_t stream);
+
+/* Depth and normal terms of get_loss_dict in ONE pass over the images (dn_model.py:702-764, 770-815;
+ * dn_splatter/losses.py:177-214 EdgeAwareLogL1, :269-285 TVLoss), with d = depth*mask, g = sensor*mask,
+ * n = normal*mask, n* = normal_gt*mask, valid = g > depth_tol, I = clamp(image, min 10/255):
+ *   col 0  sum over valid, x < W-1 of exp(-mean_c|I(x)-I(x+1)|) * log(1+|d-g|)      (EdgeAwareLogL1, x)
+ *   col 1  the same along y                                                            (EdgeAwareLogL1, y)
+ *   col 2  sum_{x<W-1} |d(x)-d(x+1)|        col 3  sum_{y<H-1} |d(y)-d(y+1)|           (TV on depth)
+ *   col 4  sum |n-n*| over 3 channels                                                  (normal L1)
+ *   col 5  sum_{x<W-1} |n(x)-n(x+1)|        col 6  sum_{y<H-1} |n(y)-n(y+1)|           (TV on normals)
+ *   col 7  number of valid pixels with x < W-1 ... unused (0)
+ * partial: [fsgs_fusion_aux_num_partials(H,W), 8] per-workgroup sums.  w[7]: the weight of every column in the
+ * loss (lambda / count; the two EdgeAwareLogL1 counts are per-view constants, fsgs_depth_valid_counts).
+ * v_loss != NULL: also writes v_depth [H,W] and v_normal [H,W,3] = v_loss[0] * d loss / d image (mask applied).
+ * normal / normal_gt / mask nullable (columns 4-6 then 0). */
+int64_t fsgs_fusion_aux_num_partials(int H, int W);
+int fsgs_fusion_aux_loss(int H, int W, const float *depth, const float *normal, const float *image,
+                         const float *sensor_depth, const float *normal_gt, const float *mask, float depth_tol,
+                         const float *w, const float *v_loss, float *partial, float *v_depth, float *v_normal,
+                         fsgs_stream_t stream);
+/* counts[0] = #{valid, x < W-1}, counts[1] = #{valid, y < H-1} with valid = sensor*mask > depth_tol (the sizes of
+ * the two masked selections of losses.py:208-209); device int64[2], zeroed by the call. */
+int fsgs_depth_valid_counts(int H, int W, const float *sensor_depth, const float *mask, float depth_tol,
+                            int64_t *counts, fsgs_stream_t stream);
+/* two_d_gaussians term (dn_model.py:817-819): partial[ceil(N/256), 2] col 0 = sum_n min_k exp(log_scales[n,k]);
+ * v_loss != NULL: g_log_scales[n, argmin] += v_loss[0] * g * exp(min) (accumulated: runs after the rasterizer's
+ * own gradient has been written; first minimum on ties). */
+int fsgs_min_scale_loss(int N, const float *log_scales, float g, const float *v_loss, float *partial,
+                        float *g_log_scales, fsgs_stream_t stream);
+/* touch-normal MSE (dn_model.py:893-902): partial[ceil(n/256), 2] col 0 = sum over the n anchor rows idx[i] of
+ * |normals_world[idx[i]] - touch_normals[i]|^2.  Value only: the reference's normals entry is a detached leaf. */
+int fsgs_touch_normal_sqerr(int n, const int64_t *idx, const float *normals_world, const float *touch_normals,
+                            float *partial, fsgs_stream_t stream);
 
 #ifdef __cplusplus
 }
