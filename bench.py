@@ -1,12 +1,19 @@
 #!/usr/bin/env python3
-"""Headline benchmark: train iters/s (+ rendered Mpix/s) on BASELINE.json config #2 —
-synthetic "lego-like" scene, 300k Gaussians, 800x800, SH degree 3, one view per rank per step.
+"""Headline benchmark: train iters/s (+ rendered Mpix/s) of the Gaussian-splatting hot path.
+
+Default (what the driver runs): BASELINE.json config #2 — synthetic "lego-like" scene, 300k Gaussians, 800x800,
+SH degree 3, 100 hemisphere cameras, one view per rank per step.  ``--config 3|4|5`` run the other single-GPU-sized
+BASELINE configurations through the same loop (they are parity-test cases first; their lines are for DESIGN.md):
+  3  FusionSense-shaped scene: 1280x720, 9 views, ~60k seeds, RGB + sensor depth + mono normals + mask + 5 touch
+     patches, the reference's get_loss_dict, a 300-step window of the real schedule (steps 950..1249: touch patches
+     added at 1000, three refinements, binary opacities, SH degree 0 -> 1)
+  4  "bicycle-like": 6 M Gaussians, 1920x1080, 8 views (one view per rank per step when launched on 8 GPUs)
+  5  10 M Gaussians with half-precision attribute storage (fp32 master + Adam), 1920x1080
 
 A step = one full training iteration of the hot path exactly as FusionSense drives it
-(dn_splatter/dn_model.py:469-671 + trainer order): RGB+ED rasterization,
-per-Gaussian normals + legacy normal rasterization, losses, backward through both rasterizers /
-SH / projection, gradient all-reduce (N>1), Adam step on the 6 live parameter groups, densify
-statistics.  Prints ONE JSON line (rank 0).
+(dn_splatter/dn_model.py:469-671 + trainer order): RGB+ED rasterization, per-Gaussian normals +
+normal rasterization, losses, backward through both rasterizers / SH / projection, gradient exchange (N>1), Adam
+step on the 6 live parameter groups, densify statistics (config 3: + the callbacks).  Prints ONE JSON line (rank 0).
 
     python bench.py --gpus 1 --steps 20 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -17,7 +24,9 @@ from __future__ import annotations
 import argparse
 import gc
 import json
+import math
 import os
+import statistics
 import sys
 import time
 
@@ -37,67 +46,93 @@ def log(msg):
 
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy)
+DEFAULTS = {2: dict(steps=100, warmup=10, views=100), 3: dict(steps=300, warmup=10, views=9),
+            4: dict(steps=20, warmup=3, views=8), 5: dict(steps=10, warmup=2, views=4)}
+# render tolerance of the fp32 path against the reference semantics: images 1e-4 of the tensor
+# maximum, gradients 3e-3 of each tensor's own maximum (fp32 atomics reorder sums); index outputs bit-exact
+RENDER_TOLERANCE = {"forward_rel": 1e-4, "gradient_rel": 3e-3, "indices": "bit-exact"}
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--n-gauss", type=int, default=300_000)
-    ap.add_argument("--res", type=int, default=800)
-    ap.add_argument("--views", type=int, default=8)
+    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4, 5])
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--n-gauss", type=int, default=None)
+    ap.add_argument("--res", type=int, default=800, help="config 2: square image edge")
+    ap.add_argument("--views", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-dropin", action="store_true", help="skip the side measurement through the drop-in surface")
     ap.add_argument("--unfused-caller", action="store_true",
                     help="drive the rasterizer through the drop-in rasterization()/rasterize_gaussians() "
                          "surface with the reference's op-by-op caller glue instead of the fused get_outputs node")
-    ap.add_argument("--cpu-crop", type=int, default=400, help="CPU-baseline sample: central crop edge")
-    ap.add_argument("--cpu-timeout", type=float, default=150.0)
+    ap.add_argument("--cpu-crop", type=int, default=280, help="CPU-baseline sample: central crop edge")
+    ap.add_argument("--cpu-views", type=int, default=3)
+    ap.add_argument("--cpu-timeout", type=float, default=200.0)
     ap.add_argument("--cpu-threads", type=int, default=8)
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
-    return ap.parse_args()
+    a = ap.parse_args()
+    d = DEFAULTS[a.config]
+    a.steps = d["steps"] if a.steps is None else a.steps
+    a.warmup = d["warmup"] if a.warmup is None else a.warmup
+    a.views = d["views"] if a.views is None else a.views
+    if a.n_gauss is None:
+        a.n_gauss = {2: 300_000, 3: 60_000, 4: 6_000_000, 5: 10_000_000}[a.config]
+    return a
 
 
-def cpu_baseline_worker(n_gauss: int, res: int, crop: int, threads: int):
-    """Child-process body: oracle (pure-PyTorch CPU rasterizer) forward+backward on a central
-    crop of view 0 of the same scene; scaled to full-frame-equivalent iters/s by pixel count."""
+# ------------------------------------------------------------------------------------------------------------
+# CPU baseline (child process, never touches the GPU): the oracle on the host cores
+# ------------------------------------------------------------------------------------------------------------
+def cpu_baseline_worker(n_gauss: int, res: int, crop: int, threads: int, n_views: int):
+    """oracle (pure-PyTorch CPU rasterizer) forward+backward of config #2 on a central crop of ``n_views`` views
+    (median, scaled to full-frame-equivalent iters/s by pixel count) + config #1 (1k cube, 128x128) in full."""
     from fusionsense_amd import scenes
     from fusionsense_amd.scenes import Camera
     from oracle.fusion_ref import render_fusionsense as render_ref
 
     torch.set_num_threads(threads)
+
+    def fwd_bwd(params, cam):
+        cp = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+        t0 = time.time()
+        out = render_ref(cp, cam, sh_degree=3)
+        (out["rgb"].mean() + 0.2 * out["depth"].mean() + 0.1 * out["normal"].mean()).backward()
+        return time.time() - t0
+
+    p1, c1 = scenes.cube_scene(1000, seed=0)
+    t_cfg1 = fwd_bwd(p1, c1)
     params = scenes.lego_like_scene(n_gauss, seed=0)
-    cam = scenes.hemisphere_cameras(1, width=res, height=res, focal=1111.11 * res / 800.0, seed=0)[0]
-    x0 = (cam.width - crop) // 2
-    y0 = (cam.height - crop) // 2
-    ccam = Camera(cam.c2w, cam.fx, cam.fy, cam.cx - x0, cam.cy - y0, crop, crop)
-    cp = {k: v.clone().requires_grad_(True) for k, v in params.items()}
-    t0 = time.time()
-    out = render_ref(cp, ccam, sh_degree=3)
-    loss = out["rgb"].mean() + 0.2 * out["depth"].mean() + 0.1 * out["normal"].mean()
-    loss.backward()
-    dt = time.time() - t0
-    frac = (crop * crop) / float(cam.width * cam.height)
+    cams = scenes.hemisphere_cameras(n_views, width=res, height=res, focal=1111.11 * res / 800.0, seed=0)
+    times = []
+    for cam in cams:
+        x0, y0 = (cam.width - crop) // 2, (cam.height - crop) // 2
+        times.append(fwd_bwd(params, Camera(cam.c2w, cam.fx, cam.fy, cam.cx - x0, cam.cy - y0, crop, crop)))
+    dt = statistics.median(times)
+    frac = (crop * crop) / float(res * res)
     print(json.dumps({
         "value": round(frac / dt, 6),
         "unit": "iters/s (full-frame equivalent)",
         "cores": threads,
         "kind": "port",
-        "sample": f"oracle fwd+bwd of view 0, central {crop}x{crop} crop of {cam.width}x{cam.height} "
-                  f"({frac:.4f} of the pixels) in {dt:.1f}s on {threads} threads, scaled by pixel count",
+        "config1_full_iters_per_s": round(1.0 / t_cfg1, 4),
+        "sample": f"oracle fwd+bwd, config #2: median of {n_views} views, central {crop}x{crop} crop of {res}x{res} "
+                  f"({frac:.4f} of the pixels; {', '.join(f'{t:.1f}' for t in times)} s) scaled by pixel count; "
+                  f"config #1 (1k cube, 128x128) in full: {t_cfg1:.2f} s; {threads} threads",
     }))
 
 
 def cpu_baseline(args):
-    """Run the oracle in a child process (never touches the GPU) under a hard wall-clock limit."""
     import subprocess
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
     threads = max(1, min(avail, 8))
-    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", "--n-gauss", str(args.n_gauss),
-           "--res", str(args.res), "--cpu-crop", str(args.cpu_crop), "--cpu-threads", str(threads)]
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", "--n-gauss", "300000",
+           "--res", "800", "--cpu-crop", str(args.cpu_crop), "--cpu-threads", str(threads),
+           "--cpu-views", str(args.cpu_views)]
     env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads), HIP_VISIBLE_DEVICES="")
     try:
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=args.cpu_timeout, env=env)
@@ -108,28 +143,115 @@ def cpu_baseline(args):
                 "sample": f"oracle child failed rc={r.returncode}: {r.stderr[-200:]}"}
     except subprocess.TimeoutExpired:
         return {"value": None, "unit": "iters/s", "cores": threads, "kind": "port",
-                "sample": f"oracle child exceeded {args.cpu_timeout}s on a {args.cpu_crop}^2 crop"}
+                "sample": f"oracle child exceeded {args.cpu_timeout}s on {args.cpu_views} {args.cpu_crop}^2 crops"}
 
 
-def pmc_record(kernel_key):
-    """Counters of a kernel from the committed PMC run (profiles/pmc_traffic.json), or {}."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")
+def pmc_record(kernel_key, config):
+    """Counters of a kernel from the committed PMC run of this round (profiles/pmc_traffic.json), or {}.
+    PMC counters cannot be read from inside the timed process; tools/pmc_summary.py writes this file from the
+    rocprofv3 --pmc passes of the same bench command."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(path) as f:
-            return json.load(f).get(kernel_key, {}) or {}
+            d = json.load(f)
+        return d.get(f"config{config}", d if config == 2 else {}).get(kernel_key, {}) or {}
     except (OSError, ValueError):
         return {}
 
 
-def pmc_traffic(kernel_key):
-    """HBM bytes per launch of a kernel from the committed PMC run, or None."""
-    return pmc_record(kernel_key).get("hbm_bytes_per_launch")
+# ------------------------------------------------------------------------------------------------------------
+# workloads
+# ------------------------------------------------------------------------------------------------------------
+def render_targets(tr, cams, keys=("rgb", "depth", "normal", "accumulation")):
+    out = []
+    with torch.no_grad():
+        for cam in cams:
+            o = tr.forward(cam)
+            out.append({k: o[k].detach().clone() for k in keys})
+    torch.cuda.synchronize()
+    return out
+
+
+def build_workload(args, dev):
+    from fusionsense_amd import scenes
+    from fusionsense_amd.splatfacto import DensifyStrategy, SplatfactoConfig
+    from fusionsense_amd.trainer import SplatTrainer
+    fused = not args.unfused_caller
+    w = dict(start_step=0, extra={})
+    if args.config == 2:
+        W = H = args.res
+        cams = scenes.hemisphere_cameras(args.views, width=W, height=H, focal=1111.11 * args.res / 800.0, seed=0)
+        params = scenes.lego_like_scene(args.n_gauss, seed=0)
+        strategy = DensifyStrategy(SplatfactoConfig(), num_train_data=args.views, stats_only=True)
+        trainer = SplatTrainer(params, dev, sh_degree=3, strategy=strategy, seed=0, fused=fused)
+        tgt = SplatTrainer(scenes.lego_like_scene(args.n_gauss, seed=1), dev, sh_degree=3, fused=fused)
+        targets = [{k: t[k] for k in ("rgb", "depth", "normal")} for t in render_targets(tgt, cams)]
+        w.update(name=f"BASELINE config #2: synthetic lego-like, {args.n_gauss} Gaussians, {W}x{H}, SH deg 3, "
+                      f"{args.views} hemisphere cameras, RGB+ED + normal pass, benchmark loss (L1+SSIM rgb, L1 depth, "
+                      "L1 normal), fwd+bwd+Adam+densify stats", params=params)
+    elif args.config == 3:
+        from fusionsense_amd.losses import LossConfig, prepare_batch
+        n_hull = args.n_gauss // 3
+        params, cams = scenes.fusionsense_like_scene(seed=0, n_hull=n_hull, n_bg=args.n_gauss - n_hull)
+        g = torch.Generator().manual_seed(5)
+        params["opacities"] = 1.5 * torch.randn(params["opacities"].shape, generator=g)  # ~950 steps into training
+        cams = cams[:args.views]
+        H, W = cams[0].height, cams[0].width
+        strategy = DensifyStrategy(SplatfactoConfig(), num_train_data=len(cams))
+        patches = scenes.touch_patches_on_blob(5, 2000, radius=0.1, seed=0)
+        strategy.set_metadata(touch_patches=patches, gel_scale_factor=6.34e-5, add_touch_at=1000,
+                              visual_hull=params["means"][:n_hull].clone(), scale_factor=1.0)
+        cfg = LossConfig()
+        trainer = SplatTrainer(params, dev, sh_degree=3, strategy=strategy, seed=0, fused=fused,
+                               sh_degree_interval=1000, loss_cfg=cfg)
+        tp, _ = scenes.fusionsense_like_scene(seed=1, n_hull=n_hull, n_bg=args.n_gauss - n_hull)
+        tp["opacities"] = tp["opacities"] + 3.0
+        tgt = SplatTrainer(tp, dev, sh_degree=3, fused=fused)
+        yy, xx = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
+        mask = (((xx - W / 2) / (0.42 * W)) ** 2 + ((yy - H / 2) / (0.46 * H)) ** 2 < 1.0)[..., None]
+        targets = []
+        for t in render_targets(tgt, cams):
+            sensor = torch.where(t["accumulation"] > 0.5, t["depth"], torch.zeros_like(t["depth"]))  # holes
+            targets.append(prepare_batch({"image": t["rgb"], "sensor_depth": sensor, "normal": t["normal"],
+                                          "mask": mask}, cfg, dev))
+        w.update(name=f"BASELINE config #3: FusionSense-shaped scene, {args.n_gauss} seed Gaussians (1/3 object blob), "
+                      f"{W}x{H}, {len(cams)} views, RGB + sensor depth + mono normals + mask + 5 touch patches x ~2000 "
+                      "points; loss = the reference's get_loss_dict; steps 950..: add_touch_patch at 1000, refinement "
+                      "(densify / cull / hull + touch pruning) every 100, binary opacities, SH degree step//1000",
+                 params=params, start_step=950)
+    else:
+        W, H = 1920, 1080
+        cams = []
+        for i in range(args.views):
+            az = 2 * math.pi * i / args.views
+            eye = torch.tensor([2.4 * math.cos(az), 2.4 * math.sin(az), 0.9])
+            cams.append(scenes.Camera(scenes.look_at_c2w(eye, torch.tensor([0.0, 0.0, 0.0])), 1500.0, 1500.0, W / 2.0,
+                                      H / 2.0, W, H))
+        params = scenes.bicycle_like_scene(args.n_gauss, seed=0)
+        strategy = DensifyStrategy(SplatfactoConfig(), num_train_data=args.views, stats_only=True)
+        half = args.config == 5
+        trainer = SplatTrainer(params, dev, sh_degree=3, strategy=strategy, seed=0, fused=fused,
+                               **({"half_attributes": True} if half else {}))
+        tgt = SplatTrainer(scenes.bicycle_like_scene(args.n_gauss, seed=1), dev, sh_degree=3, fused=fused)
+        targets = [{k: t[k] for k in ("rgb", "depth", "normal")} for t in render_targets(tgt, cams)]
+        name = ("BASELINE config #4: synthetic bicycle-like" if not half else
+                "BASELINE config #5: fp16 attribute storage (features, scales, quats, opacities; fp32 means, fp32 master + "
+                "Adam), synthetic bicycle-like")
+        w.update(name=f"{name}, {args.n_gauss} Gaussians, {W}x{H}, SH deg 3, {args.views} views, benchmark loss, "
+                      "fwd+bwd+Adam+densify stats", params=params)
+    try:
+        del tgt
+    except NameError:
+        pass
+    torch.cuda.empty_cache()
+    w.update(trainer=trainer, cams=cams, targets=targets, W=cams[0].width, H=cams[0].height)
+    return w
 
 
 def main():
     args = parse()
     if args.cpu_baseline_worker:
-        cpu_baseline_worker(args.n_gauss, args.res, args.cpu_crop, args.cpu_threads)
+        cpu_baseline_worker(args.n_gauss, args.res, args.cpu_crop, args.cpu_threads, args.cpu_views)
         return
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -150,31 +272,13 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    from fusionsense_amd import frame_cache, ops, scenes
-    from fusionsense_amd.splatfacto import DensifyStrategy, SplatfactoConfig
-    from fusionsense_amd.trainer import SplatTrainer
+    from fusionsense_amd import frame_cache, ops
 
-    W = H = args.res
-    focal = 1111.11 * args.res / 800.0
-    cams = scenes.hemisphere_cameras(args.views, width=W, height=H, focal=focal, seed=0)
-    log('building scene')
-    params = scenes.lego_like_scene(args.n_gauss, seed=0)
-    log('scene built')
-    # statistics only (no refinement inside the timed window: refine_every > steps)
-    strategy = DensifyStrategy(SplatfactoConfig(), num_train_data=args.views, stats_only=True)
-    trainer = SplatTrainer(params, dev, sh_degree=3, strategy=strategy, seed=0, fused=not args.unfused_caller)
-
-    # targets: renders of a differently seeded scene, so gradients are non-trivial
-    tgt_tr = SplatTrainer(scenes.lego_like_scene(args.n_gauss, seed=1), dev, sh_degree=3, fused=not args.unfused_caller)
-    targets = []
-    with torch.no_grad():
-        for ci, cam in enumerate(cams):
-            o = tgt_tr.forward(cam)
-            torch.cuda.synchronize()
-            log(f'target {ci} rendered, M={o["info"]["flatten_ids"].numel()}')
-            targets.append({k: o[k].detach().clone() for k in ("rgb", "depth", "normal")})
-    del tgt_tr
-    torch.cuda.empty_cache()
+    log('building workload')
+    wl = build_workload(args, dev)
+    trainer, cams, targets, W, H = wl["trainer"], wl["cams"], wl["targets"], wl["W"], wl["H"]
+    fused = not args.unfused_caller
+    log('workload built')
 
     def view_of(step):
         return (step * world + rank) % len(cams)
@@ -185,12 +289,17 @@ def main():
 
     # ---- setup: size the workspace pool for every view (forward + backward, no optimizer step), so that
     # neither the warmup nor the timed steps meet a first-time device allocation ----
+    strategy = trainer.strategy
     if not os.environ.get("FSGS_BENCH_NO_PRIME"):
+        so = strategy.stats_only
+        strategy.stats_only = True  # (no callbacks while priming)
         for v in range(len(cams)):
             trainer.train_step(cams[v], targets[v], optimizer_step=False)
         torch.cuda.synchronize()
-        trainer.step = 0
+        strategy.stats_only = so
+        strategy.xys_grad_norm = strategy.vis_counts = strategy.max_2Dsize = None
         log('workspace primed')
+    trainer.step = wl["start_step"] - args.warmup if wl["start_step"] else 0
 
     # ---- warmup ----
     for s in range(args.warmup):
@@ -206,8 +315,6 @@ def main():
     # host time right in front of it, i.e. a GPU bubble; every other kernel is timed in the untimed pass below
     ops.TIMER.reset(enabled=not os.environ.get("FSGS_BENCH_NO_TIMER"), only=("raster_bwd",), prealloc=args.steps + 2)
     # keep the interpreter's cyclic collector out of the timed region (a generation-2 pass costs tens of ms).
-    # No gc.collect() here: freeing the setup's garbage right now reshuffles the caching allocator's pools and
-    # was measured to cost 7 % in the steps that follow.
     gcm = os.environ.get("FSGS_BENCH_GC", "fd")
     if "c" in gcm:
         gc.collect()
@@ -217,12 +324,13 @@ def main():
         gc.disable()
     torch.cuda.synchronize()
     n_alloc0 = torch.cuda.memory_stats(dev).get('num_device_alloc', 0)
+    n_before = trainer.num_gaussians()
     t0 = time.perf_counter()
     step_ends = []
     for s in range(args.steps):
         v = view_of(args.warmup + s)
         trainer.train_step(cams[v], targets[v])
-        step_ends.append(time.perf_counter())  # (every step waits for its live-pair count: host time tracks the GPU)
+        step_ends.append(time.perf_counter())
     trainer.flush()  # (data-parallel runs: the last step's deferred feature update belongs to the timed work)
     torch.cuda.synchronize()
     barrier()
@@ -245,9 +353,11 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
 
-    # ---- side measurements (outside the timed region) ----
+    # ---- side measurements (outside the timed region; no callbacks, so the scene stays as the timed region left it) ----
+    strategy.stats_only = True
+    side_steps = min(args.steps, 10)
     ops.TIMER.reset(enabled=True)
-    for s in range(min(args.steps, 10)):
+    for s in range(side_steps):
         v = view_of(s)
         trainer.train_step(cams[v], targets[v])
     torch.cuda.synchronize()
@@ -263,24 +373,47 @@ def main():
     n_live = int(info["flatten_ids"].numel())
     n_vis = int((info["radii"] > 0).sum().item())
     P = W * H
-    # iteration without the optimizer step
+    side_n = min(args.steps, 50)
     torch.cuda.synchronize()
     t1 = time.perf_counter()
-    for s in range(args.steps):
+    for s in range(side_n):
         v = view_of(s)
         trainer.train_step(cams[v], targets[v], optimizer_step=False)
     torch.cuda.synchronize()
-    t_noopt = (time.perf_counter() - t1) / args.steps
+    t_noopt = (time.perf_counter() - t1) / side_n
     # forward-only latency -> rendered Mpix/s (num_rays_per_sec of dn_pipeline.py:246-248)
     with torch.no_grad():
         for s in range(2):
             trainer.forward(cams[view_of(s)])
         torch.cuda.synchronize()
         t2 = time.perf_counter()
-        for s in range(args.steps):
+        for s in range(side_n):
             trainer.forward(cams[view_of(s)])
         torch.cuda.synchronize()
-        t_fwd = (time.perf_counter() - t2) / args.steps
+        t_fwd = (time.perf_counter() - t2) / side_n
+
+    # the same steps through the drop-in surface (rasterization() + rasterize_gaussians(), the reference's own call
+    # structure): what a FusionSense maintainer gets without touching dn_model.py
+    dropin = None
+    if fused and not args.no_dropin and args.config in (2, 3) and world == 1:
+        from fusionsense_amd.splatfacto import DensifyStrategy, SplatfactoConfig
+        from fusionsense_amd.trainer import SplatTrainer
+        d_st = DensifyStrategy(SplatfactoConfig(), num_train_data=len(cams), stats_only=True)
+        d_st.add_mask, d_st.touch_normals = strategy.add_mask, strategy.touch_normals
+        d_tr = SplatTrainer({k: p.data for k, p in trainer.params.items()}, dev, sh_degree=3, fused=False,
+                            loss_cfg=trainer.loss_cfg, strategy=d_st)
+        d_tr.step = trainer.step
+        d_tr.sh_degree_interval = trainer.sh_degree_interval
+        for s in range(5):
+            d_tr.train_step(cams[view_of(s)], targets[view_of(s)])
+        torch.cuda.synchronize()
+        t3 = time.perf_counter()
+        nd = 30
+        for s in range(nd):
+            d_tr.train_step(cams[view_of(s)], targets[view_of(s)])
+        torch.cuda.synchronize()
+        dropin = nd / (time.perf_counter() - t3)
+        del d_tr
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -290,7 +423,6 @@ def main():
         key_bits = 32 + ops.tile_bits((W // 16 + (W % 16 > 0)) * (H // 16 + (H % 16 > 0)))
         sort_b = 2 * 12 * ((key_bits + 7) // 8)
         b_isect = 12 + sort_b + 8 + 44 + 44
-        fused = not args.unfused_caller
         reused = fused or (frame_cache.hits > 0 and frame_cache.misses == 0)
         b_isect_normal = (40 + 40) if reused else (12 + sort_b + 8 + 40 + 40)
         b_iter = N * 352 + n_vis * 444 + M * (b_isect + b_isect_normal) + P * 92
@@ -308,6 +440,7 @@ def main():
             "raster_bwd_d4": ("raster_bwd_kernel<4,true>", M * 44 + P * 28 + n_vis * 48),
             "sort_pairs": ("radix sort (hist + scan + scatter per 8-bit pass)", M * sort_b),
             "tile_sort": ("partition by tile + per-tile LDS sort", M * sort_b),
+            "adam_step": ("adam_kernel (six parameter groups, one launch)", N * 59 * 28),
         }
         cand = [(v["avg_ms"], k) for k, v in kernel_ms.items() if k in alg]  # (each is launched once per step)
         roofline = None
@@ -316,16 +449,16 @@ def main():
             dom_ms = kernel_ms[dom]["avg_ms"]
             name, dom_bytes = alg[dom]
             ach = dom_bytes / (dom_ms * 1e-3) / 1e9
+            rec = pmc_record(dom, args.config)
             roofline = {"kernel": name, "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
-                        # PMC counters cannot be read from inside the timed process: `traffic` is the
-                        # rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE figure (bytes per launch, gfx950-corrected)
-                        # of this kernel from the committed run in profiles/ (DESIGN.md §5), null if absent
-                        "traffic": pmc_traffic(dom), "algorithmic_bytes": dom_bytes,
-                        "avg_launch_ms": round(dom_ms, 4)}
+                        # rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE (bytes per launch, gfx950-corrected) of this kernel
+                        # from this round's committed run in profiles/ (DESIGN.md §5), null if absent
+                        "traffic": rec.get("hbm_bytes_per_launch"), "traffic_source": rec.get("source"),
+                        "algorithmic_bytes": dom_bytes, "avg_launch_ms": round(dom_ms, 4)}
             # the compositing kernels are bound by fp32 VALU issue, not by HBM (the contract's `bound` has no
             # such value): say how busy the vector ALUs are, from the committed SQ counters and THIS run's time
-            q = pmc_record(dom).get("sq_active_inst_valu_quadcycles_per_launch")
+            q = rec.get("sq_active_inst_valu_quadcycles_per_launch")
             if q:
                 roofline["valu_busy_frac"] = round(4.0 * q / (1024 * dom_ms * 1e-3 * 2.4e9), 4)
                 roofline["limiter"] = "fp32 VALU issue (see DESIGN.md 5)"
@@ -340,18 +473,23 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32" if args.config != 5 else "f32 arithmetic, f16 attribute storage",
             "data": "synthetic",
-            "config": {"workload": f"BASELINE config #2: synthetic lego-like, {N} Gaussians, {W}x{H}, "
-                                   "SH deg 3, RGB+ED + normal pass, fwd+bwd+Adam+densify stats, "
-                                   "1 view/rank/step; caller = " + ("fused get_outputs node" if fused else
-                                                                    "reference-style op-by-op glue over the drop-in surface"),
-                       "n_gaussians": N, "width": W, "height": H, "views": len(cams),
-                       "n_isects": M, "n_isects_live": n_live, "n_visible": n_vis, "isects_per_gaussian": round(M / max(N, 1), 3),
-                       "normal_pass_list_reuse": bool(reused), "parallelism": f"dp{world}"},
+            "config": {"workload": wl["name"] + "; 1 view/rank/step; caller = " +
+                                   ("fused get_outputs node" if fused else
+                                    "reference-style op-by-op glue over the drop-in surface"),
+                       "baseline_config": args.config, "n_gaussians": N, "n_gaussians_start": n_before,
+                       "width": W, "height": H, "views": len(cams),
+                       "n_isects": M, "n_isects_live": n_live, "n_visible": n_vis,
+                       "isects_per_gaussian": round(M / max(N, 1), 3),
+                       "normal_pass_list_reuse": bool(reused), "parallelism": f"dp{world}",
+                       "backend": (backend if world > 1 else None),
+                       "comm_bytes_per_step_per_rank": getattr(trainer, "comm_bytes_last_step", 0) if world > 1 else 0},
             "rendered_mpix_per_s": round(world * P / t_fwd / 1e6, 2),
             "fwd_ms": round(t_fwd * 1e3, 3),
             "iters_per_s_excl_optimizer": round(world / t_noopt, 3),
+            "dropin_iters_per_s": None if dropin is None else round(dropin, 2),
+            "render_tolerance": RENDER_TOLERANCE,
             "iter_algorithmic_bytes": b_iter,
             "iter_hbm_frac": round(b_iter / (elapsed / args.steps) / (HBM_PEAK_GBS * 1e9), 5),
             "device_mallocs_in_timed_region": n_alloc,
@@ -360,6 +498,9 @@ def main():
             "kernels_ms": kernel_ms,
             "roofline": roofline,
         }
+        if args.config == 3:
+            line["config"]["refinement"] = dict(strategy.last_report)
+            line["config"]["touch_anchors"] = int(strategy.add_mask.sum()) if strategy.add_mask is not None else 0
         log('gpu part done')
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(args)

@@ -94,6 +94,36 @@ split_samples_kernel(int64_t S, int n_samples, const int64_t *__restrict__ ids,
     }
 }
 
+// a-14: nearest point of a set for every query (hull_pruning's cdist(...).min and add_touch_patch's 1-NN colour
+// lookup, /root/reference/dn_splatter/dn_model.py:1181-1182, 1258-1264), brute force: a thread keeps its query in
+// registers, the point set streams through LDS in tiles of 1024 (broadcast reads).  Exact fp32 differences (no
+// |a|^2 + |b|^2 - 2ab expansion), ties -> lowest index.
+__global__ void __launch_bounds__(256)
+nearest_point_kernel(int nq, const float *__restrict__ q, int np, const float *__restrict__ p,
+                     float *__restrict__ out_dist, int64_t *__restrict__ out_idx) {
+    __shared__ float sp[1024 * 3];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool on = i < nq;
+    const float qx = on ? q[i * 3 + 0] : 0.f, qy = on ? q[i * 3 + 1] : 0.f, qz = on ? q[i * 3 + 2] : 0.f;
+    float best = INFINITY;
+    int best_j = 0;
+    for (int base = 0; base < np; base += 1024) {
+        const int n = min(1024, np - base);
+        __syncthreads();
+        for (int k = threadIdx.x; k < n * 3; k += 256) sp[k] = p[(int64_t)base * 3 + k];
+        __syncthreads();
+        for (int j = 0; j < n; ++j) {
+            const float dx = qx - sp[j * 3 + 0], dy = qy - sp[j * 3 + 1], dz = qz - sp[j * 3 + 2];
+            const float d2 = dx * dx + dy * dy + dz * dz;
+            if (d2 < best) { best = d2; best_j = base + j; }
+        }
+    }
+    if (on) {
+        if (out_dist) out_dist[i] = sqrtf(best);
+        if (out_idx) out_idx[i] = best_j;
+    }
+}
+
 }  // namespace fsgs
 
 using namespace fsgs;
@@ -160,5 +190,15 @@ extern "C" int fsgs_split_samples(int64_t S, int n_samples, const int64_t *ids, 
     hipLaunchKernelGGL(split_samples_kernel, dim3(ceil_div(S * n_samples, 256)), dim3(256), 0,
                        as_stream(stream), S, n_samples, ids, means, quats, log_scales, randn, new_means,
                        new_log_scales);
+    return check_launch();
+}
+
+extern "C" int fsgs_nearest_point(int nq, const float *queries, int np, const float *points, float *out_dist,
+                                  int64_t *out_idx, fsgs_stream_t stream) {
+    if (nq < 0 || np < 1) return FSGS_EINVAL;
+    if (nq == 0) return FSGS_OK;
+    if (!queries || !points || (!out_dist && !out_idx)) return FSGS_EINVAL;
+    hipLaunchKernelGGL(nearest_point_kernel, dim3(ceil_div(nq, 256)), dim3(256), 0, as_stream(stream), nq, queries, np,
+                       points, out_dist, out_idx);
     return check_launch();
 }

@@ -183,8 +183,8 @@ __device__ __forceinline__ void combine_partials(const CombineArgs &a, float *__
     for (int t = 0; t < a.n_terms; ++t) {
         const float *p = a.partials[t];
         const int cols = a.cols[t];
-        const long long n = a.rows[t] * cols;
-        for (long long e = threadIdx.x; e < n; e += THREADS) acc += (double)p[e] * (double)a.w[t][e % cols];
+        for (long long r = threadIdx.x; r < a.rows[t]; r += THREADS)
+            for (int c = 0; c < cols; ++c) acc += (double)p[r * cols + c] * (double)a.w[t][c];
     }
 #pragma unroll
     for (int s = 32; s >= 1; s >>= 1) acc += __shfl_xor(acc, s, 64);

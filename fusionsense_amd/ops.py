@@ -767,6 +767,18 @@ def compact_rows(src: Tensor, keep8: Tensor, positions: Tensor, n_keep: int,
     return out
 
 
+def nearest_point(queries: Tensor, points: Tensor, want_idx: bool = False):
+    """Distance from every query [nq,3] to the nearest of points [np,3] (and its index with ``want_idx``)."""
+    lib = load()
+    queries, points = queries.contiguous(), points.contiguous()
+    nq, dev = queries.shape[0], queries.device
+    dist = torch.empty(nq, dtype=torch.float32, device=dev)
+    idx = torch.empty(nq, dtype=torch.int64, device=dev) if want_idx else None
+    _run(lib.fsgs_nearest_point, (nq, ptr(queries), points.shape[0], ptr(points), ptr(dist), ptr(idx),
+                                  stream_ptr(dev)), "fsgs_nearest_point")
+    return (dist, idx) if want_idx else dist
+
+
 def split_samples(ids: Tensor, n_samples: int, means: Tensor, quats: Tensor, log_scales: Tensor,
                   randn: Tensor) -> Tuple[Tensor, Tensor]:
     lib = load()

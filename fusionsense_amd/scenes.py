@@ -193,3 +193,38 @@ def bicycle_like_scene(n: int = 6_000_000, seed: int = 0, sh_degree: int = 3) ->
     opac = 1.0 + 1.5 * torch.randn(n, 1, generator=g)
     dc, rest = _sh_params(n, sh_degree, g)
     return dict(means=means, scales=scales, quats=quats, features_dc=dc, features_rest=rest, opacities=opac)
+
+
+def touch_patches_on_blob(n_patches: int = 5, pts_per_patch: int = 2000, radius: float = 0.1, seed: int = 0,
+                          extent=(0.0101, 0.0076), depth: float = 0.01):
+    """Config #3's tactile supervision: ``n_patches`` gel-sensor contact patches on the surface of the object blob,
+    in the dictionary layout the reference's dataparser hands to the model
+    (dn_splatter/data/normal_nerfstudio.py:593-683): ``points_xyz`` [n,3] (a regular grid on the tangent plane: the
+    gel image is 320x240 pixels at 6.34e-5 m, every 5th point kept), ``normals`` [n,3] (contact normals: outward),
+    ``bbox`` [8,3] — the oriented box around the patch, vertex index = 4*xi + 2*yi + zi, reaching ``depth`` behind
+    the contact plane (z_diff*5 there)."""
+    g = torch.Generator().manual_seed(seed + 991)
+    patches = []
+    nx = int(round(math.sqrt(pts_per_patch * extent[0] / extent[1])))
+    ny = max(pts_per_patch // nx, 1)
+    for _ in range(n_patches):
+        d = torch.nn.functional.normalize(torch.randn(3, generator=g), dim=0)
+        d[2] = d[2].abs() * 0.5 + 0.1  # upper half: visible from the camera ring
+        d = torch.nn.functional.normalize(d, dim=0)
+        centre = radius * d
+        a = torch.linalg.cross(d, torch.tensor([0.0, 0.0, 1.0]))
+        a = torch.nn.functional.normalize(a, dim=0)
+        b = torch.linalg.cross(d, a)
+        u = torch.linspace(-extent[0], extent[0], nx)
+        v = torch.linspace(-extent[1], extent[1], ny)
+        uu, vv = torch.meshgrid(u, v, indexing="ij")
+        pts = centre + uu.reshape(-1, 1) * a + vv.reshape(-1, 1) * b
+        normals = d.expand_as(pts).clone() + 0.05 * torch.randn(pts.shape, generator=g)
+        normals = torch.nn.functional.normalize(normals, dim=-1)
+        corners = []
+        for i in range(8):
+            xi, yi, zi = (i >> 2) & 1, (i >> 1) & 1, i & 1
+            corners.append(centre + (2 * xi - 1) * extent[0] * a + (2 * yi - 1) * extent[1] * b + (1.05 * zi - 1) * depth * d)
+        patches.append(dict(points_xyz=pts.contiguous(), points_rgb=torch.zeros_like(pts), normals=normals,
+                            bbox=torch.stack(corners)))
+    return patches

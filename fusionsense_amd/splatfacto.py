@@ -132,6 +132,12 @@ class DensifyStrategy:
         self.add_mask: Optional[Tensor] = None  # touch anchors (dn_model.py:292, 366-378)
         self.touch_normals: Optional[Tensor] = None  # [n_touch,3] contact normals of the anchors, patch order (:897-899)
         self._touch_rows = (None, None)
+        # what the dataparser's metadata carries for the FusionSense callbacks (normal_nerfstudio.py:593-690)
+        self.touch_patches = None
+        self.gel_scale_factor = 6.34e-5   # normal_nerfstudio.py:72
+        self.add_touch_at = 1000          # dn_model.py:136, configs/config.py:7
+        self.visual_hull: Optional[Tensor] = None
+        self.scale_factor = 1.0
         self.extra_cull_fn = None  # hook for hull / touch pruning (a-14)
         self.last_report: Dict[str, int] = {}
 
@@ -187,15 +193,31 @@ class DensifyStrategy:
         self.vis_counts = extra + 1.0
         dist.all_reduce(self.max_2Dsize, op=dist.ReduceOp.MAX)
 
+    def set_metadata(self, touch_patches=None, gel_scale_factor: float = 6.34e-5, add_touch_at: int = 1000,
+                     visual_hull: Optional[Tensor] = None, scale_factor: float = 1.0) -> None:
+        """The scene metadata the reference's callbacks read from ``self.kwargs["metadata"]``."""
+        self.touch_patches, self.gel_scale_factor, self.add_touch_at = touch_patches, gel_scale_factor, add_touch_at
+        self.visual_hull, self.scale_factor = visual_hull, scale_factor
+
+    def before_train(self, trainer) -> None:
+        """BEFORE_TRAIN_ITERATION callbacks (dn_model.py:1370-1383): add_touch_patch at step == add_touch_at."""
+        if self.stats_only or self.touch_patches is None or trainer.step != self.add_touch_at:
+            return
+        self.add_touch_patch(trainer, self.touch_patches, self.gel_scale_factor)
+
     def maybe_refine(self, trainer) -> None:
-        """AFTER_TRAIN_ITERATION callback with update_every_num_iters=refine_every
-        (dn_model.py:1398-1404)."""
+        """AFTER_TRAIN_ITERATION callbacks with update_every_num_iters=refine_every, in the reference's order
+        (dn_model.py:1394-1424): refinement_after, hull_pruning, touch_pruning."""
         if self.stats_only:
             return
         if trainer.step % self.cfg.refine_every == 0:
             if hasattr(trainer, "flush"):
                 trainer.flush()  # a deferred feature update must land before rows are split / culled
             self.refinement_after(trainer, trainer.step)
+            if self.visual_hull is not None:
+                self.hull_pruning(trainer, self.visual_hull, self.scale_factor)
+            if self.touch_patches is not None:
+                self.touch_pruning(trainer, self.touch_patches)
 
     # ---- a-13 ---------------------------------------------------------------------------
     @torch.no_grad()
@@ -328,7 +350,8 @@ class DensifyStrategy:
             x = patch["points_xyz"].to(means.device)
             if x.shape[0] == 0:
                 continue
-            nn_idx = torch.cdist(x, means).argmin(dim=-1)  # 1-NN on the device (reference: sklearn on CPU)
+            # 1-NN on the device (reference: sklearn on CPU); brute force in libfsgs, no BLAS, no [n, N] matrix
+            nn_idx = ops.nearest_point(x, means, want_idx=True)[1] if means.is_cuda else torch.cdist(x, means).argmin(dim=-1)
             pts.append(x)
             nrm.append(patch["normals"].to(means.device))
             rgb.append(base_rgb[nn_idx])

@@ -92,7 +92,11 @@ def hull_prune_mask(means: Tensor, visual_hull: Tensor, scale_factor: float,
     distance to the hull point set is in (0.005 s, 0.02 s] are culled; touch anchors never."""
     center = visual_hull.mean(dim=0)
     close = torch.norm(means - center, dim=1) <= 0.2 * scale_factor
-    d = torch.cdist(means[close], visual_hull).min(dim=-1).values
+    if means.is_cuda:
+        from .ops import nearest_point
+        d = nearest_point(means[close], visual_hull)  # exact differences, no [n, n_hull] matrix
+    else:  # (host mirror used by the CPU tests of the mask logic)
+        d = torch.cdist(means[close], visual_hull).min(dim=-1).values
     sel = (d > 0.005 * scale_factor) & (d <= 0.02 * scale_factor)
     mask = torch.zeros(means.shape[0], dtype=torch.bool, device=means.device)
     mask[close] = sel

@@ -378,6 +378,8 @@ class SplatTrainer:
             self._one = torch.ones((), dtype=torch.float32, device=self.device)
         from .losses import FrameBatch
         is_fb = isinstance(target, FrameBatch)
+        if self.strategy is not None and hasattr(self.strategy, "before_train"):
+            self.strategy.before_train(self)
         direct = self.fused and self.direct and self.device.type == "cuda" and (is_fb or "depth" in target)
         if not direct:
             # the previous step's deferred feature update reads the slab: it must land before the slab is cleared

@@ -354,6 +354,11 @@ int fsgs_mask_scan(int64_t n_rows, const uint8_t *keep, int64_t *positions, void
 int fsgs_compact_rows(int64_t n_rows, int row_floats, const uint8_t *keep,
                       const int64_t *positions, const float *src, float *dst,
                       fsgs_stream_t stream);
+/* a-14: for every query [nq,3] the nearest of points [np,3] (np >= 1): Euclidean distance (out_dist, nullable) and
+ * index (out_idx, nullable; lowest index on ties).  Replaces torch.cdist(...).min(-1) in hull_pruning
+ * (dn_splatter/dn_model.py:1258-1264) and the k=1 neighbour search of add_touch_patch (:1181-1182). */
+int fsgs_nearest_point(int nq, const float *queries, int np, const float *points, float *out_dist,
+                       int64_t *out_idx, fsgs_stream_t stream);
 /* split_gaussians sample kernel: for every selected parent p (ids[S]) and sample s<n_samples,
  * new_mean = mean[p] + R(q[p]/|q|) (exp(log_scale[p]) * z[s*S+i]); new_log_scale = log(exp(ls)/1.6).
  * Writes new_means[n_samples*S,3], new_log_scales[n_samples*S,3] (sample-major, like .repeat). */

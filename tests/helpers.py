@@ -69,3 +69,30 @@ def rel_err(a, b):
     a = a.detach().double().cpu()
     b = b.detach().double().cpu()
     return ((a - b).abs().max() / (b.abs().max() + 1e-12)).item()
+
+
+def run_bench_ranks(n_ranks, bench_args, env_extra=None, timeout=240):
+    """bench.py under torch.distributed.run the way the driver launches it (one process per rank, 127.0.0.1
+    rendezvous), with one retry on a fresh port; returns (parsed JSON line, stderr).  Kills only its own launcher's
+    process group on a hang."""
+    import json, os, signal, socket, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FSGS_BENCH_VERBOSE="1", **(env_extra or {}))
+    out = err = ""
+    p = None
+    for attempt in range(2):
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus",
+               str(n_ranks)] + list(bench_args)
+        p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=root,
+                             start_new_session=True)
+        try:
+            out, err = p.communicate(timeout=timeout)
+            break
+        except subprocess.TimeoutExpired:
+            os.killpg(p.pid, signal.SIGKILL)  # this launcher's own process group only
+            out, err = p.communicate()
+            assert attempt == 0, f"{n_ranks}-rank run hung twice:\n" + err[-3000:]
+    assert p.returncode == 0, err[-3000:]
+    return json.loads([l for l in out.splitlines() if l.startswith("{")][-1]), err

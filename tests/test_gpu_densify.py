@@ -192,3 +192,22 @@ def test_row_moving_callbacks_flush_a_deferred_feature_update(dev):
         for k in PARAM_ORDER:
             d = (a.params[k].data - b.params[k].data).abs()
             assert float((d > 2e-5).float().mean()) < 2e-3 and float(d.mean()) < 2e-6, (factored, k)
+
+
+@pytest.mark.parametrize("nq,np_", [(1, 1), (300, 1), (1000, 1025), (5000, 4097), (70, 20000)])
+def test_nearest_point_kernel(dev, nq, np_):
+    """fsgs_nearest_point (hull_pruning's cdist(...).min, add_touch_patch's 1-NN) against exhaustive fp64 search."""
+    from fusionsense_amd import ops
+    g = torch.Generator().manual_seed(nq * 7 + np_)
+    q, p = torch.randn(nq, 3, generator=g), torch.randn(np_, 3, generator=g)
+    if np_ > 10:
+        p[7] = p[3]  # duplicated point: ties -> lowest index
+        q[0] = p[3]
+    d, i = ops.nearest_point(q.to(dev), p.to(dev), want_idx=True)
+    ref = torch.cdist(q.double(), p.double())
+    rd, ri = ref.min(dim=-1)
+    assert torch.allclose(d.cpu().double(), rd, atol=1e-6)
+    chosen = ref[torch.arange(nq), i.cpu()]
+    assert torch.allclose(chosen, rd, atol=1e-6), "the returned index is a nearest point"
+    if np_ > 10:
+        assert int(i[0]) == 3
