@@ -460,3 +460,55 @@ def test_two_ranks_over_rccl_when_two_gpus():
                                     "--no-cpu-baseline"], dict(FSGS_BENCH_CHECK_REPLICAS="1"))
     assert line["n_gpus"] == 2 and line["config"]["backend"] == "nccl" and line["value"] > 0
     assert err.count("replicas identical") == 2, err[-2000:]
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# inference callers (row N4): eval loop and mesh back-projection over the HIP forward
+# ---------------------------------------------------------------------------------------------------------------
+def test_eval_loop_and_backprojection(dev):
+    """The eval pass (get_outputs_for_camera + metrics + num_rays_per_sec / fps, dn_pipeline.py:233-253) and the mesh
+    exporters' back-projection loop (export_mesh.py:338-455) over the HIP forward: rendering a scene against its own
+    renders scores perfectly; back-projected points re-project onto their pixels at their rendered depth; the
+    normals are unit vectors; a crop box reaches the render."""
+    from fusionsense_amd import inference as inf
+    from fusionsense_amd.crop import OrientedBox
+    from fusionsense_amd.trainer import SplatTrainer
+    params, cams = _small_fusionsense(dev, 160, 96)
+    params["opacities"] = params["opacities"] + 3.0
+    cams = cams[:3]
+    tr = SplatTrainer(params, dev, sh_degree=3)
+    batches = []
+    for c in cams:
+        o = inf.get_outputs_for_camera(tr, c)
+        batches.append({"image": o["rgb"].clone(), "sensor_depth": o["depth"].clone(), "normal": o["normal"].clone(),
+                        "mask": (o["accumulation"] > 0.5)})
+    m = inf.eval_loop(tr, cams, batches, get_std=True)
+    assert m["rgb_psnr"] == float("inf") and abs(m["rgb_ssim"] - 1.0) < 1e-5
+    assert m["depth_abs_rel"] == 0.0 and m["depth_a1"] == 1.0 and m["normal_mean_err"] == 0.0
+    assert m["num_rays_per_sec"] > 0 and abs(m["fps"] - m["num_rays_per_sec"] / (160 * 96)) < 1e-6 * m["fps"]
+    assert "rgb_psnr_std" in m
+    # a different scene scores worse
+    p2, _ = _small_fusionsense(dev, 160, 96, seed=4)
+    m2 = inf.eval_loop(SplatTrainer(p2, dev, sh_degree=3), cams, batches)
+    assert m2["rgb_psnr"] < 40 and m2["rgb_ssim"] < 0.99 and m2["depth_abs_rel"] > 0
+    # back-projection
+    g = torch.Generator().manual_seed(0)
+    pts, cols, nrm = inf.backproject_views(tr, cams, batches, total_points=3000, generator=g)
+    assert pts.shape == cols.shape == nrm.shape and pts.shape[0] > 2000
+    assert torch.allclose(nrm.norm(dim=-1), torch.ones_like(nrm[:, 0]), atol=1e-4)
+    cam = cams[0]
+    out = inf.get_outputs_for_camera(tr, cam)
+    c2w = torch.eye(4, device=dev)
+    c2w[:3, :4] = cam.c2w.to(dev)
+    c2w = (c2w @ torch.diag(torch.tensor([1.0, -1.0, -1.0, 1.0], device=dev)))[:3, :4]
+    P, _ = inf.get_means3d_backproj(out["depth"], cam.fx, cam.fy, cam.cx, cam.cy, (160, 96), c2w)
+    uvz = inf.project_pix(P, cam.fx, cam.fy, cam.cx, cam.cy, c2w, return_z_depths=True)
+    coords = inf.get_camera_coords((160, 96), device=dev)
+    assert torch.allclose(uvz[:, :2], coords, atol=2e-3) and torch.allclose(uvz[:, 2], out["depth"].reshape(-1), rtol=1e-5)
+    # world points of the object blob lie near the blob (radius 0.1 around the origin) where the blob is hit
+    near = out["depth"].reshape(-1) < 1.2
+    assert float(P[near].norm(dim=-1).median()) < 0.6
+    # obb crop: only the blob survives, the image changes
+    box = OrientedBox(torch.eye(3), torch.zeros(3), torch.full((3,), 0.25))
+    cropped = inf.get_outputs_for_camera(tr, cam, obb_box=box)
+    assert cropped["rgb"].shape == out["rgb"].shape and not torch.equal(cropped["rgb"], out["rgb"])

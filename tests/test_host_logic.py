@@ -1,5 +1,6 @@
 """CPU tests of the host side: C-ABI export table, loud failure without a GPU, gsplat shim,
 densify schedule/masks against the oracle, reference-helper goldens, data-parallel plumbing."""
+import math
 import os
 import re
 import subprocess
@@ -517,3 +518,143 @@ def test_unfused_train_step_flushes_deferred_features_before_clearing_the_slab(m
         assert torch.equal(a.params[k].data, b.params[k].data), k
     for k in PARAM_ORDER:  # the trainer owns a copy: the caller's tensors are untouched
         assert torch.equal(init[k], init0[k]) and not torch.equal(init[k], a.params[k].data), k
+
+
+def _write_scene_dir(root, rng):
+    """A miniature FusionSense scene directory: transforms.json (+ images, masks, 16-bit depth, mono normals), seed
+    and hull PLYs, gelsight_transform.json with two gel patches."""
+    import json
+    from PIL import Image
+    from fusionsense_amd import io as fio
+    H, W = 12, 16
+    (root / "images").mkdir(); (root / "masks").mkdir(); (root / "depth").mkdir()
+    (root / "normals_from_pretrain").mkdir(); (root / "tactile").mkdir()
+    names = ["frame_00002", "frame_00000", "frame_00001"]  # listed out of order on purpose
+    frames, c2ws = [], {}
+    for i, n in enumerate(names):
+        img = rng.integers(0, 256, size=(H, W, 3), dtype=np.uint8)
+        Image.fromarray(img).save(root / "images" / f"{n}.png")
+        Image.fromarray(((rng.random((H, W)) > 0.4) * 255).astype(np.uint8)).save(root / "masks" / f"{n}.png")
+        Image.fromarray(rng.integers(300, 2000, size=(H, W)).astype(np.uint16)).save(root / "depth" / f"{n}.png")
+        Image.fromarray(rng.integers(0, 256, size=(H, W, 3), dtype=np.uint8)).save(root / "normals_from_pretrain" / f"{n}.png")
+        q = rng.normal(size=(3, 3)); R, _ = np.linalg.qr(q)
+        if np.linalg.det(R) < 0:
+            R[:, 0] *= -1
+        T = np.eye(4); T[:3, :3] = R; T[:3, 3] = rng.normal(size=3) * (i + 1)
+        c2ws[n] = T
+        frames.append({"file_path": f"images/{n}.png", "mask_path": f"masks/{n}.png", "depth_file_path": f"depth/{n}.png",
+                       "transform_matrix": T.tolist()})
+    pts = rng.normal(size=(60, 3)).astype(np.float32) * 0.3
+    col = rng.integers(0, 256, size=(60, 3)).astype(np.uint8)
+    fio.write_ply(str(root / "merged_pcd.ply"), {"x": pts[:, 0], "y": pts[:, 1], "z": pts[:, 2], "red": col[:, 0],
+                                                  "green": col[:, 1], "blue": col[:, 2]})
+    hull = rng.normal(size=(25, 3)).astype(np.float32) * 0.1
+    fio.write_ply(str(root / "foreground_pcd.ply"), {"x": hull[:, 0], "y": hull[:, 1], "z": hull[:, 2]})
+    meta = {"fl_x": 20.0, "fl_y": 21.0, "cx": 8.0, "cy": 6.0, "w": W, "h": H, "frames": frames,
+            "ply_file_path": "merged_pcd.ply", "object_pc_path": "foreground_pcd.ply"}
+    (root / "transforms.json").write_text(json.dumps(meta))
+    tframes, raws = [], []
+    for k in range(2):
+        gx, gy = np.meshgrid(np.arange(20), np.arange(15), indexing="ij")
+        raw = np.stack([gx.ravel(), gy.ravel(), -rng.random(300) * 40], -1).astype(np.float32)
+        with open(root / "tactile" / f"patch_{k}.pcd", "w") as f:
+            f.write("# .PCD v0.7\nVERSION 0.7\nFIELDS x y z\nSIZE 4 4 4\nTYPE F F F\nCOUNT 1 1 1\n"
+                    f"WIDTH 300\nHEIGHT 1\nVIEWPOINT 0 0 0 1 0 0 0\nPOINTS 300\nDATA ascii\n")
+            for r in raw:
+                f.write(f"{r[0]:.6f} {r[1]:.6f} {r[2]:.6f}\n")
+        mask = rng.random(300) > 0.3
+        np.save(root / "tactile" / f"mask_{k}.npy", mask)
+        nrm = rng.normal(size=(300, 3)).astype(np.float32)
+        nrm /= np.linalg.norm(nrm, axis=-1, keepdims=True)
+        np.save(root / "tactile" / f"normal_{k}.npy", nrm)
+        q = rng.normal(size=(3, 3)); R, _ = np.linalg.qr(q)
+        T = np.eye(4); T[:3, :3] = R; T[:3, 3] = rng.normal(size=3) * 0.2
+        tframes.append({"patch_path": f"tactile/patch_{k}.pcd", "mask_path": f"tactile/mask_{k}.npy",
+                        "normal_path": f"tactile/normal_{k}.npy", "transform_matrix": T.tolist()})
+        raws.append((raw, mask, nrm, T))
+    (root / "gelsight_transform.json").write_text(json.dumps({"frames": tframes}))
+    return names, c2ws, pts, col, hull, raws
+
+
+def test_dataparser_scene_directory(tmp_path):
+    """transforms.json -> cameras (frames in file-name order, y/z axis flip, no re-orientation, max |t| scaled to 1),
+    seed + hull points and touch patches moved by the same transform and scale, per-view batches in the units
+    get_loss_dict expects (normal_nerfstudio.py:136-725, dn_dataset.py:110-243) — against an independent numpy
+    computation on a generated scene directory."""
+    from fusionsense_amd import dataparser as dp, touch
+    rng = np.random.default_rng(0)
+    names, c2ws, pts, col, hull, raws = _write_scene_dir(tmp_path, rng)
+    out = dp.parse_transforms(tmp_path, load_touches=True)
+    order = sorted(names)
+    assert [p.stem for p in out.image_filenames] == order and [p.stem for p in out.mask_filenames] == order
+    assert [Path_.stem for Path_ in out.metadata["normal_filenames"]] == order
+    tmax = max(np.abs(c2ws[n][:3, 3]).max() for n in names)
+    assert abs(out.dataparser_scale - 1.0 / tmax) < 1e-6
+    assert torch.equal(out.dataparser_transform, torch.eye(4)[:3])
+    for cam, n in zip(out.cameras, order):
+        T = c2ws[n].astype(np.float32)
+        exp = T[:3, :4].copy()
+        exp[:, 1:3] *= -1
+        exp[:, 3] *= out.dataparser_scale
+        assert np.allclose(cam.c2w.numpy(), exp, atol=1e-6)
+        assert (cam.fx, cam.fy, cam.cx, cam.cy, cam.width, cam.height) == (20.0, 21.0, 8.0, 6.0, 16, 12)
+    assert max(float(c.c2w[:, 3].abs().max()) for c in out.cameras) == pytest.approx(1.0, abs=1e-6)
+    md = out.metadata
+    assert np.allclose(md["points3D_xyz"].numpy(), pts * out.dataparser_scale, atol=1e-6)
+    assert np.array_equal(md["points3D_rgb"].numpy(), col)
+    assert np.allclose(md["visual_hull"].numpy(), hull * out.dataparser_scale, atol=1e-6)
+    n3 = md["points3D_normals"]
+    assert n3.shape == (60, 3) and torch.allclose(n3.norm(dim=-1), torch.ones(60), atol=1e-5)
+    # touch patches
+    assert len(md["touch_patches"]) == 2 and md["gel_scale_factor"] == 6.34e-5
+    for patch, (raw, mask, nrm, T) in zip(md["touch_patches"], raws):
+        r = raw[::5].astype(np.float64)
+        c = r.copy()
+        c[:, :2] -= r.mean(0)[:2]
+        c *= 6.34e-5
+        c = (c @ T[:3, :3].T + T[:3, 3]) * out.dataparser_scale
+        m = mask[::5]
+        assert np.allclose(patch["points_xyz"].numpy(), c[m], atol=1e-6)
+        assert np.allclose(patch["normals"].numpy(), nrm[::5][m] @ T[:3, :3].T + T[:3, 3], atol=1e-5)
+        assert patch["bbox"].shape == (8, 3) and patch["points_rgb"].abs().sum() == 0
+        inside = touch.points_in_non_aabb(patch["points_xyz"], patch["bbox"])
+        assert float(inside.float().mean()) > 0.9, "the oriented box is built around the patch"
+    # a plane of seed points: the PCA normal is the plane's normal (either sign)
+    g = torch.Generator().manual_seed(0)
+    plane = torch.cat([torch.rand(200, 2, generator=g) * 0.2, torch.zeros(200, 1)], -1)
+    assert bool((dp.estimate_normals(plane)[:, 2].abs() > 0.999).all())
+    # per-view batch
+    b = dp.load_batch(out, 1)
+    assert b["image"].shape == (12, 16, 3) and b["image"].dtype == torch.float32 and 0 <= float(b["image"].min()) <= float(b["image"].max()) <= 1
+    assert b["mask"].shape == (12, 16, 1) and b["mask"].dtype == torch.bool
+    from PIL import Image
+    raw_d = np.array(Image.open(tmp_path / "depth" / f"{order[1]}.png")).astype(np.float64)
+    assert torch.allclose(b["sensor_depth"][..., 0].double(), torch.from_numpy(raw_d * 1e-3 * out.dataparser_scale), atol=1e-6)
+    assert b["normal"].shape == (12, 16, 3) and 0 <= float(b["normal"].min()) and float(b["normal"].max()) <= 1
+    gp = dp.seed_gauss_params(out)
+    assert gp["means"].shape == (60, 3) and gp["features_rest"].shape == (60, 15, 3) and gp["quats"].shape == (60, 4)
+    assert torch.allclose(gp["scales"][:, 2], gp["scales"][:, 0] + math.log(0.1), atol=1e-5), "seed normals: 10x thinner z axis"
+
+
+def test_inference_helpers_match_reference_goldens():
+    """fusionsense_amd/inference.py against outputs of the reference's own dn_splatter/metrics.py,
+    utils/camera_utils.py and export_mesh.find_depth_edges (tests/golden/make_reference_inference_goldens.py)."""
+    from fusionsense_amd import inference as inf
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_inference.npz"))
+    t = lambda k: torch.from_numpy(d[k])  # noqa: E731
+    got = torch.stack(list(inf.depth_metrics(t("dm_pred"), t("dm_gt")))).double()
+    assert torch.allclose(got, t("dm_out"), rtol=1e-6, atol=1e-7)
+    got = torch.stack(list(inf.normal_metrics(t("nm_pred"), t("nm_gt")))).double()
+    assert torch.allclose(got, t("nm_out"), rtol=1e-6, atol=1e-7)
+    assert torch.allclose(inf.mean_angular_error(t("nm_pred"), t("nm_gt")), t("mae_map"), atol=1e-6)
+    fx, fy, cx, cy = [float(v) for v in d["bp_intr"]]
+    H, W = d["bp_depth"].shape[:2]
+    assert torch.equal(inf.get_camera_coords((W, H)), t("bp_coords"))
+    pts, _ = inf.get_means3d_backproj(t("bp_depth"), fx, fy, cx, cy, (W, H), t("bp_c2w"))
+    assert torch.allclose(pts, t("bp_points"), atol=1e-5)
+    p2, c2 = inf.get_colored_points_from_depth(t("bp_depth"), t("bp_rgb"), t("bp_c2w"), fx, fy, cx, cy, (W, H), t("bp_idx"))
+    assert torch.allclose(p2, t("bp_points_sel"), atol=1e-5) and torch.equal(c2, t("bp_colors_sel"))
+    assert torch.allclose(inf.project_pix(pts, fx, fy, cx, cy, t("bp_c2w"), return_z_depths=True), t("bp_uvz"), atol=1e-4)
+    assert torch.equal(inf.find_depth_edges(t("edge_depth"), 0.01, 3), t("edge_out"))
+    assert torch.equal(inf.find_depth_edges(t("edge_depth"), 0.05, 1), t("edge_out_1"))
+    assert float(t("edge_out").sum()) > 0 and float(t("edge_out_1").sum()) < float(t("edge_out").sum())
