@@ -86,6 +86,12 @@ SIGNATURES = {
     "fsgs_ssim_l1_bwd": (_i, [_i, _i, _p, _p, _p, _p, _p, _p, _f, _f, _p, _p]),
     "fsgs_ssim_l1_bwd_combine": (_i, [_i, _i, _p, _p, _p, _p, _p, _p, _f, _f, _p, _i, _p, _p, _p, _f, _p, _p]),
     "fsgs_loss_combine": (_i, [_i, _p, _p, _p, _f, _p, _p]),
+    "fsgs_project_bin_live_count_h16": (_i, [_i, _p, _p, _p, _p, _p, _i, _f, _p, _p, _i, _i, _f, _f, _f, _f, _p, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p, _sz, _p, _p]),
+    "fsgs_project_fwd_act_h16": (_i, [_i, _i, _p, _p, _p, _p, _p, _i, _f, _p, _p, _i, _i, _f, _f, _f, _f, _p, _p, _p, _p, _p, _p, _p]),
+    "fsgs_sh_fwd_pack_h16": (_i, [_i, _i, _i] + [_p] * 15 + [_i, _p]),
+    "fsgs_sh_bwd_split_h16": (_i, [_i, _i, _i, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _i, _p]),
+    "fsgs_gaussian_bwd_h16": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _f, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _f, _p, _p]),
+    "fsgs_adam_step_h16": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _i, C.c_double, C.c_double, _f, _p]),
     "fsgs_loss_combine_cols": (_i, [_i, _p, _p, _p, _p, _f, _p, _p]),
     "fsgs_ssim_l1_fwd_masked": (_i, [_i, _i, _p, _p, _p, _p, _p, _p, _p, _p]),
     "fsgs_ssim_l1_bwd_masked": (_i, [_i, _i, _p, _p, _p, _p, _p, _p, _p, _f, _f, _p, _i, _p, _p, _p, _p, _f, _p, _p]),

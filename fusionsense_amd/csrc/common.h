@@ -1,5 +1,6 @@
 // Shared helpers for the gfx950 kernels of libfsgs.so.  CDNA4 only: wave = 64 lanes.
 #pragma once
+#include <hip/hip_fp16.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -131,5 +132,28 @@ __device__ __forceinline__ void adam_one(float &p, float g, float &m, float &v, 
 }
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+// ---- attribute storage (BASELINE config #5) ---------------------------------------------------------------------
+// Per-Gaussian attributes other than the means (SH features, log-scales, quaternions, opacity logits) are read either
+// as fp32 or as IEEE half mirrors of the fp32 master parameters (`half` != 0, uniform per launch): all arithmetic
+// stays fp32, only the bytes per Gaussian on the render path shrink (236 -> 124).  Adam keeps the masters and
+// refreshes the mirrors in the same launch (glue.hip).
+__device__ __forceinline__ float ld_attr(const void *p, int64_t i, int half) {
+    return half ? __half2float(reinterpret_cast<const __half *>(p)[i]) : reinterpret_cast<const float *>(p)[i];
+}
+__device__ __forceinline__ float4 ld_attr4(const void *p, int64_t n, int half) {  // record n of four elements
+    if (half) {
+        const uint2 r = reinterpret_cast<const uint2 *>(p)[n];
+        const float2 a = __half22float2(*reinterpret_cast<const __half2 *>(&r.x));
+        const float2 b = __half22float2(*reinterpret_cast<const __half2 *>(&r.y));
+        return make_float4(a.x, a.y, b.x, b.y);
+    }
+    return reinterpret_cast<const float4 *>(p)[n];
+}
+__device__ __forceinline__ void ld_attr3(const void *p, int64_t n, int half, float (&o)[3]) {  // record n of three
+    o[0] = ld_attr(p, n * 3 + 0, half);
+    o[1] = ld_attr(p, n * 3 + 1, half);
+    o[2] = ld_attr(p, n * 3 + 2, half);
+}
 
 }  // namespace fsgs

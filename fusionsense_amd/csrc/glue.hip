@@ -255,6 +255,7 @@ struct AdamArgs {
     const float *g[kAdamMaxGroups];
     float *m[kAdamMaxGroups];
     float *v[kAdamMaxGroups];
+    __half *h[kAdamMaxGroups];      // nullable per group: IEEE-half mirror of the parameter, refreshed with the update
     long long n[kAdamMaxGroups];
     int block_end[kAdamMaxGroups];  // exclusive prefix ends of each group's workgroup range
     float step_size[kAdamMaxGroups];
@@ -274,8 +275,10 @@ __global__ void __launch_bounds__(256) adam_kernel(AdamArgs a) {
     if (j >= n) return;
     float *P = a.p[grp] + j, *M = a.m[grp] + j, *V = a.v[grp] + j;
     const float *G = a.g[grp] + j;
+    __half *Hm = a.h[grp] ? a.h[grp] + j : nullptr;
     const float ss = a.step_size[grp];
-    const bool vec = (j + 3 < n) && ((((uintptr_t)P | (uintptr_t)M | (uintptr_t)V | (uintptr_t)G) & 15) == 0);
+    const bool vec = (j + 3 < n) && ((((uintptr_t)P | (uintptr_t)M | (uintptr_t)V | (uintptr_t)G) & 15) == 0) &&
+                     (((uintptr_t)Hm & 7) == 0);
     if (vec) {
         float4 p = *reinterpret_cast<float4 *>(P), m = *reinterpret_cast<float4 *>(M), v = *reinterpret_cast<float4 *>(V);
         const float4 g = *reinterpret_cast<const float4 *>(G);
@@ -284,11 +287,19 @@ __global__ void __launch_bounds__(256) adam_kernel(AdamArgs a) {
         adam_one(p.z, g.z, m.z, v.z, a.b1, a.b2, a.omb1, a.omb2, ss, a.inv_sqrt_bc2, a.eps);
         adam_one(p.w, g.w, m.w, v.w, a.b1, a.b2, a.omb1, a.omb2, ss, a.inv_sqrt_bc2, a.eps);
         *reinterpret_cast<float4 *>(P) = p; *reinterpret_cast<float4 *>(M) = m; *reinterpret_cast<float4 *>(V) = v;
+        if (Hm) {  // the render path's half mirror of this parameter (BASELINE config #5): 2 more bytes per float
+            const __half2 lo = __floats2half2_rn(p.x, p.y), hi = __floats2half2_rn(p.z, p.w);
+            uint2 o;
+            o.x = *reinterpret_cast<const unsigned *>(&lo);
+            o.y = *reinterpret_cast<const unsigned *>(&hi);
+            *reinterpret_cast<uint2 *>(Hm) = o;
+        }
     } else {
         for (int k = 0; k < 4 && j + k < n; ++k) {
             float p = P[k], m = M[k], v = V[k];
             adam_one(p, G[k], m, v, a.b1, a.b2, a.omb1, a.omb2, ss, a.inv_sqrt_bc2, a.eps);
             P[k] = p; M[k] = m; V[k] = v;
+            if (Hm) Hm[k] = __float2half(p);
         }
     }
 }
@@ -297,6 +308,16 @@ __global__ void __launch_bounds__(256) adam_kernel(AdamArgs a) {
 extern "C" int fsgs_adam_step(int n_groups, float *const *params, const float *const *grads, float *const *exp_avg,
                               float *const *exp_avg_sq, const int64_t *numel, const float *lr, int step, double beta1_d,
                               double beta2_d, float eps, fsgs_stream_t stream) {
+    return fsgs_adam_step_h16(n_groups, params, grads, exp_avg, exp_avg_sq, nullptr, numel, lr, step, beta1_d, beta2_d,
+                              eps, stream);
+}
+
+// The same update; half_mirrors (nullable array, nullable entries): an IEEE-half copy of the group's parameters that
+// is rewritten together with the fp32 master (round to nearest even) — what the render kernels read in config #5.
+extern "C" int fsgs_adam_step_h16(int n_groups, float *const *params, const float *const *grads, float *const *exp_avg,
+                                  float *const *exp_avg_sq, void *const *half_mirrors, const int64_t *numel,
+                                  const float *lr, int step, double beta1_d, double beta2_d, float eps,
+                                  fsgs_stream_t stream) {
     const float beta1 = (float)beta1_d, beta2 = (float)beta2_d;
     if (n_groups < 1 || n_groups > fsgs::kAdamMaxGroups || step < 1) return FSGS_EINVAL;
     if (!params || !grads || !exp_avg || !exp_avg_sq || !numel || !lr) return FSGS_EINVAL;
@@ -307,11 +328,13 @@ extern "C" int fsgs_adam_step(int n_groups, float *const *params, const float *c
         if (k < n_groups) {
             if (!params[k] || !grads[k] || !exp_avg[k] || !exp_avg_sq[k] || numel[k] < 0) return FSGS_EINVAL;
             a.p[k] = params[k]; a.g[k] = grads[k]; a.m[k] = exp_avg[k]; a.v[k] = exp_avg_sq[k];
+            a.h[k] = half_mirrors ? reinterpret_cast<__half *>(half_mirrors[k]) : nullptr;
             a.n[k] = numel[k];
             blocks += (int)((numel[k] + fsgs::kAdamChunk - 1) / fsgs::kAdamChunk);
             a.step_size[k] = (float)((double)lr[k] / bc1);
         } else {
-            a.p[k] = nullptr; a.g[k] = nullptr; a.m[k] = nullptr; a.v[k] = nullptr; a.n[k] = 0; a.step_size[k] = 0.f;
+            a.p[k] = nullptr; a.g[k] = nullptr; a.m[k] = nullptr; a.v[k] = nullptr; a.h[k] = nullptr; a.n[k] = 0;
+            a.step_size[k] = 0.f;
         }
         a.block_end[k] = blocks;
     }

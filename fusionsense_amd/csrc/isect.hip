@@ -351,11 +351,16 @@ struct BinLds {
 // and the binary-opacity write of fsgs_project_fwd_act) and writes the projection's outputs for the later passes:
 // no projection launch, and the count pass reads 48 B of parameters instead of 28 B of projected attributes.
 struct BinProjArgs {
-    const float *means, *quats, *log_scales, *viewmat, *K;
-    float *opac_logit, *scales_out, *opac_out, *means2d, *depths, *conics;
+    const float *means;
+    const void *quats, *log_scales;  // fp32, or half mirrors when attr_half (common.h)
+    const float *viewmat, *K;
+    float *opac_logit;               // fp32 master (rewritten by the binary-opacity write)
+    float *scales_out, *opac_out, *means2d, *depths, *conics;
     int32_t *radii;
     int width, height, binarise;
     float eps2d, near_plane, far_plane, radius_clip, binary_threshold;
+    __half *opac_logit_h;            // attr_half: the mirror the opacity is READ from (and rewritten together with the master)
+    int attr_half;
 };
 
 template <bool SCATTER, bool MULTI, bool PROJ>
@@ -386,18 +391,20 @@ isect_live_bin_kernel(int C, int N, const float *__restrict__ means2d, const int
         uint32_t db = 0u;
         if (PROJ && idx < total) {
             const int64_t n = idx;  // (one camera)
-            const float s_act[3] = {expf(pj.log_scales[n * 3 + 0]), expf(pj.log_scales[n * 3 + 1]),
-                                    expf(pj.log_scales[n * 3 + 2])};
+            float ls_in[3];
+            ld_attr3(pj.log_scales, n, pj.attr_half, ls_in);
+            const float s_act[3] = {expf(ls_in[0]), expf(ls_in[1]), expf(ls_in[2])};
             pj.scales_out[n * 3 + 0] = s_act[0]; pj.scales_out[n * 3 + 1] = s_act[1]; pj.scales_out[n * 3 + 2] = s_act[2];
-            float ol = pj.opac_logit[n];
+            float ol = pj.attr_half ? __half2float(pj.opac_logit_h[n]) : pj.opac_logit[n];
             if (pj.binarise) {  // the binary-opacity write of get_outputs (dn_model.py:492-503), on the parameter itself
                 ol = (ol >= pj.binary_threshold) ? 1.f : 0.f;
-                pj.opac_logit[n] = ol;
+                if (pj.opac_logit) pj.opac_logit[n] = ol;
+                if (pj.attr_half) pj.opac_logit_h[n] = __float2half(ol);
             }
             const float o_act = 1.f / (1.f + expf(-ol));
             pj.opac_out[n] = o_act;
             const ProjOut po = project_one(pj.means[n * 3 + 0], pj.means[n * 3 + 1], pj.means[n * 3 + 2],
-                                           reinterpret_cast<const float4 *>(pj.quats)[n], s_act, pj.viewmat, pj.K,
+                                           ld_attr4(pj.quats, n, pj.attr_half), s_act, pj.viewmat, pj.K,
                                            pj.width, pj.height, pj.eps2d, pj.near_plane, pj.far_plane, pj.radius_clip);
             pj.radii[n] = po.radius;
             reinterpret_cast<float2 *>(pj.means2d)[n] = make_float2(po.u, po.v);
@@ -735,8 +742,9 @@ extern "C" int fsgs_bin_live_count(int C, int N, const float *means2d, const int
 // fsgs_project_fwd_act (one camera) + fsgs_bin_live_count in one launch chain: the count pass projects the
 // Gaussians itself.  Outputs of both: scales_out, opac_out, radii, means2d, depths, conics [N..], tiles_per_gauss,
 // isect_offsets[T + 1]; opac_logit is rewritten when binarise != 0.
-extern "C" int fsgs_project_bin_live_count(int N, const float *means, const float *quats, const float *log_scales,
-                                           float *opac_logit, int binarise, float binary_threshold,
+static int project_bin_live_count_impl(int N, const float *means, const void *quats, const void *log_scales,
+                                       float *opac_logit, void *opac_logit_h, int attr_half, int binarise,
+                                       float binary_threshold,
                                            const float *viewmat, const float *K, int width, int height, float eps2d,
                                            float near_plane, float far_plane, float radius_clip, float *scales_out,
                                            float *opac_out, int32_t *radii, float *means2d, float *depths,
@@ -757,9 +765,10 @@ extern "C" int fsgs_project_bin_live_count(int N, const float *means, const floa
         if (e != hipSuccess) { g_last_hip_error = (int)e; return FSGS_ELAUNCH; }
         return FSGS_OK;
     }
-    if (!means || !quats || !log_scales || !opac_logit || !viewmat || !K || !scales_out || !opac_out || !radii ||
+    if (!means || !quats || !log_scales || !viewmat || !K || !scales_out || !opac_out || !radii ||
         !means2d || !depths || !conics || !table_scratch)
         return FSGS_EINVAL;
+    if (attr_half ? !opac_logit_h : !opac_logit) return FSGS_EINVAL;
     if (table_bytes < fsgs_bin_live_table_bytes(1, N, tile_width, tile_height)) return FSGS_ESCRATCH;
     const int64_t total = N;
     const int nb = (int)bin_blocks(total);
@@ -769,7 +778,7 @@ extern "C" int fsgs_project_bin_live_count(int N, const float *means, const floa
     if (rc != FSGS_OK) return rc;
     const BinProjArgs pj = {means, quats, log_scales, viewmat, K, opac_logit, scales_out, opac_out, means2d, depths,
                             conics, radii, width, height, binarise, eps2d, near_plane, far_plane, radius_clip,
-                            binary_threshold};
+                            binary_threshold, reinterpret_cast<__half *>(opac_logit_h), attr_half};
 #define FSGS_BIN_PCOUNT(MU)                                                                                         \
     hipLaunchKernelGGL((isect_live_bin_kernel<false, MU, true>), dim3(nb), dim3(kBinThreads), bin_lds_bytes(T), s, 1, \
                        N, nullptr, nullptr, nullptr, nullptr, nullptr, tile_width, tile_height, T, nb,                 \
@@ -779,6 +788,38 @@ extern "C" int fsgs_project_bin_live_count(int N, const float *means, const floa
     rc = check_launch();
     if (rc != FSGS_OK) return rc;
     return launch_tile_scan_rows_offsets(T, nb, table, totals, isect_offsets, n_live_mapped, s);
+}
+
+extern "C" int fsgs_project_bin_live_count(int N, const float *means, const float *quats, const float *log_scales,
+                                           float *opac_logit, int binarise, float binary_threshold,
+                                           const float *viewmat, const float *K, int width, int height, float eps2d,
+                                           float near_plane, float far_plane, float radius_clip, float *scales_out,
+                                           float *opac_out, int32_t *radii, float *means2d, float *depths,
+                                           float *conics, int tile_width, int tile_height, int32_t *tiles_per_gauss,
+                                           int32_t *isect_offsets, void *table_scratch, size_t table_bytes,
+                                           int32_t *n_live_mapped, fsgs_stream_t stream) {
+    return project_bin_live_count_impl(N, means, quats, log_scales, opac_logit, nullptr, 0, binarise, binary_threshold,
+                                       viewmat, K, width, height, eps2d, near_plane, far_plane, radius_clip, scales_out,
+                                       opac_out, radii, means2d, depths, conics, tile_width, tile_height, tiles_per_gauss,
+                                       isect_offsets, table_scratch, table_bytes, n_live_mapped, stream);
+}
+
+// Half attribute storage (BASELINE config #5): quats / log_scales / opac_logit_h are IEEE-half mirrors of the fp32
+// masters; the binary-opacity write goes to the mirror AND to the master (opac_logit_master, nullable).
+extern "C" int fsgs_project_bin_live_count_h16(int N, const float *means, const void *quats_h, const void *log_scales_h,
+                                               void *opac_logit_h, float *opac_logit_master, int binarise,
+                                               float binary_threshold, const float *viewmat, const float *K, int width,
+                                               int height, float eps2d, float near_plane, float far_plane,
+                                               float radius_clip, float *scales_out, float *opac_out, int32_t *radii,
+                                               float *means2d, float *depths, float *conics, int tile_width,
+                                               int tile_height, int32_t *tiles_per_gauss, int32_t *isect_offsets,
+                                               void *table_scratch, size_t table_bytes, int32_t *n_live_mapped,
+                                               fsgs_stream_t stream) {
+    return project_bin_live_count_impl(N, means, quats_h, log_scales_h, opac_logit_master, opac_logit_h, 1, binarise,
+                                       binary_threshold, viewmat, K, width, height, eps2d, near_plane, far_plane,
+                                       radius_clip, scales_out, opac_out, radii, means2d, depths, conics, tile_width,
+                                       tile_height, tiles_per_gauss, isect_offsets, table_scratch, table_bytes,
+                                       n_live_mapped, stream);
 }
 
 // Pass 2 + the in-tile sorts: payload_sorted[n_live] = quadrant mask << 28 | flatten id in (tile, depth, id)

@@ -16,36 +16,39 @@ namespace fsgs {
 // never re-reads the activated scales from memory.
 template <bool ACT>
 __global__ void __launch_bounds__(256)
-project_fwd_kernel(int C, int N, const float *__restrict__ means, const float *__restrict__ quats,
-                   const float *__restrict__ scales, const float *__restrict__ viewmats,
+project_fwd_kernel(int C, int N, const float *__restrict__ means, const void *__restrict__ quats,
+                   const void *__restrict__ scales, const float *__restrict__ viewmats,
                    const float *__restrict__ Ks, int width, int height, float eps2d, float near_plane,
                    float far_plane, float radius_clip, int32_t *__restrict__ radii,
                    float *__restrict__ means2d, float *__restrict__ depths,
                    float *__restrict__ conics, float *__restrict__ compensations,
                    float *__restrict__ opac_logit, float *__restrict__ scales_out,
-                   float *__restrict__ opac_out, int binarise, float binary_threshold) {
+                   float *__restrict__ opac_out, int binarise, float binary_threshold,
+                   __half *__restrict__ opac_logit_h, int attr_half) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (int64_t)C * N) return;
     const int c = (int)(idx / N);
     const int n = (int)(idx - (int64_t)c * N);
     float s_act[3] = {0.f, 0.f, 0.f};
+    float s_in[3];
+    ld_attr3(scales, n, attr_half, s_in);
     if (ACT) {
-        s_act[0] = expf(scales[n * 3 + 0]); s_act[1] = expf(scales[n * 3 + 1]); s_act[2] = expf(scales[n * 3 + 2]);
+        s_act[0] = expf(s_in[0]); s_act[1] = expf(s_in[1]); s_act[2] = expf(s_in[2]);
         if (c == 0) {
             scales_out[n * 3 + 0] = s_act[0]; scales_out[n * 3 + 1] = s_act[1]; scales_out[n * 3 + 2] = s_act[2];
-            float ol = opac_logit[n];
+            float ol = attr_half ? __half2float(opac_logit_h[n]) : opac_logit[n];
             if (binarise) {  // the binary-opacity write of get_outputs (dn_model.py:492-503), on the parameter itself
                 ol = (ol >= binary_threshold) ? 1.f : 0.f;
-                opac_logit[n] = ol;
+                if (opac_logit) opac_logit[n] = ol;
+                if (attr_half) opac_logit_h[n] = __float2half(ol);
             }
             opac_out[n] = 1.f / (1.f + expf(-ol));
         }
     }
 
     const float mx = means[n * 3 + 0], my = means[n * 3 + 1], mz = means[n * 3 + 2];
-    const float4 q = reinterpret_cast<const float4 *>(quats)[n];
-    const float s[3] = {ACT ? s_act[0] : scales[n * 3 + 0], ACT ? s_act[1] : scales[n * 3 + 1],
-                        ACT ? s_act[2] : scales[n * 3 + 2]};
+    const float4 q = ld_attr4(quats, n, attr_half);
+    const float s[3] = {ACT ? s_act[0] : s_in[0], ACT ? s_act[1] : s_in[1], ACT ? s_act[2] : s_in[2]};
     const ProjOut po = project_one(mx, my, mz, q, s, viewmats + c * 16, Ks + c * 9, width, height, eps2d, near_plane,
                                    far_plane, radius_clip);
     const int32_t radius_out = po.radius;
@@ -69,20 +72,21 @@ project_fwd_kernel(int C, int N, const float *__restrict__ means, const float *_
 // densify_stats) that each moved the same 300 k records.
 struct GaussBwdFused {
     float4 *v_packed;            // [N,4] float4: [0..3] v_colors [4..6] v_conics [7..8] v_means2d [9..10] abs [11] v_opac [12..14] v_ncam
-    const float *log_scales;     // raw scales (argmin axis of the normal)
+    const void *log_scales;      // raw scales (argmin axis of the normal)
     const float *opac;           // sigmoid(opacities)
     const float *c2w;            // [3,4] camera-to-world of the normal pass
     float *absgrad;              // [N,2] out
     float *v_opac_logit;         // [N] out
     int accumulate_means;        // v_means += (the SH backward wrote its share first) instead of =
     const uint8_t *frozen;       // nullable [N]: touch anchors — no gradient for means / scales / opacity (dn_model.py:535-541)
+    int attr_half;               // quats / log_scales are IEEE-half mirrors (BASELINE config #5)
     float *xys_grad_norm, *vis_counts, *max_2Dsize;  // after_train statistics (nullable together)
     float inv_max_hw;
 };
 
 template <bool FUSED>
 __global__ void __launch_bounds__(256)
-project_bwd_kernel(int C, int N, const float *__restrict__ means, const float *__restrict__ quats,
+project_bwd_kernel(int C, int N, const float *__restrict__ means, const void *__restrict__ quats,
                    const float *__restrict__ scales, const float *__restrict__ viewmats,
                    const float *__restrict__ Ks, int width, int height, float eps2d,
                    const int32_t *__restrict__ radii, const float *__restrict__ conics,
@@ -101,7 +105,7 @@ project_bwd_kernel(int C, int N, const float *__restrict__ means, const float *_
         reinterpret_cast<float2 *>(fz.absgrad)[n] = make_float2(pc.y, pc.z);
     }
     const float mean[3] = {means[n * 3 + 0], means[n * 3 + 1], means[n * 3 + 2]};
-    const float4 q = reinterpret_cast<const float4 *>(quats)[n];
+    const float4 q = ld_attr4(quats, n, FUSED ? fz.attr_half : 0);
     const float qn = fmaxf(sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w), 1e-12f);
     const float inv = 1.f / qn;
     const float qw = q.x * inv, qx = q.y * inv, qy = q.z * inv, qz = q.w * inv;
@@ -294,7 +298,8 @@ project_bwd_kernel(int C, int N, const float *__restrict__ means, const float *_
     const float o = fz.opac[n];
     fz.v_opac_logit[n] = frozen ? 0.f : pc.w * o * (1.f - o);
     {   // the normal pass reaches the quaternions only (dn_model.py:618-656)
-        const float ls[3] = {fz.log_scales[n * 3 + 0], fz.log_scales[n * 3 + 1], fz.log_scales[n * 3 + 2]};
+        float ls[3];
+        ld_attr3(fz.log_scales, n, fz.attr_half, ls);
         const float vn[3] = {pd.x, pd.y, pd.z};
         const float4 vqb = normal_backward(q, ls, mean, fz.c2w, vn);
         vq.x += vqb.x; vq.y += vqb.y; vq.z += vqb.z; vq.w += vqb.w;
@@ -328,7 +333,7 @@ extern "C" int fsgs_project_fwd(int C, int N, const float *means, const float *q
     hipLaunchKernelGGL((project_fwd_kernel<false>), dim3(ceil_div(total, 256)), dim3(256), 0, as_stream(stream),
                        C, N, means, quats, scales, viewmats, Ks, width, height, eps2d, near_plane,
                        far_plane, radius_clip, radii, means2d, depths, conics, compensations, nullptr, nullptr,
-                       nullptr, 0, 0.f);
+                       nullptr, 0, 0.f, nullptr, 0);
     return check_launch();
 }
 
@@ -348,7 +353,28 @@ extern "C" int fsgs_project_fwd_act(int C, int N, const float *means, const floa
     hipLaunchKernelGGL((project_fwd_kernel<true>), dim3(ceil_div(total, 256)), dim3(256), 0, as_stream(stream),
                        C, N, means, quats, log_scales, viewmats, Ks, width, height, eps2d, near_plane, far_plane,
                        radius_clip, radii, means2d, depths, conics, nullptr, opac_logit, scales_out, opac_out,
-                       binarise, binary_threshold);
+                       binarise, binary_threshold, nullptr, 0);
+    return check_launch();
+}
+
+// Half attribute storage (BASELINE config #5): quats / log_scales / opac_logit_h are IEEE-half mirrors of the fp32
+// masters; a binary-opacity write goes to the mirror and to the master (nullable).
+extern "C" int fsgs_project_fwd_act_h16(int C, int N, const float *means, const void *quats_h,
+                                        const void *log_scales_h, void *opac_logit_h, float *opac_logit_master,
+                                        int binarise, float binary_threshold, const float *viewmats, const float *Ks,
+                                        int width, int height, float eps2d, float near_plane, float far_plane,
+                                        float radius_clip, float *scales_out, float *opac_out, int32_t *radii,
+                                        float *means2d, float *depths, float *conics, fsgs_stream_t stream) {
+    if (C < 0 || N < 0) return FSGS_EINVAL;
+    if ((int64_t)C * N == 0) return FSGS_OK;
+    if (!means || !quats_h || !log_scales_h || !opac_logit_h || !viewmats || !Ks || !scales_out || !opac_out || !radii ||
+        !means2d || !depths || !conics)
+        return FSGS_EINVAL;
+    const int64_t total = (int64_t)C * N;
+    hipLaunchKernelGGL((project_fwd_kernel<true>), dim3(ceil_div(total, 256)), dim3(256), 0, as_stream(stream),
+                       C, N, means, quats_h, log_scales_h, viewmats, Ks, width, height, eps2d, near_plane, far_plane,
+                       radius_clip, radii, means2d, depths, conics, nullptr, opac_logit_master, scales_out, opac_out,
+                       binarise, binary_threshold, reinterpret_cast<__half *>(opac_logit_h), 1);
     return check_launch();
 }
 
@@ -371,7 +397,7 @@ extern "C" int fsgs_project_bwd(int C, int N, const float *means, const float *q
     return check_launch();
 }
 
-extern "C" int fsgs_gaussian_bwd(int N, const float *means, const float *quats, const float *log_scales,
+static int gaussian_bwd_impl(int N, const float *means, const void *quats, const void *log_scales, int attr_half,
                                  const float *scales, const float *opac, const float *viewmat, const float *K,
                                  const float *c2w, int width, int height, float eps2d, const int32_t *radii,
                                  const float *conics, float *v_packed, int accumulate_means, float *v_means,
@@ -390,9 +416,35 @@ extern "C" int fsgs_gaussian_bwd(int N, const float *means, const float *quats, 
     fz.log_scales = log_scales; fz.opac = opac; fz.c2w = c2w; fz.absgrad = absgrad; fz.v_opac_logit = v_opac_logit;
     fz.accumulate_means = accumulate_means;
     fz.frozen = frozen;
+    fz.attr_half = attr_half;
     fz.xys_grad_norm = xys_grad_norm; fz.vis_counts = vis_counts; fz.max_2Dsize = max_2Dsize; fz.inv_max_hw = inv_max_hw;
     hipLaunchKernelGGL((project_bwd_kernel<true>), dim3(ceil_div(N, 256)), dim3(256), 0, as_stream(stream), 1, N,
                        means, quats, scales, viewmat, K, width, height, eps2d, radii, conics, nullptr, nullptr,
                        nullptr, nullptr, nullptr, v_means, v_quats, v_log_scales, nullptr, fz);
     return check_launch();
+}
+
+extern "C" int fsgs_gaussian_bwd(int N, const float *means, const float *quats, const float *log_scales,
+                                 const float *scales, const float *opac, const float *viewmat, const float *K,
+                                 const float *c2w, int width, int height, float eps2d, const int32_t *radii,
+                                 const float *conics, float *v_packed, int accumulate_means, float *v_means,
+                                 float *v_quats, float *v_log_scales, float *v_opac_logit, float *absgrad,
+                                 float *xys_grad_norm, float *vis_counts, float *max_2Dsize, float inv_max_hw,
+                                 const uint8_t *frozen, fsgs_stream_t stream) {
+    return gaussian_bwd_impl(N, means, quats, log_scales, 0, scales, opac, viewmat, K, c2w, width, height, eps2d, radii,
+                             conics, v_packed, accumulate_means, v_means, v_quats, v_log_scales, v_opac_logit, absgrad,
+                             xys_grad_norm, vis_counts, max_2Dsize, inv_max_hw, frozen, stream);
+}
+
+// quats_h / log_scales_h: IEEE-half mirrors (BASELINE config #5); gradients are fp32 as ever
+extern "C" int fsgs_gaussian_bwd_h16(int N, const float *means, const void *quats_h, const void *log_scales_h,
+                                     const float *scales, const float *opac, const float *viewmat, const float *K,
+                                     const float *c2w, int width, int height, float eps2d, const int32_t *radii,
+                                     const float *conics, float *v_packed, int accumulate_means, float *v_means,
+                                     float *v_quats, float *v_log_scales, float *v_opac_logit, float *absgrad,
+                                     float *xys_grad_norm, float *vis_counts, float *max_2Dsize, float inv_max_hw,
+                                     const uint8_t *frozen, fsgs_stream_t stream) {
+    return gaussian_bwd_impl(N, means, quats_h, log_scales_h, 1, scales, opac, viewmat, K, c2w, width, height, eps2d,
+                             radii, conics, v_packed, accumulate_means, v_means, v_quats, v_log_scales, v_opac_logit,
+                             absgrad, xys_grad_norm, vis_counts, max_2Dsize, inv_max_hw, frozen, stream);
 }

@@ -109,9 +109,25 @@ struct Staged {
     float4 v[RF ? (RF + 3) / 4 : 1];
 };
 
-template <int RF>
-__device__ __forceinline__ void stage_load(Staged<RF> &st, const float *__restrict__ src, int rows) {
+template <int RF, bool HALF = false>
+__device__ __forceinline__ void stage_load(Staged<RF> &st, const void *__restrict__ src_v, int rows) {
     if (!RF) return;
+    if (HALF) {
+        // IEEE-half storage (BASELINE config #5): 8 elements per 16-byte load; a block's span starts at
+        // n0 * RF halves, n0 a multiple of 256: 16-byte aligned whenever the tensor base is
+        const uint4 *src8 = reinterpret_cast<const uint4 *>(src_v);
+        const int total8 = (rows * RF) >> 3;
+#pragma unroll
+        for (int it = 0; it < (RF + 7) / 8; ++it) {
+            const int i = threadIdx.x + it * kShBlock;
+            if (i < total8) {
+                const uint4 r = src8[i];
+                st.v[it] = make_float4(__uint_as_float(r.x), __uint_as_float(r.y), __uint_as_float(r.z), __uint_as_float(r.w));
+            }
+        }
+        return;
+    }
+    const float *src = reinterpret_cast<const float *>(src_v);
     // src is 4-byte aligned only in general (row start = n0*K*3 floats); n0 is a multiple of 256
     // so the span start is 16-byte aligned whenever the tensor base is.
     const float4 *src4 = reinterpret_cast<const float4 *>(src);
@@ -120,6 +136,62 @@ __device__ __forceinline__ void stage_load(Staged<RF> &st, const float *__restri
     for (int it = 0; it < (RF + 3) / 4; ++it) {
         const int i = threadIdx.x + it * kShBlock;
         if (i < total4) st.v[it] = src4[i];  // (a select between float4s would go through scratch memory)
+    }
+}
+
+__device__ __forceinline__ void unpack_half8(const float4 &v, float (&o)[8]) {
+    const unsigned w[4] = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float2 f = __half22float2(*reinterpret_cast<const __half2 *>(&w[k]));
+        o[2 * k] = f.x;
+        o[2 * k + 1] = f.y;
+    }
+}
+
+// the half-storage counterpart of stage_store (rows parked in LDS as fp32)
+template <int RF>
+__device__ __forceinline__ void stage_store_half(const Staged<RF> &st, const void *__restrict__ src_v, int rows,
+                                                 int row_floats_rt, float *lds, int pitch, int col_off) {
+    const int row_floats = RF ? RF : row_floats_rt;
+    const int total = rows * row_floats;
+    lds += col_off;
+    const int total8 = total >> 3;
+    if (RF) {
+#pragma unroll
+        for (int it = 0; it < (RF + 7) / 8; ++it) {
+            const int i = threadIdx.x + it * kShBlock;
+            if (i < total8) {
+                float vv[8];
+                unpack_half8(st.v[it], vv);
+                const int e = i << 3;
+                int r = e / row_floats, col = e - r * row_floats;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    lds[r * pitch + col] = vv[k];
+                    if (++col == row_floats) { col = 0; ++r; }
+                }
+            }
+        }
+    } else {
+        const uint4 *src8 = reinterpret_cast<const uint4 *>(src_v);
+        for (int i = threadIdx.x; i < total8; i += kShBlock) {
+            const uint4 rr = src8[i];
+            float vv[8];
+            unpack_half8(make_float4(__uint_as_float(rr.x), __uint_as_float(rr.y), __uint_as_float(rr.z), __uint_as_float(rr.w)), vv);
+            const int e = i << 3;
+            int r = e / row_floats, col = e - r * row_floats;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                lds[r * pitch + col] = vv[k];
+                if (++col == row_floats) { col = 0; ++r; }
+            }
+        }
+    }
+    const __half *srch = reinterpret_cast<const __half *>(src_v);
+    for (int i = (total8 << 3) + threadIdx.x; i < total; i += kShBlock) {
+        const int r = i / row_floats, col = i - r * row_floats;
+        lds[r * pitch + col] = __half2float(srch[i]);
     }
 }
 
@@ -174,23 +246,44 @@ struct StagedCoeffs {
     Staged<(SPLIT && KT) ? KT * 3 - 3 : 0> b;  // features_rest
 };
 
-template <int KT, bool SPLIT>
-__device__ __forceinline__ void coeffs_load(StagedCoeffs<KT, SPLIT> &st, const float *__restrict__ coeffs,
-                                            const float *__restrict__ coeffs_rest, int n0, int rows, int K) {
+// element offset into a coefficient array stored as fp32 or (HALF) as IEEE half
+template <bool HALF>
+__device__ __forceinline__ const void *coeff_at(const void *base, int64_t elems) {
+    return HALF ? static_cast<const void *>(reinterpret_cast<const __half *>(base) + elems)
+                : static_cast<const void *>(reinterpret_cast<const float *>(base) + elems);
+}
+
+template <int KT, bool SPLIT, bool HALF = false>
+__device__ __forceinline__ void coeffs_load(StagedCoeffs<KT, SPLIT> &st, const void *__restrict__ coeffs,
+                                            const void *__restrict__ coeffs_rest, int n0, int rows, int K) {
     const int row_floats = K * 3;
     if (SPLIT) {
-        stage_load(st.a, coeffs + (int64_t)n0 * 3, rows);
-        if (K > 1) stage_load(st.b, coeffs_rest + (int64_t)n0 * (row_floats - 3), rows);
+        stage_load<SPLIT ? 3 : KT * 3, HALF>(st.a, coeff_at<HALF>(coeffs, (int64_t)n0 * 3), rows);
+        if (K > 1)
+            stage_load<(SPLIT && KT) ? KT * 3 - 3 : 0, HALF>(st.b, coeff_at<HALF>(coeffs_rest, (int64_t)n0 * (row_floats - 3)), rows);
     } else {
-        stage_load(st.a, coeffs + (int64_t)n0 * row_floats, rows);
+        stage_load<SPLIT ? 3 : KT * 3, HALF>(st.a, coeff_at<HALF>(coeffs, (int64_t)n0 * row_floats), rows);
     }
 }
 
-template <int KT, bool SPLIT>
-__device__ __forceinline__ void coeffs_park(const StagedCoeffs<KT, SPLIT> &st, const float *__restrict__ coeffs,
-                                            const float *__restrict__ coeffs_rest, int n0, int rows, int K,
+template <int KT, bool SPLIT, bool HALF = false>
+__device__ __forceinline__ void coeffs_park(const StagedCoeffs<KT, SPLIT> &st, const void *__restrict__ coeffs_v,
+                                            const void *__restrict__ coeffs_rest_v, int n0, int rows, int K,
                                             float *lds) {
     const int row_floats = K * 3, pitch = row_floats + 1;
+    if (HALF) {
+        if (SPLIT) {
+            stage_store_half(st.a, coeff_at<true>(coeffs_v, (int64_t)n0 * 3), rows, 3, lds, pitch, 0);
+            if (K > 1)
+                stage_store_half(st.b, coeff_at<true>(coeffs_rest_v, (int64_t)n0 * (row_floats - 3)), rows,
+                                 row_floats - 3, lds, pitch, 3);
+        } else {
+            stage_store_half(st.a, coeff_at<true>(coeffs_v, (int64_t)n0 * row_floats), rows, row_floats, lds, pitch, 0);
+        }
+        return;
+    }
+    const float *coeffs = reinterpret_cast<const float *>(coeffs_v);
+    const float *coeffs_rest = reinterpret_cast<const float *>(coeffs_rest_v);
     if (SPLIT) {
         stage_store(st.a, coeffs + (int64_t)n0 * 3, rows, 3, lds, pitch, 0);
         if (K > 1)
@@ -232,17 +325,19 @@ __device__ __forceinline__ void unstage_rows(float *__restrict__ dst, int rows, 
 // record per Gaussian the compositing kernels gather (centre, opacity, conic, colour + depth, camera-space normal)
 // and normals_world — instead of the colour array: one launch and a round trip of the colours less.
 struct ShPackArgs {
-    const float *means2d, *conics, *opacities, *quats, *log_scales, *c2w;
+    const float *means2d, *conics, *opacities;
+    const void *quats, *log_scales;  // fp32, or IEEE-half mirrors in the HALF instantiation
+    const float *c2w;
     float4 *packed;
     float *normals_world, *zero_cells;
     int n_zero;
 };
 
-template <int KT, bool SPLIT, bool PACK>
+template <int KT, bool SPLIT, bool PACK, bool HALF = false>
 __global__ void __launch_bounds__(kShBlock)
 sh_fwd_kernel(int C, int N, int K, int degree, const float *__restrict__ means,
-              const float *__restrict__ campos, const float *__restrict__ coeffs,
-              const float *__restrict__ coeffs_rest, const int32_t *__restrict__ radii,
+              const float *__restrict__ campos, const void *__restrict__ coeffs,
+              const void *__restrict__ coeffs_rest, const int32_t *__restrict__ radii,
               const float *__restrict__ depths, float *__restrict__ colors_out, ShPackArgs pk) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int n0 = blockIdx.x * kShBlock;
@@ -256,7 +351,7 @@ sh_fwd_kernel(int C, int N, int K, int degree, const float *__restrict__ means,
     // prefetches the next block's coefficients into registers while this one is evaluated measured no
     // faster: 20.8 vs 19.6 us at N = 300 k.)
     StagedCoeffs<KT, SPLIT> st;
-    coeffs_load(st, coeffs, coeffs_rest, n0, rows, K);
+    coeffs_load<KT, SPLIT, HALF>(st, coeffs, coeffs_rest, n0, rows, K);
     float mx = 0.f, myy = 0.f, mz = 0.f, dep0 = 0.f;
     int rad0 = 0;
     float4 pq = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -269,14 +364,15 @@ sh_fwd_kernel(int C, int N, int K, int degree, const float *__restrict__ means,
         rad0 = radii[n];
         if (depths) dep0 = depths[n];
         if (PACK) {
-            pq = reinterpret_cast<const float4 *>(pk.quats)[n];
+            pq = ld_attr4(pk.quats, n, HALF ? 1 : 0);
             pxy = reinterpret_cast<const float2 *>(pk.means2d)[n];
             pop = pk.opacities[n];
+            ld_attr3(pk.log_scales, n, HALF ? 1 : 0, pls);
 #pragma unroll
-            for (int k = 0; k < 3; ++k) { pls[k] = pk.log_scales[n * 3 + k]; pcon[k] = pk.conics[n * 3 + k]; }
+            for (int k = 0; k < 3; ++k) pcon[k] = pk.conics[n * 3 + k];
         }
     }
-    coeffs_park(st, coeffs, coeffs_rest, n0, rows, K, lds);
+    coeffs_park<KT, SPLIT, HALF>(st, coeffs, coeffs_rest, n0, rows, K, lds);
     __syncthreads();
     if (!in_range) return;
     const float *my = lds + threadIdx.x * (row_floats + 1);
@@ -328,11 +424,11 @@ sh_fwd_kernel(int C, int N, int K, int degree, const float *__restrict__ means,
     }
 }
 
-template <bool SINGLE_CAM, int KT, bool SPLIT>
+template <bool SINGLE_CAM, int KT, bool SPLIT, bool HALF = false>
 __global__ void __launch_bounds__(kShBlock)
 sh_bwd_kernel(int C, int N, int K, int degree, const float *__restrict__ means,
-              const float *__restrict__ campos, const float *__restrict__ coeffs,
-              const float *__restrict__ coeffs_rest, const int32_t *__restrict__ radii, int D,
+              const float *__restrict__ campos, const void *__restrict__ coeffs,
+              const void *__restrict__ coeffs_rest, const int32_t *__restrict__ radii, int D,
               const float *__restrict__ v_colors, float *__restrict__ v_coeffs,
               float *__restrict__ v_coeffs_rest, float *__restrict__ v_means,
               float *__restrict__ v_depths, int overwrite_means, float4 *__restrict__ v_rgb_masked) {
@@ -345,7 +441,7 @@ sh_bwd_kernel(int C, int N, int K, int degree, const float *__restrict__ means,
     const int pitch = row_floats + 1;
     const int n = n0 + threadIdx.x;
     StagedCoeffs<KT, SPLIT> st;
-    coeffs_load(st, coeffs, coeffs_rest, n0, rows, K);
+    coeffs_load<KT, SPLIT, HALF>(st, coeffs, coeffs_rest, n0, rows, K);
     // (single camera) this Gaussian's own inputs, in flight together with the coefficients
     float mx = 0.f, myy = 0.f, mz = 0.f, vc0 = 0.f, vc1 = 0.f, vc2 = 0.f, vc3 = 0.f;
     float o0 = 0.f, o1 = 0.f, o2 = 0.f;
@@ -357,7 +453,7 @@ sh_bwd_kernel(int C, int N, int K, int degree, const float *__restrict__ means,
         if (D == 4 && v_depths) vc3 = v_colors[(int64_t)n * 4 + 3];
         if (!overwrite_means) { o0 = v_means[n * 3 + 0]; o1 = v_means[n * 3 + 1]; o2 = v_means[n * 3 + 2]; }
     }
-    coeffs_park(st, coeffs, coeffs_rest, n0, rows, K, lds);
+    coeffs_park<KT, SPLIT, HALF>(st, coeffs, coeffs_rest, n0, rows, K, lds);
     __syncthreads();
     float *my = lds + threadIdx.x * pitch;
     if (SINGLE_CAM) {
@@ -663,9 +759,10 @@ extern "C" int fsgs_sh_fwd_split(int C, int N, int K, int degree, const float *m
 }
 
 static int sh_bwd_impl(int C, int N, int K, int degree, const float *means, const float *campos,
-                       const float *coeffs, const float *coeffs_rest, const int32_t *radii, int D,
+                       const void *coeffs, const void *coeffs_rest, const int32_t *radii, int D,
                        const float *v_colors, float *v_coeffs, float *v_coeffs_rest, float *v_means,
-                       float *v_depths, int overwrite_means, fsgs_stream_t stream, float *v_rgb_masked = nullptr) {
+                       float *v_depths, int overwrite_means, fsgs_stream_t stream, float *v_rgb_masked = nullptr,
+                       int attr_half = 0) {
     // D = floats per v_colors row (the colour gradient is its first three): 3, 4 (v_depths = column 3), or a
     // wider stride such as the rasterizer's packed 16-float gradient records
     if (C < 0 || N < 0 || degree < 0 || degree > 4 || K < (degree + 1) * (degree + 1) || K > kMaxK || D < 3)
@@ -680,7 +777,19 @@ static int sh_bwd_impl(int C, int N, int K, int degree, const float *means, cons
                        v_colors, v_coeffs, v_coeffs_rest, v_means, v_depths, overwrite_means,                 \
                        reinterpret_cast<float4 *>(v_rgb_masked))
 #define FSGS_SH_BWD_K(SC, SP) do { if (K == 16) FSGS_SH_BWD(SC, 16, SP); else FSGS_SH_BWD(SC, 0, SP); } while (0)
-    if (C == 1) {
+    if (attr_half) {  // half coefficient storage: one camera, split features (the training path)
+        if (C != 1 || !coeffs_rest) return FSGS_EINVAL;
+        if (K == 16)
+            hipLaunchKernelGGL((sh_bwd_kernel<true, 16, true, true>), dim3(ceil_div(N, kShBlock)), dim3(kShBlock), lds_bytes,
+                               as_stream(stream), C, N, K, degree, means, campos, coeffs, coeffs_rest, radii, D, v_colors,
+                               v_coeffs, v_coeffs_rest, v_means, v_depths, overwrite_means,
+                               reinterpret_cast<float4 *>(v_rgb_masked));
+        else
+            hipLaunchKernelGGL((sh_bwd_kernel<true, 0, true, true>), dim3(ceil_div(N, kShBlock)), dim3(kShBlock), lds_bytes,
+                               as_stream(stream), C, N, K, degree, means, campos, coeffs, coeffs_rest, radii, D, v_colors,
+                               v_coeffs, v_coeffs_rest, v_means, v_depths, overwrite_means,
+                               reinterpret_cast<float4 *>(v_rgb_masked));
+    } else if (C == 1) {
         if (coeffs_rest) FSGS_SH_BWD_K(true, true); else FSGS_SH_BWD_K(true, false);
     } else {
         if (coeffs_rest) FSGS_SH_BWD_K(false, true); else FSGS_SH_BWD_K(false, false);
@@ -706,6 +815,18 @@ extern "C" int fsgs_sh_bwd_split(int C, int N, int K, int degree, const float *m
     return sh_bwd_impl(C, N, K, degree, means, campos, features_dc, features_rest ? features_rest : features_dc,
                        radii, D, v_colors, v_features_dc, v_features_rest ? v_features_rest : v_features_dc,
                        v_means, v_depths, overwrite_means, stream);
+}
+
+// one camera, features read from IEEE-half mirrors (BASELINE config #5); gradients fp32
+extern "C" int fsgs_sh_bwd_split_h16(int N, int K, int degree, const float *means, const float *campos,
+                                     const void *features_dc_h, const void *features_rest_h, const int32_t *radii,
+                                     int D, const float *v_colors, float *v_features_dc, float *v_features_rest,
+                                     float *v_means, float *v_depths, int overwrite_means, fsgs_stream_t stream) {
+    if (N == 0) return FSGS_OK;
+    if ((!features_rest_h || !v_features_rest) && K > 1) return FSGS_EINVAL;
+    return sh_bwd_impl(1, N, K, degree, means, campos, features_dc_h, features_rest_h ? features_rest_h : features_dc_h,
+                       radii, D, v_colors, v_features_dc, v_features_rest ? v_features_rest : v_features_dc, v_means,
+                       v_depths, overwrite_means, stream, nullptr, 1);
 }
 
 // fsgs_sh_bwd_split for one camera that leaves the coefficient gradients to fsgs_sh_coeff_grad: writes v_means (as
@@ -770,12 +891,12 @@ extern "C" int fsgs_sh_coeff_grad_adam(int R, int N, int K, int degree, const fl
 
 // fsgs_sh_fwd_split (one camera, depth channel) + fsgs_live_pack_normals in one launch: the colours go straight into
 // the packed per-Gaussian records [N,16] (no colour array), normals_world [N,3] and the zeroed cells as there.
-extern "C" int fsgs_sh_fwd_pack(int N, int K, int degree, const float *means, const float *campos,
-                                const float *features_dc, const float *features_rest, const int32_t *radii,
+static int sh_fwd_pack_impl(int N, int K, int degree, const float *means, const float *campos,
+                                const void *features_dc, const void *features_rest, const int32_t *radii,
                                 const float *depths, const float *means2d, const float *conics,
-                                const float *opacities, const float *quats, const float *log_scales,
+                                const float *opacities, const void *quats, const void *log_scales,
                                 const float *c2w, float *packed, float *normals_world, float *zero_cells,
-                                int n_zero, fsgs_stream_t stream) {
+                                int n_zero, int attr_half, fsgs_stream_t stream) {
     if (N < 0 || degree < 0 || degree > 4 || K < (degree + 1) * (degree + 1) || K > kMaxK) return FSGS_EINVAL;
     if (N == 0) {
         if (zero_cells && n_zero > 0) {
@@ -789,8 +910,19 @@ extern "C" int fsgs_sh_fwd_pack(int N, int K, int degree, const float *means, co
         return FSGS_EINVAL;
     ShPackArgs pk = {means2d, conics, opacities, quats, log_scales, c2w, reinterpret_cast<float4 *>(packed),
                      normals_world, zero_cells, zero_cells ? n_zero : 0};
-    const float *rest = features_rest ? features_rest : features_dc;
+    const void *rest = features_rest ? features_rest : features_dc;
     const size_t lds_bytes = (size_t)kShBlock * (K * 3 + 1) * sizeof(float);
+    if (attr_half) {
+        if (K == 16)
+            hipLaunchKernelGGL((sh_fwd_kernel<16, true, true, true>), dim3(ceil_div(N, kShBlock)), dim3(kShBlock), lds_bytes,
+                               as_stream(stream), 1, N, K, degree, means, campos, features_dc, rest, radii, depths,
+                               nullptr, pk);
+        else
+            hipLaunchKernelGGL((sh_fwd_kernel<0, true, true, true>), dim3(ceil_div(N, kShBlock)), dim3(kShBlock), lds_bytes,
+                               as_stream(stream), 1, N, K, degree, means, campos, features_dc, rest, radii, depths,
+                               nullptr, pk);
+        return check_launch();
+    }
     if (K == 16)
         hipLaunchKernelGGL((sh_fwd_kernel<16, true, true>), dim3(ceil_div(N, kShBlock)), dim3(kShBlock), lds_bytes,
                            as_stream(stream), 1, N, K, degree, means, campos, features_dc, rest, radii, depths,
@@ -800,4 +932,26 @@ extern "C" int fsgs_sh_fwd_pack(int N, int K, int degree, const float *means, co
                            as_stream(stream), 1, N, K, degree, means, campos, features_dc, rest, radii, depths,
                            nullptr, pk);
     return check_launch();
+}
+
+extern "C" int fsgs_sh_fwd_pack(int N, int K, int degree, const float *means, const float *campos,
+                                const float *features_dc, const float *features_rest, const int32_t *radii,
+                                const float *depths, const float *means2d, const float *conics,
+                                const float *opacities, const float *quats, const float *log_scales,
+                                const float *c2w, float *packed, float *normals_world, float *zero_cells,
+                                int n_zero, fsgs_stream_t stream) {
+    return sh_fwd_pack_impl(N, K, degree, means, campos, features_dc, features_rest, radii, depths, means2d, conics,
+                            opacities, quats, log_scales, c2w, packed, normals_world, zero_cells, n_zero, 0, stream);
+}
+
+// features / quats / log_scales read from IEEE-half mirrors (BASELINE config #5): 124 instead of 236 parameter
+// bytes per Gaussian on the render path; all arithmetic fp32
+extern "C" int fsgs_sh_fwd_pack_h16(int N, int K, int degree, const float *means, const float *campos,
+                                    const void *features_dc_h, const void *features_rest_h, const int32_t *radii,
+                                    const float *depths, const float *means2d, const float *conics,
+                                    const float *opacities, const void *quats_h, const void *log_scales_h,
+                                    const float *c2w, float *packed, float *normals_world, float *zero_cells,
+                                    int n_zero, fsgs_stream_t stream) {
+    return sh_fwd_pack_impl(N, K, degree, means, campos, features_dc_h, features_rest_h, radii, depths, means2d, conics,
+                            opacities, quats_h, log_scales_h, c2w, packed, normals_world, zero_cells, n_zero, 1, stream);
 }

@@ -58,6 +58,9 @@ class FrameInfo:
         # images (fsgs_epilogue_loss_fwd); the results land in aux_loss = (partial sums, v_depth, v_normal)
         self.loss_targets: Optional[dict] = None
         self.aux_loss = None
+        # BASELINE config #5: IEEE-half mirrors of scales / quats / features_dc / features_rest / opacities that the
+        # render kernels read instead of the fp32 masters (the trainer keeps them in step with the parameters)
+        self.half: Optional[Dict[str, Tensor]] = None
 
     @property
     def flatten_ids(self):
@@ -129,6 +132,7 @@ class _FusedGetOutputs(torch.autograd.Function):
         depths = torch.empty(1, N, **f32)
         conics = torch.empty(1, N, 3, **f32)
         bthr = info.binary_threshold
+        hm = info.half  # half attribute mirrors, or None
         # live emission: only (Gaussian, tile) pairs that can reach a pixel are binned and sorted; the
         # quadrant masks ride in the payload (gsplat's full lists are not an output of get_outputs)
         opac_row = opac_sig.view(1, N)
@@ -140,7 +144,14 @@ class _FusedGetOutputs(torch.autograd.Function):
             count = ops.project_bin_live_count_async(
                 means, quats, scales, opacities, bthr, cam["viewmat"], cam["K"], W, H, tw, th,
                 dict(scales_exp=scales_exp, opac_sig=opac_sig, radii=radii, means2d=means2d, depths=depths,
-                     conics=conics))
+                     conics=conics), half=hm)
+        elif hm is not None:
+            _run(lib.fsgs_project_fwd_act_h16, (1, N, ptr(means), ptr(hm["quats"]), ptr(hm["scales"]),
+                                               ptr(hm["opacities"]), ptr(opacities), 0 if bthr is None else 1,
+                                               0.0 if bthr is None else float(bthr), ptr(cam["viewmat"]),
+                                               ptr(cam["K"]), W, H, 0.3, 0.01, 1e10, 0.0, ptr(scales_exp),
+                                               ptr(opac_sig), ptr(radii), ptr(means2d), ptr(depths), ptr(conics), sp),
+                 "fsgs_project_fwd_act")
         else:
             _run(lib.fsgs_project_fwd_act, (1, N, ptr(means), ptr(quats), ptr(scales), ptr(opacities),
                                            0 if bthr is None else 1, 0.0 if bthr is None else float(bthr),
@@ -156,6 +167,13 @@ class _FusedGetOutputs(torch.autograd.Function):
 
         def colours_and_packing():
             # SH colours (+ depth) and the camera-space normals straight into the packed records (one launch)
+            if hm is not None:
+                _run(lib.fsgs_sh_fwd_pack_h16, (N, K, sh_degree, ptr(means), ptr(cam["campos"]), ptr(hm["features_dc"]),
+                                                ptr(hm["features_rest"]), ptr(radii), ptr(depths), ptr(means2d),
+                                                ptr(conics), ptr(opac_sig), ptr(hm["quats"]), ptr(hm["scales"]),
+                                                ptr(cam["c2w"]), ptr(packed), ptr(normals_world), ptr(max_last),
+                                                n_cells, sp), "fsgs_sh_fwd_split")
+                return
             _run(lib.fsgs_sh_fwd_pack, (N, K, sh_degree, ptr(means), ptr(cam["campos"]), ptr(features_dc),
                                         ptr(features_rest), ptr(radii), ptr(depths), ptr(means2d), ptr(conics),
                                         ptr(opac_sig), ptr(quats), ptr(scales), ptr(cam["c2w"]), ptr(packed),
@@ -289,7 +307,13 @@ class _FusedGetOutputs(torch.autograd.Function):
         g_opac = out("opacities", opac_sig.view(N, 1))
         # SH: colour gradients are the first floats of the packed records; writes the view-direction share of v_means
         factors = ctx.info.sh_factors_out
-        if factors is not None:
+        hm = ctx.info.half
+        if hm is not None:
+            assert factors is None, "the factored feature exchange reads fp32 features (trainer switches it off)"
+            _run(lib.fsgs_sh_bwd_split_h16, (N, K, sh_degree, ptr(means), ptr(cam["campos"]), ptr(hm["features_dc"]),
+                                             ptr(hm["features_rest"]), ptr(radii), 16, ptr(v_packed), ptr(g_dc),
+                                             ptr(g_rest), ptr(g_means), None, 1, sp), "fsgs_sh_bwd_split")
+        elif factors is not None:
             # data-parallel step: only the FACTORS of the coefficient gradients are produced here ([N + 1,4]: masked
             # colour gradients + the camera centre); the trainer all-gathers them and fsgs_sh_coeff_grad rebuilds the
             # mean of the ranks' coefficient gradients in the slab (16 B instead of 192 B per Gaussian on the links)
@@ -306,7 +330,9 @@ class _FusedGetOutputs(torch.autograd.Function):
         stats = ctx.info.stats_out
         if stats is not None and stats["xys_grad_norm"].shape[0] != N:
             stats = None
-        _run(lib.fsgs_gaussian_bwd, (N, ptr(means), ptr(quats), ptr(scales), ptr(scales_exp), ptr(opac_sig),
+        _run(lib.fsgs_gaussian_bwd_h16 if hm is not None else lib.fsgs_gaussian_bwd,
+             (N, ptr(means), ptr(hm["quats"] if hm is not None else quats),
+                                    ptr(hm["scales"] if hm is not None else scales), ptr(scales_exp), ptr(opac_sig),
                                     ptr(cam["viewmat"]), ptr(cam["K"]), ptr(cam["c2w"]), W, H, 0.3, ptr(radii),
                                     ptr(conics), ptr(v_packed), 1, ptr(g_means), ptr(g_quats), ptr(g_scales),
                                     ptr(g_opac), ptr(v_abs),
@@ -329,7 +355,8 @@ def render_fusionsense_fused(gauss_params: Dict[str, Tensor], camera: Camera, sh
                              grad_out: Optional[Dict[str, Tensor]] = None,
                              stats_out: Optional[dict] = None, add_mask: Optional[Tensor] = None,
                              crop_box=None, training: bool = True,
-                             binary_threshold: Optional[float] = None) -> Dict[str, Tensor]:
+                             binary_threshold: Optional[float] = None,
+                             half: Optional[Dict[str, Tensor]] = None) -> Dict[str, Tensor]:
     """Same outputs as :func:`fusionsense_amd.fusion.render_fusionsense` (rgb, depth, normal,
     accumulation, radii, normals_world, ...), computed by one fused autograd node.  ``add_mask``,
     ``crop_box`` / ``training`` and ``binary_threshold`` have the meaning they have there
@@ -350,10 +377,13 @@ def render_fusionsense_fused(gauss_params: Dict[str, Tensor], camera: Camera, sh
             return get_empty_outputs(camera.width, camera.height, background)
         gauss_params = crop_params(gauss_params, crop_ids)
         grad_out = None
+        if half is not None:  # (the binary write above went to the masters: re-derive the cropped mirrors from them)
+            half = {k: gauss_params[k].detach().to(torch.float16).contiguous() for k in half}
     cam = _camera_on_device(camera, dev)
     info = FrameInfo()
     info.stats_out = stats_out
     info.binary_threshold = binary_threshold
+    info.half = half
     if add_mask is not None:
         info.frozen = add_mask.to(device=dev, dtype=torch.uint8).contiguous()
     rgb, depth, normal, alpha = _FusedGetOutputs.apply(
@@ -389,7 +419,7 @@ def fused_step_forward_backward(gauss_params: Dict[str, Tensor], camera: Camera,
                                 stats_out: Optional[dict] = None, add_mask: Optional[Tensor] = None,
                                 binary_threshold: Optional[float] = None, ssim_lambda: float = 0.2,
                                 w_depth: float = 0.2, w_normal: float = 0.1, pre_sh=None, sh_factors_out=None,
-                                fusion=None):
+                                fusion=None, half: Optional[Dict[str, Tensor]] = None):
     """get_outputs -> loss -> both backward passes, without the autograd tape.  The parameter gradients land in
     ``grad_out`` (the trainer's slab views).  Returns (loss 0-d tensor, outputs dict).
     ``target`` is either the benchmark targets of BASELINE config #2 (dict rgb / depth / normal: L1 + SSIM on rgb,
@@ -405,6 +435,7 @@ def fused_step_forward_backward(gauss_params: Dict[str, Tensor], camera: Camera,
     info.binary_threshold = binary_threshold
     info.pre_sh = pre_sh
     info.sh_factors_out = sh_factors_out
+    info.half = half
     if add_mask is not None:
         info.frozen = add_mask.to(device=dev, dtype=torch.uint8).contiguous()
     if fusion is not None:

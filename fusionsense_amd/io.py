@@ -267,6 +267,8 @@ def load_checkpoint(trainer, path: str) -> int:
         opt.param_groups[0]["params"] = [new]
         opt.state.pop(old, None)
     trainer.slab = GradSlab(trainer.params)
+    if hasattr(trainer, "mark_params_written"):
+        trainer.mark_params_written()
     for name in PARAM_ORDER:
         sd = ck["optimizers"].get(name)
         if sd is not None:

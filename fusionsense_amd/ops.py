@@ -341,7 +341,7 @@ def bin_live_count_async(means2d: Tensor, radii: Tensor, conics: Tensor, opaciti
 
 def project_bin_live_count_async(means: Tensor, quats: Tensor, log_scales: Tensor, opac_logit: Tensor,
                                  binary_threshold, viewmat: Tensor, K: Tensor, width: int, height: int,
-                                 tile_width: int, tile_height: int, out: dict) -> dict:
+                                 tile_width: int, tile_height: int, out: dict, half: Optional[dict] = None) -> dict:
     """``fsgs_project_fwd_act`` + ``bin_live_count_async`` in one launch chain (one camera): the count pass projects
     its Gaussians itself.  ``out`` holds the projection's output tensors (scales_exp, opac_sig, radii [1,N],
     means2d, depths, conics).  Returns the same state ``bin_live_count_async`` does."""
@@ -354,6 +354,16 @@ def project_bin_live_count_async(means: Tensor, quats: Tensor, log_scales: Tenso
     tbytes = lib.fsgs_bin_live_table_bytes(1, N, tile_width, tile_height)
     table = WORKSPACE.take(tbytes, dev)
     pinned = _pinned_i32(dev)
+    if half is not None:  # BASELINE config #5: quats / log-scales / opacity logits read from their half mirrors
+        _run(lib.fsgs_project_bin_live_count_h16,
+             (N, ptr(means), ptr(half["quats"]), ptr(half["scales"]), ptr(half["opacities"]), ptr(opac_logit),
+              0 if binary_threshold is None else 1, 0.0 if binary_threshold is None else float(binary_threshold),
+              ptr(viewmat), ptr(K), width, height, 0.3, 0.01, 1e10, 0.0, ptr(out["scales_exp"]), ptr(out["opac_sig"]),
+              ptr(out["radii"]), ptr(out["means2d"]), ptr(out["depths"]), ptr(out["conics"]), tile_width, tile_height,
+              ptr(tpg), ptr(offsets), ptr(table), tbytes, pinned.data_ptr(), stream_ptr(dev)), "fsgs_isect_count_live")
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(dev))
+        return dict(direct=True, tpg=tpg, offsets=offsets, table=table, pinned=pinned, event=ev, T=T)
     _run(lib.fsgs_project_bin_live_count,
          (N, ptr(means), ptr(quats), ptr(log_scales), ptr(opac_logit), 0 if binary_threshold is None else 1,
           0.0 if binary_threshold is None else float(binary_threshold), ptr(viewmat), ptr(K), width, height, 0.3, 0.01,
@@ -1176,14 +1186,25 @@ def fusion_loss(out, fb, cfg, log_scales: Tensor, touch_idx: Optional[Tensor] = 
 
 
 def adam_step_(params, grads, exp_avgs, exp_avg_sqs, lrs, step: int, beta1: float = 0.9, beta2: float = 0.999,
-               eps: float = 1e-15) -> None:
-    """In-place torch.optim.Adam update of several parameter tensors in ONE launch (row N1)."""
+               eps: float = 1e-15, half_mirrors=None) -> None:
+    """In-place torch.optim.Adam update of several parameter tensors in ONE launch (row N1).  ``half_mirrors``: per
+    parameter a float16 tensor of the same shape (or None) that is rewritten with the updated values in the same
+    launch (BASELINE config #5: what the render kernels read)."""
     lib = load()
     n = len(params)
     dev = params[0].device
     VP = C.c_void_p * n
     numel = (C.c_int64 * n)(*[p.numel() for p in params])
     lr = (C.c_float * n)(*[float(x) for x in lrs])
+    if half_mirrors is not None:
+        for p_, h_ in zip(params, half_mirrors):
+            assert h_ is None or (h_.dtype == torch.float16 and h_.shape == p_.shape and h_.is_contiguous())
+        _run(lib.fsgs_adam_step_h16, (n, VP(*[p.data_ptr() for p in params]), VP(*[g.data_ptr() for g in grads]),
+                                      VP(*[m.data_ptr() for m in exp_avgs]), VP(*[v.data_ptr() for v in exp_avg_sqs]),
+                                      VP(*[(h.data_ptr() if h is not None else None) for h in half_mirrors]),
+                                      numel, lr, int(step), float(beta1), float(beta2), float(eps), stream_ptr(dev)),
+             "fsgs_adam_step")
+        return
     _run(lib.fsgs_adam_step, (n, VP(*[p.data_ptr() for p in params]), VP(*[g.data_ptr() for g in grads]),
                               VP(*[m.data_ptr() for m in exp_avgs]), VP(*[v.data_ptr() for v in exp_avg_sqs]),
                               numel, lr, int(step), float(beta1), float(beta2), float(eps), stream_ptr(dev)),

@@ -292,6 +292,8 @@ class DensifyStrategy:
             logit = torch.logit(torch.tensor(reset_value)).item()
             op = trainer.params["opacities"]
             op.data = torch.clamp(op.data, max=logit)
+            if hasattr(trainer, "mark_params_written"):
+                trainer.mark_params_written()
             st = trainer.optimizers["opacities"].state.get(op, None)
             if st:
                 st["exp_avg"] = torch.zeros_like(st["exp_avg"])
@@ -424,3 +426,5 @@ class DensifyStrategy:
             opt.param_groups[0]["params"] = [new_p]
             trainer.params[name] = new_p
         trainer.slab.rebuild(trainer.params)
+        if hasattr(trainer, "mark_params_written"):
+            trainer.mark_params_written()

@@ -30,6 +30,7 @@ PARAM_ORDER = ["means", "scales", "quats", "features_dc", "features_rest", "opac
 GEOMETRY_GROUPS = ["means", "scales", "quats", "opacities"]
 FEATURE_GROUPS = ["features_dc", "features_rest"]
 SLAB_ORDER = GEOMETRY_GROUPS + FEATURE_GROUPS
+HALF_GROUPS = ["scales", "quats", "features_dc", "features_rest", "opacities"]  # config #5: stored half for rendering
 
 
 @dataclass
@@ -106,7 +107,7 @@ class SplatTrainer:
     def __init__(self, params: Dict[str, Tensor], device: torch.device, sh_degree: int = 3,
                  optim: Optional[OptimConfig] = None, fused_adam: bool = True, seed: int = 0,
                  strategy=None, fused: bool = True, sh_degree_interval: Optional[int] = None,
-                 direct: bool = True, loss_cfg=None):
+                 direct: bool = True, loss_cfg=None, half_attributes: bool = False):
         self.device = device
         # fused=True: get_outputs as one autograd node (fusionsense_amd/fused.py); False: the
         # reference's op-by-op caller through the drop-in rasterization()/rasterize_gaussians() surface
@@ -154,6 +155,15 @@ class SplatTrainer:
         # How the factor blocks are gathered is decided ONCE, here, from the backend — never by catching an exception
         # inside a step: ranks that disagreed on the collective would deadlock.
         self._gather_flat = None
+        # BASELINE config #5: the render kernels read IEEE-half MIRRORS of every attribute but the means (SH features,
+        # log-scales, quaternions, opacity logits: 124 instead of 236 parameter bytes per Gaussian per frame); the
+        # fp32 masters, their gradients and Adam are untouched, and the fused Adam launch rewrites the mirrors.
+        self.half_attributes = bool(half_attributes)
+        self._half: Optional[Dict[str, Tensor]] = None
+        self._half_dirty = True
+        if self.half_attributes:
+            assert fused and device.type == "cuda", "half attribute storage runs on the fused HIP path"
+            self.factored_features = False  # (the factored exchange rebuilds from fp32 features)
         self._factors = None
         self._pending = None
         self.step = 0
@@ -170,6 +180,22 @@ class SplatTrainer:
 
     def num_gaussians(self) -> int:
         return self.params["means"].shape[0]
+
+    def half_mirrors(self) -> Optional[Dict[str, Tensor]]:
+        """The float16 mirrors of HALF_GROUPS (None unless half_attributes), re-derived from the masters whenever
+        something other than the fused Adam launch has written the parameters (densify / prune, resets, loads)."""
+        if not self.half_attributes:
+            return None
+        stale = self._half is None or self._half_dirty or any(
+            self._half[k].shape != self.params[k].shape for k in HALF_GROUPS)
+        if stale:
+            self._half = {k: self.params[k].data.to(torch.float16).contiguous() for k in HALF_GROUPS}
+            self._half_dirty = False
+        return self._half
+
+    def mark_params_written(self) -> None:
+        """Tell the trainer that parameter data changed outside the optimizer step (mirrors must be re-derived)."""
+        self._half_dirty = True
 
     def _sh_degree_now(self, sh_degree_to_use: Optional[int] = None) -> int:
         if sh_degree_to_use is not None:
@@ -206,7 +232,7 @@ class SplatTrainer:
             return render_fusionsense_fused(self.params, camera, sh_degree=deg, device=self.device,
                                             grad_out=self.slab.views if grad else None, stats_out=stats,
                                             add_mask=add_mask, crop_box=crop_box, training=grad,
-                                            binary_threshold=bthr)
+                                            binary_threshold=bthr, half=self.half_mirrors())
         from .fusion import render_fusionsense
         return render_fusionsense(self.params, camera, sh_degree=deg, device=self.device, add_mask=add_mask,
                                   crop_box=crop_box, training=grad, binary_threshold=bthr)
@@ -262,7 +288,9 @@ class SplatTrainer:
         if step_no is None:
             self.adam_steps = getattr(self, "adam_steps", 0) + 1
             step_no = self.adam_steps
-        adam_step_(ps, gs, ms, vs, lrs, step_no, 0.9, 0.999, self.optim_cfg.eps)
+        hm = self.half_mirrors()
+        halves = [hm.get(name) for name in (names or PARAM_ORDER)] if hm is not None else None
+        adam_step_(ps, gs, ms, vs, lrs, step_no, 0.9, 0.999, self.optim_cfg.eps, half_mirrors=halves)
         return step_no
 
     def _optimizer_step(self, names, step_no: Optional[int] = None) -> Optional[int]:
@@ -394,7 +422,8 @@ class SplatTrainer:
                                                     binary_threshold=bthr,
                                                     pre_sh=self.flush if self._pending is not None else None,
                                                     sh_factors_out=factors[0] if factors else None,
-                                                    fusion=((self.loss_cfg,) + self._touch_rows()) if is_fb else None)
+                                                    fusion=((self.loss_cfg,) + self._touch_rows()) if is_fb else None,
+                                                    half=self.half_mirrors())
             self._factors_used = factors
         else:
             if not self.fused:

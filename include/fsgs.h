@@ -428,6 +428,47 @@ int fsgs_adam_step(int n_groups, float *const *params, const float *const *grads
                    float *const *exp_avg_sq, const int64_t *numel, const float *lr, int step, double beta1,
                    double beta2, float eps, fsgs_stream_t stream);
 
+/* ---- BASELINE config #5: half-precision attribute storage ----------------------------------------------------
+ * The render path can read the per-Gaussian attributes other than the means — SH features, log-scales, quaternions,
+ * opacity logits — from IEEE-half MIRRORS of the fp32 master parameters: 124 instead of 236 parameter bytes per
+ * Gaussian per frame.  All arithmetic and every gradient stay fp32; Adam updates the masters and rewrites the
+ * mirrors in the same launch.  The *_h16 entries take the mirrors (const void * = half) where their fp32 twins
+ * take floats and are otherwise identical, argument for argument:
+ *   fsgs_project_bin_live_count_h16 / fsgs_project_fwd_act_h16   (+ opac_logit_master, nullable: the binary-opacity
+ *       write goes to mirror and master), fsgs_sh_fwd_pack_h16, fsgs_sh_bwd_split_h16 (one camera),
+ *   fsgs_gaussian_bwd_h16, fsgs_adam_step_h16 (half_mirrors[n_groups], nullable entries). */
+int fsgs_project_bin_live_count_h16(int N, const float *means, const void *quats_h, const void *log_scales_h,
+                                    void *opac_logit_h, float *opac_logit_master, int binarise, float binary_threshold,
+                                    const float *viewmat, const float *K, int width, int height, float eps2d,
+                                    float near_plane, float far_plane, float radius_clip, float *scales_out,
+                                    float *opac_out, int32_t *radii, float *means2d, float *depths, float *conics,
+                                    int tile_width, int tile_height, int32_t *tiles_per_gauss, int32_t *isect_offsets,
+                                    void *table_scratch, size_t table_bytes, int32_t *n_live_mapped,
+                                    fsgs_stream_t stream);
+int fsgs_project_fwd_act_h16(int C, int N, const float *means, const void *quats_h, const void *log_scales_h,
+                             void *opac_logit_h, float *opac_logit_master, int binarise, float binary_threshold,
+                             const float *viewmats, const float *Ks, int width, int height, float eps2d,
+                             float near_plane, float far_plane, float radius_clip, float *scales_out, float *opac_out,
+                             int32_t *radii, float *means2d, float *depths, float *conics, fsgs_stream_t stream);
+int fsgs_sh_fwd_pack_h16(int N, int K, int degree, const float *means, const float *campos, const void *features_dc_h,
+                         const void *features_rest_h, const int32_t *radii, const float *depths, const float *means2d,
+                         const float *conics, const float *opacities, const void *quats_h, const void *log_scales_h,
+                         const float *c2w, float *packed, float *normals_world, float *zero_cells, int n_zero,
+                         fsgs_stream_t stream);
+int fsgs_sh_bwd_split_h16(int N, int K, int degree, const float *means, const float *campos, const void *features_dc_h,
+                          const void *features_rest_h, const int32_t *radii, int D, const float *v_colors,
+                          float *v_features_dc, float *v_features_rest, float *v_means, float *v_depths,
+                          int overwrite_means, fsgs_stream_t stream);
+int fsgs_gaussian_bwd_h16(int N, const float *means, const void *quats_h, const void *log_scales_h, const float *scales,
+                          const float *opac, const float *viewmat, const float *K, const float *c2w, int width,
+                          int height, float eps2d, const int32_t *radii, const float *conics, float *v_packed,
+                          int accumulate_means, float *v_means, float *v_quats, float *v_log_scales,
+                          float *v_opac_logit, float *absgrad, float *xys_grad_norm, float *vis_counts,
+                          float *max_2Dsize, float inv_max_hw, const uint8_t *frozen, fsgs_stream_t stream);
+int fsgs_adam_step_h16(int n_groups, float *const *params, const float *const *grads, float *const *exp_avg,
+                       float *const *exp_avg_sq, void *const *half_mirrors, const int64_t *numel, const float *lr,
+                       int step, double beta1, double beta2, float eps, fsgs_stream_t stream);
+
 /* ---- N2: photometric loss on the render, fused (dn_splatter/dn_model.py:683 main loss with the
  * torchmetrics SSIM(kernel_size=11) of :244).  pred, gt: [H,W,3] channel-last.
  * fwd: sums[P,2] per-workgroup partials (P = fsgs_ssim_l1_num_partials(H,W)): column 0 sums to
