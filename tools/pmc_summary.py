@@ -2,7 +2,8 @@
 """Per-kernel averages of rocprofv3 --pmc counter_collection CSVs (one or more passes) as CSV, plus the
 HBM traffic per launch that bench.py reports as `roofline.traffic`.
 
-Usage: tools/pmc_summary.py OUT_CSV OUT_JSON counter_collection.csv [more.csv ...]
+Usage: tools/pmc_summary.py OUT_CSV OUT_JSON CONFIG SOURCE_TAG counter_collection.csv [more.csv ...]
+(OUT_JSON holds {"config<CONFIG>": {span: {...}}}; merge several into profiles/pmc_traffic.json)
 
 Traffic model (MI355X_MICROARCH.md, HBM section): FETCH_SIZE and WRITE_SIZE are in KB; on gfx950
 FETCH_SIZE tallies 128-byte requests at 64 B, so it is doubled; WRITE_SIZE is taken as reported."""
@@ -18,6 +19,7 @@ SPAN = [
     ("tile_hist_kernel", "tile_sort"), ("tile_scan_kernel2", "tile_sort"), ("tile_offsets_kernel", "tile_sort"),
     ("tile_scatter_kernel", "tile_sort"), ("tile_sort_kernel2", "tile_sort"),
     ("adam_kernel", "adam_step"), ("sh_bwd_kernel", "sh_bwd_split"), ("sh_fwd_kernel", "sh_fwd_split"),
+    ("fusion_aux_kernel", "fusion_aux_loss"), ("split_slabs_kernel", "tile_sort"),
     ("ssim_l1_fwd_kernel", "ssim_l1_fwd"), ("ssim_l1_bwd_kernel", "ssim_l1_bwd"),
     ("project_bwd_kernel<true>", "gaussian_bwd"), ("project_fwd_kernel<true>", "project_fwd_act"),
     ("isect_live_flat_kernel<false>", "isect_count_live"), ("isect_live_flat_kernel<true>", "isect_emit_live"),
@@ -28,7 +30,7 @@ SPAN = [
 
 
 def main():
-    out_csv, out_json, files = sys.argv[1], sys.argv[2], sys.argv[3:]
+    out_csv, out_json, config, source, files = sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5:]
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for f in files:
         for r in csv.DictReader(open(f)):
@@ -65,7 +67,7 @@ def main():
         fetch_b = 2.0 * t["fetch_kb"] * 1024.0 / n
         write_b = t["write_kb"] * 1024.0 / n
         out[span] = {"fetch_bytes_per_launch": round(fetch_b), "write_bytes_per_launch": round(write_b),
-                     "hbm_bytes_per_launch": round(fetch_b + write_b), "launches_sampled": n}
+                     "hbm_bytes_per_launch": round(fetch_b + write_b), "launches_sampled": n, "source": source}
     # vector-ALU counters of single-symbol spans (a separate --pmc pass): instructions and busy quad-cycles per launch
     for k, d in acc.items():
         for sym, span in SPAN:
@@ -76,8 +78,9 @@ def main():
                     out[span]["sq_active_inst_valu_quadcycles_per_launch"] = round(sum(a) / len(a))
                 break
     out["_note"] = ("per-launch averages of rocprofv3 --pmc passes (FETCH_SIZE x2 per the gfx950 correction, WRITE_SIZE, "
-                    "SQ_INSTS_VALU, SQ_ACTIVE_INST_VALU) of `python3 bench.py --steps 6 --warmup 2`; made by tools/pmc_summary.py")
-    json.dump(out, open(out_json, "w"), indent=1, sort_keys=True)
+                    "SQ_INSTS_VALU, SQ_ACTIVE_INST_VALU), each counter set in its own run of bench.py; made by tools/collect.sh "
+                    "+ tools/pmc_summary.py")
+    json.dump({f"config{config}": out}, open(out_json, "w"), indent=1, sort_keys=True)
 
 
 if __name__ == "__main__":
