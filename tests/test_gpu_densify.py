@@ -211,3 +211,96 @@ def test_nearest_point_kernel(dev, nq, np_):
     assert torch.allclose(chosen, rd, atol=1e-6), "the returned index is a nearest point"
     if np_ > 10:
         assert int(i[0]) == 3
+
+
+# ---- the product's callbacks against goldens made by EXECUTING the reference's own methods ----------------------
+import os  # noqa: E402
+
+NAMES6 = ["means", "scales", "quats", "features_dc", "features_rest", "opacities"]
+
+
+def _ref_model():
+    return np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_model.npz"))
+
+
+def _trainer_from_golden(dev, d, prefix, m_prefix, v_prefix=None, step=0, num_train_data=9):
+    t = lambda k: torch.from_numpy(d[k])  # noqa: E731
+    st = DensifyStrategy(SplatfactoConfig(), num_train_data=num_train_data)
+    tr = SplatTrainer({k: t(f"{prefix}.{k}") for k in NAMES6}, dev, strategy=st, seed=0)
+    for k in NAMES6:
+        p = tr.params[k]
+        m = t(f"{m_prefix}.{k}").to(dev)
+        v = t(f"{v_prefix}.{k}").to(dev) if v_prefix else torch.zeros_like(m)
+        tr.optimizers[k].state[p] = {"step": torch.tensor(1.0), "exp_avg": m.clone(), "exp_avg_sq": v.clone()}
+    tr.step = step
+    return tr, st
+
+
+@pytest.mark.parametrize("step", [400, 700, 3100, 3500, 10000])
+def test_refinement_after_matches_reference_execution(dev, step, monkeypatch):
+    """DensifyStrategy.refinement_after (HIP row compaction, split sampler) against the reference's own
+    refinement_after, executed in the authoring container (reference_model.npz): same split noise, same statistics —
+    parameters and both Adam moments, row for row."""
+    d = _ref_model()
+    t = lambda k: torch.from_numpy(d[k])  # noqa: E731
+    tr, st = _trainer_from_golden(dev, d, f"ra.{step}.pre", f"ra.{step}.pre_m", f"ra.{step}.pre_v", step)
+    st.xys_grad_norm, st.vis_counts, st.max_2Dsize = (t(f"ra.stats.{k}").to(dev) for k in ("xys_grad_norm", "vis_counts", "max_2Dsize"))
+    st.last_size = (720, 1280)
+    n = tr.num_gaussians()
+    if step == 3500:
+        st.add_mask = torch.zeros(n, dtype=torch.bool, device=dev)
+        st.add_mask[:50] = True
+    noise = t(f"ra.{step}.randn")
+    real_randn = torch.randn
+
+    def fake_randn(*size, **kw):
+        shape = tuple(size[0]) if len(size) == 1 and not isinstance(size[0], int) else tuple(size)
+        if shape == tuple(noise.shape):
+            return noise.to(kw.get("device", "cpu"))
+        kw.pop("generator", None)
+        return real_randn(*size, **kw)
+
+    monkeypatch.setattr(torch, "randn", fake_randn)
+    st.refinement_after(tr, step)
+    for k in NAMES6:
+        ref = t(f"ra.{step}.post.{k}")
+        assert tr.params[k].shape == ref.shape, (k, tr.params[k].shape, ref.shape, st.last_report)
+        assert torch.allclose(tr.params[k].detach().cpu(), ref, atol=1e-5), k
+        s_ = tr.optimizers[k].state[tr.params[k]]
+        assert torch.equal(s_["exp_avg"].cpu(), t(f"ra.{step}.post_m.{k}")), k
+        assert torch.equal(s_["exp_avg_sq"].cpu(), t(f"ra.{step}.post_v.{k}")), k
+    am = d[f"ra.{step}.add_mask_after"]
+    if am.size:
+        assert np.array_equal(st.add_mask.cpu().numpy(), am)
+    assert (st.xys_grad_norm is None) == bool(d[f"ra.{step}.stats_cleared"])
+
+
+def test_touch_and_hull_callbacks_match_reference_execution(dev):
+    """add_touch_patch, touch_pruning and hull_pruning against the reference's own methods executed on the same
+    state (reference_model.npz): the appended anchor rows (positions, nearest-neighbour colours, gel scales,
+    orientation from the contact normals), the culled rows, zero Adam moments for the new rows, add_mask."""
+    d = _ref_model()
+    t = lambda k: torch.from_numpy(d[k])  # noqa: E731
+    tr, st = _trainer_from_golden(dev, d, "tp.in", "tp.in_m", None, 1000)
+    patches = [{k: t(f"tp.patch{i}.{k}") for k in ("points_xyz", "points_rgb", "normals", "bbox")} for i in range(3)]
+    hull = t("tp.hull")
+    added = st.add_touch_patch(tr, patches, gel_scale_factor=6.34e-5)
+    assert added == int(d["tp.add_mask"].sum())
+    assert np.array_equal(st.add_mask.cpu().numpy(), d["tp.add_mask"])
+    for k in NAMES6:
+        ref = t(f"tp.added.{k}")
+        assert tr.params[k].shape == ref.shape, k
+        assert torch.allclose(tr.params[k].detach().cpu(), ref, atol=1e-6), (k, float((tr.params[k].detach().cpu() - ref).abs().max()))
+        assert torch.equal(tr.optimizers[k].state[tr.params[k]]["exp_avg"].cpu(), t(f"tp.added_m.{k}")), k
+    assert torch.allclose(st.touch_normals.cpu(), torch.cat([p["normals"] for p in patches]))
+    tr.step = 1100
+    tr.params["means"].data.copy_(t("tp.before_touch_prune.means").to(dev))
+    st.touch_pruning(tr, patches)
+    for k in NAMES6:
+        assert torch.allclose(tr.params[k].detach().cpu(), t(f"tp.touch_pruned.{k}"), atol=1e-6), k
+    assert np.array_equal(st.add_mask.cpu().numpy(), d["tp.add_mask_touch_pruned"])
+    st.hull_pruning(tr, hull, scale_factor=1.3)
+    for k in NAMES6:
+        assert tr.params[k].shape == t(f"tp.hull_pruned.{k}").shape, k
+        assert torch.allclose(tr.params[k].detach().cpu(), t(f"tp.hull_pruned.{k}"), atol=1e-6), k
+    assert np.array_equal(st.add_mask.cpu().numpy(), d["tp.add_mask_hull_pruned"])

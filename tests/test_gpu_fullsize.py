@@ -167,6 +167,29 @@ def test_full_size_fused_equals_dropin_caller(dev, full_scene):
         assert rel_err(gf[k], gu[k]) < 5e-3, f"{k}: {rel_err(gf[k], gu[k])}"
 
 
+def test_full_size_tape_free_step_equals_dropin_caller_step(dev, full_scene):
+    """The exact entry the headline number times — SplatTrainer(fused=True, direct=True).train_step, with its folded
+    kernels (projecting count pass, SH + packing, epilogue + L1, image-gradient backward) — against the same step
+    through the reference's own call structure (rasterization() + rasterize_gaussians() + torch autograd) at
+    config #2's full size: the loss and every gradient of the slab."""
+    from fusionsense_amd.trainer import PARAM_ORDER, SplatTrainer
+    params, cams = full_scene
+    tgt_tr = SplatTrainer(scenes.lego_like_scene(N_FULL, seed=1), dev, sh_degree=3)
+    with torch.no_grad():
+        o = tgt_tr.forward(cams[0])
+        tgt = {k: o[k].clone() for k in ("rgb", "depth", "normal")}
+    del tgt_tr
+    a = SplatTrainer(params, dev, sh_degree=3, fused=True, direct=True)
+    b = SplatTrainer(params, dev, sh_degree=3, fused=False)
+    la, oa = a.train_step(cams[0], tgt, optimizer_step=False)
+    lb, ob = b.train_step(cams[0], tgt, optimizer_step=False)
+    assert abs(float(la) - float(lb)) < 1e-5 * abs(float(lb)), (float(la), float(lb))
+    for k in ("rgb", "depth"):
+        assert rel_err(oa[k], ob[k]) < 1e-4, k
+    for k in PARAM_ORDER:
+        assert rel_err(a.slab.views[k], b.slab.views[k]) < 2e-3, (k, rel_err(a.slab.views[k], b.slab.views[k]))
+
+
 @pytest.mark.parametrize("case", ["empty", "all_behind_camera", "tiny_image", "odd_size", "single_gaussian"])
 def test_fused_node_edge_cases(dev, case):
     from fusionsense_amd.fused import render_fusionsense_fused

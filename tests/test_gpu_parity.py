@@ -14,6 +14,7 @@ pytestmark = pytest.mark.gpu
 
 FWD_RTOL = 1e-4   # fp32 forward tolerance (relative to the tensor's max magnitude)
 BWD_RTOL = 2e-3   # fp32 backward tolerance (atomics reorder the sums)
+E2E_RTOL = 3e-3   # end-to-end parameter gradients, per tensor relative to that tensor's own maximum
 
 
 def test_library_loads_on_gpu(dev):
@@ -133,9 +134,13 @@ def test_raster_fwd(dev, D, with_bg, live):
         torch.from_numpy(fr["flat_s"]).to(dev), W, H, 16, False, ids)
     assert (out.cpu() - ref).abs().max().item() < FWD_RTOL * max(1.0, ref.abs().max().item())
     assert (alpha.cpu() - ref_a).abs().max().item() < FWD_RTOL
-    # last_ids: exact except where an fp32 threshold decision (alpha<1/255, T<=1e-4) is borderline
-    mism = (last.cpu().numpy() != ref_last).mean()
-    assert mism < 2e-3, f"last_ids mismatch fraction {mism}"
+    # last_ids: bit-exact wherever the threshold decisions (alpha < 1/255, T <= 1e-4) are not fp32-borderline, i.e.
+    # wherever the oracle in fp32 and in fp64 arrive at the same index
+    _, _, ref_last64 = R.rasterize_to_pixels(fr["means2d"].double(), fr["conics"].double(), cols.double(), opac.double(),
+                                             W, H, 16, fr["offsets"], fr["flat_s"], bg.double() if bg is not None else None)
+    stable = ref_last == ref_last64
+    assert stable.mean() > 0.999, "the oracle itself must be decided on (almost) every pixel"
+    assert np.array_equal(last.cpu().numpy()[stable], ref_last[stable]), "last_ids must be exact where the oracle is decided"
 
 
 @pytest.mark.parametrize("live", [False, True])
@@ -332,9 +337,10 @@ def test_end_to_end_get_outputs(dev):
     assert np.array_equal(out["info"]["flatten_ids"].cpu().numpy(), ref["info"]["flatten_ids"].numpy())
     assert np.array_equal(out["info"]["isect_ids"].cpu().numpy(), ref["info"]["isect_ids"].numpy())
     assert np.array_equal(out["info"]["isect_offsets"].cpu().numpy(), ref["info"]["isect_offsets"].numpy())
+    # parameter gradients: per tensor, relative to that tensor's own largest gradient (E2E_RTOL, fp32 atomics)
     for k in gp:
         e = rel_err(gp[k].grad, cp[k].grad)
-        assert e < 1e-2, f"grad {k}: rel err {e}"
+        assert e < E2E_RTOL, f"grad {k}: rel err {e}"
     # absgrad side output exists with the right shape
     assert out["xys"].absgrad.shape == (1, 1000, 2)
 
@@ -846,3 +852,40 @@ def test_folded_entry_points_equal_the_chains_they_replace(dev):
                                            ptr(vn_a), ptr(v_alpha), ptr(seg_state), 1, ptr(acc_b), sp) == 0
     assert float(acc_a.abs().max()) > 0
     assert rel_err(acc_b, acc_a) < 1e-5
+
+
+def test_finite_differences_of_the_hip_path(dev):
+    """A check of the HIP forward + backward that does NOT go through the recalled oracle: on an 8-Gaussian scene the
+    analytic parameter gradients of a smooth image functional equal central finite differences of the HIP forward
+    itself, along random directions in every parameter group (fp32: step 2e-3, agreement to 2 % of |g.d| + floor)."""
+    from fusionsense_amd.fused import render_fusionsense_fused
+    g = torch.Generator().manual_seed(11)
+    n = 8
+    params = dict(means=0.25 * torch.randn(n, 3, generator=g), scales=math.log(0.12) + 0.2 * torch.randn(n, 3, generator=g),
+                  quats=torch.nn.functional.normalize(torch.randn(n, 4, generator=g), dim=-1),
+                  features_dc=torch.randn(n, 3, generator=g), features_rest=0.2 * torch.randn(n, 15, 3, generator=g),
+                  opacities=0.5 + 0.5 * torch.randn(n, 1, generator=g))
+    cam = scenes.Camera(scenes.look_at_c2w(torch.tensor([0.0, 0.0, 2.5]), torch.zeros(3), up=(0.0, 1.0, 0.0)),
+                        70.0, 70.0, 32.0, 32.0, 64, 64)
+    w = {k: torch.rand(64, 64, c, generator=g).to(dev) for k, c in (("rgb", 3), ("depth", 1), ("normal", 3))}
+
+    def functional(p, grad=False):
+        pp = {k: v.to(dev).requires_grad_(grad) for k, v in p.items()}
+        o = render_fusionsense_fused(pp, cam, sh_degree=3, device=dev)
+        # smooth in the parameters away from the alpha thresholds: weighted means of the three images
+        val = sum((o[k] * w[k]).mean() for k in ("rgb", "depth", "normal"))
+        return val, pp
+
+    val, pp = functional(params, True)
+    val.backward()
+    eps = 2e-3
+    for k in params:
+        for trial in range(3):
+            d = torch.randn(params[k].shape, generator=g)
+            d = d / d.norm()
+            plus = {**params, k: params[k] + eps * d}
+            minus = {**params, k: params[k] - eps * d}
+            with torch.no_grad():
+                fd = (float(functional(plus)[0].double()) - float(functional(minus)[0].double())) / (2 * eps)
+            an = float((pp[k].grad.cpu().double() * d.double()).sum())
+            assert abs(fd - an) <= 2e-2 * abs(an) + 3e-5, (k, trial, fd, an)

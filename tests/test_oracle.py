@@ -247,3 +247,70 @@ def test_ssim_oracle_known_answers():
     # the product's CPU mirror (separable formulation) agrees with this one
     from fusionsense_amd import losses
     assert abs(float(losses.ssim(x.float(), y.float())) - float(loss_ref.ssim_torchmetrics(x, y))) < 1e-5
+
+
+# ---- goldens made by EXECUTING the reference's own DNSplatterModel methods (tests/golden/make_reference_model_goldens.py) ----
+def _model_goldens():
+    return np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_model.npz"))
+
+
+NAMES6 = ["means", "scales", "quats", "features_dc", "features_rest", "opacities"]
+
+
+@pytest.mark.parametrize("case", ["plain", "binary_anchor"])
+def test_caller_oracle_matches_reference_get_outputs(case):
+    """oracle/fusion_ref.render_fusionsense (the restated caller) against the reference's own get_outputs executed
+    over the same rasterizer stand-in: images, the binary-opacity write, per-Gaussian normals, and the parameter
+    gradients including the touch-anchor detach."""
+    from fusionsense_amd.scenes import Camera
+    from oracle import fusion_ref
+    d = _model_goldens()
+    t = lambda k: torch.from_numpy(d[k])  # noqa: E731
+    fx, fy, cx, cy, W, H = [float(v) for v in d["go.intr"]]
+    cam = Camera(t("go.c2w"), fx, fy, cx, cy, int(W), int(H))
+    params = {k: t(f"go.in.{k}").clone().requires_grad_(True) for k in NAMES6}
+    step = int(d[f"go.{case}.step"])
+    add_mask = t(f"go.{case}.add_mask") if f"go.{case}.add_mask" in d.files else None
+    bthr = 0.9 if fusion_ref.binary_opacity_step(step) else None
+    assert (bthr is not None) == (case == "binary_anchor")
+    out = fusion_ref.render_fusionsense(params, cam, sh_degree=int(d[f"go.{case}.sh_degree_to_use"]), add_mask=add_mask,
+                                        binary_threshold=bthr)
+    loss = sum((out[k] * t(f"go.w.{k}")).mean() for k in ("rgb", "depth", "normal"))
+    loss.backward()
+    for k in ("rgb", "depth", "normal", "accumulation"):
+        assert torch.allclose(out[k].detach(), t(f"go.{case}.out.{k}"), atol=1e-6), k
+    assert torch.equal(params["opacities"].detach(), t(f"go.{case}.opacities_after"))
+    assert torch.allclose(out["normals_world"].detach(), t(f"go.{case}.normals_world"), atol=1e-6)
+    for k in NAMES6:
+        g = params[k].grad if params[k].grad is not None else torch.zeros_like(params[k])
+        ref = t(f"go.{case}.grad.{k}")
+        assert torch.allclose(g, ref, rtol=1e-4, atol=1e-8 + 1e-5 * float(ref.abs().max())), (k, float((g - ref).abs().max()))
+    if add_mask is not None:
+        assert float(t(f"go.{case}.grad.means")[add_mask].abs().max()) == 0.0  # (what the golden itself says)
+
+
+@pytest.mark.parametrize("step", [400, 700, 3100, 3500, 10000])
+def test_densify_oracle_matches_reference_refinement_after(step):
+    """oracle/splatfacto_ref.refinement_after against the reference's own refinement_after (its schedule, masks,
+    the re-computed dups after the in-place shrink, cull and opacity reset), executed over stand-ins for the inherited
+    nerfstudio methods: parameters and both Adam moments, row for row."""
+    from fusionsense_amd.splatfacto import SplatfactoConfig
+    from oracle import splatfacto_ref
+    d = _model_goldens()
+    t = lambda k: torch.from_numpy(d[k])  # noqa: E731
+    names = NAMES6 + ["normals"]
+    pre = {k: t(f"ra.{step}.pre.{k}") for k in names}
+    adam = {k: {"exp_avg": t(f"ra.{step}.pre_m.{k}"), "exp_avg_sq": t(f"ra.{step}.pre_v.{k}")} for k in names}
+    state = {k: t(f"ra.stats.{k}").clone() for k in ("xys_grad_norm", "vis_counts", "max_2Dsize")}
+    add_mask = None
+    if step == 3500:
+        add_mask = torch.zeros(pre["means"].shape[0], dtype=torch.bool)
+        add_mask[:50] = True
+    post, post_adam, rep = splatfacto_ref.refinement_after(pre, adam, state, SplatfactoConfig(), step, 9, (720, 1280),
+                                                           t(f"ra.{step}.randn"), add_mask)
+    for k in names:
+        assert post[k].shape == t(f"ra.{step}.post.{k}").shape, (k, post[k].shape, rep)
+        assert torch.allclose(post[k], t(f"ra.{step}.post.{k}"), atol=1e-6), k
+        assert torch.equal(post_adam[k]["exp_avg"], t(f"ra.{step}.post_m.{k}")), k
+        assert torch.equal(post_adam[k]["exp_avg_sq"], t(f"ra.{step}.post_v.{k}")), k
+    assert bool(d[f"ra.{step}.stats_cleared"]) == (step > 500)
