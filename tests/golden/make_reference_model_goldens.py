@@ -189,7 +189,7 @@ def save(out, prefix, d):
     for k, v in d.items():
         if v is None:
             continue
-        out[f"{prefix}.{k}"] = v.detach().numpy() if torch.is_tensor(v) else np.asarray(v)
+        out[f"{prefix}.{k}"] = v.detach().clone().numpy() if torch.is_tensor(v) else np.array(v)  # (a copy: later in-place edits must not reach it)
 
 
 def main():
