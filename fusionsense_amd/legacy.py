@@ -69,6 +69,9 @@ def rasterize_gaussians(
     trunc/+1 rule, which overflows when ``mean + radius`` is an exact multiple of the tile
     size; here the legacy rule is used for both count and fill, so ``num_tiles_hit`` is only
     shape-checked.  Ties in (tile, depth) are kept in ascending Gaussian order (stable)."""
+    import time as _time
+    from .rendering import HOST_TIME
+    _t0 = _time.perf_counter()
     if not (1 < block_width <= 16):
         raise AssertionError("block_width must be between 2 and 16")
     if colors.dtype == torch.uint8:
@@ -95,8 +98,9 @@ def rasterize_gaussians(
     tw = (img_width + block_width - 1) // block_width
     th = (img_height + block_width - 1) // block_width
     cached = frame_cache.lookup(xys, depths, radii, img_width, img_height, block_width)
+    live_payload = None
     if cached is not None:
-        offsets, flatten_ids, isect_ids = cached  # same frame: reuse the first pass's sorted lists
+        offsets, flatten_ids, isect_ids, live_payload = cached  # same frame: reuse the first pass's sorted lists
     else:
         with torch.no_grad():
             _, isect_ids, flatten_ids, offsets, _ = ops.bin_and_sort(
@@ -115,8 +119,10 @@ def rasterize_gaussians(
         bg = torch.cat([bg, torch.zeros(pad, device=dev)])
     out, alpha, _ = ops._Rasterize.apply(
         xys[None], conics[None], cols[None], opacity.reshape(1, N), bg[None], offsets, flatten_ids,
-        int(img_width), int(img_height), int(block_width), False, isect_ids)
+        int(img_width), int(img_height), int(block_width), False, isect_ids, False, live_payload)
     out = out[0, ..., :ch]
+    HOST_TIME["rasterize_gaussians_s"] += _time.perf_counter() - _t0
+    HOST_TIME["rasterize_gaussians_calls"] += 1
     if return_alpha:
         return out, alpha[0, ..., 0]
     return out

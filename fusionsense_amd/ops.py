@@ -566,6 +566,19 @@ class _Workspace:
 
 
 WORKSPACE = _Workspace()
+_PACKED_ACC: dict = {}
+
+
+def _packed_accumulator(dev, n_rows: int) -> Tensor:
+    """The [n_rows,16] gradient accumulator of the compositing backward on the drop-in route: one per (device, size),
+    all zeros between uses (its reader clears it)."""
+    key = (str(dev), n_rows)
+    t = _PACKED_ACC.get(key)
+    if t is None:
+        if len(_PACKED_ACC) > 4:
+            _PACKED_ACC.clear()
+        t = _PACKED_ACC[key] = torch.zeros(n_rows, 16, dtype=torch.float32, device=dev)
+    return t
 
 
 class _Rasterize(torch.autograd.Function):
@@ -579,7 +592,9 @@ class _Rasterize(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, means2d, conics, colors, opacities, backgrounds, isect_offsets, flatten_ids, width,
-                height, tile_size, absgrad, isect_ids=None, normalize_last=False):
+                height, tile_size, absgrad, isect_ids=None, normalize_last=False, live_payload=None):
+        """``live_payload`` (with ``isect_offsets`` = the LIVE lists' offsets and flatten_ids ignored): the sorted
+        live list of the frame as the direct binning leaves it (quadrant mask << 28 | flatten id) — no payload pass."""
         means2d_in = means2d
         means2d, conics, colors, opacities = map(_c, (means2d, conics, colors, opacities))
         backgrounds = _c(backgrounds)
@@ -588,11 +603,11 @@ class _Rasterize(torch.autograd.Function):
         Cn, N = opacities.shape
         D = colors.shape[-1]
         th, tw = isect_offsets.shape[1:]
-        M = flatten_ids.numel()
+        M = live_payload.numel() if live_payload is not None else flatten_ids.numel()
         render = torch.empty(Cn, height, width, D, dtype=torch.float32, device=dev)
         alphas = torch.empty(Cn, height, width, 1, dtype=torch.float32, device=dev)
         last_ids = torch.empty(Cn, height, width, dtype=torch.int32, device=dev)
-        live = USE_LIVE_LISTS and tile_size == 16 and isect_ids is not None
+        live = USE_LIVE_LISTS and tile_size == 16 and (isect_ids is not None or live_payload is not None)
         if normalize_last and not live:
             raise ValueError("normalize_last is implemented by the live-list kernels only")
         if live:
@@ -602,10 +617,13 @@ class _Rasterize(torch.autograd.Function):
             packed = torch.empty(Cn * N, 16, dtype=torch.float32, device=dev)
             _run(lib.fsgs_live_pack, (D, Cn * N, ptr(means2d), ptr(conics), ptr(colors), ptr(opacities), None,
                                      ptr(packed), None, 0, stream_ptr(dev)), "fsgs_live_pack", f"_d{D}")
-            # quadrant mask << 28 | flatten id for every entry of the caller's sorted lists
-            payload = torch.empty(max(M, 1), dtype=torch.int32, device=dev)
-            _run(lib.fsgs_live_payload, (ptr(isect_ids), ptr(flatten_ids), M, ptr(packed), Cn * N, tw,
-                                        tile_bits(tw * th), ptr(payload), stream_ptr(dev)), "fsgs_live_payload")
+            if live_payload is not None:
+                payload = live_payload
+            else:
+                # quadrant mask << 28 | flatten id for every entry of the caller's sorted lists
+                payload = torch.empty(max(M, 1), dtype=torch.int32, device=dev)
+                _run(lib.fsgs_live_payload, (ptr(isect_ids), ptr(flatten_ids), M, ptr(packed), Cn * N, tw,
+                                            tile_bits(tw * th), ptr(payload), stream_ptr(dev)), "fsgs_live_payload")
             if needs_bwd:
                 cap = lib.fsgs_quad_stream_capacity(Cn, tw, th, M)
                 rec_bytes = 4 * cap * 48
@@ -660,7 +678,8 @@ class _Rasterize(torch.autograd.Function):
         v_render = _c(v_render) if v_render is not None else torch.zeros(Cn, height, width, D, device=dev)
         v_alphas = _c(v_alphas) if v_alphas is not None else torch.zeros(Cn, height, width, 1, device=dev)
         if live:
-            v_packed = torch.zeros(Cn * N, 16, dtype=torch.float32, device=dev)
+            # persistent, kept zeroed: the unpack launch below clears it again after reading (no 64 B/Gaussian fill)
+            v_packed = _packed_accumulator(dev, Cn * N)
             _run(lib.fsgs_raster_bwd_quad, (Cn, D, ptr(records), ptr(n_rec), ptr(isect_offsets), M,
                                            ptr(backgrounds) if has_bg else None, width, height, tw, th,
                                            int(normalize_last), ptr(render), ptr(alphas), ptr(last_ids),
@@ -673,7 +692,7 @@ class _Rasterize(torch.autograd.Function):
             v_colors = torch.empty(Cn, N, D, dtype=torch.float32, device=dev)
             v_opacities = torch.empty(Cn, N, dtype=torch.float32, device=dev)
             v_abs = torch.empty(Cn, N, 2, dtype=torch.float32, device=dev) if absgrad else None
-            _run(lib.fsgs_raster_unpack_grads, (Cn * N, D, ptr(v_packed), 0, ptr(v_means2d), ptr(v_abs),
+            _run(lib.fsgs_raster_unpack_grads, (Cn * N, D, ptr(v_packed), 1, ptr(v_means2d), ptr(v_abs),
                                                ptr(v_conics), ptr(v_colors), ptr(v_opacities), None, None,
                                                stream_ptr(dev)), "fsgs_raster_unpack_grads")
         else:
@@ -698,7 +717,7 @@ class _Rasterize(torch.autograd.Function):
             v_bg = (v_render * (1.0 - alphas)).sum(dim=(1, 2))
         ctx.means2d_obj = None
         return (v_means2d, v_conics, v_colors, v_opacities, v_bg, None, None, None, None, None, None, None,
-                None)
+                None, None)
 
 
 class _GaussianNormals(torch.autograd.Function):

@@ -17,6 +17,63 @@ from ._lib import require_gpu_tensor
 
 _RENDER_MODES = ("RGB", "D", "ED", "RGB+D", "RGB+ED")
 
+# host seconds spent inside rasterization() / rasterize_gaussians() (library side of the drop-in route) and calls,
+# for bench.py's dropin_host_ms_per_call
+HOST_TIME = {"rasterization_s": 0.0, "rasterization_calls": 0, "rasterize_gaussians_s": 0.0, "rasterize_gaussians_calls": 0}
+
+
+class LazyMeta(dict):
+    """gsplat's ``meta`` dictionary whose three list entries — ``isect_ids``, ``flatten_ids``, ``isect_offsets``:
+    gsplat's FULL bounding-box tile lists, 12 B per intersection and six radix passes to sort — are built the first
+    time someone asks for them.  FusionSense never does (dn_model.py:592-600 reads means2d, radii, depths, conics,
+    tiles_per_gauss), and the compositing itself walks the frame's LIVE lists (only pairs that can reach a pixel),
+    which give the same images, alphas and gradients."""
+    LAZY = ("isect_ids", "flatten_ids", "isect_offsets", "legacy_rule_diff")
+
+    def __init__(self, eager: dict, build):
+        super().__init__(eager)
+        self._build_lists = build
+
+    def _materialise(self):
+        if self._build_lists is not None:
+            build, self._build_lists = self._build_lists, None
+            self.update(build())
+
+    def __missing__(self, key):
+        if key in self.LAZY and self._build_lists is not None:
+            self._materialise()
+            return dict.__getitem__(self, key)
+        raise KeyError(key)
+
+    def __contains__(self, key):
+        return dict.__contains__(self, key) or (key in self.LAZY and self._build_lists is not None)
+
+    def get(self, key, default=None):
+        try:
+            return self[key]
+        except KeyError:
+            return default
+
+    def keys(self):
+        self._materialise()
+        return dict.keys(self)
+
+    def items(self):
+        self._materialise()
+        return dict.items(self)
+
+    def values(self):
+        self._materialise()
+        return dict.values(self)
+
+    def __iter__(self):
+        self._materialise()
+        return dict.__iter__(self)
+
+    def __len__(self):
+        self._materialise()
+        return dict.__len__(self)
+
 
 def _validate(means, quats, scales, opacities, colors, viewmats, Ks, sh_degree, backgrounds, render_mode,
               tile_size, rasterize_mode):
@@ -91,6 +148,8 @@ def rasterization(
     implementation always uses the dense ``[C,N,...]`` layout FusionSense asks for
     (``packed=False``) and reports ``camera_ids = gaussian_ids = None`` accordingly.
     ``sparse_grad`` is a packed-mode option and must be False."""
+    import time as _time
+    _t0 = _time.perf_counter()
     if sparse_grad:
         raise ValueError("sparse_grad=True requires packed mode, which this backend does not expose")
     N, C = _validate(means, quats, scales, opacities, colors, viewmats, Ks, sh_degree, backgrounds,
@@ -108,14 +167,27 @@ def rasterization(
 
     tile_width = math.ceil(width / tile_size)
     tile_height = math.ceil(height / tile_size)
-    with torch.no_grad():
-        tiles_per_gauss, isect_ids, flatten_ids, isect_offsets, rule_diff = ops.bin_and_sort(
-            means2d, radii, depths, tile_size, tile_width, tile_height, legacy=False)
-    # let the legacy normal pass (dn_model.py:644-653) reuse these lists when it is handed this
-    # frame's own xys / depths / radii (see frame_cache for why that is the faithful choice even
-    # for the rule_diff Gaussians whose bbox touches a tile edge exactly)
-    frame_cache.remember(means2d, depths, radii, width, height, tile_size, isect_offsets, flatten_ids, isect_ids,
-                         lists_valid_for_legacy=(C == 1))
+    lib = ops.load()
+    # Fast path (tile 16): only the (Gaussian, tile) pairs that can reach a pixel are binned, straight into their
+    # tile's bucket, and sorted per tile in LDS (ops.bin_live_*); the count's read-back overlaps the colour
+    # evaluation below.  gsplat's full lists are built lazily, if the caller ever reads them from ``meta``.
+    live_bins = (tile_size == 16 and ops.USE_LIVE_LISTS and ops.USE_BIN_LIVE
+                 and C * tile_width * tile_height <= lib.fsgs_bin_live_max_tiles())
+    count = None
+    rule_diff = None
+    if live_bins:
+        with torch.no_grad():
+            opac_c = opac.detach().contiguous()
+            count = ops.bin_live_count_async(means2d.detach(), radii, conics.detach(), opac_c, tile_width, tile_height)
+    else:
+        with torch.no_grad():
+            tiles_per_gauss, isect_ids, flatten_ids, isect_offsets, rule_diff = ops.bin_and_sort(
+                means2d, radii, depths, tile_size, tile_width, tile_height, legacy=False)
+        # let the legacy normal pass (dn_model.py:644-653) reuse these lists when it is handed this
+        # frame's own xys / depths / radii (see frame_cache for why that is the faithful choice even
+        # for the rule_diff Gaussians whose bbox touches a tile edge exactly)
+        frame_cache.remember(means2d, depths, radii, width, height, tile_size, isect_offsets, flatten_ids, isect_ids,
+                             lists_valid_for_legacy=(C == 1))
 
     want_depth = render_mode in ("RGB+D", "RGB+ED")
     only_depth = render_mode in ("D", "ED")
@@ -139,10 +211,19 @@ def rasterization(
     D = cols.shape[-1]
     expected_depth = render_mode in ("ED", "RGB+ED")
     fused_ed = expected_depth and D in (1, 3, 4) and tile_size == 16 and ops.USE_LIVE_LISTS
+    live_payload = live_offsets = None
+    if count is not None:
+        with torch.no_grad():
+            tiles_per_gauss, _, live_payload, live_offsets = ops.bin_live_finish(
+                count, means2d.detach(), radii, depths.detach(), conics.detach(), opac_c, tile_width, tile_height)
+        frame_cache.remember(means2d, depths, radii, width, height, tile_size, live_offsets, None, None,
+                             lists_valid_for_legacy=(C == 1), live_payload=live_payload)
+        isect_ids = flatten_ids = None
+        isect_offsets = live_offsets
     if D in (1, 3, 4):
         render, alphas, last_ids = ops._Rasterize.apply(
             means2d, conics, cols, opac, backgrounds, isect_offsets, flatten_ids, width, height, tile_size,
-            absgrad, isect_ids, fused_ed)
+            absgrad, isect_ids, fused_ed, live_payload)
     else:
         # arbitrary channel counts: composite in chunks of <=4 channels over the same lists
         if absgrad:
@@ -159,14 +240,14 @@ def rasterization(
                 bg = torch.cat([bg, torch.zeros_like(bg[..., :1])], dim=-1) if bg is not None else None
             r, alphas, last_ids = ops._Rasterize.apply(
                 means2d, conics, chunk.contiguous(), opac, bg, isect_offsets, flatten_ids, width, height,
-                tile_size, False, isect_ids)
+                tile_size, False, isect_ids, False, live_payload)
             outs.append(r[..., :w])
         render = torch.cat(outs, dim=-1)
 
     if expected_depth and not fused_ed:
         render = torch.cat([render[..., :-1], render[..., -1:] / alphas.clamp(min=1e-10)], dim=-1)
 
-    meta = {
+    eager = {
         "camera_ids": None,
         "gaussian_ids": None,
         "radii": radii,
@@ -177,15 +258,29 @@ def rasterization(
         "tile_width": tile_width,
         "tile_height": tile_height,
         "tiles_per_gauss": tiles_per_gauss,
-        "isect_ids": isect_ids,
-        "flatten_ids": flatten_ids,
-        "isect_offsets": isect_offsets,
         "width": width,
         "height": height,
         "tile_size": tile_size,
         "n_cameras": C,
-        # extras (not in gsplat's meta): let the legacy normal pass reuse this frame's sorted lists
+        # extras (not in gsplat's meta).  last_ids index the list the compositing walked: the live list on the fast
+        # path (live_payload / live_offsets), gsplat's full list otherwise
         "last_ids": last_ids,
-        "legacy_rule_diff": rule_diff,  # Gaussians the legacy trunc/+1 bbox rule would bin differently
+        "live_payload": live_payload,
+        "live_offsets": live_offsets,
     }
+    if live_payload is None:
+        eager.update(isect_ids=isect_ids, flatten_ids=flatten_ids, isect_offsets=isect_offsets,
+                     legacy_rule_diff=rule_diff)  # Gaussians the legacy trunc/+1 bbox rule would bin differently
+        meta = LazyMeta(eager, None)
+    else:
+        m2, rd, dp = means2d.detach(), radii, depths.detach()
+
+        def build():
+            with torch.no_grad():
+                _, ids, flat, offs, diff = ops.bin_and_sort(m2, rd, dp, tile_size, tile_width, tile_height, legacy=False)
+            return {"isect_ids": ids, "flatten_ids": flat, "isect_offsets": offs, "legacy_rule_diff": diff}
+
+        meta = LazyMeta(eager, build)
+    HOST_TIME["rasterization_s"] += _time.perf_counter() - _t0
+    HOST_TIME["rasterization_calls"] += 1
     return render, alphas, meta
