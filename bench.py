@@ -462,6 +462,21 @@ def main():
             "note": "the rest of the step is the reference's own torch glue, autograd and optimizers, untouched",
         }
         del d_tr
+        # integration.patch(): get_outputs on the fused node, but still on torch's autograd tape and under
+        # torch.optim.Adam objects stepped one by one, as nerfstudio's trainer does
+        p_tr = SplatTrainer({k: p.data for k, p in trainer.params.items()}, dev, sh_degree=3, fused=True, direct=False,
+                            loss_cfg=trainer.loss_cfg, strategy=d_st, torch_optimizers=True)
+        p_tr.step = trainer.step
+        p_tr.sh_degree_interval = trainer.sh_degree_interval
+        for s in range(5):
+            p_tr.train_step(cams[view_of(s)], targets[view_of(s)])
+        torch.cuda.synchronize()
+        t4 = time.perf_counter()
+        for s in range(nd):
+            p_tr.train_step(cams[view_of(s)], targets[view_of(s)])
+        torch.cuda.synchronize()
+        dropin_detail["patched_get_outputs_iters_per_s"] = round(nd / (time.perf_counter() - t4), 2)
+        del p_tr
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3

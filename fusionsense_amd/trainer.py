@@ -107,7 +107,7 @@ class SplatTrainer:
     def __init__(self, params: Dict[str, Tensor], device: torch.device, sh_degree: int = 3,
                  optim: Optional[OptimConfig] = None, fused_adam: bool = True, seed: int = 0,
                  strategy=None, fused: bool = True, sh_degree_interval: Optional[int] = None,
-                 direct: bool = True, loss_cfg=None, half_attributes: bool = False):
+                 direct: bool = True, loss_cfg=None, half_attributes: bool = False, torch_optimizers: bool = False):
         self.device = device
         # fused=True: get_outputs as one autograd node (fusionsense_amd/fused.py); False: the
         # reference's op-by-op caller through the drop-in rasterization()/rasterize_gaussians() surface
@@ -134,6 +134,9 @@ class SplatTrainer:
             k: torch.nn.Parameter(params[k].detach().to(device=device, dtype=torch.float32, copy=True).contiguous())
             for k in PARAM_ORDER}
         self.fused_adam = fused_adam and device.type == "cuda"
+        # torch_optimizers: step the eight torch.optim.Adam objects themselves (what nerfstudio's Optimizers does)
+        # instead of the one-launch libfsgs Adam — the configuration integration.patch() runs under
+        self.torch_optimizers = bool(torch_optimizers)
         self.optimizers: Dict[str, torch.optim.Adam] = {}
         for name in PARAM_ORDER:
             self.optimizers[name] = torch.optim.Adam(
@@ -294,7 +297,7 @@ class SplatTrainer:
         return step_no
 
     def _optimizer_step(self, names, step_no: Optional[int] = None) -> Optional[int]:
-        if self.fused and self.device.type == "cuda":
+        if self.fused and self.device.type == "cuda" and not self.torch_optimizers:
             return self._fused_adam_step(names, step_no)
         for name in names:
             self.optimizers[name].step()

@@ -628,3 +628,77 @@ def test_config5_full_size_half_storage(dev):
     assert math.isfinite(float(loss))
     for k in HALF_GROUPS:
         assert torch.equal(tr.half_mirrors()[k], tr.params[k].data.half()), k
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# integration.patch: DNSplatterModel.get_outputs on the fused node, against the reference's own get_outputs
+# ---------------------------------------------------------------------------------------------------------------
+class _FakeCameras:
+    def __init__(self, c2w, fx, fy, cx, cy, W, H):
+        self.camera_to_worlds = c2w[None]
+        self._k = torch.tensor([[[fx, 0.0, cx], [0.0, fy, cy], [0.0, 0.0, 1.0]]])
+        self.width, self.height = torch.tensor([[W]]), torch.tensor([[H]])
+        self.shape = (1,)
+        self.metadata = {"cam_idx": 3}
+
+    def rescale_output_resolution(self, f):
+        pass
+
+    def get_intrinsics_matrices(self):
+        return self._k
+
+
+@pytest.mark.parametrize("case", ["plain", "binary_anchor"])
+def test_patched_get_outputs_matches_reference_execution(dev, case):
+    """integration.get_outputs_fused bound to a model object, against what the reference's own get_outputs produced
+    on the same parameters (tests/golden/reference_model.npz; rasterizer = the CPU oracle there, the fused HIP node
+    here): the returned images, the binary-opacity write on the parameter, the model-side attributes, and the
+    parameter gradients with the touch anchors detached."""
+    import types
+    from fusionsense_amd import integration
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_model.npz"))
+    t = lambda k: torch.from_numpy(d[k])  # noqa: E731
+    names = ["means", "scales", "quats", "features_dc", "features_rest", "opacities"]
+    fx, fy, cx, cy, W, H = [float(v) for v in d["go.intr"]]
+    step = int(d[f"go.{case}.step"])
+
+    class Model:
+        training = True
+        crop_box = None
+        add_mask = None
+        get_outputs = None
+
+        def _get_downscale_factor(self):
+            return 1
+
+        def _get_background_color(self):
+            return torch.ones(3)
+
+    integration.patch(Model)
+    m = Model()
+    m.config = types.SimpleNamespace(use_binary_opacities=True, binary_opacities_threshold=0.9, warmup_length=500,
+                                     reset_alpha_every=30, refine_every=100, sh_degree=3, sh_degree_interval=1000,
+                                     rasterize_mode="classic", predict_normals=True)
+    m.step = step
+    m.gauss_params = {k: torch.nn.Parameter(t(f"go.in.{k}").to(dev)) for k in names}
+    m.camera_optimizer = types.SimpleNamespace(apply_to_camera=lambda cam: cam.camera_to_worlds)
+    if f"go.{case}.add_mask" in d.files:
+        m.add_mask = t(f"go.{case}.add_mask").to(dev)
+    cam = _FakeCameras(t("go.c2w"), fx, fy, cx, cy, int(W), int(H))
+    out = m.get_outputs(cam)
+    assert set(out) == {"rgb", "depth", "normal", "accumulation", "background"}
+    loss = sum((out[k] * t(f"go.w.{k}").to(dev)).mean() for k in ("rgb", "depth", "normal"))
+    loss.backward()
+    for k in ("rgb", "depth", "accumulation"):
+        assert rel_err(out[k], t(f"go.{case}.out.{k}")) < 2e-4, k
+    dn = (out["normal"].detach().cpu() - t(f"go.{case}.out.normal")).abs()
+    assert float(dn.mean()) < 1e-4 and float((dn > 1e-2).float().mean()) < 2e-3
+    assert torch.equal(m.gauss_params["opacities"].detach().cpu(), t(f"go.{case}.opacities_after"))
+    assert torch.allclose(m.gauss_params["normals"].detach().cpu(), t(f"go.{case}.normals_world"), atol=1e-5)
+    assert m.last_size == (int(H), int(W)) and m.camera is cam and m.camera_idx == 3
+    assert m.radii.shape == (260,) and m.xys.absgrad.shape == (1, 260, 2)
+    assert torch.equal(m.vis_indices, torch.where(m.radii > 0)[0])
+    for k in names:
+        g = m.gauss_params[k].grad
+        g = g.cpu() if g is not None else torch.zeros_like(t(f"go.in.{k}"))
+        assert rel_err(g, t(f"go.{case}.grad.{k}")) < 3e-3, (k, rel_err(g, t(f"go.{case}.grad.{k}")))
