@@ -369,7 +369,8 @@ isect_live_bin_kernel(int C, int N, const float *__restrict__ means2d, const int
                       const float *__restrict__ depths, const float *__restrict__ conics,
                       const float *__restrict__ opacities, int tw, int th, int T, int nb, int chunks,
                       int32_t *__restrict__ tiles_per_gauss, int32_t *__restrict__ table,
-                      const int32_t *__restrict__ offsets, uint64_t *__restrict__ buckets, BinProjArgs pj) {
+                      const int32_t *__restrict__ offsets, uint64_t *__restrict__ buckets, BinProjArgs pj,
+                      int bucket_cap = 0x7FFFFFFF) {
     extern __shared__ __attribute__((aligned(16))) unsigned char bin_smem[];
     BinLds &L = *reinterpret_cast<BinLds *>(bin_smem);
     int *slots = reinterpret_cast<int *>(bin_smem + sizeof(BinLds));
@@ -479,7 +480,9 @@ isect_live_bin_kernel(int C, int N, const float *__restrict__ means2d, const int
             const int64_t gidx = idx0 + o;
             const int c = (C == 1) ? 0 : (int)(gidx / N);
             const int slot = atomicAdd(&slots[c * n_tiles + y * tw + x], 1);
-            if (SCATTER)
+            // (slot >= bucket_cap only when the caller sized the buffers from an estimate that the frame exceeded:
+            // the offsets were clamped to it by tile_offsets_kernel, the frame is redone)
+            if (SCATTER && slot < bucket_cap)
                 buckets[slot] = ((uint64_t)L.depth[o] << 32) | ((uint64_t)(uint32_t)gidx << 4) | (uint64_t)m;
         }
     }
@@ -878,7 +881,7 @@ static int bin_live_emit_impl(int C, int N, const float *means2d, const int32_t 
     hipLaunchKernelGGL((isect_live_bin_kernel<true, MU, false>), dim3(nb), dim3(kBinThreads), bin_lds_bytes(T), s, C, \
                        N, means2d, radii, depths, conics, opacities, tile_width, tile_height, T, nb,                   \
                        bin_chunks((int64_t)C * N), nullptr, table, isect_offsets, reinterpret_cast<uint64_t *>(buckets), \
-                       BinProjArgs{})
+                       BinProjArgs{}, (int)n_live)
     if (bin_chunks((int64_t)C * N) > 1) FSGS_BIN_FILL(true); else FSGS_BIN_FILL(false);
 #undef FSGS_BIN_FILL
     rc = check_launch();

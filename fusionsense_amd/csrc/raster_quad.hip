@@ -59,7 +59,7 @@ raster_fwd_quad_kernel(int64_t cap, const float4 *__restrict__ packed, const int
                        float *__restrict__ render, float *__restrict__ alphas, int32_t *__restrict__ last_ids,
                        float4 *__restrict__ rec_out, int32_t *__restrict__ n_rec,
                        float *__restrict__ seg_state, int64_t seg_cap, int normalize_last,
-                       float *__restrict__ render_extra, float *__restrict__ max_last) {
+                       float *__restrict__ render_extra, float *__restrict__ max_last, int ends_on_device) {
     __shared__ QuadLds<E> S;
     constexpr int RS = E ? 4 : 3;
     // workgroup b runs on XCD b % 8: the four quadrants of a tile share its list and its Gaussians,
@@ -83,7 +83,9 @@ raster_fwd_quad_kernel(int64_t cap, const float4 *__restrict__ packed, const int
     bool done = !inside;
 
     const int l0 = tile_offsets[tile_lin];
-    const int l1 = (tile_lin == n_tiles_total - 1) ? (int)n_isects : tile_offsets[tile_lin + 1];
+    // (ends_on_device: tile_offsets holds n_tiles_total + 1 entries, the last one = the live total as the binning
+    // left it on the device — the caller did not wait for it and passed a CAPACITY as n_isects)
+    const int l1 = (tile_lin == n_tiles_total - 1 && !ends_on_device) ? (int)n_isects : tile_offsets[tile_lin + 1];
     // A quadrant's records go to stream q from position sbase on.  Padding can exceed the tile's own
     // entry count by at most 3 (last chunk only), hence the 4 spare positions per tile.
     const int64_t sbase = (int64_t)l0 + 4ll * tile_lin;
@@ -312,7 +314,11 @@ extern "C" int fsgs_raster_fwd_quad(int C, int D, const float *packed, const int
                                     float *render, float *alphas, int32_t *last_ids, float *records,
                                     int32_t *n_rec, float *seg_state, float *render_extra,
                                     float *max_last, fsgs_stream_t stream) {
-    if (C < 0 || width < 0 || height < 0 || n_isects < 0) return FSGS_EINVAL;
+    // n_isects < 0: -n_isects is the CAPACITY the caller sized records / seg_state for, and the lists' true end is
+    // isect_offsets[C * th * tw] on the device (fsgs_bin_live_count leaves it there): no host wait for the total
+    const int ends_on_device = n_isects < 0 ? 1 : 0;
+    if (ends_on_device) n_isects = -n_isects;
+    if (C < 0 || width < 0 || height < 0) return FSGS_EINVAL;
     if (C == 0 || width == 0 || height == 0) return FSGS_OK;
     if (n_isects > 0x7FFFFFF0ll) return FSGS_EINVAL;  // list indices are 32-bit (as in the reference)
     if (!isect_offsets || !render || !alphas || !last_ids || (n_isects > 0 && (!packed || !payload)))
@@ -331,7 +337,7 @@ extern "C" int fsgs_raster_fwd_quad(int C, int D, const float *packed, const int
     hipLaunchKernelGGL((raster_fwd_quad_kernel<DD, EE>), grid, dim3(256), 0, s, cap, pk, payload,                 \
                        isect_offsets, n_isects, backgrounds, width, height, tile_width, tile_height, (int)n_tiles, \
                        render, alphas, last_ids, rec, n_rec, seg_state, seg_cap, normalize_last, render_extra,     \
-                       max_last)
+                       max_last, ends_on_device)
     if (render_extra) {
         if (D != 4) return FSGS_EINVAL;  // the fused RGB+depth + normal-plane walk
         FSGS_FWD_QUAD(4, 3);

@@ -133,14 +133,24 @@ tile_scan_rows_kernel(int T, int nb, int32_t *__restrict__ table, int32_t *__res
 }
 
 // offsets[t] = sum of totals[0..t), offsets[T] = M   (one workgroup)
+// total_mapped (nullable): int32[4] in host-mapped pinned memory — [0] <- the TRUE total, [1] <- done flag,
+// [2] = capacity given by the host (0 = none): every offset is clamped to it, so that a caller who sized its list
+// buffers from an estimate instead of waiting for the total stays inside them (the lists are then truncated and the
+// caller, seeing [0] > [2], redoes the frame), [3] reserved.
 __global__ void __launch_bounds__(1024)
 tile_offsets_kernel(int T, const int32_t *__restrict__ totals, int32_t *__restrict__ offsets,
                     int32_t *__restrict__ total_mapped) {
     __shared__ int wsum[16];
     __shared__ int carry_s;
+    __shared__ int cap_s;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    if (tid == 0) carry_s = 0;
+    if (tid == 0) {
+        carry_s = 0;
+        const int c = total_mapped ? total_mapped[2] : 0;
+        cap_s = c > 0 ? c : 0x7FFFFFFF;
+    }
     __syncthreads();
+    const int cap = cap_s;
     for (int base = 0; base < T; base += 1024) {
         const int i = base + tid;
         const int v = (i < T) ? totals[i] : 0;
@@ -155,13 +165,13 @@ tile_offsets_kernel(int T, const int32_t *__restrict__ totals, int32_t *__restri
         int wbase = 0;
         for (int k = 0; k < w; ++k) wbase += wsum[k];
         const int carry = carry_s;
-        if (i < T) offsets[i] = carry + wbase + inc - v;
+        if (i < T) offsets[i] = min(carry + wbase + inc - v, cap);
         __syncthreads();
         if (tid == 1023) carry_s = carry + wbase + inc;
         __syncthreads();
     }
     if (tid == 0) {
-        offsets[T] = carry_s;
+        offsets[T] = min(carry_s, cap);
         // (optional) the total straight into host-mapped pinned memory: no device-to-host copy launch for the one
         // number the host waits for
         if (total_mapped) {

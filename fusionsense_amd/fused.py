@@ -61,6 +61,12 @@ class FrameInfo:
         # BASELINE config #5: IEEE-half mirrors of scales / quats / features_dc / features_rest / opacities that the
         # render kernels read instead of the fp32 masters (the trainer keeps them in step with the parameters)
         self.half: Optional[Dict[str, Tensor]] = None
+        # no-wait binning (the trainer's tape-free step): list buffers are sized for this many live pairs instead of
+        # waiting for the frame's count; ``pending_count`` is then checked by the caller once the forward's launches
+        # are enqueued (ops.bin_live_check), ``n_live`` is the true total after that check
+        self.live_capacity = 0
+        self.pending_count = None
+        self.n_live: Optional[int] = None
 
     @property
     def flatten_ids(self):
@@ -144,7 +150,7 @@ class _FusedGetOutputs(torch.autograd.Function):
             count = ops.project_bin_live_count_async(
                 means, quats, scales, opacities, bthr, cam["viewmat"], cam["K"], W, H, tw, th,
                 dict(scales_exp=scales_exp, opac_sig=opac_sig, radii=radii, means2d=means2d, depths=depths,
-                     conics=conics), half=hm)
+                     conics=conics), half=hm, capacity=int(info.live_capacity))
         elif hm is not None:
             _run(lib.fsgs_project_fwd_act_h16, (1, N, ptr(means), ptr(hm["quats"]), ptr(hm["scales"]),
                                                ptr(hm["opacities"]), ptr(opacities), 0 if bthr is None else 1,
@@ -195,6 +201,11 @@ class _FusedGetOutputs(torch.autograd.Function):
             colours_and_packing()
         rule_diff = 0
         M = flatten_ids.numel()
+        no_wait = direct_bins and count.get("capacity", 0) > 0  # M is then the capacity, offsets has T + 1 entries
+        if no_wait:
+            info.pending_count = count
+        else:
+            info.n_live = M
 
         needs_bwd = any(ctx.needs_input_grad[:6])
         a = lambda n: (n + 255) // 256 * 256  # noqa: E731
@@ -215,7 +226,8 @@ class _FusedGetOutputs(torch.autograd.Function):
         alphas = torch.empty(1, H, W, 1, **f32)
         last_ids = torch.empty(1, H, W, dtype=torch.int32, device=dev)
         render_extra = torch.empty(1, H, W, 3, **f32)
-        _run(lib.fsgs_raster_fwd_quad, (1, 4, ptr(packed), ptr(flatten_ids), ptr(offsets), M, None, W, H, tw, th, 1,
+        _run(lib.fsgs_raster_fwd_quad, (1, 4, ptr(packed), ptr(flatten_ids), ptr(offsets), -M if no_wait else M, None,
+                                       W, H, tw, th, 1,
                                        ptr(render), ptr(alphas), ptr(last_ids), ptr(records), ptr(n_rec),
                                        ptr(seg_state), ptr(render_extra), ptr(max_last), sp),
              "fsgs_raster_fwd_quad", "_d4e3")
@@ -243,7 +255,8 @@ class _FusedGetOutputs(torch.autograd.Function):
 
         info.radii, info.means2d, info.depths, info.conics = radii, means2d, depths, conics
         info.tiles_per_gauss, info.isect_ids, info.payload = tpg, isect_ids, flatten_ids
-        info.isect_offsets, info.last_ids, info.normals_world = offsets, last_ids, normals_world
+        info.isect_offsets = offsets[:tw * th].view(1, th, tw) if no_wait else offsets
+        info.last_ids, info.normals_world = last_ids, normals_world
         info.legacy_rule_diff = rule_diff
 
         if needs_bwd:
@@ -419,7 +432,7 @@ def fused_step_forward_backward(gauss_params: Dict[str, Tensor], camera: Camera,
                                 stats_out: Optional[dict] = None, add_mask: Optional[Tensor] = None,
                                 binary_threshold: Optional[float] = None, ssim_lambda: float = 0.2,
                                 w_depth: float = 0.2, w_normal: float = 0.1, pre_sh=None, sh_factors_out=None,
-                                fusion=None, half: Optional[Dict[str, Tensor]] = None):
+                                fusion=None, half: Optional[Dict[str, Tensor]] = None, live_capacity: int = 0):
     """get_outputs -> loss -> both backward passes, without the autograd tape.  The parameter gradients land in
     ``grad_out`` (the trainer's slab views).  Returns (loss 0-d tensor, outputs dict).
     ``target`` is either the benchmark targets of BASELINE config #2 (dict rgb / depth / normal: L1 + SSIM on rgb,
@@ -436,6 +449,22 @@ def fused_step_forward_backward(gauss_params: Dict[str, Tensor], camera: Camera,
     info.pre_sh = pre_sh
     info.sh_factors_out = sh_factors_out
     info.half = half
+    info.live_capacity = int(live_capacity)
+
+    def check_live_total(ctx):
+        """No-wait binning: the forward's launches are enqueued, now look at the frame's live total (it has normally
+        long arrived).  On overflow the truncated frame is abandoned before anything with side effects has run."""
+        if info.pending_count is None:
+            return
+        try:
+            info.n_live = ops.bin_live_check(info.pending_count)
+        except ops.LiveListOverflow:
+            WORKSPACE.give(getattr(ctx, "arena", None))
+            ctx.arena = None
+            raise
+        info.pending_count = None
+        info.payload = info.payload[:info.n_live]
+
     if add_mask is not None:
         info.frozen = add_mask.to(device=dev, dtype=torch.uint8).contiguous()
     if fusion is not None:
@@ -449,6 +478,7 @@ def fused_step_forward_backward(gauss_params: Dict[str, Tensor], camera: Camera,
             lctx = _DirectCtx((True, True, True, False) + (False,) * 7)
             loss = ops._FusionLoss.forward(lctx, rgb, depth, normal, gauss_params["scales"].data, target, cfg,
                                            info.normals_world, touch_idx, touch_normals, seed_grad, True)
+            check_live_total(ctx)
             v = ops._FusionLoss.backward(lctx, seed_grad)
             _FusedGetOutputs.backward(ctx, v[0], v[1], v[2], None)
             g_min = lctx.g[3]
@@ -472,6 +502,7 @@ def fused_step_forward_backward(gauss_params: Dict[str, Tensor], camera: Camera,
         loss = ops._TrainLoss.forward(lctx, rgb, target["rgb"], depth, target["depth"], normal if has_n else None,
                                       target["normal"] if has_n else None, float(ssim_lambda), float(w_depth),
                                       float(w_normal), seed=seed_grad, aux_done=info.aux_loss)
+        check_live_total(ctx)
         v = ops._TrainLoss.backward(lctx, seed_grad)
         _FusedGetOutputs.backward(ctx, v[0], v[2], v[4], None)
     out = {"rgb": rgb, "depth": depth, "normal": normal, "accumulation": alpha, "background": background,

@@ -287,13 +287,14 @@ def _pinned_i32(dev) -> Tensor:
     writes the total.  The tensor carries a numpy view (``._np``) for cheap polling."""
     ring = _PINNED.get(str(dev) + ":i32")
     if ring is None:
-        bufs = [torch.zeros(2, dtype=torch.int32).pin_memory() for _ in range(4)]
+        bufs = [torch.zeros(4, dtype=torch.int32).pin_memory() for _ in range(4)]  # [total, done, capacity, -]
         for b in bufs:
             b._np = b.numpy()
         ring = _PINNED.setdefault(str(dev) + ":i32", dict(bufs=bufs, i=0))
     ring["i"] = (ring["i"] + 1) % len(ring["bufs"])
     buf = ring["bufs"][ring["i"]]
     buf._np[1] = 0
+    buf._np[2] = 0  # no capacity: the offsets are exact
     return buf
 
 
@@ -341,7 +342,8 @@ def bin_live_count_async(means2d: Tensor, radii: Tensor, conics: Tensor, opaciti
 
 def project_bin_live_count_async(means: Tensor, quats: Tensor, log_scales: Tensor, opac_logit: Tensor,
                                  binary_threshold, viewmat: Tensor, K: Tensor, width: int, height: int,
-                                 tile_width: int, tile_height: int, out: dict, half: Optional[dict] = None) -> dict:
+                                 tile_width: int, tile_height: int, out: dict, half: Optional[dict] = None,
+                                 capacity: int = 0) -> dict:
     """``fsgs_project_fwd_act`` + ``bin_live_count_async`` in one launch chain (one camera): the count pass projects
     its Gaussians itself.  ``out`` holds the projection's output tensors (scales_exp, opac_sig, radii [1,N],
     means2d, depths, conics).  Returns the same state ``bin_live_count_async`` does."""
@@ -354,6 +356,10 @@ def project_bin_live_count_async(means: Tensor, quats: Tensor, log_scales: Tenso
     tbytes = lib.fsgs_bin_live_table_bytes(1, N, tile_width, tile_height)
     table = WORKSPACE.take(tbytes, dev)
     pinned = _pinned_i32(dev)
+    if capacity > 0:
+        # the caller will NOT wait for the live total before the second pass: it sizes the lists for `capacity`
+        # entries, the offsets kernel clamps to it (fsgs.h: n_live_mapped[2]) and bin_live_finish checks later
+        pinned._np[2] = int(capacity)
     if half is not None:  # BASELINE config #5: quats / log-scales / opacity logits read from their half mirrors
         _run(lib.fsgs_project_bin_live_count_h16,
              (N, ptr(means), ptr(half["quats"]), ptr(half["scales"]), ptr(half["opacities"]), ptr(opac_logit),
@@ -363,7 +369,7 @@ def project_bin_live_count_async(means: Tensor, quats: Tensor, log_scales: Tenso
               ptr(tpg), ptr(offsets), ptr(table), tbytes, pinned.data_ptr(), stream_ptr(dev)), "fsgs_isect_count_live")
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(dev))
-        return dict(direct=True, tpg=tpg, offsets=offsets, table=table, pinned=pinned, event=ev, T=T)
+        return dict(direct=True, tpg=tpg, offsets=offsets, table=table, pinned=pinned, event=ev, T=T, capacity=capacity)
     _run(lib.fsgs_project_bin_live_count,
          (N, ptr(means), ptr(quats), ptr(log_scales), ptr(opac_logit), 0 if binary_threshold is None else 1,
           0.0 if binary_threshold is None else float(binary_threshold), ptr(viewmat), ptr(K), width, height, 0.3, 0.01,
@@ -372,7 +378,25 @@ def project_bin_live_count_async(means: Tensor, quats: Tensor, log_scales: Tenso
           pinned.data_ptr(), stream_ptr(dev)), "fsgs_isect_count_live")
     ev = torch.cuda.Event()
     ev.record(torch.cuda.current_stream(dev))
-    return dict(direct=True, tpg=tpg, offsets=offsets, table=table, pinned=pinned, event=ev, T=T)
+    return dict(direct=True, tpg=tpg, offsets=offsets, table=table, pinned=pinned, event=ev, T=T, capacity=capacity)
+
+
+class LiveListOverflow(RuntimeError):
+    """A frame held more live pairs than the capacity its buffers were sized for (no-wait binning): its lists were
+    truncated on the device; ``needed`` is the true total."""
+
+    def __init__(self, needed: int, capacity: int):
+        super().__init__(f"live pairs {needed} > capacity {capacity}")
+        self.needed, self.capacity = needed, capacity
+
+
+def bin_live_check(st: dict) -> int:
+    """The deferred look at a no-wait frame's live total (by now it has normally long arrived in mapped memory).
+    Returns the total; raises LiveListOverflow if it exceeded the frame's capacity."""
+    M = _wait_total(st)
+    if st.get("capacity", 0) and M > st["capacity"]:
+        raise LiveListOverflow(M, st["capacity"])
+    return M
 
 
 def bin_live_finish(st: dict, means2d: Tensor, radii: Tensor, depths: Tensor, conics: Tensor, opacities: Tensor,
@@ -384,7 +408,9 @@ def bin_live_finish(st: dict, means2d: Tensor, radii: Tensor, depths: Tensor, co
     dev = means2d.device
     Cn, N = radii.shape
     T = st["T"]
-    M = _wait_total(st)
+    # no-wait mode: everything below is sized and launched for the capacity; the true total stays on the device
+    # (isect_offsets[T], clamped to the capacity) and the caller checks it later with bin_live_check
+    M = st["capacity"] if st.get("capacity", 0) else _wait_total(st)
     dense = not use_tile_sort(M, T)  # mean bucket beyond the LDS tiers
     split = BIN_SPLIT == "always" or (BIN_SPLIT == "auto" and dense)
     _DENSE_HINT[(str(dev), N, T)] = dense and not split
@@ -411,6 +437,8 @@ def bin_live_finish(st: dict, means2d: Tensor, radii: Tensor, depths: Tensor, co
                                      ptr(pay_s), stream_ptr(dev)), "fsgs_tile_sort")
         WORKSPACE.give(buckets)
     WORKSPACE.give(st["table"])
+    if st.get("capacity", 0):
+        return st["tpg"], None, pay_s, st["offsets"]  # all T + 1 entries: the lists' end lives in the last one
     return st["tpg"], None, pay_s, st["offsets"][:T].view(Cn, tile_height, tile_width)
 
 

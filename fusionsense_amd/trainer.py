@@ -167,6 +167,13 @@ class SplatTrainer:
         if self.half_attributes:
             assert fused and device.type == "cuda", "half attribute storage runs on the fused HIP path"
             self.factored_features = False  # (the factored exchange rebuilds from fp32 features)
+        # No host wait inside the tape-free step: the frame's list buffers are sized from the largest live-pair count
+        # this (N, tiles) shape has shown so far (+ 25 %), the kernels take the true total from the device, and the
+        # host looks at it only after the forward's launches are enqueued; a frame that exceeds the estimate is
+        # redone with exact sizes (ops.LiveListOverflow).  FSGS_NO_WAIT=0 restores the wait in front of the bucket fill.
+        self.no_wait = os.environ.get("FSGS_NO_WAIT", "1") != "0"
+        self._live_caps: Dict = {}
+        self.live_overflows = 0
         self._factors = None
         self._pending = None
         self.step = 0
@@ -420,13 +427,26 @@ class SplatTrainer:
             from .fused import fused_step_forward_backward
             stats, add_mask, bthr = self._frame_state(camera, True)
             factors = self._factor_buffers(optimizer_step)
-            loss, out = fused_step_forward_backward(self.params, camera, target, self._sh_degree_now(), self.device,
-                                                    self.slab.views, self._one, stats_out=stats, add_mask=add_mask,
-                                                    binary_threshold=bthr,
-                                                    pre_sh=self.flush if self._pending is not None else None,
-                                                    sh_factors_out=factors[0] if factors else None,
-                                                    fusion=((self.loss_cfg,) + self._touch_rows()) if is_fb else None,
-                                                    half=self.half_mirrors())
+            from .ops import LiveListOverflow
+            cap_key = (self.num_gaussians(), camera.width, camera.height)
+            cap = self._live_caps.get(cap_key, 0) if self.no_wait else 0
+            for attempt in (0, 1):
+                try:
+                    loss, out = fused_step_forward_backward(
+                        self.params, camera, target, self._sh_degree_now(), self.device, self.slab.views, self._one,
+                        stats_out=stats, add_mask=add_mask, binary_threshold=bthr,
+                        pre_sh=self.flush if self._pending is not None else None,
+                        sh_factors_out=factors[0] if factors else None,
+                        fusion=((self.loss_cfg,) + self._touch_rows()) if is_fb else None,
+                        half=self.half_mirrors(), live_capacity=cap)
+                    break
+                except LiveListOverflow as e:  # rare: the frame outgrew the estimate -> once more, with exact sizes
+                    self.live_overflows += 1
+                    self._live_caps[cap_key] = int(e.needed * 1.25) + 4096
+                    cap = 0
+            n_live = out["info"].n_live
+            if n_live is not None and self.no_wait:
+                self._live_caps[cap_key] = max(self._live_caps.get(cap_key, 0), int(n_live * 1.25) + 4096)
             self._factors_used = factors
         else:
             if not self.fused:

@@ -283,9 +283,14 @@ int fsgs_tile_sort(int64_t n, const int64_t *isect_ids, const int32_t *payload, 
  *       the number of live pairs (copy it to the host to size the second call's buffers).
  *   fsgs_bin_live_emit: enumerates again, drops every live pair into its tile's bucket and sorts the
  *       buckets on (depth, flatten id): payload_sorted [n_live] = quadrant mask << 28 | flatten id.
- * n_live_mapped (nullable): a DEVICE-ACCESSIBLE HOST pointer to TWO ints (mapped pinned memory): [0] receives the
+ * n_live_mapped (nullable): a DEVICE-ACCESSIBLE HOST pointer to FOUR ints (mapped pinned memory): [0] receives the
  * number of live pairs, then [1] is set to 1 (system-scope release) by the last kernel of the call: a caller that
- * cleared [1] beforehand can poll it instead of waiting for the stream; no copy launch.
+ * cleared [1] beforehand can poll it instead of waiting for the stream; no copy launch.  [2] (input, 0 = none) is a
+ * CAPACITY: every entry of isect_offsets, the last one included, is clamped to it, while [0] still receives the
+ * true total.  A caller that sizes the second call's buffers from an estimate (n_live := the capacity, for
+ * fsgs_bin_live_emit and the kernels after it; fsgs_raster_fwd_quad with n_isects = -capacity) therefore needs no
+ * host wait between the two calls, stays inside its buffers whatever the frame holds, and finds out from
+ * [0] > [2] — whenever it next looks — that the lists were truncated and the frame must be redone.  [3] reserved.
  * table_scratch: fsgs_bin_live_table_bytes(C, N, tw, th) bytes, untouched between the two calls;
  * buckets: n_live 64-bit words.  C*th*tw <= fsgs_bin_live_max_tiles(). */
 int fsgs_bin_live_max_tiles(void);

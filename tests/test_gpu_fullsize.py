@@ -503,3 +503,51 @@ def test_two_ranks_with_densification_stay_identical(mode):
             assert attempt == 0, "2-rank run hung twice:\n" + out[-3000:]
     assert p.returncode == 0, out[-3000:]
     assert out.count(": ok, N ") == 2, out[-2000:]
+
+
+def test_no_wait_step_is_bit_identical_and_survives_overflow(dev, full_scene):
+    """The tape-free step without the host wait in front of the bucket fill (list buffers sized from earlier frames'
+    live counts, the true total read from the device, the host's look at it deferred until the forward is enqueued):
+    lists, images and every statistic are bit-identical to the waiting path; a frame that exceeds a (deliberately
+    tiny) capacity is detected, redone with exact sizes and leaves no trace in the statistics."""
+    from fusionsense_amd import ops
+    from fusionsense_amd.splatfacto import DensifyStrategy, SplatfactoConfig
+    from fusionsense_amd.trainer import PARAM_ORDER, SplatTrainer
+    params, cams = full_scene
+    g = torch.Generator().manual_seed(4)
+    tgt = {"rgb": torch.rand(RES, RES, 3, generator=g).to(dev), "depth": torch.rand(RES, RES, 1, generator=g).to(dev) * 4,
+           "normal": torch.rand(RES, RES, 3, generator=g).to(dev)}
+
+    def run(no_wait, poison_cap=None):
+        st = DensifyStrategy(SplatfactoConfig(), num_train_data=2, stats_only=True)
+        tr = SplatTrainer(params, dev, sh_degree=3, strategy=st)
+        tr.no_wait = no_wait
+        outs = []
+        for it in range(4):
+            if poison_cap is not None and it == 2:
+                for k in tr._live_caps:
+                    tr._live_caps[k] = poison_cap  # far too small: the next frame overflows
+            loss, out = tr.train_step(cams[it % 2], tgt)
+            outs.append((float(loss), out["rgb"].clone(), out["info"].payload.clone(), out["info"].isect_offsets.clone(),
+                         out["info"].n_live))
+        return tr, st, outs
+
+    a, sa, oa = run(False)
+    b, sb, ob = run(True)
+    assert b._live_caps and b.live_overflows == 0
+    c, sc, oc = run(True, poison_cap=1000)
+    assert c.live_overflows == 1
+    for ref, other, so in ((oa, ob, sb), (oa, oc, sc)):
+        for it, ((l0, rgb0, pay0, off0, n0), (l1, rgb1, pay1, off1, n1)) in enumerate(zip(ref, other)):
+            assert n1 == pay1.numel() and off0.shape == off1.shape
+            if it == 0:  # same parameters: the same bits
+                assert n0 == n1 and torch.equal(pay0, pay1) and torch.equal(off0, off1) and torch.equal(rgb0, rgb1)
+            else:  # (the parameters have been stepped with gradients summed by float atomics: equal to their noise)
+                assert abs(n0 - n1) <= 1e-3 * n0 and float((rgb0 - rgb1).abs().max()) < 5e-3
+        # statistics: exact counters, float sums to the atomics' reordering
+        assert torch.equal(sa.vis_counts, so.vis_counts) and torch.equal(sa.max_2Dsize, so.max_2Dsize)
+        assert rel_err(so.xys_grad_norm, sa.xys_grad_norm) < 1e-3
+    for k in PARAM_ORDER:
+        for tr in (b, c):
+            d = (a.params[k].data - tr.params[k].data).abs()
+            assert float((d > 2e-5).float().mean()) < 2e-2, k  # (Adam turns atomics noise around zero gradients into +-lr)
