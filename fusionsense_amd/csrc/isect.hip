@@ -363,7 +363,7 @@ struct BinProjArgs {
     int attr_half;
 };
 
-template <bool SCATTER, bool MULTI, bool PROJ>
+template <bool SCATTER, bool MULTI, bool PROJ, bool HALF = false>
 __global__ void __launch_bounds__(kBinThreads)
 isect_live_bin_kernel(int C, int N, const float *__restrict__ means2d, const int32_t *__restrict__ radii,
                       const float *__restrict__ depths, const float *__restrict__ conics,
@@ -393,19 +393,19 @@ isect_live_bin_kernel(int C, int N, const float *__restrict__ means2d, const int
         if (PROJ && idx < total) {
             const int64_t n = idx;  // (one camera)
             float ls_in[3];
-            ld_attr3(pj.log_scales, n, pj.attr_half, ls_in);
+            ld_attr3(pj.log_scales, n, HALF ? 1 : 0, ls_in);
             const float s_act[3] = {expf(ls_in[0]), expf(ls_in[1]), expf(ls_in[2])};
             pj.scales_out[n * 3 + 0] = s_act[0]; pj.scales_out[n * 3 + 1] = s_act[1]; pj.scales_out[n * 3 + 2] = s_act[2];
-            float ol = pj.attr_half ? __half2float(pj.opac_logit_h[n]) : pj.opac_logit[n];
+            float ol = HALF ? __half2float(pj.opac_logit_h[n]) : pj.opac_logit[n];
             if (pj.binarise) {  // the binary-opacity write of get_outputs (dn_model.py:492-503), on the parameter itself
                 ol = (ol >= pj.binary_threshold) ? 1.f : 0.f;
-                if (pj.opac_logit) pj.opac_logit[n] = ol;
-                if (pj.attr_half) pj.opac_logit_h[n] = __float2half(ol);
+                if (!HALF || pj.opac_logit) pj.opac_logit[n] = ol;
+                if (HALF) pj.opac_logit_h[n] = __float2half(ol);
             }
             const float o_act = 1.f / (1.f + expf(-ol));
             pj.opac_out[n] = o_act;
             const ProjOut po = project_one(pj.means[n * 3 + 0], pj.means[n * 3 + 1], pj.means[n * 3 + 2],
-                                           ld_attr4(pj.quats, n, pj.attr_half), s_act, pj.viewmat, pj.K,
+                                           ld_attr4(pj.quats, n, HALF ? 1 : 0), s_act, pj.viewmat, pj.K,
                                            pj.width, pj.height, pj.eps2d, pj.near_plane, pj.far_plane, pj.radius_clip);
             pj.radii[n] = po.radius;
             reinterpret_cast<float2 *>(pj.means2d)[n] = make_float2(po.u, po.v);
@@ -782,11 +782,15 @@ static int project_bin_live_count_impl(int N, const float *means, const void *qu
     const BinProjArgs pj = {means, quats, log_scales, viewmat, K, opac_logit, scales_out, opac_out, means2d, depths,
                             conics, radii, width, height, binarise, eps2d, near_plane, far_plane, radius_clip,
                             binary_threshold, reinterpret_cast<__half *>(opac_logit_h), attr_half};
-#define FSGS_BIN_PCOUNT(MU)                                                                                         \
-    hipLaunchKernelGGL((isect_live_bin_kernel<false, MU, true>), dim3(nb), dim3(kBinThreads), bin_lds_bytes(T), s, 1, \
+#define FSGS_BIN_PCOUNT(MU, HF)                                                                                     \
+    hipLaunchKernelGGL((isect_live_bin_kernel<false, MU, true, HF>), dim3(nb), dim3(kBinThreads), bin_lds_bytes(T), s, 1, \
                        N, nullptr, nullptr, nullptr, nullptr, nullptr, tile_width, tile_height, T, nb,                 \
                        bin_chunks(total), tiles_per_gauss, table, nullptr, nullptr, pj)
-    if (bin_chunks(total) > 1) FSGS_BIN_PCOUNT(true); else FSGS_BIN_PCOUNT(false);
+    if (attr_half) {
+        if (bin_chunks(total) > 1) FSGS_BIN_PCOUNT(true, true); else FSGS_BIN_PCOUNT(false, true);
+    } else {
+        if (bin_chunks(total) > 1) FSGS_BIN_PCOUNT(true, false); else FSGS_BIN_PCOUNT(false, false);
+    }
 #undef FSGS_BIN_PCOUNT
     rc = check_launch();
     if (rc != FSGS_OK) return rc;

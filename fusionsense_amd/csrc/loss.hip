@@ -38,6 +38,7 @@ __device__ __forceinline__ float block_sum_256(float v, float *lds4) {
 }
 
 // partials[2*blk] = sum |pred-gt| of this (tile, channel), partials[2*blk+1] = sum of its interior SSIM values
+template <bool MASKED>
 __global__ void __launch_bounds__(256)
 ssim_l1_fwd_kernel(int H, int W, const float *__restrict__ pred, const float *__restrict__ gt,
                    const float *__restrict__ mask, float *__restrict__ dm_dmu1, float *__restrict__ dm_dsigma1,
@@ -60,9 +61,14 @@ ssim_l1_fwd_kernel(int H, int W, const float *__restrict__ pred, const float *__
         if (i < kLH * kLH && y >= 0 && y < H && x >= 0 && x < W) {
             // mask (FusionSense object mask, nullable): both images are multiplied by it first
             // (splatfacto get_loss_dict, called at /root/reference/dn_splatter/dn_model.py:683)
-            const float m = mask ? mask[(int64_t)y * W + x] : 1.f;
-            hp[it] = pred[((int64_t)y * W + x) * 3 + ch] * m;
-            hg[it] = gt[((int64_t)y * W + x) * 3 + ch] * m;
+            if (MASKED) {
+                const float m = mask[(int64_t)y * W + x];
+                hp[it] = pred[((int64_t)y * W + x) * 3 + ch] * m;
+                hg[it] = gt[((int64_t)y * W + x) * 3 + ch] * m;
+            } else {
+                hp[it] = pred[((int64_t)y * W + x) * 3 + ch];
+                hg[it] = gt[((int64_t)y * W + x) * 3 + ch];
+            }
         }
     }
 #pragma unroll
@@ -198,6 +204,7 @@ __device__ __forceinline__ void combine_partials(const CombineArgs &a, float *__
 }
 
 // v_pred = g_l1 * sign(pred-gt) + g_ssim * (G*dm_dmu1 + 2 pred G*dm_dsigma1 + gt G*dm_dsigma12)
+template <bool MASKED>
 __global__ void __launch_bounds__(256)
 ssim_l1_bwd_kernel(int H, int W, const float *__restrict__ pred, const float *__restrict__ gt,
                    const float *__restrict__ mask, const float *__restrict__ dm_dmu1, const float *__restrict__ dm_dsigma1,
@@ -235,8 +242,9 @@ ssim_l1_bwd_kernel(int H, int W, const float *__restrict__ pred, const float *__
     for (int o = 0; o < 4; ++o) {
         const int y = y0 + ry + o;
         const int64_t op = (int64_t)min(y, H - 1) * W + min(x, W - 1);
-        own_m[o] = mask ? mask[op] : 1.f;
-        own_p[o] = pred[op * 3 + ch] * own_m[o]; own_g[o] = gt[op * 3 + ch] * own_m[o];
+        own_m[o] = MASKED ? mask[op] : 1.f;
+        own_p[o] = MASKED ? pred[op * 3 + ch] * own_m[o] : pred[op * 3 + ch];
+        own_g[o] = MASKED ? gt[op * 3 + ch] * own_m[o] : gt[op * 3 + ch];
     }
     const float up = v_loss[0];
 #pragma unroll
@@ -304,8 +312,8 @@ ssim_l1_bwd_kernel(int H, int W, const float *__restrict__ pred, const float *__
         const float p = own_p[o], g = own_g[o];
         const float d = p - g;
         const float sgn = (d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f);
-        v_pred[((int64_t)y * W + x) * 3 + ch] =
-            own_m[o] * up * (g_l1 * sgn + g_ssim * (out[o][0] + 2.f * p * out[o][1] + g * out[o][2]));
+        const float gv = up * (g_l1 * sgn + g_ssim * (out[o][0] + 2.f * p * out[o][1] + g * out[o][2]));
+        v_pred[((int64_t)y * W + x) * 3 + ch] = MASKED ? own_m[o] * gv : gv;
     }
 }
 
@@ -459,8 +467,12 @@ extern "C" int fsgs_ssim_l1_fwd_masked(int H, int W, const float *pred, const fl
     if (H < 11 || W < 11) return FSGS_EINVAL;
     if (!pred || !gt || !dm_dmu1 || !dm_dsigma1 || !dm_dsigma12 || !sums) return FSGS_EINVAL;
     hipStream_t s = as_stream(stream);
-    hipLaunchKernelGGL(ssim_l1_fwd_kernel, dim3(ceil_div(W, kLT), ceil_div(H, kLT), 3), dim3(256), 0, s,
-                       H, W, pred, gt, mask, dm_dmu1, dm_dsigma1, dm_dsigma12, sums);
+    if (mask)
+        hipLaunchKernelGGL(ssim_l1_fwd_kernel<true>, dim3(ceil_div(W, kLT), ceil_div(H, kLT), 3), dim3(256), 0, s,
+                           H, W, pred, gt, mask, dm_dmu1, dm_dsigma1, dm_dsigma12, sums);
+    else
+        hipLaunchKernelGGL(ssim_l1_fwd_kernel<false>, dim3(ceil_div(W, kLT), ceil_div(H, kLT), 3), dim3(256), 0, s,
+                           H, W, pred, gt, mask, dm_dmu1, dm_dsigma1, dm_dsigma12, sums);
     return check_launch();
 }
 
@@ -497,8 +509,12 @@ extern "C" int fsgs_ssim_l1_bwd_masked(int H, int W, const float *pred, const fl
         const int rc = fill_combine_args(a, n_terms, partials, rows, cols, weights, bias);
         if (rc != FSGS_OK) return rc;
     }
-    hipLaunchKernelGGL(ssim_l1_bwd_kernel, dim3(ceil_div(W, kLT), ceil_div(H, kLT), loss_out ? 4 : 3), dim3(256), 0,
-                       as_stream(stream), H, W, pred, gt, mask, dm_dmu1, dm_dsigma1, dm_dsigma12, v_loss, g_l1,
-                       g_ssim, v_pred, a, loss_out);
+    const dim3 grid(ceil_div(W, kLT), ceil_div(H, kLT), loss_out ? 4 : 3);
+    if (mask)
+        hipLaunchKernelGGL(ssim_l1_bwd_kernel<true>, grid, dim3(256), 0, as_stream(stream), H, W, pred, gt, mask,
+                           dm_dmu1, dm_dsigma1, dm_dsigma12, v_loss, g_l1, g_ssim, v_pred, a, loss_out);
+    else
+        hipLaunchKernelGGL(ssim_l1_bwd_kernel<false>, grid, dim3(256), 0, as_stream(stream), H, W, pred, gt, mask,
+                           dm_dmu1, dm_dsigma1, dm_dsigma12, v_loss, g_l1, g_ssim, v_pred, a, loss_out);
     return check_launch();
 }
