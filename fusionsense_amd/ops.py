@@ -559,7 +559,13 @@ class _SHColors(torch.autograd.Function):
         _run(lib.fsgs_sh_bwd, (Cn, N, K, degree, ptr(means), ptr(campos), ptr(coeffs), ptr(radii), D,
                               ptr(v_colors), ptr(v_coeffs), ptr(v_means), ptr(v_depths), stream_ptr(dev)),
               "fsgs_sh_bwd")
-        return v_means, v_coeffs, None, None, v_depths, None
+        v_campos = None
+        if ctx.needs_input_grad[2]:
+            # dirs = means - campos: the camera centre receives minus the sum of the per-Gaussian direction gradients
+            # (v_means holds exactly the SH share here: it was zero before the launch).  One camera.
+            assert Cn == 1, "differentiable camera centre: one camera per call"
+            v_campos = -v_means.sum(dim=0, keepdim=True)
+        return v_means, v_coeffs, v_campos, None, v_depths, None
 
 
 USE_LIVE_LISTS = True  # tile_size == 16 fast path (csrc/live.hip); False forces the generic tile kernels
@@ -899,6 +905,18 @@ class _SsimL1Loss(torch.autograd.Function):
 
 def ssim_l1_loss(pred: Tensor, gt: Tensor, ssim_lambda: float = 0.2) -> Tensor:
     return _SsimL1Loss.apply(pred, gt, float(ssim_lambda))
+
+
+def inverse3x3(A: Tensor) -> Tensor:
+    """Differentiable inverse of [..., 3, 3] matrices by cofactors (plain elementwise torch ops: no solver library)."""
+    a, b, c = A[..., 0, 0], A[..., 0, 1], A[..., 0, 2]
+    d, e, f = A[..., 1, 0], A[..., 1, 1], A[..., 1, 2]
+    g, h, i = A[..., 2, 0], A[..., 2, 1], A[..., 2, 2]
+    co = torch.stack([torch.stack([e * i - f * h, c * h - b * i, b * f - c * e], -1),
+                      torch.stack([f * g - d * i, a * i - c * g, c * d - a * f], -1),
+                      torch.stack([d * h - e * g, b * g - a * h, a * e - b * d], -1)], -2)
+    det = a * (e * i - f * h) - b * (d * i - f * g) + c * (d * h - e * g)
+    return co / det[..., None, None]
 
 
 def campos_from_viewmats(viewmats: Tensor) -> Tensor:

@@ -201,8 +201,15 @@ def rasterization(
             cols = torch.cat([cols, depths[..., None]], dim=-1)
     else:
         if viewmats.requires_grad:
-            raise NotImplementedError("SH colours with a differentiable camera pose are not supported")
-        campos = ops.campos_from_viewmats(viewmats)
+            # differentiable camera pose (nerfstudio's camera optimiser; off in FusionSense, dn_model.py:128-130):
+            # gsplat takes campos = inverse(viewmat)[:3, 3]; for [A t; 0 1] that is -A^-1 t, formed here with torch
+            # ops so that autograd carries the SH view-direction gradient back into the view matrix
+            if C != 1:
+                raise NotImplementedError("SH colours with a differentiable camera pose: one camera per call")
+            A, t = viewmats[:, :3, :3], viewmats[:, :3, 3:]
+            campos = -ops.inverse3x3(A).matmul(t).squeeze(-1)
+        else:
+            campos = ops.campos_from_viewmats(viewmats)
         cols = ops._SHColors.apply(means, colors, campos, radii, depths if want_depth else None,
                                    int(sh_degree))
     if want_depth and backgrounds is not None:

