@@ -412,7 +412,9 @@ def bin_live_finish(st: dict, means2d: Tensor, radii: Tensor, depths: Tensor, co
     # (isect_offsets[T], clamped to the capacity) and the caller checks it later with bin_live_check
     M = st["capacity"] if st.get("capacity", 0) else _wait_total(st)
     dense = not use_tile_sort(M, T)  # mean bucket beyond the LDS tiers
-    split = BIN_SPLIT == "always" or (BIN_SPLIT == "auto" and dense)
+    # (no-wait mode cannot fall back to the list chain, which needs the exact total on the host: dense frames are
+    # always split there)
+    split = BIN_SPLIT == "always" or (dense and (BIN_SPLIT == "auto" or bool(st.get("capacity", 0))))
     _DENSE_HINT[(str(dev), N, T)] = dense and not split
     if dense and not split:
         WORKSPACE.give(st["table"])
