@@ -54,17 +54,17 @@ SIGNATURES = {
     "fsgs_live_payload": (_i, [_p, _p, _i64, _p, _i64, _i, _i, _p, _p]),
     "fsgs_raster_fwd_quad": (_i, [_i, _i, _p, _p, _p, _i64, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "fsgs_raster_bwd_quad": (_i, [_i, _i, _p, _p, _p, _i64, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p]),
-    "fsgs_raster_bwd_quad_images": (_i, [_p, _p, _p, _i64, _i, _i, _i, _i] + [_p] * 10 + [_i, _p, _p]),
+    "fsgs_raster_bwd_quad_images": (_i, [_p, _p, _p, _i64, _i, _i, _i, _i] + [_p] * 10 + [_i, _p, _i64, _p]),
     "fsgs_campos_from_viewmats": (_i, [_i, _p, _p, _p]),
     "fsgs_raster_unpack_grads": (_i, [_i64, _i, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p]),
     "fsgs_sh_fwd_split": (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p]),
-    "fsgs_sh_bwd_split": (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _i, _p]),
+    "fsgs_sh_bwd_split": (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _i, _i64, _p]),
     "fsgs_sh_fwd_pack": (_i, [_i, _i, _i] + [_p] * 15 + [_i, _p]),
-    "fsgs_sh_bwd_colors": (_i, [_i, _i, _i, _p, _p, _p, _p, _p, _i, _p, _p, _p, _i, _p]),
+    "fsgs_sh_bwd_colors": (_i, [_i, _i, _i, _p, _p, _p, _p, _p, _i, _p, _p, _p, _i, _i64, _p]),
     "fsgs_sh_coeff_grad": (_i, [_i, _i, _i, _i, _p, _p, _f, _p, _p, _p]),
     "fsgs_sh_coeff_grad_adam": (_i, [_i, _i, _i, _i, _p, _p, _f, _p, _p, _p, _f, _p, _p, _p, _f, _i, C.c_double, C.c_double, _f, _p]),
     "fsgs_project_fwd_act": (_i, [_i, _i, _p, _p, _p, _p, _i, _f, _p, _p, _i, _i, _f, _f, _f, _f, _p, _p, _p, _p, _p, _p, _p]),
-    "fsgs_gaussian_bwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _f, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _f, _p, _p]),
+    "fsgs_gaussian_bwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _f, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _f, _p, _i64, _p]),
     "fsgs_activate_fwd": (_i, [_i, _p, _p, _p, _p, _p]),
     "fsgs_activate_bwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "fsgs_epilogue_fwd": (_i, [_i64, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p]),
@@ -89,8 +89,8 @@ SIGNATURES = {
     "fsgs_project_bin_live_count_h16": (_i, [_i, _p, _p, _p, _p, _p, _i, _f, _p, _p, _i, _i, _f, _f, _f, _f, _p, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p, _sz, _p, _p]),
     "fsgs_project_fwd_act_h16": (_i, [_i, _i, _p, _p, _p, _p, _p, _i, _f, _p, _p, _i, _i, _f, _f, _f, _f, _p, _p, _p, _p, _p, _p, _p]),
     "fsgs_sh_fwd_pack_h16": (_i, [_i, _i, _i] + [_p] * 15 + [_i, _p]),
-    "fsgs_sh_bwd_split_h16": (_i, [_i, _i, _i, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _i, _p]),
-    "fsgs_gaussian_bwd_h16": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _f, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _f, _p, _p]),
+    "fsgs_sh_bwd_split_h16": (_i, [_i, _i, _i, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _i, _i64, _p]),
+    "fsgs_gaussian_bwd_h16": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _f, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _f, _p, _i64, _p]),
     "fsgs_adam_step_h16": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _i, C.c_double, C.c_double, _f, _p]),
     "fsgs_loss_combine_cols": (_i, [_i, _p, _p, _p, _p, _f, _p, _p]),
     "fsgs_ssim_l1_fwd_masked": (_i, [_i, _i, _p, _p, _p, _p, _p, _p, _p, _p]),

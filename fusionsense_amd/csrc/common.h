@@ -133,6 +133,24 @@ __device__ __forceinline__ void adam_one(float &p, float g, float &m, float &v, 
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
+// ---- spreading the gradient atomics of large Gaussians --------------------------------------------------------
+// The compositing backward adds every (row, record) total into the Gaussian's packed 64-byte gradient line with one
+// memory-side atomic transaction; transactions on one line are serial.  A Gaussian that covers many tiles receives
+// them from hundreds of workgroups at once: on BASELINE config #3 (large background Gaussians behind a small
+// object) a third of the kernel was spent there.  Gaussians whose 2-D footprint is large (det(conic) small, i.e.
+// sigma_1 sigma_2 > 64 px^2) therefore own kGradReplicas lines, `replica_rows` lines apart; a workgroup picks the
+// replica from its tile and quadrant, the SH backward sums the colour parts and the per-Gaussian backward (the last
+// reader) folds and clears them.  Writer and last reader evaluate the same predicate on the same fp32 conic, so they
+// always agree.  The threshold is measured (profiles/README.md): lower ones cost the two readers more than the
+// compositing backward gains on config #2, higher ones lose the gain on config #3.
+constexpr int kGradReplicas = 4;
+// A reader that has the radius at hand but not the conic may use the superset `radius >= kSpreadMinRadius`:
+// det(cov) > 4096 means sigma_max > 8 px, i.e. radius = ceil(3 sigma_max) >= 25; replicas never written hold zeros.
+constexpr int kSpreadMinRadius = 24;
+__device__ __forceinline__ bool grad_spread(float ca, float cb, float cc) {
+    return __builtin_fmaf(-cb, cb, ca * cc) < (1.f / 4096.f);  // (one fixed rounding sequence in every kernel)
+}
+
 // ---- attribute storage (BASELINE config #5) ---------------------------------------------------------------------
 // Per-Gaussian attributes other than the means (SH features, log-scales, quaternions, opacity logits) are read either
 // as fp32 or as IEEE half mirrors of the fp32 master parameters (`half` != 0, uniform per launch): all arithmetic

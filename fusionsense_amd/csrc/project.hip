@@ -80,6 +80,7 @@ struct GaussBwdFused {
     int accumulate_means;        // v_means += (the SH backward wrote its share first) instead of =
     const uint8_t *frozen;       // nullable [N]: touch anchors — no gradient for means / scales / opacity (dn_model.py:535-541)
     int attr_half;               // quats / log_scales are IEEE-half mirrors (BASELINE config #5)
+    int64_t replica_rows;        // > 0: large Gaussians own kGradReplicas gradient lines, this many rows apart (common.h)
     float *xys_grad_norm, *vis_counts, *max_2Dsize;  // after_train statistics (nullable together)
     float inv_max_hw;
 };
@@ -102,6 +103,18 @@ project_bwd_kernel(int C, int N, const float *__restrict__ means, const void *__
         pa = fz.v_packed[n * 4 + 0]; pb = fz.v_packed[n * 4 + 1]; pc = fz.v_packed[n * 4 + 2]; pd = fz.v_packed[n * 4 + 3];
         const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
         fz.v_packed[n * 4 + 0] = zero4; fz.v_packed[n * 4 + 1] = zero4; fz.v_packed[n * 4 + 2] = zero4; fz.v_packed[n * 4 + 3] = zero4;
+        if (fz.replica_rows > 0 && radii[n] > 0 &&
+            grad_spread(conics[n * 3 + 0], conics[n * 3 + 1], conics[n * 3 + 2])) {
+            // a large Gaussian: fold (and clear) the replicas the compositing backward spread its atomics over
+            // (the colour float4 of each replica has been read by the SH backward before; this is the last reader)
+            auto add4 = [](float4 &a, const float4 b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; };
+#pragma unroll
+            for (int r = 1; r < kGradReplicas; ++r) {
+                float4 *line = fz.v_packed + ((int64_t)r * fz.replica_rows + n) * 4;
+                add4(pa, line[0]); add4(pb, line[1]); add4(pc, line[2]); add4(pd, line[3]);
+                line[0] = zero4; line[1] = zero4; line[2] = zero4; line[3] = zero4;
+            }
+        }
         reinterpret_cast<float2 *>(fz.absgrad)[n] = make_float2(pc.y, pc.z);
     }
     const float mean[3] = {means[n * 3 + 0], means[n * 3 + 1], means[n * 3 + 2]};
@@ -398,6 +411,7 @@ extern "C" int fsgs_project_bwd(int C, int N, const float *means, const float *q
 }
 
 static int gaussian_bwd_impl(int N, const float *means, const void *quats, const void *log_scales, int attr_half,
+                             int64_t replica_rows,
                                  const float *scales, const float *opac, const float *viewmat, const float *K,
                                  const float *c2w, int width, int height, float eps2d, const int32_t *radii,
                                  const float *conics, float *v_packed, int accumulate_means, float *v_means,
@@ -417,6 +431,8 @@ static int gaussian_bwd_impl(int N, const float *means, const void *quats, const
     fz.accumulate_means = accumulate_means;
     fz.frozen = frozen;
     fz.attr_half = attr_half;
+    if (replica_rows < 0) return FSGS_EINVAL;
+    fz.replica_rows = replica_rows;
     fz.xys_grad_norm = xys_grad_norm; fz.vis_counts = vis_counts; fz.max_2Dsize = max_2Dsize; fz.inv_max_hw = inv_max_hw;
     hipLaunchKernelGGL((project_bwd_kernel<true>), dim3(ceil_div(N, 256)), dim3(256), 0, as_stream(stream), 1, N,
                        means, quats, scales, viewmat, K, width, height, eps2d, radii, conics, nullptr, nullptr,
@@ -430,8 +446,8 @@ extern "C" int fsgs_gaussian_bwd(int N, const float *means, const float *quats, 
                                  const float *conics, float *v_packed, int accumulate_means, float *v_means,
                                  float *v_quats, float *v_log_scales, float *v_opac_logit, float *absgrad,
                                  float *xys_grad_norm, float *vis_counts, float *max_2Dsize, float inv_max_hw,
-                                 const uint8_t *frozen, fsgs_stream_t stream) {
-    return gaussian_bwd_impl(N, means, quats, log_scales, 0, scales, opac, viewmat, K, c2w, width, height, eps2d, radii,
+                                 const uint8_t *frozen, int64_t replica_rows, fsgs_stream_t stream) {
+    return gaussian_bwd_impl(N, means, quats, log_scales, 0, replica_rows, scales, opac, viewmat, K, c2w, width, height, eps2d, radii,
                              conics, v_packed, accumulate_means, v_means, v_quats, v_log_scales, v_opac_logit, absgrad,
                              xys_grad_norm, vis_counts, max_2Dsize, inv_max_hw, frozen, stream);
 }
@@ -443,8 +459,8 @@ extern "C" int fsgs_gaussian_bwd_h16(int N, const float *means, const void *quat
                                      const float *conics, float *v_packed, int accumulate_means, float *v_means,
                                      float *v_quats, float *v_log_scales, float *v_opac_logit, float *absgrad,
                                      float *xys_grad_norm, float *vis_counts, float *max_2Dsize, float inv_max_hw,
-                                     const uint8_t *frozen, fsgs_stream_t stream) {
-    return gaussian_bwd_impl(N, means, quats_h, log_scales_h, 1, scales, opac, viewmat, K, c2w, width, height, eps2d,
+                                     const uint8_t *frozen, int64_t replica_rows, fsgs_stream_t stream) {
+    return gaussian_bwd_impl(N, means, quats_h, log_scales_h, 1, replica_rows, scales, opac, viewmat, K, c2w, width, height, eps2d,
                              radii, conics, v_packed, accumulate_means, v_means, v_quats, v_log_scales, v_opac_logit,
                              absgrad, xys_grad_norm, vis_counts, max_2Dsize, inv_max_hw, frozen, stream);
 }

@@ -75,7 +75,7 @@ raster_bwd_live_kernel(int64_t cap, const float4 *__restrict__ rec,
                        const float *__restrict__ v_alphas, const float *__restrict__ seg_state,
                        int64_t seg_cap, float *__restrict__ v_packed, int normalize_last,
                        const float *__restrict__ render_extra, const float *__restrict__ v_render_extra,
-                       const int32_t *__restrict__ n_rec, GetOutputsGrads ep) {
+                       const int32_t *__restrict__ n_rec, GetOutputsGrads ep, int64_t replica_rows) {
     __shared__ QLds<E> Lw[kBwdWaves];
     constexpr int RS = E ? 4 : 3;
     constexpr int SS = 64 * (1 + D + E);
@@ -183,6 +183,10 @@ raster_bwd_live_kernel(int64_t cap, const float4 *__restrict__ rec,
 #pragma unroll
     for (int r4 = 0; r4 < 4; ++r4) row_bin_final[r4] = __builtin_amdgcn_readlane(rbf, 16 * r4);
     const float quad_x0 = (float)(blockIdx.x * 8), quad_y0 = (float)(blockIdx.y * 8);
+    // this workgroup's replica of a large Gaussian's gradient line (common.h: grad_spread); 0 rows = no replicas
+    // (neighbouring tiles and the four 8x8 quadrants of a tile — one workgroup each — take different replicas)
+    const int64_t rep_off = replica_rows * 16 * (int64_t)((((unsigned)tile_lin * 2654435761u >> 16) + (blockIdx.x & 1) +
+                                                           2 * (blockIdx.y & 1)) % kGradReplicas);
 
     for (int seg = n_seg - 1 - w; seg >= 0; seg -= kBwdWaves) {
         const int b0 = s + (seg << 6);          // first stream position of the segment
@@ -301,7 +305,8 @@ raster_bwd_live_kernel(int64_t cap, const float4 *__restrict__ rec,
                                   (pl == 11) || (pl >= 12);
                 if (used) {
                     const int64_t gid = __float_as_int(a1.w) & 0x0FFFFFFF;
-                    unsafeAtomicAdd(&v_packed[gid * 16 + pl], tot);
+                    const int64_t off = grad_spread(a0.w, a1.x, a1.y) ? rep_off : 0;
+                    unsafeAtomicAdd(&v_packed[off + gid * 16 + pl], tot);
                 }
             }
         }
@@ -352,7 +357,8 @@ static int launch_bwd_live(int C, int D, const float *records, const int32_t *n_
                            int normalize_last, const float *render, const float *alphas, const int32_t *last_ids,
                            const float *v_render, const float *v_alphas, const float *seg_state, int with_abs,
                            const float *render_extra, const float *v_render_extra, float *v_packed,
-                           fsgs_stream_t stream, GetOutputsGrads ep = GetOutputsGrads{nullptr, nullptr, nullptr, nullptr, nullptr}) {
+                           fsgs_stream_t stream, GetOutputsGrads ep = GetOutputsGrads{nullptr, nullptr, nullptr, nullptr, nullptr},
+                           int64_t replica_rows = 0) {
     if (C < 0 || width < 0 || height < 0 || n_isects < 0) return FSGS_EINVAL;
     if (C == 0 || width == 0 || height == 0 || n_isects == 0) return FSGS_OK;
     if (!records || !n_rec || !isect_offsets || !render || !alphas || !last_ids || !seg_state || !v_packed)
@@ -369,7 +375,7 @@ static int launch_bwd_live(int C, int D, const float *records, const int32_t *n_
     hipLaunchKernelGGL((raster_bwd_live_kernel<DD, AA, EE>), grid, dim3(64 * kBwdWaves), 0, s, cap, rec,          \
                        isect_offsets, n_isects, backgrounds, width, height, tile_width, tile_height, render,      \
                        alphas, last_ids, v_render, v_alphas, seg_state, seg_cap, v_packed, normalize_last,         \
-                       render_extra, v_render_extra, n_rec, ep)
+                       render_extra, v_render_extra, n_rec, ep, replica_rows)
     if (render_extra) {
         if (D != 4 || (!v_render_extra && !ep.v_rgb)) return FSGS_EINVAL;
         if (with_abs) FSGS_BWD_LIVE(4, true, 3); else FSGS_BWD_LIVE(4, false, 3);
@@ -422,12 +428,12 @@ extern "C" int fsgs_raster_bwd_quad_images(const float *records, const int32_t *
                                            const float *render_extra, const float *background, const float *v_rgb,
                                            const float *v_depth, const float *v_normal, const float *v_alpha_in,
                                            const float *seg_state, int with_abs, float *v_packed,
-                                           fsgs_stream_t stream) {
+                                           int64_t replica_rows, fsgs_stream_t stream) {
     if (n_isects > 0 && (!n_rec || !v_rgb || !background)) return FSGS_EINVAL;
-    if (!v_rgb) return FSGS_EINVAL;
+    if (!v_rgb || replica_rows < 0) return FSGS_EINVAL;
     const GetOutputsGrads ep = {v_rgb, v_depth, v_normal, v_alpha_in, background};
     return launch_bwd_live(1, 4, records, n_rec, fsgs_quad_stream_capacity(1, tile_width, tile_height, n_isects),
                            fsgs_quad_seg_slots(1, tile_width, tile_height, n_isects), isect_offsets, n_isects, nullptr,
                            width, height, tile_width, tile_height, 1, render, alphas, last_ids, nullptr, nullptr,
-                           seg_state, with_abs, render_extra, nullptr, v_packed, stream, ep);
+                           seg_state, with_abs, render_extra, nullptr, v_packed, stream, ep, replica_rows);
 }

@@ -431,7 +431,8 @@ sh_bwd_kernel(int C, int N, int K, int degree, const float *__restrict__ means,
               const void *__restrict__ coeffs_rest, const int32_t *__restrict__ radii, int D,
               const float *__restrict__ v_colors, float *__restrict__ v_coeffs,
               float *__restrict__ v_coeffs_rest, float *__restrict__ v_means,
-              float *__restrict__ v_depths, int overwrite_means, float4 *__restrict__ v_rgb_masked) {
+              float *__restrict__ v_depths, int overwrite_means, float4 *__restrict__ v_rgb_masked,
+              int64_t replica_rows) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int n0 = blockIdx.x * kShBlock;
     const int rows = min(kShBlock, N - n0);
@@ -451,6 +452,15 @@ sh_bwd_kernel(int C, int N, int K, int degree, const float *__restrict__ means,
         rad0 = radii[n];
         vc0 = v_colors[(int64_t)n * D + 0]; vc1 = v_colors[(int64_t)n * D + 1]; vc2 = v_colors[(int64_t)n * D + 2];
         if (D == 4 && v_depths) vc3 = v_colors[(int64_t)n * 4 + 3];
+        if (replica_rows > 0 && rad0 >= kSpreadMinRadius) {
+            // a large Gaussian's gradient atomics may have been spread over kGradReplicas lines (common.h): sum their
+            // colour parts (the replicas of a Gaussian that was not spread hold zeros)
+#pragma unroll
+            for (int r = 1; r < kGradReplicas; ++r) {
+                const float *line = v_colors + ((int64_t)r * replica_rows + n) * D;
+                vc0 += line[0]; vc1 += line[1]; vc2 += line[2];
+            }
+        }
         if (!overwrite_means) { o0 = v_means[n * 3 + 0]; o1 = v_means[n * 3 + 1]; o2 = v_means[n * 3 + 2]; }
     }
     coeffs_park<KT, SPLIT, HALF>(st, coeffs, coeffs_rest, n0, rows, K, lds);
@@ -762,7 +772,7 @@ static int sh_bwd_impl(int C, int N, int K, int degree, const float *means, cons
                        const void *coeffs, const void *coeffs_rest, const int32_t *radii, int D,
                        const float *v_colors, float *v_coeffs, float *v_coeffs_rest, float *v_means,
                        float *v_depths, int overwrite_means, fsgs_stream_t stream, float *v_rgb_masked = nullptr,
-                       int attr_half = 0) {
+                       int attr_half = 0, int64_t replica_rows = 0) {
     // D = floats per v_colors row (the colour gradient is its first three): 3, 4 (v_depths = column 3), or a
     // wider stride such as the rasterizer's packed 16-float gradient records
     if (C < 0 || N < 0 || degree < 0 || degree > 4 || K < (degree + 1) * (degree + 1) || K > kMaxK || D < 3)
@@ -770,12 +780,13 @@ static int sh_bwd_impl(int C, int N, int K, int degree, const float *means, cons
     if (N == 0) return FSGS_OK;
     if (!means || !campos || !coeffs || !radii || !v_colors || (!v_coeffs && !v_rgb_masked) || !v_means) return FSGS_EINVAL;
     if (v_rgb_masked && C != 1) return FSGS_EINVAL;
+    if (replica_rows < 0 || (replica_rows > 0 && (C != 1 || D != 16))) return FSGS_EINVAL;
     const size_t lds_bytes = (size_t)kShBlock * (K * 3 + 1) * sizeof(float);
 #define FSGS_SH_BWD(SC, KT, SP)                                                                           \
     hipLaunchKernelGGL((sh_bwd_kernel<SC, KT, SP>), dim3(ceil_div(N, kShBlock)), dim3(kShBlock), lds_bytes,  \
                        as_stream(stream), C, N, K, degree, means, campos, coeffs, coeffs_rest, radii, D,      \
                        v_colors, v_coeffs, v_coeffs_rest, v_means, v_depths, overwrite_means,                 \
-                       reinterpret_cast<float4 *>(v_rgb_masked))
+                       reinterpret_cast<float4 *>(v_rgb_masked), replica_rows)
 #define FSGS_SH_BWD_K(SC, SP) do { if (K == 16) FSGS_SH_BWD(SC, 16, SP); else FSGS_SH_BWD(SC, 0, SP); } while (0)
     if (attr_half) {  // half coefficient storage: one camera, split features (the training path)
         if (C != 1 || !coeffs_rest) return FSGS_EINVAL;
@@ -783,12 +794,12 @@ static int sh_bwd_impl(int C, int N, int K, int degree, const float *means, cons
             hipLaunchKernelGGL((sh_bwd_kernel<true, 16, true, true>), dim3(ceil_div(N, kShBlock)), dim3(kShBlock), lds_bytes,
                                as_stream(stream), C, N, K, degree, means, campos, coeffs, coeffs_rest, radii, D, v_colors,
                                v_coeffs, v_coeffs_rest, v_means, v_depths, overwrite_means,
-                               reinterpret_cast<float4 *>(v_rgb_masked));
+                               reinterpret_cast<float4 *>(v_rgb_masked), replica_rows);
         else
             hipLaunchKernelGGL((sh_bwd_kernel<true, 0, true, true>), dim3(ceil_div(N, kShBlock)), dim3(kShBlock), lds_bytes,
                                as_stream(stream), C, N, K, degree, means, campos, coeffs, coeffs_rest, radii, D, v_colors,
                                v_coeffs, v_coeffs_rest, v_means, v_depths, overwrite_means,
-                               reinterpret_cast<float4 *>(v_rgb_masked));
+                               reinterpret_cast<float4 *>(v_rgb_masked), replica_rows);
     } else if (C == 1) {
         if (coeffs_rest) FSGS_SH_BWD_K(true, true); else FSGS_SH_BWD_K(true, false);
     } else {
@@ -809,24 +820,26 @@ extern "C" int fsgs_sh_bwd(int C, int N, int K, int degree, const float *means, 
 extern "C" int fsgs_sh_bwd_split(int C, int N, int K, int degree, const float *means, const float *campos,
                                  const float *features_dc, const float *features_rest, const int32_t *radii,
                                  int D, const float *v_colors, float *v_features_dc, float *v_features_rest,
-                                 float *v_means, float *v_depths, int overwrite_means, fsgs_stream_t stream) {
+                                 float *v_means, float *v_depths, int overwrite_means,
+                                 int64_t replica_rows, fsgs_stream_t stream) {
     if (C >= 0 && N == 0) return FSGS_OK;  // (empty tensors have no address)
     if ((!features_rest || !v_features_rest) && K > 1) return FSGS_EINVAL;
     return sh_bwd_impl(C, N, K, degree, means, campos, features_dc, features_rest ? features_rest : features_dc,
                        radii, D, v_colors, v_features_dc, v_features_rest ? v_features_rest : v_features_dc,
-                       v_means, v_depths, overwrite_means, stream);
+                       v_means, v_depths, overwrite_means, stream, nullptr, 0, replica_rows);
 }
 
 // one camera, features read from IEEE-half mirrors (BASELINE config #5); gradients fp32
 extern "C" int fsgs_sh_bwd_split_h16(int N, int K, int degree, const float *means, const float *campos,
                                      const void *features_dc_h, const void *features_rest_h, const int32_t *radii,
                                      int D, const float *v_colors, float *v_features_dc, float *v_features_rest,
-                                     float *v_means, float *v_depths, int overwrite_means, fsgs_stream_t stream) {
+                                     float *v_means, float *v_depths, int overwrite_means,
+                                     int64_t replica_rows, fsgs_stream_t stream) {
     if (N == 0) return FSGS_OK;
     if ((!features_rest_h || !v_features_rest) && K > 1) return FSGS_EINVAL;
     return sh_bwd_impl(1, N, K, degree, means, campos, features_dc_h, features_rest_h ? features_rest_h : features_dc_h,
                        radii, D, v_colors, v_features_dc, v_features_rest ? v_features_rest : v_features_dc, v_means,
-                       v_depths, overwrite_means, stream, nullptr, 1);
+                       v_depths, overwrite_means, stream, nullptr, 1, replica_rows);
 }
 
 // fsgs_sh_bwd_split for one camera that leaves the coefficient gradients to fsgs_sh_coeff_grad: writes v_means (as
@@ -835,11 +848,12 @@ extern "C" int fsgs_sh_bwd_split_h16(int N, int K, int degree, const float *mean
 extern "C" int fsgs_sh_bwd_colors(int N, int K, int degree, const float *means, const float *campos,
                                   const float *features_dc, const float *features_rest, const int32_t *radii, int D,
                                   const float *v_colors, float *v_rgb_masked, float *v_means, int overwrite_means,
-                                  fsgs_stream_t stream) {
+                                  int64_t replica_rows, fsgs_stream_t stream) {
     if (N == 0) return FSGS_OK;
     if ((!features_rest && K > 1) || !v_rgb_masked) return FSGS_EINVAL;
     return sh_bwd_impl(1, N, K, degree, means, campos, features_dc, features_rest ? features_rest : features_dc,
-                       radii, D, v_colors, nullptr, nullptr, v_means, nullptr, overwrite_means, stream, v_rgb_masked);
+                       radii, D, v_colors, nullptr, nullptr, v_means, nullptr, overwrite_means, stream, v_rgb_masked, 0,
+                       replica_rows);
 }
 
 extern "C" int fsgs_sh_coeff_grad(int R, int N, int K, int degree, const float *means, const float *gathered,

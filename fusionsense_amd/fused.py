@@ -98,13 +98,17 @@ _ACCUM: Dict[str, Tensor] = {}
 _ONES3: Dict[str, Tensor] = {}
 
 
+GRAD_REPLICAS = 4 if os.environ.get("FSGS_GRAD_REPLICAS", "1") != "0" else 1  # (= kGradReplicas of csrc/common.h)
+
+
 def _grad_accumulator(dev, N: int) -> Tensor:
-    """The packed [N,16] gradient accumulator of the backward, kept zeroed between frames (one per device;
-    re-created when N changes, i.e. after densify / prune)."""
+    """The packed gradient accumulator of the backward, [GRAD_REPLICAS * N, 16]: line n plus, for Gaussians with a
+    large footprint, three replica lines N rows apart (csrc/common.h: grad_spread).  Kept zeroed between frames by
+    its reader (one per device; re-created when N changes, i.e. after densify / prune)."""
     key = str(dev)
     t = _ACCUM.get(key)
-    if t is None or t.shape[0] != N:
-        t = torch.zeros(N, 16, dtype=torch.float32, device=dev)
+    if t is None or t.shape[0] != GRAD_REPLICAS * N:
+        t = torch.zeros(GRAD_REPLICAS * N, 16, dtype=torch.float32, device=dev)
         _ACCUM[key] = t
         if os.environ.get("FSGS_DEBUG_PTRS"):
             import sys
@@ -285,14 +289,15 @@ class _FusedGetOutputs(torch.autograd.Function):
         c = lambda t: None if t is None else t.contiguous()  # noqa: E731
         v_rgb, v_depth, v_normal, v_alpha_out = c(v_rgb), c(v_depth), c(v_normal), c(v_alpha_out)
 
-        v_packed = _grad_accumulator(dev, N)  # all zeros: the unpack kernel clears it again after reading
+        v_packed = _grad_accumulator(dev, N)  # all zeros: the per-Gaussian backward clears it again after reading
+        rep_rows = N if GRAD_REPLICAS > 1 else 0
         if v_rgb is not None and IMAGE_GRADS_IN_BWD:
             # the image gradients go straight into the compositing backward, which derives v_render / v_alphas /
             # v_render_extra per pixel itself (no epilogue launch, no 32 B/pixel round trip)
             _run(lib.fsgs_raster_bwd_quad_images, (ptr(records), ptr(n_rec), ptr(offsets), M, W, H, tw, th, ptr(render),
                                                   ptr(alphas), ptr(last_ids), ptr(render_extra), ptr(background),
                                                   ptr(v_rgb), ptr(v_depth), ptr(v_normal), ptr(v_alpha_out),
-                                                  ptr(seg_state), 1, ptr(v_packed), sp),
+                                                  ptr(seg_state), 1, ptr(v_packed), rep_rows, sp),
                  "fsgs_raster_bwd_quad", "_d4e3")
         else:
             v_render = torch.empty(1, H, W, 4, **f32)
@@ -325,7 +330,8 @@ class _FusedGetOutputs(torch.autograd.Function):
             assert factors is None, "the factored feature exchange reads fp32 features (trainer switches it off)"
             _run(lib.fsgs_sh_bwd_split_h16, (N, K, sh_degree, ptr(means), ptr(cam["campos"]), ptr(hm["features_dc"]),
                                              ptr(hm["features_rest"]), ptr(radii), 16, ptr(v_packed), ptr(g_dc),
-                                             ptr(g_rest), ptr(g_means), None, 1, sp), "fsgs_sh_bwd_split")
+                                             ptr(g_rest), ptr(g_means), None, 1, rep_rows, sp),
+                 "fsgs_sh_bwd_split")
         elif factors is not None:
             # data-parallel step: only the FACTORS of the coefficient gradients are produced here ([N + 1,4]: masked
             # colour gradients + the camera centre); the trainer all-gathers them and fsgs_sh_coeff_grad rebuilds the
@@ -333,11 +339,11 @@ class _FusedGetOutputs(torch.autograd.Function):
             assert tuple(factors.shape) == (N + 1, 4) and factors.is_contiguous()
             _run(lib.fsgs_sh_bwd_colors, (N, K, sh_degree, ptr(means), ptr(cam["campos"]), ptr(features_dc),
                                           ptr(features_rest), ptr(radii), 16, ptr(v_packed), ptr(factors),
-                                          ptr(g_means), 1, sp), "fsgs_sh_bwd_split")
+                                          ptr(g_means), 1, rep_rows, sp), "fsgs_sh_bwd_split")
         else:
             _run(lib.fsgs_sh_bwd_split, (1, N, K, sh_degree, ptr(means), ptr(cam["campos"]), ptr(features_dc),
                                          ptr(features_rest), ptr(radii), 16, ptr(v_packed), ptr(g_dc), ptr(g_rest),
-                                         ptr(g_means), None, 1, sp), "fsgs_sh_bwd_split")
+                                         ptr(g_means), None, 1, rep_rows, sp), "fsgs_sh_bwd_split")
         # everything else per Gaussian in one launch (projection / normal / activation VJPs, absgrad, statistics)
         v_abs = torch.empty(1, N, 2, **f32)
         stats = ctx.info.stats_out
@@ -352,7 +358,7 @@ class _FusedGetOutputs(torch.autograd.Function):
                                     ptr(stats["xys_grad_norm"]) if stats else None,
                                     ptr(stats["vis_counts"]) if stats else None,
                                     ptr(stats["max_2Dsize"]) if stats else None,
-                                    float(stats["inv_max_hw"]) if stats else 0.0, ptr(ctx.info.frozen), sp),
+                                    float(stats["inv_max_hw"]) if stats else 0.0, ptr(ctx.info.frozen), rep_rows, sp),
              "fsgs_gaussian_bwd")
         ctx.info.absgrad = v_abs
         ctx.info.stats_done = stats is not None

@@ -86,7 +86,8 @@ int fsgs_sh_fwd_split(int C, int N, int K, int degree, const float *means, const
 int fsgs_sh_bwd_split(int C, int N, int K, int degree, const float *means, const float *campos,
                       const float *features_dc, const float *features_rest, const int32_t *radii, int D,
                       const float *v_colors, float *v_features_dc, float *v_features_rest,
-                      float *v_means, float *v_depths, int overwrite_means, fsgs_stream_t stream);
+                      float *v_means, float *v_depths, int overwrite_means, int64_t replica_rows,
+                      fsgs_stream_t stream);
 
 /* fsgs_sh_fwd_split (one camera, with the depth channel) and fsgs_live_pack_normals in one launch: the colours go
  * straight into the packed per-Gaussian records [N,16] that the live-list kernels gather (no colour array is
@@ -106,7 +107,7 @@ int fsgs_sh_fwd_pack(int N, int K, int degree, const float *means, const float *
  * row N = (camera centre, -).  Same replaced reference call as fsgs_sh_bwd. */
 int fsgs_sh_bwd_colors(int N, int K, int degree, const float *means, const float *campos,
                        const float *features_dc, const float *features_rest, const int32_t *radii, int D,
-                       const float *v_colors, float *v_rgb_masked, float *v_means, int overwrite_means,
+                       const float *v_colors, float *v_rgb_masked, float *v_means, int overwrite_means, int64_t replica_rows,
                        fsgs_stream_t stream);
 int fsgs_sh_coeff_grad(int R, int N, int K, int degree, const float *means, const float *gathered, float scale,
                        float *v_features_dc, float *v_features_rest, fsgs_stream_t stream);
@@ -260,7 +261,15 @@ int fsgs_raster_bwd_quad_images(const float *records, const int32_t *n_rec, cons
                                 const float *render, const float *alphas, const int32_t *last_ids,
                                 const float *render_extra, const float *background, const float *v_rgb,
                                 const float *v_depth, const float *v_normal, const float *v_alpha_in,
-                                const float *seg_state, int with_abs, float *v_packed, fsgs_stream_t stream);
+                                const float *seg_state, int with_abs, float *v_packed, int64_t replica_rows,
+                                fsgs_stream_t stream);
+/* replica_rows (here and in fsgs_gaussian_bwd; 0 = off): Gaussians with a large 2-D footprint (det(conic) < 1/4096)
+ * own FOUR gradient lines, replica_rows rows apart in v_packed ([4 * replica_rows, 16], zeroed): the compositing
+ * backward picks the replica from the tile and the 8x8 quadrant, so that the hundreds of workgroups a large Gaussian
+ * is seen from do not serialise on one 64-byte line.  The SH backward (fsgs_sh_bwd_split / _h16 / fsgs_sh_bwd_colors
+ * with D = 16 and replica_rows > 0) sums the replicas' colour gradients of every Gaussian of radius >= 24 px (a
+ * superset: unwritten replicas hold zeros) as it reads them; fsgs_gaussian_bwd, the last reader, folds and clears
+ * all of them. */
 /* ---- Sort + offsets for live lists as a partition by tile plus a sort inside every tile's bucket
  * (same results, bit for bit, as fsgs_sort_pairs on the key bits + fsgs_isect_offset_encode; replaces
  * the same reference calls).  isect_ids [n] are the UNSORTED keys cam|tile|depth-bits of
@@ -401,7 +410,8 @@ int fsgs_gaussian_bwd(int N, const float *means, const float *quats, const float
                       const float *conics, float *v_packed, int accumulate_means, float *v_means,
                       float *v_quats, float *v_log_scales, float *v_opac_logit, float *absgrad,
                       float *xys_grad_norm, float *vis_counts, float *max_2Dsize, float inv_max_hw,
-                      const uint8_t *frozen, fsgs_stream_t stream);
+                      const uint8_t *frozen, int64_t replica_rows,
+                          fsgs_stream_t stream);
 /* frozen (nullable, [N] u8): rows whose v_means / v_log_scales / v_opac_logit are zero — FusionSense's touch
  * anchors, detached at dn_model.py:535-541 (their quaternion and colour gradients still flow). */
 /* dn_model.py:602-613, 655-656: rgb = clamp(render[:3] + (1-alpha) bg, 0, 1); depth = alpha > 0 ?
@@ -463,13 +473,14 @@ int fsgs_sh_fwd_pack_h16(int N, int K, int degree, const float *means, const flo
 int fsgs_sh_bwd_split_h16(int N, int K, int degree, const float *means, const float *campos, const void *features_dc_h,
                           const void *features_rest_h, const int32_t *radii, int D, const float *v_colors,
                           float *v_features_dc, float *v_features_rest, float *v_means, float *v_depths,
-                          int overwrite_means, fsgs_stream_t stream);
+                          int overwrite_means, int64_t replica_rows, fsgs_stream_t stream);
 int fsgs_gaussian_bwd_h16(int N, const float *means, const void *quats_h, const void *log_scales_h, const float *scales,
                           const float *opac, const float *viewmat, const float *K, const float *c2w, int width,
                           int height, float eps2d, const int32_t *radii, const float *conics, float *v_packed,
                           int accumulate_means, float *v_means, float *v_quats, float *v_log_scales,
                           float *v_opac_logit, float *absgrad, float *xys_grad_norm, float *vis_counts,
-                          float *max_2Dsize, float inv_max_hw, const uint8_t *frozen, fsgs_stream_t stream);
+                          float *max_2Dsize, float inv_max_hw, const uint8_t *frozen, int64_t replica_rows,
+                          fsgs_stream_t stream);
 int fsgs_adam_step_h16(int n_groups, float *const *params, const float *const *grads, float *const *exp_avg,
                        float *const *exp_avg_sq, void *const *half_mirrors, const int64_t *numel, const float *lr,
                        int step, double beta1, double beta2, float eps, fsgs_stream_t stream);

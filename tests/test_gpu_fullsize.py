@@ -193,6 +193,32 @@ def test_full_size_tape_free_step_equals_dropin_caller_step(dev, full_scene):
         assert rel_err(a.slab.views[k], b.slab.views[k]) < 5e-3, (k, rel_err(a.slab.views[k], b.slab.views[k]))
 
 
+def test_gradient_line_replicas_do_not_change_the_step(dev, full_scene, monkeypatch):
+    """Large Gaussians spread their backward atomics over 4 gradient lines (csrc/common.h grad_spread, fused.py
+    GRAD_REPLICAS): same gradients as with one line (to summation order), and the accumulator — replicas included —
+    is handed back all zero by its last reader."""
+    from fusionsense_amd import fused
+    from fusionsense_amd.trainer import PARAM_ORDER, SplatTrainer
+    params, cams = full_scene
+    big = {k: v.clone() for k, v in params.items()}
+    big["scales"][::7] += 1.5   # make sure some footprints pass the spread threshold
+    tgt = {"rgb": torch.rand(cams[0].height, cams[0].width, 3, device=dev),
+           "depth": torch.rand(cams[0].height, cams[0].width, 1, device=dev) * 4,
+           "normal": torch.nn.functional.normalize(torch.randn(cams[0].height, cams[0].width, 3, device=dev), dim=-1)}
+    grads = {}
+    for reps in (4, 1):
+        monkeypatch.setattr(fused, "GRAD_REPLICAS", reps)
+        fused._ACCUM.clear()
+        t = SplatTrainer(big, dev, sh_degree=3, fused=True, direct=True)
+        t.train_step(cams[0], tgt, optimizer_step=False)
+        grads[reps] = {k: t.slab.views[k].clone() for k in PARAM_ORDER}
+        acc = fused._ACCUM[str(torch.device(dev))] if str(torch.device(dev)) in fused._ACCUM else next(iter(fused._ACCUM.values()))
+        assert acc.shape[0] == reps * t.params["means"].shape[0] and not bool(acc.any())
+    fused._ACCUM.clear()
+    for k in PARAM_ORDER:
+        assert rel_err(grads[4][k], grads[1][k]) < 1e-4, (k, rel_err(grads[4][k], grads[1][k]))
+
+
 @pytest.mark.parametrize("case", ["empty", "all_behind_camera", "tiny_image", "odd_size", "single_gaussian"])
 def test_fused_node_edge_cases(dev, case):
     from fusionsense_amd.fused import render_fusionsense_fused

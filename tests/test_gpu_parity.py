@@ -220,11 +220,11 @@ def test_sh_gradient_from_factors(dev, degree):
         # per-view reference: the ordinary backward
         g_dc, g_rest, g_means = torch.empty_like(dc), torch.empty_like(rest), torch.empty_like(means)
         assert lib.fsgs_sh_bwd_split(1, N, K, degree, ptr(means), ptr(campos), ptr(dc), ptr(rest), ptr(radii), 16,
-                                     ptr(v_packed), ptr(g_dc), ptr(g_rest), ptr(g_means), None, 1, sp) == 0
+                                     ptr(v_packed), ptr(g_dc), ptr(g_rest), ptr(g_means), None, 1, 0, sp) == 0
         fac = torch.full((N + 1, 4), float("nan"), device=dev)
         g_means2 = torch.empty_like(means)
         assert lib.fsgs_sh_bwd_colors(N, K, degree, ptr(means), ptr(campos), ptr(dc), ptr(rest), ptr(radii), 16,
-                                      ptr(v_packed), ptr(fac), ptr(g_means2), 1, sp) == 0
+                                      ptr(v_packed), ptr(fac), ptr(g_means2), 1, 0, sp) == 0
         assert torch.equal(g_means2, g_means)
         assert torch.equal(fac[N, :3], campos) and bool((fac[:N, :3][radii[0] <= 0] == 0).all())
         r_dc, r_rest = torch.empty_like(dc), torch.empty_like(rest)
@@ -714,6 +714,7 @@ def test_folded_entry_points_equal_the_chains_they_replace(dev):
     P = {k: v.clone() for k, v in params.items()}
     P["means"][:40] *= 6.0        # some Gaussians off screen / behind the camera
     P["scales"][40:60] -= 3.0     # some below the radius threshold
+    P["scales"][60:90] += 2.0     # some with a large footprint (gradient-line replicas, see the end)
     P = {k: v.to(dev).contiguous() for k, v in P.items()}
     N, K = P["means"].shape[0], 1 + P["features_rest"].shape[1]
     W, H = cam.width, cam.height
@@ -849,9 +850,19 @@ def test_folded_entry_points_equal_the_chains_they_replace(dev):
                                     ptr(extra), ptr(v_extra), ptr(acc_a), sp) == 0
     assert lib.fsgs_raster_bwd_quad_images(ptr(records), ptr(n_rec), ptr(offsets), M, W, H, tw, th, ptr(render),
                                            ptr(alphas), ptr(last_ids), ptr(extra), ptr(bg), ptr(vr_a), ptr(vd_a),
-                                           ptr(vn_a), ptr(v_alpha), ptr(seg_state), 1, ptr(acc_b), sp) == 0
+                                           ptr(vn_a), ptr(v_alpha), ptr(seg_state), 1, ptr(acc_b), 0, sp) == 0
     assert float(acc_a.abs().max()) > 0
     assert rel_err(acc_b, acc_a) < 1e-5
+    # gradient-line replicas (common.h grad_spread): large Gaussians spread their atomics over 4 lines N rows apart,
+    # small ones keep to line 0; the lines sum to the unspread result
+    acc_r = torch.zeros(4 * N, 16, **f32)
+    assert lib.fsgs_raster_bwd_quad_images(ptr(records), ptr(n_rec), ptr(offsets), M, W, H, tw, th, ptr(render),
+                                           ptr(alphas), ptr(last_ids), ptr(extra), ptr(bg), ptr(vr_a), ptr(vd_a),
+                                           ptr(vn_a), ptr(v_alpha), ptr(seg_state), 1, ptr(acc_r), N, sp) == 0
+    lines = acc_r.view(4, N, 16)
+    assert rel_err(lines.sum(0), acc_a) < 1e-5
+    used = lines[1:].abs().sum((0, 2)) > 0
+    assert bool(used.any()) and not bool(used.all())
 
 
 def test_finite_differences_of_the_hip_path(dev):
