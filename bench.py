@@ -276,7 +276,9 @@ def main():
         local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # (FSGS_FORCE_COLLECTIVES=1 under a one-rank launcher: the multi-GPU step's RCCL calls on a one-GPU box)
+    one_rank_group = world == 1 and os.environ.get("FSGS_FORCE_COLLECTIVES") == "1" and "MASTER_PORT" in os.environ
+    if world > 1 or one_rank_group:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
@@ -294,8 +296,10 @@ def main():
     def view_of(step):
         return (step * world + rank) % len(cams)
 
+    grouped = dist.is_initialized()
+
     def barrier():
-        if world > 1:
+        if grouped:
             dist.barrier()
 
     # ---- setup: size the workspace pool for every view (forward + backward, no optimizer step), so that
@@ -370,7 +374,12 @@ def main():
     gc.enable()
     gc.unfreeze()
     kernel_ms = ops.TIMER.summary()
-    if world > 1 and os.environ.get("FSGS_BENCH_CHECK_REPLICAS"):
+    if os.environ.get("FSGS_BENCH_PARAM_DIGEST"):
+        # (float atomics: two runs agree to rounding, not to the bit — a digest to compare with a tolerance)
+        log('param digest ' + json.dumps({name: [float(trainer.params[name].data.double().mean()),
+                                                 float(trainer.params[name].data.double().abs().mean())]
+                                          for name in sorted(trainer.params)}))
+    if grouped and os.environ.get("FSGS_BENCH_CHECK_REPLICAS"):
         # the ranks must hold bit-identical parameters after the timed steps (rank-ordered gradient sums)
         for name, prm in trainer.params.items():
             ref = prm.data.clone()
@@ -380,7 +389,7 @@ def main():
     n_alloc = torch.cuda.memory_stats(dev).get('num_device_alloc', 0) - n_alloc0
     log(f'timed region done: {elapsed:.3f}s')
     ops.TIMER.reset(enabled=False)
-    if world > 1:
+    if grouped:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
@@ -546,8 +555,8 @@ def main():
                        "n_isects": M, "n_isects_live": n_live, "n_visible": n_vis,
                        "isects_per_gaussian": round(M / max(N, 1), 3),
                        "normal_pass_list_reuse": bool(reused), "parallelism": f"dp{world}",
-                       "backend": (backend if world > 1 else None),
-                       "comm_bytes_per_step_per_rank": getattr(trainer, "comm_bytes_last_step", 0) if world > 1 else 0},
+                       "backend": (backend if grouped else None),
+                       "comm_bytes_per_step_per_rank": getattr(trainer, "comm_bytes_last_step", 0) if grouped else 0},
             "rendered_mpix_per_s": round(world * P / t_fwd / 1e6, 2),
             "fwd_ms": round(t_fwd * 1e3, 3),
             "iters_per_s_excl_optimizer": round(world / t_noopt, 3),
@@ -572,7 +581,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(line))
-    if world > 1:
+    if grouped:
         dist.destroy_process_group()
 
 

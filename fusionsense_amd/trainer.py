@@ -69,13 +69,24 @@ class GradSlab:
     def zero_(self) -> None:
         self.flat.zero_()
 
+    # FSGS_FORCE_COLLECTIVES=1: issue the collectives in a one-rank group too (they are identities there) — lets a
+    # one-GPU box run the very RCCL calls of the multi-GPU step (tests/test_gpu_configs.py)
+    force_collectives = os.environ.get("FSGS_FORCE_COLLECTIVES", "0") == "1"
+
     @staticmethod
     def _world(group=None) -> int:
         return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
 
+    @classmethod
+    def _exchange(cls, group=None) -> bool:
+        """Whether a collective has to be issued at all."""
+        if not (dist.is_available() and dist.is_initialized()):
+            return False
+        return cls._world(group) > 1 or cls.force_collectives
+
     def _reduce_mean(self, t: Tensor, group, async_op: bool):
         """Mean over the ranks, in place.  Returns None (done, in stream order) or a callable that completes it."""
-        if self._world(group) <= 1 or t.numel() == 0:
+        if not self._exchange(group) or t.numel() == 0:
             return None
         if dist.get_backend(group) == "nccl":
             # RCCL averages inside the collective: no extra 2 x 236 B/Gaussian scaling pass
@@ -370,7 +381,7 @@ class SplatTrainer:
         if factors is not None:
             own, gathered = factors
             work = None
-            if GradSlab._world() > 1:
+            if GradSlab._exchange():
                 if self._gather_flat is None:
                     # RCCL has the flat form; gloo only the list form.  A function of the backend alone, so every
                     # rank decides the same way.

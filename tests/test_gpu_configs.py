@@ -462,6 +462,28 @@ def test_two_ranks_over_rccl_when_two_gpus():
     assert err.count("replicas identical") == 2, err[-2000:]
 
 
+def test_rccl_collectives_of_the_multi_gpu_step_in_a_one_rank_group():
+    """The RCCL calls of the data-parallel step (all_reduce AVG on the geometry half, asynchronous
+    all_gather_into_tensor of the SH factors, broadcast / barrier / MAX of the bench) really issued on this box's one
+    GPU: a one-rank "nccl" group with FSGS_FORCE_COLLECTIVES=1 (identities, but the same library calls, stream
+    ordering and deferred feature update as with 8 ranks).  The training must equal the plain single-process run."""
+    from helpers import run_bench_ranks
+    args = ["--steps", "8", "--warmup", "2", "--n-gauss", "50000", "--res", "320", "--views", "4", "--no-cpu-baseline"]
+    line, err = run_bench_ranks(1, args, dict(FSGS_FORCE_COLLECTIVES="1", FSGS_FORCE_SPLIT_STEP="1",
+                                              FSGS_BENCH_CHECK_REPLICAS="1", FSGS_BENCH_PARAM_DIGEST="1"))
+    assert line["n_gpus"] == 1 and line["config"]["backend"] == "nccl" and line["value"] > 0
+    assert line["config"]["comm_bytes_per_step_per_rank"] > 0, "the collectives were not issued"
+    assert "replicas identical" in err
+    plain, err2 = run_bench_ranks(1, args, dict(FSGS_FORCE_SPLIT_STEP="1", FSGS_BENCH_PARAM_DIGEST="1"))
+    assert plain["config"]["backend"] is None
+    import json
+    dig = lambda e: json.loads([l for l in e.splitlines() if "param digest" in l][-1].split("param digest")[1])
+    a, b = dig(err), dig(err2)
+    for name in a:  # (float atomics: equal to rounding; a missing or doubled update would move these by percents)
+        assert abs(a[name][1] - b[name][1]) <= 1e-4 * abs(b[name][1]) + 1e-7, (name, a[name], b[name])
+        assert abs(a[name][0] - b[name][0]) <= 1e-4 * abs(b[name][1]) + 1e-7, (name, a[name], b[name])
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # inference callers (row N4): eval loop and mesh back-projection over the HIP forward
 # ---------------------------------------------------------------------------------------------------------------
