@@ -333,18 +333,21 @@ isect_live_flat_kernel(int C, int N, const float *__restrict__ means2d, const in
 // followed by the in-tile sorts.  Four launches fewer, no emission-order arrays, no per-Gaussian scan.
 // The claiming order inside a bucket is arbitrary; the in-tile sort on (depth, id) makes the result
 // deterministic and bit-identical to the list chain's.
-constexpr int kBinWaves = 16, kBinThreads = 64 * kBinWaves;
+// Workgroup size: 1024 threads at N >= 256 k; smaller scenes take 512 / 256 so that the launch still has >= 256
+// workgroups (config #3's 75 k Gaussians in chunks of 1024 would occupy 74 of the 256 CUs).
+constexpr int kBinThreadsMax = 1024;
 
 // per workgroup: its 1024 Gaussians' reach-test constants and tile rectangles.  The pairs of ALL of them are
 // flattened over the 1024 threads (pair p of the workgroup -> its Gaussian by bisection over the exclusive
 // prefix of the rectangle sizes), so every wave gets the same share however large single splats are.
+template <int BT>
 struct BinLds {
-    int excl[kBinThreads];     // exclusive prefix of the rectangle sizes
-    float4 a[kBinThreads];     // CullPrep: mx, my, b, tau
-    float4 b[kBinThreads];     // CullPrep: ha, hc, inv_a, inv_c
-    int4 rect[kBinThreads];    // x0, y0, width, count
-    uint32_t depth[kBinThreads];
-    int wave_sum[kBinWaves];
+    int excl[BT];     // exclusive prefix of the rectangle sizes
+    float4 a[BT];     // CullPrep: mx, my, b, tau
+    float4 b[BT];     // CullPrep: ha, hc, inv_a, inv_c
+    int4 rect[BT];    // x0, y0, width, count
+    uint32_t depth[BT];
+    int wave_sum[BT / 64];
 };
 
 // PROJ (count pass, one camera): the workgroup PROJECTS its Gaussians itself (project_math.h, with the activations
@@ -363,8 +366,8 @@ struct BinProjArgs {
     int attr_half;
 };
 
-template <bool SCATTER, bool MULTI, bool PROJ, bool HALF = false>
-__global__ void __launch_bounds__(kBinThreads)
+template <bool SCATTER, bool MULTI, bool PROJ, bool HALF = false, int BT = kBinThreadsMax>
+__global__ void __launch_bounds__(BT)
 isect_live_bin_kernel(int C, int N, const float *__restrict__ means2d, const int32_t *__restrict__ radii,
                       const float *__restrict__ depths, const float *__restrict__ conics,
                       const float *__restrict__ opacities, int tw, int th, int T, int nb, int chunks,
@@ -372,8 +375,9 @@ isect_live_bin_kernel(int C, int N, const float *__restrict__ means2d, const int
                       const int32_t *__restrict__ offsets, uint64_t *__restrict__ buckets, BinProjArgs pj,
                       int bucket_cap = 0x7FFFFFFF) {
     extern __shared__ __attribute__((aligned(16))) unsigned char bin_smem[];
-    BinLds &L = *reinterpret_cast<BinLds *>(bin_smem);
-    int *slots = reinterpret_cast<int *>(bin_smem + sizeof(BinLds));
+    constexpr int kBinThreads = BT, kBinWaves = BT / 64;
+    BinLds<BT> &L = *reinterpret_cast<BinLds<BT> *>(bin_smem);
+    int *slots = reinterpret_cast<int *>(bin_smem + sizeof(BinLds<BT>));
     const int64_t total = (int64_t)C * N;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     // `chunks` groups of 1024 Gaussians per workgroup, one after the other into the same tile slots: the table has
@@ -663,16 +667,24 @@ int launch_split_sort(int T, int n_tiles, int tile_bits, const int32_t *isect_of
 int64_t split_scratch_ints(int T, int64_t n_live);
 }
 
+// threads per workgroup: the largest of 1024 / 512 / 256 that still gives >= 256 workgroups
+static inline int bin_threads(int64_t total) {
+    return total >= 256 * 1024 ? 1024 : (total >= 256 * 512 ? 512 : 256);
+}
 // chunks of 1024 Gaussians per workgroup: as many as keep the table at ~512 rows
 static inline int bin_chunks(int64_t total) {
-    const int64_t c = (total + (int64_t)kBinThreads * 512 - 1) / ((int64_t)kBinThreads * 512);
+    const int64_t c = (total + (int64_t)kBinThreadsMax * 512 - 1) / ((int64_t)kBinThreadsMax * 512);
     return c < 1 ? 1 : (int)c;
 }
 static inline int64_t bin_blocks(int64_t total) {
-    const int64_t per = (int64_t)kBinThreads * bin_chunks(total);
+    const int64_t per = (int64_t)bin_threads(total) * bin_chunks(total);
     return (total + per - 1) / per;
 }
-static inline size_t bin_lds_bytes(int T) { return sizeof(BinLds) + (size_t)T * sizeof(int); }
+static inline size_t bin_lds_bytes(int T, int64_t total) {
+    const int bt = bin_threads(total);
+    const size_t fixed = bt == 1024 ? sizeof(BinLds<1024>) : (bt == 512 ? sizeof(BinLds<512>) : sizeof(BinLds<256>));
+    return fixed + (size_t)T * sizeof(int);
+}
 
 // tiles (cameras x tiles) the direct path can take: the per-workgroup tile slots live in LDS (160 KB per CU)
 extern "C" int fsgs_bin_live_max_tiles(void) { return 24576; }
@@ -684,23 +696,30 @@ extern "C" size_t fsgs_bin_live_table_bytes(int C, int N, int tile_width, int ti
     return (size_t)(T * nb + T) * sizeof(int32_t) + 64;
 }
 
-static int bin_set_lds(int T) {
-    static size_t have[2] = {0, 0};
-    const size_t need = bin_lds_bytes(T);
-    if (need > have[0]) {
-        const void *kernels[6] = {reinterpret_cast<const void *>(&isect_live_bin_kernel<false, false, false>),
-                                  reinterpret_cast<const void *>(&isect_live_bin_kernel<false, true, false>),
-                                  reinterpret_cast<const void *>(&isect_live_bin_kernel<true, false, false>),
-                                  reinterpret_cast<const void *>(&isect_live_bin_kernel<true, true, false>),
-                                  reinterpret_cast<const void *>(&isect_live_bin_kernel<false, false, true>),
-                                  reinterpret_cast<const void *>(&isect_live_bin_kernel<false, true, true>)};
-        hipError_t e = hipSuccess;
-        for (int k = 0; k < 6 && e == hipSuccess; ++k)
-            e = hipFuncSetAttribute(kernels[k], hipFuncAttributeMaxDynamicSharedMemorySize, (int)need);
+// one launch of isect_live_bin_kernel<SC, multi?, PJ, HF, threads(total)>: dynamic LDS limit raised on first need
+template <bool SC, bool MU, bool PJ, bool HF, int BT, typename... Args>
+static int bin_launch_one(int T, int64_t total, int nb, hipStream_t s, Args... args) {
+    static size_t have = 0;
+    const size_t need = bin_lds_bytes(T, total);
+    auto kernel = &isect_live_bin_kernel<SC, MU, PJ, HF, BT>;
+    if (need > have) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)need);
         if (e != hipSuccess) { g_last_hip_error = (int)e; return FSGS_ELAUNCH; }
-        have[0] = need;
+        have = need;
     }
-    return FSGS_OK;
+    hipLaunchKernelGGL(kernel, dim3(nb), dim3(BT), need, s, args...);
+    return check_launch();
+}
+template <bool SC, bool PJ, bool HF, typename... Args>
+static int bin_launch(int T, int64_t total, int nb, hipStream_t s, Args... args) {
+    switch (bin_threads(total)) {
+    case 1024:
+        if (bin_chunks(total) > 1) return bin_launch_one<SC, true, PJ, HF, 1024>(T, total, nb, s, args...);
+        return bin_launch_one<SC, false, PJ, HF, 1024>(T, total, nb, s, args...);
+    case 512: return bin_launch_one<SC, false, PJ, HF, 512>(T, total, nb, s, args...);
+    default: return bin_launch_one<SC, false, PJ, HF, 256>(T, total, nb, s, args...);
+    }
 }
 
 // Pass 1 + the per-tile scans: tiles_per_gauss (gsplat's count, nullable), isect_offsets[T + 1] with
@@ -729,15 +748,10 @@ extern "C" int fsgs_bin_live_count(int C, int N, const float *means2d, const int
     const int nb = (int)bin_blocks(total);
     int32_t *table = reinterpret_cast<int32_t *>(table_scratch);
     int32_t *totals = table + (size_t)T * nb;
-    int rc = bin_set_lds(T);
-    if (rc != FSGS_OK) return rc;
-#define FSGS_BIN_COUNT(MU)                                                                                          \
-    hipLaunchKernelGGL((isect_live_bin_kernel<false, MU, false>), dim3(nb), dim3(kBinThreads), bin_lds_bytes(T), s,   \
-                       C, N, means2d, radii, nullptr, conics, opacities, tile_width, tile_height, T, nb,               \
-                       bin_chunks(total), tiles_per_gauss, table, nullptr, nullptr, BinProjArgs{})
-    if (bin_chunks(total) > 1) FSGS_BIN_COUNT(true); else FSGS_BIN_COUNT(false);
-#undef FSGS_BIN_COUNT
-    rc = check_launch();
+    int rc = bin_launch<false, false, false>(T, total, nb, s, C, N, means2d, radii, (const float *)nullptr, conics,
+                                             opacities, tile_width, tile_height, T, nb, bin_chunks(total),
+                                             tiles_per_gauss, table, (const int32_t *)nullptr, (uint64_t *)nullptr,
+                                             BinProjArgs{}, 0x7FFFFFFF);
     if (rc != FSGS_OK) return rc;
     return launch_tile_scan_rows_offsets(T, nb, table, totals, isect_offsets, n_live_mapped, s);
 }
@@ -777,22 +791,17 @@ static int project_bin_live_count_impl(int N, const float *means, const void *qu
     const int nb = (int)bin_blocks(total);
     int32_t *table = reinterpret_cast<int32_t *>(table_scratch);
     int32_t *totals = table + (size_t)T * nb;
-    int rc = bin_set_lds(T);
-    if (rc != FSGS_OK) return rc;
+    int rc;
     const BinProjArgs pj = {means, quats, log_scales, viewmat, K, opac_logit, scales_out, opac_out, means2d, depths,
                             conics, radii, width, height, binarise, eps2d, near_plane, far_plane, radius_clip,
                             binary_threshold, reinterpret_cast<__half *>(opac_logit_h), attr_half};
-#define FSGS_BIN_PCOUNT(MU, HF)                                                                                     \
-    hipLaunchKernelGGL((isect_live_bin_kernel<false, MU, true, HF>), dim3(nb), dim3(kBinThreads), bin_lds_bytes(T), s, 1, \
-                       N, nullptr, nullptr, nullptr, nullptr, nullptr, tile_width, tile_height, T, nb,                 \
-                       bin_chunks(total), tiles_per_gauss, table, nullptr, nullptr, pj)
-    if (attr_half) {
-        if (bin_chunks(total) > 1) FSGS_BIN_PCOUNT(true, true); else FSGS_BIN_PCOUNT(false, true);
-    } else {
-        if (bin_chunks(total) > 1) FSGS_BIN_PCOUNT(true, false); else FSGS_BIN_PCOUNT(false, false);
-    }
+#define FSGS_BIN_PCOUNT(HF)                                                                                         \
+    bin_launch<false, true, HF>(T, total, nb, s, 1, N, (const float *)nullptr, (const int32_t *)nullptr,              \
+                                (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, tile_width,  \
+                                tile_height, T, nb, bin_chunks(total), tiles_per_gauss, table,                        \
+                                (const int32_t *)nullptr, (uint64_t *)nullptr, pj, 0x7FFFFFFF)
+    rc = attr_half ? FSGS_BIN_PCOUNT(true) : FSGS_BIN_PCOUNT(false);
 #undef FSGS_BIN_PCOUNT
-    rc = check_launch();
     if (rc != FSGS_OK) return rc;
     return launch_tile_scan_rows_offsets(T, nb, table, totals, isect_offsets, n_live_mapped, s);
 }
@@ -879,16 +888,10 @@ static int bin_live_emit_impl(int C, int N, const float *means2d, const int32_t 
     hipStream_t s = as_stream(stream);
     const int nb = (int)bin_blocks((int64_t)C * N);
     int32_t *table = const_cast<int32_t *>(reinterpret_cast<const int32_t *>(table_scratch));
-    int rc = bin_set_lds(T);
-    if (rc != FSGS_OK) return rc;
-#define FSGS_BIN_FILL(MU)                                                                                           \
-    hipLaunchKernelGGL((isect_live_bin_kernel<true, MU, false>), dim3(nb), dim3(kBinThreads), bin_lds_bytes(T), s, C, \
-                       N, means2d, radii, depths, conics, opacities, tile_width, tile_height, T, nb,                   \
-                       bin_chunks((int64_t)C * N), nullptr, table, isect_offsets, reinterpret_cast<uint64_t *>(buckets), \
-                       BinProjArgs{}, (int)n_live)
-    if (bin_chunks((int64_t)C * N) > 1) FSGS_BIN_FILL(true); else FSGS_BIN_FILL(false);
-#undef FSGS_BIN_FILL
-    rc = check_launch();
+    int rc = bin_launch<true, false, false>(T, (int64_t)C * N, nb, s, C, N, means2d, radii, depths, conics, opacities,
+                                            tile_width, tile_height, T, nb, bin_chunks((int64_t)C * N),
+                                            (int32_t *)nullptr, table, isect_offsets,
+                                            reinterpret_cast<uint64_t *>(buckets), BinProjArgs{}, (int)n_live);
     if (rc != FSGS_OK) return rc;
     int tb = 0;
     while ((1ll << tb) <= n_tiles) ++tb;
