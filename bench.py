@@ -40,6 +40,32 @@ import torch.distributed as dist
 _T0 = time.time()
 
 
+def gpu_step_stats(events, views):
+    """GPU-side duration of every timed step (event to event on the step's stream): quantiles, and — the views differ
+    in work — the largest ratio of a step to the median of the steps of ITS view when views repeat (host stalls and
+    redone frames show here; a different view does not)."""
+    d = [events[i].elapsed_time(events[i + 1]) for i in range(len(events) - 1)]
+    if not d:
+        return None
+    q = sorted(d)
+    out = {"p50": round(q[len(q) // 2], 4), "p99": round(q[min(len(q) - 1, int(0.99 * len(q)))], 4),
+           "max": round(q[-1], 4)}
+    if len(d) >= 8:  # drift over the run (clocks, growing state): the mean of each quarter
+        n4 = len(d) // 4
+        out["mean_by_quarter"] = [round(sum(d[k * n4:(k + 1) * n4]) / n4, 4) for k in range(4)]
+    by_view = {}
+    for v, t in zip(views, d):
+        by_view.setdefault(v, []).append(t)
+    ratios = []
+    for v, ts in by_view.items():
+        if len(ts) >= 3:
+            med = sorted(ts)[len(ts) // 2]
+            ratios.append(max(ts) / med)
+    if ratios:
+        out["max_over_view_median"] = round(max(ratios), 4)
+    return out
+
+
 def log(msg):
     if os.environ.get("FSGS_BENCH_VERBOSE"):
         print(f"[bench +{time.time() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
@@ -363,9 +389,18 @@ def main():
     n_before = trainer.num_gaussians()
     t0 = time.perf_counter()
     step_ends = []
+    # one event per step on the step's stream: the GPU-side duration of every step, read after the timed region
+    step_events = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    step_views = []
+    with_events = not os.environ.get("FSGS_BENCH_NO_STEP_EVENTS")
+    if with_events:
+        step_events[0].record()
     for s in range(args.steps):
         v = view_of(args.warmup + s)
         trainer.train_step(cams[v], targets[v])
+        if with_events:
+            step_events[s + 1].record()
+        step_views.append(v)
         step_ends.append(time.perf_counter())
     trainer.flush()  # (data-parallel runs: the last step's deferred feature update belongs to the timed work)
     torch.cuda.synchronize()
@@ -568,6 +603,7 @@ def main():
             "device_mallocs_in_timed_region": n_alloc,
             "max_step_ms": round(1e3 * max(b - a for a, b in zip([t0] + step_ends[:-1], step_ends)), 3),
             "slowest_step": max(range(len(step_ends)), key=lambda i: step_ends[i] - ([t0] + step_ends)[i]),
+            "gpu_step_ms": gpu_step_stats(step_events, step_views) if with_events else None,
             "kernels_ms": kernel_ms,
             "roofline": roofline,
         }
