@@ -146,11 +146,13 @@ ssim_l1_fwd_kernel(int H, int W, const float *__restrict__ pred, const float *__
             const float s1 = e11 - mu1_sq, s2 = e22 - mu2_sq, s12 = e12 - mu12;
             const float A = mu1_sq + mu2_sq + C1, B = s1 + s2 + C2;
             const float C = 2.f * mu12 + C1, D = 2.f * s12 + C2;
-            ssim += (C * D) / (A * B);
-            d_mu1 = (mu2 * 2.f * D) / (A * B) - (mu2 * 2.f * C) / (A * B) - (mu1 * 2.f * C * D) / (A * A * B) +
-                    (mu1 * 2.f * C * D) / (A * B * B);
-            d_s1 = (-C * D) / (A * B * B);
-            d_s12 = (2.f * C) / (A * B);
+            // (two reciprocals instead of eight IEEE divisions: 1 ulp each, far inside the parity tolerance)
+            const float rA = __builtin_amdgcn_rcpf(A), rB = __builtin_amdgcn_rcpf(B);
+            const float X = rA * rB, CDX = C * D * X;
+            ssim += CDX;
+            d_mu1 = 2.f * (mu2 * (D - C) * X + mu1 * CDX * (rB - rA));
+            d_s1 = -CDX * rB;
+            d_s12 = 2.f * C * X;
         }
         if (in_img) {
             const int64_t oo = ((int64_t)ch * H + y) * W + x;  // planar [3,H,W]: coalesced rows
