@@ -436,9 +436,28 @@ isect_live_bin_kernel(int C, int N, const float *__restrict__ means2d, const int
             if (!SCATTER && tiles_per_gauss) tiles_per_gauss[idx] = cnt;
         }
         const CullPrep cp = cull_prepare(mx, my, op, ca, cb, cc);
+        // Enumerate only the tiles the level set {sigma <= tau} can touch: its axis-aligned extent
+        // (sqrt(2 tau cov_xx), sqrt(2 tau cov_yy)) plus one pixel of slack, inside gsplat's 3-sigma square.  Every
+        // tile left out fails the exact reach test by more than that pixel, so the live pairs are the same; on
+        // config #2 28 % of the square's tiles are never visited (elongated and faint Gaussians).
+        if (cnt > 0) {
+            if (cp.tau == -__builtin_huge_valf()) {
+                t.x1 = t.x0; t.y1 = t.y0;
+            } else if (cp.tau < 3.0e38f) {
+                const float det = 4.f * cp.ha * cp.hc - cp.b * cp.b;  // (positive: cull_prepare checked it)
+                const float k = 2.f * fmaxf(cp.tau, 0.f) / det;
+                const float ex = sqrtf(k * 2.f * cp.hc) + 1.f, ey = sqrtf(k * 2.f * cp.ha) + 1.f;
+                // tile j holds the pixel centres 16 j + 0.5 .. 16 j + 15.5
+                t.x0 = max(t.x0, (int)ceilf((mx - ex - 15.5f) * (1.f / 16.f)));
+                t.x1 = min(t.x1, (int)floorf((mx + ex - 0.5f) * (1.f / 16.f)) + 1);
+                t.y0 = max(t.y0, (int)ceilf((my - ey - 15.5f) * (1.f / 16.f)));
+                t.y1 = min(t.y1, (int)floorf((my + ey - 0.5f) * (1.f / 16.f)) + 1);
+            }
+            cnt = max(t.x1 - t.x0, 0) * max(t.y1 - t.y0, 0);
+        }
         L.a[tid] = make_float4(cp.mx, cp.my, cp.b, cp.tau);
         L.b[tid] = make_float4(cp.ha, cp.hc, cp.inv_a, cp.inv_c);
-        L.rect[tid] = make_int4(t.x0, t.y0, t.x1 - t.x0, cnt);
+        L.rect[tid] = make_int4(t.x0, t.y0, max(t.x1 - t.x0, 1), cnt);
         L.depth[tid] = db;
     }
     if (ch == 0) {  // (after the chunk's own loads were issued: the slot rows come from memory in the fill pass)
