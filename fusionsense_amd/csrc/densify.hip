@@ -25,9 +25,10 @@ normals_fwd_kernel(int N, const float *__restrict__ quats, const float *__restri
 #pragma unroll
     for (int k = 0; k < 3; ++k) normals_world[n * 3 + k] = o.n[k];
     // n_cam = n @ c2w[:3,:3]  ->  n_cam[j] = sum_i n[i] * R[i][j]
+    float ex[3];
+    normal_to_camera(o.n, c2w, ex);
 #pragma unroll
-    for (int j = 0; j < 3; ++j)
-        normals_cam[n * 3 + j] = o.n[0] * c2w[0 * 4 + j] + o.n[1] * c2w[1 * 4 + j] + o.n[2] * c2w[2 * 4 + j];
+    for (int j = 0; j < 3; ++j) normals_cam[n * 3 + j] = ex[j];
 }
 
 __global__ void __launch_bounds__(256)

@@ -49,8 +49,7 @@ live_pack_kernel(int64_t total, const float *__restrict__ means2d, const float *
         normal_forward(q, ls, mean, c2w, o);
 #pragma unroll
         for (int k = 0; k < 3; ++k) normals_world[g * 3 + k] = o.n[k];
-#pragma unroll
-        for (int j = 0; j < 3; ++j) ex[j] = o.n[0] * c2w[0 * 4 + j] + o.n[1] * c2w[1 * 4 + j] + o.n[2] * c2w[2 * 4 + j];
+        normal_to_camera(o.n, c2w, ex);
         has_extra = true;
     } else if (extra) {
         ex[0] = extra[g * 3 + 0]; ex[1] = extra[g * 3 + 1]; ex[2] = extra[g * 3 + 2];

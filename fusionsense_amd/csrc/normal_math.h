@@ -16,6 +16,9 @@ struct NormalCtx {
 
 __device__ __forceinline__ void normal_forward(const float4 q, const float *ls, const float *mean,
                                                const float *c2w, NormalCtx &o) {
+    // (no FMA contraction: the kernels that inline this — packing forward in its storage variants, the per-Gaussian
+    // backward — must produce the same normal to the bit)
+#pragma clang fp contract(off)
     const float qn = fmaxf(sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w), 1e-12f);
     o.inv_qn = 1.f / qn;
     o.qw = q.x * o.inv_qn; o.qx = q.y * o.inv_qn; o.qy = q.z * o.inv_qn; o.qz = q.w * o.inv_qn;
@@ -35,6 +38,13 @@ __device__ __forceinline__ void normal_forward(const float4 q, const float *ls, 
     const float vx = c2w[3] - mean[0], vy = c2w[7] - mean[1], vz = c2w[11] - mean[2];
     o.sign = (c0 * vx + c1 * vy + c2 * vz < 0.f) ? -1.f : 1.f;
     o.n[0] = o.sign * c0; o.n[1] = o.sign * c1; o.n[2] = o.sign * c2;
+}
+
+// world -> camera rotation of a normal (rows of c2w^T), same fixed rounding sequence
+__device__ __forceinline__ void normal_to_camera(const float *n, const float *c2w, float *ex) {
+#pragma clang fp contract(off)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) ex[j] = n[0] * c2w[0 * 4 + j] + n[1] * c2w[1 * 4 + j] + n[2] * c2w[2 * 4 + j];
 }
 
 // v_quats (raw, un-normalised quaternion) from the gradient of the CAMERA-space normal

@@ -16,10 +16,19 @@ namespace fsgs {
 
 constexpr int kMaxK = 25;
 
+// 1 / |d| with one fixed rounding sequence (see sh_basis)
+__device__ __forceinline__ float sh_inv_norm(float dx, float dy, float dz) {
+#pragma clang fp contract(off)
+    return 1.f / fmaxf(sqrtf(dx * dx + dy * dy + dz * dz), 1e-12f);
+}
+
 // basis values b[k] and (optionally) their gradients w.r.t. the unit direction.
 template <bool GRAD>
 __device__ __forceinline__ void sh_basis(int degree, float x, float y, float z, float *b, float *bx,
                                          float *by, float *bz) {
+    // (no FMA contraction: the kernels that evaluate the basis — forward, backward, and the data-parallel rebuild of
+    // the backward from its factors — are separate inlines of these statements and must agree to the bit)
+#pragma clang fp contract(off)
     b[0] = 0.2820947917738781f;
     if (GRAD) bx[0] = by[0] = bz[0] = 0.f;
     if (degree < 1) return;
@@ -382,7 +391,7 @@ sh_fwd_kernel(int C, int N, int K, int degree, const float *__restrict__ means,
         float r = 0.5f, g = 0.5f, bl = 0.5f;
         if ((c ? radii[idx] : rad0) > 0) {
             float dx = mx - campos[c * 3 + 0], dy = myy - campos[c * 3 + 1], dz = mz - campos[c * 3 + 2];
-            const float inorm = 1.f / fmaxf(sqrtf(dx * dx + dy * dy + dz * dz), 1e-12f);
+            const float inorm = sh_inv_norm(dx, dy, dz);
             dx *= inorm; dy *= inorm; dz *= inorm;
             float b[kMaxK];
             sh_basis<false>(degree, dx, dy, dz, b, nullptr, nullptr, nullptr);
@@ -390,9 +399,9 @@ sh_fwd_kernel(int C, int N, int K, int degree, const float *__restrict__ means,
 #pragma unroll
             for (int k = 0; k < kMaxK; ++k) {
                 if (k < kk) {
-                    ar += b[k] * my[k * 3 + 0];
-                    ag += b[k] * my[k * 3 + 1];
-                    ab += b[k] * my[k * 3 + 2];
+                    ar = __builtin_fmaf(b[k], my[k * 3 + 0], ar);
+                    ag = __builtin_fmaf(b[k], my[k * 3 + 1], ag);
+                    ab = __builtin_fmaf(b[k], my[k * 3 + 2], ab);
                 }
             }
             r = fmaxf(ar + 0.5f, 0.f);
@@ -407,9 +416,7 @@ sh_fwd_kernel(int C, int N, int K, int degree, const float *__restrict__ means,
             float ex[3];
 #pragma unroll
             for (int k = 0; k < 3; ++k) pk.normals_world[n * 3 + k] = o.n[k];
-#pragma unroll
-            for (int j = 0; j < 3; ++j)
-                ex[j] = o.n[0] * pk.c2w[0 * 4 + j] + o.n[1] * pk.c2w[1 * 4 + j] + o.n[2] * pk.c2w[2 * 4 + j];
+            normal_to_camera(o.n, pk.c2w, ex);
             pk.packed[n * 4 + 0] = make_float4(pxy.x, pxy.y, pop, pcon[0]);
             pk.packed[n * 4 + 1] = make_float4(pcon[1], pcon[2], 0.f, 0.f);
             pk.packed[n * 4 + 2] = make_float4(r, g, bl, dep0);
@@ -477,16 +484,16 @@ sh_bwd_kernel(int C, int N, int K, int degree, const float *__restrict__ means,
         const bool vis = rad0 > 0;
         if (vis) {
             dx = mx - campos[0]; dy = myy - campos[1]; dz = mz - campos[2];
-            inorm = 1.f / fmaxf(sqrtf(dx * dx + dy * dy + dz * dz), 1e-12f);
+            inorm = sh_inv_norm(dx, dy, dz);
             dx *= inorm; dy *= inorm; dz *= inorm;
             sh_basis<true>(degree, dx, dy, dz, b, bx, by, bz);
             float ar = 0.f, ag = 0.f, ab = 0.f;
 #pragma unroll
             for (int k = 0; k < kMaxK; ++k) {
                 if (k < kk) {
-                    ar += b[k] * my[k * 3 + 0];
-                    ag += b[k] * my[k * 3 + 1];
-                    ab += b[k] * my[k * 3 + 2];
+                    ar = __builtin_fmaf(b[k], my[k * 3 + 0], ar);
+                    ag = __builtin_fmaf(b[k], my[k * 3 + 1], ag);
+                    ab = __builtin_fmaf(b[k], my[k * 3 + 2], ab);
                 }
             }
             vr = (ar + 0.5f > 0.f) ? vc0 : 0.f;
@@ -532,7 +539,7 @@ sh_bwd_kernel(int C, int N, int K, int degree, const float *__restrict__ means,
             if (D == 4 && v_depths) v_depths[idx] = v_colors[idx * 4 + 3];
             if (radii[idx] <= 0) continue;
             float dx = mx - campos[c * 3 + 0], dy = myy - campos[c * 3 + 1], dz = mz - campos[c * 3 + 2];
-            const float inorm = 1.f / fmaxf(sqrtf(dx * dx + dy * dy + dz * dz), 1e-12f);
+            const float inorm = sh_inv_norm(dx, dy, dz);
             dx *= inorm; dy *= inorm; dz *= inorm;
             float b[kMaxK], bx[kMaxK], by[kMaxK], bz[kMaxK];
             sh_basis<true>(degree, dx, dy, dz, b, bx, by, bz);
@@ -540,9 +547,9 @@ sh_bwd_kernel(int C, int N, int K, int degree, const float *__restrict__ means,
 #pragma unroll
             for (int k = 0; k < kMaxK; ++k) {
                 if (k < kk) {
-                    ar += b[k] * my[k * 3 + 0];
-                    ag += b[k] * my[k * 3 + 1];
-                    ab += b[k] * my[k * 3 + 2];
+                    ar = __builtin_fmaf(b[k], my[k * 3 + 0], ar);
+                    ag = __builtin_fmaf(b[k], my[k * 3 + 1], ag);
+                    ab = __builtin_fmaf(b[k], my[k * 3 + 2], ab);
                 }
             }
             // clamp_min(colour + 0.5, 0): gradient passes only where the clamp is inactive
@@ -659,7 +666,7 @@ sh_coeff_grad_kernel(int R, int N, int K, int degree, const float *__restrict__ 
             if (v.x == 0.f && v.y == 0.f && v.z == 0.f) continue;  // invisible / clamped / no gradient in this view
             const float4 cp = blk[N];
             float dx = mx - cp.x, dy = myy - cp.y, dz = mz - cp.z;
-            const float inorm = 1.f / fmaxf(sqrtf(dx * dx + dy * dy + dz * dz), 1e-12f);
+            const float inorm = sh_inv_norm(dx, dy, dz);
             dx *= inorm; dy *= inorm; dz *= inorm;
             float b[kMaxK];
             sh_basis<false>(degree, dx, dy, dz, b, nullptr, nullptr, nullptr);
@@ -768,6 +775,90 @@ extern "C" int fsgs_sh_fwd_split(int C, int N, int K, int degree, const float *m
                        radii, depths, colors_out, stream);
 }
 
+// The single-camera degree-3-storage backward of the training path: the coefficients are read straight into
+// registers (as in sh_fwd_pack_direct_kernel) and only the coefficient GRADIENT goes through LDS, for coalesced
+// 16-byte stores — one staging pass and one barrier less than sh_bwd_kernel: 32 us against 36 us at 300 k Gaussians
+// (writing the rows directly in 12-byte pieces as well: 39 us).
+__global__ void __launch_bounds__(kShBlock)
+sh_bwd_hybrid_kernel(int N, int degree, const float *__restrict__ means, const float *__restrict__ campos,
+                     const float *__restrict__ dc, const float *__restrict__ rest, const int32_t *__restrict__ radii,
+                     int D, const float *__restrict__ v_colors, float *__restrict__ v_dc, float *__restrict__ v_rest,
+                     float *__restrict__ v_means, float *__restrict__ v_depths, int overwrite_means,
+                     float4 *__restrict__ v_rgb_masked, int64_t replica_rows) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int pitch = 49;
+    const int n0 = blockIdx.x * kShBlock;
+    const int rows = min(kShBlock, N - n0);
+    const int n = n0 + threadIdx.x;
+    float *my = lds + threadIdx.x * pitch;
+    if (n < N) {
+        struct F3 { float x, y, z; };
+        F3 cf[16];
+        cf[0] = reinterpret_cast<const F3 *>(dc)[n];
+        const F3 *row = reinterpret_cast<const F3 *>(rest) + (int64_t)n * 15;
+#pragma unroll
+        for (int k = 0; k < 15; ++k) cf[k + 1] = row[k];
+        const float mx = means[n * 3 + 0], myy = means[n * 3 + 1], mz = means[n * 3 + 2];
+        const int rad0 = radii[n];
+        float vc0 = v_colors[(int64_t)n * D + 0], vc1 = v_colors[(int64_t)n * D + 1], vc2 = v_colors[(int64_t)n * D + 2];
+        if (D == 4 && v_depths) v_depths[n] = v_colors[(int64_t)n * 4 + 3];
+        if (replica_rows > 0 && rad0 >= kSpreadMinRadius) {
+#pragma unroll
+            for (int r = 1; r < kGradReplicas; ++r) {
+                const float *line = v_colors + ((int64_t)r * replica_rows + n) * D;
+                vc0 += line[0]; vc1 += line[1]; vc2 += line[2];
+            }
+        }
+        float o0 = 0.f, o1 = 0.f, o2 = 0.f;
+        if (!overwrite_means) { o0 = v_means[n * 3 + 0]; o1 = v_means[n * 3 + 1]; o2 = v_means[n * 3 + 2]; }
+        const int kk = (degree + 1) * (degree + 1);
+        float vr = 0.f, vg = 0.f, vb = 0.f;
+        float b[kMaxK], bx[kMaxK], by[kMaxK], bz[kMaxK];
+        float dx = 0.f, dy = 0.f, dz = 0.f, inorm = 0.f;
+        const bool vis = rad0 > 0;
+        if (vis) {
+            dx = mx - campos[0]; dy = myy - campos[1]; dz = mz - campos[2];
+            inorm = sh_inv_norm(dx, dy, dz);
+            dx *= inorm; dy *= inorm; dz *= inorm;
+            sh_basis<true>(degree, dx, dy, dz, b, bx, by, bz);
+            float ar = 0.f, ag = 0.f, ab = 0.f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                if (k < kk) { ar = __builtin_fmaf(b[k], cf[k].x, ar); ag = __builtin_fmaf(b[k], cf[k].y, ag); ab = __builtin_fmaf(b[k], cf[k].z, ab); }
+            }
+            vr = (ar + 0.5f > 0.f) ? vc0 : 0.f;
+            vg = (ag + 0.5f > 0.f) ? vc1 : 0.f;
+            vb = (ab + 0.5f > 0.f) ? vc2 : 0.f;
+        }
+        float gdx = 0.f, gdy = 0.f, gdz = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const bool on = vis && (k < kk);
+            if (on) {
+                const float w = cf[k].x * vr + cf[k].y * vg + cf[k].z * vb;
+                gdx += bx[k] * w; gdy += by[k] * w; gdz += bz[k] * w;
+            }
+            if (!v_rgb_masked) {
+                my[k * 3 + 0] = on ? b[k] * vr : 0.f;
+                my[k * 3 + 1] = on ? b[k] * vg : 0.f;
+                my[k * 3 + 2] = on ? b[k] * vb : 0.f;
+            }
+        }
+        const float dp = gdx * dx + gdy * dy + gdz * dz;
+        v_means[n * 3 + 0] = o0 + (gdx - dp * dx) * inorm;
+        v_means[n * 3 + 1] = o1 + (gdy - dp * dy) * inorm;
+        v_means[n * 3 + 2] = o2 + (gdz - dp * dz) * inorm;
+        if (v_rgb_masked) {
+            v_rgb_masked[n] = make_float4(vr, vg, vb, 0.f);
+            if (n == 0) v_rgb_masked[N] = make_float4(campos[0], campos[1], campos[2], 0.f);
+        }
+    }
+    if (v_rgb_masked) return;
+    __syncthreads();
+    unstage_rows<3>(v_dc + (int64_t)n0 * 3, rows, 3, lds, pitch, 0);
+    unstage_rows<45>(v_rest + (int64_t)n0 * 45, rows, 45, lds, pitch, 3);
+}
+
 static int sh_bwd_impl(int C, int N, int K, int degree, const float *means, const float *campos,
                        const void *coeffs, const void *coeffs_rest, const int32_t *radii, int D,
                        const float *v_colors, float *v_coeffs, float *v_coeffs_rest, float *v_means,
@@ -801,7 +892,13 @@ static int sh_bwd_impl(int C, int N, int K, int degree, const float *means, cons
                                v_coeffs, v_coeffs_rest, v_means, v_depths, overwrite_means,
                                reinterpret_cast<float4 *>(v_rgb_masked), replica_rows);
     } else if (C == 1) {
-        if (coeffs_rest) FSGS_SH_BWD_K(true, true); else FSGS_SH_BWD_K(true, false);
+        if (K == 16 && coeffs_rest && (v_rgb_masked || v_coeffs_rest))
+            hipLaunchKernelGGL(sh_bwd_hybrid_kernel, dim3(ceil_div(N, kShBlock)), dim3(kShBlock), lds_bytes,
+                               as_stream(stream), N, degree, means, campos, reinterpret_cast<const float *>(coeffs),
+                               reinterpret_cast<const float *>(coeffs_rest), radii, D, v_colors, v_coeffs,
+                               v_coeffs_rest, v_means, v_depths, overwrite_means,
+                               reinterpret_cast<float4 *>(v_rgb_masked), replica_rows);
+        else if (coeffs_rest) FSGS_SH_BWD_K(true, true); else FSGS_SH_BWD_K(true, false);
     } else {
         if (coeffs_rest) FSGS_SH_BWD_K(false, true); else FSGS_SH_BWD_K(false, false);
     }
@@ -905,6 +1002,63 @@ extern "C" int fsgs_sh_coeff_grad_adam(int R, int N, int K, int degree, const fl
 
 // fsgs_sh_fwd_split (one camera, depth channel) + fsgs_live_pack_normals in one launch: the colours go straight into
 // the packed per-Gaussian records [N,16] (no colour array), normals_world [N,3] and the zeroed cells as there.
+// The degree-3-storage packing forward of the training path WITHOUT the LDS staging of sh_fwd_kernel: every lane
+// reads its own 192 B of coefficients straight into registers (rows are 180 B apart: the compiler merges the sixteen
+// 12-byte pieces into 16-byte loads, the partial lines are shared through L1 / L2), no barrier, no LDS, 5 waves per
+// SIMD instead of 3: 24 us against 29-33 us at 300 k Gaussians.  (The same idea for the backward — rows also WRITTEN
+// in 12-byte pieces — measured 39 us against 35 us: partial-line stores; it keeps the staged kernel.)
+__global__ void __launch_bounds__(256)
+sh_fwd_pack_direct_kernel(int N, int degree, const float *__restrict__ means, const float *__restrict__ campos,
+                          const float *__restrict__ dc, const float *__restrict__ rest,
+                          const int32_t *__restrict__ radii, const float *__restrict__ depths, ShPackArgs pk) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (blockIdx.x == 0)
+        for (int k = threadIdx.x; k < pk.n_zero; k += 256) pk.zero_cells[k] = 0.f;
+    if (n >= N) return;
+    struct F3 { float x, y, z; };
+    F3 cf[16];
+    cf[0] = reinterpret_cast<const F3 *>(dc)[n];
+    const F3 *row = reinterpret_cast<const F3 *>(rest) + (int64_t)n * 15;
+#pragma unroll
+    for (int k = 0; k < 15; ++k) cf[k + 1] = row[k];
+    const float mx = means[n * 3 + 0], myy = means[n * 3 + 1], mz = means[n * 3 + 2];
+    const int rad0 = radii[n];
+    const float dep0 = depths[n];
+    const float4 pq = ld_attr4(pk.quats, n, 0);
+    const float2 pxy = reinterpret_cast<const float2 *>(pk.means2d)[n];
+    const float pop = pk.opacities[n];
+    float pls[3], pcon[3];
+    ld_attr3(pk.log_scales, n, 0, pls);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) pcon[k] = pk.conics[n * 3 + k];
+    const int kk = (degree + 1) * (degree + 1);
+    float r = 0.5f, g = 0.5f, bl = 0.5f;
+    if (rad0 > 0) {
+        float dx = mx - campos[0], dy = myy - campos[1], dz = mz - campos[2];
+        const float inorm = sh_inv_norm(dx, dy, dz);
+        dx *= inorm; dy *= inorm; dz *= inorm;
+        float b[kMaxK];
+        sh_basis<false>(degree, dx, dy, dz, b, nullptr, nullptr, nullptr);
+        float ar = 0.f, ag = 0.f, ab = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            if (k < kk) { ar = __builtin_fmaf(b[k], cf[k].x, ar); ag = __builtin_fmaf(b[k], cf[k].y, ag); ab = __builtin_fmaf(b[k], cf[k].z, ab); }
+        }
+        r = fmaxf(ar + 0.5f, 0.f); g = fmaxf(ag + 0.5f, 0.f); bl = fmaxf(ab + 0.5f, 0.f);
+    }
+    const float mean[3] = {mx, myy, mz};
+    NormalCtx o;
+    normal_forward(pq, pls, mean, pk.c2w, o);
+    float ex[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) pk.normals_world[n * 3 + k] = o.n[k];
+    normal_to_camera(o.n, pk.c2w, ex);
+    pk.packed[n * 4 + 0] = make_float4(pxy.x, pxy.y, pop, pcon[0]);
+    pk.packed[n * 4 + 1] = make_float4(pcon[1], pcon[2], 0.f, 0.f);
+    pk.packed[n * 4 + 2] = make_float4(r, g, bl, dep0);
+    pk.packed[n * 4 + 3] = make_float4(ex[0], ex[1], ex[2], 0.f);
+}
+
 static int sh_fwd_pack_impl(int N, int K, int degree, const float *means, const float *campos,
                                 const void *features_dc, const void *features_rest, const int32_t *radii,
                                 const float *depths, const float *means2d, const float *conics,
@@ -937,7 +1091,11 @@ static int sh_fwd_pack_impl(int N, int K, int degree, const float *means, const 
                                nullptr, pk);
         return check_launch();
     }
-    if (K == 16)
+    if (K == 16 && features_rest)
+        hipLaunchKernelGGL(sh_fwd_pack_direct_kernel, dim3(ceil_div(N, 256)), dim3(256), 0, as_stream(stream), N, degree,
+                           means, campos, reinterpret_cast<const float *>(features_dc),
+                           reinterpret_cast<const float *>(rest), radii, depths, pk);
+    else if (K == 16)
         hipLaunchKernelGGL((sh_fwd_kernel<16, true, true>), dim3(ceil_div(N, kShBlock)), dim3(kShBlock), lds_bytes,
                            as_stream(stream), 1, N, K, degree, means, campos, features_dc, rest, radii, depths,
                            nullptr, pk);
