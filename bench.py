@@ -459,7 +459,7 @@ def main():
     t_noopt = (time.perf_counter() - t1) / side_n
     # forward-only latency -> rendered Mpix/s (num_rays_per_sec of dn_pipeline.py:246-248)
     with torch.no_grad():
-        for s in range(2):
+        for s in range(min(side_n, len(cams))):  # (every view once: the workspace of the no-grad path grows on first use)
             trainer.forward(cams[view_of(s)])
         torch.cuda.synchronize()
         t2 = time.perf_counter()

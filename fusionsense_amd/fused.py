@@ -99,16 +99,24 @@ _ONES3: Dict[str, Tensor] = {}
 
 
 GRAD_REPLICAS = 4 if os.environ.get("FSGS_GRAD_REPLICAS", "1") != "0" else 1  # (= kGradReplicas of csrc/common.h)
+# Scenes above this size keep one line per Gaussian: the two readers pay for three more lines per spread Gaussian,
+# and at 6-10 M Gaussians (configs #4 / #5, where ~18 % of the visible ones pass the footprint threshold) that costs
+# more than the compositing backward gains (measured: +0.11 / +0.17 ms per step with replicas).
+GRAD_REPLICAS_MAX_N = int(os.environ.get("FSGS_GRAD_REPLICAS_MAX_N", str(1 << 20)))
+
+
+def _grad_lines(N: int) -> int:
+    return GRAD_REPLICAS if N <= GRAD_REPLICAS_MAX_N else 1
 
 
 def _grad_accumulator(dev, N: int) -> Tensor:
-    """The packed gradient accumulator of the backward, [GRAD_REPLICAS * N, 16]: line n plus, for Gaussians with a
+    """The packed gradient accumulator of the backward, [_grad_lines(N) * N, 16]: line n plus, for Gaussians with a
     large footprint, three replica lines N rows apart (csrc/common.h: grad_spread).  Kept zeroed between frames by
     its reader (one per device; re-created when N changes, i.e. after densify / prune)."""
     key = str(dev)
     t = _ACCUM.get(key)
-    if t is None or t.shape[0] != GRAD_REPLICAS * N:
-        t = torch.zeros(GRAD_REPLICAS * N, 16, dtype=torch.float32, device=dev)
+    if t is None or t.shape[0] != _grad_lines(N) * N:
+        t = torch.zeros(_grad_lines(N) * N, 16, dtype=torch.float32, device=dev)
         _ACCUM[key] = t
         if os.environ.get("FSGS_DEBUG_PTRS"):
             import sys
@@ -290,7 +298,7 @@ class _FusedGetOutputs(torch.autograd.Function):
         v_rgb, v_depth, v_normal, v_alpha_out = c(v_rgb), c(v_depth), c(v_normal), c(v_alpha_out)
 
         v_packed = _grad_accumulator(dev, N)  # all zeros: the per-Gaussian backward clears it again after reading
-        rep_rows = N if GRAD_REPLICAS > 1 else 0
+        rep_rows = N if _grad_lines(N) > 1 else 0
         if v_rgb is not None and IMAGE_GRADS_IN_BWD:
             # the image gradients go straight into the compositing backward, which derives v_render / v_alphas /
             # v_render_extra per pixel itself (no epilogue launch, no 32 B/pixel round trip)
