@@ -34,6 +34,53 @@ def test_capi_exports_every_declared_symbol():
     assert lib.fsgs_sort_scratch_bytes(1 << 20) > (1 << 20) // 2048 * 256 * 4
 
 
+def test_ctypes_signatures_match_the_header():
+    """Every ctypes signature has the argument count and the argument KINDS (pointer / 32-bit / 64-bit / float) of its
+    declaration in include/fsgs.h — a stray or missing argument would otherwise only show as garbage on the GPU."""
+    import ctypes as C
+    from fusionsense_amd import _lib
+    header = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "fsgs.h")).read(), flags=re.S)
+    header = re.sub(r"//[^\n]*", "", header)
+
+    def kind_of_decl(arg):
+        a = " ".join(arg.split())
+        if "*" in a or "fsgs_stream_t" in a:
+            return "ptr"
+        if re.match(r"(const )?float\b", a):
+            return "f32"
+        if re.match(r"(const )?double\b", a):
+            return "f64"
+        if re.match(r"(const )?(int64_t|size_t|long long|uint64_t)\b", a):
+            return "i64"
+        if re.match(r"(const )?(int|int32_t|uint32_t|unsigned)\b", a):
+            return "i32"
+        raise AssertionError(f"unclassified parameter {arg!r}")
+
+    def kind_of_ctype(t):
+        if t in (C.c_void_p, C.c_char_p) or (isinstance(t, type) and issubclass(t, C._Pointer)):
+            return "ptr"
+        if t is C.c_float:
+            return "f32"
+        if t is C.c_double:
+            return "f64"
+        if t in (C.c_int64, C.c_uint64, C.c_size_t, C.c_longlong):
+            return "i64"
+        if t in (C.c_int, C.c_int32, C.c_uint32):
+            return "i32"
+        raise AssertionError(f"unclassified ctype {t}")
+
+    seen = 0
+    for m in re.finditer(r"\b(fsgs_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", header, flags=re.S):
+        name, args = m.group(1), m.group(2).strip()
+        if name not in _lib.SIGNATURES:
+            continue
+        decl = [] if args in ("", "void") else [kind_of_decl(a) for a in args.split(",")]
+        bound = [kind_of_ctype(t) for t in _lib.SIGNATURES[name][1]]
+        assert decl == bound, f"{name}: header {decl} != ctypes {bound}"
+        seen += 1
+    assert seen == len(_lib.SIGNATURES)
+
+
 def test_product_path_fails_loudly_without_gpu():
     """No CPU fallback: CPU tensors are rejected with ValueError by the operator surface."""
     from fusionsense_amd.legacy import rasterize_gaussians
