@@ -11,6 +11,7 @@
 
 #include "common.h"
 #include "normal_math.h"
+#include "gauss_bwd_body.h"
 
 namespace fsgs {
 
@@ -857,6 +858,125 @@ sh_bwd_hybrid_kernel(int N, int degree, const float *__restrict__ means, const f
     __syncthreads();
     unstage_rows<3>(v_dc + (int64_t)n0 * 3, rows, 3, lds, pitch, 0);
     unstage_rows<45>(v_rest + (int64_t)n0 * 45, rows, 45, lds, pitch, 3);
+}
+
+// The whole per-Gaussian backward of the training path in ONE launch: the SH backward (as sh_bwd_hybrid_kernel) and
+// fsgs_gaussian_bwd's body (gauss_bwd_body.h) in the same thread — the packed gradient line is read (folded, cleared)
+// once, the view-direction share of v_means stays in registers, one launch boundary less.
+struct GaussShArgs {
+    const float *means, *campos, *dc, *rest;
+    const void *quats;
+    const float *scales, *viewmat, *K;
+    const int32_t *radii;
+    const float *conics;
+    float *v_dc, *v_rest, *v_means, *v_quats, *v_scales;
+    float4 *v_rgb_masked;
+    int N, degree, width, height;
+    float eps2d;
+};
+
+__global__ void __launch_bounds__(kShBlock)
+gauss_sh_bwd_kernel(GaussShArgs A, GaussBwdFused fz) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int pitch = 49;
+    const int N = A.N;
+    const int n0 = blockIdx.x * kShBlock;
+    const int rows = min(kShBlock, N - n0);
+    const int n = n0 + threadIdx.x;
+    float *my = lds + threadIdx.x * pitch;
+    if (n < N) {
+        struct F3 { float x, y, z; };
+        F3 cf[16];
+        cf[0] = reinterpret_cast<const F3 *>(A.dc)[n];
+        const F3 *row = reinterpret_cast<const F3 *>(A.rest) + (int64_t)n * 15;
+#pragma unroll
+        for (int k = 0; k < 15; ++k) cf[k + 1] = row[k];
+        const float mx = A.means[n * 3 + 0], myy = A.means[n * 3 + 1], mz = A.means[n * 3 + 2];
+        const int rad0 = A.radii[n];
+        float4 pa, pb, pc, pd;
+        gauss_bwd_load_line(n, fz, A.radii, A.conics, pa, pb, pc, pd);
+        const int kk = (A.degree + 1) * (A.degree + 1);
+        float vr = 0.f, vg = 0.f, vb = 0.f;
+        float share[3] = {0.f, 0.f, 0.f};
+        {
+            float b[kMaxK], bx[kMaxK], by[kMaxK], bz[kMaxK];
+            float dx = 0.f, dy = 0.f, dz = 0.f, inorm = 0.f;
+            const bool vis = rad0 > 0;
+            if (vis) {
+                dx = mx - A.campos[0]; dy = myy - A.campos[1]; dz = mz - A.campos[2];
+                inorm = sh_inv_norm(dx, dy, dz);
+                dx *= inorm; dy *= inorm; dz *= inorm;
+                sh_basis<true>(A.degree, dx, dy, dz, b, bx, by, bz);
+                float ar = 0.f, ag = 0.f, ab = 0.f;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    if (k < kk) { ar = __builtin_fmaf(b[k], cf[k].x, ar); ag = __builtin_fmaf(b[k], cf[k].y, ag); ab = __builtin_fmaf(b[k], cf[k].z, ab); }
+                }
+                vr = (ar + 0.5f > 0.f) ? pa.x : 0.f;
+                vg = (ag + 0.5f > 0.f) ? pa.y : 0.f;
+                vb = (ab + 0.5f > 0.f) ? pa.z : 0.f;
+            }
+            float gdx = 0.f, gdy = 0.f, gdz = 0.f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const bool on = vis && (k < kk);
+                if (on) {
+                    const float w = cf[k].x * vr + cf[k].y * vg + cf[k].z * vb;
+                    gdx += bx[k] * w; gdy += by[k] * w; gdz += bz[k] * w;
+                }
+                if (!A.v_rgb_masked) {
+                    my[k * 3 + 0] = on ? b[k] * vr : 0.f;
+                    my[k * 3 + 1] = on ? b[k] * vg : 0.f;
+                    my[k * 3 + 2] = on ? b[k] * vb : 0.f;
+                }
+            }
+            const float dp = gdx * dx + gdy * dy + gdz * dz;
+            share[0] = (gdx - dp * dx) * inorm; share[1] = (gdy - dp * dy) * inorm; share[2] = (gdz - dp * dz) * inorm;
+        }
+        if (A.v_rgb_masked) {
+            A.v_rgb_masked[n] = make_float4(vr, vg, vb, 0.f);
+            if (n == 0) A.v_rgb_masked[N] = make_float4(A.campos[0], A.campos[1], A.campos[2], 0.f);
+        }
+        gaussian_bwd_one<true>(n, 1, N, A.means, A.quats, A.scales, A.viewmat, A.K, A.width, A.height, A.eps2d, A.radii,
+                               A.conics, nullptr, nullptr, nullptr, nullptr, nullptr, A.v_means, A.v_quats, A.v_scales,
+                               nullptr, fz, pa, pb, pc, pd, share);
+    }
+    if (A.v_rgb_masked) return;
+    __syncthreads();
+    unstage_rows<3>(A.v_dc + (int64_t)n0 * 3, rows, 3, lds, pitch, 0);
+    unstage_rows<45>(A.v_rest + (int64_t)n0 * 45, rows, 45, lds, pitch, 3);
+}
+
+// fsgs_sh_bwd_split / fsgs_sh_bwd_colors (one camera, 16 stored coefficients, D = 16 packed records) followed by
+// fsgs_gaussian_bwd, in one launch.  v_features_dc / v_features_rest, or v_rgb_masked [N + 1,4] (then the two
+// coefficient outputs are not written); the other arguments as in the two calls it replaces.
+extern "C" int fsgs_gauss_sh_bwd(int N, int degree, const float *means, const float *campos, const float *features_dc,
+                                 const float *features_rest, const float *quats, const float *log_scales,
+                                 const float *scales, const float *opac, const float *viewmat, const float *K,
+                                 const float *c2w, int width, int height, float eps2d, const int32_t *radii,
+                                 const float *conics, float *v_packed, float *v_features_dc, float *v_features_rest,
+                                 float *v_rgb_masked, float *v_means, float *v_quats, float *v_log_scales,
+                                 float *v_opac_logit, float *absgrad, float *xys_grad_norm, float *vis_counts,
+                                 float *max_2Dsize, float inv_max_hw, const uint8_t *frozen, int64_t replica_rows,
+                                 fsgs_stream_t stream) {
+    if (N < 0 || degree < 0 || degree > 3 || replica_rows < 0) return FSGS_EINVAL;
+    if (N == 0) return FSGS_OK;
+    if (!means || !campos || !features_dc || !features_rest || !quats || !log_scales || !scales || !opac || !viewmat ||
+        !K || !c2w || !radii || !conics || !v_packed || !v_means || !v_quats || !v_log_scales || !v_opac_logit || !absgrad)
+        return FSGS_EINVAL;
+    if (!v_rgb_masked && (!v_features_dc || !v_features_rest)) return FSGS_EINVAL;
+    if ((xys_grad_norm || vis_counts || max_2Dsize) && !(xys_grad_norm && vis_counts && max_2Dsize)) return FSGS_EINVAL;
+    GaussShArgs A = {means, campos, features_dc, features_rest, quats, scales, viewmat, K, radii, conics,
+                     v_features_dc, v_features_rest, v_means, v_quats, v_log_scales,
+                     reinterpret_cast<float4 *>(v_rgb_masked), N, degree, width, height, eps2d};
+    GaussBwdFused fz{};
+    fz.v_packed = reinterpret_cast<float4 *>(v_packed);
+    fz.log_scales = log_scales; fz.opac = opac; fz.c2w = c2w; fz.absgrad = absgrad; fz.v_opac_logit = v_opac_logit;
+    fz.accumulate_means = 0; fz.frozen = frozen; fz.attr_half = 0; fz.replica_rows = replica_rows;
+    fz.xys_grad_norm = xys_grad_norm; fz.vis_counts = vis_counts; fz.max_2Dsize = max_2Dsize; fz.inv_max_hw = inv_max_hw;
+    const size_t lds_bytes = (size_t)kShBlock * 49 * sizeof(float);
+    hipLaunchKernelGGL(gauss_sh_bwd_kernel, dim3(ceil_div(N, kShBlock)), dim3(kShBlock), lds_bytes, as_stream(stream), A, fz);
+    return check_launch();
 }
 
 static int sh_bwd_impl(int C, int N, int K, int degree, const float *means, const float *campos,

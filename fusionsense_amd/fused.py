@@ -98,6 +98,8 @@ _ACCUM: Dict[str, Tensor] = {}
 _ONES3: Dict[str, Tensor] = {}
 
 
+# SH backward + per-Gaussian backward in one launch (fsgs_gauss_sh_bwd) where it applies; 0 = the two launches
+ONE_LAUNCH_GAUSSIAN_BWD = os.environ.get("FSGS_ONE_LAUNCH_GAUSSIAN_BWD", "1") != "0"
 GRAD_REPLICAS = 4 if os.environ.get("FSGS_GRAD_REPLICAS", "1") != "0" else 1  # (= kGradReplicas of csrc/common.h)
 # Scenes above this size keep one line per Gaussian: the two readers pay for three more lines per spread Gaussian,
 # and at 6-10 M Gaussians (configs #4 / #5, where ~18 % of the visible ones pass the footprint threshold) that costs
@@ -331,43 +333,51 @@ class _FusedGetOutputs(torch.autograd.Function):
         g_means, g_scales, g_quats = out("means", means), out("scales", scales), out("quats", quats)
         g_dc, g_rest = out("features_dc", features_dc), out("features_rest", features_rest)
         g_opac = out("opacities", opac_sig.view(N, 1))
-        # SH: colour gradients are the first floats of the packed records; writes the view-direction share of v_means
         factors = ctx.info.sh_factors_out
         hm = ctx.info.half
-        if hm is not None:
-            assert factors is None, "the factored feature exchange reads fp32 features (trainer switches it off)"
-            _run(lib.fsgs_sh_bwd_split_h16, (N, K, sh_degree, ptr(means), ptr(cam["campos"]), ptr(hm["features_dc"]),
-                                             ptr(hm["features_rest"]), ptr(radii), 16, ptr(v_packed), ptr(g_dc),
-                                             ptr(g_rest), ptr(g_means), None, 1, rep_rows, sp),
-                 "fsgs_sh_bwd_split")
-        elif factors is not None:
-            # data-parallel step: only the FACTORS of the coefficient gradients are produced here ([N + 1,4]: masked
-            # colour gradients + the camera centre); the trainer all-gathers them and fsgs_sh_coeff_grad rebuilds the
-            # mean of the ranks' coefficient gradients in the slab (16 B instead of 192 B per Gaussian on the links)
-            assert tuple(factors.shape) == (N + 1, 4) and factors.is_contiguous()
-            _run(lib.fsgs_sh_bwd_colors, (N, K, sh_degree, ptr(means), ptr(cam["campos"]), ptr(features_dc),
-                                          ptr(features_rest), ptr(radii), 16, ptr(v_packed), ptr(factors),
-                                          ptr(g_means), 1, rep_rows, sp), "fsgs_sh_bwd_split")
-        else:
-            _run(lib.fsgs_sh_bwd_split, (1, N, K, sh_degree, ptr(means), ptr(cam["campos"]), ptr(features_dc),
-                                         ptr(features_rest), ptr(radii), 16, ptr(v_packed), ptr(g_dc), ptr(g_rest),
-                                         ptr(g_means), None, 1, rep_rows, sp), "fsgs_sh_bwd_split")
-        # everything else per Gaussian in one launch (projection / normal / activation VJPs, absgrad, statistics)
         v_abs = torch.empty(1, N, 2, **f32)
         stats = ctx.info.stats_out
         if stats is not None and stats["xys_grad_norm"].shape[0] != N:
             stats = None
-        _run(lib.fsgs_gaussian_bwd_h16 if hm is not None else lib.fsgs_gaussian_bwd,
-             (N, ptr(means), ptr(hm["quats"] if hm is not None else quats),
-                                    ptr(hm["scales"] if hm is not None else scales), ptr(scales_exp), ptr(opac_sig),
-                                    ptr(cam["viewmat"]), ptr(cam["K"]), ptr(cam["c2w"]), W, H, 0.3, ptr(radii),
-                                    ptr(conics), ptr(v_packed), 1, ptr(g_means), ptr(g_quats), ptr(g_scales),
-                                    ptr(g_opac), ptr(v_abs),
-                                    ptr(stats["xys_grad_norm"]) if stats else None,
-                                    ptr(stats["vis_counts"]) if stats else None,
-                                    ptr(stats["max_2Dsize"]) if stats else None,
-                                    float(stats["inv_max_hw"]) if stats else 0.0, ptr(ctx.info.frozen), rep_rows, sp),
-             "fsgs_gaussian_bwd")
+        stat_args = (ptr(stats["xys_grad_norm"]) if stats else None, ptr(stats["vis_counts"]) if stats else None,
+                     ptr(stats["max_2Dsize"]) if stats else None, float(stats["inv_max_hw"]) if stats else 0.0,
+                     ptr(ctx.info.frozen), rep_rows, sp)
+        if factors is not None:
+            # data-parallel step: only the FACTORS of the coefficient gradients are produced here ([N + 1,4]: masked
+            # colour gradients + the camera centre); the trainer all-gathers them and fsgs_sh_coeff_grad rebuilds the
+            # mean of the ranks' coefficient gradients in the slab (16 B instead of 192 B per Gaussian on the links)
+            assert hm is None, "the factored feature exchange reads fp32 features (trainer switches it off)"
+            assert tuple(factors.shape) == (N + 1, 4) and factors.is_contiguous()
+        if hm is None and K == 16 and sh_degree <= 3 and ONE_LAUNCH_GAUSSIAN_BWD:
+            # the SH backward and everything else per Gaussian (projection / normal / activation VJPs, absgrad,
+            # statistics) in one launch, one thread per Gaussian
+            _run(lib.fsgs_gauss_sh_bwd,
+                 (N, sh_degree, ptr(means), ptr(cam["campos"]), ptr(features_dc), ptr(features_rest), ptr(quats),
+                  ptr(scales), ptr(scales_exp), ptr(opac_sig), ptr(cam["viewmat"]), ptr(cam["K"]), ptr(cam["c2w"]), W, H,
+                  0.3, ptr(radii), ptr(conics), ptr(v_packed), None if factors is not None else ptr(g_dc),
+                  None if factors is not None else ptr(g_rest), ptr(factors) if factors is not None else None,
+                  ptr(g_means), ptr(g_quats), ptr(g_scales), ptr(g_opac), ptr(v_abs)) + stat_args, "fsgs_gaussian_bwd")
+        else:
+            # SH: colour gradients are the first floats of the packed records; writes the view-direction share of v_means
+            if hm is not None:
+                _run(lib.fsgs_sh_bwd_split_h16, (N, K, sh_degree, ptr(means), ptr(cam["campos"]), ptr(hm["features_dc"]),
+                                                 ptr(hm["features_rest"]), ptr(radii), 16, ptr(v_packed), ptr(g_dc),
+                                                 ptr(g_rest), ptr(g_means), None, 1, rep_rows, sp),
+                     "fsgs_sh_bwd_split")
+            elif factors is not None:
+                _run(lib.fsgs_sh_bwd_colors, (N, K, sh_degree, ptr(means), ptr(cam["campos"]), ptr(features_dc),
+                                              ptr(features_rest), ptr(radii), 16, ptr(v_packed), ptr(factors),
+                                              ptr(g_means), 1, rep_rows, sp), "fsgs_sh_bwd_split")
+            else:
+                _run(lib.fsgs_sh_bwd_split, (1, N, K, sh_degree, ptr(means), ptr(cam["campos"]), ptr(features_dc),
+                                             ptr(features_rest), ptr(radii), 16, ptr(v_packed), ptr(g_dc), ptr(g_rest),
+                                             ptr(g_means), None, 1, rep_rows, sp), "fsgs_sh_bwd_split")
+            # everything else per Gaussian in one launch (projection / normal / activation VJPs, absgrad, statistics)
+            _run(lib.fsgs_gaussian_bwd_h16 if hm is not None else lib.fsgs_gaussian_bwd,
+                 (N, ptr(means), ptr(hm["quats"] if hm is not None else quats),
+                  ptr(hm["scales"] if hm is not None else scales), ptr(scales_exp), ptr(opac_sig), ptr(cam["viewmat"]),
+                  ptr(cam["K"]), ptr(cam["c2w"]), W, H, 0.3, ptr(radii), ptr(conics), ptr(v_packed), 1, ptr(g_means),
+                  ptr(g_quats), ptr(g_scales), ptr(g_opac), ptr(v_abs)) + stat_args, "fsgs_gaussian_bwd")
         ctx.info.absgrad = v_abs
         ctx.info.stats_done = stats is not None
         if ctx.grad_out:

@@ -412,6 +412,18 @@ int fsgs_gaussian_bwd(int N, const float *means, const float *quats, const float
                       float *xys_grad_norm, float *vis_counts, float *max_2Dsize, float inv_max_hw,
                       const uint8_t *frozen, int64_t replica_rows,
                           fsgs_stream_t stream);
+/* fsgs_sh_bwd_split (or, with v_rgb_masked != NULL, fsgs_sh_bwd_colors) for one camera, K = 16 stored coefficients
+ * and the packed 16-float gradient records, followed by fsgs_gaussian_bwd — in ONE launch and one thread per
+ * Gaussian: the record is read (replicas folded, everything cleared) once and the view-direction share of v_means
+ * never leaves the registers.  Same results as the two calls (which stay for K != 16, several cameras and half
+ * storage).  Replaces the same reference calls as they do. */
+int fsgs_gauss_sh_bwd(int N, int degree, const float *means, const float *campos, const float *features_dc,
+                      const float *features_rest, const float *quats, const float *log_scales, const float *scales,
+                      const float *opac, const float *viewmat, const float *K, const float *c2w, int width, int height,
+                      float eps2d, const int32_t *radii, const float *conics, float *v_packed, float *v_features_dc,
+                      float *v_features_rest, float *v_rgb_masked, float *v_means, float *v_quats, float *v_log_scales,
+                      float *v_opac_logit, float *absgrad, float *xys_grad_norm, float *vis_counts, float *max_2Dsize,
+                      float inv_max_hw, const uint8_t *frozen, int64_t replica_rows, fsgs_stream_t stream);
 /* frozen (nullable, [N] u8): rows whose v_means / v_log_scales / v_opac_logit are zero — FusionSense's touch
  * anchors, detached at dn_model.py:535-541 (their quaternion and colour gradients still flow). */
 /* dn_model.py:602-613, 655-656: rgb = clamp(render[:3] + (1-alpha) bg, 0, 1); depth = alpha > 0 ?
