@@ -875,7 +875,7 @@ struct GaussShArgs {
     float eps2d;
 };
 
-__global__ void __launch_bounds__(kShBlock)
+__global__ void __launch_bounds__(kShBlock) __attribute__((amdgpu_waves_per_eu(3, 3)))
 gauss_sh_bwd_kernel(GaussShArgs A, GaussBwdFused fz) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int pitch = 49;
