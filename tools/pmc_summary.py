@@ -21,7 +21,8 @@ SPAN = [
     ("adam_kernel", "adam_step"), ("sh_bwd_kernel", "sh_bwd_split"), ("sh_fwd_kernel", "sh_fwd_split"),
     ("fusion_aux_kernel", "fusion_aux_loss"), ("split_slabs_kernel", "tile_sort"),
     ("ssim_l1_fwd_kernel", "ssim_l1_fwd"), ("ssim_l1_bwd_kernel", "ssim_l1_bwd"),
-    ("project_bwd_kernel<true>", "gaussian_bwd"), ("project_fwd_kernel<true>", "project_fwd_act"),
+    ("project_bwd_kernel<true>", "gaussian_bwd"), ("gauss_sh_bwd_kernel", "gaussian_bwd"),
+    ("sh_fwd_pack_direct_kernel", "sh_fwd_split"), ("sh_bwd_hybrid_kernel", "sh_bwd_split"), ("project_fwd_kernel<true>", "project_fwd_act"),
     ("isect_live_flat_kernel<false>", "isect_count_live"), ("isect_live_flat_kernel<true>", "isect_emit_live"),
     ("isect_live_bin_kernel<false", "isect_count_live"), ("isect_live_bin_kernel<true", "tile_sort"),
     ("tile_scan_rows_kernel", "isect_count_live"),
