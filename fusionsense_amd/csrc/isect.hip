@@ -482,31 +482,48 @@ isect_live_bin_kernel(int C, int N, const float *__restrict__ means2d, const int
     L.excl[tid] = wbase + inc - cnt;
     __syncthreads();  // prefix, constants and tile slots ready
     const int n_tiles = tw * th;
-    for (int p = tid; p < wg_total; p += kBinThreads) {
+    // Thread t takes the CONTIGUOUS pairs [t * per, (t + 1) * per) of the workgroup's flattened list: one bisection
+    // and one division for its first pair, then it walks — next tile of the rectangle, next non-empty Gaussian when
+    // the rectangle is exhausted.  (First version: pair p = t + k * 1024, i.e. a 10-step LDS bisection and an integer
+    // division for EVERY pair, ~70 of its ~300 instructions.)  Every thread gets the same number of pairs, however
+    // large single splats are.
+    const int per = (wg_total + kBinThreads - 1) / kBinThreads;
+    int p = tid * per;
+    const int p_end = min(p + per, wg_total);
+    if (p < p_end) {
         // owner = last Gaussian whose exclusive prefix is <= p (empty rectangles share the prefix of the
         // next non-empty one, so "last" skips them)
-        int lo = 0;
+        int o = 0;
 #pragma unroll
         for (int step = kBinThreads / 2; step >= 1; step >>= 1) {
-            const int mid = lo + step;
-            if (L.excl[mid] <= p) lo = mid;
+            const int mid = o + step;
+            if (L.excl[mid] <= p) o = mid;
         }
-        const int o = lo;
-        const int4 rc = L.rect[o];
-        const float4 A = L.a[o], B = L.b[o];
-        const CullPrep cp = {A.x, A.y, A.z, A.w, B.x, B.y, B.z, B.w};
-        const int jj = p - L.excl[o];
-        const int ry = jj / rc.z;
-        const int y = rc.y + ry, x = rc.x + jj - ry * rc.z;
-        const unsigned m = quadrant_mask(cp, (float)(x * 16), (float)(y * 16));
-        if (m) {
-            const int64_t gidx = idx0 + o;
-            const int c = (C == 1) ? 0 : (int)(gidx / N);
-            const int slot = atomicAdd(&slots[c * n_tiles + y * tw + x], 1);
-            // (slot >= bucket_cap only when the caller sized the buffers from an estimate that the frame exceeded:
-            // the offsets were clamped to it by tile_offsets_kernel, the frame is redone)
-            if (SCATTER && slot < bucket_cap)
-                buckets[slot] = ((uint64_t)L.depth[o] << 32) | ((uint64_t)(uint32_t)gidx << 4) | (uint64_t)m;
+        int4 rc = L.rect[o];
+        float4 A = L.a[o], B = L.b[o];
+        int jj = p - L.excl[o];
+        int y = rc.y + jj / rc.z, x = rc.x + jj % rc.z;
+        for (; p < p_end; ++p) {
+            const CullPrep cp = {A.x, A.y, A.z, A.w, B.x, B.y, B.z, B.w};
+            const unsigned m = quadrant_mask(cp, (float)(x * 16), (float)(y * 16));
+            if (m) {
+                const int64_t gidx = idx0 + o;
+                const int c = (C == 1) ? 0 : (int)(gidx / N);
+                const int slot = atomicAdd(&slots[c * n_tiles + y * tw + x], 1);
+                // (slot >= bucket_cap only when the caller sized the buffers from an estimate that the frame
+                // exceeded: the offsets were clamped to it by tile_offsets_kernel, the frame is redone)
+                if (SCATTER && slot < bucket_cap)
+                    buckets[slot] = ((uint64_t)L.depth[o] << 32) | ((uint64_t)(uint32_t)gidx << 4) | (uint64_t)m;
+            }
+            if (++jj == rc.w) {
+                if (p + 1 < p_end) {  // (so a non-empty Gaussian follows)
+                    do { ++o; } while (L.rect[o].w == 0);
+                    rc = L.rect[o]; A = L.a[o]; B = L.b[o];
+                    jj = 0; x = rc.x; y = rc.y;
+                }
+            } else if (++x == rc.x + rc.z) {
+                x = rc.x; ++y;
+            }
         }
     }
     }  // chunks
