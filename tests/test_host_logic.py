@@ -81,6 +81,25 @@ def test_ctypes_signatures_match_the_header():
     assert seen == len(_lib.SIGNATURES)
 
 
+def test_header_is_plain_c_and_links(tmp_path):
+    """include/fsgs.h is a C header (what a cgo / ctypes / FFI binding of the reference side would include): it compiles
+    as C99 with -Wall -Werror, and a C program linked against libfsgs.so calls an entry point."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    from fusionsense_amd import _lib
+    src = tmp_path / "t.c"
+    src.write_text('#include <stdio.h>\n#include "fsgs.h"\n'
+                   'int main(void) { printf("%d %s\\n", fsgs_version(), fsgs_error_string(-1)); return 0; }\n')
+    exe = tmp_path / "t"
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+                    "-L", libdir, "-l:libfsgs.so", "-Wl,-rpath," + libdir, "-Wl,--allow-shlib-undefined"], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
+    assert int(out[0]) >= 100 and out[1].startswith("invalid")
+
+
 def test_product_path_fails_loudly_without_gpu():
     """No CPU fallback: CPU tensors are rejected with ValueError by the operator surface."""
     from fusionsense_amd.legacy import rasterize_gaussians
