@@ -14,6 +14,7 @@ import sys
 
 # kernel symbol -> bench.py span key (several symbols may share a span)
 SPAN = [
+    ("gauss_sh_bwd_kernel", "gaussian_bwd"),  # (before "sh_bwd_kernel", which is a substring of it)
     ("raster_bwd_live_kernel<4, true, 3>", "raster_bwd_quad_d4e3"),
     ("raster_fwd_quad_kernel<4, 3>", "raster_fwd_quad_d4e3"),
     ("tile_hist_kernel", "tile_sort"), ("tile_scan_kernel2", "tile_sort"), ("tile_offsets_kernel", "tile_sort"),
@@ -21,7 +22,7 @@ SPAN = [
     ("adam_kernel", "adam_step"), ("sh_bwd_kernel", "sh_bwd_split"), ("sh_fwd_kernel", "sh_fwd_split"),
     ("fusion_aux_kernel", "fusion_aux_loss"), ("split_slabs_kernel", "tile_sort"),
     ("ssim_l1_fwd_kernel", "ssim_l1_fwd"), ("ssim_l1_bwd_kernel", "ssim_l1_bwd"),
-    ("project_bwd_kernel<true>", "gaussian_bwd"), ("gauss_sh_bwd_kernel", "gaussian_bwd"),
+    ("project_bwd_kernel<true>", "gaussian_bwd"),
     ("sh_fwd_pack_direct_kernel", "sh_fwd_split"), ("sh_bwd_hybrid_kernel", "sh_bwd_split"), ("project_fwd_kernel<true>", "project_fwd_act"),
     ("isect_live_flat_kernel<false>", "isect_count_live"), ("isect_live_flat_kernel<true>", "isect_emit_live"),
     ("isect_live_bin_kernel<false", "isect_count_live"), ("isect_live_bin_kernel<true", "tile_sort"),
