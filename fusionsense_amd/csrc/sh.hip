@@ -776,6 +776,50 @@ extern "C" int fsgs_sh_fwd_split(int C, int N, int K, int degree, const float *m
                        radii, depths, colors_out, stream);
 }
 
+// One Gaussian's 16 stored coefficients (split storage: dc [N,3], rest [N,15,3]) straight into registers.
+// fp32: sixteen 12-byte pieces (merged into 16-byte loads by the compiler).  HALF (IEEE-half mirrors, rows of 6 and
+// 90 bytes, i.e. only 2-byte aligned): the aligned dwords covering the row are loaded and the halves picked by the
+// row's parity — 2 + 23 dword loads instead of 48 two-byte ones.  (At most 2 bytes before / after the row are touched,
+// inside the tensor or its allocation granule.)
+struct ShF3 { float x, y, z; };
+template <bool HALF>
+__device__ __forceinline__ void load_sh_row(const void *__restrict__ dc, const void *__restrict__ rest, int64_t n,
+                                            ShF3 (&cf)[16]) {
+    if (!HALF) {
+        cf[0] = reinterpret_cast<const ShF3 *>(dc)[n];
+        const ShF3 *row = reinterpret_cast<const ShF3 *>(rest) + n * 15;
+#pragma unroll
+        for (int k = 0; k < 15; ++k) cf[k + 1] = row[k];
+        return;
+    }
+    const int par = (int)(n & 1);  // rows of an odd number of halves: odd rows start in the upper half of a dword
+    auto pick = [](const uint32_t *w, int i) {  // half i of the dword array (i static after unrolling)
+        const uint32_t v = w[i >> 1];
+        return __half2float(__ushort_as_half((unsigned short)((i & 1) ? (v >> 16) : (v & 0xFFFFu))));
+    };
+    {
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(dc) + ((n * 3) >> 1);
+        const uint32_t w[2] = {src[0], src[1]};
+        float f[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) f[j] = par ? pick(w, j + 1) : pick(w, j);
+        cf[0].x = f[0]; cf[0].y = f[1]; cf[0].z = f[2];
+    }
+    {
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(rest) + ((n * 45) >> 1);
+        uint32_t w[23];
+#pragma unroll
+        for (int k = 0; k < 23; ++k) w[k] = src[k];
+#pragma unroll
+        for (int k = 0; k < 15; ++k) {
+            float f[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) f[c] = par ? pick(w, 3 * k + c + 1) : pick(w, 3 * k + c);
+            cf[k + 1].x = f[0]; cf[k + 1].y = f[1]; cf[k + 1].z = f[2];
+        }
+    }
+}
+
 // The single-camera degree-3-storage backward of the training path: the coefficients are read straight into
 // registers (as in sh_fwd_pack_direct_kernel) and only the coefficient GRADIENT goes through LDS, for coalesced
 // 16-byte stores — one staging pass and one barrier less than sh_bwd_kernel: 32 us against 36 us at 300 k Gaussians
@@ -864,7 +908,8 @@ sh_bwd_hybrid_kernel(int N, int degree, const float *__restrict__ means, const f
 // fsgs_gaussian_bwd's body (gauss_bwd_body.h) in the same thread — the packed gradient line is read (folded, cleared)
 // once, the view-direction share of v_means stays in registers, one launch boundary less.
 struct GaussShArgs {
-    const float *means, *campos, *dc, *rest;
+    const float *means, *campos;
+    const void *dc, *rest;
     const void *quats;
     const float *scales, *viewmat, *K;
     const int32_t *radii;
@@ -875,6 +920,7 @@ struct GaussShArgs {
     float eps2d;
 };
 
+template <bool HALF>
 __global__ void __launch_bounds__(kShBlock) __attribute__((amdgpu_waves_per_eu(3, 3)))
 gauss_sh_bwd_kernel(GaussShArgs A, GaussBwdFused fz) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -885,12 +931,8 @@ gauss_sh_bwd_kernel(GaussShArgs A, GaussBwdFused fz) {
     const int n = n0 + threadIdx.x;
     float *my = lds + threadIdx.x * pitch;
     if (n < N) {
-        struct F3 { float x, y, z; };
-        F3 cf[16];
-        cf[0] = reinterpret_cast<const F3 *>(A.dc)[n];
-        const F3 *row = reinterpret_cast<const F3 *>(A.rest) + (int64_t)n * 15;
-#pragma unroll
-        for (int k = 0; k < 15; ++k) cf[k + 1] = row[k];
+        ShF3 cf[16];
+        load_sh_row<HALF>(A.dc, A.rest, n, cf);
         const float mx = A.means[n * 3 + 0], myy = A.means[n * 3 + 1], mz = A.means[n * 3 + 2];
         const int rad0 = A.radii[n];
         float4 pa, pb, pc, pd;
@@ -947,18 +989,15 @@ gauss_sh_bwd_kernel(GaussShArgs A, GaussBwdFused fz) {
     unstage_rows<45>(A.v_rest + (int64_t)n0 * 45, rows, 45, lds, pitch, 3);
 }
 
-// fsgs_sh_bwd_split / fsgs_sh_bwd_colors (one camera, 16 stored coefficients, D = 16 packed records) followed by
-// fsgs_gaussian_bwd, in one launch.  v_features_dc / v_features_rest, or v_rgb_masked [N + 1,4] (then the two
-// coefficient outputs are not written); the other arguments as in the two calls it replaces.
-extern "C" int fsgs_gauss_sh_bwd(int N, int degree, const float *means, const float *campos, const float *features_dc,
-                                 const float *features_rest, const float *quats, const float *log_scales,
-                                 const float *scales, const float *opac, const float *viewmat, const float *K,
-                                 const float *c2w, int width, int height, float eps2d, const int32_t *radii,
-                                 const float *conics, float *v_packed, float *v_features_dc, float *v_features_rest,
-                                 float *v_rgb_masked, float *v_means, float *v_quats, float *v_log_scales,
-                                 float *v_opac_logit, float *absgrad, float *xys_grad_norm, float *vis_counts,
-                                 float *max_2Dsize, float inv_max_hw, const uint8_t *frozen, int64_t replica_rows,
-                                 fsgs_stream_t stream) {
+static int gauss_sh_bwd_impl(int N, int degree, const float *means, const float *campos, const void *features_dc,
+                             const void *features_rest, const void *quats, const void *log_scales, int attr_half,
+                             const float *scales, const float *opac, const float *viewmat, const float *K,
+                             const float *c2w, int width, int height, float eps2d, const int32_t *radii,
+                             const float *conics, float *v_packed, float *v_features_dc, float *v_features_rest,
+                             float *v_rgb_masked, float *v_means, float *v_quats, float *v_log_scales,
+                             float *v_opac_logit, float *absgrad, float *xys_grad_norm, float *vis_counts,
+                             float *max_2Dsize, float inv_max_hw, const uint8_t *frozen, int64_t replica_rows,
+                             fsgs_stream_t stream) {
     if (N < 0 || degree < 0 || degree > 3 || replica_rows < 0) return FSGS_EINVAL;
     if (N == 0) return FSGS_OK;
     if (!means || !campos || !features_dc || !features_rest || !quats || !log_scales || !scales || !opac || !viewmat ||
@@ -972,11 +1011,50 @@ extern "C" int fsgs_gauss_sh_bwd(int N, int degree, const float *means, const fl
     GaussBwdFused fz{};
     fz.v_packed = reinterpret_cast<float4 *>(v_packed);
     fz.log_scales = log_scales; fz.opac = opac; fz.c2w = c2w; fz.absgrad = absgrad; fz.v_opac_logit = v_opac_logit;
-    fz.accumulate_means = 0; fz.frozen = frozen; fz.attr_half = 0; fz.replica_rows = replica_rows;
+    fz.accumulate_means = 0; fz.frozen = frozen; fz.attr_half = attr_half; fz.replica_rows = replica_rows;
     fz.xys_grad_norm = xys_grad_norm; fz.vis_counts = vis_counts; fz.max_2Dsize = max_2Dsize; fz.inv_max_hw = inv_max_hw;
     const size_t lds_bytes = (size_t)kShBlock * 49 * sizeof(float);
-    hipLaunchKernelGGL(gauss_sh_bwd_kernel, dim3(ceil_div(N, kShBlock)), dim3(kShBlock), lds_bytes, as_stream(stream), A, fz);
+    if (attr_half)
+        hipLaunchKernelGGL(gauss_sh_bwd_kernel<true>, dim3(ceil_div(N, kShBlock)), dim3(kShBlock), lds_bytes,
+                           as_stream(stream), A, fz);
+    else
+        hipLaunchKernelGGL(gauss_sh_bwd_kernel<false>, dim3(ceil_div(N, kShBlock)), dim3(kShBlock), lds_bytes,
+                           as_stream(stream), A, fz);
     return check_launch();
+}
+
+// fsgs_sh_bwd_split / fsgs_sh_bwd_colors (one camera, 16 stored coefficients, D = 16 packed records) followed by
+// fsgs_gaussian_bwd, in one launch.  v_features_dc / v_features_rest, or v_rgb_masked [N + 1,4] (then the two
+// coefficient outputs are not written); the other arguments as in the two calls it replaces.
+extern "C" int fsgs_gauss_sh_bwd(int N, int degree, const float *means, const float *campos, const float *features_dc,
+                                 const float *features_rest, const float *quats, const float *log_scales,
+                                 const float *scales, const float *opac, const float *viewmat, const float *K,
+                                 const float *c2w, int width, int height, float eps2d, const int32_t *radii,
+                                 const float *conics, float *v_packed, float *v_features_dc, float *v_features_rest,
+                                 float *v_rgb_masked, float *v_means, float *v_quats, float *v_log_scales,
+                                 float *v_opac_logit, float *absgrad, float *xys_grad_norm, float *vis_counts,
+                                 float *max_2Dsize, float inv_max_hw, const uint8_t *frozen, int64_t replica_rows,
+                                 fsgs_stream_t stream) {
+    return gauss_sh_bwd_impl(N, degree, means, campos, features_dc, features_rest, quats, log_scales, 0, scales, opac,
+                             viewmat, K, c2w, width, height, eps2d, radii, conics, v_packed, v_features_dc,
+                             v_features_rest, v_rgb_masked, v_means, v_quats, v_log_scales, v_opac_logit, absgrad,
+                             xys_grad_norm, vis_counts, max_2Dsize, inv_max_hw, frozen, replica_rows, stream);
+}
+
+// half attribute storage (features, quats, log_scales as IEEE-half mirrors; the gradients stay fp32)
+extern "C" int fsgs_gauss_sh_bwd_h16(int N, int degree, const float *means, const float *campos,
+                                     const void *features_dc_h, const void *features_rest_h, const void *quats_h,
+                                     const void *log_scales_h, const float *scales, const float *opac,
+                                     const float *viewmat, const float *K, const float *c2w, int width, int height,
+                                     float eps2d, const int32_t *radii, const float *conics, float *v_packed,
+                                     float *v_features_dc, float *v_features_rest, float *v_means, float *v_quats,
+                                     float *v_log_scales, float *v_opac_logit, float *absgrad, float *xys_grad_norm,
+                                     float *vis_counts, float *max_2Dsize, float inv_max_hw, const uint8_t *frozen,
+                                     int64_t replica_rows, fsgs_stream_t stream) {
+    return gauss_sh_bwd_impl(N, degree, means, campos, features_dc_h, features_rest_h, quats_h, log_scales_h, 1, scales,
+                             opac, viewmat, K, c2w, width, height, eps2d, radii, conics, v_packed, v_features_dc,
+                             v_features_rest, nullptr, v_means, v_quats, v_log_scales, v_opac_logit, absgrad,
+                             xys_grad_norm, vis_counts, max_2Dsize, inv_max_hw, frozen, replica_rows, stream);
 }
 
 static int sh_bwd_impl(int C, int N, int K, int degree, const float *means, const float *campos,
@@ -1127,28 +1205,25 @@ extern "C" int fsgs_sh_coeff_grad_adam(int R, int N, int K, int degree, const fl
 // 12-byte pieces into 16-byte loads, the partial lines are shared through L1 / L2), no barrier, no LDS, 5 waves per
 // SIMD instead of 3: 24 us against 29-33 us at 300 k Gaussians.  (The same idea for the backward — rows also WRITTEN
 // in 12-byte pieces — measured 39 us against 35 us: partial-line stores; it keeps the staged kernel.)
+template <bool HALF>
 __global__ void __launch_bounds__(256)
 sh_fwd_pack_direct_kernel(int N, int degree, const float *__restrict__ means, const float *__restrict__ campos,
-                          const float *__restrict__ dc, const float *__restrict__ rest,
+                          const void *__restrict__ dc, const void *__restrict__ rest,
                           const int32_t *__restrict__ radii, const float *__restrict__ depths, ShPackArgs pk) {
     const int n = blockIdx.x * 256 + threadIdx.x;
     if (blockIdx.x == 0)
         for (int k = threadIdx.x; k < pk.n_zero; k += 256) pk.zero_cells[k] = 0.f;
     if (n >= N) return;
-    struct F3 { float x, y, z; };
-    F3 cf[16];
-    cf[0] = reinterpret_cast<const F3 *>(dc)[n];
-    const F3 *row = reinterpret_cast<const F3 *>(rest) + (int64_t)n * 15;
-#pragma unroll
-    for (int k = 0; k < 15; ++k) cf[k + 1] = row[k];
+    ShF3 cf[16];
+    load_sh_row<HALF>(dc, rest, n, cf);
     const float mx = means[n * 3 + 0], myy = means[n * 3 + 1], mz = means[n * 3 + 2];
     const int rad0 = radii[n];
     const float dep0 = depths[n];
-    const float4 pq = ld_attr4(pk.quats, n, 0);
+    const float4 pq = ld_attr4(pk.quats, n, HALF ? 1 : 0);
     const float2 pxy = reinterpret_cast<const float2 *>(pk.means2d)[n];
     const float pop = pk.opacities[n];
     float pls[3], pcon[3];
-    ld_attr3(pk.log_scales, n, 0, pls);
+    ld_attr3(pk.log_scales, n, HALF ? 1 : 0, pls);
 #pragma unroll
     for (int k = 0; k < 3; ++k) pcon[k] = pk.conics[n * 3 + k];
     const int kk = (degree + 1) * (degree + 1);
@@ -1201,7 +1276,10 @@ static int sh_fwd_pack_impl(int N, int K, int degree, const float *means, const 
     const void *rest = features_rest ? features_rest : features_dc;
     const size_t lds_bytes = (size_t)kShBlock * (K * 3 + 1) * sizeof(float);
     if (attr_half) {
-        if (K == 16)
+        if (K == 16 && features_rest)
+            hipLaunchKernelGGL(sh_fwd_pack_direct_kernel<true>, dim3(ceil_div(N, 256)), dim3(256), 0, as_stream(stream), N,
+                               degree, means, campos, features_dc, rest, radii, depths, pk);
+        else if (K == 16)
             hipLaunchKernelGGL((sh_fwd_kernel<16, true, true, true>), dim3(ceil_div(N, kShBlock)), dim3(kShBlock), lds_bytes,
                                as_stream(stream), 1, N, K, degree, means, campos, features_dc, rest, radii, depths,
                                nullptr, pk);
@@ -1212,9 +1290,8 @@ static int sh_fwd_pack_impl(int N, int K, int degree, const float *means, const 
         return check_launch();
     }
     if (K == 16 && features_rest)
-        hipLaunchKernelGGL(sh_fwd_pack_direct_kernel, dim3(ceil_div(N, 256)), dim3(256), 0, as_stream(stream), N, degree,
-                           means, campos, reinterpret_cast<const float *>(features_dc),
-                           reinterpret_cast<const float *>(rest), radii, depths, pk);
+        hipLaunchKernelGGL(sh_fwd_pack_direct_kernel<false>, dim3(ceil_div(N, 256)), dim3(256), 0, as_stream(stream), N,
+                           degree, means, campos, features_dc, rest, radii, depths, pk);
     else if (K == 16)
         hipLaunchKernelGGL((sh_fwd_kernel<16, true, true>), dim3(ceil_div(N, kShBlock)), dim3(kShBlock), lds_bytes,
                            as_stream(stream), 1, N, K, degree, means, campos, features_dc, rest, radii, depths,

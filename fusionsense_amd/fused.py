@@ -348,7 +348,13 @@ class _FusedGetOutputs(torch.autograd.Function):
             # mean of the ranks' coefficient gradients in the slab (16 B instead of 192 B per Gaussian on the links)
             assert hm is None, "the factored feature exchange reads fp32 features (trainer switches it off)"
             assert tuple(factors.shape) == (N + 1, 4) and factors.is_contiguous()
-        if hm is None and K == 16 and sh_degree <= 3 and ONE_LAUNCH_GAUSSIAN_BWD:
+        if hm is not None and K == 16 and sh_degree <= 3 and ONE_LAUNCH_GAUSSIAN_BWD:
+            _run(lib.fsgs_gauss_sh_bwd_h16,
+                 (N, sh_degree, ptr(means), ptr(cam["campos"]), ptr(hm["features_dc"]), ptr(hm["features_rest"]),
+                  ptr(hm["quats"]), ptr(hm["scales"]), ptr(scales_exp), ptr(opac_sig), ptr(cam["viewmat"]), ptr(cam["K"]),
+                  ptr(cam["c2w"]), W, H, 0.3, ptr(radii), ptr(conics), ptr(v_packed), ptr(g_dc), ptr(g_rest),
+                  ptr(g_means), ptr(g_quats), ptr(g_scales), ptr(g_opac), ptr(v_abs)) + stat_args, "fsgs_gaussian_bwd")
+        elif hm is None and K == 16 and sh_degree <= 3 and ONE_LAUNCH_GAUSSIAN_BWD:
             # the SH backward and everything else per Gaussian (projection / normal / activation VJPs, absgrad,
             # statistics) in one launch, one thread per Gaussian
             _run(lib.fsgs_gauss_sh_bwd,

@@ -424,6 +424,16 @@ int fsgs_gauss_sh_bwd(int N, int degree, const float *means, const float *campos
                       float *v_features_rest, float *v_rgb_masked, float *v_means, float *v_quats, float *v_log_scales,
                       float *v_opac_logit, float *absgrad, float *xys_grad_norm, float *vis_counts, float *max_2Dsize,
                       float inv_max_hw, const uint8_t *frozen, int64_t replica_rows, fsgs_stream_t stream);
+/* fsgs_gauss_sh_bwd on half attribute storage (features, quats, log_scales read from IEEE-half mirrors; all
+ * gradients fp32; no factored output). */
+int fsgs_gauss_sh_bwd_h16(int N, int degree, const float *means, const float *campos, const void *features_dc_h,
+                          const void *features_rest_h, const void *quats_h, const void *log_scales_h,
+                          const float *scales, const float *opac, const float *viewmat, const float *K, const float *c2w,
+                          int width, int height, float eps2d, const int32_t *radii, const float *conics, float *v_packed,
+                          float *v_features_dc, float *v_features_rest, float *v_means, float *v_quats,
+                          float *v_log_scales, float *v_opac_logit, float *absgrad, float *xys_grad_norm,
+                          float *vis_counts, float *max_2Dsize, float inv_max_hw, const uint8_t *frozen,
+                          int64_t replica_rows, fsgs_stream_t stream);
 /* frozen (nullable, [N] u8): rows whose v_means / v_log_scales / v_opac_logit are zero — FusionSense's touch
  * anchors, detached at dn_model.py:535-541 (their quaternion and colour gradients still flow). */
 /* dn_model.py:602-613, 655-656: rgb = clamp(render[:3] + (1-alpha) bg, 0, 1); depth = alpha > 0 ?
