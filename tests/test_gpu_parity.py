@@ -625,6 +625,46 @@ def test_tile_sort_bit_exact(dev, case):
     assert torch.equal(offs, r_off)
 
 
+def _anisotropic_splats(seed, N, W, H):
+    """Projected Gaussians as the projection would leave them: rotated, strongly elongated covariances (+ 0.3 blur),
+    radius = ceil(3 sqrt(lambda_max)), opacities from below the 1/255 threshold up to 1 — the cases in which the
+    enumeration rectangle of the direct binning is tighter than gsplat's square."""
+    g = torch.Generator().manual_seed(seed)
+    means2d = torch.rand(1, N, 2, generator=g) * torch.tensor([W, H]) * 1.3 - torch.tensor([W, H]) * 0.15
+    s1 = torch.exp(torch.rand(1, N, generator=g) * 4.5 - 1.0)            # 0.37 .. 33 px
+    s2 = s1 * torch.exp(-torch.rand(1, N, generator=g) * 3.5)            # up to 33 : 1
+    th_ = torch.rand(1, N, generator=g) * math.pi
+    c, s_ = torch.cos(th_), torch.sin(th_)
+    a = c * c * s1**2 + s_ * s_ * s2**2 + 0.3
+    b = c * s_ * (s1**2 - s2**2)
+    d = s_ * s_ * s1**2 + c * c * s2**2 + 0.3
+    det = a * d - b * b
+    conics = torch.stack([d / det, -b / det, a / det], -1)
+    mid = 0.5 * (a + d)
+    lam = mid + torch.sqrt(torch.clamp(mid * mid - det, min=0.01))
+    radii = torch.ceil(3.0 * torch.sqrt(lam)).to(torch.int32)
+    radii[torch.rand(1, N, generator=g) < 0.1] = 0
+    opac = torch.exp(torch.rand(1, N, generator=g) * 6.5 - 6.5)           # 0.0015 .. 1
+    depths = torch.rand(1, N, generator=g) * 5 + 0.2
+    return means2d, radii, depths, conics, opac
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_direct_binning_of_anisotropic_and_faint_splats(dev, seed):
+    """The direct binning enumerates the opacity-aware axis-aligned extent of a Gaussian (isect.hip) where the list
+    chain walks gsplat's whole 3-sigma square: same live pairs, bit for bit, for rotated 30 : 1 ellipses, splats of
+    60-pixel radius, opacities around 1 / 255 and centres outside the image."""
+    from fusionsense_amd import ops
+    W, H = 333, 190
+    tw, th = math.ceil(W / 16), math.ceil(H / 16)
+    a = [t.to(dev).contiguous() for t in _anisotropic_splats(seed, 20000, W, H)]
+    tpg, ids, pay, offs = ops.bin_and_sort_live(a[0], a[1], a[2], a[3], a[4], tw, th)
+    st = ops.bin_live_count_async(a[0], a[1], a[3], a[4], tw, th)
+    d_tpg, _, d_pay, d_offs = ops.bin_live_finish(st, a[0], a[1], a[2], a[3], a[4], tw, th)
+    assert torch.equal(d_tpg, tpg) and torch.equal(d_offs, offs) and torch.equal(d_pay, pay)
+    assert pay.numel() > 20000 and int(tpg.sum()) > 1.3 * pay.numel(), "the case must contain dead pairs"
+
+
 @pytest.mark.parametrize("case", ["one_camera", "two_cameras", "ties", "one_hot_tile", "one_depth_hot_tile", "tiny_image",
                                   "nothing_visible", "empty"])
 def test_direct_binning_equals_list_chain(dev, case):
