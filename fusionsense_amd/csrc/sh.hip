@@ -779,12 +779,13 @@ extern "C" int fsgs_sh_fwd_split(int C, int N, int K, int degree, const float *m
 // One Gaussian's 16 stored coefficients (split storage: dc [N,3], rest [N,15,3]) straight into registers.
 // fp32: sixteen 12-byte pieces (merged into 16-byte loads by the compiler).  HALF (IEEE-half mirrors, rows of 6 and
 // 90 bytes, i.e. only 2-byte aligned): the aligned dwords covering the row are loaded and the halves picked by the
-// row's parity — 2 + 23 dword loads instead of 48 two-byte ones.  (At most 2 bytes before / after the row are touched,
-// inside the tensor or its allocation granule.)
+// row's parity — 2 + 23 dword loads instead of 48 two-byte ones.  (The 2 bytes before an odd row belong to the row in
+// front of it; the 2 bytes after an even row to the next one, except for the LAST row of the tensor, whose final
+// dword is read as the 2 bytes that exist.)
 struct ShF3 { float x, y, z; };
 template <bool HALF>
 __device__ __forceinline__ void load_sh_row(const void *__restrict__ dc, const void *__restrict__ rest, int64_t n,
-                                            ShF3 (&cf)[16]) {
+                                            int64_t N, ShF3 (&cf)[16]) {
     if (!HALF) {
         cf[0] = reinterpret_cast<const ShF3 *>(dc)[n];
         const ShF3 *row = reinterpret_cast<const ShF3 *>(rest) + n * 15;
@@ -799,7 +800,8 @@ __device__ __forceinline__ void load_sh_row(const void *__restrict__ dc, const v
     };
     {
         const uint32_t *src = reinterpret_cast<const uint32_t *>(dc) + ((n * 3) >> 1);
-        const uint32_t w[2] = {src[0], src[1]};
+        const bool last_even = !par && n == N - 1;
+        const uint32_t w[2] = {src[0], last_even ? (uint32_t) * reinterpret_cast<const unsigned short *>(src + 1) : src[1]};
         float f[3];
 #pragma unroll
         for (int j = 0; j < 3; ++j) f[j] = par ? pick(w, j + 1) : pick(w, j);
@@ -809,7 +811,8 @@ __device__ __forceinline__ void load_sh_row(const void *__restrict__ dc, const v
         const uint32_t *src = reinterpret_cast<const uint32_t *>(rest) + ((n * 45) >> 1);
         uint32_t w[23];
 #pragma unroll
-        for (int k = 0; k < 23; ++k) w[k] = src[k];
+        for (int k = 0; k < 22; ++k) w[k] = src[k];
+        w[22] = (!par && n == N - 1) ? (uint32_t) * reinterpret_cast<const unsigned short *>(src + 22) : src[22];
 #pragma unroll
         for (int k = 0; k < 15; ++k) {
             float f[3];
@@ -932,7 +935,7 @@ gauss_sh_bwd_kernel(GaussShArgs A, GaussBwdFused fz) {
     float *my = lds + threadIdx.x * pitch;
     if (n < N) {
         ShF3 cf[16];
-        load_sh_row<HALF>(A.dc, A.rest, n, cf);
+        load_sh_row<HALF>(A.dc, A.rest, n, N, cf);
         const float mx = A.means[n * 3 + 0], myy = A.means[n * 3 + 1], mz = A.means[n * 3 + 2];
         const int rad0 = A.radii[n];
         float4 pa, pb, pc, pd;
@@ -1215,7 +1218,7 @@ sh_fwd_pack_direct_kernel(int N, int degree, const float *__restrict__ means, co
         for (int k = threadIdx.x; k < pk.n_zero; k += 256) pk.zero_cells[k] = 0.f;
     if (n >= N) return;
     ShF3 cf[16];
-    load_sh_row<HALF>(dc, rest, n, cf);
+    load_sh_row<HALF>(dc, rest, n, N, cf);
     const float mx = means[n * 3 + 0], myy = means[n * 3 + 1], mz = means[n * 3 + 2];
     const int rad0 = radii[n];
     const float dep0 = depths[n];
