@@ -151,6 +151,21 @@ __device__ __forceinline__ bool grad_spread(float ca, float cb, float cc) {
     return __builtin_fmaf(-cb, cb, ca * cc) < (1.f / 4096.f);  // (one fixed rounding sequence in every kernel)
 }
 
+// ---- the SH forward riding in the binning's scan launch (sh.hip: scan_rows_sh_pack_kernel) ---------------------
+// What fsgs_sh_fwd_pack needs, handed to the projecting count pass so that it can launch the colours + packing
+// together with its table scan (16 stored coefficients, split features, one camera).
+struct ShPackRider {
+    int N, degree, attr_half;
+    const float *means, *campos;
+    const void *features_dc, *features_rest;   // fp32, or IEEE-half mirrors when attr_half
+    const int32_t *radii;
+    const float *depths, *means2d, *conics, *opacities;
+    const void *quats, *log_scales;            // fp32 / half like the features
+    const float *c2w;
+    float *packed, *normals_world, *zero_cells;
+    int n_zero;
+};
+
 // ---- attribute storage (BASELINE config #5) ---------------------------------------------------------------------
 // Per-Gaussian attributes other than the means (SH features, log-scales, quaternions, opacity logits) are read either
 // as fp32 or as IEEE half mirrors of the fp32 master parameters (`half` != 0, uniform per launch): all arithmetic

@@ -695,6 +695,8 @@ extern "C" int fsgs_isect_emit_live(int C, int N, const float *means2d, const in
 namespace fsgs {
 int launch_tile_scan_rows_offsets(int T, int nb, int32_t *table, int32_t *totals, int32_t *isect_offsets,
                                   int32_t *total_mapped, hipStream_t s);
+int launch_tile_offsets(int T, const int32_t *totals, int32_t *isect_offsets, int32_t *total_mapped, hipStream_t s);
+int launch_scan_rows_sh_pack(int T, int nb, int32_t *table, int32_t *totals, const ShPackRider &r, hipStream_t s);
 int launch_tile_sort_tiers(int T, int n_tiles, int tile_bits, const int32_t *isect_offsets, uint64_t *buckets,
                            int32_t *payload_sorted, int64_t *isect_ids_sorted, hipStream_t s);
 int launch_split_sort(int T, int n_tiles, int tile_bits, const int32_t *isect_offsets, int64_t n_live,
@@ -803,18 +805,24 @@ static int project_bin_live_count_impl(int N, const float *means, const void *qu
                                            float *opac_out, int32_t *radii, float *means2d, float *depths,
                                            float *conics, int tile_width, int tile_height, int32_t *tiles_per_gauss,
                                            int32_t *isect_offsets, void *table_scratch, size_t table_bytes,
-                                           int32_t *n_live_mapped, fsgs_stream_t stream) {
+                                           int32_t *n_live_mapped, fsgs_stream_t stream,
+                                           const ShPackRider *rider = nullptr) {
     if (N < 0 || tile_width < 1 || tile_height < 1 || !isect_offsets) return FSGS_EINVAL;
     const int64_t T64 = (int64_t)tile_width * tile_height;
     if (T64 > fsgs_bin_live_max_tiles()) return FSGS_EINVAL;
     const int T = (int)T64;
     hipStream_t s = as_stream(stream);
+    if (rider && (rider->degree < 0 || rider->degree > 3 || !rider->campos || !rider->c2w || (N > 0 &&
+        (!rider->features_dc || !rider->features_rest || !rider->packed || !rider->normals_world))))
+        return FSGS_EINVAL;
     if (N == 0) {
         hipError_t e = hipMemsetAsync(isect_offsets, 0, (size_t)(T + 1) * sizeof(int32_t), s);
         if (e == hipSuccess && n_live_mapped) {
             static const int32_t kZeroDone[2] = {0, 1};
             e = hipMemcpyAsync(n_live_mapped, kZeroDone, sizeof(kZeroDone), hipMemcpyHostToHost, s);
         }
+        if (e == hipSuccess && rider && rider->zero_cells && rider->n_zero > 0)
+            e = hipMemsetAsync(rider->zero_cells, 0, (size_t)rider->n_zero * sizeof(float), s);
         if (e != hipSuccess) { g_last_hip_error = (int)e; return FSGS_ELAUNCH; }
         return FSGS_OK;
     }
@@ -839,7 +847,47 @@ static int project_bin_live_count_impl(int N, const float *means, const void *qu
     rc = attr_half ? FSGS_BIN_PCOUNT(true) : FSGS_BIN_PCOUNT(false);
 #undef FSGS_BIN_PCOUNT
     if (rc != FSGS_OK) return rc;
+    if (rider) {  // the table scan and the SH forward + packing in one launch (sh.hip), then the offsets
+        rc = launch_scan_rows_sh_pack(T, nb, table, totals, *rider, s);
+        if (rc != FSGS_OK) return rc;
+        return launch_tile_offsets(T, totals, isect_offsets, n_live_mapped, s);
+    }
     return launch_tile_scan_rows_offsets(T, nb, table, totals, isect_offsets, n_live_mapped, s);
+}
+
+// fsgs_project_bin_live_count followed by fsgs_sh_fwd_pack (K = 16 stored coefficients, split features), with the
+// SH forward riding in the launch of the count pass's table scan: same outputs as the two calls.
+extern "C" int fsgs_project_bin_live_count_sh_pack(
+    int N, const float *means, const float *quats, const float *log_scales, float *opac_logit, int binarise,
+    float binary_threshold, const float *viewmat, const float *K, int width, int height, float eps2d, float near_plane,
+    float far_plane, float radius_clip, float *scales_out, float *opac_out, int32_t *radii, float *means2d,
+    float *depths, float *conics, int tile_width, int tile_height, int32_t *tiles_per_gauss, int32_t *isect_offsets,
+    void *table_scratch, size_t table_bytes, int32_t *n_live_mapped, int degree, const float *campos,
+    const float *features_dc, const float *features_rest, const float *c2w, float *packed, float *normals_world,
+    float *zero_cells, int n_zero, fsgs_stream_t stream) {
+    const ShPackRider r = {N, degree, 0, means, campos, features_dc, features_rest, radii, depths, means2d, conics,
+                           opac_out, quats, log_scales, c2w, packed, normals_world, zero_cells, n_zero};
+    return project_bin_live_count_impl(N, means, quats, log_scales, opac_logit, nullptr, 0, binarise, binary_threshold,
+                                       viewmat, K, width, height, eps2d, near_plane, far_plane, radius_clip, scales_out,
+                                       opac_out, radii, means2d, depths, conics, tile_width, tile_height, tiles_per_gauss,
+                                       isect_offsets, table_scratch, table_bytes, n_live_mapped, stream, &r);
+}
+
+extern "C" int fsgs_project_bin_live_count_sh_pack_h16(
+    int N, const float *means, const void *quats_h, const void *log_scales_h, void *opac_logit_h,
+    float *opac_logit_master, int binarise, float binary_threshold, const float *viewmat, const float *K, int width,
+    int height, float eps2d, float near_plane, float far_plane, float radius_clip, float *scales_out, float *opac_out,
+    int32_t *radii, float *means2d, float *depths, float *conics, int tile_width, int tile_height,
+    int32_t *tiles_per_gauss, int32_t *isect_offsets, void *table_scratch, size_t table_bytes, int32_t *n_live_mapped,
+    int degree, const float *campos, const void *features_dc_h, const void *features_rest_h, const float *c2w,
+    float *packed, float *normals_world, float *zero_cells, int n_zero, fsgs_stream_t stream) {
+    const ShPackRider r = {N, degree, 1, means, campos, features_dc_h, features_rest_h, radii, depths, means2d, conics,
+                           opac_out, quats_h, log_scales_h, c2w, packed, normals_world, zero_cells, n_zero};
+    return project_bin_live_count_impl(N, means, quats_h, log_scales_h, opac_logit_master, opac_logit_h, 1, binarise,
+                                       binary_threshold, viewmat, K, width, height, eps2d, near_plane, far_plane,
+                                       radius_clip, scales_out, opac_out, radii, means2d, depths, conics, tile_width,
+                                       tile_height, tiles_per_gauss, isect_offsets, table_scratch, table_bytes,
+                                       n_live_mapped, stream, &r);
 }
 
 extern "C" int fsgs_project_bin_live_count(int N, const float *means, const float *quats, const float *log_scales,

@@ -12,6 +12,7 @@
 #include "common.h"
 #include "normal_math.h"
 #include "gauss_bwd_body.h"
+#include "tile_scan.h"
 
 namespace fsgs {
 
@@ -1209,12 +1210,12 @@ extern "C" int fsgs_sh_coeff_grad_adam(int R, int N, int K, int degree, const fl
 // SIMD instead of 3: 24 us against 29-33 us at 300 k Gaussians.  (The same idea for the backward — rows also WRITTEN
 // in 12-byte pieces — measured 39 us against 35 us: partial-line stores; it keeps the staged kernel.)
 template <bool HALF>
-__global__ void __launch_bounds__(256)
-sh_fwd_pack_direct_kernel(int N, int degree, const float *__restrict__ means, const float *__restrict__ campos,
-                          const void *__restrict__ dc, const void *__restrict__ rest,
-                          const int32_t *__restrict__ radii, const float *__restrict__ depths, ShPackArgs pk) {
-    const int n = blockIdx.x * 256 + threadIdx.x;
-    if (blockIdx.x == 0)
+__device__ __forceinline__ void sh_fwd_pack_direct_body(int block, int N, int degree, const float *__restrict__ means,
+                                                        const float *__restrict__ campos, const void *__restrict__ dc,
+                                                        const void *__restrict__ rest, const int32_t *__restrict__ radii,
+                                                        const float *__restrict__ depths, const ShPackArgs &pk) {
+    const int n = block * 256 + threadIdx.x;
+    if (block == 0)
         for (int k = threadIdx.x; k < pk.n_zero; k += 256) pk.zero_cells[k] = 0.f;
     if (n >= N) return;
     ShF3 cf[16];
@@ -1256,6 +1257,47 @@ sh_fwd_pack_direct_kernel(int N, int degree, const float *__restrict__ means, co
     pk.packed[n * 4 + 2] = make_float4(r, g, bl, dep0);
     pk.packed[n * 4 + 3] = make_float4(ex[0], ex[1], ex[2], 0.f);
 }
+
+template <bool HALF>
+__global__ void __launch_bounds__(256)
+sh_fwd_pack_direct_kernel(int N, int degree, const float *__restrict__ means, const float *__restrict__ campos,
+                          const void *__restrict__ dc, const void *__restrict__ rest,
+                          const int32_t *__restrict__ radii, const float *__restrict__ depths, ShPackArgs pk) {
+    sh_fwd_pack_direct_body<HALF>(blockIdx.x, N, degree, means, campos, dc, rest, radii, depths, pk);
+}
+
+// The column scan of the direct binning's table (tile_scan.h: a few hundred latency-bound workgroups, 10 us) and
+// the SH forward (bandwidth-bound, 22 us) in ONE launch: both only need what the projecting count pass has written,
+// neither needs the other; the scan's workgroups take the first block ids, the colours fill the machine meanwhile.
+template <bool HALF>
+__global__ void __launch_bounds__(256)
+scan_rows_sh_pack_kernel(int T, int nb, int32_t *__restrict__ table, int32_t *__restrict__ totals, int n_scan_blocks,
+                         int N, int degree, const float *__restrict__ means, const float *__restrict__ campos,
+                         const void *__restrict__ dc, const void *__restrict__ rest,
+                         const int32_t *__restrict__ radii, const float *__restrict__ depths, ShPackArgs pk) {
+    if ((int)blockIdx.x < n_scan_blocks) {
+        tile_scan_rows_body(T, nb, table, totals, blockIdx.x);
+        return;
+    }
+    sh_fwd_pack_direct_body<HALF>(blockIdx.x - n_scan_blocks, N, degree, means, campos, dc, rest, radii, depths, pk);
+}
+
+namespace fsgs {
+// (called by the projecting count pass of isect.hip; the arguments are checked there and in sh_pack_rider_ok)
+int launch_scan_rows_sh_pack(int T, int nb, int32_t *table, int32_t *totals, const ShPackRider &r, hipStream_t s) {
+    ShPackArgs pk = {r.means2d, r.conics, r.opacities, r.quats, r.log_scales, r.c2w, reinterpret_cast<float4 *>(r.packed),
+                     r.normals_world, r.zero_cells, r.zero_cells ? r.n_zero : 0};
+    const int n_scan = tile_scan_rows_blocks(T);
+    const dim3 grid(n_scan + ceil_div(r.N, 256));
+    if (r.attr_half)
+        hipLaunchKernelGGL(scan_rows_sh_pack_kernel<true>, grid, dim3(256), 0, s, T, nb, table, totals, n_scan, r.N,
+                           r.degree, r.means, r.campos, r.features_dc, r.features_rest, r.radii, r.depths, pk);
+    else
+        hipLaunchKernelGGL(scan_rows_sh_pack_kernel<false>, grid, dim3(256), 0, s, T, nb, table, totals, n_scan, r.N,
+                           r.degree, r.means, r.campos, r.features_dc, r.features_rest, r.radii, r.depths, pk);
+    return check_launch();
+}
+}  // namespace fsgs
 
 static int sh_fwd_pack_impl(int N, int K, int degree, const float *means, const float *campos,
                                 const void *features_dc, const void *features_rest, const int32_t *radii,

@@ -1,0 +1,63 @@
+// The column scan of the direct binning's [workgroup][tile] table as a device function: tilesort.hip launches it on
+// its own, sh.hip launches it together with the SH forward (independent work that fills the machine meanwhile).
+#pragma once
+#include "common.h"
+
+namespace fsgs {
+
+constexpr int kTrTiles = 8, kTrRows = 512, kTrPer = kTrRows * kTrTiles / 256;
+inline int tile_scan_rows_blocks(int T) { return (T + kTrTiles - 1) / kTrTiles; }
+
+// 256 threads; `block` owns tiles block * 8 .. + 7
+__device__ __forceinline__ void tile_scan_rows_body(int T, int nb, int32_t *__restrict__ table,
+                                                    int32_t *__restrict__ totals, int block) {
+    __shared__ int buf[kTrRows][kTrTiles + 1];
+    __shared__ int carry[kTrTiles];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int t0 = block * kTrTiles;
+    const int col = tid & (kTrTiles - 1), row0 = tid / kTrTiles;  // 32 rows x 8 tiles per pass
+    const bool col_ok = t0 + col < T;
+    if (tid < kTrTiles) carry[tid] = 0;
+    for (int b0 = 0; b0 < nb; b0 += kTrRows) {
+        const int rows = min(kTrRows, nb - b0);
+        int v[kTrPer];
+#pragma unroll
+        for (int k = 0; k < kTrPer; ++k) {
+            const int r = row0 + 32 * k;
+            v[k] = (r < rows && col_ok) ? table[(int64_t)(b0 + r) * T + t0 + col] : 0;
+        }
+#pragma unroll
+        for (int k = 0; k < kTrPer; ++k) buf[row0 + 32 * k][col] = v[k];
+        __syncthreads();
+        // wave w scans tiles 2w, 2w+1: lane l owns rows 8l .. 8l+7 of the chunk
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) {
+            const int c = 2 * w + cc;
+            int x[8], mine = 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { x[k] = buf[8 * lane + k][c]; mine += x[k]; }
+            int inc = mine;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int o = __shfl_up(inc, d, 64);
+                if (lane >= d) inc += o;
+            }
+            int run = carry[c] + inc - mine;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { buf[8 * lane + k][c] = run; run += x[k]; }
+            const int tot = __shfl(inc, 63, 64);
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) carry[c] += tot;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kTrPer; ++k) {
+            const int r = row0 + 32 * k;
+            if (r < rows && col_ok) table[(int64_t)(b0 + r) * T + t0 + col] = buf[r][col];
+        }
+        __syncthreads();
+    }
+    if (tid < kTrTiles && t0 + tid < T) totals[t0 + tid] = carry[tid];
+}
+
+}  // namespace fsgs

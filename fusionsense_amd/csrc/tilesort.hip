@@ -18,6 +18,7 @@
 #include <cstdlib>
 
 #include "common.h"
+#include "tile_scan.h"
 
 namespace fsgs {
 
@@ -80,56 +81,9 @@ tile_scan_kernel2(int nb, int32_t *__restrict__ table, int32_t *__restrict__ tot
 // isect.hip and read back coalesced by its scatter pass): a workgroup owns 8 tiles, walks the blocks in chunks
 // of 512 rows through LDS (32-byte row segments; all of a thread's 16 loads are issued before the first LDS
 // write), the exclusive prefixes go back in place, the running totals are carried from chunk to chunk.
-constexpr int kTrTiles = 8, kTrRows = 512, kTrPer = kTrRows * kTrTiles / 256;
 __global__ void __launch_bounds__(256)
 tile_scan_rows_kernel(int T, int nb, int32_t *__restrict__ table, int32_t *__restrict__ totals) {
-    __shared__ int buf[kTrRows][kTrTiles + 1];
-    __shared__ int carry[kTrTiles];
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int t0 = blockIdx.x * kTrTiles;
-    const int col = tid & (kTrTiles - 1), row0 = tid / kTrTiles;  // 32 rows x 8 tiles per pass
-    const bool col_ok = t0 + col < T;
-    if (tid < kTrTiles) carry[tid] = 0;
-    for (int b0 = 0; b0 < nb; b0 += kTrRows) {
-        const int rows = min(kTrRows, nb - b0);
-        int v[kTrPer];
-#pragma unroll
-        for (int k = 0; k < kTrPer; ++k) {
-            const int r = row0 + 32 * k;
-            v[k] = (r < rows && col_ok) ? table[(int64_t)(b0 + r) * T + t0 + col] : 0;
-        }
-#pragma unroll
-        for (int k = 0; k < kTrPer; ++k) buf[row0 + 32 * k][col] = v[k];
-        __syncthreads();
-        // wave w scans tiles 2w, 2w+1: lane l owns rows 8l .. 8l+7 of the chunk
-#pragma unroll
-        for (int cc = 0; cc < 2; ++cc) {
-            const int c = 2 * w + cc;
-            int x[8], mine = 0;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) { x[k] = buf[8 * lane + k][c]; mine += x[k]; }
-            int inc = mine;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const int o = __shfl_up(inc, d, 64);
-                if (lane >= d) inc += o;
-            }
-            int run = carry[c] + inc - mine;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) { buf[8 * lane + k][c] = run; run += x[k]; }
-            const int tot = __shfl(inc, 63, 64);
-            __builtin_amdgcn_wave_barrier();
-            if (lane == 0) carry[c] += tot;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < kTrPer; ++k) {
-            const int r = row0 + 32 * k;
-            if (r < rows && col_ok) table[(int64_t)(b0 + r) * T + t0 + col] = buf[r][col];
-        }
-        __syncthreads();
-    }
-    if (tid < kTrTiles && t0 + tid < T) totals[t0 + tid] = carry[tid];
+    tile_scan_rows_body(T, nb, table, totals, blockIdx.x);
 }
 
 // offsets[t] = sum of totals[0..t), offsets[T] = M   (one workgroup)
@@ -377,6 +331,11 @@ inline int64_t ts_blocks(int64_t n) { return (n + kTsBlockKeys - 1) / kTsBlockKe
 int launch_tile_scan_offsets(int T, int nb, int32_t *table, int32_t *totals, int32_t *isect_offsets, hipStream_t s) {
     hipLaunchKernelGGL(tile_scan_kernel2, dim3(T), dim3(kTsThreads), 0, s, nb, table, totals);
     hipLaunchKernelGGL(tile_offsets_kernel, dim3(1), dim3(1024), 0, s, T, totals, isect_offsets, nullptr);
+    return check_launch();
+}
+
+int launch_tile_offsets(int T, const int32_t *totals, int32_t *isect_offsets, int32_t *total_mapped, hipStream_t s) {
+    hipLaunchKernelGGL(tile_offsets_kernel, dim3(1), dim3(1024), 0, s, T, totals, isect_offsets, total_mapped);
     return check_launch();
 }
 

@@ -98,6 +98,8 @@ _ACCUM: Dict[str, Tensor] = {}
 _ONES3: Dict[str, Tensor] = {}
 
 
+# SH forward + packing in the launch of the binning's table scan (fsgs_project_bin_live_count_sh_pack); 0 = own launch
+SH_RIDES_WITH_SCAN = os.environ.get("FSGS_SH_RIDES_WITH_SCAN", "1") != "0"
 # SH backward + per-Gaussian backward in one launch (fsgs_gauss_sh_bwd) where it applies; 0 = the two launches
 ONE_LAUNCH_GAUSSIAN_BWD = os.environ.get("FSGS_ONE_LAUNCH_GAUSSIAN_BWD", "1") != "0"
 GRAD_REPLICAS = 4 if os.environ.get("FSGS_GRAD_REPLICAS", "1") != "0" else 1  # (= kGradReplicas of csrc/common.h)
@@ -158,13 +160,25 @@ class _FusedGetOutputs(torch.autograd.Function):
         opac_row = opac_sig.view(1, N)
         direct_bins = (ops.USE_BIN_LIVE and tw * th <= lib.fsgs_bin_live_max_tiles()
                        and not ops.bin_live_is_dense(dev, N, tw * th))
+        normals_world = torch.empty(N, 3, **f32)
+        packed = torch.empty(N, 16, **f32)
+        n_cells = lib.fsgs_raster_quad_max_cells()
+        max_last = torch.empty(n_cells, **f32)  # partial image maxima: zeroed by the pack kernel, raised by the forward
+        # the SH colours + packing ride in the binning's scan launch when nothing stands between them and the
+        # features (no deferred feature exchange) and the storage is the 16-coefficient split one
+        sh_rides = direct_bins and SH_RIDES_WITH_SCAN and info.pre_sh is None and K == 16 and sh_degree <= 3 and N > 0
         if direct_bins:
             # pairs go straight into their tile's bucket (no emission-order lists), and the count pass projects the
             # Gaussians itself (activations + binary-opacity write included): no projection launch
+            rider = None
+            if sh_rides:
+                rider = (sh_degree, cam["campos"], hm["features_dc"] if hm is not None else features_dc,
+                         hm["features_rest"] if hm is not None else features_rest, cam["c2w"], packed, normals_world,
+                         max_last)
             count = ops.project_bin_live_count_async(
                 means, quats, scales, opacities, bthr, cam["viewmat"], cam["K"], W, H, tw, th,
                 dict(scales_exp=scales_exp, opac_sig=opac_sig, radii=radii, means2d=means2d, depths=depths,
-                     conics=conics), half=hm, capacity=int(info.live_capacity))
+                     conics=conics), half=hm, capacity=int(info.live_capacity), sh_pack=rider)
         elif hm is not None:
             _run(lib.fsgs_project_fwd_act_h16, (1, N, ptr(means), ptr(hm["quats"]), ptr(hm["scales"]),
                                                ptr(hm["opacities"]), ptr(opacities), 0 if bthr is None else 1,
@@ -180,12 +194,10 @@ class _FusedGetOutputs(torch.autograd.Function):
                                            ptr(radii), ptr(means2d), ptr(depths), ptr(conics), sp),
                  "fsgs_project_fwd_act")
             count = ops.isect_count_live_async(means2d, radii, conics, opac_row, tw, th)
-        normals_world = torch.empty(N, 3, **f32)
-        packed = torch.empty(N, 16, **f32)
-        n_cells = lib.fsgs_raster_quad_max_cells()
-        max_last = torch.empty(n_cells, **f32)  # partial image maxima: zeroed by the pack kernel, raised by the forward
 
         def colours_and_packing():
+            if sh_rides:
+                return  # (already done, in the count pass's scan launch)
             # SH colours (+ depth) and the camera-space normals straight into the packed records (one launch)
             if hm is not None:
                 _run(lib.fsgs_sh_fwd_pack_h16, (N, K, sh_degree, ptr(means), ptr(cam["campos"]), ptr(hm["features_dc"]),

@@ -343,7 +343,7 @@ def bin_live_count_async(means2d: Tensor, radii: Tensor, conics: Tensor, opaciti
 def project_bin_live_count_async(means: Tensor, quats: Tensor, log_scales: Tensor, opac_logit: Tensor,
                                  binary_threshold, viewmat: Tensor, K: Tensor, width: int, height: int,
                                  tile_width: int, tile_height: int, out: dict, half: Optional[dict] = None,
-                                 capacity: int = 0) -> dict:
+                                 capacity: int = 0, sh_pack: Optional[tuple] = None) -> dict:
     """``fsgs_project_fwd_act`` + ``bin_live_count_async`` in one launch chain (one camera): the count pass projects
     its Gaussians itself.  ``out`` holds the projection's output tensors (scales_exp, opac_sig, radii [1,N],
     means2d, depths, conics).  Returns the same state ``bin_live_count_async`` does."""
@@ -360,6 +360,27 @@ def project_bin_live_count_async(means: Tensor, quats: Tensor, log_scales: Tenso
         # the caller will NOT wait for the live total before the second pass: it sizes the lists for `capacity`
         # entries, the offsets kernel clamps to it (fsgs.h: n_live_mapped[2]) and bin_live_finish checks later
         pinned._np[2] = int(capacity)
+    if sh_pack is not None:
+        # the SH forward + packing rides in the launch of the count pass's table scan (fsgs.h):
+        # sh_pack = (degree, campos, features_dc, features_rest, c2w, packed, normals_world, zero_cells)
+        degree, campos, f_dc, f_rest, c2w, packed, normals_world, zero_cells = sh_pack
+        tail = (int(degree), ptr(campos), ptr(f_dc), ptr(f_rest), ptr(c2w), ptr(packed), ptr(normals_world),
+                ptr(zero_cells), int(zero_cells.numel()), stream_ptr(dev))
+        bt = (0 if binary_threshold is None else 1, 0.0 if binary_threshold is None else float(binary_threshold))
+        outs = (ptr(out["scales_exp"]), ptr(out["opac_sig"]), ptr(out["radii"]), ptr(out["means2d"]),
+                ptr(out["depths"]), ptr(out["conics"]), tile_width, tile_height, ptr(tpg), ptr(offsets), ptr(table),
+                tbytes, pinned.data_ptr())
+        if half is not None:
+            _run(lib.fsgs_project_bin_live_count_sh_pack_h16,
+                 (N, ptr(means), ptr(half["quats"]), ptr(half["scales"]), ptr(half["opacities"]), ptr(opac_logit)) + bt
+                 + (ptr(viewmat), ptr(K), width, height, 0.3, 0.01, 1e10, 0.0) + outs + tail, "fsgs_isect_count_live")
+        else:
+            _run(lib.fsgs_project_bin_live_count_sh_pack,
+                 (N, ptr(means), ptr(quats), ptr(log_scales), ptr(opac_logit)) + bt
+                 + (ptr(viewmat), ptr(K), width, height, 0.3, 0.01, 1e10, 0.0) + outs + tail, "fsgs_isect_count_live")
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(dev))
+        return dict(direct=True, tpg=tpg, offsets=offsets, table=table, pinned=pinned, event=ev, T=T, capacity=capacity)
     if half is not None:  # BASELINE config #5: quats / log-scales / opacity logits read from their half mirrors
         _run(lib.fsgs_project_bin_live_count_h16,
              (N, ptr(means), ptr(half["quats"]), ptr(half["scales"]), ptr(half["opacities"]), ptr(opac_logit),
