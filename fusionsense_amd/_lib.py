@@ -18,6 +18,15 @@ LIB_PATH = os.path.join(_HERE, "libfsgs.so")
 _i, _i64, _f, _p, _sz = C.c_int, C.c_int64, C.c_float, C.c_void_p, C.c_size_t
 
 # name -> (restype, argtypes); mirrors include/fsgs.h one to one
+class AdamGroups(C.Structure):
+    """fsgs_adam_groups of include/fsgs.h: one Adam step over up to 8 tensors as an argument block."""
+    _fields_ = [("n_groups", C.c_int), ("params", C.c_void_p * 8), ("grads", C.c_void_p * 8),
+                ("exp_avg", C.c_void_p * 8), ("exp_avg_sq", C.c_void_p * 8),
+                ("half_mirror", C.c_void_p * 8), ("numel", C.c_int64 * 8), ("lr", C.c_float * 8),
+                ("step", C.c_int), ("beta1", C.c_double), ("beta2", C.c_double),
+                ("eps", C.c_float)]
+
+
 SIGNATURES = {
     "fsgs_version": (_i, []),
     "fsgs_error_string": (C.c_char_p, [_i]),
@@ -43,9 +52,9 @@ SIGNATURES = {
     "fsgs_bin_live_table_bytes": (_sz, [_i, _i, _i, _i]),
     "fsgs_bin_live_count": (_i, [_i, _i, _p, _p, _p, _p, _i, _i, _p, _p, _p, _sz, _p, _p]),
     "fsgs_project_bin_live_count_sh_pack": (_i, [_i, _p, _p, _p, _p, _i, _f, _p, _p, _i, _i, _f, _f, _f, _f, _p, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p, _sz, _p,
-                                                 _i, _p, _p, _p, _p, _p, _p, _p, _i, _p]),
+                                                 _i, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p]),
     "fsgs_project_bin_live_count_sh_pack_h16": (_i, [_i, _p, _p, _p, _p, _p, _i, _f, _p, _p, _i, _i, _f, _f, _f, _f, _p, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p, _sz, _p,
-                                                     _i, _p, _p, _p, _p, _p, _p, _p, _i, _p]),
+                                                     _i, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p]),
     "fsgs_project_bin_live_count": (_i, [_i, _p, _p, _p, _p, _i, _f, _p, _p, _i, _i, _f, _f, _f, _f, _p, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p, _sz, _p, _p]),
     "fsgs_bin_live_emit": (_i, [_i, _i, _p, _p, _p, _p, _p, _i, _i, _p, _p, _i64, _p, _p, _p]),
     "fsgs_bin_live_split_scratch_bytes": (_sz, [_i, _i, _i, _i64]),

@@ -8,6 +8,7 @@
 //                      normal = (n / |n| + 1) / 2
 // Elementwise, HBM-bound, coalesced; used by fusionsense_amd/fused.py only.
 #include "common.h"
+#include "adam_body.h"
 
 namespace fsgs {
 
@@ -248,61 +249,7 @@ extern "C" int fsgs_epilogue_bwd(int64_t n_pixels, const float *render, const fl
 //   m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ; p -= (lr / (1-b1^t)) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
 // HBM-bound by construction: 28 B per parameter float (1.65 KB per Gaussian per step).
 namespace fsgs {
-constexpr int kAdamMaxGroups = 8;
-constexpr int kAdamChunk = 1024;  // floats per workgroup (256 threads x float4)
-struct AdamArgs {
-    float *p[kAdamMaxGroups];
-    const float *g[kAdamMaxGroups];
-    float *m[kAdamMaxGroups];
-    float *v[kAdamMaxGroups];
-    __half *h[kAdamMaxGroups];      // nullable per group: IEEE-half mirror of the parameter, refreshed with the update
-    long long n[kAdamMaxGroups];
-    int block_end[kAdamMaxGroups];  // exclusive prefix ends of each group's workgroup range
-    float step_size[kAdamMaxGroups];
-    int n_groups;
-    float b1, b2, omb1, omb2, inv_sqrt_bc2, eps;  // omb = 1 - beta, rounded from double like torch does
-};
-
-
-// every group owns a whole number of workgroups; a thread updates 4 consecutive floats
-__global__ void __launch_bounds__(256) adam_kernel(AdamArgs a) {
-    int grp = 0;
-#pragma unroll
-    for (int q = 0; q < kAdamMaxGroups - 1; ++q) grp += (q < a.n_groups - 1 && (int)blockIdx.x >= a.block_end[q]) ? 1 : 0;
-    const int blk = blockIdx.x - (grp ? a.block_end[grp - 1] : 0);
-    const long long j = (long long)blk * kAdamChunk + threadIdx.x * 4;
-    const long long n = a.n[grp];
-    if (j >= n) return;
-    float *P = a.p[grp] + j, *M = a.m[grp] + j, *V = a.v[grp] + j;
-    const float *G = a.g[grp] + j;
-    __half *Hm = a.h[grp] ? a.h[grp] + j : nullptr;
-    const float ss = a.step_size[grp];
-    const bool vec = (j + 3 < n) && ((((uintptr_t)P | (uintptr_t)M | (uintptr_t)V | (uintptr_t)G) & 15) == 0) &&
-                     (((uintptr_t)Hm & 7) == 0);
-    if (vec) {
-        float4 p = *reinterpret_cast<float4 *>(P), m = *reinterpret_cast<float4 *>(M), v = *reinterpret_cast<float4 *>(V);
-        const float4 g = *reinterpret_cast<const float4 *>(G);
-        adam_one(p.x, g.x, m.x, v.x, a.b1, a.b2, a.omb1, a.omb2, ss, a.inv_sqrt_bc2, a.eps);
-        adam_one(p.y, g.y, m.y, v.y, a.b1, a.b2, a.omb1, a.omb2, ss, a.inv_sqrt_bc2, a.eps);
-        adam_one(p.z, g.z, m.z, v.z, a.b1, a.b2, a.omb1, a.omb2, ss, a.inv_sqrt_bc2, a.eps);
-        adam_one(p.w, g.w, m.w, v.w, a.b1, a.b2, a.omb1, a.omb2, ss, a.inv_sqrt_bc2, a.eps);
-        *reinterpret_cast<float4 *>(P) = p; *reinterpret_cast<float4 *>(M) = m; *reinterpret_cast<float4 *>(V) = v;
-        if (Hm) {  // the render path's half mirror of this parameter (BASELINE config #5): 2 more bytes per float
-            const __half2 lo = __floats2half2_rn(p.x, p.y), hi = __floats2half2_rn(p.z, p.w);
-            uint2 o;
-            o.x = *reinterpret_cast<const unsigned *>(&lo);
-            o.y = *reinterpret_cast<const unsigned *>(&hi);
-            *reinterpret_cast<uint2 *>(Hm) = o;
-        }
-    } else {
-        for (int k = 0; k < 4 && j + k < n; ++k) {
-            float p = P[k], m = M[k], v = V[k];
-            adam_one(p, G[k], m, v, a.b1, a.b2, a.omb1, a.omb2, ss, a.inv_sqrt_bc2, a.eps);
-            P[k] = p; M[k] = m; V[k] = v;
-            if (Hm) Hm[k] = __float2half(p);
-        }
-    }
-}
+__global__ void __launch_bounds__(256) adam_kernel(AdamArgs a) { adam_body<1>(a, blockIdx.x, 256); }
 }  // namespace fsgs
 
 extern "C" int fsgs_adam_step(int n_groups, float *const *params, const float *const *grads, float *const *exp_avg,
@@ -318,29 +265,11 @@ extern "C" int fsgs_adam_step_h16(int n_groups, float *const *params, const floa
                                   float *const *exp_avg_sq, void *const *half_mirrors, const int64_t *numel,
                                   const float *lr, int step, double beta1_d, double beta2_d, float eps,
                                   fsgs_stream_t stream) {
-    const float beta1 = (float)beta1_d, beta2 = (float)beta2_d;
-    if (n_groups < 1 || n_groups > fsgs::kAdamMaxGroups || step < 1) return FSGS_EINVAL;
-    if (!params || !grads || !exp_avg || !exp_avg_sq || !numel || !lr) return FSGS_EINVAL;
     fsgs::AdamArgs a;
-    int blocks = 0;
-    const double bc1 = 1.0 - pow(beta1_d, (double)step), bc2 = 1.0 - pow(beta2_d, (double)step);
-    for (int k = 0; k < fsgs::kAdamMaxGroups; ++k) {
-        if (k < n_groups) {
-            if (!params[k] || !grads[k] || !exp_avg[k] || !exp_avg_sq[k] || numel[k] < 0) return FSGS_EINVAL;
-            a.p[k] = params[k]; a.g[k] = grads[k]; a.m[k] = exp_avg[k]; a.v[k] = exp_avg_sq[k];
-            a.h[k] = half_mirrors ? reinterpret_cast<__half *>(half_mirrors[k]) : nullptr;
-            a.n[k] = numel[k];
-            blocks += (int)((numel[k] + fsgs::kAdamChunk - 1) / fsgs::kAdamChunk);
-            a.step_size[k] = (float)((double)lr[k] / bc1);
-        } else {
-            a.p[k] = nullptr; a.g[k] = nullptr; a.m[k] = nullptr; a.v[k] = nullptr; a.h[k] = nullptr; a.n[k] = 0;
-            a.step_size[k] = 0.f;
-        }
-        a.block_end[k] = blocks;
-    }
-    a.n_groups = n_groups; a.b1 = beta1; a.b2 = beta2; a.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2)); a.eps = eps;
-    a.omb1 = (float)(1.0 - (double)beta1_d); a.omb2 = (float)(1.0 - (double)beta2_d);
-    if (blocks == 0) return FSGS_OK;
-    hipLaunchKernelGGL(fsgs::adam_kernel, dim3((unsigned)blocks), dim3(256), 0, fsgs::as_stream(stream), a);
+    const int rc = fsgs::build_adam_args(a, 256, n_groups, params, grads, exp_avg, exp_avg_sq, half_mirrors, numel, lr,
+                                         step, beta1_d, beta2_d, eps);
+    if (rc != FSGS_OK) return rc;
+    if (a.n_blocks == 0) return FSGS_OK;
+    hipLaunchKernelGGL(fsgs::adam_kernel, dim3((unsigned)a.n_blocks), dim3(256), 0, fsgs::as_stream(stream), a);
     return fsgs::check_launch();
 }

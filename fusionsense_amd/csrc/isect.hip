@@ -4,6 +4,7 @@
 // `map_gaussian_to_intersects` / `get_tile_bin_edges` behind gsplat.rasterize_gaussians
 // (dn_model.py:644-653).  Integer work: every output is bit-exact against the oracle.
 #include "common.h"
+#include "adam_body.h"
 #include <cstdlib>
 #include "cull.h"
 #include "project_math.h"
@@ -366,14 +367,14 @@ struct BinProjArgs {
     int attr_half;
 };
 
-template <bool SCATTER, bool MULTI, bool PROJ, bool HALF = false, int BT = kBinThreadsMax>
-__global__ void __launch_bounds__(BT)
-isect_live_bin_kernel(int C, int N, const float *__restrict__ means2d, const int32_t *__restrict__ radii,
-                      const float *__restrict__ depths, const float *__restrict__ conics,
-                      const float *__restrict__ opacities, int tw, int th, int T, int nb, int chunks,
-                      int32_t *__restrict__ tiles_per_gauss, int32_t *__restrict__ table,
-                      const int32_t *__restrict__ offsets, uint64_t *__restrict__ buckets, BinProjArgs pj,
-                      int bucket_cap = 0x7FFFFFFF) {
+template <bool SCATTER, bool MULTI, bool PROJ, bool HALF, int BT>
+__device__ __forceinline__ void
+isect_live_bin_body(const int block, int C, int N, const float *__restrict__ means2d, const int32_t *__restrict__ radii,
+                    const float *__restrict__ depths, const float *__restrict__ conics,
+                    const float *__restrict__ opacities, int tw, int th, int T, int nb, int chunks,
+                    int32_t *__restrict__ tiles_per_gauss, int32_t *__restrict__ table,
+                    const int32_t *__restrict__ offsets, uint64_t *__restrict__ buckets, const BinProjArgs &pj,
+                    int bucket_cap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char bin_smem[];
     constexpr int kBinThreads = BT, kBinWaves = BT / 64;
     BinLds<BT> &L = *reinterpret_cast<BinLds<BT> *>(bin_smem);
@@ -385,7 +386,7 @@ isect_live_bin_kernel(int C, int N, const float *__restrict__ means2d, const int
     // each would be 234 MB at 6 M Gaussians x 10 000 tiles)
     const int n_chunks = MULTI ? chunks : 1;  // (MULTI = false: the single-chunk code without the loop, 4 us faster)
     for (int ch = 0; ch < n_chunks; ++ch) {
-    const int64_t idx0 = ((int64_t)blockIdx.x * n_chunks + ch) * kBinThreads;  // the chunk's first Gaussian
+    const int64_t idx0 = ((int64_t)block * n_chunks + ch) * kBinThreads;  // the chunk's first Gaussian
     const int64_t idx = idx0 + tid;
     if (idx0 >= total) break;
     if (ch) __syncthreads();  // the previous chunk's constants are no longer read
@@ -462,7 +463,7 @@ isect_live_bin_kernel(int C, int N, const float *__restrict__ means2d, const int
     }
     if (ch == 0) {  // (after the chunk's own loads were issued: the slot rows come from memory in the fill pass)
         for (int t = tid; t < T; t += kBinThreads)
-            slots[t] = SCATTER ? offsets[t] + table[(int64_t)blockIdx.x * T + t] : 0;
+            slots[t] = SCATTER ? offsets[t] + table[(int64_t)block * T + t] : 0;
     }
     int inc = cnt;
 #pragma unroll
@@ -529,8 +530,47 @@ isect_live_bin_kernel(int C, int N, const float *__restrict__ means2d, const int
     }  // chunks
     if (!SCATTER) {
         __syncthreads();
-        for (int t = tid; t < T; t += kBinThreads) table[(int64_t)blockIdx.x * T + t] = slots[t];
+        for (int t = tid; t < T; t += kBinThreads) table[(int64_t)block * T + t] = slots[t];
     }
+}
+
+template <bool SCATTER, bool MULTI, bool PROJ, bool HALF = false, int BT = kBinThreadsMax>
+__global__ void __launch_bounds__(BT)
+isect_live_bin_kernel(int C, int N, const float *__restrict__ means2d, const int32_t *__restrict__ radii,
+                      const float *__restrict__ depths, const float *__restrict__ conics,
+                      const float *__restrict__ opacities, int tw, int th, int T, int nb, int chunks,
+                      int32_t *__restrict__ tiles_per_gauss, int32_t *__restrict__ table,
+                      const int32_t *__restrict__ offsets, uint64_t *__restrict__ buckets, BinProjArgs pj,
+                      int bucket_cap = 0x7FFFFFFF) {
+    isect_live_bin_body<SCATTER, MULTI, PROJ, HALF, BT>(blockIdx.x, C, N, means2d, radii, depths, conics, opacities, tw, th,
+                                                        T, nb, chunks, tiles_per_gauss, table, offsets, buckets, pj,
+                                                        bucket_cap);
+}
+
+#ifndef FSGS_RIDE_ADAM_UNROLL
+#define FSGS_RIDE_ADAM_UNROLL 2
+#endif
+constexpr int kRideAdamUnroll = FSGS_RIDE_ADAM_UNROLL;  // float4 runs per thread of the riding Adam blocks
+
+// The projecting count pass with a deferred Adam step riding in its grid: nb workgroups project and count
+// (vector-ALU and latency bound), the others stream the parameters, moments and gradients of a step that none of the
+// count pass's inputs depend on (the SH features: bandwidth bound) — one launch instead of two back to back.
+template <bool MULTI, bool HALF, int BT>
+__global__ void __launch_bounds__(BT)
+isect_count_adam_kernel(int N, int tw, int th, int T, int nb, int chunks, int32_t *__restrict__ tiles_per_gauss,
+                        int32_t *__restrict__ table, BinProjArgs pj, AdamArgs adam) {
+    // the count pass's workgroups are spread evenly through the grid (every stride-th block id), so that at any time
+    // the CUs hold a mix of the two kinds of work: workgroups are dispatched in id order, and with all count blocks
+    // first the memory system would idle until they retire (a CU has room for one 1024-thread workgroup of this kernel)
+    const int b = blockIdx.x, stride = (nb + adam.n_blocks) / nb;
+    const int slot = b / stride;
+    if (b % stride != 0 || slot >= nb) {
+        adam_body<kRideAdamUnroll>(adam, b - min(nb, (b + stride - 1) / stride), BT);
+        return;
+    }
+    isect_live_bin_body<false, MULTI, true, HALF, BT>(slot, 1, N, nullptr, nullptr, nullptr, nullptr, nullptr, tw, th,
+                                                      T, nb, chunks, tiles_per_gauss, table, nullptr, nullptr, pj,
+                                                      0x7FFFFFFF);
 }
 
 __global__ void __launch_bounds__(256)
@@ -760,6 +800,36 @@ static int bin_launch(int T, int64_t total, int nb, hipStream_t s, Args... args)
     }
 }
 
+// the projecting count pass + a riding Adam step (isect_count_adam_kernel)
+template <bool MU, bool HF, int BT>
+static int count_adam_launch_one(int T, int64_t total, int nb, hipStream_t s, int N, int tw, int th, int chunks,
+                                 int32_t *tiles_per_gauss, int32_t *table, const BinProjArgs &pj, const AdamArgs &adam) {
+    static size_t have = 0;
+    const size_t need = bin_lds_bytes(T, total);
+    auto kernel = &isect_count_adam_kernel<MU, HF, BT>;
+    if (need > have) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)need);
+        if (e != hipSuccess) { g_last_hip_error = (int)e; return FSGS_ELAUNCH; }
+        have = need;
+    }
+    hipLaunchKernelGGL(kernel, dim3(nb + adam.n_blocks), dim3(BT), need, s, N, tw, th, T, nb, chunks, tiles_per_gauss,
+                       table, pj, adam);
+    return check_launch();
+}
+template <bool HF>
+static int count_adam_launch(int T, int64_t total, int nb, hipStream_t s, int N, int tw, int th,
+                             int32_t *tiles_per_gauss, int32_t *table, const BinProjArgs &pj, const AdamArgs &adam) {
+    const int chunks = bin_chunks(total);
+    switch (bin_threads(total)) {
+    case 1024:
+        if (chunks > 1) return count_adam_launch_one<true, HF, 1024>(T, total, nb, s, N, tw, th, chunks, tiles_per_gauss, table, pj, adam);
+        return count_adam_launch_one<false, HF, 1024>(T, total, nb, s, N, tw, th, chunks, tiles_per_gauss, table, pj, adam);
+    case 512: return count_adam_launch_one<false, HF, 512>(T, total, nb, s, N, tw, th, chunks, tiles_per_gauss, table, pj, adam);
+    default: return count_adam_launch_one<false, HF, 256>(T, total, nb, s, N, tw, th, chunks, tiles_per_gauss, table, pj, adam);
+    }
+}
+
 // Pass 1 + the per-tile scans: tiles_per_gauss (gsplat's count, nullable), isect_offsets[T + 1] with
 // isect_offsets[T] = the number of live pairs (read it back to size pass 2's buffers).
 extern "C" int fsgs_bin_live_count(int C, int N, const float *means2d, const int32_t *radii, const float *conics,
@@ -806,7 +876,7 @@ static int project_bin_live_count_impl(int N, const float *means, const void *qu
                                            float *conics, int tile_width, int tile_height, int32_t *tiles_per_gauss,
                                            int32_t *isect_offsets, void *table_scratch, size_t table_bytes,
                                            int32_t *n_live_mapped, fsgs_stream_t stream,
-                                           const ShPackRider *rider = nullptr) {
+                                           const ShPackRider *rider = nullptr, const fsgs_adam_groups *adam = nullptr) {
     if (N < 0 || tile_width < 1 || tile_height < 1 || !isect_offsets) return FSGS_EINVAL;
     const int64_t T64 = (int64_t)tile_width * tile_height;
     if (T64 > fsgs_bin_live_max_tiles()) return FSGS_EINVAL;
@@ -844,7 +914,19 @@ static int project_bin_live_count_impl(int N, const float *means, const void *qu
                                 (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, tile_width,  \
                                 tile_height, T, nb, bin_chunks(total), tiles_per_gauss, table,                        \
                                 (const int32_t *)nullptr, (uint64_t *)nullptr, pj, 0x7FFFFFFF)
-    rc = attr_half ? FSGS_BIN_PCOUNT(true) : FSGS_BIN_PCOUNT(false);
+    AdamArgs aa;
+    aa.n_blocks = 0;
+    if (adam) {  // a deferred Adam step rides in the count pass's grid
+        rc = build_adam_args(aa, bin_threads(total) * kRideAdamUnroll, adam->n_groups, adam->params, adam->grads, adam->exp_avg,
+                             adam->exp_avg_sq, adam->half_mirror, adam->numel, adam->lr, adam->step, adam->beta1,
+                             adam->beta2, adam->eps);
+        if (rc != FSGS_OK) return rc;
+    }
+    if (aa.n_blocks > 0)
+        rc = attr_half ? count_adam_launch<true>(T, total, nb, s, N, tile_width, tile_height, tiles_per_gauss, table, pj, aa)
+                       : count_adam_launch<false>(T, total, nb, s, N, tile_width, tile_height, tiles_per_gauss, table, pj, aa);
+    else
+        rc = attr_half ? FSGS_BIN_PCOUNT(true) : FSGS_BIN_PCOUNT(false);
 #undef FSGS_BIN_PCOUNT
     if (rc != FSGS_OK) return rc;
     if (rider) {  // the table scan and the SH forward + packing in one launch (sh.hip), then the offsets
@@ -864,13 +946,14 @@ extern "C" int fsgs_project_bin_live_count_sh_pack(
     float *depths, float *conics, int tile_width, int tile_height, int32_t *tiles_per_gauss, int32_t *isect_offsets,
     void *table_scratch, size_t table_bytes, int32_t *n_live_mapped, int degree, const float *campos,
     const float *features_dc, const float *features_rest, const float *c2w, float *packed, float *normals_world,
-    float *zero_cells, int n_zero, fsgs_stream_t stream) {
+    float *zero_cells, int n_zero, const fsgs_adam_groups *adam, fsgs_stream_t stream) {
     const ShPackRider r = {N, degree, 0, means, campos, features_dc, features_rest, radii, depths, means2d, conics,
                            opac_out, quats, log_scales, c2w, packed, normals_world, zero_cells, n_zero};
     return project_bin_live_count_impl(N, means, quats, log_scales, opac_logit, nullptr, 0, binarise, binary_threshold,
                                        viewmat, K, width, height, eps2d, near_plane, far_plane, radius_clip, scales_out,
                                        opac_out, radii, means2d, depths, conics, tile_width, tile_height, tiles_per_gauss,
-                                       isect_offsets, table_scratch, table_bytes, n_live_mapped, stream, &r);
+                                       isect_offsets, table_scratch, table_bytes, n_live_mapped, stream,
+                                       packed ? &r : nullptr, adam);
 }
 
 extern "C" int fsgs_project_bin_live_count_sh_pack_h16(
@@ -880,14 +963,15 @@ extern "C" int fsgs_project_bin_live_count_sh_pack_h16(
     int32_t *radii, float *means2d, float *depths, float *conics, int tile_width, int tile_height,
     int32_t *tiles_per_gauss, int32_t *isect_offsets, void *table_scratch, size_t table_bytes, int32_t *n_live_mapped,
     int degree, const float *campos, const void *features_dc_h, const void *features_rest_h, const float *c2w,
-    float *packed, float *normals_world, float *zero_cells, int n_zero, fsgs_stream_t stream) {
+    float *packed, float *normals_world, float *zero_cells, int n_zero, const fsgs_adam_groups *adam,
+    fsgs_stream_t stream) {
     const ShPackRider r = {N, degree, 1, means, campos, features_dc_h, features_rest_h, radii, depths, means2d, conics,
                            opac_out, quats_h, log_scales_h, c2w, packed, normals_world, zero_cells, n_zero};
     return project_bin_live_count_impl(N, means, quats_h, log_scales_h, opac_logit_master, opac_logit_h, 1, binarise,
                                        binary_threshold, viewmat, K, width, height, eps2d, near_plane, far_plane,
                                        radius_clip, scales_out, opac_out, radii, means2d, depths, conics, tile_width,
                                        tile_height, tiles_per_gauss, isect_offsets, table_scratch, table_bytes,
-                                       n_live_mapped, stream, &r);
+                                       n_live_mapped, stream, packed ? &r : nullptr, adam);
 }
 
 extern "C" int fsgs_project_bin_live_count(int N, const float *means, const float *quats, const float *log_scales,

@@ -51,6 +51,9 @@ class FrameInfo:
         self.binary_threshold: Optional[float] = None  # perform the binary-opacity write (dn_model.py:492-503)
         # called right before the SH colours are evaluated (the trainer's deferred feature update, data-parallel runs)
         self.pre_sh = None
+        # a deferred Adam step that may ride in the binning's count launch: an object with `.groups` (ops.adam_groups)
+        # and `.consumed()` (called once the launch that carries it has been enqueued); `pre_sh` stays the fallback
+        self.adam_rider = None
         # [N + 1,4] buffer: the backward writes the factors of the SH coefficient gradients there INSTEAD of the
         # gradients themselves (trainer's factored exchange, data-parallel runs)
         self.sh_factors_out: Optional[Tensor] = None
@@ -166,7 +169,9 @@ class _FusedGetOutputs(torch.autograd.Function):
         max_last = torch.empty(n_cells, **f32)  # partial image maxima: zeroed by the pack kernel, raised by the forward
         # the SH colours + packing ride in the binning's scan launch when nothing stands between them and the
         # features (no deferred feature exchange) and the storage is the 16-coefficient split one
-        sh_rides = direct_bins and SH_RIDES_WITH_SCAN and info.pre_sh is None and K == 16 and sh_degree <= 3 and N > 0
+        adam_rides = direct_bins and info.adam_rider is not None and N > 0
+        pre_sh = None if adam_rides else info.pre_sh  # (a riding update IS the pending feature update)
+        sh_rides = direct_bins and SH_RIDES_WITH_SCAN and pre_sh is None and K == 16 and sh_degree <= 3 and N > 0
         if direct_bins:
             # pairs go straight into their tile's bucket (no emission-order lists), and the count pass projects the
             # Gaussians itself (activations + binary-opacity write included): no projection launch
@@ -178,7 +183,11 @@ class _FusedGetOutputs(torch.autograd.Function):
             count = ops.project_bin_live_count_async(
                 means, quats, scales, opacities, bthr, cam["viewmat"], cam["K"], W, H, tw, th,
                 dict(scales_exp=scales_exp, opac_sig=opac_sig, radii=radii, means2d=means2d, depths=depths,
-                     conics=conics), half=hm, capacity=int(info.live_capacity), sh_pack=rider)
+                     conics=conics), half=hm, capacity=int(info.live_capacity), sh_pack=rider,
+                adam=info.adam_rider.groups if adam_rides else None)
+            if adam_rides:
+                info.adam_rider.consumed()
+                info.adam_rider = None
         elif hm is not None:
             _run(lib.fsgs_project_fwd_act_h16, (1, N, ptr(means), ptr(hm["quats"]), ptr(hm["scales"]),
                                                ptr(hm["opacities"]), ptr(opacities), 0 if bthr is None else 1,
@@ -214,7 +223,7 @@ class _FusedGetOutputs(torch.autograd.Function):
         # Work that does not need the lists runs while the host waits for the live total — unless the SH features
         # are still being exchanged between the ranks (info.pre_sh: the trainer's deferred feature update): then
         # the colours come last, so that the exchange overlaps the whole binning + sort chain.
-        if info.pre_sh is None:
+        if pre_sh is None:
             colours_and_packing()
         if direct_bins:
             tpg, isect_ids, flatten_ids, offsets = ops.bin_live_finish(count, means2d, radii, depths, conics, opac_row,
@@ -222,8 +231,8 @@ class _FusedGetOutputs(torch.autograd.Function):
         else:
             tpg, isect_ids, flatten_ids, offsets = ops.isect_finish_live(count, means2d, radii, depths, conics,
                                                                          opac_row, tw, th, want_ids=False)
-        if info.pre_sh is not None:
-            info.pre_sh()
+        if pre_sh is not None:
+            pre_sh()
             colours_and_packing()
         rule_diff = 0
         M = flatten_ids.numel()
@@ -473,7 +482,7 @@ def fused_step_forward_backward(gauss_params: Dict[str, Tensor], camera: Camera,
                                 sh_degree: int, device, grad_out: Dict[str, Tensor], seed_grad: Tensor,
                                 stats_out: Optional[dict] = None, add_mask: Optional[Tensor] = None,
                                 binary_threshold: Optional[float] = None, ssim_lambda: float = 0.2,
-                                w_depth: float = 0.2, w_normal: float = 0.1, pre_sh=None, sh_factors_out=None,
+                                w_depth: float = 0.2, w_normal: float = 0.1, pre_sh=None, adam_rider=None, sh_factors_out=None,
                                 fusion=None, half: Optional[Dict[str, Tensor]] = None, live_capacity: int = 0):
     """get_outputs -> loss -> both backward passes, without the autograd tape.  The parameter gradients land in
     ``grad_out`` (the trainer's slab views).  Returns (loss 0-d tensor, outputs dict).
@@ -489,6 +498,7 @@ def fused_step_forward_backward(gauss_params: Dict[str, Tensor], camera: Camera,
     info.stats_out = stats_out
     info.binary_threshold = binary_threshold
     info.pre_sh = pre_sh
+    info.adam_rider = adam_rider
     info.sh_factors_out = sh_factors_out
     info.half = half
     info.live_capacity = int(live_capacity)

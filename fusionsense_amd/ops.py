@@ -343,7 +343,7 @@ def bin_live_count_async(means2d: Tensor, radii: Tensor, conics: Tensor, opaciti
 def project_bin_live_count_async(means: Tensor, quats: Tensor, log_scales: Tensor, opac_logit: Tensor,
                                  binary_threshold, viewmat: Tensor, K: Tensor, width: int, height: int,
                                  tile_width: int, tile_height: int, out: dict, half: Optional[dict] = None,
-                                 capacity: int = 0, sh_pack: Optional[tuple] = None) -> dict:
+                                 capacity: int = 0, sh_pack: Optional[tuple] = None, adam=None) -> dict:
     """``fsgs_project_fwd_act`` + ``bin_live_count_async`` in one launch chain (one camera): the count pass projects
     its Gaussians itself.  ``out`` holds the projection's output tensors (scales_exp, opac_sig, radii [1,N],
     means2d, depths, conics).  Returns the same state ``bin_live_count_async`` does."""
@@ -360,12 +360,17 @@ def project_bin_live_count_async(means: Tensor, quats: Tensor, log_scales: Tenso
         # the caller will NOT wait for the live total before the second pass: it sizes the lists for `capacity`
         # entries, the offsets kernel clamps to it (fsgs.h: n_live_mapped[2]) and bin_live_finish checks later
         pinned._np[2] = int(capacity)
-    if sh_pack is not None:
-        # the SH forward + packing rides in the launch of the count pass's table scan (fsgs.h):
-        # sh_pack = (degree, campos, features_dc, features_rest, c2w, packed, normals_world, zero_cells)
-        degree, campos, f_dc, f_rest, c2w, packed, normals_world, zero_cells = sh_pack
-        tail = (int(degree), ptr(campos), ptr(f_dc), ptr(f_rest), ptr(c2w), ptr(packed), ptr(normals_world),
-                ptr(zero_cells), int(zero_cells.numel()), stream_ptr(dev))
+    if sh_pack is not None or adam is not None:
+        # independent work rides in the count pass's launches (fsgs.h): the SH forward + packing in the table scan's,
+        # sh_pack = (degree, campos, features_dc, features_rest, c2w, packed, normals_world, zero_cells); a deferred
+        # Adam step (`adam`: an _lib.AdamGroups made by adam_groups()) in the count pass's own
+        if sh_pack is not None:
+            degree, campos, f_dc, f_rest, c2w, packed, normals_world, zero_cells = sh_pack
+            tail = (int(degree), ptr(campos), ptr(f_dc), ptr(f_rest), ptr(c2w), ptr(packed), ptr(normals_world),
+                    ptr(zero_cells), int(zero_cells.numel()))
+        else:
+            tail = (0, None, None, None, None, None, None, None, 0)
+        tail = tail + (C.byref(adam) if adam is not None else None, stream_ptr(dev))
         bt = (0 if binary_threshold is None else 1, 0.0 if binary_threshold is None else float(binary_threshold))
         outs = (ptr(out["scales_exp"]), ptr(out["opac_sig"]), ptr(out["radii"]), ptr(out["means2d"]),
                 ptr(out["depths"]), ptr(out["conics"]), tile_width, tile_height, ptr(tpg), ptr(offsets), ptr(table),
@@ -1271,6 +1276,27 @@ def fusion_loss(out, fb, cfg, log_scales: Tensor, touch_idx: Optional[Tensor] = 
     normals_world) against a prepared :class:`fusionsense_amd.losses.FrameBatch`."""
     return _FusionLoss.apply(out["rgb"], out["depth"], out.get("normal"), log_scales, fb, cfg,
                              out.get("normals_world"), touch_idx, touch_normals, None, False)
+
+
+def adam_groups(params, grads, exp_avgs, exp_avg_sqs, lrs, step: int, beta1: float = 0.9, beta2: float = 0.999,
+                eps: float = 1e-15, half_mirrors=None):
+    """The argument block (fsgs_adam_groups) of the Adam step adam_step_ would launch — for launches that carry it
+    (project_bin_live_count_async(adam=...)).  The tensors must stay alive until that launch has been enqueued."""
+    from ._lib import AdamGroups
+    n = len(params)
+    assert 1 <= n <= 8
+    a = AdamGroups()
+    a.n_groups = n
+    for k in range(n):
+        a.params[k], a.grads[k] = params[k].data_ptr(), grads[k].data_ptr()
+        a.exp_avg[k], a.exp_avg_sq[k] = exp_avgs[k].data_ptr(), exp_avg_sqs[k].data_ptr()
+        h = half_mirrors[k] if half_mirrors is not None else None
+        assert h is None or (h.dtype == torch.float16 and h.shape == params[k].shape and h.is_contiguous())
+        a.half_mirror[k] = h.data_ptr() if h is not None else None
+        a.numel[k] = params[k].numel()
+        a.lr[k] = float(lrs[k])
+    a.step, a.beta1, a.beta2, a.eps = int(step), float(beta1), float(beta2), float(eps)
+    return a
 
 
 def adam_step_(params, grads, exp_avgs, exp_avg_sqs, lrs, step: int, beta1: float = 0.9, beta2: float = 0.999,

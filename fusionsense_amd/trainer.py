@@ -161,6 +161,17 @@ class SplatTrainer:
         # single rank (for the tests).
         self.defer_features = os.environ.get("FSGS_DEFER_FEATURES", "1") != "0"
         self.force_split_step = os.environ.get("FSGS_FORCE_SPLIT_STEP", "0") == "1"
+        # One GPU: the SH features' Adam launch (48 of the 59 floats per Gaussian, bandwidth-bound) is deferred too and
+        # RIDES in the next frame's projecting count pass (vector-ALU / latency-bound; reads geometry only) — one
+        # launch with two independent block ranges instead of two launches back to back.  Same arithmetic, same
+        # order as seen by every reader (flush() lands a pending update for anything else that reads the features).
+        self.ride_adam = os.environ.get("FSGS_RIDE_ADAM", "1") != "0"
+        # (only while the count pass runs as one chunk per 1024-thread workgroup, 256 k .. 512 k Gaussians: the larger
+        # instantiation needs 78 VGPRs, one workgroup per CU, and the riding Adam blocks then crawl: 4.0 instead of
+        # 0.8 + 1.4 ms at 6 M Gaussians; smaller scenes have nothing to hide.  For large scenes the same update on a
+        # second HIP stream beside the next frame's binning was measured too: 6.44 against 6.41 ms at 6 M, 9.41 against
+        # 9.44 ms at 10 M Gaussians — both sides are bandwidth-sensitive there and slow each other down; not kept.)
+        self.ride_adam_n = (256 * 1024, 512 * 1024)
         # ... and what travels for the features is not their gradient (48 floats per Gaussian) but its factors: the
         # masked colour gradient + the camera centre of every rank's view (4 floats per Gaussian and rank,
         # all-gathered); fsgs_sh_coeff_grad rebuilds the mean gradient on every rank, in rank order, so the
@@ -289,11 +300,11 @@ class SplatTrainer:
             l = l + 0.1 * torch.abs(out["normal"] - target["normal"]).mean()
         return l
 
-    def _fused_adam_step(self, names=None, step_no: Optional[int] = None) -> int:
+    def _fused_adam_step(self, names=None, step_no: Optional[int] = None, as_groups: bool = False):
         """All six groups in one launch (row N1) — or the given subset, as Adam step ``step_no``.  The torch
         optimizers stay the owners of the state (exp_avg / exp_avg_sq per parameter), so densify/prune surgery
         and checkpoints see the usual layout; only their step() is replaced.  Returns the step number used."""
-        from .ops import adam_step_
+        from .ops import adam_groups, adam_step_
         ps, gs, ms, vs, lrs = [], [], [], [], []
         for name in (names or PARAM_ORDER):
             p = self.params[name]
@@ -303,7 +314,8 @@ class SplatTrainer:
                 st["step"] = torch.tensor(0.0)
                 st["exp_avg"] = torch.zeros_like(p)
                 st["exp_avg_sq"] = torch.zeros_like(p)
-            st["step"] += 1
+            if not as_groups:  # (a carried step is counted when its launch has been enqueued: _adam_rider)
+                st["step"] += 1
             ps.append(p.data); gs.append(self.slab.views[name]); ms.append(st["exp_avg"]); vs.append(st["exp_avg_sq"])
             lrs.append(opt.param_groups[0]["lr"])
         if step_no is None:
@@ -311,6 +323,8 @@ class SplatTrainer:
             step_no = self.adam_steps
         hm = self.half_mirrors()
         halves = [hm.get(name) for name in (names or PARAM_ORDER)] if hm is not None else None
+        if as_groups:  # (not launched here: the argument block for a launch that carries it, see _adam_rider)
+            return adam_groups(ps, gs, ms, vs, lrs, step_no, 0.9, 0.999, self.optim_cfg.eps, half_mirrors=halves)
         adam_step_(ps, gs, ms, vs, lrs, step_no, 0.9, 0.999, self.optim_cfg.eps, half_mirrors=halves)
         return step_no
 
@@ -321,13 +335,43 @@ class SplatTrainer:
             self.optimizers[name].step()
         return None
 
+    def _ride_mode(self) -> bool:
+        """One rank, the library's own Adam, the tape-free step: the feature update can ride in the count pass."""
+        return (self.ride_adam and self._one_rank_fused() and
+                self.ride_adam_n[0] <= self.num_gaussians() <= self.ride_adam_n[1])
+
+    def _one_rank_fused(self) -> bool:
+        return (GradSlab._world() == 1 and not self.force_split_step and self.fused and self.direct and self.fused_adam
+                and not self.torch_optimizers and self.device.type == "cuda")
+
     def _split_step(self, optimizer_step: bool) -> bool:
-        return optimizer_step and self.defer_features and (GradSlab._world() > 1 or self.force_split_step)
+        return optimizer_step and self.defer_features and (GradSlab._world() > 1 or self.force_split_step
+                                                           or self._ride_mode())
+
+    def _adam_rider(self):
+        """The pending feature update as something the next frame's count launch can carry (fused.FrameInfo.adam_rider),
+        or None when there is none or it needs more than an Adam launch (an exchange still in flight, factors)."""
+        if self._pending is None or not self._ride_mode():
+            return None
+        finish, step_no = self._pending
+        if finish is not None:
+            return None
+        trainer = self
+
+        class _Rider:
+            groups = trainer._fused_adam_step(FEATURE_GROUPS, step_no, as_groups=True)
+
+            @staticmethod
+            def consumed():
+                trainer._pending = None
+                for name in FEATURE_GROUPS:
+                    trainer.optimizers[name].state[trainer.params[name]]["step"] += 1
+        return _Rider
 
     def _factor_buffers(self, optimizer_step: bool):
         """(own [N + 1,4], gathered [R, N + 1,4]) when this step exchanges the SH gradients as factors, else None."""
         if not (self._split_step(optimizer_step) and self.factored_features and self.fused
-                and self.device.type == "cuda"):
+                and self.device.type == "cuda") or self._ride_mode():
             return None
         R, N = GradSlab._world(), self.num_gaussians()
         f = self._factors
@@ -446,7 +490,7 @@ class SplatTrainer:
                     loss, out = fused_step_forward_backward(
                         self.params, camera, target, self._sh_degree_now(), self.device, self.slab.views, self._one,
                         stats_out=stats, add_mask=add_mask, binary_threshold=bthr,
-                        pre_sh=self.flush if self._pending is not None else None,
+                        pre_sh=self.flush if self._pending is not None else None, adam_rider=self._adam_rider(),
                         sh_factors_out=factors[0] if factors else None,
                         fusion=((self.loss_cfg,) + self._touch_rows()) if is_fb else None,
                         half=self.half_mirrors(), live_capacity=cap)

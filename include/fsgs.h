@@ -317,11 +317,30 @@ int fsgs_project_bin_live_count(int N, const float *means, const float *quats, c
                                 float *depths, float *conics, int tile_width, int tile_height,
                                 int32_t *tiles_per_gauss, int32_t *isect_offsets, void *table_scratch,
                                 size_t table_bytes, int32_t *n_live_mapped, fsgs_stream_t stream);
-/* fsgs_project_bin_live_count followed by fsgs_sh_fwd_pack (16 stored coefficients, split features; opacities =
- * opac_out, the other shared arrays as named) with the SH forward + packing riding in the launch of the count pass's
- * table scan — independent work that fills the machine while a few hundred latency-bound workgroups scan: same
- * outputs as the two calls, one launch and ~10 us less.  _h16: quats / log_scales / opacity logits / features are
- * IEEE-half mirrors (as in fsgs_project_bin_live_count_h16 and fsgs_sh_fwd_pack_h16). */
+/* An Adam step over up to 8 tensors, as an argument block (the arrays of fsgs_adam_step_h16). */
+typedef struct fsgs_adam_groups {
+    int n_groups;
+    float *params[8];
+    const float *grads[8];
+    float *exp_avg[8];
+    float *exp_avg_sq[8];
+    void *half_mirror[8]; /* nullable entries */
+    int64_t numel[8];
+    float lr[8];
+    int step;
+    double beta1, beta2;
+    float eps;
+} fsgs_adam_groups;
+
+/* fsgs_project_bin_live_count with independent work riding in its launches (same outputs as the separate calls):
+ *  - packed != NULL: fsgs_sh_fwd_pack (16 stored coefficients, split features; opacities = opac_out, the other
+ *    shared arrays as named) runs in the launch of the count pass's table scan — a few hundred latency-bound
+ *    workgroups scan while the rest of the machine evaluates colours and packs records;
+ *  - adam != NULL: that Adam step (fsgs_adam_step_h16 semantics) runs in the launch of the count pass itself.  None
+ *    of its tensors may be an input of the count pass (means, quats, log_scales, opacity logits): it is meant for
+ *    the SH features' update of the previous iteration, which the colours of this one (above) then see.
+ * _h16: quats / log_scales / opacity logits / features are IEEE-half mirrors (as in fsgs_project_bin_live_count_h16
+ * and fsgs_sh_fwd_pack_h16). */
 int fsgs_project_bin_live_count_sh_pack(
     int N, const float *means, const float *quats, const float *log_scales, float *opac_logit, int binarise,
     float binary_threshold, const float *viewmat, const float *K, int width, int height, float eps2d, float near_plane,
@@ -329,7 +348,7 @@ int fsgs_project_bin_live_count_sh_pack(
     float *depths, float *conics, int tile_width, int tile_height, int32_t *tiles_per_gauss, int32_t *isect_offsets,
     void *table_scratch, size_t table_bytes, int32_t *n_live_mapped, int degree, const float *campos,
     const float *features_dc, const float *features_rest, const float *c2w, float *packed, float *normals_world,
-    float *zero_cells, int n_zero, fsgs_stream_t stream);
+    float *zero_cells, int n_zero, const fsgs_adam_groups *adam, fsgs_stream_t stream);
 int fsgs_project_bin_live_count_sh_pack_h16(
     int N, const float *means, const void *quats_h, const void *log_scales_h, void *opac_logit_h,
     float *opac_logit_master, int binarise, float binary_threshold, const float *viewmat, const float *K, int width,
@@ -337,7 +356,8 @@ int fsgs_project_bin_live_count_sh_pack_h16(
     int32_t *radii, float *means2d, float *depths, float *conics, int tile_width, int tile_height,
     int32_t *tiles_per_gauss, int32_t *isect_offsets, void *table_scratch, size_t table_bytes, int32_t *n_live_mapped,
     int degree, const float *campos, const void *features_dc_h, const void *features_rest_h, const float *c2w,
-    float *packed, float *normals_world, float *zero_cells, int n_zero, fsgs_stream_t stream);
+    float *packed, float *normals_world, float *zero_cells, int n_zero, const fsgs_adam_groups *adam,
+    fsgs_stream_t stream);
 int fsgs_bin_live_emit(int C, int N, const float *means2d, const int32_t *radii, const float *depths,
                        const float *conics, const float *opacities, int tile_width, int tile_height,
                        const int32_t *isect_offsets, const void *table_scratch, int64_t n_live, void *buckets,

@@ -179,6 +179,7 @@ def test_row_moving_callbacks_flush_a_deferred_feature_update(dev):
             st = DensifyStrategy(SplatfactoConfig(), num_train_data=2, stats_only=True)
             tr = SplatTrainer(params, dev, seed=0, strategy=st)
             tr.force_split_step = split
+            tr.ride_adam = False  # (the plain step for split = False: nothing deferred)
             tr.factored_features = factored
             tr.train_step(cams[0], tgts[0])
             assert (tr._pending is not None) == split

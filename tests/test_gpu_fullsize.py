@@ -402,6 +402,46 @@ def test_dense_scene_takes_the_depth_slab_path_and_matches_the_radix_chain(dev):
     assert int(n_tile.max()) > 8192, "some tiles exceed even the large LDS tier before the split"
 
 
+def test_feature_adam_riding_in_the_count_pass_is_the_same_training(dev):
+    """One GPU: the SH features' Adam launch of step k rides in the projecting count pass of step k + 1
+    (fsgs_project_bin_live_count_sh_pack, trainer.ride_adam: scenes of 256 k .. 512 k Gaussians; forced here).  Same
+    training as with the plain step (to the run-to-run noise of the backward's atomics), the optimizer's step
+    counters advance once per step, flush() lands the last update, and an evaluation forward in between sees the
+    updated features."""
+    from fusionsense_amd.trainer import FEATURE_GROUPS, PARAM_ORDER, SplatTrainer
+    params = scenes.lego_like_scene(20_000, seed=3)
+    cams = scenes.hemisphere_cameras(3, width=160, height=128, focal=180.0, seed=1)
+    g = torch.Generator().manual_seed(0)
+    tgts = [{"rgb": torch.rand(128, 160, 3, generator=g).to(dev), "depth": torch.rand(128, 160, 1, generator=g).to(dev),
+             "normal": torch.rand(128, 160, 3, generator=g).to(dev)} for _ in cams]
+    a = SplatTrainer(params, dev, seed=0)
+    b = SplatTrainer(params, dev, seed=0)
+    b.ride_adam = False
+    a.ride_adam_n = (0, 1 << 30)
+    assert a._ride_mode() and not b._ride_mode()
+    for it in range(6):
+        la, _ = a.train_step(cams[it % 3], tgts[it % 3])
+        lb, _ = b.train_step(cams[it % 3], tgts[it % 3])
+        assert a._pending is not None and b._pending is None
+        assert abs(float(la) - float(lb)) <= 1e-5 * abs(float(lb)), it
+        if it == 2:  # a reader in between: the no-grad forward flushes
+            with torch.no_grad():
+                ra, rb = a.forward(cams[0]), b.forward(cams[0])
+            assert a._pending is None
+            assert float((ra["rgb"] - rb["rgb"]).abs().max()) < 2e-3
+    pending = a.params["features_rest"].data.clone()
+    a.flush()
+    assert not torch.equal(a.params["features_rest"].data, pending), "the last update was still pending"
+    for k in PARAM_ORDER:
+        # Adam (eps = 1e-15) steps by +-lr whatever the size of a gradient, so the few entries whose gradient is
+        # atomics noise around zero may differ by a learning rate between ANY two runs: compare robustly
+        d = (a.params[k].data - b.params[k].data).abs()
+        assert float((d > 2e-5).float().mean()) < 1e-3 and float(d.mean()) < 1e-6, k
+        sa, sb = a.optimizers[k].state[a.params[k]], b.optimizers[k].state[b.params[k]]
+        assert float(sa["step"]) == float(sb["step"]) == 6.0, (k, float(sa["step"]), float(sb["step"]))
+        assert rel_err(sa["exp_avg_sq"], sb["exp_avg_sq"]) < 1e-3, k
+
+
 @pytest.mark.parametrize("factored", [True, False])
 def test_deferred_feature_update_is_the_same_training(dev, factored):
     """The data-parallel step order on ONE rank (FSGS_FORCE_SPLIT_STEP: geometry stepped at once, the SH features'
@@ -415,6 +455,7 @@ def test_deferred_feature_update_is_the_same_training(dev, factored):
              "normal": torch.rand(128, 160, 3, generator=g).to(dev)} for _ in cams]
     a = SplatTrainer(params, dev, seed=0)
     b = SplatTrainer(params, dev, seed=0)
+    b.ride_adam = False             # the plain step: every group stepped at the end of train_step
     a.force_split_step = True
     a.factored_features = factored  # True: the SH gradients travel as factors and are rebuilt at the flush
     for it in range(5):

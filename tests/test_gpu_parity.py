@@ -565,6 +565,7 @@ def test_fused_trainer_step_equals_unfused(dev):
         tr = SplatTrainer(params, dev, fused=fused)
         before = {k: v.detach().clone() for k, v in tr.params.items()}
         loss = tr.train_step(cam, target)[0].item()
+        tr.flush()  # (the fused trainer's feature update rides in the NEXT frame's count pass: land it)
         res.append((loss, {k: tr.slab.views[k].clone() for k in tr.params},
                     {k: (tr.params[k].detach() - before[k]) for k in tr.params}))
     assert abs(res[0][0] - res[1][0]) < 1e-5 * max(1.0, abs(res[1][0]))
