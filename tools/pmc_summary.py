@@ -26,7 +26,8 @@ SPAN = [
     ("sh_fwd_pack_direct_kernel", "sh_fwd_split"), ("sh_bwd_hybrid_kernel", "sh_bwd_split"), ("project_fwd_kernel<true>", "project_fwd_act"),
     ("isect_live_flat_kernel<false>", "isect_count_live"), ("isect_live_flat_kernel<true>", "isect_emit_live"),
     ("isect_live_bin_kernel<false", "isect_count_live"), ("isect_live_bin_kernel<true", "tile_sort"),
-    ("tile_scan_rows_kernel", "isect_count_live"),
+    ("tile_scan_rows_kernel", "isect_count_live"), ("isect_count_adam_kernel", "isect_count_live"),
+    ("scan_rows_sh_pack_kernel", "isect_count_live"),
     ("live_pack_kernel", "live_pack_normals_d4e3"),
 ]
 
