@@ -126,6 +126,9 @@ __device__ __forceinline__ void row_transpose_sum16(float (&v)[16]) {
 // one Adam update (torch.optim.Adam, amsgrad = False, weight_decay = 0): ss = lr / (1 - b1^t), isb2 = 1 / sqrt(1 - b2^t)
 __device__ __forceinline__ void adam_one(float &p, float g, float &m, float &v, float b1, float b2, float omb1,
                                          float omb2, float ss, float isb2, float eps) {
+    // (no FMA contraction: torch rounds every product, and the kernels that inline this — the Adam launch, the SH
+    // rebuild + Adam, the count pass that carries a riding step — must agree to the bit)
+#pragma clang fp contract(off)
     m = b1 * m + omb1 * g;
     v = b2 * v + omb2 * g * g;
     p -= ss * m / (sqrtf(v) * isb2 + eps);

@@ -893,6 +893,10 @@ static int project_bin_live_count_impl(int N, const float *means, const void *qu
         }
         if (e == hipSuccess && rider && rider->zero_cells && rider->n_zero > 0)
             e = hipMemsetAsync(rider->zero_cells, 0, (size_t)rider->n_zero * sizeof(float), s);
+        if (e == hipSuccess && adam)  // (nothing to ride in: the step as a launch of its own)
+            return fsgs_adam_step_h16(adam->n_groups, adam->params, adam->grads, adam->exp_avg, adam->exp_avg_sq,
+                                      adam->half_mirror, adam->numel, adam->lr, adam->step, adam->beta1, adam->beta2,
+                                      adam->eps, stream);
         if (e != hipSuccess) { g_last_hip_error = (int)e; return FSGS_ELAUNCH; }
         return FSGS_OK;
     }

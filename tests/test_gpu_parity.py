@@ -818,6 +818,44 @@ def test_folded_entry_points_equal_the_chains_they_replace(dev):
     # colours and normals are the same statements compiled into another kernel: equal to rounding
     assert (pk_a[:, 8:] - pk_b[:, 8:]).abs().max().item() <= 2e-6 and (nw_a - nw_b).abs().max().item() <= 2e-6
 
+    # ---- the count pass with riders: SH forward + packing in its scan launch, an Adam step in its own ----------
+    import ctypes as C
+    c, opl_c = proj_bufs(), P["opacities"].clone()
+    pk_c, nw_c, mx_c = torch.empty(N, 16, **f32), torch.empty(N, 3, **f32), torch.full((n_cells,), 7.0, **f32)
+    gA = torch.Generator().manual_seed(11)
+    prm = [torch.randn(5000, 3, generator=gA).to(dev), torch.randn(777, generator=gA).to(dev)]
+    grd = [torch.randn(5000, 3, generator=gA).to(dev), torch.randn(777, generator=gA).to(dev)]
+    mom = [torch.rand(5000, 3, generator=gA).to(dev) * 0.1, torch.rand(777, generator=gA).to(dev) * 0.1]
+    var = [torch.rand(5000, 3, generator=gA).to(dev) * 0.01, torch.rand(777, generator=gA).to(dev) * 0.01]
+    ref = [[t.clone() for t in grp] for grp in (prm, mom, var)]
+    ops.adam_step_(ref[0], grd, ref[1], ref[2], [1e-2, 3e-3], 4)
+    groups = ops.adam_groups(prm, grd, mom, var, [1e-2, 3e-3], 4)
+    T_ = tw * th
+    tpg_c = torch.empty(1, N, dtype=torch.int32, device=dev)
+    offs_c = torch.empty(T_ + 1, dtype=torch.int32, device=dev)
+    tbytes = lib.fsgs_bin_live_table_bytes(1, N, tw, th)
+    table = torch.empty(tbytes, dtype=torch.uint8, device=dev)
+    assert lib.fsgs_project_bin_live_count_sh_pack(
+        N, ptr(P["means"]), ptr(P["quats"]), ptr(P["scales"]), ptr(opl_c), 1, 0.1, ptr(cd["viewmat"]), ptr(cd["K"]), W, H,
+        0.3, 0.01, 1e10, 0.0, ptr(c["scales_exp"]), ptr(c["opac_sig"]), ptr(c["radii"]), ptr(c["means2d"]),
+        ptr(c["depths"]), ptr(c["conics"]), tw, th, ptr(tpg_c), ptr(offs_c), ptr(table), tbytes, None, 3,
+        ptr(cd["campos"]), ptr(P["features_dc"]), ptr(P["features_rest"]), ptr(cd["c2w"]), ptr(pk_c), ptr(nw_c),
+        ptr(mx_c), n_cells, C.byref(groups), sp) == 0
+    torch.cuda.synchronize()
+    for k in ("scales_exp", "opac_sig", "radii", "depths", "means2d", "conics"):
+        assert torch.equal(c[k], b[k]), k          # (the same kernel body as fsgs_project_bin_live_count)
+    assert torch.equal(tpg_c, st_b["tpg"]) and torch.equal(offs_c, st_b["offsets"]) and torch.equal(opl_c, opl_b)
+    # packed records from ITS projection: the copied fields exactly, colours / normals as the stand-alone launch
+    pk_d, nw_d, mx_d = torch.empty(N, 16, **f32), torch.empty(N, 3, **f32), torch.full((n_cells,), 7.0, **f32)
+    assert lib.fsgs_sh_fwd_pack(N, K, 3, ptr(P["means"]), ptr(cd["campos"]), ptr(P["features_dc"]),
+                                ptr(P["features_rest"]), ptr(c["radii"]), ptr(c["depths"]), ptr(c["means2d"]),
+                                ptr(c["conics"]), ptr(c["opac_sig"]), ptr(P["quats"]), ptr(P["scales"]), ptr(cd["c2w"]),
+                                ptr(pk_d), ptr(nw_d), ptr(mx_d), n_cells, sp) == 0
+    assert torch.equal(pk_c, pk_d) and torch.equal(nw_c, nw_d) and torch.equal(mx_c, mx_d)
+    for got, want in zip((prm, mom, var), ref):     # the riding Adam step = fsgs_adam_step, bit for bit
+        for x, y in zip(got, want):
+            assert torch.equal(x, y)
+
     # ---- forward compositing (shared), then epilogue (+ aux loss) ---------------------------------------------
     cap = lib.fsgs_quad_stream_capacity(1, tw, th, M)
     records = torch.empty(4 * cap * 16, **f32)
