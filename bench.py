@@ -601,6 +601,7 @@ def main():
             "iter_algorithmic_bytes": b_iter,
             "iter_hbm_frac": round(b_iter / (elapsed / args.steps) / (HBM_PEAK_GBS * 1e9), 5),
             "device_mallocs_in_timed_region": n_alloc,
+            "live_list_overflows": int(getattr(trainer, "live_overflows", 0)),  # frames redone (no-wait binning)
             "max_step_ms": round(1e3 * max(b - a for a, b in zip([t0] + step_ends[:-1], step_ends)), 3),
             "slowest_step": max(range(len(step_ends)), key=lambda i: step_ends[i] - ([t0] + step_ends)[i]),
             "gpu_step_ms": gpu_step_stats(step_events, step_views) if with_events else None,
