@@ -285,31 +285,96 @@ def build_workload(args, dev):
     return w
 
 
+def spawn_ranks(args) -> int:
+    """``--gpus N`` (N > 1) WITHOUT a launcher: start the N ranks as a CHILD ``python -m torch.distributed.run`` (one
+    process per GPU, 127.0.0.1 rendezvous on a free port) BEFORE this process has made any GPU call, relay rank 0's JSON
+    line and return the child's exit code.  Nothing is re-executed in place (a process that has initialised the GPU must
+    never exec), and a failed attempt is a non-zero exit, never a silent one-rank run (the reference's hook for the
+    multi-GPU path: /root/reference/dn_splatter/dn_pipeline.py:162-167)."""
+    import socket
+    import subprocess
+    n_dev = torch.cuda.device_count()  # (counting devices does not initialise the GPU on this image)
+    backend = os.environ.get("FSGS_DIST_BACKEND", "nccl")
+    if backend == "nccl" and n_dev < args.gpus:
+        print(f"bench.py: --gpus {args.gpus} over RCCL needs {args.gpus} visible GPUs, found {n_dev} "
+              "(FSGS_DIST_BACKEND=gloo runs the ranks on shared devices: a functional check, not a measurement)",
+              file=sys.stderr)
+        return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, FSGS_BENCH_SPAWNED="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # (dmabuf IPC: what RCCL needs on this driver)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, cwd=ROOT)
+    lines = []
+    for ln in p.stdout:
+        if ln.startswith("{"):
+            lines.append(ln.rstrip("\n"))
+        else:
+            sys.stderr.write(ln)
+    rc = p.wait()
+    if rc == 0 and len(lines) != 1:
+        print(f"bench.py: expected one JSON line from rank 0, got {len(lines)}", file=sys.stderr)
+        rc = 3
+    if rc == 0:
+        print(lines[0], flush=True)
+    return rc
+
+
+def ranks_seen(rank, local_dev, backend, dev):
+    """All-gather of (rank, device index): what the group really consists of, for the bench line."""
+    world = dist.get_world_size()
+    mine = torch.tensor([rank, local_dev], dtype=torch.int64, device=dev if backend == "nccl" else "cpu")
+    got = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(got, mine)
+    got = [g.cpu().tolist() for g in got]
+    return [g[0] for g in got], [g[1] for g in got]
+
+
 def main():
     args = parse()
     if args.cpu_baseline_worker:
         cpu_baseline_worker(args.n_gauss, args.res, args.cpu_crop, args.cpu_threads, args.cpu_views)
         return
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        sys.exit(spawn_ranks(args))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    assert world == args.gpus or world == 1, f"WORLD_SIZE {world} != --gpus {args.gpus}"
+    if world != args.gpus:
+        print(f"bench.py: WORLD_SIZE {world} != --gpus {args.gpus}: refusing to measure a different job than the one "
+              "asked for", file=sys.stderr)
+        sys.exit(2)
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
     # FSGS_DIST_BACKEND=gloo: functional check of the multi-rank path on a box with fewer GPUs than ranks (the ranks
     # then share devices and the collectives are staged through the host); the default is RCCL, one GPU per rank
     backend = os.environ.get("FSGS_DIST_BACKEND", "nccl")
     if backend != "nccl":
         local_rank = local_rank % max(torch.cuda.device_count(), 1)
+    elif world > 1 and torch.cuda.device_count() < world:
+        print(f"bench.py: {world} RCCL ranks need {world} GPUs, found {torch.cuda.device_count()}", file=sys.stderr)
+        sys.exit(2)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     # (FSGS_FORCE_COLLECTIVES=1 under a one-rank launcher: the multi-GPU step's RCCL calls on a one-GPU box)
     one_rank_group = world == 1 and os.environ.get("FSGS_FORCE_COLLECTIVES") == "1" and "MASTER_PORT" in os.environ
+    seen = devices = None
     if world > 1 or one_rank_group:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
+        assert dist.get_world_size() == world and dist.get_rank() == rank
+        seen, devices = ranks_seen(rank, local_rank, backend, dev)
+        if sorted(seen) != list(range(world)):
+            raise SystemExit(f"bench.py: the group holds ranks {seen}, expected 0..{world - 1}")
+        if backend == "nccl" and world > 1 and len(set(devices)) != world:
+            raise SystemExit(f"bench.py: RCCL ranks share devices {devices}: one GPU per rank is the contract")
 
     from fusionsense_amd import frame_cache, ops
 
@@ -414,12 +479,14 @@ def main():
         log('param digest ' + json.dumps({name: [float(trainer.params[name].data.double().mean()),
                                                  float(trainer.params[name].data.double().abs().mean())]
                                           for name in sorted(trainer.params)}))
-    if grouped and os.environ.get("FSGS_BENCH_CHECK_REPLICAS"):
+    replicas_ok = None
+    if grouped and os.environ.get("FSGS_BENCH_CHECK_REPLICAS", "1" if world > 1 else "") not in ("", "0"):
         # the ranks must hold bit-identical parameters after the timed steps (rank-ordered gradient sums)
         for name, prm in trainer.params.items():
             ref = prm.data.clone()
             dist.broadcast(ref, 0)
             assert torch.equal(ref, prm.data), f"rank {rank}: replica of {name} differs from rank 0"
+        replicas_ok = True
         log('replicas identical')
     n_alloc = torch.cuda.memory_stats(dev).get('num_device_alloc', 0) - n_alloc0
     log(f'timed region done: {elapsed:.3f}s')
@@ -591,6 +658,10 @@ def main():
                        "isects_per_gaussian": round(M / max(N, 1), 3),
                        "normal_pass_list_reuse": bool(reused), "parallelism": f"dp{world}",
                        "backend": (backend if grouped else None),
+                       "world_size": world, "ranks_seen": seen, "rank_devices": devices,
+                       "replicas_identical_after_timed_steps": replicas_ok,
+                       "launched_by": ("bench.py (child torch.distributed.run)" if os.environ.get("FSGS_BENCH_SPAWNED")
+                                       else ("external launcher" if "WORLD_SIZE" in os.environ else "single process")),
                        "comm_bytes_per_step_per_rank": getattr(trainer, "comm_bytes_last_step", 0) if grouped else 0},
             "rendered_mpix_per_s": round(world * P / t_fwd / 1e6, 2),
             "fwd_ms": round(t_fwd * 1e3, 3),

@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "../../include/fsgs.h"
 
 namespace fsgs {
@@ -25,6 +27,29 @@ inline int check_launch() {
 }
 
 inline hipStream_t as_stream(fsgs_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a property of (kernel, DEVICE): remembered per device of the calling
+// thread, with atomics (the library is re-entrant across threads and a process may drive several GPUs).  A lost race
+// sets the same attribute twice, which is harmless.
+constexpr int kMaxDevices = 64;
+template <auto Kernel>
+inline int ensure_dynamic_lds(size_t need) {
+    static std::atomic<size_t> have[kMaxDevices] = {};
+    int dev = -1;
+    const bool known = hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < kMaxDevices;
+    if (known && need <= have[dev].load(std::memory_order_acquire)) return FSGS_OK;
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(Kernel),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)need);
+    if (e != hipSuccess) {
+        g_last_hip_error = (int)e;
+        return FSGS_ELAUNCH;
+    }
+    if (known) {
+        size_t cur = have[dev].load(std::memory_order_relaxed);
+        while (cur < need && !have[dev].compare_exchange_weak(cur, need, std::memory_order_release)) {}
+    }
+    return FSGS_OK;
+}
 
 inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 

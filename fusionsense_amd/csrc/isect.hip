@@ -777,15 +777,9 @@ extern "C" size_t fsgs_bin_live_table_bytes(int C, int N, int tile_width, int ti
 // one launch of isect_live_bin_kernel<SC, multi?, PJ, HF, threads(total)>: dynamic LDS limit raised on first need
 template <bool SC, bool MU, bool PJ, bool HF, int BT, typename... Args>
 static int bin_launch_one(int T, int64_t total, int nb, hipStream_t s, Args... args) {
-    static size_t have = 0;
     const size_t need = bin_lds_bytes(T, total);
     auto kernel = &isect_live_bin_kernel<SC, MU, PJ, HF, BT>;
-    if (need > have) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)need);
-        if (e != hipSuccess) { g_last_hip_error = (int)e; return FSGS_ELAUNCH; }
-        have = need;
-    }
+    if (const int rc = ensure_dynamic_lds<&isect_live_bin_kernel<SC, MU, PJ, HF, BT>>(need)) return rc;
     hipLaunchKernelGGL(kernel, dim3(nb), dim3(BT), need, s, args...);
     return check_launch();
 }
@@ -804,15 +798,9 @@ static int bin_launch(int T, int64_t total, int nb, hipStream_t s, Args... args)
 template <bool MU, bool HF, int BT>
 static int count_adam_launch_one(int T, int64_t total, int nb, hipStream_t s, int N, int tw, int th, int chunks,
                                  int32_t *tiles_per_gauss, int32_t *table, const BinProjArgs &pj, const AdamArgs &adam) {
-    static size_t have = 0;
     const size_t need = bin_lds_bytes(T, total);
     auto kernel = &isect_count_adam_kernel<MU, HF, BT>;
-    if (need > have) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)need);
-        if (e != hipSuccess) { g_last_hip_error = (int)e; return FSGS_ELAUNCH; }
-        have = need;
-    }
+    if (const int rc = ensure_dynamic_lds<&isect_count_adam_kernel<MU, HF, BT>>(need)) return rc;
     hipLaunchKernelGGL(kernel, dim3(nb + adam.n_blocks), dim3(BT), need, s, N, tw, th, T, nb, chunks, tiles_per_gauss,
                        table, pj, adam);
     return check_launch();

@@ -494,13 +494,7 @@ int64_t split_scratch_ints(int T, int64_t n_live) { return (int64_t)(T + 1) + (T
 
 int launch_tile_sort_tiers(int T, int n_tiles, int tile_bits, const int32_t *isect_offsets, uint64_t *buckets,
                            int32_t *payload_sorted, int64_t *isect_ids_sorted, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&tile_sort_kernel2<1024, kTsLarge, kTsSmall, true>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, kTsLarge * 8);
-        if (e != hipSuccess) { g_last_hip_error = (int)e; return FSGS_ELAUNCH; }
-        attr_set = true;
-    }
+    if (const int rc = ensure_dynamic_lds<&tile_sort_kernel2<1024, kTsLarge, kTsSmall, true>>(kTsLarge * 8)) return rc;
     static int one_tier = -1;
     if (one_tier < 0) {
         const char *e = getenv("FSGS_SORT_ONE_TIER");
@@ -512,13 +506,7 @@ int launch_tile_sort_tiers(int T, int n_tiles, int tile_bits, const int32_t *ise
         // few long ones instead of in a launch of their own in front of them: 15 + 31 -> 40 us at config #2.
         // With tens of thousands of buckets (large images, the depth-slab path) the 64 KB of LDS per workgroup would
         // limit the small ones to 2 per CU: there the two tiers stay.
-        static bool attr2 = false;
-        if (!attr2) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&tile_sort_kernel2<1024, kTsLarge, 0, true>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, kTsLarge * 8);
-            if (e != hipSuccess) { g_last_hip_error = (int)e; return FSGS_ELAUNCH; }
-            attr2 = true;
-        }
+        if (const int rc = ensure_dynamic_lds<&tile_sort_kernel2<1024, kTsLarge, 0, true>>(kTsLarge * 8)) return rc;
         hipLaunchKernelGGL((tile_sort_kernel2<1024, kTsLarge, 0, true>), dim3(T), dim3(1024), kTsLarge * 8, s, n_tiles,
                            tile_bits, isect_offsets, buckets, payload_sorted, isect_ids_sorted);
         return check_launch();

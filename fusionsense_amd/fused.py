@@ -505,7 +505,12 @@ def fused_step_forward_backward(gauss_params: Dict[str, Tensor], camera: Camera,
 
     def check_live_total(ctx):
         """No-wait binning: the forward's launches are enqueued, now look at the frame's live total (it has normally
-        long arrived).  On overflow the truncated frame is abandoned before anything with side effects has run."""
+        long arrived).  On overflow the truncated frame is abandoned before any BACKWARD launch (statistics, gradient
+        accumulator, gradient slab, the step's own Adam).  What the count pass has already done by then is final and
+        must not be done twice: the binary-opacity write to the logits (master and half mirror), a riding feature
+        Adam step of the PREVIOUS frame and a flushed deferred update (``pre_sh``) — the trainer's retry therefore
+        runs without ``binary_threshold`` (the write is not idempotent for thresholds outside (0, 1]) and finds no
+        pending update."""
         if info.pending_count is None:
             return
         try:

@@ -74,6 +74,30 @@ class LazyMeta(dict):
         self._materialise()
         return dict.__len__(self)
 
+    # C-level dict paths (dict.copy, dict(meta), {**meta}, dict.update(other, meta), pickling, copy.copy) do not go
+    # through the overrides above: everything that hands the CONTENT on materialises the lists first and returns a
+    # plain dict, so a copy can never lack a key that ``in`` reported.
+    def copy(self):
+        self._materialise()
+        return dict(dict.items(self))
+
+    __copy__ = copy
+
+    def __deepcopy__(self, memo):
+        import copy as _copy
+        self._materialise()
+        return {k: _copy.deepcopy(v, memo) for k, v in dict.items(self)}
+
+    def __reduce__(self):
+        self._materialise()
+        return (dict, (dict(dict.items(self)),))
+
+    def __or__(self, other):
+        return self.copy() | dict(other)
+
+    def __ror__(self, other):
+        return dict(other) | self.copy()
+
 
 def _validate(means, quats, scales, opacities, colors, viewmats, Ks, sh_degree, backgrounds, render_mode,
               tile_size, rasterize_mode):

@@ -141,7 +141,7 @@ class SplatTrainer:
         self.sh_degree_interval = sh_degree_interval
         self.optim_cfg = optim or OptimConfig()
         # (a copy: training must not write into the caller's tensors)
-        self.params: Dict[str, torch.nn.Parameter] = {
+        self._params: Dict[str, torch.nn.Parameter] = {
             k: torch.nn.Parameter(params[k].detach().to(device=device, dtype=torch.float32, copy=True).contiguous())
             for k in PARAM_ORDER}
         self.fused_adam = fused_adam and device.type == "cuda"
@@ -151,9 +151,9 @@ class SplatTrainer:
         self.optimizers: Dict[str, torch.optim.Adam] = {}
         for name in PARAM_ORDER:
             self.optimizers[name] = torch.optim.Adam(
-                [self.params[name]], lr=self.optim_cfg.lr[name], eps=self.optim_cfg.eps,
+                [self._params[name]], lr=self.optim_cfg.lr[name], eps=self.optim_cfg.eps,
                 fused=self.fused_adam)
-        self.slab = GradSlab(self.params)
+        self.slab = GradSlab(self._params)
         # Data-parallel runs: the SH features' share of the all-reduce (81 % of the slab) and their Adam launch are
         # deferred until the next frame needs the colours, i.e. they overlap that frame's projection, binning and
         # sort, which read geometry only (exact: every parameter still sees its fully reduced gradient before its
@@ -210,8 +210,17 @@ class SplatTrainer:
         t = min(max(step / c.means_lr_max_steps, 0.0), 1.0)
         return math.exp(math.log(c.lr["means"]) * (1 - t) + math.log(c.means_lr_final) * t)
 
+    @property
+    def params(self) -> Dict[str, torch.nn.Parameter]:
+        """The parameter dictionary as every OUTSIDE reader must see it: a deferred feature update (data-parallel
+        runs; on one GPU the features' Adam step that rides in the next frame's count pass, 256 k .. 512 k Gaussians)
+        is landed first, so exports, EMA copies, user scripts and the densification callbacks never read features
+        that are one Adam step behind.  The step itself uses ``_params`` (no flush)."""
+        self.flush()
+        return self._params
+
     def num_gaussians(self) -> int:
-        return self.params["means"].shape[0]
+        return self._params["means"].shape[0]
 
     def half_mirrors(self) -> Optional[Dict[str, Tensor]]:
         """The float16 mirrors of HALF_GROUPS (None unless half_attributes), re-derived from the masters whenever
@@ -219,9 +228,9 @@ class SplatTrainer:
         if not self.half_attributes:
             return None
         stale = self._half is None or self._half_dirty or any(
-            self._half[k].shape != self.params[k].shape for k in HALF_GROUPS)
+            self._half[k].shape != self._params[k].shape for k in HALF_GROUPS)
         if stale:
-            self._half = {k: self.params[k].data.to(torch.float16).contiguous() for k in HALF_GROUPS}
+            self._half = {k: self._params[k].data.to(torch.float16).contiguous() for k in HALF_GROUPS}
             self._half_dirty = False
         return self._half
 
@@ -261,12 +270,12 @@ class SplatTrainer:
         stats, add_mask, bthr = self._frame_state(camera, grad)
         if self.fused:
             from .fused import render_fusionsense_fused
-            return render_fusionsense_fused(self.params, camera, sh_degree=deg, device=self.device,
+            return render_fusionsense_fused(self._params, camera, sh_degree=deg, device=self.device,
                                             grad_out=self.slab.views if grad else None, stats_out=stats,
                                             add_mask=add_mask, crop_box=crop_box, training=grad,
                                             binary_threshold=bthr, half=self.half_mirrors())
         from .fusion import render_fusionsense
-        return render_fusionsense(self.params, camera, sh_degree=deg, device=self.device, add_mask=add_mask,
+        return render_fusionsense(self._params, camera, sh_degree=deg, device=self.device, add_mask=add_mask,
                                   crop_box=crop_box, training=grad, binary_threshold=bthr)
 
     def _touch_rows(self):
@@ -286,7 +295,7 @@ class SplatTrainer:
             # The fused get_outputs node WRITES its gradients into the slab (it does not accumulate), so on that route
             # the min-scale term's direct gradient to the log-scales is added by train_step after the backward
             # instead of travelling through autograd's accumulation, whose order against the node's write is open.
-            scales = self.params["scales"].detach() if self.fused else self.params["scales"]
+            scales = self._params["scales"].detach() if self.fused else self._params["scales"]
             return fusion_loss(out, target, self.loss_cfg, scales, ti, tn)
         if self.fused and "depth" in target and out["rgb"].is_cuda:
             from .ops import train_loss
@@ -307,7 +316,7 @@ class SplatTrainer:
         from .ops import adam_groups, adam_step_
         ps, gs, ms, vs, lrs = [], [], [], [], []
         for name in (names or PARAM_ORDER):
-            p = self.params[name]
+            p = self._params[name]
             opt = self.optimizers[name]
             st = opt.state[p]
             if "exp_avg" not in st:
@@ -333,6 +342,8 @@ class SplatTrainer:
             return self._fused_adam_step(names, step_no)
         for name in names:
             self.optimizers[name].step()
+        if self.half_attributes:
+            self.mark_params_written()  # torch's step does not rewrite the half mirrors: re-derive before the next frame
         return None
 
     def _ride_mode(self) -> bool:
@@ -388,10 +399,10 @@ class SplatTrainer:
         from ._lib import load, ptr, stream_ptr
         own, gathered = self._factors
         R, N = gathered.shape[0], self.num_gaussians()
-        K = 1 + self.params["features_rest"].shape[1]
+        K = 1 + self._params["features_rest"].shape[1]
         st = []
         for name in FEATURE_GROUPS:
-            p = self.params[name]
+            p = self._params[name]
             opt = self.optimizers[name]
             s_ = opt.state[p]
             if "exp_avg" not in s_:
@@ -437,9 +448,9 @@ class SplatTrainer:
                 self.comm_bytes_last_step = 4 * (self.slab.split * 2 + gathered.numel())
             deg = self._sh_degree_now()
             mp = getattr(self, "_means_prev", None)
-            if mp is None or mp.shape != self.params["means"].shape:
-                mp = self._means_prev = torch.empty_like(self.params["means"].data)
-            mp.copy_(self.params["means"].data)  # before Adam moves them (12 B per Gaussian)
+            if mp is None or mp.shape != self._params["means"].shape:
+                mp = self._means_prev = torch.empty_like(self._params["means"].data)
+            mp.copy_(self._params["means"].data)  # before Adam moves them (12 B per Gaussian)
 
             def finish(step_no):
                 if work is not None:
@@ -488,7 +499,7 @@ class SplatTrainer:
             for attempt in (0, 1):
                 try:
                     loss, out = fused_step_forward_backward(
-                        self.params, camera, target, self._sh_degree_now(), self.device, self.slab.views, self._one,
+                        self._params, camera, target, self._sh_degree_now(), self.device, self.slab.views, self._one,
                         stats_out=stats, add_mask=add_mask, binary_threshold=bthr,
                         pre_sh=self.flush if self._pending is not None else None, adam_rider=self._adam_rider(),
                         sh_factors_out=factors[0] if factors else None,
@@ -499,6 +510,10 @@ class SplatTrainer:
                     self.live_overflows += 1
                     self._live_caps[cap_key] = int(e.needed * 1.25) + 4096
                     cap = 0
+                    # the abandoned attempt's count pass has already written the binary opacities (and landed any
+                    # pending feature update): the logits now hold the written values, the retry must not
+                    # threshold them a second time
+                    bthr = None
             n_live = out["info"].n_live
             if n_live is not None and self.no_wait:
                 self._live_caps[cap_key] = max(self._live_caps.get(cap_key, 0), int(n_live * 1.25) + 4096)
@@ -513,7 +528,7 @@ class SplatTrainer:
                 from .ops import fusion_loss_weights, min_scale_grad_
                 g_min = fusion_loss_weights(self.loss_cfg, target, self.num_gaussians(), 0)[2]
                 if g_min != 0.0:
-                    min_scale_grad_(self.params["scales"].data, g_min, self._one.reshape(1), self.slab.views["scales"])
+                    min_scale_grad_(self._params["scales"].data, g_min, self._one.reshape(1), self.slab.views["scales"])
         self._reduce_and_step(optimizer_step)
         if self.strategy is not None:
             self.strategy.after_train(self, out, camera)

@@ -450,6 +450,34 @@ def test_config4_two_ranks_scaled_down():
     assert err.count("replicas identical") == 2, err[-2000:]
 
 
+def test_bench_spawns_its_own_ranks_without_a_launcher():
+    """``python bench.py --gpus 2`` with NO launcher (the way the driver starts the 1-GPU run): bench.py starts its two
+    ranks itself as a child torch.distributed.run before touching the GPU (here both on this GPU over gloo), relays
+    rank 0's line and reports what the group really was — n_gpus 2, both ranks seen, replicas checked by default."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(FSGS_DIST_BACKEND="gloo")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
+                        "--n-gauss", "20000", "--res", "160", "--views", "4", "--no-cpu-baseline"],
+                       capture_output=True, text=True, env=env, timeout=400, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0
+    c = line["config"]
+    assert c["world_size"] == 2 and sorted(c["ranks_seen"]) == [0, 1] and c["backend"] == "gloo"
+    assert c["replicas_identical_after_timed_steps"] is True and c["launched_by"].startswith("bench.py")
+    assert c["parallelism"] == "dp2" and c["comm_bytes_per_step_per_rank"] > 0
+    # the same flags over RCCL on a box with one GPU: a loud refusal, not a one-rank measurement
+    if torch.cuda.device_count() < 2:
+        env.pop("FSGS_DIST_BACKEND")
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                           capture_output=True, text=True, env=env, timeout=200, cwd=root)
+        assert r.returncode == 2 and not r.stdout.strip()
+
+
 def test_two_ranks_over_rccl_when_two_gpus():
     """The first thing a real multi-GPU node runs: bench.py with 2 ranks on 2 GPUs over RCCL ("nccl"), replicas
     checked bit for bit.  Skipped on 1-GPU boxes (the driver's 8-GPU scaling run is the measurement)."""

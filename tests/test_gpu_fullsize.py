@@ -619,3 +619,29 @@ def test_no_wait_step_is_bit_identical_and_survives_overflow(dev, full_scene):
         for tr in (b, c):
             d = (a.params[k].data - tr.params[k].data).abs()
             assert float((d > 2e-5).float().mean()) < 2e-2, k  # (Adam turns atomics noise around zero gradients into +-lr)
+
+    # The same with the binary-opacity write becoming active exactly at the overflowing frame (and the features' Adam
+    # step riding in the count pass, on by default at this size): the abandoned attempt has already thresholded the
+    # logits, so the retry must not threshold them again.  A threshold outside (0, 1] makes a second write visible
+    # (1 >= 1.5 is false: every logit would end at 0).
+    def run_binary(poison_cap=None):
+        st = DensifyStrategy(SplatfactoConfig(binary_opacities_threshold=1.5), num_train_data=2, stats_only=True)
+        tr = SplatTrainer(params, dev, sh_degree=3, strategy=st)
+        tr.step = st.cfg.warmup_length - 1  # the write starts at the third frame (step > warmup_length)
+        ones = []
+        for it in range(3):
+            if poison_cap is not None and it == 2:
+                for k in tr._live_caps:
+                    tr._live_caps[k] = poison_cap
+            tr.train_step(cams[it % 2], tgt)
+            ones.append(float((tr.params["opacities"].data > 0.5).float().mean()))
+        return tr, ones
+
+    d_, ones_d = run_binary()
+    e_, ones_e = run_binary(poison_cap=1000)
+    assert d_.live_overflows == 0 and e_.live_overflows == 1
+    assert 0.3 < ones_d[2] < 0.9, ones_d  # N(2, 1.5) logits against 1.5
+    assert abs(ones_d[2] - ones_e[2]) < 1e-3, (ones_d, ones_e)
+    for k in PARAM_ORDER:
+        d = (d_.params[k].data - e_.params[k].data).abs()
+        assert float((d > 2e-5).float().mean()) < 2e-2, k

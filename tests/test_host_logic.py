@@ -724,3 +724,18 @@ def test_inference_helpers_match_reference_goldens():
     assert torch.equal(inf.find_depth_edges(t("edge_depth"), 0.01, 3), t("edge_out"))
     assert torch.equal(inf.find_depth_edges(t("edge_depth"), 0.05, 1), t("edge_out_1"))
     assert float(t("edge_out").sum()) > 0 and float(t("edge_out_1").sum()) < float(t("edge_out").sum())
+
+
+def test_bench_refuses_a_world_size_that_is_not_gpus():
+    """bench.py never measures a different job than the one asked for: a launcher-provided WORLD_SIZE that differs
+    from --gpus is refused (exit 2) before anything touches the GPU, and --gpus N without a launcher over RCCL on a
+    box with fewer than N GPUs fails loudly instead of silently running one rank."""
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode == 2 and "WORLD_SIZE 1 != --gpus 8" in r.stderr and not r.stdout.strip()
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "FSGS_DIST_BACKEND")}
+    if torch.cuda.device_count() < 8:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0"],
+                           capture_output=True, text=True, env=env, timeout=120)
+        assert r.returncode == 2 and "needs 8 visible GPUs" in r.stderr and not r.stdout.strip()
