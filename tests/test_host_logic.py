@@ -739,3 +739,27 @@ def test_bench_refuses_a_world_size_that_is_not_gpus():
         r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0"],
                            capture_output=True, text=True, env=env, timeout=120)
         assert r.returncode == 2 and "needs 8 visible GPUs" in r.stderr and not r.stdout.strip()
+
+
+def test_lazy_meta_copies_never_lose_the_lazy_keys():
+    """rendering.LazyMeta: every way of handing the dictionary's content on (copy, copy.copy, deepcopy, pickling,
+    dict(meta), {**meta}, update) first builds the lazy list entries — a copy can never lack a key ``in`` reported."""
+    import copy
+    import pickle
+    from fusionsense_amd.rendering import LazyMeta
+    built = []
+
+    def mk():
+        def build():
+            built.append(1)
+            return {"isect_ids": [1], "flatten_ids": [2], "isect_offsets": [3], "legacy_rule_diff": 0}
+        return LazyMeta({"radii": 7}, build)
+
+    m = mk()
+    assert "isect_offsets" in m and not built and m["radii"] == 7 and not built  # eager reads build nothing
+    for clone in (lambda x: x.copy(), copy.copy, copy.deepcopy, lambda x: pickle.loads(pickle.dumps(x)), dict,
+                  lambda x: {**x}, lambda x: (lambda d: (d.update(x), d)[1])({})):
+        m = mk()
+        c = clone(m)
+        assert type(c) is dict and set(c) == {"radii", "isect_ids", "flatten_ids", "isect_offsets", "legacy_rule_diff"}
+    assert len(built) == 7
