@@ -429,9 +429,12 @@ def test_feature_adam_riding_in_the_count_pass_is_the_same_training(dev):
                 ra, rb = a.forward(cams[0]), b.forward(cams[0])
             assert a._pending is None
             assert float((ra["rgb"] - rb["rgb"]).abs().max()) < 2e-3
-    pending = a.params["features_rest"].data.clone()
+    pending = a._params["features_rest"].data.clone()  # (white box: the public accessor lands a pending update)
+    assert a._pending is not None
+    landed = a.params["features_rest"].data
+    assert a._pending is None and not torch.equal(landed, pending), "reading trainer.params lands the pending update"
     a.flush()
-    assert not torch.equal(a.params["features_rest"].data, pending), "the last update was still pending"
+    assert torch.equal(a.params["features_rest"].data, landed)
     for k in PARAM_ORDER:
         # Adam (eps = 1e-15) steps by +-lr whatever the size of a gradient, so the few entries whose gradient is
         # atomics noise around zero may differ by a learning rate between ANY two runs: compare robustly
@@ -465,9 +468,12 @@ def test_deferred_feature_update_is_the_same_training(dev, factored):
         # (the backward's float atomics make two runs differ in the last bits; a feature update that came one step
         # late would show at the size of a learning rate, 1e-3)
         assert abs(float(la) - float(lb)) <= 1e-5 * abs(float(lb)), it
-    pending = a.params["features_rest"].data.clone()
+    pending = a._params["features_rest"].data.clone()  # (white box: the public accessor lands a pending update)
+    assert a._pending is not None
+    landed = a.params["features_rest"].data
+    assert a._pending is None and not torch.equal(landed, pending), "reading trainer.params lands the pending update"
     a.flush()
-    assert not torch.equal(a.params["features_rest"].data, pending), "the last update was still pending"
+    assert torch.equal(a.params["features_rest"].data, landed)
     for k in PARAM_ORDER:
         # Adam (eps = 1e-15) steps by +-lr whatever the size of a gradient, so the few entries whose gradient is
         # atomics noise around zero may differ by a learning rate between ANY two runs: compare robustly

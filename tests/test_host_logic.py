@@ -330,9 +330,9 @@ for it in range(4):
     a._reduce_and_step(True)
     assert a._pending is not None
     for k in FEATURE_GROUPS:
-        assert torch.equal(a.params[k].data, feat_before[k]), "features must wait for the flush"
+        assert torch.equal(a._params[k].data, feat_before[k]), "features must wait for the flush"
     for k in GEOMETRY_GROUPS:
-        assert not torch.equal(a.params[k].data, geom_before[k]), "geometry is stepped at once"
+        assert not torch.equal(a._params[k].data, geom_before[k]), "geometry is stepped at once"
     a.flush(); a.flush()
     assert a._pending is None
     b._reduce_and_step(True)
