@@ -180,7 +180,7 @@ def pmc_record(kernel_key, config):
     try:
         with open(path) as f:
             d = json.load(f)
-        return d.get(f"config{config}", d if config == 2 else {}).get(kernel_key, {}) or {}
+        return d.get(f"config{config}", {}).get(kernel_key, {}) or {}
     except (OSError, ValueError):
         return {}
 
@@ -616,26 +616,57 @@ def main():
             "tile_sort": ("partition by tile + per-tile LDS sort", M * sort_b),
             "adam_step": ("adam_kernel (six parameter groups, one launch)", N * 59 * 28),
         }
-        cand = [(v["avg_ms"], k) for k, v in kernel_ms.items() if k in alg]  # (each is launched once per step)
-        roofline = None
-        if cand:
-            _, dom = max(cand)
-            dom_ms = kernel_ms[dom]["avg_ms"]
-            name, dom_bytes = alg[dom]
-            ach = dom_bytes / (dom_ms * 1e-3) / 1e9
-            rec = pmc_record(dom, args.config)
-            roofline = {"kernel": name, "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
-                        # rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE (bytes per launch, gfx950-corrected) of this kernel
-                        # from this round's committed run in profiles/ (DESIGN.md §5), null if absent
-                        "traffic": rec.get("hbm_bytes_per_launch"), "traffic_source": rec.get("source"),
-                        "algorithmic_bytes": dom_bytes, "avg_launch_ms": round(dom_ms, 4)}
-            # the compositing kernels are bound by fp32 VALU issue, not by HBM (the contract's `bound` has no
-            # such value): say how busy the vector ALUs are, from the committed SQ counters and THIS run's time
+        riding = bool(getattr(trainer, "_ride_mode", lambda: False)())
+        alg.update({
+            "isect_count_live": ("projecting count pass + table scan with the SH colours / record packing riding"
+                                 + (" + the features' Adam step riding" if riding else ""),
+                                 N * (68 + 20 + 16) + n_vis * (216 + 64) + (N * 48 * 28 if riding else 0)),
+            "gaussian_bwd": ("gauss_sh_bwd_kernel (SH VJP + projection / normal / activation VJPs + after_train statistics)",
+                             N * (120 + 52 + 36 + 76) + n_vis * 228),
+            "ssim_l1_fwd": ("ssim_l1_fwd_kernel", P * 3 * 24),
+            "ssim_l1_bwd": ("ssim_l1_bwd_kernel (+ loss combine)", P * 3 * 36),
+        })
+
+        def roofline_of(key):
+            """Roofline block of one libfsgs span: algorithmic bytes (SURVEY.md §8d per-unit figures x this frame's
+            units) over the span's average duration from HIP events of THIS run; HBM traffic and vector-ALU counters
+            from this round's committed rocprofv3 --pmc passes of the same command (profiles/pmc_traffic.json).  The
+            limiter is DERIVED from those: vector ALUs >= 65 % busy -> VALU issue; algorithmic or counted traffic
+            >= 60 % of the HBM peak -> HBM; neither -> latency / memory-side atomics (DESIGN.md §9 cites the ablation)."""
+            name, nbytes = alg[key]
+            ms = kernel_ms[key]["avg_ms"]
+            ach = nbytes / (ms * 1e-3) / 1e9
+            rec = pmc_record(key, args.config)
+            r = {"kernel": name, "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                 "frac": round(ach / HBM_PEAK_GBS, 5),
+                 # rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE (bytes per launch, gfx950-corrected) of this kernel
+                 # from this round's committed run in profiles/ (DESIGN.md §5), null if absent
+                 "traffic": rec.get("hbm_bytes_per_launch"), "traffic_source": rec.get("source"),
+                 "algorithmic_bytes": nbytes, "avg_launch_ms": round(ms, 4)}
+            traffic_frac = (rec["hbm_bytes_per_launch"] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+                            if rec.get("hbm_bytes_per_launch") else None)
+            if traffic_frac is not None:
+                r["traffic_frac_of_peak"] = round(traffic_frac, 4)
+                r["write_bytes_per_launch"] = rec.get("write_bytes_per_launch")
             q = rec.get("sq_active_inst_valu_quadcycles_per_launch")
-            if q:
-                roofline["valu_busy_frac"] = round(4.0 * q / (1024 * dom_ms * 1e-3 * 2.4e9), 4)
-                roofline["limiter"] = "fp32 VALU issue (see DESIGN.md 5)"
+            valu = None
+            if q:  # a wave64 fp32 instruction holds its SIMD for 4 cycles; 1024 SIMDs at 2.4 GHz
+                valu = 4.0 * q / (1024 * ms * 1e-3 * 2.4e9)
+                r["valu_busy_frac"] = round(valu, 4)
+                r["valu_insts_per_launch"] = rec.get("sq_insts_valu_per_launch")
+            if valu is None and traffic_frac is None:
+                r["limiter"] = None  # no counters committed for this span and configuration
+            elif valu is not None and valu >= 0.65:
+                r["limiter"] = "vector-ALU issue (valu_busy_frac >= 0.65)"
+            elif max(ach / HBM_PEAK_GBS, traffic_frac or 0.0) >= 0.6:
+                r["limiter"] = "HBM bandwidth (>= 0.6 of the peak)"
+            else:
+                r["limiter"] = "latency / memory-side atomics (vector ALUs < 0.65 busy, HBM < 0.6 of the peak)"
+            return r
+
+        cand = sorted(((v["avg_ms"], k) for k, v in kernel_ms.items() if k in alg), reverse=True)  # (one launch per step each)
+        roofline = roofline_of(cand[0][1]) if cand else None
+        roofline_top3 = [roofline_of(k) for _, k in cand[:3]]
         line = {
             "metric": "train_iters_per_s",
             "value": round(iters_per_s, 3),
@@ -678,6 +709,7 @@ def main():
             "gpu_step_ms": gpu_step_stats(step_events, step_views) if with_events else None,
             "kernels_ms": kernel_ms,
             "roofline": roofline,
+            "roofline_top3": roofline_top3,
         }
         if args.config == 3:
             line["config"]["refinement"] = dict(strategy.last_report)
