@@ -756,3 +756,37 @@ def test_patched_get_outputs_matches_reference_execution(dev, case):
         g = m.gauss_params[k].grad
         g = g.cpu() if g is not None else torch.zeros_like(t(f"go.in.{k}"))
         assert rel_err(g, t(f"go.{case}.grad.{k}")) < 3e-3, (k, rel_err(g, t(f"go.{case}.grad.{k}")))
+
+
+@pytest.mark.parametrize("case", ["plain", "binary_anchor"])
+def test_shim_only_route_matches_reference_execution(dev, case):
+    """The FIRST integration step (gsplat_shim: the reference's own get_outputs body, op by op, over
+    rasterization() + rasterize_gaussians() on libfsgs — fusion.render_fusionsense mirrors that body) against the
+    same reference-execution goldens as the patched route: images, binary write, gradients with detached anchors."""
+    from fusionsense_amd import integration
+    from fusionsense_amd.fusion import render_fusionsense
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_model.npz"))
+    t = lambda k: torch.from_numpy(d[k])  # noqa: E731
+    names = ["means", "scales", "quats", "features_dc", "features_rest", "opacities"]
+    fx, fy, cx, cy, W, H = [float(v) for v in d["go.intr"]]
+    step = int(d[f"go.{case}.step"])
+    cfg = __import__("types").SimpleNamespace(use_binary_opacities=True, binary_opacities_threshold=0.9, warmup_length=500,
+                                              reset_alpha_every=30, refine_every=100)
+    gp = {k: torch.nn.Parameter(t(f"go.in.{k}").to(dev)) for k in names}
+    add_mask = t(f"go.{case}.add_mask").to(dev) if f"go.{case}.add_mask" in d.files else None
+    cam = scenes.Camera(t("go.c2w").float(), fx, fy, cx, cy, int(W), int(H))
+    out = render_fusionsense(gp, cam, sh_degree=min(step // 1000, 3), device=dev, add_mask=add_mask,
+                             binary_threshold=integration._binary_threshold(cfg, step))
+    loss = sum((out[k] * t(f"go.w.{k}").to(dev)).mean() for k in ("rgb", "depth", "normal"))
+    loss.backward()
+    for k in ("rgb", "depth", "accumulation"):
+        assert rel_err(out[k], t(f"go.{case}.out.{k}")) < 2e-4, k
+    dn = (out["normal"].detach().cpu() - t(f"go.{case}.out.normal")).abs()
+    assert float(dn.mean()) < 1e-4 and float((dn > 1e-2).float().mean()) < 2e-3
+    assert torch.equal(gp["opacities"].detach().cpu(), t(f"go.{case}.opacities_after"))
+    assert torch.allclose(out["normals_world"].detach().cpu(), t(f"go.{case}.normals_world"), atol=1e-5)
+    assert out["xys"].absgrad.shape == (1, 260, 2) and out["radii"].shape == (260,)
+    for k in names:
+        g = gp[k].grad
+        g = g.cpu() if g is not None else torch.zeros_like(t(f"go.in.{k}"))
+        assert rel_err(g, t(f"go.{case}.grad.{k}")) < 3e-3, (k, rel_err(g, t(f"go.{case}.grad.{k}")))

@@ -288,6 +288,44 @@ def test_two_cameras_through_quadrant_kernels(dev):
         assert rel_err(ga[k], gb[k]) < 2e-3, k
 
 
+def test_config2_against_oracle_at_its_own_size(dev, full_scene):
+    """BASELINE config #2 compared with the oracle AT ITS OWN SIZE: all 300 k Gaussians, view 0 of the 800x800
+    hemisphere rig, the central 280x280 window (a camera with the same intrinsics and shifted principal point — the
+    sample bench.py's cpu_baseline times; the oracle needs ~6 s for it).  Forward images, the integer outputs
+    (radii, tiles_per_gauss) and every parameter gradient of a seeded weighted loss, through the fused node."""
+    from fusionsense_amd.fused import render_fusionsense_fused
+    from fusionsense_amd.scenes import Camera
+    from oracle.fusion_ref import render_fusionsense as render_ref
+    params, cams = full_scene
+    cam0, crop = cams[0], 280
+    x0, y0 = (cam0.width - crop) // 2, (cam0.height - crop) // 2
+    cam = Camera(cam0.c2w, cam0.fx, cam0.fy, cam0.cx - x0, cam0.cy - y0, crop, crop)
+    g = torch.Generator().manual_seed(11)
+    w = {"rgb": torch.rand(crop, crop, 3, generator=g), "depth": torch.rand(crop, crop, 1, generator=g),
+         "normal": torch.rand(crop, crop, 3, generator=g), "accumulation": torch.rand(crop, crop, 1, generator=g)}
+
+    def loss_of(out, to):
+        return sum((out[k] * to(w[k])).mean() for k in w)
+
+    pg = {k: v.detach().clone().requires_grad_(True) for k, v in params.items()}
+    og = render_fusionsense_fused(pg, cam, sh_degree=3, device=dev)
+    loss_of(og, lambda t: t.to(dev)).backward()
+    pr = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in params.items()}
+    orf = render_ref(pr, cam, sh_degree=3)
+    loss_of(orf, lambda t: t).backward()
+    # integer outputs: gsplat's rectangle count exactly; radii wherever the projection is not on an fp32 rounding edge
+    assert float((og["info"]["tiles_per_gauss"].cpu()[0] != orf["info"]["tiles_per_gauss"][0]).float().mean()) < 1e-4
+    assert float((og["radii"].cpu() != orf["radii"]).float().mean()) < 1e-4
+    for k, tol in (("rgb", 1e-4), ("accumulation", 1e-4), ("depth", 1e-3)):
+        err = (og[k].detach().cpu() - orf[k].detach()).abs().max().item()
+        assert err < tol * max(1.0, float(orf[k].detach().abs().max())), (k, err)
+    dn = (og["normal"].detach().cpu() - orf["normal"].detach()).abs()
+    assert dn.mean().item() < 1e-5 and (dn > 1e-2).float().mean().item() < 1e-3
+    for k in pg:
+        e = rel_err(pg[k].grad, pr[k].grad)
+        assert e < 3e-3, (k, e)  # DESIGN.md §3: 3e-3 of the tensor's own largest gradient
+
+
 @pytest.mark.parametrize("route", ["fused", "dropin"])
 def test_get_outputs_touch_anchors_binary_write_and_crop(dev, route):
     """The first three steps of get_outputs (dn_model.py:492-541) on both HIP routes against the oracle:
@@ -316,7 +354,7 @@ def test_get_outputs_touch_anchors_binary_write_and_crop(dev, route):
     for k in ("means", "opacities", "scales"):
         assert float(pg[k].grad[add_mask.to(dev)].abs().max()) == 0.0, k
     for k in pg:
-        assert rel_err(pg[k].grad, pr[k].grad) < 1e-2, (k, rel_err(pg[k].grad, pr[k].grad))
+        assert rel_err(pg[k].grad, pr[k].grad) < 3e-3, (k, rel_err(pg[k].grad, pr[k].grad))
     assert float(pg["quats"].grad[add_mask.to(dev)].abs().max()) > 0.0
     # -- eval mode: crop
     box = OrientedBox(torch.eye(3), torch.zeros(3), torch.tensor([0.5, 2.0, 2.0]))

@@ -541,7 +541,7 @@ def test_fused_get_outputs_matches_unfused_and_oracle(dev):
     assert dn.mean().item() < 1e-5 and (dn > 1e-2).float().mean().item() < 1e-3
     for k in pf:
         assert rel_err(pf[k].grad, pu[k].grad) < 2e-3, f"fused vs unfused grad {k}: {rel_err(pf[k].grad, pu[k].grad)}"
-        assert rel_err(pf[k].grad, pr[k].grad) < 1e-2, f"fused vs oracle grad {k}"
+        assert rel_err(pf[k].grad, pr[k].grad) < 3e-3, f"fused vs oracle grad {k}: {rel_err(pf[k].grad, pr[k].grad)}"
     assert rel_err(of["info"].absgrad, ou["xys"].absgrad) < 2e-3
     assert torch.equal(of["radii"], ou["radii"])
     # the fused node bins only LIVE (Gaussian, tile) pairs; gsplat's rectangle count is still reported
@@ -994,6 +994,33 @@ def test_finite_differences_of_the_hip_path(dev):
                 fd = (float(functional_k(plus)[0].double()) - float(functional_k(minus)[0].double())) / (2 * eps)
             an = float((pp[k].grad.cpu().double() * d.double()).sum())
             assert abs(fd - an) <= 2e-2 * abs(an) + 3e-5, (k, trial, fd, an)
+
+    # the NORMAL PLANE alone (the E = 3 channels of the compositing walk: its gradient reaches conics and opacities —
+    # i.e. scales, quaternions, opacity logits — and its own colours, the per-Gaussian normals, never the centres):
+    for k in ("scales", "quats", "opacities"):
+        val, pp = functional(params, ("normal",), True)
+        val.backward()
+        for trial in range(3):
+            d = torch.randn(params[k].shape, generator=g)
+            d = d / d.norm()
+            with torch.no_grad():
+                fd = (float(functional({**params, k: params[k] + eps * d}, ("normal",))[0].double()) -
+                      float(functional({**params, k: params[k] - eps * d}, ("normal",))[0].double())) / (2 * eps)
+            an = float((pp[k].grad.cpu().double() * d.double()).sum())
+            assert abs(fd - an) <= 2e-2 * abs(an) + 3e-5, ("normal plane", k, trial, fd, an)
+    # ... and the SH coefficients band by band (degree 1: rows 0..2 of features_rest, degree 2: 3..7, degree 3: 8..14),
+    # so that a wrong basis constant in one band cannot hide behind the others
+    val, pp = functional(params, ("rgb",), True)
+    val.backward()
+    for lo, hi in ((0, 3), (3, 8), (8, 15)):
+        d = torch.zeros(params["features_rest"].shape)
+        d[:, lo:hi] = torch.randn(n, hi - lo, 3, generator=g)
+        d = d / d.norm()
+        with torch.no_grad():
+            fd = (float(functional({**params, "features_rest": params["features_rest"] + eps * d}, ("rgb",))[0].double()) -
+                  float(functional({**params, "features_rest": params["features_rest"] - eps * d}, ("rgb",))[0].double())) / (2 * eps)
+        an = float((pp["features_rest"].grad.cpu().double() * d.double()).sum())
+        assert abs(an) > 1e-6 and abs(fd - an) <= 2e-2 * abs(an) + 3e-5, ("SH band", lo, hi, fd, an)
 
 
 def test_sh_colours_with_differentiable_camera_pose(dev):
