@@ -13,7 +13,8 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfsgs.so")
+# (FSGS_LIB: A/B runs against another build of the same C-ABI, e.g. `make OUT=../libfsgs_x.so BUILD=build_x EXTRA=-D...`)
+LIB_PATH = os.environ.get("FSGS_LIB") or os.path.join(_HERE, "libfsgs.so")
 
 _i, _i64, _f, _p, _sz = C.c_int, C.c_int64, C.c_float, C.c_void_p, C.c_size_t
 
@@ -29,6 +30,7 @@ class AdamGroups(C.Structure):
 
 SIGNATURES = {
     "fsgs_version": (_i, []),
+    "fsgs_grad_replica_lines": (_i, []),
     "fsgs_error_string": (C.c_char_p, [_i]),
     "fsgs_last_hip_error": (_i, []),
     "fsgs_project_fwd": (_i, [_i, _i, _p, _p, _p, _p, _p, _i, _i, _f, _f, _f, _f, _p, _p, _p, _p, _p, _p]),

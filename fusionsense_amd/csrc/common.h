@@ -148,6 +148,18 @@ __device__ __forceinline__ void row_transpose_sum16(float (&v)[16]) {
         : "s"(m2), "s"(m1));
 }
 
+// lane l + lane l^16 + lane l^32 + lane l^48 in every lane: gfx950's half / row exchanges (v_permlane32_swap swaps
+// lanes 32..63 of its first operand with lanes 0..31 of its second, v_permlane16_swap the odd rows of the first
+// with the even rows of the second), 2 x (copy, swap, add); hipcc's hazard recognizer places the wait states.
+__device__ __forceinline__ float rows_sum4(float v) {
+    const unsigned x = __builtin_bit_cast(unsigned, v);
+    const auto h = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+    const float s = __builtin_bit_cast(float, (unsigned)h[0]) + __builtin_bit_cast(float, (unsigned)h[1]);
+    const unsigned y = __builtin_bit_cast(unsigned, s);
+    const auto r = __builtin_amdgcn_permlane16_swap(y, y, false, false);
+    return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+}
+
 // one Adam update (torch.optim.Adam, amsgrad = False, weight_decay = 0): ss = lr / (1 - b1^t), isb2 = 1 / sqrt(1 - b2^t)
 __device__ __forceinline__ void adam_one(float &p, float g, float &m, float &v, float b1, float b2, float omb1,
                                          float omb2, float ss, float isb2, float eps) {
@@ -177,6 +189,20 @@ constexpr int kGradReplicas = 4;
 constexpr int kSpreadMinRadius = 24;
 __device__ __forceinline__ bool grad_spread(float ca, float cb, float cc) {
     return __builtin_fmaf(-cb, cb, ca * cc) < (1.f / 4096.f);  // (one fixed rounding sequence in every kernel)
+}
+// Second tier (round 3): one line takes ~12 ns per atomic transaction (MI355X_MICROARCH.md: device-scope fan-in), so a
+// Gaussian that covers a large part of the image — tens of thousands of (block, record) totals — bounds the whole
+// kernel even with four lines (BASELINE config #3: a 1280x720 background splat = 57 600 blocks -> 0.17 ms on four
+// lines).  Footprints above sigma_1 sigma_2 = 256 px^2 (det(cov) > 65536 px^4; radius >= 49) own kGradLinesHuge
+// lines.  Same agreement rule as above: writer and last reader evaluate `grad_lines` on the same fp32 conic.
+#ifndef FSGS_HUGE_LINES
+#define FSGS_HUGE_LINES 16
+#endif
+constexpr int kGradLinesHuge = FSGS_HUGE_LINES;  // (= kGradReplicas switches the tier off)
+constexpr int kHugeMinRadius = 48;
+__device__ __forceinline__ int grad_lines(float ca, float cb, float cc) {
+    const float det = __builtin_fmaf(-cb, cb, ca * cc);
+    return det < (1.f / 65536.f) ? kGradLinesHuge : (det < (1.f / 4096.f) ? kGradReplicas : 1);
 }
 
 // ---- the SH forward riding in the binning's scan launch (sh.hip: scan_rows_sh_pack_kernel) ---------------------

@@ -12,6 +12,8 @@
 // (common.h: 33 DPP adds instead of 60), the four rows meet through two lane permutes, and lanes
 // 0..14 issue ONE global_atomic_add_f32 into a packed 64-byte per-Gaussian record (one cache line),
 // instead of 15 single-lane atomics to six different arrays.
+#include <type_traits>
+
 #include "common.h"
 #include "cull.h"
 
@@ -75,7 +77,7 @@ raster_bwd_live_kernel(int64_t cap, const float4 *__restrict__ rec,
                        const float *__restrict__ v_alphas, const float *__restrict__ seg_state,
                        int64_t seg_cap, float *__restrict__ v_packed, int normalize_last,
                        const float *__restrict__ render_extra, const float *__restrict__ v_render_extra,
-                       const int32_t *__restrict__ n_rec, GetOutputsGrads ep, int64_t replica_rows) {
+                       const int32_t *__restrict__ n_rec, GetOutputsGrads ep, int64_t replica_rows, int merge_thr16) {
     __shared__ QLds<E> Lw[kBwdWaves];
     constexpr int RS = E ? 4 : 3;
     constexpr int SS = 64 * (1 + D + E);
@@ -185,8 +187,7 @@ raster_bwd_live_kernel(int64_t cap, const float4 *__restrict__ rec,
     const float quad_x0 = (float)(blockIdx.x * 8), quad_y0 = (float)(blockIdx.y * 8);
     // this workgroup's replica of a large Gaussian's gradient line (common.h: grad_spread); 0 rows = no replicas
     // (neighbouring tiles and the four 8x8 quadrants of a tile — one workgroup each — take different replicas)
-    const int64_t rep_off = replica_rows * 16 * (int64_t)((((unsigned)tile_lin * 2654435761u >> 16) + (blockIdx.x & 1) +
-                                                           2 * (blockIdx.y & 1)) % kGradReplicas);
+    const unsigned rep_hash = ((unsigned)tile_lin * 2654435761u >> 16) + (blockIdx.x & 1) + 2 * (blockIdx.y & 1);
 
     for (int seg = n_seg - 1 - w; seg >= 0; seg -= kBwdWaves) {
         const int b0 = s + (seg << 6);          // first stream position of the segment
@@ -205,14 +206,33 @@ raster_bwd_live_kernel(int64_t cap, const float4 *__restrict__ rec,
         }
         const int isect_l = __float_as_int(r.r1.z);
         int my_n = 0, steps = 0;
+        uint64_t mrow[4];
+        unsigned rm = 0u;
 #pragma unroll
         for (int r4 = 0; r4 < 4; ++r4) {
             const bool lv = ((bm >> r4) & 1u) && (isect_l <= row_bin_final[r4]);
-            const uint64_t m = __ballot(lv);
-            if (lv) L.list[r4][__popcll(m & ((1ull << lane) - 1ull))] = (uint8_t)lane;
-            const int c = __popcll(m);
+            mrow[r4] = __ballot(lv);
+            rm |= lv ? (1u << r4) : 0u;
+            const int c = __popcll(mrow[r4]);
             my_n = (row == r4) ? c : my_n;
             steps = max(steps, c);
+        }
+        // A segment whose longest row list is (nearly) as long as the UNION of the four (records of large footprint
+        // reach every block) gains nothing from separate lists: all four rows then walk the union in lockstep, the
+        // rows' totals of a record meet through two lane-permute adds, and ONE 64-byte atomic per (quadrant, record)
+        // leaves instead of up to four — on the hot gradient lines of large Gaussians, which the memory side
+        // serialises, a quarter of the transactions.  Wave-uniform choice per segment.
+        const uint64_t many = mrow[0] | mrow[1] | mrow[2] | mrow[3];
+        const int n_union = __popcll(many);
+        const bool merge = n_union > 0 && steps * 16 >= n_union * merge_thr16;
+        const uint64_t below = (1ull << lane) - 1ull;
+        if (merge) {
+            if (rm) L.list[0][__popcll(many & below)] = (uint8_t)lane;
+            my_n = steps = n_union;
+        } else {
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4)
+                if ((rm >> r4) & 1u) L.list[r4][__popcll(mrow[r4] & below)] = (uint8_t)lane;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -229,9 +249,11 @@ raster_bwd_live_kernel(int64_t cap, const float4 *__restrict__ rec,
 #pragma unroll
             for (int k = 0; k < E; ++k) Be += (ce_total[k] - slot[64 * (1 + D + k) + p]) * v_oute[k];
         }
+        auto walk = [&](auto merge_tag) {
+        constexpr bool MERGE = decltype(merge_tag)::value;
         for (int kk = 0; kk < steps; ++kk) {
             const bool have = kk < my_n;
-            const int t = have ? (int)L.list[row][kk] : 0;
+            const int t = have ? (int)L.list[MERGE ? 0 : row][kk] : 0;
             const float4 a0 = L.r0[t], a1 = L.r1[t];
             const int isect = __float_as_int(a1.z);
             bool valid = have && inside && (isect <= bin_final);
@@ -299,17 +321,21 @@ raster_bwd_live_kernel(int64_t cap, const float4 *__restrict__ rec,
             for (int k = 0; k < 3; ++k) vals[12 + k] = (k < E) ? ge[k] : 0.f;
             vals[15] = 0.f;
             row_transpose_sum16(vals);
-            const float tot = vals[0];
-            if (pl < 12 + E && tot != 0.f) {
+            float tot = vals[0];
+            if (MERGE) tot = rows_sum4(tot);  // the same record in all four rows: their totals meet here
+            if ((!MERGE || row == 0) && pl < 12 + E && tot != 0.f) {
                 const bool used = (pl < D) || (pl >= 4 && pl <= 8) || (ABS && (pl == 9 || pl == 10)) ||
                                   (pl == 11) || (pl >= 12);
                 if (used) {
                     const int64_t gid = __float_as_int(a1.w) & 0x0FFFFFFF;
-                    const int64_t off = grad_spread(a0.w, a1.x, a1.y) ? rep_off : 0;
+                    // (line count 1 / 4 / 16 by footprint, all powers of two; replica_rows = 0: no replicas)
+                    const int64_t off = replica_rows * 16 * (int64_t)(rep_hash & (unsigned)(grad_lines(a0.w, a1.x, a1.y) - 1));
                     unsafeAtomicAdd(&v_packed[off + gid * 16 + pl], tot);
                 }
             }
         }
+        };
+        if (merge) walk(std::true_type{}); else walk(std::false_type{});
         __builtin_amdgcn_wave_barrier();  // LDS reads of this segment precede the next segment's writes
     }
 }
@@ -359,6 +385,9 @@ static int launch_bwd_live(int C, int D, const float *records, const int32_t *n_
                            const float *render_extra, const float *v_render_extra, float *v_packed,
                            fsgs_stream_t stream, GetOutputsGrads ep = GetOutputsGrads{nullptr, nullptr, nullptr, nullptr, nullptr},
                            int64_t replica_rows = 0) {
+    // FSGS_BWD_MERGE_THR16 (A/B switch): a segment walks the union list with merged atomics when its longest row list
+    // is >= thr/16 of the union; 0 = always, 17 = never
+    static const int merge_thr16 = [] { const char *e = getenv("FSGS_BWD_MERGE_THR16"); return e ? atoi(e) : 14; }();
     if (C < 0 || width < 0 || height < 0 || n_isects < 0) return FSGS_EINVAL;
     if (C == 0 || width == 0 || height == 0 || n_isects == 0) return FSGS_OK;
     if (!records || !n_rec || !isect_offsets || !render || !alphas || !last_ids || !seg_state || !v_packed)
@@ -375,7 +404,7 @@ static int launch_bwd_live(int C, int D, const float *records, const int32_t *n_
     hipLaunchKernelGGL((raster_bwd_live_kernel<DD, AA, EE>), grid, dim3(64 * kBwdWaves), 0, s, cap, rec,          \
                        isect_offsets, n_isects, backgrounds, width, height, tile_width, tile_height, render,      \
                        alphas, last_ids, v_render, v_alphas, seg_state, seg_cap, v_packed, normalize_last,         \
-                       render_extra, v_render_extra, n_rec, ep, replica_rows)
+                       render_extra, v_render_extra, n_rec, ep, replica_rows, merge_thr16)
     if (render_extra) {
         if (D != 4 || (!v_render_extra && !ep.v_rgb)) return FSGS_EINVAL;
         if (with_abs) FSGS_BWD_LIVE(4, true, 3); else FSGS_BWD_LIVE(4, false, 3);

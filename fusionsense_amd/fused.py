@@ -105,7 +105,7 @@ _ONES3: Dict[str, Tensor] = {}
 SH_RIDES_WITH_SCAN = os.environ.get("FSGS_SH_RIDES_WITH_SCAN", "1") != "0"
 # SH backward + per-Gaussian backward in one launch (fsgs_gauss_sh_bwd) where it applies; 0 = the two launches
 ONE_LAUNCH_GAUSSIAN_BWD = os.environ.get("FSGS_ONE_LAUNCH_GAUSSIAN_BWD", "1") != "0"
-GRAD_REPLICAS = 4 if os.environ.get("FSGS_GRAD_REPLICAS", "1") != "0" else 1  # (= kGradReplicas of csrc/common.h)
+GRAD_REPLICAS = 0 if os.environ.get("FSGS_GRAD_REPLICAS", "1") != "0" else 1  # 0: ask the library (fsgs_grad_replica_lines)
 # Scenes above this size keep one line per Gaussian: the two readers pay for three more lines per spread Gaussian,
 # and at 6-10 M Gaussians (configs #4 / #5, where ~18 % of the visible ones pass the footprint threshold) that costs
 # more than the compositing backward gains (measured: +0.11 / +0.17 ms per step with replicas).
@@ -113,6 +113,10 @@ GRAD_REPLICAS_MAX_N = int(os.environ.get("FSGS_GRAD_REPLICAS_MAX_N", str(1 << 20
 
 
 def _grad_lines(N: int) -> int:
+    global GRAD_REPLICAS
+    if GRAD_REPLICAS == 0:
+        from ._lib import load
+        GRAD_REPLICAS = int(load().fsgs_grad_replica_lines())  # (4 lines by footprint tier 1, all of them by tier 2)
     return GRAD_REPLICAS if N <= GRAD_REPLICAS_MAX_N else 1
 
 

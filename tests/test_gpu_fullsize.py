@@ -194,7 +194,7 @@ def test_full_size_tape_free_step_equals_dropin_caller_step(dev, full_scene):
 
 
 def test_gradient_line_replicas_do_not_change_the_step(dev, full_scene, monkeypatch):
-    """Large Gaussians spread their backward atomics over 4 gradient lines (csrc/common.h grad_spread, fused.py
+    """Large Gaussians spread their backward atomics over 4 or 16 gradient lines (csrc/common.h grad_lines, fused.py
     GRAD_REPLICAS): same gradients as with one line (to summation order), and the accumulator — replicas included —
     is handed back all zero by its last reader."""
     from fusionsense_amd import fused
@@ -205,8 +205,11 @@ def test_gradient_line_replicas_do_not_change_the_step(dev, full_scene, monkeypa
     tgt = {"rgb": torch.rand(cams[0].height, cams[0].width, 3, device=dev),
            "depth": torch.rand(cams[0].height, cams[0].width, 1, device=dev) * 4,
            "normal": torch.nn.functional.normalize(torch.randn(cams[0].height, cams[0].width, 3, device=dev), dim=-1)}
+    from fusionsense_amd._lib import load
+    LN = load().fsgs_grad_replica_lines()
+    big["scales"][::97] += 2.5  # ... and a few the second tier (all LN lines)
     grads = {}
-    for reps in (4, 1):
+    for reps in (LN, 1):
         monkeypatch.setattr(fused, "GRAD_REPLICAS", reps)
         fused._ACCUM.clear()
         t = SplatTrainer(big, dev, sh_degree=3, fused=True, direct=True)
@@ -217,7 +220,7 @@ def test_gradient_line_replicas_do_not_change_the_step(dev, full_scene, monkeypa
     fused._ACCUM.clear()
     for k in PARAM_ORDER:
         # (float atomics in another order: the quaternion gradient, a difference of large terms, moves by ~1e-4)
-        assert rel_err(grads[4][k], grads[1][k]) < 5e-4, (k, rel_err(grads[4][k], grads[1][k]))
+        assert rel_err(grads[LN][k], grads[1][k]) < 5e-4, (k, rel_err(grads[LN][k], grads[1][k]))
 
 
 @pytest.mark.parametrize("case", ["empty", "all_behind_camera", "tiny_image", "odd_size", "single_gaussian"])
@@ -316,9 +319,13 @@ def test_config2_against_oracle_at_its_own_size(dev, full_scene):
     # integer outputs: gsplat's rectangle count exactly; radii wherever the projection is not on an fp32 rounding edge
     assert float((og["info"]["tiles_per_gauss"].cpu()[0] != orf["info"]["tiles_per_gauss"][0]).float().mean()) < 1e-4
     assert float((og["radii"].cpu() != orf["radii"]).float().mean()) < 1e-4
+    # images: 1e-4 of the tensor maximum everywhere except the pixels that sit on an fp32 threshold decision of the walk
+    # (alpha >= 1/255 skip, T <= 1e-4 stop: a list of several hundred entries per pixel at this density), where one
+    # Gaussian more or less moves a channel by at most alpha T c <= 1/255
     for k, tol in (("rgb", 1e-4), ("accumulation", 1e-4), ("depth", 1e-3)):
-        err = (og[k].detach().cpu() - orf[k].detach()).abs().max().item()
-        assert err < tol * max(1.0, float(orf[k].detach().abs().max())), (k, err)
+        d = (og[k].detach().cpu() - orf[k].detach()).abs() / max(1.0, float(orf[k].detach().abs().max()))
+        assert float((d > tol).float().mean()) < 1e-3, (k, float((d > tol).float().mean()))
+        assert float(d.max()) <= 1.0 / 255.0 + tol, (k, float(d.max()))
     dn = (og["normal"].detach().cpu() - orf["normal"].detach()).abs()
     assert dn.mean().item() < 1e-5 and (dn > 1e-2).float().mean().item() < 1e-3
     for k in pg:

@@ -934,11 +934,13 @@ def test_folded_entry_points_equal_the_chains_they_replace(dev):
     assert rel_err(acc_b, acc_a) < 1e-5
     # gradient-line replicas (common.h grad_spread): large Gaussians spread their atomics over 4 lines N rows apart,
     # small ones keep to line 0; the lines sum to the unspread result
-    acc_r = torch.zeros(4 * N, 16, **f32)
+    LN = lib.fsgs_grad_replica_lines()  # 4 lines by footprint tier 1, all LN (16) by tier 2
+    assert LN >= 4
+    acc_r = torch.zeros(LN * N, 16, **f32)
     assert lib.fsgs_raster_bwd_quad_images(ptr(records), ptr(n_rec), ptr(offsets), M, W, H, tw, th, ptr(render),
                                            ptr(alphas), ptr(last_ids), ptr(extra), ptr(bg), ptr(vr_a), ptr(vd_a),
                                            ptr(vn_a), ptr(v_alpha), ptr(seg_state), 1, ptr(acc_r), N, sp) == 0
-    lines = acc_r.view(4, N, 16)
+    lines = acc_r.view(LN, N, 16)
     assert rel_err(lines.sum(0), acc_a) < 1e-5
     used = lines[1:].abs().sum((0, 2)) > 0
     assert bool(used.any()) and not bool(used.all())
