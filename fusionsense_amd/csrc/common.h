@@ -148,16 +148,38 @@ __device__ __forceinline__ void row_transpose_sum16(float (&v)[16]) {
         : "s"(m2), "s"(m1));
 }
 
-// lane l + lane l^16 + lane l^32 + lane l^48 in every lane: gfx950's half / row exchanges (v_permlane32_swap swaps
-// lanes 32..63 of its first operand with lanes 0..31 of its second, v_permlane16_swap the odd rows of the first
-// with the even rows of the second), 2 x (copy, swap, add); hipcc's hazard recognizer places the wait states.
-__device__ __forceinline__ float rows_sum4(float v) {
-    const unsigned x = __builtin_bit_cast(unsigned, v);
-    const auto h = __builtin_amdgcn_permlane32_swap(x, x, false, false);
-    const float s = __builtin_bit_cast(float, (unsigned)h[0]) + __builtin_bit_cast(float, (unsigned)h[1]);
-    const unsigned y = __builtin_bit_cast(unsigned, s);
-    const auto r = __builtin_amdgcn_permlane16_swap(y, y, false, false);
-    return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+// Sixteen values summed over ALL 64 lanes, transposed: afterwards lane (row r, column c) holds the wave total of value
+// 4 r + (c >> 2) (every lane of a quad the same one).  For a wave whose four rows work on the SAME record: the halves
+// and the row pairs meet through gfx950's v_permlane32_swap / v_permlane16_swap (swap lanes 32..63 of the first operand
+// with lanes 0..31 of the second / the odd rows of the first with the even rows of the second; each exchange + add halves
+// the values a lane carries: 16 -> 8 -> 4), the 16 columns through bank-masked DPP adds as in row_transpose_sum16
+// (4 -> 2 -> 1) and two quad butterflies: 12 swaps + 12 adds + 4 + 2 + 2 = 32 instructions, against 36 + 6 for the row
+// transpose followed by a cross-row sum.  hipcc's hazard recognizer places the wait states around the swaps.
+__device__ __forceinline__ float wave_transpose_sum16(float (&v)[16]) {
+    auto u = [](float x) { return __builtin_bit_cast(unsigned, x); };
+    auto f = [](unsigned x) { return __builtin_bit_cast(float, x); };
+    float s[8], t[4];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const auto h = __builtin_amdgcn_permlane32_swap(u(v[k]), u(v[k + 8]), false, false);
+        s[k] = f(h[0]) + f(h[1]);  // lanes 0..31: value k over (l, l + 32); lanes 32..63: value k + 8
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const auto r = __builtin_amdgcn_permlane16_swap(u(s[k]), u(s[k + 4]), false, false);
+        t[k] = f(r[0]) + f(r[1]);  // row r: value 4 r + k over the four rows
+    }
+    asm volatile(
+        "s_nop 1\n\t"
+        FSGS_T1(0, 2) FSGS_T1(1, 3)
+        "s_nop 1\n\t"  // (a DPP read needs two wait states after the VALU write of its source)
+        FSGS_T2(0, 1)
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]));
+    return t[0];
 }
 
 // one Adam update (torch.optim.Adam, amsgrad = False, weight_decay = 0): ss = lr / (1 - b1^t), isb2 = 1 / sqrt(1 - b2^t)
@@ -190,21 +212,6 @@ constexpr int kSpreadMinRadius = 24;
 __device__ __forceinline__ bool grad_spread(float ca, float cb, float cc) {
     return __builtin_fmaf(-cb, cb, ca * cc) < (1.f / 4096.f);  // (one fixed rounding sequence in every kernel)
 }
-// Second tier (round 3): one line takes ~12 ns per atomic transaction (MI355X_MICROARCH.md: device-scope fan-in), so a
-// Gaussian that covers a large part of the image — tens of thousands of (block, record) totals — bounds the whole
-// kernel even with four lines (BASELINE config #3: a 1280x720 background splat = 57 600 blocks -> 0.17 ms on four
-// lines).  Footprints above sigma_1 sigma_2 = 256 px^2 (det(cov) > 65536 px^4; radius >= 49) own kGradLinesHuge
-// lines.  Same agreement rule as above: writer and last reader evaluate `grad_lines` on the same fp32 conic.
-#ifndef FSGS_HUGE_LINES
-#define FSGS_HUGE_LINES 16
-#endif
-constexpr int kGradLinesHuge = FSGS_HUGE_LINES;  // (= kGradReplicas switches the tier off)
-constexpr int kHugeMinRadius = 48;
-__device__ __forceinline__ int grad_lines(float ca, float cb, float cc) {
-    const float det = __builtin_fmaf(-cb, cb, ca * cc);
-    return det < (1.f / 65536.f) ? kGradLinesHuge : (det < (1.f / 4096.f) ? kGradReplicas : 1);
-}
-
 // ---- the SH forward riding in the binning's scan launch (sh.hip: scan_rows_sh_pack_kernel) ---------------------
 // What fsgs_sh_fwd_pack needs, handed to the projecting count pass so that it can launch the colours + packing
 // together with its table scan (16 stored coefficients, split features, one camera).

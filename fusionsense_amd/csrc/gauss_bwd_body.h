@@ -30,12 +30,13 @@ __device__ __forceinline__ void gauss_bwd_load_line(int n, const GaussBwdFused &
     pa = fz.v_packed[n * 4 + 0]; pb = fz.v_packed[n * 4 + 1]; pc = fz.v_packed[n * 4 + 2]; pd = fz.v_packed[n * 4 + 3];
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     fz.v_packed[n * 4 + 0] = zero4; fz.v_packed[n * 4 + 1] = zero4; fz.v_packed[n * 4 + 2] = zero4; fz.v_packed[n * 4 + 3] = zero4;
-    if (fz.replica_rows > 0 && radii[n] > 0) {
+    if (fz.replica_rows > 0 && radii[n] > 0 &&
+        grad_spread(conics[n * 3 + 0], conics[n * 3 + 1], conics[n * 3 + 2])) {
         // a large Gaussian: fold (and clear) the replicas the compositing backward spread its atomics over
         // (the colour float4 of each replica has been read by the SH backward before; this is the last reader)
-        const int lines = grad_lines(conics[n * 3 + 0], conics[n * 3 + 1], conics[n * 3 + 2]);
         auto add4 = [](float4 &a, const float4 b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; };
-        for (int r = 1; r < lines; ++r) {
+#pragma unroll
+        for (int r = 1; r < kGradReplicas; ++r) {
             float4 *line = fz.v_packed + ((int64_t)r * fz.replica_rows + n) * 4;
             add4(pa, line[0]); add4(pb, line[1]); add4(pc, line[2]); add4(pd, line[3]);
             line[0] = zero4; line[1] = zero4; line[2] = zero4; line[3] = zero4;

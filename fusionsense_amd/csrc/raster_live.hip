@@ -187,7 +187,8 @@ raster_bwd_live_kernel(int64_t cap, const float4 *__restrict__ rec,
     const float quad_x0 = (float)(blockIdx.x * 8), quad_y0 = (float)(blockIdx.y * 8);
     // this workgroup's replica of a large Gaussian's gradient line (common.h: grad_spread); 0 rows = no replicas
     // (neighbouring tiles and the four 8x8 quadrants of a tile — one workgroup each — take different replicas)
-    const unsigned rep_hash = ((unsigned)tile_lin * 2654435761u >> 16) + (blockIdx.x & 1) + 2 * (blockIdx.y & 1);
+    const int64_t rep_off = replica_rows * 16 * (int64_t)((((unsigned)tile_lin * 2654435761u >> 16) + (blockIdx.x & 1) +
+                                                           2 * (blockIdx.y & 1)) % kGradReplicas);
 
     for (int seg = n_seg - 1 - w; seg >= 0; seg -= kBwdWaves) {
         const int b0 = s + (seg << 6);          // first stream position of the segment
@@ -320,17 +321,28 @@ raster_bwd_live_kernel(int64_t cap, const float4 *__restrict__ rec,
 #pragma unroll
             for (int k = 0; k < 3; ++k) vals[12 + k] = (k < E) ? ge[k] : 0.f;
             vals[15] = 0.f;
-            row_transpose_sum16(vals);
-            float tot = vals[0];
-            if (MERGE) tot = rows_sum4(tot);  // the same record in all four rows: their totals meet here
-            if ((!MERGE || row == 0) && pl < 12 + E && tot != 0.f) {
-                const bool used = (pl < D) || (pl >= 4 && pl <= 8) || (ABS && (pl == 9 || pl == 10)) ||
-                                  (pl == 11) || (pl >= 12);
+            // not merged: lane l ends with its row's total of value l & 15;  merged: lane (row, column c) with the
+            // WAVE's total of value 4 row + (c >> 2) (common.h)
+            float tot;
+            int vi;
+            bool writer;
+            if (MERGE) {
+                tot = wave_transpose_sum16(vals);
+                vi = 4 * row + (pl >> 2);
+                writer = (pl & 3) == 0;
+            } else {
+                row_transpose_sum16(vals);
+                tot = vals[0];
+                vi = pl;
+                writer = true;
+            }
+            if (writer && vi < 12 + E && tot != 0.f) {
+                const bool used = (vi < D) || (vi >= 4 && vi <= 8) || (ABS && (vi == 9 || vi == 10)) ||
+                                  (vi == 11) || (vi >= 12);
                 if (used) {
                     const int64_t gid = __float_as_int(a1.w) & 0x0FFFFFFF;
-                    // (line count 1 / 4 / 16 by footprint, all powers of two; replica_rows = 0: no replicas)
-                    const int64_t off = replica_rows * 16 * (int64_t)(rep_hash & (unsigned)(grad_lines(a0.w, a1.x, a1.y) - 1));
-                    unsafeAtomicAdd(&v_packed[off + gid * 16 + pl], tot);
+                    const int64_t off = grad_spread(a0.w, a1.x, a1.y) ? rep_off : 0;
+                    unsafeAtomicAdd(&v_packed[off + gid * 16 + vi], tot);
                 }
             }
         }

@@ -464,9 +464,8 @@ sh_bwd_kernel(int C, int N, int K, int degree, const float *__restrict__ means,
         if (replica_rows > 0 && rad0 >= kSpreadMinRadius) {
             // a large Gaussian's gradient atomics may have been spread over kGradReplicas lines (common.h): sum their
             // colour parts (the replicas of a Gaussian that was not spread hold zeros)
-            // (radius supersets of the writer's footprint tiers: replicas never written hold zeros)
-            const int lines = rad0 >= kHugeMinRadius ? kGradLinesHuge : kGradReplicas;
-            for (int r = 1; r < lines; ++r) {
+#pragma unroll
+            for (int r = 1; r < kGradReplicas; ++r) {
                 const float *line = v_colors + ((int64_t)r * replica_rows + n) * D;
                 vc0 += line[0]; vc1 += line[1]; vc2 += line[2];
             }
@@ -853,9 +852,8 @@ sh_bwd_hybrid_kernel(int N, int degree, const float *__restrict__ means, const f
         float vc0 = v_colors[(int64_t)n * D + 0], vc1 = v_colors[(int64_t)n * D + 1], vc2 = v_colors[(int64_t)n * D + 2];
         if (D == 4 && v_depths) v_depths[n] = v_colors[(int64_t)n * 4 + 3];
         if (replica_rows > 0 && rad0 >= kSpreadMinRadius) {
-            // (radius supersets of the writer's footprint tiers: replicas never written hold zeros)
-            const int lines = rad0 >= kHugeMinRadius ? kGradLinesHuge : kGradReplicas;
-            for (int r = 1; r < lines; ++r) {
+#pragma unroll
+            for (int r = 1; r < kGradReplicas; ++r) {
                 const float *line = v_colors + ((int64_t)r * replica_rows + n) * D;
                 vc0 += line[0]; vc1 += line[1]; vc2 += line[2];
             }

@@ -38,8 +38,8 @@ typedef void *fsgs_stream_t; /* hipStream_t */
 int fsgs_version(void);
 /* Lines of the packed gradient accumulator a caller that passes `replica_rows` > 0 must provide per Gaussian row:
  * `v_packed` is [fsgs_grad_replica_lines() * replica_rows, 16] floats, zeroed once (the last reader keeps it zeroed).
- * Gaussians of large 2-D footprint spread their gradient atomics over 4 (det(cov2d) > 4096 px^4) or all of these
- * lines (det > 65536 px^4); `replica_rows` = 0 means one line per Gaussian and no spreading.  (No gsplat equivalent:
+ * Gaussians of large 2-D footprint (det(cov2d) > 4096 px^4) spread their gradient atomics over these lines, picked
+ * by tile and quadrant; `replica_rows` = 0 means one line per Gaussian and no spreading.  (No gsplat equivalent:
  * gsplat's rasterize_to_pixels_bwd adds into v_means2d / v_conics / v_colors / v_opacities directly.) */
 int fsgs_grad_replica_lines(void);
 const char *fsgs_error_string(int code);

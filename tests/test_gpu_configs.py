@@ -790,3 +790,57 @@ def test_shim_only_route_matches_reference_execution(dev, case):
         g = gp[k].grad
         g = g.cpu() if g is not None else torch.zeros_like(t(f"go.in.{k}"))
         assert rel_err(g, t(f"go.{case}.grad.{k}")) < 3e-3, (k, rel_err(g, t(f"go.{case}.grad.{k}")))
+
+
+def test_scene_directory_to_training_checkpoint_and_export(dev, tmp_path):
+    """Row N3 on the GPU: a FusionSense scene directory on disk (transforms.json, images, masks, 16-bit sensor depth,
+    mono normals, seed + hull PLYs, gelsight touch patches) -> fusionsense_amd.dataparser -> seed Gaussians
+    (populate_modules) -> SplatTrainer steps with the reference's get_loss_dict over prepared FrameBatches, across
+    add_touch_patch and one refinement + hull / touch pruning -> nerfstudio checkpoint and ``ns-export gaussian-splat``
+    PLY -> reloaded: bit-identical parameters and forward."""
+    from fusionsense_amd import dataparser as dp, io as fio
+    from fusionsense_amd.fused import render_fusionsense_fused
+    from fusionsense_amd.losses import FrameBatch, LossConfig
+    from fusionsense_amd.splatfacto import DensifyStrategy, SplatfactoConfig
+    from fusionsense_amd.trainer import PARAM_ORDER, SplatTrainer
+    from helpers import write_scene_dir
+    write_scene_dir(tmp_path, np.random.default_rng(3), variant="plain", H=96, W=128, n_pts=3000, n_hull=300, look_at=True)
+    out = dp.parse_transforms(tmp_path, load_touches=True)
+    md = out.metadata
+    assert len(out.cameras) == 3 and md["points3D_xyz"].shape == (3000, 3) and len(md["touch_patches"]) == 2
+    gp = dp.seed_gauss_params(out)
+    cfg = LossConfig()
+    batches = [_fb(dp.load_batch(out, i), dev, cfg) for i in range(len(out.cameras))]
+    assert all(isinstance(b, FrameBatch) and b.has_sensor and b.mask is not None and b.normal is not None for b in batches)
+    st = DensifyStrategy(SplatfactoConfig(), num_train_data=len(out.cameras))
+    st.set_metadata(touch_patches=md["touch_patches"], gel_scale_factor=md["gel_scale_factor"], add_touch_at=595,
+                    visual_hull=md["visual_hull"], scale_factor=md["scale_factor"])
+    tr = SplatTrainer(gp, dev, sh_degree=3, strategy=st, seed=0, sh_degree_interval=1000, loss_cfg=cfg)
+    tr.step = 590  # steps 590 .. 609: add_touch_patch at 595, refinement_after + hull_pruning + touch_pruning at 600
+    n0, losses_ = tr.num_gaussians(), []
+    for s in range(20):
+        loss, o = tr.train_step(out.cameras[s % 3], batches[s % 3])
+        losses_.append(float(loss))
+    assert all(math.isfinite(v) for v in losses_) and tr.step == 610
+    assert st.add_mask is not None and int(st.add_mask.sum()) > 0, "the touch patches were added as anchors"
+    assert tr.num_gaussians() != n0 and float(o["accumulation"].max()) > 0.2, "the cameras see the scene"
+    # checkpoint + export, reloaded into a fresh trainer / a plain parameter dictionary
+    ck, ply = str(tmp_path / "step-000000609.ckpt"), str(tmp_path / "splat.ply")
+    fio.save_checkpoint(tr, ck)
+    assert fio.export_gaussian_splat_ply(tr.params, ply) == tr.num_gaussians()
+    tr2 = SplatTrainer(gp, dev, sh_degree=3, seed=0, sh_degree_interval=1000, loss_cfg=cfg)
+    assert fio.load_checkpoint(tr2, ck) == 610
+    imp = {k: v.to(dev) for k, v in fio.import_gaussian_splat_ply(ply).items()}
+    with torch.no_grad():
+        a, b = tr.forward(out.cameras[1]), tr2.forward(out.cameras[1])
+        c = render_fusionsense_fused(imp, out.cameras[1], sh_degree=tr._sh_degree_now(), device=dev)
+    for k in PARAM_ORDER:
+        assert torch.equal(tr.params[k].data, tr2.params[k].data) and torch.equal(tr.params[k].data, imp[k]), k
+        sa, sb = tr.optimizers[k].state[tr.params[k]], tr2.optimizers[k].state[tr2.params[k]]
+        assert torch.equal(sa["exp_avg"], sb["exp_avg"]) and torch.equal(sa["exp_avg_sq"], sb["exp_avg_sq"]), k
+    for k in ("rgb", "depth", "normal", "accumulation"):
+        assert torch.equal(a[k], b[k]) and torch.equal(a[k], c[k]), k
+    # the reloaded trainer continues: one more step from the same state gives the same loss (to the atomics' noise)
+    la, _ = tr.train_step(out.cameras[2], batches[2])
+    lb, _ = tr2.train_step(out.cameras[2], batches[2])
+    assert abs(float(la) - float(lb)) <= 1e-5 * abs(float(la))

@@ -586,62 +586,6 @@ def test_unfused_train_step_flushes_deferred_features_before_clearing_the_slab(m
         assert torch.equal(init[k], init0[k]) and not torch.equal(init[k], a.params[k].data), k
 
 
-def _write_scene_dir(root, rng):
-    """A miniature FusionSense scene directory: transforms.json (+ images, masks, 16-bit depth, mono normals), seed
-    and hull PLYs, gelsight_transform.json with two gel patches."""
-    import json
-    from PIL import Image
-    from fusionsense_amd import io as fio
-    H, W = 12, 16
-    (root / "images").mkdir(); (root / "masks").mkdir(); (root / "depth").mkdir()
-    (root / "normals_from_pretrain").mkdir(); (root / "tactile").mkdir()
-    names = ["frame_00002", "frame_00000", "frame_00001"]  # listed out of order on purpose
-    frames, c2ws = [], {}
-    for i, n in enumerate(names):
-        img = rng.integers(0, 256, size=(H, W, 3), dtype=np.uint8)
-        Image.fromarray(img).save(root / "images" / f"{n}.png")
-        Image.fromarray(((rng.random((H, W)) > 0.4) * 255).astype(np.uint8)).save(root / "masks" / f"{n}.png")
-        Image.fromarray(rng.integers(300, 2000, size=(H, W)).astype(np.uint16)).save(root / "depth" / f"{n}.png")
-        Image.fromarray(rng.integers(0, 256, size=(H, W, 3), dtype=np.uint8)).save(root / "normals_from_pretrain" / f"{n}.png")
-        q = rng.normal(size=(3, 3)); R, _ = np.linalg.qr(q)
-        if np.linalg.det(R) < 0:
-            R[:, 0] *= -1
-        T = np.eye(4); T[:3, :3] = R; T[:3, 3] = rng.normal(size=3) * (i + 1)
-        c2ws[n] = T
-        frames.append({"file_path": f"images/{n}.png", "mask_path": f"masks/{n}.png", "depth_file_path": f"depth/{n}.png",
-                       "transform_matrix": T.tolist()})
-    pts = rng.normal(size=(60, 3)).astype(np.float32) * 0.3
-    col = rng.integers(0, 256, size=(60, 3)).astype(np.uint8)
-    fio.write_ply(str(root / "merged_pcd.ply"), {"x": pts[:, 0], "y": pts[:, 1], "z": pts[:, 2], "red": col[:, 0],
-                                                  "green": col[:, 1], "blue": col[:, 2]})
-    hull = rng.normal(size=(25, 3)).astype(np.float32) * 0.1
-    fio.write_ply(str(root / "foreground_pcd.ply"), {"x": hull[:, 0], "y": hull[:, 1], "z": hull[:, 2]})
-    meta = {"fl_x": 20.0, "fl_y": 21.0, "cx": 8.0, "cy": 6.0, "w": W, "h": H, "frames": frames,
-            "ply_file_path": "merged_pcd.ply", "object_pc_path": "foreground_pcd.ply"}
-    (root / "transforms.json").write_text(json.dumps(meta))
-    tframes, raws = [], []
-    for k in range(2):
-        gx, gy = np.meshgrid(np.arange(20), np.arange(15), indexing="ij")
-        raw = np.stack([gx.ravel(), gy.ravel(), -rng.random(300) * 40], -1).astype(np.float32)
-        with open(root / "tactile" / f"patch_{k}.pcd", "w") as f:
-            f.write("# .PCD v0.7\nVERSION 0.7\nFIELDS x y z\nSIZE 4 4 4\nTYPE F F F\nCOUNT 1 1 1\n"
-                    f"WIDTH 300\nHEIGHT 1\nVIEWPOINT 0 0 0 1 0 0 0\nPOINTS 300\nDATA ascii\n")
-            for r in raw:
-                f.write(f"{r[0]:.6f} {r[1]:.6f} {r[2]:.6f}\n")
-        mask = rng.random(300) > 0.3
-        np.save(root / "tactile" / f"mask_{k}.npy", mask)
-        nrm = rng.normal(size=(300, 3)).astype(np.float32)
-        nrm /= np.linalg.norm(nrm, axis=-1, keepdims=True)
-        np.save(root / "tactile" / f"normal_{k}.npy", nrm)
-        q = rng.normal(size=(3, 3)); R, _ = np.linalg.qr(q)
-        T = np.eye(4); T[:3, :3] = R; T[:3, 3] = rng.normal(size=3) * 0.2
-        tframes.append({"patch_path": f"tactile/patch_{k}.pcd", "mask_path": f"tactile/mask_{k}.npy",
-                        "normal_path": f"tactile/normal_{k}.npy", "transform_matrix": T.tolist()})
-        raws.append((raw, mask, nrm, T))
-    (root / "gelsight_transform.json").write_text(json.dumps({"frames": tframes}))
-    return names, c2ws, pts, col, hull, raws
-
-
 def test_dataparser_scene_directory(tmp_path):
     """transforms.json -> cameras (frames in file-name order, y/z axis flip, no re-orientation, max |t| scaled to 1),
     seed + hull points and touch patches moved by the same transform and scale, per-view batches in the units
@@ -649,7 +593,8 @@ def test_dataparser_scene_directory(tmp_path):
     computation on a generated scene directory."""
     from fusionsense_amd import dataparser as dp, touch
     rng = np.random.default_rng(0)
-    names, c2ws, pts, col, hull, raws = _write_scene_dir(tmp_path, rng)
+    from helpers import write_scene_dir
+    names, c2ws, pts, col, hull, raws = write_scene_dir(tmp_path, rng)
     out = dp.parse_transforms(tmp_path, load_touches=True)
     order = sorted(names)
     assert [p.stem for p in out.image_filenames] == order and [p.stem for p in out.mask_filenames] == order
@@ -763,3 +708,60 @@ def test_lazy_meta_copies_never_lose_the_lazy_keys():
         c = clone(m)
         assert type(c) is dict and set(c) == {"radii", "isect_ids", "flatten_ids", "isect_offsets", "legacy_rule_diff"}
     assert len(built) == 7
+
+
+@pytest.mark.parametrize("variant", ["plain", "ragged"])
+def test_dataparser_matches_reference_execution(tmp_path, variant, monkeypatch):
+    """fusionsense_amd/dataparser.py against what the REFERENCE's own NormalNerfstudio._generate_dataparser_outputs
+    (normal_nerfstudio.py:136-725) and GDataset.get_metadata (dn_dataset.py:110-243) produced on the same scene
+    directory (tests/golden/make_reference_dataparser_goldens.py; the directory is rewritten here from the same
+    seed): frame order (file-name sort, natural sort, the second application of the permutation), camera poses after
+    the axis flip and the auto scale, per-frame intrinsics, seed / hull points, what happens to the seed normals,
+    touch patches (.npy and .pcd masks, 2- and 3-channel normals, oriented boxes), applied_transform / applied_scale,
+    and the per-view sensor depth and normal images."""
+    from pathlib import Path
+    from fusionsense_amd import dataparser as dp
+    from helpers import write_scene_dir
+    sys.path.insert(0, GOLD)
+    try:
+        from make_reference_dataparser_goldens import fake_pca_normals
+    finally:
+        sys.path.remove(GOLD)
+    d = np.load(os.path.join(GOLD, "reference_dataparser.npz"))
+    g = lambda k: d[f"{variant}.{k}"]  # noqa: E731
+    write_scene_dir(tmp_path, np.random.default_rng(int(g("seed"))), variant=variant)
+    # open3d's PCA normals cannot be executed by the generator either: both sides use the same fixed function, the
+    # golden pins what the reference does with them
+    monkeypatch.setattr(dp, "estimate_normals",
+                        lambda pts, **k: torch.from_numpy(fake_pca_normals(pts.numpy().astype(np.float64)).astype(np.float32)))
+    fmt = "opengl" if bool(g("normal_format_is_opengl")) else "opencv"
+    out = dp.parse_transforms(tmp_path, load_touches=True, normal_format=fmt)
+    stems = sorted({p.stem for p in out.image_filenames}, key=dp.natural_key)
+    assert [stems.index(p.stem) for p in out.image_filenames] == g("image_order").tolist()
+    assert [stems.index(p.stem) for p in out.mask_filenames] == g("mask_order").tolist()
+    assert [stems.index(Path(p).stem) for p in out.metadata["depth_filenames"]] == g("depth_order").tolist()
+    assert [stems.index(Path(p).stem) for p in out.metadata["normal_filenames"]] == g("normal_order").tolist()
+    assert np.array_equal(np.stack([c.c2w.numpy() for c in out.cameras]), g("c2w"))
+    for k, attr in (("fx", "fx"), ("fy", "fy"), ("cx", "cx"), ("cy", "cy"), ("width", "width"), ("height", "height")):
+        assert np.allclose(np.array([getattr(c, attr) for c in out.cameras], dtype=np.float64), g(k).astype(np.float64),
+                           rtol=0, atol=1e-6), k
+    assert out.dataparser_scale == pytest.approx(float(g("dataparser_scale")), rel=1e-12)
+    assert np.array_equal(out.dataparser_transform.numpy(), g("dataparser_transform"))
+    md = out.metadata
+    assert md["scale_factor"] == pytest.approx(float(g("scale_factor")), rel=1e-12)
+    assert np.array_equal(md["transform_matrix"].numpy(), g("transform_matrix"))
+    assert np.array_equal(md["points3D_xyz"].numpy(), g("points3D_xyz"))
+    assert np.array_equal(md["points3D_rgb"].numpy(), g("points3D_rgb"))
+    assert np.array_equal(md["visual_hull"].numpy(), g("visual_hull"))
+    assert np.allclose(md["points3D_normals"].numpy(), g("points3D_normals"), atol=1e-6)
+    assert md["gel_scale_factor"] == float(g("gel_scale_factor")) and len(md["touch_patches"]) == int(g("n_patches"))
+    for i, tp in enumerate(md["touch_patches"]):
+        for k in ("points_xyz", "points_rgb", "normals", "bbox"):
+            ref = g(f"touch{i}.{k}")
+            assert tp[k].shape == ref.shape and tp[k].dtype == torch.float32, (i, k)
+            assert np.array_equal(tp[k].numpy(), ref), (i, k, float(np.abs(tp[k].numpy() - ref).max()))
+    for idx in range(len(out.cameras)):
+        b = dp.load_batch(out, idx)
+        assert b["sensor_depth"].dtype == torch.float32
+        assert np.array_equal(b["sensor_depth"].numpy(), g(f"batch{idx}.sensor_depth").astype(np.float32)), idx
+        assert np.array_equal(b["normal"].numpy(), g(f"batch{idx}.normal")), idx
