@@ -588,6 +588,24 @@ def main():
         torch.cuda.synchronize()
         dropin_detail["patched_get_outputs_iters_per_s"] = round(nd / (time.perf_counter() - t4), 2)
         del p_tr
+        # integration.patch_all(): get_outputs AND get_loss_dict as HIP autograd nodes, the statistics applied by the
+        # backward, DensifyStrategy behind the callbacks, and the torch.optim.Adam objects stepped one by one as
+        # nerfstudio's Optimizers does with integration.AdamFuser gathering them into one libfsgs launch — the
+        # reference's loop shape (torch's tape, optimizer objects, callbacks), every kernel on the HIP path
+        f_tr = SplatTrainer({k: p.data for k, p in trainer.params.items()}, dev, sh_degree=3, fused=True, direct=False,
+                            loss_cfg=trainer.loss_cfg, strategy=d_st, torch_optimizers=True, fuse_torch_optimizers=True)
+        f_tr.step = trainer.step
+        f_tr.sh_degree_interval = trainer.sh_degree_interval
+        for s in range(5):
+            f_tr.train_step(cams[view_of(s)], targets[view_of(s)])
+        torch.cuda.synchronize()
+        t5 = time.perf_counter()
+        for s in range(nd):
+            f_tr.train_step(cams[view_of(s)], targets[view_of(s)])
+        torch.cuda.synchronize()
+        patched_full = round(nd / (time.perf_counter() - t5), 2)
+        dropin_detail["patched_full_iters_per_s"] = patched_full
+        del f_tr
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -699,6 +717,7 @@ def main():
             "iters_per_s_excl_optimizer": round(world / t_noopt, 3),
             "dropin_iters_per_s": None if dropin is None else round(dropin, 2),
             "dropin_detail": None if dropin is None else dropin_detail,
+            "patched_full_iters_per_s": None if dropin is None else dropin_detail.get("patched_full_iters_per_s"),
             "render_tolerance": RENDER_TOLERANCE,
             "iter_algorithmic_bytes": b_iter,
             "iter_hbm_frac": round(b_iter / (elapsed / args.steps) / (HBM_PEAK_GBS * 1e9), 5),

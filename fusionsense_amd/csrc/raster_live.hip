@@ -399,7 +399,7 @@ static int launch_bwd_live(int C, int D, const float *records, const int32_t *n_
                            int64_t replica_rows = 0) {
     // FSGS_BWD_MERGE_THR16 (A/B switch): a segment walks the union list with merged atomics when its longest row list
     // is >= thr/16 of the union; 0 = always, 17 = never
-    static const int merge_thr16 = [] { const char *e = getenv("FSGS_BWD_MERGE_THR16"); return e ? atoi(e) : 14; }();
+    static const int merge_thr16 = [] { const char *e = getenv("FSGS_BWD_MERGE_THR16"); return e ? atoi(e) : 15; }();
     if (C < 0 || width < 0 || height < 0 || n_isects < 0) return FSGS_EINVAL;
     if (C == 0 || width == 0 || height == 0 || n_isects == 0) return FSGS_OK;
     if (!records || !n_rec || !isect_offsets || !render || !alphas || !last_ids || !seg_state || !v_packed)

@@ -12,6 +12,22 @@ autograd tape and under nerfstudio's own optimizers and callbacks:
     integration.patch(m.DNSplatterModel)          # get_outputs -> get_outputs_fused (the original stays as
                                                   # _get_outputs_reference and is used for what the node does not cover)
 
+``integration.patch_all(m.DNSplatterModel)`` goes one step further and routes the REST of the model's training-loop
+surface to the HIP path as well — same method names, same arguments, still driven by nerfstudio's Trainer, its
+callbacks and its ``Optimizers`` (round 3):
+
+    get_loss_dict      dn_model.py:673-925   -> ops._FusionLoss over a cached FrameBatch (one autograd node); the original
+                                                stays as ``_get_loss_dict_reference`` and is used for every switch the node
+                                                does not cover (mono depth, normals from depth, cosine / sparse / SDF terms)
+    after_train        (nerfstudio, A.2)     -> nothing to do: the statistics were applied by the node's backward
+    refinement_after   dn_model.py:326-451   -> DensifyStrategy.refinement_after (HIP row compaction, split sampling)
+    add_touch_patch    dn_model.py:1156-1247 -> DensifyStrategy.add_touch_patch
+    hull_pruning       dn_model.py:1249-1276 -> DensifyStrategy.hull_pruning
+    touch_pruning      dn_model.py:1279-1302 -> DensifyStrategy.touch_pruning
+    fuse_optimizers(optimizers.optimizers)   -> the Gaussian groups' torch.optim.Adam objects keep their identity, state
+                                                layout and schedulers; their ``step()`` calls are gathered and ONE
+                                                fsgs_adam_step launch runs when the last live group has stepped
+
 Side effects reproduced (they are what after_train / refinement_after / get_loss_dict read, dn_model.py:592-600,
 607, 634, 660-663): ``self.xys`` (an object whose ``.absgrad`` [1,N,2] is filled by the backward), ``self.radii``,
 ``self.depths``, ``self.conics``, ``self.num_tiles_hit``, ``self.vis_indices``, ``self.last_size``,
@@ -63,9 +79,22 @@ def get_outputs_fused(self, camera) -> Dict[str, torch.Tensor]:
     sh_degree_to_use = min(self.step // cfg.sh_degree_interval, cfg.sh_degree)
     background = self._get_background_color().to(device=dev, dtype=torch.float32)
     crop_box = self.crop_box if (self.crop_box is not None and not self.training) else None
+    stats = None
+    if self.training and getattr(type(self), "_fsgs_patched_all", False) and self.step < cfg.stop_split_at \
+            and torch.is_grad_enabled():
+        # patch_all: the node's backward applies after_train itself (nerfstudio creates the buffers the same way on
+        # first use: zeros / ones / zeros)
+        N = self.gauss_params["means"].shape[0]
+        if getattr(self, "xys_grad_norm", None) is None or self.xys_grad_norm.shape[0] != N:
+            self.xys_grad_norm = torch.zeros(N, device=dev, dtype=torch.float32)
+            self.vis_counts = torch.ones(N, device=dev, dtype=torch.float32)
+        if getattr(self, "max_2Dsize", None) is None or self.max_2Dsize.shape[0] != N:
+            self.max_2Dsize = torch.zeros(N, device=dev, dtype=torch.float32)
+        stats = {"xys_grad_norm": self.xys_grad_norm, "vis_counts": self.vis_counts, "max_2Dsize": self.max_2Dsize,
+                 "inv_max_hw": 1.0 / float(max(H, W))}
     out = render_fusionsense_fused(self.gauss_params, cam, sh_degree=sh_degree_to_use, background=background, device=dev,
                                    add_mask=self.add_mask, crop_box=crop_box, training=bool(self.training),
-                                   binary_threshold=_binary_threshold(cfg, self.step))
+                                   binary_threshold=_binary_threshold(cfg, self.step), stats_out=stats)
     if "info" not in out:  # the crop left nothing: get_empty_outputs
         return out
     info = out["info"]
@@ -90,3 +119,293 @@ def patch(model_cls) -> None:
     model_cls._get_outputs_reference = model_cls.get_outputs
     model_cls.get_outputs = get_outputs_fused
     model_cls._fsgs_patched = True
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# patch_all: get_loss_dict, after_train and the refinement / touch / hull callbacks on the HIP path (round 3)
+# ---------------------------------------------------------------------------------------------------------------------
+GAUSS_GROUPS = ("means", "scales", "quats", "features_dc", "features_rest", "opacities")
+
+
+def _loss_config(cfg):
+    """losses.LossConfig from the model's DNSplatterModelConfig, or None when a switch is set that the fused loss node
+    does not evaluate (the caller then runs the reference's own get_loss_dict)."""
+    from .losses import LossConfig
+
+    def name_of(v):  # enum member / string -> lower-case name
+        return str(getattr(v, "name", v)).lower()
+    g = lambda k, d=None: getattr(cfg, k, d)  # noqa: E731
+    if g("use_scale_regularization", False) or g("use_sparse_loss", False) or g("use_sdf_loss", False):
+        return None
+    if g("use_normal_cosine_loss", False) or (g("use_normal_loss", False) and g("normal_supervision", "mono") != "mono"):
+        return None
+    if g("use_depth_loss", False) and "edgeawarelogl1" not in name_of(g("depth_loss_type", "EdgeAwareLogL1")):
+        return None
+    if g("use_depth_smooth_loss", False) and name_of(g("smooth_loss_type", "TV")).split(".")[-1] != "tv":
+        return None
+    return LossConfig(ssim_lambda=float(g("ssim_lambda", 0.2)), use_depth_loss=bool(g("use_depth_loss", False)),
+                      sensor_depth_lambda=float(g("sensor_depth_lambda", 0.0)),
+                      depth_tolerance=float(g("depth_tolerance", 0.1)),
+                      use_depth_smooth_loss=bool(g("use_depth_smooth_loss", False)),
+                      smooth_loss_lambda=float(g("smooth_loss_lambda", 0.1)),
+                      use_normal_loss=bool(g("use_normal_loss", False)),
+                      use_normal_tv_loss=bool(g("use_normal_tv_loss", False)),
+                      normal_lambda=float(g("normal_lambda", 0.1)), two_d_gaussians=bool(g("two_d_gaussians", False)),
+                      touch_normal_loss_lambda=1.0)
+
+
+def get_loss_dict_fused(self, outputs, batch, metrics_dict=None) -> Dict[str, torch.Tensor]:
+    """Drop-in for ``DNSplatterModel.get_loss_dict`` (dn_model.py:673-925): ``main_loss`` is one HIP autograd node over
+    the view's supervision, prepared once per ``image_idx`` and kept on the device (``self._fsgs_frames``).  What the
+    node does not cover goes to the reference's own method.  Not reproduced: the ``log_images/<step>.jpg`` debug dump of
+    every 100th step (:903-921) and the in-place masking of ``outputs["normal"]`` / ``batch["normal"]`` (:712-715),
+    which nothing reads after the loss."""
+    from . import ops
+    from .losses import prepare_batch
+    cfg = _loss_config(self.config)
+    rgb = outputs.get("rgb")
+    covered = (cfg is not None and torch.is_tensor(rgb) and rgb.is_cuda and "normal" in outputs and "depth" in outputs
+               and not ("mono_depth" in batch and float(getattr(self.config, "mono_depth_lambda", 0.0)) > 0.0)
+               and not (cfg.use_normal_loss and "normal" not in batch)
+               and int(getattr(self.config, "num_downscales", 0)) == 0)
+    if not covered:
+        return self._get_loss_dict_reference(outputs, batch, metrics_dict)
+    frames = self.__dict__.setdefault("_fsgs_frames", {})
+    key = int(batch["image_idx"]) if "image_idx" in batch else id(batch["image"])
+    fb = frames.get(key)
+    if fb is None or fb.height != rgb.shape[0] or fb.width != rgb.shape[1]:
+        fb = frames[key] = prepare_batch({k: batch[k] for k in ("image", "sensor_depth", "normal", "mask") if k in batch},
+                                         cfg, rgb.device)
+    touch_idx = touch_normals = None
+    add_mask = getattr(self, "add_mask", None)
+    if add_mask is not None:
+        touch_idx = torch.nonzero(add_mask.to(rgb.device), as_tuple=False).reshape(-1).to(torch.int32).contiguous()
+        tn = self.__dict__.get("_fsgs_touch_normals")
+        if tn is None or tn.shape[0] != touch_idx.numel():
+            tn = torch.cat([tp["normals"].to(rgb.device) for tp in self.kwargs["metadata"]["touch_patches"]], dim=0)
+            self.__dict__["_fsgs_touch_normals"] = tn = tn.to(torch.float32).contiguous()
+        touch_normals = tn
+    main_loss = ops._FusionLoss.apply(rgb, outputs["depth"], outputs["normal"], self.gauss_params["scales"], fb, cfg,
+                                      self.gauss_params["normals"] if touch_idx is not None else None, touch_idx,
+                                      touch_normals, None, False)
+    return {"main_loss": main_loss, "scale_reg": torch.zeros((), device=rgb.device)}
+
+
+class _NoSlab:
+    def rebuild(self, params) -> None:
+        pass
+
+
+class _ParamView:
+    """The model's ``gauss_params`` without the inert "normals" entry (rewritten by every get_outputs, dn_model.py:634)."""
+
+    def __init__(self, gauss_params):
+        self._p = gauss_params
+
+    def keys(self):
+        return [k for k in GAUSS_GROUPS if k in self._p]
+
+    def items(self):
+        return [(k, self._p[k]) for k in self.keys()]
+
+    def __getitem__(self, k):
+        return self._p[k]
+
+    def __setitem__(self, k, v):
+        self._p[k] = v
+
+
+class _ModelAsTrainer:
+    """What splatfacto.DensifyStrategy calls a trainer, over a DNSplatterModel and nerfstudio's ``Optimizers``."""
+
+    def __init__(self, model, optimizers):
+        self.model = model
+        self.params = _ParamView(model.gauss_params)
+        self.optimizers = optimizers.optimizers if hasattr(optimizers, "optimizers") else optimizers
+        self.slab = _NoSlab()
+        self.device = model.gauss_params["means"].device
+        rng = model.__dict__.get("_fsgs_rng")
+        if rng is None or rng.device != self.device:
+            rng = model.__dict__["_fsgs_rng"] = torch.Generator(device=self.device)
+            rng.manual_seed(torch.initial_seed() % (2 ** 63))
+        self.rng = rng
+
+    @property
+    def step(self) -> int:
+        return int(self.model.step)
+
+    def num_gaussians(self) -> int:
+        return self.model.gauss_params["means"].shape[0]
+
+
+def _strategy(model):
+    """The model's DensifyStrategy (created on first use from ``model.config``), with the model's statistics and anchor
+    mask handed in; ``_sync_back`` returns them."""
+    from .splatfacto import DensifyStrategy, SplatfactoConfig
+    st = model.__dict__.get("_fsgs_strategy")
+    if st is None:
+        fields = {f: getattr(model.config, f) for f in SplatfactoConfig.__dataclass_fields__ if hasattr(model.config, f)}
+        st = model.__dict__["_fsgs_strategy"] = DensifyStrategy(SplatfactoConfig(**fields),
+                                                                num_train_data=int(model.num_train_data))
+    for k in ("xys_grad_norm", "vis_counts", "max_2Dsize", "add_mask"):
+        setattr(st, k, getattr(model, k, None))
+    ls = getattr(model, "last_size", None)
+    if ls is not None:
+        st.last_size = ls
+    return st
+
+
+def _sync_back(model, st, adapter) -> None:
+    for k in ("xys_grad_norm", "vis_counts", "max_2Dsize", "add_mask"):
+        setattr(model, k, getattr(st, k))
+    n = adapter.num_gaussians()
+    nrm = model.gauss_params["normals"] if "normals" in model.gauss_params else None
+    if nrm is None or nrm.shape[0] != n:  # the inert group follows N (it is rewritten by the next get_outputs)
+        new = torch.nn.Parameter(torch.zeros(n, 3, device=adapter.device))
+        model.gauss_params["normals"] = new
+        opt = adapter.optimizers.get("normals") if hasattr(adapter.optimizers, "get") else None
+        if opt is not None:
+            opt.state.clear()
+            opt.param_groups[0]["params"] = [new]
+    model.__dict__.pop("_fsgs_touch_normals", None)
+    model.delete_mask_to_update_knn = None
+
+
+def after_train_fused(self, step: int):
+    """nerfstudio's ``after_train``: the fused node's backward has already accumulated the absgrad
+    norm, the visibility counts and the 2-D size maxima into ``self.xys_grad_norm / vis_counts / max_2Dsize``."""
+    if getattr(getattr(self, "xys", None), "stats_done", False):
+        return None
+    return self._after_train_reference(step)
+
+
+def refinement_after_fused(self, optimizers, step):
+    assert step == self.step
+    if self.step <= self.config.warmup_length:
+        return
+    st, ad = _strategy(self), _ModelAsTrainer(self, optimizers)
+    st.refinement_after(ad, int(step))
+    _sync_back(self, st, ad)
+
+
+def add_touch_patch_fused(self, optimizers, step):
+    assert step == self.step
+    if self.step != self.config.add_touch_at or "touch_patches" not in self.kwargs["metadata"]:
+        return
+    st, ad = _strategy(self), _ModelAsTrainer(self, optimizers)
+    md = self.kwargs["metadata"]
+    self.added_count = st.add_touch_patch(ad, md["touch_patches"], float(md["gel_scale_factor"]))
+    _sync_back(self, st, ad)
+
+
+def hull_pruning_fused(self, optimizers, step):
+    assert step == self.step
+    if self.step <= self.config.warmup_length or "visual_hull" not in self.kwargs["metadata"]:
+        return
+    st, ad = _strategy(self), _ModelAsTrainer(self, optimizers)
+    md = self.kwargs["metadata"]
+    st.hull_pruning(ad, md["visual_hull"], float(md["scale_factor"]))
+    _sync_back(self, st, ad)
+
+
+def touch_pruning_fused(self, optimizers, step):
+    assert step == self.step
+    if self.step <= self.config.warmup_length or getattr(self, "add_mask", None) is None:
+        return
+    st, ad = _strategy(self), _ModelAsTrainer(self, optimizers)
+    st.touch_pruning(ad, self.kwargs["metadata"]["touch_patches"])
+    _sync_back(self, st, ad)
+
+
+def patch_all(model_cls) -> None:
+    """``patch`` + get_loss_dict, after_train and the four row-moving callbacks on the HIP path (idempotent; every
+    original stays reachable as ``_<name>_reference``)."""
+    patch(model_cls)
+    if getattr(model_cls, "_fsgs_patched_all", False):
+        return
+    for name, fn in (("get_loss_dict", get_loss_dict_fused), ("after_train", after_train_fused),
+                     ("refinement_after", refinement_after_fused), ("add_touch_patch", add_touch_patch_fused),
+                     ("hull_pruning", hull_pruning_fused), ("touch_pruning", touch_pruning_fused)):
+        setattr(model_cls, f"_{name}_reference", getattr(model_cls, name, None))
+        setattr(model_cls, name, fn)
+    model_cls._fsgs_patched_all = True
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# nerfstudio's Optimizers: one fsgs_adam_step launch for all Gaussian groups
+# ---------------------------------------------------------------------------------------------------------------------
+class AdamFuser:
+    """Gathers the ``step()`` calls of several single-parameter ``torch.optim.Adam`` objects (nerfstudio builds one per
+    parameter group, dn_config.py:36-75) and runs them as ONE libfsgs launch when the last LIVE one has stepped (live =
+    its parameter has a gradient; the inert "normals" group never does).  The optimizer objects, their ``state``
+    (``step`` / ``exp_avg`` / ``exp_avg_sq`` per parameter, so ``state_dict()`` is unchanged), their param_groups and
+    the schedulers bound to them are untouched; only the instance's ``step`` is replaced.  A pending partial set is
+    launched by the next ``zero_grad`` of any member, by ``flush()`` and before a ``state_dict()``."""
+
+    def __init__(self, optimizers: Dict[str, torch.optim.Optimizer], names=GAUSS_GROUPS):
+        self.members = [optimizers[n] for n in names if n in optimizers]
+        self.pending = []
+        for opt in self.members:
+            assert isinstance(opt, torch.optim.Adam) and len(opt.param_groups) == 1 and \
+                len(opt.param_groups[0]["params"]) == 1, "one parameter tensor per optimizer, as nerfstudio builds them"
+            g = opt.param_groups[0]
+            assert not g.get("amsgrad", False) and g.get("weight_decay", 0) == 0 and not g.get("maximize", False)
+            self._wrap(opt)
+
+    def _wrap(self, opt) -> None:
+        fuser = self
+        orig_zero, orig_sd = opt.zero_grad, opt.state_dict
+
+        def step(closure=None):
+            assert closure is None
+            opt._step_count = getattr(opt, "_step_count", 0) + 1  # (what torch's LR schedulers look at)
+            p = opt.param_groups[0]["params"][0]
+            if p.grad is None:
+                return None
+            if not p.is_cuda:
+                raise RuntimeError("AdamFuser drives libfsgs: parameters must live on the GPU (no CPU fallback)")
+            fuser.pending.append(opt)
+            if all(o in fuser.pending for o in fuser.live()):
+                fuser.flush()
+            return None
+        step._with_counter = True
+        opt.step = step
+
+        def zero_grad(*a, **k):
+            fuser.flush()
+            return orig_zero(*a, **k)
+
+        def state_dict(*a, **k):
+            fuser.flush()
+            return orig_sd(*a, **k)
+        opt.zero_grad, opt.state_dict = zero_grad, state_dict
+
+    def live(self):
+        return [o for o in self.members if o.param_groups[0]["params"][0].grad is not None]
+
+    @torch.no_grad()
+    def flush(self) -> None:
+        if not self.pending:
+            return
+        from .ops import adam_step_
+        todo, self.pending = self.pending, []
+        by_key = {}
+        for opt in todo:
+            g = opt.param_groups[0]
+            p = g["params"][0]
+            st = opt.state[p]
+            if "exp_avg" not in st:
+                st["step"] = torch.tensor(0.0)
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            st["step"] += 1
+            key = (int(st["step"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]))
+            by_key.setdefault(key, []).append((p, st, float(g["lr"])))
+        for (step_no, b1, b2, eps), rows in by_key.items():  # (one launch: the groups step together)
+            adam_step_([p.data for p, _, _ in rows], [p.grad for p, _, _ in rows], [s["exp_avg"] for _, s, _ in rows],
+                       [s["exp_avg_sq"] for _, s, _ in rows], [lr for _, _, lr in rows], step_no, b1, b2, eps)
+
+
+def fuse_optimizers(optimizers, names=GAUSS_GROUPS) -> AdamFuser:
+    """``optimizers``: nerfstudio's ``Optimizers`` or its ``.optimizers`` dictionary."""
+    return AdamFuser(optimizers.optimizers if hasattr(optimizers, "optimizers") else optimizers, names)

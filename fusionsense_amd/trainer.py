@@ -118,7 +118,8 @@ class SplatTrainer:
     def __init__(self, params: Dict[str, Tensor], device: torch.device, sh_degree: int = 3,
                  optim: Optional[OptimConfig] = None, fused_adam: bool = True, seed: int = 0,
                  strategy=None, fused: bool = True, sh_degree_interval: Optional[int] = None,
-                 direct: bool = True, loss_cfg=None, half_attributes: bool = False, torch_optimizers: bool = False):
+                 direct: bool = True, loss_cfg=None, half_attributes: bool = False, torch_optimizers: bool = False,
+                 fuse_torch_optimizers: bool = False):
         self.device = device
         # fused=True: get_outputs as one autograd node (fusionsense_amd/fused.py); False: the
         # reference's op-by-op caller through the drop-in rasterization()/rasterize_gaussians() surface
@@ -153,6 +154,12 @@ class SplatTrainer:
             self.optimizers[name] = torch.optim.Adam(
                 [self._params[name]], lr=self.optim_cfg.lr[name], eps=self.optim_cfg.eps,
                 fused=self.fused_adam)
+        # ... and with fuse_torch_optimizers their step() calls are gathered into one libfsgs launch, the optimizer
+        # objects and their state untouched (integration.AdamFuser: what patch_all offers under nerfstudio's Optimizers)
+        self.adam_fuser = None
+        if self.torch_optimizers and fuse_torch_optimizers:
+            from .integration import fuse_optimizers
+            self.adam_fuser = fuse_optimizers(self.optimizers, PARAM_ORDER)
         self.slab = GradSlab(self._params)
         # Data-parallel runs: the SH features' share of the all-reduce (81 % of the slab) and their Adam launch are
         # deferred until the next frame needs the colours, i.e. they overlap that frame's projection, binning and
@@ -342,6 +349,8 @@ class SplatTrainer:
             return self._fused_adam_step(names, step_no)
         for name in names:
             self.optimizers[name].step()
+        if self.adam_fuser is not None:
+            self.adam_fuser.flush()  # (a subset of the groups was stepped: launch what is pending)
         if self.half_attributes:
             self.mark_params_written()  # torch's step does not rewrite the half mirrors: re-derive before the next frame
         return None

@@ -828,18 +828,24 @@ def test_scene_directory_to_training_checkpoint_and_export(dev, tmp_path):
     ck, ply = str(tmp_path / "step-000000609.ckpt"), str(tmp_path / "splat.ply")
     fio.save_checkpoint(tr, ck)
     assert fio.export_gaussian_splat_ply(tr.params, ply) == tr.num_gaussians()
-    tr2 = SplatTrainer(gp, dev, sh_degree=3, seed=0, sh_degree_interval=1000, loss_cfg=cfg)
+    tr2 = SplatTrainer(gp, dev, sh_degree=3, seed=0, sh_degree_interval=1000, loss_cfg=cfg,
+                       strategy=DensifyStrategy(SplatfactoConfig(), num_train_data=len(out.cameras)))
     assert fio.load_checkpoint(tr2, ck) == 610
+    tr2.strategy.add_mask, tr2.strategy.touch_normals = st.add_mask.clone(), st.touch_normals  # (model state, not in a ckpt)
     imp = {k: v.to(dev) for k, v in fio.import_gaussian_splat_ply(ply).items()}
-    with torch.no_grad():
-        a, b = tr.forward(out.cameras[1]), tr2.forward(out.cameras[1])
-        c = render_fusionsense_fused(imp, out.cameras[1], sh_degree=tr._sh_degree_now(), device=dev)
     for k in PARAM_ORDER:
         assert torch.equal(tr.params[k].data, tr2.params[k].data) and torch.equal(tr.params[k].data, imp[k]), k
         sa, sb = tr.optimizers[k].state[tr.params[k]], tr2.optimizers[k].state[tr2.params[k]]
         assert torch.equal(sa["exp_avg"], sb["exp_avg"]) and torch.equal(sa["exp_avg_sq"], sb["exp_avg_sq"]), k
+    from fusionsense_amd.splatfacto import binary_opacity_active
+    assert binary_opacity_active(st.cfg, tr.step)  # step 610: get_outputs thresholds the stored logits (dn_model.py:492-503)
+    with torch.no_grad():
+        a, b = tr.forward(out.cameras[1]), tr2.forward(out.cameras[1])
+        c = render_fusionsense_fused(imp, out.cameras[1], sh_degree=tr._sh_degree_now(), device=dev,
+                                     binary_threshold=st.cfg.binary_opacities_threshold, add_mask=st.add_mask)
     for k in ("rgb", "depth", "normal", "accumulation"):
         assert torch.equal(a[k], b[k]) and torch.equal(a[k], c[k]), k
+    assert torch.equal(tr.params["opacities"].data, tr2.params["opacities"].data)
     # the reloaded trainer continues: one more step from the same state gives the same loss (to the atomics' noise)
     la, _ = tr.train_step(out.cameras[2], batches[2])
     lb, _ = tr2.train_step(out.cameras[2], batches[2])

@@ -1,0 +1,363 @@
+"""integration.patch_all: the rest of DNSplatterModel's training-loop surface on the HIP path, behind the reference's own
+method names (get_loss_dict, after_train, refinement_after, add_touch_patch, hull_pruning, touch_pruning) and under
+nerfstudio-style per-group torch.optim.Adam objects (integration.AdamFuser).  Checked against the goldens made by
+EXECUTING the reference's methods (tests/golden/reference_model.npz, reference_loss.npz) and against the repo's own
+tape-free trainer.  All through the C-ABI."""
+import math
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from fusionsense_amd import integration, scenes
+from fusionsense_amd.splatfacto import SplatfactoConfig
+from helpers import rel_err
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+NAMES6 = ["means", "scales", "quats", "features_dc", "features_rest", "opacities"]
+LR = {"means": 1.6e-4, "features_dc": 0.0025, "features_rest": 0.0025 / 20, "opacities": 0.05, "scales": 0.005,
+      "quats": 0.001, "normals": 1e-3}
+
+
+class _Cameras:
+    """What get_outputs reads from a nerfstudio Cameras object."""
+
+    def __init__(self, cam, idx=0):
+        self.camera_to_worlds = cam.c2w[None]
+        self._k = torch.tensor([[[cam.fx, 0.0, cam.cx], [0.0, cam.fy, cam.cy], [0.0, 0.0, 1.0]]])
+        self.width, self.height = torch.tensor([[cam.width]]), torch.tensor([[cam.height]])
+        self.shape = (1,)
+        self.metadata = {"cam_idx": idx}
+
+    def rescale_output_resolution(self, f):
+        pass
+
+    def get_intrinsics_matrices(self):
+        return self._k
+
+
+def _model_cls():
+    class Model:
+        """A DNSplatterModel stand-in: the members the patched methods touch.  The un-patched originals raise — the test
+        fails if a patched method falls back to them."""
+        training = True
+        crop_box = None
+
+        def get_outputs(self, camera):
+            raise AssertionError("reference get_outputs called")
+
+        def get_loss_dict(self, outputs, batch, metrics_dict=None):
+            raise AssertionError("reference get_loss_dict called")
+
+        def after_train(self, step):
+            raise AssertionError("reference after_train called")
+
+        def refinement_after(self, optimizers, step):
+            raise AssertionError("reference refinement_after called")
+
+        add_touch_patch = hull_pruning = touch_pruning = refinement_after
+
+        def _get_downscale_factor(self):
+            return 1
+
+        def _get_background_color(self):
+            return torch.ones(3)
+
+    integration.patch_all(Model)
+    return Model
+
+
+def _config(**over):
+    cfg = SplatfactoConfig()
+    ns = types.SimpleNamespace(**{f: getattr(cfg, f) for f in cfg.__dataclass_fields__})
+    ns.__dict__.update(sh_degree=3, sh_degree_interval=1000, rasterize_mode="classic", predict_normals=True,
+                       add_touch_at=1000, ssim_lambda=0.2, use_depth_loss=True, sensor_depth_lambda=0.2,
+                       depth_tolerance=0.1, use_depth_smooth_loss=True, smooth_loss_lambda=0.1, use_normal_loss=True,
+                       use_normal_tv_loss=True, normal_lambda=0.4, two_d_gaussians=True, normal_supervision="mono",
+                       depth_loss_type="EdgeAwareLogL1", smooth_loss_type="TV", mono_depth_lambda=0.0, num_downscales=0)
+    ns.__dict__.update(over)
+    return ns
+
+
+def _model(dev, params, step=0, num_train_data=9, metadata=None, **cfg_over):
+    m = _model_cls()()
+    m.config = _config(**cfg_over)
+    m.step = step
+    m.num_train_data = num_train_data
+    m.gauss_params = {k: torch.nn.Parameter(params[k].to(dev).float().contiguous()) for k in NAMES6}
+    m.gauss_params["normals"] = torch.nn.Parameter(torch.zeros(params["means"].shape[0], 3, device=dev))
+    m.camera_optimizer = types.SimpleNamespace(apply_to_camera=lambda cam: cam.camera_to_worlds)
+    m.add_mask = None
+    m.xys_grad_norm = m.vis_counts = m.max_2Dsize = None
+    m.kwargs = {"metadata": metadata or {}}
+    opts = {k: torch.optim.Adam([m.gauss_params[k]], lr=LR[k], eps=1e-15) for k in NAMES6 + ["normals"]}
+    return m, types.SimpleNamespace(optimizers=opts)
+
+
+def _set_moments(m, opts, d, m_prefix, v_prefix, dev):
+    for k in NAMES6:
+        mm = torch.from_numpy(d[f"{m_prefix}.{k}"]).to(dev)
+        vv = torch.from_numpy(d[f"{v_prefix}.{k}"]).to(dev) if v_prefix else torch.zeros_like(mm)
+        opts.optimizers[k].state[m.gauss_params[k]] = {"step": torch.tensor(1.0), "exp_avg": mm.clone(), "exp_avg_sq": vv.clone()}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def test_adam_fuser_is_torch_adam_in_one_launch(dev, monkeypatch):
+    """Six single-parameter torch.optim.Adam objects (nerfstudio's layout) stepped one by one: with AdamFuser the six
+    step() calls become ONE fsgs_adam_step launch, the update equals torch's own, state_dict() keeps its layout, an LR
+    scheduler bound to one of them keeps working, a partial set (some groups without gradient) still steps, and moments
+    replaced by a densification (new tensors under a new parameter) are picked up."""
+    from fusionsense_amd import ops
+    g = torch.Generator().manual_seed(0)
+    shapes = dict(means=(501, 3), scales=(501, 3), quats=(501, 4), features_dc=(501, 3), features_rest=(501, 15, 3),
+                  opacities=(501, 1))
+    init = {k: torch.randn(*s, generator=g) for k, s in shapes.items()}
+
+    def build():
+        ps = {k: torch.nn.Parameter(init[k].to(dev).clone()) for k in NAMES6}
+        return ps, {k: torch.optim.Adam([ps[k]], lr=LR[k], eps=1e-15) for k in NAMES6}
+
+    pa, oa = build()
+    pb, ob = build()
+    sched_a = torch.optim.lr_scheduler.ExponentialLR(oa["means"], gamma=0.9)
+    sched_b = torch.optim.lr_scheduler.ExponentialLR(ob["means"], gamma=0.9)
+    fuser = integration.fuse_optimizers(oa)
+    launches = []
+    real = ops.adam_step_
+    monkeypatch.setattr(ops, "adam_step_", lambda *a, **k: (launches.append(len(a[0])), real(*a, **k))[1])
+    for it in range(6):
+        live = NAMES6 if it != 3 else NAMES6[:3]  # iteration 3: only three groups receive a gradient
+        for o in list(oa.values()) + list(ob.values()):
+            o.zero_grad()
+        for k in live:
+            gr = torch.randn(*shapes[k], generator=g).to(dev) * (0.1 + it)
+            pa[k].grad, pb[k].grad = gr.clone(), gr.clone()
+        n0 = len(launches)
+        for k in NAMES6:  # (nerfstudio steps every group; torch skips parameters without a gradient)
+            oa[k].step()
+            ob[k].step()
+        assert len(launches) == n0 + 1 and launches[-1] == len(live), (it, launches)
+        sched_a.step()
+        sched_b.step()
+    assert not fuser.pending
+    for k in NAMES6:
+        assert torch.allclose(pa[k].data, pb[k].data, rtol=1e-6, atol=1e-7), (k, float((pa[k].data - pb[k].data).abs().max()))
+        sa, sb = oa[k].state_dict(), ob[k].state_dict()
+        assert sa.keys() == sb.keys() and sa["param_groups"] == sb["param_groups"]
+        assert sa["state"][0].keys() == sb["state"][0].keys() == {"step", "exp_avg", "exp_avg_sq"}
+        assert float(sa["state"][0]["step"]) == float(sb["state"][0]["step"])
+        assert torch.allclose(sa["state"][0]["exp_avg_sq"], sb["state"][0]["exp_avg_sq"], rtol=1e-6, atol=1e-12)
+    assert oa["means"].param_groups[0]["lr"] == pytest.approx(LR["means"] * 0.9 ** 6)
+    # a densification replaces parameter and moments (remove_from_optim / dup_in_optim): the fuser follows the optimizer
+    k = "opacities"
+    old = pa[k]
+    new = torch.nn.Parameter(torch.cat([old.data[:100], torch.zeros(7, 1, device=dev)]))
+    st = oa[k].state.pop(old)
+    st["exp_avg"] = torch.cat([st["exp_avg"][:100], torch.zeros(7, 1, device=dev)])
+    st["exp_avg_sq"] = torch.cat([st["exp_avg_sq"][:100], torch.zeros(7, 1, device=dev)])
+    oa[k].state[new] = st
+    oa[k].param_groups[0]["params"] = [new]
+    new.grad = torch.ones_like(new)
+    before = new.data.clone()
+    oa[k].step()
+    fuser.flush()
+    assert not torch.equal(new.data, before) and float(oa[k].state[new]["step"]) == 7.0
+
+
+@pytest.mark.parametrize("case", ["full", "nomask", "dense"])
+def test_patched_get_loss_dict_matches_reference_goldens(dev, case):
+    """``model.get_loss_dict(outputs, batch)`` after patch_all against what the reference's get_loss_dict produced on
+    the same inputs (reference_loss.npz): value of everything FusionSense adds to the photometric term, gradient images,
+    log-scale gradient; the view's supervision is prepared once and cached by image_idx."""
+    from oracle import loss_ref
+    d = np.load(os.path.join(GOLD, "reference_loss.npz"))
+    t = lambda k: torch.from_numpy(d[f"{case}.{k}"])  # noqa: E731
+    N = t("scales").shape[0]
+    n_touch = int(d[f"{case}.n_touch"])
+    params = {k: torch.zeros(N, *s) for k, s in (("means", (3,)), ("quats", (4,)), ("features_dc", (3,)),
+                                                 ("features_rest", (15, 3)), ("opacities", (1,)))}
+    params["scales"] = t("scales")
+    md = {"touch_patches": [{"normals": t("touch_normals")}]} if n_touch else {}
+    m, _ = _model(dev, params, metadata=md)
+    if n_touch:
+        m.add_mask = torch.zeros(N, dtype=torch.bool, device=dev)
+        m.add_mask[N - n_touch:] = True
+    m.gauss_params["normals"] = t("normals_world").to(dev)
+    batch = {"image": t("image").to(dev), "sensor_depth": t("sensor_depth").to(dev), "normal": t("normal_gt").to(dev),
+             "image_idx": 4}
+    if bool(d[f"{case}.has_mask"]):
+        batch["mask"] = t("mask").to(dev)
+    out = {k: t(k).to(dev).requires_grad_(True) for k in ("rgb", "depth", "normal")}
+    ld = m.get_loss_dict(out, batch)
+    assert set(ld) == {"main_loss", "scale_reg"} and float(ld["scale_reg"]) == 0.0
+    loss = ld["main_loss"] + ld["scale_reg"]
+    loss.backward()
+    photo = loss_ref.photometric_loss(t("rgb").double(), t("image").double(),
+                                      t("mask").double() if "mask" in batch else None, 0.2)
+    ref = float(d[f"{case}.loss"])
+    assert abs(float(loss) - float(photo) - ref) < 2e-6 * max(1.0, abs(ref))
+    for name, g in (("v_depth", out["depth"].grad), ("v_normal", out["normal"].grad), ("v_scales", m.gauss_params["scales"].grad)):
+        assert torch.allclose(g.cpu(), t(name), rtol=2e-5, atol=1e-9), (name, float((g.cpu() - t(name)).abs().max()))
+    fb = m._fsgs_frames[4]
+    m.get_loss_dict({k: v.detach() for k, v in out.items()}, batch)
+    assert m._fsgs_frames[4] is fb, "the prepared view is reused"
+    # a switch the node does not evaluate goes to the reference's own method (here: the stand-in that raises)
+    m.config.use_normal_cosine_loss = True
+    with pytest.raises(AssertionError, match="reference get_loss_dict"):
+        m.get_loss_dict(out, batch)
+
+
+@pytest.mark.parametrize("step", [400, 700, 3100, 3500, 10000])
+def test_patched_refinement_after_matches_reference_execution(dev, step, monkeypatch):
+    """``model.refinement_after(optimizers, step)`` after patch_all, over nerfstudio-style per-group optimizers, against
+    the reference's own refinement_after (reference_model.npz): parameters and both Adam moments row for row, the
+    statistics reset on the model, the inert "normals" group following N."""
+    d = np.load(os.path.join(GOLD, "reference_model.npz"))
+    t = lambda k: torch.from_numpy(d[k])  # noqa: E731
+    m, opts = _model(dev, {k: t(f"ra.{step}.pre.{k}") for k in NAMES6}, step=step)
+    _set_moments(m, opts, d, f"ra.{step}.pre_m", f"ra.{step}.pre_v", dev)
+    m.xys_grad_norm, m.vis_counts, m.max_2Dsize = (t(f"ra.stats.{k}").to(dev) for k in ("xys_grad_norm", "vis_counts", "max_2Dsize"))
+    m.last_size = (720, 1280)
+    n = m.gauss_params["means"].shape[0]
+    if step == 3500:
+        m.add_mask = torch.zeros(n, dtype=torch.bool, device=dev)
+        m.add_mask[:50] = True
+    noise = t(f"ra.{step}.randn")
+    real_randn = torch.randn
+
+    def fake_randn(*size, **kw):
+        shape = tuple(size[0]) if len(size) == 1 and not isinstance(size[0], int) else tuple(size)
+        if shape == tuple(noise.shape):
+            return noise.to(kw.get("device", "cpu"))
+        kw.pop("generator", None)
+        return real_randn(*size, **kw)
+
+    monkeypatch.setattr(torch, "randn", fake_randn)
+    m.refinement_after(opts, step)
+    for k in NAMES6:
+        ref = t(f"ra.{step}.post.{k}")
+        p = m.gauss_params[k]
+        assert p.shape == ref.shape, (k, p.shape, ref.shape)
+        assert torch.allclose(p.detach().cpu(), ref, atol=1e-5), k
+        assert opts.optimizers[k].param_groups[0]["params"][0] is p
+        s_ = opts.optimizers[k].state[p]
+        assert torch.equal(s_["exp_avg"].cpu(), t(f"ra.{step}.post_m.{k}")), k
+        assert torch.equal(s_["exp_avg_sq"].cpu(), t(f"ra.{step}.post_v.{k}")), k
+    am = d[f"ra.{step}.add_mask_after"]
+    if am.size:
+        assert np.array_equal(m.add_mask.cpu().numpy(), am)
+    assert (m.xys_grad_norm is None) == bool(d[f"ra.{step}.stats_cleared"])
+    assert m.gauss_params["normals"].shape[0] == m.gauss_params["means"].shape[0]
+    assert opts.optimizers["normals"].param_groups[0]["params"][0] is m.gauss_params["normals"]
+
+
+def test_patched_touch_and_hull_callbacks_match_reference_execution(dev):
+    """``model.add_touch_patch / touch_pruning / hull_pruning(optimizers, step)`` after patch_all against the
+    reference's own methods (reference_model.npz)."""
+    d = np.load(os.path.join(GOLD, "reference_model.npz"))
+    t = lambda k: torch.from_numpy(d[k])  # noqa: E731
+    patches = [{k: t(f"tp.patch{i}.{k}") for k in ("points_xyz", "points_rgb", "normals", "bbox")} for i in range(3)]
+    md = {"touch_patches": patches, "gel_scale_factor": 6.34e-5, "visual_hull": t("tp.hull"), "scale_factor": 1.3}
+    m, opts = _model(dev, {k: t(f"tp.in.{k}") for k in NAMES6}, step=1000, metadata=md)
+    _set_moments(m, opts, d, "tp.in_m", None, dev)
+    m.step = 999
+    m.add_touch_patch(opts, 999)  # not the configured step: nothing happens
+    assert m.add_mask is None
+    m.step = 1000
+    m.add_touch_patch(opts, 1000)
+    assert m.added_count == int(d["tp.add_mask"].sum()) and np.array_equal(m.add_mask.cpu().numpy(), d["tp.add_mask"])
+    for k in NAMES6:
+        ref = t(f"tp.added.{k}")
+        assert m.gauss_params[k].shape == ref.shape, k
+        assert torch.allclose(m.gauss_params[k].detach().cpu(), ref, atol=1e-6), k
+        assert torch.equal(opts.optimizers[k].state[m.gauss_params[k]]["exp_avg"].cpu(), t(f"tp.added_m.{k}")), k
+    assert m.xys_grad_norm is None and m.gauss_params["normals"].shape[0] == m.gauss_params["means"].shape[0]
+    m.step = 1100
+    m.gauss_params["means"].data.copy_(t("tp.before_touch_prune.means").to(dev))
+    m.touch_pruning(opts, 1100)
+    for k in NAMES6:
+        assert torch.allclose(m.gauss_params[k].detach().cpu(), t(f"tp.touch_pruned.{k}"), atol=1e-6), k
+    assert np.array_equal(m.add_mask.cpu().numpy(), d["tp.add_mask_touch_pruned"])
+    m.hull_pruning(opts, 1100)
+    for k in NAMES6:
+        assert m.gauss_params[k].shape == t(f"tp.hull_pruned.{k}").shape, k
+        assert torch.allclose(m.gauss_params[k].detach().cpu(), t(f"tp.hull_pruned.{k}"), atol=1e-6), k
+    assert np.array_equal(m.add_mask.cpu().numpy(), d["tp.add_mask_hull_pruned"])
+
+
+def test_patched_model_in_the_reference_loop_shape_trains_like_the_trainer(dev, monkeypatch):
+    """The whole patched surface driven the way nerfstudio's Trainer drives a model (callbacks before,
+    zero_grad, get_outputs, get_loss_dict, sum(loss_dict).backward(), every optimizer's step(), callbacks after) for 130
+    steps across add_touch_patch, one refinement and the two prunings — against this repo's tape-free SplatTrainer from
+    the same state: same Gaussian count after the callbacks, same anchors, parameters equal to the atomics' noise, the
+    after_train statistics applied by the backward (the reference's after_train is never reached), one Adam launch per
+    step."""
+    from fusionsense_amd import ops
+    from fusionsense_amd.losses import LossConfig, prepare_batch
+    from fusionsense_amd.splatfacto import DensifyStrategy
+    from fusionsense_amd.trainer import SplatTrainer
+    params, cams = scenes.fusionsense_like_scene(seed=0, n_hull=2000, n_bg=4000)
+    cams = [scenes.Camera(c.c2w, c.fx / 4, c.fy / 4, c.cx / 4, c.cy / 4, c.width // 4, c.height // 4) for c in cams[:3]]
+    H, W = cams[0].height, cams[0].width
+    g = torch.Generator().manual_seed(1)
+    patches = scenes.touch_patches_on_blob(2, 300, radius=0.1, seed=0)
+    hull = params["means"][:2000].clone()
+    batches = []
+    for i in range(3):
+        batches.append({"image": torch.rand(H, W, 3, generator=g).to(dev), "sensor_depth": (0.5 + torch.rand(H, W, 1, generator=g)).to(dev),
+                        "normal": torch.rand(H, W, 3, generator=g).to(dev), "mask": (torch.rand(H, W, 1, generator=g) > 0.2).to(dev),
+                        "image_idx": i})
+    start, add_at, S = 930, 990, 130
+    # -- the repo's own trainer
+    st = DensifyStrategy(SplatfactoConfig(), num_train_data=3)
+    st.set_metadata(touch_patches=patches, gel_scale_factor=6.34e-5, add_touch_at=add_at, visual_hull=hull, scale_factor=1.0)
+    tr = SplatTrainer(params, dev, sh_degree=3, strategy=st, seed=0, sh_degree_interval=1000, loss_cfg=LossConfig())
+    tr.ride_adam = False
+    tr.step = start
+    fbs = [prepare_batch({k: v for k, v in b.items() if k != "image_idx"}, LossConfig(), dev) for b in batches]
+    # -- the patched model under nerfstudio-style optimizers
+    md = {"touch_patches": patches, "gel_scale_factor": 6.34e-5, "visual_hull": hull, "scale_factor": 1.0}
+    m, opts = _model(dev, params, step=start, num_train_data=3, metadata=md, add_touch_at=add_at)
+    m._fsgs_rng = torch.Generator(device=dev)
+    m._fsgs_rng.manual_seed(0)  # (the trainer's split noise: SplatTrainer(seed=0))
+    integration.fuse_optimizers(opts)
+    launches = []
+    real = ops.adam_step_
+    monkeypatch.setattr(ops, "adam_step_", lambda *a, **k: (launches.append(len(a[0])), real(*a, **k))[1])
+    ncams = [_Cameras(c, i) for i, c in enumerate(cams)]
+    for s in range(S):
+        step = start + s
+        v = s % 3
+        tr.train_step(cams[v], fbs[v])
+        n_tr = len(launches)
+        # nerfstudio's iteration
+        m.step = step
+        m.add_touch_patch(opts, step)
+        for o in opts.optimizers.values():
+            o.zero_grad()
+        opts.optimizers["means"].param_groups[0]["lr"] = tr._means_lr(step)  # (nerfstudio's ExponentialDecayScheduler)
+        out = m.get_outputs(ncams[v])
+        ld = m.get_loss_dict(out, batches[v])
+        sum(ld.values()).backward()
+        for o in opts.optimizers.values():
+            o.step()
+        assert len(launches) == n_tr + 1 and launches[-1] == 6, (s, launches[-3:])
+        m.after_train(step)
+        if step % m.config.refine_every == 0:
+            m.refinement_after(opts, step)
+            m.hull_pruning(opts, step)
+            m.touch_pruning(opts, step)
+        if s in (0, 59, 60, 69, 70, S - 1):
+            assert m.gauss_params["means"].shape[0] == tr.num_gaussians(), (s, m.gauss_params["means"].shape, tr.num_gaussians())
+    assert m.add_mask is not None and torch.equal(m.add_mask, st.add_mask) and int(m.add_mask.sum()) == 600
+    assert tr.num_gaussians() != 6000
+    assert m.vis_counts is not None and float(m.vis_counts.max()) > 1.0, "statistics were accumulated by the backward"
+    for k in NAMES6:
+        dd = (m.gauss_params[k].data - tr.params[k].data).abs()
+        assert float((dd > 2e-5).float().mean()) < 2e-2 and math.isfinite(float(dd.max())), (k, float((dd > 2e-5).float().mean()))
+    rows = st.touch_rows()
+    assert torch.equal(m.gauss_params["means"].data[rows.long()], tr.params["means"].data[rows.long()]), "anchors never move"
