@@ -31,27 +31,28 @@ def _key(t: torch.Tensor) -> Tuple:
 
 
 def remember(means2d, depths, radii, width, height, tile_size, isect_offsets, flatten_ids, isect_ids,
-             lists_valid_for_legacy: bool, live_payload=None) -> None:
+             lists_valid_for_legacy: bool, live_payload=None, ends_on_device: bool = False) -> None:
     global _frame
     if not lists_valid_for_legacy:
         _frame = None
         return
     _frame = dict(xys=_key(means2d), depths=_key(depths), radii=_key(radii), n=radii.shape[-1],
                   dims=(int(width), int(height), int(tile_size)), offsets=isect_offsets, flat=flatten_ids,
-                  ids=isect_ids, live=live_payload)
+                  ids=isect_ids, live=live_payload, ends_on_device=bool(ends_on_device))
 
 
 def lookup(xys, depths, radii, width, height, tile_size):
-    """(isect_offsets [1,th,tw], flatten_ids [M], isect_ids [M], live_payload) of the remembered frame, or None.
-    With ``live_payload`` (the frame was binned with the live direct path) the offsets are the live lists' and the
-    other two are None."""
+    """(isect_offsets [1,th,tw], flatten_ids [M], isect_ids [M], live_payload, ends_on_device) of the remembered frame,
+    or None.  With ``live_payload`` (the frame was binned with the live direct path) the offsets are the live lists' and
+    the other two are None; ``ends_on_device``: the payload is sized for a capacity and the lists' true end is entry T
+    of the storage behind the offsets (no-wait binning, rendering.py)."""
     global hits, misses
     f = _frame
     if (enabled and f is not None and f["dims"] == (int(width), int(height), int(tile_size))
             and xys.shape[0] == f["n"] and _key(xys) == f["xys"] and _key(depths) == f["depths"]
             and _key(radii) == f["radii"]):
         hits += 1
-        return f["offsets"], f["flat"], f["ids"], f.get("live")
+        return f["offsets"], f["flat"], f["ids"], f.get("live"), f.get("ends_on_device", False)
     misses += 1
     return None
 

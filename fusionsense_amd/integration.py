@@ -368,7 +368,8 @@ class AdamFuser:
             if all(o in fuser.pending for o in fuser.live()):
                 fuser.flush()
             return None
-        step._with_counter = True
+        step._with_counter = True          # (torch < 2.2) / _wrapped_by_lr_sched (torch >= 2.2): what an LR scheduler
+        step._wrapped_by_lr_sched = True   # bound to this optimizer looks for; _step_count is kept above
         opt.step = step
 
         def zero_grad(*a, **k):

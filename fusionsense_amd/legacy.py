@@ -99,8 +99,9 @@ def rasterize_gaussians(
     th = (img_height + block_width - 1) // block_width
     cached = frame_cache.lookup(xys, depths, radii, img_width, img_height, block_width)
     live_payload = None
+    on_dev = False
     if cached is not None:
-        offsets, flatten_ids, isect_ids, live_payload = cached  # same frame: reuse the first pass's sorted lists
+        offsets, flatten_ids, isect_ids, live_payload, on_dev = cached  # same frame: reuse the first pass's sorted lists
     else:
         with torch.no_grad():
             _, isect_ids, flatten_ids, offsets, _ = ops.bin_and_sort(
@@ -119,7 +120,7 @@ def rasterize_gaussians(
         bg = torch.cat([bg, torch.zeros(pad, device=dev)])
     out, alpha, _ = ops._Rasterize.apply(
         xys[None], conics[None], cols[None], opacity.reshape(1, N), bg[None], offsets, flatten_ids,
-        int(img_width), int(img_height), int(block_width), False, isect_ids, False, live_payload)
+        int(img_width), int(img_height), int(block_width), False, isect_ids, False, live_payload, on_dev)
     out = out[0, ..., :ch]
     HOST_TIME["rasterize_gaussians_s"] += _time.perf_counter() - _t0
     HOST_TIME["rasterize_gaussians_calls"] += 1

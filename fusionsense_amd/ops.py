@@ -320,9 +320,11 @@ def bin_live_is_dense(dev, n_gaussians: int, n_tiles_total: int) -> bool:
 
 
 def bin_live_count_async(means2d: Tensor, radii: Tensor, conics: Tensor, opacities: Tensor,
-                         tile_width: int, tile_height: int) -> dict:
+                         tile_width: int, tile_height: int, capacity: int = 0) -> dict:
     """Pass 1 of the direct binning (csrc/isect.hip: fsgs_bin_live_count) WITHOUT the host wait: per-tile
-    counts of the live pairs, isect_offsets, and the live total on its way to pinned memory behind an event."""
+    counts of the live pairs, isect_offsets, and the live total on its way to pinned memory behind an event.
+    ``capacity`` > 0: the caller will not wait for the total before the second pass either (see
+    project_bin_live_count_async): the offsets are clamped to it on the device, bin_live_check looks later."""
     lib = load()
     dev = means2d.device
     Cn, N = radii.shape
@@ -332,12 +334,14 @@ def bin_live_count_async(means2d: Tensor, radii: Tensor, conics: Tensor, opaciti
     tbytes = lib.fsgs_bin_live_table_bytes(Cn, N, tile_width, tile_height)
     table = WORKSPACE.take(tbytes, dev)
     pinned = _pinned_i32(dev)  # mapped host memory: the last kernel of the call writes the total there itself
+    if capacity > 0:
+        pinned._np[2] = int(capacity)
     _run(lib.fsgs_bin_live_count, (Cn, N, ptr(means2d), ptr(radii), ptr(conics), ptr(opacities), tile_width,
                                   tile_height, ptr(tpg), ptr(offsets), ptr(table), tbytes, pinned.data_ptr(),
                                   stream_ptr(dev)), "fsgs_isect_count_live")
     ev = torch.cuda.Event()
     ev.record(torch.cuda.current_stream(dev))
-    return dict(direct=True, tpg=tpg, offsets=offsets, table=table, pinned=pinned, event=ev, T=T)
+    return dict(direct=True, tpg=tpg, offsets=offsets, table=table, pinned=pinned, event=ev, T=T, capacity=int(capacity))
 
 
 def project_bin_live_count_async(means: Tensor, quats: Tensor, log_scales: Tensor, opac_logit: Tensor,
@@ -654,9 +658,12 @@ class _Rasterize(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, means2d, conics, colors, opacities, backgrounds, isect_offsets, flatten_ids, width,
-                height, tile_size, absgrad, isect_ids=None, normalize_last=False, live_payload=None):
+                height, tile_size, absgrad, isect_ids=None, normalize_last=False, live_payload=None,
+                ends_on_device=False):
         """``live_payload`` (with ``isect_offsets`` = the LIVE lists' offsets and flatten_ids ignored): the sorted
-        live list of the frame as the direct binning leaves it (quadrant mask << 28 | flatten id) — no payload pass."""
+        live list of the frame as the direct binning leaves it (quadrant mask << 28 | flatten id) — no payload pass.
+        ``ends_on_device``: no-wait binning — ``live_payload`` is sized for a CAPACITY, ``isect_offsets`` is a
+        [C,th,tw] view of T + 1 stored entries whose last one holds the lists' true end (fsgs.h: n_isects < 0)."""
         means2d_in = means2d
         means2d, conics, colors, opacities = map(_c, (means2d, conics, colors, opacities))
         backgrounds = _c(backgrounds)
@@ -698,7 +705,9 @@ class _Rasterize(torch.autograd.Function):
                 n_rec = arena[o:o + nrec_bytes].view(torch.int32)
             else:
                 arena = records = seg_state = n_rec = None
-            _run(lib.fsgs_raster_fwd_quad, (Cn, D, ptr(packed), ptr(payload), ptr(isect_offsets), M,
+            assert not ends_on_device or live_payload is not None
+            _run(lib.fsgs_raster_fwd_quad, (Cn, D, ptr(packed), ptr(payload), isect_offsets.data_ptr(),
+                                           -M if ends_on_device else M,
                                            ptr(backgrounds), width, height, tw, th, int(normalize_last),
                                            ptr(render), ptr(alphas), ptr(last_ids), ptr(records), ptr(n_rec),
                                            ptr(seg_state), None, None, stream_ptr(dev)),
@@ -779,7 +788,7 @@ class _Rasterize(torch.autograd.Function):
             v_bg = (v_render * (1.0 - alphas)).sum(dim=(1, 2))
         ctx.means2d_obj = None
         return (v_means2d, v_conics, v_colors, v_opacities, v_bg, None, None, None, None, None, None, None,
-                None, None)
+                None, None, None)
 
 
 class _GaussianNormals(torch.autograd.Function):

@@ -17,6 +17,16 @@ from ._lib import require_gpu_tensor
 
 _RENDER_MODES = ("RGB", "D", "ED", "RGB+D", "RGB+ED")
 
+# No host wait inside rasterization() either (round 3; the tape-free step has had it since round 2): the live lists
+# are sized from the largest live-pair count this (device, C, N, image) shape has shown so far (+ 25 %), the kernels
+# take the lists' true end from the device, and the host looks at the total only after the compositing forward is
+# enqueued; a frame that exceeds the estimate is binned and composited once more with exact sizes (forward only: nothing
+# to undo).  FSGS_NO_WAIT=0 restores the wait in front of the bucket fill.
+import os as _os
+NO_WAIT = _os.environ.get("FSGS_NO_WAIT", "1") != "0"
+_LIVE_CAPS: Dict = {}
+live_overflows = 0
+
 # host seconds spent inside rasterization() / rasterize_gaussians() (library side of the drop-in route) and calls,
 # for bench.py's dropin_host_ms_per_call
 HOST_TIME = {"rasterization_s": 0.0, "rasterization_calls": 0, "rasterize_gaussians_s": 0.0, "rasterize_gaussians_calls": 0}
@@ -199,10 +209,12 @@ def rasterization(
                  and C * tile_width * tile_height <= lib.fsgs_bin_live_max_tiles())
     count = None
     rule_diff = None
+    cap_key = (str(dev), C, N, width, height)
     if live_bins:
         with torch.no_grad():
             opac_c = opac.detach().contiguous()
-            count = ops.bin_live_count_async(means2d.detach(), radii, conics.detach(), opac_c, tile_width, tile_height)
+            count = ops.bin_live_count_async(means2d.detach(), radii, conics.detach(), opac_c, tile_width, tile_height,
+                                             capacity=_LIVE_CAPS.get(cap_key, 0) if NO_WAIT else 0)
     else:
         with torch.no_grad():
             tiles_per_gauss, isect_ids, flatten_ids, isect_offsets, rule_diff = ops.bin_and_sort(
@@ -243,24 +255,29 @@ def rasterization(
     expected_depth = render_mode in ("ED", "RGB+ED")
     fused_ed = expected_depth and D in (1, 3, 4) and tile_size == 16 and ops.USE_LIVE_LISTS
     live_payload = live_offsets = None
-    if count is not None:
+    T = C * tile_width * tile_height
+
+    def bin_finish(cnt):
+        """Second binning pass + in-tile sorts -> (tiles_per_gauss, payload, offsets [C,th,tw] view, ends_on_device)."""
         with torch.no_grad():
-            tiles_per_gauss, _, live_payload, live_offsets = ops.bin_live_finish(
-                count, means2d.detach(), radii, depths.detach(), conics.detach(), opac_c, tile_width, tile_height)
-        frame_cache.remember(means2d, depths, radii, width, height, tile_size, live_offsets, None, None,
-                             lists_valid_for_legacy=(C == 1), live_payload=live_payload)
-        isect_ids = flatten_ids = None
-        isect_offsets = live_offsets
-    if D in (1, 3, 4):
-        render, alphas, last_ids = ops._Rasterize.apply(
-            means2d, conics, cols, opac, backgrounds, isect_offsets, flatten_ids, width, height, tile_size,
-            absgrad, isect_ids, fused_ed, live_payload)
-    else:
+            tpg, _, pay, offs = ops.bin_live_finish(cnt, means2d.detach(), radii, depths.detach(), conics.detach(),
+                                                    opac_c, tile_width, tile_height)
+        on_dev = bool(cnt.get("capacity", 0)) and offs.dim() == 1  # (a dense frame's fallback chain waits and is exact)
+        if on_dev:
+            offs = offs[:T].view(C, tile_height, tile_width)  # (entry T of the storage behind it: the lists' end)
+        frame_cache.remember(means2d, depths, radii, width, height, tile_size, offs, None, None,
+                             lists_valid_for_legacy=(C == 1), live_payload=pay, ends_on_device=on_dev)
+        return tpg, pay, offs, on_dev
+
+    def composite(pay, offs, on_dev):
+        if D in (1, 3, 4):
+            return ops._Rasterize.apply(means2d, conics, cols, opac, backgrounds, offs, flatten_ids, width, height,
+                                        tile_size, absgrad, isect_ids, fused_ed, pay, on_dev)
         # arbitrary channel counts: composite in chunks of <=4 channels over the same lists
         if absgrad:
             raise NotImplementedError("absgrad is defined per pixel over all channels; only D in {1,3,4}")
         outs = []
-        alphas = last_ids = None
+        alphas_ = last_ = None
         for s in range(0, D, 4):
             e = min(s + 4, D)
             w = e - s
@@ -269,11 +286,37 @@ def rasterization(
             if w == 2:
                 chunk = torch.cat([chunk, torch.zeros_like(chunk[..., :1])], dim=-1)
                 bg = torch.cat([bg, torch.zeros_like(bg[..., :1])], dim=-1) if bg is not None else None
-            r, alphas, last_ids = ops._Rasterize.apply(
-                means2d, conics, chunk.contiguous(), opac, bg, isect_offsets, flatten_ids, width, height,
-                tile_size, False, isect_ids, False, live_payload)
+            r, alphas_, last_ = ops._Rasterize.apply(
+                means2d, conics, chunk.contiguous(), opac, bg, offs, flatten_ids, width, height,
+                tile_size, False, isect_ids, False, pay, on_dev)
             outs.append(r[..., :w])
-        render = torch.cat(outs, dim=-1)
+        return torch.cat(outs, dim=-1), alphas_, last_
+
+    if count is not None:
+        isect_ids = flatten_ids = None
+        tiles_per_gauss, live_payload, live_offsets, on_dev = bin_finish(count)
+        render, alphas, last_ids = composite(live_payload, live_offsets, on_dev)
+        if on_dev:
+            # the forward is enqueued: now look at the frame's live total (it has normally long arrived)
+            global live_overflows
+            try:
+                n_live = ops.bin_live_check(count)
+            except ops.LiveListOverflow as e:  # rare: once more with exact sizes (and the wait)
+                live_overflows += 1
+                n_live = e.needed
+                with torch.no_grad():
+                    count = ops.bin_live_count_async(means2d.detach(), radii, conics.detach(), opac_c, tile_width,
+                                                     tile_height)
+                tiles_per_gauss, live_payload, live_offsets, on_dev = bin_finish(count)
+                render, alphas, last_ids = composite(live_payload, live_offsets, on_dev)
+            live_payload = live_payload[:n_live]
+        else:
+            n_live = int(live_payload.numel())
+        if NO_WAIT:
+            _LIVE_CAPS[cap_key] = max(_LIVE_CAPS.get(cap_key, 0), int(n_live * 1.25) + 4096)
+        isect_offsets = live_offsets
+    else:
+        render, alphas, last_ids = composite(None, isect_offsets, False)
 
     if expected_depth and not fused_ed:
         render = torch.cat([render[..., :-1], render[..., -1:] / alphas.clamp(min=1e-10)], dim=-1)

@@ -1053,3 +1053,50 @@ def test_sh_colours_with_differentiable_camera_pose(dev):
                              act["colors"].to(dev), vm2, K.to(dev), cam.width, cam.height, sh_degree=0,
                              render_mode="RGB+ED", packed=False)
     assert r2.shape == r.shape
+
+
+def test_rasterization_without_host_wait_is_bit_identical_and_survives_overflow(dev):
+    """rasterization() (the drop-in surface) sizes its live lists from earlier frames of the same shape and looks at
+    the frame's live total only after the compositing forward is enqueued (rendering.NO_WAIT): same images, lists and
+    gradients as the waiting path, the legacy normal pass reuses the capacity-sized lists, and a frame that exceeds a
+    (deliberately tiny) capacity is binned and composited once more with exact sizes."""
+    from fusionsense_amd import rendering
+    from fusionsense_amd.fusion import render_fusionsense
+    params, cam = scenes.cube_scene(3000, seed=12)
+
+    def run(no_wait, poison=None):
+        rendering.NO_WAIT = no_wait
+        rendering._LIVE_CAPS.clear()
+        outs = []
+        for it in range(3):
+            if poison is not None and it == 2:
+                for k in rendering._LIVE_CAPS:
+                    rendering._LIVE_CAPS[k] = poison
+            gp = {k: v.to(dev).requires_grad_(True) for k, v in params.items()}
+            o = render_fusionsense(gp, cam, sh_degree=3, device=dev)
+            (o["rgb"].sum() + o["depth"].sum() + o["normal"].sum()).backward()
+            outs.append((o, {k: p.grad.clone() for k, p in gp.items()}))
+        return outs
+
+    try:
+        ref = run(False)
+        assert not rendering._LIVE_CAPS
+        nw = run(True)
+        assert rendering._LIVE_CAPS and rendering.live_overflows == 0
+        n0 = rendering.live_overflows
+        ov = run(True, poison=64)
+        assert rendering.live_overflows == n0 + 1
+    finally:
+        rendering.NO_WAIT = True
+        rendering._LIVE_CAPS.clear()
+    for other in (nw, ov):
+        for (o0, g0), (o1, g1) in zip(ref, other):
+            for k in ("rgb", "depth", "normal", "accumulation"):
+                assert torch.equal(o0[k], o1[k]), k
+            assert torch.equal(o0["info"]["live_payload"], o1["info"]["live_payload"])
+            assert torch.equal(o0["info"]["live_offsets"], o1["info"]["live_offsets"])
+            assert torch.equal(o0["info"]["last_ids"], o1["info"]["last_ids"])
+            assert torch.equal(o0["info"]["isect_ids"], o1["info"]["isect_ids"])  # gsplat's full lists, built lazily
+            for k in g0:
+                assert rel_err(g1[k], g0[k]) < 2e-4, (k, rel_err(g1[k], g0[k]))  # (float atomics in another order)
+            assert rel_err(o1["xys"].absgrad, o0["xys"].absgrad) < 2e-4
