@@ -708,6 +708,7 @@ def main():
                        "normal_pass_list_reuse": bool(reused), "parallelism": f"dp{world}",
                        "backend": (backend if grouped else None),
                        "world_size": world, "ranks_seen": seen, "rank_devices": devices,
+                       "sharded_geometry": getattr(trainer, "_geo", None) is not None,
                        "replicas_identical_after_timed_steps": replicas_ok,
                        "launched_by": ("bench.py (child torch.distributed.run)" if os.environ.get("FSGS_BENCH_SPAWNED")
                                        else ("external launcher" if "WORLD_SIZE" in os.environ else "single process")),

@@ -237,6 +237,8 @@ def save_checkpoint(trainer, path: str) -> None:
     ``pipeline`` as ``_model.gauss_params.<name>`` and one optimizer state dict per parameter group."""
     if hasattr(trainer, "flush"):
         trainer.flush()  # a deferred feature update (data-parallel runs) must be in the parameters
+    if hasattr(trainer, "sync_optimizer_state"):
+        trainer.sync_optimizer_state()  # (sharded geometry step: a collective — every rank saves or none)
     pipeline = {_CKPT_PREFIX + k: v.detach().cpu() for k, v in trainer.params.items()}
     # gauss_params["normals"] is re-derived by every get_outputs (dn_model.py:634) but is a key of the reference's
     # state dict: the last frame's world-space normals, or zeros before the first frame
@@ -266,7 +268,7 @@ def load_checkpoint(trainer, path: str) -> int:
         opt = trainer.optimizers[name]
         opt.param_groups[0]["params"] = [new]
         opt.state.pop(old, None)
-    trainer.slab = GradSlab(trainer.params)
+    trainer.slab.rebuild(trainer.params)
     if hasattr(trainer, "mark_params_written"):
         trainer.mark_params_written()
     for name in PARAM_ORDER:
@@ -277,6 +279,8 @@ def load_checkpoint(trainer, path: str) -> int:
                 for k2, t2 in list(st.items()):
                     if torch.is_tensor(t2) and k2 != "step":
                         st[k2] = t2.to(dev)
+    if getattr(trainer, "_geo", None) is not None:
+        trainer._flatten_geometry()  # (load_state_dict replaced the moment tensors: back into the flat slabs)
     # a nerfstudio-written file has only "step" (the completed one): resume at step + 1, as its Trainer does
     trainer.step = int(ck["fsgs_next_step"]) if "fsgs_next_step" in ck else int(ck["step"]) + 1
     if "adam_steps" in ck:

@@ -60,8 +60,9 @@ def binary_opacity_active(cfg: SplatfactoConfig, step: int) -> bool:
 
 def binary_opacity_write_(opacities: Tensor, threshold: float) -> None:
     """``opacities.data = where(opacities >= thr, 1, 0)`` — in logit space, as the reference does."""
-    opacities.data = torch.where(opacities.data >= threshold, torch.ones_like(opacities.data),
-                                 torch.zeros_like(opacities.data))
+    # (written in place — the result is the reference's; the parameter may be a view of a flat slab)
+    opacities.data.copy_(torch.where(opacities.data >= threshold, torch.ones_like(opacities.data),
+                                     torch.zeros_like(opacities.data)))
 
 
 def refine_schedule(cfg: SplatfactoConfig, step: int, num_train_data: int) -> Dict[str, bool]:
@@ -290,14 +291,16 @@ class DensifyStrategy:
         if sched["reset_opacity"]:
             reset_value = cfg.cull_alpha_thresh * 2.0
             logit = torch.logit(torch.tensor(reset_value)).item()
+            if hasattr(trainer, "sync_optimizer_state"):
+                trainer.sync_optimizer_state()
             op = trainer.params["opacities"]
-            op.data = torch.clamp(op.data, max=logit)
+            op.data.clamp_(max=logit)  # (in place: the parameter may be a view of the trainer's flat geometry slab)
             if hasattr(trainer, "mark_params_written"):
                 trainer.mark_params_written()
             st = trainer.optimizers["opacities"].state.get(op, None)
             if st:
-                st["exp_avg"] = torch.zeros_like(st["exp_avg"])
-                st["exp_avg_sq"] = torch.zeros_like(st["exp_avg_sq"])
+                st["exp_avg"].zero_()
+                st["exp_avg_sq"].zero_()
 
         self.xys_grad_norm = None
         self.vis_counts = None
@@ -404,6 +407,8 @@ class DensifyStrategy:
             # a deferred feature update (data-parallel runs) is sized for the old N and reads the old slab: it must
             # land before any row moves — add_touch_patch / hull_pruning / touch_pruning run between two steps
             trainer.flush()
+        if hasattr(trainer, "sync_optimizer_state"):
+            trainer.sync_optimizer_state()  # (sharded geometry step: whole moment tensors are about to be compacted)
         keep8 = keep_old.to(torch.uint8).contiguous()
         positions = ops.mask_positions(keep8)
         n_final = n_keep_old + n_keep_new

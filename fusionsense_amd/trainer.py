@@ -44,27 +44,56 @@ class OptimConfig:
     means_lr_max_steps: int = 30000
 
 
-class GradSlab:
-    """All parameter gradients as views into one flat fp32 buffer (one collective per step)."""
+def _adam_range_torch(p: Tensor, g: Tensor, m: Tensor, v: Tensor, lr: float, step: int, b1: float, b2: float,
+                      eps: float) -> None:
+    """torch.optim.Adam's single-tensor update (amsgrad off, no weight decay) on flat ranges — the host-side twin of
+    fsgs_adam_step for the CPU (gloo) tests of the sharded step."""
+    m.lerp_(g, 1 - b1)
+    v.mul_(b2).addcmul_(g, g, value=1 - b2)
+    bc1, bc2 = 1 - b1 ** step, 1 - b2 ** step
+    denom = (v.sqrt() / math.sqrt(bc2)).add_(eps)
+    p.addcdiv_(m, denom, value=-(lr / bc1))
 
-    def __init__(self, params: Dict[str, torch.nn.Parameter]):
+
+class GradSlab:
+    """All parameter gradients as views into one flat fp32 buffer (one collective per step).
+
+    ``align`` / ``world`` (sharded geometry step, SplatTrainer._reduce_and_step): every geometry group then starts at a
+    multiple of ``align`` floats and the geometry half's length is a multiple of ``align * world``, so that the half
+    splits into ``world`` equal shards whose intersections with the groups are 16-byte aligned ranges; ``geo_ranges``
+    lists the groups' (name, start, numel) inside the half.  Padding floats stay zero."""
+
+    def __init__(self, params: Dict[str, torch.nn.Parameter], align: int = 1, world: int = 1, on_rebuild=None,
+                 after_rebuild=None):
+        self.align, self.world = int(align), int(world)
+        self.on_rebuild, self.after_rebuild = on_rebuild, after_rebuild
         self.rebuild(params)
 
     def rebuild(self, params: Dict[str, torch.nn.Parameter]) -> None:
-        total = sum(p.numel() for p in params.values())
+        if self.on_rebuild is not None:
+            self.on_rebuild(params)  # (may change align / world: the trainer decides the layout from N)
+        up = lambda x, a: (x + a - 1) // a * a  # noqa: E731
+        offs, off = {}, 0
+        for name in GEOMETRY_GROUPS:
+            off = up(off, self.align)
+            offs[name] = off
+            off += params[name].numel()
+        self.split = up(off, self.align * self.world)  # first element of the feature half
+        self.geo_ranges = [(name, offs[name], params[name].numel()) for name in GEOMETRY_GROUPS]
+        off = self.split
+        for name in FEATURE_GROUPS:
+            offs[name] = off
+            off += params[name].numel()
         dev = next(iter(params.values())).device
-        self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
-        off = 0
+        self.flat = torch.zeros(off, dtype=torch.float32, device=dev)
         self.views = {}
-        self.split = 0  # first element of the feature half
         for name in SLAB_ORDER:
             p = params[name]
-            if name == FEATURE_GROUPS[0]:
-                self.split = off
-            v = self.flat[off:off + p.numel()].view_as(p)
+            v = self.flat[offs[name]:offs[name] + p.numel()].view_as(p)
             self.views[name] = v
             p.grad = v
-            off += p.numel()
+        if self.after_rebuild is not None:
+            self.after_rebuild()  # (the trainer re-creates its flat parameter / moment slabs for the new layout)
 
     def zero_(self) -> None:
         self.flat.zero_()
@@ -160,7 +189,23 @@ class SplatTrainer:
         if self.torch_optimizers and fuse_torch_optimizers:
             from .integration import fuse_optimizers
             self.adam_fuser = fuse_optimizers(self.optimizers, PARAM_ORDER)
-        self.slab = GradSlab(self._params)
+        # Sharded geometry step (data-parallel runs of large scenes): instead of all-reducing the geometry
+        # half of the slab and running Adam on all of it on every rank, the half is REDUCE-SCATTERED (each rank receives
+        # the mean gradient of its 1/W shard), Adam runs on the owned shard only, and the updated PARAMETERS are
+        # all-gathered — the same bytes on the links as the all-reduce, 1/W of the geometry's Adam traffic per rank
+        # (28 B per parameter float), and replicas that are bit-identical by construction.  The four geometry parameters
+        # and their Adam moments then live in flat, padded slabs with the gradient slab's layout (``_geo``).
+        # FSGS_SHARDED_GEOMETRY: "auto" (default) = with several ranks and at least 2^20 Gaussians, "1" = whenever a
+        # group exists, "0" = never.
+        self.sharded_geometry_mode = os.environ.get("FSGS_SHARDED_GEOMETRY", "auto")
+        self.sharded_min_n = 1 << 20
+        self._geo = None            # dict(P, M, V flat slabs, shard bounds) while the sharded layout is active
+        self._moments_local = False  # moments outside the owned shard are stale until sync_optimizer_state()
+        self.half_attributes = bool(half_attributes)
+        self.slab = None
+        self.slab = GradSlab(self._params, on_rebuild=self._choose_layout, after_rebuild=self._flatten_geometry)
+        if self._want_sharded(self.num_gaussians()):
+            self.slab.rebuild(self._params)  # (now that the slab exists: the padded layout + the flat slabs)
         # Data-parallel runs: the SH features' share of the all-reduce (81 % of the slab) and their Adam launch are
         # deferred until the next frame needs the colours, i.e. they overlap that frame's projection, binning and
         # sort, which read geometry only (exact: every parameter still sees its fully reduced gradient before its
@@ -210,6 +255,108 @@ class SplatTrainer:
         self.rng = torch.Generator(device=device)
         self.rng.manual_seed(seed)
         self.last_info = None
+
+    # -- sharded geometry step -------------------------------------------------------------------------------------
+    def _want_sharded(self, n: int) -> bool:
+        mode = getattr(self, "sharded_geometry_mode", "0")
+        if mode == "0" or self.half_attributes or not GradSlab._exchange():
+            return False
+        return mode == "1" or (GradSlab._world() > 1 and n >= self.sharded_min_n)
+
+    def _choose_layout(self, params) -> None:
+        """GradSlab.on_rebuild: the slab's layout follows the step the trainer will run for this N."""
+        if self.slab is None:
+            return  # (first build: GradSlab.__init__ is still running; _init_layout below sets it and rebuilds)
+        sh = self._want_sharded(params["means"].shape[0])
+        self.slab.align, self.slab.world = (64, GradSlab._world()) if sh else (1, 1)
+
+    def _flatten_geometry(self) -> None:
+        """(Re-)creates the flat parameter / moment slabs of the geometry half after the parameters were (re)built:
+        every geometry parameter becomes a view into ``P`` and its Adam moments views into ``M`` / ``V``, at the
+        gradient slab's offsets.  No-op (and back to ordinary tensors) when the sharded step is not in use."""
+        sl = self.slab
+        if sl is None or sl.align == 1:
+            self._geo = None
+            self._moments_local = False
+            return
+        dev = sl.flat.device
+        L, W, r = sl.split, sl.world, (dist.get_rank() if GradSlab._exchange() else 0)
+        P, M, V = (torch.zeros(L, dtype=torch.float32, device=dev) for _ in range(3))
+        for name, off, n in sl.geo_ranges:
+            old = self._params[name]
+            opt = self.optimizers[name]
+            st = opt.state.pop(old, None)
+            P[off:off + n].copy_(old.data.reshape(-1))
+            new = torch.nn.Parameter(P[off:off + n].view_as(old))
+            new.grad = sl.views[name]
+            st = st if st else {"step": torch.tensor(0.0)}
+            for key, flat in (("exp_avg", M), ("exp_avg_sq", V)):
+                if key in st:
+                    flat[off:off + n].copy_(st[key].reshape(-1))
+                st[key] = flat[off:off + n].view_as(old)
+            opt.state[new] = st
+            opt.param_groups[0]["params"] = [new]
+            self._params[name] = new
+        shard = L // W
+        self._geo = dict(P=P, M=M, V=V, shard=shard, lo=r * shard, hi=(r + 1) * shard,
+                         grad=torch.zeros(shard, dtype=torch.float32, device=dev))
+        self._moments_local = False
+
+    def sync_optimizer_state(self) -> None:
+        """Sharded geometry step: every rank has updated the Adam moments of its own shard only; before anything reads
+        or moves whole moment tensors (densification surgery, opacity reset, checkpoints) the shards are all-gathered.
+        A collective: every rank calls it at the same point (the callers are deterministic in the step number)."""
+        g = self._geo
+        if g is None or not self._moments_local:
+            return
+        for flat in (g["M"], g["V"]):
+            self._all_gather_shards(flat, g)
+        self._moments_local = False
+
+    def _all_gather_shards(self, flat: Tensor, g) -> None:
+        if not GradSlab._exchange():
+            return
+        mine = flat[g["lo"]:g["hi"]]
+        if dist.get_backend() == "nccl":
+            dist.all_gather_into_tensor(flat, mine)  # in place: the input is the output's own slice (RCCL's in-place form)
+        else:
+            dist.all_gather(list(flat.view(self.slab.world, g["shard"]).unbind(0)), mine.clone())
+
+    def _sharded_geometry_step(self) -> int:
+        """reduce-scatter (mean) of the geometry half -> Adam on the owned shard -> all-gather of the parameters."""
+        g, sl = self._geo, self.slab
+        W = sl.world
+        geo = sl.flat[:sl.split]
+        if GradSlab._exchange():
+            if dist.get_backend() == "nccl":
+                dist.reduce_scatter_tensor(g["grad"], geo, op=dist.ReduceOp.AVG)
+            else:  # gloo has no reduce-scatter: the functional stand-in (CPU tests, ranks sharing a GPU)
+                dist.all_reduce(geo, op=dist.ReduceOp.SUM)
+                torch.mul(geo[g["lo"]:g["hi"]], 1.0 / W, out=g["grad"])
+        else:
+            g["grad"].copy_(geo[g["lo"]:g["hi"]])
+        self.adam_steps = getattr(self, "adam_steps", 0) + 1
+        step_no = self.adam_steps
+        ps, gs, ms, vs, lrs = [], [], [], [], []
+        for name, off, n in sl.geo_ranges:
+            st = self.optimizers[name].state[self._params[name]]
+            st["step"] += 1
+            a, b = max(off, g["lo"]), min(off + n, g["hi"])
+            if a >= b:
+                continue
+            ps.append(g["P"][a:b]); gs.append(g["grad"][a - g["lo"]:b - g["lo"]])
+            ms.append(g["M"][a:b]); vs.append(g["V"][a:b])
+            lrs.append(self.optimizers[name].param_groups[0]["lr"])
+        if ps:
+            if self.device.type == "cuda":
+                from .ops import adam_step_
+                adam_step_(ps, gs, ms, vs, lrs, step_no, 0.9, 0.999, self.optim_cfg.eps)
+            else:
+                for p_, g_, m_, v_, lr in zip(ps, gs, ms, vs, lrs):
+                    _adam_range_torch(p_, g_, m_, v_, lr, step_no, 0.9, 0.999, self.optim_cfg.eps)
+        self._all_gather_shards(g["P"], g)
+        self._moments_local = W > 1
+        return step_no
 
     # -- schedule: ExponentialDecayScheduler on the means group (dn_config.py:38-41) --------
     def _means_lr(self, step: int) -> float:
@@ -434,12 +581,15 @@ class SplatTrainer:
         assert self._pending is None, "the previous step's feature update has not been flushed"
         split = self._split_step(optimizer_step)
         if not split:
+            self.sync_optimizer_state()  # (a full Adam step must not read moments that are stale outside the own shard)
             self.slab.all_reduce_mean_()
             if optimizer_step:
                 self.optimizers["means"].param_groups[0]["lr"] = self._means_lr(self.step)
                 self._optimizer_step(PARAM_ORDER)
             return
-        self.slab.all_reduce_geometry_mean_()
+        sharded = self._geo is not None
+        if not sharded:
+            self.slab.all_reduce_geometry_mean_()
         factors = getattr(self, "_factors_used", None)
         self._factors_used = None
         if factors is not None:
@@ -469,7 +619,7 @@ class SplatTrainer:
         else:
             finish = self.slab.all_reduce_features_async()
         self.optimizers["means"].param_groups[0]["lr"] = self._means_lr(self.step)
-        step_no = self._optimizer_step(GEOMETRY_GROUPS)
+        step_no = self._sharded_geometry_step() if sharded else self._optimizer_step(GEOMETRY_GROUPS)
         self._pending = (finish, step_no)
 
     def flush(self) -> None:

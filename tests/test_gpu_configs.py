@@ -436,15 +436,17 @@ def test_config4_backward_linear_and_steps_allocation_free(dev, config4):
     assert st.vis_counts is not None and float(st.vis_counts.max()) >= 2.0
 
 
-def test_config4_two_ranks_scaled_down():
+@pytest.mark.parametrize("sharded", ["0", "1"])
+def test_config4_two_ranks_scaled_down(sharded):
     """Config #4's data-parallel layout (view-sharded, one 1080p view per rank per step, geometry all-reduce + SH
     factors all-gather) with 2 ranks sharing this GPU over gloo, 200 k Gaussians: bench.py as the driver launches it;
     the ranks end with bit-identical replicas and the line carries the exchange's size."""
     from helpers import run_bench_ranks
     line, err = run_bench_ranks(2, ["--config", "4", "--n-gauss", "200000", "--views", "4", "--steps", "4", "--warmup", "1",
                                     "--no-cpu-baseline"],
-                                dict(FSGS_DIST_BACKEND="gloo", FSGS_BENCH_CHECK_REPLICAS="1"))
+                                dict(FSGS_DIST_BACKEND="gloo", FSGS_BENCH_CHECK_REPLICAS="1", FSGS_SHARDED_GEOMETRY=sharded))
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0
+    assert line["config"]["sharded_geometry"] is (sharded == "1")
     assert line["config"]["baseline_config"] == 4 and line["config"]["width"] == 1920
     assert line["config"]["comm_bytes_per_step_per_rank"] > 0 and line["config"]["backend"] == "gloo"
     assert err.count("replicas identical") == 2, err[-2000:]
@@ -510,6 +512,15 @@ def test_rccl_collectives_of_the_multi_gpu_step_in_a_one_rank_group():
     for name in a:  # (float atomics: equal to rounding; a missing or doubled update would move these by percents)
         assert abs(a[name][1] - b[name][1]) <= 1e-4 * abs(b[name][1]) + 1e-7, (name, a[name], b[name])
         assert abs(a[name][0] - b[name][0]) <= 1e-4 * abs(b[name][1]) + 1e-7, (name, a[name], b[name])
+    # the sharded geometry step's RCCL calls (reduce_scatter_tensor AVG, the in-place all_gather_into_tensor of the
+    # parameter slab): identities in a one-rank group, the same training
+    shard, err3 = run_bench_ranks(1, args, dict(FSGS_FORCE_COLLECTIVES="1", FSGS_FORCE_SPLIT_STEP="1", FSGS_SHARDED_GEOMETRY="1",
+                                                FSGS_BENCH_CHECK_REPLICAS="1", FSGS_BENCH_PARAM_DIGEST="1"))
+    assert shard["config"]["backend"] == "nccl" and shard["config"]["sharded_geometry"] is True
+    c = dig(err3)
+    for name in c:
+        assert abs(c[name][1] - b[name][1]) <= 1e-4 * abs(b[name][1]) + 1e-7, (name, c[name], b[name])
+        assert abs(c[name][0] - b[name][0]) <= 1e-4 * abs(b[name][1]) + 1e-7, (name, c[name], b[name])
 
 
 # ---------------------------------------------------------------------------------------------------------------

@@ -596,7 +596,7 @@ def test_training_with_densification_converges(dev):
         assert bool(torch.isfinite(p_.data).all()), k
 
 
-@pytest.mark.parametrize("mode", ["factored_deferred", "plain"])
+@pytest.mark.parametrize("mode", ["factored_deferred", "plain", "sharded_geometry"])
 def test_two_ranks_with_densification_stay_identical(mode):
     """tests/dp_soak_worker.py under torch.distributed.run: 2 ranks (gloo, both on this GPU) train different views
     for 300 steps with splits / culls / opacity resets on; at the end both hold the same number of Gaussians and
@@ -605,7 +605,10 @@ def test_two_ranks_with_densification_stay_identical(mode):
     import os, signal, socket, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, FSGS_DEFER_FEATURES="0" if mode == "plain" else "1",
-               FSGS_FACTORED_FEATURES="0" if mode == "plain" else "1")
+               FSGS_FACTORED_FEATURES="0" if mode == "plain" else "1",
+               # reduce-scatter -> Adam on the owned shard -> all-gather for the geometry half, with the flat parameter /
+               # moment slabs re-created after every split / cull and the moments gathered before each surgery
+               FSGS_SHARDED_GEOMETRY="1" if mode == "sharded_geometry" else "0")
     out = ""
     for attempt in range(2):
         s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
@@ -622,6 +625,7 @@ def test_two_ranks_with_densification_stay_identical(mode):
             assert attempt == 0, "2-rank run hung twice:\n" + out[-3000:]
     assert p.returncode == 0, out[-3000:]
     assert out.count(": ok, N ") == 2, out[-2000:]
+    assert out.count("sharded=True" if mode == "sharded_geometry" else "sharded=False") == 2, out[-2000:]
 
 
 def test_no_wait_step_is_bit_identical_and_survives_overflow(dev, full_scene):

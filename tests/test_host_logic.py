@@ -765,3 +765,88 @@ def test_dataparser_matches_reference_execution(tmp_path, variant, monkeypatch):
         assert b["sensor_depth"].dtype == torch.float32
         assert np.array_equal(b["sensor_depth"].numpy(), g(f"batch{idx}.sensor_depth").astype(np.float32)), idx
         assert np.array_equal(b["normal"].numpy(), g(f"batch{idx}.normal")), idx
+
+
+_SHARD_WORKER = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+rank = int(os.environ["RANK"]); world = int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d", rank=rank, world_size=world)
+from fusionsense_amd.trainer import SplatTrainer, PARAM_ORDER, GEOMETRY_GROUPS
+torch.manual_seed(0)
+n = 45
+shapes = dict(means=(n,3), scales=(n,3), quats=(n,4), features_dc=(n,3), features_rest=(n,15,3), opacities=(n,1))
+init = {k: torch.randn(*shapes[k]) for k in PARAM_ORDER}
+dev = torch.device("cpu")
+os.environ["FSGS_SHARDED_GEOMETRY"] = "1"
+a = SplatTrainer(init, dev, fused=False)   # reduce-scatter -> Adam on the owned shard -> all-gather of the parameters
+os.environ["FSGS_SHARDED_GEOMETRY"] = "0"
+b = SplatTrainer(init, dev, fused=False)   # all-reduce -> Adam on everything
+assert a._geo is not None and b._geo is None
+assert a.slab.align == 64 and a.slab.split %% (64 * world) == 0 and b.slab.split == n * 11
+for name, off, cnt in a.slab.geo_ranges:
+    assert off %% 64 == 0 and a.params[name].data.data_ptr() == a._geo["P"].data_ptr() + 4 * off
+def grads(tr, it):
+    for i, k in enumerate(PARAM_ORDER):
+        tr.slab.views[k].copy_(torch.sin(tr.params[k].data * (i + 1) + it) * (rank + 1) + 0.1 * rank)
+for it in range(5):
+    grads(a, it); grads(b, it)
+    a._reduce_and_step(True); b._reduce_and_step(True)
+    assert a._moments_local
+    a.flush(); b.flush()
+    a.step += 1; b.step += 1
+    for k in PARAM_ORDER:
+        assert torch.allclose(a.params[k].data, b.params[k].data, rtol=1e-6, atol=1e-7), (it, k)
+# the moments of the other rank's shard are stale until they are gathered
+lo, hi = a._geo["lo"], a._geo["hi"]
+stale = False
+for name, off, cnt in a.slab.geo_ranges:
+    sa = a.optimizers[name].state[a.params[name]]["exp_avg"].reshape(-1)
+    sb = b.optimizers[name].state[b.params[name]]["exp_avg"].reshape(-1)
+    for j in range(cnt):
+        inside = lo <= off + j < hi
+        same = torch.allclose(sa[j], sb[j], rtol=1e-5, atol=1e-8)
+        assert same or not inside, (name, j)
+        stale |= (not same)
+assert stale
+a.sync_optimizer_state()
+assert not a._moments_local
+for k in PARAM_ORDER:
+    sa, sb = a.optimizers[k].state[a.params[k]], b.optimizers[k].state[b.params[k]]
+    assert torch.allclose(sa["exp_avg"], sb["exp_avg"], rtol=1e-5, atol=1e-8), k
+    assert torch.allclose(sa["exp_avg_sq"], sb["exp_avg_sq"], rtol=1e-5, atol=1e-10), k
+    assert float(sa["step"]) == float(sb["step"]) == 5.0
+# a step without the deferred split (no optimizer step / a full step) first gathers the moments, then runs on everything
+grads(a, 7); grads(b, 7)
+a.defer_features = b.defer_features = False
+a._reduce_and_step(True); b._reduce_and_step(True)
+for k in PARAM_ORDER:
+    assert torch.allclose(a.params[k].data, b.params[k].data, rtol=1e-6, atol=1e-7), k
+# replicas: bit-identical across the ranks (the all-gather hands every rank the same bytes)
+for k in PARAM_ORDER:
+    t = a.params[k].data.clone(); dist.broadcast(t, 0)
+    assert torch.equal(t, a.params[k].data), k
+dist.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+def test_sharded_geometry_step_equals_allreduce_step_gloo_world2():
+    """Data-parallel step with the geometry half reduce-scattered, Adam on the owned shard and the updated parameters
+    all-gathered (trainer._sharded_geometry_step; gloo stands in for RCCL's reduce-scatter) against all-reduce + Adam
+    on everything: same parameters every step, moments equal once gathered, padded 64-float-aligned layout, flat
+    parameter slab, replicas bit-identical."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    code = _SHARD_WORKER % (ROOT, port)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    for p in procs:
+        out, err = p.communicate(timeout=180)
+        assert p.returncode == 0 and "ok" in out, err[-3000:]
