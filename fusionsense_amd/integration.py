@@ -179,7 +179,7 @@ def get_loss_dict_fused(self, outputs, batch, metrics_dict=None) -> Dict[str, to
     touch_idx = touch_normals = None
     add_mask = getattr(self, "add_mask", None)
     if add_mask is not None:
-        touch_idx = torch.nonzero(add_mask.to(rgb.device), as_tuple=False).reshape(-1).to(torch.int32).contiguous()
+        touch_idx = torch.nonzero(add_mask.to(rgb.device), as_tuple=False).reshape(-1).contiguous()  # int64 rows
         tn = self.__dict__.get("_fsgs_touch_normals")
         if tn is None or tn.shape[0] != touch_idx.numel():
             tn = torch.cat([tp["normals"].to(rgb.device) for tp in self.kwargs["metadata"]["touch_patches"]], dim=0)

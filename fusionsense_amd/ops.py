@@ -1196,6 +1196,10 @@ class _FusionLoss(torch.autograd.Function):
         H, W = fb.height, fb.width
         N = log_scales.shape[0]
         n_touch = 0 if touch_idx is None else int(touch_idx.numel())
+        if n_touch and (touch_idx.dtype != torch.int64 or not touch_idx.is_cuda):
+            raise ValueError("touch_idx must be an int64 tensor of row indices on the GPU (fsgs_touch_normal_sqerr)")
+        if n_touch and (normals_world is None or touch_normals is None or touch_normals.shape[0] != n_touch):
+            raise ValueError("touch anchors need normals_world [N,3] and touch_normals [n_touch,3]")
         (g_l1, g_ssim), w_aux, g_min, g_touch = fusion_loss_weights(cfg, fb, N, n_touch)
         f32 = dict(dtype=torch.float32, device=dev)
         maps = torch.empty(3, H, W, 3, **f32)
