@@ -220,11 +220,9 @@ __device__ __forceinline__ void sort128(uint64_t &e0, uint64_t &e1, int lane) {
 // where they lie (L1-bypassing loads/stores, missing words act as +inf without being stored: slow, for
 // tiles too dense for LDS — the caller keeps the global radix sort for scenes that dense).
 template <int THREADS, int CAP, int LO, bool SPILL>
-__global__ void __launch_bounds__(THREADS)
-tile_sort_kernel2(int n_tiles, int tile_bits, const int32_t *__restrict__ offsets, uint64_t *__restrict__ buckets,
-                  int32_t *__restrict__ payload_out, int64_t *__restrict__ isect_ids_out) {
-    extern __shared__ __attribute__((aligned(16))) uint64_t sk[];
-    const int tile_lin = blockIdx.x;
+__device__ __forceinline__ void
+tile_sort_body(uint64_t *sk, const int tile_lin, int n_tiles, int tile_bits, const int32_t *__restrict__ offsets,
+               uint64_t *__restrict__ buckets, int32_t *__restrict__ payload_out, int64_t *__restrict__ isect_ids_out) {
     const int s = offsets[tile_lin], e = offsets[tile_lin + 1];
     const int n = e - s;
     if (n <= LO || (CAP > 0 && !SPILL && n > CAP)) return;
@@ -324,6 +322,31 @@ tile_sort_kernel2(int n_tiles, int tile_bits, const int32_t *__restrict__ offset
     for (int i = tid; i < n; i += THREADS) emit(i, ld(i));
 }
 
+template <int THREADS, int CAP, int LO, bool SPILL>
+__global__ void __launch_bounds__(THREADS)
+tile_sort_kernel2(int n_tiles, int tile_bits, const int32_t *__restrict__ offsets, uint64_t *__restrict__ buckets,
+                  int32_t *__restrict__ payload_out, int64_t *__restrict__ isect_ids_out) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t sk[];
+    tile_sort_body<THREADS, CAP, LO, SPILL>(sk, blockIdx.x, n_tiles, tile_bits, offsets, buckets, payload_out,
+                                            isect_ids_out);
+}
+
+// The same over a list of buckets whose LENGTH lives on the device (`n_sub`: the sub-buckets the depth-slab split
+// produced for the few tiles too large for the in-LDS split + sort): a fixed grid strides over them, so a frame
+// without such tiles costs a handful of workgroups instead of one early-out workgroup per possible sub-bucket.
+template <int THREADS, int CAP, int LO, bool SPILL>
+__global__ void __launch_bounds__(THREADS)
+tile_sort_strided_kernel(const int32_t *__restrict__ n_sub, int n_tiles, int tile_bits,
+                         const int32_t *__restrict__ offsets, uint64_t *__restrict__ buckets,
+                         int32_t *__restrict__ payload_out) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t sk[];
+    const int limit = *n_sub;
+    for (int b = blockIdx.x; b < limit; b += gridDim.x) {
+        tile_sort_body<THREADS, CAP, LO, SPILL>(sk, b, n_tiles, tile_bits, offsets, buckets, payload_out, nullptr);
+        __syncthreads();  // (the next bucket reuses the LDS words)
+    }
+}
+
 constexpr int kTsSmall = 1024, kTsLarge = 8192;  // LDS words per tile: 8 KB x 8 workgroups, 64 KB x 2 per CU
 inline int64_t ts_blocks(int64_t n) { return (n + kTsBlockKeys - 1) / kTsBlockKeys; }
 
@@ -362,7 +385,7 @@ __device__ __host__ inline int split_slabs(int n) {
 
 // sub_base[t] = number of sub-buckets in front of tile t, sub_base[T] = their total   (one workgroup)
 __global__ void __launch_bounds__(1024)
-split_base_kernel(int T, const int32_t *__restrict__ offsets, int32_t *__restrict__ sub_base) {
+split_base_kernel(int T, const int32_t *__restrict__ offsets, int32_t *__restrict__ sub_base, int lds_cap) {
     __shared__ int wsum[16];
     __shared__ int carry_s;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -370,7 +393,11 @@ split_base_kernel(int T, const int32_t *__restrict__ offsets, int32_t *__restric
     __syncthreads();
     for (int base = 0; base < T; base += 1024) {
         const int i = base + tid;
-        const int v = (i < T) ? split_slabs(offsets[i + 1] - offsets[i]) : 0;
+        int v = 0;
+        if (i < T) {
+            const int n_i = offsets[i + 1] - offsets[i];
+            v = (n_i <= lds_cap) ? 0 : split_slabs(n_i);  // (tiles the in-LDS split + sort has taken: no sub-buckets)
+        }
         int inc = v;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
@@ -411,7 +438,8 @@ split_slabs_kernel(int T, const int32_t *__restrict__ offsets, const int32_t *__
         const int total = offsets[T];
         for (int i = sub_base[T] + tid; i <= max_sub; i += kSplitThreads) sub_offsets[i] = total;
     }
-    if (S <= 1) {
+    if (S == 0) return;  // (sorted by tile_split_sort_lds_kernel)
+    if (S == 1) {
         for (int i = tid; i < n; i += kSplitThreads) out[s + i] = in[s + i];
         if (tid == 0) sub_offsets[sb] = s;
         return;
@@ -473,21 +501,204 @@ split_slabs_kernel(int T, const int32_t *__restrict__ offsets, const int32_t *__
     }
 }
 
+// ---- depth slabs in LDS: split + sort of a whole tile in ONE workgroup (round 3) ---------------------------------
+// Dense scenes (BASELINE configs #4 / #5: thousands of live pairs per tile) went bucket -> split_slabs_kernel (three
+// reads of the bucket, one scattered 8-byte write per word to a second global buffer) -> tile_sort (read + sort +
+// write): 1.07 ms of a 6.3 ms step at 6 M Gaussians.  A bucket of up to kLdsCap words fits the LDS of one workgroup
+// together with its depth histogram, so the same algorithm runs without the intermediate buffer: every thread keeps
+// its 8 words in registers, the 2048-bin histogram of the (linearised) depth and its scan give quantile slabs of
+// ~kLdsTarget words, the words are scattered into LDS slab by slab, and every WAVE sorts whole slabs of <= 128 words
+// in registers (sort128: no barrier) and writes the payload from there.  Slabs that a depth cluster pushed beyond 128
+// words are sorted by the whole workgroup in LDS afterwards.  The slab of a word is a monotone function of its depth
+// and the words of a slab are sorted on (depth, id): the result is the sorted tile, bit for bit what the bitonic
+// tiers produce.
+constexpr int kLdsCap = 8192, kLdsThreads = 1024, kLdsItems = kLdsCap / kLdsThreads, kLdsTarget = 80;
+constexpr int kLdsMaxSlabs = kLdsCap / kLdsTarget + 2;
+
+struct LdsSplitShared {
+    int hist[kSplitBins];            // words per depth bin, then words in front of the bin
+    int start[kLdsMaxSlabs + 1];     // first word of every slab; start[S] = n
+    int cursor[kLdsMaxSlabs];
+    unsigned int red_min[kLdsThreads / 64], red_max[kLdsThreads / 64];
+    int wsum[kLdsThreads / 64];
+};
+
+__global__ void __launch_bounds__(kLdsThreads)
+tile_split_sort_lds_kernel(const int32_t *__restrict__ offsets, const uint64_t *__restrict__ buckets,
+                           int32_t *__restrict__ payload_out) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t sk[];  // kLdsCap words, then LdsSplitShared
+    LdsSplitShared &L = *reinterpret_cast<LdsSplitShared *>(sk + kLdsCap);
+    const int t = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int s = offsets[t], n = offsets[t + 1] - s;
+    if (n <= 0 || n > kLdsCap) return;  // (larger tiles: the global depth-slab split, launch_split_sort)
+    auto emit = [&](int pos, uint64_t k) {
+        const uint32_t lo32 = (uint32_t)(k & 0xFFFFFFFFull);
+        payload_out[(int64_t)s + pos] = (int32_t)(((lo32 & 0xFu) << 28) | (lo32 >> 4));
+    };
+    const uint64_t *g = buckets + s;
+    if (n <= 128) {  // one wave, one register sort
+        if (w == 0) {
+            uint64_t e0 = lane < n ? g[lane] : ~0ull, e1 = lane + 64 < n ? g[lane + 64] : ~0ull;
+            sort128(e0, e1, lane);
+            if (lane < n) emit(lane, e0);
+            if (lane + 64 < n) emit(lane + 64, e1);
+        }
+        return;
+    }
+    // the thread's words (all loads in flight together) and the bucket's depth range
+    uint64_t word[kLdsItems];
+    unsigned int lo = 0xFFFFFFFFu, hi = 0u;
+#pragma unroll
+    for (int k = 0; k < kLdsItems; ++k) {
+        const int i = tid + k * kLdsThreads;
+        word[k] = i < n ? g[i] : ~0ull;
+    }
+#pragma unroll
+    for (int k = 0; k < kLdsItems; ++k) {
+        if (tid + k * kLdsThreads < n) {
+            const unsigned int d = (unsigned int)(word[k] >> 32);
+            lo = min(lo, d); hi = max(hi, d);
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        lo = min(lo, (unsigned int)__shfl_xor((int)lo, d, 64));
+        hi = max(hi, (unsigned int)__shfl_xor((int)hi, d, 64));
+    }
+    if (lane == 0) { L.red_min[w] = lo; L.red_max[w] = hi; }
+    for (int k = tid; k < kSplitBins; k += kLdsThreads) L.hist[k] = 0;
+    const int S = (n - 1) / kLdsTarget + 1;  // <= kLdsMaxSlabs - 1
+    for (int k = tid; k <= S; k += kLdsThreads) L.start[k] = n;  // slabs no bin opens stay empty at the end
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kLdsThreads / 64; ++k) { lo = min(lo, L.red_min[k]); hi = max(hi, L.red_max[k]); }
+    // bin = floor((d - lo) * 2048 / span) in float: rounding cannot break monotonicity (u32 -> f32 conversion, a
+    // product with a positive constant and the truncation are all non-decreasing), and only monotonicity matters
+    const float scale = (float)kSplitBins / ((float)(hi - lo) + 1.0f);
+    auto bin_of = [&](unsigned int d) -> int {
+        return min((int)(__uint2float_rz(d - lo) * scale), kSplitBins - 1);
+    };
+    int bin[kLdsItems];
+#pragma unroll
+    for (int k = 0; k < kLdsItems; ++k) {
+        bin[k] = 0;
+        if (tid + k * kLdsThreads < n) {
+            bin[k] = bin_of((unsigned int)(word[k] >> 32));
+            atomicAdd(&L.hist[bin[k]], 1);
+        }
+    }
+    __syncthreads();
+    {   // exclusive scan of the 2048 bin counts: two per thread
+        const int v0 = L.hist[2 * tid], v1 = L.hist[2 * tid + 1];
+        int inc = v0 + v1;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(inc, d, 64);
+            if (lane >= d) inc += o;
+        }
+        if (lane == 63) L.wsum[w] = inc;
+        __syncthreads();
+        int run = inc - (v0 + v1);
+        for (int k = 0; k < w; ++k) run += L.wsum[k];
+        L.hist[2 * tid] = run;
+        L.hist[2 * tid + 1] = run + v0;
+    }
+    __syncthreads();
+    // bin b opens the slabs in (slab of the bin in front of it, slab(b)]: their first word is the bin's first word
+    for (int b = tid; b < kSplitBins; b += kLdsThreads) {
+        const int sl = min(L.hist[b] / kLdsTarget, S - 1);
+        const int before = (b == 0) ? -1 : min(L.hist[b - 1] / kLdsTarget, S - 1);
+        for (int k = before + 1; k <= sl; ++k) L.start[k] = L.hist[b];
+    }
+    __syncthreads();
+    for (int k = tid; k < S; k += kLdsThreads) L.cursor[k] = L.start[k];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kLdsItems; ++k) {
+        if (tid + k * kLdsThreads < n) {
+            const int sl = min(L.hist[bin[k]] / kLdsTarget, S - 1);
+            sk[atomicAdd(&L.cursor[sl], 1)] = word[k];
+        }
+    }
+    __syncthreads();
+    // every wave: whole slabs of <= 128 words in registers, straight to the payload
+    bool any_big = false;
+    for (int j = w; j < S; j += kLdsThreads / 64) {
+        const int a = L.start[j], m = L.start[j + 1] - a;
+        if (m > 128) { any_big = true; continue; }
+        if (m <= 0) continue;
+        uint64_t e0 = lane < m ? sk[a + lane] : ~0ull, e1 = lane + 64 < m ? sk[a + lane + 64] : ~0ull;
+        if (m > 1) sort128(e0, e1, lane);
+        if (lane < m) emit(a + lane, e0);
+        if (lane + 64 < m) emit(a + lane + 64, e1);
+    }
+    if (!__syncthreads_or(any_big ? 1 : 0)) return;
+    // (rare: a depth cluster left a slab of more than 128 words) the workgroup sorts it where it lies in LDS
+    for (int j = 0; j < S; ++j) {
+        const int a = L.start[j], m = L.start[j + 1] - a;
+        if (m <= 128) continue;  // (uniform over the workgroup)
+        int np = 256;
+        while (np < m) np <<= 1;
+        const int half = np >> 1;
+        uint64_t *q = sk + a;
+        auto cmpex = [&](int x, int y) {
+            if (y < m) {
+                const uint64_t kx = q[x], ky = q[y];
+                if (kx > ky) { q[x] = ky; q[y] = kx; }
+            }
+        };
+        for (int k = 2; k <= np; k <<= 1) {
+            for (int i = tid; i < half; i += kLdsThreads) {
+                const int hk = k >> 1, blk = i / hk, off = i - blk * hk;
+                cmpex(blk * k + off, blk * k + k - 1 - off);
+            }
+            __syncthreads();
+            for (int d = k >> 2; d > 0; d >>= 1) {
+                for (int i = tid; i < half; i += kLdsThreads) {
+                    const int x = ((i & ~(d - 1)) << 1) | (i & (d - 1));
+                    cmpex(x, x | d);
+                }
+                __syncthreads();
+            }
+        }
+        for (int i = tid; i < m; i += kLdsThreads) emit(a + i, q[i]);
+        __syncthreads();
+    }
+}
+
 int launch_tile_sort_tiers(int T, int n_tiles, int tile_bits, const int32_t *isect_offsets, uint64_t *buckets,
                            int32_t *payload_sorted, int64_t *isect_ids_sorted, hipStream_t s);
 
 // buckets -> (split by depth where large) buckets2 -> sorted payload.  scratch: [sub_base i32: T + 1][sub_offsets i32: max_sub + 1]
+// lds_cap > 0: tiles of up to lds_cap words have been sorted by tile_split_sort_lds_kernel and yield no sub-buckets here.
 int launch_split_sort(int T, int n_tiles, int tile_bits, const int32_t *isect_offsets, int64_t n_live,
                       const uint64_t *buckets, uint64_t *buckets2, int32_t *scratch, int32_t *payload_sorted,
                       hipStream_t s) {
+    static const int use_lds = [] { const char *e = getenv("FSGS_LDS_SPLIT_SORT"); return e ? atoi(e) : 1; }();
     const int max_sub = (int)(T + n_live / kSplitTarget + 1);
     int32_t *sub_base = scratch, *sub_offsets = scratch + (T + 1);
-    hipLaunchKernelGGL(split_base_kernel, dim3(1), dim3(1024), 0, s, T, isect_offsets, sub_base);
+    const int lds_cap = use_lds ? kLdsCap : 0;
+    if (use_lds) {
+        const size_t lds = (size_t)kLdsCap * 8 + sizeof(LdsSplitShared);
+        if (const int rc = ensure_dynamic_lds<&tile_split_sort_lds_kernel>(lds)) return rc;
+        hipLaunchKernelGGL(tile_split_sort_lds_kernel, dim3(T), dim3(kLdsThreads), lds, s, isect_offsets, buckets,
+                           payload_sorted);
+    }
+    hipLaunchKernelGGL(split_base_kernel, dim3(1), dim3(1024), 0, s, T, isect_offsets, sub_base, lds_cap);
     hipLaunchKernelGGL(split_slabs_kernel, dim3(T), dim3(kSplitThreads), 0, s, T, isect_offsets, sub_base, buckets,
                        buckets2, sub_offsets, max_sub);
     int rc = check_launch();
     if (rc != FSGS_OK) return rc;
-    return launch_tile_sort_tiers(max_sub, n_tiles, tile_bits, sub_offsets, buckets2, payload_sorted, nullptr, s);
+    if (!use_lds) return launch_tile_sort_tiers(max_sub, n_tiles, tile_bits, sub_offsets, buckets2, payload_sorted, nullptr, s);
+    // what is left are the slabs of tiles beyond lds_cap words: their number is sub_base[T], on the device
+    if (const int rc2 = ensure_dynamic_lds<&tile_sort_strided_kernel<1024, kTsLarge, kTsSmall, true>>(kTsLarge * 8)) return rc2;
+    const int grid = max_sub < 2048 ? max_sub : 2048;
+    hipLaunchKernelGGL((tile_sort_strided_kernel<256, kTsSmall, 0, false>), dim3(grid), dim3(256), kTsSmall * 8, s,
+                       sub_base + T, n_tiles, tile_bits, sub_offsets, buckets2, payload_sorted);
+    hipLaunchKernelGGL((tile_sort_strided_kernel<1024, kTsLarge, kTsSmall, true>), dim3(grid < 512 ? grid : 512),
+                       dim3(1024), kTsLarge * 8, s, sub_base + T, n_tiles, tile_bits, sub_offsets, buckets2,
+                       payload_sorted);
+    return check_launch();
 }
 
 int64_t split_scratch_ints(int T, int64_t n_live) { return (int64_t)(T + 1) + (T + n_live / kSplitTarget + 1) + 1; }
