@@ -222,8 +222,10 @@ __device__ __forceinline__ void sort128(uint64_t &e0, uint64_t &e1, int lane) {
 template <int THREADS, int CAP, int LO, bool SPILL>
 __device__ __forceinline__ void
 tile_sort_body(uint64_t *sk, const int tile_lin, int n_tiles, int tile_bits, const int32_t *__restrict__ offsets,
-               uint64_t *__restrict__ buckets, int32_t *__restrict__ payload_out, int64_t *__restrict__ isect_ids_out) {
-    const int s = offsets[tile_lin], e = offsets[tile_lin + 1];
+               uint64_t *__restrict__ buckets, int32_t *__restrict__ payload_out, int64_t *__restrict__ isect_ids_out,
+               const int32_t *__restrict__ ends = nullptr) {
+    // (ends: explicit end of every bucket, for bucket lists with gaps between consecutive entries)
+    const int s = offsets[tile_lin], e = ends ? ends[tile_lin] : offsets[tile_lin + 1];
     const int n = e - s;
     if (n <= LO || (CAP > 0 && !SPILL && n > CAP)) return;
     const bool in_lds = CAP > 0 && n <= CAP;
@@ -337,12 +339,12 @@ tile_sort_kernel2(int n_tiles, int tile_bits, const int32_t *__restrict__ offset
 template <int THREADS, int CAP, int LO, bool SPILL>
 __global__ void __launch_bounds__(THREADS)
 tile_sort_strided_kernel(const int32_t *__restrict__ n_sub, int n_tiles, int tile_bits,
-                         const int32_t *__restrict__ offsets, uint64_t *__restrict__ buckets,
-                         int32_t *__restrict__ payload_out) {
+                         const int32_t *__restrict__ offsets, const int32_t *__restrict__ ends,
+                         uint64_t *__restrict__ buckets, int32_t *__restrict__ payload_out) {
     extern __shared__ __attribute__((aligned(16))) uint64_t sk[];
     const int limit = *n_sub;
     for (int b = blockIdx.x; b < limit; b += gridDim.x) {
-        tile_sort_body<THREADS, CAP, LO, SPILL>(sk, b, n_tiles, tile_bits, offsets, buckets, payload_out, nullptr);
+        tile_sort_body<THREADS, CAP, LO, SPILL>(sk, b, n_tiles, tile_bits, offsets, buckets, payload_out, nullptr, ends);
         __syncthreads();  // (the next bucket reuses the LDS words)
     }
 }
@@ -375,17 +377,18 @@ int launch_tile_scan_rows_offsets(int T, int nb, int32_t *table, int32_t *totals
 // every slab is then sorted on (depth, id) like a small tile and the slabs lie in order: the tile is sorted.
 // One more pass over the words (24 B / word) instead of the 6 radix passes (32 B / pair each) that scenes with
 // thousands of pairs per tile needed.  Slabs that still exceed the LDS tiers (skewed depths) are sorted in place.
-constexpr int kSplitMin = 1024, kSplitTarget = 512, kSplitMaxSlabs = 2048, kSplitThreads = 512;
+constexpr int kSplitMin = 1024, kSplitTarget = 512, kSplitMaxSlabs = 2048, kSplitThreads = 1024;
 
-__device__ __host__ inline int split_slabs(int n) {
+__device__ __host__ inline int split_slabs(int n, int target = kSplitTarget) {
     if (n <= kSplitMin) return 1;
-    const int s = (n + kSplitTarget - 1) / kSplitTarget;
+    const int s = (n + target - 1) / target;
     return s < kSplitMaxSlabs ? s : kSplitMaxSlabs;
 }
 
 // sub_base[t] = number of sub-buckets in front of tile t, sub_base[T] = their total   (one workgroup)
 __global__ void __launch_bounds__(1024)
-split_base_kernel(int T, const int32_t *__restrict__ offsets, int32_t *__restrict__ sub_base, int lds_cap) {
+split_base_kernel(int T, const int32_t *__restrict__ offsets, int32_t *__restrict__ sub_base, int lds_cap,
+                  int target) {
     __shared__ int wsum[16];
     __shared__ int carry_s;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -396,7 +399,7 @@ split_base_kernel(int T, const int32_t *__restrict__ offsets, int32_t *__restric
         int v = 0;
         if (i < T) {
             const int n_i = offsets[i + 1] - offsets[i];
-            v = (n_i <= lds_cap) ? 0 : split_slabs(n_i);  // (tiles the in-LDS split + sort has taken: no sub-buckets)
+            v = (n_i <= lds_cap) ? 0 : split_slabs(n_i, target);  // (tiles the in-LDS split + sort has taken: none)
         }
         int inc = v;
 #pragma unroll
@@ -426,7 +429,7 @@ constexpr int kSplitBins = 2048;
 __global__ void __launch_bounds__(kSplitThreads)
 split_slabs_kernel(int T, const int32_t *__restrict__ offsets, const int32_t *__restrict__ sub_base,
                    const uint64_t *__restrict__ in, uint64_t *__restrict__ out, int32_t *__restrict__ sub_offsets,
-                   int max_sub) {
+                   int32_t *__restrict__ sub_ends, int max_sub) {
     __shared__ unsigned int red_min[kSplitThreads / 64], red_max[kSplitThreads / 64];
     __shared__ int excl[kSplitBins];    // words per depth bin, then words in front of the bin
     __shared__ int cursor[kSplitMaxSlabs];
@@ -441,14 +444,24 @@ split_slabs_kernel(int T, const int32_t *__restrict__ offsets, const int32_t *__
     if (S == 0) return;  // (sorted by tile_split_sort_lds_kernel)
     if (S == 1) {
         for (int i = tid; i < n; i += kSplitThreads) out[s + i] = in[s + i];
-        if (tid == 0) sub_offsets[sb] = s;
+        if (tid == 0) { sub_offsets[sb] = s; sub_ends[sb] = e; }
         return;
     }
+    const int tgt = (n + S - 1) / S;  // words per slab (the caller's target, or more where S hit kSplitMaxSlabs)
+    // One workgroup walks the whole bucket three times; the largest tile of a dense frame (10^5 words) sets the
+    // kernel's duration, so every pass keeps eight independent loads per thread in flight (1024 threads).
+    constexpr int U = 8;
     // depth range of the bucket
     unsigned int lo = 0xFFFFFFFFu, hi = 0u;
-    for (int i = tid; i < n; i += kSplitThreads) {
-        const unsigned int d = (unsigned int)(in[s + i] >> 32);
-        lo = min(lo, d); hi = max(hi, d);
+    for (int i0 = tid; i0 < n; i0 += U * kSplitThreads) {
+        uint64_t wd[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) wd[u] = (i0 + u * kSplitThreads < n) ? in[s + i0 + u * kSplitThreads] : in[s + i0];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const unsigned int d = (unsigned int)(wd[u] >> 32);
+            lo = min(lo, d); hi = max(hi, d);
+        }
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
@@ -465,12 +478,20 @@ split_slabs_kernel(int T, const int32_t *__restrict__ offsets, const int32_t *__
     auto bin_of = [&](unsigned int d) -> int {
         return (int)(((unsigned long long)(d - lo) * (unsigned long long)kSplitBins) / span);
     };
-    for (int i = tid; i < n; i += kSplitThreads) atomicAdd(&excl[bin_of((unsigned int)(in[s + i] >> 32))], 1);
-    __syncthreads();
-    // exclusive scan of the 2048 bin counts: 4 per thread
-    int v[4], mine = 0;
+    for (int i0 = tid; i0 < n; i0 += U * kSplitThreads) {
+        uint64_t wd[U];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { v[k] = excl[4 * tid + k]; mine += v[k]; }
+        for (int u = 0; u < U; ++u) wd[u] = (i0 + u * kSplitThreads < n) ? in[s + i0 + u * kSplitThreads] : 0ull;
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (i0 + u * kSplitThreads < n) atomicAdd(&excl[bin_of((unsigned int)(wd[u] >> 32))], 1);
+    }
+    __syncthreads();
+    // exclusive scan of the 2048 bin counts: kSplitBins / kSplitThreads per thread
+    constexpr int BPT = kSplitBins / kSplitThreads;
+    int v[BPT], mine = 0;
+#pragma unroll
+    for (int k = 0; k < BPT; ++k) { v[k] = excl[BPT * tid + k]; mine += v[k]; }
     int inc = mine;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -482,22 +503,31 @@ split_slabs_kernel(int T, const int32_t *__restrict__ offsets, const int32_t *__
     int run = inc - mine;
     for (int k = 0; k < w; ++k) run += wsum[k];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { excl[4 * tid + k] = run; run += v[k]; }
+    for (int k = 0; k < BPT; ++k) { excl[BPT * tid + k] = run; run += v[k]; }
     __syncthreads();
     // bin b opens the slabs in (slab of the bin in front of it, slab(b)]: their first word is the bin's first word
     for (int b = tid; b < kSplitBins; b += kSplitThreads) {
-        const int sl = min(excl[b] / kSplitTarget, S - 1);
-        const int before = (b == 0) ? -1 : min(excl[b - 1] / kSplitTarget, S - 1);
+        const int sl = min(excl[b] / tgt, S - 1);
+        const int before = (b == 0) ? -1 : min(excl[b - 1] / tgt, S - 1);
         for (int k = before + 1; k <= sl; ++k) cursor[k] = s + excl[b];
     }
     __syncthreads();
-    for (int k = tid; k < S; k += kSplitThreads) sub_offsets[sb + k] = cursor[k];
+    for (int k = tid; k < S; k += kSplitThreads) {
+        sub_offsets[sb + k] = cursor[k];
+        sub_ends[sb + k] = (k + 1 < S) ? cursor[k + 1] : e;  // (explicit: tiles without sub-buckets may lie in between)
+    }
     __syncthreads();
-    for (int i = tid; i < n; i += kSplitThreads) {
-        const uint64_t word = in[s + i];
-        const int sl = min(excl[bin_of((unsigned int)(word >> 32))] / kSplitTarget, S - 1);
-        const int pos = atomicAdd(&cursor[sl], 1);
-        out[pos] = word;
+    for (int i0 = tid; i0 < n; i0 += U * kSplitThreads) {
+        uint64_t wd[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) wd[u] = (i0 + u * kSplitThreads < n) ? in[s + i0 + u * kSplitThreads] : 0ull;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (i0 + u * kSplitThreads < n) {
+                const int sl = min(excl[bin_of((unsigned int)(wd[u] >> 32))] / tgt, S - 1);
+                out[atomicAdd(&cursor[sl], 1)] = wd[u];
+            }
+        }
     }
 }
 
@@ -513,6 +543,7 @@ split_slabs_kernel(int T, const int32_t *__restrict__ offsets, const int32_t *__
 // and the words of a slab are sorted on (depth, id): the result is the sorted tile, bit for bit what the bitonic
 // tiers produce.
 constexpr int kLdsCap = 8192, kLdsThreads = 1024, kLdsItems = kLdsCap / kLdsThreads, kLdsTarget = 80;
+constexpr int kLdsCoarse = 5120;  // words per coarse slab of a tile beyond kLdsCap (bins of a 10^5-word tile hold ~50)
 constexpr int kLdsMaxSlabs = kLdsCap / kLdsTarget + 2;
 
 struct LdsSplitShared {
@@ -523,14 +554,12 @@ struct LdsSplitShared {
     int wsum[kLdsThreads / 64];
 };
 
-__global__ void __launch_bounds__(kLdsThreads)
-tile_split_sort_lds_kernel(const int32_t *__restrict__ offsets, const uint64_t *__restrict__ buckets,
-                           int32_t *__restrict__ payload_out) {
-    extern __shared__ __attribute__((aligned(16))) uint64_t sk[];  // kLdsCap words, then LdsSplitShared
+__device__ __forceinline__ void
+lds_split_sort_body(uint64_t *sk, const int s, const int n, const uint64_t *__restrict__ buckets,
+                    int32_t *__restrict__ payload_out) {
     LdsSplitShared &L = *reinterpret_cast<LdsSplitShared *>(sk + kLdsCap);
-    const int t = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int s = offsets[t], n = offsets[t + 1] - s;
-    if (n <= 0 || n > kLdsCap) return;  // (larger tiles: the global depth-slab split, launch_split_sort)
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (n <= 0 || n > kLdsCap) return;  // (larger buckets: the global depth-slab split first, launch_split_sort)
     auto emit = [&](int pos, uint64_t k) {
         const uint32_t lo32 = (uint32_t)(k & 0xFFFFFFFFull);
         payload_out[(int64_t)s + pos] = (int32_t)(((lo32 & 0xFu) << 28) | (lo32 >> 4));
@@ -666,6 +695,29 @@ tile_split_sort_lds_kernel(const int32_t *__restrict__ offsets, const uint64_t *
     }
 }
 
+// one workgroup per tile of the frame ...
+__global__ void __launch_bounds__(kLdsThreads)
+tile_split_sort_lds_kernel(const int32_t *__restrict__ offsets, const uint64_t *__restrict__ buckets,
+                           int32_t *__restrict__ payload_out) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t sk[];  // kLdsCap words, then LdsSplitShared
+    const int t = blockIdx.x;
+    lds_split_sort_body(sk, offsets[t], offsets[t + 1] - offsets[t], buckets, payload_out);
+}
+
+// ... and a fixed grid striding over the coarse depth slabs (~kLdsCoarse words each) that split_slabs_kernel cut the
+// tiles beyond kLdsCap words into; their number lives on the device (sub_base[T])
+__global__ void __launch_bounds__(kLdsThreads)
+slab_split_sort_lds_kernel(const int32_t *__restrict__ n_sub, const int32_t *__restrict__ starts,
+                           const int32_t *__restrict__ ends, const uint64_t *__restrict__ words,
+                           int32_t *__restrict__ payload_out) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t sk[];
+    const int limit = *n_sub;
+    for (int b = blockIdx.x; b < limit; b += gridDim.x) {
+        lds_split_sort_body(sk, starts[b], ends[b] - starts[b], words, payload_out);
+        __syncthreads();  // (the next slab reuses the LDS words)
+    }
+}
+
 int launch_tile_sort_tiers(int T, int n_tiles, int tile_bits, const int32_t *isect_offsets, uint64_t *buckets,
                            int32_t *payload_sorted, int64_t *isect_ids_sorted, hipStream_t s);
 
@@ -675,33 +727,38 @@ int launch_split_sort(int T, int n_tiles, int tile_bits, const int32_t *isect_of
                       const uint64_t *buckets, uint64_t *buckets2, int32_t *scratch, int32_t *payload_sorted,
                       hipStream_t s) {
     static const int use_lds = [] { const char *e = getenv("FSGS_LDS_SPLIT_SORT"); return e ? atoi(e) : 1; }();
-    const int max_sub = (int)(T + n_live / kSplitTarget + 1);
-    int32_t *sub_base = scratch, *sub_offsets = scratch + (T + 1);
+    const int target = use_lds ? kLdsCoarse : kSplitTarget;
+    const int max_sub = (int)(T + n_live / target + 1);
+    int32_t *sub_base = scratch, *sub_offsets = scratch + (T + 1), *sub_ends = sub_offsets + (max_sub + 1);
     const int lds_cap = use_lds ? kLdsCap : 0;
+    const size_t lds = (size_t)kLdsCap * 8 + sizeof(LdsSplitShared);
     if (use_lds) {
-        const size_t lds = (size_t)kLdsCap * 8 + sizeof(LdsSplitShared);
         if (const int rc = ensure_dynamic_lds<&tile_split_sort_lds_kernel>(lds)) return rc;
         hipLaunchKernelGGL(tile_split_sort_lds_kernel, dim3(T), dim3(kLdsThreads), lds, s, isect_offsets, buckets,
                            payload_sorted);
     }
-    hipLaunchKernelGGL(split_base_kernel, dim3(1), dim3(1024), 0, s, T, isect_offsets, sub_base, lds_cap);
+    hipLaunchKernelGGL(split_base_kernel, dim3(1), dim3(1024), 0, s, T, isect_offsets, sub_base, lds_cap, target);
     hipLaunchKernelGGL(split_slabs_kernel, dim3(T), dim3(kSplitThreads), 0, s, T, isect_offsets, sub_base, buckets,
-                       buckets2, sub_offsets, max_sub);
+                       buckets2, sub_offsets, sub_ends, max_sub);
     int rc = check_launch();
     if (rc != FSGS_OK) return rc;
     if (!use_lds) return launch_tile_sort_tiers(max_sub, n_tiles, tile_bits, sub_offsets, buckets2, payload_sorted, nullptr, s);
-    // what is left are the slabs of tiles beyond lds_cap words: their number is sub_base[T], on the device
-    if (const int rc2 = ensure_dynamic_lds<&tile_sort_strided_kernel<1024, kTsLarge, kTsSmall, true>>(kTsLarge * 8)) return rc2;
-    const int grid = max_sub < 2048 ? max_sub : 2048;
-    hipLaunchKernelGGL((tile_sort_strided_kernel<256, kTsSmall, 0, false>), dim3(grid), dim3(256), kTsSmall * 8, s,
-                       sub_base + T, n_tiles, tile_bits, sub_offsets, buckets2, payload_sorted);
-    hipLaunchKernelGGL((tile_sort_strided_kernel<1024, kTsLarge, kTsSmall, true>), dim3(grid < 512 ? grid : 512),
-                       dim3(1024), kTsLarge * 8, s, sub_base + T, n_tiles, tile_bits, sub_offsets, buckets2,
+    // what is left are the coarse slabs of the tiles beyond lds_cap words (their number: sub_base[T], on the device):
+    // each through the same in-LDS split + sort; a slab a depth cluster pushed beyond lds_cap is sorted where it lies
+    if (const int rc2 = ensure_dynamic_lds<&slab_split_sort_lds_kernel>(lds)) return rc2;
+    if (const int rc2 = ensure_dynamic_lds<&tile_sort_strided_kernel<1024, kTsLarge, kLdsCap, true>>(kTsLarge * 8)) return rc2;
+    const int grid = max_sub < 512 ? max_sub : 512;
+    hipLaunchKernelGGL(slab_split_sort_lds_kernel, dim3(grid), dim3(kLdsThreads), lds, s, sub_base + T, sub_offsets,
+                       sub_ends, buckets2, payload_sorted);
+    hipLaunchKernelGGL((tile_sort_strided_kernel<1024, kTsLarge, kLdsCap, true>), dim3(grid < 256 ? grid : 256),
+                       dim3(1024), kTsLarge * 8, s, sub_base + T, n_tiles, tile_bits, sub_offsets, sub_ends, buckets2,
                        payload_sorted);
     return check_launch();
 }
 
-int64_t split_scratch_ints(int T, int64_t n_live) { return (int64_t)(T + 1) + (T + n_live / kSplitTarget + 1) + 1; }
+// [sub_base: T + 1] [sub_offsets: max_sub + 1] [sub_ends: max_sub + 1], max_sub = T + n_live / target + 1 (sized for the
+// smaller of the two targets)
+int64_t split_scratch_ints(int T, int64_t n_live) { return (int64_t)(T + 1) + 2 * ((T + n_live / kSplitTarget + 1) + 1); }
 
 int launch_tile_sort_tiers(int T, int n_tiles, int tile_bits, const int32_t *isect_offsets, uint64_t *buckets,
                            int32_t *payload_sorted, int64_t *isect_ids_sorted, hipStream_t s) {
