@@ -187,8 +187,9 @@ raster_bwd_live_kernel(int64_t cap, const float4 *__restrict__ rec,
     const float quad_x0 = (float)(blockIdx.x * 8), quad_y0 = (float)(blockIdx.y * 8);
     // this workgroup's replica of a large Gaussian's gradient line (common.h: grad_spread); 0 rows = no replicas
     // (neighbouring tiles and the four 8x8 quadrants of a tile — one workgroup each — take different replicas)
-    const int64_t rep_off = replica_rows * 16 * (int64_t)((((unsigned)tile_lin * 2654435761u >> 16) + (blockIdx.x & 1) +
-                                                           2 * (blockIdx.y & 1)) % kGradReplicas);
+    // (32-bit float offsets into v_packed: the launcher guarantees the accumulator stays below 2^32 bytes)
+    const uint32_t rep_off = (uint32_t)replica_rows * 16u * ((((unsigned)tile_lin * 2654435761u >> 16) + (blockIdx.x & 1) +
+                                                             2 * (blockIdx.y & 1)) % kGradReplicas);
 
     for (int seg = n_seg - 1 - w; seg >= 0; seg -= kBwdWaves) {
         const int b0 = s + (seg << 6);          // first stream position of the segment
@@ -340,9 +341,9 @@ raster_bwd_live_kernel(int64_t cap, const float4 *__restrict__ rec,
                 const bool used = (vi < D) || (vi >= 4 && vi <= 8) || (ABS && (vi == 9 || vi == 10)) ||
                                   (vi == 11) || (vi >= 12);
                 if (used) {
-                    const int64_t gid = __float_as_int(a1.w) & 0x0FFFFFFF;
-                    const int64_t off = grad_spread(a0.w, a1.x, a1.y) ? rep_off : 0;
-                    unsafeAtomicAdd(&v_packed[off + gid * 16 + vi], tot);
+                    const uint32_t gid = __float_as_uint(a1.w) & 0x0FFFFFFFu;
+                    const uint32_t off = grad_spread(a0.w, a1.x, a1.y) ? rep_off : 0u;
+                    unsafeAtomicAdd(v_packed + (off + gid * 16u + (uint32_t)vi), tot);
                 }
             }
         }
@@ -402,6 +403,9 @@ static int launch_bwd_live(int C, int D, const float *records, const int32_t *n_
     static const int merge_thr16 = [] { const char *e = getenv("FSGS_BWD_MERGE_THR16"); return e ? atoi(e) : 15; }();
     if (C < 0 || width < 0 || height < 0 || n_isects < 0) return FSGS_EINVAL;
     if (C == 0 || width == 0 || height == 0 || n_isects == 0) return FSGS_OK;
+    // (the kernel addresses the accumulator with 32-bit float offsets: record ids are 28-bit, 16 floats each, plus the
+    // replica lines — (2^28 + kGradReplicas * replica_rows) * 16 floats must stay below 2^32 bytes / 4)
+    if (replica_rows > (int64_t)1 << 24) return FSGS_EINVAL;
     if (!records || !n_rec || !isect_offsets || !render || !alphas || !last_ids || !seg_state || !v_packed)
         return FSGS_EINVAL;
     if (ep.v_rgb) {
