@@ -358,7 +358,8 @@ class AdamFuser:
 
         def step(closure=None):
             assert closure is None
-            opt._step_count = getattr(opt, "_step_count", 0) + 1  # (what torch's LR schedulers look at)
+            opt._step_count = getattr(opt, "_step_count", 0) + 1  # (what torch's LR schedulers look at:
+            opt._opt_called = True                                # "optimizer.step() before lr_scheduler.step()")
             p = opt.param_groups[0]["params"][0]
             if p.grad is None:
                 return None
