@@ -21,6 +21,8 @@ SPAN = [
     ("tile_scatter_kernel", "tile_sort"), ("tile_sort_kernel2", "tile_sort"),
     ("adam_kernel", "adam_step"), ("sh_bwd_kernel", "sh_bwd_split"), ("sh_fwd_kernel", "sh_fwd_split"),
     ("fusion_aux_kernel", "fusion_aux_loss"), ("split_slabs_kernel", "tile_sort"),
+    ("tile_split_sort_lds_kernel", "tile_sort"), ("slab_split_sort_lds_kernel", "tile_sort"),
+    ("tile_sort_strided_kernel", "tile_sort"), ("split_base_kernel", "tile_sort"),
     ("ssim_l1_fwd_kernel", "ssim_l1_fwd"), ("ssim_l1_bwd_kernel", "ssim_l1_bwd"),
     ("project_bwd_kernel<true>", "gaussian_bwd"),
     ("sh_fwd_pack_direct_kernel", "sh_fwd_split"), ("sh_bwd_hybrid_kernel", "sh_bwd_split"), ("project_fwd_kernel<true>", "project_fwd_act"),
