@@ -542,8 +542,14 @@ split_slabs_kernel(int T, const int32_t *__restrict__ offsets, const int32_t *__
 // words are sorted by the whole workgroup in LDS afterwards.  The slab of a word is a monotone function of its depth
 // and the words of a slab are sorted on (depth, id): the result is the sorted tile, bit for bit what the bitonic
 // tiers produce.
-constexpr int kLdsCap = 8192, kLdsThreads = 1024, kLdsItems = kLdsCap / kLdsThreads, kLdsTarget = 80;
-constexpr int kLdsCoarse = 5120;  // words per coarse slab of a tile beyond kLdsCap (bins of a 10^5-word tile hold ~50)
+#ifndef FSGS_LDS_TARGET
+#define FSGS_LDS_TARGET 80
+#endif
+constexpr int kLdsCap = 8192, kLdsThreads = 1024, kLdsItems = kLdsCap / kLdsThreads, kLdsTarget = FSGS_LDS_TARGET;
+#ifndef FSGS_LDS_COARSE
+#define FSGS_LDS_COARSE 5120
+#endif
+constexpr int kLdsCoarse = FSGS_LDS_COARSE;  // words per coarse slab of a tile beyond kLdsCap (bins of a 10^5-word tile hold ~50)
 constexpr int kLdsMaxSlabs = kLdsCap / kLdsTarget + 2;
 
 struct LdsSplitShared {
