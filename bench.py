@@ -88,6 +88,8 @@ def parse():
     ap.add_argument("--n-gauss", type=int, default=None)
     ap.add_argument("--res", type=int, default=800, help="config 2: square image edge")
     ap.add_argument("--views", type=int, default=None)
+    ap.add_argument("--start-step", type=int, default=950,
+                    help="config 3: first step of the timed window of the 15 000-step schedule (0 + --steps 15000 = all of it)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dropin", action="store_true", help="skip the side measurement through the drop-in surface")
     ap.add_argument("--unfused-caller", action="store_true",
@@ -253,9 +255,9 @@ def build_workload(args, dev):
         del ptr_, ps, pp
         w.update(name=f"BASELINE config #3: FusionSense-shaped scene, {args.n_gauss} seed Gaussians (1/3 object blob), "
                       f"{W}x{H}, {len(cams)} views, RGB + sensor depth + mono normals + mask + 5 touch patches x ~2000 "
-                      "points; loss = the reference's get_loss_dict; steps 950..: add_touch_patch at 1000, refinement "
+                      f"points; loss = the reference's get_loss_dict; steps {args.start_step}..: add_touch_patch at 1000, refinement "
                       "(densify / cull / hull + touch pruning) every 100, binary opacities, SH degree step//1000",
-                 params=params, start_step=950)
+                 params=params, start_step=args.start_step)
     else:
         W, H = 1920, 1080
         cams = []
