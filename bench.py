@@ -73,7 +73,7 @@ def log(msg):
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy)
 DEFAULTS = {2: dict(steps=100, warmup=10, views=100), 3: dict(steps=300, warmup=10, views=9),
-            4: dict(steps=20, warmup=3, views=8), 5: dict(steps=10, warmup=2, views=4)}
+            4: dict(steps=20, warmup=8, views=8), 5: dict(steps=10, warmup=4, views=4)}
 # render tolerance of the fp32 path against the reference semantics: images 1e-4 of the tensor
 # maximum, gradients 3e-3 of each tensor's own maximum (fp32 atomics reorder sums); index outputs bit-exact
 RENDER_TOLERANCE = {"forward_rel": 1e-4, "gradient_rel": 3e-3, "indices": "bit-exact"}
@@ -726,6 +726,12 @@ def main():
             "iter_hbm_frac": round(b_iter / (elapsed / args.steps) / (HBM_PEAK_GBS * 1e9), 5),
             "device_mallocs_in_timed_region": n_alloc,
             "live_list_overflows": int(getattr(trainer, "live_overflows", 0)),  # frames redone (no-wait binning)
+            # occlusion cuts (dense scenes): frames binned with cuts / of those, redone uncut because a
+            # cut tile did not saturate (both over warmup + timed steps; the redone frames are inside the timed region)
+            "occlusion_cut": {"mode": getattr(trainer, "occlusion_cut_mode", "0"),
+                              "cut_frames": int(getattr(trainer, "cut_frames", 0)),
+                              "cut_redone": int(getattr(trainer, "cut_redone", 0)),
+                              "margins": list(getattr(trainer, "zcut_margins", ()))},
             "max_step_ms": round(1e3 * max(b - a for a, b in zip([t0] + step_ends[:-1], step_ends)), 3),
             "slowest_step": max(range(len(step_ends)), key=lambda i: step_ends[i] - ([t0] + step_ends)[i]),
             "gpu_step_ms": gpu_step_stats(step_events, step_views) if with_events else None,

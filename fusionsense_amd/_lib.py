@@ -54,20 +54,21 @@ SIGNATURES = {
     "fsgs_bin_live_table_bytes": (_sz, [_i, _i, _i, _i]),
     "fsgs_bin_live_count": (_i, [_i, _i, _p, _p, _p, _p, _i, _i, _p, _p, _p, _sz, _p, _p]),
     "fsgs_project_bin_live_count_sh_pack": (_i, [_i, _p, _p, _p, _p, _i, _f, _p, _p, _i, _i, _f, _f, _f, _f, _p, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p, _sz, _p,
-                                                 _i, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p]),
+                                                 _i, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p]),
     "fsgs_project_bin_live_count_sh_pack_h16": (_i, [_i, _p, _p, _p, _p, _p, _i, _f, _p, _p, _i, _i, _f, _f, _f, _f, _p, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p, _sz, _p,
-                                                     _i, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p]),
+                                                     _i, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p]),
     "fsgs_project_bin_live_count": (_i, [_i, _p, _p, _p, _p, _i, _f, _p, _p, _i, _i, _f, _f, _f, _f, _p, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p, _sz, _p, _p]),
-    "fsgs_bin_live_emit": (_i, [_i, _i, _p, _p, _p, _p, _p, _i, _i, _p, _p, _i64, _p, _p, _p]),
+    "fsgs_bin_live_emit": (_i, [_i, _i, _p, _p, _p, _p, _p, _i, _i, _p, _p, _i64, _p, _p, _p, _p]),
     "fsgs_bin_live_split_scratch_bytes": (_sz, [_i, _i, _i, _i64]),
-    "fsgs_bin_live_emit_split": (_i, [_i, _i, _p, _p, _p, _p, _p, _i, _i, _p, _p, _i64, _p, _p, _p, _sz, _p, _p]),
+    "fsgs_bin_live_emit_split": (_i, [_i, _i, _p, _p, _p, _p, _p, _i, _i, _p, _p, _i64, _p, _p, _p, _sz, _p, _p, _p]),
+    "fsgs_tile_zcut_update": (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _f, _f, _p]),
     "fsgs_quad_stream_capacity": (_i64, [_i, _i, _i, _i64]),
     "fsgs_quad_seg_slots": (_i64, [_i, _i, _i, _i64]),
     "fsgs_live_pack": (_i, [_i, _i64, _p, _p, _p, _p, _p, _p, _p, _i, _p]),
     "fsgs_raster_quad_max_cells": (_i, []),
     "fsgs_live_pack_normals": (_i, [_i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p]),
     "fsgs_live_payload": (_i, [_p, _p, _i64, _p, _i64, _i, _i, _p, _p]),
-    "fsgs_raster_fwd_quad": (_i, [_i, _i, _p, _p, _p, _i64, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "fsgs_raster_fwd_quad": (_i, [_i, _i, _p, _p, _p, _i64, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "fsgs_raster_bwd_quad": (_i, [_i, _i, _p, _p, _p, _i64, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p]),
     "fsgs_raster_bwd_quad_images": (_i, [_p, _p, _p, _i64, _i, _i, _i, _i] + [_p] * 10 + [_i, _p, _i64, _p]),
     "fsgs_campos_from_viewmats": (_i, [_i, _p, _p, _p]),

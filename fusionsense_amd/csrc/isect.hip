@@ -365,6 +365,16 @@ struct BinProjArgs {
     float eps2d, near_plane, far_plane, radius_clip, binary_threshold;
     __half *opac_logit_h;            // attr_half: the mirror the opacity is READ from (and rewritten together with the master)
     int attr_half;
+    // Occlusion cut (nullable; both binning passes of a frame get the same array): tile_zcut[t] = a depth beyond which
+    // tile t's pairs are NOT binned at all.  The caller derived it from an earlier frame of the same view (the depth at
+    // which every pixel of the tile had become opaque, plus a margin) and validates the frame afterwards
+    // (fsgs_tile_zcut_update): the kept pairs are a depth PREFIX of the tile's full list, so a frame whose tiles all
+    // saturate inside their prefix is bit-identical to the uncut one; any other frame is redone without the cut.
+    const float *tile_zcut;
+    int zcut_in_lds;                 // the workgroup keeps a copy of tile_zcut behind its tile slots (T more LDS words)
+    // count pass only (nullable): zcut_hit[t] <- 1 when a LIVE pair of tile t fell behind its cut.  An open tile that
+    // lost no live pair has its complete list, so it does not spoil the frame (fsgs_tile_zcut_update).
+    int32_t *zcut_hit;
 };
 
 template <bool SCATTER, bool MULTI, bool PROJ, bool HALF, int BT>
@@ -421,6 +431,7 @@ isect_live_bin_body(const int block, int C, int N, const float *__restrict__ mea
                 t = tile_rect(mx, my, po.radius, 16, tw, th, 0);
                 cnt = (t.x1 - t.x0) * (t.y1 - t.y0);
                 op = o_act; ca = po.ca; cb = po.cb; cc = po.cc;
+                db = (uint32_t)__float_as_int(po.depth);
             }
             if (tiles_per_gauss) tiles_per_gauss[idx] = cnt;
         } else if (idx < total) {
@@ -464,6 +475,10 @@ isect_live_bin_body(const int block, int C, int N, const float *__restrict__ mea
     if (ch == 0) {  // (after the chunk's own loads were issued: the slot rows come from memory in the fill pass)
         for (int t = tid; t < T; t += kBinThreads)
             slots[t] = SCATTER ? offsets[t] + table[(int64_t)block * T + t] : 0;
+        if (pj.tile_zcut && pj.zcut_in_lds) {
+            float *zl = reinterpret_cast<float *>(slots + T);
+            for (int t = tid; t < T; t += kBinThreads) zl[t] = pj.tile_zcut[t];
+        }
     }
     int inc = cnt;
 #pragma unroll
@@ -504,9 +519,23 @@ isect_live_bin_body(const int block, int C, int N, const float *__restrict__ mea
         float4 A = L.a[o], B = L.b[o];
         int jj = p - L.excl[o];
         int y = rc.y + jj / rc.z, x = rc.x + jj % rc.z;
+        float *zc = pj.tile_zcut ? (pj.zcut_in_lds ? reinterpret_cast<float *>(slots + T) : const_cast<float *>(pj.tile_zcut)) : nullptr;
+        float z_o = __uint_as_float(L.depth[o]);
         for (; p < p_end; ++p) {
             const CullPrep cp = {A.x, A.y, A.z, A.w, B.x, B.y, B.z, B.w};
-            const unsigned m = quadrant_mask(cp, (float)(x * 16), (float)(y * 16));
+            // (occlusion cut, one camera: a pair behind its tile's cut depth is not binned.  The count pass still
+            // reach-tests it: the frame's verdict needs to know which tiles lost a LIVE pair; the LDS copy of the
+            // cut carries that in its sign bit until the workgroup's end)
+            const float zt = zc ? zc[y * tw + x] : 0.f;
+            const bool cut = zc && z_o > fabsf(zt);
+            unsigned m = (cut && (SCATTER || !pj.zcut_hit)) ? 0u : quadrant_mask(cp, (float)(x * 16), (float)(y * 16));
+            if (!SCATTER && cut) {
+                if (m && pj.zcut_hit) {
+                    if (!pj.zcut_in_lds) pj.zcut_hit[y * tw + x] = 1;
+                    else if (zt > 0.f) atomicOr(reinterpret_cast<unsigned *>(&zc[y * tw + x]), 0x80000000u);
+                }
+                m = 0u;
+            }
             if (m) {
                 const int64_t gidx = idx0 + o;
                 const int c = (C == 1) ? 0 : (int)(gidx / N);
@@ -520,6 +549,7 @@ isect_live_bin_body(const int block, int C, int N, const float *__restrict__ mea
                 if (p + 1 < p_end) {  // (so a non-empty Gaussian follows)
                     do { ++o; } while (L.rect[o].w == 0);
                     rc = L.rect[o]; A = L.a[o]; B = L.b[o];
+                    z_o = __uint_as_float(L.depth[o]);
                     jj = 0; x = rc.x; y = rc.y;
                 }
             } else if (++x == rc.x + rc.z) {
@@ -531,6 +561,11 @@ isect_live_bin_body(const int block, int C, int N, const float *__restrict__ mea
     if (!SCATTER) {
         __syncthreads();
         for (int t = tid; t < T; t += kBinThreads) table[(int64_t)block * T + t] = slots[t];
+        if (pj.tile_zcut && pj.zcut_in_lds && pj.zcut_hit) {
+            const float *zl = reinterpret_cast<const float *>(slots + T);
+            for (int t = tid; t < T; t += kBinThreads)
+                if (zl[t] < 0.f) pj.zcut_hit[t] = 1;  // (-inf never: nothing lies behind an infinite cut)
+        }
     }
 }
 
@@ -776,29 +811,41 @@ extern "C" size_t fsgs_bin_live_table_bytes(int C, int N, int tile_width, int ti
 
 // one launch of isect_live_bin_kernel<SC, multi?, PJ, HF, threads(total)>: dynamic LDS limit raised on first need
 template <bool SC, bool MU, bool PJ, bool HF, int BT, typename... Args>
-static int bin_launch_one(int T, int64_t total, int nb, hipStream_t s, Args... args) {
-    const size_t need = bin_lds_bytes(T, total);
+static int bin_launch_one(size_t extra_lds, int T, int64_t total, int nb, hipStream_t s, Args... args) {
+    const size_t need = bin_lds_bytes(T, total) + extra_lds;
     auto kernel = &isect_live_bin_kernel<SC, MU, PJ, HF, BT>;
     if (const int rc = ensure_dynamic_lds<&isect_live_bin_kernel<SC, MU, PJ, HF, BT>>(need)) return rc;
     hipLaunchKernelGGL(kernel, dim3(nb), dim3(BT), need, s, args...);
     return check_launch();
 }
 template <bool SC, bool PJ, bool HF, typename... Args>
-static int bin_launch(int T, int64_t total, int nb, hipStream_t s, Args... args) {
+static int bin_launch(size_t extra_lds, int T, int64_t total, int nb, hipStream_t s, Args... args) {
     switch (bin_threads(total)) {
     case 1024:
-        if (bin_chunks(total) > 1) return bin_launch_one<SC, true, PJ, HF, 1024>(T, total, nb, s, args...);
-        return bin_launch_one<SC, false, PJ, HF, 1024>(T, total, nb, s, args...);
-    case 512: return bin_launch_one<SC, false, PJ, HF, 512>(T, total, nb, s, args...);
-    default: return bin_launch_one<SC, false, PJ, HF, 256>(T, total, nb, s, args...);
+        if (bin_chunks(total) > 1) return bin_launch_one<SC, true, PJ, HF, 1024>(extra_lds, T, total, nb, s, args...);
+        return bin_launch_one<SC, false, PJ, HF, 1024>(extra_lds, T, total, nb, s, args...);
+    case 512: return bin_launch_one<SC, false, PJ, HF, 512>(extra_lds, T, total, nb, s, args...);
+    default: return bin_launch_one<SC, false, PJ, HF, 256>(extra_lds, T, total, nb, s, args...);
+    }
+}
+// the tile cuts of a frame in LDS behind the tile slots, where both fit (T more words); else they are read from memory
+static inline void bin_place_zcut(BinProjArgs &pj, const float *tile_zcut, int32_t *zcut_hit, int T, int64_t total,
+                                  size_t &extra_lds) {
+    pj.tile_zcut = tile_zcut;
+    pj.zcut_hit = tile_zcut ? zcut_hit : nullptr;
+    pj.zcut_in_lds = 0;
+    extra_lds = 0;
+    if (tile_zcut && bin_lds_bytes(T, total) + (size_t)T * sizeof(float) <= 150 * 1024) {
+        pj.zcut_in_lds = 1;
+        extra_lds = (size_t)T * sizeof(float);
     }
 }
 
 // the projecting count pass + a riding Adam step (isect_count_adam_kernel)
 template <bool MU, bool HF, int BT>
-static int count_adam_launch_one(int T, int64_t total, int nb, hipStream_t s, int N, int tw, int th, int chunks,
+static int count_adam_launch_one(size_t extra_lds, int T, int64_t total, int nb, hipStream_t s, int N, int tw, int th, int chunks,
                                  int32_t *tiles_per_gauss, int32_t *table, const BinProjArgs &pj, const AdamArgs &adam) {
-    const size_t need = bin_lds_bytes(T, total);
+    const size_t need = bin_lds_bytes(T, total) + extra_lds;
     auto kernel = &isect_count_adam_kernel<MU, HF, BT>;
     if (const int rc = ensure_dynamic_lds<&isect_count_adam_kernel<MU, HF, BT>>(need)) return rc;
     hipLaunchKernelGGL(kernel, dim3(nb + adam.n_blocks), dim3(BT), need, s, N, tw, th, T, nb, chunks, tiles_per_gauss,
@@ -806,15 +853,15 @@ static int count_adam_launch_one(int T, int64_t total, int nb, hipStream_t s, in
     return check_launch();
 }
 template <bool HF>
-static int count_adam_launch(int T, int64_t total, int nb, hipStream_t s, int N, int tw, int th,
+static int count_adam_launch(size_t extra_lds, int T, int64_t total, int nb, hipStream_t s, int N, int tw, int th,
                              int32_t *tiles_per_gauss, int32_t *table, const BinProjArgs &pj, const AdamArgs &adam) {
     const int chunks = bin_chunks(total);
     switch (bin_threads(total)) {
     case 1024:
-        if (chunks > 1) return count_adam_launch_one<true, HF, 1024>(T, total, nb, s, N, tw, th, chunks, tiles_per_gauss, table, pj, adam);
-        return count_adam_launch_one<false, HF, 1024>(T, total, nb, s, N, tw, th, chunks, tiles_per_gauss, table, pj, adam);
-    case 512: return count_adam_launch_one<false, HF, 512>(T, total, nb, s, N, tw, th, chunks, tiles_per_gauss, table, pj, adam);
-    default: return count_adam_launch_one<false, HF, 256>(T, total, nb, s, N, tw, th, chunks, tiles_per_gauss, table, pj, adam);
+        if (chunks > 1) return count_adam_launch_one<true, HF, 1024>(extra_lds, T, total, nb, s, N, tw, th, chunks, tiles_per_gauss, table, pj, adam);
+        return count_adam_launch_one<false, HF, 1024>(extra_lds, T, total, nb, s, N, tw, th, chunks, tiles_per_gauss, table, pj, adam);
+    case 512: return count_adam_launch_one<false, HF, 512>(extra_lds, T, total, nb, s, N, tw, th, chunks, tiles_per_gauss, table, pj, adam);
+    default: return count_adam_launch_one<false, HF, 256>(extra_lds, T, total, nb, s, N, tw, th, chunks, tiles_per_gauss, table, pj, adam);
     }
 }
 
@@ -844,7 +891,7 @@ extern "C" int fsgs_bin_live_count(int C, int N, const float *means2d, const int
     const int nb = (int)bin_blocks(total);
     int32_t *table = reinterpret_cast<int32_t *>(table_scratch);
     int32_t *totals = table + (size_t)T * nb;
-    int rc = bin_launch<false, false, false>(T, total, nb, s, C, N, means2d, radii, (const float *)nullptr, conics,
+    int rc = bin_launch<false, false, false>((size_t)0, T, total, nb, s, C, N, means2d, radii, (const float *)nullptr, conics,
                                              opacities, tile_width, tile_height, T, nb, bin_chunks(total),
                                              tiles_per_gauss, table, (const int32_t *)nullptr, (uint64_t *)nullptr,
                                              BinProjArgs{}, 0x7FFFFFFF);
@@ -864,7 +911,8 @@ static int project_bin_live_count_impl(int N, const float *means, const void *qu
                                            float *conics, int tile_width, int tile_height, int32_t *tiles_per_gauss,
                                            int32_t *isect_offsets, void *table_scratch, size_t table_bytes,
                                            int32_t *n_live_mapped, fsgs_stream_t stream,
-                                           const ShPackRider *rider = nullptr, const fsgs_adam_groups *adam = nullptr) {
+                                           const ShPackRider *rider = nullptr, const fsgs_adam_groups *adam = nullptr,
+                                           const float *tile_zcut = nullptr, int32_t *zcut_hit = nullptr) {
     if (N < 0 || tile_width < 1 || tile_height < 1 || !isect_offsets) return FSGS_EINVAL;
     const int64_t T64 = (int64_t)tile_width * tile_height;
     if (T64 > fsgs_bin_live_max_tiles()) return FSGS_EINVAL;
@@ -898,11 +946,13 @@ static int project_bin_live_count_impl(int N, const float *means, const void *qu
     int32_t *table = reinterpret_cast<int32_t *>(table_scratch);
     int32_t *totals = table + (size_t)T * nb;
     int rc;
-    const BinProjArgs pj = {means, quats, log_scales, viewmat, K, opac_logit, scales_out, opac_out, means2d, depths,
-                            conics, radii, width, height, binarise, eps2d, near_plane, far_plane, radius_clip,
-                            binary_threshold, reinterpret_cast<__half *>(opac_logit_h), attr_half};
+    BinProjArgs pj = {means, quats, log_scales, viewmat, K, opac_logit, scales_out, opac_out, means2d, depths,
+                      conics, radii, width, height, binarise, eps2d, near_plane, far_plane, radius_clip,
+                      binary_threshold, reinterpret_cast<__half *>(opac_logit_h), attr_half, nullptr, 0, nullptr};
+    size_t extra_lds = 0;
+    bin_place_zcut(pj, tile_zcut, zcut_hit, T, total, extra_lds);
 #define FSGS_BIN_PCOUNT(HF)                                                                                         \
-    bin_launch<false, true, HF>(T, total, nb, s, 1, N, (const float *)nullptr, (const int32_t *)nullptr,              \
+    bin_launch<false, true, HF>(extra_lds, T, total, nb, s, 1, N, (const float *)nullptr, (const int32_t *)nullptr,   \
                                 (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, tile_width,  \
                                 tile_height, T, nb, bin_chunks(total), tiles_per_gauss, table,                        \
                                 (const int32_t *)nullptr, (uint64_t *)nullptr, pj, 0x7FFFFFFF)
@@ -915,8 +965,8 @@ static int project_bin_live_count_impl(int N, const float *means, const void *qu
         if (rc != FSGS_OK) return rc;
     }
     if (aa.n_blocks > 0)
-        rc = attr_half ? count_adam_launch<true>(T, total, nb, s, N, tile_width, tile_height, tiles_per_gauss, table, pj, aa)
-                       : count_adam_launch<false>(T, total, nb, s, N, tile_width, tile_height, tiles_per_gauss, table, pj, aa);
+        rc = attr_half ? count_adam_launch<true>(extra_lds, T, total, nb, s, N, tile_width, tile_height, tiles_per_gauss, table, pj, aa)
+                       : count_adam_launch<false>(extra_lds, T, total, nb, s, N, tile_width, tile_height, tiles_per_gauss, table, pj, aa);
     else
         rc = attr_half ? FSGS_BIN_PCOUNT(true) : FSGS_BIN_PCOUNT(false);
 #undef FSGS_BIN_PCOUNT
@@ -938,14 +988,15 @@ extern "C" int fsgs_project_bin_live_count_sh_pack(
     float *depths, float *conics, int tile_width, int tile_height, int32_t *tiles_per_gauss, int32_t *isect_offsets,
     void *table_scratch, size_t table_bytes, int32_t *n_live_mapped, int degree, const float *campos,
     const float *features_dc, const float *features_rest, const float *c2w, float *packed, float *normals_world,
-    float *zero_cells, int n_zero, const fsgs_adam_groups *adam, fsgs_stream_t stream) {
+    float *zero_cells, int n_zero, const fsgs_adam_groups *adam, const float *tile_zcut, int32_t *zcut_hit,
+    fsgs_stream_t stream) {
     const ShPackRider r = {N, degree, 0, means, campos, features_dc, features_rest, radii, depths, means2d, conics,
                            opac_out, quats, log_scales, c2w, packed, normals_world, zero_cells, n_zero};
     return project_bin_live_count_impl(N, means, quats, log_scales, opac_logit, nullptr, 0, binarise, binary_threshold,
                                        viewmat, K, width, height, eps2d, near_plane, far_plane, radius_clip, scales_out,
                                        opac_out, radii, means2d, depths, conics, tile_width, tile_height, tiles_per_gauss,
                                        isect_offsets, table_scratch, table_bytes, n_live_mapped, stream,
-                                       packed ? &r : nullptr, adam);
+                                       packed ? &r : nullptr, adam, tile_zcut, zcut_hit);
 }
 
 extern "C" int fsgs_project_bin_live_count_sh_pack_h16(
@@ -956,14 +1007,14 @@ extern "C" int fsgs_project_bin_live_count_sh_pack_h16(
     int32_t *tiles_per_gauss, int32_t *isect_offsets, void *table_scratch, size_t table_bytes, int32_t *n_live_mapped,
     int degree, const float *campos, const void *features_dc_h, const void *features_rest_h, const float *c2w,
     float *packed, float *normals_world, float *zero_cells, int n_zero, const fsgs_adam_groups *adam,
-    fsgs_stream_t stream) {
+    const float *tile_zcut, int32_t *zcut_hit, fsgs_stream_t stream) {
     const ShPackRider r = {N, degree, 1, means, campos, features_dc_h, features_rest_h, radii, depths, means2d, conics,
                            opac_out, quats_h, log_scales_h, c2w, packed, normals_world, zero_cells, n_zero};
     return project_bin_live_count_impl(N, means, quats_h, log_scales_h, opac_logit_master, opac_logit_h, 1, binarise,
                                        binary_threshold, viewmat, K, width, height, eps2d, near_plane, far_plane,
                                        radius_clip, scales_out, opac_out, radii, means2d, depths, conics, tile_width,
                                        tile_height, tiles_per_gauss, isect_offsets, table_scratch, table_bytes,
-                                       n_live_mapped, stream, packed ? &r : nullptr, adam);
+                                       n_live_mapped, stream, packed ? &r : nullptr, adam, tile_zcut, zcut_hit);
 }
 
 extern "C" int fsgs_project_bin_live_count(int N, const float *means, const float *quats, const float *log_scales,
@@ -1004,7 +1055,7 @@ static int bin_live_emit_impl(int C, int N, const float *means2d, const int32_t 
                               const float *conics, const float *opacities, int tile_width, int tile_height,
                               const int32_t *isect_offsets, const void *table_scratch, int64_t n_live,
                               void *buckets, void *buckets2, void *split_scratch, int32_t *payload_sorted,
-                              fsgs_stream_t stream);
+                              fsgs_stream_t stream, const float *tile_zcut);
 
 extern "C" size_t fsgs_bin_live_split_scratch_bytes(int C, int tile_width, int tile_height, int64_t n_live) {
     return (size_t)split_scratch_ints(C * tile_width * tile_height, n_live > 0 ? n_live : 0) * sizeof(int32_t) + 64;
@@ -1017,27 +1068,28 @@ extern "C" int fsgs_bin_live_emit_split(int C, int N, const float *means2d, cons
                                         const float *conics, const float *opacities, int tile_width, int tile_height,
                                         const int32_t *isect_offsets, const void *table_scratch, int64_t n_live,
                                         void *buckets, void *buckets2, void *split_scratch, size_t split_bytes,
-                                        int32_t *payload_sorted, fsgs_stream_t stream) {
+                                        int32_t *payload_sorted, const float *tile_zcut, fsgs_stream_t stream) {
     if (n_live > 0 && (!buckets2 || !split_scratch)) return FSGS_EINVAL;
     if (n_live > 0 && split_bytes < fsgs_bin_live_split_scratch_bytes(C, tile_width, tile_height, n_live)) return FSGS_ESCRATCH;
     return bin_live_emit_impl(C, N, means2d, radii, depths, conics, opacities, tile_width, tile_height, isect_offsets,
-                              table_scratch, n_live, buckets, buckets2, split_scratch, payload_sorted, stream);
+                              table_scratch, n_live, buckets, buckets2, split_scratch, payload_sorted, stream, tile_zcut);
 }
 
 extern "C" int fsgs_bin_live_emit(int C, int N, const float *means2d, const int32_t *radii, const float *depths,
                                   const float *conics, const float *opacities, int tile_width, int tile_height,
                                   const int32_t *isect_offsets, const void *table_scratch, int64_t n_live,
-                                  void *buckets, int32_t *payload_sorted, fsgs_stream_t stream) {
+                                  void *buckets, int32_t *payload_sorted, const float *tile_zcut, fsgs_stream_t stream) {
     return bin_live_emit_impl(C, N, means2d, radii, depths, conics, opacities, tile_width, tile_height, isect_offsets,
-                              table_scratch, n_live, buckets, nullptr, nullptr, payload_sorted, stream);
+                              table_scratch, n_live, buckets, nullptr, nullptr, payload_sorted, stream, tile_zcut);
 }
 
 static int bin_live_emit_impl(int C, int N, const float *means2d, const int32_t *radii, const float *depths,
                               const float *conics, const float *opacities, int tile_width, int tile_height,
                               const int32_t *isect_offsets, const void *table_scratch, int64_t n_live,
                               void *buckets, void *buckets2, void *split_scratch, int32_t *payload_sorted,
-                              fsgs_stream_t stream) {
+                              fsgs_stream_t stream, const float *tile_zcut) {
     if (C < 1 || N < 0 || tile_width < 1 || tile_height < 1 || n_live < 0 || !isect_offsets) return FSGS_EINVAL;
+    if (tile_zcut && C != 1) return FSGS_EINVAL;
     const int64_t T64 = (int64_t)C * tile_width * tile_height;
     if (T64 > fsgs_bin_live_max_tiles() || n_live > 0x7FFFFFF0ll) return FSGS_EINVAL;
     if (n_live == 0 || (int64_t)C * N == 0) return FSGS_OK;
@@ -1048,10 +1100,13 @@ static int bin_live_emit_impl(int C, int N, const float *means2d, const int32_t 
     hipStream_t s = as_stream(stream);
     const int nb = (int)bin_blocks((int64_t)C * N);
     int32_t *table = const_cast<int32_t *>(reinterpret_cast<const int32_t *>(table_scratch));
-    int rc = bin_launch<true, false, false>(T, (int64_t)C * N, nb, s, C, N, means2d, radii, depths, conics, opacities,
-                                            tile_width, tile_height, T, nb, bin_chunks((int64_t)C * N),
+    BinProjArgs pj{};
+    size_t extra_lds = 0;
+    bin_place_zcut(pj, tile_zcut, nullptr, T, (int64_t)C * N, extra_lds);
+    int rc = bin_launch<true, false, false>(extra_lds, T, (int64_t)C * N, nb, s, C, N, means2d, radii, depths, conics,
+                                            opacities, tile_width, tile_height, T, nb, bin_chunks((int64_t)C * N),
                                             (int32_t *)nullptr, table, isect_offsets,
-                                            reinterpret_cast<uint64_t *>(buckets), BinProjArgs{}, (int)n_live);
+                                            reinterpret_cast<uint64_t *>(buckets), pj, (int)n_live);
     if (rc != FSGS_OK) return rc;
     int tb = 0;
     while ((1ll << tb) <= n_tiles) ++tb;
@@ -1062,4 +1117,77 @@ static int bin_live_emit_impl(int C, int N, const float *means2d, const int32_t 
                                  payload_sorted, s);
     return launch_tile_sort_tiers(T, n_tiles, tb, isect_offsets, reinterpret_cast<uint64_t *>(buckets),
                                   payload_sorted, nullptr, s);
+}
+
+
+// ---- occlusion cut: next frame's tile cuts from this frame's walk, and the verdict on this frame's own cuts --------
+// One 64-thread workgroup per tile.  tile_open[t] != 0: some pixel of the tile was still transparent when its list
+// ended (set by fsgs_raster_fwd_quad) -> no cut for this tile next time (+inf), and if the frame was binned WITH a finite
+// cut for it the frame is invalid (entries behind the cut could have contributed).  Otherwise every pixel stopped at or
+// before the tile's deepest composited entry: the cut is that entry's depth plus a margin (half the walked depth range,
+// at least 1 %): entries behind it were not reached by this frame and will not be binned by the next frame of this view.
+__global__ void __launch_bounds__(64)
+tile_zcut_kernel(int tw, int th, int W, int H, const int32_t *__restrict__ last_ids, const int32_t *__restrict__ payload,
+                 const float *__restrict__ depths, const int32_t *__restrict__ offsets, int32_t *__restrict__ tile_open,
+                 const float *__restrict__ zcut_in, int32_t *__restrict__ zcut_hit, float *__restrict__ zcut_out,
+                 int32_t *__restrict__ bad, float margin_span, float margin_rel) {
+    const int t = blockIdx.x, lane = threadIdx.x;
+    const int ty = t / tw, tx = t - ty * tw;
+    int best = -1;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int pidx = lane * 4 + k, i = ty * 16 + (pidx >> 4), j = tx * 16 + (pidx & 15);
+        if (i < H && j < W) best = max(best, last_ids[(int64_t)i * W + j]);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) best = max(best, __shfl_xor(best, d, 64));
+    if (lane != 0) return;
+    const int l0 = offsets[t], l1 = offsets[t + 1];
+    const int open = tile_open[t];
+    tile_open[t] = 0;  // (left cleared for the next frame's forward)
+    const int hit = zcut_hit ? zcut_hit[t] : 1;
+    if (zcut_hit) zcut_hit[t] = 0;
+    const float inf = __builtin_huge_valf();
+    float z = inf;
+    if (open) {
+        // an open tile under a cut spoils the frame — unless no live pair of it fell behind the cut (its list is the
+        // complete one then; without the count pass's flags every open cut tile counts)
+        if (zcut_in && zcut_in[t] < inf && hit) atomicOr(bad, 1);
+    } else if (l1 > l0) {
+        const int last = min(max(best, l0), l1 - 1);
+        const float z_last = depths[payload[last] & 0x0FFFFFFF], z_first = depths[payload[l0] & 0x0FFFFFFF];
+        z = z_last + fmaxf(margin_span * (z_last - z_first), margin_rel * z_last);
+    } else if (zcut_in) {
+        z = zcut_in[t];  // (an empty list under a cut: keep the cut; without a cut an empty tile needs none)
+    }
+    zcut_out[t] = z;
+}
+
+// the verdict into host-mapped memory once every tile has been looked at: [0] <- bad, [1] <- 1 ("landed")
+__global__ void zcut_verdict_kernel(int32_t *__restrict__ bad, int32_t *__restrict__ verdict_mapped) {
+    verdict_mapped[0] = *bad;
+    *bad = 0;
+    __threadfence_system();
+    __hip_atomic_store(&verdict_mapped[1], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// One camera.  last_ids [H,W] and payload / isect_offsets [T + 1] as the forward used them, depths [N], tile_open [T]
+// (int32, written by fsgs_raster_fwd_quad, cleared here), zcut_in (nullable: the cuts this frame was binned with),
+// zcut_out [T], bad_scratch: one zeroed int32 on the device (left zeroed), verdict_mapped: int32[2] in host-mapped
+// memory ([1] cleared by the caller beforehand).  zcut_hit (nullable, [T] int32): the flags the count pass raised
+// for tiles that lost a live pair to their cut (fsgs_project_bin_live_count_sh_pack); cleared here.
+extern "C" int fsgs_tile_zcut_update(int tile_width, int tile_height, int width, int height, const int32_t *last_ids,
+                                     const int32_t *payload, const float *depths, const int32_t *isect_offsets,
+                                     int32_t *tile_open, const float *zcut_in, int32_t *zcut_hit, float *zcut_out,
+                                     int32_t *bad_scratch,
+                                     int32_t *verdict_mapped, float margin_span, float margin_rel, fsgs_stream_t stream) {
+    if (tile_width < 1 || tile_height < 1 || width < 1 || height < 1 || margin_span < 0.f || margin_rel < 0.f) return FSGS_EINVAL;
+    if (!last_ids || !payload || !depths || !isect_offsets || !tile_open || !zcut_out || !bad_scratch || !verdict_mapped)
+        return FSGS_EINVAL;
+    hipStream_t s = as_stream(stream);
+    hipLaunchKernelGGL(tile_zcut_kernel, dim3(tile_width * tile_height), dim3(64), 0, s, tile_width, tile_height, width,
+                       height, last_ids, payload, depths, isect_offsets, tile_open, zcut_in, zcut_hit, zcut_out, bad_scratch,
+                       margin_span, margin_rel);
+    hipLaunchKernelGGL(zcut_verdict_kernel, dim3(1), dim3(1), 0, s, bad_scratch, verdict_mapped);
+    return check_launch();
 }

@@ -59,7 +59,8 @@ raster_fwd_quad_kernel(int64_t cap, const float4 *__restrict__ packed, const int
                        float *__restrict__ render, float *__restrict__ alphas, int32_t *__restrict__ last_ids,
                        float4 *__restrict__ rec_out, int32_t *__restrict__ n_rec,
                        float *__restrict__ seg_state, int64_t seg_cap, int normalize_last,
-                       float *__restrict__ render_extra, float *__restrict__ max_last, int ends_on_device) {
+                       float *__restrict__ render_extra, float *__restrict__ max_last, int ends_on_device,
+                       int32_t *__restrict__ tile_open) {
     __shared__ QuadLds<E> S;
     constexpr int RS = E ? 4 : 3;
     // workgroup b runs on XCD b % 8: the four quadrants of a tile share its list and its Gaussians,
@@ -247,6 +248,9 @@ raster_fwd_quad_kernel(int64_t cap, const float4 *__restrict__ packed, const int
         cnt += n_proc;
     }
     if (n_rec && tid == 0) n_rec[(int64_t)q * n_tiles_total + tile_lin] = cnt;
+    // (occlusion cut, isect.hip: fsgs_tile_zcut_update) a pixel that is still transparent at the end of the list makes
+    // its tile "open": this frame needed — or would have needed — everything the tile had
+    if (tile_open && !__all(done) && lane == 0) tile_open[tile_lin] = 1;
 
     // a pixel's sums are spread over its four slot lanes
 #pragma unroll
@@ -313,7 +317,7 @@ extern "C" int fsgs_raster_fwd_quad(int C, int D, const float *packed, const int
                                     int width, int height, int tile_width, int tile_height, int normalize_last,
                                     float *render, float *alphas, int32_t *last_ids, float *records,
                                     int32_t *n_rec, float *seg_state, float *render_extra,
-                                    float *max_last, fsgs_stream_t stream) {
+                                    float *max_last, int32_t *tile_open, fsgs_stream_t stream) {
     // n_isects < 0: -n_isects is the CAPACITY the caller sized records / seg_state for, and the lists' true end is
     // isect_offsets[C * th * tw] on the device (fsgs_bin_live_count leaves it there): no host wait for the total
     const int ends_on_device = n_isects < 0 ? 1 : 0;
@@ -337,7 +341,7 @@ extern "C" int fsgs_raster_fwd_quad(int C, int D, const float *packed, const int
     hipLaunchKernelGGL((raster_fwd_quad_kernel<DD, EE>), grid, dim3(256), 0, s, cap, pk, payload,                 \
                        isect_offsets, n_isects, backgrounds, width, height, tile_width, tile_height, (int)n_tiles, \
                        render, alphas, last_ids, rec, n_rec, seg_state, seg_cap, normalize_last, render_extra,     \
-                       max_last, ends_on_device)
+                       max_last, ends_on_device, tile_open)
     if (render_extra) {
         if (D != 4) return FSGS_EINVAL;  // the fused RGB+depth + normal-plane walk
         FSGS_FWD_QUAD(4, 3);

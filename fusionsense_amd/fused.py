@@ -70,6 +70,14 @@ class FrameInfo:
         self.live_capacity = 0
         self.pending_count = None
         self.n_live: Optional[int] = None
+        # occlusion cuts (dense scenes): ``zcut_in`` [T] float32 = per-tile depth behind which pairs
+        # are not binned (the previous frame of this view saturated in front of it; +inf = no cut), ``zcut_out`` [T]
+        # receives this frame's cuts for the next one.  A cut tile that does NOT saturate inside its prefix makes the
+        # frame invalid (ops.OcclusionCutInvalid from the caller's check; to be redone without cuts).
+        self.zcut_in: Optional[Tensor] = None
+        self.zcut_out: Optional[Tensor] = None
+        self.zcut_margins = (0.5, 0.01)
+        self.pending_verdict = None
 
     @property
     def flatten_ids(self):
@@ -188,7 +196,8 @@ class _FusedGetOutputs(torch.autograd.Function):
                 means, quats, scales, opacities, bthr, cam["viewmat"], cam["K"], W, H, tw, th,
                 dict(scales_exp=scales_exp, opac_sig=opac_sig, radii=radii, means2d=means2d, depths=depths,
                      conics=conics), half=hm, capacity=int(info.live_capacity), sh_pack=rider,
-                adam=info.adam_rider.groups if adam_rides else None)
+                adam=info.adam_rider.groups if adam_rides else None, zcut=info.zcut_in,
+                zcut_hit=None if info.zcut_in is None else ops.zcut_scratch(dev, tw * th)[2])
             if adam_rides:
                 info.adam_rider.consumed()
                 info.adam_rider = None
@@ -234,7 +243,7 @@ class _FusedGetOutputs(torch.autograd.Function):
                                                                        tw, th)
         else:
             tpg, isect_ids, flatten_ids, offsets = ops.isect_finish_live(count, means2d, radii, depths, conics,
-                                                                         opac_row, tw, th, want_ids=False)
+                                                                         opac_row, tw, th, want_ids=False, route_hint=True)
         if pre_sh is not None:
             pre_sh()
             colours_and_packing()
@@ -265,11 +274,28 @@ class _FusedGetOutputs(torch.autograd.Function):
         alphas = torch.empty(1, H, W, 1, **f32)
         last_ids = torch.empty(1, H, W, dtype=torch.int32, device=dev)
         render_extra = torch.empty(1, H, W, 3, **f32)
+        if not direct_bins:
+            # (the list chain + radix sort of very dense frames knows no cuts: none applied, none recorded — the caller
+            # sees zcut_out = None)
+            info.zcut_in = info.zcut_out = None
+        track_cuts = info.zcut_out is not None
+        tile_open, bad, hit = (ops.zcut_scratch(dev, n_tiles) if (track_cuts or info.zcut_in is not None)
+                               else (None, None, None))
         _run(lib.fsgs_raster_fwd_quad, (1, 4, ptr(packed), ptr(flatten_ids), ptr(offsets), -M if no_wait else M, None,
                                        W, H, tw, th, 1,
                                        ptr(render), ptr(alphas), ptr(last_ids), ptr(records), ptr(n_rec),
-                                       ptr(seg_state), ptr(render_extra), ptr(max_last), sp),
+                                       ptr(seg_state), ptr(render_extra), ptr(max_last), ptr(tile_open), sp),
              "fsgs_raster_fwd_quad", "_d4e3")
+        if tile_open is not None:
+            # this frame's saturation depths become the next frame's cuts; a cut tile left open spoils the frame
+            verdict = ops.zcut_verdict_buffer(dev)
+            zout = info.zcut_out if info.zcut_out is not None else torch.empty(n_tiles, **f32)
+            _run(lib.fsgs_tile_zcut_update, (tw, th, W, H, ptr(last_ids), ptr(flatten_ids), ptr(depths), ptr(offsets),
+                                            ptr(tile_open), ptr(info.zcut_in),
+                                            ptr(hit) if info.zcut_in is not None else None, ptr(zout), ptr(bad),
+                                            verdict.data_ptr(), float(info.zcut_margins[0]),
+                                            float(info.zcut_margins[1]), sp), "fsgs_tile_zcut_update")
+            info.pending_verdict = verdict if info.zcut_in is not None else None
         rgb = torch.empty(H, W, 3, **f32)
         depth = torch.empty(H, W, 1, **f32)
         normal = torch.empty(H, W, 3, **f32)
@@ -487,7 +513,9 @@ def fused_step_forward_backward(gauss_params: Dict[str, Tensor], camera: Camera,
                                 stats_out: Optional[dict] = None, add_mask: Optional[Tensor] = None,
                                 binary_threshold: Optional[float] = None, ssim_lambda: float = 0.2,
                                 w_depth: float = 0.2, w_normal: float = 0.1, pre_sh=None, adam_rider=None, sh_factors_out=None,
-                                fusion=None, half: Optional[Dict[str, Tensor]] = None, live_capacity: int = 0):
+                                fusion=None, half: Optional[Dict[str, Tensor]] = None, live_capacity: int = 0,
+                                zcut_in: Optional[Tensor] = None, zcut_out: Optional[Tensor] = None,
+                                zcut_margins=None):
     """get_outputs -> loss -> both backward passes, without the autograd tape.  The parameter gradients land in
     ``grad_out`` (the trainer's slab views).  Returns (loss 0-d tensor, outputs dict).
     ``target`` is either the benchmark targets of BASELINE config #2 (dict rgb / depth / normal: L1 + SSIM on rgb,
@@ -506,6 +534,9 @@ def fused_step_forward_backward(gauss_params: Dict[str, Tensor], camera: Camera,
     info.sh_factors_out = sh_factors_out
     info.half = half
     info.live_capacity = int(live_capacity)
+    info.zcut_in, info.zcut_out = zcut_in, zcut_out
+    if zcut_margins is not None:
+        info.zcut_margins = zcut_margins
 
     def check_live_total(ctx):
         """No-wait binning: the forward's launches are enqueued, now look at the frame's live total (it has normally
@@ -515,16 +546,24 @@ def fused_step_forward_backward(gauss_params: Dict[str, Tensor], camera: Camera,
         Adam step of the PREVIOUS frame and a flushed deferred update (``pre_sh``) — the trainer's retry therefore
         runs without ``binary_threshold`` (the write is not idempotent for thresholds outside (0, 1]) and finds no
         pending update."""
-        if info.pending_count is None:
-            return
-        try:
-            info.n_live = ops.bin_live_check(info.pending_count)
-        except ops.LiveListOverflow:
-            WORKSPACE.give(getattr(ctx, "arena", None))
-            ctx.arena = None
-            raise
-        info.pending_count = None
-        info.payload = info.payload[:info.n_live]
+        if info.pending_count is not None:
+            try:
+                info.n_live = ops.bin_live_check(info.pending_count)
+            except ops.LiveListOverflow:
+                WORKSPACE.give(getattr(ctx, "arena", None))
+                ctx.arena = None
+                raise
+            info.pending_count = None
+            info.payload = info.payload[:info.n_live]
+        if info.pending_verdict is not None:
+            # occlusion cuts: the verdict lands right after the forward walk; a cut tile that did not saturate inside
+            # its prefix -> the images miss contributions, the frame is abandoned like an overflowed one
+            ok = ops.zcut_check(info.pending_verdict)
+            info.pending_verdict = None
+            if not ok:
+                WORKSPACE.give(getattr(ctx, "arena", None))
+                ctx.arena = None
+                raise ops.OcclusionCutInvalid("a cut tile did not saturate inside its depth prefix")
 
     if add_mask is not None:
         info.frozen = add_mask.to(device=dev, dtype=torch.uint8).contiguous()

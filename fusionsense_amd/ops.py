@@ -224,8 +224,10 @@ def _pinned_i64(dev) -> Tensor:
 
 
 def isect_finish_live(st: dict, means2d: Tensor, radii: Tensor, depths: Tensor, conics: Tensor, opacities: Tensor,
-                      tile_width: int, tile_height: int, want_ids: bool = True):
-    """Wait for the live total, then emit + sort + offsets.  Returns what ``bin_and_sort_live`` returns."""
+                      tile_width: int, tile_height: int, want_ids: bool = True, route_hint: bool = False):
+    """Wait for the live total, then emit + sort + offsets.  Returns what ``bin_and_sort_live`` returns.
+    ``route_hint``: the caller is the fused node choosing its binning route from ``bin_live_is_dense`` — the frame's
+    density is noted for the next one (an explicit call to this chain must not redirect the fused node)."""
     lib = load()
     dev = means2d.device
     Cn, N = radii.shape
@@ -240,7 +242,8 @@ def isect_finish_live(st: dict, means2d: Tensor, radii: Tensor, depths: Tensor, 
                                        ptr(st["cum"]), tile_width, tile_height, ptr(ids), ptr(pay), stream_ptr(dev)),
              "fsgs_isect_emit_live")
         n_tiles = tile_width * tile_height
-        _DENSE_HINT[(str(dev), N, Cn * n_tiles)] = not use_tile_sort(M, Cn * n_tiles)
+        if route_hint:
+            _DENSE_HINT[(str(dev), N, Cn * n_tiles)] = not use_tile_sort(M, Cn * n_tiles)
         if use_tile_sort(M, Cn * n_tiles):
             ids_s, pay_s, offsets = tile_sort(ids, pay, Cn, tile_width, tile_height, want_ids=want_ids)
             return st["tpg"], ids_s, pay_s, offsets
@@ -347,7 +350,8 @@ def bin_live_count_async(means2d: Tensor, radii: Tensor, conics: Tensor, opaciti
 def project_bin_live_count_async(means: Tensor, quats: Tensor, log_scales: Tensor, opac_logit: Tensor,
                                  binary_threshold, viewmat: Tensor, K: Tensor, width: int, height: int,
                                  tile_width: int, tile_height: int, out: dict, half: Optional[dict] = None,
-                                 capacity: int = 0, sh_pack: Optional[tuple] = None, adam=None) -> dict:
+                                 capacity: int = 0, sh_pack: Optional[tuple] = None, adam=None,
+                                 zcut: Optional[Tensor] = None, zcut_hit: Optional[Tensor] = None) -> dict:
     """``fsgs_project_fwd_act`` + ``bin_live_count_async`` in one launch chain (one camera): the count pass projects
     its Gaussians itself.  ``out`` holds the projection's output tensors (scales_exp, opac_sig, radii [1,N],
     means2d, depths, conics).  Returns the same state ``bin_live_count_async`` does."""
@@ -364,7 +368,9 @@ def project_bin_live_count_async(means: Tensor, quats: Tensor, log_scales: Tenso
         # the caller will NOT wait for the live total before the second pass: it sizes the lists for `capacity`
         # entries, the offsets kernel clamps to it (fsgs.h: n_live_mapped[2]) and bin_live_finish checks later
         pinned._np[2] = int(capacity)
-    if sh_pack is not None or adam is not None:
+    if zcut is not None:
+        assert zcut.dtype == torch.float32 and zcut.numel() == T and zcut.is_contiguous()
+    if sh_pack is not None or adam is not None or zcut is not None:
         # independent work rides in the count pass's launches (fsgs.h): the SH forward + packing in the table scan's,
         # sh_pack = (degree, campos, features_dc, features_rest, c2w, packed, normals_world, zero_cells); a deferred
         # Adam step (`adam`: an _lib.AdamGroups made by adam_groups()) in the count pass's own
@@ -374,7 +380,7 @@ def project_bin_live_count_async(means: Tensor, quats: Tensor, log_scales: Tenso
                     ptr(zero_cells), int(zero_cells.numel()))
         else:
             tail = (0, None, None, None, None, None, None, None, 0)
-        tail = tail + (C.byref(adam) if adam is not None else None, stream_ptr(dev))
+        tail = tail + (C.byref(adam) if adam is not None else None, ptr(zcut), ptr(zcut_hit), stream_ptr(dev))
         bt = (0 if binary_threshold is None else 1, 0.0 if binary_threshold is None else float(binary_threshold))
         outs = (ptr(out["scales_exp"]), ptr(out["opac_sig"]), ptr(out["radii"]), ptr(out["means2d"]),
                 ptr(out["depths"]), ptr(out["conics"]), tile_width, tile_height, ptr(tpg), ptr(offsets), ptr(table),
@@ -389,7 +395,8 @@ def project_bin_live_count_async(means: Tensor, quats: Tensor, log_scales: Tenso
                  + (ptr(viewmat), ptr(K), width, height, 0.3, 0.01, 1e10, 0.0) + outs + tail, "fsgs_isect_count_live")
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(dev))
-        return dict(direct=True, tpg=tpg, offsets=offsets, table=table, pinned=pinned, event=ev, T=T, capacity=capacity)
+        return dict(direct=True, tpg=tpg, offsets=offsets, table=table, pinned=pinned, event=ev, T=T, capacity=capacity,
+                    zcut=zcut)
     if half is not None:  # BASELINE config #5: quats / log-scales / opacity logits read from their half mirrors
         _run(lib.fsgs_project_bin_live_count_h16,
              (N, ptr(means), ptr(half["quats"]), ptr(half["scales"]), ptr(half["opacities"]), ptr(opac_logit),
@@ -418,6 +425,48 @@ class LiveListOverflow(RuntimeError):
     def __init__(self, needed: int, capacity: int):
         super().__init__(f"live pairs {needed} > capacity {capacity}")
         self.needed, self.capacity = needed, capacity
+
+
+class OcclusionCutInvalid(RuntimeError):
+    """A frame binned with per-tile occlusion cuts (fsgs_tile_zcut_update) in which a cut tile did not saturate inside
+    its depth prefix: entries behind the cut could have contributed — the frame must be redone without cuts."""
+
+
+def zcut_verdict_buffer(dev) -> Tensor:
+    """Host-mapped int32 (verdict, landed-flag, -, -) from a ring of its own; the flag is cleared."""
+    ring = _PINNED.get(str(dev) + ":zcut")
+    if ring is None:
+        bufs = [torch.zeros(4, dtype=torch.int32).pin_memory() for _ in range(4)]
+        for b in bufs:
+            b._np = b.numpy()
+        ring = _PINNED.setdefault(str(dev) + ":zcut", dict(bufs=bufs, i=0))
+    ring["i"] = (ring["i"] + 1) % len(ring["bufs"])
+    buf = ring["bufs"][ring["i"]]
+    buf._np[0] = 0
+    buf._np[1] = 0
+    return buf
+
+
+_ZCUT_SCRATCH: dict = {}
+
+
+def zcut_scratch(dev, T: int):
+    """(tile_open [T], bad [1], zcut_hit [T]; int32): zeroed once, left zeroed by fsgs_tile_zcut_update."""
+    key = (str(dev), T)
+    t = _ZCUT_SCRATCH.get(key)
+    if t is None:
+        t = _ZCUT_SCRATCH[key] = torch.zeros(2 * T + 1, dtype=torch.int32, device=dev)
+    return t[:T], t[T:T + 1], t[T + 1:]
+
+
+def zcut_check(pinned: Tensor) -> bool:
+    """Waits for the verdict of fsgs_tile_zcut_update (normally long landed); True = the frame's cuts were valid."""
+    arr = pinned._np
+    for _ in range(2000000):
+        if arr[1] != 0:
+            return int(arr[0]) == 0
+    torch.cuda.synchronize()
+    return int(arr[0]) == 0
 
 
 def bin_live_check(st: dict) -> int:
@@ -450,7 +499,7 @@ def bin_live_finish(st: dict, means2d: Tensor, radii: Tensor, depths: Tensor, co
         WORKSPACE.give(st["table"])
         st2 = isect_count_live_async(means2d, radii, conics, opacities, tile_width, tile_height)
         return isect_finish_live(st2, means2d, radii, depths, conics, opacities, tile_width, tile_height,
-                                 want_ids=False)
+                                 want_ids=False, route_hint=True)
     pay_s = torch.empty(M, dtype=torch.int32, device=dev)
     if M > 0 and split:
         # large buckets are split into depth slabs before the LDS sorts (no radix sort, no emission-order lists)
@@ -460,13 +509,13 @@ def bin_live_finish(st: dict, means2d: Tensor, radii: Tensor, depths: Tensor, co
         _run(lib.fsgs_bin_live_emit_split, (Cn, N, ptr(means2d), ptr(radii), ptr(depths), ptr(conics), ptr(opacities),
                                            tile_width, tile_height, ptr(st["offsets"]), ptr(st["table"]), M,
                                            arena.data_ptr(), arena.data_ptr() + b2, arena.data_ptr() + 2 * b2, sbytes,
-                                           ptr(pay_s), stream_ptr(dev)), "fsgs_tile_sort")
+                                           ptr(pay_s), ptr(st.get("zcut")), stream_ptr(dev)), "fsgs_tile_sort")
         WORKSPACE.give(arena)
     elif M > 0:
         buckets = WORKSPACE.take(8 * M, dev)
         _run(lib.fsgs_bin_live_emit, (Cn, N, ptr(means2d), ptr(radii), ptr(depths), ptr(conics), ptr(opacities),
                                      tile_width, tile_height, ptr(st["offsets"]), ptr(st["table"]), M, ptr(buckets),
-                                     ptr(pay_s), stream_ptr(dev)), "fsgs_tile_sort")
+                                     ptr(pay_s), ptr(st.get("zcut")), stream_ptr(dev)), "fsgs_tile_sort")
         WORKSPACE.give(buckets)
     WORKSPACE.give(st["table"])
     if st.get("capacity", 0):
@@ -710,7 +759,7 @@ class _Rasterize(torch.autograd.Function):
                                            -M if ends_on_device else M,
                                            ptr(backgrounds), width, height, tw, th, int(normalize_last),
                                            ptr(render), ptr(alphas), ptr(last_ids), ptr(records), ptr(n_rec),
-                                           ptr(seg_state), None, None, stream_ptr(dev)),
+                                           ptr(seg_state), None, None, None, stream_ptr(dev)),
                  "fsgs_raster_fwd_quad", f"_d{D}")
             empty = torch.empty(0, device=dev)
             ctx.save_for_backward(records if records is not None else empty,

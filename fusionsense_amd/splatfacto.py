@@ -293,6 +293,8 @@ class DensifyStrategy:
             logit = torch.logit(torch.tensor(reset_value)).item()
             if hasattr(trainer, "sync_optimizer_state"):
                 trainer.sync_optimizer_state()
+            if hasattr(trainer, "drop_occlusion_cuts"):
+                trainer.drop_occlusion_cuts()  # (nothing saturates where it did any more)
             op = trainer.params["opacities"]
             op.data.clamp_(max=logit)  # (in place: the parameter may be a view of the trainer's flat geometry slab)
             if hasattr(trainer, "mark_params_written"):
@@ -409,6 +411,8 @@ class DensifyStrategy:
             trainer.flush()
         if hasattr(trainer, "sync_optimizer_state"):
             trainer.sync_optimizer_state()  # (sharded geometry step: whole moment tensors are about to be compacted)
+        if hasattr(trainer, "drop_occlusion_cuts"):
+            trainer.drop_occlusion_cuts()
         keep8 = keep_old.to(torch.uint8).contiguous()
         positions = ops.mask_positions(keep8)
         n_final = n_keep_old + n_keep_new

@@ -250,7 +250,7 @@ int fsgs_raster_fwd_quad(int C, int D, const float *packed, const int32_t *paylo
                          int width, int height, int tile_width, int tile_height, int normalize_last,
                          float *render, float *alphas, int32_t *last_ids, float *records, int32_t *n_rec,
                          float *seg_state, float *render_extra, float *max_last,
-                         fsgs_stream_t stream);
+                         int32_t *tile_open /* nullable [C*th*tw]: see fsgs_tile_zcut_update */, fsgs_stream_t stream);
 int fsgs_raster_bwd_quad(int C, int D, const float *records, const int32_t *n_rec,
                          const int32_t *isect_offsets, int64_t n_isects, const float *backgrounds,
                          int width, int height, int tile_width, int tile_height, int normalize_last,
@@ -345,6 +345,11 @@ typedef struct fsgs_adam_groups {
  *  - adam != NULL: that Adam step (fsgs_adam_step_h16 semantics) runs in the launch of the count pass itself.  None
  *    of its tensors may be an input of the count pass (means, quats, log_scales, opacity logits): it is meant for
  *    the SH features' update of the previous iteration, which the colours of this one (above) then see.
+ *  - tile_zcut != NULL (occlusion cut, one float per tile, +inf = none): a pair whose Gaussian lies behind its tile's
+ *    cut depth is neither counted here nor binned by fsgs_bin_live_emit(_split), which must be given the SAME array;
+ *    the cuts come from fsgs_tile_zcut_update of an earlier frame of the same view, which also validates this frame.
+ *    zcut_hit (nullable, [T] int32, zeroed): zcut_hit[t] <- 1 when a LIVE pair of tile t fell behind its cut (the
+ *    count pass then still reach-tests the pairs it drops); fsgs_tile_zcut_update reads and clears the flags.
  * _h16: quats / log_scales / opacity logits / features are IEEE-half mirrors (as in fsgs_project_bin_live_count_h16
  * and fsgs_sh_fwd_pack_h16). */
 int fsgs_project_bin_live_count_sh_pack(
@@ -354,7 +359,8 @@ int fsgs_project_bin_live_count_sh_pack(
     float *depths, float *conics, int tile_width, int tile_height, int32_t *tiles_per_gauss, int32_t *isect_offsets,
     void *table_scratch, size_t table_bytes, int32_t *n_live_mapped, int degree, const float *campos,
     const float *features_dc, const float *features_rest, const float *c2w, float *packed, float *normals_world,
-    float *zero_cells, int n_zero, const fsgs_adam_groups *adam, fsgs_stream_t stream);
+    float *zero_cells, int n_zero, const fsgs_adam_groups *adam, const float *tile_zcut, int32_t *zcut_hit,
+    fsgs_stream_t stream);
 int fsgs_project_bin_live_count_sh_pack_h16(
     int N, const float *means, const void *quats_h, const void *log_scales_h, void *opac_logit_h,
     float *opac_logit_master, int binarise, float binary_threshold, const float *viewmat, const float *K, int width,
@@ -363,11 +369,11 @@ int fsgs_project_bin_live_count_sh_pack_h16(
     int32_t *tiles_per_gauss, int32_t *isect_offsets, void *table_scratch, size_t table_bytes, int32_t *n_live_mapped,
     int degree, const float *campos, const void *features_dc_h, const void *features_rest_h, const float *c2w,
     float *packed, float *normals_world, float *zero_cells, int n_zero, const fsgs_adam_groups *adam,
-    fsgs_stream_t stream);
+    const float *tile_zcut, int32_t *zcut_hit, fsgs_stream_t stream);
 int fsgs_bin_live_emit(int C, int N, const float *means2d, const int32_t *radii, const float *depths,
                        const float *conics, const float *opacities, int tile_width, int tile_height,
                        const int32_t *isect_offsets, const void *table_scratch, int64_t n_live, void *buckets,
-                       int32_t *payload_sorted, fsgs_stream_t stream);
+                       int32_t *payload_sorted, const float *tile_zcut /* nullable; C == 1 */, fsgs_stream_t stream);
 
 /* fsgs_bin_live_emit for buckets of any size: tiles with more than 1024 live pairs are first split into depth
  * slabs of ~512 (monotone in depth, so sorted slabs in order = a sorted tile), every slab sorted like a small
@@ -378,7 +384,27 @@ int fsgs_bin_live_emit_split(int C, int N, const float *means2d, const int32_t *
                              const float *conics, const float *opacities, int tile_width, int tile_height,
                              const int32_t *isect_offsets, const void *table_scratch, int64_t n_live, void *buckets,
                              void *buckets2, void *split_scratch, size_t split_bytes, int32_t *payload_sorted,
-                             fsgs_stream_t stream);
+                             const float *tile_zcut /* nullable; C == 1 */, fsgs_stream_t stream);
+
+/* Occlusion cut (no gsplat equivalent; an exact speculation on temporal coherence).  A dense scene's tiles turn opaque
+ * after a small depth prefix of their sorted lists (BASELINE config #4: 2 % of 39 M live pairs are ever composited), yet
+ * every pair is reach-tested twice, binned and sorted.  A trainer that revisits its views hands the two binning passes a
+ * per-tile cut depth taken from the view's previous frame: pairs behind it are not binned.  The kept pairs are a depth
+ * PREFIX of the tile's full list, so a frame in which every cut tile saturates inside its prefix is bit-identical to the
+ * uncut frame — images, last_ids, record streams, gradients; any other frame must be redone without cuts.
+ * fsgs_raster_fwd_quad(tile_open != NULL) marks the tiles in which a pixel was still transparent at the end of its list;
+ * this call (one camera) turns that and last_ids into
+ *   zcut_out[t] = +inf if tile t was open, else depth(deepest composited entry of t) + max(margin_span * (that depth -
+ *                 the tile's first entry's depth), margin_rel * that depth),
+ *   verdict_mapped[0] = 1 if an open tile had been binned with a finite zcut_in AND lost a live pair to it (zcut_hit[t];
+ *                       without the flags: any open tile under a finite cut) — the frame is INVALID —, else 0, and
+ *   verdict_mapped[1] = 1 once [0] has landed (host-mapped memory; the caller clears [1] beforehand);
+ * tile_open and zcut_hit are left cleared, bad_scratch (one zeroed int32 on the device) is left zeroed. */
+int fsgs_tile_zcut_update(int tile_width, int tile_height, int width, int height, const int32_t *last_ids,
+                          const int32_t *payload, const float *depths, const int32_t *isect_offsets,
+                          int32_t *tile_open, const float *zcut_in, int32_t *zcut_hit, float *zcut_out,
+                          int32_t *bad_scratch,
+                          int32_t *verdict_mapped, float margin_span, float margin_rel, fsgs_stream_t stream);
 
 /* Split packed gradient records into the five gsplat-shaped arrays (written, not accumulated).
  * rezero != 0: v_packed is cleared after it has been read, ready for the next frame's atomics. */

@@ -1,0 +1,173 @@
+"""Occlusion cuts of the tape-free step in dense scenes (trainer.py: FSGS_OCCLUSION_CUT): pairs behind
+the depth at which the previous frame of the same view saturated are not binned.  The claim is exactness, so the
+checker is the same frame without cuts: images bit for bit, every tile's list a prefix of the uncut list, gradients to
+the float atomics' reordering; a frame whose cuts turn out too tight is detected on the device, redone uncut and leaves
+no trace.  All through the C-ABI (fsgs_project_bin_live_count_sh_pack / fsgs_bin_live_emit* with ``tile_zcut``,
+fsgs_raster_fwd_quad's ``tile_open``, fsgs_tile_zcut_update)."""
+import math
+
+import pytest
+import torch
+
+from fusionsense_amd import scenes
+from helpers import rel_err
+
+pytestmark = pytest.mark.gpu
+
+N_DENSE, RES = 1_200_000, 640
+
+
+@pytest.fixture(scope="module")
+def dense_scene(dev):
+    params = {k: v.to(dev) for k, v in scenes.lego_like_scene(N_DENSE, seed=2).items()}
+    cams = scenes.hemisphere_cameras(2, width=RES, height=RES, focal=888.9, seed=2)
+    g = torch.Generator().manual_seed(9)
+    tgt = {"rgb": torch.rand(RES, RES, 3, generator=g).to(dev), "depth": torch.rand(RES, RES, 1, generator=g).to(dev) * 4,
+           "normal": torch.rand(RES, RES, 3, generator=g).to(dev)}
+    return params, cams, tgt
+
+
+def _frame(tr, cam, tgt):
+    loss, out = tr.train_step(cam, tgt, optimizer_step=False)
+    info = out["info"]
+    T = math.ceil(RES / 16) ** 2
+    offs = info.isect_offsets.flatten()[:T].clone()
+    grads = {k: v.clone() for k, v in tr.slab.views.items()}
+    return dict(loss=float(loss), rgb=out["rgb"].clone(), depth=out["depth"].clone(), normal=out["normal"].clone(),
+                alpha=out["accumulation"].clone(), payload=info.payload.clone(), offs=offs, n_live=info.n_live,
+                last=info.last_ids.clone(), grads=grads)
+
+
+def _same_frame(ref, got, cut, shrink=0.6):
+    for k in ("rgb", "depth", "normal", "alpha"):
+        assert torch.equal(ref[k], got[k]), k
+    assert ref["loss"] == got["loss"]
+    if cut:
+        # every tile's list is a prefix of the uncut list (same depth order), and it is shorter where it matters
+        assert got["n_live"] < shrink * ref["n_live"], (got["n_live"], ref["n_live"])
+        T = ref["offs"].numel()
+        ends_r = torch.cat([ref["offs"][1:], ref["offs"].new_tensor([ref["n_live"]])])
+        ends_g = torch.cat([got["offs"][1:], got["offs"].new_tensor([got["n_live"]])])
+        len_r, len_g = ends_r - ref["offs"], ends_g - got["offs"]
+        assert bool((len_g <= len_r).all())
+        tile_of = torch.repeat_interleave(torch.arange(T, device=len_g.device), len_g.long())
+        pos = torch.arange(got["n_live"], device=len_g.device) - got["offs"].long()[tile_of]
+        assert torch.equal(got["payload"], ref["payload"][ref["offs"].long()[tile_of] + pos])
+        # the index of a pixel's last contributor, relative to its tile's list start
+        # (tiles are 16x16; last_ids are list positions)
+        th = tw = math.ceil(RES / 16)
+        ii = torch.arange(RES, device=len_g.device) // 16
+        tmap = (ii[:, None] * tw + ii[None, :]).flatten()
+        hit_r, hit_g = ref["last"].flatten(), got["last"].flatten()
+        some = hit_r > 0  # (0 = no contributor at all, gsplat's initial value)
+        assert torch.equal(some, hit_g > 0)
+        assert torch.equal((hit_r - ref["offs"][tmap])[some], (hit_g - got["offs"][tmap])[some])
+    else:
+        assert ref["n_live"] == got["n_live"] and torch.equal(ref["payload"], got["payload"])
+    for k in ref["grads"]:
+        assert rel_err(got["grads"][k], ref["grads"][k]) < 2e-4, k
+
+
+def test_cut_frames_equal_uncut_frames(dev, dense_scene):
+    from fusionsense_amd.trainer import SplatTrainer
+    params, cams, tgt = dense_scene
+    plain = SplatTrainer(params, dev, sh_degree=3)
+    plain.occlusion_cut_mode = "0"
+    cutting = SplatTrainer(params, dev, sh_degree=3)
+    cutting.occlusion_cut_mode = "1"
+    ref = [_frame(plain, c, tgt) for c in cams]
+    first = [_frame(cutting, c, tgt) for c in cams]   # no cuts known yet: plain frames that record them
+    assert cutting.cut_frames == 0 and len(cutting._zcuts) == 2
+    for r, g in zip(ref, first):
+        _same_frame(r, g, cut=False)
+    zc = next(iter(cutting._zcuts.values()))
+    finite = torch.isfinite(zc)
+    assert float(finite.float().mean()) > 0.5, "the dense scene saturates in most tiles"
+    for rounds in range(2):  # (the second round runs on cuts recorded by CUT frames)
+        again = [_frame(cutting, c, tgt) for c in cams]
+        for r, g in zip(ref, again):
+            _same_frame(r, g, cut=True)
+    assert cutting.cut_frames == 4 and cutting.cut_redone == 0
+    # the no-wait capacity follows what the frames need
+    assert cutting.live_overflows == 0
+
+
+def test_too_tight_cuts_are_detected_and_the_frame_redone(dev, dense_scene):
+    from fusionsense_amd.trainer import SplatTrainer
+    params, cams, tgt = dense_scene
+    plain = SplatTrainer(params, dev, sh_degree=3)
+    plain.occlusion_cut_mode = "0"
+    ref = _frame(plain, cams[0], tgt)
+    tr = SplatTrainer(params, dev, sh_degree=3)
+    tr.occlusion_cut_mode = "1"
+    _frame(tr, cams[0], tgt)
+    (key, zc), = tr._zcuts.items()
+    good = zc.clone()
+    # (a) every cut far too near: lists empty or short, no tile saturates
+    tr._zcuts[key] = torch.where(torch.isfinite(zc), torch.full_like(zc, 0.05), zc)
+    got = _frame(tr, cams[0], tgt)
+    assert tr.cut_frames == 1 and tr.cut_redone == 1
+    _same_frame(ref, got, cut=False)
+    # the redone frame records what an uncut frame records — with this view's margins doubled after the miss
+    assert torch.equal(torch.isfinite(tr._zcuts[key]), torch.isfinite(good))
+    fin = torch.isfinite(good)
+    assert bool((tr._zcuts[key][fin] >= good[fin]).all()) and tr._zcut_widen[key] == 2.0
+    # (b) one single tile cut just in front of its saturation depth
+    t = int(torch.nonzero(torch.isfinite(good))[good[torch.isfinite(good)].argmax()])
+    bad = good.clone()
+    first_depth = float(tr.last_info.depths[0, tr.last_info.payload[ref["offs"][t].long()] & 0x0FFFFFFF])
+    bad[t] = first_depth * (1 + 1e-6)
+    tr._zcuts[key] = bad
+    got = _frame(tr, cams[0], tgt)
+    assert tr.cut_frames == 2 and tr.cut_redone == 2
+    _same_frame(ref, got, cut=False)
+    # (c) and with the good cuts back: a cut frame, not redone
+    got = _frame(tr, cams[0], tgt)
+    assert tr.cut_frames == 3 and tr.cut_redone == 2
+    _same_frame(ref, got, cut=True, shrink=1.0)  # (this view's margins are 4x the default by now)
+
+
+def test_training_with_cuts_is_the_same_training(dev, dense_scene):
+    """Stepping parameters (Adam on, statistics on): cuts go stale by one visit of the other view; frames stay exact or
+    are redone.  Compared with the uncut run to the float atomics' noise, like the no-wait test does."""
+    from fusionsense_amd.splatfacto import DensifyStrategy, SplatfactoConfig
+    from fusionsense_amd.trainer import PARAM_ORDER, SplatTrainer
+    params, cams, tgt = dense_scene
+
+    def run(mode):
+        st = DensifyStrategy(SplatfactoConfig(), num_train_data=2, stats_only=True)
+        tr = SplatTrainer(params, dev, sh_degree=3, strategy=st)
+        tr.occlusion_cut_mode = mode
+        losses = [float(tr.train_step(cams[it % 2], tgt)[0]) for it in range(8)]
+        return tr, st, losses
+
+    a, sa, la = run("0")
+    b, sb, lb = run("1")
+    assert b.cut_frames == 6 and b.cut_redone <= 2, (b.cut_frames, b.cut_redone)
+    assert la[0] == lb[0] and max(abs(x - y) for x, y in zip(la, lb)) < 2e-4 * abs(la[0])
+    assert torch.equal(sa.vis_counts, sb.vis_counts) or float((sa.vis_counts != sb.vis_counts).float().mean()) < 1e-3
+    for k in PARAM_ORDER:
+        d = (a.params[k].data - b.params[k].data).abs()
+        assert float((d > 2e-5).float().mean()) < 2e-2, k
+
+
+def test_cuts_are_dropped_when_the_model_is_rebuilt(dev):
+    from fusionsense_amd.splatfacto import DensifyStrategy, SplatfactoConfig
+    from fusionsense_amd.trainer import SplatTrainer
+    params = {k: v.to(dev) for k, v in scenes.lego_like_scene(60_000, seed=3).items()}
+    cams = scenes.hemisphere_cameras(2, width=256, height=256, focal=355.0, seed=3)
+    g = torch.Generator().manual_seed(1)
+    tgt = {"rgb": torch.rand(256, 256, 3, generator=g).to(dev), "depth": torch.rand(256, 256, 1, generator=g).to(dev) * 4,
+           "normal": torch.rand(256, 256, 3, generator=g).to(dev)}
+    cfg = SplatfactoConfig(warmup_length=2, refine_every=4, reset_alpha_every=1000)
+    st = DensifyStrategy(cfg, num_train_data=2)
+    tr = SplatTrainer(params, dev, sh_degree=3, strategy=st)
+    tr.occlusion_cut_mode = "1"
+    seen_drop = False
+    for it in range(10):
+        n0, had = tr.num_gaussians(), len(tr._zcuts)
+        tr.train_step(cams[it % 2], tgt)
+        if tr.num_gaussians() != n0:
+            assert len(tr._zcuts) == 0, "refinement forgets the cuts"
+            seen_drop = seen_drop or had > 0
+    assert seen_drop and tr.cut_frames > 0

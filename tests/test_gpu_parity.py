@@ -840,7 +840,7 @@ def test_folded_entry_points_equal_the_chains_they_replace(dev):
         0.3, 0.01, 1e10, 0.0, ptr(c["scales_exp"]), ptr(c["opac_sig"]), ptr(c["radii"]), ptr(c["means2d"]),
         ptr(c["depths"]), ptr(c["conics"]), tw, th, ptr(tpg_c), ptr(offs_c), ptr(table), tbytes, None, 3,
         ptr(cd["campos"]), ptr(P["features_dc"]), ptr(P["features_rest"]), ptr(cd["c2w"]), ptr(pk_c), ptr(nw_c),
-        ptr(mx_c), n_cells, C.byref(groups), sp) == 0
+        ptr(mx_c), n_cells, C.byref(groups), None, None, sp) == 0
     torch.cuda.synchronize()
     for k in ("scales_exp", "opac_sig", "radii", "depths", "means2d", "conics"):
         assert torch.equal(c[k], b[k]), k          # (the same kernel body as fsgs_project_bin_live_count)
@@ -866,7 +866,7 @@ def test_folded_entry_points_equal_the_chains_they_replace(dev):
     extra = torch.empty(1, H, W, 3, **f32)
     assert lib.fsgs_raster_fwd_quad(1, 4, ptr(pk_a), ptr(payload), ptr(offsets), M, None, W, H, tw, th, 1, ptr(render),
                                     ptr(alphas), ptr(last_ids), ptr(records), ptr(n_rec), ptr(seg_state), ptr(extra),
-                                    ptr(mx_a), sp) == 0
+                                    ptr(mx_a), None, sp) == 0
     g = torch.Generator().manual_seed(3)
     bg = torch.tensor([1.0, 0.5, 0.25], device=dev)
     depth_gt, normal_gt = torch.rand(H, W, 1, generator=g).to(dev), torch.rand(H, W, 3, generator=g).to(dev)
