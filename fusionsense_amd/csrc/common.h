@@ -225,6 +225,7 @@ struct ShPackRider {
     const float *c2w;
     float *packed, *normals_world, *zero_cells;
     int n_zero;
+    const uint8_t *kept;                       // nullable [N]: 0 = the Gaussian has no binned pair (no colours, no record)
 };
 
 // ---- attribute storage (BASELINE config #5) ---------------------------------------------------------------------

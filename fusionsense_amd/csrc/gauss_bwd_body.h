@@ -29,7 +29,11 @@ __device__ __forceinline__ void gauss_bwd_load_line(int n, const GaussBwdFused &
                                                     float4 &pc, float4 &pd) {
     pa = fz.v_packed[n * 4 + 0]; pb = fz.v_packed[n * 4 + 1]; pc = fz.v_packed[n * 4 + 2]; pd = fz.v_packed[n * 4 + 3];
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    fz.v_packed[n * 4 + 0] = zero4; fz.v_packed[n * 4 + 1] = zero4; fz.v_packed[n * 4 + 2] = zero4; fz.v_packed[n * 4 + 3] = zero4;
+    // (a line nothing was added to is already clear: in dense scenes that is most of them, 64 B of stores less each)
+    auto any4 = [](const float4 v) { return (__float_as_uint(v.x) | __float_as_uint(v.y) | __float_as_uint(v.z) | __float_as_uint(v.w)) != 0u; };
+    if (any4(pa) || any4(pb) || any4(pc) || any4(pd)) {
+        fz.v_packed[n * 4 + 0] = zero4; fz.v_packed[n * 4 + 1] = zero4; fz.v_packed[n * 4 + 2] = zero4; fz.v_packed[n * 4 + 3] = zero4;
+    }
     if (fz.replica_rows > 0 && radii[n] > 0 &&
         grad_spread(conics[n * 3 + 0], conics[n * 3 + 1], conics[n * 3 + 2])) {
         // a large Gaussian: fold (and clear) the replicas the compositing backward spread its atomics over

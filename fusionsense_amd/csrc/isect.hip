@@ -375,6 +375,9 @@ struct BinProjArgs {
     // count pass only (nullable): zcut_hit[t] <- 1 when a LIVE pair of tile t fell behind its cut.  An open tile that
     // lost no live pair has its complete list, so it does not spoil the frame (fsgs_tile_zcut_update).
     int32_t *zcut_hit;
+    // count pass only (nullable, [N] bytes): kept[n] <- 1 if Gaussian n has at least one binned (live, not cut) pair,
+    // else 0.  A Gaussian without one is in no list: the frame needs neither its colours nor its packed record.
+    uint8_t *kept;
 };
 
 template <bool SCATTER, bool MULTI, bool PROJ, bool HALF, int BT>
@@ -434,6 +437,7 @@ isect_live_bin_body(const int block, int C, int N, const float *__restrict__ mea
                 db = (uint32_t)__float_as_int(po.depth);
             }
             if (tiles_per_gauss) tiles_per_gauss[idx] = cnt;
+            if (!SCATTER && pj.kept) pj.kept[idx] = 0;  // (raised below, after a barrier, by whichever thread bins a pair)
         } else if (idx < total) {
             const int r = radii[idx];
             if (r > 0) {
@@ -521,6 +525,7 @@ isect_live_bin_body(const int block, int C, int N, const float *__restrict__ mea
         int y = rc.y + jj / rc.z, x = rc.x + jj % rc.z;
         float *zc = pj.tile_zcut ? (pj.zcut_in_lds ? reinterpret_cast<float *>(slots + T) : const_cast<float *>(pj.tile_zcut)) : nullptr;
         float z_o = __uint_as_float(L.depth[o]);
+        bool told = false;  // this thread has raised its current owner's kept flag
         for (; p < p_end; ++p) {
             const CullPrep cp = {A.x, A.y, A.z, A.w, B.x, B.y, B.z, B.w};
             // (occlusion cut, one camera: a pair behind its tile's cut depth is not binned.  The count pass still
@@ -540,6 +545,7 @@ isect_live_bin_body(const int block, int C, int N, const float *__restrict__ mea
                 const int64_t gidx = idx0 + o;
                 const int c = (C == 1) ? 0 : (int)(gidx / N);
                 const int slot = atomicAdd(&slots[c * n_tiles + y * tw + x], 1);
+                if (!SCATTER && PROJ && pj.kept && !told) { pj.kept[gidx] = 1; told = true; }
                 // (slot >= bucket_cap only when the caller sized the buffers from an estimate that the frame
                 // exceeded: the offsets were clamped to it by tile_offsets_kernel, the frame is redone)
                 if (SCATTER && slot < bucket_cap)
@@ -550,6 +556,7 @@ isect_live_bin_body(const int block, int C, int N, const float *__restrict__ mea
                     do { ++o; } while (L.rect[o].w == 0);
                     rc = L.rect[o]; A = L.a[o]; B = L.b[o];
                     z_o = __uint_as_float(L.depth[o]);
+                    told = false;
                     jj = 0; x = rc.x; y = rc.y;
                 }
             } else if (++x == rc.x + rc.z) {
@@ -912,7 +919,8 @@ static int project_bin_live_count_impl(int N, const float *means, const void *qu
                                            int32_t *isect_offsets, void *table_scratch, size_t table_bytes,
                                            int32_t *n_live_mapped, fsgs_stream_t stream,
                                            const ShPackRider *rider = nullptr, const fsgs_adam_groups *adam = nullptr,
-                                           const float *tile_zcut = nullptr, int32_t *zcut_hit = nullptr) {
+                                           const float *tile_zcut = nullptr, int32_t *zcut_hit = nullptr,
+                                           uint8_t *kept = nullptr) {
     if (N < 0 || tile_width < 1 || tile_height < 1 || !isect_offsets) return FSGS_EINVAL;
     const int64_t T64 = (int64_t)tile_width * tile_height;
     if (T64 > fsgs_bin_live_max_tiles()) return FSGS_EINVAL;
@@ -951,6 +959,9 @@ static int project_bin_live_count_impl(int N, const float *means, const void *qu
                       binary_threshold, reinterpret_cast<__half *>(opac_logit_h), attr_half, nullptr, 0, nullptr};
     size_t extra_lds = 0;
     bin_place_zcut(pj, tile_zcut, zcut_hit, T, total, extra_lds);
+    pj.kept = kept;
+    ShPackRider rider_kept;
+    if (rider && kept) { rider_kept = *rider; rider_kept.kept = kept; rider = &rider_kept; }
 #define FSGS_BIN_PCOUNT(HF)                                                                                         \
     bin_launch<false, true, HF>(extra_lds, T, total, nb, s, 1, N, (const float *)nullptr, (const int32_t *)nullptr,   \
                                 (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, tile_width,  \
@@ -989,14 +1000,14 @@ extern "C" int fsgs_project_bin_live_count_sh_pack(
     void *table_scratch, size_t table_bytes, int32_t *n_live_mapped, int degree, const float *campos,
     const float *features_dc, const float *features_rest, const float *c2w, float *packed, float *normals_world,
     float *zero_cells, int n_zero, const fsgs_adam_groups *adam, const float *tile_zcut, int32_t *zcut_hit,
-    fsgs_stream_t stream) {
+    uint8_t *kept, fsgs_stream_t stream) {
     const ShPackRider r = {N, degree, 0, means, campos, features_dc, features_rest, radii, depths, means2d, conics,
-                           opac_out, quats, log_scales, c2w, packed, normals_world, zero_cells, n_zero};
+                           opac_out, quats, log_scales, c2w, packed, normals_world, zero_cells, n_zero, nullptr};
     return project_bin_live_count_impl(N, means, quats, log_scales, opac_logit, nullptr, 0, binarise, binary_threshold,
                                        viewmat, K, width, height, eps2d, near_plane, far_plane, radius_clip, scales_out,
                                        opac_out, radii, means2d, depths, conics, tile_width, tile_height, tiles_per_gauss,
                                        isect_offsets, table_scratch, table_bytes, n_live_mapped, stream,
-                                       packed ? &r : nullptr, adam, tile_zcut, zcut_hit);
+                                       packed ? &r : nullptr, adam, tile_zcut, zcut_hit, kept);
 }
 
 extern "C" int fsgs_project_bin_live_count_sh_pack_h16(
@@ -1007,14 +1018,14 @@ extern "C" int fsgs_project_bin_live_count_sh_pack_h16(
     int32_t *tiles_per_gauss, int32_t *isect_offsets, void *table_scratch, size_t table_bytes, int32_t *n_live_mapped,
     int degree, const float *campos, const void *features_dc_h, const void *features_rest_h, const float *c2w,
     float *packed, float *normals_world, float *zero_cells, int n_zero, const fsgs_adam_groups *adam,
-    const float *tile_zcut, int32_t *zcut_hit, fsgs_stream_t stream) {
+    const float *tile_zcut, int32_t *zcut_hit, uint8_t *kept, fsgs_stream_t stream) {
     const ShPackRider r = {N, degree, 1, means, campos, features_dc_h, features_rest_h, radii, depths, means2d, conics,
-                           opac_out, quats_h, log_scales_h, c2w, packed, normals_world, zero_cells, n_zero};
+                           opac_out, quats_h, log_scales_h, c2w, packed, normals_world, zero_cells, n_zero, nullptr};
     return project_bin_live_count_impl(N, means, quats_h, log_scales_h, opac_logit_master, opac_logit_h, 1, binarise,
                                        binary_threshold, viewmat, K, width, height, eps2d, near_plane, far_plane,
                                        radius_clip, scales_out, opac_out, radii, means2d, depths, conics, tile_width,
                                        tile_height, tiles_per_gauss, isect_offsets, table_scratch, table_bytes,
-                                       n_live_mapped, stream, packed ? &r : nullptr, adam, tile_zcut, zcut_hit);
+                                       n_live_mapped, stream, packed ? &r : nullptr, adam, tile_zcut, zcut_hit, kept);
 }
 
 extern "C" int fsgs_project_bin_live_count(int N, const float *means, const float *quats, const float *log_scales,

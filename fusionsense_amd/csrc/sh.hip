@@ -9,6 +9,8 @@
 // lane consumes its own record; LDS rows are padded by one dword so the per-lane stride is odd.
 #include <math.h>
 
+#include <atomic>
+#include <cstdlib>
 #include "common.h"
 #include "normal_math.h"
 #include "gauss_bwd_body.h"
@@ -342,6 +344,7 @@ struct ShPackArgs {
     float4 *packed;
     float *normals_world, *zero_cells;
     int n_zero;
+    const uint8_t *kept;  // nullable [N] (sh_fwd_pack_direct_body only): 0 = in no list, see ShPackRider
 };
 
 template <int KT, bool SPLIT, bool PACK, bool HALF = false>
@@ -922,6 +925,10 @@ struct GaussShArgs {
     float4 *v_rgb_masked;
     int N, degree, width, height;
     float eps2d;
+    // dense scenes: the coefficients (192 of ~320 B read per Gaussian) are fetched only AFTER the gradient line, and
+    // only by the Gaussians whose line carries a colour gradient — a dependent load, so only where most lines are
+    // empty (large N: config #4 composites 2 % of its pairs); the outputs are the same numbers either way
+    int lazy_sh;
 };
 
 template <bool HALF>
@@ -936,18 +943,22 @@ gauss_sh_bwd_kernel(GaussShArgs A, GaussBwdFused fz) {
     float *my = lds + threadIdx.x * pitch;
     if (n < N) {
         ShF3 cf[16];
-        load_sh_row<HALF>(A.dc, A.rest, n, N, cf);
+        if (!A.lazy_sh) load_sh_row<HALF>(A.dc, A.rest, n, N, cf);
         const float mx = A.means[n * 3 + 0], myy = A.means[n * 3 + 1], mz = A.means[n * 3 + 2];
         const int rad0 = A.radii[n];
         float4 pa, pb, pc, pd;
         gauss_bwd_load_line(n, fz, A.radii, A.conics, pa, pb, pc, pd);
+        // (lazy: a Gaussian without colour gradient has vr = vg = vb = 0 below whatever its coefficients are: every
+        // coefficient gradient and the view-direction share of v_means are zero)
+        const bool coloured = rad0 > 0 && (pa.x != 0.f || pa.y != 0.f || pa.z != 0.f);
+        if (A.lazy_sh && coloured) load_sh_row<HALF>(A.dc, A.rest, n, N, cf);
         const int kk = (A.degree + 1) * (A.degree + 1);
         float vr = 0.f, vg = 0.f, vb = 0.f;
         float share[3] = {0.f, 0.f, 0.f};
         {
             float b[kMaxK], bx[kMaxK], by[kMaxK], bz[kMaxK];
             float dx = 0.f, dy = 0.f, dz = 0.f, inorm = 0.f;
-            const bool vis = rad0 > 0;
+            const bool vis = A.lazy_sh ? coloured : rad0 > 0;
             if (vis) {
                 dx = mx - A.campos[0]; dy = myy - A.campos[1]; dz = mz - A.campos[2];
                 inorm = sh_inv_norm(dx, dy, dz);
@@ -993,6 +1004,13 @@ gauss_sh_bwd_kernel(GaussShArgs A, GaussBwdFused fz) {
     unstage_rows<45>(A.v_rest + (int64_t)n0 * 45, rows, 45, lds, pitch, 3);
 }
 
+// from this many Gaussians on, fsgs_gauss_sh_bwd fetches coefficients lazily (GaussShArgs::lazy_sh)
+static std::atomic<int> g_lazy_sh_min_n{[] {
+    const char *e = getenv("FSGS_LAZY_SH_MIN_N");
+    return e ? atoi(e) : (1 << 20);
+}()};
+extern "C" int fsgs_set_lazy_sh_min_n(int n) { return g_lazy_sh_min_n.exchange(n); }
+
 static int gauss_sh_bwd_impl(int N, int degree, const float *means, const float *campos, const void *features_dc,
                              const void *features_rest, const void *quats, const void *log_scales, int attr_half,
                              const float *scales, const float *opac, const float *viewmat, const float *K,
@@ -1011,7 +1029,8 @@ static int gauss_sh_bwd_impl(int N, int degree, const float *means, const float 
     if ((xys_grad_norm || vis_counts || max_2Dsize) && !(xys_grad_norm && vis_counts && max_2Dsize)) return FSGS_EINVAL;
     GaussShArgs A = {means, campos, features_dc, features_rest, quats, scales, viewmat, K, radii, conics,
                      v_features_dc, v_features_rest, v_means, v_quats, v_log_scales,
-                     reinterpret_cast<float4 *>(v_rgb_masked), N, degree, width, height, eps2d};
+                     reinterpret_cast<float4 *>(v_rgb_masked), N, degree, width, height, eps2d, 0};
+    A.lazy_sh = N >= g_lazy_sh_min_n.load(std::memory_order_relaxed) ? 1 : 0;
     GaussBwdFused fz{};
     fz.v_packed = reinterpret_cast<float4 *>(v_packed);
     fz.log_scales = log_scales; fz.opac = opac; fz.c2w = c2w; fz.absgrad = absgrad; fz.v_opac_logit = v_opac_logit;
@@ -1218,10 +1237,13 @@ __device__ __forceinline__ void sh_fwd_pack_direct_body(int block, int N, int de
     if (block == 0)
         for (int k = threadIdx.x; k < pk.n_zero; k += 256) pk.zero_cells[k] = 0.f;
     if (n >= N) return;
+    // (dense scenes: most Gaussians are in no tile's list — behind their tiles' occlusion cuts, or reaching no pixel —
+    // and the walk gathers records only through the lists: no colours (192 of ~350 B read) and no record for those)
+    const bool listed = !pk.kept || pk.kept[n] != 0;
     ShF3 cf[16];
-    load_sh_row<HALF>(dc, rest, n, N, cf);
+    if (listed) load_sh_row<HALF>(dc, rest, n, N, cf);
     const float mx = means[n * 3 + 0], myy = means[n * 3 + 1], mz = means[n * 3 + 2];
-    const int rad0 = radii[n];
+    const int rad0 = listed ? radii[n] : 0;
     const float dep0 = depths[n];
     const float4 pq = ld_attr4(pk.quats, n, HALF ? 1 : 0);
     const float2 pxy = reinterpret_cast<const float2 *>(pk.means2d)[n];
@@ -1251,6 +1273,7 @@ __device__ __forceinline__ void sh_fwd_pack_direct_body(int block, int N, int de
     float ex[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) pk.normals_world[n * 3 + k] = o.n[k];
+    if (!listed) return;
     normal_to_camera(o.n, pk.c2w, ex);
     pk.packed[n * 4 + 0] = make_float4(pxy.x, pxy.y, pop, pcon[0]);
     pk.packed[n * 4 + 1] = make_float4(pcon[1], pcon[2], 0.f, 0.f);
@@ -1286,7 +1309,7 @@ namespace fsgs {
 // (called by the projecting count pass of isect.hip; the arguments are checked there and in sh_pack_rider_ok)
 int launch_scan_rows_sh_pack(int T, int nb, int32_t *table, int32_t *totals, const ShPackRider &r, hipStream_t s) {
     ShPackArgs pk = {r.means2d, r.conics, r.opacities, r.quats, r.log_scales, r.c2w, reinterpret_cast<float4 *>(r.packed),
-                     r.normals_world, r.zero_cells, r.zero_cells ? r.n_zero : 0};
+                     r.normals_world, r.zero_cells, r.zero_cells ? r.n_zero : 0, r.kept};
     const int n_scan = tile_scan_rows_blocks(T);
     const dim3 grid(n_scan + ceil_div(r.N, 256));
     if (r.attr_half)
@@ -1317,7 +1340,7 @@ static int sh_fwd_pack_impl(int N, int K, int degree, const float *means, const 
         !opacities || !quats || !log_scales || !c2w || !packed || !normals_world)
         return FSGS_EINVAL;
     ShPackArgs pk = {means2d, conics, opacities, quats, log_scales, c2w, reinterpret_cast<float4 *>(packed),
-                     normals_world, zero_cells, zero_cells ? n_zero : 0};
+                     normals_world, zero_cells, zero_cells ? n_zero : 0, nullptr};
     const void *rest = features_rest ? features_rest : features_dc;
     const size_t lds_bytes = (size_t)kShBlock * (K * 3 + 1) * sizeof(float);
     if (attr_half) {

@@ -78,6 +78,7 @@ class FrameInfo:
         self.zcut_out: Optional[Tensor] = None
         self.zcut_margins = (0.5, 0.01)
         self.pending_verdict = None
+        self.kept: Optional[Tensor] = None  # [N] uint8 (dense scenes): the Gaussian is in at least one tile's list
 
     @property
     def flatten_ids(self):
@@ -144,6 +145,8 @@ def _grad_accumulator(dev, N: int) -> Tensor:
 
 
 IMAGE_GRADS_IN_BWD = os.environ.get("FSGS_IMAGE_GRADS_IN_BWD", "1") != "0"
+# from this many Gaussians on, the SH forward evaluates only Gaussians that are in some tile's list (fsgs.h: kept)
+KEPT_MIN_N = int(os.environ.get("FSGS_KEPT_MIN_N", str(1 << 20)))
 
 
 class _FusedGetOutputs(torch.autograd.Function):
@@ -188,6 +191,10 @@ class _FusedGetOutputs(torch.autograd.Function):
             # pairs go straight into their tile's bucket (no emission-order lists), and the count pass projects the
             # Gaussians itself (activations + binary-opacity write included): no projection launch
             rider = None
+            # dense scenes: the count pass notes which Gaussians are in any list at all; the riding SH forward skips
+            # the others (no coefficient read, no record written — nothing gathers it)
+            kept = torch.empty(N, dtype=torch.uint8, device=dev) if (sh_rides and N >= KEPT_MIN_N) else None
+            info.kept = kept
             if sh_rides:
                 rider = (sh_degree, cam["campos"], hm["features_dc"] if hm is not None else features_dc,
                          hm["features_rest"] if hm is not None else features_rest, cam["c2w"], packed, normals_world,
@@ -196,7 +203,7 @@ class _FusedGetOutputs(torch.autograd.Function):
                 means, quats, scales, opacities, bthr, cam["viewmat"], cam["K"], W, H, tw, th,
                 dict(scales_exp=scales_exp, opac_sig=opac_sig, radii=radii, means2d=means2d, depths=depths,
                      conics=conics), half=hm, capacity=int(info.live_capacity), sh_pack=rider,
-                adam=info.adam_rider.groups if adam_rides else None, zcut=info.zcut_in,
+                adam=info.adam_rider.groups if adam_rides else None, zcut=info.zcut_in, kept=kept,
                 zcut_hit=None if info.zcut_in is None else ops.zcut_scratch(dev, tw * th)[2])
             if adam_rides:
                 info.adam_rider.consumed()

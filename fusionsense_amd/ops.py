@@ -351,7 +351,8 @@ def project_bin_live_count_async(means: Tensor, quats: Tensor, log_scales: Tenso
                                  binary_threshold, viewmat: Tensor, K: Tensor, width: int, height: int,
                                  tile_width: int, tile_height: int, out: dict, half: Optional[dict] = None,
                                  capacity: int = 0, sh_pack: Optional[tuple] = None, adam=None,
-                                 zcut: Optional[Tensor] = None, zcut_hit: Optional[Tensor] = None) -> dict:
+                                 zcut: Optional[Tensor] = None, zcut_hit: Optional[Tensor] = None,
+                                 kept: Optional[Tensor] = None) -> dict:
     """``fsgs_project_fwd_act`` + ``bin_live_count_async`` in one launch chain (one camera): the count pass projects
     its Gaussians itself.  ``out`` holds the projection's output tensors (scales_exp, opac_sig, radii [1,N],
     means2d, depths, conics).  Returns the same state ``bin_live_count_async`` does."""
@@ -370,7 +371,7 @@ def project_bin_live_count_async(means: Tensor, quats: Tensor, log_scales: Tenso
         pinned._np[2] = int(capacity)
     if zcut is not None:
         assert zcut.dtype == torch.float32 and zcut.numel() == T and zcut.is_contiguous()
-    if sh_pack is not None or adam is not None or zcut is not None:
+    if sh_pack is not None or adam is not None or zcut is not None or kept is not None:
         # independent work rides in the count pass's launches (fsgs.h): the SH forward + packing in the table scan's,
         # sh_pack = (degree, campos, features_dc, features_rest, c2w, packed, normals_world, zero_cells); a deferred
         # Adam step (`adam`: an _lib.AdamGroups made by adam_groups()) in the count pass's own
@@ -380,7 +381,7 @@ def project_bin_live_count_async(means: Tensor, quats: Tensor, log_scales: Tenso
                     ptr(zero_cells), int(zero_cells.numel()))
         else:
             tail = (0, None, None, None, None, None, None, None, 0)
-        tail = tail + (C.byref(adam) if adam is not None else None, ptr(zcut), ptr(zcut_hit), stream_ptr(dev))
+        tail = tail + (C.byref(adam) if adam is not None else None, ptr(zcut), ptr(zcut_hit), ptr(kept), stream_ptr(dev))
         bt = (0 if binary_threshold is None else 1, 0.0 if binary_threshold is None else float(binary_threshold))
         outs = (ptr(out["scales_exp"]), ptr(out["opac_sig"]), ptr(out["radii"]), ptr(out["means2d"]),
                 ptr(out["depths"]), ptr(out["conics"]), tile_width, tile_height, ptr(tpg), ptr(offsets), ptr(table),

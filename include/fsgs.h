@@ -350,6 +350,10 @@ typedef struct fsgs_adam_groups {
  *    the cuts come from fsgs_tile_zcut_update of an earlier frame of the same view, which also validates this frame.
  *    zcut_hit (nullable, [T] int32, zeroed): zcut_hit[t] <- 1 when a LIVE pair of tile t fell behind its cut (the
  *    count pass then still reach-tests the pairs it drops); fsgs_tile_zcut_update reads and clears the flags.
+ *  - kept != NULL ([N] bytes, written): kept[n] = 1 if Gaussian n has at least one binned pair (live and not behind a
+ *    cut), else 0.  A Gaussian with kept = 0 is in no tile's list, so the riding SH forward neither reads its
+ *    coefficients nor writes its packed record (the record is never gathered); normals_world is written for all.
+ *    Meant for dense scenes, where most Gaussians are in no list; it makes the coefficient loads dependent ones.
  * _h16: quats / log_scales / opacity logits / features are IEEE-half mirrors (as in fsgs_project_bin_live_count_h16
  * and fsgs_sh_fwd_pack_h16). */
 int fsgs_project_bin_live_count_sh_pack(
@@ -360,7 +364,7 @@ int fsgs_project_bin_live_count_sh_pack(
     void *table_scratch, size_t table_bytes, int32_t *n_live_mapped, int degree, const float *campos,
     const float *features_dc, const float *features_rest, const float *c2w, float *packed, float *normals_world,
     float *zero_cells, int n_zero, const fsgs_adam_groups *adam, const float *tile_zcut, int32_t *zcut_hit,
-    fsgs_stream_t stream);
+    uint8_t *kept, fsgs_stream_t stream);
 int fsgs_project_bin_live_count_sh_pack_h16(
     int N, const float *means, const void *quats_h, const void *log_scales_h, void *opac_logit_h,
     float *opac_logit_master, int binarise, float binary_threshold, const float *viewmat, const float *K, int width,
@@ -369,7 +373,7 @@ int fsgs_project_bin_live_count_sh_pack_h16(
     int32_t *tiles_per_gauss, int32_t *isect_offsets, void *table_scratch, size_t table_bytes, int32_t *n_live_mapped,
     int degree, const float *campos, const void *features_dc_h, const void *features_rest_h, const float *c2w,
     float *packed, float *normals_world, float *zero_cells, int n_zero, const fsgs_adam_groups *adam,
-    const float *tile_zcut, int32_t *zcut_hit, fsgs_stream_t stream);
+    const float *tile_zcut, int32_t *zcut_hit, uint8_t *kept, fsgs_stream_t stream);
 int fsgs_bin_live_emit(int C, int N, const float *means2d, const int32_t *radii, const float *depths,
                        const float *conics, const float *opacities, int tile_width, int tile_height,
                        const int32_t *isect_offsets, const void *table_scratch, int64_t n_live, void *buckets,
@@ -485,6 +489,11 @@ int fsgs_gaussian_bwd(int N, const float *means, const float *quats, const float
                       float *xys_grad_norm, float *vis_counts, float *max_2Dsize, float inv_max_hw,
                       const uint8_t *frozen, int64_t replica_rows,
                           fsgs_stream_t stream);
+/* fsgs_gauss_sh_bwd(_h16) with N >= this threshold fetches a Gaussian's SH coefficients only after its gradient line,
+ * and only if the line carries a colour gradient (dense scenes: most lines are empty; same outputs, 192 B less read per
+ * empty line, at the price of a dependent load).  Default 2^20 (env FSGS_LAZY_SH_MIN_N); returns the previous value. */
+int fsgs_set_lazy_sh_min_n(int n);
+
 /* fsgs_sh_bwd_split (or, with v_rgb_masked != NULL, fsgs_sh_bwd_colors) for one camera, K = 16 stored coefficients
  * and the packed 16-float gradient records, followed by fsgs_gaussian_bwd — in ONE launch and one thread per
  * Gaussian: the record is read (replicas folded, everything cleared) once and the view-direction share of v_means

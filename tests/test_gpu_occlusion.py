@@ -171,3 +171,49 @@ def test_cuts_are_dropped_when_the_model_is_rebuilt(dev):
             assert len(tr._zcuts) == 0, "refinement forgets the cuts"
             seen_drop = seen_drop or had > 0
     assert seen_drop and tr.cut_frames > 0
+
+
+def test_unlisted_gaussians_are_skipped_without_changing_anything(dev, dense_scene, monkeypatch):
+    """Dense scenes (N >= 2^20): the count pass marks the Gaussians that are in any tile's list (``kept``), the riding
+    SH forward skips the others, and the per-Gaussian backward fetches coefficients only for lines with a colour
+    gradient (fsgs_set_lazy_sh_min_n).  Both are pure savings: flags exact against the lists, images and every
+    parameter gradient equal to the eager route's — with and without occlusion cuts."""
+    from fusionsense_amd import fused
+    from fusionsense_amd._lib import load
+    from fusionsense_amd.trainer import SplatTrainer
+    params, cams, tgt = dense_scene
+    lib = load()
+
+    def frames(eager, cuts):
+        monkeypatch.setattr(fused, "KEPT_MIN_N", 1 << 30 if eager else 1 << 20)
+        prev = lib.fsgs_set_lazy_sh_min_n(1 << 30 if eager else 1 << 20)
+        try:
+            tr = SplatTrainer(params, dev, sh_degree=3)
+            tr.occlusion_cut_mode = "1" if cuts else "0"
+            out = []
+            for it in range(2 if cuts else 1):  # (with cuts: the second frame of the view is the cut one)
+                f = _frame(tr, cams[0], tgt)
+                f["kept"] = None if tr.last_info.kept is None else tr.last_info.kept.clone()
+                f["ids"] = (tr.last_info.payload & 0x0FFFFFFF).long()
+                out.append(f)
+            assert tr.cut_frames == (1 if cuts else 0) and tr.cut_redone == 0
+            return out[-1]
+        finally:
+            lib.fsgs_set_lazy_sh_min_n(prev)
+
+    for cuts in (False, True):
+        eager, lazy = frames(True, cuts), frames(False, cuts)
+        assert eager["kept"] is None and lazy["kept"] is not None
+        listed = torch.zeros(N_DENSE, dtype=torch.uint8, device=dev)
+        listed[lazy["ids"]] = 1
+        assert torch.equal(lazy["kept"], listed)
+        assert 0.02 < float(listed.float().mean()) < (0.6 if cuts else 1.0001)  # (uncut, this scene lists nearly all)
+        for k in ("rgb", "depth", "normal", "alpha", "payload", "offs", "last"):
+            assert torch.equal(eager[k], lazy[k]), k
+        assert eager["loss"] == lazy["loss"]
+        for k in eager["grads"]:
+            assert rel_err(lazy["grads"][k], eager["grads"][k]) < 2e-4, k  # (float atomics in the compositing backward)
+            # exactly zero where the eager route has exact zeros (unlisted Gaussians), and nothing non-finite
+            z = eager["grads"][k] == 0
+            assert bool(torch.isfinite(lazy["grads"][k]).all())
+            assert float(((lazy["grads"][k] == 0) != z).float().mean()) < 1e-4, k
