@@ -372,9 +372,7 @@ struct BinProjArgs {
     // saturate inside their prefix is bit-identical to the uncut one; any other frame is redone without the cut.
     const float *tile_zcut;
     int zcut_in_lds;                 // the workgroup keeps a copy of tile_zcut behind its tile slots (T more LDS words)
-    // count pass only (nullable): zcut_hit[t] <- 1 when a LIVE pair of tile t fell behind its cut.  An open tile that
-    // lost no live pair has its complete list, so it does not spoil the frame (fsgs_tile_zcut_update).
-    int32_t *zcut_hit;
+    int zcut_gw, zcut_gh;            // (zcut_in_lds) coarse grid of 4x4-tile blocks behind the copy: each block's largest cut
     // count pass only (nullable, [N] bytes): kept[n] <- 1 if Gaussian n has at least one binned (live, not cut) pair,
     // else 0.  A Gaussian without one is in no list: the frame needs neither its colours nor its packed record.
     uint8_t *kept;
@@ -398,6 +396,26 @@ isect_live_bin_body(const int block, int C, int N, const float *__restrict__ mea
     // one row per WORKGROUP, so large N is given more chunks instead of more rows (N / 1024 rows of T counters
     // each would be 234 MB at 6 M Gaussians x 10 000 tiles)
     const int n_chunks = MULTI ? chunks : 1;  // (MULTI = false: the single-chunk code without the loop, 4 us faster)
+    // Occlusion cuts: a copy of the frame's cuts behind the tile slots, and behind it the largest cut of every block of
+    // 4x4 tiles — a Gaussian that lies behind the largest cut of every block its rectangle touches has no pair to bin
+    // at all and leaves the pair loop (in a dense scene most of them: their pairs are nine in ten of all pairs)
+    float *const zl = (pj.tile_zcut && pj.zcut_in_lds) ? reinterpret_cast<float *>(slots + T) : nullptr;
+    float *const zg = zl ? zl + T : nullptr;
+    if (zl) {
+        for (int t = tid; t < T; t += kBinThreads) zl[t] = pj.tile_zcut[t];
+        __syncthreads();
+        for (int g = tid; g < pj.zcut_gw * pj.zcut_gh; g += kBinThreads) {
+            const int gy = g / pj.zcut_gw, gx = g - gy * pj.zcut_gw;
+            float zm = 0.f;
+            for (int dy = 0; dy < 4; ++dy)
+                for (int dx = 0; dx < 4; ++dx) {
+                    const int ty = gy * 4 + dy, tx = gx * 4 + dx;
+                    if (ty < th && tx < tw) zm = fmaxf(zm, zl[ty * tw + tx]);
+                }
+            zg[g] = zm;
+        }
+        __syncthreads();
+    }
     for (int ch = 0; ch < n_chunks; ++ch) {
     const int64_t idx0 = ((int64_t)block * n_chunks + ch) * kBinThreads;  // the chunk's first Gaussian
     const int64_t idx = idx0 + tid;
@@ -470,6 +488,18 @@ isect_live_bin_body(const int block, int C, int N, const float *__restrict__ mea
                 t.y1 = min(t.y1, (int)floorf((my + ey - 0.5f) * (1.f / 16.f)) + 1);
             }
             cnt = max(t.x1 - t.x0, 0) * max(t.y1 - t.y0, 0);
+            if (zg && cnt > 0) {
+                const int bx0 = t.x0 >> 2, bx1 = (t.x1 - 1) >> 2, by0 = t.y0 >> 2, by1 = (t.y1 - 1) >> 2;
+                if (bx1 - bx0 < 3 && by1 - by0 < 3) {  // (larger rectangles keep their per-pair tests)
+                    float zm = 0.f;
+#pragma unroll
+                    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                        for (int dx = 0; dx < 3; ++dx)
+                            zm = fmaxf(zm, zg[min(by0 + dy, by1) * pj.zcut_gw + min(bx0 + dx, bx1)]);
+                    if (__uint_as_float(db) > zm) cnt = 0;
+                }
+            }
         }
         L.a[tid] = make_float4(cp.mx, cp.my, cp.b, cp.tau);
         L.b[tid] = make_float4(cp.ha, cp.hc, cp.inv_a, cp.inv_c);
@@ -479,10 +509,6 @@ isect_live_bin_body(const int block, int C, int N, const float *__restrict__ mea
     if (ch == 0) {  // (after the chunk's own loads were issued: the slot rows come from memory in the fill pass)
         for (int t = tid; t < T; t += kBinThreads)
             slots[t] = SCATTER ? offsets[t] + table[(int64_t)block * T + t] : 0;
-        if (pj.tile_zcut && pj.zcut_in_lds) {
-            float *zl = reinterpret_cast<float *>(slots + T);
-            for (int t = tid; t < T; t += kBinThreads) zl[t] = pj.tile_zcut[t];
-        }
     }
     int inc = cnt;
 #pragma unroll
@@ -523,24 +549,14 @@ isect_live_bin_body(const int block, int C, int N, const float *__restrict__ mea
         float4 A = L.a[o], B = L.b[o];
         int jj = p - L.excl[o];
         int y = rc.y + jj / rc.z, x = rc.x + jj % rc.z;
-        float *zc = pj.tile_zcut ? (pj.zcut_in_lds ? reinterpret_cast<float *>(slots + T) : const_cast<float *>(pj.tile_zcut)) : nullptr;
+        const float *zc = pj.tile_zcut ? (zl ? zl : pj.tile_zcut) : nullptr;
         float z_o = __uint_as_float(L.depth[o]);
         bool told = false;  // this thread has raised its current owner's kept flag
         for (; p < p_end; ++p) {
             const CullPrep cp = {A.x, A.y, A.z, A.w, B.x, B.y, B.z, B.w};
-            // (occlusion cut, one camera: a pair behind its tile's cut depth is not binned.  The count pass still
-            // reach-tests it: the frame's verdict needs to know which tiles lost a LIVE pair; the LDS copy of the
-            // cut carries that in its sign bit until the workgroup's end)
-            const float zt = zc ? zc[y * tw + x] : 0.f;
-            const bool cut = zc && z_o > fabsf(zt);
-            unsigned m = (cut && (SCATTER || !pj.zcut_hit)) ? 0u : quadrant_mask(cp, (float)(x * 16), (float)(y * 16));
-            if (!SCATTER && cut) {
-                if (m && pj.zcut_hit) {
-                    if (!pj.zcut_in_lds) pj.zcut_hit[y * tw + x] = 1;
-                    else if (zt > 0.f) atomicOr(reinterpret_cast<unsigned *>(&zc[y * tw + x]), 0x80000000u);
-                }
-                m = 0u;
-            }
+            // (occlusion cut, one camera: a pair behind its tile's cut depth is not binned)
+            const bool cut = zc && z_o > zc[y * tw + x];
+            const unsigned m = cut ? 0u : quadrant_mask(cp, (float)(x * 16), (float)(y * 16));
             if (m) {
                 const int64_t gidx = idx0 + o;
                 const int c = (C == 1) ? 0 : (int)(gidx / N);
@@ -568,11 +584,6 @@ isect_live_bin_body(const int block, int C, int N, const float *__restrict__ mea
     if (!SCATTER) {
         __syncthreads();
         for (int t = tid; t < T; t += kBinThreads) table[(int64_t)block * T + t] = slots[t];
-        if (pj.tile_zcut && pj.zcut_in_lds && pj.zcut_hit) {
-            const float *zl = reinterpret_cast<const float *>(slots + T);
-            for (int t = tid; t < T; t += kBinThreads)
-                if (zl[t] < 0.f) pj.zcut_hit[t] = 1;  // (-inf never: nothing lies behind an infinite cut)
-        }
     }
 }
 
@@ -836,15 +847,17 @@ static int bin_launch(size_t extra_lds, int T, int64_t total, int nb, hipStream_
     }
 }
 // the tile cuts of a frame in LDS behind the tile slots, where both fit (T more words); else they are read from memory
-static inline void bin_place_zcut(BinProjArgs &pj, const float *tile_zcut, int32_t *zcut_hit, int T, int64_t total,
+static inline void bin_place_zcut(BinProjArgs &pj, const float *tile_zcut, int tw, int th, int T, int64_t total,
                                   size_t &extra_lds) {
     pj.tile_zcut = tile_zcut;
-    pj.zcut_hit = tile_zcut ? zcut_hit : nullptr;
     pj.zcut_in_lds = 0;
+    pj.zcut_gw = (tw + 3) / 4;
+    pj.zcut_gh = (th + 3) / 4;
     extra_lds = 0;
-    if (tile_zcut && bin_lds_bytes(T, total) + (size_t)T * sizeof(float) <= 150 * 1024) {
+    const size_t need = ((size_t)T + (size_t)pj.zcut_gw * pj.zcut_gh) * sizeof(float);
+    if (tile_zcut && bin_lds_bytes(T, total) + need <= 150 * 1024) {
         pj.zcut_in_lds = 1;
-        extra_lds = (size_t)T * sizeof(float);
+        extra_lds = need;
     }
 }
 
@@ -919,8 +932,7 @@ static int project_bin_live_count_impl(int N, const float *means, const void *qu
                                            int32_t *isect_offsets, void *table_scratch, size_t table_bytes,
                                            int32_t *n_live_mapped, fsgs_stream_t stream,
                                            const ShPackRider *rider = nullptr, const fsgs_adam_groups *adam = nullptr,
-                                           const float *tile_zcut = nullptr, int32_t *zcut_hit = nullptr,
-                                           uint8_t *kept = nullptr) {
+                                           const float *tile_zcut = nullptr, uint8_t *kept = nullptr) {
     if (N < 0 || tile_width < 1 || tile_height < 1 || !isect_offsets) return FSGS_EINVAL;
     const int64_t T64 = (int64_t)tile_width * tile_height;
     if (T64 > fsgs_bin_live_max_tiles()) return FSGS_EINVAL;
@@ -956,9 +968,9 @@ static int project_bin_live_count_impl(int N, const float *means, const void *qu
     int rc;
     BinProjArgs pj = {means, quats, log_scales, viewmat, K, opac_logit, scales_out, opac_out, means2d, depths,
                       conics, radii, width, height, binarise, eps2d, near_plane, far_plane, radius_clip,
-                      binary_threshold, reinterpret_cast<__half *>(opac_logit_h), attr_half, nullptr, 0, nullptr};
+                      binary_threshold, reinterpret_cast<__half *>(opac_logit_h), attr_half, nullptr, 0, 0, 0, nullptr};
     size_t extra_lds = 0;
-    bin_place_zcut(pj, tile_zcut, zcut_hit, T, total, extra_lds);
+    bin_place_zcut(pj, tile_zcut, tile_width, tile_height, T, total, extra_lds);
     pj.kept = kept;
     ShPackRider rider_kept;
     if (rider && kept) { rider_kept = *rider; rider_kept.kept = kept; rider = &rider_kept; }
@@ -999,15 +1011,15 @@ extern "C" int fsgs_project_bin_live_count_sh_pack(
     float *depths, float *conics, int tile_width, int tile_height, int32_t *tiles_per_gauss, int32_t *isect_offsets,
     void *table_scratch, size_t table_bytes, int32_t *n_live_mapped, int degree, const float *campos,
     const float *features_dc, const float *features_rest, const float *c2w, float *packed, float *normals_world,
-    float *zero_cells, int n_zero, const fsgs_adam_groups *adam, const float *tile_zcut, int32_t *zcut_hit,
-    uint8_t *kept, fsgs_stream_t stream) {
+    float *zero_cells, int n_zero, const fsgs_adam_groups *adam, const float *tile_zcut, uint8_t *kept,
+    fsgs_stream_t stream) {
     const ShPackRider r = {N, degree, 0, means, campos, features_dc, features_rest, radii, depths, means2d, conics,
                            opac_out, quats, log_scales, c2w, packed, normals_world, zero_cells, n_zero, nullptr};
     return project_bin_live_count_impl(N, means, quats, log_scales, opac_logit, nullptr, 0, binarise, binary_threshold,
                                        viewmat, K, width, height, eps2d, near_plane, far_plane, radius_clip, scales_out,
                                        opac_out, radii, means2d, depths, conics, tile_width, tile_height, tiles_per_gauss,
                                        isect_offsets, table_scratch, table_bytes, n_live_mapped, stream,
-                                       packed ? &r : nullptr, adam, tile_zcut, zcut_hit, kept);
+                                       packed ? &r : nullptr, adam, tile_zcut, kept);
 }
 
 extern "C" int fsgs_project_bin_live_count_sh_pack_h16(
@@ -1018,14 +1030,14 @@ extern "C" int fsgs_project_bin_live_count_sh_pack_h16(
     int32_t *tiles_per_gauss, int32_t *isect_offsets, void *table_scratch, size_t table_bytes, int32_t *n_live_mapped,
     int degree, const float *campos, const void *features_dc_h, const void *features_rest_h, const float *c2w,
     float *packed, float *normals_world, float *zero_cells, int n_zero, const fsgs_adam_groups *adam,
-    const float *tile_zcut, int32_t *zcut_hit, uint8_t *kept, fsgs_stream_t stream) {
+    const float *tile_zcut, uint8_t *kept, fsgs_stream_t stream) {
     const ShPackRider r = {N, degree, 1, means, campos, features_dc_h, features_rest_h, radii, depths, means2d, conics,
                            opac_out, quats_h, log_scales_h, c2w, packed, normals_world, zero_cells, n_zero, nullptr};
     return project_bin_live_count_impl(N, means, quats_h, log_scales_h, opac_logit_master, opac_logit_h, 1, binarise,
                                        binary_threshold, viewmat, K, width, height, eps2d, near_plane, far_plane,
                                        radius_clip, scales_out, opac_out, radii, means2d, depths, conics, tile_width,
                                        tile_height, tiles_per_gauss, isect_offsets, table_scratch, table_bytes,
-                                       n_live_mapped, stream, packed ? &r : nullptr, adam, tile_zcut, zcut_hit, kept);
+                                       n_live_mapped, stream, packed ? &r : nullptr, adam, tile_zcut, kept);
 }
 
 extern "C" int fsgs_project_bin_live_count(int N, const float *means, const float *quats, const float *log_scales,
@@ -1113,7 +1125,7 @@ static int bin_live_emit_impl(int C, int N, const float *means2d, const int32_t 
     int32_t *table = const_cast<int32_t *>(reinterpret_cast<const int32_t *>(table_scratch));
     BinProjArgs pj{};
     size_t extra_lds = 0;
-    bin_place_zcut(pj, tile_zcut, nullptr, T, (int64_t)C * N, extra_lds);
+    bin_place_zcut(pj, tile_zcut, tile_width, tile_height, T, (int64_t)C * N, extra_lds);
     int rc = bin_launch<true, false, false>(extra_lds, T, (int64_t)C * N, nb, s, C, N, means2d, radii, depths, conics,
                                             opacities, tile_width, tile_height, T, nb, bin_chunks((int64_t)C * N),
                                             (int32_t *)nullptr, table, isect_offsets,
@@ -1140,7 +1152,7 @@ static int bin_live_emit_impl(int C, int N, const float *means2d, const int32_t 
 __global__ void __launch_bounds__(64)
 tile_zcut_kernel(int tw, int th, int W, int H, const int32_t *__restrict__ last_ids, const int32_t *__restrict__ payload,
                  const float *__restrict__ depths, const int32_t *__restrict__ offsets, int32_t *__restrict__ tile_open,
-                 const float *__restrict__ zcut_in, int32_t *__restrict__ zcut_hit, float *__restrict__ zcut_out,
+                 const float *__restrict__ zcut_in, int32_t *__restrict__ cand, float *__restrict__ zcut_out,
                  int32_t *__restrict__ bad, float margin_span, float margin_rel) {
     const int t = blockIdx.x, lane = threadIdx.x;
     const int ty = t / tw, tx = t - ty * tw;
@@ -1156,14 +1168,15 @@ tile_zcut_kernel(int tw, int th, int W, int H, const int32_t *__restrict__ last_
     const int l0 = offsets[t], l1 = offsets[t + 1];
     const int open = tile_open[t];
     tile_open[t] = 0;  // (left cleared for the next frame's forward)
-    const int hit = zcut_hit ? zcut_hit[t] : 1;
-    if (zcut_hit) zcut_hit[t] = 0;
     const float inf = __builtin_huge_valf();
     float z = inf;
     if (open) {
-        // an open tile under a cut spoils the frame — unless no live pair of it fell behind the cut (its list is the
-        // complete one then; without the count pass's flags every open cut tile counts)
-        if (zcut_in && zcut_in[t] < inf && hit) atomicOr(bad, 1);
+        // an open tile under a cut: the frame is exact only if no LIVE pair of the tile fell behind the cut — to be
+        // looked at by fsgs_tile_zcut_recheck (rare: the tile saturated in front of the cut one visit ago)
+        if (zcut_in && zcut_in[t] < inf) {
+            cand[t] = 1;
+            atomicOr(bad, 2);
+        }
     } else if (l1 > l0) {
         const int last = min(max(best, l0), l1 - 1);
         const float z_last = depths[payload[last] & 0x0FFFFFFF], z_first = depths[payload[l0] & 0x0FFFFFFF];
@@ -1175,7 +1188,10 @@ tile_zcut_kernel(int tw, int th, int W, int H, const int32_t *__restrict__ last_
 }
 
 // the verdict into host-mapped memory once every tile has been looked at: [0] <- bad, [1] <- 1 ("landed")
-__global__ void zcut_verdict_kernel(int32_t *__restrict__ bad, int32_t *__restrict__ verdict_mapped) {
+__global__ void zcut_verdict_kernel(int32_t *__restrict__ bad, int32_t *__restrict__ verdict_mapped,
+                                    int32_t *__restrict__ clear, int n_clear) {
+    for (int t = threadIdx.x; t < n_clear; t += blockDim.x) clear[t] = 0;
+    if (threadIdx.x != 0) return;
     verdict_mapped[0] = *bad;
     *bad = 0;
     __threadfence_system();
@@ -1184,21 +1200,71 @@ __global__ void zcut_verdict_kernel(int32_t *__restrict__ bad, int32_t *__restri
 
 // One camera.  last_ids [H,W] and payload / isect_offsets [T + 1] as the forward used them, depths [N], tile_open [T]
 // (int32, written by fsgs_raster_fwd_quad, cleared here), zcut_in (nullable: the cuts this frame was binned with),
-// zcut_out [T], bad_scratch: one zeroed int32 on the device (left zeroed), verdict_mapped: int32[2] in host-mapped
-// memory ([1] cleared by the caller beforehand).  zcut_hit (nullable, [T] int32): the flags the count pass raised
-// for tiles that lost a live pair to their cut (fsgs_project_bin_live_count_sh_pack); cleared here.
+// zcut_cand ([T] int32, zeroed; required with zcut_in), zcut_out [T], bad_scratch: one zeroed int32 on the device (left
+// zeroed), verdict_mapped: int32[2] in host-mapped memory ([1] cleared by the caller beforehand).
 extern "C" int fsgs_tile_zcut_update(int tile_width, int tile_height, int width, int height, const int32_t *last_ids,
                                      const int32_t *payload, const float *depths, const int32_t *isect_offsets,
-                                     int32_t *tile_open, const float *zcut_in, int32_t *zcut_hit, float *zcut_out,
-                                     int32_t *bad_scratch,
-                                     int32_t *verdict_mapped, float margin_span, float margin_rel, fsgs_stream_t stream) {
+                                     int32_t *tile_open, const float *zcut_in, int32_t *zcut_cand, float *zcut_out,
+                                     int32_t *bad_scratch, int32_t *verdict_mapped, float margin_span, float margin_rel,
+                                     fsgs_stream_t stream) {
     if (tile_width < 1 || tile_height < 1 || width < 1 || height < 1 || margin_span < 0.f || margin_rel < 0.f) return FSGS_EINVAL;
-    if (!last_ids || !payload || !depths || !isect_offsets || !tile_open || !zcut_out || !bad_scratch || !verdict_mapped)
+    if (!last_ids || !payload || !depths || !isect_offsets || !tile_open || !zcut_out || !bad_scratch || !verdict_mapped ||
+        (zcut_in && !zcut_cand))
         return FSGS_EINVAL;
     hipStream_t s = as_stream(stream);
     hipLaunchKernelGGL(tile_zcut_kernel, dim3(tile_width * tile_height), dim3(64), 0, s, tile_width, tile_height, width,
-                       height, last_ids, payload, depths, isect_offsets, tile_open, zcut_in, zcut_hit, zcut_out, bad_scratch,
-                       margin_span, margin_rel);
-    hipLaunchKernelGGL(zcut_verdict_kernel, dim3(1), dim3(1), 0, s, bad_scratch, verdict_mapped);
+                       height, last_ids, payload, depths, isect_offsets, tile_open, zcut_in, zcut_cand, zcut_out,
+                       bad_scratch, margin_span, margin_rel);
+    hipLaunchKernelGGL(zcut_verdict_kernel, dim3(1), dim3(64), 0, s, bad_scratch, verdict_mapped, (int32_t *)nullptr, 0);
+    return check_launch();
+}
+
+// The second look at a frame whose verdict was 2: does any candidate tile (open, under a finite cut) have a LIVE pair
+// behind its cut?  One thread per Gaussian over its gsplat rectangle, the binning's own reach test on candidate tiles.
+__global__ void __launch_bounds__(256)
+zcut_recheck_kernel(int N, const float *__restrict__ means2d, const int32_t *__restrict__ radii,
+                    const float *__restrict__ depths, const float *__restrict__ conics,
+                    const float *__restrict__ opacities, int tw, int th, const float *__restrict__ zcut_in,
+                    const int32_t *__restrict__ cand, int32_t *__restrict__ bad) {
+    extern __shared__ unsigned char cand_l[];
+    for (int t = threadIdx.x; t < tw * th; t += 256) cand_l[t] = cand[t] ? 1 : 0;
+    __syncthreads();
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const int r = radii[n];
+    if (r <= 0) return;
+    const float2 m = reinterpret_cast<const float2 *>(means2d)[n];
+    const TileRect t = tile_rect(m.x, m.y, r, 16, tw, th, 0);
+    bool any = false;
+    for (int y = t.y0; y < t.y1 && !any; ++y)
+        for (int x = t.x0; x < t.x1; ++x) any = any || cand_l[y * tw + x];
+    if (!any) return;
+    const float z = depths[n];
+    const CullPrep cp = cull_prepare(m.x, m.y, opacities[n], conics[n * 3 + 0], conics[n * 3 + 1], conics[n * 3 + 2]);
+    for (int y = t.y0; y < t.y1; ++y)
+        for (int x = t.x0; x < t.x1; ++x)
+            if (cand_l[y * tw + x] && z > zcut_in[y * tw + x] && quadrant_mask(cp, (float)(x * 16), (float)(y * 16))) {
+                *bad = 1;  // (same value from every writer)
+                return;
+            }
+}
+
+// verdict_mapped[0] <- 1 if a candidate tile of zcut_cand lost a live pair to zcut_in (the frame is INVALID) else 0,
+// [1] <- 1 once landed ([1] cleared by the caller beforehand); zcut_cand and bad_scratch are left zeroed.  means2d /
+// radii / depths / conics / opacities [N]: the frame's projection outputs (one camera).
+extern "C" int fsgs_tile_zcut_recheck(int N, const float *means2d, const int32_t *radii, const float *depths,
+                                      const float *conics, const float *opacities, int tile_width, int tile_height,
+                                      const float *zcut_in, int32_t *zcut_cand, int32_t *bad_scratch,
+                                      int32_t *verdict_mapped, fsgs_stream_t stream) {
+    if (N < 0 || tile_width < 1 || tile_height < 1 || !zcut_in || !zcut_cand || !bad_scratch || !verdict_mapped)
+        return FSGS_EINVAL;
+    if (N > 0 && (!means2d || !radii || !depths || !conics || !opacities)) return FSGS_EINVAL;
+    const int T = tile_width * tile_height;
+    if (T > fsgs_bin_live_max_tiles()) return FSGS_EINVAL;
+    hipStream_t s = as_stream(stream);
+    if (N > 0)
+        hipLaunchKernelGGL(zcut_recheck_kernel, dim3(ceil_div(N, 256)), dim3(256), (size_t)T, s, N, means2d, radii, depths,
+                           conics, opacities, tile_width, tile_height, zcut_in, zcut_cand, bad_scratch);
+    hipLaunchKernelGGL(zcut_verdict_kernel, dim3(1), dim3(64), 0, s, bad_scratch, verdict_mapped, zcut_cand, T);
     return check_launch();
 }

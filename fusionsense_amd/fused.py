@@ -203,8 +203,7 @@ class _FusedGetOutputs(torch.autograd.Function):
                 means, quats, scales, opacities, bthr, cam["viewmat"], cam["K"], W, H, tw, th,
                 dict(scales_exp=scales_exp, opac_sig=opac_sig, radii=radii, means2d=means2d, depths=depths,
                      conics=conics), half=hm, capacity=int(info.live_capacity), sh_pack=rider,
-                adam=info.adam_rider.groups if adam_rides else None, zcut=info.zcut_in, kept=kept,
-                zcut_hit=None if info.zcut_in is None else ops.zcut_scratch(dev, tw * th)[2])
+                adam=info.adam_rider.groups if adam_rides else None, zcut=info.zcut_in, kept=kept)
             if adam_rides:
                 info.adam_rider.consumed()
                 info.adam_rider = None
@@ -326,6 +325,7 @@ class _FusedGetOutputs(torch.autograd.Function):
                                         ptr(normal), sp), "fsgs_epilogue_fwd")
 
         info.radii, info.means2d, info.depths, info.conics = radii, means2d, depths, conics
+        info.opac_row, info.tiles = opac_row, (tw, th)
         info.tiles_per_gauss, info.isect_ids, info.payload = tpg, isect_ids, flatten_ids
         info.isect_offsets = offsets[:tw * th].view(1, th, tw) if no_wait else offsets
         info.last_ids, info.normals_world = last_ids, normals_world
@@ -567,6 +567,10 @@ def fused_step_forward_backward(gauss_params: Dict[str, Tensor], camera: Camera,
             # its prefix -> the images miss contributions, the frame is abandoned like an overflowed one
             ok = ops.zcut_check(info.pending_verdict)
             info.pending_verdict = None
+            if ok == 2:  # open tiles under cuts: exact only if none of them lost a live pair
+                ok = 0 if ops.zcut_recheck(info.means2d, info.radii, info.depths, info.conics, info.opac_row,
+                                           info.tiles[0], info.tiles[1], info.zcut_in) else 1
+            ok = ok == 0
             if not ok:
                 WORKSPACE.give(getattr(ctx, "arena", None))
                 ctx.arena = None

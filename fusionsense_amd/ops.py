@@ -351,8 +351,7 @@ def project_bin_live_count_async(means: Tensor, quats: Tensor, log_scales: Tenso
                                  binary_threshold, viewmat: Tensor, K: Tensor, width: int, height: int,
                                  tile_width: int, tile_height: int, out: dict, half: Optional[dict] = None,
                                  capacity: int = 0, sh_pack: Optional[tuple] = None, adam=None,
-                                 zcut: Optional[Tensor] = None, zcut_hit: Optional[Tensor] = None,
-                                 kept: Optional[Tensor] = None) -> dict:
+                                 zcut: Optional[Tensor] = None, kept: Optional[Tensor] = None) -> dict:
     """``fsgs_project_fwd_act`` + ``bin_live_count_async`` in one launch chain (one camera): the count pass projects
     its Gaussians itself.  ``out`` holds the projection's output tensors (scales_exp, opac_sig, radii [1,N],
     means2d, depths, conics).  Returns the same state ``bin_live_count_async`` does."""
@@ -381,7 +380,7 @@ def project_bin_live_count_async(means: Tensor, quats: Tensor, log_scales: Tenso
                     ptr(zero_cells), int(zero_cells.numel()))
         else:
             tail = (0, None, None, None, None, None, None, None, 0)
-        tail = tail + (C.byref(adam) if adam is not None else None, ptr(zcut), ptr(zcut_hit), ptr(kept), stream_ptr(dev))
+        tail = tail + (C.byref(adam) if adam is not None else None, ptr(zcut), ptr(kept), stream_ptr(dev))
         bt = (0 if binary_threshold is None else 1, 0.0 if binary_threshold is None else float(binary_threshold))
         outs = (ptr(out["scales_exp"]), ptr(out["opac_sig"]), ptr(out["radii"]), ptr(out["means2d"]),
                 ptr(out["depths"]), ptr(out["conics"]), tile_width, tile_height, ptr(tpg), ptr(offsets), ptr(table),
@@ -452,7 +451,7 @@ _ZCUT_SCRATCH: dict = {}
 
 
 def zcut_scratch(dev, T: int):
-    """(tile_open [T], bad [1], zcut_hit [T]; int32): zeroed once, left zeroed by fsgs_tile_zcut_update."""
+    """(tile_open [T], bad [1], zcut_cand [T]; int32): zeroed once, left zeroed by fsgs_tile_zcut_update / _recheck."""
     key = (str(dev), T)
     t = _ZCUT_SCRATCH.get(key)
     if t is None:
@@ -460,14 +459,33 @@ def zcut_scratch(dev, T: int):
     return t[:T], t[T:T + 1], t[T + 1:]
 
 
-def zcut_check(pinned: Tensor) -> bool:
-    """Waits for the verdict of fsgs_tile_zcut_update (normally long landed); True = the frame's cuts were valid."""
+def zcut_check(pinned: Tensor) -> int:
+    """Waits for a verdict of fsgs_tile_zcut_update / fsgs_tile_zcut_recheck (normally long landed): 0 = the frame is
+    exact, 1 = invalid, 2 = open tiles under cuts exist (fsgs_tile_zcut_recheck decides)."""
     arr = pinned._np
     for _ in range(2000000):
         if arr[1] != 0:
-            return int(arr[0]) == 0
+            return int(arr[0])
     torch.cuda.synchronize()
-    return int(arr[0]) == 0
+    return int(arr[0])
+
+
+zcut_rechecks = 0  # frames that needed the second look
+
+
+def zcut_recheck(means2d: Tensor, radii: Tensor, depths: Tensor, conics: Tensor, opacities: Tensor, tile_width: int,
+                 tile_height: int, zcut_in: Tensor) -> bool:
+    """The second look (fsgs_tile_zcut_recheck) + wait; True = no candidate tile lost a live pair: the frame is exact."""
+    global zcut_rechecks
+    zcut_rechecks += 1
+    lib = load()
+    dev = means2d.device
+    _, bad, cand = zcut_scratch(dev, tile_width * tile_height)
+    verdict = zcut_verdict_buffer(dev)
+    _run(lib.fsgs_tile_zcut_recheck, (radii.shape[-1], ptr(means2d), ptr(radii), ptr(depths), ptr(conics), ptr(opacities),
+                                     tile_width, tile_height, ptr(zcut_in), ptr(cand), ptr(bad), verdict.data_ptr(),
+                                     stream_ptr(dev)), "fsgs_tile_zcut_update")
+    return zcut_check(verdict) == 0
 
 
 def bin_live_check(st: dict) -> int:

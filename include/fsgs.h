@@ -348,8 +348,7 @@ typedef struct fsgs_adam_groups {
  *  - tile_zcut != NULL (occlusion cut, one float per tile, +inf = none): a pair whose Gaussian lies behind its tile's
  *    cut depth is neither counted here nor binned by fsgs_bin_live_emit(_split), which must be given the SAME array;
  *    the cuts come from fsgs_tile_zcut_update of an earlier frame of the same view, which also validates this frame.
- *    zcut_hit (nullable, [T] int32, zeroed): zcut_hit[t] <- 1 when a LIVE pair of tile t fell behind its cut (the
- *    count pass then still reach-tests the pairs it drops); fsgs_tile_zcut_update reads and clears the flags.
+ *    A Gaussian behind the largest cut of every 4x4-tile block its rectangle touches is dropped before the pair loop.
  *  - kept != NULL ([N] bytes, written): kept[n] = 1 if Gaussian n has at least one binned pair (live and not behind a
  *    cut), else 0.  A Gaussian with kept = 0 is in no tile's list, so the riding SH forward neither reads its
  *    coefficients nor writes its packed record (the record is never gathered); normals_world is written for all.
@@ -363,8 +362,8 @@ int fsgs_project_bin_live_count_sh_pack(
     float *depths, float *conics, int tile_width, int tile_height, int32_t *tiles_per_gauss, int32_t *isect_offsets,
     void *table_scratch, size_t table_bytes, int32_t *n_live_mapped, int degree, const float *campos,
     const float *features_dc, const float *features_rest, const float *c2w, float *packed, float *normals_world,
-    float *zero_cells, int n_zero, const fsgs_adam_groups *adam, const float *tile_zcut, int32_t *zcut_hit,
-    uint8_t *kept, fsgs_stream_t stream);
+    float *zero_cells, int n_zero, const fsgs_adam_groups *adam, const float *tile_zcut, uint8_t *kept,
+    fsgs_stream_t stream);
 int fsgs_project_bin_live_count_sh_pack_h16(
     int N, const float *means, const void *quats_h, const void *log_scales_h, void *opac_logit_h,
     float *opac_logit_master, int binarise, float binary_threshold, const float *viewmat, const float *K, int width,
@@ -373,7 +372,7 @@ int fsgs_project_bin_live_count_sh_pack_h16(
     int32_t *tiles_per_gauss, int32_t *isect_offsets, void *table_scratch, size_t table_bytes, int32_t *n_live_mapped,
     int degree, const float *campos, const void *features_dc_h, const void *features_rest_h, const float *c2w,
     float *packed, float *normals_world, float *zero_cells, int n_zero, const fsgs_adam_groups *adam,
-    const float *tile_zcut, int32_t *zcut_hit, uint8_t *kept, fsgs_stream_t stream);
+    const float *tile_zcut, uint8_t *kept, fsgs_stream_t stream);
 int fsgs_bin_live_emit(int C, int N, const float *means2d, const int32_t *radii, const float *depths,
                        const float *conics, const float *opacities, int tile_width, int tile_height,
                        const int32_t *isect_offsets, const void *table_scratch, int64_t n_live, void *buckets,
@@ -400,15 +399,24 @@ int fsgs_bin_live_emit_split(int C, int N, const float *means2d, const int32_t *
  * this call (one camera) turns that and last_ids into
  *   zcut_out[t] = +inf if tile t was open, else depth(deepest composited entry of t) + max(margin_span * (that depth -
  *                 the tile's first entry's depth), margin_rel * that depth),
- *   verdict_mapped[0] = 1 if an open tile had been binned with a finite zcut_in AND lost a live pair to it (zcut_hit[t];
- *                       without the flags: any open tile under a finite cut) — the frame is INVALID —, else 0, and
+ *   zcut_cand[t]      = 1 for every open tile that had been binned with a finite zcut_in (the "candidates"),
+ *   verdict_mapped[0] = 2 if there is a candidate, else 0 (the frame is exact), and
  *   verdict_mapped[1] = 1 once [0] has landed (host-mapped memory; the caller clears [1] beforehand);
- * tile_open and zcut_hit are left cleared, bad_scratch (one zeroed int32 on the device) is left zeroed. */
+ * tile_open is left cleared, bad_scratch (one zeroed int32 on the device) is left zeroed.  zcut_cand ([T] int32, zeroed)
+ * is required with zcut_in.  After a verdict of 2 the caller runs fsgs_tile_zcut_recheck: an open tile under a cut
+ * spoils the frame only if a LIVE pair of it lies behind the cut (a tile that barely saturated one visit ago and does
+ * not now has usually lost nothing); verdict_mapped[0] = 1 there means the frame is INVALID.  The recheck applies the
+ * binning's reach test to the candidate tiles only (one thread per Gaussian over its gsplat rectangle) and leaves
+ * zcut_cand zeroed. */
 int fsgs_tile_zcut_update(int tile_width, int tile_height, int width, int height, const int32_t *last_ids,
                           const int32_t *payload, const float *depths, const int32_t *isect_offsets,
-                          int32_t *tile_open, const float *zcut_in, int32_t *zcut_hit, float *zcut_out,
-                          int32_t *bad_scratch,
-                          int32_t *verdict_mapped, float margin_span, float margin_rel, fsgs_stream_t stream);
+                          int32_t *tile_open, const float *zcut_in, int32_t *zcut_cand, float *zcut_out,
+                          int32_t *bad_scratch, int32_t *verdict_mapped, float margin_span, float margin_rel,
+                          fsgs_stream_t stream);
+int fsgs_tile_zcut_recheck(int N, const float *means2d, const int32_t *radii, const float *depths, const float *conics,
+                           const float *opacities, int tile_width, int tile_height, const float *zcut_in,
+                           int32_t *zcut_cand, int32_t *bad_scratch, int32_t *verdict_mapped, fsgs_stream_t stream);
+
 
 /* Split packed gradient records into the five gsplat-shaped arrays (written, not accumulated).
  * rezero != 0: v_packed is cleared after it has been read, ready for the next frame's atomics. */

@@ -125,6 +125,18 @@ def test_too_tight_cuts_are_detected_and_the_frame_redone(dev, dense_scene):
     got = _frame(tr, cams[0], tgt)
     assert tr.cut_frames == 3 and tr.cut_redone == 2
     _same_frame(ref, got, cut=True, shrink=1.0)  # (this view's margins are 4x the default by now)
+    # (d) an OPEN tile under a finite cut that removes nothing live: the verdict is "look again" (2), the second look
+    # (fsgs_tile_zcut_recheck) finds no live pair behind the cut, the frame stands
+    from fusionsense_amd import ops
+    open_tiles = torch.nonzero(~torch.isfinite(good)).flatten()
+    assert open_tiles.numel() > 0
+    far = tr._zcuts[key].clone()
+    far[open_tiles] = 1.0e6
+    tr._zcuts[key] = far
+    n0 = ops.zcut_rechecks
+    got = _frame(tr, cams[0], tgt)
+    assert ops.zcut_rechecks == n0 + 1 and tr.cut_frames == 4 and tr.cut_redone == 2
+    _same_frame(ref, got, cut=True, shrink=1.0)
 
 
 def test_training_with_cuts_is_the_same_training(dev, dense_scene):
