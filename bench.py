@@ -637,12 +637,16 @@ def main():
             "adam_step": ("adam_kernel (six parameter groups, one launch)", N * 59 * 28),
         }
         riding = bool(getattr(trainer, "_ride_mode", lambda: False)())
+        aib_on = int(getattr(trainer, "adam_in_backward_steps", 0)) > 0
         alg.update({
             "isect_count_live": ("projecting count pass + table scan with the SH colours / record packing riding"
                                  + (" + the features' Adam step riding" if riding else ""),
                                  N * (68 + 20 + 16) + n_vis * (216 + 64) + (N * 48 * 28 if riding else 0)),
-            "gaussian_bwd": ("gauss_sh_bwd_kernel (SH VJP + projection / normal / activation VJPs + after_train statistics)",
-                             N * (120 + 52 + 36 + 76) + n_vis * 228),
+            # (with the step's Adam applied in this launch — trainer.adam_in_backward_steps — the 236 B of gradients
+            # are not written; parameters and both moments are read and written instead: 59 floats x 6 streams)
+            "gaussian_bwd": ("gauss_sh_bwd_kernel (SH VJP + projection / normal / activation VJPs + after_train statistics"
+                             + (" + the Adam step of all six groups" if aib_on else "") + ")",
+                             N * (120 + 52 + 36 + 76 + (59 * 24 - 236 if aib_on else 0)) + n_vis * 228),
             "ssim_l1_fwd": ("ssim_l1_fwd_kernel", P * 3 * 24),
             "ssim_l1_bwd": ("ssim_l1_bwd_kernel (+ loss combine)", P * 3 * 36),
         })
@@ -726,6 +730,9 @@ def main():
             "iter_hbm_frac": round(b_iter / (elapsed / args.steps) / (HBM_PEAK_GBS * 1e9), 5),
             "device_mallocs_in_timed_region": n_alloc,
             "live_list_overflows": int(getattr(trainer, "live_overflows", 0)),  # frames redone (no-wait binning)
+            # steps whose Adam update was applied inside the per-Gaussian backward launch (no gradient slab, no Adam
+            # launch: DESIGN.md §9.9; FSGS_ADAM_IN_BACKWARD=auto|1|0)
+            "adam_in_backward_steps": int(getattr(trainer, "adam_in_backward_steps", 0)),
             # occlusion cuts (dense scenes): frames binned with cuts / of those, redone uncut because a
             # cut tile did not saturate (both over warmup + timed steps; the redone frames are inside the timed region)
             "occlusion_cut": {"mode": getattr(trainer, "occlusion_cut_mode", "0"),

@@ -1,11 +1,31 @@
 // The per-Gaussian VJP of the projection (+ the fused tail of the training backward) as a device function, shared by
 // project_bwd_kernel (project.hip) and the kernel that runs the SH backward in the same thread (sh.hip).
 #pragma once
+#include <hip/hip_fp16.h>
 #include "common.h"
 #include "normal_math.h"
 #include "project_math.h"
 
 namespace fsgs {
+
+// Adam inside the per-Gaussian backward (fsgs_gauss_sh_bwd_adam): the gradients are applied where they are formed and
+// never written.  Groups in the trainer's order: 0 means, 1 log-scales, 2 quats, 3 features_dc, 4 features_rest,
+// 5 opacity logits; h = the IEEE-half mirror the render kernels read (nullable per group), rewritten with the update.
+struct GaussAdam {
+    int on;
+    float *p[6], *m[6], *v[6];
+    __half *h[6];
+    float ss[6];
+    float b1, b2, omb1, omb2, isb2, eps;
+};
+
+// element i of group g takes gradient gr (same arithmetic as adam_kernel: common.h adam_one)
+__device__ __forceinline__ void gauss_adam_at(const GaussAdam &a, int g, int64_t i, float gr) {
+    float p = a.p[g][i], m = a.m[g][i], v = a.v[g][i];
+    adam_one(p, gr, m, v, a.b1, a.b2, a.omb1, a.omb2, a.ss[g], a.isb2, a.eps);
+    a.p[g][i] = p; a.m[g][i] = m; a.v[g][i] = v;
+    if (a.h[g]) a.h[g][i] = __float2half(p);
+}
 
 struct GaussBwdFused {
     float4 *v_packed;            // [N,4] float4: [0..3] v_colors [4..6] v_conics [7..8] v_means2d [9..10] abs [11] v_opac [12..14] v_ncam
@@ -20,6 +40,7 @@ struct GaussBwdFused {
     int64_t replica_rows;        // > 0: large Gaussians own kGradReplicas gradient lines, this many rows apart (common.h)
     float *xys_grad_norm, *vis_counts, *max_2Dsize;  // after_train statistics (nullable together)
     float inv_max_hw;
+    GaussAdam adam;              // .on: apply instead of writing v_means / v_quats / v_scales / v_opac_logit
 };
 
 // FUSED: this Gaussian's packed gradient record — read, replicas folded in (common.h: grad_spread), everything cleared
@@ -238,22 +259,22 @@ __device__ __forceinline__ void gaussian_bwd_one(
         return;
     }
     const bool frozen = fz.frozen != nullptr && fz.frozen[n] != 0;
+    float gm[3];
+    bool gm_known = true;
     if (frozen) {
-        v_means[n * 3 + 0] = 0.f; v_means[n * 3 + 1] = 0.f; v_means[n * 3 + 2] = 0.f;
+        gm[0] = 0.f; gm[1] = 0.f; gm[2] = 0.f;
     } else if (mean_share) {  // (the SH backward ran in this thread: its view-direction share arrives in registers)
-        v_means[n * 3 + 0] = mean_share[0] + g_mean[0]; v_means[n * 3 + 1] = mean_share[1] + g_mean[1];
-        v_means[n * 3 + 2] = mean_share[2] + g_mean[2];
+        gm[0] = mean_share[0] + g_mean[0]; gm[1] = mean_share[1] + g_mean[1]; gm[2] = mean_share[2] + g_mean[2];
     } else if (fz.accumulate_means) {
+        gm_known = false;
         v_means[n * 3 + 0] += g_mean[0]; v_means[n * 3 + 1] += g_mean[1]; v_means[n * 3 + 2] += g_mean[2];
     } else {
-        v_means[n * 3 + 0] = g_mean[0]; v_means[n * 3 + 1] = g_mean[1]; v_means[n * 3 + 2] = g_mean[2];
+        gm[0] = g_mean[0]; gm[1] = g_mean[1]; gm[2] = g_mean[2];
     }
     // `scales` holds exp(log_scales): d/d log_scale = v * exp(log_scale)
-    v_scales[n * 3 + 0] = frozen ? 0.f : vs[0] * s[0];
-    v_scales[n * 3 + 1] = frozen ? 0.f : vs[1] * s[1];
-    v_scales[n * 3 + 2] = frozen ? 0.f : vs[2] * s[2];
+    const float gs[3] = {frozen ? 0.f : vs[0] * s[0], frozen ? 0.f : vs[1] * s[1], frozen ? 0.f : vs[2] * s[2]};
     const float o = fz.opac[n];
-    fz.v_opac_logit[n] = frozen ? 0.f : pc.w * o * (1.f - o);
+    const float go = frozen ? 0.f : pc.w * o * (1.f - o);
     {   // the normal pass reaches the quaternions only (dn_model.py:618-656)
         float ls[3];
         ld_attr3(fz.log_scales, n, fz.attr_half, ls);
@@ -261,7 +282,21 @@ __device__ __forceinline__ void gaussian_bwd_one(
         const float4 vqb = normal_backward(q, ls, mean, fz.c2w, vn);
         vq.x += vqb.x; vq.y += vqb.y; vq.z += vqb.z; vq.w += vqb.w;
     }
-    reinterpret_cast<float4 *>(v_quats)[n] = vq;
+    if (fz.adam.on) {  // (every input of this Gaussian has been read above: its parameters may move now)
+        const float gq[4] = {vq.x, vq.y, vq.z, vq.w};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) gauss_adam_at(fz.adam, 0, (int64_t)n * 3 + k, gm[k]);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) gauss_adam_at(fz.adam, 1, (int64_t)n * 3 + k, gs[k]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) gauss_adam_at(fz.adam, 2, (int64_t)n * 4 + k, gq[k]);
+        gauss_adam_at(fz.adam, 5, n, go);
+    } else {
+        if (gm_known) { v_means[n * 3 + 0] = gm[0]; v_means[n * 3 + 1] = gm[1]; v_means[n * 3 + 2] = gm[2]; }
+        v_scales[n * 3 + 0] = gs[0]; v_scales[n * 3 + 1] = gs[1]; v_scales[n * 3 + 2] = gs[2];
+        fz.v_opac_logit[n] = go;
+        reinterpret_cast<float4 *>(v_quats)[n] = vq;
+    }
     if (fz.xys_grad_norm) {  // SplatfactoModel.after_train (dn_model.py:1385-1389 registration)
         const int r = radii[n];
         if (r > 0) {

@@ -648,6 +648,62 @@ __device__ __forceinline__ void adam_rows(float *__restrict__ P, float *__restri
     }
 }
 
+// the same on a group of a GaussAdam block (fsgs_gauss_sh_bwd_adam), with the group's half mirror if it has one; U
+// float4 triples (parameter, both moments) are in flight per thread before the first store
+template <int RF, int U = 4>
+__device__ __forceinline__ void adam_rows_g(const GaussAdam &a, int grp, int64_t first, int rows, const float *lds,
+                                            int pitch, int col_off) {
+    float4 *__restrict__ const P4 = reinterpret_cast<float4 *>(a.p[grp] + first);
+    float4 *__restrict__ const M4 = reinterpret_cast<float4 *>(a.m[grp] + first);
+    float4 *__restrict__ const V4 = reinterpret_cast<float4 *>(a.v[grp] + first);
+    float *const P = a.p[grp] + first, *const M = a.m[grp] + first, *const V = a.v[grp] + first;
+    __half *const H = a.h[grp] ? a.h[grp] + first : nullptr;
+    const float ss = a.ss[grp];
+    const int total = rows * RF;
+    lds += col_off;
+    const int total4 = total >> 2;
+    for (int i0 = threadIdx.x; i0 < total4; i0 += kShBlock * U) {
+        float4 p[U], m[U], v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = i0 + u * kShBlock;
+            if (i < total4) { p[u] = P4[i]; m[u] = M4[i]; v[u] = V4[i]; }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = i0 + u * kShBlock;
+            if (i >= total4) break;
+            const int e = i << 2;
+            int r = e / RF, col = e - r * RF;
+            float g[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                g[k] = lds[r * pitch + col];
+                if (++col == RF) { col = 0; ++r; }
+            }
+            adam_one(p[u].x, g[0], m[u].x, v[u].x, a.b1, a.b2, a.omb1, a.omb2, ss, a.isb2, a.eps);
+            adam_one(p[u].y, g[1], m[u].y, v[u].y, a.b1, a.b2, a.omb1, a.omb2, ss, a.isb2, a.eps);
+            adam_one(p[u].z, g[2], m[u].z, v[u].z, a.b1, a.b2, a.omb1, a.omb2, ss, a.isb2, a.eps);
+            adam_one(p[u].w, g[3], m[u].w, v[u].w, a.b1, a.b2, a.omb1, a.omb2, ss, a.isb2, a.eps);
+            P4[i] = p[u]; M4[i] = m[u]; V4[i] = v[u];
+            if (H) {
+                const __half2 lo = __floats2half2_rn(p[u].x, p[u].y), hi = __floats2half2_rn(p[u].z, p[u].w);
+                uint2 o;
+                o.x = *reinterpret_cast<const unsigned *>(&lo);
+                o.y = *reinterpret_cast<const unsigned *>(&hi);
+                reinterpret_cast<uint2 *>(H)[i] = o;
+            }
+        }
+    }
+    for (int i = (total4 << 2) + threadIdx.x; i < total; i += kShBlock) {
+        const int r = i / RF, col = i - r * RF;
+        float p = P[i], m = M[i], v = V[i];
+        adam_one(p, lds[r * pitch + col], m, v, a.b1, a.b2, a.omb1, a.omb2, ss, a.isb2, a.eps);
+        P[i] = p; M[i] = m; V[i] = v;
+        if (H) H[i] = __float2half(p);
+    }
+}
+
 template <int KT, bool ADAM>
 __global__ void __launch_bounds__(kShBlock)
 sh_coeff_grad_kernel(int R, int N, int K, int degree, const float *__restrict__ means,
@@ -1000,6 +1056,11 @@ gauss_sh_bwd_kernel(GaussShArgs A, GaussBwdFused fz) {
     }
     if (A.v_rgb_masked) return;
     __syncthreads();
+    if (fz.adam.on) {  // (every thread of the block has read its coefficients: the block's rows may move)
+        adam_rows_g<3>(fz.adam, 3, (int64_t)n0 * 3, rows, lds, pitch, 0);
+        adam_rows_g<45>(fz.adam, 4, (int64_t)n0 * 45, rows, lds, pitch, 3);
+        return;
+    }
     unstage_rows<3>(A.v_dc + (int64_t)n0 * 3, rows, 3, lds, pitch, 0);
     unstage_rows<45>(A.v_rest + (int64_t)n0 * 45, rows, 45, lds, pitch, 3);
 }
@@ -1019,13 +1080,31 @@ static int gauss_sh_bwd_impl(int N, int degree, const float *means, const float 
                              float *v_rgb_masked, float *v_means, float *v_quats, float *v_log_scales,
                              float *v_opac_logit, float *absgrad, float *xys_grad_norm, float *vis_counts,
                              float *max_2Dsize, float inv_max_hw, const uint8_t *frozen, int64_t replica_rows,
-                             fsgs_stream_t stream) {
+                             fsgs_stream_t stream, const fsgs_adam_groups *adam = nullptr) {
     if (N < 0 || degree < 0 || degree > 3 || replica_rows < 0) return FSGS_EINVAL;
     if (N == 0) return FSGS_OK;
     if (!means || !campos || !features_dc || !features_rest || !quats || !log_scales || !scales || !opac || !viewmat ||
-        !K || !c2w || !radii || !conics || !v_packed || !v_means || !v_quats || !v_log_scales || !v_opac_logit || !absgrad)
+        !K || !c2w || !radii || !conics || !v_packed || !absgrad)
         return FSGS_EINVAL;
-    if (!v_rgb_masked && (!v_features_dc || !v_features_rest)) return FSGS_EINVAL;
+    if (!adam && (!v_means || !v_quats || !v_log_scales || !v_opac_logit)) return FSGS_EINVAL;
+    if (!adam && !v_rgb_masked && (!v_features_dc || !v_features_rest)) return FSGS_EINVAL;
+    GaussAdam ga{};
+    if (adam) {
+        // the six groups in the trainer's order (fsgs.h); the gradients are applied, not written
+        static const int64_t kRow[6] = {3, 3, 4, 3, 45, 1};
+        if (v_rgb_masked || adam->n_groups != 6 || adam->step < 1) return FSGS_EINVAL;
+        const double bc1 = 1.0 - pow(adam->beta1, (double)adam->step), bc2 = 1.0 - pow(adam->beta2, (double)adam->step);
+        for (int g = 0; g < 6; ++g) {
+            if (!adam->params[g] || !adam->exp_avg[g] || !adam->exp_avg_sq[g] || adam->numel[g] != kRow[g] * N)
+                return FSGS_EINVAL;
+            ga.p[g] = adam->params[g]; ga.m[g] = adam->exp_avg[g]; ga.v[g] = adam->exp_avg_sq[g];
+            ga.h[g] = reinterpret_cast<__half *>(adam->half_mirror[g]);
+            ga.ss[g] = (float)((double)adam->lr[g] / bc1);  // (as build_adam_args: adam_body.h)
+        }
+        ga.b1 = (float)adam->beta1; ga.b2 = (float)adam->beta2; ga.isb2 = (float)(1.0 / sqrt(bc2)); ga.eps = adam->eps;
+        ga.omb1 = (float)(1.0 - adam->beta1); ga.omb2 = (float)(1.0 - adam->beta2);
+        ga.on = 1;
+    }
     if ((xys_grad_norm || vis_counts || max_2Dsize) && !(xys_grad_norm && vis_counts && max_2Dsize)) return FSGS_EINVAL;
     GaussShArgs A = {means, campos, features_dc, features_rest, quats, scales, viewmat, K, radii, conics,
                      v_features_dc, v_features_rest, v_means, v_quats, v_log_scales,
@@ -1036,6 +1115,7 @@ static int gauss_sh_bwd_impl(int N, int degree, const float *means, const float 
     fz.log_scales = log_scales; fz.opac = opac; fz.c2w = c2w; fz.absgrad = absgrad; fz.v_opac_logit = v_opac_logit;
     fz.accumulate_means = 0; fz.frozen = frozen; fz.attr_half = attr_half; fz.replica_rows = replica_rows;
     fz.xys_grad_norm = xys_grad_norm; fz.vis_counts = vis_counts; fz.max_2Dsize = max_2Dsize; fz.inv_max_hw = inv_max_hw;
+    fz.adam = ga;
     const size_t lds_bytes = (size_t)kShBlock * 49 * sizeof(float);
     if (attr_half)
         hipLaunchKernelGGL(gauss_sh_bwd_kernel<true>, dim3(ceil_div(N, kShBlock)), dim3(kShBlock), lds_bytes,
@@ -1078,6 +1158,40 @@ extern "C" int fsgs_gauss_sh_bwd_h16(int N, int degree, const float *means, cons
                              opac, viewmat, K, c2w, width, height, eps2d, radii, conics, v_packed, v_features_dc,
                              v_features_rest, nullptr, v_means, v_quats, v_log_scales, v_opac_logit, absgrad,
                              xys_grad_norm, vis_counts, max_2Dsize, inv_max_hw, frozen, replica_rows, stream);
+}
+
+// fsgs_gauss_sh_bwd / _h16 with the Adam step of all six parameter groups applied where the gradients are formed (the
+// gradients are never written: 236 B per Gaussian less written here, 236 B less read by an Adam launch that no longer
+// exists).  adam: six groups in the order means, log-scales, quats, features_dc, features_rest, opacity logits.
+extern "C" int fsgs_gauss_sh_bwd_adam(int N, int degree, const float *means, const float *campos, const float *features_dc,
+                                      const float *features_rest, const float *quats, const float *log_scales,
+                                      const float *scales, const float *opac, const float *viewmat, const float *K,
+                                      const float *c2w, int width, int height, float eps2d, const int32_t *radii,
+                                      const float *conics, float *v_packed, float *absgrad, float *xys_grad_norm,
+                                      float *vis_counts, float *max_2Dsize, float inv_max_hw, const uint8_t *frozen,
+                                      int64_t replica_rows, const fsgs_adam_groups *adam, fsgs_stream_t stream) {
+    if (!adam) return FSGS_EINVAL;
+    return gauss_sh_bwd_impl(N, degree, means, campos, features_dc, features_rest, quats, log_scales, 0, scales, opac,
+                             viewmat, K, c2w, width, height, eps2d, radii, conics, v_packed, nullptr, nullptr, nullptr,
+                             nullptr, nullptr, nullptr, nullptr, absgrad, xys_grad_norm, vis_counts, max_2Dsize,
+                             inv_max_hw, frozen, replica_rows, stream, adam);
+}
+
+extern "C" int fsgs_gauss_sh_bwd_adam_h16(int N, int degree, const float *means, const float *campos,
+                                          const void *features_dc_h, const void *features_rest_h, const void *quats_h,
+                                          const void *log_scales_h, const float *scales, const float *opac,
+                                          const float *viewmat, const float *K, const float *c2w, int width, int height,
+                                          float eps2d, const int32_t *radii, const float *conics, float *v_packed,
+                                          float *absgrad, float *xys_grad_norm, float *vis_counts, float *max_2Dsize,
+                                          float inv_max_hw, const uint8_t *frozen, int64_t replica_rows,
+                                          const fsgs_adam_groups *adam, fsgs_stream_t stream) {
+    if (!adam) return FSGS_EINVAL;
+    for (int g = 1; g < 6; ++g)  // (the render path reads the mirrors: every group but the means must have one)
+        if (g != 0 && !adam->half_mirror[g]) return FSGS_EINVAL;
+    return gauss_sh_bwd_impl(N, degree, means, campos, features_dc_h, features_rest_h, quats_h, log_scales_h, 1, scales,
+                             opac, viewmat, K, c2w, width, height, eps2d, radii, conics, v_packed, nullptr, nullptr,
+                             nullptr, nullptr, nullptr, nullptr, nullptr, absgrad, xys_grad_norm, vis_counts, max_2Dsize,
+                             inv_max_hw, frozen, replica_rows, stream, adam);
 }
 
 static int sh_bwd_impl(int C, int N, int K, int degree, const float *means, const float *campos,

@@ -79,6 +79,10 @@ class FrameInfo:
         self.zcut_margins = (0.5, 0.01)
         self.pending_verdict = None
         self.kept: Optional[Tensor] = None  # [N] uint8 (dense scenes): the Gaussian is in at least one tile's list
+        # an _lib.AdamGroups of the six parameter groups (trainer's order): the backward applies this Adam step in its
+        # per-Gaussian launch instead of writing gradients (fsgs_gauss_sh_bwd_adam); adam_applied tells the caller
+        self.adam_in_backward = None
+        self.adam_applied = False
 
     @property
     def flatten_ids(self):
@@ -406,7 +410,20 @@ class _FusedGetOutputs(torch.autograd.Function):
             # mean of the ranks' coefficient gradients in the slab (16 B instead of 192 B per Gaussian on the links)
             assert hm is None, "the factored feature exchange reads fp32 features (trainer switches it off)"
             assert tuple(factors.shape) == (N + 1, 4) and factors.is_contiguous()
-        if hm is not None and K == 16 and sh_degree <= 3 and ONE_LAUNCH_GAUSSIAN_BWD:
+        aib = ctx.info.adam_in_backward
+        if aib is not None and factors is None and K == 16 and sh_degree <= 3 and ONE_LAUNCH_GAUSSIAN_BWD:
+            # the step's Adam update rides in this launch: the gradients are applied where they are formed and never
+            # written (the caller's gradient buffers are NOT filled; trainer: FSGS_ADAM_IN_BACKWARD)
+            import ctypes as C
+            f = lib.fsgs_gauss_sh_bwd_adam_h16 if hm is not None else lib.fsgs_gauss_sh_bwd_adam
+            src = hm if hm is not None else dict(features_dc=features_dc, features_rest=features_rest, quats=quats,
+                                                 scales=scales)
+            _run(f, (N, sh_degree, ptr(means), ptr(cam["campos"]), ptr(src["features_dc"]), ptr(src["features_rest"]),
+                     ptr(src["quats"]), ptr(src["scales"]), ptr(scales_exp), ptr(opac_sig), ptr(cam["viewmat"]),
+                     ptr(cam["K"]), ptr(cam["c2w"]), W, H, 0.3, ptr(radii), ptr(conics), ptr(v_packed), ptr(v_abs))
+                 + stat_args[:-1] + (C.byref(aib), sp), "fsgs_gaussian_bwd")
+            ctx.info.adam_applied = True
+        elif hm is not None and K == 16 and sh_degree <= 3 and ONE_LAUNCH_GAUSSIAN_BWD:
             _run(lib.fsgs_gauss_sh_bwd_h16,
                  (N, sh_degree, ptr(means), ptr(cam["campos"]), ptr(hm["features_dc"]), ptr(hm["features_rest"]),
                   ptr(hm["quats"]), ptr(hm["scales"]), ptr(scales_exp), ptr(opac_sig), ptr(cam["viewmat"]), ptr(cam["K"]),
@@ -522,7 +539,7 @@ def fused_step_forward_backward(gauss_params: Dict[str, Tensor], camera: Camera,
                                 w_depth: float = 0.2, w_normal: float = 0.1, pre_sh=None, adam_rider=None, sh_factors_out=None,
                                 fusion=None, half: Optional[Dict[str, Tensor]] = None, live_capacity: int = 0,
                                 zcut_in: Optional[Tensor] = None, zcut_out: Optional[Tensor] = None,
-                                zcut_margins=None):
+                                zcut_margins=None, adam_in_backward=None):
     """get_outputs -> loss -> both backward passes, without the autograd tape.  The parameter gradients land in
     ``grad_out`` (the trainer's slab views).  Returns (loss 0-d tensor, outputs dict).
     ``target`` is either the benchmark targets of BASELINE config #2 (dict rgb / depth / normal: L1 + SSIM on rgb,
@@ -542,6 +559,7 @@ def fused_step_forward_backward(gauss_params: Dict[str, Tensor], camera: Camera,
     info.half = half
     info.live_capacity = int(live_capacity)
     info.zcut_in, info.zcut_out = zcut_in, zcut_out
+    info.adam_in_backward = adam_in_backward
     if zcut_margins is not None:
         info.zcut_margins = zcut_margins
 
@@ -590,6 +608,8 @@ def fused_step_forward_backward(gauss_params: Dict[str, Tensor], camera: Camera,
             loss = ops._FusionLoss.forward(lctx, rgb, depth, normal, gauss_params["scales"].data, target, cfg,
                                            info.normals_world, touch_idx, touch_normals, seed_grad, True)
             check_live_total(ctx)
+            if lctx.g[3] != 0.0:
+                info.adam_in_backward = None  # (the min-scale term below adds to the scales' gradient: it must exist)
             v = ops._FusionLoss.backward(lctx, seed_grad)
             _FusedGetOutputs.backward(ctx, v[0], v[1], v[2], None)
             g_min = lctx.g[3]

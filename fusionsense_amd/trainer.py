@@ -265,6 +265,13 @@ class SplatTrainer:
         self.zcut_margins = (float(m[0]), float(m[1]))
         self._zcuts: Dict = {}
         self._zcut_widen: Dict = {}
+        # Adam in the backward: on one rank, when nothing else needs the gradients, the per-Gaussian
+        # backward launch applies the step's Adam update itself (fsgs_gauss_sh_bwd_adam) — the 236 B of gradients per
+        # Gaussian are neither written nor read back, and the Adam launch disappears.  The gradient slab is then NOT
+        # filled by that step.  FSGS_ADAM_IN_BACKWARD = auto (N >= 2^20) | 1 | 0.
+        self.adam_in_backward_mode = os.environ.get("FSGS_ADAM_IN_BACKWARD", "auto")
+        self.adam_in_backward_min_n = 1 << 20
+        self.adam_in_backward_steps = 0
         self.cut_frames = 0
         self.cut_redone = 0
         self._factors = None
@@ -641,6 +648,15 @@ class SplatTrainer:
         step_no = self._sharded_geometry_step() if sharded else self._optimizer_step(GEOMETRY_GROUPS)
         self._pending = (finish, step_no)
 
+    def _adam_in_backward_ok(self, optimizer_step: bool) -> bool:
+        """One rank, the library's own Adam on all six groups right after the backward, nothing else reading the
+        gradients (no exchange, no deferred / riding feature update, no sharded geometry step)."""
+        mode = self.adam_in_backward_mode
+        if not optimizer_step or mode == "0" or (mode != "1" and self.num_gaussians() < self.adam_in_backward_min_n):
+            return False
+        return (self._one_rank_fused() and not self._split_step(optimizer_step) and self._geo is None
+                and self._pending is None and not GradSlab._exchange())
+
     def _view_cuts(self, camera: Camera):
         """(key, cuts this view was last rendered with or None, buffer for this frame's cuts) — or (None, None, None)
         when occlusion cuts are off for this model size."""
@@ -700,6 +716,11 @@ class SplatTrainer:
             cap = self._live_caps.get(cap_key, 0) if self.no_wait else 0
             from .ops import OcclusionCutInvalid
             view_key, zin, zout = self._view_cuts(camera)
+            aib, aib_step = None, None
+            if self._adam_in_backward_ok(optimizer_step):
+                self.optimizers["means"].param_groups[0]["lr"] = self._means_lr(self.step)
+                aib_step = getattr(self, "adam_steps", 0) + 1
+                aib = self._fused_adam_step(PARAM_ORDER, aib_step, as_groups=True)
             if zin is not None:
                 self.cut_frames += 1
             for attempt in (0, 1, 2):
@@ -712,7 +733,7 @@ class SplatTrainer:
                         fusion=((self.loss_cfg,) + self._touch_rows()) if is_fb else None,
                         half=self.half_mirrors(), live_capacity=cap, zcut_in=zin, zcut_out=zout,
                         zcut_margins=self.zcut_margins if view_key not in self._zcut_widen else tuple(
-                            self._zcut_widen[view_key] * x for x in self.zcut_margins))
+                            self._zcut_widen[view_key] * x for x in self.zcut_margins), adam_in_backward=aib)
                     break
                 except OcclusionCutInvalid:  # a cut tile did not saturate inside its prefix: the exact frame, uncut
                     self.cut_redone += 1
@@ -739,6 +760,13 @@ class SplatTrainer:
             if n_live is not None and self.no_wait:
                 self._live_caps[cap_key] = max(self._live_caps.get(cap_key, 0), int(n_live * 1.25) + 4096)
             self._factors_used = factors
+            if aib is not None and out["info"].adam_applied:
+                # the backward launch has stepped all six groups: count the step, nothing left to launch
+                self.adam_steps = aib_step
+                for name in PARAM_ORDER:
+                    self.optimizers[name].state[self._params[name]]["step"] += 1
+                self.adam_in_backward_steps += 1
+                optimizer_step = False
         else:
             if not self.fused:
                 self.slab.zero_()  # autograd accumulates into the slab views; the fused node overwrites them

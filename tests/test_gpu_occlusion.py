@@ -229,3 +229,61 @@ def test_unlisted_gaussians_are_skipped_without_changing_anything(dev, dense_sce
             z = eager["grads"][k] == 0
             assert bool(torch.isfinite(lazy["grads"][k]).all())
             assert float(((lazy["grads"][k] == 0) != z).float().mean()) < 1e-4, k
+
+
+@pytest.mark.parametrize("half", [False, True])
+def test_adam_in_the_backward_is_the_same_update_bit_for_bit(dev, monkeypatch, half):
+    """FSGS_ADAM_IN_BACKWARD: the per-Gaussian backward launch applies the Adam step of all six groups itself
+    (fsgs_gauss_sh_bwd_adam(_h16)) instead of writing gradients for an Adam launch.  Fed the SAME packed gradient
+    accumulator (the compositing backward's float atomics are replayed from the reference run), parameters, both moments,
+    the half mirrors and the statistics must come out bit-identical to gradients + fsgs_adam_step."""
+    from fusionsense_amd import fused
+    from fusionsense_amd.splatfacto import DensifyStrategy, SplatfactoConfig
+    from fusionsense_amd.trainer import PARAM_ORDER, SplatTrainer
+    params = {k: v.to(dev) for k, v in scenes.lego_like_scene(50_001, seed=5).items()}
+    cams = scenes.hemisphere_cameras(2, width=256, height=256, focal=355.0, seed=5)
+    g = torch.Generator().manual_seed(2)
+    tgt = {"rgb": torch.rand(256, 256, 3, generator=g).to(dev), "depth": torch.rand(256, 256, 1, generator=g).to(dev) * 4,
+           "normal": torch.rand(256, 256, 3, generator=g).to(dev)}
+    tape = {"mode": None, "snaps": [], "i": 0, "calls": []}
+    real_run = fused._run
+
+    def run(fn, args, label, *rest):
+        if label == "fsgs_gaussian_bwd" and tape["mode"] is not None:
+            acc = fused._ACCUM[str(dev)]
+            tape["calls"].append(fn.__name__ if hasattr(fn, "__name__") else str(fn))
+            if tape["mode"] == "record":
+                tape["snaps"].append(acc.clone())
+            else:
+                acc.copy_(tape["snaps"][tape["i"]])
+                tape["i"] += 1
+        return real_run(fn, args, label, *rest)
+    monkeypatch.setattr(fused, "_run", run)
+
+    def train(mode, tape_mode):
+        st = DensifyStrategy(SplatfactoConfig(), num_train_data=2, stats_only=True)
+        tr = SplatTrainer(params, dev, sh_degree=3, strategy=st, half_attributes=half)
+        tr.adam_in_backward_mode = mode
+        tape["mode"], tape["i"] = tape_mode, 0
+        losses = [float(tr.train_step(cams[it % 2], tgt)[0]) for it in range(3)]
+        tape["mode"] = None
+        return tr, st, losses
+
+    a, sa, la = train("0", "record")
+    b, sb, lb = train("1", "replay")
+    assert a.adam_in_backward_steps == 0 and b.adam_in_backward_steps == 3
+    assert la[0] == lb[0]
+    for k in PARAM_ORDER:
+        pa, pb = a.params[k], b.params[k]
+        assert torch.equal(pa.data, pb.data), k
+        sta, stb = a.optimizers[k].state[pa], b.optimizers[k].state[pb]
+        assert torch.equal(sta["exp_avg"], stb["exp_avg"]) and torch.equal(sta["exp_avg_sq"], stb["exp_avg_sq"]), k
+        assert float(sta["step"]) == float(stb["step"]) == 3.0
+    assert la == lb  # (the second and third frames started from identical parameters)
+    assert torch.equal(sa.xys_grad_norm, sb.xys_grad_norm) and torch.equal(sa.vis_counts, sb.vis_counts)
+    if half:
+        for k, m in b.half_mirrors().items():
+            assert torch.equal(m, b.params[k].data.half()) and torch.equal(m, a.half_mirrors()[k]), k
+    # a step without optimizer (gradients wanted) still fills the slab
+    b.train_step(cams[0], tgt, optimizer_step=False)
+    assert b.adam_in_backward_steps == 3 and float(b.slab.views["means"].abs().sum()) > 0
