@@ -660,7 +660,8 @@ def main():
             name, nbytes = alg[key]
             ms = kernel_ms[key]["avg_ms"]
             ach = nbytes / (ms * 1e-3) / 1e9
-            rec = pmc_record(key, args.config)
+            # (the per-Gaussian backward that also applies the Adam step is an instantiation of its own: own counters)
+            rec = pmc_record("gaussian_bwd_adam" if (key == "gaussian_bwd" and aib_on) else key, args.config)
             r = {"kernel": name, "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                  "frac": round(ach / HBM_PEAK_GBS, 5),
                  # rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE (bytes per launch, gfx950-corrected) of this kernel

@@ -70,7 +70,7 @@ __device__ __forceinline__ void gauss_bwd_load_line(int n, const GaussBwdFused &
     reinterpret_cast<float2 *>(fz.absgrad)[n] = make_float2(pc.y, pc.z);
 }
 
-template <bool FUSED>
+template <bool FUSED, bool ADAM = false>
 __device__ __forceinline__ void gaussian_bwd_one(
     int n, int C, int N, const float *__restrict__ means, const void *__restrict__ quats,
     const float *__restrict__ scales, const float *__restrict__ viewmats, const float *__restrict__ Ks, int width,
@@ -282,7 +282,7 @@ __device__ __forceinline__ void gaussian_bwd_one(
         const float4 vqb = normal_backward(q, ls, mean, fz.c2w, vn);
         vq.x += vqb.x; vq.y += vqb.y; vq.z += vqb.z; vq.w += vqb.w;
     }
-    if (fz.adam.on) {  // (every input of this Gaussian has been read above: its parameters may move now)
+    if (ADAM) {  // (every input of this Gaussian has been read above: its parameters may move now)
         const float gq[4] = {vq.x, vq.y, vq.z, vq.w};
 #pragma unroll
         for (int k = 0; k < 3; ++k) gauss_adam_at(fz.adam, 0, (int64_t)n * 3 + k, gm[k]);

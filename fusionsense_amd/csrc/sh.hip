@@ -987,7 +987,7 @@ struct GaussShArgs {
     int lazy_sh;
 };
 
-template <bool HALF>
+template <bool HALF, bool ADAM>
 __global__ void __launch_bounds__(kShBlock) __attribute__((amdgpu_waves_per_eu(3, 3)))
 gauss_sh_bwd_kernel(GaussShArgs A, GaussBwdFused fz) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -1050,13 +1050,13 @@ gauss_sh_bwd_kernel(GaussShArgs A, GaussBwdFused fz) {
             A.v_rgb_masked[n] = make_float4(vr, vg, vb, 0.f);
             if (n == 0) A.v_rgb_masked[N] = make_float4(A.campos[0], A.campos[1], A.campos[2], 0.f);
         }
-        gaussian_bwd_one<true>(n, 1, N, A.means, A.quats, A.scales, A.viewmat, A.K, A.width, A.height, A.eps2d, A.radii,
-                               A.conics, nullptr, nullptr, nullptr, nullptr, nullptr, A.v_means, A.v_quats, A.v_scales,
-                               nullptr, fz, pa, pb, pc, pd, share);
+        gaussian_bwd_one<true, ADAM>(n, 1, N, A.means, A.quats, A.scales, A.viewmat, A.K, A.width, A.height, A.eps2d,
+                                     A.radii, A.conics, nullptr, nullptr, nullptr, nullptr, nullptr, A.v_means, A.v_quats,
+                                     A.v_scales, nullptr, fz, pa, pb, pc, pd, share);
     }
     if (A.v_rgb_masked) return;
     __syncthreads();
-    if (fz.adam.on) {  // (every thread of the block has read its coefficients: the block's rows may move)
+    if (ADAM) {  // (every thread of the block has read its coefficients: the block's rows may move)
         adam_rows_g<3>(fz.adam, 3, (int64_t)n0 * 3, rows, lds, pitch, 0);
         adam_rows_g<45>(fz.adam, 4, (int64_t)n0 * 45, rows, lds, pitch, 3);
         return;
@@ -1117,12 +1117,12 @@ static int gauss_sh_bwd_impl(int N, int degree, const float *means, const float 
     fz.xys_grad_norm = xys_grad_norm; fz.vis_counts = vis_counts; fz.max_2Dsize = max_2Dsize; fz.inv_max_hw = inv_max_hw;
     fz.adam = ga;
     const size_t lds_bytes = (size_t)kShBlock * 49 * sizeof(float);
-    if (attr_half)
-        hipLaunchKernelGGL(gauss_sh_bwd_kernel<true>, dim3(ceil_div(N, kShBlock)), dim3(kShBlock), lds_bytes,
-                           as_stream(stream), A, fz);
-    else
-        hipLaunchKernelGGL(gauss_sh_bwd_kernel<false>, dim3(ceil_div(N, kShBlock)), dim3(kShBlock), lds_bytes,
-                           as_stream(stream), A, fz);
+    const dim3 grid(ceil_div(N, kShBlock)), block(kShBlock);
+    hipStream_t s = as_stream(stream);
+    if (attr_half && ga.on) hipLaunchKernelGGL((gauss_sh_bwd_kernel<true, true>), grid, block, lds_bytes, s, A, fz);
+    else if (attr_half) hipLaunchKernelGGL((gauss_sh_bwd_kernel<true, false>), grid, block, lds_bytes, s, A, fz);
+    else if (ga.on) hipLaunchKernelGGL((gauss_sh_bwd_kernel<false, true>), grid, block, lds_bytes, s, A, fz);
+    else hipLaunchKernelGGL((gauss_sh_bwd_kernel<false, false>), grid, block, lds_bytes, s, A, fz);
     return check_launch();
 }
 

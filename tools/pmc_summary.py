@@ -14,6 +14,7 @@ import sys
 
 # kernel symbol -> bench.py span key (several symbols may share a span)
 SPAN = [
+    ("gauss_sh_bwd_kernel<false, true>", "gaussian_bwd_adam"), ("gauss_sh_bwd_kernel<true, true>", "gaussian_bwd_adam"),
     ("gauss_sh_bwd_kernel", "gaussian_bwd"),  # (before "sh_bwd_kernel", which is a substring of it)
     ("raster_bwd_live_kernel<4, true, 3>", "raster_bwd_quad_d4e3"),
     ("raster_fwd_quad_kernel<4, 3>", "raster_fwd_quad_d4e3"),
