@@ -751,6 +751,8 @@ class SplatTrainer:
                     bthr = None
                     if zout is not None:
                         zout = torch.empty_like(zout)  # (the truncated frame's cuts are not kept)
+            else:  # (cannot happen: the third attempt runs uncut and with exact sizes)
+                raise RuntimeError("a frame was abandoned three times (occlusion cut / live-list capacity)")
             if view_key is not None:
                 if out["info"].zcut_out is None:  # (the frame took a binning route without cuts)
                     self._zcuts.pop(view_key, None)

@@ -26,5 +26,5 @@ for k, p in tr.params.items():
     ref = p.data.clone(); dist.broadcast(ref, 0)
     assert torch.equal(ref, p.data), (rank, k)
 assert math.isfinite(float(loss))
-print(f"rank {rank}: ok, N {N0} -> {tr.num_gaussians()} ({len(sizes)} sizes), loss {float(loss):.4f}, deferred={tr.defer_features} factored={tr.factored_features} sharded={tr._geo is not None}", flush=True)
+print(f"rank {rank}: ok, N {N0} -> {tr.num_gaussians()} ({len(sizes)} sizes), loss {float(loss):.4f}, deferred={tr.defer_features} factored={tr.factored_features} sharded={tr._geo is not None} cut_frames={tr.cut_frames} cut_redone={tr.cut_redone}", flush=True)
 dist.destroy_process_group()

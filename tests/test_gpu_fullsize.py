@@ -596,7 +596,7 @@ def test_training_with_densification_converges(dev):
         assert bool(torch.isfinite(p_.data).all()), k
 
 
-@pytest.mark.parametrize("mode", ["factored_deferred", "plain", "sharded_geometry"])
+@pytest.mark.parametrize("mode", ["factored_deferred", "plain", "sharded_geometry", "occlusion_cuts"])
 def test_two_ranks_with_densification_stay_identical(mode):
     """tests/dp_soak_worker.py under torch.distributed.run: 2 ranks (gloo, both on this GPU) train different views
     for 300 steps with splits / culls / opacity resets on; at the end both hold the same number of Gaussians and
@@ -609,6 +609,11 @@ def test_two_ranks_with_densification_stay_identical(mode):
                # reduce-scatter -> Adam on the owned shard -> all-gather for the geometry half, with the flat parameter /
                # moment slabs re-created after every split / cull and the moments gathered before each surgery
                FSGS_SHARDED_GEOMETRY="1" if mode == "sharded_geometry" else "0")
+    if mode == "occlusion_cuts":
+        # the dense-scene machinery forced on at this size: per-view occlusion cuts (every rank keeps its own views'
+        # cuts; a frame one rank has to redo is redone before any collective), unlisted Gaussians skipped, lazy
+        # coefficients — all exact, so the replicas stay identical
+        env.update(FSGS_OCCLUSION_CUT="1", FSGS_KEPT_MIN_N="0", FSGS_LAZY_SH_MIN_N="0")
     out = ""
     for attempt in range(2):
         s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
@@ -626,6 +631,10 @@ def test_two_ranks_with_densification_stay_identical(mode):
     assert p.returncode == 0, out[-3000:]
     assert out.count(": ok, N ") == 2, out[-2000:]
     assert out.count("sharded=True" if mode == "sharded_geometry" else "sharded=False") == 2, out[-2000:]
+    if mode == "occlusion_cuts":
+        import re
+        cuts = [int(m) for m in re.findall(r"cut_frames=(\d+)", out)]
+        assert len(cuts) == 2 and min(cuts) > 100, out[-2000:]
 
 
 def test_no_wait_step_is_bit_identical_and_survives_overflow(dev, full_scene):
