@@ -265,6 +265,7 @@ class SplatTrainer:
         self.zcut_margins = (float(m[0]), float(m[1]))
         self._zcuts: Dict = {}
         self._zcut_widen: Dict = {}
+        self.zcut_max_views = 1024  # least recently rendered views beyond this are forgotten (T floats each)
         # Adam in the backward: on one rank, when nothing else needs the gradients, the per-Gaussian
         # backward launch applies the step's Adam update itself (fsgs_gauss_sh_bwd_adam) — the 236 B of gradients per
         # Gaussian are neither written nor read back, and the Adam launch disappears.  The gradient slab is then NOT
@@ -671,15 +672,13 @@ class SplatTrainer:
         zin = self._zcuts.get(key)
         if zin is not None and zin.numel() != tiles:
             zin = None
-        if len(self._zcuts) > 4096:
-            self._zcuts.clear()
-            self._zcut_widen.clear()
         return key, zin, torch.empty(tiles, dtype=torch.float32, device=self.device)
 
     def drop_occlusion_cuts(self) -> None:
         """Forgets every view's cuts (after densification, pruning or an opacity reset the saturation depths of the
         previous frames say little about the next ones; keeping them would only cost redone frames)."""
         self._zcuts.clear()
+        self._zcut_widen.clear()
 
     def flush(self) -> None:
         """Completes a deferred feature update (no-op otherwise).  Called before the colours are evaluated, before
@@ -754,10 +753,13 @@ class SplatTrainer:
             else:  # (cannot happen: the third attempt runs uncut and with exact sizes)
                 raise RuntimeError("a frame was abandoned three times (occlusion cut / live-list capacity)")
             if view_key is not None:
-                if out["info"].zcut_out is None:  # (the frame took a binning route without cuts)
-                    self._zcuts.pop(view_key, None)
-                else:
-                    self._zcuts[view_key] = zout
+                self._zcuts.pop(view_key, None)
+                if out["info"].zcut_out is not None:  # (None: the frame took a binning route without cuts)
+                    self._zcuts[view_key] = zout  # (most recently used last)
+                    while len(self._zcuts) > self.zcut_max_views:  # e.g. poses that move every step never repeat
+                        old_key = next(iter(self._zcuts))
+                        del self._zcuts[old_key]
+                        self._zcut_widen.pop(old_key, None)
             n_live = out["info"].n_live
             if n_live is not None and self.no_wait:
                 self._live_caps[cap_key] = max(self._live_caps.get(cap_key, 0), int(n_live * 1.25) + 4096)

@@ -183,6 +183,12 @@ def test_cuts_are_dropped_when_the_model_is_rebuilt(dev):
             assert len(tr._zcuts) == 0, "refinement forgets the cuts"
             seen_drop = seen_drop or had > 0
     assert seen_drop and tr.cut_frames > 0
+    # views that never repeat (e.g. poses under optimisation) must not pile up: least recently rendered views go first
+    tr.strategy = None
+    tr.zcut_max_views = 1
+    for it in range(4):
+        tr.train_step(cams[it % 2], tgt)
+        assert len(tr._zcuts) == 1 and len(tr._zcut_widen) <= 1
 
 
 def test_unlisted_gaussians_are_skipped_without_changing_anything(dev, dense_scene, monkeypatch):
