@@ -82,8 +82,8 @@ SIGNATURES = {
     "fsgs_sh_coeff_grad": (_i, [_i, _i, _i, _i, _p, _p, _f, _p, _p, _p]),
     "fsgs_sh_coeff_grad_adam": (_i, [_i, _i, _i, _i, _p, _p, _f, _p, _p, _p, _f, _p, _p, _p, _f, _i, C.c_double, C.c_double, _f, _p]),
     "fsgs_project_fwd_act": (_i, [_i, _i, _p, _p, _p, _p, _i, _f, _p, _p, _i, _i, _f, _f, _f, _f, _p, _p, _p, _p, _p, _p, _p]),
-    "fsgs_gauss_sh_bwd_adam": (_i, [_i, _i] + [_p] * 11 + [_i, _i, _f] + [_p] * 7 + [_f, _p, _i64, _p, _p]),
-    "fsgs_gauss_sh_bwd_adam_h16": (_i, [_i, _i] + [_p] * 11 + [_i, _i, _f] + [_p] * 7 + [_f, _p, _i64, _p, _p]),
+    "fsgs_gauss_sh_bwd_adam": (_i, [_i, _i] + [_p] * 11 + [_i, _i, _f] + [_p] * 7 + [_f, _p, _i64, _p, _f, _p]),
+    "fsgs_gauss_sh_bwd_adam_h16": (_i, [_i, _i] + [_p] * 11 + [_i, _i, _f] + [_p] * 7 + [_f, _p, _i64, _p, _f, _p]),
     "fsgs_gauss_sh_bwd_h16": (_i, [_i, _i] + [_p] * 11 + [_i, _i, _f] + [_p] * 13 + [_f, _p, _i64, _p]),
     "fsgs_gauss_sh_bwd": (_i, [_i, _i] + [_p] * 11 + [_i, _i, _f] + [_p] * 14 + [_f, _p, _i64, _p]),
     "fsgs_gaussian_bwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _f, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _f, _p, _i64, _p]),

@@ -152,7 +152,8 @@ min_scale_kernel(int N, const float *__restrict__ log_scales, float g, const flo
         if (s1 < sm) { sm = s1; k = 1; }
         if (s2 < sm) { sm = s2; k = 2; }
         v = expf(sm);  // min exp = exp min (monotone)
-        if (GRADS) g_log_scales[n * 3 + k] += v_loss[0] * g * v;
+        // (an explicit fused multiply-add: fsgs_gauss_sh_bwd_adam folds this term into its launch and must agree to the bit)
+        if (GRADS) g_log_scales[n * 3 + k] = __builtin_fmaf(v_loss[0] * g, v, g_log_scales[n * 3 + k]);
     }
     v = wave_sum_to_last_row(v);
     if ((threadIdx.x & 63) == 63) red[threadIdx.x >> 6] = v;

@@ -17,6 +17,10 @@ struct GaussAdam {
     __half *h[6];
     float ss[6];
     float b1, b2, omb1, omb2, isb2, eps;
+    // the two_d_gaussians term of get_loss_dict (dn_model.py:817-819) reaches the log-scales directly: its gradient,
+    // min_scale_g * exp(min_k log_scale_k) on the arg-min axis (what fsgs_min_scale_loss adds to the gradient slab after
+    // the backward), is added here when the slab does not exist; 0 = no such term
+    float min_scale_g;
 };
 
 // element i of group g takes gradient gr (same arithmetic as adam_kernel: common.h adam_one)
@@ -272,7 +276,17 @@ __device__ __forceinline__ void gaussian_bwd_one(
         gm[0] = g_mean[0]; gm[1] = g_mean[1]; gm[2] = g_mean[2];
     }
     // `scales` holds exp(log_scales): d/d log_scale = v * exp(log_scale)
-    const float gs[3] = {frozen ? 0.f : vs[0] * s[0], frozen ? 0.f : vs[1] * s[1], frozen ? 0.f : vs[2] * s[2]};
+    float gs[3] = {frozen ? 0.f : vs[0] * s[0], frozen ? 0.f : vs[1] * s[1], frozen ? 0.f : vs[2] * s[2]};
+    if (ADAM && fz.adam.min_scale_g != 0.f) {  // (fp32 masters, first minimum on ties: as min_scale_kernel)
+        const float *lsm = fz.adam.p[1] + (int64_t)n * 3;
+        int k = 0;
+        float sm = lsm[0];
+        if (lsm[1] < sm) { sm = lsm[1]; k = 1; }
+        if (lsm[2] < sm) { sm = lsm[2]; k = 2; }
+        const float e = expf(sm);  // (one fused multiply-add, as min_scale_kernel accumulates it)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) gs[j] = (k == j) ? __builtin_fmaf(fz.adam.min_scale_g, e, gs[j]) : gs[j];
+    }
     const float o = fz.opac[n];
     const float go = frozen ? 0.f : pc.w * o * (1.f - o);
     {   // the normal pass reaches the quaternions only (dn_model.py:618-656)

@@ -1080,7 +1080,7 @@ static int gauss_sh_bwd_impl(int N, int degree, const float *means, const float 
                              float *v_rgb_masked, float *v_means, float *v_quats, float *v_log_scales,
                              float *v_opac_logit, float *absgrad, float *xys_grad_norm, float *vis_counts,
                              float *max_2Dsize, float inv_max_hw, const uint8_t *frozen, int64_t replica_rows,
-                             fsgs_stream_t stream, const fsgs_adam_groups *adam = nullptr) {
+                             fsgs_stream_t stream, const fsgs_adam_groups *adam = nullptr, float min_scale_g = 0.f) {
     if (N < 0 || degree < 0 || degree > 3 || replica_rows < 0) return FSGS_EINVAL;
     if (N == 0) return FSGS_OK;
     if (!means || !campos || !features_dc || !features_rest || !quats || !log_scales || !scales || !opac || !viewmat ||
@@ -1103,6 +1103,7 @@ static int gauss_sh_bwd_impl(int N, int degree, const float *means, const float 
         }
         ga.b1 = (float)adam->beta1; ga.b2 = (float)adam->beta2; ga.isb2 = (float)(1.0 / sqrt(bc2)); ga.eps = adam->eps;
         ga.omb1 = (float)(1.0 - adam->beta1); ga.omb2 = (float)(1.0 - adam->beta2);
+        ga.min_scale_g = min_scale_g;
         ga.on = 1;
     }
     if ((xys_grad_norm || vis_counts || max_2Dsize) && !(xys_grad_norm && vis_counts && max_2Dsize)) return FSGS_EINVAL;
@@ -1169,12 +1170,13 @@ extern "C" int fsgs_gauss_sh_bwd_adam(int N, int degree, const float *means, con
                                       const float *c2w, int width, int height, float eps2d, const int32_t *radii,
                                       const float *conics, float *v_packed, float *absgrad, float *xys_grad_norm,
                                       float *vis_counts, float *max_2Dsize, float inv_max_hw, const uint8_t *frozen,
-                                      int64_t replica_rows, const fsgs_adam_groups *adam, fsgs_stream_t stream) {
+                                      int64_t replica_rows, const fsgs_adam_groups *adam, float min_scale_g,
+                                      fsgs_stream_t stream) {
     if (!adam) return FSGS_EINVAL;
     return gauss_sh_bwd_impl(N, degree, means, campos, features_dc, features_rest, quats, log_scales, 0, scales, opac,
                              viewmat, K, c2w, width, height, eps2d, radii, conics, v_packed, nullptr, nullptr, nullptr,
                              nullptr, nullptr, nullptr, nullptr, absgrad, xys_grad_norm, vis_counts, max_2Dsize,
-                             inv_max_hw, frozen, replica_rows, stream, adam);
+                             inv_max_hw, frozen, replica_rows, stream, adam, min_scale_g);
 }
 
 extern "C" int fsgs_gauss_sh_bwd_adam_h16(int N, int degree, const float *means, const float *campos,
@@ -1184,14 +1186,14 @@ extern "C" int fsgs_gauss_sh_bwd_adam_h16(int N, int degree, const float *means,
                                           float eps2d, const int32_t *radii, const float *conics, float *v_packed,
                                           float *absgrad, float *xys_grad_norm, float *vis_counts, float *max_2Dsize,
                                           float inv_max_hw, const uint8_t *frozen, int64_t replica_rows,
-                                          const fsgs_adam_groups *adam, fsgs_stream_t stream) {
+                                          const fsgs_adam_groups *adam, float min_scale_g, fsgs_stream_t stream) {
     if (!adam) return FSGS_EINVAL;
     for (int g = 1; g < 6; ++g)  // (the render path reads the mirrors: every group but the means must have one)
         if (g != 0 && !adam->half_mirror[g]) return FSGS_EINVAL;
     return gauss_sh_bwd_impl(N, degree, means, campos, features_dc_h, features_rest_h, quats_h, log_scales_h, 1, scales,
                              opac, viewmat, K, c2w, width, height, eps2d, radii, conics, v_packed, nullptr, nullptr,
                              nullptr, nullptr, nullptr, nullptr, nullptr, absgrad, xys_grad_norm, vis_counts, max_2Dsize,
-                             inv_max_hw, frozen, replica_rows, stream, adam);
+                             inv_max_hw, frozen, replica_rows, stream, adam, min_scale_g);
 }
 
 static int sh_bwd_impl(int C, int N, int K, int degree, const float *means, const float *campos,

@@ -83,6 +83,7 @@ class FrameInfo:
         # per-Gaussian launch instead of writing gradients (fsgs_gauss_sh_bwd_adam); adam_applied tells the caller
         self.adam_in_backward = None
         self.adam_applied = False
+        self.min_scale_g = 0.0  # (with adam_in_backward: the min-scale term's gradient weight, folded into that launch)
 
     @property
     def flatten_ids(self):
@@ -421,7 +422,7 @@ class _FusedGetOutputs(torch.autograd.Function):
             _run(f, (N, sh_degree, ptr(means), ptr(cam["campos"]), ptr(src["features_dc"]), ptr(src["features_rest"]),
                      ptr(src["quats"]), ptr(src["scales"]), ptr(scales_exp), ptr(opac_sig), ptr(cam["viewmat"]),
                      ptr(cam["K"]), ptr(cam["c2w"]), W, H, 0.3, ptr(radii), ptr(conics), ptr(v_packed), ptr(v_abs))
-                 + stat_args[:-1] + (C.byref(aib), sp), "fsgs_gaussian_bwd")
+                 + stat_args[:-1] + (C.byref(aib), float(ctx.info.min_scale_g), sp), "fsgs_gaussian_bwd")
             ctx.info.adam_applied = True
         elif hm is not None and K == 16 and sh_degree <= 3 and ONE_LAUNCH_GAUSSIAN_BWD:
             _run(lib.fsgs_gauss_sh_bwd_h16,
@@ -608,12 +609,12 @@ def fused_step_forward_backward(gauss_params: Dict[str, Tensor], camera: Camera,
             loss = ops._FusionLoss.forward(lctx, rgb, depth, normal, gauss_params["scales"].data, target, cfg,
                                            info.normals_world, touch_idx, touch_normals, seed_grad, True)
             check_live_total(ctx)
-            if lctx.g[3] != 0.0:
-                info.adam_in_backward = None  # (the min-scale term below adds to the scales' gradient: it must exist)
+            g_min = lctx.g[3]
+            info.min_scale_g = g_min  # (an Adam step carried by the backward takes the term's gradient with it)
             v = ops._FusionLoss.backward(lctx, seed_grad)
             _FusedGetOutputs.backward(ctx, v[0], v[1], v[2], None)
-            g_min = lctx.g[3]
-            if g_min != 0.0:  # the min-scale term reaches the log-scales directly, touch anchors included (:817-819)
+            if g_min != 0.0 and not info.adam_applied:
+                # the min-scale term reaches the log-scales directly, touch anchors included (:817-819)
                 ops.min_scale_grad_(gauss_params["scales"].data, g_min, seed_grad.reshape(1), grad_out["scales"])
         out = {"rgb": rgb, "depth": depth, "normal": normal, "accumulation": alpha, "background": background,
                "info": info, "xys": info, "radii": info.radii[0], "normals_world": info.normals_world}

@@ -269,9 +269,11 @@ class SplatTrainer:
         # Adam in the backward: on one rank, when nothing else needs the gradients, the per-Gaussian
         # backward launch applies the step's Adam update itself (fsgs_gauss_sh_bwd_adam) — the 236 B of gradients per
         # Gaussian are neither written nor read back, and the Adam launch disappears.  The gradient slab is then NOT
-        # filled by that step.  FSGS_ADAM_IN_BACKWARD = auto (N >= 2^20) | 1 | 0.
+        # filled by that step.  Measured: +0.9 % at 100 k Gaussians, +2.7 % at config #3, +7 % at 700 k, +13-15 % at
+        # configs #4 / #5; sizes whose feature update rides in the next count pass (ride_adam_n) keep that instead.
+        # FSGS_ADAM_IN_BACKWARD = auto (whenever the step qualifies) | 1 (the same) | 0.
         self.adam_in_backward_mode = os.environ.get("FSGS_ADAM_IN_BACKWARD", "auto")
-        self.adam_in_backward_min_n = 1 << 20
+        self.adam_in_backward_min_n = 0
         self.adam_in_backward_steps = 0
         self.cut_frames = 0
         self.cut_redone = 0

@@ -530,13 +530,15 @@ int fsgs_gauss_sh_bwd_h16(int N, int degree, const float *means, const float *ca
  * six groups in the order means [N,3], log-scales [N,3], quats [N,4], features_dc [N,3], features_rest [N,45], opacity
  * logits [N,1]; grads[] is ignored; half_mirror[] entries (nullable; required for all but the means by _h16) are
  * rewritten with the update.  A Gaussian's parameters move after the thread that owns it has read them; nothing else in
- * the launch reads them.  For single-rank steps whose gradients nobody else needs (no exchange, no min-scale term). */
+ * the launch reads them.  min_scale_g != 0: the gradient of get_loss_dict's two_d_gaussians term (dn_model.py:817-819;
+ * what fsgs_min_scale_loss(v_loss = 1, g = min_scale_g) adds to the log-scale gradients after the backward) is added to
+ * the log-scale gradients here, from the fp32 masters.  For single-rank steps whose gradients nobody else needs. */
 int fsgs_gauss_sh_bwd_adam(int N, int degree, const float *means, const float *campos, const float *features_dc,
                            const float *features_rest, const float *quats, const float *log_scales, const float *scales,
                            const float *opac, const float *viewmat, const float *K, const float *c2w, int width,
                            int height, float eps2d, const int32_t *radii, const float *conics, float *v_packed,
                            float *absgrad, float *xys_grad_norm, float *vis_counts, float *max_2Dsize, float inv_max_hw,
-                           const uint8_t *frozen, int64_t replica_rows, const fsgs_adam_groups *adam,
+                           const uint8_t *frozen, int64_t replica_rows, const fsgs_adam_groups *adam, float min_scale_g,
                            fsgs_stream_t stream);
 int fsgs_gauss_sh_bwd_adam_h16(int N, int degree, const float *means, const float *campos, const void *features_dc_h,
                                const void *features_rest_h, const void *quats_h, const void *log_scales_h,
@@ -544,7 +546,8 @@ int fsgs_gauss_sh_bwd_adam_h16(int N, int degree, const float *means, const floa
                                const float *c2w, int width, int height, float eps2d, const int32_t *radii,
                                const float *conics, float *v_packed, float *absgrad, float *xys_grad_norm,
                                float *vis_counts, float *max_2Dsize, float inv_max_hw, const uint8_t *frozen,
-                               int64_t replica_rows, const fsgs_adam_groups *adam, fsgs_stream_t stream);
+                               int64_t replica_rows, const fsgs_adam_groups *adam, float min_scale_g,
+                               fsgs_stream_t stream);
 /* frozen (nullable, [N] u8): rows whose v_means / v_log_scales / v_opac_logit are zero — FusionSense's touch
  * anchors, detached at dn_model.py:535-541 (their quaternion and colour gradients still flow). */
 /* dn_model.py:602-613, 655-656: rgb = clamp(render[:3] + (1-alpha) bg, 0, 1); depth = alpha > 0 ?

@@ -293,3 +293,70 @@ def test_adam_in_the_backward_is_the_same_update_bit_for_bit(dev, monkeypatch, h
     # a step without optimizer (gradients wanted) still fills the slab
     b.train_step(cams[0], tgt, optimizer_step=False)
     assert b.adam_in_backward_steps == 3 and float(b.slab.views["means"].abs().sum()) > 0
+
+
+def test_adam_in_the_backward_with_the_fusionsense_loss(dev, monkeypatch):
+    """The same bit-for-bit claim under the reference's get_loss_dict (FrameBatch route): its two_d_gaussians term adds
+    to the log-scale gradients AFTER the backward (fsgs_min_scale_loss) — with the Adam step inside the backward that
+    gradient is folded into the launch (min_scale_g), touch anchors (frozen means / scales / opacities) included."""
+    from fusionsense_amd import fused
+    from fusionsense_amd.losses import LossConfig, prepare_batch
+    from fusionsense_amd.splatfacto import DensifyStrategy, SplatfactoConfig
+    from fusionsense_amd.trainer import PARAM_ORDER, SplatTrainer
+    W, H = 160, 96
+    params, cams = scenes.fusionsense_like_scene(seed=0, n_hull=1200, n_bg=2400)
+    params = {k: v.to(dev) for k, v in params.items()}
+    params["opacities"] = params["opacities"] + 2.0
+    cams = [scenes.Camera(c.c2w, c.fx * W / 1280.0, c.fy * H / 720.0, c.cx * W / 1280.0, c.cy * H / 720.0, W, H)
+            for c in cams]
+    N = params["means"].shape[0]
+    g = torch.Generator().manual_seed(11)
+    sensor = 0.4 + 1.2 * torch.rand(H, W, 1, generator=g)
+    sensor[torch.rand(H, W, 1, generator=g) < 0.15] = 0.0
+    batch = {"image": torch.rand(H, W, 3, generator=g), "sensor_depth": sensor, "normal": torch.rand(H, W, 3, generator=g)}
+    cfg = LossConfig()
+    assert cfg.two_d_gaussians
+    fb = prepare_batch(batch, cfg, dev)
+    n_touch = 150
+    add_mask = torch.zeros(N, dtype=torch.bool)
+    add_mask[-n_touch:] = True
+    touch_normals = torch.nn.functional.normalize(torch.randn(n_touch, 3, generator=g), dim=-1)
+    tape = {"mode": None, "snaps": [], "i": 0, "fns": []}
+    real_run = fused._run
+
+    def run(fn, args, label, *rest):
+        if label == "fsgs_gaussian_bwd" and tape["mode"] is not None:
+            acc = fused._ACCUM[str(dev)]
+            tape["fns"].append(getattr(fn, "__name__", str(fn)))
+            if tape["mode"] == "record":
+                tape["snaps"].append(acc.clone())
+            else:
+                acc.copy_(tape["snaps"][tape["i"]])
+                tape["i"] += 1
+        return real_run(fn, args, label, *rest)
+    monkeypatch.setattr(fused, "_run", run)
+
+    def train(mode, tape_mode):
+        st = DensifyStrategy(SplatfactoConfig(), num_train_data=2, stats_only=True)
+        st.add_mask = add_mask.to(dev)
+        st.touch_normals = touch_normals.to(dev)
+        tr = SplatTrainer(params, dev, sh_degree=3, strategy=st, loss_cfg=cfg)
+        tr.adam_in_backward_mode = mode
+        tape["mode"], tape["i"] = tape_mode, 0
+        losses = [float(tr.train_step(cams[it % 2], fb)[0]) for it in range(3)]
+        tape["mode"] = None
+        return tr, losses
+
+    a, la = train("0", "record")
+    b, lb = train("1", "replay")
+    assert a.adam_in_backward_steps == 0 and b.adam_in_backward_steps == 3 and la == lb
+    for k in PARAM_ORDER:
+        assert torch.equal(a.params[k].data, b.params[k].data), k
+        sa_, sb_ = a.optimizers[k].state[a.params[k]], b.optimizers[k].state[b.params[k]]
+        assert torch.equal(sa_["exp_avg"], sb_["exp_avg"]) and torch.equal(sa_["exp_avg_sq"], sb_["exp_avg_sq"]), k
+    # the anchors' scales moved (the min-scale term reaches them), their means did not get a render gradient: the first
+    # moment of the means stays exactly zero there
+    st_m = b.optimizers["means"].state[b.params["means"]]["exp_avg"]
+    assert float(st_m[-n_touch:].abs().max()) == 0.0
+    st_s = b.optimizers["scales"].state[b.params["scales"]]["exp_avg"]
+    assert float(st_s[-n_touch:].abs().max()) > 0.0

@@ -561,14 +561,22 @@ def test_fused_trainer_step_equals_unfused(dev):
     target = {"rgb": torch.rand(128, 128, 3).to(dev), "depth": torch.rand(128, 128, 1).to(dev),
               "normal": torch.rand(128, 128, 3).to(dev)}
     res = []
-    for fused in (True, False):
+    for fused, aib in ((True, "0"), (False, "0"), (True, "1")):
         tr = SplatTrainer(params, dev, fused=fused)
+        # "1": the Adam step is applied inside the per-Gaussian backward launch and the gradient slab is NOT filled
+        # (trainer.adam_in_backward_mode, the default where the step qualifies); "0" keeps gradients + Adam launch
+        tr.adam_in_backward_mode = aib
         before = {k: v.detach().clone() for k, v in tr.params.items()}
         loss = tr.train_step(cam, target)[0].item()
         tr.flush()  # (the fused trainer's feature update rides in the NEXT frame's count pass: land it)
+        assert tr.adam_in_backward_steps == (1 if aib == "1" else 0)
         res.append((loss, {k: tr.slab.views[k].clone() for k in tr.params},
                     {k: (tr.params[k].detach() - before[k]) for k in tr.params}))
-    assert abs(res[0][0] - res[1][0]) < 1e-5 * max(1.0, abs(res[1][0]))
+    assert abs(res[0][0] - res[1][0]) < 1e-5 * max(1.0, abs(res[1][0])) and res[2][0] == res[0][0]
+    for k in res[0][1]:  # the step with Adam in the backward moves the parameters like the unfused step does
+        gu = res[1][1][k]
+        solid = gu.abs() > 1e-3 * gu.abs().max()
+        assert (res[2][2][k][solid] - res[1][2][k][solid]).abs().max().item() < 1e-3 * tr.optim_cfg.lr[k] + 1e-9, k
     for k in res[0][1]:
         gf, gu = res[0][1][k], res[1][1][k]
         assert rel_err(gf, gu) < 5e-3, f"slab grad {k}: {rel_err(gf, gu)}"
