@@ -18,7 +18,7 @@ callbacks and its ``Optimizers`` (round 3):
 
     get_loss_dict      dn_model.py:673-925   -> ops._FusionLoss over a cached FrameBatch (one autograd node); the original
                                                 stays as ``_get_loss_dict_reference`` and is used for every switch the node
-                                                does not cover (mono depth, normals from depth, cosine / sparse / SDF terms)
+                                                does not cover (normals from depth, cosine / sparse / SDF terms, other depth-loss types)
     after_train        (nerfstudio, A.2)     -> nothing to do: the statistics were applied by the node's backward
     refinement_after   dn_model.py:326-451   -> DensifyStrategy.refinement_after (HIP row compaction, split sampling)
     add_touch_patch    dn_model.py:1156-1247 -> DensifyStrategy.add_touch_patch
@@ -145,6 +145,7 @@ def _loss_config(cfg):
         return None
     return LossConfig(ssim_lambda=float(g("ssim_lambda", 0.2)), use_depth_loss=bool(g("use_depth_loss", False)),
                       sensor_depth_lambda=float(g("sensor_depth_lambda", 0.0)),
+                      mono_depth_lambda=float(g("mono_depth_lambda", 0.0)),
                       depth_tolerance=float(g("depth_tolerance", 0.1)),
                       use_depth_smooth_loss=bool(g("use_depth_smooth_loss", False)),
                       smooth_loss_lambda=float(g("smooth_loss_lambda", 0.1)),
@@ -165,7 +166,6 @@ def get_loss_dict_fused(self, outputs, batch, metrics_dict=None) -> Dict[str, to
     cfg = _loss_config(self.config)
     rgb = outputs.get("rgb")
     covered = (cfg is not None and torch.is_tensor(rgb) and rgb.is_cuda and "normal" in outputs and "depth" in outputs
-               and not ("mono_depth" in batch and float(getattr(self.config, "mono_depth_lambda", 0.0)) > 0.0)
                and not (cfg.use_normal_loss and "normal" not in batch)
                and int(getattr(self.config, "num_downscales", 0)) == 0)
     if not covered:
@@ -174,7 +174,8 @@ def get_loss_dict_fused(self, outputs, batch, metrics_dict=None) -> Dict[str, to
     key = int(batch["image_idx"]) if "image_idx" in batch else id(batch["image"])
     fb = frames.get(key)
     if fb is None or fb.height != rgb.shape[0] or fb.width != rgb.shape[1]:
-        fb = frames[key] = prepare_batch({k: batch[k] for k in ("image", "sensor_depth", "normal", "mask") if k in batch},
+        fb = frames[key] = prepare_batch({k: batch[k] for k in ("image", "sensor_depth", "mono_depth", "normal", "mask")
+                                          if k in batch},
                                          cfg, rgb.device)
     touch_idx = touch_normals = None
     add_mask = getattr(self, "add_mask", None)

@@ -19,6 +19,7 @@ class LossConfig:
     ssim_lambda: float = 0.2            # nerfstudio SplatfactoModelConfig default
     use_depth_loss: bool = True         # configs/config.py:9
     sensor_depth_lambda: float = 0.2    # configs/config.py:11
+    mono_depth_lambda: float = 0.2      # dn_model.py:70 (acts only on batches that carry "mono_depth": :737-750)
     depth_tolerance: float = 0.1        # dn_model.py:64
     use_depth_smooth_loss: bool = True  # configs/config.py:12
     smooth_loss_lambda: float = 0.1     # dn_model.py:74
@@ -36,9 +37,12 @@ class FrameBatch:
     valid sensor-depth pixels with a right / a lower neighbour.  Built once per view by :func:`prepare_batch`
     (the reference's datamanager likewise keeps its images cached on the device)."""
 
-    def __init__(self, image, sensor_depth, normal, mask, cnt_x, cnt_y, has_sensor):
+    def __init__(self, image, sensor_depth, normal, mask, cnt_x, cnt_y, has_sensor, mono_depth=None, mono_cnt_x=0,
+                 mono_cnt_y=0):
         self.image, self.sensor_depth, self.normal, self.mask = image, sensor_depth, normal, mask
         self.cnt_x, self.cnt_y, self.has_sensor = cnt_x, cnt_y, has_sensor
+        # monocular depth (dn_model.py:737-750; FusionSense's batches carry none): [H,W] + its two valid counts
+        self.mono_depth, self.mono_cnt_x, self.mono_cnt_y = mono_depth, mono_cnt_x, mono_cnt_y
         self.height, self.width = image.shape[0], image.shape[1]
 
 
@@ -60,7 +64,11 @@ def prepare_batch(batch: Dict[str, Tensor], cfg: LossConfig, device) -> FrameBat
     normal = img(batch["normal"]) if "normal" in batch else None
     mask = batch["mask"].to(**f32).reshape(H, W).contiguous() if "mask" in batch else None
     cnt_x, cnt_y = ops.depth_valid_counts(sensor, mask, cfg.depth_tolerance) if has_sensor else (0, 0)
-    return FrameBatch(image, sensor, normal, mask, cnt_x, cnt_y, has_sensor)
+    mono, mcx, mcy = None, 0, 0
+    if "mono_depth" in batch:
+        mono = batch["mono_depth"].to(**f32).reshape(H, W).contiguous()
+        mcx, mcy = ops.depth_valid_counts(mono, mask, cfg.depth_tolerance)
+    return FrameBatch(image, sensor, normal, mask, cnt_x, cnt_y, has_sensor, mono, mcx, mcy)
 
 
 def _gaussian_window(size: int, sigma: float, device, dtype) -> Tensor:

@@ -1211,6 +1211,18 @@ def depth_valid_counts(sensor_depth: Tensor, mask: Optional[Tensor], depth_tol: 
     return int(cx), int(cy)
 
 
+def mono_depth_weights(cfg, fb):
+    """The two EdgeAwareLogL1 column weights of the monocular-depth term (dn_model.py:737-745) as a w_aux[7] row, or
+    None when the batch carries no mono depth / the term is off."""
+    if not (cfg.use_depth_loss and getattr(fb, "mono_depth", None) is not None
+            and getattr(cfg, "mono_depth_lambda", 0.0) > 0.0):
+        return None
+    w = [0.0] * 7
+    w[0] = cfg.mono_depth_lambda / fb.mono_cnt_x if fb.mono_cnt_x else float("inf")
+    w[1] = cfg.mono_depth_lambda / fb.mono_cnt_y if fb.mono_cnt_y else float("inf")
+    return w
+
+
 def fusion_loss_weights(cfg, fb, n_gauss: int, n_touch: int):
     """Every partial-sum column's weight in get_loss_dict's total (dn_model.py:673-925), as host floats:
     (g_l1, g_ssim), w_aux[7], g_minscale, g_touch."""
@@ -1285,6 +1297,19 @@ class _FusionLoss(torch.autograd.Function):
                                         float(cfg.depth_tolerance), wa, ptr(seed), ptr(aux), ptr(v_depth),
                                         ptr(v_normal), sp), "fsgs_fusion_aux_loss")
         partials, weights = [sums, aux], [(g_l1, g_ssim), tuple(w_aux) + (0.0,)]
+        w_mono = mono_depth_weights(cfg, fb)
+        if w_mono is not None:
+            # monocular depth (dn_model.py:737-745): the same EdgeAwareLogL1 columns against a second target — a
+            # second pass of the kernel with every other column's weight zero; its depth gradient is added
+            aux_m = torch.empty_like(aux)
+            v_depth_m = torch.empty_like(depth) if seed is not None else None
+            _run(lib.fsgs_fusion_aux_loss, (H, W, ptr(depth), None, ptr(fb.image), ptr(fb.mono_depth), None, ptr(fb.mask),
+                                            float(cfg.depth_tolerance), (C.c_float * 7)(*w_mono), ptr(seed), ptr(aux_m),
+                                            ptr(v_depth_m), None, sp), "fsgs_fusion_aux_loss")
+            if v_depth_m is not None:
+                v_depth.add_(v_depth_m)
+            partials.append(aux_m)
+            weights.append(tuple(w_mono) + (0.0,))
         if g_min != 0.0:
             pm = torch.empty((N + 255) // 256, 2, **f32)
             _run(lib.fsgs_min_scale_loss, (N, ptr(log_scales), 0.0, None, ptr(pm), None, sp), "fsgs_min_scale_loss")
@@ -1331,6 +1356,14 @@ class _FusionLoss(torch.autograd.Function):
                                             ptr(fb.sensor_depth), ptr(fb.normal) if has_n else None, ptr(fb.mask),
                                             float(cfg.depth_tolerance), (C.c_float * 7)(*w_aux), ptr(v_loss),
                                             ptr(scratch), ptr(v_depth), ptr(v_normal), sp), "fsgs_fusion_aux_loss")
+            w_mono = mono_depth_weights(cfg, fb)
+            if w_mono is not None:
+                v_depth_m = torch.empty_like(depth)
+                _run(lib.fsgs_fusion_aux_loss, (H, W, ptr(depth), None, ptr(fb.image), ptr(fb.mono_depth), None,
+                                                ptr(fb.mask), float(cfg.depth_tolerance), (C.c_float * 7)(*w_mono),
+                                                ptr(v_loss), ptr(scratch), ptr(v_depth_m), None, sp),
+                     "fsgs_fusion_aux_loss")
+                v_depth.add_(v_depth_m)
         v_rgb = torch.empty_like(rgb)
         dl = ctx.deferred_loss
         if dl is not None:

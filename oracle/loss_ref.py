@@ -30,6 +30,7 @@ class LossConfig:
     ssim_lambda: float = 0.2            # nerfstudio default
     use_depth_loss: bool = True         # configs/config.py:9
     sensor_depth_lambda: float = 0.2    # configs/config.py:11
+    mono_depth_lambda: float = 0.2      # dn_model.py:70 (used only when the batch carries "mono_depth")
     depth_tolerance: float = 0.1        # dn_model.py:64
     use_depth_smooth_loss: bool = True  # configs/config.py:12
     smooth_loss_lambda: float = 0.1     # dn_model.py:74
@@ -100,20 +101,27 @@ def dn_terms(outputs: Dict[str, Tensor], batch: Dict[str, Tensor], log_scales: T
     """What dn_model.py:673-925 adds to splatfacto's main loss (sensor-depth + mono-normal configuration)."""
     gt_img = batch["image"].clamp(min=10 / 255.0)                      # :692
     depth_out = outputs["depth"]
-    sensor = batch["sensor_depth"]
+    sensor = batch.get("sensor_depth")
+    mono = batch.get("mono_depth")
     normal_gt = batch.get("normal")
     pred_normal = outputs["normal"]
     if "mask" in batch:                                                # :702-714
         mask = batch["mask"]
         depth_out = depth_out * mask
-        sensor = sensor * mask
+        if sensor is not None:
+            sensor = sensor * mask
+        if mono is not None:
+            mono = mono * mask
         if normal_gt is not None:
             normal_gt = normal_gt * mask
         pred_normal = pred_normal * mask
     depth_loss = 0
-    if cfg.use_depth_loss and cfg.sensor_depth_lambda > 0.0:           # :720-728
+    if cfg.use_depth_loss and sensor is not None and cfg.sensor_depth_lambda > 0.0:   # :720-728
         valid = sensor > cfg.depth_tolerance
         depth_loss = depth_loss + cfg.sensor_depth_lambda * edge_aware_log_l1(depth_out, sensor.float(), gt_img, valid)
+    if cfg.use_depth_loss and mono is not None and cfg.mono_depth_lambda > 0.0:       # :737-745 (EdgeAwareLogL1)
+        valid = mono > cfg.depth_tolerance
+        depth_loss = depth_loss + cfg.mono_depth_lambda * edge_aware_log_l1(depth_out, mono.float(), gt_img, valid)
     if cfg.use_depth_smooth_loss:                                      # :752-755
         depth_loss = depth_loss + cfg.smooth_loss_lambda * tv(depth_out)
     normal_loss = 0

@@ -53,7 +53,7 @@ def _splatfacto_standin():
     return m
 
 
-def case(model_mod, losses, seed, H, W, n_gauss, with_mask, with_touch, holes):
+def case(model_mod, losses, seed, H, W, n_gauss, with_mask, with_touch, holes, mono=None):
     g = torch.Generator().manual_seed(seed)
     cfgd = {}
     sys.path.insert(0, os.path.join(base.REF, "configs"))
@@ -96,6 +96,15 @@ def case(model_mod, losses, seed, H, W, n_gauss, with_mask, with_touch, holes):
         sensor[torch.rand(H, W, 1, generator=g) < 0.25] = 0.0  # invalid sensor depth (<= depth_tolerance)
     normal_gt = torch.rand(H, W, 3, generator=g)
     batch = {"image": image.clone(), "sensor_depth": sensor.clone(), "normal": normal_gt.clone()}
+    mono_depth = None
+    if mono is not None:
+        # the monocular-depth branch (dn_model.py:737-750; off in FusionSense, whose batches carry no "mono_depth"):
+        # "both" = next to the sensor depth, "only" = instead of it
+        mono_depth = 0.2 + 2.5 * torch.rand(H, W, 1, generator=g)
+        mono_depth[torch.rand(H, W, 1, generator=g) < 0.2] = 0.05  # (<= depth_tolerance: invalid)
+        batch["mono_depth"] = mono_depth.clone()
+        if mono == "only":
+            del batch["sensor_depth"]
     if with_mask:
         mask = torch.rand(H, W, 1, generator=g) > 0.3
         batch["mask"] = mask
@@ -108,7 +117,9 @@ def case(model_mod, losses, seed, H, W, n_gauss, with_mask, with_touch, holes):
     return dict(rgb=rgb, depth=depth.detach(), normal=normal.detach(), image=image, sensor_depth=sensor,
                 normal_gt=normal_gt, mask=mask, has_mask=np.array(with_mask), scales=scales.detach(),
                 normals_world=normals_world, n_touch=np.array(n_touch), touch_normals=tn,
-                loss=loss.detach(), v_depth=depth.grad, v_normal=normal.grad, v_scales=scales.grad)
+                loss=loss.detach(), v_depth=depth.grad, v_normal=normal.grad, v_scales=scales.grad,
+                **({} if mono is None else dict(mono_depth=mono_depth, mono_only=np.array(mono == "only"),
+                                                mono_depth_lambda=np.array(cfg.mono_depth_lambda, dtype=np.float32))))
 
 
 def main():
@@ -122,7 +133,9 @@ def main():
     out = {}
     cases = {"full": dict(seed=1, H=24, W=40, n_gauss=50, with_mask=True, with_touch=True, holes=True),
              "nomask": dict(seed=2, H=17, W=33, n_gauss=30, with_mask=False, with_touch=False, holes=True),
-             "dense": dict(seed=3, H=32, W=32, n_gauss=64, with_mask=True, with_touch=True, holes=False)}
+             "dense": dict(seed=3, H=32, W=32, n_gauss=64, with_mask=True, with_touch=True, holes=False),
+             "mono": dict(seed=4, H=21, W=37, n_gauss=40, with_mask=True, with_touch=False, holes=True, mono="both"),
+             "monoonly": dict(seed=5, H=19, W=26, n_gauss=20, with_mask=False, with_touch=False, holes=True, mono="only")}
     for name, kw in cases.items():
         for k, v in case(model, losses, **kw).items():
             out[f"{name}.{k}"] = v.numpy() if torch.is_tensor(v) else v

@@ -25,7 +25,7 @@ def _fb(batch, dev, cfg=None):
     return prepare_batch(batch, cfg or LossConfig(), dev)
 
 
-@pytest.mark.parametrize("case", ["full", "nomask", "dense"])
+@pytest.mark.parametrize("case", ["full", "nomask", "dense", "mono", "monoonly"])
 def test_fusion_loss_kernels_match_reference_goldens(dev, case):
     """ops._FusionLoss against numbers the reference's get_loss_dict produced itself: the gradient images of depth
     and normals, the log-scale gradient, and the value of everything FusionSense adds to the photometric term."""
@@ -36,6 +36,11 @@ def test_fusion_loss_kernels_match_reference_goldens(dev, case):
     t = lambda k: torch.from_numpy(d[f"{case}.{k}"])  # noqa: E731
     cfg = LossConfig()
     batch = {"image": t("image"), "sensor_depth": t("sensor_depth"), "normal": t("normal_gt")}
+    if f"{case}.mono_depth" in d.files:  # the monocular-depth branch (dn_model.py:737-750)
+        batch["mono_depth"] = t("mono_depth")
+        assert abs(cfg.mono_depth_lambda - float(d[f"{case}.mono_depth_lambda"])) < 1e-7
+        if bool(d[f"{case}.mono_only"]):
+            del batch["sensor_depth"]
     if bool(d[f"{case}.has_mask"]):
         batch["mask"] = t("mask")
     fb = _fb(batch, dev, cfg)
@@ -862,3 +867,29 @@ def test_scene_directory_to_training_checkpoint_and_export(dev, tmp_path):
     la, _ = tr.train_step(out.cameras[2], batches[2])
     lb, _ = tr2.train_step(out.cameras[2], batches[2])
     assert abs(float(la) - float(lb)) <= 1e-5 * abs(float(la))
+
+
+def test_monocular_depth_term_on_both_trainer_routes(dev):
+    """A batch that carries "mono_depth" (dn_model.py:737-750; FusionSense's own batches do not): the EdgeAwareLogL1 term
+    against the second target is evaluated by the loss node — pinned to the reference's execution in
+    test_fusion_loss_kernels_match_reference_goldens[mono*] — and its depth gradient reaches the parameters the same
+    way on the tape-free step (gradient images formed in the forward's pass, seed known) and on the autograd tape."""
+    from fusionsense_amd.losses import LossConfig
+    from fusionsense_amd.trainer import PARAM_ORDER, SplatTrainer
+    W, H = 160, 96
+    params, cams = _small_fusionsense(dev, W, H)
+    batch = _synthetic_batch(H, W, 5)
+    g = torch.Generator().manual_seed(8)
+    batch["mono_depth"] = 0.3 + 1.5 * torch.rand(H, W, 1, generator=g)
+    cfg = LossConfig()
+    res = {}
+    for name, b, direct in (("with", batch, True), ("tape", batch, False),
+                            ("without", {k: v for k, v in batch.items() if k != "mono_depth"}, True)):
+        tr = SplatTrainer(params, dev, sh_degree=3, loss_cfg=cfg, direct=direct)
+        loss, _ = tr.train_step(cams[1], _fb(b, dev, cfg), optimizer_step=False)
+        res[name] = (float(loss), {k: tr.slab.views[k].clone() for k in PARAM_ORDER})
+    assert abs(res["with"][0] - res["tape"][0]) < 1e-6 * abs(res["tape"][0])
+    assert res["with"][0] > res["without"][0] + 1e-3, "the term adds to the loss"
+    for k in PARAM_ORDER:
+        assert rel_err(res["with"][1][k], res["tape"][1][k]) < 1e-3, k
+    assert rel_err(res["with"][1]["means"], res["without"][1]["means"]) > 1e-2, "and to the gradients"

@@ -169,7 +169,7 @@ def test_adam_fuser_is_torch_adam_in_one_launch(dev, monkeypatch):
     assert not torch.equal(new.data, before) and float(oa[k].state[new]["step"]) == 6.0
 
 
-@pytest.mark.parametrize("case", ["full", "nomask", "dense"])
+@pytest.mark.parametrize("case", ["full", "nomask", "dense", "mono", "monoonly"])
 def test_patched_get_loss_dict_matches_reference_goldens(dev, case):
     """``model.get_loss_dict(outputs, batch)`` after patch_all against what the reference's get_loss_dict produced on
     the same inputs (reference_loss.npz): value of everything FusionSense adds to the photometric term, gradient images,
@@ -190,6 +190,11 @@ def test_patched_get_loss_dict_matches_reference_goldens(dev, case):
     m.gauss_params["normals"] = t("normals_world").to(dev)
     batch = {"image": t("image").to(dev), "sensor_depth": t("sensor_depth").to(dev), "normal": t("normal_gt").to(dev),
              "image_idx": 4}
+    if f"{case}.mono_depth" in d.files:  # the monocular-depth branch (dn_model.py:737-750), evaluated by the node too
+        batch["mono_depth"] = t("mono_depth").to(dev)
+        m.config.mono_depth_lambda = float(d[f"{case}.mono_depth_lambda"])
+        if bool(d[f"{case}.mono_only"]):
+            del batch["sensor_depth"]
     if bool(d[f"{case}.has_mask"]):
         batch["mask"] = t("mask").to(dev)
     out = {k: t(k).to(dev).requires_grad_(True) for k in ("rgb", "depth", "normal")}

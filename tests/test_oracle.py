@@ -204,7 +204,7 @@ def test_config1_full_frame_matches_committed_checksum():
     assert np.array_equal(meta["isect_offsets"].numpy(), g["cfg1_offsets"])
 
 
-@pytest.mark.parametrize("case", ["full", "nomask", "dense"])
+@pytest.mark.parametrize("case", ["full", "nomask", "dense", "mono", "monoonly"])
 def test_loss_oracle_matches_reference_goldens(case):
     """oracle/loss_ref.dn_terms against numbers produced by EXECUTING the reference's own
     DNSplatterModel.get_loss_dict (tests/golden/make_reference_loss_goldens.py): value and the gradients with
@@ -216,6 +216,10 @@ def test_loss_oracle_matches_reference_goldens(case):
     normal = t("normal").clone().requires_grad_(True)
     scales = t("scales").clone().requires_grad_(True)
     batch = {"image": t("image"), "sensor_depth": t("sensor_depth"), "normal": t("normal_gt")}
+    if f"{case}.mono_depth" in d.files:  # the monocular-depth branch (dn_model.py:737-750)
+        batch["mono_depth"] = t("mono_depth")
+        if bool(d[f"{case}.mono_only"]):
+            del batch["sensor_depth"]
     if bool(d[f"{case}.has_mask"]):
         batch["mask"] = t("mask")
     n_touch = int(d[f"{case}.n_touch"])
