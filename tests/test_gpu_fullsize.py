@@ -563,7 +563,8 @@ def test_two_ranks_train_identical_replicas(mode):
     assert err.count("replicas identical") == 2, err[-2000:]
 
 
-def test_training_with_densification_converges(dev):
+@pytest.mark.parametrize("dense_machinery", [False, True])
+def test_training_with_densification_converges(dev, dense_machinery, monkeypatch):
     """The whole loop as FusionSense runs it — get_outputs, loss, backward, Adam, after_train statistics, splits /
     duplicates / culls, opacity resets and binary-opacity writes on their schedules, the SH degree ramp — for 1500
     steps towards renders of a differently seeded scene: the loss falls by more than 3x, the Gaussian count
@@ -576,6 +577,16 @@ def test_training_with_densification_converges(dev):
     strategy = DensifyStrategy(cfg, num_train_data=V)
     tr = SplatTrainer(scenes.lego_like_scene(N0, seed=0), dev, sh_degree=3, strategy=strategy, seed=0,
                       sh_degree_interval=300)
+    if dense_machinery:
+        # what scenes of >= 2^20 Gaussians switch on by themselves, forced on here so that it lives through splits,
+        # culls, opacity resets and binary-opacity writes: per-view occlusion cuts (dropped at every rebuild / reset,
+        # frames redone when a cut turns out too tight), unlisted Gaussians skipped, lazy coefficients — next to the
+        # Adam step inside the backward, which this size runs anyway
+        from fusionsense_amd import fused
+        from fusionsense_amd._lib import load
+        tr.occlusion_cut_mode = "1"
+        monkeypatch.setattr(fused, "KEPT_MIN_N", 0)
+        prev_lazy = load().fsgs_set_lazy_sh_min_n(0)
     gt = SplatTrainer(scenes.lego_like_scene(N0, seed=1), dev, sh_degree=3)
     with torch.no_grad():
         tg = []
@@ -590,6 +601,10 @@ def test_training_with_densification_converges(dev):
             assert math.isfinite(last), s
             first = last if first is None else first
             sizes.add(tr.num_gaussians())
+    if dense_machinery:
+        load().fsgs_set_lazy_sh_min_n(prev_lazy)
+        assert tr.cut_frames > 1000 and tr.cut_redone < tr.cut_frames // 4, (tr.cut_frames, tr.cut_redone)
+    assert tr.adam_in_backward_steps == 1500
     assert last < first / 3.0, (first, last)
     assert len(sizes) > 1, "densification never changed the Gaussian count"
     for k, p_ in tr.params.items():
