@@ -174,6 +174,15 @@ def cpu_baseline(args):
                 "sample": f"oracle child exceeded {args.cpu_timeout}s on {args.cpu_views} {args.cpu_crop}^2 crops"}
 
 
+def never_updated_frac(trainer):
+    try:
+        p = trainer._params["opacities"]
+        v = trainer.optimizers["opacities"].state[p]["exp_avg_sq"]
+        return round(float((v.reshape(-1) == 0).float().mean()), 4)
+    except Exception:  # (no optimizer state yet)
+        return None
+
+
 def pmc_record(kernel_key, config):
     """Counters of a kernel from the committed PMC run of this round (profiles/pmc_traffic.json), or {}.
     PMC counters cannot be read from inside the timed process; tools/pmc_summary.py writes this file from the
@@ -734,6 +743,10 @@ def main():
             # steps whose Adam update was applied inside the per-Gaussian backward launch (no gradient slab, no Adam
             # launch: DESIGN.md §9.9; FSGS_ADAM_IN_BACKWARD=auto|1|0)
             "adam_in_backward_steps": int(getattr(trainer, "adam_in_backward_steps", 0)),
+            # Gaussians whose opacity logit has never received a gradient (second moment still exactly 0) after the run:
+            # the Adam step inside the backward neither reads their parameters nor writes anything for them (an exact
+            # no-op).  In this synthetic scene that is every Gaussian no view has reached yet — a real capture has fewer.
+            "never_updated_gaussians_frac": never_updated_frac(trainer),
             # occlusion cuts (dense scenes): frames binned with cuts / of those, redone uncut because a
             # cut tile did not saturate (both over warmup + timed steps; the redone frames are inside the timed region)
             "occlusion_cut": {"mode": getattr(trainer, "occlusion_cut_mode", "0"),

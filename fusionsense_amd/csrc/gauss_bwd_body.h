@@ -25,7 +25,11 @@ struct GaussAdam {
 
 // element i of group g takes gradient gr (same arithmetic as adam_kernel: common.h adam_one)
 __device__ __forceinline__ void gauss_adam_at(const GaussAdam &a, int g, int64_t i, float gr) {
-    float p = a.p[g][i], m = a.m[g][i], v = a.v[g][i];
+    float m = a.m[g][i], v = a.v[g][i];
+    // (zero gradient on zero moments — a Gaussian no view has reached yet: the update is exactly "nothing changes",
+    // so the parameter is not even read and nothing is written: 8 instead of 24 B for this float)
+    if (gr == 0.f && m == 0.f && v == 0.f) return;
+    float p = a.p[g][i];
     adam_one(p, gr, m, v, a.b1, a.b2, a.omb1, a.omb2, a.ss[g], a.isb2, a.eps);
     a.p[g][i] = p; a.m[g][i] = m; a.v[g][i] = v;
     if (a.h[g]) a.h[g][i] = __float2half(p);

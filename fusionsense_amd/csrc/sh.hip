@@ -664,27 +664,43 @@ __device__ __forceinline__ void adam_rows_g(const GaussAdam &a, int grp, int64_t
     const int total4 = total >> 2;
     for (int i0 = threadIdx.x; i0 < total4; i0 += kShBlock * U) {
         float4 p[U], m[U], v[U];
+        float g[U][4];
+        bool idle[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int i = i0 + u * kShBlock;
-            if (i < total4) { p[u] = P4[i]; m[u] = M4[i]; v[u] = V4[i]; }
+            idle[u] = true;
+            if (i < total4) {
+                m[u] = M4[i]; v[u] = V4[i];
+                const int e = i << 2;
+                int r = e / RF, col = e - r * RF;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    g[u][k] = lds[r * pitch + col];
+                    if (++col == RF) { col = 0; ++r; }
+                }
+            }
+        }
+        // zero gradients on zero moments (Gaussians no view has reached yet): nothing changes — the parameters are not
+        // read and nothing is written (32 instead of 96 B per float4)
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = i0 + u * kShBlock;
+            if (i < total4) {
+                auto z4 = [](const float4 q) { return q.x == 0.f && q.y == 0.f && q.z == 0.f && q.w == 0.f; };
+                idle[u] = z4(m[u]) && z4(v[u]) && g[u][0] == 0.f && g[u][1] == 0.f && g[u][2] == 0.f && g[u][3] == 0.f;
+                if (!idle[u]) p[u] = P4[i];
+            }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int i = i0 + u * kShBlock;
             if (i >= total4) break;
-            const int e = i << 2;
-            int r = e / RF, col = e - r * RF;
-            float g[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                g[k] = lds[r * pitch + col];
-                if (++col == RF) { col = 0; ++r; }
-            }
-            adam_one(p[u].x, g[0], m[u].x, v[u].x, a.b1, a.b2, a.omb1, a.omb2, ss, a.isb2, a.eps);
-            adam_one(p[u].y, g[1], m[u].y, v[u].y, a.b1, a.b2, a.omb1, a.omb2, ss, a.isb2, a.eps);
-            adam_one(p[u].z, g[2], m[u].z, v[u].z, a.b1, a.b2, a.omb1, a.omb2, ss, a.isb2, a.eps);
-            adam_one(p[u].w, g[3], m[u].w, v[u].w, a.b1, a.b2, a.omb1, a.omb2, ss, a.isb2, a.eps);
+            if (idle[u]) continue;
+            adam_one(p[u].x, g[u][0], m[u].x, v[u].x, a.b1, a.b2, a.omb1, a.omb2, ss, a.isb2, a.eps);
+            adam_one(p[u].y, g[u][1], m[u].y, v[u].y, a.b1, a.b2, a.omb1, a.omb2, ss, a.isb2, a.eps);
+            adam_one(p[u].z, g[u][2], m[u].z, v[u].z, a.b1, a.b2, a.omb1, a.omb2, ss, a.isb2, a.eps);
+            adam_one(p[u].w, g[u][3], m[u].w, v[u].w, a.b1, a.b2, a.omb1, a.omb2, ss, a.isb2, a.eps);
             P4[i] = p[u]; M4[i] = m[u]; V4[i] = v[u];
             if (H) {
                 const __half2 lo = __floats2half2_rn(p[u].x, p[u].y), hi = __floats2half2_rn(p[u].z, p[u].w);
