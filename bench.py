@@ -647,6 +647,7 @@ def main():
         }
         riding = bool(getattr(trainer, "_ride_mode", lambda: False)())
         aib_on = int(getattr(trainer, "adam_in_backward_steps", 0)) > 0
+        idle_frac = never_updated_frac(trainer) or 0.0
         alg.update({
             "isect_count_live": ("projecting count pass + table scan with the SH colours / record packing riding"
                                  + (" + the features' Adam step riding" if riding else ""),
@@ -655,7 +656,9 @@ def main():
             # are not written; parameters and both moments are read and written instead: 59 floats x 6 streams)
             "gaussian_bwd": ("gauss_sh_bwd_kernel (SH VJP + projection / normal / activation VJPs + after_train statistics"
                              + (" + the Adam step of all six groups" if aib_on else "") + ")",
-                             N * (120 + 52 + 36 + 76 + (59 * 24 - 236 if aib_on else 0)) + n_vis * 228),
+                             # (... of which a float with zero gradient on zero moments only has its moments read: 8 B)
+                             N * (120 + 52 + 36 + 76 + ((59 * 8 - 236) if aib_on else 0)) + n_vis * 228
+                             + (int((1.0 - idle_frac) * N) * 59 * 16 if aib_on else 0)),
             "ssim_l1_fwd": ("ssim_l1_fwd_kernel", P * 3 * 24),
             "ssim_l1_bwd": ("ssim_l1_bwd_kernel (+ loss combine)", P * 3 * 36),
         })
