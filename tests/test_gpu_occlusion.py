@@ -360,3 +360,77 @@ def test_adam_in_the_backward_with_the_fusionsense_loss(dev, monkeypatch):
     assert float(st_m[-n_touch:].abs().max()) == 0.0
     st_s = b.optimizers["scales"].state[b.params["scales"]]["exp_avg"]
     assert float(st_s[-n_touch:].abs().max()) > 0.0
+
+
+def test_new_entry_points_reject_bad_arguments_and_take_empty_scenes(dev):
+    """The round's C-ABI additions through ctypes: null / inconsistent arguments come back as FSGS_EINVAL (no launch),
+    an empty scene is fine, and a direct call of fsgs_tile_zcut_update / fsgs_tile_zcut_recheck on hand-made inputs
+    gives the documented cuts, candidates and verdicts."""
+    import ctypes as C
+    from fusionsense_amd._lib import AdamGroups, load, ptr, stream_ptr
+    lib = load()
+    sp = stream_ptr(dev)
+    EINVAL = -1
+    f32 = dict(dtype=torch.float32, device=dev)
+    i32 = dict(dtype=torch.int32, device=dev)
+    tw = th = 2
+    W = H = 32
+    T = tw * th
+    # four tiles; lists: tile 0 = entries 0..2, tile 1 = 3..4, tile 2 = empty, tile 3 = 5
+    offsets = torch.tensor([0, 3, 5, 5, 6], **i32)
+    payload = torch.tensor([0, 1, 2, 3, 4, 5], **i32)
+    depths = torch.tensor([1.0, 2.0, 3.0, 1.5, 2.5, 4.0], **f32)
+    last = torch.zeros(H, W, **i32)
+    last[:16, :16] = 1      # tile 0: deepest composited entry 1 (depth 2)
+    last[:16, 16:] = 4      # tile 1: entry 4 (depth 2.5)
+    last[16:, 16:] = 5      # tile 3: entry 5
+    tile_open = torch.tensor([0, 1, 0, 0], **i32)   # tile 1 did not saturate
+    zin = torch.tensor([9.0, 2.0, 7.0, float("inf")], **f32)
+    cand = torch.zeros(T, **i32)
+    zout = torch.empty(T, **f32)
+    bad = torch.zeros(1, **i32)
+    verdict = torch.zeros(4, dtype=torch.int32).pin_memory()
+    args = [tw, th, W, H, ptr(last), ptr(payload), ptr(depths), ptr(offsets), ptr(tile_open), ptr(zin), ptr(cand),
+            ptr(zout), ptr(bad), verdict.data_ptr(), 1.0, 0.03, sp]
+    for k in (4, 5, 6, 7, 8, 11, 12, 13):  # any required pointer missing
+        a = list(args)
+        a[k] = None
+        assert lib.fsgs_tile_zcut_update(*a) == EINVAL
+    a = list(args); a[10] = None
+    assert lib.fsgs_tile_zcut_update(*a) == EINVAL, "cuts without a candidate array"
+    a = list(args); a[14] = -1.0
+    assert lib.fsgs_tile_zcut_update(*a) == EINVAL
+    assert lib.fsgs_tile_zcut_update(*args) == 0
+    torch.cuda.synchronize()
+    inf = float("inf")
+    # tile 0: 2 + max(1.0 * (2 - 1), 0.03 * 2) = 3; tile 1 open -> inf (+ candidate: it was cut at 2.0); tile 2 empty
+    # under a cut: the cut is kept; tile 3: 4 + max(0, 0.12)
+    assert torch.allclose(zout.cpu(), torch.tensor([3.0, inf, 7.0, 4.12])), zout
+    assert cand.tolist() == [0, 1, 0, 0] and verdict[:2].tolist() == [2, 1]
+    assert tile_open.tolist() == [0, 0, 0, 0] and int(bad) == 0
+    # second look: Gaussian 0 sits in tile 1 in front of its cut, Gaussian 1 behind it -> invalid; without Gaussian 1 -> fine
+    means2d = torch.tensor([[24.0, 8.0], [24.0, 8.0]], **f32)
+    radii = torch.tensor([4, 4], **i32)
+    gd = torch.tensor([1.5, 2.5], **f32)
+    conics = torch.tensor([[0.5, 0.0, 0.5], [0.5, 0.0, 0.5]], **f32)
+    opac = torch.tensor([0.9, 0.9], **f32)
+    for n, want in ((2, 1), (1, 0)):
+        cand.copy_(torch.tensor([0, 1, 0, 0], **i32))
+        verdict.zero_()
+        assert lib.fsgs_tile_zcut_recheck(n, ptr(means2d), ptr(radii), ptr(gd), ptr(conics), ptr(opac), tw, th, ptr(zin),
+                                          ptr(cand), ptr(bad), verdict.data_ptr(), sp) == 0
+        torch.cuda.synchronize()
+        assert verdict[:2].tolist() == [want, 1] and cand.tolist() == [0, 0, 0, 0] and int(bad) == 0, (n, verdict)
+    assert lib.fsgs_tile_zcut_recheck(2, None, ptr(radii), ptr(gd), ptr(conics), ptr(opac), tw, th, ptr(zin), ptr(cand),
+                                      ptr(bad), verdict.data_ptr(), sp) == EINVAL
+    assert lib.fsgs_tile_zcut_recheck(0, None, None, None, None, None, tw, th, ptr(zin), ptr(cand), ptr(bad),
+                                      verdict.data_ptr(), sp) == 0  # (no Gaussians: nothing can have been lost)
+    torch.cuda.synchronize()
+    assert verdict[:2].tolist() == [0, 1]
+    # fsgs_gauss_sh_bwd_adam: the argument block must hold exactly the six groups with N-sized tensors
+    g = AdamGroups()
+    g.n_groups = 5
+    common = (0, 3) + (None,) * 11 + (16, 16, 0.3) + (None,) * 7 + (0.0, None, 0)
+    assert lib.fsgs_gauss_sh_bwd_adam(*common, C.byref(g), 0.0, sp) == 0, "N = 0: nothing to do"
+    assert lib.fsgs_gauss_sh_bwd_adam(*common, None, 0.0, sp) == EINVAL
+    assert lib.fsgs_set_lazy_sh_min_n(lib.fsgs_set_lazy_sh_min_n(123)) == 123
