@@ -55,7 +55,10 @@ __device__ __forceinline__ void load_rec(Rec &r, const float4 *__restrict__ rec,
 // to come  buffer_end(k) = C_total - C_before(k+1)  (or 0).  A workgroup of kBwdWaves waves owns a
 // quadrant; wave w takes segments w, w+kBwdWaves, ... independently (no barriers between waves), which
 // removes the long-list tail that otherwise sets the kernel's duration.
-constexpr int kBwdWaves = 4;
+#ifndef FSGS_BWD_WAVES
+#define FSGS_BWD_WAVES 4
+#endif
+constexpr int kBwdWaves = FSGS_BWD_WAVES;
 
 // Optional: the gradients arrive as those of FusionSense's get_outputs images (D = 4, E = 3, C = 1; what
 // fsgs_epilogue_bwd would first turn into v_render / v_alphas / v_render_extra, dn_model.py:602-613, 655-664):
