@@ -270,7 +270,8 @@ class SplatTrainer:
         # backward launch applies the step's Adam update itself (fsgs_gauss_sh_bwd_adam) — the 236 B of gradients per
         # Gaussian are neither written nor read back, and the Adam launch disappears.  The gradient slab is then NOT
         # filled by that step.  Measured: +0.9 % at 100 k Gaussians, +2.7 % at config #3, +7 % at 700 k, +13-15 % at
-        # configs #4 / #5; sizes whose feature update rides in the next count pass (ride_adam_n) keep that instead.
+        # configs #4 / #5, +0.6 % at config #2 (against the feature update riding in the next count pass, which remains
+        # the route of FSGS_ADAM_IN_BACKWARD=0 for ride_adam_n sizes).
         # FSGS_ADAM_IN_BACKWARD = auto (whenever the step qualifies) | 1 (the same) | 0.
         self.adam_in_backward_mode = os.environ.get("FSGS_ADAM_IN_BACKWARD", "auto")
         self.adam_in_backward_min_n = 0
@@ -533,7 +534,10 @@ class SplatTrainer:
 
     def _ride_mode(self) -> bool:
         """One rank, the library's own Adam, the tape-free step: the feature update can ride in the count pass."""
-        return (self.ride_adam and self._one_rank_fused() and
+        # (... unless the whole Adam step can go into the backward launch, §9.9: measured at config #2, 0.584 against
+        # 0.588 ms per step — the count pass no longer carries 400 MB of feature moments, the per-Gaussian backward
+        # carries all six groups; riding remains what FSGS_ADAM_IN_BACKWARD=0 gets)
+        return (self.ride_adam and self._one_rank_fused() and self.adam_in_backward_mode == "0" and
                 self.ride_adam_n[0] <= self.num_gaussians() <= self.ride_adam_n[1])
 
     def _one_rank_fused(self) -> bool:
