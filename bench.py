@@ -755,7 +755,7 @@ def main():
             "occlusion_cut": {"mode": getattr(trainer, "occlusion_cut_mode", "0"),
                               "cut_frames": int(getattr(trainer, "cut_frames", 0)),
                               "cut_redone": int(getattr(trainer, "cut_redone", 0)),
-                              "second_looks": int(__import__("fusionsense_amd.ops", fromlist=["x"]).zcut_rechecks),
+                              "second_looks": int(ops.zcut_rechecks),
                               "margins": list(getattr(trainer, "zcut_margins", ()))},
             "max_step_ms": round(1e3 * max(b - a for a, b in zip([t0] + step_ends[:-1], step_ends)), 3),
             "slowest_step": max(range(len(step_ends)), key=lambda i: step_ends[i] - ([t0] + step_ends)[i]),
