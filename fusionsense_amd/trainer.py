@@ -681,8 +681,8 @@ class SplatTrainer:
         return key, zin, torch.empty(tiles, dtype=torch.float32, device=self.device)
 
     def drop_occlusion_cuts(self) -> None:
-        """Forgets every view's cuts (after densification, pruning or an opacity reset the saturation depths of the
-        previous frames say little about the next ones; keeping them would only cost redone frames)."""
+        """Forgets every view's cuts (after an opacity reset the saturation depths of the previous frames say nothing
+        about the next ones; keeping them would only cost second looks and redone frames)."""
         self._zcuts.clear()
         self._zcut_widen.clear()
 

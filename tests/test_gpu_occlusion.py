@@ -163,7 +163,9 @@ def test_training_with_cuts_is_the_same_training(dev, dense_scene):
         assert float((d > 2e-5).float().mean()) < 2e-2, k
 
 
-def test_cuts_are_dropped_when_the_model_is_rebuilt(dev):
+def test_cuts_outlive_a_rebuild_and_are_dropped_by_an_opacity_reset(dev):
+    """Cuts are depths per tile, not rows of the model: a refinement (splits / culls) leaves them in place — a cut that
+    has become too tight is found out on the device —, an opacity reset drops them (nothing saturates where it did)."""
     from fusionsense_amd.splatfacto import DensifyStrategy, SplatfactoConfig
     from fusionsense_amd.trainer import SplatTrainer
     params = {k: v.to(dev) for k, v in scenes.lego_like_scene(60_000, seed=3).items()}
@@ -171,18 +173,21 @@ def test_cuts_are_dropped_when_the_model_is_rebuilt(dev):
     g = torch.Generator().manual_seed(1)
     tgt = {"rgb": torch.rand(256, 256, 3, generator=g).to(dev), "depth": torch.rand(256, 256, 1, generator=g).to(dev) * 4,
            "normal": torch.rand(256, 256, 3, generator=g).to(dev)}
-    cfg = SplatfactoConfig(warmup_length=2, refine_every=4, reset_alpha_every=1000)
+    cfg = SplatfactoConfig(warmup_length=2, refine_every=4, reset_alpha_every=3)  # refinements at 8, 16 ..; reset at 16
     st = DensifyStrategy(cfg, num_train_data=2)
     tr = SplatTrainer(params, dev, sh_degree=3, strategy=st)
     tr.occlusion_cut_mode = "1"
-    seen_drop = False
-    for it in range(10):
+    rebuilt_with_cuts = dropped = False
+    for it in range(20):
         n0, had = tr.num_gaussians(), len(tr._zcuts)
+        op0 = float(tr._params["opacities"].data.max())
         tr.train_step(cams[it % 2], tgt)
-        if tr.num_gaussians() != n0:
-            assert len(tr._zcuts) == 0, "refinement forgets the cuts"
-            seen_drop = seen_drop or had > 0
-    assert seen_drop and tr.cut_frames > 0
+        if tr.num_gaussians() != n0 and had == 2 and len(tr._zcuts) == 2:
+            rebuilt_with_cuts = True
+        if had == 2 and len(tr._zcuts) == 0:
+            dropped = True
+            assert float(tr._params["opacities"].data.max()) < op0, "only an opacity reset forgets the cuts"
+    assert rebuilt_with_cuts and dropped and tr.cut_frames > 0
     # views that never repeat (e.g. poses under optimisation) must not pile up: least recently rendered views go first
     tr.strategy = None
     tr.zcut_max_views = 1
