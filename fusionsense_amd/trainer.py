@@ -717,10 +717,12 @@ class SplatTrainer:
             stats, add_mask, bthr = self._frame_state(camera, True)
             factors = self._factor_buffers(optimizer_step)
             from .ops import LiveListOverflow
-            cap_key = (self.num_gaussians(), camera.width, camera.height)
-            cap = self._live_caps.get(cap_key, 0) if self.no_wait else 0
             from .ops import OcclusionCutInvalid
             view_key, zin, zout = self._view_cuts(camera)
+            # (frames binned with occlusion cuts hold a fraction of the pairs: their own capacity estimate, or the first
+            # uncut frame after them — a new view, a redone frame — would overflow it)
+            cap_key = (self.num_gaussians(), camera.width, camera.height, zin is not None)
+            cap = self._live_caps.get(cap_key, 0) if self.no_wait else 0
             aib, aib_step = None, None
             if self._adam_in_backward_ok(optimizer_step):
                 self.optimizers["means"].param_groups[0]["lr"] = self._means_lr(self.step)
@@ -746,6 +748,8 @@ class SplatTrainer:
                     zin = None
                     zout = torch.empty_like(zout)
                     bthr = None  # (as below: the abandoned attempt's count pass has run)
+                    cap_key = cap_key[:3] + (False,)
+                    cap = self._live_caps.get(cap_key, 0) if (self.no_wait and cap > 0) else 0
                 except LiveListOverflow as e:  # rare: the frame outgrew the estimate -> once more, with exact sizes
                     self.live_overflows += 1
                     self._live_caps[cap_key] = int(e.needed * 1.25) + 4096
