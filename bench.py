@@ -756,7 +756,7 @@ def main():
                               "cut_frames": int(getattr(trainer, "cut_frames", 0)),
                               "cut_redone": int(getattr(trainer, "cut_redone", 0)),
                               "second_looks": int(ops.zcut_rechecks),
-                              "margins": list(getattr(trainer, "zcut_margins", ()))},
+                              "margins_span_rel_tail": list(getattr(trainer, "zcut_margins", ()))},
             "max_step_ms": round(1e3 * max(b - a for a, b in zip([t0] + step_ends[:-1], step_ends)), 3),
             "slowest_step": max(range(len(step_ends)), key=lambda i: step_ends[i] - ([t0] + step_ends)[i]),
             "gpu_step_ms": gpu_step_stats(step_events, step_views) if with_events else None,

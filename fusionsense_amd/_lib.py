@@ -63,7 +63,7 @@ SIGNATURES = {
     "fsgs_bin_live_emit_split": (_i, [_i, _i, _p, _p, _p, _p, _p, _i, _i, _p, _p, _i64, _p, _p, _p, _sz, _p, _p, _p]),
     "fsgs_set_lazy_sh_min_n": (_i, [_i]),
     "fsgs_tile_zcut_recheck": (_i, [_i, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _p]),
-    "fsgs_tile_zcut_update": (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _f, _f, _p]),
+    "fsgs_tile_zcut_update": (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _f, _f, _f, _p]),
     "fsgs_quad_stream_capacity": (_i64, [_i, _i, _i, _i64]),
     "fsgs_quad_seg_slots": (_i64, [_i, _i, _i, _i64]),
     "fsgs_live_pack": (_i, [_i, _i64, _p, _p, _p, _p, _p, _p, _p, _i, _p]),

@@ -1153,7 +1153,7 @@ __global__ void __launch_bounds__(64)
 tile_zcut_kernel(int tw, int th, int W, int H, const int32_t *__restrict__ last_ids, const int32_t *__restrict__ payload,
                  const float *__restrict__ depths, const int32_t *__restrict__ offsets, int32_t *__restrict__ tile_open,
                  const float *__restrict__ zcut_in, int32_t *__restrict__ cand, float *__restrict__ zcut_out,
-                 int32_t *__restrict__ bad, float margin_span, float margin_rel) {
+                 int32_t *__restrict__ bad, float margin_span, float margin_rel, float tail_frac) {
     const int t = blockIdx.x, lane = threadIdx.x;
     const int ty = t / tw, tx = t - ty * tw;
     int best = -1;
@@ -1181,6 +1181,9 @@ tile_zcut_kernel(int tw, int th, int W, int H, const int32_t *__restrict__ last_
         const int last = min(max(best, l0), l1 - 1);
         const float z_last = depths[payload[last] & 0x0FFFFFFF], z_first = depths[payload[l0] & 0x0FFFFFFF];
         z = z_last + fmaxf(margin_span * (z_last - z_first), margin_rel * z_last);
+        // a tile that needed (nearly) all of its list to saturate gains nothing from a cut and is the tile that will
+        // be found open one visit later: no cut for it (FSGS_ZCUT_TAIL: the fraction of the list that must lie behind)
+        if ((float)(l1 - 1 - last) < tail_frac * (float)(l1 - l0)) z = inf;
     } else if (zcut_in) {
         z = zcut_in[t];  // (an empty list under a cut: keep the cut; without a cut an empty tile needs none)
     }
@@ -1206,15 +1209,17 @@ extern "C" int fsgs_tile_zcut_update(int tile_width, int tile_height, int width,
                                      const int32_t *payload, const float *depths, const int32_t *isect_offsets,
                                      int32_t *tile_open, const float *zcut_in, int32_t *zcut_cand, float *zcut_out,
                                      int32_t *bad_scratch, int32_t *verdict_mapped, float margin_span, float margin_rel,
-                                     fsgs_stream_t stream) {
-    if (tile_width < 1 || tile_height < 1 || width < 1 || height < 1 || margin_span < 0.f || margin_rel < 0.f) return FSGS_EINVAL;
+                                     float tail_frac, fsgs_stream_t stream) {
+    if (tile_width < 1 || tile_height < 1 || width < 1 || height < 1 || margin_span < 0.f || margin_rel < 0.f ||
+        !(tail_frac >= 0.f && tail_frac <= 1.f))
+        return FSGS_EINVAL;
     if (!last_ids || !payload || !depths || !isect_offsets || !tile_open || !zcut_out || !bad_scratch || !verdict_mapped ||
         (zcut_in && !zcut_cand))
         return FSGS_EINVAL;
     hipStream_t s = as_stream(stream);
     hipLaunchKernelGGL(tile_zcut_kernel, dim3(tile_width * tile_height), dim3(64), 0, s, tile_width, tile_height, width,
                        height, last_ids, payload, depths, isect_offsets, tile_open, zcut_in, zcut_cand, zcut_out,
-                       bad_scratch, margin_span, margin_rel);
+                       bad_scratch, margin_span, margin_rel, tail_frac);
     hipLaunchKernelGGL(zcut_verdict_kernel, dim3(1), dim3(64), 0, s, bad_scratch, verdict_mapped, (int32_t *)nullptr, 0);
     return check_launch();
 }

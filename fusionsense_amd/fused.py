@@ -76,7 +76,7 @@ class FrameInfo:
         # frame invalid (ops.OcclusionCutInvalid from the caller's check; to be redone without cuts).
         self.zcut_in: Optional[Tensor] = None
         self.zcut_out: Optional[Tensor] = None
-        self.zcut_margins = (0.5, 0.01)
+        self.zcut_margins = (1.0, 0.03, 0.25)  # (span, rel, tail: fsgs_tile_zcut_update)
         self.pending_verdict = None
         self.kept: Optional[Tensor] = None  # [N] uint8 (dense scenes): the Gaussian is in at least one tile's list
         # an _lib.AdamGroups of the six parameter groups (trainer's order): the backward applies this Adam step in its
@@ -305,7 +305,8 @@ class _FusedGetOutputs(torch.autograd.Function):
                                             ptr(tile_open), ptr(info.zcut_in),
                                             ptr(hit) if info.zcut_in is not None else None, ptr(zout), ptr(bad),
                                             verdict.data_ptr(), float(info.zcut_margins[0]),
-                                            float(info.zcut_margins[1]), sp), "fsgs_tile_zcut_update")
+                                            float(info.zcut_margins[1]), float(info.zcut_margins[2]), sp),
+                 "fsgs_tile_zcut_update")
             info.pending_verdict = verdict if info.zcut_in is not None else None
         rgb = torch.empty(H, W, 3, **f32)
         depth = torch.empty(H, W, 1, **f32)

@@ -261,8 +261,10 @@ class SplatTrainer:
         # i.e. large steps): (0.5, 0.01) keeps 1.6 M of 39 M pairs and 4 of 58 cut frames are redone, (1.0, 0.03)
         # keeps 2.7 M and none is redone, (2.0, 0.06) keeps 8.3 M.  A view whose frame had to be redone doubles its own
         # margins (up to 8x).
-        m = os.environ.get("FSGS_ZCUT_MARGIN", "1.0,0.03").split(",")
-        self.zcut_margins = (float(m[0]), float(m[1]))
+        # Third number (tail): a tile that saturated only within the last quarter of its list gets no cut — it gains little
+        # and is the tile found open one visit later (config #4: 17 → 3 second looks per 58 cut frames, same pairs kept).
+        m = (os.environ.get("FSGS_ZCUT_MARGIN", "1.0,0.03,0.25") + ",0.25").split(",")
+        self.zcut_margins = (float(m[0]), float(m[1]), float(m[2]))
         self._zcuts: Dict = {}
         self._zcut_widen: Dict = {}
         self.zcut_max_views = 1024  # least recently rendered views beyond this are forgotten (T floats each)
@@ -740,7 +742,8 @@ class SplatTrainer:
                         fusion=((self.loss_cfg,) + self._touch_rows()) if is_fb else None,
                         half=self.half_mirrors(), live_capacity=cap, zcut_in=zin, zcut_out=zout,
                         zcut_margins=self.zcut_margins if view_key not in self._zcut_widen else tuple(
-                            self._zcut_widen[view_key] * x for x in self.zcut_margins), adam_in_backward=aib)
+                            self._zcut_widen[view_key] * x for x in self.zcut_margins[:2]) + self.zcut_margins[2:],
+                        adam_in_backward=aib)
                     break
                 except OcclusionCutInvalid:  # a cut tile did not saturate inside its prefix: the exact frame, uncut
                     self.cut_redone += 1

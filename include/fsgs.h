@@ -397,8 +397,10 @@ int fsgs_bin_live_emit_split(int C, int N, const float *means2d, const int32_t *
  * uncut frame — images, last_ids, record streams, gradients; any other frame must be redone without cuts.
  * fsgs_raster_fwd_quad(tile_open != NULL) marks the tiles in which a pixel was still transparent at the end of its list;
  * this call (one camera) turns that and last_ids into
- *   zcut_out[t] = +inf if tile t was open, else depth(deepest composited entry of t) + max(margin_span * (that depth -
- *                 the tile's first entry's depth), margin_rel * that depth),
+ *   zcut_out[t] = +inf if tile t was open — or saturated only within the last tail_frac of its list (such a tile gains
+ *                 little from a cut and is the one found open a visit later; tail_frac, 0.25 in the trainer) —, else
+ *                 depth(deepest composited entry of t) + max(margin_span * (that depth - the tile's first entry's
+ *                 depth), margin_rel * that depth),
  *   zcut_cand[t]      = 1 for every open tile that had been binned with a finite zcut_in (the "candidates"),
  *   verdict_mapped[0] = 2 if there is a candidate, else 0 (the frame is exact), and
  *   verdict_mapped[1] = 1 once [0] has landed (host-mapped memory; the caller clears [1] beforehand);
@@ -412,7 +414,7 @@ int fsgs_tile_zcut_update(int tile_width, int tile_height, int width, int height
                           const int32_t *payload, const float *depths, const int32_t *isect_offsets,
                           int32_t *tile_open, const float *zcut_in, int32_t *zcut_cand, float *zcut_out,
                           int32_t *bad_scratch, int32_t *verdict_mapped, float margin_span, float margin_rel,
-                          fsgs_stream_t stream);
+                          float tail_frac, fsgs_stream_t stream);
 int fsgs_tile_zcut_recheck(int N, const float *means2d, const int32_t *radii, const float *depths, const float *conics,
                            const float *opacities, int tile_width, int tile_height, const float *zcut_in,
                            int32_t *zcut_cand, int32_t *bad_scratch, int32_t *verdict_mapped, fsgs_stream_t stream);

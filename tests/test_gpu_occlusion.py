@@ -75,6 +75,7 @@ def test_cut_frames_equal_uncut_frames(dev, dense_scene):
     plain.occlusion_cut_mode = "0"
     cutting = SplatTrainer(params, dev, sh_degree=3)
     cutting.occlusion_cut_mode = "1"
+    cutting.zcut_margins = (1.0, 0.03, 0.0)  # (this scene saturates late in its lists: no tail rule, the mechanism itself)
     ref = [_frame(plain, c, tgt) for c in cams]
     first = [_frame(cutting, c, tgt) for c in cams]   # no cuts known yet: plain frames that record them
     assert cutting.cut_frames == 0 and len(cutting._zcuts) == 2
@@ -100,6 +101,7 @@ def test_too_tight_cuts_are_detected_and_the_frame_redone(dev, dense_scene):
     ref = _frame(plain, cams[0], tgt)
     tr = SplatTrainer(params, dev, sh_degree=3)
     tr.occlusion_cut_mode = "1"
+    tr.zcut_margins = (1.0, 0.03, 0.0)
     _frame(tr, cams[0], tgt)
     (key, zc), = tr._zcuts.items()
     good = zc.clone()
@@ -150,6 +152,7 @@ def test_training_with_cuts_is_the_same_training(dev, dense_scene):
         st = DensifyStrategy(SplatfactoConfig(), num_train_data=2, stats_only=True)
         tr = SplatTrainer(params, dev, sh_degree=3, strategy=st)
         tr.occlusion_cut_mode = mode
+        tr.zcut_margins = (1.0, 0.03, 0.0)
         losses = [float(tr.train_step(cams[it % 2], tgt)[0]) for it in range(8)]
         return tr, st, losses
 
@@ -213,6 +216,7 @@ def test_unlisted_gaussians_are_skipped_without_changing_anything(dev, dense_sce
         try:
             tr = SplatTrainer(params, dev, sh_degree=3)
             tr.occlusion_cut_mode = "1" if cuts else "0"
+            tr.zcut_margins = (1.0, 0.03, 0.0)
             out = []
             for it in range(2 if cuts else 1):  # (with cuts: the second frame of the view is the cut one)
                 f = _frame(tr, cams[0], tgt)
@@ -396,7 +400,7 @@ def test_new_entry_points_reject_bad_arguments_and_take_empty_scenes(dev):
     bad = torch.zeros(1, **i32)
     verdict = torch.zeros(4, dtype=torch.int32).pin_memory()
     args = [tw, th, W, H, ptr(last), ptr(payload), ptr(depths), ptr(offsets), ptr(tile_open), ptr(zin), ptr(cand),
-            ptr(zout), ptr(bad), verdict.data_ptr(), 1.0, 0.03, sp]
+            ptr(zout), ptr(bad), verdict.data_ptr(), 1.0, 0.03, 0.25, sp]
     for k in (4, 5, 6, 7, 8, 11, 12, 13):  # any required pointer missing
         a = list(args)
         a[k] = None
@@ -408,9 +412,10 @@ def test_new_entry_points_reject_bad_arguments_and_take_empty_scenes(dev):
     assert lib.fsgs_tile_zcut_update(*args) == 0
     torch.cuda.synchronize()
     inf = float("inf")
-    # tile 0: 2 + max(1.0 * (2 - 1), 0.03 * 2) = 3; tile 1 open -> inf (+ candidate: it was cut at 2.0); tile 2 empty
-    # under a cut: the cut is kept; tile 3: 4 + max(0, 0.12)
-    assert torch.allclose(zout.cpu(), torch.tensor([3.0, inf, 7.0, 4.12])), zout
+    # tile 0: 2 + max(1.0 * (2 - 1), 0.03 * 2) = 3 (one of its three entries lies behind the deepest composited one: more
+    # than the last quarter); tile 1 open -> inf (+ candidate: it was cut at 2.0); tile 2 empty under a cut: the cut is
+    # kept; tile 3 needed its whole list to saturate: no cut
+    assert torch.allclose(zout.cpu(), torch.tensor([3.0, inf, 7.0, inf])), zout
     assert cand.tolist() == [0, 1, 0, 0] and verdict[:2].tolist() == [2, 1]
     assert tile_open.tolist() == [0, 0, 0, 0] and int(bad) == 0
     # second look: Gaussian 0 sits in tile 1 in front of its cut, Gaussian 1 behind it -> invalid; without Gaussian 1 -> fine
