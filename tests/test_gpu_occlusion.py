@@ -444,3 +444,44 @@ def test_new_entry_points_reject_bad_arguments_and_take_empty_scenes(dev):
     assert lib.fsgs_gauss_sh_bwd_adam(*common, C.byref(g), 0.0, sp) == 0, "N = 0: nothing to do"
     assert lib.fsgs_gauss_sh_bwd_adam(*common, None, 0.0, sp) == EINVAL
     assert lib.fsgs_set_lazy_sh_min_n(lib.fsgs_set_lazy_sh_min_n(123)) == 123
+
+
+@pytest.mark.parametrize("margins", [(0.05, 0.0, 0.0), (0.3, 0.01, 0.1), (1.0, 0.03, 0.25)])
+def test_every_frame_is_exact_whatever_the_margins(dev, margins):
+    """Lockstep fuzz of the whole speculate / check / second look / redo machinery: a cutting trainer and a plain one
+    step through the same views with Adam on; before every frame the cutting trainer is given the plain one's parameters
+    and moments (the compositing backward's float atomics would otherwise let them drift apart), so both render the same
+    model — and whatever the margins do (tight ones make many cuts invalid: second looks, redone frames, widened
+    margins), every frame's images and loss must equal the plain trainer's to the bit."""
+    from fusionsense_amd import ops
+    from fusionsense_amd.splatfacto import DensifyStrategy, SplatfactoConfig
+    from fusionsense_amd.trainer import PARAM_ORDER, SplatTrainer
+    params = {k: v.to(dev) for k, v in scenes.lego_like_scene(400_000, seed=7).items()}
+    params["opacities"] = params["opacities"] + 1.0  # (denser: more tiles saturate)
+    cams = scenes.hemisphere_cameras(3, width=256, height=256, focal=355.0, seed=7)
+    g = torch.Generator().manual_seed(3)
+    tgts = [{"rgb": torch.rand(256, 256, 3, generator=g).to(dev), "depth": torch.rand(256, 256, 1, generator=g).to(dev) * 4,
+             "normal": torch.rand(256, 256, 3, generator=g).to(dev)} for _ in cams]
+
+    def make(mode):
+        st = DensifyStrategy(SplatfactoConfig(), num_train_data=3, stats_only=True)
+        tr = SplatTrainer(params, dev, sh_degree=3, strategy=st)
+        tr.occlusion_cut_mode = mode
+        tr.zcut_margins = margins
+        return tr
+    plain, cutting = make("0"), make("1")
+    looks0 = ops.zcut_rechecks
+    for it in range(24):
+        for k in PARAM_ORDER:  # same model in front of every frame
+            cutting._params[k].data.copy_(plain._params[k].data)
+            sp_, sc_ = plain.optimizers[k].state.get(plain._params[k]), cutting.optimizers[k].state.get(cutting._params[k])
+            if sp_ and sc_:
+                sc_["exp_avg"].copy_(sp_["exp_avg"]); sc_["exp_avg_sq"].copy_(sp_["exp_avg_sq"])
+        lp, op_ = plain.train_step(cams[it % 3], tgts[it % 3])
+        lc, oc_ = cutting.train_step(cams[it % 3], tgts[it % 3])
+        assert float(lp) == float(lc), it
+        for k in ("rgb", "depth", "normal", "accumulation"):
+            assert torch.equal(op_[k], oc_[k]), (it, k)
+    assert cutting.cut_frames == 21
+    if margins[0] < 0.1:
+        assert cutting.cut_redone + (ops.zcut_rechecks - looks0) > 0, "tight margins must have been caught"
