@@ -631,11 +631,16 @@ def main():
         b_iter = N * 352 + n_vis * 444 + M * (b_isect + b_isect_normal) + P * 92
         # dominant kernel = the libfsgs launch with the largest share of the step; algorithmic bytes
         # per launch from the per-unit figures of SURVEY.md §8d
+        # (frames binned with occlusion cuts hand the compositing kernels a depth prefix of the lists: their unit is then
+        # the pairs that were binned at all, not gsplat's rectangle count, which would price them at > 1 of the peak)
+        cuts_on = int(getattr(trainer, "cut_frames", 0)) > 0
+        M_r = n_live if cuts_on else M
+        r_note = " [unit: binned pairs — occlusion cuts]" if cuts_on else ""
         alg = {
-            "raster_bwd_quad_d4e3": ("raster_bwd_live_kernel<4,true,3> (RGB+ED and normal plane, one walk)",
-                                     M * (44 + 40) + P * (28 + 20) + n_vis * (48 + 28)),
-            "raster_fwd_quad_d4e3": ("raster_fwd_quad_kernel<4,3> (filter + gather + composite, RGB+ED and normal plane)",
-                                     M * (44 + 40) + P * (24 + 20)),
+            "raster_bwd_quad_d4e3": ("raster_bwd_live_kernel<4,true,3> (RGB+ED and normal plane, one walk)" + r_note,
+                                     M_r * (44 + 40) + P * (28 + 20) + n_vis * (48 + 28)),
+            "raster_fwd_quad_d4e3": ("raster_fwd_quad_kernel<4,3> (filter + gather + composite, RGB+ED and normal plane)" + r_note,
+                                     M_r * (44 + 40) + P * (24 + 20)),
             "raster_bwd_quad_d4": ("raster_bwd_live_kernel<4,true,0>", M * 44 + P * 28 + n_vis * 48),
             "raster_bwd_quad_d3": ("raster_bwd_live_kernel<3,false,0>", M * 40 + P * 20 + n_vis * 28),
             "raster_fwd_quad_d4": ("raster_fwd_quad_kernel<4,0>", M * 44 + P * 24),
