@@ -174,6 +174,17 @@ def cpu_baseline(args):
                 "sample": f"oracle child exceeded {args.cpu_timeout}s on {args.cpu_views} {args.cpu_crop}^2 crops"}
 
 
+def bwd_dispatch_choice(dev, W, H):
+    try:
+        from fusionsense_amd.fused import BWD_DISPATCH
+        st = BWD_DISPATCH.state.get((str(dev), W, H))
+        if not st or st["decided"] is None:
+            return None
+        return {"stride": int(st["decided"]), "medians_ms": {str(k): round(v, 4) for k, v in st.get("medians_ms", {}).items()}}
+    except Exception:
+        return None
+
+
 def never_updated_frac(trainer):
     try:
         p = trainer._params["opacities"]
@@ -748,6 +759,9 @@ def main():
             "iter_hbm_frac": round(b_iter / (elapsed / args.steps) / (HBM_PEAK_GBS * 1e9), 5),
             "device_mallocs_in_timed_region": n_alloc,
             "live_list_overflows": int(getattr(trainer, "live_overflows", 0)),  # frames redone (no-wait binning)
+            # dispatch order of the compositing backward as measured and chosen in this run (fused._BwdDispatchTuner):
+            # {"stride": 0 = row-major | k, "medians_ms": per candidate}; null while still measuring / when forced
+            "bwd_dispatch": bwd_dispatch_choice(dev, W, H),
             # steps whose Adam update was applied inside the per-Gaussian backward launch (no gradient slab, no Adam
             # launch: DESIGN.md §9.9; FSGS_ADAM_IN_BACKWARD=auto|1|0)
             "adam_in_backward_steps": int(getattr(trainer, "adam_in_backward_steps", 0)),

@@ -12,6 +12,8 @@
 // (common.h: 33 DPP adds instead of 60), the four rows meet through two lane permutes, and lanes
 // 0..14 issue ONE global_atomic_add_f32 into a packed 64-byte per-Gaussian record (one cache line),
 // instead of 15 single-lane atomics to six different arrays.
+#include <atomic>
+#include <cstdlib>
 #include <type_traits>
 
 #include "common.h"
@@ -80,13 +82,22 @@ raster_bwd_live_kernel(int64_t cap, const float4 *__restrict__ rec,
                        const float *__restrict__ v_alphas, const float *__restrict__ seg_state,
                        int64_t seg_cap, float *__restrict__ v_packed, int normalize_last,
                        const float *__restrict__ render_extra, const float *__restrict__ v_render_extra,
-                       const int32_t *__restrict__ n_rec, GetOutputsGrads ep, int64_t replica_rows, int merge_thr16) {
+                       const int32_t *__restrict__ n_rec, GetOutputsGrads ep, int64_t replica_rows, int merge_thr16,
+                       int perm_stride) {
     __shared__ QLds<E> Lw[kBwdWaves];
     constexpr int RS = E ? 4 : 3;
     constexpr int SS = 64 * (1 + D + E);
     const int cam = blockIdx.z;
-    const int tile_x = blockIdx.x >> 1, tile_y = blockIdx.y >> 1;
-    const int q = ((blockIdx.y & 1) << 1) | (blockIdx.x & 1);
+    // (perm_stride > 1: workgroups that are dispatched together take quadrants that lie `stride` apart instead of
+    // neighbours, so that their atomics land on different Gaussians' gradient lines: fsgs_set_bwd_dispatch_stride)
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (perm_stride > 1) {
+        const unsigned total = gridDim.x * gridDim.y;
+        const unsigned lin = (unsigned)(((unsigned long long)(blockIdx.y * gridDim.x + blockIdx.x) * (unsigned)perm_stride) % total);
+        by = lin / gridDim.x; bx = lin - by * gridDim.x;
+    }
+    const int tile_x = bx >> 1, tile_y = by >> 1;
+    const int q = ((by & 1) << 1) | (bx & 1);
     const int tile_lin = (cam * th + tile_y) * tw + tile_x;
     const int n_tiles_total = gridDim.z * th * tw;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -96,7 +107,7 @@ raster_bwd_live_kernel(int64_t cap, const float4 *__restrict__ rec,
     // blocks on average, so a 64-record segment costs max_r(n_r) ~ 45 steps instead of 64
     const int row = lane >> 4, pl = lane & 15;
     const int p = (((row >> 1) << 2) + (pl >> 2)) * 8 + ((row & 1) << 2) + (pl & 3);  // row-major in the quadrant
-    const int j = blockIdx.x * 8 + (p & 7), i = blockIdx.y * 8 + (p >> 3);
+    const int j = bx * 8 + (p & 7), i = by * 8 + (p >> 3);
     const float px = (float)j + 0.5f, py = (float)i + 0.5f;
     const bool inside = (i < H) && (j < W);
     const int64_t pix_id = ((int64_t)cam * H + min(i, H - 1)) * W + min(j, W - 1);
@@ -187,12 +198,12 @@ raster_bwd_live_kernel(int64_t cap, const float4 *__restrict__ rec,
     int row_bin_final[4];
 #pragma unroll
     for (int r4 = 0; r4 < 4; ++r4) row_bin_final[r4] = __builtin_amdgcn_readlane(rbf, 16 * r4);
-    const float quad_x0 = (float)(blockIdx.x * 8), quad_y0 = (float)(blockIdx.y * 8);
+    const float quad_x0 = (float)(bx * 8), quad_y0 = (float)(by * 8);
     // this workgroup's replica of a large Gaussian's gradient line (common.h: grad_spread); 0 rows = no replicas
     // (neighbouring tiles and the four 8x8 quadrants of a tile — one workgroup each — take different replicas)
     // (32-bit float offsets into v_packed: the launcher guarantees the accumulator stays below 2^32 bytes)
-    const uint32_t rep_off = (uint32_t)replica_rows * 16u * ((((unsigned)tile_lin * 2654435761u >> 16) + (blockIdx.x & 1) +
-                                                             2 * (blockIdx.y & 1)) % kGradReplicas);
+    const uint32_t rep_off = (uint32_t)replica_rows * 16u * ((((unsigned)tile_lin * 2654435761u >> 16) + (bx & 1) +
+                                                             2 * (by & 1)) % kGradReplicas);
 
     for (int seg = n_seg - 1 - w; seg >= 0; seg -= kBwdWaves) {
         const int b0 = s + (seg << 6);          // first stream position of the segment
@@ -393,6 +404,17 @@ using namespace fsgs;
 extern "C" int64_t fsgs_quad_stream_capacity(int C, int tile_width, int tile_height, int64_t n_isects);
 extern "C" int64_t fsgs_quad_seg_slots(int C, int tile_width, int tile_height, int64_t n_isects);
 
+// Dispatch order of the quadrants (0 / 1: row-major; k > 1: consecutive workgroups take quadrants k apart, made coprime
+// with the number of quadrants).  Neighbouring quadrants share their Gaussians: dispatched together they add to the same
+// gradient lines at the same time.  Measured (ms of the launch, row-major vs stride 7): config #2 0.181 / 0.168, config #4
+// 0.720 / 0.611, config #5 0.703 / 0.610 — and config #3 0.209 / 0.279 (there the lines of the large hull Gaussians stay
+// L2-resident under the row-major sweep).  Not decided here: the caller measures (fused.py tunes it per frame shape).
+static std::atomic<int> g_bwd_dispatch_stride{[] {
+    const char *e = getenv("FSGS_BWD_PERM");
+    return e ? atoi(e) : 0;
+}()};
+extern "C" int fsgs_set_bwd_dispatch_stride(int stride) { return g_bwd_dispatch_stride.exchange(stride < 0 ? 0 : stride); }
+
 static int launch_bwd_live(int C, int D, const float *records, const int32_t *n_rec,
                            int64_t cap, int64_t seg_cap, const int32_t *isect_offsets, int64_t n_isects,
                            const float *backgrounds, int width, int height, int tile_width, int tile_height,
@@ -419,11 +441,17 @@ static int launch_bwd_live(int C, int D, const float *records, const int32_t *n_
     hipStream_t s = as_stream(stream);
     const dim3 grid(2 * tile_width, 2 * tile_height, C);
     const float4 *rec = reinterpret_cast<const float4 *>(records);
+    int perm_stride = g_bwd_dispatch_stride.load(std::memory_order_relaxed);
+    if (perm_stride > 1) {  // coprime with the number of quadrants
+        const long long total = 4ll * tile_width * tile_height;
+        auto gcd = [](long long a, long long b) { while (b) { const long long t = a % b; a = b; b = t; } return a; };
+        while (gcd(perm_stride, total) != 1) ++perm_stride;
+    }
 #define FSGS_BWD_LIVE(DD, AA, EE)                                                                                \
     hipLaunchKernelGGL((raster_bwd_live_kernel<DD, AA, EE>), grid, dim3(64 * kBwdWaves), 0, s, cap, rec,          \
                        isect_offsets, n_isects, backgrounds, width, height, tile_width, tile_height, render,      \
                        alphas, last_ids, v_render, v_alphas, seg_state, seg_cap, v_packed, normalize_last,         \
-                       render_extra, v_render_extra, n_rec, ep, replica_rows, merge_thr16)
+                       render_extra, v_render_extra, n_rec, ep, replica_rows, merge_thr16, perm_stride)
     if (render_extra) {
         if (D != 4 || (!v_render_extra && !ep.v_rgb)) return FSGS_EINVAL;
         if (with_abs) FSGS_BWD_LIVE(4, true, 3); else FSGS_BWD_LIVE(4, false, 3);

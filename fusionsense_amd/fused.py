@@ -154,6 +154,62 @@ IMAGE_GRADS_IN_BWD = os.environ.get("FSGS_IMAGE_GRADS_IN_BWD", "1") != "0"
 KEPT_MIN_N = int(os.environ.get("FSGS_KEPT_MIN_N", str(1 << 20)))
 
 
+class _BwdDispatchTuner:
+    """Picks the dispatch order of the compositing backward per (device, frame shape) by measuring it
+    (fsgs_set_bwd_dispatch_stride): quadrants in row-major order, or consecutive workgroups a few quadrants apart.  Which
+    is faster is a property of the scene — config #2: 0.181 vs 0.168 ms, config #4: 0.720 vs 0.611, config #3: 0.209 vs
+    0.279 — so a few frames of each (assigned at random, not by view) are timed with HIP events and the faster kept
+    until the model's size has changed by a quarter.  FSGS_BWD_PERM=<k> fixes the stride, FSGS_BWD_PERM=0 the old order."""
+    CANDIDATES = (0, 7)
+    WARM, SAMPLES, MIN_GAIN = 2, 5, 0.03
+
+    def __init__(self):
+        self.state: Dict = {}
+        self.rng = __import__("random").Random(0)
+        self.forced = os.environ.get("FSGS_BWD_PERM", "auto") != "auto"
+
+    def launch(self, key, n: int, fn):
+        """Runs ``fn()`` (the launch) under the stride to use for this frame."""
+        if self.forced:
+            return fn()
+        lib = load()
+        st = self.state.get(key)
+        if st is None or (st["decided"] is not None and abs(n - st["n_ref"]) > 0.25 * st["n_ref"]):
+            st = self.state[key] = dict(n_ref=n, frames=0, samples={c: [] for c in self.CANDIDATES}, pending=[],
+                                        decided=None)
+        if st["decided"] is not None:
+            lib.fsgs_set_bwd_dispatch_stride(st["decided"])
+            return fn()
+        st["frames"] += 1
+        for item in list(st["pending"]):  # harvest finished measurements
+            stride, e0, e1 = item
+            if e1.query():
+                st["samples"][stride].append(e0.elapsed_time(e1))
+                st["pending"].remove(item)
+        if all(len(v) >= self.SAMPLES for v in st["samples"].values()):
+            med = {c: sorted(v)[len(v) // 2] for c, v in st["samples"].items()}
+            best = min(med, key=med.get)
+            st["decided"] = best if med[best] < (1.0 - self.MIN_GAIN) * med[self.CANDIDATES[0]] else self.CANDIDATES[0]
+            st["medians_ms"] = med
+            lib.fsgs_set_bwd_dispatch_stride(st["decided"])
+            return fn()
+        if st["frames"] <= self.WARM:
+            lib.fsgs_set_bwd_dispatch_stride(self.CANDIDATES[0])
+            return fn()
+        need = [c for c in self.CANDIDATES if len(st["samples"][c]) + sum(1 for p in st["pending"] if p[0] == c) < self.SAMPLES]
+        stride = self.rng.choice(need or list(self.CANDIDATES))
+        lib.fsgs_set_bwd_dispatch_stride(stride)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = fn()
+        e1.record()
+        st["pending"].append((stride, e0, e1))
+        return out
+
+
+BWD_DISPATCH = _BwdDispatchTuner()
+
+
 class _FusedGetOutputs(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means, scales, quats, features_dc, features_rest, opacities, cam, width, height,
@@ -368,11 +424,12 @@ class _FusedGetOutputs(torch.autograd.Function):
         if v_rgb is not None and IMAGE_GRADS_IN_BWD:
             # the image gradients go straight into the compositing backward, which derives v_render / v_alphas /
             # v_render_extra per pixel itself (no epilogue launch, no 32 B/pixel round trip)
-            _run(lib.fsgs_raster_bwd_quad_images, (ptr(records), ptr(n_rec), ptr(offsets), M, W, H, tw, th, ptr(render),
+            BWD_DISPATCH.launch((str(dev), W, H), N, lambda: _run(
+                lib.fsgs_raster_bwd_quad_images, (ptr(records), ptr(n_rec), ptr(offsets), M, W, H, tw, th, ptr(render),
                                                   ptr(alphas), ptr(last_ids), ptr(render_extra), ptr(background),
                                                   ptr(v_rgb), ptr(v_depth), ptr(v_normal), ptr(v_alpha_out),
                                                   ptr(seg_state), 1, ptr(v_packed), rep_rows, sp),
-                 "fsgs_raster_bwd_quad", "_d4e3")
+                "fsgs_raster_bwd_quad", "_d4e3"))
         else:
             v_render = torch.empty(1, H, W, 4, **f32)
             v_alphas = torch.empty(1, H, W, 1, **f32)

@@ -258,6 +258,13 @@ int fsgs_raster_bwd_quad(int C, int D, const float *records, const int32_t *n_re
                          const float *v_render, const float *v_alphas, const float *seg_state,
                          int with_abs, const float *render_extra, const float *v_render_extra,
                          float *v_packed, fsgs_stream_t stream);
+/* Dispatch order of the backward compositing launches that follow (fsgs_raster_bwd_quad, fsgs_raster_bwd_quad_images):
+ * 0 or 1 = quadrants in row-major order, k > 1 = consecutive workgroups take quadrants k apart (raised to the next value
+ * coprime with the number of quadrants).  Same gradients up to the order of the float atomics; which order is faster
+ * depends on the scene (neighbouring quadrants share Gaussians and collide on their gradient lines; far-apart ones lose
+ * the L2 residency of those lines), so callers measure.  Returns the previous value; initial value: env FSGS_BWD_PERM or 0. */
+int fsgs_set_bwd_dispatch_stride(int stride);
+
 /* fsgs_epilogue_bwd + fsgs_raster_bwd_quad for FusionSense's get_outputs (one camera; RGB + expected depth and the
  * normal plane in one walk): takes the gradients of the rgb / depth / normal images (and of the accumulation,
  * nullable) and derives v_render / v_alphas / v_render_extra per pixel inside the kernel

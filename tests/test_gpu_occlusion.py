@@ -485,3 +485,45 @@ def test_every_frame_is_exact_whatever_the_margins(dev, margins):
     assert cutting.cut_frames == 21
     if margins[0] < 0.1:
         assert cutting.cut_redone + (ops.zcut_rechecks - looks0) > 0, "tight margins must have been caught"
+
+
+def test_backward_dispatch_order_changes_nothing_but_the_speed(dev):
+    """fsgs_set_bwd_dispatch_stride: consecutive workgroups of the compositing backward take quadrants k apart instead of
+    neighbours.  Every quadrant is still processed exactly once (odd image sizes, strides that are not coprime with the
+    number of quadrants are raised to the next coprime), so the gradients agree to the float atomics' reordering; and the
+    trainer's tuner measures both orders and settles on one."""
+    from fusionsense_amd import fused
+    from fusionsense_amd._lib import load
+    from fusionsense_amd.trainer import PARAM_ORDER, SplatTrainer
+    lib = load()
+    params = {k: v.to(dev) for k, v in scenes.lego_like_scene(120_000, seed=4).items()}
+    cams = scenes.hemisphere_cameras(2, width=333, height=207, focal=420.0, seed=4)  # 42 x 26 quadrants, ragged edges
+    g = torch.Generator().manual_seed(4)
+    tgt = {"rgb": torch.rand(207, 333, 3, generator=g).to(dev), "depth": torch.rand(207, 333, 1, generator=g).to(dev) * 4,
+           "normal": torch.rand(207, 333, 3, generator=g).to(dev)}
+    tr = SplatTrainer(params, dev, sh_degree=3)
+    fused.BWD_DISPATCH.forced, keep = True, fused.BWD_DISPATCH.forced
+    prev = lib.fsgs_set_bwd_dispatch_stride(0)
+    try:
+        grads = {}
+        for stride in (0, 2, 7, 13, 1092):  # (2, 13 and 1092 = 42 * 26 share factors with the 1092 quadrants)
+            assert lib.fsgs_set_bwd_dispatch_stride(stride) is not None
+            tr.train_step(cams[0], tgt, optimizer_step=False)
+            grads[stride] = {k: tr.slab.views[k].clone() for k in PARAM_ORDER}
+        for stride in (2, 7, 13, 1092):
+            for k in PARAM_ORDER:
+                assert rel_err(grads[stride][k], grads[0][k]) < 2e-4, (stride, k)
+                assert torch.equal(grads[stride][k] == 0, grads[0][k] == 0), (stride, k)  # the same Gaussians are reached
+    finally:
+        lib.fsgs_set_bwd_dispatch_stride(prev)
+        fused.BWD_DISPATCH.forced = keep
+    # the tuner: a few frames of each order, then a decision that is kept
+    if not fused.BWD_DISPATCH.forced:
+        key = (str(dev), 333, 207)
+        fused.BWD_DISPATCH.state.pop(key, None)
+        for it in range(40):
+            tr.train_step(cams[it % 2], tgt)
+            torch.cuda.synchronize()
+        st = fused.BWD_DISPATCH.state[key]
+        assert st["decided"] in fused.BWD_DISPATCH.CANDIDATES and set(st["medians_ms"]) == set(fused.BWD_DISPATCH.CANDIDATES)
+        lib.fsgs_set_bwd_dispatch_stride(0)
