@@ -158,52 +158,60 @@ class _BwdDispatchTuner:
     """Picks the dispatch order of the compositing backward per (device, frame shape) by measuring it
     (fsgs_set_bwd_dispatch_stride): quadrants in row-major order, or consecutive workgroups a few quadrants apart.  Which
     is faster is a property of the scene — config #2: 0.181 vs 0.168 ms, config #4: 0.720 vs 0.611, config #3: 0.209 vs
-    0.279 — so a few frames of each (assigned at random, not by view) are timed with HIP events and the faster kept
-    until the model's size has changed by a quarter.  FSGS_BWD_PERM=<k> fixes the stride, FSGS_BWD_PERM=0 the old order."""
+    0.279 — so on a few early frames the launch is issued TWICE, once per order, on the same inputs (the second one into
+    a scratch accumulator that nobody reads; which order goes first alternates), both timed with HIP events; the faster
+    order is kept until the model's size has changed by a quarter.  FSGS_BWD_PERM=<k> fixes the stride (0: row-major)."""
     CANDIDATES = (0, 7)
-    WARM, SAMPLES, MIN_GAIN = 2, 5, 0.03
+    WARM, PAIRS, MIN_GAIN = 1, 4, 0.015
 
     def __init__(self):
         self.state: Dict = {}
-        self.rng = __import__("random").Random(0)
         self.forced = os.environ.get("FSGS_BWD_PERM", "auto") != "auto"
 
-    def launch(self, key, n: int, fn):
-        """Runs ``fn()`` (the launch) under the stride to use for this frame."""
+    def launch(self, key, n: int, acc: Tensor, fn):
+        """Runs ``fn(acc)`` — the launch, accumulating into ``acc`` — under the stride to use for this frame."""
         if self.forced:
-            return fn()
+            return fn(acc)
         lib = load()
         st = self.state.get(key)
         if st is None or (st["decided"] is not None and abs(n - st["n_ref"]) > 0.25 * st["n_ref"]):
-            st = self.state[key] = dict(n_ref=n, frames=0, samples={c: [] for c in self.CANDIDATES}, pending=[],
-                                        decided=None)
+            st = self.state[key] = dict(n_ref=n, frames=0, pending=[], total={c: 0.0 for c in self.CANDIDATES}, pairs=0,
+                                        decided=None, scratch=None)
         if st["decided"] is not None:
             lib.fsgs_set_bwd_dispatch_stride(st["decided"])
-            return fn()
+            return fn(acc)
         st["frames"] += 1
-        for item in list(st["pending"]):  # harvest finished measurements
-            stride, e0, e1 = item
-            if e1.query():
-                st["samples"][stride].append(e0.elapsed_time(e1))
+        for item in list(st["pending"]):  # harvest finished pairs
+            if item[-1].query():
+                (ca, a0, a1), (cb, b0, b1) = item[0], item[1]
+                st["total"][ca] += a0.elapsed_time(a1)
+                st["total"][cb] += b0.elapsed_time(b1)
+                st["pairs"] += 1
                 st["pending"].remove(item)
-        if all(len(v) >= self.SAMPLES for v in st["samples"].values()):
-            med = {c: sorted(v)[len(v) // 2] for c, v in st["samples"].items()}
-            best = min(med, key=med.get)
-            st["decided"] = best if med[best] < (1.0 - self.MIN_GAIN) * med[self.CANDIDATES[0]] else self.CANDIDATES[0]
-            st["medians_ms"] = med
+        if st["pairs"] >= self.PAIRS:
+            base, other = self.CANDIDATES
+            t = st["total"]
+            st["decided"] = other if t[other] < (1.0 - self.MIN_GAIN) * t[base] else base
+            st["medians_ms"] = {c: t[c] / st["pairs"] for c in self.CANDIDATES}  # (means of the paired launches)
+            st["scratch"] = None
             lib.fsgs_set_bwd_dispatch_stride(st["decided"])
-            return fn()
-        if st["frames"] <= self.WARM:
+            return fn(acc)
+        if st["frames"] <= self.WARM or st["pairs"] + len(st["pending"]) >= self.PAIRS:
             lib.fsgs_set_bwd_dispatch_stride(self.CANDIDATES[0])
-            return fn()
-        need = [c for c in self.CANDIDATES if len(st["samples"][c]) + sum(1 for p in st["pending"] if p[0] == c) < self.SAMPLES]
-        stride = self.rng.choice(need or list(self.CANDIDATES))
-        lib.fsgs_set_bwd_dispatch_stride(stride)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        out = fn()
-        e1.record()
-        st["pending"].append((stride, e0, e1))
+            return fn(acc)
+        if st["scratch"] is None or st["scratch"].shape != acc.shape:
+            st["scratch"] = torch.zeros_like(acc)
+        order = self.CANDIDATES if st["frames"] % 2 == 0 else self.CANDIDATES[::-1]
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        lib.fsgs_set_bwd_dispatch_stride(order[0])
+        ev[0].record()
+        out = fn(acc)
+        ev[1].record()
+        lib.fsgs_set_bwd_dispatch_stride(order[1])
+        ev[2].record()
+        fn(st["scratch"])  # (same inputs, the other order, results discarded)
+        ev[3].record()
+        st["pending"].append(((order[0], ev[0], ev[1]), (order[1], ev[2], ev[3]), ev[3]))
         return out
 
 
@@ -424,11 +432,11 @@ class _FusedGetOutputs(torch.autograd.Function):
         if v_rgb is not None and IMAGE_GRADS_IN_BWD:
             # the image gradients go straight into the compositing backward, which derives v_render / v_alphas /
             # v_render_extra per pixel itself (no epilogue launch, no 32 B/pixel round trip)
-            BWD_DISPATCH.launch((str(dev), W, H), N, lambda: _run(
+            BWD_DISPATCH.launch((str(dev), W, H), N, v_packed, lambda acc: _run(
                 lib.fsgs_raster_bwd_quad_images, (ptr(records), ptr(n_rec), ptr(offsets), M, W, H, tw, th, ptr(render),
                                                   ptr(alphas), ptr(last_ids), ptr(render_extra), ptr(background),
                                                   ptr(v_rgb), ptr(v_depth), ptr(v_normal), ptr(v_alpha_out),
-                                                  ptr(seg_state), 1, ptr(v_packed), rep_rows, sp),
+                                                  ptr(seg_state), 1, ptr(acc), rep_rows, sp),
                 "fsgs_raster_bwd_quad", "_d4e3"))
         else:
             v_render = torch.empty(1, H, W, 4, **f32)

@@ -526,4 +526,5 @@ def test_backward_dispatch_order_changes_nothing_but_the_speed(dev):
             torch.cuda.synchronize()
         st = fused.BWD_DISPATCH.state[key]
         assert st["decided"] in fused.BWD_DISPATCH.CANDIDATES and set(st["medians_ms"]) == set(fused.BWD_DISPATCH.CANDIDATES)
+        assert st["scratch"] is None and st["pairs"] >= fused.BWD_DISPATCH.PAIRS
         lib.fsgs_set_bwd_dispatch_stride(0)
