@@ -188,15 +188,17 @@ class _BwdDispatchTuner:
                 st["total"][cb] += b0.elapsed_time(b1)
                 st["pairs"] += 1
                 st["pending"].remove(item)
-        if st["pairs"] >= self.PAIRS:
-            base, other = self.CANDIDATES
-            t = st["total"]
+        base, other = self.CANDIDATES
+        t = st["total"]
+        # (a close call after the first pairs — within 4 % either way — gets as many pairs again before it is settled)
+        close = st["pairs"] >= self.PAIRS and 0.96 * t[base] < t[other] < 1.04 * t[base]
+        if st["pairs"] >= (2 * self.PAIRS if close else self.PAIRS):
             st["decided"] = other if t[other] < (1.0 - self.MIN_GAIN) * t[base] else base
             st["medians_ms"] = {c: t[c] / st["pairs"] for c in self.CANDIDATES}  # (means of the paired launches)
             st["scratch"] = None
             lib.fsgs_set_bwd_dispatch_stride(st["decided"])
             return fn(acc)
-        if st["frames"] <= self.WARM or st["pairs"] + len(st["pending"]) >= self.PAIRS:
+        if st["frames"] <= self.WARM or st["pairs"] + len(st["pending"]) >= (2 * self.PAIRS if close else self.PAIRS):
             lib.fsgs_set_bwd_dispatch_stride(self.CANDIDATES[0])
             return fn(acc)
         if st["scratch"] is None or st["scratch"].shape != acc.shape:
