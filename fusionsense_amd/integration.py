@@ -19,6 +19,7 @@ callbacks and its ``Optimizers`` (round 3):
     get_loss_dict      dn_model.py:673-925   -> ops._FusionLoss over a cached FrameBatch (one autograd node); the original
                                                 stays as ``_get_loss_dict_reference`` and is used for every switch the node
                                                 does not cover (normals from depth, cosine / sparse / SDF terms, other depth-loss types)
+    get_metrics_dict   dn_model.py:927-1003  -> the per-iteration PSNR / SSIM / depth metrics on the device, one transfer
     after_train        (nerfstudio, A.2)     -> nothing to do: the statistics were applied by the node's backward
     refinement_after   dn_model.py:326-451   -> DensifyStrategy.refinement_after (HIP row compaction, split sampling)
     add_touch_patch    dn_model.py:1156-1247 -> DensifyStrategy.add_touch_patch
@@ -192,6 +193,45 @@ def get_loss_dict_fused(self, outputs, batch, metrics_dict=None) -> Dict[str, to
     return {"main_loss": main_loss, "scale_reg": torch.zeros((), device=rgb.device)}
 
 
+def get_metrics_dict_fused(self, outputs, batch) -> Dict[str, object]:
+    """Drop-in for ``DNSplatterModel.get_metrics_dict`` (dn_model.py:927-1003), which nerfstudio's pipeline calls on
+    EVERY training iteration: rgb MSE / PSNR / SSIM11, the seven depth metrics against the sensor depth
+    (dn_splatter/metrics.py:109-145), the Gaussian count and ``avg_min_scale`` — PSNR / MSE as device reductions, SSIM
+    from the loss kernel's forward (fsgs_ssim_l1_fwd), and ONE device-to-host transfer for all of the floats instead of
+    thirteen ``.item()`` calls.  ``rgb_lpips`` needs the reference's pretrained network: the model's own
+    ``rgb_metrics.lpips`` module is called when it is there (as the reference does, on every step), NaN otherwise.
+    Falls back to the reference's method for down-scaled training images (``num_downscales`` > 0)."""
+    from .inference import depth_metrics, psnr, ssim_metric
+    rgb = outputs.get("rgb")
+    d = self._get_downscale_factor() if hasattr(self, "_get_downscale_factor") else 1
+    if not (torch.is_tensor(rgb) and rgb.is_cuda) or d > 1:
+        return self._get_metrics_dict_reference(outputs, batch)
+    dev = rgb.device
+    with torch.no_grad():
+        pred = rgb[0] if rgb.dim() == 4 else rgb
+        gt = batch["image"].to(dev)
+        if gt.dtype == torch.uint8:
+            gt = gt.float() / 255.0
+        gt = gt[..., :3].to(torch.float32)
+        vals = [torch.mean((gt - pred) ** 2), psnr(gt, pred), ssim_metric(gt.contiguous(), pred.contiguous())]
+        names = ["rgb_mse", "rgb_psnr", "rgb_ssim"]
+        lp = getattr(getattr(self, "rgb_metrics", None), "lpips", None)
+        if lp is not None:
+            vals.append(lp.to(dev)(pred.permute(2, 0, 1).unsqueeze(0), gt.permute(2, 0, 1).unsqueeze(0)).reshape(()))
+            names.append("rgb_lpips")
+        if getattr(self.config, "use_depth_loss", False) and "sensor_depth" in batch:
+            gd = batch["sensor_depth"].to(dev).to(torch.float32)
+            tol = float(getattr(getattr(self, "depth_metrics", None), "tolerance", 0.1))
+            vals += list(depth_metrics(outputs["depth"].permute(2, 0, 1), gd.permute(2, 0, 1), tol))
+            names += ["depth_abs_rel", "depth_sq_rel", "depth_rmse", "depth_rmse_log", "depth_a1", "depth_a2", "depth_a3"]
+        host = torch.stack([v.reshape(()).float() for v in vals]).tolist()  # the step's one transfer
+        md = dict(zip(names, host))
+        md.setdefault("rgb_lpips", float("nan"))
+        md["gaussian_count"] = self.gauss_params["means"].shape[0]
+        md["avg_min_scale"] = torch.nanmean(torch.exp(self.gauss_params["scales"][..., -1]))  # (a tensor there too)
+    return md
+
+
 class _NoSlab:
     def rebuild(self, params) -> None:
         pass
@@ -324,7 +364,8 @@ def patch_all(model_cls) -> None:
     patch(model_cls)
     if getattr(model_cls, "_fsgs_patched_all", False):
         return
-    for name, fn in (("get_loss_dict", get_loss_dict_fused), ("after_train", after_train_fused),
+    for name, fn in (("get_loss_dict", get_loss_dict_fused), ("get_metrics_dict", get_metrics_dict_fused),
+                     ("after_train", after_train_fused),
                      ("refinement_after", refinement_after_fused), ("add_touch_patch", add_touch_patch_fused),
                      ("hull_pruning", hull_pruning_fused), ("touch_pruning", touch_pruning_fused)):
         setattr(model_cls, f"_{name}_reference", getattr(model_cls, name, None))

@@ -53,6 +53,9 @@ def _model_cls():
         def get_loss_dict(self, outputs, batch, metrics_dict=None):
             raise AssertionError("reference get_loss_dict called")
 
+        def get_metrics_dict(self, outputs, batch):
+            raise AssertionError("reference get_metrics_dict called")
+
         def after_train(self, step):
             raise AssertionError("reference after_train called")
 
@@ -381,3 +384,51 @@ def test_patched_model_in_the_reference_loop_shape_trains_like_the_trainer(dev, 
         assert abs(float(a.double().abs().mean()) - float(b.double().abs().mean())) <= 2e-3 * float(b.double().abs().mean()) + 1e-6, k
     # the anchors never move, whatever happened around them
     assert torch.equal(m.gauss_params["means"].data[m.add_mask], tr.params["means"].data[st.add_mask])
+
+
+def test_patched_get_metrics_dict(dev):
+    """``model.get_metrics_dict(outputs, batch)`` after patch_all (dn_model.py:927-1003, called by nerfstudio's pipeline
+    on every training iteration): rgb MSE / PSNR / SSIM11 and the seven depth metrics against fp64 restatements of the
+    reference's formulas (torchmetrics PSNR, the SSIM of oracle/loss_ref, dn_splatter/metrics.py:109-145 — the latter
+    pinned to the reference's execution by tests/golden/reference_inference.npz), the Gaussian count and avg_min_scale;
+    Python floats like the reference's, from one transfer."""
+    from oracle import loss_ref
+    g = torch.Generator().manual_seed(5)
+    H, W, N = 72, 100, 500
+    params = {k: torch.zeros(N, *s_) for k, s_ in (("means", (3,)), ("quats", (4,)), ("features_dc", (3,)),
+                                                   ("features_rest", (15, 3)), ("opacities", (1,)))}
+    params["scales"] = torch.randn(N, 3, generator=g) * 0.5 - 4.0
+    m, _ = _model(dev, params)
+    out = {"rgb": torch.rand(H, W, 3, generator=g).to(dev), "depth": (0.3 + 2 * torch.rand(H, W, 1, generator=g)).to(dev),
+           "normal": torch.rand(H, W, 3, generator=g).to(dev)}
+    sensor = 0.3 + 2 * torch.rand(H, W, 1, generator=g)
+    sensor[torch.rand(H, W, 1, generator=g) < 0.2] = 0.0
+    batch = {"image": torch.rand(H, W, 3, generator=g).to(dev), "sensor_depth": sensor.to(dev)}
+    md = m.get_metrics_dict(out, batch)
+    assert all(isinstance(md[k], float) for k in md if k not in ("gaussian_count", "avg_min_scale"))
+    p, t = out["rgb"].double().cpu(), batch["image"].double().cpu()
+    mse = float(((p - t) ** 2).mean())
+    assert abs(md["rgb_mse"] - mse) < 1e-6 * mse and abs(md["rgb_psnr"] - 10 * np.log10(1.0 / mse)) < 1e-4
+    ssim = float(loss_ref.ssim_torchmetrics(p.permute(2, 0, 1), t.permute(2, 0, 1)))
+    assert abs(md["rgb_ssim"] - ssim) < 2e-5
+    assert np.isnan(md["rgb_lpips"]) and md["gaussian_count"] == N
+    gd, pd = sensor.double()[..., 0], out["depth"].double().cpu()[..., 0]
+    ok = gd > 0.1
+    gg, pp = gd[ok], pd[ok]
+    th = torch.max(gg / pp, pp / gg)
+    ref = {"depth_abs_rel": float(((gg - pp).abs() / gg).mean()), "depth_sq_rel": float(((gg - pp) ** 2 / gg).mean()),
+           "depth_rmse": float(((gg - pp) ** 2).mean().sqrt()), "depth_rmse_log": float((gg.log() - pp.log()).abs().mean()),
+           "depth_a1": float((th < 1.25).double().mean()), "depth_a2": float((th < 1.25 ** 2).double().mean()),
+           "depth_a3": float((th < 1.25 ** 3).double().mean())}
+    for k, v in ref.items():
+        assert abs(md[k] - v) < 1e-5 * max(1.0, abs(v)), (k, md[k], v)
+    ams = float(torch.exp(params["scales"][..., -1].double()).mean())
+    assert torch.is_tensor(md["avg_min_scale"]) and abs(float(md["avg_min_scale"]) - ams) < 1e-6 * ams
+    # the model's own LPIPS module is used when it is there (the reference evaluates it on every step as well)
+    m.rgb_metrics = types.SimpleNamespace(lpips=types.SimpleNamespace(to=lambda d: (lambda a, b: (a - b).abs().mean())))
+    md2 = m.get_metrics_dict(out, batch)
+    assert abs(md2["rgb_lpips"] - float((p - t).abs().mean())) < 1e-6
+    # down-scaled training images are the reference's own business
+    m._get_downscale_factor = lambda: 2
+    with pytest.raises(AssertionError, match="reference get_metrics_dict"):
+        m.get_metrics_dict(out, batch)
