@@ -98,8 +98,13 @@ def parse():
     ap.add_argument("--cpu-crop", type=int, default=280, help="CPU-baseline sample: central crop edge")
     ap.add_argument("--cpu-views", type=int, default=3)
     ap.add_argument("--cpu-timeout", type=float, default=200.0)
-    ap.add_argument("--cpu-threads", type=int, default=8)
+    ap.add_argument("--cpu-threads", type=int, default=0, help="CPU baseline: cap on the threads (0 = all host cores)")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--spawn-timeout", type=float, default=float(os.environ.get("FSGS_SPAWN_TIMEOUT", "900")),
+                    help="--gpus N without a launcher: seconds after which the ranks' process group is killed")
+    ap.add_argument("--scene", default=None, choices=["surface", "volume"],
+                    help="configs 4 / 5: 'surface' (default) = ground + objects seen from a ring outside the content; "
+                         "'volume' = the round-1 fog of Gaussians with the cameras inside it")
     a = ap.parse_args()
     d = DEFAULTS[a.config]
     a.steps = d["steps"] if a.steps is None else a.steps
@@ -152,26 +157,40 @@ def cpu_baseline_worker(n_gauss: int, res: int, crop: int, threads: int, n_views
 
 
 def cpu_baseline(args):
+    """The oracle on ALL of this box's host cores (``cores`` = the threads torch was given = the cores this process may
+    run on), and — a pure-PyTorch rasterizer does not scale far — the same sample on 8 threads beside it (one view)."""
     import subprocess
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    threads = max(1, min(avail, 8))
-    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", "--n-gauss", "300000",
-           "--res", "800", "--cpu-crop", str(args.cpu_crop), "--cpu-threads", str(threads),
-           "--cpu-views", str(args.cpu_views)]
-    env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads), HIP_VISIBLE_DEVICES="")
-    try:
-        r = subprocess.run(cmd, capture_output=True, text=True, timeout=args.cpu_timeout, env=env)
-        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-        if r.returncode == 0 and lines:
-            return json.loads(lines[-1])
-        return {"value": None, "unit": "iters/s", "cores": threads, "kind": "port",
-                "sample": f"oracle child failed rc={r.returncode}: {r.stderr[-200:]}"}
-    except subprocess.TimeoutExpired:
-        return {"value": None, "unit": "iters/s", "cores": threads, "kind": "port",
-                "sample": f"oracle child exceeded {args.cpu_timeout}s on {args.cpu_views} {args.cpu_crop}^2 crops"}
+    if args.cpu_threads and args.cpu_threads > 0:
+        avail = min(avail, args.cpu_threads)
+
+    def child(threads, views, timeout):
+        cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", "--n-gauss", "300000",
+               "--res", "800", "--cpu-crop", str(args.cpu_crop), "--cpu-threads", str(threads), "--cpu-views", str(views)]
+        env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads), HIP_VISIBLE_DEVICES="")
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
+            lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            if r.returncode == 0 and lines:
+                return json.loads(lines[-1])
+            return {"value": None, "unit": "iters/s", "cores": threads, "kind": "port",
+                    "sample": f"oracle child failed rc={r.returncode}: {r.stderr[-200:]}"}
+        except subprocess.TimeoutExpired:
+            return {"value": None, "unit": "iters/s", "cores": threads, "kind": "port",
+                    "sample": f"oracle child exceeded {timeout}s on {views} {args.cpu_crop}^2 crops with {threads} threads"}
+
+    out = child(avail, args.cpu_views, args.cpu_timeout)
+    out["host_cores_available"] = avail
+    if avail > 8:
+        eight = child(8, 1, args.cpu_timeout / 2)
+        out["eight_threads"] = {k: eight.get(k) for k in ("value", "unit", "cores", "sample")}
+        if out.get("value") is None and eight.get("value") is not None:
+            # (the all-core run did not finish: the 8-thread figure is the baseline, the failure stays in the record)
+            out = dict(eight, host_cores_available=avail, all_cores_attempt=out.get("sample"))
+    return out
 
 
 def bwd_dispatch_choice(dev, W, H):
@@ -192,6 +211,11 @@ def never_updated_frac(trainer):
         return round(float((v.reshape(-1) == 0).float().mean()), 4)
     except Exception:  # (no optimizer state yet)
         return None
+
+
+def trainer_last_alpha(trainer):
+    """The accumulation image of the trainer's last frame (kept by the side-measurement loop below)."""
+    return trainer._bench_last_out["accumulation"]
 
 
 def pmc_record(kernel_key, config):
@@ -280,24 +304,37 @@ def build_workload(args, dev):
                  params=params, start_step=args.start_step)
     else:
         W, H = 1920, 1080
-        cams = []
-        for i in range(args.views):
-            az = 2 * math.pi * i / args.views
-            eye = torch.tensor([2.4 * math.cos(az), 2.4 * math.sin(az), 0.9])
-            cams.append(scenes.Camera(scenes.look_at_c2w(eye, torch.tensor([0.0, 0.0, 0.0])), 1500.0, 1500.0, W / 2.0,
-                                      H / 2.0, W, H))
-        params = scenes.bicycle_like_scene(args.n_gauss, seed=0)
+        scene = args.scene or "surface"
+        if scene == "surface":
+            # round 4: Gaussians on surfaces (ground + boxes), cameras on a ring OUTSIDE the content — every surface faces
+            # some camera, pixels saturate on the first surfaces, what lies behind them is occluded (not empty)
+            kw = dict(kv.split("=") for kv in os.environ.get("FSGS_SCENE_PARAMS", "").split(",") if "=" in kv)
+            kw = {k: (int(v) if k == "n_objects" else float(v)) for k, v in kw.items()}
+            ring = {k: kw.pop(k) for k in ("radius", "height") if k in kw}
+            cams = scenes.ring_cameras(args.views, width=W, height_px=H, focal=1500.0, **ring)
+            make = lambda seed: scenes.surface_dense_scene(args.n_gauss, seed=seed, **kw)  # noqa: E731
+            what = "surface-bearing (ground disc + 600 boxes, discs lying in their surfaces, bimodal opacities, ring cameras outside)"
+        else:
+            cams = []
+            for i in range(args.views):
+                az = 2 * math.pi * i / args.views
+                eye = torch.tensor([2.4 * math.cos(az), 2.4 * math.sin(az), 0.9])
+                cams.append(scenes.Camera(scenes.look_at_c2w(eye, torch.tensor([0.0, 0.0, 0.0])), 1500.0, 1500.0, W / 2.0,
+                                          H / 2.0, W, H))
+            make = lambda seed: scenes.bicycle_like_scene(args.n_gauss, seed=seed)  # noqa: E731
+            what = "volume (round-1 recipe: a fog of small Gaussians with the cameras inside it)"
+        params = make(0)
         strategy = DensifyStrategy(SplatfactoConfig(), num_train_data=args.views, stats_only=True)
         half = args.config == 5
         trainer = SplatTrainer(params, dev, sh_degree=3, strategy=strategy, seed=0, fused=fused,
                                **({"half_attributes": True} if half else {}))
-        tgt = SplatTrainer(scenes.bicycle_like_scene(args.n_gauss, seed=1), dev, sh_degree=3, fused=fused)
+        tgt = SplatTrainer(make(1), dev, sh_degree=3, fused=fused)
         targets = [{k: t[k] for k in ("rgb", "depth", "normal")} for t in render_targets(tgt, cams)]
         name = ("BASELINE config #4: synthetic bicycle-like" if not half else
                 "BASELINE config #5: fp16 attribute storage (features, scales, quats, opacities; fp32 means, fp32 master + "
                 "Adam), synthetic bicycle-like")
-        w.update(name=f"{name}, {args.n_gauss} Gaussians, {W}x{H}, SH deg 3, {args.views} views, benchmark loss, "
-                      "fwd+bwd+Adam+densify stats", params=params)
+        w.update(name=f"{name}, scene = {what}, {args.n_gauss} Gaussians, {W}x{H}, SH deg 3, {args.views} views, "
+                      "benchmark loss, fwd+bwd+Adam+densify stats", params=params, scene=scene)
     try:
         del tgt
     except NameError:
@@ -307,15 +344,47 @@ def build_workload(args, dev):
     return w
 
 
+def visible_gpu_count() -> int:
+    """GPUs this process may use, counted WITHOUT touching the HIP runtime (the parent of the ranks must never
+    initialise the GPU): the KFD topology's nodes with SIMDs, narrowed by HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES /
+    CUDA_VISIBLE_DEVICES when set.  Falls back to torch.cuda.device_count() (which does not create a context on this
+    image) only where the topology is unreadable."""
+    n = None
+    try:
+        base = "/sys/class/kfd/kfd/topology/nodes"
+        n = 0
+        for node in os.listdir(base):
+            with open(os.path.join(base, node, "properties")) as f:
+                props = dict(ln.split()[:2] for ln in f if len(ln.split()) >= 2)
+            if int(props.get("simd_count", "0")) > 0:
+                n += 1
+    except (OSError, ValueError):
+        n = None
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            listed = len([x for x in v.split(",") if x.strip() != ""])
+            n = listed if n is None else min(n, listed)
+    if n is None:
+        n = torch.cuda.device_count()
+    return n
+
+
 def spawn_ranks(args) -> int:
     """``--gpus N`` (N > 1) WITHOUT a launcher: start the N ranks as a CHILD ``python -m torch.distributed.run`` (one
-    process per GPU, 127.0.0.1 rendezvous on a free port) BEFORE this process has made any GPU call, relay rank 0's JSON
-    line and return the child's exit code.  Nothing is re-executed in place (a process that has initialised the GPU must
-    never exec), and a failed attempt is a non-zero exit, never a silent one-rank run (the reference's hook for the
-    multi-GPU path: /root/reference/dn_splatter/dn_pipeline.py:162-167)."""
+    process per GPU, 127.0.0.1 rendezvous on a free port) in a session of its own, BEFORE this process has made any GPU
+    call, relay rank 0's JSON line and return the child's exit code.  Nothing is re-executed in place (a process that has
+    initialised the GPU must never exec), and a failed attempt is a non-zero exit, never a silent one-rank run (the
+    reference's hook for the multi-GPU path: /root/reference/dn_splatter/dn_pipeline.py:162-167).
+    Watchdog: after ``--spawn-timeout`` seconds (default 900, well under the driver's limit) the child's whole process
+    group is killed, the tail of what the ranks printed is shown and the exit code is 124 — a hung rendezvous or
+    collective must not hold the GPUs until someone else's clock runs out."""
+    import collections
+    import signal
     import socket
     import subprocess
-    n_dev = torch.cuda.device_count()  # (counting devices does not initialise the GPU on this image)
+    import threading
+    n_dev = visible_gpu_count()
     backend = os.environ.get("FSGS_DIST_BACKEND", "nccl")
     if backend == "nccl" and n_dev < args.gpus:
         print(f"bench.py: --gpus {args.gpus} over RCCL needs {args.gpus} visible GPUs, found {n_dev} "
@@ -331,19 +400,43 @@ def spawn_ranks(args) -> int:
     env = dict(os.environ, FSGS_BENCH_SPAWNED="1")
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # (dmabuf IPC: what RCCL needs on this driver)
     env.setdefault("OMP_NUM_THREADS", "1")
-    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, cwd=ROOT)
-    lines = []
-    for ln in p.stdout:
-        if ln.startswith("{"):
-            lines.append(ln.rstrip("\n"))
-        else:
-            sys.stderr.write(ln)
-    rc = p.wait()
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, cwd=ROOT,
+                         start_new_session=True)  # (its own process group: the ranks can be reaped together)
+    lines, tail = [], collections.deque(maxlen=60)
+
+    def pump():
+        for ln in p.stdout:
+            if ln.startswith("{"):
+                lines.append(ln.rstrip("\n"))
+            else:
+                tail.append(ln)
+                sys.stderr.write(ln)
+    t = threading.Thread(target=pump, daemon=True)
+    t.start()
+    try:
+        rc = p.wait(timeout=args.spawn_timeout)
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(p.pid, signal.SIGTERM)
+            try:
+                p.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                os.killpg(p.pid, signal.SIGKILL)
+                p.wait(timeout=10)
+        except (ProcessLookupError, subprocess.TimeoutExpired):
+            pass
+        t.join(timeout=5)
+        print(f"bench.py: the {args.gpus} ranks did not finish within --spawn-timeout {args.spawn_timeout:.0f} s: their "
+              f"process group was killed.  Last output of the ranks:\n{''.join(tail)}", file=sys.stderr)
+        return 124
+    t.join(timeout=10)
     if rc == 0 and len(lines) != 1:
         print(f"bench.py: expected one JSON line from rank 0, got {len(lines)}", file=sys.stderr)
         rc = 3
     if rc == 0:
         print(lines[0], flush=True)
+    elif tail:
+        print(f"bench.py: the ranks exited with code {rc}", file=sys.stderr)
     return rc
 
 
@@ -371,6 +464,9 @@ def main():
         print(f"bench.py: WORLD_SIZE {world} != --gpus {args.gpus}: refusing to measure a different job than the one "
               "asked for", file=sys.stderr)
         sys.exit(2)
+    if os.environ.get("FSGS_BENCH_TEST_HANG") == "1":  # (test hook: a rank that never reaches the rendezvous)
+        print(f"rank {rank}: hanging for the watchdog test", file=sys.stderr, flush=True)
+        time.sleep(3600)
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
     # FSGS_DIST_BACKEND=gloo: functional check of the multi-rank path on a box with fewer GPUs than ranks (the ranks
     # then share devices and the collectives are staged through the host); the default is RCCL, one GPU per rank
@@ -471,6 +567,8 @@ def main():
     if args.config == 3:
         strategy.before_train = timed_cb("before_train")
         strategy.maybe_refine = timed_cb("maybe_refine")
+    if grouped:
+        trainer.comm_events = []  # HIP-event pairs around every collective / wait of the timed steps (trainer._comm)
     torch.cuda.synchronize()
     n_alloc0 = torch.cuda.memory_stats(dev).get('num_device_alloc', 0)
     n_before = trainer.num_gaussians()
@@ -491,6 +589,7 @@ def main():
         step_ends.append(time.perf_counter())
     trainer.flush()  # (data-parallel runs: the last step's deferred feature update belongs to the timed work)
     torch.cuda.synchronize()
+    own_elapsed = time.perf_counter() - t0  # (this rank's own clock, before it waits for the others)
     barrier()
     elapsed = time.perf_counter() - t0
     gc.enable()
@@ -513,7 +612,28 @@ def main():
     n_alloc = torch.cuda.memory_stats(dev).get('num_device_alloc', 0) - n_alloc0
     log(f'timed region done: {elapsed:.3f}s')
     ops.TIMER.reset(enabled=False)
+    rank_stats = None
     if grouped:
+        # per-rank step time and EXPOSED communication (time the step's stream spent inside / blocked by a collective:
+        # what the deferred exchange did not hide), gathered so that a scaling curve can be read from the line
+        comm_ms = sum(a.elapsed_time(b) for _, a, b in (trainer.comm_events or [])) / max(args.steps, 1)
+        trainer.comm_events = None
+        gs = gpu_step_stats(step_events, step_views) if with_events else None
+        mine = torch.tensor([own_elapsed / args.steps * 1e3, comm_ms, gs["p50"] if gs else float("nan")],
+                            dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        got = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(got, mine)
+        per = [g.cpu().tolist() for g in got]
+        sm, cm, gm = sorted(x[0] for x in per), sorted(x[1] for x in per), sorted(x[2] for x in per)
+        rank_stats = {"step_ms_per_rank": {"min": round(sm[0], 4), "median": round(sm[len(sm) // 2], 4),
+                                           "max": round(sm[-1], 4),
+                                           "gpu_p50_min_median_max": [round(gm[0], 4), round(gm[len(gm) // 2], 4),
+                                                                      round(gm[-1], 4)]},
+                      "comm_ms_exposed": {"min": round(cm[0], 4), "median": round(cm[len(cm) // 2], 4),
+                                          "max": round(cm[-1], 4),
+                                          "note": "per step and rank: HIP-event time of the step's stream inside or "
+                                                  "blocked by collectives (reduce / reduce-scatter / all-gather and the "
+                                                  "wait for the deferred feature exchange)"}}
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
@@ -524,7 +644,7 @@ def main():
     ops.TIMER.reset(enabled=True)
     for s in range(side_steps):
         v = view_of(s)
-        trainer.train_step(cams[v], targets[v])
+        _, trainer._bench_last_out = trainer.train_step(cams[v], targets[v])
     torch.cuda.synchronize()
     kernel_ms_all = ops.TIMER.summary()
     ops.TIMER.reset(enabled=False)
@@ -538,6 +658,18 @@ def main():
     n_live = int(info["flatten_ids"].numel())
     n_vis = int((info["radii"] > 0).sum().item())
     P = W * H
+    # L: entries of its tile's sorted live list a pixel walks up to and including the last one it
+    # composites (last_ids - the tile's list start + 1; 0 for pixels nothing reached), mean over the frame's pixels
+    with torch.no_grad():
+        li = info["last_ids"].reshape(H, W).long()
+        offs = info["isect_offsets"].reshape(-1)[: ((H + 15) // 16) * ((W + 15) // 16)].long()
+        ty = torch.arange(H, device=dev) // 16
+        tx = torch.arange(W, device=dev) // 16
+        start = offs[(ty[:, None] * ((W + 15) // 16) + tx[None, :])]
+        acc_img = trainer_last_alpha(trainer)
+        walked = torch.where(acc_img.reshape(H, W) > 0, li - start + 1, torch.zeros_like(li)).clamp_min(0)
+        mean_walked = float(walked.float().mean())
+        max_walked = int(walked.max())
     side_n = min(args.steps, 50)
     torch.cuda.synchronize()
     t1 = time.perf_counter()
@@ -575,6 +707,7 @@ def main():
         torch.cuda.synchronize()
         for k_ in rendering.HOST_TIME:
             rendering.HOST_TIME[k_] = 0
+        rendering.MEASURE_HOST_TIME = True  # (clock reads inside the two calls only for this side measurement)
         ops.TIMER.reset(enabled=True)
         t3 = time.perf_counter()
         nd = 30
@@ -585,6 +718,7 @@ def main():
         d_k = ops.TIMER.summary()
         ops.TIMER.reset(enabled=False)
         ht = rendering.HOST_TIME
+        rendering.MEASURE_HOST_TIME = False
         # library side of the drop-in route per step: host time inside rasterization() + rasterize_gaussians()
         # (forward calls; includes the one wait for the live-pair count) against the GPU time of the library's kernels
         dropin_detail = {
@@ -639,13 +773,14 @@ def main():
         b_isect = 12 + sort_b + 8 + 44 + 44
         reused = fused or (frame_cache.hits > 0 and frame_cache.misses == 0)
         b_isect_normal = (40 + 40) if reused else (12 + sort_b + 8 + 40 + 40)
-        b_iter = N * 352 + n_vis * 444 + M * (b_isect + b_isect_normal) + P * 92
+        b_iter_rect = N * 352 + n_vis * 444 + M * (b_isect + b_isect_normal) + P * 92
         # dominant kernel = the libfsgs launch with the largest share of the step; algorithmic bytes
         # per launch from the per-unit figures of SURVEY.md §8d
         # (frames binned with occlusion cuts hand the compositing kernels a depth prefix of the lists: their unit is then
         # the pairs that were binned at all, not gsplat's rectangle count, which would price them at > 1 of the peak)
         cuts_on = int(getattr(trainer, "cut_frames", 0)) > 0
         M_r = n_live if cuts_on else M
+        b_iter = N * 352 + n_vis * 444 + M_r * (b_isect + b_isect_normal) + P * 92
         r_note = " [unit: binned pairs — occlusion cuts]" if cuts_on else ""
         alg = {
             "raster_bwd_quad_d4e3": ("raster_bwd_live_kernel<4,true,3> (RGB+ED and normal plane, one walk)" + r_note,
@@ -658,7 +793,12 @@ def main():
             "raster_fwd_quad_d3": ("raster_fwd_quad_kernel<3,0>", M * 40 + P * 20),
             "raster_bwd_d4": ("raster_bwd_kernel<4,true>", M * 44 + P * 28 + n_vis * 48),
             "sort_pairs": ("radix sort (hist + scan + scatter per 8-bit pass)", M * sort_b),
-            "tile_sort": ("partition by tile + per-tile LDS sort", M * sort_b),
+            # bucket fill + in-tile sorts (direct binning): per LIVE pair the fill pass writes one 8-byte word into its
+            # tile's bucket, the sort reads it once and writes the 4-byte payload (the word never leaves LDS / registers
+            # in between); both enumeration passes read 28 B per Gaussian (centre, radius, conic, opacity, depth)
+            "tile_sort": ("isect_live_bin<fill> + tile_sort_kernel2 (bucket fill + per-tile LDS sort), priced on what "
+                          "it moves: 8 B written + 8 B read + 4 B written per live pair, 28 B per Gaussian",
+                          n_live * 20 + N * 28),
             "adam_step": ("adam_kernel (six parameter groups, one launch)", N * 59 * 28),
         }
         riding = bool(getattr(trainer, "_ride_mode", lambda: False)())
@@ -740,6 +880,11 @@ def main():
                        "width": W, "height": H, "views": len(cams),
                        "n_isects": M, "n_isects_live": n_live, "n_visible": n_vis,
                        "isects_per_gaussian": round(M / max(N, 1), 3),
+                       # L of SURVEY.md §8d: list entries a pixel walks up to its last composited one (frame mean / max)
+                       "mean_walked_list": round(mean_walked, 2), "max_walked_list": max_walked,
+                       # live (binned) pairs over gsplat's rectangle pairs: reach test + (dense scenes) occlusion cuts
+                       "binned_over_rect_pairs": round(n_live / max(M, 1), 4),
+                       "scene": wl.get("scene"),
                        "normal_pass_list_reuse": bool(reused), "parallelism": f"dp{world}",
                        "backend": (backend if grouped else None),
                        "world_size": world, "ranks_seen": seen, "rank_devices": devices,
@@ -756,7 +901,10 @@ def main():
             "patched_full_iters_per_s": None if dropin is None else dropin_detail.get("patched_full_iters_per_s"),
             "render_tolerance": RENDER_TOLERANCE,
             "iter_algorithmic_bytes": b_iter,
+            # (frames binned with occlusion cuts: priced on the pairs that were binned — the work the step does — so
+            # that the fraction stays a fraction; the §8d figure on gsplat's rectangle pairs is kept beside it)
             "iter_hbm_frac": round(b_iter / (elapsed / args.steps) / (HBM_PEAK_GBS * 1e9), 5),
+            "iter_algorithmic_bytes_rect_pairs": b_iter_rect,
             "device_mallocs_in_timed_region": n_alloc,
             "live_list_overflows": int(getattr(trainer, "live_overflows", 0)),  # frames redone (no-wait binning)
             # dispatch order of the compositing backward as measured and chosen in this run (fused._BwdDispatchTuner):
@@ -783,6 +931,8 @@ def main():
             "roofline": roofline,
             "roofline_top3": roofline_top3,
         }
+        if rank_stats is not None:
+            line.update(rank_stats)
         if args.config == 3:
             line["config"]["refinement"] = dict(strategy.last_report)
             line["config"]["touch_anchors"] = int(strategy.add_mask.sum()) if strategy.add_mask is not None else 0

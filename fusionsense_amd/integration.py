@@ -156,14 +156,151 @@ def _loss_config(cfg):
                       touch_normal_loss_lambda=1.0)
 
 
+class SupervisionCache:
+    """Prepared supervision (``losses.FrameBatch``) of the views ``get_loss_dict`` has seen, resident on the device.
+
+    The reference rebuilds its ground truth from the batch on every call (dn_model.py:683-735); its datamanager hands
+    out a ``deepcopy`` of ``cached_train[image_idx]`` / ``cached_eval[image_idx]`` each time (dn_datamanager.py:103,
+    161), i.e. the same DATA under new tensors.  So an entry is keyed on **(split, image_idx)** — nerfstudio's pipeline
+    also calls ``get_loss_dict`` with EVAL batches (``get_eval_loss_dict``), whose indices count the eval dataset and
+    would otherwise collide with the train view of the same number — and a hit is verified:
+
+    * shapes and dtypes of every supervision tensor must match the entry's;
+    * the very tensors the entry was prepared from (same ``data_ptr`` and version) are a hit at once;
+    * otherwise a sampled fingerprint of the batch (every 16th pixel of each tensor, summed on the device) is compared
+      with the entry's ON THE DEVICE — no host wait in the step — and the flag is read when the next call finds it
+      finished: a batch that carried other data under a cached key raises ``RuntimeError`` there (loudly, one call
+      late) and the entry is dropped.  ``FSGS_FRAME_CACHE_VERIFY=1`` compares in full and synchronously (tests).
+
+    A batch without ``image_idx`` is prepared uncached.  Least recently used entries leave once the cache holds more
+    than ``FSGS_FRAME_CACHE_MB`` (default 8192; ~36 B per pixel and view).  ``FSGS_FRAME_CACHE=0`` disables caching."""
+    KEYS = ("image", "sensor_depth", "mono_depth", "normal", "mask")
+
+    def __init__(self, budget_bytes=None):
+        import os
+        from collections import OrderedDict
+        self.entries = OrderedDict()
+        self.enabled = os.environ.get("FSGS_FRAME_CACHE", "1") != "0"
+        self.verify_full = os.environ.get("FSGS_FRAME_CACHE_VERIFY", "0") == "1"
+        self.budget = int(float(os.environ.get("FSGS_FRAME_CACHE_MB", "8192")) * (1 << 20)) if budget_bytes is None \
+            else int(budget_bytes)
+        self.bytes = 0
+        self.hits = self.misses = self.evictions = 0
+        self._checks = []  # (key, device flag, event) of fingerprint comparisons not read yet
+
+    def __len__(self):
+        return len(self.entries)
+
+    @staticmethod
+    def _signature(batch):
+        return tuple((k, tuple(batch[k].shape), batch[k].dtype) for k in SupervisionCache.KEYS if k in batch)
+
+    @staticmethod
+    def _identity(batch):
+        return tuple((batch[k].data_ptr(), batch[k]._version) for k in SupervisionCache.KEYS if k in batch)
+
+    @staticmethod
+    def _fingerprint(batch, device):
+        parts = []
+        for k in SupervisionCache.KEYS:
+            if k in batch:
+                t = batch[k].to(device)
+                t = t.reshape(t.shape[0], t.shape[1], -1)[::16, ::16]
+                parts.append(t.to(torch.float64).sum())
+                parts.append((t.to(torch.float64) * t.to(torch.float64)).sum())
+        return torch.stack(parts)
+
+    @staticmethod
+    def _nbytes(fb):
+        n = 0
+        for t in (fb.image, fb.sensor_depth, fb.normal, fb.mask, fb.mono_depth):
+            if torch.is_tensor(t):
+                n += t.numel() * t.element_size()
+        return n
+
+    def _harvest(self, block=False):
+        keep = []
+        for key, flag, ev in self._checks:
+            if block or ev is None or ev.query():
+                if bool(flag.item()):
+                    self._drop(key)
+                    self._checks = [c for c in self._checks if c[0] != key]
+                    raise RuntimeError(
+                        f"get_loss_dict: the batch of {'train' if key[0] else 'eval'} image_idx {key[1]} carried other "
+                        "data than the supervision cached for that view (SupervisionCache; the entry has been dropped — "
+                        "FSGS_FRAME_CACHE=0 prepares every batch afresh)")
+            else:
+                keep.append((key, flag, ev))
+        self._checks = keep
+
+    def _drop(self, key):
+        e = self.entries.pop(key, None)
+        if e is not None:
+            self.bytes -= e["bytes"]
+
+    def clear(self):
+        self.entries.clear()
+        self._checks = []
+        self.bytes = 0
+
+    def get(self, training, batch, cfg, device, height, width):
+        from .losses import prepare_batch
+        sub = {k: batch[k] for k in self.KEYS if k in batch}
+        if not self.enabled or "image_idx" not in batch:
+            return prepare_batch(sub, cfg, device)
+        self._harvest()
+        key = (bool(training), int(batch["image_idx"]))
+        sig = self._signature(sub)
+        e = self.entries.get(key)
+        if e is not None and (e["sig"] != sig or e["fb"].height != height or e["fb"].width != width
+                              or e["tol"] != float(cfg.depth_tolerance)):
+            self._drop(key)
+            e = None
+        if e is not None:
+            ident = self._identity(sub)
+            if ident != e["ident"]:
+                if self.verify_full:
+                    fresh = prepare_batch(sub, cfg, device)
+                    same = all((a is None and b is None) or (a is not None and b is not None and torch.equal(a, b))
+                               for a, b in ((fresh.image, e["fb"].image), (fresh.sensor_depth, e["fb"].sensor_depth),
+                                            (fresh.normal, e["fb"].normal), (fresh.mask, e["fb"].mask),
+                                            (fresh.mono_depth, e["fb"].mono_depth)))
+                    if not same:
+                        self._drop(key)
+                        raise RuntimeError(f"get_loss_dict: batch of {'train' if key[0] else 'eval'} image_idx {key[1]} "
+                                           "differs from the cached supervision of that view")
+                else:
+                    flag = (self._fingerprint(sub, device) != e["fp"]).any()
+                    ev = None
+                    if flag.is_cuda:
+                        ev = torch.cuda.Event()
+                        ev.record()
+                    self._checks.append((key, flag, ev))
+            self.entries.move_to_end(key)
+            self.hits += 1
+            return e["fb"]
+        fb = prepare_batch(sub, cfg, device)
+        nb = self._nbytes(fb)
+        self.misses += 1
+        if nb <= self.budget:
+            self.entries[key] = dict(fb=fb, sig=sig, ident=self._identity(sub), fp=self._fingerprint(sub, device), bytes=nb,
+                                     tol=float(cfg.depth_tolerance))
+            self.bytes += nb
+            while self.bytes > self.budget and len(self.entries) > 1:
+                old = next(iter(self.entries))
+                self._drop(old)
+                self.evictions += 1
+        return fb
+
+
 def get_loss_dict_fused(self, outputs, batch, metrics_dict=None) -> Dict[str, torch.Tensor]:
     """Drop-in for ``DNSplatterModel.get_loss_dict`` (dn_model.py:673-925): ``main_loss`` is one HIP autograd node over
-    the view's supervision, prepared once per ``image_idx`` and kept on the device (``self._fsgs_frames``).  What the
+    the view's supervision, prepared once per (split, ``image_idx``) and kept on the device (``self._fsgs_frames``, a
+    :class:`SupervisionCache`: train and eval batches never share an entry, hits are verified, bounded).  What the
     node does not cover goes to the reference's own method.  Not reproduced: the ``log_images/<step>.jpg`` debug dump of
     every 100th step (:903-921) and the in-place masking of ``outputs["normal"]`` / ``batch["normal"]`` (:712-715),
     which nothing reads after the loss."""
     from . import ops
-    from .losses import prepare_batch
     cfg = _loss_config(self.config)
     rgb = outputs.get("rgb")
     covered = (cfg is not None and torch.is_tensor(rgb) and rgb.is_cuda and "normal" in outputs and "depth" in outputs
@@ -171,13 +308,10 @@ def get_loss_dict_fused(self, outputs, batch, metrics_dict=None) -> Dict[str, to
                and int(getattr(self.config, "num_downscales", 0)) == 0)
     if not covered:
         return self._get_loss_dict_reference(outputs, batch, metrics_dict)
-    frames = self.__dict__.setdefault("_fsgs_frames", {})
-    key = int(batch["image_idx"]) if "image_idx" in batch else id(batch["image"])
-    fb = frames.get(key)
-    if fb is None or fb.height != rgb.shape[0] or fb.width != rgb.shape[1]:
-        fb = frames[key] = prepare_batch({k: batch[k] for k in ("image", "sensor_depth", "mono_depth", "normal", "mask")
-                                          if k in batch},
-                                         cfg, rgb.device)
+    frames = self.__dict__.get("_fsgs_frames")
+    if frames is None:
+        frames = self.__dict__["_fsgs_frames"] = SupervisionCache()
+    fb = frames.get(bool(self.training), batch, cfg, rgb.device, rgb.shape[0], rgb.shape[1])
     touch_idx = touch_normals = None
     add_mask = getattr(self, "add_mask", None)
     if add_mask is not None:

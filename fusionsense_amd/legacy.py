@@ -69,9 +69,10 @@ def rasterize_gaussians(
     trunc/+1 rule, which overflows when ``mean + radius`` is an exact multiple of the tile
     size; here the legacy rule is used for both count and fill, so ``num_tiles_hit`` is only
     shape-checked.  Ties in (tile, depth) are kept in ascending Gaussian order (stable)."""
-    import time as _time
-    from .rendering import HOST_TIME
-    _t0 = _time.perf_counter()
+    from . import rendering as _rendering
+    if _rendering.MEASURE_HOST_TIME:
+        import time as _time
+        _t0 = _time.perf_counter()
     if not (1 < block_width <= 16):
         raise AssertionError("block_width must be between 2 and 16")
     if colors.dtype == torch.uint8:
@@ -122,8 +123,9 @@ def rasterize_gaussians(
         xys[None], conics[None], cols[None], opacity.reshape(1, N), bg[None], offsets, flatten_ids,
         int(img_width), int(img_height), int(block_width), False, isect_ids, False, live_payload, on_dev)
     out = out[0, ..., :ch]
-    HOST_TIME["rasterize_gaussians_s"] += _time.perf_counter() - _t0
-    HOST_TIME["rasterize_gaussians_calls"] += 1
+    if _rendering.MEASURE_HOST_TIME:
+        _rendering.HOST_TIME["rasterize_gaussians_s"] += _time.perf_counter() - _t0
+        _rendering.HOST_TIME["rasterize_gaussians_calls"] += 1
     if return_alpha:
         return out, alpha[0, ..., 0]
     return out

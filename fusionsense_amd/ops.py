@@ -447,7 +447,8 @@ def zcut_verdict_buffer(dev) -> Tensor:
     return buf
 
 
-_ZCUT_SCRATCH: dict = {}
+from .capacity import LRU as _LRU
+_ZCUT_SCRATCH = _LRU(16)  # (one entry per (device, tile count): a handful of image shapes)
 
 
 def zcut_scratch(dev, T: int):

@@ -24,11 +24,14 @@ _RENDER_MODES = ("RGB", "D", "ED", "RGB+D", "RGB+ED")
 # to undo).  FSGS_NO_WAIT=0 restores the wait in front of the bucket fill.
 import os as _os
 NO_WAIT = _os.environ.get("FSGS_NO_WAIT", "1") != "0"
-_LIVE_CAPS: Dict = {}
+from .capacity import LiveCapacity as _LiveCapacity
+_LIVE_CAPS = _LiveCapacity()  # (bucketed N, windowed maximum, LRU-bounded: capacity.py)
 live_overflows = 0
 
 # host seconds spent inside rasterization() / rasterize_gaussians() (library side of the drop-in route) and calls,
-# for bench.py's dropin_host_ms_per_call
+# for bench.py's dropin_host_ms_per_call — only while MEASURE_HOST_TIME is set (bench.py does, around that side
+# measurement; FSGS_MEASURE_HOST_TIME=1 from the environment): the product call carries no clock reads otherwise
+MEASURE_HOST_TIME = _os.environ.get("FSGS_MEASURE_HOST_TIME", "0") == "1"
 HOST_TIME = {"rasterization_s": 0.0, "rasterization_calls": 0, "rasterize_gaussians_s": 0.0, "rasterize_gaussians_calls": 0}
 
 
@@ -182,8 +185,9 @@ def rasterization(
     implementation always uses the dense ``[C,N,...]`` layout FusionSense asks for
     (``packed=False``) and reports ``camera_ids = gaussian_ids = None`` accordingly.
     ``sparse_grad`` is a packed-mode option and must be False."""
-    import time as _time
-    _t0 = _time.perf_counter()
+    if MEASURE_HOST_TIME:
+        import time as _time
+        _t0 = _time.perf_counter()
     if sparse_grad:
         raise ValueError("sparse_grad=True requires packed mode, which this backend does not expose")
     N, C = _validate(means, quats, scales, opacities, colors, viewmats, Ks, sh_degree, backgrounds,
@@ -209,12 +213,12 @@ def rasterization(
                  and C * tile_width * tile_height <= lib.fsgs_bin_live_max_tiles())
     count = None
     rule_diff = None
-    cap_key = (str(dev), C, N, width, height)
+    cap_key = _LIVE_CAPS.key(dev, C, N, width, height)
     if live_bins:
         with torch.no_grad():
             opac_c = opac.detach().contiguous()
             count = ops.bin_live_count_async(means2d.detach(), radii, conics.detach(), opac_c, tile_width, tile_height,
-                                             capacity=_LIVE_CAPS.get(cap_key, 0) if NO_WAIT else 0)
+                                             capacity=_LIVE_CAPS.get(cap_key) if NO_WAIT else 0)
     else:
         with torch.no_grad():
             tiles_per_gauss, isect_ids, flatten_ids, isect_offsets, rule_diff = ops.bin_and_sort(
@@ -313,7 +317,7 @@ def rasterization(
         else:
             n_live = int(live_payload.numel())
         if NO_WAIT:
-            _LIVE_CAPS[cap_key] = max(_LIVE_CAPS.get(cap_key, 0), int(n_live * 1.25) + 4096)
+            _LIVE_CAPS.update(cap_key, n_live)
         isect_offsets = live_offsets
     else:
         render, alphas, last_ids = composite(None, isect_offsets, False)
@@ -355,6 +359,7 @@ def rasterization(
             return {"isect_ids": ids, "flatten_ids": flat, "isect_offsets": offs, "legacy_rule_diff": diff}
 
         meta = LazyMeta(eager, build)
-    HOST_TIME["rasterization_s"] += _time.perf_counter() - _t0
-    HOST_TIME["rasterization_calls"] += 1
+    if MEASURE_HOST_TIME:
+        HOST_TIME["rasterization_s"] += _time.perf_counter() - _t0
+        HOST_TIME["rasterization_calls"] += 1
     return render, alphas, meta

@@ -195,6 +195,97 @@ def bicycle_like_scene(n: int = 6_000_000, seed: int = 0, sh_degree: int = 3) ->
     return dict(means=means, scales=scales, quats=quats, features_dc=dc, features_rest=rest, opacities=opac)
 
 
+def _quats_from_normals(normals: Tensor, g) -> Tensor:
+    """Unit quaternions (wxyz) whose rotation takes the local z axis to ``normals`` [n,3], with a random spin about
+    it: the orientation of a disc-like Gaussian lying IN a surface (its thin axis is the surface normal, which is also
+    what dn_model.py:618-636 reads back as the Gaussian's normal)."""
+    n = torch.nn.functional.normalize(normals, dim=-1)
+    q = torch.stack([1.0 + n[:, 2], -n[:, 1], n[:, 0], torch.zeros_like(n[:, 0])], dim=-1)
+    flip = q[:, 0] < 1e-6  # normal = -z: any half turn about an in-plane axis
+    q[flip] = torch.tensor([0.0, 1.0, 0.0, 0.0])
+    q = torch.nn.functional.normalize(q, dim=-1)
+    t = math.pi * torch.rand(n.shape[0], generator=g)
+    c, s_ = torch.cos(t), torch.sin(t)
+    w, x, y, z = q.unbind(-1)
+    return torch.stack([w * c - z * s_, x * c + y * s_, y * c - x * s_, w * s_ + z * c], dim=-1)  # q * (c, 0, 0, s)
+
+
+def surface_dense_scene(n: int = 6_000_000, seed: int = 0, sh_degree: int = 3, extent: float = 4.0,
+                        n_objects: int = 600, scale_lo: float = 0.003, scale_hi: float = 0.03,
+                        opaque_frac: float = 0.6, floater_frac: float = 0.08) -> Dict[str, Tensor]:
+    """Configs #4 / #5 (round 4): a scene whose Gaussians sit ON SURFACES that cameras see — what a trained capture of
+    an unbounded scene looks like to the rasterizer — instead of a fog with the cameras inside it
+    (``bicycle_like_scene``, kept as ``--scene volume``):
+
+    * 25 % on a ground disc of radius ``extent`` (z = 0, slight relief), 67 % on the faces of ``n_objects`` boxes of
+      half-size 0.05 .. 0.3 standing on the ground inside 0.85 x extent, ``floater_frac`` semi-transparent floaters;
+    * config #2's scale law (exp U(log ``scale_lo``, log ``scale_hi``), one axis x 0.1), the thin axis ALONG the surface
+      normal (discs lying in their surface; floaters oriented at random);
+    * bimodal opacities: ``opaque_frac`` of the surface Gaussians logit N(3, 1), the others N(-2.5, 1); floaters N(-3, 1);
+    * storage order shuffled (no spatial locality in the rows).
+    Rendered from ``ring_cameras`` OUTSIDE the content, every surface faces some camera, a ray meets the objects'
+    front faces, then what lies behind them: pixels saturate on the first surfaces and the lists behind them are
+    occluded — not empty."""
+    g = torch.Generator().manual_seed(seed)
+    n_float = int(floater_frac * n)
+    n_ground = int(0.25 * n)
+    n_obj = n - n_float - n_ground
+    # ground disc
+    r = extent * torch.sqrt(torch.rand(n_ground, generator=g))
+    a = 2 * math.pi * torch.rand(n_ground, generator=g)
+    ground = torch.stack([r * torch.cos(a), r * torch.sin(a), 0.004 * torch.randn(n_ground, generator=g)], dim=-1)
+    ground_n = torch.tensor([0.0, 0.0, 1.0]).expand(n_ground, 3) + 0.03 * torch.randn(n_ground, 3, generator=g)
+    # boxes standing on the ground
+    half = 0.05 + 0.25 * torch.rand(n_objects, 3, generator=g)
+    rc = 0.85 * extent * torch.sqrt(torch.rand(n_objects, generator=g))
+    ac = 2 * math.pi * torch.rand(n_objects, generator=g)
+    centers = torch.stack([rc * torch.cos(ac), rc * torch.sin(ac), half[:, 2]], dim=-1)
+    yaw = 2 * math.pi * torch.rand(n_objects, generator=g)
+    # faces picked by area, so the Gaussian density per unit area is the same on every face of every box
+    fa = torch.stack([half[:, 1] * half[:, 2], half[:, 0] * half[:, 2], half[:, 0] * half[:, 1]], dim=-1)  # x, y, z faces
+    w_ = (fa / fa.sum()).repeat_interleave(2, dim=1).reshape(-1) / 2  # [n_objects * 6]
+    pick = torch.multinomial(w_, n_obj, replacement=True, generator=g)
+    b, face = pick // 6, pick % 6
+    axis, sign = face // 2, (face % 2).to(torch.float32) * 2 - 1
+    uvw = torch.rand(n_obj, 3, generator=g) * 2 - 1
+    uvw[torch.arange(n_obj), axis] = sign
+    local = half[b] * uvw
+    ln = torch.zeros(n_obj, 3)
+    ln[torch.arange(n_obj), axis] = sign
+    cy, sy = torch.cos(yaw[b]), torch.sin(yaw[b])
+    rot = lambda v: torch.stack([cy * v[:, 0] - sy * v[:, 1], sy * v[:, 0] + cy * v[:, 1], v[:, 2]], dim=-1)  # noqa: E731
+    obj = centers[b] + rot(local)
+    obj_n = rot(ln) + 0.03 * torch.randn(n_obj, 3, generator=g)
+    # floaters
+    fl = torch.stack([(torch.rand(n_float, generator=g) * 2 - 1) * extent, (torch.rand(n_float, generator=g) * 2 - 1) * extent,
+                      torch.rand(n_float, generator=g) * 0.8], dim=-1)
+    means = torch.cat([ground, obj, fl], 0)
+    lo, hi = math.log(scale_lo), math.log(scale_hi)
+    scales = lo + (hi - lo) * torch.rand(n, 3, generator=g)
+    scales[:, 2] += math.log(0.1)
+    quats = torch.cat([_quats_from_normals(torch.cat([ground_n, obj_n], 0), g), random_quat_tensor(n_float, g)], 0)
+    n_surf = n_ground + n_obj
+    opaque = torch.rand(n_surf, generator=g) < opaque_frac
+    opac_s = torch.where(opaque, 3.0 + torch.randn(n_surf, generator=g), -2.5 + torch.randn(n_surf, generator=g))
+    opac = torch.cat([opac_s, -3.0 + torch.randn(n_float, generator=g)], 0)[:, None]
+    dc, rest = _sh_params(n, sh_degree, g)
+    perm = torch.randperm(n, generator=g)
+    return dict(means=means[perm].contiguous(), scales=scales[perm].contiguous(), quats=quats[perm].contiguous(),
+                features_dc=dc[perm].contiguous(), features_rest=rest[perm].contiguous(), opacities=opac[perm].contiguous())
+
+
+def ring_cameras(n_views: int = 8, radius: float = 6.5, height: float = 2.5, target=(0.0, 0.0, 0.3), width: int = 1920,
+                 height_px: int = 1080, focal: float = 1500.0) -> list:
+    """Cameras on a horizontal ring OUTSIDE the content of ``surface_dense_scene``, looking at its centre."""
+    cams = []
+    for i in range(n_views):
+        az = 2 * math.pi * i / n_views
+        eye = torch.tensor([radius * math.cos(az), radius * math.sin(az), height])
+        cams.append(Camera(look_at_c2w(eye, torch.tensor(target)), focal, focal, width / 2.0, height_px / 2.0, width,
+                           height_px))
+    return cams
+
+
 def touch_patches_on_blob(n_patches: int = 5, pts_per_patch: int = 2000, radius: float = 0.1, seed: int = 0,
                           extent=(0.0101, 0.0076), depth: float = 0.01):
     """Config #3's tactile supervision: ``n_patches`` gel-sensor contact patches on the surface of the object blob,

