@@ -313,7 +313,7 @@ def build_workload(args, dev):
             ring = {k: kw.pop(k) for k in ("radius", "height") if k in kw}
             cams = scenes.ring_cameras(args.views, width=W, height_px=H, focal=1500.0, **ring)
             make = lambda seed: scenes.surface_dense_scene(args.n_gauss, seed=seed, **kw)  # noqa: E731
-            what = "surface-bearing (ground disc + 600 boxes, discs lying in their surfaces, bimodal opacities, ring cameras outside)"
+            what = "surface-bearing (ground disc + 1200 boxes, discs lying in their surfaces, bimodal opacities, ring cameras outside)"
         else:
             cams = []
             for i in range(args.views):

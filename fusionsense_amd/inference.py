@@ -241,3 +241,159 @@ def backproject_views(trainer, cameras: List[Camera], batches: Optional[List[Dic
         nm = (c2w[:3, :3] @ nm).T[idx]
         points.append(xyz); colors.append(rgb); normals.append(nm)
     return torch.cat(points), torch.cat(colors), torch.cat(normals)
+
+
+# ---- level-set extraction (dn_model.py:1706-1946; the LevelSetExtractor of export_mesh.py:486-600) ---------------
+def knn_drop_first(x: Tensor, y: Tensor, k: int) -> Tensor:
+    """``dn_splatter.utils.knn.knn_sk(x, y, k)`` (utils/knn.py:29-44): for every row of ``y`` the indices of rows of
+    ``x`` ranked 2nd .. (k+1)-th nearest — sklearn is asked for k + 1 neighbours and the first column is dropped (the
+    self-match when y == x; for other queries it is the true nearest neighbour that goes, which every caller on this
+    path inherits).  Exact fp32 differences (no |a|^2 + |b|^2 - 2ab), brute force in query chunks on ``x``'s device."""
+    x, y = x.float(), y.float().to(x.device)
+    n, m = x.shape[0], y.shape[0]
+    kk = min(k + 1, n)
+    out = torch.empty(m, kk - 1, dtype=torch.int64, device=x.device)
+    chunk = max(1, min(m, (1 << 28) // max(n, 1)))
+    for s in range(0, m, chunk):
+        q = y[s:s + chunk]
+        d = (q[:, None, 0] - x[None, :, 0]) ** 2
+        d += (q[:, None, 1] - x[None, :, 1]) ** 2
+        d += (q[:, None, 2] - x[None, :, 2]) ** 2
+        out[s:s + chunk] = d.topk(kk, dim=1, largest=False).indices[:, 1:]
+    return out
+
+
+def _quat_to_rotmat(q: Tensor) -> Tensor:
+    from .legacy import quat_to_rotmat
+    return quat_to_rotmat(q)
+
+
+def gaussian_density(samples: Tensor, idx: Tensor, means: Tensor, inv_scaled_rot: Tensor, strengths: Tensor,
+                     want_grad: bool = False):
+    """The density field of dn_model.py:1812-1844 (also get_density :1580-1635) at ``samples`` [S,3] over each
+    sample's ``idx`` [S,k] Gaussians: sum_k sigmoid(opacity_k) exp(-1/2 |M_k^T (s - mu_k)|^2) with
+    M = R(q) diag(1 / max(scale, 1e-3)) (scale_rot_to_inv_cov3d(return_sqrt=True), :2141-2150); values >= 1 are
+    renormalised d / (d + 1e-5).  ``want_grad``: also sum_k w_k (M_k M_k^T (s - mu_k)) — the negative density gradient
+    up to the factor the "analytical" normal normalises away (:1900-1919)."""
+    shift = samples[:, None, :] - means[idx]                       # [S,k,3]
+    M = inv_scaled_rot[idx]                                        # [S,k,3,3]
+    man = (M.transpose(-1, -2) @ shift[..., None])                 # [S,k,3,1]
+    d2 = (man[..., 0] * man[..., 0]).sum(dim=-1).clamp(min=0.0, max=1e8)
+    w = strengths[idx][..., 0] * torch.exp(-0.5 * d2)              # [S,k]
+    dens = w.sum(dim=-1)
+    big = dens >= 1.0
+    dens = torch.where(big, dens / (dens + 1e-5), dens)
+    if want_grad:
+        return dens, (w[..., None] * (M @ man)[..., 0]).sum(dim=-2)
+    return dens
+
+
+@torch.no_grad()
+def level_surface_points_from_render(params: Dict[str, Tensor], normals_world: Tensor, depth: Tensor, rgb: Tensor,
+                                     camera: Camera, num_samples: int, mask: Optional[Tensor] = None,
+                                     surface_levels=(0.1, 0.3, 0.5), return_normal: str = "closest_gaussian",
+                                     knn_to_track: int = 16, sample_fn=None, n_points_per_pass: int = 2_000_000):
+    """``DNSplatterModel.compute_level_surface_points`` (dn_model.py:1706-1946) after its ``get_outputs`` call: every
+    pixel with depth is back-projected, 21 samples are laid along its ray over +-3 standard deviations of the point's
+    (2nd-)closest Gaussian in that direction, the density of the point's ``knn_to_track`` Gaussians is evaluated at them,
+    and for each level the first crossing from below is located by linear interpolation.  Returns
+    {level: {"points", "normals", "colors"}} like the reference; ``sample_fn(n_available, n_wanted) -> indices`` replaces
+    its ``random.sample`` (default: exactly that)."""
+    import random
+    dev = depth.device
+    H, W = camera.height, camera.width
+    c2w_gl = camera.c2w.to(device=dev, dtype=torch.float32)        # [3,4], OpenGL axes as nerfstudio stores it
+    campos = c2w_gl[None, :3, 3]                                   # [1,3] (camera.camera_to_worlds[..., :3, 3])
+    c2w = c2w_gl @ torch.diag(torch.tensor([1.0, -1.0, -1.0, 1.0], device=dev))
+    means, quats = params["means"].detach().to(dev), params["quats"].detach().to(dev)
+    scales, opac = params["scales"].detach().to(dev), params["opacities"].detach().to(dev)
+    depth = depth.reshape(H, W, 1)
+    points, colors = get_colored_points_from_depth(depths=depth, rgbs=rgb, fx=camera.fx, fy=camera.fy, cx=camera.cx,
+                                                   cy=camera.cy, img_size=(W, H), c2w=c2w)
+    points, colors = points.view(H, W, -1), colors.reshape(H, W, 3)
+    if mask is not None:
+        mask = mask.to(dev)
+        points = points * mask
+        depth = depth * mask
+    keep = ~(depth <= 0.0)[..., 0]
+    points, colors = points[keep], colors[keep]
+    pixel_ids = torch.nonzero(keep.reshape(-1)).reshape(-1)
+    closest = knn_drop_first(means, points, knn_to_track)
+
+    viewdirs = -means + campos
+    viewdirs = viewdirs / viewdirs.norm(dim=-1, keepdim=True)
+    qn = quats / quats.norm(dim=-1, keepdim=True)
+    inv_rots = _quat_to_rotmat(qn * torch.tensor([1.0, -1.0, -1.0, -1.0], device=dev))  # invert_quaternion (:2153-2163)
+    stds = (torch.exp(scales) * torch.bmm(inv_rots, viewdirs[..., None])[..., 0]).norm(dim=-1)
+    points_stds = stds[closest][..., 0]
+
+    n_in_range = 21
+    points_range = torch.linspace(-3, 3, n_in_range, device=dev).view(1, -1, 1) * points_stds[..., None, None]
+    cam_to_samples = F.normalize(points - campos, dim=-1)
+    samples = (points[:, None, :] + points_range * cam_to_samples[:, None, :]).view(-1, 3)
+    samples_idx = closest[:, None, :].expand(-1, n_in_range, -1).reshape(-1, closest.shape[1])
+    strengths = torch.sigmoid(opac)
+    inv_sr = _quat_to_rotmat(quats) * (1.0 / torch.exp(scales).clamp(min=1e-3))[..., None, :]
+    densities = torch.empty(samples.shape[0], dtype=torch.float32, device=dev)
+    for s in range(0, samples.shape[0], n_points_per_pass):
+        e = min(samples.shape[0], s + n_points_per_pass)
+        densities[s:e] = gaussian_density(samples[s:e], samples_idx[s:e], means, inv_sr, strengths)
+    densities = densities.reshape(-1, n_in_range)
+
+    out = {}
+    for level in surface_levels:
+        under, above = densities - level < 0, densities - level > 0
+        first = above.to(torch.uint8).max(dim=-1, keepdim=True).indices  # first sample above the level (0: none / the first)
+        empty = ~under[..., 0] | (first[..., 0] == 0)
+        vd, vr, vf = densities[~empty], points_range[~empty][..., 0], first[~empty]
+        v1, v0 = vd.gather(-1, vf).view(-1), vd.gather(-1, vf - 1).view(-1)
+        t1, t0 = vr.gather(-1, vf).view(-1), vr.gather(-1, vf - 1).view(-1)
+        t = (level - v0) / (v1 - v0) * (t1 - t0) + t0
+        ipts = points[~empty] + t[:, None] * cam_to_samples[~empty]
+        icol = colors[~empty]
+        idx_k = closest[~empty]
+        if return_normal == "analytical":
+            _, g = gaussian_density(ipts, idx_k, means, inv_sr, strengths, want_grad=True)
+            inrm = -F.normalize(g, dim=-1)
+        elif return_normal == "closest_gaussian":
+            inrm = normals_world.to(dev)[idx_k[..., 0]]
+        else:
+            raise NotImplementedError(return_normal)
+        n_av = ipts.shape[0]
+        want = num_samples if num_samples < n_av else n_av
+        pick = sample_fn(n_av, want) if sample_fn is not None else random.sample(range(n_av), want)
+        pick = torch.as_tensor(pick, device=dev, dtype=torch.int64)
+        out[level] = {"points": ipts[pick], "normals": inrm[pick], "colors": icol[pick],
+                      "pixel_ids": pixel_ids[~empty][pick]}  # (extra: the flat pixel index every point came from)
+    return out
+
+
+@torch.no_grad()
+def compute_level_surface_points(trainer, camera: Camera, num_samples: int, mask: Optional[Tensor] = None,
+                                 surface_levels=(0.1, 0.3, 0.5), return_normal: str = "closest_gaussian",
+                                 knn_to_track: int = 16, sample_fn=None):
+    """``model.compute_level_surface_points(camera, num_samples, mask, surface_levels, return_normal)`` over the HIP
+    forward: get_outputs (eval mode) renders depth + rgb and leaves the world-space normals of the Gaussians
+    (``gauss_params["normals"]``, dn_model.py:634), the rest is :func:`level_surface_points_from_render`."""
+    o = trainer.forward(camera)
+    return level_surface_points_from_render(trainer.params, o["normals_world"], o["depth"], o["rgb"], camera, num_samples,
+                                            mask, surface_levels, return_normal, knn_to_track, sample_fn)
+
+
+@torch.no_grad()
+def extract_level_sets(trainer, cameras: List[Camera], batches: Optional[List[Dict[str, Tensor]]] = None,
+                       total_points: int = 100_000, use_masks: bool = False, surface_levels=(0.1, 0.3, 0.5),
+                       return_normal: str = "closest_gaussian", sample_fn=None):
+    """LevelSetExtractor.main up to its point clouds (export_mesh.py:506-583): ``samples_per_frame`` level-surface
+    points from every training camera, concatenated per level -> {level: (points, colors, normals)} — what the
+    reference hands to open3d's Poisson reconstruction (off the path, not provided)."""
+    n = len(cameras)
+    per_frame = (total_points + n) // n
+    acc = {lv: {"points": [], "colors": [], "normals": []} for lv in surface_levels}
+    for i, cam in enumerate(cameras):
+        mask = batches[i].get("mask") if (batches is not None and use_masks) else None
+        fo = compute_level_surface_points(trainer, cam, per_frame, mask, surface_levels, return_normal, sample_fn=sample_fn)
+        for lv in surface_levels:
+            for key in acc[lv]:
+                acc[lv][key].append(fo[lv][key])
+    return {lv: tuple(torch.cat(acc[lv][k]) for k in ("points", "colors", "normals")) for lv in surface_levels}

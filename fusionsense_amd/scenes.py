@@ -210,17 +210,18 @@ def _quats_from_normals(normals: Tensor, g) -> Tensor:
     return torch.stack([w * c - z * s_, x * c + y * s_, y * c - x * s_, w * s_ + z * c], dim=-1)  # q * (c, 0, 0, s)
 
 
-def surface_dense_scene(n: int = 6_000_000, seed: int = 0, sh_degree: int = 3, extent: float = 4.0,
-                        n_objects: int = 600, scale_lo: float = 0.003, scale_hi: float = 0.03,
-                        opaque_frac: float = 0.6, floater_frac: float = 0.08) -> Dict[str, Tensor]:
+def surface_dense_scene(n: int = 6_000_000, seed: int = 0, sh_degree: int = 3, extent: float = 6.0,
+                        n_objects: int = 1200, scale_lo: float = 0.002, scale_hi: float = 0.015,
+                        opaque_frac: float = 0.5, floater_frac: float = 0.08) -> Dict[str, Tensor]:
     """Configs #4 / #5 (round 4): a scene whose Gaussians sit ON SURFACES that cameras see — what a trained capture of
     an unbounded scene looks like to the rasterizer — instead of a fog with the cameras inside it
     (``bicycle_like_scene``, kept as ``--scene volume``):
 
     * 25 % on a ground disc of radius ``extent`` (z = 0, slight relief), 67 % on the faces of ``n_objects`` boxes of
       half-size 0.05 .. 0.3 standing on the ground inside 0.85 x extent, ``floater_frac`` semi-transparent floaters;
-    * config #2's scale law (exp U(log ``scale_lo``, log ``scale_hi``), one axis x 0.1), the thin axis ALONG the surface
-      normal (discs lying in their surface; floaters oriented at random);
+    * config #2's scale law at two thirds of its size (exp U(log ``scale_lo``, log ``scale_hi``), one axis x 0.1: 20 times
+      the Gaussians of config #2 describe finer detail), the thin axis ALONG the surface normal (discs lying in their
+      surface; floaters oriented at random);
     * bimodal opacities: ``opaque_frac`` of the surface Gaussians logit N(3, 1), the others N(-2.5, 1); floaters N(-3, 1);
     * storage order shuffled (no spatial locality in the rows).
     Rendered from ``ring_cameras`` OUTSIDE the content, every surface faces some camera, a ray meets the objects'
@@ -274,7 +275,7 @@ def surface_dense_scene(n: int = 6_000_000, seed: int = 0, sh_degree: int = 3, e
                 features_dc=dc[perm].contiguous(), features_rest=rest[perm].contiguous(), opacities=opac[perm].contiguous())
 
 
-def ring_cameras(n_views: int = 8, radius: float = 6.5, height: float = 2.5, target=(0.0, 0.0, 0.3), width: int = 1920,
+def ring_cameras(n_views: int = 8, radius: float = 9.0, height: float = 3.5, target=(0.0, 0.0, 0.3), width: int = 1920,
                  height_px: int = 1080, focal: float = 1500.0) -> list:
     """Cameras on a horizontal ring OUTSIDE the content of ``surface_dense_scene``, looking at its centre."""
     cams = []

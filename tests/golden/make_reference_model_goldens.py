@@ -192,7 +192,8 @@ def save(out, prefix, d):
         out[f"{prefix}.{k}"] = v.detach().clone().numpy() if torch.is_tensor(v) else np.array(v)  # (a copy: later in-place edits must not reach it)
 
 
-def main():
+def load_reference_model():
+    """The reference's dn_model module, loaded over the stand-ins (rasterizer = oracle/gsplat_ref.py)."""
     if not os.path.isdir(base.REF):
         raise SystemExit("reference not present")
     base._install_stubs()
@@ -218,7 +219,11 @@ def main():
     def knn_exact(x, y, k):  # dn_splatter.utils.knn.knn_sk(x, y, k): for every row of y the k nearest rows of x
         return torch.cdist(y.double(), x.double()).topk(k, largest=False).indices
     mm.knn_sk = knn_exact
+    return mm
 
+
+def main():
+    mm = load_reference_model()
     from fusionsense_amd import scenes
     out = {}
 

@@ -319,7 +319,9 @@ def test_config3_schedule_window_touch_patches_and_densify(dev, config3):
     assert st.last_report["step"] == 1100 and len(set(n_hist)) >= 3, (st.last_report, sorted(set(n_hist)))
     for k in PARAM_ORDER:
         p = tr.params[k]
-        assert p.grad is tr.slab.views[k] and p.shape[0] == tr.num_gaussians()
+        # (the window's last step applied Adam inside the backward: no gradients written, .grad says so)
+        assert (p.grad is None and not tr.last_step_grads_valid) or p.grad is tr.slab.views[k]
+        assert p.shape[0] == tr.num_gaussians() and tr.slab.views[k].shape == p.shape
         s_ = tr.optimizers[k].state[p]
         assert s_["exp_avg"].shape == p.shape and s_["exp_avg_sq"].shape == p.shape
     # the touch-normal MSE is part of the reported loss once the anchors exist (dn_model.py:893-902)
@@ -485,6 +487,34 @@ def test_bench_spawns_its_own_ranks_without_a_launcher():
         assert r.returncode == 2 and not r.stdout.strip()
 
 
+@pytest.mark.parametrize("sharded", ["0", "1"])
+def test_bench_with_eight_ranks_over_gloo_on_this_gpu(sharded):
+    """``python bench.py --gpus 8`` — the command of the driver's scaling run — with all EIGHT ranks sharing this GPU over
+    gloo (functional, small N; VERDICT r3 Next 3: nothing had ever run at W = 8): spawned by bench.py itself under its
+    watchdog, the 8-way SH-factor all-gather + in-order rebuild, the geometry half all-reduced or reduce-scattered into
+    eight padded shards (N = 20 011 is no multiple of 64 x 8), replicas bit-identical, and the line carries the
+    per-rank step time and the exposed communication time a scaling curve is read with."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(FSGS_DIST_BACKEND="gloo", FSGS_SHARDED_GEOMETRY=sharded, FSGS_BENCH_VERBOSE="1")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "4", "--warmup", "1",
+                        "--n-gauss", "20011", "--res", "160", "--views", "16", "--no-cpu-baseline", "--spawn-timeout", "500"],
+                       capture_output=True, text=True, env=env, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    c = line["config"]
+    assert line["n_gpus"] == 8 and c["world_size"] == 8 and sorted(c["ranks_seen"]) == list(range(8))
+    assert c["parallelism"] == "dp8" and c["backend"] == "gloo" and c["launched_by"].startswith("bench.py")
+    assert c["replicas_identical_after_timed_steps"] is True and r.stderr.count("replicas identical") == 8
+    assert c["sharded_geometry"] is (sharded == "1") and c["comm_bytes_per_step_per_rank"] > 0
+    sm, cm = line["step_ms_per_rank"], line["comm_ms_exposed"]
+    assert 0 < sm["min"] <= sm["median"] <= sm["max"] and 0 <= cm["min"] <= cm["max"] < sm["max"]
+    assert line["value"] == pytest.approx(8 * 4 / (line["ms_per_step"] * 4e-3), rel=1e-3)  # whole-job views per second
+
+
 def test_two_ranks_over_rccl_when_two_gpus():
     """The first thing a real multi-GPU node runs: bench.py with 2 ranks on 2 GPUs over RCCL ("nccl"), replicas
     checked bit for bit.  Skipped on 1-GPU boxes (the driver's 8-GPU scaling run is the measurement)."""
@@ -577,6 +607,81 @@ def test_eval_loop_and_backprojection(dev):
     box = OrientedBox(torch.eye(3), torch.zeros(3), torch.full((3,), 0.25))
     cropped = inf.get_outputs_for_camera(tr, cam, obb_box=box)
     assert cropped["rgb"].shape == out["rgb"].shape and not torch.equal(cropped["rgb"], out["rgb"])
+
+
+def test_eval_loop_scores_equal_the_oracle_renders_scores(dev):
+    """The eval pass over the HIP forward against the SAME pass over the CPU oracle's renders (the eval loop
+    had only been compared with itself): a cube scene scored against supervision rendered by the oracle from another
+    scene — every metric of dn_model.py:1032-1148 / metrics.py agrees to the render tolerance."""
+    from fusionsense_amd import inference as inf
+    from fusionsense_amd.trainer import SplatTrainer
+    from oracle.fusion_ref import render_fusionsense as render_ref
+    params, cam = scenes.cube_scene(1500, seed=3)
+    other, _ = scenes.cube_scene(1500, seed=8)
+    with torch.no_grad():
+        sup = render_ref({k: v.clone() for k, v in other.items()}, cam, sh_degree=3)
+        ref = render_ref({k: v.clone() for k, v in params.items()}, cam, sh_degree=3)
+    batch = {"image": sup["rgb"], "sensor_depth": sup["depth"], "normal": sup["normal"], "mask": sup["accumulation"] > 0.3}
+    m_ref, _ = inf.get_image_metrics_and_images({k: ref[k] for k in ("rgb", "depth", "normal")}, batch)
+    tr = SplatTrainer(params, dev, sh_degree=3)
+    out = inf.get_outputs_for_camera(tr, cam)
+    for k in ("rgb", "depth", "normal", "accumulation"):
+        assert rel_err(out[k], ref[k]) < 1e-4, k
+    m = inf.eval_loop(tr, [cam], [batch])
+    for k, v in m_ref.items():
+        if k == "rgb_lpips":
+            continue
+        assert abs(m[k] - v) <= 2e-4 * max(1.0, abs(v)), (k, m[k], v)
+    assert 5 < m["rgb_psnr"] < 40 and m["depth_abs_rel"] > 0  # (a real comparison, not a scene against itself)
+
+
+@pytest.mark.parametrize("case", ["closest", "analytical"])
+def test_level_set_extraction_over_the_hip_forward(dev, case):
+    """Row N4's last piece: ``compute_level_surface_points`` (dn_model.py:1706-1946) over the HIP forward against the
+    REFERENCE's own method executed over the oracle rasterizer (tests/golden/reference_levelset.npz): the same pixels
+    cross each level (a handful sit on a threshold of the 1e-4-different depth images), at the same points, with the same
+    normals; then the LevelSetExtractor loop (export_mesh.py:506-583) over several cameras."""
+    import numpy as np
+    from fusionsense_amd import inference as inf
+    from fusionsense_amd.trainer import SplatTrainer
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_levelset.npz"))
+    t = lambda k: torch.from_numpy(d[k])  # noqa: E731
+    params = {k: t(f"in.{k}") for k in ("means", "scales", "quats", "features_dc", "features_rest", "opacities")}
+    fx, fy, cx, cy, W, H = (float(x) for x in d["intr"])
+    W, H = int(W), int(H)
+    cam = scenes.Camera(t("c2w"), fx, fy, cx, cy, W, H)
+    tr = SplatTrainer(params, dev, sh_degree=3)
+    o = tr.forward(cam)
+    assert rel_err(o["depth"], t("render.depth")) < 1e-4 and rel_err(o["normals_world"], t("render.normals_world")) < 1e-5
+    mode = ["closest_gaussian", "analytical"][int(d[f"{case}.mode"])]
+    mask = t("mask") if bool(d[f"{case}.use_mask"]) else None
+    res = inf.compute_level_surface_points(tr, cam, 10 ** 9, mask, (0.1, 0.3, 0.5), mode,
+                                           sample_fn=lambda n, k: list(range(n))[:k])
+    c2w = torch.eye(4)
+    c2w[:3] = cam.c2w
+    c2w = (c2w @ torch.diag(torch.tensor([1.0, -1.0, -1.0, 1.0])))[:3]
+    for lv in (0.1, 0.3, 0.5):
+        ref_p, ref_n, ref_c = (t(f"{case}.{lv}.{k}") for k in ("points", "normals", "colors"))
+        uv = inf.project_pix(ref_p, fx, fy, cx, cy, c2w)  # the pixel every reference point came from
+        ref_pid = (torch.round(uv[:, 1] - 0.5).long() * W + torch.round(uv[:, 0] - 0.5).long())
+        pid = res[lv]["pixel_ids"].cpu()
+        common, ia, ib = np.intersect1d(pid.numpy(), ref_pid.numpy(), return_indices=True)
+        assert len(common) >= 0.98 * max(len(pid), len(ref_pid)), (lv, len(pid), len(ref_pid), len(common))
+        got_p, got_n, got_c = (res[lv][k].cpu()[ia] for k in ("points", "normals", "colors"))
+        # (a pixel whose 2nd-nearest Gaussian changes with the 1e-4 depth difference samples another ray interval)
+        close = (got_p - ref_p[ib]).norm(dim=-1) < 2e-3
+        assert float(close.float().mean()) > 0.97, (lv, float(close.float().mean()))
+        ok_n = (got_n[close] - ref_n[ib][close]).abs().max(dim=-1).values < (2e-2 if mode == "analytical" else 1e-3)
+        assert float(ok_n.float().mean()) > 0.97, (lv, float(ok_n.float().mean()))
+        assert torch.allclose(got_c[close], ref_c[ib][close], atol=2e-4)
+    # the extractor's loop: points of three cameras, per level, sub-sampled per frame
+    cams = [cam, scenes.Camera(scenes.look_at_c2w(torch.tensor([2.0, 1.0, 1.2]), torch.zeros(3)), fx, fy, cx, cy, W, H),
+            scenes.Camera(scenes.look_at_c2w(torch.tensor([-1.5, 2.0, 0.4]), torch.zeros(3)), fx, fy, cx, cy, W, H)]
+    sets = inf.extract_level_sets(tr, cams, total_points=600, return_normal=mode)
+    for lv, (P, C, Nn) in sets.items():
+        assert P.shape == C.shape == Nn.shape and 0 < P.shape[0] <= 3 * 201
+        assert torch.allclose(Nn.norm(dim=-1), torch.ones_like(Nn[:, 0]), atol=1e-3)
+        assert float(P.abs().max()) < 1.5  # on / near the unit cube's surface
 
 
 # ---------------------------------------------------------------------------------------------------------------

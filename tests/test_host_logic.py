@@ -947,3 +947,213 @@ def test_bench_watchdog_reaps_hung_ranks():
     left = [p for p in psutil.process_iter(["cmdline", "environ"]) if p.info["cmdline"] and "bench.py" in " ".join(p.info["cmdline"])
             and (p.info.get("environ") or {}).get("FSGS_BENCH_TEST_HANG") == "1"]
     assert not left, [p.info["cmdline"] for p in left]
+
+
+_W8_WORKER = r"""
+import os, sys, math, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+rank = int(os.environ["RANK"]); world = int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d", rank=rank, world_size=world)
+from fusionsense_amd import ops
+from fusionsense_amd.trainer import SplatTrainer, PARAM_ORDER, GEOMETRY_GROUPS, FEATURE_GROUPS
+from fusionsense_amd.splatfacto import DensifyStrategy, SplatfactoConfig
+# the row surgery of a refinement runs through HIP kernels in the product (no CPU fallback, by design); this test is
+# about the EXCHANGE and the slab layout around it, so the three row primitives get torch stand-ins here
+ops.mask_positions = lambda keep: torch.cumsum(keep.to(torch.int64), 0) - keep.to(torch.int64)
+def _compact(src, keep8, positions, n_keep, out=None, out_offset=0):
+    rows = src[keep8.bool()]
+    if out is None:
+        return rows
+    out[out_offset:out_offset + n_keep] = rows
+    return out
+ops.compact_rows = _compact
+def _split(ids, samps, means, quats, log_scales, randn):
+    from fusionsense_amd.legacy import quat_to_rotmat
+    q = quats[ids] / quats[ids].norm(dim=-1, keepdim=True)
+    R = quat_to_rotmat(q.repeat(samps, 1))
+    sc = torch.exp(log_scales[ids].repeat(samps, 1)) * randn
+    return (R @ sc[..., None]).squeeze(-1) + means[ids].repeat(samps, 1), torch.log(torch.exp(log_scales[ids]) / 1.6).repeat(samps, 1)
+ops.split_samples = _split
+
+torch.manual_seed(0)
+n = 173                      # 11 * 173 = 1903 geometry floats: no multiple of 64, let alone of 64 * 8
+shapes = dict(means=(n,3), scales=(n,3), quats=(n,4), features_dc=(n,3), features_rest=(n,15,3), opacities=(n,1))
+init = {k: torch.randn(*shapes[k]) for k in PARAM_ORDER}
+init["scales"] = init["scales"] * 0.5 - 4.0       # around exp(-4) = 0.018: some above, some below the 0.01 size threshold
+init["opacities"] = init["opacities"] + 2.0
+dev = torch.device("cpu")
+cfg = SplatfactoConfig()
+os.environ["FSGS_SHARDED_GEOMETRY"] = "1"
+a = SplatTrainer(init, dev, fused=False, seed=3, strategy=DensifyStrategy(cfg, num_train_data=8))
+os.environ["FSGS_SHARDED_GEOMETRY"] = "0"
+# the single-process run "on the concatenated views": the mean of all eight ranks' gradients, formed locally (the
+# gradient of a rank is a function of (parameters, rank, step)), stepped without any collective
+c = SplatTrainer(init, dev, fused=False, seed=3, strategy=DensifyStrategy(cfg, num_train_data=8))
+assert a._geo is not None and c._geo is None
+assert a.slab.align == 64 and a.slab.world == 8 and a.slab.split %% (64 * 8) == 0 and a.slab.split >= 11 * n
+assert a._geo["shard"] * 8 == a.slab.split and a._geo["lo"] == rank * a._geo["shard"]
+
+def grad_of(tr, k, i, it, r):
+    return torch.sin(tr._params[k].data * (i + 1) + it) * (r + 1) + 0.1 * r
+
+def step_a(it):
+    for i, k in enumerate(PARAM_ORDER):
+        a.slab.views[k].copy_(grad_of(a, k, i, it, rank))
+    a._reduce_and_step(True)
+    assert a._pending is not None and a._moments_local
+    a.flush()
+    a.step += 1
+
+def step_c(it):
+    for i, k in enumerate(PARAM_ORDER):
+        g = torch.zeros_like(c._params[k].data)
+        for r in range(world):          # rank order, like the collectives' sums
+            g += grad_of(c, k, i, it, r)
+        c.slab.views[k].copy_(g / world)
+    c.optimizers["means"].param_groups[0]["lr"] = c._means_lr(c.step)
+    for k in PARAM_ORDER:
+        c.optimizers[k].step()
+    c.step += 1
+
+def check(tag, rtol=2e-5, atol=1e-6):
+    for k in PARAM_ORDER:
+        pa, pc = a.params[k].data, c._params[k].data
+        assert pa.shape == pc.shape, (tag, k, pa.shape, pc.shape)
+        assert torch.allclose(pa, pc, rtol=rtol, atol=atol), (tag, k, float((pa - pc).abs().max()))
+    for k in PARAM_ORDER:               # replicas: bit-identical on every rank
+        t = a.params[k].data.clone(); dist.broadcast(t, 0)
+        assert torch.equal(t, a.params[k].data), (tag, k)
+
+a.step = c.step = 690
+for it in range(5):
+    step_a(it); step_c(it)
+check("after 5 sharded steps")
+
+# ---- one refinement: statistics differ per rank, the all-reduce (SUM / SUM of count-1 / MAX) makes the decisions equal
+g = torch.Generator().manual_seed(100 + rank)
+sa = a.strategy
+sa.xys_grad_norm = torch.rand(n, generator=g) * 0.01
+sa.vis_counts = 1.0 + torch.randint(0, 3, (n,), generator=g).float()
+sa.max_2Dsize = torch.rand(n, generator=g) * 0.08
+sa.last_size = (720, 1280)
+parts = [torch.zeros(3, n) for _ in range(world)]
+dist.all_gather(parts, torch.stack([sa.xys_grad_norm, sa.vis_counts - 1.0, sa.max_2Dsize]))
+sc = c.strategy
+sc.xys_grad_norm = sum(p[0] for p in parts)
+sc.vis_counts = 1.0 + sum(p[1] for p in parts)
+sc.max_2Dsize = torch.stack([p[2] for p in parts]).max(0).values
+sc.last_size = (720, 1280)
+import torch.distributed as _d
+a.step = c.step = 700
+sa.refinement_after(a, 700)             # (collectives inside: stats all-reduce, moment all-gather before the surgery)
+_real_init = _d.is_initialized
+_d.is_initialized = lambda: False       # the reference run takes no part in any collective
+try:
+    sc.refinement_after(c, 700)
+finally:
+    _d.is_initialized = _real_init
+n2 = a.num_gaussians()
+assert n2 == c.num_gaussians() and n2 != n, (n2, c.num_gaussians())
+rep = sa.last_report
+assert rep["n_split"] > 0 and rep["n_dup"] > 0 and rep["n_deleted"] > 0, rep
+ns = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+dist.all_gather(ns, torch.tensor([n2]))
+assert all(int(x) == n2 for x in ns), "N differs between the ranks after the refinement"
+# the slab, the flat geometry slabs and the shard bounds follow the new N
+assert a._geo is not None and a.slab.split %% (64 * 8) == 0 and a.slab.split >= 11 * n2 and a._geo["shard"] * 8 == a.slab.split
+for name, off, cnt in a.slab.geo_ranges:
+    assert off %% 64 == 0 and cnt == a._params[name].numel()
+    assert a._params[name].data.data_ptr() == a._geo["P"].data_ptr() + 4 * off
+    assert a._params[name].grad.data_ptr() == a.slab.views[name].data_ptr()
+check("right after the refinement")
+for k in PARAM_ORDER:                   # moments: survivors keep theirs, new rows start at zero — as in the single run
+    ma, mc = a.optimizers[k].state[a._params[k]], c.optimizers[k].state[c._params[k]]
+    assert torch.allclose(ma["exp_avg"], mc["exp_avg"], rtol=2e-5, atol=1e-7), k
+    assert torch.allclose(ma["exp_avg_sq"], mc["exp_avg_sq"], rtol=2e-5, atol=1e-9), k
+for it in range(5, 9):
+    step_a(it); step_c(it)
+check("after the refinement + 4 sharded steps")
+a.sync_optimizer_state()
+for k in PARAM_ORDER:
+    ma, mc = a.optimizers[k].state[a._params[k]], c.optimizers[k].state[c._params[k]]
+    assert torch.allclose(ma["exp_avg"], mc["exp_avg"], rtol=2e-5, atol=1e-6), (k, float((ma["exp_avg"] - mc["exp_avg"]).abs().max()))
+    assert float(ma["step"]) == float(mc["step"]) == 9.0, (k, float(ma["step"]), float(mc["step"]))
+dist.barrier()
+dist.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+def test_world8_sharded_step_statistics_and_refinement_gloo():
+    """EIGHT ranks over gloo (VERDICT r3 Next 3: nothing had ever run at W = 8): the sharded geometry step with a
+    Gaussian count that is no multiple of 64 x 8 (padding, shard bounds, four-group shard intersections), the deferred
+    feature exchange, the per-refinement statistics all-reduce, ONE refinement with splits / dups / culls (moment
+    all-gather before the surgery, slab + flat geometry slabs rebuilt for the new N) — and the parameters equal those of
+    a single process that steps on the mean gradient of the eight views; replicas bit-identical throughout."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    code = _W8_WORKER % (ROOT, port)
+    procs = []
+    for r in range(8):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="8", OMP_NUM_THREADS="1", MKL_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    fails = []
+    for r, p in enumerate(procs):
+        try:
+            out, err = p.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            out, err = p.communicate()
+            err += "\n[timeout]"
+        if p.returncode != 0 or "ok" not in out:
+            fails.append((r, err[-1500:]))
+    assert not fails, fails[0]
+
+
+@pytest.mark.parametrize("case", ["closest", "analytical", "few"])
+def test_level_surface_points_match_reference_execution(case):
+    """inference.level_surface_points_from_render against what the reference's own
+    ``compute_level_surface_points`` (dn_model.py:1706-1946) produced — executed by
+    tests/golden/make_reference_levelset_goldens.py — from the same render (the oracle rasterizer's depth / rgb and the
+    per-Gaussian world normals stored with the golden): the same pixels cross each level, at the same points, with the
+    same normals (closest-Gaussian and analytical mode, with and without a mask, sub-sampled)."""
+    from fusionsense_amd import inference as inf
+    d = np.load(os.path.join(GOLD, "reference_levelset.npz"))
+    t = lambda k: torch.from_numpy(d[k])  # noqa: E731
+    params = {k: t(f"in.{k}") for k in ("means", "scales", "quats", "opacities")}
+    fx, fy, cx, cy, W, H = (float(x) for x in d["intr"])
+    cam = scenes.Camera(t("c2w"), fx, fy, cx, cy, int(W), int(H))
+    mode = ["closest_gaussian", "analytical"][int(d[f"{case}.mode"])]
+    mask = t("mask") if bool(d[f"{case}.use_mask"]) else None
+    res = inf.level_surface_points_from_render(params, t("render.normals_world"), t("render.depth"), t("render.rgb"), cam,
+                                               int(d[f"{case}.num_samples"]), mask, (0.1, 0.3, 0.5), mode,
+                                               sample_fn=lambda n, k: list(range(n))[:k])
+    for lv in (0.1, 0.3, 0.5):
+        for key in ("points", "normals", "colors"):
+            ref = t(f"{case}.{lv}.{key}")
+            got = res[lv][key]
+            assert got.shape == ref.shape, (lv, key, got.shape, ref.shape)
+            assert torch.allclose(got, ref, rtol=1e-4, atol=2e-5), (lv, key, float((got - ref).abs().max()))
+        # every point lies on the ray of the pixel it is attributed to
+        c2w = torch.eye(4)
+        c2w[:3] = cam.c2w
+        c2w = (c2w @ torch.diag(torch.tensor([1.0, -1.0, -1.0, 1.0])))[:3]
+        uv = inf.project_pix(res[lv]["points"], fx, fy, cx, cy, c2w)
+        pid = res[lv]["pixel_ids"]
+        assert torch.allclose(uv[:, 0], (pid % int(W)).float() + 0.5, atol=2e-2) and torch.allclose(uv[:, 1], (pid // int(W)).float() + 0.5, atol=2e-2)
+    assert res[0.1]["points"].shape[0] >= res[0.3]["points"].shape[0] >= res[0.5]["points"].shape[0] > 0
+
+
+def test_knn_drop_first_is_sklearn_minus_its_first_column():
+    """inference.knn_drop_first = dn_splatter.utils.knn.knn_sk (utils/knn.py:29-44): sklearn's k + 1 nearest with the
+    first column dropped — checked against sklearn itself."""
+    from sklearn.neighbors import NearestNeighbors
+    from fusionsense_amd.inference import knn_drop_first
+    g = torch.Generator().manual_seed(0)
+    x, y = torch.randn(500, 3, generator=g), torch.randn(77, 3, generator=g)
+    ref = NearestNeighbors(n_neighbors=6, algorithm="auto", metric="euclidean").fit(x.numpy()).kneighbors(y.numpy())[1][:, 1:]
+    assert np.array_equal(knn_drop_first(x, y, 5).numpy(), ref)
