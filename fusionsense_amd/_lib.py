@@ -72,8 +72,8 @@ SIGNATURES = {
     "fsgs_live_payload": (_i, [_p, _p, _i64, _p, _i64, _i, _i, _p, _p]),
     "fsgs_raster_fwd_quad": (_i, [_i, _i, _p, _p, _p, _i64, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "fsgs_set_bwd_dispatch_stride": (_i, [_i]),
-    "fsgs_raster_bwd_quad": (_i, [_i, _i, _p, _p, _p, _i64, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p]),
-    "fsgs_raster_bwd_quad_images": (_i, [_p, _p, _p, _i64, _i, _i, _i, _i] + [_p] * 10 + [_i, _p, _i64, _p]),
+    "fsgs_raster_bwd_quad": (_i, [_i, _i, _p, _p, _p, _i64, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _i, _p]),
+    "fsgs_raster_bwd_quad_images": (_i, [_p, _p, _p, _i64, _i, _i, _i, _i] + [_p] * 10 + [_i, _p, _i64, _i, _p]),
     "fsgs_campos_from_viewmats": (_i, [_i, _p, _p, _p]),
     "fsgs_raster_unpack_grads": (_i, [_i64, _i, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p]),
     "fsgs_sh_fwd_split": (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p]),
@@ -83,10 +83,10 @@ SIGNATURES = {
     "fsgs_sh_coeff_grad": (_i, [_i, _i, _i, _i, _p, _p, _f, _p, _p, _p]),
     "fsgs_sh_coeff_grad_adam": (_i, [_i, _i, _i, _i, _p, _p, _f, _p, _p, _p, _f, _p, _p, _p, _f, _i, C.c_double, C.c_double, _f, _p]),
     "fsgs_project_fwd_act": (_i, [_i, _i, _p, _p, _p, _p, _i, _f, _p, _p, _i, _i, _f, _f, _f, _f, _p, _p, _p, _p, _p, _p, _p]),
-    "fsgs_gauss_sh_bwd_adam": (_i, [_i, _i] + [_p] * 11 + [_i, _i, _f] + [_p] * 7 + [_f, _p, _i64, _p, _f, _p]),
-    "fsgs_gauss_sh_bwd_adam_h16": (_i, [_i, _i] + [_p] * 11 + [_i, _i, _f] + [_p] * 7 + [_f, _p, _i64, _p, _f, _p]),
-    "fsgs_gauss_sh_bwd_h16": (_i, [_i, _i] + [_p] * 11 + [_i, _i, _f] + [_p] * 13 + [_f, _p, _i64, _p]),
-    "fsgs_gauss_sh_bwd": (_i, [_i, _i] + [_p] * 11 + [_i, _i, _f] + [_p] * 14 + [_f, _p, _i64, _p]),
+    "fsgs_gauss_sh_bwd_adam": (_i, [_i, _i] + [_p] * 11 + [_i, _i, _f] + [_p] * 7 + [_f, _p, _i64, _p, _f, _i, _p]),
+    "fsgs_gauss_sh_bwd_adam_h16": (_i, [_i, _i] + [_p] * 11 + [_i, _i, _f] + [_p] * 7 + [_f, _p, _i64, _p, _f, _i, _p]),
+    "fsgs_gauss_sh_bwd_h16": (_i, [_i, _i] + [_p] * 11 + [_i, _i, _f] + [_p] * 13 + [_f, _p, _i64, _i, _p]),
+    "fsgs_gauss_sh_bwd": (_i, [_i, _i] + [_p] * 11 + [_i, _i, _f] + [_p] * 14 + [_f, _p, _i64, _i, _p]),
     "fsgs_gaussian_bwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _f, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _f, _p, _i64, _p]),
     "fsgs_activate_fwd": (_i, [_i, _p, _p, _p, _p, _p]),
     "fsgs_activate_bwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),

@@ -21,18 +21,54 @@ struct GaussAdam {
     // min_scale_g * exp(min_k log_scale_k) on the arg-min axis (what fsgs_min_scale_loss adds to the gradient slab after
     // the backward), is added here when the slab does not exist; 0 = no such term
     float min_scale_g;
+    // 1: an element with zero gradient on zero moments is left alone (8 instead of 24 B: its moments are read first,
+    // the parameter only if something changes — a dependent load, for scenes most of whose Gaussians no view has
+    // reached); 0: parameter and moments are read together (one round trip) and every element is stepped.  Same
+    // parameters either way: the skipped update is exactly "nothing changes".
+    int skip_idle;
 };
 
-// element i of group g takes gradient gr (same arithmetic as adam_kernel: common.h adam_one)
-__device__ __forceinline__ void gauss_adam_at(const GaussAdam &a, int g, int64_t i, float gr) {
-    float m = a.m[g][i], v = a.v[g][i];
-    // (zero gradient on zero moments — a Gaussian no view has reached yet: the update is exactly "nothing changes",
-    // so the parameter is not even read and nothing is written: 8 instead of 24 B for this float)
-    if (gr == 0.f && m == 0.f && v == 0.f) return;
-    float p = a.p[g][i];
-    adam_one(p, gr, m, v, a.b1, a.b2, a.omb1, a.omb2, a.ss[g], a.isb2, a.eps);
-    a.p[g][i] = p; a.m[g][i] = m; a.v[g][i] = v;
-    if (a.h[g]) a.h[g][i] = __float2half(p);
+// The eleven geometry elements of Gaussian n (means 3, log-scales 3, quaternion 4, opacity logit 1) take the gradients
+// gr[0..10] — same arithmetic as adam_kernel (common.h adam_one).  All loads of the thread are issued BEFORE its first
+// store (the compiler cannot move a load of element k + 1 above the stores of element k: the pointers may alias as far
+// as it knows, and eleven dependent load -> store round trips per thread were what bounded this launch in round 3):
+// moments of all elements, then — with skip_idle — the parameters of the elements that change, else everything at once.
+__device__ __forceinline__ void gauss_adam_geometry(const GaussAdam &a, int64_t n, const float (&gr)[11]) {
+    constexpr int G[11] = {0, 0, 0, 1, 1, 1, 2, 2, 2, 2, 5};
+    constexpr int W[11] = {3, 3, 3, 3, 3, 3, 4, 4, 4, 4, 1};
+    constexpr int K[11] = {0, 1, 2, 0, 1, 2, 0, 1, 2, 3, 0};
+    float m[11], v[11], p[11];
+    bool act[11];
+#pragma unroll
+    for (int e = 0; e < 11; ++e) {
+        const int64_t i = n * W[e] + K[e];
+        m[e] = a.m[G[e]][i]; v[e] = a.v[G[e]][i];
+    }
+    if (a.skip_idle) {
+        // (zero gradient on zero moments — a Gaussian no view has reached yet: the update is exactly "nothing changes",
+        // so the parameter is not even read and nothing is written: 8 instead of 24 B for this float)
+#pragma unroll
+        for (int e = 0; e < 11; ++e) {
+            act[e] = !(gr[e] == 0.f && m[e] == 0.f && v[e] == 0.f);
+            p[e] = act[e] ? a.p[G[e]][n * W[e] + K[e]] : 0.f;
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 11; ++e) {
+            act[e] = true;
+            p[e] = a.p[G[e]][n * W[e] + K[e]];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 11; ++e)
+        if (act[e]) adam_one(p[e], gr[e], m[e], v[e], a.b1, a.b2, a.omb1, a.omb2, a.ss[G[e]], a.isb2, a.eps);
+#pragma unroll
+    for (int e = 0; e < 11; ++e) {
+        if (!act[e]) continue;
+        const int64_t i = n * W[e] + K[e];
+        a.p[G[e]][i] = p[e]; a.m[G[e]][i] = m[e]; a.v[G[e]][i] = v[e];
+        if (a.h[G[e]]) a.h[G[e]][i] = __float2half(p[e]);
+    }
 }
 
 struct GaussBwdFused {
@@ -301,14 +337,8 @@ __device__ __forceinline__ void gaussian_bwd_one(
         vq.x += vqb.x; vq.y += vqb.y; vq.z += vqb.z; vq.w += vqb.w;
     }
     if (ADAM) {  // (every input of this Gaussian has been read above: its parameters may move now)
-        const float gq[4] = {vq.x, vq.y, vq.z, vq.w};
-#pragma unroll
-        for (int k = 0; k < 3; ++k) gauss_adam_at(fz.adam, 0, (int64_t)n * 3 + k, gm[k]);
-#pragma unroll
-        for (int k = 0; k < 3; ++k) gauss_adam_at(fz.adam, 1, (int64_t)n * 3 + k, gs[k]);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) gauss_adam_at(fz.adam, 2, (int64_t)n * 4 + k, gq[k]);
-        gauss_adam_at(fz.adam, 5, n, go);
+        const float gr[11] = {gm[0], gm[1], gm[2], gs[0], gs[1], gs[2], vq.x, vq.y, vq.z, vq.w, go};
+        gauss_adam_geometry(fz.adam, (int64_t)n, gr);
     } else {
         if (gm_known) { v_means[n * 3 + 0] = gm[0]; v_means[n * 3 + 1] = gm[1]; v_means[n * 3 + 2] = gm[2]; }
         v_scales[n * 3 + 0] = gs[0]; v_scales[n * 3 + 1] = gs[1]; v_scales[n * 3 + 2] = gs[2];

@@ -409,6 +409,8 @@ extern "C" int64_t fsgs_quad_seg_slots(int C, int tile_width, int tile_height, i
 // gradient lines at the same time.  Measured (ms of the launch, row-major vs stride 7): config #2 0.181 / 0.168, config #4
 // 0.720 / 0.611, config #5 0.703 / 0.610 — and config #3 0.209 / 0.279 (there the lines of the large hull Gaussians stay
 // L2-resident under the row-major sweep).  Not decided here: the caller measures (fused.py tunes it per frame shape).
+// The stride is an ARGUMENT of the two launch entry points (dispatch_stride >= 0).  DEPRECATED: a negative argument takes
+// this process-wide default (FSGS_BWD_PERM / fsgs_set_bwd_dispatch_stride), kept for callers written against round 3.
 static std::atomic<int> g_bwd_dispatch_stride{[] {
     const char *e = getenv("FSGS_BWD_PERM");
     return e ? atoi(e) : 0;
@@ -421,7 +423,8 @@ static int launch_bwd_live(int C, int D, const float *records, const int32_t *n_
                            int normalize_last, const float *render, const float *alphas, const int32_t *last_ids,
                            const float *v_render, const float *v_alphas, const float *seg_state, int with_abs,
                            const float *render_extra, const float *v_render_extra, float *v_packed,
-                           fsgs_stream_t stream, GetOutputsGrads ep = GetOutputsGrads{nullptr, nullptr, nullptr, nullptr, nullptr},
+                           fsgs_stream_t stream, int dispatch_stride,
+                           GetOutputsGrads ep = GetOutputsGrads{nullptr, nullptr, nullptr, nullptr, nullptr},
                            int64_t replica_rows = 0) {
     // FSGS_BWD_MERGE_THR16 (A/B switch): a segment walks the union list with merged atomics when its longest row list
     // is >= thr/16 of the union; 0 = always, 17 = never
@@ -441,7 +444,7 @@ static int launch_bwd_live(int C, int D, const float *records, const int32_t *n_
     hipStream_t s = as_stream(stream);
     const dim3 grid(2 * tile_width, 2 * tile_height, C);
     const float4 *rec = reinterpret_cast<const float4 *>(records);
-    int perm_stride = g_bwd_dispatch_stride.load(std::memory_order_relaxed);
+    int perm_stride = dispatch_stride >= 0 ? dispatch_stride : g_bwd_dispatch_stride.load(std::memory_order_relaxed);
     if (perm_stride > 1) {  // coprime with the number of quadrants
         const long long total = 4ll * tile_width * tile_height;
         auto gcd = [](long long a, long long b) { while (b) { const long long t = a % b; a = b; b = t; } return a; };
@@ -473,14 +476,14 @@ extern "C" int fsgs_raster_bwd_quad(int C, int D, const float *records, const in
                                     const float *render, const float *alphas, const int32_t *last_ids,
                                     const float *v_render, const float *v_alphas, const float *seg_state,
                                     int with_abs, const float *render_extra, const float *v_render_extra,
-                                    float *v_packed, fsgs_stream_t stream) {
+                                    float *v_packed, int dispatch_stride, fsgs_stream_t stream) {
     if (n_isects > 0 && !n_rec) return FSGS_EINVAL;
     return launch_bwd_live(C, D, records, n_rec,
                            fsgs_quad_stream_capacity(C, tile_width, tile_height, n_isects),
                            fsgs_quad_seg_slots(C, tile_width, tile_height, n_isects), isect_offsets, n_isects,
                            backgrounds, width, height, tile_width, tile_height, normalize_last, render, alphas,
                            last_ids, v_render, v_alphas, seg_state, with_abs, render_extra, v_render_extra,
-                           v_packed, stream);
+                           v_packed, stream, dispatch_stride);
 }
 
 extern "C" int fsgs_raster_unpack_grads(int64_t total, int D, float *v_packed, int rezero, float *v_means2d,
@@ -504,12 +507,12 @@ extern "C" int fsgs_raster_bwd_quad_images(const float *records, const int32_t *
                                            const float *render_extra, const float *background, const float *v_rgb,
                                            const float *v_depth, const float *v_normal, const float *v_alpha_in,
                                            const float *seg_state, int with_abs, float *v_packed,
-                                           int64_t replica_rows, fsgs_stream_t stream) {
+                                           int64_t replica_rows, int dispatch_stride, fsgs_stream_t stream) {
     if (n_isects > 0 && (!n_rec || !v_rgb || !background)) return FSGS_EINVAL;
     if (!v_rgb || replica_rows < 0) return FSGS_EINVAL;
     const GetOutputsGrads ep = {v_rgb, v_depth, v_normal, v_alpha_in, background};
     return launch_bwd_live(1, 4, records, n_rec, fsgs_quad_stream_capacity(1, tile_width, tile_height, n_isects),
                            fsgs_quad_seg_slots(1, tile_width, tile_height, n_isects), isect_offsets, n_isects, nullptr,
                            width, height, tile_width, tile_height, 1, render, alphas, last_ids, nullptr, nullptr,
-                           seg_state, with_abs, render_extra, nullptr, v_packed, stream, ep, replica_rows);
+                           seg_state, with_abs, render_extra, nullptr, v_packed, stream, dispatch_stride, ep, replica_rows);
 }

@@ -649,8 +649,10 @@ __device__ __forceinline__ void adam_rows(float *__restrict__ P, float *__restri
 }
 
 // the same on a group of a GaussAdam block (fsgs_gauss_sh_bwd_adam), with the group's half mirror if it has one; U
-// float4 triples (parameter, both moments) are in flight per thread before the first store
-template <int RF, int U = 4>
+// float4 triples (parameter, both moments) are in flight per thread before the first store.  SKIP (GaussAdam::skip_idle):
+// the moments are read first and the parameter only where something changes — a second, dependent round trip; without
+// it all three streams are read at once and every element is stepped (identical parameters: a skipped update is a no-op).
+template <int RF, int U, bool SKIP>
 __device__ __forceinline__ void adam_rows_g(const GaussAdam &a, int grp, int64_t first, int rows, const float *lds,
                                             int pitch, int col_off) {
     float4 *__restrict__ const P4 = reinterpret_cast<float4 *>(a.p[grp] + first);
@@ -672,6 +674,7 @@ __device__ __forceinline__ void adam_rows_g(const GaussAdam &a, int grp, int64_t
             idle[u] = true;
             if (i < total4) {
                 m[u] = M4[i]; v[u] = V4[i];
+                if (!SKIP) p[u] = P4[i];
                 const int e = i << 2;
                 int r = e / RF, col = e - r * RF;
 #pragma unroll
@@ -681,15 +684,19 @@ __device__ __forceinline__ void adam_rows_g(const GaussAdam &a, int grp, int64_t
                 }
             }
         }
-        // zero gradients on zero moments (Gaussians no view has reached yet): nothing changes — the parameters are not
-        // read and nothing is written (32 instead of 96 B per float4)
+        // SKIP: zero gradients on zero moments (Gaussians no view has reached yet): nothing changes — the parameters are
+        // not read and nothing is written (32 instead of 96 B per float4)
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int i = i0 + u * kShBlock;
             if (i < total4) {
-                auto z4 = [](const float4 q) { return q.x == 0.f && q.y == 0.f && q.z == 0.f && q.w == 0.f; };
-                idle[u] = z4(m[u]) && z4(v[u]) && g[u][0] == 0.f && g[u][1] == 0.f && g[u][2] == 0.f && g[u][3] == 0.f;
-                if (!idle[u]) p[u] = P4[i];
+                if (SKIP) {
+                    auto z4 = [](const float4 q) { return q.x == 0.f && q.y == 0.f && q.z == 0.f && q.w == 0.f; };
+                    idle[u] = z4(m[u]) && z4(v[u]) && g[u][0] == 0.f && g[u][1] == 0.f && g[u][2] == 0.f && g[u][3] == 0.f;
+                    if (!idle[u]) p[u] = P4[i];
+                } else {
+                    idle[u] = false;
+                }
             }
         }
 #pragma unroll
@@ -1003,6 +1010,10 @@ struct GaussShArgs {
     int lazy_sh;
 };
 
+#ifndef FSGS_ADAM_ROWS_U
+#define FSGS_ADAM_ROWS_U 6
+#endif
+constexpr int kAdamRowsU = FSGS_ADAM_ROWS_U;  // float4 triples in flight per thread in the cooperative Adam of the features
 template <bool HALF, bool ADAM>
 __global__ void __launch_bounds__(kShBlock) __attribute__((amdgpu_waves_per_eu(3, 3)))
 gauss_sh_bwd_kernel(GaussShArgs A, GaussBwdFused fz) {
@@ -1073,15 +1084,21 @@ gauss_sh_bwd_kernel(GaussShArgs A, GaussBwdFused fz) {
     if (A.v_rgb_masked) return;
     __syncthreads();
     if (ADAM) {  // (every thread of the block has read its coefficients: the block's rows may move)
-        adam_rows_g<3>(fz.adam, 3, (int64_t)n0 * 3, rows, lds, pitch, 0);
-        adam_rows_g<45>(fz.adam, 4, (int64_t)n0 * 45, rows, lds, pitch, 3);
+        if (fz.adam.skip_idle) {
+            adam_rows_g<3, 4, true>(fz.adam, 3, (int64_t)n0 * 3, rows, lds, pitch, 0);
+            adam_rows_g<45, 4, true>(fz.adam, 4, (int64_t)n0 * 45, rows, lds, pitch, 3);
+        } else {
+            adam_rows_g<3, 1, false>(fz.adam, 3, (int64_t)n0 * 3, rows, lds, pitch, 0);
+            adam_rows_g<45, kAdamRowsU, false>(fz.adam, 4, (int64_t)n0 * 45, rows, lds, pitch, 3);
+        }
         return;
     }
     unstage_rows<3>(A.v_dc + (int64_t)n0 * 3, rows, 3, lds, pitch, 0);
     unstage_rows<45>(A.v_rest + (int64_t)n0 * 45, rows, 45, lds, pitch, 3);
 }
 
-// from this many Gaussians on, fsgs_gauss_sh_bwd fetches coefficients lazily (GaussShArgs::lazy_sh)
+// DEPRECATED process-wide default for callers that pass flags < 0 (round-3 behaviour): from this many Gaussians on,
+// fsgs_gauss_sh_bwd fetches coefficients lazily and skips idle Adam elements.  The flags argument decides per launch.
 static std::atomic<int> g_lazy_sh_min_n{[] {
     const char *e = getenv("FSGS_LAZY_SH_MIN_N");
     return e ? atoi(e) : (1 << 20);
@@ -1096,7 +1113,8 @@ static int gauss_sh_bwd_impl(int N, int degree, const float *means, const float 
                              float *v_rgb_masked, float *v_means, float *v_quats, float *v_log_scales,
                              float *v_opac_logit, float *absgrad, float *xys_grad_norm, float *vis_counts,
                              float *max_2Dsize, float inv_max_hw, const uint8_t *frozen, int64_t replica_rows,
-                             fsgs_stream_t stream, const fsgs_adam_groups *adam = nullptr, float min_scale_g = 0.f) {
+                             fsgs_stream_t stream, const fsgs_adam_groups *adam = nullptr, float min_scale_g = 0.f,
+                             int flags = -1) {
     if (N < 0 || degree < 0 || degree > 3 || replica_rows < 0) return FSGS_EINVAL;
     if (N == 0) return FSGS_OK;
     if (!means || !campos || !features_dc || !features_rest || !quats || !log_scales || !scales || !opac || !viewmat ||
@@ -1126,7 +1144,11 @@ static int gauss_sh_bwd_impl(int N, int degree, const float *means, const float 
     GaussShArgs A = {means, campos, features_dc, features_rest, quats, scales, viewmat, K, radii, conics,
                      v_features_dc, v_features_rest, v_means, v_quats, v_log_scales,
                      reinterpret_cast<float4 *>(v_rgb_masked), N, degree, width, height, eps2d, 0};
-    A.lazy_sh = N >= g_lazy_sh_min_n.load(std::memory_order_relaxed) ? 1 : 0;
+    // flags >= 0: FSGS_GSB_LAZY_COEFFS (1) | FSGS_GSB_SKIP_IDLE (2) as the caller decided for THIS launch; flags < 0
+    // (deprecated): the process-wide threshold of fsgs_set_lazy_sh_min_n decides both from N
+    if (flags < 0) flags = N >= g_lazy_sh_min_n.load(std::memory_order_relaxed) ? 3 : 0;
+    A.lazy_sh = (flags & 1) ? 1 : 0;
+    ga.skip_idle = (flags & 2) ? 1 : 0;
     GaussBwdFused fz{};
     fz.v_packed = reinterpret_cast<float4 *>(v_packed);
     fz.log_scales = log_scales; fz.opac = opac; fz.c2w = c2w; fz.absgrad = absgrad; fz.v_opac_logit = v_opac_logit;
@@ -1154,11 +1176,11 @@ extern "C" int fsgs_gauss_sh_bwd(int N, int degree, const float *means, const fl
                                  float *v_rgb_masked, float *v_means, float *v_quats, float *v_log_scales,
                                  float *v_opac_logit, float *absgrad, float *xys_grad_norm, float *vis_counts,
                                  float *max_2Dsize, float inv_max_hw, const uint8_t *frozen, int64_t replica_rows,
-                                 fsgs_stream_t stream) {
+                                 int flags, fsgs_stream_t stream) {
     return gauss_sh_bwd_impl(N, degree, means, campos, features_dc, features_rest, quats, log_scales, 0, scales, opac,
                              viewmat, K, c2w, width, height, eps2d, radii, conics, v_packed, v_features_dc,
                              v_features_rest, v_rgb_masked, v_means, v_quats, v_log_scales, v_opac_logit, absgrad,
-                             xys_grad_norm, vis_counts, max_2Dsize, inv_max_hw, frozen, replica_rows, stream);
+                             xys_grad_norm, vis_counts, max_2Dsize, inv_max_hw, frozen, replica_rows, stream, nullptr, 0.f, flags);
 }
 
 // half attribute storage (features, quats, log_scales as IEEE-half mirrors; the gradients stay fp32)
@@ -1170,11 +1192,11 @@ extern "C" int fsgs_gauss_sh_bwd_h16(int N, int degree, const float *means, cons
                                      float *v_features_dc, float *v_features_rest, float *v_means, float *v_quats,
                                      float *v_log_scales, float *v_opac_logit, float *absgrad, float *xys_grad_norm,
                                      float *vis_counts, float *max_2Dsize, float inv_max_hw, const uint8_t *frozen,
-                                     int64_t replica_rows, fsgs_stream_t stream) {
+                                     int64_t replica_rows, int flags, fsgs_stream_t stream) {
     return gauss_sh_bwd_impl(N, degree, means, campos, features_dc_h, features_rest_h, quats_h, log_scales_h, 1, scales,
                              opac, viewmat, K, c2w, width, height, eps2d, radii, conics, v_packed, v_features_dc,
                              v_features_rest, nullptr, v_means, v_quats, v_log_scales, v_opac_logit, absgrad,
-                             xys_grad_norm, vis_counts, max_2Dsize, inv_max_hw, frozen, replica_rows, stream);
+                             xys_grad_norm, vis_counts, max_2Dsize, inv_max_hw, frozen, replica_rows, stream, nullptr, 0.f, flags);
 }
 
 // fsgs_gauss_sh_bwd / _h16 with the Adam step of all six parameter groups applied where the gradients are formed (the
@@ -1187,12 +1209,12 @@ extern "C" int fsgs_gauss_sh_bwd_adam(int N, int degree, const float *means, con
                                       const float *conics, float *v_packed, float *absgrad, float *xys_grad_norm,
                                       float *vis_counts, float *max_2Dsize, float inv_max_hw, const uint8_t *frozen,
                                       int64_t replica_rows, const fsgs_adam_groups *adam, float min_scale_g,
-                                      fsgs_stream_t stream) {
+                                      int flags, fsgs_stream_t stream) {
     if (!adam) return FSGS_EINVAL;
     return gauss_sh_bwd_impl(N, degree, means, campos, features_dc, features_rest, quats, log_scales, 0, scales, opac,
                              viewmat, K, c2w, width, height, eps2d, radii, conics, v_packed, nullptr, nullptr, nullptr,
                              nullptr, nullptr, nullptr, nullptr, absgrad, xys_grad_norm, vis_counts, max_2Dsize,
-                             inv_max_hw, frozen, replica_rows, stream, adam, min_scale_g);
+                             inv_max_hw, frozen, replica_rows, stream, adam, min_scale_g, flags);
 }
 
 extern "C" int fsgs_gauss_sh_bwd_adam_h16(int N, int degree, const float *means, const float *campos,
@@ -1202,14 +1224,14 @@ extern "C" int fsgs_gauss_sh_bwd_adam_h16(int N, int degree, const float *means,
                                           float eps2d, const int32_t *radii, const float *conics, float *v_packed,
                                           float *absgrad, float *xys_grad_norm, float *vis_counts, float *max_2Dsize,
                                           float inv_max_hw, const uint8_t *frozen, int64_t replica_rows,
-                                          const fsgs_adam_groups *adam, float min_scale_g, fsgs_stream_t stream) {
+                                          const fsgs_adam_groups *adam, float min_scale_g, int flags, fsgs_stream_t stream) {
     if (!adam) return FSGS_EINVAL;
     for (int g = 1; g < 6; ++g)  // (the render path reads the mirrors: every group but the means must have one)
         if (g != 0 && !adam->half_mirror[g]) return FSGS_EINVAL;
     return gauss_sh_bwd_impl(N, degree, means, campos, features_dc_h, features_rest_h, quats_h, log_scales_h, 1, scales,
                              opac, viewmat, K, c2w, width, height, eps2d, radii, conics, v_packed, nullptr, nullptr,
                              nullptr, nullptr, nullptr, nullptr, nullptr, absgrad, xys_grad_norm, vis_counts, max_2Dsize,
-                             inv_max_hw, frozen, replica_rows, stream, adam, min_scale_g);
+                             inv_max_hw, frozen, replica_rows, stream, adam, min_scale_g, flags);
 }
 
 static int sh_bwd_impl(int C, int N, int K, int degree, const float *means, const float *campos,

@@ -150,6 +150,10 @@ def _grad_accumulator(dev, N: int) -> Tensor:
 
 
 IMAGE_GRADS_IN_BWD = os.environ.get("FSGS_IMAGE_GRADS_IN_BWD", "1") != "0"
+# from this many Gaussians on, the per-Gaussian backward fetches SH coefficients lazily / skips idle Adam elements
+# (flags of fsgs_gauss_sh_bwd*, decided here per launch; module attributes so that tests can move them)
+LAZY_SH_MIN_N = int(os.environ.get("FSGS_LAZY_SH_MIN_N", str(1 << 20)))
+SKIP_IDLE_MIN_N = int(os.environ.get("FSGS_SKIP_IDLE_MIN_N", str(1 << 20)))
 # from this many Gaussians on, the SH forward evaluates only Gaussians that are in some tile's list (fsgs.h: kept)
 KEPT_MIN_N = int(os.environ.get("FSGS_KEPT_MIN_N", str(1 << 20)))
 
@@ -167,19 +171,19 @@ class _BwdDispatchTuner:
     def __init__(self):
         self.state: Dict = {}
         self.forced = os.environ.get("FSGS_BWD_PERM", "auto") != "auto"
+        self.forced_stride = int(os.environ.get("FSGS_BWD_PERM", "0")) if self.forced else 0
 
     def launch(self, key, n: int, acc: Tensor, fn):
-        """Runs ``fn(acc)`` — the launch, accumulating into ``acc`` — under the stride to use for this frame."""
+        """Runs ``fn(acc, stride)`` — the launch, accumulating into ``acc``, quadrants dispatched ``stride`` apart — with
+        the stride to use for this frame (an argument of the launch: nothing process-wide is set)."""
         if self.forced:
-            return fn(acc)
-        lib = load()
+            return fn(acc, self.forced_stride)
         st = self.state.get(key)
         if st is None or (st["decided"] is not None and abs(n - st["n_ref"]) > 0.25 * st["n_ref"]):
             st = self.state[key] = dict(n_ref=n, frames=0, pending=[], total={c: 0.0 for c in self.CANDIDATES}, pairs=0,
                                         decided=None, scratch=None)
         if st["decided"] is not None:
-            lib.fsgs_set_bwd_dispatch_stride(st["decided"])
-            return fn(acc)
+            return fn(acc, st["decided"])
         st["frames"] += 1
         for item in list(st["pending"]):  # harvest finished pairs
             if item[-1].query():
@@ -195,24 +199,23 @@ class _BwdDispatchTuner:
         if st["pairs"] >= (2 * self.PAIRS if close else self.PAIRS):
             st["decided"] = other if t[other] < (1.0 - self.MIN_GAIN) * t[base] else base
             st["medians_ms"] = {c: t[c] / st["pairs"] for c in self.CANDIDATES}  # (means of the paired launches)
-            st["scratch"] = None
-            lib.fsgs_set_bwd_dispatch_stride(st["decided"])
-            return fn(acc)
+            st["scratch"] = None  # (freed: nothing reads it)
+            return fn(acc, st["decided"])
         if st["frames"] <= self.WARM or st["pairs"] + len(st["pending"]) >= (2 * self.PAIRS if close else self.PAIRS):
-            lib.fsgs_set_bwd_dispatch_stride(self.CANDIDATES[0])
-            return fn(acc)
+            return fn(acc, self.CANDIDATES[0])
         if st["scratch"] is None or st["scratch"].shape != acc.shape:
             st["scratch"] = torch.zeros_like(acc)
+        else:
+            st["scratch"].zero_()  # (per pair: it would otherwise drift to inf / NaN over the pairs)
         order = self.CANDIDATES if st["frames"] % 2 == 0 else self.CANDIDATES[::-1]
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
-        lib.fsgs_set_bwd_dispatch_stride(order[0])
         ev[0].record()
-        out = fn(acc)
+        out = fn(acc, order[0])
         ev[1].record()
-        lib.fsgs_set_bwd_dispatch_stride(order[1])
         ev[2].record()
-        fn(st["scratch"])  # (same inputs, the other order, results discarded)
+        fn(st["scratch"], order[1])  # (same inputs, the other order, results discarded)
         ev[3].record()
+        st["tuning_frames"] = st.get("tuning_frames", 0) + 1
         st["pending"].append(((order[0], ev[0], ev[1]), (order[1], ev[2], ev[3]), ev[3]))
         return out
 
@@ -434,11 +437,11 @@ class _FusedGetOutputs(torch.autograd.Function):
         if v_rgb is not None and IMAGE_GRADS_IN_BWD:
             # the image gradients go straight into the compositing backward, which derives v_render / v_alphas /
             # v_render_extra per pixel itself (no epilogue launch, no 32 B/pixel round trip)
-            BWD_DISPATCH.launch((str(dev), W, H), N, v_packed, lambda acc: _run(
+            BWD_DISPATCH.launch((str(dev), W, H), N, v_packed, lambda acc, stride: _run(
                 lib.fsgs_raster_bwd_quad_images, (ptr(records), ptr(n_rec), ptr(offsets), M, W, H, tw, th, ptr(render),
                                                   ptr(alphas), ptr(last_ids), ptr(render_extra), ptr(background),
                                                   ptr(v_rgb), ptr(v_depth), ptr(v_normal), ptr(v_alpha_out),
-                                                  ptr(seg_state), 1, ptr(acc), rep_rows, sp),
+                                                  ptr(seg_state), 1, ptr(acc), rep_rows, int(stride), sp),
                 "fsgs_raster_bwd_quad", "_d4e3"))
         else:
             v_render = torch.empty(1, H, W, 4, **f32)
@@ -450,7 +453,7 @@ class _FusedGetOutputs(torch.autograd.Function):
             _run(lib.fsgs_raster_bwd_quad, (1, 4, ptr(records), ptr(n_rec), ptr(offsets), M, None, W, H, tw, th, 1,
                                            ptr(render), ptr(alphas), ptr(last_ids), ptr(v_render), ptr(v_alphas),
                                            ptr(seg_state), 1, ptr(render_extra), ptr(v_render_extra), ptr(v_packed),
-                                           sp), "fsgs_raster_bwd_quad", "_d4e3")
+                                           0, sp), "fsgs_raster_bwd_quad", "_d4e3")
         WORKSPACE.give(getattr(ctx, "arena", None))
         ctx.arena = None
 
@@ -479,6 +482,9 @@ class _FusedGetOutputs(torch.autograd.Function):
             # mean of the ranks' coefficient gradients in the slab (16 B instead of 192 B per Gaussian on the links)
             assert hm is None, "the factored feature exchange reads fp32 features (trainer switches it off)"
             assert tuple(factors.shape) == (N + 1, 4) and factors.is_contiguous()
+        # per-launch switches of the per-Gaussian backward (fsgs.h: FSGS_GSB_*): lazy coefficient fetch and idle-element
+        # skipping both turn independent loads into dependent ones — they pay where most gradient lines are empty
+        gsb_flags = (1 if N >= LAZY_SH_MIN_N else 0) | (2 if N >= SKIP_IDLE_MIN_N else 0)
         aib = ctx.info.adam_in_backward
         if aib is not None and factors is None and K == 16 and sh_degree <= 3 and ONE_LAUNCH_GAUSSIAN_BWD:
             # the step's Adam update rides in this launch: the gradients are applied where they are formed and never
@@ -490,14 +496,15 @@ class _FusedGetOutputs(torch.autograd.Function):
             _run(f, (N, sh_degree, ptr(means), ptr(cam["campos"]), ptr(src["features_dc"]), ptr(src["features_rest"]),
                      ptr(src["quats"]), ptr(src["scales"]), ptr(scales_exp), ptr(opac_sig), ptr(cam["viewmat"]),
                      ptr(cam["K"]), ptr(cam["c2w"]), W, H, 0.3, ptr(radii), ptr(conics), ptr(v_packed), ptr(v_abs))
-                 + stat_args[:-1] + (C.byref(aib), float(ctx.info.min_scale_g), sp), "fsgs_gaussian_bwd")
+                 + stat_args[:-1] + (C.byref(aib), float(ctx.info.min_scale_g), gsb_flags, sp), "fsgs_gaussian_bwd")
             ctx.info.adam_applied = True
         elif hm is not None and K == 16 and sh_degree <= 3 and ONE_LAUNCH_GAUSSIAN_BWD:
             _run(lib.fsgs_gauss_sh_bwd_h16,
                  (N, sh_degree, ptr(means), ptr(cam["campos"]), ptr(hm["features_dc"]), ptr(hm["features_rest"]),
                   ptr(hm["quats"]), ptr(hm["scales"]), ptr(scales_exp), ptr(opac_sig), ptr(cam["viewmat"]), ptr(cam["K"]),
                   ptr(cam["c2w"]), W, H, 0.3, ptr(radii), ptr(conics), ptr(v_packed), ptr(g_dc), ptr(g_rest),
-                  ptr(g_means), ptr(g_quats), ptr(g_scales), ptr(g_opac), ptr(v_abs)) + stat_args, "fsgs_gaussian_bwd")
+                  ptr(g_means), ptr(g_quats), ptr(g_scales), ptr(g_opac), ptr(v_abs)) + stat_args[:-1] + (gsb_flags, sp),
+                 "fsgs_gaussian_bwd")
         elif hm is None and K == 16 and sh_degree <= 3 and ONE_LAUNCH_GAUSSIAN_BWD:
             # the SH backward and everything else per Gaussian (projection / normal / activation VJPs, absgrad,
             # statistics) in one launch, one thread per Gaussian
@@ -506,7 +513,8 @@ class _FusedGetOutputs(torch.autograd.Function):
                   ptr(scales), ptr(scales_exp), ptr(opac_sig), ptr(cam["viewmat"]), ptr(cam["K"]), ptr(cam["c2w"]), W, H,
                   0.3, ptr(radii), ptr(conics), ptr(v_packed), None if factors is not None else ptr(g_dc),
                   None if factors is not None else ptr(g_rest), ptr(factors) if factors is not None else None,
-                  ptr(g_means), ptr(g_quats), ptr(g_scales), ptr(g_opac), ptr(v_abs)) + stat_args, "fsgs_gaussian_bwd")
+                  ptr(g_means), ptr(g_quats), ptr(g_scales), ptr(g_opac), ptr(v_abs)) + stat_args[:-1] + (gsb_flags, sp),
+                 "fsgs_gaussian_bwd")
         else:
             # SH: colour gradients are the first floats of the packed records; writes the view-direction share of v_means
             if hm is not None:

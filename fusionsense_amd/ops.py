@@ -99,6 +99,11 @@ def _run(fn, args, what: str, tag: str = "") -> None:
     check(rc, what)
 
 
+# dispatch order of the compositing backward on the drop-in route (an argument of the launch; the fused node measures
+# its own per frame shape, fused._BwdDispatchTuner): row-major unless FSGS_BWD_PERM=<stride> asks otherwise
+DROPIN_BWD_STRIDE = int(os.environ.get("FSGS_BWD_PERM", "0")) if os.environ.get("FSGS_BWD_PERM", "auto") != "auto" else 0
+
+
 def tile_bits(n_tiles: int) -> int:
     return int(math.floor(math.log2(n_tiles))) + 1 if n_tiles > 0 else 1
 
@@ -825,7 +830,7 @@ class _Rasterize(torch.autograd.Function):
                                            int(normalize_last), ptr(render), ptr(alphas), ptr(last_ids),
                                            ptr(v_render), ptr(v_alphas),
                                            ptr(seg_state), int(bool(absgrad)), None, None, ptr(v_packed),
-                                           stream_ptr(dev)),
+                                           DROPIN_BWD_STRIDE, stream_ptr(dev)),
                  "fsgs_raster_bwd_quad", f"_d{D}")
             v_means2d = torch.empty(Cn, N, 2, dtype=torch.float32, device=dev)
             v_conics = torch.empty(Cn, N, 3, dtype=torch.float32, device=dev)

@@ -17,6 +17,11 @@
  *     the ONLY call that synchronises is fsgs_isect_count (it returns n_isects to the host,
  *     the same point at which the reference syncs)
  *   - return 0 on success, a negative FSGS_E* code otherwise; never throws; re-entrant
+ *   - no global state: everything a launch depends on is an argument of the call (since round 4 that includes the
+ *     dispatch order of the compositing backward and the lazy / idle-skipping switches of the per-Gaussian backward).
+ *     The two process-wide setters of round 3 — fsgs_set_bwd_dispatch_stride, fsgs_set_lazy_sh_min_n — remain as
+ *     DEPRECATED defaults that only a caller passing a negative value for the corresponding argument ever reads;
+ *     A/B switches read from the environment (FSGS_*) are build / debugging aids and never change results
  */
 #ifndef FSGS_H
 #define FSGS_H
@@ -257,12 +262,14 @@ int fsgs_raster_bwd_quad(int C, int D, const float *records, const int32_t *n_re
                          const float *render, const float *alphas, const int32_t *last_ids,
                          const float *v_render, const float *v_alphas, const float *seg_state,
                          int with_abs, const float *render_extra, const float *v_render_extra,
-                         float *v_packed, fsgs_stream_t stream);
-/* Dispatch order of the backward compositing launches that follow (fsgs_raster_bwd_quad, fsgs_raster_bwd_quad_images):
- * 0 or 1 = quadrants in row-major order, k > 1 = consecutive workgroups take quadrants k apart (raised to the next value
- * coprime with the number of quadrants).  Same gradients up to the order of the float atomics; which order is faster
- * depends on the scene (neighbouring quadrants share Gaussians and collide on their gradient lines; far-apart ones lose
- * the L2 residency of those lines), so callers measure.  Returns the previous value; initial value: env FSGS_BWD_PERM or 0. */
+                         float *v_packed, int dispatch_stride, fsgs_stream_t stream);
+/* dispatch_stride (fsgs_raster_bwd_quad, fsgs_raster_bwd_quad_images) — the dispatch order of THIS launch's quadrants:
+ * 0 or 1 = row-major, k > 1 = consecutive workgroups take quadrants k apart (raised to the next value coprime with the
+ * number of quadrants).  Same gradients up to the order of the float atomics; which order is faster depends on the scene
+ * (neighbouring quadrants share Gaussians and collide on their gradient lines; far-apart ones lose the L2 residency of
+ * those lines), so callers measure (fusionsense_amd/fused.py does, per frame shape).  A launch argument since round 4: no
+ * state outlives the call.  DEPRECATED: a negative value takes the process-wide default that
+ * fsgs_set_bwd_dispatch_stride sets (initially env FSGS_BWD_PERM or 0; returns the previous value) — round-3 callers. */
 int fsgs_set_bwd_dispatch_stride(int stride);
 
 /* fsgs_epilogue_bwd + fsgs_raster_bwd_quad for FusionSense's get_outputs (one camera; RGB + expected depth and the
@@ -275,7 +282,7 @@ int fsgs_raster_bwd_quad_images(const float *records, const int32_t *n_rec, cons
                                 const float *render_extra, const float *background, const float *v_rgb,
                                 const float *v_depth, const float *v_normal, const float *v_alpha_in,
                                 const float *seg_state, int with_abs, float *v_packed, int64_t replica_rows,
-                                fsgs_stream_t stream);
+                                int dispatch_stride, fsgs_stream_t stream);
 /* replica_rows (here and in fsgs_gaussian_bwd; 0 = off): Gaussians with a large 2-D footprint (det(conic) < 1/4096)
  * own FOUR gradient lines, replica_rows rows apart in v_packed ([4 * replica_rows, 16], zeroed): the compositing
  * backward picks the replica from the tile and the 8x8 quadrant, so that the hundreds of workgroups a large Gaussian
@@ -506,9 +513,18 @@ int fsgs_gaussian_bwd(int N, const float *means, const float *quats, const float
                       float *xys_grad_norm, float *vis_counts, float *max_2Dsize, float inv_max_hw,
                       const uint8_t *frozen, int64_t replica_rows,
                           fsgs_stream_t stream);
-/* fsgs_gauss_sh_bwd(_h16) with N >= this threshold fetches a Gaussian's SH coefficients only after its gradient line,
- * and only if the line carries a colour gradient (dense scenes: most lines are empty; same outputs, 192 B less read per
- * empty line, at the price of a dependent load).  Default 2^20 (env FSGS_LAZY_SH_MIN_N); returns the previous value. */
+/* flags of fsgs_gauss_sh_bwd / _h16 / _adam / _adam_h16 (per launch; the outputs are the same numbers either way):
+ *   FSGS_GSB_LAZY_COEFFS  a Gaussian's SH coefficients are fetched only after its gradient line, and only if the line
+ *                         carries a colour gradient (dense scenes: most lines are empty; 192 B less read per empty line,
+ *                         at the price of a dependent load);
+ *   FSGS_GSB_SKIP_IDLE    (_adam) an element with zero gradient on zero moments is left alone: its moments are read
+ *                         first and the parameter only if something changes (8 instead of 24 B for such a float, a
+ *                         dependent load for the others) — for scenes most of whose Gaussians no view has reached yet;
+ *                         without it parameter and moments are read together and every element is stepped.
+ * DEPRECATED: flags < 0 = both on from the process-wide threshold of fsgs_set_lazy_sh_min_n on (default 2^20, env
+ * FSGS_LAZY_SH_MIN_N; returns the previous value), the round-3 behaviour. */
+#define FSGS_GSB_LAZY_COEFFS 1
+#define FSGS_GSB_SKIP_IDLE 2
 int fsgs_set_lazy_sh_min_n(int n);
 
 /* fsgs_sh_bwd_split (or, with v_rgb_masked != NULL, fsgs_sh_bwd_colors) for one camera, K = 16 stored coefficients
@@ -522,7 +538,7 @@ int fsgs_gauss_sh_bwd(int N, int degree, const float *means, const float *campos
                       float eps2d, const int32_t *radii, const float *conics, float *v_packed, float *v_features_dc,
                       float *v_features_rest, float *v_rgb_masked, float *v_means, float *v_quats, float *v_log_scales,
                       float *v_opac_logit, float *absgrad, float *xys_grad_norm, float *vis_counts, float *max_2Dsize,
-                      float inv_max_hw, const uint8_t *frozen, int64_t replica_rows, fsgs_stream_t stream);
+                      float inv_max_hw, const uint8_t *frozen, int64_t replica_rows, int flags, fsgs_stream_t stream);
 /* fsgs_gauss_sh_bwd on half attribute storage (features, quats, log_scales read from IEEE-half mirrors; all
  * gradients fp32; no factored output). */
 int fsgs_gauss_sh_bwd_h16(int N, int degree, const float *means, const float *campos, const void *features_dc_h,
@@ -532,7 +548,7 @@ int fsgs_gauss_sh_bwd_h16(int N, int degree, const float *means, const float *ca
                           float *v_features_dc, float *v_features_rest, float *v_means, float *v_quats,
                           float *v_log_scales, float *v_opac_logit, float *absgrad, float *xys_grad_norm,
                           float *vis_counts, float *max_2Dsize, float inv_max_hw, const uint8_t *frozen,
-                          int64_t replica_rows, fsgs_stream_t stream);
+                          int64_t replica_rows, int flags, fsgs_stream_t stream);
 /* fsgs_gauss_sh_bwd / _h16 with the Adam step of all six parameter groups (dn_config.py:36-75) applied where the
  * gradients are formed: no gradient is written (236 B per Gaussian less written here and less read by the Adam launch
  * this replaces; same update, bit for bit, as fsgs_adam_step on the gradients fsgs_gauss_sh_bwd writes).  adam: exactly
@@ -548,7 +564,7 @@ int fsgs_gauss_sh_bwd_adam(int N, int degree, const float *means, const float *c
                            int height, float eps2d, const int32_t *radii, const float *conics, float *v_packed,
                            float *absgrad, float *xys_grad_norm, float *vis_counts, float *max_2Dsize, float inv_max_hw,
                            const uint8_t *frozen, int64_t replica_rows, const fsgs_adam_groups *adam, float min_scale_g,
-                           fsgs_stream_t stream);
+                           int flags, fsgs_stream_t stream);
 int fsgs_gauss_sh_bwd_adam_h16(int N, int degree, const float *means, const float *campos, const void *features_dc_h,
                                const void *features_rest_h, const void *quats_h, const void *log_scales_h,
                                const float *scales, const float *opac, const float *viewmat, const float *K,
@@ -556,7 +572,7 @@ int fsgs_gauss_sh_bwd_adam_h16(int N, int degree, const float *means, const floa
                                const float *conics, float *v_packed, float *absgrad, float *xys_grad_norm,
                                float *vis_counts, float *max_2Dsize, float inv_max_hw, const uint8_t *frozen,
                                int64_t replica_rows, const fsgs_adam_groups *adam, float min_scale_g,
-                               fsgs_stream_t stream);
+                               int flags, fsgs_stream_t stream);
 /* frozen (nullable, [N] u8): rows whose v_means / v_log_scales / v_opac_logit are zero — FusionSense's touch
  * anchors, detached at dn_model.py:535-541 (their quaternion and colour gradients still flow). */
 /* dn_model.py:602-613, 655-656: rgb = clamp(render[:3] + (1-alpha) bg, 0, 1); depth = alpha > 0 ?

@@ -5,7 +5,8 @@ TEST INFRASTRUCTURE ONLY — never imported by the product path (fusionsense_amd
 Pinning:
   * everything FusionSense's own code adds (mask handling :702-714, EdgeAwareLogL1 with the valid mask :721-736 and
     losses.py:177-214, TV on depth :752-760 and losses.py:269-285, normal L1 + TV :809-815, min-scale :817-819,
-    touch-normal MSE :893-904) is PINNED: tests/golden/reference_loss.npz holds values and gradients produced by
+    touch-normal MSE :893-904; round 4: normals from depth :774-795, EdgeAwareTV :757-760, the cosine term :807-813,
+    the L1 / LogL1 / MSE depth-loss types :731-736) is PINNED: tests/golden/reference_loss.npz holds values and gradients produced by
     executing the reference's own method (tests/golden/make_reference_loss_goldens.py), and
     tests/test_oracle.py::test_loss_oracle_matches_reference_goldens checks this file against them.
   * the photometric term (1-l)*L1 + l*(1-SSIM) comes from nerfstudio 1.1.3 ``SplatfactoModel.get_loss_dict`` with
@@ -39,6 +40,12 @@ class LossConfig:
     normal_lambda: float = 0.4          # configs/config.py:10
     two_d_gaussians: bool = True        # dn_model.py:98
     touch_normal_loss_lambda: float = 1.0  # dn_model.py:901
+    # switches that are off in FusionSense's configuration (round 4; pinned by the ndepth / eatv / cosine / l1 / logl1 /
+    # mse cases of reference_loss.npz, which the reference's own get_loss_dict produced)
+    normal_supervision: str = "mono"    # dn_model.py:84 default "depth"; configs/config.py:15 passes "mono"
+    smooth_loss_type: str = "TV"        # dn_model.py:66 ("TV" | "EdgeAwareTV")
+    use_normal_cosine_loss: bool = False  # dn_model.py:80
+    depth_loss_type: str = "EdgeAwareLogL1"  # dn_model.py:62 ("EdgeAwareLogL1" | "L1" | "LogL1" | "MSE")
 
 
 def ssim_torchmetrics(pred: Tensor, gt: Tensor, kernel_size: int = 11, sigma: float = 1.5,
@@ -95,10 +102,54 @@ def tv(pred: Tensor) -> Tensor:
     return torch.mean(torch.abs(pred[:, :-1, :] - pred[:, 1:, :])) + torch.mean(torch.abs(pred[:-1, :, :] - pred[1:, :, :]))
 
 
+def edge_aware_tv(depth: Tensor, rgb: Tensor) -> Tensor:
+    """losses.py:241-266 (EdgeAwareTV): |d depth| weighted by exp(-mean_c |d rgb|), mean over each shifted grid."""
+    gdx = torch.abs(depth[:, :-1, :] - depth[:, 1:, :])
+    gdy = torch.abs(depth[:-1, :, :] - depth[1:, :, :])
+    gix = torch.mean(torch.abs(rgb[:, :-1, :] - rgb[:, 1:, :]), -1, keepdim=True)
+    giy = torch.mean(torch.abs(rgb[:-1, :, :] - rgb[1:, :, :]), -1, keepdim=True)
+    return (gdx * torch.exp(-gix)).mean() + (gdy * torch.exp(-giy)).mean()
+
+
+def normal_from_depth(depth: Tensor, fx: float, fy: float, cx: float, cy: float) -> Tensor:
+    """utils/normal_utils.py:23-46 with c2w = identity, smooth = False (as dn_model.py:779-789 calls it) over
+    utils/camera_utils.py:92-144: every pixel centre (x + 0.5, y + 0.5) is back-projected with its z-depth, the
+    normal of an interior pixel is normalize(cross(right - left, top - bottom)), the one-pixel border is zero."""
+    H, W = depth.shape[0], depth.shape[1]
+    d = depth.reshape(H, W)
+    ys, xs = torch.meshgrid(torch.arange(H, dtype=d.dtype), torch.arange(W, dtype=d.dtype), indexing="ij")
+    xyz = torch.stack([(xs + 0.5 - cx) * d / fx, (ys + 0.5 - cy) * d / fy, d], dim=-1)
+    l2r = xyz[1:H - 1, 2:W] - xyz[1:H - 1, 0:W - 2]
+    b2t = xyz[0:H - 2, 1:W - 1] - xyz[2:H, 1:W - 1]
+    n = F.normalize(torch.cross(l2r, b2t, dim=-1), p=2, dim=-1)
+    return F.pad(n.permute(2, 0, 1), (1, 1, 1, 1)).permute(1, 2, 0)
+
+
+def mean_angular_error_as_called(pred_hw3: Tensor, gt_hw3: Tensor) -> Tensor:
+    """dn_model.py:807-813 calls metrics.mean_angular_error (metrics.py:58-73, written for [B,3,H,W]) with [3,H,W]
+    tensors: its ``sum(dim=1)`` then runs over the image ROWS — one dot product per (channel, column).  Reproduced as
+    called: acos(clamp(sum_y gt * pred, -1, 1)) over [3, W], mean."""
+    p = (pred_hw3.permute(2, 0, 1) - 1) / 2
+    g = (gt_hw3.permute(2, 0, 1) - 1) / 2
+    return torch.acos(torch.clamp(torch.sum(g * p, dim=1), -1.0, 1.0)).mean()
+
+
+def plain_depth_loss(kind: str, pred: Tensor, gt: Tensor) -> Tensor:
+    """losses.py: L1 (:147-158), LogL1 (:161-174), torch.nn.MSELoss — on the VALID pixels (dn_model.py:731-736)."""
+    if kind == "L1":
+        return torch.abs(pred - gt).mean()
+    if kind == "LogL1":
+        return torch.log(1 + torch.abs(pred - gt)).mean()
+    if kind == "MSE":
+        return ((pred - gt) ** 2).mean()
+    raise ValueError(kind)
+
+
 def dn_terms(outputs: Dict[str, Tensor], batch: Dict[str, Tensor], log_scales: Tensor,
              normals_world: Optional[Tensor], add_mask: Optional[Tensor], touch_normals: Optional[Tensor],
-             cfg: LossConfig) -> Tensor:
-    """What dn_model.py:673-925 adds to splatfacto's main loss (sensor-depth + mono-normal configuration)."""
+             cfg: LossConfig, intrinsics=None) -> Tensor:
+    """What dn_model.py:673-925 adds to splatfacto's main loss.  ``intrinsics`` = (fx, fy, cx, cy) of the camera of the
+    last get_outputs, read by ``normal_supervision == "depth"`` (:775-786)."""
     gt_img = batch["image"].clamp(min=10 / 255.0)                      # :692
     depth_out = outputs["depth"]
     sensor = batch.get("sensor_depth")
@@ -116,17 +167,32 @@ def dn_terms(outputs: Dict[str, Tensor], batch: Dict[str, Tensor], log_scales: T
             normal_gt = normal_gt * mask
         pred_normal = pred_normal * mask
     depth_loss = 0
-    if cfg.use_depth_loss and sensor is not None and cfg.sensor_depth_lambda > 0.0:   # :720-728
+    edge = cfg.depth_loss_type == "EdgeAwareLogL1"
+    if cfg.use_depth_loss and sensor is not None and cfg.sensor_depth_lambda > 0.0:   # :720-736
         valid = sensor > cfg.depth_tolerance
-        depth_loss = depth_loss + cfg.sensor_depth_lambda * edge_aware_log_l1(depth_out, sensor.float(), gt_img, valid)
-    if cfg.use_depth_loss and mono is not None and cfg.mono_depth_lambda > 0.0:       # :737-745 (EdgeAwareLogL1)
-        valid = mono > cfg.depth_tolerance
-        depth_loss = depth_loss + cfg.mono_depth_lambda * edge_aware_log_l1(depth_out, mono.float(), gt_img, valid)
-    if cfg.use_depth_smooth_loss:                                      # :752-755
-        depth_loss = depth_loss + cfg.smooth_loss_lambda * tv(depth_out)
+        term = (edge_aware_log_l1(depth_out, sensor.float(), gt_img, valid) if edge else
+                plain_depth_loss(cfg.depth_loss_type, depth_out[valid], sensor[valid].float()))
+        depth_loss = depth_loss + cfg.sensor_depth_lambda * term
+    if cfg.use_depth_loss and mono is not None and cfg.mono_depth_lambda > 0.0:       # :737-750
+        valid = mono > (cfg.depth_tolerance if edge else 0.0)          # (the plain types test > 0, :739)
+        term = (edge_aware_log_l1(depth_out, mono.float(), gt_img, valid) if edge else
+                plain_depth_loss(cfg.depth_loss_type, depth_out[valid], mono[valid].float()))
+        depth_loss = depth_loss + cfg.mono_depth_lambda * term
+    if cfg.use_depth_smooth_loss:                                      # :752-760
+        sm = tv(depth_out) if cfg.smooth_loss_type == "TV" else edge_aware_tv(depth_out, gt_img)
+        depth_loss = depth_loss + cfg.smooth_loss_lambda * sm
     normal_loss = 0
-    if cfg.use_normal_loss:                                            # :770-815 (normal_supervision == "mono")
-        normal_loss = normal_loss + torch.abs(normal_gt - pred_normal).mean()
+    if cfg.use_normal_loss:                                            # :770-815
+        if cfg.normal_supervision == "depth":                          # :774-795: pseudo normals of the (masked) depth
+            fx, fy, cx, cy = intrinsics
+            gt_normal = normal_from_depth(depth_out.detach(), fx, fy, cx, cy)
+            gt_normal = gt_normal * torch.tensor([1.0, -1.0, -1.0], dtype=gt_normal.dtype)
+            gt_normal = (1 + gt_normal) / 2
+        else:
+            gt_normal = normal_gt
+        normal_loss = normal_loss + torch.abs(gt_normal - pred_normal).mean()
+        if cfg.use_normal_cosine_loss:                                 # :807-813
+            normal_loss = normal_loss + mean_angular_error_as_called(pred_normal, gt_normal)
         if cfg.use_normal_tv_loss:
             normal_loss = normal_loss + tv(pred_normal)
     if cfg.two_d_gaussians:                                            # :817-819
@@ -143,9 +209,10 @@ def dn_terms(outputs: Dict[str, Tensor], batch: Dict[str, Tensor], log_scales: T
 
 def get_loss_dict(outputs: Dict[str, Tensor], batch: Dict[str, Tensor], log_scales: Tensor,
                   normals_world: Optional[Tensor] = None, add_mask: Optional[Tensor] = None,
-                  touch_normals: Optional[Tensor] = None, cfg: Optional[LossConfig] = None) -> Dict[str, Tensor]:
+                  touch_normals: Optional[Tensor] = None, cfg: Optional[LossConfig] = None,
+                  intrinsics=None) -> Dict[str, Tensor]:
     """{"main_loss", "scale_reg"} as the reference returns them (nerfstudio's Trainer sums the values)."""
     cfg = cfg or LossConfig()
     main = photometric_loss(outputs["rgb"], batch["image"], batch.get("mask"), cfg.ssim_lambda)
-    main = main + dn_terms(outputs, batch, log_scales, normals_world, add_mask, touch_normals, cfg)
+    main = main + dn_terms(outputs, batch, log_scales, normals_world, add_mask, touch_normals, cfg, intrinsics)
     return {"main_loss": main, "scale_reg": torch.zeros((), dtype=main.dtype)}

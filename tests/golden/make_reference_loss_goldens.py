@@ -53,17 +53,23 @@ def _splatfacto_standin():
     return m
 
 
-def case(model_mod, losses, seed, H, W, n_gauss, with_mask, with_touch, holes, mono=None):
+def case(model_mod, losses, seed, H, W, n_gauss, with_mask, with_touch, holes, mono=None, normal_supervision=None,
+         smooth="TV", cosine=False, depth_type="EdgeAwareLogL1", intr=None):
+    """Round 4: the switches that are OFF in FusionSense's configuration but reachable from scripts/train.py:117-145 /
+    the model config — ``normal_supervision="depth"`` (pseudo normals from the rendered depth, dn_model.py:774-795 with
+    utils/normal_utils.py:8-46 executed as is), ``smooth="EdgeAwareTV"`` (:757-760, losses.py:241-266), ``cosine``
+    (:807-813 with metrics.mean_angular_error) and the plain depth-loss types L1 / LogL1 / MSE (:731-736)."""
     g = torch.Generator().manual_seed(seed)
     cfgd = {}
     sys.path.insert(0, os.path.join(base.REF, "configs"))
     import config as ref_cfg  # /root/reference/configs/config.py: the values scripts/train.py passes on
     cfg = types.SimpleNamespace(
         use_depth_loss=ref_cfg.use_depth_loss, sensor_depth_lambda=ref_cfg.sensor_depth_lambda,
-        depth_tolerance=0.1, depth_loss_type=losses.DepthLossType.EdgeAwareLogL1, mono_depth_lambda=0.2,
-        use_depth_smooth_loss=ref_cfg.use_depth_smooth_loss, smooth_loss_type=losses.DepthLossType.TV,
-        smooth_loss_lambda=0.1, use_normal_loss=ref_cfg.use_normal_loss, normal_supervision=ref_cfg.normal_supervision,
-        use_normal_cosine_loss=False, use_normal_tv_loss=True, normal_lambda=ref_cfg.normal_lambda,
+        depth_tolerance=0.1, depth_loss_type=getattr(losses.DepthLossType, depth_type), mono_depth_lambda=0.2,
+        use_depth_smooth_loss=ref_cfg.use_depth_smooth_loss, smooth_loss_type=getattr(losses.DepthLossType, smooth),
+        smooth_loss_lambda=0.1, use_normal_loss=ref_cfg.use_normal_loss,
+        normal_supervision=normal_supervision or ref_cfg.normal_supervision,
+        use_normal_cosine_loss=bool(cosine), use_normal_tv_loss=True, normal_lambda=ref_cfg.normal_lambda,
         two_d_gaussians=True, use_sparse_loss=False, use_sdf_loss=False, sdf_loss_lambda=0.1,
         reset_alpha_every=30, refine_every=100)
     self = object.__new__(model_mod.DNSplatterModel)
@@ -71,7 +77,12 @@ def case(model_mod, losses, seed, H, W, n_gauss, with_mask, with_touch, holes, m
     self.device = torch.device("cpu")
     self.step = 7  # (not a multiple of 100: the reference writes a debug JPEG there)
     self.depth_loss = losses.DepthLoss(cfg.depth_loss_type)
-    self.smooth_loss = losses.DepthLoss(depth_loss_type=losses.DepthLossType.TV)
+    self.smooth_loss = losses.DepthLoss(depth_loss_type=getattr(losses.DepthLossType, smooth))  # (dn_model.py:239-242)
+    if intr is not None:  # what the "depth" normal supervision reads from the last get_outputs' camera (:775-786)
+        t1 = lambda v: torch.tensor([[float(v)]])  # noqa: E731
+        self.camera = types.SimpleNamespace(camera_to_worlds=torch.eye(4)[None, :3], fx=t1(intr[0]), fy=t1(intr[1]),
+                                            cx=t1(intr[2]), cy=t1(intr[3]), width=torch.tensor([[W]]),
+                                            height=torch.tensor([[H]]))
     self.tv_loss = losses.TVLoss()
     scales = (torch.randn(n_gauss, 3, generator=g) * 0.7 - 4.0).requires_grad_(True)
     normals_world = torch.nn.functional.normalize(torch.randn(n_gauss, 3, generator=g), dim=-1)
@@ -119,7 +130,10 @@ def case(model_mod, losses, seed, H, W, n_gauss, with_mask, with_touch, holes, m
                 normals_world=normals_world, n_touch=np.array(n_touch), touch_normals=tn,
                 loss=loss.detach(), v_depth=depth.grad, v_normal=normal.grad, v_scales=scales.grad,
                 **({} if mono is None else dict(mono_depth=mono_depth, mono_only=np.array(mono == "only"),
-                                                mono_depth_lambda=np.array(cfg.mono_depth_lambda, dtype=np.float32))))
+                                                mono_depth_lambda=np.array(cfg.mono_depth_lambda, dtype=np.float32))),
+                **({} if intr is None else dict(intr=np.array(intr, dtype=np.float64))),
+                **({} if (normal_supervision is None and smooth == "TV" and not cosine and depth_type == "EdgeAwareLogL1")
+                   else dict(switches=np.array([normal_supervision or "mono", smooth, "cosine" if cosine else "", depth_type]))))
 
 
 def main():
@@ -130,12 +144,38 @@ def main():
     sys.modules["nerfstudio.models"].splatfacto = sys.modules["nerfstudio.models.splatfacto"]
     losses = base._load(os.path.join(base.REF, "dn_splatter", "losses.py"), "dn_splatter.losses")
     model = base._load(os.path.join(base.REF, "dn_splatter", "dn_model.py"), "dn_splatter.dn_model")
+    # the real helpers of the "depth" normal supervision and of the cosine term (numpy + torch only)
+    cu = base._load(os.path.join(base.REF, "dn_splatter", "utils", "camera_utils.py"), "dn_splatter.utils.camera_utils")
+    nu = base._load(os.path.join(base.REF, "dn_splatter", "utils", "normal_utils.py"), "dn_splatter.utils.normal_utils")
+    model.normal_from_depth_image = nu.normal_from_depth_image
+    mt = sys.modules.get("dn_splatter.metrics")
+    if mt is None or isinstance(mt, base._Stub):
+        mt = types.ModuleType("dn_splatter.metrics")
+        sys.modules["dn_splatter.metrics"] = mt
+    import re
+    src = open(os.path.join(base.REF, "dn_splatter", "metrics.py")).read()
+    fn = re.search(r"^def mean_angular_error\(.*?(?=^\S)", src, re.S | re.M).group(0)  # (the function alone: the module imports torchmetrics)
+    exec(compile("import torch\n" + fn, "dn_splatter/metrics.py:mean_angular_error", "exec"), mt.__dict__)
     out = {}
     cases = {"full": dict(seed=1, H=24, W=40, n_gauss=50, with_mask=True, with_touch=True, holes=True),
              "nomask": dict(seed=2, H=17, W=33, n_gauss=30, with_mask=False, with_touch=False, holes=True),
              "dense": dict(seed=3, H=32, W=32, n_gauss=64, with_mask=True, with_touch=True, holes=False),
              "mono": dict(seed=4, H=21, W=37, n_gauss=40, with_mask=True, with_touch=False, holes=True, mono="both"),
-             "monoonly": dict(seed=5, H=19, W=26, n_gauss=20, with_mask=False, with_touch=False, holes=True, mono="only")}
+             "monoonly": dict(seed=5, H=19, W=26, n_gauss=20, with_mask=False, with_touch=False, holes=True, mono="only"),
+             # ---- round 4: the remaining switches ----
+             "ndepth": dict(seed=6, H=22, W=35, n_gauss=30, with_mask=True, with_touch=False, holes=True,
+                            normal_supervision="depth", intr=(30.0, 28.0, 17.5, 11.0)),
+             "ndepth_nomask": dict(seed=7, H=18, W=27, n_gauss=20, with_mask=False, with_touch=True, holes=False,
+                                   normal_supervision="depth", intr=(25.0, 25.0, 13.0, 9.5)),
+             "eatv": dict(seed=8, H=20, W=31, n_gauss=25, with_mask=True, with_touch=False, holes=True, smooth="EdgeAwareTV"),
+             "cosine": dict(seed=9, H=6, W=29, n_gauss=20, with_mask=True, with_touch=False, holes=True, cosine=True),
+             "cosine_depth": dict(seed=10, H=5, W=24, n_gauss=20, with_mask=False, with_touch=False, holes=False, cosine=True,
+                                  normal_supervision="depth", intr=(20.0, 20.0, 12.0, 2.5)),
+             "l1": dict(seed=11, H=19, W=30, n_gauss=20, with_mask=True, with_touch=False, holes=True, depth_type="L1"),
+             "logl1": dict(seed=12, H=19, W=30, n_gauss=20, with_mask=False, with_touch=False, holes=True, depth_type="LogL1",
+                           mono="both"),
+             "mse": dict(seed=13, H=16, W=28, n_gauss=20, with_mask=True, with_touch=False, holes=True, depth_type="MSE",
+                         smooth="EdgeAwareTV")}
     for name, kw in cases.items():
         for k, v in case(model, losses, **kw).items():
             out[f"{name}.{k}"] = v.numpy() if torch.is_tensor(v) else v

@@ -650,9 +650,11 @@ def test_level_set_extraction_over_the_hip_forward(dev, case):
     fx, fy, cx, cy, W, H = (float(x) for x in d["intr"])
     W, H = int(W), int(H)
     cam = scenes.Camera(t("c2w"), fx, fy, cx, cy, W, H)
-    tr = SplatTrainer(params, dev, sh_degree=3)
+    tr = SplatTrainer(params, dev, sh_degree=3, sh_degree_interval=1000)
+    tr.step = 100  # (the golden's model was at step 100: sh_degree_to_use = 100 // 1000 = 0, dn_model.py:562-565)
     o = tr.forward(cam)
     assert rel_err(o["depth"], t("render.depth")) < 1e-4 and rel_err(o["normals_world"], t("render.normals_world")) < 1e-5
+    assert rel_err(o["rgb"], t("render.rgb")) < 1e-4
     mode = ["closest_gaussian", "analytical"][int(d[f"{case}.mode"])]
     mask = t("mask") if bool(d[f"{case}.use_mask"]) else None
     res = inf.compute_level_surface_points(tr, cam, 10 ** 9, mask, (0.1, 0.3, 0.5), mode,
@@ -673,7 +675,8 @@ def test_level_set_extraction_over_the_hip_forward(dev, case):
         assert float(close.float().mean()) > 0.97, (lv, float(close.float().mean()))
         ok_n = (got_n[close] - ref_n[ib][close]).abs().max(dim=-1).values < (2e-2 if mode == "analytical" else 1e-3)
         assert float(ok_n.float().mean()) > 0.97, (lv, float(ok_n.float().mean()))
-        assert torch.allclose(got_c[close], ref_c[ib][close], atol=2e-4)
+        dc = (got_c[close] - ref_c[ib][close]).abs().max(dim=-1).values  # (rgb: 1e-4 of the image, but for the pixels
+        assert float((dc < 5e-4).float().mean()) > 0.99 and float(dc.max()) <= 1.0 / 255.0 + 1e-4, (lv, float(dc.max()))  # on an alpha >= 1/255 decision)
     # the extractor's loop: points of three cameras, per level, sub-sampled per frame
     cams = [cam, scenes.Camera(scenes.look_at_c2w(torch.tensor([2.0, 1.0, 1.2]), torch.zeros(3)), fx, fy, cx, cy, W, H),
             scenes.Camera(scenes.look_at_c2w(torch.tensor([-1.5, 2.0, 0.4]), torch.zeros(3)), fx, fy, cx, cy, W, H)]

@@ -587,7 +587,8 @@ def test_training_with_densification_converges(dev, dense_machinery, monkeypatch
         from fusionsense_amd._lib import load
         tr.occlusion_cut_mode = "1"
         monkeypatch.setattr(fused, "KEPT_MIN_N", 0)
-        prev_lazy = load().fsgs_set_lazy_sh_min_n(0)
+        monkeypatch.setattr(fused, "LAZY_SH_MIN_N", 0)
+        monkeypatch.setattr(fused, "SKIP_IDLE_MIN_N", 0)
     gt = SplatTrainer(scenes.lego_like_scene(N0, seed=1), dev, sh_degree=3)
     with torch.no_grad():
         tg = []
@@ -603,7 +604,6 @@ def test_training_with_densification_converges(dev, dense_machinery, monkeypatch
             first = last if first is None else first
             sizes.add(tr.num_gaussians())
     if dense_machinery:
-        load().fsgs_set_lazy_sh_min_n(prev_lazy)
         assert tr.cut_frames > 1000 and tr.cut_redone < tr.cut_frames // 4, (tr.cut_frames, tr.cut_redone)
     assert tr.adam_in_backward_steps == 1500
     assert last < first / 3.0, (first, last)

@@ -202,7 +202,7 @@ def test_cuts_outlive_a_rebuild_and_are_dropped_by_an_opacity_reset(dev):
 def test_unlisted_gaussians_are_skipped_without_changing_anything(dev, dense_scene, monkeypatch):
     """Dense scenes (N >= 2^20): the count pass marks the Gaussians that are in any tile's list (``kept``), the riding
     SH forward skips the others, and the per-Gaussian backward fetches coefficients only for lines with a colour
-    gradient (fsgs_set_lazy_sh_min_n).  Both are pure savings: flags exact against the lists, images and every
+    gradient (FSGS_GSB_LAZY_COEFFS, a per-launch flag).  Both are pure savings: flags exact against the lists, images and every
     parameter gradient equal to the eager route's — with and without occlusion cuts."""
     from fusionsense_amd import fused
     from fusionsense_amd._lib import load
@@ -212,7 +212,9 @@ def test_unlisted_gaussians_are_skipped_without_changing_anything(dev, dense_sce
 
     def frames(eager, cuts):
         monkeypatch.setattr(fused, "KEPT_MIN_N", 1 << 30 if eager else 1 << 20)
-        prev = lib.fsgs_set_lazy_sh_min_n(1 << 30 if eager else 1 << 20)
+        monkeypatch.setattr(fused, "LAZY_SH_MIN_N", 1 << 30 if eager else 1 << 20)  # (FSGS_GSB_LAZY_COEFFS per launch)
+        monkeypatch.setattr(fused, "SKIP_IDLE_MIN_N", 1 << 30 if eager else 1 << 20)
+        prev = lib.fsgs_set_lazy_sh_min_n(0 if eager else 1 << 30)  # (the deprecated default, set the OTHER way: it must not matter)
         try:
             tr = SplatTrainer(params, dev, sh_degree=3)
             tr.occlusion_cut_mode = "1" if cuts else "0"
@@ -447,9 +449,9 @@ def test_new_entry_points_reject_bad_arguments_and_take_empty_scenes(dev):
     g = AdamGroups()
     g.n_groups = 5
     common = (0, 3) + (None,) * 11 + (16, 16, 0.3) + (None,) * 7 + (0.0, None, 0)
-    assert lib.fsgs_gauss_sh_bwd_adam(*common, C.byref(g), 0.0, sp) == 0, "N = 0: nothing to do"
-    assert lib.fsgs_gauss_sh_bwd_adam(*common, None, 0.0, sp) == EINVAL
-    assert lib.fsgs_set_lazy_sh_min_n(lib.fsgs_set_lazy_sh_min_n(123)) == 123
+    assert lib.fsgs_gauss_sh_bwd_adam(*common, C.byref(g), 0.0, 0, sp) == 0, "N = 0: nothing to do"
+    assert lib.fsgs_gauss_sh_bwd_adam(*common, None, 0.0, 3, sp) == EINVAL
+    assert lib.fsgs_set_lazy_sh_min_n(lib.fsgs_set_lazy_sh_min_n(123)) == 123  # (deprecated default, flags < 0 only)
 
 
 @pytest.mark.parametrize("margins", [(0.05, 0.0, 0.0), (0.3, 0.01, 0.1), (1.0, 0.03, 0.25)])
@@ -494,8 +496,9 @@ def test_every_frame_is_exact_whatever_the_margins(dev, margins):
 
 
 def test_backward_dispatch_order_changes_nothing_but_the_speed(dev):
-    """fsgs_set_bwd_dispatch_stride: consecutive workgroups of the compositing backward take quadrants k apart instead of
-    neighbours.  Every quadrant is still processed exactly once (odd image sizes, strides that are not coprime with the
+    """dispatch_stride of fsgs_raster_bwd_quad_images (an argument of the launch since round 4; the process-wide setter
+    of round 3 is a deprecated default): consecutive workgroups of the compositing backward take quadrants k apart
+    instead of neighbours.  Every quadrant is still processed exactly once (odd image sizes, strides that are not coprime with the
     number of quadrants are raised to the next coprime), so the gradients agree to the float atomics' reordering; and the
     trainer's tuner measures both orders and settles on one."""
     from fusionsense_amd import fused
@@ -508,12 +511,13 @@ def test_backward_dispatch_order_changes_nothing_but_the_speed(dev):
     tgt = {"rgb": torch.rand(207, 333, 3, generator=g).to(dev), "depth": torch.rand(207, 333, 1, generator=g).to(dev) * 4,
            "normal": torch.rand(207, 333, 3, generator=g).to(dev)}
     tr = SplatTrainer(params, dev, sh_degree=3)
-    fused.BWD_DISPATCH.forced, keep = True, fused.BWD_DISPATCH.forced
-    prev = lib.fsgs_set_bwd_dispatch_stride(0)
+    keep = (fused.BWD_DISPATCH.forced, fused.BWD_DISPATCH.forced_stride)
+    fused.BWD_DISPATCH.forced = True
+    prev = lib.fsgs_set_bwd_dispatch_stride(5)  # (the deprecated process-wide default: must not reach these launches)
     try:
         grads = {}
         for stride in (0, 2, 7, 13, 1092):  # (2, 13 and 1092 = 42 * 26 share factors with the 1092 quadrants)
-            assert lib.fsgs_set_bwd_dispatch_stride(stride) is not None
+            fused.BWD_DISPATCH.forced_stride = stride
             tr.train_step(cams[0], tgt, optimizer_step=False)
             grads[stride] = {k: tr.slab.views[k].clone() for k in PARAM_ORDER}
         for stride in (2, 7, 13, 1092):
@@ -521,8 +525,8 @@ def test_backward_dispatch_order_changes_nothing_but_the_speed(dev):
                 assert rel_err(grads[stride][k], grads[0][k]) < 2e-4, (stride, k)
                 assert torch.equal(grads[stride][k] == 0, grads[0][k] == 0), (stride, k)  # the same Gaussians are reached
     finally:
-        lib.fsgs_set_bwd_dispatch_stride(prev)
-        fused.BWD_DISPATCH.forced = keep
+        assert lib.fsgs_set_bwd_dispatch_stride(prev) == 5
+        fused.BWD_DISPATCH.forced, fused.BWD_DISPATCH.forced_stride = keep
     # the tuner: a few frames of each order, then a decision that is kept
     if not fused.BWD_DISPATCH.forced:
         key = (str(dev), 333, 207)
@@ -533,4 +537,3 @@ def test_backward_dispatch_order_changes_nothing_but_the_speed(dev):
         st = fused.BWD_DISPATCH.state[key]
         assert st["decided"] in fused.BWD_DISPATCH.CANDIDATES and set(st["medians_ms"]) == set(fused.BWD_DISPATCH.CANDIDATES)
         assert st["scratch"] is None and st["pairs"] >= fused.BWD_DISPATCH.PAIRS
-        lib.fsgs_set_bwd_dispatch_stride(0)

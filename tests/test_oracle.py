@@ -204,7 +204,22 @@ def test_config1_full_frame_matches_committed_checksum():
     assert np.array_equal(meta["isect_offsets"].numpy(), g["cfg1_offsets"])
 
 
-@pytest.mark.parametrize("case", ["full", "nomask", "dense", "mono", "monoonly"])
+LOSS_CASES = ["full", "nomask", "dense", "mono", "monoonly",
+              "ndepth", "ndepth_nomask", "eatv", "cosine", "cosine_depth", "l1", "logl1", "mse"]  # (round 4: the other switches)
+
+
+def loss_case_config(d, case, cls):
+    """The LossConfig of a reference_loss.npz case (``<case>.switches`` = normal supervision, smooth type, cosine, depth
+    type; absent for FusionSense's own configuration) and the camera intrinsics the depth-normal supervision read."""
+    kw = {}
+    if f"{case}.switches" in d.files:
+        ns, sm, cs, dt = (str(x) for x in d[f"{case}.switches"])
+        kw = dict(normal_supervision=ns, smooth_loss_type=sm, use_normal_cosine_loss=(cs == "cosine"), depth_loss_type=dt)
+    intr = tuple(float(x) for x in d[f"{case}.intr"]) if f"{case}.intr" in d.files else None
+    return cls(**kw), intr
+
+
+@pytest.mark.parametrize("case", LOSS_CASES)
 def test_loss_oracle_matches_reference_goldens(case):
     """oracle/loss_ref.dn_terms against numbers produced by EXECUTING the reference's own
     DNSplatterModel.get_loss_dict (tests/golden/make_reference_loss_goldens.py): value and the gradients with
@@ -228,8 +243,9 @@ def test_loss_oracle_matches_reference_goldens(case):
         add_mask = torch.zeros(scales.shape[0], dtype=torch.bool)
         add_mask[-n_touch:] = True
     out = {"rgb": t("rgb"), "depth": depth, "normal": normal}
+    cfg, intr = loss_case_config(d, case, loss_ref.LossConfig)
     loss = loss_ref.dn_terms(out, batch, scales, t("normals_world"), add_mask, t("touch_normals") if n_touch else None,
-                             loss_ref.LossConfig())
+                             cfg, intr)
     loss.backward()
     assert abs(float(loss) - float(d[f"{case}.loss"])) <= 1e-6 * abs(float(d[f"{case}.loss"]))
     for name, g in (("v_depth", depth.grad), ("v_normal", normal.grad), ("v_scales", scales.grad)):
