@@ -119,7 +119,10 @@ SIGNATURES = {
     "fsgs_ssim_l1_fwd_masked": (_i, [_i, _i, _p, _p, _p, _p, _p, _p, _p, _p]),
     "fsgs_ssim_l1_bwd_masked": (_i, [_i, _i, _p, _p, _p, _p, _p, _p, _p, _f, _f, _p, _i, _p, _p, _p, _p, _f, _p, _p]),
     "fsgs_fusion_aux_num_partials": (_i64, [_i, _i]),
-    "fsgs_fusion_aux_loss": (_i, [_i, _i, _p, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p, _p]),
+    "fsgs_fusion_aux_loss": (_i, [_i, _i, _p, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p, _i, _p]),
+    "fsgs_normals_from_depth": (_i, [_i, _i, _p, _p, _f, _f, _f, _f, _p, _p]),
+    "fsgs_normal_cosine_num_partials": (_i64, [_i]),
+    "fsgs_normal_cosine_loss": (_i, [_i, _i, _p, _p, _p, _i, _f, _p, _p, _p, _p]),
     "fsgs_depth_valid_counts": (_i, [_i, _i, _p, _p, _f, _p, _p]),
     "fsgs_min_scale_loss": (_i, [_i, _p, _f, _p, _p, _p, _p]),
     "fsgs_touch_normal_sqerr": (_i, [_i, _p, _p, _p, _p, _p]),

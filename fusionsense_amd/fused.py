@@ -683,7 +683,8 @@ def fused_step_forward_backward(gauss_params: Dict[str, Tensor], camera: Camera,
                 int(sh_degree), background, info, grad_out)
             lctx = _DirectCtx((True, True, True, False) + (False,) * 7)
             loss = ops._FusionLoss.forward(lctx, rgb, depth, normal, gauss_params["scales"].data, target, cfg,
-                                           info.normals_world, touch_idx, touch_normals, seed_grad, True)
+                                           info.normals_world, touch_idx, touch_normals, seed_grad, True,
+                                           (camera.fx, camera.fy, camera.cx, camera.cy))
             check_live_total(ctx)
             g_min = lctx.g[3]
             info.min_scale_g = g_min  # (an Adam step carried by the backward takes the term's gradient with it)

@@ -16,9 +16,11 @@ autograd tape and under nerfstudio's own optimizers and callbacks:
 surface to the HIP path as well — same method names, same arguments, still driven by nerfstudio's Trainer, its
 callbacks and its ``Optimizers`` (round 3):
 
-    get_loss_dict      dn_model.py:673-925   -> ops._FusionLoss over a cached FrameBatch (one autograd node); the original
-                                                stays as ``_get_loss_dict_reference`` and is used for every switch the node
-                                                does not cover (normals from depth, cosine / sparse / SDF terms, other depth-loss types)
+    get_loss_dict      dn_model.py:673-925   -> ops._FusionLoss over a cached FrameBatch (one autograd node: every switch
+                                                reachable from scripts/train.py — incl. normals from depth — and
+                                                EdgeAwareTV, the cosine term, the L1 / LogL1 / MSE depth losses); the
+                                                original stays as ``_get_loss_dict_reference`` for the sparse / SDF /
+                                                scale-regularisation terms and HuberL1
     get_metrics_dict   dn_model.py:927-1003  -> the per-iteration PSNR / SSIM / depth metrics on the device, one transfer
     after_train        (nerfstudio, A.2)     -> nothing to do: the statistics were applied by the node's backward
     refinement_after   dn_model.py:326-451   -> DensifyStrategy.refinement_after (HIP row compaction, split sampling)
@@ -76,6 +78,7 @@ def get_outputs_fused(self, camera) -> Dict[str, torch.Tensor]:
     self.last_size = (H, W)
     cam = Camera(c2w.reshape(-1, 3, 4)[0].detach().cpu().float(), float(K[0, 0]), float(K[1, 1]), float(K[0, 2]),
                  float(K[1, 2]), W, H)
+    self.__dict__["_fsgs_intrinsics"] = (cam.fx, cam.fy, cam.cx, cam.cy)
     dev = self.gauss_params["means"].device
     sh_degree_to_use = min(self.step // cfg.sh_degree_interval, cfg.sh_degree)
     background = self._get_background_color().to(device=dev, dtype=torch.float32)
@@ -136,15 +139,24 @@ def _loss_config(cfg):
     def name_of(v):  # enum member / string -> lower-case name
         return str(getattr(v, "name", v)).lower()
     g = lambda k, d=None: getattr(cfg, k, d)  # noqa: E731
+    # not evaluated by the node (the reference's own torch code runs them): the PhysGaussian scale regularisation, the
+    # sparse-opacity term and the SuGaR-style SDF term (:821-882), HuberL1 (a global maximum inside the loss)
     if g("use_scale_regularization", False) or g("use_sparse_loss", False) or g("use_sdf_loss", False):
         return None
-    if g("use_normal_cosine_loss", False) or (g("use_normal_loss", False) and g("normal_supervision", "mono") != "mono"):
+    types = {"edgeawarelogl1": "EdgeAwareLogL1", "l1": "L1", "logl1": "LogL1", "mse": "MSE"}
+    dtype = types.get(name_of(g("depth_loss_type", "EdgeAwareLogL1")).split(".")[-1])
+    if g("use_depth_loss", False) and dtype is None:
         return None
-    if g("use_depth_loss", False) and "edgeawarelogl1" not in name_of(g("depth_loss_type", "EdgeAwareLogL1")):
+    smooth = {"tv": "TV", "edgeawaretv": "EdgeAwareTV"}.get(name_of(g("smooth_loss_type", "TV")).split(".")[-1])
+    if g("use_depth_smooth_loss", False) and smooth is None:
         return None
-    if g("use_depth_smooth_loss", False) and name_of(g("smooth_loss_type", "TV")).split(".")[-1] != "tv":
+    supervision = str(g("normal_supervision", "mono"))
+    if g("use_normal_loss", False) and supervision not in ("mono", "depth"):
         return None
-    return LossConfig(ssim_lambda=float(g("ssim_lambda", 0.2)), use_depth_loss=bool(g("use_depth_loss", False)),
+    return LossConfig(normal_supervision=supervision, smooth_loss_type=smooth or "TV",
+                      use_normal_cosine_loss=bool(g("use_normal_cosine_loss", False)),
+                      depth_loss_type=dtype or "EdgeAwareLogL1",
+                      ssim_lambda=float(g("ssim_lambda", 0.2)), use_depth_loss=bool(g("use_depth_loss", False)),
                       sensor_depth_lambda=float(g("sensor_depth_lambda", 0.0)),
                       mono_depth_lambda=float(g("mono_depth_lambda", 0.0)),
                       depth_tolerance=float(g("depth_tolerance", 0.1)),
@@ -293,6 +305,16 @@ class SupervisionCache:
         return fb
 
 
+def _intrinsics_of(model):
+    """(fx, fy, cx, cy) of the camera of the model's last get_outputs — what normal_supervision == "depth" reads from
+    ``self.camera`` (dn_model.py:775-786)."""
+    cam = getattr(model, "camera", None)
+    try:
+        return (float(cam.fx.item()), float(cam.fy.item()), float(cam.cx.item()), float(cam.cy.item()))
+    except (AttributeError, ValueError, RuntimeError):
+        return model.__dict__.get("_fsgs_intrinsics")
+
+
 def get_loss_dict_fused(self, outputs, batch, metrics_dict=None) -> Dict[str, torch.Tensor]:
     """Drop-in for ``DNSplatterModel.get_loss_dict`` (dn_model.py:673-925): ``main_loss`` is one HIP autograd node over
     the view's supervision, prepared once per (split, ``image_idx``) and kept on the device (``self._fsgs_frames``, a
@@ -304,7 +326,8 @@ def get_loss_dict_fused(self, outputs, batch, metrics_dict=None) -> Dict[str, to
     cfg = _loss_config(self.config)
     rgb = outputs.get("rgb")
     covered = (cfg is not None and torch.is_tensor(rgb) and rgb.is_cuda and "normal" in outputs and "depth" in outputs
-               and not (cfg.use_normal_loss and "normal" not in batch)
+               and not (cfg.use_normal_loss and cfg.normal_supervision == "mono" and "normal" not in batch)
+               and not (cfg.use_normal_loss and cfg.normal_supervision == "depth" and _intrinsics_of(self) is None)
                and int(getattr(self.config, "num_downscales", 0)) == 0)
     if not covered:
         return self._get_loss_dict_reference(outputs, batch, metrics_dict)
@@ -323,7 +346,7 @@ def get_loss_dict_fused(self, outputs, batch, metrics_dict=None) -> Dict[str, to
         touch_normals = tn
     main_loss = ops._FusionLoss.apply(rgb, outputs["depth"], outputs["normal"], self.gauss_params["scales"], fb, cfg,
                                       self.gauss_params["normals"] if touch_idx is not None else None, touch_idx,
-                                      touch_normals, None, False)
+                                      touch_normals, None, False, _intrinsics_of(self))
     return {"main_loss": main_loss, "scale_reg": torch.zeros((), device=rgb.device)}
 
 

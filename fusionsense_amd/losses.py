@@ -28,6 +28,11 @@ class LossConfig:
     normal_lambda: float = 0.4          # configs/config.py:10
     two_d_gaussians: bool = True        # dn_model.py:98
     touch_normal_loss_lambda: float = 1.0  # dn_model.py:901
+    # switches that FusionSense's configuration leaves at other values (round 4: evaluated by the HIP loss node too)
+    normal_supervision: str = "mono"    # dn_model.py:84 ("mono" | "depth": pseudo normals of the rendered depth, :774-795)
+    smooth_loss_type: str = "TV"        # dn_model.py:66 ("TV" | "EdgeAwareTV", :752-760)
+    use_normal_cosine_loss: bool = False  # dn_model.py:80 (:807-813)
+    depth_loss_type: str = "EdgeAwareLogL1"  # dn_model.py:62 ("EdgeAwareLogL1" | "L1" | "LogL1" | "MSE", :725-750)
 
 
 class FrameBatch:
@@ -38,11 +43,13 @@ class FrameBatch:
     (the reference's datamanager likewise keeps its images cached on the device)."""
 
     def __init__(self, image, sensor_depth, normal, mask, cnt_x, cnt_y, has_sensor, mono_depth=None, mono_cnt_x=0,
-                 mono_cnt_y=0):
+                 mono_cnt_y=0, cnt=0, mono_cnt=0):
         self.image, self.sensor_depth, self.normal, self.mask = image, sensor_depth, normal, mask
         self.cnt_x, self.cnt_y, self.has_sensor = cnt_x, cnt_y, has_sensor
         # monocular depth (dn_model.py:737-750; FusionSense's batches carry none): [H,W] + its two valid counts
         self.mono_depth, self.mono_cnt_x, self.mono_cnt_y = mono_depth, mono_cnt_x, mono_cnt_y
+        # number of valid pixels as such: the mean of the plain depth-loss types runs over them (dn_model.py:731-750)
+        self.cnt, self.mono_cnt = cnt, mono_cnt
         self.height, self.width = image.shape[0], image.shape[1]
 
 
@@ -63,12 +70,14 @@ def prepare_batch(batch: Dict[str, Tensor], cfg: LossConfig, device) -> FrameBat
     sensor = batch["sensor_depth"].to(**f32).reshape(H, W).contiguous() if has_sensor else torch.zeros(H, W, **f32)
     normal = img(batch["normal"]) if "normal" in batch else None
     mask = batch["mask"].to(**f32).reshape(H, W).contiguous() if "mask" in batch else None
-    cnt_x, cnt_y = ops.depth_valid_counts(sensor, mask, cfg.depth_tolerance) if has_sensor else (0, 0)
-    mono, mcx, mcy = None, 0, 0
+    cnt_x, cnt_y, cnt = ops.depth_valid_counts(sensor, mask, cfg.depth_tolerance) if has_sensor else (0, 0, 0)
+    mono, mcx, mcy, mc = None, 0, 0, 0
     if "mono_depth" in batch:
         mono = batch["mono_depth"].to(**f32).reshape(H, W).contiguous()
-        mcx, mcy = ops.depth_valid_counts(mono, mask, cfg.depth_tolerance)
-    return FrameBatch(image, sensor, normal, mask, cnt_x, cnt_y, has_sensor, mono, mcx, mcy)
+        # (the plain depth-loss types test mono > 0 instead of > depth_tolerance: dn_model.py:739-741)
+        edge = getattr(cfg, "depth_loss_type", "EdgeAwareLogL1") == "EdgeAwareLogL1"
+        mcx, mcy, mc = ops.depth_valid_counts(mono, mask, cfg.depth_tolerance if edge else 0.0)
+    return FrameBatch(image, sensor, normal, mask, cnt_x, cnt_y, has_sensor, mono, mcx, mcy, cnt, mc)
 
 
 def _gaussian_window(size: int, sigma: float, device, dtype) -> Tensor:

@@ -1204,17 +1204,30 @@ def _combine_args(partials, weights):
     return VP(*[p.data_ptr() for p in partials]), rows, cols, (C.c_float * len(flat))(*flat)
 
 
-def depth_valid_counts(sensor_depth: Tensor, mask: Optional[Tensor], depth_tol: float) -> Tuple[int, int]:
-    """(#valid pixels with a right neighbour, #valid with a lower neighbour), valid = sensor*mask > tol: the sizes
-    of EdgeAwareLogL1's two masked selections (dn_splatter/losses.py:208-209).  One host read-back — per VIEW, at
-    batch preparation, never inside a step."""
+def depth_valid_counts(sensor_depth: Tensor, mask: Optional[Tensor], depth_tol: float) -> Tuple[int, int, int]:
+    """(#valid pixels with a right neighbour, #valid with a lower neighbour, #valid), valid = sensor*mask > tol: the
+    sizes of EdgeAwareLogL1's two masked selections (dn_splatter/losses.py:208-209) and of the plain depth-loss
+    types' selection (dn_model.py:733).  One host read-back — per VIEW, at batch preparation, never inside a step."""
     lib = load()
     H, W = sensor_depth.shape[0], sensor_depth.shape[1]
-    counts = torch.empty(2, dtype=torch.int64, device=sensor_depth.device)
+    counts = torch.empty(3, dtype=torch.int64, device=sensor_depth.device)
     _run(lib.fsgs_depth_valid_counts, (H, W, ptr(sensor_depth), ptr(mask), float(depth_tol), ptr(counts),
                                        stream_ptr(sensor_depth.device)), "fsgs_depth_valid_counts")
-    cx, cy = counts.tolist()
-    return int(cx), int(cy)
+    cx, cy, ca = counts.tolist()
+    return int(cx), int(cy), int(ca)
+
+
+_FA_TYPE = {"EdgeAwareLogL1": 0, "L1": 4, "LogL1": 8, "MSE": 12}  # fsgs.h: FSGS_FA_DEPTH_*
+
+
+def fusion_aux_flags(cfg) -> int:
+    """The flags of fsgs_fusion_aux_loss for a LossConfig (fsgs.h: FSGS_FA_*)."""
+    f = _FA_TYPE[getattr(cfg, "depth_loss_type", "EdgeAwareLogL1")]
+    if getattr(cfg, "smooth_loss_type", "TV") == "EdgeAwareTV":
+        f |= 2
+    if getattr(cfg, "normal_supervision", "mono") == "depth":
+        f |= 1
+    return f
 
 
 def mono_depth_weights(cfg, fb):
@@ -1224,8 +1237,11 @@ def mono_depth_weights(cfg, fb):
             and getattr(cfg, "mono_depth_lambda", 0.0) > 0.0):
         return None
     w = [0.0] * 7
-    w[0] = cfg.mono_depth_lambda / fb.mono_cnt_x if fb.mono_cnt_x else float("inf")
-    w[1] = cfg.mono_depth_lambda / fb.mono_cnt_y if fb.mono_cnt_y else float("inf")
+    if getattr(cfg, "depth_loss_type", "EdgeAwareLogL1") == "EdgeAwareLogL1":
+        w[0] = cfg.mono_depth_lambda / fb.mono_cnt_x if fb.mono_cnt_x else float("inf")
+        w[1] = cfg.mono_depth_lambda / fb.mono_cnt_y if fb.mono_cnt_y else float("inf")
+    else:  # (L1 / LogL1 / MSE: one column, mean over the valid pixels)
+        w[0] = cfg.mono_depth_lambda / fb.mono_cnt if fb.mono_cnt else float("inf")
     return w
 
 
@@ -1238,13 +1254,16 @@ def fusion_loss_weights(cfg, fb, n_gauss: int, n_touch: int):
     w = [0.0] * 7
     if cfg.use_depth_loss and fb.has_sensor and cfg.sensor_depth_lambda > 0.0:
         # (an empty selection makes the reference's mean NaN; so does 0 * inf here)
-        w[0] = cfg.sensor_depth_lambda / fb.cnt_x if fb.cnt_x else float("inf")
-        w[1] = cfg.sensor_depth_lambda / fb.cnt_y if fb.cnt_y else float("inf")
-    if cfg.use_depth_smooth_loss:
+        if getattr(cfg, "depth_loss_type", "EdgeAwareLogL1") == "EdgeAwareLogL1":
+            w[0] = cfg.sensor_depth_lambda / fb.cnt_x if fb.cnt_x else float("inf")
+            w[1] = cfg.sensor_depth_lambda / fb.cnt_y if fb.cnt_y else float("inf")
+        else:  # L1 / LogL1 / MSE: column 0 only, mean over the valid pixels (dn_model.py:731-736)
+            w[0] = cfg.sensor_depth_lambda / fb.cnt if fb.cnt else float("inf")
+    if cfg.use_depth_smooth_loss:  # (TV and EdgeAwareTV average over the same two shifted grids)
         w[2] = cfg.smooth_loss_lambda / (H * (W - 1))
         w[3] = cfg.smooth_loss_lambda / ((H - 1) * W)
     if cfg.use_normal_loss:
-        if fb.normal is not None:
+        if fb.normal is not None or getattr(cfg, "normal_supervision", "mono") == "depth":
             w[4] = cfg.normal_lambda / (3.0 * H * W)
         if cfg.use_normal_tv_loss:
             w[5] = cfg.normal_lambda / (3.0 * H * (W - 1))
@@ -1274,7 +1293,9 @@ class _FusionLoss(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, rgb, depth, normal, log_scales, fb, cfg, normals_world=None, touch_idx=None,
-                touch_normals=None, seed=None, defer_combine=False):
+                touch_normals=None, seed=None, defer_combine=False, intrinsics=None):
+        """``intrinsics`` = (fx, fy, cx, cy) of the frame's camera: read by normal_supervision == "depth" only
+        (the reference takes them from ``self.camera``, dn_model.py:775-786)."""
         rgb, depth, normal, log_scales = map(_c, (rgb, depth, normal, log_scales))
         lib = load()
         dev = rgb.device
@@ -1294,28 +1315,54 @@ class _FusionLoss(torch.autograd.Function):
                                            maps[1].data_ptr(), maps[2].data_ptr(), ptr(sums), sp), "fsgs_ssim_l1_fwd")
         aux = torch.empty(lib.fsgs_fusion_aux_num_partials(H, W), 8, **f32)
         wa = (C.c_float * 7)(*w_aux)
+        flags = fusion_aux_flags(cfg)
+        edge = (flags & 12) == 0
+        # the target of the normal L1 (and cosine) term: the view's monocular normals — or, normal_supervision ==
+        # "depth", the pseudo normals of THIS frame's masked depth (detached: no gradient flows through the target)
+        normal_gt = fb.normal if normal is not None else None
+        if normal is not None and cfg.use_normal_loss and getattr(cfg, "normal_supervision", "mono") == "depth":
+            if intrinsics is None:
+                raise ValueError("normal_supervision='depth' needs the frame's camera intrinsics (fx, fy, cx, cy)")
+            normal_gt = torch.empty(H, W, 3, **f32)
+            _run(lib.fsgs_normals_from_depth, (H, W, ptr(depth), ptr(fb.mask), float(intrinsics[0]), float(intrinsics[1]),
+                                               float(intrinsics[2]), float(intrinsics[3]), ptr(normal_gt), sp),
+                 "fsgs_normals_from_depth")
+        elif normal_gt is None:
+            flags &= ~1
         v_depth = v_normal = None
         if seed is not None:
             v_depth = torch.empty_like(depth)
             v_normal = torch.empty_like(normal) if normal is not None else None
         _run(lib.fsgs_fusion_aux_loss, (H, W, ptr(depth), ptr(normal), ptr(fb.image), ptr(fb.sensor_depth),
-                                        ptr(fb.normal) if normal is not None else None, ptr(fb.mask),
+                                        ptr(normal_gt), ptr(fb.mask),
                                         float(cfg.depth_tolerance), wa, ptr(seed), ptr(aux), ptr(v_depth),
-                                        ptr(v_normal), sp), "fsgs_fusion_aux_loss")
+                                        ptr(v_normal), flags, sp), "fsgs_fusion_aux_loss")
         partials, weights = [sums, aux], [(g_l1, g_ssim), tuple(w_aux) + (0.0,)]
         w_mono = mono_depth_weights(cfg, fb)
         if w_mono is not None:
-            # monocular depth (dn_model.py:737-745): the same EdgeAwareLogL1 columns against a second target — a
-            # second pass of the kernel with every other column's weight zero; its depth gradient is added
+            # monocular depth (dn_model.py:737-750): the same depth columns against a second target — a second pass of
+            # the kernel with every other column's weight zero; its depth gradient is added.  (The plain depth-loss
+            # types take mono > 0 as valid, EdgeAwareLogL1 mono > depth_tolerance: :739-741.)
             aux_m = torch.empty_like(aux)
             v_depth_m = torch.empty_like(depth) if seed is not None else None
             _run(lib.fsgs_fusion_aux_loss, (H, W, ptr(depth), None, ptr(fb.image), ptr(fb.mono_depth), None, ptr(fb.mask),
-                                            float(cfg.depth_tolerance), (C.c_float * 7)(*w_mono), ptr(seed), ptr(aux_m),
-                                            ptr(v_depth_m), None, sp), "fsgs_fusion_aux_loss")
+                                            float(cfg.depth_tolerance) if edge else 0.0, (C.c_float * 7)(*w_mono),
+                                            ptr(seed), ptr(aux_m), ptr(v_depth_m), None, flags & 12, sp),
+                 "fsgs_fusion_aux_loss")
             if v_depth_m is not None:
                 v_depth.add_(v_depth_m)
             partials.append(aux_m)
             weights.append(tuple(w_mono) + (0.0,))
+        g_cos = 0.0
+        if normal is not None and cfg.use_normal_loss and getattr(cfg, "use_normal_cosine_loss", False) \
+                and normal_gt is not None:
+            # the cosine term as the reference calls it (dn_model.py:807-813): one value per (channel, column)
+            g_cos = cfg.normal_lambda / (3.0 * W)
+            pc = torch.empty(lib.fsgs_normal_cosine_num_partials(W), 2, **f32)
+            _run(lib.fsgs_normal_cosine_loss, (H, W, ptr(normal), ptr(normal_gt), ptr(fb.mask), flags & 1, g_cos, ptr(seed),
+                                               ptr(pc), ptr(v_normal), sp), "fsgs_normal_cosine_loss")
+            partials.append(pc)
+            weights.append((g_cos, 0.0))
         if g_min != 0.0:
             pm = torch.empty((N + 255) // 256, 2, **f32)
             _run(lib.fsgs_min_scale_loss, (N, ptr(log_scales), 0.0, None, ptr(pm), None, sp), "fsgs_min_scale_loss")
@@ -1331,6 +1378,7 @@ class _FusionLoss(torch.autograd.Function):
                               log_scales)
         ctx.fb, ctx.cfg = fb, cfg
         ctx.g = (g_l1, g_ssim, w_aux, g_min, normal is not None)
+        ctx.extra = (normal_gt, flags, g_cos)  # (the frame's own target normals, when they came from its depth)
         ctx.aux_grads = (seed, v_depth, v_normal) if seed is not None else None
         ctx.deferred_loss = None
         if seed is not None and defer_combine:
@@ -1357,19 +1405,25 @@ class _FusionLoss(torch.autograd.Function):
         else:
             v_depth = torch.empty_like(depth)
             v_normal = torch.empty_like(normal) if has_n else None
+            normal_gt, flags, g_cos = ctx.extra
+            edge = (flags & 12) == 0
             scratch = torch.empty(lib.fsgs_fusion_aux_num_partials(H, W), 8, dtype=torch.float32, device=dev)
             _run(lib.fsgs_fusion_aux_loss, (H, W, ptr(depth), ptr(normal) if has_n else None, ptr(fb.image),
-                                            ptr(fb.sensor_depth), ptr(fb.normal) if has_n else None, ptr(fb.mask),
+                                            ptr(fb.sensor_depth), ptr(normal_gt) if has_n else None, ptr(fb.mask),
                                             float(cfg.depth_tolerance), (C.c_float * 7)(*w_aux), ptr(v_loss),
-                                            ptr(scratch), ptr(v_depth), ptr(v_normal), sp), "fsgs_fusion_aux_loss")
+                                            ptr(scratch), ptr(v_depth), ptr(v_normal), flags, sp), "fsgs_fusion_aux_loss")
             w_mono = mono_depth_weights(cfg, fb)
             if w_mono is not None:
                 v_depth_m = torch.empty_like(depth)
                 _run(lib.fsgs_fusion_aux_loss, (H, W, ptr(depth), None, ptr(fb.image), ptr(fb.mono_depth), None,
-                                                ptr(fb.mask), float(cfg.depth_tolerance), (C.c_float * 7)(*w_mono),
-                                                ptr(v_loss), ptr(scratch), ptr(v_depth_m), None, sp),
-                     "fsgs_fusion_aux_loss")
+                                                ptr(fb.mask), float(cfg.depth_tolerance) if edge else 0.0,
+                                                (C.c_float * 7)(*w_mono), ptr(v_loss), ptr(scratch), ptr(v_depth_m), None,
+                                                flags & 12, sp), "fsgs_fusion_aux_loss")
                 v_depth.add_(v_depth_m)
+            if g_cos != 0.0:
+                pc = torch.empty(lib.fsgs_normal_cosine_num_partials(W), 2, dtype=torch.float32, device=dev)
+                _run(lib.fsgs_normal_cosine_loss, (H, W, ptr(normal), ptr(normal_gt), ptr(fb.mask), flags & 1, g_cos,
+                                                   ptr(v_loss), ptr(pc), ptr(v_normal), sp), "fsgs_normal_cosine_loss")
         v_rgb = torch.empty_like(rgb)
         dl = ctx.deferred_loss
         if dl is not None:
@@ -1387,15 +1441,16 @@ class _FusionLoss(torch.autograd.Function):
             v_scales = torch.zeros_like(log_scales)
             if g_min != 0.0:
                 min_scale_grad_(log_scales, g_min, v_loss, v_scales)
-        return v_rgb, v_depth, v_normal, v_scales, None, None, None, None, None, None, None
+        return v_rgb, v_depth, v_normal, v_scales, None, None, None, None, None, None, None, None
 
 
 def fusion_loss(out, fb, cfg, log_scales: Tensor, touch_idx: Optional[Tensor] = None,
-                touch_normals: Optional[Tensor] = None) -> Tensor:
+                touch_normals: Optional[Tensor] = None, intrinsics=None) -> Tensor:
     """get_loss_dict's main_loss + scale_reg for the outputs of get_outputs (``out``: rgb, depth, normal,
-    normals_world) against a prepared :class:`fusionsense_amd.losses.FrameBatch`."""
+    normals_world) against a prepared :class:`fusionsense_amd.losses.FrameBatch`; ``intrinsics`` = (fx, fy, cx, cy) of
+    the frame's camera (needed by normal_supervision == "depth" only)."""
     return _FusionLoss.apply(out["rgb"], out["depth"], out.get("normal"), log_scales, fb, cfg,
-                             out.get("normals_world"), touch_idx, touch_normals, None, False)
+                             out.get("normals_world"), touch_idx, touch_normals, None, False, intrinsics)
 
 
 def adam_groups(params, grads, exp_avgs, exp_avg_sqs, lrs, step: int, beta1: float = 0.9, beta2: float = 0.999,

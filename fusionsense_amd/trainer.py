@@ -501,7 +501,7 @@ class SplatTrainer:
             return None, None
         return st.touch_rows(), st.touch_normals
 
-    def loss(self, out, target) -> Tensor:
+    def loss(self, out, target, camera: Optional[Camera] = None) -> Tensor:
         """FrameBatch -> get_loss_dict (dn_model.py:673-925).  Dict of target images -> the config-#2 benchmark loss
         (SURVEY.md §8d): 0.8*L1 + 0.2*(1-SSIM) on rgb, L1 on depth, L1 on normals."""
         from .losses import FrameBatch, rgb_loss
@@ -512,7 +512,8 @@ class SplatTrainer:
             # the min-scale term's direct gradient to the log-scales is added by train_step after the backward
             # instead of travelling through autograd's accumulation, whose order against the node's write is open.
             scales = self._params["scales"].detach() if self.fused else self._params["scales"]
-            return fusion_loss(out, target, self.loss_cfg, scales, ti, tn)
+            intr = (camera.fx, camera.fy, camera.cx, camera.cy) if camera is not None else None
+            return fusion_loss(out, target, self.loss_cfg, scales, ti, tn, intr)
         if self.fused and "depth" in target and out["rgb"].is_cuda:
             from .ops import train_loss
             has_n = "normal" in target
@@ -848,7 +849,7 @@ class SplatTrainer:
             if not self.fused:
                 self.slab.zero_()  # autograd accumulates into the slab views; the fused node overwrites them
             out = self.forward(camera)
-            loss = self.loss(out, target)
+            loss = self.loss(out, target, camera)
             self._grads_written()
             loss.backward(gradient=self._one)  # (the default would launch a fill kernel for the seed gradient)
             if is_fb and self.fused:

@@ -715,14 +715,42 @@ int fsgs_ssim_l1_bwd_masked(int H, int W, const float *pred, const float *gt, co
  * partial: [fsgs_fusion_aux_num_partials(H,W), 8] per-workgroup sums.  w[7]: the weight of every column in the
  * loss (lambda / count; the two EdgeAwareLogL1 counts are per-view constants, fsgs_depth_valid_counts).
  * v_loss != NULL: also writes v_depth [H,W] and v_normal [H,W,3] = v_loss[0] * d loss / d image (mask applied).
- * normal / normal_gt / mask nullable (columns 4-6 then 0). */
+ * normal / normal_gt / mask nullable (columns 4-6 then 0).
+ * flags (round 4: the switches of get_loss_dict that FusionSense's configuration leaves off, 0 = none):
+ *   FSGS_FA_NORMAL_GT_UNMASKED  n* = normal_gt as given (the pseudo normals of fsgs_normals_from_depth, which
+ *                               dn_model.py:774-795 does not multiply by the mask), not normal_gt * mask;
+ *   FSGS_FA_EDGE_AWARE_TV       cols 2 / 3 = EdgeAwareTV (losses.py:241-266): |d(x)-d(x+1)| * exp(-mean_c|I(x)-I(x+1)|);
+ *   FSGS_FA_DEPTH_L1 / _LOGL1 / _MSE  the plain depth-loss types of dn_model.py:731-736 (losses.py:147-174,
+ *                               torch.nn.MSELoss) over the valid pixels: col 0 = sum |d-g| / log(1+|d-g|) / (d-g)^2,
+ *                               col 1 = 0; w[0] = lambda / #valid (counts[2] of fsgs_depth_valid_counts). */
+#define FSGS_FA_NORMAL_GT_UNMASKED 1
+#define FSGS_FA_EDGE_AWARE_TV 2
+#define FSGS_FA_DEPTH_L1 4
+#define FSGS_FA_DEPTH_LOGL1 8
+#define FSGS_FA_DEPTH_MSE 12
 int64_t fsgs_fusion_aux_num_partials(int H, int W);
 int fsgs_fusion_aux_loss(int H, int W, const float *depth, const float *normal, const float *image,
                          const float *sensor_depth, const float *normal_gt, const float *mask, float depth_tol,
                          const float *w, const float *v_loss, float *partial, float *v_depth, float *v_normal,
-                         fsgs_stream_t stream);
-/* counts[0] = #{valid, x < W-1}, counts[1] = #{valid, y < H-1} with valid = sensor*mask > depth_tol (the sizes of
- * the two masked selections of losses.py:208-209); device int64[2], zeroed by the call. */
+                         int flags, fsgs_stream_t stream);
+/* get_loss_dict's normal_supervision == "depth" target (dn_model.py:774-795; utils/normal_utils.py:8-46 over
+ * utils/camera_utils.py:92-144 with an identity pose): pseudo normals of depth * mask — interior pixels
+ * normalize(cross(right - left, top - bottom)) of the back-projected pixel centres, border zero — with y and z negated,
+ * mapped to [0,1]: normal_out [H,W,3] = (1 + n * (1,-1,-1)) / 2.  (fx, fy, cx, cy): the camera of the frame. */
+int fsgs_normals_from_depth(int H, int W, const float *depth, const float *mask, float fx, float fy, float cx, float cy,
+                            float *normal_out, fsgs_stream_t stream);
+/* use_normal_cosine_loss (dn_model.py:807-813) AS CALLED there: metrics.mean_angular_error (metrics.py:58-73) on
+ * [3,H,W] tensors sums over the image rows, so the term is mean over (channel, column) of
+ * acos(clamp(sum_y ((n*-1)/2)((n-1)/2), -1, 1)), n = normal * mask, n* = normal_gt (* mask unless gt_unmasked).
+ * partial [fsgs_normal_cosine_num_partials(W), 2]: col 0 = sum of the acos values (weight normal_lambda / (3 W));
+ * v_loss != NULL: v_normal [H,W,3] += v_loss[0] * w * d/d normal (ACCUMULATED onto fsgs_fusion_aux_loss's output). */
+int64_t fsgs_normal_cosine_num_partials(int W);
+int fsgs_normal_cosine_loss(int H, int W, const float *normal, const float *normal_gt, const float *mask,
+                            int gt_unmasked, float w, const float *v_loss, float *partial, float *v_normal,
+                            fsgs_stream_t stream);
+/* counts[0] = #{valid, x < W-1}, counts[1] = #{valid, y < H-1}, counts[2] = #{valid} with valid = sensor*mask > depth_tol
+ * (the sizes of the two masked selections of losses.py:208-209 and of the plain selection of dn_model.py:733);
+ * device int64[3], zeroed by the call. */
 int fsgs_depth_valid_counts(int H, int W, const float *sensor_depth, const float *mask, float depth_tol,
                             int64_t *counts, fsgs_stream_t stream);
 /* two_d_gaussians term (dn_model.py:817-819): partial[ceil(N/256), 2] col 0 = sum_n min_k exp(log_scales[n,k]);

@@ -25,16 +25,20 @@ def _fb(batch, dev, cfg=None):
     return prepare_batch(batch, cfg or LossConfig(), dev)
 
 
-@pytest.mark.parametrize("case", ["full", "nomask", "dense", "mono", "monoonly"])
+@pytest.mark.parametrize("case", ["full", "nomask", "dense", "mono", "monoonly",
+                                  "ndepth", "ndepth_nomask", "eatv", "cosine", "cosine_depth", "l1", "logl1", "mse"])
 def test_fusion_loss_kernels_match_reference_goldens(dev, case):
     """ops._FusionLoss against numbers the reference's get_loss_dict produced itself: the gradient images of depth
-    and normals, the log-scale gradient, and the value of everything FusionSense adds to the photometric term."""
+    and normals, the log-scale gradient, and the value of everything FusionSense adds to the photometric term —
+    FusionSense's own configuration and (round 4) the switches it leaves off: normals from depth, EdgeAwareTV, the
+    cosine term, the L1 / LogL1 / MSE depth-loss types."""
     from fusionsense_amd import ops
     from fusionsense_amd.losses import LossConfig
     from oracle import loss_ref
+    from test_oracle import loss_case_config
     d = np.load(GOLD)
     t = lambda k: torch.from_numpy(d[f"{case}.{k}"])  # noqa: E731
-    cfg = LossConfig()
+    cfg, intr = loss_case_config(d, case, LossConfig)
     batch = {"image": t("image"), "sensor_depth": t("sensor_depth"), "normal": t("normal_gt")}
     if f"{case}.mono_depth" in d.files:  # the monocular-depth branch (dn_model.py:737-750)
         batch["mono_depth"] = t("mono_depth")
@@ -53,7 +57,7 @@ def test_fusion_loss_kernels_match_reference_goldens(dev, case):
     normal = t("normal").to(dev).requires_grad_(True)
     scales = t("scales").to(dev).requires_grad_(True)
     out = {"rgb": rgb, "depth": depth, "normal": normal, "normals_world": t("normals_world").to(dev)}
-    loss = ops.fusion_loss(out, fb, cfg, scales, touch_idx, touch_normals)
+    loss = ops.fusion_loss(out, fb, cfg, scales, touch_idx, touch_normals, intr)
     loss.backward()
     # the photometric share of the value comes from the oracle (it does not touch depth / normal / scales)
     photo = loss_ref.photometric_loss(t("rgb").double(), t("image").double(),
@@ -62,6 +66,43 @@ def test_fusion_loss_kernels_match_reference_goldens(dev, case):
     for name, g in (("v_depth", depth.grad), ("v_normal", normal.grad), ("v_scales", scales.grad)):
         ref = t(name)
         assert torch.allclose(g.cpu(), ref, rtol=2e-5, atol=1e-9), (name, float((g.cpu() - ref).abs().max()))
+    if intr is not None:
+        # the tape-free route (seed known in the forward: the gradient images leave the forward's own pass, the cosine
+        # term accumulates onto them) gives the same numbers
+        from fusionsense_amd.fused import _DirectCtx
+        one = torch.ones((), device=dev)
+        with torch.no_grad():
+            lctx = _DirectCtx((True, True, True, False) + (False,) * 8)
+            l2 = ops._FusionLoss.forward(lctx, rgb.detach(), depth.detach(), normal.detach(), scales.detach(), fb, cfg,
+                                         out["normals_world"], touch_idx, touch_normals, one, True, intr)
+            v = ops._FusionLoss.backward(lctx, one)
+        assert abs(float(l2) - float(loss)) <= 1e-6 * abs(float(loss))
+        assert torch.allclose(v[1], depth.grad, rtol=1e-6, atol=1e-10) and torch.allclose(v[2], normal.grad, rtol=1e-6, atol=1e-10)
+
+
+def test_pseudo_normals_and_valid_counts(dev):
+    """fsgs_normals_from_depth against the oracle's restatement of utils/normal_utils.py (itself pinned through the
+    ndepth cases), on a ragged image with a mask; fsgs_depth_valid_counts' three counts against torch."""
+    from fusionsense_amd import ops
+    from fusionsense_amd._lib import load, ptr, stream_ptr
+    from oracle import loss_ref
+    g = torch.Generator().manual_seed(5)
+    H, W = 37, 53
+    depth = 0.5 + 2 * torch.rand(H, W, 1, generator=g)
+    mask = (torch.rand(H, W, 1, generator=g) > 0.2).float()
+    ref = loss_ref.normal_from_depth((depth * mask).double(), 41.0, 39.0, 25.5, 19.0)
+    ref = (1 + ref * torch.tensor([1.0, -1.0, -1.0], dtype=torch.float64)) / 2
+    out = torch.empty(H, W, 3, device=dev)
+    d_, m_ = depth.to(dev).contiguous(), mask.reshape(H, W).to(dev).contiguous()
+    assert load().fsgs_normals_from_depth(H, W, ptr(d_), ptr(m_), 41.0, 39.0, 25.5, 19.0, ptr(out), stream_ptr(dev)) == 0
+    # (pixels whose cross product is ~0 — a masked neighbourhood — normalise noise: compare where it is well defined)
+    good = (ref - 0.5).abs().sum(-1) > 1e-3
+    assert float((out.cpu().double() - ref)[good].abs().max()) < 2e-4 and float(good.float().mean()) > 0.5
+    assert torch.equal(out.cpu()[0], torch.full((W, 3), 0.5)) and torch.equal(out.cpu()[:, -1], torch.full((H, 3), 0.5))
+    sensor = depth.reshape(H, W) * (torch.rand(H, W, generator=g) > 0.3)
+    cx, cy, ca = ops.depth_valid_counts(sensor.to(dev).contiguous(), m_, 0.1)
+    valid = (sensor * mask.reshape(H, W)) > 0.1
+    assert (cx, cy, ca) == (int(valid[:, :-1].sum()), int(valid[:-1].sum()), int(valid.sum()))
 
 
 @pytest.mark.parametrize("H,W,with_mask,with_touch", [(64, 96, True, True), (45, 77, True, False), (33, 32, False, True),
@@ -1001,3 +1042,38 @@ def test_monocular_depth_term_on_both_trainer_routes(dev):
     for k in PARAM_ORDER:
         assert rel_err(res["with"][1][k], res["tape"][1][k]) < 1e-3, k
     assert rel_err(res["with"][1]["means"], res["without"][1]["means"]) > 1e-2, "and to the gradients"
+
+
+@pytest.mark.parametrize("switch", ["normals_from_depth", "edge_aware_tv_cosine_logl1"])
+def test_other_loss_switches_on_both_trainer_routes_and_against_the_oracle(dev, switch):
+    """The get_loss_dict switches that FusionSense's CLI leaves at other values (normal_supervision = "depth" is the
+    MODEL's default, dn_model.py:84; EdgeAwareTV, the cosine term and the plain depth losses are one flag away) through
+    the whole step: the same loss and parameter gradients on the tape-free step and on the autograd tape, and the loss
+    value equal to oracle/loss_ref (pinned by the reference-execution goldens) on the HIP render."""
+    from fusionsense_amd.losses import LossConfig
+    from fusionsense_amd.trainer import PARAM_ORDER, SplatTrainer
+    from oracle import loss_ref
+    W, H = 160, 96
+    params, cams = _small_fusionsense(dev, W, H)
+    batch = _synthetic_batch(H, W, 6)
+    kw = (dict(normal_supervision="depth") if switch == "normals_from_depth" else
+          dict(smooth_loss_type="EdgeAwareTV", use_normal_cosine_loss=True, depth_loss_type="LogL1"))
+    cfg = LossConfig(**kw)
+    cam = cams[1]
+    res = {}
+    for name, direct in (("direct", True), ("tape", False)):
+        tr = SplatTrainer(params, dev, sh_degree=3, loss_cfg=cfg, direct=direct)
+        loss, out = tr.train_step(cam, _fb(batch, dev, cfg), optimizer_step=False)
+        res[name] = (float(loss), {k: tr.slab.views[k].clone() for k in PARAM_ORDER}, out)
+    assert abs(res["direct"][0] - res["tape"][0]) < 1e-6 * abs(res["tape"][0])
+    for k in PARAM_ORDER:
+        assert rel_err(res["direct"][1][k], res["tape"][1][k]) < 1e-3, k
+    plain = SplatTrainer(params, dev, sh_degree=3, loss_cfg=LossConfig(), direct=True)
+    l0, _ = plain.train_step(cam, _fb(batch, dev, LossConfig()), optimizer_step=False)
+    assert abs(float(l0) - res["direct"][0]) > 1e-4, "the switch changes the loss"
+    out = res["direct"][2]
+    o = {k: out[k].detach().cpu().double() for k in ("rgb", "depth", "normal")}
+    b = {k: (v.double() if v.dtype.is_floating_point else v) for k, v in batch.items()}
+    ref = loss_ref.get_loss_dict(o, b, params["scales"].double(), cfg=loss_ref.LossConfig(**kw),
+                                 intrinsics=(cam.fx, cam.fy, cam.cx, cam.cy))["main_loss"]
+    assert abs(res["direct"][0] - float(ref)) < 1e-4 * abs(float(ref)), (res["direct"][0], float(ref))

@@ -172,7 +172,8 @@ def test_adam_fuser_is_torch_adam_in_one_launch(dev, monkeypatch):
     assert not torch.equal(new.data, before) and float(oa[k].state[new]["step"]) == 6.0
 
 
-@pytest.mark.parametrize("case", ["full", "nomask", "dense", "mono", "monoonly"])
+@pytest.mark.parametrize("case", ["full", "nomask", "dense", "mono", "monoonly",
+                                  "ndepth", "ndepth_nomask", "eatv", "cosine", "cosine_depth", "l1", "logl1", "mse"])
 def test_patched_get_loss_dict_matches_reference_goldens(dev, case):
     """``model.get_loss_dict(outputs, batch)`` after patch_all against what the reference's get_loss_dict produced on
     the same inputs (reference_loss.npz): value of everything FusionSense adds to the photometric term, gradient images,
@@ -186,7 +187,15 @@ def test_patched_get_loss_dict_matches_reference_goldens(dev, case):
                                                  ("features_rest", (15, 3)), ("opacities", (1,)))}
     params["scales"] = t("scales")
     md = {"touch_patches": [{"normals": t("touch_normals")}]} if n_touch else {}
-    m, _ = _model(dev, params, metadata=md)
+    over = {}
+    if f"{case}.switches" in d.files:  # (round 4) the switches FusionSense leaves off — still on the HIP node
+        ns, sm, cs, dt = (str(x) for x in d[f"{case}.switches"])
+        over = dict(normal_supervision=ns, smooth_loss_type=sm, use_normal_cosine_loss=(cs == "cosine"), depth_loss_type=dt)
+    m, _ = _model(dev, params, metadata=md, **over)
+    if f"{case}.intr" in d.files:  # what normal_supervision == "depth" reads from the last get_outputs' camera
+        fx, fy, cx, cy = (float(x) for x in d[f"{case}.intr"])
+        t1 = lambda v: torch.tensor([[v]])  # noqa: E731
+        m.camera = types.SimpleNamespace(fx=t1(fx), fy=t1(fy), cx=t1(cx), cy=t1(cy))
     if n_touch:
         m.add_mask = torch.zeros(N, dtype=torch.bool, device=dev)
         m.add_mask[N - n_touch:] = True
@@ -222,7 +231,7 @@ def test_patched_get_loss_dict_matches_reference_goldens(dev, case):
     assert m._fsgs_frames.hits == 2 and len(m._fsgs_frames) == 1
     m._fsgs_frames._harvest(block=True)  # (the fingerprint comparison found nothing)
     # a switch the node does not evaluate goes to the reference's own method (here: the stand-in that raises)
-    m.config.use_normal_cosine_loss = True
+    m.config.use_sparse_loss = True
     with pytest.raises(AssertionError, match="reference get_loss_dict"):
         m.get_loss_dict(out, batch)
 

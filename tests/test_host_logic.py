@@ -564,7 +564,7 @@ def test_unfused_train_step_flushes_deferred_features_before_clearing_the_slab(m
             val = sum(((p * (i + 1)).sin() * (1.0 + 0.1 * self.step)).sum() for i, p in enumerate(self.params.values()))
             return {"val": val, "info": None}
 
-        def loss(self, out, target):
+        def loss(self, out, target, camera=None):
             return out["val"]
 
     torch.manual_seed(0)
