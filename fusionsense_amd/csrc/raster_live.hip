@@ -72,6 +72,14 @@ struct GetOutputsGrads {
     const float *v_rgb, *v_depth, *v_normal, *v_alpha_in, *bg;  // v_rgb == nullptr: not used
 };
 
+#ifdef FSGS_BWD_STATS
+// Diagnostic build only (make EXTRA=-DFSGS_BWD_STATS OUT=../libfsgs_stats.so; tools/bwd_lane_stats.py): how full the
+// 64 lanes of a step are.  [0] loop iterations, [1] iterations executed (some lane valid), [2] lanes with a list entry
+// in executed iterations, [3] lanes that pass the alpha test in executed iterations, [4] segments, [5] segments walked
+// merged, [6] sum of the segments' longest row list, [7] sum of the segments' union sizes.
+__device__ unsigned long long g_bwd_stats[8];
+#endif
+
 template <int D, bool ABS, int E>
 __global__ void __launch_bounds__(64 * kBwdWaves) __attribute__((amdgpu_waves_per_eu(6, 6)))
 raster_bwd_live_kernel(int64_t cap, const float4 *__restrict__ rec,
@@ -205,6 +213,9 @@ raster_bwd_live_kernel(int64_t cap, const float4 *__restrict__ rec,
     const uint32_t rep_off = (uint32_t)replica_rows * 16u * ((((unsigned)tile_lin * 2654435761u >> 16) + (bx & 1) +
                                                              2 * (by & 1)) % kGradReplicas);
 
+#ifdef FSGS_BWD_STATS
+    unsigned long long st_iter = 0, st_exec = 0, st_have = 0, st_valid = 0, st_seg = 0, st_merge = 0, st_long = 0, st_union = 0;
+#endif
     for (int seg = n_seg - 1 - w; seg >= 0; seg -= kBwdWaves) {
         const int b0 = s + (seg << 6);          // first stream position of the segment
         const int n = min(64, e - b0);
@@ -241,6 +252,9 @@ raster_bwd_live_kernel(int64_t cap, const float4 *__restrict__ rec,
         const uint64_t many = mrow[0] | mrow[1] | mrow[2] | mrow[3];
         const int n_union = __popcll(many);
         const bool merge = n_union > 0 && steps * 16 >= n_union * merge_thr16;
+#ifdef FSGS_BWD_STATS
+        st_seg += 1; st_merge += merge ? 1 : 0; st_long += steps; st_union += n_union;
+#endif
         const uint64_t below = (1ull << lane) - 1ull;
         if (merge) {
             if (rm) L.list[0][__popcll(many & below)] = (uint8_t)lane;
@@ -277,6 +291,10 @@ raster_bwd_live_kernel(int64_t cap, const float4 *__restrict__ rec,
             const float sigma = 0.5f * (a0.w * dx * dx + a1.y * dy * dy) + a1.x * dx * dy;
             const float vis0 = __expf(-sigma);
             if (sigma < 0.f || fminf(kAlphaMax, a0.z * vis0) < kAlphaMin) valid = false;
+#ifdef FSGS_BWD_STATS
+            st_iter += 1;
+            if (__any(valid)) { st_exec += 1; st_have += __popcll(__ballot(have)); st_valid += __popcll(__ballot(valid)); }
+#endif
             if (!__any(valid)) continue;
 
             // Branch-free from here: a lane that does not contribute gets vis = 0, hence alpha = 0,
@@ -365,6 +383,12 @@ raster_bwd_live_kernel(int64_t cap, const float4 *__restrict__ rec,
         if (merge) walk(std::true_type{}); else walk(std::false_type{});
         __builtin_amdgcn_wave_barrier();  // LDS reads of this segment precede the next segment's writes
     }
+#ifdef FSGS_BWD_STATS
+    if (lane == 0) {
+        const unsigned long long v[8] = {st_iter, st_exec, st_have, st_valid, st_seg, st_merge, st_long, st_union};
+        for (int k = 0; k < 8; ++k) atomicAdd(&g_bwd_stats[k], v[k]);
+    }
+#endif
 }
 
 __global__ void __launch_bounds__(256)
@@ -416,6 +440,17 @@ static std::atomic<int> g_bwd_dispatch_stride{[] {
     return e ? atoi(e) : 0;
 }()};
 extern "C" int fsgs_set_bwd_dispatch_stride(int stride) { return g_bwd_dispatch_stride.exchange(stride < 0 ? 0 : stride); }
+
+#ifdef FSGS_BWD_STATS
+extern "C" int fsgs_debug_bwd_stats(unsigned long long *out8, int reset) {
+    if (out8 && hipMemcpyFromSymbol(out8, HIP_SYMBOL(fsgs::g_bwd_stats), sizeof(unsigned long long) * 8) != hipSuccess) return -2;
+    if (reset) {
+        const unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(fsgs::g_bwd_stats), z, sizeof(z)) != hipSuccess) return -2;
+    }
+    return 0;
+}
+#endif
 
 static int launch_bwd_live(int C, int D, const float *records, const int32_t *n_rec,
                            int64_t cap, int64_t seg_cap, const int32_t *isect_offsets, int64_t n_isects,
