@@ -705,16 +705,24 @@ def main():
         for s in range(5):
             d_tr.train_step(cams[view_of(s)], targets[view_of(s)])
         torch.cuda.synchronize()
-        for k_ in rendering.HOST_TIME:
-            rendering.HOST_TIME[k_] = 0
-        rendering.MEASURE_HOST_TIME = True  # (clock reads inside the two calls only for this side measurement)
-        ops.TIMER.reset(enabled=True)
-        t3 = time.perf_counter()
+        # the rate first, UNINSTRUMENTED (per-launch HIP events and clock reads cost this host-bound route ~25 %: round 3
+        # quoted the instrumented figure) ...
         nd = 30
+        t3 = time.perf_counter()
         for s in range(nd):
             d_tr.train_step(cams[view_of(s)], targets[view_of(s)])
         torch.cuda.synchronize()
         dropin = nd / (time.perf_counter() - t3)
+        # ... then the same steps again with the library's host time and kernel time taken
+        for k_ in rendering.HOST_TIME:
+            rendering.HOST_TIME[k_] = 0
+        rendering.MEASURE_HOST_TIME = True  # (clock reads inside the two calls only for this side measurement)
+        ops.TIMER.reset(enabled=True)
+        t3i = time.perf_counter()
+        for s in range(nd):
+            d_tr.train_step(cams[view_of(s)], targets[view_of(s)])
+        torch.cuda.synchronize()
+        dropin_instrumented = nd / (time.perf_counter() - t3i)
         d_k = ops.TIMER.summary()
         ops.TIMER.reset(enabled=False)
         ht = rendering.HOST_TIME
@@ -726,7 +734,9 @@ def main():
             "host_ms_in_rasterize_gaussians_per_call": round(1e3 * ht["rasterize_gaussians_s"] / max(ht["rasterize_gaussians_calls"], 1), 4),
             "library_kernels_gpu_ms_per_step": round(sum(v["avg_ms"] * v["calls"] for v in d_k.values()) / nd, 4),
             "ms_per_step": round(1e3 / dropin, 3),
-            "note": "the rest of the step is the reference's own torch glue, autograd and optimizers, untouched",
+            "iters_per_s_while_instrumented": round(dropin_instrumented, 2),
+            "note": "the rest of the step is the reference's own torch glue, autograd and optimizers, untouched; the two "
+                    "host times and the kernel time are from the instrumented pass, ms_per_step from the plain one",
         }
         del d_tr
         # integration.patch(): get_outputs on the fused node, but still on torch's autograd tape and under

@@ -163,7 +163,16 @@ def ptr(t: Optional[torch.Tensor]):
     return t.data_ptr()
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream_ptr(device: torch.device):
+    """The hipStream_t of torch's CURRENT stream on ``device`` (what every launch is enqueued on).  Through torch's raw
+    accessor where it exists: building a ``torch.cuda.Stream`` object per launch cost ~6 us of host time — 80-90 us per
+    step over the 13-15 launches of a frame (cProfile of the shim route, round 4)."""
+    if _raw_stream is not None:
+        idx = device.index
+        return _raw_stream(idx if idx is not None else torch.cuda.current_device())
     return torch.cuda.current_stream(device).cuda_stream
 
 

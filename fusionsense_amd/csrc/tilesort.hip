@@ -333,108 +333,12 @@ tile_sort_kernel2(int n_tiles, int tile_bits, const int32_t *__restrict__ offset
                                             isect_ids_out);
 }
 
-// ---- one WAVE per bucket of up to 1024 words, everything in registers (round 4) ----------------------------------
-// At a few hundred words per tile (config #2: 465 on average) the workgroup kernel above is latency: sixteen waves are
-// launched per tile, four of them sort a 128-word block each and everybody meets at six workgroup barriers for the two
-// merge levels (measured: 40.8 us for 14 MB at config #2, two 1024-thread workgroups per CU).  Here a wave owns a whole
-// bucket: lane l holds words l and l + 64 of each of its NB = 1 / 2 / 4 / 8 blocks of 128, sorts the blocks with
-// sort128 (independent chains: the compiler interleaves them) and merges them without leaving the registers — the
-// mirror stage of a merge pairs block q with block G - 1 - q of its group at lane 63 - l and the other slot (two
-// 64-bit lane reversals), the stages of distance >= 128 pair the SAME lane and slot of two blocks (plain register
-// compares), distance 64 pairs a lane's own two words, and merge_tail_32 finishes.  No LDS storage, no barrier; four
-// buckets per 256-thread workgroup, up to eight waves per SIMD.  Same network as tile_sort_body, so the same (bit-exact)
-// result.  Buckets beyond 1024 words are left to the workgroup kernel (launched with LO = 1024).
-template <int NB>
-__device__ __forceinline__ void wave_sort_blocks(uint64_t (&e)[NB][2], int lane) {
-#pragma unroll
-    for (int b = 0; b < NB; ++b) sort128(e[b][0], e[b][1], lane);
-#pragma unroll
-    for (int G = 2; G <= NB; G <<= 1) {  // merge groups of G blocks (k = 128 G words)
-        // mirror stage: word i <-> word k - 1 - i
-#pragma unroll
-        for (int g0 = 0; g0 < NB; g0 += G) {
-#pragma unroll
-            for (int q = 0; q < G / 2; ++q) {
-                uint64_t &a0 = e[g0 + q][0], &a1 = e[g0 + q][1], &b0 = e[g0 + G - 1 - q][0], &b1 = e[g0 + G - 1 - q][1];
-                const uint64_t ra0 = lane_xor64<63>(b1), ra1 = lane_xor64<63>(b0);  // partners of a0 / a1
-                const uint64_t rb0 = lane_xor64<63>(a1), rb1 = lane_xor64<63>(a0);  // partners of b0 / b1
-                keep(a0, ra0, true); keep(a1, ra1, true);
-                keep(b0, rb0, false); keep(b1, rb1, false);
-            }
-        }
-        // distances k/4 .. 128: the same lane and slot of two blocks
-#pragma unroll
-        for (int J = G / 2; J >= 1; J >>= 1) {
-            if (J == G / 2 && true) {
-                // (J = G / 2 is the partner distance k / 2 — already done by the mirror stage)
-                continue;
-            }
-#pragma unroll
-            for (int b = 0; b < NB; ++b) {
-                if ((b & J) == 0) {
-#pragma unroll
-                    for (int sl = 0; sl < 2; ++sl) {
-                        uint64_t &lo = e[b][sl], &hi = e[b | J][sl];
-                        if (lo > hi) { const uint64_t t = lo; lo = hi; hi = t; }
-                    }
-                }
-            }
-        }
-        // distance 64 (a lane's own two words), then 32 .. 1
-#pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            if (e[b][0] > e[b][1]) { const uint64_t t = e[b][0]; e[b][0] = e[b][1]; e[b][1] = t; }
-            merge_tail_32(e[b][0], e[b][1], lane);
-        }
-    }
-}
-
-template <int NB>
-__device__ __forceinline__ void wave_sort_bucket(const uint64_t *__restrict__ g, int n, int lane, int64_t s, int64_t hi,
-                                                 int32_t *__restrict__ payload_out, int64_t *__restrict__ isect_ids_out) {
-    uint64_t e[NB][2];
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-        const int i0 = b * 128 + lane, i1 = i0 + 64;
-        e[b][0] = (i0 < n) ? g[i0] : ~0ull;  // (missing words are +inf: they end up behind everything)
-        e[b][1] = (i1 < n) ? g[i1] : ~0ull;
-    }
-    wave_sort_blocks<NB>(e, lane);
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-#pragma unroll
-        for (int sl = 0; sl < 2; ++sl) {
-            const int pos = b * 128 + lane + 64 * sl;
-            if (pos < n) {
-                const uint64_t k = e[b][sl];
-                const uint32_t lo = (uint32_t)(k & 0xFFFFFFFFull);
-                payload_out[s + pos] = (int32_t)(((lo & 0xFu) << 28) | (lo >> 4));
-                if (isect_ids_out) isect_ids_out[s + pos] = hi | (int64_t)(k >> 32);
-            }
-        }
-    }
-}
-
-constexpr int kWaveSortMax = 1024;  // words a single wave sorts (8 blocks of 128: 32 VGPRs of keys)
-
-__global__ void __launch_bounds__(256)
-tile_sort_wave_kernel(int T, int n_tiles, int tile_bits, const int32_t *__restrict__ offsets,
-                      const uint64_t *__restrict__ buckets, int32_t *__restrict__ payload_out,
-                      int64_t *__restrict__ isect_ids_out) {
-    const int lane = threadIdx.x & 63;
-    const int tile_lin = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (tile_lin >= T) return;
-    const int s = offsets[tile_lin], n = offsets[tile_lin + 1] - s;
-    if (n <= 0 || n > kWaveSortMax) return;
-    const int cam = tile_lin / n_tiles, tile = tile_lin - cam * n_tiles;
-    const int64_t hi = ((int64_t)cam << (32 + tile_bits)) | ((int64_t)tile << 32);
-    const uint64_t *g = buckets + s;
-    if (n <= 128) wave_sort_bucket<1>(g, n, lane, s, hi, payload_out, isect_ids_out);
-    else if (n <= 256) wave_sort_bucket<2>(g, n, lane, s, hi, payload_out, isect_ids_out);
-    else if (n <= 512) wave_sort_bucket<4>(g, n, lane, s, hi, payload_out, isect_ids_out);
-    else wave_sort_bucket<8>(g, n, lane, s, hi, payload_out, isect_ids_out);
-}
-
+// (Round 4, measured and removed: one WAVE per bucket of up to 1024 words — 1 / 2 / 4 / 8 blocks of 128 per lane pair,
+// sort128 per block, the merges' mirror / block-distance / distance-64 stages as register compares and lane reversals,
+// no LDS storage and no barrier, four buckets per 256-thread workgroup.  Bit-identical (the whole binning suite passed)
+// and SLOWER: bucket fill + sorts 0.0818 vs 0.0695 ms at config #2, 0.0928 vs 0.0724 ms at config #3 — a wave walks its
+// blocks' 57-stage networks one after the other, so a 512-word bucket's critical path is four times the workgroup
+// kernel's, where four waves sort one block each; the barriers it removes were not the cost.)
 // The same over a list of buckets whose LENGTH lives on the device (`n_sub`: the sub-buckets the depth-slab split
 // produced for the few tiles too large for the in-LDS split + sort): a fixed grid strides over them, so a frame
 // without such tiles costs a handful of workgroups instead of one early-out workgroup per possible sub-bucket.
@@ -875,21 +779,6 @@ int launch_tile_sort_tiers(int T, int n_tiles, int tile_bits, const int32_t *ise
     if (one_tier < 0) {
         const char *e = getenv("FSGS_SORT_ONE_TIER");
         one_tier = e ? atoi(e) : 1;
-    }
-    static int wave_tier = -1;
-    if (wave_tier < 0) {
-        const char *e = getenv("FSGS_SORT_WAVE_TIER");
-        wave_tier = e ? atoi(e) : 1;
-    }
-    if (wave_tier && T <= 8192) {
-        // buckets of up to 1024 words: one wave each, registers only; the rest through the workgroup kernel (its
-        // workgroups for the small buckets leave at once).  Config #2: 40.8 us -> see DESIGN.md
-        if (const int rc = ensure_dynamic_lds<&tile_sort_kernel2<1024, kTsLarge, kWaveSortMax, true>>(kTsLarge * 8)) return rc;
-        hipLaunchKernelGGL(tile_sort_wave_kernel, dim3((T + 3) / 4), dim3(256), 0, s, T, n_tiles, tile_bits, isect_offsets,
-                           buckets, payload_sorted, isect_ids_sorted);
-        hipLaunchKernelGGL((tile_sort_kernel2<1024, kTsLarge, kWaveSortMax, true>), dim3(T), dim3(1024), kTsLarge * 8, s,
-                           n_tiles, tile_bits, isect_offsets, buckets, payload_sorted, isect_ids_sorted);
-        return check_launch();
     }
     if (one_tier && T <= 8192) {
         // a moderate number of buckets: EVERY bucket through the 1024-thread kernel in one launch — the small

@@ -339,9 +339,9 @@ class _FusedGetOutputs(torch.autograd.Function):
         a = lambda n: (n + 255) // 256 * 256  # noqa: E731
         n_tiles = tw * th
         if needs_bwd:
-            cap = lib.fsgs_quad_stream_capacity(1, tw, th, M)
+            cap, slots = ops.quad_stream_sizes(1, tw, th, M)
             rec_bytes = 4 * cap * 64
-            seg_bytes = 4 * lib.fsgs_quad_seg_slots(1, tw, th, M) * 64 * (1 + 4 + 3) * 4
+            seg_bytes = 4 * slots * 64 * (1 + 4 + 3) * 4
             nrec_bytes = 4 * n_tiles * 4
             arena = WORKSPACE.take(a(rec_bytes) + a(seg_bytes) + a(nrec_bytes), dev)
             records = arena[:rec_bytes].view(torch.float32)

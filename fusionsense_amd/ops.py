@@ -8,6 +8,7 @@ all arithmetic happens in libfsgs.so.  There is no CPU fallback.
 from __future__ import annotations
 
 import ctypes as C
+import functools
 import os
 import time
 import math
@@ -94,6 +95,11 @@ TIMER = _KernelTimer()
 
 def _run(fn, args, what: str, tag: str = "") -> None:
     """Call one C-ABI entry point, time it if the timer is on, raise on a non-zero code."""
+    if not TIMER.enabled:  # (the common case: no span object, no context manager)
+        rc = fn(*args)
+        if rc != 0:
+            check(rc, what)
+        return
     with TIMER.span(what[5:] + tag):
         rc = fn(*args)
     check(rc, what)
@@ -706,6 +712,14 @@ class _Workspace:
 
 
 WORKSPACE = _Workspace()
+
+
+@functools.lru_cache(maxsize=256)
+def quad_stream_sizes(Cn: int, tw: int, th: int, M: int):
+    """(fsgs_quad_stream_capacity, fsgs_quad_seg_slots) of a frame shape — pure functions of their arguments, asked
+    once per shape (with the no-wait binning M is the frame shape's capacity and repeats from frame to frame)."""
+    lib = load()
+    return int(lib.fsgs_quad_stream_capacity(Cn, tw, th, M)), int(lib.fsgs_quad_seg_slots(Cn, tw, th, M))
 _PACKED_ACC: dict = {}
 
 
@@ -768,9 +782,9 @@ class _Rasterize(torch.autograd.Function):
                 _run(lib.fsgs_live_payload, (ptr(isect_ids), ptr(flatten_ids), M, ptr(packed), Cn * N, tw,
                                             tile_bits(tw * th), ptr(payload), stream_ptr(dev)), "fsgs_live_payload")
             if needs_bwd:
-                cap = lib.fsgs_quad_stream_capacity(Cn, tw, th, M)
+                cap, slots = quad_stream_sizes(Cn, tw, th, M)
                 rec_bytes = 4 * cap * 48
-                seg_bytes = 4 * lib.fsgs_quad_seg_slots(Cn, tw, th, M) * 64 * (1 + D) * 4
+                seg_bytes = 4 * slots * 64 * (1 + D) * 4
                 nrec_bytes = 4 * n_tiles * 4
                 arena = WORKSPACE.take(a(rec_bytes) + a(seg_bytes) + a(nrec_bytes), dev)
                 records = arena[:rec_bytes].view(torch.float32)
