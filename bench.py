@@ -97,7 +97,7 @@ def parse():
                          "surface with the reference's op-by-op caller glue instead of the fused get_outputs node")
     ap.add_argument("--cpu-crop", type=int, default=280, help="CPU-baseline sample: central crop edge")
     ap.add_argument("--cpu-views", type=int, default=3)
-    ap.add_argument("--cpu-timeout", type=float, default=200.0)
+    ap.add_argument("--cpu-timeout", type=float, default=90.0)
     ap.add_argument("--cpu-threads", type=int, default=0, help="CPU baseline: cap on the threads (0 = all host cores)")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--spawn-timeout", type=float, default=float(os.environ.get("FSGS_SPAWN_TIMEOUT", "900")),
@@ -157,8 +157,12 @@ def cpu_baseline_worker(n_gauss: int, res: int, crop: int, threads: int, n_views
 
 
 def cpu_baseline(args):
-    """The oracle on ALL of this box's host cores (``cores`` = the threads torch was given = the cores this process may
-    run on), and — a pure-PyTorch rasterizer does not scale far — the same sample on 8 threads beside it (one view)."""
+    """The oracle on this box's host cores.  A pure-PyTorch rasterizer does not scale with threads (measured on the
+    256-core host of the GPU boxes: the 3-view sample that takes 22 s on 8 threads did not finish in 200 s on 256), so the
+    thread count is CHOSEN by measurement: one view of a smaller crop at all cores, 64, 16 and 8 threads, 25 s each at
+    most, then the full sample (``--cpu-views`` views, ``--cpu-crop``^2 crop) at the fastest count.  ``cores`` = the
+    threads of the quoted figure, ``host_cores_available`` = what the process may run on, ``thread_sweep_s`` = the
+    probe times (None = did not finish)."""
     import subprocess
     try:
         avail = len(os.sched_getaffinity(0))
@@ -167,29 +171,37 @@ def cpu_baseline(args):
     if args.cpu_threads and args.cpu_threads > 0:
         avail = min(avail, args.cpu_threads)
 
-    def child(threads, views, timeout):
+    def child(threads, views, crop, timeout):
         cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", "--n-gauss", "300000",
-               "--res", "800", "--cpu-crop", str(args.cpu_crop), "--cpu-threads", str(threads), "--cpu-views", str(views)]
+               "--res", "800", "--cpu-crop", str(crop), "--cpu-threads", str(threads), "--cpu-views", str(views)]
         env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads), HIP_VISIBLE_DEVICES="")
+        t0 = time.time()
         try:
             r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
             lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
             if r.returncode == 0 and lines:
-                return json.loads(lines[-1])
+                return json.loads(lines[-1]), time.time() - t0
             return {"value": None, "unit": "iters/s", "cores": threads, "kind": "port",
-                    "sample": f"oracle child failed rc={r.returncode}: {r.stderr[-200:]}"}
+                    "sample": f"oracle child failed rc={r.returncode}: {r.stderr[-200:]}"}, None
         except subprocess.TimeoutExpired:
             return {"value": None, "unit": "iters/s", "cores": threads, "kind": "port",
-                    "sample": f"oracle child exceeded {timeout}s on {views} {args.cpu_crop}^2 crops with {threads} threads"}
+                    "sample": f"oracle child exceeded {timeout}s on {views} {crop}^2 crops with {threads} threads"}, None
 
-    out = child(avail, args.cpu_views, args.cpu_timeout)
+    candidates = sorted({t for t in (avail, 64, 16, 8) if t <= avail}, reverse=True)
+    sweep = {}
+    best = None
+    if len(candidates) > 1:
+        for t in candidates:
+            res, secs = child(t, 1, 96, 25.0)
+            ok = res.get("value") is not None and secs is not None
+            sweep[str(t)] = round(secs, 1) if ok else None
+            if ok and (best is None or secs < sweep[str(best)]):
+                best = t
+    if best is None:
+        best = candidates[-1]
+    out, _ = child(best, args.cpu_views, args.cpu_crop, args.cpu_timeout)
     out["host_cores_available"] = avail
-    if avail > 8:
-        eight = child(8, 1, args.cpu_timeout / 2)
-        out["eight_threads"] = {k: eight.get(k) for k in ("value", "unit", "cores", "sample")}
-        if out.get("value") is None and eight.get("value") is not None:
-            # (the all-core run did not finish: the 8-thread figure is the baseline, the failure stays in the record)
-            out = dict(eight, host_cores_available=avail, all_cores_attempt=out.get("sample"))
+    out["thread_sweep_s"] = sweep or None
     return out
 
 
@@ -199,7 +211,8 @@ def bwd_dispatch_choice(dev, W, H):
         st = BWD_DISPATCH.state.get((str(dev), W, H))
         if not st or st["decided"] is None:
             return None
-        return {"stride": int(st["decided"]), "medians_ms": {str(k): round(v, 4) for k, v in st.get("medians_ms", {}).items()}}
+        return {"stride": int(st["decided"]), "medians_ms": {str(k): round(v, 4) for k, v in st.get("medians_ms", {}).items()},
+                "tuning_frames": int(st.get("tuning_frames", 0))}
     except Exception:
         return None
 
@@ -520,6 +533,18 @@ def main():
         for v in range(len(cams)):
             trainer.train_step(cams[v], targets[v], optimizer_step=False)
         torch.cuda.synchronize()
+        # the compositing backward's dispatch order is measured on a few early frames (the launch is issued twice on
+        # those: fused._BwdDispatchTuner): let it settle HERE, not inside the timed region (with 4 views and
+        # 4 warm-up steps config #5 timed some of its tuning frames)
+        if fused:
+            from fusionsense_amd.fused import BWD_DISPATCH
+            for extra in range(32):
+                st_ = BWD_DISPATCH.state.get((str(dev), W, H))
+                if BWD_DISPATCH.forced or (st_ is not None and st_["decided"] is not None):
+                    break
+                v = extra % len(cams)
+                trainer.train_step(cams[v], targets[v], optimizer_step=False)
+                torch.cuda.synchronize()
         strategy.stats_only = so
         strategy.xys_grad_norm = strategy.vis_counts = strategy.max_2Dsize = None
         log('workspace primed')
@@ -572,6 +597,7 @@ def main():
     torch.cuda.synchronize()
     n_alloc0 = torch.cuda.memory_stats(dev).get('num_device_alloc', 0)
     n_before = trainer.num_gaussians()
+    tune0 = (bwd_dispatch_choice(dev, W, H) or {}).get("tuning_frames", 0)
     t0 = time.perf_counter()
     step_ends = []
     # one event per step on the step's stream: the GPU-side duration of every step, read after the timed region
@@ -589,7 +615,8 @@ def main():
         step_ends.append(time.perf_counter())
     trainer.flush()  # (data-parallel runs: the last step's deferred feature update belongs to the timed work)
     torch.cuda.synchronize()
-    own_elapsed = time.perf_counter() - t0  # (this rank's own clock, before it waits for the others)
+    own_elapsed = time.perf_counter() - t0
+    tune_in_region = (bwd_dispatch_choice(dev, W, H) or {}).get("tuning_frames", 0) - tune0  # (this rank's own clock, before it waits for the others)
     barrier()
     elapsed = time.perf_counter() - t0
     gc.enable()
@@ -920,6 +947,9 @@ def main():
             # dispatch order of the compositing backward as measured and chosen in this run (fused._BwdDispatchTuner):
             # {"stride": 0 = row-major | k, "medians_ms": per candidate}; null while still measuring / when forced
             "bwd_dispatch": bwd_dispatch_choice(dev, W, H),
+            # frames of the timed region on which the tuner issued the launch twice (0: it had settled during the setup;
+            # it starts over when the model has grown or shrunk by a quarter)
+            "bwd_dispatch_tuning_frames_in_timed_region": tune_in_region,
             # steps whose Adam update was applied inside the per-Gaussian backward launch (no gradient slab, no Adam
             # launch: DESIGN.md §9.9; FSGS_ADAM_IN_BACKWARD=auto|1|0)
             "adam_in_backward_steps": int(getattr(trainer, "adam_in_backward_steps", 0)),

@@ -76,8 +76,10 @@ struct GetOutputsGrads {
 // Diagnostic build only (make EXTRA=-DFSGS_BWD_STATS OUT=../libfsgs_stats.so; tools/bwd_lane_stats.py): how full the
 // 64 lanes of a step are.  [0] loop iterations, [1] iterations executed (some lane valid), [2] lanes with a list entry
 // in executed iterations, [3] lanes that pass the alpha test in executed iterations, [4] segments, [5] segments walked
-// merged, [6] sum of the segments' longest row list, [7] sum of the segments' union sizes.
-__device__ unsigned long long g_bwd_stats[8];
+// merged, [6] sum of the segments' longest row list, [7] sum of the segments' union sizes, and — what a finer pixel group
+// would need — [8] sum over segments of max over the 8 half-rows (4x2 pixels) of the steps in which that half-row had a
+// valid lane, [9] the same for the 16 quads (2x2 pixels), [10] / [11] (step, half-row) / (step, quad) pairs with a valid lane.
+__device__ unsigned long long g_bwd_stats[12];
 #endif
 
 template <int D, bool ABS, int E>
@@ -215,6 +217,7 @@ raster_bwd_live_kernel(int64_t cap, const float4 *__restrict__ rec,
 
 #ifdef FSGS_BWD_STATS
     unsigned long long st_iter = 0, st_exec = 0, st_have = 0, st_valid = 0, st_seg = 0, st_merge = 0, st_long = 0, st_union = 0;
+    unsigned long long st_half_max = 0, st_quad_max = 0, st_half_pairs = 0, st_quad_pairs = 0;
 #endif
     for (int seg = n_seg - 1 - w; seg >= 0; seg -= kBwdWaves) {
         const int b0 = s + (seg << 6);          // first stream position of the segment
@@ -254,6 +257,7 @@ raster_bwd_live_kernel(int64_t cap, const float4 *__restrict__ rec,
         const bool merge = n_union > 0 && steps * 16 >= n_union * merge_thr16;
 #ifdef FSGS_BWD_STATS
         st_seg += 1; st_merge += merge ? 1 : 0; st_long += steps; st_union += n_union;
+        int half_cnt = 0, quad_cnt = 0;  // steps of this segment in which this lane's half-row / quad had a valid lane
 #endif
         const uint64_t below = (1ull << lane) - 1ull;
         if (merge) {
@@ -293,7 +297,20 @@ raster_bwd_live_kernel(int64_t cap, const float4 *__restrict__ rec,
             if (sigma < 0.f || fminf(kAlphaMax, a0.z * vis0) < kAlphaMin) valid = false;
 #ifdef FSGS_BWD_STATS
             st_iter += 1;
-            if (__any(valid)) { st_exec += 1; st_have += __popcll(__ballot(have)); st_valid += __popcll(__ballot(valid)); }
+            if (__any(valid)) {
+                st_exec += 1; st_have += __popcll(__ballot(have)); st_valid += __popcll(__ballot(valid));
+                const uint64_t vb = __ballot(valid);
+                // lane = 16 row + pl, pl = 4 y + x inside the 4x4 block: half-row = pl >> 3 (two pixel rows), quad = 2x2
+                const int hshift = (lane & ~7);
+                half_cnt += ((vb >> hshift) & 0xFFull) ? 1 : 0;
+                const int qy = (pl >> 3), qx = (pl >> 1) & 1;  // quad (qy, qx) holds pl in {8 qy + 2 qx + {0, 1, 4, 5}}
+                const uint64_t qmask = (0x33ull << (2 * qx + 8 * qy)) << (16 * row);
+                quad_cnt += (vb & qmask) ? 1 : 0;
+                for (int hh = 0; hh < 8; ++hh) st_half_pairs += ((vb >> (8 * hh)) & 0xFFull) ? 1 : 0;
+                for (int r4 = 0; r4 < 4; ++r4)
+                    for (int qq = 0; qq < 4; ++qq)
+                        st_quad_pairs += (vb & ((0x33ull << (2 * (qq & 1) + 8 * (qq >> 1))) << (16 * r4))) ? 1 : 0;
+            }
 #endif
             if (!__any(valid)) continue;
 
@@ -381,12 +398,20 @@ raster_bwd_live_kernel(int64_t cap, const float4 *__restrict__ rec,
         }
         };
         if (merge) walk(std::true_type{}); else walk(std::false_type{});
+#ifdef FSGS_BWD_STATS
+        {
+            int hm = half_cnt, qm = quad_cnt;
+            for (int d = 32; d >= 1; d >>= 1) { hm = max(hm, __shfl_xor(hm, d, 64)); qm = max(qm, __shfl_xor(qm, d, 64)); }
+            st_half_max += hm; st_quad_max += qm;
+        }
+#endif
         __builtin_amdgcn_wave_barrier();  // LDS reads of this segment precede the next segment's writes
     }
 #ifdef FSGS_BWD_STATS
     if (lane == 0) {
-        const unsigned long long v[8] = {st_iter, st_exec, st_have, st_valid, st_seg, st_merge, st_long, st_union};
-        for (int k = 0; k < 8; ++k) atomicAdd(&g_bwd_stats[k], v[k]);
+        const unsigned long long v[12] = {st_iter, st_exec, st_have, st_valid, st_seg, st_merge, st_long, st_union,
+                                          st_half_max, st_quad_max, st_half_pairs, st_quad_pairs};
+        for (int k = 0; k < 12; ++k) atomicAdd(&g_bwd_stats[k], v[k]);
     }
 #endif
 }
@@ -443,9 +468,9 @@ extern "C" int fsgs_set_bwd_dispatch_stride(int stride) { return g_bwd_dispatch_
 
 #ifdef FSGS_BWD_STATS
 extern "C" int fsgs_debug_bwd_stats(unsigned long long *out8, int reset) {
-    if (out8 && hipMemcpyFromSymbol(out8, HIP_SYMBOL(fsgs::g_bwd_stats), sizeof(unsigned long long) * 8) != hipSuccess) return -2;
+    if (out8 && hipMemcpyFromSymbol(out8, HIP_SYMBOL(fsgs::g_bwd_stats), sizeof(unsigned long long) * 12) != hipSuccess) return -2;
     if (reset) {
-        const unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        const unsigned long long z[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         if (hipMemcpyToSymbol(HIP_SYMBOL(fsgs::g_bwd_stats), z, sizeof(z)) != hipSuccess) return -2;
     }
     return 0;
