@@ -1077,3 +1077,33 @@ def test_other_loss_switches_on_both_trainer_routes_and_against_the_oracle(dev, 
     ref = loss_ref.get_loss_dict(o, b, params["scales"].double(), cfg=loss_ref.LossConfig(**kw),
                                  intrinsics=(cam.fx, cam.fy, cam.cx, cam.cy))["main_loss"]
     assert abs(res["direct"][0] - float(ref)) < 1e-4 * abs(float(ref)), (res["direct"][0], float(ref))
+
+
+def test_bench_line_carries_the_contract_fields():
+    """One small single-GPU run of bench.py as the driver invokes it: ONE JSON line with the contract's fields — metric /
+    value / unit / n_gpus / steps / warmup / ms_per_step / scaling / dtype / data / config.workload, the `roofline` object
+    of the dominant kernel (bound, achieved, peak, unit, frac, traffic), `cpu_baseline` (value, unit, cores, kind, sample)
+    — and this round's additions (L, pair ratio, tuner settled before the timed region)."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "6", "--warmup", "2", "--n-gauss", "30000",
+                        "--res", "256", "--views", "4", "--no-dropin", "--cpu-crop", "32", "--cpu-views", "1",
+                        "--cpu-threads", "8"], capture_output=True, text=True, env=env, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["metric"] == "train_iters_per_s" and d["unit"] == "iters/s" and d["n_gpus"] == 1 and d["steps"] == 6
+    assert d["warmup"] == 2 and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["dtype"] == "f32" and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    assert d["value"] == pytest.approx(1e3 / d["ms_per_step"], rel=2e-3)
+    ro = d["roofline"]
+    assert ro["bound"] == "hbm" and ro["unit"] == "GB/s" and ro["peak"] == 8000.0
+    assert ro["frac"] == pytest.approx(ro["achieved"] / ro["peak"], rel=1e-3) and 0 < ro["frac"] < 1 and "traffic" in ro
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb and cb["host_cores_available"] >= cb["cores"]
+    c = d["config"]
+    assert c["mean_walked_list"] > 1 and 0 < c["binned_over_rect_pairs"] <= 1 and c["max_walked_list"] >= c["mean_walked_list"]
+    assert d["bwd_dispatch_tuning_frames_in_timed_region"] == 0 and d["device_mallocs_in_timed_region"] == 0
+    assert 0 < d["iter_hbm_frac"] < 1 and d["iter_algorithmic_bytes"] <= d["iter_algorithmic_bytes_rect_pairs"]
