@@ -133,7 +133,9 @@ def case(model_mod, losses, seed, H, W, n_gauss, with_mask, with_touch, holes, m
                                                 mono_depth_lambda=np.array(cfg.mono_depth_lambda, dtype=np.float32))),
                 **({} if intr is None else dict(intr=np.array(intr, dtype=np.float64))),
                 **({} if (normal_supervision is None and smooth == "TV" and not cosine and depth_type == "EdgeAwareLogL1")
-                   else dict(switches=np.array([normal_supervision or "mono", smooth, "cosine" if cosine else "", depth_type]))))
+                   else dict(switches=np.array([["mono", "depth"].index(normal_supervision or "mono"),
+                                                ["TV", "EdgeAwareTV"].index(smooth), int(bool(cosine)),
+                                                ["EdgeAwareLogL1", "L1", "LogL1", "MSE"].index(depth_type)], dtype=np.int32))))  # (numeric codes)
 
 
 def main():

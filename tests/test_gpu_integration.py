@@ -189,8 +189,9 @@ def test_patched_get_loss_dict_matches_reference_goldens(dev, case):
     md = {"touch_patches": [{"normals": t("touch_normals")}]} if n_touch else {}
     over = {}
     if f"{case}.switches" in d.files:  # (round 4) the switches FusionSense leaves off — still on the HIP node
-        ns, sm, cs, dt = (str(x) for x in d[f"{case}.switches"])
-        over = dict(normal_supervision=ns, smooth_loss_type=sm, use_normal_cosine_loss=(cs == "cosine"), depth_loss_type=dt)
+        ns, sm, cs, dt = (int(x) for x in d[f"{case}.switches"])  # numeric codes, see make_reference_loss_goldens.py
+        over = dict(normal_supervision=["mono", "depth"][ns], smooth_loss_type=["TV", "EdgeAwareTV"][sm],
+                    use_normal_cosine_loss=bool(cs), depth_loss_type=["EdgeAwareLogL1", "L1", "LogL1", "MSE"][dt])
     m, _ = _model(dev, params, metadata=md, **over)
     if f"{case}.intr" in d.files:  # what normal_supervision == "depth" reads from the last get_outputs' camera
         fx, fy, cx, cy = (float(x) for x in d[f"{case}.intr"])

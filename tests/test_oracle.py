@@ -213,8 +213,9 @@ def loss_case_config(d, case, cls):
     type; absent for FusionSense's own configuration) and the camera intrinsics the depth-normal supervision read."""
     kw = {}
     if f"{case}.switches" in d.files:
-        ns, sm, cs, dt = (str(x) for x in d[f"{case}.switches"])
-        kw = dict(normal_supervision=ns, smooth_loss_type=sm, use_normal_cosine_loss=(cs == "cosine"), depth_loss_type=dt)
+        ns, sm, cs, dt = (int(x) for x in d[f"{case}.switches"])  # numeric codes, see make_reference_loss_goldens.py
+        kw = dict(normal_supervision=["mono", "depth"][ns], smooth_loss_type=["TV", "EdgeAwareTV"][sm],
+                  use_normal_cosine_loss=bool(cs), depth_loss_type=["EdgeAwareLogL1", "L1", "LogL1", "MSE"][dt])
     intr = tuple(float(x) for x in d[f"{case}.intr"]) if f"{case}.intr" in d.files else None
     return cls(**kw), intr
 
