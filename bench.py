@@ -538,11 +538,14 @@ def main():
         # 4 warm-up steps config #5 timed some of its tuning frames)
         if fused:
             from fusionsense_amd.fused import BWD_DISPATCH
-            for extra in range(32):
+            # (several ranks: a FIXED number of extra frames — every step carries collectives, so the ranks must not
+            # decide from their own timings how many they run; 12 covers the tuner's warm-up + 2 x 4 pairs)
+            for extra in range(12 if grouped else 32):
                 st_ = BWD_DISPATCH.state.get((str(dev), W, H))
-                if BWD_DISPATCH.forced or (st_ is not None and st_["decided"] is not None):
+                settled = BWD_DISPATCH.forced or (st_ is not None and st_["decided"] is not None)
+                if settled and not grouped:
                     break
-                v = extra % len(cams)
+                v = (extra * world + rank) % len(cams)
                 trainer.train_step(cams[v], targets[v], optimizer_step=False)
                 torch.cuda.synchronize()
         strategy.stats_only = so
