@@ -99,6 +99,7 @@ SIGNATURES = {
     "fsgs_mask_scan": (_i, [_i64, _p, _p, _p, _sz, _p]),
     "fsgs_compact_rows": (_i, [_i64, _i, _p, _p, _p, _p, _p]),
     "fsgs_nearest_point": (_i, [_i, _p, _i, _p, _p, _p, _p]),
+    "fsgs_knn_points": (_i, [_i64, _p, _i, _p, _i, _i, _p, _p]),
     "fsgs_split_samples": (_i, [_i64, _i, _p, _p, _p, _p, _p, _p, _p, _p]),
     "fsgs_ssim_l1_num_partials": (_i64, [_i, _i]),
     "fsgs_ssim_l1_fwd": (_i, [_i, _i, _p, _p, _p, _p, _p, _p, _p]),

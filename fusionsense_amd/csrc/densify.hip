@@ -125,9 +125,78 @@ nearest_point_kernel(int nq, const float *__restrict__ q, int np, const float *_
     }
 }
 
+// The k nearest points of a set for every query (compute_level_surface_points' knn_sk, dn_model.py:1762-1764, and
+// sklearn's kneighbors behind it): brute force like nearest_point_kernel — the point set streams through LDS in tiles of
+// 1024 (broadcast reads), a thread keeps its query and a sorted list of its KK best (distance, index) pairs in
+// registers; a candidate is first tested against the list's worst entry (one compare: after the first few hundred points
+// almost every candidate fails it) and only then sifted in through an unrolled compare-exchange chain.  Exact fp32
+// differences, every product and sum rounded on its own (no contraction: the order of torch's elementwise formulation);
+// ties -> lowest index.  out_idx [nq, KK - skip]: the neighbours ranked skip .. KK - 1 (skip = 1 is knn_sk's
+// "drop the first column").  640 k queries x 300 k points (one 800 x 800 frame against config #2): O(100 ms) instead of
+// the ~10 s of a KD-tree on the host.
+template <int KK>
+__global__ void __launch_bounds__(256)
+knn_points_kernel(int64_t nq, const float *__restrict__ q, int np, const float *__restrict__ p, int kk, int skip,
+                  int64_t *__restrict__ out_idx) {
+    __shared__ float sp[1024 * 3];
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool on = i < nq;
+    const float qx = on ? q[i * 3 + 0] : 0.f, qy = on ? q[i * 3 + 1] : 0.f, qz = on ? q[i * 3 + 2] : 0.f;
+    float bd[KK];
+    int bi[KK];
+#pragma unroll
+    for (int s = 0; s < KK; ++s) { bd[s] = INFINITY; bi[s] = 0; }
+    // (lists shorter than KK: the entries beyond kk are never reported; the worst REPORTED entry is slot kk - 1)
+    for (int base = 0; base < np; base += 1024) {
+        const int n = min(1024, np - base);
+        __syncthreads();
+        for (int k = threadIdx.x; k < n * 3; k += 256) sp[k] = p[(int64_t)base * 3 + k];
+        __syncthreads();
+        for (int j = 0; j < n; ++j) {
+            const float dx = qx - sp[j * 3 + 0], dy = qy - sp[j * 3 + 1], dz = qz - sp[j * 3 + 2];
+            const float d2 = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+            if (d2 < bd[KK - 1]) {
+                float cd = d2;
+                int ci = base + j;
+                bool inserted = false;
+#pragma unroll
+                for (int s = 0; s < KK; ++s) {  // sift in: strict <, so equal distances keep the earlier index in front;
+                    const bool before = inserted || cd < bd[s];  // once inserted, the rest of the list shifts down
+                    inserted = before;
+                    const float td = before ? bd[s] : cd;
+                    const int ti = before ? bi[s] : ci;
+                    bd[s] = before ? cd : bd[s];
+                    bi[s] = before ? ci : bi[s];
+                    cd = td; ci = ti;
+                }
+            }
+        }
+    }
+    if (on) {
+#pragma unroll
+        for (int s = 0; s < KK; ++s)
+            if (s >= skip && s < kk) out_idx[i * (kk - skip) + (s - skip)] = bi[s];
+    }
+}
+
 }  // namespace fsgs
 
 using namespace fsgs;
+
+extern "C" int fsgs_knn_points(int64_t nq, const float *queries, int np, const float *points, int k, int skip,
+                               int64_t *out_idx, fsgs_stream_t stream) {
+    // k = neighbours searched per query (<= 33, <= np), skip = leading ones not reported (0 or 1): out_idx [nq, k - skip]
+    if (nq < 0 || np < 1 || k < 1 || k > 33 || k > np || skip < 0 || skip >= k) return FSGS_EINVAL;
+    if (nq == 0) return FSGS_OK;
+    if (!queries || !points || !out_idx) return FSGS_EINVAL;
+    const dim3 grid((unsigned)((nq + 255) / 256));
+    hipStream_t s = as_stream(stream);
+    // (the list is kept at its compiled length; with k below it the worst kept entry is still slot KK - 1, so the list
+    // holds the KK best and the first k of them are the k best)
+    if (k <= 17) hipLaunchKernelGGL(knn_points_kernel<17>, grid, dim3(256), 0, s, nq, queries, np, points, k, skip, out_idx);
+    else hipLaunchKernelGGL(knn_points_kernel<33>, grid, dim3(256), 0, s, nq, queries, np, points, k, skip, out_idx);
+    return check_launch();
+}
 
 extern "C" int fsgs_normals_fwd(int N, const float *quats, const float *log_scales, const float *means,
                                 const float *c2w, float *normals_world, float *normals_cam,

@@ -252,6 +252,15 @@ def knn_drop_first(x: Tensor, y: Tensor, k: int) -> Tensor:
     x, y = x.float(), y.float().to(x.device)
     n, m = x.shape[0], y.shape[0]
     kk = min(k + 1, n)
+    if x.is_cuda and kk <= 33:
+        # on the device: one launch of the brute-force k-NN kernel (fsgs_knn_points; ~100 ms for a full 800 x 800 frame
+        # against 300 k Gaussians, where the chunked torch formulation below needs hundreds of [chunk, N] passes)
+        from ._lib import load, ptr, stream_ptr
+        from .ops import _run
+        out = torch.empty(m, kk - 1, dtype=torch.int64, device=x.device)
+        xc, yc = x.contiguous(), y.contiguous()
+        _run(load().fsgs_knn_points, (m, ptr(yc), n, ptr(xc), kk, 1, ptr(out), stream_ptr(x.device)), "fsgs_knn_points")
+        return out
     out = torch.empty(m, kk - 1, dtype=torch.int64, device=x.device)
     chunk = max(1, min(m, (1 << 28) // max(n, 1)))
     for s in range(0, m, chunk):
@@ -277,14 +286,16 @@ def gaussian_density(samples: Tensor, idx: Tensor, means: Tensor, inv_scaled_rot
     up to the factor the "analytical" normal normalises away (:1900-1919)."""
     shift = samples[:, None, :] - means[idx]                       # [S,k,3]
     M = inv_scaled_rot[idx]                                        # [S,k,3,3]
-    man = (M.transpose(-1, -2) @ shift[..., None])                 # [S,k,3,1]
-    d2 = (man[..., 0] * man[..., 0]).sum(dim=-1).clamp(min=0.0, max=1e8)
+    # M^T shift and M man as explicit 3-term sums: tens of millions of 3x3 products per pass are elementwise work, not
+    # a batched GEMM (a [32 M]-batch bmm of 3x3 matrices faulted in the BLAS library on the GPU box)
+    man = (M * shift[..., :, None]).sum(dim=-2)                    # [S,k,3]: sum_i M[i][j] shift[i]
+    d2 = (man * man).sum(dim=-1).clamp(min=0.0, max=1e8)
     w = strengths[idx][..., 0] * torch.exp(-0.5 * d2)              # [S,k]
     dens = w.sum(dim=-1)
     big = dens >= 1.0
     dens = torch.where(big, dens / (dens + 1e-5), dens)
     if want_grad:
-        return dens, (w[..., None] * (M @ man)[..., 0]).sum(dim=-2)
+        return dens, (w[..., None] * (M * man[..., None, :]).sum(dim=-1)).sum(dim=-2)
     return dens
 
 
@@ -324,7 +335,7 @@ def level_surface_points_from_render(params: Dict[str, Tensor], normals_world: T
     viewdirs = viewdirs / viewdirs.norm(dim=-1, keepdim=True)
     qn = quats / quats.norm(dim=-1, keepdim=True)
     inv_rots = _quat_to_rotmat(qn * torch.tensor([1.0, -1.0, -1.0, -1.0], device=dev))  # invert_quaternion (:2153-2163)
-    stds = (torch.exp(scales) * torch.bmm(inv_rots, viewdirs[..., None])[..., 0]).norm(dim=-1)
+    stds = (torch.exp(scales) * (inv_rots * viewdirs[:, None, :]).sum(dim=-1)).norm(dim=-1)  # (R^-1 viewdir, no BLAS)
     points_stds = stds[closest][..., 0]
 
     n_in_range = 21

@@ -474,6 +474,12 @@ int fsgs_compact_rows(int64_t n_rows, int row_floats, const uint8_t *keep,
  * (dn_splatter/dn_model.py:1258-1264) and the k=1 neighbour search of add_touch_patch (:1181-1182). */
 int fsgs_nearest_point(int nq, const float *queries, int np, const float *points, float *out_dist,
                        int64_t *out_idx, fsgs_stream_t stream);
+/* The k nearest points (exact fp32 differences, brute force, ties -> lowest index) of every query, reported from rank
+ * `skip` on: out_idx [nq, k - skip] int64.  k <= 33, k <= np; skip = 1 reproduces dn_splatter/utils/knn.py:29-44
+ * (knn_sk asks sklearn for k + 1 neighbours and drops the first column) — what compute_level_surface_points
+ * (dn_model.py:1762-1764) tracks per back-projected pixel.  No counterpart in gsplat. */
+int fsgs_knn_points(int64_t nq, const float *queries, int np, const float *points, int k, int skip, int64_t *out_idx,
+                    fsgs_stream_t stream);
 /* split_gaussians sample kernel: for every selected parent p (ids[S]) and sample s<n_samples,
  * new_mean = mean[p] + R(q[p]/|q|) (exp(log_scale[p]) * z[s*S+i]); new_log_scale = log(exp(ls)/1.6).
  * Writes new_means[n_samples*S,3], new_log_scales[n_samples*S,3] (sample-major, like .repeat). */

@@ -1107,3 +1107,35 @@ def test_bench_line_carries_the_contract_fields():
     assert c["mean_walked_list"] > 1 and 0 < c["binned_over_rect_pairs"] <= 1 and c["max_walked_list"] >= c["mean_walked_list"]
     assert d["bwd_dispatch_tuning_frames_in_timed_region"] == 0 and d["device_mallocs_in_timed_region"] == 0
     assert 0 < d["iter_hbm_frac"] < 1 and d["iter_algorithmic_bytes"] <= d["iter_algorithmic_bytes_rect_pairs"]
+
+
+def test_knn_kernel_is_sklearn_minus_its_first_column(dev):
+    """fsgs_knn_points (what inference.knn_drop_first runs on the GPU) against sklearn's NearestNeighbors — the library
+    behind the reference's knn_sk (utils/knn.py:29-44): k + 1 neighbours, first column dropped; k = 16 (knn_to_track) and
+    the long-list instantiation; duplicate points keep ascending index order; a frame-sized query set runs in one launch."""
+    from sklearn.neighbors import NearestNeighbors
+    from fusionsense_amd.inference import knn_drop_first
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(5000, 3, generator=g)
+    x[100:110] = x[50]  # duplicates: ties on the distance
+    y = torch.randn(1777, 3, generator=g)
+    for k in (1, 16, 24):
+        ref = NearestNeighbors(n_neighbors=k + 1, algorithm="brute", metric="euclidean").fit(x.double().numpy()).kneighbors(y.double().numpy())
+        got = knn_drop_first(x.to(dev), y.to(dev), k).cpu()
+        assert got.shape == (1777, k)
+        # compare through the distances (sklearn's order among exact ties is unspecified)
+        d_got = (y[:, None, :] - x[got]).double().norm(dim=-1)
+        assert torch.allclose(d_got, torch.from_numpy(ref[0][:, 1:]), rtol=1e-5, atol=1e-6), k
+        same = (got.numpy() == ref[1][:, 1:]).mean()
+        assert same > 0.995, (k, same)
+    # the tied points come out in ascending index order
+    q = x[50:51].to(dev)
+    idx = knn_drop_first(x.to(dev), q, 10).cpu()[0].tolist()
+    tied = [i for i in idx if i == 50 or 100 <= i < 110]
+    assert tied == sorted(tied) and len(tied) >= 9
+    # and equals the chunked torch formulation bit for bit on the device-free path's own arithmetic
+    x2 = torch.randn(5000, 3, generator=g)  # (no duplicates: torch.topk's order among exact ties is unspecified too)
+    cpu = knn_drop_first(x2, y[:300], 16)
+    assert torch.equal(cpu, knn_drop_first(x2.to(dev), y[:300].to(dev), 16).cpu())
+    big = knn_drop_first(torch.randn(300_000, 3, generator=g).to(dev), torch.randn(200_000, 3, generator=g).to(dev), 16)
+    assert big.shape == (200_000, 16) and int(big.min()) >= 0 and int(big.max()) < 300_000

@@ -786,3 +786,34 @@ def test_no_wait_step_is_bit_identical_and_survives_overflow(dev, full_scene):
     for k in PARAM_ORDER:
         d = (d_.params[k].data - e_.params[k].data).abs()
         assert float((d > 2e-5).float().mean()) < 2e-2, k
+
+
+def test_level_sets_of_a_full_size_frame(dev, full_scene):
+    """The level-set extraction (dn_model.py:1706-1946) at config #2's own size — 300 k Gaussians, one 800x800 frame:
+    ~640 k back-projected pixels x 16 tracked Gaussians x 21 ray samples (13 M density evaluations per pass) — runs on
+    the device (k-NN kernel + elementwise passes; a [32 M]-batch 3x3 bmm used to fault in the BLAS library), finds
+    surface points for every level on the scene's surfaces, nested as the levels are."""
+    from fusionsense_amd import inference as inf
+    from fusionsense_amd.trainer import SplatTrainer
+    params, cams = full_scene
+    tr = SplatTrainer(params, dev, sh_degree=3)
+    res = inf.compute_level_surface_points(tr, cams[0], 50_000)
+    torch.cuda.synchronize()
+    n = [res[lv]["points"].shape[0] for lv in (0.1, 0.3, 0.5)]
+    assert all(0 < k <= 50_000 for k in n), n
+    for lv in (0.1, 0.3, 0.5):
+        P, Nn = res[lv]["points"], res[lv]["normals"]
+        assert bool(torch.isfinite(P).all()) and float(P.abs().max()) < 1.6  # the scene lives in [-1, 1]^3
+        assert torch.allclose(Nn.norm(dim=-1), torch.ones_like(Nn[:, 0]), atol=1e-3)
+    # without sub-sampling: thousands of crossings per level, each pixel at most once, every point on its pixel's ray
+    full = inf.compute_level_surface_points(tr, cams[0], 10 ** 9)
+    cam = cams[0]
+    c2w = torch.eye(4, device=dev)
+    c2w[:3] = cam.c2w.to(dev)
+    c2w = (c2w @ torch.diag(torch.tensor([1.0, -1.0, -1.0, 1.0], device=dev)))[:3]
+    for lv in (0.1, 0.3, 0.5):
+        pid = full[lv]["pixel_ids"]
+        assert pid.numel() > 1000 and pid.unique().numel() == pid.numel()
+        uv = inf.project_pix(full[lv]["points"], cam.fx, cam.fy, cam.cx, cam.cy, c2w)
+        assert torch.allclose(uv[:, 0], (pid % cam.width).float() + 0.5, atol=5e-2)
+        assert torch.allclose(uv[:, 1], (pid // cam.width).float() + 0.5, atol=5e-2)
