@@ -618,8 +618,8 @@ def main():
         step_ends.append(time.perf_counter())
     trainer.flush()  # (data-parallel runs: the last step's deferred feature update belongs to the timed work)
     torch.cuda.synchronize()
-    own_elapsed = time.perf_counter() - t0
-    tune_in_region = (bwd_dispatch_choice(dev, W, H) or {}).get("tuning_frames", 0) - tune0  # (this rank's own clock, before it waits for the others)
+    own_elapsed = time.perf_counter() - t0  # (this rank's own clock, before it waits for the others)
+    tune_in_region = (bwd_dispatch_choice(dev, W, H) or {}).get("tuning_frames", 0) - tune0
     barrier()
     elapsed = time.perf_counter() - t0
     gc.enable()
