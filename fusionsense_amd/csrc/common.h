@@ -251,4 +251,16 @@ __device__ __forceinline__ void ld_attr3(const void *p, int64_t n, int half, flo
     o[2] = ld_attr(p, n * 3 + 2, half);
 }
 
+// Non-temporal 16-byte accesses for data that is written once and read once (record streams, Adam streams of large
+// scenes): they leave the caches to the data that is re-used (gathered records, gradient lines).
+typedef float fsgs_nt_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 nt_load_f4(const float4 *p) {
+    const fsgs_nt_f4 v = __builtin_nontemporal_load(reinterpret_cast<const fsgs_nt_f4 *>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void nt_store_f4(const float4 &v, float4 *p) {
+    fsgs_nt_f4 t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<fsgs_nt_f4 *>(p));
+}
+
 }  // namespace fsgs

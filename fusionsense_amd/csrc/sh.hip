@@ -673,8 +673,11 @@ __device__ __forceinline__ void adam_rows_g(const GaussAdam &a, int grp, int64_t
             const int i = i0 + u * kShBlock;
             idle[u] = true;
             if (i < total4) {
-                m[u] = M4[i]; v[u] = V4[i];
-                if (!SKIP) p[u] = P4[i];
+                // (non-temporal: each element of the three streams is read once and written once per frame, and at 6 M
+                // Gaussians they are 3.5 GB — kept out of the L2 / MALL they stop evicting the gradient lines this launch
+                // gathers: 2.14-2.18 ms -> 1.65-1.92 ms at config #4, four runs each; no change at 300 k)
+                m[u] = nt_load_f4(&M4[i]); v[u] = nt_load_f4(&V4[i]);
+                if (!SKIP) p[u] = nt_load_f4(&P4[i]);
                 const int e = i << 2;
                 int r = e / RF, col = e - r * RF;
 #pragma unroll
@@ -708,7 +711,7 @@ __device__ __forceinline__ void adam_rows_g(const GaussAdam &a, int grp, int64_t
             adam_one(p[u].y, g[u][1], m[u].y, v[u].y, a.b1, a.b2, a.omb1, a.omb2, ss, a.isb2, a.eps);
             adam_one(p[u].z, g[u][2], m[u].z, v[u].z, a.b1, a.b2, a.omb1, a.omb2, ss, a.isb2, a.eps);
             adam_one(p[u].w, g[u][3], m[u].w, v[u].w, a.b1, a.b2, a.omb1, a.omb2, ss, a.isb2, a.eps);
-            P4[i] = p[u]; M4[i] = m[u]; V4[i] = v[u];
+            nt_store_f4(p[u], &P4[i]); nt_store_f4(m[u], &M4[i]); nt_store_f4(v[u], &V4[i]);
             if (H) {
                 const __half2 lo = __floats2half2_rn(p[u].x, p[u].y), hi = __floats2half2_rn(p[u].z, p[u].w);
                 uint2 o;
