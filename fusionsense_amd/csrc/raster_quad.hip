@@ -65,8 +65,9 @@ raster_fwd_quad_kernel(int64_t cap, const float4 *__restrict__ packed, const int
     constexpr int RS = E ? 4 : 3;
     // workgroup b runs on XCD b % 8: the four quadrants of a tile share its list and its Gaussians,
     // so they are given ids that differ by 8 (same XCD, dispatched together)
-    const int tile_lin = (blockIdx.x >> 5) * 8 + (blockIdx.x & 7);
-    const int q = (blockIdx.x >> 3) & 3;
+    const unsigned bid = blockIdx.x;
+    const int tile_lin = (bid >> 5) * 8 + (bid & 7);
+    const int q = (bid >> 3) & 3;
     if (tile_lin >= n_tiles_total) return;
     const int cam = tile_lin / (tw * th);
     const int tile_in = tile_lin - cam * tw * th;
@@ -290,8 +291,270 @@ raster_fwd_quad_kernel(int64_t cap, const float4 *__restrict__ packed, const int
         // the memory side); non-negative floats order like their bit patterns
         if (tid == 0) {
             const int mm = max(max(S.wcount[0], S.wcount[1]), max(S.wcount[2], S.wcount[3]));
-            if (mm > 0) atomicMax(reinterpret_cast<int *>(max_last) + (blockIdx.x & (kMaxCells - 1)), mm);
+            if (mm > 0) atomicMax(reinterpret_cast<int *>(max_last) + (bid & (kMaxCells - 1)), mm);
         }
+    }
+}
+
+#ifndef FSGS_FWD_WAVE_OCC
+#define FSGS_FWD_WAVE_OCC 6  // waves per SIMD: 4 / 6 / 8 measured at 92.5 / 85.0 / 87.8 us (config #2), 0.598 / 0.550 / 0.562 ms (#4)
+#endif
+// Third generation (round 4), the training path's forward (D = 4, E = 3): ONE WAVE per 8x8 quadrant, lane = pixel, one
+// record per step.  The (pixel, slot) walk above spends ~50 vector instructions per step of 4 records x 16 pixels — 50 per
+// (quadrant, record) — of which the quad prefix products, the slot selects and the four-way reductions are pure
+// bookkeeping; with one record per step and all 64 lanes on one pixel each, a (quadrant, record) costs 27 (the plain
+// arithmetic of the reference's loop body).  Counters at config #2: 24.6 M vector instructions per launch against 49.1 M.
+//   * the wave takes the tile's list 64 entries at a time (payloads two chunks ahead, the 64-byte lines of the entries
+//     with its quadrant bit one chunk ahead), streams them out for the backward (no padding records) and parks them in
+//     LDS, structure of arrays; the walk reads ONE record per step with broadcast reads (52 B per lane), the next
+//     record's reads issued before this one's use, two register sets in turn;
+//   * finished pixels have gate = 0 (their alpha is 0, nothing passes), the number of open pixels is a wave-uniform
+//     counter, wave masks are taken from the compares themselves; the hot loop runs to the next 64-record boundary, the
+//     segment-state stores sit outside it;
+//   * long lists first: the grid holds every quadrant twice, the first copy walks the quadrants of tiles with more than
+//     twice the mean list length, the second copy the others (the other copy leaves at once, ~3 us per launch) — a lone
+//     wave advances at ~0.17 us per record whatever shares its SIMD, so the longest walks of a frame (450 records at
+//     config #2: 75 us) must start at once.
+// Measured (MI355X, us per launch, config #2 / #3 / #4): second generation 95 / 99 / 675, this kernel 85 / 90 / 550.
+// Measured and dropped on the way (profiles/README.md): the record through the scalar cache
+// (s_load_dwordx16 of its line, operands in SGPRs, 135 / 121 / 920: one line in flight per wave, and a deeper queue does
+// not fit the 102 SGPRs); four records per step branch-free (115 / 138 / 980); s_setprio for the long walks (no effect);
+// long-lists-first for the second-generation kernel (98: it is not bound by its tail).
+#ifdef FSGS_FWD_TRACE
+// Diagnostic build only (tools/fwd_trace.py): start / end clock, records walked, list length, chunks of every wave.
+__device__ long long g_fwd_trace[1 << 17][6];
+#endif
+template <int E>
+struct WaveLds { float4 r0[66], r1[66], r2[66], r3[E ? 66 : 1]; };  // (+2: the walk reads one record ahead)
+
+template <int D, int E>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FSGS_FWD_WAVE_OCC, FSGS_FWD_WAVE_OCC)))
+raster_fwd_wave_kernel(int64_t cap, const float4 *__restrict__ packed, const int32_t *__restrict__ payload,
+                       const int32_t *__restrict__ tile_offsets, int64_t n_isects,
+                       const float *__restrict__ backgrounds, int W, int H, int tw, int th, int n_tiles_total,
+                       float *__restrict__ render, float *__restrict__ alphas, int32_t *__restrict__ last_ids,
+                       float4 *__restrict__ rec_out, int32_t *__restrict__ n_rec,
+                       float *__restrict__ seg_state, int64_t seg_cap, int normalize_last,
+                       float *__restrict__ render_extra, float *__restrict__ max_last, int ends_on_device,
+                       int32_t *__restrict__ tile_open) {
+    __shared__ WaveLds<E> S;
+    constexpr int RS = E ? 4 : 3;
+#ifdef FSGS_FWD_TRACE
+    const long long t_start = wall_clock64();
+#endif
+    // long lists first (see above)
+    const unsigned half_grid = gridDim.x >> 1;
+    const bool long_pass = blockIdx.x < half_grid;
+    const unsigned bid = long_pass ? blockIdx.x : blockIdx.x - half_grid;
+    const int tile_lin = (bid >> 5) * 8 + (bid & 7);
+    const int q = (bid >> 3) & 3;
+    if (tile_lin >= n_tiles_total) return;
+    {
+        const int total = ends_on_device ? tile_offsets[n_tiles_total] : (int)n_isects;
+        const int a0 = tile_offsets[tile_lin];
+        const int a1 = (tile_lin == n_tiles_total - 1 && !ends_on_device) ? (int)n_isects : tile_offsets[tile_lin + 1];
+        const bool is_long = (int64_t)(a1 - a0) * n_tiles_total > 2ll * total;
+        if (is_long != long_pass) return;
+    }
+    const int cam = tile_lin / (tw * th);
+    const int tile_in = tile_lin - cam * tw * th;
+    const int tile_y = tile_in / tw, tile_x = tile_in - tile_y * tw;
+    const int qx = 2 * tile_x + (q & 1), qy = 2 * tile_y + (q >> 1);
+    const int lane = threadIdx.x;
+    const int j = qx * 8 + (lane & 7), i = qy * 8 + (lane >> 3);  // lane = the pixel's row-major index in the quadrant
+    const float px = (float)j + 0.5f, py = (float)i + 0.5f;
+    const bool inside = (i < H) && (j < W);
+    // a finished pixel (outside the image, or stopped) has gate = 0: its alpha is 0 and nothing passes any more; the
+    // number of unfinished pixels is a wave-uniform counter (no per-lane flag carried through the loop)
+    float gate = inside ? 1.f : 0.f;
+    int n_open = __popcll(__builtin_amdgcn_ballot_w64(inside));
+
+    const int l0 = tile_offsets[tile_lin];
+    const int l1 = (tile_lin == n_tiles_total - 1 && !ends_on_device) ? (int)n_isects : tile_offsets[tile_lin + 1];
+    const int64_t sbase = (int64_t)l0 + 4ll * tile_lin;
+    float4 *stream = rec_out ? rec_out + RS * ((int64_t)q * cap + sbase) : nullptr;
+    constexpr int SS = 64 * (1 + D + E);
+    float *seg_q = seg_state ? seg_state + (int64_t)q * seg_cap * SS : nullptr;
+
+    float T = 1.f;
+    int32_t cur_idx = 0;
+    float pix[D], pxe[E ? E : 1];
+#pragma unroll
+    for (int k = 0; k < D; ++k) pix[k] = 0.f;
+#pragma unroll
+    for (int k = 0; k < E; ++k) pxe[k] = 0.f;
+
+    // the list is taken 64 entries at a time: lane l holds entry c0 + l; payloads are fetched two chunks ahead, the
+    // records of the lanes whose entry carries this quadrant's bit one chunk ahead (for the backward's stream)
+    auto load_pay = [&](int c0) -> uint32_t {
+        const int idx = c0 + lane;
+        return (idx < l1) ? (uint32_t)payload[idx] : 0u;
+    };
+    uint32_t pay_cur = load_pay(l0);
+    uint32_t pay_nxt = (l0 + 64 < l1) ? load_pay(l0 + 64) : 0u;
+    float4 f0, f1, f2, f3;
+    auto gather = [&](uint32_t pay) {
+        if ((pay >> (28 + q)) & 1u) {
+            const float4 *src = packed + (int64_t)(pay & 0x0FFFFFFFu) * 4;
+            f0 = src[0]; f1 = src[1]; f2 = src[2];
+            if (E) f3 = src[3];
+        }
+    };
+    gather(pay_cur);
+
+    int cnt = 0;  // records streamed so far
+    auto composite_v = [&](float mx, float my, float op, float ca, float cb, float cc, auto colour, int idx) {
+        const float dx = mx - px, dy = my - py;
+        const float sigma = 0.5f * (ca * dx * dx + cc * dy * dy) + cb * dx * dy;
+        const float alpha = fminf(kAlphaMax, (op * gate) * __expf(-sigma));
+        // (wave masks taken from the compares themselves: a ballot of a combined flag costs two vector instructions)
+        const bool ok_s = !(sigma < 0.f), ok_a = !(alpha < kAlphaMin);
+        const uint64_t pm = __builtin_amdgcn_ballot_w64(ok_s) & __builtin_amdgcn_ballot_w64(ok_a);
+        if (pm) {
+            const float Tn = T * (1.f - alpha);
+            // a record that would take T to <= 1e-4 ends the pixel and is not composited
+            const bool low = Tn <= kTMin;
+            const uint64_t sm = __builtin_amdgcn_ballot_w64(low) & pm;
+            if (ok_s && ok_a && !low) {
+                const float vis = alpha * T;
+                float c7[7];
+                colour(c7);
+                pix[0] += c7[0] * vis;
+                if (D > 1) pix[1] += c7[1] * vis;
+                if (D > 2) pix[2] += c7[2] * vis;
+                if (D > 3) pix[D - 1] += c7[3] * vis;
+                if (E) {
+                    pxe[0] += c7[4] * vis;
+                    if (E > 1) pxe[1] += c7[5] * vis;
+                    if (E > 2) pxe[E - 1] += c7[6] * vis;
+                }
+                cur_idx = idx;
+                T = Tn;
+            }
+            if (sm) {
+                if (ok_s && ok_a && low) gate = 0.f;
+                n_open -= __popcll(sm);
+            }
+        }
+    };
+    for (int c0 = l0; c0 < l1; c0 += 64) {
+        if (n_open == 0) break;  // every pixel is opaque (or outside)
+        const uint32_t pay = pay_cur;
+        const bool live = (pay >> (28 + q)) & 1u;
+        uint64_t m = __builtin_amdgcn_ballot_w64(live);
+        if (stream && live) {
+            const int pos = cnt + __popcll(m & ((1ull << lane) - 1ull));
+            f1.z = __int_as_float(c0 + lane);
+            f1.w = __int_as_float((int)(pay & 0x0FFFFFFFu));
+            float4 *dst = stream + RS * (int64_t)pos;
+            dst[0] = f0; dst[1] = f1; dst[2] = f2;
+            if (E) dst[3] = f3;
+        }
+        const float4 g0 = f0, g1 = f1, g2 = f2, g3 = f3;  // (this chunk's records, parked below)
+        pay_cur = pay_nxt;
+        if (c0 + 64 < l1) gather(pay_cur);
+        pay_nxt = (c0 + 128 < l1) ? load_pay(c0 + 128) : 0u;
+        if (!m) continue;
+
+        {
+            // the chunk's records parked in LDS in list order (structure of arrays: conflict-free 16-byte writes); every
+            // step all lanes read ONE record (broadcast reads), the next record's reads issued before this one's use
+            __builtin_amdgcn_s_barrier();  // (one wave: the previous chunk's reads are done)
+            static_assert(E == 3, "the list index rides in the free fourth word of the normal-plane record");
+            if (live) {
+                const int pos = __popcll(m & ((1ull << lane) - 1ull));
+                S.r0[pos] = g0; S.r1[pos] = g1; S.r2[pos] = g2;
+                S.r3[pos] = make_float4(g3.x, g3.y, g3.z, __int_as_float(c0 + lane));
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            const int n = __popcll(m);
+            // Two register sets in turn (a copy per record would cost as much as the walk saves); the hot loop runs to
+            // the next 64-record boundary of the stream, so the segment-state stores stay outside it.
+            auto lds_rec = [&](int k, float4 &r0, float2 &r1, float4 &r2, float4 &r3) {
+                r0 = S.r0[k];
+                r1 = *reinterpret_cast<const float2 *>(&S.r1[k]);
+                r2 = S.r2[k];
+                r3 = S.r3[k];
+            };
+            auto step = [&](const float4 &r0, const float2 &r1, const float4 &r2, const float4 &r3) {
+                composite_v(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y,
+                            [&](float *c7) {
+                                c7[0] = r2.x; c7[1] = r2.y; c7[2] = r2.z; c7[3] = r2.w;
+                                c7[4] = r3.x; c7[5] = r3.y; c7[6] = r3.z;
+                            }, __float_as_int(r3.w));
+            };
+            int k = 0;
+            while (k < n) {
+                const int run = min(n - k, 64 - (cnt & 63));
+                int r = 0;
+                if (n_open) {
+                    float4 a0, a2, a3, b0, b2, b3;
+                    float2 a1, b1;
+                    lds_rec(k, a0, a1, a2, a3);
+                    while (true) {
+                        lds_rec(k + r + 1, b0, b1, b2, b3);
+                        step(a0, a1, a2, a3);
+                        ++r;
+                        if (r >= run || !n_open) break;
+                        lds_rec(k + r + 1, a0, a1, a2, a3);
+                        step(b0, b1, b2, b3);
+                        ++r;
+                        if (r >= run || !n_open) break;
+                    }
+                }
+                // (every pixel finished inside the run: the state no longer changes, the rest only counts)
+                k += run;
+                cnt += run;
+                if (seg_q && (cnt & 63) == 0) {
+                    float *sl = seg_q + (((sbase + cnt) >> 6) + tile_lin) * SS;
+                    sl[lane] = T;
+#pragma unroll
+                    for (int kk = 0; kk < D; ++kk) sl[64 * (1 + kk) + lane] = pix[kk];
+#pragma unroll
+                    for (int kk = 0; kk < E; ++kk) sl[64 * (1 + D + kk) + lane] = pxe[kk];
+                }
+            }
+        }
+    }
+    if (n_rec && lane == 0) n_rec[(int64_t)q * n_tiles_total + tile_lin] = cnt;
+    if (tile_open && n_open && lane == 0) tile_open[tile_lin] = 1;
+#ifdef FSGS_FWD_TRACE
+    if (lane == 0 && blockIdx.x < (1u << 17)) {
+        long long *tr = g_fwd_trace[blockIdx.x];
+        unsigned hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        tr[0] = t_start; tr[1] = wall_clock64(); tr[2] = cnt; tr[3] = l1 - l0; tr[4] = hw; tr[5] = n_open;
+    }
+#endif
+
+    if (backgrounds) {
+#pragma unroll
+        for (int k = 0; k < D; ++k) pix[k] += T * backgrounds[cam * D + k];
+    }
+    if (normalize_last) pix[D - 1] = pix[D - 1] / fmaxf(1.f - T, 1e-10f);  // expected depth
+    if (inside) {
+        const int64_t pix_id = ((int64_t)cam * H + i) * W + j;
+        if (D == 4) {
+            reinterpret_cast<float4 *>(render)[pix_id] = make_float4(pix[0], pix[1], pix[2], pix[D - 1]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < D; ++k) render[pix_id * D + k] = pix[k];
+        }
+        if (E) {
+#pragma unroll
+            for (int k = 0; k < E; ++k) render_extra[pix_id * E + k] = pxe[k] + T;  // background = 1
+        }
+        alphas[pix_id] = 1.f - T;
+        last_ids[pix_id] = cur_idx;
+    }
+    if (max_last) {
+        float mx = inside ? pix[D - 1] : 0.f;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d, 64));
+        const int mm = __float_as_int(mx);
+        if (lane == 0 && mm > 0) atomicMax(reinterpret_cast<int *>(max_last) + (bid & (kMaxCells - 1)), mm);
     }
 }
 
@@ -311,6 +574,13 @@ extern "C" int64_t fsgs_quad_seg_slots(int C, int tile_width, int tile_height, i
 }
 
 extern "C" int fsgs_raster_quad_max_cells(void) { return kMaxCells; }
+
+#ifdef FSGS_FWD_TRACE
+extern "C" int fsgs_debug_fwd_trace(long long *out, int n_blocks) {
+    hipDeviceSynchronize();
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fwd_trace), sizeof(long long) * 6 * n_blocks) == hipSuccess ? 0 : 1;
+}
+#endif
 
 extern "C" int fsgs_raster_fwd_quad(int C, int D, const float *packed, const int32_t *payload,
                                     const int32_t *isect_offsets, int64_t n_isects, const float *backgrounds,
@@ -344,7 +614,15 @@ extern "C" int fsgs_raster_fwd_quad(int C, int D, const float *packed, const int
                        max_last, ends_on_device, tile_open)
     if (render_extra) {
         if (D != 4) return FSGS_EINVAL;  // the fused RGB+depth + normal-plane walk
+#ifdef FSGS_FWD_GEN2  // (A/B build: the second-generation kernel on the training path too)
         FSGS_FWD_QUAD(4, 3);
+#else
+        // third generation: one wave per quadrant; the grid holds every quadrant twice (long lists first)
+        hipLaunchKernelGGL((raster_fwd_wave_kernel<4, 3>), dim3(grid.x * 2), dim3(64), 0, s, cap, pk, payload,
+                           isect_offsets, n_isects, backgrounds, width, height, tile_width, tile_height, (int)n_tiles,
+                           render, alphas, last_ids, rec, n_rec, seg_state, seg_cap, normalize_last, render_extra,
+                           max_last, ends_on_device, tile_open);
+#endif
         return check_launch();
     }
     switch (D) {
