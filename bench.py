@@ -217,6 +217,21 @@ def bwd_dispatch_choice(dev, W, H):
         return None
 
 
+def fwd_walk_choice(dev, W, H):
+    try:
+        from fusionsense_amd.fused import FWD_WALK
+        st = FWD_WALK.state.get((str(dev), W, H))
+        if FWD_WALK.forced:
+            return {"walk": int(FWD_WALK.forced_walk), "forced": True, "tuning_frames": 0}
+        if not st:
+            return None
+        return {"walk": None if st["decided"] is None else int(st["decided"]),
+                "means_ms": {str(k): round(v, 4) for k, v in st.get("means_ms", {}).items()},
+                "tuning_frames": int(st.get("tuning_frames", 0))}
+    except Exception:
+        return None
+
+
 def never_updated_frac(trainer):
     try:
         p = trainer._params["opacities"]
@@ -537,12 +552,15 @@ def main():
         # those: fused._BwdDispatchTuner): let it settle HERE, not inside the timed region (with 4 views and
         # 4 warm-up steps config #5 timed some of its tuning frames)
         if fused:
-            from fusionsense_amd.fused import BWD_DISPATCH
+            from fusionsense_amd.fused import BWD_DISPATCH, FWD_WALK
             # (several ranks: a FIXED number of extra frames — every step carries collectives, so the ranks must not
-            # decide from their own timings how many they run; 12 covers the tuner's warm-up + 2 x 4 pairs)
-            for extra in range(12 if grouped else 32):
+            # decide from their own timings how many they run; 20 covers the backward tuner's warm-up + 2 x 4 pairs and
+            # the forward tuner's 2 x 6 alternating frames, fused._FwdWalkTuner)
+            for extra in range(20 if grouped else 40):
                 st_ = BWD_DISPATCH.state.get((str(dev), W, H))
-                settled = BWD_DISPATCH.forced or (st_ is not None and st_["decided"] is not None)
+                sf_ = FWD_WALK.state.get((str(dev), W, H))
+                settled = ((BWD_DISPATCH.forced or (st_ is not None and st_["decided"] is not None))
+                           and (FWD_WALK.forced or (sf_ is not None and sf_["decided"] is not None)))
                 if settled and not grouped:
                     break
                 v = (extra * world + rank) % len(cams)
@@ -601,6 +619,7 @@ def main():
     n_alloc0 = torch.cuda.memory_stats(dev).get('num_device_alloc', 0)
     n_before = trainer.num_gaussians()
     tune0 = (bwd_dispatch_choice(dev, W, H) or {}).get("tuning_frames", 0)
+    ftune0 = (fwd_walk_choice(dev, W, H) or {}).get("tuning_frames", 0)
     t0 = time.perf_counter()
     step_ends = []
     # one event per step on the step's stream: the GPU-side duration of every step, read after the timed region
@@ -620,6 +639,7 @@ def main():
     torch.cuda.synchronize()
     own_elapsed = time.perf_counter() - t0  # (this rank's own clock, before it waits for the others)
     tune_in_region = (bwd_dispatch_choice(dev, W, H) or {}).get("tuning_frames", 0) - tune0
+    ftune_in_region = (fwd_walk_choice(dev, W, H) or {}).get("tuning_frames", 0) - ftune0
     barrier()
     elapsed = time.perf_counter() - t0
     gc.enable()
@@ -953,6 +973,11 @@ def main():
             # frames of the timed region on which the tuner issued the launch twice (0: it had settled during the setup;
             # it starts over when the model has grown or shrunk by a quarter)
             "bwd_dispatch_tuning_frames_in_timed_region": tune_in_region,
+            # the forward compositing's walk as measured and chosen in this run (fused._FwdWalkTuner; the ``walk``
+            # argument of fsgs_raster_fwd_quad): 0 = four waves per quadrant, 1 = one wave per quadrant; the means are
+            # those of the alternating frames; frames of the timed region that were still alternating
+            "fwd_walk": fwd_walk_choice(dev, W, H),
+            "fwd_walk_tuning_frames_in_timed_region": ftune_in_region,
             # steps whose Adam update was applied inside the per-Gaussian backward launch (no gradient slab, no Adam
             # launch: DESIGN.md §9.9; FSGS_ADAM_IN_BACKWARD=auto|1|0)
             "adam_in_backward_steps": int(getattr(trainer, "adam_in_backward_steps", 0)),

@@ -22,7 +22,7 @@ constexpr int kLT = 32;             // output tile edge
 constexpr int kLR = 5;              // window radius
 constexpr int kLH = kLT + 2 * kLR;  // 42
 constexpr int kLP = kLH + 1;        // halo row pitch (odd: the row pass reads 8 rows x 8 column groups per wave)
-constexpr int kLQ = kLT + 8;        // blurred-row pitch: 4 rows apart = 32 banks apart (column pass, 2 row groups per wave)
+constexpr int kLQ = kLT + 1;        // blurred-row pitch (odd: conflict-free for the row pass's writes and the column pass's reads)
 constexpr int kHaloIters = (kLH * kLH + 255) / 256;
 
 __constant__ float kGauss11[11] = {0.0010283801f, 0.0075987581f, 0.0360007721f, 0.1093606895f,
@@ -43,9 +43,15 @@ __global__ void __launch_bounds__(256)
 ssim_l1_fwd_kernel(int H, int W, const float *__restrict__ pred, const float *__restrict__ gt,
                    const float *__restrict__ mask, float *__restrict__ dm_dmu1, float *__restrict__ dm_dsigma1,
                    float *__restrict__ dm_dsigma12, float *__restrict__ sums) {
-    __shared__ float sp[kLH][kLP], sg[kLH][kLP];
-    __shared__ float hb[5][kLH][kLQ];
+    // ONE arena: the two halos first, the five row-blurred maps over them once every thread holds its row results in
+    // registers (27.7 KB instead of 48: five workgroups per CU instead of three — the kernel is bound by its three
+    // dependent phases, not by bytes or instructions; round 4)
+    constexpr int kArena = (5 * kLH * kLQ > 2 * kLH * kLP) ? 5 * kLH * kLQ : 2 * kLH * kLP;
+    __shared__ float arena[kArena];
     __shared__ float red[4];
+    float (*sp)[kLP] = reinterpret_cast<float (*)[kLP]>(arena);
+    float (*sg)[kLP] = reinterpret_cast<float (*)[kLP]>(arena + kLH * kLP);
+    auto hb = [&](int m, int ly, int lx) -> float & { return arena[(m * kLH + ly) * kLQ + lx]; };
     const int ch = blockIdx.z;
     const int x0 = blockIdx.x * kLT, y0 = blockIdx.y * kLT;
     const int tr = threadIdx.x;
@@ -81,14 +87,19 @@ ssim_l1_fwd_kernel(int H, int W, const float *__restrict__ pred, const float *__
         }
     }
     __syncthreads();
-    // row pass: 42 rows x 8 groups of 4 columns; the 14 inputs of a group slide through registers
-    for (int item = tr; item < kLH * (kLT / 4); item += 256) {
-        const int ly = item >> 3, cx = (item & 7) * 4;
-        float acc[4][5];
+    // row pass: 42 rows x 8 groups of 4 columns (336 items, at most two per thread); the 14 inputs of a group slide
+    // through registers, the results stay in registers until every thread has read its inputs
+    constexpr int kRowItems = kLH * (kLT / 4), kRowReps = (kRowItems + 255) / 256;
+    float acc[kRowReps][4][5];
+#pragma unroll
+    for (int rep = 0; rep < kRowReps; ++rep) {
+        const int item = tr + rep * 256;
+        const int ly = min(item, kRowItems - 1) >> 3, cx = (item & 7) * 4;
 #pragma unroll
         for (int o = 0; o < 4; ++o)
 #pragma unroll
-            for (int m = 0; m < 5; ++m) acc[o][m] = 0.f;
+            for (int m = 0; m < 5; ++m) acc[rep][o][m] = 0.f;
+        if (item < kRowItems)
 #pragma unroll
         for (int t = 0; t < 14; ++t) {
             const float p = sp[ly][cx + t], g = sg[ly][cx + t];
@@ -98,18 +109,30 @@ ssim_l1_fwd_kernel(int H, int W, const float *__restrict__ pred, const float *__
                 const int k = t - o;
                 if (k >= 0 && k < 11) {
                     const float w = kGauss11[k];
-                    acc[o][0] += w * p; acc[o][1] += w * g; acc[o][2] += w * pp; acc[o][3] += w * gg; acc[o][4] += w * pg;
+                    acc[rep][o][0] += w * p; acc[rep][o][1] += w * g; acc[rep][o][2] += w * pp;
+                    acc[rep][o][3] += w * gg; acc[rep][o][4] += w * pg;
                 }
             }
         }
+    }
+    // column pass: thread = (column lx, group of 4 rows); its own four pixels for the L1 term
+    const int lx = tr & 31, ry = (tr >> 5) * 4;
+    float own_d[4];
 #pragma unroll
-        for (int m = 0; m < 5; ++m)
+    for (int o = 0; o < 4; ++o) own_d[o] = fabsf(sp[ry + o + kLR][lx + kLR] - sg[ry + o + kLR][lx + kLR]);
+    __syncthreads();  // every input read: the arena now takes the row-blurred maps
 #pragma unroll
-            for (int o = 0; o < 4; ++o) hb[m][ly][cx + o] = acc[o][m];
+    for (int rep = 0; rep < kRowReps; ++rep) {
+        const int item = tr + rep * 256;
+        if (item < kRowItems) {
+            const int ly = item >> 3, cx = (item & 7) * 4;
+#pragma unroll
+            for (int m = 0; m < 5; ++m)
+#pragma unroll
+                for (int o = 0; o < 4; ++o) hb(m, ly, cx + o) = acc[rep][o][m];
+        }
     }
     __syncthreads();
-    // column pass: thread = (column lx, group of 4 rows)
-    const int lx = tr & 31, ry = (tr >> 5) * 4;
     float mom[4][5];
 #pragma unroll
     for (int o = 0; o < 4; ++o)
@@ -119,7 +142,7 @@ ssim_l1_fwd_kernel(int H, int W, const float *__restrict__ pred, const float *__
     for (int t = 0; t < 14; ++t) {
         float v[5];
 #pragma unroll
-        for (int m = 0; m < 5; ++m) v[m] = hb[m][ry + t][lx];
+        for (int m = 0; m < 5; ++m) v[m] = hb(m, ry + t, lx);
 #pragma unroll
         for (int o = 0; o < 4; ++o) {
             const int k = t - o;
@@ -138,7 +161,7 @@ ssim_l1_fwd_kernel(int H, int W, const float *__restrict__ pred, const float *__
         const bool in_img = (x < W) && (y < H);
         const bool interior = in_img && x >= kLR && x < W - kLR && y >= kLR && y < H - kLR;
         float d_mu1 = 0.f, d_s1 = 0.f, d_s12 = 0.f;
-        if (in_img) l1 += fabsf(sp[ly + kLR][lx + kLR] - sg[ly + kLR][lx + kLR]);
+        if (in_img) l1 += own_d[o];
         if (interior) {
             const float mu1 = mom[o][0], mu2 = mom[o][1], e11 = mom[o][2], e22 = mom[o][3], e12 = mom[o][4];
             const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
@@ -212,9 +235,12 @@ ssim_l1_bwd_kernel(int H, int W, const float *__restrict__ pred, const float *__
                    const float *__restrict__ mask, const float *__restrict__ dm_dmu1, const float *__restrict__ dm_dsigma1,
                    const float *__restrict__ dm_dsigma12, const float *__restrict__ v_loss, float g_l1,
                    float g_ssim, float *__restrict__ v_pred, CombineArgs comb, float *__restrict__ loss_out) {
-    __shared__ float sm[3][kLH][kLP];
-    __shared__ float hb[3][kLH][kLQ];
+    // (one arena, as in the forward: the three halos, then the three row-blurred maps over them — 21.7 KB instead of 41.8)
+    constexpr int kArena = (3 * kLH * kLQ > 3 * kLH * kLP) ? 3 * kLH * kLQ : 3 * kLH * kLP;
+    __shared__ float arena[kArena];
     __shared__ double comb_red[4];
+    auto sm = [&](int m, int ly, int lx) -> float & { return arena[(m * kLH + ly) * kLP + lx]; };
+    auto hb = [&](int m, int ly, int lx) -> float & { return arena[(m * kLH + ly) * kLQ + lx]; };
     if (blockIdx.z == 3) {
         // a fourth z-slice (when launched): one workgroup of it combines the loss partials into the scalar loss —
         // the value is only reported, so it rides in this launch instead of one of its own
@@ -254,36 +280,48 @@ ssim_l1_bwd_kernel(int H, int W, const float *__restrict__ pred, const float *__
         const int i = tr + it * 256;
         const int ly = i / kLH, lxx = i - ly * kLH;
         if (i < kLH * kLH) {
-            sm[0][ly][lxx] = ha[it]; sm[1][ly][lxx] = hbv[it]; sm[2][ly][lxx] = hc[it];
+            sm(0, ly, lxx) = ha[it]; sm(1, ly, lxx) = hbv[it]; sm(2, ly, lxx) = hc[it];
         }
     }
     __syncthreads();
-    for (int item = tr; item < kLH * (kLT / 4); item += 256) {
-        const int ly = item >> 3, cx = (item & 7) * 4;
-        float acc[4][3];
+    constexpr int kRowItems = kLH * (kLT / 4), kRowReps = (kRowItems + 255) / 256;
+    float acc[kRowReps][4][3];
+#pragma unroll
+    for (int rep = 0; rep < kRowReps; ++rep) {
+        const int item = tr + rep * 256;
+        const int ly = min(item, kRowItems - 1) >> 3, cx = (item & 7) * 4;
 #pragma unroll
         for (int o = 0; o < 4; ++o)
 #pragma unroll
-            for (int m = 0; m < 3; ++m) acc[o][m] = 0.f;
+            for (int m = 0; m < 3; ++m) acc[rep][o][m] = 0.f;
+        if (item < kRowItems)
 #pragma unroll
         for (int t = 0; t < 14; ++t) {
             float v[3];
 #pragma unroll
-            for (int m = 0; m < 3; ++m) v[m] = sm[m][ly][cx + t];
+            for (int m = 0; m < 3; ++m) v[m] = sm(m, ly, cx + t);
 #pragma unroll
             for (int o = 0; o < 4; ++o) {
                 const int k = t - o;
                 if (k >= 0 && k < 11) {
                     const float w = kGauss11[k];
 #pragma unroll
-                    for (int m = 0; m < 3; ++m) acc[o][m] += w * v[m];
+                    for (int m = 0; m < 3; ++m) acc[rep][o][m] += w * v[m];
                 }
             }
         }
+    }
+    __syncthreads();  // every input read: the arena now takes the row-blurred maps
 #pragma unroll
-        for (int m = 0; m < 3; ++m)
+    for (int rep = 0; rep < kRowReps; ++rep) {
+        const int item = tr + rep * 256;
+        if (item < kRowItems) {
+            const int ly = item >> 3, cx = (item & 7) * 4;
 #pragma unroll
-            for (int o = 0; o < 4; ++o) hb[m][ly][cx + o] = acc[o][m];
+            for (int m = 0; m < 3; ++m)
+#pragma unroll
+                for (int o = 0; o < 4; ++o) hb(m, ly, cx + o) = acc[rep][o][m];
+        }
     }
     __syncthreads();
     float out[4][3];
@@ -295,7 +333,7 @@ ssim_l1_bwd_kernel(int H, int W, const float *__restrict__ pred, const float *__
     for (int t = 0; t < 14; ++t) {
         float v[3];
 #pragma unroll
-        for (int m = 0; m < 3; ++m) v[m] = hb[m][ry + t][lx];
+        for (int m = 0; m < 3; ++m) v[m] = hb(m, ry + t, lx);
 #pragma unroll
         for (int o = 0; o < 4; ++o) {
             const int k = t - o;

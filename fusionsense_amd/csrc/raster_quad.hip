@@ -319,7 +319,10 @@ raster_fwd_quad_kernel(int64_t cap, const float4 *__restrict__ packed, const int
 // Measured and dropped on the way (profiles/README.md): the record through the scalar cache
 // (s_load_dwordx16 of its line, operands in SGPRs, 135 / 121 / 920: one line in flight per wave, and a deeper queue does
 // not fit the 102 SGPRs); four records per step branch-free (115 / 138 / 980); s_setprio for the long walks (no effect);
-// long-lists-first for the second-generation kernel (98: it is not bound by its tail).
+// long-lists-first for the second-generation kernel (98: it is not bound by its tail); a hybrid launch of 256-thread
+// workgroups — four waves on one quadrant of a long tile (the second generation's walk: 12.5 instructions per record on a
+// wave's critical path instead of 27), one wave per quadrant of the others — 115 / 111 / 663: the one-wave walk loses
+// more as a quarter of a four-wave workgroup than the long tiles gain.
 #ifdef FSGS_FWD_TRACE
 // Diagnostic build only (tools/fwd_trace.py): start / end clock, records walked, list length, chunks of every wave.
 __device__ long long g_fwd_trace[1 << 17][6];
@@ -587,12 +590,12 @@ extern "C" int fsgs_raster_fwd_quad(int C, int D, const float *packed, const int
                                     int width, int height, int tile_width, int tile_height, int normalize_last,
                                     float *render, float *alphas, int32_t *last_ids, float *records,
                                     int32_t *n_rec, float *seg_state, float *render_extra,
-                                    float *max_last, int32_t *tile_open, fsgs_stream_t stream) {
+                                    float *max_last, int32_t *tile_open, int walk, fsgs_stream_t stream) {
     // n_isects < 0: -n_isects is the CAPACITY the caller sized records / seg_state for, and the lists' true end is
     // isect_offsets[C * th * tw] on the device (fsgs_bin_live_count leaves it there): no host wait for the total
     const int ends_on_device = n_isects < 0 ? 1 : 0;
     if (ends_on_device) n_isects = -n_isects;
-    if (C < 0 || width < 0 || height < 0) return FSGS_EINVAL;
+    if (C < 0 || width < 0 || height < 0 || walk < 0 || walk > 1) return FSGS_EINVAL;
     if (C == 0 || width == 0 || height == 0) return FSGS_OK;
     if (n_isects > 0x7FFFFFF0ll) return FSGS_EINVAL;  // list indices are 32-bit (as in the reference)
     if (!isect_offsets || !render || !alphas || !last_ids || (n_isects > 0 && (!packed || !payload)))
@@ -614,15 +617,15 @@ extern "C" int fsgs_raster_fwd_quad(int C, int D, const float *packed, const int
                        max_last, ends_on_device, tile_open)
     if (render_extra) {
         if (D != 4) return FSGS_EINVAL;  // the fused RGB+depth + normal-plane walk
-#ifdef FSGS_FWD_GEN2  // (A/B build: the second-generation kernel on the training path too)
-        FSGS_FWD_QUAD(4, 3);
-#else
-        // third generation: one wave per quadrant; the grid holds every quadrant twice (long lists first)
-        hipLaunchKernelGGL((raster_fwd_wave_kernel<4, 3>), dim3(grid.x * 2), dim3(64), 0, s, cap, pk, payload,
-                           isect_offsets, n_isects, backgrounds, width, height, tile_width, tile_height, (int)n_tiles,
-                           render, alphas, last_ids, rec, n_rec, seg_state, seg_cap, normalize_last, render_extra,
-                           max_last, ends_on_device, tile_open);
-#endif
+        if (walk == FSGS_WALK_ONE_WAVE) {
+            // third generation: one wave per quadrant; the grid holds every quadrant twice (long lists first)
+            hipLaunchKernelGGL((raster_fwd_wave_kernel<4, 3>), dim3(grid.x * 2), dim3(64), 0, s, cap, pk, payload,
+                               isect_offsets, n_isects, backgrounds, width, height, tile_width, tile_height,
+                               (int)n_tiles, render, alphas, last_ids, rec, n_rec, seg_state, seg_cap, normalize_last,
+                               render_extra, max_last, ends_on_device, tile_open);
+        } else {
+            FSGS_FWD_QUAD(4, 3);
+        }
         return check_launch();
     }
     switch (D) {

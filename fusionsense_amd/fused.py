@@ -70,6 +70,10 @@ class FrameInfo:
         self.live_capacity = 0
         self.pending_count = None
         self.n_live: Optional[int] = None
+        # the forward compositing's walk (fsgs_raster_fwd_quad's ``walk``): measured per frame shape when the caller
+        # asks for it (FWD_WALK), the default otherwise; ``fwd_walk`` tells which one this frame used
+        self.tune_forward = False
+        self.fwd_walk = 0
         # occlusion cuts (dense scenes): ``zcut_in`` [T] float32 = per-tile depth behind which pairs
         # are not binned (the previous frame of this view saturated in front of it; +inf = no cut), ``zcut_out`` [T]
         # receives this frame's cuts for the next one.  A cut tile that does NOT saturate inside its prefix makes the
@@ -223,6 +227,76 @@ class _BwdDispatchTuner:
 BWD_DISPATCH = _BwdDispatchTuner()
 
 
+class _FwdWalkTuner:
+    """Picks the forward compositing's walk per (device, frame shape) by measuring it (the ``walk`` argument of
+    fsgs_raster_fwd_quad): four waves per quadrant, or one wave per quadrant — half the vector instructions, but the
+    frame's longest list becomes one wave's dependent chain.  Config #2: 95 vs 79 us; config #4: 0.67 vs 0.52 ms; config
+    #3 once densification has left lists of 2 800 entries: 153 vs 278 us.  Both walks give valid frames (same arithmetic
+    per record, transmittance products associated differently), so nothing is launched twice: early frames ALTERNATE
+    between the two, each timed with a pair of HIP events that is read when it has completed, and the faster mean is
+    kept until the model's size has changed by a quarter or ``RETUNE_EVERY`` frames have passed (the lists grow as a
+    scene trains).  Only callers that ask for it are tuned (the trainer's steps); everything else uses ``DEFAULT``.
+    FSGS_FWD_WALK=<0|1> fixes the walk."""
+    CANDIDATES = (0, 1)
+    WARM, SAMPLES, RETUNE_EVERY = 1, 6, 4000
+    DEFAULT = 0
+
+    def __init__(self):
+        self.state: Dict = {}
+        self.forced = os.environ.get("FSGS_FWD_WALK", "auto") != "auto"
+        self.forced_walk = int(os.environ.get("FSGS_FWD_WALK", "0")) if self.forced else 0
+
+    def pick(self, key, n: int):
+        """-> (walk for this frame, callback to wrap around the launch or None)."""
+        if self.forced:
+            return self.forced_walk, None
+        st = self.state.get(key)
+        if st is None or (st["decided"] is not None and (abs(n - st["n_ref"]) > 0.25 * st["n_ref"]
+                                                         or st["since"] >= self.RETUNE_EVERY)):
+            prev = st["decided"] if st is not None else None
+            st = self.state[key] = dict(n_ref=n, frames=0, pending=[], total={c: 0.0 for c in self.CANDIDATES},
+                                        count={c: 0 for c in self.CANDIDATES}, decided=None, since=0, previous=prev,
+                                        tuning_frames=0)
+        if st["decided"] is not None:
+            st["since"] += 1
+            return st["decided"], None
+        st["frames"] += 1
+        for item in list(st["pending"]):  # harvest finished samples
+            c, e0, e1 = item
+            if e1.query():
+                st["total"][c] += e0.elapsed_time(e1)
+                st["count"][c] += 1
+                st["pending"].remove(item)
+        if all(st["count"][c] >= self.SAMPLES for c in self.CANDIDATES):
+            mean = {c: st["total"][c] / st["count"][c] for c in self.CANDIDATES}
+            st["decided"] = min(self.CANDIDATES, key=lambda c: mean[c])
+            st["means_ms"] = mean
+            return st["decided"], None
+        if st["frames"] <= self.WARM:
+            return (st["previous"] if st["previous"] is not None else self.DEFAULT), None
+        # the candidate with fewer samples taken or in flight (ties: alternate)
+        inflight = {c: st["count"][c] + sum(1 for it in st["pending"] if it[0] == c) for c in self.CANDIDATES}
+        if all(inflight[c] >= self.SAMPLES for c in self.CANDIDATES):
+            return (st["previous"] if st["previous"] is not None else self.DEFAULT), None  # (waiting for the events)
+        c = min(self.CANDIDATES, key=lambda k: (inflight[k], (k + st["frames"]) % 2))
+        st["tuning_frames"] += 1
+
+        def timed(launch):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            launch()
+            e1.record()
+            st["pending"].append((c, e0, e1))
+        return c, timed
+
+    def decided(self, key):
+        st = self.state.get(key)
+        return None if st is None else st["decided"]
+
+
+FWD_WALK = _FwdWalkTuner()
+
+
 class _FusedGetOutputs(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means, scales, quats, features_dc, features_rest, opacities, cam, width, height,
@@ -361,11 +435,23 @@ class _FusedGetOutputs(torch.autograd.Function):
         track_cuts = info.zcut_out is not None
         tile_open, bad, hit = (ops.zcut_scratch(dev, n_tiles) if (track_cuts or info.zcut_in is not None)
                                else (None, None, None))
-        _run(lib.fsgs_raster_fwd_quad, (1, 4, ptr(packed), ptr(flatten_ids), ptr(offsets), -M if no_wait else M, None,
-                                       W, H, tw, th, 1,
-                                       ptr(render), ptr(alphas), ptr(last_ids), ptr(records), ptr(n_rec),
-                                       ptr(seg_state), ptr(render_extra), ptr(max_last), ptr(tile_open), sp),
-             "fsgs_raster_fwd_quad", "_d4e3")
+        if info.tune_forward:
+            walk, timed = FWD_WALK.pick((str(dev), W, H), N)
+        else:
+            walk, timed = (FWD_WALK.forced_walk if FWD_WALK.forced else FWD_WALK.DEFAULT), None
+        info.fwd_walk = walk
+
+        def composite():
+            _run(lib.fsgs_raster_fwd_quad, (1, 4, ptr(packed), ptr(flatten_ids), ptr(offsets), -M if no_wait else M,
+                                           None, W, H, tw, th, 1,
+                                           ptr(render), ptr(alphas), ptr(last_ids), ptr(records), ptr(n_rec),
+                                           ptr(seg_state), ptr(render_extra), ptr(max_last), ptr(tile_open), walk,
+                                           sp),
+                 "fsgs_raster_fwd_quad", "_d4e3")
+        if timed is not None:
+            timed(composite)
+        else:
+            composite()
         if tile_open is not None:
             # this frame's saturation depths become the next frame's cuts; a cut tile left open spoils the frame
             verdict = ops.zcut_verdict_buffer(dev)
@@ -637,6 +723,7 @@ def fused_step_forward_backward(gauss_params: Dict[str, Tensor], camera: Camera,
     info.live_capacity = int(live_capacity)
     info.zcut_in, info.zcut_out = zcut_in, zcut_out
     info.adam_in_backward = adam_in_backward
+    info.tune_forward = True  # (the trainer's steps: the forward's walk is measured per frame shape, FWD_WALK)
     if zcut_margins is not None:
         info.zcut_margins = zcut_margins
 

@@ -218,7 +218,9 @@ def rasterization(
         with torch.no_grad():
             opac_c = opac.detach().contiguous()
             count = ops.bin_live_count_async(means2d.detach(), radii, conics.detach(), opac_c, tile_width, tile_height,
-                                             capacity=_LIVE_CAPS.get(cap_key) if NO_WAIT else 0)
+                                             # (no Gaussians: nothing to gather from — an estimate left by frames of the
+                                             # same shape with one Gaussian would announce pairs that have no records)
+                                             capacity=_LIVE_CAPS.get(cap_key) if (NO_WAIT and N > 0) else 0)
     else:
         with torch.no_grad():
             tiles_per_gauss, isect_ids, flatten_ids, isect_offsets, rule_diff = ops.bin_and_sort(

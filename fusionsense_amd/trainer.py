@@ -779,7 +779,7 @@ class SplatTrainer:
             # uncut frame after them — a new view, a redone frame — would overflow it)
             cap_key = self._live_caps.key(self.device, 1, self.num_gaussians(), camera.width, camera.height,
                                           zin is not None)
-            cap = self._live_caps.get(cap_key) if self.no_wait else 0
+            cap = self._live_caps.get(cap_key) if (self.no_wait and self.num_gaussians() > 0) else 0
             aib, aib_step = None, None
             if self._adam_in_backward_ok(optimizer_step):
                 self.optimizers["means"].param_groups[0]["lr"] = self._means_lr(self.step)

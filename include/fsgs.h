@@ -255,7 +255,17 @@ int fsgs_raster_fwd_quad(int C, int D, const float *packed, const int32_t *paylo
                          int width, int height, int tile_width, int tile_height, int normalize_last,
                          float *render, float *alphas, int32_t *last_ids, float *records, int32_t *n_rec,
                          float *seg_state, float *render_extra, float *max_last,
-                         int32_t *tile_open /* nullable [C*th*tw]: see fsgs_tile_zcut_update */, fsgs_stream_t stream);
+                         int32_t *tile_open /* nullable [C*th*tw]: see fsgs_tile_zcut_update */,
+                         int walk /* FSGS_WALK_*: how THIS launch walks the lists */, fsgs_stream_t stream);
+/* walk (fsgs_raster_fwd_quad): FSGS_WALK_FOUR_WAVES — a workgroup of four waves per 8x8 quadrant, lane = (pixel, one of
+ * four consecutive records); FSGS_WALK_ONE_WAVE (render_extra != NULL only; else ignored) — one wave per quadrant,
+ * lane = pixel, one record per step: half the vector instructions per (quadrant, record), but a quadrant's walk is one
+ * wave's dependent chain (~0.17 us per record on MI355X), so the frame's longest list bounds the launch.  Same images up
+ * to the association of the transmittance products (<= 1 ulp per step), same streams for the backward (the one-wave
+ * walk writes no padding records).  Which is faster depends on the frame (config #2: 95 vs 79 us; config #3 after
+ * densification, lists of 2 800 entries: 153 vs 278 us): callers measure (fusionsense_amd/fused.py does). */
+#define FSGS_WALK_FOUR_WAVES 0
+#define FSGS_WALK_ONE_WAVE 1
 int fsgs_raster_bwd_quad(int C, int D, const float *records, const int32_t *n_rec,
                          const int32_t *isect_offsets, int64_t n_isects, const float *backgrounds,
                          int width, int height, int tile_width, int tile_height, int normalize_last,

@@ -130,7 +130,7 @@ def test_full_size_backward_linear_and_reproducible(dev, full_scene):
         assert rel_err(g12b[k], g12[k]) < 5e-4, k  # (fp32 atomics arrive in a different order each run)
 
 
-def test_full_size_fused_equals_dropin_caller(dev, full_scene):
+def test_full_size_fused_equals_dropin_caller(dev, full_scene, fwd_walk):
     """Two independent routes through the library at config #2: the fused get_outputs node (live emission,
     tile sort, one 7-channel walk) and the reference-style call sequence over the drop-in surface (full
     gsplat lists, radix sort, two rasterizations) must give the same images and parameter gradients."""
@@ -224,7 +224,7 @@ def test_gradient_line_replicas_do_not_change_the_step(dev, full_scene, monkeypa
 
 
 @pytest.mark.parametrize("case", ["empty", "all_behind_camera", "tiny_image", "odd_size", "single_gaussian"])
-def test_fused_node_edge_cases(dev, case):
+def test_fused_node_edge_cases(dev, case, fwd_walk):
     from fusionsense_amd.fused import render_fusionsense_fused
     from fusionsense_amd.fusion import render_fusionsense
     params, cam = scenes.cube_scene(600, seed=4)
@@ -291,7 +291,7 @@ def test_two_cameras_through_quadrant_kernels(dev):
         assert rel_err(ga[k], gb[k]) < 2e-3, k
 
 
-def test_config2_against_oracle_at_its_own_size(dev, full_scene):
+def test_config2_against_oracle_at_its_own_size(dev, full_scene, fwd_walk):
     """BASELINE config #2 compared with the oracle AT ITS OWN SIZE: all 300 k Gaussians, view 0 of the 800x800
     hemisphere rig, the central 280x280 window (a camera with the same intrinsics and shifted principal point — the
     sample bench.py's cpu_baseline times; the oracle needs ~6 s for it).  Forward images, the integer outputs
@@ -716,7 +716,7 @@ def test_two_ranks_with_densification_stay_identical(mode):
         assert len(cuts) == 2 and min(cuts) > 100, out[-2000:]
 
 
-def test_no_wait_step_is_bit_identical_and_survives_overflow(dev, full_scene):
+def test_no_wait_step_is_bit_identical_and_survives_overflow(dev, full_scene, fwd_walk):
     """The tape-free step without the host wait in front of the bucket fill (list buffers sized from earlier frames'
     live counts, the true total read from the device, the host's look at it deferred until the forward is enqueued):
     lists, images and every statistic are bit-identical to the waiting path; a frame that exceeds a (deliberately

@@ -68,7 +68,7 @@ def _same_frame(ref, got, cut, shrink=0.6):
         assert rel_err(got["grads"][k], ref["grads"][k]) < 2e-4, k
 
 
-def test_cut_frames_equal_uncut_frames(dev, dense_scene):
+def test_cut_frames_equal_uncut_frames(dev, dense_scene, fwd_walk):
     from fusionsense_amd.trainer import SplatTrainer
     params, cams, tgt = dense_scene
     plain = SplatTrainer(params, dev, sh_degree=3)
@@ -455,7 +455,7 @@ def test_new_entry_points_reject_bad_arguments_and_take_empty_scenes(dev):
 
 
 @pytest.mark.parametrize("margins", [(0.05, 0.0, 0.0), (0.3, 0.01, 0.1), (1.0, 0.03, 0.25)])
-def test_every_frame_is_exact_whatever_the_margins(dev, margins):
+def test_every_frame_is_exact_whatever_the_margins(dev, margins, fwd_walk):
     """Lockstep fuzz of the whole speculate / check / second look / redo machinery: a cutting trainer and a plain one
     step through the same views with Adam on; before every frame the cutting trainer is given the plain one's parameters
     and moments (the compositing backward's float atomics would otherwise let them drift apart), so both render the same
@@ -537,3 +537,45 @@ def test_backward_dispatch_order_changes_nothing_but_the_speed(dev):
         st = fused.BWD_DISPATCH.state[key]
         assert st["decided"] in fused.BWD_DISPATCH.CANDIDATES and set(st["medians_ms"]) == set(fused.BWD_DISPATCH.CANDIDATES)
         assert st["scratch"] is None and st["pairs"] >= fused.BWD_DISPATCH.PAIRS
+
+
+@pytest.mark.gpu
+def test_forward_walks_give_the_same_frame_and_the_tuner_settles(dev, free_forward_walk):
+    """``walk`` of fsgs_raster_fwd_quad (round 4): one wave per quadrant instead of four.  Same images to the association
+    of the transmittance products, the same last composited entries, gradients through either walk's streams equal to the
+    float atomics' reordering; the trainer alternates the two on early frames, then keeps one."""
+    from fusionsense_amd import fused
+    from fusionsense_amd.trainer import PARAM_ORDER, SplatTrainer
+    params = {k: v.to(dev) for k, v in scenes.lego_like_scene(120_000, seed=6).items()}
+    cams = scenes.hemisphere_cameras(2, width=333, height=207, focal=420.0, seed=6)  # ragged edges
+    g = torch.Generator().manual_seed(6)
+    tgt = {"rgb": torch.rand(207, 333, 3, generator=g).to(dev), "depth": torch.rand(207, 333, 1, generator=g).to(dev) * 4,
+           "normal": torch.rand(207, 333, 3, generator=g).to(dev)}
+    tr = SplatTrainer(params, dev, sh_degree=3)
+    tuner = free_forward_walk
+    tuner.forced = True
+    outs, grads = {}, {}
+    for walk in (0, 1):
+        tuner.forced_walk = walk
+        _, out = tr.train_step(cams[0], tgt, optimizer_step=False)
+        assert out["info"].fwd_walk == walk
+        outs[walk] = {k: out[k].clone() for k in ("rgb", "depth", "normal", "accumulation")}
+        outs[walk]["last_ids"] = out["info"].last_ids.clone()
+        grads[walk] = {k: tr.slab.views[k].clone() for k in PARAM_ORDER}
+    for k in ("rgb", "depth", "normal", "accumulation"):
+        assert (outs[0][k] - outs[1][k]).abs().max().item() < 2e-5 * max(1.0, outs[0][k].abs().max().item()), k
+    assert (outs[0]["last_ids"] != outs[1]["last_ids"]).float().mean().item() < 1e-4  # (T' <= 1e-4 decided on a rounding)
+    for k in PARAM_ORDER:
+        assert rel_err(grads[1][k], grads[0][k]) < 2e-4, k
+    # the tuner: alternating frames, then a decision that is kept
+    tuner.forced = False
+    tuner.state.clear()
+    seen = []
+    for it in range(3 * tuner.SAMPLES + 8):
+        _, out = tr.train_step(cams[it % 2], tgt)
+        seen.append(out["info"].fwd_walk)
+        torch.cuda.synchronize()
+    st = tuner.state[(str(dev), 333, 207)]
+    assert st["decided"] in tuner.CANDIDATES and set(st["means_ms"]) == set(tuner.CANDIDATES)
+    assert {0, 1} <= set(seen[:2 * tuner.SAMPLES + 4]) and len(set(seen[-4:])) == 1 and seen[-1] == st["decided"]
+    assert all(c >= tuner.SAMPLES for c in st["count"].values())

@@ -509,7 +509,7 @@ def test_render_modes_fused_vs_generic(dev, mode):
         assert rel_err(outs[0][2][k], outs[1][2][k]) < 2e-3, k
 
 
-def test_fused_get_outputs_matches_unfused_and_oracle(dev):
+def test_fused_get_outputs_matches_unfused_and_oracle(dev, fwd_walk):
     """One-node get_outputs (single 7-channel walk, fused glue) against the op-by-op caller that
     goes through the drop-in surface, and against the CPU oracle, forward and gradients."""
     from fusionsense_amd.fused import render_fusionsense_fused
@@ -552,7 +552,7 @@ def test_fused_get_outputs_matches_unfused_and_oracle(dev):
     assert live_ids <= set(orf["info"]["flatten_ids"].numpy().tolist())
 
 
-def test_fused_trainer_step_equals_unfused(dev):
+def test_fused_trainer_step_equals_unfused(dev, fwd_walk):
     """Two trainers from the same state, fused vs op-by-op caller: same loss, same gradients in the
     slab views, same parameters after the Adam step wherever the gradient is not numerically
     zero (Adam's g/sqrt(v) turns rounding noise on ~0 gradients into +-lr steps)."""
@@ -874,7 +874,7 @@ def test_folded_entry_points_equal_the_chains_they_replace(dev):
     extra = torch.empty(1, H, W, 3, **f32)
     assert lib.fsgs_raster_fwd_quad(1, 4, ptr(pk_a), ptr(payload), ptr(offsets), M, None, W, H, tw, th, 1, ptr(render),
                                     ptr(alphas), ptr(last_ids), ptr(records), ptr(n_rec), ptr(seg_state), ptr(extra),
-                                    ptr(mx_a), None, sp) == 0
+                                    ptr(mx_a), None, 0, sp) == 0
     g = torch.Generator().manual_seed(3)
     bg = torch.tensor([1.0, 0.5, 0.25], device=dev)
     depth_gt, normal_gt = torch.rand(H, W, 1, generator=g).to(dev), torch.rand(H, W, 3, generator=g).to(dev)
