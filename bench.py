@@ -227,7 +227,7 @@ def fwd_walk_choice(dev, W, H):
             return None
         return {"walk": None if st["decided"] is None else int(st["decided"]),
                 "means_ms": {str(k): round(v, 4) for k, v in st.get("means_ms", {}).items()},
-                "tuning_frames": int(st.get("tuning_frames", 0))}
+                "tuning_frames": int(st.get("tuning_frames", 0)), "retunes": int(st.get("retunes", 0))}
     except Exception:
         return None
 
@@ -845,7 +845,9 @@ def main():
         alg = {
             "raster_bwd_quad_d4e3": ("raster_bwd_live_kernel<4,true,3> (RGB+ED and normal plane, one walk)" + r_note,
                                      M_r * (44 + 40) + P * (28 + 20) + n_vis * (48 + 28)),
-            "raster_fwd_quad_d4e3": ("raster_fwd_quad_kernel<4,3> (filter + gather + composite, RGB+ED and normal plane)" + r_note,
+            "raster_fwd_quad_d4e3": (("raster_fwd_wave_kernel<4,3> (one wave per quadrant" if (fwd_walk_choice(dev, W, H) or {}).get("walk") == 1
+                                      else "raster_fwd_quad_kernel<4,3> (four waves per quadrant") +
+                                     ": filter + gather + composite, RGB+ED and normal plane)" + r_note,
                                      M_r * (44 + 40) + P * (24 + 20)),
             "raster_bwd_quad_d4": ("raster_bwd_live_kernel<4,true,0>", M * 44 + P * 28 + n_vis * 48),
             "raster_bwd_quad_d3": ("raster_bwd_live_kernel<3,false,0>", M * 40 + P * 20 + n_vis * 28),
@@ -905,7 +907,12 @@ def main():
             valu = None
             if q:  # a wave64 fp32 instruction holds its SIMD for 4 cycles; 1024 SIMDs at 2.4 GHz
                 valu = 4.0 * q / (1024 * ms * 1e-3 * 2.4e9)
-                r["valu_busy_frac"] = round(valu, 4)
+                # (instructions that hold the SIMD for more than one quad-cycle — DPP reductions, v_permlane, 64-bit
+                # moves — are counted per quad-cycle by SQ_ACTIVE_INST_VALU on some launches: a raw figure above 1 means
+                # "saturated", not more than all cycles)
+                r["valu_busy_frac"] = round(min(valu, 1.0), 4)
+                if valu > 1.0:
+                    r["valu_busy_raw"] = round(valu, 4)
                 r["valu_insts_per_launch"] = rec.get("sq_insts_valu_per_launch")
             if valu is None and traffic_frac is None:
                 r["limiter"] = None  # no counters committed for this span and configuration

@@ -231,14 +231,16 @@ class _FwdWalkTuner:
     """Picks the forward compositing's walk per (device, frame shape) by measuring it (the ``walk`` argument of
     fsgs_raster_fwd_quad): four waves per quadrant, or one wave per quadrant — half the vector instructions, but the
     frame's longest list becomes one wave's dependent chain.  Config #2: 95 vs 79 us; config #4: 0.67 vs 0.52 ms; config
-    #3 once densification has left lists of 2 800 entries: 153 vs 278 us.  Both walks give valid frames (same arithmetic
+    #3 once training has left lists of 2 800 entries: 153 vs 278 us.  Both walks give valid frames (same arithmetic
     per record, transmittance products associated differently), so nothing is launched twice: early frames ALTERNATE
     between the two, each timed with a pair of HIP events that is read when it has completed, and the faster mean is
-    kept until the model's size has changed by a quarter or ``RETUNE_EVERY`` frames have passed (the lists grow as a
-    scene trains).  Only callers that ask for it are tuned (the trainer's steps); everything else uses ``DEFAULT``.
-    FSGS_FWD_WALK=<0|1> fixes the walk."""
+    kept.  The lists change as a scene trains (config #3's schedule turns the verdict round within a few hundred
+    steps, long before the model's size has moved), so the chosen walk stays under watch: every ``MONITOR``-th frame is
+    timed, and two samples in a row outside +-30 % of the mean it was chosen with start the measurement over (as does a
+    change of the model's size by a quarter, or ``RETUNE_EVERY`` frames).  Only callers that ask for it are tuned (the
+    trainer's steps); everything else uses ``DEFAULT``.  FSGS_FWD_WALK=<0|1> fixes the walk."""
     CANDIDATES = (0, 1)
-    WARM, SAMPLES, RETUNE_EVERY = 1, 6, 4000
+    WARM, SAMPLES, RETUNE_EVERY, MONITOR, BAND = 1, 6, 4000, 16, 0.30
     DEFAULT = 0
 
     def __init__(self):
@@ -246,19 +248,38 @@ class _FwdWalkTuner:
         self.forced = os.environ.get("FSGS_FWD_WALK", "auto") != "auto"
         self.forced_walk = int(os.environ.get("FSGS_FWD_WALK", "0")) if self.forced else 0
 
+    def _fresh(self, n, prev, retunes=0, tuning_frames=0):
+        return dict(n_ref=n, frames=0, pending=[], total={c: 0.0 for c in self.CANDIDATES},
+                    count={c: 0 for c in self.CANDIDATES}, decided=None, since=0, previous=prev,
+                    tuning_frames=tuning_frames, watch=[], off=0, retunes=retunes)
+
     def pick(self, key, n: int):
-        """-> (walk for this frame, callback to wrap around the launch or None)."""
+        """-> (walk for this frame, callable to wrap around the launch or None)."""
         if self.forced:
             return self.forced_walk, None
         st = self.state.get(key)
-        if st is None or (st["decided"] is not None and (abs(n - st["n_ref"]) > 0.25 * st["n_ref"]
-                                                         or st["since"] >= self.RETUNE_EVERY)):
-            prev = st["decided"] if st is not None else None
-            st = self.state[key] = dict(n_ref=n, frames=0, pending=[], total={c: 0.0 for c in self.CANDIDATES},
-                                        count={c: 0 for c in self.CANDIDATES}, decided=None, since=0, previous=prev,
-                                        tuning_frames=0)
+        if st is not None and st["decided"] is not None:
+            for item in list(st["watch"]):  # the chosen walk under watch
+                e0, e1 = item
+                if e1.query():
+                    ms = e0.elapsed_time(e1)
+                    ref = st["means_ms"][st["decided"]]
+                    st["off"] = st["off"] + 1 if abs(ms - ref) > self.BAND * ref else 0
+                    st["watch"].remove(item)
+            if (st["off"] >= 2 or abs(n - st["n_ref"]) > 0.25 * st["n_ref"] or st["since"] >= self.RETUNE_EVERY):
+                st = self.state[key] = self._fresh(n, st["decided"], st["retunes"] + 1, st["tuning_frames"])
+        if st is None:
+            st = self.state[key] = self._fresh(n, None)
         if st["decided"] is not None:
             st["since"] += 1
+            if st["since"] % self.MONITOR == 0 and len(st["watch"]) < 4:
+                def watched(launch):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    launch()
+                    e1.record()
+                    st["watch"].append((e0, e1))
+                return st["decided"], watched
             return st["decided"], None
         st["frames"] += 1
         for item in list(st["pending"]):  # harvest finished samples
@@ -267,17 +288,18 @@ class _FwdWalkTuner:
                 st["total"][c] += e0.elapsed_time(e1)
                 st["count"][c] += 1
                 st["pending"].remove(item)
+        fallback = st["previous"] if st["previous"] is not None else self.DEFAULT
         if all(st["count"][c] >= self.SAMPLES for c in self.CANDIDATES):
             mean = {c: st["total"][c] / st["count"][c] for c in self.CANDIDATES}
             st["decided"] = min(self.CANDIDATES, key=lambda c: mean[c])
             st["means_ms"] = mean
             return st["decided"], None
         if st["frames"] <= self.WARM:
-            return (st["previous"] if st["previous"] is not None else self.DEFAULT), None
+            return fallback, None
         # the candidate with fewer samples taken or in flight (ties: alternate)
         inflight = {c: st["count"][c] + sum(1 for it in st["pending"] if it[0] == c) for c in self.CANDIDATES}
         if all(inflight[c] >= self.SAMPLES for c in self.CANDIDATES):
-            return (st["previous"] if st["previous"] is not None else self.DEFAULT), None  # (waiting for the events)
+            return fallback, None  # (waiting for the events)
         c = min(self.CANDIDATES, key=lambda k: (inflight[k], (k + st["frames"]) % 2))
         st["tuning_frames"] += 1
 

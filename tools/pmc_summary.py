@@ -17,7 +17,7 @@ SPAN = [
     ("gauss_sh_bwd_kernel<false, true>", "gaussian_bwd_adam"), ("gauss_sh_bwd_kernel<true, true>", "gaussian_bwd_adam"),
     ("gauss_sh_bwd_kernel", "gaussian_bwd"),  # (before "sh_bwd_kernel", which is a substring of it)
     ("raster_bwd_live_kernel<4, true, 3>", "raster_bwd_quad_d4e3"),
-    ("raster_fwd_quad_kernel<4, 3>", "raster_fwd_quad_d4e3"),
+    ("raster_fwd_quad_kernel<4, 3>", "raster_fwd_quad_d4e3"), ("raster_fwd_wave_kernel<4, 3>", "raster_fwd_quad_d4e3"),
     ("tile_hist_kernel", "tile_sort"), ("tile_scan_kernel2", "tile_sort"), ("tile_offsets_kernel", "tile_sort"),
     ("tile_scatter_kernel", "tile_sort"), ("tile_sort_kernel2", "tile_sort"),
     ("adam_kernel", "adam_step"), ("sh_bwd_kernel", "sh_bwd_split"), ("sh_fwd_kernel", "sh_fwd_split"),
@@ -35,6 +35,9 @@ SPAN = [
 ]
 
 
+ALTERNATIVES = ("raster_fwd_quad_d4e3",)
+
+
 def main():
     out_csv, out_json, config, source, files = sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5:]
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
@@ -50,6 +53,15 @@ def main():
                 continue
             n = max(len(v) for v in d.values())
             w.writerow([k.split("(")[0], n] + [round(sum(d[c]) / len(d[c]), 3) if d[c] else "" for c in counters])
+    # symbols that are ALTERNATIVES for one span (the forward compositing's two walks: the trainer alternates them on a
+    # few early frames, then keeps one): only the symbol with the most launches describes the span
+    for span in ALTERNATIVES:
+        syms = [k for k in acc if any(sym in k and sp == span for sym, sp in SPAN)]
+        if len(syms) > 1:
+            keep = max(syms, key=lambda k: max(len(v) for v in acc[k].values()))
+            for k in syms:
+                if k != keep:
+                    del acc[k]
     traffic = collections.defaultdict(lambda: {"fetch_kb": 0.0, "write_kb": 0.0})
     for k, d in acc.items():
         for sym, span in SPAN:
