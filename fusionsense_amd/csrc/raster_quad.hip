@@ -406,6 +406,10 @@ raster_fwd_wave_kernel(int64_t cap, const float4 *__restrict__ packed, const int
     gather(pay_cur);
 
     int cnt = 0;  // records streamed so far
+    int lim = 0;  // the hot loop's end (set to 0 by the record that finishes the last open pixel)
+    // (branch-free past the "does any lane pass" test: on a lone wave's critical path every instruction is a slot of its
+    // own, scalar mask logic and skips included — selects instead of an exec-masked block and one loop bound instead of
+    // two tests: 99 -> 92 instructions per two records, 79 -> 74 us at config #2)
     auto composite_v = [&](float mx, float my, float op, float ca, float cb, float cc, auto colour, int idx) {
         const float dx = mx - px, dy = my - py;
         const float sigma = 0.5f * (ca * dx * dx + cc * dy * dy) + cb * dx * dy;
@@ -417,26 +421,26 @@ raster_fwd_wave_kernel(int64_t cap, const float4 *__restrict__ packed, const int
             const float Tn = T * (1.f - alpha);
             // a record that would take T to <= 1e-4 ends the pixel and is not composited
             const bool low = Tn <= kTMin;
-            const uint64_t sm = __builtin_amdgcn_ballot_w64(low) & pm;
-            if (ok_s && ok_a && !low) {
-                const float vis = alpha * T;
-                float c7[7];
-                colour(c7);
-                pix[0] += c7[0] * vis;
-                if (D > 1) pix[1] += c7[1] * vis;
-                if (D > 2) pix[2] += c7[2] * vis;
-                if (D > 3) pix[D - 1] += c7[3] * vis;
-                if (E) {
-                    pxe[0] += c7[4] * vis;
-                    if (E > 1) pxe[1] += c7[5] * vis;
-                    if (E > 2) pxe[E - 1] += c7[6] * vis;
-                }
-                cur_idx = idx;
-                T = Tn;
+            const bool commit = ok_s && ok_a && !low;
+            const float vis = commit ? alpha * T : 0.f;
+            float c7[7];
+            colour(c7);
+            pix[0] += c7[0] * vis;
+            if (D > 1) pix[1] += c7[1] * vis;
+            if (D > 2) pix[2] += c7[2] * vis;
+            if (D > 3) pix[D - 1] += c7[3] * vis;
+            if (E) {
+                pxe[0] += c7[4] * vis;
+                if (E > 1) pxe[1] += c7[5] * vis;
+                if (E > 2) pxe[E - 1] += c7[6] * vis;
             }
+            cur_idx = commit ? idx : cur_idx;
+            T = commit ? Tn : T;
+            const uint64_t sm = __builtin_amdgcn_ballot_w64(low) & pm;
             if (sm) {
                 if (ok_s && ok_a && low) gate = 0.f;
                 n_open -= __popcll(sm);
+                if (n_open == 0) lim = 0;
             }
         }
     };
@@ -491,20 +495,18 @@ raster_fwd_wave_kernel(int64_t cap, const float4 *__restrict__ packed, const int
             int k = 0;
             while (k < n) {
                 const int run = min(n - k, 64 - (cnt & 63));
-                int r = 0;
                 if (n_open) {
                     float4 a0, a2, a3, b0, b2, b3;
                     float2 a1, b1;
                     lds_rec(k, a0, a1, a2, a3);
-                    while (true) {
-                        lds_rec(k + r + 1, b0, b1, b2, b3);
+                    lim = run;
+                    for (int r = 1;; r += 2) {
+                        lds_rec(k + r, b0, b1, b2, b3);
                         step(a0, a1, a2, a3);
-                        ++r;
-                        if (r >= run || !n_open) break;
+                        if (r >= lim) break;
                         lds_rec(k + r + 1, a0, a1, a2, a3);
                         step(b0, b1, b2, b3);
-                        ++r;
-                        if (r >= run || !n_open) break;
+                        if (r + 1 >= lim) break;
                     }
                 }
                 // (every pixel finished inside the run: the state no longer changes, the rest only counts)
