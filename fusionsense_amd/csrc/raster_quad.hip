@@ -321,8 +321,9 @@ raster_fwd_quad_kernel(int64_t cap, const float4 *__restrict__ packed, const int
 // not fit the 102 SGPRs); four records per step branch-free (115 / 138 / 980); s_setprio for the long walks (no effect);
 // long-lists-first for the second-generation kernel (98: it is not bound by its tail); a hybrid launch of 256-thread
 // workgroups — four waves on one quadrant of a long tile (the second generation's walk: 12.5 instructions per record on a
-// wave's critical path instead of 27), one wave per quadrant of the others — 115 / 111 / 663: the one-wave walk loses
-// more as a quarter of a four-wave workgroup than the long tiles gain.
+// wave's critical path instead of 27), one wave per quadrant of the others — 102 us at config #2 with tiles above twice
+// the mean list length taken as long, 92 above four times, 84 with none (config #4: 0.62 / 0.57 / 0.54 ms): every tile
+// handed to the four-wave walk costs more than its shorter chain saves.
 #ifdef FSGS_FWD_TRACE
 // Diagnostic build only (tools/fwd_trace.py): start / end clock, records walked, list length, chunks of every wave.
 __device__ long long g_fwd_trace[1 << 17][6];
