@@ -19,8 +19,9 @@ callbacks and its ``Optimizers`` (round 3):
     get_loss_dict      dn_model.py:673-925   -> ops._FusionLoss over a cached FrameBatch (one autograd node: every switch
                                                 reachable from scripts/train.py — incl. normals from depth — and
                                                 EdgeAwareTV, the cosine term, the L1 / LogL1 / MSE depth losses); the
-                                                original stays as ``_get_loss_dict_reference`` for the sparse / SDF /
-                                                scale-regularisation terms and HuberL1
+                                                HuberL1, the sparse-opacity term and the scale regularisation are
+                                                small torch terms on the node's outputs; the original stays as
+                                                ``_get_loss_dict_reference`` for the SDF term
     get_metrics_dict   dn_model.py:927-1003  -> the per-iteration PSNR / SSIM / depth metrics on the device, one transfer
     after_train        (nerfstudio, A.2)     -> nothing to do: the statistics were applied by the node's backward
     refinement_after   dn_model.py:326-451   -> DensifyStrategy.refinement_after (HIP row compaction, split sampling)
@@ -132,21 +133,32 @@ GAUSS_GROUPS = ("means", "scales", "quats", "features_dc", "features_rest", "opa
 
 
 def _loss_config(cfg):
-    """losses.LossConfig from the model's DNSplatterModelConfig, or None when a switch is set that the fused loss node
-    does not evaluate (the caller then runs the reference's own get_loss_dict)."""
+    """(losses.LossConfig, extras) from the model's DNSplatterModelConfig, or None when a switch is set that neither the
+    fused loss node nor the torch terms on top of it evaluate (the caller then runs the reference's own get_loss_dict:
+    the SuGaR-style SDF term, :838-882, with its random surface samples).  ``extras`` names the terms that stay small
+    torch expressions on the node's outputs (``_extra_terms``): "huber" — the HuberL1 depth loss, whose threshold is a
+    maximum over the frame's valid pixels (losses.py:217-238); "sparse" — the entropy of the visible Gaussians'
+    opacities (:821-837); "scale_reg" — splatfacto's PhysGaussian scale regularisation."""
     from .losses import LossConfig
 
     def name_of(v):  # enum member / string -> lower-case name
         return str(getattr(v, "name", v)).lower()
     g = lambda k, d=None: getattr(cfg, k, d)  # noqa: E731
-    # not evaluated by the node (the reference's own torch code runs them): the PhysGaussian scale regularisation, the
-    # sparse-opacity term and the SuGaR-style SDF term (:821-882), HuberL1 (a global maximum inside the loss)
-    if g("use_scale_regularization", False) or g("use_sparse_loss", False) or g("use_sdf_loss", False):
+    if g("use_sdf_loss", False):
         return None
-    types = {"edgeawarelogl1": "EdgeAwareLogL1", "l1": "L1", "logl1": "LogL1", "mse": "MSE"}
+    extras = set()
+    if g("use_scale_regularization", False):
+        extras.add("scale_reg")
+    if g("use_sparse_loss", False):
+        extras.add("sparse")
+    types = {"edgeawarelogl1": "EdgeAwareLogL1", "l1": "L1", "logl1": "LogL1", "mse": "MSE", "huberl1": "HuberL1"}
     dtype = types.get(name_of(g("depth_loss_type", "EdgeAwareLogL1")).split(".")[-1])
     if g("use_depth_loss", False) and dtype is None:
         return None
+    lam_sensor, lam_mono = float(g("sensor_depth_lambda", 0.0)), float(g("mono_depth_lambda", 0.0))
+    if g("use_depth_loss", False) and dtype == "HuberL1":
+        extras.add("huber")  # (the node keeps the smoothness term; the two data terms are added in torch)
+        dtype, lam_sensor, lam_mono = "EdgeAwareLogL1", 0.0, 0.0
     smooth = {"tv": "TV", "edgeawaretv": "EdgeAwareTV"}.get(name_of(g("smooth_loss_type", "TV")).split(".")[-1])
     if g("use_depth_smooth_loss", False) and smooth is None:
         return None
@@ -157,15 +169,61 @@ def _loss_config(cfg):
                       use_normal_cosine_loss=bool(g("use_normal_cosine_loss", False)),
                       depth_loss_type=dtype or "EdgeAwareLogL1",
                       ssim_lambda=float(g("ssim_lambda", 0.2)), use_depth_loss=bool(g("use_depth_loss", False)),
-                      sensor_depth_lambda=float(g("sensor_depth_lambda", 0.0)),
-                      mono_depth_lambda=float(g("mono_depth_lambda", 0.0)),
+                      sensor_depth_lambda=lam_sensor, mono_depth_lambda=lam_mono,
                       depth_tolerance=float(g("depth_tolerance", 0.1)),
                       use_depth_smooth_loss=bool(g("use_depth_smooth_loss", False)),
                       smooth_loss_lambda=float(g("smooth_loss_lambda", 0.1)),
                       use_normal_loss=bool(g("use_normal_loss", False)),
                       use_normal_tv_loss=bool(g("use_normal_tv_loss", False)),
                       normal_lambda=float(g("normal_lambda", 0.1)), two_d_gaussians=bool(g("two_d_gaussians", False)),
-                      touch_normal_loss_lambda=1.0)
+                      touch_normal_loss_lambda=1.0), frozenset(extras)
+
+
+def _extra_terms(self, outputs, batch, extras):
+    """The loss terms that stay torch code (see ``_loss_config``) -> (term added to main_loss or None, scale_reg or None).
+    A handful of small launches on the steps that have them; autograd carries their gradients."""
+    cfg = self.config
+    dev = outputs["rgb"].device
+    main = None
+    if "huber" in extras:
+        # dn_model.py:702-709, 721-750 with losses.py:217-238 as called: the valid pixels as 1-D tensors, the threshold a
+        # fifth of the frame's largest error (mask = gt != 0 is all true for them)
+        depth_out = outputs["depth"]
+        mask = batch["mask"].to(dev) if "mask" in batch else None
+        if mask is not None:
+            depth_out = depth_out * mask
+
+        def huber(pred, gt):
+            l1 = torch.abs(pred - gt)
+            d = 0.2 * torch.max(l1)
+            return torch.where(l1 < d, ((pred - gt) ** 2 + d ** 2) / (2 * d), l1).mean()
+        for key, lam, tol in (("sensor_depth", float(getattr(cfg, "sensor_depth_lambda", 0.0)),
+                               float(getattr(cfg, "depth_tolerance", 0.1))),
+                              ("mono_depth", float(getattr(cfg, "mono_depth_lambda", 0.0)), 0.0)):
+            if key in batch and lam > 0.0:
+                gt = batch[key].to(dev)
+                if mask is not None:
+                    gt = gt * mask
+                valid = gt > tol
+                term = lam * huber(depth_out[valid], gt[valid].float())
+                main = term if main is None else main + term
+    if "sparse" in extras:
+        # dn_model.py:821-837: every sparse_loss_steps-th step, not on an opacity reset's step nor in the 100 steps behind it
+        step = int(self.step)
+        period = int(cfg.reset_alpha_every) * int(cfg.refine_every)
+        if step % int(cfg.sparse_loss_steps) == 0 and step % period != 0 and not (1 <= step % period <= 100):
+            o = torch.sigmoid(self.gauss_params["opacities"][self.vis_indices])
+            term = float(cfg.sparse_lambda) * (-o * torch.log(o + 1e-10) - (1 - o) * torch.log(1 - o + 1e-10)).mean()
+            main = term if main is None else main + term
+    scale_reg = None
+    if "scale_reg" in extras and int(self.step) % 10 == 0:
+        # nerfstudio 1.1.3 splatfacto.get_loss_dict (un-vendored; published algorithm, PhysGaussian): a tenth of the mean
+        # excess of the largest over the smallest scale above max_gauss_ratio
+        e = torch.exp(self.gauss_params["scales"])
+        ratio = e.amax(dim=-1) / e.amin(dim=-1)
+        cap = float(getattr(cfg, "max_gauss_ratio", 10.0))
+        scale_reg = 0.1 * (torch.maximum(ratio, torch.tensor(cap, device=ratio.device)) - cap).mean()
+    return main, scale_reg
 
 
 class SupervisionCache:
@@ -329,7 +387,7 @@ def get_loss_dict_fused(self, outputs, batch, metrics_dict=None) -> Dict[str, to
     every 100th step (:903-921) and the in-place masking of ``outputs["normal"]`` / ``batch["normal"]`` (:712-715),
     which nothing reads after the loss."""
     from . import ops
-    cfg = _loss_config(self.config)
+    cfg, extras = _loss_config(self.config) or (None, frozenset())
     rgb = outputs.get("rgb")
     covered = (cfg is not None and torch.is_tensor(rgb) and rgb.is_cuda and "normal" in outputs and "depth" in outputs
                and not (cfg.use_normal_loss and cfg.normal_supervision == "mono" and "normal" not in batch)
@@ -353,7 +411,12 @@ def get_loss_dict_fused(self, outputs, batch, metrics_dict=None) -> Dict[str, to
     main_loss = ops._FusionLoss.apply(rgb, outputs["depth"], outputs["normal"], self.gauss_params["scales"], fb, cfg,
                                       self.gauss_params["normals"] if touch_idx is not None else None, touch_idx,
                                       touch_normals, None, False, _intrinsics_of(self))
-    return {"main_loss": main_loss, "scale_reg": torch.zeros((), device=rgb.device)}
+    scale_reg = None
+    if extras:
+        extra, scale_reg = _extra_terms(self, outputs, batch, extras)
+        if extra is not None:
+            main_loss = main_loss + extra
+    return {"main_loss": main_loss, "scale_reg": scale_reg if scale_reg is not None else torch.zeros((), device=rgb.device)}
 
 
 def get_metrics_dict_fused(self, outputs, batch) -> Dict[str, object]:

@@ -45,7 +45,7 @@ class LossConfig:
     normal_supervision: str = "mono"    # dn_model.py:84 default "depth"; configs/config.py:15 passes "mono"
     smooth_loss_type: str = "TV"        # dn_model.py:66 ("TV" | "EdgeAwareTV")
     use_normal_cosine_loss: bool = False  # dn_model.py:80
-    depth_loss_type: str = "EdgeAwareLogL1"  # dn_model.py:62 ("EdgeAwareLogL1" | "L1" | "LogL1" | "MSE")
+    depth_loss_type: str = "EdgeAwareLogL1"  # dn_model.py:62 ("EdgeAwareLogL1" | "L1" | "LogL1" | "MSE" | "HuberL1")
 
 
 def ssim_torchmetrics(pred: Tensor, gt: Tensor, kernel_size: int = 11, sigma: float = 1.5,
@@ -142,7 +142,28 @@ def plain_depth_loss(kind: str, pred: Tensor, gt: Tensor) -> Tensor:
         return torch.log(1 + torch.abs(pred - gt)).mean()
     if kind == "MSE":
         return ((pred - gt) ** 2).mean()
+    if kind == "HuberL1":
+        # losses.py:217-238 as called with the valid pixels only (1-D tensors): the threshold is a fifth of the LARGEST
+        # error of the frame, below it the error is quadratic
+        m = gt != 0
+        l1 = torch.abs(pred[m] - gt[m])
+        d = 0.2 * torch.max(l1)
+        return torch.where(l1 < d, ((pred - gt) ** 2 + d ** 2) / (2 * d), l1).mean()
     raise ValueError(kind)
+
+
+def sparse_opacity_term(opacity_logits: Tensor, vis_indices: Tensor, step: int, sparse_loss_steps: int = 10,
+                        reset_alpha_every: int = 30, refine_every: int = 100, sparse_lambda: float = 0.1) -> Tensor:
+    """dn_model.py:821-837: the binary entropy of the VISIBLE Gaussians' opacities, every ``sparse_loss_steps``-th
+    step, except on an opacity reset's step and during the 100 steps behind it."""
+    zero = torch.zeros((), dtype=opacity_logits.dtype)
+    if step % sparse_loss_steps != 0:
+        return zero
+    r = step % (reset_alpha_every * refine_every)
+    if r == 0 or 1 <= r <= 100:
+        return zero
+    o = torch.sigmoid(opacity_logits[vis_indices])
+    return sparse_lambda * (-o * torch.log(o + 1e-10) - (1 - o) * torch.log(1 - o + 1e-10)).mean()
 
 
 def dn_terms(outputs: Dict[str, Tensor], batch: Dict[str, Tensor], log_scales: Tensor,

@@ -48,17 +48,24 @@ def _splatfacto_standin():
         def scales(self):
             return self.gauss_params["scales"]
 
+        @property
+        def opacities(self):
+            return self.gauss_params["opacities"]
+
     m.SplatfactoModel = SplatfactoModel
     m.SplatfactoModelConfig = SplatfactoModelConfig
     return m
 
 
 def case(model_mod, losses, seed, H, W, n_gauss, with_mask, with_touch, holes, mono=None, normal_supervision=None,
-         smooth="TV", cosine=False, depth_type="EdgeAwareLogL1", intr=None):
+         smooth="TV", cosine=False, depth_type="EdgeAwareLogL1", intr=None, sparse=None):
     """Round 4: the switches that are OFF in FusionSense's configuration but reachable from scripts/train.py:117-145 /
     the model config — ``normal_supervision="depth"`` (pseudo normals from the rendered depth, dn_model.py:774-795 with
     utils/normal_utils.py:8-46 executed as is), ``smooth="EdgeAwareTV"`` (:757-760, losses.py:241-266), ``cosine``
-    (:807-813 with metrics.mean_angular_error) and the plain depth-loss types L1 / LogL1 / MSE (:731-736)."""
+    (:807-813 with metrics.mean_angular_error) and the plain depth-loss types L1 / LogL1 / MSE / HuberL1 (:731-736).
+    ``sparse`` = the model's step: the sparse-opacity term (:821-837; entropy of the visible Gaussians' opacities, every
+    ``sparse_loss_steps``-th step outside the 100 steps after an opacity reset) is on, the opacity logits and the
+    visible indices are part of the case."""
     g = torch.Generator().manual_seed(seed)
     cfgd = {}
     sys.path.insert(0, os.path.join(base.REF, "configs"))
@@ -70,12 +77,12 @@ def case(model_mod, losses, seed, H, W, n_gauss, with_mask, with_touch, holes, m
         smooth_loss_lambda=0.1, use_normal_loss=ref_cfg.use_normal_loss,
         normal_supervision=normal_supervision or ref_cfg.normal_supervision,
         use_normal_cosine_loss=bool(cosine), use_normal_tv_loss=True, normal_lambda=ref_cfg.normal_lambda,
-        two_d_gaussians=True, use_sparse_loss=False, use_sdf_loss=False, sdf_loss_lambda=0.1,
-        reset_alpha_every=30, refine_every=100)
+        two_d_gaussians=True, use_sparse_loss=sparse is not None, sparse_lambda=0.1, sparse_loss_steps=10,
+        use_sdf_loss=False, sdf_loss_lambda=0.1, reset_alpha_every=30, refine_every=100)
     self = object.__new__(model_mod.DNSplatterModel)
     self.config = cfg
     self.device = torch.device("cpu")
-    self.step = 7  # (not a multiple of 100: the reference writes a debug JPEG there)
+    self.step = 7 if sparse is None else int(sparse)  # (not a multiple of 100: the reference writes a debug JPEG there)
     self.depth_loss = losses.DepthLoss(cfg.depth_loss_type)
     self.smooth_loss = losses.DepthLoss(depth_loss_type=getattr(losses.DepthLossType, smooth))  # (dn_model.py:239-242)
     if intr is not None:  # what the "depth" normal supervision reads from the last get_outputs' camera (:775-786)
@@ -87,6 +94,12 @@ def case(model_mod, losses, seed, H, W, n_gauss, with_mask, with_touch, holes, m
     scales = (torch.randn(n_gauss, 3, generator=g) * 0.7 - 4.0).requires_grad_(True)
     normals_world = torch.nn.functional.normalize(torch.randn(n_gauss, 3, generator=g), dim=-1)
     self.gauss_params = {"scales": scales, "normals": normals_world}
+    opac = vis = None
+    if sparse is not None:
+        opac = (torch.randn(n_gauss, 1, generator=g) * 2.0).requires_grad_(True)
+        vis = torch.nonzero(torch.rand(n_gauss, generator=g) < 0.7).reshape(-1)
+        self.gauss_params["opacities"] = opac
+        self.vis_indices = vis
     n_touch = 9 if with_touch else 0
     if with_touch:
         add_mask = torch.zeros(n_gauss, dtype=torch.bool)
@@ -132,10 +145,14 @@ def case(model_mod, losses, seed, H, W, n_gauss, with_mask, with_touch, holes, m
                 **({} if mono is None else dict(mono_depth=mono_depth, mono_only=np.array(mono == "only"),
                                                 mono_depth_lambda=np.array(cfg.mono_depth_lambda, dtype=np.float32))),
                 **({} if intr is None else dict(intr=np.array(intr, dtype=np.float64))),
+                **({} if sparse is None else dict(
+                    opacities=opac.detach(), vis_indices=vis, v_opacities=opac.grad if opac.grad is not None else torch.zeros_like(opac),
+                    sparse=np.array([int(sparse), cfg.sparse_loss_steps, cfg.reset_alpha_every, cfg.refine_every], dtype=np.int32),
+                    sparse_lambda=np.array(cfg.sparse_lambda, dtype=np.float32))),
                 **({} if (normal_supervision is None and smooth == "TV" and not cosine and depth_type == "EdgeAwareLogL1")
                    else dict(switches=np.array([["mono", "depth"].index(normal_supervision or "mono"),
                                                 ["TV", "EdgeAwareTV"].index(smooth), int(bool(cosine)),
-                                                ["EdgeAwareLogL1", "L1", "LogL1", "MSE"].index(depth_type)], dtype=np.int32))))  # (numeric codes)
+                                                ["EdgeAwareLogL1", "L1", "LogL1", "MSE", "HuberL1"].index(depth_type)], dtype=np.int32))))  # (numeric codes)
 
 
 def main():
@@ -179,7 +196,12 @@ def main():
              "logl1": dict(seed=12, H=19, W=30, n_gauss=20, with_mask=False, with_touch=False, holes=True, depth_type="LogL1",
                            mono="both"),
              "mse": dict(seed=13, H=16, W=28, n_gauss=20, with_mask=True, with_touch=False, holes=True, depth_type="MSE",
-                         smooth="EdgeAwareTV")}
+                         smooth="EdgeAwareTV"),
+             # ---- terms that stay torch code on top of the HIP node (integration.get_loss_dict_fused) ----
+             "huber": dict(seed=14, H=18, W=29, n_gauss=20, with_mask=True, with_touch=False, holes=True,
+                           depth_type="HuberL1", mono="both"),
+             "sparse": dict(seed=15, H=17, W=26, n_gauss=40, with_mask=True, with_touch=True, holes=True, sparse=110),
+             "sparse_off": dict(seed=16, H=17, W=26, n_gauss=40, with_mask=False, with_touch=False, holes=True, sparse=3050)}
     for name, kw in cases.items():
         for k, v in case(model, losses, **kw).items():
             out[f"{name}.{k}"] = v.numpy() if torch.is_tensor(v) else v

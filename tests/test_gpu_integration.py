@@ -173,7 +173,8 @@ def test_adam_fuser_is_torch_adam_in_one_launch(dev, monkeypatch):
 
 
 @pytest.mark.parametrize("case", ["full", "nomask", "dense", "mono", "monoonly",
-                                  "ndepth", "ndepth_nomask", "eatv", "cosine", "cosine_depth", "l1", "logl1", "mse"])
+                                  "ndepth", "ndepth_nomask", "eatv", "cosine", "cosine_depth", "l1", "logl1", "mse",
+                                  "huber", "sparse", "sparse_off"])
 def test_patched_get_loss_dict_matches_reference_goldens(dev, case):
     """``model.get_loss_dict(outputs, batch)`` after patch_all against what the reference's get_loss_dict produced on
     the same inputs (reference_loss.npz): value of everything FusionSense adds to the photometric term, gradient images,
@@ -191,8 +192,18 @@ def test_patched_get_loss_dict_matches_reference_goldens(dev, case):
     if f"{case}.switches" in d.files:  # (round 4) the switches FusionSense leaves off — still on the HIP node
         ns, sm, cs, dt = (int(x) for x in d[f"{case}.switches"])  # numeric codes, see make_reference_loss_goldens.py
         over = dict(normal_supervision=["mono", "depth"][ns], smooth_loss_type=["TV", "EdgeAwareTV"][sm],
-                    use_normal_cosine_loss=bool(cs), depth_loss_type=["EdgeAwareLogL1", "L1", "LogL1", "MSE"][dt])
+                    use_normal_cosine_loss=bool(cs),
+                    depth_loss_type=["EdgeAwareLogL1", "L1", "LogL1", "MSE", "HuberL1"][dt])
+    sparse = f"{case}.sparse" in d.files  # the sparse-opacity term (dn_model.py:821-837): torch on top of the node
+    if sparse:
+        step, every, reset, refine = (int(x) for x in d[f"{case}.sparse"])
+        over.update(use_sparse_loss=True, sparse_loss_steps=every, reset_alpha_every=reset, refine_every=refine,
+                    sparse_lambda=float(d[f"{case}.sparse_lambda"]))
+        params["opacities"] = t("opacities")
     m, _ = _model(dev, params, metadata=md, **over)
+    if sparse:
+        m.step = step
+        m.vis_indices = t("vis_indices").to(dev)
     if f"{case}.intr" in d.files:  # what normal_supervision == "depth" reads from the last get_outputs' camera
         fx, fy, cx, cy = (float(x) for x in d[f"{case}.intr"])
         t1 = lambda v: torch.tensor([[v]])  # noqa: E731
@@ -221,6 +232,11 @@ def test_patched_get_loss_dict_matches_reference_goldens(dev, case):
     assert abs(float(loss) - float(photo) - ref) < 2e-6 * max(1.0, abs(ref))
     for name, g in (("v_depth", out["depth"].grad), ("v_normal", out["normal"].grad), ("v_scales", m.gauss_params["scales"].grad)):
         assert torch.allclose(g.cpu(), t(name), rtol=2e-5, atol=1e-9), (name, float((g.cpu() - t(name)).abs().max()))
+    if sparse:
+        go = m.gauss_params["opacities"].grad
+        go = torch.zeros_like(m.gauss_params["opacities"]) if go is None else go
+        assert torch.allclose(go.cpu(), t("v_opacities"), rtol=2e-5, atol=1e-10)
+        assert (float(go.abs().max()) > 0) == (case == "sparse")
     key = (bool(m.training), 4)
     fb = m._fsgs_frames.entries[key]["fb"]
     m.get_loss_dict({k: v.detach() for k, v in out.items()}, batch)
@@ -231,8 +247,18 @@ def test_patched_get_loss_dict_matches_reference_goldens(dev, case):
     m.get_loss_dict({k: v.detach() for k, v in out.items()}, copy)
     assert m._fsgs_frames.hits == 2 and len(m._fsgs_frames) == 1
     m._fsgs_frames._harvest(block=True)  # (the fingerprint comparison found nothing)
-    # a switch the node does not evaluate goes to the reference's own method (here: the stand-in that raises)
-    m.config.use_sparse_loss = True
+    # the scale regularisation of splatfacto (nerfstudio 1.1.3, un-vendored: its published formula) rides as torch too
+    m.config.use_scale_regularization, m.config.max_gauss_ratio, m.step = True, 2.0, 20
+    ld = m.get_loss_dict({k: v.detach() for k, v in out.items()}, batch)
+    e = torch.exp(m.gauss_params["scales"].detach())
+    want = 0.1 * (torch.clamp(e.amax(-1) / e.amin(-1), min=2.0) - 2.0).mean()
+    assert abs(float(ld["scale_reg"]) - float(want)) <= 1e-6 * max(1.0, float(want)) and float(want) > 0
+    m.step = 21
+    assert float(m.get_loss_dict({k: v.detach() for k, v in out.items()}, batch)["scale_reg"]) == 0.0
+    m.config.use_scale_regularization = False
+    # a switch neither the node nor the torch terms evaluate goes to the reference's own method (here: the stand-in
+    # that raises)
+    m.config.use_sdf_loss = True
     with pytest.raises(AssertionError, match="reference get_loss_dict"):
         m.get_loss_dict(out, batch)
 

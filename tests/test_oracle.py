@@ -205,7 +205,8 @@ def test_config1_full_frame_matches_committed_checksum():
 
 
 LOSS_CASES = ["full", "nomask", "dense", "mono", "monoonly",
-              "ndepth", "ndepth_nomask", "eatv", "cosine", "cosine_depth", "l1", "logl1", "mse"]  # (round 4: the other switches)
+              "ndepth", "ndepth_nomask", "eatv", "cosine", "cosine_depth", "l1", "logl1", "mse",  # (round 4: the other switches)
+              "huber", "sparse", "sparse_off"]  # (terms that stay torch code on top of the HIP node)
 
 
 def loss_case_config(d, case, cls):
@@ -215,7 +216,7 @@ def loss_case_config(d, case, cls):
     if f"{case}.switches" in d.files:
         ns, sm, cs, dt = (int(x) for x in d[f"{case}.switches"])  # numeric codes, see make_reference_loss_goldens.py
         kw = dict(normal_supervision=["mono", "depth"][ns], smooth_loss_type=["TV", "EdgeAwareTV"][sm],
-                  use_normal_cosine_loss=bool(cs), depth_loss_type=["EdgeAwareLogL1", "L1", "LogL1", "MSE"][dt])
+                  use_normal_cosine_loss=bool(cs), depth_loss_type=["EdgeAwareLogL1", "L1", "LogL1", "MSE", "HuberL1"][dt])
     intr = tuple(float(x) for x in d[f"{case}.intr"]) if f"{case}.intr" in d.files else None
     return cls(**kw), intr
 
@@ -247,11 +248,21 @@ def test_loss_oracle_matches_reference_goldens(case):
     cfg, intr = loss_case_config(d, case, loss_ref.LossConfig)
     loss = loss_ref.dn_terms(out, batch, scales, t("normals_world"), add_mask, t("touch_normals") if n_touch else None,
                              cfg, intr)
+    opac = None
+    if f"{case}.sparse" in d.files:  # the sparse-opacity term (dn_model.py:821-837)
+        opac = t("opacities").clone().requires_grad_(True)
+        step, every, reset, refine = (int(x) for x in d[f"{case}.sparse"])
+        loss = loss + loss_ref.sparse_opacity_term(opac, t("vis_indices"), step, every, reset, refine,
+                                                   float(d[f"{case}.sparse_lambda"]))
     loss.backward()
     assert abs(float(loss) - float(d[f"{case}.loss"])) <= 1e-6 * abs(float(d[f"{case}.loss"]))
     for name, g in (("v_depth", depth.grad), ("v_normal", normal.grad), ("v_scales", scales.grad)):
         ref = t(name)
         assert torch.allclose(g, ref, rtol=1e-5, atol=1e-9), (name, float((g - ref).abs().max()))
+    if opac is not None:
+        g = opac.grad if opac.grad is not None else torch.zeros_like(opac)
+        assert torch.allclose(g, t("v_opacities"), rtol=1e-5, atol=1e-10)
+        assert (float(g.abs().max()) > 0) == (case == "sparse")  # ("sparse_off": inside the window after a reset)
 
 
 def test_ssim_oracle_known_answers():
