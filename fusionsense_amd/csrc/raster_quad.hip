@@ -323,7 +323,10 @@ raster_fwd_quad_kernel(int64_t cap, const float4 *__restrict__ packed, const int
 // workgroups — four waves on one quadrant of a long tile (the second generation's walk: 12.5 instructions per record on a
 // wave's critical path instead of 27), one wave per quadrant of the others — 102 us at config #2 with tiles above twice
 // the mean list length taken as long, 92 above four times, 84 with none (config #4: 0.62 / 0.57 / 0.54 ms): every tile
-// handed to the four-wave walk costs more than its shorter chain saves.
+// handed to the four-wave walk costs more than its shorter chain saves; four INDEPENDENT waves per quadrant of a long
+// tile (one per 4x4 block, the four-wave walk's lanes without its workgroup: each stages the list for itself, none knows
+// when the quadrant has finished, so the lists are streamed to their end) — 172 / 126 / 97 us with tiles above 2 / 3 / 4
+// times the mean taken as long (config #4: 1.21 / 0.97 / 0.81 ms).  What would help is in DESIGN.md 10.2.
 #ifdef FSGS_FWD_TRACE
 // Diagnostic build only (tools/fwd_trace.py): start / end clock, records walked, list length, chunks of every wave.
 __device__ long long g_fwd_trace[1 << 17][6];
