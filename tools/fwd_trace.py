@@ -1,6 +1,6 @@
 """Per-wave timeline of the wave-per-quadrant forward (diagnostic build):
     make -C fusionsense_amd/csrc OUT=../libfsgs_trace.so BUILD=build_trace EXTRA=-DFSGS_FWD_TRACE
-    FSGS_LIB=$PWD/fusionsense_amd/libfsgs_trace.so FSGS_FWD_WAVE=2 python tools/fwd_trace.py [config]"""
+    FSGS_LIB=$PWD/fusionsense_amd/libfsgs_trace.so FSGS_FWD_WALK=1 python tools/fwd_trace.py [config]"""
 import ctypes as C
 import json
 import os
