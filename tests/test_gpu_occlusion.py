@@ -579,3 +579,11 @@ def test_forward_walks_give_the_same_frame_and_the_tuner_settles(dev, free_forwa
     assert st["decided"] in tuner.CANDIDATES and set(st["means_ms"]) == set(tuner.CANDIDATES)
     assert {0, 1} <= set(seen[:2 * tuner.SAMPLES + 4]) and len(set(seen[-4:])) == 1 and seen[-1] == st["decided"]
     assert all(c >= tuner.SAMPLES for c in st["count"].values())
+    # the chosen walk stays under watch: two timed frames in a row far from the mean it was chosen with (here: the mean
+    # is falsified) start the measurement over
+    st["means_ms"][st["decided"]] *= 0.05
+    for it in range(4 * tuner.MONITOR):
+        tr.train_step(cams[it % 2], tgt)
+        torch.cuda.synchronize()
+    st2 = tuner.state[(str(dev), 333, 207)]
+    assert st2["retunes"] >= 1 and st2 is not st
