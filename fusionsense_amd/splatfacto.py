@@ -144,6 +144,16 @@ class DensifyStrategy:
         self.extra_cull_fn = None  # hook for hull / touch pruning (a-14)
         self.last_report: Dict[str, int] = {}
 
+    def add_mask_u8(self) -> Optional[Tensor]:
+        """The touch-anchor mask as the uint8 row the HIP kernels read, converted only when the mask object changed (the
+        tape-free step converted it on every frame: one cast launch per step at BASELINE config #3)."""
+        if self.add_mask is None:
+            return None
+        c = getattr(self, "_add_mask_u8", None)
+        if c is None or c[0] is not self.add_mask:
+            c = self._add_mask_u8 = (self.add_mask, self.add_mask.to(torch.uint8).contiguous())
+        return c[1]
+
     def touch_rows(self) -> Optional[Tensor]:
         """Row indices of the touch anchors (``add_mask.nonzero()``), recomputed only when the mask object changed."""
         if self.add_mask is None:

@@ -771,6 +771,9 @@ class SplatTrainer:
         if direct:
             from .fused import fused_step_forward_backward
             stats, add_mask, bthr = self._frame_state(camera, True)
+            # (the kernels read the anchors as a uint8 row: the strategy keeps the converted mask with the mask)
+            frozen = (self.strategy.add_mask_u8() if (add_mask is not None and hasattr(self.strategy, "add_mask_u8"))
+                      else add_mask)
             factors = self._factor_buffers(optimizer_step)
             from .ops import LiveListOverflow
             from .ops import OcclusionCutInvalid
@@ -791,7 +794,7 @@ class SplatTrainer:
                 try:
                     loss, out = fused_step_forward_backward(
                         self._params, camera, target, self._sh_degree_now(), self.device, self.slab.views, self._one,
-                        stats_out=stats, add_mask=add_mask, binary_threshold=bthr,
+                        stats_out=stats, add_mask=frozen, binary_threshold=bthr,
                         pre_sh=self.flush if self._pending is not None else None, adam_rider=self._adam_rider(),
                         sh_factors_out=factors[0] if factors else None,
                         fusion=((self.loss_cfg,) + self._touch_rows()) if is_fb else None,
