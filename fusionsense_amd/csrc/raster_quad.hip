@@ -297,7 +297,9 @@ raster_fwd_quad_kernel(int64_t cap, const float4 *__restrict__ packed, const int
 }
 
 #ifndef FSGS_FWD_WAVE_OCC
-#define FSGS_FWD_WAVE_OCC 6  // waves per SIMD: 4 / 6 / 8 measured at 92.5 / 85.0 / 87.8 us (config #2), 0.598 / 0.550 / 0.562 ms (#4)
+#define FSGS_FWD_WAVE_OCC 6  // waves per SIMD: 4 / 6 / 8 measured at 92.5 / 85.0 / 87.8 us (config #2), 0.598 / 0.550 / 0.562 ms (#4);
+                             // with the final hot loop 5 / 6 / 7: 77.0 / 75.8 / 77.9 us, 0.527 / 0.521 / 0.534 ms; "long" from 1.5 / 2 / 3
+                             // times the mean list length: 75.3 / 75.8 / 76.2 us, 0.528 / 0.521 / 0.530 ms
 #endif
 // Third generation (round 4), the training path's forward (D = 4, E = 3): ONE WAVE per 8x8 quadrant, lane = pixel, one
 // record per step.  The (pixel, slot) walk above spends ~50 vector instructions per step of 4 records x 16 pixels — 50 per
