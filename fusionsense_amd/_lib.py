@@ -28,8 +28,14 @@ class AdamGroups(C.Structure):
                 ("eps", C.c_float)]
 
 
+# == FSGS_ABI_VERSION of include/fsgs.h as of the SIGNATURES table below: load() refuses any other library (a stale
+# build — the .so files are git-ignored and travel separately, A/B builds come in through FSGS_LIB — would read a stream
+# pointer as a flag or write past a buffer that has since grown)
+ABI_VERSION = 5
+
 SIGNATURES = {
     "fsgs_version": (_i, []),
+    "fsgs_abi_version": (_i, []),
     "fsgs_grad_replica_lines": (_i, []),
     "fsgs_error_string": (C.c_char_p, [_i]),
     "fsgs_last_hip_error": (_i, []),
@@ -148,6 +154,14 @@ def load() -> C.CDLL:
             "There is no CPU fallback."
         )
     lib = C.CDLL(LIB_PATH)
+    try:
+        lib.fsgs_abi_version.restype = C.c_int
+        found = int(lib.fsgs_abi_version())
+    except AttributeError:
+        found = None
+    if found != ABI_VERSION:
+        raise FsgsError(f"{LIB_PATH} has C-ABI version {found}, this binding was written against {ABI_VERSION} "
+                        "(include/fsgs.h: FSGS_ABI_VERSION): rebuild it (`make -C fusionsense_amd/csrc`)")
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
         fn.restype = res

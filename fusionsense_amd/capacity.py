@@ -42,7 +42,6 @@ class LiveCapacity:
     def __init__(self, max_keys: int = 64, window: int = 256, margin: float = 1.25, slack: int = 4096):
         self.table = LRU(max_keys)
         self.window, self.margin, self.slack = int(window), float(margin), int(slack)
-        self._poison = None
 
     @staticmethod
     def key(dev, cams: int, n: int, width: int, height: int, extra=None):
@@ -53,9 +52,6 @@ class LiveCapacity:
         e = self.table.get(key)
         if e is None:
             return 0
-        if self._poison is not None:
-            p, self._poison = self._poison, None
-            return p
         return int(max(e[0], e[1]) * self.margin) + self.slack
 
     def update(self, key, n_live: int) -> None:
@@ -71,13 +67,8 @@ class LiveCapacity:
         """After an overflow: the frame needed this many."""
         self.update(key, needed)
 
-    def poison(self, pairs: int) -> None:
-        """Tests: every known shape's estimate becomes ``pairs`` (no margin), so the next frame overflows."""
-        self._poison = int(pairs)
-
     def clear(self) -> None:
         self.table.clear()
-        self._poison = None
 
     def __len__(self):
         return len(self.table)

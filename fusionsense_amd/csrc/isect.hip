@@ -10,6 +10,12 @@
 #include "project_math.h"
 #include "scan.h"
 
+// A/B build switch (make EXTRA=-DFSGS_ISECT_PER_THREAD=1): one thread per Gaussian in the drop-in path's live count / emit
+// passes instead of the flattened pair enumeration.  The library reads no environment variable.
+#ifndef FSGS_ISECT_PER_THREAD
+#define FSGS_ISECT_PER_THREAD 0
+#endif
+
 namespace fsgs {
 
 struct TileRect {
@@ -743,7 +749,7 @@ extern "C" int fsgs_isect_count_live(int C, int N, const float *means2d, const i
         return FSGS_EINVAL;
     if (scratch_bytes < fsgs_scan_scratch_bytes(total) || !scratch) return FSGS_ESCRATCH;
     hipStream_t s = as_stream(stream);
-    static const bool per_thread = getenv("FSGS_ISECT_PER_THREAD") != nullptr;
+    constexpr bool per_thread = FSGS_ISECT_PER_THREAD != 0;  // (build macro: the library reads no environment)
     if (per_thread)
         hipLaunchKernelGGL((isect_live_kernel<false>), dim3(ceil_div(total, 256)), dim3(256), 0, s, C, N, means2d,
                            radii, nullptr, conics, opacities, nullptr, tile_width, tile_height, 0, tiles_per_gauss,
@@ -772,7 +778,7 @@ extern "C" int fsgs_isect_emit_live(int C, int N, const float *means2d, const in
     if (!means2d || !radii || !depths || !conics || !opacities || !cum_live || !isect_ids || !payload)
         return FSGS_EINVAL;
     const int tb = tile_bits_for(tile_width * tile_height);
-    static const bool per_thread = getenv("FSGS_ISECT_PER_THREAD") != nullptr;
+    constexpr bool per_thread = FSGS_ISECT_PER_THREAD != 0;  // (build macro: the library reads no environment)
     if (per_thread)
         hipLaunchKernelGGL((isect_live_kernel<true>), dim3(ceil_div(total, 256)), dim3(256), 0, as_stream(stream), C,
                            N, means2d, radii, depths, conics, opacities, cum_live, tile_width, tile_height, tb,

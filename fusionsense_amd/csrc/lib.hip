@@ -7,6 +7,8 @@ thread_local int g_last_hip_error = 0;
 
 extern "C" int fsgs_version(void) { return 100; /* 0.1.0 */ }
 
+extern "C" int fsgs_abi_version(void) { return FSGS_ABI_VERSION; }
+
 extern "C" int fsgs_grad_replica_lines(void) { return fsgs::kGradReplicas; }
 
 extern "C" int fsgs_last_hip_error(void) { return fsgs::g_last_hip_error; }

@@ -57,6 +57,9 @@ __device__ __forceinline__ void load_rec(Rec &r, const float4 *__restrict__ rec,
 // to come  buffer_end(k) = C_total - C_before(k+1)  (or 0).  A workgroup of kBwdWaves waves owns a
 // quadrant; wave w takes segments w, w+kBwdWaves, ... independently (no barriers between waves), which
 // removes the long-list tail that otherwise sets the kernel's duration.
+#ifndef FSGS_BWD_MERGE_THR16
+#define FSGS_BWD_MERGE_THR16 15
+#endif
 #ifndef FSGS_BWD_WAVES
 #define FSGS_BWD_WAVES 4
 #endif
@@ -459,11 +462,8 @@ extern "C" int64_t fsgs_quad_seg_slots(int C, int tile_width, int tile_height, i
 // 0.720 / 0.611, config #5 0.703 / 0.610 — and config #3 0.209 / 0.279 (there the lines of the large hull Gaussians stay
 // L2-resident under the row-major sweep).  Not decided here: the caller measures (fused.py tunes it per frame shape).
 // The stride is an ARGUMENT of the two launch entry points (dispatch_stride >= 0).  DEPRECATED: a negative argument takes
-// this process-wide default (FSGS_BWD_PERM / fsgs_set_bwd_dispatch_stride), kept for callers written against round 3.
-static std::atomic<int> g_bwd_dispatch_stride{[] {
-    const char *e = getenv("FSGS_BWD_PERM");
-    return e ? atoi(e) : 0;
-}()};
+// this process-wide default (fsgs_set_bwd_dispatch_stride; initially row-major), kept for callers written against round 3.
+static std::atomic<int> g_bwd_dispatch_stride{0};
 extern "C" int fsgs_set_bwd_dispatch_stride(int stride) { return g_bwd_dispatch_stride.exchange(stride < 0 ? 0 : stride); }
 
 #ifdef FSGS_BWD_STATS
@@ -486,9 +486,9 @@ static int launch_bwd_live(int C, int D, const float *records, const int32_t *n_
                            fsgs_stream_t stream, int dispatch_stride,
                            GetOutputsGrads ep = GetOutputsGrads{nullptr, nullptr, nullptr, nullptr, nullptr},
                            int64_t replica_rows = 0) {
-    // FSGS_BWD_MERGE_THR16 (A/B switch): a segment walks the union list with merged atomics when its longest row list
-    // is >= thr/16 of the union; 0 = always, 17 = never
-    static const int merge_thr16 = [] { const char *e = getenv("FSGS_BWD_MERGE_THR16"); return e ? atoi(e) : 15; }();
+    // FSGS_BWD_MERGE_THR16 (build macro, make EXTRA=-DFSGS_BWD_MERGE_THR16=n): a segment walks the union list with merged
+    // atomics when its longest row list is >= thr/16 of the union; 0 = always, 17 = never
+    constexpr int merge_thr16 = FSGS_BWD_MERGE_THR16;
     if (C < 0 || width < 0 || height < 0 || n_isects < 0) return FSGS_EINVAL;
     if (C == 0 || width == 0 || height == 0 || n_isects == 0) return FSGS_OK;
     // (the kernel addresses the accumulator with 32-bit float offsets: record ids are 28-bit, 16 floats each, plus the

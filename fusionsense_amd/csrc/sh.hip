@@ -1102,10 +1102,7 @@ gauss_sh_bwd_kernel(GaussShArgs A, GaussBwdFused fz) {
 
 // DEPRECATED process-wide default for callers that pass flags < 0 (round-3 behaviour): from this many Gaussians on,
 // fsgs_gauss_sh_bwd fetches coefficients lazily and skips idle Adam elements.  The flags argument decides per launch.
-static std::atomic<int> g_lazy_sh_min_n{[] {
-    const char *e = getenv("FSGS_LAZY_SH_MIN_N");
-    return e ? atoi(e) : (1 << 20);
-}()};
+static std::atomic<int> g_lazy_sh_min_n{1 << 20};
 extern "C" int fsgs_set_lazy_sh_min_n(int n) { return g_lazy_sh_min_n.exchange(n); }
 
 static int gauss_sh_bwd_impl(int N, int degree, const float *means, const float *campos, const void *features_dc,

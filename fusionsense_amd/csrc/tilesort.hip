@@ -20,6 +20,14 @@
 #include "common.h"
 #include "tile_scan.h"
 
+// A/B build switches (make EXTRA=-D...=0); the library reads no environment variable.
+#ifndef FSGS_LDS_SPLIT_SORT
+#define FSGS_LDS_SPLIT_SORT 1
+#endif
+#ifndef FSGS_SORT_ONE_TIER
+#define FSGS_SORT_ONE_TIER 1
+#endif
+
 namespace fsgs {
 
 constexpr int kTsThreads = 256;                                  // scan / small-sort workgroup
@@ -738,7 +746,7 @@ int launch_tile_sort_tiers(int T, int n_tiles, int tile_bits, const int32_t *ise
 int launch_split_sort(int T, int n_tiles, int tile_bits, const int32_t *isect_offsets, int64_t n_live,
                       const uint64_t *buckets, uint64_t *buckets2, int32_t *scratch, int32_t *payload_sorted,
                       hipStream_t s) {
-    static const int use_lds = [] { const char *e = getenv("FSGS_LDS_SPLIT_SORT"); return e ? atoi(e) : 1; }();
+    constexpr int use_lds = FSGS_LDS_SPLIT_SORT;  // (build macro: 0 = the round-2 route through global sub-buckets)
     const int target = use_lds ? kLdsCoarse : kSplitTarget;
     const int max_sub = (int)(T + n_live / target + 1);
     int32_t *sub_base = scratch, *sub_offsets = scratch + (T + 1), *sub_ends = sub_offsets + (max_sub + 1);
@@ -775,11 +783,7 @@ int64_t split_scratch_ints(int T, int64_t n_live) { return (int64_t)(T + 1) + 2 
 int launch_tile_sort_tiers(int T, int n_tiles, int tile_bits, const int32_t *isect_offsets, uint64_t *buckets,
                            int32_t *payload_sorted, int64_t *isect_ids_sorted, hipStream_t s) {
     if (const int rc = ensure_dynamic_lds<&tile_sort_kernel2<1024, kTsLarge, kTsSmall, true>>(kTsLarge * 8)) return rc;
-    static int one_tier = -1;
-    if (one_tier < 0) {
-        const char *e = getenv("FSGS_SORT_ONE_TIER");
-        one_tier = e ? atoi(e) : 1;
-    }
+    constexpr int one_tier = FSGS_SORT_ONE_TIER;  // (build macro)
     if (one_tier && T <= 8192) {
         // a moderate number of buckets: EVERY bucket through the 1024-thread kernel in one launch — the small
         // buckets' workgroups (12 of their 16 waves have nothing to do and only meet the barriers) run beside the

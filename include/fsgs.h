@@ -20,8 +20,10 @@
  *   - no global state: everything a launch depends on is an argument of the call (since round 4 that includes the
  *     dispatch order of the compositing backward and the lazy / idle-skipping switches of the per-Gaussian backward).
  *     The two process-wide setters of round 3 — fsgs_set_bwd_dispatch_stride, fsgs_set_lazy_sh_min_n — remain as
- *     DEPRECATED defaults that only a caller passing a negative value for the corresponding argument ever reads;
- *     A/B switches read from the environment (FSGS_*) are build / debugging aids and never change results
+ *     DEPRECATED defaults that only a caller passing a negative value for the corresponding argument ever reads.
+ *     The library reads NO environment variable (round 5): its A/B switches are build macros of csrc/ (make EXTRA=-D...)
+ *   - FSGS_ABI_VERSION changes with every change of a signature or of a buffer's size / layout; a binding must refuse a
+ *     library whose fsgs_abi_version() differs from the header it was written against (fusionsense_amd/_lib.py does)
  */
 #ifndef FSGS_H
 #define FSGS_H
@@ -40,7 +42,9 @@ typedef void *fsgs_stream_t; /* hipStream_t */
 #define FSGS_ELAUNCH -2  /* hipLaunch / runtime error; see fsgs_last_hip_error() */
 #define FSGS_ESCRATCH -3 /* scratch arena too small */
 
+#define FSGS_ABI_VERSION 5
 int fsgs_version(void);
+int fsgs_abi_version(void); /* == FSGS_ABI_VERSION of the header the library was built from */
 /* Lines of the packed gradient accumulator a caller that passes `replica_rows` > 0 must provide per Gaussian row:
  * `v_packed` is [fsgs_grad_replica_lines() * replica_rows, 16] floats, zeroed once (the last reader keeps it zeroed).
  * Gaussians of large 2-D footprint (det(cov2d) > 4096 px^4) spread their gradient atomics over these lines, picked

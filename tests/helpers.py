@@ -65,11 +65,168 @@ def oracle_frame(act, viewmat, K, W, H, tile=16):
                 ids_s=ids_s, flat_s=flat_s, offsets=offs, tw=tw, th=th)
 
 
+def poison_capacity(caps, pairs):
+    """The next estimate a KNOWN frame shape asks ``caps`` (a capacity.LiveCapacity) for is ``pairs`` (no margin), so that
+    frame overflows its lists; the estimate after it is the real one again.  (A test hook: it patches the instance.)"""
+    real = caps.get
+
+    def once(key):
+        if real(key) == 0:
+            return 0
+        del caps.get  # (the instance attribute: the class's method is back)
+        return int(pairs)
+    caps.get = once
+
+
 def rel_err(a, b):
     a = a.detach().double().cpu()
     b = b.detach().double().cpu()
     return ((a - b).abs().max() / (b.abs().max() + 1e-12)).item()
 
+
+def crop_camera(cam0, crop_w, crop_h=None, shift=(0, 0)):
+    """The window of ``cam0``'s image of size crop_w x crop_h centred at the image centre + ``shift`` (pixels), as a
+    camera of its own: same pose and focal lengths, shifted principal point."""
+    from fusionsense_amd.scenes import Camera
+    crop_h = crop_h or crop_w
+    x0 = (cam0.width - crop_w) // 2 + shift[0]
+    y0 = (cam0.height - crop_h) // 2 + shift[1]
+    return Camera(cam0.c2w, cam0.fx, cam0.fy, cam0.cx - x0, cam0.cy - y0, crop_w, crop_h)
+
+
+class OracleWindow:
+    """The CPU oracle's frame of ALL of ``params_cpu``'s Gaussians through the (small) camera ``cam`` — forward once
+    (fp32, graph kept), the fp32 / fp64 projections that decide which integer mismatches are rounding edges — against
+    which any number of HIP routes are then checked (``check``): forward images, the integer outputs (radii,
+    tiles_per_gauss) and every parameter gradient of a loss.
+
+    No blanket allowance: every radii / tiles_per_gauss mismatch must be a Gaussian on which the fp32 and the fp64 oracle
+    themselves disagree or whose fp64 pre-ceil radius / rectangle bound / cull bound sits within 1e-3 of an integer, and
+    every pixel beyond the image tolerance must, walked in fp64, hold an entry on a threshold decision (alpha within 2e-6
+    of 1/255 or of the 0.999 cap, running transmittance within 2e-7 of 1e-4)."""
+
+    def __init__(self, params_cpu, cam, seed=11):
+        from oracle.fusion_ref import render_fusionsense as render_ref
+        self.cam = cam
+        W, H = cam.width, cam.height
+        g = torch.Generator().manual_seed(seed)
+        self.w = {"rgb": torch.rand(H, W, 3, generator=g), "depth": torch.rand(H, W, 1, generator=g),
+                  "normal": torch.rand(H, W, 3, generator=g), "accumulation": torch.rand(H, W, 1, generator=g)}
+        self.pr = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in params_cpu.items()}
+        self.orf = render_ref(self.pr, cam, sh_degree=3)
+        act = activated({k: v.detach() for k, v in self.pr.items() if k not in ("features_dc", "features_rest")} |
+                        {"features_dc": torch.zeros(1, 3), "features_rest": torch.zeros(1, 0, 3)})
+        viewmat, K = camera_mats(cam)
+        p32 = R.project(act["means"], act["quats"], act["scales"], viewmat, K, W, H)
+        p64 = R.project(act["means"].double(), act["quats"].double(), act["scales"].double(), viewmat.double(),
+                        K.double(), W, H)
+        assert torch.equal(p32[0][0], self.orf["radii"])  # (the oracle run above is the fp32 oracle)
+        # fp64 pre-ceil radius, recomputed from the fp64 conic (conic = inverse of the blurred 2-D covariance)
+        cn = p64[3][0]
+        detc = (cn[:, 0] * cn[:, 2] - cn[:, 1] ** 2).clamp(min=1e-300)
+        a_, c_ = cn[:, 2] / detc, cn[:, 0] / detc
+        det = 1.0 / detc
+        bb = 0.5 * (a_ + c_)
+        pre = 3.0 * torch.sqrt(bb + torch.sqrt(torch.clamp(bb * bb - det, min=0.01)))
+        edge_r = ((pre - torch.round(pre)).abs() < 1e-3) | (p32[0][0] != p64[0][0])
+        # culling / bbox edges: centre +- radius against the image borders within 1e-3 px
+        mx, my, rr = p64[1][0][:, 0], p64[1][0][:, 1], p64[0][0].double()
+        edge_cull = (((mx + rr).abs() < 1e-3) | ((mx - rr - W).abs() < 1e-3) | ((my + rr).abs() < 1e-3) |
+                     ((my - rr - H).abs() < 1e-3))
+        self.edge_radius = edge_r | edge_cull
+        # tile rectangles: bounds (mean / 16 -+ radius / 16) within 1e-3 of an integer in fp64, or an unstable radius
+        lo = torch.stack([mx, my], -1) / 16.0 - rr[:, None] / 16.0
+        hi = torch.stack([mx, my], -1) / 16.0 + rr[:, None] / 16.0
+        edge_t = (((lo - torch.round(lo)).abs() < 1e-3) | ((hi - torch.round(hi)).abs() < 1e-3)).any(-1)
+        self.tw, self.th = (W + 15) // 16, (H + 15) // 16
+        t32 = R.isect_tiles(p32[1], p32[0], p32[2], 16, self.tw, self.th)[0]
+        t64 = R.isect_tiles(p64[1], p64[0], p64[2], 16, self.tw, self.th)[0]
+        self.edge_tiles = (edge_t | torch.from_numpy(np.asarray(t32).reshape(-1) != np.asarray(t64).reshape(-1)) |
+                           self.edge_radius)
+        info = self.orf["info"]
+        self.offs = np.concatenate([np.asarray(info["isect_offsets"]).reshape(-1).astype(np.int64),
+                                    [len(info["flatten_ids"])]])
+        self.flat = np.asarray(info["flatten_ids"]).astype(np.int64)
+        self.m2_64, self.cn_64 = p64[1][0], p64[3][0]
+        self.op_64 = act["opacities"].double().reshape(-1)
+
+    def loss_of(self, out, to):
+        """The default loss: seeded random weights on every output image."""
+        return sum((out[k] * to(self.w[k])).mean() for k in self.w)
+
+    def _on_a_threshold(self, y, x):
+        t = (y // 16) * self.tw + (x // 16)
+        gi = torch.from_numpy(self.flat[self.offs[t]:self.offs[t + 1]])
+        dx, dy = self.m2_64[gi, 0] - (x + 0.5), self.m2_64[gi, 1] - (y + 0.5)
+        sigma = 0.5 * (self.cn_64[gi, 0] * dx * dx + self.cn_64[gi, 2] * dy * dy) + self.cn_64[gi, 1] * dx * dy
+        alpha = torch.clamp(self.op_64[gi] * torch.exp(-sigma), max=0.999)
+        valid = (sigma >= 0) & (alpha >= 1.0 / 255.0)
+        T = torch.cumprod(1.0 - torch.where(valid, alpha, torch.zeros_like(alpha)), 0)
+        alive = torch.cat([torch.ones(1, dtype=torch.bool), T[:-1] > 1e-4])  # entries reached before the stop
+        near_skip = ((alpha - 1.0 / 255.0).abs() < 2e-6) & (sigma >= -1e-9) & alive
+        near_stop = ((T - 1e-4).abs() < 2e-7) & alive
+        near_cap = ((self.op_64[gi] * torch.exp(-sigma) - 0.999).abs() < 2e-6) & alive
+        return bool(near_skip.any() | near_stop.any() | near_cap.any())
+
+    def check(self, og, grads, max_bad_radii, oracle_loss=None, grad_tol=3e-3, max_outlier_frac=1e-3):
+        """``og`` / ``grads``: a HIP route's outputs and parameter gradients of the loss whose oracle-side statement is
+        ``oracle_loss(out, to)`` (default: ``loss_of``)."""
+        orf, pr = self.orf, self.pr
+        W, H = self.cam.width, self.cam.height
+        for v in pr.values():
+            v.grad = None
+        l_ref = (oracle_loss or self.loss_of)(orf, lambda t: t)
+        l_ref.backward(retain_graph=True)
+        # ---- integer outputs
+        hip_radii = og["radii"] if "radii" in og else og["info"]["radii"][0]
+        bad_r = hip_radii.cpu().reshape(-1) != orf["radii"].reshape(-1)
+        n_bad_r = int(bad_r.sum())
+        assert n_bad_r == int((bad_r & self.edge_radius).sum()), \
+            f"{int((bad_r & ~self.edge_radius).sum())} of {n_bad_r} radii mismatches are not fp32 rounding edges"
+        assert n_bad_r <= max_bad_radii  # (context: ~1e-4 of the Gaussians is what an fp32 projection leaves on an edge)
+        bad_t = og["info"]["tiles_per_gauss"].cpu()[0] != orf["info"]["tiles_per_gauss"][0]
+        assert int(bad_t.sum()) == int((bad_t & self.edge_tiles).sum()), \
+            f"{int((bad_t & ~self.edge_tiles).sum())} of {int(bad_t.sum())} tiles_per_gauss mismatches are not fp32 rounding edges"
+        # ---- images: 1e-4 of the tensor maximum — and EVERY outlier pixel must sit on a threshold decision of its walk:
+        # in fp64, some entry of its tile's list has alpha within 2e-6 of 1/255 (the skip), or the running transmittance
+        # passes within 2e-7 of 1e-4 (the stop) — where one Gaussian more or less moves a channel by at most
+        # alpha T c <= 1/255
+        outliers = torch.zeros(H, W, dtype=torch.bool)
+        for k, tol in (("rgb", 1e-4), ("accumulation", 1e-4), ("depth", 1e-3)):
+            d = (og[k].detach().cpu() - orf[k].detach()).abs() / max(1.0, float(orf[k].detach().abs().max()))
+            outliers |= (d > tol).any(-1)
+            assert float(d.max()) <= 1.0 / 255.0 + tol, (k, float(d.max()))
+        # (a Gaussian whose radius is an fp32 edge case is in or out of a tile's list: its pixels are explained too)
+        unexplained = sum(0 if self._on_a_threshold(y, x) else 1 for y, x in torch.nonzero(outliers).tolist())
+        n_out = int(outliers.sum())
+        assert unexplained == 0, f"{unexplained} of {n_out} outlier pixels are not on an alpha >= 1/255 / T <= 1e-4 decision"
+        assert n_out < max_outlier_frac * H * W, n_out  # (context only: the justification above is the check)
+        dn = (og["normal"].detach().cpu() - orf["normal"].detach()).abs()
+        assert dn.mean().item() < 1e-5 and (dn > 1e-2).float().mean().item() < 1e-3
+        for k in pr:
+            e = rel_err(grads[k], pr[k].grad)
+            assert e < grad_tol, (k, e)  # DESIGN.md §3: 3e-3 of the tensor's own largest gradient
+        return dict(n_bad_radii=n_bad_r, n_bad_tiles=int(bad_t.sum()), n_outliers=n_out, oracle_loss=float(l_ref.detach()),
+                    visible=int((orf["radii"] > 0).sum()), n_isects=len(self.flat))
+
+
+def fused_node_route(dev, params):
+    """``route(cam, loss_of) -> (outputs, grads)``: the fused autograd node on clones of ``params``."""
+    from fusionsense_amd.fused import render_fusionsense_fused
+
+    def route(cam, loss_of):
+        pg = {k: v.detach().clone().requires_grad_(True) for k, v in params.items()}
+        og = render_fusionsense_fused(pg, cam, sh_degree=3, device=dev)
+        loss_of(og, lambda t: t.to(dev)).backward()
+        return og, {k: v.grad for k, v in pg.items()}
+    return route
+
+
+def check_fused_node_against_oracle_on_crop(dev, params, cam, max_bad_radii):
+    """The fused autograd node against the CPU oracle on ALL of ``params``' Gaussians through ``cam`` (OracleWindow)."""
+    win = OracleWindow({k: v.detach().cpu() for k, v in params.items()}, cam)
+    og, grads = fused_node_route(dev, params)(cam, win.loss_of)
+    return win.check(og, grads, max_bad_radii)
 
 def run_bench_ranks(n_ranks, bench_args, env_extra=None, timeout=240):
     """bench.py under torch.distributed.run the way the driver launches it (one process per rank, 127.0.0.1

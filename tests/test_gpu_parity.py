@@ -8,7 +8,7 @@ import torch
 
 from fusionsense_amd import scenes
 from oracle import gsplat_ref as R
-from tests.helpers import activated, adversarial_gaussians, camera_mats, oracle_frame, rel_err
+from tests.helpers import activated, adversarial_gaussians, camera_mats, oracle_frame, poison_capacity, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -1078,7 +1078,7 @@ def test_rasterization_without_host_wait_is_bit_identical_and_survives_overflow(
         outs = []
         for it in range(3):
             if poison is not None and it == 2:
-                rendering._LIVE_CAPS.poison(poison)
+                poison_capacity(rendering._LIVE_CAPS, poison)
             gp = {k: v.to(dev).requires_grad_(True) for k, v in params.items()}
             o = render_fusionsense(gp, cam, sh_degree=3, device=dev)
             (o["rgb"].sum() + o["depth"].sum() + o["normal"].sum()).backward()

@@ -34,6 +34,23 @@ def test_capi_exports_every_declared_symbol():
     assert lib.fsgs_sort_scratch_bytes(1 << 20) > (1 << 20) // 2048 * 256 * 4
 
 
+def test_binding_refuses_a_library_of_another_abi_version(monkeypatch):
+    """include/fsgs.h, the built library and the ctypes table carry ONE C-ABI version; load() refuses a library whose
+    fsgs_abi_version() differs (a stale libfsgs.so / FSGS_LIB build would otherwise take a stream pointer for a flag)."""
+    from fusionsense_amd import _lib
+    header = open(os.path.join(ROOT, "include", "fsgs.h")).read()
+    declared = int(re.search(r"#define\s+FSGS_ABI_VERSION\s+(\d+)", header).group(1))
+    assert declared == _lib.ABI_VERSION == _lib.load().fsgs_abi_version()
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "ABI_VERSION", declared + 1)
+    with pytest.raises(_lib.FsgsError, match="C-ABI version"):
+        _lib.load()
+    # the library reads no environment variable (fsgs.h: "no global state")
+    import glob
+    for src in glob.glob(os.path.join(ROOT, "fusionsense_amd", "csrc", "*.h*")):
+        assert "getenv" not in open(src).read(), src
+
+
 def test_ctypes_signatures_match_the_header():
     """Every ctypes signature has the argument count and the argument KINDS (pointer / 32-bit / 64-bit / float) of its
     declaration in include/fsgs.h — a stray or missing argument would otherwise only show as garbage on the GPU."""
@@ -919,9 +936,10 @@ def test_live_capacity_is_bucketed_windowed_and_bounded():
     for n in (1_000, 10_000, 100_000, 1_000_000, 10_000_000):
         c.update(c.key("cuda:0", 1, n, 64, 64), 5)
     assert len(c) == 4 and c.get(k) == 0
-    c.poison(7)
+    from helpers import poison_capacity
+    poison_capacity(c, 7)
     kk = c.key("cuda:0", 1, 10_000_000, 64, 64)
-    assert c.get(kk) == 7 and c.get(kk) == 4102
+    assert c.get(k) == 0 and c.get(kk) == 7 and c.get(kk) == 4102  # (the hook waits for a shape the table knows)
     d = LRU(2)
     d["a"], d["b"] = 1, 2
     assert d.get("a") == 1
