@@ -105,6 +105,15 @@ def parse():
     ap.add_argument("--scene", default=None, choices=["surface", "volume"],
                     help="configs 4 / 5: 'surface' (default) = ground + objects seen from a ring outside the content; "
                          "'volume' = the round-1 fog of Gaussians with the cameras inside it")
+    ap.add_argument("--fwd-walk", type=int, default=None, choices=[0, 1],
+                    help="A/B: the forward compositing's walk (0 = four waves per quadrant, 1 = one wave); default = "
+                         "the product's (fused.FWD_WALK: one wave per quadrant + hand-off of long walks)")
+    ap.add_argument("--handoff", type=int, default=None,
+                    help="A/B: records a wave streams before it hands the rest of its list to the second pass "
+                         "(0 = never; default = fused.FWD_WALK.handoff_records)")
+    ap.add_argument("--handoff-rel-len", type=int, default=None, help="A/B: hand off only lists longer than this many "
+                    "times the frame's mean list length")
+    ap.add_argument("--tail-items", type=int, default=None, help="A/B: queue positions of the hand-off (= tail workgroups)")
     a = ap.parse_args()
     d = DEFAULTS[a.config]
     a.steps = d["steps"] if a.steps is None else a.steps
@@ -158,11 +167,13 @@ def cpu_baseline_worker(n_gauss: int, res: int, crop: int, threads: int, n_views
 
 def cpu_baseline(args):
     """The oracle on this box's host cores.  A pure-PyTorch rasterizer does not scale with threads (measured on the
-    256-core host of the GPU boxes: the 3-view sample that takes 22 s on 8 threads did not finish in 200 s on 256), so the
-    thread count is CHOSEN by measurement: one view of a smaller crop at all cores, 64, 16 and 8 threads, 25 s each at
-    most, then the full sample (``--cpu-views`` views, ``--cpu-crop``^2 crop) at the fastest count.  ``cores`` = the
-    threads of the quoted figure, ``host_cores_available`` = what the process may run on, ``thread_sweep_s`` = the
-    probe times (None = did not finish)."""
+    256-core host of the GPU boxes, round 4: one small view takes 2.7 s on 8 threads, 2.6 s on 16, 5.4 s on 64 and does
+    not finish in 25 s on 256), so the thread count is CHOSEN by a bounded probe — one view of a 96^2 crop at 16 and at 8
+    threads, 8 s each at most (round 5: the 64- and all-core probes, which only ever lost, are gone: they cost 30 s of
+    every driver run) — then the full sample (``--cpu-views`` views, ``--cpu-crop``^2 crop) at the faster count.
+    ``cores`` = the threads of the quoted figure, ``host_cores_available`` = what the process may run on,
+    ``thread_sweep_s`` = the probe times (None = did not finish).  The figure is an EXTRAPOLATION from the crop to the
+    full frame by pixel count (``extrapolated``)."""
     import subprocess
     try:
         avail = len(os.sched_getaffinity(0))
@@ -187,12 +198,12 @@ def cpu_baseline(args):
             return {"value": None, "unit": "iters/s", "cores": threads, "kind": "port",
                     "sample": f"oracle child exceeded {timeout}s on {views} {crop}^2 crops with {threads} threads"}, None
 
-    candidates = sorted({t for t in (avail, 64, 16, 8) if t <= avail}, reverse=True)
+    candidates = sorted({t for t in (16, 8) if t <= avail} or {avail}, reverse=True)
     sweep = {}
     best = None
     if len(candidates) > 1:
         for t in candidates:
-            res, secs = child(t, 1, 96, 25.0)
+            res, secs = child(t, 1, 96, 8.0)
             ok = res.get("value") is not None and secs is not None
             sweep[str(t)] = round(secs, 1) if ok else None
             if ok and (best is None or secs < sweep[str(best)]):
@@ -202,6 +213,8 @@ def cpu_baseline(args):
     out, _ = child(best, args.cpu_views, args.cpu_crop, args.cpu_timeout)
     out["host_cores_available"] = avail
     out["thread_sweep_s"] = sweep or None
+    out["extrapolated"] = (f"from a central {args.cpu_crop}x{args.cpu_crop} crop of the 800x800 frame, scaled by pixel count; "
+                           "more threads only lose (round 4 on this host class: 64 threads 5.4 s, 256 > 25 s for the 2.6 s probe)")
     return out
 
 
@@ -218,16 +231,15 @@ def bwd_dispatch_choice(dev, W, H):
 
 
 def fwd_walk_choice(dev, W, H):
+    """The forward compositing's walk of this run (fixed since round 5: fused.FWD_WALK): walk 1 = one wave per quadrant,
+    ``handoff_records`` > 0 = long walks finished chunk-parallel by the launch's second pass; ``tail_error`` = 1 if a
+    look-back wait of that pass ever ran into its bound (results invalid; never observed)."""
     try:
         from fusionsense_amd.fused import FWD_WALK
-        st = FWD_WALK.state.get((str(dev), W, H))
-        if FWD_WALK.forced:
-            return {"walk": int(FWD_WALK.forced_walk), "forced": True, "tuning_frames": 0}
-        if not st:
-            return None
-        return {"walk": None if st["decided"] is None else int(st["decided"]),
-                "means_ms": {str(k): round(v, 4) for k, v in st.get("means_ms", {}).items()},
-                "tuning_frames": int(st.get("tuning_frames", 0)), "retunes": int(st.get("retunes", 0))}
+        walk, handoff = FWD_WALK.choice()
+        return {"walk": int(walk), "handoff_records": int(handoff), "forced": bool(FWD_WALK.forced),
+                "second_pass_items_max": int(FWD_WALK.max_items), "tail_error": FWD_WALK.error(dev) if handoff else 0,
+                "tuning_frames": 0}
     except Exception:
         return None
 
@@ -525,6 +537,17 @@ def main():
     from fusionsense_amd import frame_cache, ops
 
     log('building workload')
+    if args.handoff_rel_len is not None:
+        from fusionsense_amd.fused import FWD_WALK
+        FWD_WALK.handoff_rel_len = int(args.handoff_rel_len)
+    if args.fwd_walk is not None or args.handoff is not None or args.tail_items is not None:  # A/B switches
+        from fusionsense_amd.fused import FWD_WALK
+        if args.tail_items is not None:
+            FWD_WALK.max_items = int(args.tail_items)
+        if args.fwd_walk is not None:
+            FWD_WALK.forced, FWD_WALK.forced_walk = True, int(args.fwd_walk)
+        if args.handoff is not None:
+            FWD_WALK.handoff_records = int(args.handoff)
     wl = build_workload(args, dev)
     trainer, cams, targets, W, H = wl["trainer"], wl["cams"], wl["targets"], wl["W"], wl["H"]
     fused = not args.unfused_caller
@@ -552,15 +575,12 @@ def main():
         # those: fused._BwdDispatchTuner): let it settle HERE, not inside the timed region (with 4 views and
         # 4 warm-up steps config #5 timed some of its tuning frames)
         if fused:
-            from fusionsense_amd.fused import BWD_DISPATCH, FWD_WALK
+            from fusionsense_amd.fused import BWD_DISPATCH
             # (several ranks: a FIXED number of extra frames — every step carries collectives, so the ranks must not
-            # decide from their own timings how many they run; 20 covers the backward tuner's warm-up + 2 x 4 pairs and
-            # the forward tuner's 2 x 6 alternating frames, fused._FwdWalkTuner)
+            # decide from their own timings how many they run; 20 covers the backward tuner's warm-up + 2 x 4 pairs)
             for extra in range(20 if grouped else 40):
                 st_ = BWD_DISPATCH.state.get((str(dev), W, H))
-                sf_ = FWD_WALK.state.get((str(dev), W, H))
-                settled = ((BWD_DISPATCH.forced or (st_ is not None and st_["decided"] is not None))
-                           and (FWD_WALK.forced or (sf_ is not None and sf_["decided"] is not None)))
+                settled = BWD_DISPATCH.forced or (st_ is not None and st_["decided"] is not None)
                 if settled and not grouped:
                     break
                 v = (extra * world + rank) % len(cams)
@@ -845,7 +865,9 @@ def main():
         alg = {
             "raster_bwd_quad_d4e3": ("raster_bwd_live_kernel<4,true,3> (RGB+ED and normal plane, one walk)" + r_note,
                                      M_r * (44 + 40) + P * (28 + 20) + n_vis * (48 + 28)),
-            "raster_fwd_quad_d4e3": (("raster_fwd_wave_kernel<4,3> (one wave per quadrant" if (fwd_walk_choice(dev, W, H) or {}).get("walk") == 1
+            "raster_fwd_quad_d4e3": (("raster_fwd_wave_kernel<4,3> + raster_fwd_tail_kernel<4,3> (one wave per quadrant, long "
+                                      "walks finished chunk-parallel by the second pass" if (fwd_walk_choice(dev, W, H) or {}).get("handoff_records")
+                                      else "raster_fwd_wave_kernel<4,3> (one wave per quadrant" if (fwd_walk_choice(dev, W, H) or {}).get("walk") == 1
                                       else "raster_fwd_quad_kernel<4,3> (four waves per quadrant") +
                                      ": filter + gather + composite, RGB+ED and normal plane)" + r_note,
                                      M_r * (44 + 40) + P * (24 + 20)),
@@ -914,6 +936,13 @@ def main():
                 if valu > 1.0:
                     r["valu_busy_raw"] = round(valu, 4)
                 r["valu_insts_per_launch"] = rec.get("sq_insts_valu_per_launch")
+                n_valu = rec.get("sq_insts_valu_per_launch")
+                if n_valu:
+                    # the vector-ALU roofline beside the HBM one: a wave64 instruction issues over 4
+                    # cycles on one of 1024 SIMDs at 2.4 GHz -> the launch cannot be shorter than insts x 4 / (1024 x 2.4e9)
+                    floor_ms = n_valu * 4.0 / (1024 * 2.4e9) * 1e3
+                    r["valu_roofline"] = {"bound": "valu", "insts_per_launch": n_valu, "cycles_per_inst": 4, "simds": 1024,
+                                          "clock_ghz": 2.4, "floor_ms": round(floor_ms, 4), "frac": round(floor_ms / ms, 4)}
             if valu is None and traffic_frac is None:
                 r["limiter"] = None  # no counters committed for this span and configuration
             elif valu is not None and valu >= 0.65:
@@ -967,6 +996,10 @@ def main():
             "dropin_detail": None if dropin is None else dropin_detail,
             "patched_full_iters_per_s": None if dropin is None else dropin_detail.get("patched_full_iters_per_s"),
             "render_tolerance": RENDER_TOLERANCE,
+            # what the parity tests compare against: the rasterizer arithmetic lives in gsplat 1.0.0 /
+            # nerfstudio 1.1.3, both absent from /root/reference — the oracle restates them and nothing reference-held pins it
+            "oracle": "parity unpinned (gsplat 1.0.0 / nerfstudio 1.1.3 absent from the reference tree; the FusionSense-owned "
+                      "glue, losses, densification and data formats ARE pinned by goldens produced by executing the reference)",
             "iter_algorithmic_bytes": b_iter,
             # (frames binned with occlusion cuts: priced on the pairs that were binned — the work the step does — so
             # that the fraction stays a fraction; the §8d figure on gsplat's rectangle pairs is kept beside it)
@@ -980,9 +1013,8 @@ def main():
             # frames of the timed region on which the tuner issued the launch twice (0: it had settled during the setup;
             # it starts over when the model has grown or shrunk by a quarter)
             "bwd_dispatch_tuning_frames_in_timed_region": tune_in_region,
-            # the forward compositing's walk as measured and chosen in this run (fused._FwdWalkTuner; the ``walk``
-            # argument of fsgs_raster_fwd_quad): 0 = four waves per quadrant, 1 = one wave per quadrant; the means are
-            # those of the alternating frames; frames of the timed region that were still alternating
+            # the forward compositing's walk (fixed since round 5 — no tuner, reproducible runs: fused.FWD_WALK; the
+            # ``walk`` / ``handoff_records`` arguments of fsgs_raster_fwd_quad)
             "fwd_walk": fwd_walk_choice(dev, W, H),
             "fwd_walk_tuning_frames_in_timed_region": ftune_in_region,
             # steps whose Adam update was applied inside the per-Gaussian backward launch (no gradient slab, no Adam

@@ -31,7 +31,7 @@ class AdamGroups(C.Structure):
 # == FSGS_ABI_VERSION of include/fsgs.h as of the SIGNATURES table below: load() refuses any other library (a stale
 # build — the .so files are git-ignored and travel separately, A/B builds come in through FSGS_LIB — would read a stream
 # pointer as a flag or write past a buffer that has since grown)
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 SIGNATURES = {
     "fsgs_version": (_i, []),
@@ -76,7 +76,9 @@ SIGNATURES = {
     "fsgs_raster_quad_max_cells": (_i, []),
     "fsgs_live_pack_normals": (_i, [_i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p]),
     "fsgs_live_payload": (_i, [_p, _p, _i64, _p, _i64, _i, _i, _p, _p]),
-    "fsgs_raster_fwd_quad": (_i, [_i, _i, _p, _p, _p, _i64, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p]),
+    "fsgs_raster_fwd_quad": (_i, [_i, _i, _p, _p, _p, _i64, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _i64, _i, _i, _i64, _p]),
+    "fsgs_raster_fwd_tail_scratch_bytes": (_i64, [_i]),
+    "fsgs_raster_fwd_tail_error": (_i, [_p, _p]),
     "fsgs_set_bwd_dispatch_stride": (_i, [_i]),
     "fsgs_raster_bwd_quad": (_i, [_i, _i, _p, _p, _p, _i64, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _i, _p]),
     "fsgs_raster_bwd_quad_images": (_i, [_p, _p, _p, _i64, _i, _i, _i, _i] + [_p] * 10 + [_i, _p, _i64, _i, _p]),

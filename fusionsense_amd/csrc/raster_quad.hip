@@ -336,6 +336,165 @@ __device__ long long g_fwd_trace[1 << 17][6];
 template <int E>
 struct WaveLds { float4 r0[66], r1[66], r2[66], r3[E ? 66 : 1]; };  // (+2: the walk reads one record ahead)
 
+// ---- Fourth generation (round 5): the long walks are HANDED OFF and finished chunk-parallel -------------------------
+// The one-wave walk is the cheapest per record (27 vector instructions) but a quadrant's walk is one wave's dependent
+// chain, so a launch ended with its longest lists (config #2: the bulk done after 45 us, the 450-record walks at 75 us;
+// config #3 after densification: lists of 2 800 entries, 278 us — the four-wave walk had to be used there).  A list is a
+// serial dependence only through the transmittance T, so:
+//   base waves (one per quadrant, as before): a wave that has streamed `handoff_records` records and still has open
+//     pixels and list entries left stops at the end of its 64-entry chunk, claims one queue position per remaining chunk
+//     with ONE returning atomic, leaves its per-pixel state (T, the 7 sums, last index, open flag) and exits;
+//   tail waves (the LAST `qmax` workgroups of the SAME launch, one per queue position — they are dispatched when the
+//     base workgroups have all been dispatched, i.e. into the SIMD slots the launch's drain phase leaves idle, and wait
+//     for their position to be filled or for every base workgroup to have left): (1) a chunk forms the product of
+//     (1 - alpha) over its records for each pixel — no dependence on anything — and publishes it; (2) the transmittance at
+//     its start is the handed-off T times its predecessors' products, read straight from their positions (consecutive
+//     ones, held by workgroups dispatched before it); (3) it composites its records from that T with the reference's
+//     stop rule (a pixel whose T at the chunk's start is <= 1e-4 stopped before it), streams them for the backward and
+//     keeps chunk-local sums; (4) the wave of the list's last chunk adds the partial sums IN CHUNK ORDER
+//     (deterministic), completes the saved segment states and writes the pixels.
+// Same arithmetic per record; products and sums are associated per chunk (like the four-wave walk's quad products),
+// covered by the image tolerance; results depend neither on the queue positions the atomics hand out nor on whether the
+// queue had room (a wave whose claim does not fit walks the rest of its list itself with the chunks' arithmetic).
+// Cross-workgroup traffic (cdna_hip_programming.md, Guideline 16): everything one workgroup leaves for another is stored
+// write-through (sc1) and read L1-bypassing; look-back words are self-validating 8-byte granules (epoch << 32 | value),
+// payloads are followed by `s_waitcnt vmcnt(0)` and a granule.  No agent-scope release fence (it writes back every dirty
+// line of the XCD's L2: one per chunk took the launch from 77 to 141 us at config #2; as a second LAUNCH the tail cost
+// its whole chain on top of the base waves': 78 -> 94 us at config #2, 272 -> 124 at config #3).  Every wait is
+// bounded: a protocol failure sets scratch.error instead of hanging the GPU.
+constexpr int kTailAreaBytes = 6144;    // per work item
+constexpr int kTailHeaderBytes = 256 + 8192 + 4096;  // counters of two consecutive frames, error word, shards
+constexpr int kTailMaxChunks = 1024;    // per quadrant (65 536 list entries); longer remainders are walked serially
+constexpr int kTailSpinLimit = 1 << 18;
+struct TailHeader {
+    int32_t counter[2];   // queue positions claimed (two consecutive launches alternate)
+    int32_t error, pad0;
+    int32_t pad[60];
+    // walking base waves that have left: 64 shards (blockIdx & 63), one 64-byte line each — one address saturates at ~88
+    // atomics/us, and a line that is polled while it takes atomics stalls both (measured: 2048 waiting tail waves reading
+    // these lines took the launch from 118 to 258 us).  Only the WATCHER (the last tail wave) reads them; it then sets
+    // all_left, 64 granules on lines of their own, which the other tail waves poll (position & 63).
+    int32_t done[2][64][16];
+    unsigned long long all_left[64][8];
+};
+static_assert(sizeof(TailHeader) == 256 + 8192 + 4096, "tail header");
+struct TailArea {
+    unsigned long long cntw, donew;     // tagged: live records of the chunk; 1 + "composited something"
+    unsigned long long readyw, pad1;    // tagged by the base wave: 1 = this queue position holds an item, 2 = voided
+    unsigned long long P[64];           // tagged: per pixel product of (1 - alpha) over the chunk
+    float base[10][64];                 // (first item of a quadrant only) pass A's state: T, 7 sums, last index, open
+    int32_t base_cnt, base_pad[3];      // ... and the records it streamed
+    float part[10][64];                 // chunk-local: 7 sums, last index, T after the chunk (frozen at a stop), open
+};
+static_assert(sizeof(TailArea) <= kTailAreaBytes, "work item area");
+struct TailQueue {
+    uint8_t *mem;   // [header][int4 items x qmax][areas x qmax], zeroed once by the caller; nullptr = no hand-off
+    int qmax;
+    uint32_t epoch; // unique per launch pair on this memory (the caller counts up from 1)
+    __device__ TailHeader *header() const { return reinterpret_cast<TailHeader *>(mem); }
+    __device__ int4 *items() const { return reinterpret_cast<int4 *>(mem + kTailHeaderBytes); }
+    __device__ TailArea *area(int i) const {
+        return reinterpret_cast<TailArea *>(mem + kTailHeaderBytes + 16ll * qmax + (int64_t)kTailAreaBytes * i);
+    }
+};
+__device__ __forceinline__ void store_tagged(unsigned long long *p, uint32_t epoch, uint32_t v) {
+    __hip_atomic_store(p, ((unsigned long long)epoch << 32) | v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ uint32_t wait_tagged(const unsigned long long *p, uint32_t epoch, int32_t *error) {
+    for (int spin = 0; spin < kTailSpinLimit; ++spin) {
+        const unsigned long long w = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((uint32_t)(w >> 32) == epoch) return (uint32_t)w;
+        __builtin_amdgcn_s_sleep(4);
+    }
+    *error = 1;  // (never seen; a dispatch order that breaks the look-back's assumption would end here, not in a hang)
+    return 0u;
+}
+// (sc1 = write-through / L1-bypassing accesses of 4-byte words: what one workgroup leaves for ANOTHER inside a launch
+// goes through these and a tagged word stored after `s_waitcnt vmcnt(0)` — no agent-scope release fence, which would
+// write back every dirty line of the XCD's L2 once per chunk: measured, 77 -> 141 us at config #2)
+__device__ __forceinline__ void st_sc1(float *p, float v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float ld_sc1(const float *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// The chunk arithmetic of the second pass.  ONE definition, compiled WITHOUT floating-point contraction, so that its
+// results are the same bits wherever it is inlined: in the second pass's two phases (the running product of phase 3 must
+// reproduce the factor phase 1 published), and in pass A's serial continuation when the queue is full — whether a list
+// went through the queue or not must not show in the image (the order of the queue's atomics is not reproducible).
+// alpha of one record at this lane's pixel = the reference's loop body
+__device__ __forceinline__ bool tail_alpha(float px, float py, const float4 &r0, const float2 &r1, float &alpha) {
+#pragma clang fp contract(off)
+    const float dx = r0.x - px, dy = r0.y - py;
+    const float sigma = 0.5f * (r0.w * dx * dx + r1.y * dy * dy) + r1.x * dx * dy;
+    alpha = fminf(kAlphaMax, r0.z * __expf(-sigma));
+    return !(sigma < 0.f) && !(alpha < kAlphaMin);
+}
+// phase 1: the product of (1 - alpha) over the chunk's n parked records (no stop rule)
+template <int E>
+__device__ __forceinline__ float tail_factor(const WaveLds<E> &S, int n, float px, float py) {
+#pragma clang fp contract(off)
+    float p = 1.f;
+    for (int r = 0; r < n; ++r) {
+        const float4 a0 = S.r0[r];
+        const float2 a1 = *reinterpret_cast<const float2 *>(&S.r1[r]);
+        float alpha;
+        const bool ok = tail_alpha(px, py, a0, a1, alpha);
+        p = ok ? p * (1.f - alpha) : p;
+    }
+    return p;
+}
+// phase 3: composite the chunk's n parked records from the transmittance T_in at its start with the reference's stop
+// rule; chunk-local sums; `boundary(T_cur, pixl)` is called after record r_b (the 64-record boundary of the stream)
+struct TailChunk {
+    float pixl[7];     // chunk-local sums: 4 colour channels, 3 normal-plane channels
+    int32_t cur_idx;   // last composited list index (0: none)
+    float T_cur;       // transmittance after the chunk (frozen where the pixel stopped)
+    float p_end;       // == tail_factor(...) of the same records
+};
+template <int E, class Boundary>
+__device__ __forceinline__ void tail_composite(const WaveLds<E> &S, int n, float px, float py, float T_in, bool &open,
+                                               int r_b, TailChunk &o, Boundary boundary) {
+#pragma clang fp contract(off)
+#pragma unroll
+    for (int k = 0; k < 7; ++k) o.pixl[k] = 0.f;
+    o.cur_idx = 0;
+    o.T_cur = T_in;
+    float p_run = 1.f;
+    for (int r = 0; r < n; ++r) {
+        const float4 a0 = S.r0[r];
+        const float2 a1 = *reinterpret_cast<const float2 *>(&S.r1[r]);
+        float alpha;
+        const bool ok = tail_alpha(px, py, a0, a1, alpha);
+        const float p_next = ok ? p_run * (1.f - alpha) : p_run;
+        const float T_next = T_in * p_next;
+        const bool low = ok && open && (T_next <= kTMin);
+        const bool commit = ok && open && !low;
+        const float vis = commit ? alpha * (T_in * p_run) : 0.f;
+        const float4 c4 = S.r2[r], e4 = S.r3[r];
+        o.pixl[0] += c4.x * vis; o.pixl[1] += c4.y * vis; o.pixl[2] += c4.z * vis; o.pixl[3] += c4.w * vis;
+        o.pixl[4] += e4.x * vis; o.pixl[5] += e4.y * vis; o.pixl[6] += e4.z * vis;
+        o.cur_idx = commit ? __float_as_int(e4.w) : o.cur_idx;
+        o.T_cur = commit ? T_next : o.T_cur;
+        open = open && !low;
+        p_run = p_next;
+        if (r == r_b) boundary(o.T_cur, o.pixl);
+    }
+    o.p_end = p_run;
+}
+
+template <int D, int E>
+__device__ __forceinline__ void
+raster_fwd_tail_wave(WaveLds<E> &S, const int item, const int n_base_blocks, int64_t cap,
+                     const float4 *__restrict__ packed, const int32_t *__restrict__ payload,
+                     const int32_t *__restrict__ tile_offsets, int64_t n_isects,
+                     const float *__restrict__ backgrounds, int W, int H, int tw, int th, int n_tiles_total,
+                     float *__restrict__ render, float *__restrict__ alphas, int32_t *__restrict__ last_ids,
+                     float4 *__restrict__ rec_out, int32_t *__restrict__ n_rec,
+                     float *__restrict__ seg_state, int64_t seg_cap, int normalize_last,
+                     float *__restrict__ render_extra, float *__restrict__ max_last, int ends_on_device,
+                     int32_t *__restrict__ tile_open, const TailQueue &tq);
+
 template <int D, int E>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FSGS_FWD_WAVE_OCC, FSGS_FWD_WAVE_OCC)))
 raster_fwd_wave_kernel(int64_t cap, const float4 *__restrict__ packed, const int32_t *__restrict__ payload,
@@ -345,14 +504,31 @@ raster_fwd_wave_kernel(int64_t cap, const float4 *__restrict__ packed, const int
                        float4 *__restrict__ rec_out, int32_t *__restrict__ n_rec,
                        float *__restrict__ seg_state, int64_t seg_cap, int normalize_last,
                        float *__restrict__ render_extra, float *__restrict__ max_last, int ends_on_device,
-                       int32_t *__restrict__ tile_open) {
+                       int32_t *__restrict__ tile_open, int handoff_records, TailQueue tq, int n_base_blocks,
+                       int handoff_rel_len) {
     __shared__ WaveLds<E> S;
     constexpr int RS = E ? 4 : 3;
 #ifdef FSGS_FWD_TRACE
     const long long t_start = wall_clock64();
 #endif
+    if ((int)blockIdx.x >= n_base_blocks) {
+        // the launch's last workgroups: the watcher (item -1), then one per queue position (TailQueue)
+        if constexpr (D == 4 && E == 3)
+            raster_fwd_tail_wave<D, E>(S, (int)blockIdx.x - n_base_blocks - 1, n_base_blocks, cap, packed, payload,
+                                       tile_offsets, n_isects, backgrounds, W, H, tw, th, n_tiles_total, render, alphas,
+                                       last_ids, rec_out, n_rec, seg_state, seg_cap, normalize_last, render_extra,
+                                       max_last, ends_on_device, tile_open, tq);
+        return;
+    }
+    // a WALKING base wave (one of a quadrant's two copies) counts itself out when it leaves: the tail waves stop waiting
+    // once all 4 x tiles have
+    auto leave = [&]() {
+        if (tq.mem && threadIdx.x == 0)
+            __hip_atomic_fetch_add(&tq.header()->done[tq.epoch & 1u][blockIdx.x & 63u][0], 1, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+    };
     // long lists first (see above)
-    const unsigned half_grid = gridDim.x >> 1;
+    const unsigned half_grid = (unsigned)n_base_blocks >> 1;
     const bool long_pass = blockIdx.x < half_grid;
     const unsigned bid = long_pass ? blockIdx.x : blockIdx.x - half_grid;
     const int tile_lin = (bid >> 5) * 8 + (bid & 7);
@@ -364,6 +540,10 @@ raster_fwd_wave_kernel(int64_t cap, const float4 *__restrict__ packed, const int
         const int a1 = (tile_lin == n_tiles_total - 1 && !ends_on_device) ? (int)n_isects : tile_offsets[tile_lin + 1];
         const bool is_long = (int64_t)(a1 - a0) * n_tiles_total > 2ll * total;
         if (is_long != long_pass) return;
+        // only lists far longer than the frame's mean are worth queueing: they are the ones that outlast the bulk of the
+        // launch (config #3's hull tiles: 2 800 entries against a mean of ~200; config #2's longest list is 5.7 x its mean
+        // and saturates early — queueing those cost 10 us per launch)
+        if ((int64_t)(a1 - a0) * n_tiles_total <= (int64_t)handoff_rel_len * total) handoff_records = 0;
     }
     const int cam = tile_lin / (tw * th);
     const int tile_in = tile_lin - cam * tw * th;
@@ -419,7 +599,9 @@ raster_fwd_wave_kernel(int64_t cap, const float4 *__restrict__ packed, const int
     auto composite_v = [&](float mx, float my, float op, float ca, float cb, float cc, auto colour, int idx) {
         const float dx = mx - px, dy = my - py;
         const float sigma = 0.5f * (ca * dx * dx + cc * dy * dy) + cb * dx * dy;
-        const float alpha = fminf(kAlphaMax, (op * gate) * __expf(-sigma));
+        // (the gate multiplies the CLAMPED value: fminf(0.999, NaN) = 0.999 must not let a record with NaN sigma commit on
+        // a finished or outside lane; same instruction count, same bits for open lanes)
+        const float alpha = fminf(kAlphaMax, op * __expf(-sigma)) * gate;
         // (wave masks taken from the compares themselves: a ballot of a combined flag costs two vector instructions)
         const bool ok_s = !(sigma < 0.f), ok_a = !(alpha < kAlphaMin);
         const uint64_t pm = __builtin_amdgcn_ballot_w64(ok_s) & __builtin_amdgcn_ballot_w64(ok_a);
@@ -528,6 +710,120 @@ raster_fwd_wave_kernel(int64_t cap, const float4 *__restrict__ packed, const int
                 }
             }
         }
+        // hand-off (see above): enough records walked, pixels still open, entries left
+        if (handoff_records > 0 && cnt >= handoff_records && n_open > 0 && c0 + 64 < l1) {
+            const int n_chunks = (l1 - (c0 + 64) + 63) >> 6;
+            int slot0 = 0;
+            if (n_chunks <= kTailMaxChunks) {
+                if (lane == 0) slot0 = atomicAdd(&tq.header()->counter[tq.epoch & 1u], n_chunks);
+                slot0 = __builtin_amdgcn_readfirstlane(slot0);
+            } else {
+                slot0 = tq.qmax;
+            }
+            if (slot0 + n_chunks <= tq.qmax) {
+                // items and state leave write-through, are drained, and only then are the positions marked filled
+                for (int i = lane; i < n_chunks; i += 64) {
+                    int32_t *ip = reinterpret_cast<int32_t *>(&tq.items()[slot0 + i]);
+                    __hip_atomic_store(ip + 0, tile_lin | (q << 28), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(ip + 1, c0 + 64 + 64 * i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(ip + 2, slot0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(ip + 3, n_chunks, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                TailArea *a = tq.area(slot0);
+                st_sc1(&a->base[0][lane], T);
+#pragma unroll
+                for (int kk = 0; kk < D; ++kk) st_sc1(&a->base[1 + kk][lane], pix[kk]);
+#pragma unroll
+                for (int kk = 0; kk < E; ++kk) st_sc1(&a->base[1 + D + kk][lane], pxe[kk]);
+                st_sc1(&a->base[8][lane], __int_as_float(cur_idx));
+                st_sc1(&a->base[9][lane], gate);
+                if (lane == 0) __hip_atomic_store(&a->base_cnt, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                for (int i = lane; i < n_chunks; i += 64) store_tagged(&tq.area(slot0 + i)->readyw, tq.epoch, 1u);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                leave();
+                return;  // the wave of this list's last chunk writes the pixels, n_rec and tile_open
+            }
+            // the queue is full (or the remainder too long): the claimed items that exist are voided and THIS wave walks
+            // the rest of the list chunk by chunk with the second pass's arithmetic (tail_composite: same bits as if
+            // the list had gone through the queue — which lists do is decided by the order of the atomics)
+            if (n_chunks <= kTailMaxChunks) {
+                for (int i = lane; i < n_chunks; i += 64)
+                    if (slot0 + i < tq.qmax) store_tagged(&tq.area(slot0 + i)->readyw, tq.epoch, 2u);
+            }
+            float sum[D + E];
+#pragma unroll
+            for (int kk = 0; kk < D; ++kk) sum[kk] = pix[kk];
+#pragma unroll
+            for (int kk = 0; kk < E; ++kk) sum[D + kk] = pxe[kk];
+            float T_in = T;
+            bool open = gate != 0.f;
+            // (the next chunk's entries and records are in flight while this chunk is composited)
+            float4 h0, h1, h2, h3;
+            h0 = h1 = h2 = h3 = make_float4(0.f, 0.f, 0.f, 0.f);
+            auto fetch = [&](int c) -> uint32_t {
+                const int idx = c + lane;
+                const uint32_t pc = (idx < l1) ? (uint32_t)payload[idx] : 0u;
+                if ((pc >> (28 + q)) & 1u) {
+                    const float4 *src = packed + (int64_t)(pc & 0x0FFFFFFFu) * 4;
+                    h0 = src[0]; h1 = src[1]; h2 = src[2]; h3 = src[3];
+                }
+                return pc;
+            };
+            uint32_t pc_next = fetch(c0 + 64);
+            for (int c = c0 + 64; c < l1; c += 64) {
+                const bool opn = open && (T_in > kTMin);
+                if (__builtin_amdgcn_ballot_w64(opn) == 0ull) break;  // (the active chunks are a prefix)
+                const int idx = c + lane;
+                const uint32_t pc = pc_next;
+                const bool lv = (pc >> (28 + q)) & 1u;
+                const uint64_t mc = __builtin_amdgcn_ballot_w64(lv);
+                const int n = __popcll(mc);
+                __builtin_amdgcn_s_barrier();
+                if (lv) {
+                    const int g = (int)(pc & 0x0FFFFFFFu);
+                    h1.z = __int_as_float(idx);
+                    h1.w = __int_as_float(g);
+                    const int pos = __popcll(mc & ((1ull << lane) - 1ull));
+                    S.r0[pos] = h0; S.r1[pos] = h1; S.r2[pos] = h2;
+                    S.r3[pos] = make_float4(h3.x, h3.y, h3.z, __int_as_float(idx));
+                    if (stream) {
+                        float4 *dst = stream + RS * (int64_t)(cnt + pos);
+                        dst[0] = h0; dst[1] = h1; dst[2] = h2; dst[3] = h3;
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                if (c + 64 < l1) pc_next = fetch(c + 64);
+                TailChunk o;
+                bool op2 = opn;
+                float *slot = seg_q ? seg_q + (((sbase + ((cnt >> 6) + 1) * 64) >> 6) + tile_lin) * SS : nullptr;
+                tail_composite<E>(S, n, px, py, T_in, op2, 63 - (cnt & 63), o, [&](float T_b, const float (&pl)[7]) {
+                    if (slot) {
+                        slot[lane] = open ? T_b : T;  // (a pixel that had stopped before this chunk keeps its T)
+#pragma unroll
+                        for (int kk = 0; kk < D + E; ++kk) slot[64 * (1 + kk) + lane] = pl[kk] + sum[kk];
+                    }
+                });
+#pragma unroll
+                for (int kk = 0; kk < D + E; ++kk) sum[kk] += o.pixl[kk];
+                cur_idx = max(cur_idx, o.cur_idx);
+                T = open ? o.T_cur : T;  // (as the finishing wave of the second pass has it)
+                open = open && op2;
+                {
+#pragma clang fp contract(off)
+                    T_in = T_in * o.p_end;
+                }
+                cnt += n;
+            }
+#pragma unroll
+            for (int kk = 0; kk < D; ++kk) pix[kk] = sum[kk];
+#pragma unroll
+            for (int kk = 0; kk < E; ++kk) pxe[kk] = sum[D + kk];
+            n_open = __popcll(__builtin_amdgcn_ballot_w64(open));
+            break;
+        }
     }
     if (n_rec && lane == 0) n_rec[(int64_t)q * n_tiles_total + tile_lin] = cnt;
     if (tile_open && n_open && lane == 0) tile_open[tile_lin] = 1;
@@ -567,6 +863,268 @@ raster_fwd_wave_kernel(int64_t cap, const float4 *__restrict__ packed, const int
         const int mm = __float_as_int(mx);
         if (lane == 0 && mm > 0) atomicMax(reinterpret_cast<int *>(max_last) + (bid & (kMaxCells - 1)), mm);
     }
+    leave();
+}
+
+
+// A tail wave (see TailQueue above): queue position `item` = one 64-entry chunk of a list whose walk a base wave handed
+// off.  D = 4, E = 3 (the training path's fused RGB+ED + normal-plane walk).
+template <int D, int E>
+__device__ __forceinline__ void
+raster_fwd_tail_wave(WaveLds<E> &S, const int item, const int n_base_blocks, int64_t cap,
+                     const float4 *__restrict__ packed, const int32_t *__restrict__ payload,
+                     const int32_t *__restrict__ tile_offsets, int64_t n_isects,
+                     const float *__restrict__ backgrounds, int W, int H, int tw, int th, int n_tiles_total,
+                     float *__restrict__ render, float *__restrict__ alphas, int32_t *__restrict__ last_ids,
+                     float4 *__restrict__ rec_out, int32_t *__restrict__ n_rec,
+                     float *__restrict__ seg_state, int64_t seg_cap, int normalize_last,
+                     float *__restrict__ render_extra, float *__restrict__ max_last, int ends_on_device,
+                     int32_t *__restrict__ tile_open, const TailQueue &tq) {
+    static_assert(D == 4 && E == 3, "the fused RGB+ED + normal-plane walk");
+    constexpr int RS = 4;
+    constexpr int SS = 64 * (1 + D + E);
+    const int lane = threadIdx.x;
+    TailHeader *hdr = tq.header();
+    const uint32_t epoch = tq.epoch, par = epoch & 1u;
+    int32_t *err = &hdr->error;
+    // (the NEXT launch on this memory counts from zero again; it starts after this one has ended)
+    if (item < 0) {
+        // the watcher: waits until every walking base wave has left, tells the tail waves (64 granules, one per line)
+        // and prepares the other parity's counters for the next launch on this memory
+        hdr->done[par ^ 1u][lane][0] = 0;
+        if (lane == 0) hdr->counter[par ^ 1u] = 0;
+        for (int spin = 0;; ++spin) {
+            int dn = __hip_atomic_load(&hdr->done[par][lane][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int dd = 32; dd >= 1; dd >>= 1) dn += __shfl_xor(dn, dd, 64);
+            if (__builtin_amdgcn_readfirstlane(dn) >= 4 * n_tiles_total) break;
+            if (spin >= kTailSpinLimit) { *err = 1; break; }
+            __builtin_amdgcn_s_sleep(32);
+        }
+        store_tagged(&hdr->all_left[lane][0], epoch, 1u);
+        return;
+    }
+    TailArea *mine = tq.area(item);
+    // wait until a base wave has filled this position — or until every base workgroup has left without doing so
+    {
+        uint32_t state = 0u;
+        for (int spin = 0;; ++spin) {
+            unsigned long long w = __hip_atomic_load(&mine->readyw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((uint32_t)(w >> 32) == epoch) { state = (uint32_t)w; break; }
+            bool left = false;
+            {   // (64 lines: a few dozen waiting waves per line, one read every ~2 us each)
+                const unsigned long long a = __hip_atomic_load(&hdr->all_left[item & 63][0], __ATOMIC_RELAXED,
+                                                               __HIP_MEMORY_SCOPE_AGENT);
+                left = (uint32_t)(a >> 32) == epoch;
+            }
+            {
+                if (left) {  // (a base wave fills its positions before it counts itself out: one last look)
+                    w = __hip_atomic_load(&mine->readyw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((uint32_t)(w >> 32) == epoch) state = (uint32_t)w;
+                    break;
+                }
+            }
+            if (spin >= kTailSpinLimit) { *err = 1; break; }
+            // (back-off: a position that is not filled soon is most likely never filled)
+            if (spin < 8) __builtin_amdgcn_s_sleep(24); else __builtin_amdgcn_s_sleep(64);
+        }
+        if (state != 1u) return;  // nothing queued here (0) or voided (2)
+    }
+    int4 it;
+    {
+        const int32_t *ip = reinterpret_cast<const int32_t *>(&tq.items()[item]);
+        it.x = __hip_atomic_load(ip + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        it.y = __hip_atomic_load(ip + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        it.z = __hip_atomic_load(ip + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        it.w = __hip_atomic_load(ip + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    const int tile_lin = it.x & 0x0FFFFFFF, q = (it.x >> 28) & 3;
+    const int c0 = it.y, slot0 = it.z, n_chunks = it.w, j = item - slot0;
+    const int cam = tile_lin / (tw * th);
+    const int tile_in = tile_lin - cam * tw * th;
+    const int tile_y = tile_in / tw, tile_x = tile_in - tile_y * tw;
+    const int qx = 2 * tile_x + (q & 1), qy = 2 * tile_y + (q >> 1);
+    const int pj = qx * 8 + (lane & 7), pi = qy * 8 + (lane >> 3);
+    const float px = (float)pj + 0.5f, py = (float)pi + 0.5f;
+    const bool inside = (pi < H) && (pj < W);
+    const int l0 = tile_offsets[tile_lin];
+    const int l1 = (tile_lin == n_tiles_total - 1 && !ends_on_device) ? (int)n_isects : tile_offsets[tile_lin + 1];
+    const int64_t sbase = (int64_t)l0 + 4ll * tile_lin;
+    float4 *stream = rec_out ? rec_out + RS * ((int64_t)q * cap + sbase) : nullptr;
+    float *seg_q = seg_state ? seg_state + (int64_t)q * seg_cap * SS : nullptr;
+    const TailArea *first = tq.area(slot0);
+
+    // (0) this chunk's entries, filtered by the quadrant bit; the count is published at once (stream positions)
+    const int idx = c0 + lane;
+    const uint32_t pay = (idx < l1) ? (uint32_t)payload[idx] : 0u;
+    const bool live = (pay >> (28 + q)) & 1u;
+    const uint64_t m = __builtin_amdgcn_ballot_w64(live);
+    const int n = __popcll(m);
+    if (lane == 0) store_tagged(&mine->cntw, epoch, (uint32_t)n);
+    float4 f0, f1, f2, f3;
+    f0 = f1 = f2 = f3 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int pos = __popcll(m & ((1ull << lane) - 1ull));
+    if (live) {
+        const int g = (int)(pay & 0x0FFFFFFFu);
+        const float4 *src = packed + (int64_t)g * 4;
+        f0 = src[0]; f1 = src[1]; f2 = src[2]; f3 = src[3];
+        f1.z = __int_as_float(idx);
+        f1.w = __int_as_float(g);
+        S.r0[pos] = f0; S.r1[pos] = f1; S.r2[pos] = f2;
+        S.r3[pos] = make_float4(f3.x, f3.y, f3.z, __int_as_float(idx));
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+
+    // (1) the chunk's transmittance factor per pixel: the product of (1 - alpha) over its records (no stop rule here)
+    const float p_all = tail_factor<E>(S, n, px, py);
+    store_tagged(&mine->P[lane], epoch, __float_as_uint(p_all));
+
+    // (2) look-back: the handed-off state times the predecessors' factors, in chunk order; stream position likewise
+    float T_in = ld_sc1(&first->base[0][lane]);
+    bool open = ld_sc1(&first->base[9][lane]) != 0.f;
+    int base = __hip_atomic_load(&first->base_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int i0 = 0; i0 < j; i0 += 64) {
+        const int i = i0 + lane;
+        int c = (i < j) ? (int)wait_tagged(&tq.area(slot0 + i)->cntw, epoch, err) : 0;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d, 64);
+        base += c;
+    }
+    for (int i0 = 0; i0 < j; i0 += 8) {
+        unsigned long long w[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            w[u] = (i0 + u < j) ? __hip_atomic_load(&tq.area(slot0 + i0 + u)->P[lane], __ATOMIC_RELAXED,
+                                                    __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (i0 + u < j) {
+                uint32_t v = (uint32_t)w[u];
+                if ((uint32_t)(w[u] >> 32) != epoch) v = wait_tagged(&tq.area(slot0 + i0 + u)->P[lane], epoch, err);
+                {
+#pragma clang fp contract(off)
+                    T_in = T_in * __uint_as_float(v);
+                }
+            }
+        }
+    }
+    // a pixel whose transmittance at the chunk's start is <= 1e-4 stopped inside an earlier chunk (the record that
+    // took it there was not composited: the reference's rule, applied below with the same products)
+    open = open && (T_in > kTMin);
+    const bool active = __builtin_amdgcn_ballot_w64(open) != 0ull;
+
+    // (3) composite the chunk from T_in; chunk-local sums; records streamed at stream position base + r
+    if (active) {
+        if (stream && live) {
+            float4 *dst = stream + RS * (int64_t)(base + pos);
+            dst[0] = f0; dst[1] = f1; dst[2] = f2; dst[3] = f3;
+        }
+        // the one 64-record boundary of the quadrant's stream this chunk can cross: after its record r_b; its slot gets
+        // the chunk-local sums (the finishing wave adds what lies in front of this chunk)
+        const int r_b = 63 - (base & 63);
+        float *sl = seg_q ? seg_q + (((sbase + base + r_b + 1) >> 6) + tile_lin) * SS : nullptr;
+        TailChunk o;
+        tail_composite<E>(S, n, px, py, T_in, open, r_b, o, [&](float T_b, const float (&pl)[7]) {
+            if (sl) {
+                st_sc1(sl + lane, T_b);
+#pragma unroll
+                for (int k = 0; k < D + E; ++k) st_sc1(sl + 64 * (1 + k) + lane, pl[k]);
+            }
+        });
+#pragma unroll
+        for (int k = 0; k < D + E; ++k) st_sc1(&mine->part[k][lane], o.pixl[k]);
+        st_sc1(&mine->part[7][lane], __int_as_float(o.cur_idx));
+        st_sc1(&mine->part[8][lane], o.T_cur);
+        st_sc1(&mine->part[9][lane], open ? 1.f : 0.f);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (write-through stores acknowledged before the tagged word)
+    }
+    if (lane == 0) store_tagged(&mine->donew, epoch, active ? 2u : 1u);
+    if (j != n_chunks - 1) return;
+
+    // (4) the list's last chunk finishes the quadrant: partial sums in chunk order, segment states completed, pixels out
+    int n_active = 0;  // the active chunks are a prefix (open pixels only ever close)
+    for (int i0 = 0; i0 < n_chunks; i0 += 64) {
+        const int i = i0 + lane;
+        const bool act = (i < n_chunks) && wait_tagged(&tq.area(slot0 + i)->donew, epoch, err) == 2u;
+        n_active += __popcll(__builtin_amdgcn_ballot_w64(act));
+    }
+    float sum[D + E];
+    float T = ld_sc1(&first->base[0][lane]);
+#pragma unroll
+    for (int k = 0; k < D + E; ++k) sum[k] = ld_sc1(&first->base[1 + k][lane]);
+    int32_t last = __float_as_int(ld_sc1(&first->base[8][lane]));
+    bool op = ld_sc1(&first->base[9][lane]) != 0.f;
+    int at = __hip_atomic_load(&first->base_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    constexpr int kFinB = 2;  // (chunks in flight: the tail waves live inside the base waves' register budget)
+    for (int i0 = 0; i0 < n_active; i0 += kFinB) {
+        // several chunks' partial sums (and the boundary slots they wrote) in flight at once, combined in chunk order
+        float part[kFinB][10], slot_v[kFinB][1 + D + E];
+        float *slot_p[kFinB];
+        int n_u[kFinB];
+        int at_u = at;
+#pragma unroll
+        for (int u = 0; u < kFinB; ++u) {
+            const bool have = i0 + u < n_active;
+            const TailArea *a = tq.area(slot0 + (have ? i0 + u : i0));
+            n_u[u] = have ? (int)(__hip_atomic_load(&a->cntw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0xFFFFFFFFull) : 0;
+#pragma unroll
+            for (int k = 0; k < 10; ++k) part[u][k] = have ? ld_sc1(&a->part[k][lane]) : 0.f;
+            // the boundary inside (at_u, at_u + n_u], if any: its slot holds chunk-local sums
+            const int g = ((at_u >> 6) + 1) << 6;
+            slot_p[u] = (have && seg_q && g <= at_u + n_u[u]) ? seg_q + (((sbase + g) >> 6) + tile_lin) * SS : nullptr;
+#pragma unroll
+            for (int k = 0; k < 1 + D + E; ++k) slot_v[u][k] = slot_p[u] ? ld_sc1(slot_p[u] + 64 * k + lane) : 0.f;
+            at_u += n_u[u];
+        }
+#pragma unroll
+        for (int u = 0; u < kFinB; ++u) {
+            if (i0 + u < n_active) {
+                if (slot_p[u]) {
+                    // (the chunk knew neither the sums in front of it nor the T of pixels that had stopped before it)
+                    slot_p[u][lane] = op ? slot_v[u][0] : T;
+#pragma unroll
+                    for (int k = 0; k < D + E; ++k) slot_p[u][64 * (1 + k) + lane] = slot_v[u][1 + k] + sum[k];
+                }
+#pragma unroll
+                for (int k = 0; k < D + E; ++k) sum[k] += part[u][k];
+                last = max(last, __float_as_int(part[u][7]));
+                T = op ? part[u][8] : T;
+                op = op && (part[u][9] != 0.f);
+                at += n_u[u];
+            }
+        }
+    }
+    if (n_rec && lane == 0) n_rec[(int64_t)q * n_tiles_total + tile_lin] = at;
+    const bool any_open = __builtin_amdgcn_ballot_w64(op) != 0ull;
+    if (tile_open && any_open && lane == 0) tile_open[tile_lin] = 1;
+    float pix[D], pxe[E];
+#pragma unroll
+    for (int k = 0; k < D; ++k) pix[k] = sum[k];
+#pragma unroll
+    for (int k = 0; k < E; ++k) pxe[k] = sum[D + k];
+    if (backgrounds) {
+#pragma unroll
+        for (int k = 0; k < D; ++k) pix[k] += T * backgrounds[cam * D + k];
+    }
+    if (normalize_last) pix[D - 1] = pix[D - 1] / fmaxf(1.f - T, 1e-10f);  // expected depth
+    if (inside) {
+        const int64_t pix_id = ((int64_t)cam * H + pi) * W + pj;
+        reinterpret_cast<float4 *>(render)[pix_id] = make_float4(pix[0], pix[1], pix[2], pix[3]);
+#pragma unroll
+        for (int k = 0; k < E; ++k) render_extra[pix_id * E + k] = pxe[k] + T;  // background = 1
+        alphas[pix_id] = 1.f - T;
+        last_ids[pix_id] = last;
+    }
+    if (max_last) {
+        float mx = inside ? pix[D - 1] : 0.f;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d, 64));
+        const int mm = __float_as_int(mx);
+        const unsigned bid = (unsigned)(tile_lin >> 3) * 32u + (unsigned)q * 8u + (unsigned)(tile_lin & 7);
+        if (lane == 0 && mm > 0) atomicMax(reinterpret_cast<int *>(max_last) + (bid & (kMaxCells - 1)), mm);
+    }
 }
 
 }  // namespace fsgs
@@ -593,17 +1151,39 @@ extern "C" int fsgs_debug_fwd_trace(long long *out, int n_blocks) {
 }
 #endif
 
+// bytes of tail scratch for a queue of `max_items` work items (fsgs_raster_fwd_quad: tail_scratch)
+extern "C" int64_t fsgs_raster_fwd_tail_scratch_bytes(int max_items) {
+    return max_items <= 0 ? 0 : (int64_t)kTailHeaderBytes + (16ll + kTailAreaBytes) * max_items;
+}
+
+// the error word of a tail scratch (0 = every look-back wait of every launch so far ended in time); synchronous copy
+extern "C" int fsgs_raster_fwd_tail_error(const void *tail_scratch, fsgs_stream_t stream) {
+    if (!tail_scratch) return FSGS_EINVAL;
+    TailHeader h;
+    hipError_t e = hipMemcpyAsync(&h, tail_scratch, sizeof(h), hipMemcpyDeviceToHost, as_stream(stream));
+    if (e == hipSuccess) e = hipStreamSynchronize(as_stream(stream));
+    if (e != hipSuccess) { g_last_hip_error = (int)e; return FSGS_ELAUNCH; }
+    return h.error != 0 ? 1 : 0;
+}
+
 extern "C" int fsgs_raster_fwd_quad(int C, int D, const float *packed, const int32_t *payload,
                                     const int32_t *isect_offsets, int64_t n_isects, const float *backgrounds,
                                     int width, int height, int tile_width, int tile_height, int normalize_last,
                                     float *render, float *alphas, int32_t *last_ids, float *records,
                                     int32_t *n_rec, float *seg_state, float *render_extra,
-                                    float *max_last, int32_t *tile_open, int walk, fsgs_stream_t stream) {
+                                    float *max_last, int32_t *tile_open, int walk, void *tail_scratch,
+                                    int64_t tail_scratch_bytes, int handoff_records, int handoff_rel_len,
+                                    int64_t tail_epoch, fsgs_stream_t stream) {
     // n_isects < 0: -n_isects is the CAPACITY the caller sized records / seg_state for, and the lists' true end is
     // isect_offsets[C * th * tw] on the device (fsgs_bin_live_count leaves it there): no host wait for the total
     const int ends_on_device = n_isects < 0 ? 1 : 0;
     if (ends_on_device) n_isects = -n_isects;
     if (C < 0 || width < 0 || height < 0 || walk < 0 || walk > 1) return FSGS_EINVAL;
+    // the one-wave walk exists for the fused RGB+ED + normal-plane launch only: asking for it elsewhere is an error, not
+    // a silent four-wave launch; a hand-off needs the one-wave walk, its scratch and a positive epoch
+    if (walk == FSGS_WALK_ONE_WAVE && !render_extra) return FSGS_EINVAL;
+    if (handoff_records < 0 || tail_scratch_bytes < 0) return FSGS_EINVAL;
+    if (handoff_records > 0 && (walk != FSGS_WALK_ONE_WAVE || !tail_scratch || tail_epoch <= 0)) return FSGS_EINVAL;
     if (C == 0 || width == 0 || height == 0) return FSGS_OK;
     if (n_isects > 0x7FFFFFF0ll) return FSGS_EINVAL;  // list indices are 32-bit (as in the reference)
     if (!isect_offsets || !render || !alphas || !last_ids || (n_isects > 0 && (!packed || !payload)))
@@ -626,11 +1206,26 @@ extern "C" int fsgs_raster_fwd_quad(int C, int D, const float *packed, const int
     if (render_extra) {
         if (D != 4) return FSGS_EINVAL;  // the fused RGB+depth + normal-plane walk
         if (walk == FSGS_WALK_ONE_WAVE) {
-            // third generation: one wave per quadrant; the grid holds every quadrant twice (long lists first)
-            hipLaunchKernelGGL((raster_fwd_wave_kernel<4, 3>), dim3(grid.x * 2), dim3(64), 0, s, cap, pk, payload,
-                               isect_offsets, n_isects, backgrounds, width, height, tile_width, tile_height,
+            // third generation: one wave per quadrant; the grid holds every quadrant twice (long lists first);
+            // fourth generation (handoff_records > 0): long walks are handed to a queue and finished chunk-parallel by
+            // the second launch, one wave per 64-entry chunk
+            TailQueue tq = {nullptr, 0, 0u};
+            if (handoff_records > 0) {
+                const int64_t room = (tail_scratch_bytes - kTailHeaderBytes) / (16 + kTailAreaBytes);
+                tq.mem = static_cast<uint8_t *>(tail_scratch);
+                // (positions are claimed in increasing order and their workgroups dispatched in increasing order: the tail
+                // waves need not all be resident at once)
+                tq.qmax = (int)(room < 0 ? 0 : (room > 65536 ? 65536 : room));
+                tq.epoch = (uint32_t)(tail_epoch & 0xFFFFFFFFll);
+                if (tq.qmax <= 0 || tq.epoch == 0u) return FSGS_ESCRATCH;
+            }
+            // (the tail waves = the last qmax workgroups of the launch, one per queue position)
+            const int n_base = (int)grid.x * 2;
+            hipLaunchKernelGGL((raster_fwd_wave_kernel<4, 3>), dim3(n_base + (tq.mem ? tq.qmax + 1 : 0)), dim3(64), 0, s, cap,
+                               pk, payload, isect_offsets, n_isects, backgrounds, width, height, tile_width, tile_height,
                                (int)n_tiles, render, alphas, last_ids, rec, n_rec, seg_state, seg_cap, normalize_last,
-                               render_extra, max_last, ends_on_device, tile_open);
+                               render_extra, max_last, ends_on_device, tile_open, tq.mem ? handoff_records : 0, tq, n_base,
+                               handoff_rel_len < 0 ? 0 : handoff_rel_len);
         } else {
             FSGS_FWD_QUAD(4, 3);
         }

@@ -70,9 +70,7 @@ class FrameInfo:
         self.live_capacity = 0
         self.pending_count = None
         self.n_live: Optional[int] = None
-        # the forward compositing's walk (fsgs_raster_fwd_quad's ``walk``): measured per frame shape when the caller
-        # asks for it (FWD_WALK), the default otherwise; ``fwd_walk`` tells which one this frame used
-        self.tune_forward = False
+        # the forward compositing's walk this frame used (fsgs_raster_fwd_quad's ``walk``; FWD_WALK)
         self.fwd_walk = 0
         # occlusion cuts (dense scenes): ``zcut_in`` [T] float32 = per-tile depth behind which pairs
         # are not binned (the previous frame of this view saturated in front of it; +inf = no cut), ``zcut_out`` [T]
@@ -227,96 +225,58 @@ class _BwdDispatchTuner:
 BWD_DISPATCH = _BwdDispatchTuner()
 
 
-class _FwdWalkTuner:
-    """Picks the forward compositing's walk per (device, frame shape) by measuring it (the ``walk`` argument of
-    fsgs_raster_fwd_quad): four waves per quadrant, or one wave per quadrant — half the vector instructions, but the
-    frame's longest list becomes one wave's dependent chain.  Config #2: 95 vs 79 us; config #4: 0.67 vs 0.52 ms; config
-    #3 once training has left lists of 2 800 entries: 153 vs 278 us.  Both walks give valid frames (same arithmetic
-    per record, transmittance products associated differently), so nothing is launched twice: early frames ALTERNATE
-    between the two, each timed with a pair of HIP events that is read when it has completed, and the faster mean is
-    kept.  The lists change as a scene trains (config #3's schedule turns the verdict round within a few hundred
-    steps, long before the model's size has moved), so the chosen walk stays under watch: every ``MONITOR``-th frame is
-    timed, and two samples in a row outside +-30 % of the mean it was chosen with start the measurement over (as does a
-    change of the model's size by a quarter, or ``RETUNE_EVERY`` frames).  Only callers that ask for it are tuned (the
-    trainer's steps); everything else uses ``DEFAULT``.  FSGS_FWD_WALK=<0|1> fixes the walk."""
-    CANDIDATES = (0, 1)
-    WARM, SAMPLES, RETUNE_EVERY, MONITOR, BAND = 1, 6, 4000, 16, 0.30
-    DEFAULT = 0
+class _FwdWalk:
+    """How the fused node's forward compositing walks the lists (the ``walk`` / ``handoff_records`` arguments of
+    fsgs_raster_fwd_quad).  ONE walk for every frame since round 5, so two runs of a seed give the same frames bit for
+    bit: one wave per 8x8 quadrant (27 vector instructions per record), and a wave that has streamed ``handoff_records``
+    records with pixels still open queues the rest of its list for the launch's second pass, which finishes it
+    chunk-parallel (raster_quad.hip: TailQueue) — so the frame's longest list no longer bounds the launch.  Rounds 3-4
+    chose between this walk WITHOUT the hand-off and the four-waves-per-quadrant walk by timing them per frame shape
+    (config #2: 79 vs 95 us; config #3's trained scene with lists of 2 800 entries: 278 vs 153 us); that tuner is gone.
+    ``forced`` / ``forced_walk`` / ``handoff_records`` are attributes so that tests and bench.py can run the other walks
+    (0 = four waves per quadrant; 1 = one wave; handoff_records = 0: never hand off)."""
+    ONE_WAVE, FOUR_WAVES = 1, 0
 
     def __init__(self):
-        self.state: Dict = {}
-        self.forced = os.environ.get("FSGS_FWD_WALK", "auto") != "auto"
-        self.forced_walk = int(os.environ.get("FSGS_FWD_WALK", "0")) if self.forced else 0
+        self.walk = self.ONE_WAVE
+        # records a wave streams before it hands the rest of its list off (0 = never), if the list is more than
+        # ``handoff_rel_len`` times the frame's mean list length.  Measured (MI355X, us per launch, config #2 / #3's
+        # schedule window): no hand-off 78 / 255-274; 64 / 128 / 192 records at 4 x the mean: 81 / 82 / 82 and
+        # 104 / 102 / 101 (at 8 x: 126 at config #3); every list whatever its length: 101-122 / 99-104; the four-wave
+        # walk: 96 / 152.  The ~4 us at config #2 are the tail workgroups waiting for the base waves to leave.
+        self.handoff_records = 192
+        self.handoff_rel_len = 4
+        # dense scenes (the depth-slab binning route, configs #4 / #5): tens of thousands of quadrants keep every SIMD busy
+        # and every list is long — nothing to gain, a queue to overflow: no hand-off from this many Gaussians on
+        self.handoff_max_n = 1 << 20
+        self.max_items = 16384       # queue positions = tail workgroups of the launch (64-entry chunks per frame)
+        self.forced = False          # tests: use ``forced_walk`` (and ``handoff_records`` as set)
+        self.forced_walk = 0
+        self.state: Dict = {}        # (device) -> [scratch tensor, epoch]
+        self.frames_with_handoff = 0
 
-    def _fresh(self, n, prev, retunes=0, tuning_frames=0):
-        return dict(n_ref=n, frames=0, pending=[], total={c: 0.0 for c in self.CANDIDATES},
-                    count={c: 0 for c in self.CANDIDATES}, decided=None, since=0, previous=prev,
-                    tuning_frames=tuning_frames, watch=[], off=0, retunes=retunes)
+    def choice(self, n_gaussians: int = 0):
+        walk = self.forced_walk if self.forced else self.walk
+        on = walk == self.ONE_WAVE and (self.forced or n_gaussians < self.handoff_max_n)
+        return walk, (self.handoff_records if on else 0)
 
-    def pick(self, key, n: int):
-        """-> (walk for this frame, callable to wrap around the launch or None)."""
-        if self.forced:
-            return self.forced_walk, None
+    def scratch(self, dev):
+        """(tail scratch of this device — zeroed once —, the epoch of this launch)."""
+        key = str(dev)
         st = self.state.get(key)
-        if st is not None and st["decided"] is not None:
-            for item in list(st["watch"]):  # the chosen walk under watch
-                e0, e1 = item
-                if e1.query():
-                    ms = e0.elapsed_time(e1)
-                    ref = st["means_ms"][st["decided"]]
-                    st["off"] = st["off"] + 1 if abs(ms - ref) > self.BAND * ref else 0
-                    st["watch"].remove(item)
-            if (st["off"] >= 2 or abs(n - st["n_ref"]) > 0.25 * st["n_ref"] or st["since"] >= self.RETUNE_EVERY):
-                st = self.state[key] = self._fresh(n, st["decided"], st["retunes"] + 1, st["tuning_frames"])
-        if st is None:
-            st = self.state[key] = self._fresh(n, None)
-        if st["decided"] is not None:
-            st["since"] += 1
-            if st["since"] % self.MONITOR == 0 and len(st["watch"]) < 4:
-                def watched(launch):
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record()
-                    launch()
-                    e1.record()
-                    st["watch"].append((e0, e1))
-                return st["decided"], watched
-            return st["decided"], None
-        st["frames"] += 1
-        for item in list(st["pending"]):  # harvest finished samples
-            c, e0, e1 = item
-            if e1.query():
-                st["total"][c] += e0.elapsed_time(e1)
-                st["count"][c] += 1
-                st["pending"].remove(item)
-        fallback = st["previous"] if st["previous"] is not None else self.DEFAULT
-        if all(st["count"][c] >= self.SAMPLES for c in self.CANDIDATES):
-            mean = {c: st["total"][c] / st["count"][c] for c in self.CANDIDATES}
-            st["decided"] = min(self.CANDIDATES, key=lambda c: mean[c])
-            st["means_ms"] = mean
-            return st["decided"], None
-        if st["frames"] <= self.WARM:
-            return fallback, None
-        # the candidate with fewer samples taken or in flight (ties: alternate)
-        inflight = {c: st["count"][c] + sum(1 for it in st["pending"] if it[0] == c) for c in self.CANDIDATES}
-        if all(inflight[c] >= self.SAMPLES for c in self.CANDIDATES):
-            return fallback, None  # (waiting for the events)
-        c = min(self.CANDIDATES, key=lambda k: (inflight[k], (k + st["frames"]) % 2))
-        st["tuning_frames"] += 1
+        need = int(load().fsgs_raster_fwd_tail_scratch_bytes(int(self.max_items)))
+        if st is None or st[0].numel() != need:
+            st = self.state[key] = [torch.zeros(need, dtype=torch.uint8, device=dev), 0]
+        st[1] += 1
+        return st[0], st[1]
 
-        def timed(launch):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            launch()
-            e1.record()
-            st["pending"].append((c, e0, e1))
-        return c, timed
-
-    def decided(self, key):
-        st = self.state.get(key)
-        return None if st is None else st["decided"]
+    def error(self, dev) -> int:
+        """1 if a look-back wait of any frame on this device ever ran into its bound (tests), else 0."""
+        st = self.state.get(str(dev))
+        return 0 if st is None else int(load().fsgs_raster_fwd_tail_error(st[0].data_ptr(), stream_ptr(dev)))
 
 
-FWD_WALK = _FwdWalkTuner()
+FWD_WALK = _FwdWalk()
 
 
 class _FusedGetOutputs(torch.autograd.Function):
@@ -457,23 +417,16 @@ class _FusedGetOutputs(torch.autograd.Function):
         track_cuts = info.zcut_out is not None
         tile_open, bad, hit = (ops.zcut_scratch(dev, n_tiles) if (track_cuts or info.zcut_in is not None)
                                else (None, None, None))
-        if info.tune_forward:
-            walk, timed = FWD_WALK.pick((str(dev), W, H), N)
-        else:
-            walk, timed = (FWD_WALK.forced_walk if FWD_WALK.forced else FWD_WALK.DEFAULT), None
+        walk, handoff = FWD_WALK.choice(N)
         info.fwd_walk = walk
-
-        def composite():
-            _run(lib.fsgs_raster_fwd_quad, (1, 4, ptr(packed), ptr(flatten_ids), ptr(offsets), -M if no_wait else M,
-                                           None, W, H, tw, th, 1,
-                                           ptr(render), ptr(alphas), ptr(last_ids), ptr(records), ptr(n_rec),
-                                           ptr(seg_state), ptr(render_extra), ptr(max_last), ptr(tile_open), walk,
-                                           sp),
-                 "fsgs_raster_fwd_quad", "_d4e3")
-        if timed is not None:
-            timed(composite)
-        else:
-            composite()
+        tail, epoch = FWD_WALK.scratch(dev) if handoff > 0 else (None, 0)
+        _run(lib.fsgs_raster_fwd_quad, (1, 4, ptr(packed), ptr(flatten_ids), ptr(offsets), -M if no_wait else M,
+                                       None, W, H, tw, th, 1,
+                                       ptr(render), ptr(alphas), ptr(last_ids), ptr(records), ptr(n_rec),
+                                       ptr(seg_state), ptr(render_extra), ptr(max_last), ptr(tile_open), walk,
+                                       ptr(tail), 0 if tail is None else tail.numel(), int(handoff),
+                                       int(FWD_WALK.handoff_rel_len), int(epoch), sp),
+             "fsgs_raster_fwd_quad", "_d4e3")
         if tile_open is not None:
             # this frame's saturation depths become the next frame's cuts; a cut tile left open spoils the frame
             verdict = ops.zcut_verdict_buffer(dev)
@@ -513,6 +466,7 @@ class _FusedGetOutputs(torch.autograd.Function):
         info.isect_offsets = offsets[:tw * th].view(1, th, tw) if no_wait else offsets
         info.last_ids, info.normals_world = last_ids, normals_world
         info.legacy_rule_diff = rule_diff
+        info.streams = (records, n_rec, seg_state)  # (what the backward reads; valid until it has run: tools / tests)
 
         if needs_bwd:
             ctx.save_for_backward(means, scales, quats, features_dc, features_rest, scales_exp, opac_sig, radii,
@@ -745,7 +699,6 @@ def fused_step_forward_backward(gauss_params: Dict[str, Tensor], camera: Camera,
     info.live_capacity = int(live_capacity)
     info.zcut_in, info.zcut_out = zcut_in, zcut_out
     info.adam_in_backward = adam_in_backward
-    info.tune_forward = True  # (the trainer's steps: the forward's walk is measured per frame shape, FWD_WALK)
     if zcut_margins is not None:
         info.zcut_margins = zcut_margins
 

@@ -42,7 +42,7 @@ typedef void *fsgs_stream_t; /* hipStream_t */
 #define FSGS_ELAUNCH -2  /* hipLaunch / runtime error; see fsgs_last_hip_error() */
 #define FSGS_ESCRATCH -3 /* scratch arena too small */
 
-#define FSGS_ABI_VERSION 5
+#define FSGS_ABI_VERSION 6
 int fsgs_version(void);
 int fsgs_abi_version(void); /* == FSGS_ABI_VERSION of the header the library was built from */
 /* Lines of the packed gradient accumulator a caller that passes `replica_rows` > 0 must provide per Gaussian row:
@@ -260,11 +260,29 @@ int fsgs_raster_fwd_quad(int C, int D, const float *packed, const int32_t *paylo
                          float *render, float *alphas, int32_t *last_ids, float *records, int32_t *n_rec,
                          float *seg_state, float *render_extra, float *max_last,
                          int32_t *tile_open /* nullable [C*th*tw]: see fsgs_tile_zcut_update */,
-                         int walk /* FSGS_WALK_*: how THIS launch walks the lists */, fsgs_stream_t stream);
+                         int walk /* FSGS_WALK_*: how THIS launch walks the lists */,
+                         void *tail_scratch /* nullable */, int64_t tail_scratch_bytes, int handoff_records,
+                         int handoff_rel_len, int64_t tail_epoch, fsgs_stream_t stream);
+/* Hand-off of long walks (round 5; FSGS_WALK_ONE_WAVE, handoff_records > 0): a wave that has streamed `handoff_records`
+ * records and still has open pixels and list entries left stops at the end of its 64-entry chunk and queues the rest of
+ * its list; a SECOND launch of the same call (one wave per queued 64-entry chunk) forms every chunk's transmittance
+ * factor independently, takes the transmittance at its start from its predecessors' factors, composites the chunk with
+ * the reference's stop rule and adds the chunks' partial sums in list order — a list of n entries costs two chunk walks
+ * of latency instead of n dependent steps (config #3 after densification: lists of 2 800 entries).  Same outputs up to
+ * the association of products and sums per chunk (image tolerance), bit-reproducible, same streams / segment states /
+ * n_rec for the backward.  `tail_scratch`: fsgs_raster_fwd_tail_scratch_bytes(max_items) bytes, ZEROED ONCE by the
+ * caller and then only ever passed to this function; `tail_epoch` >= 1 must increase by one with every call that passes
+ * the scratch (two frames' counters alternate inside it).  A queue that runs full makes the remaining walks finish
+ * serially (exact, only slower).  handoff_records = 0: the plain one-wave walk (tail_scratch may be NULL).
+ * fsgs_raster_fwd_tail_error: 1 if any look-back wait ever ran into its bound (never observed; results of that frame
+ * are then invalid), 0 otherwise — a synchronous read for tests. */
+int64_t fsgs_raster_fwd_tail_scratch_bytes(int max_items);
+int fsgs_raster_fwd_tail_error(const void *tail_scratch, fsgs_stream_t stream);
 /* walk (fsgs_raster_fwd_quad): FSGS_WALK_FOUR_WAVES — a workgroup of four waves per 8x8 quadrant, lane = (pixel, one of
- * four consecutive records); FSGS_WALK_ONE_WAVE (render_extra != NULL only; else ignored) — one wave per quadrant,
+ * four consecutive records); FSGS_WALK_ONE_WAVE (render_extra != NULL only; FSGS_EINVAL otherwise) — one wave per quadrant,
  * lane = pixel, one record per step: half the vector instructions per (quadrant, record), but a quadrant's walk is one
- * wave's dependent chain (~0.17 us per record on MI355X), so the frame's longest list bounds the launch.  Same images up
+ * wave's dependent chain (~0.17 us per record on MI355X), so the frame's longest list bounds the launch unless long
+ * walks are handed off (handoff_records, below).  Same images up
  * to the association of the transmittance products (<= 1 ulp per step), same streams for the backward (the one-wave
  * walk writes no padding records).  Which is faster depends on the frame (config #2: 95 vs 79 us; config #3 after
  * densification, lists of 2 800 entries: 153 vs 278 us): callers measure (fusionsense_amd/fused.py does). */

@@ -22,33 +22,31 @@ def dev():
 
 
 @pytest.fixture(autouse=True)
-def _fixed_forward_walk():
-    """Tests run with a FIXED walk of the forward compositing (four waves per quadrant) so that two runs of a frame are
-    comparable bit for bit; the trainer's own choice (fused._FwdWalkTuner alternates the two walks on early frames and
-    keeps the faster) is exercised by the tests that ask for ``free_forward_walk``, the one-wave walk by ``fwd_walk``."""
+def _default_forward_walk():
+    """Every test starts from (and leaves behind) the product's forward walk: one wave per quadrant with long walks
+    handed off to the second pass (fused.FWD_WALK).  The walk is fixed — no measurement decides it any more — so two runs
+    of a frame are comparable bit for bit; ``fwd_walk`` runs a test once per walk."""
     try:
         from fusionsense_amd import fused
     except Exception:  # (the package needs torch; CPU-only helpers do not)
         yield
         return
     t = fused.FWD_WALK
-    saved = (t.forced, t.forced_walk)
-    t.forced, t.forced_walk = True, 0
+    saved = (t.forced, t.forced_walk, t.handoff_records, t.max_items, t.handoff_rel_len)
     yield
-    t.forced, t.forced_walk = saved
-    t.state.clear()
+    t.forced, t.forced_walk, t.handoff_records, t.max_items, t.handoff_rel_len = saved
 
 
-@pytest.fixture(params=[0, 1], ids=["four_waves", "one_wave"])
-def fwd_walk(request, _fixed_forward_walk):
+# (id, walk, handoff_records): the four-wave walk of rounds 2-3, the one-wave walk without a hand-off (round 4), and the
+# product's walk with the hand-off forced EARLY (after 64 records: at test sizes most quadrants with more than one chunk
+# of entries then go through the second pass) — the default (128) is what every test without this fixture runs
+_WALKS = [("four_waves", 0, 0), ("one_wave", 1, 0), ("handoff", 1, 64)]
+
+
+@pytest.fixture(params=_WALKS, ids=[w[0] for w in _WALKS])
+def fwd_walk(request, _default_forward_walk):
     from fusionsense_amd import fused
-    fused.FWD_WALK.forced, fused.FWD_WALK.forced_walk = True, int(request.param)
-    return int(request.param)
-
-
-@pytest.fixture
-def free_forward_walk(_fixed_forward_walk):
-    from fusionsense_amd import fused
-    fused.FWD_WALK.forced = False
-    fused.FWD_WALK.state.clear()
-    return fused.FWD_WALK
+    _, walk, handoff = request.param
+    fused.FWD_WALK.forced, fused.FWD_WALK.forced_walk, fused.FWD_WALK.handoff_records = True, walk, handoff
+    fused.FWD_WALK.handoff_rel_len = 0  # (every quadrant that reaches the threshold hands off, whatever its list's length)
+    return request.param[0]

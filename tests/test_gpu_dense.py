@@ -140,8 +140,9 @@ def test_config4_surface_scene_bench_route(dev, surface4, fwd_walk):
     g0 = {k: v.clone() for k, v in tr.slab.views.items()}
     img0 = {k: o0[k].clone() for k in ("rgb", "depth", "normal", "accumulation")}
     pay0, offs0 = o0["info"].payload.clone(), o0["info"].isect_offsets.flatten().long().clone()
-    for k in img0:
-        assert torch.equal(img0[k], ref[k]), k  # the trainer's frame IS the fused node's frame
+    for k in img0:  # the trainer's frame IS the fused node's frame (its epilogue is the loss-fused instantiation: the
+        # normalisation of the normal image may round differently by an ulp)
+        assert torch.equal(img0[k], ref[k]) if k != "normal" else float((img0[k] - ref[k]).abs().max()) <= 2e-7, k
     l1, o1 = tr.train_step(views[0], tgt[0], optimizer_step=False)  # second visit: binned with the view's cuts
     assert tr.cut_frames >= 1, "a 6 M-Gaussian trainer bins a revisited view with occlusion cuts"
     for k in img0:
@@ -224,13 +225,17 @@ def _bench_route(dev, params, tgt, seen, **kw):
     return route
 
 
-def test_config4_surface_scene_against_oracle_on_a_window(dev, surface4, fwd_walk):
+@pytest.mark.parametrize("walk", ["product", "one_wave_no_handoff"])
+def test_config4_surface_scene_against_oracle_on_a_window(dev, surface4, walk):
     """All 6 M Gaussians of the surface scene against the CPU oracle on a 128x128 window of ring view 0 (the oracle needs
     ~40 s for it), two routes against one oracle frame: (a) the fused autograd node with a seeded weighted loss, (b) the
     route bench.py takes — SplatTrainer.train_step with the benchmark loss, second visit of the view (occlusion cuts on) —
     against the oracle's render + the oracle's SSIM / L1 loss.  Integer outputs, images, every parameter gradient; every
     mismatch must be an fp32 threshold case."""
+    from fusionsense_amd import fused
     from helpers import OracleWindow, fused_node_route
+    if walk != "product":  # (the product's walk = fused.FWD_WALK's defaults: one wave per quadrant, hand-off after 128)
+        fused.FWD_WALK.forced, fused.FWD_WALK.forced_walk, fused.FWD_WALK.handoff_records = True, 1, 0
     params, cams = surface4
     cam = crop_camera(cams[0], CROP, shift=CROP_SHIFT)
     win = OracleWindow({k: v.cpu() for k, v in params.items()}, cam)
@@ -244,6 +249,7 @@ def test_config4_surface_scene_against_oracle_on_a_window(dev, surface4, fwd_wal
     rep = win.check(og, grads, max_bad_radii=int(1e-4 * N4), oracle_loss=_bench_loss_oracle({k: v.cpu() for k, v in tgt.items()}))
     assert seen["cut_frames"] >= 1
     assert abs(seen["loss"] - rep["oracle_loss"]) <= 2e-5 * abs(rep["oracle_loss"]), (seen["loss"], rep["oracle_loss"])
+    assert fused.FWD_WALK.error(dev) == 0
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -305,13 +311,13 @@ def test_config5_surface_scene_half_storage_bench_route(dev, surface5, fwd_walk)
 
 def test_config5_bench_step_against_oracle_on_a_window(dev, surface5):
     """All 10 M Gaussians, half storage, through SplatTrainer.train_step with the benchmark loss on a 128x128 window of a
-    ring view, second visit (cuts on), the walk bench.py quotes config #5 on (one wave per quadrant): against the CPU
+    ring view, second visit (cuts on), the product's forward walk: against the CPU
     oracle fed the fp16-ROUNDED attributes (means stay fp32) — integer outputs, images, the gradient slab; every mismatch
     an fp32 threshold case."""
     from fusionsense_amd import fused
     from helpers import OracleWindow
     params, rounded, cams = surface5
-    fused.FWD_WALK.forced, fused.FWD_WALK.forced_walk = True, 1
+    assert fused.FWD_WALK.choice() == (1, 128)  # the product's walk
     cam = crop_camera(cams[0], CROP, shift=CROP_SHIFT)
     tgt = _targets(dev, CROP, CROP, 33)
     seen = {}
