@@ -758,17 +758,11 @@ raster_fwd_wave_kernel(int64_t cap, const float4 *__restrict__ packed, const int
             for (int kk = 0; kk < E; ++kk) sum[D + kk] = pxe[kk];
             float T_in = T;
             bool open = gate != 0.f;
-            // (the next chunk's entries and records are in flight while this chunk is composited)
-            float4 h0, h1, h2, h3;
-            h0 = h1 = h2 = h3 = make_float4(0.f, 0.f, 0.f, 0.f);
+            // (the next chunk's entries are in flight while this chunk is composited; its records are not — their 16
+            // registers across tail_composite would push the kernel past the 6-waves-per-SIMD budget into scratch)
             auto fetch = [&](int c) -> uint32_t {
                 const int idx = c + lane;
-                const uint32_t pc = (idx < l1) ? (uint32_t)payload[idx] : 0u;
-                if ((pc >> (28 + q)) & 1u) {
-                    const float4 *src = packed + (int64_t)(pc & 0x0FFFFFFFu) * 4;
-                    h0 = src[0]; h1 = src[1]; h2 = src[2]; h3 = src[3];
-                }
-                return pc;
+                return (idx < l1) ? (uint32_t)payload[idx] : 0u;
             };
             uint32_t pc_next = fetch(c0 + 64);
             for (int c = c0 + 64; c < l1; c += 64) {
@@ -782,6 +776,8 @@ raster_fwd_wave_kernel(int64_t cap, const float4 *__restrict__ packed, const int
                 __builtin_amdgcn_s_barrier();
                 if (lv) {
                     const int g = (int)(pc & 0x0FFFFFFFu);
+                    const float4 *src = packed + (int64_t)g * 4;
+                    float4 h0 = src[0], h1 = src[1], h2 = src[2], h3 = src[3];
                     h1.z = __int_as_float(idx);
                     h1.w = __int_as_float(g);
                     const int pos = __popcll(mc & ((1ull << lane) - 1ull));

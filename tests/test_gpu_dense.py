@@ -225,7 +225,7 @@ def _bench_route(dev, params, tgt, seen, **kw):
     return route
 
 
-@pytest.mark.parametrize("walk", ["product", "one_wave_no_handoff"])
+@pytest.mark.parametrize("walk", ["product", "one_wave_with_handoff"])
 def test_config4_surface_scene_against_oracle_on_a_window(dev, surface4, walk):
     """All 6 M Gaussians of the surface scene against the CPU oracle on a 128x128 window of ring view 0 (the oracle needs
     ~40 s for it), two routes against one oracle frame: (a) the fused autograd node with a seeded weighted loss, (b) the
@@ -234,8 +234,9 @@ def test_config4_surface_scene_against_oracle_on_a_window(dev, surface4, walk):
     mismatch must be an fp32 threshold case."""
     from fusionsense_amd import fused
     from helpers import OracleWindow, fused_node_route
-    if walk != "product":  # (the product's walk = fused.FWD_WALK's defaults: one wave per quadrant, hand-off after 128)
-        fused.FWD_WALK.forced, fused.FWD_WALK.forced_walk, fused.FWD_WALK.handoff_records = True, 1, 0
+    if walk != "product":  # (the product's walk for a scene this dense IS the plain one-wave walk: force the hand-off on)
+        fused.FWD_WALK.forced, fused.FWD_WALK.forced_walk = True, 1
+        fused.FWD_WALK.handoff_records, fused.FWD_WALK.handoff_rel_len = 128, 0
     params, cams = surface4
     cam = crop_camera(cams[0], CROP, shift=CROP_SHIFT)
     win = OracleWindow({k: v.cpu() for k, v in params.items()}, cam)
@@ -317,7 +318,7 @@ def test_config5_bench_step_against_oracle_on_a_window(dev, surface5):
     from fusionsense_amd import fused
     from helpers import OracleWindow
     params, rounded, cams = surface5
-    assert fused.FWD_WALK.choice() == (1, 128)  # the product's walk
+    assert fused.FWD_WALK.choice(N5)[0] == 1  # the product's walk (dense scenes: one wave per quadrant, no hand-off)
     cam = crop_camera(cams[0], CROP, shift=CROP_SHIFT)
     tgt = _targets(dev, CROP, CROP, 33)
     seen = {}
