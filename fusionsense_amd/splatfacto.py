@@ -21,7 +21,6 @@ from dataclasses import dataclass
 from typing import Dict, Optional
 
 import torch
-import torch.distributed as dist
 from torch import Tensor
 
 from . import ops
@@ -196,15 +195,14 @@ class DensifyStrategy:
 
     def _all_reduce_stats(self) -> None:
         """DP: every rank must take identical split/cull decisions."""
-        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        from . import comm
+        if comm.world() <= 1 or self.xys_grad_norm is None:
             return
-        if self.xys_grad_norm is None:
-            return
-        dist.all_reduce(self.xys_grad_norm, op=dist.ReduceOp.SUM)
+        comm.all_reduce_(self.xys_grad_norm, "sum")
         extra = self.vis_counts - 1.0
-        dist.all_reduce(extra, op=dist.ReduceOp.SUM)
+        comm.all_reduce_(extra, "sum")
         self.vis_counts = extra + 1.0
-        dist.all_reduce(self.max_2Dsize, op=dist.ReduceOp.MAX)
+        comm.all_reduce_(self.max_2Dsize, "max")
 
     def set_metadata(self, touch_patches=None, gel_scale_factor: float = 6.34e-5, add_touch_at: int = 1000,
                      visual_hull: Optional[Tensor] = None, scale_factor: float = 1.0) -> None:

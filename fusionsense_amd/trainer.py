@@ -18,9 +18,9 @@ from dataclasses import dataclass, field
 from typing import Dict, List, Optional
 
 import torch
-import torch.distributed as dist
 from torch import Tensor
 
+from . import comm
 from .scenes import Camera
 
 PARAM_ORDER = ["means", "scales", "quats", "features_dc", "features_rest", "opacities"]
@@ -98,39 +98,19 @@ class GradSlab:
     def zero_(self) -> None:
         self.flat.zero_()
 
-    # FSGS_FORCE_COLLECTIVES=1: issue the collectives in a one-rank group too (they are identities there) — lets a
-    # one-GPU box run the very RCCL calls of the multi-GPU step (tests/test_gpu_configs.py)
-    force_collectives = os.environ.get("FSGS_FORCE_COLLECTIVES", "0") == "1"
-
+    # (every collective of the step goes through fusionsense_amd/comm.py: one code path for RCCL and gloo)
     @staticmethod
     def _world(group=None) -> int:
-        return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        return comm.world(group)
 
-    @classmethod
-    def _exchange(cls, group=None) -> bool:
+    @staticmethod
+    def _exchange(group=None) -> bool:
         """Whether a collective has to be issued at all."""
-        if not (dist.is_available() and dist.is_initialized()):
-            return False
-        return cls._world(group) > 1 or cls.force_collectives
+        return comm.exchange(group)
 
     def _reduce_mean(self, t: Tensor, group, async_op: bool):
         """Mean over the ranks, in place.  Returns None (done, in stream order) or a callable that completes it."""
-        if not self._exchange(group) or t.numel() == 0:
-            return None
-        if dist.get_backend(group) == "nccl":
-            # RCCL averages inside the collective: no extra 2 x 236 B/Gaussian scaling pass
-            work = dist.all_reduce(t, op=dist.ReduceOp.AVG, group=group, async_op=async_op)
-            return work.wait if async_op else None
-        work = dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
-        scale = 1.0 / self._world(group)
-        if not async_op:
-            t.mul_(scale)
-            return None
-
-        def finish():
-            work.wait()
-            t.mul_(scale)
-        return finish
+        return comm.all_reduce_mean_(t, group, async_op)
 
     def all_reduce_mean_(self, group=None) -> None:
         self._reduce_mean(self.flat, group, False)
@@ -229,9 +209,6 @@ class SplatTrainer:
         # all-gathered); fsgs_sh_coeff_grad rebuilds the mean gradient on every rank, in rank order, so the
         # replicas stay bit-identical.  Fused CUDA path only; FSGS_FACTORED_FEATURES=0 switches it off.
         self.factored_features = os.environ.get("FSGS_FACTORED_FEATURES", "1") != "0"
-        # How the factor blocks are gathered is decided ONCE, here, from the backend — never by catching an exception
-        # inside a step: ranks that disagreed on the collective would deadlock.
-        self._gather_flat = None
         # BASELINE config #5: the render kernels read IEEE-half MIRRORS of every attribute but the means (SH features,
         # log-scales, quaternions, opacity logits: 124 instead of 236 parameter bytes per Gaussian per frame); the
         # fp32 masters, their gradients and Adam are untouched, and the fused Adam launch rewrites the mirrors.
@@ -339,7 +316,7 @@ class SplatTrainer:
             self._moments_local = False
             return
         dev = sl.flat.device
-        L, W, r = sl.split, sl.world, (dist.get_rank() if GradSlab._exchange() else 0)
+        L, W, r = sl.split, sl.world, (comm.rank() if GradSlab._exchange() else 0)
         P, M, V = (torch.zeros(L, dtype=torch.float32, device=dev) for _ in range(3))
         for name, off, n in sl.geo_ranges:
             old = self._params[name]
@@ -376,11 +353,7 @@ class SplatTrainer:
     def _all_gather_shards(self, flat: Tensor, g) -> None:
         if not GradSlab._exchange():
             return
-        mine = flat[g["lo"]:g["hi"]]
-        if dist.get_backend() == "nccl":
-            dist.all_gather_into_tensor(flat, mine)  # in place: the input is the output's own slice (RCCL's in-place form)
-        else:
-            dist.all_gather(list(flat.view(self.slab.world, g["shard"]).unbind(0)), mine.clone())
+        comm.all_gather_shards_(flat, g["lo"], g["hi"])  # (in place: the input is the output's own slice)
 
     def _sharded_geometry_step(self) -> int:
         """reduce-scatter (mean) of the geometry half -> Adam on the owned shard -> all-gather of the parameters."""
@@ -389,11 +362,7 @@ class SplatTrainer:
         geo = sl.flat[:sl.split]
         if GradSlab._exchange():
             with self._comm():
-                if dist.get_backend() == "nccl":
-                    dist.reduce_scatter_tensor(g["grad"], geo, op=dist.ReduceOp.AVG)
-                else:  # gloo has no reduce-scatter: the functional stand-in (CPU tests, ranks sharing a GPU)
-                    dist.all_reduce(geo, op=dist.ReduceOp.SUM)
-                    torch.mul(geo[g["lo"]:g["hi"]], 1.0 / W, out=g["grad"])
+                comm.reduce_scatter_mean(g["grad"], geo)
         else:
             g["grad"].copy_(geo[g["lo"]:g["hi"]])
         self.adam_steps = getattr(self, "adam_steps", 0) + 1
@@ -664,14 +633,7 @@ class SplatTrainer:
             own, gathered = factors
             work = None
             if GradSlab._exchange():
-                if self._gather_flat is None:
-                    # RCCL has the flat form; gloo only the list form.  A function of the backend alone, so every
-                    # rank decides the same way.
-                    self._gather_flat = dist.get_backend() == "nccl"
-                if self._gather_flat:
-                    work = dist.all_gather_into_tensor(gathered.view(-1), own.view(-1), async_op=True)
-                else:
-                    work = dist.all_gather(list(gathered.unbind(0)), own, async_op=True)
+                work = comm.all_gather_blocks_async(gathered, own)
                 self.comm_bytes_last_step = 4 * (self.slab.split * 2 + gathered.numel())
             deg = self._sh_degree_now()
             mp = getattr(self, "_means_prev", None)

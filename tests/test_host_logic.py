@@ -322,6 +322,63 @@ def test_data_parallel_allreduce_gloo_world2():
         assert p.returncode == 0 and "ok" in out, err[-2000:]
 
 
+_COMM_WORKER = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+from fusionsense_amd import comm
+rank = int(os.environ["RANK"]); world = int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d", rank=rank, world_size=world)
+assert comm.world() == world and comm.rank() == rank and comm.exchange()
+# all_reduce(AVG), in stream order and asynchronous
+t = torch.arange(6, dtype=torch.float32) * (rank + 1)
+assert comm.all_reduce_mean_(t) is None and torch.equal(t, torch.arange(6, dtype=torch.float32) * 1.5)
+t = torch.full((5,), float(rank)); fin = comm.all_reduce_mean_(t, async_op=True); fin(); assert torch.equal(t, torch.full((5,), 0.5))
+assert comm.all_reduce_mean_(torch.empty(0)) is None
+# reduce_scatter(AVG): the own shard of the mean
+full = torch.arange(8, dtype=torch.float32) + 10.0 * rank
+out = torch.empty(4); comm.reduce_scatter_mean(out, full)
+assert torch.equal(out, torch.arange(8, dtype=torch.float32)[4 * rank:4 * rank + 4] + 5.0)
+# in-place all-gather of the ranks' own slices
+flat = torch.zeros(8); flat[4 * rank:4 * rank + 4] = rank + 1.0
+comm.all_gather_shards_(flat, 4 * rank, 4 * rank + 4)
+assert torch.equal(flat, torch.tensor([1., 1, 1, 1, 2, 2, 2, 2]))
+# asynchronous gather of per-rank blocks, rank order
+own = torch.full((3, 4), float(rank + 1)); gathered = torch.empty(world, 3, 4)
+comm.all_gather_blocks_async(gathered, own).wait()
+assert torch.equal(gathered[0], torch.ones(3, 4)) and torch.equal(gathered[1], 2 * torch.ones(3, 4))
+m = torch.tensor([float(rank), 5.0 - rank]); comm.all_reduce_(m, "max"); assert torch.equal(m, torch.tensor([1.0, 5.0]))
+s_ = torch.tensor([1.0 + rank]); comm.all_reduce_(s_, "sum"); assert float(s_) == 3.0
+dist.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+def test_collectives_single_code_path_gloo_world2():
+    """fusionsense_amd/comm.py: the collectives of the data-parallel step are ONE code path — the calls an RCCL job
+    makes (all_reduce AVG, reduce_scatter_tensor AVG, in-place all_gather_into_tensor, the asynchronous block gather)
+    are the calls the gloo tests make; no module branches on the backend any more."""
+    import socket
+    for mod in ("trainer.py", "comm.py", "splatfacto.py"):
+        src = open(os.path.join(ROOT, "fusionsense_amd", mod)).read()
+        assert "get_backend" not in src, f"{mod} must not choose its collectives by backend"
+    for mod in ("trainer.py", "splatfacto.py"):
+        src = open(os.path.join(ROOT, "fusionsense_amd", mod)).read()
+        assert not re.search(r"\bdist\.(all_|reduce_|broadcast)", src), f"{mod} must issue collectives through comm.py"
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    code = _COMM_WORKER % (ROOT, port)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    for p in procs:
+        out, err = p.communicate(timeout=180)
+        assert p.returncode == 0 and "ok" in out, err[-2000:]
+
+
 _DEFER_WORKER = r"""
 import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, %r)
