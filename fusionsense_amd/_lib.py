@@ -76,12 +76,12 @@ SIGNATURES = {
     "fsgs_raster_quad_max_cells": (_i, []),
     "fsgs_live_pack_normals": (_i, [_i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p]),
     "fsgs_live_payload": (_i, [_p, _p, _i64, _p, _i64, _i, _i, _p, _p]),
-    "fsgs_raster_fwd_quad": (_i, [_i, _i, _p, _p, _p, _i64, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _i64, _i, _i, _i64, _p]),
+    "fsgs_raster_fwd_quad": (_i, [_i, _i, _p, _p, _p, _i64, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _i64, _i, _i, _i64, _p, _p, _i, _p]),
     "fsgs_raster_fwd_tail_scratch_bytes": (_i64, [_i]),
     "fsgs_raster_fwd_tail_error": (_i, [_p, _p]),
     "fsgs_set_bwd_dispatch_stride": (_i, [_i]),
-    "fsgs_raster_bwd_quad": (_i, [_i, _i, _p, _p, _p, _i64, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _i, _p]),
-    "fsgs_raster_bwd_quad_images": (_i, [_p, _p, _p, _i64, _i, _i, _i, _i] + [_p] * 10 + [_i, _p, _i64, _i, _p]),
+    "fsgs_raster_bwd_quad": (_i, [_i, _i, _p, _p, _p, _i64, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _i, _p, _p, _i, _p]),
+    "fsgs_raster_bwd_quad_images": (_i, [_p, _p, _p, _i64, _i, _i, _i, _i] + [_p] * 10 + [_i, _p, _i64, _i, _p, _p, _i, _p]),
     "fsgs_campos_from_viewmats": (_i, [_i, _p, _p, _p]),
     "fsgs_raster_unpack_grads": (_i, [_i64, _i, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p]),
     "fsgs_sh_fwd_split": (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p]),

@@ -96,23 +96,36 @@ raster_bwd_live_kernel(int64_t cap, const float4 *__restrict__ rec,
                        int64_t seg_cap, float *__restrict__ v_packed, int normalize_last,
                        const float *__restrict__ render_extra, const float *__restrict__ v_render_extra,
                        const int32_t *__restrict__ n_rec, GetOutputsGrads ep, int64_t replica_rows, int merge_thr16,
-                       int perm_stride) {
+                       int perm_stride, const int32_t *__restrict__ seg_split, const int32_t *__restrict__ bwd_queue,
+                       int bwd_qcap) {
     __shared__ QLds<E> Lw[kBwdWaves];
     constexpr int RS = E ? 4 : 3;
     constexpr int SS = 64 * (1 + D + E);
     const int cam = blockIdx.z;
+    const int n_tiles_total = gridDim.z * th * tw;
     // (perm_stride > 1: workgroups that are dispatched together take quadrants that lie `stride` apart instead of
     // neighbours, so that their atomics land on different Gaussians' gradient lines: fsgs_set_bwd_dispatch_stride)
     int bx = blockIdx.x, by = blockIdx.y;
-    if (perm_stride > 1) {
-        const unsigned total = gridDim.x * gridDim.y;
+    // Rows beyond the image's quadrant rows are EXTRA workgroups (single camera only): each takes one queued group of
+    // segments of a long quadrant, whose own workgroup keeps the segments from seg_split on (raster_quad.hip:
+    // split_backward) — a list of 44 segments is walked by six workgroups side by side instead of 11 rounds of one.
+    int seg_lo = 0, seg_hi = -1;  // (-1: the quadrant's own workgroup: [seg_split, n_seg))
+    if ((int)blockIdx.y >= 2 * th) {
+        const int item = ((int)blockIdx.y - 2 * th) * (int)gridDim.x + (int)blockIdx.x;
+        if (!bwd_queue || item >= min(bwd_queue[0], bwd_qcap)) return;
+        const int4 it = reinterpret_cast<const int4 *>(bwd_queue + 4)[item];
+        const int t = it.x & 0x0FFFFFFF, qq = (it.x >> 28) & 3;
+        const int ty = t / tw, tx = t - ty * tw;
+        bx = 2 * tx + (qq & 1); by = 2 * ty + (qq >> 1);
+        seg_lo = it.y; seg_hi = it.z;
+    } else if (perm_stride > 1) {
+        const unsigned total = gridDim.x * (unsigned)(2 * th);
         const unsigned lin = (unsigned)(((unsigned long long)(blockIdx.y * gridDim.x + blockIdx.x) * (unsigned)perm_stride) % total);
         by = lin / gridDim.x; bx = lin - by * gridDim.x;
     }
     const int tile_x = bx >> 1, tile_y = by >> 1;
     const int q = ((by & 1) << 1) | (bx & 1);
     const int tile_lin = (cam * th + tile_y) * tw + tile_x;
-    const int n_tiles_total = gridDim.z * th * tw;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     QLds<E> &L = Lw[w];
     // row r of the wave (16 lanes) owns the 4x4 pixel block (r >> 1, r & 1) of the quadrant and walks ITS OWN
@@ -130,7 +143,11 @@ raster_bwd_live_kernel(int64_t cap, const float4 *__restrict__ rec,
     const int s = (int)l0 + 4 * tile_lin;
     const int e = s + n_rec[(int64_t)q * n_tiles_total + tile_lin];
     const int n_seg = (e - s + 63) >> 6;
-    if (w >= n_seg) return;
+    if (seg_hi < 0) {
+        seg_hi = n_seg;
+        seg_lo = seg_split ? seg_split[(int64_t)q * n_tiles_total + tile_lin] : 0;
+    }
+    if (w >= seg_hi - seg_lo) return;
     const float4 *stream = rec + RS * ((int64_t)q * cap);
     const float *seg_q = seg_state + (int64_t)q * seg_cap * SS;
 
@@ -222,7 +239,7 @@ raster_bwd_live_kernel(int64_t cap, const float4 *__restrict__ rec,
     unsigned long long st_iter = 0, st_exec = 0, st_have = 0, st_valid = 0, st_seg = 0, st_merge = 0, st_long = 0, st_union = 0;
     unsigned long long st_half_max = 0, st_quad_max = 0, st_half_pairs = 0, st_quad_pairs = 0;
 #endif
-    for (int seg = n_seg - 1 - w; seg >= 0; seg -= kBwdWaves) {
+    for (int seg = seg_hi - 1 - w; seg >= seg_lo; seg -= kBwdWaves) {
         const int b0 = s + (seg << 6);          // first stream position of the segment
         const int n = min(64, e - b0);
         // slot t holds stream position b0 + n - 1 - t (descending list order)
@@ -485,7 +502,8 @@ static int launch_bwd_live(int C, int D, const float *records, const int32_t *n_
                            const float *render_extra, const float *v_render_extra, float *v_packed,
                            fsgs_stream_t stream, int dispatch_stride,
                            GetOutputsGrads ep = GetOutputsGrads{nullptr, nullptr, nullptr, nullptr, nullptr},
-                           int64_t replica_rows = 0) {
+                           int64_t replica_rows = 0, const int32_t *seg_split = nullptr,
+                           const int32_t *bwd_queue = nullptr, int bwd_queue_items = 0) {
     // FSGS_BWD_MERGE_THR16 (build macro, make EXTRA=-DFSGS_BWD_MERGE_THR16=n): a segment walks the union list with merged
     // atomics when its longest row list is >= thr/16 of the union; 0 = always, 17 = never
     constexpr int merge_thr16 = FSGS_BWD_MERGE_THR16;
@@ -502,7 +520,10 @@ static int launch_bwd_live(int C, int D, const float *records, const int32_t *n_
         return FSGS_EINVAL;
     }
     hipStream_t s = as_stream(stream);
-    const dim3 grid(2 * tile_width, 2 * tile_height, C);
+    if (bwd_queue_items < 0 || (bwd_queue && (!seg_split || C != 1))) return FSGS_EINVAL;
+    // (extra rows of workgroups, one per queue item: see the kernel)
+    const int extra_rows = (bwd_queue && bwd_queue_items > 0) ? ceil_div(bwd_queue_items, 2 * tile_width) : 0;
+    const dim3 grid(2 * tile_width, 2 * tile_height + extra_rows, C);
     const float4 *rec = reinterpret_cast<const float4 *>(records);
     int perm_stride = dispatch_stride >= 0 ? dispatch_stride : g_bwd_dispatch_stride.load(std::memory_order_relaxed);
     if (perm_stride > 1) {  // coprime with the number of quadrants
@@ -514,7 +535,8 @@ static int launch_bwd_live(int C, int D, const float *records, const int32_t *n_
     hipLaunchKernelGGL((raster_bwd_live_kernel<DD, AA, EE>), grid, dim3(64 * kBwdWaves), 0, s, cap, rec,          \
                        isect_offsets, n_isects, backgrounds, width, height, tile_width, tile_height, render,      \
                        alphas, last_ids, v_render, v_alphas, seg_state, seg_cap, v_packed, normalize_last,         \
-                       render_extra, v_render_extra, n_rec, ep, replica_rows, merge_thr16, perm_stride)
+                       render_extra, v_render_extra, n_rec, ep, replica_rows, merge_thr16, perm_stride, seg_split,  \
+                       bwd_queue, bwd_queue_items)
     if (render_extra) {
         if (D != 4 || (!v_render_extra && !ep.v_rgb)) return FSGS_EINVAL;
         if (with_abs) FSGS_BWD_LIVE(4, true, 3); else FSGS_BWD_LIVE(4, false, 3);
@@ -536,14 +558,16 @@ extern "C" int fsgs_raster_bwd_quad(int C, int D, const float *records, const in
                                     const float *render, const float *alphas, const int32_t *last_ids,
                                     const float *v_render, const float *v_alphas, const float *seg_state,
                                     int with_abs, const float *render_extra, const float *v_render_extra,
-                                    float *v_packed, int dispatch_stride, fsgs_stream_t stream) {
+                                    float *v_packed, int dispatch_stride, const int32_t *seg_split,
+                                    const int32_t *bwd_queue, int bwd_queue_items, fsgs_stream_t stream) {
     if (n_isects > 0 && !n_rec) return FSGS_EINVAL;
     return launch_bwd_live(C, D, records, n_rec,
                            fsgs_quad_stream_capacity(C, tile_width, tile_height, n_isects),
                            fsgs_quad_seg_slots(C, tile_width, tile_height, n_isects), isect_offsets, n_isects,
                            backgrounds, width, height, tile_width, tile_height, normalize_last, render, alphas,
                            last_ids, v_render, v_alphas, seg_state, with_abs, render_extra, v_render_extra,
-                           v_packed, stream, dispatch_stride);
+                           v_packed, stream, dispatch_stride, GetOutputsGrads{nullptr, nullptr, nullptr, nullptr, nullptr},
+                           0, seg_split, bwd_queue, bwd_queue_items);
 }
 
 extern "C" int fsgs_raster_unpack_grads(int64_t total, int D, float *v_packed, int rezero, float *v_means2d,
@@ -567,12 +591,14 @@ extern "C" int fsgs_raster_bwd_quad_images(const float *records, const int32_t *
                                            const float *render_extra, const float *background, const float *v_rgb,
                                            const float *v_depth, const float *v_normal, const float *v_alpha_in,
                                            const float *seg_state, int with_abs, float *v_packed,
-                                           int64_t replica_rows, int dispatch_stride, fsgs_stream_t stream) {
+                                           int64_t replica_rows, int dispatch_stride, const int32_t *seg_split,
+                                           const int32_t *bwd_queue, int bwd_queue_items, fsgs_stream_t stream) {
     if (n_isects > 0 && (!n_rec || !v_rgb || !background)) return FSGS_EINVAL;
     if (!v_rgb || replica_rows < 0) return FSGS_EINVAL;
     const GetOutputsGrads ep = {v_rgb, v_depth, v_normal, v_alpha_in, background};
     return launch_bwd_live(1, 4, records, n_rec, fsgs_quad_stream_capacity(1, tile_width, tile_height, n_isects),
                            fsgs_quad_seg_slots(1, tile_width, tile_height, n_isects), isect_offsets, n_isects, nullptr,
                            width, height, tile_width, tile_height, 1, render, alphas, last_ids, nullptr, nullptr,
-                           seg_state, with_abs, render_extra, nullptr, v_packed, stream, dispatch_stride, ep, replica_rows);
+                           seg_state, with_abs, render_extra, nullptr, v_packed, stream, dispatch_stride, ep, replica_rows,
+                           seg_split, bwd_queue, bwd_queue_items);
 }

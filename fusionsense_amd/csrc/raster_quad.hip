@@ -28,6 +28,35 @@ constexpr int kMaxCells = 256;               // partial image maxima (fsgs_raste
 constexpr int kQuadChunk = 256;             // list entries examined per step by the workgroup
 constexpr int kQuadStage = kQuadChunk + 4;  // staged records (+ padding to a multiple of 4)
 
+// Long lists in the BACKWARD (round 5): its workgroup of four waves takes a quadrant's 64-record segments four at a time,
+// so a quadrant of 44 segments (config #3's hull tiles) is 11 dependent rounds while the launch's other workgroups have
+// long left (0.21 ms at 0.62 of the vector-ALU cycles).  The wave that finishes a quadrant's forward therefore splits a
+// stream of more than kBwdOwnSegs segments: the quadrant's own workgroup keeps the LAST kBwdOwnSegs (seg_split = where
+// they start), the segments in front of them are queued in groups of kBwdOwnSegs for extra workgroups of the backward
+// launch (fsgs_raster_bwd_quad*: bwd_queue).  The queue's counter is zeroed by the caller (it rides behind the max_last
+// cells); a queue without room leaves the quadrant whole (seg_split = 0).
+constexpr int kBwdOwnSegs = 8;
+__device__ __forceinline__ void split_backward(int tile_lin, int q, int n_tiles_total, int n_records,
+                                               int32_t *__restrict__ seg_split, int32_t *__restrict__ bwd_queue,
+                                               int bwd_qcap) {  // (one lane)
+    if (!seg_split) return;
+    const int n_seg = (n_records + 63) >> 6;
+    int split = 0;
+    if (bwd_queue && n_seg > kBwdOwnSegs) {
+        const int rest = n_seg - kBwdOwnSegs, groups = (rest + kBwdOwnSegs - 1) / kBwdOwnSegs;
+        const int slot = atomicAdd(bwd_queue, groups);
+        if (slot + groups <= bwd_qcap) {
+            int4 *items = reinterpret_cast<int4 *>(bwd_queue + 4);
+            for (int g = 0; g < groups; ++g) {
+                const int hi = rest - kBwdOwnSegs * g;
+                items[slot + g] = make_int4(tile_lin | (q << 28), max(hi - kBwdOwnSegs, 0), hi, 0);
+            }
+            split = rest;
+        }
+    }
+    seg_split[(int64_t)q * n_tiles_total + tile_lin] = split;
+}
+
 template <int E>
 struct QuadLds {
     float4 r0[kQuadStage], r1[kQuadStage], r2[kQuadStage], r3[E ? kQuadStage : 1];
@@ -60,7 +89,8 @@ raster_fwd_quad_kernel(int64_t cap, const float4 *__restrict__ packed, const int
                        float4 *__restrict__ rec_out, int32_t *__restrict__ n_rec,
                        float *__restrict__ seg_state, int64_t seg_cap, int normalize_last,
                        float *__restrict__ render_extra, float *__restrict__ max_last, int ends_on_device,
-                       int32_t *__restrict__ tile_open) {
+                       int32_t *__restrict__ tile_open, int32_t *__restrict__ seg_split,
+                       int32_t *__restrict__ bwd_queue, int bwd_qcap) {
     __shared__ QuadLds<E> S;
     constexpr int RS = E ? 4 : 3;
     // workgroup b runs on XCD b % 8: the four quadrants of a tile share its list and its Gaussians,
@@ -248,7 +278,10 @@ raster_fwd_quad_kernel(int64_t cap, const float4 *__restrict__ packed, const int
         }
         cnt += n_proc;
     }
-    if (n_rec && tid == 0) n_rec[(int64_t)q * n_tiles_total + tile_lin] = cnt;
+    if (n_rec && tid == 0) {
+        n_rec[(int64_t)q * n_tiles_total + tile_lin] = cnt;
+        split_backward(tile_lin, q, n_tiles_total, cnt, seg_split, bwd_queue, bwd_qcap);
+    }
     // (occlusion cut, isect.hip: fsgs_tile_zcut_update) a pixel that is still transparent at the end of the list makes
     // its tile "open": this frame needed — or would have needed — everything the tile had
     if (tile_open && !__all(done) && lane == 0) tile_open[tile_lin] = 1;
@@ -493,7 +526,8 @@ raster_fwd_tail_wave(WaveLds<E> &S, const int item, const int n_base_blocks, int
                      float4 *__restrict__ rec_out, int32_t *__restrict__ n_rec,
                      float *__restrict__ seg_state, int64_t seg_cap, int normalize_last,
                      float *__restrict__ render_extra, float *__restrict__ max_last, int ends_on_device,
-                     int32_t *__restrict__ tile_open, const TailQueue &tq);
+                     int32_t *__restrict__ tile_open, const TailQueue &tq, int32_t *__restrict__ seg_split,
+                     int32_t *__restrict__ bwd_queue, int bwd_qcap);
 
 template <int D, int E>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FSGS_FWD_WAVE_OCC, FSGS_FWD_WAVE_OCC)))
@@ -505,7 +539,8 @@ raster_fwd_wave_kernel(int64_t cap, const float4 *__restrict__ packed, const int
                        float *__restrict__ seg_state, int64_t seg_cap, int normalize_last,
                        float *__restrict__ render_extra, float *__restrict__ max_last, int ends_on_device,
                        int32_t *__restrict__ tile_open, int handoff_records, TailQueue tq, int n_base_blocks,
-                       int handoff_rel_len) {
+                       int handoff_rel_len, int32_t *__restrict__ seg_split, int32_t *__restrict__ bwd_queue,
+                       int bwd_qcap) {
     __shared__ WaveLds<E> S;
     constexpr int RS = E ? 4 : 3;
 #ifdef FSGS_FWD_TRACE
@@ -517,7 +552,7 @@ raster_fwd_wave_kernel(int64_t cap, const float4 *__restrict__ packed, const int
             raster_fwd_tail_wave<D, E>(S, (int)blockIdx.x - n_base_blocks - 1, n_base_blocks, cap, packed, payload,
                                        tile_offsets, n_isects, backgrounds, W, H, tw, th, n_tiles_total, render, alphas,
                                        last_ids, rec_out, n_rec, seg_state, seg_cap, normalize_last, render_extra,
-                                       max_last, ends_on_device, tile_open, tq);
+                                       max_last, ends_on_device, tile_open, tq, seg_split, bwd_queue, bwd_qcap);
         return;
     }
     // a WALKING base wave (one of a quadrant's two copies) counts itself out when it leaves: the tail waves stop waiting
@@ -821,7 +856,10 @@ raster_fwd_wave_kernel(int64_t cap, const float4 *__restrict__ packed, const int
             break;
         }
     }
-    if (n_rec && lane == 0) n_rec[(int64_t)q * n_tiles_total + tile_lin] = cnt;
+    if (n_rec && lane == 0) {
+        n_rec[(int64_t)q * n_tiles_total + tile_lin] = cnt;
+        split_backward(tile_lin, q, n_tiles_total, cnt, seg_split, bwd_queue, bwd_qcap);
+    }
     if (tile_open && n_open && lane == 0) tile_open[tile_lin] = 1;
 #ifdef FSGS_FWD_TRACE
     if (lane == 0 && blockIdx.x < (1u << 17)) {
@@ -875,7 +913,8 @@ raster_fwd_tail_wave(WaveLds<E> &S, const int item, const int n_base_blocks, int
                      float4 *__restrict__ rec_out, int32_t *__restrict__ n_rec,
                      float *__restrict__ seg_state, int64_t seg_cap, int normalize_last,
                      float *__restrict__ render_extra, float *__restrict__ max_last, int ends_on_device,
-                     int32_t *__restrict__ tile_open, const TailQueue &tq) {
+                     int32_t *__restrict__ tile_open, const TailQueue &tq, int32_t *__restrict__ seg_split,
+                     int32_t *__restrict__ bwd_queue, int bwd_qcap) {
     static_assert(D == 4 && E == 3, "the fused RGB+ED + normal-plane walk");
     constexpr int RS = 4;
     constexpr int SS = 64 * (1 + D + E);
@@ -1092,7 +1131,10 @@ raster_fwd_tail_wave(WaveLds<E> &S, const int item, const int n_base_blocks, int
             }
         }
     }
-    if (n_rec && lane == 0) n_rec[(int64_t)q * n_tiles_total + tile_lin] = at;
+    if (n_rec && lane == 0) {
+        n_rec[(int64_t)q * n_tiles_total + tile_lin] = at;
+        split_backward(tile_lin, q, n_tiles_total, at, seg_split, bwd_queue, bwd_qcap);
+    }
     const bool any_open = __builtin_amdgcn_ballot_w64(op) != 0ull;
     if (tile_open && any_open && lane == 0) tile_open[tile_lin] = 1;
     float pix[D], pxe[E];
@@ -1169,7 +1211,8 @@ extern "C" int fsgs_raster_fwd_quad(int C, int D, const float *packed, const int
                                     int32_t *n_rec, float *seg_state, float *render_extra,
                                     float *max_last, int32_t *tile_open, int walk, void *tail_scratch,
                                     int64_t tail_scratch_bytes, int handoff_records, int handoff_rel_len,
-                                    int64_t tail_epoch, fsgs_stream_t stream) {
+                                    int64_t tail_epoch, int32_t *seg_split, int32_t *bwd_queue, int bwd_queue_items,
+                                    fsgs_stream_t stream) {
     // n_isects < 0: -n_isects is the CAPACITY the caller sized records / seg_state for, and the lists' true end is
     // isect_offsets[C * th * tw] on the device (fsgs_bin_live_count leaves it there): no host wait for the total
     const int ends_on_device = n_isects < 0 ? 1 : 0;
@@ -1185,6 +1228,7 @@ extern "C" int fsgs_raster_fwd_quad(int C, int D, const float *packed, const int
     if (!isect_offsets || !render || !alphas || !last_ids || (n_isects > 0 && (!packed || !payload)))
         return FSGS_EINVAL;
     if ((records != nullptr) != (n_rec != nullptr)) return FSGS_EINVAL;
+    if ((seg_split && !n_rec) || (bwd_queue && !seg_split) || bwd_queue_items < 0) return FSGS_EINVAL;
     if (seg_state && !records) return FSGS_EINVAL;
     const int64_t n_tiles = (int64_t)C * tile_width * tile_height;
     if (n_tiles >= (1ll << 26)) return FSGS_EINVAL;
@@ -1198,7 +1242,7 @@ extern "C" int fsgs_raster_fwd_quad(int C, int D, const float *packed, const int
     hipLaunchKernelGGL((raster_fwd_quad_kernel<DD, EE>), grid, dim3(256), 0, s, cap, pk, payload,                 \
                        isect_offsets, n_isects, backgrounds, width, height, tile_width, tile_height, (int)n_tiles, \
                        render, alphas, last_ids, rec, n_rec, seg_state, seg_cap, normalize_last, render_extra,     \
-                       max_last, ends_on_device, tile_open)
+                       max_last, ends_on_device, tile_open, seg_split, bwd_queue, bwd_queue_items)
     if (render_extra) {
         if (D != 4) return FSGS_EINVAL;  // the fused RGB+depth + normal-plane walk
         if (walk == FSGS_WALK_ONE_WAVE) {
@@ -1221,7 +1265,7 @@ extern "C" int fsgs_raster_fwd_quad(int C, int D, const float *packed, const int
                                pk, payload, isect_offsets, n_isects, backgrounds, width, height, tile_width, tile_height,
                                (int)n_tiles, render, alphas, last_ids, rec, n_rec, seg_state, seg_cap, normalize_last,
                                render_extra, max_last, ends_on_device, tile_open, tq.mem ? handoff_records : 0, tq, n_base,
-                               handoff_rel_len < 0 ? 0 : handoff_rel_len);
+                               handoff_rel_len < 0 ? 0 : handoff_rel_len, seg_split, bwd_queue, bwd_queue_items);
         } else {
             FSGS_FWD_QUAD(4, 3);
         }

@@ -152,6 +152,9 @@ def _grad_accumulator(dev, N: int) -> Tensor:
 
 
 IMAGE_GRADS_IN_BWD = os.environ.get("FSGS_IMAGE_GRADS_IN_BWD", "1") != "0"
+# queue positions for the backward's extra workgroups (groups of 8 segments of streams longer than 8 segments: fsgs.h,
+# seg_split / bwd_queue); 0 = every quadrant's stream is walked by its own workgroup alone (round 4)
+BWD_QUEUE_ITEMS = 1024
 # from this many Gaussians on, the per-Gaussian backward fetches SH coefficients lazily / skips idle Adam elements
 # (flags of fsgs_gauss_sh_bwd*, decided here per launch; module attributes so that tests can move them)
 LAZY_SH_MIN_N = int(os.environ.get("FSGS_LAZY_SH_MIN_N", str(1 << 20)))
@@ -311,7 +314,10 @@ class _FusedGetOutputs(torch.autograd.Function):
         normals_world = torch.empty(N, 3, **f32)
         packed = torch.empty(N, 16, **f32)
         n_cells = lib.fsgs_raster_quad_max_cells()
-        max_last = torch.empty(n_cells, **f32)  # partial image maxima: zeroed by the pack kernel, raised by the forward
+        # partial image maxima: zeroed by the pack kernel, raised by the forward — and behind them, zeroed by the same
+        # kernel, the queue of the backward's extra workgroups (a counter + BWD_QUEUE_ITEMS int4 items: fsgs.h, seg_split)
+        max_last = torch.empty(n_cells + 4 + 4 * BWD_QUEUE_ITEMS, **f32)
+        bwd_queue = max_last[n_cells:].view(torch.int32) if BWD_QUEUE_ITEMS > 0 else None
         # the SH colours + packing ride in the binning's scan launch when nothing stands between them and the
         # features (no deferred feature exchange) and the storage is the 16-coefficient split one
         adam_rides = direct_bins and info.adam_rider is not None and N > 0
@@ -362,12 +368,12 @@ class _FusedGetOutputs(torch.autograd.Function):
                                                 ptr(hm["features_rest"]), ptr(radii), ptr(depths), ptr(means2d),
                                                 ptr(conics), ptr(opac_sig), ptr(hm["quats"]), ptr(hm["scales"]),
                                                 ptr(cam["c2w"]), ptr(packed), ptr(normals_world), ptr(max_last),
-                                                n_cells, sp), "fsgs_sh_fwd_split")
+                                                max_last.numel(), sp), "fsgs_sh_fwd_split")
                 return
             _run(lib.fsgs_sh_fwd_pack, (N, K, sh_degree, ptr(means), ptr(cam["campos"]), ptr(features_dc),
                                         ptr(features_rest), ptr(radii), ptr(depths), ptr(means2d), ptr(conics),
                                         ptr(opac_sig), ptr(quats), ptr(scales), ptr(cam["c2w"]), ptr(packed),
-                                        ptr(normals_world), ptr(max_last), n_cells, sp), "fsgs_sh_fwd_split")
+                                        ptr(normals_world), ptr(max_last), max_last.numel(), sp), "fsgs_sh_fwd_split")
 
         # Work that does not need the lists runs while the host waits for the live total — unless the SH features
         # are still being exchanged between the ranks (info.pre_sh: the trainer's deferred feature update): then
@@ -399,13 +405,15 @@ class _FusedGetOutputs(torch.autograd.Function):
             rec_bytes = 4 * cap * 64
             seg_bytes = 4 * slots * 64 * (1 + 4 + 3) * 4
             nrec_bytes = 4 * n_tiles * 4
-            arena = WORKSPACE.take(a(rec_bytes) + a(seg_bytes) + a(nrec_bytes), dev)
+            arena = WORKSPACE.take(a(rec_bytes) + a(seg_bytes) + 2 * a(nrec_bytes), dev)
             records = arena[:rec_bytes].view(torch.float32)
             seg_state = arena[a(rec_bytes):a(rec_bytes) + seg_bytes].view(torch.float32)
             o = a(rec_bytes) + a(seg_bytes)
             n_rec = arena[o:o + nrec_bytes].view(torch.int32)
+            seg_split = arena[o + a(nrec_bytes):o + a(nrec_bytes) + nrec_bytes].view(torch.int32)
         else:
-            arena = records = seg_state = n_rec = None
+            arena = records = seg_state = n_rec = seg_split = None
+            bwd_queue = None
         render = torch.empty(1, H, W, 4, **f32)
         alphas = torch.empty(1, H, W, 1, **f32)
         last_ids = torch.empty(1, H, W, dtype=torch.int32, device=dev)
@@ -425,7 +433,8 @@ class _FusedGetOutputs(torch.autograd.Function):
                                        ptr(render), ptr(alphas), ptr(last_ids), ptr(records), ptr(n_rec),
                                        ptr(seg_state), ptr(render_extra), ptr(max_last), ptr(tile_open), walk,
                                        ptr(tail), 0 if tail is None else tail.numel(), int(handoff),
-                                       int(FWD_WALK.handoff_rel_len), int(epoch), sp),
+                                       int(FWD_WALK.handoff_rel_len), int(epoch), ptr(seg_split), ptr(bwd_queue),
+                                       BWD_QUEUE_ITEMS if bwd_queue is not None else 0, sp),
              "fsgs_raster_fwd_quad", "_d4e3")
         if tile_open is not None:
             # this frame's saturation depths become the next frame's cuts; a cut tile left open spoils the frame
@@ -471,7 +480,8 @@ class _FusedGetOutputs(torch.autograd.Function):
         if needs_bwd:
             ctx.save_for_backward(means, scales, quats, features_dc, features_rest, scales_exp, opac_sig, radii,
                                   conics, records, n_rec, offsets, render, alphas, last_ids, render_extra, seg_state,
-                                  background)
+                                  background, seg_split, bwd_queue if bwd_queue is not None else seg_split)
+            ctx.has_bwd_queue = bwd_queue is not None
             ctx.arena = arena
         else:
             WORKSPACE.give(arena)
@@ -484,7 +494,10 @@ class _FusedGetOutputs(torch.autograd.Function):
     @staticmethod
     def backward(ctx, v_rgb, v_depth, v_normal, v_alpha_out):
         (means, scales, quats, features_dc, features_rest, scales_exp, opac_sig, radii, conics, records, n_rec,
-         offsets, render, alphas, last_ids, render_extra, seg_state, background) = ctx.saved_tensors
+         offsets, render, alphas, last_ids, render_extra, seg_state, background, seg_split, bwd_queue) = ctx.saved_tensors
+        if not ctx.has_bwd_queue:
+            bwd_queue = None
+        n_queue = BWD_QUEUE_ITEMS if bwd_queue is not None else 0
         N, K, W, H, tw, th, M, sh_degree = ctx.dims
         cam = ctx.cam
         lib = load()
@@ -503,7 +516,8 @@ class _FusedGetOutputs(torch.autograd.Function):
                 lib.fsgs_raster_bwd_quad_images, (ptr(records), ptr(n_rec), ptr(offsets), M, W, H, tw, th, ptr(render),
                                                   ptr(alphas), ptr(last_ids), ptr(render_extra), ptr(background),
                                                   ptr(v_rgb), ptr(v_depth), ptr(v_normal), ptr(v_alpha_out),
-                                                  ptr(seg_state), 1, ptr(acc), rep_rows, int(stride), sp),
+                                                  ptr(seg_state), 1, ptr(acc), rep_rows, int(stride), ptr(seg_split),
+                                                  ptr(bwd_queue), n_queue, sp),
                 "fsgs_raster_bwd_quad", "_d4e3"))
         else:
             v_render = torch.empty(1, H, W, 4, **f32)
@@ -515,7 +529,7 @@ class _FusedGetOutputs(torch.autograd.Function):
             _run(lib.fsgs_raster_bwd_quad, (1, 4, ptr(records), ptr(n_rec), ptr(offsets), M, None, W, H, tw, th, 1,
                                            ptr(render), ptr(alphas), ptr(last_ids), ptr(v_render), ptr(v_alphas),
                                            ptr(seg_state), 1, ptr(render_extra), ptr(v_render_extra), ptr(v_packed),
-                                           0, sp), "fsgs_raster_bwd_quad", "_d4e3")
+                                           0, ptr(seg_split), ptr(bwd_queue), n_queue, sp), "fsgs_raster_bwd_quad", "_d4e3")
         WORKSPACE.give(getattr(ctx, "arena", None))
         ctx.arena = None
 

@@ -262,7 +262,14 @@ int fsgs_raster_fwd_quad(int C, int D, const float *packed, const int32_t *paylo
                          int32_t *tile_open /* nullable [C*th*tw]: see fsgs_tile_zcut_update */,
                          int walk /* FSGS_WALK_*: how THIS launch walks the lists */,
                          void *tail_scratch /* nullable */, int64_t tail_scratch_bytes, int handoff_records,
-                         int handoff_rel_len, int64_t tail_epoch, fsgs_stream_t stream);
+                         int handoff_rel_len, int64_t tail_epoch, int32_t *seg_split /* nullable */,
+                         int32_t *bwd_queue /* nullable */, int bwd_queue_items, fsgs_stream_t stream);
+/* Long streams in the backward (round 5): seg_split [4, C*th*tw] i32 (next to n_rec) receives, per quadrant, the first
+ * 64-record segment its own backward workgroup walks — 0 unless the stream has more than 8 segments AND bwd_queue
+ * ([4 + 4 * bwd_queue_items] i32: a counter the CALLER ZEROES before the call + 3 pad words, then int4 items) had room:
+ * then the segments in front of the last 8 are queued in groups of 8 for extra workgroups of fsgs_raster_bwd_quad* (pass
+ * it the same three arguments).  A list of 44 segments (config #3's hull tiles) is then walked by six workgroups side
+ * by side instead of 11 rounds of one.  Gradients are unchanged up to the order of the float atomics. */
 /* Hand-off of long walks (round 5; FSGS_WALK_ONE_WAVE, handoff_records > 0): a wave that has streamed `handoff_records`
  * records and still has open pixels and list entries left stops at the end of its 64-entry chunk and queues the rest of
  * its list; a SECOND launch of the same call (one wave per queued 64-entry chunk) forms every chunk's transmittance
@@ -294,7 +301,8 @@ int fsgs_raster_bwd_quad(int C, int D, const float *records, const int32_t *n_re
                          const float *render, const float *alphas, const int32_t *last_ids,
                          const float *v_render, const float *v_alphas, const float *seg_state,
                          int with_abs, const float *render_extra, const float *v_render_extra,
-                         float *v_packed, int dispatch_stride, fsgs_stream_t stream);
+                         float *v_packed, int dispatch_stride, const int32_t *seg_split /* nullable */,
+                         const int32_t *bwd_queue /* nullable; C == 1 */, int bwd_queue_items, fsgs_stream_t stream);
 /* dispatch_stride (fsgs_raster_bwd_quad, fsgs_raster_bwd_quad_images) — the dispatch order of THIS launch's quadrants:
  * 0 or 1 = row-major, k > 1 = consecutive workgroups take quadrants k apart (raised to the next value coprime with the
  * number of quadrants).  Same gradients up to the order of the float atomics; which order is faster depends on the scene
@@ -314,7 +322,8 @@ int fsgs_raster_bwd_quad_images(const float *records, const int32_t *n_rec, cons
                                 const float *render_extra, const float *background, const float *v_rgb,
                                 const float *v_depth, const float *v_normal, const float *v_alpha_in,
                                 const float *seg_state, int with_abs, float *v_packed, int64_t replica_rows,
-                                int dispatch_stride, fsgs_stream_t stream);
+                                int dispatch_stride, const int32_t *seg_split /* nullable */,
+                                const int32_t *bwd_queue /* nullable */, int bwd_queue_items, fsgs_stream_t stream);
 /* replica_rows (here and in fsgs_gaussian_bwd; 0 = off): Gaussians with a large 2-D footprint (det(conic) < 1/4096)
  * own FOUR gradient lines, replica_rows rows apart in v_packed ([4 * replica_rows, 16], zeroed): the compositing
  * backward picks the replica from the tile and the 8x8 quadrant, so that the hundreds of workgroups a large Gaussian

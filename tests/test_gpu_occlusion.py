@@ -586,3 +586,42 @@ def test_forward_walks_give_the_same_frame(dev):
         assert (outs[name]["last_ids"] != outs["one"]["last_ids"]).float().mean().item() < 1e-4, name
         for k in PARAM_ORDER:
             assert rel_err(grads[name][k], grads["one"][k]) < 2e-4, (name, k)
+
+
+@pytest.mark.gpu
+def test_backward_extra_workgroups_for_long_streams(dev, monkeypatch):
+    """Streams of more than 8 segments (faint Gaussians: pixels stay open through thousands of list entries, as under
+    config #3's hull tiles) are split for the backward: the quadrant's own workgroup keeps the last 8 segments, the rest
+    is queued in groups of 8 for extra workgroups (fsgs.h: seg_split / bwd_queue).  Same forward bit for bit, the same
+    gradients up to the order of the float atomics — with the queue, without it, and with a queue of two positions that
+    overflows (the quadrants that find no room stay whole); on both forward walks that write the streams."""
+    from fusionsense_amd import fused
+    from fusionsense_amd.trainer import PARAM_ORDER, SplatTrainer
+    params = scenes.lego_like_scene(150_000, seed=9)
+    params["opacities"] = params["opacities"] - 5.0  # faint: nothing saturates, every list is walked to its end
+    cam = scenes.hemisphere_cameras(1, width=208, height=160, focal=260.0, seed=9)[0]
+    g = torch.Generator().manual_seed(9)
+    tgt = {"rgb": torch.rand(160, 208, 3, generator=g).to(dev), "depth": torch.rand(160, 208, 1, generator=g).to(dev) * 4,
+           "normal": torch.rand(160, 208, 3, generator=g).to(dev)}
+    w = fused.FWD_WALK
+    res = {}
+    for walk in ("handoff", "one"):
+        w.forced, w.forced_walk, w.handoff_rel_len = True, 1, 0
+        w.handoff_records = 128 if walk == "handoff" else 0
+        for items in (1024, 0, 2):
+            monkeypatch.setattr(fused, "BWD_QUEUE_ITEMS", items)
+            tr = SplatTrainer(params, dev, sh_degree=3)
+            _, out = tr.train_step(cam, tgt, optimizer_step=False)
+            rec, n_rec, seg = out["info"].streams
+            res[(walk, items)] = dict(rgb=out["rgb"].clone(), n_rec=n_rec.clone(),
+                                      grads={k: tr.slab.views[k].clone() for k in PARAM_ORDER})
+        assert int(res[(walk, 1024)]["n_rec"].max()) > 64 * 16, "the scene must leave streams of many segments"
+        for items in (0, 2):
+            assert torch.equal(res[(walk, items)]["rgb"], res[(walk, 1024)]["rgb"])
+            assert torch.equal(res[(walk, items)]["n_rec"], res[(walk, 1024)]["n_rec"])
+            for k in PARAM_ORDER:
+                e = rel_err(res[(walk, items)]["grads"][k], res[(walk, 1024)]["grads"][k])
+                assert e < 2e-4, (walk, items, k, e)
+    for k in PARAM_ORDER:
+        assert rel_err(res[("handoff", 1024)]["grads"][k], res[("one", 1024)]["grads"][k]) < 2e-4, k
+    assert w.error(dev) == 0
