@@ -230,15 +230,20 @@ def bwd_dispatch_choice(dev, W, H):
         return None
 
 
-def fwd_walk_choice(dev, W, H):
+def fwd_walk_choice(dev, W, H, n_gaussians=0):
     """The forward compositing's walk of this run (fixed since round 5: fused.FWD_WALK): walk 1 = one wave per quadrant,
     ``handoff_records`` > 0 = long walks finished chunk-parallel by the launch's second pass; ``tail_error`` = 1 if a
     look-back wait of that pass ever ran into its bound (results invalid; never observed)."""
     try:
         from fusionsense_amd.fused import FWD_WALK
-        walk, handoff = FWD_WALK.choice()
+        walk, handoff = FWD_WALK.choice(n_gaussians)
         return {"walk": int(walk), "handoff_records": int(handoff), "forced": bool(FWD_WALK.forced),
-                "second_pass_items_max": int(FWD_WALK.max_items), "tail_error": FWD_WALK.error(dev) if handoff else 0,
+                "handoff_rel_len": int(FWD_WALK.handoff_rel_len), "tail_workgroups_max": int(FWD_WALK.max_items),
+                # tail workgroups the launches carry NOW (0 while no list of this run's frames asked for a hand-off
+                # lately: performance only, the results do not depend on it) and hand-offs asked for so far
+                "tail_workgroups_now": FWD_WALK.tail_items_now(dev) if handoff else 0,
+                "handoffs_seen": int((FWD_WALK.state.get(str(dev)) or {}).get("seen", 0)) if handoff else 0,
+                "tail_error": FWD_WALK.error(dev) if handoff else 0,
                 "tuning_frames": 0}
     except Exception:
         return None
@@ -639,7 +644,7 @@ def main():
     n_alloc0 = torch.cuda.memory_stats(dev).get('num_device_alloc', 0)
     n_before = trainer.num_gaussians()
     tune0 = (bwd_dispatch_choice(dev, W, H) or {}).get("tuning_frames", 0)
-    ftune0 = (fwd_walk_choice(dev, W, H) or {}).get("tuning_frames", 0)
+    ftune0 = (fwd_walk_choice(dev, W, H, trainer.num_gaussians()) or {}).get("tuning_frames", 0)
     t0 = time.perf_counter()
     step_ends = []
     # one event per step on the step's stream: the GPU-side duration of every step, read after the timed region
@@ -659,7 +664,7 @@ def main():
     torch.cuda.synchronize()
     own_elapsed = time.perf_counter() - t0  # (this rank's own clock, before it waits for the others)
     tune_in_region = (bwd_dispatch_choice(dev, W, H) or {}).get("tuning_frames", 0) - tune0
-    ftune_in_region = (fwd_walk_choice(dev, W, H) or {}).get("tuning_frames", 0) - ftune0
+    ftune_in_region = (fwd_walk_choice(dev, W, H, trainer.num_gaussians()) or {}).get("tuning_frames", 0) - ftune0
     barrier()
     elapsed = time.perf_counter() - t0
     gc.enable()
@@ -866,8 +871,8 @@ def main():
             "raster_bwd_quad_d4e3": ("raster_bwd_live_kernel<4,true,3> (RGB+ED and normal plane, one walk)" + r_note,
                                      M_r * (44 + 40) + P * (28 + 20) + n_vis * (48 + 28)),
             "raster_fwd_quad_d4e3": (("raster_fwd_wave_kernel<4,3> + raster_fwd_tail_kernel<4,3> (one wave per quadrant, long "
-                                      "walks finished chunk-parallel by the second pass" if (fwd_walk_choice(dev, W, H) or {}).get("handoff_records")
-                                      else "raster_fwd_wave_kernel<4,3> (one wave per quadrant" if (fwd_walk_choice(dev, W, H) or {}).get("walk") == 1
+                                      "walks finished chunk-parallel by the second pass" if (fwd_walk_choice(dev, W, H, trainer.num_gaussians()) or {}).get("handoff_records")
+                                      else "raster_fwd_wave_kernel<4,3> (one wave per quadrant" if (fwd_walk_choice(dev, W, H, trainer.num_gaussians()) or {}).get("walk") == 1
                                       else "raster_fwd_quad_kernel<4,3> (four waves per quadrant") +
                                      ": filter + gather + composite, RGB+ED and normal plane)" + r_note,
                                      M_r * (44 + 40) + P * (24 + 20)),
@@ -1015,7 +1020,7 @@ def main():
             "bwd_dispatch_tuning_frames_in_timed_region": tune_in_region,
             # the forward compositing's walk (fixed since round 5 — no tuner, reproducible runs: fused.FWD_WALK; the
             # ``walk`` / ``handoff_records`` arguments of fsgs_raster_fwd_quad)
-            "fwd_walk": fwd_walk_choice(dev, W, H),
+            "fwd_walk": fwd_walk_choice(dev, W, H, trainer.num_gaussians()),
             "fwd_walk_tuning_frames_in_timed_region": ftune_in_region,
             # steps whose Adam update was applied inside the per-Gaussian backward launch (no gradient slab, no Adam
             # launch: DESIGN.md §9.9; FSGS_ADAM_IN_BACKWARD=auto|1|0)

@@ -401,7 +401,8 @@ constexpr int kTailMaxChunks = 1024;    // per quadrant (65 536 list entries); l
 constexpr int kTailSpinLimit = 1 << 18;
 struct TailHeader {
     int32_t counter[2];   // queue positions claimed (two consecutive launches alternate)
-    int32_t error, pad0;
+    int32_t error;
+    int32_t demand;       // (byte offset 12) lists handed off or wanting to be, ever: callers size the tail from its growth
     int32_t pad[60];
     // walking base waves that have left: 64 shards (blockIdx & 63), one 64-byte line each — one address saturates at ~88
     // atomics/us, and a line that is polled while it takes atomics stalls both (measured: 2048 waiting tail waves reading
@@ -558,7 +559,7 @@ raster_fwd_wave_kernel(int64_t cap, const float4 *__restrict__ packed, const int
     // a WALKING base wave (one of a quadrant's two copies) counts itself out when it leaves: the tail waves stop waiting
     // once all 4 x tiles have
     auto leave = [&]() {
-        if (tq.mem && threadIdx.x == 0)
+        if (tq.mem && tq.qmax > 0 && threadIdx.x == 0)
             __hip_atomic_fetch_add(&tq.header()->done[tq.epoch & 1u][blockIdx.x & 63u][0], 1, __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);
     };
@@ -749,7 +750,9 @@ raster_fwd_wave_kernel(int64_t cap, const float4 *__restrict__ packed, const int
         if (handoff_records > 0 && cnt >= handoff_records && n_open > 0 && c0 + 64 < l1) {
             const int n_chunks = (l1 - (c0 + 64) + 63) >> 6;
             int slot0 = 0;
-            if (n_chunks <= kTailMaxChunks) {
+            if (lane == 0)
+                __hip_atomic_fetch_add(&tq.header()->demand, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (n_chunks <= kTailMaxChunks && tq.qmax > 0) {
                 if (lane == 0) slot0 = atomicAdd(&tq.header()->counter[tq.epoch & 1u], n_chunks);
                 slot0 = __builtin_amdgcn_readfirstlane(slot0);
             } else {
@@ -782,7 +785,7 @@ raster_fwd_wave_kernel(int64_t cap, const float4 *__restrict__ packed, const int
             // the queue is full (or the remainder too long): the claimed items that exist are voided and THIS wave walks
             // the rest of the list chunk by chunk with the second pass's arithmetic (tail_composite: same bits as if
             // the list had gone through the queue — which lists do is decided by the order of the atomics)
-            if (n_chunks <= kTailMaxChunks) {
+            if (n_chunks <= kTailMaxChunks && tq.qmax > 0) {
                 for (int i = lane; i < n_chunks; i += 64)
                     if (slot0 + i < tq.qmax) store_tagged(&tq.area(slot0 + i)->readyw, tq.epoch, 2u);
             }
@@ -1210,7 +1213,7 @@ extern "C" int fsgs_raster_fwd_quad(int C, int D, const float *packed, const int
                                     float *render, float *alphas, int32_t *last_ids, float *records,
                                     int32_t *n_rec, float *seg_state, float *render_extra,
                                     float *max_last, int32_t *tile_open, int walk, void *tail_scratch,
-                                    int64_t tail_scratch_bytes, int handoff_records, int handoff_rel_len,
+                                    int64_t tail_scratch_bytes, int tail_items, int handoff_records, int handoff_rel_len,
                                     int64_t tail_epoch, int32_t *seg_split, int32_t *bwd_queue, int bwd_queue_items,
                                     fsgs_stream_t stream) {
     // n_isects < 0: -n_isects is the CAPACITY the caller sized records / seg_state for, and the lists' true end is
@@ -1221,8 +1224,9 @@ extern "C" int fsgs_raster_fwd_quad(int C, int D, const float *packed, const int
     // the one-wave walk exists for the fused RGB+ED + normal-plane launch only: asking for it elsewhere is an error, not
     // a silent four-wave launch; a hand-off needs the one-wave walk, its scratch and a positive epoch
     if (walk == FSGS_WALK_ONE_WAVE && !render_extra) return FSGS_EINVAL;
-    if (handoff_records < 0 || tail_scratch_bytes < 0) return FSGS_EINVAL;
-    if (handoff_records > 0 && (walk != FSGS_WALK_ONE_WAVE || !tail_scratch || tail_epoch <= 0)) return FSGS_EINVAL;
+    if (handoff_records < 0 || tail_scratch_bytes < 0 || tail_items < 0) return FSGS_EINVAL;
+    if (handoff_records > 0 && (walk != FSGS_WALK_ONE_WAVE || !tail_scratch)) return FSGS_EINVAL;
+    if (handoff_records > 0 && tail_items > 0 && tail_epoch <= 0) return FSGS_EINVAL;
     if (C == 0 || width == 0 || height == 0) return FSGS_OK;
     if (n_isects > 0x7FFFFFF0ll) return FSGS_EINVAL;  // list indices are 32-bit (as in the reference)
     if (!isect_offsets || !render || !alphas || !last_ids || (n_isects > 0 && (!packed || !payload)))
@@ -1255,13 +1259,14 @@ extern "C" int fsgs_raster_fwd_quad(int C, int D, const float *packed, const int
                 tq.mem = static_cast<uint8_t *>(tail_scratch);
                 // (positions are claimed in increasing order and their workgroups dispatched in increasing order: the tail
                 // waves need not all be resident at once)
-                tq.qmax = (int)(room < 0 ? 0 : (room > 65536 ? 65536 : room));
+                if (room < (tail_items > 0 ? tail_items : 1)) return FSGS_ESCRATCH;
+                tq.qmax = tail_items > 65536 ? 65536 : tail_items;
                 tq.epoch = (uint32_t)(tail_epoch & 0xFFFFFFFFll);
-                if (tq.qmax <= 0 || tq.epoch == 0u) return FSGS_ESCRATCH;
+                if (tq.qmax > 0 && tq.epoch == 0u) return FSGS_EINVAL;
             }
             // (the tail waves = the last qmax workgroups of the launch, one per queue position)
             const int n_base = (int)grid.x * 2;
-            hipLaunchKernelGGL((raster_fwd_wave_kernel<4, 3>), dim3(n_base + (tq.mem ? tq.qmax + 1 : 0)), dim3(64), 0, s, cap,
+            hipLaunchKernelGGL((raster_fwd_wave_kernel<4, 3>), dim3(n_base + (tq.qmax > 0 ? tq.qmax + 1 : 0)), dim3(64), 0, s, cap,
                                pk, payload, isect_offsets, n_isects, backgrounds, width, height, tile_width, tile_height,
                                (int)n_tiles, render, alphas, last_ids, rec, n_rec, seg_state, seg_cap, normalize_last,
                                render_extra, max_last, ends_on_device, tile_open, tq.mem ? handoff_records : 0, tq, n_base,

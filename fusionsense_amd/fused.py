@@ -229,16 +229,25 @@ BWD_DISPATCH = _BwdDispatchTuner()
 
 
 class _FwdWalk:
-    """How the fused node's forward compositing walks the lists (the ``walk`` / ``handoff_records`` arguments of
-    fsgs_raster_fwd_quad).  ONE walk for every frame since round 5, so two runs of a seed give the same frames bit for
-    bit: one wave per 8x8 quadrant (27 vector instructions per record), and a wave that has streamed ``handoff_records``
-    records with pixels still open queues the rest of its list for the launch's second pass, which finishes it
-    chunk-parallel (raster_quad.hip: TailQueue) — so the frame's longest list no longer bounds the launch.  Rounds 3-4
-    chose between this walk WITHOUT the hand-off and the four-waves-per-quadrant walk by timing them per frame shape
-    (config #2: 79 vs 95 us; config #3's trained scene with lists of 2 800 entries: 278 vs 153 us); that tuner is gone.
+    """How the fused node's forward compositing walks the lists (the ``walk`` / ``handoff_records`` / ``tail_items``
+    arguments of fsgs_raster_fwd_quad).  ONE walk for every frame since round 5, so two runs of a seed give the same
+    frames bit for bit: one wave per 8x8 quadrant (27 vector instructions per record), and a wave that has streamed
+    ``handoff_records`` records of a list far longer than the frame's mean, with pixels still open, hands the rest of the
+    list to the tail waves of the same launch, which finish it chunk-parallel (raster_quad.hip: TailQueue) — the frame's
+    longest list no longer bounds the launch.  Rounds 3-4 chose between this walk WITHOUT the hand-off and the
+    four-waves-per-quadrant walk by timing them per frame shape (config #2: 79 vs 95 us; config #3's trained scene with
+    lists of 2 800 entries: 278 vs 153 us); that tuner is gone.
+
+    What IS still decided from what earlier frames showed is only how many tail workgroups a launch carries (``tail_items``:
+    0 while no list of this device's frames has asked for a hand-off lately — then waiting tail workgroups would cost
+    ~4 us per launch for nothing, config #2 — else ``max_items``).  It cannot change a result: a list that finds no tail
+    is finished by its own wave with the chunks' arithmetic, the same bits (tests: a queue of 8 positions).  The demand
+    is a counter in the scratch, copied to pinned memory every ``PROBE_EVERY`` frames without a host wait.
+
     ``forced`` / ``forced_walk`` / ``handoff_records`` are attributes so that tests and bench.py can run the other walks
-    (0 = four waves per quadrant; 1 = one wave; handoff_records = 0: never hand off)."""
+    (0 = four waves per quadrant; 1 = one wave; handoff_records = 0: never hand off); forced walks always carry the tail."""
     ONE_WAVE, FOUR_WAVES = 1, 0
+    PROBE_EVERY, KEEP_FRAMES = 16, 1024
 
     def __init__(self):
         self.walk = self.ONE_WAVE
@@ -246,37 +255,60 @@ class _FwdWalk:
         # ``handoff_rel_len`` times the frame's mean list length.  Measured (MI355X, us per launch, config #2 / #3's
         # schedule window): no hand-off 78 / 255-274; 64 / 128 / 192 records at 4 x the mean: 81 / 82 / 82 and
         # 104 / 102 / 101 (at 8 x: 126 at config #3); every list whatever its length: 101-122 / 99-104; the four-wave
-        # walk: 96 / 152.  The ~4 us at config #2 are the tail workgroups waiting for the base waves to leave.
+        # walk: 96 / 152.  The ~4 us at config #2 are tail workgroups waiting for the base waves to leave: not launched
+        # while nothing asks for them (see above).
         self.handoff_records = 192
         self.handoff_rel_len = 4
         # dense scenes (the depth-slab binning route, configs #4 / #5): tens of thousands of quadrants keep every SIMD busy
         # and every list is long — nothing to gain, a queue to overflow: no hand-off from this many Gaussians on
         self.handoff_max_n = 1 << 20
-        self.max_items = 16384       # queue positions = tail workgroups of the launch (64-entry chunks per frame)
+        self.max_items = 16384       # queue positions = tail workgroups of a launch that carries the tail
         self.forced = False          # tests: use ``forced_walk`` (and ``handoff_records`` as set)
         self.forced_walk = 0
-        self.state: Dict = {}        # (device) -> [scratch tensor, epoch]
-        self.frames_with_handoff = 0
+        self.state: Dict = {}        # device -> dict(scratch, epoch, frames, keep_until, seen, probe)
 
     def choice(self, n_gaussians: int = 0):
         walk = self.forced_walk if self.forced else self.walk
         on = walk == self.ONE_WAVE and (self.forced or n_gaussians < self.handoff_max_n)
         return walk, (self.handoff_records if on else 0)
 
-    def scratch(self, dev):
-        """(tail scratch of this device — zeroed once —, the epoch of this launch)."""
+    def _state(self, dev):
         key = str(dev)
         st = self.state.get(key)
         need = int(load().fsgs_raster_fwd_tail_scratch_bytes(int(self.max_items)))
-        if st is None or st[0].numel() != need:
-            st = self.state[key] = [torch.zeros(need, dtype=torch.uint8, device=dev), 0]
-        st[1] += 1
-        return st[0], st[1]
+        if st is None or st["scratch"].numel() != need:
+            st = self.state[key] = dict(scratch=torch.zeros(need, dtype=torch.uint8, device=dev), epoch=0, frames=0,
+                                        keep_until=0, seen=0, probe=None,
+                                        pinned=torch.zeros(1, dtype=torch.int32).pin_memory())
+        return st
+
+    def scratch(self, dev):
+        """(tail scratch of this device — zeroed once —, tail workgroups of this launch, its epoch)."""
+        st = self._state(dev)
+        st["frames"] += 1
+        if st["probe"] is not None and st["probe"].query():
+            st["probe"] = None
+            demand = int(st["pinned"][0])
+            if demand != st["seen"]:
+                st["seen"], st["keep_until"] = demand, st["frames"] + self.KEEP_FRAMES
+        if st["probe"] is None and st["frames"] % self.PROBE_EVERY == 0:
+            # (TailHeader.demand: the int32 at byte offset 12 — lists handed off, or wanting to be, so far)
+            st["pinned"].copy_(st["scratch"][12:16].view(torch.int32), non_blocking=True)
+            st["probe"] = torch.cuda.Event()
+            st["probe"].record()
+        items = int(self.max_items) if (self.forced or st["frames"] <= st["keep_until"]) else 0
+        if items > 0:
+            st["epoch"] += 1  # (two launches WITH a tail alternate the queue's counters)
+        return st["scratch"], items, st["epoch"]
+
+    def tail_items_now(self, dev) -> int:
+        st = self.state.get(str(dev))
+        return 0 if st is None else (int(self.max_items) if (self.forced or st["frames"] <= st["keep_until"]) else 0)
 
     def error(self, dev) -> int:
         """1 if a look-back wait of any frame on this device ever ran into its bound (tests), else 0."""
         st = self.state.get(str(dev))
-        return 0 if st is None else int(load().fsgs_raster_fwd_tail_error(st[0].data_ptr(), stream_ptr(dev)))
+        return 0 if st is None else int(load().fsgs_raster_fwd_tail_error(st["scratch"].data_ptr(), stream_ptr(dev)))
 
 
 FWD_WALK = _FwdWalk()
@@ -427,12 +459,12 @@ class _FusedGetOutputs(torch.autograd.Function):
                                else (None, None, None))
         walk, handoff = FWD_WALK.choice(N)
         info.fwd_walk = walk
-        tail, epoch = FWD_WALK.scratch(dev) if handoff > 0 else (None, 0)
+        tail, tail_items, epoch = FWD_WALK.scratch(dev) if handoff > 0 else (None, 0, 0)
         _run(lib.fsgs_raster_fwd_quad, (1, 4, ptr(packed), ptr(flatten_ids), ptr(offsets), -M if no_wait else M,
                                        None, W, H, tw, th, 1,
                                        ptr(render), ptr(alphas), ptr(last_ids), ptr(records), ptr(n_rec),
                                        ptr(seg_state), ptr(render_extra), ptr(max_last), ptr(tile_open), walk,
-                                       ptr(tail), 0 if tail is None else tail.numel(), int(handoff),
+                                       ptr(tail), 0 if tail is None else tail.numel(), int(tail_items), int(handoff),
                                        int(FWD_WALK.handoff_rel_len), int(epoch), ptr(seg_split), ptr(bwd_queue),
                                        BWD_QUEUE_ITEMS if bwd_queue is not None else 0, sp),
              "fsgs_raster_fwd_quad", "_d4e3")

@@ -261,8 +261,8 @@ int fsgs_raster_fwd_quad(int C, int D, const float *packed, const int32_t *paylo
                          float *seg_state, float *render_extra, float *max_last,
                          int32_t *tile_open /* nullable [C*th*tw]: see fsgs_tile_zcut_update */,
                          int walk /* FSGS_WALK_*: how THIS launch walks the lists */,
-                         void *tail_scratch /* nullable */, int64_t tail_scratch_bytes, int handoff_records,
-                         int handoff_rel_len, int64_t tail_epoch, int32_t *seg_split /* nullable */,
+                         void *tail_scratch /* nullable */, int64_t tail_scratch_bytes, int tail_items,
+                         int handoff_records, int handoff_rel_len, int64_t tail_epoch, int32_t *seg_split /* nullable */,
                          int32_t *bwd_queue /* nullable */, int bwd_queue_items, fsgs_stream_t stream);
 /* Long streams in the backward (round 5): seg_split [4, C*th*tw] i32 (next to n_rec) receives, per quadrant, the first
  * 64-record segment its own backward workgroup walks — 0 unless the stream has more than 8 segments AND bwd_queue

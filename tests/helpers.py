@@ -78,6 +78,20 @@ def poison_capacity(caps, pairs):
     caps.get = once
 
 
+def device_kernels_of(fn):
+    """Names of the device kernels (and copies / memsets) ``fn()`` launches, from torch.profiler's device activity."""
+    from torch.profiler import ProfilerActivity, profile
+    torch.cuda.synchronize()
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+        fn()
+        torch.cuda.synchronize()
+    names = []
+    for e in prof.events():
+        if str(getattr(e, "device_type", "")).endswith("CUDA") and e.name:
+            names.append(e.name)
+    return names
+
+
 def rel_err(a, b):
     a = a.detach().double().cpu()
     b = b.detach().double().cpu()

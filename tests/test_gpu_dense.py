@@ -308,6 +308,16 @@ def test_config5_surface_scene_half_storage_bench_route(dev, surface5, fwd_walk)
     assert math.isfinite(float(loss))
     for k in HALF_GROUPS:
         assert torch.equal(tr.half_mirrors()[k], tr.params[k].data.half()), k
+    # ... and a step of this configuration launches libfsgs kernels only: no torch (at::native) kernel, no fill, no copy
+    # (the 594 us torch fills of profiles/r4_c5_kernel_stats.csv are the trainer's construction — zeroed
+    # moments, slab and mirrors —, not its steps)
+    from helpers import device_kernels_of
+    names = device_kernels_of(lambda: [tr.train_step(view, tgt) for _ in range(2)])
+    assert names, "the profiler saw no device activity"
+    ours = ("fsgs", "gauss_sh_bwd_kernel", "scan_rows_sh_pack_kernel", "sh_bwd_hybrid_kernel", "sh_fwd_pack_direct_kernel",
+            "zcut_verdict_kernel")  # (libfsgs kernels; the last five are defined outside its namespace)
+    foreign = [n for n in names if not any(o in n for o in ours)]
+    assert not foreign, sorted(set(foreign))
 
 
 def test_config5_bench_step_against_oracle_on_a_window(dev, surface5):
