@@ -113,6 +113,9 @@ def parse():
                          "(0 = never; default = fused.FWD_WALK.handoff_records)")
     ap.add_argument("--handoff-rel-len", type=int, default=None, help="A/B: hand off only lists longer than this many "
                     "times the frame's mean list length")
+    ap.add_argument("--handoff-gate-len", type=int, default=None, help="A/B: hand off only in frames whose longest list "
+                    "exceeds this many times the mean list length (0 = any frame)")
+    ap.add_argument("--bwd-queue", type=int, default=None, help="A/B: queue positions for the backward's extra workgroups")
     ap.add_argument("--tail-items", type=int, default=None, help="A/B: queue positions of the hand-off (= tail workgroups)")
     a = ap.parse_args()
     d = DEFAULTS[a.config]
@@ -238,7 +241,8 @@ def fwd_walk_choice(dev, W, H, n_gaussians=0):
         from fusionsense_amd.fused import FWD_WALK
         walk, handoff = FWD_WALK.choice(n_gaussians)
         return {"walk": int(walk), "handoff_records": int(handoff), "forced": bool(FWD_WALK.forced),
-                "handoff_rel_len": int(FWD_WALK.handoff_rel_len), "tail_workgroups_max": int(FWD_WALK.max_items),
+                "handoff_rel_len": int(FWD_WALK.handoff_rel_len), "handoff_gate_len": int(FWD_WALK.handoff_gate_len),
+                "tail_workgroups_max": int(FWD_WALK.max_items),
                 # tail workgroups the launches carry NOW (0 while no list of this run's frames asked for a hand-off
                 # lately: performance only, the results do not depend on it) and hand-offs asked for so far
                 "tail_workgroups_now": FWD_WALK.tail_items_now(dev) if handoff else 0,
@@ -542,9 +546,15 @@ def main():
     from fusionsense_amd import frame_cache, ops
 
     log('building workload')
+    if args.bwd_queue is not None:
+        import fusionsense_amd.fused as _f
+        _f.BWD_QUEUE_ITEMS = int(args.bwd_queue)
     if args.handoff_rel_len is not None:
         from fusionsense_amd.fused import FWD_WALK
         FWD_WALK.handoff_rel_len = int(args.handoff_rel_len)
+    if args.handoff_gate_len is not None:
+        from fusionsense_amd.fused import FWD_WALK
+        FWD_WALK.handoff_gate_len = int(args.handoff_gate_len)
     if args.fwd_walk is not None or args.handoff is not None or args.tail_items is not None:  # A/B switches
         from fusionsense_amd.fused import FWD_WALK
         if args.tail_items is not None:

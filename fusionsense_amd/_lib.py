@@ -64,7 +64,7 @@ SIGNATURES = {
     "fsgs_project_bin_live_count_sh_pack_h16": (_i, [_i, _p, _p, _p, _p, _p, _i, _f, _p, _p, _i, _i, _f, _f, _f, _f, _p, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p, _sz, _p,
                                                      _i, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p]),
     "fsgs_project_bin_live_count": (_i, [_i, _p, _p, _p, _p, _i, _f, _p, _p, _i, _i, _f, _f, _f, _f, _p, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p, _sz, _p, _p]),
-    "fsgs_bin_live_emit": (_i, [_i, _i, _p, _p, _p, _p, _p, _i, _i, _p, _p, _i64, _p, _p, _p, _p]),
+    "fsgs_bin_live_emit": (_i, [_i, _i, _p, _p, _p, _p, _p, _i, _i, _p, _p, _i64, _p, _p, _p, _p, _i, _p]),
     "fsgs_bin_live_split_scratch_bytes": (_sz, [_i, _i, _i, _i64]),
     "fsgs_bin_live_emit_split": (_i, [_i, _i, _p, _p, _p, _p, _p, _i, _i, _p, _p, _i64, _p, _p, _p, _sz, _p, _p, _p]),
     "fsgs_set_lazy_sh_min_n": (_i, [_i]),
@@ -76,7 +76,7 @@ SIGNATURES = {
     "fsgs_raster_quad_max_cells": (_i, []),
     "fsgs_live_pack_normals": (_i, [_i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p]),
     "fsgs_live_payload": (_i, [_p, _p, _i64, _p, _i64, _i, _i, _p, _p]),
-    "fsgs_raster_fwd_quad": (_i, [_i, _i, _p, _p, _p, _i64, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _i64, _i, _i, _i, _i64, _p, _p, _i, _p]),
+    "fsgs_raster_fwd_quad": (_i, [_i, _i, _p, _p, _p, _i64, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _i64, _i, _i, _i, _p, _i64, _p, _p, _i, _p]),
     "fsgs_raster_fwd_tail_scratch_bytes": (_i64, [_i]),
     "fsgs_raster_fwd_tail_error": (_i, [_p, _p]),
     "fsgs_set_bwd_dispatch_stride": (_i, [_i]),

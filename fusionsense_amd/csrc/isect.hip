@@ -797,7 +797,8 @@ int launch_tile_scan_rows_offsets(int T, int nb, int32_t *table, int32_t *totals
 int launch_tile_offsets(int T, const int32_t *totals, int32_t *isect_offsets, int32_t *total_mapped, hipStream_t s);
 int launch_scan_rows_sh_pack(int T, int nb, int32_t *table, int32_t *totals, const ShPackRider &r, hipStream_t s);
 int launch_tile_sort_tiers(int T, int n_tiles, int tile_bits, const int32_t *isect_offsets, uint64_t *buckets,
-                           int32_t *payload_sorted, int64_t *isect_ids_sorted, hipStream_t s);
+                           int32_t *payload_sorted, int64_t *isect_ids_sorted, hipStream_t s, int32_t *long_flag = nullptr,
+                           int rel_gate = 0);
 int launch_split_sort(int T, int n_tiles, int tile_bits, const int32_t *isect_offsets, int64_t n_live,
                       const uint64_t *buckets, uint64_t *buckets2, int32_t *scratch, int32_t *payload_sorted,
                       hipStream_t s);
@@ -1084,7 +1085,8 @@ static int bin_live_emit_impl(int C, int N, const float *means2d, const int32_t 
                               const float *conics, const float *opacities, int tile_width, int tile_height,
                               const int32_t *isect_offsets, const void *table_scratch, int64_t n_live,
                               void *buckets, void *buckets2, void *split_scratch, int32_t *payload_sorted,
-                              fsgs_stream_t stream, const float *tile_zcut);
+                              fsgs_stream_t stream, const float *tile_zcut, int32_t *long_flag = nullptr,
+                              int rel_gate = 0);
 
 extern "C" size_t fsgs_bin_live_split_scratch_bytes(int C, int tile_width, int tile_height, int64_t n_live) {
     return (size_t)split_scratch_ints(C * tile_width * tile_height, n_live > 0 ? n_live : 0) * sizeof(int32_t) + 64;
@@ -1107,16 +1109,19 @@ extern "C" int fsgs_bin_live_emit_split(int C, int N, const float *means2d, cons
 extern "C" int fsgs_bin_live_emit(int C, int N, const float *means2d, const int32_t *radii, const float *depths,
                                   const float *conics, const float *opacities, int tile_width, int tile_height,
                                   const int32_t *isect_offsets, const void *table_scratch, int64_t n_live,
-                                  void *buckets, int32_t *payload_sorted, const float *tile_zcut, fsgs_stream_t stream) {
+                                  void *buckets, int32_t *payload_sorted, const float *tile_zcut, int32_t *long_flag,
+                                  int rel_gate, fsgs_stream_t stream) {
+    if (rel_gate < 0) return FSGS_EINVAL;
     return bin_live_emit_impl(C, N, means2d, radii, depths, conics, opacities, tile_width, tile_height, isect_offsets,
-                              table_scratch, n_live, buckets, nullptr, nullptr, payload_sorted, stream, tile_zcut);
+                              table_scratch, n_live, buckets, nullptr, nullptr, payload_sorted, stream, tile_zcut,
+                              long_flag, rel_gate);
 }
 
 static int bin_live_emit_impl(int C, int N, const float *means2d, const int32_t *radii, const float *depths,
                               const float *conics, const float *opacities, int tile_width, int tile_height,
                               const int32_t *isect_offsets, const void *table_scratch, int64_t n_live,
                               void *buckets, void *buckets2, void *split_scratch, int32_t *payload_sorted,
-                              fsgs_stream_t stream, const float *tile_zcut) {
+                              fsgs_stream_t stream, const float *tile_zcut, int32_t *long_flag, int rel_gate) {
     if (C < 1 || N < 0 || tile_width < 1 || tile_height < 1 || n_live < 0 || !isect_offsets) return FSGS_EINVAL;
     if (tile_zcut && C != 1) return FSGS_EINVAL;
     const int64_t T64 = (int64_t)C * tile_width * tile_height;
@@ -1145,7 +1150,7 @@ static int bin_live_emit_impl(int C, int N, const float *means2d, const int32_t 
                                  reinterpret_cast<uint64_t *>(buckets2), reinterpret_cast<int32_t *>(split_scratch),
                                  payload_sorted, s);
     return launch_tile_sort_tiers(T, n_tiles, tb, isect_offsets, reinterpret_cast<uint64_t *>(buckets),
-                                  payload_sorted, nullptr, s);
+                                  payload_sorted, nullptr, s, long_flag, rel_gate);
 }
 
 

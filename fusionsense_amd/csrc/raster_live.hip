@@ -110,8 +110,11 @@ raster_bwd_live_kernel(int64_t cap, const float4 *__restrict__ rec,
     // segments of a long quadrant, whose own workgroup keeps the segments from seg_split on (raster_quad.hip:
     // split_backward) — a list of 44 segments is walked by six workgroups side by side instead of 11 rounds of one.
     int seg_lo = 0, seg_hi = -1;  // (-1: the quadrant's own workgroup: [seg_split, n_seg))
-    if ((int)blockIdx.y >= 2 * th) {
-        const int item = ((int)blockIdx.y - 2 * th) * (int)gridDim.x + (int)blockIdx.x;
+    // (the extra rows come FIRST in the dispatch order: they hold the segments of the launch's longest streams)
+    const int extra_rows = (int)gridDim.y - 2 * th;
+    const int grid_row = (int)blockIdx.y - extra_rows;
+    if (grid_row < 0) {
+        const int item = (int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x;
         if (!bwd_queue || item >= min(bwd_queue[0], bwd_qcap)) return;
         const int4 it = reinterpret_cast<const int4 *>(bwd_queue + 4)[item];
         const int t = it.x & 0x0FFFFFFF, qq = (it.x >> 28) & 3;
@@ -120,8 +123,10 @@ raster_bwd_live_kernel(int64_t cap, const float4 *__restrict__ rec,
         seg_lo = it.y; seg_hi = it.z;
     } else if (perm_stride > 1) {
         const unsigned total = gridDim.x * (unsigned)(2 * th);
-        const unsigned lin = (unsigned)(((unsigned long long)(blockIdx.y * gridDim.x + blockIdx.x) * (unsigned)perm_stride) % total);
+        const unsigned lin = (unsigned)(((unsigned long long)((unsigned)grid_row * gridDim.x + blockIdx.x) * (unsigned)perm_stride) % total);
         by = lin / gridDim.x; bx = lin - by * gridDim.x;
+    } else {
+        by = grid_row;
     }
     const int tile_x = bx >> 1, tile_y = by >> 1;
     const int q = ((by & 1) << 1) | (bx & 1);

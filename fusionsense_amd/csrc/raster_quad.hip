@@ -541,7 +541,7 @@ raster_fwd_wave_kernel(int64_t cap, const float4 *__restrict__ packed, const int
                        float *__restrict__ render_extra, float *__restrict__ max_last, int ends_on_device,
                        int32_t *__restrict__ tile_open, int handoff_records, TailQueue tq, int n_base_blocks,
                        int handoff_rel_len, int32_t *__restrict__ seg_split, int32_t *__restrict__ bwd_queue,
-                       int bwd_qcap) {
+                       int bwd_qcap, const int32_t *__restrict__ handoff_gate) {
     __shared__ WaveLds<E> S;
     constexpr int RS = E ? 4 : 3;
 #ifdef FSGS_FWD_TRACE
@@ -580,6 +580,8 @@ raster_fwd_wave_kernel(int64_t cap, const float4 *__restrict__ packed, const int
         // launch (config #3's hull tiles: 2 800 entries against a mean of ~200; config #2's longest list is 5.7 x its mean
         // and saturates early — queueing those cost 10 us per launch)
         if ((int64_t)(a1 - a0) * n_tiles_total <= (int64_t)handoff_rel_len * total) handoff_records = 0;
+        // ... and only in frames that have lists FAR beyond the bulk (fsgs_bin_live_emit: long_flag)
+        if (handoff_gate && handoff_records > 0 && *handoff_gate == 0) handoff_records = 0;
     }
     const int cam = tile_lin / (tw * th);
     const int tile_in = tile_lin - cam * tw * th;
@@ -1214,7 +1216,7 @@ extern "C" int fsgs_raster_fwd_quad(int C, int D, const float *packed, const int
                                     int32_t *n_rec, float *seg_state, float *render_extra,
                                     float *max_last, int32_t *tile_open, int walk, void *tail_scratch,
                                     int64_t tail_scratch_bytes, int tail_items, int handoff_records, int handoff_rel_len,
-                                    int64_t tail_epoch, int32_t *seg_split, int32_t *bwd_queue, int bwd_queue_items,
+                                    const int32_t *handoff_gate, int64_t tail_epoch, int32_t *seg_split, int32_t *bwd_queue, int bwd_queue_items,
                                     fsgs_stream_t stream) {
     // n_isects < 0: -n_isects is the CAPACITY the caller sized records / seg_state for, and the lists' true end is
     // isect_offsets[C * th * tw] on the device (fsgs_bin_live_count leaves it there): no host wait for the total
@@ -1270,7 +1272,8 @@ extern "C" int fsgs_raster_fwd_quad(int C, int D, const float *packed, const int
                                pk, payload, isect_offsets, n_isects, backgrounds, width, height, tile_width, tile_height,
                                (int)n_tiles, render, alphas, last_ids, rec, n_rec, seg_state, seg_cap, normalize_last,
                                render_extra, max_last, ends_on_device, tile_open, tq.mem ? handoff_records : 0, tq, n_base,
-                               handoff_rel_len < 0 ? 0 : handoff_rel_len, seg_split, bwd_queue, bwd_queue_items);
+                               handoff_rel_len < 0 ? 0 : handoff_rel_len, seg_split, bwd_queue, bwd_queue_items,
+                               handoff_gate);
         } else {
             FSGS_FWD_QUAD(4, 3);
         }

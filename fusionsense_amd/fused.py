@@ -259,6 +259,11 @@ class _FwdWalk:
         # while nothing asks for them (see above).
         self.handoff_records = 192
         self.handoff_rel_len = 4
+        # ... and only in frames in which SOME list is more than this many times the mean (0 = any frame): a frame
+        # statistic the in-tile sort leaves on the device.  Config #2's longest list is 5.7 x its mean in most frames (a
+        # few reach 8 x): next to nothing is queued there — its quadrants saturate early, queueing cost 5 us per launch;
+        # config #3's hull tiles: 16 x (gate 0 / 8 / 12: 102 / 101 / 101 us).
+        self.handoff_gate_len = 12
         # dense scenes (the depth-slab binning route, configs #4 / #5): tens of thousands of quadrants keep every SIMD busy
         # and every list is long — nothing to gain, a queue to overflow: no hand-off from this many Gaussians on
         self.handoff_max_n = 1 << 20
@@ -278,7 +283,7 @@ class _FwdWalk:
         need = int(load().fsgs_raster_fwd_tail_scratch_bytes(int(self.max_items)))
         if st is None or st["scratch"].numel() != need:
             st = self.state[key] = dict(scratch=torch.zeros(need, dtype=torch.uint8, device=dev), epoch=0, frames=0,
-                                        keep_until=0, seen=0, probe=None,
+                                        keep_until=0, seen=0, probed_at=0, probe=None,
                                         pinned=torch.zeros(1, dtype=torch.int32).pin_memory())
         return st
 
@@ -289,8 +294,11 @@ class _FwdWalk:
         if st["probe"] is not None and st["probe"].query():
             st["probe"] = None
             demand = int(st["pinned"][0])
-            if demand != st["seen"]:
-                st["seen"], st["keep_until"] = demand, st["frames"] + self.KEEP_FRAMES
+            # (at least one hand-off per frame since the last look: a stray long list now and then — config #2 has one
+            # in every tenth frame — is finished by its own wave)
+            if demand - st["seen"] >= st["frames"] - st["probed_at"]:
+                st["keep_until"] = st["frames"] + self.KEEP_FRAMES
+            st["seen"], st["probed_at"] = demand, st["frames"]
         if st["probe"] is None and st["frames"] % self.PROBE_EVERY == 0:
             # (TailHeader.demand: the int32 at byte offset 12 — lists handed off, or wanting to be, so far)
             st["pinned"].copy_(st["scratch"][12:16].view(torch.int32), non_blocking=True)
@@ -348,8 +356,10 @@ class _FusedGetOutputs(torch.autograd.Function):
         n_cells = lib.fsgs_raster_quad_max_cells()
         # partial image maxima: zeroed by the pack kernel, raised by the forward — and behind them, zeroed by the same
         # kernel, the queue of the backward's extra workgroups (a counter + BWD_QUEUE_ITEMS int4 items: fsgs.h, seg_split)
-        max_last = torch.empty(n_cells + 4 + 4 * BWD_QUEUE_ITEMS, **f32)
-        bwd_queue = max_last[n_cells:].view(torch.int32) if BWD_QUEUE_ITEMS > 0 else None
+        max_last = torch.empty(n_cells + 4 + 4 * BWD_QUEUE_ITEMS + 4, **f32)
+        bwd_queue = max_last[n_cells:n_cells + 4 + 4 * BWD_QUEUE_ITEMS].view(torch.int32) if BWD_QUEUE_ITEMS > 0 else None
+        # ... and the frame statistic that gates the forward's hand-off (set by the in-tile sort: fsgs_bin_live_emit)
+        long_flag = max_last[n_cells + 4 + 4 * BWD_QUEUE_ITEMS:].view(torch.int32)
         # the SH colours + packing ride in the binning's scan launch when nothing stands between them and the
         # features (no deferred feature exchange) and the storage is the 16-coefficient split one
         adam_rides = direct_bins and info.adam_rider is not None and N > 0
@@ -413,8 +423,10 @@ class _FusedGetOutputs(torch.autograd.Function):
         if pre_sh is None:
             colours_and_packing()
         if direct_bins:
+            # (the statistic's word is zeroed by the packing launch: it can be taken only when that ran before the sort)
+            gate = long_flag if (pre_sh is None and FWD_WALK.handoff_gate_len > 0) else None
             tpg, isect_ids, flatten_ids, offsets = ops.bin_live_finish(count, means2d, radii, depths, conics, opac_row,
-                                                                       tw, th)
+                                                                       tw, th, gate, FWD_WALK.handoff_gate_len)
         else:
             tpg, isect_ids, flatten_ids, offsets = ops.isect_finish_live(count, means2d, radii, depths, conics,
                                                                          opac_row, tw, th, want_ids=False, route_hint=True)
@@ -458,6 +470,8 @@ class _FusedGetOutputs(torch.autograd.Function):
         tile_open, bad, hit = (ops.zcut_scratch(dev, n_tiles) if (track_cuts or info.zcut_in is not None)
                                else (None, None, None))
         walk, handoff = FWD_WALK.choice(N)
+        if not direct_bins or (FWD_WALK.handoff_gate_len > 0 and pre_sh is not None and not FWD_WALK.forced):
+            handoff = 0  # (no frame statistic on these routes: the plain one-wave walk)
         info.fwd_walk = walk
         tail, tail_items, epoch = FWD_WALK.scratch(dev) if handoff > 0 else (None, 0, 0)
         _run(lib.fsgs_raster_fwd_quad, (1, 4, ptr(packed), ptr(flatten_ids), ptr(offsets), -M if no_wait else M,
@@ -465,7 +479,9 @@ class _FusedGetOutputs(torch.autograd.Function):
                                        ptr(render), ptr(alphas), ptr(last_ids), ptr(records), ptr(n_rec),
                                        ptr(seg_state), ptr(render_extra), ptr(max_last), ptr(tile_open), walk,
                                        ptr(tail), 0 if tail is None else tail.numel(), int(tail_items), int(handoff),
-                                       int(FWD_WALK.handoff_rel_len), int(epoch), ptr(seg_split), ptr(bwd_queue),
+                                       int(FWD_WALK.handoff_rel_len),
+                                       ptr(long_flag) if (direct_bins and pre_sh is None and FWD_WALK.handoff_gate_len > 0)
+                                       else None, int(epoch), ptr(seg_split), ptr(bwd_queue),
                                        BWD_QUEUE_ITEMS if bwd_queue is not None else 0, sp),
              "fsgs_raster_fwd_quad", "_d4e3")
         if tile_open is not None:

@@ -510,7 +510,7 @@ def bin_live_check(st: dict) -> int:
 
 
 def bin_live_finish(st: dict, means2d: Tensor, radii: Tensor, depths: Tensor, conics: Tensor, opacities: Tensor,
-                    tile_width: int, tile_height: int):
+                    tile_width: int, tile_height: int, long_flag: Optional[Tensor] = None, rel_gate: int = 0):
     """Wait for the live total, then scatter into the tile buckets + sort them.  Returns (tiles_per_gauss,
     None, payload_sorted, isect_offsets [C,th,tw]) — or falls back to the list chain (radix sort) when the
     tiles are too dense for LDS buckets."""
@@ -546,7 +546,8 @@ def bin_live_finish(st: dict, means2d: Tensor, radii: Tensor, depths: Tensor, co
         buckets = WORKSPACE.take(8 * M, dev)
         _run(lib.fsgs_bin_live_emit, (Cn, N, ptr(means2d), ptr(radii), ptr(depths), ptr(conics), ptr(opacities),
                                      tile_width, tile_height, ptr(st["offsets"]), ptr(st["table"]), M, ptr(buckets),
-                                     ptr(pay_s), ptr(st.get("zcut")), stream_ptr(dev)), "fsgs_tile_sort")
+                                     ptr(pay_s), ptr(st.get("zcut")), ptr(long_flag), int(rel_gate), stream_ptr(dev)),
+             "fsgs_tile_sort")
         WORKSPACE.give(buckets)
     WORKSPACE.give(st["table"])
     if st.get("capacity", 0):
@@ -798,7 +799,7 @@ class _Rasterize(torch.autograd.Function):
                                            -M if ends_on_device else M,
                                            ptr(backgrounds), width, height, tw, th, int(normalize_last),
                                            ptr(render), ptr(alphas), ptr(last_ids), ptr(records), ptr(n_rec),
-                                           ptr(seg_state), None, None, None, 0, None, 0, 0, 0, 0, 0, None, None, 0, stream_ptr(dev)),
+                                           ptr(seg_state), None, None, None, 0, None, 0, 0, 0, 0, None, 0, None, None, 0, stream_ptr(dev)),
                  "fsgs_raster_fwd_quad", f"_d{D}")
             empty = torch.empty(0, device=dev)
             ctx.save_for_backward(records if records is not None else empty,

@@ -262,7 +262,8 @@ int fsgs_raster_fwd_quad(int C, int D, const float *packed, const int32_t *paylo
                          int32_t *tile_open /* nullable [C*th*tw]: see fsgs_tile_zcut_update */,
                          int walk /* FSGS_WALK_*: how THIS launch walks the lists */,
                          void *tail_scratch /* nullable */, int64_t tail_scratch_bytes, int tail_items,
-                         int handoff_records, int handoff_rel_len, int64_t tail_epoch, int32_t *seg_split /* nullable */,
+                         int handoff_records, int handoff_rel_len, const int32_t *handoff_gate /* nullable */,
+                         int64_t tail_epoch, int32_t *seg_split /* nullable */,
                          int32_t *bwd_queue /* nullable */, int bwd_queue_items, fsgs_stream_t stream);
 /* Long streams in the backward (round 5): seg_split [4, C*th*tw] i32 (next to n_rec) receives, per quadrant, the first
  * 64-record segment its own backward workgroup walks — 0 unless the stream has more than 8 segments AND bwd_queue
@@ -431,7 +432,11 @@ int fsgs_project_bin_live_count_sh_pack_h16(
 int fsgs_bin_live_emit(int C, int N, const float *means2d, const int32_t *radii, const float *depths,
                        const float *conics, const float *opacities, int tile_width, int tile_height,
                        const int32_t *isect_offsets, const void *table_scratch, int64_t n_live, void *buckets,
-                       int32_t *payload_sorted, const float *tile_zcut /* nullable; C == 1 */, fsgs_stream_t stream);
+                       int32_t *payload_sorted, const float *tile_zcut /* nullable; C == 1 */,
+                       int32_t *long_flag /* nullable */, int rel_gate, fsgs_stream_t stream);
+/* long_flag (round 5; a word the caller zeroes): set to 1 if any tile's list is longer than rel_gate times the mean list
+ * length — the frame statistic fsgs_raster_fwd_quad's hand-off is gated on (handoff_gate): only frames that HAVE lists far
+ * beyond the bulk (config #3's hull tiles: 16 x the mean; config #2's longest list: 5.7 x) queue anything. */
 
 /* fsgs_bin_live_emit for buckets of any size: tiles with more than 1024 live pairs are first split into depth
  * slabs of ~512 (monotone in depth, so sorted slabs in order = a sorted tile), every slab sorted like a small

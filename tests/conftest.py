@@ -32,9 +32,9 @@ def _default_forward_walk():
         yield
         return
     t = fused.FWD_WALK
-    saved = (t.forced, t.forced_walk, t.handoff_records, t.max_items, t.handoff_rel_len)
+    saved = (t.forced, t.forced_walk, t.handoff_records, t.max_items, t.handoff_rel_len, t.handoff_gate_len)
     yield
-    t.forced, t.forced_walk, t.handoff_records, t.max_items, t.handoff_rel_len = saved
+    t.forced, t.forced_walk, t.handoff_records, t.max_items, t.handoff_rel_len, t.handoff_gate_len = saved
 
 
 # (id, walk, handoff_records): the four-wave walk of rounds 2-3, the one-wave walk without a hand-off (round 4), and the
@@ -48,5 +48,6 @@ def fwd_walk(request, _default_forward_walk):
     from fusionsense_amd import fused
     _, walk, handoff = request.param
     fused.FWD_WALK.forced, fused.FWD_WALK.forced_walk, fused.FWD_WALK.handoff_records = True, walk, handoff
-    fused.FWD_WALK.handoff_rel_len = 0  # (every quadrant that reaches the threshold hands off, whatever its list's length)
+    # (every quadrant that reaches the threshold hands off, whatever its list's length and the frame's longest list)
+    fused.FWD_WALK.handoff_rel_len, fused.FWD_WALK.handoff_gate_len = 0, 0
     return request.param[0]

@@ -236,7 +236,7 @@ def test_config4_surface_scene_against_oracle_on_a_window(dev, surface4, walk):
     from helpers import OracleWindow, fused_node_route
     if walk != "product":  # (the product's walk for a scene this dense IS the plain one-wave walk: force the hand-off on)
         fused.FWD_WALK.forced, fused.FWD_WALK.forced_walk = True, 1
-        fused.FWD_WALK.handoff_records, fused.FWD_WALK.handoff_rel_len = 128, 0
+        fused.FWD_WALK.handoff_records, fused.FWD_WALK.handoff_rel_len, fused.FWD_WALK.handoff_gate_len = 128, 0, 0
     params, cams = surface4
     cam = crop_camera(cams[0], CROP, shift=CROP_SHIFT)
     win = OracleWindow({k: v.cpu() for k, v in params.items()}, cam)

@@ -557,7 +557,7 @@ def test_forward_walks_give_the_same_frame(dev):
            "normal": torch.rand(207, 333, 3, generator=g).to(dev)}
     tr = SplatTrainer(params, dev, sh_degree=3)
     w = fused.FWD_WALK
-    w.forced, w.handoff_rel_len = True, 0  # (every quadrant that reaches the threshold hands off)
+    w.forced, w.handoff_rel_len, w.handoff_gate_len = True, 0, 0  # (every quadrant that reaches the threshold hands off)
     outs, grads = {}, {}
     variants = {"four": (0, 0, 8192), "one": (1, 0, 8192), "h16": (1, 16, 8192), "h64": (1, 64, 8192),
                 "h128": (1, 128, 8192), "h16_q8": (1, 16, 8)}
@@ -606,7 +606,7 @@ def test_backward_extra_workgroups_for_long_streams(dev, monkeypatch):
     w = fused.FWD_WALK
     res = {}
     for walk in ("handoff", "one"):
-        w.forced, w.forced_walk, w.handoff_rel_len = True, 1, 0
+        w.forced, w.forced_walk, w.handoff_rel_len, w.handoff_gate_len = True, 1, 0, 0
         w.handoff_records = 128 if walk == "handoff" else 0
         for items in (1024, 0, 2):
             monkeypatch.setattr(fused, "BWD_QUEUE_ITEMS", items)
