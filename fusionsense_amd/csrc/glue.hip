@@ -61,62 +61,138 @@ struct EpilogueLoss {
     float g_depth, g_normal;
 };
 
+// One WAVE per 256 pixels, four consecutive pixels per lane (round 5): every array is read and written with 16-byte
+// accesses — the 3-channel images as three float4 per lane (12 floats = 4 pixels) instead of twelve 4-byte accesses at a
+// stride of 12 bytes, which cost three partial-line transactions each (17.4 -> see DESIGN.md 5.4).  The per-256-pixel
+// partial sums keep their layout (one row per workgroup, as fsgs_aux_l1_fwd leaves them).
 template <bool LOSS>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(64)
 epilogue_fwd_kernel(int64_t P, const float4 *__restrict__ render, const float *__restrict__ alphas,
                     const float *__restrict__ render_extra, const float *__restrict__ bg,
                     const float *__restrict__ max_last, int n_cells, float *__restrict__ rgb,
                     float *__restrict__ depth, float *__restrict__ normal, EpilogueLoss L) {
-    __shared__ float red[4];
-    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const float4 r = (p < P) ? render[p] : make_float4(0.f, 0.f, 0.f, 0.f);
-    const float a = (p < P) ? alphas[p] : 1.f;
+    const int lane = threadIdx.x;
+    const int64_t p0 = ((int64_t)blockIdx.x * 64 + lane) * 4;  // this lane's first pixel
+    const bool full = p0 + 3 < P;                              // all four pixels exist (else: per-pixel accesses)
+    float a[4];
+    float4 r[4];
+    if (full) {
+        const float4 a4 = *reinterpret_cast<const float4 *>(alphas + p0);
+        a[0] = a4.x; a[1] = a4.y; a[2] = a4.z; a[3] = a4.w;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) r[k] = render[p0 + k];
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            a[k] = (p0 + k < P) ? alphas[p0 + k] : 1.f;
+            r[k] = (p0 + k < P) ? render[p0 + k] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
     // the image maximum arrives as n_cells partial maxima; only waves with an empty pixel need it
     float fill = 0.f;
-    if (__any(!(a > 0.f))) {
-        for (int k = threadIdx.x & 63; k < n_cells; k += 64) fill = fmaxf(fill, max_last[k]);
+    const bool empty = !(a[0] > 0.f) || !(a[1] > 0.f) || !(a[2] > 0.f) || !(a[3] > 0.f);
+    if (__any(empty)) {
+        for (int k = lane; k < n_cells; k += 64) fill = fmaxf(fill, max_last[k]);
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) fill = fmaxf(fill, __shfl_xor(fill, d, 64));
     }
+    const float up = LOSS ? L.v_loss[0] : 0.f;
+    const float b0 = bg[0], b1 = bg[1], b2 = bg[2];
+    float out_rgb[12], out_d[4], out_vd[4], out_n[12], out_vn[12];
     float sd = 0.f, sn = 0.f;
-    if (p < P) {
-        const float t = 1.f - a;
-        rgb[p * 3 + 0] = fminf(fmaxf(r.x + t * bg[0], 0.f), 1.f);
-        rgb[p * 3 + 1] = fminf(fmaxf(r.y + t * bg[1], 0.f), 1.f);
-        rgb[p * 3 + 2] = fminf(fmaxf(r.z + t * bg[2], 0.f), 1.f);
-        const float dep = (a > 0.f) ? r.w : fill;
-        depth[p] = dep;
-        const float up = LOSS ? L.v_loss[0] : 0.f;
+    float dgt[4] = {0.f, 0.f, 0.f, 0.f}, ex[12], ngt[12];
+    const bool have_ngt = LOSS && L.normal_gt != nullptr;
+    if (full) {
         if (LOSS) {
-            const float d = dep - L.depth_gt[p];
-            sd = fabsf(d);
-            L.v_depth[p] = up * L.g_depth * ((d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f));
+            const float4 g4 = *reinterpret_cast<const float4 *>(L.depth_gt + p0);
+            dgt[0] = g4.x; dgt[1] = g4.y; dgt[2] = g4.z; dgt[3] = g4.w;
         }
         if (normal) {
-            const float nx = render_extra[p * 3 + 0], ny = render_extra[p * 3 + 1], nz = render_extra[p * 3 + 2];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float4 e4 = *reinterpret_cast<const float4 *>(render_extra + p0 * 3 + 4 * k);
+                ex[4 * k + 0] = e4.x; ex[4 * k + 1] = e4.y; ex[4 * k + 2] = e4.z; ex[4 * k + 3] = e4.w;
+                if (have_ngt) {
+                    const float4 n4 = *reinterpret_cast<const float4 *>(L.normal_gt + p0 * 3 + 4 * k);
+                    ngt[4 * k + 0] = n4.x; ngt[4 * k + 1] = n4.y; ngt[4 * k + 2] = n4.z; ngt[4 * k + 3] = n4.w;
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const bool in = p0 + k < P;
+            if (LOSS) dgt[k] = in ? L.depth_gt[p0 + k] : 0.f;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                ex[3 * k + c] = (in && normal) ? render_extra[(p0 + k) * 3 + c] : 1.f;
+                ngt[3 * k + c] = (in && have_ngt) ? L.normal_gt[(p0 + k) * 3 + c] : 0.f;
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const bool in = p0 + k < P;
+        const float t = 1.f - a[k];
+        out_rgb[3 * k + 0] = fminf(fmaxf(r[k].x + t * b0, 0.f), 1.f);
+        out_rgb[3 * k + 1] = fminf(fmaxf(r[k].y + t * b1, 0.f), 1.f);
+        out_rgb[3 * k + 2] = fminf(fmaxf(r[k].z + t * b2, 0.f), 1.f);
+        const float dep = (a[k] > 0.f) ? r[k].w : fill;
+        out_d[k] = dep;
+        if (LOSS) {
+            const float d = dep - dgt[k];
+            sd += in ? fabsf(d) : 0.f;
+            out_vd[k] = up * L.g_depth * ((d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f));
+        }
+        if (normal) {
+            const float nx = ex[3 * k + 0], ny = ex[3 * k + 1], nz = ex[3 * k + 2];
             const float inv = 1.f / sqrtf(nx * nx + ny * ny + nz * nz);
             const float nn[3] = {(nx * inv + 1.f) * 0.5f, (ny * inv + 1.f) * 0.5f, (nz * inv + 1.f) * 0.5f};
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                normal[p * 3 + k] = nn[k];
-                if (LOSS && L.normal_gt) {
-                    const float e = nn[k] - L.normal_gt[p * 3 + k];
-                    sn += fabsf(e);
-                    L.v_normal[p * 3 + k] = up * L.g_normal * ((e > 0.f) ? 1.f : ((e < 0.f) ? -1.f : 0.f));
+            for (int c = 0; c < 3; ++c) {
+                out_n[3 * k + c] = nn[c];
+                if (have_ngt) {
+                    const float e = nn[c] - ngt[3 * k + c];
+                    sn += in ? fabsf(e) : 0.f;
+                    out_vn[3 * k + c] = up * L.g_normal * ((e > 0.f) ? 1.f : ((e < 0.f) ? -1.f : 0.f));
                 }
+            }
+        }
+    }
+    auto st4 = [](float *dst, const float *v) { *reinterpret_cast<float4 *>(dst) = make_float4(v[0], v[1], v[2], v[3]); };
+    if (full) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) st4(rgb + p0 * 3 + 4 * k, out_rgb + 4 * k);
+        st4(depth + p0, out_d);
+        if (LOSS) st4(L.v_depth + p0, out_vd);
+        if (normal) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                st4(normal + p0 * 3 + 4 * k, out_n + 4 * k);
+                if (have_ngt) st4(L.v_normal + p0 * 3 + 4 * k, out_vn + 4 * k);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (p0 + k < P) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    rgb[(p0 + k) * 3 + c] = out_rgb[3 * k + c];
+                    if (normal) normal[(p0 + k) * 3 + c] = out_n[3 * k + c];
+                    if (normal && have_ngt) L.v_normal[(p0 + k) * 3 + c] = out_vn[3 * k + c];
+                }
+                depth[p0 + k] = out_d[k];
+                if (LOSS) L.v_depth[p0 + k] = out_vd[k];
             }
         }
     }
     if (LOSS) {  // per-workgroup partial sums, same layout as fsgs_aux_l1_fwd (256 pixels per row)
         sd = wave_sum_to_last_row(sd);
         sn = wave_sum_to_last_row(sn);
-        const int tr = threadIdx.x;
-        __shared__ float red2[4];
-        if ((tr & 63) == 63) { red[tr >> 6] = sd; red2[tr >> 6] = sn; }
-        __syncthreads();
-        if (tr == 0) {
-            L.partial[2 * blockIdx.x + 0] = red[0] + red[1] + red[2] + red[3];
-            L.partial[2 * blockIdx.x + 1] = red2[0] + red2[1] + red2[2] + red2[3];
+        if (lane == 63) {
+            L.partial[2 * blockIdx.x + 0] = sd;
+            L.partial[2 * blockIdx.x + 1] = sn;
         }
     }
 }
@@ -203,7 +279,7 @@ extern "C" int fsgs_epilogue_fwd(int64_t n_pixels, const float *render, const fl
     if (n_partial > 0)  // n_partial <= 0: max_last already holds max(1, -n_partial) partial maxima (fsgs_raster_fwd_quad)
         hipLaunchKernelGGL(max_reduce_kernel, dim3(1), dim3(1024), 0, s, n_partial, max_last_partial, max_last);
     const int n_cells = n_partial < 0 ? -n_partial : 1;
-    hipLaunchKernelGGL(epilogue_fwd_kernel<false>, dim3(ceil_div(n_pixels, 256)), dim3(256), 0, s, n_pixels,
+    hipLaunchKernelGGL(epilogue_fwd_kernel<false>, dim3(ceil_div(n_pixels, 256)), dim3(64), 0, s, n_pixels,
                        reinterpret_cast<const float4 *>(render), alphas, render_extra, bg, max_last, n_cells, rgb, depth,
                        normal, EpilogueLoss{});
     return check_launch();
@@ -222,7 +298,7 @@ extern "C" int fsgs_epilogue_loss_fwd(int64_t n_pixels, const float *render, con
         return FSGS_EINVAL;
     if ((normal && !render_extra) || (normal_gt && (!normal || !v_normal))) return FSGS_EINVAL;
     const EpilogueLoss L = {depth_gt, normal_gt, v_loss, partial, v_depth, v_normal, g_depth, g_normal};
-    hipLaunchKernelGGL(epilogue_fwd_kernel<true>, dim3(ceil_div(n_pixels, 256)), dim3(256), 0, as_stream(stream),
+    hipLaunchKernelGGL(epilogue_fwd_kernel<true>, dim3(ceil_div(n_pixels, 256)), dim3(64), 0, as_stream(stream),
                        n_pixels, reinterpret_cast<const float4 *>(render), alphas, render_extra, bg, max_last, n_cells,
                        rgb, depth, normal, L);
     return check_launch();

@@ -382,6 +382,9 @@ struct BinProjArgs {
     // count pass only (nullable, [N] bytes): kept[n] <- 1 if Gaussian n has at least one binned (live, not cut) pair,
     // else 0.  A Gaussian without one is in no list: the frame needs neither its colours nor its packed record.
     uint8_t *kept;
+    // count pass only (nullable): a word the first workgroup zeroes — the ticket of the scan launch that follows
+    // (scan_rows_sh_pack_kernel: the last scan workgroup to arrive forms isect_offsets)
+    int32_t *zero_word;
 };
 
 template <bool SCATTER, bool MULTI, bool PROJ, bool HALF, int BT>
@@ -398,6 +401,7 @@ isect_live_bin_body(const int block, int C, int N, const float *__restrict__ mea
     int *slots = reinterpret_cast<int *>(bin_smem + sizeof(BinLds<BT>));
     const int64_t total = (int64_t)C * N;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (PROJ && !SCATTER && block == 0 && tid == 0 && pj.zero_word) *pj.zero_word = 0;  // (the next launch's ticket)
     // `chunks` groups of 1024 Gaussians per workgroup, one after the other into the same tile slots: the table has
     // one row per WORKGROUP, so large N is given more chunks instead of more rows (N / 1024 rows of T counters
     // each would be 234 MB at 6 M Gaussians x 10 000 tiles)
@@ -795,7 +799,8 @@ namespace fsgs {
 int launch_tile_scan_rows_offsets(int T, int nb, int32_t *table, int32_t *totals, int32_t *isect_offsets,
                                   int32_t *total_mapped, hipStream_t s);
 int launch_tile_offsets(int T, const int32_t *totals, int32_t *isect_offsets, int32_t *total_mapped, hipStream_t s);
-int launch_scan_rows_sh_pack(int T, int nb, int32_t *table, int32_t *totals, const ShPackRider &r, hipStream_t s);
+int launch_scan_rows_sh_pack(int T, int nb, int32_t *table, int32_t *totals, const ShPackRider &r, hipStream_t s,
+                             int32_t *ticket, int32_t *isect_offsets, int32_t *total_mapped);
 int launch_tile_sort_tiers(int T, int n_tiles, int tile_bits, const int32_t *isect_offsets, uint64_t *buckets,
                            int32_t *payload_sorted, int64_t *isect_ids_sorted, hipStream_t s, int32_t *long_flag = nullptr,
                            int rel_gate = 0);
@@ -975,10 +980,13 @@ static int project_bin_live_count_impl(int N, const float *means, const void *qu
     int rc;
     BinProjArgs pj = {means, quats, log_scales, viewmat, K, opac_logit, scales_out, opac_out, means2d, depths,
                       conics, radii, width, height, binarise, eps2d, near_plane, far_plane, radius_clip,
-                      binary_threshold, reinterpret_cast<__half *>(opac_logit_h), attr_half, nullptr, 0, 0, 0, nullptr};
+                      binary_threshold, reinterpret_cast<__half *>(opac_logit_h), attr_half, nullptr, 0, 0, 0, nullptr,
+                      nullptr};
     size_t extra_lds = 0;
     bin_place_zcut(pj, tile_zcut, tile_width, tile_height, T, total, extra_lds);
     pj.kept = kept;
+    int32_t *ticket = rider ? totals + T : nullptr;  // (inside table_scratch's 64 spare bytes)
+    pj.zero_word = ticket;
     ShPackRider rider_kept;
     if (rider && kept) { rider_kept = *rider; rider_kept.kept = kept; rider = &rider_kept; }
 #define FSGS_BIN_PCOUNT(HF)                                                                                         \
@@ -1001,11 +1009,8 @@ static int project_bin_live_count_impl(int N, const float *means, const void *qu
         rc = attr_half ? FSGS_BIN_PCOUNT(true) : FSGS_BIN_PCOUNT(false);
 #undef FSGS_BIN_PCOUNT
     if (rc != FSGS_OK) return rc;
-    if (rider) {  // the table scan and the SH forward + packing in one launch (sh.hip), then the offsets
-        rc = launch_scan_rows_sh_pack(T, nb, table, totals, *rider, s);
-        if (rc != FSGS_OK) return rc;
-        return launch_tile_offsets(T, totals, isect_offsets, n_live_mapped, s);
-    }
+    if (rider)  // the table scan, the SH forward + packing AND the offsets in one launch (sh.hip)
+        return launch_scan_rows_sh_pack(T, nb, table, totals, *rider, s, ticket, isect_offsets, n_live_mapped);
     return launch_tile_scan_rows_offsets(T, nb, table, totals, isect_offsets, n_live_mapped, s);
 }
 

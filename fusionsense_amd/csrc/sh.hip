@@ -1451,9 +1451,22 @@ __global__ void __launch_bounds__(256)
 scan_rows_sh_pack_kernel(int T, int nb, int32_t *__restrict__ table, int32_t *__restrict__ totals, int n_scan_blocks,
                          int N, int degree, const float *__restrict__ means, const float *__restrict__ campos,
                          const void *__restrict__ dc, const void *__restrict__ rest,
-                         const int32_t *__restrict__ radii, const float *__restrict__ depths, ShPackArgs pk) {
+                         const int32_t *__restrict__ radii, const float *__restrict__ depths, ShPackArgs pk,
+                         int32_t *__restrict__ ticket, int32_t *__restrict__ isect_offsets,
+                         int32_t *__restrict__ total_mapped) {
     if ((int)blockIdx.x < n_scan_blocks) {
         tile_scan_rows_body(T, nb, table, totals, blockIdx.x);
+        if (!ticket) return;
+        // the scan workgroup that arrives LAST turns the totals into isect_offsets inside this launch, beside the colour
+        // workgroups (round 5: tile_offsets_kernel was a one-workgroup launch of its own, 6.7 us of the step; round 2's
+        // attempt at this used agent-scope fences and lost).  Totals are stored write-through, drained, then ticketed.
+        __shared__ int last;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0)
+            last = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == n_scan_blocks - 1;
+        __syncthreads();
+        if (last) tile_offsets_body256(T, totals, isect_offsets, total_mapped);
         return;
     }
     sh_fwd_pack_direct_body<HALF>(blockIdx.x - n_scan_blocks, N, degree, means, campos, dc, rest, radii, depths, pk);
@@ -1461,17 +1474,20 @@ scan_rows_sh_pack_kernel(int T, int nb, int32_t *__restrict__ table, int32_t *__
 
 namespace fsgs {
 // (called by the projecting count pass of isect.hip; the arguments are checked there and in sh_pack_rider_ok)
-int launch_scan_rows_sh_pack(int T, int nb, int32_t *table, int32_t *totals, const ShPackRider &r, hipStream_t s) {
+int launch_scan_rows_sh_pack(int T, int nb, int32_t *table, int32_t *totals, const ShPackRider &r, hipStream_t s,
+                             int32_t *ticket, int32_t *isect_offsets, int32_t *total_mapped) {
     ShPackArgs pk = {r.means2d, r.conics, r.opacities, r.quats, r.log_scales, r.c2w, reinterpret_cast<float4 *>(r.packed),
                      r.normals_world, r.zero_cells, r.zero_cells ? r.n_zero : 0, r.kept};
     const int n_scan = tile_scan_rows_blocks(T);
     const dim3 grid(n_scan + ceil_div(r.N, 256));
     if (r.attr_half)
         hipLaunchKernelGGL(scan_rows_sh_pack_kernel<true>, grid, dim3(256), 0, s, T, nb, table, totals, n_scan, r.N,
-                           r.degree, r.means, r.campos, r.features_dc, r.features_rest, r.radii, r.depths, pk);
+                           r.degree, r.means, r.campos, r.features_dc, r.features_rest, r.radii, r.depths, pk, ticket,
+                           isect_offsets, total_mapped);
     else
         hipLaunchKernelGGL(scan_rows_sh_pack_kernel<false>, grid, dim3(256), 0, s, T, nb, table, totals, n_scan, r.N,
-                           r.degree, r.means, r.campos, r.features_dc, r.features_rest, r.radii, r.depths, pk);
+                           r.degree, r.means, r.campos, r.features_dc, r.features_rest, r.radii, r.depths, pk, ticket,
+                           isect_offsets, total_mapped);
     return check_launch();
 }
 }  // namespace fsgs

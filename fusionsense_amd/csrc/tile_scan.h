@@ -57,7 +57,46 @@ __device__ __forceinline__ void tile_scan_rows_body(int T, int nb, int32_t *__re
         }
         __syncthreads();
     }
-    if (tid < kTrTiles && t0 + tid < T) totals[t0 + tid] = carry[tid];
+    // (write-through: the workgroup that arrives last in scan_rows_sh_pack_kernel reads every tile's total in the launch)
+    if (tid < kTrTiles && t0 + tid < T)
+        __hip_atomic_store(&totals[t0 + tid], carry[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// isect_offsets from the per-tile totals by ONE workgroup of 256 threads (what tile_offsets_kernel does as a launch of its
+// own): offsets[t] = min(sum of totals before t, capacity), offsets[T] = min(total, capacity); total_mapped as there.
+__device__ __forceinline__ void tile_offsets_body256(int T, const int32_t *__restrict__ totals,
+                                                     int32_t *__restrict__ offsets, int32_t *__restrict__ total_mapped) {
+    __shared__ int wsum[4];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int per = (T + 255) / 256;          // consecutive tiles per thread
+    const int i0 = tid * per, i1 = min(i0 + per, T);
+    const int c = total_mapped ? total_mapped[2] : 0;
+    const int cap = c > 0 ? c : 0x7FFFFFFF;
+    int mine = 0;
+    for (int i = i0; i < i1; ++i) mine += __hip_atomic_load(&totals[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int inc = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += o;
+    }
+    if (lane == 63) wsum[w] = inc;
+    __syncthreads();
+    int run = inc - mine;
+    for (int k = 0; k < w; ++k) run += wsum[k];
+    for (int i = i0; i < i1; ++i) {
+        offsets[i] = min(run, cap);
+        run += __hip_atomic_load(&totals[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (tid == 255) {
+        const int total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        offsets[T] = min(total, cap);
+        if (total_mapped) {
+            total_mapped[0] = total;
+            __threadfence_system();
+            __hip_atomic_store(&total_mapped[1], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);  // "the total has landed"
+        }
+    }
 }
 
 }  // namespace fsgs

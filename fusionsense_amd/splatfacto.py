@@ -136,6 +136,7 @@ class DensifyStrategy:
         self._touch_rows = (None, None)
         # what the dataparser's metadata carries for the FusionSense callbacks (normal_nerfstudio.py:593-690)
         self.touch_patches = None
+        self._staged_on = None
         self.gel_scale_factor = 6.34e-5   # normal_nerfstudio.py:72
         self.add_touch_at = 1000          # dn_model.py:136, configs/config.py:7
         self.visual_hull: Optional[Tensor] = None
@@ -209,6 +210,21 @@ class DensifyStrategy:
         """The scene metadata the reference's callbacks read from ``self.kwargs["metadata"]``."""
         self.touch_patches, self.gel_scale_factor, self.add_touch_at = touch_patches, gel_scale_factor, add_touch_at
         self.visual_hull, self.scale_factor = visual_hull, scale_factor
+        self._staged_on = None
+
+    def stage(self, device) -> None:
+        """The callbacks' scene metadata (touch patches, visual hull) moved to the training device ONCE — the reference
+        keeps them on the host and copies them inside every callback (dn_model.py:1170-1190, 1262-1264): 93 small
+        host-to-device copies with their waits were 9 of the 29 ms config #3's four callback steps took (round 5,
+        tools/profile_refine.py).  Same values; called by SplatTrainer at construction and, lazily, by the callbacks."""
+        if self._staged_on == str(device):
+            return
+        if self.touch_patches is not None:
+            self.touch_patches = [{k: (v.to(device) if torch.is_tensor(v) else v) for k, v in p.items()}
+                                  for p in self.touch_patches]
+        if self.visual_hull is not None:
+            self.visual_hull = self.visual_hull.to(device)
+        self._staged_on = str(device)
 
     def before_train(self, trainer) -> None:
         """BEFORE_TRAIN_ITERATION callbacks (dn_model.py:1370-1383): add_touch_patch at step == add_touch_at."""
@@ -357,6 +373,9 @@ class DensifyStrategy:
         of the new points come from the nearest existing Gaussian (knn_sk, k=1, dn_model.py:1181-1182)."""
         _flush(trainer)
         from .touch import make_touch_gaussians, touch_aabb_mask
+        if touch_patches is self.touch_patches:
+            self.stage(trainer.params["means"].device)
+            touch_patches = self.touch_patches
         P = trainer.params
         means = P["means"].data
         aabb = touch_aabb_mask(means, touch_patches)
@@ -394,6 +413,9 @@ class DensifyStrategy:
         from .touch import hull_prune_mask
         if trainer.step <= self.cfg.warmup_length:
             return None
+        if visual_hull is self.visual_hull:
+            self.stage(trainer.device)
+            visual_hull = self.visual_hull
         mask = hull_prune_mask(trainer.params["means"].data, visual_hull.to(trainer.device), scale_factor,
                                self.add_mask)
         self.max_2Dsize = None
@@ -406,6 +428,9 @@ class DensifyStrategy:
         from .touch import touch_aabb_mask
         if trainer.step <= self.cfg.warmup_length or self.add_mask is None:
             return None
+        if touch_patches is self.touch_patches:
+            self.stage(trainer.device)
+            touch_patches = self.touch_patches
         mask = touch_aabb_mask(trainer.params["means"].data, touch_patches)
         mask[self.add_mask] = False
         return self.cull_gaussians(trainer, mask)

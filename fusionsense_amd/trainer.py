@@ -266,6 +266,8 @@ class SplatTrainer:
         self.comm_events = None  # a list: (step, start, end) HIP-event pairs around every collective / wait (see _comm)
         self.step = 0
         self.strategy = strategy  # fusionsense_amd.splatfacto.DensifyStrategy or None
+        if strategy is not None and hasattr(strategy, "stage"):
+            strategy.stage(device)  # (the callbacks' scene metadata: on the device once, not inside every callback)
         self.rng = torch.Generator(device=device)
         self.rng.manual_seed(seed)
         self.last_info = None
