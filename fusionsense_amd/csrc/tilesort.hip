@@ -27,6 +27,13 @@
 #ifndef FSGS_SORT_ONE_TIER
 #define FSGS_SORT_ONE_TIER 1
 #endif
+// the one-tier launch's workgroup size and LDS words per tile (larger tiles are sorted in place: slow)
+#ifndef FSGS_SORT_TIER_THREADS
+#define FSGS_SORT_TIER_THREADS 1024
+#endif
+#ifndef FSGS_SORT_TIER_CAP
+#define FSGS_SORT_TIER_CAP 8192
+#endif
 
 namespace fsgs {
 
@@ -799,8 +806,9 @@ int launch_tile_sort_tiers(int T, int n_tiles, int tile_bits, const int32_t *ise
         // few long ones instead of in a launch of their own in front of them: 15 + 31 -> 40 us at config #2.
         // With tens of thousands of buckets (large images, the depth-slab path) the 64 KB of LDS per workgroup would
         // limit the small ones to 2 per CU: there the two tiers stay.
-        if (const int rc = ensure_dynamic_lds<&tile_sort_kernel2<1024, kTsLarge, 0, true>>(kTsLarge * 8)) return rc;
-        hipLaunchKernelGGL((tile_sort_kernel2<1024, kTsLarge, 0, true>), dim3(T), dim3(1024), kTsLarge * 8, s, n_tiles,
+        constexpr int TT = FSGS_SORT_TIER_THREADS, TC = FSGS_SORT_TIER_CAP;
+        if (const int rc = ensure_dynamic_lds<&tile_sort_kernel2<TT, TC, 0, true>>(TC * 8)) return rc;
+        hipLaunchKernelGGL((tile_sort_kernel2<TT, TC, 0, true>), dim3(T), dim3(TT), TC * 8, s, n_tiles,
                            tile_bits, isect_offsets, buckets, payload_sorted, isect_ids_sorted, long_flag, rel_gate);
         return check_launch();
     }
