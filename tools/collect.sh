@@ -10,9 +10,7 @@ export TMPDIR=/tmp
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && cd $ROOT
 timeout 900 python bench.py --config $CFG > $O/bench.json 2> $O/bench.err
-# the profiled runs use the walk the plain run settled on (under the profiler's serialisation the trainer's tuner, which
-# times the forward's two walks, may decide otherwise)
-export FSGS_FWD_WALK=$(python3 -c "import json,sys; d=json.loads(open('$O/bench.json').read().strip().splitlines()[-1]); w=(d.get('fwd_walk') or {}).get('walk'); print('auto' if w is None else w)")
+# (round 5: the forward's walk is fixed — nothing to carry over from the plain run to the profiled ones)
 timeout 900 rocprofv3 --kernel-trace --stats -d $O/trace -o t -- python3 bench.py --config $CFG --no-cpu-baseline --no-dropin "$@" > $O/trace_bench.json 2> $O/trace.err
 python tools/rocpd_summary.py $O/trace/t_results.db > $O/kernel_stats.csv
 for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES"; do
