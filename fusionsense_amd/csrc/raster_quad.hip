@@ -42,7 +42,10 @@ __device__ __forceinline__ void split_backward(int tile_lin, int q, int n_tiles_
     if (!seg_split) return;
     const int n_seg = (n_records + 63) >> 6;
     int split = 0;
-    if (bwd_queue && n_seg > kBwdOwnSegs) {
+    // (a queue that is already full is not asked again: in a dense frame every quadrant qualifies, and tens of thousands
+    // of returning atomics on one word would queue up behind each other)
+    if (bwd_queue && n_seg > kBwdOwnSegs &&
+        __hip_atomic_load(bwd_queue, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < bwd_qcap) {
         const int rest = n_seg - kBwdOwnSegs, groups = (rest + kBwdOwnSegs - 1) / kBwdOwnSegs;
         const int slot = atomicAdd(bwd_queue, groups);
         if (slot + groups <= bwd_qcap) {

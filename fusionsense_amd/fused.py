@@ -357,7 +357,9 @@ class _FusedGetOutputs(torch.autograd.Function):
         # partial image maxima: zeroed by the pack kernel, raised by the forward — and behind them, zeroed by the same
         # kernel, the queue of the backward's extra workgroups (a counter + BWD_QUEUE_ITEMS int4 items: fsgs.h, seg_split)
         max_last = torch.empty(n_cells + 4 + 4 * BWD_QUEUE_ITEMS + 4, **f32)
-        bwd_queue = max_last[n_cells:n_cells + 4 + 4 * BWD_QUEUE_ITEMS].view(torch.int32) if BWD_QUEUE_ITEMS > 0 else None
+        # (dense scenes, N >= 2^20: every quadrant's stream is long and every SIMD busy — measured: nothing gained)
+        bwd_queue = (max_last[n_cells:n_cells + 4 + 4 * BWD_QUEUE_ITEMS].view(torch.int32)
+                     if (BWD_QUEUE_ITEMS > 0 and N < FWD_WALK.handoff_max_n) else None)
         # ... and the frame statistic that gates the forward's hand-off (set by the in-tile sort: fsgs_bin_live_emit)
         long_flag = max_last[n_cells + 4 + 4 * BWD_QUEUE_ITEMS:].view(torch.int32)
         # the SH colours + packing ride in the binning's scan launch when nothing stands between them and the

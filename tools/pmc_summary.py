@@ -81,7 +81,10 @@ def main():
         n = max(t.get("n", 1), 1)
         # tile_sort: 6 launches per call, 5 different symbols -> calls = launches of the histogram kernel
         if span == "tile_sort":
-            n = max(len(d.get("FETCH_SIZE", d.get("WRITE_SIZE", []))) for k, d in acc.items() if "tile_offsets_kernel" in k)
+            # (one of these runs once per frame: the offsets kernel until round 4, the bucket fill since)
+            per_frame = [len(d.get("FETCH_SIZE", d.get("WRITE_SIZE", []))) for k, d in acc.items()
+                         if "tile_offsets_kernel" in k or "isect_live_bin_kernel<true" in k or "tile_scatter_kernel" in k]
+            n = max(per_frame) if per_frame else n
         fetch_b = 2.0 * t["fetch_kb"] * 1024.0 / n
         write_b = t["write_kb"] * 1024.0 / n
         out[span] = {"fetch_bytes_per_launch": round(fetch_b), "write_bytes_per_launch": round(write_b),
