@@ -7,6 +7,7 @@
 #include "adam_body.h"
 #include <cstdlib>
 #include "cull.h"
+#include "tile_scan.h"
 #include "project_math.h"
 #include "scan.h"
 
@@ -385,9 +386,13 @@ struct BinProjArgs {
     // count pass only (nullable): a word the first workgroup zeroes — the ticket of the scan launch that follows
     // (scan_rows_sh_pack_kernel: the last scan workgroup to arrive forms isect_offsets)
     int32_t *zero_word;
+    // FUSED (count-free route, fsgs_project_bin_live_fill_sh_pack): fill_base[t] .. [t + 1] = tile t's bucket in
+    // `buckets` (room from the view's previous frame), fill_cursor[t] = words claimed in it so far (zero on entry)
+    const int32_t *fill_base;
+    int32_t *fill_cursor;
 };
 
-template <bool SCATTER, bool MULTI, bool PROJ, bool HALF, int BT>
+template <bool SCATTER, bool MULTI, bool PROJ, bool HALF, int BT, bool FUSED = false>
 __device__ __forceinline__ void
 isect_live_bin_body(const int block, int C, int N, const float *__restrict__ means2d, const int32_t *__restrict__ radii,
                     const float *__restrict__ depths, const float *__restrict__ conics,
@@ -546,6 +551,8 @@ isect_live_bin_body(const int block, int C, int N, const float *__restrict__ mea
     const int per = (wg_total + kBinThreads - 1) / kBinThreads;
     int p = tid * per;
     const int p_end = min(p + per, wg_total);
+    unsigned long long mask_lo = 0ull, mask_hi = 0ull;  // (FUSED) the reach masks of this thread's pairs, 4 bits each
+    const int p_first = p;
     if (p < p_end) {
         // owner = last Gaussian whose exclusive prefix is <= p (empty rectangles share the prefix of the
         // next non-empty one, so "last" skips them)
@@ -567,6 +574,10 @@ isect_live_bin_body(const int block, int C, int N, const float *__restrict__ mea
             // (occlusion cut, one camera: a pair behind its tile's cut depth is not binned)
             const bool cut = zc && z_o > zc[y * tw + x];
             const unsigned m = cut ? 0u : quadrant_mask(cp, (float)(x * 16), (float)(y * 16));
+            if (FUSED) {  // (the second walk reads the masks back: a 128-bit shift register, no indexed registers)
+                mask_hi = (mask_hi << 4) | (mask_lo >> 60);
+                mask_lo = (mask_lo << 4) | (unsigned long long)m;
+            }
             if (m) {
                 const int64_t gidx = idx0 + o;
                 const int c = (C == 1) ? 0 : (int)(gidx / N);
@@ -590,8 +601,66 @@ isect_live_bin_body(const int block, int C, int N, const float *__restrict__ mea
             }
         }
     }
+    if (FUSED) {
+        // ---- count-free route: claim room in every touched tile's bucket, then walk the same pairs again and fill ----
+        // (one returning atomic per (workgroup, touched tile) — ~400 per workgroup of 1024 Gaussians — instead of the
+        // [workgroup][tile] table, its column scan and the second launch's re-enumeration)
+        constexpr int kNoRoom = 0x40000000;
+        __syncthreads();  // every pair of the workgroup is counted
+        for (int t = tid; t < T; t += kBinThreads) {
+            const int c = slots[t];
+            int sl = kNoRoom;
+            if (c > 0) {
+                const int start = atomicAdd(&pj.fill_cursor[t], c);
+                const int b0 = pj.fill_base[t];
+                if (start + c <= pj.fill_base[t + 1] - b0) sl = b0 + start;  // (else: the frame is redone, see fsgs.h)
+            }
+            slots[t] = sl;
+        }
+        __syncthreads();
+        p = p_first;
+        if (p < p_end) {
+            const int n_mine = p_end - p_first;
+            const bool stored = n_mine <= 32;  // (else the masks did not fit: evaluated again)
+            int o = 0;
+#pragma unroll
+            for (int step = kBinThreads / 2; step >= 1; step >>= 1) {
+                const int mid = o + step;
+                if (L.excl[mid] <= p) o = mid;
+            }
+            int4 rc = L.rect[o];
+            float4 A = L.a[o], B = L.b[o];
+            int jj = p - L.excl[o];
+            int y = rc.y + jj / rc.z, x = rc.x + jj % rc.z;
+            for (int k = 0; p < p_end; ++p, ++k) {
+                unsigned m;
+                if (stored) {
+                    const int pos = 4 * (n_mine - 1 - k);
+                    m = (unsigned)((pos < 64 ? (mask_lo >> pos) : (mask_hi >> (pos - 64))) & 0xFull);
+                } else {
+                    const CullPrep cp = {A.x, A.y, A.z, A.w, B.x, B.y, B.z, B.w};
+                    m = quadrant_mask(cp, (float)(x * 16), (float)(y * 16));
+                }
+                if (m) {
+                    const int64_t gidx = idx0 + o;
+                    const int slot = atomicAdd(&slots[y * tw + x], 1);
+                    if (slot < bucket_cap)
+                        buckets[slot] = ((uint64_t)L.depth[o] << 32) | ((uint64_t)(uint32_t)gidx << 4) | (uint64_t)m;
+                }
+                if (++jj == rc.w) {
+                    if (p + 1 < p_end) {
+                        do { ++o; } while (L.rect[o].w == 0);
+                        rc = L.rect[o]; A = L.a[o]; B = L.b[o];
+                        jj = 0; x = rc.x; y = rc.y;
+                    }
+                } else if (++x == rc.x + rc.z) {
+                    x = rc.x; ++y;
+                }
+            }
+        }
+    }
     }  // chunks
-    if (!SCATTER) {
+    if (!SCATTER && !FUSED) {
         __syncthreads();
         for (int t = tid; t < T; t += kBinThreads) table[(int64_t)block * T + t] = slots[t];
     }
@@ -608,6 +677,16 @@ isect_live_bin_kernel(int C, int N, const float *__restrict__ means2d, const int
     isect_live_bin_body<SCATTER, MULTI, PROJ, HALF, BT>(blockIdx.x, C, N, means2d, radii, depths, conics, opacities, tw, th,
                                                         T, nb, chunks, tiles_per_gauss, table, offsets, buckets, pj,
                                                         bucket_cap);
+}
+
+// the count-free route's one binning launch (FUSED): project, count, claim, fill
+template <bool HALF, int BT>
+__global__ void __launch_bounds__(BT)
+isect_live_bin_fill_kernel(int N, int tw, int th, int T, int nb, int32_t *__restrict__ tiles_per_gauss,
+                           uint64_t *__restrict__ buckets, BinProjArgs pj, int bucket_cap) {
+    isect_live_bin_body<false, false, true, HALF, BT, true>(blockIdx.x, 1, N, nullptr, nullptr, nullptr, nullptr, nullptr, tw,
+                                                            th, T, nb, 1, tiles_per_gauss, nullptr, nullptr, buckets, pj,
+                                                            bucket_cap);
 }
 
 #ifndef FSGS_RIDE_ADAM_UNROLL
@@ -800,10 +879,10 @@ int launch_tile_scan_rows_offsets(int T, int nb, int32_t *table, int32_t *totals
                                   int32_t *total_mapped, hipStream_t s);
 int launch_tile_offsets(int T, const int32_t *totals, int32_t *isect_offsets, int32_t *total_mapped, hipStream_t s);
 int launch_scan_rows_sh_pack(int T, int nb, int32_t *table, int32_t *totals, const ShPackRider &r, hipStream_t s,
-                             int32_t *ticket, int32_t *isect_offsets, int32_t *total_mapped);
+                             int32_t *ticket, int32_t *isect_offsets, int32_t *total_mapped, const BucketBook &bk);
 int launch_tile_sort_tiers(int T, int n_tiles, int tile_bits, const int32_t *isect_offsets, uint64_t *buckets,
                            int32_t *payload_sorted, int64_t *isect_ids_sorted, hipStream_t s, int32_t *long_flag = nullptr,
-                           int rel_gate = 0);
+                           int rel_gate = 0, const int32_t *src_offsets = nullptr);
 int launch_split_sort(int T, int n_tiles, int tile_bits, const int32_t *isect_offsets, int64_t n_live,
                       const uint64_t *buckets, uint64_t *buckets2, int32_t *scratch, int32_t *payload_sorted,
                       hipStream_t s);
@@ -981,7 +1060,7 @@ static int project_bin_live_count_impl(int N, const float *means, const void *qu
     BinProjArgs pj = {means, quats, log_scales, viewmat, K, opac_logit, scales_out, opac_out, means2d, depths,
                       conics, radii, width, height, binarise, eps2d, near_plane, far_plane, radius_clip,
                       binary_threshold, reinterpret_cast<__half *>(opac_logit_h), attr_half, nullptr, 0, 0, 0, nullptr,
-                      nullptr};
+                      nullptr, nullptr, nullptr};
     size_t extra_lds = 0;
     bin_place_zcut(pj, tile_zcut, tile_width, tile_height, T, total, extra_lds);
     pj.kept = kept;
@@ -1010,7 +1089,8 @@ static int project_bin_live_count_impl(int N, const float *means, const void *qu
 #undef FSGS_BIN_PCOUNT
     if (rc != FSGS_OK) return rc;
     if (rider)  // the table scan, the SH forward + packing AND the offsets in one launch (sh.hip)
-        return launch_scan_rows_sh_pack(T, nb, table, totals, *rider, s, ticket, isect_offsets, n_live_mapped);
+        return launch_scan_rows_sh_pack(T, nb, table, totals, *rider, s, ticket, isect_offsets, n_live_mapped,
+                                        BucketBook{nullptr, nullptr, nullptr, 0.f, 0});
     return launch_tile_scan_rows_offsets(T, nb, table, totals, isect_offsets, n_live_mapped, s);
 }
 
@@ -1158,6 +1238,85 @@ static int bin_live_emit_impl(int C, int N, const float *means2d, const int32_t 
                                   payload_sorted, nullptr, s, long_flag, rel_gate);
 }
 
+
+// ---- count-free binning (round 5): ONE enumeration instead of two ----------------------------------------------------
+// fsgs_project_bin_live_count_sh_pack + fsgs_bin_live_emit enumerate every (Gaussian, tile) pair twice — once to count
+// per tile, once to fill — with a [workgroup][tile] table, its column scan and the offsets in between.  When the caller
+// knows how much room every tile's bucket needs (it does: the same VIEW's previous frame, plus a margin), the pairs can
+// be dropped into buckets with room to spare in ONE pass: a workgroup projects its 1024 Gaussians, counts its live pairs
+// per tile in LDS, claims that many words in every touched bucket with one returning atomic per tile, and walks the same
+// pairs again (their reach masks kept in two registers) to fill.  The SH / packing launch follows with ONE extra
+// workgroup that turns the claimed counts into isect_offsets (exact, compact), the NEXT frame's bucket bases and the
+// verdict: n_live_mapped[3] = 1 if a tile outgrew its bucket — then the frame must be redone through the exact two-pass
+// route (nothing else has consumed the lists yet: the caller looks before the backward, as it does for the capacity).
+// fsgs_bin_live_sort_buckets then sorts every bucket from its place in `buckets` into the compact payload list.
+//   bucket_base [T + 1] i32 (in): bucket_base[T] <= bucket_words; tile_cursor [T] i32: zero on entry, zero on return;
+//   next_bucket_base [T + 1] i32 (out): exclusive sums of  count * growth + slack.
+// One camera, N such that a workgroup takes one chunk (N <= 1024 x 65535), no occlusion cuts (dense scenes keep the
+// two-pass route), fp32 attributes.  Lists are bit-identical to the two-pass route's (the in-tile sort orders them).
+extern "C" int fsgs_project_bin_live_fill_sh_pack(
+    int N, const float *means, const float *quats, const float *log_scales, float *opac_logit, int binarise,
+    float binary_threshold, const float *viewmat, const float *K, int width, int height, float eps2d, float near_plane,
+    float far_plane, float radius_clip, float *scales_out, float *opac_out, int32_t *radii, float *means2d,
+    float *depths, float *conics, int tile_width, int tile_height, int32_t *tiles_per_gauss, int32_t *isect_offsets,
+    const int32_t *bucket_base, int32_t *tile_cursor, void *buckets, int64_t bucket_words, int32_t *next_bucket_base,
+    float growth, int slack, int32_t *n_live_mapped, int degree, const float *campos, const float *features_dc,
+    const float *features_rest, const float *c2w, float *packed, float *normals_world, float *zero_cells, int n_zero,
+    fsgs_stream_t stream) {
+    if (N < 1 || tile_width < 1 || tile_height < 1 || !isect_offsets || !bucket_base || !tile_cursor || !buckets ||
+        !next_bucket_base || bucket_words < 1 || bucket_words >= 0x40000000ll || growth < 1.f || slack < 0)
+        return FSGS_EINVAL;
+    const int64_t T64 = (int64_t)tile_width * tile_height;
+    if (T64 > fsgs_bin_live_max_tiles()) return FSGS_EINVAL;
+    const int T = (int)T64;
+    if (!means || !quats || !log_scales || !opac_logit || !viewmat || !K || !scales_out || !opac_out || !radii ||
+        !means2d || !depths || !conics || !campos || !features_dc || !features_rest || !c2w || !packed || !normals_world ||
+        degree < 0 || degree > 3)
+        return FSGS_EINVAL;
+    const int64_t total = N;
+    if (bin_chunks(total) != 1) return FSGS_EINVAL;
+    hipStream_t s = as_stream(stream);
+    const int nb = (int)bin_blocks(total);
+    BinProjArgs pj = {means, quats, log_scales, viewmat, K, opac_logit, scales_out, opac_out, means2d, depths,
+                      conics, radii, width, height, binarise, eps2d, near_plane, far_plane, radius_clip,
+                      binary_threshold, nullptr, 0, nullptr, 0, 0, 0, nullptr, nullptr, bucket_base, tile_cursor};
+    const size_t need = bin_lds_bytes(T, total);
+    uint64_t *bk = reinterpret_cast<uint64_t *>(buckets);
+#define FSGS_BIN_FILL(BT)                                                                                              \
+    do {                                                                                                               \
+        if (const int rc = ensure_dynamic_lds<&isect_live_bin_fill_kernel<false, BT>>(need)) return rc;                \
+        hipLaunchKernelGGL((isect_live_bin_fill_kernel<false, BT>), dim3(nb), dim3(BT), need, s, N, tile_width,         \
+                           tile_height, T, nb, tiles_per_gauss, bk, pj, (int)bucket_words);                             \
+    } while (0)
+    switch (bin_threads(total)) {
+    case 1024: FSGS_BIN_FILL(1024); break;
+    case 512: FSGS_BIN_FILL(512); break;
+    default: FSGS_BIN_FILL(256); break;
+    }
+#undef FSGS_BIN_FILL
+    int rc = check_launch();
+    if (rc != FSGS_OK) return rc;
+    const ShPackRider r = {N, degree, 0, means, campos, features_dc, features_rest, radii, depths, means2d, conics,
+                           opac_out, quats, log_scales, c2w, packed, normals_world, zero_cells, n_zero, nullptr};
+    return launch_scan_rows_sh_pack(T, nb, nullptr, nullptr, r, s, nullptr, isect_offsets, n_live_mapped,
+                                    BucketBook{tile_cursor, bucket_base, next_bucket_base, growth, slack});
+}
+
+// the in-tile sorts of the count-free route: bucket t = `buckets`[bucket_base[t] ..) with isect_offsets[t + 1] -
+// isect_offsets[t] words -> payload_sorted[isect_offsets[t] ..)  (long_flag / rel_gate as in fsgs_bin_live_emit)
+extern "C" int fsgs_bin_live_sort_buckets(int tile_width, int tile_height, const int32_t *isect_offsets,
+                                          const int32_t *bucket_base, void *buckets, int32_t *payload_sorted,
+                                          int32_t *long_flag, int rel_gate, fsgs_stream_t stream) {
+    if (tile_width < 1 || tile_height < 1 || !isect_offsets || !bucket_base || !buckets || !payload_sorted || rel_gate < 0)
+        return FSGS_EINVAL;
+    const int n_tiles = tile_width * tile_height;
+    if (n_tiles > fsgs_bin_live_max_tiles()) return FSGS_EINVAL;
+    int tb = 0;
+    while ((1ll << tb) <= n_tiles) ++tb;
+    if (tb < 1) tb = 1;
+    return launch_tile_sort_tiers(n_tiles, n_tiles, tb, isect_offsets, reinterpret_cast<uint64_t *>(buckets),
+                                  payload_sorted, nullptr, as_stream(stream), long_flag, rel_gate, bucket_base);
+}
 
 // ---- occlusion cut: next frame's tile cuts from this frame's walk, and the verdict on this frame's own cuts --------
 // One 64-thread workgroup per tile.  tile_open[t] != 0: some pixel of the tile was still transparent when its list

@@ -1453,8 +1453,12 @@ scan_rows_sh_pack_kernel(int T, int nb, int32_t *__restrict__ table, int32_t *__
                          const void *__restrict__ dc, const void *__restrict__ rest,
                          const int32_t *__restrict__ radii, const float *__restrict__ depths, ShPackArgs pk,
                          int32_t *__restrict__ ticket, int32_t *__restrict__ isect_offsets,
-                         int32_t *__restrict__ total_mapped) {
+                         int32_t *__restrict__ total_mapped, BucketBook bk) {
     if ((int)blockIdx.x < n_scan_blocks) {
+        if (bk.cursor) {  // the count-free route: no table to scan — one workgroup does the buckets' bookkeeping
+            bucket_offsets_body256(T, bk.cursor, bk.base, isect_offsets, bk.next_base, bk.growth, bk.slack, total_mapped);
+            return;
+        }
         tile_scan_rows_body(T, nb, table, totals, blockIdx.x);
         if (!ticket) return;
         // the scan workgroup that arrives LAST turns the totals into isect_offsets inside this launch, beside the colour
@@ -1475,19 +1479,19 @@ scan_rows_sh_pack_kernel(int T, int nb, int32_t *__restrict__ table, int32_t *__
 namespace fsgs {
 // (called by the projecting count pass of isect.hip; the arguments are checked there and in sh_pack_rider_ok)
 int launch_scan_rows_sh_pack(int T, int nb, int32_t *table, int32_t *totals, const ShPackRider &r, hipStream_t s,
-                             int32_t *ticket, int32_t *isect_offsets, int32_t *total_mapped) {
+                             int32_t *ticket, int32_t *isect_offsets, int32_t *total_mapped, const BucketBook &bk) {
     ShPackArgs pk = {r.means2d, r.conics, r.opacities, r.quats, r.log_scales, r.c2w, reinterpret_cast<float4 *>(r.packed),
                      r.normals_world, r.zero_cells, r.zero_cells ? r.n_zero : 0, r.kept};
-    const int n_scan = tile_scan_rows_blocks(T);
+    const int n_scan = bk.cursor ? 1 : tile_scan_rows_blocks(T);
     const dim3 grid(n_scan + ceil_div(r.N, 256));
     if (r.attr_half)
         hipLaunchKernelGGL(scan_rows_sh_pack_kernel<true>, grid, dim3(256), 0, s, T, nb, table, totals, n_scan, r.N,
                            r.degree, r.means, r.campos, r.features_dc, r.features_rest, r.radii, r.depths, pk, ticket,
-                           isect_offsets, total_mapped);
+                           isect_offsets, total_mapped, bk);
     else
         hipLaunchKernelGGL(scan_rows_sh_pack_kernel<false>, grid, dim3(256), 0, s, T, nb, table, totals, n_scan, r.N,
                            r.degree, r.means, r.campos, r.features_dc, r.features_rest, r.radii, r.depths, pk, ticket,
-                           isect_offsets, total_mapped);
+                           isect_offsets, total_mapped, bk);
     return check_launch();
 }
 }  // namespace fsgs

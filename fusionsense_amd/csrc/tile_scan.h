@@ -99,4 +99,68 @@ __device__ __forceinline__ void tile_offsets_body256(int T, const int32_t *__res
     }
 }
 
+struct BucketBook {  // (arguments of bucket_offsets_body256; cursor == nullptr: not the count-free route)
+    int32_t *cursor;
+    const int32_t *base;
+    int32_t *next_base;
+    float growth;
+    int slack;
+};
+
+// The count-free binning route's bookkeeping, ONE workgroup of 256 threads (rides in the SH launch as block 0):
+// cursor[t] = the live pairs the fill kernel dropped into tile t's bucket, bucket_base[t] .. [t + 1] = the bucket's room.
+//   isect_offsets[t] = exclusive sum of the counts (clamped to the list capacity, as tile_offsets_kernel does),
+//   next_base[t]     = exclusive sum of  count * growth + slack  — the room the NEXT frame of this view gets,
+//   cursor[t]        = 0 again (this is its last reader in the frame),
+//   total_mapped     = [0] the total, [3] 1 if some tile outgrew its bucket (the frame is redone through the exact
+//                      two-pass route), then [1] = 1.
+__device__ __forceinline__ void bucket_offsets_body256(int T, int32_t *__restrict__ cursor,
+                                                       const int32_t *__restrict__ bucket_base,
+                                                       int32_t *__restrict__ offsets, int32_t *__restrict__ next_base,
+                                                       float growth, int slack, int32_t *__restrict__ total_mapped) {
+    __shared__ int wsum[4], wsum2[4], over_s[4];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int per = (T + 255) / 256;
+    const int i0 = tid * per, i1 = min(i0 + per, T);
+    const int c = total_mapped ? total_mapped[2] : 0;
+    const int cap = c > 0 ? c : 0x7FFFFFFF;
+    int mine = 0, mine2 = 0, over = 0;
+    for (int i = i0; i < i1; ++i) {
+        const int n = cursor[i];
+        over |= (n > bucket_base[i + 1] - bucket_base[i]) ? 1 : 0;
+        mine += n;
+        mine2 += (int)((float)n * growth) + slack;
+    }
+    int inc = mine, inc2 = mine2;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(inc, d, 64), o2 = __shfl_up(inc2, d, 64);
+        if (lane >= d) { inc += o; inc2 += o2; }
+    }
+    over = __any(over) ? 1 : 0;
+    if (lane == 63) { wsum[w] = inc; wsum2[w] = inc2; over_s[w] = over; }
+    __syncthreads();
+    int run = inc - mine, run2 = inc2 - mine2;
+    for (int k = 0; k < w; ++k) { run += wsum[k]; run2 += wsum2[k]; }
+    for (int i = i0; i < i1; ++i) {
+        const int n = cursor[i];
+        offsets[i] = min(run, cap);
+        next_base[i] = run2;
+        run += n;
+        run2 += (int)((float)n * growth) + slack;
+        cursor[i] = 0;
+    }
+    if (tid == 255) {
+        const int total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        offsets[T] = min(total, cap);
+        next_base[T] = wsum2[0] + wsum2[1] + wsum2[2] + wsum2[3];
+        if (total_mapped) {
+            total_mapped[0] = total;
+            total_mapped[3] = over_s[0] | over_s[1] | over_s[2] | over_s[3];
+            __threadfence_system();
+            __hip_atomic_store(&total_mapped[1], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
 }  // namespace fsgs

@@ -238,7 +238,7 @@ template <int THREADS, int CAP, int LO, bool SPILL>
 __device__ __forceinline__ void
 tile_sort_body(uint64_t *sk, const int tile_lin, int n_tiles, int tile_bits, const int32_t *__restrict__ offsets,
                uint64_t *__restrict__ buckets, int32_t *__restrict__ payload_out, int64_t *__restrict__ isect_ids_out,
-               const int32_t *__restrict__ ends = nullptr) {
+               const int32_t *__restrict__ ends = nullptr, const int32_t *__restrict__ src_offsets = nullptr) {
     // (ends: explicit end of every bucket, for bucket lists with gaps between consecutive entries)
     const int s = offsets[tile_lin], e = ends ? ends[tile_lin] : offsets[tile_lin + 1];
     const int n = e - s;
@@ -248,7 +248,9 @@ tile_sort_body(uint64_t *sk, const int tile_lin, int n_tiles, int tile_bits, con
     while (np < n) np <<= 1;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     constexpr int NW = THREADS / 64;
-    uint64_t *g = buckets + s;
+    // (src_offsets: the bucket's words lie at another place than the sorted list goes to — buckets with room to spare,
+    // filled without a count pass: fsgs_project_bin_live_fill_sh_pack)
+    uint64_t *g = buckets + (src_offsets ? src_offsets[tile_lin] : s);
     auto ld = [&](int i) -> uint64_t {
         return in_lds ? sk[i] : __hip_atomic_load(&g[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
@@ -343,7 +345,7 @@ template <int THREADS, int CAP, int LO, bool SPILL>
 __global__ void __launch_bounds__(THREADS)
 tile_sort_kernel2(int n_tiles, int tile_bits, const int32_t *__restrict__ offsets, uint64_t *__restrict__ buckets,
                   int32_t *__restrict__ payload_out, int64_t *__restrict__ isect_ids_out,
-                  int32_t *__restrict__ long_flag, int rel_gate) {
+                  int32_t *__restrict__ long_flag, int rel_gate, const int32_t *__restrict__ src_offsets) {
     extern __shared__ __attribute__((aligned(16))) uint64_t sk[];
     // (frame statistic for the forward's hand-off, fsgs_bin_live_emit: does ANY tile hold a list of more than rel_gate
     // times the mean length?  The caller zeroes the word; every writer writes the same 1.)
@@ -352,7 +354,7 @@ tile_sort_kernel2(int n_tiles, int tile_bits, const int32_t *__restrict__ offset
         if (n > 0 && (int64_t)n * (int)gridDim.x > (int64_t)rel_gate * offsets[gridDim.x]) *long_flag = 1;
     }
     tile_sort_body<THREADS, CAP, LO, SPILL>(sk, blockIdx.x, n_tiles, tile_bits, offsets, buckets, payload_out,
-                                            isect_ids_out);
+                                            isect_ids_out, nullptr, src_offsets);
 }
 
 // (Round 4, measured and removed: one WAVE per bucket of up to 1024 words — 1 / 2 / 4 / 8 blocks of 128 per lane pair,
@@ -754,7 +756,7 @@ slab_split_sort_lds_kernel(const int32_t *__restrict__ n_sub, const int32_t *__r
 
 int launch_tile_sort_tiers(int T, int n_tiles, int tile_bits, const int32_t *isect_offsets, uint64_t *buckets,
                            int32_t *payload_sorted, int64_t *isect_ids_sorted, hipStream_t s,
-                           int32_t *long_flag = nullptr, int rel_gate = 0);
+                           int32_t *long_flag = nullptr, int rel_gate = 0, const int32_t *src_offsets = nullptr);
 
 // buckets -> (split by depth where large) buckets2 -> sorted payload.  scratch: [sub_base i32: T + 1][sub_offsets i32: max_sub + 1]
 // lds_cap > 0: tiles of up to lds_cap words have been sorted by tile_split_sort_lds_kernel and yield no sub-buckets here.
@@ -797,7 +799,7 @@ int64_t split_scratch_ints(int T, int64_t n_live) { return (int64_t)(T + 1) + 2 
 
 int launch_tile_sort_tiers(int T, int n_tiles, int tile_bits, const int32_t *isect_offsets, uint64_t *buckets,
                            int32_t *payload_sorted, int64_t *isect_ids_sorted, hipStream_t s, int32_t *long_flag,
-                           int rel_gate) {
+                           int rel_gate, const int32_t *src_offsets) {
     if (const int rc = ensure_dynamic_lds<&tile_sort_kernel2<1024, kTsLarge, kTsSmall, true>>(kTsLarge * 8)) return rc;
     constexpr int one_tier = FSGS_SORT_ONE_TIER;  // (build macro)
     if (one_tier && T <= 8192) {
@@ -809,14 +811,17 @@ int launch_tile_sort_tiers(int T, int n_tiles, int tile_bits, const int32_t *ise
         constexpr int TT = FSGS_SORT_TIER_THREADS, TC = FSGS_SORT_TIER_CAP;
         if (const int rc = ensure_dynamic_lds<&tile_sort_kernel2<TT, TC, 0, true>>(TC * 8)) return rc;
         hipLaunchKernelGGL((tile_sort_kernel2<TT, TC, 0, true>), dim3(T), dim3(TT), TC * 8, s, n_tiles,
-                           tile_bits, isect_offsets, buckets, payload_sorted, isect_ids_sorted, long_flag, rel_gate);
+                           tile_bits, isect_offsets, buckets, payload_sorted, isect_ids_sorted, long_flag, rel_gate,
+                           src_offsets);
         return check_launch();
     }
     // two size tiers, each skipping the tiles of the other (an early-out workgroup costs ~2 ns)
     hipLaunchKernelGGL((tile_sort_kernel2<256, kTsSmall, 0, false>), dim3(T), dim3(256), kTsSmall * 8, s, n_tiles,
-                       tile_bits, isect_offsets, buckets, payload_sorted, isect_ids_sorted, long_flag, rel_gate);
+                       tile_bits, isect_offsets, buckets, payload_sorted, isect_ids_sorted, long_flag, rel_gate,
+                       src_offsets);
     hipLaunchKernelGGL((tile_sort_kernel2<1024, kTsLarge, kTsSmall, true>), dim3(T), dim3(1024), kTsLarge * 8, s,
-                       n_tiles, tile_bits, isect_offsets, buckets, payload_sorted, isect_ids_sorted, (int32_t *)nullptr, 0);
+                       n_tiles, tile_bits, isect_offsets, buckets, payload_sorted, isect_ids_sorted, (int32_t *)nullptr, 0,
+                       src_offsets);
     return check_launch();
 }
 

@@ -68,6 +68,12 @@ class FrameInfo:
         # waiting for the frame's count; ``pending_count`` is then checked by the caller once the forward's launches
         # are enqueued (ops.bin_live_check), ``n_live`` is the true total after that check
         self.live_capacity = 0
+        # count-free binning (ops.project_bin_live_fill_async): the view's bucket bases from its previous frame
+        # ({"base": int32 [T + 1], "n_live": pairs of that frame} or None), whether this frame should leave the bases for
+        # the next one, and where it leaves them ({"base": ...}; the caller adds "n_live" once it knows it)
+        self.bin_hist_in: Optional[dict] = None
+        self.bin_hist_want = False
+        self.bin_hist_out: Optional[dict] = None
         self.pending_count = None
         self.n_live: Optional[int] = None
         # the forward compositing's walk this frame used (fsgs_raster_fwd_quad's ``walk``; FWD_WALK)
@@ -155,6 +161,10 @@ IMAGE_GRADS_IN_BWD = os.environ.get("FSGS_IMAGE_GRADS_IN_BWD", "1") != "0"
 # queue positions for the backward's extra workgroups (groups of 8 segments of streams longer than 8 segments: fsgs.h,
 # seg_split / bwd_queue); 0 = every quadrant's stream is walked by its own workgroup alone (round 4)
 BWD_QUEUE_ITEMS = 1024
+# count-free binning of revisited views (ops.project_bin_live_fill_async; fsgs.h): on / off, and the model size from which
+# the dense machinery (occlusion cuts, several chunks per workgroup) keeps the two-pass route
+BIN_FILL = True
+BIN_FILL_MAX_N = 1 << 20
 # from this many Gaussians on, the per-Gaussian backward fetches SH coefficients lazily / skips idle Adam elements
 # (flags of fsgs_gauss_sh_bwd*, decided here per launch; module attributes so that tests can move them)
 LAZY_SH_MIN_N = int(os.environ.get("FSGS_LAZY_SH_MIN_N", str(1 << 20)))
@@ -379,11 +389,21 @@ class _FusedGetOutputs(torch.autograd.Function):
                 rider = (sh_degree, cam["campos"], hm["features_dc"] if hm is not None else features_dc,
                          hm["features_rest"] if hm is not None else features_rest, cam["c2w"], packed, normals_world,
                          max_last)
-            count = ops.project_bin_live_count_async(
-                means, quats, scales, opacities, bthr, cam["viewmat"], cam["K"], W, H, tw, th,
-                dict(scales_exp=scales_exp, opac_sig=opac_sig, radii=radii, means2d=means2d, depths=depths,
-                     conics=conics), half=hm, capacity=int(info.live_capacity), sh_pack=rider,
-                adam=info.adam_rider.groups if adam_rides else None, zcut=info.zcut_in, kept=kept)
+            proj_out = dict(scales_exp=scales_exp, opac_sig=opac_sig, radii=radii, means2d=means2d, depths=depths,
+                            conics=conics)
+            hist = info.bin_hist_in
+            use_fill = (BIN_FILL and sh_rides and hist is not None and int(info.live_capacity) > 0 and hm is None
+                        and kept is None and info.zcut_in is None and not adam_rides and N < BIN_FILL_MAX_N
+                        and hist["base"].numel() == tw * th + 1)
+            if use_fill:
+                # ONE enumeration: the pairs go straight into buckets sized from this view's previous frame
+                count = ops.project_bin_live_fill_async(means, quats, scales, opacities, bthr, cam["viewmat"], cam["K"],
+                                                        W, H, tw, th, proj_out, int(info.live_capacity), rider, hist)
+            else:
+                count = ops.project_bin_live_count_async(
+                    means, quats, scales, opacities, bthr, cam["viewmat"], cam["K"], W, H, tw, th, proj_out, half=hm,
+                    capacity=int(info.live_capacity), sh_pack=rider,
+                    adam=info.adam_rider.groups if adam_rides else None, zcut=info.zcut_in, kept=kept)
             if adam_rides:
                 info.adam_rider.consumed()
                 info.adam_rider = None
@@ -435,6 +455,12 @@ class _FusedGetOutputs(torch.autograd.Function):
         if pre_sh is not None:
             pre_sh()
             colours_and_packing()
+        if info.bin_hist_want and direct_bins and BIN_FILL and N < BIN_FILL_MAX_N and count.get("direct"):
+            # the room every tile's bucket gets in this view's next frame
+            if count.get("fill"):
+                info.bin_hist_out = {"base": count["next_base"]}
+            elif count["offsets"].numel() == tw * th + 1 and hm is None and info.zcut_in is None:
+                info.bin_hist_out = {"base": ops.bin_fill_history_from_offsets(count["offsets"], tw * th)}
         rule_diff = 0
         M = flatten_ids.numel()
         no_wait = direct_bins and count.get("capacity", 0) > 0  # M is then the capacity, offsets has T + 1 entries
@@ -742,7 +768,8 @@ def fused_step_forward_backward(gauss_params: Dict[str, Tensor], camera: Camera,
                                 w_depth: float = 0.2, w_normal: float = 0.1, pre_sh=None, adam_rider=None, sh_factors_out=None,
                                 fusion=None, half: Optional[Dict[str, Tensor]] = None, live_capacity: int = 0,
                                 zcut_in: Optional[Tensor] = None, zcut_out: Optional[Tensor] = None,
-                                zcut_margins=None, adam_in_backward=None):
+                                zcut_margins=None, adam_in_backward=None, bin_hist: Optional[dict] = None,
+                                want_bin_hist: bool = False):
     """get_outputs -> loss -> both backward passes, without the autograd tape.  The parameter gradients land in
     ``grad_out`` (the trainer's slab views).  Returns (loss 0-d tensor, outputs dict).
     ``target`` is either the benchmark targets of BASELINE config #2 (dict rgb / depth / normal: L1 + SSIM on rgb,
@@ -763,6 +790,7 @@ def fused_step_forward_backward(gauss_params: Dict[str, Tensor], camera: Camera,
     info.live_capacity = int(live_capacity)
     info.zcut_in, info.zcut_out = zcut_in, zcut_out
     info.adam_in_backward = adam_in_backward
+    info.bin_hist_in, info.bin_hist_want = bin_hist, bool(want_bin_hist)
     if zcut_margins is not None:
         info.zcut_margins = zcut_margins
 

@@ -309,6 +309,7 @@ def _pinned_i32(dev) -> Tensor:
     buf = ring["bufs"][ring["i"]]
     buf._np[1] = 0
     buf._np[2] = 0  # no capacity: the offsets are exact
+    buf._np[3] = 0  # (count-free binning: "a tile outgrew its bucket")
     return buf
 
 
@@ -429,6 +430,65 @@ def project_bin_live_count_async(means: Tensor, quats: Tensor, log_scales: Tenso
     return dict(direct=True, tpg=tpg, offsets=offsets, table=table, pinned=pinned, event=ev, T=T, capacity=capacity)
 
 
+# ---- count-free binning (fsgs_project_bin_live_fill_sh_pack): one enumeration of the pairs instead of two ------------
+# A view's frame tells how much room every tile's bucket needs in the view's NEXT frame: count * growth + slack words.
+BIN_FILL_GROWTH, BIN_FILL_SLACK = 1.25, 64
+_BIN_CURSORS: dict = {}  # (device, T) -> int32 [T], zeroed once: the route's own bookkeeping leaves it zeroed
+
+
+def bin_fill_history_from_offsets(offsets: Tensor, T: int) -> Tensor:
+    """bucket bases [T + 1] for the next frame of a view from this frame's EXACT isect_offsets (a frame that went
+    through the two-pass route: a view's first visit, a redone frame) — the arithmetic of tile_scan.h:
+    bucket_offsets_body256.  A few torch launches, on such frames only."""
+    cnt = (offsets[1:T + 1] - offsets[:T]).to(torch.float32)
+    room = (cnt * BIN_FILL_GROWTH).to(torch.int32) + BIN_FILL_SLACK
+    base = torch.zeros(T + 1, dtype=torch.int32, device=offsets.device)
+    base[1:] = torch.cumsum(room, 0)
+    return base
+
+
+def bin_fill_words(n_live_prev: int, T: int) -> int:
+    """An upper bound, known on the host, of bucket_base[T] made from a frame of ``n_live_prev`` live pairs."""
+    return int(BIN_FILL_GROWTH * n_live_prev) + (BIN_FILL_SLACK + 1) * T + 64
+
+
+def project_bin_live_fill_async(means: Tensor, quats: Tensor, log_scales: Tensor, opac_logit: Tensor, binary_threshold,
+                                viewmat: Tensor, K: Tensor, width: int, height: int, tile_width: int, tile_height: int,
+                                out: dict, capacity: int, sh_pack: tuple, hist: dict) -> dict:
+    """The count-free route's first call (one camera, fp32, no cuts): projection + ONE enumeration that fills buckets
+    sized from ``hist`` (base [T + 1] int32 of the view's previous frame, n_live = that frame's live pairs) + the SH /
+    packing launch with the bookkeeping workgroup.  Returns the state bin_live_finish / bin_live_check take."""
+    lib = load()
+    dev = means.device
+    N = means.shape[0]
+    T = tile_width * tile_height
+    assert capacity > 0 and hist["base"].numel() == T + 1
+    tpg = torch.empty(1, N, dtype=torch.int32, device=dev)
+    offsets = torch.empty(T + 1, dtype=torch.int32, device=dev)
+    next_base = torch.empty(T + 1, dtype=torch.int32, device=dev)
+    cursor = _BIN_CURSORS.get((str(dev), T))
+    if cursor is None:
+        cursor = _BIN_CURSORS[(str(dev), T)] = torch.zeros(T, dtype=torch.int32, device=dev)
+    words = bin_fill_words(int(hist["n_live"]), T)
+    buckets = WORKSPACE.take(8 * words, dev)
+    pinned = _pinned_i32(dev)
+    pinned._np[2] = int(capacity)
+    degree, campos, f_dc, f_rest, c2w, packed, normals_world, zero_cells = sh_pack
+    bt = (0 if binary_threshold is None else 1, 0.0 if binary_threshold is None else float(binary_threshold))
+    _run(lib.fsgs_project_bin_live_fill_sh_pack,
+         (N, ptr(means), ptr(quats), ptr(log_scales), ptr(opac_logit)) + bt
+         + (ptr(viewmat), ptr(K), width, height, 0.3, 0.01, 1e10, 0.0, ptr(out["scales_exp"]), ptr(out["opac_sig"]),
+            ptr(out["radii"]), ptr(out["means2d"]), ptr(out["depths"]), ptr(out["conics"]), tile_width, tile_height,
+            ptr(tpg), ptr(offsets), ptr(hist["base"]), ptr(cursor), ptr(buckets), words, ptr(next_base),
+            float(BIN_FILL_GROWTH), int(BIN_FILL_SLACK), pinned.data_ptr(), int(degree), ptr(campos), ptr(f_dc),
+            ptr(f_rest), ptr(c2w), ptr(packed), ptr(normals_world), ptr(zero_cells), int(zero_cells.numel()),
+            stream_ptr(dev)), "fsgs_isect_count_live")
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(dev))
+    return dict(direct=True, fill=True, tpg=tpg, offsets=offsets, table=None, pinned=pinned, event=ev, T=T,
+                capacity=int(capacity), buckets=buckets, base=hist["base"], next_base=next_base)
+
+
 class LiveListOverflow(RuntimeError):
     """A frame held more live pairs than the capacity its buffers were sized for (no-wait binning): its lists were
     truncated on the device; ``needed`` is the true total."""
@@ -506,6 +566,8 @@ def bin_live_check(st: dict) -> int:
     M = _wait_total(st)
     if st.get("capacity", 0) and M > st["capacity"]:
         raise LiveListOverflow(M, st["capacity"])
+    if st.get("fill") and st["pinned"]._np[3] != 0:  # (count-free route: a tile outgrew its bucket — redo, two passes)
+        raise LiveListOverflow(M, st["capacity"])
     return M
 
 
@@ -521,6 +583,13 @@ def bin_live_finish(st: dict, means2d: Tensor, radii: Tensor, depths: Tensor, co
     # no-wait mode: everything below is sized and launched for the capacity; the true total stays on the device
     # (isect_offsets[T], clamped to the capacity) and the caller checks it later with bin_live_check
     M = st["capacity"] if st.get("capacity", 0) else _wait_total(st)
+    if st.get("fill"):  # count-free route: the buckets are filled, sort each into the compact payload list
+        pay_s = torch.empty(M, dtype=torch.int32, device=dev)
+        _run(lib.fsgs_bin_live_sort_buckets, (tile_width, tile_height, ptr(st["offsets"]), ptr(st["base"]),
+                                              ptr(st["buckets"]), ptr(pay_s), ptr(long_flag), int(rel_gate),
+                                              stream_ptr(dev)), "fsgs_tile_sort")
+        WORKSPACE.give(st["buckets"])
+        return st["tpg"], None, pay_s, st["offsets"]
     dense = not use_tile_sort(M, T)  # mean bucket beyond the LDS tiers
     # (no-wait mode cannot fall back to the list chain, which needs the exact total on the host: dense frames are
     # always split there)

@@ -245,6 +245,8 @@ class SplatTrainer:
         self.zcut_margins = (float(m[0]), float(m[1]), float(m[2]))
         self._zcuts: Dict = {}
         self._zcut_widen: Dict = {}
+        self._bin_hist: Dict = {}   # view -> {"base": bucket bases [T + 1], "n_live": pairs} of its previous frame
+        self._bin_hist_n = -1
         self.zcut_max_views = 1024  # least recently rendered views beyond this are forgotten (T floats each)
         # Adam in the backward: on one rank, when nothing else needs the gradients, the per-Gaussian
         # backward launch applies the step's Adam update itself (fsgs_gauss_sh_bwd_adam) — the 236 B of gradients per
@@ -683,16 +685,23 @@ class SplatTrainer:
                                "(set trainer.adam_in_backward_mode = '0' or FSGS_ADAM_IN_BACKWARD=0 to keep them)")
         return self.slab.views
 
+    @staticmethod
+    def _view_key(camera: Camera):
+        """What identifies a VIEW (pose + intrinsics + size): per-view state — occlusion cuts, bucket room — is kept
+        under it; computed once per camera object."""
+        key = camera.__dict__.get("_view_key")
+        if key is None:
+            key = camera.__dict__["_view_key"] = (camera.c2w.to(torch.float32).cpu().numpy().tobytes(), camera.fx,
+                                                  camera.fy, camera.cx, camera.cy, camera.width, camera.height)
+        return key
+
     def _view_cuts(self, camera: Camera):
         """(key, cuts this view was last rendered with or None, buffer for this frame's cuts) — or (None, None, None)
         when occlusion cuts are off for this model size."""
         mode = self.occlusion_cut_mode
         if mode == "0" or (mode != "1" and self.num_gaussians() < self.occlusion_cut_min_n):
             return None, None, None
-        key = camera.__dict__.get("_view_key")
-        if key is None:
-            key = camera.__dict__["_view_key"] = (camera.c2w.to(torch.float32).cpu().numpy().tobytes(), camera.fx,
-                                                  camera.fy, camera.cx, camera.cy, camera.width, camera.height)
+        key = self._view_key(camera)
         tiles = math.ceil(camera.width / 16) * math.ceil(camera.height / 16)
         zin = self._zcuts.get(key)
         if zin is not None and zin.numel() != tiles:
@@ -742,6 +751,13 @@ class SplatTrainer:
             from .ops import LiveListOverflow
             from .ops import OcclusionCutInvalid
             view_key, zin, zout = self._view_cuts(camera)
+            # count-free binning (fused.BIN_FILL): the room every tile's bucket needs comes from this view's previous
+            # frame; a model that has changed size (densification) starts its views over through the two-pass route
+            bin_key = self._view_key(camera) if (self.no_wait and self.num_gaussians() > 0) else None
+            if self._bin_hist_n != self.num_gaussians():
+                self._bin_hist.clear()
+                self._bin_hist_n = self.num_gaussians()
+            bin_hist = self._bin_hist.get(bin_key) if bin_key is not None else None
             # (frames binned with occlusion cuts hold a fraction of the pairs: their own capacity estimate, or the first
             # uncut frame after them — a new view, a redone frame — would overflow it)
             cap_key = self._live_caps.key(self.device, 1, self.num_gaussians(), camera.width, camera.height,
@@ -765,7 +781,8 @@ class SplatTrainer:
                         half=self.half_mirrors(), live_capacity=cap, zcut_in=zin, zcut_out=zout,
                         zcut_margins=self.zcut_margins if view_key not in self._zcut_widen else tuple(
                             self._zcut_widen[view_key] * x for x in self.zcut_margins[:2]) + self.zcut_margins[2:],
-                        adam_in_backward=aib)
+                        adam_in_backward=aib, bin_hist=bin_hist if cap > 0 else None,
+                        want_bin_hist=bin_key is not None)
                     break
                 except OcclusionCutInvalid:  # a cut tile did not saturate inside its prefix: the exact frame, uncut
                     self.cut_redone += 1
@@ -777,6 +794,8 @@ class SplatTrainer:
                     cap = self._live_caps.get(cap_key) if (self.no_wait and cap > 0) else 0
                 except LiveListOverflow as e:  # rare: the frame outgrew the estimate -> once more, with exact sizes
                     self.live_overflows += 1
+                    self._bin_hist.pop(bin_key, None)  # (or a tile outgrew its bucket: the redone frame leaves new room)
+                    bin_hist = None
                     self._live_caps.raise_to(cap_key, e.needed)
                     cap = 0
                     # the abandoned attempt's count pass has already written the binary opacities (and landed any
@@ -798,6 +817,14 @@ class SplatTrainer:
             n_live = out["info"].n_live
             if n_live is not None and self.no_wait:
                 self._live_caps.update(cap_key, n_live)
+            hist_out = out["info"].bin_hist_out
+            if bin_key is not None:
+                self._bin_hist.pop(bin_key, None)
+                if hist_out is not None and n_live is not None:
+                    hist_out["n_live"] = int(n_live)
+                    self._bin_hist[bin_key] = hist_out  # (most recently used last)
+                    while len(self._bin_hist) > self.zcut_max_views:
+                        del self._bin_hist[next(iter(self._bin_hist))]
             self._factors_used = factors
             if aib is not None and out["info"].adam_applied:
                 # the backward launch has stepped all six groups: count the step, nothing left to launch

@@ -434,6 +434,32 @@ int fsgs_bin_live_emit(int C, int N, const float *means2d, const int32_t *radii,
                        const int32_t *isect_offsets, const void *table_scratch, int64_t n_live, void *buckets,
                        int32_t *payload_sorted, const float *tile_zcut /* nullable; C == 1 */,
                        int32_t *long_flag /* nullable */, int rel_gate, fsgs_stream_t stream);
+/* ---- Count-free binning (round 5): ONE enumeration of the (Gaussian, tile) pairs instead of two.  Replaces, for a view
+ * whose previous frame told how much room every tile's bucket needs, the chain fsgs_project_bin_live_count_sh_pack ->
+ * fsgs_bin_live_emit (same outputs, lists bit for bit; the same reference calls: gsplat 1.0.0 fully_fused_projection +
+ * isect_tiles(sort=True) + isect_offset_encode + spherical_harmonics as reached from dn_model.py:570-591).
+ *   bucket_base [T + 1] i32: tile t's bucket is words bucket_base[t] .. bucket_base[t + 1] of `buckets` (bucket_words
+ *       >= bucket_base[T] 64-bit words); tile_cursor [T] i32, ZERO on entry and zero again on return;
+ *   outputs beside the projection's and the packing's: tiles_per_gauss, isect_offsets [T + 1] (exact and compact; the
+ *       last entry = the number of live pairs, clamped to n_live_mapped[2] like fsgs_bin_live_count's),
+ *       next_bucket_base [T + 1] = exclusive sums of (int)(count * growth) + slack: the room for this view's NEXT frame;
+ *   n_live_mapped (device-accessible host int[4], as for fsgs_bin_live_count): [0] the total, [3] = 1 if some tile
+ *       outgrew its bucket — its surplus pairs were dropped and the caller must redo the frame through the two-pass
+ *       route before anything with side effects has consumed the lists — then [1] = 1.
+ * One camera, fp32 attributes, degree <= 3 with 16 stored coefficients, no occlusion cuts, N <= 1024 x 65535.
+ * fsgs_bin_live_sort_buckets: the in-tile sorts, bucket t -> payload_sorted[isect_offsets[t] ..). */
+int fsgs_project_bin_live_fill_sh_pack(
+    int N, const float *means, const float *quats, const float *log_scales, float *opac_logit, int binarise,
+    float binary_threshold, const float *viewmat, const float *K, int width, int height, float eps2d, float near_plane,
+    float far_plane, float radius_clip, float *scales_out, float *opac_out, int32_t *radii, float *means2d,
+    float *depths, float *conics, int tile_width, int tile_height, int32_t *tiles_per_gauss, int32_t *isect_offsets,
+    const int32_t *bucket_base, int32_t *tile_cursor, void *buckets, int64_t bucket_words, int32_t *next_bucket_base,
+    float growth, int slack, int32_t *n_live_mapped, int degree, const float *campos, const float *features_dc,
+    const float *features_rest, const float *c2w, float *packed, float *normals_world, float *zero_cells, int n_zero,
+    fsgs_stream_t stream);
+int fsgs_bin_live_sort_buckets(int tile_width, int tile_height, const int32_t *isect_offsets,
+                               const int32_t *bucket_base, void *buckets, int32_t *payload_sorted,
+                               int32_t *long_flag /* nullable */, int rel_gate, fsgs_stream_t stream);
 /* long_flag (round 5; a word the caller zeroes): set to 1 if any tile's list is longer than rel_gate times the mean list
  * length — the frame statistic fsgs_raster_fwd_quad's hand-off is gated on (handoff_gate): only frames that HAVE lists far
  * beyond the bulk (config #3's hull tiles: 16 x the mean; config #2's longest list: 5.7 x) queue anything. */

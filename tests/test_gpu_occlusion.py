@@ -625,3 +625,59 @@ def test_backward_extra_workgroups_for_long_streams(dev, monkeypatch):
     for k in PARAM_ORDER:
         assert rel_err(res[("handoff", 1024)]["grads"][k], res[("one", 1024)]["grads"][k]) < 2e-4, k
     assert w.error(dev) == 0
+
+
+@pytest.mark.gpu
+def test_count_free_binning_equals_the_two_pass_route(dev, monkeypatch):
+    """fsgs_project_bin_live_fill_sh_pack (round 5): a revisited view is binned with ONE enumeration of its pairs into
+    buckets sized from the view's previous frame.  Its lists, offsets, images and losses are bit-identical to the
+    two-pass route's (the in-tile sort orders each bucket), frame after frame as the model trains; a view's first visit
+    and a model that changed size go through the two-pass route; a tile that outgrows its bucket (forced: the room
+    shrunk to 1/4) makes the frame be redone exactly, once, with the same results."""
+    from fusionsense_amd import fused, ops
+    from fusionsense_amd.trainer import SplatTrainer
+    params = scenes.lego_like_scene(90_000, seed=12)
+    cams = scenes.hemisphere_cameras(3, width=304, height=208, focal=400.0, seed=12)
+    g = torch.Generator().manual_seed(12)
+    tgts = [{"rgb": torch.rand(208, 304, 3, generator=g).to(dev), "depth": torch.rand(208, 304, 1, generator=g).to(dev) * 4,
+             "normal": torch.rand(208, 304, 3, generator=g).to(dev)} for _ in cams]
+    calls = {"fill": 0, "count": 0}
+    real_fill, real_count = ops.project_bin_live_fill_async, ops.project_bin_live_count_async
+
+    def fill(*a, **k):
+        calls["fill"] += 1
+        return real_fill(*a, **k)
+
+    def count(*a, **k):
+        calls["count"] += 1
+        return real_count(*a, **k)
+    monkeypatch.setattr(ops, "project_bin_live_fill_async", fill)
+    monkeypatch.setattr(ops, "project_bin_live_count_async", count)
+
+    def run(enabled, shrink_at=None):
+        monkeypatch.setattr(fused, "BIN_FILL", enabled)
+        tr = SplatTrainer(params, dev, sh_degree=3, seed=3)
+        seen = []
+        for it in range(12):
+            v = it % 3
+            if shrink_at is not None and it == shrink_at:
+                for h in tr._bin_hist.values():  # every bucket far too small: some tile must outgrow its room
+                    h["base"] = (h["base"].float() * 0.25).to(torch.int32)
+            loss, out = tr.train_step(cams[v], tgts[v])
+            info = out["info"]
+            seen.append((float(loss), out["rgb"].clone(), info.payload[:int(info.n_live)].clone(),
+                         info.isect_offsets.flatten()[:21 * 13].clone(), int(info.n_live)))
+        return tr, seen
+    calls.update(fill=0, count=0)
+    tr_a, a = run(True)
+    assert calls["fill"] >= 8 and calls["count"] >= 3, calls  # first visits: two passes; revisits: one
+    assert tr_a.live_overflows == 0
+    tr_b, b = run(False)
+    tr_c, c = run(True, shrink_at=7)
+    assert tr_c.live_overflows >= 1, "the shrunk buckets must have overflowed"
+    for other in (b, c):
+        for it, (x, y) in enumerate(zip(a, other)):
+            assert x[0] == y[0] and x[4] == y[4], (it, x[0], y[0], x[4], y[4])
+            assert torch.equal(x[1], y[1]) and torch.equal(x[2], y[2]) and torch.equal(x[3], y[3]), it
+    for k in tr_a.params:
+        assert torch.equal(tr_a.params[k].data, tr_b.params[k].data), k
