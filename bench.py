@@ -1022,6 +1022,10 @@ def main():
             "iter_algorithmic_bytes_rect_pairs": b_iter_rect,
             "device_mallocs_in_timed_region": n_alloc,
             "live_list_overflows": int(getattr(trainer, "live_overflows", 0)),  # frames redone (no-wait binning)
+            # frames by binning route over the whole run: "fill" = the count-free route (one enumeration of the pairs into
+            # buckets sized from the view's previous frame), "two_pass" = count + fill (first visits, after densification,
+            # dense scenes, redone frames)
+            "binning_frames": dict(getattr(trainer, "bin_frames", {})),
             # dispatch order of the compositing backward as measured and chosen in this run (fused._BwdDispatchTuner):
             # {"stride": 0 = row-major | k, "medians_ms": per candidate}; null while still measuring / when forced
             "bwd_dispatch": bwd_dispatch_choice(dev, W, H),

@@ -118,17 +118,21 @@ __device__ __forceinline__ void bucket_offsets_body256(int T, int32_t *__restric
                                                        const int32_t *__restrict__ bucket_base,
                                                        int32_t *__restrict__ offsets, int32_t *__restrict__ next_base,
                                                        float growth, int slack, int32_t *__restrict__ total_mapped) {
-    __shared__ int wsum[4], wsum2[4], over_s[4];
+    __shared__ int wsum[4], wsum2[4], over_s[4], tsum[4];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int per = (T + 255) / 256;
     const int i0 = tid * per, i1 = min(i0 + per, T);
     const int c = total_mapped ? total_mapped[2] : 0;
     const int cap = c > 0 ? c : 0x7FFFFFFF;
-    int mine = 0, mine2 = 0, over = 0;
+    // (a tile that outgrew its bucket holds a valid prefix of unknown length: its list is left EMPTY — the frame is
+    // flagged and redone, but nothing downstream may ever read an unwritten word as a Gaussian id)
+    int mine = 0, mine2 = 0, over = 0, true_total = 0;
     for (int i = i0; i < i1; ++i) {
         const int n = cursor[i];
-        over |= (n > bucket_base[i + 1] - bucket_base[i]) ? 1 : 0;
-        mine += n;
+        const bool fits = n <= bucket_base[i + 1] - bucket_base[i];
+        over |= fits ? 0 : 1;
+        mine += fits ? n : 0;
+        true_total += n;
         mine2 += (int)((float)n * growth) + slack;
     }
     int inc = mine, inc2 = mine2;
@@ -146,16 +150,20 @@ __device__ __forceinline__ void bucket_offsets_body256(int T, int32_t *__restric
         const int n = cursor[i];
         offsets[i] = min(run, cap);
         next_base[i] = run2;
-        run += n;
+        run += (n <= bucket_base[i + 1] - bucket_base[i]) ? n : 0;
         run2 += (int)((float)n * growth) + slack;
         cursor[i] = 0;
     }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) true_total += __shfl_xor(true_total, d, 64);
+    if (lane == 0) tsum[w] = true_total;
+    __syncthreads();
     if (tid == 255) {
         const int total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
         offsets[T] = min(total, cap);
         next_base[T] = wsum2[0] + wsum2[1] + wsum2[2] + wsum2[3];
         if (total_mapped) {
-            total_mapped[0] = total;
+            total_mapped[0] = tsum[0] + tsum[1] + tsum[2] + tsum[3];  // (the true number of live pairs)
             total_mapped[3] = over_s[0] | over_s[1] | over_s[2] | over_s[3];
             __threadfence_system();
             __hip_atomic_store(&total_mapped[1], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);

@@ -74,6 +74,7 @@ class FrameInfo:
         self.bin_hist_in: Optional[dict] = None
         self.bin_hist_want = False
         self.bin_hist_out: Optional[dict] = None
+        self.bin_route = "two_pass"  # or "fill": the count-free route
         self.pending_count = None
         self.n_live: Optional[int] = None
         # the forward compositing's walk this frame used (fsgs_raster_fwd_quad's ``walk``; FWD_WALK)
@@ -458,6 +459,7 @@ class _FusedGetOutputs(torch.autograd.Function):
         if info.bin_hist_want and direct_bins and BIN_FILL and N < BIN_FILL_MAX_N and count.get("direct"):
             # the room every tile's bucket gets in this view's next frame
             if count.get("fill"):
+                info.bin_route = "fill"
                 info.bin_hist_out = {"base": count["next_base"]}
             elif count["offsets"].numel() == tw * th + 1 and hm is None and info.zcut_in is None:
                 info.bin_hist_out = {"base": ops.bin_fill_history_from_offsets(count["offsets"], tw * th)}

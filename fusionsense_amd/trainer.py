@@ -247,6 +247,7 @@ class SplatTrainer:
         self._zcut_widen: Dict = {}
         self._bin_hist: Dict = {}   # view -> {"base": bucket bases [T + 1], "n_live": pairs} of its previous frame
         self._bin_hist_n = -1
+        self.bin_frames: Dict = {}  # frames by binning route ("fill": count-free, "two_pass")
         self.zcut_max_views = 1024  # least recently rendered views beyond this are forgotten (T floats each)
         # Adam in the backward: on one rank, when nothing else needs the gradients, the per-Gaussian
         # backward launch applies the step's Adam update itself (fsgs_gauss_sh_bwd_adam) — the 236 B of gradients per
@@ -817,6 +818,7 @@ class SplatTrainer:
             n_live = out["info"].n_live
             if n_live is not None and self.no_wait:
                 self._live_caps.update(cap_key, n_live)
+            self.bin_frames[out["info"].bin_route] = self.bin_frames.get(out["info"].bin_route, 0) + 1
             hist_out = out["info"].bin_hist_out
             if bin_key is not None:
                 self._bin_hist.pop(bin_key, None)
