@@ -115,6 +115,7 @@ def parse():
                     "times the frame's mean list length")
     ap.add_argument("--handoff-gate-len", type=int, default=None, help="A/B: hand off only in frames whose longest list "
                     "exceeds this many times the mean list length (0 = any frame)")
+    ap.add_argument("--bin-fill", type=int, default=None, help="A/B: 0 = two-pass binning on every frame")
     ap.add_argument("--bwd-queue", type=int, default=None, help="A/B: queue positions for the backward's extra workgroups")
     ap.add_argument("--tail-items", type=int, default=None, help="A/B: queue positions of the hand-off (= tail workgroups)")
     a = ap.parse_args()
@@ -546,6 +547,9 @@ def main():
     from fusionsense_amd import frame_cache, ops
 
     log('building workload')
+    if args.bin_fill is not None:
+        import fusionsense_amd.fused as _f
+        _f.BIN_FILL = bool(args.bin_fill)
     if args.bwd_queue is not None:
         import fusionsense_amd.fused as _f
         _f.BWD_QUEUE_ITEMS = int(args.bwd_queue)

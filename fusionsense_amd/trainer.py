@@ -247,6 +247,7 @@ class SplatTrainer:
         self._zcut_widen: Dict = {}
         self._bin_hist: Dict = {}   # view -> {"base": bucket bases [T + 1], "n_live": pairs} of its previous frame
         self._bin_hist_n = -1
+        self.bin_hist_keep_rel = 0.10
         self.bin_frames: Dict = {}  # frames by binning route ("fill": count-free, "two_pass")
         self.zcut_max_views = 1024  # least recently rendered views beyond this are forgotten (T floats each)
         # Adam in the backward: on one rank, when nothing else needs the gradients, the per-Gaussian
@@ -753,10 +754,13 @@ class SplatTrainer:
             from .ops import OcclusionCutInvalid
             view_key, zin, zout = self._view_cuts(camera)
             # count-free binning (fused.BIN_FILL): the room every tile's bucket needs comes from this view's previous
-            # frame; a model that has changed size (densification) starts its views over through the two-pass route
+            # frame.  The buckets belong to TILES, not to Gaussians: a refinement that moves the model's size by a few
+            # per cent moves the tiles' lists by as much (inside the buckets' growth room; a tile that does outgrow its
+            # bucket redoes the frame); a model that changed by more than bin_hist_keep_rel starts its views over
             bin_key = self._view_key(camera) if (self.no_wait and self.num_gaussians() > 0) else None
             if self._bin_hist_n != self.num_gaussians():
-                self._bin_hist.clear()
+                if abs(self.num_gaussians() - self._bin_hist_n) > self.bin_hist_keep_rel * max(self._bin_hist_n, 1):
+                    self._bin_hist.clear()
                 self._bin_hist_n = self.num_gaussians()
             bin_hist = self._bin_hist.get(bin_key) if bin_key is not None else None
             # (frames binned with occlusion cuts hold a fraction of the pairs: their own capacity estimate, or the first
