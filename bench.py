@@ -225,11 +225,7 @@ def cpu_baseline(args):
 def bwd_dispatch_choice(dev, W, H):
     try:
         from fusionsense_amd.fused import BWD_DISPATCH
-        st = BWD_DISPATCH.state.get((str(dev), W, H))
-        if not st or st["decided"] is None:
-            return None
-        return {"stride": int(st["decided"]), "medians_ms": {str(k): round(v, 4) for k, v in st.get("medians_ms", {}).items()},
-                "tuning_frames": int(st.get("tuning_frames", 0))}
+        return {"stride": int(BWD_DISPATCH.stride(W, H)), "rule": "7 apart up to 2^20 pixels, row-major above", "tuning_frames": 0}
     except Exception:
         return None
 
@@ -587,24 +583,11 @@ def main():
     if not os.environ.get("FSGS_BENCH_NO_PRIME"):
         so = strategy.stats_only
         strategy.stats_only = True  # (no callbacks while priming)
-        for v in range(len(cams)):
+        # (twice: a view's first visit is binned by the two-pass route, its revisits by the count-free one, whose bucket
+        # room has to be in the pool as well; the forward's demand probe for tail workgroups also settles here)
+        for v in list(range(len(cams))) * 2 + list(range(min(len(cams), 24))):
             trainer.train_step(cams[v], targets[v], optimizer_step=False)
         torch.cuda.synchronize()
-        # the compositing backward's dispatch order is measured on a few early frames (the launch is issued twice on
-        # those: fused._BwdDispatchTuner): let it settle HERE, not inside the timed region (with 4 views and
-        # 4 warm-up steps config #5 timed some of its tuning frames)
-        if fused:
-            from fusionsense_amd.fused import BWD_DISPATCH
-            # (several ranks: a FIXED number of extra frames — every step carries collectives, so the ranks must not
-            # decide from their own timings how many they run; 20 covers the backward tuner's warm-up + 2 x 4 pairs)
-            for extra in range(20 if grouped else 40):
-                st_ = BWD_DISPATCH.state.get((str(dev), W, H))
-                settled = BWD_DISPATCH.forced or (st_ is not None and st_["decided"] is not None)
-                if settled and not grouped:
-                    break
-                v = (extra * world + rank) % len(cams)
-                trainer.train_step(cams[v], targets[v], optimizer_step=False)
-                torch.cuda.synchronize()
         strategy.stats_only = so
         strategy.xys_grad_norm = strategy.vis_counts = strategy.max_2Dsize = None
         log('workspace primed')
@@ -1030,11 +1013,8 @@ def main():
             # buckets sized from the view's previous frame), "two_pass" = count + fill (first visits, after densification,
             # dense scenes, redone frames)
             "binning_frames": dict(getattr(trainer, "bin_frames", {})),
-            # dispatch order of the compositing backward as measured and chosen in this run (fused._BwdDispatchTuner):
-            # {"stride": 0 = row-major | k, "medians_ms": per candidate}; null while still measuring / when forced
+            # dispatch order of the compositing backward: a rule of the frame's size since round 5 (fused._BwdDispatch)
             "bwd_dispatch": bwd_dispatch_choice(dev, W, H),
-            # frames of the timed region on which the tuner issued the launch twice (0: it had settled during the setup;
-            # it starts over when the model has grown or shrunk by a quarter)
             "bwd_dispatch_tuning_frames_in_timed_region": tune_in_region,
             # the forward compositing's walk (fixed since round 5 — no tuner, reproducible runs: fused.FWD_WALK; the
             # ``walk`` / ``handoff_records`` arguments of fsgs_raster_fwd_quad)

@@ -31,7 +31,7 @@ class AdamGroups(C.Structure):
 # == FSGS_ABI_VERSION of include/fsgs.h as of the SIGNATURES table below: load() refuses any other library (a stale
 # build — the .so files are git-ignored and travel separately, A/B builds come in through FSGS_LIB — would read a stream
 # pointer as a flag or write past a buffer that has since grown)
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 SIGNATURES = {
     "fsgs_version": (_i, []),
@@ -109,7 +109,9 @@ SIGNATURES = {
     "fsgs_densify_stats": (_i, [_i, _p, _p, _f, _p, _p, _p, _p]),
     "fsgs_mask_scan": (_i, [_i64, _p, _p, _p, _sz, _p]),
     "fsgs_compact_rows": (_i, [_i64, _i, _p, _p, _p, _p, _p]),
-    "fsgs_nearest_point": (_i, [_i, _p, _i, _p, _p, _p, _p]),
+    "fsgs_compact_rows_multi": (_i, [_i, _p, _p, _p, _p, _p, _p, _p]),
+    "fsgs_points_in_boxes": (_i, [_i64, _p, _i, _p, _p, _p]),
+    "fsgs_nearest_point": (_i, [_i, _p, _i, _p, _p, _p, _p, _i, _p]),
     "fsgs_knn_points": (_i, [_i64, _p, _i, _p, _i, _i, _p, _p]),
     "fsgs_split_samples": (_i, [_i64, _i, _p, _p, _p, _p, _p, _p, _p, _p]),
     "fsgs_ssim_l1_num_partials": (_i64, [_i, _i]),

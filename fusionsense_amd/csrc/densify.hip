@@ -71,6 +71,32 @@ compact_rows_kernel(int64_t n_rows, int row_floats, const uint8_t *__restrict__ 
     dst[positions[row] * row_floats + col] = src[e];
 }
 
+// The same for up to kCompactMaxJobs tensors in ONE launch (a refinement compacts six parameters, their twelve Adam
+// moments and the six blocks of new rows: 24 launches with their host overhead were a third of a rebuild).  Every job has
+// its own mask / positions / row width; consecutive workgroups take consecutive 256-float pieces of job 0, then job 1, ...
+constexpr int kCompactMaxJobs = 32;
+struct CompactJobs {
+    const float *src[kCompactMaxJobs];
+    float *dst[kCompactMaxJobs];
+    const uint8_t *keep[kCompactMaxJobs];
+    const int64_t *positions[kCompactMaxJobs];
+    int64_t n_rows[kCompactMaxJobs];
+    int64_t first_block[kCompactMaxJobs + 1];
+    int row_floats[kCompactMaxJobs];
+    int n_jobs;
+};
+
+__global__ void __launch_bounds__(256) compact_rows_multi_kernel(CompactJobs J) {
+    int j = 0;
+    while (j + 1 < J.n_jobs && (int64_t)blockIdx.x >= J.first_block[j + 1]) ++j;  // (wave-uniform: scalar loads)
+    const int64_t e = ((int64_t)blockIdx.x - J.first_block[j]) * 256 + threadIdx.x;
+    const int rf = J.row_floats[j];
+    const int64_t row = e / rf;
+    if (row >= J.n_rows[j] || !J.keep[j][row]) return;
+    const int col = (int)(e - row * rf);
+    J.dst[j][J.positions[j][row] * rf + col] = J.src[j][e];
+}
+
 __global__ void __launch_bounds__(256)
 split_samples_kernel(int64_t S, int n_samples, const int64_t *__restrict__ ids,
                      const float *__restrict__ means, const float *__restrict__ quats,
@@ -95,34 +121,90 @@ split_samples_kernel(int64_t S, int n_samples, const int64_t *__restrict__ ids,
     }
 }
 
+// a-14: the union of oriented-box tests of touch_pruning / add_touch_patch (points_in_non_aabb per patch,
+// /root/reference/dn_splatter/dn_model.py:1173-1184, 1284-1294, 1996-2034) in ONE launch: a box is 18 floats — centre,
+// three unit axes (rows), lower and upper bounds of the vertices' coordinates along them (fusionsense_amd/touch.py:
+// box_frames, computed once per run) —, a point is inside when lo <= (p - centre) . axis <= hi on all three, bounds
+// inclusive.  (The reference and rounds 1-4 ran ~15 small torch operators per patch: 1.2 ms of host time per refinement.)
+__global__ void __launch_bounds__(256)
+points_in_boxes_kernel(int64_t n, const float *__restrict__ pts, int n_boxes, const float *__restrict__ boxes,
+                       uint8_t *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float x = pts[i * 3 + 0], y = pts[i * 3 + 1], z = pts[i * 3 + 2];
+    bool any = false;
+    for (int b = 0; b < n_boxes; ++b) {
+        const float *B = boxes + 18 * b;
+        const float dx = x - B[0], dy = y - B[1], dz = z - B[2];
+        bool in = true;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float r = fmaf(dz, B[3 + 3 * k + 2], fmaf(dy, B[3 + 3 * k + 1], dx * B[3 + 3 * k + 0]));
+            in = in && (r >= B[12 + k]) && (r <= B[15 + k]);
+        }
+        any = any || in;
+    }
+    out[i] = any ? 1 : 0;
+}
+
 // a-14: nearest point of a set for every query (hull_pruning's cdist(...).min and add_touch_patch's 1-NN colour
 // lookup, /root/reference/dn_splatter/dn_model.py:1181-1182, 1258-1264), brute force: a thread keeps its query in
-// registers, the point set streams through LDS in tiles of 1024 (broadcast reads).  Exact fp32 differences (no
-// |a|^2 + |b|^2 - 2ab expansion), ties -> lowest index.
+// registers, a slice of the point set streams through LDS in tiles of 1024 (broadcast reads).  Exact fp32 differences
+// (no |a|^2 + |b|^2 - 2ab expansion), ties -> lowest index.
+// The point set is SLICED over gridDim.y (round 5: with one workgroup per 256 queries the 2 000 points of a touch patch
+// against 60 000 Gaussians ran on 8 of 256 CUs for 0.72 ms): every (query block, slice) workgroup folds its best
+// (squared distance, index) into the query's 64-bit word of ``best`` — distance bits above index bits, so that the
+// unsigned minimum IS the nearest point with the lowest index on ties (squared distances are >= +0: their bit patterns
+// order like the values) —, and nearest_point_unpack_kernel turns the words into the two outputs.
+// WANT_IDX = false (hull_pruning needs distances only): the running minimum is one v_min instead of a compare and two
+// selects.  ``active`` (nullable): queries whose byte is 0 are skipped — a wave without an active query leaves at once
+// (hull_pruning only asks for the rows near the object; their distance reads +inf, their index 0).
+template <bool WANT_IDX>
 __global__ void __launch_bounds__(256)
-nearest_point_kernel(int nq, const float *__restrict__ q, int np, const float *__restrict__ p,
-                     float *__restrict__ out_dist, int64_t *__restrict__ out_idx) {
-    __shared__ float sp[1024 * 3];
+nearest_point_kernel(int nq, const float *__restrict__ q, int np, const float *__restrict__ p, int tiles_per_slice,
+                     const uint8_t *__restrict__ active, unsigned long long *__restrict__ best_out) {
+    __shared__ float4 sp[1024];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool on = i < nq;
+    const bool on = i < nq && (!active || active[i]);
+    if (!__syncthreads_or(on)) return;
     const float qx = on ? q[i * 3 + 0] : 0.f, qy = on ? q[i * 3 + 1] : 0.f, qz = on ? q[i * 3 + 2] : 0.f;
     float best = INFINITY;
     int best_j = 0;
-    for (int base = 0; base < np; base += 1024) {
-        const int n = min(1024, np - base);
+    const int lo = (int)blockIdx.y * tiles_per_slice * 1024;
+    const int hi = min(np, lo + tiles_per_slice * 1024);
+    for (int base = lo; base < hi; base += 1024) {
+        const int n = min(1024, hi - base);
         __syncthreads();
-        for (int k = threadIdx.x; k < n * 3; k += 256) sp[k] = p[(int64_t)base * 3 + k];
+        for (int k = threadIdx.x; k < n; k += 256) {
+            const float *s = p + (int64_t)(base + k) * 3;
+            sp[k] = make_float4(s[0], s[1], s[2], 0.f);
+        }
         __syncthreads();
+        if (!__any(on)) continue;
         for (int j = 0; j < n; ++j) {
-            const float dx = qx - sp[j * 3 + 0], dy = qy - sp[j * 3 + 1], dz = qz - sp[j * 3 + 2];
-            const float d2 = dx * dx + dy * dy + dz * dz;
-            if (d2 < best) { best = d2; best_j = base + j; }
+            const float4 c = sp[j];
+            const float dx = qx - c.x, dy = qy - c.y, dz = qz - c.z;
+            const float d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));  // (spelled out: the same bits in both instantiations)
+            if (WANT_IDX) {
+                if (d2 < best) { best = d2; best_j = base + j; }
+            } else {
+                best = fminf(best, d2);  // (fminf drops a NaN operand, like the comparison above never takes one)
+            }
         }
     }
-    if (on) {
-        if (out_dist) out_dist[i] = sqrtf(best);
-        if (out_idx) out_idx[i] = best_j;
-    }
+    if (on && best < INFINITY)
+        atomicMin(best_out + i, ((unsigned long long)__float_as_uint(best) << 32) | (unsigned)best_j);
+}
+
+__global__ void __launch_bounds__(256)
+nearest_point_unpack_kernel(int nq, int64_t *__restrict__ best_idx, float *__restrict__ out_dist) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nq) return;
+    const unsigned long long w = reinterpret_cast<const unsigned long long *>(best_idx)[i];
+    // (no point compared below +inf — NaN coordinates, or all of them infinitely far: distance inf, index 0)
+    const bool none = w == ~0ull;
+    if (out_dist) out_dist[i] = none ? INFINITY : sqrtf(__uint_as_float((unsigned)(w >> 32)));
+    best_idx[i] = none ? 0 : (int64_t)(w & 0xFFFFFFFFull);
 }
 
 // The k nearest points of a set for every query (compute_level_surface_points' knn_sk, dn_model.py:1762-1764, and
@@ -251,6 +333,32 @@ extern "C" int fsgs_compact_rows(int64_t n_rows, int row_floats, const uint8_t *
     return check_launch();
 }
 
+extern "C" int fsgs_compact_rows_multi(int n_jobs, const int64_t *n_rows, const int *row_floats,
+                                       const uint8_t *const *keep, const int64_t *const *positions,
+                                       const float *const *src, float *const *dst, fsgs_stream_t stream) {
+    if (n_jobs < 0 || n_jobs > kCompactMaxJobs) return FSGS_EINVAL;
+    if (n_jobs == 0) return FSGS_OK;
+    if (!n_rows || !row_floats || !keep || !positions || !src || !dst) return FSGS_EINVAL;
+    CompactJobs J;
+    J.n_jobs = 0;
+    int64_t blocks = 0;
+    for (int j = 0; j < n_jobs; ++j) {
+        if (n_rows[j] < 0 || row_floats[j] < 1) return FSGS_EINVAL;
+        if (n_rows[j] == 0) continue;
+        if (!keep[j] || !positions[j] || !src[j] || !dst[j]) return FSGS_EINVAL;
+        const int k = J.n_jobs++;
+        J.src[k] = src[j]; J.dst[k] = dst[j]; J.keep[k] = keep[j]; J.positions[k] = positions[j];
+        J.n_rows[k] = n_rows[j]; J.row_floats[k] = row_floats[j];
+        J.first_block[k] = blocks;
+        blocks += ceil_div(n_rows[j] * row_floats[j], 256);
+    }
+    if (J.n_jobs == 0) return FSGS_OK;
+    J.first_block[J.n_jobs] = blocks;
+    if (blocks > 0x7FFFFFFFll) return FSGS_EINVAL;
+    hipLaunchKernelGGL(compact_rows_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), J);
+    return check_launch();
+}
+
 extern "C" int fsgs_split_samples(int64_t S, int n_samples, const int64_t *ids, const float *means,
                                   const float *quats, const float *log_scales, const float *randn,
                                   float *new_means, float *new_log_scales, fsgs_stream_t stream) {
@@ -263,12 +371,33 @@ extern "C" int fsgs_split_samples(int64_t S, int n_samples, const int64_t *ids, 
     return check_launch();
 }
 
-extern "C" int fsgs_nearest_point(int nq, const float *queries, int np, const float *points, float *out_dist,
-                                  int64_t *out_idx, fsgs_stream_t stream) {
+extern "C" int fsgs_points_in_boxes(int64_t n, const float *points, int n_boxes, const float *boxes, uint8_t *out_mask,
+                                    fsgs_stream_t stream) {
+    if (n < 0 || n_boxes < 0) return FSGS_EINVAL;
+    if (n == 0) return FSGS_OK;
+    if (!points || !out_mask || (n_boxes > 0 && !boxes)) return FSGS_EINVAL;
+    hipLaunchKernelGGL(points_in_boxes_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, as_stream(stream), n, points, n_boxes,
+                       boxes, out_mask);
+    return check_launch();
+}
+
+extern "C" int fsgs_nearest_point(int nq, const float *queries, int np, const float *points, const uint8_t *active,
+                                  float *out_dist, int64_t *out_idx, int want_idx, fsgs_stream_t stream) {
     if (nq < 0 || np < 1) return FSGS_EINVAL;
     if (nq == 0) return FSGS_OK;
-    if (!queries || !points || (!out_dist && !out_idx)) return FSGS_EINVAL;
-    hipLaunchKernelGGL(nearest_point_kernel, dim3(ceil_div(nq, 256)), dim3(256), 0, as_stream(stream), nq, queries, np,
-                       points, out_dist, out_idx);
+    if (!queries || !points || !out_idx) return FSGS_EINVAL;  // (out_idx doubles as the slices' meeting place)
+    const int q_blocks = (int)ceil_div(nq, 256), tiles = (int)ceil_div(np, 1024);
+    // slices: as many as keep the launch at a few thousand workgroups (one tile of 1024 points costs a thread ~4 us)
+    const int tiles_per_slice = (int)std::max<int64_t>(1, ceil_div((int64_t)q_blocks * tiles, 4096));
+    const int slices = (int)ceil_div(tiles, tiles_per_slice);
+    if (hipMemsetAsync(out_idx, 0xFF, (size_t)nq * sizeof(int64_t), as_stream(stream)) != hipSuccess) return FSGS_ELAUNCH;
+    auto *best = reinterpret_cast<unsigned long long *>(out_idx);
+    if (want_idx)
+        hipLaunchKernelGGL(nearest_point_kernel<true>, dim3(q_blocks, slices), dim3(256), 0, as_stream(stream), nq, queries,
+                           np, points, tiles_per_slice, active, best);
+    else
+        hipLaunchKernelGGL(nearest_point_kernel<false>, dim3(q_blocks, slices), dim3(256), 0, as_stream(stream), nq, queries,
+                           np, points, tiles_per_slice, active, best);
+    hipLaunchKernelGGL(nearest_point_unpack_kernel, dim3(q_blocks), dim3(256), 0, as_stream(stream), nq, out_idx, out_dist);
     return check_launch();
 }

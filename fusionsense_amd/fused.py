@@ -174,69 +174,28 @@ SKIP_IDLE_MIN_N = int(os.environ.get("FSGS_SKIP_IDLE_MIN_N", str(1 << 20)))
 KEPT_MIN_N = int(os.environ.get("FSGS_KEPT_MIN_N", str(1 << 20)))
 
 
-class _BwdDispatchTuner:
-    """Picks the dispatch order of the compositing backward per (device, frame shape) by measuring it
-    (fsgs_set_bwd_dispatch_stride): quadrants in row-major order, or consecutive workgroups a few quadrants apart.  Which
-    is faster is a property of the scene — config #2: 0.181 vs 0.168 ms, config #4: 0.720 vs 0.611, config #3: 0.209 vs
-    0.279 — so on a few early frames the launch is issued TWICE, once per order, on the same inputs (the second one into
-    a scratch accumulator that nobody reads; which order goes first alternates), both timed with HIP events; the faster
-    order is kept until the model's size has changed by a quarter.  FSGS_BWD_PERM=<k> fixes the stride (0: row-major)."""
-    CANDIDATES = (0, 7)
-    WARM, PAIRS, MIN_GAIN = 1, 4, 0.015
+class _BwdDispatch:
+    """The dispatch order of the compositing backward (the ``dispatch_stride`` argument of fsgs_raster_bwd_quad*):
+    quadrants in row-major order, or consecutive workgroups ``stride`` quadrants apart.  A RULE of the frame's size since
+    round 5 (rounds 3-4 timed both orders on a few early frames of every frame shape and kept the faster one: two runs of
+    a seed could differ, ranks could disagree, and the duplicate launches needed a scratch accumulator): frames of up to
+    ``small_frame_pixels`` pixels — fewer quadrants than a few rounds of resident workgroups, where neighbours' equally
+    long lists would otherwise end up side by side on a CU — are dispatched 7 apart (config #2: 0.169 vs 0.176 ms;
+    config #3: 0.208 vs 0.211), larger ones row-major (config #4: 0.927 vs 0.947).  ``forced`` / ``forced_stride``: tests."""
+    small_frame_pixels = 1 << 20
+    small_frame_stride = 7
 
     def __init__(self):
-        self.state: Dict = {}
-        self.forced = os.environ.get("FSGS_BWD_PERM", "auto") != "auto"
-        self.forced_stride = int(os.environ.get("FSGS_BWD_PERM", "0")) if self.forced else 0
+        self.forced = False
+        self.forced_stride = 0
 
-    def launch(self, key, n: int, acc: Tensor, fn):
-        """Runs ``fn(acc, stride)`` — the launch, accumulating into ``acc``, quadrants dispatched ``stride`` apart — with
-        the stride to use for this frame (an argument of the launch: nothing process-wide is set)."""
+    def stride(self, W: int, H: int) -> int:
         if self.forced:
-            return fn(acc, self.forced_stride)
-        st = self.state.get(key)
-        if st is None or (st["decided"] is not None and abs(n - st["n_ref"]) > 0.25 * st["n_ref"]):
-            st = self.state[key] = dict(n_ref=n, frames=0, pending=[], total={c: 0.0 for c in self.CANDIDATES}, pairs=0,
-                                        decided=None, scratch=None)
-        if st["decided"] is not None:
-            return fn(acc, st["decided"])
-        st["frames"] += 1
-        for item in list(st["pending"]):  # harvest finished pairs
-            if item[-1].query():
-                (ca, a0, a1), (cb, b0, b1) = item[0], item[1]
-                st["total"][ca] += a0.elapsed_time(a1)
-                st["total"][cb] += b0.elapsed_time(b1)
-                st["pairs"] += 1
-                st["pending"].remove(item)
-        base, other = self.CANDIDATES
-        t = st["total"]
-        # (a close call after the first pairs — within 4 % either way — gets as many pairs again before it is settled)
-        close = st["pairs"] >= self.PAIRS and 0.96 * t[base] < t[other] < 1.04 * t[base]
-        if st["pairs"] >= (2 * self.PAIRS if close else self.PAIRS):
-            st["decided"] = other if t[other] < (1.0 - self.MIN_GAIN) * t[base] else base
-            st["medians_ms"] = {c: t[c] / st["pairs"] for c in self.CANDIDATES}  # (means of the paired launches)
-            st["scratch"] = None  # (freed: nothing reads it)
-            return fn(acc, st["decided"])
-        if st["frames"] <= self.WARM or st["pairs"] + len(st["pending"]) >= (2 * self.PAIRS if close else self.PAIRS):
-            return fn(acc, self.CANDIDATES[0])
-        if st["scratch"] is None or st["scratch"].shape != acc.shape:
-            st["scratch"] = torch.zeros_like(acc)
-        else:
-            st["scratch"].zero_()  # (per pair: it would otherwise drift to inf / NaN over the pairs)
-        order = self.CANDIDATES if st["frames"] % 2 == 0 else self.CANDIDATES[::-1]
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
-        ev[0].record()
-        out = fn(acc, order[0])
-        ev[1].record()
-        ev[2].record()
-        fn(st["scratch"], order[1])  # (same inputs, the other order, results discarded)
-        ev[3].record()
-        st["tuning_frames"] = st.get("tuning_frames", 0) + 1
-        st["pending"].append(((order[0], ev[0], ev[1]), (order[1], ev[2], ev[3]), ev[3]))
-        return out
+            return self.forced_stride
+        return self.small_frame_stride if W * H <= self.small_frame_pixels else 0
 
 
-BWD_DISPATCH = _BwdDispatchTuner()
+BWD_DISPATCH = _BwdDispatch()
 
 
 class _FwdWalk:
@@ -590,13 +549,12 @@ class _FusedGetOutputs(torch.autograd.Function):
         if v_rgb is not None and IMAGE_GRADS_IN_BWD:
             # the image gradients go straight into the compositing backward, which derives v_render / v_alphas /
             # v_render_extra per pixel itself (no epilogue launch, no 32 B/pixel round trip)
-            BWD_DISPATCH.launch((str(dev), W, H), N, v_packed, lambda acc, stride: _run(
-                lib.fsgs_raster_bwd_quad_images, (ptr(records), ptr(n_rec), ptr(offsets), M, W, H, tw, th, ptr(render),
-                                                  ptr(alphas), ptr(last_ids), ptr(render_extra), ptr(background),
-                                                  ptr(v_rgb), ptr(v_depth), ptr(v_normal), ptr(v_alpha_out),
-                                                  ptr(seg_state), 1, ptr(acc), rep_rows, int(stride), ptr(seg_split),
-                                                  ptr(bwd_queue), n_queue, sp),
-                "fsgs_raster_bwd_quad", "_d4e3"))
+            _run(lib.fsgs_raster_bwd_quad_images, (ptr(records), ptr(n_rec), ptr(offsets), M, W, H, tw, th, ptr(render),
+                                                   ptr(alphas), ptr(last_ids), ptr(render_extra), ptr(background),
+                                                   ptr(v_rgb), ptr(v_depth), ptr(v_normal), ptr(v_alpha_out),
+                                                   ptr(seg_state), 1, ptr(v_packed), rep_rows, BWD_DISPATCH.stride(W, H),
+                                                   ptr(seg_split), ptr(bwd_queue), n_queue, sp),
+                 "fsgs_raster_bwd_quad", "_d4e3")
         else:
             v_render = torch.empty(1, H, W, 4, **f32)
             v_alphas = torch.empty(1, H, W, 1, **f32)

@@ -105,8 +105,8 @@ def _run(fn, args, what: str, tag: str = "") -> None:
     check(rc, what)
 
 
-# dispatch order of the compositing backward on the drop-in route (an argument of the launch; the fused node measures
-# its own per frame shape, fused._BwdDispatchTuner): row-major unless FSGS_BWD_PERM=<stride> asks otherwise
+# dispatch order of the compositing backward on the drop-in route (an argument of the launch; the fused node applies
+# its rule of the frame's size, fused._BwdDispatch): row-major unless FSGS_BWD_PERM=<stride> asks otherwise
 DROPIN_BWD_STRIDE = int(os.environ.get("FSGS_BWD_PERM", "0")) if os.environ.get("FSGS_BWD_PERM", "auto") != "auto" else 0
 
 
@@ -1025,15 +1025,56 @@ def compact_rows(src: Tensor, keep8: Tensor, positions: Tensor, n_keep: int,
     return out
 
 
-def nearest_point(queries: Tensor, points: Tensor, want_idx: bool = False):
-    """Distance from every query [nq,3] to the nearest of points [np,3] (and its index with ``want_idx``)."""
+def compact_rows_multi(jobs) -> None:
+    """``jobs`` = [(src [n, ...] fp32, keep8 [n] uint8, positions [n] int64, dst)]: every job's kept rows of ``src`` land
+    at ``dst[positions[row]]`` (dst: a contiguous tensor of the same row shape, possibly a view that starts at a row
+    offset), all in ONE launch (fsgs_compact_rows_multi).  Jobs without rows or of zero-width rows are skipped."""
+    lib = load()
+    keepalive, rows = [], []
+    for src, keep8, positions, dst in jobs:
+        n = src.shape[0]
+        if n == 0 or dst.shape[0] == 0 or src[0].numel() == 0:
+            continue
+        src = src.contiguous()
+        assert src.dtype == torch.float32 and dst.dtype == torch.float32 and dst.is_contiguous()
+        keepalive.append(src)
+        rows.append((n, int(src[0].numel()), ptr(keep8), ptr(positions), src.data_ptr(), dst.data_ptr()))
+    if not rows:
+        return
+    dev = jobs[0][0].device
+    for lo in range(0, len(rows), 32):
+        part = rows[lo:lo + 32]
+        k = len(part)
+        n_rows = (C.c_int64 * k)(*[r[0] for r in part])
+        widths = (C.c_int * k)(*[r[1] for r in part])
+        arr = lambda col: (C.c_void_p * k)(*[r[col] for r in part])  # noqa: E731
+        _run(lib.fsgs_compact_rows_multi, (k, n_rows, widths, arr(2), arr(3), arr(4), arr(5), stream_ptr(dev)),
+             "fsgs_compact_rows_multi")
+
+
+def points_in_boxes(points: Tensor, boxes: Tensor) -> Tensor:
+    """[n] bool: point i lies inside any of the oriented boxes [B, 18] (touch.box_frames; fsgs_points_in_boxes)."""
+    lib = load()
+    points, boxes = points.contiguous(), boxes.contiguous()
+    out = torch.empty(points.shape[0], dtype=torch.bool, device=points.device)
+    _run(lib.fsgs_points_in_boxes, (points.shape[0], ptr(points), boxes.shape[0], ptr(boxes), ptr(out),
+                                    stream_ptr(points.device)), "fsgs_points_in_boxes")
+    return out
+
+
+def nearest_point(queries: Tensor, points: Tensor, want_idx: bool = False, active: Optional[Tensor] = None):
+    """Distance from every query [nq,3] to the nearest of points [np,3] (and its index with ``want_idx``).  ``active``
+    ([nq] bool / uint8, optional): queries with a zero entry are skipped — distance +inf, index 0."""
     lib = load()
     queries, points = queries.contiguous(), points.contiguous()
     nq, dev = queries.shape[0], queries.device
     dist = torch.empty(nq, dtype=torch.float32, device=dev)
-    idx = torch.empty(nq, dtype=torch.int64, device=dev) if want_idx else None
-    _run(lib.fsgs_nearest_point, (nq, ptr(queries), points.shape[0], ptr(points), ptr(dist), ptr(idx),
-                                  stream_ptr(dev)), "fsgs_nearest_point")
+    idx = torch.empty(nq, dtype=torch.int64, device=dev)  # (also the kernel's accumulator: fsgs.h)
+    if active is not None:
+        active = active.contiguous()
+        assert active.numel() == nq and active.element_size() == 1
+    _run(lib.fsgs_nearest_point, (nq, ptr(queries), points.shape[0], ptr(points), ptr(active), ptr(dist), ptr(idx),
+                                  1 if want_idx else 0, stream_ptr(dev)), "fsgs_nearest_point")
     return (dist, idx) if want_idx else dist
 
 

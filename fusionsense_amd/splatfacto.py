@@ -222,9 +222,16 @@ class DensifyStrategy:
         if self.touch_patches is not None:
             self.touch_patches = [{k: (v.to(device) if torch.is_tensor(v) else v) for k, v in p.items()}
                                   for p in self.touch_patches]
+            from .touch import box_frames
+            self._touch_frames = (self.touch_patches, box_frames(self.touch_patches, device))
         if self.visual_hull is not None:
             self.visual_hull = self.visual_hull.to(device)
         self._staged_on = str(device)
+
+    def _frames_of(self, touch_patches):
+        """The staged boxes' frames when ``touch_patches`` is the staged list (else None: touch_aabb_mask derives them)."""
+        tf = getattr(self, "_touch_frames", None)
+        return tf[1] if (tf is not None and tf[0] is touch_patches) else None
 
     def before_train(self, trainer) -> None:
         """BEFORE_TRAIN_ITERATION callbacks (dn_model.py:1370-1383): add_touch_patch at step == add_touch_at."""
@@ -241,9 +248,11 @@ class DensifyStrategy:
             if hasattr(trainer, "flush"):
                 trainer.flush()  # a deferred feature update must land before rows are split / culled
             self.refinement_after(trainer, trainer.step)
-            if self.visual_hull is not None:
+            if self.visual_hull is not None and self.touch_patches is not None:
+                self.hull_and_touch_pruning(trainer)
+            elif self.visual_hull is not None:
                 self.hull_pruning(trainer, self.visual_hull, self.scale_factor)
-            if self.touch_patches is not None:
+            elif self.touch_patches is not None:
                 self.touch_pruning(trainer, self.touch_patches)
 
     # ---- a-13 ---------------------------------------------------------------------------
@@ -378,7 +387,7 @@ class DensifyStrategy:
             touch_patches = self.touch_patches
         P = trainer.params
         means = P["means"].data
-        aabb = touch_aabb_mask(means, touch_patches)
+        aabb = touch_aabb_mask(means, touch_patches, self._frames_of(touch_patches))
         pts, nrm, rgb = [], [], []
         from .scenes import sh_to_rgb
         base_rgb = sh_to_rgb(P["features_dc"].data) if self.cfg.sh_degree > 0 else torch.sigmoid(P["features_dc"].data)
@@ -431,8 +440,29 @@ class DensifyStrategy:
         if touch_patches is self.touch_patches:
             self.stage(trainer.device)
             touch_patches = self.touch_patches
-        mask = touch_aabb_mask(trainer.params["means"].data, touch_patches)
+        mask = touch_aabb_mask(trainer.params["means"].data, touch_patches, self._frames_of(touch_patches))
         mask[self.add_mask] = False
+        return self.cull_gaussians(trainer, mask)
+
+    @torch.no_grad()
+    def hull_and_touch_pruning(self, trainer) -> Optional[Tensor]:
+        """hull_pruning followed by touch_pruning (the reference's order, dn_model.py:1394-1424) with ONE cull and one
+        rebuild of the parameters instead of two: every test of the two callbacks is a function of the row alone —
+        sigmoid(opacity) < cull_alpha_thresh, the too-big test on the row's own scales (no screen sizes: both callbacks
+        run with max_2Dsize = None), the distance to the hull, the boxes of the patches — so the rows that survive
+        "cull A, then cull B on the survivors" are the rows that fail neither test.  Same survivors, same order
+        (tests/test_gpu_densify.py checks it against the two calls); returns the deleted mask over the rows before it."""
+        if trainer.step <= self.cfg.warmup_length:
+            return None
+        if self.add_mask is None:  # touch_pruning does nothing before add_touch_patch
+            return self.hull_pruning(trainer, self.visual_hull, self.scale_factor)
+        _flush(trainer)
+        from .touch import hull_prune_mask, touch_aabb_mask
+        self.stage(trainer.device)
+        means = trainer.params["means"].data
+        mask = hull_prune_mask(means, self.visual_hull, self.scale_factor, self.add_mask)
+        mask |= touch_aabb_mask(means, self.touch_patches, self._frames_of(self.touch_patches)) & ~self.add_mask
+        self.max_2Dsize = None
         return self.cull_gaussians(trainer, mask)
 
     def _rebuild(self, trainer, keep_old: Tensor, n_keep_old: int, new_rows: Dict[str, Tensor],
@@ -453,21 +483,37 @@ class DensifyStrategy:
         keep8 = keep_old.to(torch.uint8).contiguous()
         positions = ops.mask_positions(keep8)
         n_final = n_keep_old + n_keep_new
+        if n_keep_new > 0:
+            knew8 = keep_new.to(torch.uint8).contiguous()
+            pos_new = ops.mask_positions(knew8)
+        # one launch moves every kept row of the six parameters, their twelve moments and the six blocks of new rows
+        # (round 5: 24 launches + six boolean-mask gathers, each with its wait for the host, were a third of a rebuild)
+        jobs = []
+        fresh = {}
         for name in list(trainer.params.keys()):
             old_p = trainer.params[name]
             opt = trainer.optimizers[name]
             shape = (n_final,) + tuple(old_p.shape[1:])
             new_data = torch.empty(shape, dtype=old_p.dtype, device=old_p.device)
-            ops.compact_rows(old_p.data, keep8, positions, n_keep_old, out=new_data, out_offset=0)
+            jobs.append((old_p.data, keep8, positions, new_data))
             if n_keep_new > 0:
-                new_data[n_keep_old:] = new_rows[name][keep_new.to(new_rows[name].device)]
-            new_p = torch.nn.Parameter(new_data)
+                jobs.append((new_rows[name].to(old_p.device), knew8, pos_new, new_data[n_keep_old:]))
             state = opt.state.pop(old_p, None)
+            moments = {}
             if state:
                 for key in ("exp_avg", "exp_avg_sq"):
-                    buf = torch.zeros(shape, dtype=old_p.dtype, device=old_p.device)
-                    ops.compact_rows(state[key], keep8, positions, n_keep_old, out=buf, out_offset=0)
-                    state[key] = buf
+                    buf = torch.empty(shape, dtype=old_p.dtype, device=old_p.device)
+                    if n_keep_new > 0:
+                        buf[n_keep_old:].zero_()  # (new rows start with zero moments: dup_in_optim)
+                    jobs.append((state[key], keep8, positions, buf))
+                    moments[key] = buf
+            fresh[name] = (new_data, state, moments)
+        ops.compact_rows_multi(jobs)
+        for name, (new_data, state, moments) in fresh.items():
+            opt = trainer.optimizers[name]
+            new_p = torch.nn.Parameter(new_data)
+            if state:
+                state.update(moments)
                 opt.state[new_p] = state
             opt.param_groups[0]["params"] = [new_p]
             trainer.params[name] = new_p

@@ -76,9 +76,31 @@ def invert_quaternion(quat: Tensor) -> Tensor:
     return quat * torch.tensor([1, -1, -1, -1], device=quat.device, dtype=quat.dtype)
 
 
-def touch_aabb_mask(means: Tensor, touch_patches: List[Dict[str, Tensor]]) -> Tensor:
+def box_frames(touch_patches: List[Dict[str, Tensor]], device=None) -> Tensor:
+    """[B, 18] float32: centre, unit axes (rows), lower and upper bounds of every non-empty patch's oriented box — the
+    per-box half of points_in_non_aabb (dn_model.py:2008-2027), computed once per run (DensifyStrategy.stage)."""
+    rows = []
+    for patch in touch_patches:
+        if patch["points_xyz"].shape[0] == 0:
+            continue
+        bv = patch["bbox"].to(torch.float32)
+        center = bv.mean(dim=0)
+        axes = torch.nn.functional.normalize(torch.stack([bv[1] - bv[0], bv[2] - bv[0], bv[4] - bv[0]]), dim=1)
+        rel_c = (bv - center) @ axes.T
+        rows.append(torch.cat([center, axes.reshape(-1), rel_c.min(dim=0).values, rel_c.max(dim=0).values]))
+    out = torch.stack(rows) if rows else torch.zeros(0, 18)
+    return out.to(device) if device is not None else out
+
+
+def touch_aabb_mask(means: Tensor, touch_patches: List[Dict[str, Tensor]], frames: Optional[Tensor] = None) -> Tensor:
     """Union of the oriented-box tests over all non-empty patches (dn_model.py:1173-1184,
-    1284-1294)."""
+    1284-1294).  On the device: one launch over the boxes' frames (``frames`` = box_frames(touch_patches), computed
+    here when the caller has not kept them)."""
+    if means.is_cuda:
+        from .ops import points_in_boxes
+        if frames is None:
+            frames = box_frames(touch_patches, means.device)
+        return points_in_boxes(means, frames)
     mask = torch.zeros(means.shape[0], dtype=torch.bool, device=means.device)
     for patch in touch_patches:
         if patch["points_xyz"].shape[0] > 0:
@@ -93,15 +115,18 @@ def hull_prune_mask(means: Tensor, visual_hull: Tensor, scale_factor: float,
     center = visual_hull.mean(dim=0)
     close = torch.norm(means - center, dim=1) <= 0.2 * scale_factor
     if means.is_cuda:
+        # the close rows' distances (exact differences, no [n, n_hull] matrix), selected ON the device: the kernel skips
+        # the other rows (+inf) — no wait for the host to learn how many rows are close, no gather / scatter
         from .ops import nearest_point
-        d = nearest_point(means[close], visual_hull)  # exact differences, no [n, n_hull] matrix
+        d = nearest_point(means, visual_hull, active=close)
+        mask = close & (d > 0.005 * scale_factor) & (d <= 0.02 * scale_factor)
     else:  # (host mirror used by the CPU tests of the mask logic)
         d = torch.cdist(means[close], visual_hull).min(dim=-1).values
-    sel = (d > 0.005 * scale_factor) & (d <= 0.02 * scale_factor)
-    mask = torch.zeros(means.shape[0], dtype=torch.bool, device=means.device)
-    mask[close] = sel
+        sel = (d > 0.005 * scale_factor) & (d <= 0.02 * scale_factor)
+        mask = torch.zeros(means.shape[0], dtype=torch.bool, device=means.device)
+        mask[close] = sel
     if add_mask is not None:
-        mask[add_mask] = False
+        mask = mask & ~add_mask
     return mask
 
 

@@ -42,7 +42,7 @@ typedef void *fsgs_stream_t; /* hipStream_t */
 #define FSGS_ELAUNCH -2  /* hipLaunch / runtime error; see fsgs_last_hip_error() */
 #define FSGS_ESCRATCH -3 /* scratch arena too small */
 
-#define FSGS_ABI_VERSION 6
+#define FSGS_ABI_VERSION 7
 int fsgs_version(void);
 int fsgs_abi_version(void); /* == FSGS_ABI_VERSION of the header the library was built from */
 /* Lines of the packed gradient accumulator a caller that passes `replica_rows` > 0 must provide per Gaussian row:
@@ -541,11 +541,25 @@ int fsgs_mask_scan(int64_t n_rows, const uint8_t *keep, int64_t *positions, void
 int fsgs_compact_rows(int64_t n_rows, int row_floats, const uint8_t *keep,
                       const int64_t *positions, const float *src, float *dst,
                       fsgs_stream_t stream);
+/* fsgs_compact_rows for n_jobs <= 32 tensors in one launch: job j moves the kept rows of src[j] ([n_rows[j], row_floats[j]])
+ * to dst[j] + positions[j][row] * row_floats[j] under its own mask keep[j].  The six arrays are HOST arrays of n_jobs
+ * entries (their elements device pointers); jobs of zero rows are skipped. */
+int fsgs_compact_rows_multi(int n_jobs, const int64_t *n_rows, const int *row_floats, const uint8_t *const *keep,
+                            const int64_t *const *positions, const float *const *src, float *const *dst,
+                            fsgs_stream_t stream);
+/* a-14: out_mask[i] = 1 when point i [n,3] lies inside ANY of n_boxes oriented boxes, 0 otherwise.  A box is 18 floats:
+ * centre (3), three unit axes (3 x 3, one per row), lower (3) and upper (3) bounds of the box's extent along the axes;
+ * inside = lower <= (p - centre) . axis <= upper on all three axes, bounds inclusive.  Replaces the per-patch
+ * points_in_non_aabb loop of touch_pruning / add_touch_patch (dn_splatter/dn_model.py:1173-1184, 1284-1294, 1996-2034). */
+int fsgs_points_in_boxes(int64_t n, const float *points, int n_boxes, const float *boxes, uint8_t *out_mask,
+                         fsgs_stream_t stream);
 /* a-14: for every query [nq,3] the nearest of points [np,3] (np >= 1): Euclidean distance (out_dist, nullable) and
- * index (out_idx, nullable; lowest index on ties).  Replaces torch.cdist(...).min(-1) in hull_pruning
- * (dn_splatter/dn_model.py:1258-1264) and the k=1 neighbour search of add_touch_patch (:1181-1182). */
-int fsgs_nearest_point(int nq, const float *queries, int np, const float *points, float *out_dist,
-                       int64_t *out_idx, fsgs_stream_t stream);
+ * index (out_idx, REQUIRED since ABI 7: the point set is sliced over workgroups, which meet in out_idx's 64-bit words;
+ * lowest index on ties; all zeros with want_idx == 0, which saves the kernel its index bookkeeping).  active (nullable,
+ * [nq] bytes): queries whose byte is 0 are skipped — distance +inf, index 0.  Replaces torch.cdist(...).min(-1) in
+ * hull_pruning (dn_splatter/dn_model.py:1258-1264) and the k=1 neighbour search of add_touch_patch (:1181-1182). */
+int fsgs_nearest_point(int nq, const float *queries, int np, const float *points, const uint8_t *active, float *out_dist,
+                       int64_t *out_idx, int want_idx, fsgs_stream_t stream);
 /* The k nearest points (exact fp32 differences, brute force, ties -> lowest index) of every query, reported from rank
  * `skip` on: out_idx [nq, k - skip] int64.  k <= 33, k <= np; skip = 1 reproduces dn_splatter/utils/knn.py:29-44
  * (knn_sk asks sklearn for k + 1 neighbours and drops the first column) — what compute_level_surface_points

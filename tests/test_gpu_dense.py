@@ -313,13 +313,7 @@ def test_config5_surface_scene_half_storage_bench_route(dev, surface5, fwd_walk)
     # moments, slab and mirrors —, not its steps)
     from fusionsense_amd import fused
     from helpers import device_kernels_of
-    # (the backward's dispatch-order tuner issues the launch twice on a few early frames of a frame shape, into a scratch
-    # accumulator it zeroes with a torch fill — 640 MB here: THAT is the 594 us fill of the round-4 profile; let it settle)
-    for _ in range(40):
-        st_ = fused.BWD_DISPATCH.state.get((str(dev), W4, H4))
-        if fused.BWD_DISPATCH.forced or (st_ is not None and st_["decided"] is not None):
-            break
-        tr.train_step(view, tgt)
+    # (THAT fill was the round-4 dispatch-order tuner's 640 MB scratch accumulator; the order is a rule since round 5)
     names = device_kernels_of(lambda: [tr.train_step(view, tgt) for _ in range(2)])
     assert names, "the profiler saw no device activity"
     theirs = ("at::", "rocprim", "hipcub", "Cijk_", "__amd_rocclr", "emcpy", "emset", "elementwise", "reduce_kernel")

@@ -212,6 +212,13 @@ def test_nearest_point_kernel(dev, nq, np_):
     assert torch.allclose(chosen, rd, atol=1e-6), "the returned index is a nearest point"
     if np_ > 10:
         assert int(i[0]) == 3
+    # distances only (no index bookkeeping), and with a mask of the queries that matter: the same values, +inf elsewhere
+    assert torch.equal(ops.nearest_point(q.to(dev), p.to(dev)), d)
+    act = torch.rand(nq, generator=g) < 0.3
+    act[: min(nq, 300)] = False  # (whole workgroups without an active query)
+    da, ia = ops.nearest_point(q.to(dev), p.to(dev), want_idx=True, active=act.to(dev))
+    assert torch.equal(da[act.to(dev)], d[act.to(dev)]) and torch.equal(ia[act.to(dev)], i[act.to(dev)])
+    assert bool(torch.isinf(da[~act.to(dev)]).all()) and int(ia[~act.to(dev)].abs().sum()) == 0
 
 
 # ---- the product's callbacks against goldens made by EXECUTING the reference's own methods ----------------------
@@ -305,3 +312,53 @@ def test_touch_and_hull_callbacks_match_reference_execution(dev):
         assert tr.params[k].shape == t(f"tp.hull_pruned.{k}").shape, k
         assert torch.allclose(tr.params[k].detach().cpu(), t(f"tp.hull_pruned.{k}"), atol=1e-6), k
     assert np.array_equal(st.add_mask.cpu().numpy(), d["tp.add_mask_hull_pruned"])
+    # ... and the two prunings as maybe_refine runs them since round 5 — ONE cull over the union of the two tests — leave
+    # the same rows, moments and anchors, bit for bit
+    tr2, st2 = _trainer_from_golden(dev, d, "tp.in", "tp.in_m", None, 1000)
+    st2.set_metadata(touch_patches=patches, gel_scale_factor=6.34e-5, add_touch_at=1000, visual_hull=hull, scale_factor=1.3)
+    st2.stage(dev)
+    st2.add_touch_patch(tr2, st2.touch_patches, gel_scale_factor=6.34e-5)
+    tr2.step = 1100
+    tr2.params["means"].data.copy_(t("tp.before_touch_prune.means").to(dev))
+    deleted = st2.hull_and_touch_pruning(tr2)
+    assert deleted is not None and int(deleted.sum()) > 0
+    for k in NAMES6:
+        assert torch.equal(tr2.params[k].detach(), tr.params[k].detach()), k
+        for mom in ("exp_avg", "exp_avg_sq"):
+            assert torch.equal(tr2.optimizers[k].state[tr2.params[k]][mom], tr.optimizers[k].state[tr.params[k]][mom]), (k, mom)
+    assert torch.equal(st2.add_mask, st.add_mask)
+
+
+def test_points_in_boxes_kernel(dev):
+    """fsgs_points_in_boxes (one launch for all patches) against the per-patch points_in_non_aabb loop of the reference
+    (dn_model.py:1996-2034, mirrored in touch.py and pinned there by reference_helpers.npz): the same mask except for
+    points within rounding of a face (the kernel's dot product is an fma chain, torch's a matrix product)."""
+    from fusionsense_amd import ops, touch
+    g = torch.Generator().manual_seed(11)
+    patches = []
+    for b in range(4):
+        ax = torch.linalg.qr(torch.randn(3, 3, generator=g))[0]
+        ext = 0.05 + 0.3 * torch.rand(3, generator=g)
+        c = 0.4 * torch.randn(3, generator=g)
+        box = torch.stack([c + (ax * ((torch.tensor([(i >> 0) & 1, (i >> 1) & 1, (i >> 2) & 1]).float() * 2 - 1) * ext)[None]).sum(-1)
+                           for i in range(8)])
+        patches.append(dict(points_xyz=torch.zeros(0 if b == 2 else 5, 3), bbox=box))  # (an empty patch has no box)
+    pts = 0.6 * torch.randn(20001, 3, generator=g)
+    ref = torch.zeros(pts.shape[0], dtype=torch.bool)
+    margin = torch.full((pts.shape[0],), float("inf"))
+    for patch in patches:
+        if patch["points_xyz"].shape[0] == 0:
+            continue
+        ref |= touch.points_in_non_aabb(pts, patch["bbox"])
+        bv = patch["bbox"]
+        axes = torch.nn.functional.normalize(torch.stack([bv[1] - bv[0], bv[2] - bv[0], bv[4] - bv[0]]), dim=1)
+        rel_p, rel_c = (pts - bv.mean(0)) @ axes.T, (bv - bv.mean(0)) @ axes.T
+        margin = torch.minimum(margin, torch.minimum((rel_p - rel_c.min(0).values).abs(), (rel_p - rel_c.max(0).values).abs()).min(-1).values)
+    frames = touch.box_frames(patches, dev)
+    assert frames.shape == (3, 18)
+    got = ops.points_in_boxes(pts.to(dev), frames).cpu()
+    assert got.dtype == torch.bool and 0.02 < float(ref.float().mean()) < 0.9
+    differ = got != ref
+    assert not bool((differ & (margin > 1e-5)).any()), int(differ.sum())
+    assert torch.equal(touch.touch_aabb_mask(pts.to(dev), patches).cpu(), got)
+    assert ops.points_in_boxes(pts.to(dev), frames[:0]).sum() == 0  # no boxes: nothing is inside

@@ -527,16 +527,8 @@ def test_backward_dispatch_order_changes_nothing_but_the_speed(dev):
     finally:
         assert lib.fsgs_set_bwd_dispatch_stride(prev) == 5
         fused.BWD_DISPATCH.forced, fused.BWD_DISPATCH.forced_stride = keep
-    # the tuner: a few frames of each order, then a decision that is kept
-    if not fused.BWD_DISPATCH.forced:
-        key = (str(dev), 333, 207)
-        fused.BWD_DISPATCH.state.pop(key, None)
-        for it in range(40):
-            tr.train_step(cams[it % 2], tgt)
-            torch.cuda.synchronize()
-        st = fused.BWD_DISPATCH.state[key]
-        assert st["decided"] in fused.BWD_DISPATCH.CANDIDATES and set(st["medians_ms"]) == set(fused.BWD_DISPATCH.CANDIDATES)
-        assert st["scratch"] is None and st["pairs"] >= fused.BWD_DISPATCH.PAIRS
+    # the order is a rule of the frame's size (no timing): the same for every run and every rank
+    assert fused.BWD_DISPATCH.stride(800, 800) == 7 and fused.BWD_DISPATCH.stride(1920, 1080) == 0
 
 
 @pytest.mark.gpu

@@ -1042,6 +1042,11 @@ def _compact(src, keep8, positions, n_keep, out=None, out_offset=0):
     out[out_offset:out_offset + n_keep] = rows
     return out
 ops.compact_rows = _compact
+def _compact_multi(jobs):
+    for src, keep8, positions, dst in jobs:
+        if src.shape[0] and dst.shape[0]:
+            dst[:int(keep8.sum())] = src[keep8.bool()]
+ops.compact_rows_multi = _compact_multi
 def _split(ids, samps, means, quats, log_scales, randn):
     from fusionsense_amd.legacy import quat_to_rotmat
     q = quats[ids] / quats[ids].norm(dim=-1, keepdim=True)
