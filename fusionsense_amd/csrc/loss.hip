@@ -37,6 +37,29 @@ __device__ __forceinline__ float block_sum_256(float v, float *lds4) {
     return lds4[0] + lds4[1] + lds4[2] + lds4[3];
 }
 
+// Which (tile, channel) a workgroup of the 1-D grid takes.  Block b runs on XCD b % 8 (observed placement: speed only), each
+// XCD with its own L2: the three channel workgroups of a tile read the same cache lines of the channel-last images and
+// neighbouring tiles share 10 halo columns / rows, so every XCD gets a CONTIGUOUS run of (tile, channel) ids, channels
+// fastest, tiles row-major — dispatched back to back on that XCD.  (Round 5: with channels in blockIdx.z the three
+// readers of a line ran a third of the launch apart, on different XCDs: FETCH 75 MB forward / 120 MB backward at 800x800
+// for 15 / 38 MB of distinct input; 24.6 -> 13.1 us backward, 22.9 -> 20.9 us forward.)  ``extra`` ids beyond the tiles
+// are returned with ch = 3 (the backward's combine).
+__device__ __forceinline__ bool loss_tile_of_block(int gx, int gy, int extra, int &ch, int &tx, int &ty) {
+    const int tiles3 = gx * gy * 3, total = tiles3 + extra;
+    const int per = (total + 7) >> 3;
+    const int id = ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3);
+    if (id >= total) return false;
+    if (id >= tiles3) { ch = 3; tx = ty = 0; return true; }
+    ch = id % 3;
+    const int t = id / 3;
+    ty = t / gx; tx = t - ty * gx;
+    return true;
+}
+__host__ inline unsigned loss_grid_blocks(int H, int W, int extra) {
+    const int total = (int)(ceil_div(W, kLT) * ceil_div(H, kLT)) * 3 + extra;
+    return 8u * (unsigned)((total + 7) >> 3);
+}
+
 // partials[2*blk] = sum |pred-gt| of this (tile, channel), partials[2*blk+1] = sum of its interior SSIM values
 template <bool MASKED>
 __global__ void __launch_bounds__(256)
@@ -52,8 +75,10 @@ ssim_l1_fwd_kernel(int H, int W, const float *__restrict__ pred, const float *__
     float (*sp)[kLP] = reinterpret_cast<float (*)[kLP]>(arena);
     float (*sg)[kLP] = reinterpret_cast<float (*)[kLP]>(arena + kLH * kLP);
     auto hb = [&](int m, int ly, int lx) -> float & { return arena[(m * kLH + ly) * kLQ + lx]; };
-    const int ch = blockIdx.z;
-    const int x0 = blockIdx.x * kLT, y0 = blockIdx.y * kLT;
+    const int gx = (W + kLT - 1) / kLT, gy = (H + kLT - 1) / kLT;
+    int ch, tx, ty;
+    if (!loss_tile_of_block(gx, gy, 0, ch, tx, ty)) return;
+    const int x0 = tx * kLT, y0 = ty * kLT;
     const int tr = threadIdx.x;
     // the halo: every load of this thread is issued before the first LDS write (written as one loop the
     // compiler waits for each element in turn: serialised HBM round trips)
@@ -188,7 +213,7 @@ ssim_l1_fwd_kernel(int H, int W, const float *__restrict__ pred, const float *__
     __syncthreads();
     const float t_ss = block_sum_256(ssim, red);
     if (tr == 255) {  // per-workgroup partials: same-address float atomics from thousands of blocks serialise
-        const int blk = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        const int blk = (ch * gy + ty) * gx + tx;
         sums[2 * blk + 0] = t_l1;
         sums[2 * blk + 1] = t_ss;
     }
@@ -241,14 +266,16 @@ ssim_l1_bwd_kernel(int H, int W, const float *__restrict__ pred, const float *__
     __shared__ double comb_red[4];
     auto sm = [&](int m, int ly, int lx) -> float & { return arena[(m * kLH + ly) * kLP + lx]; };
     auto hb = [&](int m, int ly, int lx) -> float & { return arena[(m * kLH + ly) * kLQ + lx]; };
-    if (blockIdx.z == 3) {
-        // a fourth z-slice (when launched): one workgroup of it combines the loss partials into the scalar loss —
-        // the value is only reported, so it rides in this launch instead of one of its own
-        if (blockIdx.x == 0 && blockIdx.y == 0) combine_partials<256>(comb, loss_out, comb_red);
+    const int gx = (W + kLT - 1) / kLT, gy = (H + kLT - 1) / kLT;
+    int ch, tx, ty;
+    if (!loss_tile_of_block(gx, gy, loss_out ? 1 : 0, ch, tx, ty)) return;
+    if (ch == 3) {
+        // one workgroup more (when asked for): it combines the loss partials into the scalar loss — the value is only
+        // reported, so it rides in this launch instead of one of its own
+        combine_partials<256>(comb, loss_out, comb_red);
         return;
     }
-    const int ch = blockIdx.z;
-    const int x0 = blockIdx.x * kLT, y0 = blockIdx.y * kLT;
+    const int x0 = tx * kLT, y0 = ty * kLT;
     const int tr = threadIdx.x;
     float ha[kHaloIters], hbv[kHaloIters], hc[kHaloIters];  // (all loads first, as in the forward)
 #pragma unroll
@@ -508,10 +535,10 @@ extern "C" int fsgs_ssim_l1_fwd_masked(int H, int W, const float *pred, const fl
     if (!pred || !gt || !dm_dmu1 || !dm_dsigma1 || !dm_dsigma12 || !sums) return FSGS_EINVAL;
     hipStream_t s = as_stream(stream);
     if (mask)
-        hipLaunchKernelGGL(ssim_l1_fwd_kernel<true>, dim3(ceil_div(W, kLT), ceil_div(H, kLT), 3), dim3(256), 0, s,
+        hipLaunchKernelGGL(ssim_l1_fwd_kernel<true>, dim3(loss_grid_blocks(H, W, 0)), dim3(256), 0, s,
                            H, W, pred, gt, mask, dm_dmu1, dm_dsigma1, dm_dsigma12, sums);
     else
-        hipLaunchKernelGGL(ssim_l1_fwd_kernel<false>, dim3(ceil_div(W, kLT), ceil_div(H, kLT), 3), dim3(256), 0, s,
+        hipLaunchKernelGGL(ssim_l1_fwd_kernel<false>, dim3(loss_grid_blocks(H, W, 0)), dim3(256), 0, s,
                            H, W, pred, gt, mask, dm_dmu1, dm_dsigma1, dm_dsigma12, sums);
     return check_launch();
 }
@@ -549,7 +576,7 @@ extern "C" int fsgs_ssim_l1_bwd_masked(int H, int W, const float *pred, const fl
         const int rc = fill_combine_args(a, n_terms, partials, rows, cols, weights, bias);
         if (rc != FSGS_OK) return rc;
     }
-    const dim3 grid(ceil_div(W, kLT), ceil_div(H, kLT), loss_out ? 4 : 3);
+    const dim3 grid(loss_grid_blocks(H, W, loss_out ? 1 : 0));
     if (mask)
         hipLaunchKernelGGL(ssim_l1_bwd_kernel<true>, grid, dim3(256), 0, as_stream(stream), H, W, pred, gt, mask,
                            dm_dmu1, dm_dsigma1, dm_dsigma12, v_loss, g_l1, g_ssim, v_pred, a, loss_out);
