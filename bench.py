@@ -109,7 +109,7 @@ def parse():
                     help="A/B: the forward compositing's walk (0 = four waves per quadrant, 1 = one wave); default = "
                          "the product's (fused.FWD_WALK: one wave per quadrant + hand-off of long walks)")
     ap.add_argument("--handoff", type=int, default=None,
-                    help="A/B: records a wave streams before it hands the rest of its list to the second pass "
+                    help="A/B: records a wave streams before it hands the rest of its list to the tail workgroups "
                          "(0 = never; default = fused.FWD_WALK.handoff_records)")
     ap.add_argument("--handoff-rel-len", type=int, default=None, help="A/B: hand off only lists longer than this many "
                     "times the frame's mean list length")
@@ -232,7 +232,7 @@ def bwd_dispatch_choice(dev, W, H):
 
 def fwd_walk_choice(dev, W, H, n_gaussians=0):
     """The forward compositing's walk of this run (fixed since round 5: fused.FWD_WALK): walk 1 = one wave per quadrant,
-    ``handoff_records`` > 0 = long walks finished chunk-parallel by the launch's second pass; ``tail_error`` = 1 if a
+    ``handoff_records`` > 0 = long walks finished chunk-parallel by the launch's tail workgroups; ``tail_error`` = 1 if a
     look-back wait of that pass ever ran into its bound (results invalid; never observed)."""
     try:
         from fusionsense_amd.fused import FWD_WALK
@@ -867,8 +867,8 @@ def main():
         alg = {
             "raster_bwd_quad_d4e3": ("raster_bwd_live_kernel<4,true,3> (RGB+ED and normal plane, one walk)" + r_note,
                                      M_r * (44 + 40) + P * (28 + 20) + n_vis * (48 + 28)),
-            "raster_fwd_quad_d4e3": (("raster_fwd_wave_kernel<4,3> + raster_fwd_tail_kernel<4,3> (one wave per quadrant, long "
-                                      "walks finished chunk-parallel by the second pass" if (fwd_walk_choice(dev, W, H, trainer.num_gaussians()) or {}).get("handoff_records")
+            "raster_fwd_quad_d4e3": (("raster_fwd_wave_kernel<4,3> (one wave per quadrant, long walks "
+                                      "finished chunk-parallel by tail workgroups of the same launch" if (fwd_walk_choice(dev, W, H, trainer.num_gaussians()) or {}).get("handoff_records")
                                       else "raster_fwd_wave_kernel<4,3> (one wave per quadrant" if (fwd_walk_choice(dev, W, H, trainer.num_gaussians()) or {}).get("walk") == 1
                                       else "raster_fwd_quad_kernel<4,3> (four waves per quadrant") +
                                      ": filter + gather + composite, RGB+ED and normal plane)" + r_note,

@@ -273,8 +273,8 @@ int fsgs_raster_fwd_quad(int C, int D, const float *packed, const int32_t *paylo
  * by side instead of 11 rounds of one.  Gradients are unchanged up to the order of the float atomics. */
 /* Hand-off of long walks (round 5; FSGS_WALK_ONE_WAVE, handoff_records > 0): a wave that has streamed `handoff_records`
  * records and still has open pixels and list entries left stops at the end of its 64-entry chunk and queues the rest of
- * its list; a SECOND launch of the same call (one wave per queued 64-entry chunk) forms every chunk's transmittance
- * factor independently, takes the transmittance at its start from its predecessors' factors, composites the chunk with
+ * its list; TAIL workgroups of the same launch (one wave per queued 64-entry chunk; `tail_items` of them are launched,
+ * which the caller sizes from the demand counter of earlier frames) form every chunk's transmittance factor independently, takes the transmittance at its start from its predecessors' factors, composites the chunk with
  * the reference's stop rule and adds the chunks' partial sums in list order — a list of n entries costs two chunk walks
  * of latency instead of n dependent steps (config #3 after densification: lists of 2 800 entries).  Same outputs up to
  * the association of products and sums per chunk (image tolerance), bit-reproducible, same streams / segment states /
@@ -292,8 +292,9 @@ int fsgs_raster_fwd_tail_error(const void *tail_scratch, fsgs_stream_t stream);
  * wave's dependent chain (~0.17 us per record on MI355X), so the frame's longest list bounds the launch unless long
  * walks are handed off (handoff_records, below).  Same images up
  * to the association of the transmittance products (<= 1 ulp per step), same streams for the backward (the one-wave
- * walk writes no padding records).  Which is faster depends on the frame (config #2: 95 vs 79 us; config #3 after
- * densification, lists of 2 800 entries: 153 vs 278 us): callers measure (fusionsense_amd/fused.py does). */
+ * walk writes no padding records).  Without the hand-off which is faster depends on the frame (config #2: 95 vs 79 us;
+ * config #3 after densification, lists of 2 800 entries: 153 vs 278 us); with it the one-wave walk wins on both (78 /
+ * 100 us) and fusionsense_amd/fused.py uses it for every frame. */
 #define FSGS_WALK_FOUR_WAVES 0
 #define FSGS_WALK_ONE_WAVE 1
 int fsgs_raster_bwd_quad(int C, int D, const float *records, const int32_t *n_rec,
@@ -308,7 +309,8 @@ int fsgs_raster_bwd_quad(int C, int D, const float *records, const int32_t *n_re
  * 0 or 1 = row-major, k > 1 = consecutive workgroups take quadrants k apart (raised to the next value coprime with the
  * number of quadrants).  Same gradients up to the order of the float atomics; which order is faster depends on the scene
  * (neighbouring quadrants share Gaussians and collide on their gradient lines; far-apart ones lose the L2 residency of
- * those lines), so callers measure (fusionsense_amd/fused.py does, per frame shape).  A launch argument since round 4: no
+ * those lines): fusionsense_amd/fused.py goes by the frame's size (7 apart up to 2^20 pixels, row-major above; measured
+ * 0.169 vs 0.176 ms at 800x800, 0.927 vs 0.947 ms at 1080p the other way round).  A launch argument since round 4: no
  * state outlives the call.  DEPRECATED: a negative value takes the process-wide default that
  * fsgs_set_bwd_dispatch_stride sets (initially env FSGS_BWD_PERM or 0; returns the previous value) — round-3 callers. */
 int fsgs_set_bwd_dispatch_stride(int stride);
