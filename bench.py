@@ -945,6 +945,9 @@ def main():
                     floor_ms = n_valu * 4.0 / (1024 * 2.4e9) * 1e3
                     r["valu_roofline"] = {"bound": "valu", "insts_per_launch": n_valu, "cycles_per_inst": 4, "simds": 1024,
                                           "clock_ghz": 2.4, "floor_ms": round(floor_ms, 4), "frac": round(floor_ms / ms, 4)}
+                    if floor_ms > ms:
+                        r["valu_roofline"]["note"] = ("above 1: many counted instructions ran with an empty EXEC mask (few "
+                                                      "useful lanes) and retire in fewer than 4 cycles — not a bound here")
             if valu is None and traffic_frac is None:
                 r["limiter"] = None  # no counters committed for this span and configuration
             elif valu is not None and valu >= 0.65:
