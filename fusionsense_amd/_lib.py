@@ -134,6 +134,8 @@ SIGNATURES = {
     "fsgs_ssim_l1_bwd_masked": (_i, [_i, _i, _p, _p, _p, _p, _p, _p, _p, _f, _f, _p, _i, _p, _p, _p, _p, _f, _p, _p]),
     "fsgs_fusion_aux_num_partials": (_i64, [_i, _i]),
     "fsgs_fusion_aux_loss": (_i, [_i, _i, _p, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p, _i, _p]),
+    "fsgs_fusion_aux_loss_riders": (_i, [_i, _i, _p, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p, _i,
+                                         _i, _p, _p, _i, _p, _p, _p, _p, _p]),
     "fsgs_normals_from_depth": (_i, [_i, _i, _p, _p, _f, _f, _f, _f, _p, _p]),
     "fsgs_normal_cosine_num_partials": (_i64, [_i]),
     "fsgs_normal_cosine_loss": (_i, [_i, _i, _p, _p, _p, _i, _f, _p, _p, _p, _p]),

@@ -22,6 +22,60 @@ constexpr int kFaGtUnmasked = 1;   // normal_gt is used as it is (pseudo normals
 constexpr int kFaEdgeTv = 2;       // depth smoothness = EdgeAwareTV (losses.py:241-266) instead of TVLoss
 constexpr int kFaTypeShift = 2;    // bits 2-3: depth-loss type 0 EdgeAwareLogL1, 1 L1, 2 LogL1, 3 MSE (dn_model.py:725-736)
 
+// Riders of the fusion_aux launch (round 5): the min-scale term's and the touch-normal term's partial sums are two
+// launches of a few workgroups each (5 us apiece with their boundaries) that depend on nothing the step has not long
+// finished — their blocks take extra grid ROWS of this launch instead (blockIdx.y >= gy).
+struct FusionAuxRiders {
+    int gy;                       // first rider row (= the image's block rows)
+    int N, nm;                    // min-scale: Gaussians, blocks
+    const float *log_scales;
+    float *ms_partial;
+    int n_touch, nt;              // touch normals: anchors, blocks
+    const int64_t *touch_idx;
+    const float *normals_world, *touch_normals;
+    float *t_partial;
+};
+
+__device__ __forceinline__ void min_scale_partial_block(int block, int N, const float *__restrict__ log_scales,
+                                                        float *__restrict__ partial, float *red) {
+    const int n = block * 256 + threadIdx.x;
+    float v = 0.f;
+    if (n < N) {
+        const float s0 = log_scales[n * 3 + 0], s1 = log_scales[n * 3 + 1], s2 = log_scales[n * 3 + 2];
+        v = expf(fminf(s0, fminf(s1, s2)));  // min exp = exp min (monotone)
+    }
+    v = wave_sum_to_last_row(v);
+    if ((threadIdx.x & 63) == 63) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        partial[2 * block + 0] = red[0] + red[1] + red[2] + red[3];
+        partial[2 * block + 1] = 0.f;
+    }
+}
+
+__device__ __forceinline__ void touch_sqerr_partial_block(int block, int n, const int64_t *__restrict__ idx,
+                                                          const float *__restrict__ normals_world,
+                                                          const float *__restrict__ touch_normals,
+                                                          float *__restrict__ partial, float *red) {
+    const int i = block * 256 + threadIdx.x;
+    float v = 0.f;
+    if (i < n) {
+        const int64_t r = idx[i];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float e = normals_world[r * 3 + k] - touch_normals[(int64_t)i * 3 + k];
+            v += e * e;
+        }
+    }
+    v = wave_sum_to_last_row(v);
+    if ((threadIdx.x & 63) == 63) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        partial[2 * block + 0] = red[0] + red[1] + red[2] + red[3];
+        partial[2 * block + 1] = 0.f;
+    }
+}
+
 // 256 threads = 32 x 8 pixels
 template <bool GRADS>
 __global__ void __launch_bounds__(256)
@@ -29,8 +83,16 @@ fusion_aux_kernel(int H, int W, const float *__restrict__ depth, const float *__
                   const float *__restrict__ image, const float *__restrict__ sensor,
                   const float *__restrict__ normal_gt, const float *__restrict__ mask, float tol, FusionAuxW ww,
                   const float *__restrict__ v_loss, float *__restrict__ partial, float *__restrict__ v_depth,
-                  float *__restrict__ v_normal, int flags) {
+                  float *__restrict__ v_normal, int flags, FusionAuxRiders rd) {
     __shared__ float red[4][kFA];
+    if ((int)blockIdx.y >= rd.gy) {  // a rider block (uniform per workgroup)
+        const int r = ((int)blockIdx.y - rd.gy) * (int)gridDim.x + (int)blockIdx.x;
+        if (r < rd.nm) min_scale_partial_block(r, rd.N, rd.log_scales, rd.ms_partial, &red[0][0]);
+        else if (r - rd.nm < rd.nt)
+            touch_sqerr_partial_block(r - rd.nm, rd.n_touch, rd.touch_idx, rd.normals_world, rd.touch_normals, rd.t_partial,
+                                      &red[0][0]);
+        return;
+    }
     const int x = blockIdx.x * 32 + (threadIdx.x & 31);
     const int y = blockIdx.y * 8 + (threadIdx.x >> 5);
     const bool in = x < W && y < H;
@@ -307,21 +369,38 @@ extern "C" int fsgs_fusion_aux_loss(int H, int W, const float *depth, const floa
                                     const float *sensor_depth, const float *normal_gt, const float *mask,
                                     float depth_tol, const float *w, const float *v_loss, float *partial,
                                     float *v_depth, float *v_normal, int flags, fsgs_stream_t stream) {
-    if (H < 0 || W < 0 || flags < 0 || flags > 15) return FSGS_EINVAL;
-    if (H == 0 || W == 0) return FSGS_OK;
+    return fsgs_fusion_aux_loss_riders(H, W, depth, normal, image, sensor_depth, normal_gt, mask, depth_tol, w, v_loss,
+                                       partial, v_depth, v_normal, flags, 0, nullptr, nullptr, 0, nullptr, nullptr,
+                                       nullptr, nullptr, stream);
+}
+
+extern "C" int fsgs_fusion_aux_loss_riders(int H, int W, const float *depth, const float *normal, const float *image,
+                                           const float *sensor_depth, const float *normal_gt, const float *mask,
+                                           float depth_tol, const float *w, const float *v_loss, float *partial,
+                                           float *v_depth, float *v_normal, int flags, int N, const float *log_scales,
+                                           float *min_scale_partial, int n_touch, const int64_t *touch_idx,
+                                           const float *normals_world, const float *touch_normals,
+                                           float *touch_partial, fsgs_stream_t stream) {
+    if (H < 0 || W < 0 || flags < 0 || flags > 15 || N < 0 || n_touch < 0) return FSGS_EINVAL;
+    if (H == 0 || W == 0) return (N > 0 || n_touch > 0) ? FSGS_EINVAL : FSGS_OK;  // (riders need an image's launch)
     if (!depth || !image || !sensor_depth || !w || !partial) return FSGS_EINVAL;
     if (normal_gt && !normal) return FSGS_EINVAL;
     if (v_loss && (!v_depth || (normal && !v_normal))) return FSGS_EINVAL;
+    if (N > 0 && (!log_scales || !min_scale_partial)) return FSGS_EINVAL;
+    if (n_touch > 0 && (!touch_idx || !normals_world || !touch_normals || !touch_partial)) return FSGS_EINVAL;
     FusionAuxW ww;
     for (int k = 0; k < 7; ++k) ww.w[k] = w[k];
     ww.w[7] = 0.f;
-    const dim3 grid(ceil_div(W, 32), ceil_div(H, 8));
+    const int gx = (int)ceil_div(W, 32), gy = (int)ceil_div(H, 8);
+    FusionAuxRiders rd = {gy, N, (int)ceil_div(N, 256), log_scales, min_scale_partial, n_touch, (int)ceil_div(n_touch, 256),
+                          touch_idx, normals_world, touch_normals, touch_partial};
+    const dim3 grid(gx, gy + (int)ceil_div(rd.nm + rd.nt, gx));
     if (v_loss)
         hipLaunchKernelGGL(fusion_aux_kernel<true>, grid, dim3(256), 0, as_stream(stream), H, W, depth, normal, image,
-                           sensor_depth, normal_gt, mask, depth_tol, ww, v_loss, partial, v_depth, v_normal, flags);
+                           sensor_depth, normal_gt, mask, depth_tol, ww, v_loss, partial, v_depth, v_normal, flags, rd);
     else
         hipLaunchKernelGGL(fusion_aux_kernel<false>, grid, dim3(256), 0, as_stream(stream), H, W, depth, normal, image,
-                           sensor_depth, normal_gt, mask, depth_tol, ww, nullptr, partial, nullptr, nullptr, flags);
+                           sensor_depth, normal_gt, mask, depth_tol, ww, nullptr, partial, nullptr, nullptr, flags, rd);
     return check_launch();
 }
 

@@ -1458,10 +1458,17 @@ class _FusionLoss(torch.autograd.Function):
         if seed is not None:
             v_depth = torch.empty_like(depth)
             v_normal = torch.empty_like(normal) if normal is not None else None
-        _run(lib.fsgs_fusion_aux_loss, (H, W, ptr(depth), ptr(normal), ptr(fb.image), ptr(fb.sensor_depth),
-                                        ptr(normal_gt), ptr(fb.mask),
-                                        float(cfg.depth_tolerance), wa, ptr(seed), ptr(aux), ptr(v_depth),
-                                        ptr(v_normal), flags, sp), "fsgs_fusion_aux_loss")
+        # the min-scale term's and the touch-normal term's partial sums ride in this launch (extra workgroups: fsgs.h)
+        pm = torch.empty((N + 255) // 256, 2, **f32) if g_min != 0.0 else None
+        pt = torch.empty((n_touch + 255) // 256, 2, **f32) if n_touch > 0 else None
+        _run(lib.fsgs_fusion_aux_loss_riders, (H, W, ptr(depth), ptr(normal), ptr(fb.image), ptr(fb.sensor_depth),
+                                               ptr(normal_gt), ptr(fb.mask),
+                                               float(cfg.depth_tolerance), wa, ptr(seed), ptr(aux), ptr(v_depth),
+                                               ptr(v_normal), flags,
+                                               N if pm is not None else 0, ptr(log_scales), ptr(pm),
+                                               n_touch, ptr(touch_idx), ptr(normals_world),
+                                               ptr(_c(touch_normals)) if n_touch > 0 else None, ptr(pt), sp),
+             "fsgs_fusion_aux_loss")
         partials, weights = [sums, aux], [(g_l1, g_ssim), tuple(w_aux) + (0.0,)]
         w_mono = mono_depth_weights(cfg, fb)
         if w_mono is not None:
@@ -1488,15 +1495,10 @@ class _FusionLoss(torch.autograd.Function):
                                                ptr(pc), ptr(v_normal), sp), "fsgs_normal_cosine_loss")
             partials.append(pc)
             weights.append((g_cos, 0.0))
-        if g_min != 0.0:
-            pm = torch.empty((N + 255) // 256, 2, **f32)
-            _run(lib.fsgs_min_scale_loss, (N, ptr(log_scales), 0.0, None, ptr(pm), None, sp), "fsgs_min_scale_loss")
+        if pm is not None:
             partials.append(pm)
             weights.append((g_min, 0.0))
-        if n_touch > 0:
-            pt = torch.empty((n_touch + 255) // 256, 2, **f32)
-            _run(lib.fsgs_touch_normal_sqerr, (n_touch, ptr(touch_idx), ptr(normals_world), ptr(_c(touch_normals)),
-                                               ptr(pt), sp), "fsgs_touch_normal_sqerr")
+        if pt is not None:
             partials.append(pt)
             weights.append((g_touch, 0.0))
         ctx.save_for_backward(rgb, maps, depth, normal if normal is not None else torch.empty(0, device=dev),

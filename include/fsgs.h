@@ -827,6 +827,16 @@ int fsgs_fusion_aux_loss(int H, int W, const float *depth, const float *normal, 
                          const float *sensor_depth, const float *normal_gt, const float *mask, float depth_tol,
                          const float *w, const float *v_loss, float *partial, float *v_depth, float *v_normal,
                          int flags, fsgs_stream_t stream);
+/* fsgs_fusion_aux_loss with the partial sums of fsgs_min_scale_loss (forward only: g = 0, no gradient) and
+ * fsgs_touch_normal_sqerr riding in the same launch as extra workgroups: N > 0 -> min_scale_partial [ceil(N / 256), 2],
+ * n_touch > 0 -> touch_partial [ceil(n_touch / 256), 2], the same values as the stand-alone calls (two launches less on
+ * FusionSense's training step). */
+int fsgs_fusion_aux_loss_riders(int H, int W, const float *depth, const float *normal, const float *image,
+                                const float *sensor_depth, const float *normal_gt, const float *mask, float depth_tol,
+                                const float *w, const float *v_loss, float *partial, float *v_depth, float *v_normal,
+                                int flags, int N, const float *log_scales, float *min_scale_partial, int n_touch,
+                                const int64_t *touch_idx, const float *normals_world, const float *touch_normals,
+                                float *touch_partial, fsgs_stream_t stream);
 /* get_loss_dict's normal_supervision == "depth" target (dn_model.py:774-795; utils/normal_utils.py:8-46 over
  * utils/camera_utils.py:92-144 with an identity pose): pseudo normals of depth * mask — interior pixels
  * normalize(cross(right - left, top - bottom)) of the back-projected pixel centres, border zero — with y and z negated,

@@ -363,6 +363,47 @@ def test_fused_ssim_l1_loss(dev, H, W):
     assert rel_err(p_g.grad / 3.0, p_ref.grad) < 1e-3
 
 
+def test_fusion_aux_riders_equal_the_stand_alone_launches(dev):
+    """fsgs_fusion_aux_loss_riders: the min-scale and touch-normal partial sums computed by extra workgroups of the aux
+    launch are those of fsgs_min_scale_loss / fsgs_touch_normal_sqerr, and the aux partials are untouched by the riders
+    (ragged sizes: rider blocks spill over several extra grid rows)."""
+    import ctypes as C
+    from fusionsense_amd._lib import load, ptr, stream_ptr
+    lib = load()
+    H, W, N, nt = 45, 70, 2001, 700   # gx = 3: 8 + 3 rider blocks over 4 extra rows
+    g = torch.Generator().manual_seed(9)
+    r = lambda *sh: torch.rand(*sh, generator=g).to(dev)  # noqa: E731
+    depth, normal, image, sensor, ngt = r(H, W, 1) * 3, r(H, W, 3), r(H, W, 3), r(H, W) * 3, r(H, W, 3)
+    mask = (r(H, W) > 0.2).float()
+    log_scales = (torch.randn(N, 3, generator=g) - 4).to(dev)
+    nw, tn = r(N, 3), r(nt, 3)
+    idx = torch.randint(0, N, (nt,), generator=g).to(dev)
+    w = (C.c_float * 7)(*[0.3, 0.2, 0.1, 0.05, 0.4, 0.1, 0.2])
+    sp = stream_ptr(dev)
+    P = lib.fsgs_fusion_aux_num_partials(H, W)
+    a0, a1 = torch.zeros(P, 8, device=dev), torch.zeros(P, 8, device=dev)
+    pm0, pm1 = torch.zeros((N + 255) // 256, 2, device=dev), torch.full(((N + 255) // 256, 2), -1.0, device=dev)
+    pt0, pt1 = torch.zeros((nt + 255) // 256, 2, device=dev), torch.full(((nt + 255) // 256, 2), -1.0, device=dev)
+    assert lib.fsgs_fusion_aux_loss(H, W, ptr(depth), ptr(normal), ptr(image), ptr(sensor), ptr(ngt), ptr(mask), 0.01, w,
+                                    None, ptr(a0), None, None, 0, sp) == 0
+    assert lib.fsgs_min_scale_loss(N, ptr(log_scales), 0.0, None, ptr(pm0), None, sp) == 0
+    assert lib.fsgs_touch_normal_sqerr(nt, ptr(idx), ptr(nw), ptr(tn), ptr(pt0), sp) == 0
+    assert lib.fsgs_fusion_aux_loss_riders(H, W, ptr(depth), ptr(normal), ptr(image), ptr(sensor), ptr(ngt), ptr(mask), 0.01,
+                                           w, None, ptr(a1), None, None, 0, N, ptr(log_scales), ptr(pm1), nt, ptr(idx),
+                                           ptr(nw), ptr(tn), ptr(pt1), sp) == 0
+    assert torch.equal(a0, a1) and torch.equal(pm0, pm1) and torch.equal(pt0, pt1)
+    assert float(pm0[:, 0].sum()) > 0 and float(pt0[:, 0].sum()) > 0
+    # one rider only, and a missing buffer is refused
+    pm1.fill_(-1.0)
+    assert lib.fsgs_fusion_aux_loss_riders(H, W, ptr(depth), ptr(normal), ptr(image), ptr(sensor), ptr(ngt), ptr(mask), 0.01,
+                                           w, None, ptr(a1), None, None, 0, N, ptr(log_scales), ptr(pm1), 0, None, None,
+                                           None, None, sp) == 0
+    assert torch.equal(pm0, pm1)
+    assert lib.fsgs_fusion_aux_loss_riders(H, W, ptr(depth), ptr(normal), ptr(image), ptr(sensor), ptr(ngt), ptr(mask), 0.01,
+                                           w, None, ptr(a1), None, None, 0, N, ptr(log_scales), None, 0, None, None, None,
+                                           None, sp) != 0
+
+
 @pytest.mark.parametrize("with_normal", [True, False])
 def test_train_loss_single_node(dev, with_normal):
     """The whole config-#2 loss as one node (ssim+l1 on rgb, l1 on depth and normal) against torch."""
