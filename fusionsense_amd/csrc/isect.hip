@@ -889,9 +889,16 @@ int launch_split_sort(int T, int n_tiles, int tile_bits, const int32_t *isect_of
 int64_t split_scratch_ints(int T, int64_t n_live);
 }
 
-// threads per workgroup: the largest of 1024 / 512 / 256 that still gives >= 256 workgroups
+// Workgroup size of the binning passes: the largest of 1024 / 512 / 256 threads that still gives FSGS_BIN_WGS_MIN
+// workgroups — TWO per CU (round 5; rounds 1-4: one).  The passes are chains of dependent phases (project, scan, enumerate,
+// claim with returning atomics, store) with barriers in between: a second workgroup on the CU fills the first one's waits.
+// Config #2 (300 k Gaussians: 586 workgroups of 512 instead of 293 of 1024): GPU step 0.515-0.518 -> 0.506-0.507 ms;
+// 1172 workgroups of 256: 0.530 (every workgroup claims its own run in every tile it touches).
+#ifndef FSGS_BIN_WGS_MIN
+#define FSGS_BIN_WGS_MIN 512
+#endif
 static inline int bin_threads(int64_t total) {
-    return total >= 256 * 1024 ? 1024 : (total >= 256 * 512 ? 512 : 256);
+    return total >= (int64_t)FSGS_BIN_WGS_MIN * 1024 ? 1024 : (total >= (int64_t)FSGS_BIN_WGS_MIN * 512 ? 512 : 256);
 }
 // chunks of 1024 Gaussians per workgroup: as many as keep the table at ~512 rows
 static inline int bin_chunks(int64_t total) {
