@@ -115,6 +115,7 @@ def parse():
                     "times the frame's mean list length")
     ap.add_argument("--handoff-gate-len", type=int, default=None, help="A/B: hand off only in frames whose longest list "
                     "exceeds this many times the mean list length (0 = any frame)")
+    ap.add_argument("--bwd-order", type=int, default=None, help="A/B: 0 = the backward's quadrants in the size rule's order")
     ap.add_argument("--bin-fill", type=int, default=None, help="A/B: 0 = two-pass binning on every frame")
     ap.add_argument("--bwd-queue", type=int, default=None, help="A/B: queue positions for the backward's extra workgroups")
     ap.add_argument("--tail-items", type=int, default=None, help="A/B: queue positions of the hand-off (= tail workgroups)")
@@ -224,8 +225,10 @@ def cpu_baseline(args):
 
 def bwd_dispatch_choice(dev, W, H):
     try:
-        from fusionsense_amd.fused import BWD_DISPATCH
-        return {"stride": int(BWD_DISPATCH.stride(W, H)), "rule": "7 apart up to 2^20 pixels, row-major above", "tuning_frames": 0}
+        import fusionsense_amd.fused as _f
+        return {"stride": int(_f.BWD_DISPATCH.stride(W, H)), "rule": "7 apart up to 2^20 pixels, row-major above",
+                "longest_share_first": bool(_f.BWD_ORDER and _f.BWD_QUEUE_ITEMS > 0),  # (models below 2^20 Gaussians)
+                "tuning_frames": 0}
     except Exception:
         return None
 
@@ -546,6 +549,9 @@ def main():
     if args.bin_fill is not None:
         import fusionsense_amd.fused as _f
         _f.BIN_FILL = bool(args.bin_fill)
+    if args.bwd_order is not None:
+        import fusionsense_amd.fused as _f
+        _f.BWD_ORDER = bool(args.bwd_order)
     if args.bwd_queue is not None:
         import fusionsense_amd.fused as _f
         _f.BWD_QUEUE_ITEMS = int(args.bwd_queue)

@@ -31,7 +31,7 @@ class AdamGroups(C.Structure):
 # == FSGS_ABI_VERSION of include/fsgs.h as of the SIGNATURES table below: load() refuses any other library (a stale
 # build — the .so files are git-ignored and travel separately, A/B builds come in through FSGS_LIB — would read a stream
 # pointer as a flag or write past a buffer that has since grown)
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 SIGNATURES = {
     "fsgs_version": (_i, []),
@@ -83,8 +83,8 @@ SIGNATURES = {
     "fsgs_raster_fwd_tail_scratch_bytes": (_i64, [_i]),
     "fsgs_raster_fwd_tail_error": (_i, [_p, _p]),
     "fsgs_set_bwd_dispatch_stride": (_i, [_i]),
-    "fsgs_raster_bwd_quad": (_i, [_i, _i, _p, _p, _p, _i64, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _i, _p, _p, _i, _p]),
-    "fsgs_raster_bwd_quad_images": (_i, [_p, _p, _p, _i64, _i, _i, _i, _i] + [_p] * 10 + [_i, _p, _i64, _i, _p, _p, _i, _p]),
+    "fsgs_raster_bwd_quad": (_i, [_i, _i, _p, _p, _p, _i64, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _i, _p, _p, _i, _p, _p]),
+    "fsgs_raster_bwd_quad_images": (_i, [_p, _p, _p, _i64, _i, _i, _i, _i] + [_p] * 10 + [_i, _p, _i64, _i, _p, _p, _i, _p, _p]),
     "fsgs_campos_from_viewmats": (_i, [_i, _p, _p, _p]),
     "fsgs_raster_unpack_grads": (_i, [_i64, _i, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p]),
     "fsgs_sh_fwd_split": (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p]),
@@ -103,6 +103,8 @@ SIGNATURES = {
     "fsgs_activate_bwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "fsgs_epilogue_fwd": (_i, [_i64, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p]),
     "fsgs_epilogue_loss_fwd": (_i, [_i64, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p]),
+    "fsgs_epilogue_fwd_order": (_i, [_i64, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _f, _f, _p, _p, _p,
+                                     _p, _p, _p, _p, _i, _i, _p]),
     "fsgs_epilogue_bwd": (_i, [_i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "fsgs_normals_fwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _p]),
     "fsgs_normals_bwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _p]),

@@ -61,6 +61,53 @@ struct EpilogueLoss {
     float g_depth, g_normal;
 };
 
+// Rider of the epilogue launch (round 5): the dispatch order of the compositing BACKWARD.  A backward workgroup's time is its
+// quadrant's own share of records, and the launch is ~6 rounds of resident workgroups: started longest first, its last
+// round is the short ones (config #3's trained scene: 0.191 -> 0.174 ms; config #2: 0.1675 -> 0.165).  The streams' lengths
+// are known once the forward has finished — i.e. here: extra blocks of this launch (one wave per 1024 quadrants) file every
+// quadrant under one of kOrderClasses classes of record counts (16 records wide, the last one open-ended) — a counting
+// sort: per-block class counts in LDS, ONE returning atomic per (block, class) on the class's counter reserves the block's
+// run in the class's list, order[class][slot] = the quadrant's position in the backward's grid.  (Filing from the
+// forward's finishing waves — one returning atomic per quadrant on a handful of hot counters — took the forward from 78 to
+// 130 us.)  One camera.
+constexpr int kOrderClasses = 32;
+struct BwdOrderRider {
+    const int32_t *n_rec, *seg_split;  // [4, T]
+    int32_t *counters;                 // [kOrderClasses], zeroed by the caller (behind the backward's queue)
+    int32_t *order;                    // [kOrderClasses, 4 T]
+    int tw, n_tiles, first_block;      // rider blocks = blockIdx.x >= first_block
+};
+
+__device__ __forceinline__ void bwd_order_rider_block(const BwdOrderRider &r, int block) {
+    __shared__ int cnt[kOrderClasses], base[kOrderClasses];
+    const int lane = threadIdx.x;  // 64 threads
+    const int nq = 4 * r.n_tiles;
+    if (lane < kOrderClasses) cnt[lane] = 0;
+    __syncthreads();
+    int cls[16], rank[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int i = block * 1024 + k * 64 + lane;  // index into [4, T]: quadrant q = i / T of tile i % T
+        cls[k] = -1;
+        if (i < nq) {
+            const int own = r.n_rec[i] - 64 * (r.seg_split ? r.seg_split[i] : 0);
+            cls[k] = min(max(own, 0) >> 4, kOrderClasses - 1);
+            rank[k] = atomicAdd(&cnt[cls[k]], 1);
+        }
+    }
+    __syncthreads();
+    if (lane < kOrderClasses) base[lane] = cnt[lane] > 0 ? atomicAdd(r.counters + lane, cnt[lane]) : 0;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        if (cls[k] < 0) continue;
+        const int i = block * 1024 + k * 64 + lane;
+        const int q = i / r.n_tiles, t = i - q * r.n_tiles;
+        const int ty = t / r.tw, tx = t - ty * r.tw;
+        r.order[(int64_t)cls[k] * nq + base[cls[k]] + rank[k]] = (2 * ty + (q >> 1)) * (2 * r.tw) + 2 * tx + (q & 1);
+    }
+}
+
 // One WAVE per 256 pixels, four consecutive pixels per lane (round 5): every array is read and written with 16-byte
 // accesses — the 3-channel images as three float4 per lane (12 floats = 4 pixels) instead of twelve 4-byte accesses at a
 // stride of 12 bytes, which cost three partial-line transactions each (17.4 -> see DESIGN.md 5.4).  The per-256-pixel
@@ -70,7 +117,11 @@ __global__ void __launch_bounds__(64)
 epilogue_fwd_kernel(int64_t P, const float4 *__restrict__ render, const float *__restrict__ alphas,
                     const float *__restrict__ render_extra, const float *__restrict__ bg,
                     const float *__restrict__ max_last, int n_cells, float *__restrict__ rgb,
-                    float *__restrict__ depth, float *__restrict__ normal, EpilogueLoss L) {
+                    float *__restrict__ depth, float *__restrict__ normal, EpilogueLoss L, BwdOrderRider rider) {
+    if (rider.order && (int)blockIdx.x >= rider.first_block) {
+        bwd_order_rider_block(rider, (int)blockIdx.x - rider.first_block);
+        return;
+    }
     const int lane = threadIdx.x;
     const int64_t p0 = ((int64_t)blockIdx.x * 64 + lane) * 4;  // this lane's first pixel
     const bool full = p0 + 3 < P;                              // all four pixels exist (else: per-pixel accesses)
@@ -281,7 +332,7 @@ extern "C" int fsgs_epilogue_fwd(int64_t n_pixels, const float *render, const fl
     const int n_cells = n_partial < 0 ? -n_partial : 1;
     hipLaunchKernelGGL(epilogue_fwd_kernel<false>, dim3(ceil_div(n_pixels, 256)), dim3(64), 0, s, n_pixels,
                        reinterpret_cast<const float4 *>(render), alphas, render_extra, bg, max_last, n_cells, rgb, depth,
-                       normal, EpilogueLoss{});
+                       normal, EpilogueLoss{}, BwdOrderRider{});
     return check_launch();
 }
 
@@ -292,15 +343,43 @@ extern "C" int fsgs_epilogue_loss_fwd(int64_t n_pixels, const float *render, con
                                       float *rgb, float *depth, float *normal, const float *depth_gt,
                                       const float *normal_gt, const float *v_loss, float g_depth, float g_normal,
                                       float *partial, float *v_depth, float *v_normal, fsgs_stream_t stream) {
+    if (!depth_gt) return FSGS_EINVAL;
+    return fsgs_epilogue_fwd_order(n_pixels, render, alphas, render_extra, bg, max_last, n_cells, rgb, depth, normal,
+                                   depth_gt, normal_gt, v_loss, g_depth, g_normal, partial, v_depth, v_normal, nullptr,
+                                   nullptr, nullptr, nullptr, 0, 0, stream);
+}
+
+// fsgs_epilogue_loss_fwd (depth_gt != NULL) or fsgs_epilogue_fwd over the forward's partial maxima (depth_gt == NULL: no
+// loss terms) — and, riding in the launch, the dispatch order of the compositing backward (bwd_order != NULL: fsgs.h)
+extern "C" int fsgs_epilogue_fwd_order(int64_t n_pixels, const float *render, const float *alphas,
+                                       const float *render_extra, const float *bg, const float *max_last, int n_cells,
+                                       float *rgb, float *depth, float *normal, const float *depth_gt,
+                                       const float *normal_gt, const float *v_loss, float g_depth, float g_normal,
+                                       float *partial, float *v_depth, float *v_normal, const int32_t *n_rec,
+                                       const int32_t *seg_split, int32_t *order_counters, int32_t *bwd_order,
+                                       int tile_width, int tile_height, fsgs_stream_t stream) {
     if (n_pixels < 0 || n_cells < 1) return FSGS_EINVAL;
     if (n_pixels == 0) return FSGS_OK;
-    if (!render || !alphas || !bg || !max_last || !rgb || !depth || !depth_gt || !v_loss || !partial || !v_depth)
-        return FSGS_EINVAL;
-    if ((normal && !render_extra) || (normal_gt && (!normal || !v_normal))) return FSGS_EINVAL;
-    const EpilogueLoss L = {depth_gt, normal_gt, v_loss, partial, v_depth, v_normal, g_depth, g_normal};
-    hipLaunchKernelGGL(epilogue_fwd_kernel<true>, dim3(ceil_div(n_pixels, 256)), dim3(64), 0, as_stream(stream),
-                       n_pixels, reinterpret_cast<const float4 *>(render), alphas, render_extra, bg, max_last, n_cells,
-                       rgb, depth, normal, L);
+    if (!render || !alphas || !bg || !max_last || !rgb || !depth) return FSGS_EINVAL;
+    if (depth_gt && (!v_loss || !partial || !v_depth)) return FSGS_EINVAL;
+    if ((normal && !render_extra) || (normal_gt && (!depth_gt || !normal || !v_normal))) return FSGS_EINVAL;
+    if (bwd_order && (!n_rec || !order_counters || tile_width < 1 || tile_height < 1)) return FSGS_EINVAL;
+    const int n_blocks = (int)ceil_div(n_pixels, 256);
+    BwdOrderRider rd{};
+    int n_rider = 0;
+    if (bwd_order) {
+        rd = BwdOrderRider{n_rec, seg_split, order_counters, bwd_order, tile_width, tile_width * tile_height, n_blocks};
+        n_rider = (int)ceil_div((int64_t)4 * tile_width * tile_height, 1024);
+    }
+    const float4 *r4 = reinterpret_cast<const float4 *>(render);
+    if (depth_gt) {
+        const EpilogueLoss L = {depth_gt, normal_gt, v_loss, partial, v_depth, v_normal, g_depth, g_normal};
+        hipLaunchKernelGGL(epilogue_fwd_kernel<true>, dim3(n_blocks + n_rider), dim3(64), 0, as_stream(stream), n_pixels, r4,
+                           alphas, render_extra, bg, max_last, n_cells, rgb, depth, normal, L, rd);
+    } else {
+        hipLaunchKernelGGL(epilogue_fwd_kernel<false>, dim3(n_blocks + n_rider), dim3(64), 0, as_stream(stream), n_pixels,
+                           r4, alphas, render_extra, bg, max_last, n_cells, rgb, depth, normal, EpilogueLoss{}, rd);
+    }
     return check_launch();
 }
 

@@ -97,7 +97,7 @@ raster_bwd_live_kernel(int64_t cap, const float4 *__restrict__ rec,
                        const float *__restrict__ render_extra, const float *__restrict__ v_render_extra,
                        const int32_t *__restrict__ n_rec, GetOutputsGrads ep, int64_t replica_rows, int merge_thr16,
                        int perm_stride, const int32_t *__restrict__ seg_split, const int32_t *__restrict__ bwd_queue,
-                       int bwd_qcap) {
+                       int bwd_qcap, const int32_t *__restrict__ bwd_order) {
     __shared__ QLds<E> Lw[kBwdWaves];
     constexpr int RS = E ? 4 : 3;
     constexpr int SS = 64 * (1 + D + E);
@@ -121,6 +121,26 @@ raster_bwd_live_kernel(int64_t cap, const float4 *__restrict__ rec,
         const int ty = t / tw, tx = t - ty * tw;
         bx = 2 * tx + (qq & 1); by = 2 * ty + (qq >> 1);
         seg_lo = it.y; seg_hi = it.z;
+    } else if (bwd_order) {
+        // longest own share first (raster_quad.hip: split_backward files every quadrant under a class of record counts):
+        // workgroup b of the image rows takes entry b of the classes laid end to end, the longest class first
+        constexpr int kOrderClasses = 32;
+        const int b = grid_row * (int)gridDim.x + (int)blockIdx.x;
+        const int lane_o = threadIdx.x & 63;
+        const int32_t *cnt = bwd_queue + 4 + 4 * bwd_qcap;
+        const int mine = lane_o < kOrderClasses ? cnt[kOrderClasses - 1 - lane_o] : 0;  // lane l: class 31 - l
+        int incl = mine;
+#pragma unroll
+        for (int d = 1; d < kOrderClasses; d <<= 1) {
+            const int o = __shfl_up(incl, d, 64);
+            if (lane_o >= d) incl += o;
+        }
+        const uint64_t past = __ballot(lane_o < kOrderClasses && incl > b);  // classes whose end lies beyond b
+        if (past == 0ull) return;  // (b >= the quadrants filed: nothing left — quadrants the forward never finished)
+        const int l = __ffsll((long long)past) - 1;
+        const int excl = __builtin_amdgcn_readlane(incl - mine, l);
+        const unsigned lin = (unsigned)bwd_order[(int64_t)(kOrderClasses - 1 - l) * (gridDim.x * 2 * th) + (b - excl)];
+        by = lin / gridDim.x; bx = lin - by * gridDim.x;
     } else if (perm_stride > 1) {
         const unsigned total = gridDim.x * (unsigned)(2 * th);
         const unsigned lin = (unsigned)(((unsigned long long)((unsigned)grid_row * gridDim.x + blockIdx.x) * (unsigned)perm_stride) % total);
@@ -508,7 +528,8 @@ static int launch_bwd_live(int C, int D, const float *records, const int32_t *n_
                            fsgs_stream_t stream, int dispatch_stride,
                            GetOutputsGrads ep = GetOutputsGrads{nullptr, nullptr, nullptr, nullptr, nullptr},
                            int64_t replica_rows = 0, const int32_t *seg_split = nullptr,
-                           const int32_t *bwd_queue = nullptr, int bwd_queue_items = 0) {
+                           const int32_t *bwd_queue = nullptr, int bwd_queue_items = 0,
+                           const int32_t *bwd_order = nullptr) {
     // FSGS_BWD_MERGE_THR16 (build macro, make EXTRA=-DFSGS_BWD_MERGE_THR16=n): a segment walks the union list with merged
     // atomics when its longest row list is >= thr/16 of the union; 0 = always, 17 = never
     constexpr int merge_thr16 = FSGS_BWD_MERGE_THR16;
@@ -526,6 +547,7 @@ static int launch_bwd_live(int C, int D, const float *records, const int32_t *n_
     }
     hipStream_t s = as_stream(stream);
     if (bwd_queue_items < 0 || (bwd_queue && (!seg_split || C != 1))) return FSGS_EINVAL;
+    if (bwd_order && !bwd_queue) return FSGS_EINVAL;
     // (extra rows of workgroups, one per queue item: see the kernel)
     const int extra_rows = (bwd_queue && bwd_queue_items > 0) ? ceil_div(bwd_queue_items, 2 * tile_width) : 0;
     const dim3 grid(2 * tile_width, 2 * tile_height + extra_rows, C);
@@ -541,7 +563,7 @@ static int launch_bwd_live(int C, int D, const float *records, const int32_t *n_
                        isect_offsets, n_isects, backgrounds, width, height, tile_width, tile_height, render,      \
                        alphas, last_ids, v_render, v_alphas, seg_state, seg_cap, v_packed, normalize_last,         \
                        render_extra, v_render_extra, n_rec, ep, replica_rows, merge_thr16, perm_stride, seg_split,  \
-                       bwd_queue, bwd_queue_items)
+                       bwd_queue, bwd_queue_items, bwd_order)
     if (render_extra) {
         if (D != 4 || (!v_render_extra && !ep.v_rgb)) return FSGS_EINVAL;
         if (with_abs) FSGS_BWD_LIVE(4, true, 3); else FSGS_BWD_LIVE(4, false, 3);
@@ -564,7 +586,8 @@ extern "C" int fsgs_raster_bwd_quad(int C, int D, const float *records, const in
                                     const float *v_render, const float *v_alphas, const float *seg_state,
                                     int with_abs, const float *render_extra, const float *v_render_extra,
                                     float *v_packed, int dispatch_stride, const int32_t *seg_split,
-                                    const int32_t *bwd_queue, int bwd_queue_items, fsgs_stream_t stream) {
+                                    const int32_t *bwd_queue, int bwd_queue_items, const int32_t *bwd_order,
+                                    fsgs_stream_t stream) {
     if (n_isects > 0 && !n_rec) return FSGS_EINVAL;
     return launch_bwd_live(C, D, records, n_rec,
                            fsgs_quad_stream_capacity(C, tile_width, tile_height, n_isects),
@@ -572,7 +595,7 @@ extern "C" int fsgs_raster_bwd_quad(int C, int D, const float *records, const in
                            backgrounds, width, height, tile_width, tile_height, normalize_last, render, alphas,
                            last_ids, v_render, v_alphas, seg_state, with_abs, render_extra, v_render_extra,
                            v_packed, stream, dispatch_stride, GetOutputsGrads{nullptr, nullptr, nullptr, nullptr, nullptr},
-                           0, seg_split, bwd_queue, bwd_queue_items);
+                           0, seg_split, bwd_queue, bwd_queue_items, bwd_order);
 }
 
 extern "C" int fsgs_raster_unpack_grads(int64_t total, int D, float *v_packed, int rezero, float *v_means2d,
@@ -597,7 +620,8 @@ extern "C" int fsgs_raster_bwd_quad_images(const float *records, const int32_t *
                                            const float *v_depth, const float *v_normal, const float *v_alpha_in,
                                            const float *seg_state, int with_abs, float *v_packed,
                                            int64_t replica_rows, int dispatch_stride, const int32_t *seg_split,
-                                           const int32_t *bwd_queue, int bwd_queue_items, fsgs_stream_t stream) {
+                                           const int32_t *bwd_queue, int bwd_queue_items, const int32_t *bwd_order,
+                                           fsgs_stream_t stream) {
     if (n_isects > 0 && (!n_rec || !v_rgb || !background)) return FSGS_EINVAL;
     if (!v_rgb || replica_rows < 0) return FSGS_EINVAL;
     const GetOutputsGrads ep = {v_rgb, v_depth, v_normal, v_alpha_in, background};
@@ -605,5 +629,5 @@ extern "C" int fsgs_raster_bwd_quad_images(const float *records, const int32_t *
                            fsgs_quad_seg_slots(1, tile_width, tile_height, n_isects), isect_offsets, n_isects, nullptr,
                            width, height, tile_width, tile_height, 1, render, alphas, last_ids, nullptr, nullptr,
                            seg_state, with_abs, render_extra, nullptr, v_packed, stream, dispatch_stride, ep, replica_rows,
-                           seg_split, bwd_queue, bwd_queue_items);
+                           seg_split, bwd_queue, bwd_queue_items, bwd_order);
 }

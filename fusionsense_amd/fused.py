@@ -162,6 +162,9 @@ IMAGE_GRADS_IN_BWD = os.environ.get("FSGS_IMAGE_GRADS_IN_BWD", "1") != "0"
 # queue positions for the backward's extra workgroups (groups of 8 segments of streams longer than 8 segments: fsgs.h,
 # seg_split / bwd_queue); 0 = every quadrant's stream is walked by its own workgroup alone (round 4)
 BWD_QUEUE_ITEMS = 1024
+# the backward's quadrants start longest own share first (fsgs.h: bwd_order; needs the queue); classes = the library's
+BWD_ORDER = True
+BWD_ORDER_CLASSES = 32
 # count-free binning of revisited views (ops.project_bin_live_fill_async; fsgs.h): on / off, and the model size from which
 # the dense machinery (occlusion cuts, several chunks per workgroup) keeps the two-pass route
 BIN_FILL = True
@@ -326,12 +329,14 @@ class _FusedGetOutputs(torch.autograd.Function):
         n_cells = lib.fsgs_raster_quad_max_cells()
         # partial image maxima: zeroed by the pack kernel, raised by the forward — and behind them, zeroed by the same
         # kernel, the queue of the backward's extra workgroups (a counter + BWD_QUEUE_ITEMS int4 items: fsgs.h, seg_split)
-        max_last = torch.empty(n_cells + 4 + 4 * BWD_QUEUE_ITEMS + 4, **f32)
+        # ... behind the items the BWD_ORDER_CLASSES counters of the backward's dispatch order (fsgs.h: bwd_order)
+        q_words = 4 + 4 * BWD_QUEUE_ITEMS + BWD_ORDER_CLASSES
+        max_last = torch.empty(n_cells + q_words + 4, **f32)
         # (dense scenes, N >= 2^20: every quadrant's stream is long and every SIMD busy — measured: nothing gained)
-        bwd_queue = (max_last[n_cells:n_cells + 4 + 4 * BWD_QUEUE_ITEMS].view(torch.int32)
+        bwd_queue = (max_last[n_cells:n_cells + q_words].view(torch.int32)
                      if (BWD_QUEUE_ITEMS > 0 and N < FWD_WALK.handoff_max_n) else None)
         # ... and the frame statistic that gates the forward's hand-off (set by the in-tile sort: fsgs_bin_live_emit)
-        long_flag = max_last[n_cells + 4 + 4 * BWD_QUEUE_ITEMS:].view(torch.int32)
+        long_flag = max_last[n_cells + q_words:].view(torch.int32)
         # the SH colours + packing ride in the binning's scan launch when nothing stands between them and the
         # features (no deferred feature exchange) and the storage is the 16-coefficient split one
         adam_rides = direct_bins and info.adam_rider is not None and N > 0
@@ -438,14 +443,17 @@ class _FusedGetOutputs(torch.autograd.Function):
             rec_bytes = 4 * cap * 64
             seg_bytes = 4 * slots * 64 * (1 + 4 + 3) * 4
             nrec_bytes = 4 * n_tiles * 4
-            arena = WORKSPACE.take(a(rec_bytes) + a(seg_bytes) + 2 * a(nrec_bytes), dev)
+            order_bytes = BWD_ORDER_CLASSES * nrec_bytes if (bwd_queue is not None and BWD_ORDER) else 0
+            arena = WORKSPACE.take(a(rec_bytes) + a(seg_bytes) + 2 * a(nrec_bytes) + order_bytes, dev)
             records = arena[:rec_bytes].view(torch.float32)
             seg_state = arena[a(rec_bytes):a(rec_bytes) + seg_bytes].view(torch.float32)
             o = a(rec_bytes) + a(seg_bytes)
             n_rec = arena[o:o + nrec_bytes].view(torch.int32)
             seg_split = arena[o + a(nrec_bytes):o + a(nrec_bytes) + nrec_bytes].view(torch.int32)
+            o += 2 * a(nrec_bytes)
+            bwd_order = arena[o:o + order_bytes].view(torch.int32) if order_bytes else None
         else:
-            arena = records = seg_state = n_rec = seg_split = None
+            arena = records = seg_state = n_rec = seg_split = bwd_order = None
             bwd_queue = None
         render = torch.empty(1, H, W, 4, **f32)
         alphas = torch.empty(1, H, W, 1, **f32)
@@ -488,6 +496,9 @@ class _FusedGetOutputs(torch.autograd.Function):
         depth = torch.empty(H, W, 1, **f32)
         normal = torch.empty(H, W, 3, **f32)
         lt = info.loss_targets
+        # (riding in the epilogue launch: the backward's dispatch order — the streams' lengths are known now)
+        order_args = ((ptr(n_rec), ptr(seg_split), bwd_queue[4 + 4 * BWD_QUEUE_ITEMS:].data_ptr(), ptr(bwd_order), tw, th)
+                      if bwd_order is not None else (None, None, None, None, 0, 0))
         if lt is not None:
             # the trainer's tape-free step: the depth / normal L1 terms of its loss are evaluated on the pixels as
             # they are formed (partial sums + gradient images), no separate pass over the two images
@@ -495,16 +506,17 @@ class _FusedGetOutputs(torch.autograd.Function):
             partial = torch.empty((P + 255) // 256, 2, **f32)
             v_depth_img = torch.empty(H, W, 1, **f32)
             v_normal_img = torch.empty(H, W, 3, **f32) if lt.get("normal") is not None else None
-            _run(lib.fsgs_epilogue_loss_fwd, (P, ptr(render), ptr(alphas), ptr(render_extra), ptr(background),
-                                             ptr(max_last), n_cells, ptr(rgb), ptr(depth), ptr(normal),
-                                             ptr(lt["depth"]), ptr(lt.get("normal")), ptr(lt["seed"]),
-                                             float(lt["g_depth"]), float(lt["g_normal"]), ptr(partial),
-                                             ptr(v_depth_img), ptr(v_normal_img), sp), "fsgs_epilogue_fwd")
+            _run(lib.fsgs_epilogue_fwd_order, (P, ptr(render), ptr(alphas), ptr(render_extra), ptr(background),
+                                              ptr(max_last), n_cells, ptr(rgb), ptr(depth), ptr(normal),
+                                              ptr(lt["depth"]), ptr(lt.get("normal")), ptr(lt["seed"]),
+                                              float(lt["g_depth"]), float(lt["g_normal"]), ptr(partial),
+                                              ptr(v_depth_img), ptr(v_normal_img)) + order_args + (sp,),
+                 "fsgs_epilogue_fwd")
             info.aux_loss = (partial, v_depth_img, v_normal_img)
         else:
-            _run(lib.fsgs_epilogue_fwd, (H * W, ptr(render), ptr(alphas), ptr(render_extra), ptr(background),
-                                        None, -n_cells, ptr(max_last), ptr(rgb), ptr(depth),
-                                        ptr(normal), sp), "fsgs_epilogue_fwd")
+            _run(lib.fsgs_epilogue_fwd_order, (H * W, ptr(render), ptr(alphas), ptr(render_extra), ptr(background),
+                                              ptr(max_last), n_cells, ptr(rgb), ptr(depth), ptr(normal), None, None,
+                                              None, 0.0, 0.0, None, None, None) + order_args + (sp,), "fsgs_epilogue_fwd")
 
         info.radii, info.means2d, info.depths, info.conics = radii, means2d, depths, conics
         info.opac_row, info.tiles = opac_row, (tw, th)
@@ -519,6 +531,7 @@ class _FusedGetOutputs(torch.autograd.Function):
                                   conics, records, n_rec, offsets, render, alphas, last_ids, render_extra, seg_state,
                                   background, seg_split, bwd_queue if bwd_queue is not None else seg_split)
             ctx.has_bwd_queue = bwd_queue is not None
+            ctx.bwd_order = bwd_order  # (a view of the frame's arena, like the streams)
             ctx.arena = arena
         else:
             WORKSPACE.give(arena)
@@ -535,6 +548,7 @@ class _FusedGetOutputs(torch.autograd.Function):
         if not ctx.has_bwd_queue:
             bwd_queue = None
         n_queue = BWD_QUEUE_ITEMS if bwd_queue is not None else 0
+        bwd_order = getattr(ctx, "bwd_order", None) if bwd_queue is not None else None
         N, K, W, H, tw, th, M, sh_degree = ctx.dims
         cam = ctx.cam
         lib = load()
@@ -553,7 +567,7 @@ class _FusedGetOutputs(torch.autograd.Function):
                                                    ptr(alphas), ptr(last_ids), ptr(render_extra), ptr(background),
                                                    ptr(v_rgb), ptr(v_depth), ptr(v_normal), ptr(v_alpha_out),
                                                    ptr(seg_state), 1, ptr(v_packed), rep_rows, BWD_DISPATCH.stride(W, H),
-                                                   ptr(seg_split), ptr(bwd_queue), n_queue, sp),
+                                                   ptr(seg_split), ptr(bwd_queue), n_queue, ptr(bwd_order), sp),
                  "fsgs_raster_bwd_quad", "_d4e3")
         else:
             v_render = torch.empty(1, H, W, 4, **f32)
@@ -565,7 +579,8 @@ class _FusedGetOutputs(torch.autograd.Function):
             _run(lib.fsgs_raster_bwd_quad, (1, 4, ptr(records), ptr(n_rec), ptr(offsets), M, None, W, H, tw, th, 1,
                                            ptr(render), ptr(alphas), ptr(last_ids), ptr(v_render), ptr(v_alphas),
                                            ptr(seg_state), 1, ptr(render_extra), ptr(v_render_extra), ptr(v_packed),
-                                           0, ptr(seg_split), ptr(bwd_queue), n_queue, sp), "fsgs_raster_bwd_quad", "_d4e3")
+                                           0, ptr(seg_split), ptr(bwd_queue), n_queue, ptr(bwd_order), sp),
+                 "fsgs_raster_bwd_quad", "_d4e3")
         WORKSPACE.give(getattr(ctx, "arena", None))
         ctx.arena = None
 

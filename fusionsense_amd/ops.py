@@ -914,7 +914,7 @@ class _Rasterize(torch.autograd.Function):
                                            int(normalize_last), ptr(render), ptr(alphas), ptr(last_ids),
                                            ptr(v_render), ptr(v_alphas),
                                            ptr(seg_state), int(bool(absgrad)), None, None, ptr(v_packed),
-                                           DROPIN_BWD_STRIDE, None, None, 0, stream_ptr(dev)),
+                                           DROPIN_BWD_STRIDE, None, None, 0, None, stream_ptr(dev)),
                  "fsgs_raster_bwd_quad", f"_d{D}")
             v_means2d = torch.empty(Cn, N, 2, dtype=torch.float32, device=dev)
             v_conics = torch.empty(Cn, N, 3, dtype=torch.float32, device=dev)

@@ -42,7 +42,7 @@ typedef void *fsgs_stream_t; /* hipStream_t */
 #define FSGS_ELAUNCH -2  /* hipLaunch / runtime error; see fsgs_last_hip_error() */
 #define FSGS_ESCRATCH -3 /* scratch arena too small */
 
-#define FSGS_ABI_VERSION 7
+#define FSGS_ABI_VERSION 8
 int fsgs_version(void);
 int fsgs_abi_version(void); /* == FSGS_ABI_VERSION of the header the library was built from */
 /* Lines of the packed gradient accumulator a caller that passes `replica_rows` > 0 must provide per Gaussian row:
@@ -271,6 +271,14 @@ int fsgs_raster_fwd_quad(int C, int D, const float *packed, const int32_t *paylo
  * then the segments in front of the last 8 are queued in groups of 8 for extra workgroups of fsgs_raster_bwd_quad* (pass
  * it the same three arguments).  A list of 44 segments (config #3's hull tiles) is then walked by six workgroups side
  * by side instead of 11 rounds of one.  Gradients are unchanged up to the order of the float atomics. */
+/* Dispatch order of the backward (round 5): bwd_order (nullable; needs bwd_queue, C == 1) = [32, 4 * th * tw] i32, filled
+ * between the forward and the backward by fsgs_epilogue_fwd_order (below): every quadrant is filed under a class of its
+ * own share's record count (16 records wide, the last class open-ended), bwd_order[class][slot] = the quadrant's position
+ * in the backward's grid; the classes' 32 i32 counters sit BEHIND the queue's items (bwd_queue then needs 4 + 4 *
+ * bwd_queue_items + 32 words, zeroed by the caller).  fsgs_raster_bwd_quad* given bwd_order start the quadrants longest
+ * class first (dispatch_stride is then not used): a backward workgroup's time is its quadrant's share, and the launch
+ * ends with its last round of workgroups — config #3's trained scene 0.191 -> 0.174 ms.  Gradients are unchanged up to
+ * the order of the float atomics. */
 /* Hand-off of long walks (round 5; FSGS_WALK_ONE_WAVE, handoff_records > 0): a wave that has streamed `handoff_records`
  * records and still has open pixels and list entries left stops at the end of its 64-entry chunk and queues the rest of
  * its list; TAIL workgroups of the same launch (one wave per queued 64-entry chunk; `tail_items` of them are launched,
@@ -304,7 +312,8 @@ int fsgs_raster_bwd_quad(int C, int D, const float *records, const int32_t *n_re
                          const float *v_render, const float *v_alphas, const float *seg_state,
                          int with_abs, const float *render_extra, const float *v_render_extra,
                          float *v_packed, int dispatch_stride, const int32_t *seg_split /* nullable */,
-                         const int32_t *bwd_queue /* nullable; C == 1 */, int bwd_queue_items, fsgs_stream_t stream);
+                         const int32_t *bwd_queue /* nullable; C == 1 */, int bwd_queue_items,
+                         const int32_t *bwd_order /* nullable */, fsgs_stream_t stream);
 /* dispatch_stride (fsgs_raster_bwd_quad, fsgs_raster_bwd_quad_images) — the dispatch order of THIS launch's quadrants:
  * 0 or 1 = row-major, k > 1 = consecutive workgroups take quadrants k apart (raised to the next value coprime with the
  * number of quadrants).  Same gradients up to the order of the float atomics; which order is faster depends on the scene
@@ -326,7 +335,8 @@ int fsgs_raster_bwd_quad_images(const float *records, const int32_t *n_rec, cons
                                 const float *v_depth, const float *v_normal, const float *v_alpha_in,
                                 const float *seg_state, int with_abs, float *v_packed, int64_t replica_rows,
                                 int dispatch_stride, const int32_t *seg_split /* nullable */,
-                                const int32_t *bwd_queue /* nullable */, int bwd_queue_items, fsgs_stream_t stream);
+                                const int32_t *bwd_queue /* nullable */, int bwd_queue_items,
+                                const int32_t *bwd_order /* nullable */, fsgs_stream_t stream);
 /* replica_rows (here and in fsgs_gaussian_bwd; 0 = off): Gaussians with a large 2-D footprint (det(conic) < 1/4096)
  * own FOUR gradient lines, replica_rows rows apart in v_packed ([4 * replica_rows, 16], zeroed): the compositing
  * backward picks the replica from the tile and the 8x8 quadrant, so that the hundreds of workgroups a large Gaussian
@@ -686,6 +696,16 @@ int fsgs_epilogue_loss_fwd(int64_t n_pixels, const float *render, const float *a
                            float *normal, const float *depth_gt, const float *normal_gt, const float *v_loss,
                            float g_depth, float g_normal, float *partial, float *v_depth, float *v_normal,
                            fsgs_stream_t stream);
+/* fsgs_epilogue_loss_fwd (depth_gt != NULL) or fsgs_epilogue_fwd over the forward's n_cells partial maxima (depth_gt ==
+ * NULL: no loss terms; v_loss / partial / v_depth / v_normal unused) — and, riding in the launch as extra workgroups, the
+ * dispatch order of the compositing backward: bwd_order != NULL -> the counting sort described at fsgs_raster_fwd_quad
+ * (n_rec, seg_split [4, th * tw] as the forward left them; order_counters = the 32 zeroed words behind bwd_queue's items). */
+int fsgs_epilogue_fwd_order(int64_t n_pixels, const float *render, const float *alphas, const float *render_extra,
+                            const float *bg, const float *max_last, int n_cells, float *rgb, float *depth, float *normal,
+                            const float *depth_gt, const float *normal_gt, const float *v_loss, float g_depth,
+                            float g_normal, float *partial, float *v_depth, float *v_normal, const int32_t *n_rec,
+                            const int32_t *seg_split, int32_t *order_counters, int32_t *bwd_order, int tile_width,
+                            int tile_height, fsgs_stream_t stream);
 int fsgs_epilogue_bwd(int64_t n_pixels, const float *render, const float *alphas,
                       const float *render_extra, const float *bg, const float *v_rgb,
                       const float *v_depth, const float *v_normal, const float *v_alpha_in,

@@ -600,15 +600,17 @@ def test_backward_extra_workgroups_for_long_streams(dev, monkeypatch):
     for walk in ("handoff", "one"):
         w.forced, w.forced_walk, w.handoff_rel_len, w.handoff_gate_len = True, 1, 0, 0
         w.handoff_records = 128 if walk == "handoff" else 0
-        for items in (1024, 0, 2):
-            monkeypatch.setattr(fused, "BWD_QUEUE_ITEMS", items)
+        # (-1024: the queue without the longest-first dispatch order of the backward, fsgs.h: bwd_order)
+        for items in (1024, 0, 2, -1024):
+            monkeypatch.setattr(fused, "BWD_QUEUE_ITEMS", abs(items))
+            monkeypatch.setattr(fused, "BWD_ORDER", items >= 0)
             tr = SplatTrainer(params, dev, sh_degree=3)
             _, out = tr.train_step(cam, tgt, optimizer_step=False)
             rec, n_rec, seg = out["info"].streams
             res[(walk, items)] = dict(rgb=out["rgb"].clone(), n_rec=n_rec.clone(),
                                       grads={k: tr.slab.views[k].clone() for k in PARAM_ORDER})
         assert int(res[(walk, 1024)]["n_rec"].max()) > 64 * 16, "the scene must leave streams of many segments"
-        for items in (0, 2):
+        for items in (0, 2, -1024):
             assert torch.equal(res[(walk, items)]["rgb"], res[(walk, 1024)]["rgb"])
             assert torch.equal(res[(walk, items)]["n_rec"], res[(walk, 1024)]["n_rec"])
             for k in PARAM_ORDER:

@@ -975,11 +975,11 @@ def test_folded_entry_points_equal_the_chains_they_replace(dev):
     acc_a, acc_b = torch.zeros(N, 16, **f32), torch.zeros(N, 16, **f32)
     assert lib.fsgs_raster_bwd_quad(1, 4, ptr(records), ptr(n_rec), ptr(offsets), M, None, W, H, tw, th, 1, ptr(render),
                                     ptr(alphas), ptr(last_ids), ptr(v_render), ptr(v_alphas), ptr(seg_state), 1,
-                                    ptr(extra), ptr(v_extra), ptr(acc_a), 0, None, None, 0, sp) == 0
+                                    ptr(extra), ptr(v_extra), ptr(acc_a), 0, None, None, 0, None, sp) == 0
     assert lib.fsgs_raster_bwd_quad_images(ptr(records), ptr(n_rec), ptr(offsets), M, W, H, tw, th, ptr(render),
                                            ptr(alphas), ptr(last_ids), ptr(extra), ptr(bg), ptr(vr_a), ptr(vd_a),
                                            ptr(vn_a), ptr(v_alpha), ptr(seg_state), 1, ptr(acc_b), 0, 7, None, None, 0,
-                                           sp) == 0
+                                           None, sp) == 0
     assert float(acc_a.abs().max()) > 0
     assert rel_err(acc_b, acc_a) < 1e-5
     # gradient-line replicas (common.h grad_spread): large Gaussians spread their atomics over 4 lines N rows apart,
@@ -990,7 +990,7 @@ def test_folded_entry_points_equal_the_chains_they_replace(dev):
     assert lib.fsgs_raster_bwd_quad_images(ptr(records), ptr(n_rec), ptr(offsets), M, W, H, tw, th, ptr(render),
                                            ptr(alphas), ptr(last_ids), ptr(extra), ptr(bg), ptr(vr_a), ptr(vd_a),
                                            ptr(vn_a), ptr(v_alpha), ptr(seg_state), 1, ptr(acc_r), N, -1, None, None, 0,
-                                           sp) == 0
+                                           None, sp) == 0
     lines = acc_r.view(LN, N, 16)
     assert rel_err(lines.sum(0), acc_a) < 1e-5
     used = lines[1:].abs().sum((0, 2)) > 0
