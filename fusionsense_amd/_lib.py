@@ -66,8 +66,8 @@ SIGNATURES = {
     "fsgs_project_bin_live_count": (_i, [_i, _p, _p, _p, _p, _i, _f, _p, _p, _i, _i, _f, _f, _f, _f, _p, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p, _sz, _p, _p]),
     "fsgs_bin_live_emit": (_i, [_i, _i, _p, _p, _p, _p, _p, _i, _i, _p, _p, _i64, _p, _p, _p, _p, _i, _p]),
     "fsgs_project_bin_live_fill_sh_pack": (_i, [_i, _p, _p, _p, _p, _i, _f, _p, _p, _i, _i, _f, _f, _f, _f, _p, _p, _p, _p, _p, _p, _i, _i, _p, _p,
-                                                _p, _p, _p, _i64, _p, _f, _i, _p, _i, _p, _p, _p, _p, _p, _p, _p, _i, _p]),
-    "fsgs_bin_live_sort_buckets": (_i, [_i, _i, _p, _p, _p, _p, _p, _i, _p]),
+                                                _p, _p, _p, _i64, _p, _f, _i, _p, _i, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p]),
+    "fsgs_bin_live_sort_buckets": (_i, [_i, _i, _p, _p, _p, _p, _p, _i, _p, _p]),
     "fsgs_bin_live_split_scratch_bytes": (_sz, [_i, _i, _i, _i64]),
     "fsgs_bin_live_emit_split": (_i, [_i, _i, _p, _p, _p, _p, _p, _i, _i, _p, _p, _i64, _p, _p, _p, _sz, _p, _p, _p]),
     "fsgs_set_lazy_sh_min_n": (_i, [_i]),

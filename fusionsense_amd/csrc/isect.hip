@@ -882,7 +882,7 @@ int launch_scan_rows_sh_pack(int T, int nb, int32_t *table, int32_t *totals, con
                              int32_t *ticket, int32_t *isect_offsets, int32_t *total_mapped, const BucketBook &bk);
 int launch_tile_sort_tiers(int T, int n_tiles, int tile_bits, const int32_t *isect_offsets, uint64_t *buckets,
                            int32_t *payload_sorted, int64_t *isect_ids_sorted, hipStream_t s, int32_t *long_flag = nullptr,
-                           int rel_gate = 0, const int32_t *src_offsets = nullptr);
+                           int rel_gate = 0, const int32_t *src_offsets = nullptr, const int32_t *tile_order = nullptr);
 int launch_split_sort(int T, int n_tiles, int tile_bits, const int32_t *isect_offsets, int64_t n_live,
                       const uint64_t *buckets, uint64_t *buckets2, int32_t *scratch, int32_t *payload_sorted,
                       hipStream_t s);
@@ -1269,7 +1269,7 @@ extern "C" int fsgs_project_bin_live_fill_sh_pack(
     const int32_t *bucket_base, int32_t *tile_cursor, void *buckets, int64_t bucket_words, int32_t *next_bucket_base,
     float growth, int slack, int32_t *n_live_mapped, int degree, const float *campos, const float *features_dc,
     const float *features_rest, const float *c2w, float *packed, float *normals_world, float *zero_cells, int n_zero,
-    fsgs_stream_t stream) {
+    int32_t *tile_order, fsgs_stream_t stream) {
     if (N < 1 || tile_width < 1 || tile_height < 1 || !isect_offsets || !bucket_base || !tile_cursor || !buckets ||
         !next_bucket_base || bucket_words < 1 || bucket_words >= 0x40000000ll || growth < 1.f || slack < 0)
         return FSGS_EINVAL;
@@ -1306,14 +1306,15 @@ extern "C" int fsgs_project_bin_live_fill_sh_pack(
     const ShPackRider r = {N, degree, 0, means, campos, features_dc, features_rest, radii, depths, means2d, conics,
                            opac_out, quats, log_scales, c2w, packed, normals_world, zero_cells, n_zero, nullptr};
     return launch_scan_rows_sh_pack(T, nb, nullptr, nullptr, r, s, nullptr, isect_offsets, n_live_mapped,
-                                    BucketBook{tile_cursor, bucket_base, next_bucket_base, growth, slack});
+                                    BucketBook{tile_cursor, bucket_base, next_bucket_base, growth, slack, tile_order});
 }
 
 // the in-tile sorts of the count-free route: bucket t = `buckets`[bucket_base[t] ..) with isect_offsets[t + 1] -
 // isect_offsets[t] words -> payload_sorted[isect_offsets[t] ..)  (long_flag / rel_gate as in fsgs_bin_live_emit)
 extern "C" int fsgs_bin_live_sort_buckets(int tile_width, int tile_height, const int32_t *isect_offsets,
                                           const int32_t *bucket_base, void *buckets, int32_t *payload_sorted,
-                                          int32_t *long_flag, int rel_gate, fsgs_stream_t stream) {
+                                          int32_t *long_flag, int rel_gate, const int32_t *tile_order,
+                                          fsgs_stream_t stream) {
     if (tile_width < 1 || tile_height < 1 || !isect_offsets || !bucket_base || !buckets || !payload_sorted || rel_gate < 0)
         return FSGS_EINVAL;
     const int n_tiles = tile_width * tile_height;
@@ -1322,7 +1323,7 @@ extern "C" int fsgs_bin_live_sort_buckets(int tile_width, int tile_height, const
     while ((1ll << tb) <= n_tiles) ++tb;
     if (tb < 1) tb = 1;
     return launch_tile_sort_tiers(n_tiles, n_tiles, tb, isect_offsets, reinterpret_cast<uint64_t *>(buckets),
-                                  payload_sorted, nullptr, as_stream(stream), long_flag, rel_gate, bucket_base);
+                                  payload_sorted, nullptr, as_stream(stream), long_flag, rel_gate, bucket_base, tile_order);
 }
 
 // ---- occlusion cut: next frame's tile cuts from this frame's walk, and the verdict on this frame's own cuts --------

@@ -1456,7 +1456,8 @@ scan_rows_sh_pack_kernel(int T, int nb, int32_t *__restrict__ table, int32_t *__
                          int32_t *__restrict__ total_mapped, BucketBook bk) {
     if ((int)blockIdx.x < n_scan_blocks) {
         if (bk.cursor) {  // the count-free route: no table to scan — one workgroup does the buckets' bookkeeping
-            bucket_offsets_body256(T, bk.cursor, bk.base, isect_offsets, bk.next_base, bk.growth, bk.slack, total_mapped);
+            bucket_offsets_body256(T, bk.cursor, bk.base, isect_offsets, bk.next_base, bk.growth, bk.slack, total_mapped,
+                                   bk.tile_order);
             return;
         }
         tile_scan_rows_body(T, nb, table, totals, blockIdx.x);

@@ -105,6 +105,9 @@ struct BucketBook {  // (arguments of bucket_offsets_body256; cursor == nullptr:
     int32_t *next_base;
     float growth;
     int slack;
+    // nullable [T]: the tiles longest list first (classes of 64 entries) — the dispatch order of the in-tile sorts, whose
+    // workgroups take as long as their tile is long (the launch is 5-7 rounds of resident workgroups)
+    int32_t *tile_order;
 };
 
 // The count-free binning route's bookkeeping, ONE workgroup of 256 threads (rides in the SH launch as block 0):
@@ -117,8 +120,12 @@ struct BucketBook {  // (arguments of bucket_offsets_body256; cursor == nullptr:
 __device__ __forceinline__ void bucket_offsets_body256(int T, int32_t *__restrict__ cursor,
                                                        const int32_t *__restrict__ bucket_base,
                                                        int32_t *__restrict__ offsets, int32_t *__restrict__ next_base,
-                                                       float growth, int slack, int32_t *__restrict__ total_mapped) {
+                                                       float growth, int slack, int32_t *__restrict__ total_mapped,
+                                                       int32_t *__restrict__ tile_order = nullptr) {
     __shared__ int wsum[4], wsum2[4], over_s[4], tsum[4];
+    __shared__ int ocnt[32], obase[32];
+    if (tile_order && threadIdx.x < 32) ocnt[threadIdx.x] = 0;
+    if (tile_order) __syncthreads();
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int per = (T + 255) / 256;
     const int i0 = tid * per, i1 = min(i0 + per, T);
@@ -134,6 +141,7 @@ __device__ __forceinline__ void bucket_offsets_body256(int T, int32_t *__restric
         mine += fits ? n : 0;
         true_total += n;
         mine2 += (int)((float)n * growth) + slack;
+        if (tile_order) atomicAdd(&ocnt[min((fits ? n : 0) >> 6, 31)], 1);
     }
     int inc = mine, inc2 = mine2;
 #pragma unroll
@@ -144,15 +152,26 @@ __device__ __forceinline__ void bucket_offsets_body256(int T, int32_t *__restric
     over = __any(over) ? 1 : 0;
     if (lane == 63) { wsum[w] = inc; wsum2[w] = inc2; over_s[w] = over; }
     __syncthreads();
+    if (tile_order) {
+        // counting sort of the tiles by list length, longest class first (the class counts are complete: a barrier lies
+        // behind them); obase[c] then runs as the class's cursor
+        if (tid == 0) {
+            int run_o = 0;
+            for (int cc = 31; cc >= 0; --cc) { obase[cc] = run_o; run_o += ocnt[cc]; }
+        }
+        __syncthreads();
+    }
     int run = inc - mine, run2 = inc2 - mine2;
     for (int k = 0; k < w; ++k) { run += wsum[k]; run2 += wsum2[k]; }
     for (int i = i0; i < i1; ++i) {
         const int n = cursor[i];
+        const bool fits = n <= bucket_base[i + 1] - bucket_base[i];
         offsets[i] = min(run, cap);
         next_base[i] = run2;
-        run += (n <= bucket_base[i + 1] - bucket_base[i]) ? n : 0;
+        run += fits ? n : 0;
         run2 += (int)((float)n * growth) + slack;
         cursor[i] = 0;
+        if (tile_order) tile_order[atomicAdd(&obase[min((fits ? n : 0) >> 6, 31)], 1)] = i;
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) true_total += __shfl_xor(true_total, d, 64);

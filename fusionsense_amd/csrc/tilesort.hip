@@ -345,15 +345,19 @@ template <int THREADS, int CAP, int LO, bool SPILL>
 __global__ void __launch_bounds__(THREADS)
 tile_sort_kernel2(int n_tiles, int tile_bits, const int32_t *__restrict__ offsets, uint64_t *__restrict__ buckets,
                   int32_t *__restrict__ payload_out, int64_t *__restrict__ isect_ids_out,
-                  int32_t *__restrict__ long_flag, int rel_gate, const int32_t *__restrict__ src_offsets) {
+                  int32_t *__restrict__ long_flag, int rel_gate, const int32_t *__restrict__ src_offsets,
+                  const int32_t *__restrict__ tile_order) {
     extern __shared__ __attribute__((aligned(16))) uint64_t sk[];
+    // (tile_order, nullable: the tiles longest first — a workgroup takes as long as its tile is long, and the launch is
+    // 5-7 rounds of resident workgroups: its last round should be the short ones)
+    const int t = tile_order ? tile_order[blockIdx.x] : (int)blockIdx.x;
     // (frame statistic for the forward's hand-off, fsgs_bin_live_emit: does ANY tile hold a list of more than rel_gate
     // times the mean length?  The caller zeroes the word; every writer writes the same 1.)
     if (long_flag && threadIdx.x == 0) {
-        const int n = offsets[blockIdx.x + 1] - offsets[blockIdx.x];
+        const int n = offsets[t + 1] - offsets[t];
         if (n > 0 && (int64_t)n * (int)gridDim.x > (int64_t)rel_gate * offsets[gridDim.x]) *long_flag = 1;
     }
-    tile_sort_body<THREADS, CAP, LO, SPILL>(sk, blockIdx.x, n_tiles, tile_bits, offsets, buckets, payload_out,
+    tile_sort_body<THREADS, CAP, LO, SPILL>(sk, t, n_tiles, tile_bits, offsets, buckets, payload_out,
                                             isect_ids_out, nullptr, src_offsets);
 }
 
@@ -756,7 +760,8 @@ slab_split_sort_lds_kernel(const int32_t *__restrict__ n_sub, const int32_t *__r
 
 int launch_tile_sort_tiers(int T, int n_tiles, int tile_bits, const int32_t *isect_offsets, uint64_t *buckets,
                            int32_t *payload_sorted, int64_t *isect_ids_sorted, hipStream_t s,
-                           int32_t *long_flag = nullptr, int rel_gate = 0, const int32_t *src_offsets = nullptr);
+                           int32_t *long_flag = nullptr, int rel_gate = 0, const int32_t *src_offsets = nullptr,
+                           const int32_t *tile_order = nullptr);
 
 // buckets -> (split by depth where large) buckets2 -> sorted payload.  scratch: [sub_base i32: T + 1][sub_offsets i32: max_sub + 1]
 // lds_cap > 0: tiles of up to lds_cap words have been sorted by tile_split_sort_lds_kernel and yield no sub-buckets here.
@@ -799,7 +804,7 @@ int64_t split_scratch_ints(int T, int64_t n_live) { return (int64_t)(T + 1) + 2 
 
 int launch_tile_sort_tiers(int T, int n_tiles, int tile_bits, const int32_t *isect_offsets, uint64_t *buckets,
                            int32_t *payload_sorted, int64_t *isect_ids_sorted, hipStream_t s, int32_t *long_flag,
-                           int rel_gate, const int32_t *src_offsets) {
+                           int rel_gate, const int32_t *src_offsets, const int32_t *tile_order) {
     if (const int rc = ensure_dynamic_lds<&tile_sort_kernel2<1024, kTsLarge, kTsSmall, true>>(kTsLarge * 8)) return rc;
     constexpr int one_tier = FSGS_SORT_ONE_TIER;  // (build macro)
     if (one_tier && T <= 8192) {
@@ -812,16 +817,16 @@ int launch_tile_sort_tiers(int T, int n_tiles, int tile_bits, const int32_t *ise
         if (const int rc = ensure_dynamic_lds<&tile_sort_kernel2<TT, TC, 0, true>>(TC * 8)) return rc;
         hipLaunchKernelGGL((tile_sort_kernel2<TT, TC, 0, true>), dim3(T), dim3(TT), TC * 8, s, n_tiles,
                            tile_bits, isect_offsets, buckets, payload_sorted, isect_ids_sorted, long_flag, rel_gate,
-                           src_offsets);
+                           src_offsets, tile_order);
         return check_launch();
     }
     // two size tiers, each skipping the tiles of the other (an early-out workgroup costs ~2 ns)
     hipLaunchKernelGGL((tile_sort_kernel2<256, kTsSmall, 0, false>), dim3(T), dim3(256), kTsSmall * 8, s, n_tiles,
                        tile_bits, isect_offsets, buckets, payload_sorted, isect_ids_sorted, long_flag, rel_gate,
-                       src_offsets);
+                       src_offsets, tile_order);
     hipLaunchKernelGGL((tile_sort_kernel2<1024, kTsLarge, kTsSmall, true>), dim3(T), dim3(1024), kTsLarge * 8, s,
                        n_tiles, tile_bits, isect_offsets, buckets, payload_sorted, isect_ids_sorted, (int32_t *)nullptr, 0,
-                       src_offsets);
+                       src_offsets, tile_order);
     return check_launch();
 }
 

@@ -433,6 +433,8 @@ def project_bin_live_count_async(means: Tensor, quats: Tensor, log_scales: Tenso
 # ---- count-free binning (fsgs_project_bin_live_fill_sh_pack): one enumeration of the pairs instead of two ------------
 # A view's frame tells how much room every tile's bucket needs in the view's NEXT frame: count * growth + slack words.
 BIN_FILL_GROWTH, BIN_FILL_SLACK = 1.25, 64
+# the count-free route's in-tile sorts are dispatched longest tile first (fsgs.h: tile_order)
+BIN_FILL_SORT_ORDER = True
 _BIN_CURSORS: dict = {}  # (device, T) -> int32 [T], zeroed once: the route's own bookkeeping leaves it zeroed
 
 
@@ -471,6 +473,8 @@ def project_bin_live_fill_async(means: Tensor, quats: Tensor, log_scales: Tensor
         cursor = _BIN_CURSORS[(str(dev), T)] = torch.zeros(T, dtype=torch.int32, device=dev)
     words = bin_fill_words(int(hist["n_live"]), T)
     buckets = WORKSPACE.take(8 * words, dev)
+    # (the in-tile sorts' dispatch order, longest tile first: written by the bookkeeping workgroup)
+    tile_order = torch.empty(T, dtype=torch.int32, device=dev) if BIN_FILL_SORT_ORDER else None
     pinned = _pinned_i32(dev)
     pinned._np[2] = int(capacity)
     degree, campos, f_dc, f_rest, c2w, packed, normals_world, zero_cells = sh_pack
@@ -482,11 +486,11 @@ def project_bin_live_fill_async(means: Tensor, quats: Tensor, log_scales: Tensor
             ptr(tpg), ptr(offsets), ptr(hist["base"]), ptr(cursor), ptr(buckets), words, ptr(next_base),
             float(BIN_FILL_GROWTH), int(BIN_FILL_SLACK), pinned.data_ptr(), int(degree), ptr(campos), ptr(f_dc),
             ptr(f_rest), ptr(c2w), ptr(packed), ptr(normals_world), ptr(zero_cells), int(zero_cells.numel()),
-            stream_ptr(dev)), "fsgs_isect_count_live")
+            ptr(tile_order), stream_ptr(dev)), "fsgs_isect_count_live")
     ev = torch.cuda.Event()
     ev.record(torch.cuda.current_stream(dev))
     return dict(direct=True, fill=True, tpg=tpg, offsets=offsets, table=None, pinned=pinned, event=ev, T=T,
-                capacity=int(capacity), buckets=buckets, base=hist["base"], next_base=next_base)
+                capacity=int(capacity), buckets=buckets, base=hist["base"], next_base=next_base, tile_order=tile_order)
 
 
 class LiveListOverflow(RuntimeError):
@@ -587,7 +591,7 @@ def bin_live_finish(st: dict, means2d: Tensor, radii: Tensor, depths: Tensor, co
         pay_s = torch.empty(M, dtype=torch.int32, device=dev)
         _run(lib.fsgs_bin_live_sort_buckets, (tile_width, tile_height, ptr(st["offsets"]), ptr(st["base"]),
                                               ptr(st["buckets"]), ptr(pay_s), ptr(long_flag), int(rel_gate),
-                                              stream_ptr(dev)), "fsgs_tile_sort")
+                                              ptr(st.get("tile_order")), stream_ptr(dev)), "fsgs_tile_sort")
         WORKSPACE.give(st["buckets"])
         return st["tpg"], None, pay_s, st["offsets"]
     dense = not use_tile_sort(M, T)  # mean bucket beyond the LDS tiers

@@ -468,10 +468,14 @@ int fsgs_project_bin_live_fill_sh_pack(
     const int32_t *bucket_base, int32_t *tile_cursor, void *buckets, int64_t bucket_words, int32_t *next_bucket_base,
     float growth, int slack, int32_t *n_live_mapped, int degree, const float *campos, const float *features_dc,
     const float *features_rest, const float *c2w, float *packed, float *normals_world, float *zero_cells, int n_zero,
-    fsgs_stream_t stream);
+    int32_t *tile_order /* nullable */, fsgs_stream_t stream);
 int fsgs_bin_live_sort_buckets(int tile_width, int tile_height, const int32_t *isect_offsets,
                                const int32_t *bucket_base, void *buckets, int32_t *payload_sorted,
-                               int32_t *long_flag /* nullable */, int rel_gate, fsgs_stream_t stream);
+                               int32_t *long_flag /* nullable */, int rel_gate, const int32_t *tile_order /* nullable */,
+                               fsgs_stream_t stream);
+/* tile_order [tw * th] i32 (nullable): the bookkeeping workgroup of fsgs_project_bin_live_fill_sh_pack leaves the tiles
+ * longest list first (classes of 64 entries) there, and fsgs_bin_live_sort_buckets dispatches its workgroups in that order:
+ * a tile's sort takes as long as its list is long, and the launch is 5-7 rounds of resident workgroups. */
 /* long_flag (round 5; a word the caller zeroes): set to 1 if any tile's list is longer than rel_gate times the mean list
  * length — the frame statistic fsgs_raster_fwd_quad's hand-off is gated on (handoff_gate): only frames that HAVE lists far
  * beyond the bulk (config #3's hull tiles: 16 x the mean; config #2's longest list: 5.7 x) queue anything. */
