@@ -104,7 +104,7 @@ SIGNATURES = {
     "fsgs_epilogue_fwd": (_i, [_i64, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p]),
     "fsgs_epilogue_loss_fwd": (_i, [_i64, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p]),
     "fsgs_epilogue_fwd_order": (_i, [_i64, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _f, _f, _p, _p, _p,
-                                     _p, _p, _p, _p, _i, _i, _p]),
+                                     _p, _p, _p, _p, _i, _i, _i, _p]),
     "fsgs_epilogue_bwd": (_i, [_i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "fsgs_normals_fwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _p]),
     "fsgs_normals_bwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _p]),

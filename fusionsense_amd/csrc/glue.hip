@@ -76,6 +76,7 @@ struct BwdOrderRider {
     int32_t *counters;                 // [kOrderClasses], zeroed by the caller (behind the backward's queue)
     int32_t *order;                    // [kOrderClasses, 4 T]
     int tw, n_tiles, first_block;      // rider blocks = blockIdx.x >= first_block
+    int shift;                         // class = min(own records >> shift, kOrderClasses - 1)
 };
 
 __device__ __forceinline__ void bwd_order_rider_block(const BwdOrderRider &r, int block) {
@@ -91,7 +92,7 @@ __device__ __forceinline__ void bwd_order_rider_block(const BwdOrderRider &r, in
         cls[k] = -1;
         if (i < nq) {
             const int own = r.n_rec[i] - 64 * (r.seg_split ? r.seg_split[i] : 0);
-            cls[k] = min(max(own, 0) >> 4, kOrderClasses - 1);
+            cls[k] = min(max(own, 0) >> r.shift, kOrderClasses - 1);
             rank[k] = atomicAdd(&cnt[cls[k]], 1);
         }
     }
@@ -346,7 +347,7 @@ extern "C" int fsgs_epilogue_loss_fwd(int64_t n_pixels, const float *render, con
     if (!depth_gt) return FSGS_EINVAL;
     return fsgs_epilogue_fwd_order(n_pixels, render, alphas, render_extra, bg, max_last, n_cells, rgb, depth, normal,
                                    depth_gt, normal_gt, v_loss, g_depth, g_normal, partial, v_depth, v_normal, nullptr,
-                                   nullptr, nullptr, nullptr, 0, 0, stream);
+                                   nullptr, nullptr, nullptr, 0, 0, 0, stream);
 }
 
 // fsgs_epilogue_loss_fwd (depth_gt != NULL) or fsgs_epilogue_fwd over the forward's partial maxima (depth_gt == NULL: no
@@ -357,18 +358,20 @@ extern "C" int fsgs_epilogue_fwd_order(int64_t n_pixels, const float *render, co
                                        const float *normal_gt, const float *v_loss, float g_depth, float g_normal,
                                        float *partial, float *v_depth, float *v_normal, const int32_t *n_rec,
                                        const int32_t *seg_split, int32_t *order_counters, int32_t *bwd_order,
-                                       int tile_width, int tile_height, fsgs_stream_t stream) {
+                                       int order_shift, int tile_width, int tile_height, fsgs_stream_t stream) {
     if (n_pixels < 0 || n_cells < 1) return FSGS_EINVAL;
     if (n_pixels == 0) return FSGS_OK;
     if (!render || !alphas || !bg || !max_last || !rgb || !depth) return FSGS_EINVAL;
     if (depth_gt && (!v_loss || !partial || !v_depth)) return FSGS_EINVAL;
     if ((normal && !render_extra) || (normal_gt && (!depth_gt || !normal || !v_normal))) return FSGS_EINVAL;
-    if (bwd_order && (!n_rec || !order_counters || tile_width < 1 || tile_height < 1)) return FSGS_EINVAL;
+    if (bwd_order && (!n_rec || !order_counters || tile_width < 1 || tile_height < 1 || order_shift < 0 || order_shift > 16))
+        return FSGS_EINVAL;
     const int n_blocks = (int)ceil_div(n_pixels, 256);
     BwdOrderRider rd{};
     int n_rider = 0;
     if (bwd_order) {
-        rd = BwdOrderRider{n_rec, seg_split, order_counters, bwd_order, tile_width, tile_width * tile_height, n_blocks};
+        rd = BwdOrderRider{n_rec, seg_split, order_counters, bwd_order, tile_width, tile_width * tile_height, n_blocks,
+                           order_shift};
         n_rider = (int)ceil_div((int64_t)4 * tile_width * tile_height, 1024);
     }
     const float4 *r4 = reinterpret_cast<const float4 *>(render);

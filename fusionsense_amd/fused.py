@@ -165,6 +165,7 @@ BWD_QUEUE_ITEMS = 1024
 # the backward's quadrants start longest own share first (fsgs.h: bwd_order; needs the queue); classes = the library's
 BWD_ORDER = True
 BWD_ORDER_CLASSES = 32
+BWD_ORDER_DENSE = False  # (models of 2^20 Gaussians and more — no queue items there: measured, config #4 0.939 ms either way)
 # count-free binning of revisited views (ops.project_bin_live_fill_async; fsgs.h): on / off, and the model size from which
 # the dense machinery (occlusion cuts, several chunks per workgroup) keeps the two-pass route
 BIN_FILL = True
@@ -330,11 +331,14 @@ class _FusedGetOutputs(torch.autograd.Function):
         # partial image maxima: zeroed by the pack kernel, raised by the forward — and behind them, zeroed by the same
         # kernel, the queue of the backward's extra workgroups (a counter + BWD_QUEUE_ITEMS int4 items: fsgs.h, seg_split)
         # ... behind the items the BWD_ORDER_CLASSES counters of the backward's dispatch order (fsgs.h: bwd_order)
-        q_words = 4 + 4 * BWD_QUEUE_ITEMS + BWD_ORDER_CLASSES
+        # (dense scenes, N >= 2^20: no queue items — every quadrant's stream is long and every SIMD busy: nothing gained —
+        # but the dispatch order is kept: a queue of zero items is its counter, padding and the order's class counters)
+        n_q_items = BWD_QUEUE_ITEMS if N < FWD_WALK.handoff_max_n else (0 if BWD_ORDER_DENSE else -1)
+        q_words = 4 + 4 * max(n_q_items, 0) + BWD_ORDER_CLASSES
         max_last = torch.empty(n_cells + q_words + 4, **f32)
         # (dense scenes, N >= 2^20: every quadrant's stream is long and every SIMD busy — measured: nothing gained)
         bwd_queue = (max_last[n_cells:n_cells + q_words].view(torch.int32)
-                     if (BWD_QUEUE_ITEMS > 0 and N < FWD_WALK.handoff_max_n) else None)
+                     if (BWD_QUEUE_ITEMS > 0 and n_q_items >= 0) else None)
         # ... and the frame statistic that gates the forward's hand-off (set by the in-tile sort: fsgs_bin_live_emit)
         long_flag = max_last[n_cells + q_words:].view(torch.int32)
         # the SH colours + packing ride in the binning's scan launch when nothing stands between them and the
@@ -479,7 +483,7 @@ class _FusedGetOutputs(torch.autograd.Function):
                                        int(FWD_WALK.handoff_rel_len),
                                        ptr(long_flag) if (direct_bins and pre_sh is None and FWD_WALK.handoff_gate_len > 0)
                                        else None, int(epoch), ptr(seg_split), ptr(bwd_queue),
-                                       BWD_QUEUE_ITEMS if bwd_queue is not None else 0, sp),
+                                       n_q_items if bwd_queue is not None else 0, sp),
              "fsgs_raster_fwd_quad", "_d4e3")
         if tile_open is not None:
             # this frame's saturation depths become the next frame's cuts; a cut tile left open spoils the frame
@@ -497,8 +501,11 @@ class _FusedGetOutputs(torch.autograd.Function):
         normal = torch.empty(H, W, 3, **f32)
         lt = info.loss_targets
         # (riding in the epilogue launch: the backward's dispatch order — the streams' lengths are known now)
-        order_args = ((ptr(n_rec), ptr(seg_split), bwd_queue[4 + 4 * BWD_QUEUE_ITEMS:].data_ptr(), ptr(bwd_order), tw, th)
-                      if bwd_order is not None else (None, None, None, None, 0, 0))
+        # (classes of 16 records of a quadrant's own share — at most 8 segments where long streams are shared out —, of 128
+        # in dense scenes, whose quadrants keep whole streams of hundreds to thousands of records)
+        order_args = ((ptr(n_rec), ptr(seg_split), bwd_queue[4 + 4 * n_q_items:].data_ptr(), ptr(bwd_order),
+                       4 if n_q_items > 0 else 7, tw, th)
+                      if bwd_order is not None else (None, None, None, None, 0, 0, 0))
         if lt is not None:
             # the trainer's tape-free step: the depth / normal L1 terms of its loss are evaluated on the pixels as
             # they are formed (partial sums + gradient images), no separate pass over the two images
@@ -532,6 +539,7 @@ class _FusedGetOutputs(torch.autograd.Function):
                                   background, seg_split, bwd_queue if bwd_queue is not None else seg_split)
             ctx.has_bwd_queue = bwd_queue is not None
             ctx.bwd_order = bwd_order  # (a view of the frame's arena, like the streams)
+            ctx.n_q_items = max(n_q_items, 0)
             ctx.arena = arena
         else:
             WORKSPACE.give(arena)
@@ -547,7 +555,7 @@ class _FusedGetOutputs(torch.autograd.Function):
          offsets, render, alphas, last_ids, render_extra, seg_state, background, seg_split, bwd_queue) = ctx.saved_tensors
         if not ctx.has_bwd_queue:
             bwd_queue = None
-        n_queue = BWD_QUEUE_ITEMS if bwd_queue is not None else 0
+        n_queue = ctx.n_q_items if bwd_queue is not None else 0
         bwd_order = getattr(ctx, "bwd_order", None) if bwd_queue is not None else None
         N, K, W, H, tw, th, M, sh_degree = ctx.dims
         cam = ctx.cam

@@ -273,7 +273,7 @@ int fsgs_raster_fwd_quad(int C, int D, const float *packed, const int32_t *paylo
  * by side instead of 11 rounds of one.  Gradients are unchanged up to the order of the float atomics. */
 /* Dispatch order of the backward (round 5): bwd_order (nullable; needs bwd_queue, C == 1) = [32, 4 * th * tw] i32, filled
  * between the forward and the backward by fsgs_epilogue_fwd_order (below): every quadrant is filed under a class of its
- * own share's record count (16 records wide, the last class open-ended), bwd_order[class][slot] = the quadrant's position
+ * own share's record count (2^order_shift records wide, the last class open-ended), bwd_order[class][slot] = the quadrant's position
  * in the backward's grid; the classes' 32 i32 counters sit BEHIND the queue's items (bwd_queue then needs 4 + 4 *
  * bwd_queue_items + 32 words, zeroed by the caller).  fsgs_raster_bwd_quad* given bwd_order start the quadrants longest
  * class first (dispatch_stride is then not used): a backward workgroup's time is its quadrant's share, and the launch
@@ -708,7 +708,8 @@ int fsgs_epilogue_fwd_order(int64_t n_pixels, const float *render, const float *
                             const float *bg, const float *max_last, int n_cells, float *rgb, float *depth, float *normal,
                             const float *depth_gt, const float *normal_gt, const float *v_loss, float g_depth,
                             float g_normal, float *partial, float *v_depth, float *v_normal, const int32_t *n_rec,
-                            const int32_t *seg_split, int32_t *order_counters, int32_t *bwd_order, int tile_width,
+                            const int32_t *seg_split, int32_t *order_counters, int32_t *bwd_order,
+                            int order_shift /* class = min(own records >> order_shift, 31) */, int tile_width,
                             int tile_height, fsgs_stream_t stream);
 int fsgs_epilogue_bwd(int64_t n_pixels, const float *render, const float *alphas,
                       const float *render_extra, const float *bg, const float *v_rgb,
