@@ -64,18 +64,19 @@ struct EpilogueLoss {
 // Rider of the epilogue launch (round 5): the dispatch order of the compositing BACKWARD.  A backward workgroup's time is its
 // quadrant's own share of records, and the launch is ~6 rounds of resident workgroups: started longest first, its last
 // round is the short ones (config #3's trained scene: 0.191 -> 0.174 ms; config #2: 0.1675 -> 0.165).  The streams' lengths
-// are known once the forward has finished — i.e. here: extra blocks of this launch (one wave per 1024 quadrants) file every
+// are known once the forward has finished — i.e. here: extra blocks of this launch (one wave per 256 quadrants, dispatched first) file every
 // quadrant under one of kOrderClasses classes of record counts (16 records wide, the last one open-ended) — a counting
 // sort: per-block class counts in LDS, ONE returning atomic per (block, class) on the class's counter reserves the block's
 // run in the class's list, order[class][slot] = the quadrant's position in the backward's grid.  (Filing from the
 // forward's finishing waves — one returning atomic per quadrant on a handful of hot counters — took the forward from 78 to
 // 130 us.)  One camera.
 constexpr int kOrderClasses = 32;
+constexpr int kOrderPerLane = 4;  // a rider wave files 256 quadrants (16 per lane in ~12 blocks left a tail behind the bulk)
 struct BwdOrderRider {
     const int32_t *n_rec, *seg_split;  // [4, T]
     int32_t *counters;                 // [kOrderClasses], zeroed by the caller (behind the backward's queue)
     int32_t *order;                    // [kOrderClasses, 4 T]
-    int tw, n_tiles, first_block;      // rider blocks = blockIdx.x >= first_block
+    int tw, n_tiles, n_rider;          // rider blocks = blockIdx.x < n_rider: dispatched FIRST, beside the launch's bulk
     int shift;                         // class = min(own records >> shift, kOrderClasses - 1)
 };
 
@@ -85,10 +86,10 @@ __device__ __forceinline__ void bwd_order_rider_block(const BwdOrderRider &r, in
     const int nq = 4 * r.n_tiles;
     if (lane < kOrderClasses) cnt[lane] = 0;
     __syncthreads();
-    int cls[16], rank[16];
+    int cls[kOrderPerLane], rank[kOrderPerLane];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const int i = block * 1024 + k * 64 + lane;  // index into [4, T]: quadrant q = i / T of tile i % T
+    for (int k = 0; k < kOrderPerLane; ++k) {
+        const int i = (block * kOrderPerLane + k) * 64 + lane;  // index into [4, T]: quadrant q = i / T of tile i % T
         cls[k] = -1;
         if (i < nq) {
             const int own = r.n_rec[i] - 64 * (r.seg_split ? r.seg_split[i] : 0);
@@ -100,9 +101,9 @@ __device__ __forceinline__ void bwd_order_rider_block(const BwdOrderRider &r, in
     if (lane < kOrderClasses) base[lane] = cnt[lane] > 0 ? atomicAdd(r.counters + lane, cnt[lane]) : 0;
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
+    for (int k = 0; k < kOrderPerLane; ++k) {
         if (cls[k] < 0) continue;
-        const int i = block * 1024 + k * 64 + lane;
+        const int i = (block * kOrderPerLane + k) * 64 + lane;
         const int q = i / r.n_tiles, t = i - q * r.n_tiles;
         const int ty = t / r.tw, tx = t - ty * r.tw;
         r.order[(int64_t)cls[k] * nq + base[cls[k]] + rank[k]] = (2 * ty + (q >> 1)) * (2 * r.tw) + 2 * tx + (q & 1);
@@ -119,12 +120,13 @@ epilogue_fwd_kernel(int64_t P, const float4 *__restrict__ render, const float *_
                     const float *__restrict__ render_extra, const float *__restrict__ bg,
                     const float *__restrict__ max_last, int n_cells, float *__restrict__ rgb,
                     float *__restrict__ depth, float *__restrict__ normal, EpilogueLoss L, BwdOrderRider rider) {
-    if (rider.order && (int)blockIdx.x >= rider.first_block) {
-        bwd_order_rider_block(rider, (int)blockIdx.x - rider.first_block);
+    if ((int)blockIdx.x < rider.n_rider) {
+        bwd_order_rider_block(rider, (int)blockIdx.x);
         return;
     }
     const int lane = threadIdx.x;
-    const int64_t p0 = ((int64_t)blockIdx.x * 64 + lane) * 4;  // this lane's first pixel
+    const int blk = (int)blockIdx.x - rider.n_rider;
+    const int64_t p0 = ((int64_t)blk * 64 + lane) * 4;  // this lane's first pixel
     const bool full = p0 + 3 < P;                              // all four pixels exist (else: per-pixel accesses)
     float a[4];
     float4 r[4];
@@ -243,8 +245,8 @@ epilogue_fwd_kernel(int64_t P, const float4 *__restrict__ render, const float *_
         sd = wave_sum_to_last_row(sd);
         sn = wave_sum_to_last_row(sn);
         if (lane == 63) {
-            L.partial[2 * blockIdx.x + 0] = sd;
-            L.partial[2 * blockIdx.x + 1] = sn;
+            L.partial[2 * blk + 0] = sd;
+            L.partial[2 * blk + 1] = sn;
         }
     }
 }
@@ -370,9 +372,9 @@ extern "C" int fsgs_epilogue_fwd_order(int64_t n_pixels, const float *render, co
     BwdOrderRider rd{};
     int n_rider = 0;
     if (bwd_order) {
-        rd = BwdOrderRider{n_rec, seg_split, order_counters, bwd_order, tile_width, tile_width * tile_height, n_blocks,
+        n_rider = (int)ceil_div((int64_t)4 * tile_width * tile_height, 64 * kOrderPerLane);
+        rd = BwdOrderRider{n_rec, seg_split, order_counters, bwd_order, tile_width, tile_width * tile_height, n_rider,
                            order_shift};
-        n_rider = (int)ceil_div((int64_t)4 * tile_width * tile_height, 1024);
     }
     const float4 *r4 = reinterpret_cast<const float4 *>(render);
     if (depth_gt) {
