@@ -115,6 +115,7 @@ def parse():
                     "times the frame's mean list length")
     ap.add_argument("--handoff-gate-len", type=int, default=None, help="A/B: hand off only in frames whose longest list "
                     "exceeds this many times the mean list length (0 = any frame)")
+    ap.add_argument("--fwd-order", type=int, default=None, help="A/B: 0 = the forward's two-pass long-lists-first order")
     ap.add_argument("--sort-order", type=int, default=None, help="A/B: 0 = the in-tile sorts in tile order")
     ap.add_argument("--bwd-order", type=int, default=None, help="A/B: 0 = the backward's quadrants in the size rule's order")
     ap.add_argument("--bin-fill", type=int, default=None, help="A/B: 0 = two-pass binning on every frame")
@@ -555,6 +556,9 @@ def main():
         _f.BWD_ORDER = bool(args.bwd_order)
     if args.sort_order is not None:
         ops.BIN_FILL_SORT_ORDER = bool(args.sort_order)
+    if args.fwd_order is not None:
+        import fusionsense_amd.fused as _f
+        _f.FWD_TILE_ORDER = bool(args.fwd_order)
     if args.bwd_queue is not None:
         import fusionsense_amd.fused as _f
         _f.BWD_QUEUE_ITEMS = int(args.bwd_queue)

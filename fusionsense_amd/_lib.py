@@ -79,7 +79,7 @@ SIGNATURES = {
     "fsgs_raster_quad_max_cells": (_i, []),
     "fsgs_live_pack_normals": (_i, [_i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p]),
     "fsgs_live_payload": (_i, [_p, _p, _i64, _p, _i64, _i, _i, _p, _p]),
-    "fsgs_raster_fwd_quad": (_i, [_i, _i, _p, _p, _p, _i64, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _i64, _i, _i, _i, _p, _i64, _p, _p, _i, _p]),
+    "fsgs_raster_fwd_quad": (_i, [_i, _i, _p, _p, _p, _i64, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _i64, _i, _i, _i, _p, _i64, _p, _p, _i, _p, _p]),
     "fsgs_raster_fwd_tail_scratch_bytes": (_i64, [_i]),
     "fsgs_raster_fwd_tail_error": (_i, [_p, _p]),
     "fsgs_set_bwd_dispatch_stride": (_i, [_i]),

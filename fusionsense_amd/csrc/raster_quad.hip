@@ -544,7 +544,7 @@ raster_fwd_wave_kernel(int64_t cap, const float4 *__restrict__ packed, const int
                        float *__restrict__ render_extra, float *__restrict__ max_last, int ends_on_device,
                        int32_t *__restrict__ tile_open, int handoff_records, TailQueue tq, int n_base_blocks,
                        int handoff_rel_len, int32_t *__restrict__ seg_split, int32_t *__restrict__ bwd_queue,
-                       int bwd_qcap, const int32_t *__restrict__ handoff_gate) {
+                       int bwd_qcap, const int32_t *__restrict__ handoff_gate, const int32_t *__restrict__ tile_order) {
     __shared__ WaveLds<E> S;
     constexpr int RS = E ? 4 : 3;
 #ifdef FSGS_FWD_TRACE
@@ -566,19 +566,21 @@ raster_fwd_wave_kernel(int64_t cap, const float4 *__restrict__ packed, const int
             __hip_atomic_fetch_add(&tq.header()->done[tq.epoch & 1u][blockIdx.x & 63u][0], 1, __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);
     };
-    // long lists first (see above)
-    const unsigned half_grid = (unsigned)n_base_blocks >> 1;
+    // long lists first (see above) — or, given the tiles longest first (tile_order: the count-free binning route's
+    // bookkeeping leaves it), every quadrant ONCE in that order
+    const unsigned half_grid = tile_order ? (unsigned)n_base_blocks : (unsigned)n_base_blocks >> 1;
     const bool long_pass = blockIdx.x < half_grid;
     const unsigned bid = long_pass ? blockIdx.x : blockIdx.x - half_grid;
-    const int tile_lin = (bid >> 5) * 8 + (bid & 7);
+    const int tile_slot = (bid >> 5) * 8 + (bid & 7);
     const int q = (bid >> 3) & 3;
-    if (tile_lin >= n_tiles_total) return;
+    if (tile_slot >= n_tiles_total) return;
+    const int tile_lin = tile_order ? tile_order[tile_slot] : tile_slot;
     {
         const int total = ends_on_device ? tile_offsets[n_tiles_total] : (int)n_isects;
         const int a0 = tile_offsets[tile_lin];
         const int a1 = (tile_lin == n_tiles_total - 1 && !ends_on_device) ? (int)n_isects : tile_offsets[tile_lin + 1];
         const bool is_long = (int64_t)(a1 - a0) * n_tiles_total > 2ll * total;
-        if (is_long != long_pass) return;
+        if (!tile_order && is_long != long_pass) return;
         // only lists far longer than the frame's mean are worth queueing: they are the ones that outlast the bulk of the
         // launch (config #3's hull tiles: 2 800 entries against a mean of ~200; config #2's longest list is 5.7 x its mean
         // and saturates early — queueing those cost 10 us per launch)
@@ -1220,7 +1222,7 @@ extern "C" int fsgs_raster_fwd_quad(int C, int D, const float *packed, const int
                                     float *max_last, int32_t *tile_open, int walk, void *tail_scratch,
                                     int64_t tail_scratch_bytes, int tail_items, int handoff_records, int handoff_rel_len,
                                     const int32_t *handoff_gate, int64_t tail_epoch, int32_t *seg_split, int32_t *bwd_queue, int bwd_queue_items,
-                                    fsgs_stream_t stream) {
+                                    const int32_t *tile_order, fsgs_stream_t stream) {
     // n_isects < 0: -n_isects is the CAPACITY the caller sized records / seg_state for, and the lists' true end is
     // isect_offsets[C * th * tw] on the device (fsgs_bin_live_count leaves it there): no host wait for the total
     const int ends_on_device = n_isects < 0 ? 1 : 0;
@@ -1270,13 +1272,14 @@ extern "C" int fsgs_raster_fwd_quad(int C, int D, const float *packed, const int
                 if (tq.qmax > 0 && tq.epoch == 0u) return FSGS_EINVAL;
             }
             // (the tail waves = the last qmax workgroups of the launch, one per queue position)
-            const int n_base = (int)grid.x * 2;
+            if (tile_order && C != 1) return FSGS_EINVAL;
+            const int n_base = tile_order ? (int)grid.x : (int)grid.x * 2;
             hipLaunchKernelGGL((raster_fwd_wave_kernel<4, 3>), dim3(n_base + (tq.qmax > 0 ? tq.qmax + 1 : 0)), dim3(64), 0, s, cap,
                                pk, payload, isect_offsets, n_isects, backgrounds, width, height, tile_width, tile_height,
                                (int)n_tiles, render, alphas, last_ids, rec, n_rec, seg_state, seg_cap, normalize_last,
                                render_extra, max_last, ends_on_device, tile_open, tq.mem ? handoff_records : 0, tq, n_base,
                                handoff_rel_len < 0 ? 0 : handoff_rel_len, seg_split, bwd_queue, bwd_queue_items,
-                               handoff_gate);
+                               handoff_gate, tile_order);
         } else {
             FSGS_FWD_QUAD(4, 3);
         }

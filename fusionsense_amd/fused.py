@@ -165,6 +165,8 @@ BWD_QUEUE_ITEMS = 1024
 # the backward's quadrants start longest own share first (fsgs.h: bwd_order; needs the queue); classes = the library's
 BWD_ORDER = True
 BWD_ORDER_CLASSES = 32
+# the forward walks the tiles longest list first where the binning left that order (count-free route: ops.BIN_FILL_SORT_ORDER)
+FWD_TILE_ORDER = True
 BWD_ORDER_DENSE = False  # (models of 2^20 Gaussians and more — no queue items there: measured, config #4 0.939 ms either way)
 # count-free binning of revisited views (ops.project_bin_live_fill_async; fsgs.h): on / off, and the model size from which
 # the dense machinery (occlusion cuts, several chunks per workgroup) keeps the two-pass route
@@ -483,7 +485,9 @@ class _FusedGetOutputs(torch.autograd.Function):
                                        int(FWD_WALK.handoff_rel_len),
                                        ptr(long_flag) if (direct_bins and pre_sh is None and FWD_WALK.handoff_gate_len > 0)
                                        else None, int(epoch), ptr(seg_split), ptr(bwd_queue),
-                                       n_q_items if bwd_queue is not None else 0, sp),
+                                       n_q_items if bwd_queue is not None else 0,
+                                       ptr(count.get("tile_order")) if (direct_bins and FWD_TILE_ORDER and walk == 1) else None,
+                                       sp),
              "fsgs_raster_fwd_quad", "_d4e3")
         if tile_open is not None:
             # this frame's saturation depths become the next frame's cuts; a cut tile left open spoils the frame

@@ -872,7 +872,7 @@ class _Rasterize(torch.autograd.Function):
                                            -M if ends_on_device else M,
                                            ptr(backgrounds), width, height, tw, th, int(normalize_last),
                                            ptr(render), ptr(alphas), ptr(last_ids), ptr(records), ptr(n_rec),
-                                           ptr(seg_state), None, None, None, 0, None, 0, 0, 0, 0, None, 0, None, None, 0, stream_ptr(dev)),
+                                           ptr(seg_state), None, None, None, 0, None, 0, 0, 0, 0, None, 0, None, None, 0, None, stream_ptr(dev)),
                  "fsgs_raster_fwd_quad", f"_d{D}")
             empty = torch.empty(0, device=dev)
             ctx.save_for_backward(records if records is not None else empty,

@@ -264,7 +264,11 @@ int fsgs_raster_fwd_quad(int C, int D, const float *packed, const int32_t *paylo
                          void *tail_scratch /* nullable */, int64_t tail_scratch_bytes, int tail_items,
                          int handoff_records, int handoff_rel_len, const int32_t *handoff_gate /* nullable */,
                          int64_t tail_epoch, int32_t *seg_split /* nullable */,
-                         int32_t *bwd_queue /* nullable */, int bwd_queue_items, fsgs_stream_t stream);
+                         int32_t *bwd_queue /* nullable */, int bwd_queue_items,
+                         const int32_t *tile_order /* nullable; FSGS_WALK_ONE_WAVE, C == 1: the tiles longest list first
+                         (fsgs_project_bin_live_fill_sh_pack) — the quadrants are then walked once, in that order,
+                         instead of in two passes (tiles above twice the mean list length, then the others) */,
+                         fsgs_stream_t stream);
 /* Long streams in the backward (round 5): seg_split [4, C*th*tw] i32 (next to n_rec) receives, per quadrant, the first
  * 64-record segment its own backward workgroup walks — 0 unless the stream has more than 8 segments AND bwd_queue
  * ([4 + 4 * bwd_queue_items] i32: a counter the CALLER ZEROES before the call + 3 pad words, then int4 items) had room:

@@ -915,7 +915,7 @@ def test_folded_entry_points_equal_the_chains_they_replace(dev):
     extra = torch.empty(1, H, W, 3, **f32)
     assert lib.fsgs_raster_fwd_quad(1, 4, ptr(pk_a), ptr(payload), ptr(offsets), M, None, W, H, tw, th, 1, ptr(render),
                                     ptr(alphas), ptr(last_ids), ptr(records), ptr(n_rec), ptr(seg_state), ptr(extra),
-                                    ptr(mx_a), None, 0, None, 0, 0, 0, 0, None, 0, None, None, 0, sp) == 0
+                                    ptr(mx_a), None, 0, None, 0, 0, 0, 0, None, 0, None, None, 0, None, sp) == 0
     g = torch.Generator().manual_seed(3)
     bg = torch.tensor([1.0, 0.5, 0.25], device=dev)
     depth_gt, normal_gt = torch.rand(H, W, 1, generator=g).to(dev), torch.rand(H, W, 3, generator=g).to(dev)
