@@ -556,6 +556,7 @@ def main():
         _f.BWD_ORDER = bool(args.bwd_order)
     if args.sort_order is not None:
         ops.BIN_FILL_SORT_ORDER = bool(args.sort_order)
+        ops.TWO_PASS_TILE_ORDER = bool(args.sort_order)
     if args.fwd_order is not None:
         import fusionsense_amd.fused as _f
         _f.FWD_TILE_ORDER = bool(args.fwd_order)

@@ -60,9 +60,9 @@ SIGNATURES = {
     "fsgs_bin_live_table_bytes": (_sz, [_i, _i, _i, _i]),
     "fsgs_bin_live_count": (_i, [_i, _i, _p, _p, _p, _p, _i, _i, _p, _p, _p, _sz, _p, _p]),
     "fsgs_project_bin_live_count_sh_pack": (_i, [_i, _p, _p, _p, _p, _i, _f, _p, _p, _i, _i, _f, _f, _f, _f, _p, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p, _sz, _p,
-                                                 _i, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p]),
+                                                 _i, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p]),
     "fsgs_project_bin_live_count_sh_pack_h16": (_i, [_i, _p, _p, _p, _p, _p, _i, _f, _p, _p, _i, _i, _f, _f, _f, _f, _p, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p, _sz, _p,
-                                                     _i, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p]),
+                                                     _i, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p]),
     "fsgs_project_bin_live_count": (_i, [_i, _p, _p, _p, _p, _i, _f, _p, _p, _i, _i, _f, _f, _f, _f, _p, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p, _sz, _p, _p]),
     "fsgs_bin_live_emit": (_i, [_i, _i, _p, _p, _p, _p, _p, _i, _i, _p, _p, _i64, _p, _p, _p, _p, _i, _p]),
     "fsgs_project_bin_live_fill_sh_pack": (_i, [_i, _p, _p, _p, _p, _i, _f, _p, _p, _i, _i, _f, _f, _f, _f, _p, _p, _p, _p, _p, _p, _i, _i, _p, _p,

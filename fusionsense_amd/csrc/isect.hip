@@ -1030,7 +1030,8 @@ static int project_bin_live_count_impl(int N, const float *means, const void *qu
                                            int32_t *isect_offsets, void *table_scratch, size_t table_bytes,
                                            int32_t *n_live_mapped, fsgs_stream_t stream,
                                            const ShPackRider *rider = nullptr, const fsgs_adam_groups *adam = nullptr,
-                                           const float *tile_zcut = nullptr, uint8_t *kept = nullptr) {
+                                           const float *tile_zcut = nullptr, uint8_t *kept = nullptr,
+                                           int32_t *tile_order = nullptr) {
     if (N < 0 || tile_width < 1 || tile_height < 1 || !isect_offsets) return FSGS_EINVAL;
     const int64_t T64 = (int64_t)tile_width * tile_height;
     if (T64 > fsgs_bin_live_max_tiles()) return FSGS_EINVAL;
@@ -1097,7 +1098,7 @@ static int project_bin_live_count_impl(int N, const float *means, const void *qu
     if (rc != FSGS_OK) return rc;
     if (rider)  // the table scan, the SH forward + packing AND the offsets in one launch (sh.hip)
         return launch_scan_rows_sh_pack(T, nb, table, totals, *rider, s, ticket, isect_offsets, n_live_mapped,
-                                        BucketBook{nullptr, nullptr, nullptr, 0.f, 0});
+                                        BucketBook{nullptr, nullptr, nullptr, 0.f, 0, tile_order});
     return launch_tile_scan_rows_offsets(T, nb, table, totals, isect_offsets, n_live_mapped, s);
 }
 
@@ -1111,14 +1112,14 @@ extern "C" int fsgs_project_bin_live_count_sh_pack(
     void *table_scratch, size_t table_bytes, int32_t *n_live_mapped, int degree, const float *campos,
     const float *features_dc, const float *features_rest, const float *c2w, float *packed, float *normals_world,
     float *zero_cells, int n_zero, const fsgs_adam_groups *adam, const float *tile_zcut, uint8_t *kept,
-    fsgs_stream_t stream) {
+    int32_t *tile_order, fsgs_stream_t stream) {
     const ShPackRider r = {N, degree, 0, means, campos, features_dc, features_rest, radii, depths, means2d, conics,
                            opac_out, quats, log_scales, c2w, packed, normals_world, zero_cells, n_zero, nullptr};
     return project_bin_live_count_impl(N, means, quats, log_scales, opac_logit, nullptr, 0, binarise, binary_threshold,
                                        viewmat, K, width, height, eps2d, near_plane, far_plane, radius_clip, scales_out,
                                        opac_out, radii, means2d, depths, conics, tile_width, tile_height, tiles_per_gauss,
                                        isect_offsets, table_scratch, table_bytes, n_live_mapped, stream,
-                                       packed ? &r : nullptr, adam, tile_zcut, kept);
+                                       packed ? &r : nullptr, adam, tile_zcut, kept, packed ? tile_order : nullptr);
 }
 
 extern "C" int fsgs_project_bin_live_count_sh_pack_h16(
@@ -1129,14 +1130,15 @@ extern "C" int fsgs_project_bin_live_count_sh_pack_h16(
     int32_t *tiles_per_gauss, int32_t *isect_offsets, void *table_scratch, size_t table_bytes, int32_t *n_live_mapped,
     int degree, const float *campos, const void *features_dc_h, const void *features_rest_h, const float *c2w,
     float *packed, float *normals_world, float *zero_cells, int n_zero, const fsgs_adam_groups *adam,
-    const float *tile_zcut, uint8_t *kept, fsgs_stream_t stream) {
+    const float *tile_zcut, uint8_t *kept, int32_t *tile_order, fsgs_stream_t stream) {
     const ShPackRider r = {N, degree, 1, means, campos, features_dc_h, features_rest_h, radii, depths, means2d, conics,
                            opac_out, quats_h, log_scales_h, c2w, packed, normals_world, zero_cells, n_zero, nullptr};
     return project_bin_live_count_impl(N, means, quats_h, log_scales_h, opac_logit_master, opac_logit_h, 1, binarise,
                                        binary_threshold, viewmat, K, width, height, eps2d, near_plane, far_plane,
                                        radius_clip, scales_out, opac_out, radii, means2d, depths, conics, tile_width,
                                        tile_height, tiles_per_gauss, isect_offsets, table_scratch, table_bytes,
-                                       n_live_mapped, stream, packed ? &r : nullptr, adam, tile_zcut, kept);
+                                       n_live_mapped, stream, packed ? &r : nullptr, adam, tile_zcut, kept,
+                                       packed ? tile_order : nullptr);
 }
 
 extern "C" int fsgs_project_bin_live_count(int N, const float *means, const float *quats, const float *log_scales,

@@ -1471,7 +1471,7 @@ scan_rows_sh_pack_kernel(int T, int nb, int32_t *__restrict__ table, int32_t *__
         if (threadIdx.x == 0)
             last = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == n_scan_blocks - 1;
         __syncthreads();
-        if (last) tile_offsets_body256(T, totals, isect_offsets, total_mapped);
+        if (last) tile_offsets_body256(T, totals, isect_offsets, total_mapped, bk.tile_order);
         return;
     }
     sh_fwd_pack_direct_body<HALF>(blockIdx.x - n_scan_blocks, N, degree, means, campos, dc, rest, radii, depths, pk);

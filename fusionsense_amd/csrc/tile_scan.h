@@ -65,15 +65,23 @@ __device__ __forceinline__ void tile_scan_rows_body(int T, int nb, int32_t *__re
 // isect_offsets from the per-tile totals by ONE workgroup of 256 threads (what tile_offsets_kernel does as a launch of its
 // own): offsets[t] = min(sum of totals before t, capacity), offsets[T] = min(total, capacity); total_mapped as there.
 __device__ __forceinline__ void tile_offsets_body256(int T, const int32_t *__restrict__ totals,
-                                                     int32_t *__restrict__ offsets, int32_t *__restrict__ total_mapped) {
+                                                     int32_t *__restrict__ offsets, int32_t *__restrict__ total_mapped,
+                                                     int32_t *__restrict__ tile_order = nullptr) {
     __shared__ int wsum[4];
+    __shared__ int ocnt2[32], obase2[32];
+    if (tile_order && threadIdx.x < 32) ocnt2[threadIdx.x] = 0;
+    if (tile_order) __syncthreads();
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int per = (T + 255) / 256;          // consecutive tiles per thread
     const int i0 = tid * per, i1 = min(i0 + per, T);
     const int c = total_mapped ? total_mapped[2] : 0;
     const int cap = c > 0 ? c : 0x7FFFFFFF;
     int mine = 0;
-    for (int i = i0; i < i1; ++i) mine += __hip_atomic_load(&totals[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int i = i0; i < i1; ++i) {
+        const int n = __hip_atomic_load(&totals[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        mine += n;
+        if (tile_order) atomicAdd(&ocnt2[min(n >> 6, 31)], 1);
+    }
     int inc = mine;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -82,11 +90,20 @@ __device__ __forceinline__ void tile_offsets_body256(int T, const int32_t *__res
     }
     if (lane == 63) wsum[w] = inc;
     __syncthreads();
+    if (tile_order) {  // the tiles longest list first (classes of 64 entries), as bucket_offsets_body256 leaves them
+        if (tid == 0) {
+            int run_o = 0;
+            for (int cc = 31; cc >= 0; --cc) { obase2[cc] = run_o; run_o += ocnt2[cc]; }
+        }
+        __syncthreads();
+    }
     int run = inc - mine;
     for (int k = 0; k < w; ++k) run += wsum[k];
     for (int i = i0; i < i1; ++i) {
+        const int n = __hip_atomic_load(&totals[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         offsets[i] = min(run, cap);
-        run += __hip_atomic_load(&totals[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        run += n;
+        if (tile_order) tile_order[atomicAdd(&obase2[min(n >> 6, 31)], 1)] = i;
     }
     if (tid == 255) {
         const int total = wsum[0] + wsum[1] + wsum[2] + wsum[3];

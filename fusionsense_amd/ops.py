@@ -392,7 +392,10 @@ def project_bin_live_count_async(means: Tensor, quats: Tensor, log_scales: Tenso
                     ptr(zero_cells), int(zero_cells.numel()))
         else:
             tail = (0, None, None, None, None, None, None, None, 0)
-        tail = tail + (C.byref(adam) if adam is not None else None, ptr(zcut), ptr(kept), stream_ptr(dev))
+        # (the tiles longest list first, for the forward's walk: left by the scan launch's last workgroup)
+        tile_order = (torch.empty(T, dtype=torch.int32, device=dev)
+                      if (sh_pack is not None and TWO_PASS_TILE_ORDER) else None)
+        tail = tail + (C.byref(adam) if adam is not None else None, ptr(zcut), ptr(kept), ptr(tile_order), stream_ptr(dev))
         bt = (0 if binary_threshold is None else 1, 0.0 if binary_threshold is None else float(binary_threshold))
         outs = (ptr(out["scales_exp"]), ptr(out["opac_sig"]), ptr(out["radii"]), ptr(out["means2d"]),
                 ptr(out["depths"]), ptr(out["conics"]), tile_width, tile_height, ptr(tpg), ptr(offsets), ptr(table),
@@ -408,7 +411,7 @@ def project_bin_live_count_async(means: Tensor, quats: Tensor, log_scales: Tenso
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(dev))
         return dict(direct=True, tpg=tpg, offsets=offsets, table=table, pinned=pinned, event=ev, T=T, capacity=capacity,
-                    zcut=zcut)
+                    zcut=zcut, tile_order=tile_order)
     if half is not None:  # BASELINE config #5: quats / log-scales / opacity logits read from their half mirrors
         _run(lib.fsgs_project_bin_live_count_h16,
              (N, ptr(means), ptr(half["quats"]), ptr(half["scales"]), ptr(half["opacities"]), ptr(opac_logit),
@@ -435,6 +438,7 @@ def project_bin_live_count_async(means: Tensor, quats: Tensor, log_scales: Tenso
 BIN_FILL_GROWTH, BIN_FILL_SLACK = 1.25, 64
 # the count-free route's in-tile sorts are dispatched longest tile first (fsgs.h: tile_order)
 BIN_FILL_SORT_ORDER = True
+TWO_PASS_TILE_ORDER = True  # (... and the two-pass route's scan launch leaves the same order for the forward's walk)
 _BIN_CURSORS: dict = {}  # (device, T) -> int32 [T], zeroed once: the route's own bookkeeping leaves it zeroed
 
 

@@ -435,6 +435,7 @@ int fsgs_project_bin_live_count_sh_pack(
     void *table_scratch, size_t table_bytes, int32_t *n_live_mapped, int degree, const float *campos,
     const float *features_dc, const float *features_rest, const float *c2w, float *packed, float *normals_world,
     float *zero_cells, int n_zero, const fsgs_adam_groups *adam, const float *tile_zcut, uint8_t *kept,
+    int32_t *tile_order /* nullable [tw * th]: the tiles longest list first (as from ..._fill_sh_pack; packed != NULL) */,
     fsgs_stream_t stream);
 int fsgs_project_bin_live_count_sh_pack_h16(
     int N, const float *means, const void *quats_h, const void *log_scales_h, void *opac_logit_h,
@@ -444,7 +445,7 @@ int fsgs_project_bin_live_count_sh_pack_h16(
     int32_t *tiles_per_gauss, int32_t *isect_offsets, void *table_scratch, size_t table_bytes, int32_t *n_live_mapped,
     int degree, const float *campos, const void *features_dc_h, const void *features_rest_h, const float *c2w,
     float *packed, float *normals_world, float *zero_cells, int n_zero, const fsgs_adam_groups *adam,
-    const float *tile_zcut, uint8_t *kept, fsgs_stream_t stream);
+    const float *tile_zcut, uint8_t *kept, int32_t *tile_order /* nullable */, fsgs_stream_t stream);
 int fsgs_bin_live_emit(int C, int N, const float *means2d, const int32_t *radii, const float *depths,
                        const float *conics, const float *opacities, int tile_width, int tile_height,
                        const int32_t *isect_offsets, const void *table_scratch, int64_t n_live, void *buckets,

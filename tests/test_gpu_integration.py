@@ -476,9 +476,11 @@ def test_patched_model_in_the_reference_loop_shape_trains_like_the_trainer(dev, 
         if same_rows:
             # two independent 130-step trainings: the float atomics' summation order differs, and Adam (eps = 1e-15) turns
             # a sign flip of a near-zero gradient into a +-lr step — most entries agree to rounding, a minority has
-            # drifted by a few learning rates, none by more
+            # drifted by a few learning rates, none by more.  (Median bound 4e-5 since round 5: with the backward's
+            # workgroups started longest share first the order of a Gaussian's atomics varies more from launch to
+            # launch, and the log-scales' median drift over the 130 steps moved from ~1.5e-5 to 2.1-3.0e-5 of 5e-3 steps.)
             dd = (a - b).abs()
-            assert float(dd.median()) < 2e-5 and float((dd > 40 * LR[k]).float().mean()) < 1e-2, \
+            assert float(dd.median()) < 4e-5 and float((dd > 40 * LR[k]).float().mean()) < 1e-2, \
                 (k, float(dd.median()), float((dd > 40 * LR[k]).float().mean()))
             assert math.isfinite(float(dd.max()))
         assert abs(float(a.double().abs().mean()) - float(b.double().abs().mean())) <= 2e-3 * float(b.double().abs().mean()) + 1e-6, k

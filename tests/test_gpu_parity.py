@@ -889,7 +889,7 @@ def test_folded_entry_points_equal_the_chains_they_replace(dev):
         0.3, 0.01, 1e10, 0.0, ptr(c["scales_exp"]), ptr(c["opac_sig"]), ptr(c["radii"]), ptr(c["means2d"]),
         ptr(c["depths"]), ptr(c["conics"]), tw, th, ptr(tpg_c), ptr(offs_c), ptr(table), tbytes, None, 3,
         ptr(cd["campos"]), ptr(P["features_dc"]), ptr(P["features_rest"]), ptr(cd["c2w"]), ptr(pk_c), ptr(nw_c),
-        ptr(mx_c), n_cells, C.byref(groups), None, None, sp) == 0
+        ptr(mx_c), n_cells, C.byref(groups), None, None, None, sp) == 0
     torch.cuda.synchronize()
     for k in ("scales_exp", "opac_sig", "radii", "depths", "means2d", "conics"):
         assert torch.equal(c[k], b[k]), k          # (the same kernel body as fsgs_project_bin_live_count)
