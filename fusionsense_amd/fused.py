@@ -534,6 +534,7 @@ class _FusedGetOutputs(torch.autograd.Function):
         info.tiles_per_gauss, info.isect_ids, info.payload = tpg, isect_ids, flatten_ids
         info.isect_offsets = offsets[:tw * th].view(1, th, tw) if no_wait else offsets
         info.last_ids, info.normals_world = last_ids, normals_world
+        info.tile_order = count.get("tile_order") if direct_bins else None  # (tiles longest list first, or None: tests)
         info.legacy_rule_diff = rule_diff
         info.streams = (records, n_rec, seg_state)  # (what the backward reads; valid until it has run: tools / tests)
 

@@ -680,3 +680,73 @@ def test_count_free_binning_equals_the_two_pass_route(dev, monkeypatch):
     for it in range(9):
         loss, out = tr.train_step(cams[it % 3], tgts[it % 3])
     assert math.isfinite(float(loss)) and tr.bin_frames.get("fill", 0) == 6 and tr.live_overflows == 0, tr.bin_frames
+
+
+@pytest.mark.gpu
+def test_longest_first_orders_are_permutations_sorted_by_class(dev):
+    """The two device-side orders of round 5.  (1) ``tile_order`` of the binning's bookkeeping workgroup (both routes):
+    every tile exactly once, list lengths in classes of 64 entries non-increasing.  (2) fsgs_epilogue_fwd_order's rider: every
+    quadrant exactly once in bwd_order, filed under min(own records >> shift, 31) with own = n_rec - 64 * seg_split, the
+    class counters equal to the class sizes — on a ragged grid whose quadrant count is no multiple of a rider block."""
+    from fusionsense_amd._lib import load, ptr, stream_ptr
+    from fusionsense_amd.trainer import SplatTrainer
+    lib = load()
+    params = {k: v.to(dev) for k, v in scenes.lego_like_scene(60_000, seed=5).items()}
+    cam = scenes.hemisphere_cameras(1, width=333, height=207, focal=420.0, seed=5)[0]
+    g = torch.Generator().manual_seed(5)
+    tgt = {"rgb": torch.rand(207, 333, 3, generator=g).to(dev), "depth": torch.rand(207, 333, 1, generator=g).to(dev) * 4,
+           "normal": torch.rand(207, 333, 3, generator=g).to(dev)}
+    tr = SplatTrainer(params, dev, sh_degree=3)
+    routes = set()
+    for visit in range(3):  # first visit: two-pass route; revisits: the count-free route
+        _, out = tr.train_step(cam, tgt, optimizer_step=False)
+        info = out["info"]
+        routes.add(info.bin_route)
+        order = info.tile_order
+        assert order is not None
+        tw, th = info.tiles
+        T = tw * th
+        assert order.numel() == T and torch.equal(torch.sort(order.long()).values, torch.arange(T, device=dev))
+        offs = info.isect_offsets.reshape(-1).long()
+        n_live = int(info.n_live)
+        lens = torch.diff(torch.cat([offs[:T], torch.tensor([n_live], device=dev)]))
+        cls = torch.clamp(lens[order.long()] >> 6, max=31)
+        assert bool((cls[1:] <= cls[:-1]).all()), visit
+        assert int(cls[0]) >= 1, "the scene must have tiles of more than 64 entries"
+    assert routes == {"two_pass", "fill"}
+    # (2) the rider, through the C-ABI, on synthetic stream lengths
+    tw, th = 21, 13   # 4 * 273 = 1092 quadrants: 4 rider blocks of 256 + a ragged fifth
+    T = tw * th
+    n_rec = torch.randint(0, 2000, (4, T), generator=g, dtype=torch.int32).to(dev)
+    n_rec[:, ::7] = 0
+    seg_split = torch.where(n_rec > 1200, (n_rec - 512 + 63) // 64, torch.zeros_like(n_rec)).to(torch.int32)
+    P = 64 * 48
+    f = lambda *sh: torch.rand(*sh, generator=g).to(dev)  # noqa: E731
+    render, alphas, extra, bg = f(P, 4), f(P), f(P, 3), f(3)
+    mx = torch.zeros(lib.fsgs_raster_quad_max_cells(), device=dev)
+    rgb, depth, normal = torch.empty(P, 3, device=dev), torch.empty(P, device=dev), torch.empty(P, 3, device=dev)
+    for shift in (4, 7):
+        counters = torch.zeros(32, dtype=torch.int32, device=dev)
+        order = torch.full((32, 4 * T), -1, dtype=torch.int32, device=dev)
+        assert lib.fsgs_epilogue_fwd_order(P, ptr(render), ptr(alphas), ptr(extra), ptr(bg), ptr(mx), mx.numel(), ptr(rgb),
+                                           ptr(depth), ptr(normal), None, None, None, 0.0, 0.0, None, None, None,
+                                           ptr(n_rec), ptr(seg_split), ptr(counters), ptr(order), shift, tw, th,
+                                           stream_ptr(dev)) == 0
+        own = (n_rec - 64 * seg_split).clamp(min=0).long()
+        want = torch.clamp(own >> shift, max=31)                       # [4, T]
+        assert torch.equal(counters.long(), torch.bincount(want.reshape(-1), minlength=32))
+        q = torch.arange(4, device=dev)[:, None].expand(4, T)
+        t = torch.arange(T, device=dev)[None, :].expand(4, T)
+        lin = (2 * (t // tw) + (q >> 1)) * (2 * tw) + 2 * (t % tw) + (q & 1)   # the backward's grid position
+        seen = torch.zeros(4 * T, dtype=torch.int32, device=dev)
+        for c in range(32):
+            ids = order[c, :int(counters[c])].long()
+            assert bool((ids >= 0).all())
+            seen[ids] += 1
+            assert torch.equal(torch.sort(ids).values, torch.sort(lin[want == c]).values), (shift, c)
+        assert bool((seen == 1).all())
+    # the epilogue's own outputs are those of the plain launch
+    rgb2, depth2, normal2 = torch.empty_like(rgb), torch.empty_like(depth), torch.empty_like(normal)
+    assert lib.fsgs_epilogue_fwd(P, ptr(render), ptr(alphas), ptr(extra), ptr(bg), None, -mx.numel(), ptr(mx), ptr(rgb2),
+                                 ptr(depth2), ptr(normal2), stream_ptr(dev)) == 0
+    assert torch.equal(rgb, rgb2) and torch.equal(depth, depth2) and torch.equal(normal, normal2)
