@@ -1053,6 +1053,11 @@ def main():
                               "margins_span_rel_tail": list(getattr(trainer, "zcut_margins", ()))},
             "max_step_ms": round(1e3 * max(b - a for a, b in zip([t0] + step_ends[:-1], step_ends)), 3),
             "slowest_step": max(range(len(step_ends)), key=lambda i: step_ends[i] - ([t0] + step_ends)[i]),
+            # host-side duration (ms) of the steps around the slowest one, and the view it rendered
+            "slowest_step_view": step_views[max(range(len(step_ends)), key=lambda i: step_ends[i] - ([t0] + step_ends)[i])],
+            "host_ms_around_slowest": (lambda d, i: [round(1e3 * x, 3) for x in d[max(i - 3, 0):i + 4]])(
+                [b - a for a, b in zip([t0] + step_ends[:-1], step_ends)],
+                max(range(len(step_ends)), key=lambda i: step_ends[i] - ([t0] + step_ends)[i])),
             "gpu_step_ms": gpu_step_stats(step_events, step_views) if with_events else None,
             "kernels_ms": kernel_ms,
             "roofline": roofline,
