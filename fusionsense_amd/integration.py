@@ -19,9 +19,10 @@ callbacks and its ``Optimizers`` (round 3):
     get_loss_dict      dn_model.py:673-925   -> ops._FusionLoss over a cached FrameBatch (one autograd node: every switch
                                                 reachable from scripts/train.py — incl. normals from depth — and
                                                 EdgeAwareTV, the cosine term, the L1 / LogL1 / MSE depth losses); the
-                                                HuberL1, the sparse-opacity term and the scale regularisation are
-                                                small torch terms on the node's outputs; the original stays as
-                                                ``_get_loss_dict_reference`` for the SDF term
+                                                HuberL1, the sparse-opacity term, the scale regularisation and the SDF
+                                                term (sdf.py) are small torch terms on the node's outputs; the original
+                                                stays as ``_get_loss_dict_reference`` for batches / shapes the node
+                                                does not take
     get_metrics_dict   dn_model.py:927-1003  -> the per-iteration PSNR / SSIM / depth metrics on the device, one transfer
     after_train        (nerfstudio, A.2)     -> nothing to do: the statistics were applied by the node's backward
     refinement_after   dn_model.py:326-451   -> DensifyStrategy.refinement_after (HIP row compaction, split sampling)
@@ -134,19 +135,21 @@ GAUSS_GROUPS = ("means", "scales", "quats", "features_dc", "features_rest", "opa
 
 def _loss_config(cfg):
     """(losses.LossConfig, extras) from the model's DNSplatterModelConfig, or None when a switch is set that neither the
-    fused loss node nor the torch terms on top of it evaluate (the caller then runs the reference's own get_loss_dict:
-    the SuGaR-style SDF term, :838-882, with its random surface samples).  ``extras`` names the terms that stay small
+    fused loss node nor the torch terms on top of it evaluate (the caller then runs the reference's own get_loss_dict).
+    ``extras`` names the terms that stay small
     torch expressions on the node's outputs (``_extra_terms``): "huber" — the HuberL1 depth loss, whose threshold is a
     maximum over the frame's valid pixels (losses.py:217-238); "sparse" — the entropy of the visible Gaussians'
-    opacities (:821-837); "scale_reg" — splatfacto's PhysGaussian scale regularisation."""
+    opacities (:821-837); "scale_reg" — splatfacto's PhysGaussian scale regularisation; "sdf" — the SuGaR-style SDF term
+    (:838-882) over random surface samples (fusionsense_amd/sdf.py; every apply_sdf_loss_iters-th step after
+    apply_sdf_loss_after_iters, on the neighbour table ``self._knn`` the reference's own recompute_knn callback keeps)."""
     from .losses import LossConfig
 
     def name_of(v):  # enum member / string -> lower-case name
         return str(getattr(v, "name", v)).lower()
     g = lambda k, d=None: getattr(cfg, k, d)  # noqa: E731
-    if g("use_sdf_loss", False):
-        return None
     extras = set()
+    if g("use_sdf_loss", False):
+        extras.add("sdf")  # (round 5: fusionsense_amd/sdf.py, pinned by tests/golden/reference_sdf.npz)
     if g("use_scale_regularization", False):
         extras.add("scale_reg")
     if g("use_sparse_loss", False):
@@ -214,6 +217,19 @@ def _extra_terms(self, outputs, batch, extras):
         if step % int(cfg.sparse_loss_steps) == 0 and step % period != 0 and not (1 <= step % period <= 100):
             o = torch.sigmoid(self.gauss_params["opacities"][self.vis_indices])
             term = float(cfg.sparse_lambda) * (-o * torch.log(o + 1e-10) - (1 - o) * torch.log(1 - o + 1e-10)).mean()
+            main = term if main is None else main + term
+    if "sdf" in extras:
+        from . import sdf
+        if sdf.sdf_term_due(cfg, int(self.step)):
+            P = self.gauss_params
+            cam = self.camera
+            c2w = cam.camera_to_worlds
+            c2w = (c2w.squeeze(0) if c2w.dim() == 3 else c2w).to(dev)
+            term = float(cfg.sdf_loss_lambda) * sdf.sdf_loss(
+                P["means"], P["scales"], P["quats"], P["opacities"], self._knn.to(dev), self.vis_indices,
+                getattr(self, "add_mask", None), outputs["depth"], c2w, float(cam.fx.item()), float(cam.cx.item()),
+                float(cam.cy.item()), int(cam.width.item()), int(cam.height.item()),
+                batch["mask"].to(dev) if "mask" in batch else None, int(cfg.num_sdf_samples))
             main = term if main is None else main + term
     scale_reg = None
     if "scale_reg" in extras and int(self.step) % 10 == 0:

@@ -257,8 +257,8 @@ def test_patched_get_loss_dict_matches_reference_goldens(dev, case):
     assert float(m.get_loss_dict({k: v.detach() for k, v in out.items()}, batch)["scale_reg"]) == 0.0
     m.config.use_scale_regularization = False
     # a switch neither the node nor the torch terms evaluate goes to the reference's own method (here: the stand-in
-    # that raises)
-    m.config.use_sdf_loss = True
+    # that raises) — since round 5 the SDF term is not one of them (test_patched_get_loss_dict_with_the_sdf_term)
+    m.config.depth_loss_type = "SomeOtherDepthLoss"
     with pytest.raises(AssertionError, match="reference get_loss_dict"):
         m.get_loss_dict(out, batch)
 
@@ -486,6 +486,64 @@ def test_patched_model_in_the_reference_loop_shape_trains_like_the_trainer(dev, 
         assert abs(float(a.double().abs().mean()) - float(b.double().abs().mean())) <= 2e-3 * float(b.double().abs().mean()) + 1e-6, k
     # the anchors never move, whatever happened around them
     assert torch.equal(m.gauss_params["means"].data[m.add_mask], tr.params["means"].data[st.add_mask])
+
+
+@pytest.mark.parametrize("case", ["plain", "masked"])
+def test_patched_get_loss_dict_with_the_sdf_term(dev, case, monkeypatch):
+    """``use_sdf_loss`` under patch_all (round 5: the last term of get_loss_dict that fell back to the reference's own
+    method): the patched get_loss_dict adds sdf_loss_lambda * sdf.sdf_loss on the steps that have it — the reference's
+    value and parameter gradients (reference_sdf.npz: the reference executed with the term off and on) when the sampler
+    is handed the reference's draws, nothing on other steps, and the un-patched method is never called."""
+    from fusionsense_amd import sdf
+    d = np.load(os.path.join(GOLD, "reference_sdf.npz"))
+    t = lambda k: torch.from_numpy(d[f"{case}.{k}"])  # noqa: E731
+    N = t("means").shape[0]
+    fx, cx, cy, W, H = (float(x) for x in d[f"{case}.intr"])
+    W, H = int(W), int(H)
+    params = {"means": t("means"), "scales": t("scales"), "quats": t("quats"), "opacities": t("opacities"),
+              "features_dc": torch.zeros(N, 3), "features_rest": torch.zeros(N, 15, 3)}
+    over = dict(use_sdf_loss=True, sdf_loss_lambda=float(d[f"{case}.cfg"][1]), num_sdf_samples=int(d[f"{case}.cfg"][0]),
+                apply_sdf_loss_after_iters=10, apply_sdf_loss_iters=5, knn_to_track=int(t("knn").shape[1]))
+    g = torch.Generator().manual_seed(4)
+    batch = {"image": torch.rand(H, W, 3, generator=g).to(dev), "sensor_depth": (0.5 + torch.rand(H, W, 1, generator=g)).to(dev),
+             "normal": torch.rand(H, W, 3, generator=g).to(dev), "image_idx": 2}
+    if bool(d[f"{case}.has_mask"]):
+        batch["mask"] = t("mask").to(dev)
+    t1 = lambda v: torch.tensor([[float(v)]])  # noqa: E731
+    cam = types.SimpleNamespace(camera_to_worlds=t("c2w")[None].to(dev), fx=t1(fx), fy=t1(fx * 1.1), cx=t1(cx), cy=t1(cy),
+                                width=torch.tensor([[W]]), height=torch.tensor([[H]]))
+    draws = (t("picks").to(dev), t("centered").to(dev))
+    real = sdf.sample_points_in_gaussians
+    monkeypatch.setattr(sdf, "sample_points_in_gaussians",
+                        lambda means, scales, quats, n, vis=None, dr=None, gen=None: real(means, scales, quats, n, vis, draws, gen))
+    res = {}
+    for step in (15, 16):  # 15: the term is due; 16: it is not
+        m, _ = _model(dev, params, step=step, **over)
+        m._knn = t("knn").to(dev)
+        m.vis_indices = t("vis_indices").to(dev)
+        m.add_mask = t("add_mask").to(dev) if bool(d[f"{case}.has_anchors"]) else None
+        if m.add_mask is not None:
+            n_t = int(m.add_mask.sum())
+            m.kwargs = {"metadata": {"touch_patches": [{"normals": torch.nn.functional.normalize(torch.rand(n_t, 3), dim=-1)}]}}
+        m.camera = cam
+        out = {"rgb": torch.rand(H, W, 3, generator=g).to(dev).requires_grad_(True), "depth": t("depth").to(dev).requires_grad_(True),
+               "normal": torch.rand(H, W, 3, generator=g).to(dev).requires_grad_(True)}
+        ld = m.get_loss_dict(out, batch)
+        (ld["main_loss"] + ld["scale_reg"]).backward()
+        res[step] = (float(ld["main_loss"]), {k: (m.gauss_params[k].grad.clone() if m.gauss_params[k].grad is not None
+                                                   else torch.zeros_like(m.gauss_params[k])) for k in ("means", "quats", "opacities")})
+    # the step without the term: no gradient reaches means / quats / opacities from the loss at all
+    for k in ("means", "quats", "opacities"):
+        assert float(res[16][1][k].abs().max()) == 0.0, k
+        r = t("v_" + k).to(dev)
+        assert float((res[15][1][k] - r).abs().max()) < 5e-5 * max(1.0, float(r.abs().max())), k
+    # (the rgb / normal images differ between the two calls — fresh random renders —, so the VALUE is checked directly)
+    P = {k: t(k).to(dev) for k in ("means", "scales", "quats", "opacities")}
+    val = float(d[f"{case}.cfg"][1]) * float(sdf.sdf_loss(
+        P["means"], P["scales"], P["quats"], P["opacities"], t("knn").to(dev), t("vis_indices").to(dev),
+        t("add_mask").to(dev) if bool(d[f"{case}.has_anchors"]) else None, t("depth").to(dev), t("c2w").to(dev), fx, cx, cy, W, H,
+        batch.get("mask"), int(d[f"{case}.cfg"][0])))
+    assert abs(val - float(d[f"{case}.term"])) < 5e-5 * max(1.0, abs(float(d[f"{case}.term"])))
 
 
 def test_patched_get_metrics_dict(dev):

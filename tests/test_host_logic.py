@@ -1237,3 +1237,43 @@ def test_knn_drop_first_is_sklearn_minus_its_first_column():
     x, y = torch.randn(500, 3, generator=g), torch.randn(77, 3, generator=g)
     ref = NearestNeighbors(n_neighbors=6, algorithm="auto", metric="euclidean").fit(x.numpy()).kneighbors(y.numpy())[1][:, 1:]
     assert np.array_equal(knn_drop_first(x, y, 5).numpy(), ref)
+
+
+@pytest.mark.parametrize("name", ["plain", "masked"])
+def test_sdf_term_matches_reference_execution(name):
+    """fusionsense_amd/sdf.py against tests/golden/reference_sdf.npz: the reference's own get_loss_dict executed with the
+    SDF term off and on (the stored term and gradients are the difference), on the reference's own random draws."""
+    import os
+    import numpy as np
+    from fusionsense_amd import sdf
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_sdf.npz"))
+    t = lambda k: torch.from_numpy(d[f"{name}.{k}"])  # noqa: E731
+    P = {k: t(k).clone().requires_grad_(True) for k in ("means", "scales", "quats", "opacities")}
+    fx, cx, cy, W, H = [float(x) for x in d[f"{name}.intr"]]
+    n_samples, lam = int(d[f"{name}.cfg"][0]), float(d[f"{name}.cfg"][1])
+    add_mask = t("add_mask") if bool(d[f"{name}.has_anchors"]) else None
+    mask = t("mask") if bool(d[f"{name}.has_mask"]) else None
+    term = lam * sdf.sdf_loss(P["means"], P["scales"], P["quats"], P["opacities"], t("knn"), t("vis_indices"), add_mask,
+                              t("depth"), t("c2w"), fx, cx, cy, int(W), int(H), mask, n_samples,
+                              draws=(t("picks"), t("centered")))
+    term.backward()
+    ref = float(d[f"{name}.term"])
+    assert abs(float(term) - ref) < 2e-5 * max(1.0, abs(ref)), (float(term), ref)
+    for k in P:
+        g, r = P[k].grad, t("v_" + k)
+        assert float((g - r).abs().max()) < 2e-5 * max(1.0, float(r.abs().max())), (k, float((g - r).abs().max()))
+    assert float(t("v_means").abs().max()) > 0 and float(t("v_opacities").abs().max()) > 0
+    # without handed-in draws the term samples for itself (a seeded generator: reproducible), and fewer Gaussians than
+    # num_sdf_samples is the reference's own IndexError (its weight indexes the Gaussians with the samples' mask)
+    g1 = torch.Generator().manual_seed(3)
+    a = sdf.sdf_loss(P["means"].detach(), P["scales"].detach(), P["quats"].detach(), P["opacities"].detach(), t("knn"),
+                     t("vis_indices"), add_mask, t("depth"), t("c2w"), fx, cx, cy, int(W), int(H), mask, n_samples, generator=g1)
+    g2 = torch.Generator().manual_seed(3)
+    b = sdf.sdf_loss(P["means"].detach(), P["scales"].detach(), P["quats"].detach(), P["opacities"].detach(), t("knn"),
+                     t("vis_indices"), add_mask, t("depth"), t("c2w"), fx, cx, cy, int(W), int(H), mask, n_samples, generator=g2)
+    assert float(a) == float(b) and math.isfinite(float(a))
+    with pytest.raises(IndexError):
+        sdf.sdf_loss(P["means"].detach(), P["scales"].detach(), P["quats"].detach(), P["opacities"].detach(), t("knn"),
+                     t("vis_indices"), add_mask, t("depth"), t("c2w"), fx, cx, cy, int(W), int(H), mask, 10_000)
+    cfg = type("C", (), dict(use_sdf_loss=True, apply_sdf_loss_after_iters=2000, apply_sdf_loss_iters=100))
+    assert sdf.sdf_term_due(cfg, 2100) and not sdf.sdf_term_due(cfg, 2000) and not sdf.sdf_term_due(cfg, 2150)
