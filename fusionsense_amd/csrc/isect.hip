@@ -13,6 +13,13 @@
 
 // A/B build switch (make EXTRA=-DFSGS_ISECT_PER_THREAD=1): one thread per Gaussian in the drop-in path's live count / emit
 // passes instead of the flattened pair enumeration.  The library reads no environment variable.
+// count-free route: threads per Gaussian of a workgroup, by the workgroup's Gaussians (bin_threads)
+#ifndef FSGS_FILL_MULT_256
+#define FSGS_FILL_MULT_256 4
+#endif
+#ifndef FSGS_FILL_MULT_512
+#define FSGS_FILL_MULT_512 1
+#endif
 #ifndef FSGS_ISECT_PER_THREAD
 #define FSGS_ISECT_PER_THREAD 0
 #endif
@@ -399,9 +406,14 @@ isect_live_bin_body(const int block, int C, int N, const float *__restrict__ mea
                     const float *__restrict__ opacities, int tw, int th, int T, int nb, int chunks,
                     int32_t *__restrict__ tiles_per_gauss, int32_t *__restrict__ table,
                     const int32_t *__restrict__ offsets, uint64_t *__restrict__ buckets, const BinProjArgs &pj,
-                    int bucket_cap) {
+                    int bucket_cap, int gpw = 0) {
     extern __shared__ __attribute__((aligned(16))) unsigned char bin_smem[];
     constexpr int kBinThreads = BT, kBinWaves = BT / 64;
+    // gpw (count-free route, small models): Gaussians per workgroup when that is FEWER than its threads — the first gpw
+    // threads project one Gaussian each, ALL threads share the flattened pairs.  A model of 70 k Gaussians with 23
+    // rectangle pairs each (config #3) gave 274 workgroups of 256 threads one wave per SIMD for ~3 500 dependent
+    // instructions per thread; halving the Gaussians per workgroup instead would double the (workgroup, tile) claims.
+    const int gauss_per_wg = gpw > 0 ? gpw : kBinThreads;
     BinLds<BT> &L = *reinterpret_cast<BinLds<BT> *>(bin_smem);
     int *slots = reinterpret_cast<int *>(bin_smem + sizeof(BinLds<BT>));
     const int64_t total = (int64_t)C * N;
@@ -432,8 +444,9 @@ isect_live_bin_body(const int block, int C, int N, const float *__restrict__ mea
         __syncthreads();
     }
     for (int ch = 0; ch < n_chunks; ++ch) {
-    const int64_t idx0 = ((int64_t)block * n_chunks + ch) * kBinThreads;  // the chunk's first Gaussian
-    const int64_t idx = idx0 + tid;
+    const int64_t idx0 = ((int64_t)block * n_chunks + ch) * gauss_per_wg;  // the chunk's first Gaussian
+    // (a thread beyond the workgroup's Gaussians projects nothing: idx = total makes every "idx < total" below false)
+    const int64_t idx = tid < gauss_per_wg ? idx0 + tid : total;
     if (idx0 >= total) break;
     if (ch) __syncthreads();  // the previous chunk's constants are no longer read
     int cnt = 0;
@@ -683,10 +696,10 @@ isect_live_bin_kernel(int C, int N, const float *__restrict__ means2d, const int
 template <bool HALF, int BT>
 __global__ void __launch_bounds__(BT)
 isect_live_bin_fill_kernel(int N, int tw, int th, int T, int nb, int32_t *__restrict__ tiles_per_gauss,
-                           uint64_t *__restrict__ buckets, BinProjArgs pj, int bucket_cap) {
+                           uint64_t *__restrict__ buckets, BinProjArgs pj, int bucket_cap, int gpw) {
     isect_live_bin_body<false, false, true, HALF, BT, true>(blockIdx.x, 1, N, nullptr, nullptr, nullptr, nullptr, nullptr, tw,
                                                             th, T, nb, 1, tiles_per_gauss, nullptr, nullptr, buckets, pj,
-                                                            bucket_cap);
+                                                            bucket_cap, gpw);
 }
 
 #ifndef FSGS_RIDE_ADAM_UNROLL
@@ -1285,19 +1298,23 @@ extern "C" int fsgs_project_bin_live_fill_sh_pack(
     const int64_t total = N;
     if (bin_chunks(total) != 1) return FSGS_EINVAL;
     hipStream_t s = as_stream(stream);
-    const int nb = (int)bin_blocks(total);
+    // (more threads than Gaussians in a workgroup — see isect_live_bin_body)
+    const int gpw = bin_threads(total);
+    const int bt = gpw * (gpw == 256 ? FSGS_FILL_MULT_256 : (gpw == 512 ? FSGS_FILL_MULT_512 : 1));
+    const int nb = (int)((total + gpw - 1) / gpw);
     BinProjArgs pj = {means, quats, log_scales, viewmat, K, opac_logit, scales_out, opac_out, means2d, depths,
                       conics, radii, width, height, binarise, eps2d, near_plane, far_plane, radius_clip,
                       binary_threshold, nullptr, 0, nullptr, 0, 0, 0, nullptr, nullptr, bucket_base, tile_cursor};
-    const size_t need = bin_lds_bytes(T, total);
+    const size_t need = (bt == 1024 ? sizeof(BinLds<1024>) : (bt == 512 ? sizeof(BinLds<512>) : sizeof(BinLds<256>))) +
+                        (size_t)T * sizeof(int);
     uint64_t *bk = reinterpret_cast<uint64_t *>(buckets);
 #define FSGS_BIN_FILL(BT)                                                                                              \
     do {                                                                                                               \
         if (const int rc = ensure_dynamic_lds<&isect_live_bin_fill_kernel<false, BT>>(need)) return rc;                \
         hipLaunchKernelGGL((isect_live_bin_fill_kernel<false, BT>), dim3(nb), dim3(BT), need, s, N, tile_width,         \
-                           tile_height, T, nb, tiles_per_gauss, bk, pj, (int)bucket_words);                             \
+                           tile_height, T, nb, tiles_per_gauss, bk, pj, (int)bucket_words, gpw);                        \
     } while (0)
-    switch (bin_threads(total)) {
+    switch (bt) {
     case 1024: FSGS_BIN_FILL(1024); break;
     case 512: FSGS_BIN_FILL(512); break;
     default: FSGS_BIN_FILL(256); break;
