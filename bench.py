@@ -34,6 +34,16 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# The HIP runtime forces a host wait every DEBUG_CLR_MAX_BATCH_SIZE (1000) commands enqueued without a synchronisation
+# in between — here every ~77 steps of 13 commands.  Normally that costs 0.1 ms; in ~1 run of 15 the wait went to sleep
+# for 5 + 15 ms on the GPU boxes of this pool (always at timed step 77-78, whatever view was there; 8 of 119 default runs
+# against 0 of 50 with the limit raised — DESIGN.md §7).  A training loop synchronises long before 16384 commands
+# (its refinement callbacks read mask counts every 100 steps), so the limit is moved out of the way, before the runtime
+# loads; an explicit setting of the caller's wins.
+RUNTIME_ENV = {"DEBUG_CLR_MAX_BATCH_SIZE": "16384"}
+for _k, _v in RUNTIME_ENV.items():
+    RUNTIME_ENV[_k] = os.environ.setdefault(_k, _v)
+
 import torch
 import torch.distributed as dist
 
@@ -664,6 +674,23 @@ def main():
     with_events = not os.environ.get("FSGS_BENCH_NO_STEP_EVENTS")
     if with_events:
         step_events[0].record()
+    stall_calls = []
+    if os.environ.get("FSGS_BENCH_STALL_TRACE"):
+        # diagnostic: which C-ABI call (a launch: it should return in microseconds) blocks the host for over 1 ms
+        from fusionsense_amd import _lib as _L
+        lib_ = _L.load()
+
+        def timed_entry(name, fn):
+            def call(*a):
+                t_ = time.perf_counter()
+                r_ = fn(*a)
+                dt = time.perf_counter() - t_
+                if dt > 1e-3:
+                    stall_calls.append((len(step_ends), name, round(dt * 1e3, 2)))
+                return r_
+            return call
+        for name in _L.SIGNATURES:
+            setattr(lib_, name, timed_entry(name, getattr(lib_, name)))
     for s in range(args.steps):
         v = view_of(args.warmup + s)
         trainer.train_step(cams[v], targets[v])
@@ -671,6 +698,8 @@ def main():
             step_events[s + 1].record()
         step_views.append(v)
         step_ends.append(time.perf_counter())
+    if stall_calls:
+        log("C-ABI calls over 1 ms: " + json.dumps(stall_calls))
     trainer.flush()  # (data-parallel runs: the last step's deferred feature update belongs to the timed work)
     torch.cuda.synchronize()
     own_elapsed = time.perf_counter() - t0  # (this rank's own clock, before it waits for the others)
@@ -1025,6 +1054,7 @@ def main():
             "iter_hbm_frac": round(b_iter / (elapsed / args.steps) / (HBM_PEAK_GBS * 1e9), 5),
             "iter_algorithmic_bytes_rect_pairs": b_iter_rect,
             "device_mallocs_in_timed_region": n_alloc,
+            "runtime_env": dict(RUNTIME_ENV),
             "live_list_overflows": int(getattr(trainer, "live_overflows", 0)),  # frames redone (no-wait binning)
             # frames by binning route over the whole run: "fill" = the count-free route (one enumeration of the pairs into
             # buckets sized from the view's previous frame), "two_pass" = count + fill (first visits, after densification,
