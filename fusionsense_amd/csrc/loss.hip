@@ -60,6 +60,26 @@ __host__ inline unsigned loss_grid_blocks(int H, int W, int extra) {
     return 8u * (unsigned)((total + 7) >> 3);
 }
 
+// One pixel's SSIM value and its derivatives by mu1, sigma1^2, sigma12 from the five blurred moments (mu1, mu2, E[pp], E[gg],
+// E[pg]).  No contraction: what the optimiser fuses depends on the code around the call, and the two instantiations of the
+// forward kernel (and the short way of its all-masked tiles) must give the same bits on the same moments.
+__device__ __forceinline__ void ssim_point(const float (&mom)[5], float &ssim, float &d_mu1, float &d_s1, float &d_s12) {
+#pragma clang fp contract(off)
+    const float mu1 = mom[0], mu2 = mom[1], e11 = mom[2], e22 = mom[3], e12 = mom[4];
+    const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+    const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
+    const float s1 = e11 - mu1_sq, s2 = e22 - mu2_sq, s12 = e12 - mu12;
+    const float A = mu1_sq + mu2_sq + C1, B = s1 + s2 + C2;
+    const float C = 2.f * mu12 + C1, D = 2.f * s12 + C2;
+    // (two reciprocals instead of eight IEEE divisions: 1 ulp each, far inside the parity tolerance)
+    const float rA = __builtin_amdgcn_rcpf(A), rB = __builtin_amdgcn_rcpf(B);
+    const float X = rA * rB, CDX = C * D * X;
+    ssim = CDX;
+    d_mu1 = 2.f * (mu2 * (D - C) * X + mu1 * CDX * (rB - rA));
+    d_s1 = -CDX * rB;
+    d_s12 = 2.f * C * X;
+}
+
 // partials[2*blk] = sum |pred-gt| of this (tile, channel), partials[2*blk+1] = sum of its interior SSIM values
 template <bool MASKED>
 __global__ void __launch_bounds__(256)
@@ -80,6 +100,28 @@ ssim_l1_fwd_kernel(int H, int W, const float *__restrict__ pred, const float *__
     if (!loss_tile_of_block(gx, gy, 0, ch, tx, ty)) return;
     const int x0 = tx * kLT, y0 = ty * kLT;
     const int tr = threadIdx.x;
+    // mask (FusionSense object mask, nullable): both images are multiplied by it first (splatfacto get_loss_dict, called
+    // at /root/reference/dn_splatter/dn_model.py:683).  An object mask leaves most of a frame at zero: a tile whose
+    // whole halo is masked out has all-zero inputs — it skips the image loads and both blur passes and runs the
+    // per-pixel tail on zero moments (the same instructions on the same values: the same bits as the long way).
+    float hm[MASKED ? kHaloIters : 1];
+    bool live = true;
+    if (MASKED) {
+        bool any = false;
+#pragma unroll
+        for (int it = 0; it < kHaloIters; ++it) {
+            const int i = tr + it * 256;
+            const int ly = i / kLH, lx = i - ly * kLH;
+            const int y = y0 + ly - kLR, x = x0 + lx - kLR;
+            hm[it] = 0.f;
+            if (i < kLH * kLH && y >= 0 && y < H && x >= 0 && x < W) hm[it] = mask[(int64_t)y * W + x];
+            any |= hm[it] != 0.f;
+        }
+        live = __syncthreads_or(any);
+    }
+    const int lx = tr & 31, ry = (tr >> 5) * 4;
+    float own_d[4], mom[4][5];
+    if (live) {
     // the halo: every load of this thread is issued before the first LDS write (written as one loop the
     // compiler waits for each element in turn: serialised HBM round trips)
     float hp[kHaloIters], hg[kHaloIters];
@@ -90,10 +132,8 @@ ssim_l1_fwd_kernel(int H, int W, const float *__restrict__ pred, const float *__
         const int y = y0 + ly - kLR, x = x0 + lx - kLR;
         hp[it] = 0.f; hg[it] = 0.f;
         if (i < kLH * kLH && y >= 0 && y < H && x >= 0 && x < W) {
-            // mask (FusionSense object mask, nullable): both images are multiplied by it first
-            // (splatfacto get_loss_dict, called at /root/reference/dn_splatter/dn_model.py:683)
             if (MASKED) {
-                const float m = mask[(int64_t)y * W + x];
+                const float m = hm[it];
                 hp[it] = pred[((int64_t)y * W + x) * 3 + ch] * m;
                 hg[it] = gt[((int64_t)y * W + x) * 3 + ch] * m;
             } else {
@@ -141,8 +181,6 @@ ssim_l1_fwd_kernel(int H, int W, const float *__restrict__ pred, const float *__
         }
     }
     // column pass: thread = (column lx, group of 4 rows); its own four pixels for the L1 term
-    const int lx = tr & 31, ry = (tr >> 5) * 4;
-    float own_d[4];
 #pragma unroll
     for (int o = 0; o < 4; ++o) own_d[o] = fabsf(sp[ry + o + kLR][lx + kLR] - sg[ry + o + kLR][lx + kLR]);
     __syncthreads();  // every input read: the arena now takes the row-blurred maps
@@ -158,7 +196,6 @@ ssim_l1_fwd_kernel(int H, int W, const float *__restrict__ pred, const float *__
         }
     }
     __syncthreads();
-    float mom[4][5];
 #pragma unroll
     for (int o = 0; o < 4; ++o)
 #pragma unroll
@@ -178,6 +215,18 @@ ssim_l1_fwd_kernel(int H, int W, const float *__restrict__ pred, const float *__
             }
         }
     }
+    } else {
+        // (a zero the optimiser cannot see through: the tail below must stay the code that runs on the device for
+        // every tile, not a constant folded at compile time with another rounding of the reciprocals)
+        float z = 0.f;
+        asm volatile("" : "+v"(z));
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            own_d[o] = z;
+#pragma unroll
+            for (int m = 0; m < 5; ++m) mom[o][m] = z;
+        }
+    }
     const int x = x0 + lx;
     float l1 = 0.f, ssim = 0.f;
 #pragma unroll
@@ -188,19 +237,9 @@ ssim_l1_fwd_kernel(int H, int W, const float *__restrict__ pred, const float *__
         float d_mu1 = 0.f, d_s1 = 0.f, d_s12 = 0.f;
         if (in_img) l1 += own_d[o];
         if (interior) {
-            const float mu1 = mom[o][0], mu2 = mom[o][1], e11 = mom[o][2], e22 = mom[o][3], e12 = mom[o][4];
-            const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
-            const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
-            const float s1 = e11 - mu1_sq, s2 = e22 - mu2_sq, s12 = e12 - mu12;
-            const float A = mu1_sq + mu2_sq + C1, B = s1 + s2 + C2;
-            const float C = 2.f * mu12 + C1, D = 2.f * s12 + C2;
-            // (two reciprocals instead of eight IEEE divisions: 1 ulp each, far inside the parity tolerance)
-            const float rA = __builtin_amdgcn_rcpf(A), rB = __builtin_amdgcn_rcpf(B);
-            const float X = rA * rB, CDX = C * D * X;
-            ssim += CDX;
-            d_mu1 = 2.f * (mu2 * (D - C) * X + mu1 * CDX * (rB - rA));
-            d_s1 = -CDX * rB;
-            d_s12 = 2.f * C * X;
+            float v;
+            ssim_point(mom[o], v, d_mu1, d_s1, d_s12);
+            ssim += v;
         }
         if (in_img) {
             const int64_t oo = ((int64_t)ch * H + y) * W + x;  // planar [3,H,W]: coalesced rows
@@ -277,6 +316,29 @@ ssim_l1_bwd_kernel(int H, int W, const float *__restrict__ pred, const float *__
     }
     const int x0 = tx * kLT, y0 = ty * kLT;
     const int tr = threadIdx.x;
+    // this thread's own four pixels
+    const int lx = tr & 31, ry = (tr >> 5) * 4;
+    const int x = x0 + lx;
+    float own_m[4];
+    if (MASKED) {
+        // a tile whose own pixels are all masked out has v_pred = mask * (...) = 0: written without reading anything else
+        bool any = false;
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            const int y = y0 + ry + o;
+            own_m[o] = mask[(int64_t)min(y, H - 1) * W + min(x, W - 1)];
+            any |= own_m[o] != 0.f;
+        }
+        if (!__syncthreads_or(any)) {
+            if (x < W)
+#pragma unroll
+                for (int o = 0; o < 4; ++o) {
+                    const int y = y0 + ry + o;
+                    if (y < H) v_pred[((int64_t)y * W + x) * 3 + ch] = 0.f;
+                }
+            return;
+        }
+    }
     float ha[kHaloIters], hbv[kHaloIters], hc[kHaloIters];  // (all loads first, as in the forward)
 #pragma unroll
     for (int it = 0; it < kHaloIters; ++it) {
@@ -289,15 +351,13 @@ ssim_l1_bwd_kernel(int H, int W, const float *__restrict__ pred, const float *__
             ha[it] = dm_dmu1[o]; hbv[it] = dm_dsigma1[o]; hc[it] = dm_dsigma12[o];
         }
     }
-    // this thread's own four pixels and the upstream scalar, in flight with the halo
-    const int lx = tr & 31, ry = (tr >> 5) * 4;
-    const int x = x0 + lx;
-    float own_p[4], own_g[4], own_m[4];
+    // the images at its own pixels and the upstream scalar, in flight with the halo
+    float own_p[4], own_g[4];
 #pragma unroll
     for (int o = 0; o < 4; ++o) {
         const int y = y0 + ry + o;
         const int64_t op = (int64_t)min(y, H - 1) * W + min(x, W - 1);
-        own_m[o] = MASKED ? mask[op] : 1.f;
+        if (!MASKED) own_m[o] = 1.f;
         own_p[o] = MASKED ? pred[op * 3 + ch] * own_m[o] : pred[op * 3 + ch];
         own_g[o] = MASKED ? gt[op * 3 + ch] * own_m[o] : gt[op * 3 + ch];
     }

@@ -363,6 +363,71 @@ def test_fused_ssim_l1_loss(dev, H, W):
     assert rel_err(p_g.grad / 3.0, p_ref.grad) < 1e-3
 
 
+@pytest.mark.parametrize("mask_kind", ["ellipse", "all_zero", "one_pixel", "all_one"])
+def test_masked_ssim_zero_tiles_take_the_short_way_to_the_same_bits(dev, mask_kind):
+    """fsgs_ssim_l1_fwd_masked / _bwd_masked skip the image loads and the blur passes of tiles whose mask is all zero
+    (forward: over the tile's halo; backward: over its own pixels).  The results must be those of the UNMASKED kernels on
+    images multiplied by the mask beforehand — partial sums, the three derivative maps and mask * v_pred, bit for bit —
+    whatever falls on a tile border (a single live pixel in a corner reaches four tiles through their halos)."""
+    from fusionsense_amd._lib import load, ptr, stream_ptr
+    lib = load()
+    H, W = 150, 210  # 5 x 7 tiles of 32, ragged last row / column
+    g = torch.Generator().manual_seed(31)
+    pred, gt = torch.rand(H, W, 3, generator=g).to(dev), torch.rand(H, W, 3, generator=g).to(dev)
+    yy, xx = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
+    if mask_kind == "ellipse":
+        mask = (((xx - 80) / 60.0) ** 2 + ((yy - 70) / 45.0) ** 2 < 1.0).float()
+    elif mask_kind == "all_zero":
+        mask = torch.zeros(H, W)
+    elif mask_kind == "all_one":
+        mask = torch.ones(H, W)
+    else:
+        mask = torch.zeros(H, W)
+        mask[64, 96] = 1.0  # the first pixel of tile (2, 3): inside the halos of (1, 2), (1, 3), (2, 2) too
+    mask = mask.to(dev).contiguous()
+    sp = stream_ptr(dev)
+    n_blk = 3 * ((H + 31) // 32) * ((W + 31) // 32)
+    v_loss = torch.tensor([0.7], device=dev)
+
+    def run(p_, g_, m_):
+        maps = [torch.full((3, H, W), float("nan"), device=dev) for _ in range(3)]
+        sums = torch.full((n_blk, 2), float("nan"), device=dev)
+        assert lib.fsgs_ssim_l1_fwd_masked(H, W, ptr(p_), ptr(g_), ptr(m_), ptr(maps[0]), ptr(maps[1]), ptr(maps[2]),
+                                           ptr(sums), sp) == 0
+        v = torch.full((H, W, 3), float("nan"), device=dev)
+        assert lib.fsgs_ssim_l1_bwd_masked(H, W, ptr(p_), ptr(g_), ptr(m_), ptr(maps[0]), ptr(maps[1]), ptr(maps[2]),
+                                           ptr(v_loss), 0.8 / (H * W * 3), -0.2 / ((H - 10) * (W - 10) * 3), ptr(v), 0,
+                                           None, None, None, None, 0.0, None, sp) == 0
+        torch.cuda.synchronize()
+        return maps, sums, v
+    maps_m, sums_m, v_m = run(pred, gt, mask)
+    maps_u, sums_u, v_u = run((pred * mask[..., None]).contiguous(), (gt * mask[..., None]).contiguous(), None)
+    assert torch.equal(sums_m, sums_u)
+    for a, b in zip(maps_m, maps_u):
+        assert torch.equal(a, b)
+    assert torch.isfinite(v_m).all()
+    assert torch.equal(v_m, v_u * mask[..., None])
+    if mask_kind == "all_zero":
+        assert float(v_m.abs().max()) == 0.0 and float(sums_m[:, 0].abs().max()) == 0.0
+    # ... and the short way against the LONG way of the same instantiation: all-zero images under an all-one mask (every
+    # tile live, every moment zero) must leave in every masked-out tile what the masked run left there
+    zeros = torch.zeros(H, W, 3, device=dev)
+    maps_z, sums_z, _ = run(zeros, zeros, torch.ones(H, W, device=dev))
+    gy, gx = (H + 31) // 32, (W + 31) // 32
+    n_short = 0
+    for ty in range(gy):
+        for tx in range(gx):
+            if bool(mask[max(0, ty * 32 - 5):ty * 32 + 37, max(0, tx * 32 - 5):tx * 32 + 37].any()):
+                continue
+            n_short += 1
+            for ch in range(3):
+                blk = (ch * gy + ty) * gx + tx
+                assert torch.equal(sums_m[blk], sums_z[blk])
+            for a, b in zip(maps_m, maps_z):
+                assert torch.equal(a[:, ty * 32:ty * 32 + 32, tx * 32:tx * 32 + 32], b[:, ty * 32:ty * 32 + 32, tx * 32:tx * 32 + 32])
+    assert n_short == {"ellipse": 17, "all_zero": gy * gx, "one_pixel": gy * gx - 4, "all_one": 0}[mask_kind]
+
+
 def test_fusion_aux_riders_equal_the_stand_alone_launches(dev):
     """fsgs_fusion_aux_loss_riders: the min-scale and touch-normal partial sums computed by extra workgroups of the aux
     launch are those of fsgs_min_scale_loss / fsgs_touch_normal_sqerr, and the aux partials are untouched by the riders

@@ -19,7 +19,8 @@ for a, b in zip(marks[:-1], marks[1:]):
     if dt < cap:
         steps.append((dt, a, b))
 print("steps", len(steps), "median ms", sorted(s[0] for s in steps)[len(steps) // 2])
-for dt, a, b in sorted(steps, reverse=True)[:n]:
+ranked = sorted(steps, reverse=True)
+for dt, a, b in ranked[:n] + [ranked[len(ranked) // 2]]:  # ... and the median step
     print(f"--- step of {dt:.3f} ms, backward #{marks.index(a)} of {len(marks)}")
     t0, end = rows[a][0], rows[a][0]
     for s, e, name in rows[a:b + 1]:
