@@ -13,7 +13,9 @@
 
 // A/B build switch (make EXTRA=-DFSGS_ISECT_PER_THREAD=1): one thread per Gaussian in the drop-in path's live count / emit
 // passes instead of the flattened pair enumeration.  The library reads no environment variable.
-// count-free route: threads per Gaussian of a workgroup, by the workgroup's Gaussians (bin_threads)
+// count-free route: threads per Gaussian of a workgroup, by the workgroup's Gaussians (bin_threads).  Config #3 (256):
+// x2 0.527, x4 0.525 ms per step against 0.538; config #2 (512): x2 0.501 against 0.496 (586 workgroups of 1024 threads
+// are not all resident).
 #ifndef FSGS_FILL_MULT_256
 #define FSGS_FILL_MULT_256 4
 #endif
@@ -411,8 +413,9 @@ isect_live_bin_body(const int block, int C, int N, const float *__restrict__ mea
     constexpr int kBinThreads = BT, kBinWaves = BT / 64;
     // gpw (count-free route, small models): Gaussians per workgroup when that is FEWER than its threads — the first gpw
     // threads project one Gaussian each, ALL threads share the flattened pairs.  A model of 70 k Gaussians with 23
-    // rectangle pairs each (config #3) gave 274 workgroups of 256 threads one wave per SIMD for ~3 500 dependent
-    // instructions per thread; halving the Gaussians per workgroup instead would double the (workgroup, tile) claims.
+    // rectangle pairs each (config #3) is 274 workgroups of 256 Gaussians: with 256 threads the chip held one wave per
+    // SIMD and the two pair walks were 16 of the pass's 40 us; with 1024 threads the pass takes 23 us.  Fewer Gaussians
+    // per workgroup would have doubled the (workgroup, tile) claims instead.  Measured: DESIGN.md section 5.1.
     const int gauss_per_wg = gpw > 0 ? gpw : kBinThreads;
     BinLds<BT> &L = *reinterpret_cast<BinLds<BT> *>(bin_smem);
     int *slots = reinterpret_cast<int *>(bin_smem + sizeof(BinLds<BT>));
