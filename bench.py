@@ -648,10 +648,10 @@ def main():
             if strategy.stats_only or (name == "maybe_refine" and trainer.step % strategy.cfg.refine_every != 0) or \
                     (name == "before_train" and trainer.step != strategy.add_touch_at):
                 return fn(*a, **k)
-            torch.cuda.synchronize()
+            # (no synchronisation added around the call: the window is timed as a trainer would run it; a callback's
+            # own waits — its mask counts — are inside the figure, launches it leaves queued are not)
             t_ = time.perf_counter()
             r_ = fn(*a, **k)
-            torch.cuda.synchronize()
             cb_ms[name].append(round((time.perf_counter() - t_) * 1e3, 2))
             return r_
         return wrapper
