@@ -34,14 +34,16 @@ class _KernelTimer:
         self.records = []
         self.only = None
         self.pool = []
+        self.every, self.seen = 1, 0
 
-    def reset(self, enabled: bool = False, only=None, prealloc: int = 0) -> None:
+    def reset(self, enabled: bool = False, only=None, prealloc: int = 0, every: int = 1) -> None:
         """only: optional tuple of name prefixes; other launches are not timed (creating and recording two
         events per launch costs ~10 us of host time, i.e. a GPU bubble in front of the launch).  prealloc:
         number of spans whose events are created AND instantiated now, outside the region being timed."""
         self.enabled = enabled
         self.records = []
         self.only = tuple(only) if only else None
+        self.every, self.seen = max(1, int(every)), 0  # (every: time each k-th of the selected launches only)
         self.pool = []
         for _ in range(2 * prealloc):
             e = torch.cuda.Event(enable_timing=True)
@@ -57,6 +59,9 @@ class _KernelTimer:
 
         def __enter__(self):
             self.on = self.timer.enabled and (self.timer.only is None or self.name.startswith(self.timer.only))
+            if self.on and self.timer.every > 1:
+                self.timer.seen += 1
+                self.on = (self.timer.seen - 1) % self.timer.every == 0
             if self.on:
                 self.start = self.timer._event()
                 self.end = self.timer._event()
@@ -95,7 +100,8 @@ TIMER = _KernelTimer()
 
 def _run(fn, args, what: str, tag: str = "") -> None:
     """Call one C-ABI entry point, time it if the timer is on, raise on a non-zero code."""
-    if not TIMER.enabled:  # (the common case: no span object, no context manager)
+    # (the common case — timer off, or on for other launches than this one: no span object, no context manager)
+    if not TIMER.enabled or (TIMER.only is not None and not what.startswith(TIMER.only, 5)):
         rc = fn(*args)
         if rc != 0:
             check(rc, what)
