@@ -1277,3 +1277,54 @@ def test_sdf_term_matches_reference_execution(name):
                      t("vis_indices"), add_mask, t("depth"), t("c2w"), fx, cx, cy, int(W), int(H), mask, 10_000)
     cfg = type("C", (), dict(use_sdf_loss=True, apply_sdf_loss_after_iters=2000, apply_sdf_loss_iters=100))
     assert sdf.sdf_term_due(cfg, 2100) and not sdf.sdf_term_due(cfg, 2000) and not sdf.sdf_term_due(cfg, 2150)
+
+
+def test_kernel_timer_selects_and_samples_launches(monkeypatch):
+    """ops.TIMER as bench.py uses it inside its timed window: only the selected launches get a span, of those every k-th
+    is bracketed by events, every other launch takes the plain path (no span object) — and a non-zero return code raises
+    on either path."""
+    from fusionsense_amd import ops
+    from fusionsense_amd._lib import FsgsError
+
+    class FakeEvent:
+        made = 0
+
+        def __init__(self, enable_timing=False):
+            FakeEvent.made += 1
+            self.t = None
+
+        def record(self):
+            FakeEvent.clock = getattr(FakeEvent, "clock", 0.0) + 1.0
+            self.t = FakeEvent.clock
+
+        def elapsed_time(self, other):
+            return other.t - self.t
+    monkeypatch.setattr(ops.torch.cuda, "Event", FakeEvent)
+    monkeypatch.setattr(ops.torch.cuda, "synchronize", lambda *a, **k: None)
+    spans = []
+    real_span = ops._KernelTimer.span
+    monkeypatch.setattr(ops._KernelTimer, "span", lambda self, name: (spans.append(name), real_span(self, name))[1])
+    calls = []
+    ok = lambda *a: (calls.append(a), 0)[1]  # noqa: E731
+    try:
+        ops.TIMER.reset(enabled=True, only=("raster_bwd",), prealloc=3, every=4)
+        assert FakeEvent.made == 6
+        for _ in range(10):
+            ops._run(ok, (1, 2), "fsgs_tile_sort")
+            ops._run(ok, (3,), "fsgs_raster_bwd_quad", "_d4e3")
+        assert len(calls) == 20
+        assert spans == ["raster_bwd_quad_d4e3"] * 10      # the unselected launch never made a span
+        s = ops.TIMER.summary()
+        assert list(s) == ["raster_bwd_quad_d4e3"] and s["raster_bwd_quad_d4e3"]["calls"] == 3  # launches 1, 5, 9
+        assert s["raster_bwd_quad_d4e3"]["avg_ms"] == 1.0
+        with pytest.raises(FsgsError):
+            ops._run(lambda *a: 2, (), "fsgs_tile_sort")
+        with pytest.raises(FsgsError):
+            ops._run(lambda *a: 2, (), "fsgs_raster_bwd_quad")
+        ops.TIMER.reset(enabled=True)  # no selection: every launch timed
+        ops._run(ok, (), "fsgs_tile_sort")
+        assert list(ops.TIMER.summary()) == ["tile_sort"]
+    finally:
+        ops.TIMER.reset(enabled=False)
+    ops._run(ok, (), "fsgs_tile_sort")
+    assert ops.TIMER.summary() == {}
