@@ -220,6 +220,8 @@ _PINNED: dict = {}
 
 SPIN_WAIT = os.environ.get("FSGS_SPIN_WAIT", "1") != "0"
 WAIT_ON_FLAG = os.environ.get("FSGS_WAIT_ON_FLAG", "0") == "1"  # (polling the kernel-set flag instead of the event: measured no faster)
+# count-free route: the flag is the ONLY signal (no event recorded behind the launch); FSGS_FILL_WAIT_ON_FLAG=0 for A/B
+FILL_WAIT_ON_FLAG = os.environ.get("FSGS_FILL_WAIT_ON_FLAG", "1") != "0"
 
 
 def _wait_event(ev) -> None:
@@ -323,11 +325,15 @@ def _wait_total(st: dict) -> int:
     """The step's one host wait: poll the done-flag the offsets kernel sets in mapped host memory right after the
     total (falls back to the event)."""
     arr = st["pinned"]._np
-    if SPIN_WAIT and WAIT_ON_FLAG:
+    ev = st.get("event")
+    if SPIN_WAIT and (WAIT_ON_FLAG or ev is None):
         for _ in range(400000):
             if arr[1] != 0:
                 return int(arr[0])
-    _wait_event(st["event"])
+    if ev is None:  # (count-free route: the flag's kernel is enqueued on this stream)
+        torch.cuda.current_stream(st["pinned_dev"]).synchronize()
+        return int(arr[0])
+    _wait_event(ev)
     return int(arr[0])
 
 
@@ -497,9 +503,13 @@ def project_bin_live_fill_async(means: Tensor, quats: Tensor, log_scales: Tensor
             float(BIN_FILL_GROWTH), int(BIN_FILL_SLACK), pinned.data_ptr(), int(degree), ptr(campos), ptr(f_dc),
             ptr(f_rest), ptr(c2w), ptr(packed), ptr(normals_world), ptr(zero_cells), int(zero_cells.numel()),
             ptr(tile_order), stream_ptr(dev)), "fsgs_isect_count_live")
-    ev = torch.cuda.Event()
-    ev.record(torch.cuda.current_stream(dev))
-    return dict(direct=True, fill=True, tpg=tpg, offsets=offsets, table=None, pinned=pinned, event=ev, T=T,
+    # (no event behind the launch: the bookkeeping workgroup raises a flag in mapped host memory right after the total,
+    # and an event record is a marker packet of its own — ~6 us of idle GPU in front of the next launch, every step)
+    ev = None
+    if not FILL_WAIT_ON_FLAG:
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(dev))
+    return dict(direct=True, fill=True, tpg=tpg, offsets=offsets, table=None, pinned=pinned, event=ev, T=T, pinned_dev=dev,
                 capacity=int(capacity), buckets=buckets, base=hist["base"], next_base=next_base, tile_order=tile_order)
 
 
