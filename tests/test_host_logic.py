@@ -1328,3 +1328,41 @@ def test_kernel_timer_selects_and_samples_launches(monkeypatch):
         ops.TIMER.reset(enabled=False)
     ops._run(ok, (), "fsgs_tile_sort")
     assert ops.TIMER.summary() == {}
+
+
+def test_count_free_route_waits_on_the_mapped_flag(monkeypatch):
+    """ops._wait_total on the count-free route (no event behind the launch): the total is returned as soon as the
+    bookkeeping workgroup's flag is up; if it never comes up within the spin, the stream is synchronised before the read.
+    With an event (the two-pass route) the event is what is waited for."""
+    from fusionsense_amd import ops
+    arr = np.array([1234, 1, 0, 0], dtype=np.int32)
+    pinned = type("P", (), {"_np": arr})()
+    monkeypatch.setattr(ops, "SPIN_WAIT", True)
+    assert ops._wait_total(dict(pinned=pinned, event=None, pinned_dev="d")) == 1234
+    synced = []
+
+    class Stream:
+        def synchronize(self):
+            synced.append(1)
+            arr[0], arr[1] = 77, 1
+    monkeypatch.setattr(ops.torch.cuda, "current_stream", lambda dev=None: Stream())
+    arr[1] = 0
+    monkeypatch.setattr(ops, "SPIN_WAIT", False)  # (no spin: straight to the fallback)
+    assert ops._wait_total(dict(pinned=pinned, event=None, pinned_dev="d")) == 77 and synced == [1]
+    waited = []
+    monkeypatch.setattr(ops, "_wait_event", lambda ev: waited.append(ev))
+    arr[0] = 5
+    assert ops._wait_total(dict(pinned=pinned, event="EV")) == 5 and waited == ["EV"]
+
+
+def test_bench_sets_the_runtime_limit_before_the_runtime_loads():
+    """bench.py moves the HIP runtime's command-batch limit with os.environ.setdefault BEFORE torch —
+    and with it libamdhip64 — is imported, and a caller's own setting wins."""
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py")).read()
+    assert src.index("RUNTIME_ENV = {") < src.index("\nimport torch\n")
+    assert 'os.environ.setdefault(_k, _v)' in src
+    env = dict(os.environ, DEBUG_CLR_MAX_BATCH_SIZE="4321")
+    out = subprocess.run([sys.executable, "-c", "import bench; print(bench.RUNTIME_ENV)"], env=env, capture_output=True,
+                         text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "'DEBUG_CLR_MAX_BATCH_SIZE': '4321'" in out.stdout
