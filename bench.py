@@ -129,6 +129,8 @@ def parse():
     ap.add_argument("--sort-order", type=int, default=None, help="A/B: 0 = the in-tile sorts in tile order")
     ap.add_argument("--bwd-order", type=int, default=None, help="A/B: 0 = the backward's quadrants in the size rule's order")
     ap.add_argument("--bin-fill", type=int, default=None, help="A/B: 0 = two-pass binning on every frame")
+    ap.add_argument("--express", type=int, default=None, choices=[0, 1],
+                    help="A/B: 0 = every step launch by launch from Python (no fsgs_step_run)")
     ap.add_argument("--bwd-queue", type=int, default=None, help="A/B: queue positions for the backward's extra workgroups")
     ap.add_argument("--tail-items", type=int, default=None, help="A/B: queue positions of the hand-off (= tail workgroups)")
     a = ap.parse_args()
@@ -288,6 +290,23 @@ def pmc_record(kernel_key, config):
         with open(path) as f:
             d = json.load(f)
         return d.get(f"config{config}", {}).get(kernel_key, {}) or {}
+    except (OSError, ValueError):
+        return {}
+
+
+# kernel key of bench.py -> entry of profiles/r6_isa_mix.json (tools/isa_mix_all.sh: the hot loop's static instruction mix)
+_ISA_MIX_KEY = {"raster_bwd_quad_d4e3": "raster_bwd_live<4,true,3>", "raster_fwd_quad_d4e3": "raster_fwd_wave<4,3>",
+                "gaussian_bwd": "gauss_sh_bwd", "ssim_l1_fwd": "ssim_l1_fwd", "ssim_l1_bwd": "ssim_l1_bwd",
+                "isect_count_live": "isect_live_bin_fill", "tile_sort": "tile_sort_kernel2"}
+
+
+def isa_mix_record(kernel_key):
+    """{"simple_share", "dpp_share", "trans_share", "loop"} of a kernel's hot loop, or {} (then every instruction is priced
+    as a full 4-cycle pass)."""
+    path = os.path.join(ROOT, "profiles", "r6_isa_mix.json")
+    try:
+        with open(path) as f:
+            return json.load(f).get(_ISA_MIX_KEY.get(kernel_key, kernel_key), {}) or {}
     except (OSError, ValueError):
         return {}
 
@@ -558,6 +577,8 @@ def main():
     from fusionsense_amd import frame_cache, ops
 
     log('building workload')
+    if args.express is not None:
+        os.environ["FSGS_EXPRESS"] = str(args.express)  # (read by SplatTrainer at construction)
     if args.bin_fill is not None:
         import fusionsense_amd.fused as _f
         _f.BIN_FILL = bool(args.bin_fill)
@@ -695,9 +716,14 @@ def main():
             return call
         for name in _L.SIGNATURES:
             setattr(lib_, name, timed_entry(name, getattr(lib_, name)))
+    host_issue = []  # per step: host time inside train_step MINUS the wait for the frame's verdict (one-call steps only)
     for s in range(args.steps):
         v = view_of(args.warmup + s)
+        h0_ = time.perf_counter()
+        x0_ = getattr(trainer, "express_steps", 0)
         trainer.train_step(cams[v], targets[v])
+        if getattr(trainer, "express_steps", 0) > x0_:
+            host_issue.append((time.perf_counter() - h0_) * 1e3 - trainer._express.last_wait_ms)
         if with_events:
             step_events[s + 1].record()
         step_views.append(v)
@@ -976,34 +1002,60 @@ def main():
                 r["traffic_frac_of_peak"] = round(traffic_frac, 4)
                 r["write_bytes_per_launch"] = rec.get("write_bytes_per_launch")
             q = rec.get("sq_active_inst_valu_quadcycles_per_launch")
-            valu = None
-            if q:  # a wave64 fp32 instruction holds its SIMD for 4 cycles; 1024 SIMDs at 2.4 GHz
-                valu = 4.0 * q / (1024 * ms * 1e-3 * 2.4e9)
-                # (instructions that hold the SIMD for more than one quad-cycle — DPP reductions, v_permlane, 64-bit
-                # moves — are counted per quad-cycle by SQ_ACTIVE_INST_VALU on some launches: a raw figure above 1 means
-                # "saturated", not more than all cycles)
-                r["valu_busy_frac"] = round(min(valu, 1.0), 4)
-                if valu > 1.0:
-                    r["valu_busy_raw"] = round(valu, 4)
-                r["valu_insts_per_launch"] = rec.get("sq_insts_valu_per_launch")
-                n_valu = rec.get("sq_insts_valu_per_launch")
-                if n_valu:
-                    # the vector-ALU roofline beside the HBM one: a wave64 instruction issues over 4
-                    # cycles on one of 1024 SIMDs at 2.4 GHz -> the launch cannot be shorter than insts x 4 / (1024 x 2.4e9)
-                    floor_ms = n_valu * 4.0 / (1024 * 2.4e9) * 1e3
-                    r["valu_roofline"] = {"bound": "valu", "insts_per_launch": n_valu, "cycles_per_inst": 4, "simds": 1024,
-                                          "clock_ghz": 2.4, "floor_ms": round(floor_ms, 4), "frac": round(floor_ms / ms, 4)}
-                    if floor_ms > ms:
-                        r["valu_roofline"]["note"] = ("above 1: many counted instructions ran with an empty EXEC mask (few "
-                                                      "useful lanes) and retire in fewer than 4 cycles — not a bound here")
-            if valu is None and traffic_frac is None:
+            n_valu = rec.get("sq_insts_valu_per_launch")
+            issue = None
+            if q and n_valu:
+                # The vector-issue roofline beside the HBM one, on MEASURED rates (profiles/r6_valu_rate.txt, tools/valu_rate.hip):
+                # SQ_INSTS_VALU counts wave instructions; SQ_ACTIVE_INST_VALU counts 4-cycle PASSES as if nothing paired
+                # (1 per ordinary instruction, 2 per transcendental / v_permlane*_swap).  A SIMD retires a DPP / compare /
+                # select / min-max class instruction in 4.2 cycles, a transcendental in 8.2, and a simple fp32 / integer
+                # instruction (v_fma / mul / add / sub / mov / and / or / add_u32) in 2.2 when a second wave's instruction
+                # shares the pass — never when that is a DPP or transcendental one — else 4.4.  The static class shares of the
+                # kernel's hot loop (tools/isa_mix.py -> profiles/r6_isa_mix.json) split the counted instructions.
+                mix = isa_mix_record(key)
+                n_trans = max(q - n_valu, 0)
+                n_rest = max(n_valu - n_trans, 0)
+                sh_simple, sh_dpp = mix.get("simple_share", 0.0), mix.get("dpp_share", 0.0)
+                n_simple, n_dpp = n_rest * sh_simple, n_rest * sh_dpp
+                n_full = n_rest - n_simple - n_dpp
+                # best case: every non-DPP 4-cycle instruction shares its pass with a simple one, the remaining simple ones pair up
+                passes_best = max((n_simple + n_full) / 2.0, n_full) + n_dpp
+                cyc_best = 4.3 * passes_best + 8.2 * n_trans
+                cyc_unpaired = 4.3 * n_rest + 8.2 * n_trans
+                simd_hz = 1024 * 2.4e9
+                floor_ms = cyc_best / simd_hz * 1e3
+                unpaired_ms = cyc_unpaired / simd_hz * 1e3
+                issue = min(unpaired_ms / ms, 1.0)  # share of the launch the SIMDs issue vector work if NOTHING paired
+                r["valu_insts_per_launch"] = n_valu
+                r["valu_roofline"] = {
+                    "bound": "valu", "insts_per_launch": n_valu, "transcendental_or_permlane_swap": int(n_trans),
+                    "hot_loop_mix": mix or None, "cycles": {"simple_paired": 2.2, "simple_alone": 4.4, "full": 4.2,
+                                                            "transcendental": 8.2},
+                    "simds": 1024, "clock_ghz": 2.4, "floor_ms": round(floor_ms, 4), "frac": round(min(floor_ms / ms, 1.0), 4),
+                    "issue_ms_if_nothing_paired": round(unpaired_ms, 4),
+                    "calibration": "profiles/r6_valu_rate.txt",
+                    "note": ("floor = every simple instruction shares its 4-cycle pass (the best the issue logic was seen to do); "
+                             "issue_ms_if_nothing_paired = the same instructions one per pass: the launch lies between the two")}
+                # (round 5 reported 4 x SQ_ACTIVE_INST_VALU / SIMD cycles as 'valu_busy': it exceeds 1 when simple
+                # instructions pair, because the counter charges them a full pass each — kept only as the raw count)
+                r["sq_active_inst_valu_passes_per_launch"] = q
+            wr = rec.get("write_bytes_per_launch")
+            if wr and key.startswith("raster_bwd"):
+                # memory-side atomics: every (instruction, 64-byte line) of a global_atomic_add_f32 is one operation that
+                # WRITE_SIZE charges 64 B, and the chip retires 20.2 G of them per second whatever the footprint
+                ops = wr / 64.0
+                a_ms = ops / 20.2e9 * 1e3
+                r["atomic_roofline"] = {"bound": "memory-side atomics", "line_ops_per_launch": int(ops), "peak_gops": 20.2,
+                                        "floor_ms": round(a_ms, 4), "frac": round(min(a_ms / ms, 1.0), 4),
+                                        "calibration": "profiles/r6_valu_rate.txt"}
+            if issue is None and traffic_frac is None:
                 r["limiter"] = None  # no counters committed for this span and configuration
-            elif valu is not None and valu >= 0.65:
-                r["limiter"] = "vector-ALU issue (valu_busy_frac >= 0.65)"
+            elif issue is not None and issue >= 0.65:
+                r["limiter"] = "vector-ALU issue (>= 0.65 of the launch if no two instructions shared a pass)"
             elif max(ach / HBM_PEAK_GBS, traffic_frac or 0.0) >= 0.6:
                 r["limiter"] = "HBM bandwidth (>= 0.6 of the peak)"
             else:
-                r["limiter"] = "latency / memory-side atomics (vector ALUs < 0.65 busy, HBM < 0.6 of the peak)"
+                r["limiter"] = "latency / memory-side atomics (vector issue < 0.65, HBM < 0.6 of the peak)"
             return r
 
         cand = sorted(((v["avg_ms"], k) for k, v in kernel_ms.items() if k in alg), reverse=True)  # (one launch per step each)
@@ -1065,6 +1117,13 @@ def main():
             # buckets sized from the view's previous frame), "two_pass" = count + fill (first visits, after densification,
             # dense scenes, redone frames)
             "binning_frames": dict(getattr(trainer, "bin_frames", {})),
+            # steps of the timed region enqueued by ONE library call (fsgs_step_run; fusionsense_amd/express.py), and what
+            # issuing such a step costs the host: time inside train_step minus the wait for the frame's verdict
+            "express_steps_total": getattr(trainer, "express_steps", 0),
+            "express_steps_timed": len(host_issue),
+            "host_issue_ms_per_step": ({"p50": round(sorted(host_issue)[len(host_issue) // 2], 4),
+                                        "p99": round(sorted(host_issue)[min(len(host_issue) - 1, int(0.99 * len(host_issue)))], 4),
+                                        "max": round(max(host_issue), 4)} if host_issue else None),
             # dispatch order of the compositing backward: a rule of the frame's size since round 5 (fused._BwdDispatch)
             "bwd_dispatch": bwd_dispatch_choice(dev, W, H),
             "bwd_dispatch_tuning_frames_in_timed_region": tune_in_region,

@@ -28,10 +28,48 @@ class AdamGroups(C.Structure):
                 ("eps", C.c_float)]
 
 
+class StepPlan(C.Structure):
+    """fsgs_step_plan of include/fsgs.h, field for field (tests/test_host_logic.py compares every offset with the C
+    compiler's): one training step's launches as one argument block (fusionsense_amd/express.py fills it)."""
+    _fields_ = [
+        ("n", _i), ("sh_degree", _i), ("width", _i), ("height", _i), ("tile_width", _i), ("tile_height", _i),
+        ("capacity", _i64),
+        ("means", _p), ("quats", _p), ("log_scales", _p), ("opac_logit", _p), ("features_dc", _p), ("features_rest", _p),
+        ("viewmat", _p), ("K", _p), ("campos", _p), ("c2w", _p), ("background", _p),
+        ("binarise", _i), ("binary_threshold", _f),
+        ("scales_exp", _p), ("opac_sig", _p), ("radii", _p), ("means2d", _p), ("depths", _p), ("conics", _p),
+        ("tiles_per_gauss", _p), ("isect_offsets", _p),
+        ("bucket_base", _p), ("tile_cursor", _p),
+        ("buckets", _p), ("bucket_words", _i64), ("next_bucket_base", _p),
+        ("growth", _f), ("slack", _i), ("mapped", _p),
+        ("packed", _p), ("normals_world", _p), ("zero_cells", _p), ("n_zero", _i),
+        ("tile_order", _p),
+        ("payload", _p), ("long_flag", _p), ("rel_gate", _i),
+        ("render", _p), ("alphas", _p), ("last_ids", _p), ("render_extra", _p),
+        ("records", _p), ("n_rec", _p), ("seg_state", _p), ("seg_split", _p),
+        ("max_last", _p),
+        ("tail_scratch", _p), ("tail_scratch_bytes", _i64), ("tail_items", _i), ("handoff_records", _i),
+        ("handoff_rel_len", _i), ("tail_epoch", _i64),
+        ("bwd_queue", _p), ("bwd_queue_items", _i),
+        ("rgb", _p), ("depth", _p), ("normal", _p), ("n_cells", _i),
+        ("gt_rgb", _p), ("gt_depth", _p), ("gt_normal", _p), ("seed", _p),
+        ("g_depth", _f), ("g_normal", _f), ("aux_partial", _p), ("v_depth_img", _p), ("v_normal_img", _p),
+        ("order_counters", _p), ("bwd_order", _p), ("order_shift", _i),
+        ("ssim_maps", _p), ("ssim_sums", _p), ("ssim_rows", _i64), ("aux_rows", _i64),
+        ("g_l1", _f), ("g_ssim", _f), ("ssim_lambda", _f), ("v_rgb", _p), ("loss_out", _p),
+        ("v_packed", _p), ("replica_rows", _i64), ("dispatch_stride", _i),
+        ("absgrad", _p), ("xys_grad_norm", _p), ("vis_counts", _p), ("max_2Dsize", _p),
+        ("inv_max_hw", _f), ("frozen", _p),
+        ("adam", AdamGroups), ("min_scale_g", _f), ("gsb_flags", _i),
+        ("ev_before", _p * 8), ("ev_after", _p * 8),
+        ("armed", _i), ("wait_ns", _i64),
+    ]
+
+
 # == FSGS_ABI_VERSION of include/fsgs.h as of the SIGNATURES table below: load() refuses any other library (a stale
 # build — the .so files are git-ignored and travel separately, A/B builds come in through FSGS_LIB — would read a stream
 # pointer as a flag or write past a buffer that has since grown)
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 SIGNATURES = {
     "fsgs_version": (_i, []),
@@ -144,6 +182,10 @@ SIGNATURES = {
     "fsgs_depth_valid_counts": (_i, [_i, _i, _p, _p, _f, _p, _p]),
     "fsgs_min_scale_loss": (_i, [_i, _p, _f, _p, _p, _p, _p]),
     "fsgs_touch_normal_sqerr": (_i, [_i, _p, _p, _p, _p, _p]),
+    "fsgs_step_forward": (_i, [C.POINTER(StepPlan), _p]),
+    "fsgs_step_backward": (_i, [C.POINTER(StepPlan), _i64, C.POINTER(_i64), _p]),
+    "fsgs_step_run": (_i, [C.POINTER(StepPlan), _i64, C.POINTER(_i64), _p]),
+    "fsgs_step_plan_bytes": (_i64, []),
 }
 
 _lib: Optional[C.CDLL] = None

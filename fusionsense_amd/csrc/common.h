@@ -8,6 +8,18 @@
 
 #include "../../include/fsgs.h"
 
+// The hand-rolled inter-workgroup hand-offs of this library (raster_quad.hip: the forward's tail queue; sh.hip: the scan
+// launch's last workgroup forming isect_offsets) publish data with relaxed agent-scope atomic stores — which gfx942 / gfx950
+// compile to write-through (sc1) stores — followed by `s_waitcnt vmcnt(0)` and a tagged word or a relaxed ticket, and read
+// it back with relaxed agent-scope loads.  That is OUTSIDE the HIP memory model: it relies on stores being counted by
+// vmcnt and on sc1 accesses bypassing the non-coherent caches, as they do on these two targets (MI355X_MICROARCH.md,
+// "Inter-workgroup visibility"; an architecture with a separate store counter, or a compiler that stops emitting sc1 for
+// agent scope, would let a reader see stale data with no error).  Refuse to build for anything else.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx942__) && !defined(__gfx950__)
+#error "libfsgs's write-through hand-off protocols are validated for gfx942 / gfx950 only (see common.h)"
+#endif
+
+
 namespace fsgs {
 
 constexpr int kWave = 64;

@@ -7,6 +7,8 @@
 //   epilogue_fwd/bwd : rgb = clamp(render + (1-alpha) * bg, 0, 1); depth = alpha > 0 ? ED : max(ED);
 //                      normal = (n / |n| + 1) / 2
 // Elementwise, HBM-bound, coalesced; used by fusionsense_amd/fused.py only.
+#include <initializer_list>
+
 #include "common.h"
 #include "adam_body.h"
 
@@ -108,6 +110,15 @@ __device__ __forceinline__ void bwd_order_rider_block(const BwdOrderRider &r, in
         const int ty = t / r.tw, tx = t - ty * r.tw;
         r.order[(int64_t)cls[k] * nq + base[cls[k]] + rank[k]] = (2 * ty + (q >> 1)) * (2 * r.tw) + 2 * tx + (q & 1);
     }
+}
+
+// The image epilogues read and write four pixels per lane with 16-byte accesses: every image pointer must be 16-byte
+// aligned (fsgs.h says so; a view that starts in the middle of an allocation is refused instead of relying on the GPU's
+// unaligned-access mode).
+static inline bool aligned16(std::initializer_list<const void *> ps) {
+    for (const void *q : ps)
+        if (q && (reinterpret_cast<uintptr_t>(q) & 15u)) return false;
+    return true;
 }
 
 // One WAVE per 256 pixels, four consecutive pixels per lane (round 5): every array is read and written with 16-byte
@@ -329,6 +340,7 @@ extern "C" int fsgs_epilogue_fwd(int64_t n_pixels, const float *render, const fl
     if (!render || !alphas || !bg || (n_partial > 0 && !max_last_partial) || !max_last || !rgb || !depth)
         return FSGS_EINVAL;
     if (normal && !render_extra) return FSGS_EINVAL;
+    if (!aligned16({render, alphas, render_extra, rgb, depth, normal})) return FSGS_EINVAL;
     hipStream_t s = as_stream(stream);
     if (n_partial > 0)  // n_partial <= 0: max_last already holds max(1, -n_partial) partial maxima (fsgs_raster_fwd_quad)
         hipLaunchKernelGGL(max_reduce_kernel, dim3(1), dim3(1024), 0, s, n_partial, max_last_partial, max_last);
@@ -368,6 +380,7 @@ extern "C" int fsgs_epilogue_fwd_order(int64_t n_pixels, const float *render, co
     if ((normal && !render_extra) || (normal_gt && (!depth_gt || !normal || !v_normal))) return FSGS_EINVAL;
     if (bwd_order && (!n_rec || !order_counters || tile_width < 1 || tile_height < 1 || order_shift < 0 || order_shift > 16))
         return FSGS_EINVAL;
+    if (!aligned16({render, alphas, render_extra, rgb, depth, normal, depth_gt, normal_gt, v_depth, v_normal})) return FSGS_EINVAL;
     const int n_blocks = (int)ceil_div(n_pixels, 256);
     BwdOrderRider rd{};
     int n_rider = 0;

@@ -19,6 +19,7 @@ extern "C" const char *fsgs_error_string(int code) {
         case FSGS_EINVAL: return "invalid argument (null pointer, unsupported size or channel count)";
         case FSGS_ELAUNCH: return "HIP launch/runtime error (see fsgs_last_hip_error)";
         case FSGS_ESCRATCH: return "scratch arena too small";
+        case FSGS_EPROTOCOL: return "a bounded wait ran into its bound, or calls arrived out of order";
         default: return "unknown error";
     }
 }

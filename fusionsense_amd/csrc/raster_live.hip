@@ -64,6 +64,10 @@ __device__ __forceinline__ void load_rec(Rec &r, const float4 *__restrict__ rec,
 #define FSGS_BWD_WAVES 4
 #endif
 constexpr int kBwdWaves = FSGS_BWD_WAVES;
+// waves per SIMD the register allocator aims at (78 VGPRs -> 6; A/B: make EXTRA=-DFSGS_BWD_OCC=n)
+#ifndef FSGS_BWD_OCC
+#define FSGS_BWD_OCC 6
+#endif
 
 // Optional: the gradients arrive as those of FusionSense's get_outputs images (D = 4, E = 3, C = 1; what
 // fsgs_epilogue_bwd would first turn into v_render / v_alphas / v_render_extra, dn_model.py:602-613, 655-664):
@@ -86,7 +90,7 @@ __device__ unsigned long long g_bwd_stats[12];
 #endif
 
 template <int D, bool ABS, int E>
-__global__ void __launch_bounds__(64 * kBwdWaves) __attribute__((amdgpu_waves_per_eu(6, 6)))
+__global__ void __launch_bounds__(64 * kBwdWaves) __attribute__((amdgpu_waves_per_eu(FSGS_BWD_OCC, FSGS_BWD_OCC)))
 raster_bwd_live_kernel(int64_t cap, const float4 *__restrict__ rec,
                        const int32_t *__restrict__ tile_offsets, int64_t n_isects,
                        const float *__restrict__ backgrounds, int W, int H, int tw, int th,

@@ -246,6 +246,7 @@ class _FwdWalk:
         self.max_items = 16384       # queue positions = tail workgroups of a launch that carries the tail
         self.forced = False          # tests: use ``forced_walk`` (and ``handoff_records`` as set)
         self.forced_walk = 0
+        self.failed = False          # a hand-off wait ever ran into its bound on some device (see scratch())
         self.state: Dict = {}        # device -> dict(scratch, epoch, frames, keep_until, seen, probe)
 
     def choice(self, n_gaussians: int = 0):
@@ -260,7 +261,7 @@ class _FwdWalk:
         if st is None or st["scratch"].numel() != need:
             st = self.state[key] = dict(scratch=torch.zeros(need, dtype=torch.uint8, device=dev), epoch=0, frames=0,
                                         keep_until=0, seen=0, probed_at=0, probe=None,
-                                        pinned=torch.zeros(1, dtype=torch.int32).pin_memory())
+                                        pinned=torch.zeros(2, dtype=torch.int32).pin_memory())
         return st
 
     def scratch(self, dev):
@@ -269,15 +270,28 @@ class _FwdWalk:
         st["frames"] += 1
         if st["probe"] is not None and st["probe"].query():
             st["probe"] = None
-            demand = int(st["pinned"][0])
+            if int(st["pinned"][0]) != 0:
+                # TailHeader.error: a bounded look-back wait of the hand-off ran into its bound (a broken dispatch-order
+                # assumption: CU masking, a pre-empted or shared GPU, another driver) — the frames since the last probe
+                # may hold wrong pixels and gradients.  Never silently: the hand-off is switched off for good and the
+                # caller is told.  The word is sticky; the scratch is dropped so that a run that carries on
+                # (after catching this) starts from a clean one, without hand-off.
+                self.handoff_records = 0
+                self.failed = True
+                self.state.pop(str(dev), None)
+                raise RuntimeError("fsgs: the forward hand-off protocol timed out on this device (TailHeader.error); frames "
+                                   f"of the last {self.PROBE_EVERY} steps may be wrong — the hand-off is now disabled "
+                                   "(FWD_WALK.handoff_records = 0)")
+            demand = int(st["pinned"][1])
             # (at least one hand-off per frame since the last look: a stray long list now and then — config #2 has one
             # in every tenth frame — is finished by its own wave)
             if demand - st["seen"] >= st["frames"] - st["probed_at"]:
                 st["keep_until"] = st["frames"] + self.KEEP_FRAMES
             st["seen"], st["probed_at"] = demand, st["frames"]
         if st["probe"] is None and st["frames"] % self.PROBE_EVERY == 0:
-            # (TailHeader.demand: the int32 at byte offset 12 — lists handed off, or wanting to be, so far)
-            st["pinned"].copy_(st["scratch"][12:16].view(torch.int32), non_blocking=True)
+            # (TailHeader.error and .demand: the int32s at byte offsets 8 and 12 — a protocol timeout ever, and the lists
+            # handed off, or wanting to be, so far)
+            st["pinned"].copy_(st["scratch"][8:16].view(torch.int32), non_blocking=True)
             st["probe"] = torch.cuda.Event()
             st["probe"].record()
         items = int(self.max_items) if (self.forced or st["frames"] <= st["keep_until"]) else 0

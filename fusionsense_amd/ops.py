@@ -330,8 +330,8 @@ def _wait_total(st: dict) -> int:
         for _ in range(400000):
             if arr[1] != 0:
                 return int(arr[0])
-    if ev is None:  # (count-free route: the flag's kernel is enqueued on this stream)
-        torch.cuda.current_stream(st["pinned_dev"]).synchronize()
+    if ev is None:  # (count-free route: the flag's kernel was enqueued on the stream that was current AT THE LAUNCH)
+        (st.get("stream") or torch.cuda.current_stream(st["pinned_dev"])).synchronize()
         return int(arr[0])
     _wait_event(ev)
     return int(arr[0])
@@ -510,6 +510,7 @@ def project_bin_live_fill_async(means: Tensor, quats: Tensor, log_scales: Tensor
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(dev))
     return dict(direct=True, fill=True, tpg=tpg, offsets=offsets, table=None, pinned=pinned, event=ev, T=T, pinned_dev=dev,
+                stream=torch.cuda.current_stream(dev),
                 capacity=int(capacity), buckets=buckets, base=hist["base"], next_base=next_base, tile_order=tile_order)
 
 

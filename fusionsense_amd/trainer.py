@@ -267,6 +267,11 @@ class SplatTrainer:
         # False after a step whose Adam update ran inside the backward launch (no gradients written: gradients() raises,
         # every parameter's .grad is None); True after any step that left gradients in the slab
         self.last_step_grads_valid = True
+        # express.py: qualifying steps are enqueued by ONE library call (fsgs_step_run).  FSGS_EXPRESS=0 / .express = False
+        # keeps the launch-by-launch route everywhere (A/B, tests of that route)
+        self.express = os.environ.get("FSGS_EXPRESS", "1") != "0"
+        self._express = None
+        self.express_steps = 0
         self.comm_events = None  # a list: (step, start, end) HIP-event pairs around every collective / wait (see _comm)
         self.step = 0
         self.strategy = strategy  # fusionsense_amd.splatfacto.DensifyStrategy or None
@@ -731,6 +736,53 @@ class SplatTrainer:
                 finish()
         self._optimizer_step(FEATURE_GROUPS, step_no)
 
+    # -- the step as one library call (express.py) ---------------------------------------------------------------------
+    def _express_ok(self, camera: Camera, target, is_fb: bool, factors, zin) -> bool:
+        """The conditions of fused._FusedGetOutputs' count-free route (``use_fill``) + the benchmark loss + nothing
+        pending: everything else keeps the per-op route."""
+        from . import fused, ops
+        if not self.express or is_fb or factors is not None or zin is not None or self._pending is not None:
+            return False
+        if self.half_attributes or not (fused.BIN_FILL and fused.SH_RIDES_WITH_SCAN and fused.ONE_LAUNCH_GAUSSIAN_BWD
+                                        and fused.IMAGE_GRADS_IN_BWD and fused.FWD_TILE_ORDER and ops.USE_BIN_LIVE
+                                        and ops.BIN_FILL_SORT_ORDER and ops.FILL_WAIT_ON_FLAG and ops.DEFER_COMBINE):
+            return False
+        N = self.num_gaussians()
+        if not (0 < N < min(fused.BIN_FILL_MAX_N, fused.KEPT_MIN_N)) or self._params["features_rest"].shape[1] != 15:
+            return False
+        if self._sh_degree_now() > 3 or fused.FWD_WALK.choice(N)[0] != fused.FWD_WALK.ONE_WAVE:
+            return False
+        tiles = math.ceil(camera.width / 16) * math.ceil(camera.height / 16)
+        if tiles > self._bin_live_max_tiles() or ops.bin_live_is_dense(self.device, N, tiles):
+            return False
+        for k in ("rgb", "depth"):
+            t = target.get(k)
+            if t is None or not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous():
+                return False
+        tn = target.get("normal")
+        return tn is None or (tn.is_cuda and tn.dtype == torch.float32 and tn.is_contiguous())
+
+    def _bin_live_max_tiles(self) -> int:
+        v = getattr(self, "_max_tiles", None)
+        if v is None:
+            from ._lib import load
+            v = self._max_tiles = int(load().fsgs_bin_live_max_tiles())
+        return v
+
+    def _express_step(self, camera: Camera, cap: int, has_normal: bool):
+        """The argument blocks of this frame shape (re-made when the model, the capacity or the shape has changed)."""
+        from .express import ExpressStep
+        ex = self._express
+        # (the estimate `cap` moves with every new maximum of the frame shape: the blocks are sized with some headroom
+        # and kept while the estimate stays between half of and all of their capacity — a larger capacity only makes an
+        # overflow less likely, the lists are the same)
+        if (ex is None or ex.key[:3] != (self.num_gaussians(), camera.width, camera.height) or ex.key[4] != bool(has_normal)
+                or not (ex.capacity // 2 <= cap <= ex.capacity) or not ex.still_fits(self)):
+            ex = self._express = None  # (free the old buffers first)
+            roomy = -(-int(cap * 1.125) // 65536) * 65536
+            ex = self._express = ExpressStep(self, camera.width, camera.height, roomy, has_normal)
+        return ex
+
     def train_step(self, camera: Camera, target: Dict[str, Tensor], optimizer_step: bool = True):
         if getattr(self, "_one", None) is None or self._one.device != self.device:
             self._one = torch.ones((), dtype=torch.float32, device=self.device)
@@ -769,13 +821,43 @@ class SplatTrainer:
                                           zin is not None)
             cap = self._live_caps.get(cap_key) if (self.no_wait and self.num_gaussians() > 0) else 0
             aib, aib_step = None, None
-            if self._adam_in_backward_ok(optimizer_step):
+            aib_ok = self._adam_in_backward_ok(optimizer_step)
+            if aib_ok:
                 self.optimizers["means"].param_groups[0]["lr"] = self._means_lr(self.step)
                 aib_step = getattr(self, "adam_steps", 0) + 1
+            use_express = (aib_ok and bin_hist is not None and cap > 0
+                           and self._express_ok(camera, target, is_fb, factors, zin))
+            if aib_ok and not use_express:
                 aib = self._fused_adam_step(PARAM_ORDER, aib_step, as_groups=True)
             if zin is not None:
                 self.cut_frames += 1
-            for attempt in (0, 1, 2):
+            # The step as ONE library call (express.py; fsgs_step_run) where the count-free route applies: same launches,
+            # same arguments, same results — the host issues the step in microseconds instead of ~0.45 ms.
+            express_done = False
+            if use_express:
+                from .ops import bin_fill_words
+                ex = self._express_step(camera, cap, "normal" in target)
+                if bin_fill_words(int(bin_hist["n_live"]), ex.T) > ex.words:  # (a view last seen under a larger model)
+                    use_express = False
+                    aib = self._fused_adam_step(PARAM_ORDER, aib_step, as_groups=True)
+            if use_express:
+                ex.adam.step = int(aib_step)
+                for k, name in enumerate(PARAM_ORDER):
+                    ex.adam.lr[k] = float(self.optimizers[name].param_groups[0]["lr"])
+                over, n_live_x, loss, out = ex.run(self, camera, target, bin_hist, stats, frozen, bthr, ex.adam,
+                                                   self._sh_degree_now(), self._one)
+                if over:  # the frame outgrew its lists / a bucket: once more through the exact two-pass route (below)
+                    self.live_overflows += 1
+                    self._bin_hist.pop(bin_key, None)
+                    bin_hist = None
+                    self._live_caps.raise_to(cap_key, n_live_x)
+                    cap = 0
+                    bthr = None  # (launch 1 has written the binary opacities: the redo must not threshold them again)
+                    aib = self._fused_adam_step(PARAM_ORDER, aib_step, as_groups=True)
+                else:
+                    express_done = True
+                    self.express_steps += 1
+            for attempt in (() if express_done else (0, 1, 2)):
                 try:
                     loss, out = fused_step_forward_backward(
                         self._params, camera, target, self._sh_degree_now(), self.device, self.slab.views, self._one,
@@ -810,7 +892,8 @@ class SplatTrainer:
                     if zout is not None:
                         zout = torch.empty_like(zout)  # (the truncated frame's cuts are not kept)
             else:  # (cannot happen: the third attempt runs uncut and with exact sizes)
-                raise RuntimeError("a frame was abandoned three times (occlusion cut / live-list capacity)")
+                if not express_done:
+                    raise RuntimeError("a frame was abandoned three times (occlusion cut / live-list capacity)")
             if view_key is not None:
                 self._zcuts.pop(view_key, None)
                 if out["info"].zcut_out is not None:  # (None: the frame took a binning route without cuts)
@@ -832,7 +915,7 @@ class SplatTrainer:
                     while len(self._bin_hist) > self.zcut_max_views:
                         del self._bin_hist[next(iter(self._bin_hist))]
             self._factors_used = factors
-            if aib is not None and out["info"].adam_applied:
+            if (aib is not None or express_done) and out["info"].adam_applied:
                 # the backward launch has stepped all six groups: count the step, nothing left to launch
                 self.adam_steps = aib_step
                 for name in PARAM_ORDER:

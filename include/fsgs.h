@@ -41,8 +41,9 @@ typedef void *fsgs_stream_t; /* hipStream_t */
 #define FSGS_EINVAL -1   /* bad argument (null pointer, unsupported size / channel count) */
 #define FSGS_ELAUNCH -2  /* hipLaunch / runtime error; see fsgs_last_hip_error() */
 #define FSGS_ESCRATCH -3 /* scratch arena too small */
+#define FSGS_EPROTOCOL -4 /* a bounded cross-workgroup / host wait ran into its bound, or calls arrived out of order */
 
-#define FSGS_ABI_VERSION 8
+#define FSGS_ABI_VERSION 9
 int fsgs_version(void);
 int fsgs_abi_version(void); /* == FSGS_ABI_VERSION of the header the library was built from */
 /* Lines of the packed gradient accumulator a caller that passes `replica_rows` > 0 must provide per Gaussian row:
@@ -692,7 +693,10 @@ int fsgs_gauss_sh_bwd_adam_h16(int N, int degree, const float *means, const floa
  * render[3] : max(render[3]); normal = (n/|n| + 1)/2.  render [P,4], alphas [P], render_extra [P,3],
  * bg [3]; n_partial > 0: max_last_partial [n_partial] (per-workgroup partial maxima) is reduced into max_last[0]
  * first; n_partial <= 0: max_last already holds max(1, -n_partial) partial maxima.  bwd: any of v_rgb / v_depth / v_normal /
- * v_alpha_in may be NULL (= zero); writes v_render [P,4], v_alphas [P], v_render_extra [P,3]. */
+ * v_alpha_in may be NULL (= zero); writes v_render [P,4], v_alphas [P], v_render_extra [P,3].
+ * ALIGNMENT: the forward epilogues (fsgs_epilogue_fwd, _loss_fwd, _fwd_order) move four pixels per lane with 16-byte
+ * accesses: render, alphas, render_extra, rgb, depth, normal, depth_gt, normal_gt, v_depth, v_normal must be 16-byte
+ * aligned (any allocation's start is; a view at an odd pixel offset is not) — FSGS_EINVAL otherwise. */
 int fsgs_epilogue_fwd(int64_t n_pixels, const float *render, const float *alphas,
                       const float *render_extra, const float *bg, const float *max_last_partial,
                       int n_partial, float *max_last, float *rgb, float *depth, float *normal,
@@ -896,6 +900,89 @@ int fsgs_min_scale_loss(int N, const float *log_scales, float g, const float *v_
  * |normals_world[idx[i]] - touch_normals[i]|^2.  Value only: the reference's normals entry is a detached leaf. */
 int fsgs_touch_normal_sqerr(int n, const int64_t *idx, const float *normals_world, const float *touch_normals,
                             float *partial, fsgs_stream_t stream);
+
+/* ---- One training step as ONE call (round 6).  `DNSplatterModel.get_outputs` (dn_model.py:469-671: rasterization() at
+ * :570-591 + the legacy normal pass at :644-653 + the image epilogue :602-613, 655-664), the loss on its images, both
+ * backward passes, nerfstudio's after_train statistics (registered at dn_model.py:1385-1389) and the Adam step of the six
+ * Gaussian parameter groups (dn_config.py:36-75) — the launches the per-op entry points above enqueue one by one when a
+ * host drives them (fusionsense_amd/fused.py), here enqueued back to back by the library from ONE argument block, so that
+ * issuing a step costs the host microseconds instead of ~0.45 ms of interpreter time.  Nothing new runs on the device:
+ * every launch is one of the entry points above with the arguments named here; results are theirs, bit for bit.
+ *
+ * The route is the COUNT-FREE one (fsgs_project_bin_live_fill_sh_pack): one camera, fp32 attributes, 16 stored SH
+ * coefficients, degree <= 3, no occlusion cuts, a view whose previous frame left bucket room (`bucket_base`).  Loss: the
+ * benchmark loss of BASELINE config #2 ((1 - l) L1 + l (1 - SSIM11) on rgb, plain L1 on depth / normal).
+ * Frames that do not qualify (first visit of a view, half storage, dense scenes, get_loss_dict's terms, several ranks)
+ * keep the per-op route; so does the frame that is redone after an overflow.
+ *
+ *   fsgs_step_forward   launches 1-5: project + bin + SH / pack | in-tile sorts | compositing forward | image epilogue
+ *                       with the depth / normal L1 terms and the backward's dispatch order | SSIM forward
+ *   fsgs_step_backward  waits (bounded spin on the mapped flag the binning's bookkeeping workgroup raises, then a stream
+ *                       synchronise) for the frame's live total, returns FSGS_STEP_OVERFLOW (> 0) WITHOUT launching
+ *                       anything if the lists were truncated (total > capacity) or a tile outgrew its bucket — nothing
+ *                       with side effects has run by then: statistics, gradient accumulator, parameters and moments are
+ *                       untouched and the caller redoes the frame through the exact two-pass route — else launches 6-8:
+ *                       SSIM backward + loss combine | compositing backward | per-Gaussian backward + statistics + Adam
+ *   fsgs_step_run       both, back to back
+ * n_live_out (nullable): the frame's true number of live pairs (valid after fsgs_step_backward / _run, also on overflow).
+ *
+ * The block is PLAIN DATA owned by the caller; the library keeps no copy and no state.  Every pointer is device memory
+ * unless marked (host) / (mapped).  `mapped` = int32[4] in host memory the device can write (hipHostMalloc mapped /
+ * a pinned torch tensor): [0] live total, [1] done flag, [2] capacity (written by fsgs_step_forward), [3] bucket
+ * overflow; fsgs_step_forward clears [1] and [3]; a block must not be passed to fsgs_step_forward again before
+ * fsgs_step_backward (or _run) has returned for it — FSGS_EPROTOCOL otherwise (`armed`, the one field the calls write).
+ * Buffers marked [frame] are outputs a caller may read after the step; [scratch] are overwritten by every step. */
+#define FSGS_STEP_OVERFLOW 1
+typedef struct fsgs_step_plan {
+    /* -- shape -- */
+    int32_t n, sh_degree, width, height, tile_width, tile_height;
+    int64_t capacity;        /* live pairs the list buffers hold (payload, records: fsgs_quad_stream_capacity(1, tw, th, capacity)) */
+    /* -- parameters (read; stepped in place by launch 8) and the camera -- */
+    float *means, *quats, *log_scales, *opac_logit, *features_dc, *features_rest;
+    const float *viewmat, *K, *campos, *c2w, *background; /* [4,4] [3,3] [3] [3,4] as fsgs_sh_fwd_pack takes it, [3] */
+    int32_t binarise; float binary_threshold;             /* dn_model.py:492-503 (the write happens in launch 1) */
+    /* -- launch 1: projection outputs [frame], binning -- */
+    float *scales_exp, *opac_sig; int32_t *radii; float *means2d, *depths, *conics;
+    int32_t *tiles_per_gauss, *isect_offsets /* [T + 1] */;
+    const int32_t *bucket_base /* [T + 1], the view's previous frame */; int32_t *tile_cursor /* [T], zero */;
+    void *buckets /* [scratch] */; int64_t bucket_words; int32_t *next_bucket_base /* [T + 1] [frame] */;
+    float growth; int32_t slack; int32_t *mapped /* (mapped) int32[4] */;
+    float *packed /* [N,16] [scratch] */, *normals_world /* [N,3] [frame] */, *zero_cells; int32_t n_zero;
+    int32_t *tile_order /* [T] [scratch] */;
+    /* -- launch 2 -- */
+    int32_t *payload /* [capacity] [frame] */, *long_flag /* nullable (a word inside zero_cells) */; int32_t rel_gate;
+    /* -- launch 3: compositing forward (fsgs_raster_fwd_quad; walk = FSGS_WALK_ONE_WAVE) -- */
+    float *render, *alphas; int32_t *last_ids; float *render_extra;          /* [frame] */
+    float *records; int32_t *n_rec; float *seg_state; int32_t *seg_split;     /* [scratch] streams of the frame */
+    float *max_last /* == zero_cells */;
+    void *tail_scratch; int64_t tail_scratch_bytes; int32_t tail_items, handoff_records, handoff_rel_len; int64_t tail_epoch;
+    int32_t *bwd_queue /* nullable */; int32_t bwd_queue_items;
+    /* -- launch 4: images [frame] + the depth / normal L1 terms + the backward's dispatch order -- */
+    float *rgb, *depth, *normal; int32_t n_cells;
+    const float *gt_rgb, *gt_depth, *gt_normal /* nullable */, *seed /* [1]: d loss (1.0) */;
+    float g_depth, g_normal; float *aux_partial, *v_depth_img, *v_normal_img /* nullable with gt_normal */;
+    int32_t *order_counters /* nullable */, *bwd_order /* nullable */; int32_t order_shift;
+    /* -- launches 5-6: SSIM + L1 on rgb, loss value -- */
+    float *ssim_maps /* [3,H,W,3] */, *ssim_sums; int64_t ssim_rows, aux_rows;
+    float g_l1, g_ssim, ssim_lambda; float *v_rgb, *loss_out /* [1] [frame] */;
+    /* -- launch 7: compositing backward -- */
+    float *v_packed; int64_t replica_rows; int32_t dispatch_stride;
+    /* -- launch 8: per-Gaussian backward + after_train statistics + Adam -- */
+    float *absgrad /* [N,2] [frame] */, *xys_grad_norm, *vis_counts, *max_2Dsize /* nullable: no statistics */;
+    float inv_max_hw; const uint8_t *frozen /* nullable */;
+    fsgs_adam_groups adam; float min_scale_g; int32_t gsb_flags;
+    /* -- optional timing hooks: hipEvent_t handles (as void *) recorded on `stream` right before / behind launch k
+     *    (k = 0..7 in the order above: project+bin, sorts, forward, epilogue, SSIM fwd | SSIM bwd, backward, per-Gaussian);
+     *    NULL = none.  A recorded event costs the GPU ~6 us of idle time in front of the next launch. -- */
+    void *ev_before[8], *ev_after[8];
+    /* -- written by the calls -- */
+    int32_t armed;   /* 1 between fsgs_step_forward and fsgs_step_backward */
+    int64_t wait_ns; /* fsgs_step_backward: host time spent waiting for the frame's verdict (the rest of a call is issue time) */
+} fsgs_step_plan;
+int fsgs_step_forward(fsgs_step_plan *plan, fsgs_stream_t stream);
+int fsgs_step_backward(fsgs_step_plan *plan, int64_t spin_limit, int64_t *n_live_out, fsgs_stream_t stream);
+int fsgs_step_run(fsgs_step_plan *plan, int64_t spin_limit, int64_t *n_live_out, fsgs_stream_t stream);
+int64_t fsgs_step_plan_bytes(void); /* sizeof(fsgs_step_plan): a binding checks its own layout against it */
 
 #ifdef __cplusplus
 }

@@ -163,6 +163,7 @@ class OracleWindow:
         self.flat = np.asarray(info["flatten_ids"]).astype(np.int64)
         self.m2_64, self.cn_64 = p64[1][0], p64[3][0]
         self.op_64 = act["opacities"].double().reshape(-1)
+        self._oracle_grads = {}  # loss key -> (oracle loss value, oracle parameter gradients): see check()
 
     def loss_of(self, out, to):
         """The default loss: seeded random weights on every output image."""
@@ -182,15 +183,24 @@ class OracleWindow:
         near_cap = ((self.op_64[gi] * torch.exp(-sigma) - 0.999).abs() < 2e-6) & alive
         return bool(near_skip.any() | near_stop.any() | near_cap.any())
 
-    def check(self, og, grads, max_bad_radii, oracle_loss=None, grad_tol=3e-3, max_outlier_frac=1e-3):
+    def check(self, og, grads, max_bad_radii, oracle_loss=None, grad_tol=3e-3, max_outlier_frac=1e-3, loss_key=None):
         """``og`` / ``grads``: a HIP route's outputs and parameter gradients of the loss whose oracle-side statement is
-        ``oracle_loss(out, to)`` (default: ``loss_of``)."""
+        ``oracle_loss(out, to)`` (default: ``loss_of``).  The oracle's backward of a loss — the slow part: tens of seconds
+        at 6-10 M Gaussians — is run ONCE per loss and kept: the default loss, or any loss the caller names (``loss_key``:
+        the same key must mean the same loss), so that several HIP routes / walks are checked against one oracle frame."""
         orf, pr = self.orf, self.pr
         W, H = self.cam.width, self.cam.height
-        for v in pr.values():
-            v.grad = None
-        l_ref = (oracle_loss or self.loss_of)(orf, lambda t: t)
-        l_ref.backward(retain_graph=True)
+        key = loss_key if loss_key is not None else ("default" if oracle_loss is None else None)
+        kept = self._oracle_grads.get(key) if key is not None else None
+        if kept is None:
+            for v in pr.values():
+                v.grad = None
+            l_ref = (oracle_loss or self.loss_of)(orf, lambda t: t)
+            l_ref.backward(retain_graph=True)
+            kept = (l_ref.detach(), {k: v.grad.clone() for k, v in pr.items()})
+            if key is not None:
+                self._oracle_grads[key] = kept
+        l_ref, ref_grads = kept
         # ---- integer outputs
         hip_radii = og["radii"] if "radii" in og else og["info"]["radii"][0]
         bad_r = hip_radii.cpu().reshape(-1) != orf["radii"].reshape(-1)
@@ -218,7 +228,7 @@ class OracleWindow:
         dn = (og["normal"].detach().cpu() - orf["normal"].detach()).abs()
         assert dn.mean().item() < 1e-5 and (dn > 1e-2).float().mean().item() < 1e-3
         for k in pr:
-            e = rel_err(grads[k], pr[k].grad)
+            e = rel_err(grads[k], ref_grads[k])
             assert e < grad_tol, (k, e)  # 3e-3 of the tensor's own largest gradient
         return dict(n_bad_radii=n_bad_r, n_bad_tiles=int(bad_t.sum()), n_outliers=n_out, oracle_loss=float(l_ref.detach()),
                     visible=int((orf["radii"] > 0).sum()), n_isects=len(self.flat))
@@ -236,9 +246,25 @@ def fused_node_route(dev, params):
     return route
 
 
-def check_fused_node_against_oracle_on_crop(dev, params, cam, max_bad_radii):
-    """The fused autograd node against the CPU oracle on ALL of ``params``' Gaussians through ``cam`` (OracleWindow)."""
-    win = OracleWindow({k: v.detach().cpu() for k, v in params.items()}, cam)
+_WINDOW = {}  # the most recent shared oracle frame: {key: OracleWindow} (one entry: a frame of 6-10 M Gaussians is large)
+
+
+def shared_oracle_window(key, make):
+    """The oracle frame ``key`` — made by ``make()`` on first use and kept until another key is asked for — so that the
+    parametrisations of one test (forward walks, routes) are checked against ONE oracle run instead of one each (round 6:
+    the oracle runs were 330 of the GPU suite's 530 s).  The frame depends on scene and camera only, never on the walk."""
+    win = _WINDOW.get(key)
+    if win is None:
+        _WINDOW.clear()
+        win = _WINDOW[key] = make()
+    return win
+
+
+def check_fused_node_against_oracle_on_crop(dev, params, cam, max_bad_radii, share_key=None):
+    """The fused autograd node against the CPU oracle on ALL of ``params``' Gaussians through ``cam`` (OracleWindow);
+    ``share_key``: name of the (scene, camera) frame when several parametrisations check against it."""
+    make = lambda: OracleWindow({k: v.detach().cpu() for k, v in params.items()}, cam)  # noqa: E731
+    win = shared_oracle_window(share_key, make) if share_key is not None else make()
     og, grads = fused_node_route(dev, params)(cam, win.loss_of)
     return win.check(og, grads, max_bad_radii)
 

@@ -233,13 +233,14 @@ def test_config4_surface_scene_against_oracle_on_a_window(dev, surface4, walk):
     against the oracle's render + the oracle's SSIM / L1 loss.  Integer outputs, images, every parameter gradient; every
     mismatch must be an fp32 threshold case."""
     from fusionsense_amd import fused
-    from helpers import OracleWindow, fused_node_route
+    from helpers import OracleWindow, fused_node_route, shared_oracle_window
     if walk != "product":  # (the product's walk for a scene this dense IS the plain one-wave walk: force the hand-off on)
         fused.FWD_WALK.forced, fused.FWD_WALK.forced_walk = True, 1
         fused.FWD_WALK.handoff_records, fused.FWD_WALK.handoff_rel_len, fused.FWD_WALK.handoff_gate_len = 128, 0, 0
     params, cams = surface4
     cam = crop_camera(cams[0], CROP, shift=CROP_SHIFT)
-    win = OracleWindow({k: v.cpu() for k, v in params.items()}, cam)
+    # (ONE oracle frame and one oracle backward per loss for both walks: the oracle's side does not depend on the walk)
+    win = shared_oracle_window("config4_view0_window", lambda: OracleWindow({k: v.cpu() for k, v in params.items()}, cam))
     og, grads = fused_node_route(dev, params)(cam, win.loss_of)
     rep = win.check(og, grads, max_bad_radii=int(1e-4 * N4))
     assert rep["visible"] > 50_000 and rep["n_isects"] > 1024 * 64, rep  # (a dense window: the slab sorts ran)
@@ -247,7 +248,8 @@ def test_config4_surface_scene_against_oracle_on_a_window(dev, surface4, walk):
     tgt = _targets(dev, CROP, CROP, 21)
     seen = {}
     og, grads = _bench_route(dev, params, tgt, seen)(cam, None)
-    rep = win.check(og, grads, max_bad_radii=int(1e-4 * N4), oracle_loss=_bench_loss_oracle({k: v.cpu() for k, v in tgt.items()}))
+    rep = win.check(og, grads, max_bad_radii=int(1e-4 * N4), oracle_loss=_bench_loss_oracle({k: v.cpu() for k, v in tgt.items()}),
+                    loss_key="bench_loss_targets_seed21")
     assert seen["cut_frames"] >= 1
     assert abs(seen["loss"] - rep["oracle_loss"]) <= 2e-5 * abs(rep["oracle_loss"]), (seen["loss"], rep["oracle_loss"])
     assert fused.FWD_WALK.error(dev) == 0

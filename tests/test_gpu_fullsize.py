@@ -299,7 +299,9 @@ def test_config2_against_oracle_at_its_own_size(dev, full_scene, fwd_walk):
     (helpers.check_fused_node_against_oracle_on_crop: every mismatch must be an fp32 threshold case)."""
     from helpers import check_fused_node_against_oracle_on_crop, crop_camera
     params, cams = full_scene
-    check_fused_node_against_oracle_on_crop(dev, params, crop_camera(cams[0], 280), max_bad_radii=30)
+    # (ONE oracle frame for the three walks: the oracle's side depends on scene and camera only)
+    check_fused_node_against_oracle_on_crop(dev, params, crop_camera(cams[0], 280), max_bad_radii=30,
+                                            share_key="config2_view0_crop280")
 
 
 @pytest.mark.parametrize("route", ["fused", "dropin"])

@@ -98,6 +98,41 @@ def test_ctypes_signatures_match_the_header():
     assert seen == len(_lib.SIGNATURES)
 
 
+def test_step_plan_layout_matches_the_c_compiler(tmp_path):
+    """fsgs_step_plan (include/fsgs.h: one training step's launches as one argument block) and its ctypes mirror
+    _lib.StepPlan agree on the offset of EVERY field and on the size — a shifted field would make the library read a
+    stream pointer as a count on the GPU, nowhere else."""
+    import ctypes as C
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    from fusionsense_amd._lib import AdamGroups, StepPlan
+    names = [f[0] for f in StepPlan._fields_]
+    body = "".join(f'printf("{n} %zu\\n", offsetof(fsgs_step_plan, {n}));' for n in names)
+    body += "".join(f'printf("adam.{f[0]} %zu\\n", offsetof(fsgs_adam_groups, {f[0]}));' for f in AdamGroups._fields_)
+    src = tmp_path / "o.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "fsgs.h"\nint main(void) {' + body +
+                   'printf("sizeof %zu %zu\\n", sizeof(fsgs_step_plan), sizeof(fsgs_adam_groups)); return 0; }\n')
+    exe = tmp_path / "o"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)],
+                   check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split("\n")
+    seen = 0
+    for line in out:
+        if not line:
+            continue
+        k, *v = line.split()
+        if k == "sizeof":
+            assert int(v[0]) == C.sizeof(StepPlan) and int(v[1]) == C.sizeof(AdamGroups)
+        elif k.startswith("adam."):
+            assert int(v[0]) == getattr(AdamGroups, k[5:]).offset, k
+        else:
+            assert int(v[0]) == getattr(StepPlan, k).offset, k
+            seen += 1
+    assert seen == len(names)
+
+
 def test_header_is_plain_c_and_links(tmp_path):
     """include/fsgs.h is a C header (what a cgo / ctypes / FFI binding of the reference side would include): it compiles
     as C99 with -Wall -Werror, and a C program linked against libfsgs.so calls an entry point."""

@@ -69,6 +69,50 @@ enum Op {
     MIX_FMA_DPP,  // alternating v_fma_f32 / v_add_f32_dpp row_shr
     MIX_FMA_EXP,  // 3 v_fma_f32 : 1 v_exp_f32
     ATOM_ISSUE,   // global_atomic_add_f32 (no return), 15 lanes of every row -> one 64-B line per row: ISSUE cost
+    G_SUB,
+    G_FMAC,
+    G_MIN,
+    G_MUL_E64,
+    G_ADD_NEG,
+    G_FMA_SGPR,
+    G_FMA_CONST,
+    G_MUL_LIT,
+    G_AND,
+    G_OR,
+    G_LSHL,
+    G_ADDU,
+    G_SUBU,
+    G_ADDCO,
+    G_CVT_F_I,
+    G_CVT_I_F,
+    G_MULLO,
+    G_BFE,
+    G_MED3,
+    G_MAX3,
+    G_LDEXP,
+    G_SQRT,
+    G_RSQ,
+    G_MOV_DPP,
+    G_MBCNT,
+    G_CND_SGPR,
+    G_CND_VCC_D,
+    G_CND_E64_VCC,
+    P_CMP_CND,
+    P_CMPS_CNDS,
+    P_FMA_MAX,
+    P_FMA3_MAX,
+    P_FMA_MUL_ADD,
+    P_FMA_DPP_ALT,
+    P_FMA7_EXP,
+    P_FMA_SUB_MIN,
+    P_FMA_LDS,
+    P_FMAC_MAX,
+    P_FMAC_FMA,
+    P_FMAC_MUL_ADD,
+    P_CMP_CND3,
+    P_CMP_FMA_CND,
+    P_FMA_MAX2,
+    P_FMA_MAX_1_3,
     N_OPS
 };
 static const char *kOpName[N_OPS] = {"v_fma_f32",           "v_fma_f32 (dependent)", "v_mul_f32",          "v_add_f32",
@@ -78,7 +122,8 @@ static const char *kOpName[N_OPS] = {"v_fma_f32",           "v_fma_f32 (dependen
                                      "v_cmp_lt_f32 sgpr",   "v_pk_fma_f32",          "v_pk_mul_f32",       "v_mov_b32",
                                      "v_readlane_b32",      "ds_bpermute_b32",       "ds_swizzle_b32",     "ds_read_b128 broadcast",
                                      "ds_read_b32 broadcast", "ds_read_b128 per lane", "ds_read_b32 per lane",
-                                     "mix fma : dpp 1:1",   "mix fma : exp 3:1",     "global_atomic_add_f32 (issue)"};
+                                     "mix fma : dpp 1:1",   "mix fma : exp 3:1",     "global_atomic_add_f32 (issue)",
+    "v_sub_f32", "v_fmac_f32", "v_min_f32", "v_mul_f32 e64 |x|", "v_add_f32 e64 -x", "v_fma_f32 sgpr src", "v_fma_f32 inline 0.5", "v_mul_f32 literal", "v_and_b32", "v_or_b32", "v_lshlrev_b32", "v_add_u32", "v_sub_u32", "v_add_co_u32 vcc", "v_cvt_f32_i32", "v_cvt_i32_f32", "v_mul_lo_u32", "v_bfe_u32", "v_med3_f32", "v_max3_f32", "v_ldexp_f32", "v_sqrt_f32", "v_rsq_f32", "v_mov_b32_dpp row_shr:1", "v_mbcnt_lo_u32_b32", "v_cndmask_b32 e64 sgpr mask", "v_cndmask_b32 vcc, dst != src", "v_cndmask_b32 e64 vcc", "cmp vcc ; cndmask vcc (1:1)", "cmp sgpr ; cndmask sgpr (1:1)", "fma ; max alternating", "3 fma ; 1 max", "fma ; mul ; add ; mov", "fma ; dpp alternating", "7 fma ; 1 exp", "fma ; sub ; min ; cmp", "7 fma ; 1 ds_read_b128 bcast", "fmac ; max alternating", "fmac ; fma alternating", "fmac ; mul ; add ; mov", "cmp vcc ; 3 cndmask vcc (VOP2)", "cmp vcc ; 4 fma ; cndmask vcc ; 2 fma", "2 fma ; 2 max", "1 fma ; 3 max"};
 
 enum ExecMode { EX_FULL = 0, EX_LOW32, EX_EVEN, EX_LOW16, EX_ONE, EX_ZERO, EX_ROW15, N_EXEC };
 static const char *kExecName[N_EXEC] = {"full", "lanes 0-31", "even lanes", "lanes 0-15", "one lane", "EMPTY", "15 of 16 per row"};
@@ -147,6 +192,7 @@ __device__ __forceinline__ unsigned long long memrealtime() {
 #define I_P16A "v_permlane16_swap_b32 %0, %4\n v_permlane16_swap_b32 %1, %5\n v_permlane16_swap_b32 %2, %6\n v_permlane16_swap_b32 %3, %7\n"
 #define I_P16B "v_permlane16_swap_b32 %4, %0\n v_permlane16_swap_b32 %5, %1\n v_permlane16_swap_b32 %6, %2\n v_permlane16_swap_b32 %7, %3\n"
 #define FS_X8(A, B) A B A B A B A B A B A B A B A B
+#define FS_X8R(A) A A A A A A A A
 // lanes of row r add into line r of a group of four 64-byte lines; sixteen groups (immediate offsets) per wave
 #define I_ATOM(n) "global_atomic_add_f32 %0, %1, %2 offset:" #n "*256\n global_atomic_add_f32 %0, %1, %2 offset:" #n "*256+2048\n"
 #define FS_ATOM32 FS_B8(I_ATOM) FS_B8(I_ATOM)
@@ -155,7 +201,7 @@ __device__ __forceinline__ unsigned long long memrealtime() {
 template <int OP>
 __device__ __forceinline__ void body(float (&a)[8], f2 (&p)[8], f4 (&q)[8], float b, float c, f2 pb, f2 pc, unsigned lds_addr_bc,
                                      unsigned lds_addr_lane, unsigned bperm_addr, unsigned long long &sg, unsigned &sg32, float *gp,
-                                     unsigned goff) {
+                                     unsigned goff, float sb, unsigned long long sm, unsigned long long &smw) {
     if constexpr (OP == FMA) asm volatile(FS_B64(I_FMA) : FS_ACC8 : "v"(b), "v"(c));
     if constexpr (OP == FMA_DEP) asm volatile(FS_B64(I_FMA_DEP) : FS_ACC8 : "v"(b), "v"(c));
     if constexpr (OP == MUL) asm volatile(FS_B64(I_MUL) : FS_ACC8 : "v"(b), "v"(c));
@@ -186,6 +232,50 @@ __device__ __forceinline__ void body(float (&a)[8], f2 (&p)[8], f4 (&q)[8], floa
         asm volatile(FS_B8(I_FMA) FS_B8(I_DPP_SHR) FS_B8(I_FMA) FS_B8(I_DPP_SHR) FS_B8(I_FMA) FS_B8(I_DPP_SHR) FS_B8(I_FMA) FS_B8(I_DPP_SHR)
                      : FS_ACC8 : "v"(b), "v"(c));
     if constexpr (OP == MIX_FMA_EXP) asm volatile(I_MIX4 I_MIX4 I_MIX4 I_MIX4 I_MIX4 I_MIX4 I_MIX4 I_MIX4 : FS_ACC8 : "v"(b), "v"(c));
+    if constexpr (OP == G_SUB) asm volatile(FS_X8R("v_sub_f32 %0, %0, %8\n" "v_sub_f32 %1, %1, %8\n" "v_sub_f32 %2, %2, %8\n" "v_sub_f32 %3, %3, %8\n" "v_sub_f32 %4, %4, %8\n" "v_sub_f32 %5, %5, %8\n" "v_sub_f32 %6, %6, %8\n" "v_sub_f32 %7, %7, %8\n" ) : FS_ACC8 : "v"(b), "v"(c), "s"(sb), "s"(sm));
+    if constexpr (OP == G_FMAC) asm volatile(FS_X8R("v_fmac_f32 %0, %8, %9\n" "v_fmac_f32 %1, %8, %9\n" "v_fmac_f32 %2, %8, %9\n" "v_fmac_f32 %3, %8, %9\n" "v_fmac_f32 %4, %8, %9\n" "v_fmac_f32 %5, %8, %9\n" "v_fmac_f32 %6, %8, %9\n" "v_fmac_f32 %7, %8, %9\n" ) : FS_ACC8 : "v"(b), "v"(c), "s"(sb), "s"(sm));
+    if constexpr (OP == G_MIN) asm volatile(FS_X8R("v_min_f32 %0, %0, %9\n" "v_min_f32 %1, %1, %9\n" "v_min_f32 %2, %2, %9\n" "v_min_f32 %3, %3, %9\n" "v_min_f32 %4, %4, %9\n" "v_min_f32 %5, %5, %9\n" "v_min_f32 %6, %6, %9\n" "v_min_f32 %7, %7, %9\n" ) : FS_ACC8 : "v"(b), "v"(c), "s"(sb), "s"(sm));
+    if constexpr (OP == G_MUL_E64) asm volatile(FS_X8R("v_mul_f32_e64 %0, |%0|, %8\n" "v_mul_f32_e64 %1, |%1|, %8\n" "v_mul_f32_e64 %2, |%2|, %8\n" "v_mul_f32_e64 %3, |%3|, %8\n" "v_mul_f32_e64 %4, |%4|, %8\n" "v_mul_f32_e64 %5, |%5|, %8\n" "v_mul_f32_e64 %6, |%6|, %8\n" "v_mul_f32_e64 %7, |%7|, %8\n" ) : FS_ACC8 : "v"(b), "v"(c), "s"(sb), "s"(sm));
+    if constexpr (OP == G_ADD_NEG) asm volatile(FS_X8R("v_add_f32_e64 %0, -%0, %9\n" "v_add_f32_e64 %1, -%1, %9\n" "v_add_f32_e64 %2, -%2, %9\n" "v_add_f32_e64 %3, -%3, %9\n" "v_add_f32_e64 %4, -%4, %9\n" "v_add_f32_e64 %5, -%5, %9\n" "v_add_f32_e64 %6, -%6, %9\n" "v_add_f32_e64 %7, -%7, %9\n" ) : FS_ACC8 : "v"(b), "v"(c), "s"(sb), "s"(sm));
+    if constexpr (OP == G_FMA_SGPR) asm volatile(FS_X8R("v_fma_f32 %0, %0, %10, %9\n" "v_fma_f32 %1, %1, %10, %9\n" "v_fma_f32 %2, %2, %10, %9\n" "v_fma_f32 %3, %3, %10, %9\n" "v_fma_f32 %4, %4, %10, %9\n" "v_fma_f32 %5, %5, %10, %9\n" "v_fma_f32 %6, %6, %10, %9\n" "v_fma_f32 %7, %7, %10, %9\n" ) : FS_ACC8 : "v"(b), "v"(c), "s"(sb), "s"(sm));
+    if constexpr (OP == G_FMA_CONST) asm volatile(FS_X8R("v_fma_f32 %0, %0, 0.5, %9\n" "v_fma_f32 %1, %1, 0.5, %9\n" "v_fma_f32 %2, %2, 0.5, %9\n" "v_fma_f32 %3, %3, 0.5, %9\n" "v_fma_f32 %4, %4, 0.5, %9\n" "v_fma_f32 %5, %5, 0.5, %9\n" "v_fma_f32 %6, %6, 0.5, %9\n" "v_fma_f32 %7, %7, 0.5, %9\n" ) : FS_ACC8 : "v"(b), "v"(c), "s"(sb), "s"(sm));
+    if constexpr (OP == G_MUL_LIT) asm volatile(FS_X8R("v_mul_f32 %0, 0x3f8ccccd, %0\n" "v_mul_f32 %1, 0x3f8ccccd, %1\n" "v_mul_f32 %2, 0x3f8ccccd, %2\n" "v_mul_f32 %3, 0x3f8ccccd, %3\n" "v_mul_f32 %4, 0x3f8ccccd, %4\n" "v_mul_f32 %5, 0x3f8ccccd, %5\n" "v_mul_f32 %6, 0x3f8ccccd, %6\n" "v_mul_f32 %7, 0x3f8ccccd, %7\n" ) : FS_ACC8 : "v"(b), "v"(c), "s"(sb), "s"(sm));
+    if constexpr (OP == G_AND) asm volatile(FS_X8R("v_and_b32 %0, %0, %8\n" "v_and_b32 %1, %1, %8\n" "v_and_b32 %2, %2, %8\n" "v_and_b32 %3, %3, %8\n" "v_and_b32 %4, %4, %8\n" "v_and_b32 %5, %5, %8\n" "v_and_b32 %6, %6, %8\n" "v_and_b32 %7, %7, %8\n" ) : FS_ACC8 : "v"(b), "v"(c), "s"(sb), "s"(sm));
+    if constexpr (OP == G_OR) asm volatile(FS_X8R("v_or_b32 %0, %0, %9\n" "v_or_b32 %1, %1, %9\n" "v_or_b32 %2, %2, %9\n" "v_or_b32 %3, %3, %9\n" "v_or_b32 %4, %4, %9\n" "v_or_b32 %5, %5, %9\n" "v_or_b32 %6, %6, %9\n" "v_or_b32 %7, %7, %9\n" ) : FS_ACC8 : "v"(b), "v"(c), "s"(sb), "s"(sm));
+    if constexpr (OP == G_LSHL) asm volatile(FS_X8R("v_lshlrev_b32 %0, 1, %0\n" "v_lshlrev_b32 %1, 1, %1\n" "v_lshlrev_b32 %2, 1, %2\n" "v_lshlrev_b32 %3, 1, %3\n" "v_lshlrev_b32 %4, 1, %4\n" "v_lshlrev_b32 %5, 1, %5\n" "v_lshlrev_b32 %6, 1, %6\n" "v_lshlrev_b32 %7, 1, %7\n" ) : FS_ACC8 : "v"(b), "v"(c), "s"(sb), "s"(sm));
+    if constexpr (OP == G_ADDU) asm volatile(FS_X8R("v_add_u32 %0, %0, %8\n" "v_add_u32 %1, %1, %8\n" "v_add_u32 %2, %2, %8\n" "v_add_u32 %3, %3, %8\n" "v_add_u32 %4, %4, %8\n" "v_add_u32 %5, %5, %8\n" "v_add_u32 %6, %6, %8\n" "v_add_u32 %7, %7, %8\n" ) : FS_ACC8 : "v"(b), "v"(c), "s"(sb), "s"(sm));
+    if constexpr (OP == G_SUBU) asm volatile(FS_X8R("v_sub_u32 %0, %0, %8\n" "v_sub_u32 %1, %1, %8\n" "v_sub_u32 %2, %2, %8\n" "v_sub_u32 %3, %3, %8\n" "v_sub_u32 %4, %4, %8\n" "v_sub_u32 %5, %5, %8\n" "v_sub_u32 %6, %6, %8\n" "v_sub_u32 %7, %7, %8\n" ) : FS_ACC8 : "v"(b), "v"(c), "s"(sb), "s"(sm));
+    if constexpr (OP == G_ADDCO) asm volatile(FS_X8R("v_add_co_u32 %0, vcc, %0, %8\n" "v_add_co_u32 %1, vcc, %1, %8\n" "v_add_co_u32 %2, vcc, %2, %8\n" "v_add_co_u32 %3, vcc, %3, %8\n" "v_add_co_u32 %4, vcc, %4, %8\n" "v_add_co_u32 %5, vcc, %5, %8\n" "v_add_co_u32 %6, vcc, %6, %8\n" "v_add_co_u32 %7, vcc, %7, %8\n" ) : FS_ACC8 : "v"(b), "v"(c), "s"(sb), "s"(sm) : "vcc");
+    if constexpr (OP == G_CVT_F_I) asm volatile(FS_X8R("v_cvt_f32_i32 %0, %0\n" "v_cvt_f32_i32 %1, %1\n" "v_cvt_f32_i32 %2, %2\n" "v_cvt_f32_i32 %3, %3\n" "v_cvt_f32_i32 %4, %4\n" "v_cvt_f32_i32 %5, %5\n" "v_cvt_f32_i32 %6, %6\n" "v_cvt_f32_i32 %7, %7\n" ) : FS_ACC8 : "v"(b), "v"(c), "s"(sb), "s"(sm));
+    if constexpr (OP == G_CVT_I_F) asm volatile(FS_X8R("v_cvt_i32_f32 %0, %0\n" "v_cvt_i32_f32 %1, %1\n" "v_cvt_i32_f32 %2, %2\n" "v_cvt_i32_f32 %3, %3\n" "v_cvt_i32_f32 %4, %4\n" "v_cvt_i32_f32 %5, %5\n" "v_cvt_i32_f32 %6, %6\n" "v_cvt_i32_f32 %7, %7\n" ) : FS_ACC8 : "v"(b), "v"(c), "s"(sb), "s"(sm));
+    if constexpr (OP == G_MULLO) asm volatile(FS_X8R("v_mul_lo_u32 %0, %0, %8\n" "v_mul_lo_u32 %1, %1, %8\n" "v_mul_lo_u32 %2, %2, %8\n" "v_mul_lo_u32 %3, %3, %8\n" "v_mul_lo_u32 %4, %4, %8\n" "v_mul_lo_u32 %5, %5, %8\n" "v_mul_lo_u32 %6, %6, %8\n" "v_mul_lo_u32 %7, %7, %8\n" ) : FS_ACC8 : "v"(b), "v"(c), "s"(sb), "s"(sm));
+    if constexpr (OP == G_BFE) asm volatile(FS_X8R("v_bfe_u32 %0, %0, 3, 8\n" "v_bfe_u32 %1, %1, 3, 8\n" "v_bfe_u32 %2, %2, 3, 8\n" "v_bfe_u32 %3, %3, 3, 8\n" "v_bfe_u32 %4, %4, 3, 8\n" "v_bfe_u32 %5, %5, 3, 8\n" "v_bfe_u32 %6, %6, 3, 8\n" "v_bfe_u32 %7, %7, 3, 8\n" ) : FS_ACC8 : "v"(b), "v"(c), "s"(sb), "s"(sm));
+    if constexpr (OP == G_MED3) asm volatile(FS_X8R("v_med3_f32 %0, %0, %8, %9\n" "v_med3_f32 %1, %1, %8, %9\n" "v_med3_f32 %2, %2, %8, %9\n" "v_med3_f32 %3, %3, %8, %9\n" "v_med3_f32 %4, %4, %8, %9\n" "v_med3_f32 %5, %5, %8, %9\n" "v_med3_f32 %6, %6, %8, %9\n" "v_med3_f32 %7, %7, %8, %9\n" ) : FS_ACC8 : "v"(b), "v"(c), "s"(sb), "s"(sm));
+    if constexpr (OP == G_MAX3) asm volatile(FS_X8R("v_max3_f32 %0, %0, %8, %9\n" "v_max3_f32 %1, %1, %8, %9\n" "v_max3_f32 %2, %2, %8, %9\n" "v_max3_f32 %3, %3, %8, %9\n" "v_max3_f32 %4, %4, %8, %9\n" "v_max3_f32 %5, %5, %8, %9\n" "v_max3_f32 %6, %6, %8, %9\n" "v_max3_f32 %7, %7, %8, %9\n" ) : FS_ACC8 : "v"(b), "v"(c), "s"(sb), "s"(sm));
+    if constexpr (OP == G_LDEXP) asm volatile(FS_X8R("v_ldexp_f32 %0, %0, 1\n" "v_ldexp_f32 %1, %1, 1\n" "v_ldexp_f32 %2, %2, 1\n" "v_ldexp_f32 %3, %3, 1\n" "v_ldexp_f32 %4, %4, 1\n" "v_ldexp_f32 %5, %5, 1\n" "v_ldexp_f32 %6, %6, 1\n" "v_ldexp_f32 %7, %7, 1\n" ) : FS_ACC8 : "v"(b), "v"(c), "s"(sb), "s"(sm));
+    if constexpr (OP == G_SQRT) asm volatile(FS_X8R("v_sqrt_f32 %0, %0\n" "v_sqrt_f32 %1, %1\n" "v_sqrt_f32 %2, %2\n" "v_sqrt_f32 %3, %3\n" "v_sqrt_f32 %4, %4\n" "v_sqrt_f32 %5, %5\n" "v_sqrt_f32 %6, %6\n" "v_sqrt_f32 %7, %7\n" ) : FS_ACC8 : "v"(b), "v"(c), "s"(sb), "s"(sm));
+    if constexpr (OP == G_RSQ) asm volatile(FS_X8R("v_rsq_f32 %0, %0\n" "v_rsq_f32 %1, %1\n" "v_rsq_f32 %2, %2\n" "v_rsq_f32 %3, %3\n" "v_rsq_f32 %4, %4\n" "v_rsq_f32 %5, %5\n" "v_rsq_f32 %6, %6\n" "v_rsq_f32 %7, %7\n" ) : FS_ACC8 : "v"(b), "v"(c), "s"(sb), "s"(sm));
+    if constexpr (OP == G_MOV_DPP) asm volatile(FS_X8R("v_mov_b32_dpp %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n" "v_mov_b32_dpp %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n" "v_mov_b32_dpp %2, %2 row_shr:1 row_mask:0xf bank_mask:0xf\n" "v_mov_b32_dpp %3, %3 row_shr:1 row_mask:0xf bank_mask:0xf\n" "v_mov_b32_dpp %4, %4 row_shr:1 row_mask:0xf bank_mask:0xf\n" "v_mov_b32_dpp %5, %5 row_shr:1 row_mask:0xf bank_mask:0xf\n" "v_mov_b32_dpp %6, %6 row_shr:1 row_mask:0xf bank_mask:0xf\n" "v_mov_b32_dpp %7, %7 row_shr:1 row_mask:0xf bank_mask:0xf\n" ) : FS_ACC8 : "v"(b), "v"(c), "s"(sb), "s"(sm));
+    if constexpr (OP == G_MBCNT) asm volatile(FS_X8R("v_mbcnt_lo_u32_b32 %0, -1, %0\n" "v_mbcnt_lo_u32_b32 %1, -1, %1\n" "v_mbcnt_lo_u32_b32 %2, -1, %2\n" "v_mbcnt_lo_u32_b32 %3, -1, %3\n" "v_mbcnt_lo_u32_b32 %4, -1, %4\n" "v_mbcnt_lo_u32_b32 %5, -1, %5\n" "v_mbcnt_lo_u32_b32 %6, -1, %6\n" "v_mbcnt_lo_u32_b32 %7, -1, %7\n" ) : FS_ACC8 : "v"(b), "v"(c), "s"(sb), "s"(sm));
+    if constexpr (OP == G_CND_SGPR) asm volatile(FS_X8R("v_cndmask_b32_e64 %0, %0, %8, %11\n" "v_cndmask_b32_e64 %1, %1, %8, %11\n" "v_cndmask_b32_e64 %2, %2, %8, %11\n" "v_cndmask_b32_e64 %3, %3, %8, %11\n" "v_cndmask_b32_e64 %4, %4, %8, %11\n" "v_cndmask_b32_e64 %5, %5, %8, %11\n" "v_cndmask_b32_e64 %6, %6, %8, %11\n" "v_cndmask_b32_e64 %7, %7, %8, %11\n" ) : FS_ACC8 : "v"(b), "v"(c), "s"(sb), "s"(sm));
+    if constexpr (OP == G_CND_VCC_D) asm volatile(FS_X8R("v_cndmask_b32 %0, %8, %9, vcc\n" "v_cndmask_b32 %1, %8, %9, vcc\n" "v_cndmask_b32 %2, %8, %9, vcc\n" "v_cndmask_b32 %3, %8, %9, vcc\n" "v_cndmask_b32 %4, %8, %9, vcc\n" "v_cndmask_b32 %5, %8, %9, vcc\n" "v_cndmask_b32 %6, %8, %9, vcc\n" "v_cndmask_b32 %7, %8, %9, vcc\n" ) : FS_ACC8 : "v"(b), "v"(c), "s"(sb), "s"(sm));
+    if constexpr (OP == G_CND_E64_VCC) asm volatile(FS_X8R("v_cndmask_b32_e64 %0, %0, %8, vcc\n" "v_cndmask_b32_e64 %1, %1, %8, vcc\n" "v_cndmask_b32_e64 %2, %2, %8, vcc\n" "v_cndmask_b32_e64 %3, %3, %8, vcc\n" "v_cndmask_b32_e64 %4, %4, %8, vcc\n" "v_cndmask_b32_e64 %5, %5, %8, vcc\n" "v_cndmask_b32_e64 %6, %6, %8, vcc\n" "v_cndmask_b32_e64 %7, %7, %8, vcc\n" ) : FS_ACC8 : "v"(b), "v"(c), "s"(sb), "s"(sm));
+    if constexpr (OP == P_CMP_CND) asm volatile(FS_X8R("v_cmp_lt_f32 vcc, %0, %8\n" "v_cndmask_b32 %1, %1, %9, vcc\n" "v_cmp_lt_f32 vcc, %2, %8\n" "v_cndmask_b32 %3, %3, %9, vcc\n" "v_cmp_lt_f32 vcc, %4, %8\n" "v_cndmask_b32 %5, %5, %9, vcc\n" "v_cmp_lt_f32 vcc, %6, %8\n" "v_cndmask_b32 %7, %7, %9, vcc\n" ) : FS_ACC8 : "v"(b), "v"(c), "s"(sb), "s"(sm) : "vcc");
+    if constexpr (OP == P_CMPS_CNDS) asm volatile(FS_X8R("v_cmp_lt_f32 %8, %0, %9\n" "v_cndmask_b32_e64 %1, %1, %10, %8\n" "v_cmp_lt_f32 %8, %2, %9\n" "v_cndmask_b32_e64 %3, %3, %10, %8\n" "v_cmp_lt_f32 %8, %4, %9\n" "v_cndmask_b32_e64 %5, %5, %10, %8\n" "v_cmp_lt_f32 %8, %6, %9\n" "v_cndmask_b32_e64 %7, %7, %10, %8\n" ) : FS_ACC8, "+s"(smw) : "v"(b), "v"(c));
+    if constexpr (OP == P_FMA_MAX) asm volatile(FS_X8R("v_fma_f32 %0, %0, %8, %9\n" "v_max_f32 %1, %1, %9\n" "v_fma_f32 %2, %2, %8, %9\n" "v_max_f32 %3, %3, %9\n" "v_fma_f32 %4, %4, %8, %9\n" "v_max_f32 %5, %5, %9\n" "v_fma_f32 %6, %6, %8, %9\n" "v_max_f32 %7, %7, %9\n" ) : FS_ACC8 : "v"(b), "v"(c), "s"(sb), "s"(sm));
+    if constexpr (OP == P_FMA3_MAX) asm volatile(FS_X8R("v_fma_f32 %0, %0, %8, %9\n" "v_fma_f32 %1, %1, %8, %9\n" "v_fma_f32 %2, %2, %8, %9\n" "v_max_f32 %3, %3, %9\n" "v_fma_f32 %4, %4, %8, %9\n" "v_fma_f32 %5, %5, %8, %9\n" "v_fma_f32 %6, %6, %8, %9\n" "v_max_f32 %7, %7, %9\n" ) : FS_ACC8 : "v"(b), "v"(c), "s"(sb), "s"(sm));
+    if constexpr (OP == P_FMA_MUL_ADD) asm volatile(FS_X8R("v_fma_f32 %0, %0, %8, %9\n" "v_mul_f32 %1, %1, %8\n" "v_add_f32 %2, %2, %9\n" "v_mov_b32 %3, %8\n" "v_fma_f32 %4, %4, %8, %9\n" "v_mul_f32 %5, %5, %8\n" "v_add_f32 %6, %6, %9\n" "v_mov_b32 %7, %8\n" ) : FS_ACC8 : "v"(b), "v"(c), "s"(sb), "s"(sm));
+    if constexpr (OP == P_FMA_DPP_ALT) asm volatile(FS_X8R("v_fma_f32 %0, %0, %8, %9\n" "v_add_f32_dpp %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n" "v_fma_f32 %2, %2, %8, %9\n" "v_add_f32_dpp %3, %3, %3 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n" "v_fma_f32 %4, %4, %8, %9\n" "v_add_f32_dpp %5, %5, %5 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n" "v_fma_f32 %6, %6, %8, %9\n" "v_add_f32_dpp %7, %7, %7 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n" ) : FS_ACC8 : "v"(b), "v"(c), "s"(sb), "s"(sm));
+    if constexpr (OP == P_FMA7_EXP) asm volatile(FS_X8R("v_fma_f32 %0, %0, %8, %9\n" "v_fma_f32 %1, %1, %8, %9\n" "v_fma_f32 %2, %2, %8, %9\n" "v_fma_f32 %3, %3, %8, %9\n" "v_fma_f32 %4, %4, %8, %9\n" "v_fma_f32 %5, %5, %8, %9\n" "v_fma_f32 %6, %6, %8, %9\n" "v_exp_f32 %7, %7\n" ) : FS_ACC8 : "v"(b), "v"(c), "s"(sb), "s"(sm));
+    if constexpr (OP == P_FMA_SUB_MIN) asm volatile(FS_X8R("v_fma_f32 %0, %0, %8, %9\n" "v_sub_f32 %1, %1, %8\n" "v_min_f32 %2, %2, %9\n" "v_cmp_lt_f32 vcc, %3, %8\n" "v_fma_f32 %4, %4, %8, %9\n" "v_sub_f32 %5, %5, %8\n" "v_min_f32 %6, %6, %9\n" "v_cmp_lt_f32 vcc, %7, %8\n" ) : FS_ACC8 : "v"(b), "v"(c), "s"(sb), "s"(sm) : "vcc");
+    if constexpr (OP == P_FMA_LDS) asm volatile(FS_X8R("v_fma_f32 %0, %0, %9, %10\n" "v_fma_f32 %1, %1, %9, %10\n" "v_fma_f32 %2, %2, %9, %10\n" "v_fma_f32 %3, %3, %9, %10\n" "v_fma_f32 %4, %4, %9, %10\n" "v_fma_f32 %5, %5, %9, %10\n" "v_fma_f32 %6, %6, %9, %10\n" "ds_read_b128 %8, %11\n" ) "s_waitcnt lgkmcnt(0)\n" : FS_ACC8, "=v"(q[0]) : "v"(b), "v"(c), "v"(lds_addr_bc));
+    if constexpr (OP == P_FMAC_MAX) asm volatile(FS_X8R("v_fmac_f32 %0, %8, %9\n" "v_max_f32 %1, %1, %9\n" "v_fmac_f32 %2, %8, %9\n" "v_max_f32 %3, %3, %9\n" "v_fmac_f32 %4, %8, %9\n" "v_max_f32 %5, %5, %9\n" "v_fmac_f32 %6, %8, %9\n" "v_max_f32 %7, %7, %9\n" ) : FS_ACC8 : "v"(b), "v"(c), "s"(sb), "s"(sm));
+    if constexpr (OP == P_FMAC_FMA) asm volatile(FS_X8R("v_fmac_f32 %0, %8, %9\n" "v_fma_f32 %1, %1, %8, %9\n" "v_fmac_f32 %2, %8, %9\n" "v_fma_f32 %3, %3, %8, %9\n" "v_fmac_f32 %4, %8, %9\n" "v_fma_f32 %5, %5, %8, %9\n" "v_fmac_f32 %6, %8, %9\n" "v_fma_f32 %7, %7, %8, %9\n" ) : FS_ACC8 : "v"(b), "v"(c), "s"(sb), "s"(sm));
+    if constexpr (OP == P_FMAC_MUL_ADD) asm volatile(FS_X8R("v_fmac_f32 %0, %8, %9\n" "v_mul_f32 %1, %1, %8\n" "v_add_f32 %2, %2, %9\n" "v_mov_b32 %3, %8\n" "v_fmac_f32 %4, %8, %9\n" "v_mul_f32 %5, %5, %8\n" "v_add_f32 %6, %6, %9\n" "v_mov_b32 %7, %8\n" ) : FS_ACC8 : "v"(b), "v"(c), "s"(sb), "s"(sm));
+    if constexpr (OP == P_CMP_CND3) asm volatile(FS_X8R("v_cmp_lt_f32 vcc, %0, %8\n" "v_cndmask_b32 %1, %1, %9, vcc\n" "v_cndmask_b32 %2, %2, %9, vcc\n" "v_cndmask_b32 %3, %3, %9, vcc\n" "v_cmp_lt_f32 vcc, %4, %8\n" "v_cndmask_b32 %5, %5, %9, vcc\n" "v_cndmask_b32 %6, %6, %9, vcc\n" "v_cndmask_b32 %7, %7, %9, vcc\n" ) : FS_ACC8 : "v"(b), "v"(c), "s"(sb), "s"(sm) : "vcc");
+    if constexpr (OP == P_CMP_FMA_CND) asm volatile(FS_X8R("v_cmp_lt_f32 vcc, %0, %8\n" "v_fma_f32 %1, %1, %8, %9\n" "v_fma_f32 %2, %2, %8, %9\n" "v_fma_f32 %3, %3, %8, %9\n" "v_fma_f32 %4, %4, %8, %9\n" "v_cndmask_b32 %5, %5, %9, vcc\n" "v_fma_f32 %6, %6, %8, %9\n" "v_fma_f32 %7, %7, %8, %9\n" ) : FS_ACC8 : "v"(b), "v"(c), "s"(sb), "s"(sm) : "vcc");
+    if constexpr (OP == P_FMA_MAX2) asm volatile(FS_X8R("v_fma_f32 %0, %0, %8, %9\n" "v_fma_f32 %1, %1, %8, %9\n" "v_max_f32 %2, %2, %9\n" "v_max_f32 %3, %3, %9\n" "v_fma_f32 %4, %4, %8, %9\n" "v_fma_f32 %5, %5, %8, %9\n" "v_max_f32 %6, %6, %9\n" "v_max_f32 %7, %7, %9\n" ) : FS_ACC8 : "v"(b), "v"(c), "s"(sb), "s"(sm));
+    if constexpr (OP == P_FMA_MAX_1_3) asm volatile(FS_X8R("v_fma_f32 %0, %0, %8, %9\n" "v_max_f32 %1, %1, %9\n" "v_max_f32 %2, %2, %9\n" "v_max_f32 %3, %3, %9\n" "v_fma_f32 %4, %4, %8, %9\n" "v_max_f32 %5, %5, %9\n" "v_max_f32 %6, %6, %9\n" "v_max_f32 %7, %7, %9\n" ) : FS_ACC8 : "v"(b), "v"(c), "s"(sb), "s"(sm));
     if constexpr (OP == ATOM_ISSUE) asm volatile(FS_ATOM32 FS_ATOM32 : : "v"(goff), "v"(b), "s"(gp) : "memory");
 }
 
@@ -202,9 +292,12 @@ __global__ void __launch_bounds__(1024) chain(Stamp *stamps, float *sink, float 
     for (int i = 0; i < 8; ++i) a[i] = 1.0f + 1e-3f * (float)(lane + i);
 #pragma unroll
     for (int i = 0; i < 8; ++i) p[i] = f2{1.0f + 1e-3f * i, 1.0f - 1e-3f * lane}, q[i] = f4{0.f, 0.f, 0.f, 0.f};
-    const unsigned l0 = 64u, l1 = (unsigned)tid * 16u, bp = (unsigned)((lane ^ 17) * 4);
+    const unsigned l0 = 64u, l1 = (unsigned)tid * ((OP == LDS_B32) ? 4u : 16u), bp = (unsigned)((lane ^ 17) * 4);
     unsigned long long sg = 0;
     unsigned sg32 = 0;
+    const float sb = __builtin_amdgcn_readfirstlane(__float_as_uint(b)) ? 1.0001f : b;  // (an SGPR copy of b)
+    unsigned long long sm = 0x5555aaaa3333ccccull ^ (unsigned long long)reps, smw = sm;
+    asm volatile("s_mov_b64 %0, %0" : "+s"(sm));
     const f2 pb = f2{b, b}, pc = f2{c, c};
     // ATOM_ISSUE: wave w of block k owns 16 groups of 4 lines (4 KB); lane -> (row's line, own dword)
     float *gp;
@@ -222,14 +315,14 @@ __global__ void __launch_bounds__(1024) chain(Stamp *stamps, float *sink, float 
     const unsigned long long t0 = memtime();
     if constexpr (EXEC != EX_FULL) asm volatile("s_mov_b64 %0, exec\n s_mov_b64 exec, %1" : "=s"(saved) : "s"(M));
     for (int r = 0; r < reps; ++r) {
-        body<OP>(a, p, q, b, c, pb, pc, l0, l1, bp, sg, sg32, gp, goff);
+        body<OP>(a, p, q, b, c, pb, pc, l0, l1, bp, sg, sg32, gp, goff, sb, sm, smw);
     }
     if constexpr (EXEC != EX_FULL) asm volatile("s_mov_b64 exec, %0" : : "s"(saved));
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     const unsigned long long t1 = memtime();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const unsigned long long real1 = memrealtime();
-    float s = (float)(sg & 1) + (float)(sg32 & 1);
+    float s = (float)(sg & 1) + (float)(sg32 & 1) + (float)(smw & 1);
 #pragma unroll
     for (int i = 0; i < 8; ++i) s += a[i];
 #pragma unroll
@@ -480,6 +573,50 @@ int main(int argc, char **argv) {
         RUN(LDS_B32, EX_FULL);
         RUN(MIX_FMA_DPP, EX_FULL);
         RUN(MIX_FMA_EXP, EX_FULL);
+        RUN(G_SUB, EX_FULL);
+        RUN(G_FMAC, EX_FULL);
+        RUN(G_MIN, EX_FULL);
+        RUN(G_MUL_E64, EX_FULL);
+        RUN(G_ADD_NEG, EX_FULL);
+        RUN(G_FMA_SGPR, EX_FULL);
+        RUN(G_FMA_CONST, EX_FULL);
+        RUN(G_MUL_LIT, EX_FULL);
+        RUN(G_AND, EX_FULL);
+        RUN(G_OR, EX_FULL);
+        RUN(G_LSHL, EX_FULL);
+        RUN(G_ADDU, EX_FULL);
+        RUN(G_SUBU, EX_FULL);
+        RUN(G_ADDCO, EX_FULL);
+        RUN(G_CVT_F_I, EX_FULL);
+        RUN(G_CVT_I_F, EX_FULL);
+        RUN(G_MULLO, EX_FULL);
+        RUN(G_BFE, EX_FULL);
+        RUN(G_MED3, EX_FULL);
+        RUN(G_MAX3, EX_FULL);
+        RUN(G_LDEXP, EX_FULL);
+        RUN(G_SQRT, EX_FULL);
+        RUN(G_RSQ, EX_FULL);
+        RUN(G_MOV_DPP, EX_FULL);
+        RUN(G_MBCNT, EX_FULL);
+        RUN(G_CND_SGPR, EX_FULL);
+        RUN(G_CND_VCC_D, EX_FULL);
+        RUN(G_CND_E64_VCC, EX_FULL);
+        RUN(P_CMP_CND, EX_FULL);
+        RUN(P_CMPS_CNDS, EX_FULL);
+        RUN(P_FMA_MAX, EX_FULL);
+        RUN(P_FMA3_MAX, EX_FULL);
+        RUN(P_FMA_MUL_ADD, EX_FULL);
+        RUN(P_FMA_DPP_ALT, EX_FULL);
+        RUN(P_FMA7_EXP, EX_FULL);
+        RUN(P_FMA_SUB_MIN, EX_FULL);
+        RUN(P_FMA_LDS, EX_FULL);
+        RUN(P_FMAC_MAX, EX_FULL);
+        RUN(P_FMAC_FMA, EX_FULL);
+        RUN(P_FMAC_MUL_ADD, EX_FULL);
+        RUN(P_CMP_CND3, EX_FULL);
+        RUN(P_CMP_FMA_CND, EX_FULL);
+        RUN(P_FMA_MAX2, EX_FULL);
+        RUN(P_FMA_MAX_1_3, EX_FULL);
         // EXEC dependence
         RUN(FMA, EX_LOW32);
         RUN(FMA, EX_EVEN);

@@ -15,10 +15,8 @@ import re
 import sys
 
 root = sys.argv[1]
-OPS = ["v_fma_f32", "v_fma_f32 dep", "v_mul_f32", "v_add_f32", "v_max_f32", "v_exp_f32", "v_rcp_f32", "v_log_f32", "dpp row_shr",
-       "dpp row_bcast15", "dpp quad_perm", "v_permlane32_swap", "v_permlane16_swap", "v_cndmask", "v_cmp vcc", "v_cmp sgpr",
-       "v_pk_fma_f32", "v_pk_mul_f32", "v_mov_b32", "v_readlane", "ds_bpermute", "ds_swizzle", "ds_read_b128 bc", "ds_read_b32 bc",
-       "ds_read_b128", "ds_read_b32", "mix fma:dpp", "mix fma:exp 3:1", "global_atomic issue"]
+_src = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "valu_rate.hip")).read()
+OPS = re.findall(r'"([^"]*)"', _src[_src.index("kOpName[N_OPS] = {"):_src.index("};", _src.index("kOpName[N_OPS] = {"))])
 EXEC = ["full", "low32", "even", "low16", "one", "EMPTY", "row15"]
 PATS = ["atomic 15 lanes/row -> line", "atomic 16 lanes/row -> line", "atomic 64 lanes -> 64 lines", "atomic 64 lanes -> 256 B",
         "atomic 64 lanes -> 1 address", "store 16 B/lane", "store 4 B/lane", "store row15 pattern", "load 16 B/lane"]
@@ -43,7 +41,9 @@ for k in sorted(acc):
     op, ex = int(m.group(1)), int(m.group(2))
     d = {c: sum(v) / len(v) for c, v in acc[k].items()}
     n = WAVES * REPS_QUICK * UNROLL
-    line = "%-22s %-6s" % (OPS[op], EXEC[ex])
+    if op == OPS.index("global_atomic_add_f32 (issue)"):
+        n //= 16
+    line = "%-32s %-6s" % (OPS[op], EXEC[ex])
     for c in sorted(d):
         line += "  %s=%.4g (%.3f/inst)" % (c, d[c], d[c] / n)
     print(line)
