@@ -57,11 +57,15 @@ class StepPlan(C.Structure):
         ("order_counters", _p), ("bwd_order", _p), ("order_shift", _i),
         ("ssim_maps", _p), ("ssim_sums", _p), ("ssim_rows", _i64), ("aux_rows", _i64),
         ("g_l1", _f), ("g_ssim", _f), ("ssim_lambda", _f), ("v_rgb", _p), ("loss_out", _p),
+        ("loss_kind", _i), ("mask", _p), ("sensor_depth", _p), ("depth_tol", _f), ("w_aux", _f * 7), ("fa_flags", _i),
+        ("fa_partial", _p), ("fa_rows", _i64), ("ms_partial", _p), ("ms_rows", _i64), ("g_min", _f),
+        ("n_touch", _i), ("touch_idx", _p), ("touch_normals", _p), ("touch_partial", _p), ("touch_rows", _i64),
+        ("g_touch", _f),
         ("v_packed", _p), ("replica_rows", _i64), ("dispatch_stride", _i),
         ("absgrad", _p), ("xys_grad_norm", _p), ("vis_counts", _p), ("max_2Dsize", _p),
         ("inv_max_hw", _f), ("frozen", _p),
         ("adam", AdamGroups), ("min_scale_g", _f), ("gsb_flags", _i),
-        ("ev_before", _p * 8), ("ev_after", _p * 8),
+        ("ev_before", _p * 9), ("ev_after", _p * 9),
         ("armed", _i), ("wait_ns", _i64),
     ]
 

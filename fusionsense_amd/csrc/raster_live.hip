@@ -64,6 +64,14 @@ __device__ __forceinline__ void load_rec(Rec &r, const float4 *__restrict__ rec,
 #define FSGS_BWD_WAVES 4
 #endif
 constexpr int kBwdWaves = FSGS_BWD_WAVES;
+// waves per SIMD the register allocator aims at (78 VGPRs -> 6).  Round 6, measured (make EXTRA=-DFSGS_BWD_OCC=n, config #2,
+// it/s of two runs each): 5 -> 2043 / 2059, 6 -> 2040 / 2042, 7 (5 spills) -> 2033 / 2018, 8 (13 spills) -> 1994 / 1989 — and
+// a software-pipelined walk (the next step's list entry and record loaded from LDS one step ahead, +12 v_mov per step, 89-95
+// VGPRs at 5 waves): 2053 / 2043 and 2041 / 2043 against 2049 / 2045: the walk is bound by vector ISSUE, not
+// by the latency of its LDS reads.
+#ifndef FSGS_BWD_OCC
+#define FSGS_BWD_OCC 6
+#endif
 // waves per SIMD the register allocator aims at (78 VGPRs -> 6; A/B: make EXTRA=-DFSGS_BWD_OCC=n)
 #ifndef FSGS_BWD_OCC
 #define FSGS_BWD_OCC 6

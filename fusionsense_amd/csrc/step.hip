@@ -19,8 +19,15 @@ inline int bad_plan(const fsgs_step_plan *p) {
     if (!p->tiles_per_gauss || !p->isect_offsets || !p->bucket_base || !p->tile_cursor || !p->buckets || !p->next_bucket_base) return 1;
     if (!p->mapped || !p->packed || !p->normals_world || !p->zero_cells || !p->payload) return 1;
     if (!p->render || !p->alphas || !p->last_ids || !p->render_extra || !p->records || !p->n_rec || !p->seg_state || !p->seg_split) return 1;
-    if (!p->rgb || !p->depth || !p->normal || !p->gt_rgb || !p->gt_depth || !p->seed || !p->aux_partial || !p->v_depth_img) return 1;
-    if (p->gt_normal && !p->v_normal_img) return 1;
+    if (!p->rgb || !p->depth || !p->normal || !p->gt_rgb || !p->seed || !p->v_depth_img) return 1;
+    if (p->loss_kind == 0) {
+        if (!p->gt_depth || !p->aux_partial || (p->gt_normal && !p->v_normal_img)) return 1;
+    } else if (p->loss_kind == 1) {
+        if (!p->sensor_depth || !p->fa_partial || !p->v_normal_img) return 1;
+        if (p->n_touch < 0 || (p->n_touch > 0 && (!p->touch_idx || !p->touch_normals || !p->touch_partial))) return 1;
+    } else {
+        return 1;
+    }
     if (!p->ssim_maps || !p->ssim_sums || !p->v_rgb || !p->loss_out || !p->v_packed || !p->absgrad) return 1;
     if (p->adam.n_groups != 6) return 1;
     if (p->bwd_order && (!p->bwd_queue || !p->order_counters)) return 1;
@@ -86,19 +93,35 @@ extern "C" int fsgs_step_forward(fsgs_step_plan *p, fsgs_stream_t stream) {
                               stream);
     }
     if (rc) return rc;
+    const bool fusion = p->loss_kind == 1;
     {
     Hook h(p, hs, 3);
     rc = fsgs_epilogue_fwd_order(P, p->render, p->alphas, p->render_extra, p->background, p->max_last, p->n_cells, p->rgb, p->depth,
-                                 p->normal, p->gt_depth, p->gt_normal, p->seed, p->g_depth, p->g_normal, p->aux_partial,
-                                 p->v_depth_img, p->gt_normal ? p->v_normal_img : nullptr, p->bwd_order ? p->n_rec : nullptr,
+                                 p->normal, fusion ? nullptr : p->gt_depth, fusion ? nullptr : p->gt_normal,
+                                 fusion ? nullptr : p->seed, fusion ? 0.f : p->g_depth, fusion ? 0.f : p->g_normal,
+                                 fusion ? nullptr : p->aux_partial, fusion ? nullptr : p->v_depth_img,
+                                 (fusion || !p->gt_normal) ? nullptr : p->v_normal_img, p->bwd_order ? p->n_rec : nullptr,
                                  p->bwd_order ? p->seg_split : nullptr, p->bwd_order ? p->order_counters : nullptr, p->bwd_order,
                                  p->bwd_order ? p->order_shift : 0, p->bwd_order ? tw : 0, p->bwd_order ? th : 0, stream);
     }
     if (rc) return rc;
     float *maps = p->ssim_maps;
     const int64_t plane = P * 3;
+    if (!fusion) {
+        Hook h(p, hs, 4);
+        return fsgs_ssim_l1_fwd(H, W, p->rgb, p->gt_rgb, maps, maps + plane, maps + 2 * plane, p->ssim_sums, stream);
+    }
+    {
     Hook h(p, hs, 4);
-    return fsgs_ssim_l1_fwd(H, W, p->rgb, p->gt_rgb, maps, maps + plane, maps + 2 * plane, p->ssim_sums, stream);
+    rc = fsgs_ssim_l1_fwd_masked(H, W, p->rgb, p->gt_rgb, p->mask, maps, maps + plane, maps + 2 * plane, p->ssim_sums, stream);
+    }
+    if (rc) return rc;
+    // the depth / normal terms with their gradient images (the seed is known) + the min-scale and touch-normal partial sums
+    Hook h(p, hs, 8);
+    return fsgs_fusion_aux_loss_riders(H, W, p->depth, p->normal, p->gt_rgb, p->sensor_depth, p->gt_normal, p->mask, p->depth_tol,
+                                       p->w_aux, p->seed, p->fa_partial, p->v_depth_img, p->v_normal_img, p->fa_flags,
+                                       p->ms_partial ? p->n : 0, p->log_scales, p->ms_partial, p->n_touch, p->touch_idx,
+                                       p->normals_world, p->touch_normals, p->touch_partial, stream);
 }
 
 extern "C" int fsgs_step_backward(fsgs_step_plan *p, int64_t spin_limit, int64_t *n_live_out, fsgs_stream_t stream) {
@@ -128,22 +151,39 @@ extern "C" int fsgs_step_backward(fsgs_step_plan *p, int64_t spin_limit, int64_t
     const int64_t P = (int64_t)W * H;
     float *maps = p->ssim_maps;
     const int64_t plane = P * 3;
-    const float *partials[2] = {p->ssim_sums, p->aux_partial};
-    const int64_t rows[2] = {p->ssim_rows, p->aux_rows};
-    const float weights[4] = {p->g_l1, p->g_ssim, p->g_depth, p->g_normal};
     hipStream_t hs = fsgs::as_stream(stream);
     int rc;
-    {
-    Hook h(p, hs, 5);
-    rc = fsgs_ssim_l1_bwd_combine(H, W, p->rgb, p->gt_rgb, maps, maps + plane, maps + 2 * plane, p->seed, p->g_l1, p->g_ssim,
+    const bool fusion = p->loss_kind == 1;
+    if (!fusion) {
+        const float *partials[2] = {p->ssim_sums, p->aux_partial};
+        const int64_t rows[2] = {p->ssim_rows, p->aux_rows};
+        const float weights[4] = {p->g_l1, p->g_ssim, p->g_depth, p->g_normal};
+        Hook h(p, hs, 5);
+        rc = fsgs_ssim_l1_bwd_combine(H, W, p->rgb, p->gt_rgb, maps, maps + plane, maps + 2 * plane, p->seed, p->g_l1, p->g_ssim,
                                       p->v_rgb, 2, partials, rows, weights, p->ssim_lambda, p->loss_out, stream);
+    } else {
+        // every partial-sum column's weight in get_loss_dict's total (ops.fusion_loss_weights), combined by the SSIM backward
+        const float *partials[4];
+        int64_t rows[4];
+        int cols[4];
+        float weights[2 + 8 + 2 + 2];
+        int n = 0, nw = 0;
+        partials[n] = p->ssim_sums; rows[n] = p->ssim_rows; cols[n] = 2; weights[nw++] = p->g_l1; weights[nw++] = p->g_ssim; ++n;
+        partials[n] = p->fa_partial; rows[n] = p->fa_rows; cols[n] = 8;
+        for (int k = 0; k < 7; ++k) weights[nw++] = p->w_aux[k];
+        weights[nw++] = 0.f; ++n;
+        if (p->ms_partial) { partials[n] = p->ms_partial; rows[n] = p->ms_rows; cols[n] = 2; weights[nw++] = p->g_min; weights[nw++] = 0.f; ++n; }
+        if (p->n_touch > 0) { partials[n] = p->touch_partial; rows[n] = p->touch_rows; cols[n] = 2; weights[nw++] = p->g_touch; weights[nw++] = 0.f; ++n; }
+        Hook h(p, hs, 5);
+        rc = fsgs_ssim_l1_bwd_masked(H, W, p->rgb, p->gt_rgb, p->mask, maps, maps + plane, maps + 2 * plane, p->seed, p->g_l1,
+                                     p->g_ssim, p->v_rgb, n, partials, rows, cols, weights, p->ssim_lambda, p->loss_out, stream);
     }
     if (rc) return rc;
     {
     Hook h(p, hs, 6);
     rc = fsgs_raster_bwd_quad_images(p->records, p->n_rec, p->isect_offsets, p->capacity, W, H, tw, th, p->render, p->alphas,
                                      p->last_ids, p->render_extra, p->background, p->v_rgb, p->v_depth_img,
-                                     p->gt_normal ? p->v_normal_img : nullptr, nullptr, p->seg_state, 1, p->v_packed,
+                                     (fusion || p->gt_normal) ? p->v_normal_img : nullptr, nullptr, p->seg_state, 1, p->v_packed,
                                      p->replica_rows, p->dispatch_stride, p->seg_split, p->bwd_queue,
                                      p->bwd_queue ? p->bwd_queue_items : 0, p->bwd_order, stream);
     }
@@ -152,7 +192,7 @@ extern "C" int fsgs_step_backward(fsgs_step_plan *p, int64_t spin_limit, int64_t
     return fsgs_gauss_sh_bwd_adam(p->n, p->sh_degree, p->means, p->campos, p->features_dc, p->features_rest, p->quats,
                                   p->log_scales, p->scales_exp, p->opac_sig, p->viewmat, p->K, p->c2w, W, H, 0.3f, p->radii,
                                   p->conics, p->v_packed, p->absgrad, p->xys_grad_norm, p->vis_counts, p->max_2Dsize,
-                                  p->inv_max_hw, p->frozen, p->replica_rows, &p->adam, p->min_scale_g, p->gsb_flags, stream);
+                                  p->inv_max_hw, p->frozen, p->replica_rows, &p->adam, fusion ? p->g_min : p->min_scale_g, p->gsb_flags, stream);
 }
 
 extern "C" int fsgs_step_run(fsgs_step_plan *p, int64_t spin_limit, int64_t *n_live_out, fsgs_stream_t stream) {

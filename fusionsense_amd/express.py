@@ -34,7 +34,7 @@ from ._lib import StepPlan, check, load, stream_ptr
 SPIN_LIMIT = 50_000_000  # polls of the mapped flag before the call falls back to a stream synchronise (~ seconds)
 # launch names as ops.TIMER / bench.py know them (the per-op route's span names), in the order of the step
 LAUNCHES = ("isect_count_live", "tile_sort", "raster_fwd_quad_d4e3", "epilogue_fwd", "ssim_l1_fwd", "ssim_l1_bwd",
-            "raster_bwd_quad_d4e3", "gaussian_bwd")
+            "raster_bwd_quad_d4e3", "gaussian_bwd", "fusion_aux_loss")
 
 
 def fused_param_order():
@@ -91,6 +91,9 @@ class ExpressStep:
         self.aux_partial = torch.empty(self.aux_rows, 2, **f32)
         self.v_depth_img = torch.empty(H, W, 1, **f32)
         self.v_normal_img = torch.empty(H, W, 3, **f32) if has_normal else None
+        # get_loss_dict's terms (loss_kind 1): the depth / normal columns, the min-scale and the touch-normal partial sums
+        self.fa_rows = int(lib.fsgs_fusion_aux_num_partials(H, W))
+        self.fa_partial = self.ms_partial = self.touch_partial = None  # (made on the first FrameBatch step)
         self.v_rgb = torch.empty(H, W, 3, **f32)
         self.v_packed = fused._grad_accumulator(dev, N)
         self.rep_rows = N if fused._grad_lines(N) > 1 else 0
@@ -172,9 +175,11 @@ class ExpressStep:
 
     def run(self, trainer, camera, target: Dict[str, Tensor], hist: dict, stats: Optional[dict], frozen: Optional[Tensor],
             binary_threshold: Optional[float], adam, sh_degree: int, seed: Tensor, ssim_lambda: float = 0.2,
-            w_depth: float = 0.2, w_normal: float = 0.1):
+            w_depth: float = 0.2, w_normal: float = 0.1, fusion=None):
         """One step.  Returns (overflowed: bool, n_live, loss 0-d tensor, outputs dict).  On overflow nothing with side
-        effects has run except the binary-opacity write of launch 1 (the caller's redo must not threshold again)."""
+        effects has run except the binary-opacity write of launch 1 (the caller's redo must not threshold again).
+        ``fusion`` = (LossConfig, touch_idx, touch_normals): ``target`` is a prepared FrameBatch and the loss is
+        get_loss_dict's (the terms ops._FusionLoss evaluates for FusionSense's configuration); None: the benchmark loss."""
         lib = load()
         dev = trainer.device
         fr = self.frames[self.turn]
@@ -203,15 +208,49 @@ class ExpressStep:
         else:
             p.tail_scratch, p.tail_scratch_bytes, p.tail_items, p.tail_epoch = None, 0, 0, 0
         p.handoff_records, p.handoff_rel_len = int(handoff), int(fused.FWD_WALK.handoff_rel_len)
-        # targets and loss weights (ops._TrainLoss with the epilogue's riding L1 terms)
-        n_pix = W * H
-        gt_n = target.get("normal")
-        p.gt_rgb, p.gt_depth, p.gt_normal, p.seed = _p(target["rgb"]), _p(target["depth"]), _p(gt_n), _p(seed)
-        p.g_depth = float(w_depth) / n_pix
-        p.g_normal = float(w_normal) / (3.0 * n_pix) if gt_n is not None else 0.0
-        p.g_l1 = (1.0 - ssim_lambda) / (3.0 * H * W)
-        p.g_ssim = -ssim_lambda / (3.0 * (H - 10) * (W - 10))
-        p.ssim_lambda = float(ssim_lambda)
+        p.seed = _p(seed)
+        if fusion is None:
+            # targets and loss weights of the benchmark loss (ops._TrainLoss with the epilogue's riding L1 terms)
+            n_pix = W * H
+            gt_n = target.get("normal")
+            p.loss_kind = 0
+            p.gt_rgb, p.gt_depth, p.gt_normal = _p(target["rgb"]), _p(target["depth"]), _p(gt_n)
+            p.g_depth = float(w_depth) / n_pix
+            p.g_normal = float(w_normal) / (3.0 * n_pix) if gt_n is not None else 0.0
+            p.g_l1 = (1.0 - ssim_lambda) / (3.0 * H * W)
+            p.g_ssim = -ssim_lambda / (3.0 * (H - 10) * (W - 10))
+            p.ssim_lambda = float(ssim_lambda)
+        else:
+            # get_loss_dict (ops._FusionLoss, default terms): ``target`` is the view's FrameBatch
+            cfg, touch_idx, touch_normals = fusion
+            fb = target
+            n_touch = 0 if touch_idx is None else int(touch_idx.numel())
+            (g_l1, g_ssim), w_aux, g_min, g_touch = ops.fusion_loss_weights(cfg, fb, self.N, n_touch)
+            flags = ops.fusion_aux_flags(cfg)
+            if fb.normal is None:
+                flags &= ~1
+            f32 = dict(dtype=torch.float32, device=dev)
+            if self.fa_partial is None:
+                self.fa_partial = torch.empty(self.fa_rows, 8, **f32)
+                self.ms_partial = torch.empty((self.N + 255) // 256, 2, **f32)
+            if n_touch > 0 and (self.touch_partial is None or self.touch_partial.shape[0] != (n_touch + 255) // 256):
+                self.touch_partial = torch.empty((n_touch + 255) // 256, 2, **f32)
+            p.loss_kind = 1
+            p.gt_rgb, p.gt_depth, p.gt_normal = _p(fb.image), None, _p(fb.normal)
+            p.mask, p.sensor_depth, p.depth_tol, p.fa_flags = _p(fb.mask), _p(fb.sensor_depth), float(cfg.depth_tolerance), int(flags)
+            for k in range(7):
+                p.w_aux[k] = float(w_aux[k])
+            p.fa_partial, p.fa_rows = _p(self.fa_partial), self.fa_rows
+            p.ms_partial = _p(self.ms_partial) if g_min != 0.0 else None
+            p.ms_rows, p.g_min = (self.N + 255) // 256, float(g_min)
+            p.n_touch = n_touch
+            p.touch_idx = _p(touch_idx) if n_touch > 0 else None
+            self._touch_normals = touch_normals.contiguous() if n_touch > 0 else None  # (kept alive for the launch)
+            p.touch_normals = _p(self._touch_normals)
+            p.touch_partial = _p(self.touch_partial) if n_touch > 0 else None
+            p.touch_rows, p.g_touch = (n_touch + 255) // 256, float(g_touch)
+            p.g_l1, p.g_ssim, p.ssim_lambda = float(g_l1), float(g_ssim), float(cfg.ssim_lambda)
+            p.g_depth = p.g_normal = 0.0
         # after_train statistics, touch anchors, Adam
         if stats is not None and stats["xys_grad_norm"].shape[0] == self.N:
             p.xys_grad_norm, p.vis_counts, p.max_2Dsize = (_p(stats["xys_grad_norm"]), _p(stats["vis_counts"]),
@@ -264,13 +303,15 @@ class ExpressStep:
     # -- bench.py's kernel timer (ops.TIMER): HIP events around the launches it asks for, recorded by the library ----------
     def _arm_timer(self, p: StepPlan):
         t = ops.TIMER
-        for k in range(8):
+        for k in range(9):
             p.ev_before[k] = None
             p.ev_after[k] = None
         if not t.enabled:
             return None
         timed = []
         for k, name in enumerate(LAUNCHES):
+            if k == 8 and p.loss_kind != 1:
+                continue
             if t.only is not None and not name.startswith(t.only):
                 continue
             if t.every > 1:
@@ -288,6 +329,6 @@ class ExpressStep:
     def _file_timer(self, p: StepPlan, timed) -> None:
         for name, a, b in timed:
             ops.TIMER.records.append((name, a, b, 0.0))
-        for k in range(8):
+        for k in range(9):
             p.ev_before[k] = None
             p.ev_after[k] = None

@@ -741,8 +741,20 @@ class SplatTrainer:
         """The conditions of fused._FusedGetOutputs' count-free route (``use_fill``) + the benchmark loss + nothing
         pending: everything else keeps the per-op route."""
         from . import fused, ops
-        if not self.express or is_fb or factors is not None or zin is not None or self._pending is not None:
+        if not self.express or factors is not None or zin is not None or self._pending is not None:
             return False
+        if is_fb:
+            # get_loss_dict: the terms ops._FusionLoss evaluates for FusionSense's configuration; a second depth target,
+            # the cosine term and normals from depth keep the per-op route
+            cfg, fb = self.loss_cfg, target
+            if (ops.mono_depth_weights(cfg, fb) is not None or getattr(cfg, "normal_supervision", "mono") == "depth"
+                    or (cfg.use_normal_loss and getattr(cfg, "use_normal_cosine_loss", False))):
+                return False
+            for t in (fb.image, fb.sensor_depth, fb.normal, fb.mask):
+                if t is not None and (not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous()):
+                    return False
+            if fb.width != camera.width or fb.height != camera.height:
+                return False
         if self.half_attributes or not (fused.BIN_FILL and fused.SH_RIDES_WITH_SCAN and fused.ONE_LAUNCH_GAUSSIAN_BWD
                                         and fused.IMAGE_GRADS_IN_BWD and fused.FWD_TILE_ORDER and ops.USE_BIN_LIVE
                                         and ops.BIN_FILL_SORT_ORDER and ops.FILL_WAIT_ON_FLAG and ops.DEFER_COMBINE):
@@ -755,6 +767,8 @@ class SplatTrainer:
         tiles = math.ceil(camera.width / 16) * math.ceil(camera.height / 16)
         if tiles > self._bin_live_max_tiles() or ops.bin_live_is_dense(self.device, N, tiles):
             return False
+        if is_fb:
+            return True
         for k in ("rgb", "depth"):
             t = target.get(k)
             if t is None or not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous():
@@ -836,7 +850,7 @@ class SplatTrainer:
             express_done = False
             if use_express:
                 from .ops import bin_fill_words
-                ex = self._express_step(camera, cap, "normal" in target)
+                ex = self._express_step(camera, cap, True if is_fb else "normal" in target)
                 if bin_fill_words(int(bin_hist["n_live"]), ex.T) > ex.words:  # (a view last seen under a larger model)
                     use_express = False
                     aib = self._fused_adam_step(PARAM_ORDER, aib_step, as_groups=True)
@@ -845,7 +859,8 @@ class SplatTrainer:
                 for k, name in enumerate(PARAM_ORDER):
                     ex.adam.lr[k] = float(self.optimizers[name].param_groups[0]["lr"])
                 over, n_live_x, loss, out = ex.run(self, camera, target, bin_hist, stats, frozen, bthr, ex.adam,
-                                                   self._sh_degree_now(), self._one)
+                                                   self._sh_degree_now(), self._one,
+                                                   fusion=((self.loss_cfg,) + self._touch_rows()) if is_fb else None)
                 if over:  # the frame outgrew its lists / a bucket: once more through the exact two-pass route (below)
                     self.live_overflows += 1
                     self._bin_hist.pop(bin_key, None)

@@ -965,6 +965,20 @@ typedef struct fsgs_step_plan {
     /* -- launches 5-6: SSIM + L1 on rgb, loss value -- */
     float *ssim_maps /* [3,H,W,3] */, *ssim_sums; int64_t ssim_rows, aux_rows;
     float g_l1, g_ssim, ssim_lambda; float *v_rgb, *loss_out /* [1] [frame] */;
+    /* -- loss_kind = 1: get_loss_dict's default terms (dn_model.py:673-925 with FusionSense's switches: masked L1 + SSIM
+     *    on rgb, EdgeAwareLogL1 / L1 / LogL1 / MSE + TV on the depth, L1 + TV on the normals, the min-scale term, the
+     *    touch-normal MSE) instead of the benchmark loss: launch 4 then forms the images only, launch 5 is
+     *    fsgs_ssim_l1_fwd_masked (gt_rgb = the view's image), one more launch — fsgs_fusion_aux_loss_riders (hook 8) —
+     *    leaves the depth / normal gradient images (seed known) and the riders' partial sums, launch 6 is
+     *    fsgs_ssim_l1_bwd_masked with the combine of all partial sums, and launch 8 carries min_scale_g.  gt_depth,
+     *    g_depth, g_normal, aux_partial are not used.  (Mono depth, the cosine term and normals-from-depth keep the
+     *    per-op route.) -- */
+    int32_t loss_kind;
+    const float *mask /* nullable [H,W] */, *sensor_depth /* [H,W] */;
+    float depth_tol; float w_aux[7]; int32_t fa_flags;
+    float *fa_partial; int64_t fa_rows;               /* [fa_rows, 8], fa_rows = fsgs_fusion_aux_num_partials(H, W) */
+    float *ms_partial /* nullable: no min-scale term */; int64_t ms_rows; float g_min;
+    int32_t n_touch; const int64_t *touch_idx; const float *touch_normals; float *touch_partial; int64_t touch_rows; float g_touch;
     /* -- launch 7: compositing backward -- */
     float *v_packed; int64_t replica_rows; int32_t dispatch_stride;
     /* -- launch 8: per-Gaussian backward + after_train statistics + Adam -- */
@@ -972,9 +986,10 @@ typedef struct fsgs_step_plan {
     float inv_max_hw; const uint8_t *frozen /* nullable */;
     fsgs_adam_groups adam; float min_scale_g; int32_t gsb_flags;
     /* -- optional timing hooks: hipEvent_t handles (as void *) recorded on `stream` right before / behind launch k
-     *    (k = 0..7 in the order above: project+bin, sorts, forward, epilogue, SSIM fwd | SSIM bwd, backward, per-Gaussian);
+     *    (k = 0..7 in the order above: project+bin, sorts, forward, epilogue, SSIM fwd | SSIM bwd, backward, per-Gaussian;
+     *    k = 8: loss_kind 1's fsgs_fusion_aux_loss_riders, which runs behind launch 5);
      *    NULL = none.  A recorded event costs the GPU ~6 us of idle time in front of the next launch. -- */
-    void *ev_before[8], *ev_after[8];
+    void *ev_before[9], *ev_after[9];
     /* -- written by the calls -- */
     int32_t armed;   /* 1 between fsgs_step_forward and fsgs_step_backward */
     int64_t wait_ns; /* fsgs_step_backward: host time spent waiting for the frame's verdict (the rest of a call is issue time) */

@@ -131,6 +131,10 @@ def test_step_plan_layout_matches_the_c_compiler(tmp_path):
             assert int(v[0]) == getattr(StepPlan, k).offset, k
             seen += 1
     assert seen == len(names)
+    # ... and the built library was compiled from this header (a stale libfsgs.so would be refused by load() only if its
+    # ABI number differs: the block's size catches an edit of the header that forgot the number)
+    from fusionsense_amd import _lib
+    assert int(_lib.load().fsgs_step_plan_bytes()) == C.sizeof(StepPlan)
 
 
 def test_header_is_plain_c_and_links(tmp_path):
