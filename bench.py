@@ -129,6 +129,10 @@ def parse():
     ap.add_argument("--sort-order", type=int, default=None, help="A/B: 0 = the in-tile sorts in tile order")
     ap.add_argument("--bwd-order", type=int, default=None, help="A/B: 0 = the backward's quadrants in the size rule's order")
     ap.add_argument("--bin-fill", type=int, default=None, help="A/B: 0 = two-pass binning on every frame")
+    ap.add_argument("--densify", action="store_true",
+                    help="config 2: run the schedule's refinements (split / dup / cull every 100 steps from step 600 on) "
+                         "inside the timed region, e.g. --steps 300: the count-free binning's hit rate over an epoch with "
+                         "densification (binning_frames, live_list_overflows) instead of over frozen model sizes")
     ap.add_argument("--express", type=int, default=None, choices=[0, 1],
                     help="A/B: 0 = every step launch by launch from Python (no fsgs_step_run)")
     ap.add_argument("--bwd-queue", type=int, default=None, help="A/B: queue positions for the backward's extra workgroups")
@@ -176,7 +180,7 @@ def cpu_baseline_worker(n_gauss: int, res: int, crop: int, threads: int, n_views
         "value": round(frac / dt, 6),
         "unit": "iters/s (full-frame equivalent)",
         "cores": threads,
-        "kind": "port",
+        "kind": "port, extrapolated from crop",
         "config1_full_iters_per_s": round(1.0 / t_cfg1, 4),
         "sample": f"oracle fwd+bwd, config #2: median of {n_views} views, central {crop}x{crop} crop of {res}x{res} "
                   f"({frac:.4f} of the pixels; {', '.join(f'{t:.1f}' for t in times)} s) scaled by pixel count; "
@@ -334,8 +338,12 @@ def build_workload(args, dev):
         W = H = args.res
         cams = scenes.hemisphere_cameras(args.views, width=W, height=H, focal=1111.11 * args.res / 800.0, seed=0)
         params = scenes.lego_like_scene(args.n_gauss, seed=0)
-        strategy = DensifyStrategy(SplatfactoConfig(), num_train_data=args.views, stats_only=True)
+        # (stats_only: the statistics of after_train are kept every step, the refinement itself is not run — unless
+        # --densify asks for the real schedule; the scene then starts 600 steps in, behind the warm-up of dn_model.py:116)
+        strategy = DensifyStrategy(SplatfactoConfig(), num_train_data=args.views, stats_only=not args.densify)
         trainer = SplatTrainer(params, dev, sh_degree=3, strategy=strategy, seed=0, fused=fused)
+        if args.densify:
+            w.update(start_step=600)
         tgt = SplatTrainer(scenes.lego_like_scene(args.n_gauss, seed=1), dev, sh_degree=3, fused=fused)
         targets = [{k: t[k] for k in ("rgb", "depth", "normal")} for t in render_targets(tgt, cams)]
         w.update(name=f"BASELINE config #2: synthetic lego-like, {args.n_gauss} Gaussians, {W}x{H}, SH deg 3, "
@@ -1068,7 +1076,7 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 3),
+            "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -1094,6 +1102,11 @@ def main():
                        "launched_by": ("bench.py (child torch.distributed.run)" if os.environ.get("FSGS_BENCH_SPAWNED")
                                        else ("external launcher" if "WORLD_SIZE" in os.environ else "single process")),
                        "comm_bytes_per_step_per_rank": getattr(trainer, "comm_bytes_last_step", 0) if grouped else 0},
+            # row (e) of SURVEY.md 8: this line is ONE point of the 1 / 2 / 4 / 8-GPU curve the driver measures; no N > 1 RCCL
+            # run exists in this repository's own records (the development pool has one GPU per box) — the efficiencies
+            # in DESIGN.md 6 are sized from link figures, not measured
+            "multi_gpu_curve": ("this line is one point of it" if world > 1 else
+                                "unmeasured by the builder (1-GPU pool): see the driver's SCALE record"),
             "rendered_mpix_per_s": round(world * P / t_fwd / 1e6, 2),
             "fwd_ms": round(t_fwd * 1e3, 3),
             "iters_per_s_excl_optimizer": round(world / t_noopt, 3),

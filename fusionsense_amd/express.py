@@ -5,9 +5,10 @@ calls with 20-45 converted arguments each, the autograd-free contexts — 0.43-0
 runs in 0.49 ms (config #2), so the host is never ahead and every hiccup of it is a GPU bubble.  Here the same launches,
 with the same arguments, are enqueued by ``fsgs_step_run`` from one argument block that lives across steps:
 
-* every buffer of a frame is allocated once per (model size, frame shape, list capacity) and reused — the frame's
-  OUTPUTS (images, projection results, lists) exist twice and alternate, so a frame's outputs stay valid until the
-  next-but-one step (comparing two consecutive steps' outputs works as it does with fresh tensors);
+* every internal buffer of a frame is allocated once per (model size, frame shape, list capacity) and reused; what a
+  caller may keep — the loss scalar and the rgb / depth / normal / accumulation images — are fresh tensors every step, as
+  on the per-op route; the frame's side outputs (``info``: projection results, lists, ``absgrad`` ...) exist twice and
+  alternate, so they stay valid until the next-but-one step (comparing two consecutive steps works as it does there);
 * per step only what changes is written into the block: the camera's and targets' pointers, the view's bucket room,
   the Adam step number and the means' learning rate, the statistics' pointers;
 * the one host wait of the step (the live total / bucket-overflow verdict, in mapped memory) happens inside the call,
@@ -107,9 +108,7 @@ class ExpressStep:
                       means2d=torch.empty(1, N, 2, **f32), depths=torch.empty(1, N, **f32), conics=torch.empty(1, N, 3, **f32),
                       tpg=torch.empty(1, N, **i32), offsets=torch.empty(T + 1, **i32), normals_world=torch.empty(N, 3, **f32),
                       payload=torch.empty(self.capacity, **i32), render=torch.empty(1, H, W, 4, **f32),
-                      alphas=torch.empty(1, H, W, 1, **f32), last_ids=torch.empty(1, H, W, **i32),
-                      render_extra=torch.empty(1, H, W, 3, **f32), rgb=torch.empty(H, W, 3, **f32),
-                      depth=torch.empty(H, W, 1, **f32), normal=torch.empty(H, W, 3, **f32), loss=torch.empty((), **f32),
+                      last_ids=torch.empty(1, H, W, **i32), render_extra=torch.empty(1, H, W, 3, **f32),
                       absgrad=torch.empty(1, N, 2, **f32),
                       mapped=torch.zeros(4, dtype=torch.int32).pin_memory())
             fr["mapped_np"] = fr["mapped"].numpy()
@@ -140,18 +139,17 @@ class ExpressStep:
         p.zero_cells, p.n_zero, p.max_last = _p(self.max_last), int(self.max_last.numel()), _p(self.max_last)
         p.tile_order = _p(self.tile_order) if ops.BIN_FILL_SORT_ORDER else None
         p.payload = _p(fr["payload"])
-        p.render, p.alphas, p.last_ids, p.render_extra = (_p(fr["render"]), _p(fr["alphas"]), _p(fr["last_ids"]),
-                                                          _p(fr["render_extra"]))
+        p.render, p.last_ids, p.render_extra = _p(fr["render"]), _p(fr["last_ids"]), _p(fr["render_extra"])
         p.records, p.n_rec, p.seg_state, p.seg_split = _p(self.records), _p(self.n_rec), _p(self.seg_state), _p(self.seg_split)
         p.bwd_queue, p.bwd_queue_items = _p(self.bwd_queue), max(self.n_q_items, 0)
-        p.rgb, p.depth, p.normal, p.n_cells = _p(fr["rgb"]), _p(fr["depth"]), _p(fr["normal"]), self.n_cells
+        p.n_cells = self.n_cells  # (rgb / depth / normal / alphas / loss: fresh tensors per step, see run())
         p.aux_partial, p.v_depth_img, p.v_normal_img = _p(self.aux_partial), _p(self.v_depth_img), _p(self.v_normal_img)
         if self.bwd_order is not None:
             p.order_counters = self.bwd_queue[4 + 4 * max(self.n_q_items, 0):].data_ptr()
             p.bwd_order = _p(self.bwd_order)
             p.order_shift = 4 if self.n_q_items > 0 else 7
         p.ssim_maps, p.ssim_sums, p.ssim_rows, p.aux_rows = _p(self.ssim_maps), _p(self.ssim_sums), self.ssim_rows, self.aux_rows
-        p.v_rgb, p.loss_out = _p(self.v_rgb), _p(fr["loss"])
+        p.v_rgb = _p(self.v_rgb)
         p.v_packed, p.replica_rows, p.dispatch_stride = _p(self.v_packed), self.rep_rows, fused.BWD_DISPATCH.stride(W, H)
         p.absgrad = _p(fr["absgrad"])
         p.gsb_flags = (1 if N >= fused.LAZY_SH_MIN_N else 0) | (2 if N >= fused.SKIP_IDLE_MIN_N else 0)
@@ -186,6 +184,12 @@ class ExpressStep:
         self.turn ^= 1
         p = fr["plan"]
         W, H, T = self.W, self.H, self.T
+        # what the caller may keep: fresh every step (five small allocations from torch's cache)
+        f32 = dict(dtype=torch.float32, device=dev)
+        rgb, depth, normal = torch.empty(H, W, 3, **f32), torch.empty(H, W, 1, **f32), torch.empty(H, W, 3, **f32)
+        alphas, loss = torch.empty(1, H, W, 1, **f32), torch.empty((), **f32)
+        p.rgb, p.depth, p.normal, p.alphas, p.loss_out = (rgb.data_ptr(), depth.data_ptr(), normal.data_ptr(),
+                                                          alphas.data_ptr(), loss.data_ptr())
         cam = fused._camera_on_device(camera, dev)
         p.viewmat, p.K, p.campos, p.c2w = _p(cam["viewmat"]), _p(cam["K"]), _p(cam["campos"]), _p(cam["c2w"])
         p.sh_degree = int(sh_degree)
@@ -229,7 +233,6 @@ class ExpressStep:
             flags = ops.fusion_aux_flags(cfg)
             if fb.normal is None:
                 flags &= ~1
-            f32 = dict(dtype=torch.float32, device=dev)
             if self.fa_partial is None:
                 self.fa_partial = torch.empty(self.fa_rows, 8, **f32)
                 self.ms_partial = torch.empty((self.N + 255) // 256, 2, **f32)
@@ -295,10 +298,10 @@ class ExpressStep:
         info.stats_out = stats
         info.stats_done = stats_on
         info.adam_applied = True
-        out = {"rgb": fr["rgb"], "depth": fr["depth"], "normal": fr["normal"], "accumulation": fr["alphas"][0],
+        out = {"rgb": rgb, "depth": depth, "normal": normal, "accumulation": alphas[0],
                "background": self.background, "info": info, "xys": info, "radii": fr["radii"][0],
                "normals_world": fr["normals_world"]}
-        return False, n_live, fr["loss"], out
+        return False, n_live, loss, out
 
     # -- bench.py's kernel timer (ops.TIMER): HIP events around the launches it asks for, recorded by the library ----------
     def _arm_timer(self, p: StepPlan):

@@ -150,27 +150,34 @@ def test_express_get_loss_dict_step_equals_the_per_op_step(dev):
 
 
 def test_express_outputs_survive_the_next_step_and_training_converges_alike(dev):
-    """A frame's outputs stay valid until the next-but-one step (they alternate between two buffer sets), and a short
-    training run through the one-call route ends where the per-op route ends (loss within the atomics' noise)."""
+    """Losses and images are the caller's to keep (fresh tensors every step: a list of losses read at the end holds every
+    step's own value), a frame's side outputs stay valid until the next-but-one step, and a short training run through
+    the one-call route follows the per-op route's losses (first steps: identical parameters -> identical losses; later
+    ones within what the atomics' noise, fed back through Adam, leaves)."""
     from fusionsense_amd.trainer import SplatTrainer
     params, cams, tgts = _scene(dev, n=50_000, seed=5)
     finals = {}
     for express in (True, False):
         tr = SplatTrainer(params, dev, sh_degree=3, seed=3)
         tr.express = express
-        kept = None
+        kept, images = None, []
         losses = []
         for it in range(15):
             loss, out = tr.train_step(cams[it % 3], tgts[it % 3])
             if kept is not None:
-                assert torch.equal(kept[0], kept[1]), "the previous step's image was overwritten"
-            kept = (out["rgb"], out["rgb"].clone())
+                assert torch.equal(kept[0], kept[1]), "the previous step's side outputs were overwritten"
+            kept = (out["info"].means2d, out["info"].means2d.clone())
             losses.append(loss)
+            images.append((out["rgb"], out["rgb"].clone()))
+        torch.cuda.synchronize()
+        for a, b in images:
+            assert torch.equal(a, b), "an image the caller kept was overwritten by a later step"
         finals[express] = [float(x) for x in losses]
+        assert len(set(finals[express])) > 10  # (every step's own value)
         assert (tr.express_steps == 12) if express else (tr.express_steps == 0)
         assert tr.bin_frames.get("fill", 0) == 12 and tr.live_overflows == 0
-    for x, y in zip(finals[True], finals[False]):
-        assert math.isfinite(x) and abs(x - y) <= 2e-4 * abs(y), (x, y)
+    for it, (x, y) in enumerate(zip(finals[True], finals[False])):
+        assert math.isfinite(x) and abs(x - y) <= (1e-5 if it < 4 else 1e-3) * abs(y), (it, x, y)
 
 
 def test_express_overflow_is_redone_by_the_per_op_route(dev):
