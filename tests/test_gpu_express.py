@@ -123,7 +123,14 @@ def test_express_get_loss_dict_step_equals_the_per_op_step(dev):
     fbs = [prepare_batch({"image": torch.rand(h, w, 3, generator=g), "sensor_depth": torch.rand(h, w, 1, generator=g) * 3 + 0.5,
                           "normal": torch.rand(h, w, 3, generator=g), "mask": torch.rand(h, w, 1, generator=g) > 0.3}, cfg, dev)
            for _ in cams]
-    tr = SplatTrainer(params, dev, sh_degree=3, seed=3, loss_cfg=cfg)
+    # touch anchors (dn_model.py:535-541, 893-902): the last 200 rows are frozen, with contact normals for the MSE term
+    from fusionsense_amd.splatfacto import DensifyStrategy, SplatfactoConfig
+    N = params["means"].shape[0]
+    st = DensifyStrategy(SplatfactoConfig(), num_train_data=3, stats_only=True)
+    st.add_mask = torch.zeros(N, dtype=torch.bool, device=dev)
+    st.add_mask[-200:] = True
+    st.touch_normals = torch.nn.functional.normalize(torch.randn(200, 3, generator=g), dim=-1).to(dev)
+    tr = SplatTrainer(params, dev, sh_degree=3, seed=3, loss_cfg=cfg, strategy=st)
     for it in range(6):
         tr.train_step(cams[it % 3], fbs[it % 3])
     assert tr.express_steps == 3
@@ -143,6 +150,10 @@ def test_express_get_loss_dict_step_equals_the_per_op_step(dev):
     assert a["loss"] == b["loss"] and math.isfinite(a["loss"])
     for k in ("rgb", "depth", "normal"):
         assert torch.equal(a[k], b[k]), k
+    for k in ("means", "opacities"):  # the anchors did not move on either route (their log-scales do: the min-scale
+        # term reaches them directly, dn_model.py:817-819)
+        assert torch.equal(b["p"][k][-200:], snap["p"][k][-200:]) and torch.equal(a["p"][k][-200:], snap["p"][k][-200:]), k
+    assert not torch.equal(b["p"]["scales"][-200:], snap["p"]["scales"][-200:])
     for k in PARAM_ORDER:  # (tolerances as in test_express_step_equals_the_per_op_step)
         assert _rel(b["m"][k], a["m"][k]) <= 1e-4, k
         spread = _rel(c["p"][k] - snap["p"][k], a["p"][k] - snap["p"][k])

@@ -359,7 +359,8 @@ def test_adam_in_the_backward_with_the_fusionsense_loss(dev, monkeypatch):
         st.add_mask = add_mask.to(dev)
         st.touch_normals = touch_normals.to(dev)
         tr = SplatTrainer(params, dev, sh_degree=3, strategy=st, loss_cfg=cfg)
-        tr.adam_in_backward_mode = mode
+        tr.express = False  # (the launch-by-launch route: the replay hooks into fused._run; tests/test_gpu_express.py
+        tr.adam_in_backward_mode = mode  # compares the one-call route with it)
         tape["mode"], tape["i"] = tape_mode, 0
         losses = [float(tr.train_step(cams[it % 2], fb)[0]) for it in range(3)]
         tape["mode"] = None
