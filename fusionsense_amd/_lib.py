@@ -65,6 +65,8 @@ class StepPlan(C.Structure):
         ("absgrad", _p), ("xys_grad_norm", _p), ("vis_counts", _p), ("max_2Dsize", _p),
         ("inv_max_hw", _f), ("frozen", _p),
         ("adam", AdamGroups), ("min_scale_g", _f), ("gsb_flags", _i),
+        ("g_means", _p), ("g_log_scales", _p), ("g_quats", _p), ("g_features_dc", _p), ("g_features_rest", _p),
+        ("g_opac_logit", _p),
         ("ev_before", _p * 9), ("ev_after", _p * 9),
         ("armed", _i), ("wait_ns", _i64),
     ]

@@ -29,7 +29,10 @@ inline int bad_plan(const fsgs_step_plan *p) {
         return 1;
     }
     if (!p->ssim_maps || !p->ssim_sums || !p->v_rgb || !p->loss_out || !p->v_packed || !p->absgrad) return 1;
-    if (p->adam.n_groups != 6) return 1;
+    if (p->adam.n_groups != 6 && p->adam.n_groups != 0) return 1;
+    if (p->adam.n_groups == 0 && (!p->g_means || !p->g_log_scales || !p->g_quats || !p->g_features_dc || !p->g_features_rest ||
+                                  !p->g_opac_logit))
+        return 1;
     if (p->bwd_order && (!p->bwd_queue || !p->order_counters)) return 1;
     return 0;
 }
@@ -188,6 +191,20 @@ extern "C" int fsgs_step_backward(fsgs_step_plan *p, int64_t spin_limit, int64_t
                                      p->bwd_queue ? p->bwd_queue_items : 0, p->bwd_order, stream);
     }
     if (rc) return rc;
+    if (p->adam.n_groups == 0) {
+        {
+        Hook h(p, hs, 7);
+        rc = fsgs_gauss_sh_bwd(p->n, p->sh_degree, p->means, p->campos, p->features_dc, p->features_rest, p->quats, p->log_scales,
+                               p->scales_exp, p->opac_sig, p->viewmat, p->K, p->c2w, W, H, 0.3f, p->radii, p->conics, p->v_packed,
+                               p->g_features_dc, p->g_features_rest, nullptr, p->g_means, p->g_quats, p->g_log_scales,
+                               p->g_opac_logit, p->absgrad, p->xys_grad_norm, p->vis_counts, p->max_2Dsize, p->inv_max_hw,
+                               p->frozen, p->replica_rows, p->gsb_flags, stream);
+        }
+        if (rc || !fusion || p->g_min == 0.f) return rc;
+        if (!p->ms_partial) return FSGS_EINVAL;
+        // (dn_model.py:817-819: the min-scale term reaches the log-scales directly, touch anchors included)
+        return fsgs_min_scale_loss(p->n, p->log_scales, p->g_min, p->seed, p->ms_partial, p->g_log_scales, stream);
+    }
     Hook h(p, hs, 7);
     return fsgs_gauss_sh_bwd_adam(p->n, p->sh_degree, p->means, p->campos, p->features_dc, p->features_rest, p->quats,
                                   p->log_scales, p->scales_exp, p->opac_sig, p->viewmat, p->K, p->c2w, W, H, 0.3f, p->radii,

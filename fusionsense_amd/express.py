@@ -265,7 +265,14 @@ class ExpressStep:
             p.inv_max_hw = 0.0
             stats_on = False
         p.frozen = _p(frozen)
-        p.adam = adam
+        if adam is not None:
+            p.adam = adam
+        else:
+            # a step WITHOUT its optimizer: the per-Gaussian backward writes the gradients into the trainer's slab views
+            p.adam.n_groups = 0
+            gv = trainer.slab.views
+            p.g_means, p.g_log_scales, p.g_quats = _p(gv["means"]), _p(gv["scales"]), _p(gv["quats"])
+            p.g_features_dc, p.g_features_rest, p.g_opac_logit = _p(gv["features_dc"]), _p(gv["features_rest"]), _p(gv["opacities"])
         p.min_scale_g = 0.0
         timed = self._arm_timer(p)
         sp = stream_ptr(dev)
@@ -297,7 +304,7 @@ class ExpressStep:
         info.absgrad = fr["absgrad"]
         info.stats_out = stats
         info.stats_done = stats_on
-        info.adam_applied = True
+        info.adam_applied = adam is not None
         out = {"rgb": rgb, "depth": depth, "normal": normal, "accumulation": alphas[0],
                "background": self.background, "info": info, "xys": info, "radii": fr["radii"][0],
                "normals_world": fr["normals_world"]}

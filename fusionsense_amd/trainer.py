@@ -839,7 +839,10 @@ class SplatTrainer:
             if aib_ok:
                 self.optimizers["means"].param_groups[0]["lr"] = self._means_lr(self.step)
                 aib_step = getattr(self, "adam_steps", 0) + 1
-            use_express = (aib_ok and bin_hist is not None and cap > 0
+            # (the one-call route: with the Adam step inside the backward, or — optimizer_step=False on one rank — writing
+            # the gradients; a step whose optimizer runs as launches of its own keeps the per-op route)
+            grad_mode = (not optimizer_step) and self._one_rank_fused() and self._geo is None
+            use_express = ((aib_ok or grad_mode) and bin_hist is not None and cap > 0
                            and self._express_ok(camera, target, is_fb, factors, zin))
             if aib_ok and not use_express:
                 aib = self._fused_adam_step(PARAM_ORDER, aib_step, as_groups=True)
@@ -853,12 +856,15 @@ class SplatTrainer:
                 ex = self._express_step(camera, cap, True if is_fb else "normal" in target)
                 if bin_fill_words(int(bin_hist["n_live"]), ex.T) > ex.words:  # (a view last seen under a larger model)
                     use_express = False
-                    aib = self._fused_adam_step(PARAM_ORDER, aib_step, as_groups=True)
+                    if aib_ok:
+                        aib = self._fused_adam_step(PARAM_ORDER, aib_step, as_groups=True)
             if use_express:
-                ex.adam.step = int(aib_step)
-                for k, name in enumerate(PARAM_ORDER):
-                    ex.adam.lr[k] = float(self.optimizers[name].param_groups[0]["lr"])
-                over, n_live_x, loss, out = ex.run(self, camera, target, bin_hist, stats, frozen, bthr, ex.adam,
+                if aib_ok:
+                    ex.adam.step = int(aib_step)
+                    for k, name in enumerate(PARAM_ORDER):
+                        ex.adam.lr[k] = float(self.optimizers[name].param_groups[0]["lr"])
+                over, n_live_x, loss, out = ex.run(self, camera, target, bin_hist, stats, frozen, bthr,
+                                                   ex.adam if aib_ok else None,
                                                    self._sh_degree_now(), self._one,
                                                    fusion=((self.loss_cfg,) + self._touch_rows()) if is_fb else None)
                 if over:  # the frame outgrew its lists / a bucket: once more through the exact two-pass route (below)
@@ -868,7 +874,8 @@ class SplatTrainer:
                     self._live_caps.raise_to(cap_key, n_live_x)
                     cap = 0
                     bthr = None  # (launch 1 has written the binary opacities: the redo must not threshold them again)
-                    aib = self._fused_adam_step(PARAM_ORDER, aib_step, as_groups=True)
+                    if aib_ok:
+                        aib = self._fused_adam_step(PARAM_ORDER, aib_step, as_groups=True)
                 else:
                     express_done = True
                     self.express_steps += 1

@@ -985,6 +985,11 @@ typedef struct fsgs_step_plan {
     float *absgrad /* [N,2] [frame] */, *xys_grad_norm, *vis_counts, *max_2Dsize /* nullable: no statistics */;
     float inv_max_hw; const uint8_t *frozen /* nullable */;
     fsgs_adam_groups adam; float min_scale_g; int32_t gsb_flags;
+    /* adam.n_groups == 0: launch 8 is fsgs_gauss_sh_bwd instead — the parameter gradients are WRITTEN (a step without its
+     * optimizer: gradient accumulation, callers that clip / log gradients, bench.py's figure without the optimizer), in
+     * the layout of the parameters; with loss_kind 1 the min-scale term's gradient is then added by one more launch
+     * (fsgs_min_scale_loss over ms_partial as scratch), as the per-op route does */
+    float *g_means, *g_log_scales, *g_quats, *g_features_dc, *g_features_rest, *g_opac_logit;
     /* -- optional timing hooks: hipEvent_t handles (as void *) recorded on `stream` right before / behind launch k
      *    (k = 0..7 in the order above: project+bin, sorts, forward, epilogue, SSIM fwd | SSIM bwd, backward, per-Gaussian;
      *    k = 8: loss_kind 1's fsgs_fusion_aux_loss_riders, which runs behind launch 5);

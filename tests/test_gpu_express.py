@@ -160,6 +160,42 @@ def test_express_get_loss_dict_step_equals_the_per_op_step(dev):
         assert _rel(b["p"][k] - snap["p"][k], a["p"][k] - snap["p"][k]) <= max(1e-3, 20 * spread), (k, spread)
 
 
+def test_express_step_without_the_optimizer_writes_the_gradients(dev):
+    """optimizer_step=False through the one-call route (adam.n_groups = 0: fsgs_gauss_sh_bwd writes the gradients into the
+    trainer's slab) against the launch-by-launch route: same images and lists bit for bit, gradients equal within the
+    atomics' reordering, parameters untouched — for both losses (the FrameBatch one adds the min-scale launch)."""
+    from fusionsense_amd.losses import LossConfig, prepare_batch
+    from fusionsense_amd.trainer import PARAM_ORDER, SplatTrainer
+    params, cams, tgts = _scene(dev, n=40_000, seed=17)
+    g = torch.Generator().manual_seed(17)
+    h, w = cams[0].height, cams[0].width
+    cfg = LossConfig()
+    fbs = [prepare_batch({"image": torch.rand(h, w, 3, generator=g), "sensor_depth": torch.rand(h, w, 1, generator=g) * 3 + 0.5,
+                          "normal": torch.rand(h, w, 3, generator=g), "mask": torch.rand(h, w, 1, generator=g) > 0.3}, cfg, dev)
+           for _ in cams]
+    for sup in (tgts, fbs):
+        tr = SplatTrainer(params, dev, sh_degree=3, seed=3, loss_cfg=cfg)
+        for it in range(3):
+            tr.train_step(cams[it], sup[it], optimizer_step=False)  # first visits: two-pass route
+        before = {k: tr._params[k].detach().clone() for k in PARAM_ORDER}
+        res = {}
+        for route in ("per_op", "express"):
+            tr.express = route == "express"
+            x0 = tr.express_steps
+            loss, out = tr.train_step(cams[1], sup[1], optimizer_step=False)
+            torch.cuda.synchronize()
+            assert tr.express_steps - x0 == (1 if route == "express" else 0) and tr.last_step_grads_valid
+            res[route] = dict(loss=float(loss), rgb=out["rgb"].clone(), payload=out["info"].payload.clone(),
+                              g={k: tr.gradients()[k].clone() for k in PARAM_ORDER},
+                              pg={k: tr._params[k].grad.clone() for k in PARAM_ORDER})
+        a, b = res["per_op"], res["express"]
+        assert a["loss"] == b["loss"] and torch.equal(a["rgb"], b["rgb"]) and torch.equal(a["payload"], b["payload"])
+        for k in PARAM_ORDER:
+            assert torch.equal(tr._params[k].detach(), before[k]), k
+            assert float(a["g"][k].abs().max()) > 0 and _rel(b["g"][k], a["g"][k]) <= 2e-4, (k, _rel(b["g"][k], a["g"][k]))
+            assert torch.equal(b["pg"][k], b["g"][k])
+
+
 def test_express_outputs_survive_the_next_step_and_training_converges_alike(dev):
     """Losses and images are the caller's to keep (fresh tensors every step: a list of losses read at the end holds every
     step's own value), a frame's side outputs stay valid until the next-but-one step, and a short training run through

@@ -653,6 +653,7 @@ def test_count_free_binning_equals_the_two_pass_route(dev, monkeypatch):
     def run(enabled, shrink_at=None):
         monkeypatch.setattr(fused, "BIN_FILL", enabled)
         tr = SplatTrainer(params, dev, sh_degree=3, seed=3)
+        tr.express = False  # (this test counts the per-op route's Python-level calls; tests/test_gpu_express.py has the other)
         seen = []
         for it in range(12):
             v = it % 3
