@@ -447,7 +447,12 @@ def project_bin_live_count_async(means: Tensor, quats: Tensor, log_scales: Tenso
 
 # ---- count-free binning (fsgs_project_bin_live_fill_sh_pack): one enumeration of the pairs instead of two ------------
 # A view's frame tells how much room every tile's bucket needs in the view's NEXT frame: count * growth + slack words.
-BIN_FILL_GROWTH, BIN_FILL_SLACK = 1.25, 64
+# Round 6: 1.25 -> 2.0.  `bench.py --config 2 --steps 300 --densify` (three refinements of +5 % Gaussians each, 100 views, each
+# view seen once between two refinements): growth 1.25 / 1.5 / 2.0 -> 90 / 19 / 0 of the 300 frames outgrew a bucket and were
+# redone (+0.25 ms each; GPU ms per step over the last three quarters 0.77 / 0.58 / 0.58-0.62) — densification adds its
+# Gaussians where the gradients are, so a few tiles grow far more than the model; the room costs 8 bytes of address space per
+# spare word and no time (config #2 without refinements: 2048 it/s either way).  FSGS_BIN_FILL_GROWTH: A/B.
+BIN_FILL_GROWTH, BIN_FILL_SLACK = float(os.environ.get("FSGS_BIN_FILL_GROWTH", "2.0")), 64
 # the count-free route's in-tile sorts are dispatched longest tile first (fsgs.h: tile_order)
 BIN_FILL_SORT_ORDER = True
 TWO_PASS_TILE_ORDER = True  # (... and the two-pass route's scan launch leaves the same order for the forward's walk)

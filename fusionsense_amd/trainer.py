@@ -247,7 +247,12 @@ class SplatTrainer:
         self._zcut_widen: Dict = {}
         self._bin_hist: Dict = {}   # view -> {"base": bucket bases [T + 1], "n_live": pairs} of its previous frame
         self._bin_hist_n = -1
-        self.bin_hist_keep_rel = 0.10
+        # A model whose size moved by more than this fraction since a view's bucket room was noted starts its views over
+        # (their next visit takes the exact two-pass route and leaves fresh room).  Round 6 measured the alternative under
+        # densification (`bench.py --config 2 --steps 300 --densify`, ops.BIN_FILL_GROWTH): dropping the room at every
+        # refinement (0.02) makes every frame of a 100-view epoch a two-pass frame (0.62 ms per step); keeping it with
+        # buckets grown by 2.0 instead of 1.25 keeps the count-free route without a single redone frame (0.58).
+        self.bin_hist_keep_rel = float(os.environ.get("FSGS_BIN_HIST_KEEP_REL", "0.10"))
         self.bin_frames: Dict = {}  # frames by binning route ("fill": count-free, "two_pass")
         self.zcut_max_views = 1024  # least recently rendered views beyond this are forgotten (T floats each)
         # Adam in the backward: on one rank, when nothing else needs the gradients, the per-Gaussian
