@@ -396,7 +396,9 @@ class DensifyStrategy:
             if x.shape[0] == 0:
                 continue
             # 1-NN on the device (reference: sklearn on CPU); brute force in libfsgs, no BLAS, no [n, N] matrix
-            nn_idx = ops.nearest_point(x, means, want_idx=True)[1] if means.is_cuda else torch.cdist(x, means).argmin(dim=-1)
+            if not means.is_cuda:
+                raise ValueError("add_touch_patch runs on the GPU (fsgs_nearest_point): there is no CPU path")
+            nn_idx = ops.nearest_point(x, means, want_idx=True)[1]
             pts.append(x)
             nrm.append(patch["normals"].to(means.device))
             rgb.append(base_rgb[nn_idx])

@@ -114,17 +114,13 @@ def hull_prune_mask(means: Tensor, visual_hull: Tensor, scale_factor: float,
     distance to the hull point set is in (0.005 s, 0.02 s] are culled; touch anchors never."""
     center = visual_hull.mean(dim=0)
     close = torch.norm(means - center, dim=1) <= 0.2 * scale_factor
-    if means.is_cuda:
-        # the close rows' distances (exact differences, no [n, n_hull] matrix), selected ON the device: the kernel skips
-        # the other rows (+inf) — no wait for the host to learn how many rows are close, no gather / scatter
-        from .ops import nearest_point
-        d = nearest_point(means, visual_hull, active=close)
-        mask = close & (d > 0.005 * scale_factor) & (d <= 0.02 * scale_factor)
-    else:  # (host mirror used by the CPU tests of the mask logic)
-        d = torch.cdist(means[close], visual_hull).min(dim=-1).values
-        sel = (d > 0.005 * scale_factor) & (d <= 0.02 * scale_factor)
-        mask = torch.zeros(means.shape[0], dtype=torch.bool, device=means.device)
-        mask[close] = sel
+    if not means.is_cuda:
+        raise ValueError("hull_prune_mask runs on the GPU (fsgs_nearest_point): there is no CPU path")
+    # the close rows' distances (exact differences, no [n, n_hull] matrix), selected ON the device: the kernel skips
+    # the other rows (+inf) — no wait for the host to learn how many rows are close, no gather / scatter
+    from .ops import nearest_point
+    d = nearest_point(means, visual_hull, active=close)
+    mask = close & (d > 0.005 * scale_factor) & (d <= 0.02 * scale_factor)
     if add_mask is not None:
         mask = mask & ~add_mask
     return mask
