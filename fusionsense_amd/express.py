@@ -55,6 +55,8 @@ class ExpressStep:
         dev = trainer.device
         N = trainer.num_gaussians()
         self.key = (N, W, H, int(capacity), bool(has_normal))
+        # module switches the buffers' layout depends on (tests and A/B runs move them): a change re-makes the blocks
+        self.switches = self._switches()
         self.N, self.W, self.H, self.capacity = N, W, H, int(capacity)
         tw, th = math.ceil(W / fused.TILE), math.ceil(H / fused.TILE)
         self.tw, self.th, self.T = tw, th, tw * th
@@ -156,11 +158,18 @@ class ExpressStep:
         p.armed = 0
         return p
 
+    @staticmethod
+    def _switches():
+        return (fused.BWD_QUEUE_ITEMS, fused.BWD_ORDER, fused.BWD_ORDER_DENSE, fused.FWD_WALK.handoff_max_n,
+                ops.BIN_FILL_SORT_ORDER, ops.BIN_FILL_GROWTH, ops.BIN_FILL_SLACK, fused.GRAD_REPLICAS_MAX_N)
+
     def still_fits(self, trainer) -> bool:
         """The blocks hold raw pointers: parameters / moments that were re-created (densify, prune, a loaded checkpoint)
         make them stale."""
         pr = trainer._params
         if pr["means"].shape[0] != self.N or self.v_packed is not fused._ACCUM.get(str(trainer.device)):
+            return False
+        if self.switches != self._switches():
             return False
         a = self.adam
         for k, name in enumerate(fused_param_order()):
@@ -265,6 +274,8 @@ class ExpressStep:
             p.inv_max_hw = 0.0
             stats_on = False
         p.frozen = _p(frozen)
+        p.dispatch_stride = fused.BWD_DISPATCH.stride(W, H)
+        p.gsb_flags = (1 if self.N >= fused.LAZY_SH_MIN_N else 0) | (2 if self.N >= fused.SKIP_IDLE_MIN_N else 0)
         if adam is not None:
             p.adam = adam
         else:

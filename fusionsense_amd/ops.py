@@ -315,9 +315,15 @@ def _pinned_i32(dev) -> Tensor:
         ring = _PINNED.setdefault(str(dev) + ":i32", dict(bufs=bufs, i=0))
     ring["i"] = (ring["i"] + 1) % len(ring["bufs"])
     buf = ring["bufs"][ring["i"]]
+    if getattr(buf, "_pending", False):
+        # the launch this slot was last armed for was never looked at (an exception between a launch and its
+        # bin_live_check, a caller that dropped the state): its kernel may still be about to write total and flag, and a
+        # bare flag cannot tell whose it is.  Never re-arm under it — drain the device first (a path no training step takes).
+        torch.cuda.synchronize(dev)
     buf._np[1] = 0
     buf._np[2] = 0  # no capacity: the offsets are exact
     buf._np[3] = 0  # (count-free binning: "a tile outgrew its bucket")
+    buf._pending = True  # (cleared by _wait_total, the only reader)
     return buf
 
 
@@ -326,6 +332,7 @@ def _wait_total(st: dict) -> int:
     total (falls back to the event)."""
     arr = st["pinned"]._np
     ev = st.get("event")
+    st["pinned"]._pending = False  # (whatever happens below ends with this launch's total read or the stream drained)
     if SPIN_WAIT and (WAIT_ON_FLAG or ev is None):
         for _ in range(400000):
             if arr[1] != 0:

@@ -1394,6 +1394,42 @@ def test_count_free_route_waits_on_the_mapped_flag(monkeypatch):
     assert ops._wait_total(dict(pinned=pinned, event="EV")) == 5 and waited == ["EV"]
 
 
+def test_flag_ring_never_rearms_a_slot_nobody_read(monkeypatch):
+    """the live total's flag is a bare 1 in a ring of four mapped blocks.  A slot whose launch was never looked
+    at (an exception between the launch and its check) must not be re-armed while that launch may still write it: the
+    ring drains the device first; a slot that WAS read is re-armed without any wait.  And importing the package sets the
+    runtime's command-batch limit unless the caller has."""
+    from fusionsense_amd import ops
+    bufs = []
+    for _ in range(4):
+        arr = np.zeros(4, dtype=np.int32)
+        bufs.append(type("P", (), {"_np": arr})())
+    monkeypatch.setitem(ops._PINNED, "dev0:i32", dict(bufs=bufs, i=0))
+    drained = []
+    monkeypatch.setattr(ops.torch.cuda, "synchronize", lambda dev=None: drained.append(dev))
+    monkeypatch.setattr(ops, "SPIN_WAIT", True)
+    seen = []
+    for frame in range(8):  # every frame's total is read: two laps of the ring without a single drain
+        b = ops._pinned_i32("dev0")
+        assert b._pending and b._np[1] == 0
+        b._np[0], b._np[1] = 100 + frame, 1  # (the kernel lands)
+        seen.append(ops._wait_total(dict(pinned=b, event=None, pinned_dev="dev0")))
+        assert not b._pending
+    assert seen == [100 + f for f in range(8)] and drained == []
+    lost = ops._pinned_i32("dev0")  # armed, launched ... and never checked
+    for _ in range(3):
+        b = ops._pinned_i32("dev0")
+        b._np[1] = 1
+        ops._wait_total(dict(pinned=b, event=None, pinned_dev="dev0"))
+    assert drained == []
+    again = ops._pinned_i32("dev0")  # the ring comes back to the lost slot: drained before it is cleared and re-armed
+    assert again is lost and drained == ["dev0"]
+    out = subprocess.run([sys.executable, "-c", "import os; os.environ.pop('DEBUG_CLR_MAX_BATCH_SIZE', None); "
+                          "import fusionsense_amd; print(os.environ['DEBUG_CLR_MAX_BATCH_SIZE'])"], capture_output=True, text=True,
+                         cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), timeout=120)
+    assert out.returncode == 0 and out.stdout.strip() == "16384", out.stderr[-500:]
+
+
 def test_bench_sets_the_runtime_limit_before_the_runtime_loads():
     """bench.py moves the HIP runtime's command-batch limit with os.environ.setdefault BEFORE torch —
     and with it libamdhip64 — is imported, and a caller's own setting wins."""
