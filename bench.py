@@ -50,16 +50,21 @@ import torch.distributed as dist
 _T0 = time.time()
 
 
-def gpu_step_stats(events, views):
-    """GPU-side duration of every timed step (event to event on the step's stream): quantiles, and — the views differ
+def gpu_step_stats(events, views, every=1):
+    """GPU-side duration of the timed steps (event to event on the step's stream): quantiles, and — the views differ
     in work — the largest ratio of a step to the median of the steps of ITS view when views repeat (host stalls and
-    redone frames show here; a different view does not)."""
-    d = [events[i].elapsed_time(events[i + 1]) for i in range(len(events) - 1)]
+    redone frames show here; a different view does not).  ``every`` > 1: an event was recorded behind every ``every``-th
+    step only (an event record is a marker packet: ~6 us of idle GPU in front of the next launch, 1.3 % of a config-#2
+    step) — the figures are then per-step MEANS over groups of ``every`` consecutive steps."""
+    d = [events[i].elapsed_time(events[i + 1]) / every for i in range(len(events) - 1)]
     if not d:
         return None
     q = sorted(d)
     out = {"p50": round(q[len(q) // 2], 4), "p99": round(q[min(len(q) - 1, int(0.99 * len(q)))], 4),
            "max": round(q[-1], 4)}
+    if every > 1:
+        out["per"] = f"mean of {every} consecutive steps"
+        views = []  # (groups mix views)
     if len(d) >= 8:  # drift over the run (clocks, growing state): the mean of each quarter
         n4 = len(d) // 4
         out["mean_by_quarter"] = [round(sum(d[k * n4:(k + 1) * n4]) / n4, 4) for k in range(4)]
@@ -660,7 +665,7 @@ def main():
     # host time right in front of it, i.e. a GPU bubble; every other kernel is timed in the untimed pass below
     # ... and of its launches every fourth (runs of 40 steps and more): the two event records cost ~5 us of every step
     # they bracket (config #2: 2 017 it/s with all hundred launches timed, 2 042 with none)
-    timer_every = 4 if args.steps >= 40 else 1
+    timer_every = 8 if args.steps >= 80 else (4 if args.steps >= 40 else 1)
     ops.TIMER.reset(enabled=not os.environ.get("FSGS_BENCH_NO_TIMER"), only=("raster_bwd",), prealloc=args.steps + 2,
                     every=timer_every)
     # keep the interpreter's cyclic collector out of the timed region (a generation-2 pass costs tens of ms).
@@ -702,7 +707,10 @@ def main():
     t0 = time.perf_counter()
     step_ends = []
     # one event per step on the step's stream: the GPU-side duration of every step, read after the timed region
-    step_events = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    # (config #2's long default run: behind every fourth step only — see gpu_step_stats; FSGS_BENCH_STEP_EVENTS_EVERY moves it)
+    ev_every = int(os.environ.get("FSGS_BENCH_STEP_EVENTS_EVERY", "4" if (args.config == 2 and args.steps >= 40
+                                                                           and args.steps % 4 == 0 and not args.densify) else "1"))
+    step_events = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps // ev_every + 1)]
     step_views = []
     with_events = not os.environ.get("FSGS_BENCH_NO_STEP_EVENTS")
     if with_events:
@@ -732,8 +740,8 @@ def main():
         trainer.train_step(cams[v], targets[v])
         if getattr(trainer, "express_steps", 0) > x0_:
             host_issue.append((time.perf_counter() - h0_) * 1e3 - trainer._express.last_wait_ms)
-        if with_events:
-            step_events[s + 1].record()
+        if with_events and (s + 1) % ev_every == 0:
+            step_events[(s + 1) // ev_every].record()
         step_views.append(v)
         step_ends.append(time.perf_counter())
     if stall_calls:
@@ -771,7 +779,7 @@ def main():
         # what the deferred exchange did not hide), gathered so that a scaling curve can be read from the line
         comm_ms = sum(a.elapsed_time(b) for _, a, b in (trainer.comm_events or [])) / max(args.steps, 1)
         trainer.comm_events = None
-        gs = gpu_step_stats(step_events, step_views) if with_events else None
+        gs = gpu_step_stats(step_events, step_views, ev_every) if with_events else None
         mine = torch.tensor([own_elapsed / args.steps * 1e3, comm_ms, gs["p50"] if gs else float("nan")],
                             dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         got = [torch.empty_like(mine) for _ in range(world)]
@@ -1165,7 +1173,7 @@ def main():
             "host_ms_around_slowest": (lambda d, i: [round(1e3 * x, 3) for x in d[max(i - 3, 0):i + 4]])(
                 [b - a for a, b in zip([t0] + step_ends[:-1], step_ends)],
                 max(range(len(step_ends)), key=lambda i: step_ends[i] - ([t0] + step_ends)[i])),
-            "gpu_step_ms": gpu_step_stats(step_events, step_views) if with_events else None,
+            "gpu_step_ms": gpu_step_stats(step_events, step_views, ev_every) if with_events else None,
             "kernels_ms": kernel_ms,
             "roofline": roofline,
             "roofline_top3": roofline_top3,
