@@ -17,7 +17,7 @@ CSRC = os.path.join(ROOT, "fusionsense_amd", "csrc")
 NOSLP = {"raster_live", "sh"}
 KERNELS = [  # (name in the JSON, source, substring of the mangled name, rule)
     ("raster_bwd_live<4,true,3>", "raster_live", "raster_bwd_live_kernelILi4ELb1ELi3E", "atomic"),
-    ("raster_fwd_wave<4,3>", "raster_quad", "raster_fwd_wave_kernelILi4ELi3E", "max_inner"),
+    ("raster_fwd_wave<4,3>", "raster_quad", "raster_fwd_wave_kernelILi4ELi3E", "whole"),
     ("gauss_sh_bwd", "sh", "gauss_sh_bwd_kernelILb0ELb1E", "whole"),
     ("ssim_l1_fwd", "loss", "ssim_l1_fwd_kernel", "whole"),
     ("ssim_l1_bwd", "loss", "ssim_l1_bwd_kernel", "whole"),
