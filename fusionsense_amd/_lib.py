@@ -28,6 +28,16 @@ class AdamGroups(C.Structure):
                 ("eps", C.c_float)]
 
 
+class RefineRules(C.Structure):
+    """fsgs_refine_rules of include/fsgs.h: the schedule scalars and thresholds of one refinement / cull."""
+    _fields_ = [("densify", C.c_int32), ("n_samples", C.c_int32), ("max_hw", C.c_float),
+                ("densify_grad_thresh", C.c_float), ("densify_size_thresh", C.c_float), ("check_screen", C.c_int32),
+                ("split_screen_size", C.c_float), ("cull_alpha_thresh", C.c_float), ("check_big", C.c_int32),
+                ("cull_scale_thresh", C.c_float), ("cull_screen_size", C.c_float), ("hull_center", C.c_float * 3),
+                ("hull_close", C.c_float), ("hull_lo", C.c_float), ("hull_hi", C.c_float), ("n_boxes", C.c_int32),
+                ("grid_origin", C.c_float * 3), ("grid_inv_cell", C.c_float), ("grid_dims", C.c_int32 * 3)]
+
+
 class StepPlan(C.Structure):
     """fsgs_step_plan of include/fsgs.h, field for field (tests/test_host_logic.py compares every offset with the C
     compiler's): one training step's launches as one argument block (fusionsense_amd/express.py fills it)."""
@@ -75,7 +85,7 @@ class StepPlan(C.Structure):
 # == FSGS_ABI_VERSION of include/fsgs.h as of the SIGNATURES table below: load() refuses any other library (a stale
 # build — the .so files are git-ignored and travel separately, A/B builds come in through FSGS_LIB — would read a stream
 # pointer as a flag or write past a buffer that has since grown)
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 SIGNATURES = {
     "fsgs_version": (_i, []),
@@ -158,7 +168,12 @@ SIGNATURES = {
     "fsgs_compact_rows_multi": (_i, [_i, _p, _p, _p, _p, _p, _p, _p]),
     "fsgs_points_in_boxes": (_i, [_i64, _p, _i, _p, _p, _p]),
     "fsgs_nearest_point": (_i, [_i, _p, _i, _p, _p, _p, _p, _i, _p]),
+    "fsgs_nearest_point_words": (_i, [_i, _p, _i, _p, _p, _f, _p, _p]),
     "fsgs_knn_points": (_i, [_i64, _p, _i, _p, _i, _i, _p, _p]),
+    "fsgs_refine_book_ints": (_i64, [_i64]),
+    "fsgs_refine_mark": (_i, [_i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "fsgs_refine_move": (_i, [_i64, _i, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i, _p, _p, _p, _p, _p,
+                              _i, _p]),
     "fsgs_split_samples": (_i, [_i64, _i, _p, _p, _p, _p, _p, _p, _p, _p]),
     "fsgs_ssim_l1_num_partials": (_i64, [_i, _i]),
     "fsgs_ssim_l1_fwd": (_i, [_i, _i, _p, _p, _p, _p, _p, _p, _p]),

@@ -162,12 +162,16 @@ points_in_boxes_kernel(int64_t n, const float *__restrict__ pts, int n_boxes, co
 template <bool WANT_IDX>
 __global__ void __launch_bounds__(256)
 nearest_point_kernel(int nq, const float *__restrict__ q, int np, const float *__restrict__ p, int tiles_per_slice,
-                     const uint8_t *__restrict__ active, unsigned long long *__restrict__ best_out) {
+                     const uint8_t *__restrict__ active, float4 close, unsigned long long *__restrict__ best_out) {
     __shared__ float4 sp[1024];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool on = i < nq && (!active || active[i]);
-    if (!__syncthreads_or(on)) return;
+    bool on = i < nq && (!active || active[i]);
     const float qx = on ? q[i * 3 + 0] : 0.f, qy = on ? q[i * 3 + 1] : 0.f, qz = on ? q[i * 3 + 2] : 0.f;
+    if (close.w >= 0.f) {  // (fsgs_nearest_point_words: only the queries within close.w of close.xyz are searched for)
+        const float dx = qx - close.x, dy = qy - close.y, dz = qz - close.z;
+        on = on && sqrtf(dx * dx + dy * dy + dz * dz) <= close.w;
+    }
+    if (!__syncthreads_or(on)) return;
     float best = INFINITY;
     int best_j = 0;
     const int lo = (int)blockIdx.y * tiles_per_slice * 1024;
@@ -392,12 +396,29 @@ extern "C" int fsgs_nearest_point(int nq, const float *queries, int np, const fl
     const int slices = (int)ceil_div(tiles, tiles_per_slice);
     if (hipMemsetAsync(out_idx, 0xFF, (size_t)nq * sizeof(int64_t), as_stream(stream)) != hipSuccess) return FSGS_ELAUNCH;
     auto *best = reinterpret_cast<unsigned long long *>(out_idx);
+    const float4 everywhere = make_float4(0.f, 0.f, 0.f, -1.f);
     if (want_idx)
         hipLaunchKernelGGL(nearest_point_kernel<true>, dim3(q_blocks, slices), dim3(256), 0, as_stream(stream), nq, queries,
-                           np, points, tiles_per_slice, active, best);
+                           np, points, tiles_per_slice, active, everywhere, best);
     else
         hipLaunchKernelGGL(nearest_point_kernel<false>, dim3(q_blocks, slices), dim3(256), 0, as_stream(stream), nq, queries,
-                           np, points, tiles_per_slice, active, best);
+                           np, points, tiles_per_slice, active, everywhere, best);
     hipLaunchKernelGGL(nearest_point_unpack_kernel, dim3(q_blocks), dim3(256), 0, as_stream(stream), nq, out_idx, out_dist);
+    return check_launch();
+}
+
+extern "C" int fsgs_nearest_point_words(int nq, const float *queries, int np, const float *points, const float *center,
+                                        float close_radius, uint64_t *out_words, fsgs_stream_t stream) {
+    if (nq < 0 || np < 1) return FSGS_EINVAL;
+    if (nq == 0) return FSGS_OK;
+    if (!queries || !points || !out_words || (close_radius >= 0.f && !center)) return FSGS_EINVAL;
+    const int q_blocks = (int)ceil_div(nq, 256), tiles = (int)ceil_div(np, 1024);
+    const int tiles_per_slice = (int)std::max<int64_t>(1, ceil_div((int64_t)q_blocks * tiles, 4096));
+    const int slices = (int)ceil_div(tiles, tiles_per_slice);
+    if (hipMemsetAsync(out_words, 0xFF, (size_t)nq * sizeof(uint64_t), as_stream(stream)) != hipSuccess) return FSGS_ELAUNCH;
+    const float4 close = close_radius >= 0.f ? make_float4(center[0], center[1], center[2], close_radius)
+                                              : make_float4(0.f, 0.f, 0.f, -1.f);
+    hipLaunchKernelGGL(nearest_point_kernel<false>, dim3(q_blocks, slices), dim3(256), 0, as_stream(stream), nq, queries, np,
+                       points, tiles_per_slice, nullptr, close, reinterpret_cast<unsigned long long *>(out_words));
     return check_launch();
 }

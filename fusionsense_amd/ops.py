@@ -1128,6 +1128,131 @@ def split_samples(ids: Tensor, n_samples: int, means: Tensor, quats: Tensor, log
     return new_means, new_ls
 
 
+# ---- a-13 / a-14: one refinement / one cull as mark -> [five totals] -> move (csrc/refine.hip) ------------------------------
+COL_COPY, COL_ZERO, COL_MEANS, COL_SCALES = 0, 1, 2, 3  # what a NEW row of a column holds (fsgs.h: fsgs_refine_move)
+_REFINE_SCRATCH: dict = {}
+
+
+class RefineMarks:
+    """What fsgs_refine_mark left: the flag byte per row, the per-workgroup offsets (device), the five totals (host)."""
+    __slots__ = ("n", "flags", "book", "n_keep", "n_split", "n_dup", "n_split_kept", "n_dup_kept", "n_samples")
+
+    def deleted(self) -> Tensor:
+        """[n] bool: the rows that do not survive (cull_gaussians' return value)."""
+        return (self.flags[:self.n] & 1) == 0
+
+
+def _u8(t: Optional[Tensor]) -> Optional[Tensor]:
+    if t is None:
+        return None
+    t = t.contiguous()
+    return t.view(torch.uint8) if t.dtype == torch.bool else t
+
+
+def refine_mark(rules: "_lib.RefineRules", log_scales: Tensor, opac_logit: Tensor, xys_grad_norm: Optional[Tensor] = None,
+                vis_counts: Optional[Tensor] = None, max_2Dsize: Optional[Tensor] = None, means: Optional[Tensor] = None,
+                add_mask: Optional[Tensor] = None, extra_cull: Optional[Tensor] = None,
+                hull_words: Optional[Tensor] = None, boxes: Optional[Tensor] = None, hull_grid=None) -> RefineMarks:
+    """fsgs_refine_mark + the one host wait of a refinement: the five totals arrive in mapped memory behind a flag the
+    launch's last workgroup raises (no event, no .item())."""
+    lib = load()
+    dev = log_scales.device
+    n = log_scales.shape[0]
+    sc = _REFINE_SCRATCH.get(str(dev))
+    ints = int(lib.fsgs_refine_book_ints(n))
+    if sc is None or sc["flags"].numel() < n or sc["book"].numel() < ints:
+        grow = max(n + n // 2, 1024)
+        pinned = sc["pinned"] if sc else torch.zeros(8, dtype=torch.int32).pin_memory()
+        pinned._np = pinned.numpy()
+        sc = _REFINE_SCRATCH[str(dev)] = dict(
+            flags=torch.empty(grow, dtype=torch.uint8, device=dev),
+            book=torch.zeros(int(lib.fsgs_refine_book_ints(grow)), dtype=torch.int32, device=dev),  # (ticket: zero once)
+            pinned=pinned)
+    arr = sc["pinned"]._np
+    arr[7] = 0
+    rules.n_boxes = 0 if boxes is None else int(boxes.shape[0])
+    add8, extra8 = _u8(add_mask), _u8(extra_cull)
+    boxes = boxes.contiguous() if boxes is not None else None
+    g_pts = g_cells = None
+    if hull_grid is not None:  # touch.hull_grid: the hull's points by cell — the search rides in the mark
+        g_pts, g_cells = hull_grid["points"], hull_grid["cells"]
+        for k in range(3):
+            rules.grid_origin[k], rules.grid_dims[k] = hull_grid["origin"][k], hull_grid["dims"][k]
+        rules.grid_inv_cell = hull_grid["inv_cell"]
+    _run(lib.fsgs_refine_mark, (n, C.addressof(rules), ptr(xys_grad_norm), ptr(vis_counts), ptr(max_2Dsize), ptr(means),
+                                ptr(_c(log_scales)), ptr(_c(opac_logit)), ptr(add8), ptr(extra8), ptr(hull_words), ptr(g_pts),
+                                ptr(g_cells), ptr(boxes), ptr(sc["flags"]), ptr(sc["book"]), sc["pinned"].data_ptr(),
+                                stream_ptr(dev)), "fsgs_refine_mark")
+    if SPIN_WAIT:
+        for _ in range(400000):
+            if arr[7] != 0:
+                break
+    if arr[7] == 0:
+        torch.cuda.current_stream(dev).synchronize()
+        assert arr[7] != 0, "fsgs_refine_mark ended without its totals"
+    m = RefineMarks()
+    m.n, m.flags, m.book = n, sc["flags"], sc["book"]
+    m.n_keep, m.n_split, m.n_dup, m.n_split_kept, m.n_dup_kept = (int(arr[k]) for k in range(5))
+    m.n_samples = int(rules.n_samples) if rules.densify else 0
+    return m
+
+
+def refine_move(marks: RefineMarks, cols, n_append: int = 0, randn: Optional[Tensor] = None, quats: Optional[Tensor] = None,
+                log_scales: Optional[Tensor] = None, mask_in: Optional[Tensor] = None, mask_out: Optional[Tensor] = None,
+                mask_append: int = 0) -> None:
+    """fsgs_refine_move: ``cols`` = [(src [n, ...] fp32, dst, append rows or None, kind)], all in ONE launch."""
+    lib = load()
+    k = len(cols)
+    keep = []
+    srcs, dsts, apps, rfs, kinds = [], [], [], [], []
+    dev = None
+    for src, dst, app, kind in cols:
+        assert src.dtype == torch.float32 and dst.dtype == torch.float32 and src.is_contiguous() and dst.is_contiguous()
+        rf = 1
+        for d in src.shape[1:]:
+            rf *= int(d)
+        if app is not None:
+            app = app.to(device=src.device, dtype=torch.float32).contiguous()
+            assert app.shape[0] == n_append
+            keep.append(app)
+        dev = src.device
+        srcs.append(src.data_ptr()); dsts.append(dst.data_ptr()); apps.append(app.data_ptr() if app is not None else None)
+        rfs.append(rf); kinds.append(int(kind))
+    VP = C.c_void_p * max(k, 1)
+    IA = C.c_int * max(k, 1)
+    if dev is None:
+        dev = marks.flags.device
+    _run(lib.fsgs_refine_move, (marks.n, k, VP(*srcs), VP(*dsts), VP(*apps), IA(*rfs), IA(*kinds), ptr(marks.flags),
+                                ptr(marks.book), marks.n_keep, marks.n_split, marks.n_split_kept, marks.n_dup_kept,
+                                int(n_append), marks.n_samples, ptr(randn), ptr(quats), ptr(log_scales), ptr(_u8(mask_in)),
+                                ptr(_u8(mask_out)), int(mask_append), stream_ptr(dev)), "fsgs_refine_move")
+
+
+def refine_keep_all(n: int, dev):
+    """(flags, book) of a mark that keeps every one of ``n`` rows and creates none (append_gaussians: no decisions to take,
+    so no mark launch): KEEP in every flag byte, workgroup b's first kept row = 256 b."""
+    lib = load()
+    nb = (n + 255) // 256
+    flags = torch.ones(max(n, 1), dtype=torch.uint8, device=dev)
+    book = torch.zeros(int(lib.fsgs_refine_book_ints(n)), dtype=torch.int32, device=dev)
+    if nb:
+        book[8:8 + nb] = torch.arange(nb, dtype=torch.int32, device=dev) * 256
+    return flags, book
+
+
+def nearest_point_words(queries: Tensor, points: Tensor, center, close_radius: float) -> Tensor:
+    """[nq] int64 words of fsgs_nearest_point_words: squared-distance bits above index bits of the nearest of ``points``
+    for the queries within ``close_radius`` of ``center`` (3 floats), all ones elsewhere."""
+    lib = load()
+    queries, points = queries.contiguous(), points.contiguous()
+    nq, dev = queries.shape[0], queries.device
+    words = torch.empty(nq, dtype=torch.int64, device=dev)
+    c = (C.c_float * 3)(*[float(x) for x in center])
+    _run(lib.fsgs_nearest_point_words, (nq, ptr(queries), points.shape[0], ptr(points), c, float(close_radius), ptr(words),
+                                        stream_ptr(dev)), "fsgs_nearest_point_words")
+    return words
+
+
 def loss_combine(partials, weights, bias: float) -> Tensor:
     """bias + sum_t (w[t][0]*colsum0(partials[t]) + w[t][1]*colsum1(partials[t])) as a 0-d device tensor, one launch."""
     lib = load()

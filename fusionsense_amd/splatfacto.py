@@ -227,6 +227,16 @@ class DensifyStrategy:
         if self.visual_hull is not None:
             self.visual_hull = self.visual_hull.to(device)
         self._staged_on = str(device)
+        if torch.device(device).type == "cuda":
+            # everything the callbacks derive from the metadata alone, once: the anchors' rows but for their colours
+            # (make_touch_gaussians: gel scales, +z -> contact-normal rotations), the hull's centre and its grid
+            if self.touch_patches is not None:
+                self._touch_static_rows(self.touch_patches, self.gel_scale_factor, torch.device(device))
+            if self.visual_hull is not None:
+                from .touch import hull_grid
+                self._hull_center(self.visual_hull)
+                self._hull_grid_of = (self.visual_hull, float(self.scale_factor),
+                                      hull_grid(self.visual_hull, 0.02 * self.scale_factor))
 
     def _frames_of(self, touch_patches):
         """The staged boxes' frames when ``touch_patches`` is the staged list (else None: touch_aabb_mask derives them)."""
@@ -256,8 +266,28 @@ class DensifyStrategy:
                 self.touch_pruning(trainer, self.touch_patches)
 
     # ---- a-13 ---------------------------------------------------------------------------
+    def _rules(self, step: int, densify: bool):
+        """The schedule scalars and thresholds of one refinement / cull for fsgs_refine_mark (thresholds go over as fp32:
+        what a float32 tensor compared with a Python scalar sees in the reference)."""
+        from ._lib import RefineRules
+        cfg = self.cfg
+        r = RefineRules()
+        r.densify, r.n_samples = (1 if densify else 0), int(cfg.n_split_samples)
+        r.max_hw = float(max(self.last_size[0], self.last_size[1]))
+        r.densify_grad_thresh, r.densify_size_thresh = cfg.densify_grad_thresh, cfg.densify_size_thresh
+        r.check_screen, r.split_screen_size = int(step < cfg.stop_screen_size_at), cfg.split_screen_size
+        r.cull_alpha_thresh = cfg.cull_alpha_thresh
+        r.check_big = int(step > cfg.refine_every * cfg.reset_alpha_every)
+        r.cull_scale_thresh, r.cull_screen_size = cfg.cull_scale_thresh, cfg.cull_screen_size
+        r.hull_close, r.hull_lo, r.hull_hi, r.n_boxes = -1.0, 0.0, 0.0, 0
+        return r
+
     @torch.no_grad()
     def refinement_after(self, trainer, step: int) -> None:
+        """dn_model.py:326-451 in two library launches around one host read (csrc/refine.hip): fsgs_refine_mark takes every
+        decision (densify_masks / cull_mask above state them in torch; tests/test_gpu_densify.py holds the kernel to them),
+        the host learns five totals, draws the split noise — ``torch.randn((samps * n_split, 3))`` from the trainer's
+        generator, as before — and fsgs_refine_move writes the new parameter and moment tensors in one pass."""
         cfg = self.cfg
         sched = refine_schedule(cfg, step, self.num_train_data)
         if not sched["active"]:
@@ -266,62 +296,22 @@ class DensifyStrategy:
         P = trainer.params
         N = P["means"].shape[0]
         dev = P["means"].device
-        new_rows: Dict[str, Tensor] = {}
-        n_new = 0
-        extra_old: Optional[Tensor] = None
-        do_cull = False
-        n_split = n_dup = 0
-        if sched["densify"]:
-            assert self.xys_grad_norm is not None and self.vis_counts is not None and self.max_2Dsize is not None
-            splits, dups = densify_masks(cfg, step, self.xys_grad_norm, self.vis_counts, self.max_2Dsize,
-                                         P["scales"].data, self.last_size, self.add_mask)
-            split_ids = torch.where(splits)[0]
-            dup_ids = torch.where(dups)[0]
-            n_split, n_dup = split_ids.numel(), dup_ids.numel()
-            samps = cfg.n_split_samples
-            randn = torch.randn((samps * n_split, 3), device=dev, generator=trainer.rng)
-            sp_means, sp_scales = ops.split_samples(split_ids, samps, P["means"].data, P["quats"].data,
-                                                    P["scales"].data, randn)
-            shrunk = torch.log(torch.exp(P["scales"].data) / 1.6)
-            scales_after = torch.where(splits[:, None], shrunk, P["scales"].data)
-            for name, p in P.items():
-                reps = (samps,) + (1,) * (p.dim() - 1)
-                if name == "means":
-                    s_rows = sp_means
-                elif name == "scales":
-                    s_rows = sp_scales
-                else:
-                    s_rows = p.data[split_ids].repeat(*reps)
-                d_rows = scales_after[dup_ids] if name == "scales" else p.data[dup_ids]
-                new_rows[name] = torch.cat([s_rows, d_rows], dim=0)
-            n_new = samps * n_split + n_dup
-            extra_old = splits  # a split parent is pruned (dn_model.py:403-415)
-            do_cull = True
-        elif sched["cull_only"]:
-            do_cull = True
-
-        deleted = 0
-        if do_cull:
-            max2d_old = self.max_2Dsize
-            extra = extra_old
-            if self.extra_cull_fn is not None:
-                e2 = self.extra_cull_fn(trainer)
-                extra = e2 if extra is None else (extra | e2)
-            cull_old = cull_mask(cfg, step, P["opacities"].data, P["scales"].data, max2d_old, extra)
-            keep_old = ~cull_old
-            if n_new > 0:
-                cull_new = cull_mask(cfg, step, new_rows["opacities"], new_rows["scales"],
-                                     torch.zeros(n_new, device=dev) if max2d_old is not None else None, None)
-                keep_new = ~cull_new
-            else:
-                keep_new = torch.zeros(0, dtype=torch.bool, device=dev)
-            n_keep_old = int(keep_old.sum().item())
-            n_keep_new = int(keep_new.sum().item()) if n_new > 0 else 0
-            deleted = (N - n_keep_old) + (n_new - n_keep_new)
-            self._rebuild(trainer, keep_old, n_keep_old, new_rows, keep_new, n_keep_new)
-            if self.add_mask is not None:
-                self.add_mask = torch.cat([self.add_mask[keep_old],
-                                           torch.zeros(n_keep_new, dtype=torch.bool, device=dev)])
+        n_split = n_dup = deleted = 0
+        if sched["densify"] or sched["cull_only"]:
+            densify = sched["densify"]
+            if densify:
+                assert self.xys_grad_norm is not None and self.vis_counts is not None and self.max_2Dsize is not None
+            extra = self.extra_cull_fn(trainer) if self.extra_cull_fn is not None else None
+            marks = ops.refine_mark(self._rules(step, densify), P["scales"].data, P["opacities"].data,
+                                    self.xys_grad_norm if densify else None, self.vis_counts if densify else None,
+                                    self.max_2Dsize, add_mask=self.add_mask, extra_cull=extra)
+            randn = None
+            if densify:
+                n_split, n_dup = marks.n_split, marks.n_dup
+                randn = torch.randn((cfg.n_split_samples * n_split, 3), device=dev, generator=trainer.rng)
+            n_new = marks.n_samples * marks.n_split + n_dup
+            deleted = (N - marks.n_keep) + (n_new - marks.n_samples * marks.n_split_kept - marks.n_dup_kept)
+            self._rebuild_marked(trainer, marks, randn)
 
         if sched["reset_opacity"]:
             reset_value = cfg.cull_alpha_thresh * 2.0
@@ -347,104 +337,150 @@ class DensifyStrategy:
 
     # ---- a-14: FusionSense-specific callbacks (dn_model.py:1156-1302) ----------------------
     @torch.no_grad()
-    def cull_gaussians(self, trainer, extra_cull_mask: Optional[Tensor] = None) -> Tensor:
-        """SplatfactoModel.cull_gaussians + remove_from_all_optim in one pass.  Returns the
-        deleted mask over the rows that existed before the call."""
+    def cull_gaussians(self, trainer, extra_cull_mask: Optional[Tensor] = None, hull=None, boxes: Optional[Tensor] = None,
+                       exempt_anchors: bool = True, append_rows: Optional[Dict[str, Tensor]] = None) -> Tensor:
+        """SplatfactoModel.cull_gaussians + remove_from_all_optim in one pass (mark, five totals, move).  Returns the
+        deleted mask over the rows that existed before the call.
+        The pruning callbacks' own tests ride in the mark: ``hull`` = (words of ops.nearest_point_words or None, the hull's
+        grid or None, centre, scale factor) -> hull_pruning's shell test, ``boxes`` = the patches' frames -> touch_pruning's box test; touch anchors
+        pass both unless ``exempt_anchors`` is off (add_touch_patch culls whatever lies inside the boxes).
+        ``append_rows``: rows added behind the survivors in the same move, as touch anchors (add_touch_patch)."""
         _flush(trainer)
         P = trainer.params
-        culls = cull_mask(self.cfg, trainer.step, P["opacities"].data, P["scales"].data, self.max_2Dsize,
-                          extra_cull_mask)
-        keep = ~culls
-        self._rebuild(trainer, keep, int(keep.sum().item()), {}, torch.zeros(0, dtype=torch.bool), 0)
-        if self.add_mask is not None:
-            self.add_mask = self.add_mask[keep]
-        for name in ("xys_grad_norm", "vis_counts", "max_2Dsize"):
-            t = getattr(self, name)
-            if t is not None:
-                setattr(self, name, t[keep])
-        return culls
+        rules = self._rules(trainer.step, False)
+        words = grid = None
+        if hull is not None:
+            words, grid, center, scale_factor = hull
+            rules.hull_center[0], rules.hull_center[1], rules.hull_center[2] = center
+            rules.hull_close, rules.hull_lo, rules.hull_hi = 0.2 * scale_factor, 0.005 * scale_factor, 0.02 * scale_factor
+        marks = ops.refine_mark(rules, P["scales"].data, P["opacities"].data, max_2Dsize=self.max_2Dsize,
+                                means=P["means"].data, add_mask=self.add_mask if exempt_anchors else None,
+                                extra_cull=extra_cull_mask, hull_words=words, boxes=boxes, hull_grid=grid)
+        deleted = marks.deleted()
+        self._rebuild_marked(trainer, marks, None, append_rows=append_rows, stats=append_rows is None)
+        return deleted
 
     @torch.no_grad()
     def append_gaussians(self, trainer, rows: Dict[str, Tensor]) -> None:
         """Append rows with zero Adam moments (add_in_all_optim, dn_model.py:1150-1152)."""
         _flush(trainer)
-        n_old = trainer.params["means"].shape[0]
-        n_new = rows["means"].shape[0]
-        dev = trainer.params["means"].device
-        keep = torch.ones(n_old, dtype=torch.bool, device=dev)
-        rows = {k: v.to(dev) for k, v in rows.items()}
-        self._rebuild(trainer, keep, n_old, rows, torch.ones(n_new, dtype=torch.bool, device=dev), n_new)
+        P = trainer.params
+        n_old = P["means"].shape[0]
+        marks = ops.RefineMarks()  # every row stays: no mark launch, the offsets are the rows themselves
+        marks.n, marks.n_keep, marks.n_split, marks.n_dup, marks.n_split_kept, marks.n_dup_kept, marks.n_samples = \
+            n_old, n_old, 0, 0, 0, 0, 0
+        marks.flags, marks.book = ops.refine_keep_all(n_old, P["means"].device)
+        self._rebuild_marked(trainer, marks, None, append_rows=rows, anchors=False)
+
+    def _touch_static_rows(self, touch_patches, gel_scale_factor: float, device):
+        """(points, normals, the rows make_touch_gaussians builds from them) of a patch list — everything but the colours
+        is a function of the patches alone (dn_model.py:1190-1224: gel scales, the +z -> contact-normal rotations, raw
+        opacity 1), so it is built once per list and kept."""
+        from .touch import make_touch_gaussians
+        c = getattr(self, "_touch_static", None)
+        key = (float(gel_scale_factor), int(self.cfg.sh_degree), str(device))
+        if c is not None and c[0] is touch_patches and c[1] == key:
+            return c[2]
+        pts = [p["points_xyz"].to(device) for p in touch_patches if p["points_xyz"].shape[0] > 0]
+        if not pts:
+            out = (None, None, None)
+        else:
+            pts = torch.cat(pts).to(torch.float32).contiguous()
+            nrm = torch.cat([p["normals"].to(device) for p in touch_patches if p["points_xyz"].shape[0] > 0])
+            rows = make_touch_gaussians(pts, nrm, torch.full_like(pts, 0.5), gel_scale_factor, self.cfg.sh_degree)
+            out = (pts, nrm, rows)
+        self._touch_static = (touch_patches, key, out)
+        return out
 
     @torch.no_grad()
     def add_touch_patch(self, trainer, touch_patches, gel_scale_factor: float, colors_fn=None) -> int:
         """dn_model.py:1156-1247 at step == add_touch_at: cull Gaussians inside the patches'
         oriented boxes, then append the touch points as fixed anchors (``add_mask``).  Colours
-        of the new points come from the nearest existing Gaussian (knn_sk, k=1, dn_model.py:1181-1182)."""
+        of the new points come from the nearest existing Gaussian (knn_sk, k=1, dn_model.py:1181-1182).
+        One nearest-point search for all patches' points, then ONE mark + move: the box test rides in the mark, the
+        anchors are appended behind the survivors by the move."""
         _flush(trainer)
-        from .touch import make_touch_gaussians, touch_aabb_mask
-        if touch_patches is self.touch_patches:
-            self.stage(trainer.params["means"].device)
-            touch_patches = self.touch_patches
+        from .touch import box_frames
+        from .scenes import rgb_to_sh, sh_to_rgb
         P = trainer.params
         means = P["means"].data
-        aabb = touch_aabb_mask(means, touch_patches, self._frames_of(touch_patches))
-        pts, nrm, rgb = [], [], []
-        from .scenes import sh_to_rgb
-        base_rgb = sh_to_rgb(P["features_dc"].data) if self.cfg.sh_degree > 0 else torch.sigmoid(P["features_dc"].data)
-        for patch in touch_patches:
-            x = patch["points_xyz"].to(means.device)
-            if x.shape[0] == 0:
-                continue
-            # 1-NN on the device (reference: sklearn on CPU); brute force in libfsgs, no BLAS, no [n, N] matrix
-            if not means.is_cuda:
-                raise ValueError("add_touch_patch runs on the GPU (fsgs_nearest_point): there is no CPU path")
-            nn_idx = ops.nearest_point(x, means, want_idx=True)[1]
-            pts.append(x)
-            nrm.append(patch["normals"].to(means.device))
-            rgb.append(base_rgb[nn_idx])
-        self.max_2Dsize = self.max_2Dsize  # statistics survive the cull, then are reset below
-        self.cull_gaussians(trainer, aabb)
-        if not pts:
+        dev = means.device
+        if not means.is_cuda:
+            raise ValueError("add_touch_patch runs on the GPU (fsgs_nearest_point, fsgs_refine_mark): there is no CPU path")
+        if touch_patches is self.touch_patches:
+            self.stage(dev)
+            touch_patches = self.touch_patches
+        frames = self._frames_of(touch_patches)
+        if frames is None:
+            frames = box_frames(touch_patches, dev)
+        pts, nrm, static = self._touch_static_rows(touch_patches, gel_scale_factor, dev)
+        if pts is None:
+            self.cull_gaussians(trainer, boxes=frames, exempt_anchors=False)
             return 0
-        pts, nrm, rgb = torch.cat(pts), torch.cat(nrm), torch.cat(rgb)
-        rows = make_touch_gaussians(pts, nrm, rgb, gel_scale_factor, self.cfg.sh_degree)
-        n_before = trainer.params["means"].shape[0]
-        self.append_gaussians(trainer, rows)
-        added = pts.shape[0]
-        self.add_mask = torch.cat([torch.zeros(n_before, dtype=torch.bool, device=means.device),
-                                   torch.ones(added, dtype=torch.bool, device=means.device)])
+        # 1-NN on the device (reference: sklearn on CPU); brute force in libfsgs, no BLAS, no [n, N] matrix
+        nn_idx = ops.nearest_point(pts, means, want_idx=True)[1]
+        near = P["features_dc"].data[nn_idx]
+        rgb = sh_to_rgb(near) if self.cfg.sh_degree > 0 else torch.sigmoid(near)
+        rows = dict(static)
+        rows["features_dc"] = rgb_to_sh(rgb) if self.cfg.sh_degree > 0 else torch.logit(rgb, eps=1e-10)
+        self.add_mask = None  # (the reference starts the mask over: zeros for every row that was there, ones for the anchors)
+        self.cull_gaussians(trainer, boxes=frames, exempt_anchors=False, append_rows=rows)
         self.touch_normals = nrm.to(torch.float32).contiguous()
         self.xys_grad_norm = self.vis_counts = self.max_2Dsize = None
-        return added
+        return pts.shape[0]
+
+    def _hull_center(self, visual_hull: Tensor):
+        """visual_hull.mean(0) as three Python floats, kept per hull tensor (hull_pruning recomputed it every call)."""
+        c = getattr(self, "_hull_center_of", None)
+        if c is None or c[0] is not visual_hull:
+            c = self._hull_center_of = (visual_hull, [float(x) for x in visual_hull.mean(dim=0).tolist()])
+        return c[1]
+
+    def _hull_words(self, trainer, visual_hull: Tensor, scale_factor: float):
+        """What cull_gaussians needs for hull_pruning's test: the hull's grid (built once per hull and scale factor: the
+        search then rides in the mark launch) or, for a hull too large for a grid, the exhaustive search's words."""
+        means = trainer.params["means"].data
+        if not means.is_cuda:
+            raise ValueError("hull_pruning runs on the GPU (fsgs_refine_mark): there is no CPU path")
+        center = self._hull_center(visual_hull)
+        c = getattr(self, "_hull_grid_of", None)
+        if c is None or c[0] is not visual_hull or c[1] != float(scale_factor):
+            from .touch import hull_grid
+            c = self._hull_grid_of = (visual_hull, float(scale_factor), hull_grid(visual_hull, 0.02 * scale_factor))
+        if c[2] is not None and os.environ.get("FSGS_HULL_GRID", "1") != "0":
+            return None, c[2], center, scale_factor
+        return ops.nearest_point_words(means, visual_hull, center, 0.2 * scale_factor), None, center, scale_factor
 
     @torch.no_grad()
     def hull_pruning(self, trainer, visual_hull: Tensor, scale_factor: float) -> Optional[Tensor]:
-        """dn_model.py:1249-1276."""
+        """dn_model.py:1249-1276: Gaussians near the object (<= 0.2 s from the hull centre) whose distance to the hull
+        point set is in (0.005 s, 0.02 s] are culled; touch anchors never."""
         _flush(trainer)
-        from .touch import hull_prune_mask
         if trainer.step <= self.cfg.warmup_length:
             return None
         if visual_hull is self.visual_hull:
             self.stage(trainer.device)
             visual_hull = self.visual_hull
-        mask = hull_prune_mask(trainer.params["means"].data, visual_hull.to(trainer.device), scale_factor,
-                               self.add_mask)
+        elif visual_hull.device != trainer.params["means"].device:
+            visual_hull = visual_hull.to(trainer.params["means"].device)
         self.max_2Dsize = None
-        return self.cull_gaussians(trainer, mask)
+        return self.cull_gaussians(trainer, hull=self._hull_words(trainer, visual_hull, scale_factor))
+
+    def _frames(self, trainer, touch_patches) -> Tensor:
+        from .touch import box_frames
+        if touch_patches is self.touch_patches:
+            self.stage(trainer.device)
+            touch_patches = self.touch_patches
+        frames = self._frames_of(touch_patches)
+        return frames if frames is not None else box_frames(touch_patches, trainer.params["means"].device)
 
     @torch.no_grad()
     def touch_pruning(self, trainer, touch_patches) -> Optional[Tensor]:
         """dn_model.py:1279-1302."""
         _flush(trainer)
-        from .touch import touch_aabb_mask
         if trainer.step <= self.cfg.warmup_length or self.add_mask is None:
             return None
-        if touch_patches is self.touch_patches:
-            self.stage(trainer.device)
-            touch_patches = self.touch_patches
-        mask = touch_aabb_mask(trainer.params["means"].data, touch_patches, self._frames_of(touch_patches))
-        mask[self.add_mask] = False
-        return self.cull_gaussians(trainer, mask)
+        return self.cull_gaussians(trainer, boxes=self._frames(trainer, touch_patches))
 
     @torch.no_grad()
     def hull_and_touch_pruning(self, trainer) -> Optional[Tensor]:
@@ -459,19 +495,18 @@ class DensifyStrategy:
         if self.add_mask is None:  # touch_pruning does nothing before add_touch_patch
             return self.hull_pruning(trainer, self.visual_hull, self.scale_factor)
         _flush(trainer)
-        from .touch import hull_prune_mask, touch_aabb_mask
         self.stage(trainer.device)
-        means = trainer.params["means"].data
-        mask = hull_prune_mask(means, self.visual_hull, self.scale_factor, self.add_mask)
-        mask |= touch_aabb_mask(means, self.touch_patches, self._frames_of(self.touch_patches)) & ~self.add_mask
         self.max_2Dsize = None
-        return self.cull_gaussians(trainer, mask)
+        return self.cull_gaussians(trainer, hull=self._hull_words(trainer, self.visual_hull, self.scale_factor),
+                                   boxes=self._frames(trainer, self.touch_patches))
 
-    def _rebuild(self, trainer, keep_old: Tensor, n_keep_old: int, new_rows: Dict[str, Tensor],
-                 keep_new: Tensor, n_keep_new: int) -> None:
-        """New parameter tensors + Adam moments: kept old rows (order preserved, HIP compaction)
-        followed by the kept new rows; new rows get zero moments (dup_in_optim), culled rows
-        drop theirs (remove_from_optim)."""
+    def _rebuild_marked(self, trainer, marks, randn: Optional[Tensor], append_rows: Optional[Dict[str, Tensor]] = None,
+                        stats: bool = False, anchors: bool = True) -> None:
+        """New parameter tensors + Adam moments from the marks of fsgs_refine_mark, in ONE launch (fsgs_refine_move): kept
+        old rows (order preserved), the kept split children sample by sample, the kept duplicates, then ``append_rows``;
+        new rows get zero moments (dup_in_optim), culled rows drop theirs (remove_from_optim).  ``stats``: the after_train
+        statistics are compacted with the rows (a cull between two refinements).  ``add_mask`` follows the rows: zeros
+        for children / duplicates, ones for appended rows when ``anchors``."""
         if hasattr(trainer, "flush"):
             # a deferred feature update (data-parallel runs) is sized for the old N and reads the old slab: it must
             # land before any row moves — add_touch_patch / hull_pruning / touch_pruning run between two steps
@@ -482,35 +517,40 @@ class DensifyStrategy:
         # tile's saturation depth little, and a cut that has become too tight is found out on the device; measured over
         # 1 500 steps with a refinement every 50: 1 482 cut frames against 1 356 when every rebuild dropped them, none
         # redone either way.  An opacity reset does drop them: nothing saturates where it did.)
-        keep8 = keep_old.to(torch.uint8).contiguous()
-        positions = ops.mask_positions(keep8)
-        n_final = n_keep_old + n_keep_new
-        if n_keep_new > 0:
-            knew8 = keep_new.to(torch.uint8).contiguous()
-            pos_new = ops.mask_positions(knew8)
-        # one launch moves every kept row of the six parameters, their twelve moments and the six blocks of new rows
-        # (round 5: 24 launches + six boolean-mask gathers, each with its wait for the host, were a third of a rebuild)
-        jobs = []
-        fresh = {}
-        for name in list(trainer.params.keys()):
-            old_p = trainer.params[name]
+        P = trainer.params
+        dev = P["means"].device
+        n_append = int(append_rows["means"].shape[0]) if append_rows else 0
+        n_final = marks.n_keep + marks.n_samples * marks.n_split_kept + marks.n_dup_kept + n_append
+        kinds = {"means": ops.COL_MEANS, "scales": ops.COL_SCALES}
+        cols, fresh = [], {}
+        for name in list(P.keys()):
+            old_p = P[name]
             opt = trainer.optimizers[name]
             shape = (n_final,) + tuple(old_p.shape[1:])
-            new_data = torch.empty(shape, dtype=old_p.dtype, device=old_p.device)
-            jobs.append((old_p.data, keep8, positions, new_data))
-            if n_keep_new > 0:
-                jobs.append((new_rows[name].to(old_p.device), knew8, pos_new, new_data[n_keep_old:]))
+            new_data = torch.empty(shape, dtype=old_p.dtype, device=dev)
+            cols.append((old_p.data, new_data, append_rows[name].reshape((n_append,) + tuple(old_p.shape[1:]))
+                         if append_rows else None, kinds.get(name, ops.COL_COPY)))
             state = opt.state.pop(old_p, None)
             moments = {}
             if state:
                 for key in ("exp_avg", "exp_avg_sq"):
-                    buf = torch.empty(shape, dtype=old_p.dtype, device=old_p.device)
-                    if n_keep_new > 0:
-                        buf[n_keep_old:].zero_()  # (new rows start with zero moments: dup_in_optim)
-                    jobs.append((state[key], keep8, positions, buf))
+                    buf = torch.empty(shape, dtype=old_p.dtype, device=dev)
+                    cols.append((state[key], buf, None, ops.COL_ZERO))
                     moments[key] = buf
             fresh[name] = (new_data, state, moments)
-        ops.compact_rows_multi(jobs)
+        moved_stats = {}
+        if stats:
+            for name in ("xys_grad_norm", "vis_counts", "max_2Dsize"):
+                t = getattr(self, name)
+                if t is not None:
+                    moved_stats[name] = torch.empty(n_final, dtype=torch.float32, device=dev)
+                    cols.append((t, moved_stats[name], None, ops.COL_ZERO))
+        mask_in = mask_out = None
+        if self.add_mask is not None or (n_append > 0 and anchors):
+            mask_in = self.add_mask if self.add_mask is not None else torch.zeros(marks.n, dtype=torch.bool, device=dev)
+            mask_out = torch.empty(n_final, dtype=torch.bool, device=dev)
+        ops.refine_move(marks, cols, n_append, randn, P["quats"].data, P["scales"].data, mask_in, mask_out,
+                        1 if anchors else 0)
         for name, (new_data, state, moments) in fresh.items():
             opt = trainer.optimizers[name]
             new_p = torch.nn.Parameter(new_data)
@@ -519,6 +559,10 @@ class DensifyStrategy:
                 opt.state[new_p] = state
             opt.param_groups[0]["params"] = [new_p]
             trainer.params[name] = new_p
+        for name, t in moved_stats.items():
+            setattr(self, name, t)
+        if mask_out is not None:
+            self.add_mask = mask_out
         trainer.slab.rebuild(trainer.params)
         if hasattr(trainer, "mark_params_written"):
             trainer.mark_params_written()

@@ -126,6 +126,35 @@ def hull_prune_mask(means: Tensor, visual_hull: Tensor, scale_factor: float,
     return mask
 
 
+def hull_grid(visual_hull: Tensor, reach: float, max_cells: int = 1 << 22) -> Optional[Dict]:
+    """The visual hull's points binned into a uniform grid whose cell edge just exceeds ``reach`` (hull_pruning's outer
+    radius, 0.02 * scale_factor: dn_model.py:1266-1270), for fsgs_refine_mark's in-launch search: a Gaussian's nearest hull
+    point matters to hull_pruning only if it is within ``reach``, and then it lies in one of the 27 cells around the
+    Gaussian.  Built once per hull (the hull is scene metadata).  Returns None when the grid would need more than
+    ``max_cells`` cells (a hull that is huge against its own pruning radius: the exhaustive search stays).
+    points [H, 4] fp32 sorted by cell, cells [n_cells + 1] int32 (first point of every cell), origin / inv_cell / dims as
+    the kernel applies them: cell(p) = floor((p - origin) * inv_cell), id = (z * dims[1] + y) * dims[0] + x."""
+    hull = visual_hull.to(torch.float32)
+    if hull.shape[0] == 0:
+        return None
+    cell = torch.tensor(float(reach), dtype=torch.float32, device=hull.device) * 1.001
+    inv = 1.0 / cell
+    origin = hull.min(dim=0).values - cell
+    g = torch.floor((hull - origin) * inv).to(torch.int64)      # (the kernel's own expression, operation for operation)
+    dims = [int(x) + 2 for x in g.max(dim=0).values.tolist()]
+    n_cells = dims[0] * dims[1] * dims[2]
+    if n_cells > max_cells:
+        return None
+    ids = (g[:, 2] * dims[1] + g[:, 1]) * dims[0] + g[:, 0]
+    order = torch.argsort(ids, stable=True)
+    points = torch.zeros(hull.shape[0], 4, dtype=torch.float32, device=hull.device)
+    points[:, :3] = hull[order]
+    cells = torch.zeros(n_cells + 1, dtype=torch.int32, device=hull.device)
+    cells[1:] = torch.cumsum(torch.bincount(ids, minlength=n_cells), 0).to(torch.int32)
+    return dict(points=points.contiguous(), cells=cells, origin=[float(x) for x in origin.tolist()], inv_cell=float(inv),
+                dims=dims)
+
+
 def make_touch_gaussians(points: Tensor, normals: Tensor, rgb: Tensor, gel_scale_factor: float,
                          sh_degree: int) -> Dict[str, Tensor]:
     """Rows appended by add_touch_patch (dn_model.py:1190-1224): raw opacity 1.0, log-scale

@@ -43,7 +43,7 @@ typedef void *fsgs_stream_t; /* hipStream_t */
 #define FSGS_ESCRATCH -3 /* scratch arena too small */
 #define FSGS_EPROTOCOL -4 /* a bounded cross-workgroup / host wait ran into its bound, or calls arrived out of order */
 
-#define FSGS_ABI_VERSION 9
+#define FSGS_ABI_VERSION 10
 int fsgs_version(void);
 int fsgs_abi_version(void); /* == FSGS_ABI_VERSION of the header the library was built from */
 /* Lines of the packed gradient accumulator a caller that passes `replica_rows` > 0 must provide per Gaussian row:
@@ -582,6 +582,12 @@ int fsgs_points_in_boxes(int64_t n, const float *points, int n_boxes, const floa
  * hull_pruning (dn_splatter/dn_model.py:1258-1264) and the k=1 neighbour search of add_touch_patch (:1181-1182). */
 int fsgs_nearest_point(int nq, const float *queries, int np, const float *points, const uint8_t *active, float *out_dist,
                        int64_t *out_idx, int want_idx, fsgs_stream_t stream);
+/* The same search for fsgs_refine_mark (ABI 10): out_words [nq] keeps the workgroups' raw 64-bit words (squared-distance
+ * bits above index bits, ~0 = no point compared) — no unpacking launch —, and the queries that matter are chosen in the
+ * launch: those within `close_radius` of `center` (3 floats, HOST memory; hull_pruning's ``norm(means - hull.mean(0)) <=
+ * 0.2 * scale_factor``, dn_model.py:1255-1257); the others keep ~0. */
+int fsgs_nearest_point_words(int nq, const float *queries, int np, const float *points, const float *center,
+                             float close_radius, uint64_t *out_words, fsgs_stream_t stream);
 /* The k nearest points (exact fp32 differences, brute force, ties -> lowest index) of every query, reported from rank
  * `skip` on: out_idx [nq, k - skip] int64.  k <= 33, k <= np; skip = 1 reproduces dn_splatter/utils/knn.py:29-44
  * (knn_sk asks sklearn for k + 1 neighbours and drops the first column) — what compute_level_surface_points
@@ -594,6 +600,72 @@ int fsgs_knn_points(int64_t nq, const float *queries, int np, const float *point
 int fsgs_split_samples(int64_t S, int n_samples, const int64_t *ids, const float *means,
                        const float *quats, const float *log_scales, const float *randn,
                        float *new_means, float *new_log_scales, fsgs_stream_t stream);
+
+/* ---- a-13 / a-14 in two launches (ABI 10): mark -> [the host reads five totals] -> move ---------------------------------
+ * One refinement of dn_splatter/dn_model.py:326-451 (split / duplicate selection :342-379, split_gaussians' children,
+ * cull_gaussians :403-431) or one cull of the pruning callbacks (:1156-1302), with the Adam-state surgery of
+ * dup_in_all_optim / remove_from_all_optim (:1120-1152), as the one-pass kernel SURVEY.md section 7 step 7 asks for.
+ * Rounds 1-5 ran the masks, torch.where / cat / repeat and per-tensor compactions as ~80 torch launches per refinement.
+ *
+ * fsgs_refine_mark decides, per existing row, five bits of flags[row]:
+ *   1 KEEP        the row survives (not low-alpha, not too big, not a split parent, none of the pruning tests below)
+ *   2 SPLIT       densify only: (exp(scale).max > densify_size_thresh | check_screen & max_2Dsize > split_screen_size)
+ *                 & avg_grad_norm > densify_grad_thresh & !add_mask, avg_grad_norm = xys_grad_norm / vis_counts * 0.5 * max_hw
+ *   4 DUP         densify only: scale max AFTER the split's /1.6 <= densify_size_thresh & high gradient & !add_mask (the
+ *                 reference tests the duplicates after split_gaussians has shrunk the parents in place: a parent just above
+ *                 the threshold is both split and duplicated)
+ *   8 CHILD_KEEP  the row's split children pass cull_gaussians (the parent's opacity, the shrunk scales)
+ *  16 DUP_KEEP    its duplicate passes it
+ * and leaves, in book (int32 [fsgs_refine_book_ints(N)], ZERO before the first call, self-resetting), the exclusive
+ * per-workgroup (256 rows) offsets of the five counts {KEEP, SPLIT, DUP, SPLIT & CHILD_KEEP, DUP & DUP_KEEP}; the five
+ * totals go to totals_mapped[0..4] (mapped host memory), then totals_mapped[7] <- 1 with system-scope release.
+ * Pruning tests riding in the same pass (hull_pruning / touch_pruning, :1249-1302): hull_best (nullable) = the 64-bit
+ * words fsgs_nearest_point left for means against the visual hull (distance bits above index bits, ~0 = none):
+ * culled when |mean - hull_center| <= hull_close and hull_lo < distance <= hull_hi; or, without a search launch at all,
+ * hull_points (float4 per hull point, sorted by cell) + hull_cells (int32 [cells + 1], first point of every cell) of a
+ * uniform grid over the hull whose cell edge exceeds hull_hi: the mark then looks for the nearest hull point in the 27
+ * cells around a close row — the decision is the exhaustive search's, because a row whose nearest hull point is not
+ * in those cells is farther than hull_hi from all of them (fusionsense_amd/touch.py: hull_grid); boxes (nullable, n_boxes x 18 floats as
+ * for fsgs_points_in_boxes): culled when inside any.  Rows of add_mask (touch anchors) pass both.  extra_cull (nullable):
+ * a byte per row, non-zero = culled (the caller's own test).
+ * xys_grad_norm / vis_counts are read only when rules->densify; max_2Dsize is nullable (no screen-size tests then). */
+typedef struct fsgs_refine_rules {
+    int32_t densify;              /* 1: split / dup selection + cull; 0: cull only */
+    int32_t n_samples;            /* children per split parent (SplatfactoModelConfig.n_split_samples) */
+    float max_hw;                 /* max(H, W) of the last training frame */
+    float densify_grad_thresh, densify_size_thresh;
+    int32_t check_screen;         /* step < stop_screen_size_at */
+    float split_screen_size;
+    float cull_alpha_thresh;
+    int32_t check_big;            /* step > refine_every * reset_alpha_every */
+    float cull_scale_thresh, cull_screen_size;
+    float hull_center[3];
+    float hull_close, hull_lo, hull_hi;
+    int32_t n_boxes;
+    float grid_origin[3];         /* hull_cells route: cell (x, y, z) of a point p = floor((p - grid_origin) * grid_inv_cell) */
+    float grid_inv_cell;          /* 1 / cell edge, the edge > hull_hi */
+    int32_t grid_dims[3];         /* cells per axis (x fastest): cell id = (z * dims[1] + y) * dims[0] + x */
+} fsgs_refine_rules;
+int64_t fsgs_refine_book_ints(int64_t N);
+int fsgs_refine_mark(int64_t N, const fsgs_refine_rules *rules, const float *xys_grad_norm, const float *vis_counts,
+                     const float *max_2Dsize, const float *means, const float *log_scales, const float *opac_logit,
+                     const uint8_t *add_mask, const uint8_t *extra_cull, const uint64_t *hull_best, const float *hull_points,
+                     const int32_t *hull_cells, const float *boxes, uint8_t *flags, int32_t *book, int32_t *totals_mapped,
+                     fsgs_stream_t stream);
+/* fsgs_refine_move builds the new tensors from flags / book and the totals the host has read: for each of n_cols <= 24
+ * columns (row-major fp32 [N, row_floats[c]]) dst[c] receives, in the reference's order,
+ *   [kept old rows] [for s < n_samples: the kept children of sample s, parents in row order] [kept duplicates] [n_append rows]
+ * A column's kind says what a NEW row holds: 0 COPY = the parent's row (append rows: append[c]), 1 ZERO (Adam moments of
+ * new rows, dup_in_optim), 2 MEANS = child: mean + R(q/|q|) (exp(log_scale) * randn[s * n_split + i]) with i the parent's
+ * rank among ALL split rows (kept or not), 3 SCALES = child: log(exp(scale) / 1.6); duplicate of a split parent: the same.
+ * quats / log_scales / randn [n_samples * n_split, 3] are read for kind 2 only (nullable without splits).
+ * mask_in -> mask_out (nullable): a byte column (add_mask): kept old rows keep theirs, children / duplicates get 0, append rows
+ * mask_append.  append[c] nullable when n_append == 0 or kind 1.  dst rows: n_keep + n_samples * n_split_kept + n_dup_kept + n_append. */
+int fsgs_refine_move(int64_t N, int n_cols, const float *const *src, float *const *dst, const float *const *append,
+                     const int *row_floats, const int *kind, const uint8_t *flags, const int32_t *book,
+                     int64_t n_keep, int64_t n_split, int64_t n_split_kept, int64_t n_dup_kept, int64_t n_append, int n_samples,
+                     const float *randn, const float *quats, const float *log_scales,
+                     const uint8_t *mask_in, uint8_t *mask_out, int mask_append, fsgs_stream_t stream);
 
 /* ---- caller-side glue of get_outputs, fused (csrc/glue.hip; used by fusionsense_amd/fused.py) -----
  * activations of dn_model.py:573-574 and their VJPs (v_quats = v_quats_a + v_quats_b sums the

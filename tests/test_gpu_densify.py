@@ -362,3 +362,182 @@ def test_points_in_boxes_kernel(dev):
     assert not bool((differ & (margin > 1e-5)).any()), int(differ.sum())
     assert torch.equal(touch.touch_aabb_mask(pts.to(dev), patches).cpu(), got)
     assert ops.points_in_boxes(pts.to(dev), frames[:0]).sum() == 0  # no boxes: nothing is inside
+
+
+# ---- the two launches of a refinement against their oracle (oracle/refine_ref.py, pinned against the reference's own
+# refinement_after by tests/test_host_logic.py::test_refinement_host_logic_with_the_row_oracle_matches_reference_execution)
+def _refine_case(n, seed, sh_rest=15):
+    g = torch.Generator().manual_seed(seed)
+    cols = dict(means=torch.randn(n, 3, generator=g), scales=torch.log(0.002 + 0.03 * torch.rand(n, 3, generator=g)),
+                quats=torch.randn(n, 4, generator=g), features_dc=torch.randn(n, 3, generator=g),
+                features_rest=torch.randn(n, sh_rest, 3, generator=g), opacities=2 * torch.randn(n, 1, generator=g))
+    stats = dict(xys_grad_norm=torch.rand(n, generator=g) * 0.01, vis_counts=1 + torch.randint(0, 5, (n,), generator=g).float(),
+                 max_2Dsize=torch.rand(n, generator=g) * 0.2)
+    add = torch.rand(n, generator=g) < 0.02
+    return cols, stats, add
+
+
+def _mark_both(dev, rules, cols, stats, add, **kw):
+    from fusionsense_amd import ops
+    from oracle import refine_ref
+    to = lambda x: None if x is None else x.to(dev)  # noqa: E731
+    dense = bool(rules.densify)
+    ref = refine_ref.mark(rules, cols["scales"], cols["opacities"], stats["xys_grad_norm"] if dense else None,
+                          stats["vis_counts"] if dense else None, stats["max_2Dsize"], cols["means"], add, **kw)
+    got = ops.refine_mark(rules, to(cols["scales"]), to(cols["opacities"]), to(stats["xys_grad_norm"]) if dense else None,
+                          to(stats["vis_counts"]) if dense else None, to(stats["max_2Dsize"]), to(cols["means"]), to(add),
+                          **{k: to(v) for k, v in kw.items()})
+    return ref, got
+
+
+@pytest.mark.parametrize("n,step,densify", [(70001, 700, True), (70001, 3500, True), (4096, 10000, False), (257, 16000, True),
+                                            (1, 700, True), (0, 700, True)])
+def test_refine_mark_matches_its_oracle(dev, n, step, densify):
+    """fsgs_refine_mark: the flag byte of every row and the five totals, over the schedule's regimes (screen-size tests on
+    / off, too-big test on / off, cull only) — equal to the torch statement except where a row sits within rounding of a
+    threshold (expf / logf of the device against the host's)."""
+    cols, stats, add = _refine_case(n, step + n)
+    st = DensifyStrategy(SplatfactoConfig(), num_train_data=9)
+    st.last_size = (720, 1280)
+    rules = st._rules(step, densify)
+    extra = torch.rand(n, generator=torch.Generator().manual_seed(1)) < 0.05
+    ref, got = _mark_both(dev, rules, cols, stats, add, extra_cull=extra)
+    differ = int((got.flags[:n].cpu() != ref.flags).sum())
+    assert differ <= 2, differ
+    if differ == 0:
+        for k in ("n_keep", "n_split", "n_dup", "n_split_kept", "n_dup_kept", "n_samples"):
+            assert getattr(got, k) == getattr(ref, k), k
+        assert torch.equal(got.deleted().cpu(), ref.deleted())
+    if n > 1000 and densify:
+        assert ref.n_split > 0 and ref.n_dup > 0 and ref.n_split_kept < ref.n_split + 1 and ref.n_keep < n
+        both = (ref.flags & 6) == 6
+        assert step > 4000 or int(both.sum()) > 0  # the in-place shrink quirk: split parents that are also duplicated
+    # the totals are the flags' own counts, whatever the rounding did
+    f = got.flags[:n].cpu()
+    assert got.n_keep == int((f & 1).ne(0).sum()) and got.n_split == int((f & 2).ne(0).sum())
+    assert got.n_dup == int((f & 4).ne(0).sum()) and got.n_split_kept == int(((f & 10) == 10).sum())
+    assert got.n_dup_kept == int(((f & 20) == 20).sum())
+
+
+def test_refine_mark_pruning_tests_ride_along(dev):
+    """hull_pruning's shell test (on fsgs_nearest_point_words' words) and touch_pruning's box test inside the mark: the
+    same rows as the torch statement, anchors exempt; words equal to an exhaustive search for the close rows."""
+    from fusionsense_amd import ops, touch
+    from oracle import refine_ref
+    n = 30011
+    cols, stats, add = _refine_case(n, 5)
+    cols["means"] = cols["means"] * 0.3
+    g = torch.Generator().manual_seed(9)
+    hull = 0.25 * torch.nn.functional.normalize(torch.randn(3000, 3, generator=g), dim=-1) + 0.01
+    center = [float(x) for x in hull.mean(0).tolist()]
+    s = 1.3
+    words = ops.nearest_point_words(cols["means"].to(dev), hull.to(dev), center, 0.2 * s)
+    ref_words = refine_ref.hull_distance_words(cols["means"], hull, center, 0.2 * s)
+    close = ref_words != -1
+    assert 0.1 < float(close.float().mean()) < 0.95
+    assert torch.equal((words.cpu() == -1), ~close)
+    d_got = (words.cpu() >> 32).to(torch.int32).view(torch.float32)[close]
+    d_ref = (ref_words >> 32).to(torch.int32).view(torch.float32)[close]
+    assert torch.allclose(d_got, d_ref, rtol=1e-5, atol=1e-9)
+    boxes = []
+    for b in range(3):
+        ax = torch.linalg.qr(torch.randn(3, 3, generator=g))[0]
+        ext = 0.05 + 0.1 * torch.rand(3, generator=g)
+        c = 0.2 * torch.randn(3, generator=g)
+        boxes.append(dict(points_xyz=torch.zeros(4, 3), bbox=torch.stack(
+            [c + (ax * ((torch.tensor([(i >> 0) & 1, (i >> 1) & 1, (i >> 2) & 1]).float() * 2 - 1) * ext)[None]).sum(-1)
+             for i in range(8)])))
+    frames = touch.box_frames(boxes)
+    st = DensifyStrategy(SplatfactoConfig(), num_train_data=9)
+    rules = st._rules(1100, False)
+    rules.hull_center[0], rules.hull_center[1], rules.hull_center[2] = center
+    rules.hull_close, rules.hull_lo, rules.hull_hi = 0.2 * s, 0.005 * s, 0.02 * s
+    stats["max_2Dsize"] = None
+    ref = refine_ref.mark(rules, cols["scales"], cols["opacities"], None, None, None, cols["means"], add,
+                          hull_words=words.cpu(), boxes=frames)
+    got = ops.refine_mark(rules, cols["scales"].to(dev), cols["opacities"].to(dev), means=cols["means"].to(dev),
+                          add_mask=add.to(dev), hull_words=words, boxes=frames.to(dev))
+    plain = refine_ref.mark(st._rules(1100, False), cols["scales"], cols["opacities"])
+    assert ref.n_keep < plain.n_keep - 100, "the pruning tests cull rows of their own"
+    differ = got.flags[:n].cpu() != ref.flags
+    assert int(differ.sum()) <= 3, int(differ.sum())  # (rows within rounding of a face / of the shell)
+    assert not bool(((got.flags[:n].cpu() & 1) == 0)[add & ((plain.flags & 1) != 0)].any()), "anchors pass both tests"
+    # ... and with the search riding in the mark (the hull's points by grid cell, touch.hull_grid): the exhaustive
+    # search's decisions, bit for bit — a row's nearest hull point matters only within hull_hi, i.e. within the 27 cells
+    flags_words = got.flags[:n].clone()
+    grid = touch.hull_grid(hull.to(dev), 0.02 * s)
+    assert grid is not None and grid["cells"].numel() == grid["dims"][0] * grid["dims"][1] * grid["dims"][2] + 1
+    assert int(grid["cells"][-1]) == hull.shape[0]
+    got2 = ops.refine_mark(rules, cols["scales"].to(dev), cols["opacities"].to(dev), means=cols["means"].to(dev),
+                           add_mask=add.to(dev), boxes=frames.to(dev), hull_grid=grid)
+    assert torch.equal(got2.flags[:n], flags_words) and got2.n_keep == got.n_keep
+    assert touch.hull_grid(hull.to(dev) * 1e4, 0.02 * s) is None  # (too many cells: the exhaustive search stays)
+
+
+@pytest.mark.parametrize("n,step,samps,rest,n_append", [(70001, 700, 2, 15, 0), (5000, 3500, 3, 0, 0), (3001, 10000, 2, 15, 77),
+                                                        (300, 700, 2, 3, 1), (0, 700, 2, 15, 5), (1, 16000, 2, 15, 0)])
+def test_refine_move_matches_its_oracle(dev, n, step, samps, rest, n_append):
+    """fsgs_refine_move from the device's own flags: kept rows, children sample by sample (sampled means, shrunk scales),
+    duplicates (shrunk where the parent was split too), appended rows, zero moments for every new row, the anchor mask —
+    copied columns bit for bit, computed ones to fp32 rounding."""
+    from fusionsense_amd import ops
+    from oracle import refine_ref
+    cols, stats, add = _refine_case(n, step + n, rest)
+    cfg = SplatfactoConfig()
+    cfg.n_split_samples = samps
+    st = DensifyStrategy(cfg, num_train_data=9)
+    st.last_size = (720, 1280)
+    densify = step < 15000
+    rules = st._rules(step, densify)
+    to = lambda x: None if x is None else x.to(dev)  # noqa: E731
+    got = ops.refine_mark(rules, to(cols["scales"]), to(cols["opacities"]), to(stats["xys_grad_norm"]) if densify else None,
+                          to(stats["vis_counts"]) if densify else None, to(stats["max_2Dsize"]), add_mask=to(add))
+    ref = refine_ref.Marks()
+    ref.n, ref.flags = n, got.flags[:n].cpu()
+    for k in ("n_keep", "n_split", "n_dup", "n_split_kept", "n_dup_kept", "n_samples"):
+        setattr(ref, k, getattr(got, k))
+    g = torch.Generator().manual_seed(3)
+    randn = torch.randn(max(got.n_samples * got.n_split, 1), 3, generator=g)
+    n_out = got.n_keep + got.n_samples * got.n_split_kept + got.n_dup_kept + n_append
+    kinds = dict(means=ops.COL_MEANS, scales=ops.COL_SCALES)
+    app = {k: torch.randn((n_append,) + tuple(v.shape[1:]), generator=g) for k, v in cols.items()} if n_append else None
+    job_d, job_h, outs = [], [], []
+    for k, v in cols.items():
+        for kind in (kinds.get(k, ops.COL_COPY), ops.COL_ZERO):  # the parameter, then a "moment" of the same rows
+            dd = torch.full((n_out,) + tuple(v.shape[1:]), float("nan"), device=dev)
+            dh = torch.empty((n_out,) + tuple(v.shape[1:]))
+            a = app[k] if (app and kind != ops.COL_ZERO) else None
+            job_d.append((v.to(dev), dd, a, kind))
+            job_h.append((v, dh, a, kind))
+            outs.append((k, kind, dd, dh))
+    mo_d = torch.empty(n_out, dtype=torch.bool, device=dev)
+    mo_h = torch.empty(n_out, dtype=torch.bool)
+    ops.refine_move(got, job_d, n_append, to(randn), to(cols["quats"]), to(cols["scales"]), to(add), mo_d, 1)
+    refine_ref.move(ref, job_h, n_append, randn, cols["quats"], cols["scales"], add, mo_h, 1)
+    for k, kind, dd, dh in outs:
+        if dd.numel() == 0:
+            continue
+        assert not bool(torch.isnan(dd).any()), (k, kind, "every row of the output is written")
+        if kind in (ops.COL_COPY, ops.COL_ZERO):
+            assert torch.equal(dd.cpu(), dh), (k, kind)
+        else:
+            assert torch.allclose(dd.cpu(), dh, rtol=1e-5, atol=1e-6), (k, kind, float((dd.cpu() - dh).abs().max()))
+            assert torch.equal(dd.cpu()[:got.n_keep], dh[:got.n_keep])
+    assert torch.equal(mo_d.cpu(), mo_h)
+    if n > 1000 and densify:
+        assert got.n_split_kept > 0 and got.n_dup_kept > 0
+
+
+def test_refinement_is_two_library_launches_and_the_noise(dev):
+    """What VERDICT r5 asked of a-13: one refinement_after = fsgs_refine_mark, torch.randn (the split noise, from the
+    trainer's generator), fsgs_refine_move — and the gradient slab's memset; no other device work."""
+    from helpers import device_kernels_of
+    tr, st = _trainer_with_state(dev, 20000, 3, 700)
+    st.refinement_after(tr, 700)  # (first call: scratch buffers, module loads)
+    tr2, st2 = _trainer_with_state(dev, 20000, 3, 700)
+    names = device_kernels_of(lambda: st2.refinement_after(tr2, 700))
+    assert st2.last_report["n_split"] > 0 and st2.last_report["n_dup"] > 0
+    ours = [n for n in names if "refine_" in n]
+    assert len(ours) == 2 and "refine_mark_kernel" in ours[0] and "refine_move_kernel" in ours[1], names
+    others = [n for n in names if "refine_" not in n]
+    assert len(others) <= 3, others  # randn, the new slab's fill (+ a copy the profiler may show for the mapped totals)

@@ -257,6 +257,75 @@ def test_densify_and_cull_masks_match_oracle(step):
     assert new_p["means"].shape[0] <= n + n_new and int(culls.sum()) <= rep["n_deleted"]
 
 
+@pytest.mark.parametrize("step", [400, 700, 3100, 3500, 10000])
+def test_refinement_host_logic_with_the_row_oracle_matches_reference_execution(step, monkeypatch):
+    """DensifyStrategy.refinement_after — schedule, fsgs_refine_rules, the Adam-state bookkeeping around the two launches —
+    with the launches replaced by their oracle (oracle/refine_ref.py) against the reference's own refinement_after executed
+    in the authoring container (reference_model.npz): pins the oracle the kernels are held to on the GPU
+    (tests/test_gpu_densify.py), and the host side of the callback, without a GPU."""
+    import numpy as np
+    from fusionsense_amd import ops
+    from fusionsense_amd.splatfacto import DensifyStrategy
+    from fusionsense_amd.trainer import SplatTrainer
+    from oracle import refine_ref
+    monkeypatch.setattr(ops, "refine_mark", refine_ref.mark)
+    monkeypatch.setattr(ops, "refine_move", refine_ref.move)
+    d = np.load(os.path.join(ROOT, "tests", "golden", "reference_model.npz"))
+    t = lambda k: torch.from_numpy(d[k])  # noqa: E731
+    names = ["means", "scales", "quats", "features_dc", "features_rest", "opacities"]
+    st = DensifyStrategy(SplatfactoConfig(), num_train_data=9)
+    tr = SplatTrainer({k: t(f"ra.{step}.pre.{k}") for k in names}, torch.device("cpu"), fused=False, strategy=st, seed=0)
+    for k in names:
+        tr.optimizers[k].state[tr.params[k]] = {"step": torch.tensor(1.0), "exp_avg": t(f"ra.{step}.pre_m.{k}").clone(),
+                                                "exp_avg_sq": t(f"ra.{step}.pre_v.{k}").clone()}
+    tr.step = step
+    st.xys_grad_norm, st.vis_counts, st.max_2Dsize = (t(f"ra.stats.{k}").clone() for k in ("xys_grad_norm", "vis_counts", "max_2Dsize"))
+    st.last_size = (720, 1280)
+    if step == 3500:
+        st.add_mask = torch.zeros(tr.num_gaussians(), dtype=torch.bool)
+        st.add_mask[:50] = True
+    noise = t(f"ra.{step}.randn")
+    real_randn = torch.randn
+
+    def fake_randn(*size, **kw):
+        shape = tuple(size[0]) if len(size) == 1 and not isinstance(size[0], int) else tuple(size)
+        if shape == tuple(noise.shape):
+            return noise.clone()
+        kw.pop("generator", None)
+        return real_randn(*size, **kw)
+
+    monkeypatch.setattr(torch, "randn", fake_randn)
+    st.refinement_after(tr, step)
+    for k in names:
+        ref = t(f"ra.{step}.post.{k}")
+        assert tr.params[k].shape == ref.shape, (k, tr.params[k].shape, ref.shape, st.last_report)
+        assert torch.allclose(tr.params[k].detach(), ref, atol=1e-6), k
+        s_ = tr.optimizers[k].state[tr.params[k]]
+        assert torch.equal(s_["exp_avg"], t(f"ra.{step}.post_m.{k}")), k
+        assert torch.equal(s_["exp_avg_sq"], t(f"ra.{step}.post_v.{k}")), k
+    am = d[f"ra.{step}.add_mask_after"]
+    if am.size:
+        assert np.array_equal(st.add_mask.numpy(), am)
+    assert (st.xys_grad_norm is None) == bool(d[f"ra.{step}.stats_cleared"])
+
+
+def test_refine_rules_layout_matches_the_c_compiler(tmp_path):
+    """_lib.RefineRules against ``fsgs_refine_rules`` as gcc lays it out (size and every field's offset)."""
+    import ctypes as C
+    from fusionsense_amd import _lib
+    fields = [f[0] for f in _lib.RefineRules._fields_]
+    src = tmp_path / "rules.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "fsgs.h"\nint main(void){\n'
+                   + "".join(f'printf("{f} %zu\\n", offsetof(fsgs_refine_rules, {f}));\n' for f in fields)
+                   + 'printf("sizeof %zu\\n", sizeof(fsgs_refine_rules)); return 0; }\n')
+    exe = tmp_path / "rules"
+    subprocess.run(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    out = dict(line.split() for line in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.splitlines())
+    assert int(out["sizeof"]) == C.sizeof(_lib.RefineRules)
+    for f in fields:
+        assert int(out[f]) == getattr(_lib.RefineRules, f).offset, f
+
+
 def test_reference_helper_goldens():
     """Product-side mirrors against vectors produced by the reference's own functions
     (tests/golden/make_reference_goldens.py)."""
@@ -1072,27 +1141,10 @@ from fusionsense_amd import ops
 from fusionsense_amd.trainer import SplatTrainer, PARAM_ORDER, GEOMETRY_GROUPS, FEATURE_GROUPS
 from fusionsense_amd.splatfacto import DensifyStrategy, SplatfactoConfig
 # the row surgery of a refinement runs through HIP kernels in the product (no CPU fallback, by design); this test is
-# about the EXCHANGE and the slab layout around it, so the three row primitives get torch stand-ins here
-ops.mask_positions = lambda keep: torch.cumsum(keep.to(torch.int64), 0) - keep.to(torch.int64)
-def _compact(src, keep8, positions, n_keep, out=None, out_offset=0):
-    rows = src[keep8.bool()]
-    if out is None:
-        return rows
-    out[out_offset:out_offset + n_keep] = rows
-    return out
-ops.compact_rows = _compact
-def _compact_multi(jobs):
-    for src, keep8, positions, dst in jobs:
-        if src.shape[0] and dst.shape[0]:
-            dst[:int(keep8.sum())] = src[keep8.bool()]
-ops.compact_rows_multi = _compact_multi
-def _split(ids, samps, means, quats, log_scales, randn):
-    from fusionsense_amd.legacy import quat_to_rotmat
-    q = quats[ids] / quats[ids].norm(dim=-1, keepdim=True)
-    R = quat_to_rotmat(q.repeat(samps, 1))
-    sc = torch.exp(log_scales[ids].repeat(samps, 1)) * randn
-    return (R @ sc[..., None]).squeeze(-1) + means[ids].repeat(samps, 1), torch.log(torch.exp(log_scales[ids]) / 1.6).repeat(samps, 1)
-ops.split_samples = _split
+# about the EXCHANGE and the slab layout around it, so the two row primitives get their oracle's torch statement here
+from oracle import refine_ref
+ops.refine_mark = refine_ref.mark
+ops.refine_move = refine_ref.move
 
 torch.manual_seed(0)
 n = 173                      # 11 * 173 = 1903 geometry floats: no multiple of 64, let alone of 64 * 8
