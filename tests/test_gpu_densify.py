@@ -541,3 +541,41 @@ def test_refinement_is_two_library_launches_and_the_noise(dev):
     assert len(ours) == 2 and "refine_mark_kernel" in ours[0] and "refine_move_kernel" in ours[1], names
     others = [n for n in names if "refine_" not in n]
     assert len(others) <= 3, others  # randn, the new slab's fill (+ a copy the profiler may show for the mapped totals)
+
+
+def test_cull_moves_the_statistics_and_append_keeps_every_row(dev):
+    """cull_gaussians between two refinements compacts the after_train statistics with the rows (a pruning callback must
+    not shift them against the Gaussians they describe); append_gaussians keeps every row where it is, adds the new rows
+    with zero moments and leaves the anchor mask's old entries alone."""
+    tr, st = _trainer_with_state(dev, 5000, 11, 1100)
+    before = {k: tr.params[k].detach().clone() for k in PARAM_ORDER}
+    mom = {k: tr.optimizers[k].state[tr.params[k]]["exp_avg"].clone() for k in PARAM_ORDER}
+    stats = {k: getattr(st, k).clone() for k in ("xys_grad_norm", "vis_counts", "max_2Dsize")}
+    st.add_mask = torch.zeros(5000, dtype=torch.bool, device=dev)
+    st.add_mask[::7] = True
+    g = torch.Generator().manual_seed(2)
+    extra = (torch.rand(5000, generator=g) < 0.3).to(dev)
+    deleted = st.cull_gaussians(tr, extra)
+    keep = ~deleted
+    assert bool((deleted | ~extra).all()) and 0 < int(keep.sum()) < 5000 - int(extra.sum()) + 1
+    n1 = int(keep.sum())
+    assert tr.num_gaussians() == n1
+    for k in PARAM_ORDER:
+        assert torch.equal(tr.params[k].detach(), before[k][keep]), k
+        assert torch.equal(tr.optimizers[k].state[tr.params[k]]["exp_avg"], mom[k][keep]), k
+    for k, v in stats.items():
+        assert torch.equal(getattr(st, k), v[keep]), k
+    assert torch.equal(st.add_mask, (torch.arange(5000, device=dev) % 7 == 0)[keep])
+    # append: 33 new rows behind the survivors
+    rows = {k: torch.randn((33,) + tuple(before[k].shape[1:]), generator=g) for k in PARAM_ORDER}
+    kept = {k: tr.params[k].detach().clone() for k in PARAM_ORDER}
+    mask_before = st.add_mask.clone()
+    st.append_gaussians(tr, rows)
+    assert tr.num_gaussians() == n1 + 33
+    for k in PARAM_ORDER:
+        assert torch.equal(tr.params[k].detach()[:n1], kept[k]), k
+        assert torch.equal(tr.params[k].detach()[n1:].cpu(), rows[k]), k
+        s_ = tr.optimizers[k].state[tr.params[k]]
+        assert torch.equal(s_["exp_avg"][:n1], mom[k][keep]) and not bool(s_["exp_avg"][n1:].any()), k
+        assert not bool(s_["exp_avg_sq"][n1:].any()), k
+    assert torch.equal(st.add_mask[:n1], mask_before) and not bool(st.add_mask[n1:].any())
